@@ -1,0 +1,264 @@
+"""Pin the CPU oracle for the sequence criteria.
+
+The reference holds no golden vectors for FAC/FCC/Viterbi/CTC ("parity
+unpinned"), so the oracle is pinned by brute-force path enumeration, analytic
+identities, fp64 finite differences and torch's CPU CTC.
+"""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+
+def lse(v):
+    v = np.asarray(v, np.float64)
+    m = v.max()
+    return m + np.log(np.exp(v - m).sum())
+
+
+def brute_fcc(x, A):
+    T, N = x.shape
+    scores = []
+    for path in itertools.product(range(N), repeat=T):
+        s = x[0, path[0]]
+        for t in range(1, T):
+            s += x[t, path[t]] + A[path[t], path[t - 1]]
+        scores.append(s)
+    return lse(scores)
+
+
+def brute_fac(x, A, y):
+    """all monotone alignments of y (len L) to T frames, each label >= 1 frame"""
+    T, N = x.shape
+    L = len(y)
+    scores = []
+    for cuts in itertools.combinations(range(1, T), L - 1):
+        bounds = (0,) + cuts + (T,)
+        pos = []
+        for i in range(L):
+            pos += [i] * (bounds[i + 1] - bounds[i])
+        s = x[0, y[pos[0]]]
+        for t in range(1, T):
+            s += x[t, y[pos[t]]] + A[y[pos[t]], y[pos[t - 1]]]
+        scores.append(s)
+    return lse(scores)
+
+
+def brute_viterbi(x, A):
+    T, N = x.shape
+    best, arg = -np.inf, None
+    for path in itertools.product(range(N), repeat=T):
+        s = x[0, path[0]]
+        for t in range(1, T):
+            s += x[t, path[t]] + A[path[t], path[t - 1]]
+        if s > best:
+            best, arg = s, path
+    return best, arg
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fcc_bruteforce(oracle, seed):
+    rng = np.random.default_rng(seed)
+    T, N = int(rng.integers(2, 7)), int(rng.integers(2, 5))
+    x = rng.normal(size=(1, T, N)).astype(np.float32)
+    A = rng.normal(size=(N, N)).astype(np.float32)
+    got = oracle.FCC(x, A, [1]).forward()[0]
+    assert abs(got - brute_fcc(x[0].astype(np.float64), A.astype(np.float64))) < 1e-10
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fac_bruteforce(oracle, seed):
+    rng = np.random.default_rng(100 + seed)
+    T, N = int(rng.integers(3, 9)), int(rng.integers(2, 5))
+    L = int(rng.integers(1, T + 1))
+    y = rng.integers(0, N, size=L)
+    x = rng.normal(size=(1, T, N)).astype(np.float32)
+    A = rng.normal(size=(N, N)).astype(np.float32)
+    tgt = np.full((1, L + 2), -1, np.int32)
+    tgt[0, :L] = y
+    got = oracle.FAC(x, A, tgt).forward()[0]
+    assert abs(got - brute_fac(x[0].astype(np.float64), A.astype(np.float64), list(y))) < 1e-10
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_viterbi_bruteforce(oracle, seed):
+    rng = np.random.default_rng(200 + seed)
+    T, N = int(rng.integers(2, 7)), int(rng.integers(2, 5))
+    x = rng.normal(size=(1, T, N)).astype(np.float32)
+    A = rng.normal(size=(N, N)).astype(np.float32)
+    path = oracle.viterbi(x, A)[0]
+    best, arg = brute_viterbi(x[0].astype(np.float64), A.astype(np.float64))
+    assert tuple(path) == arg
+
+
+def test_viterbi_tie_break_first_max(oracle):
+    # all-equal scores: first index must win everywhere (strict '>' scan)
+    x = np.zeros((2, 5, 4), np.float32)
+    A = np.zeros((4, 4), np.float32)
+    assert (oracle.viterbi(x, A) == 0).all()
+    assert (oracle.ctc_viterbi(x) == 0).all()
+
+
+def test_identities_b6(oracle):
+    rng = np.random.default_rng(7)
+    B, T, N = 3, 9, 5
+    x = rng.normal(size=(B, T, N)).astype(np.float32)
+    # (i) A = 0 => FCC = sum_t LSE_n x
+    fcc = oracle.FCC(x, np.zeros((N, N), np.float32), [1] * B)
+    want = np.array([sum(lse(x[b, t]) for t in range(T)) for b in range(B)])
+    assert np.allclose(fcc.forward(), want, atol=1e-10)
+    A = rng.normal(size=(N, N)).astype(np.float32)
+    # (ii) T == L => FAC = sum x[t][y_t] + sum A[y_t][y_t-1]
+    y = rng.integers(0, N, size=(B, T)).astype(np.int32)
+    fac = oracle.FAC(x, A, y)
+    want = np.array([sum(float(x[b, t, y[b, t]]) for t in range(T)) +
+                     sum(float(A[y[b, t], y[b, t - 1]]) for t in range(1, T)) for b in range(B)])
+    assert np.allclose(fac.forward(), want, atol=1e-10)
+    # (iii) L == 1
+    y1 = np.full((B, 3), -1, np.int32)
+    y1[:, 0] = [0, 2, 4]
+    want = np.array([x[b, :, y1[b, 0]].astype(np.float64).sum() + (T - 1) * float(A[y1[b, 0], y1[b, 0]])
+                     for b in range(B)])
+    assert np.allclose(oracle.FAC(x, A, y1).forward(), want, atol=1e-10)
+    # (iv),(v) gradient mass
+    yl = np.full((B, 6), -1, np.int32)
+    yl[0, :4] = [1, 2, 2, 0]; yl[1, :2] = [3, 3]; yl[2, :6] = [0, 1, 0, 1, 4, 4]
+    for crit in (oracle.FCC(x, A, [4, 2, 6]), oracle.FAC(x, A, yl)):
+        crit.forward()
+        dx, dA = crit.backward()
+        assert np.allclose(dx.sum(-1), 1.0, atol=1e-10)
+        assert abs(dA.sum() - B * (T - 1)) < 1e-9
+
+
+def _fd(f, x, eps=1e-3):
+    g = np.zeros(x.shape, np.float64)
+    it = np.nditer(x, flags=["multi_index"])
+    while not it.finished:
+        i = it.multi_index
+        old = x[i]
+        x[i] = old + eps; fp = f()
+        x[i] = old - eps; fm = f()
+        x[i] = old
+        g[i] = (fp - fm) / (2 * eps)
+        it.iternext()
+    return g
+
+
+def test_asg_finite_differences(oracle):
+    rng = np.random.default_rng(11)
+    B, T, N, L = 2, 6, 4, 3
+    x = rng.normal(size=(B, T, N)).astype(np.float32)
+    A = rng.normal(size=(N, N)).astype(np.float32) * 0.5
+    y = np.array([[1, 2, -1], [0, 0, 3]], np.int32)
+    w = np.array([0.7, -1.3])
+    mode = oracle.SCALE_TARGET_SZ_SQRT
+
+    def f():
+        return float((oracle.asg(x, A, y, mode)[0] * w).sum())
+
+    _, dx, dA = oracle.asg(x, A, y, mode, grad=w)
+    # float32 storage => central differences with eps 1e-2..1e-3; tolerance accordingly
+    assert np.allclose(_fd(f, x, 1e-2), dx, atol=2e-3)
+    assert np.allclose(_fd(f, A, 1e-2), dA, atol=2e-3)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+def test_scale_modes(oracle, mode):
+    rng = np.random.default_rng(3)
+    B, T, N = 2, 16, 4
+    x = rng.normal(size=(B, T, N)).astype(np.float32)
+    A = np.zeros((N, N), np.float32)
+    y = np.array([[1, 2, 0, 1, -1], [3, -1, -1, -1, -1]], np.int32)
+    base = oracle.FAC(x, A, y, scale_mode=0).forward()
+    got = oracle.FAC(x, A, y, scale_mode=mode).forward()
+    Ls = np.array([4, 1])
+    s = {0: np.ones(2), 1: np.full(2, 1 / T), 2: np.full(2, np.sqrt(1 / T)), 3: 1 / Ls,
+         4: np.sqrt(1 / Ls)}[mode]
+    assert np.allclose(got, base * s, rtol=1e-12)
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_ctc_vs_torch(oracle, seed):
+    rng = np.random.default_rng(300 + seed)
+    B, T, N, L = 4, int(rng.integers(8, 30)), int(rng.integers(3, 12)), 6
+    x = (rng.normal(size=(B, T, N)) * 2).astype(np.float32)
+    tgt = np.full((B, L), -1, np.int32)
+    lens = []
+    for b in range(B):
+        l = int(rng.integers(0, L + 1)) if b else L
+        tgt[b, :l] = rng.integers(0, N - 1, size=l)
+        lens.append(l)
+    if seed == 0:
+        tgt[0, :L] = [1, 1, 1, 0, 0, 1]  # repeats
+    ctc = oracle.CTC(x, tgt)
+    loss = ctc.forward()
+    w = rng.normal(size=B)
+    dx = ctc.backward(w)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    lp = torch.log_softmax(xt, -1).transpose(0, 1)  # T,B,N
+    tl = torch.tensor(lens)
+    tt = torch.tensor(np.where(tgt < 0, 0, tgt), dtype=torch.long)
+    ref = torch.nn.functional.ctc_loss(lp, tt, torch.full((B,), T), tl, blank=N - 1, reduction="none")
+    assert np.allclose(loss, ref.detach().numpy(), atol=1e-8)
+    (ref * torch.tensor(w)).sum().backward()
+    assert np.allclose(dx, xt.grad.numpy(), atol=1e-8)
+
+
+def test_ctc_target_truncation(oracle):
+    # L + repeats > T: target size is reduced to what fits (App. B.0)
+    tgt = np.array([[1, 1, 1, 1, -1]], np.int32)
+    assert oracle.batch_ctc_target_size(tgt, 5)[0] == 2  # R=3: min(4+3,5)-3
+    assert oracle.batch_ctc_target_size(tgt, 7)[0] == 4
+    assert oracle.batch_target_size(tgt, 3)[0] == 3
+
+
+def test_ctc_identity_T_equals_L(oracle):
+    rng = np.random.default_rng(5)
+    T, N = 6, 7
+    x = rng.normal(size=(1, T, N)).astype(np.float32)
+    y = np.array([[0, 1, 2, 3, 4, 5]], np.int32)
+    lp = x[0].astype(np.float64) - np.array([lse(r) for r in x[0]])[:, None]
+    want = -sum(lp[t, y[0, t]] for t in range(T))
+    assert abs(oracle.CTC(x, y).forward()[0] - want) < 1e-10
+
+
+def test_fac_viterbi_matches_enumeration(oracle):
+    rng = np.random.default_rng(9)
+    T, N, L = 7, 4, 3
+    x = rng.normal(size=(1, T, N)).astype(np.float32)
+    A = rng.normal(size=(N, N)).astype(np.float32)
+    y = [2, 0, 3]
+    tgt = np.array([y + [-1]], np.int32)
+    got = oracle.FAC(x, A, tgt).viterbi()[0]
+    best, arg = -np.inf, None
+    for cuts in itertools.combinations(range(1, T), L - 1):
+        bounds = (0,) + cuts + (T,)
+        pos = []
+        for i in range(L):
+            pos += [i] * (bounds[i + 1] - bounds[i])
+        s = float(x[0, 0, y[pos[0]]])
+        for t in range(1, T):
+            s += float(x[0, t, y[pos[t]]]) + float(A[y[pos[t]], y[pos[t - 1]]])
+        if s > best:
+            best, arg = s, [y[p] for p in pos]
+    assert list(got) == arg
+
+
+def test_viterbi_score_le_fcc(oracle):
+    rng = np.random.default_rng(13)
+    B, T, N = 3, 12, 6
+    x = rng.normal(size=(B, T, N)).astype(np.float32)
+    A = rng.normal(size=(N, N)).astype(np.float32)
+    p = oracle.viterbi(x, A)
+    fcc = oracle.FCC(x, A, [1] * B).forward()
+    for b in range(B):
+        s = float(x[b, 0, p[b, 0]]) + sum(float(x[b, t, p[b, t]]) + float(A[p[b, t], p[b, t - 1]])
+                                          for t in range(1, T))
+        assert s <= fcc[b] + 1e-9
+    big = oracle.FCC(x * 50, A * 50, [1] * B).forward()
+    p2 = oracle.viterbi(x * 50, A * 50)
+    for b in range(B):
+        s = 50 * (float(x[b, 0, p2[b, 0]]) + sum(float(x[b, t, p2[b, t]]) + float(A[p2[b, t], p2[b, t - 1]])
+                                                 for t in range(1, T)))
+        assert abs(s - big[b]) < 1e-3 * abs(big[b])

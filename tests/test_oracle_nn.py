@@ -1,0 +1,193 @@
+"""Pin the CPU oracle for the network operators: the reference's two golden
+vectors (Conv1dTest.cpp:30-104, TDSBlockTest.cpp:27-188) and torch-CPU
+cross-checks of every forward/backward."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import refnet
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_golden_conv1d_streaming_form(oracle):
+    g = json.load(open(os.path.join(GOLD, "conv1d_golden.json")))
+    T, G, Cc = g["T"], g["groups"], g["channels"] // g["groups"]
+    y = oracle.streaming_conv1d(np.array(g["input"]), np.array(g["weights"]), np.array(g["bias"]),
+                                T, G, Cc, Cc, g["kernelSize"], g["stride"], g["leftPadding"], g["rightPadding"])
+    err = np.abs(y - np.array(g["target"])).max()
+    assert err < g["tol"], err
+    assert err < 2e-3  # fp16-packed weights in the reference => ~1e-3
+
+
+def test_golden_conv1d_train_form(oracle):
+    """same vector through the train-time Conv2D restatement ([B][C][H][T], w [Cout][Cin][kw])"""
+    g = json.load(open(os.path.join(GOLD, "conv1d_golden.json")))
+    T, H, Cc, kw = g["T"], g["groups"], g["channels"] // g["groups"], g["kernelSize"]
+    x = np.array(g["input"], np.float32).reshape(T, H, Cc).transpose(2, 1, 0)[None]  # [1][C][H][T]
+    w = np.array(g["weights"], np.float32).reshape(Cc, kw, Cc).transpose(0, 2, 1)     # [co][ci][k]
+    y = oracle.conv_fwd(x, w, np.array(g["bias"], np.float32), 1, g["leftPadding"], g["rightPadding"])
+    got = y[0].transpose(2, 1, 0).reshape(-1)
+    assert np.abs(got - np.array(g["target"])).max() < 2e-3
+
+
+def test_golden_tdsblock(oracle):
+    g = json.load(open(os.path.join(GOLD, "tdsblock_golden.json")))
+    T, H, Cc, kw = g["T"], g["groups"], g["channels"] // g["groups"], g["kernelSize"]
+    p = refnet.TDSParams(Cc, kw, H)
+    p.wc = np.array(g["conv_weights"], np.float32).reshape(Cc, kw, Cc).transpose(0, 2, 1).copy()
+    p.bc = np.array(g["conv_bias"], np.float32)
+    p.g1, p.b1n = np.float32(g["ln1_weights"][0]), np.float32(g["ln1_bias"][0])
+    p.w1 = np.array(g["lin1_weights"], np.float32).reshape(10, 10)  # memory [in][out]
+    p.b1 = np.array(g["lin1_bias"], np.float32)
+    p.w2 = np.array(g["lin2_weights"], np.float32).reshape(10, 10)
+    p.b2 = np.array(g["lin2_bias"], np.float32)
+    p.g2, p.b2n = np.float32(g["ln2_weights"][0]), np.float32(g["ln2_bias"][0])
+    x = np.array(g["in"], np.float32).reshape(T, H, Cc).transpose(2, 1, 0)[None].copy()
+    out = refnet.tds_fwd(x, p, g["leftPadding"], g["rightPadding"], ln_mode="frame", streaming=True)
+    got = out[0].transpose(2, 1, 0).reshape(-1)
+    err = np.abs(got - np.array(g["expectedOutput"])).max()
+    assert err < g["tol"], err
+    assert err < 2e-3
+    # train-time LayerNorm (eps inside sqrt) differs only at the 1e-4 level here
+    out2 = refnet.tds_fwd(x, p, 1, 1, ln_mode="frame", streaming=False)
+    assert np.abs(out2 - out).max() < 5e-3
+
+
+@pytest.mark.parametrize("stride,kw,padl,padr,H", [(1, 5, 2, 2, 3), (2, 7, 3, 3, 2), (1, 4, 0, 0, 1), (2, 21, 10, 10, 4)])
+def test_conv_vs_torch(oracle, stride, kw, padl, padr, H):
+    rng = np.random.default_rng(kw)
+    B, Cin, Cout, T = 2, 3, 5, 23
+    x = rng.normal(size=(B, Cin, H, T)).astype(np.float32)
+    w = rng.normal(size=(Cout, Cin, kw)).astype(np.float32)
+    b = rng.normal(size=Cout).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    xp = F.pad(xt, (padl, padr))
+    yt = F.conv2d(xp, wt[:, :, None, :], bt, stride=(1, stride))
+    y = oracle.conv_fwd(x, w, b, stride, padl, padr)
+    assert y.shape == tuple(yt.shape)
+    assert np.allclose(y, yt.detach().numpy(), atol=1e-5)
+    dy = rng.normal(size=y.shape).astype(np.float32)
+    yt.backward(torch.tensor(dy, dtype=torch.float64))
+    dx, dw, db = oracle.conv_bwd(x, w, dy, stride, padl, padr)
+    assert np.allclose(dx, xt.grad.numpy(), atol=1e-5)
+    assert np.allclose(dw, wt.grad.numpy(), atol=1e-4)
+    assert np.allclose(db, bt.grad.numpy(), atol=1e-4)
+
+
+def test_same_pad_semantics(oracle):
+    # odd kw stride 1 => T'=T; even kw stride 1 => T'=T+1; kw=21 stride 2 => ceil(T/2)
+    for T in (100, 101, 1500, 750, 375):
+        p = oracle.same_pad(T, 21, 2)
+        assert oracle.conv_out_len(T, 21, 2, p, p) == (T + 1) // 2
+    p = oracle.same_pad(50, 7, 1)
+    assert oracle.conv_out_len(50, 7, 1, p, p) == 50
+    p = oracle.same_pad(50, 4, 1)
+    assert oracle.conv_out_len(50, 4, 1, p, p) == 51
+
+
+def test_linear_vs_torch(oracle):
+    rng = np.random.default_rng(1)
+    M, K, N = 7, 5, 9
+    x = rng.normal(size=(M, K)).astype(np.float32)
+    w = rng.normal(size=(K, N)).astype(np.float32)
+    b = rng.normal(size=N).astype(np.float32)
+    assert np.allclose(oracle.linear_fwd(x, w, b), x.astype(np.float64) @ w + b, atol=1e-5)
+    dy = rng.normal(size=(M, N)).astype(np.float32)
+    dx, dw, db = oracle.linear_bwd(x, w, dy)
+    assert np.allclose(dx, dy.astype(np.float64) @ w.T, atol=1e-5)
+    assert np.allclose(dw, x.T.astype(np.float64) @ dy, atol=1e-5)
+    assert np.allclose(db, dy.sum(0), atol=1e-5)
+
+
+def test_layernorm_vs_torch(oracle):
+    rng = np.random.default_rng(2)
+    G, inner = 3, 40
+    x = rng.normal(size=(G, inner)).astype(np.float32) * 2 + 1
+    dy = rng.normal(size=(G, inner)).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    gam = torch.tensor(1.3, dtype=torch.float64, requires_grad=True)
+    bet = torch.tensor(-0.2, dtype=torch.float64, requires_grad=True)
+    yt = F.layer_norm(xt, (inner,), eps=1e-5) * gam + bet
+    y = oracle.layernorm_fwd(x, G, 1.3, -0.2, 1e-5)
+    assert np.allclose(y, yt.detach().numpy(), atol=1e-5)
+    yt.backward(torch.tensor(dy, dtype=torch.float64))
+    dx, dg, db = oracle.layernorm_bwd(x, dy, G, 1.3, 1e-5)
+    assert np.allclose(dx, xt.grad.numpy(), atol=1e-5)
+    assert abs(dg - gam.grad.item()) < 1e-4 and abs(db - bet.grad.item()) < 1e-4
+
+
+def test_glu_weightnorm_vs_torch(oracle):
+    rng = np.random.default_rng(3)
+    outer, half, inner = 2, 3, 5
+    x = rng.normal(size=(outer, 2 * half, inner)).astype(np.float32)
+    dy = rng.normal(size=(outer, half, inner)).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    yt = F.glu(xt, 1)
+    assert np.allclose(oracle.glu_fwd(x, outer, half, inner).reshape(yt.shape), yt.detach().numpy(), atol=1e-6)
+    yt.backward(torch.tensor(dy, dtype=torch.float64))
+    assert np.allclose(oracle.glu_bwd(x, dy, outer, half, inner), xt.grad.numpy(), atol=1e-6)
+    # WN dim 3 on conv weights [Cout][Cin][kw]
+    v = rng.normal(size=(4, 3, 5)).astype(np.float32)
+    g = rng.normal(size=4).astype(np.float32)
+    dw = rng.normal(size=v.shape).astype(np.float32)
+    vt = torch.tensor(v, dtype=torch.float64, requires_grad=True)
+    gt = torch.tensor(g, dtype=torch.float64, requires_grad=True)
+    wt = vt * (gt / vt.reshape(4, -1).norm(dim=1))[:, None, None]
+    assert np.allclose(oracle.weightnorm_fwd(v, g, 1, 4, 15), wt.detach().numpy(), atol=1e-6)
+    wt.backward(torch.tensor(dw, dtype=torch.float64))
+    dv, dg = oracle.weightnorm_bwd(v, g, dw, 1, 4, 15)
+    assert np.allclose(dv, vt.grad.numpy(), atol=1e-5) and np.allclose(dg, gt.grad.numpy(), atol=1e-5)
+    # WN dim 0 on linear W memory [in][out]: norm over `in` per output column
+    v = rng.normal(size=(6, 4)).astype(np.float32)
+    w = oracle.weightnorm_fwd(v, g, 6, 4, 1)
+    assert np.allclose(w, v * (g / np.linalg.norm(v.astype(np.float64), axis=0)), atol=1e-6)
+
+
+@pytest.mark.parametrize("ln_mode", ["all", "frame"])
+def test_tds_block_backward_vs_torch(oracle, ln_mode):
+    rng = np.random.default_rng(4)
+    B, Cc, H, T, kw = 2, 3, 4, 9, 5
+    p = refnet.TDSParams(Cc, kw, H, l2=20, rng=rng)
+    x = rng.normal(size=(B, Cc, H, T)).astype(np.float32)
+    dout = rng.normal(size=x.shape).astype(np.float32)
+    out, saved = refnet.tds_fwd(x, p, 2, 2, ln_mode, keep=True)
+    dx, g = refnet.tds_bwd(dout, p, saved, 2, 2, ln_mode)
+
+    td = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64, requires_grad=True)
+    xt, wc, bc, w1, b1, w2, b2 = map(td, (x, p.wc, p.bc, p.w1, p.b1, p.w2, p.b2))
+    g1, b1n, g2, b2n = map(td, (p.g1, p.b1n, p.g2, p.b2n))
+
+    def ln(v, gam, bet):
+        dims = (1, 2, 3) if ln_mode == "all" else (1, 2)
+        mu = v.mean(dims, keepdim=True)
+        var = ((v - mu) ** 2).mean(dims, keepdim=True)
+        return (v - mu) / torch.sqrt(var + 1e-5) * gam + bet
+
+    a = F.conv2d(F.pad(xt, (2, 2)), wc[:, :, None, :], bc)
+    y = ln(torch.relu(a) + xt, g1, b1n)
+    z = y.permute(0, 3, 2, 1).reshape(B * T, H * Cc)
+    v = torch.relu(z @ w1 + b1) @ w2 + b2
+    s = v.reshape(B, T, H, Cc).permute(0, 3, 2, 1) + y
+    ot = ln(s, g2, b2n)
+    assert np.allclose(out, ot.detach().numpy(), atol=1e-4)
+    ot.backward(torch.tensor(dout, dtype=torch.float64))
+    assert np.allclose(dx, xt.grad.numpy(), atol=1e-4)
+    for name, t in dict(wc=wc, bc=bc, w1=w1, b1=b1, w2=w2, b2=b2, g1=g1, b1n=b1n, g2=g2, b2n=b2n).items():
+        assert np.allclose(g[name], t.grad.numpy(), atol=2e-4), name
+
+
+def test_dropout_hash_statistics(oracle):
+    x = np.ones(200000, np.float32)
+    y = oracle.dropout(x, 0.25, 1234, 7)
+    keep = (y != 0).mean()
+    assert abs(keep - 0.75) < 0.01
+    assert np.allclose(y[y != 0], 1 / 0.75)
+    y2 = oracle.dropout(x, 0.25, 1234, 8)
+    assert 0.5 < ((y != 0) == (y2 != 0)).mean() < 0.7  # streams decorrelated (0.75^2+0.25^2=0.625)
