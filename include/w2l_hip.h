@@ -1,0 +1,112 @@
+/*
+ * w2l_hip.h -- C ABI of libw2l_hip.so: the MI355X (gfx950) implementation of the
+ * wav2letter acoustic-training hot path.
+ *
+ * Every pointer is a DEVICE pointer unless its name starts with h_.  All entry
+ * points are asynchronous on `stream` (a hipStream_t passed as void*; NULL =
+ * the default stream), re-entrant, keep no global state and return a
+ * w2l_status (0 = OK) instead of throwing.  The caller owns every buffer,
+ * including the workspaces sized by the *_workspace_size queries.
+ *
+ * Section 1 mirrors, one for one, the static functions of Flashlight's
+ *   fl::lib::{cpu,cuda}::{ForceAlignmentCriterion, FullConnectionCriterion,
+ *   ViterbiPath, ConnectionistTemporalClassificationCriterion}<float>
+ *   and CriterionUtils (flashlight/lib/sequence/criterion/, un-vendored; call
+ *   sites in /root/reference: recipes/slimIPL/src/Train.cpp:406-410, :1675,
+ *   :838, :1375; recipes/joint_training_vox_populi/cpc/Train.cpp:813),
+ * which is what fl::pkg::speech::{ASGLoss,CTCLoss} bind.
+ * Layouts: emissions [B][T][N] (ArrayFire dims (N,T,B)); targets [B][L] int32
+ * padded with negative values; transitions [N][N] indexed [to][from]; CTC
+ * blank = N-1; paths [B][T] int32.
+ */
+#ifndef W2L_HIP_H_
+#define W2L_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* w2l_stream_t; /* hipStream_t */
+
+typedef enum {
+  W2L_OK = 0,
+  W2L_EINVAL = 1,       /* bad shape / null pointer (Flashlight throws std::invalid_argument) */
+  W2L_EHIP = 2,         /* a HIP runtime call failed; see w2l_last_hip_error() */
+  W2L_EUNSUPPORTED = 3  /* shape outside what this build implements */
+} w2l_status;
+
+/* fl::lib::seq::CriterionScaleMode (selected by --onorm / --sqnorm,
+ * recipes/slimIPL/src/Train.cpp:389; recipes/conv_glu/librispeech/train.cfg:20-21) */
+typedef enum {
+  W2L_SCALE_NONE = 0,
+  W2L_SCALE_INPUT_SZ = 1,
+  W2L_SCALE_INPUT_SZ_SQRT = 2,
+  W2L_SCALE_TARGET_SZ = 3,
+  W2L_SCALE_TARGET_SZ_SQRT = 4
+} w2l_scale_mode;
+
+const char* w2l_version(void);
+int w2l_last_hip_error(void); /* hipError_t of the last failing call on this thread */
+
+/* ------------------------------------------------------------------------
+ * 1. Sequence criteria
+ * ---------------------------------------------------------------------- */
+
+/* CriterionUtils::batchTargetSize: targetSize[b] = #leading non-negative labels
+ * of target[b][0..L), clamped to maxSize (== T for ASG). */
+int w2l_batch_target_size(int B, int L, int maxSize, const int* target, int* targetSize,
+                          w2l_stream_t stream);
+/* CTC flavour: with R = adjacent repeats, L <- min(L + R, T) - R */
+int w2l_batch_ctc_target_size(int B, int L, int T, const int* target, int* targetSize,
+                              w2l_stream_t stream);
+
+/* FullConnectionCriterion<float>: log-partition over all N^T paths. */
+size_t w2l_fcc_workspace_size(int B, int T, int N);
+int w2l_fcc_forward(int B, int T, int N, int scaleMode, const float* input,
+                    const int* targetSize, const float* trans, float* loss,
+                    void* workspace, w2l_stream_t stream);
+/* inputGrad [B][T][N] and transGrad [N][N] are OVERWRITTEN (transGrad summed over b). */
+int w2l_fcc_backward(int B, int T, int N, const float* trans, const float* grad,
+                     float* inputGrad, float* transGrad, void* workspace,
+                     w2l_stream_t stream);
+
+/* ForceAlignmentCriterion<float>: log-sum over monotone alignments of target. */
+size_t w2l_fac_workspace_size(int B, int T, int N, int L);
+int w2l_fac_forward(int B, int T, int N, int L, int scaleMode, const float* input,
+                    const int* target, const int* targetSize, const float* trans,
+                    float* loss, void* workspace, w2l_stream_t stream);
+int w2l_fac_backward(int B, int T, int N, int L, const int* target, const int* targetSize,
+                     const float* grad, float* inputGrad, float* transGrad,
+                     void* workspace, w2l_stream_t stream);
+/* forced alignment; bestPaths [B][T] holds target labels */
+int w2l_fac_viterbi(int B, int T, int N, int L, const float* input, const int* target,
+                    const int* targetSize, const float* trans, int* bestPaths,
+                    void* workspace, w2l_stream_t stream);
+
+/* ViterbiPath<float>: max-product path, first-max tie break, BIT-EXACT with the
+ * CPU recursion (fp32 adds in the order (delta[j] + trans[i][j]) + x[t][i]). */
+size_t w2l_viterbi_workspace_size(int B, int T, int N);
+int w2l_viterbi_compute(int B, int T, int N, const float* input, const float* trans,
+                        int* path, void* workspace, w2l_stream_t stream);
+
+/* ConnectionistTemporalClassificationCriterion<float>; input are raw emissions
+ * (log-softmax is applied inside), blank = N-1. */
+size_t w2l_ctc_workspace_size(int B, int T, int N, int L);
+int w2l_ctc_forward(int B, int T, int N, int L, int scaleMode, const float* input,
+                    const int* target, const int* targetSize, float* loss,
+                    void* workspace, w2l_stream_t stream);
+/* needs `input` again (the softmax is recomputed instead of stored: 12*B*T*N
+ * bytes of HBM traffic per fwd+bwd instead of 16). inputGrad OVERWRITTEN. */
+int w2l_ctc_backward(int B, int T, int N, int L, const float* input, const int* target,
+                     const int* targetSize, const float* grad, float* inputGrad,
+                     void* workspace, w2l_stream_t stream);
+/* CTCLoss::viterbiPath: per-frame argmax, first max wins */
+int w2l_ctc_viterbi(int B, int T, int N, const float* input, int* path, w2l_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* W2L_HIP_H_ */

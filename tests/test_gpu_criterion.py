@@ -1,0 +1,283 @@
+"""Parity of the HIP sequence criteria (through the C ABI) against the CPU oracle.
+
+Bar (BASELINE.json north_star): Viterbi paths bit-exact; loss / gradients within
+1e-4 of the oracle relative to the largest reference magnitude, fp32.
+"""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def relerr(got, want):
+    want = np.asarray(want, np.float64)
+    got = np.asarray(got, np.float64)
+    return np.abs(got - want).max() / max(1.0, np.abs(want).max())
+
+
+def gradrel(got, want):
+    want = np.asarray(want, np.float64)
+    got = np.asarray(got, np.float64)
+    return np.abs(got - want).max() / max(1e-30, np.abs(want).max())
+
+
+def make_targets(rng, B, L, N, T, min_len=1, no_adjacent_repeat=False, hi=None):
+    hi = N if hi is None else hi
+    tgt = np.full((B, L), -1, np.int32)
+    for b in range(B):
+        l = int(rng.integers(min_len, min(L, T) + 1))
+        y = rng.integers(0, hi, size=l)
+        if no_adjacent_repeat:
+            for i in range(1, l):
+                while y[i] == y[i - 1]:
+                    y[i] = rng.integers(0, hi)
+        tgt[b, :l] = y
+    return tgt
+
+
+def test_wave_ops_selftest():
+    from wav2letter_amd import _lib
+    rng = np.random.default_rng(0)
+    v = rng.normal(size=64).astype(np.float32)
+    i = dev(v)
+    o = torch.zeros(384, device="cuda")
+    _lib.check(_lib.lib().w2l_selftest_wave_ops(i.data_ptr(), o.data_ptr(), None))
+    torch.cuda.synchronize()
+    o = o.cpu().numpy()
+    assert (o[:64] == v.max()).all()
+    assert np.allclose(o[64:128], v.astype(np.float64).sum(), rtol=1e-5, atol=1e-5)
+    assert o[128] == -1 and (o[129:192] == v[:-1]).all()
+    assert o[255] == -2 and (o[192:255] == v[1:]).all()
+    assert o[256] == -3 and np.allclose(o[257:320], 3 * v[:-1], rtol=1e-6)
+    assert (o[320:384] == v[17]).all()
+
+
+@pytest.mark.parametrize("B,T,N", [(3, 1, 2), (2, 2, 5), (3, 9, 30), (2, 50, 33), (2, 17, 64), (4, 301, 30)])
+@pytest.mark.parametrize("mode", [0, 4])
+def test_fcc_matches_oracle(oracle, B, T, N, mode):
+    from wav2letter_amd import FullConnectionCriterion
+    rng = np.random.default_rng(B * 1000 + T * 10 + N)
+    x = (rng.normal(size=(B, T, N)) * 1.5).astype(np.float32)
+    A = rng.normal(size=(N, N)).astype(np.float32)
+    tgt = make_targets(rng, B, 7, N, T)
+    w = rng.normal(size=B).astype(np.float32)
+    crit = FullConnectionCriterion(N, mode).cuda()
+    crit.transitions.data = dev(A)
+    xt = dev(x).requires_grad_(True)
+    loss = crit(xt, dev(tgt))
+    (loss * dev(w)).sum().backward()
+    ts = oracle.batch_target_size(tgt, T)
+    o = oracle.FCC(x, A, ts, mode)
+    ol = o.forward()
+    odx, odA = o.backward(w.astype(np.float64))
+    assert relerr(loss.detach().cpu().numpy(), ol) < TOL
+    assert gradrel(xt.grad.cpu().numpy(), odx) < TOL
+    assert gradrel(crit.transitions.grad.cpu().numpy(), odA) < TOL
+
+
+@pytest.mark.parametrize("B,T,N,L", [(3, 6, 4, 3), (2, 40, 30, 40), (3, 90, 30, 70), (2, 300, 28, 200),
+                                      (2, 400, 30, 300), (2, 120, 100, 64), (2, 50, 1500, 20)])
+@pytest.mark.parametrize("mode", [0, 4])
+def test_fac_matches_oracle(oracle, B, T, N, L, mode):
+    from wav2letter_amd import ForceAlignmentCriterion
+    rng = np.random.default_rng(L * 7 + T)
+    x = (rng.normal(size=(B, T, N)) * 1.5).astype(np.float32)
+    A = rng.normal(size=(N, N)).astype(np.float32)
+    tgt = make_targets(rng, B, L, N, T)
+    tgt[0, :min(L, T)] = rng.integers(0, N, size=min(L, T))  # one utterance with L == min(L,T)
+    w = rng.normal(size=B).astype(np.float32)
+    crit = ForceAlignmentCriterion(N, mode).cuda()
+    crit.transitions.data = dev(A)
+    xt = dev(x).requires_grad_(True)
+    loss = crit(xt, dev(tgt))
+    (loss * dev(w)).sum().backward()
+    o = oracle.FAC(x, A, tgt, scale_mode=mode)
+    ol = o.forward()
+    odx, odA = o.backward(w.astype(np.float64))
+    assert relerr(loss.detach().cpu().numpy(), ol) < TOL
+    assert gradrel(xt.grad.cpu().numpy(), odx) < TOL
+    assert gradrel(crit.transitions.grad.cpu().numpy(), odA) < TOL
+    # forced alignment path: bit-exact
+    p = crit.viterbiPath(dev(x), dev(tgt)).cpu().numpy()
+    assert (p == o.viterbi()).all()
+
+
+def test_asg_loss_librispeech_shape_slice(oracle):
+    """conv_glu LibriSpeech ASG geometry (N=30, --transdiag=4, target/sqrt scaling), B reduced"""
+    from wav2letter_amd import ASGLoss, CriterionScaleMode
+    rng = np.random.default_rng(42)
+    B, T, N, L = 4, 500, 30, 120
+    x = rng.normal(size=(B, T, N)).astype(np.float32)
+    tgt = make_targets(rng, B, L, 28, T, min_len=20, no_adjacent_repeat=True)
+    crit = ASGLoss(N, CriterionScaleMode.TARGET_SZ_SQRT, 4.0).cuda()
+    A = (np.eye(N) * 4 + rng.normal(size=(N, N)) * 0.1).astype(np.float32)
+    crit.transitions.data = dev(A)
+    xt = dev(x).requires_grad_(True)
+    loss = crit(xt, dev(tgt))
+    loss.sum().backward()
+    ol, odx, odA = oracle.asg(x, A, tgt, 4)
+    assert relerr(loss.detach().cpu().numpy(), ol) < TOL
+    assert gradrel(xt.grad.cpu().numpy(), odx) < TOL
+    assert gradrel(crit.transitions.grad.cpu().numpy(), odA) < TOL
+
+
+def test_asg_full_size_identities():
+    """BASELINE config 4 criterion shape (B=64,T=2000,N=30): size-independent properties
+    (SURVEY App. B.6 iv, v): per-frame gradient mass and transition-gradient mass."""
+    from wav2letter_amd import ForceAlignmentCriterion, FullConnectionCriterion
+    rng = np.random.default_rng(4)
+    B, T, N, L = 64, 2000, 30, 300
+    x = dev(rng.normal(size=(B, T, N)).astype(np.float32))
+    tgt = dev(make_targets(rng, B, L, 28, T, min_len=60))
+    A = dev((np.eye(N) * 4 + rng.normal(size=(N, N)) * 0.1).astype(np.float32))
+    for cls in (FullConnectionCriterion, ForceAlignmentCriterion):
+        crit = cls(N, 0).cuda()
+        crit.transitions.data = A.clone()
+        xt = x.clone().requires_grad_(True)
+        loss = crit(xt, tgt)
+        assert torch.isfinite(loss).all()
+        loss.sum().backward()
+        mass = xt.grad.double().sum(-1)
+        assert (mass - 1).abs().max().item() < 1e-4
+        assert abs(crit.transitions.grad.double().sum().item() - B * (T - 1)) < 1e-4 * B * (T - 1)
+
+
+@pytest.mark.parametrize("B,T,N", [(3, 1, 2), (2, 7, 5), (5, 60, 30), (2, 33, 64), (3, 700, 30)])
+def test_viterbi_bit_exact(oracle, B, T, N):
+    from wav2letter_amd import ASGLoss
+    rng = np.random.default_rng(T + N)
+    x = rng.normal(size=(B, T, N)).astype(np.float32)
+    A = rng.normal(size=(N, N)).astype(np.float32)
+    crit = ASGLoss(N).cuda()
+    crit.transitions.data = dev(A)
+    got = crit.viterbiPath(dev(x)).cpu().numpy()
+    assert (got == oracle.viterbi(x, A)).all()
+    # heavy ties: quantised scores, first max must win exactly like the CPU scan
+    xq = np.round(x * 2) / 2
+    Aq = np.round(A * 2) / 2
+    crit.transitions.data = dev(Aq.astype(np.float32))
+    got = crit.viterbiPath(dev(xq.astype(np.float32))).cpu().numpy()
+    assert (got == oracle.viterbi(xq, Aq)).all()
+
+
+def test_viterbi_full_size_bit_exact(oracle):
+    from wav2letter_amd import ASGLoss
+    rng = np.random.default_rng(9)
+    B, T, N = 64, 2000, 30
+    x = rng.normal(size=(B, T, N)).astype(np.float32)
+    A = (np.eye(N) * 4 + rng.normal(size=(N, N)) * 0.1).astype(np.float32)
+    crit = ASGLoss(N).cuda()
+    crit.transitions.data = dev(A)
+    got = crit.viterbiPath(dev(x)).cpu().numpy()
+    assert (got == oracle.viterbi(x, A)).all()
+
+
+@pytest.mark.parametrize("B,T,N,L", [(3, 8, 3, 4), (4, 30, 29, 10), (2, 50, 1000, 40), (3, 64, 9998, 80),
+                                      (2, 300, 50, 140), (2, 20, 12290, 5)])
+@pytest.mark.parametrize("mode", [0, 4])
+def test_ctc_matches_oracle(oracle, B, T, N, L, mode):
+    from wav2letter_amd import CTCLoss
+    rng = np.random.default_rng(N + L)
+    x = (rng.normal(size=(B, T, N)) * 2).astype(np.float32)
+    tgt = make_targets(rng, B, L, N, T, hi=N - 1)
+    tgt[0, :] = -1                      # empty transcription
+    if L >= 4:
+        tgt[1, :4] = [1, 1, 0, 0]       # repeats
+    w = rng.normal(size=B).astype(np.float32)
+    crit = CTCLoss(mode)
+    xt = dev(x).requires_grad_(True)
+    loss = crit(xt, dev(tgt))
+    (loss * dev(w)).sum().backward()
+    o = oracle.CTC(x, tgt, scale_mode=mode)
+    ol = o.forward()
+    odx = o.backward(w.astype(np.float64))
+    assert relerr(loss.detach().cpu().numpy(), ol) < TOL
+    assert gradrel(xt.grad.cpu().numpy(), odx) < TOL
+    assert (crit.viterbiPath(dev(x)).cpu().numpy() == oracle.ctc_viterbi(x)).all()
+
+
+def test_ctc_target_longer_than_input_is_truncated(oracle):
+    from wav2letter_amd import CTCLoss
+    rng = np.random.default_rng(1)
+    B, T, N, L = 2, 5, 6, 9
+    x = rng.normal(size=(B, T, N)).astype(np.float32)
+    tgt = np.array([[1, 1, 1, 1, 2, 3, 4, 0, 1], [0, 1, 2, 3, 4, 0, 1, 2, 3]], np.int32)
+    loss = CTCLoss()(dev(x), dev(tgt)).cpu().numpy()
+    ol = oracle.CTC(x, tgt).forward()
+    assert np.isfinite(ol).all() == np.isfinite(loss).all()
+    fin = np.isfinite(ol)
+    assert relerr(loss[fin], ol[fin]) < TOL
+
+
+def test_ctc_tds_shape_full_size(oracle):
+    """BASELINE config 2 criterion shape: B=32, T'=188, N=9998 word pieces + blank."""
+    from wav2letter_amd import CTCLoss, CriterionScaleMode
+    rng = np.random.default_rng(2)
+    B, T, N, L = 32, 188, 9998, 80
+    x = rng.normal(size=(B, T, N)).astype(np.float32)
+    tgt = make_targets(rng, B, L, N, T, min_len=20, hi=N - 1)
+    crit = CTCLoss(CriterionScaleMode.TARGET_SZ_SQRT)
+    xt = dev(x).requires_grad_(True)
+    loss = crit(xt, dev(tgt))
+    loss.sum().backward()
+    o = oracle.CTC(x, tgt, scale_mode=4)
+    assert relerr(loss.detach().cpu().numpy(), o.forward()) < TOL
+    assert gradrel(xt.grad.cpu().numpy(), o.backward()) < TOL
+    # softmax - occupancy sums to 0 over classes for every frame
+    assert xt.grad.double().sum(-1).abs().max().item() < 1e-5
+
+
+def test_error_behaviour_mirrors_flashlight():
+    from wav2letter_amd import ASGLoss, CTCLoss
+    from wav2letter_amd._lib import W2LInvalidArgument
+    x = torch.zeros(2, 5, 7, device="cuda")
+    with pytest.raises(W2LInvalidArgument):
+        CTCLoss()(x.double(), torch.zeros(2, 3, dtype=torch.int32, device="cuda"))
+    with pytest.raises(W2LInvalidArgument):
+        CTCLoss()(x, torch.zeros(2, 3, dtype=torch.int64, device="cuda"))
+    with pytest.raises(W2LInvalidArgument):
+        ASGLoss(6).cuda()(x, torch.zeros(2, 3, dtype=torch.int32, device="cuda"))
+
+
+def test_criterion_timings_report():
+    """not a pass/fail test: prints kernel timings at the BASELINE criterion shapes"""
+    from wav2letter_amd import ASGLoss, CTCLoss, CriterionScaleMode
+    rng = np.random.default_rng(0)
+
+    def timeit(f, n=5):
+        f(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            f()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    B, T, N, L = 64, 2000, 30, 300
+    x = dev(rng.normal(size=(B, T, N)).astype(np.float32)).requires_grad_(True)
+    tgt = dev(make_targets(rng, B, L, 28, T, min_len=60, no_adjacent_repeat=True))
+    asg = ASGLoss(N, CriterionScaleMode.TARGET_SZ_SQRT, 4.0).cuda()
+    f_ms = timeit(lambda: asg(x, tgt))
+    fb_ms = timeit(lambda: asg(x, tgt).sum().backward())
+    v_ms = timeit(lambda: asg.viterbiPath(x.detach()))
+    print(f"\n[timing] ASG B={B} T={T} N={N}: fwd {f_ms:.3f} ms, fwd+bwd {fb_ms:.3f} ms, viterbi {v_ms:.3f} ms")
+    B, T, N, L = 32, 188, 9998, 80
+    x = dev(rng.normal(size=(B, T, N)).astype(np.float32)).requires_grad_(True)
+    tgt = dev(make_targets(rng, B, L, N, T, min_len=20, hi=N - 1))
+    ctc = CTCLoss(CriterionScaleMode.TARGET_SZ_SQRT)
+    f_ms = timeit(lambda: ctc(x, tgt))
+    fb_ms = timeit(lambda: ctc(x, tgt).sum().backward())
+    gb = 12 * B * T * N / 1e9
+    print(f"[timing] CTC B={B} T={T} N={N}: fwd {f_ms:.3f} ms, fwd+bwd {fb_ms:.3f} ms "
+          f"({gb / (fb_ms * 1e-3):.0f} GB/s algorithmic incl. host overhead)")

@@ -1,0 +1,85 @@
+"""ctypes binding of libw2l_hip.so (the C ABI declared in include/w2l_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` /
+`make -C wav2letter_amd/csrc`.  There is NO fallback: if the shared object is
+missing or a call fails, this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libw2l_hip.so")
+_lib = None
+
+W2L_OK, W2L_EINVAL, W2L_EHIP, W2L_EUNSUPPORTED = 0, 1, 2, 3
+_ERR = {1: "W2L_EINVAL (bad shape / null pointer)", 2: "W2L_EHIP (HIP runtime error)",
+        3: "W2L_EUNSUPPORTED (shape outside this build)"}
+
+
+class W2LError(RuntimeError):
+    pass
+
+
+class W2LInvalidArgument(W2LError, ValueError):
+    """mirrors the std::invalid_argument Flashlight's criteria throw"""
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise W2LError(
+                f"{SO_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C wav2letter_amd/csrc` (no CPU fallback exists)")
+        _lib = C.CDLL(SO_PATH)
+        _lib.w2l_version.restype = C.c_char_p
+        for name in dir(_SIGS):
+            if name.startswith("w2l_"):
+                fn = getattr(_lib, name)
+                restype, argtypes = getattr(_SIGS, name)
+                fn.restype = restype
+                fn.argtypes = argtypes
+    return _lib
+
+
+_p, _i, _sz, _f, _u32, _u64, _d = C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_uint32, C.c_uint64, C.c_double
+
+
+class _SIGS:
+    w2l_last_hip_error = (_i, [])
+    w2l_selftest_wave_ops = (_i, [_p, _p, _p])
+    w2l_batch_target_size = (_i, [_i, _i, _i, _p, _p, _p])
+    w2l_batch_ctc_target_size = (_i, [_i, _i, _i, _p, _p, _p])
+    w2l_fcc_workspace_size = (_sz, [_i, _i, _i])
+    w2l_fcc_forward = (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p])
+    w2l_fcc_backward = (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p])
+    w2l_fac_workspace_size = (_sz, [_i, _i, _i, _i])
+    w2l_fac_forward = (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p])
+    w2l_fac_backward = (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p])
+    w2l_fac_viterbi = (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p])
+    w2l_viterbi_workspace_size = (_sz, [_i, _i, _i])
+    w2l_viterbi_compute = (_i, [_i, _i, _i, _p, _p, _p, _p, _p])
+    w2l_ctc_workspace_size = (_sz, [_i, _i, _i, _i])
+    w2l_ctc_forward = (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p])
+    w2l_ctc_backward = (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p])
+    w2l_ctc_viterbi = (_i, [_i, _i, _i, _p, _p, _p])
+
+
+def check(status, what=""):
+    if status == W2L_OK:
+        return
+    msg = f"{what}: {_ERR.get(status, status)}"
+    if status == W2L_EHIP:
+        msg += f" (hipError {lib().w2l_last_hip_error()})"
+    if status == W2L_EINVAL:
+        raise W2LInvalidArgument(msg)
+    raise W2LError(msg)
+
+
+def exported_symbols():
+    """names declared in include/w2l_hip.h (parsed), for the ABI-completeness test"""
+    import re
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "w2l_hip.h")
+    src = open(hdr).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(w2l_[a-z0-9_]+)\s*\(", src)))

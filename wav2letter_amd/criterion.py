@@ -1,0 +1,274 @@
+"""Host-side mirror of fl::pkg::speech sequence criteria over the C ABI.
+
+Mirrors (same names, argument meaning, error behaviour) the interface the
+reference's Trainer uses (recipes/slimIPL/src/Train.cpp:406-410, :1675, :838;
+shape of SequenceCriterion in recipes/joint_training_vox_populi/cpc/CPCCriterion.h:30-50):
+
+  ASGLoss(N, scalemode, transdiag).forward(emission, target) -> loss[B]
+  CTCLoss(scalemode).forward(emission, target) -> loss[B]
+  crit.viterbiPath(emission) -> int32 [B][T];  crit.viterbiPathWithTarget(...)
+
+Tensors are torch CUDA(HIP) tensors used only as device buffers: emission is
+[B][T][N] float32 contiguous (== ArrayFire dims (N,T,B)), target [B][L] int32
+padded with -1.  Every op runs in libw2l_hip.so; there is no PyTorch fallback.
+"""
+import enum
+
+import torch
+
+from . import _lib
+
+
+class CriterionScaleMode(enum.IntEnum):
+    NONE = 0
+    INPUT_SZ = 1
+    INPUT_SZ_SQRT = 2
+    TARGET_SZ = 3
+    TARGET_SZ_SQRT = 4
+
+
+def getCriterionScaleMode(onorm: str, sqnorm: bool) -> CriterionScaleMode:
+    """recipes/slimIPL/src/Train.cpp:389 (--onorm / --sqnorm)"""
+    if onorm == "none":
+        return CriterionScaleMode.NONE
+    if onorm == "input":
+        return CriterionScaleMode.INPUT_SZ_SQRT if sqnorm else CriterionScaleMode.INPUT_SZ
+    if onorm == "target":
+        return CriterionScaleMode.TARGET_SZ_SQRT if sqnorm else CriterionScaleMode.TARGET_SZ
+    raise _lib.W2LInvalidArgument(f"invalid onorm option: {onorm}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check_dev(*ts):
+    for t in ts:
+        if not t.is_cuda:
+            raise _lib.W2LError("w2l criteria run on the GPU only (no CPU fallback)")
+
+
+def _emission_checks(emission, target=None):
+    if emission.dim() != 3:
+        raise _lib.W2LInvalidArgument("emission must be [B][T][N]")
+    if emission.dtype != torch.float32:
+        raise _lib.W2LInvalidArgument("emission must be float32")
+    if target is not None:
+        if target.dtype != torch.int32:
+            raise _lib.W2LInvalidArgument("target must be int32")
+        if target.dim() != 2 or target.shape[0] != emission.shape[0]:
+            raise _lib.W2LInvalidArgument("target must be [B][L]")
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def batch_target_size(target, max_size, ctc=False):
+    B, L = target.shape
+    out = torch.empty(B, dtype=torch.int32, device=target.device)
+    fn = _lib.lib().w2l_batch_ctc_target_size if ctc else _lib.lib().w2l_batch_target_size
+    _lib.check(fn(B, L, int(max_size), target.data_ptr(), out.data_ptr(), _stream()), "batch_target_size")
+    return out
+
+
+class _FCC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emission, trans, target_size, scale_mode):
+        L = _lib.lib()
+        emission = emission.contiguous()
+        trans = trans.contiguous()
+        B, T, N = emission.shape
+        ws = _ws(L.w2l_fcc_workspace_size(B, T, N), emission.device)
+        loss = torch.empty(B, dtype=torch.float32, device=emission.device)
+        _lib.check(L.w2l_fcc_forward(B, T, N, int(scale_mode), emission.data_ptr(), target_size.data_ptr(),
+                                     trans.data_ptr(), loss.data_ptr(), ws.data_ptr(), _stream()), "fcc_forward")
+        ctx.save_for_backward(trans, ws)
+        ctx.dims = (B, T, N)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad):
+        L = _lib.lib()
+        trans, ws = ctx.saved_tensors
+        B, T, N = ctx.dims
+        grad = grad.contiguous().float()
+        dx = torch.empty(B, T, N, dtype=torch.float32, device=grad.device)
+        dt = torch.empty(N, N, dtype=torch.float32, device=grad.device)
+        _lib.check(L.w2l_fcc_backward(B, T, N, trans.data_ptr(), grad.data_ptr(), dx.data_ptr(), dt.data_ptr(),
+                                      ws.data_ptr(), _stream()), "fcc_backward")
+        return dx, dt, None, None
+
+
+class _FAC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emission, trans, target, target_size, scale_mode):
+        L = _lib.lib()
+        emission = emission.contiguous()
+        trans = trans.contiguous()
+        target = target.contiguous()
+        B, T, N = emission.shape
+        Lt = target.shape[1]
+        ws = _ws(L.w2l_fac_workspace_size(B, T, N, Lt), emission.device)
+        loss = torch.empty(B, dtype=torch.float32, device=emission.device)
+        _lib.check(L.w2l_fac_forward(B, T, N, Lt, int(scale_mode), emission.data_ptr(), target.data_ptr(),
+                                     target_size.data_ptr(), trans.data_ptr(), loss.data_ptr(), ws.data_ptr(),
+                                     _stream()), "fac_forward")
+        ctx.save_for_backward(target, target_size, ws)
+        ctx.dims = (B, T, N, Lt)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad):
+        L = _lib.lib()
+        target, target_size, ws = ctx.saved_tensors
+        B, T, N, Lt = ctx.dims
+        grad = grad.contiguous().float()
+        dx = torch.empty(B, T, N, dtype=torch.float32, device=grad.device)
+        dt = torch.empty(N, N, dtype=torch.float32, device=grad.device)
+        _lib.check(L.w2l_fac_backward(B, T, N, Lt, target.data_ptr(), target_size.data_ptr(), grad.data_ptr(),
+                                      dx.data_ptr(), dt.data_ptr(), ws.data_ptr(), _stream()), "fac_backward")
+        return dx, dt, None, None, None
+
+
+class _CTC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emission, target, target_size, scale_mode):
+        L = _lib.lib()
+        emission = emission.contiguous()
+        target = target.contiguous()
+        B, T, N = emission.shape
+        Lt = target.shape[1]
+        ws = _ws(L.w2l_ctc_workspace_size(B, T, N, Lt), emission.device)
+        loss = torch.empty(B, dtype=torch.float32, device=emission.device)
+        _lib.check(L.w2l_ctc_forward(B, T, N, Lt, int(scale_mode), emission.data_ptr(), target.data_ptr(),
+                                     target_size.data_ptr(), loss.data_ptr(), ws.data_ptr(), _stream()),
+                   "ctc_forward")
+        ctx.save_for_backward(emission, target, target_size, ws)
+        ctx.dims = (B, T, N, Lt)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad):
+        L = _lib.lib()
+        emission, target, target_size, ws = ctx.saved_tensors
+        B, T, N, Lt = ctx.dims
+        grad = grad.contiguous().float()
+        dx = torch.empty(B, T, N, dtype=torch.float32, device=grad.device)
+        _lib.check(L.w2l_ctc_backward(B, T, N, Lt, emission.data_ptr(), target.data_ptr(), target_size.data_ptr(),
+                                      grad.data_ptr(), dx.data_ptr(), ws.data_ptr(), _stream()), "ctc_backward")
+        return dx, None, None, None
+
+
+class SequenceCriterion(torch.nn.Module):
+    """fl::pkg::speech::SequenceCriterion: forward({emission,target}) -> {loss[B]},
+    viterbiPath(emission) -> [B][T] int32."""
+
+    def prettyString(self):
+        return type(self).__name__
+
+
+class FullConnectionCriterion(SequenceCriterion):
+    def __init__(self, N, scalemode=CriterionScaleMode.NONE, transitions=None):
+        super().__init__()
+        self.N, self.scalemode = N, scalemode
+        self.transitions = transitions if transitions is not None else torch.nn.Parameter(torch.zeros(N, N))
+
+    def forward(self, emission, target):
+        _emission_checks(emission, target)
+        _check_dev(emission, target)
+        if emission.shape[2] != self.N:
+            raise _lib.W2LInvalidArgument("FullConnectionCriterion: N doesn't match with the letter size")
+        ts = batch_target_size(target, emission.shape[1])
+        return _FCC.apply(emission, self.transitions, ts, self.scalemode)
+
+
+class ForceAlignmentCriterion(SequenceCriterion):
+    def __init__(self, N, scalemode=CriterionScaleMode.NONE, transitions=None):
+        super().__init__()
+        self.N, self.scalemode = N, scalemode
+        self.transitions = transitions if transitions is not None else torch.nn.Parameter(torch.zeros(N, N))
+
+    def forward(self, emission, target):
+        _emission_checks(emission, target)
+        _check_dev(emission, target)
+        if emission.shape[2] != self.N:
+            raise _lib.W2LInvalidArgument("ForceAlignmentCriterion: N doesn't match with the letter size")
+        ts = batch_target_size(target, emission.shape[1])
+        return _FAC.apply(emission, self.transitions, target, ts, self.scalemode)
+
+    def viterbiPath(self, emission, target):
+        _emission_checks(emission, target)
+        L = _lib.lib()
+        emission = emission.contiguous()
+        B, T, N = emission.shape
+        Lt = target.shape[1]
+        ts = batch_target_size(target, T)
+        ws = _ws(L.w2l_fac_workspace_size(B, T, N, Lt), emission.device)
+        path = torch.empty(B, T, dtype=torch.int32, device=emission.device)
+        _lib.check(L.w2l_fac_viterbi(B, T, N, Lt, emission.data_ptr(), target.data_ptr(), ts.data_ptr(),
+                                     self.transitions.detach().contiguous().data_ptr(), path.data_ptr(),
+                                     ws.data_ptr(), _stream()), "fac_viterbi")
+        return path
+
+
+class ASGLoss(SequenceCriterion):
+    """AutoSegmentationCriterion = FCC - FAC sharing one N x N transition
+    parameter initialised to transdiag * I (recipes/slimIPL/src/Train.cpp:410;
+    --transdiag, recipes/conv_glu/librispeech/train.cfg:25)."""
+
+    def __init__(self, N, scalemode=CriterionScaleMode.NONE, transdiag=0.0):
+        super().__init__()
+        self.N, self.scalemode = N, scalemode
+        self.transitions = torch.nn.Parameter(torch.eye(N) * float(transdiag))
+        self.fac = ForceAlignmentCriterion(N, scalemode, self.transitions)
+        self.fcc = FullConnectionCriterion(N, scalemode, self.transitions)
+
+    def forward(self, emission, target):
+        return self.fcc(emission, target) - self.fac(emission, target)
+
+    def viterbiPath(self, emission, inputSize=None):
+        _emission_checks(emission)
+        _check_dev(emission)
+        L = _lib.lib()
+        emission = emission.contiguous()
+        B, T, N = emission.shape
+        ws = _ws(L.w2l_viterbi_workspace_size(B, T, N), emission.device)
+        path = torch.empty(B, T, dtype=torch.int32, device=emission.device)
+        _lib.check(L.w2l_viterbi_compute(B, T, N, emission.data_ptr(),
+                                         self.transitions.detach().contiguous().data_ptr(), path.data_ptr(),
+                                         ws.data_ptr(), _stream()), "viterbi_compute")
+        return path
+
+    def viterbiPathWithTarget(self, emission, target):
+        return self.fac.viterbiPath(emission, target)
+
+    def prettyString(self):
+        return "AutoSegmentationCriterion"
+
+
+class CTCLoss(SequenceCriterion):
+    """ConnectionistTemporalClassificationCriterion(scalemode); blank = N-1"""
+
+    def __init__(self, scalemode=CriterionScaleMode.NONE):
+        super().__init__()
+        self.scalemode = scalemode
+
+    def forward(self, emission, target):
+        _emission_checks(emission, target)
+        _check_dev(emission, target)
+        ts = batch_target_size(target, emission.shape[1], ctc=True)
+        return _CTC.apply(emission, target, ts, self.scalemode)
+
+    def viterbiPath(self, emission, inputSize=None):
+        _emission_checks(emission)
+        _check_dev(emission)
+        emission = emission.contiguous()
+        B, T, N = emission.shape
+        path = torch.empty(B, T, dtype=torch.int32, device=emission.device)
+        _lib.check(_lib.lib().w2l_ctc_viterbi(B, T, N, emission.data_ptr(), path.data_ptr(), _stream()),
+                   "ctc_viterbi")
+        return path
+
+    def prettyString(self):
+        return "ConnectionistTemporalClassificationCriterion"

@@ -1,0 +1,118 @@
+// common.hpp -- shared device/host helpers for libw2l_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "../../include/w2l_hip.h"
+
+#define W2L_API extern "C" __attribute__((visibility("default")))
+
+namespace w2l {
+
+extern thread_local int g_last_hip_error;
+
+inline int hip_fail(hipError_t e) {
+  g_last_hip_error = (int)e;
+  return W2L_EHIP;
+}
+
+#define W2L_HIP_CHECK(expr)                         \
+  do {                                              \
+    hipError_t _e = (expr);                         \
+    if (_e != hipSuccess) return ::w2l::hip_fail(_e); \
+  } while (0)
+
+#define W2L_LAUNCH_CHECK() W2L_HIP_CHECK(hipGetLastError())
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+constexpr int kWave = 64;
+
+// ---- scale modes (CriterionUtils::computeScale) ---------------------------
+__host__ __device__ inline float scale_of(int mode, int T, int L) {
+  switch (mode) {
+    case W2L_SCALE_INPUT_SZ: return T > 0 ? 1.0f / (float)T : 1.0f;
+    case W2L_SCALE_INPUT_SZ_SQRT: return T > 0 ? sqrtf(1.0f / (float)T) : 1.0f;
+    case W2L_SCALE_TARGET_SZ: return L > 0 ? 1.0f / (float)L : 1.0f;
+    case W2L_SCALE_TARGET_SZ_SQRT: return L > 0 ? sqrtf(1.0f / (float)L) : 1.0f;
+    default: return 1.0f;
+  }
+}
+
+// ---- wavefront helpers (wave = 64 lanes) ----------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// DPP row rotate-right by n inside each row of 16 lanes (dpp_ctrl 0x120 + n)
+template <int N>
+__device__ __forceinline__ float dpp_row_ror(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
+}
+
+__device__ __forceinline__ float readlane(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// max over all 64 lanes, result uniform. 4 DPP rotations give every lane its
+// 16-lane row maximum; 4 v_readlane + 3 max combine the rows. No LDS.
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, dpp_row_ror<1>(v));
+  v = fmaxf(v, dpp_row_ror<2>(v));
+  v = fmaxf(v, dpp_row_ror<4>(v));
+  v = fmaxf(v, dpp_row_ror<8>(v));
+  float a = readlane(v, 0), b = readlane(v, 16), c = readlane(v, 32), d = readlane(v, 48);
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_row_ror<1>(v);
+  v += dpp_row_ror<2>(v);
+  v += dpp_row_ror<4>(v);
+  v += dpp_row_ror<8>(v);
+  float a = readlane(v, 0), b = readlane(v, 16), c = readlane(v, 32), d = readlane(v, 48);
+  return (a + b) + (c + d);
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// value of lane-1 (lane 0 receives `fill`)
+__device__ __forceinline__ float lane_shift_up(float v, float fill) {
+  float r = __shfl_up(v, 1);
+  return lane_id() == 0 ? fill : r;
+}
+__device__ __forceinline__ double lane_shift_up(double v, double fill) {
+  double r = __shfl_up(v, 1);
+  return lane_id() == 0 ? fill : r;
+}
+__device__ __forceinline__ float lane_shift_down(float v, float fill) {
+  float r = __shfl_down(v, 1);
+  return lane_id() == 63 ? fill : r;
+}
+__device__ __forceinline__ double lane_shift_down(double v, double fill) {
+  double r = __shfl_down(v, 1);
+  return lane_id() == 63 ? fill : r;
+}
+
+// ---- stateless dropout hash: must stay bit-identical to oracle/nn_oracle.c --
+__host__ __device__ inline uint32_t hash32(uint32_t idx, uint32_t seed, uint32_t stream) {
+  uint32_t h = idx * 0x9E3779B1u + seed;
+  h ^= stream * 0x85EBCA77u;
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+__host__ __device__ inline bool keep_elem(uint64_t idx, uint32_t seed, uint32_t stream, uint32_t thr) {
+  uint32_t h = hash32((uint32_t)idx ^ (uint32_t)(idx >> 32) * 0x27D4EB2Fu, seed, stream);
+  return (h >> 8) >= thr;
+}
+inline uint32_t dropout_threshold(double p) {
+  double t = p * 16777216.0;
+  if (t < 0) t = 0;
+  if (t > 16777216.0) t = 16777216.0;
+  return (uint32_t)t;
+}
+
+}  // namespace w2l

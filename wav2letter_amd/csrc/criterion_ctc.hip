@@ -1,0 +1,523 @@
+// criterion_ctc.hip -- ConnectionistTemporalClassificationCriterion for gfx950.
+//
+// Replaces Flashlight's CTC criterion (CUDA build: warp-ctc; CPU build:
+// flashlight/lib/sequence/criterion/cpu/ConnectionistTemporalClassificationCriterion.cpp,
+// un-vendored).  Reference call sites: recipes/slimIPL/src/Train.cpp:406-407, :1675;
+// blank is the LAST class (Train.cpp:248-251).  Math: SURVEY.md App. B.4; CPU
+// restatement: oracle/criterion_oracle.c (== torch ctc_loss(blank=N-1)).
+//
+// At the north-star size (N = 9998 word pieces) the criterion is HBM-bound on
+// streaming the [B][T][N] emissions, so it is split by access pattern:
+//   ctc_rows_lse   one workgroup per (b,t) row: the row is read ONCE into
+//                  registers (coalesced, 16 B/lane where alignment allows) and
+//                  reduced to lse[b][t]; the <= 2L+1 label log-probs the lattice
+//                  needs are gathered from the register-resident row's source.
+//   ctc_lattice    one wavefront per utterance: alpha and beta scans over the
+//                  2L+1 extended labels (positions blocked over lanes, fp64
+//                  carries with fp32 log-sum-exp corrections), loss, and the
+//                  occupancies gamma[t][s] = exp(alpha+beta-lp-logZ).
+//   ctc_rows_grad  one workgroup per row: grad = g*(softmax(x) - occupancy):
+//                  streams x once more, writes grad once, then subtracts the
+//                  <= 2L+1 occupancies of that frame.
+// Algorithmic HBM bytes: 4BTN (fwd) + 8BTN (bwd) = 12*B*T*N.
+#include "common.hpp"
+
+namespace w2l {
+
+constexpr int kRowThreads = 256;
+constexpr int kRowMaxPer = 48;  // register-resident row: N <= 256*48 = 12288
+
+struct CtcWs {
+  float* lse;     // [B][T]
+  float* lp;      // [B][T][S]   label log-probs, later overwritten by gamma
+  double* alpha;  // [B][T][S]
+  float* scale;   // [B]
+  float* nll;     // [B]  (-log likelihood, unscaled)
+  int S;          // 2L+1 for the padded L
+};
+
+__host__ __device__ inline CtcWs ctc_ws(void* ws, int B, int T, int N, int L) {
+  (void)N;
+  CtcWs w;
+  w.S = 2 * L + 1;
+  char* p = (char*)ws;
+  w.lse = (float*)p; p += align_up((size_t)B * T * sizeof(float), 256);
+  w.lp = (float*)p; p += align_up((size_t)B * T * w.S * sizeof(float), 256);
+  w.alpha = (double*)p; p += align_up((size_t)B * T * w.S * sizeof(double), 256);
+  w.scale = (float*)p; p += align_up((size_t)B * sizeof(float), 256);
+  w.nll = (float*)p;
+  return w;
+}
+
+__device__ __forceinline__ float block_reduce_max(float v, float* sm) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  float r = sm[0];
+  for (int k = 1; k < (int)(blockDim.x >> 6); ++k) r = fmaxf(r, sm[k]);
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ float block_reduce_sum(float v, float* sm) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  float r = sm[0];
+  for (int k = 1; k < (int)(blockDim.x >> 6); ++k) r += sm[k];
+  __syncthreads();
+  return r;
+}
+
+// Row loader: elements [0,N) of a row that is only 4-byte aligned. Thread tid owns
+// element indices  head: tid (< nh);  body: nh + 4*(tid + 256*k) .. +3;  tail scalars.
+// nh = number of leading scalars so that the body is 16-byte aligned.
+struct RowSplit { int nh, nbody4, ntail; };
+__device__ __forceinline__ RowSplit row_split(const float* row, int N) {
+  RowSplit r;
+  int mis = (int)(((uintptr_t)row >> 2) & 3);
+  r.nh = mis ? 4 - mis : 0;
+  if (r.nh > N) r.nh = N;
+  r.nbody4 = (N - r.nh) >> 2;
+  r.ntail = (N - r.nh) & 3;
+  return r;
+}
+
+// lse[b][t] and the label log-probs lp[b][t][s] = x[ext_s] - lse
+__global__ __launch_bounds__(kRowThreads) void ctc_rows_lse(int T, int N, int L,
+                                                            const float* __restrict__ x,
+                                                            const int* __restrict__ target,
+                                                            const int* __restrict__ targetSize,
+                                                            CtcWs ws) {
+  __shared__ float sm[8];
+  const size_t r = blockIdx.x;  // row = b*T + t
+  const int b = (int)(r / T);
+  const float* row = x + r * N;
+  const int tid = threadIdx.x;
+  RowSplit sp = row_split(row, N);
+  const float4* body = (const float4*)(row + sp.nh);
+
+  float4 v[kRowMaxPer / 4];
+  float m = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < kRowMaxPer / 4; ++k) {
+    int idx = tid + kRowThreads * k;
+    if (idx < sp.nbody4) {
+      v[k] = body[idx];
+      m = fmaxf(m, fmaxf(fmaxf(v[k].x, v[k].y), fmaxf(v[k].z, v[k].w)));
+    }
+  }
+  float hv = -INFINITY;
+  if (tid < sp.nh) hv = row[tid];
+  else if (tid >= 64 && tid - 64 < sp.ntail) hv = row[sp.nh + 4 * sp.nbody4 + (tid - 64)];
+  m = fmaxf(m, hv);
+  m = block_reduce_max(m, sm);
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < kRowMaxPer / 4; ++k) {
+    int idx = tid + kRowThreads * k;
+    if (idx < sp.nbody4)
+      s += (__expf(v[k].x - m) + __expf(v[k].y - m)) + (__expf(v[k].z - m) + __expf(v[k].w - m));
+  }
+  if (hv != -INFINITY) s += __expf(hv - m);
+  s = block_reduce_sum(s, sm);
+  const float lse = m + __logf(s);
+  if (tid == 0) ws.lse[r] = lse;
+  // gather label log-probs
+  const int Lb = targetSize[b];
+  const int S = 2 * Lb + 1;
+  const int* y = target + (size_t)b * L;
+  float* lp = ws.lp + r * ws.S;
+  for (int si = tid; si < S; si += kRowThreads) {
+    int lab = (si & 1) ? y[si >> 1] : (N - 1);
+    lp[si] = row[lab] - lse;
+  }
+}
+
+// generic-N fallback (N > 256*kRowMaxPer): two passes over the row
+__global__ __launch_bounds__(kRowThreads) void ctc_rows_lse_big(int T, int N, int L,
+                                                                const float* __restrict__ x,
+                                                                const int* __restrict__ target,
+                                                                const int* __restrict__ targetSize,
+                                                                CtcWs ws) {
+  __shared__ float sm[8];
+  const size_t r = blockIdx.x;
+  const int b = (int)(r / T);
+  const float* row = x + r * N;
+  const int tid = threadIdx.x;
+  float m = -INFINITY;
+  for (int n = tid; n < N; n += kRowThreads) m = fmaxf(m, row[n]);
+  m = block_reduce_max(m, sm);
+  float s = 0.f;
+  for (int n = tid; n < N; n += kRowThreads) s += __expf(row[n] - m);
+  s = block_reduce_sum(s, sm);
+  const float lse = m + __logf(s);
+  if (tid == 0) ws.lse[r] = lse;
+  const int Lb = targetSize[b];
+  const int S = 2 * Lb + 1;
+  const int* y = target + (size_t)b * L;
+  float* lp = ws.lp + r * ws.S;
+  for (int si = tid; si < S; si += kRowThreads) {
+    int lab = (si & 1) ? y[si >> 1] : (N - 1);
+    lp[si] = row[lab] - lse;
+  }
+}
+
+__device__ __forceinline__ double lse3(double a, double b, double c) {
+  double m = fmax(a, fmax(b, c));
+  if (m == -INFINITY) return m;
+  float s = __expf((float)(a - m)) + __expf((float)(b - m)) + __expf((float)(c - m));
+  return m + (double)__logf(s);
+}
+
+// alpha / beta over the extended label sequence; positions blocked over lanes.
+template <int P>
+__global__ __launch_bounds__(64) void ctc_lattice(int T, int N, int L, int scaleMode,
+                                                  const int* __restrict__ target,
+                                                  const int* __restrict__ targetSize,
+                                                  float* __restrict__ loss, CtcWs ws) {
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int Lb = targetSize[b];
+  const int S = 2 * Lb + 1;
+  const int SW = ws.S;
+  const int* y = target + (size_t)b * L;
+  float* lp = ws.lp + (size_t)b * T * SW;
+  double* al = ws.alpha + (size_t)b * T * SW;
+  const double NEG = -INFINITY;
+  const float sc = scale_of(scaleMode, T, Lb);
+
+  bool skipPrev[P];  // may come from s-2
+  bool skipNext[P];  // may go to s+2
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    int si = lane * P + p;
+    int e0 = (si & 1) ? ((si >> 1) < Lb ? y[si >> 1] : -1) : (N - 1);
+    int em2 = (si >= 2 && (si & 1)) ? y[(si - 2) >> 1] : -2;
+    int ep2 = ((si & 1) && si + 2 < S) ? y[(si + 2) >> 1] : -2;
+    skipPrev[p] = (si < S) && (si & 1) && si >= 2 && e0 != em2;
+    skipNext[p] = (si < S) && (si & 1) && si + 2 < S && e0 != ep2;
+  }
+
+  // ---- alpha
+  constexpr int D = 4;  // lattice-row prefetch depth (steps)
+  double a[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    int si = lane * P + p;
+    a[p] = (si < S && si < 2) ? (double)lp[si] : NEG;
+    if (si < S) al[si] = a[p];
+  }
+  {
+    float lc[D][P], ln[D][P];
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        int si = lane * P + p, t = 1 + u;
+        lc[u][p] = (t < T && si < S) ? lp[(size_t)t * SW + si] : 0.f;
+      }
+    for (int t0 = 1; t0 < T; t0 += D) {
+#pragma unroll
+      for (int u = 0; u < D; ++u)
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          int si = lane * P + p, t = t0 + D + u;
+          ln[u][p] = (t < T && si < S) ? lp[(size_t)t * SW + si] : 0.f;
+        }
+#pragma unroll
+      for (int u = 0; u < D; ++u) {
+        const int t = t0 + u;
+        if (t < T) {
+          double c1 = lane_shift_up(a[P - 1], NEG);                              // alpha[lane*P - 1]
+          double c2 = lane_shift_up(P >= 2 ? a[P >= 2 ? P - 2 : 0] : NEG, NEG);  // alpha[lane*P - 2]
+          if (P == 1) c2 = lane_shift_up(c1, NEG);
+          double pm1 = c1, pm2 = c2;
+          double* alt = al + (size_t)t * SW;
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            int si = lane * P + p;
+            double cur = a[p];
+            double v = lse3(cur, pm1, skipPrev[p] ? pm2 : NEG);
+            double na = NEG;
+            if (si < S && v != NEG) na = v + (double)lc[u][p];
+            if (si < S) alt[si] = na;
+            pm2 = pm1;
+            pm1 = cur;
+            a[p] = na;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < D; ++u)
+#pragma unroll
+        for (int p = 0; p < P; ++p) lc[u][p] = ln[u][p];
+    }
+  }
+  // log-likelihood = lse(alpha[T-1][S-1], alpha[T-1][S-2])
+  double ll = NEG;
+  {
+    double v1 = NEG, v2 = NEG;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      int si = lane * P + p;
+      if (si == S - 1) v1 = a[p];
+      if (si == S - 2) v2 = a[p];
+    }
+    // gather across lanes
+    double m1 = v1, m2 = v2;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      m1 = fmax(m1, __shfl_xor(m1, off));
+      m2 = fmax(m2, __shfl_xor(m2, off));
+    }
+    ll = lse3(m1, m2, NEG);
+  }
+  if (lane == 0) {
+    loss[b] = (float)(-(double)sc * ll);
+    ws.scale[b] = sc;
+    ws.nll[b] = (float)(-ll);
+  }
+
+  // ---- beta, fused with gamma[t][s] = exp(alpha + beta - lp - ll) (overwrites lp)
+  double be[P];
+  {
+    const float* lpt = lp + (size_t)(T - 1) * SW;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      int si = lane * P + p;
+      be[p] = (si < S && si >= S - 2) ? (double)lpt[si] : NEG;
+    }
+  }
+  __syncthreads();  // alpha stores of this wave drained before they are re-read
+  {
+    // per step t (descending): lpA = lp[t], alA = alpha[t], lpB = lp[t-1]
+    float lpA[D][P], lpB[D][P], nlpA[D][P], nlpB[D][P];
+    double alA[D][P], nalA[D][P];
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        int si = lane * P + p, t = T - 1 - u;
+        bool ok = t >= 0 && si < S;
+        lpA[u][p] = ok ? lp[(size_t)t * SW + si] : 0.f;
+        alA[u][p] = ok ? al[(size_t)t * SW + si] : NEG;
+        lpB[u][p] = (ok && t >= 1) ? lp[(size_t)(t - 1) * SW + si] : 0.f;
+      }
+    for (int thi = T - 1; thi >= 0; thi -= D) {
+#pragma unroll
+      for (int u = 0; u < D; ++u)
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          int si = lane * P + p, t = thi - D - u;
+          bool ok = t >= 0 && si < S;
+          nlpA[u][p] = ok ? lp[(size_t)t * SW + si] : 0.f;
+          nalA[u][p] = ok ? al[(size_t)t * SW + si] : NEG;
+          nlpB[u][p] = (ok && t >= 1) ? lp[(size_t)(t - 1) * SW + si] : 0.f;
+        }
+#pragma unroll
+      for (int u = 0; u < D; ++u) {
+        const int t = thi - u;
+        if (t >= 0) {
+          float* lpt = lp + (size_t)t * SW;
+          // gamma for frame t from beta_t (be) and alpha_t; overwrites lp[t]
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            int si = lane * P + p;
+            if (si < S) {
+              double av = alA[u][p];
+              float gm = 0.f;
+              if (av != NEG && be[p] != NEG && ll != NEG)
+                gm = __expf((float)(av + be[p] - (double)lpA[u][p] - ll));
+              lpt[si] = gm;
+            }
+          }
+          if (t >= 1) {
+            // beta_{t-1}[s] = lse(beta_t[s], beta_t[s+1], beta_t[s+2] if allowed) + lp[t-1][s]
+            double n1 = lane_shift_down(be[0], NEG);                               // beta[(lane+1)*P]
+            double n2 = lane_shift_down(P >= 2 ? be[P >= 2 ? 1 : 0] : NEG, NEG);   // beta[(lane+1)*P + 1]
+            if (P == 1) n2 = lane_shift_down(n1, NEG);
+            double nb[P];
+#pragma unroll
+            for (int p = P - 1; p >= 0; --p) {
+              int si = lane * P + p;
+              double b1 = (p + 1 < P) ? be[p + 1 < P ? p + 1 : 0] : n1;
+              double b2 = (p + 2 < P) ? be[p + 2 < P ? p + 2 : 0] : ((p + 1 < P) ? n1 : n2);
+              double v = lse3(be[p], b1, skipNext[p] ? b2 : NEG);
+              nb[p] = (si < S && v != NEG) ? v + (double)lpB[u][p] : NEG;
+            }
+#pragma unroll
+            for (int p = 0; p < P; ++p) be[p] = nb[p];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < D; ++u)
+#pragma unroll
+        for (int p = 0; p < P; ++p) { lpA[u][p] = nlpA[u][p]; alA[u][p] = nalA[u][p]; lpB[u][p] = nlpB[u][p]; }
+    }
+  }
+}
+
+// grad row = g * softmax(x); then subtract g * gamma at the frame's labels
+__global__ __launch_bounds__(kRowThreads) void ctc_rows_grad(int T, int N, int L,
+                                                             const float* __restrict__ x,
+                                                             const int* __restrict__ target,
+                                                             const int* __restrict__ targetSize,
+                                                             const float* __restrict__ grad,
+                                                             float* __restrict__ dx, CtcWs ws) {
+  const size_t r = blockIdx.x;
+  const int b = (int)(r / T);
+  const float* row = x + r * N;
+  float* out = dx + r * N;
+  const int tid = threadIdx.x;
+  const float g = ws.scale[b] * grad[b];
+  const float lse = ws.lse[r];
+  RowSplit sp = row_split(row, N);  // dx has the same alignment as x modulo 16 B iff bases agree
+  const bool same = ((((uintptr_t)row) ^ ((uintptr_t)out)) & 15) == 0;
+  if (same) {
+    const float4* body = (const float4*)(row + sp.nh);
+    float4* obody = (float4*)(out + sp.nh);
+    for (int idx = tid; idx < sp.nbody4; idx += kRowThreads) {
+      float4 v = body[idx];
+      v.x = g * __expf(v.x - lse); v.y = g * __expf(v.y - lse);
+      v.z = g * __expf(v.z - lse); v.w = g * __expf(v.w - lse);
+      obody[idx] = v;
+    }
+    if (tid < sp.nh) out[tid] = g * __expf(row[tid] - lse);
+    else if (tid >= 64 && tid - 64 < sp.ntail) {
+      int n = sp.nh + 4 * sp.nbody4 + (tid - 64);
+      out[n] = g * __expf(row[n] - lse);
+    }
+  } else {
+    for (int n = tid; n < N; n += kRowThreads) out[n] = g * __expf(row[n] - lse);
+  }
+  __syncthreads();  // drains the row stores (vmcnt(0)) before the label fix-up
+  const int Lb = targetSize[b];
+  const int S = 2 * Lb + 1;
+  const int* y = target + (size_t)b * L;
+  const float* gm = ws.lp + r * ws.S;
+  for (int si = tid; si < S; si += kRowThreads) {
+    int lab = (si & 1) ? y[si >> 1] : (N - 1);
+    float v = gm[si];
+    if (v != 0.f) atomicAdd(&out[lab], -g * v);
+  }
+}
+
+__global__ __launch_bounds__(kRowThreads) void ctc_rows_argmax(int N, const float* __restrict__ x,
+                                                               int* __restrict__ path) {
+  __shared__ float smv[4];
+  __shared__ int smi[4];
+  const size_t r = blockIdx.x;
+  const float* row = x + r * N;
+  const int tid = threadIdx.x;
+  float best = -INFINITY;
+  int arg = 0x7fffffff;
+  for (int n = tid; n < N; n += kRowThreads) {
+    float v = row[n];
+    if (v > best) { best = v; arg = n; }  // ascending n per thread: first max kept
+  }
+  // wave: max value, then smallest index among lanes holding it
+  float m = wave_max(best);
+  int cand = (best == m) ? arg : 0x7fffffff;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) cand = min(cand, __shfl_xor(cand, off));
+  if ((tid & 63) == 0) { smv[tid >> 6] = m; smi[tid >> 6] = cand; }
+  __syncthreads();
+  if (tid == 0) {
+    float bm = smv[0];
+    int bi = smi[0];
+    for (int k = 1; k < kRowThreads / 64; ++k) {
+      if (smv[k] > bm || (smv[k] == bm && smi[k] < bi)) { bm = smv[k]; bi = smi[k]; }
+    }
+    path[r] = bi;
+  }
+}
+
+__global__ void batch_target_size_k(int B, int L, int maxSize, const int* __restrict__ target,
+                                    int* __restrict__ targetSize, int ctc) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int* y = target + (size_t)b * L;
+  int n = 0;
+  while (n < L && y[n] >= 0) ++n;
+  if (!ctc) {
+    targetSize[b] = n < maxSize ? n : maxSize;
+  } else {
+    int R = 0;
+    for (int i = 1; i < n; ++i) R += (y[i] == y[i - 1]);
+    int m = (n + R < maxSize ? n + R : maxSize) - R;
+    targetSize[b] = m < 0 ? 0 : m;
+  }
+}
+
+}  // namespace w2l
+
+using namespace w2l;
+
+W2L_API int w2l_batch_target_size(int B, int L, int maxSize, const int* target, int* targetSize,
+                                  w2l_stream_t stream) {
+  if (B <= 0 || L <= 0 || !target || !targetSize) return W2L_EINVAL;
+  hipLaunchKernelGGL(batch_target_size_k, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, L, maxSize, target, targetSize, 0);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+W2L_API int w2l_batch_ctc_target_size(int B, int L, int T, const int* target, int* targetSize,
+                                      w2l_stream_t stream) {
+  if (B <= 0 || L <= 0 || !target || !targetSize) return W2L_EINVAL;
+  hipLaunchKernelGGL(batch_target_size_k, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, L, T, target, targetSize, 1);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+W2L_API size_t w2l_ctc_workspace_size(int B, int T, int N, int L) {
+  if (B <= 0 || T <= 0 || N <= 0 || L < 0) return 0;
+  size_t S = 2 * (size_t)L + 1;
+  return align_up((size_t)B * T * sizeof(float), 256) + align_up((size_t)B * T * S * sizeof(float), 256) +
+         align_up((size_t)B * T * S * sizeof(double), 256) + 2 * align_up((size_t)B * sizeof(float), 256);
+}
+
+W2L_API int w2l_ctc_forward(int B, int T, int N, int L, int scaleMode, const float* input,
+                            const int* target, const int* targetSize, float* loss,
+                            void* workspace, w2l_stream_t stream) {
+  if (B <= 0 || T <= 0 || N <= 1 || L <= 0 || !input || !target || !targetSize || !loss || !workspace)
+    return W2L_EINVAL;
+  if (2 * L + 1 > 64 * 8) return W2L_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  CtcWs ws = ctc_ws(workspace, B, T, N, L);
+  const unsigned rows = (unsigned)((size_t)B * T);
+  if (N <= kRowThreads * kRowMaxPer)
+    hipLaunchKernelGGL(ctc_rows_lse, dim3(rows), dim3(kRowThreads), 0, s, T, N, L, input, target, targetSize, ws);
+  else
+    hipLaunchKernelGGL(ctc_rows_lse_big, dim3(rows), dim3(kRowThreads), 0, s, T, N, L, input, target, targetSize, ws);
+  W2L_LAUNCH_CHECK();
+  const int S = 2 * L + 1;
+  if (S <= 64) hipLaunchKernelGGL(ctc_lattice<1>, dim3(B), dim3(64), 0, s, T, N, L, scaleMode, target, targetSize, loss, ws);
+  else if (S <= 128) hipLaunchKernelGGL(ctc_lattice<2>, dim3(B), dim3(64), 0, s, T, N, L, scaleMode, target, targetSize, loss, ws);
+  else if (S <= 256) hipLaunchKernelGGL(ctc_lattice<4>, dim3(B), dim3(64), 0, s, T, N, L, scaleMode, target, targetSize, loss, ws);
+  else hipLaunchKernelGGL(ctc_lattice<8>, dim3(B), dim3(64), 0, s, T, N, L, scaleMode, target, targetSize, loss, ws);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+W2L_API int w2l_ctc_backward(int B, int T, int N, int L, const float* input, const int* target,
+                             const int* targetSize, const float* grad, float* inputGrad,
+                             void* workspace, w2l_stream_t stream) {
+  if (B <= 0 || T <= 0 || N <= 1 || L <= 0 || !input || !target || !targetSize || !grad || !inputGrad || !workspace)
+    return W2L_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  CtcWs ws = ctc_ws(workspace, B, T, N, L);
+  const unsigned rows = (unsigned)((size_t)B * T);
+  hipLaunchKernelGGL(ctc_rows_grad, dim3(rows), dim3(kRowThreads), 0, s, T, N, L, input, target, targetSize, grad, inputGrad, ws);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+W2L_API int w2l_ctc_viterbi(int B, int T, int N, const float* input, int* path, w2l_stream_t stream) {
+  if (B <= 0 || T <= 0 || N <= 0 || !input || !path) return W2L_EINVAL;
+  hipLaunchKernelGGL(ctc_rows_argmax, dim3((unsigned)((size_t)B * T)), dim3(kRowThreads), 0, (hipStream_t)stream, N, input, path);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}

@@ -1,0 +1,384 @@
+// criterion_fac.hip -- ForceAlignmentCriterion (forward / backward / viterbi), gfx950.
+//
+// Replaces fl::lib::cuda::ForceAlignmentCriterion<float> (un-vendored Flashlight;
+// the reference's call sites: recipes/slimIPL/src/Train.cpp:408-410, :1675).
+// Math: SURVEY.md App. B.1; CPU restatement: oracle/criterion_oracle.c.
+//
+// One wavefront per utterance scans T in a single launch.  Target positions are
+// blocked over lanes (lane l owns positions [l*P, (l+1)*P), P = ceil(L/64) as a
+// template parameter) so only ONE cross-lane hand-off (alpha of position l*P-1)
+// is needed per time step.  alpha is carried in fp64 registers; the two-way
+// log-sum-exp correction log(1 + exp(-|d|)) is evaluated in fp32 (|error| < 1e-7
+// per step), which keeps ASG = FCC - FAC inside the 1e-4 parity bar without any
+// per-step renormalisation.  The forward stores only the "stay" posterior
+// w1[t][i] = exp(s_stay - lse) (fp32, [B][T][L]); backward is then exp-free:
+//   dalpha_{t-1}[i] = dalpha_t[i] w1[t][i] + dalpha_t[i+1] (1 - w1[t][i+1]).
+// Emission values x[t][y_i] are gathered straight from the coalesced [B][T][N]
+// rows (L1/L2 resident: the row is 120 B at N = 30), prefetched kFacChunk steps ahead.
+#include "common.hpp"
+
+namespace w2l {
+
+constexpr int kFacChunk = 4;
+constexpr int kFacMaxN = 2048;  // LDS row buffer for the input-gradient scatter
+
+struct FacWs {
+  float* w1;     // [B][T][L]
+  float* scale;  // [B]
+  float* tgpart; // [B][N][N] (only when it is small enough, else NULL -> atomics)
+  unsigned char* bp;  // viterbi back pointers [B][T][L]
+};
+
+__host__ __device__ inline bool fac_use_partials(int B, int N) {
+  return (size_t)B * N * N <= ((size_t)1 << 22);
+}
+
+__host__ __device__ inline FacWs fac_ws(void* ws, int B, int T, int N, int L) {
+  FacWs w;
+  char* p = (char*)ws;
+  w.w1 = (float*)p; p += align_up((size_t)B * T * L * sizeof(float), 256);
+  w.scale = (float*)p; p += align_up((size_t)B * sizeof(float), 256);
+  w.bp = (unsigned char*)w.w1;  // viterbi reuses the w1 region (needs B*T*L bytes)
+  w.tgpart = fac_use_partials(B, N) ? (float*)p : nullptr;
+  return w;
+}
+
+template <int P>
+__global__ __launch_bounds__(64) void fac_fwd(int T, int N, int L, int scaleMode,
+                                              const float* __restrict__ x,
+                                              const int* __restrict__ target,
+                                              const int* __restrict__ targetSize,
+                                              const float* __restrict__ trans,
+                                              float* __restrict__ loss, FacWs ws) {
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int S = targetSize[b];
+  const float sc = scale_of(scaleMode, T, S);
+  if (lane == 0) ws.scale[b] = sc;
+  if (S <= 0) {
+    if (lane == 0) loss[b] = 0.f;
+    return;
+  }
+  const int* y = target + (size_t)b * L;
+  const float* xb = x + (size_t)b * T * N;
+  float* w1b = ws.w1 + (size_t)b * T * L;
+  const double NEG = -INFINITY;
+
+  int yi[P];
+  float selfT[P], prevT[P];
+  double alpha[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    int i = lane * P + p;
+    bool v = i < S;
+    yi[p] = v ? y[i] : 0;
+    int yp = (v && i > 0) ? y[i - 1] : 0;
+    selfT[p] = v ? trans[(size_t)yi[p] * N + yi[p]] : 0.f;
+    prevT[p] = (v && i > 0) ? trans[(size_t)yi[p] * N + yp] : 0.f;
+    alpha[p] = NEG;
+  }
+
+  float xc[kFacChunk][P], xn[kFacChunk][P];
+#pragma unroll
+  for (int u = 0; u < kFacChunk; ++u)
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+      xc[u][p] = (u < T && lane * P + p < S) ? xb[(size_t)u * N + yi[p]] : 0.f;
+
+  for (int t0 = 0; t0 < T; t0 += kFacChunk) {
+#pragma unroll
+    for (int u = 0; u < kFacChunk; ++u) {
+      int tn = t0 + kFacChunk + u;
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        xn[u][p] = (tn < T && lane * P + p < S) ? xb[(size_t)tn * N + yi[p]] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < kFacChunk; ++u) {
+      const int t = t0 + u;
+      if (t < T) {
+        if (t == 0) {
+          if (lane == 0) alpha[0] = (double)xc[u][0];
+        } else {
+          double carry = lane_shift_up(alpha[P - 1], NEG);  // alpha_{t-1}[lane*P - 1]
+          double prevA = carry;
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            const int i = lane * P + p;
+            double cur = alpha[p];
+            double s1 = cur + (double)selfT[p];
+            double s2 = prevA + (double)prevT[p];
+            double m = fmax(s1, s2);
+            double na = NEG;
+            float w = 0.f;
+            if (i < S && m != NEG) {
+              float d = (float)(fmin(s1, s2) - m);   // <= 0, may be -inf
+              float ed = __expf(d);
+              float den = 1.f + ed;
+              na = m + (double)__logf(den) + (double)xc[u][p];
+              float inv = 1.f / den;
+              w = (s1 >= s2) ? inv : ed * inv;
+            }
+            if (i < S) w1b[(size_t)t * L + i] = w;
+            prevA = cur;
+            alpha[p] = na;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kFacChunk; ++u)
+#pragma unroll
+      for (int p = 0; p < P; ++p) xc[u][p] = xn[u][p];
+  }
+  // loss = scale * alpha[T-1][S-1]
+  const int il = S - 1;
+#pragma unroll
+  for (int p = 0; p < P; ++p)
+    if (lane * P + p == il) loss[b] = (float)((double)sc * alpha[p]);
+}
+
+template <int P>
+__global__ __launch_bounds__(64) void fac_bwd(int T, int N, int L, const int* __restrict__ target,
+                                              const int* __restrict__ targetSize,
+                                              const float* __restrict__ grad,
+                                              float* __restrict__ inputGrad,
+                                              float* __restrict__ transGrad, FacWs ws) {
+  __shared__ float row[kFacMaxN];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int S = targetSize[b];
+  float* dxb = inputGrad + (size_t)b * T * N;
+  if (S <= 0) {
+    for (size_t k = lane; k < (size_t)T * N; k += 64) dxb[k] = 0.f;
+    return;
+  }
+  const int* y = target + (size_t)b * L;
+  const float* w1b = ws.w1 + (size_t)b * T * L;
+  const float g = ws.scale[b] * grad[b];
+
+  int yi[P], yp[P];
+  float da[P], accS[P], accP[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    int i = lane * P + p;
+    bool v = i < S;
+    yi[p] = v ? y[i] : 0;
+    yp[p] = (v && i > 0) ? y[i - 1] : 0;
+    da[p] = (i == S - 1) ? 1.f : 0.f;
+    accS[p] = 0.f;
+    accP[p] = 0.f;
+  }
+  for (int k = lane; k < N; k += 64) row[k] = 0.f;
+  __syncthreads();
+
+  float wc[kFacChunk][P], wn[kFacChunk][P];
+#pragma unroll
+  for (int u = 0; u < kFacChunk; ++u) {
+    int t = T - 1 - u;
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+      wc[u][p] = (t >= 1 && lane * P + p < S) ? w1b[(size_t)t * L + lane * P + p] : 0.f;
+  }
+  for (int thi = T - 1; thi >= 0; thi -= kFacChunk) {
+#pragma unroll
+    for (int u = 0; u < kFacChunk; ++u) {
+      int t = thi - kFacChunk - u;
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        wn[u][p] = (t >= 1 && lane * P + p < S) ? w1b[(size_t)t * L + lane * P + p] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < kFacChunk; ++u) {
+      const int t = thi - u;
+      if (t >= 0) {
+        // scatter-add dalpha_t[i] into the emission-gradient row of frame t
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+          if (lane * P + p < S && da[p] != 0.f) atomicAdd(&row[yi[p]], g * da[p]);
+        __syncthreads();
+        for (int k = lane; k < N; k += 64) {
+          dxb[(size_t)t * N + k] = row[k];
+          row[k] = 0.f;
+        }
+        __syncthreads();
+        if (t >= 1) {
+          // advance part handed to position i-1: da_t[i] * (1 - w1[t][i])
+          float adv[P];
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            float w = wc[u][p];
+            float st = da[p] * w;
+            adv[p] = da[p] - st;
+            accS[p] += st;
+            accP[p] += adv[p];
+            da[p] = st;
+          }
+          float fromNext = lane_shift_down(adv[0], 0.f);  // adv of position (lane+1)*P
+#pragma unroll
+          for (int p = 0; p < P; ++p) da[p] += (p + 1 < P) ? adv[p + 1 < P ? p + 1 : 0] : fromNext;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kFacChunk; ++u)
+#pragma unroll
+      for (int p = 0; p < P; ++p) wc[u][p] = wn[u][p];
+  }
+  float* tg = ws.tgpart ? ws.tgpart + (size_t)b * N * N : transGrad;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    int i = lane * P + p;
+    if (i < S) {
+      if (accS[p] != 0.f) atomicAdd(&tg[(size_t)yi[p] * N + yi[p]], g * accS[p]);
+      if (i > 0 && accP[p] != 0.f) atomicAdd(&tg[(size_t)yi[p] * N + yp[p]], g * accP[p]);
+    }
+  }
+}
+
+__global__ void reduce_over_b_fac(int B, size_t n, const float* __restrict__ part, float* __restrict__ out) {
+  size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += part[(size_t)b * n + k];
+  out[k] = s;
+}
+
+constexpr int kFacBt = 128;  // backtrace chunk
+
+template <int P>
+__global__ __launch_bounds__(64) void fac_vit(int T, int N, int L, const float* __restrict__ x,
+                                              const int* __restrict__ target,
+                                              const int* __restrict__ targetSize,
+                                              const float* __restrict__ trans,
+                                              int* __restrict__ bestPaths, unsigned char* bpAll) {
+  extern __shared__ unsigned char sBp[];  // kFacBt * L bytes, then kFacBt ints
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int S = targetSize[b];
+  int* pb = bestPaths + (size_t)b * T;
+  if (S <= 0) {
+    for (int t = lane; t < T; t += 64) pb[t] = -1;
+    return;
+  }
+  const int* y = target + (size_t)b * L;
+  const float* xb = x + (size_t)b * T * N;
+  unsigned char* bp = bpAll + (size_t)b * T * L;
+  const float NEG = -INFINITY;
+  int yi[P];
+  float selfT[P], prevT[P], alpha[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    int i = lane * P + p;
+    bool v = i < S;
+    yi[p] = v ? y[i] : 0;
+    int ypv = (v && i > 0) ? y[i - 1] : 0;
+    selfT[p] = v ? trans[(size_t)yi[p] * N + yi[p]] : 0.f;
+    prevT[p] = (v && i > 0) ? trans[(size_t)yi[p] * N + ypv] : 0.f;
+    alpha[p] = NEG;
+  }
+  if (lane == 0) alpha[0] = xb[yi[0]];
+  for (int t = 1; t < T; ++t) {
+    float carry = lane_shift_up(alpha[P - 1], NEG);
+    float prevA = carry;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = lane * P + p;
+      float cur = alpha[p];
+      float s1 = cur + selfT[p];
+      float s2 = prevA + prevT[p];
+      float xv = (i < S) ? xb[(size_t)t * N + yi[p]] : 0.f;
+      bool adv = s2 > s1;  // ties: stay wins (oracle order)
+      float na = (adv ? s2 : s1) + xv;
+      if (i < S) bp[(size_t)t * L + i] = adv ? 1 : 0;
+      prevA = cur;
+      alpha[p] = (i < S) ? na : NEG;
+    }
+  }
+  __syncthreads();
+  int* sPath = (int*)(sBp + (size_t)kFacBt * L);
+  int cur = S - 1;
+  for (int thi = T - 1; thi >= 0; thi -= kFacBt) {
+    int tlo = thi - kFacBt + 1;
+    if (tlo < 0) tlo = 0;
+    int nsteps = thi - tlo + 1;
+    for (int k = lane; k < nsteps * L; k += 64) sBp[k] = bp[(size_t)tlo * L + k];
+    __syncthreads();
+    if (lane == 0) {
+      for (int t = thi; t >= tlo; --t) {
+        sPath[t - tlo] = y[cur];
+        if (t >= 1 && sBp[(t - tlo) * L + cur]) --cur;
+      }
+    }
+    cur = __builtin_amdgcn_readfirstlane(cur);
+    __syncthreads();
+    for (int k = lane; k < nsteps; k += 64) pb[tlo + k] = sPath[k];
+    __syncthreads();
+  }
+}
+
+}  // namespace w2l
+
+using namespace w2l;
+
+W2L_API size_t w2l_fac_workspace_size(int B, int T, int N, int L) {
+  if (B <= 0 || T <= 0 || N <= 0 || L <= 0) return 0;
+  size_t sz = align_up((size_t)B * T * L * sizeof(float), 256) + align_up((size_t)B * sizeof(float), 256);
+  if (fac_use_partials(B, N)) sz += align_up((size_t)B * N * N * sizeof(float), 256);
+  return sz;
+}
+
+#define W2L_FAC_DISPATCH(KERNEL, SHMEM, ...)                                                   \
+  do {                                                                                         \
+    if (L <= 64) hipLaunchKernelGGL(KERNEL<1>, dim3(B), dim3(64), SHMEM, s, __VA_ARGS__);      \
+    else if (L <= 128) hipLaunchKernelGGL(KERNEL<2>, dim3(B), dim3(64), SHMEM, s, __VA_ARGS__); \
+    else if (L <= 256) hipLaunchKernelGGL(KERNEL<4>, dim3(B), dim3(64), SHMEM, s, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL<8>, dim3(B), dim3(64), SHMEM, s, __VA_ARGS__);              \
+  } while (0)
+
+W2L_API int w2l_fac_forward(int B, int T, int N, int L, int scaleMode, const float* input,
+                            const int* target, const int* targetSize, const float* trans,
+                            float* loss, void* workspace, w2l_stream_t stream) {
+  if (B <= 0 || T <= 0 || N <= 0 || L <= 0 || !input || !target || !targetSize || !trans || !loss || !workspace)
+    return W2L_EINVAL;
+  if (L > 512) return W2L_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  FacWs ws = fac_ws(workspace, B, T, N, L);
+  W2L_FAC_DISPATCH(fac_fwd, 0, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+W2L_API int w2l_fac_backward(int B, int T, int N, int L, const int* target, const int* targetSize,
+                             const float* grad, float* inputGrad, float* transGrad,
+                             void* workspace, w2l_stream_t stream) {
+  if (B <= 0 || T <= 0 || N <= 0 || L <= 0 || !target || !targetSize || !grad || !inputGrad || !transGrad || !workspace)
+    return W2L_EINVAL;
+  if (L > 512 || N > kFacMaxN) return W2L_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  FacWs ws = fac_ws(workspace, B, T, N, L);
+  size_t n = (size_t)N * N;
+  if (ws.tgpart) W2L_HIP_CHECK(hipMemsetAsync(ws.tgpart, 0, (size_t)B * n * sizeof(float), s));
+  else W2L_HIP_CHECK(hipMemsetAsync(transGrad, 0, n * sizeof(float), s));
+  W2L_FAC_DISPATCH(fac_bwd, 0, T, N, L, target, targetSize, grad, inputGrad, transGrad, ws);
+  W2L_LAUNCH_CHECK();
+  if (ws.tgpart) {
+    hipLaunchKernelGGL(reduce_over_b_fac, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, B, n, ws.tgpart, transGrad);
+    W2L_LAUNCH_CHECK();
+  }
+  return W2L_OK;
+}
+
+W2L_API int w2l_fac_viterbi(int B, int T, int N, int L, const float* input, const int* target,
+                            const int* targetSize, const float* trans, int* bestPaths,
+                            void* workspace, w2l_stream_t stream) {
+  if (B <= 0 || T <= 0 || N <= 0 || L <= 0 || !input || !target || !targetSize || !trans || !bestPaths || !workspace)
+    return W2L_EINVAL;
+  if (L > 512) return W2L_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  FacWs ws = fac_ws(workspace, B, T, N, L);
+  size_t shmem = (size_t)kFacBt * L + kFacBt * sizeof(int);
+  W2L_FAC_DISPATCH(fac_vit, shmem, T, N, L, input, target, targetSize, trans, bestPaths, ws.bp);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}

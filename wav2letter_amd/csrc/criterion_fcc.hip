@@ -1,0 +1,358 @@
+// criterion_fcc.hip -- FullConnectionCriterion + ViterbiPath for gfx950.
+//
+// Replaces Flashlight's fl::lib::cuda::FullConnectionCriterion<float> /
+// ViterbiPath<float> (un-vendored; one kernel launch PER TIME STEP there, see
+// SURVEY.md 2.4).  Call sites in the reference: recipes/slimIPL/src/Train.cpp:410
+// (ASGLoss), :1675 (forward), :838 (viterbiPath).  Math: SURVEY.md App. B.2/B.3,
+// CPU restatement: oracle/criterion_oracle.c.
+//
+// Small-N path (N <= 64, the ASG letter/phone case, N = 30 for LibriSpeech):
+// ONE WAVEFRONT PER UTTERANCE scans T inside a single launch.
+//   lane i <-> state i.  exp(A[i][j] - rowmax_i) lives in NP registers per lane.
+//   Step: e_j = exp(ahat_{t-1}[j]) (one v_exp per lane); s_i = sum_j EA[i][j] e_j
+//   with e_j broadcast by v_readlane into an SGPR operand of v_fmac (no LDS, no
+//   barrier); ahat_t[i] = x_t[i] + rowmax_i + log s_i - c_t, c_t = max_i (DPP).
+//   The running offset sum_t c_t is kept in fp64 so the fp32 recursion never
+//   carries O(T) magnitudes (ASG = FCC - FAC cancellation, SURVEY 7 hard part 2b).
+//   Emission rows are read as coalesced [t][0..N) rows, prefetched 8 steps ahead.
+// Workspace keeps ahat [B][T][N] and log s [B][T][N] (fp32) for backward, which
+// then needs neither the emissions nor any exp-domain re-summation:
+//   w_ij = EA[i][j] e_j / s_i.
+#include "common.hpp"
+
+namespace w2l {
+
+constexpr int kChunk = 8;  // emission-row prefetch depth (steps)
+
+struct FccWs {
+  float* ahat;   // [B][T][N]
+  float* logs;   // [B][T][N]
+  float* scale;  // [B]
+  float* tgpart; // [B][N][N] per-utterance transition-gradient partials
+};
+
+__host__ __device__ inline FccWs fcc_ws(void* ws, int B, int T, int N) {
+  FccWs w;
+  char* p = (char*)ws;
+  size_t btn = align_up((size_t)B * T * N * sizeof(float), 256);
+  w.ahat = (float*)p; p += btn;
+  w.logs = (float*)p; p += btn;
+  w.scale = (float*)p; p += align_up((size_t)B * sizeof(float), 256);
+  w.tgpart = (float*)p;
+  return w;
+}
+
+template <int NP>
+__global__ __launch_bounds__(64) void fcc_fwd_small(int T, int N, int scaleMode,
+                                                    const float* __restrict__ x,
+                                                    const int* __restrict__ targetSize,
+                                                    const float* __restrict__ trans,
+                                                    float* __restrict__ loss, FccWs ws) {
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const bool act = lane < N;
+  const float NEG = -INFINITY;
+
+  float EA[NP];
+  float rowmax = NEG;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    float a = (act && j < N) ? trans[(size_t)lane * N + j] : NEG;
+    EA[j] = a;
+    rowmax = fmaxf(rowmax, a);
+  }
+  if (!act) rowmax = 0.f;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) EA[j] = (act && j < N) ? __expf(EA[j] - rowmax) : 0.f;
+
+  const float* xb = x + (size_t)b * T * N;
+  float* ahb = ws.ahat + (size_t)b * T * N;
+  float* lsb = ws.logs + (size_t)b * T * N;
+
+  float xc[kChunk], xn[kChunk];
+#pragma unroll
+  for (int u = 0; u < kChunk; ++u) xc[u] = (act && u < T) ? xb[(size_t)u * N + lane] : 0.f;
+
+  float ah = 0.f;
+  double C = 0.0;
+  for (int t0 = 0; t0 < T; t0 += kChunk) {
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) {
+      int tn = t0 + kChunk + u;
+      xn[u] = (act && tn < T) ? xb[(size_t)tn * N + lane] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) {
+      const int t = t0 + u;
+      if (t < T) {  // wave-uniform
+        float a, ls = 0.f;
+        if (t == 0) {
+          a = act ? xc[u] : NEG;
+        } else {
+          float e = act ? __expf(ah) : 0.f;
+          float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+          for (int j = 0; j < NP; j += 2) {
+            s0 = fmaf(EA[j], readlane(e, j), s0);
+            s1 = fmaf(EA[j + 1], readlane(e, j + 1), s1);
+          }
+          float s = fmaxf(s0 + s1, 1e-37f);
+          ls = __logf(s);
+          a = act ? (xc[u] + rowmax + ls) : NEG;
+        }
+        float c = wave_max(a);
+        ah = a - c;
+        C += (double)c;
+        if (act) {
+          ahb[(size_t)t * N + lane] = ah;
+          lsb[(size_t)t * N + lane] = ls;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) xc[u] = xn[u];
+  }
+  float e = act ? __expf(ah) : 0.f;
+  float tot = wave_sum(e);
+  float sc = scale_of(scaleMode, T, targetSize[b]);
+  if (lane == 0) {
+    loss[b] = (float)((double)sc * (C + (double)__logf(tot)));
+    ws.scale[b] = sc;
+  }
+}
+
+template <int NP>
+__global__ __launch_bounds__(64) void fcc_bwd_small(int T, int N, const float* __restrict__ trans,
+                                                    const float* __restrict__ grad,
+                                                    float* __restrict__ inputGrad, FccWs ws) {
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const bool act = lane < N;
+  const float NEG = -INFINITY;
+
+  // rowmax_i in lane i, then EAT[i] = exp(A[i][lane] - rowmax_i) (column `lane`)
+  float rowmax = NEG;
+  for (int j = 0; j < N; ++j)
+    if (act) rowmax = fmaxf(rowmax, trans[(size_t)lane * N + j]);
+  if (!act) rowmax = 0.f;
+  float EAT[NP], acc[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    float rm = readlane(rowmax, i);
+    EAT[i] = (act && i < N) ? __expf(trans[(size_t)i * N + lane] - rm) : 0.f;
+    acc[i] = 0.f;
+  }
+
+  const float* ahb = ws.ahat + (size_t)b * T * N;
+  const float* lsb = ws.logs + (size_t)b * T * N;
+  float* dxb = inputGrad + (size_t)b * T * N;
+  const float g = ws.scale[b] * grad[b];
+
+  // d loss / d alpha_{T-1} = softmax(ahat_{T-1})
+  float e = act ? __expf(ahb[(size_t)(T - 1) * N + lane]) : 0.f;
+  float da = e / wave_sum(e);
+
+  float lc[kChunk], an[kChunk], ln[kChunk], ac[kChunk];
+  // chunk c covers steps t = thi - u, u = 0..kChunk-1; needs logs[t], ahat[t-1]
+#pragma unroll
+  for (int u = 0; u < kChunk; ++u) {
+    int t = T - 1 - u;
+    lc[u] = (act && t >= 1) ? lsb[(size_t)t * N + lane] : 0.f;
+    ac[u] = (act && t >= 1) ? ahb[(size_t)(t - 1) * N + lane] : NEG;
+  }
+  for (int thi = T - 1; thi >= 1; thi -= kChunk) {
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) {
+      int t = thi - kChunk - u;
+      ln[u] = (act && t >= 1) ? lsb[(size_t)t * N + lane] : 0.f;
+      an[u] = (act && t >= 1) ? ahb[(size_t)(t - 1) * N + lane] : NEG;
+    }
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) {
+      const int t = thi - u;
+      if (t >= 1) {  // wave-uniform
+        if (act) dxb[(size_t)t * N + lane] = g * da;
+        float r = act ? da * __expf(-lc[u]) : 0.f;  // da_t[i] / s_t[i]
+        float ep = act ? __expf(ac[u]) : 0.f;       // e_{t-1}[j]
+        float n0 = 0.f, n1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NP; k += 2) {
+          float r0 = readlane(r, k), r1 = readlane(r, k + 1);
+          float e0 = readlane(ep, k), e1 = readlane(ep, k + 1);
+          n0 = fmaf(EAT[k], r0, n0);
+          n1 = fmaf(EAT[k + 1], r1, n1);
+          acc[k] = fmaf(r, e0, acc[k]);
+          acc[k + 1] = fmaf(r, e1, acc[k + 1]);
+        }
+        da = ep * (n0 + n1);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) { lc[u] = ln[u]; ac[u] = an[u]; }
+  }
+  if (act) dxb[lane] = g * da;
+  // dA[i][j] = g * EA[i][j] * sum_t r_t[i] e_{t-1}[j]; lane = i
+  float* tg = ws.tgpart + (size_t)b * N * N;
+#pragma unroll
+  for (int j = 0; j < NP; ++j)
+    if (act && j < N) tg[(size_t)lane * N + j] = g * __expf(trans[(size_t)lane * N + j] - rowmax) * acc[j];
+}
+
+// out[k] = sum_b part[b][k]  (deterministic order)
+__global__ void reduce_over_b(int B, size_t n, const float* __restrict__ part, float* __restrict__ out) {
+  size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += part[(size_t)b * n + k];
+  out[k] = s;
+}
+
+// ---------------------------------------------------------------- Viterbi
+struct VitWs {
+  unsigned char* psi;  // [B][T][N]
+};
+
+constexpr int kBtChunk = 256;  // backtrace chunk (time steps staged in LDS)
+
+template <int NP>
+__global__ __launch_bounds__(64) void viterbi_small(int T, int N, const float* __restrict__ x,
+                                                    const float* __restrict__ trans,
+                                                    int* __restrict__ path, unsigned char* psiAll) {
+  __shared__ unsigned char sPsi[kBtChunk * 64];
+  __shared__ int sPath[kBtChunk];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const bool act = lane < N;
+  const float NEG = -INFINITY;
+
+  float A[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) A[j] = (act && j < N) ? trans[(size_t)lane * N + j] : NEG;
+
+  const float* xb = x + (size_t)b * T * N;
+  unsigned char* psi = psiAll + (size_t)b * T * N;
+
+  float xc[kChunk], xn[kChunk];
+#pragma unroll
+  for (int u = 0; u < kChunk; ++u) xc[u] = (act && u < T) ? xb[(size_t)u * N + lane] : 0.f;
+  float delta = NEG;
+  for (int t0 = 0; t0 < T; t0 += kChunk) {
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) {
+      int tn = t0 + kChunk + u;
+      xn[u] = (act && tn < T) ? xb[(size_t)tn * N + lane] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) {
+      const int t = t0 + u;
+      if (t < T) {
+        if (t == 0) {
+          delta = act ? xc[u] : NEG;
+        } else {
+          // strict '>' scan over j upward: first maximum wins (oracle order)
+          float best = readlane(delta, 0) + A[0];
+          int arg = 0;
+#pragma unroll
+          for (int j = 1; j < NP; ++j) {
+            float v = readlane(delta, j) + A[j];
+            bool gt = v > best;
+            best = gt ? v : best;
+            arg = gt ? j : arg;
+          }
+          delta = act ? best + xc[u] : NEG;
+          if (act) psi[(size_t)t * N + lane] = (unsigned char)arg;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) xc[u] = xn[u];
+  }
+  // final state: first argmax over i
+  float m = wave_max(delta);
+  unsigned long long eq = __ballot(act && delta == m);
+  int cur = __ffsll((long long)eq) - 1;
+  __syncthreads();  // drains this wave's psi stores before they are re-read
+  int* pb = path + (size_t)b * T;
+  // backtrace, chunks of kBtChunk steps staged through LDS
+  for (int thi = T - 1; thi >= 0; thi -= kBtChunk) {
+    int tlo = thi - kBtChunk + 1;
+    if (tlo < 0) tlo = 0;
+    int nsteps = thi - tlo + 1;
+    for (int k = lane; k < nsteps * N; k += 64) sPsi[k] = psi[(size_t)tlo * N + k];
+    __syncthreads();
+    if (lane == 0) {
+      for (int t = thi; t >= tlo; --t) {
+        sPath[t - tlo] = cur;
+        if (t >= 1) cur = sPsi[(t - tlo) * N + cur];
+      }
+    }
+    cur = __builtin_amdgcn_readfirstlane(cur);
+    __syncthreads();
+    for (int k = lane; k < nsteps; k += 64) pb[tlo + k] = sPath[k];
+    __syncthreads();
+  }
+}
+
+}  // namespace w2l
+
+using namespace w2l;
+
+W2L_API size_t w2l_fcc_workspace_size(int B, int T, int N) {
+  if (B <= 0 || T <= 0 || N <= 0) return 0;
+  size_t btn = align_up((size_t)B * T * N * sizeof(float), 256);
+  return 2 * btn + align_up((size_t)B * sizeof(float), 256) +
+         align_up((size_t)B * N * N * sizeof(float), 256);
+}
+
+W2L_API int w2l_fcc_forward(int B, int T, int N, int scaleMode, const float* input,
+                            const int* targetSize, const float* trans, float* loss,
+                            void* workspace, w2l_stream_t stream) {
+  if (B <= 0 || T <= 0 || N <= 0 || !input || !targetSize || !trans || !loss || !workspace)
+    return W2L_EINVAL;
+  if (N > 64) return W2L_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  FccWs ws = fcc_ws(workspace, B, T, N);
+  if (N <= 32)
+    hipLaunchKernelGGL(fcc_fwd_small<32>, dim3(B), dim3(64), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws);
+  else
+    hipLaunchKernelGGL(fcc_fwd_small<64>, dim3(B), dim3(64), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+W2L_API int w2l_fcc_backward(int B, int T, int N, const float* trans, const float* grad,
+                             float* inputGrad, float* transGrad, void* workspace,
+                             w2l_stream_t stream) {
+  if (B <= 0 || T <= 0 || N <= 0 || !trans || !grad || !inputGrad || !transGrad || !workspace)
+    return W2L_EINVAL;
+  if (N > 64) return W2L_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  FccWs ws = fcc_ws(workspace, B, T, N);
+  if (N <= 32)
+    hipLaunchKernelGGL(fcc_bwd_small<32>, dim3(B), dim3(64), 0, s, T, N, trans, grad, inputGrad, ws);
+  else
+    hipLaunchKernelGGL(fcc_bwd_small<64>, dim3(B), dim3(64), 0, s, T, N, trans, grad, inputGrad, ws);
+  W2L_LAUNCH_CHECK();
+  size_t n = (size_t)N * N;
+  hipLaunchKernelGGL(reduce_over_b, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, B, n, ws.tgpart, transGrad);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+W2L_API size_t w2l_viterbi_workspace_size(int B, int T, int N) {
+  if (B <= 0 || T <= 0 || N <= 0) return 0;
+  return align_up((size_t)B * T * N, 256);
+}
+
+W2L_API int w2l_viterbi_compute(int B, int T, int N, const float* input, const float* trans,
+                                int* path, void* workspace, w2l_stream_t stream) {
+  if (B <= 0 || T <= 0 || N <= 0 || !input || !trans || !path || !workspace) return W2L_EINVAL;
+  if (N > 64) return W2L_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (N <= 32)
+    hipLaunchKernelGGL(viterbi_small<32>, dim3(B), dim3(64), 0, s, T, N, input, trans, path, (unsigned char*)workspace);
+  else
+    hipLaunchKernelGGL(viterbi_small<64>, dim3(B), dim3(64), 0, s, T, N, input, trans, path, (unsigned char*)workspace);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
