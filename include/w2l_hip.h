@@ -106,6 +106,75 @@ int w2l_ctc_backward(int B, int T, int N, int L, const float* input, const int* 
 /* CTCLoss::viterbiPath: per-frame argmax, first max wins */
 int w2l_ctc_viterbi(int B, int T, int N, const float* input, int* path, w2l_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * 2. Network operators (fp32).  Activations are FRAME-MAJOR: a tensor the
+ * reference holds as ArrayFire dims (T, H, C, B) lives here as x[B][T][H][C]
+ * (C fastest), i.e. a row-major [M = B*T*H][C] matrix; Linear layers see
+ * [M = B*T][H*C].  Replaces fl::conv2d / fl::linear / fl::LayerNorm /
+ * fl::GatedLinearUnit / fl::Dropout autograd functions (un-vendored Flashlight;
+ * grammar in recipes/joint_training_vox_populi/cpc/SequentialBuilder.cpp:92-626).
+ * ---------------------------------------------------------------------- */
+
+/* generic C[M][N] = op(A) op(B) (+bias[n]) (relu). a_kcontig: A stored [M][K];
+ * else [K][M]. b_kcontig: B stored [N][K]; else [K][N]. splitk > 1: atomics. */
+int w2l_gemm_f32(int M, int N, int K, const float* A, int lda, int a_kcontig, const float* B,
+                 int ldb, int b_kcontig, float* C, int ldc, const float* bias, int relu,
+                 int splitk, w2l_stream_t stream);
+
+/* fl::Linear: y[M][out] = x[M][in] . w[in][out] + bias (w is Flashlight's (out,in)
+ * column-major weight, byte-identical); optional fused ReLU. */
+int w2l_linear_forward(int M, int in, int out, const float* x, const float* w,
+                       const float* bias, float* y, int relu, w2l_stream_t stream);
+int w2l_linear_backward_data(int M, int in, int out, const float* dy, const float* w, float* dx,
+                             int accumulate, const float* maskSrc, float maskScale,
+                             w2l_stream_t stream);
+int w2l_linear_backward_weight(int M, int in, int out, const float* x, const float* dy, float* dw,
+                               w2l_stream_t stream);
+int w2l_colsum(const float* x, float* out, size_t M, int N, w2l_stream_t stream); /* bias grads */
+
+/* fl::Conv2D kw x 1 over time (arch tokens C / C2 / TDS). x [B][T][H][Cin],
+ * w [kw][Cin][Cout], y [B][To][H][Cout]; cross-correlation, zero padding. */
+typedef struct {
+  int B, T, H, Cin, Cout, kw, stride, padl, padr;
+} w2l_conv_desc;
+int w2l_conv_out_len(int T, int kw, int stride, int padl, int padr);
+int w2l_conv_same_pad(int T, int kw, int stride); /* PaddingMode::SAME (pad = -1) */
+int w2l_conv_forward(const w2l_conv_desc* d, const float* x, const float* w, const float* bias,
+                     float* y, int relu, w2l_stream_t stream);
+int w2l_conv_backward_data(const w2l_conv_desc* d, const float* dy, const float* w, float* dx,
+                           int accumulate, w2l_stream_t stream);
+int w2l_conv_backward_filter(const w2l_conv_desc* d, const float* x, const float* dy, float* dw,
+                             float* dbias, w2l_stream_t stream);
+
+/* r = dropout(a) + x ; y = LayerNorm(r) over `groups` contiguous chunks of `inner`
+ * elements with scalar affine gammaBeta[2] (fl::LayerNorm axes {0,1,2}: groups = B).
+ * a is updated in place to its dropped value; r, meanRstd[2*groups] are kept for
+ * backward; stats is double[2*groups] scratch.  Dropout mask = stateless hash of
+ * (flat index, seed, rngStream), reproduced bit-exactly by the oracle. */
+int w2l_residual_layernorm_forward(int groups, size_t inner, float* a, const float* x, float* r,
+                                   float* y, const float* gammaBeta, float eps, double p,
+                                   uint32_t seed, uint32_t rngStream, double* stats,
+                                   float* meanRstd, w2l_stream_t stream);
+int w2l_layernorm_backward(int groups, size_t inner, const float* r, const float* dy,
+                           const float* gammaBeta, const float* meanRstd, float* dr,
+                           float* dGammaBeta, const float* maskSrc, float* dmask, float maskScale,
+                           double* sums, w2l_stream_t stream);
+int w2l_dropout_inplace(float* x, size_t n, double p, uint32_t seed, uint32_t rngStream,
+                        w2l_stream_t stream);
+int w2l_mask_backward(const float* dy, const float* src, float* dx, size_t n, float scale,
+                      w2l_stream_t stream);
+int w2l_axpy(float* y, const float* x, size_t n, float alpha, w2l_stream_t stream);
+int w2l_transpose(const float* in, float* out, int G, int R, int C, w2l_stream_t stream);
+int w2l_glu_forward(const float* x, float* y, size_t M, int half, w2l_stream_t stream);
+int w2l_glu_backward(const float* x, const float* dy, float* dx, size_t M, int half,
+                     w2l_stream_t stream);
+
+/* fl::SGDOptimizer + fl::clipGradNorm over a flat parameter arena
+ * (recipes/slimIPL/src/Train.cpp:1791-1804). */
+int w2l_sumsq(const float* g, size_t n, double* out, int zeroFirst, w2l_stream_t stream);
+int w2l_sgd_step(float* p, const float* g, float* v, size_t n, float lr, float momentum,
+                 float gradScale, float maxGradNorm, const double* sumsq, w2l_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,241 @@
+"""Parity of the HIP network operators (GEMM engine, implicit-GEMM time
+convolution, fused residual/dropout/LayerNorm, GLU, SGD) against the CPU oracle.
+Tolerance: 1e-4 relative to the largest reference magnitude (fp32)."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import refnet
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def rel(got, want):
+    want = np.asarray(want, np.float64)
+    got = np.asarray(got.detach().cpu().numpy() if torch.is_tensor(got) else got, np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    return np.abs(got - want).max() / max(1e-30, np.abs(want).max())
+
+
+def to_fm(x):  # reference [B][C][H][T] -> frame-major [B][T][H][C]
+    return np.ascontiguousarray(x.transpose(0, 3, 2, 1))
+
+
+def from_fm(y):
+    return np.ascontiguousarray(y.transpose(0, 3, 2, 1))
+
+
+def w_to_dev(w):  # reference [Cout][Cin][kw] -> [kw][Cin][Cout]
+    return np.ascontiguousarray(w.transpose(2, 1, 0))
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 7, 3), (128, 128, 32), (130, 250, 70), (257, 129, 33),
+                                    (300, 9998, 64), (64, 10, 210)])
+@pytest.mark.parametrize("akc,bkc", [(True, False), (True, True), (False, False), (False, True)])
+def test_gemm_all_layouts(oracle, M, N, K, akc, bkc):
+    from wav2letter_amd import ops
+    rng = np.random.default_rng(M + N + K)
+    A = rng.normal(size=(M, K)).astype(np.float32)
+    Bm = rng.normal(size=(K, N)).astype(np.float32)
+    bias = rng.normal(size=N).astype(np.float32)
+    want = A.astype(np.float64) @ Bm.astype(np.float64) + bias
+    Ad = dev(A if akc else A.T)
+    Bd = dev(Bm.T if bkc else Bm)
+    got = ops.gemm(Ad, Bd, akc, bkc, dev(bias))
+    assert rel(got, want) < TOL
+    got = ops.gemm(Ad, Bd, akc, bkc, dev(bias), relu=True)
+    assert rel(got, np.maximum(want, 0)) < TOL
+    if K >= 64:
+        got = ops.gemm(Ad, Bd, akc, bkc, splitk=2)
+        assert rel(got, want - bias) < TOL
+
+
+def test_gemm_asymmetric_identity():
+    """A = I with an asymmetric B catches row/col swaps in the C write (guide G9)"""
+    from wav2letter_amd import ops
+    n = 192
+    Bm = np.arange(n * n, dtype=np.float32).reshape(n, n) / 100
+    got = ops.gemm(dev(np.eye(n, dtype=np.float32)), dev(Bm))
+    assert (got.cpu().numpy() == Bm).all()
+
+
+@pytest.mark.parametrize("M,K,N", [(37, 20, 13), (300, 800, 2400), (188, 1440, 9998)])
+def test_linear_fwd_bwd(oracle, M, K, N):
+    from wav2letter_amd import ops
+    rng = np.random.default_rng(K)
+    x = rng.normal(size=(M, K)).astype(np.float32)
+    w = (rng.normal(size=(K, N)) / np.sqrt(K)).astype(np.float32)
+    b = rng.normal(size=N).astype(np.float32)
+    dy = rng.normal(size=(M, N)).astype(np.float32)
+    y = ops.linear_forward(dev(x), dev(w), dev(b))
+    assert rel(y, oracle.linear_fwd(x, w, b)) < TOL
+    dx, dw, db = ops.linear_backward(dev(x), dev(w), dev(dy))
+    odx, odw, odb = oracle.linear_bwd(x, w, dy)
+    assert rel(dx, odx) < TOL and rel(dw, odw) < TOL and rel(db, odb) < TOL
+    # fused ReLU forward + mask epilogue backward
+    u = ops.linear_forward(dev(x), dev(w), dev(b), relu=True)
+    assert rel(u, np.maximum(oracle.linear_fwd(x, w, b), 0)) < TOL
+
+
+CONV_CASES = [
+    # B, Cin, Cout, H, T, kw, stride, padl, padr
+    (2, 1, 10, 8, 50, 21, 2, 10, 10),     # first TDS-CTC layer geometry (C2 1 10 21 1 2 1 -1 -1)
+    (2, 10, 10, 8, 40, 21, 1, 10, 10),    # TDS conv c=10
+    (1, 14, 14, 5, 33, 21, 1, 10, 10),    # c=14
+    (2, 18, 18, 4, 30, 21, 1, 10, 10),    # c=18 (BN=32 skinny)
+    (2, 10, 14, 6, 41, 21, 2, 10, 10),    # stage transition, odd T
+    (2, 40, 100, 1, 60, 13, 1, 6, 6),     # conv_glu style: H=1, wide channels (128-tile)
+    (1, 33, 70, 1, 45, 4, 1, 2, 2),       # even kw, odd channels (scalar loads)
+    (2, 3, 5, 2, 9, 3, 1, 0, 0),          # valid (no padding)
+    (1, 6, 40, 2, 64, 5, 1, 4, 0),        # asymmetric (streaming) padding
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,T,kw,stride,padl,padr", CONV_CASES)
+def test_conv_fwd_bwd(oracle, B, Cin, Cout, H, T, kw, stride, padl, padr):
+    from wav2letter_amd import ops
+    rng = np.random.default_rng(Cin * 100 + Cout)
+    x = rng.normal(size=(B, Cin, H, T)).astype(np.float32)
+    w = (rng.normal(size=(Cout, Cin, kw)) / np.sqrt(Cin * kw)).astype(np.float32)
+    b = rng.normal(size=Cout).astype(np.float32)
+    y_ref = oracle.conv_fwd(x, w, b, stride, padl, padr)
+    xd, wd = dev(to_fm(x)), dev(w_to_dev(w))
+    y = ops.conv_forward(xd, wd, dev(b), stride, padl, padr)
+    assert rel(from_fm(y.cpu().numpy()), y_ref) < TOL
+    yr = ops.conv_forward(xd, wd, dev(b), stride, padl, padr, relu=True)
+    assert rel(from_fm(yr.cpu().numpy()), np.maximum(y_ref, 0)) < TOL
+    dy = rng.normal(size=y_ref.shape).astype(np.float32)
+    odx, odw, odb = oracle.conv_bwd(x, w, dy, stride, padl, padr)
+    dx, dw, db = ops.conv_backward(xd, wd, dev(to_fm(dy)), stride, padl, padr)
+    assert rel(from_fm(dx.cpu().numpy()), odx) < TOL
+    assert rel(dw.cpu().numpy(), w_to_dev(odw)) < TOL
+    assert rel(db, odb) < TOL
+
+
+def test_golden_conv1d_on_device():
+    """the reference's own golden vector (Conv1dTest.cpp:30-104) through the HIP conv"""
+    import json, os
+    from wav2letter_amd import ops
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "conv1d_golden.json")))
+    T, H, Cc, kw = g["T"], g["groups"], g["channels"] // g["groups"], g["kernelSize"]
+    x = np.array(g["input"], np.float32).reshape(1, T, H, Cc)          # streaming layout == frame-major
+    w = np.array(g["weights"], np.float32).reshape(Cc, kw, Cc).transpose(1, 2, 0)  # [co][k][ci] -> [k][ci][co]
+    y = ops.conv_forward(dev(x), dev(np.ascontiguousarray(w)), dev(np.array(g["bias"], np.float32)), 1,
+                         g["leftPadding"], g["rightPadding"])
+    assert np.abs(y.cpu().numpy().reshape(-1) - np.array(g["target"])).max() < 2e-3
+
+
+@pytest.mark.parametrize("p", [0.0, 0.25])
+def test_residual_dropout_layernorm(oracle, p):
+    from wav2letter_amd import ops
+    rng = np.random.default_rng(5)
+    B, inner = 3, 4 * 1237
+    a = np.maximum(rng.normal(size=(B, inner)), 0).astype(np.float32)
+    x = rng.normal(size=(B, inner)).astype(np.float32)
+    gb = np.array([1.3, -0.2], np.float32)
+    ad = dev(a)
+    y, r, mr = ops.residual_layernorm_forward(ad, dev(x), dev(gb), B, 1e-5, p, 77, 5)
+    a_drop = oracle.dropout(a.reshape(-1), p, 77, 5).reshape(a.shape) if p > 0 else a
+    assert (ad.cpu().numpy() == a_drop).all()          # identical mask (integer hash), bit-exact
+    r_ref = a_drop + x
+    assert rel(r, r_ref) < 1e-6
+    y_ref = oracle.layernorm_fwd(r_ref, B, 1.3, -0.2, 1e-5).reshape(B, inner)
+    assert rel(y, y_ref) < TOL
+    dy = rng.normal(size=(B, inner)).astype(np.float32)
+    odr, odg, odb = oracle.layernorm_bwd(r_ref, dy, B, 1.3, 1e-5)
+    sc = 1.0 / (1.0 - p)
+    dr, dgb, dmask = ops.layernorm_backward(r, dev(dy), dev(gb), mr, B, mask_src=ad, mask_scale=sc)
+    assert rel(dr, odr.reshape(B, inner)) < TOL
+    assert abs(dgb[0].item() - odg) < TOL * max(1, abs(odg)) * 10
+    assert abs(dgb[1].item() - odb) < TOL * max(1, abs(odb)) * 10
+    assert rel(dmask, odr.reshape(B, inner) * (a_drop > 0) * sc) < TOL
+
+
+def test_tds_block_composed_from_kernels(oracle):
+    """forward + backward of one TDS block built from the C-ABI ops == oracle composition"""
+    from wav2letter_amd import ops
+    rng = np.random.default_rng(6)
+    B, Cc, H, T, kw, l2 = 2, 10, 6, 24, 21, 96
+    p = refnet.TDSParams(Cc, kw, H, l2=l2, rng=rng)
+    x = rng.normal(size=(B, Cc, H, T)).astype(np.float32)
+    dout = rng.normal(size=x.shape).astype(np.float32)
+    out_ref, saved = refnet.tds_fwd(x, p, 10, 10, "all", keep=True)
+    dx_ref, g_ref = refnet.tds_bwd(dout, p, saved, 10, 10, "all")
+
+    xd = dev(to_fm(x))
+    wc = dev(w_to_dev(p.wc))
+    gb1 = dev(np.array([p.g1, p.b1n], np.float32)); gb2 = dev(np.array([p.g2, p.b2n], np.float32))
+    w1, b1, w2, b2 = dev(p.w1), dev(p.b1), dev(p.w2), dev(p.b2)
+    # forward
+    a = ops.conv_forward(xd, wc, dev(p.bc), 1, 10, 10, relu=True)
+    y, r, mr1 = ops.residual_layernorm_forward(a, xd, gb1, B)
+    M, l = B * T, H * Cc
+    u = ops.linear_forward(y.view(M, l), w1, b1, relu=True)
+    v = ops.linear_forward(u, w2, b2)
+    out, s, mr2 = ops.residual_layernorm_forward(v.view(B, T, H, Cc), y, gb2, B)
+    assert rel(from_fm(out.cpu().numpy()), out_ref) < TOL
+    # backward
+    dd = dev(to_fm(dout))
+    ds, dgb2, _ = ops.layernorm_backward(s, dd, gb2, mr2, B)
+    du, dw2, db2 = ops.linear_backward(u, w2, ds.view(M, l), mask_src=u, mask_scale=1.0)
+    dz, dw1, db1 = ops.linear_backward(y.view(M, l), w1, du)
+    dy = ds + dz.view(B, T, H, Cc)
+    dr, dgb1, da = ops.layernorm_backward(r, dy, gb1, mr1, B, mask_src=a, mask_scale=1.0)
+    dxc, dwc, dbc = ops.conv_backward(xd, wc, da, 1, 10, 10)
+    dx = dr + dxc
+    assert rel(from_fm(dx.cpu().numpy()), dx_ref) < TOL
+    assert rel(dwc.cpu().numpy(), w_to_dev(g_ref["wc"])) < TOL
+    assert rel(dbc, g_ref["bc"]) < TOL
+    assert rel(dw1, g_ref["w1"]) < TOL and rel(db1, g_ref["b1"]) < TOL
+    assert rel(dw2, g_ref["w2"]) < TOL and rel(db2, g_ref["b2"]) < TOL
+    assert abs(dgb1[0].item() - g_ref["g1"]) < 1e-3 * max(1, abs(g_ref["g1"]))
+    assert abs(dgb2[1].item() - g_ref["b2n"]) < 1e-3 * max(1, abs(g_ref["b2n"]))
+
+
+def test_glu_transpose_sgd(oracle):
+    from wav2letter_amd import ops
+    rng = np.random.default_rng(8)
+    M, half = 37, 13
+    x = rng.normal(size=(M, 2 * half)).astype(np.float32)
+    dy = rng.normal(size=(M, half)).astype(np.float32)
+    assert rel(ops.glu_forward(dev(x)), oracle.glu_fwd(x, M, half, 1).reshape(M, half)) < TOL
+    assert rel(ops.glu_backward(dev(x), dev(dy)), oracle.glu_bwd(x, dy, M, half, 1)) < TOL
+    t = rng.normal(size=(3, 45, 70)).astype(np.float32)
+    assert (ops.transpose(dev(t)).cpu().numpy() == t.transpose(0, 2, 1)).all()
+    n = 10007
+    p0 = rng.normal(size=n).astype(np.float32); g = rng.normal(size=n).astype(np.float32)
+    v0 = rng.normal(size=n).astype(np.float32)
+    pd, vd = dev(p0), dev(v0)
+    ops.sgd_step_(pd, dev(g), vd, 0.3, 0.5, grad_scale=0.25, max_grad_norm=1.0)
+    gs = g.astype(np.float64) * 0.25
+    coef = min(1.0, 1.0 / (np.linalg.norm(gs) + 1e-6))
+    v1 = 0.5 * v0 + gs * coef
+    assert rel(vd, v1) < 1e-5 and rel(pd, p0 - 0.3 * v1) < 1e-5
+
+
+def test_gemm_throughput_report():
+    """not pass/fail: prints achieved TFLOP/s on the TDS-CTC fc shapes (fp32 MFMA peak 157.3)"""
+    from wav2letter_amd import ops
+    torch.manual_seed(0)
+    for (M, K, N, tag) in [(24000, 800, 2400, "fc1 s1"), (24000, 2400, 800, "fc2 s1"), (12000, 1120, 3360, "fc1 s2"),
+                           (6016, 1440, 4320, "fc1 s3"), (6016, 1440, 9998, "final"), (4096, 4096, 4096, "4096^3")]:
+        x = torch.randn(M, K, device="cuda"); w = torch.randn(K, N, device="cuda") / K ** 0.5
+        b = torch.randn(N, device="cuda"); dy = torch.randn(M, N, device="cuda")
+        for name, fn in [("fwd", lambda: ops.linear_forward(x, w, b, relu=True)),
+                         ("bwd", lambda: ops.linear_backward(x, w, dy))]:
+            fn(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 5
+            fl = 2.0 * M * K * N * (1 if name == "fwd" else 2)
+            print(f"\n[gemm] {tag:8s} {name} M={M} K={K} N={N}: {dt * 1e3:.3f} ms  {fl / dt / 1e12:.1f} TFLOP/s", end="")
+    print()

@@ -63,6 +63,30 @@ class _SIGS:
     w2l_ctc_forward = (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p])
     w2l_ctc_backward = (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p])
     w2l_ctc_viterbi = (_i, [_i, _i, _i, _p, _p, _p])
+    w2l_gemm_f32 = (_i, [_i, _i, _i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _i, _i, _p])
+    w2l_linear_forward = (_i, [_i, _i, _i, _p, _p, _p, _p, _i, _p])
+    w2l_linear_backward_data = (_i, [_i, _i, _i, _p, _p, _p, _i, _p, _f, _p])
+    w2l_linear_backward_weight = (_i, [_i, _i, _i, _p, _p, _p, _p])
+    w2l_colsum = (_i, [_p, _p, _sz, _i, _p])
+    w2l_conv_out_len = (_i, [_i, _i, _i, _i, _i])
+    w2l_conv_same_pad = (_i, [_i, _i, _i])
+    w2l_conv_forward = (_i, [_p, _p, _p, _p, _p, _i, _p])
+    w2l_conv_backward_data = (_i, [_p, _p, _p, _p, _i, _p])
+    w2l_conv_backward_filter = (_i, [_p, _p, _p, _p, _p, _p])
+    w2l_residual_layernorm_forward = (_i, [_i, _sz, _p, _p, _p, _p, _p, _f, _d, _u32, _u32, _p, _p, _p])
+    w2l_layernorm_backward = (_i, [_i, _sz, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p])
+    w2l_dropout_inplace = (_i, [_p, _sz, _d, _u32, _u32, _p])
+    w2l_mask_backward = (_i, [_p, _p, _p, _sz, _f, _p])
+    w2l_axpy = (_i, [_p, _p, _sz, _f, _p])
+    w2l_transpose = (_i, [_p, _p, _i, _i, _i, _p])
+    w2l_glu_forward = (_i, [_p, _p, _sz, _i, _p])
+    w2l_glu_backward = (_i, [_p, _p, _p, _sz, _i, _p])
+    w2l_sumsq = (_i, [_p, _sz, _p, _i, _p])
+    w2l_sgd_step = (_i, [_p, _p, _p, _sz, _f, _f, _f, _f, _p, _p])
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "T", "H", "Cin", "Cout", "kw", "stride", "padl", "padr")]
 
 
 def check(status, what=""):

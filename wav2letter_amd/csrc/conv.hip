@@ -1,0 +1,343 @@
+// conv.hip -- time convolution (fl::Conv2D kw x 1) forward / backward as an
+// IM2COL-FREE implicit GEMM on the fp32 MFMA engine (gemm.hpp).
+//
+// Reference semantics: cross-correlation over time, y[to] += x[to*stride + tap - pad] * w[tap]
+// (recipes/streaming_convnets/inference/inference/module/nn/backend/fbgemm/Conv1dFbGemm.cpp:104-185;
+// arch tokens C / C2 / TDS in recipes/joint_training_vox_populi/cpc/SequentialBuilder.cpp:203-301).
+// In the reference this is cudnnConvolutionForward/BackwardData/BackwardFilter on
+// WHCN tensors; here activations live FRAME-MAJOR  x[B][T][H][C]  (C fastest) so
+// that a GEMM row m = (b, t, h) is a contiguous C-vector and the K index
+// (tap, c_in) of the implicit GEMM maps to a row shift of tap frames -- the
+// unfolded matrix is never materialised:
+//   forward   Y[(b,to,h)][co] = sum_{tap,ci} X[b][to*s+tap-pl][h][ci] * W[(tap,ci)][co]
+//   bwd-data  dX[(b,ti,h)][ci] = sum_{tap,co} dY[b][(ti+pl-tap)/s][h][co] * W[(tap,ci)][co]
+//   bwd-filt  dW[(tap,ci)][co] = sum_{(b,to,h)} X[b][to*s+tap-pl][h][ci] * dY[(b,to,h)][co]
+// Weights are stored [kw][Cin][Cout] (== [K][Cout], "k-rows" B operand).  Small
+// output widths (TDS: C = 10/14/18) use the 16x16x4 skinny kernel.
+#include "gemm.hpp"
+
+namespace w2l {
+
+struct FastDiv {
+  uint32_t mul, shr, d;
+  __device__ __forceinline__ uint32_t div(uint32_t n) const { return (uint32_t)(((uint64_t)__umulhi(n, mul) + n) >> shr); }
+};
+static FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  uint32_t s = 0;
+  while ((1ull << s) < d) ++s;
+  f.shr = s;
+  f.mul = (uint32_t)((((1ull << s) - d) << 32) / d + 1);
+  return f;
+}
+
+struct ConvGeom {
+  int T_src;       // frames of the tensor being read
+  int T_rows;      // frames of the row space (output frames for fwd, input frames for bwd-data)
+  int H, C;        // rows per frame, channels of the tensor being read
+  int sA, sB, off, div;  // src frame = (t_row*sA + tap*sB + off) / div  (must divide, be in [0,T_src))
+  FastDiv dH, dT, dC;
+};
+
+__device__ __forceinline__ bool conv_src_frame(const ConvGeom& g, int trow, int tap, int& tsrc) {
+  int num = trow * g.sA + tap * g.sB + g.off;
+  if (num < 0) return false;
+  if (g.div != 1) {
+    if (num % g.div) return false;
+    num /= g.div;
+  }
+  tsrc = num;
+  return num < g.T_src;
+}
+
+// A operand of forward / backward-data: element (kk=(tap,c), m=(b,trow,h))
+struct ConvAOp {
+  const float* src;
+  ConvGeom g;
+  int M, K;
+  static constexpr int kPad = 1;
+  static constexpr int kPadSkinny = 2;
+
+  template <int BI, int BK>
+  __device__ __forceinline__ void load_t(float (&r)[16], int i0, int k0, int tid) const {
+    constexpr int RPP = 256 / BK;
+    constexpr int NP = BI / RPP;
+    const int kk = k0 + tid % BK;
+    const int rr = tid / BK;
+    const uint32_t tap = g.dC.div((uint32_t)kk);
+    const int c = kk - (int)tap * g.C;
+    const bool kok = kk < K;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int m = i0 + rr + RPP * j;
+      float v = 0.f;
+      if (kok && m < M) {
+        const uint32_t bt = g.dH.div((uint32_t)m);
+        const int h = m - (int)bt * g.H;
+        const uint32_t b = g.dT.div(bt);
+        const int trow = (int)bt - (int)b * g.T_rows;
+        int ts;
+        if (conv_src_frame(g, trow, (int)tap, ts))
+          v = src[(((size_t)b * g.T_src + ts) * g.H + h) * g.C + c];
+      }
+      r[j] = v;
+    }
+  }
+  template <int BI, int BK>
+  __device__ __forceinline__ void store_t(float* lds, int ldS, const float (&r)[16], int tid) const {
+    constexpr int RPP = 256 / BK;
+    constexpr int NP = BI / RPP;
+    const int kc = tid % BK, rr = tid / BK;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) lds[kc * ldS + rr + RPP * j] = r[j];
+  }
+  __device__ __forceinline__ void load(float (&r)[16], int i0, int k0, int tid) const { load_t<128, 32>(r, i0, k0, tid); }
+  __device__ __forceinline__ void store(float* lds, int ldS, const float (&r)[16], int tid) const { store_t<128, 32>(lds, ldS, r, tid); }
+  template <int BM, int BK>
+  __device__ __forceinline__ void load_bk(float (&r)[16], int i0, int k0, int tid) const { load_t<BM, BK>(r, i0, k0, tid); }
+  template <int BM, int BK>
+  __device__ __forceinline__ void store_bk(float* lds, int ldS, const float (&r)[16], int tid) const { store_t<BM, BK>(lds, ldS, r, tid); }
+};
+
+// B operand of backward-data: element (kk=(tap,co), j=ci) = W[(tap*Cin + ci)*Cout + co]
+struct ConvWTOp {
+  const float* w;
+  int Cin, Cout, K;  // K = kw*Cout
+  FastDiv dCo;
+  static constexpr int kPad = 1;
+
+  __device__ __forceinline__ void load(float (&r)[16], int n0, int k0, int tid) const {
+    const int kk = k0 + tid % 32;
+    const int rr = tid / 32;
+    const uint32_t tap = dCo.div((uint32_t)kk);
+    const int co = kk - (int)tap * Cout;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int ci = n0 + rr + 8 * j;
+      r[j] = (kk < K && ci < Cin) ? w[((size_t)tap * Cin + ci) * Cout + co] : 0.f;
+    }
+  }
+  __device__ __forceinline__ void store(float* lds, int ldS, const float (&r)[16], int tid) const {
+    const int kc = tid % 32, rr = tid / 32;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) lds[kc * ldS + rr + 8 * j] = r[j];
+  }
+  template <int BN, int BK>
+  __device__ __forceinline__ void load_small(float (&r)[(BK * BN + 255) / 256], int n0, int k0, int tid) const {
+    constexpr int NE = (BK * BN + 255) / 256;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const int e = tid + 256 * j;
+      const int k = e % BK, n = e / BK;
+      const int kk = k0 + k, ci = n0 + n;
+      const uint32_t tap = dCo.div((uint32_t)kk);
+      const int co = kk - (int)tap * Cout;
+      r[j] = (e < BK * BN && kk < K && ci < Cin) ? w[((size_t)tap * Cin + ci) * Cout + co] : 0.f;
+    }
+  }
+  template <int BN, int BK>
+  __device__ __forceinline__ void store_small(float* lds, int ldS, const float (&r)[(BK * BN + 255) / 256], int tid) const {
+    constexpr int NE = (BK * BN + 255) / 256;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const int e = tid + 256 * j;
+      if (e < BK * BN) lds[(e % BK) * ldS + e / BK] = r[j];
+    }
+  }
+};
+
+// A operand of backward-filter: element (k = m = (b,to,h), i = (tap,ci)) -- "k-rows"
+struct ConvFilterAOp {
+  const float* src;
+  ConvGeom g;  // T_rows = To (row space of dY), reads x with C = Cin
+  int Mi;      // kw*Cin  (extent of i)
+  int Kred;    // B*To*H  (reduction length)
+  static constexpr int kPad = 4;
+  static constexpr int kPadSkinny = 4;
+
+  template <int BI, int BK>
+  __device__ __forceinline__ void load_t(float (&r)[16], int i0, int k0, int tid) const {
+    constexpr int RPP = 256 / BI;  // k-rows per pass
+    constexpr int NP = BK / RPP;
+    const int i = i0 + tid % BI;
+    const int kr = tid / BI;
+    const uint32_t tap = g.dC.div((uint32_t)i);
+    const int c = i - (int)tap * g.C;
+    const bool iok = i < Mi;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int m = k0 + kr + RPP * j;
+      float v = 0.f;
+      if (iok && m < Kred) {
+        const uint32_t bt = g.dH.div((uint32_t)m);
+        const int h = m - (int)bt * g.H;
+        const uint32_t b = g.dT.div(bt);
+        const int trow = (int)bt - (int)b * g.T_rows;
+        int ts;
+        if (conv_src_frame(g, trow, (int)tap, ts))
+          v = src[(((size_t)b * g.T_src + ts) * g.H + h) * g.C + c];
+      }
+      r[j] = v;
+    }
+  }
+  template <int BI, int BK>
+  __device__ __forceinline__ void store_t(float* lds, int ldS, const float (&r)[16], int tid) const {
+    constexpr int RPP = 256 / BI;
+    constexpr int NP = BK / RPP;
+    const int ic = tid % BI, kr = tid / BI;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) lds[(kr + RPP * j) * ldS + ic] = r[j];
+  }
+  __device__ __forceinline__ void load(float (&r)[16], int i0, int k0, int tid) const { load_t<128, 32>(r, i0, k0, tid); }
+  __device__ __forceinline__ void store(float* lds, int ldS, const float (&r)[16], int tid) const { store_t<128, 32>(lds, ldS, r, tid); }
+  template <int BM, int BK>
+  __device__ __forceinline__ void load_bk(float (&r)[16], int i0, int k0, int tid) const { load_t<BM, BK>(r, i0, k0, tid); }
+  template <int BM, int BK>
+  __device__ __forceinline__ void store_bk(float* lds, int ldS, const float (&r)[16], int tid) const { store_t<BM, BK>(lds, ldS, r, tid); }
+};
+
+// column sums: out[n] = sum_m x[m][n]   (bias gradients)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                     size_t M, int N, size_t rowsPerBlock) {
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6;
+  __shared__ float sm[4][64];
+  size_t m0 = (size_t)blockIdx.y * rowsPerBlock;
+  size_t m1 = m0 + rowsPerBlock;
+  if (m1 > M) m1 = M;
+  float s = 0.f;
+  if (n < N)
+    for (size_t m = m0 + part; m < m1; m += 4) s += x[m * N + n];
+  sm[part][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (part == 0 && n < N) atomicAdd(&out[n], sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
+int colsum(const float* x, float* out, size_t M, int N, hipStream_t s) {
+  W2L_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s));
+  size_t rowsPerBlock = 512;
+  dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + rowsPerBlock - 1) / rowsPerBlock));
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, x, out, M, N, rowsPerBlock);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+static inline int out_len(int T, int kw, int stride, int padl, int padr) {
+  int n = T + padl + padr - kw;
+  return n < 0 ? 0 : n / stride + 1;
+}
+
+static inline int pick_vec_rows(const float* p, int ld, int extent) {
+  if ((((uintptr_t)p) & 15) == 0 && ld % 4 == 0 && extent % 4 == 0) return 4;
+  if ((((uintptr_t)p) & 7) == 0 && ld % 2 == 0 && extent % 2 == 0) return 2;
+  return 1;
+}
+
+template <class AOp>
+static int conv_launch_rowsB(const AOp& a, const float* Bp, int ldb, int N, int K, const GemmOut& o, int epi,
+                             int splitk, hipStream_t s) {
+  // B is a plain "k-rows" matrix [K][N]
+  if (N <= 16) return launch_skinny<AOp, PlainOp<false, 1>, 16>(a, PlainOp<false, 1>{Bp, ldb, N, K}, o, epi, splitk, s);
+  if (N <= 32) return launch_skinny<AOp, PlainOp<false, 1>, 32>(a, PlainOp<false, 1>{Bp, ldb, N, K}, o, epi, splitk, s);
+  int v = pick_vec_rows(Bp, ldb, N);
+  if (v == 4) return launch128(a, PlainOp<false, 4>{Bp, ldb, N, K}, o, epi, splitk, s);
+  if (v == 2) return launch128(a, PlainOp<false, 2>{Bp, ldb, N, K}, o, epi, splitk, s);
+  return launch128(a, PlainOp<false, 1>{Bp, ldb, N, K}, o, epi, splitk, s);
+}
+
+}  // namespace w2l
+
+using namespace w2l;
+
+W2L_API int w2l_conv_out_len(int T, int kw, int stride, int padl, int padr) {
+  return out_len(T, kw, stride, padl, padr);
+}
+
+// Flashlight PaddingMode::SAME for one axis (pad = -1 in arch files): the same
+// p = ceil(total/2) on both sides.
+W2L_API int w2l_conv_same_pad(int T, int kw, int stride) {
+  int total = (T % stride == 0) ? (kw - 1) - stride + 1 : (kw - 1) - (T % stride) + 1;
+  if (total < 0) total = 0;
+  return (total + 1) / 2;
+}
+
+static int check_desc(const w2l_conv_desc* d) {
+  if (!d || d->B <= 0 || d->T <= 0 || d->H <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->kw <= 0 ||
+      d->stride <= 0 || d->padl < 0 || d->padr < 0)
+    return W2L_EINVAL;
+  if (out_len(d->T, d->kw, d->stride, d->padl, d->padr) <= 0) return W2L_EINVAL;
+  if ((int64_t)d->B * d->T * d->H >= (1ll << 31)) return W2L_EUNSUPPORTED;
+  return W2L_OK;
+}
+
+W2L_API int w2l_conv_forward(const w2l_conv_desc* d, const float* x, const float* w, const float* bias,
+                             float* y, int relu, w2l_stream_t stream) {
+  int st = check_desc(d);
+  if (st) return st;
+  if (!x || !w || !y) return W2L_EINVAL;
+  const int To = out_len(d->T, d->kw, d->stride, d->padl, d->padr);
+  const int M = d->B * To * d->H, K = d->kw * d->Cin, N = d->Cout;
+  ConvGeom g{d->T, To, d->H, d->Cin, d->stride, 1, -d->padl, 1,
+             make_fastdiv((uint32_t)d->H), make_fastdiv((uint32_t)To), make_fastdiv((uint32_t)d->Cin)};
+  ConvAOp a{x, g, M, K};
+  GemmOut o{y, bias, M, N, K, N, 0, nullptr, 1.f};
+  int epi = (bias ? EPI_BIAS : 0) | (relu ? EPI_RELU : 0);
+  return conv_launch_rowsB(a, w, N, N, K, o, epi, 1, (hipStream_t)stream);
+}
+
+W2L_API int w2l_conv_backward_data(const w2l_conv_desc* d, const float* dy, const float* w, float* dx,
+                                   int accumulate, w2l_stream_t stream) {
+  int st = check_desc(d);
+  if (st) return st;
+  if (!dy || !w || !dx) return W2L_EINVAL;
+  const int To = out_len(d->T, d->kw, d->stride, d->padl, d->padr);
+  const int M = d->B * d->T * d->H, K = d->kw * d->Cout, N = d->Cin;
+  // rows are input frames ti; source frame of dY = (ti + padl - tap) / stride
+  ConvGeom g{To, d->T, d->H, d->Cout, 1, -1, d->padl, d->stride,
+             make_fastdiv((uint32_t)d->H), make_fastdiv((uint32_t)d->T), make_fastdiv((uint32_t)d->Cout)};
+  ConvAOp a{dy, g, M, K};
+  ConvWTOp b{w, d->Cin, d->Cout, K, make_fastdiv((uint32_t)d->Cout)};
+  GemmOut o{dx, nullptr, M, N, K, N, 0, nullptr, 1.f};
+  int epi = accumulate ? EPI_ACCUM : 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (N <= 16) return launch_skinny<ConvAOp, ConvWTOp, 16>(a, b, o, epi, 1, s);
+  if (N <= 32) return launch_skinny<ConvAOp, ConvWTOp, 32>(a, b, o, epi, 1, s);
+  return launch128(a, b, o, epi, 1, s);
+}
+
+W2L_API int w2l_conv_backward_filter(const w2l_conv_desc* d, const float* x, const float* dy, float* dw,
+                                     float* dbias, w2l_stream_t stream) {
+  int st = check_desc(d);
+  if (st) return st;
+  if (!x || !dy || !dw) return W2L_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int To = out_len(d->T, d->kw, d->stride, d->padl, d->padr);
+  const int Kred = d->B * To * d->H, Mi = d->kw * d->Cin, N = d->Cout;
+  ConvGeom g{d->T, To, d->H, d->Cin, d->stride, 1, -d->padl, 1,
+             make_fastdiv((uint32_t)d->H), make_fastdiv((uint32_t)To), make_fastdiv((uint32_t)d->Cin)};
+  ConvFilterAOp a{x, g, Mi, Kred};
+  GemmOut o{dw, nullptr, Mi, N, Kred, N, 0, nullptr, 1.f};
+  // small output, long reduction: split K until the grid covers the chip a few times
+  const bool skinny = N <= 32;
+  const int bm = skinny ? 256 : 128, bn = skinny ? (N <= 16 ? 16 : 32) : 128, bk = skinny ? 16 : 32;
+  const int tiles = ((Mi + bm - 1) / bm) * ((N + bn - 1) / bn);
+  const int kTiles = (Kred + bk - 1) / bk;
+  int splitk = (1024 + tiles - 1) / tiles;
+  if (splitk > kTiles / 8) splitk = kTiles / 8;
+  if (splitk < 1) splitk = 1;
+  int epi = 0;
+  if (splitk > 1) {
+    W2L_HIP_CHECK(hipMemsetAsync(dw, 0, (size_t)Mi * N * sizeof(float), s));
+    epi = EPI_ATOMIC;
+  }
+  st = conv_launch_rowsB(a, dy, N, N, Kred, o, epi, splitk, s);
+  if (st) return st;
+  if (dbias) return colsum(dy, dbias, (size_t)Kred, N, s);
+  return W2L_OK;
+}
+
+W2L_API int w2l_colsum(const float* x, float* out, size_t M, int N, w2l_stream_t stream) {
+  if (!x || !out || N <= 0) return W2L_EINVAL;
+  return colsum(x, out, M, N, (hipStream_t)stream);
+}

@@ -1,0 +1,413 @@
+// elementwise.hip -- HBM-bound glue of the TDS / conv_glu stacks, fused so that
+// every activation tensor is read and written as few times as the data flow allows:
+//   residual + dropout + LayerNorm statistics in one pass, LayerNorm apply,
+//   LayerNorm backward (reduce + apply, with the ReLU/dropout mask of the producer
+//   folded into the apply), GLU forward/backward, layout transposes, SGD.
+// Reference modules: fl::LayerNorm / fl::ReLU / fl::Dropout / fl::GatedLinearUnit /
+// fl::Reorder (arch grammar: recipes/joint_training_vox_populi/cpc/SequentialBuilder.cpp
+// :358-377, :423-428, :388-394, :467-473, :106-119); TDS data flow:
+// recipes/streaming_convnets/inference/inference/module/nn/TDSBlock.cpp:58-70.
+// All kernels are float4-vectorised grid-stride loops (coalesced 16 B/lane).
+#include "common.hpp"
+
+namespace w2l {
+
+constexpr int kEwThreads = 256;
+
+static inline unsigned ew_grid(size_t n4) {
+  size_t g = (n4 + kEwThreads - 1) / kEwThreads;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+__device__ __forceinline__ void block_atomic_add2(double a, double b, double* dst, double* sm) {
+  // wave reduce then one double atomic per wave
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_xor(a, off);
+    b += __shfl_xor(b, off);
+  }
+  (void)sm;
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(dst, a);
+    atomicAdd(dst + 1, b);
+  }
+}
+
+// ---- r = dropout(a) + x (a updated in place to its dropped value), stats[g] += (sum r, sum r^2)
+// groups are contiguous chunks of `inner` elements (LayerNorm axes {0,1,2}: one per utterance)
+__global__ __launch_bounds__(kEwThreads) void residual_dropout_stats_k(
+    float* __restrict__ a, const float* __restrict__ x, float* __restrict__ r, double* __restrict__ stats,
+    size_t inner, uint32_t thr, float keepScale, uint32_t seed, uint32_t stream) {
+  const int g = blockIdx.y;
+  const size_t base = (size_t)g * inner;
+  const size_t n4 = inner >> 2;
+  double s = 0, ss = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = base + 4 * i;
+    float4 av = *(const float4*)(a + e);
+    float4 rv = x ? *(const float4*)(x + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (thr) {
+      av.x = keep_elem(e, seed, stream, thr) ? av.x * keepScale : 0.f;
+      av.y = keep_elem(e + 1, seed, stream, thr) ? av.y * keepScale : 0.f;
+      av.z = keep_elem(e + 2, seed, stream, thr) ? av.z * keepScale : 0.f;
+      av.w = keep_elem(e + 3, seed, stream, thr) ? av.w * keepScale : 0.f;
+      *(float4*)(a + e) = av;
+    }
+    rv.x += av.x; rv.y += av.y; rv.z += av.z; rv.w += av.w;
+    *(float4*)(r + e) = rv;
+    s += (double)rv.x + (double)rv.y + (double)rv.z + (double)rv.w;
+    ss += (double)rv.x * rv.x + (double)rv.y * rv.y + (double)rv.z * rv.z + (double)rv.w * rv.w;
+  }
+  block_atomic_add2(s, ss, stats + 2 * g, nullptr);
+}
+
+// y = gamma * (r - mu) * rstd + beta ; mu/rstd from stats (sum, sumsq), biased variance + eps.
+// writes mean/rstd (fp32) for the backward pass.
+__global__ __launch_bounds__(kEwThreads) void ln_apply_k(const float* __restrict__ r, float* __restrict__ y,
+                                                        const double* __restrict__ stats,
+                                                        float* __restrict__ meanRstd, size_t inner,
+                                                        const float* __restrict__ gammaBeta, float eps) {
+  const int g = blockIdx.y;
+  const double mu = stats[2 * g] / (double)inner;
+  double var = stats[2 * g + 1] / (double)inner - mu * mu;
+  if (var < 0) var = 0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float muf = (float)mu;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { meanRstd[2 * g] = muf; meanRstd[2 * g + 1] = rstd; }
+  const float gam = gammaBeta[0] * rstd, bet = gammaBeta[1];
+  const size_t base = (size_t)g * inner, n4 = inner >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 v = *(const float4*)(r + base + 4 * i);
+    v.x = (v.x - muf) * gam + bet; v.y = (v.y - muf) * gam + bet;
+    v.z = (v.z - muf) * gam + bet; v.w = (v.w - muf) * gam + bet;
+    *(float4*)(y + base + 4 * i) = v;
+  }
+}
+
+// backward reduce: sums[g] += (sum dy, sum dy * xhat), xhat = (r - mu) * rstd
+__global__ __launch_bounds__(kEwThreads) void ln_bwd_reduce_k(const float* __restrict__ r,
+                                                             const float* __restrict__ dy,
+                                                             const float* __restrict__ meanRstd,
+                                                             double* __restrict__ sums, size_t inner) {
+  const int g = blockIdx.y;
+  const float mu = meanRstd[2 * g], rstd = meanRstd[2 * g + 1];
+  const size_t base = (size_t)g * inner, n4 = inner >> 2;
+  double s1 = 0, s2 = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 rv = *(const float4*)(r + base + 4 * i);
+    float4 dv = *(const float4*)(dy + base + 4 * i);
+    s1 += (double)dv.x + (double)dv.y + (double)dv.z + (double)dv.w;
+    s2 += (double)(dv.x * ((rv.x - mu) * rstd)) + (double)(dv.y * ((rv.y - mu) * rstd)) +
+          (double)(dv.z * ((rv.z - mu) * rstd)) + (double)(dv.w * ((rv.w - mu) * rstd));
+  }
+  block_atomic_add2(s1, s2, sums + 2 * g, nullptr);
+}
+
+// backward apply: dr = gamma*rstd*(dy - S1/n - xhat*S2/n).
+// Optional second output dmask = dr * (maskSrc > 0 ? maskScale : 0)  (ReLU+dropout of the
+// producer branch: maskSrc is its stored post-dropout output).
+__global__ __launch_bounds__(kEwThreads) void ln_bwd_apply_k(const float* __restrict__ r,
+                                                            const float* __restrict__ dy,
+                                                            const float* __restrict__ meanRstd,
+                                                            const double* __restrict__ sums,
+                                                            const float* __restrict__ gammaBeta,
+                                                            float* __restrict__ dr,
+                                                            const float* __restrict__ maskSrc,
+                                                            float* __restrict__ dmask, float maskScale,
+                                                            size_t inner) {
+  const int g = blockIdx.y;
+  const float mu = meanRstd[2 * g], rstd = meanRstd[2 * g + 1];
+  const float c1 = (float)(sums[2 * g] / (double)inner), c2 = (float)(sums[2 * g + 1] / (double)inner);
+  const float gr = gammaBeta[0] * rstd;
+  const size_t base = (size_t)g * inner, n4 = inner >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = base + 4 * i;
+    float4 rv = *(const float4*)(r + e);
+    float4 dv = *(const float4*)(dy + e);
+    float4 o;
+    o.x = gr * (dv.x - c1 - (rv.x - mu) * rstd * c2);
+    o.y = gr * (dv.y - c1 - (rv.y - mu) * rstd * c2);
+    o.z = gr * (dv.z - c1 - (rv.z - mu) * rstd * c2);
+    o.w = gr * (dv.w - c1 - (rv.w - mu) * rstd * c2);
+    *(float4*)(dr + e) = o;
+    if (dmask) {
+      float4 mv = *(const float4*)(maskSrc + e);
+      float4 d2;
+      d2.x = mv.x > 0.f ? o.x * maskScale : 0.f;
+      d2.y = mv.y > 0.f ? o.y * maskScale : 0.f;
+      d2.z = mv.z > 0.f ? o.z * maskScale : 0.f;
+      d2.w = mv.w > 0.f ? o.w * maskScale : 0.f;
+      *(float4*)(dmask + e) = d2;
+    }
+  }
+}
+
+// scalar-parameter gradients: dgamma = sum_g S2_g, dbeta = sum_g S1_g
+__global__ void ln_param_grad_k(const double* __restrict__ sums, int groups, float* __restrict__ dGammaBeta) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s1 = 0, s2 = 0;
+    for (int g = 0; g < groups; ++g) { s1 += sums[2 * g]; s2 += sums[2 * g + 1]; }
+    dGammaBeta[0] = (float)s2;
+    dGammaBeta[1] = (float)s1;
+  }
+}
+
+// ---- dropout in place (+ optional ReLU first), mask from the stateless hash
+__global__ __launch_bounds__(kEwThreads) void dropout_k(float* __restrict__ x, size_t n, uint32_t thr,
+                                                       float keepScale, uint32_t seed, uint32_t stream) {
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = 4 * i;
+    float4 v = *(const float4*)(x + e);
+    v.x = keep_elem(e, seed, stream, thr) ? v.x * keepScale : 0.f;
+    v.y = keep_elem(e + 1, seed, stream, thr) ? v.y * keepScale : 0.f;
+    v.z = keep_elem(e + 2, seed, stream, thr) ? v.z * keepScale : 0.f;
+    v.w = keep_elem(e + 3, seed, stream, thr) ? v.w * keepScale : 0.f;
+    *(float4*)(x + e) = v;
+  }
+  for (size_t e = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
+    x[e] = keep_elem(e, seed, stream, thr) ? x[e] * keepScale : 0.f;
+}
+
+// dx = dy * (src > 0 ? scale : 0)   (ReLU [+dropout] backward from the stored output)
+__global__ __launch_bounds__(kEwThreads) void mask_bwd_k(const float* __restrict__ dy, const float* __restrict__ src,
+                                                        float* __restrict__ dx, size_t n, float scale) {
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 d = *(const float4*)(dy + 4 * i);
+    float4 s = *(const float4*)(src + 4 * i);
+    d.x = s.x > 0.f ? d.x * scale : 0.f; d.y = s.y > 0.f ? d.y * scale : 0.f;
+    d.z = s.z > 0.f ? d.z * scale : 0.f; d.w = s.w > 0.f ? d.w * scale : 0.f;
+    *(float4*)(dx + 4 * i) = d;
+  }
+  for (size_t e = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
+    dx[e] = src[e] > 0.f ? dy[e] * scale : 0.f;
+}
+
+// y (+)= alpha * x
+__global__ __launch_bounds__(kEwThreads) void axpy_k(float* __restrict__ y, const float* __restrict__ x, size_t n, float alpha) {
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 a = *(const float4*)(y + 4 * i), b = *(const float4*)(x + 4 * i);
+    a.x += alpha * b.x; a.y += alpha * b.y; a.z += alpha * b.z; a.w += alpha * b.w;
+    *(float4*)(y + 4 * i) = a;
+  }
+  for (size_t e = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
+    y[e] += alpha * x[e];
+}
+
+// ---- batched 2-D transpose: in [G][R][Cc] -> out [G][Cc][R]  (Reorder between the
+// reference's time-fastest input (T,NFEAT,1,B) and the frame-major internal layout)
+__global__ __launch_bounds__(256) void transpose_k(const float* __restrict__ in, float* __restrict__ out, int R, int Cc) {
+  __shared__ float tile[32][33];
+  const size_t g = blockIdx.z;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {
+    int rr = r0 + k, cc = c0 + tx;
+    tile[k][tx] = (rr < R && cc < Cc) ? in[(g * R + rr) * Cc + cc] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    int cc = c0 + k, rr = r0 + tx;
+    if (rr < R && cc < Cc) out[(g * Cc + cc) * R + rr] = tile[tx][k];
+  }
+}
+
+// ---- GLU over the last (channel) axis: x [M][2*half] -> y [M][half] = a * sigmoid(b)
+__global__ __launch_bounds__(kEwThreads) void glu_fwd_k(const float* __restrict__ x, float* __restrict__ y, size_t M, int half) {
+  const size_t n = M * (size_t)half;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    size_t m = e / half;
+    int c = (int)(e - m * half);
+    float a = x[m * 2 * half + c], b = x[m * 2 * half + half + c];
+    y[e] = a / (1.f + __expf(-b));
+  }
+}
+__global__ __launch_bounds__(kEwThreads) void glu_bwd_k(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       float* __restrict__ dx, size_t M, int half) {
+  const size_t n = M * (size_t)half;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    size_t m = e / half;
+    int c = (int)(e - m * half);
+    float a = x[m * 2 * half + c], b = x[m * 2 * half + half + c];
+    float s = 1.f / (1.f + __expf(-b));
+    float d = dy[e];
+    dx[m * 2 * half + c] = d * s;
+    dx[m * 2 * half + half + c] = d * a * s * (1.f - s);
+  }
+}
+
+// ---- optimizer: sum of squares (fp64 accumulate), then SGD with momentum + global-norm clip
+__global__ __launch_bounds__(kEwThreads) void sumsq_k(const float* __restrict__ g, size_t n, double* __restrict__ out) {
+  double s = 0;
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 v = *(const float4*)(g + 4 * i);
+    s += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+  }
+  for (size_t e = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
+    s += (double)g[e] * g[e];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+// fl::SGDOptimizer::step with momentum (no dampening/nesterov/wd, as the recipes use):
+//   g' = g * gradScale * clipCoef ; v = mom*v + g' ; p -= lr * v
+// clipCoef = min(1, maxNorm / (||g*gradScale|| + 1e-6))  (fl::clipGradNorm), maxNorm <= 0: off.
+__global__ __launch_bounds__(kEwThreads) void sgd_k(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ v, size_t n, float lr, float mom,
+                                                   float gradScale, float maxNorm, const double* __restrict__ sumsq) {
+  float coef = gradScale;
+  if (maxNorm > 0.f) {
+    float norm = (float)sqrt(*sumsq) * gradScale;
+    float c = maxNorm / (norm + 1e-6f);
+    if (c < 1.f) coef *= c;
+  }
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 pv = *(const float4*)(p + 4 * i), gv = *(const float4*)(g + 4 * i);
+    if (mom != 0.f) {
+      float4 vv = *(const float4*)(v + 4 * i);
+      vv.x = mom * vv.x + gv.x * coef; vv.y = mom * vv.y + gv.y * coef;
+      vv.z = mom * vv.z + gv.z * coef; vv.w = mom * vv.w + gv.w * coef;
+      *(float4*)(v + 4 * i) = vv;
+      pv.x -= lr * vv.x; pv.y -= lr * vv.y; pv.z -= lr * vv.z; pv.w -= lr * vv.w;
+    } else {
+      pv.x -= lr * gv.x * coef; pv.y -= lr * gv.y * coef; pv.z -= lr * gv.z * coef; pv.w -= lr * gv.w * coef;
+    }
+    *(float4*)(p + 4 * i) = pv;
+  }
+  for (size_t e = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    float gg = g[e] * coef;
+    if (mom != 0.f) { float vv = mom * v[e] + gg; v[e] = vv; p[e] -= lr * vv; }
+    else p[e] -= lr * gg;
+  }
+}
+
+}  // namespace w2l
+
+using namespace w2l;
+
+#define W2L_S ((hipStream_t)stream)
+
+// LayerNorm over `groups` contiguous chunks of `inner` elements (inner % 4 == 0):
+// fused with the residual add and the dropout of the incoming branch.
+//   a   [groups*inner]  branch output (dropout applied IN PLACE when p > 0)
+//   x   residual input or NULL
+//   r   pre-norm sum (kept for backward), y normalised output
+//   stats  double[2*groups] scratch, meanRstd float[2*groups] (kept for backward)
+W2L_API int w2l_residual_layernorm_forward(int groups, size_t inner, float* a, const float* x, float* r,
+                                           float* y, const float* gammaBeta, float eps, double p,
+                                           uint32_t seed, uint32_t rngStream, double* stats,
+                                           float* meanRstd, w2l_stream_t stream) {
+  if (groups <= 0 || inner == 0 || (inner & 3) || !a || !r || !y || !gammaBeta || !stats || !meanRstd)
+    return W2L_EINVAL;
+  W2L_HIP_CHECK(hipMemsetAsync(stats, 0, sizeof(double) * 2 * groups, W2L_S));
+  const uint32_t thr = dropout_threshold(p);
+  const float ks = (float)(1.0 / (1.0 - p));
+  unsigned gx = ew_grid(inner >> 2);
+  if (gx > 512) gx = 512;
+  dim3 grid(gx, (unsigned)groups);
+  hipLaunchKernelGGL(residual_dropout_stats_k, grid, dim3(kEwThreads), 0, W2L_S, a, x, r, stats, inner, thr, ks, seed, rngStream);
+  W2L_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ln_apply_k, grid, dim3(kEwThreads), 0, W2L_S, r, y, stats, meanRstd, inner, gammaBeta, eps);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+// dr = LayerNorm backward of (r -> y) given dy; dGammaBeta[2] overwritten;
+// if maskSrc: dmask = dr * (maskSrc > 0 ? maskScale : 0)
+W2L_API int w2l_layernorm_backward(int groups, size_t inner, const float* r, const float* dy,
+                                   const float* gammaBeta, const float* meanRstd, float* dr,
+                                   float* dGammaBeta, const float* maskSrc, float* dmask, float maskScale,
+                                   double* sums, w2l_stream_t stream) {
+  if (groups <= 0 || inner == 0 || (inner & 3) || !r || !dy || !gammaBeta || !meanRstd || !dr || !sums)
+    return W2L_EINVAL;
+  W2L_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 2 * groups, W2L_S));
+  unsigned gx = ew_grid(inner >> 2);
+  if (gx > 512) gx = 512;
+  dim3 grid(gx, (unsigned)groups);
+  hipLaunchKernelGGL(ln_bwd_reduce_k, grid, dim3(kEwThreads), 0, W2L_S, r, dy, meanRstd, sums, inner);
+  W2L_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ln_bwd_apply_k, grid, dim3(kEwThreads), 0, W2L_S, r, dy, meanRstd, sums, gammaBeta, dr,
+                     maskSrc, maskSrc ? dmask : nullptr, maskScale, inner);
+  W2L_LAUNCH_CHECK();
+  if (dGammaBeta) {
+    hipLaunchKernelGGL(ln_param_grad_k, dim3(1), dim3(64), 0, W2L_S, sums, groups, dGammaBeta);
+    W2L_LAUNCH_CHECK();
+  }
+  return W2L_OK;
+}
+
+W2L_API int w2l_dropout_inplace(float* x, size_t n, double p, uint32_t seed, uint32_t rngStream,
+                                w2l_stream_t stream) {
+  if (!x) return W2L_EINVAL;
+  const uint32_t thr = dropout_threshold(p);
+  if (!thr || !n) return W2L_OK;
+  hipLaunchKernelGGL(dropout_k, dim3(ew_grid((n >> 2) + 1)), dim3(kEwThreads), 0, W2L_S, x, n, thr,
+                     (float)(1.0 / (1.0 - p)), seed, rngStream);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+W2L_API int w2l_mask_backward(const float* dy, const float* src, float* dx, size_t n, float scale,
+                              w2l_stream_t stream) {
+  if (!dy || !src || !dx) return W2L_EINVAL;
+  if (!n) return W2L_OK;
+  hipLaunchKernelGGL(mask_bwd_k, dim3(ew_grid((n >> 2) + 1)), dim3(kEwThreads), 0, W2L_S, dy, src, dx, n, scale);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+W2L_API int w2l_axpy(float* y, const float* x, size_t n, float alpha, w2l_stream_t stream) {
+  if (!y || !x) return W2L_EINVAL;
+  if (!n) return W2L_OK;
+  hipLaunchKernelGGL(axpy_k, dim3(ew_grid((n >> 2) + 1)), dim3(kEwThreads), 0, W2L_S, y, x, n, alpha);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+W2L_API int w2l_transpose(const float* in, float* out, int G, int R, int Cc, w2l_stream_t stream) {
+  if (!in || !out || G <= 0 || R <= 0 || Cc <= 0) return W2L_EINVAL;
+  dim3 grid((unsigned)((Cc + 31) / 32), (unsigned)((R + 31) / 32), (unsigned)G);
+  hipLaunchKernelGGL(transpose_k, grid, dim3(256), 0, W2L_S, in, out, R, Cc);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+W2L_API int w2l_glu_forward(const float* x, float* y, size_t M, int half, w2l_stream_t stream) {
+  if (!x || !y || half <= 0) return W2L_EINVAL;
+  hipLaunchKernelGGL(glu_fwd_k, dim3(ew_grid(M * half)), dim3(kEwThreads), 0, W2L_S, x, y, M, half);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+W2L_API int w2l_glu_backward(const float* x, const float* dy, float* dx, size_t M, int half, w2l_stream_t stream) {
+  if (!x || !dy || !dx || half <= 0) return W2L_EINVAL;
+  hipLaunchKernelGGL(glu_bwd_k, dim3(ew_grid(M * half)), dim3(kEwThreads), 0, W2L_S, x, dy, dx, M, half);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+W2L_API int w2l_sumsq(const float* g, size_t n, double* out, int zeroFirst, w2l_stream_t stream) {
+  if (!g || !out) return W2L_EINVAL;
+  if (zeroFirst) W2L_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(double), W2L_S));
+  if (!n) return W2L_OK;
+  hipLaunchKernelGGL(sumsq_k, dim3(ew_grid((n >> 2) + 1)), dim3(kEwThreads), 0, W2L_S, g, n, out);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+W2L_API int w2l_sgd_step(float* p, const float* g, float* v, size_t n, float lr, float momentum,
+                         float gradScale, float maxGradNorm, const double* sumsq, w2l_stream_t stream) {
+  if (!p || !g || (momentum != 0.f && !v) || (maxGradNorm > 0.f && !sumsq)) return W2L_EINVAL;
+  if (!n) return W2L_OK;
+  hipLaunchKernelGGL(sgd_k, dim3(ew_grid((n >> 2) + 1)), dim3(kEwThreads), 0, W2L_S, p, g, v, n, lr, momentum,
+                     gradScale, maxGradNorm, sumsq);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}

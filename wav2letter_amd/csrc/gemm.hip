@@ -1,0 +1,120 @@
+// gemm.hip -- fp32 MFMA GEMM engine for gfx950 (v_mfma_f32_32x32x2_f32 / 16x16x4_f32).
+//
+// Replaces the cuBLAS / cuDNN calls behind fl::Linear and fl::Conv2D in the
+// reference's training step (fl::linear / fl::conv2d autograd functions,
+// un-vendored Flashlight; instantiated by the arch grammar in
+// recipes/joint_training_vox_populi/cpc/SequentialBuilder.cpp:203-252, :305-313):
+//   forward      Y = X W + b            (A k-contiguous, B k-rows)
+//   backward dX  dX = dY W^T            (A k-contiguous, B k-contiguous)
+//   backward dW  dW = X^T dY            (A k-rows,       B k-rows)
+// and, through the implicit-GEMM operand in conv.hip, the time convolutions.
+//
+// fp32 in / fp32 accumulate MFMA is bit-for-bit a k-ordered fmaf chain
+// (cdna_hip_programming.md section 3), so results are within fp32 round-off of
+// the fp64 oracle (parity bar 1e-4).  Peak is 157.3 TFLOP/s.
+//
+// Structure: 256 threads = 4 wavefronts (2x2), block tile 128x128x32, each wave a
+// 64x64 sub-tile = 2x2 MFMA tiles of 32x32.  Operand tiles are staged through LDS
+// in K-major form  As[k][m], Bs[k][n]  so that a half-wave's fragment read is 32
+// consecutive dwords (conflict-free ds_read_b32), double-buffered with register
+// prefetch of the next K-tile (one barrier per K-tile).
+#include "gemm.hpp"
+
+namespace w2l {
+
+static inline int pick_vec(const float* p, int ld, int extent) {
+  if ((((uintptr_t)p) & 15) == 0 && ld % 4 == 0 && extent % 4 == 0) return 4;
+  if ((((uintptr_t)p) & 7) == 0 && ld % 2 == 0 && extent % 2 == 0) return 2;
+  return 1;
+}
+
+template <class AOp>
+static int dispatch_b(const AOp& a, const float* B, int ldb, int b_kcontig, const GemmOut& o, int epi,
+                      int splitk, hipStream_t s) {
+  if (b_kcontig) {
+    int v = pick_vec(B, ldb, o.K);
+    if (v == 4) return launch128(a, PlainOp<true, 4>{B, ldb, o.N, o.K}, o, epi, splitk, s);
+    if (v == 2) return launch128(a, PlainOp<true, 2>{B, ldb, o.N, o.K}, o, epi, splitk, s);
+    return launch128(a, PlainOp<true, 1>{B, ldb, o.N, o.K}, o, epi, splitk, s);
+  }
+  int v = pick_vec(B, ldb, o.N);
+  if (v == 4) return launch128(a, PlainOp<false, 4>{B, ldb, o.N, o.K}, o, epi, splitk, s);
+  if (v == 2) return launch128(a, PlainOp<false, 2>{B, ldb, o.N, o.K}, o, epi, splitk, s);
+  return launch128(a, PlainOp<false, 1>{B, ldb, o.N, o.K}, o, epi, splitk, s);
+}
+
+int gemm_f32(const float* A, int lda, int a_kcontig, const float* B, int ldb, int b_kcontig, float* C,
+             int ldc, int M, int N, int K, const float* bias, int epi, int splitk, hipStream_t s,
+             const float* mask, float maskScale) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return W2L_EINVAL;
+  GemmOut o{C, bias, M, N, K, ldc, 0};
+  o.mask = mask;
+  o.maskScale = maskScale;
+  if (mask) epi |= EPI_MASK;
+  if (splitk < 1) splitk = 1;
+  if (splitk > 1) {
+    if (epi != EPI_ATOMIC) return W2L_EINVAL;
+  }
+  if (a_kcontig) {
+    int v = pick_vec(A, lda, K);
+    if (v == 4) return dispatch_b(PlainOp<true, 4>{A, lda, M, K}, B, ldb, b_kcontig, o, epi, splitk, s);
+    if (v == 2) return dispatch_b(PlainOp<true, 2>{A, lda, M, K}, B, ldb, b_kcontig, o, epi, splitk, s);
+    return dispatch_b(PlainOp<true, 1>{A, lda, M, K}, B, ldb, b_kcontig, o, epi, splitk, s);
+  }
+  int v = pick_vec(A, lda, M);
+  if (v == 4) return dispatch_b(PlainOp<false, 4>{A, lda, M, K}, B, ldb, b_kcontig, o, epi, splitk, s);
+  if (v == 2) return dispatch_b(PlainOp<false, 2>{A, lda, M, K}, B, ldb, b_kcontig, o, epi, splitk, s);
+  return dispatch_b(PlainOp<false, 1>{A, lda, M, K}, B, ldb, b_kcontig, o, epi, splitk, s);
+}
+
+}  // namespace w2l
+
+using namespace w2l;
+
+// ---- C ABI: fl::linear forward / backward ----------------------------------
+W2L_API int w2l_linear_forward(int M, int in, int out, const float* x, const float* w,
+                               const float* bias, float* y, int relu, w2l_stream_t stream) {
+  int epi = (bias ? EPI_BIAS : 0) | (relu ? EPI_RELU : 0);
+  return gemm_f32(x, in, 1, w, out, 0, y, out, M, out, in, bias, epi, 1, (hipStream_t)stream);
+}
+
+W2L_API int w2l_linear_backward_data(int M, int in, int out, const float* dy, const float* w,
+                                     float* dx, int accumulate, const float* maskSrc, float maskScale,
+                                     w2l_stream_t stream) {
+  // dx[M][in] = dy[M][out] . w[in][out]^T : reduction over `out`, both operands k-contiguous.
+  // maskSrc (optional, [M][in]): dx = maskSrc > 0 ? dx * maskScale : 0 -- the ReLU(+dropout)
+  // backward of the layer that produced this Linear's input, fused into the epilogue.
+  return gemm_f32(dy, out, 1, w, out, 1, dx, in, M, in, out, nullptr, accumulate ? EPI_ACCUM : 0, 1,
+                  (hipStream_t)stream, maskSrc, maskScale);
+}
+
+W2L_API int w2l_linear_backward_weight(int M, int in, int out, const float* x, const float* dy,
+                                       float* dw, w2l_stream_t stream) {
+  // dw[in][out] = x[M][in]^T . dy[M][out] : reduction over M, both operands k-rows.
+  // The output is small (in x out) and the reduction long: split K so the grid fills 256 CUs.
+  hipStream_t s = (hipStream_t)stream;
+  const int tiles = ((in + 127) / 128) * ((out + 127) / 128);
+  int splitk = 1;
+  if (tiles < 512) splitk = (512 + tiles - 1) / tiles;
+  const int kTiles = (M + 31) / 32;
+  if (splitk > kTiles / 4) splitk = kTiles / 4 > 0 ? kTiles / 4 : 1;
+  if (splitk > 1) {
+    W2L_HIP_CHECK(hipMemsetAsync(dw, 0, (size_t)in * out * sizeof(float), s));
+    return gemm_f32(x, in, 0, dy, out, 0, dw, out, in, out, M, nullptr, EPI_ATOMIC, splitk, s);
+  }
+  return gemm_f32(x, in, 0, dy, out, 0, dw, out, in, out, M, nullptr, 0, 1, s);
+}
+
+// generic entry (tests / benchmarks): C[M][N] = op(A) op(B) (+bias)(relu)
+W2L_API int w2l_gemm_f32(int M, int N, int K, const float* A, int lda, int a_kcontig, const float* B,
+                         int ldb, int b_kcontig, float* C, int ldc, const float* bias, int relu,
+                         int splitk, w2l_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (splitk > 1) {
+    if (bias || relu) return W2L_EINVAL;
+    W2L_HIP_CHECK(hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s));
+    return gemm_f32(A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, M, N, K, nullptr, EPI_ATOMIC, splitk, s);
+  }
+  int epi = (bias ? EPI_BIAS : 0) | (relu ? EPI_RELU : 0);
+  return gemm_f32(A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, M, N, K, bias, epi, 1, s);
+}

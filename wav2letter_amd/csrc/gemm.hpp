@@ -1,0 +1,382 @@
+// gemm.hpp -- operand loaders and launch interface of the fp32 MFMA GEMM engine.
+#pragma once
+#include "common.hpp"
+
+namespace w2l {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { EPI_BIAS = 1, EPI_RELU = 2, EPI_ACCUM = 4, EPI_ATOMIC = 8, EPI_MASK = 16 };
+
+struct GemmOut {
+  float* C;
+  const float* bias;
+  int M, N, K, ldc;
+  int epi;  // EPI_* flags (runtime: the epilogue is outside the K loop)
+  const float* mask = nullptr;  // EPI_MASK: v = mask[m][n] > 0 ? v * maskScale : 0 (same ld as C)
+  float maskScale = 1.f;
+};
+
+// A GEMM operand viewed as op(k, i): i = row of A (m) or column of B (n).
+//   KCONTIG = true : element (k,i) at p[i*ld + k]   (reduction index contiguous)
+//   KCONTIG = false: element (k,i) at p[k*ld + i]   ("k-rows")
+// V = global-load vector width in floats (4/2/1), chosen by the host on alignment.
+// load()/store() stage a [32][128] tile (k x i) through 16 registers per thread into
+// the K-major LDS image lds[k*ldS + i]; *_bk<> are the [BK][BM] forms of the skinny kernel.
+template <bool KCONTIG, int V>
+struct PlainOp {
+  const float* p;
+  int ld;
+  int extent;  // number of valid i
+  int K;
+  static constexpr int kPad = KCONTIG ? 1 : 4;
+  static constexpr int kPadSkinny = KCONTIG ? 2 : 4;
+
+  template <int BI, int BK>
+  __device__ __forceinline__ void load_t(float (&r)[16], int i0, int k0, int tid) const {
+    static_assert(BI * BK == 4096, "16 floats per thread");
+    if (KCONTIG) {
+      constexpr int TPR = BK / V;          // threads per row
+      constexpr int RPP = 256 / TPR;       // rows per pass
+      constexpr int NP = BI / RPP;         // passes
+      const int kc = (tid % TPR) * V;
+      const int rr = tid / TPR;
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const int gi = i0 + rr + RPP * j, gk = k0 + kc;
+        const bool ok = gi < extent && gk < K;
+        const float* src = p + (size_t)gi * ld + gk;
+        if (V == 4) {
+          float4 v = ok ? *(const float4*)src : make_float4(0.f, 0.f, 0.f, 0.f);
+          r[4 * j] = v.x; r[4 * j + 1] = v.y; r[4 * j + 2] = v.z; r[4 * j + 3] = v.w;
+        } else if (V == 2) {
+          float2 v = ok ? *(const float2*)src : make_float2(0.f, 0.f);
+          r[2 * j] = v.x; r[2 * j + 1] = v.y;
+        } else {
+          r[j] = ok ? *src : 0.f;
+        }
+      }
+    } else {
+      constexpr int TPR = BI / V;          // threads per k-row
+      constexpr int RPP = 256 / TPR;       // k-rows per pass
+      constexpr int NP = BK / RPP;
+      const int ic = (tid % TPR) * V;
+      const int kr = tid / TPR;
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const int gi = i0 + ic, gk = k0 + kr + RPP * j;
+        const bool ok = gi < extent && gk < K;
+        const float* src = p + (size_t)gk * ld + gi;
+        if (V == 4) {
+          float4 v = ok ? *(const float4*)src : make_float4(0.f, 0.f, 0.f, 0.f);
+          r[4 * j] = v.x; r[4 * j + 1] = v.y; r[4 * j + 2] = v.z; r[4 * j + 3] = v.w;
+        } else if (V == 2) {
+          float2 v = ok ? *(const float2*)src : make_float2(0.f, 0.f);
+          r[2 * j] = v.x; r[2 * j + 1] = v.y;
+        } else {
+          r[j] = ok ? *src : 0.f;
+        }
+      }
+    }
+  }
+
+  template <int BI, int BK>
+  __device__ __forceinline__ void store_t(float* lds, int ldS, const float (&r)[16], int tid) const {
+    if (KCONTIG) {
+      constexpr int TPR = BK / V;
+      constexpr int RPP = 256 / TPR;
+      constexpr int NP = BI / RPP;
+      const int kc = (tid % TPR) * V;
+      const int rr = tid / TPR;
+#pragma unroll
+      for (int j = 0; j < NP; ++j)
+#pragma unroll
+        for (int e = 0; e < V; ++e) lds[(kc + e) * ldS + rr + RPP * j] = r[V * j + e];
+    } else {
+      constexpr int TPR = BI / V;
+      constexpr int RPP = 256 / TPR;
+      constexpr int NP = BK / RPP;
+      const int ic = (tid % TPR) * V;
+      const int kr = tid / TPR;
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        float* dst = lds + (kr + RPP * j) * ldS + ic;
+        if (V == 4) *(float4*)dst = make_float4(r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]);
+        else if (V == 2) *(float2*)dst = make_float2(r[2 * j], r[2 * j + 1]);
+        else *dst = r[j];
+      }
+    }
+  }
+
+  __device__ __forceinline__ void load(float (&r)[16], int i0, int k0, int tid) const { load_t<128, 32>(r, i0, k0, tid); }
+  __device__ __forceinline__ void store(float* lds, int ldS, const float (&r)[16], int tid) const { store_t<128, 32>(lds, ldS, r, tid); }
+  template <int BM, int BK>
+  __device__ __forceinline__ void load_bk(float (&r)[16], int i0, int k0, int tid) const { load_t<BM, BK>(r, i0, k0, tid); }
+  template <int BM, int BK>
+  __device__ __forceinline__ void store_bk(float* lds, int ldS, const float (&r)[16], int tid) const { store_t<BM, BK>(lds, ldS, r, tid); }
+
+  // small B tiles of the skinny kernel: [BK][BN] with BN*BK/256 scalars per thread
+  template <int BN, int BK>
+  __device__ __forceinline__ void load_small(float (&r)[(BK * BN + 255) / 256], int n0, int k0, int tid) const {
+    constexpr int NE = (BK * BN + 255) / 256;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const int e = tid + 256 * j;
+      int k, n;
+      if (KCONTIG) { k = e % BK; n = e / BK; } else { n = e % BN; k = e / BN; }
+      const int gn = n0 + n, gk = k0 + k;
+      const bool ok = e < BK * BN && gn < extent && gk < K;
+      r[j] = ok ? (KCONTIG ? p[(size_t)gn * ld + gk] : p[(size_t)gk * ld + gn]) : 0.f;
+    }
+  }
+  template <int BN, int BK>
+  __device__ __forceinline__ void store_small(float* lds, int ldS, const float (&r)[(BK * BN + 255) / 256], int tid) const {
+    constexpr int NE = (BK * BN + 255) / 256;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const int e = tid + 256 * j;
+      int k, n;
+      if (KCONTIG) { k = e % BK; n = e / BK; } else { n = e % BN; k = e / BN; }
+      if (e < BK * BN) lds[k * ldS + n] = r[j];
+    }
+  }
+};
+
+// ---------------------------------------------------------------- kernels
+template <class AOp, class BOp>
+__global__ __launch_bounds__(256, 2) void gemm128_kernel(AOp aop, BOp bop, GemmOut out) {
+  constexpr int BM = 128, BN = 128, BK = 32;
+  constexpr int LDA_S = BM + AOp::kPad, LDB_S = BN + BOp::kPad;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As0 = smem;
+  float* Bs0 = As0 + BK * LDA_S;
+  float* As1 = Bs0 + BK * LDB_S;
+  float* Bs1 = As1 + BK * LDA_S;
+
+  const int EPI = out.epi;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int li = lane & 31, lh = lane >> 5;
+
+  // tile coordinates: blockIdx.x walks M fastest inside an XCD-sized group so that
+  // neighbouring workgroups on one XCD share the same B (weight) panel in L2
+  const int tilesM = (out.M + BM - 1) / BM;
+  const int bx = blockIdx.x % tilesM, by = blockIdx.x / tilesM;
+  const int m0 = bx * BM, n0 = by * BN;
+
+  // split-K range for this z-slice
+  const int kTilesTotal = (out.K + BK - 1) / BK;
+  const int perSplit = (kTilesTotal + gridDim.z - 1) / gridDim.z;
+  const int ktBegin = blockIdx.z * perSplit;
+  int ktEnd = ktBegin + perSplit;
+  if (ktEnd > kTilesTotal) ktEnd = kTilesTotal;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float ra[16], rb[16];
+  if (ktBegin < ktEnd) {
+    aop.load(ra, m0, ktBegin * BK, tid);
+    bop.load(rb, n0, ktBegin * BK, tid);
+    aop.store(As0, LDA_S, ra, tid);
+    bop.store(Bs0, LDB_S, rb, tid);
+  }
+  __syncthreads();
+
+  for (int kt = ktBegin; kt < ktEnd; ++kt) {
+    const bool more = kt + 1 < ktEnd;
+    const int cur = (kt - ktBegin) & 1;
+    const float* As = cur ? As1 : As0;
+    const float* Bs = cur ? Bs1 : Bs0;
+    if (more) {
+      aop.load(ra, m0, (kt + 1) * BK, tid);
+      bop.load(rb, n0, (kt + 1) * BK, tid);
+    }
+#pragma unroll
+    for (int kp = 0; kp < BK / 2; ++kp) {
+      const float* ar = As + (2 * kp + lh) * LDA_S + wm + li;
+      const float* br = Bs + (2 * kp + lh) * LDB_S + wn + li;
+      float a0 = ar[0], a1 = ar[32];
+      float b0 = br[0], b1 = br[32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) {
+      aop.store(cur ? As0 : As1, LDA_S, ra, tid);
+      bop.store(cur ? Bs0 : Bs1, LDB_S, rb, tid);
+    }
+    __syncthreads();
+  }
+
+  // epilogue. C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn + j * 32 + li;
+      if (n >= out.N) continue;
+      float bv = 0.f;
+      if ((EPI & EPI_BIAS) && blockIdx.z == 0) bv = out.bias[n];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= out.M) continue;
+        float v = acc[i][j][r] + bv;
+        float* dst = out.C + (size_t)m * out.ldc + n;
+        if (EPI & EPI_ATOMIC) {
+          atomicAdd(dst, v);
+        } else {
+          if (EPI & EPI_RELU) v = fmaxf(v, 0.f);
+          if (EPI & EPI_MASK) v = out.mask[(size_t)m * out.ldc + n] > 0.f ? v * out.maskScale : 0.f;
+          if (EPI & EPI_ACCUM) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+}
+
+// Skinny-N variant for small output widths (TDS time convolutions, C = 10..18):
+// 16x16x4 MFMA, block tile 256 x BN (BN = 16 or 32), 4 waves stacked along M, each
+// wave 64 x BN = 4 x (BN/16) MFMA tiles (>= 4 independent accumulators cover the
+// 40-cycle dependent latency of v_mfma_f32_16x16x4_f32).
+template <class AOp, class BOp, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(AOp aop, BOp bop, GemmOut out) {
+  constexpr int BM = 256, BK = 16;
+  constexpr int NT = BN / 16;
+  constexpr int LDA_S = BM + AOp::kPadSkinny, LDB_S = BN + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As0 = smem;
+  float* Bs0 = As0 + BK * LDA_S;
+  float* As1 = Bs0 + BK * LDB_S;
+  float* Bs1 = As1 + BK * LDA_S;
+
+  const int EPI = out.epi;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave * 64;
+  const int li = lane & 15, lq = lane >> 4;
+
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int kTilesTotal = (out.K + BK - 1) / BK;
+  const int perSplit = (kTilesTotal + gridDim.z - 1) / gridDim.z;
+  const int ktBegin = blockIdx.z * perSplit;
+  int ktEnd = ktBegin + perSplit;
+  if (ktEnd > kTilesTotal) ktEnd = kTilesTotal;
+
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+  float ra[16];
+  float rb[(BK * BN + 255) / 256];
+  if (ktBegin < ktEnd) {
+    aop.template load_bk<BM, BK>(ra, m0, ktBegin * BK, tid);
+    bop.template load_small<BN, BK>(rb, n0, ktBegin * BK, tid);
+    aop.template store_bk<BM, BK>(As0, LDA_S, ra, tid);
+    bop.template store_small<BN, BK>(Bs0, LDB_S, rb, tid);
+  }
+  __syncthreads();
+  for (int kt = ktBegin; kt < ktEnd; ++kt) {
+    const bool more = kt + 1 < ktEnd;
+    const int cur = (kt - ktBegin) & 1;
+    const float* As = cur ? As1 : As0;
+    const float* Bs = cur ? Bs1 : Bs0;
+    if (more) {
+      aop.template load_bk<BM, BK>(ra, m0, (kt + 1) * BK, tid);
+      bop.template load_small<BN, BK>(rb, n0, (kt + 1) * BK, tid);
+    }
+#pragma unroll
+    for (int kq = 0; kq < BK / 4; ++kq) {
+      const float* ar = As + (4 * kq + lq) * LDA_S + wm + li;
+      const float* br = Bs + (4 * kq + lq) * LDB_S + li;
+      float a[4], b[NT];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = ar[16 * i];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[j] = br[16 * j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      aop.template store_bk<BM, BK>(cur ? As0 : As1, LDA_S, ra, tid);
+      bop.template store_small<BN, BK>(cur ? Bs0 : Bs1, LDB_S, rb, tid);
+    }
+    __syncthreads();
+  }
+  // C/D layout of 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + r
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + j * 16 + li;
+      if (n >= out.N) continue;
+      float bv = 0.f;
+      if ((EPI & EPI_BIAS) && blockIdx.z == 0) bv = out.bias[n];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm + i * 16 + 4 * lq + r;
+        if (m >= out.M) continue;
+        float v = acc[i][j][r] + bv;
+        float* dst = out.C + (size_t)m * out.ldc + n;
+        if (EPI & EPI_ATOMIC) {
+          atomicAdd(dst, v);
+        } else {
+          if (EPI & EPI_RELU) v = fmaxf(v, 0.f);
+          if (EPI & EPI_MASK) v = out.mask[(size_t)m * out.ldc + n] > 0.f ? v * out.maskScale : 0.f;
+          if (EPI & EPI_ACCUM) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------
+template <class AOp, class BOp>
+inline int launch128(const AOp& a, const BOp& b, GemmOut o, int epi, int splitk, hipStream_t s) {
+  constexpr int BK = 32;
+  const size_t shmem = 2 * (size_t)BK * ((128 + AOp::kPad) + (128 + BOp::kPad)) * sizeof(float);
+  const int tilesM = (o.M + 127) / 128, tilesN = (o.N + 127) / 128;
+  dim3 grid((unsigned)(tilesM * tilesN), 1, (unsigned)splitk), block(256);
+  o.epi = epi;
+  hipLaunchKernelGGL((gemm128_kernel<AOp, BOp>), grid, block, shmem, s, a, b, o);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+template <class AOp, class BOp, int BN>
+inline int launch_skinny(const AOp& a, const BOp& b, GemmOut o, int epi, int splitk, hipStream_t s) {
+  constexpr int BK = 16;
+  const size_t shmem = 2 * (size_t)BK * ((256 + AOp::kPadSkinny) + (BN + 4)) * sizeof(float);
+  dim3 grid((unsigned)((o.M + 255) / 256), (unsigned)((o.N + BN - 1) / BN), (unsigned)splitk), block(256);
+  o.epi = epi;
+  hipLaunchKernelGGL((gemm_skinny_kernel<AOp, BOp, BN>), grid, block, shmem, s, a, b, o);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+// C[M][N] = op(A)[M][K] . op(B)[K][N] (+bias[n]) (relu) ; a_kcontig: A is [M][K] row-major;
+// b_kcontig: B is stored [N][K] row-major.  epi = EPI_* flags; splitk > 1 needs EPI_ATOMIC
+// and a pre-zeroed C.
+int gemm_f32(const float* A, int lda, int a_kcontig, const float* B, int ldb, int b_kcontig, float* C,
+             int ldc, int M, int N, int K, const float* bias, int epi, int splitk, hipStream_t s,
+             const float* mask = nullptr, float maskScale = 1.f);
+
+}  // namespace w2l

@@ -1,0 +1,134 @@
+"""Thin torch-tensor front-ends of the network-operator C ABI (include/w2l_hip.h
+section 2).  Used by tests and by the Python side of bench.py; the C++ host
+(wav2letter_amd/csrc/host) calls the same kernels directly.  Frame-major
+activations: [B][T][H][C]."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def gemm(A, B, a_kcontig=True, b_kcontig=False, bias=None, relu=False, splitk=1):
+    """C = op(A) op(B): A [M][K] if a_kcontig else [K][M]; B [N][K] if b_kcontig else [K][N]"""
+    M, K = (A.shape if a_kcontig else A.shape[::-1])
+    N = B.shape[0] if b_kcontig else B.shape[1]
+    Cm = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    check(_lib.lib().w2l_gemm_f32(M, N, K, _p(A), A.stride(0), int(a_kcontig), _p(B), B.stride(0), int(b_kcontig),
+                                  _p(Cm), N, _p(bias), int(relu), splitk, _s()), "gemm")
+    return Cm
+
+
+def linear_forward(x, w, bias=None, relu=False):
+    M, K = x.shape
+    N = w.shape[1]
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    check(_lib.lib().w2l_linear_forward(M, K, N, _p(x), _p(w), _p(bias), _p(y), int(relu), _s()), "linear_forward")
+    return y
+
+
+def linear_backward(x, w, dy, mask_src=None, mask_scale=1.0):
+    M, K = x.shape
+    N = w.shape[1]
+    dx = torch.empty_like(x)
+    dw = torch.empty_like(w)
+    db = torch.empty(N, device=x.device, dtype=torch.float32)
+    L = _lib.lib()
+    check(L.w2l_linear_backward_data(M, K, N, _p(dy), _p(w), _p(dx), 0, _p(mask_src), mask_scale, _s()), "linear_bwd_data")
+    check(L.w2l_linear_backward_weight(M, K, N, _p(x), _p(dy), _p(dw), _s()), "linear_bwd_weight")
+    check(L.w2l_colsum(_p(dy), _p(db), M, N, _s()), "colsum")
+    return dx, dw, db
+
+
+def conv_desc(x, w, stride, padl, padr):
+    B, T, H, Cin = x.shape
+    kw, _, Cout = w.shape
+    return ConvDesc(B, T, H, Cin, Cout, kw, stride, padl, padr)
+
+
+def conv_forward(x, w, bias=None, stride=1, padl=0, padr=0, relu=False):
+    """x [B][T][H][Cin], w [kw][Cin][Cout] -> y [B][To][H][Cout]"""
+    d = conv_desc(x, w, stride, padl, padr)
+    To = _lib.lib().w2l_conv_out_len(d.T, d.kw, stride, padl, padr)
+    y = torch.empty(d.B, To, d.H, d.Cout, device=x.device, dtype=torch.float32)
+    check(_lib.lib().w2l_conv_forward(C.byref(d), _p(x), _p(w), _p(bias), _p(y), int(relu), _s()), "conv_forward")
+    return y
+
+
+def conv_backward(x, w, dy, stride=1, padl=0, padr=0, need_dx=True):
+    d = conv_desc(x, w, stride, padl, padr)
+    L = _lib.lib()
+    dx = torch.empty_like(x) if need_dx else None
+    dw = torch.empty_like(w)
+    db = torch.empty(d.Cout, device=x.device, dtype=torch.float32)
+    if need_dx:
+        check(L.w2l_conv_backward_data(C.byref(d), _p(dy), _p(w), _p(dx), 0, _s()), "conv_bwd_data")
+    check(L.w2l_conv_backward_filter(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _s()), "conv_bwd_filter")
+    return dx, dw, db
+
+
+def residual_layernorm_forward(a, x, gamma_beta, groups, eps=1e-5, p=0.0, seed=0, stream_id=0):
+    """returns (y, r, mean_rstd); `a` is dropped in place when p > 0"""
+    inner = a.numel() // groups
+    r = torch.empty_like(a)
+    y = torch.empty_like(a)
+    stats = torch.empty(2 * groups, device=a.device, dtype=torch.float64)
+    mr = torch.empty(2 * groups, device=a.device, dtype=torch.float32)
+    check(_lib.lib().w2l_residual_layernorm_forward(groups, inner, _p(a), _p(x), _p(r), _p(y), _p(gamma_beta), eps,
+                                                    p, seed, stream_id, _p(stats), _p(mr), _s()), "res_ln_fwd")
+    return y, r, mr
+
+
+def layernorm_backward(r, dy, gamma_beta, mean_rstd, groups, mask_src=None, mask_scale=1.0):
+    inner = r.numel() // groups
+    dr = torch.empty_like(r)
+    dgb = torch.empty(2, device=r.device, dtype=torch.float32)
+    dmask = torch.empty_like(r) if mask_src is not None else None
+    sums = torch.empty(2 * groups, device=r.device, dtype=torch.float64)
+    check(_lib.lib().w2l_layernorm_backward(groups, inner, _p(r), _p(dy), _p(gamma_beta), _p(mean_rstd), _p(dr),
+                                            _p(dgb), _p(mask_src), _p(dmask), mask_scale, _p(sums), _s()), "ln_bwd")
+    return dr, dgb, dmask
+
+
+def dropout_(x, p, seed, stream_id):
+    check(_lib.lib().w2l_dropout_inplace(_p(x), x.numel(), p, seed, stream_id, _s()), "dropout")
+    return x
+
+
+def transpose(x):
+    """[G][R][C] -> [G][C][R]"""
+    G, R, Cc = x.shape
+    out = torch.empty(G, Cc, R, device=x.device, dtype=torch.float32)
+    check(_lib.lib().w2l_transpose(_p(x), _p(out), G, R, Cc, _s()), "transpose")
+    return out
+
+
+def glu_forward(x):
+    M, two = x.shape
+    y = torch.empty(M, two // 2, device=x.device, dtype=torch.float32)
+    check(_lib.lib().w2l_glu_forward(_p(x), _p(y), M, two // 2, _s()), "glu_fwd")
+    return y
+
+
+def glu_backward(x, dy):
+    M, two = x.shape
+    dx = torch.empty_like(x)
+    check(_lib.lib().w2l_glu_backward(_p(x), _p(dy), _p(dx), M, two // 2, _s()), "glu_bwd")
+    return dx
+
+
+def sgd_step_(p, g, v, lr, momentum, grad_scale=1.0, max_grad_norm=0.0):
+    L = _lib.lib()
+    ss = torch.zeros(1, device=p.device, dtype=torch.float64)
+    if max_grad_norm > 0:
+        check(L.w2l_sumsq(_p(g), g.numel(), _p(ss), 1, _s()), "sumsq")
+    check(L.w2l_sgd_step(_p(p), _p(g), _p(v), p.numel(), lr, momentum, grad_scale, max_grad_norm, _p(ss), _s()), "sgd")
