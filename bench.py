@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X-native wav2letter acoustic-training hot path.
+
+Metric (BASELINE.json): utterances/sec (whole job) on the TDS-CTC LibriSpeech training
+step -- sota/2019 am_tds_ctc.arch, 80-mel x T=1500, 9998 classes (10k word pieces + blank),
+batch 32 per GPU, fp32 -- plus the ASG criterion time (ms/step) at the conv_glu
+LibriSpeech criterion shape (B=64, T=2000, N=30).
+
+A "step" = SpecAugment + network forward + CTC forward/backward + network backward +
+(N>1: ONE all-reduce of the flat gradient arena over RCCL) + gradient clipping + SGD with
+momentum, exactly the reference's hot loop (recipes/slimIPL/src/Train.cpp:1454-1804).
+Inputs are synthetic, generated on the device before the timed region.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md chip table
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--frames", type=int, default=1500)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-asg", action="store_true")
+    return ap.parse_args()
+
+
+def make_batch(B, T, nfeat, nlabel, Lmax, seed, device):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(B, nfeat, T, generator=g, dtype=torch.float32)  # reference input (T,NFEAT,1,B)
+    tgt = torch.full((B, Lmax), -1, dtype=torch.int32)
+    for b in range(B):
+        l = int(torch.randint(20, Lmax + 1, (1,), generator=g))
+        tgt[b, :l] = torch.randint(0, nlabel - 1, (l,), generator=g, dtype=torch.int32)
+    return x.to(device), tgt.to(device)
+
+
+def asg_criterion_ms(device):
+    """ASG (FCC + FAC) forward and forward+backward at the conv_glu LibriSpeech criterion shape"""
+    from wav2letter_amd import ASGLoss, CriterionScaleMode
+    B, T, N, L = 64, 2000, 30, 300
+    g = torch.Generator(device="cpu").manual_seed(4)
+    x = torch.randn(B, T, N, generator=g).to(device).requires_grad_(True)
+    tgt = torch.full((B, L), -1, dtype=torch.int32)
+    for b in range(B):
+        l = int(torch.randint(60, L + 1, (1,), generator=g))
+        y = torch.randint(0, 28, (l,), generator=g, dtype=torch.int32)
+        for i in range(1, l):  # replabel convention: no identical neighbours
+            if y[i] == y[i - 1]:
+                y[i] = (y[i] + 1) % 28
+        tgt[b, :l] = y
+    tgt = tgt.to(device)
+    crit = ASGLoss(N, CriterionScaleMode.TARGET_SZ_SQRT, 4.0).to(device)
+
+    def timeit(fn, n=10):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    fwd = timeit(lambda: crit(x, tgt))
+    fb = timeit(lambda: crit(x, tgt).sum().backward())
+    return {"shape": f"B={B},T={T},N={N},L<={L}", "fwd_ms": round(fwd, 4), "fwd_bwd_ms": round(fb, 4),
+            "algorithmic_bytes": 16 * B * T * N, "achieved_GBps": round(16 * B * T * N / (fb * 1e-3) / 1e9, 2),
+            "note": "serial-in-T scan: latency-bound at N=30 (SURVEY 8d); HBM time would be ~10 us"}
+
+
+def cpu_baseline(nfeat, nlabel, T):
+    """the oracle ("port") timed on this box's host cores on a bounded sample: ONE utterance,
+    network forward+backward + CTC, same arch and shapes (B=1)."""
+    from oracle import pyoracle as O
+    from oracle import refnet
+    from wav2letter_amd import recipes
+    cores = O.num_threads()
+    Ts = T if cores >= 32 else max(200, T // 8)
+    arch = recipes.tds_ctc_arch()
+    arch = "\n".join(l for l in arch.splitlines()
+                     if not l.startswith("SAUG"))  # eval-style pass, dropout-free lines rewritten below
+    arch = "\n".join((" ".join(f[:4] + ["0.0"] + f[5:]) if f and f[0] == "TDS" else " ".join(f))
+                     for f in (l.split() for l in arch.splitlines())) + "\n"
+    net = refnet.RefNet(arch, nfeat, nlabel)
+    rng = np.random.default_rng(0)
+    params = net.random_params(rng)
+    x = rng.normal(size=(1, 1, nfeat, Ts)).astype(np.float32)
+    tgt = rng.integers(0, nlabel - 1, size=(1, 20)).astype(np.int32)
+    t0 = time.perf_counter()
+    em = net.forward(x, params)
+    ctc = O.CTC(em, tgt, scale_mode=4)
+    ctc.forward()
+    d_em = ctc.backward().astype(np.float32)
+    net.backward(d_em, len(params))
+    dt = time.perf_counter() - t0
+    return {"value": round((Ts / T) / dt, 4), "unit": "utterances/sec", "cores": cores, "kind": "port",
+            "sample": f"1 utterance x {Ts} frames (scaled to T={T}), forward+backward+CTC, no optimizer, "
+                      f"oracle C loops with OpenMP; {dt:.1f} s"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world and world > 1:
+        a.gpus = world
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from wav2letter_amd import CriterionScaleMode, _lib, recipes
+    from wav2letter_amd.trainer import Trainer
+
+    nfeat, nlabel, Lmax = 80, 9998, 80
+    B, T = a.batch, a.frames
+    fl = recipes.TDS_CTC_FLAGS
+    tr = Trainer(recipes.tds_ctc_arch(), nfeat, nlabel, "ctc", CriterionScaleMode.TARGET_SZ_SQRT, device=device)
+    tr.init_params(seed=1)  # identical replicas on every rank (== allReduceParameters at start)
+    Tout = tr.plan(B, T, Lmax)
+    tr.to_device()
+    x, tgt = make_batch(B, T, nfeat, nlabel, Lmax, 2026 + rank, device)
+    total_batch = B * world
+
+    def step():
+        loss = tr.forward_backward(x, tgt)
+        if dist is not None:
+            dist.all_reduce(tr.grads)  # ONE collective over the flat gradient arena (814 MB fp32)
+        tr.update(lr=fl["lr"], momentum=fl["momentum"], max_grad_norm=fl["maxgradnorm"],
+                  total_batch=total_batch)
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    L = _lib.lib()
+    L.w2l_profile_enable.argtypes = [C.c_int]
+    L.w2l_profile_report.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if rank == 0:
+        L.w2l_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    last_loss = float(loss.float().mean().item())
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    nl, ms, flops = C.c_int(0), C.c_double(0), C.c_double(0)
+    L.w2l_profile_report(C.byref(nl), C.byref(ms), C.byref(flops))
+    L.w2l_profile_enable(0)
+    achieved = flops.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+    out = {
+        "metric": "utterances/sec", "value": round(total_batch * a.steps / dt, 3), "unit": "utterances/sec",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "seq2seq_tds LibriSpeech TDS-CTC (sota/2019 am_tds_ctc.arch): 80-mel x T=%d, "
+                               "9998 classes, batch %d/GPU, fp32, SGD+momentum, CTC" % (T, B),
+                   "global_batch": total_batch, "frames": T, "emission_frames": Tout, "parallelism": f"dp{world}",
+                   "params": int(tr.n_net), "final_loss": round(last_loss, 4)},
+        "roofline": {"bound": "mfma", "kernel": "gemm128_kernel / gemm_skinny_kernel (fp32 MFMA 32x32x2 / 16x16x4)",
+                     "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                     "launches_per_step": nl.value // max(1, a.steps),
+                     "gemm_ms_per_step": round(ms.value / max(1, a.steps), 3),
+                     "algorithmic_tflop_per_step": round(flops.value / max(1, a.steps) / 1e12, 3)},
+    }
+    if not a.no_asg:
+        out["asg_loss_ms_per_step"] = asg_criterion_ms(device)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(nfeat, nlabel, T)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -164,16 +164,62 @@ int w2l_dropout_inplace(float* x, size_t n, double p, uint32_t seed, uint32_t rn
 int w2l_mask_backward(const float* dy, const float* src, float* dx, size_t n, float scale,
                       w2l_stream_t stream);
 int w2l_axpy(float* y, const float* x, size_t n, float alpha, w2l_stream_t stream);
+int w2l_fill(float* y, size_t n, float v, w2l_stream_t stream);
 int w2l_transpose(const float* in, float* out, int G, int R, int C, w2l_stream_t stream);
 int w2l_glu_forward(const float* x, float* y, size_t M, int half, w2l_stream_t stream);
 int w2l_glu_backward(const float* x, const float* dy, float* dx, size_t M, int half,
                      w2l_stream_t stream);
+
+/* fl::WeightNorm on an internal [K][N] weight (per-column norm); norm[N], dot[N] scratch */
+int w2l_weightnorm_forward(const float* v, const float* g, float* w, float* norm, int K, int N,
+                           w2l_stream_t stream);
+int w2l_weightnorm_backward(const float* v, const float* g, const float* norm, const float* dw,
+                            float* dv, float* dg, float* dot, int K, int N, w2l_stream_t stream);
+/* fl::SpecAugment (SAUG token): frequency / time masking with zeros, in place on x[B][T][F] */
+int w2l_specaugment_inplace(float* x, int B, int T, int F, int fMaskF, int nFMask, int tMaskT,
+                            float tMaskP, int nTMask, uint32_t seed, w2l_stream_t stream);
 
 /* fl::SGDOptimizer + fl::clipGradNorm over a flat parameter arena
  * (recipes/slimIPL/src/Train.cpp:1791-1804). */
 int w2l_sumsq(const float* g, size_t n, double* out, int zeroFirst, w2l_stream_t stream);
 int w2l_sgd_step(float* p, const float* g, float* v, size_t n, float lr, float momentum,
                  float gradScale, float maxGradNorm, const double* sumsq, w2l_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * 3. Trainer: arch file -> module graph -> one optimisation step.
+ * Mirrors buildSequentialModule (recipes/joint_training_vox_populi/cpc/SequentialBuilder.h:23-26),
+ * ASGLoss / CTCLoss construction (recipes/slimIPL/src/Train.cpp:406-410) and the hot loop
+ * (Train.cpp:1454-1804).  The caller owns all device memory: query sizes, allocate, bind.
+ * params / grads / momentum are flat arenas [network params | criterion params]; the
+ * data-parallel all-reduce is ONE collective over `grads` between forward_backward and update.
+ * ---------------------------------------------------------------------- */
+const char* w2l_host_last_error(void);
+void* w2l_trainer_create(const char* archText, int nFeat, int nLabel, const char* criterion,
+                         int scaleMode, double transdiag);
+void w2l_trainer_destroy(void* h);
+const char* w2l_trainer_describe(void* h);
+size_t w2l_trainer_param_floats(void* h);
+size_t w2l_trainer_net_param_floats(void* h);
+int w2l_trainer_num_params(void* h);
+int w2l_trainer_param_info(void* h, int i, char* name, int nameCap, size_t* numel, size_t* offset);
+int w2l_trainer_init_params(void* h, float* h_params, uint64_t seed);
+int w2l_trainer_import_param(void* h, int i, const float* h_ref, float* h_params);
+int w2l_trainer_export_param(void* h, int i, const float* h_arena, float* h_ref);
+int w2l_trainer_plan(void* h, int B, int T, int L, size_t* arenaFloats, size_t* critWsBytes, int* Tout);
+int w2l_trainer_bind(void* h, float* params, float* grads, float* momentum, float* arena, void* critWs);
+/* x: [B][NFEAT][T] (the reference's (T,NFEAT,1,B) input); target [B][L] int32, -1 padded */
+int w2l_trainer_forward(void* h, const float* x, int train, const float** emission, void* stream);
+int w2l_trainer_forward_backward(void* h, const float* x, const int* target, float** lossDev,
+                                 void* stream);
+int w2l_trainer_update(void* h, float lr, float lrcrit, float momentum, float maxGradNorm,
+                       float totalBatch, int clampCrit, void* stream);
+int w2l_trainer_viterbi(void* h, const float* emission, int* path, void* stream);
+int w2l_trainer_set_step(void* h, uint32_t step);
+/* roofline instrumentation: bracket every MFMA GEMM launch with hipEvents on its stream */
+int w2l_profile_enable(int on);
+int w2l_profile_report(int* launches, double* totalMs, double* totalFlops);
+int w2l_arch_check(const char* archText, int nFeat, int nLabel, int* numLayers);
+int w2l_flags_check(const char* flagsText, int* numFlags);
 
 #ifdef __cplusplus
 }

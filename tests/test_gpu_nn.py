@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-import refnet
+from oracle import refnet
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4

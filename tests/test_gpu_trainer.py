@@ -1,0 +1,129 @@
+"""End-to-end parity of the C++ host graph (arch file -> layers -> forward / criterion /
+backward / SGD) against the oracle-side reference-layout interpreter (tests/refnet.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import refnet
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def rel(got, want):
+    want = np.asarray(want, np.float64).reshape(-1)
+    got = np.asarray(got, np.float64).reshape(-1)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    return np.abs(got - want).max() / max(1e-30, np.abs(want).max())
+
+
+def build(arch, nfeat, nlabel, crit, mode, transdiag, rng, B, T, L):
+    from wav2letter_amd.trainer import Trainer
+    tr = Trainer(arch, nfeat, nlabel, crit, mode, transdiag)
+    ref = refnet.RefNet(arch, nfeat, nlabel)
+    params = ref.random_params(rng)
+    table = tr.param_table()
+    assert len(table) == len(params), (len(table), len(params))
+    for i, p in enumerate(params):
+        assert table[i][1] == p.size, (i, table[i], p.shape)
+        tr.import_param(i, p)
+    if crit == "asg":
+        A = (np.eye(nlabel) * transdiag + 0.1 * rng.normal(size=(nlabel, nlabel))).astype(np.float32)
+        tr.host_params[tr.n_net:tr.n_net + nlabel * nlabel] = A.reshape(-1)
+    else:
+        A = None
+    tr.plan(B, T, L)
+    tr.to_device()
+    return tr, ref, params, A
+
+
+def check_grads(tr, ref_grads):
+    g = tr.grads.cpu().numpy()
+    table = tr.param_table()
+    worst = 0.0
+    for i, want in enumerate(ref_grads):
+        got = tr.export_from(i, g)
+        e = rel(got, want)
+        worst = max(worst, e)
+        assert e < 2 * TOL, (i, table[i][0], e)
+    return worst
+
+
+def test_tds_ctc_small_end_to_end(oracle):
+    from wav2letter_amd import recipes
+    rng = np.random.default_rng(0)
+    nfeat, nlabel, B, T, L = 8, 21, 3, 64, 6
+    arch = recipes.tds_ctc_small_arch(c=(4, 6), h=nfeat, kw=5)
+    tr, ref, params, _ = build(arch, nfeat, nlabel, "ctc", 4, 0.0, rng, B, T, L)
+    x = rng.normal(size=(B, 1, nfeat, T)).astype(np.float32)
+    tgt = np.full((B, L), -1, np.int32)
+    for b in range(B):
+        l = int(rng.integers(1, L + 1))
+        tgt[b, :l] = rng.integers(0, nlabel - 1, l)
+    xd = torch.tensor(x.reshape(B, nfeat, T)).cuda()
+    td = torch.tensor(tgt).cuda()
+    em = tr.forward(xd, train=False).cpu().numpy()
+    em_ref = ref.forward(x, params)
+    assert em.shape == em_ref.shape
+    assert rel(em, em_ref) < TOL
+    loss = tr.forward_backward(xd, td).cpu().numpy()
+    o = oracle.CTC(em_ref, tgt, scale_mode=4)
+    assert rel(loss, o.forward()) < TOL
+    d_em = o.backward().astype(np.float32)
+    ref_grads = ref.backward(d_em, len(params))
+    check_grads(tr, ref_grads)
+    # one SGD step with clipping == reference formula on the flat arena
+    p0 = tr.params.cpu().numpy().copy()
+    g0 = tr.grads.cpu().numpy().copy()
+    tr.update(lr=0.3, momentum=0.5, max_grad_norm=1.0, total_batch=B)
+    gs = g0.astype(np.float64) / B
+    coef = min(1.0, 1.0 / (np.linalg.norm(gs) + 1e-6))
+    want = p0 - 0.3 * (gs * coef)
+    assert rel(tr.params.cpu().numpy(), want) < 1e-5
+
+
+def test_conv_glu_asg_small_end_to_end(oracle):
+    """BASELINE config 1 geometry in miniature: WN-Conv+GLU stack, ASG criterion, 2 utterances"""
+    from wav2letter_amd import recipes
+    rng = np.random.default_rng(1)
+    nfeat, nlabel, B, T, L = 6, 9, 2, 40, 7
+    arch = recipes.conv_glu_small_arch(widths=(16, 24), kws=(5, 4), pad0=2)
+    tr, ref, params, A = build(arch, nfeat, nlabel, "asg", 4, 4.0, rng, B, T, L)
+    x = rng.normal(size=(B, 1, nfeat, T)).astype(np.float32)
+    tgt = np.array([[1, 2, 3, 1, -1, -1, -1], [0, 5, 5, 2, 7, 1, 0]], np.int32)
+    xd = torch.tensor(x.reshape(B, nfeat, T)).cuda()
+    td = torch.tensor(tgt).cuda()
+    em = tr.forward(xd, train=False).cpu().numpy()
+    em_ref = ref.forward(x, params)
+    assert em.shape == em_ref.shape, (em.shape, em_ref.shape)
+    assert rel(em, em_ref) < TOL
+    loss = tr.forward_backward(xd, td).cpu().numpy()
+    ol, odx, odA = oracle.asg(em_ref, A, tgt, 4)
+    assert rel(loss, ol) < TOL
+    ref_grads = ref.backward(odx.astype(np.float32), len(params))
+    check_grads(tr, ref_grads)
+    gA = tr.grads.cpu().numpy()[tr.n_net:tr.n_net + nlabel * nlabel]
+    assert rel(gA, odA) < TOL
+    # Viterbi through the trainer: bit-exact
+    path = tr.viterbi(tr.forward(xd, train=False)).cpu().numpy()
+    assert (path == oracle.viterbi(em, A)).all()
+
+
+def test_training_reduces_loss():
+    """a few SGD steps on a fixed batch must drive the CTC loss down (plumbing sanity)"""
+    from wav2letter_amd import recipes
+    from wav2letter_amd.trainer import Trainer
+    rng = np.random.default_rng(2)
+    nfeat, nlabel, B, T, L = 8, 12, 4, 48, 5
+    tr = Trainer(recipes.tds_ctc_small_arch(c=(4,), h=nfeat, kw=5, drop=0.1), nfeat, nlabel, "ctc", 4)
+    tr.init_params(3)
+    tr.plan(B, T, L)
+    tr.to_device()
+    x = torch.tensor(rng.normal(size=(B, nfeat, T)).astype(np.float32)).cuda()
+    tgt = torch.tensor(rng.integers(0, nlabel - 1, size=(B, L)).astype(np.int32)).cuda()
+    losses = []
+    for _ in range(30):
+        losses.append(tr.forward_backward(x, tgt).sum().item())
+        tr.update(lr=0.05, momentum=0.5, max_grad_norm=1.0)
+    assert np.isfinite(losses).all()
+    assert losses[-1] < 0.7 * losses[0], losses

@@ -9,7 +9,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-import refnet
+from oracle import refnet
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 

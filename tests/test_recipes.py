@@ -1,0 +1,79 @@
+"""The reference's recipes must load unchanged: every .arch file parses with the reference's
+own grammar/arity rules, every train .cfg parses as a gflags file, and the arch generators
+in wav2letter_amd.recipes reproduce the reference files line for line."""
+import glob
+import os
+
+import pytest
+
+REF = "/root/reference/recipes"
+need_ref = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+
+
+def _lines(text):
+    return [l.strip() for l in text.splitlines() if l.strip() and not l.strip().startswith("#")]
+
+
+@need_ref
+def test_generators_reproduce_reference_arch_files():
+    from wav2letter_amd import recipes
+    assert _lines(recipes.tds_ctc_arch()) == _lines(open(f"{REF}/sota/2019/am_arch/am_tds_ctc.arch").read())
+    assert _lines(recipes.conv_glu_librispeech_arch()) == _lines(open(f"{REF}/conv_glu/librispeech/network.arch").read())
+
+
+@need_ref
+def test_all_reference_arch_files_parse():
+    from wav2letter_amd.trainer import arch_check
+    files = sorted(glob.glob(f"{REF}/**/*.arch", recursive=True))
+    assert len(files) >= 30
+    from wav2letter_amd._lib import W2LInvalidArgument
+    rejected = []
+    for f in files:
+        try:
+            n = arch_check(open(f).read(), 80, 9998)
+        except W2LInvalidArgument as e:
+            assert "LN 3" in str(e), (f, e)
+            rejected.append(os.path.relpath(f, REF))
+            continue
+        assert n == len(_lines(open(f).read())), f
+    # the reference's own builder rejects exactly these two pre-migration files (SequentialBuilder.cpp:366-375)
+    assert sorted(rejected) == ["self_training/librispeech/am/baseline.arch", "seq2seq_tds/librispeech/network.arch"]
+
+
+@need_ref
+def test_all_reference_train_cfgs_parse():
+    from wav2letter_amd.trainer import flags_check
+    files = [f for f in glob.glob(f"{REF}/**/*.cfg", recursive=True)]
+    assert len(files) >= 100
+    for f in files:
+        assert flags_check(open(f).read()) > 0, f
+
+
+def test_grammar_errors_match_reference_behaviour():
+    from wav2letter_amd._lib import W2LInvalidArgument
+    from wav2letter_amd.trainer import arch_check
+    for bad in ["V 1 2 3", "RO 0 1 2", "FOO 1 2", "TDS 10", "LN 3", "DO", "PD 0 1", "C2 1 2 3"]:
+        with pytest.raises(W2LInvalidArgument):
+            arch_check(bad, 80, 30)
+    assert arch_check("# comment\n\nV -1 NFEAT 1 0\nL NFEAT NLABEL\n", 80, 30) == 2
+
+
+def test_headline_archs_build_and_have_the_published_parameter_counts():
+    from wav2letter_amd import recipes
+    from wav2letter_amd.trainer import Trainer
+    t = Trainer(recipes.tds_ctc_arch(), 80, 9998, "ctc", device="cpu")
+    n = sum(n for _, n, _ in t.param_table())
+    # 203.4 M parameters (LayerNorm scalars counted as 2 per LN here)
+    assert abs(n - 203.4e6) < 0.1e6, n
+    t = Trainer(recipes.conv_glu_librispeech_arch(), 40, 30, "asg", transdiag=4.0, device="cpu")
+    n = sum(n for _, n, _ in t.param_table())
+    assert abs(n - 208.9e6) < 0.1e6, n
+
+
+def test_unsupported_layers_fail_loudly():
+    from wav2letter_amd._lib import W2LInvalidArgument
+    from wav2letter_amd.trainer import Trainer
+    with pytest.raises(W2LInvalidArgument):
+        Trainer("V -1 1 NFEAT 0\nTR 80 320 4 460 0.2\n", 80, 30, "ctc", device="cpu")
+    with pytest.raises(W2LInvalidArgument):
+        Trainer("V -1 NFEAT 1 0\nL 80 NLABEL\n", 80, 30, "seq2seq", device="cpu")

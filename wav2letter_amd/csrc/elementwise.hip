@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kEwThreads) void residual_dropout_stats_k(
       *(float4*)(a + e) = av;
     }
     rv.x += av.x; rv.y += av.y; rv.z += av.z; rv.w += av.w;
-    *(float4*)(r + e) = rv;
+    if (r != a || x) *(float4*)(r + e) = rv;  // plain LayerNorm (r aliases a, no residual): nothing to write
     s += (double)rv.x + (double)rv.y + (double)rv.z + (double)rv.w;
     ss += (double)rv.x * rv.x + (double)rv.y * rv.y + (double)rv.z * rv.z + (double)rv.w * rv.w;
   }
@@ -184,6 +184,10 @@ __global__ __launch_bounds__(kEwThreads) void mask_bwd_k(const float* __restrict
   }
   for (size_t e = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
     dx[e] = src[e] > 0.f ? dy[e] * scale : 0.f;
+}
+
+__global__ __launch_bounds__(kEwThreads) void fill_k(float* __restrict__ y, size_t n, float v) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) y[e] = v;
 }
 
 // y (+)= alpha * x
@@ -367,6 +371,14 @@ W2L_API int w2l_axpy(float* y, const float* x, size_t n, float alpha, w2l_stream
   if (!y || !x) return W2L_EINVAL;
   if (!n) return W2L_OK;
   hipLaunchKernelGGL(axpy_k, dim3(ew_grid((n >> 2) + 1)), dim3(kEwThreads), 0, W2L_S, y, x, n, alpha);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+W2L_API int w2l_fill(float* y, size_t n, float v, w2l_stream_t stream) {
+  if (!y) return W2L_EINVAL;
+  if (!n) return W2L_OK;
+  hipLaunchKernelGGL(fill_k, dim3(ew_grid(n)), dim3(kEwThreads), 0, W2L_S, y, n, v);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }

@@ -22,6 +22,11 @@
 
 namespace w2l {
 
+GemmProf& gemm_prof() {
+  static GemmProf p;
+  return p;
+}
+
 static inline int pick_vec(const float* p, int ld, int extent) {
   if ((((uintptr_t)p) & 15) == 0 && ld % 4 == 0 && extent % 4 == 0) return 4;
   if ((((uintptr_t)p) & 7) == 0 && ld % 2 == 0 && extent % 2 == 0) return 2;
@@ -117,4 +122,30 @@ W2L_API int w2l_gemm_f32(int M, int N, int K, const float* A, int lda, int a_kco
   }
   int epi = (bias ? EPI_BIAS : 0) | (relu ? EPI_RELU : 0);
   return gemm_f32(A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, M, N, K, bias, epi, 1, s);
+}
+
+// ---- launch profiling of the MFMA GEMM kernels (see gemm.hpp) -------------------
+W2L_API int w2l_profile_enable(int on) {
+  GemmProf& p = gemm_prof();
+  p.on = on != 0;
+  p.used = 0;
+  p.flops.clear();
+  return W2L_OK;
+}
+// call after a device synchronisation: launches, total ms, total algorithmic FLOPs
+W2L_API int w2l_profile_report(int* launches, double* totalMs, double* totalFlops) {
+  GemmProf& p = gemm_prof();
+  double ms = 0, fl = 0;
+  int n = 0;
+  for (size_t i = 0; i + 1 < p.used; i += 2) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, p.ev[i], p.ev[i + 1]) != hipSuccess) continue;
+    ms += t;
+    fl += p.flops[i / 2];
+    ++n;
+  }
+  if (launches) *launches = n;
+  if (totalMs) *totalMs = ms;
+  if (totalFlops) *totalFlops = fl;
+  return W2L_OK;
 }

@@ -1,5 +1,7 @@
 // gemm.hpp -- operand loaders and launch interface of the fp32 MFMA GEMM engine.
 #pragma once
+#include <vector>
+
 #include "common.hpp"
 
 namespace w2l {
@@ -142,6 +144,32 @@ struct PlainOp {
     }
   }
 };
+
+// ---------------------------------------------------------------- launch profiling
+// bench.py's roofline leg: when enabled, every MFMA GEMM launch is bracketed by a pair of
+// hipEvents on ITS stream; w2l_profile_report() sums durations and algorithmic FLOPs.
+struct GemmProf {
+  bool on = false;
+  std::vector<hipEvent_t> ev;      // pairs
+  std::vector<double> flops;
+  size_t used = 0;
+};
+GemmProf& gemm_prof();
+inline void prof_begin(hipStream_t s, double flops) {
+  GemmProf& p = gemm_prof();
+  if (!p.on) return;
+  if (p.used + 2 > p.ev.size()) {
+    for (int i = 0; i < 2; ++i) { hipEvent_t e; (void)hipEventCreate(&e); p.ev.push_back(e); }
+  }
+  p.flops.push_back(flops);
+  (void)hipEventRecord(p.ev[p.used], s);
+}
+inline void prof_end(hipStream_t s) {
+  GemmProf& p = gemm_prof();
+  if (!p.on) return;
+  (void)hipEventRecord(p.ev[p.used + 1], s);
+  p.used += 2;
+}
 
 // ---------------------------------------------------------------- kernels
 template <class AOp, class BOp>
@@ -356,7 +384,9 @@ inline int launch128(const AOp& a, const BOp& b, GemmOut o, int epi, int splitk,
   const int tilesM = (o.M + 127) / 128, tilesN = (o.N + 127) / 128;
   dim3 grid((unsigned)(tilesM * tilesN), 1, (unsigned)splitk), block(256);
   o.epi = epi;
+  prof_begin(s, 2.0 * o.M * (double)o.N * o.K);
   hipLaunchKernelGGL((gemm128_kernel<AOp, BOp>), grid, block, shmem, s, a, b, o);
+  prof_end(s);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }
@@ -367,7 +397,9 @@ inline int launch_skinny(const AOp& a, const BOp& b, GemmOut o, int epi, int spl
   const size_t shmem = 2 * (size_t)BK * ((256 + AOp::kPadSkinny) + (BN + 4)) * sizeof(float);
   dim3 grid((unsigned)((o.M + 255) / 256), (unsigned)((o.N + BN - 1) / BN), (unsigned)splitk), block(256);
   o.epi = epi;
+  prof_begin(s, 2.0 * o.M * (double)o.N * o.K);
   hipLaunchKernelGGL((gemm_skinny_kernel<AOp, BOp, BN>), grid, block, shmem, s, a, b, o);
+  prof_end(s);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }

@@ -1,0 +1,104 @@
+// criterion_host.cpp -- fl::pkg::speech::{CTCLoss, ASGLoss} over the kernel C ABI.
+// Construction and use in the reference: recipes/slimIPL/src/Train.cpp:406-410 (ctor),
+// :1675 (forward), :1720 (backward), :838 (viterbiPath).  ASGLoss = FullConnectionCriterion
+// - ForceAlignmentCriterion sharing one N x N transition parameter initialised to
+// transdiag * I (--transdiag, recipes/conv_glu/librispeech/train.cfg:25).
+#include <cstring>
+
+#include "w2l_host.hpp"
+
+namespace w2l {
+namespace {
+
+inline size_t up(size_t v) { return (v + 255) / 256 * 256; }
+
+class CTCLossImpl : public SequenceCriterion {
+ public:
+  explicit CTCLossImpl(int mode) : mode_(mode) {}
+  std::string prettyString() const override { return "ConnectionistTemporalClassificationCriterion"; }
+  size_t workspaceBytes(int B, int T, int N, int L) const override {
+    return up(sizeof(int) * B) + w2l_ctc_workspace_size(B, T, N, L);
+  }
+  void forward(Ctx& c, int B, int T, int N, int L, const float* em, const int* target, float* loss, void* ws,
+               float*) override {
+    int* ts = (int*)ws;
+    void* kws = (char*)ws + up(sizeof(int) * B);
+    w2lCheck(w2l_batch_ctc_target_size(B, L, T, target, ts, c.stream), "ctc target size");
+    w2lCheck(w2l_ctc_forward(B, T, N, L, mode_, em, target, ts, loss, kws, c.stream), "ctc forward");
+  }
+  void backward(Ctx& c, int B, int T, int N, int L, const float* em, const int* target, const float* gradLoss,
+                float* dEm, void* ws, float*, float*) override {
+    int* ts = (int*)ws;
+    void* kws = (char*)ws + up(sizeof(int) * B);
+    w2lCheck(w2l_ctc_backward(B, T, N, L, em, target, ts, gradLoss, dEm, kws, c.stream), "ctc backward");
+  }
+  void viterbiPath(Ctx& c, int B, int T, int N, const float* em, int* path, void*, float*) override {
+    w2lCheck(w2l_ctc_viterbi(B, T, N, em, path, c.stream), "ctc viterbi");
+  }
+
+ private:
+  int mode_;
+};
+
+class ASGLossImpl : public SequenceCriterion {
+ public:
+  ASGLossImpl(int N, int mode, double transdiag) : N_(N), mode_(mode), transdiag_(transdiag) {}
+  std::string prettyString() const override { return "AutoSegmentationCriterion"; }
+  size_t paramFloats() const override { return ((size_t)N_ * N_ + 3) / 4 * 4; }
+  void initParams(float* host) const override {
+    std::memset(host, 0, sizeof(float) * paramFloats());
+    for (int i = 0; i < N_; ++i) host[(size_t)i * N_ + i] = (float)transdiag_;
+  }
+  struct Ws { int* ts; void* fcc; void* fac; float* dx2; float* dt2; float* loss2; void* vit; };
+  Ws carve(void* ws, int B, int T, int N, int L) const {
+    char* p = (char*)ws;
+    Ws w;
+    w.ts = (int*)p; p += up(sizeof(int) * B);
+    w.fcc = p; p += up(w2l_fcc_workspace_size(B, T, N));
+    w.fac = p; p += up(w2l_fac_workspace_size(B, T, N, L));
+    w.dx2 = (float*)p; p += up(sizeof(float) * (size_t)B * T * N);
+    w.dt2 = (float*)p; p += up(sizeof(float) * (size_t)N * N);
+    w.loss2 = (float*)p; p += up(sizeof(float) * B);
+    w.vit = p;
+    return w;
+  }
+  size_t workspaceBytes(int B, int T, int N, int L) const override {
+    return up(sizeof(int) * B) + up(w2l_fcc_workspace_size(B, T, N)) + up(w2l_fac_workspace_size(B, T, N, L)) +
+           up(sizeof(float) * (size_t)B * T * N) + up(sizeof(float) * (size_t)N * N) + up(sizeof(float) * B) +
+           up(w2l_viterbi_workspace_size(B, T, N));
+  }
+  void forward(Ctx& c, int B, int T, int N, int L, const float* em, const int* target, float* loss, void* ws,
+               float* trans) override {
+    if (N != N_) throw std::invalid_argument("ASGLoss: N doesn't match with the letter size");
+    Ws w = carve(ws, B, T, N, L);
+    w2lCheck(w2l_batch_target_size(B, L, T, target, w.ts, c.stream), "asg target size");
+    w2lCheck(w2l_fcc_forward(B, T, N, mode_, em, w.ts, trans, loss, w.fcc, c.stream), "fcc forward");
+    w2lCheck(w2l_fac_forward(B, T, N, L, mode_, em, target, w.ts, trans, w.loss2, w.fac, c.stream), "fac forward");
+    w2lCheck(w2l_axpy(loss, w.loss2, (size_t)B, -1.f, c.stream), "asg loss");
+  }
+  void backward(Ctx& c, int B, int T, int N, int L, const float*, const int* target, const float* gradLoss,
+                float* dEm, void* ws, float* trans, float* dTrans) override {
+    Ws w = carve(ws, B, T, N, L);
+    w2lCheck(w2l_fcc_backward(B, T, N, trans, gradLoss, dEm, dTrans, w.fcc, c.stream), "fcc backward");
+    w2lCheck(w2l_fac_backward(B, T, N, L, target, w.ts, gradLoss, w.dx2, w.dt2, w.fac, c.stream), "fac backward");
+    w2lCheck(w2l_axpy(dEm, w.dx2, (size_t)B * T * N, -1.f, c.stream), "asg dx");
+    w2lCheck(w2l_axpy(dTrans, w.dt2, (size_t)N * N, -1.f, c.stream), "asg dtrans");
+  }
+  void viterbiPath(Ctx& c, int B, int T, int N, const float* em, int* path, void* ws, float* trans) override {
+    Ws w = carve(ws, B, T, N, 1);
+    w2lCheck(w2l_viterbi_compute(B, T, N, em, trans, path, w.fcc, c.stream), "viterbi");
+  }
+
+ private:
+  int N_, mode_;
+  double transdiag_;
+};
+
+}  // namespace
+
+std::shared_ptr<SequenceCriterion> makeCTCLoss(int scaleMode) { return std::make_shared<CTCLossImpl>(scaleMode); }
+std::shared_ptr<SequenceCriterion> makeASGLoss(int N, int scaleMode, double transdiag) {
+  return std::make_shared<ASGLossImpl>(N, scaleMode, transdiag);
+}
+
+}  // namespace w2l

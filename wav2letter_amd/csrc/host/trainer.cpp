@@ -1,0 +1,212 @@
+// trainer.cpp -- one optimisation step of the acoustic-model trainer and its C ABI.
+// Step order restated from the reference's hot loop (recipes/slimIPL/src/Train.cpp):
+//   forward network :1463-1470 -> criterion forward :1675 -> zeroGrad + loss.backward() :1718-1720
+//   -> all-reduce of all gradients :1721-1735 (here: ONE collective over the flat arena,
+//   issued by the caller between w2l_trainer_forward_backward and w2l_trainer_update)
+//   -> grads / totalBatchSize :1748-1784 -> clipGradNorm :1791-1798 -> critopt/netopt step :1801-1802.
+// The five af::sync() per step of the reference are gone: a step enqueues ~500 kernels
+// on one stream and never blocks the host.
+#include <cstring>
+#include <map>
+#include <mutex>
+
+#include "w2l_host.hpp"
+
+namespace w2l {
+
+struct Trainer {
+  std::shared_ptr<Sequential> net;
+  std::shared_ptr<SequenceCriterion> crit;
+  int nFeat = 0, nLabel = 0;
+  std::string critName;
+  // geometry
+  int B = 0, T = 0, L = 0, Tout = 0;
+  size_t netFloats = 0, critFloats = 0, arenaFloats = 0, critWsBytes = 0;
+  // bound device memory (owned by the caller)
+  float *params = nullptr, *grads = nullptr, *mom = nullptr, *arena = nullptr;
+  void* critWs = nullptr;
+  float *loss = nullptr, *gradLoss = nullptr, *dEm = nullptr;
+  double* sumsq = nullptr;
+  const float* emission = nullptr;
+  uint32_t step = 0;
+  std::string lastError;
+};
+
+}  // namespace w2l
+
+using namespace w2l;
+
+#define W2L_API extern "C" __attribute__((visibility("default")))
+#define TRY(h, body)                                   \
+  try { body; return W2L_OK; }                         \
+  catch (const std::invalid_argument& e) { if (h) ((Trainer*)h)->lastError = e.what(); g_err = e.what(); return W2L_EINVAL; } \
+  catch (const std::exception& e) { if (h) ((Trainer*)h)->lastError = e.what(); g_err = e.what(); return W2L_EHIP; }
+
+static thread_local std::string g_err;
+
+W2L_API const char* w2l_host_last_error(void) { return g_err.c_str(); }
+
+// criterion: "ctc" | "asg" ; archText: contents of an .arch file (NFEAT/NLABEL substituted here)
+W2L_API void* w2l_trainer_create(const char* archText, int nFeat, int nLabel, const char* criterion,
+                                 int scaleMode, double transdiag) {
+  try {
+    auto t = new Trainer();
+    t->nFeat = nFeat; t->nLabel = nLabel; t->critName = criterion ? criterion : "ctc";
+    t->net = buildSequentialFromText(archText, nFeat, nLabel);
+    if (t->critName == "ctc") t->crit = makeCTCLoss(scaleMode);
+    else if (t->critName == "asg") t->crit = makeASGLoss(nLabel, scaleMode, transdiag);
+    else { delete t; throw std::invalid_argument("unsupported criterion: " + std::string(criterion)); }
+    t->netFloats = t->net->paramFloats();
+    t->critFloats = t->crit->paramFloats();
+    return t;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+
+W2L_API void w2l_trainer_destroy(void* h) { delete (Trainer*)h; }
+
+W2L_API size_t w2l_trainer_param_floats(void* h) { Trainer* t = (Trainer*)h; return t->netFloats + t->critFloats; }
+W2L_API size_t w2l_trainer_net_param_floats(void* h) { return ((Trainer*)h)->netFloats; }
+W2L_API int w2l_trainer_num_params(void* h) { return (int)((Trainer*)h)->net->params().size(); }
+W2L_API const char* w2l_trainer_describe(void* h) {
+  Trainer* t = (Trainer*)h;
+  t->lastError = t->net->prettyString() + " | criterion: " + t->crit->prettyString();
+  return t->lastError.c_str();
+}
+// name / numel / offset of network parameter i (internal arena order = Flashlight params() order)
+W2L_API int w2l_trainer_param_info(void* h, int i, char* name, int nameCap, size_t* numel, size_t* offset) {
+  Trainer* t = (Trainer*)h;
+  if (i < 0 || i >= (int)t->net->params().size()) return W2L_EINVAL;
+  const ParamInfo& p = t->net->params()[i];
+  if (name && nameCap > 0) { std::strncpy(name, p.name.c_str(), nameCap - 1); name[nameCap - 1] = 0; }
+  if (numel) *numel = p.numel;
+  if (offset) *offset = p.offset;
+  return W2L_OK;
+}
+
+// host-side parameter helpers (h_* are HOST pointers)
+W2L_API int w2l_trainer_init_params(void* h, float* h_params, uint64_t seed) {
+  Trainer* t = (Trainer*)h;
+  TRY(h, { t->net->initParams(h_params, seed); t->crit->initParams(h_params + t->netFloats); });
+}
+W2L_API int w2l_trainer_import_param(void* h, int i, const float* h_ref, float* h_params) {
+  Trainer* t = (Trainer*)h;
+  TRY(h, { if (i < 0 || i >= (int)t->net->params().size()) throw std::invalid_argument("bad param index"); t->net->importParam(i, h_ref, h_params); });
+}
+W2L_API int w2l_trainer_export_param(void* h, int i, const float* h_arena, float* h_ref) {
+  Trainer* t = (Trainer*)h;
+  TRY(h, { if (i < 0 || i >= (int)t->net->params().size()) throw std::invalid_argument("bad param index"); t->net->exportParam(i, h_arena, h_ref); });
+}
+
+// plan for a batch geometry: B utterances of T frames, targets padded to L.
+W2L_API int w2l_trainer_plan(void* h, int B, int T, int L, size_t* arenaFloats, size_t* critWsBytes,
+                             int* Tout) {
+  Trainer* t = (Trainer*)h;
+  TRY(h, {
+    size_t used = t->net->plan(B, T, t->nFeat);
+    t->B = B; t->T = T; t->L = L;
+    t->Tout = t->net->outAct().T;
+    if (t->net->outAct().F != t->nLabel) throw std::invalid_argument("network output width != NLABEL");
+    size_t extra = ((size_t)B * t->Tout * t->nLabel + 63) / 64 * 64 + 3 * 64 + 64;  // dEmission, loss, gradLoss, sumsq
+    t->arenaFloats = used + extra;
+    t->critWsBytes = t->crit->workspaceBytes(B, t->Tout, t->nLabel, L);
+    if (arenaFloats) *arenaFloats = t->arenaFloats;
+    if (critWsBytes) *critWsBytes = t->critWsBytes;
+    if (Tout) *Tout = t->Tout;
+  });
+}
+
+// all device pointers; params/grads/momentum hold net params followed by criterion params
+W2L_API int w2l_trainer_bind(void* h, float* params, float* grads, float* momentum, float* arena,
+                             void* critWs) {
+  Trainer* t = (Trainer*)h;
+  if (!params || !grads || !arena || !critWs || !t->arenaFloats) return W2L_EINVAL;
+  t->params = params; t->grads = grads; t->mom = momentum; t->arena = arena; t->critWs = critWs;
+  size_t used = t->arenaFloats - (((size_t)t->B * t->Tout * t->nLabel + 63) / 64 * 64 + 3 * 64 + 64);
+  t->dEm = arena + used;
+  t->loss = t->dEm + ((size_t)t->B * t->Tout * t->nLabel + 63) / 64 * 64;
+  t->gradLoss = t->loss + ((size_t)t->B + 63) / 64 * 64;
+  t->sumsq = (double*)(t->gradLoss + ((size_t)t->B + 63) / 64 * 64 + 64);
+  if (t->B > 64) return W2L_EUNSUPPORTED;  // loss / gradLoss slots are 64 floats
+  return W2L_OK;
+}
+
+static Ctx makeCtx(Trainer* t, void* stream, bool train) {
+  Ctx c;
+  c.stream = (hipStream_t)stream;
+  c.train = train;
+  c.seed = 0x9E3779B9u * (t->step + 1);
+  c.params = t->params;
+  c.grads = t->grads;
+  return c;
+}
+
+// network forward only (eval mode when train == 0); returns the device pointer of emissions [B][T'][N]
+W2L_API int w2l_trainer_forward(void* h, const float* x, int train, const float** emission, void* stream) {
+  Trainer* t = (Trainer*)h;
+  TRY(h, {
+    Ctx c = makeCtx(t, stream, train != 0);
+    t->emission = t->net->forward(c, t->arena, x);
+    if (emission) *emission = t->emission;
+  });
+}
+
+// forward + criterion + backward: leaves every gradient (network ‖ criterion) in the grads
+// arena, UNSCALED (sum over the utterances of this rank).  loss_out (device, [B]) optional.
+W2L_API int w2l_trainer_forward_backward(void* h, const float* x, const int* target, float** lossDev,
+                                         void* stream) {
+  Trainer* t = (Trainer*)h;
+  TRY(h, {
+    Ctx c = makeCtx(t, stream, true);
+    t->emission = t->net->forward(c, t->arena, x);
+    float* cp = t->params + t->netFloats;
+    float* cg = t->grads + t->netFloats;
+    t->crit->forward(c, t->B, t->Tout, t->nLabel, t->L, t->emission, target, t->loss, t->critWs, cp);
+    // d(sum_b loss_b)/d loss_b = 1
+    hipCheck(hipMemsetAsync(t->gradLoss, 0, sizeof(float) * 64, c.stream), "memset");
+    w2lCheck(w2l_fill(t->gradLoss, (size_t)t->B, 1.f, c.stream), "fill");
+    t->crit->backward(c, t->B, t->Tout, t->nLabel, t->L, t->emission, target, t->gradLoss, t->dEm, t->critWs, cp, cg);
+    t->net->backward(c, t->arena, t->dEm);
+    if (lossDev) *lossDev = t->loss;
+  });
+}
+
+// optimizer: grads *= 1/totalBatch, global-norm clip (network, and criterion if clampCrit), SGD+momentum
+// on the network (lr, momentum), plain SGD on the criterion (lrcrit)  [Train.cpp:577-582, :1791-1802]
+W2L_API int w2l_trainer_update(void* h, float lr, float lrcrit, float momentum, float maxGradNorm,
+                               float totalBatch, int clampCrit, void* stream) {
+  Trainer* t = (Trainer*)h;
+  TRY(h, {
+    hipStream_t s = (hipStream_t)stream;
+    const float gs = 1.f / totalBatch;
+    if (maxGradNorm > 0.f) {
+      size_t n = t->netFloats + (clampCrit ? t->critFloats : 0);
+      w2lCheck(w2l_sumsq(t->grads, n, t->sumsq, 1, s), "sumsq");
+    }
+    if (t->critFloats)
+      w2lCheck(w2l_sgd_step(t->params + t->netFloats, t->grads + t->netFloats, nullptr, t->critFloats, lrcrit, 0.f, gs,
+                            clampCrit ? maxGradNorm : 0.f, t->sumsq, s), "crit sgd");
+    w2lCheck(w2l_sgd_step(t->params, t->grads, t->mom, t->netFloats, lr, momentum, gs, maxGradNorm, t->sumsq, s), "net sgd");
+    t->step++;
+  });
+}
+
+W2L_API int w2l_trainer_viterbi(void* h, const float* emission, int* path, void* stream) {
+  Trainer* t = (Trainer*)h;
+  TRY(h, {
+    Ctx c = makeCtx(t, stream, false);
+    t->crit->viterbiPath(c, t->B, t->Tout, t->nLabel, emission, path, t->critWs, t->params + t->netFloats);
+  });
+}
+
+W2L_API int w2l_trainer_set_step(void* h, uint32_t step) { ((Trainer*)h)->step = step; return W2L_OK; }
+
+// arch / flags parsing without building kernels (recipes must load unchanged)
+W2L_API int w2l_arch_check(const char* archText, int nFeat, int nLabel, int* numLayers) {
+  TRY(nullptr, { auto v = parseArch(archText, nFeat, nLabel); if (numLayers) *numLayers = (int)v.size(); });
+}
+W2L_API int w2l_flags_check(const char* flagsText, int* numFlags) {
+  TRY(nullptr, { auto f = parseFlagsText(flagsText); if (numFlags) *numFlags = (int)f.kv.size(); });
+}

@@ -1,0 +1,128 @@
+// weightnorm.hip -- fl::WeightNorm reparameterisation w = v * g / ||v|| and its backward,
+// plus SpecAugment masking.  Reference: WN token (recipes/joint_training_vox_populi/cpc/
+// SequentialBuilder.cpp:379-386), parameter order v, g, bias (recipes/utilities/
+// convlm_serializer/Utils.cpp:112-143); SAUG token (SequentialBuilder.cpp:602-613).
+// Both internal weight layouts ([kw*Cin][Cout] for "WN 3 C", [in][out] for "WN 0 L") are
+// [K][Nout] matrices normalised per column, so one kernel pair serves both.
+#include "common.hpp"
+
+namespace w2l {
+
+// one block per 64 columns, 4 waves split the rows; sums of squares / dot products per column
+__global__ __launch_bounds__(256) void wn_colreduce_k(const float* __restrict__ a, const float* __restrict__ b,
+                                                      float* __restrict__ out, int K, int N, int sqrtOut) {
+  __shared__ float sm[4][64];
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6;
+  float s = 0.f;
+  if (n < N)
+    for (int k = part; k < K; k += 4) s += a[(size_t)k * N + n] * b[(size_t)k * N + n];
+  sm[part][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (part == 0 && n < N) {
+    float t = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+    out[n] = sqrtOut ? sqrtf(t) : t;
+  }
+}
+
+__global__ __launch_bounds__(256) void wn_apply_k(const float* __restrict__ v, const float* __restrict__ g,
+                                                  const float* __restrict__ norm, float* __restrict__ w,
+                                                  size_t total, int N) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    int n = (int)(e % N);
+    w[e] = v[e] * (g[n] / norm[n]);
+  }
+}
+
+// dv = g/norm * (dw - v * dot/norm^2), dg = dot/norm   (dot = sum_k v*dw per column)
+__global__ __launch_bounds__(256) void wn_bwd_k(const float* __restrict__ v, const float* __restrict__ g,
+                                                const float* __restrict__ norm, const float* __restrict__ dot,
+                                                const float* __restrict__ dw, float* __restrict__ dv,
+                                                float* __restrict__ dg, size_t total, int N) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    int n = (int)(e % N);
+    float nn = norm[n];
+    dv[e] = g[n] / nn * (dw[e] - v[e] * dot[n] / (nn * nn));
+    if (e < (size_t)N) dg[e] = dot[e] / norm[e];
+  }
+}
+
+// SpecAugment (frequency + time masking, fill 0) on frame-major features x[B][T][F].
+// Mask positions come from the stateless hash so a step is reproducible from (seed).
+__global__ __launch_bounds__(256) void specaug_k(float* __restrict__ x, int T, int F, int fMaskF, int nFMask,
+                                                 int tMaskT, float tMaskP, int nTMask, uint32_t seed) {
+  const int b = blockIdx.y;
+  __shared__ int f0s[8], f1s[8], t0s[8], t1s[8];
+  if (threadIdx.x < 8) {
+    int k = threadIdx.x;
+    f0s[k] = f1s[k] = t0s[k] = t1s[k] = 0;
+    if (k < nFMask) {
+      uint32_t h1 = hash32(4 * k, seed, 1000 + b), h2 = hash32(4 * k + 1, seed, 1000 + b);
+      int fw = (int)(h1 % (uint32_t)(fMaskF + 1));
+      if (fw > F) fw = F;
+      int f0 = (int)(h2 % (uint32_t)(F - fw + 1));
+      f0s[k] = f0; f1s[k] = f0 + fw;
+    }
+    if (k < nTMask) {
+      uint32_t h1 = hash32(4 * k + 2, seed, 1000 + b), h2 = hash32(4 * k + 3, seed, 1000 + b);
+      int tmax = (int)(tMaskP * T);
+      if (tmax > tMaskT) tmax = tMaskT;
+      int tw = (int)(h1 % (uint32_t)(tmax + 1));
+      int t0 = (int)(h2 % (uint32_t)(T - tw + 1));
+      t0s[k] = t0; t1s[k] = t0 + tw;
+    }
+  }
+  __syncthreads();
+  float* xb = x + (size_t)b * T * F;
+  const size_t n = (size_t)T * F;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    int t = (int)(e / F), f = (int)(e - (size_t)t * F);
+    bool m = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m = m || (f >= f0s[k] && f < f1s[k]) || (t >= t0s[k] && t < t1s[k]);
+    if (m) xb[e] = 0.f;
+  }
+}
+
+}  // namespace w2l
+
+using namespace w2l;
+
+// w[K][N] = v * g / ||v||_col ; norm[N] kept for backward
+W2L_API int w2l_weightnorm_forward(const float* v, const float* g, float* w, float* norm, int K, int N,
+                                   w2l_stream_t stream) {
+  if (!v || !g || !w || !norm || K <= 0 || N <= 0) return W2L_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(wn_colreduce_k, dim3((N + 63) / 64), dim3(256), 0, s, v, v, norm, K, N, 1);
+  W2L_LAUNCH_CHECK();
+  size_t total = (size_t)K * N;
+  unsigned grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(wn_apply_k, dim3(grid), dim3(256), 0, s, v, g, norm, w, total, N);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+// dot[N] is scratch
+W2L_API int w2l_weightnorm_backward(const float* v, const float* g, const float* norm, const float* dw,
+                                    float* dv, float* dg, float* dot, int K, int N, w2l_stream_t stream) {
+  if (!v || !g || !norm || !dw || !dv || !dg || !dot || K <= 0 || N <= 0) return W2L_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(wn_colreduce_k, dim3((N + 63) / 64), dim3(256), 0, s, v, dw, dot, K, N, 0);
+  W2L_LAUNCH_CHECK();
+  size_t total = (size_t)K * N;
+  unsigned grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(wn_bwd_k, dim3(grid), dim3(256), 0, s, v, g, norm, dot, dw, dv, dg, total, N);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+W2L_API int w2l_specaugment_inplace(float* x, int B, int T, int F, int fMaskF, int nFMask, int tMaskT,
+                                    float tMaskP, int nTMask, uint32_t seed, w2l_stream_t stream) {
+  if (!x || B <= 0 || T <= 0 || F <= 0 || nFMask > 8 || nTMask > 8 || nFMask < 0 || nTMask < 0) return W2L_EINVAL;
+  size_t n = (size_t)T * F;
+  unsigned gx = (unsigned)((n + 255) / 256 > 256 ? 256 : (n + 255) / 256);
+  hipLaunchKernelGGL(specaug_k, dim3(gx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, T, F, fMaskF, nFMask,
+                     tMaskT, tMaskP, nTMask, seed);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}

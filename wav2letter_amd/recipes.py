@@ -1,0 +1,69 @@
+"""The reference's recipe inputs this build targets, regenerated programmatically.
+
+The GPU box has no /root/reference, so the arch texts bench.py / smoke() need are
+produced here from compact specs; tests/test_recipes.py checks (when /root/reference is
+present) that each generator reproduces the reference file line for line, i.e. the
+recipes load unchanged:
+  recipes/sota/2019/am_arch/am_tds_ctc.arch                        (BASELINE config 2)
+  recipes/conv_glu/librispeech/network.arch, conv_glu/wsj/network.arch   (configs 4, 1)
+  recipes/streaming_convnets/librispeech/am_500ms_future_context.arch    (config 3)
+"""
+
+
+def tds_ctc_arch():
+    """sota/2019 TDS-CTC: 3 x (strided C2 + R + DO + LN + k TDS) + Linear, 203.4 M params"""
+    lines = ["SAUG 80 27 2 100 1.0 2", "V -1 NFEAT 1 0"]
+    stages = [(1, 10, 2400, [0.05, 0.05, 0.05, 0.1, 0.1]),
+              (10, 14, 3360, [0.15] * 6),
+              (14, 18, 4320, [0.15, 0.15, 0.15, 0.15, 0.2, 0.2, 0.25, 0.25, 0.25, 0.25])]
+    for cin, c, l2, drops in stages:
+        lines += [f"C2 {cin} {c} 21 1 2 1 -1 -1", "R", "DO 0.0", "LN 0 1 2"]
+        lines += [f"TDS {c} 21 80 {p} {l2}" for p in drops]
+    lines += ["V 0 1440 1 0", "RO 1 0 3 2", "L 1440 NLABEL"]
+    return "\n".join(lines) + "\n"
+
+
+def conv_glu_librispeech_arch():
+    """conv_glu LibriSpeech: 17 WN-Conv+GLU layers, widths x1.1, kernel 13..29, 208.9 M params"""
+    lines = ["V -1 1 NFEAT 0"]
+    outs = [400, 440, 484, 532, 584, 642, 706, 776, 852, 936, 1028, 1130, 1242, 1366, 1502, 1652, 1816]
+    drops = ["0.2", "0.214", "0.22898", "0.2450086", "0.262159202", "0.28051034614", "0.30014607037",
+             "0.321156295296", "0.343637235966", "0.367691842484", "0.393430271458", "0.42097039046",
+             "0.450438317792", "0.481969000038", "0.51570683004", "0.551806308143", "0.590432749713"]
+    cin = "NFEAT"
+    for i, (co, p) in enumerate(zip(outs, drops)):
+        pad = 170 if i == 0 else 0
+        lines += [f"WN 3 C {cin} {co} {13 + i} 1 {pad}", "GLU 2", f"DO {p}"]
+        cin = co // 2
+    lines += ["RO 2 0 3 1", "WN 0 L 908 1816", "GLU 0", "DO 0.590432749713", "WN 0 L 908 NLABEL"]
+    return "\n".join(lines) + "\n"
+
+
+def tds_ctc_small_arch(c=(4, 6), h=8, kw=5, l2mult=2, drop=0.0):
+    """a reduced TDS-CTC of the same topology (tests)"""
+    lines = [f"V -1 NFEAT 1 0"]
+    cin = 1
+    for ci in c:
+        lines += [f"C2 {cin} {ci} {kw} 1 2 1 -1 -1", "R", f"DO {drop}", "LN 0 1 2",
+                  f"TDS {ci} {kw} {h} {drop} {ci * h * l2mult}", f"TDS {ci} {kw} {h} {drop} 0"]
+        cin = ci
+    lines += [f"V 0 {c[-1] * h} 1 0", "RO 1 0 3 2", f"L {c[-1] * h} NLABEL"]
+    return "\n".join(lines) + "\n"
+
+
+def conv_glu_small_arch(widths=(16, 24), kws=(5, 4), pad0=4, drop=0.0):
+    lines = ["V -1 1 NFEAT 0"]
+    cin = "NFEAT"
+    for i, (co, kw) in enumerate(zip(widths, kws)):
+        lines += [f"WN 3 C {cin} {co} {kw} 1 {pad0 if i == 0 else -1}", "GLU 2", f"DO {drop}"]
+        cin = co // 2
+    lines += ["RO 2 0 3 1", f"WN 0 L {cin} {2 * cin}", "GLU 0", f"DO {drop}", f"WN 0 L {cin} NLABEL"]
+    return "\n".join(lines) + "\n"
+
+
+# train.cfg essentials of the two headline recipes (flags the hot path consumes)
+TDS_CTC_FLAGS = dict(criterion="ctc", lr=0.3, momentum=0.5, maxgradnorm=1.0, onorm="target", sqnorm=True,
+                     filterbanks=80, batchsize=4)       # recipes/sota/2019/librispeech/train_am_tds_ctc.cfg:11-30
+CONV_GLU_FLAGS = dict(criterion="asg", lr=0.6, lrcrit=0.006, momentum=0.8, maxgradnorm=0.2, onorm="target",
+                      sqnorm=True, filterbanks=40, batchsize=4, transdiag=4, replabel=2, linseg=1)
+#                                                        recipes/conv_glu/librispeech/train.cfg:12-26

@@ -1,0 +1,173 @@
+"""Python front-end of the C++ trainer (wav2letter_amd/csrc/host/trainer.cpp).
+
+Mirrors the reference's Trainer step (recipes/slimIPL/src/Train.cpp:1454-1804): torch is
+used to own the device arenas and to run the ONE gradient all-reduce per step over RCCL
+(torch.distributed backend "nccl"); every kernel launch happens inside libw2l_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .criterion import CriterionScaleMode
+
+_sigs_done = False
+
+
+def _lib_tr():
+    global _sigs_done
+    L = _lib.lib()
+    if not _sigs_done:
+        vp, i, sz, f, d, u32, u64 = C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_double, C.c_uint32, C.c_uint64
+        L.w2l_host_last_error.restype = C.c_char_p
+        L.w2l_trainer_create.restype = vp
+        L.w2l_trainer_create.argtypes = [C.c_char_p, i, i, C.c_char_p, i, d]
+        L.w2l_trainer_destroy.argtypes = [vp]
+        L.w2l_trainer_describe.restype = C.c_char_p
+        L.w2l_trainer_describe.argtypes = [vp]
+        for n in ("w2l_trainer_param_floats", "w2l_trainer_net_param_floats"):
+            getattr(L, n).restype = sz
+            getattr(L, n).argtypes = [vp]
+        L.w2l_trainer_num_params.argtypes = [vp]
+        L.w2l_trainer_param_info.argtypes = [vp, i, C.c_char_p, i, C.POINTER(sz), C.POINTER(sz)]
+        L.w2l_trainer_init_params.argtypes = [vp, vp, u64]
+        L.w2l_trainer_import_param.argtypes = [vp, i, vp, vp]
+        L.w2l_trainer_export_param.argtypes = [vp, i, vp, vp]
+        L.w2l_trainer_plan.argtypes = [vp, i, i, i, C.POINTER(sz), C.POINTER(sz), C.POINTER(i)]
+        L.w2l_trainer_bind.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.w2l_trainer_forward.argtypes = [vp, vp, i, C.POINTER(vp), vp]
+        L.w2l_trainer_forward_backward.argtypes = [vp, vp, vp, C.POINTER(vp), vp]
+        L.w2l_trainer_update.argtypes = [vp, f, f, f, f, f, i, vp]
+        L.w2l_trainer_viterbi.argtypes = [vp, vp, vp, vp]
+        L.w2l_trainer_set_step.argtypes = [vp, u32]
+        L.w2l_arch_check.argtypes = [C.c_char_p, i, i, C.POINTER(i)]
+        L.w2l_flags_check.argtypes = [C.c_char_p, C.POINTER(i)]
+        _sigs_done = True
+    return L
+
+
+def _check(st, what):
+    if st != 0:
+        msg = _lib_tr().w2l_host_last_error().decode()
+        if st == _lib.W2L_EINVAL:
+            raise _lib.W2LInvalidArgument(f"{what}: {msg}")
+        raise _lib.W2LError(f"{what}: {msg}")
+
+
+def arch_check(arch_text, nfeat, nlabel):
+    """parse an arch file (all tokens of the reference grammar); returns the number of layer lines"""
+    n = C.c_int(0)
+    _check(_lib_tr().w2l_arch_check(arch_text.encode(), nfeat, nlabel, C.byref(n)), "arch")
+    return n.value
+
+
+def flags_check(flags_text):
+    n = C.c_int(0)
+    _check(_lib_tr().w2l_flags_check(flags_text.encode(), C.byref(n)), "flags")
+    return n.value
+
+
+class Trainer:
+    def __init__(self, arch_text, nfeat, nlabel, criterion="ctc", scalemode=CriterionScaleMode.NONE,
+                 transdiag=0.0, device="cuda"):
+        L = _lib_tr()
+        self.L = L
+        self.h = L.w2l_trainer_create(arch_text.encode(), nfeat, nlabel, criterion.encode(), int(scalemode),
+                                      float(transdiag))
+        if not self.h:
+            raise _lib.W2LInvalidArgument(L.w2l_host_last_error().decode())
+        self.nfeat, self.nlabel = nfeat, nlabel
+        self.device = device
+        self.n_floats = L.w2l_trainer_param_floats(self.h)
+        self.n_net = L.w2l_trainer_net_param_floats(self.h)
+        self.host_params = np.zeros(self.n_floats, np.float32)
+        self.params = self.grads = self.mom = None
+        self.B = self.T = self.Lt = self.Tout = 0
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.w2l_trainer_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def describe(self):
+        return self.L.w2l_trainer_describe(self.h).decode()
+
+    def param_table(self):
+        out = []
+        for i in range(self.L.w2l_trainer_num_params(self.h)):
+            name = C.create_string_buffer(64)
+            n, off = C.c_size_t(0), C.c_size_t(0)
+            self.L.w2l_trainer_param_info(self.h, i, name, 64, C.byref(n), C.byref(off))
+            out.append((name.value.decode(), n.value, off.value))
+        return out
+
+    def init_params(self, seed=0):
+        _check(self.L.w2l_trainer_init_params(self.h, self.host_params.ctypes.data, seed), "init_params")
+
+    def import_param(self, i, ref):
+        ref = np.ascontiguousarray(ref, np.float32)
+        _check(self.L.w2l_trainer_import_param(self.h, i, ref.ctypes.data, self.host_params.ctypes.data), "import")
+
+    def export_from(self, i, host_arena):
+        name, n, off = self.param_table()[i]
+        out = np.zeros(n, np.float32)
+        host_arena = np.ascontiguousarray(host_arena, np.float32)
+        _check(self.L.w2l_trainer_export_param(self.h, i, host_arena.ctypes.data, out.ctypes.data), "export")
+        return out
+
+    def to_device(self):
+        """upload host_params, allocate grads / momentum"""
+        self.params = torch.from_numpy(self.host_params).to(self.device)
+        self.grads = torch.zeros_like(self.params)
+        self.mom = torch.zeros_like(self.params)
+        if self.B:
+            self._bind()
+
+    def plan(self, B, T, L):
+        af, cw, to = C.c_size_t(0), C.c_size_t(0), C.c_int(0)
+        _check(self.L.w2l_trainer_plan(self.h, B, T, L, C.byref(af), C.byref(cw), C.byref(to)), "plan")
+        self.B, self.T, self.Lt, self.Tout = B, T, L, to.value
+        self.arena = torch.empty(af.value, dtype=torch.float32, device=self.device)
+        self.crit_ws = torch.empty(max(cw.value, 256), dtype=torch.uint8, device=self.device)
+        if self.params is not None:
+            self._bind()
+        return to.value
+
+    def _bind(self):
+        _check(self.L.w2l_trainer_bind(self.h, self.params.data_ptr(), self.grads.data_ptr(), self.mom.data_ptr(),
+                                       self.arena.data_ptr(), self.crit_ws.data_ptr()), "bind")
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def forward(self, x, train=False):
+        """x: [B][NFEAT][T] float32 -> emissions view [B][T'][N] (aliases the arena)"""
+        ptr = C.c_void_p(0)
+        _check(self.L.w2l_trainer_forward(self.h, x.data_ptr(), int(train), C.byref(ptr), self._stream()), "forward")
+        off = (ptr.value - self.arena.data_ptr()) // 4
+        return self.arena[off:off + self.B * self.Tout * self.nlabel].view(self.B, self.Tout, self.nlabel)
+
+    def forward_backward(self, x, target):
+        ptr = C.c_void_p(0)
+        _check(self.L.w2l_trainer_forward_backward(self.h, x.data_ptr(), target.data_ptr(), C.byref(ptr),
+                                                   self._stream()), "forward_backward")
+        off = (ptr.value - self.arena.data_ptr()) // 4
+        return self.arena[off:off + self.B]
+
+    def update(self, lr, lrcrit=0.0, momentum=0.0, max_grad_norm=0.0, total_batch=None, clamp_crit=True):
+        tb = float(total_batch if total_batch is not None else self.B)
+        _check(self.L.w2l_trainer_update(self.h, lr, lrcrit, momentum, max_grad_norm, tb, int(clamp_crit),
+                                         self._stream()), "update")
+
+    def viterbi(self, emission):
+        path = torch.empty(self.B, self.Tout, dtype=torch.int32, device=self.device)
+        _check(self.L.w2l_trainer_viterbi(self.h, emission.data_ptr(), path.data_ptr(), self._stream()), "viterbi")
+        return path
+
+    def set_step(self, step):
+        self.L.w2l_trainer_set_step(self.h, step)
