@@ -1,0 +1,81 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel plumbing: sharding without overlap, one
+all-reduce over the flat arena carrying the batch-size scalar, replicas staying identical."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from wav2letter_amd import parallel
+    r, w = parallel.init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    n = 1003
+    # replicas start different, sync_parameters makes them identical (mean)
+    params = torch.full((n,), float(rank + 1))
+    parallel.sync_parameters(params)
+    assert torch.allclose(params, torch.full((n,), (1 + world) / 2.0))
+    # sharded minibatch: each rank computes "gradients" on its shard of 7 utterances
+    lo, hi = parallel.shard_range(7, rank, world)
+    rng = np.random.default_rng(0)
+    per_utt = torch.tensor(rng.normal(size=(7, n)).astype(np.float32))
+    arena = parallel.GradientArena(n, "cpu")
+    arena.grads.copy_(per_utt[lo:hi].sum(0))
+    arena.set_local_batch(hi - lo)
+    total = arena.all_reduce()
+    assert total.item() == 7.0
+    assert torch.allclose(arena.grads, per_utt.sum(0), atol=1e-5)
+    # SGD step on every replica with the reduced gradient: replicas stay bit-identical
+    params -= 0.1 * arena.grads / total
+    gathered = [torch.zeros_like(params) for _ in range(world)]
+    dist.all_gather(gathered, params)
+    assert all(torch.equal(gathered[0], g) for g in gathered)
+    ret[rank] = (lo, hi)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_gloo_step():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    shards = [ret[r] for r in range(world)]
+    assert shards[0][0] == 0 and shards[-1][1] == 7
+    assert all(shards[i][1] == shards[i + 1][0] for i in range(world - 1))
+
+
+def test_shard_range_partitions():
+    from wav2letter_amd.parallel import shard_range
+    for n in (0, 1, 7, 64, 65):
+        for w in (1, 2, 3, 8):
+            r = [shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+            assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+def test_single_process_is_a_no_op():
+    from wav2letter_amd import parallel
+    os.environ.pop("WORLD_SIZE", None)
+    os.environ.pop("RANK", None)
+    assert parallel.init_distributed() == (0, 1)
+    a = parallel.GradientArena(5, "cpu")
+    a.set_local_batch(3)
+    assert a.all_reduce().item() == 3.0
