@@ -149,8 +149,10 @@ int w2l_conv_backward_filter(const w2l_conv_desc* d, const float* x, const float
 /* r = dropout(a) + x ; y = LayerNorm(r) over `groups` contiguous chunks of `inner`
  * elements with scalar affine gammaBeta[2] (fl::LayerNorm axes {0,1,2}: groups = B).
  * a is updated in place to its dropped value; r, meanRstd[2*groups] are kept for
- * backward; stats is double[2*groups] scratch.  Dropout mask = stateless hash of
+ * backward; stats / sums are double[w2l_layernorm_scratch_doubles(groups, inner)] scratch
+ * (per-block partial sums, added in a fixed order: no atomics, run-to-run deterministic).  Dropout mask = stateless hash of
  * (flat index, seed, rngStream), reproduced bit-exactly by the oracle. */
+size_t w2l_layernorm_scratch_doubles(int groups, size_t inner);
 int w2l_residual_layernorm_forward(int groups, size_t inner, float* a, const float* x, float* r,
                                    float* y, const float* gammaBeta, float eps, double p,
                                    uint32_t seed, uint32_t rngStream, double* stats,

@@ -281,3 +281,80 @@ def test_criterion_timings_report():
     gb = 12 * B * T * N / 1e9
     print(f"[timing] CTC B={B} T={T} N={N}: fwd {f_ms:.3f} ms, fwd+bwd {fb_ms:.3f} ms "
           f"({gb / (fb_ms * 1e-3):.0f} GB/s algorithmic incl. host overhead)")
+
+
+# ----------------------------------------------------------------------------------------------
+# large label sets (N > 64): criterion_fcc_big.hip -- packed-transition streaming MFMA recursion
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,T,N", [(3, 1, 70), (2, 7, 100), (5, 12, 257), (33, 5, 130), (70, 4, 96), (2, 30, 1000)])
+@pytest.mark.parametrize("mode", [0, 4])
+def test_fcc_large_n_matches_oracle(oracle, B, T, N, mode):
+    from wav2letter_amd import FullConnectionCriterion
+    rng = np.random.default_rng(B * 1000 + T * 10 + N)
+    x = (rng.normal(size=(B, T, N)) * 1.5).astype(np.float32)
+    A = (rng.normal(size=(N, N)) + 4 * np.eye(N)).astype(np.float32)
+    tgt = make_targets(rng, B, 7, N, T)
+    w = rng.normal(size=B).astype(np.float32)
+    crit = FullConnectionCriterion(N, mode).cuda()
+    crit.transitions.data = dev(A)
+    xt = dev(x).requires_grad_(True)
+    loss = crit(xt, dev(tgt))
+    (loss * dev(w)).sum().backward()
+    ts = oracle.batch_target_size(tgt, T)
+    o = oracle.FCC(x, A, ts, mode)
+    ol = o.forward()
+    odx, odA = o.backward(w.astype(np.float64))
+    assert relerr(loss.detach().cpu().numpy(), ol) < TOL
+    assert gradrel(xt.grad.cpu().numpy(), odx) < TOL
+    assert gradrel(crit.transitions.grad.cpu().numpy(), odA) < TOL
+
+
+def test_fcc_north_star_size_identities():
+    """N = 9998 word pieces (the BASELINE stress width; T reduced so the test runs in seconds).
+    Size-independent known answers (SURVEY App. B.6): (i) A = 0  =>  FCC = sum_t LSE_n x[t][n];
+    (iv) sum_n dFCC/dx[t][n] = 1 for every t; (v) sum_ij dFCC/dA[i][j] = T - 1."""
+    from wav2letter_amd import FullConnectionCriterion
+    B, T, N = 4, 6, 9998
+    g = torch.Generator(device="cpu").manual_seed(9)
+    x = torch.randn(B, T, N, generator=g) * 2
+    tgt = torch.zeros(B, 3, dtype=torch.int32)
+    crit = FullConnectionCriterion(N, 0).cuda()
+    crit.transitions.data = torch.zeros(N, N, device="cuda")
+    xt = x.cuda().requires_grad_(True)
+    loss = crit(xt, tgt.cuda())
+    loss.sum().backward()
+    want = torch.logsumexp(x.double(), dim=2).sum(dim=1).numpy()
+    assert relerr(loss.detach().cpu().numpy(), want) < 1e-5
+    colsum = xt.grad.double().sum(dim=2).cpu().numpy()
+    assert np.abs(colsum - 1.0).max() < 1e-4
+    # with A = 0 the posterior factorises: dx[t] = softmax(x[t])
+    assert gradrel(xt.grad.cpu().numpy(), torch.softmax(x.double(), dim=2).numpy()) < TOL
+    assert abs(crit.transitions.grad.double().sum().item() - B * (T - 1)) < 1e-3 * B * (T - 1)
+    # non-trivial transitions at full width: still a probability distribution per frame
+    crit.transitions.data = (torch.randn(N, N, generator=g) * 0.1 + 4 * torch.eye(N)).cuda()
+    crit.transitions.grad = None
+    xt.grad = None
+    loss = crit(xt, tgt.cuda())
+    loss.sum().backward()
+    assert np.isfinite(loss.detach().cpu().numpy()).all()
+    assert np.abs(xt.grad.double().sum(dim=2).cpu().numpy() - 1.0).max() < 1e-4
+    assert abs(crit.transitions.grad.double().sum().item() - B * (T - 1)) < 1e-3 * B * (T - 1)
+    assert (xt.grad >= 0).all()
+
+
+@pytest.mark.parametrize("B,T,N", [(1, 9, 100), (3, 40, 300), (9, 11, 129), (33, 6, 200), (2, 8, 3000)])
+def test_viterbi_large_n_bit_exact(oracle, B, T, N):
+    from wav2letter_amd import ASGLoss
+    rng = np.random.default_rng(B + T + N)
+    x = rng.normal(size=(B, T, N)).astype(np.float32)
+    A = rng.normal(size=(N, N)).astype(np.float32)
+    crit = ASGLoss(N, 0, 0.0).cuda()
+    crit.transitions.data = dev(A)
+    got = crit.viterbiPath(dev(x)).cpu().numpy()
+    assert (got == oracle.viterbi(x, A)).all()
+    # heavy ties: small-integer scores -> the first-max rule decides everywhere
+    xq = rng.integers(-2, 3, size=(B, T, N)).astype(np.float32)
+    Aq = rng.integers(-1, 2, size=(N, N)).astype(np.float32)
+    crit.transitions.data = dev(Aq)
+    got = crit.viterbiPath(dev(xq)).cpu().numpy()
+    assert (got == oracle.viterbi(xq, Aq)).all()

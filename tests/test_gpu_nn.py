@@ -57,6 +57,30 @@ def test_gemm_all_layouts(oracle, M, N, K, akc, bkc):
         assert rel(got, want - bias) < TOL
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 384, 2000),      # 6 tiles < 512 slots: pure stream-K, ranges span two tiles
+                                    (6016, 1440, 416),    # 564 tiles: one data-parallel round + stream-K tail
+                                    (1500, 700, 4096),    # 72 tiles, long K: many partial slabs per tile
+                                    (129, 129, 8192)])    # ragged edge tiles through the slab fix-up
+@pytest.mark.parametrize("akc,bkc", [(True, False), (False, False), (True, True)])
+def test_gemm_stream_k_schedule(M, N, K, akc, bkc):
+    """the hybrid data-parallel + stream-K schedule (partial slabs + ordered fix-up) against a
+    float64 product, bias + ReLU through the fix-up epilogue, and run-to-run determinism"""
+    from wav2letter_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(K, N, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    want = (A.double() @ Bm.double() + bias.double()).numpy()
+    Ad = (A if akc else A.T.contiguous()).cuda()
+    Bd = (Bm.T.contiguous() if bkc else Bm).cuda()
+    got = ops.gemm(Ad, Bd, akc, bkc, bias.cuda())
+    assert rel(got, want) < TOL
+    got2 = ops.gemm(Ad, Bd, akc, bkc, bias.cuda())
+    assert torch.equal(got, got2)
+    got = ops.gemm(Ad, Bd, akc, bkc, bias.cuda(), relu=True)
+    assert rel(got, np.maximum(want, 0)) < TOL
+
+
 def test_gemm_asymmetric_identity():
     """A = I with an asymmetric B catches row/col swaps in the C write (guide G9)"""
     from wav2letter_amd import ops
@@ -132,11 +156,12 @@ def test_golden_conv1d_on_device():
     assert np.abs(y.cpu().numpy().reshape(-1) - np.array(g["target"])).max() < 2e-3
 
 
+@pytest.mark.parametrize("B,inner", [(3, 4 * 1237), (37, 1440), (5, 8192), (2, 4 * 40001)])
 @pytest.mark.parametrize("p", [0.0, 0.25])
-def test_residual_dropout_layernorm(oracle, p):
+def test_residual_dropout_layernorm(oracle, p, B, inner):
+    """utterance-sized groups (two-level deterministic reduction) and frame-sized groups (one-pass kernel)"""
     from wav2letter_amd import ops
     rng = np.random.default_rng(5)
-    B, inner = 3, 4 * 1237
     a = np.maximum(rng.normal(size=(B, inner)), 0).astype(np.float32)
     x = rng.normal(size=(B, inner)).astype(np.float32)
     gb = np.array([1.3, -0.2], np.float32)

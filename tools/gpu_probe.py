@@ -1,0 +1,163 @@
+#!/usr/bin/env python
+"""GPU micro-benchmarks of the individual hot-path kernels (run on the MI355X box via gpurun).
+Prints one line per measurement; used to fill DESIGN.md's per-kernel roofline table.
+
+  python tools/gpu_probe.py gemm ln conv asg fccbig vitbig
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from wav2letter_amd import _lib, ops
+from wav2letter_amd.criterion import (ASGLoss, CriterionScaleMode, ForceAlignmentCriterion, FullConnectionCriterion)
+
+
+def timeit(fn, n=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def probe_gemm():
+    shapes = [("fc1 s1", 24000, 800, 2400), ("fc2 s1", 24000, 2400, 800), ("fc1 s2", 12000, 1120, 3360),
+              ("fc2 s2", 12000, 3360, 1120), ("fc1 s3", 6016, 1440, 4320), ("fc2 s3", 6016, 4320, 1440),
+              ("final", 6016, 1440, 9998), ("4096^3", 4096, 4096, 4096)]
+    for name, M, K, N in shapes:
+        x = torch.randn(M, K, device="cuda")
+        w = torch.randn(K, N, device="cuda") / K ** 0.5
+        b = torch.randn(N, device="cuda")
+        dy = torch.randn(M, N, device="cuda")
+        y = torch.empty(M, N, device="cuda")
+        dx = torch.empty(M, K, device="cuda")
+        dw = torch.empty(K, N, device="cuda")
+        L = _lib.lib()
+        s = torch.cuda.current_stream().cuda_stream
+        fl = 2.0 * M * N * K
+        for sk in ("1", "0"):
+            os.environ["W2L_GEMM_SK"] = sk
+            tf = timeit(lambda: L.w2l_linear_forward(M, K, N, x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), 1, s))
+            td = timeit(lambda: L.w2l_linear_backward_data(M, K, N, dy.data_ptr(), w.data_ptr(), dx.data_ptr(), 0, None, 1.0, s))
+            tw = timeit(lambda: L.w2l_linear_backward_weight(M, K, N, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), s))
+            print(f"[gemm] {name:7s} M={M} K={K} N={N} sk={sk}: fwd {tf:.3f} ms {fl / tf / 1e9:.1f} TF | "
+                  f"dX {td:.3f} ms {fl / td / 1e9:.1f} TF | dW {tw:.3f} ms {fl / tw / 1e9:.1f} TF", flush=True)
+        os.environ["W2L_GEMM_SK"] = "1"
+
+
+def probe_ln():
+    for name, B, inner in [("tds s1", 32, 750 * 800), ("tds s2", 32, 375 * 1120), ("tds s3", 32, 188 * 1440),
+                           ("frame", 32 * 188, 1440)]:
+        a = torch.randn(B, inner, device="cuda").clamp_min(0)
+        x = torch.randn(B, inner, device="cuda")
+        gb = torch.tensor([1.1, 0.1], device="cuda")
+        dy = torch.randn(B, inner, device="cuda")
+        nbytes = B * inner * 4
+        y, r, mr = ops.residual_layernorm_forward(a.clone(), x, gb, B, 1e-5, 0.2, 3, 1)
+        tf = timeit(lambda: ops.residual_layernorm_forward(a, x, gb, B, 1e-5, 0.2, 3, 1))
+        tb = timeit(lambda: ops.layernorm_backward(r, dy, gb, mr, B, mask_src=a, mask_scale=1.25))
+        # fwd: read a,x write a,r (stats pass) + read r write y ; bwd: read r,dy twice, read mask, write dr,dmask
+        print(f"[ln] {name}: B={B} inner={inner} fwd {tf * 1e3:.1f} us ({6 * nbytes / tf / 1e9:.2f} TB/s alg) "
+              f"bwd {tb * 1e3:.1f} us ({7 * nbytes / tb / 1e9:.2f} TB/s alg)  [includes torch.empty allocs]", flush=True)
+
+
+def probe_conv():
+    L = _lib.lib()
+    import ctypes as C
+    s = torch.cuda.current_stream().cuda_stream
+    for name, B, T, H, Cc, kw in [("tds s1", 32, 750, 80, 10, 21), ("tds s2", 32, 375, 80, 14, 21), ("tds s3", 32, 188, 80, 18, 21)]:
+        d = _lib.ConvDesc(B, T, H, Cc, Cc, kw, 1, 10, 10)
+        x = torch.randn(B, T, H, Cc, device="cuda")
+        w = torch.randn(kw, Cc, Cc, device="cuda")
+        b = torch.randn(Cc, device="cuda")
+        y = torch.empty_like(x)
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        db = torch.empty_like(b)
+        fl = 2.0 * B * T * H * Cc * Cc * kw
+        nb = x.numel() * 4
+        tf = timeit(lambda: L.w2l_conv_forward(C.byref(d), x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), 1, s))
+        td = timeit(lambda: L.w2l_conv_backward_data(C.byref(d), y.data_ptr(), w.data_ptr(), dx.data_ptr(), 0, s))
+        tw = timeit(lambda: L.w2l_conv_backward_filter(C.byref(d), x.data_ptr(), y.data_ptr(), dw.data_ptr(), db.data_ptr(), s))
+        print(f"[conv] {name}: fwd {tf * 1e3:.0f} us {fl / tf / 1e9:.1f} TF {2 * nb / tf / 1e9:.2f} TB/s | "
+              f"dX {td * 1e3:.0f} us {fl / td / 1e9:.1f} TF | dW+db {tw * 1e3:.0f} us {fl / tw / 1e9:.1f} TF", flush=True)
+
+
+def asg_targets(B, L, g):
+    tgt = torch.full((B, L), -1, dtype=torch.int32)
+    for b in range(B):
+        l = int(torch.randint(60, L + 1, (1,), generator=g))
+        y = torch.randint(0, 28, (l,), generator=g, dtype=torch.int32)
+        for i in range(1, l):
+            if y[i] == y[i - 1]:
+                y[i] = (y[i] + 1) % 28
+        tgt[b, :l] = y
+    return tgt
+
+
+def probe_asg():
+    B, T, N, L = 64, 2000, 30, 300
+    g = torch.Generator(device="cpu").manual_seed(4)
+    x = torch.randn(B, T, N, generator=g).cuda()
+    tgt = asg_targets(B, L, g).cuda()
+    A = (torch.eye(N) * 4 + torch.randn(N, N, generator=g) * 0.1).cuda()
+    for name, cls in [("FCC", FullConnectionCriterion), ("FAC", ForceAlignmentCriterion)]:
+        crit = cls(N, CriterionScaleMode.TARGET_SZ_SQRT).cuda()
+        crit.transitions.data = A.clone()
+        xr = x.clone().requires_grad_(True)
+        tf = timeit(lambda: crit(xr, tgt))
+        tfb = timeit(lambda: crit(xr, tgt).sum().backward())
+        print(f"[asg] {name} B={B} T={T} N={N}: fwd {tf:.3f} ms, fwd+bwd {tfb:.3f} ms", flush=True)
+    crit = ASGLoss(N, CriterionScaleMode.TARGET_SZ_SQRT, 4.0).cuda()
+    tv = timeit(lambda: crit.viterbiPath(x))
+    print(f"[asg] Viterbi B={B} T={T} N={N}: {tv:.3f} ms", flush=True)
+
+
+def probe_fccbig(T=64):
+    B, N = 32, 9998
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(B, T, N, generator=g).cuda()
+    A = (torch.randn(N, N, generator=g) * 0.1 + 4 * torch.eye(N)).cuda()
+    tgt = torch.zeros(B, 4, dtype=torch.int32).cuda()
+    crit = FullConnectionCriterion(N, CriterionScaleMode.NONE).cuda()
+    crit.transitions.data = A
+    xr = x.requires_grad_(True)
+    tf = timeit(lambda: crit(xr, tgt), n=3, warm=1)
+    tfb = timeit(lambda: crit(xr, tgt).sum().backward(), n=3, warm=1)
+    step_bytes = 4.0 * N * N + 8.0 * B * N
+    print(f"[fccbig] B={B} T={T} N={N}: fwd {tf:.2f} ms = {tf / T * 1e3:.1f} us/step "
+          f"({step_bytes * (T - 1) / tf / 1e9:.2f} TB/s algorithmic incl. packing), fwd+bwd {tfb:.2f} ms", flush=True)
+
+
+def probe_vitbig(T=24):
+    N = 9998
+    g = torch.Generator(device="cpu").manual_seed(6)
+    A = (torch.randn(N, N, generator=g) * 0.1 + 4 * torch.eye(N)).cuda()
+    crit = ASGLoss(N, CriterionScaleMode.NONE, 0.0).cuda()
+    crit.transitions.data = A
+    for B in (1, 32):
+        x = torch.randn(B, T, N, generator=g).cuda()
+        tv = timeit(lambda: crit.viterbiPath(x), n=2, warm=1)
+        print(f"[vitbig] B={B} T={T} N={N}: {tv:.2f} ms = {tv / T * 1e3:.1f} us/step "
+              f"({4.0 * N * N * (T - 1) / tv / 1e9:.2f} TB/s algorithmic)", flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["gemm", "ln", "conv", "asg", "fccbig", "vitbig"]
+    print("device:", torch.cuda.get_device_name(0), flush=True)
+    for w in which:
+        t0 = time.time()
+        {"gemm": probe_gemm, "ln": probe_ln, "conv": probe_conv, "asg": probe_asg, "fccbig": probe_fccbig,
+         "vitbig": probe_vitbig}[w]()
+        print(f"[{w}] done in {time.time() - t0:.1f} s", flush=True)

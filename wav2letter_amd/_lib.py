@@ -73,6 +73,7 @@ class _SIGS:
     w2l_conv_forward = (_i, [_p, _p, _p, _p, _p, _i, _p])
     w2l_conv_backward_data = (_i, [_p, _p, _p, _p, _i, _p])
     w2l_conv_backward_filter = (_i, [_p, _p, _p, _p, _p, _p])
+    w2l_layernorm_scratch_doubles = (_sz, [_i, _sz])
     w2l_residual_layernorm_forward = (_i, [_i, _sz, _p, _p, _p, _p, _p, _f, _d, _u32, _u32, _p, _p, _p])
     w2l_layernorm_backward = (_i, [_i, _sz, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p])
     w2l_dropout_inplace = (_i, [_p, _sz, _d, _u32, _u32, _p])

@@ -327,6 +327,7 @@ W2L_API int w2l_conv_backward_filter(const w2l_conv_desc* d, const float* x, con
   if (splitk > kTiles / 8) splitk = kTiles / 8;
   if (splitk < 1) splitk = 1;
   int epi = 0;
+  if (!skinny) splitk = 1;  // the 128x128 engine splits K itself (stream-K, deterministic)
   if (splitk > 1) {
     W2L_HIP_CHECK(hipMemsetAsync(dw, 0, (size_t)Mi * N * sizeof(float), s));
     epi = EPI_ATOMIC;

@@ -293,12 +293,25 @@ __global__ __launch_bounds__(64) void viterbi_small(int T, int N, const float* _
   }
 }
 
+// large-N path (criterion_fcc_big.hip)
+bool fcc_big_supported(int B, int T, int N);
+size_t fcc_big_workspace_size(int B, int T, int N);
+int fcc_big_forward(int B, int T, int N, int scaleMode, const float* input, const int* targetSize,
+                    const float* trans, float* loss, void* workspace, hipStream_t s);
+int fcc_big_backward(int B, int T, int N, const float* trans, const float* grad, float* inputGrad,
+                     float* transGrad, void* workspace, hipStream_t s);
+bool viterbi_big_supported(int B, int T, int N);
+size_t viterbi_big_workspace_size(int B, int T, int N);
+int viterbi_big_compute(int B, int T, int N, const float* input, const float* trans, int* path,
+                        void* workspace, hipStream_t s);
+
 }  // namespace w2l
 
 using namespace w2l;
 
 W2L_API size_t w2l_fcc_workspace_size(int B, int T, int N) {
   if (B <= 0 || T <= 0 || N <= 0) return 0;
+  if (N > 64) return fcc_big_supported(B, T, N) ? fcc_big_workspace_size(B, T, N) : 0;
   size_t btn = align_up((size_t)B * T * N * sizeof(float), 256);
   return 2 * btn + align_up((size_t)B * sizeof(float), 256) +
          align_up((size_t)B * N * N * sizeof(float), 256);
@@ -309,7 +322,10 @@ W2L_API int w2l_fcc_forward(int B, int T, int N, int scaleMode, const float* inp
                             void* workspace, w2l_stream_t stream) {
   if (B <= 0 || T <= 0 || N <= 0 || !input || !targetSize || !trans || !loss || !workspace)
     return W2L_EINVAL;
-  if (N > 64) return W2L_EUNSUPPORTED;
+  if (N > 64) {
+    if (!fcc_big_supported(B, T, N)) return W2L_EUNSUPPORTED;
+    return fcc_big_forward(B, T, N, scaleMode, input, targetSize, trans, loss, workspace, (hipStream_t)stream);
+  }
   hipStream_t s = (hipStream_t)stream;
   FccWs ws = fcc_ws(workspace, B, T, N);
   if (N <= 32)
@@ -325,7 +341,10 @@ W2L_API int w2l_fcc_backward(int B, int T, int N, const float* trans, const floa
                              w2l_stream_t stream) {
   if (B <= 0 || T <= 0 || N <= 0 || !trans || !grad || !inputGrad || !transGrad || !workspace)
     return W2L_EINVAL;
-  if (N > 64) return W2L_EUNSUPPORTED;
+  if (N > 64) {
+    if (!fcc_big_supported(B, T, N)) return W2L_EUNSUPPORTED;
+    return fcc_big_backward(B, T, N, trans, grad, inputGrad, transGrad, workspace, (hipStream_t)stream);
+  }
   hipStream_t s = (hipStream_t)stream;
   FccWs ws = fcc_ws(workspace, B, T, N);
   if (N <= 32)
@@ -341,13 +360,17 @@ W2L_API int w2l_fcc_backward(int B, int T, int N, const float* trans, const floa
 
 W2L_API size_t w2l_viterbi_workspace_size(int B, int T, int N) {
   if (B <= 0 || T <= 0 || N <= 0) return 0;
+  if (N > 64) return viterbi_big_supported(B, T, N) ? viterbi_big_workspace_size(B, T, N) : 0;
   return align_up((size_t)B * T * N, 256);
 }
 
 W2L_API int w2l_viterbi_compute(int B, int T, int N, const float* input, const float* trans,
                                 int* path, void* workspace, w2l_stream_t stream) {
   if (B <= 0 || T <= 0 || N <= 0 || !input || !trans || !path || !workspace) return W2L_EINVAL;
-  if (N > 64) return W2L_EUNSUPPORTED;
+  if (N > 64) {
+    if (!viterbi_big_supported(B, T, N)) return W2L_EUNSUPPORTED;
+    return viterbi_big_compute(B, T, N, input, trans, path, workspace, (hipStream_t)stream);
+  }
   hipStream_t s = (hipStream_t)stream;
   if (N <= 32)
     hipLaunchKernelGGL(viterbi_small<32>, dim3(B), dim3(64), 0, s, T, N, input, trans, path, (unsigned char*)workspace);

@@ -1,0 +1,702 @@
+// criterion_fcc_big.hip -- FullConnectionCriterion for LARGE label sets (N > 64; the
+// north-star stress shape is T = 1500, N = 9998 word pieces, B = 32), gfx950.
+//
+// Replaces fl::lib::cuda::FullConnectionCriterion<float> (un-vendored Flashlight; call
+// sites recipes/slimIPL/src/Train.cpp:410, :1675).  Math: SURVEY.md App. B.2; CPU
+// restatement oracle/criterion_oracle.c.  Same results as the small-N kernel of
+// criterion_fcc.hip, different machine mapping:
+//
+// The transition matrix (4 N^2 = 400 MB at N = 9998) is larger than the 256 MiB Infinity
+// Cache and EVERY one of the T dependent steps needs all of it, so the recursion is
+// HBM-bound on re-streaming A (T (4 N^2 + 8 B N) bytes).  One step
+//     alpha_t[b][i] = x_t[b][i] + LSE_j(alpha_{t-1}[b][j] + A[i][j])
+// is evaluated in the exp domain as a skinny GEMM  S[b][i] = sum_j E[b][j] EA[i][j]  with
+//     EA[i][j] = exp(A[i][j] - rowmax_i)  in (0, 1]      (packed once per call)
+//     E[b][j]  = exp(ahat_{t-1}[b][j]),   ahat = alpha - running max   in (0, 1]
+// on v_mfma_f32_32x32x2_f32 (exact fp32 fma chains): the 16 flop/byte of this product sit
+// just under the fp32 ridge (157 TF / 6.3 TB/s), i.e. the matrix cores keep up with the
+// stream and leave the VALU idle.  EA is stored PRE-PACKED in MFMA operand order
+//     EAp[tile of 32 rows][chunk of 8 k][lane][4]  (lane = row%32 + 32*h holds k = 8c+4h+q)
+// so a wavefront's global_load_dwordx4 is one fully coalesced 1 KiB burst that lands in
+// registers already in fragment layout -- no LDS staging, no transposition, no im2col.
+// Per step: kernel 1 (`fcc_big_gemm`: 64 rows x 1/(4 SW) of K per wave, 4-wave LDS
+// reduction, deterministic partial slabs) and kernel 2 (`fcc_big_step`: one workgroup per
+// utterance adds the SW slabs, takes log, adds x_t and rowmax, renormalises by the exact
+// maximum and emits E both plain (for backward) and packed (for the next step)).  A kernel
+// boundary (~1.5-2 us) is cheaper than a grid barrier (4-7 us) on this chip.
+//
+// Backward streams the transposed pack EATp the same way:
+//     dalpha_{t-1}[b][j] = e_{t-1}[b][j] * sum_i r_t[b][i] EA[i][j],  r_t = dalpha_t / s_t
+// and the transition gradient is ONE fp32 MFMA GEMM over (t, b) at the end:
+//     dA[i][j] = EA[i][j] * sum_{t,b} g_b r_t[b][i] e_{t-1}[b][j]      (2 N^2 T B flop).
+#include "gemm.hpp"
+
+namespace w2l {
+
+constexpr int kBigU = 4;          // chunks (of 8 k) per pipeline stage -> K padded to 32
+constexpr int kBigMaxNB = 4;      // utterance tiles of 32 -> B <= 128
+constexpr int kBigStepThreads = 1024;
+constexpr int kBigMaxQuads = 8;   // quads of 4 labels per thread in fcc_big_step -> N <= 32768
+
+struct BigDims {
+  int B, T, N;
+  int Np;   // rows padded to 64
+  int Kp;   // reduction length padded to 32
+  int NC;   // Kp / 8 chunks
+  int NB;   // ceil(B / 32) rounded to 1, 2, 4
+  int Bp;   // 32 * NB
+  int G;    // Np / 64 row groups
+  int SW;   // workgroup-level K splits (partial slabs)
+};
+
+__host__ __device__ inline BigDims big_dims(int B, int T, int N) {
+  BigDims d;
+  d.B = B; d.T = T; d.N = N;
+  d.Np = (N + 63) / 64 * 64;
+  d.Kp = (N + 31) / 32 * 32;
+  d.NC = d.Kp / 8;
+  int nb = (B + 31) / 32;
+  d.NB = nb <= 1 ? 1 : (nb <= 2 ? 2 : 4);
+  d.Bp = 32 * d.NB;
+  d.G = d.Np / 64;
+  // workgroups = G * SW should cover the 256 CUs 2-3 times; every wave needs >= 1 stage
+  int sw = (640 + d.G - 1) / d.G;
+  int maxsw = d.NC / kBigU / 4;
+  if (sw > maxsw) sw = maxsw;
+  if (sw < 1) sw = 1;
+  if (sw > 16) sw = 16;
+  d.SW = sw;
+  return d;
+}
+
+struct BigWs {
+  float* rm;      // [Np] row maxima of A
+  float* pack;    // [Np * Kp] EAp (forward) / EATp (backward)
+  float* ep[2];   // [Bp * Kp] packed E / R operand, double-buffered over t
+  float* part;    // [SW][Bp][Np] partial sums of one step
+  float* e;       // [T][B][N]  e_t = exp(ahat_t)
+  float* invs;    // [T][B][N]  1 / s_t
+  float* rg;      // [T][B][N]  g_b * r_t (backward)
+  double* cacc;   // [B] running sum of the per-step maxima
+  float* scale;   // [B]
+  float* gb;      // [B] scale * upstream grad
+  size_t bytes;
+};
+
+__host__ __device__ inline BigWs big_ws(void* ws, const BigDims& d) {
+  BigWs w;
+  char* p = (char*)ws;
+  auto take = [&](size_t bytes) { char* q = p; p += align_up(bytes, 256); return q; };
+  const size_t btn = (size_t)d.T * d.B * d.N * sizeof(float);
+  w.rm = (float*)take((size_t)d.Np * sizeof(float));
+  w.pack = (float*)take((size_t)d.Np * d.Kp * sizeof(float));
+  w.ep[0] = (float*)take((size_t)d.Bp * d.Kp * sizeof(float));
+  w.ep[1] = (float*)take((size_t)d.Bp * d.Kp * sizeof(float));
+  w.part = (float*)take((size_t)d.SW * d.Bp * d.Np * sizeof(float));
+  w.e = (float*)take(btn);
+  w.invs = (float*)take(btn);
+  w.rg = (float*)take(btn);
+  w.cacc = (double*)take((size_t)d.B * sizeof(double));
+  w.scale = (float*)take((size_t)d.B * sizeof(float));
+  w.gb = (float*)take((size_t)d.B * sizeof(float));
+  w.bytes = (size_t)(p - (char*)ws);
+  return w;
+}
+
+// ------------------------------------------------------------------ packing (once per call)
+__global__ __launch_bounds__(256) void big_rowmax_k(int N, int Np, const float* __restrict__ A, float* __restrict__ rm) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= Np) return;
+  float m = -INFINITY;
+  if (row < N)
+    for (int j = lane; j < N; j += 64) m = fmaxf(m, A[(size_t)row * N + j]);
+  m = wave_max(m);
+  if (lane == 0) rm[row] = row < N ? m : 0.f;
+}
+
+// TRANSPOSED = false: pack[tile][chunk][lane][q] = EA[32 tile + r][8 chunk + 4 h + q]
+// TRANSPOSED = true : pack[tile][chunk][lane][q] = EA[8 chunk + 4 h + q][32 tile + r]
+// zero outside N x N.  One float4 per thread.
+template <bool TRANSPOSED>
+__global__ __launch_bounds__(256) void big_pack_k(int N, int NC, size_t total4, const float* __restrict__ A,
+                                                  const float* __restrict__ rm, float4* __restrict__ pack) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total4) return;
+  const int lane = (int)(idx & 63);
+  const size_t tc = idx >> 6;
+  const int chunk = (int)(tc % NC);
+  const int tile = (int)(tc / NC);
+  const int r = 32 * tile + (lane & 31);
+  const int k0 = 8 * chunk + 4 * (lane >> 5);
+  float v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int k = k0 + q;
+    const int i = TRANSPOSED ? k : r, j = TRANSPOSED ? r : k;
+    v[q] = (i < N && j < N) ? __expf(A[(size_t)i * N + j] - rm[i]) : 0.f;
+  }
+  pack[idx] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// ------------------------------------------------------------------ kernel 1: the streaming GEMM
+// part[sw][b][r] = sum_{k in split} op[b][k] * pack[r][k]   for the 64 rows of group g.
+template <int NB>
+__global__ __launch_bounds__(256) void fcc_big_gemm(const float4* __restrict__ pack, const float4* __restrict__ op,
+                                                    float* __restrict__ part, int NC, int SW, int Np, int Bp) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][NB*2*16 regs][64 lanes]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = blockIdx.x / SW, sw = blockIdx.x - g * SW;
+  const int nStages = NC / kBigU;
+  const int ss = sw * 4 + wave, nss = 4 * SW;
+  const int s0 = (int)((long long)nStages * ss / nss), s1 = (int)((long long)nStages * (ss + 1) / nss);
+
+  f32x16 acc[NB][2];
+#pragma unroll
+  for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[bt][h][r] = 0.f;
+
+  const float4* pa0 = pack + ((size_t)(2 * g) * NC) * 64 + lane;
+  const float4* pa1 = pack + ((size_t)(2 * g + 1) * NC) * 64 + lane;
+  const float4* pe = op + lane;
+
+  float4 ca0[kBigU], ca1[kBigU], ce[NB][kBigU];
+  float4 na0[kBigU], na1[kBigU], ne[NB][kBigU];
+  if (s0 < s1) {
+#pragma unroll
+    for (int u = 0; u < kBigU; ++u) {
+      const size_t c = (size_t)s0 * kBigU + u;
+      ca0[u] = pa0[c * 64];
+      ca1[u] = pa1[c * 64];
+#pragma unroll
+      for (int bt = 0; bt < NB; ++bt) ce[bt][u] = pe[((size_t)bt * NC + c) * 64];
+    }
+  }
+  for (int s = s0; s < s1; ++s) {
+    if (s + 1 < s1) {
+#pragma unroll
+      for (int u = 0; u < kBigU; ++u) {
+        const size_t c = (size_t)(s + 1) * kBigU + u;
+        na0[u] = pa0[c * 64];
+        na1[u] = pa1[c * 64];
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) ne[bt][u] = pe[((size_t)bt * NC + c) * 64];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kBigU; ++u) {
+      const float a0[4] = {ca0[u].x, ca0[u].y, ca0[u].z, ca0[u].w};
+      const float a1[4] = {ca1[u].x, ca1[u].y, ca1[u].z, ca1[u].w};
+#pragma unroll
+      for (int bt = 0; bt < NB; ++bt) {
+        const float ev[4] = {ce[bt][u].x, ce[bt][u].y, ce[bt][u].z, ce[bt][u].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[bt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ev[q], a0[q], acc[bt][0], 0, 0, 0);
+          acc[bt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ev[q], a1[q], acc[bt][1], 0, 0, 0);
+        }
+      }
+    }
+    if (s + 1 < s1) {
+#pragma unroll
+      for (int u = 0; u < kBigU; ++u) {
+        ca0[u] = na0[u];
+        ca1[u] = na1[u];
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) ce[bt][u] = ne[bt][u];
+      }
+    }
+  }
+
+  // 4-wave reduction through LDS, fixed order (deterministic)
+  constexpr int NR = NB * 2 * 16;
+#pragma unroll
+  for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((wave * NR) + (bt * 2 + h) * 16 + r) * 64 + lane] = acc[bt][h][r];
+  __syncthreads();
+  // D layout of the 32x32 MFMA: column (row of EA) = lane & 31, row (utterance) = (r&3) + 8 (r>>2) + 4 (lane>>5)
+  float* dst = part + (size_t)sw * Bp * Np;
+  for (int o = threadIdx.x; o < NR * 64; o += 256) {
+    const float v = (red[o] + red[NR * 64 + o]) + (red[2 * NR * 64 + o] + red[3 * NR * 64 + o]);
+    const int l = o & 63, rr = o >> 6;
+    const int r = rr & 15, h = (rr >> 4) & 1, bt = rr >> 5;
+    const int b = 32 * bt + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    const int i = 64 * g + 32 * h + (l & 31);
+    dst[(size_t)b * Np + i] = v;
+  }
+}
+
+// ------------------------------------------------------------------ kernel 2 (forward): one workgroup per utterance
+__device__ __forceinline__ float block_max_1024(float v, float* sm) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  float m = sm[0];
+#pragma unroll
+  for (int i = 1; i < kBigStepThreads / 64; ++i) m = fmaxf(m, sm[i]);
+  return m;
+}
+__device__ __forceinline__ float block_sum_1024(float v, float* sm) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < kBigStepThreads / 64; ++i) s += sm[i];
+  return s;
+}
+
+__device__ __forceinline__ size_t packed_op_index(int b, int i0, int NC) {
+  // float index of the float4 holding labels i0..i0+3 (i0 % 4 == 0) of utterance b
+  return ((((size_t)(b >> 5) * NC + (i0 >> 3)) * 64) + (b & 31) + 32 * ((i0 >> 2) & 1)) * 4;
+}
+
+__global__ __launch_bounds__(kBigStepThreads) void fcc_big_step(BigDims d, int t, int scaleMode,
+                                                               const float* __restrict__ x,
+                                                               const int* __restrict__ targetSize,
+                                                               float* __restrict__ loss, BigWs ws) {
+  __shared__ float sm[kBigStepThreads / 64];
+  const int b = blockIdx.x;
+  const int N = d.N;
+  const float* xr = x + ((size_t)b * d.T + t) * N;
+  float* er = ws.e + ((size_t)t * d.B + b) * N;
+  float* ir = ws.invs + ((size_t)t * d.B + b) * N;
+  float* epk = ws.ep[t & 1];
+  float a[kBigMaxQuads][4], sv[kBigMaxQuads][4];
+  float m = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < kBigMaxQuads; ++k) {
+    const int i0 = 4 * (threadIdx.x + kBigStepThreads * k);
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t > 0 && i0 < N)
+      for (int s = 0; s < d.SW; ++s) {
+        const float4 p4 = *(const float4*)(ws.part + ((size_t)s * d.Bp + b) * d.Np + i0);
+        s4.x += p4.x; s4.y += p4.y; s4.z += p4.z; s4.w += p4.w;
+      }
+    const float ssum[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u;
+      float v = -INFINITY, sc = 1.f;
+      if (i < N) {
+        v = xr[i];
+        if (t > 0) {
+          sc = fmaxf(ssum[u], 1e-37f);
+          v += ws.rm[i] + __logf(sc);
+        }
+      }
+      a[k][u] = v;
+      sv[k][u] = sc;
+      m = fmaxf(m, v);
+    }
+  }
+  const float c = block_max_1024(m, sm);
+  float tot = 0.f;
+#pragma unroll
+  for (int k = 0; k < kBigMaxQuads; ++k) {
+    const int i0 = 4 * (threadIdx.x + kBigStepThreads * k);
+    if (i0 < N) {
+      float e4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u;
+        e4[u] = i < N ? __expf(a[k][u] - c) : 0.f;
+        tot += e4[u];
+        if (i < N) {
+          er[i] = e4[u];
+          ir[i] = 1.f / sv[k][u];
+        }
+      }
+      *(float4*)(epk + packed_op_index(b, i0, d.NC)) = make_float4(e4[0], e4[1], e4[2], e4[3]);
+    }
+  }
+  double C = 0.0;
+  if (threadIdx.x == 0) {
+    C = (t > 0 ? ws.cacc[b] : 0.0) + (double)c;
+    ws.cacc[b] = C;
+  }
+  if (t == d.T - 1) {
+    tot = block_sum_1024(tot, sm);
+    if (threadIdx.x == 0) {
+      const float sc = scale_of(scaleMode, d.T, targetSize[b]);
+      loss[b] = (float)((double)sc * (C + (double)__logf(tot)));
+      ws.scale[b] = sc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ backward kernels
+// t = T-1: dalpha = softmax(ahat_{T-1}) = e / sum e ; emits dx, g*r (plain) and r (packed)
+__global__ __launch_bounds__(kBigStepThreads) void fcc_big_bwd_init(BigDims d, const float* __restrict__ grad,
+                                                                   float* __restrict__ dx, BigWs ws) {
+  __shared__ float sm[kBigStepThreads / 64];
+  const int b = blockIdx.x, N = d.N, t = d.T - 1;
+  const float* er = ws.e + ((size_t)t * d.B + b) * N;
+  const float* ir = ws.invs + ((size_t)t * d.B + b) * N;
+  float* dxr = dx + ((size_t)b * d.T + t) * N;
+  float* rgr = ws.rg + ((size_t)t * d.B + b) * N;
+  float* rpk = ws.ep[t & 1];
+  const float g = ws.scale[b] * grad[b];
+  if (threadIdx.x == 0) ws.gb[b] = g;
+  float tot = 0.f;
+  for (int i = threadIdx.x; i < N; i += kBigStepThreads) tot += er[i];
+  tot = block_sum_1024(tot, sm);
+  const float inv = 1.f / tot;
+  for (int i0 = 4 * threadIdx.x; i0 < N; i0 += 4 * kBigStepThreads) {
+    float r4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u;
+      r4[u] = 0.f;
+      if (i < N) {
+        const float da = er[i] * inv;
+        dxr[i] = g * da;
+        if (t > 0) {
+          r4[u] = da * ir[i];
+          rgr[i] = g * r4[u];
+        }
+      }
+    }
+    if (t > 0) *(float4*)(rpk + packed_op_index(b, i0, d.NC)) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+  }
+}
+
+// step t -> t-1 (tm = t-1): dalpha_tm[b][j] = e_tm[b][j] * sum_s part[s][b][j]
+__global__ __launch_bounds__(256) void fcc_big_bwd_step(BigDims d, int tm, float* __restrict__ dx, BigWs ws) {
+  const int b = blockIdx.y, N = d.N;
+  const int i0 = 4 * (blockIdx.x * 256 + threadIdx.x);
+  if (i0 >= N) return;
+  const float g = ws.gb[b];
+  const float* er = ws.e + ((size_t)tm * d.B + b) * N;
+  const float* ir = ws.invs + ((size_t)tm * d.B + b) * N;
+  float* dxr = dx + ((size_t)b * d.T + tm) * N;
+  float* rgr = ws.rg + ((size_t)tm * d.B + b) * N;
+  float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < d.SW; ++s) {
+    const float4 p4 = *(const float4*)(ws.part + ((size_t)s * d.Bp + b) * d.Np + i0);
+    s4.x += p4.x; s4.y += p4.y; s4.z += p4.z; s4.w += p4.w;
+  }
+  const float D[4] = {s4.x, s4.y, s4.z, s4.w};
+  float r4[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = i0 + u;
+    r4[u] = 0.f;
+    if (i < N) {
+      const float da = er[i] * D[u];
+      dxr[i] = g * da;
+      if (tm > 0) {
+        r4[u] = da * ir[i];
+        rgr[i] = g * r4[u];
+      }
+    }
+  }
+  if (tm > 0) *(float4*)(ws.ep[tm & 1] + packed_op_index(b, i0, d.NC)) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+}
+
+// dA[i][j] *= exp(A[i][j] - rowmax_i)
+__global__ __launch_bounds__(256) void fcc_big_scale_dtrans(int N, const float* __restrict__ A, const float* __restrict__ rm,
+                                                           float* __restrict__ dA) {
+  const size_t n = (size_t)N * N;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    const int i = (int)(e / N);
+    dA[e] *= __expf(A[e] - rm[i]);
+  }
+}
+
+template <int NB>
+static int launch_big_gemm(const BigDims& d, const float* pack, const float* op, float* part, hipStream_t s) {
+  const size_t shmem = (size_t)4 * NB * 2 * 16 * 64 * sizeof(float);
+  hipLaunchKernelGGL((fcc_big_gemm<NB>), dim3((unsigned)(d.G * d.SW)), dim3(256), shmem, s, (const float4*)pack,
+                     (const float4*)op, part, d.NC, d.SW, d.Np, d.Bp);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+static int big_gemm(const BigDims& d, const float* pack, const float* op, float* part, hipStream_t s) {
+  if (d.NB == 1) return launch_big_gemm<1>(d, pack, op, part, s);
+  if (d.NB == 2) return launch_big_gemm<2>(d, pack, op, part, s);
+  return launch_big_gemm<4>(d, pack, op, part, s);
+}
+
+bool fcc_big_supported(int B, int T, int N) {
+  (void)T;
+  return B <= 32 * kBigMaxNB && N <= 4 * kBigStepThreads * kBigMaxQuads && N >= 64;
+}
+
+size_t fcc_big_workspace_size(int B, int T, int N) {
+  BigDims d = big_dims(B, T, N);
+  return big_ws(nullptr, d).bytes;
+}
+
+static int big_pack(const BigDims& d, const BigWs& ws, const float* trans, bool transposed, hipStream_t s) {
+  const size_t total4 = (size_t)d.Np * d.Kp / 4;
+  const unsigned blocks = (unsigned)((total4 + 255) / 256);
+  if (transposed)
+    hipLaunchKernelGGL(big_pack_k<true>, dim3(blocks), dim3(256), 0, s, d.N, d.NC, total4, trans, ws.rm, (float4*)ws.pack);
+  else
+    hipLaunchKernelGGL(big_pack_k<false>, dim3(blocks), dim3(256), 0, s, d.N, d.NC, total4, trans, ws.rm, (float4*)ws.pack);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+int fcc_big_forward(int B, int T, int N, int scaleMode, const float* input, const int* targetSize,
+                    const float* trans, float* loss, void* workspace, hipStream_t s) {
+  const BigDims d = big_dims(B, T, N);
+  const BigWs ws = big_ws(workspace, d);
+  hipLaunchKernelGGL(big_rowmax_k, dim3((unsigned)((d.Np + 3) / 4)), dim3(256), 0, s, N, d.Np, trans, ws.rm);
+  W2L_LAUNCH_CHECK();
+  int st = big_pack(d, ws, trans, false, s);
+  if (st) return st;
+  // padded utterances / labels of the packed operand must read as zero
+  W2L_HIP_CHECK(hipMemsetAsync(ws.ep[0], 0, 2 * align_up((size_t)d.Bp * d.Kp * sizeof(float), 256), s));
+  for (int t = 0; t < T; ++t) {
+    if (t > 0) {
+      st = big_gemm(d, ws.pack, ws.ep[(t - 1) & 1], ws.part, s);
+      if (st) return st;
+    }
+    hipLaunchKernelGGL(fcc_big_step, dim3((unsigned)B), dim3(kBigStepThreads), 0, s, d, t, scaleMode, input, targetSize,
+                       loss, ws);
+    W2L_LAUNCH_CHECK();
+  }
+  return W2L_OK;
+}
+
+int fcc_big_backward(int B, int T, int N, const float* trans, const float* grad, float* inputGrad,
+                     float* transGrad, void* workspace, hipStream_t s) {
+  const BigDims d = big_dims(B, T, N);
+  const BigWs ws = big_ws(workspace, d);
+  int st = big_pack(d, ws, trans, true, s);  // rm is still valid from forward
+  if (st) return st;
+  W2L_HIP_CHECK(hipMemsetAsync(ws.ep[0], 0, 2 * align_up((size_t)d.Bp * d.Kp * sizeof(float), 256), s));
+  hipLaunchKernelGGL(fcc_big_bwd_init, dim3((unsigned)B), dim3(kBigStepThreads), 0, s, d, grad, inputGrad, ws);
+  W2L_LAUNCH_CHECK();
+  const dim3 sgrid((unsigned)((N + 1023) / 1024), (unsigned)B);
+  for (int t = T - 1; t >= 1; --t) {
+    st = big_gemm(d, ws.pack, ws.ep[t & 1], ws.part, s);
+    if (st) return st;
+    hipLaunchKernelGGL(fcc_big_bwd_step, sgrid, dim3(256), 0, s, d, t - 1, inputGrad, ws);
+    W2L_LAUNCH_CHECK();
+  }
+  if (T == 1) {
+    W2L_HIP_CHECK(hipMemsetAsync(transGrad, 0, (size_t)N * N * sizeof(float), s));
+    return W2L_OK;
+  }
+  // dA_raw[i][j] = sum_{t>=1,b} (g r_t)[b][i] * e_{t-1}[b][j] : both operands "k-rows", reduction over (t,b)
+  st = gemm_f32(ws.rg + (size_t)B * N, N, 0, ws.e, N, 0, transGrad, N, N, N, (T - 1) * B, nullptr, 0, 1, s);
+  if (st) return st;
+  hipLaunchKernelGGL(fcc_big_scale_dtrans, dim3(2048), dim3(256), 0, s, N, trans, ws.rm, transGrad);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+}  // namespace w2l
+
+// =====================================================================================
+// ViterbiPath for large N (ASGLoss::viterbiPath, recipes/slimIPL/src/Train.cpp:838, :1375).
+// BIT-EXACT with the CPU recursion (oracle/criterion_oracle.c: v = delta[j] + A[i][j] in fp32,
+// strict '>' scanning j upward, then + x[t][i]; first maximum wins everywhere).
+//
+// Max-plus has no matrix-core form: N^2 B (add, compare, 2 selects) per step on the VALU.
+// Mapping: lane <-> destination state i over a TRANSPOSED copy AT[j][i] of the transitions
+// (coalesced 256 B row segments), delta_{t-1}[b][j] is wave-uniform and comes through the
+// scalar cache (stored [j][b]), so the inner loop is 4 VALU ops per (b, j) with no cross-lane
+// traffic and exactly the oracle's j order.  The j range is split over gridDim.y waves per
+// 64-state group (partials combined in split order => still first-max-wins).
+// =====================================================================================
+namespace w2l {
+
+struct VitBigWs {
+  float* AT;             // [N][Np]   AT[j][i] = A[i][j]
+  float* dT[2];          // [N][Bp]   delta^T, double-buffered over t
+  float* pbest;          // [S][Bp][Np]
+  int* parg;             // [S][Bp][Np]
+  unsigned short* psi;   // [B][T][N]
+  int S, Np, Bp;
+  size_t bytes;
+};
+
+__host__ inline VitBigWs vit_big_ws(void* ws, int B, int T, int N) {
+  VitBigWs w;
+  char* p = (char*)ws;
+  auto take = [&](size_t bytes) { char* q = p; p += align_up(bytes, 256); return q; };
+  w.Np = (N + 63) / 64 * 64;
+  w.Bp = B <= 1 ? 1 : (B <= 8 ? 8 : (B + 31) / 32 * 32);
+  const int groups = w.Np / 64;
+  int S = (2560 + groups - 1) / groups;
+  if (S > N / 64) S = N / 64;
+  if (S < 1) S = 1;
+  w.S = S;
+  w.AT = (float*)take((size_t)N * w.Np * sizeof(float));
+  w.dT[0] = (float*)take((size_t)N * w.Bp * sizeof(float));
+  w.dT[1] = (float*)take((size_t)N * w.Bp * sizeof(float));
+  w.pbest = (float*)take((size_t)S * w.Bp * w.Np * sizeof(float));
+  w.parg = (int*)take((size_t)S * w.Bp * w.Np * sizeof(int));
+  w.psi = (unsigned short*)take((size_t)B * T * N * sizeof(unsigned short));
+  w.bytes = (size_t)(p - (char*)ws);
+  return w;
+}
+
+// AT[j][i] = A[i][j], rows padded to Np with 0 (padded states are never read back)
+__global__ __launch_bounds__(256) void vit_big_transpose(int N, int Np, const float* __restrict__ A, float* __restrict__ AT) {
+  __shared__ float tile[32][33];
+  const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {
+    const int i = i0 + k, j = j0 + tx;
+    tile[k][tx] = (i < N && j < N) ? A[(size_t)i * N + j] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int j = j0 + k, i = i0 + tx;
+    if (j < N && i < Np) AT[(size_t)j * Np + i] = tile[tx][k];
+  }
+}
+
+// delta_0 = x_0, stored transposed [j][Bp]
+__global__ __launch_bounds__(256) void vit_big_init(int B, int T, int N, int Bp, const float* __restrict__ x, float* __restrict__ dT) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  for (int b = 0; b < Bp; ++b) dT[(size_t)j * Bp + b] = b < B ? x[((size_t)b * T) * N + j] : 0.f;
+}
+
+template <int BT>
+__global__ __launch_bounds__(64) void vit_big_scan(int N, int Np, int Bp, int S, const float* __restrict__ AT,
+                                                   const float* __restrict__ dT, float* __restrict__ pbest,
+                                                   int* __restrict__ parg) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  const int s = blockIdx.y, b0 = blockIdx.z * BT;
+  const int j0 = (int)((long long)N * s / S), j1 = (int)((long long)N * (s + 1) / S);
+  float best[BT];
+  int arg[BT];
+  {
+    const float a = AT[(size_t)j0 * Np + i];
+    const float* d = dT + (size_t)j0 * Bp + b0;
+#pragma unroll
+    for (int b = 0; b < BT; ++b) { best[b] = d[b] + a; arg[b] = j0; }
+  }
+  int j = j0 + 1;
+  for (; j + 4 <= j1; j += 4) {
+    float a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = AT[(size_t)(j + u) * Np + i];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* d = dT + (size_t)(j + u) * Bp + b0;
+#pragma unroll
+      for (int b = 0; b < BT; ++b) {
+        const float v = d[b] + a[u];
+        const bool gt = v > best[b];
+        best[b] = gt ? v : best[b];
+        arg[b] = gt ? j + u : arg[b];
+      }
+    }
+  }
+  for (; j < j1; ++j) {
+    const float a = AT[(size_t)j * Np + i];
+    const float* d = dT + (size_t)j * Bp + b0;
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      const float v = d[b] + a;
+      const bool gt = v > best[b];
+      best[b] = gt ? v : best[b];
+      arg[b] = gt ? j : arg[b];
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < BT; ++b) {
+    pbest[((size_t)s * Bp + b0 + b) * Np + i] = best[b];
+    parg[((size_t)s * Bp + b0 + b) * Np + i] = arg[b];
+  }
+}
+
+// combine the S split partials in j order, add x_t, emit delta_t^T and psi_t
+__global__ __launch_bounds__(256) void vit_big_combine(int B, int T, int N, int Np, int Bp, int S, int t,
+                                                      const float* __restrict__ x, const float* __restrict__ pbest,
+                                                      const int* __restrict__ parg, float* __restrict__ dTout,
+                                                      unsigned short* __restrict__ psi) {
+  const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (i >= N) return;
+  float best = pbest[((size_t)b) * Np + i];
+  int arg = parg[((size_t)b) * Np + i];
+  for (int s = 1; s < S; ++s) {
+    const float v = pbest[((size_t)s * Bp + b) * Np + i];
+    if (v > best) { best = v; arg = parg[((size_t)s * Bp + b) * Np + i]; }
+  }
+  dTout[(size_t)i * Bp + b] = best + x[((size_t)b * T + t) * N + i];
+  psi[((size_t)b * T + t) * N + i] = (unsigned short)arg;
+}
+
+// final state (first argmax) + backtrace: one wavefront per utterance
+__global__ __launch_bounds__(64) void vit_big_backtrace(int T, int N, int Bp, const float* __restrict__ dT,
+                                                        const unsigned short* __restrict__ psi, int* __restrict__ path) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float best = -INFINITY;
+  int arg = 0x7fffffff;
+  for (int i = lane; i < N; i += 64) {
+    const float v = dT[(size_t)i * Bp + b];
+    if (v > best || (v == best && i < arg)) { best = v; arg = i; }
+  }
+  // lexicographic (max value, min index) across lanes
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(best, off);
+    const int oa = __shfl_xor(arg, off);
+    if (ov > best || (ov == best && oa < arg)) { best = ov; arg = oa; }
+  }
+  if (lane == 0) {
+    int cur = arg == 0x7fffffff ? 0 : arg;
+    int* pb = path + (size_t)b * T;
+    pb[T - 1] = cur;
+    for (int t = T - 1; t >= 1; --t) {
+      cur = psi[((size_t)b * T + t) * N + cur];
+      pb[t - 1] = cur;
+    }
+  }
+}
+
+bool viterbi_big_supported(int B, int T, int N) {
+  (void)T;
+  return N >= 64 && N <= 65535 && B >= 1;
+}
+size_t viterbi_big_workspace_size(int B, int T, int N) { return vit_big_ws(nullptr, B, T, N).bytes; }
+
+int viterbi_big_compute(int B, int T, int N, const float* input, const float* trans, int* path, void* workspace,
+                        hipStream_t s) {
+  const VitBigWs w = vit_big_ws(workspace, B, T, N);
+  hipLaunchKernelGGL(vit_big_transpose, dim3((unsigned)(w.Np / 32), (unsigned)((N + 31) / 32)), dim3(256), 0, s, N, w.Np,
+                     trans, w.AT);
+  W2L_LAUNCH_CHECK();
+  hipLaunchKernelGGL(vit_big_init, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, B, T, N, w.Bp, input, w.dT[0]);
+  W2L_LAUNCH_CHECK();
+  const int BT = w.Bp >= 32 ? 32 : w.Bp;
+  const dim3 sgrid((unsigned)(w.Np / 64), (unsigned)w.S, (unsigned)(w.Bp / BT));
+  const dim3 cgrid((unsigned)((N + 255) / 256), (unsigned)B);
+  for (int t = 1; t < T; ++t) {
+    const float* din = w.dT[(t - 1) & 1];
+    if (BT == 32)
+      hipLaunchKernelGGL(vit_big_scan<32>, sgrid, dim3(64), 0, s, N, w.Np, w.Bp, w.S, w.AT, din, w.pbest, w.parg);
+    else if (BT == 8)
+      hipLaunchKernelGGL(vit_big_scan<8>, sgrid, dim3(64), 0, s, N, w.Np, w.Bp, w.S, w.AT, din, w.pbest, w.parg);
+    else
+      hipLaunchKernelGGL(vit_big_scan<1>, sgrid, dim3(64), 0, s, N, w.Np, w.Bp, w.S, w.AT, din, w.pbest, w.parg);
+    W2L_LAUNCH_CHECK();
+    hipLaunchKernelGGL(vit_big_combine, cgrid, dim3(256), 0, s, B, T, N, w.Np, w.Bp, w.S, t, input, w.pbest, w.parg,
+                       w.dT[t & 1], w.psi);
+    W2L_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(vit_big_backtrace, dim3((unsigned)B), dim3(64), 0, s, T, N, w.Bp, w.dT[(T - 1) & 1], w.psi, path);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+}  // namespace w2l

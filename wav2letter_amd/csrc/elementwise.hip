@@ -21,24 +21,39 @@ static inline unsigned ew_grid(size_t n4) {
   return (unsigned)g;
 }
 
-__device__ __forceinline__ void block_atomic_add2(double a, double b, double* dst, double* sm) {
-  // wave reduce then one double atomic per wave
+constexpr int kLnMaxParts = 64;   // partial sums per group (utterance-sized groups)
+constexpr size_t kLnSmall = 8192;  // groups of at most this many floats: one block, one pass
+
+// Deterministic two-level reduction: every block leaves ONE (a, b) partial in
+// part[2*(g*gridDim.x + blockIdx.x)]; consumers add the gridDim.x partials of their group in
+// index order (no atomics: 32 groups x thousands of waves on 64 addresses was the old cost).
+__device__ __forceinline__ void block_partial2(double a, double b, double* part) {
+  __shared__ double sm[2][kEwThreads / 64];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     a += __shfl_xor(a, off);
     b += __shfl_xor(b, off);
   }
-  (void)sm;
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(dst, a);
-    atomicAdd(dst + 1, b);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sm[0][w] = a; sm[1][w] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sa = 0, sb = 0;
+#pragma unroll
+    for (int i = 0; i < kEwThreads / 64; ++i) { sa += sm[0][i]; sb += sm[1][i]; }
+    part[0] = sa;
+    part[1] = sb;
   }
 }
+__device__ __forceinline__ void sum_parts(const double* __restrict__ part, int g, int nparts, double& a, double& b) {
+  a = 0; b = 0;
+  for (int i = 0; i < nparts; ++i) { a += part[2 * ((size_t)g * nparts + i)]; b += part[2 * ((size_t)g * nparts + i) + 1]; }
+}
 
-// ---- r = dropout(a) + x (a updated in place to its dropped value), stats[g] += (sum r, sum r^2)
+// ---- r = dropout(a) + x (a updated in place to its dropped value), part[g][bx] = (sum r, sum r^2)
 // groups are contiguous chunks of `inner` elements (LayerNorm axes {0,1,2}: one per utterance)
 __global__ __launch_bounds__(kEwThreads) void residual_dropout_stats_k(
-    float* __restrict__ a, const float* __restrict__ x, float* __restrict__ r, double* __restrict__ stats,
+    float* __restrict__ a, const float* __restrict__ x, float* __restrict__ r, double* __restrict__ part,
     size_t inner, uint32_t thr, float keepScale, uint32_t seed, uint32_t stream) {
   const int g = blockIdx.y;
   const size_t base = (size_t)g * inner;
@@ -57,21 +72,25 @@ __global__ __launch_bounds__(kEwThreads) void residual_dropout_stats_k(
     }
     rv.x += av.x; rv.y += av.y; rv.z += av.z; rv.w += av.w;
     if (r != a || x) *(float4*)(r + e) = rv;  // plain LayerNorm (r aliases a, no residual): nothing to write
-    s += (double)rv.x + (double)rv.y + (double)rv.z + (double)rv.w;
-    ss += (double)rv.x * rv.x + (double)rv.y * rv.y + (double)rv.z * rv.z + (double)rv.w * rv.w;
+    const float p1 = (rv.x + rv.y) + (rv.z + rv.w);
+    const float p2 = (rv.x * rv.x + rv.y * rv.y) + (rv.z * rv.z + rv.w * rv.w);
+    s += (double)p1;
+    ss += (double)p2;
   }
-  block_atomic_add2(s, ss, stats + 2 * g, nullptr);
+  block_partial2(s, ss, part + 2 * ((size_t)g * gridDim.x + blockIdx.x));
 }
 
-// y = gamma * (r - mu) * rstd + beta ; mu/rstd from stats (sum, sumsq), biased variance + eps.
+// y = gamma * (r - mu) * rstd + beta ; mu/rstd from the partials (sum, sumsq), biased variance + eps.
 // writes mean/rstd (fp32) for the backward pass.
 __global__ __launch_bounds__(kEwThreads) void ln_apply_k(const float* __restrict__ r, float* __restrict__ y,
-                                                        const double* __restrict__ stats,
+                                                        const double* __restrict__ part,
                                                         float* __restrict__ meanRstd, size_t inner,
                                                         const float* __restrict__ gammaBeta, float eps) {
   const int g = blockIdx.y;
-  const double mu = stats[2 * g] / (double)inner;
-  double var = stats[2 * g + 1] / (double)inner - mu * mu;
+  double s1, s2;
+  sum_parts(part, g, gridDim.x, s1, s2);
+  const double mu = s1 / (double)inner;
+  double var = s2 / (double)inner - mu * mu;
   if (var < 0) var = 0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   const float muf = (float)mu;
@@ -86,11 +105,67 @@ __global__ __launch_bounds__(kEwThreads) void ln_apply_k(const float* __restrict
   }
 }
 
-// backward reduce: sums[g] += (sum dy, sum dy * xhat), xhat = (r - mu) * rstd
+// Small groups (per-frame LayerNorm, axes {1,2}: inner = H*C <= kLnSmall): ONE block per group,
+// ONE pass -- the group is held in registers between the statistics and the apply.
+constexpr int kLnSmallV = (int)(kLnSmall / 4 / kEwThreads);  // float4 per thread
+__global__ __launch_bounds__(kEwThreads) void residual_ln_small_k(
+    float* __restrict__ a, const float* __restrict__ x, float* __restrict__ r, float* __restrict__ y,
+    float* __restrict__ meanRstd, size_t inner, const float* __restrict__ gammaBeta, float eps,
+    uint32_t thr, float keepScale, uint32_t seed, uint32_t stream) {
+  __shared__ double bc[2];
+  const int g = blockIdx.x;
+  const size_t base = (size_t)g * inner;
+  const int n4 = (int)(inner >> 2);
+  float4 v[kLnSmallV];
+  double s = 0, ss = 0;
+#pragma unroll
+  for (int j = 0; j < kLnSmallV; ++j) {
+    const int i = threadIdx.x + j * kEwThreads;
+    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+      const size_t e = base + 4 * (size_t)i;
+      float4 av = *(const float4*)(a + e);
+      float4 rv = x ? *(const float4*)(x + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (thr) {
+        av.x = keep_elem(e, seed, stream, thr) ? av.x * keepScale : 0.f;
+        av.y = keep_elem(e + 1, seed, stream, thr) ? av.y * keepScale : 0.f;
+        av.z = keep_elem(e + 2, seed, stream, thr) ? av.z * keepScale : 0.f;
+        av.w = keep_elem(e + 3, seed, stream, thr) ? av.w * keepScale : 0.f;
+        *(float4*)(a + e) = av;
+      }
+      rv.x += av.x; rv.y += av.y; rv.z += av.z; rv.w += av.w;
+      if (r != a || x) *(float4*)(r + e) = rv;
+      v[j] = rv;
+      s += (double)((rv.x + rv.y) + (rv.z + rv.w));
+      ss += (double)((rv.x * rv.x + rv.y * rv.y) + (rv.z * rv.z + rv.w * rv.w));
+    }
+  }
+  block_partial2(s, ss, bc);
+  __syncthreads();
+  const double mu = bc[0] / (double)inner;
+  double var = bc[1] / (double)inner - mu * mu;
+  if (var < 0) var = 0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float muf = (float)mu;
+  if (threadIdx.x == 0) { meanRstd[2 * g] = muf; meanRstd[2 * g + 1] = rstd; }
+  const float gam = gammaBeta[0] * rstd, bet = gammaBeta[1];
+#pragma unroll
+  for (int j = 0; j < kLnSmallV; ++j) {
+    const int i = threadIdx.x + j * kEwThreads;
+    if (i < n4) {
+      float4 o = v[j];
+      o.x = (o.x - muf) * gam + bet; o.y = (o.y - muf) * gam + bet;
+      o.z = (o.z - muf) * gam + bet; o.w = (o.w - muf) * gam + bet;
+      *(float4*)(y + base + 4 * (size_t)i) = o;
+    }
+  }
+}
+
+// backward reduce: part[g][bx] = (sum dy, sum dy * xhat), xhat = (r - mu) * rstd
 __global__ __launch_bounds__(kEwThreads) void ln_bwd_reduce_k(const float* __restrict__ r,
                                                              const float* __restrict__ dy,
                                                              const float* __restrict__ meanRstd,
-                                                             double* __restrict__ sums, size_t inner) {
+                                                             double* __restrict__ part, size_t inner) {
   const int g = blockIdx.y;
   const float mu = meanRstd[2 * g], rstd = meanRstd[2 * g + 1];
   const size_t base = (size_t)g * inner, n4 = inner >> 2;
@@ -98,20 +173,22 @@ __global__ __launch_bounds__(kEwThreads) void ln_bwd_reduce_k(const float* __res
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     float4 rv = *(const float4*)(r + base + 4 * i);
     float4 dv = *(const float4*)(dy + base + 4 * i);
-    s1 += (double)dv.x + (double)dv.y + (double)dv.z + (double)dv.w;
-    s2 += (double)(dv.x * ((rv.x - mu) * rstd)) + (double)(dv.y * ((rv.y - mu) * rstd)) +
-          (double)(dv.z * ((rv.z - mu) * rstd)) + (double)(dv.w * ((rv.w - mu) * rstd));
+    s1 += (double)((dv.x + dv.y) + (dv.z + dv.w));
+    s2 += (double)((dv.x * ((rv.x - mu) * rstd) + dv.y * ((rv.y - mu) * rstd)) +
+                   (dv.z * ((rv.z - mu) * rstd) + dv.w * ((rv.w - mu) * rstd)));
   }
-  block_atomic_add2(s1, s2, sums + 2 * g, nullptr);
+  block_partial2(s1, s2, part + 2 * ((size_t)g * gridDim.x + blockIdx.x));
 }
 
 // backward apply: dr = gamma*rstd*(dy - S1/n - xhat*S2/n).
 // Optional second output dmask = dr * (maskSrc > 0 ? maskScale : 0)  (ReLU+dropout of the
 // producer branch: maskSrc is its stored post-dropout output).
+// Block (0, g) also leaves the group totals in sums[2g..2g+1] for the parameter gradients.
 __global__ __launch_bounds__(kEwThreads) void ln_bwd_apply_k(const float* __restrict__ r,
                                                             const float* __restrict__ dy,
                                                             const float* __restrict__ meanRstd,
-                                                            const double* __restrict__ sums,
+                                                            const double* __restrict__ part,
+                                                            double* __restrict__ sums,
                                                             const float* __restrict__ gammaBeta,
                                                             float* __restrict__ dr,
                                                             const float* __restrict__ maskSrc,
@@ -119,7 +196,10 @@ __global__ __launch_bounds__(kEwThreads) void ln_bwd_apply_k(const float* __rest
                                                             size_t inner) {
   const int g = blockIdx.y;
   const float mu = meanRstd[2 * g], rstd = meanRstd[2 * g + 1];
-  const float c1 = (float)(sums[2 * g] / (double)inner), c2 = (float)(sums[2 * g + 1] / (double)inner);
+  double S1, S2;
+  sum_parts(part, g, gridDim.x, S1, S2);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { sums[2 * g] = S1; sums[2 * g + 1] = S2; }
+  const float c1 = (float)(S1 / (double)inner), c2 = (float)(S2 / (double)inner);
   const float gr = gammaBeta[0] * rstd;
   const size_t base = (size_t)g * inner, n4 = inner >> 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -144,11 +224,70 @@ __global__ __launch_bounds__(kEwThreads) void ln_bwd_apply_k(const float* __rest
   }
 }
 
-// scalar-parameter gradients: dgamma = sum_g S2_g, dbeta = sum_g S1_g
-__global__ void ln_param_grad_k(const double* __restrict__ sums, int groups, float* __restrict__ dGammaBeta) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s1 = 0, s2 = 0;
-    for (int g = 0; g < groups; ++g) { s1 += sums[2 * g]; s2 += sums[2 * g + 1]; }
+// small groups: one block per group, r and dy held in registers between reduce and apply
+__global__ __launch_bounds__(kEwThreads) void ln_bwd_small_k(const float* __restrict__ r, const float* __restrict__ dy,
+                                                            const float* __restrict__ meanRstd,
+                                                            double* __restrict__ sums,
+                                                            const float* __restrict__ gammaBeta,
+                                                            float* __restrict__ dr,
+                                                            const float* __restrict__ maskSrc,
+                                                            float* __restrict__ dmask, float maskScale,
+                                                            size_t inner) {
+  __shared__ double bc[2];
+  const int g = blockIdx.x;
+  const float mu = meanRstd[2 * g], rstd = meanRstd[2 * g + 1];
+  const size_t base = (size_t)g * inner;
+  const int n4 = (int)(inner >> 2);
+  float4 xh[kLnSmallV], dv[kLnSmallV];
+  double s1 = 0, s2 = 0;
+#pragma unroll
+  for (int j = 0; j < kLnSmallV; ++j) {
+    const int i = threadIdx.x + j * kEwThreads;
+    xh[j] = dv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+      float4 rv = *(const float4*)(r + base + 4 * (size_t)i);
+      dv[j] = *(const float4*)(dy + base + 4 * (size_t)i);
+      xh[j] = make_float4((rv.x - mu) * rstd, (rv.y - mu) * rstd, (rv.z - mu) * rstd, (rv.w - mu) * rstd);
+      s1 += (double)((dv[j].x + dv[j].y) + (dv[j].z + dv[j].w));
+      s2 += (double)((dv[j].x * xh[j].x + dv[j].y * xh[j].y) + (dv[j].z * xh[j].z + dv[j].w * xh[j].w));
+    }
+  }
+  block_partial2(s1, s2, bc);
+  __syncthreads();
+  if (threadIdx.x == 0) { sums[2 * g] = bc[0]; sums[2 * g + 1] = bc[1]; }
+  const float c1 = (float)(bc[0] / (double)inner), c2 = (float)(bc[1] / (double)inner);
+  const float gr = gammaBeta[0] * rstd;
+#pragma unroll
+  for (int j = 0; j < kLnSmallV; ++j) {
+    const int i = threadIdx.x + j * kEwThreads;
+    if (i < n4) {
+      const size_t e = base + 4 * (size_t)i;
+      float4 o;
+      o.x = gr * (dv[j].x - c1 - xh[j].x * c2);
+      o.y = gr * (dv[j].y - c1 - xh[j].y * c2);
+      o.z = gr * (dv[j].z - c1 - xh[j].z * c2);
+      o.w = gr * (dv[j].w - c1 - xh[j].w * c2);
+      *(float4*)(dr + e) = o;
+      if (dmask) {
+        float4 mv = *(const float4*)(maskSrc + e);
+        float4 d2;
+        d2.x = mv.x > 0.f ? o.x * maskScale : 0.f;
+        d2.y = mv.y > 0.f ? o.y * maskScale : 0.f;
+        d2.z = mv.z > 0.f ? o.z * maskScale : 0.f;
+        d2.w = mv.w > 0.f ? o.w * maskScale : 0.f;
+        *(float4*)(dmask + e) = d2;
+      }
+    }
+  }
+}
+
+// scalar-parameter gradients: dgamma = sum_g S2_g, dbeta = sum_g S1_g (one wave, fixed order)
+__global__ __launch_bounds__(64) void ln_param_grad_k(const double* __restrict__ sums, int groups, float* __restrict__ dGammaBeta) {
+  double s1 = 0, s2 = 0;
+  for (int g = threadIdx.x; g < groups; g += 64) { s1 += sums[2 * g]; s2 += sums[2 * g + 1]; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+  if (threadIdx.x == 0) {
     dGammaBeta[0] = (float)s2;
     dGammaBeta[1] = (float)s1;
   }
@@ -298,27 +437,44 @@ using namespace w2l;
 
 #define W2L_S ((hipStream_t)stream)
 
+static inline unsigned ln_parts(size_t inner) {
+  size_t g = ((inner >> 2) + kEwThreads * 4 - 1) / (kEwThreads * 4);  // >= 4 float4 per thread
+  if (g > (size_t)kLnMaxParts) g = kLnMaxParts;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+// scratch (in doubles) of the two LayerNorm entry points: [2*groups totals | 2*groups*parts partials]
+W2L_API size_t w2l_layernorm_scratch_doubles(int groups, size_t inner) {
+  if (groups <= 0) return 0;
+  return 2 * (size_t)groups * (1 + (inner <= kLnSmall ? 0 : ln_parts(inner)));
+}
+
 // LayerNorm over `groups` contiguous chunks of `inner` elements (inner % 4 == 0):
 // fused with the residual add and the dropout of the incoming branch.
 //   a   [groups*inner]  branch output (dropout applied IN PLACE when p > 0)
 //   x   residual input or NULL
 //   r   pre-norm sum (kept for backward), y normalised output
-//   stats  double[2*groups] scratch, meanRstd float[2*groups] (kept for backward)
+//   stats  double[w2l_layernorm_scratch_doubles] scratch, meanRstd float[2*groups] (kept for backward)
 W2L_API int w2l_residual_layernorm_forward(int groups, size_t inner, float* a, const float* x, float* r,
                                            float* y, const float* gammaBeta, float eps, double p,
                                            uint32_t seed, uint32_t rngStream, double* stats,
                                            float* meanRstd, w2l_stream_t stream) {
   if (groups <= 0 || inner == 0 || (inner & 3) || !a || !r || !y || !gammaBeta || !stats || !meanRstd)
     return W2L_EINVAL;
-  W2L_HIP_CHECK(hipMemsetAsync(stats, 0, sizeof(double) * 2 * groups, W2L_S));
   const uint32_t thr = dropout_threshold(p);
   const float ks = (float)(1.0 / (1.0 - p));
-  unsigned gx = ew_grid(inner >> 2);
-  if (gx > 512) gx = 512;
-  dim3 grid(gx, (unsigned)groups);
-  hipLaunchKernelGGL(residual_dropout_stats_k, grid, dim3(kEwThreads), 0, W2L_S, a, x, r, stats, inner, thr, ks, seed, rngStream);
+  if (inner <= kLnSmall) {
+    hipLaunchKernelGGL(residual_ln_small_k, dim3((unsigned)groups), dim3(kEwThreads), 0, W2L_S, a, x, r, y, meanRstd,
+                       inner, gammaBeta, eps, thr, ks, seed, rngStream);
+    W2L_LAUNCH_CHECK();
+    return W2L_OK;
+  }
+  double* part = stats + 2 * (size_t)groups;
+  dim3 grid(ln_parts(inner), (unsigned)groups);
+  hipLaunchKernelGGL(residual_dropout_stats_k, grid, dim3(kEwThreads), 0, W2L_S, a, x, r, part, inner, thr, ks, seed, rngStream);
   W2L_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ln_apply_k, grid, dim3(kEwThreads), 0, W2L_S, r, y, stats, meanRstd, inner, gammaBeta, eps);
+  hipLaunchKernelGGL(ln_apply_k, grid, dim3(kEwThreads), 0, W2L_S, r, y, part, meanRstd, inner, gammaBeta, eps);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }
@@ -331,15 +487,19 @@ W2L_API int w2l_layernorm_backward(int groups, size_t inner, const float* r, con
                                    double* sums, w2l_stream_t stream) {
   if (groups <= 0 || inner == 0 || (inner & 3) || !r || !dy || !gammaBeta || !meanRstd || !dr || !sums)
     return W2L_EINVAL;
-  W2L_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 2 * groups, W2L_S));
-  unsigned gx = ew_grid(inner >> 2);
-  if (gx > 512) gx = 512;
-  dim3 grid(gx, (unsigned)groups);
-  hipLaunchKernelGGL(ln_bwd_reduce_k, grid, dim3(kEwThreads), 0, W2L_S, r, dy, meanRstd, sums, inner);
-  W2L_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ln_bwd_apply_k, grid, dim3(kEwThreads), 0, W2L_S, r, dy, meanRstd, sums, gammaBeta, dr,
-                     maskSrc, maskSrc ? dmask : nullptr, maskScale, inner);
-  W2L_LAUNCH_CHECK();
+  if (inner <= kLnSmall) {
+    hipLaunchKernelGGL(ln_bwd_small_k, dim3((unsigned)groups), dim3(kEwThreads), 0, W2L_S, r, dy, meanRstd, sums,
+                       gammaBeta, dr, maskSrc, maskSrc ? dmask : nullptr, maskScale, inner);
+    W2L_LAUNCH_CHECK();
+  } else {
+    double* part = sums + 2 * (size_t)groups;
+    dim3 grid(ln_parts(inner), (unsigned)groups);
+    hipLaunchKernelGGL(ln_bwd_reduce_k, grid, dim3(kEwThreads), 0, W2L_S, r, dy, meanRstd, part, inner);
+    W2L_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ln_bwd_apply_k, grid, dim3(kEwThreads), 0, W2L_S, r, dy, meanRstd, part, sums, gammaBeta, dr,
+                       maskSrc, maskSrc ? dmask : nullptr, maskScale, inner);
+    W2L_LAUNCH_CHECK();
+  }
   if (dGammaBeta) {
     hipLaunchKernelGGL(ln_param_grad_k, dim3(1), dim3(64), 0, W2L_S, sums, groups, dGammaBeta);
     W2L_LAUNCH_CHECK();

@@ -18,6 +18,11 @@
 // in K-major form  As[k][m], Bs[k][n]  so that a half-wave's fragment read is 32
 // consecutive dwords (conflict-free ds_read_b32), double-buffered with register
 // prefetch of the next K-tile (one barrier per K-tile).
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "gemm.hpp"
 
 namespace w2l {
@@ -25,6 +30,32 @@ namespace w2l {
 GemmProf& gemm_prof() {
   static GemmProf p;
   return p;
+}
+
+// stream-K partial-tile slabs: library-owned, ONE buffer per stream (work on a stream is
+// serialised, so launches on the same stream may share it); allocated on first use.
+float* sk_scratch(hipStream_t s, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, std::pair<float*, size_t>> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  auto& e = cache[{dev, s}];
+  if (e.second < bytes) {
+    if (e.first) (void)hipFree(e.first);
+    e.first = nullptr;
+    e.second = 0;
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    e.first = (float*)p;
+    e.second = bytes;
+  }
+  return e.first;
+}
+
+bool sk_enabled() {
+  const char* e = getenv("W2L_GEMM_SK");
+  return !(e && e[0] == '0');
 }
 
 static inline int pick_vec(const float* p, int ld, int extent) {
@@ -56,10 +87,7 @@ int gemm_f32(const float* A, int lda, int a_kcontig, const float* B, int ldb, in
   o.mask = mask;
   o.maskScale = maskScale;
   if (mask) epi |= EPI_MASK;
-  if (splitk < 1) splitk = 1;
-  if (splitk > 1) {
-    if (epi != EPI_ATOMIC) return W2L_EINVAL;
-  }
+  splitk = 1;
   if (a_kcontig) {
     int v = pick_vec(A, lda, K);
     if (v == 4) return dispatch_b(PlainOp<true, 4>{A, lda, M, K}, B, ldb, b_kcontig, o, epi, splitk, s);
@@ -97,16 +125,8 @@ W2L_API int w2l_linear_backward_weight(int M, int in, int out, const float* x, c
                                        float* dw, w2l_stream_t stream) {
   // dw[in][out] = x[M][in]^T . dy[M][out] : reduction over M, both operands k-rows.
   // The output is small (in x out) and the reduction long: split K so the grid fills 256 CUs.
+  // The output is small (in x out) and the reduction long: the stream-K schedule splits K.
   hipStream_t s = (hipStream_t)stream;
-  const int tiles = ((in + 127) / 128) * ((out + 127) / 128);
-  int splitk = 1;
-  if (tiles < 512) splitk = (512 + tiles - 1) / tiles;
-  const int kTiles = (M + 31) / 32;
-  if (splitk > kTiles / 4) splitk = kTiles / 4 > 0 ? kTiles / 4 : 1;
-  if (splitk > 1) {
-    W2L_HIP_CHECK(hipMemsetAsync(dw, 0, (size_t)in * out * sizeof(float), s));
-    return gemm_f32(x, in, 0, dy, out, 0, dw, out, in, out, M, nullptr, EPI_ATOMIC, splitk, s);
-  }
   return gemm_f32(x, in, 0, dy, out, 0, dw, out, in, out, M, nullptr, 0, 1, s);
 }
 
@@ -115,11 +135,7 @@ W2L_API int w2l_gemm_f32(int M, int N, int K, const float* A, int lda, int a_kco
                          int ldb, int b_kcontig, float* C, int ldc, const float* bias, int relu,
                          int splitk, w2l_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (splitk > 1) {
-    if (bias || relu) return W2L_EINVAL;
-    W2L_HIP_CHECK(hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s));
-    return gemm_f32(A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, M, N, K, nullptr, EPI_ATOMIC, splitk, s);
-  }
+  (void)splitk;  // kept for ABI stability: K is split by the stream-K schedule
   int epi = (bias ? EPI_BIAS : 0) | (relu ? EPI_RELU : 0);
   return gemm_f32(A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, M, N, K, bias, epi, 1, s);
 }

@@ -171,38 +171,70 @@ inline void prof_end(hipStream_t s) {
   p.used += 2;
 }
 
+// ---------------------------------------------------------------- stream-K schedule
+// A data-parallel grid of 128x128 tiles quantises badly on the TDS shapes (M = 6016, N = 1440:
+// 564 tiles on 512 resident workgroups = 2 rounds for 1.1 rounds of work).  Hybrid schedule:
+// the first `dpTiles` tiles (whole rounds) run one tile per workgroup; the K iterations of the
+// remaining `skTiles` tiles are cut into `skBlocks` EQUAL contiguous ranges, one per workgroup
+// (each range touches at most two tiles).  A range that covers a whole tile runs the normal
+// epilogue; otherwise the accumulators go to a per-workgroup slab (in MFMA register order,
+// coalesced) and gemm128_fixup adds the slabs of a tile IN RANGE ORDER and runs the epilogue:
+// no atomics, run-to-run deterministic, no pre-zeroed output.
+struct SkPlan {
+  int tilesM, tilesN, kTiles;
+  int dpTiles, skTiles, skBlocks;
+  float* slabs;  // [skBlocks][2][128*128]
+};
+constexpr int kSkSlots = 512;           // resident 256-thread workgroups (2 per CU)
+constexpr int kSlabFloats = 128 * 128;
+
+__host__ __device__ inline long long sk_begin(const SkPlan& p, int s) {
+  return (long long)p.skTiles * p.kTiles * s / p.skBlocks;
+}
+
+inline SkPlan make_sk_plan(int M, int N, int K, bool allowSk) {
+  SkPlan p;
+  p.tilesM = (M + 127) / 128;
+  p.tilesN = (N + 127) / 128;
+  p.kTiles = (K + 31) / 32;
+  const int tiles = p.tilesM * p.tilesN;
+  p.dpTiles = tiles; p.skTiles = 0; p.skBlocks = 0; p.slabs = nullptr;
+  if (!allowSk || p.kTiles < 8) return p;
+  const int rounds = (tiles + kSkSlots - 1) / kSkSlots;
+  const double eff = (double)tiles / ((double)rounds * kSkSlots);
+  if (eff >= 0.93) return p;
+  const int full = tiles / kSkSlots;
+  p.dpTiles = full * kSkSlots;
+  p.skTiles = tiles - p.dpTiles;
+  long long iters = (long long)p.skTiles * p.kTiles;
+  long long blocks = iters / 4;  // >= 4 K iterations per workgroup
+  if (blocks > kSkSlots) blocks = kSkSlots;
+  if (blocks < 1) blocks = 1;
+  p.skBlocks = (int)blocks;
+  // every range must stay within two tiles
+  if (iters / p.skBlocks + 1 > p.kTiles) { p.dpTiles = tiles; p.skTiles = 0; p.skBlocks = 0; }
+  return p;
+}
+
+float* sk_scratch(hipStream_t s, size_t bytes);  // library-owned, one buffer per stream (gemm.hip)
+bool sk_enabled();                               // W2L_GEMM_SK=0 turns the schedule off (A/B runs)
+
 // ---------------------------------------------------------------- kernels
 template <class AOp, class BOp>
-__global__ __launch_bounds__(256, 2) void gemm128_kernel(AOp aop, BOp bop, GemmOut out) {
+__device__ __forceinline__ void gemm128_mainloop(const AOp& aop, const BOp& bop, int m0, int n0, int ktBegin, int ktEnd,
+                                                 float* smem, f32x16 (&acc)[2][2]) {
   constexpr int BM = 128, BN = 128, BK = 32;
   constexpr int LDA_S = BM + AOp::kPad, LDB_S = BN + BOp::kPad;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As0 = smem;
   float* Bs0 = As0 + BK * LDA_S;
   float* As1 = Bs0 + BK * LDB_S;
   float* Bs1 = As1 + BK * LDA_S;
-
-  const int EPI = out.epi;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int li = lane & 31, lh = lane >> 5;
 
-  // tile coordinates: blockIdx.x walks M fastest inside an XCD-sized group so that
-  // neighbouring workgroups on one XCD share the same B (weight) panel in L2
-  const int tilesM = (out.M + BM - 1) / BM;
-  const int bx = blockIdx.x % tilesM, by = blockIdx.x / tilesM;
-  const int m0 = bx * BM, n0 = by * BN;
-
-  // split-K range for this z-slice
-  const int kTilesTotal = (out.K + BK - 1) / BK;
-  const int perSplit = (kTilesTotal + gridDim.z - 1) / gridDim.z;
-  const int ktBegin = blockIdx.z * perSplit;
-  int ktEnd = ktBegin + perSplit;
-  if (ktEnd > kTilesTotal) ktEnd = kTilesTotal;
-
-  f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -211,6 +243,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(AOp aop, BOp bop, GemmO
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float ra[16], rb[16];
+  __syncthreads();  // a previous segment of this workgroup may still be reading the LDS tiles
   if (ktBegin < ktEnd) {
     aop.load(ra, m0, ktBegin * BK, tid);
     bop.load(rb, n0, ktBegin * BK, tid);
@@ -245,8 +278,14 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(AOp aop, BOp bop, GemmO
     }
     __syncthreads();
   }
+}
 
-  // epilogue. C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+// epilogue. C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+__device__ __forceinline__ void gemm128_epilogue(const GemmOut& out, int m0, int n0, const f32x16 (&acc)[2][2]) {
+  const int EPI = out.epi;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -254,23 +293,96 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(AOp aop, BOp bop, GemmO
       const int n = n0 + wn + j * 32 + li;
       if (n >= out.N) continue;
       float bv = 0.f;
-      if ((EPI & EPI_BIAS) && blockIdx.z == 0) bv = out.bias[n];
+      if (EPI & EPI_BIAS) bv = out.bias[n];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (m >= out.M) continue;
         float v = acc[i][j][r] + bv;
         float* dst = out.C + (size_t)m * out.ldc + n;
-        if (EPI & EPI_ATOMIC) {
-          atomicAdd(dst, v);
-        } else {
-          if (EPI & EPI_RELU) v = fmaxf(v, 0.f);
-          if (EPI & EPI_MASK) v = out.mask[(size_t)m * out.ldc + n] > 0.f ? v * out.maskScale : 0.f;
-          if (EPI & EPI_ACCUM) v += *dst;
-          *dst = v;
-        }
+        if (EPI & EPI_RELU) v = fmaxf(v, 0.f);
+        if (EPI & EPI_MASK) v = out.mask[(size_t)m * out.ldc + n] > 0.f ? v * out.maskScale : 0.f;
+        if (EPI & EPI_ACCUM) v += *dst;
+        *dst = v;
       }
     }
+}
+
+// slab element of (acc index a = 2i+j, register r) of this thread: ((wave*4 + a)*16 + r)*64 + lane
+__device__ __forceinline__ void gemm128_store_partial(float* slab, const f32x16 (&acc)[2][2]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) slab[((wave * 4 + i * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+}
+
+template <class AOp, class BOp>
+__global__ __launch_bounds__(256, 2) void gemm128_kernel(AOp aop, BOp bop, GemmOut out, SkPlan plan) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  f32x16 acc[2][2];
+  const int bid = blockIdx.x;
+  // tile coordinates: the tile index walks M fastest so that neighbouring workgroups on one
+  // XCD share the same B (weight) panel in L2
+  if (bid < plan.dpTiles) {
+    const int bx = bid % plan.tilesM, by = bid / plan.tilesM;
+    gemm128_mainloop(aop, bop, bx * 128, by * 128, 0, plan.kTiles, smem, acc);
+    gemm128_epilogue(out, bx * 128, by * 128, acc);
+    return;
+  }
+  const int s = bid - plan.dpTiles;
+  long long it = sk_begin(plan, s);
+  const long long itEnd = sk_begin(plan, s + 1);
+  int seg = 0;
+  while (it < itEnd) {
+    const int tile = plan.dpTiles + (int)(it / plan.kTiles);
+    const int kb = (int)(it % plan.kTiles);
+    int ke = plan.kTiles;
+    if (itEnd - it < (long long)(ke - kb)) ke = kb + (int)(itEnd - it);
+    const int bx = tile % plan.tilesM, by = tile / plan.tilesM;
+    gemm128_mainloop(aop, bop, bx * 128, by * 128, kb, ke, smem, acc);
+    if (kb == 0 && ke == plan.kTiles) gemm128_epilogue(out, bx * 128, by * 128, acc);
+    else gemm128_store_partial(plan.slabs + ((size_t)s * 2 + seg) * kSlabFloats, acc);
+    it += ke - kb;
+    ++seg;
+  }
+}
+
+// one workgroup per stream-K tile: add the partial slabs in range order, then the epilogue
+template <int kUnused>
+__global__ __launch_bounds__(256) void gemm128_fixup(GemmOut out, SkPlan plan) {
+  const int t = blockIdx.x;  // index inside the stream-K region
+  const long long tb = (long long)t * plan.kTiles, te = tb + plan.kTiles;
+  const long long I = (long long)plan.skTiles * plan.kTiles;
+  int s = (int)(tb * plan.skBlocks / I);
+  while (s + 1 < plan.skBlocks && sk_begin(plan, s + 1) <= tb) ++s;
+  while (s > 0 && sk_begin(plan, s) > tb) --s;
+  if (sk_begin(plan, s) <= tb && sk_begin(plan, s + 1) >= te) return;  // one range covered the tile: done in-kernel
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (; s < plan.skBlocks && sk_begin(plan, s) < te; ++s) {
+    const long long b0 = sk_begin(plan, s);
+    if (sk_begin(plan, s + 1) <= tb) continue;
+    const int segIdx = t - (int)(b0 / plan.kTiles);  // ranges span <= 2 tiles: 0 or 1
+    const float* slab = plan.slabs + ((size_t)s * 2 + segIdx) * kSlabFloats;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += slab[((wave * 4 + i * 2 + j) * 16 + r) * 64 + lane];
+  }
+  const int tile = plan.dpTiles + t;
+  const int bx = tile % plan.tilesM, by = tile / plan.tilesM;
+  gemm128_epilogue(out, bx * 128, by * 128, acc);
 }
 
 // Skinny-N variant for small output widths (TDS time convolutions, C = 10..18):
@@ -380,12 +492,19 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(AOp aop, BOp bop, G
 template <class AOp, class BOp>
 inline int launch128(const AOp& a, const BOp& b, GemmOut o, int epi, int splitk, hipStream_t s) {
   constexpr int BK = 32;
+  (void)splitk;          // K is split by the stream-K schedule, deterministically
+  epi &= ~EPI_ATOMIC;    // (callers of the old atomic split-K path need no pre-zeroed C any more)
   const size_t shmem = 2 * (size_t)BK * ((128 + AOp::kPad) + (128 + BOp::kPad)) * sizeof(float);
-  const int tilesM = (o.M + 127) / 128, tilesN = (o.N + 127) / 128;
-  dim3 grid((unsigned)(tilesM * tilesN), 1, (unsigned)splitk), block(256);
+  SkPlan plan = make_sk_plan(o.M, o.N, o.K, sk_enabled());
+  if (plan.skBlocks > 0) {
+    plan.slabs = sk_scratch(s, (size_t)kSkSlots * 2 * kSlabFloats * sizeof(float));
+    if (!plan.slabs) plan = make_sk_plan(o.M, o.N, o.K, false);
+  }
+  dim3 grid((unsigned)(plan.dpTiles + plan.skBlocks)), block(256);
   o.epi = epi;
   prof_begin(s, 2.0 * o.M * (double)o.N * o.K);
-  hipLaunchKernelGGL((gemm128_kernel<AOp, BOp>), grid, block, shmem, s, a, b, o);
+  hipLaunchKernelGGL((gemm128_kernel<AOp, BOp>), grid, block, shmem, s, a, b, o, plan);
+  if (plan.skBlocks > 0) hipLaunchKernelGGL(gemm128_fixup<0>, dim3((unsigned)plan.skTiles), block, 0, s, o, plan);
   prof_end(s);
   W2L_LAUNCH_CHECK();
   return W2L_OK;

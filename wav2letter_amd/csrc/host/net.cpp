@@ -450,7 +450,7 @@ class LayerNormLayer : public Layer {
     if (inner % 4) throw std::invalid_argument("LayerNorm: normalised size must be a multiple of 4");
     yOff = pl.alloc(in.numel());
     dxOff = pl.alloc(in.numel());
-    statOff = pl.alloc(4 * (size_t)groups);  // doubles
+    statOff = pl.alloc(2 * w2l_layernorm_scratch_doubles(groups, inner));  // doubles
     mrOff = pl.alloc(2 * (size_t)groups);
     return in;
   }
@@ -545,8 +545,8 @@ class TDSLayer : public Layer {
     inner = n / groups;
     if (inner % 4) throw std::invalid_argument("TDSBlock: LayerNorm size must be a multiple of 4");
     aOff = pl.alloc(n); r1Off = pl.alloc(n); y1Off = pl.alloc(n); uOff = pl.alloc((size_t)M * l2); vOff = pl.alloc(n); outOff = pl.alloc(n);
-    st1Off = pl.alloc(4 * (size_t)groups); mr1Off = pl.alloc(2 * (size_t)groups);
-    st2Off = pl.alloc(4 * (size_t)groups); mr2Off = pl.alloc(2 * (size_t)groups);
+    st1Off = pl.alloc(2 * w2l_layernorm_scratch_doubles(groups, inner)); mr1Off = pl.alloc(2 * (size_t)groups);
+    st2Off = pl.alloc(2 * w2l_layernorm_scratch_doubles(groups, inner)); mr2Off = pl.alloc(2 * (size_t)groups);
     dsOff = pl.alloc(n); duOff = pl.alloc((size_t)M * l2); dy1Off = pl.alloc(n); dr1Off = pl.alloc(n);
     daOff = pl.alloc(n); dxOff = pl.alloc(n);
     return in;

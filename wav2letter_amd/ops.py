@@ -76,12 +76,16 @@ def conv_backward(x, w, dy, stride=1, padl=0, padr=0, need_dx=True):
     return dx, dw, db
 
 
+def _ln_scratch(groups, inner):
+    return int(_lib.lib().w2l_layernorm_scratch_doubles(groups, inner))
+
+
 def residual_layernorm_forward(a, x, gamma_beta, groups, eps=1e-5, p=0.0, seed=0, stream_id=0):
     """returns (y, r, mean_rstd); `a` is dropped in place when p > 0"""
     inner = a.numel() // groups
     r = torch.empty_like(a)
     y = torch.empty_like(a)
-    stats = torch.empty(2 * groups, device=a.device, dtype=torch.float64)
+    stats = torch.empty(_ln_scratch(groups, inner), device=a.device, dtype=torch.float64)
     mr = torch.empty(2 * groups, device=a.device, dtype=torch.float32)
     check(_lib.lib().w2l_residual_layernorm_forward(groups, inner, _p(a), _p(x), _p(r), _p(y), _p(gamma_beta), eps,
                                                     p, seed, stream_id, _p(stats), _p(mr), _s()), "res_ln_fwd")
@@ -93,7 +97,7 @@ def layernorm_backward(r, dy, gamma_beta, mean_rstd, groups, mask_src=None, mask
     dr = torch.empty_like(r)
     dgb = torch.empty(2, device=r.device, dtype=torch.float32)
     dmask = torch.empty_like(r) if mask_src is not None else None
-    sums = torch.empty(2 * groups, device=r.device, dtype=torch.float64)
+    sums = torch.empty(_ln_scratch(groups, inner), device=r.device, dtype=torch.float64)
     check(_lib.lib().w2l_layernorm_backward(groups, inner, _p(r), _p(dy), _p(gamma_beta), _p(mean_rstd), _p(dr),
                                             _p(dgb), _p(mask_src), _p(dmask), mask_scale, _p(sums), _s()), "ln_bwd")
     return dr, dgb, dmask
