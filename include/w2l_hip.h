@@ -143,6 +143,9 @@ int w2l_conv_forward(const w2l_conv_desc* d, const float* x, const float* w, con
                      float* y, int relu, w2l_stream_t stream);
 int w2l_conv_backward_data(const w2l_conv_desc* d, const float* dy, const float* w, float* dx,
                            int accumulate, w2l_stream_t stream);
+/* dx = add + backward-data(dy, w): fused residual join (add has the layout of dx) */
+int w2l_conv_backward_data_add(const w2l_conv_desc* d, const float* dy, const float* w,
+                               const float* add, float* dx, w2l_stream_t stream);
 int w2l_conv_backward_filter(const w2l_conv_desc* d, const float* x, const float* dy, float* dw,
                              float* dbias, w2l_stream_t stream);
 

@@ -119,6 +119,10 @@ CONV_CASES = [
     (1, 33, 70, 1, 45, 4, 1, 2, 2),       # even kw, odd channels (scalar loads)
     (2, 3, 5, 2, 9, 3, 1, 0, 0),          # valid (no padding)
     (1, 6, 40, 2, 64, 5, 1, 4, 0),        # asymmetric (streaming) padding
+    (2, 10, 10, 80, 70, 21, 1, 10, 10),   # full TDS geometry: H = 80 (5 row blocks), 3 time blocks
+    (1, 18, 18, 40, 37, 21, 1, 10, 10),   # c = 18, ragged last row block (H % 16 = 8)
+    (1, 14, 18, 19, 66, 21, 2, 10, 10),   # strided stage transition, H % 16 = 3 (scalar slab loads)
+    (2, 5, 7, 3, 20, 9, 1, 8, 0),         # causal padding, odd channel counts
 ]
 
 

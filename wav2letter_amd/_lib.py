@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libw2l_hip.so")
+SO_PATH = os.environ.get("W2L_HIP_SO") or os.path.join(_HERE, "libw2l_hip.so")  # W2L_HIP_SO: A/B builds of the same ABI
 _lib = None
 
 W2L_OK, W2L_EINVAL, W2L_EHIP, W2L_EUNSUPPORTED = 0, 1, 2, 3
@@ -72,6 +72,7 @@ class _SIGS:
     w2l_conv_same_pad = (_i, [_i, _i, _i])
     w2l_conv_forward = (_i, [_p, _p, _p, _p, _p, _i, _p])
     w2l_conv_backward_data = (_i, [_p, _p, _p, _p, _i, _p])
+    w2l_conv_backward_data_add = (_i, [_p, _p, _p, _p, _p, _p])
     w2l_conv_backward_filter = (_i, [_p, _p, _p, _p, _p, _p])
     w2l_layernorm_scratch_doubles = (_sz, [_i, _sz])
     w2l_residual_layernorm_forward = (_i, [_i, _sz, _p, _p, _p, _p, _p, _f, _d, _u32, _u32, _p, _p, _p])

@@ -14,6 +14,8 @@
 //   bwd-filt  dW[(tap,ci)][co] = sum_{(b,to,h)} X[b][to*s+tap-pl][h][ci] * dY[(b,to,h)][co]
 // Weights are stored [kw][Cin][Cout] (== [K][Cout], "k-rows" B operand).  Small
 // output widths (TDS: C = 10/14/18) use the 16x16x4 skinny kernel.
+#include <cstdlib>
+
 #include "gemm.hpp"
 
 namespace w2l {
@@ -53,6 +55,10 @@ __device__ __forceinline__ bool conv_src_frame(const ConvGeom& g, int trow, int 
 
 // A operand of forward / backward-data: element (kk=(tap,c), m=(b,trow,h))
 struct ConvAOp {
+  static constexpr bool kFast = false;
+  struct Ptrs {};
+  __device__ __forceinline__ void init(Ptrs&, int, int) const {}
+  __device__ __forceinline__ void load_fast(float (&)[16], const Ptrs&, int) const {}
   const float* src;
   ConvGeom g;
   int M, K;
@@ -102,6 +108,10 @@ struct ConvAOp {
 
 // B operand of backward-data: element (kk=(tap,co), j=ci) = W[(tap*Cin + ci)*Cout + co]
 struct ConvWTOp {
+  static constexpr bool kFast = false;
+  struct Ptrs {};
+  __device__ __forceinline__ void init(Ptrs&, int, int) const {}
+  __device__ __forceinline__ void load_fast(float (&)[16], const Ptrs&, int) const {}
   const float* w;
   int Cin, Cout, K;  // K = kw*Cout
   FastDiv dCo;
@@ -149,6 +159,10 @@ struct ConvWTOp {
 
 // A operand of backward-filter: element (k = m = (b,to,h), i = (tap,ci)) -- "k-rows"
 struct ConvFilterAOp {
+  static constexpr bool kFast = false;
+  struct Ptrs {};
+  __device__ __forceinline__ void init(Ptrs&, int, int) const {}
+  __device__ __forceinline__ void load_fast(float (&)[16], const Ptrs&, int) const {}
   const float* src;
   ConvGeom g;  // T_rows = To (row space of dY), reads x with C = Cin
   int Mi;      // kw*Cin  (extent of i)
@@ -246,6 +260,20 @@ static int conv_launch_rowsB(const AOp& a, const float* Bp, int ldb, int N, int 
   return launch128(a, PlainOp<false, 1>{Bp, ldb, N, K}, o, epi, splitk, s);
 }
 
+// conv_tds.hip: slab-in-LDS kernels for few-channel convolutions (TDS, C2 sub-sampling)
+bool tds_conv_applicable(const w2l_conv_desc* d);
+int tds_conv_forward(const w2l_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int relu,
+                     hipStream_t s);
+int tds_conv_backward_data(const w2l_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate,
+                           const float* add, hipStream_t s);
+int tds_conv_backward_filter(const w2l_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                             hipStream_t s);
+
+static bool tds_path() {
+  const char* e = getenv("W2L_CONV_TDS");
+  return !(e && e[0] == '0');
+}
+
 }  // namespace w2l
 
 using namespace w2l;
@@ -276,6 +304,10 @@ W2L_API int w2l_conv_forward(const w2l_conv_desc* d, const float* x, const float
   int st = check_desc(d);
   if (st) return st;
   if (!x || !w || !y) return W2L_EINVAL;
+  if (tds_path() && tds_conv_applicable(d)) {
+    st = tds_conv_forward(d, x, w, bias, y, relu, (hipStream_t)stream);
+    if (st != W2L_EUNSUPPORTED) return st;
+  }
   const int To = out_len(d->T, d->kw, d->stride, d->padl, d->padr);
   const int M = d->B * To * d->H, K = d->kw * d->Cin, N = d->Cout;
   ConvGeom g{d->T, To, d->H, d->Cin, d->stride, 1, -d->padl, 1,
@@ -291,6 +323,10 @@ W2L_API int w2l_conv_backward_data(const w2l_conv_desc* d, const float* dy, cons
   int st = check_desc(d);
   if (st) return st;
   if (!dy || !w || !dx) return W2L_EINVAL;
+  if (tds_path() && tds_conv_applicable(d) && d->stride == 1) {
+    st = tds_conv_backward_data(d, dy, w, dx, accumulate, nullptr, (hipStream_t)stream);
+    if (st != W2L_EUNSUPPORTED) return st;
+  }
   const int To = out_len(d->T, d->kw, d->stride, d->padl, d->padr);
   const int M = d->B * d->T * d->H, K = d->kw * d->Cout, N = d->Cin;
   // rows are input frames ti; source frame of dY = (ti + padl - tap) / stride
@@ -306,12 +342,33 @@ W2L_API int w2l_conv_backward_data(const w2l_conv_desc* d, const float* dy, cons
   return launch128(a, b, o, epi, 1, s);
 }
 
+// dx = add + backward-data(dy): the residual / upstream gradient joins in the epilogue instead of
+// a device-to-device copy followed by an accumulating launch (TDS block backward).
+W2L_API int w2l_conv_backward_data_add(const w2l_conv_desc* d, const float* dy, const float* w, const float* add,
+                                       float* dx, w2l_stream_t stream) {
+  int st = check_desc(d);
+  if (st) return st;
+  if (!dy || !w || !dx || !add) return W2L_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (tds_path() && tds_conv_applicable(d) && d->stride == 1) {
+    st = tds_conv_backward_data(d, dy, w, dx, 0, add, s);
+    if (st != W2L_EUNSUPPORTED) return st;
+  }
+  if (dx != add)
+    W2L_HIP_CHECK(hipMemcpyAsync(dx, add, (size_t)d->B * d->T * d->H * d->Cin * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return w2l_conv_backward_data(d, dy, w, dx, 1, stream);
+}
+
 W2L_API int w2l_conv_backward_filter(const w2l_conv_desc* d, const float* x, const float* dy, float* dw,
                                      float* dbias, w2l_stream_t stream) {
   int st = check_desc(d);
   if (st) return st;
   if (!x || !dy || !dw) return W2L_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  if (tds_path() && tds_conv_applicable(d)) {
+    st = tds_conv_backward_filter(d, x, dy, dw, dbias, s);
+    if (st != W2L_EUNSUPPORTED) return st;
+  }
   const int To = out_len(d->T, d->kw, d->stride, d->padl, d->padr);
   const int Kred = d->B * To * d->H, Mi = d->kw * d->Cin, N = d->Cout;
   ConvGeom g{d->T, To, d->H, d->Cin, d->stride, 1, -d->padl, 1,

@@ -1,0 +1,360 @@
+// conv_tds.hip -- the TDS time convolution (fl::Conv2D kw x 1 over (T, H) with few channels:
+// C = 10 / 14 / 18, kw = 21, H = 80 mel rows) forward / backward-data / backward-filter.
+//
+// Reference: fl::TDSBlock's conv (recipes/joint_training_vox_populi/cpc/SequentialBuilder.cpp
+// :254-268; arithmetic recipes/streaming_convnets/inference/inference/module/nn/backend/fbgemm/
+// Conv1dFbGemm.cpp:104-185) and the C2 sub-sampling convolutions of am_tds_ctc.arch:3-6; cuDNN
+// forward / backward-data / backward-filter in the reference.
+//
+// The generic implicit-GEMM operand of conv.hip gathers one scalar per (row, k) with two
+// divisions: at N = C_out = 10 the GEMM is so skinny that this address arithmetic, not the
+// matrix pipe, was the bound (16 TF/s, 0.3 TB/s).  Here the convolution is IM2COL-FREE in
+// LDS: a workgroup stages the input slab it needs ONCE
+//     slab[frame f][h][ci],  f in [t0*stride - padl, ... + (BT-1)*stride + kw)
+// (rows of 16*C_in contiguous floats, coalesced float4 loads, halo (BT+kw-1)/BT), and the
+// v_mfma_f32_16x16x4_f32 A fragments are read straight out of it:
+//     A[(t,h)][(tap,ci)] = slab[(t*stride + tap)*FS + h*C_in + ci]
+// = one ds_read_b32 at  rowoff(t,h) + koff(tap,ci)  with koff from a 1 KB LDS table.  The
+// 16 rows of an MFMA tile are 16 consecutive mel rows h (stride C_in = 10/14/18 floats:
+// conflict-free banks), a wave owns 8 output frames x 16 h.  Output tiles are staged through
+// LDS and written as whole contiguous frames.  backward-data (stride 1) is the same kernel
+// with tap-flipped, transposed weights; backward-filter keeps the (tap,ci) x co accumulators
+// of a PERSISTENT workgroup in registers over many (b, t, h) chunks, gets the bias gradient
+// from an extra all-ones row, and ends with a deterministic partial-sum reduction.
+//
+// MFMA roofline note: N = C_out is padded to 16 (32 for C = 18), so the matrix-pipe ceiling
+// of this op is C/16 = 62.5 % / 87.5 % / 56 % of the fp32 peak by construction.
+#include "gemm.hpp"
+
+namespace w2l {
+
+constexpr int kTdsBT = 32;   // output frames per workgroup (forward / backward-data)
+constexpr int kTdsBTF = 16;  // frames per chunk (backward-filter)
+constexpr int kTdsBH = 16;   // mel rows per workgroup = rows of one MFMA tile
+constexpr int kTdsMaxTilesPerWave = 6;  // backward-filter: (K+1)/16 row tiles over 4 waves -> K <= 383
+
+struct TdsConvP {
+  const float* x;     // tensor being read as the GEMM A operand [B][Tin][H][Cin]
+  const float* w;     // [kw][CinW][CoutW] weights of the layer (forward orientation)
+  const float* bias;  // [Cout] or null
+  const float* add;   // optional addend with the layout of y (residual / upstream gradient), or null
+  float* y;           // [B][Tout][H][Cout]
+  int B, Tin, Tout, H, Cin, Cout, kw, stride, padl;
+  int K, Kp, FS, NF;
+  int relu, accum, flip;
+  int CinW, CoutW;
+};
+
+__device__ __forceinline__ void tds_load_slab(const TdsConvP& p, float* slab, int b, int tIn0, int h0, int nf) {
+  const int rowLen = kTdsBH * p.Cin;            // floats per slab frame (without pad)
+  int hc = p.H - h0;
+  if (hc > kTdsBH) hc = kTdsBH;
+  const int valid = hc * p.Cin;
+  const bool vec = ((p.H * p.Cin) & 3) == 0 && (valid & 3) == 0 && ((h0 * p.Cin) & 3) == 0;
+  if (vec) {
+    const int q = rowLen >> 2, total = nf * (q + 1);  // + 1: the 4-float pad of each frame is zero-filled
+    for (int e = threadIdx.x; e < total; e += 256) {
+      const int f = e / (q + 1), o = (e - f * (q + 1)) << 2;
+      const int ti = tIn0 + f;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ti >= 0 && ti < p.Tin && o < valid) v = *(const float4*)(p.x + (((size_t)b * p.Tin + ti) * p.H + h0) * p.Cin + o);
+      *(float4*)(slab + f * p.FS + o) = v;
+    }
+  } else {
+    const int total = nf * p.FS;
+    for (int e = threadIdx.x; e < total; e += 256) {
+      const int f = e / p.FS, o = e - f * p.FS;
+      const int ti = tIn0 + f;
+      float v = 0.f;
+      if (ti >= 0 && ti < p.Tin && o < valid) v = p.x[(((size_t)b * p.Tin + ti) * p.H + h0) * p.Cin + o];
+      slab[e] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- forward / backward-data
+// grid (ceil(H/16), ceil(Tout/32), B), 256 threads.  LDS: slab | weights [Kp][Cout] | koff[Kp]
+template <int NT>
+__global__ __launch_bounds__(256) void tds_conv_fwd_k(TdsConvP p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int slabFloats = max(p.NF * p.FS, kTdsBT * kTdsBH * p.Cout);
+  float* slab = lds;
+  float* wS = slab + ((slabFloats + 3) & ~3);
+  int* koff = (int*)(wS + ((p.Kp * p.Cout + 3) & ~3));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h0 = blockIdx.x * kTdsBH, t0 = blockIdx.y * kTdsBT, b = blockIdx.z;
+
+  // weights: forward W[(tap,ci)][co]; backward-data W'[(tap',co_w)][ci_w] = W[kw-1-tap'][ci_w][co_w]
+  for (int e = tid; e < p.Kp * p.Cout; e += 256) {
+    const int kk = e / p.Cout, co = e - kk * p.Cout;
+    float v = 0.f;
+    if (kk < p.K) {
+      if (!p.flip) {
+        v = p.w[e];
+      } else {
+        const int tap = kk / p.Cin, c = kk - tap * p.Cin;  // c indexes CoutW, co indexes CinW
+        v = p.w[((size_t)(p.kw - 1 - tap) * p.CinW + co) * p.CoutW + c];
+      }
+    }
+    wS[e] = v;
+  }
+  for (int kk = tid; kk < p.Kp; kk += 256) {
+    const int tap = kk / p.Cin, c = kk - tap * p.Cin;
+    koff[kk] = kk < p.K ? tap * p.FS + c : 0;
+  }
+  tds_load_slab(p, slab, b, t0 * p.stride - p.padl, h0, p.NF);
+  __syncthreads();
+
+  const int i = lane & 15, lq = lane >> 4;
+  f32x4 acc[8][NT];
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[r][nt][q] = 0.f;
+
+  const float* sl = slab + i * p.Cin + (wave * 8 * p.stride) * p.FS;
+  const int rstep = p.stride * p.FS;
+  const int nk = p.Kp >> 2;
+  for (int kq = 0; kq < nk; ++kq) {
+    const int kk = 4 * kq + lq;
+    const int ko = koff[kk];
+    float bf[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bf[nt] = (16 * nt + i < p.Cout) ? wS[kk * p.Cout + 16 * nt + i] : 0.f;
+    float a[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a[r] = sl[r * rstep + ko];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], bf[nt], acc[r][nt], 0, 0, 0);
+  }
+  __syncthreads();  // all fragment reads done: the slab region becomes the output stage
+
+  // D layout: col = lane & 15 (co within the N tile), row = 4 * (lane >> 4) + q (mel row)
+  float* outS = slab;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int co = 16 * nt + i;
+    if (co < p.Cout) {
+      const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = acc[r][nt][q] + bv;
+          if (p.relu) v = fmaxf(v, 0.f);
+          outS[((wave * 8 + r) * kTdsBH + 4 * lq + q) * p.Cout + co] = v;
+        }
+    }
+  }
+  __syncthreads();
+  int hc = p.H - h0;
+  if (hc > kTdsBH) hc = kTdsBH;
+  const int rowLen = hc * p.Cout;
+  int tc = p.Tout - t0;
+  if (tc > kTdsBT) tc = kTdsBT;
+  const int total = tc * rowLen;
+  for (int e = tid; e < total; e += 256) {
+    const int t = e / rowLen, o = e - t * rowLen;
+    const size_t g = (((size_t)b * p.Tout + t0 + t) * p.H + h0) * p.Cout + o;
+    float v = outS[t * kTdsBH * p.Cout + o];
+    if (p.add) v += p.add[g];
+    if (p.accum) v += p.y[g];
+    p.y[g] = v;
+  }
+}
+
+// ---------------------------------------------------------------- backward-filter (+ bias gradient)
+// persistent grid; chunk = (b, 16 frames, 16 mel rows).  A = x^T: rows (tap,ci) [+ one all-ones row
+// for the bias gradient], k = the chunk's 256 (t,h) positions; B = dy [(t,h)][co].
+// partial[block][rowTile*16 + row][16*NT]
+template <int NT>
+__global__ __launch_bounds__(256) void tds_conv_filter_k(TdsConvP p, const float* __restrict__ dy, float* __restrict__ partial,
+                                                        int nChunks, int tBlocks, int hBlocks, int rowTiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* slab = lds;
+  float* dyS = slab + ((p.NF * p.FS + 3) & ~3);  // [256][Cout]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, lq = lane >> 4;
+
+  int ko[kTdsMaxTilesPerWave];
+  bool one[kTdsMaxTilesPerWave], val[kTdsMaxTilesPerWave];
+#pragma unroll
+  for (int tl = 0; tl < kTdsMaxTilesPerWave; ++tl) {
+    const int kk = 16 * (wave + 4 * tl) + i;
+    const int tap = kk / p.Cin, c = kk - tap * p.Cin;
+    val[tl] = kk < p.K;
+    one[tl] = kk == p.K;
+    ko[tl] = val[tl] ? tap * p.FS + c : 0;
+  }
+  f32x4 acc[kTdsMaxTilesPerWave][NT];
+#pragma unroll
+  for (int tl = 0; tl < kTdsMaxTilesPerWave; ++tl)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[tl][nt][q] = 0.f;
+
+  for (int chunk = blockIdx.x; chunk < nChunks; chunk += gridDim.x) {
+    const int hb = chunk % hBlocks, tb = (chunk / hBlocks) % tBlocks, b = chunk / (hBlocks * tBlocks);
+    const int h0 = hb * kTdsBH, t0 = tb * kTdsBTF;
+    __syncthreads();  // previous chunk's fragment reads are done
+    tds_load_slab(p, slab, b, t0 * p.stride - p.padl, h0, p.NF);
+    int hc = p.H - h0;
+    if (hc > kTdsBH) hc = kTdsBH;
+    for (int e = tid; e < kTdsBTF * kTdsBH * p.Cout; e += 256) {
+      const int m = e / p.Cout, co = e - m * p.Cout;
+      const int t = m >> 4, h = m & 15;
+      float v = 0.f;
+      if (t0 + t < p.Tout && h < hc) v = dy[(((size_t)b * p.Tout + t0 + t) * p.H + h0 + h) * p.Cout + co];
+      dyS[e] = v;
+    }
+    __syncthreads();
+    for (int kq = 0; kq < kTdsBTF * kTdsBH / 4; ++kq) {
+      const int m = 4 * kq + lq;
+      const int rowoff = (m >> 4) * p.stride * p.FS + (m & 15) * p.Cin;
+      float bf[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bf[nt] = (16 * nt + i < p.Cout) ? dyS[m * p.Cout + 16 * nt + i] : 0.f;
+#pragma unroll
+      for (int tl = 0; tl < kTdsMaxTilesPerWave; ++tl) {
+        if (wave + 4 * tl < rowTiles) {  // wave-uniform
+          float a = slab[rowoff + ko[tl]];
+          a = one[tl] ? 1.f : (val[tl] ? a : 0.f);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[tl][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[nt], acc[tl][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float* dst = partial + (size_t)blockIdx.x * rowTiles * 16 * (16 * NT);
+#pragma unroll
+  for (int tl = 0; tl < kTdsMaxTilesPerWave; ++tl) {
+    const int tile = wave + 4 * tl;
+    if (tile < rowTiles) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[(size_t)(tile * 16 + 4 * lq + q) * (16 * NT) + 16 * nt + i] = acc[tl][nt][q];
+    }
+  }
+}
+
+// dw[kk][co] = sum_g partial[g][kk][co] ; dbias[co] = row K
+__global__ __launch_bounds__(256) void tds_conv_filter_reduce_k(const float* __restrict__ partial, int nParts, int rows, int ncp,
+                                                               int K, int Cout, float* __restrict__ dw, float* __restrict__ dbias) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= (K + 1) * Cout) return;
+  const int kk = e / Cout, co = e - kk * Cout;
+  float s = 0.f;
+  for (int g = 0; g < nParts; ++g) s += partial[((size_t)g * rows + kk) * ncp + co];
+  if (kk < K) dw[e] = s;
+  else if (dbias) dbias[co] = s;
+}
+
+float* sk_scratch(hipStream_t s, size_t bytes);
+
+static inline int tds_out_len(int T, int kw, int stride, int padl, int padr) {
+  int n = T + padl + padr - kw;
+  return n < 0 ? 0 : n / stride + 1;
+}
+
+bool tds_conv_applicable(const w2l_conv_desc* d) {
+  return d->Cout <= 32 && d->Cin <= 32 && d->kw * d->Cin + 1 <= 16 * 4 * kTdsMaxTilesPerWave;
+}
+
+static TdsConvP make_p(int B, int Tin, int Tout, int H, int Cin, int Cout, int kw, int stride, int padl, int bt) {
+  TdsConvP p{};
+  p.B = B; p.Tin = Tin; p.Tout = Tout; p.H = H; p.Cin = Cin; p.Cout = Cout; p.kw = kw; p.stride = stride; p.padl = padl;
+  p.K = kw * Cin;
+  p.Kp = (p.K + 3) & ~3;
+  p.FS = kTdsBH * Cin + 4;
+  p.NF = (bt - 1) * stride + kw;
+  return p;
+}
+
+static size_t fwd_lds_bytes(const TdsConvP& p) {
+  size_t slab = (size_t)p.NF * p.FS;
+  const size_t outS = (size_t)kTdsBT * kTdsBH * p.Cout;
+  if (outS > slab) slab = outS;
+  slab = (slab + 3) & ~(size_t)3;
+  const size_t ws = ((size_t)p.Kp * p.Cout + 3) & ~(size_t)3;
+  return (slab + ws + p.Kp) * sizeof(float);
+}
+
+static int launch_fwd(const TdsConvP& p, hipStream_t s) {
+  const size_t shmem = fwd_lds_bytes(p);
+  if (shmem > 160 * 1024) return W2L_EUNSUPPORTED;
+  dim3 grid((unsigned)((p.H + kTdsBH - 1) / kTdsBH), (unsigned)((p.Tout + kTdsBT - 1) / kTdsBT), (unsigned)p.B);
+  const double flops = 2.0 * p.B * p.Tout * (double)p.H * p.K * p.Cout;
+  prof_begin(s, flops);
+  if (p.Cout <= 16) {
+    if (shmem > 64 * 1024) W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_fwd_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(tds_conv_fwd_k<1>, grid, dim3(256), shmem, s, p);
+  } else {
+    if (shmem > 64 * 1024) W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_fwd_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(tds_conv_fwd_k<2>, grid, dim3(256), shmem, s, p);
+  }
+  prof_end(s);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+int tds_conv_forward(const w2l_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int relu,
+                     hipStream_t s) {
+  const int To = tds_out_len(d->T, d->kw, d->stride, d->padl, d->padr);
+  TdsConvP p = make_p(d->B, d->T, To, d->H, d->Cin, d->Cout, d->kw, d->stride, d->padl, kTdsBT);
+  p.x = x; p.w = w; p.bias = bias; p.y = y; p.relu = relu;
+  p.CinW = d->Cin; p.CoutW = d->Cout;
+  return launch_fwd(p, s);
+}
+
+// stride 1 only: dx = conv(dy, flipped W^T) with left padding kw-1-padl; dx = add + conv (add may be null)
+int tds_conv_backward_data(const w2l_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate,
+                           const float* add, hipStream_t s) {
+  if (d->stride != 1) return W2L_EUNSUPPORTED;
+  const int To = tds_out_len(d->T, d->kw, 1, d->padl, d->padr);
+  TdsConvP p = make_p(d->B, To, d->T, d->H, d->Cout, d->Cin, d->kw, 1, d->kw - 1 - d->padl, kTdsBT);
+  p.x = dy; p.w = w; p.y = dx; p.accum = accumulate; p.add = add; p.flip = 1;
+  p.CinW = d->Cin; p.CoutW = d->Cout;
+  return launch_fwd(p, s);
+}
+
+int tds_conv_backward_filter(const w2l_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                             hipStream_t s) {
+  const int To = tds_out_len(d->T, d->kw, d->stride, d->padl, d->padr);
+  TdsConvP p = make_p(d->B, d->T, To, d->H, d->Cin, d->Cout, d->kw, d->stride, d->padl, kTdsBTF);
+  p.x = x;
+  const int rowTiles = (p.K + 1 + 15) / 16;
+  if (rowTiles > 4 * kTdsMaxTilesPerWave) return W2L_EUNSUPPORTED;
+  const int NT = d->Cout <= 16 ? 1 : 2;
+  const int tBlocks = (To + kTdsBTF - 1) / kTdsBTF, hBlocks = (d->H + kTdsBH - 1) / kTdsBH;
+  const int nChunks = d->B * tBlocks * hBlocks;
+  int blocks = nChunks < 512 ? nChunks : 512;
+  const size_t shmem = ((((size_t)p.NF * p.FS + 3) & ~(size_t)3) + (size_t)kTdsBTF * kTdsBH * p.Cout) * sizeof(float);
+  if (shmem > 160 * 1024) return W2L_EUNSUPPORTED;
+  const size_t partFloats = (size_t)blocks * rowTiles * 16 * 16 * NT;
+  // partial sums live in the library's per-stream scratch (shared with the stream-K slabs: same stream => ordered)
+  float* partial = sk_scratch(s, (size_t)kSkSlots * 2 * kSlabFloats * sizeof(float));
+  if (!partial || partFloats > (size_t)kSkSlots * 2 * kSlabFloats) return W2L_EUNSUPPORTED;
+  const double flops = 2.0 * d->B * To * (double)d->H * p.K * d->Cout;
+  prof_begin(s, flops);
+  if (NT == 1) {
+    if (shmem > 64 * 1024) W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_filter_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(tds_conv_filter_k<1>, dim3((unsigned)blocks), dim3(256), shmem, s, p, dy, partial, nChunks, tBlocks, hBlocks, rowTiles);
+  } else {
+    if (shmem > 64 * 1024) W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_filter_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(tds_conv_filter_k<2>, dim3((unsigned)blocks), dim3(256), shmem, s, p, dy, partial, nChunks, tBlocks, hBlocks, rowTiles);
+  }
+  const int n = (p.K + 1) * d->Cout;
+  hipLaunchKernelGGL(tds_conv_filter_reduce_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, partial, blocks, rowTiles * 16,
+                     16 * NT, p.K, d->Cout, dw, dbias);
+  prof_end(s);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+}  // namespace w2l

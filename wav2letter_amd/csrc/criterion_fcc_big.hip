@@ -19,11 +19,15 @@
 //     EAp[tile of 32 rows][chunk of 8 k][lane][4]  (lane = row%32 + 32*h holds k = 8c+4h+q)
 // so a wavefront's global_load_dwordx4 is one fully coalesced 1 KiB burst that lands in
 // registers already in fragment layout -- no LDS staging, no transposition, no im2col.
-// Per step: kernel 1 (`fcc_big_gemm`: 64 rows x 1/(4 SW) of K per wave, 4-wave LDS
-// reduction, deterministic partial slabs) and kernel 2 (`fcc_big_step`: one workgroup per
-// utterance adds the SW slabs, takes log, adds x_t and rowmax, renormalises by the exact
-// maximum and emits E both plain (for backward) and packed (for the next step)).  A kernel
-// boundary (~1.5-2 us) is cheaper than a grid barrier (4-7 us) on this chip.
+// Per step: kernel 1 (`fcc_big_gemm`: 64 rows x 1/(4 SW) of K per wave, two register sets
+// in ping-pong so a stage's loads stay in flight behind the previous stage's MFMAs, 4-wave
+// LDS reduction, deterministic partial slabs) and kernel 2 (`fcc_big_step`, 8 workgroups per
+// utterance: adds the SW slabs, takes log, adds x_t and rowmax, stores the un-normalised
+// a_t = alpha_t - C_{t-1} plain (for backward) and packed (for the next step) plus the
+// workgroup's maximum).  The exact per-utterance maximum c_t = max of the 8 partial maxima is
+// applied by the NEXT kernel 1 while it builds its operand fragments (E = exp(a_t - c_t): one
+// v_exp per MFMA, free beside the matrix pipe), so no step ever waits on a 32-workgroup
+// reduction.  A kernel boundary (~1.5-2 us) is cheaper than a grid barrier (4-7 us) here.
 //
 // Backward streams the transposed pack EATp the same way:
 //     dalpha_{t-1}[b][j] = e_{t-1}[b][j] * sum_i r_t[b][i] EA[i][j],  r_t = dalpha_t / s_t
@@ -35,8 +39,9 @@ namespace w2l {
 
 constexpr int kBigU = 4;          // chunks (of 8 k) per pipeline stage -> K padded to 32
 constexpr int kBigMaxNB = 4;      // utterance tiles of 32 -> B <= 128
-constexpr int kBigStepThreads = 1024;
-constexpr int kBigMaxQuads = 8;   // quads of 4 labels per thread in fcc_big_step -> N <= 32768
+constexpr int kBigStepThreads = 1024;  // per-utterance kernels that run once per call
+constexpr int kBigParts = 16;          // workgroups (partial maxima) per utterance and step
+constexpr int kBigMaxSW = 16;          // K splits at workgroup level (partial slabs)
 
 struct BigDims {
   int B, T, N;
@@ -59,12 +64,22 @@ __host__ __device__ inline BigDims big_dims(int B, int T, int N) {
   d.NB = nb <= 1 ? 1 : (nb <= 2 ? 2 : 4);
   d.Bp = 32 * d.NB;
   d.G = d.Np / 64;
-  // workgroups = G * SW should cover the 256 CUs 2-3 times; every wave needs >= 1 stage
-  int sw = (640 + d.G - 1) / d.G;
+  // workgroups = G * SW: as close as possible below a multiple of the 256 CUs (a grid of 3.07
+  // workgroups per CU runs 4 rounds: measured 96 us vs 80 us at 4.9 per CU), at most 5 per CU,
+  // and every wave needs at least one pipeline stage
   int maxsw = d.NC / kBigU / 4;
-  if (sw > maxsw) sw = maxsw;
-  if (sw < 1) sw = 1;
-  if (sw > 16) sw = 16;
+  if (maxsw > kBigMaxSW) maxsw = kBigMaxSW;
+  if (maxsw < 1) maxsw = 1;
+  int sw = 1;
+  double best = -1.0;
+  for (int c = 1; c <= maxsw; ++c) {
+    const int wgs = d.G * c;
+    if (wgs > 1280 && c > 1) break;
+    const int rounds = (wgs + 255) / 256;
+    double eff = (double)wgs / (rounds * 256.0);
+    if (rounds < 4) eff *= 0.9 + 0.025 * rounds;  // few waves per SIMD hide HBM latency poorly
+    if (eff > best) { best = eff; sw = c; }
+  }
   d.SW = sw;
   return d;
 }
@@ -74,7 +89,8 @@ struct BigWs {
   float* pack;    // [Np * Kp] EAp (forward) / EATp (backward)
   float* ep[2];   // [Bp * Kp] packed E / R operand, double-buffered over t
   float* part;    // [SW][Bp][Np] partial sums of one step
-  float* e;       // [T][B][N]  e_t = exp(ahat_t)
+  float* e;       // [T][B][N]  a_t = alpha_t - C_{t-1} (forward); overwritten by e_t = exp(a_t - c_t) in backward
+  float* pmax;    // [T][B][kBigParts] partial maxima of a_t
   float* invs;    // [T][B][N]  1 / s_t
   float* rg;      // [T][B][N]  g_b * r_t (backward)
   double* cacc;   // [B] running sum of the per-step maxima
@@ -94,6 +110,7 @@ __host__ __device__ inline BigWs big_ws(void* ws, const BigDims& d) {
   w.ep[1] = (float*)take((size_t)d.Bp * d.Kp * sizeof(float));
   w.part = (float*)take((size_t)d.SW * d.Bp * d.Np * sizeof(float));
   w.e = (float*)take(btn);
+  w.pmax = (float*)take((size_t)d.T * d.B * kBigParts * sizeof(float));
   w.invs = (float*)take(btn);
   w.rg = (float*)take(btn);
   w.cacc = (double*)take((size_t)d.B * sizeof(double));
@@ -140,10 +157,52 @@ __global__ __launch_bounds__(256) void big_pack_k(int N, int NC, size_t total4, 
 }
 
 // ------------------------------------------------------------------ kernel 1: the streaming GEMM
-// part[sw][b][r] = sum_{k in split} op[b][k] * pack[r][k]   for the 64 rows of group g.
+// part[sw][b][r] = sum_{k in split} f(op[b][k]) * pack[r][k]   for the 64 rows of group g,
+// f = exp(. - c_b) in the forward recursion (EXPOP), identity in the backward one.
 template <int NB>
+struct BigStage {
+  float4 a0[kBigU], a1[kBigU], e[NB][kBigU];
+};
+
+template <int NB>
+__device__ __forceinline__ void big_load_stage(BigStage<NB>& st, const float4* __restrict__ pa0,
+                                               const float4* __restrict__ pa1, const float4* __restrict__ pe, int NC, int s) {
+#pragma unroll
+  for (int u = 0; u < kBigU; ++u) {
+    const size_t c = (size_t)s * kBigU + u;
+    st.a0[u] = pa0[c * 64];
+    st.a1[u] = pa1[c * 64];
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt) st.e[bt][u] = pe[((size_t)bt * NC + c) * 64];
+  }
+}
+
+template <int NB, bool EXPOP>
+__device__ __forceinline__ void big_compute_stage(const BigStage<NB>& st, const float (&cb)[NB], f32x16 (&acc)[NB][2]) {
+#pragma unroll
+  for (int u = 0; u < kBigU; ++u) {
+    const float a0[4] = {st.a0[u].x, st.a0[u].y, st.a0[u].z, st.a0[u].w};
+    const float a1[4] = {st.a1[u].x, st.a1[u].y, st.a1[u].z, st.a1[u].w};
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt) {
+      float ev[4] = {st.e[bt][u].x, st.e[bt][u].y, st.e[bt][u].z, st.e[bt][u].w};
+      if (EXPOP) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ev[q] = __expf(ev[q] - cb[bt]);  // padding holds -inf -> 0
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc[bt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ev[q], a0[q], acc[bt][0], 0, 0, 0);
+        acc[bt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ev[q], a1[q], acc[bt][1], 0, 0, 0);
+      }
+    }
+  }
+}
+
+template <int NB, bool EXPOP>
 __global__ __launch_bounds__(256) void fcc_big_gemm(const float4* __restrict__ pack, const float4* __restrict__ op,
-                                                    float* __restrict__ part, int NC, int SW, int Np, int Bp) {
+                                                    const float* __restrict__ pmax, int B, float* __restrict__ part,
+                                                    int NC, int SW, int Np, int Bp) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][NB*2*16 regs][64 lanes]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = blockIdx.x / SW, sw = blockIdx.x - g * SW;
@@ -159,56 +218,36 @@ __global__ __launch_bounds__(256) void fcc_big_gemm(const float4* __restrict__ p
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[bt][h][r] = 0.f;
 
+  // this lane's utterance(s): b = 32 bt + (lane & 31); c_b = exact maximum of a_{t-1}[b][:]
+  float cb[NB];
+#pragma unroll
+  for (int bt = 0; bt < NB; ++bt) {
+    cb[bt] = 0.f;
+    if (EXPOP) {
+      const int b = 32 * bt + (lane & 31);
+      float m = -INFINITY;
+      if (b < B) {
+#pragma unroll
+        for (int p = 0; p < kBigParts; ++p) m = fmaxf(m, pmax[(size_t)b * kBigParts + p]);
+      } else {
+        m = 0.f;
+      }
+      cb[bt] = m;
+    }
+  }
+
   const float4* pa0 = pack + ((size_t)(2 * g) * NC) * 64 + lane;
   const float4* pa1 = pack + ((size_t)(2 * g + 1) * NC) * 64 + lane;
   const float4* pe = op + lane;
 
-  float4 ca0[kBigU], ca1[kBigU], ce[NB][kBigU];
-  float4 na0[kBigU], na1[kBigU], ne[NB][kBigU];
-  if (s0 < s1) {
-#pragma unroll
-    for (int u = 0; u < kBigU; ++u) {
-      const size_t c = (size_t)s0 * kBigU + u;
-      ca0[u] = pa0[c * 64];
-      ca1[u] = pa1[c * 64];
-#pragma unroll
-      for (int bt = 0; bt < NB; ++bt) ce[bt][u] = pe[((size_t)bt * NC + c) * 64];
-    }
-  }
-  for (int s = s0; s < s1; ++s) {
-    if (s + 1 < s1) {
-#pragma unroll
-      for (int u = 0; u < kBigU; ++u) {
-        const size_t c = (size_t)(s + 1) * kBigU + u;
-        na0[u] = pa0[c * 64];
-        na1[u] = pa1[c * 64];
-#pragma unroll
-        for (int bt = 0; bt < NB; ++bt) ne[bt][u] = pe[((size_t)bt * NC + c) * 64];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < kBigU; ++u) {
-      const float a0[4] = {ca0[u].x, ca0[u].y, ca0[u].z, ca0[u].w};
-      const float a1[4] = {ca1[u].x, ca1[u].y, ca1[u].z, ca1[u].w};
-#pragma unroll
-      for (int bt = 0; bt < NB; ++bt) {
-        const float ev[4] = {ce[bt][u].x, ce[bt][u].y, ce[bt][u].z, ce[bt][u].w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          acc[bt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ev[q], a0[q], acc[bt][0], 0, 0, 0);
-          acc[bt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ev[q], a1[q], acc[bt][1], 0, 0, 0);
-        }
-      }
-    }
-    if (s + 1 < s1) {
-#pragma unroll
-      for (int u = 0; u < kBigU; ++u) {
-        ca0[u] = na0[u];
-        ca1[u] = na1[u];
-#pragma unroll
-        for (int bt = 0; bt < NB; ++bt) ce[bt][u] = ne[bt][u];
-      }
-    }
+  // two register sets in ping-pong: the loads of stage s+1 are in flight behind the MFMAs of stage s
+  BigStage<NB> sa, sb;
+  if (s0 < s1) big_load_stage<NB>(sa, pa0, pa1, pe, NC, s0);
+  for (int s = s0; s < s1; s += 2) {
+    if (s + 1 < s1) big_load_stage<NB>(sb, pa0, pa1, pe, NC, s + 1);
+    big_compute_stage<NB, EXPOP>(sa, cb, acc);
+    if (s + 2 < s1) big_load_stage<NB>(sa, pa0, pa1, pe, NC, s + 2);
+    if (s + 1 < s1) big_compute_stage<NB, EXPOP>(sb, cb, acc);
   }
 
   // 4-wave reduction through LDS, fixed order (deterministic)
@@ -232,8 +271,9 @@ __global__ __launch_bounds__(256) void fcc_big_gemm(const float4* __restrict__ p
   }
 }
 
-// ------------------------------------------------------------------ kernel 2 (forward): one workgroup per utterance
-__device__ __forceinline__ float block_max_1024(float v, float* sm) {
+// ------------------------------------------------------------------ block reductions
+template <int THREADS>
+__device__ __forceinline__ float block_max(float v, float* sm) {
   v = wave_max(v);
   const int w = threadIdx.x >> 6;
   __syncthreads();
@@ -241,10 +281,11 @@ __device__ __forceinline__ float block_max_1024(float v, float* sm) {
   __syncthreads();
   float m = sm[0];
 #pragma unroll
-  for (int i = 1; i < kBigStepThreads / 64; ++i) m = fmaxf(m, sm[i]);
+  for (int i = 1; i < THREADS / 64; ++i) m = fmaxf(m, sm[i]);
   return m;
 }
-__device__ __forceinline__ float block_sum_1024(float v, float* sm) {
+template <int THREADS>
+__device__ __forceinline__ float block_sum(float v, float* sm) {
   v = wave_sum(v);
   const int w = threadIdx.x >> 6;
   __syncthreads();
@@ -252,7 +293,7 @@ __device__ __forceinline__ float block_sum_1024(float v, float* sm) {
   __syncthreads();
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < kBigStepThreads / 64; ++i) s += sm[i];
+  for (int i = 0; i < THREADS / 64; ++i) s += sm[i];
   return s;
 }
 
@@ -261,96 +302,108 @@ __device__ __forceinline__ size_t packed_op_index(int b, int i0, int NC) {
   return ((((size_t)(b >> 5) * NC + (i0 >> 3)) * 64) + (b & 31) + 32 * ((i0 >> 2) & 1)) * 4;
 }
 
-__global__ __launch_bounds__(kBigStepThreads) void fcc_big_step(BigDims d, int t, int scaleMode,
-                                                               const float* __restrict__ x,
-                                                               const int* __restrict__ targetSize,
-                                                               float* __restrict__ loss, BigWs ws) {
-  __shared__ float sm[kBigStepThreads / 64];
-  const int b = blockIdx.x;
-  const int N = d.N;
-  const float* xr = x + ((size_t)b * d.T + t) * N;
-  float* er = ws.e + ((size_t)t * d.B + b) * N;
-  float* ir = ws.invs + ((size_t)t * d.B + b) * N;
-  float* epk = ws.ep[t & 1];
-  float a[kBigMaxQuads][4], sv[kBigMaxQuads][4];
-  float m = -INFINITY;
+__device__ __forceinline__ float big_cmax(const float* __restrict__ pmax, int B, int t, int b) {
+  const float* p = pmax + ((size_t)t * B + b) * kBigParts;
+  float m = p[0];
 #pragma unroll
-  for (int k = 0; k < kBigMaxQuads; ++k) {
-    const int i0 = 4 * (threadIdx.x + kBigStepThreads * k);
+  for (int q = 1; q < kBigParts; ++q) m = fmaxf(m, p[q]);
+  return m;
+}
+
+// ------------------------------------------------------------------ kernel 2 (forward)
+// grid (kBigParts, B): a_t[b][i] = x_t[b][i] + rowmax_i + log(sum_s part[s][b][i])   (t = 0: x_0)
+__global__ __launch_bounds__(256) void fcc_big_step(BigDims d, int t, const float* __restrict__ x, BigWs ws) {
+  __shared__ float sm[4];
+  const int b = blockIdx.y, N = d.N;
+  const int quads = (N + 3) >> 2;
+  const int qPer = (quads + kBigParts - 1) / kBigParts;
+  const int q0 = blockIdx.x * qPer, q1 = min(quads, q0 + qPer);
+  const float* xr = x + ((size_t)b * d.T + t) * N;
+  float* ar = ws.e + ((size_t)t * d.B + b) * N;
+  float* ir = ws.invs + ((size_t)t * d.B + b) * N;
+  float* apk = ws.ep[t & 1];
+  float m = -INFINITY;
+  for (int q = q0 + threadIdx.x; q < q1; q += 256) {
+    const int i0 = 4 * q;
     float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t > 0 && i0 < N)
-      for (int s = 0; s < d.SW; ++s) {
-        const float4 p4 = *(const float4*)(ws.part + ((size_t)s * d.Bp + b) * d.Np + i0);
-        s4.x += p4.x; s4.y += p4.y; s4.z += p4.z; s4.w += p4.w;
-      }
+    if (t > 0) {
+      float4 p4[kBigMaxSW];  // all slab loads in flight together, added in slab order
+#pragma unroll
+      for (int s = 0; s < kBigMaxSW; ++s)
+        p4[s] = s < d.SW ? *(const float4*)(ws.part + ((size_t)s * d.Bp + b) * d.Np + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int s = 0; s < kBigMaxSW; ++s) { s4.x += p4[s].x; s4.y += p4[s].y; s4.z += p4[s].z; s4.w += p4[s].w; }
+    }
     const float ssum[4] = {s4.x, s4.y, s4.z, s4.w};
+    float a4[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + u;
-      float v = -INFINITY, sc = 1.f;
+      float v = -INFINITY;  // padding labels: exp(-inf - c) = 0 in the next operand
       if (i < N) {
         v = xr[i];
         if (t > 0) {
-          sc = fmaxf(ssum[u], 1e-37f);
+          const float sc = fmaxf(ssum[u], 1e-37f);
           v += ws.rm[i] + __logf(sc);
+          ir[i] = 1.f / sc;
         }
+        ar[i] = v;
       }
-      a[k][u] = v;
-      sv[k][u] = sc;
+      a4[u] = v;
       m = fmaxf(m, v);
     }
+    *(float4*)(apk + packed_op_index(b, i0, d.NC)) = make_float4(a4[0], a4[1], a4[2], a4[3]);
   }
-  const float c = block_max_1024(m, sm);
-  float tot = 0.f;
-#pragma unroll
-  for (int k = 0; k < kBigMaxQuads; ++k) {
-    const int i0 = 4 * (threadIdx.x + kBigStepThreads * k);
-    if (i0 < N) {
-      float e4[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u;
-        e4[u] = i < N ? __expf(a[k][u] - c) : 0.f;
-        tot += e4[u];
-        if (i < N) {
-          er[i] = e4[u];
-          ir[i] = 1.f / sv[k][u];
-        }
-      }
-      *(float4*)(epk + packed_op_index(b, i0, d.NC)) = make_float4(e4[0], e4[1], e4[2], e4[3]);
-    }
-  }
+  m = block_max<256>(m, sm);
+  if (threadIdx.x == 0) ws.pmax[((size_t)t * d.B + b) * kBigParts + blockIdx.x] = m;
+}
+
+// once per call: loss[b] = scale * (sum_t c_t + log sum_i exp(a_{T-1}[i] - c_{T-1}))
+__global__ __launch_bounds__(kBigStepThreads) void fcc_big_loss(BigDims d, int scaleMode, const int* __restrict__ targetSize,
+                                                               float* __restrict__ loss, BigWs ws) {
+  __shared__ float sm[kBigStepThreads / 64];
+  __shared__ double smd[kBigStepThreads / 64];
+  const int b = blockIdx.x, N = d.N, T = d.T;
   double C = 0.0;
+  for (int t = threadIdx.x; t < T; t += kBigStepThreads) C += (double)big_cmax(ws.pmax, d.B, t, b);
+  C = wave_sum_f64(C);
+  if ((threadIdx.x & 63) == 0) smd[threadIdx.x >> 6] = C;
+  __syncthreads();
+  C = 0.0;
+  for (int i = 0; i < kBigStepThreads / 64; ++i) C += smd[i];
+  const float c = big_cmax(ws.pmax, d.B, T - 1, b);
+  const float* ar = ws.e + ((size_t)(T - 1) * d.B + b) * N;
+  float tot = 0.f;
+  for (int i = threadIdx.x; i < N; i += kBigStepThreads) tot += __expf(ar[i] - c);
+  tot = block_sum<kBigStepThreads>(tot, sm);
   if (threadIdx.x == 0) {
-    C = (t > 0 ? ws.cacc[b] : 0.0) + (double)c;
-    ws.cacc[b] = C;
-  }
-  if (t == d.T - 1) {
-    tot = block_sum_1024(tot, sm);
-    if (threadIdx.x == 0) {
-      const float sc = scale_of(scaleMode, d.T, targetSize[b]);
-      loss[b] = (float)((double)sc * (C + (double)__logf(tot)));
-      ws.scale[b] = sc;
-    }
+    const float sc = scale_of(scaleMode, T, targetSize[b]);
+    loss[b] = (float)((double)sc * (C + (double)__logf(tot)));
+    ws.scale[b] = sc;
   }
 }
 
 // ------------------------------------------------------------------ backward kernels
-// t = T-1: dalpha = softmax(ahat_{T-1}) = e / sum e ; emits dx, g*r (plain) and r (packed)
+// t = T-1: dalpha = softmax(a_{T-1}); converts a -> e in place; emits dx, g*r (plain) and r (packed)
 __global__ __launch_bounds__(kBigStepThreads) void fcc_big_bwd_init(BigDims d, const float* __restrict__ grad,
                                                                    float* __restrict__ dx, BigWs ws) {
   __shared__ float sm[kBigStepThreads / 64];
   const int b = blockIdx.x, N = d.N, t = d.T - 1;
-  const float* er = ws.e + ((size_t)t * d.B + b) * N;
+  float* er = ws.e + ((size_t)t * d.B + b) * N;
   const float* ir = ws.invs + ((size_t)t * d.B + b) * N;
   float* dxr = dx + ((size_t)b * d.T + t) * N;
   float* rgr = ws.rg + ((size_t)t * d.B + b) * N;
   float* rpk = ws.ep[t & 1];
   const float g = ws.scale[b] * grad[b];
   if (threadIdx.x == 0) ws.gb[b] = g;
+  const float c = big_cmax(ws.pmax, d.B, t, b);
   float tot = 0.f;
-  for (int i = threadIdx.x; i < N; i += kBigStepThreads) tot += er[i];
-  tot = block_sum_1024(tot, sm);
+  for (int i = threadIdx.x; i < N; i += kBigStepThreads) {
+    const float e = __expf(er[i] - c);
+    er[i] = e;  // same thread re-reads it below
+    tot += e;
+  }
+  tot = block_sum<kBigStepThreads>(tot, sm);
   const float inv = 1.f / tot;
   for (int i0 = 4 * threadIdx.x; i0 < N; i0 += 4 * kBigStepThreads) {
     float r4[4];
@@ -371,20 +424,26 @@ __global__ __launch_bounds__(kBigStepThreads) void fcc_big_bwd_init(BigDims d, c
   }
 }
 
-// step t -> t-1 (tm = t-1): dalpha_tm[b][j] = e_tm[b][j] * sum_s part[s][b][j]
+// step t -> t-1 (tm = t-1): e_tm = exp(a_tm - c_tm) (stored in place);
+// dalpha_tm[b][j] = e_tm[b][j] * sum_s part[s][b][j]
 __global__ __launch_bounds__(256) void fcc_big_bwd_step(BigDims d, int tm, float* __restrict__ dx, BigWs ws) {
   const int b = blockIdx.y, N = d.N;
   const int i0 = 4 * (blockIdx.x * 256 + threadIdx.x);
   if (i0 >= N) return;
   const float g = ws.gb[b];
-  const float* er = ws.e + ((size_t)tm * d.B + b) * N;
+  const float c = big_cmax(ws.pmax, d.B, tm, b);
+  float* er = ws.e + ((size_t)tm * d.B + b) * N;
   const float* ir = ws.invs + ((size_t)tm * d.B + b) * N;
   float* dxr = dx + ((size_t)b * d.T + tm) * N;
   float* rgr = ws.rg + ((size_t)tm * d.B + b) * N;
   float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int s = 0; s < d.SW; ++s) {
-    const float4 p4 = *(const float4*)(ws.part + ((size_t)s * d.Bp + b) * d.Np + i0);
-    s4.x += p4.x; s4.y += p4.y; s4.z += p4.z; s4.w += p4.w;
+  {
+    float4 p4[kBigMaxSW];
+#pragma unroll
+    for (int s = 0; s < kBigMaxSW; ++s)
+      p4[s] = s < d.SW ? *(const float4*)(ws.part + ((size_t)s * d.Bp + b) * d.Np + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int s = 0; s < kBigMaxSW; ++s) { s4.x += p4[s].x; s4.y += p4[s].y; s4.z += p4[s].z; s4.w += p4[s].w; }
   }
   const float D[4] = {s4.x, s4.y, s4.z, s4.w};
   float r4[4];
@@ -393,7 +452,9 @@ __global__ __launch_bounds__(256) void fcc_big_bwd_step(BigDims d, int tm, float
     const int i = i0 + u;
     r4[u] = 0.f;
     if (i < N) {
-      const float da = er[i] * D[u];
+      const float e = __expf(er[i] - c);
+      er[i] = e;
+      const float da = e * D[u];
       dxr[i] = g * da;
       if (tm > 0) {
         r4[u] = da * ir[i];
@@ -414,23 +475,25 @@ __global__ __launch_bounds__(256) void fcc_big_scale_dtrans(int N, const float* 
   }
 }
 
-template <int NB>
-static int launch_big_gemm(const BigDims& d, const float* pack, const float* op, float* part, hipStream_t s) {
+template <int NB, bool EXPOP>
+static int launch_big_gemm(const BigDims& d, const float* pack, const float* op, const float* pmax, float* part,
+                           hipStream_t s) {
   const size_t shmem = (size_t)4 * NB * 2 * 16 * 64 * sizeof(float);
-  hipLaunchKernelGGL((fcc_big_gemm<NB>), dim3((unsigned)(d.G * d.SW)), dim3(256), shmem, s, (const float4*)pack,
-                     (const float4*)op, part, d.NC, d.SW, d.Np, d.Bp);
+  hipLaunchKernelGGL((fcc_big_gemm<NB, EXPOP>), dim3((unsigned)(d.G * d.SW)), dim3(256), shmem, s, (const float4*)pack,
+                     (const float4*)op, pmax, d.B, part, d.NC, d.SW, d.Np, d.Bp);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }
-static int big_gemm(const BigDims& d, const float* pack, const float* op, float* part, hipStream_t s) {
-  if (d.NB == 1) return launch_big_gemm<1>(d, pack, op, part, s);
-  if (d.NB == 2) return launch_big_gemm<2>(d, pack, op, part, s);
-  return launch_big_gemm<4>(d, pack, op, part, s);
+template <bool EXPOP>
+static int big_gemm(const BigDims& d, const float* pack, const float* op, const float* pmax, float* part, hipStream_t s) {
+  if (d.NB == 1) return launch_big_gemm<1, EXPOP>(d, pack, op, pmax, part, s);
+  if (d.NB == 2) return launch_big_gemm<2, EXPOP>(d, pack, op, pmax, part, s);
+  return launch_big_gemm<4, EXPOP>(d, pack, op, pmax, part, s);
 }
 
 bool fcc_big_supported(int B, int T, int N) {
   (void)T;
-  return B <= 32 * kBigMaxNB && N <= 4 * kBigStepThreads * kBigMaxQuads && N >= 64;
+  return B <= 32 * kBigMaxNB && N >= 64 && N <= (1 << 20);
 }
 
 size_t fcc_big_workspace_size(int B, int T, int N) {
@@ -449,6 +512,11 @@ static int big_pack(const BigDims& d, const BigWs& ws, const float* trans, bool 
   return W2L_OK;
 }
 
+// packed operand buffers: forward operand a (padding must read as -inf -> exp = 0), backward r (padding 0)
+__global__ __launch_bounds__(256) void big_fill_k(float* __restrict__ p, size_t n, float v) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) p[e] = v;
+}
+
 int fcc_big_forward(int B, int T, int N, int scaleMode, const float* input, const int* targetSize,
                     const float* trans, float* loss, void* workspace, hipStream_t s) {
   const BigDims d = big_dims(B, T, N);
@@ -457,17 +525,20 @@ int fcc_big_forward(int B, int T, int N, int scaleMode, const float* input, cons
   W2L_LAUNCH_CHECK();
   int st = big_pack(d, ws, trans, false, s);
   if (st) return st;
-  // padded utterances / labels of the packed operand must read as zero
-  W2L_HIP_CHECK(hipMemsetAsync(ws.ep[0], 0, 2 * align_up((size_t)d.Bp * d.Kp * sizeof(float), 256), s));
+  const size_t opFloats = 2 * align_up((size_t)d.Bp * d.Kp * sizeof(float), 256) / sizeof(float);
+  hipLaunchKernelGGL(big_fill_k, dim3(512), dim3(256), 0, s, ws.ep[0], opFloats, -INFINITY);
+  W2L_LAUNCH_CHECK();
+  const dim3 sgrid(kBigParts, (unsigned)B);
   for (int t = 0; t < T; ++t) {
     if (t > 0) {
-      st = big_gemm(d, ws.pack, ws.ep[(t - 1) & 1], ws.part, s);
+      st = big_gemm<true>(d, ws.pack, ws.ep[(t - 1) & 1], ws.pmax + (size_t)(t - 1) * B * kBigParts, ws.part, s);
       if (st) return st;
     }
-    hipLaunchKernelGGL(fcc_big_step, dim3((unsigned)B), dim3(kBigStepThreads), 0, s, d, t, scaleMode, input, targetSize,
-                       loss, ws);
+    hipLaunchKernelGGL(fcc_big_step, sgrid, dim3(256), 0, s, d, t, input, ws);
     W2L_LAUNCH_CHECK();
   }
+  hipLaunchKernelGGL(fcc_big_loss, dim3((unsigned)B), dim3(kBigStepThreads), 0, s, d, scaleMode, targetSize, loss, ws);
+  W2L_LAUNCH_CHECK();
   return W2L_OK;
 }
 
@@ -482,7 +553,7 @@ int fcc_big_backward(int B, int T, int N, const float* trans, const float* grad,
   W2L_LAUNCH_CHECK();
   const dim3 sgrid((unsigned)((N + 1023) / 1024), (unsigned)B);
   for (int t = T - 1; t >= 1; --t) {
-    st = big_gemm(d, ws.pack, ws.ep[t & 1], ws.part, s);
+    st = big_gemm<false>(d, ws.pack, ws.ep[t & 1], nullptr, ws.part, s);
     if (st) return st;
     hipLaunchKernelGGL(fcc_big_bwd_step, sgrid, dim3(256), 0, s, d, t - 1, inputGrad, ws);
     W2L_LAUNCH_CHECK();

@@ -4,6 +4,13 @@
 
 #include "common.hpp"
 
+#ifndef W2L_MIDSTORE
+#define W2L_MIDSTORE 0
+#endif
+#ifndef W2L_BRANCHFREE
+#define W2L_BRANCHFREE 0
+#endif
+
 namespace w2l {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -35,6 +42,50 @@ struct PlainOp {
   static constexpr int kPad = KCONTIG ? 1 : 4;
   static constexpr int kPadSkinny = KCONTIG ? 2 : 4;
 
+  // Fast path of the 128x128x32 main loop: per-thread source pointers are computed ONCE per tile with
+  // out-of-range rows / columns CLAMPED to valid ones (their products only reach accumulator rows /
+  // columns that the epilogue never stores), so full K tiles load unconditionally -- no per-load
+  // branches, selects or 64-bit multiplies between the MFMAs.  Only a ragged last K tile zero-fills.
+  static constexpr bool kFast = true;
+  static constexpr int kNP = 16 / V;
+  struct Ptrs { const float* q[kNP]; };
+  __device__ __forceinline__ void init(Ptrs& P, int i0, int tid) const {
+    if (KCONTIG) {
+      constexpr int TPR = 32 / V, RPP = 256 / TPR;
+      const int kc = (tid % TPR) * V, rr = tid / TPR;
+#pragma unroll
+      for (int j = 0; j < kNP; ++j) {
+        int gi = i0 + rr + RPP * j;
+        if (gi > extent - 1) gi = extent - 1;
+        P.q[j] = p + (size_t)gi * ld + kc;
+      }
+    } else {
+      constexpr int TPR = 128 / V, RPP = 256 / TPR;
+      const int kr = tid / TPR;
+      int gi = i0 + (tid % TPR) * V;
+      if (gi > extent - V) gi = extent - V;  // V > 1 implies extent % V == 0 (pick_vec): stays aligned
+      if (gi < 0) gi = 0;
+#pragma unroll
+      for (int j = 0; j < kNP; ++j) P.q[j] = p + (size_t)(kr + RPP * j) * ld + gi;
+    }
+  }
+  __device__ __forceinline__ void load_fast(float (&r)[16], const Ptrs& P, int k0) const {
+    const size_t off = KCONTIG ? (size_t)k0 : (size_t)k0 * ld;
+#pragma unroll
+    for (int j = 0; j < kNP; ++j) {
+      const float* src = P.q[j] + off;
+      if (V == 4) {
+        float4 v = *(const float4*)src;
+        r[4 * j] = v.x; r[4 * j + 1] = v.y; r[4 * j + 2] = v.z; r[4 * j + 3] = v.w;
+      } else if (V == 2) {
+        float2 v = *(const float2*)src;
+        r[2 * j] = v.x; r[2 * j + 1] = v.y;
+      } else {
+        r[j] = *src;
+      }
+    }
+  }
+
   template <int BI, int BK>
   __device__ __forceinline__ void load_t(float (&r)[16], int i0, int k0, int tid) const {
     static_assert(BI * BK == 4096, "16 floats per thread");
@@ -48,15 +99,17 @@ struct PlainOp {
       for (int j = 0; j < NP; ++j) {
         const int gi = i0 + rr + RPP * j, gk = k0 + kc;
         const bool ok = gi < extent && gk < K;
-        const float* src = p + (size_t)gi * ld + gk;
+        // branch-free guard: load from a clamped (always valid) address, then select zero
+        const float* src = p + (size_t)((ok || !W2L_BRANCHFREE) ? gi : 0) * ld + ((ok || !W2L_BRANCHFREE) ? gk : 0);
         if (V == 4) {
-          float4 v = ok ? *(const float4*)src : make_float4(0.f, 0.f, 0.f, 0.f);
-          r[4 * j] = v.x; r[4 * j + 1] = v.y; r[4 * j + 2] = v.z; r[4 * j + 3] = v.w;
+          float4 v = (W2L_BRANCHFREE || ok) ? *(const float4*)src : make_float4(0.f, 0.f, 0.f, 0.f);
+          r[4 * j] = ok ? v.x : 0.f; r[4 * j + 1] = ok ? v.y : 0.f; r[4 * j + 2] = ok ? v.z : 0.f; r[4 * j + 3] = ok ? v.w : 0.f;
         } else if (V == 2) {
-          float2 v = ok ? *(const float2*)src : make_float2(0.f, 0.f);
-          r[2 * j] = v.x; r[2 * j + 1] = v.y;
+          float2 v = (W2L_BRANCHFREE || ok) ? *(const float2*)src : make_float2(0.f, 0.f);
+          r[2 * j] = ok ? v.x : 0.f; r[2 * j + 1] = ok ? v.y : 0.f;
         } else {
-          r[j] = ok ? *src : 0.f;
+          const float v = (W2L_BRANCHFREE || ok) ? *src : 0.f;
+          r[j] = ok ? v : 0.f;
         }
       }
     } else {
@@ -69,15 +122,16 @@ struct PlainOp {
       for (int j = 0; j < NP; ++j) {
         const int gi = i0 + ic, gk = k0 + kr + RPP * j;
         const bool ok = gi < extent && gk < K;
-        const float* src = p + (size_t)gk * ld + gi;
+        const float* src = p + (size_t)((ok || !W2L_BRANCHFREE) ? gk : 0) * ld + ((ok || !W2L_BRANCHFREE) ? gi : 0);
         if (V == 4) {
-          float4 v = ok ? *(const float4*)src : make_float4(0.f, 0.f, 0.f, 0.f);
-          r[4 * j] = v.x; r[4 * j + 1] = v.y; r[4 * j + 2] = v.z; r[4 * j + 3] = v.w;
+          float4 v = (W2L_BRANCHFREE || ok) ? *(const float4*)src : make_float4(0.f, 0.f, 0.f, 0.f);
+          r[4 * j] = ok ? v.x : 0.f; r[4 * j + 1] = ok ? v.y : 0.f; r[4 * j + 2] = ok ? v.z : 0.f; r[4 * j + 3] = ok ? v.w : 0.f;
         } else if (V == 2) {
-          float2 v = ok ? *(const float2*)src : make_float2(0.f, 0.f);
-          r[2 * j] = v.x; r[2 * j + 1] = v.y;
+          float2 v = (W2L_BRANCHFREE || ok) ? *(const float2*)src : make_float2(0.f, 0.f);
+          r[2 * j] = ok ? v.x : 0.f; r[2 * j + 1] = ok ? v.y : 0.f;
         } else {
-          r[j] = ok ? *src : 0.f;
+          const float v = (W2L_BRANCHFREE || ok) ? *src : 0.f;
+          r[j] = ok ? v : 0.f;
         }
       }
     }
@@ -222,7 +276,7 @@ bool sk_enabled();                               // W2L_GEMM_SK=0 turns the sche
 // ---------------------------------------------------------------- kernels
 template <class AOp, class BOp>
 __device__ __forceinline__ void gemm128_mainloop(const AOp& aop, const BOp& bop, int m0, int n0, int ktBegin, int ktEnd,
-                                                 float* smem, f32x16 (&acc)[2][2]) {
+                                                 int K, float* smem, f32x16 (&acc)[2][2]) {
   constexpr int BM = 128, BN = 128, BK = 32;
   constexpr int LDA_S = BM + AOp::kPad, LDB_S = BN + BOp::kPad;
   float* As0 = smem;
@@ -243,10 +297,26 @@ __device__ __forceinline__ void gemm128_mainloop(const AOp& aop, const BOp& bop,
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float ra[16], rb[16];
+  typename AOp::Ptrs pa;
+  typename BOp::Ptrs pb;
+  // hoisted pointers pay off on long reductions (dW: +3 %, 4096^3: +2..6 %); on short K (fc1: K = 800)
+  // their per-tile set-up costs more than it saves (-3 %, within-run A/B on MI355X)
+  const bool fast = K >= 2048;
+  if (AOp::kFast && fast) aop.init(pa, m0, tid);
+  if (BOp::kFast && fast) bop.init(pb, n0, tid);
+  const int kFull = fast ? K / BK : 0;  // K tiles below this index load unconditionally
+  auto loadA = [&](int kt) {
+    if (AOp::kFast && kt < kFull) aop.load_fast(ra, pa, kt * BK);
+    else aop.load(ra, m0, kt * BK, tid);
+  };
+  auto loadB = [&](int kt) {
+    if (BOp::kFast && kt < kFull) bop.load_fast(rb, pb, kt * BK);
+    else bop.load(rb, n0, kt * BK, tid);
+  };
   __syncthreads();  // a previous segment of this workgroup may still be reading the LDS tiles
   if (ktBegin < ktEnd) {
-    aop.load(ra, m0, ktBegin * BK, tid);
-    bop.load(rb, n0, ktBegin * BK, tid);
+    loadA(ktBegin);
+    loadB(ktBegin);
     aop.store(As0, LDA_S, ra, tid);
     bop.store(Bs0, LDB_S, rb, tid);
   }
@@ -258,21 +328,46 @@ __device__ __forceinline__ void gemm128_mainloop(const AOp& aop, const BOp& bop,
     const float* As = cur ? As1 : As0;
     const float* Bs = cur ? Bs1 : Bs0;
     if (more) {
-      aop.load(ra, m0, (kt + 1) * BK, tid);
-      bop.load(rb, n0, (kt + 1) * BK, tid);
+      loadA(kt + 1);
+      loadB(kt + 1);
     }
+    // Fragments of k-pair kp+1 are read from LDS BEFORE the four MFMAs of k-pair kp are issued (two
+    // named register sets, order pinned with sched_barrier): left alone hipcc emits
+    // "ds_read; s_waitcnt lgkmcnt(0); 4 x mfma" per k-pair and the LDS latency is exposed 16 times
+    // per K tile (MFMA pipe 75 % busy at 4096^3 by rocprof PMC).
+    const float* ar = As + lh * LDA_S + wm + li;
+    const float* br = Bs + lh * LDB_S + wn + li;
+    float a0 = ar[0], a1 = ar[32], b0 = br[0], b1 = br[32];
+    float c0, c1, d0, d1;
 #pragma unroll
-    for (int kp = 0; kp < BK / 2; ++kp) {
-      const float* ar = As + (2 * kp + lh) * LDA_S + wm + li;
-      const float* br = Bs + (2 * kp + lh) * LDB_S + wn + li;
-      float a0 = ar[0], a1 = ar[32];
-      float b0 = br[0], b1 = br[32];
+    for (int kp = 0; kp < BK / 2; kp += 2) {
+      if (W2L_MIDSTORE && kp == BK / 4 && more) {
+        // the next tile's registers go to the other LDS buffer in the MIDDLE of the MFMA phase (their
+        // global loads were issued ~2000 cycles ago), so no separate write phase precedes the barrier
+        aop.store(cur ? As0 : As1, LDA_S, ra, tid);
+        bop.store(cur ? Bs0 : Bs1, LDB_S, rb, tid);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      c0 = ar[(2 * kp + 2) * LDA_S]; c1 = ar[(2 * kp + 2) * LDA_S + 32];
+      d0 = br[(2 * kp + 2) * LDB_S]; d1 = br[(2 * kp + 2) * LDB_S + 32];
+      __builtin_amdgcn_sched_barrier(0);
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kp + 2 < BK / 2) {
+        a0 = ar[(2 * kp + 4) * LDA_S]; a1 = ar[(2 * kp + 4) * LDA_S + 32];
+        b0 = br[(2 * kp + 4) * LDB_S]; b1 = br[(2 * kp + 4) * LDB_S + 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, d0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, d1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, d0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, d1, acc[1][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (more) {
+    if (!W2L_MIDSTORE && more) {
       aop.store(cur ? As0 : As1, LDA_S, ra, tid);
       bop.store(cur ? Bs0 : Bs1, LDB_S, rb, tid);
     }
@@ -328,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(AOp aop, BOp bop, GemmO
   // XCD share the same B (weight) panel in L2
   if (bid < plan.dpTiles) {
     const int bx = bid % plan.tilesM, by = bid / plan.tilesM;
-    gemm128_mainloop(aop, bop, bx * 128, by * 128, 0, plan.kTiles, smem, acc);
+    gemm128_mainloop(aop, bop, bx * 128, by * 128, 0, plan.kTiles, out.K, smem, acc);
     gemm128_epilogue(out, bx * 128, by * 128, acc);
     return;
   }
@@ -342,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(AOp aop, BOp bop, GemmO
     int ke = plan.kTiles;
     if (itEnd - it < (long long)(ke - kb)) ke = kb + (int)(itEnd - it);
     const int bx = tile % plan.tilesM, by = tile / plan.tilesM;
-    gemm128_mainloop(aop, bop, bx * 128, by * 128, kb, ke, smem, acc);
+    gemm128_mainloop(aop, bop, bx * 128, by * 128, kb, ke, out.K, smem, acc);
     if (kb == 0 && ke == plan.kTiles) gemm128_epilogue(out, bx * 128, by * 128, acc);
     else gemm128_store_partial(plan.slabs + ((size_t)s * 2 + seg) * kSlabFloats, acc);
     it += ke - kb;

@@ -599,8 +599,7 @@ class TDSLayer : public Layer {
     w2lCheck(w2l_conv_backward_filter(&d, xSaved, da, wc.g(cx), bc.g(cx), s), "tds conv bwd filter");
     if (needDx) {
       dx = ar + dxOff;
-      w2lCheck(hipMemcpyAsync(dx, dr1, n * sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess ? W2L_OK : W2L_EHIP, "tds copy");
-      w2lCheck(w2l_conv_backward_data(&d, da, wc.w(cx), dx, 1, s), "tds conv bwd data");
+      w2lCheck(w2l_conv_backward_data_add(&d, da, wc.w(cx), dr1, dx, s), "tds conv bwd data");
     }
   }
 };
