@@ -28,6 +28,7 @@ import numpy as np
 import torch
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md chip table
+PEAK_HBM_GBPS = 8000.0         # same table (6.29 TB/s measured-achievable)
 
 
 def parse():
@@ -39,6 +40,8 @@ def parse():
     ap.add_argument("--frames", type=int, default=1500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-asg", action="store_true")
+    ap.add_argument("--no-stress", action="store_true", help="skip the ASG N=9998 stress leg")
+    ap.add_argument("--stress-frames", type=int, default=1500)
     return ap.parse_args()
 
 
@@ -52,8 +55,22 @@ def make_batch(B, T, nfeat, nlabel, Lmax, seed, device):
     return x.to(device), tgt.to(device)
 
 
+def _timeit(fn, n=10, warm=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
 def asg_criterion_ms(device):
-    """ASG (FCC + FAC) forward and forward+backward at the conv_glu LibriSpeech criterion shape"""
+    """ASG (FCC + FAC) forward and forward+backward at the conv_glu LibriSpeech criterion shape
+    (BASELINE config C4: B=64/GPU, T=2000, N=30 letters, --transdiag=4, target/sqrt scaling)"""
     from wav2letter_amd import ASGLoss, CriterionScaleMode
     B, T, N, L = 64, 2000, 30, 300
     g = torch.Generator(device="cpu").manual_seed(4)
@@ -68,21 +85,58 @@ def asg_criterion_ms(device):
         tgt[b, :l] = y
     tgt = tgt.to(device)
     crit = ASGLoss(N, CriterionScaleMode.TARGET_SZ_SQRT, 4.0).to(device)
-
-    def timeit(fn, n=10):
-        fn(); torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(n):
-            fn()
-        e1.record(); torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / n
-
-    fwd = timeit(lambda: crit(x, tgt))
-    fb = timeit(lambda: crit(x, tgt).sum().backward())
+    fwd = _timeit(lambda: crit(x, tgt))
+    fb = _timeit(lambda: crit(x, tgt).sum().backward())
+    fcc_f = _timeit(lambda: crit.fcc(x, tgt))
+    fac_f = _timeit(lambda: crit.fac(x, tgt))
+    vit = _timeit(lambda: crit.viterbiPath(x.detach()))
     return {"shape": f"B={B},T={T},N={N},L<={L}", "fwd_ms": round(fwd, 4), "fwd_bwd_ms": round(fb, 4),
+            "fcc_fwd_ms": round(fcc_f, 4), "fac_fwd_ms": round(fac_f, 4), "viterbi_ms": round(vit, 4),
             "algorithmic_bytes": 16 * B * T * N, "achieved_GBps": round(16 * B * T * N / (fb * 1e-3) / 1e9, 2),
-            "note": "serial-in-T scan: latency-bound at N=30 (SURVEY 8d); HBM time would be ~10 us"}
+            "us_per_frame_fwd": round(fwd * 1e3 / T, 3),
+            "note": "T dependent steps per utterance: latency-bound at N=30 (SURVEY 8d), HBM time would be ~10 us; "
+                    "the HBM roofline is quoted on the N=9998 stress shape (asg_stress)"}
+
+
+def asg_stress(device, L, T):
+    """The north-star stress shape of the ASG alpha/beta recursion: B=32, T=1500, N=9998 word pieces.
+    The 400 MB transition matrix exceeds the 256 MiB Infinity Cache and is re-streamed at every one of the
+    T dependent steps: algorithmic bytes per step = 4 N^2 + 8 B N.  The dominant kernel
+    (fcc_big_gemm, one launch per step) is timed with HIP events on its own stream inside the library."""
+    import ctypes as C
+    from wav2letter_amd import CriterionScaleMode, FullConnectionCriterion
+    B, N = 32, 9998
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x = torch.randn(B, T, N, generator=g).to(device).requires_grad_(True)
+    tgt = torch.zeros(B, 8, dtype=torch.int32, device=device)
+    crit = FullConnectionCriterion(N, CriterionScaleMode.TARGET_SZ_SQRT).to(device)
+    crit.transitions.data = (torch.randn(N, N, generator=g) * 0.1 + 4.0 * torch.eye(N)).to(device)
+    loss = crit(x, tgt)          # warm-up (allocates the 6 GB workspace)
+    loss.sum().backward()
+    torch.cuda.synchronize()
+    L.w2l_profile_enable(1)
+    t0 = time.perf_counter()
+    loss = crit(x, tgt)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    loss.sum().backward()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    nl, ms, by = C.c_int(0), C.c_double(0), C.c_double(0)
+    L.w2l_profile_report_kind(3, C.byref(nl), C.byref(ms), C.byref(by))
+    L.w2l_profile_enable(0)
+    achieved = by.value / (ms.value * 1e-3) / 1e9 if ms.value > 0 else 0.0
+    step_bytes = 4.0 * N * N + 8.0 * B * N
+    fwd_ms, bwd_ms = (t1 - t0) * 1e3, (t2 - t1) * 1e3
+    return {"shape": f"B={B},T={T},N={N}", "fwd_ms": round(fwd_ms, 2), "bwd_ms": round(bwd_ms, 2),
+            "fwd_us_per_step": round(fwd_ms * 1e3 / T, 2),
+            "whole_forward_GBps": round(step_bytes * (T - 1) / (fwd_ms * 1e-3) / 1e9, 1),
+            "finite": bool(torch.isfinite(loss).all().item()),
+            "roofline": {"bound": "hbm", "kernel": "fcc_big_gemm (packed-transition stream, fp32 MFMA 32x32x2)",
+                         "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / PEAK_HBM_GBPS, 4), "traffic": None,
+                         "launches": nl.value, "avg_launch_us": round(ms.value * 1e3 / max(1, nl.value), 2),
+                         "algorithmic_bytes_per_launch": step_bytes}}
 
 
 def cpu_baseline(nfeat, nlabel, T):
@@ -155,8 +209,6 @@ def main():
     for _ in range(a.warmup):
         step()
     L = _lib.lib()
-    L.w2l_profile_enable.argtypes = [C.c_int]
-    L.w2l_profile_report.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -182,10 +234,15 @@ def main():
             dist.destroy_process_group()
         return
 
-    nl, ms, flops = C.c_int(0), C.c_double(0), C.c_double(0)
-    L.w2l_profile_report(C.byref(nl), C.byref(ms), C.byref(flops))
+    def kind(k):
+        n_, ms_, w_ = C.c_int(0), C.c_double(0), C.c_double(0)
+        L.w2l_profile_report_kind(k, C.byref(n_), C.byref(ms_), C.byref(w_))
+        return n_.value, ms_.value, w_.value
+    nl, ms, flops = kind(0)          # the dominant kernel: 128x128 fp32 MFMA GEMM (+ its stream-K fix-up)
+    nc, msc, flc = kind(2)           # TDS slab convolutions
+    ns, mss, fls = kind(1)           # generic skinny implicit GEMM (strided backward-data only)
     L.w2l_profile_enable(0)
-    achieved = flops.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     out = {
         "metric": "utterances/sec", "value": round(total_batch * a.steps / dt, 3), "unit": "utterances/sec",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
@@ -194,15 +251,25 @@ def main():
                                "9998 classes, batch %d/GPU, fp32, SGD+momentum, CTC" % (T, B),
                    "global_batch": total_batch, "frames": T, "emission_frames": Tout, "parallelism": f"dp{world}",
                    "params": int(tr.n_net), "final_loss": round(last_loss, 4)},
-        "roofline": {"bound": "mfma", "kernel": "gemm128_kernel / gemm_skinny_kernel (fp32 MFMA 32x32x2 / 16x16x4)",
+        "roofline": {"bound": "mfma", "kernel": "gemm128_kernel (fp32 v_mfma_f32_32x32x2_f32, 128x128x32 tiles, stream-K)",
                      "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                     "launches_per_step": nl.value // max(1, a.steps),
-                     "gemm_ms_per_step": round(ms.value / max(1, a.steps), 3),
-                     "algorithmic_tflop_per_step": round(flops.value / max(1, a.steps) / 1e12, 3)},
+                     "launches_per_step": nl // max(1, a.steps),
+                     "avg_launch_us": round(ms * 1e3 / max(1, nl), 1),
+                     "algorithmic_gflop_per_launch": round(flops / max(1, nl) / 1e9, 2),
+                     "gemm_ms_per_step": round(ms / max(1, a.steps), 3),
+                     "algorithmic_tflop_per_step": round(flops / max(1, a.steps) / 1e12, 3),
+                     "tds_conv": {"launches_per_step": nc // max(1, a.steps), "ms_per_step": round(msc / max(1, a.steps), 3),
+                                  "achieved_TFLOPs": round(flc / (msc * 1e-3) / 1e12, 2) if msc > 0 else None,
+                                  "note": "N = C_out (10/14/18) padded to 16/16/32 MFMA columns: ceiling 62.5/87.5/56 % of peak"},
+                     "skinny_gemm": {"launches_per_step": ns // max(1, a.steps), "ms_per_step": round(mss / max(1, a.steps), 3)}},
     }
     if not a.no_asg:
         out["asg_loss_ms_per_step"] = asg_criterion_ms(device)
+    if world == 1 and not a.no_stress:
+        del tr, x, tgt
+        torch.cuda.empty_cache()
+        out["asg_stress"] = asg_stress(device, L, a.stress_frames)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -222,7 +222,10 @@ int w2l_trainer_viterbi(void* h, const float* emission, int* path, void* stream)
 int w2l_trainer_set_step(void* h, uint32_t step);
 /* roofline instrumentation: bracket every MFMA GEMM launch with hipEvents on its stream */
 int w2l_profile_enable(int on);
-int w2l_profile_report(int* launches, double* totalMs, double* totalFlops);
+int w2l_profile_report(int* launches, double* totalMs, double* totalFlops); /* kind 0 */
+/* kind: 0 = 128x128 MFMA GEMM, 1 = skinny implicit GEMM, 2 = TDS slab convolution (work = FLOPs),
+ * 3 = FCC transition stream (work = algorithmic bytes), -1 = all */
+int w2l_profile_report_kind(int kind, int* launches, double* totalMs, double* totalWork);
 int w2l_arch_check(const char* archText, int nFeat, int nLabel, int* numLayers);
 int w2l_flags_check(const char* flagsText, int* numFlags);
 

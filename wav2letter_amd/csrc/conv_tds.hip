@@ -290,7 +290,7 @@ static int launch_fwd(const TdsConvP& p, hipStream_t s) {
   if (shmem > 160 * 1024) return W2L_EUNSUPPORTED;
   dim3 grid((unsigned)((p.H + kTdsBH - 1) / kTdsBH), (unsigned)((p.Tout + kTdsBT - 1) / kTdsBT), (unsigned)p.B);
   const double flops = 2.0 * p.B * p.Tout * (double)p.H * p.K * p.Cout;
-  prof_begin(s, flops);
+  prof_begin(s, flops, PROF_TDSCONV);
   if (p.Cout <= 16) {
     if (shmem > 64 * 1024) W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_fwd_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL(tds_conv_fwd_k<1>, grid, dim3(256), shmem, s, p);
@@ -341,7 +341,7 @@ int tds_conv_backward_filter(const w2l_conv_desc* d, const float* x, const float
   float* partial = sk_scratch(s, (size_t)kSkSlots * 2 * kSlabFloats * sizeof(float));
   if (!partial || partFloats > (size_t)kSkSlots * 2 * kSlabFloats) return W2L_EUNSUPPORTED;
   const double flops = 2.0 * d->B * To * (double)d->H * p.K * d->Cout;
-  prof_begin(s, flops);
+  prof_begin(s, flops, PROF_TDSCONV);
   if (NT == 1) {
     if (shmem > 64 * 1024) W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_filter_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL(tds_conv_filter_k<1>, dim3((unsigned)blocks), dim3(256), shmem, s, p, dy, partial, nChunks, tBlocks, hBlocks, rowTiles);

@@ -479,8 +479,11 @@ template <int NB, bool EXPOP>
 static int launch_big_gemm(const BigDims& d, const float* pack, const float* op, const float* pmax, float* part,
                            hipStream_t s) {
   const size_t shmem = (size_t)4 * NB * 2 * 16 * 64 * sizeof(float);
+  // algorithmic bytes of one step: the transition matrix once + read/write of one [B][N] row pair
+  prof_begin(s, 4.0 * d.N * (double)d.N + 8.0 * d.B * (double)d.N, PROF_FCC_STREAM);
   hipLaunchKernelGGL((fcc_big_gemm<NB, EXPOP>), dim3((unsigned)(d.G * d.SW)), dim3(256), shmem, s, (const float4*)pack,
                      (const float4*)op, pmax, d.B, part, d.NC, d.SW, d.Np, d.Bp);
+  prof_end(s);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }

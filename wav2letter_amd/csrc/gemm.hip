@@ -140,28 +140,34 @@ W2L_API int w2l_gemm_f32(int M, int N, int K, const float* A, int lda, int a_kco
   return gemm_f32(A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, M, N, K, bias, epi, 1, s);
 }
 
-// ---- launch profiling of the MFMA GEMM kernels (see gemm.hpp) -------------------
+// ---- launch profiling (see gemm.hpp): kind 0 = 128x128 MFMA GEMM (+ stream-K fix-up), 1 = skinny
+// implicit-GEMM, 2 = TDS slab convolutions, 3 = FCC transition stream (work = bytes) ----------------
 W2L_API int w2l_profile_enable(int on) {
   GemmProf& p = gemm_prof();
   p.on = on != 0;
   p.used = 0;
-  p.flops.clear();
+  p.work.clear();
+  p.kind.clear();
   return W2L_OK;
 }
-// call after a device synchronisation: launches, total ms, total algorithmic FLOPs
-W2L_API int w2l_profile_report(int* launches, double* totalMs, double* totalFlops) {
+// call after a device synchronisation: launches, total ms, total algorithmic work of one kind
+W2L_API int w2l_profile_report_kind(int kind, int* launches, double* totalMs, double* totalWork) {
   GemmProf& p = gemm_prof();
-  double ms = 0, fl = 0;
+  double ms = 0, wk = 0;
   int n = 0;
   for (size_t i = 0; i + 1 < p.used; i += 2) {
+    if (kind >= 0 && p.kind[i / 2] != kind) continue;
     float t = 0.f;
     if (hipEventElapsedTime(&t, p.ev[i], p.ev[i + 1]) != hipSuccess) continue;
     ms += t;
-    fl += p.flops[i / 2];
+    wk += p.work[i / 2];
     ++n;
   }
   if (launches) *launches = n;
   if (totalMs) *totalMs = ms;
-  if (totalFlops) *totalFlops = fl;
+  if (totalWork) *totalWork = wk;
   return W2L_OK;
+}
+W2L_API int w2l_profile_report(int* launches, double* totalMs, double* totalFlops) {
+  return w2l_profile_report_kind(PROF_GEMM128, launches, totalMs, totalFlops);
 }

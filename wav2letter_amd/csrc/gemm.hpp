@@ -200,22 +200,26 @@ struct PlainOp {
 };
 
 // ---------------------------------------------------------------- launch profiling
-// bench.py's roofline leg: when enabled, every MFMA GEMM launch is bracketed by a pair of
-// hipEvents on ITS stream; w2l_profile_report() sums durations and algorithmic FLOPs.
+// bench.py's roofline leg: when enabled, every launch of a roofline-relevant kernel is bracketed
+// by a pair of hipEvents on ITS stream; w2l_profile_report(kind) sums durations and the
+// algorithmic work (FLOPs for the MFMA kinds, bytes for the HBM-streaming kind).
+enum { PROF_GEMM128 = 0, PROF_SKINNY = 1, PROF_TDSCONV = 2, PROF_FCC_STREAM = 3, PROF_KINDS = 4 };
 struct GemmProf {
   bool on = false;
   std::vector<hipEvent_t> ev;      // pairs
-  std::vector<double> flops;
+  std::vector<double> work;
+  std::vector<int> kind;
   size_t used = 0;
 };
 GemmProf& gemm_prof();
-inline void prof_begin(hipStream_t s, double flops) {
+inline void prof_begin(hipStream_t s, double work, int kind = PROF_GEMM128) {
   GemmProf& p = gemm_prof();
   if (!p.on) return;
   if (p.used + 2 > p.ev.size()) {
     for (int i = 0; i < 2; ++i) { hipEvent_t e; (void)hipEventCreate(&e); p.ev.push_back(e); }
   }
-  p.flops.push_back(flops);
+  p.work.push_back(work);
+  p.kind.push_back(kind);
   (void)hipEventRecord(p.ev[p.used], s);
 }
 inline void prof_end(hipStream_t s) {
@@ -611,7 +615,7 @@ inline int launch_skinny(const AOp& a, const BOp& b, GemmOut o, int epi, int spl
   const size_t shmem = 2 * (size_t)BK * ((256 + AOp::kPadSkinny) + (BN + 4)) * sizeof(float);
   dim3 grid((unsigned)((o.M + 255) / 256), (unsigned)((o.N + BN - 1) / BN), (unsigned)splitk), block(256);
   o.epi = epi;
-  prof_begin(s, 2.0 * o.M * (double)o.N * o.K);
+  prof_begin(s, 2.0 * o.M * (double)o.N * o.K, PROF_SKINNY);
   hipLaunchKernelGGL((gemm_skinny_kernel<AOp, BOp, BN>), grid, block, shmem, s, a, b, o);
   prof_end(s);
   W2L_LAUNCH_CHECK();
