@@ -3,8 +3,11 @@
 tag=$1; shift; ctr=$1; shift
 export TMPDIR=/tmp
 out=$PWD/gpurun_out
+root=$PWD
+script=$root/$1; shift
+export PYTHONPATH=$root:$PYTHONPATH
 mkdir -p $out /tmp/pmc_$tag
-(cd /tmp && rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$tag -o $tag -- python "$@") > $out/${tag}_pmc_run.log 2>&1
+(cd /tmp && rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$tag -o $tag -- python $script "$@") > $out/${tag}_pmc_run.log 2>&1
 f=$(find /tmp/pmc_$tag -name "*counter_collection.csv" | head -1)
 if [ -n "$f" ]; then python - "$f" > $out/${tag}_pmc.csv <<'PY'
 import csv, sys, collections

@@ -3,8 +3,11 @@
 tag=$1; shift
 export TMPDIR=/tmp
 out=$PWD/gpurun_out
+root=$PWD
+script=$root/$1; shift
+export PYTHONPATH=$root:$PYTHONPATH
 mkdir -p $out /tmp/prof_$tag
-(cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o $tag -- python "$@") > $out/${tag}_run.log 2>&1
+(cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o $tag -- python $script "$@") > $out/${tag}_run.log 2>&1
 db=$(find /tmp/prof_$tag -name "*.db" | head -1)
 if [ -n "$db" ]; then python $out/../profiles/summarize_rocpd.py $db $out/${tag}_kernel_stats.csv; fi
 csv=$(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1)
