@@ -81,6 +81,37 @@ def test_gemm_stream_k_schedule(M, N, K, akc, bkc):
     assert rel(got, np.maximum(want, 0)) < TOL
 
 
+@pytest.mark.parametrize("M,N,K", [(4, 4, 32),             # one clamped tile, one K step
+                                    (260, 388, 96),        # ragged edge tiles in both directions
+                                    (1028, 2052, 1440),    # 153 tiles: pure stream-K ranges crossing tiles
+                                    (6016, 4320, 1440),    # 1598 tiles: 3 persistent rounds + stream-K tail
+                                    (640, 136, 24000)])    # dW-like: few tiles, very long reduction
+@pytest.mark.parametrize("akc,bkc", [(True, False), (True, True), (False, False), (False, True)])
+def test_gemm_lds_dma_path(M, N, K, akc, bkc):
+    """the persistent LDS-DMA kernel (K % 32 == 0, 16-byte aligned operands) against a float64 product
+    and against the register-staged kernel (W2L_GEMM_GLDS=0) on the same inputs; deterministic"""
+    import os
+    from wav2letter_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + 3 * N + 7 * K)
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(K, N, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    want = (A.double() @ Bm.double() + bias.double()).numpy()
+    Ad = (A if akc else A.T.contiguous()).cuda()
+    Bd = (Bm.T.contiguous() if bkc else Bm).cuda()
+    got = ops.gemm(Ad, Bd, akc, bkc, bias.cuda())
+    assert rel(got, want) < TOL
+    assert torch.equal(got, ops.gemm(Ad, Bd, akc, bkc, bias.cuda()))
+    os.environ["W2L_GEMM_GLDS"] = "0"
+    try:
+        old = ops.gemm(Ad, Bd, akc, bkc, bias.cuda())
+    finally:
+        os.environ.pop("W2L_GEMM_GLDS")
+    assert rel(got, old.cpu().numpy()) < 1e-5
+    got = ops.gemm(Ad, Bd, akc, bkc, bias.cuda(), relu=True)
+    assert rel(got, np.maximum(want, 0)) < TOL
+
+
 def test_gemm_asymmetric_identity():
     """A = I with an asymmetric B catches row/col swaps in the C write (guide G9)"""
     from wav2letter_amd import ops

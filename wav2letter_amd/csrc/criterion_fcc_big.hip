@@ -19,10 +19,11 @@
 //     EAp[tile of 32 rows][chunk of 8 k][lane][4]  (lane = row%32 + 32*h holds k = 8c+4h+q)
 // so a wavefront's global_load_dwordx4 is one fully coalesced 1 KiB burst that lands in
 // registers already in fragment layout -- no LDS staging, no transposition, no im2col.
-// Per step: kernel 1 (`fcc_big_gemm`: 64 rows x 1/(4 SW) of K per wave, two register sets
-// in ping-pong so a stage's loads stay in flight behind the previous stage's MFMAs, 4-wave
-// LDS reduction, deterministic partial slabs) and kernel 2 (`fcc_big_step`, 8 workgroups per
-// utterance: adds the SW slabs, takes log, adds x_t and rowmax, stores the un-normalised
+// Per step: kernel 1 (`fcc_big_gemm`: 2 persistent workgroups per CU, each streaming an equal
+// contiguous share of the (64-row group x 32-k) stage-units; two register sets in ping-pong so
+// a stage's loads stay in flight behind the previous stage's MFMAs, 4-wave LDS reduction,
+// deterministic partial slabs per row group) and kernel 2 (`fcc_big_step`, 16 workgroups per
+// utterance: adds a row group's slabs in worker order, takes log, adds x_t and rowmax, stores the un-normalised
 // a_t = alpha_t - C_{t-1} plain (for backward) and packed (for the next step) plus the
 // workgroup's maximum).  The exact per-utterance maximum c_t = max of the 8 partial maxima is
 // applied by the NEXT kernel 1 while it builds its operand fragments (E = exp(a_t - c_t): one
@@ -33,6 +34,8 @@
 //     dalpha_{t-1}[b][j] = e_{t-1}[b][j] * sum_i r_t[b][i] EA[i][j],  r_t = dalpha_t / s_t
 // and the transition gradient is ONE fp32 MFMA GEMM over (t, b) at the end:
 //     dA[i][j] = EA[i][j] * sum_{t,b} g_b r_t[b][i] e_{t-1}[b][j]      (2 N^2 T B flop).
+#include <cstdlib>
+
 #include "gemm.hpp"
 
 namespace w2l {
@@ -41,7 +44,7 @@ constexpr int kBigU = 4;          // chunks (of 8 k) per pipeline stage -> K pad
 constexpr int kBigMaxNB = 4;      // utterance tiles of 32 -> B <= 128
 constexpr int kBigStepThreads = 1024;  // per-utterance kernels that run once per call
 constexpr int kBigParts = 16;          // workgroups (partial maxima) per utterance and step
-constexpr int kBigMaxSW = 16;          // K splits at workgroup level (partial slabs)
+constexpr int kBigMaxSW = 16;          // bound on partial slabs per row group
 
 struct BigDims {
   int B, T, N;
@@ -51,10 +54,23 @@ struct BigDims {
   int NB;   // ceil(B / 32) rounded to 1, 2, 4
   int Bp;   // 32 * NB
   int G;    // Np / 64 row groups
-  int SW;   // workgroup-level K splits (partial slabs)
+  int nS;   // pipeline stages (of kBigU chunks) per row group
+  int U;    // G * nS stage-units of one step
+  int W;    // persistent workgroups of the streaming kernel: worker w owns units [U w / W, U (w+1) / W)
+  int P;    // bound on the workers (= partial slabs) that share one row group
 };
 
-__host__ __device__ inline BigDims big_dims(int B, int T, int N) {
+// persistent workgroups per CU of the streaming kernel: register-limited (160 / 232 / 486 VGPRs at
+// NB = 1 / 2 / 4).  W2L_FCC_WPC overrides the NB = 1 choice (2 or 3) for A/B runs.
+inline int big_workers_per_cu(int NB) {
+  if (NB >= 4) return 1;
+  if (NB == 2) return 2;
+  const char* e = getenv("W2L_FCC_WPC");
+  if (e && e[0] >= '1' && e[0] <= '3') return e[0] - '0';
+  return 2;
+}
+
+inline BigDims big_dims(int B, int T, int N) {
   BigDims d;
   d.B = B; d.T = T; d.N = N;
   d.Np = (N + 63) / 64 * 64;
@@ -64,31 +80,44 @@ __host__ __device__ inline BigDims big_dims(int B, int T, int N) {
   d.NB = nb <= 1 ? 1 : (nb <= 2 ? 2 : 4);
   d.Bp = 32 * d.NB;
   d.G = d.Np / 64;
-  // workgroups = G * SW: as close as possible below a multiple of the 256 CUs (a grid of 3.07
-  // workgroups per CU runs 4 rounds: measured 96 us vs 80 us at 4.9 per CU), at most 5 per CU,
-  // and every wave needs at least one pipeline stage
-  int maxsw = d.NC / kBigU / 4;
-  if (maxsw > kBigMaxSW) maxsw = kBigMaxSW;
-  if (maxsw < 1) maxsw = 1;
-  int sw = 1;
-  double best = -1.0;
-  for (int c = 1; c <= maxsw; ++c) {
-    const int wgs = d.G * c;
-    if (wgs > 1280 && c > 1) break;
-    const int rounds = (wgs + 255) / 256;
-    double eff = (double)wgs / (rounds * 256.0);
-    if (rounds < 4) eff *= 0.9 + 0.025 * rounds;  // few waves per SIMD hide HBM latency poorly
-    if (eff > best) { best = eff; sw = c; }
-  }
-  d.SW = sw;
+  // The step is cut into U = G * nS stage-units (64 rows x 32 k) in row-group-major order and dealt
+  // to W PERSISTENT workgroups in equal contiguous ranges: 2 workgroups per CU at B <= 32 (register-
+  // limited, big_workers_per_cu) all resident at once, so the stream has no partially filled last
+  // round (the old (row group x K split) grid of 1256 workgroups ran 2.45 rounds on 512 slots).  A
+  // range touches at most two row groups when U / W <= nS; every row group is then shared by at
+  // most P workers, each of which leaves one partial slab for the step kernel to add in worker order.
+  d.nS = d.NC / kBigU;
+  d.U = d.G * d.nS;
+  int w = 256 * big_workers_per_cu(d.NB);
+  if (w > d.U / 16) w = d.U / 16;                     // >= four stages per wave
+  const int perMin = (d.nS + 13) / 14;                // keeps P <= 16
+  if (w > d.U / perMin) w = d.U / perMin;
+  if (w < 1) w = 1;
+  d.W = w;
+  const int per = d.U / d.W;                          // floor: the shortest range
+  d.P = (d.nS + per - 1) / per + 1;
+  if (d.P > kBigMaxSW) d.P = kBigMaxSW;
   return d;
+}
+
+__host__ __device__ inline int big_unit_begin(const BigDims& d, int w) { return (int)((long long)d.U * w / d.W); }
+// the worker whose range holds stage-unit u
+__host__ __device__ inline int big_worker_of(const BigDims& d, int u) {
+  int w = (int)((long long)u * d.W / d.U);
+  while (w + 1 < d.W && big_unit_begin(d, w + 1) <= u) ++w;
+  while (w > 0 && big_unit_begin(d, w) > u) --w;
+  return w;
+}
+// number of workers (partial slabs) of row group g
+__host__ __device__ inline int big_pieces(const BigDims& d, int g) {
+  return big_worker_of(d, (g + 1) * d.nS - 1) - big_worker_of(d, g * d.nS) + 1;
 }
 
 struct BigWs {
   float* rm;      // [Np] row maxima of A
   float* pack;    // [Np * Kp] EAp (forward) / EATp (backward)
   float* ep[2];   // [Bp * Kp] packed E / R operand, double-buffered over t
-  float* part;    // [SW][Bp][Np] partial sums of one step
+  float* part;    // [P][Bp][Np] partial sums of one step (slab = ordinal of the worker inside its row group)
   float* e;       // [T][B][N]  a_t = alpha_t - C_{t-1} (forward); overwritten by e_t = exp(a_t - c_t) in backward
   float* pmax;    // [T][B][kBigParts] partial maxima of a_t
   float* invs;    // [T][B][N]  1 / s_t
@@ -108,7 +137,7 @@ __host__ __device__ inline BigWs big_ws(void* ws, const BigDims& d) {
   w.pack = (float*)take((size_t)d.Np * d.Kp * sizeof(float));
   w.ep[0] = (float*)take((size_t)d.Bp * d.Kp * sizeof(float));
   w.ep[1] = (float*)take((size_t)d.Bp * d.Kp * sizeof(float));
-  w.part = (float*)take((size_t)d.SW * d.Bp * d.Np * sizeof(float));
+  w.part = (float*)take((size_t)d.P * d.Bp * d.Np * sizeof(float));
   w.e = (float*)take(btn);
   w.pmax = (float*)take((size_t)d.T * d.B * kBigParts * sizeof(float));
   w.invs = (float*)take(btn);
@@ -200,23 +229,14 @@ __device__ __forceinline__ void big_compute_stage(const BigStage<NB>& st, const 
 }
 
 template <int NB, bool EXPOP>
-__global__ __launch_bounds__(256) void fcc_big_gemm(const float4* __restrict__ pack, const float4* __restrict__ op,
-                                                    const float* __restrict__ pmax, int B, float* __restrict__ part,
-                                                    int NC, int SW, int Np, int Bp) {
+__global__ __launch_bounds__(256, NB == 1 ? 3 : (NB == 2 ? 2 : 1)) void fcc_big_gemm(const float4* __restrict__ pack, const float4* __restrict__ op,
+                                                       const float* __restrict__ pmax, float* __restrict__ part, BigDims d) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][NB*2*16 regs][64 lanes]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = blockIdx.x / SW, sw = blockIdx.x - g * SW;
-  const int nStages = NC / kBigU;
-  const int ss = sw * 4 + wave, nss = 4 * SW;
-  const int s0 = (int)((long long)nStages * ss / nss), s1 = (int)((long long)nStages * (ss + 1) / nss);
-
-  f32x16 acc[NB][2];
-#pragma unroll
-  for (int bt = 0; bt < NB; ++bt)
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[bt][h][r] = 0.f;
+  const int NC = d.NC, Np = d.Np, Bp = d.Bp, B = d.B;
+  const int w = blockIdx.x;
+  int u0 = big_unit_begin(d, w);
+  const int u1 = big_unit_begin(d, w + 1);
 
   // this lane's utterance(s): b = 32 bt + (lane & 31); c_b = exact maximum of a_{t-1}[b][:]
   float cb[NB];
@@ -235,39 +255,58 @@ __global__ __launch_bounds__(256) void fcc_big_gemm(const float4* __restrict__ p
       cb[bt] = m;
     }
   }
-
-  const float4* pa0 = pack + ((size_t)(2 * g) * NC) * 64 + lane;
-  const float4* pa1 = pack + ((size_t)(2 * g + 1) * NC) * 64 + lane;
   const float4* pe = op + lane;
 
-  // two register sets in ping-pong: the loads of stage s+1 are in flight behind the MFMAs of stage s
-  BigStage<NB> sa, sb;
-  if (s0 < s1) big_load_stage<NB>(sa, pa0, pa1, pe, NC, s0);
-  for (int s = s0; s < s1; s += 2) {
-    if (s + 1 < s1) big_load_stage<NB>(sb, pa0, pa1, pe, NC, s + 1);
-    big_compute_stage<NB, EXPOP>(sa, cb, acc);
-    if (s + 2 < s1) big_load_stage<NB>(sa, pa0, pa1, pe, NC, s + 2);
-    if (s + 1 < s1) big_compute_stage<NB, EXPOP>(sb, cb, acc);
-  }
+  while (u0 < u1) {
+    // segment: the part of this worker's range inside row group g, split over the 4 waves
+    const int g = u0 / d.nS, sb = u0 - g * d.nS;
+    int len = d.nS - sb;
+    if (len > u1 - u0) len = u1 - u0;
+    const int s0 = sb + (int)((long long)len * wave / 4), s1 = sb + (int)((long long)len * (wave + 1) / 4);
+    const int piece = w - big_worker_of(d, g * d.nS);
 
-  // 4-wave reduction through LDS, fixed order (deterministic)
-  constexpr int NR = NB * 2 * 16;
+    f32x16 acc[NB][2];
 #pragma unroll
-  for (int bt = 0; bt < NB; ++bt)
+    for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[((wave * NR) + (bt * 2 + h) * 16 + r) * 64 + lane] = acc[bt][h][r];
-  __syncthreads();
-  // D layout of the 32x32 MFMA: column (row of EA) = lane & 31, row (utterance) = (r&3) + 8 (r>>2) + 4 (lane>>5)
-  float* dst = part + (size_t)sw * Bp * Np;
-  for (int o = threadIdx.x; o < NR * 64; o += 256) {
-    const float v = (red[o] + red[NR * 64 + o]) + (red[2 * NR * 64 + o] + red[3 * NR * 64 + o]);
-    const int l = o & 63, rr = o >> 6;
-    const int r = rr & 15, h = (rr >> 4) & 1, bt = rr >> 5;
-    const int b = 32 * bt + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-    const int i = 64 * g + 32 * h + (l & 31);
-    dst[(size_t)b * Np + i] = v;
+        for (int r = 0; r < 16; ++r) acc[bt][h][r] = 0.f;
+
+    const float4* pa0 = pack + ((size_t)(2 * g) * NC) * 64 + lane;
+    const float4* pa1 = pack + ((size_t)(2 * g + 1) * NC) * 64 + lane;
+
+    // two register sets in ping-pong: the loads of stage s+1 are in flight behind the MFMAs of stage s
+    BigStage<NB> sa, sb2;
+    if (s0 < s1) big_load_stage<NB>(sa, pa0, pa1, pe, NC, s0);
+    for (int s = s0; s < s1; s += 2) {
+      if (s + 1 < s1) big_load_stage<NB>(sb2, pa0, pa1, pe, NC, s + 1);
+      big_compute_stage<NB, EXPOP>(sa, cb, acc);
+      if (s + 2 < s1) big_load_stage<NB>(sa, pa0, pa1, pe, NC, s + 2);
+      if (s + 1 < s1) big_compute_stage<NB, EXPOP>(sb2, cb, acc);
+    }
+
+    // 4-wave reduction through LDS, fixed order (deterministic)
+    constexpr int NR = NB * 2 * 16;
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave * NR) + (bt * 2 + h) * 16 + r) * 64 + lane] = acc[bt][h][r];
+    __syncthreads();
+    // D layout of the 32x32 MFMA: column (row of EA) = lane & 31, row (utterance) = (r&3) + 8 (r>>2) + 4 (lane>>5)
+    float* dst = part + (size_t)piece * Bp * Np;
+    for (int o = threadIdx.x; o < NR * 64; o += 256) {
+      const float v = (red[o] + red[NR * 64 + o]) + (red[2 * NR * 64 + o] + red[3 * NR * 64 + o]);
+      const int l = o & 63, rr = o >> 6;
+      const int r = rr & 15, h = (rr >> 4) & 1, bt = rr >> 5;
+      const int b = 32 * bt + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+      const int i = 64 * g + 32 * h + (l & 31);
+      dst[(size_t)b * Np + i] = v;
+    }
+    u0 += len;
+    if (u0 < u1) __syncthreads();  // `red` is reused by the next segment
   }
 }
 
@@ -327,10 +366,11 @@ __global__ __launch_bounds__(256) void fcc_big_step(BigDims d, int t, const floa
     const int i0 = 4 * q;
     float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (t > 0) {
-      float4 p4[kBigMaxSW];  // all slab loads in flight together, added in slab order
+      float4 p4[kBigMaxSW];  // all slab loads in flight together, added in worker order
+      const int np = big_pieces(d, i0 >> 6);
 #pragma unroll
       for (int s = 0; s < kBigMaxSW; ++s)
-        p4[s] = s < d.SW ? *(const float4*)(ws.part + ((size_t)s * d.Bp + b) * d.Np + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        p4[s] = s < np ? *(const float4*)(ws.part + ((size_t)s * d.Bp + b) * d.Np + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int s = 0; s < kBigMaxSW; ++s) { s4.x += p4[s].x; s4.y += p4[s].y; s4.z += p4[s].z; s4.w += p4[s].w; }
     }
@@ -439,9 +479,10 @@ __global__ __launch_bounds__(256) void fcc_big_bwd_step(BigDims d, int tm, float
   float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
   {
     float4 p4[kBigMaxSW];
+    const int np = big_pieces(d, i0 >> 6);
 #pragma unroll
     for (int s = 0; s < kBigMaxSW; ++s)
-      p4[s] = s < d.SW ? *(const float4*)(ws.part + ((size_t)s * d.Bp + b) * d.Np + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      p4[s] = s < np ? *(const float4*)(ws.part + ((size_t)s * d.Bp + b) * d.Np + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int s = 0; s < kBigMaxSW; ++s) { s4.x += p4[s].x; s4.y += p4[s].y; s4.z += p4[s].z; s4.w += p4[s].w; }
   }
@@ -481,8 +522,8 @@ static int launch_big_gemm(const BigDims& d, const float* pack, const float* op,
   const size_t shmem = (size_t)4 * NB * 2 * 16 * 64 * sizeof(float);
   // algorithmic bytes of one step: the transition matrix once + read/write of one [B][N] row pair
   prof_begin(s, 4.0 * d.N * (double)d.N + 8.0 * d.B * (double)d.N, PROF_FCC_STREAM);
-  hipLaunchKernelGGL((fcc_big_gemm<NB, EXPOP>), dim3((unsigned)(d.G * d.SW)), dim3(256), shmem, s, (const float4*)pack,
-                     (const float4*)op, pmax, d.B, part, d.NC, d.SW, d.Np, d.Bp);
+  hipLaunchKernelGGL((fcc_big_gemm<NB, EXPOP>), dim3((unsigned)d.W), dim3(256), shmem, s, (const float4*)pack,
+                     (const float4*)op, pmax, part, d);
   prof_end(s);
   W2L_LAUNCH_CHECK();
   return W2L_OK;

@@ -24,6 +24,7 @@
 #include <utility>
 
 #include "gemm.hpp"
+#include "gemm_glds.hpp"
 
 namespace w2l {
 
@@ -51,6 +52,16 @@ float* sk_scratch(hipStream_t s, size_t bytes) {
     e.second = bytes;
   }
   return e.first;
+}
+
+// W2L_GEMM_GLDS=0 routes every GEMM through the register-staged first-generation kernel (A/B runs)
+static bool glds_enabled() {
+  const char* e = getenv("W2L_GEMM_GLDS");
+  return !(e && e[0] == '0');
+}
+
+static inline bool glds_ok(const float* p, int ld, int extent) {
+  return (((uintptr_t)p) & 15) == 0 && ld % 4 == 0 && extent % 4 == 0 && extent >= 4;
 }
 
 bool sk_enabled() {
@@ -88,6 +99,8 @@ int gemm_f32(const float* A, int lda, int a_kcontig, const float* B, int ldb, in
   o.maskScale = maskScale;
   if (mask) epi |= EPI_MASK;
   splitk = 1;
+  if (K % 32 == 0 && glds_ok(A, lda, M) && glds_ok(B, ldb, N) && glds_enabled())
+    return launch128g(GOp{A, lda, M}, a_kcontig != 0, GOp{B, ldb, N}, b_kcontig != 0, o, epi, s);
   if (a_kcontig) {
     int v = pick_vec(A, lda, K);
     if (v == 4) return dispatch_b(PlainOp<true, 4>{A, lda, M, K}, B, ldb, b_kcontig, o, epi, splitk, s);

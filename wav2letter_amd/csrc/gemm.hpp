@@ -242,6 +242,7 @@ struct SkPlan {
   int tilesM, tilesN, kTiles;
   int dpTiles, skTiles, skBlocks;
   float* slabs;  // [skBlocks][2][128*128]
+  int grouped;   // tile rasterisation: 0 = M-fastest, 1 = groups of 8 tile-columns, N-fastest inside a group
 };
 constexpr int kSkSlots = 512;           // resident 256-thread workgroups (2 per CU)
 constexpr int kSlabFloats = 128 * 128;
@@ -250,13 +251,24 @@ __host__ __device__ inline long long sk_begin(const SkPlan& p, int s) {
   return (long long)p.skTiles * p.kTiles * s / p.skBlocks;
 }
 
+// linear tile index -> tile coordinates (bijective for either rasterisation)
+__host__ __device__ inline void sk_tile_xy(const SkPlan& p, int t, int& bx, int& by) {
+  if (!p.grouped) { bx = t % p.tilesM; by = t / p.tilesM; return; }
+  const int perGroup = 8 * p.tilesM;
+  const int grp = t / perGroup, first = grp * 8;
+  const int gsize = p.tilesN - first < 8 ? p.tilesN - first : 8;
+  const int tin = t - grp * perGroup;
+  by = first + tin % gsize;
+  bx = tin / gsize;
+}
+
 inline SkPlan make_sk_plan(int M, int N, int K, bool allowSk) {
   SkPlan p;
   p.tilesM = (M + 127) / 128;
   p.tilesN = (N + 127) / 128;
   p.kTiles = (K + 31) / 32;
   const int tiles = p.tilesM * p.tilesN;
-  p.dpTiles = tiles; p.skTiles = 0; p.skBlocks = 0; p.slabs = nullptr;
+  p.dpTiles = tiles; p.skTiles = 0; p.skBlocks = 0; p.slabs = nullptr; p.grouped = 0;
   if (!allowSk || p.kTiles < 8) return p;
   const int rounds = (tiles + kSkSlots - 1) / kSkSlots;
   const double eff = (double)tiles / ((double)rounds * kSkSlots);
@@ -426,7 +438,8 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(AOp aop, BOp bop, GemmO
   // tile coordinates: the tile index walks M fastest so that neighbouring workgroups on one
   // XCD share the same B (weight) panel in L2
   if (bid < plan.dpTiles) {
-    const int bx = bid % plan.tilesM, by = bid / plan.tilesM;
+    int bx, by;
+    sk_tile_xy(plan, bid, bx, by);
     gemm128_mainloop(aop, bop, bx * 128, by * 128, 0, plan.kTiles, out.K, smem, acc);
     gemm128_epilogue(out, bx * 128, by * 128, acc);
     return;
@@ -440,7 +453,8 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(AOp aop, BOp bop, GemmO
     const int kb = (int)(it % plan.kTiles);
     int ke = plan.kTiles;
     if (itEnd - it < (long long)(ke - kb)) ke = kb + (int)(itEnd - it);
-    const int bx = tile % plan.tilesM, by = tile / plan.tilesM;
+    int bx, by;
+    sk_tile_xy(plan, tile, bx, by);
     gemm128_mainloop(aop, bop, bx * 128, by * 128, kb, ke, out.K, smem, acc);
     if (kb == 0 && ke == plan.kTiles) gemm128_epilogue(out, bx * 128, by * 128, acc);
     else gemm128_store_partial(plan.slabs + ((size_t)s * 2 + seg) * kSlabFloats, acc);
@@ -480,7 +494,8 @@ __global__ __launch_bounds__(256) void gemm128_fixup(GemmOut out, SkPlan plan) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] += slab[((wave * 4 + i * 2 + j) * 16 + r) * 64 + lane];
   }
   const int tile = plan.dpTiles + t;
-  const int bx = tile % plan.tilesM, by = tile / plan.tilesM;
+  int bx, by;
+  sk_tile_xy(plan, tile, bx, by);
   gemm128_epilogue(out, bx * 128, by * 128, acc);
 }
 

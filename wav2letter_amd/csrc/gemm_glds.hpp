@@ -1,0 +1,245 @@
+// gemm_glds.hpp -- persistent fp32 MFMA GEMM with direct-to-LDS operand staging (gfx950).
+//
+// The second-generation main loop of the fl::Linear GEMMs (see gemm.hip for the reference call sites).
+// Same 128x128x32 block tile / 4 waves x (2x2) v_mfma_f32_32x32x2_f32 as gemm128_kernel, but
+//   * operand tiles go global -> LDS by `global_load_lds_dwordx4` (LDS-DMA): no staging VGPRs, no
+//     ds_write pass, no transposing scalar stores between the MFMAs.  The LDS image is lane-linear
+//     per wave-instruction (1 KiB pieces), so the bank-conflict-free layout is produced by permuting
+//     the per-lane SOURCE address (XOR swizzle), not by padding;
+//   * k-contiguous operands keep k contiguous in LDS ([i][32 k], 128-B rows) and a lane fetches FOUR
+//     consecutive k of its row with one ds_read_b128.  The MFMA k-slot assignment inside a group of
+//     8 k is  k = 8g + 4*(lane>>5) + q  (q = 0..3 = the four MFMA k-steps of the group) for BOTH
+//     operands, which only permutes the order of the k-sum;
+//   * the kernel is persistent: 2 workgroups per CU walk a static list of (tile, k-range) segments
+//     (whole tiles first, then one stream-K range) and the first K tile of the NEXT segment is
+//     already in flight while the current segment's last K tile is multiplied and its epilogue
+//     runs -- the per-tile prologue latency (5.6 K-iterations per tile in the first-generation kernel,
+//     measured on MI355X) is off the critical path;
+//   * tiles are rasterised in groups of 8 tile-columns, N-fastest inside a group, and the worker id
+//     is XCD-major, so the 64 workgroups of one XCD work on an 8x8 block of tiles that shares
+//     8 + 8 operand panels in that XCD's L2.
+// Requirements (checked by the host; otherwise gemm128_kernel runs): K % 32 == 0, 16-byte aligned
+// operand pointers and leading dimensions, extents % 4 == 0.
+#pragma once
+#include "gemm.hpp"
+
+namespace w2l {
+
+struct GOp {
+  const float* p;
+  int ld;
+  int extent;  // number of valid i (rows of A / columns of B)
+};
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int kGStageFloats = 2 * 128 * 32;  // A tile + B tile of one K step
+
+// XCD-major worker id: hardware workgroup b runs on XCD b % 8; give XCD x the 64 consecutive
+// logical workers [64x, 64x + 64) of a 512-wide round (bijective for any worker count)
+__device__ __forceinline__ int xcd_major(int b, int workers) {
+  const int q = workers / 8, r = workers % 8, x = b % 8;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
+}
+
+template <bool KC>
+__device__ __forceinline__ void g_init_ptrs(const float* (&q)[4], const GOp& op, int i0, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (KC) {
+      const int r = (wave * 4 + j) * 8 + (lane >> 3);             // tile row 0..127
+      const int c = (lane & 7) ^ ((r >> 1) & 7);                  // source chunk of this LDS slot
+      int gi = i0 + r;
+      if (gi > op.extent - 1) gi = op.extent - 1;
+      q[j] = op.p + (size_t)gi * op.ld + 4 * c;
+    } else {
+      const int kr = (wave * 4 + j) * 2 + (lane >> 5);            // tile k-row 0..31
+      int gi = i0 + 4 * (lane & 31);
+      if (gi > op.extent - 4) gi = op.extent - 4;
+      q[j] = op.p + (size_t)kr * op.ld + gi;
+    }
+  }
+}
+
+__device__ __forceinline__ void g_issue(const float* const (&q)[4], size_t off, float* ldsTile, int wave) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    __builtin_amdgcn_global_load_lds((gptr_t)(q[j] + off), (lptr_t)(ldsTile + (wave * 4 + j) * 256), 16, 0, 0);
+}
+
+__device__ __forceinline__ void g_issue1(const float* q, size_t off, float* ldsTile, int wave, int j) {
+  __builtin_amdgcn_global_load_lds((gptr_t)(q + off), (lptr_t)(ldsTile + (wave * 4 + j) * 256), 16, 0, 0);
+}
+
+// fragments of one 8-k group for the two 32-row MFMA tiles of this wave
+template <bool KC>
+__device__ __forceinline__ void g_frag(float (&f)[2][4], const float* tile, int w0, int g, int li, int lh) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (KC) {
+      const int r = w0 + 32 * i + li;
+      const int c = (2 * g) ^ lh ^ ((li >> 1) & 7);
+      const f32x4 v = *(const f32x4*)(tile + r * 32 + 4 * c);
+      f[i][0] = v[0]; f[i][1] = v[1]; f[i][2] = v[2]; f[i][3] = v[3];
+    } else {
+      const float* src = tile + (8 * g + 4 * lh) * 128 + w0 + 32 * i + li;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) f[i][q] = src[q * 128];
+    }
+  }
+}
+
+struct GSeg {
+  int tile, kb, ke, slab;  // slab: index of the partial slab (stream-K ranges), -1 = whole tile
+  bool valid;
+};
+
+// segment `ord` of logical worker w: whole tiles w, w + workers, ... then the stream-K range w
+__device__ __forceinline__ GSeg g_segment(const SkPlan& p, int w, int workers, int ord) {
+  GSeg s;
+  s.valid = false;
+  s.tile = 0; s.kb = 0; s.ke = 0; s.slab = -1;
+  const int nDp = w < p.dpTiles ? (p.dpTiles - w + workers - 1) / workers : 0;
+  if (ord < nDp) {
+    s.tile = w + ord * workers; s.kb = 0; s.ke = p.kTiles; s.valid = true;
+    return s;
+  }
+  if (w >= p.skBlocks) return s;
+  const int o = ord - nDp;
+  if (o > 1) return s;
+  long long it = sk_begin(p, w);
+  const long long itEnd = sk_begin(p, w + 1);
+  if (it >= itEnd) return s;
+  long long firstEnd = (it / p.kTiles + 1) * (long long)p.kTiles;
+  if (firstEnd > itEnd) firstEnd = itEnd;
+  if (o == 1) {
+    it = firstEnd;
+    if (it >= itEnd) return s;
+    firstEnd = itEnd;
+  }
+  s.tile = p.dpTiles + (int)(it / p.kTiles);
+  s.kb = (int)(it % p.kTiles);
+  s.ke = s.kb + (int)(firstEnd - it);
+  s.slab = (s.kb == 0 && s.ke == p.kTiles) ? -1 : w * 2 + o;
+  s.valid = true;
+  return s;
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, GemmOut out, SkPlan plan, int workers) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int li = lane & 31, lh = lane >> 5;
+  const int w = xcd_major(blockIdx.x, workers);
+  const size_t aStep = AKC ? 32 : (size_t)32 * aop.ld;
+  const size_t bStep = BKC ? 32 : (size_t)32 * bop.ld;
+
+  GSeg seg = g_segment(plan, w, workers, 0);
+  if (!seg.valid) return;
+  const float* qa[4];
+  const float* qb[4];
+  int bx, by;
+  sk_tile_xy(plan, seg.tile, bx, by);
+  g_init_ptrs<AKC>(qa, aop, bx * 128, wave, lane);
+  g_init_ptrs<BKC>(qb, bop, by * 128, wave, lane);
+  g_issue(qa, aStep * seg.kb, smem, wave);
+  g_issue(qb, bStep * seg.kb, smem + 4096, wave);
+  int stage = 0;
+  __syncthreads();  // (drains the LDS-DMA: vmcnt(0) precedes the barrier)
+
+  for (int ord = 0;; ++ord) {
+    const GSeg nxt = g_segment(plan, w, workers, ord + 1);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int kt = seg.kb; kt < seg.ke; ++kt) {
+      const float* As = smem + stage * kGStageFloats;
+      const float* Bs = As + 4096;
+      float* An = smem + (stage ^ 1) * kGStageFloats;
+      float fa[2][2][4], fb[2][2][4];
+      g_frag<AKC>(fa[0], As, wm, 0, li, lh);
+      g_frag<BKC>(fb[0], Bs, wn, 0, li, lh);
+      // What goes to the other stage during this iteration: the next K tile, or the first K tile of
+      // the next segment, or (very last iteration of this worker) a harmless re-load of this tile.
+      // Every wave has passed the barrier that ended the previous iteration, so nobody reads that stage.
+      size_t offA = aStep * kt, offB = bStep * kt;
+      if (kt + 1 < seg.ke) {
+        offA += aStep; offB += bStep;
+      } else if (nxt.valid) {
+        int nbx, nby;
+        sk_tile_xy(plan, nxt.tile, nbx, nby);
+        g_init_ptrs<AKC>(qa, aop, nbx * 128, wave, lane);
+        g_init_ptrs<BKC>(qb, bop, nby * 128, wave, lane);
+        offA = aStep * nxt.kb; offB = bStep * nxt.kb;
+      }
+      // 16 k-steps of 4 MFMAs; the 8 LDS-DMA pieces and the fragment reads of the next 8-k group are
+      // slotted BETWEEN k-steps (one filler per gap, order pinned) so that their issue cost and latency
+      // sit behind MFMA execution instead of in front of it.
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cur = g & 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0][q], fb[cur][0][q], acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0][q], fb[cur][1][q], acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1][q], fb[cur][0][q], acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1][q], fb[cur][1][q], acc[1][1], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          const int step = 4 * g + q;
+          if (q == 0) {
+            if (g < 3) {
+              g_frag<AKC>(fa[cur ^ 1], As, wm, g + 1, li, lh);
+              g_frag<BKC>(fb[cur ^ 1], Bs, wn, g + 1, li, lh);
+            }
+          } else {
+            const int piece = step - 1 - g;  // steps 1,2,3,5,6,7,9,10 -> pieces 0..7
+            if (piece < 4) g_issue1(qa[piece], offA, An, wave, piece);
+            else if (piece < 8) g_issue1(qb[piece - 4], offB, An + 4096, wave, piece - 4);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      stage ^= 1;
+      __syncthreads();  // the stage just filled has landed (vmcnt(0)) and is visible to all waves
+    }
+
+    if (seg.slab < 0) gemm128_epilogue(out, bx * 128, by * 128, acc);
+    else gemm128_store_partial(plan.slabs + (size_t)seg.slab * kSlabFloats, acc);
+    if (!nxt.valid) break;
+    seg = nxt;
+    sk_tile_xy(plan, seg.tile, bx, by);
+  }
+}
+
+inline int launch128g(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o, int epi, hipStream_t s) {
+  epi &= ~EPI_ATOMIC;
+  SkPlan plan = make_sk_plan(o.M, o.N, o.K, sk_enabled());
+  plan.grouped = 1;
+  if (plan.skBlocks > 0) {
+    plan.slabs = sk_scratch(s, (size_t)kSkSlots * 2 * kSlabFloats * sizeof(float));
+    if (!plan.slabs) { plan = make_sk_plan(o.M, o.N, o.K, false); plan.grouped = 1; }
+  }
+  int workers = plan.dpTiles < kSkSlots ? plan.dpTiles : kSkSlots;
+  if (workers < plan.skBlocks) workers = plan.skBlocks;
+  const size_t shmem = 2 * (size_t)kGStageFloats * sizeof(float);
+  dim3 grid((unsigned)workers), block(256);
+  o.epi = epi;
+  prof_begin(s, 2.0 * o.M * (double)o.N * o.K);
+  if (akc && bkc) hipLaunchKernelGGL((gemm128g_kernel<true, true>), grid, block, shmem, s, a, b, o, plan, workers);
+  else if (akc) hipLaunchKernelGGL((gemm128g_kernel<true, false>), grid, block, shmem, s, a, b, o, plan, workers);
+  else if (bkc) hipLaunchKernelGGL((gemm128g_kernel<false, true>), grid, block, shmem, s, a, b, o, plan, workers);
+  else hipLaunchKernelGGL((gemm128g_kernel<false, false>), grid, block, shmem, s, a, b, o, plan, workers);
+  if (plan.skBlocks > 0) hipLaunchKernelGGL(gemm128_fixup<0>, dim3((unsigned)plan.skTiles), block, 0, s, o, plan);
+  prof_end(s);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+}  // namespace w2l
