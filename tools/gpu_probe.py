@@ -56,6 +56,22 @@ def probe_gemm():
         os.environ["W2L_GEMM_SK"] = "1"
 
 
+def probe_gemmfwd():
+    """forward GEMM only (ablation runs: W2L_GEMM_ABL is read once per process)"""
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    for name, M, K, N in [("fc1 s1", 24000, 800, 2400), ("fc2 s3", 6016, 4320, 1440), ("4096^3", 4096, 4096, 4096),
+                          ("8192^3", 8192, 8192, 8192)]:
+        x = torch.randn(M, K, device="cuda")
+        w = torch.randn(K, N, device="cuda") / K ** 0.5
+        b = torch.randn(N, device="cuda")
+        y = torch.empty(M, N, device="cuda")
+        fl = 2.0 * M * N * K
+        tf = timeit(lambda: L.w2l_linear_forward(M, K, N, x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), 1, s), n=20, warm=3)
+        print(f"[gemmfwd abl={os.environ.get('W2L_GEMM_ABL', '0')} glds={os.environ.get('W2L_GEMM_GLDS', '1')}] "
+              f"{name:7s} M={M} K={K} N={N}: {tf:.3f} ms {fl / tf / 1e9:.1f} TF", flush=True)
+
+
 def probe_ln():
     for name, B, inner in [("tds s1", 32, 750 * 800), ("tds s2", 32, 375 * 1120), ("tds s3", 32, 188 * 1440),
                            ("frame", 32 * 188, 1440)]:
@@ -158,6 +174,6 @@ if __name__ == "__main__":
     print("device:", torch.cuda.get_device_name(0), flush=True)
     for w in which:
         t0 = time.time()
-        {"gemm": probe_gemm, "ln": probe_ln, "conv": probe_conv, "asg": probe_asg, "fccbig": probe_fccbig,
+        {"gemm": probe_gemm, "gemmfwd": probe_gemmfwd, "ln": probe_ln, "conv": probe_conv, "asg": probe_asg, "fccbig": probe_fccbig,
          "vitbig": probe_vitbig}[w]()
         print(f"[{w}] done in {time.time() - t0:.1f} s", flush=True)

@@ -60,13 +60,12 @@ struct BigDims {
   int P;    // bound on the workers (= partial slabs) that share one row group
 };
 
-// persistent workgroups per CU of the streaming kernel: register-limited (160 / 232 / 486 VGPRs at
-// NB = 1 / 2 / 4).  W2L_FCC_WPC overrides the NB = 1 choice (2 or 3) for A/B runs.
+// persistent workgroups per CU of the streaming kernel: register-limited (three operand stages of
+// 48 NB VGPRs + 32 NB accumulators).  W2L_FCC_WPC overrides the NB = 1 choice (1 or 2) for A/B runs.
 inline int big_workers_per_cu(int NB) {
-  if (NB >= 4) return 1;
-  if (NB == 2) return 2;
+  if (NB >= 2) return 1;
   const char* e = getenv("W2L_FCC_WPC");
-  if (e && e[0] >= '1' && e[0] <= '3') return e[0] - '0';
+  if (e && e[0] >= '1' && e[0] <= '2') return e[0] - '0';
   return 2;
 }
 
@@ -229,7 +228,7 @@ __device__ __forceinline__ void big_compute_stage(const BigStage<NB>& st, const 
 }
 
 template <int NB, bool EXPOP>
-__global__ __launch_bounds__(256, NB == 1 ? 3 : (NB == 2 ? 2 : 1)) void fcc_big_gemm(const float4* __restrict__ pack, const float4* __restrict__ op,
+__global__ __launch_bounds__(256, NB <= 1 ? 2 : 1) void fcc_big_gemm(const float4* __restrict__ pack, const float4* __restrict__ op,
                                                        const float* __restrict__ pmax, float* __restrict__ part, BigDims d) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][NB*2*16 regs][64 lanes]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -276,14 +275,39 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : (NB == 2 ? 2 : 1)) void fcc_big_
     const float4* pa0 = pack + ((size_t)(2 * g) * NC) * 64 + lane;
     const float4* pa1 = pack + ((size_t)(2 * g + 1) * NC) * 64 + lane;
 
-    // two register sets in ping-pong: the loads of stage s+1 are in flight behind the MFMAs of stage s
-    BigStage<NB> sa, sb2;
-    if (s0 < s1) big_load_stage<NB>(sa, pa0, pa1, pe, NC, s0);
-    for (int s = s0; s < s1; s += 2) {
-      if (s + 1 < s1) big_load_stage<NB>(sb2, pa0, pa1, pe, NC, s + 1);
-      big_compute_stage<NB, EXPOP>(sa, cb, acc);
-      if (s + 2 < s1) big_load_stage<NB>(sa, pa0, pa1, pe, NC, s + 2);
-      if (s + 1 < s1) big_compute_stage<NB, EXPOP>(sb2, cb, acc);
+    // three register sets in a ring: the loads of stages s+1 and s+2 are in flight behind the MFMAs of
+    // stage s (24 KiB per wave, 192 KiB per CU: one set in flight left the stream latency-bound --
+    // bytes in flight / loaded HBM latency -- at 4.4 TB/s on MI355X)
+    // Operand loads are issued UNCONDITIONALLY (stage index clamped to the wave's last stage; the few
+    // redundant loads at the tail hit L2): a load under a branch makes hipcc's s_waitcnt placement
+    // assume the worst at the join and wait vmcnt(0), which drains the whole ring every stage.
+    if (s0 < s1) {
+      const int sl = s1 - 1;
+      if constexpr (NB >= 4) {  // 192 operand VGPRs per stage: two sets in ping-pong are all that fits
+        BigStage<NB> sa, sb2;
+        big_load_stage<NB>(sa, pa0, pa1, pe, NC, s0);
+        for (int s = s0; s < s1; s += 2) {
+          big_load_stage<NB>(sb2, pa0, pa1, pe, NC, min(s + 1, sl));
+          big_compute_stage<NB, EXPOP>(sa, cb, acc);
+          big_load_stage<NB>(sa, pa0, pa1, pe, NC, min(s + 2, sl));
+          if (s + 1 < s1) big_compute_stage<NB, EXPOP>(sb2, cb, acc);
+        }
+      } else {
+        // three register sets in a ring: the loads of stages s+1 and s+2 are in flight behind the MFMAs
+        // of stage s (24 KiB per wave, 192 KiB per CU: with one set in flight the stream was latency-bound
+        // -- bytes in flight / loaded HBM latency -- at 4.4 TB/s on MI355X)
+        BigStage<NB> r0, r1, r2;
+        big_load_stage<NB>(r0, pa0, pa1, pe, NC, s0);
+        big_load_stage<NB>(r1, pa0, pa1, pe, NC, min(s0 + 1, sl));
+        for (int s = s0; s < s1; s += 3) {
+          big_load_stage<NB>(r2, pa0, pa1, pe, NC, min(s + 2, sl));
+          big_compute_stage<NB, EXPOP>(r0, cb, acc);
+          big_load_stage<NB>(r0, pa0, pa1, pe, NC, min(s + 3, sl));
+          if (s + 1 < s1) big_compute_stage<NB, EXPOP>(r1, cb, acc);
+          big_load_stage<NB>(r1, pa0, pa1, pe, NC, min(s + 4, sl));
+          if (s + 2 < s1) big_compute_stage<NB, EXPOP>(r2, cb, acc);
+        }
+      }
     }
 
     // 4-wave reduction through LDS, fixed order (deterministic)

@@ -21,6 +21,8 @@
 // Requirements (checked by the host; otherwise gemm128_kernel runs): K % 32 == 0, 16-byte aligned
 // operand pointers and leading dimensions, extents % 4 == 0.
 #pragma once
+#include <cstdlib>
+
 #include "gemm.hpp"
 
 namespace w2l {
@@ -126,7 +128,9 @@ __device__ __forceinline__ GSeg g_segment(const SkPlan& p, int w, int workers, i
   return s;
 }
 
-template <bool AKC, bool BKC>
+// ABL: timing-only ablations (results are garbage) selected by W2L_GEMM_ABL for the probe tool:
+//   1 = no LDS-DMA, 2 = no per-K-tile barrier, 4 = no fragment reads in the loop, 8 = no epilogue
+template <bool AKC, bool BKC, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, GemmOut out, SkPlan plan, int workers) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -144,8 +148,10 @@ __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, Gemm
   sk_tile_xy(plan, seg.tile, bx, by);
   g_init_ptrs<AKC>(qa, aop, bx * 128, wave, lane);
   g_init_ptrs<BKC>(qb, bop, by * 128, wave, lane);
-  g_issue(qa, aStep * seg.kb, smem, wave);
-  g_issue(qb, bStep * seg.kb, smem + 4096, wave);
+  if (!(ABL & 1)) {
+    g_issue(qa, aStep * seg.kb, smem, wave);
+    g_issue(qb, bStep * seg.kb, smem + 4096, wave);
+  }
   int stage = 0;
   __syncthreads();  // (drains the LDS-DMA: vmcnt(0) precedes the barrier)
 
@@ -166,6 +172,10 @@ __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, Gemm
       float fa[2][2][4], fb[2][2][4];
       g_frag<AKC>(fa[0], As, wm, 0, li, lh);
       g_frag<BKC>(fb[0], Bs, wn, 0, li, lh);
+      if (ABL & 4) {
+        g_frag<AKC>(fa[1], As, wm, 1, li, lh);
+        g_frag<BKC>(fb[1], Bs, wn, 1, li, lh);
+      }
       // What goes to the other stage during this iteration: the next K tile, or the first K tile of
       // the next segment, or (very last iteration of this worker) a harmless re-load of this tile.
       // Every wave has passed the barrier that ended the previous iteration, so nobody reads that stage.
@@ -194,23 +204,27 @@ __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, Gemm
           __builtin_amdgcn_sched_barrier(0);
           const int step = 4 * g + q;
           if (q == 0) {
-            if (g < 3) {
+            if (g < 3 && !(ABL & 4)) {
               g_frag<AKC>(fa[cur ^ 1], As, wm, g + 1, li, lh);
               g_frag<BKC>(fb[cur ^ 1], Bs, wn, g + 1, li, lh);
             }
           } else {
             const int piece = step - 1 - g;  // steps 1,2,3,5,6,7,9,10 -> pieces 0..7
-            if (piece < 4) g_issue1(qa[piece], offA, An, wave, piece);
-            else if (piece < 8) g_issue1(qb[piece - 4], offB, An + 4096, wave, piece - 4);
+            if (!(ABL & 1)) {
+              if (piece < 4) g_issue1(qa[piece], offA, An, wave, piece);
+              else if (piece < 8) g_issue1(qb[piece - 4], offB, An + 4096, wave, piece - 4);
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
       stage ^= 1;
-      __syncthreads();  // the stage just filled has landed (vmcnt(0)) and is visible to all waves
+      if (!(ABL & 2)) __syncthreads();  // the stage just filled has landed (vmcnt(0)) and is visible to all waves
     }
 
-    if (seg.slab < 0) gemm128_epilogue(out, bx * 128, by * 128, acc);
+    if (ABL & 8) {
+      if (acc[0][0][0] == 123.456f) out.C[0] = acc[1][1][3];  // keeps the accumulators live
+    } else if (seg.slab < 0) gemm128_epilogue(out, bx * 128, by * 128, acc);
     else gemm128_store_partial(plan.slabs + (size_t)seg.slab * kSlabFloats, acc);
     if (!nxt.valid) break;
     seg = nxt;
@@ -232,7 +246,18 @@ inline int launch128g(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o,
   dim3 grid((unsigned)workers), block(256);
   o.epi = epi;
   prof_begin(s, 2.0 * o.M * (double)o.N * o.K);
-  if (akc && bkc) hipLaunchKernelGGL((gemm128g_kernel<true, true>), grid, block, shmem, s, a, b, o, plan, workers);
+  static const int abl = [] { const char* e = getenv("W2L_GEMM_ABL"); return e ? atoi(e) : 0; }();
+  if (abl && akc && !bkc) {
+    switch (abl) {
+      case 1: hipLaunchKernelGGL((gemm128g_kernel<true, false, 1>), grid, block, shmem, s, a, b, o, plan, workers); break;
+      case 3: hipLaunchKernelGGL((gemm128g_kernel<true, false, 3>), grid, block, shmem, s, a, b, o, plan, workers); break;
+      case 7: hipLaunchKernelGGL((gemm128g_kernel<true, false, 7>), grid, block, shmem, s, a, b, o, plan, workers); break;
+      case 15: hipLaunchKernelGGL((gemm128g_kernel<true, false, 15>), grid, block, shmem, s, a, b, o, plan, workers); break;
+      case 8: hipLaunchKernelGGL((gemm128g_kernel<true, false, 8>), grid, block, shmem, s, a, b, o, plan, workers); break;
+      case 2: hipLaunchKernelGGL((gemm128g_kernel<true, false, 2>), grid, block, shmem, s, a, b, o, plan, workers); break;
+      default: hipLaunchKernelGGL((gemm128g_kernel<true, false, 4>), grid, block, shmem, s, a, b, o, plan, workers); break;
+    }
+  } else if (akc && bkc) hipLaunchKernelGGL((gemm128g_kernel<true, true>), grid, block, shmem, s, a, b, o, plan, workers);
   else if (akc) hipLaunchKernelGGL((gemm128g_kernel<true, false>), grid, block, shmem, s, a, b, o, plan, workers);
   else if (bkc) hipLaunchKernelGGL((gemm128g_kernel<false, true>), grid, block, shmem, s, a, b, o, plan, workers);
   else hipLaunchKernelGGL((gemm128g_kernel<false, false>), grid, block, shmem, s, a, b, o, plan, workers);
