@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=1500)
+    ap.add_argument("--buckets", type=int, default=4, help="gradient all-reduce buckets (N > 1)")
+    ap.add_argument("--force-dist", action="store_true", help="run the RCCL path even with one rank (smoke test)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-asg", action="store_true")
     ap.add_argument("--no-stress", action="store_true", help="skip the ASG N=9998 stress leg")
@@ -179,10 +181,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from wav2letter_amd import CriterionScaleMode, _lib, recipes
@@ -198,10 +201,17 @@ def main():
     x, tgt = make_batch(B, T, nfeat, nlabel, Lmax, 2026 + rank, device)
     total_batch = B * world
 
+    reducer = None
+    if dist is not None:
+        from wav2letter_amd.parallel import OverlappedReducer
+        reducer = OverlappedReducer(tr, n_buckets=a.buckets)
+
     def step():
         loss = tr.forward_backward(x, tgt)
-        if dist is not None:
-            dist.all_reduce(tr.grads)  # ONE collective over the flat gradient arena (814 MB fp32)
+        if reducer is not None:
+            # the flat gradient arena (814 MB fp32) in a few large buckets, last layers first, on a side
+            # stream gated by per-bucket events: the sum crosses xGMI under the rest of the backward pass
+            reducer.reduce()
         tr.update(lr=fl["lr"], momentum=fl["momentum"], max_grad_norm=fl["maxgradnorm"],
                   total_batch=total_batch)
         return loss

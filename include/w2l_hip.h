@@ -220,6 +220,13 @@ int w2l_trainer_update(void* h, float lr, float lrcrit, float momentum, float ma
                        float totalBatch, int clampCrit, void* stream);
 int w2l_trainer_viterbi(void* h, const float* emission, int* path, void* stream);
 int w2l_trainer_set_step(void* h, uint32_t step);
+/* Data-parallel overlap (replaces fl::CoalescingReducer, recipes/slimIPL/src/Train.cpp:195, :1721-1735):
+ * bucket k = [offsets[k], offsets[k+1]) of the flat gradient arena (ascending float offsets; the last
+ * bucket runs to the end).  forward_backward records one event per bucket on its stream as soon as every
+ * gradient at offset >= offsets[k] is final (backward walks the layers last to first);
+ * wait_bucket makes `stream` (the collective's stream) wait for bucket k.  n = 0 removes the hooks. */
+int w2l_trainer_set_grad_buckets(void* h, int n, const size_t* offsets);
+int w2l_trainer_wait_bucket(void* h, int k, void* stream);
 /* roofline instrumentation: bracket every MFMA GEMM launch with hipEvents on its stream */
 int w2l_profile_enable(int on);
 int w2l_profile_report(int* launches, double* totalMs, double* totalFlops); /* kind 0 */

@@ -79,3 +79,44 @@ def test_single_process_is_a_no_op():
     a = parallel.GradientArena(5, "cpu")
     a.set_local_batch(3)
     assert a.all_reduce().item() == 3.0
+
+
+def test_bucket_offsets_cut_at_parameter_boundaries():
+    from wav2letter_amd.parallel import bucket_offsets
+    table, off = [], 0
+    for i, n in enumerate([10, 4000, 12, 3000, 3000, 8, 52000, 100, 7000]):
+        table.append((f"p{i}", n, off))
+        off += (n + 3) // 4 * 4
+    total = off + 900  # criterion parameters behind the network's
+    bounds = {o for _, _, o in table}
+    for nb in (1, 2, 3, 4, 8, 32):
+        offs = bucket_offsets(table, total, nb)
+        assert offs[0] == 0 and offs == sorted(set(offs)) and len(offs) <= nb
+        assert all(o in bounds for o in offs)
+    assert bucket_offsets(table, total, 1) == [0]
+
+
+def _bucket_worker(rank, world, port):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from wav2letter_amd import parallel
+    parallel.init_distributed("gloo")
+    n = 10007
+    g = torch.Generator().manual_seed(rank)
+    grads = torch.randn(n, generator=g)
+    whole = grads.clone()
+    dist.all_reduce(whole)
+    offs = [0, 1000, 1004, 7000] + [n]
+    works = []
+    for k in reversed(range(len(offs) - 1)):  # the order OverlappedReducer uses: last layers first
+        works.append(dist.all_reduce(grads[offs[k]:offs[k + 1]], async_op=True))
+    for w in works:
+        w.wait()
+    assert torch.equal(grads, whole)  # bucketing must not change the sum (same pairwise order per element)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_bucketed_reduce_equals_one_collective():
+    mp.spawn(_bucket_worker, args=(2, _free_port()), nprocs=2, join=True)

@@ -127,3 +127,54 @@ def test_training_reduces_loss():
         tr.update(lr=0.05, momentum=0.5, max_grad_norm=1.0)
     assert np.isfinite(losses).all()
     assert losses[-1] < 0.7 * losses[0], losses
+
+
+def test_gradient_bucket_events_and_single_rank_rccl():
+    """the data-parallel overlap path on one GPU: bucket events recorded during backward gate a side stream,
+    a 1-rank RCCL ("nccl") process group runs the bucketed all-reduce, gradients and the update are
+    unchanged against the plain step"""
+    import os
+    import socket
+    import torch.distributed as dist
+    from wav2letter_amd import recipes
+    from wav2letter_amd.parallel import OverlappedReducer
+    from wav2letter_amd.trainer import Trainer
+    rng = np.random.default_rng(5)
+    nfeat, nlabel, B, T, L = 8, 12, 4, 48, 5
+    arch = recipes.tds_ctc_small_arch(c=(4, 6), h=nfeat, kw=5)
+
+    def make():
+        tr = Trainer(arch, nfeat, nlabel, "ctc", 4)
+        tr.init_params(3)
+        tr.plan(B, T, L)
+        tr.to_device()
+        return tr
+    x = torch.tensor(rng.normal(size=(B, nfeat, T)).astype(np.float32)).cuda()
+    tgt = torch.tensor(rng.integers(0, nlabel - 1, size=(B, L)).astype(np.int32)).cuda()
+    ref = make()
+    ref.forward_backward(x, tgt)
+    g_ref = ref.grads.clone()
+    ref.update(lr=0.1, momentum=0.5, max_grad_norm=1.0)
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        tr = make()
+        red = OverlappedReducer(tr, n_buckets=3)
+        assert red.offsets[0] == 0 and red.offsets[-1] == tr.n_floats and len(red.offsets) >= 3
+        for _ in range(2):  # events are re-recorded every step
+            tr.set_step(0)
+            tr.grads.zero_()
+            tr.forward_backward(x, tgt)
+            red.reduce()
+            torch.cuda.synchronize()
+            assert torch.equal(tr.grads, g_ref)
+        tr.update(lr=0.1, momentum=0.5, max_grad_norm=1.0)
+        assert torch.equal(tr.params, ref.params)
+        with pytest.raises(Exception):
+            tr.wait_bucket(99, red.comm)
+        tr.set_grad_buckets([])  # hooks off again
+        tr.forward_backward(x, tgt)
+    finally:
+        dist.destroy_process_group()

@@ -24,6 +24,8 @@
 //
 // MFMA roofline note: N = C_out is padded to 16 (32 for C = 18), so the matrix-pipe ceiling
 // of this op is C/16 = 62.5 % / 87.5 % / 56 % of the fp32 peak by construction.
+#include <cstdlib>
+
 #include "gemm.hpp"
 
 namespace w2l {
@@ -243,6 +245,152 @@ __global__ __launch_bounds__(256) void tds_conv_filter_k(TdsConvP p, const float
   }
 }
 
+
+// ---------------------------------------------------------------- backward-filter, pipelined
+// Same chunking / fragment scheme as tds_conv_filter_k, but the global -> LDS staging is built for
+// latency: every thread owns a FIXED set of float4 pieces of a chunk (slab pieces + dy pieces,
+// descriptors in registers), issues all of them for chunk c+1 back to back BEFORE multiplying chunk
+// c, and writes them to LDS afterwards.  The first version loaded one element per loop trip with the
+// s_waitcnt right behind it: ~16 serialized HBM round trips per chunk (43 us per chunk measured,
+// against 3 us of MFMA work).  Requires whole 16-row mel blocks (H % 16 == 0), 16-byte aligned rows.
+constexpr int kTdsMaxXV = 12;  // float4 slab pieces per thread
+constexpr int kTdsMaxDV = 5;   // float4 dy pieces per thread
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void tds_conv_filter2_k(TdsConvP p, const float* __restrict__ dy, float* __restrict__ partial,
+                                                            int nChunks, int tBlocks, int hBlocks, int rowTiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* slab = lds;
+  float* dyS = slab + ((p.NF * p.FS + 3) & ~3);  // [256][Cout]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, lq = lane >> 4;
+
+  int ko[kTdsMaxTilesPerWave];
+  bool one[kTdsMaxTilesPerWave], val[kTdsMaxTilesPerWave];
+#pragma unroll
+  for (int tl = 0; tl < kTdsMaxTilesPerWave; ++tl) {
+    const int kk = 16 * (wave + 4 * tl) + i;
+    const int tap = kk / p.Cin, c = kk - tap * p.Cin;
+    val[tl] = kk < p.K;
+    one[tl] = kk == p.K;
+    ko[tl] = val[tl] ? tap * p.FS + c : 0;
+  }
+  f32x4 acc[kTdsMaxTilesPerWave][NT];
+#pragma unroll
+  for (int tl = 0; tl < kTdsMaxTilesPerWave; ++tl)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[tl][nt][q] = 0.f;
+
+  // piece descriptors (chunk-independent): slab piece v -> frame f, float offset o inside the frame
+  const int xq = (kTdsBH * p.Cin) >> 2;          // float4 per slab frame
+  const int xTotal = p.NF * xq;
+  const int dq = (kTdsBH * p.Cout) >> 2;         // float4 per dy frame
+  const int dTotal = kTdsBTF * dq;
+  const int HCi = p.H * p.Cin, HCo = p.H * p.Cout;
+  int xf[kTdsMaxXV], xo[kTdsMaxXV];
+#pragma unroll
+  for (int v = 0; v < kTdsMaxXV; ++v) {
+    const int e = tid + 256 * v;
+    xf[v] = e < xTotal ? e / xq : -1;
+    xo[v] = e < xTotal ? (e - xf[v] * xq) << 2 : 0;
+  }
+  int df[kTdsMaxDV], dof[kTdsMaxDV];
+#pragma unroll
+  for (int v = 0; v < kTdsMaxDV; ++v) {
+    const int e = tid + 256 * v;
+    df[v] = e < dTotal ? e / dq : -1;
+    dof[v] = e < dTotal ? (e - df[v] * dq) << 2 : 0;
+  }
+  // the 4-float pad of every slab frame is never overwritten: zero it once
+  for (int f = tid; f < p.NF; f += 256) *(float4*)(slab + f * p.FS + kTdsBH * p.Cin) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  float4 xr[kTdsMaxXV], dr[kTdsMaxDV];
+  auto fetch = [&](int chunk) {
+    const int hb = chunk % hBlocks, tb = (chunk / hBlocks) % tBlocks, b = chunk / (hBlocks * tBlocks);
+    const int h0 = hb * kTdsBH, t0 = tb * kTdsBTF, tIn0 = t0 * p.stride - p.padl;
+    const float* xb = p.x + ((size_t)b * p.Tin * p.H + h0) * p.Cin;
+    const float* db = dy + ((size_t)b * p.Tout * p.H + h0) * p.Cout;
+#pragma unroll
+    for (int v = 0; v < kTdsMaxXV; ++v) {
+      const int ti = tIn0 + xf[v];
+      const bool ok = xf[v] >= 0 && ti >= 0 && ti < p.Tin;
+      // unconditional load from a clamped (valid) address + select: no branch around the load
+      const float4 t4 = *(const float4*)(xb + (size_t)(ok ? ti : 0) * HCi + xo[v]);
+      xr[v] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int v = 0; v < kTdsMaxDV; ++v) {
+      const int t = t0 + df[v];
+      const bool ok = df[v] >= 0 && t < p.Tout;
+      const float4 t4 = *(const float4*)(db + (size_t)(ok ? t : 0) * HCo + dof[v]);
+      dr[v] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  int chunk = blockIdx.x;
+  if (chunk < nChunks) fetch(chunk);
+  for (; chunk < nChunks; chunk += gridDim.x) {
+    __syncthreads();  // previous chunk's fragment reads are done
+#pragma unroll
+    for (int v = 0; v < kTdsMaxXV; ++v)
+      if (xf[v] >= 0) *(float4*)(slab + xf[v] * p.FS + xo[v]) = xr[v];
+#pragma unroll
+    for (int v = 0; v < kTdsMaxDV; ++v)
+      if (df[v] >= 0) *(float4*)(dyS + df[v] * (kTdsBH * p.Cout) + dof[v]) = dr[v];
+    __syncthreads();
+    const int nxt = chunk + gridDim.x;
+    fetch(nxt < nChunks ? nxt : chunk);  // in flight behind this chunk's MFMAs (last trip: harmless re-load)
+#pragma unroll 4
+    for (int kq = 0; kq < kTdsBTF * kTdsBH / 4; ++kq) {
+      const int m = 4 * kq + lq;
+      const int rowoff = (m >> 4) * p.stride * p.FS + (m & 15) * p.Cin;
+      float bf[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bf[nt] = (16 * nt + i < p.Cout) ? dyS[m * p.Cout + 16 * nt + i] : 0.f;
+#pragma unroll
+      for (int tl = 0; tl < kTdsMaxTilesPerWave; ++tl) {
+        if (wave + 4 * tl < rowTiles) {  // wave-uniform
+          float a = slab[rowoff + ko[tl]];
+          a = one[tl] ? 1.f : (val[tl] ? a : 0.f);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[tl][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[nt], acc[tl][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float* dst = partial + (size_t)blockIdx.x * rowTiles * 16 * (16 * NT);
+#pragma unroll
+  for (int tl = 0; tl < kTdsMaxTilesPerWave; ++tl) {
+    const int tile = wave + 4 * tl;
+    if (tile < rowTiles) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[(size_t)(tile * 16 + 4 * lq + q) * (16 * NT) + 16 * nt + i] = acc[tl][nt][q];
+    }
+  }
+}
+
+// dw[kk][co] = sum_g partial[g][kk][co] ; dbias[co] = row K.  One workgroup per output row kk: 16 lanes
+// span the columns, 16 lane groups stride over the parts, fixed-order LDS tree (deterministic).
+__global__ __launch_bounds__(256) void tds_conv_filter_reduce2_k(const float* __restrict__ partial, int nParts, int rows, int ncp,
+                                                                int K, int Cout, float* __restrict__ dw, float* __restrict__ dbias) {
+  __shared__ float red[16][32];
+  const int kk = blockIdx.x, col = threadIdx.x % ncp, grp = threadIdx.x / ncp, ngrp = 256 / ncp;
+  float s = 0.f;
+  for (int g = grp; g < nParts; g += ngrp) s += partial[((size_t)g * rows + kk) * ncp + col];
+  red[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && col < Cout) {
+    float t = 0.f;
+    for (int g = 0; g < ngrp; ++g) t += red[g][col];
+    if (kk < K) dw[(size_t)kk * Cout + col] = t;
+    else if (dbias) dbias[col] = t;
+  }
+}
+
 // dw[kk][co] = sum_g partial[g][kk][co] ; dbias[co] = row K
 __global__ __launch_bounds__(256) void tds_conv_filter_reduce_k(const float* __restrict__ partial, int nParts, int rows, int ncp,
                                                                int K, int Cout, float* __restrict__ dw, float* __restrict__ dbias) {
@@ -341,7 +489,26 @@ int tds_conv_backward_filter(const w2l_conv_desc* d, const float* x, const float
   float* partial = sk_scratch(s, (size_t)kSkSlots * 2 * kSlabFloats * sizeof(float));
   if (!partial || partFloats > (size_t)kSkSlots * 2 * kSlabFloats) return W2L_EUNSUPPORTED;
   const double flops = 2.0 * d->B * To * (double)d->H * p.K * d->Cout;
+  // pipelined kernel: whole mel blocks, float4-addressable rows, piece counts within the register budget
+  const int xPieces = (p.NF * ((kTdsBH * p.Cin) >> 2) + 255) / 256, dPieces = (kTdsBTF * ((kTdsBH * p.Cout) >> 2) + 255) / 256;
+  const bool fast = d->H % kTdsBH == 0 && (d->H * d->Cin) % 4 == 0 && (d->H * d->Cout) % 4 == 0 && (kTdsBH * d->Cin) % 4 == 0 &&
+                    (kTdsBH * d->Cout) % 4 == 0 && xPieces <= kTdsMaxXV && dPieces <= kTdsMaxDV &&
+                    (((uintptr_t)x | (uintptr_t)dy) & 15) == 0 && !getenv("W2L_TDS_FILTER_V1");
   prof_begin(s, flops, PROF_TDSCONV);
+  if (fast) {
+    if (NT == 1) {
+      if (shmem > 64 * 1024) W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_filter2_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+      hipLaunchKernelGGL(tds_conv_filter2_k<1>, dim3((unsigned)blocks), dim3(256), shmem, s, p, dy, partial, nChunks, tBlocks, hBlocks, rowTiles);
+    } else {
+      if (shmem > 64 * 1024) W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_filter2_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+      hipLaunchKernelGGL(tds_conv_filter2_k<2>, dim3((unsigned)blocks), dim3(256), shmem, s, p, dy, partial, nChunks, tBlocks, hBlocks, rowTiles);
+    }
+    hipLaunchKernelGGL(tds_conv_filter_reduce2_k, dim3((unsigned)(p.K + 1)), dim3(256), 0, s, partial, blocks, rowTiles * 16,
+                       16 * NT, p.K, d->Cout, dw, dbias);
+    prof_end(s);
+    W2L_LAUNCH_CHECK();
+    return W2L_OK;
+  }
   if (NT == 1) {
     if (shmem > 64 * 1024) W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_filter_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL(tds_conv_filter_k<1>, dim3((unsigned)blocks), dim3(256), shmem, s, p, dy, partial, nChunks, tBlocks, hBlocks, rowTiles);

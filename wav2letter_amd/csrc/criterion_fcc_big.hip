@@ -48,12 +48,13 @@ constexpr int kBigMaxSW = 16;          // bound on partial slabs per row group
 
 struct BigDims {
   int B, T, N;
-  int Np;   // rows padded to 64
+  int RT;   // 32-row MFMA tiles per wave (row group = 32 RT rows)
+  int Np;   // rows padded to a whole number of row groups
   int Kp;   // reduction length padded to 32
   int NC;   // Kp / 8 chunks
   int NB;   // ceil(B / 32) rounded to 1, 2, 4
   int Bp;   // 32 * NB
-  int G;    // Np / 64 row groups
+  int G;    // Np / (32 RT) row groups
   int nS;   // pipeline stages (of kBigU chunks) per row group
   int U;    // G * nS stage-units of one step
   int W;    // persistent workgroups of the streaming kernel: worker w owns units [U w / W, U (w+1) / W)
@@ -69,16 +70,28 @@ inline int big_workers_per_cu(int NB) {
   return 2;
 }
 
+// 32-row tiles per wave.  One E fragment (the [utterance][k] operand, re-read by EVERY row group out of
+// L2) feeds RT MFMAs: at RT = 2 a third of the kernel's vector-memory instructions were E re-reads and
+// the stream sat at the per-CU load-path rate (~11 B/clk/CU) rather than at HBM's; RT = 4 makes it a
+// fifth.  NB >= 2 keeps RT = 2 (registers).  W2L_FCC_RT=2 forces the old shape for A/B runs.
+inline int big_row_tiles(int NB) {
+  if (NB >= 2) return 2;
+  const char* e = getenv("W2L_FCC_RT");
+  if (e && e[0] == '2') return 2;
+  return 4;
+}
+
 inline BigDims big_dims(int B, int T, int N) {
   BigDims d;
   d.B = B; d.T = T; d.N = N;
-  d.Np = (N + 63) / 64 * 64;
   d.Kp = (N + 31) / 32 * 32;
   d.NC = d.Kp / 8;
   int nb = (B + 31) / 32;
   d.NB = nb <= 1 ? 1 : (nb <= 2 ? 2 : 4);
   d.Bp = 32 * d.NB;
-  d.G = d.Np / 64;
+  d.RT = big_row_tiles(d.NB);
+  d.Np = (N + 32 * d.RT - 1) / (32 * d.RT) * (32 * d.RT);
+  d.G = d.Np / (32 * d.RT);
   // The step is cut into U = G * nS stage-units (64 rows x 32 k) in row-group-major order and dealt
   // to W PERSISTENT workgroups in equal contiguous ranges: 2 workgroups per CU at B <= 32 (register-
   // limited, big_workers_per_cu) all resident at once, so the stream has no partially filled last
@@ -187,30 +200,28 @@ __global__ __launch_bounds__(256) void big_pack_k(int N, int NC, size_t total4, 
 // ------------------------------------------------------------------ kernel 1: the streaming GEMM
 // part[sw][b][r] = sum_{k in split} f(op[b][k]) * pack[r][k]   for the 64 rows of group g,
 // f = exp(. - c_b) in the forward recursion (EXPOP), identity in the backward one.
-template <int NB>
+template <int NB, int RT>
 struct BigStage {
-  float4 a0[kBigU], a1[kBigU], e[NB][kBigU];
+  float4 a[RT][kBigU], e[NB][kBigU];
 };
 
-template <int NB>
-__device__ __forceinline__ void big_load_stage(BigStage<NB>& st, const float4* __restrict__ pa0,
-                                               const float4* __restrict__ pa1, const float4* __restrict__ pe, int NC, int s) {
+template <int NB, int RT>
+__device__ __forceinline__ void big_load_stage(BigStage<NB, RT>& st, const float4* __restrict__ pa, size_t tileStride,
+                                               const float4* __restrict__ pe, int NC, int s) {
 #pragma unroll
   for (int u = 0; u < kBigU; ++u) {
     const size_t c = (size_t)s * kBigU + u;
-    st.a0[u] = pa0[c * 64];
-    st.a1[u] = pa1[c * 64];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) st.a[rt][u] = pa[rt * tileStride + c * 64];
 #pragma unroll
     for (int bt = 0; bt < NB; ++bt) st.e[bt][u] = pe[((size_t)bt * NC + c) * 64];
   }
 }
 
-template <int NB, bool EXPOP>
-__device__ __forceinline__ void big_compute_stage(const BigStage<NB>& st, const float (&cb)[NB], f32x16 (&acc)[NB][2]) {
+template <int NB, int RT, bool EXPOP>
+__device__ __forceinline__ void big_compute_stage(const BigStage<NB, RT>& st, const float (&cb)[NB], f32x16 (&acc)[NB][RT]) {
 #pragma unroll
   for (int u = 0; u < kBigU; ++u) {
-    const float a0[4] = {st.a0[u].x, st.a0[u].y, st.a0[u].z, st.a0[u].w};
-    const float a1[4] = {st.a1[u].x, st.a1[u].y, st.a1[u].z, st.a1[u].w};
 #pragma unroll
     for (int bt = 0; bt < NB; ++bt) {
       float ev[4] = {st.e[bt][u].x, st.e[bt][u].y, st.e[bt][u].z, st.e[bt][u].w};
@@ -219,18 +230,20 @@ __device__ __forceinline__ void big_compute_stage(const BigStage<NB>& st, const 
         for (int q = 0; q < 4; ++q) ev[q] = __expf(ev[q] - cb[bt]);  // padding holds -inf -> 0
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        acc[bt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ev[q], a0[q], acc[bt][0], 0, 0, 0);
-        acc[bt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ev[q], a1[q], acc[bt][1], 0, 0, 0);
-      }
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const float av = q == 0 ? st.a[rt][u].x : (q == 1 ? st.a[rt][u].y : (q == 2 ? st.a[rt][u].z : st.a[rt][u].w));
+          acc[bt][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ev[q], av, acc[bt][rt], 0, 0, 0);
+        }
     }
   }
 }
 
-template <int NB, bool EXPOP>
+template <int NB, int RT, bool EXPOP>
 __global__ __launch_bounds__(256, NB <= 1 ? 2 : 1) void fcc_big_gemm(const float4* __restrict__ pack, const float4* __restrict__ op,
                                                        const float* __restrict__ pmax, float* __restrict__ part, BigDims d) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][NB*2*16 regs][64 lanes]
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][NB*RT*16 regs][64 lanes]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int NC = d.NC, Np = d.Np, Bp = d.Bp, B = d.B;
   const int w = blockIdx.x;
@@ -264,16 +277,16 @@ __global__ __launch_bounds__(256, NB <= 1 ? 2 : 1) void fcc_big_gemm(const float
     const int s0 = sb + (int)((long long)len * wave / 4), s1 = sb + (int)((long long)len * (wave + 1) / 4);
     const int piece = w - big_worker_of(d, g * d.nS);
 
-    f32x16 acc[NB][2];
+    f32x16 acc[NB][RT];
 #pragma unroll
     for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < RT; ++h)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[bt][h][r] = 0.f;
 
-    const float4* pa0 = pack + ((size_t)(2 * g) * NC) * 64 + lane;
-    const float4* pa1 = pack + ((size_t)(2 * g + 1) * NC) * 64 + lane;
+    const float4* pa = pack + ((size_t)(RT * g) * NC) * 64 + lane;  // row tile rt of the group: + rt * tileStride
+    const size_t tileStride = (size_t)NC * 64;
 
     // three register sets in a ring: the loads of stages s+1 and s+2 are in flight behind the MFMAs of
     // stage s (24 KiB per wave, 192 KiB per CU: one set in flight left the stream latency-bound --
@@ -283,50 +296,50 @@ __global__ __launch_bounds__(256, NB <= 1 ? 2 : 1) void fcc_big_gemm(const float
     // assume the worst at the join and wait vmcnt(0), which drains the whole ring every stage.
     if (s0 < s1) {
       const int sl = s1 - 1;
-      if constexpr (NB >= 4) {  // 192 operand VGPRs per stage: two sets in ping-pong are all that fits
-        BigStage<NB> sa, sb2;
-        big_load_stage<NB>(sa, pa0, pa1, pe, NC, s0);
+      if constexpr (NB >= 4 || RT >= 4) {  // 192 (80 at RT = 4) operand VGPRs per stage: two sets in ping-pong are all that fits
+        BigStage<NB, RT> sa, sb2;
+        big_load_stage<NB, RT>(sa, pa, tileStride, pe, NC, s0);
         for (int s = s0; s < s1; s += 2) {
-          big_load_stage<NB>(sb2, pa0, pa1, pe, NC, min(s + 1, sl));
-          big_compute_stage<NB, EXPOP>(sa, cb, acc);
-          big_load_stage<NB>(sa, pa0, pa1, pe, NC, min(s + 2, sl));
-          if (s + 1 < s1) big_compute_stage<NB, EXPOP>(sb2, cb, acc);
+          big_load_stage<NB, RT>(sb2, pa, tileStride, pe, NC, min(s + 1, sl));
+          big_compute_stage<NB, RT, EXPOP>(sa, cb, acc);
+          big_load_stage<NB, RT>(sa, pa, tileStride, pe, NC, min(s + 2, sl));
+          if (s + 1 < s1) big_compute_stage<NB, RT, EXPOP>(sb2, cb, acc);
         }
       } else {
         // three register sets in a ring: the loads of stages s+1 and s+2 are in flight behind the MFMAs
         // of stage s (24 KiB per wave, 192 KiB per CU: with one set in flight the stream was latency-bound
         // -- bytes in flight / loaded HBM latency -- at 4.4 TB/s on MI355X)
-        BigStage<NB> r0, r1, r2;
-        big_load_stage<NB>(r0, pa0, pa1, pe, NC, s0);
-        big_load_stage<NB>(r1, pa0, pa1, pe, NC, min(s0 + 1, sl));
+        BigStage<NB, RT> r0, r1, r2;
+        big_load_stage<NB, RT>(r0, pa, tileStride, pe, NC, s0);
+        big_load_stage<NB, RT>(r1, pa, tileStride, pe, NC, min(s0 + 1, sl));
         for (int s = s0; s < s1; s += 3) {
-          big_load_stage<NB>(r2, pa0, pa1, pe, NC, min(s + 2, sl));
-          big_compute_stage<NB, EXPOP>(r0, cb, acc);
-          big_load_stage<NB>(r0, pa0, pa1, pe, NC, min(s + 3, sl));
-          if (s + 1 < s1) big_compute_stage<NB, EXPOP>(r1, cb, acc);
-          big_load_stage<NB>(r1, pa0, pa1, pe, NC, min(s + 4, sl));
-          if (s + 2 < s1) big_compute_stage<NB, EXPOP>(r2, cb, acc);
+          big_load_stage<NB, RT>(r2, pa, tileStride, pe, NC, min(s + 2, sl));
+          big_compute_stage<NB, RT, EXPOP>(r0, cb, acc);
+          big_load_stage<NB, RT>(r0, pa, tileStride, pe, NC, min(s + 3, sl));
+          if (s + 1 < s1) big_compute_stage<NB, RT, EXPOP>(r1, cb, acc);
+          big_load_stage<NB, RT>(r1, pa, tileStride, pe, NC, min(s + 4, sl));
+          if (s + 2 < s1) big_compute_stage<NB, RT, EXPOP>(r2, cb, acc);
         }
       }
     }
 
     // 4-wave reduction through LDS, fixed order (deterministic)
-    constexpr int NR = NB * 2 * 16;
+    constexpr int NR = NB * RT * 16;
 #pragma unroll
     for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < RT; ++h)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[((wave * NR) + (bt * 2 + h) * 16 + r) * 64 + lane] = acc[bt][h][r];
+        for (int r = 0; r < 16; ++r) red[((wave * NR) + (bt * RT + h) * 16 + r) * 64 + lane] = acc[bt][h][r];
     __syncthreads();
     // D layout of the 32x32 MFMA: column (row of EA) = lane & 31, row (utterance) = (r&3) + 8 (r>>2) + 4 (lane>>5)
     float* dst = part + (size_t)piece * Bp * Np;
     for (int o = threadIdx.x; o < NR * 64; o += 256) {
       const float v = (red[o] + red[NR * 64 + o]) + (red[2 * NR * 64 + o] + red[3 * NR * 64 + o]);
       const int l = o & 63, rr = o >> 6;
-      const int r = rr & 15, h = (rr >> 4) & 1, bt = rr >> 5;
+      const int r = rr & 15, h = (rr >> 4) % RT, bt = (rr >> 4) / RT;
       const int b = 32 * bt + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-      const int i = 64 * g + 32 * h + (l & 31);
+      const int i = 32 * RT * g + 32 * h + (l & 31);
       dst[(size_t)b * Np + i] = v;
     }
     u0 += len;
@@ -391,7 +404,7 @@ __global__ __launch_bounds__(256) void fcc_big_step(BigDims d, int t, const floa
     float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (t > 0) {
       float4 p4[kBigMaxSW];  // all slab loads in flight together, added in worker order
-      const int np = big_pieces(d, i0 >> 6);
+      const int np = big_pieces(d, i0 / (32 * d.RT));
 #pragma unroll
       for (int s = 0; s < kBigMaxSW; ++s)
         p4[s] = s < np ? *(const float4*)(ws.part + ((size_t)s * d.Bp + b) * d.Np + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -503,7 +516,7 @@ __global__ __launch_bounds__(256) void fcc_big_bwd_step(BigDims d, int tm, float
   float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
   {
     float4 p4[kBigMaxSW];
-    const int np = big_pieces(d, i0 >> 6);
+    const int np = big_pieces(d, i0 / (32 * d.RT));
 #pragma unroll
     for (int s = 0; s < kBigMaxSW; ++s)
       p4[s] = s < np ? *(const float4*)(ws.part + ((size_t)s * d.Bp + b) * d.Np + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -540,13 +553,15 @@ __global__ __launch_bounds__(256) void fcc_big_scale_dtrans(int N, const float* 
   }
 }
 
-template <int NB, bool EXPOP>
+template <int NB, int RT, bool EXPOP>
 static int launch_big_gemm(const BigDims& d, const float* pack, const float* op, const float* pmax, float* part,
                            hipStream_t s) {
-  const size_t shmem = (size_t)4 * NB * 2 * 16 * 64 * sizeof(float);
+  const size_t shmem = (size_t)4 * NB * RT * 16 * 64 * sizeof(float);
+  if (shmem > 64 * 1024)
+    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)fcc_big_gemm<NB, RT, EXPOP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   // algorithmic bytes of one step: the transition matrix once + read/write of one [B][N] row pair
   prof_begin(s, 4.0 * d.N * (double)d.N + 8.0 * d.B * (double)d.N, PROF_FCC_STREAM);
-  hipLaunchKernelGGL((fcc_big_gemm<NB, EXPOP>), dim3((unsigned)d.W), dim3(256), shmem, s, (const float4*)pack,
+  hipLaunchKernelGGL((fcc_big_gemm<NB, RT, EXPOP>), dim3((unsigned)d.W), dim3(256), shmem, s, (const float4*)pack,
                      (const float4*)op, pmax, part, d);
   prof_end(s);
   W2L_LAUNCH_CHECK();
@@ -554,9 +569,10 @@ static int launch_big_gemm(const BigDims& d, const float* pack, const float* op,
 }
 template <bool EXPOP>
 static int big_gemm(const BigDims& d, const float* pack, const float* op, const float* pmax, float* part, hipStream_t s) {
-  if (d.NB == 1) return launch_big_gemm<1, EXPOP>(d, pack, op, pmax, part, s);
-  if (d.NB == 2) return launch_big_gemm<2, EXPOP>(d, pack, op, pmax, part, s);
-  return launch_big_gemm<4, EXPOP>(d, pack, op, pmax, part, s);
+  if (d.NB == 1) return d.RT == 4 ? launch_big_gemm<1, 4, EXPOP>(d, pack, op, pmax, part, s)
+                                  : launch_big_gemm<1, 2, EXPOP>(d, pack, op, pmax, part, s);
+  if (d.NB == 2) return launch_big_gemm<2, 2, EXPOP>(d, pack, op, pmax, part, s);
+  return launch_big_gemm<4, 2, EXPOP>(d, pack, op, pmax, part, s);
 }
 
 bool fcc_big_supported(int B, int T, int N) {

@@ -419,15 +419,21 @@ __device__ __forceinline__ void gemm128_epilogue(const GemmOut& out, int m0, int
     }
 }
 
-// slab element of (acc index a = 2i+j, register r) of this thread: ((wave*4 + a)*16 + r)*64 + lane
+// slab float4 of (acc index a = 2i+j, register quad q) of this thread: ((wave*4 + a)*4 + q)*64 + lane
+// (16-byte stores: 16 per lane instead of 64 dword stores)
 __device__ __forceinline__ void gemm128_store_partial(float* slab, const f32x16 (&acc)[2][2]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4* s4 = (f32x4*)slab;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) slab[((wave * 4 + i * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+        v[0] = acc[i][j][4 * q]; v[1] = acc[i][j][4 * q + 1]; v[2] = acc[i][j][4 * q + 2]; v[3] = acc[i][j][4 * q + 3];
+        s4[((wave * 4 + i * 2 + j) * 4 + q) * 64 + lane] = v;
+      }
 }
 
 template <class AOp, class BOp>
@@ -485,13 +491,16 @@ __global__ __launch_bounds__(256) void gemm128_fixup(GemmOut out, SkPlan plan) {
     const long long b0 = sk_begin(plan, s);
     if (sk_begin(plan, s + 1) <= tb) continue;
     const int segIdx = t - (int)(b0 / plan.kTiles);  // ranges span <= 2 tiles: 0 or 1
-    const float* slab = plan.slabs + ((size_t)s * 2 + segIdx) * kSlabFloats;
+    const f32x4* s4 = (const f32x4*)(plan.slabs + ((size_t)s * 2 + segIdx) * kSlabFloats);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] += slab[((wave * 4 + i * 2 + j) * 16 + r) * 64 + lane];
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = s4[((wave * 4 + i * 2 + j) * 4 + q) * 64 + lane];
+          acc[i][j][4 * q] += v[0]; acc[i][j][4 * q + 1] += v[1]; acc[i][j][4 * q + 2] += v[2]; acc[i][j][4 * q + 3] += v[3];
+        }
   }
   const int tile = plan.dpTiles + t;
   int bx, by;

@@ -92,6 +92,76 @@ __device__ __forceinline__ void g_frag(float (&f)[2][4], const float* tile, int 
   }
 }
 
+
+// Epilogue with 16-byte stores.  The MFMA C layout gives a lane 16 rows of ONE column, so the direct
+// epilogue (gemm128_epilogue) issues 64 global_store_dword per lane and per tile -- store-issue bound: with
+// the K loop ablated the TDS fc shapes ran at 117 TF/s against 145 TF/s at 4096^3 (MI355X).  Here each
+// wave turns its 64x64 sub-tile through its own 8 KiB slice of the LDS stage that the K loop has just
+// released (two 32-row halves): ds_write_b32 in C layout, ds_read_b128 as 4 rows x 16 float4 per
+// instruction, then 16 global_store_dwordx4 per lane.  Bias / ReLU / mask / accumulate are applied on
+// the float4.  Requires a 16-byte aligned C and ldc % 4 == 0 (host-checked; `wide` false otherwise).
+__device__ __forceinline__ void gemm128g_epilogue_wide(const GemmOut& out, int m0, int n0, const f32x16 (&acc)[2][2],
+                                                       float* scratch) {
+  const int EPI = out.epi;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int li = lane & 31, lh = lane >> 5;
+  float* sc = scratch + wave * 2048;       // [32 rows][64 cols] of this wave
+  const int c4 = 4 * (lane & 15), rq = lane >> 4;
+  const int n = n0 + wn + c4;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (EPI & EPI_BIAS) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = n + e < out.N ? out.bias[n + e] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[((r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + j * 32 + li] = acc[i][j][r];
+    // same wave wrote and reads: LDS operations of one wave complete in order, no barrier needed
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int row = 4 * p + rq;
+      const f32x4 v4 = *(const f32x4*)(sc + row * 64 + c4);
+      const int m = m0 + wm + 32 * i + row;
+      if (m >= out.M || n >= out.N) continue;
+      float v[4] = {v4[0] + bv[0], v4[1] + bv[1], v4[2] + bv[2], v4[3] + bv[3]};
+      float* dst = out.C + (size_t)m * out.ldc + n;
+      if (EPI & EPI_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (n + 3 < out.N) {
+        if (EPI & EPI_MASK) {
+          const f32x4 mk = *(const f32x4*)(out.mask + (size_t)m * out.ldc + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] * out.maskScale : 0.f;
+        }
+        if (EPI & EPI_ACCUM) {
+          const f32x4 o = *(const f32x4*)dst;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += o[e];
+        }
+        f32x4 w4;
+        w4[0] = v[0]; w4[1] = v[1]; w4[2] = v[2]; w4[3] = v[3];
+        *(f32x4*)dst = w4;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (n + e >= out.N) continue;
+          float t = v[e];
+          if (EPI & EPI_MASK) t = out.mask[(size_t)m * out.ldc + n + e] > 0.f ? t * out.maskScale : 0.f;
+          if (EPI & EPI_ACCUM) t += dst[e];
+          dst[e] = t;
+        }
+      }
+    }
+    // the second half overwrites the slice only after this wave's reads have returned (in-order LDS queue)
+  }
+}
+
 struct GSeg {
   int tile, kb, ke, slab;  // slab: index of the partial slab (stream-K ranges), -1 = whole tile
   bool valid;
@@ -129,9 +199,10 @@ __device__ __forceinline__ GSeg g_segment(const SkPlan& p, int w, int workers, i
 }
 
 // ABL: timing-only ablations (results are garbage) selected by W2L_GEMM_ABL for the probe tool:
-//   1 = no LDS-DMA, 2 = no per-K-tile barrier, 4 = no fragment reads in the loop, 8 = no epilogue
+//   1 = no LDS-DMA, 2 = no per-K-tile barrier, 4 = no fragment reads in the loop, 8 = no epilogue,
+//   16 = LDS-DMA always re-reads K tile 0 (cache-resident source), 32 = LDS-DMA of the A operand only
 template <bool AKC, bool BKC, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, GemmOut out, SkPlan plan, int workers) {
+__global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, GemmOut out, SkPlan plan, int workers, int wide) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -211,8 +282,8 @@ __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, Gemm
           } else {
             const int piece = step - 1 - g;  // steps 1,2,3,5,6,7,9,10 -> pieces 0..7
             if (!(ABL & 1)) {
-              if (piece < 4) g_issue1(qa[piece], offA, An, wave, piece);
-              else if (piece < 8) g_issue1(qb[piece - 4], offB, An + 4096, wave, piece - 4);
+              if (piece < 4) g_issue1(qa[piece], (ABL & 16) ? 0 : offA, An, wave, piece);
+              else if (piece < 8 && !(ABL & 32)) g_issue1(qb[piece - 4], (ABL & 16) ? 0 : offB, An + 4096, wave, piece - 4);
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -223,10 +294,19 @@ __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, Gemm
     }
 
     if (ABL & 8) {
-      if (acc[0][0][0] == 123.456f) out.C[0] = acc[1][1][3];  // keeps the accumulators live
-    } else if (seg.slab < 0) gemm128_epilogue(out, bx * 128, by * 128, acc);
-    else gemm128_store_partial(plan.slabs + (size_t)seg.slab * kSlabFloats, acc);
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += acc[0][0][r] + acc[0][1][r] + acc[1][0][r] + acc[1][1][r];
+      if (t == 123.456f) out.C[0] = t;  // keeps every accumulator live
+    } else if (seg.slab < 0) {
+      // `stage` now names the buffer holding the prefetched next K tile; the other one is free
+      if (wide) gemm128g_epilogue_wide(out, bx * 128, by * 128, acc, smem + (stage ^ 1) * kGStageFloats);
+      else gemm128_epilogue(out, bx * 128, by * 128, acc);
+    } else {
+      gemm128_store_partial(plan.slabs + (size_t)seg.slab * kSlabFloats, acc);
+    }
     if (!nxt.valid) break;
+    if (wide) __syncthreads();  // the next iteration's LDS-DMA lands in the slices the epilogue used
     seg = nxt;
     sk_tile_xy(plan, seg.tile, bx, by);
   }
@@ -246,21 +326,26 @@ inline int launch128g(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o,
   dim3 grid((unsigned)workers), block(256);
   o.epi = epi;
   prof_begin(s, 2.0 * o.M * (double)o.N * o.K);
+  static const int wideOn = [] { const char* e = getenv("W2L_GEMM_WIDE"); return e ? atoi(e) : 1; }();
+  const int wide = wideOn && (((uintptr_t)o.C) & 15) == 0 && o.ldc % 4 == 0 &&
+                   (!o.mask || (((uintptr_t)o.mask) & 15) == 0);
   static const int abl = [] { const char* e = getenv("W2L_GEMM_ABL"); return e ? atoi(e) : 0; }();
   if (abl && akc && !bkc) {
     switch (abl) {
-      case 1: hipLaunchKernelGGL((gemm128g_kernel<true, false, 1>), grid, block, shmem, s, a, b, o, plan, workers); break;
-      case 3: hipLaunchKernelGGL((gemm128g_kernel<true, false, 3>), grid, block, shmem, s, a, b, o, plan, workers); break;
-      case 7: hipLaunchKernelGGL((gemm128g_kernel<true, false, 7>), grid, block, shmem, s, a, b, o, plan, workers); break;
-      case 15: hipLaunchKernelGGL((gemm128g_kernel<true, false, 15>), grid, block, shmem, s, a, b, o, plan, workers); break;
-      case 8: hipLaunchKernelGGL((gemm128g_kernel<true, false, 8>), grid, block, shmem, s, a, b, o, plan, workers); break;
-      case 2: hipLaunchKernelGGL((gemm128g_kernel<true, false, 2>), grid, block, shmem, s, a, b, o, plan, workers); break;
-      default: hipLaunchKernelGGL((gemm128g_kernel<true, false, 4>), grid, block, shmem, s, a, b, o, plan, workers); break;
+      case 1: hipLaunchKernelGGL((gemm128g_kernel<true, false, 1>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
+      case 3: hipLaunchKernelGGL((gemm128g_kernel<true, false, 3>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
+      case 7: hipLaunchKernelGGL((gemm128g_kernel<true, false, 7>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
+      case 15: hipLaunchKernelGGL((gemm128g_kernel<true, false, 15>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
+      case 8: hipLaunchKernelGGL((gemm128g_kernel<true, false, 8>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
+      case 16: hipLaunchKernelGGL((gemm128g_kernel<true, false, 16>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
+      case 32: hipLaunchKernelGGL((gemm128g_kernel<true, false, 32>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
+      case 2: hipLaunchKernelGGL((gemm128g_kernel<true, false, 2>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
+      default: hipLaunchKernelGGL((gemm128g_kernel<true, false, 4>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
     }
-  } else if (akc && bkc) hipLaunchKernelGGL((gemm128g_kernel<true, true>), grid, block, shmem, s, a, b, o, plan, workers);
-  else if (akc) hipLaunchKernelGGL((gemm128g_kernel<true, false>), grid, block, shmem, s, a, b, o, plan, workers);
-  else if (bkc) hipLaunchKernelGGL((gemm128g_kernel<false, true>), grid, block, shmem, s, a, b, o, plan, workers);
-  else hipLaunchKernelGGL((gemm128g_kernel<false, false>), grid, block, shmem, s, a, b, o, plan, workers);
+  } else if (akc && bkc) hipLaunchKernelGGL((gemm128g_kernel<true, true>), grid, block, shmem, s, a, b, o, plan, workers, wide);
+  else if (akc) hipLaunchKernelGGL((gemm128g_kernel<true, false>), grid, block, shmem, s, a, b, o, plan, workers, wide);
+  else if (bkc) hipLaunchKernelGGL((gemm128g_kernel<false, true>), grid, block, shmem, s, a, b, o, plan, workers, wide);
+  else hipLaunchKernelGGL((gemm128g_kernel<false, false>), grid, block, shmem, s, a, b, o, plan, workers, wide);
   if (plan.skBlocks > 0) hipLaunchKernelGGL(gemm128_fixup<0>, dim3((unsigned)plan.skTiles), block, 0, s, o, plan);
   prof_end(s);
   W2L_LAUNCH_CHECK();

@@ -619,9 +619,11 @@ void Sequential::finalize() {
   params_.clear();
   params_.reserve(layers_.size() * 10 + 16);  // P handles keep pointers to this vector: never reallocate later
   int stream = 1;
+  std::vector<size_t> firstIdx;
   for (auto& l : layers_) {
     l->rngStream = stream;
     stream += 4;
+    firstIdx.push_back(params_.size());
     l->registerParams(params_);
   }
   size_t off = 0;
@@ -630,6 +632,8 @@ void Sequential::finalize() {
     off += (p.numel + 3) / 4 * 4;  // 16-byte aligned slots (float4 optimizer)
   }
   paramFloats_ = off;
+  layerLo_.clear();
+  for (size_t i = 0; i < layers_.size(); ++i) layerLo_.push_back(firstIdx[i] < params_.size() ? params_[firstIdx[i]].offset : paramFloats_);
 }
 
 size_t Sequential::plan(int B, int T, int nFeat) {
@@ -677,13 +681,16 @@ void Sequential::backward(Ctx& c, float* arena, const float* dOut) {
     const std::string nm = layers_[i]->name();
     if (nm != "View" && nm != "Reorder" && nm != "SpecAugment" && nm != "Dropout" && nm != "ReLU") { firstParam = i; break; }
   }
+  size_t nb = bOff_.size();  // buckets [nb, ...) already signalled
   for (size_t ii = layers_.size(); ii-- > 0;) {
     float* dx = nullptr;
     bool needDx = ii > firstParam;
     layers_[ii]->backward(c, arena, dy, dx, needDx);
+    for (; nb > 0 && bOff_[nb - 1] >= layerLo_[ii]; --nb) hipCheck(hipEventRecord(bEv_[nb - 1], c.stream), "bucket event");
     if (!needDx) break;
     dy = dx;
   }
+  for (; nb > 0; --nb) hipCheck(hipEventRecord(bEv_[nb - 1], c.stream), "bucket event");
 }
 
 // ---- parameter init / import / export ----------------------------------------

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <vector>
 
 #include "w2l_host.hpp"
 
@@ -30,6 +31,8 @@ struct Trainer {
   const float* emission = nullptr;
   uint32_t step = 0;
   std::string lastError;
+  std::vector<hipEvent_t> bucketEvents;  // owned (w2l_trainer_set_grad_buckets)
+  ~Trainer() { for (auto e : bucketEvents) (void)hipEventDestroy(e); }
 };
 
 }  // namespace w2l
@@ -198,6 +201,37 @@ W2L_API int w2l_trainer_viterbi(void* h, const float* emission, int* path, void*
   TRY(h, {
     Ctx c = makeCtx(t, stream, false);
     t->crit->viterbiPath(c, t->B, t->Tout, t->nLabel, emission, path, t->critWs, t->params + t->netFloats);
+  });
+}
+
+// Gradient buckets for the data-parallel overlap (fl's CoalescingReducer, recipes/slimIPL/src/Train.cpp:1721-1735,
+// restated for one flat arena): offsets[0..n) ascending float offsets into the gradient arena, bucket k =
+// [offsets[k], offsets[k+1]) and the last one runs to the end (criterion gradients included).  During
+// w2l_trainer_forward_backward an event per bucket is recorded on the step's stream once every gradient at
+// offset >= offsets[k] is final; w2l_trainer_wait_bucket makes another stream (the collective's) wait for it.
+// n = 0 removes the hooks.
+W2L_API int w2l_trainer_set_grad_buckets(void* h, int n, const size_t* offsets) {
+  Trainer* t = (Trainer*)h;
+  TRY(h, {
+    if (n < 0 || (n > 0 && !offsets)) throw std::invalid_argument("set_grad_buckets: bad arguments");
+    for (int k = 1; k < n; ++k)
+      if (offsets[k] <= offsets[k - 1]) throw std::invalid_argument("set_grad_buckets: offsets must ascend");
+    for (auto e : t->bucketEvents) (void)hipEventDestroy(e);
+    t->bucketEvents.clear();
+    std::vector<size_t> off(offsets, offsets + n);
+    for (int k = 0; k < n; ++k) {
+      hipEvent_t e;
+      hipCheck(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+      t->bucketEvents.push_back(e);
+    }
+    t->net->setGradBuckets(off, t->bucketEvents);
+  });
+}
+W2L_API int w2l_trainer_wait_bucket(void* h, int k, void* stream) {
+  Trainer* t = (Trainer*)h;
+  TRY(h, {
+    if (k < 0 || k >= (int)t->bucketEvents.size()) throw std::invalid_argument("wait_bucket: no such bucket");
+    hipCheck(hipStreamWaitEvent((hipStream_t)stream, t->bucketEvents[k], 0), "hipStreamWaitEvent");
   });
 }
 

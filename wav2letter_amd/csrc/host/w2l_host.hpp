@@ -124,6 +124,13 @@ class Sequential {
   // dEmission: [B][T'][N]; accumulates nothing, overwrites all parameter gradients
   void backward(Ctx& c, float* arena, const float* dOut);
 
+  // Data-parallel overlap: parameters sit in the flat arena in layer order and backward walks the layers
+  // last to first, so after layer i every gradient at offset >= firstOffset(i) is final.  Bucket k =
+  // [offsets[k], offsets[k+1]) (ascending); events[k] is recorded on the step's stream as soon as all
+  // gradients at offsets >= offsets[k] are complete, so the caller's reduce of the LAST buckets runs
+  // under the backward pass of the earlier layers.  Empty vectors switch the hooks off.
+  void setGradBuckets(std::vector<size_t> offsets, std::vector<hipEvent_t> events) { bOff_ = std::move(offsets); bEv_ = std::move(events); }
+
   void initParams(float* hostParams, uint64_t seed) const;            // Flashlight-style init, internal layout
   void importParam(size_t i, const float* ref, float* hostParams) const;  // reference layout -> internal
   void exportParam(size_t i, const float* hostArena, float* ref) const;   // internal -> reference layout
@@ -137,6 +144,9 @@ class Sequential {
   std::vector<size_t> dOff_;  // gradient buffer per layer boundary
   std::vector<Act> acts_;
   std::vector<float*> ys_;
+  std::vector<size_t> layerLo_;  // per layer: arena offset of its first parameter (paramFloats_ if it has none after it)
+  std::vector<size_t> bOff_;
+  std::vector<hipEvent_t> bEv_;
 };
 
 // arch file -> Sequential (throws std::invalid_argument like the reference's builder)

@@ -41,6 +41,8 @@ def _lib_tr():
         L.w2l_trainer_update.argtypes = [vp, f, f, f, f, f, i, vp]
         L.w2l_trainer_viterbi.argtypes = [vp, vp, vp, vp]
         L.w2l_trainer_set_step.argtypes = [vp, u32]
+        L.w2l_trainer_set_grad_buckets.argtypes = [vp, i, C.POINTER(sz)]
+        L.w2l_trainer_wait_bucket.argtypes = [vp, i, vp]
         L.w2l_arch_check.argtypes = [C.c_char_p, i, i, C.POINTER(i)]
         L.w2l_flags_check.argtypes = [C.c_char_p, C.POINTER(i)]
         _sigs_done = True
@@ -171,3 +173,15 @@ class Trainer:
 
     def set_step(self, step):
         self.L.w2l_trainer_set_step(self.h, step)
+
+    # ---- data-parallel overlap (parallel.OverlappedReducer drives these)
+    def set_grad_buckets(self, offsets):
+        """bucket k = grads[offsets[k]:offsets[k+1]] (last one to the end); forward_backward then records
+        one event per bucket as soon as that part of the gradient arena is final"""
+        arr = (C.c_size_t * len(offsets))(*offsets)
+        _check(self.L.w2l_trainer_set_grad_buckets(self.h, len(offsets), arr), "set_grad_buckets")
+        self.bucket_offsets = list(offsets)
+
+    def wait_bucket(self, k, stream):
+        """make `stream` (torch.cuda.Stream) wait until bucket k of the step enqueued last is final"""
+        _check(self.L.w2l_trainer_wait_bucket(self.h, k, stream.cuda_stream), "wait_bucket")
