@@ -156,6 +156,29 @@ def probe_fccbig(T=64):
           f"({step_bytes * (T - 1) / tf / 1e9:.2f} TB/s algorithmic incl. packing), fwd+bwd {tfb:.2f} ms", flush=True)
 
 
+def probe_fccstream(T=200):
+    """per-launch time of the N=9998 transition stream (fcc_big_gemm) by the library's own HIP events"""
+    import ctypes as C
+    B, N = 32, 9998
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(B, T, N, generator=g).cuda().requires_grad_(True)
+    tgt = torch.zeros(B, 4, dtype=torch.int32).cuda()
+    crit = FullConnectionCriterion(N, CriterionScaleMode.NONE).cuda()
+    crit.transitions.data = (torch.randn(N, N, generator=g) * 0.1 + 4 * torch.eye(N)).cuda()
+    crit(x, tgt).sum().backward()
+    torch.cuda.synchronize()
+    L = _lib.lib()
+    L.w2l_profile_enable(1)
+    crit(x, tgt).sum().backward()
+    torch.cuda.synchronize()
+    nl, ms, by = C.c_int(0), C.c_double(0), C.c_double(0)
+    L.w2l_profile_report_kind(3, C.byref(nl), C.byref(ms), C.byref(by))
+    L.w2l_profile_enable(0)
+    env = {k: os.environ[k] for k in ("W2L_FCC_RT", "W2L_FCC_RING", "W2L_FCC_ABL", "W2L_FCC_WPC") if k in os.environ}
+    print(f"[fccstream {env}] {nl.value} launches, {ms.value * 1e3 / nl.value:.2f} us/launch, "
+          f"{by.value / (ms.value * 1e-3) / 1e12:.3f} TB/s algorithmic", flush=True)
+
+
 def probe_vitbig(T=24):
     N = 9998
     g = torch.Generator(device="cpu").manual_seed(6)
@@ -174,6 +197,6 @@ if __name__ == "__main__":
     print("device:", torch.cuda.get_device_name(0), flush=True)
     for w in which:
         t0 = time.time()
-        {"gemm": probe_gemm, "gemmfwd": probe_gemmfwd, "ln": probe_ln, "conv": probe_conv, "asg": probe_asg, "fccbig": probe_fccbig,
+        {"gemm": probe_gemm, "gemmfwd": probe_gemmfwd, "ln": probe_ln, "conv": probe_conv, "asg": probe_asg, "fccbig": probe_fccbig, "fccstream": probe_fccstream,
          "vitbig": probe_vitbig}[w]()
         print(f"[{w}] done in {time.time() - t0:.1f} s", flush=True)

@@ -74,6 +74,62 @@ __device__ __forceinline__ void tds_load_slab(const TdsConvP& p, float* slab, in
   }
 }
 
+
+// Batched staging: every thread issues up to NV independent loads back to back, THEN stores them -- one
+// exposed memory latency per batch instead of one per element (the element-at-a-time loops above wait
+// for each load before the next trip: ~9-18 serialized L2/HBM round trips per workgroup).
+template <int NV, class LoadF, class StoreF>
+__device__ __forceinline__ void tds_batched_copy4(int total, LoadF ld, StoreF st) {
+  for (int base = 0; base < total; base += NV * 256) {
+    float4 v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int e = base + threadIdx.x + 256 * j;
+      v[j] = ld(e < total ? e : total - 1);
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int e = base + threadIdx.x + 256 * j;
+      if (e < total) st(e, v[j]);
+    }
+  }
+}
+template <int NV, class LoadF, class StoreF>
+__device__ __forceinline__ void tds_batched_copy1(int total, LoadF ld, StoreF st) {
+  for (int base = 0; base < total; base += NV * 256) {
+    float v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int e = base + threadIdx.x + 256 * j;
+      v[j] = ld(e < total ? e : total - 1);
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int e = base + threadIdx.x + 256 * j;
+      if (e < total) st(e, v[j]);
+    }
+  }
+}
+
+// slab load, float4 pieces in batches (whole 16-row mel block, 16-byte aligned rows: checked by the caller)
+__device__ __forceinline__ void tds_load_slab_batched(const TdsConvP& p, float* slab, int b, int tIn0, int h0, int nf) {
+  const int q = (kTdsBH * p.Cin) >> 2;  // float4 per frame; + 1 = the zero pad of the frame
+  const float* xb = p.x + ((size_t)b * p.Tin * p.H + h0) * p.Cin;
+  const int HCi = p.H * p.Cin;
+  tds_batched_copy4<8>(nf * (q + 1),
+      [&](int e) {
+        const int f = e / (q + 1), o = e - f * (q + 1);
+        const int ti = tIn0 + f;
+        const bool ok = ti >= 0 && ti < p.Tin && o < q;
+        const float4 t4 = *(const float4*)(xb + (size_t)(ok ? ti : 0) * HCi + (ok ? (o << 2) : 0));
+        return ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
+      },
+      [&](int e, float4 v) {
+        const int f = e / (q + 1), o = e - f * (q + 1);
+        *(float4*)(slab + f * p.FS + (o << 2)) = v;
+      });
+}
+
 // ---------------------------------------------------------------- forward / backward-data
 // grid (ceil(H/16), ceil(Tout/32), B), 256 threads.  LDS: slab | weights [Kp][Cout] | koff[Kp]
 template <int NT>
@@ -87,24 +143,45 @@ __global__ __launch_bounds__(256) void tds_conv_fwd_k(TdsConvP p) {
   const int h0 = blockIdx.x * kTdsBH, t0 = blockIdx.y * kTdsBT, b = blockIdx.z;
 
   // weights: forward W[(tap,ci)][co]; backward-data W'[(tap',co_w)][ci_w] = W[kw-1-tap'][ci_w][co_w]
-  for (int e = tid; e < p.Kp * p.Cout; e += 256) {
-    const int kk = e / p.Cout, co = e - kk * p.Cout;
-    float v = 0.f;
-    if (kk < p.K) {
-      if (!p.flip) {
-        v = p.w[e];
-      } else {
-        const int tap = kk / p.Cin, c = kk - tap * p.Cin;  // c indexes CoutW, co indexes CinW
-        v = p.w[((size_t)(p.kw - 1 - tap) * p.CinW + co) * p.CoutW + c];
-      }
-    }
-    wS[e] = v;
+  const int wTot = p.Kp * p.Cout, wValid = p.K * p.Cout;
+  if (!p.flip && (wValid & 3) == 0 && ((((uintptr_t)p.w) & 15) == 0)) {
+    tds_batched_copy4<8>((wTot + 3) >> 2,
+        [&](int e) {
+          const bool ok = 4 * e < wValid;
+          const float4 t4 = *(const float4*)(p.w + (ok ? 4 * e : 0));
+          return ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
+        },
+        [&](int e, float4 v) { *(float4*)(wS + 4 * e) = v; });
+  } else {
+    tds_batched_copy1<8>(wTot,
+        [&](int e) {
+          const int kk = e / p.Cout, co = e - kk * p.Cout;
+          const bool ok = kk < p.K;
+          size_t src = 0;
+          if (ok) {
+            if (!p.flip) {
+              src = (size_t)e;
+            } else {
+              const int tap = kk / p.Cin, c = kk - tap * p.Cin;  // c indexes CoutW, co indexes CinW
+              src = ((size_t)(p.kw - 1 - tap) * p.CinW + co) * p.CoutW + c;
+            }
+          }
+          const float t = p.w[src];
+          return ok ? t : 0.f;
+        },
+        [&](int e, float v) { wS[e] = v; });
   }
   for (int kk = tid; kk < p.Kp; kk += 256) {
     const int tap = kk / p.Cin, c = kk - tap * p.Cin;
     koff[kk] = kk < p.K ? tap * p.FS + c : 0;
   }
-  tds_load_slab(p, slab, b, t0 * p.stride - p.padl, h0, p.NF);
+  {
+    int hc = p.H - h0;
+    if (hc > kTdsBH) hc = kTdsBH;
+    const bool vec = hc == kTdsBH && ((p.H * p.Cin) & 3) == 0 && ((kTdsBH * p.Cin) & 3) == 0 && ((((uintptr_t)p.x) & 15) == 0);
+    if (vec) tds_load_slab_batched(p, slab, b, t0 * p.stride - p.padl, h0, p.NF);
+    else tds_load_slab(p, slab, b, t0 * p.stride - p.padl, h0, p.NF);
+  }
   __syncthreads();
 
   const int i = lane & 15, lq = lane >> 4;
@@ -159,13 +236,39 @@ __global__ __launch_bounds__(256) void tds_conv_fwd_k(TdsConvP p) {
   int tc = p.Tout - t0;
   if (tc > kTdsBT) tc = kTdsBT;
   const int total = tc * rowLen;
-  for (int e = tid; e < total; e += 256) {
-    const int t = e / rowLen, o = e - t * rowLen;
-    const size_t g = (((size_t)b * p.Tout + t0 + t) * p.H + h0) * p.Cout + o;
-    float v = outS[t * kTdsBH * p.Cout + o];
-    if (p.add) v += p.add[g];
-    if (p.accum) v += p.y[g];
-    p.y[g] = v;
+  const size_t gBase = (((size_t)b * p.Tout + t0) * p.H + h0) * p.Cout;
+  const size_t gRow = (size_t)p.H * p.Cout;
+  const bool vec = (rowLen & 3) == 0 && ((p.H * p.Cout) & 3) == 0 && ((kTdsBH * p.Cout) & 3) == 0 &&
+                   ((((uintptr_t)p.y) | ((uintptr_t)p.add)) & 15) == 0;
+  if (vec) {
+    // whole contiguous frames as float4; the optional addend / accumulate reads are batched like the loads above
+    const int rq = rowLen >> 2;
+    tds_batched_copy4<8>(tc * rq,
+        [&](int e) {
+          const int t = e / rq, o = (e - t * rq) << 2;
+          const size_t g = gBase + (size_t)t * gRow + o;
+          float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (p.add) a = *(const float4*)(p.add + g);
+          if (p.accum) {
+            const float4 y0 = *(const float4*)(p.y + g);
+            a.x += y0.x; a.y += y0.y; a.z += y0.z; a.w += y0.w;
+          }
+          return a;
+        },
+        [&](int e, float4 a) {
+          const int t = e / rq, o = (e - t * rq) << 2;
+          const float4 v = *(const float4*)(outS + t * kTdsBH * p.Cout + o);
+          *(float4*)(p.y + gBase + (size_t)t * gRow + o) = make_float4(v.x + a.x, v.y + a.y, v.z + a.z, v.w + a.w);
+        });
+  } else {
+    for (int e = tid; e < total; e += 256) {
+      const int t = e / rowLen, o = e - t * rowLen;
+      const size_t g = gBase + (size_t)t * gRow + o;
+      float v = outS[t * kTdsBH * p.Cout + o];
+      if (p.add) v += p.add[g];
+      if (p.accum) v += p.y[g];
+      p.y[g] = v;
+    }
   }
 }
 

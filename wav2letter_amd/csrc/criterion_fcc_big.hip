@@ -59,6 +59,8 @@ struct BigDims {
   int U;    // G * nS stage-units of one step
   int W;    // persistent workgroups of the streaming kernel: worker w owns units [U w / W, U (w+1) / W)
   int P;    // bound on the workers (= partial slabs) that share one row group
+  int ring; // 1: three operand register sets in a ring, 0: two in ping-pong (W2L_FCC_RING, A/B runs)
+  int abl;  // timing-only ablations (W2L_FCC_ABL): 1 = no MFMA, 2 = no E-operand loads
 };
 
 // persistent workgroups per CU of the streaming kernel: register-limited (three operand stages of
@@ -73,12 +75,14 @@ inline int big_workers_per_cu(int NB) {
 // 32-row tiles per wave.  One E fragment (the [utterance][k] operand, re-read by EVERY row group out of
 // L2) feeds RT MFMAs: at RT = 2 a third of the kernel's vector-memory instructions were E re-reads and
 // the stream sat at the per-CU load-path rate (~11 B/clk/CU) rather than at HBM's; RT = 4 makes it a
-// fifth.  NB >= 2 keeps RT = 2 (registers).  W2L_FCC_RT=2 forces the old shape for A/B runs.
+// fifth.  MEASURED (MI355X, B=32, N=9998): RT = 4 is SLOWER (109.5 us per step against 90.9 us at RT = 2),
+// so the load path is not what bounds the stream; RT = 2 stays the default, W2L_FCC_RT=4 selects the
+// wide shape for A/B runs.  NB >= 2 keeps RT = 2 (registers).
 inline int big_row_tiles(int NB) {
   if (NB >= 2) return 2;
   const char* e = getenv("W2L_FCC_RT");
-  if (e && e[0] == '2') return 2;
-  return 4;
+  if (e && e[0] == '4') return 4;
+  return 2;
 }
 
 inline BigDims big_dims(int B, int T, int N) {
@@ -90,6 +94,8 @@ inline BigDims big_dims(int B, int T, int N) {
   d.NB = nb <= 1 ? 1 : (nb <= 2 ? 2 : 4);
   d.Bp = 32 * d.NB;
   d.RT = big_row_tiles(d.NB);
+  { const char* e = getenv("W2L_FCC_RING"); d.ring = e ? atoi(e) : 0; }
+  { const char* e = getenv("W2L_FCC_ABL"); d.abl = e ? atoi(e) : 0; }
   d.Np = (N + 32 * d.RT - 1) / (32 * d.RT) * (32 * d.RT);
   d.G = d.Np / (32 * d.RT);
   // The step is cut into U = G * nS stage-units (64 rows x 32 k) in row-group-major order and dealt
@@ -205,7 +211,7 @@ struct BigStage {
   float4 a[RT][kBigU], e[NB][kBigU];
 };
 
-template <int NB, int RT>
+template <int NB, int RT, int ABL = 0>
 __device__ __forceinline__ void big_load_stage(BigStage<NB, RT>& st, const float4* __restrict__ pa, size_t tileStride,
                                                const float4* __restrict__ pe, int NC, int s) {
 #pragma unroll
@@ -214,11 +220,11 @@ __device__ __forceinline__ void big_load_stage(BigStage<NB, RT>& st, const float
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) st.a[rt][u] = pa[rt * tileStride + c * 64];
 #pragma unroll
-    for (int bt = 0; bt < NB; ++bt) st.e[bt][u] = pe[((size_t)bt * NC + c) * 64];
+    for (int bt = 0; bt < NB; ++bt) st.e[bt][u] = pe[((size_t)bt * NC + ((ABL & 2) ? 0 : c)) * 64];
   }
 }
 
-template <int NB, int RT, bool EXPOP>
+template <int NB, int RT, bool EXPOP, int ABL = 0>
 __device__ __forceinline__ void big_compute_stage(const BigStage<NB, RT>& st, const float (&cb)[NB], f32x16 (&acc)[NB][RT]) {
 #pragma unroll
   for (int u = 0; u < kBigU; ++u) {
@@ -234,13 +240,14 @@ __device__ __forceinline__ void big_compute_stage(const BigStage<NB, RT>& st, co
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           const float av = q == 0 ? st.a[rt][u].x : (q == 1 ? st.a[rt][u].y : (q == 2 ? st.a[rt][u].z : st.a[rt][u].w));
-          acc[bt][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ev[q], av, acc[bt][rt], 0, 0, 0);
+          if (ABL & 1) acc[bt][rt][q] += ev[q] * av;  // timing ablation: no matrix pipe
+          else acc[bt][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ev[q], av, acc[bt][rt], 0, 0, 0);
         }
     }
   }
 }
 
-template <int NB, int RT, bool EXPOP>
+template <int NB, int RT, bool EXPOP, int ABL = 0>
 __global__ __launch_bounds__(256, NB <= 1 ? 2 : 1) void fcc_big_gemm(const float4* __restrict__ pack, const float4* __restrict__ op,
                                                        const float* __restrict__ pmax, float* __restrict__ part, BigDims d) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][NB*RT*16 regs][64 lanes]
@@ -288,37 +295,37 @@ __global__ __launch_bounds__(256, NB <= 1 ? 2 : 1) void fcc_big_gemm(const float
     const float4* pa = pack + ((size_t)(RT * g) * NC) * 64 + lane;  // row tile rt of the group: + rt * tileStride
     const size_t tileStride = (size_t)NC * 64;
 
-    // three register sets in a ring: the loads of stages s+1 and s+2 are in flight behind the MFMAs of
-    // stage s (24 KiB per wave, 192 KiB per CU: one set in flight left the stream latency-bound --
-    // bytes in flight / loaded HBM latency -- at 4.4 TB/s on MI355X)
     // Operand loads are issued UNCONDITIONALLY (stage index clamped to the wave's last stage; the few
     // redundant loads at the tail hit L2): a load under a branch makes hipcc's s_waitcnt placement
-    // assume the worst at the join and wait vmcnt(0), which drains the whole ring every stage.
+    // assume the worst at the join and wait vmcnt(0), which drains the prefetch every stage.
     if (s0 < s1) {
       const int sl = s1 - 1;
-      if constexpr (NB >= 4 || RT >= 4) {  // 192 (80 at RT = 4) operand VGPRs per stage: two sets in ping-pong are all that fits
+      bool ring = false;
+      if constexpr (NB < 4 && RT < 4) ring = d.ring != 0;  // 192 (80 at RT = 4) operand VGPRs per stage: no room for three
+      if (!ring) {
+        // two register sets in ping-pong: the loads of stage s+1 are in flight behind the MFMAs of stage s
         BigStage<NB, RT> sa, sb2;
-        big_load_stage<NB, RT>(sa, pa, tileStride, pe, NC, s0);
+        big_load_stage<NB, RT, ABL>(sa, pa, tileStride, pe, NC, s0);
         for (int s = s0; s < s1; s += 2) {
-          big_load_stage<NB, RT>(sb2, pa, tileStride, pe, NC, min(s + 1, sl));
-          big_compute_stage<NB, RT, EXPOP>(sa, cb, acc);
-          big_load_stage<NB, RT>(sa, pa, tileStride, pe, NC, min(s + 2, sl));
-          if (s + 1 < s1) big_compute_stage<NB, RT, EXPOP>(sb2, cb, acc);
+          big_load_stage<NB, RT, ABL>(sb2, pa, tileStride, pe, NC, min(s + 1, sl));
+          big_compute_stage<NB, RT, EXPOP, ABL>(sa, cb, acc);
+          big_load_stage<NB, RT, ABL>(sa, pa, tileStride, pe, NC, min(s + 2, sl));
+          if (s + 1 < s1) big_compute_stage<NB, RT, EXPOP, ABL>(sb2, cb, acc);
         }
-      } else {
-        // three register sets in a ring: the loads of stages s+1 and s+2 are in flight behind the MFMAs
-        // of stage s (24 KiB per wave, 192 KiB per CU: with one set in flight the stream was latency-bound
-        // -- bytes in flight / loaded HBM latency -- at 4.4 TB/s on MI355X)
+      } else if constexpr (NB < 4 && RT < 4) {
+        // three register sets in a ring (W2L_FCC_RING=1): stages s+1 and s+2 in flight behind stage s.
+        // Measured on MI355X: 95.6 us per step against 90.9 us for the ping-pong -- more bytes in flight do
+        // not help, the stream is not latency-bound.
         BigStage<NB, RT> r0, r1, r2;
-        big_load_stage<NB, RT>(r0, pa, tileStride, pe, NC, s0);
-        big_load_stage<NB, RT>(r1, pa, tileStride, pe, NC, min(s0 + 1, sl));
+        big_load_stage<NB, RT, ABL>(r0, pa, tileStride, pe, NC, s0);
+        big_load_stage<NB, RT, ABL>(r1, pa, tileStride, pe, NC, min(s0 + 1, sl));
         for (int s = s0; s < s1; s += 3) {
-          big_load_stage<NB, RT>(r2, pa, tileStride, pe, NC, min(s + 2, sl));
-          big_compute_stage<NB, RT, EXPOP>(r0, cb, acc);
-          big_load_stage<NB, RT>(r0, pa, tileStride, pe, NC, min(s + 3, sl));
-          if (s + 1 < s1) big_compute_stage<NB, RT, EXPOP>(r1, cb, acc);
-          big_load_stage<NB, RT>(r1, pa, tileStride, pe, NC, min(s + 4, sl));
-          if (s + 2 < s1) big_compute_stage<NB, RT, EXPOP>(r2, cb, acc);
+          big_load_stage<NB, RT, ABL>(r2, pa, tileStride, pe, NC, min(s + 2, sl));
+          big_compute_stage<NB, RT, EXPOP, ABL>(r0, cb, acc);
+          big_load_stage<NB, RT, ABL>(r0, pa, tileStride, pe, NC, min(s + 3, sl));
+          if (s + 1 < s1) big_compute_stage<NB, RT, EXPOP, ABL>(r1, cb, acc);
+          big_load_stage<NB, RT, ABL>(r1, pa, tileStride, pe, NC, min(s + 4, sl));
+          if (s + 2 < s1) big_compute_stage<NB, RT, EXPOP, ABL>(r2, cb, acc);
         }
       }
     }
@@ -569,6 +576,16 @@ static int launch_big_gemm(const BigDims& d, const float* pack, const float* op,
 }
 template <bool EXPOP>
 static int big_gemm(const BigDims& d, const float* pack, const float* op, const float* pmax, float* part, hipStream_t s) {
+  if (d.NB == 1 && d.RT == 2 && d.abl) {  // timing ablations of the probe tool (results are garbage)
+    const size_t shmem = (size_t)4 * 1 * 2 * 16 * 64 * sizeof(float);
+    prof_begin(s, 4.0 * d.N * (double)d.N + 8.0 * d.B * (double)d.N, PROF_FCC_STREAM);
+    if (d.abl == 1) hipLaunchKernelGGL((fcc_big_gemm<1, 2, EXPOP, 1>), dim3((unsigned)d.W), dim3(256), shmem, s, (const float4*)pack, (const float4*)op, pmax, part, d);
+    else if (d.abl == 2) hipLaunchKernelGGL((fcc_big_gemm<1, 2, EXPOP, 2>), dim3((unsigned)d.W), dim3(256), shmem, s, (const float4*)pack, (const float4*)op, pmax, part, d);
+    else hipLaunchKernelGGL((fcc_big_gemm<1, 2, EXPOP, 3>), dim3((unsigned)d.W), dim3(256), shmem, s, (const float4*)pack, (const float4*)op, pmax, part, d);
+    prof_end(s);
+    W2L_LAUNCH_CHECK();
+    return W2L_OK;
+  }
   if (d.NB == 1) return d.RT == 4 ? launch_big_gemm<1, 4, EXPOP>(d, pack, op, pmax, part, s)
                                   : launch_big_gemm<1, 2, EXPOP>(d, pack, op, pmax, part, s);
   if (d.NB == 2) return launch_big_gemm<2, 2, EXPOP>(d, pack, op, pmax, part, s);

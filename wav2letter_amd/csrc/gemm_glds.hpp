@@ -204,7 +204,9 @@ __device__ __forceinline__ GSeg g_segment(const SkPlan& p, int w, int workers, i
 template <bool AKC, bool BKC, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, GemmOut out, SkPlan plan, int workers, int wide) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // wave id as a SCALAR: LDS-DMA destinations (M0) and piece indices stay on the SALU, no v_readfirstlane per piece
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int li = lane & 31, lh = lane >> 5;
   const int w = xcd_major(blockIdx.x, workers);
@@ -339,6 +341,7 @@ inline int launch128g(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o,
       case 8: hipLaunchKernelGGL((gemm128g_kernel<true, false, 8>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
       case 16: hipLaunchKernelGGL((gemm128g_kernel<true, false, 16>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
       case 32: hipLaunchKernelGGL((gemm128g_kernel<true, false, 32>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
+      case 9: hipLaunchKernelGGL((gemm128g_kernel<true, false, 9>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
       case 2: hipLaunchKernelGGL((gemm128g_kernel<true, false, 2>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
       default: hipLaunchKernelGGL((gemm128g_kernel<true, false, 4>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
     }
