@@ -60,7 +60,8 @@ struct BigDims {
   int W;    // persistent workgroups of the streaming kernel: worker w owns units [U w / W, U (w+1) / W)
   int P;    // bound on the workers (= partial slabs) that share one row group
   int ring; // 1: three operand register sets in a ring, 0: two in ping-pong (W2L_FCC_RING, A/B runs)
-  int abl;  // timing-only ablations (W2L_FCC_ABL): 1 = no MFMA, 2 = no E-operand loads
+  int abl;  // W2L_FCC_ABL: timing-only ablations 1 = no MFMA, 2 = no E-operand traffic; 4 = nontemporal loads of the
+            // transition stream (results stay correct)
 };
 
 // persistent workgroups per CU of the streaming kernel: register-limited (three operand stages of
@@ -218,7 +219,14 @@ __device__ __forceinline__ void big_load_stage(BigStage<NB, RT>& st, const float
   for (int u = 0; u < kBigU; ++u) {
     const size_t c = (size_t)s * kBigU + u;
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) st.a[rt][u] = pa[rt * tileStride + c * 64];
+    for (int rt = 0; rt < RT; ++rt) {
+      if (ABL & 4) {
+        const f32x4 t = __builtin_nontemporal_load((const f32x4*)(pa + rt * tileStride + c * 64));
+        st.a[rt][u] = make_float4(t[0], t[1], t[2], t[3]);
+      } else {
+        st.a[rt][u] = pa[rt * tileStride + c * 64];
+      }
+    }
 #pragma unroll
     for (int bt = 0; bt < NB; ++bt) st.e[bt][u] = pe[((size_t)bt * NC + ((ABL & 2) ? 0 : c)) * 64];
   }
@@ -295,37 +303,56 @@ __global__ __launch_bounds__(256, NB <= 1 ? 2 : 1) void fcc_big_gemm(const float
     const float4* pa = pack + ((size_t)(RT * g) * NC) * 64 + lane;  // row tile rt of the group: + rt * tileStride
     const size_t tileStride = (size_t)NC * 64;
 
-    // Operand loads are issued UNCONDITIONALLY (stage index clamped to the wave's last stage; the few
-    // redundant loads at the tail hit L2): a load under a branch makes hipcc's s_waitcnt placement
-    // assume the worst at the join and wait vmcnt(0), which drains the prefetch every stage.
+    // The steady-state loops contain NO branch around a load: a load under a branch makes hipcc's
+    // s_waitcnt placement assume the worst at the join and wait vmcnt(0), which drains the prefetch at every
+    // stage.  The last one or two stages of a wave are peeled off instead (no redundant tail loads: at ~24
+    // stages per wave two clamped extra stages were 8 % more traffic).
     if (s0 < s1) {
-      const int sl = s1 - 1;
       bool ring = false;
       if constexpr (NB < 4 && RT < 4) ring = d.ring != 0;  // 192 (80 at RT = 4) operand VGPRs per stage: no room for three
       if (!ring) {
         // two register sets in ping-pong: the loads of stage s+1 are in flight behind the MFMAs of stage s
         BigStage<NB, RT> sa, sb2;
         big_load_stage<NB, RT, ABL>(sa, pa, tileStride, pe, NC, s0);
-        for (int s = s0; s < s1; s += 2) {
-          big_load_stage<NB, RT, ABL>(sb2, pa, tileStride, pe, NC, min(s + 1, sl));
+        int s = s0;
+        for (; s + 2 < s1; s += 2) {
+          big_load_stage<NB, RT, ABL>(sb2, pa, tileStride, pe, NC, s + 1);
           big_compute_stage<NB, RT, EXPOP, ABL>(sa, cb, acc);
-          big_load_stage<NB, RT, ABL>(sa, pa, tileStride, pe, NC, min(s + 2, sl));
-          if (s + 1 < s1) big_compute_stage<NB, RT, EXPOP, ABL>(sb2, cb, acc);
+          big_load_stage<NB, RT, ABL>(sa, pa, tileStride, pe, NC, s + 2);
+          big_compute_stage<NB, RT, EXPOP, ABL>(sb2, cb, acc);
+        }
+        if (s + 1 < s1) {  // two stages left: sa holds s
+          big_load_stage<NB, RT, ABL>(sb2, pa, tileStride, pe, NC, s + 1);
+          big_compute_stage<NB, RT, EXPOP, ABL>(sa, cb, acc);
+          big_compute_stage<NB, RT, EXPOP, ABL>(sb2, cb, acc);
+        } else {
+          big_compute_stage<NB, RT, EXPOP, ABL>(sa, cb, acc);
         }
       } else if constexpr (NB < 4 && RT < 4) {
-        // three register sets in a ring (W2L_FCC_RING=1): stages s+1 and s+2 in flight behind stage s.
-        // Measured on MI355X: 95.6 us per step against 90.9 us for the ping-pong -- more bytes in flight do
-        // not help, the stream is not latency-bound.
+        // three register sets in a ring (W2L_FCC_RING=1): stages s+1 and s+2 in flight behind stage s
         BigStage<NB, RT> r0, r1, r2;
         big_load_stage<NB, RT, ABL>(r0, pa, tileStride, pe, NC, s0);
-        big_load_stage<NB, RT, ABL>(r1, pa, tileStride, pe, NC, min(s0 + 1, sl));
-        for (int s = s0; s < s1; s += 3) {
-          big_load_stage<NB, RT, ABL>(r2, pa, tileStride, pe, NC, min(s + 2, sl));
+        int s = s0;
+        if (s + 1 < s1) {
+          big_load_stage<NB, RT, ABL>(r1, pa, tileStride, pe, NC, s + 1);
+          for (; s + 4 < s1; s += 3) {  // invariant: r0 = stage s, r1 = stage s+1 loaded / in flight
+            big_load_stage<NB, RT, ABL>(r2, pa, tileStride, pe, NC, s + 2);
+            big_compute_stage<NB, RT, EXPOP, ABL>(r0, cb, acc);
+            big_load_stage<NB, RT, ABL>(r0, pa, tileStride, pe, NC, s + 3);
+            big_compute_stage<NB, RT, EXPOP, ABL>(r1, cb, acc);
+            big_load_stage<NB, RT, ABL>(r1, pa, tileStride, pe, NC, s + 4);
+            big_compute_stage<NB, RT, EXPOP, ABL>(r2, cb, acc);
+          }
+          // 2..4 stages left, r0 = s, r1 = s+1
+          const int left = s1 - s;
+          if (left >= 3) big_load_stage<NB, RT, ABL>(r2, pa, tileStride, pe, NC, s + 2);
           big_compute_stage<NB, RT, EXPOP, ABL>(r0, cb, acc);
-          big_load_stage<NB, RT, ABL>(r0, pa, tileStride, pe, NC, min(s + 3, sl));
-          if (s + 1 < s1) big_compute_stage<NB, RT, EXPOP, ABL>(r1, cb, acc);
-          big_load_stage<NB, RT, ABL>(r1, pa, tileStride, pe, NC, min(s + 4, sl));
-          if (s + 2 < s1) big_compute_stage<NB, RT, EXPOP, ABL>(r2, cb, acc);
+          if (left >= 4) big_load_stage<NB, RT, ABL>(r0, pa, tileStride, pe, NC, s + 3);
+          big_compute_stage<NB, RT, EXPOP, ABL>(r1, cb, acc);
+          if (left >= 3) big_compute_stage<NB, RT, EXPOP, ABL>(r2, cb, acc);
+          if (left >= 4) big_compute_stage<NB, RT, EXPOP, ABL>(r0, cb, acc);
+        } else {
+          big_compute_stage<NB, RT, EXPOP, ABL>(r0, cb, acc);
         }
       }
     }
@@ -579,7 +606,9 @@ static int big_gemm(const BigDims& d, const float* pack, const float* op, const 
   if (d.NB == 1 && d.RT == 2 && d.abl) {  // timing ablations of the probe tool (results are garbage)
     const size_t shmem = (size_t)4 * 1 * 2 * 16 * 64 * sizeof(float);
     prof_begin(s, 4.0 * d.N * (double)d.N + 8.0 * d.B * (double)d.N, PROF_FCC_STREAM);
-    if (d.abl == 1) hipLaunchKernelGGL((fcc_big_gemm<1, 2, EXPOP, 1>), dim3((unsigned)d.W), dim3(256), shmem, s, (const float4*)pack, (const float4*)op, pmax, part, d);
+    if (d.abl == 4) hipLaunchKernelGGL((fcc_big_gemm<1, 2, EXPOP, 4>), dim3((unsigned)d.W), dim3(256), shmem, s, (const float4*)pack, (const float4*)op, pmax, part, d);
+    else if (d.abl == 7) hipLaunchKernelGGL((fcc_big_gemm<1, 2, EXPOP, 7>), dim3((unsigned)d.W), dim3(256), shmem, s, (const float4*)pack, (const float4*)op, pmax, part, d);
+    else if (d.abl == 1) hipLaunchKernelGGL((fcc_big_gemm<1, 2, EXPOP, 1>), dim3((unsigned)d.W), dim3(256), shmem, s, (const float4*)pack, (const float4*)op, pmax, part, d);
     else if (d.abl == 2) hipLaunchKernelGGL((fcc_big_gemm<1, 2, EXPOP, 2>), dim3((unsigned)d.W), dim3(256), shmem, s, (const float4*)pack, (const float4*)op, pmax, part, d);
     else hipLaunchKernelGGL((fcc_big_gemm<1, 2, EXPOP, 3>), dim3((unsigned)d.W), dim3(256), shmem, s, (const float4*)pack, (const float4*)op, pmax, part, d);
     prof_end(s);

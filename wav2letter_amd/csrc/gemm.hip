@@ -100,7 +100,13 @@ int gemm_f32(const float* A, int lda, int a_kcontig, const float* B, int ldb, in
   if (mask) epi |= EPI_MASK;
   splitk = 1;
   if (K % 32 == 0 && glds_ok(A, lda, M) && glds_ok(B, ldb, N) && glds_enabled())
-    return launch128g(GOp{A, lda, M}, a_kcontig != 0, GOp{B, ldb, N}, b_kcontig != 0, o, epi, s);
+  {
+    // address range of each operand in bytes (buffer-addressed variant needs 32-bit offsets)
+    const unsigned long long ab = 4ull * (a_kcontig ? (unsigned long long)(M - 1) * lda + K : (unsigned long long)(K - 1) * lda + M);
+    const unsigned long long bb = 4ull * (b_kcontig ? (unsigned long long)(N - 1) * ldb + K : (unsigned long long)(K - 1) * ldb + N);
+    GOp ga{A, lda, M, ab < 0x7fffffffull ? (unsigned)ab : 0u}, gb{B, ldb, N, bb < 0x7fffffffull ? (unsigned)bb : 0u};
+    return launch128g(ga, a_kcontig != 0, gb, b_kcontig != 0, o, epi, s);
+  }
   if (a_kcontig) {
     int v = pick_vec(A, lda, K);
     if (v == 4) return dispatch_b(PlainOp<true, 4>{A, lda, M, K}, B, ldb, b_kcontig, o, epi, splitk, s);

@@ -31,6 +31,7 @@ struct GOp {
   const float* p;
   int ld;
   int extent;  // number of valid i (rows of A / columns of B)
+  unsigned bytes = 0;  // size of the operand's address range (buffer-addressed variant; 0 = too large)
 };
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -72,6 +73,31 @@ __device__ __forceinline__ void g_issue(const float* const (&q)[4], size_t off, 
 
 __device__ __forceinline__ void g_issue1(const float* q, size_t off, float* ldsTile, int wave, int j) {
   __builtin_amdgcn_global_load_lds((gptr_t)(q + off), (lptr_t)(ldsTile + (wave * 4 + j) * 256), 16, 0, 0);
+}
+
+// ---- buffer-addressed variant (BUF): the operand is described by a 128-bit buffer resource in SGPRs, the
+// lane supplies ONE 32-bit byte offset (half the address VGPR traffic of a 64-bit global pointer) and the
+// K advance rides in the scalar offset of the instruction -- no per-piece 64-bit VALU add.
+template <bool KC>
+__device__ __forceinline__ void g_init_offs(uint32_t (&vo)[4], const GOp& op, int i0, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (KC) {
+      const int r = (wave * 4 + j) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      int gi = i0 + r;
+      if (gi > op.extent - 1) gi = op.extent - 1;
+      vo[j] = ((uint32_t)gi * (uint32_t)op.ld + 4u * c) * 4u;
+    } else {
+      const int kr = (wave * 4 + j) * 2 + (lane >> 5);
+      int gi = i0 + 4 * (lane & 31);
+      if (gi > op.extent - 4) gi = op.extent - 4;
+      vo[j] = ((uint32_t)kr * (uint32_t)op.ld + (uint32_t)gi) * 4u;
+    }
+  }
+}
+__device__ __forceinline__ void g_issue1_buf(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff, float* ldsTile, int wave, int j) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(ldsTile + (wave * 4 + j) * 256), 16, (int)voff, (int)soff, 0, 0);
 }
 
 // fragments of one 8-k group for the two 32-row MFMA tiles of this wave
@@ -201,7 +227,7 @@ __device__ __forceinline__ GSeg g_segment(const SkPlan& p, int w, int workers, i
 // ABL: timing-only ablations (results are garbage) selected by W2L_GEMM_ABL for the probe tool:
 //   1 = no LDS-DMA, 2 = no per-K-tile barrier, 4 = no fragment reads in the loop, 8 = no epilogue,
 //   16 = LDS-DMA always re-reads K tile 0 (cache-resident source), 32 = LDS-DMA of the A operand only
-template <bool AKC, bool BKC, int ABL = 0>
+template <bool AKC, bool BKC, int ABL = 0, bool BUF = false>
 __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, GemmOut out, SkPlan plan, int workers, int wide) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -217,13 +243,29 @@ __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, Gemm
   if (!seg.valid) return;
   const float* qa[4];
   const float* qb[4];
+  uint32_t va[4], vb[4];
+  __amdgpu_buffer_rsrc_t ra, rb;
+  if (BUF) {
+    ra = __builtin_amdgcn_make_buffer_rsrc((void*)aop.p, 0, (int)aop.bytes, 0x00020000);
+    rb = __builtin_amdgcn_make_buffer_rsrc((void*)bop.p, 0, (int)bop.bytes, 0x00020000);
+  }
   int bx, by;
   sk_tile_xy(plan, seg.tile, bx, by);
-  g_init_ptrs<AKC>(qa, aop, bx * 128, wave, lane);
-  g_init_ptrs<BKC>(qb, bop, by * 128, wave, lane);
-  if (!(ABL & 1)) {
-    g_issue(qa, aStep * seg.kb, smem, wave);
-    g_issue(qb, bStep * seg.kb, smem + 4096, wave);
+  if (BUF) {
+    g_init_offs<AKC>(va, aop, bx * 128, wave, lane);
+    g_init_offs<BKC>(vb, bop, by * 128, wave, lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      g_issue1_buf(ra, va[j], (uint32_t)(aStep * seg.kb * 4), smem, wave, j);
+      g_issue1_buf(rb, vb[j], (uint32_t)(bStep * seg.kb * 4), smem + 4096, wave, j);
+    }
+  } else {
+    g_init_ptrs<AKC>(qa, aop, bx * 128, wave, lane);
+    g_init_ptrs<BKC>(qb, bop, by * 128, wave, lane);
+    if (!(ABL & 1)) {
+      g_issue(qa, aStep * seg.kb, smem, wave);
+      g_issue(qb, bStep * seg.kb, smem + 4096, wave);
+    }
   }
   int stage = 0;
   __syncthreads();  // (drains the LDS-DMA: vmcnt(0) precedes the barrier)
@@ -258,8 +300,13 @@ __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, Gemm
       } else if (nxt.valid) {
         int nbx, nby;
         sk_tile_xy(plan, nxt.tile, nbx, nby);
-        g_init_ptrs<AKC>(qa, aop, nbx * 128, wave, lane);
-        g_init_ptrs<BKC>(qb, bop, nby * 128, wave, lane);
+        if (BUF) {
+          g_init_offs<AKC>(va, aop, nbx * 128, wave, lane);
+          g_init_offs<BKC>(vb, bop, nby * 128, wave, lane);
+        } else {
+          g_init_ptrs<AKC>(qa, aop, nbx * 128, wave, lane);
+          g_init_ptrs<BKC>(qb, bop, nby * 128, wave, lane);
+        }
         offA = aStep * nxt.kb; offB = bStep * nxt.kb;
       }
       // 16 k-steps of 4 MFMAs; the 8 LDS-DMA pieces and the fragment reads of the next 8-k group are
@@ -283,7 +330,10 @@ __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, Gemm
             }
           } else {
             const int piece = step - 1 - g;  // steps 1,2,3,5,6,7,9,10 -> pieces 0..7
-            if (!(ABL & 1)) {
+            if (BUF) {
+              if (piece < 4) g_issue1_buf(ra, va[piece], (uint32_t)(offA * 4), An, wave, piece);
+              else if (piece < 8) g_issue1_buf(rb, vb[piece - 4], (uint32_t)(offB * 4), An + 4096, wave, piece - 4);
+            } else if (!(ABL & 1)) {
               if (piece < 4) g_issue1(qa[piece], (ABL & 16) ? 0 : offA, An, wave, piece);
               else if (piece < 8 && !(ABL & 32)) g_issue1(qb[piece - 4], (ABL & 16) ? 0 : offB, An + 4096, wave, piece - 4);
             }
@@ -331,6 +381,7 @@ inline int launch128g(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o,
   static const int wideOn = [] { const char* e = getenv("W2L_GEMM_WIDE"); return e ? atoi(e) : 1; }();
   const int wide = wideOn && (((uintptr_t)o.C) & 15) == 0 && o.ldc % 4 == 0 &&
                    (!o.mask || (((uintptr_t)o.mask) & 15) == 0);
+  static const int bufOn = [] { const char* e = getenv("W2L_GEMM_BUF"); return e ? atoi(e) : 0; }();
   static const int abl = [] { const char* e = getenv("W2L_GEMM_ABL"); return e ? atoi(e) : 0; }();
   if (abl && akc && !bkc) {
     switch (abl) {
@@ -345,6 +396,11 @@ inline int launch128g(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o,
       case 2: hipLaunchKernelGGL((gemm128g_kernel<true, false, 2>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
       default: hipLaunchKernelGGL((gemm128g_kernel<true, false, 4>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
     }
+  } else if (bufOn && a.bytes && b.bytes) {
+    if (akc && bkc) hipLaunchKernelGGL((gemm128g_kernel<true, true, 0, true>), grid, block, shmem, s, a, b, o, plan, workers, wide);
+    else if (akc) hipLaunchKernelGGL((gemm128g_kernel<true, false, 0, true>), grid, block, shmem, s, a, b, o, plan, workers, wide);
+    else if (bkc) hipLaunchKernelGGL((gemm128g_kernel<false, true, 0, true>), grid, block, shmem, s, a, b, o, plan, workers, wide);
+    else hipLaunchKernelGGL((gemm128g_kernel<false, false, 0, true>), grid, block, shmem, s, a, b, o, plan, workers, wide);
   } else if (akc && bkc) hipLaunchKernelGGL((gemm128g_kernel<true, true>), grid, block, shmem, s, a, b, o, plan, workers, wide);
   else if (akc) hipLaunchKernelGGL((gemm128g_kernel<true, false>), grid, block, shmem, s, a, b, o, plan, workers, wide);
   else if (bkc) hipLaunchKernelGGL((gemm128g_kernel<false, true>), grid, block, shmem, s, a, b, o, plan, workers, wide);
