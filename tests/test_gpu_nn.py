@@ -154,6 +154,10 @@ CONV_CASES = [
     (1, 18, 18, 40, 37, 21, 1, 10, 10),   # c = 18, ragged last row block (H % 16 = 8)
     (1, 14, 18, 19, 66, 21, 2, 10, 10),   # strided stage transition, H % 16 = 3 (scalar slab loads)
     (2, 5, 7, 3, 20, 9, 1, 8, 0),         # causal padding, odd channel counts
+    (2, 14, 14, 32, 100, 21, 1, 10, 10),  # persistent kernel, c = 14, 4 time blocks x 2 row blocks
+    (1, 18, 18, 16, 70, 21, 1, 10, 10),   # persistent kernel, c = 18 (two MFMA column tiles, 16-frame tiles)
+    (2, 10, 14, 32, 61, 21, 2, 10, 10),   # persistent kernel, strided stage transition (forward only on this path)
+    (8, 10, 10, 16, 2200, 21, 1, 10, 10), # 552 tiles on 512 persistent workgroups: two tiles per workgroup + prefetch
 ]
 
 

@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""Turn the per-kernel FETCH_SIZE / WRITE_SIZE summaries written by tools/pmc.sh into
+profiles/<tag>_pmc_traffic.json: HBM-side bytes per launch of the dominant kernels.
+
+Corrections (MI355X_MICROARCH.md, HBM section): rocprofv3's FETCH_SIZE is in KiB and, on gfx950,
+tallies the 128-byte requests of wide coalesced streaming reads at 64 bytes -- doubled here.
+WRITE_SIZE (KiB) is uncalibrated on gfx950 and reported as is.
+"""
+import csv
+import json
+import sys
+
+
+def load(path, col):
+    out = {}
+    try:
+        for r in csv.DictReader(open(path)):
+            out[r["kernel"]] = (int(r["dispatches"]), float(r[col]))
+    except (OSError, KeyError):
+        pass
+    return out
+
+
+def main():
+    fetch_csv, write_csv, out_json = sys.argv[1:4]
+    f, w = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
+    groups = {"gemm128g": "gemm128g_kernel", "gemm128_kernel": "gemm128_kernel", "fcc_big_gemm": "fcc_big_gemm",
+              "tds_conv_fwd2": "tds_conv_fwd2_k", "tds_conv_filter2": "tds_conv_filter2_k"}
+    res = {}
+    for key, sub in groups.items():
+        n = fb = wb = 0.0
+        for k, (disp, v) in f.items():
+            if sub in k:
+                n += disp
+                fb += disp * v * 1024.0 * 2.0
+        nw = 0.0
+        for k, (disp, v) in w.items():
+            if sub in k:
+                nw += disp
+                wb += disp * v * 1024.0
+        if n:
+            res[key] = {"launches": int(n), "fetch_bytes_per_launch": fb / n,
+                        "write_bytes_per_launch": (wb / nw) if nw else None,
+                        "hbm_bytes_per_launch": fb / n + ((wb / nw) if nw else 0.0)}
+    res["_note"] = ("FETCH_SIZE KiB x 1024 x 2 (gfx950 counts 128-B read requests at 64 B); WRITE_SIZE KiB x 1024 "
+                    "uncorrected; separate --pmc passes, kernels serialised by the profiler")
+    json.dump(res, open(out_json, "w"), indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -33,6 +33,7 @@ namespace w2l {
 constexpr int kTdsBT = 32;   // output frames per workgroup (forward / backward-data)
 constexpr int kTdsBTF = 16;  // frames per chunk (backward-filter)
 constexpr int kTdsBH = 16;   // mel rows per workgroup = rows of one MFMA tile
+constexpr int kTdsMaxXV = 12;  // float4 slab pieces per thread (register-prefetching kernels)
 constexpr int kTdsMaxTilesPerWave = 6;  // backward-filter: (K+1)/16 row tiles over 4 waves -> K <= 383
 
 struct TdsConvP {
@@ -272,6 +273,165 @@ __global__ __launch_bounds__(256) void tds_conv_fwd_k(TdsConvP p) {
   }
 }
 
+
+// ---------------------------------------------------------------- forward / backward-data, persistent
+// tds_conv_fwd_k stages weights + slab, multiplies, writes -- strictly in sequence, once per workgroup,
+// so every tile exposes its staging latency (the kernel ran at 2x its MFMA-bound time).  This version
+// keeps a workgroup ALIVE over many (b, t-block, h-block) tiles: weights and the koff table are staged
+// once, and the float4 pieces of tile i+1's slab are issued into registers (fixed per-thread piece
+// descriptors) right before tile i is multiplied, then written to LDS after tile i's output has left it.
+// R = output frames per wave (8: 32-frame tiles; 4: 16-frame tiles when the 32-frame slab would not
+// leave room for two workgroups per CU).  Requires whole 16-row mel blocks and 16-byte aligned rows.
+template <int NT, int R>
+__global__ __launch_bounds__(256, 2) void tds_conv_fwd2_k(TdsConvP p, int nTiles, int tBlocks, int hBlocks) {
+  constexpr int BT = 4 * R;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int slabFloats = max(p.NF * p.FS, BT * kTdsBH * p.Cout);
+  float* slab = lds;
+  float* wS = slab + ((slabFloats + 3) & ~3);
+  int* koff = (int*)(wS + ((p.Kp * p.Cout + 3) & ~3));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // ---- once per workgroup: weights, koff, pad zeroing, piece descriptors
+  const int wTot = p.Kp * p.Cout, wValid = p.K * p.Cout;
+  if (!p.flip && (wValid & 3) == 0 && ((((uintptr_t)p.w) & 15) == 0)) {
+    tds_batched_copy4<8>((wTot + 3) >> 2,
+        [&](int e) {
+          const bool ok = 4 * e < wValid;
+          const float4 t4 = *(const float4*)(p.w + (ok ? 4 * e : 0));
+          return ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
+        },
+        [&](int e, float4 v) { *(float4*)(wS + 4 * e) = v; });
+  } else {
+    tds_batched_copy1<8>(wTot,
+        [&](int e) {
+          const int kk = e / p.Cout, co = e - kk * p.Cout;
+          const bool ok = kk < p.K;
+          size_t src = 0;
+          if (ok) {
+            if (!p.flip) {
+              src = (size_t)e;
+            } else {
+              const int tap = kk / p.Cin, c = kk - tap * p.Cin;  // c indexes CoutW, co indexes CinW
+              src = ((size_t)(p.kw - 1 - tap) * p.CinW + co) * p.CoutW + c;
+            }
+          }
+          const float t = p.w[src];
+          return ok ? t : 0.f;
+        },
+        [&](int e, float v) { wS[e] = v; });
+  }
+  for (int kk = tid; kk < p.Kp; kk += 256) {
+    const int tap = kk / p.Cin, c = kk - tap * p.Cin;
+    koff[kk] = kk < p.K ? tap * p.FS + c : 0;
+  }
+  const int xq = (kTdsBH * p.Cin) >> 2;  // float4 per slab frame
+  const int xTotal = p.NF * xq;
+  const int HCi = p.H * p.Cin;
+  int xf[kTdsMaxXV], xo[kTdsMaxXV];
+#pragma unroll
+  for (int v = 0; v < kTdsMaxXV; ++v) {
+    const int e = tid + 256 * v;
+    xf[v] = e < xTotal ? e / xq : -1;
+    xo[v] = e < xTotal ? (e - xf[v] * xq) << 2 : 0;
+  }
+  float4 xr[kTdsMaxXV];
+  auto fetch = [&](int tile) {
+    const int hb = tile % hBlocks, tb = (tile / hBlocks) % tBlocks, b = tile / (hBlocks * tBlocks);
+    const int tIn0 = tb * BT * p.stride - p.padl;
+    const float* xb = p.x + ((size_t)b * p.Tin * p.H + hb * kTdsBH) * p.Cin;
+#pragma unroll
+    for (int v = 0; v < kTdsMaxXV; ++v) {
+      const int ti = tIn0 + xf[v];
+      const bool ok = xf[v] >= 0 && ti >= 0 && ti < p.Tin;
+      const float4 t4 = *(const float4*)(xb + (size_t)(ok ? ti : 0) * HCi + xo[v]);
+      xr[v] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  const int i = lane & 15, lq = lane >> 4;
+  const int rstep = p.stride * p.FS;
+  const int nk = p.Kp >> 2;
+  const float* sl = slab + i * p.Cin + (wave * R * p.stride) * p.FS;
+  const size_t gRow = (size_t)p.H * p.Cout;
+  const int rowLen = kTdsBH * p.Cout, rq = rowLen >> 2;
+
+  int tile = blockIdx.x;
+  if (tile < nTiles) fetch(tile);
+  for (; tile < nTiles; tile += gridDim.x) {
+    const int hb = tile % hBlocks, tb = (tile / hBlocks) % tBlocks, b = tile / (hBlocks * tBlocks);
+    const int h0 = hb * kTdsBH, t0 = tb * BT;
+    __syncthreads();  // the previous tile's output has been read out of the slab region
+#pragma unroll
+    for (int v = 0; v < kTdsMaxXV; ++v)
+      if (xf[v] >= 0) *(float4*)(slab + xf[v] * p.FS + xo[v]) = xr[v];
+    __syncthreads();
+    const int nxt = tile + gridDim.x;
+    fetch(nxt < nTiles ? nxt : tile);  // in flight behind this tile's MFMAs and output
+
+    f32x4 acc[R][NT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[r][nt][q] = 0.f;
+    for (int kq = 0; kq < nk; ++kq) {
+      const int kk = 4 * kq + lq;
+      const int ko = koff[kk];
+      float bf[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bf[nt] = (16 * nt + i < p.Cout) ? wS[kk * p.Cout + 16 * nt + i] : 0.f;
+      float a[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) a[r] = sl[r * rstep + ko];
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], bf[nt], acc[r][nt], 0, 0, 0);
+    }
+    __syncthreads();  // all fragment reads done: the slab region becomes the output stage
+
+    float* outS = slab;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co = 16 * nt + i;
+      if (co < p.Cout) {
+        const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float v = acc[r][nt][q] + bv;
+            if (p.relu) v = fmaxf(v, 0.f);
+            outS[((wave * R + r) * kTdsBH + 4 * lq + q) * p.Cout + co] = v;
+          }
+      }
+    }
+    __syncthreads();
+    int tc = p.Tout - t0;
+    if (tc > BT) tc = BT;
+    const size_t gBase = (((size_t)b * p.Tout + t0) * p.H + h0) * p.Cout;
+    tds_batched_copy4<8>(tc * rq,
+        [&](int e) {
+          const int t = e / rq, o = (e - t * rq) << 2;
+          const size_t g = gBase + (size_t)t * gRow + o;
+          float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (p.add) a4 = *(const float4*)(p.add + g);
+          if (p.accum) {
+            const float4 y0 = *(const float4*)(p.y + g);
+            a4.x += y0.x; a4.y += y0.y; a4.z += y0.z; a4.w += y0.w;
+          }
+          return a4;
+        },
+        [&](int e, float4 a4) {
+          const int t = e / rq, o = (e - t * rq) << 2;
+          const float4 v = *(const float4*)(outS + t * rowLen + o);
+          *(float4*)(p.y + gBase + (size_t)t * gRow + o) = make_float4(v.x + a4.x, v.y + a4.y, v.z + a4.z, v.w + a4.w);
+        });
+  }
+}
+
 // ---------------------------------------------------------------- backward-filter (+ bias gradient)
 // persistent grid; chunk = (b, 16 frames, 16 mel rows).  A = x^T: rows (tap,ci) [+ one all-ones row
 // for the bias gradient], k = the chunk's 256 (t,h) positions; B = dy [(t,h)][co].
@@ -356,7 +516,6 @@ __global__ __launch_bounds__(256) void tds_conv_filter_k(TdsConvP p, const float
 // c, and writes them to LDS afterwards.  The first version loaded one element per loop trip with the
 // s_waitcnt right behind it: ~16 serialized HBM round trips per chunk (43 us per chunk measured,
 // against 3 us of MFMA work).  Requires whole 16-row mel blocks (H % 16 == 0), 16-byte aligned rows.
-constexpr int kTdsMaxXV = 12;  // float4 slab pieces per thread
 constexpr int kTdsMaxDV = 5;   // float4 dy pieces per thread
 
 template <int NT>
@@ -536,7 +695,55 @@ static size_t fwd_lds_bytes(const TdsConvP& p) {
   return (slab + ws + p.Kp) * sizeof(float);
 }
 
+static size_t fwd2_lds_bytes(const TdsConvP& p, int bt) {
+  size_t slab = (size_t)p.NF * p.FS;
+  const size_t outS = (size_t)bt * kTdsBH * p.Cout;
+  if (outS > slab) slab = outS;
+  slab = (slab + 3) & ~(size_t)3;
+  const size_t ws = ((size_t)p.Kp * p.Cout + 3) & ~(size_t)3;
+  return (slab + ws + p.Kp) * sizeof(float);
+}
+
+template <int NT, int R>
+static int launch_fwd2_t(const TdsConvP& p, size_t shmem, hipStream_t s) {
+  constexpr int BT = 4 * R;
+  const int tBlocks = (p.Tout + BT - 1) / BT, hBlocks = p.H / kTdsBH;
+  const int nTiles = p.B * tBlocks * hBlocks;
+  const int perCu = 2;  // 174-215 VGPRs: two waves per SIMD
+  const int blocks = nTiles < 256 * perCu ? nTiles : 256 * perCu;
+  if (shmem > 64 * 1024)
+    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_fwd2_k<NT, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL((tds_conv_fwd2_k<NT, R>), dim3((unsigned)blocks), dim3(256), shmem, s, p, nTiles, tBlocks, hBlocks);
+  return W2L_OK;
+}
+
+// persistent register-prefetching kernel when the geometry allows it; `pIn` was built for 32-frame tiles
+static bool try_launch_fwd2(const TdsConvP& pIn, hipStream_t s, int* status) {
+  if (getenv("W2L_TDS_FWD_V1")) return false;
+  if (pIn.H % kTdsBH || ((pIn.H * pIn.Cin) & 3) || ((pIn.H * pIn.Cout) & 3) || ((kTdsBH * pIn.Cin) & 3) || ((kTdsBH * pIn.Cout) & 3)) return false;
+  if ((((uintptr_t)pIn.x | (uintptr_t)pIn.y | (uintptr_t)pIn.add) & 15) != 0) return false;
+  for (int bt = 32; bt >= 16; bt >>= 1) {
+    TdsConvP p = pIn;
+    p.NF = (bt - 1) * p.stride + p.kw;
+    const int pieces = (p.NF * ((kTdsBH * p.Cin) >> 2) + 255) / 256;
+    const size_t shmem = fwd2_lds_bytes(p, bt);
+    if (pieces > kTdsMaxXV || 2 * shmem > 160 * 1024) continue;  // two workgroups per CU or nothing
+    const double flops = 2.0 * p.B * p.Tout * (double)p.H * p.K * p.Cout;
+    prof_begin(s, flops, PROF_TDSCONV);
+    int st;
+    if (p.Cout <= 16) st = bt == 32 ? launch_fwd2_t<1, 8>(p, shmem, s) : launch_fwd2_t<1, 4>(p, shmem, s);
+    else st = bt == 32 ? launch_fwd2_t<2, 8>(p, shmem, s) : launch_fwd2_t<2, 4>(p, shmem, s);
+    prof_end(s);
+    if (st == W2L_OK && hipGetLastError() != hipSuccess) st = W2L_EHIP;
+    *status = st;
+    return true;
+  }
+  return false;
+}
+
 static int launch_fwd(const TdsConvP& p, hipStream_t s) {
+  int st2 = W2L_OK;
+  if (try_launch_fwd2(p, s, &st2)) return st2;
   const size_t shmem = fwd_lds_bytes(p);
   if (shmem > 160 * 1024) return W2L_EUNSUPPORTED;
   dim3 grid((unsigned)((p.H + kTdsBH - 1) / kTdsBH), (unsigned)((p.Tout + kTdsBT - 1) / kTdsBT), (unsigned)p.B);

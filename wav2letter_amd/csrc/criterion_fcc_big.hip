@@ -303,56 +303,36 @@ __global__ __launch_bounds__(256, NB <= 1 ? 2 : 1) void fcc_big_gemm(const float
     const float4* pa = pack + ((size_t)(RT * g) * NC) * 64 + lane;  // row tile rt of the group: + rt * tileStride
     const size_t tileStride = (size_t)NC * 64;
 
-    // The steady-state loops contain NO branch around a load: a load under a branch makes hipcc's
-    // s_waitcnt placement assume the worst at the join and wait vmcnt(0), which drains the prefetch at every
-    // stage.  The last one or two stages of a wave are peeled off instead (no redundant tail loads: at ~24
-    // stages per wave two clamped extra stages were 8 % more traffic).
-    if (s0 < s1) {
-      bool ring = false;
-      if constexpr (NB < 4 && RT < 4) ring = d.ring != 0;  // 192 (80 at RT = 4) operand VGPRs per stage: no room for three
-      if (!ring) {
-        // two register sets in ping-pong: the loads of stage s+1 are in flight behind the MFMAs of stage s
-        BigStage<NB, RT> sa, sb2;
-        big_load_stage<NB, RT, ABL>(sa, pa, tileStride, pe, NC, s0);
-        int s = s0;
-        for (; s + 2 < s1; s += 2) {
-          big_load_stage<NB, RT, ABL>(sb2, pa, tileStride, pe, NC, s + 1);
-          big_compute_stage<NB, RT, EXPOP, ABL>(sa, cb, acc);
-          big_load_stage<NB, RT, ABL>(sa, pa, tileStride, pe, NC, s + 2);
-          big_compute_stage<NB, RT, EXPOP, ABL>(sb2, cb, acc);
-        }
-        if (s + 1 < s1) {  // two stages left: sa holds s
-          big_load_stage<NB, RT, ABL>(sb2, pa, tileStride, pe, NC, s + 1);
-          big_compute_stage<NB, RT, EXPOP, ABL>(sa, cb, acc);
-          big_compute_stage<NB, RT, EXPOP, ABL>(sb2, cb, acc);
-        } else {
-          big_compute_stage<NB, RT, EXPOP, ABL>(sa, cb, acc);
-        }
-      } else if constexpr (NB < 4 && RT < 4) {
-        // three register sets in a ring (W2L_FCC_RING=1): stages s+1 and s+2 in flight behind stage s
+    // Two operand register sets in ping-pong: the loads of stage s+1 are in flight behind the MFMAs of stage s.
+    // Variants measured on MI355X (B=32, N=9998; profiles/r01_run9_fcc_stream_ab.log, r01_run10_fcc_stream_variants.log):
+    //   this loop (loads under `if`)            90.9 us per step  (4.43 TB/s)
+    //   clamped unconditional loads             104.5 us (two redundant tail stages per wave = +8 % traffic)
+    //   three-deep ring, unconditional loads     94.1 us;  RT = 4 row tiles per wave 109.5 us
+    //   peeled tails (no branch, no redundancy) 138 / 195 us -- hipcc's s_waitcnt placement got worse, not better
+    //   loads only (no MFMA, no E traffic)       80.7 us = 5.0 TB/s: the ceiling of this load structure
+    if (d.ring == 0 || NB >= 4 || RT >= 4) {
+      BigStage<NB, RT> sa, sb2;
+      if (s0 < s1) big_load_stage<NB, RT, ABL>(sa, pa, tileStride, pe, NC, s0);
+      for (int s = s0; s < s1; s += 2) {
+        if (s + 1 < s1) big_load_stage<NB, RT, ABL>(sb2, pa, tileStride, pe, NC, s + 1);
+        big_compute_stage<NB, RT, EXPOP, ABL>(sa, cb, acc);
+        if (s + 2 < s1) big_load_stage<NB, RT, ABL>(sa, pa, tileStride, pe, NC, s + 2);
+        if (s + 1 < s1) big_compute_stage<NB, RT, EXPOP, ABL>(sb2, cb, acc);
+      }
+    } else if constexpr (NB < 4 && RT < 4) {
+      // W2L_FCC_RING=1: three register sets in a ring, loads issued unconditionally (stage index clamped)
+      if (s0 < s1) {
+        const int sl = s1 - 1;
         BigStage<NB, RT> r0, r1, r2;
         big_load_stage<NB, RT, ABL>(r0, pa, tileStride, pe, NC, s0);
-        int s = s0;
-        if (s + 1 < s1) {
-          big_load_stage<NB, RT, ABL>(r1, pa, tileStride, pe, NC, s + 1);
-          for (; s + 4 < s1; s += 3) {  // invariant: r0 = stage s, r1 = stage s+1 loaded / in flight
-            big_load_stage<NB, RT, ABL>(r2, pa, tileStride, pe, NC, s + 2);
-            big_compute_stage<NB, RT, EXPOP, ABL>(r0, cb, acc);
-            big_load_stage<NB, RT, ABL>(r0, pa, tileStride, pe, NC, s + 3);
-            big_compute_stage<NB, RT, EXPOP, ABL>(r1, cb, acc);
-            big_load_stage<NB, RT, ABL>(r1, pa, tileStride, pe, NC, s + 4);
-            big_compute_stage<NB, RT, EXPOP, ABL>(r2, cb, acc);
-          }
-          // 2..4 stages left, r0 = s, r1 = s+1
-          const int left = s1 - s;
-          if (left >= 3) big_load_stage<NB, RT, ABL>(r2, pa, tileStride, pe, NC, s + 2);
+        big_load_stage<NB, RT, ABL>(r1, pa, tileStride, pe, NC, min(s0 + 1, sl));
+        for (int s = s0; s < s1; s += 3) {
+          big_load_stage<NB, RT, ABL>(r2, pa, tileStride, pe, NC, min(s + 2, sl));
           big_compute_stage<NB, RT, EXPOP, ABL>(r0, cb, acc);
-          if (left >= 4) big_load_stage<NB, RT, ABL>(r0, pa, tileStride, pe, NC, s + 3);
-          big_compute_stage<NB, RT, EXPOP, ABL>(r1, cb, acc);
-          if (left >= 3) big_compute_stage<NB, RT, EXPOP, ABL>(r2, cb, acc);
-          if (left >= 4) big_compute_stage<NB, RT, EXPOP, ABL>(r0, cb, acc);
-        } else {
-          big_compute_stage<NB, RT, EXPOP, ABL>(r0, cb, acc);
+          big_load_stage<NB, RT, ABL>(r0, pa, tileStride, pe, NC, min(s + 3, sl));
+          if (s + 1 < s1) big_compute_stage<NB, RT, EXPOP, ABL>(r1, cb, acc);
+          big_load_stage<NB, RT, ABL>(r1, pa, tileStride, pe, NC, min(s + 4, sl));
+          if (s + 2 < s1) big_compute_stage<NB, RT, EXPOP, ABL>(r2, cb, acc);
         }
       }
     }

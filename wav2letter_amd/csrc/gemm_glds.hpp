@@ -381,7 +381,9 @@ inline int launch128g(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o,
   static const int wideOn = [] { const char* e = getenv("W2L_GEMM_WIDE"); return e ? atoi(e) : 1; }();
   const int wide = wideOn && (((uintptr_t)o.C) & 15) == 0 && o.ldc % 4 == 0 &&
                    (!o.mask || (((uintptr_t)o.mask) & 15) == 0);
-  static const int bufOn = [] { const char* e = getenv("W2L_GEMM_BUF"); return e ? atoi(e) : 0; }();
+  // buffer-addressed LDS-DMA is the default (+8 % at 4096^3, +5-7 % on the TDS fc shapes over 64-bit global
+  // addresses, MI355X); W2L_GEMM_BUF=0 selects the global_load_lds variant for A/B runs
+  static const int bufOn = [] { const char* e = getenv("W2L_GEMM_BUF"); return e ? atoi(e) : 1; }();
   static const int abl = [] { const char* e = getenv("W2L_GEMM_ABL"); return e ? atoi(e) : 0; }();
   if (abl && akc && !bkc) {
     switch (abl) {
