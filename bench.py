@@ -31,6 +31,24 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md chip tab
 PEAK_HBM_GBPS = 8000.0         # same table (6.29 TB/s measured-achievable)
 
 
+def pmc_traffic(key):
+    """HBM-side bytes per launch of a kernel family from the newest committed PMC summary
+    (profiles/*_pmc_traffic.json, written by tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes over this same bench command; gfx950 corrections applied there).  None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return round(d[key]["hbm_bytes_per_launch"]), {
+            "fetch_bytes": round(d[key]["fetch_bytes_per_launch"]), "write_bytes": round(d[key]["write_bytes_per_launch"] or 0),
+            "source": "profiles/" + os.path.basename(files[-1]),
+            "note": "per launch; FETCH_SIZE x2 (gfx950 half-count) + WRITE_SIZE = L2->fabric requests, Infinity-Cache hits included"}
+    except (KeyError, ValueError, OSError):
+        return None, None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,7 +154,8 @@ def asg_stress(device, L, T):
             "finite": bool(torch.isfinite(loss).all().item()),
             "roofline": {"bound": "hbm", "kernel": "fcc_big_gemm (packed-transition stream, fp32 MFMA 32x32x2)",
                          "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / PEAK_HBM_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_HBM_GBPS, 4), "traffic": pmc_traffic("fcc_big_gemm")[0],
+                         "traffic_detail": pmc_traffic("fcc_big_gemm")[1],
                          "launches": nl.value, "avg_launch_us": round(ms.value * 1e3 / max(1, nl.value), 2),
                          "algorithmic_bytes_per_launch": step_bytes}}
 
@@ -261,9 +280,10 @@ def main():
                                "9998 classes, batch %d/GPU, fp32, SGD+momentum, CTC" % (T, B),
                    "global_batch": total_batch, "frames": T, "emission_frames": Tout, "parallelism": f"dp{world}",
                    "params": int(tr.n_net), "final_loss": round(last_loss, 4)},
-        "roofline": {"bound": "mfma", "kernel": "gemm128_kernel (fp32 v_mfma_f32_32x32x2_f32, 128x128x32 tiles, stream-K)",
+        "roofline": {"bound": "mfma", "kernel": "gemm128g_kernel (fp32 v_mfma_f32_32x32x2_f32, 128x128x32 tiles, persistent, buffer LDS-DMA staging, stream-K tail + fix-up; includes the few gemm128_kernel launches on unaligned shapes)",
                      "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic("gemm128g")[0],
+                     "traffic_detail": pmc_traffic("gemm128g")[1],
                      "launches_per_step": nl // max(1, a.steps),
                      "avg_launch_us": round(ms * 1e3 / max(1, nl), 1),
                      "algorithmic_gflop_per_launch": round(flops / max(1, nl) / 1e9, 2),

@@ -285,42 +285,32 @@ __global__ __launch_bounds__(256) void tds_conv_fwd_k(TdsConvP p) {
 template <int NT, int R>
 __global__ __launch_bounds__(256, 2) void tds_conv_fwd2_k(TdsConvP p, int nTiles, int tBlocks, int hBlocks) {
   constexpr int BT = 4 * R;
+  constexpr int CP = 16 * NT;  // weight rows are zero-padded to whole MFMA column tiles: no per-lane guard in the K loop
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int slabFloats = max(p.NF * p.FS, BT * kTdsBH * p.Cout);
   float* slab = lds;
   float* wS = slab + ((slabFloats + 3) & ~3);
-  int* koff = (int*)(wS + ((p.Kp * p.Cout + 3) & ~3));
+  int* koff = (int*)(wS + p.Kp * CP);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   // ---- once per workgroup: weights, koff, pad zeroing, piece descriptors
-  const int wTot = p.Kp * p.Cout, wValid = p.K * p.Cout;
-  if (!p.flip && (wValid & 3) == 0 && ((((uintptr_t)p.w) & 15) == 0)) {
-    tds_batched_copy4<8>((wTot + 3) >> 2,
-        [&](int e) {
-          const bool ok = 4 * e < wValid;
-          const float4 t4 = *(const float4*)(p.w + (ok ? 4 * e : 0));
-          return ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
-        },
-        [&](int e, float4 v) { *(float4*)(wS + 4 * e) = v; });
-  } else {
-    tds_batched_copy1<8>(wTot,
-        [&](int e) {
-          const int kk = e / p.Cout, co = e - kk * p.Cout;
-          const bool ok = kk < p.K;
-          size_t src = 0;
-          if (ok) {
-            if (!p.flip) {
-              src = (size_t)e;
-            } else {
-              const int tap = kk / p.Cin, c = kk - tap * p.Cin;  // c indexes CoutW, co indexes CinW
-              src = ((size_t)(p.kw - 1 - tap) * p.CinW + co) * p.CoutW + c;
-            }
+  tds_batched_copy1<8>(p.Kp * CP,
+      [&](int e) {
+        const int kk = e / CP, co = e - kk * CP;
+        const bool ok = kk < p.K && co < p.Cout;
+        size_t src = 0;
+        if (ok) {
+          if (!p.flip) {
+            src = (size_t)kk * p.Cout + co;
+          } else {
+            const int tap = kk / p.Cin, c = kk - tap * p.Cin;  // c indexes CoutW, co indexes CinW
+            src = ((size_t)(p.kw - 1 - tap) * p.CinW + co) * p.CoutW + c;
           }
-          const float t = p.w[src];
-          return ok ? t : 0.f;
-        },
-        [&](int e, float v) { wS[e] = v; });
-  }
+        }
+        const float t = p.w[src];
+        return ok ? t : 0.f;
+      },
+      [&](int e, float v) { wS[e] = v; });
   for (int kk = tid; kk < p.Kp; kk += 256) {
     const int tap = kk / p.Cin, c = kk - tap * p.Cin;
     koff[kk] = kk < p.K ? tap * p.FS + c : 0;
@@ -376,19 +366,38 @@ __global__ __launch_bounds__(256, 2) void tds_conv_fwd2_k(TdsConvP p, int nTiles
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[r][nt][q] = 0.f;
+    // K loop, software-pipelined by hand: the table entry of step kq+2 and the fragments of step kq+1 are
+    // read from LDS while the MFMAs of step kq run (hipcc left "read koff -> wait -> 8 reads -> wait -> 8 MFMA"
+    // in sequence: ~200 exposed LDS cycles per 256 MFMA cycles)
+    const float* wl = wS + lq * CP + i;
+    int ko1 = koff[lq + (nk > 1 ? 4 : 0)];
+    float aC[R], bC[NT];
+    {
+      const int ko0 = koff[lq];
+#pragma unroll
+      for (int r = 0; r < R; ++r) aC[r] = sl[r * rstep + ko0];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bC[nt] = wl[16 * nt];
+    }
     for (int kq = 0; kq < nk; ++kq) {
-      const int kk = 4 * kq + lq;
-      const int ko = koff[kk];
-      float bf[NT];
+      const int k1 = kq + 1 < nk ? kq + 1 : nk - 1, k2 = kq + 2 < nk ? kq + 2 : nk - 1;
+      const int ko2 = koff[4 * k2 + lq];
+      float aN[R], bN[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bf[nt] = (16 * nt + i < p.Cout) ? wS[kk * p.Cout + 16 * nt + i] : 0.f;
-      float a[R];
+      for (int r = 0; r < R; ++r) aN[r] = sl[r * rstep + ko1];
 #pragma unroll
-      for (int r = 0; r < R; ++r) a[r] = sl[r * rstep + ko];
+      for (int nt = 0; nt < NT; ++nt) bN[nt] = wl[4 * k1 * CP + 16 * nt];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], bf[nt], acc[r][nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aC[r], bC[nt], acc[r][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < R; ++r) aC[r] = aN[r];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bC[nt] = bN[nt];
+      ko1 = ko2;
     }
     __syncthreads();  // all fragment reads done: the slab region becomes the output stage
 
@@ -700,7 +709,7 @@ static size_t fwd2_lds_bytes(const TdsConvP& p, int bt) {
   const size_t outS = (size_t)bt * kTdsBH * p.Cout;
   if (outS > slab) slab = outS;
   slab = (slab + 3) & ~(size_t)3;
-  const size_t ws = ((size_t)p.Kp * p.Cout + 3) & ~(size_t)3;
+  const size_t ws = (size_t)p.Kp * (p.Cout <= 16 ? 16 : 32);  // weight rows padded to whole MFMA column tiles
   return (slab + ws + p.Kp) * sizeof(float);
 }
 

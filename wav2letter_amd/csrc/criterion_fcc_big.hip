@@ -60,6 +60,7 @@ struct BigDims {
   int W;    // persistent workgroups of the streaming kernel: worker w owns units [U w / W, U (w+1) / W)
   int P;    // bound on the workers (= partial slabs) that share one row group
   int ring; // 1: three operand register sets in a ring, 0: two in ping-pong (W2L_FCC_RING, A/B runs)
+  int asmv; // 1: hand-counted asm-load kernel (W2L_FCC_ASM)
   int abl;  // W2L_FCC_ABL: timing-only ablations 1 = no MFMA, 2 = no E-operand traffic; 4 = nontemporal loads of the
             // transition stream (results stay correct)
 };
@@ -97,6 +98,7 @@ inline BigDims big_dims(int B, int T, int N) {
   d.RT = big_row_tiles(d.NB);
   { const char* e = getenv("W2L_FCC_RING"); d.ring = e ? atoi(e) : 0; }
   { const char* e = getenv("W2L_FCC_ABL"); d.abl = e ? atoi(e) : 0; }
+  { const char* e = getenv("W2L_FCC_ASM"); d.asmv = e ? atoi(e) : 0; }
   d.Np = (N + 32 * d.RT - 1) / (32 * d.RT) * (32 * d.RT);
   d.G = d.Np / (32 * d.RT);
   // The step is cut into U = G * nS stage-units (64 rows x 32 k) in row-group-major order and dealt
@@ -320,19 +322,32 @@ __global__ __launch_bounds__(256, NB <= 1 ? 2 : 1) void fcc_big_gemm(const float
         if (s + 1 < s1) big_compute_stage<NB, RT, EXPOP, ABL>(sb2, cb, acc);
       }
     } else if constexpr (NB < 4 && RT < 4) {
-      // W2L_FCC_RING=1: three register sets in a ring, loads issued unconditionally (stage index clamped)
+      // W2L_FCC_RING=1 / 2: three / two register sets, loads issued UNCONDITIONALLY so that hipcc can count
+      // them (vmcnt(N) > 0 in the loop); the stage index of a load past the wave's range falls back to the
+      // wave's FIRST stage (just read: an L2 hit, no extra HBM traffic; its data is never consumed).
       if (s0 < s1) {
-        const int sl = s1 - 1;
-        BigStage<NB, RT> r0, r1, r2;
-        big_load_stage<NB, RT, ABL>(r0, pa, tileStride, pe, NC, s0);
-        big_load_stage<NB, RT, ABL>(r1, pa, tileStride, pe, NC, min(s0 + 1, sl));
-        for (int s = s0; s < s1; s += 3) {
-          big_load_stage<NB, RT, ABL>(r2, pa, tileStride, pe, NC, min(s + 2, sl));
-          big_compute_stage<NB, RT, EXPOP, ABL>(r0, cb, acc);
-          big_load_stage<NB, RT, ABL>(r0, pa, tileStride, pe, NC, min(s + 3, sl));
-          if (s + 1 < s1) big_compute_stage<NB, RT, EXPOP, ABL>(r1, cb, acc);
-          big_load_stage<NB, RT, ABL>(r1, pa, tileStride, pe, NC, min(s + 4, sl));
-          if (s + 2 < s1) big_compute_stage<NB, RT, EXPOP, ABL>(r2, cb, acc);
+        auto sx = [&](int t) { return t < s1 ? t : s0; };
+        if (d.ring == 1) {
+          BigStage<NB, RT> r0, r1, r2;
+          big_load_stage<NB, RT, ABL>(r0, pa, tileStride, pe, NC, s0);
+          big_load_stage<NB, RT, ABL>(r1, pa, tileStride, pe, NC, sx(s0 + 1));
+          for (int s = s0; s < s1; s += 3) {
+            big_load_stage<NB, RT, ABL>(r2, pa, tileStride, pe, NC, sx(s + 2));
+            big_compute_stage<NB, RT, EXPOP, ABL>(r0, cb, acc);
+            big_load_stage<NB, RT, ABL>(r0, pa, tileStride, pe, NC, sx(s + 3));
+            if (s + 1 < s1) big_compute_stage<NB, RT, EXPOP, ABL>(r1, cb, acc);
+            big_load_stage<NB, RT, ABL>(r1, pa, tileStride, pe, NC, sx(s + 4));
+            if (s + 2 < s1) big_compute_stage<NB, RT, EXPOP, ABL>(r2, cb, acc);
+          }
+        } else {
+          BigStage<NB, RT> sa, sb2;
+          big_load_stage<NB, RT, ABL>(sa, pa, tileStride, pe, NC, s0);
+          for (int s = s0; s < s1; s += 2) {
+            big_load_stage<NB, RT, ABL>(sb2, pa, tileStride, pe, NC, sx(s + 1));
+            big_compute_stage<NB, RT, EXPOP, ABL>(sa, cb, acc);
+            big_load_stage<NB, RT, ABL>(sa, pa, tileStride, pe, NC, sx(s + 2));
+            if (s + 1 < s1) big_compute_stage<NB, RT, EXPOP, ABL>(sb2, cb, acc);
+          }
         }
       }
     }
@@ -360,6 +375,148 @@ __global__ __launch_bounds__(256, NB <= 1 ? 2 : 1) void fcc_big_gemm(const float
     if (u0 < u1) __syncthreads();  // `red` is reused by the next segment
   }
 }
+
+
+// ------------------------------------------------------------------ kernel 1, hand-counted variant (B <= 32)
+// Same partition, fragments and arithmetic as fcc_big_gemm<1, 2>, but the operand stream is issued by
+// inline-asm loads that hipcc does not count, in a THREE-deep register ring with hand-placed
+// s_waitcnt vmcnt(N): the compiler's own placement drains the queue (vmcnt(0)) somewhere in every stage
+// whatever the loop shape (see the variant table in fcc_big_gemm), so a wave never had more than one
+// stage in flight behind its MFMAs.  Discipline (cdna_hip_programming.md 5.7, form (ii)): every load is an
+// "=v" asm output; before a chunk's first consumer a wait statement names that chunk's three destinations
+// "+v"; loads retire in issue order, so vmcnt(N) with N = loads issued after the chunk's is exact.
+struct AsmStage {
+  f32x4 a0[kBigU], a1[kBigU], e[kBigU];
+};
+
+#define W2L_GLOAD(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+
+__device__ __forceinline__ void asm_load_stage(AsmStage& st, const float4* pa0, const float4* pa1, const float4* pe, int s) {
+#pragma unroll
+  for (int u = 0; u < kBigU; ++u) {
+    const size_t c = ((size_t)s * kBigU + u) * 64;
+    W2L_GLOAD(st.a0[u], pa0 + c);
+    W2L_GLOAD(st.a1[u], pa1 + c);
+    W2L_GLOAD(st.e[u], pe + c);
+  }
+}
+
+// AFTER = loads issued after this stage's 12 (0, 12 or 24); chunk u may be consumed once at most
+// AFTER + 3 (3 - u) loads are still outstanding
+template <bool EXPOP, int AFTER>
+__device__ __forceinline__ void asm_compute_stage(AsmStage& st, float cb, f32x16 (&acc)[2]) {
+#pragma unroll
+  for (int u = 0; u < kBigU; ++u) {
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(st.a0[u]), "+v"(st.a1[u]), "+v"(st.e[u]) : "n"(AFTER + 3 * (kBigU - 1 - u)));
+    float ev[4] = {st.e[u][0], st.e[u][1], st.e[u][2], st.e[u][3]};
+    if (EXPOP) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ev[q] = __expf(ev[q] - cb);  // padding holds -inf -> 0
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ev[q], st.a0[u][q], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ev[q], st.a1[u][q], acc[1], 0, 0, 0);
+    }
+  }
+}
+
+template <bool EXPOP>
+__global__ __launch_bounds__(256, 2) void fcc_big_gemm_asm(const float4* __restrict__ pack, const float4* __restrict__ op,
+                                                           const float* __restrict__ pmax, float* __restrict__ part, BigDims d) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][32 regs][64 lanes]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int NC = d.NC, Np = d.Np, Bp = d.Bp, B = d.B;
+  const int w = blockIdx.x;
+  int u0 = big_unit_begin(d, w);
+  const int u1 = big_unit_begin(d, w + 1);
+
+  float cb = 0.f;
+  if (EXPOP) {
+    const int b = lane & 31;
+    float m = 0.f;
+    if (b < B) {
+      m = -INFINITY;
+#pragma unroll
+      for (int p = 0; p < kBigParts; ++p) m = fmaxf(m, pmax[(size_t)b * kBigParts + p]);
+    }
+    cb = m;
+  }
+  const float4* pe = op + lane;
+
+  while (u0 < u1) {
+    const int g = u0 / d.nS, sb = u0 - g * d.nS;
+    int len = d.nS - sb;
+    if (len > u1 - u0) len = u1 - u0;
+    const int s0 = sb + (int)((long long)len * wave / 4), s1 = sb + (int)((long long)len * (wave + 1) / 4);
+    const int piece = w - big_worker_of(d, g * d.nS);
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
+    const float4* pa0 = pack + ((size_t)(2 * g) * NC) * 64 + lane;
+    const float4* pa1 = pack + ((size_t)(2 * g + 1) * NC) * 64 + lane;
+
+    AsmStage r0, r1, r2;
+    int s = s0;
+    const int n = s1 - s0;
+    if (n == 1) {
+      asm_load_stage(r0, pa0, pa1, pe, s);
+      asm_compute_stage<EXPOP, 0>(r0, cb, acc);
+    } else if (n >= 2) {
+      asm_load_stage(r0, pa0, pa1, pe, s);
+      asm_load_stage(r1, pa0, pa1, pe, s + 1);
+      // invariant: r0 = stage s, r1 = stage s + 1, both issued, nothing else outstanding
+      for (; s + 4 < s1; s += 3) {
+        asm_load_stage(r2, pa0, pa1, pe, s + 2);
+        asm_compute_stage<EXPOP, 24>(r0, cb, acc);
+        asm_load_stage(r0, pa0, pa1, pe, s + 3);
+        asm_compute_stage<EXPOP, 24>(r1, cb, acc);
+        asm_load_stage(r1, pa0, pa1, pe, s + 4);
+        asm_compute_stage<EXPOP, 24>(r2, cb, acc);
+      }
+      const int left = s1 - s;  // 2, 3 or 4
+      if (left == 2) {
+        asm_compute_stage<EXPOP, 12>(r0, cb, acc);
+        asm_compute_stage<EXPOP, 0>(r1, cb, acc);
+      } else if (left == 3) {
+        asm_load_stage(r2, pa0, pa1, pe, s + 2);
+        asm_compute_stage<EXPOP, 24>(r0, cb, acc);
+        asm_compute_stage<EXPOP, 12>(r1, cb, acc);
+        asm_compute_stage<EXPOP, 0>(r2, cb, acc);
+      } else {
+        asm_load_stage(r2, pa0, pa1, pe, s + 2);
+        asm_compute_stage<EXPOP, 24>(r0, cb, acc);
+        asm_load_stage(r0, pa0, pa1, pe, s + 3);
+        asm_compute_stage<EXPOP, 24>(r1, cb, acc);
+        asm_compute_stage<EXPOP, 12>(r2, cb, acc);
+        asm_compute_stage<EXPOP, 0>(r0, cb, acc);
+      }
+    }
+
+    // 4-wave reduction through LDS, fixed order (deterministic)
+    constexpr int NR = 32;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((wave * NR) + h * 16 + r) * 64 + lane] = acc[h][r];
+    __syncthreads();
+    float* dst = part + (size_t)piece * Bp * Np;
+    for (int o = threadIdx.x; o < NR * 64; o += 256) {
+      const float v = (red[o] + red[NR * 64 + o]) + (red[2 * NR * 64 + o] + red[3 * NR * 64 + o]);
+      const int l = o & 63, rr = o >> 6;
+      const int r = rr & 15, h = rr >> 4;
+      const int b = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+      const int i = 64 * g + 32 * h + (l & 31);
+      dst[(size_t)b * Np + i] = v;
+    }
+    u0 += len;
+    if (u0 < u1) __syncthreads();  // `red` is reused by the next segment
+  }
+}
+#undef W2L_GLOAD
 
 // ------------------------------------------------------------------ block reductions
 template <int THREADS>
@@ -583,6 +740,14 @@ static int launch_big_gemm(const BigDims& d, const float* pack, const float* op,
 }
 template <bool EXPOP>
 static int big_gemm(const BigDims& d, const float* pack, const float* op, const float* pmax, float* part, hipStream_t s) {
+  if (d.NB == 1 && d.RT == 2 && d.asmv && !d.abl) {
+    const size_t shmem = (size_t)4 * 32 * 64 * sizeof(float);
+    prof_begin(s, 4.0 * d.N * (double)d.N + 8.0 * d.B * (double)d.N, PROF_FCC_STREAM);
+    hipLaunchKernelGGL((fcc_big_gemm_asm<EXPOP>), dim3((unsigned)d.W), dim3(256), shmem, s, (const float4*)pack, (const float4*)op, pmax, part, d);
+    prof_end(s);
+    W2L_LAUNCH_CHECK();
+    return W2L_OK;
+  }
   if (d.NB == 1 && d.RT == 2 && d.abl) {  // timing ablations of the probe tool (results are garbage)
     const size_t shmem = (size_t)4 * 1 * 2 * 16 * 64 * sizeof(float);
     prof_begin(s, 4.0 * d.N * (double)d.N + 8.0 * d.B * (double)d.N, PROF_FCC_STREAM);

@@ -392,9 +392,10 @@ __device__ __forceinline__ void gemm128_mainloop(const AOp& aop, const BOp& bop,
 }
 
 // epilogue. C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-__device__ __forceinline__ void gemm128_epilogue(const GemmOut& out, int m0, int n0, const f32x16 (&acc)[2][2]) {
+__device__ __forceinline__ void gemm128_epilogue(const GemmOut& out, int m0, int n0, const f32x16 (&acc)[2][2],
+                                                 int waveOverride = -1) {
   const int EPI = out.epi;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = waveOverride >= 0 ? waveOverride : (int)(threadIdx.x >> 6);
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
@@ -469,10 +470,13 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(AOp aop, BOp bop, GemmO
   }
 }
 
-// one workgroup per stream-K tile: add the partial slabs in range order, then the epilogue
+// one WAVEFRONT per quadrant of a stream-K tile (grid = 4 x skTiles workgroups of 64 threads: four times the
+// waves of the one-workgroup-per-tile version, the kernel is latency-bound on the slab reads): add the
+// partial slabs in range order, then the epilogue
 template <int kUnused>
-__global__ __launch_bounds__(256) void gemm128_fixup(GemmOut out, SkPlan plan) {
-  const int t = blockIdx.x;  // index inside the stream-K region
+__global__ __launch_bounds__(64) void gemm128_fixup(GemmOut out, SkPlan plan) {
+  const int t = blockIdx.x >> 2;  // index inside the stream-K region
+  const int wave = blockIdx.x & 3, lane = threadIdx.x;
   const long long tb = (long long)t * plan.kTiles, te = tb + plan.kTiles;
   const long long I = (long long)plan.skTiles * plan.kTiles;
   int s = (int)(tb * plan.skBlocks / I);
@@ -486,7 +490,6 @@ __global__ __launch_bounds__(256) void gemm128_fixup(GemmOut out, SkPlan plan) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (; s < plan.skBlocks && sk_begin(plan, s) < te; ++s) {
     const long long b0 = sk_begin(plan, s);
     if (sk_begin(plan, s + 1) <= tb) continue;
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(256) void gemm128_fixup(GemmOut out, SkPlan plan) {
   const int tile = plan.dpTiles + t;
   int bx, by;
   sk_tile_xy(plan, tile, bx, by);
-  gemm128_epilogue(out, bx * 128, by * 128, acc);
+  gemm128_epilogue(out, bx * 128, by * 128, acc, wave);
 }
 
 // Skinny-N variant for small output widths (TDS time convolutions, C = 10..18):
@@ -627,7 +630,7 @@ inline int launch128(const AOp& a, const BOp& b, GemmOut o, int epi, int splitk,
   o.epi = epi;
   prof_begin(s, 2.0 * o.M * (double)o.N * o.K);
   hipLaunchKernelGGL((gemm128_kernel<AOp, BOp>), grid, block, shmem, s, a, b, o, plan);
-  if (plan.skBlocks > 0) hipLaunchKernelGGL(gemm128_fixup<0>, dim3((unsigned)plan.skTiles), block, 0, s, o, plan);
+  if (plan.skBlocks > 0) hipLaunchKernelGGL(gemm128_fixup<0>, dim3((unsigned)plan.skTiles * 4), dim3(64), 0, s, o, plan);
   prof_end(s);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
