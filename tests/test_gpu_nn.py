@@ -112,6 +112,36 @@ def test_gemm_lds_dma_path(M, N, K, akc, bkc):
     assert rel(got, np.maximum(want, 0)) < TOL
 
 
+@pytest.mark.parametrize("M,N,K", [(4, 4, 32), (260, 388, 96), (1028, 2052, 1440), (6016, 4320, 1440), (640, 136, 24000),
+                                    (24000, 800, 2400)])
+@pytest.mark.parametrize("akc,bkc", [(True, False), (True, True), (False, False), (False, True)])
+def test_gemm_three_stage_256x128(M, N, K, akc, bkc):
+    """the 256x128 three-stage kernel (counted vmcnt, raw barriers) forced on every eligible shape
+    (W2L_GEMM_P3=2): float64 product, determinism, bias + ReLU, and agreement with the 128x128 kernel"""
+    import os
+    from wav2letter_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5 * M + 3 * N + K)
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(K, N, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    want = (A.double() @ Bm.double() + bias.double()).numpy()
+    Ad = (A if akc else A.T.contiguous()).cuda()
+    Bd = (Bm.T.contiguous() if bkc else Bm).cuda()
+    os.environ["W2L_GEMM_P3"] = "2"
+    try:
+        got = ops.gemm(Ad, Bd, akc, bkc, bias.cuda())
+        got2 = ops.gemm(Ad, Bd, akc, bkc, bias.cuda())
+        gotr = ops.gemm(Ad, Bd, akc, bkc, bias.cuda(), relu=True)
+        os.environ["W2L_GEMM_P3"] = "0"
+        old = ops.gemm(Ad, Bd, akc, bkc, bias.cuda())
+    finally:
+        os.environ.pop("W2L_GEMM_P3")
+    assert rel(got, want) < TOL
+    assert torch.equal(got, got2)
+    assert rel(gotr, np.maximum(want, 0)) < TOL
+    assert rel(got, old.cpu().numpy()) < 1e-5
+
+
 def test_gemm_asymmetric_identity():
     """A = I with an asymmetric B catches row/col swaps in the C write (guide G9)"""
     from wav2letter_amd import ops

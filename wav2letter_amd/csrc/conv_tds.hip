@@ -46,6 +46,7 @@ struct TdsConvP {
   int K, Kp, FS, NF;
   int relu, accum, flip;
   int CinW, CoutW;
+  int abl;  // timing-only ablations of the probe tool (W2L_TDS_ABL): 1 = no K loop, 2 = no slab staging, 4 = no output
 };
 
 __device__ __forceinline__ void tds_load_slab(const TdsConvP& p, float* slab, int b, int tIn0, int h0, int nf) {
@@ -285,19 +286,19 @@ __global__ __launch_bounds__(256) void tds_conv_fwd_k(TdsConvP p) {
 template <int NT, int R>
 __global__ __launch_bounds__(256, 2) void tds_conv_fwd2_k(TdsConvP p, int nTiles, int tBlocks, int hBlocks) {
   constexpr int BT = 4 * R;
-  constexpr int CP = 16 * NT;  // weight rows are zero-padded to whole MFMA column tiles: no per-lane guard in the K loop
+  const int CP = p.Cout;  // weight row stride; lanes past Cout re-read column Cout-1 (their MFMA columns are never stored)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int slabFloats = max(p.NF * p.FS, BT * kTdsBH * p.Cout);
   float* slab = lds;
   float* wS = slab + ((slabFloats + 3) & ~3);
-  int* koff = (int*)(wS + p.Kp * CP);
+  int* koff = (int*)(wS + ((p.Kp * CP + 3) & ~3));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   // ---- once per workgroup: weights, koff, pad zeroing, piece descriptors
   tds_batched_copy1<8>(p.Kp * CP,
       [&](int e) {
         const int kk = e / CP, co = e - kk * CP;
-        const bool ok = kk < p.K && co < p.Cout;
+        const bool ok = kk < p.K;
         size_t src = 0;
         if (ok) {
           if (!p.flip) {
@@ -352,12 +353,14 @@ __global__ __launch_bounds__(256, 2) void tds_conv_fwd2_k(TdsConvP p, int nTiles
     const int hb = tile % hBlocks, tb = (tile / hBlocks) % tBlocks, b = tile / (hBlocks * tBlocks);
     const int h0 = hb * kTdsBH, t0 = tb * BT;
     __syncthreads();  // the previous tile's output has been read out of the slab region
+    if (!(p.abl & 2)) {
 #pragma unroll
-    for (int v = 0; v < kTdsMaxXV; ++v)
-      if (xf[v] >= 0) *(float4*)(slab + xf[v] * p.FS + xo[v]) = xr[v];
+      for (int v = 0; v < kTdsMaxXV; ++v)
+        if (xf[v] >= 0) *(float4*)(slab + xf[v] * p.FS + xo[v]) = xr[v];
+    }
     __syncthreads();
     const int nxt = tile + gridDim.x;
-    fetch(nxt < nTiles ? nxt : tile);  // in flight behind this tile's MFMAs and output
+    if (!(p.abl & 2)) fetch(nxt < nTiles ? nxt : tile);  // in flight behind this tile's MFMAs and output
 
     f32x4 acc[R][NT];
 #pragma unroll
@@ -369,7 +372,10 @@ __global__ __launch_bounds__(256, 2) void tds_conv_fwd2_k(TdsConvP p, int nTiles
     // K loop, software-pipelined by hand: the table entry of step kq+2 and the fragments of step kq+1 are
     // read from LDS while the MFMAs of step kq run (hipcc left "read koff -> wait -> 8 reads -> wait -> 8 MFMA"
     // in sequence: ~200 exposed LDS cycles per 256 MFMA cycles)
-    const float* wl = wS + lq * CP + i;
+    int wcol[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wcol[nt] = 16 * nt + i < p.Cout ? 16 * nt + i : p.Cout - 1;
+    const float* wl = wS + lq * CP;
     int ko1 = koff[lq + (nk > 1 ? 4 : 0)];
     float aC[R], bC[NT];
     {
@@ -377,16 +383,16 @@ __global__ __launch_bounds__(256, 2) void tds_conv_fwd2_k(TdsConvP p, int nTiles
 #pragma unroll
       for (int r = 0; r < R; ++r) aC[r] = sl[r * rstep + ko0];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bC[nt] = wl[16 * nt];
+      for (int nt = 0; nt < NT; ++nt) bC[nt] = wl[wcol[nt]];
     }
-    for (int kq = 0; kq < nk; ++kq) {
+    for (int kq = 0; kq < ((p.abl & 1) ? 0 : nk); ++kq) {
       const int k1 = kq + 1 < nk ? kq + 1 : nk - 1, k2 = kq + 2 < nk ? kq + 2 : nk - 1;
       const int ko2 = koff[4 * k2 + lq];
       float aN[R], bN[NT];
 #pragma unroll
       for (int r = 0; r < R; ++r) aN[r] = sl[r * rstep + ko1];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bN[nt] = wl[4 * k1 * CP + 16 * nt];
+      for (int nt = 0; nt < NT; ++nt) bN[nt] = wl[4 * k1 * CP + wcol[nt]];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int r = 0; r < R; ++r)
@@ -420,6 +426,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_fwd2_k(TdsConvP p, int nTiles
     __syncthreads();
     int tc = p.Tout - t0;
     if (tc > BT) tc = BT;
+    if (p.abl & 4) tc = 0;
     const size_t gBase = (((size_t)b * p.Tout + t0) * p.H + h0) * p.Cout;
     tds_batched_copy4<8>(tc * rq,
         [&](int e) {
@@ -709,7 +716,7 @@ static size_t fwd2_lds_bytes(const TdsConvP& p, int bt) {
   const size_t outS = (size_t)bt * kTdsBH * p.Cout;
   if (outS > slab) slab = outS;
   slab = (slab + 3) & ~(size_t)3;
-  const size_t ws = (size_t)p.Kp * (p.Cout <= 16 ? 16 : 32);  // weight rows padded to whole MFMA column tiles
+  const size_t ws = ((size_t)p.Kp * p.Cout + 3) & ~(size_t)3;
   return (slab + ws + p.Kp) * sizeof(float);
 }
 
@@ -727,8 +734,10 @@ static int launch_fwd2_t(const TdsConvP& p, size_t shmem, hipStream_t s) {
 }
 
 // persistent register-prefetching kernel when the geometry allows it; `pIn` was built for 32-frame tiles
-static bool try_launch_fwd2(const TdsConvP& pIn, hipStream_t s, int* status) {
+static bool try_launch_fwd2(const TdsConvP& pIn0, hipStream_t s, int* status) {
   if (getenv("W2L_TDS_FWD_V1")) return false;
+  TdsConvP pIn = pIn0;
+  { const char* e = getenv("W2L_TDS_ABL"); pIn.abl = e ? atoi(e) : 0; }
   if (pIn.H % kTdsBH || ((pIn.H * pIn.Cin) & 3) || ((pIn.H * pIn.Cout) & 3) || ((kTdsBH * pIn.Cin) & 3) || ((kTdsBH * pIn.Cout) & 3)) return false;
   if ((((uintptr_t)pIn.x | (uintptr_t)pIn.y | (uintptr_t)pIn.add) & 15) != 0) return false;
   for (int bt = 32; bt >= 16; bt >>= 1) {

@@ -25,6 +25,7 @@
 
 #include "gemm.hpp"
 #include "gemm_glds.hpp"
+#include "gemm_p3.hpp"
 
 namespace w2l {
 
@@ -58,6 +59,11 @@ float* sk_scratch(hipStream_t s, size_t bytes) {
 static bool glds_enabled() {
   const char* e = getenv("W2L_GEMM_GLDS");
   return !(e && e[0] == '0');
+}
+
+static int p3_mode() {
+  const char* e = getenv("W2L_GEMM_P3");
+  return e ? atoi(e) : 1;
 }
 
 static inline bool glds_ok(const float* p, int ld, int extent) {
@@ -105,6 +111,13 @@ int gemm_f32(const float* A, int lda, int a_kcontig, const float* B, int ldb, in
     const unsigned long long ab = 4ull * (a_kcontig ? (unsigned long long)(M - 1) * lda + K : (unsigned long long)(K - 1) * lda + M);
     const unsigned long long bb = 4ull * (b_kcontig ? (unsigned long long)(N - 1) * ldb + K : (unsigned long long)(K - 1) * ldb + N);
     GOp ga{A, lda, M, ab < 0x7fffffffull ? (unsigned)ab : 0u}, gb{B, ldb, N, bb < 0x7fffffffull ? (unsigned)bb : 0u};
+    // 256x128 three-stage kernel unless its taller tile wastes more than 3 % extra padded area
+    // (W2L_GEMM_P3: 0 = never, 2 = whenever eligible)
+    const int p3 = p3_mode();
+    if (p3 && ga.bytes && gb.bytes) {
+      const double pad256 = (double)((M + 255) / 256 * 256), pad128 = (double)((M + 127) / 128 * 128);
+      if (p3 == 2 || pad256 <= 1.03 * pad128) return launch256(ga, a_kcontig != 0, gb, b_kcontig != 0, o, epi, s);
+    }
     return launch128g(ga, a_kcontig != 0, gb, b_kcontig != 0, o, epi, s);
   }
   if (a_kcontig) {
