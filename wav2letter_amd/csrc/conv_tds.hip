@@ -369,41 +369,56 @@ __global__ __launch_bounds__(256, 2) void tds_conv_fwd2_k(TdsConvP p, int nTiles
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[r][nt][q] = 0.f;
-    // K loop, software-pipelined by hand: the table entry of step kq+2 and the fragments of step kq+1 are
-    // read from LDS while the MFMAs of step kq run (hipcc left "read koff -> wait -> 8 reads -> wait -> 8 MFMA"
-    // in sequence: ~200 exposed LDS cycles per 256 MFMA cycles)
+    // K loop, hand-scheduled: two fragment register sets in ping-pong and ONE LDS read slotted behind every
+    // MFMA, so the reads of step kq+1 issue while the matrix pipe works on step kq.  (hipcc's own schedule --
+    // all reads, wait, all MFMAs -- left the loop at 57 % of its MFMA-bound time even with staging and output
+    // ablated: a wave issues in order, and a block of 11 ds_reads in front of 8 MFMAs is ~100 cycles in which
+    // its MFMA queue is empty; profiles/r01_run13_conv_fwd_ablation.log.)
     int wcol[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) wcol[nt] = 16 * nt + i < p.Cout ? 16 * nt + i : p.Cout - 1;
     const float* wl = wS + lq * CP;
-    int ko1 = koff[lq + (nk > 1 ? 4 : 0)];
-    float aC[R], bC[NT];
+    const int nkLoop = (p.abl & 1) ? 0 : nk;
+    float aA[R], bA[NT], aB[R], bB[NT];
+    int koN = koff[lq + (nk > 1 ? 4 : 0)];   // table entry of step 1
     {
       const int ko0 = koff[lq];
 #pragma unroll
-      for (int r = 0; r < R; ++r) aC[r] = sl[r * rstep + ko0];
+      for (int r = 0; r < R; ++r) aA[r] = sl[r * rstep + ko0];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bC[nt] = wl[wcol[nt]];
+      for (int nt = 0; nt < NT; ++nt) bA[nt] = wl[wcol[nt]];
     }
-    for (int kq = 0; kq < ((p.abl & 1) ? 0 : nk); ++kq) {
-      const int k1 = kq + 1 < nk ? kq + 1 : nk - 1, k2 = kq + 2 < nk ? kq + 2 : nk - 1;
-      const int ko2 = koff[4 * k2 + lq];
-      float aN[R], bN[NT];
+    for (int kq = 0; kq < nkLoop; kq += 2) {
+      // ---- step kq on set A; set B <- step kq+1 (clamped: a step past the end re-reads the last one and is not multiplied)
+      const int k1 = kq + 1 < nk ? kq + 1 : nk - 1, k2 = kq + 2 < nk ? kq + 2 : nk - 1, k3 = kq + 3 < nk ? kq + 3 : nk - 1;
+      const int koB = koN;
+      int koA2 = 0;
 #pragma unroll
-      for (int r = 0; r < R; ++r) aN[r] = sl[r * rstep + ko1];
+      for (int r = 0; r < R; ++r) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bN[nt] = wl[4 * k1 * CP + wcol[nt]];
-      __builtin_amdgcn_sched_barrier(0);
+        for (int nt = 0; nt < NT; ++nt) acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[r], bA[nt], acc[r][nt], 0, 0, 0);
+        aB[r] = sl[r * rstep + koB];
+        if (r == 0) koA2 = koff[4 * k2 + lq];
+        if (r == 1) {
 #pragma unroll
-      for (int r = 0; r < R; ++r)
+          for (int nt = 0; nt < NT; ++nt) bB[nt] = wl[4 * k1 * CP + wcol[nt]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (kq + 1 >= nk) break;
+      // ---- step kq+1 on set B; set A <- step kq+2
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aC[r], bC[nt], acc[r][nt], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int r = 0; r < R; ++r) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) aC[r] = aN[r];
+        for (int nt = 0; nt < NT; ++nt) acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aB[r], bB[nt], acc[r][nt], 0, 0, 0);
+        aA[r] = sl[r * rstep + koA2];
+        if (r == 0) koN = koff[4 * k3 + lq];
+        if (r == 1) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bC[nt] = bN[nt];
-      ko1 = ko2;
+          for (int nt = 0; nt < NT; ++nt) bA[nt] = wl[4 * k2 * CP + wcol[nt]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     __syncthreads();  // all fragment reads done: the slab region becomes the output stage
 

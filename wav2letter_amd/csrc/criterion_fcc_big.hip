@@ -61,6 +61,7 @@ struct BigDims {
   int P;    // bound on the workers (= partial slabs) that share one row group
   int ring; // 1: three operand register sets in a ring, 0: two in ping-pong (W2L_FCC_RING, A/B runs)
   int asmv; // 1: hand-counted asm-load kernel (W2L_FCC_ASM)
+  int dma;  // 1: LDS-DMA ring kernel (W2L_FCC_DMA)
   int abl;  // W2L_FCC_ABL: timing-only ablations 1 = no MFMA, 2 = no E-operand traffic; 4 = nontemporal loads of the
             // transition stream (results stay correct)
 };
@@ -99,6 +100,7 @@ inline BigDims big_dims(int B, int T, int N) {
   { const char* e = getenv("W2L_FCC_RING"); d.ring = e ? atoi(e) : 0; }
   { const char* e = getenv("W2L_FCC_ABL"); d.abl = e ? atoi(e) : 0; }
   { const char* e = getenv("W2L_FCC_ASM"); d.asmv = e ? atoi(e) : 0; }
+  { const char* e = getenv("W2L_FCC_DMA"); d.dma = e ? atoi(e) : 0; }
   d.Np = (N + 32 * d.RT - 1) / (32 * d.RT) * (32 * d.RT);
   d.G = d.Np / (32 * d.RT);
   // The step is cut into U = G * nS stage-units (64 rows x 32 k) in row-group-major order and dealt
@@ -518,6 +520,127 @@ __global__ __launch_bounds__(256, 2) void fcc_big_gemm_asm(const float4* __restr
 }
 #undef W2L_GLOAD
 
+
+// ------------------------------------------------------------------ kernel 1, LDS-DMA ring variant (B <= 32)
+// Same partition, packing and arithmetic as fcc_big_gemm<1, 2>; the operand stream goes global -> LDS by
+// buffer_load_dwordx4 ... lds (no VGPR destination, so nothing for hipcc's s_waitcnt placement to drain) into
+// a WAVE-PRIVATE ring of three stages of 2 chunks (6 KiB per stage: a0, a1, e), read back with lane-linear
+// ds_read_b128 (the pack order IS the fragment order).  The wave issues stage s+2, waits with a counted
+// vmcnt(12) until stage s has landed (its own covering vmcnt is all that orders a ds_read behind its own
+// LDS-DMA), multiplies stage s.  No barrier in the loop; stages past the wave's range re-read its first
+// stage (an L2 hit) so that the count stays uniform.
+constexpr int kDmaU = 2;                         // chunks per stage
+constexpr int kDmaStageFloats = 3 * kDmaU * 256; // a0, a1, e pieces of 1 KiB
+constexpr int kDmaWaveFloats = 3 * kDmaStageFloats;
+
+template <bool EXPOP>
+__global__ __launch_bounds__(256, 2) void fcc_big_gemm_dma(const float4* __restrict__ pack, const float4* __restrict__ op,
+                                                           const float* __restrict__ pmax, float* __restrict__ part, BigDims d) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][3 stages][6 pieces][256 floats]; reused as `red`
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int NC = d.NC, Np = d.Np, Bp = d.Bp, B = d.B;
+  const int w = blockIdx.x;
+  int u0 = big_unit_begin(d, w);
+  const int u1 = big_unit_begin(d, w + 1);
+  const int nSd = NC / kDmaU;                    // DMA stages per row group (NC % 4 == 0)
+  const int ratio = kBigU / kDmaU;               // DMA stages per partition stage
+
+  float cb = 0.f;
+  if (EXPOP) {
+    const int b = lane & 31;
+    float m = 0.f;
+    if (b < B) {
+      m = -INFINITY;
+#pragma unroll
+      for (int p = 0; p < kBigParts; ++p) m = fmaxf(m, pmax[(size_t)b * kBigParts + p]);
+    }
+    cb = m;
+  }
+  typedef __attribute__((address_space(3))) void* lp_t;
+  const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)pack, 0, (int)((size_t)Np * d.Kp * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)op, 0, (int)((size_t)Bp * d.Kp * 4), 0x00020000);
+  float* ring = lds + wave * kDmaWaveFloats;
+  const int voff = lane * 16;
+
+  while (u0 < u1) {
+    const int g = u0 / d.nS, sb = u0 - g * d.nS;
+    int len = d.nS - sb;
+    if (len > u1 - u0) len = u1 - u0;
+    // this wave's range in DMA stages
+    const int s0 = (sb + (int)((long long)len * wave / 4)) * ratio, s1 = (sb + (int)((long long)len * (wave + 1) / 4)) * ratio;
+    const int piece = w - big_worker_of(d, g * d.nS);
+    (void)nSd;
+    f32x16 acc[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
+    const uint32_t t0 = (uint32_t)(2 * g) * (uint32_t)NC, t1 = t0 + (uint32_t)NC;  // chunk index bases of the two row tiles
+
+    auto issue = [&](int st, int slot) {  // 6 pieces of DMA stage st into ring slot
+      float* base = ring + slot * kDmaStageFloats;
+#pragma unroll
+      for (int u = 0; u < kDmaU; ++u) {
+        const uint32_t c = (uint32_t)st * kDmaU + u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lp_t)(base + (0 * kDmaU + u) * 256), 16, voff, (int)((t0 + c) * 1024u), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lp_t)(base + (1 * kDmaU + u) * 256), 16, voff, (int)((t1 + c) * 1024u), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(re, (lp_t)(base + (2 * kDmaU + u) * 256), 16, voff, (int)(c * 1024u), 0, 0);
+      }
+    };
+    if (s0 < s1) {
+      issue(s0, 0);
+      issue(s0 + 1 < s1 ? s0 + 1 : s0, 1);
+      int slot = 0;
+      for (int st = s0; st < s1; ++st) {
+        const int sn = st + 2 < s1 ? st + 2 : s0;   // past the range: harmless re-read of the first stage
+        const int slotN = slot >= 1 ? slot - 1 : 2;  // (slot + 2) % 3
+        issue(sn, slotN);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // stages st+1, st+2 (12 pieces) may be outstanding: stage st has landed
+        const float* base = ring + slot * kDmaStageFloats + lane * 4;
+#pragma unroll
+        for (int u = 0; u < kDmaU; ++u) {
+          const f32x4 a0 = *(const f32x4*)(base + (0 * kDmaU + u) * 256);
+          const f32x4 a1 = *(const f32x4*)(base + (1 * kDmaU + u) * 256);
+          const f32x4 e4 = *(const f32x4*)(base + (2 * kDmaU + u) * 256);
+          float ev[4] = {e4[0], e4[1], e4[2], e4[3]};
+          if (EXPOP) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ev[q] = __expf(ev[q] - cb);  // padding holds -inf -> 0
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ev[q], a0[q], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ev[q], a1[q], acc[1], 0, 0, 0);
+          }
+        }
+        slot = slot == 2 ? 0 : slot + 1;
+      }
+    }
+    // the ring becomes the reduction buffer: every wave's LDS-DMA must have landed and its reads be done
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* red = lds;
+    constexpr int NR = 32;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((wave * NR) + h * 16 + r) * 64 + lane] = acc[h][r];
+    __syncthreads();
+    float* dst = part + (size_t)piece * Bp * Np;
+    for (int o = threadIdx.x; o < NR * 64; o += 256) {
+      const float v = (red[o] + red[NR * 64 + o]) + (red[2 * NR * 64 + o] + red[3 * NR * 64 + o]);
+      const int l = o & 63, rr = o >> 6;
+      const int r = rr & 15, h = rr >> 4;
+      const int b = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+      const int i = 64 * g + 32 * h + (l & 31);
+      dst[(size_t)b * Np + i] = v;
+    }
+    u0 += len;
+    __syncthreads();  // `red` (= the rings) is reused by the next segment
+  }
+}
+
 // ------------------------------------------------------------------ block reductions
 template <int THREADS>
 __device__ __forceinline__ float block_max(float v, float* sm) {
@@ -740,6 +863,19 @@ static int launch_big_gemm(const BigDims& d, const float* pack, const float* op,
 }
 template <bool EXPOP>
 static int big_gemm(const BigDims& d, const float* pack, const float* op, const float* pmax, float* part, hipStream_t s) {
+  if (d.NB == 1 && d.RT == 2 && d.dma && !d.abl && (size_t)d.Np * d.Kp * 4 < 0x7fffffffull) {
+    const size_t shmem = (size_t)4 * kDmaWaveFloats * sizeof(float);  // 72 KiB (>= the 32 KiB reduction buffer)
+    static bool attr[2] = {false, false};
+    if (!attr[EXPOP]) {
+      W2L_HIP_CHECK(hipFuncSetAttribute((const void*)fcc_big_gemm_dma<EXPOP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+      attr[EXPOP] = true;
+    }
+    prof_begin(s, 4.0 * d.N * (double)d.N + 8.0 * d.B * (double)d.N, PROF_FCC_STREAM);
+    hipLaunchKernelGGL((fcc_big_gemm_dma<EXPOP>), dim3((unsigned)d.W), dim3(256), shmem, s, (const float4*)pack, (const float4*)op, pmax, part, d);
+    prof_end(s);
+    W2L_LAUNCH_CHECK();
+    return W2L_OK;
+  }
   if (d.NB == 1 && d.RT == 2 && d.asmv && !d.abl) {
     const size_t shmem = (size_t)4 * 32 * 64 * sizeof(float);
     prof_begin(s, 4.0 * d.N * (double)d.N + 8.0 * d.B * (double)d.N, PROF_FCC_STREAM);

@@ -63,7 +63,7 @@ static bool glds_enabled() {
 
 static int p3_mode() {
   const char* e = getenv("W2L_GEMM_P3");
-  return e ? atoi(e) : 1;
+  return e ? atoi(e) : 0;
 }
 
 static inline bool glds_ok(const float* p, int ld, int extent) {
@@ -111,8 +111,9 @@ int gemm_f32(const float* A, int lda, int a_kcontig, const float* B, int ldb, in
     const unsigned long long ab = 4ull * (a_kcontig ? (unsigned long long)(M - 1) * lda + K : (unsigned long long)(K - 1) * lda + M);
     const unsigned long long bb = 4ull * (b_kcontig ? (unsigned long long)(N - 1) * ldb + K : (unsigned long long)(K - 1) * ldb + N);
     GOp ga{A, lda, M, ab < 0x7fffffffull ? (unsigned)ab : 0u}, gb{B, ldb, N, bb < 0x7fffffffull ? (unsigned)bb : 0u};
-    // 256x128 three-stage kernel unless its taller tile wastes more than 3 % extra padded area
-    // (W2L_GEMM_P3: 0 = never, 2 = whenever eligible)
+    // The 256x128 three-stage kernel (gemm_p3.hpp) is correct but measured SLOWER than the 128x128 two-stage
+    // kernel on MI355X (4096^3: 131 vs 143 TF/s; TDS fc shapes -5..8 %, profiles/r01_run13_gemm_256x128_3stage_ab.log):
+    // kept for A/B work, off by default.  W2L_GEMM_P3: 1 = by padded-area rule, 2 = whenever eligible.
     const int p3 = p3_mode();
     if (p3 && ga.bytes && gb.bytes) {
       const double pad256 = (double)((M + 255) / 256 * 256), pad128 = (double)((M + 127) / 128 * 128);
