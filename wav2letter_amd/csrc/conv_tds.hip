@@ -46,7 +46,7 @@ struct TdsConvP {
   int K, Kp, FS, NF;
   int relu, accum, flip;
   int CinW, CoutW;
-  int abl;  // timing-only ablations of the probe tool (W2L_TDS_ABL): 1 = no K loop, 2 = no slab staging, 4 = no output
+  int abl;  // timing-only ablations of the probe tool (W2L_TDS_ABL): 1 = no K loop, 2 = no slab staging, 4 = no output, 8 = no A-fragment reads in the K loop
 };
 
 __device__ __forceinline__ void tds_load_slab(const TdsConvP& p, float* slab, int b, int tIn0, int h0, int nf) {
@@ -347,6 +347,10 @@ __global__ __launch_bounds__(256, 2) void tds_conv_fwd2_k(TdsConvP p, int nTiles
   const size_t gRow = (size_t)p.H * p.Cout;
   const int rowLen = kTdsBH * p.Cout, rq = rowLen >> 2;
 
+  float biasv[NT];  // once per workgroup: a load per tile would expose a global round trip in every tile's epilogue
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) biasv[nt] = (p.bias && 16 * nt + i < p.Cout) ? p.bias[16 * nt + i] : 0.f;
+
   int tile = blockIdx.x;
   if (tile < nTiles) fetch(tile);
   for (; tile < nTiles; tile += gridDim.x) {
@@ -387,6 +391,10 @@ __global__ __launch_bounds__(256, 2) void tds_conv_fwd2_k(TdsConvP p, int nTiles
       for (int r = 0; r < R; ++r) aA[r] = sl[r * rstep + ko0];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bA[nt] = wl[wcol[nt]];
+#pragma unroll
+      for (int r = 0; r < R; ++r) aB[r] = aA[r];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bB[nt] = bA[nt];
     }
     for (int kq = 0; kq < nkLoop; kq += 2) {
       // ---- step kq on set A; set B <- step kq+1 (clamped: a step past the end re-reads the last one and is not multiplied)
@@ -397,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_fwd2_k(TdsConvP p, int nTiles
       for (int r = 0; r < R; ++r) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[r], bA[nt], acc[r][nt], 0, 0, 0);
-        aB[r] = sl[r * rstep + koB];
+        if (!(p.abl & 8)) aB[r] = sl[r * rstep + koB];
         if (r == 0) koA2 = koff[4 * k2 + lq];
         if (r == 1) {
 #pragma unroll
@@ -411,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_fwd2_k(TdsConvP p, int nTiles
       for (int r = 0; r < R; ++r) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aB[r], bB[nt], acc[r][nt], 0, 0, 0);
-        aA[r] = sl[r * rstep + koA2];
+        if (!(p.abl & 8)) aA[r] = sl[r * rstep + koA2];
         if (r == 0) koN = koff[4 * k3 + lq];
         if (r == 1) {
 #pragma unroll
@@ -427,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_fwd2_k(TdsConvP p, int nTiles
     for (int nt = 0; nt < NT; ++nt) {
       const int co = 16 * nt + i;
       if (co < p.Cout) {
-        const float bv = p.bias ? p.bias[co] : 0.f;
+        const float bv = biasv[nt];
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll

@@ -61,7 +61,7 @@ struct BigDims {
   int P;    // bound on the workers (= partial slabs) that share one row group
   int ring; // 1: three operand register sets in a ring, 0: two in ping-pong (W2L_FCC_RING, A/B runs)
   int asmv; // 1: hand-counted asm-load kernel (W2L_FCC_ASM)
-  int dma;  // 1: LDS-DMA ring kernel (W2L_FCC_DMA)
+  int dma;  // W2L_FCC_DMA: 0 = register ping-pong kernel; 1..5 = LDS-DMA ring (chunks per stage x depth, nontemporal): 1 = 2x3, 2 = 1x6, 3 = 2x3 nt, 4 = 1x6 nt
   int abl;  // W2L_FCC_ABL: timing-only ablations 1 = no MFMA, 2 = no E-operand traffic; 4 = nontemporal loads of the
             // transition stream (results stay correct)
 };
@@ -100,7 +100,7 @@ inline BigDims big_dims(int B, int T, int N) {
   { const char* e = getenv("W2L_FCC_RING"); d.ring = e ? atoi(e) : 0; }
   { const char* e = getenv("W2L_FCC_ABL"); d.abl = e ? atoi(e) : 0; }
   { const char* e = getenv("W2L_FCC_ASM"); d.asmv = e ? atoi(e) : 0; }
-  { const char* e = getenv("W2L_FCC_DMA"); d.dma = e ? atoi(e) : 0; }
+  { const char* e = getenv("W2L_FCC_DMA"); d.dma = e ? atoi(e) : 1; }  // LDS-DMA ring is the default (0 = register ping-pong)
   d.Np = (N + 32 * d.RT - 1) / (32 * d.RT) * (32 * d.RT);
   d.G = d.Np / (32 * d.RT);
   // The step is cut into U = G * nS stage-units (64 rows x 32 k) in row-group-major order and dealt
@@ -529,11 +529,10 @@ __global__ __launch_bounds__(256, 2) void fcc_big_gemm_asm(const float4* __restr
 // vmcnt(12) until stage s has landed (its own covering vmcnt is all that orders a ds_read behind its own
 // LDS-DMA), multiplies stage s.  No barrier in the loop; stages past the wave's range re-read its first
 // stage (an L2 hit) so that the count stays uniform.
-constexpr int kDmaU = 2;                         // chunks per stage
-constexpr int kDmaStageFloats = 3 * kDmaU * 256; // a0, a1, e pieces of 1 KiB
-constexpr int kDmaWaveFloats = 3 * kDmaStageFloats;
+constexpr int kDmaWaveFloats = 3 * 2 * 256 * 3;  // ring of one wave: U x D = 6 chunks of (a0, a1, e) pieces = 18 KiB
 
-template <bool EXPOP>
+// U = chunks per stage, D = ring depth (U * D == 6), NT = nontemporal loads of the transition stream
+template <bool EXPOP, int kDmaU, int kDmaD, bool NT>
 __global__ __launch_bounds__(256, 2) void fcc_big_gemm_dma(const float4* __restrict__ pack, const float4* __restrict__ op,
                                                            const float* __restrict__ pmax, float* __restrict__ part, BigDims d) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][3 stages][6 pieces][256 floats]; reused as `red`
@@ -543,7 +542,8 @@ __global__ __launch_bounds__(256, 2) void fcc_big_gemm_dma(const float4* __restr
   const int w = blockIdx.x;
   int u0 = big_unit_begin(d, w);
   const int u1 = big_unit_begin(d, w + 1);
-  const int nSd = NC / kDmaU;                    // DMA stages per row group (NC % 4 == 0)
+  constexpr int kDmaStageFloats = 3 * kDmaU * 256;  // a0, a1, e pieces of 1 KiB
+  static_assert(kDmaU * kDmaD == 6 && kBigU % kDmaU == 0, "ring is 18 KiB per wave; DMA stages tile the partition stages");
   const int ratio = kBigU / kDmaU;               // DMA stages per partition stage
 
   float cb = 0.f;
@@ -570,7 +570,6 @@ __global__ __launch_bounds__(256, 2) void fcc_big_gemm_dma(const float4* __restr
     // this wave's range in DMA stages
     const int s0 = (sb + (int)((long long)len * wave / 4)) * ratio, s1 = (sb + (int)((long long)len * (wave + 1) / 4)) * ratio;
     const int piece = w - big_worker_of(d, g * d.nS);
-    (void)nSd;
     f32x16 acc[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -583,20 +582,21 @@ __global__ __launch_bounds__(256, 2) void fcc_big_gemm_dma(const float4* __restr
 #pragma unroll
       for (int u = 0; u < kDmaU; ++u) {
         const uint32_t c = (uint32_t)st * kDmaU + u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lp_t)(base + (0 * kDmaU + u) * 256), 16, voff, (int)((t0 + c) * 1024u), 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lp_t)(base + (1 * kDmaU + u) * 256), 16, voff, (int)((t1 + c) * 1024u), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lp_t)(base + (0 * kDmaU + u) * 256), 16, voff, (int)((t0 + c) * 1024u), 0, NT ? 2 : 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lp_t)(base + (1 * kDmaU + u) * 256), 16, voff, (int)((t1 + c) * 1024u), 0, NT ? 2 : 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(re, (lp_t)(base + (2 * kDmaU + u) * 256), 16, voff, (int)(c * 1024u), 0, 0);
       }
     };
     if (s0 < s1) {
-      issue(s0, 0);
-      issue(s0 + 1 < s1 ? s0 + 1 : s0, 1);
+#pragma unroll
+      for (int k = 0; k < kDmaD - 1; ++k) issue(s0 + k < s1 ? s0 + k : s0, k);
       int slot = 0;
       for (int st = s0; st < s1; ++st) {
-        const int sn = st + 2 < s1 ? st + 2 : s0;   // past the range: harmless re-read of the first stage
-        const int slotN = slot >= 1 ? slot - 1 : 2;  // (slot + 2) % 3
+        const int sn = st + kDmaD - 1 < s1 ? st + kDmaD - 1 : s0;   // past the range: harmless re-read of the first stage
+        const int slotN = slot >= 1 ? slot - 1 : kDmaD - 1;          // (slot + D - 1) % D
         issue(sn, slotN);
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // stages st+1, st+2 (12 pieces) may be outstanding: stage st has landed
+        // stages st+1 .. st+D-1 (3 U (D-1) pieces) may be outstanding: stage st has landed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * kDmaU * (kDmaD - 1)) : "memory");
         const float* base = ring + slot * kDmaStageFloats + lane * 4;
 #pragma unroll
         for (int u = 0; u < kDmaU; ++u) {
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256, 2) void fcc_big_gemm_dma(const float4* __restr
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ev[q], a1[q], acc[1], 0, 0, 0);
           }
         }
-        slot = slot == 2 ? 0 : slot + 1;
+        slot = slot == kDmaD - 1 ? 0 : slot + 1;
       }
     }
     // the ring becomes the reduction buffer: every wave's LDS-DMA must have landed and its reads be done
@@ -865,13 +865,25 @@ template <bool EXPOP>
 static int big_gemm(const BigDims& d, const float* pack, const float* op, const float* pmax, float* part, hipStream_t s) {
   if (d.NB == 1 && d.RT == 2 && d.dma && !d.abl && (size_t)d.Np * d.Kp * 4 < 0x7fffffffull) {
     const size_t shmem = (size_t)4 * kDmaWaveFloats * sizeof(float);  // 72 KiB (>= the 32 KiB reduction buffer)
-    static bool attr[2] = {false, false};
-    if (!attr[EXPOP]) {
-      W2L_HIP_CHECK(hipFuncSetAttribute((const void*)fcc_big_gemm_dma<EXPOP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-      attr[EXPOP] = true;
-    }
     prof_begin(s, 4.0 * d.N * (double)d.N + 8.0 * d.B * (double)d.N, PROF_FCC_STREAM);
-    hipLaunchKernelGGL((fcc_big_gemm_dma<EXPOP>), dim3((unsigned)d.W), dim3(256), shmem, s, (const float4*)pack, (const float4*)op, pmax, part, d);
+#define W2L_DMA_LAUNCH(U, D, NTF)                                                                                              \
+  do {                                                                                                                         \
+    static bool attr = false;                                                                                                  \
+    if (!attr) {                                                                                                               \
+      W2L_HIP_CHECK(hipFuncSetAttribute((const void*)fcc_big_gemm_dma<EXPOP, U, D, NTF>,                                       \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                              \
+      attr = true;                                                                                                             \
+    }                                                                                                                          \
+    hipLaunchKernelGGL((fcc_big_gemm_dma<EXPOP, U, D, NTF>), dim3((unsigned)d.W), dim3(256), shmem, s, (const float4*)pack,    \
+                       (const float4*)op, pmax, part, d);                                                                      \
+  } while (0)
+    switch (d.dma) {
+      case 2: W2L_DMA_LAUNCH(1, 6, false); break;
+      case 3: W2L_DMA_LAUNCH(2, 3, true); break;
+      case 4: W2L_DMA_LAUNCH(1, 6, true); break;
+      default: W2L_DMA_LAUNCH(2, 3, false); break;
+    }
+#undef W2L_DMA_LAUNCH
     prof_end(s);
     W2L_LAUNCH_CHECK();
     return W2L_OK;
