@@ -46,7 +46,7 @@ struct TdsConvP {
   int K, Kp, FS, NF;
   int relu, accum, flip;
   int CinW, CoutW;
-  int abl;  // timing-only ablations of the probe tool (W2L_TDS_ABL): 1 = no K loop, 2 = no slab staging, 4 = no output, 8 = no A-fragment reads in the K loop
+  int abl;  // timing-only ablations of the probe tool (W2L_TDS_ABL): 1 = no K loop, 2 = no slab staging, 4 = no output
 };
 
 __device__ __forceinline__ void tds_load_slab(const TdsConvP& p, float* slab, int b, int tIn0, int h0, int nf) {
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_fwd2_k(TdsConvP p, int nTiles
       for (int r = 0; r < R; ++r) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[r], bA[nt], acc[r][nt], 0, 0, 0);
-        if (!(p.abl & 8)) aB[r] = sl[r * rstep + koB];
+        aB[r] = sl[r * rstep + koB];
         if (r == 0) koA2 = koff[4 * k2 + lq];
         if (r == 1) {
 #pragma unroll
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_fwd2_k(TdsConvP p, int nTiles
       for (int r = 0; r < R; ++r) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aB[r], bB[nt], acc[r][nt], 0, 0, 0);
-        if (!(p.abl & 8)) aA[r] = sl[r * rstep + koA2];
+        aA[r] = sl[r * rstep + koA2];
         if (r == 0) koN = koff[4 * k3 + lq];
         if (r == 1) {
 #pragma unroll

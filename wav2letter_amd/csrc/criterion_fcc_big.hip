@@ -100,7 +100,9 @@ inline BigDims big_dims(int B, int T, int N) {
   { const char* e = getenv("W2L_FCC_RING"); d.ring = e ? atoi(e) : 0; }
   { const char* e = getenv("W2L_FCC_ABL"); d.abl = e ? atoi(e) : 0; }
   { const char* e = getenv("W2L_FCC_ASM"); d.asmv = e ? atoi(e) : 0; }
-  { const char* e = getenv("W2L_FCC_DMA"); d.dma = e ? atoi(e) : 1; }  // LDS-DMA ring is the default (0 = register ping-pong)
+  // LDS-DMA ring with a nontemporal transition stream is the default (0 = register ping-pong): measured on MI355X
+  // (profiles/r01_run16_fcc_dma_ring_variants.log) 2x3 85.5 us, 1x6 85.8, 2x3 nt 77.6, 1x6 nt 76.0, ping-pong 94.0
+  { const char* e = getenv("W2L_FCC_DMA"); d.dma = e ? atoi(e) : 4; }
   d.Np = (N + 32 * d.RT - 1) / (32 * d.RT) * (32 * d.RT);
   d.G = d.Np / (32 * d.RT);
   // The step is cut into U = G * nS stage-units (64 rows x 32 k) in row-group-major order and dealt
