@@ -283,7 +283,9 @@ __global__ __launch_bounds__(256) void tds_conv_fwd_k(TdsConvP p) {
 // descriptors) right before tile i is multiplied, then written to LDS after tile i's output has left it.
 // R = output frames per wave (8: 32-frame tiles; 4: 16-frame tiles when the 32-frame slab would not
 // leave room for two workgroups per CU).  Requires whole 16-row mel blocks and 16-byte aligned rows.
-template <int NT, int R>
+// CIN > 0: input channels known at compile time (stride 1): the slab frame stride is a constant, the R
+// fragment reads of a K step share ONE address VGPR and differ in their immediate offsets.
+template <int NT, int R, int CIN>
 __global__ __launch_bounds__(256, 2) void tds_conv_fwd2_k(TdsConvP p, int nTiles, int tBlocks, int hBlocks) {
   constexpr int BT = 4 * R;
   const int CP = p.Cout;  // weight row stride; lanes past Cout re-read column Cout-1 (their MFMA columns are never stored)
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_fwd2_k(TdsConvP p, int nTiles
   };
 
   const int i = lane & 15, lq = lane >> 4;
-  const int rstep = p.stride * p.FS;
+  const int rstep = CIN ? 16 * CIN + 4 : p.stride * p.FS;
   const int nk = p.Kp >> 2;
   const float* sl = slab + i * p.Cin + (wave * R * p.stride) * p.FS;
   const size_t gRow = (size_t)p.H * p.Cout;
@@ -396,7 +398,12 @@ __global__ __launch_bounds__(256, 2) void tds_conv_fwd2_k(TdsConvP p, int nTiles
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bB[nt] = bA[nt];
     }
+    // PMC (profiles/r01_run17_conv_fwd_sq_pmc.csv): 8.6 instructions per MFMA at 4 cycles of issue each against
+    // a 32-cycle MFMA -- the loop was instruction-issue bound (MFMA pipe 46 % busy).  Diet: immediate-offset
+    // fragment reads (CIN) and ONE lgkmcnt(0) per step instead of a counted wait in front of every MFMA (all of
+    // a step's operands were read during the previous step).
     for (int kq = 0; kq < nkLoop; kq += 2) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only (vmcnt / expcnt fields at their maxima)
       // ---- step kq on set A; set B <- step kq+1 (clamped: a step past the end re-reads the last one and is not multiplied)
       const int k1 = kq + 1 < nk ? kq + 1 : nk - 1, k2 = kq + 2 < nk ? kq + 2 : nk - 1, k3 = kq + 3 < nk ? kq + 3 : nk - 1;
       const int koB = koN;
@@ -414,6 +421,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_fwd2_k(TdsConvP p, int nTiles
         __builtin_amdgcn_sched_barrier(0);
       }
       if (kq + 1 >= nk) break;
+      __builtin_amdgcn_s_waitcnt(0xC07F);
       // ---- step kq+1 on set B; set A <- step kq+2
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -743,7 +751,7 @@ static size_t fwd2_lds_bytes(const TdsConvP& p, int bt) {
   return (slab + ws + p.Kp) * sizeof(float);
 }
 
-template <int NT, int R>
+template <int NT, int R, int CIN>
 static int launch_fwd2_t(const TdsConvP& p, size_t shmem, hipStream_t s) {
   constexpr int BT = 4 * R;
   const int tBlocks = (p.Tout + BT - 1) / BT, hBlocks = p.H / kTdsBH;
@@ -751,8 +759,8 @@ static int launch_fwd2_t(const TdsConvP& p, size_t shmem, hipStream_t s) {
   const int perCu = 2;  // 174-215 VGPRs: two waves per SIMD
   const int blocks = nTiles < 256 * perCu ? nTiles : 256 * perCu;
   if (shmem > 64 * 1024)
-    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_fwd2_k<NT, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL((tds_conv_fwd2_k<NT, R>), dim3((unsigned)blocks), dim3(256), shmem, s, p, nTiles, tBlocks, hBlocks);
+    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_fwd2_k<NT, R, CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL((tds_conv_fwd2_k<NT, R, CIN>), dim3((unsigned)blocks), dim3(256), shmem, s, p, nTiles, tBlocks, hBlocks);
   return W2L_OK;
 }
 
@@ -772,8 +780,14 @@ static bool try_launch_fwd2(const TdsConvP& pIn0, hipStream_t s, int* status) {
     const double flops = 2.0 * p.B * p.Tout * (double)p.H * p.K * p.Cout;
     prof_begin(s, flops, PROF_TDSCONV);
     int st;
-    if (p.Cout <= 16) st = bt == 32 ? launch_fwd2_t<1, 8>(p, shmem, s) : launch_fwd2_t<1, 4>(p, shmem, s);
-    else st = bt == 32 ? launch_fwd2_t<2, 8>(p, shmem, s) : launch_fwd2_t<2, 4>(p, shmem, s);
+    const int cin = p.stride == 1 ? p.Cin : 0;  // compile-time channel counts of the TDS-CTC recipe; anything else: runtime stride
+    if (p.Cout <= 16) {
+      if (bt == 32) st = cin == 10 ? launch_fwd2_t<1, 8, 10>(p, shmem, s) : cin == 14 ? launch_fwd2_t<1, 8, 14>(p, shmem, s) : launch_fwd2_t<1, 8, 0>(p, shmem, s);
+      else st = cin == 10 ? launch_fwd2_t<1, 4, 10>(p, shmem, s) : cin == 14 ? launch_fwd2_t<1, 4, 14>(p, shmem, s) : launch_fwd2_t<1, 4, 0>(p, shmem, s);
+    } else {
+      if (bt == 32) st = cin == 18 ? launch_fwd2_t<2, 8, 18>(p, shmem, s) : launch_fwd2_t<2, 8, 0>(p, shmem, s);
+      else st = cin == 18 ? launch_fwd2_t<2, 4, 18>(p, shmem, s) : launch_fwd2_t<2, 4, 0>(p, shmem, s);
+    }
     prof_end(s);
     if (st == W2L_OK && hipGetLastError() != hipSuccess) st = W2L_EHIP;
     *status = st;
