@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU session M: parity, conv probe, bench
 mkdir -p gpurun_out
-tag=${1:-r18}
+tag=${1:-r19}
 timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/${tag}_tests.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${tag}_tests.log
 tail -4 gpurun_out/${tag}_tests.log | cut -c1-200
 for a in 0 6 0; do

@@ -556,6 +556,62 @@ __global__ __launch_bounds__(256) void tds_conv_filter_k(TdsConvP p, const float
 }
 
 
+
+// Lean K loop of the backward-filter kernel for the TDS convolutions proper (C -> C channels, stride 1, both
+// compile-time): one chunk = 16 frames x 16 mel rows = 64 K steps of 4 positions.  The generic loop spent
+// ~10 instructions per MFMA (runtime row offsets, a wave-uniform branch and two selects per row tile, a guard
+// per column) against the 8 issue slots a 32-cycle MFMA allows; here every LDS read is `base VGPR + immediate`
+// (frame stride and channel count are constants), invalid rows / columns are NOT masked (they only feed
+// partial rows / columns the reduction never reads), the all-ones row of the bias gradient exists only in
+// the last row tile of the wave that owns it, and the row-tile count per wave NTW is a template parameter.
+template <int NT, int C, int NTW>
+__device__ __forceinline__ void tds_filter_kloop(const float* __restrict__ slab, const float* __restrict__ dyS,
+                                                 const int (&abase)[kTdsMaxTilesPerWave], const int (&dbase)[NT],
+                                                 bool ownsOne, bool oneLane, f32x4 (&acc)[kTdsMaxTilesPerWave][NT]) {
+  constexpr int FS = kTdsBH * C + 4;
+  float aA[NTW], bA[NT], aB[NTW], bB[NT];
+#pragma unroll
+  for (int tl = 0; tl < NTW; ++tl) aA[tl] = slab[abase[tl]];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bA[nt] = dyS[dbase[nt]];
+  if (ownsOne) aA[NTW - 1] = oneLane ? 1.f : aA[NTW - 1];
+#pragma unroll
+  for (int kq = 0; kq < kTdsBTF * kTdsBH / 4; kq += 2) {
+    // position m = 4 kq + lq: frame t = kq / 4, mel row 4 (kq % 4) + lq  (lq is inside abase / dbase)
+    constexpr int dummy = 0;
+    (void)dummy;
+    const int k1 = kq + 1, k2 = kq + 2 < 64 ? kq + 2 : 63;
+    const int aoff1 = (k1 >> 2) * FS + 4 * (k1 & 3) * C, doff1 = (16 * (k1 >> 2) + 4 * (k1 & 3)) * C;
+    const int aoff2 = (k2 >> 2) * FS + 4 * (k2 & 3) * C, doff2 = (16 * (k2 >> 2) + 4 * (k2 & 3)) * C;
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): set A was read during the previous step
+#pragma unroll
+    for (int tl = 0; tl < NTW; ++tl) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[tl][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[tl], bA[nt], acc[tl][nt], 0, 0, 0);
+      aB[tl] = slab[abase[tl] + aoff1];
+      if (tl == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bB[nt] = dyS[dbase[nt] + doff1];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ownsOne) aB[NTW - 1] = oneLane ? 1.f : aB[NTW - 1];
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll
+    for (int tl = 0; tl < NTW; ++tl) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[tl][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aB[tl], bB[nt], acc[tl][nt], 0, 0, 0);
+      aA[tl] = slab[abase[tl] + aoff2];
+      if (tl == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bA[nt] = dyS[dbase[nt] + doff2];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ownsOne) aA[NTW - 1] = oneLane ? 1.f : aA[NTW - 1];
+  }
+}
+
 // ---------------------------------------------------------------- backward-filter, pipelined
 // Same chunking / fragment scheme as tds_conv_filter_k, but the global -> LDS staging is built for
 // latency: every thread owns a FIXED set of float4 pieces of a chunk (slab pieces + dy pieces,
@@ -565,7 +621,7 @@ __global__ __launch_bounds__(256) void tds_conv_filter_k(TdsConvP p, const float
 // against 3 us of MFMA work).  Requires whole 16-row mel blocks (H % 16 == 0), 16-byte aligned rows.
 constexpr int kTdsMaxDV = 5;   // float4 dy pieces per thread
 
-template <int NT>
+template <int NT, int C>
 __global__ __launch_bounds__(256, 2) void tds_conv_filter2_k(TdsConvP p, const float* __restrict__ dy, float* __restrict__ partial,
                                                             int nChunks, int tBlocks, int hBlocks, int rowTiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -615,6 +671,18 @@ __global__ __launch_bounds__(256, 2) void tds_conv_filter2_k(TdsConvP p, const f
   // the 4-float pad of every slab frame is never overwritten: zero it once
   for (int f = tid; f < p.NF; f += 256) *(float4*)(slab + f * p.FS + kTdsBH * p.Cin) = make_float4(0.f, 0.f, 0.f, 0.f);
 
+  // lean-loop constants: fragment base offsets (floats) with the lane's lq folded in, tiles of this wave, and
+  // whether this wave's LAST tile carries the all-ones row (row K) of the bias gradient
+  int abase[kTdsMaxTilesPerWave], dbase[NT];
+#pragma unroll
+  for (int tl = 0; tl < kTdsMaxTilesPerWave; ++tl) abase[tl] = ko[tl] + lq * p.Cin;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) dbase[nt] = lq * p.Cout + (16 * nt + i < p.Cout ? 16 * nt + i : p.Cout - 1);
+  const int ntw = wave < rowTiles ? (rowTiles - wave + 3) / 4 : 0;
+  const bool ownsOne = ntw > 0 && (wave + 4 * (ntw - 1)) == p.K / 16;
+  const bool oneLane = i == (p.K & 15);
+  (void)abase; (void)dbase; (void)ownsOne; (void)oneLane;
+
   float4 xr[kTdsMaxXV], dr[kTdsMaxDV];
   auto fetch = [&](int chunk) {
     const int hb = chunk % hBlocks, tb = (chunk / hBlocks) % tBlocks, b = chunk / (hBlocks * tBlocks);
@@ -651,20 +719,30 @@ __global__ __launch_bounds__(256, 2) void tds_conv_filter2_k(TdsConvP p, const f
     __syncthreads();
     const int nxt = chunk + gridDim.x;
     fetch(nxt < nChunks ? nxt : chunk);  // in flight behind this chunk's MFMAs (last trip: harmless re-load)
+    if constexpr (C > 0) {
+      switch (ntw) {  // wave-uniform
+        case 3: tds_filter_kloop<NT, C, 3>(slab, dyS, abase, dbase, ownsOne, oneLane, acc); break;
+        case 4: tds_filter_kloop<NT, C, 4>(slab, dyS, abase, dbase, ownsOne, oneLane, acc); break;
+        case 5: tds_filter_kloop<NT, C, 5>(slab, dyS, abase, dbase, ownsOne, oneLane, acc); break;
+        case 6: tds_filter_kloop<NT, C, 6>(slab, dyS, abase, dbase, ownsOne, oneLane, acc); break;
+        default: break;  // (host guarantees 3..6 for the compile-time channel counts)
+      }
+    } else {
 #pragma unroll 4
-    for (int kq = 0; kq < kTdsBTF * kTdsBH / 4; ++kq) {
-      const int m = 4 * kq + lq;
-      const int rowoff = (m >> 4) * p.stride * p.FS + (m & 15) * p.Cin;
-      float bf[NT];
+      for (int kq = 0; kq < kTdsBTF * kTdsBH / 4; ++kq) {
+        const int m = 4 * kq + lq;
+        const int rowoff = (m >> 4) * p.stride * p.FS + (m & 15) * p.Cin;
+        float bf[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bf[nt] = (16 * nt + i < p.Cout) ? dyS[m * p.Cout + 16 * nt + i] : 0.f;
+        for (int nt = 0; nt < NT; ++nt) bf[nt] = (16 * nt + i < p.Cout) ? dyS[m * p.Cout + 16 * nt + i] : 0.f;
 #pragma unroll
-      for (int tl = 0; tl < kTdsMaxTilesPerWave; ++tl) {
-        if (wave + 4 * tl < rowTiles) {  // wave-uniform
-          float a = slab[rowoff + ko[tl]];
-          a = one[tl] ? 1.f : (val[tl] ? a : 0.f);
+        for (int tl = 0; tl < kTdsMaxTilesPerWave; ++tl) {
+          if (wave + 4 * tl < rowTiles) {  // wave-uniform
+            float a = slab[rowoff + ko[tl]];
+            a = one[tl] ? 1.f : (val[tl] ? a : 0.f);
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[tl][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[nt], acc[tl][nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) acc[tl][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[nt], acc[tl][nt], 0, 0, 0);
+          }
         }
       }
     }
@@ -861,13 +939,25 @@ int tds_conv_backward_filter(const w2l_conv_desc* d, const float* x, const float
                     (((uintptr_t)x | (uintptr_t)dy) & 15) == 0 && !getenv("W2L_TDS_FILTER_V1");
   prof_begin(s, flops, PROF_TDSCONV);
   if (fast) {
+#define W2L_FILTER2(NTv, Cv)                                                                                                    \
+  do {                                                                                                                          \
+    if (shmem > 64 * 1024)                                                                                                      \
+      W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_filter2_k<NTv, Cv>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        (int)shmem));                                                                           \
+    hipLaunchKernelGGL((tds_conv_filter2_k<NTv, Cv>), dim3((unsigned)blocks), dim3(256), shmem, s, p, dy, partial, nChunks,     \
+                       tBlocks, hBlocks, rowTiles);                                                                             \
+  } while (0)
+    // lean K loop for the TDS convolutions proper (C -> C, stride 1, 3..6 row tiles per wave)
+    const int cc = (d->Cin == d->Cout && d->stride == 1 && rowTiles >= 12 && !getenv("W2L_TDS_FILTER_GENERIC")) ? d->Cin : 0;
     if (NT == 1) {
-      if (shmem > 64 * 1024) W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_filter2_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-      hipLaunchKernelGGL(tds_conv_filter2_k<1>, dim3((unsigned)blocks), dim3(256), shmem, s, p, dy, partial, nChunks, tBlocks, hBlocks, rowTiles);
+      if (cc == 10) W2L_FILTER2(1, 10);
+      else if (cc == 14) W2L_FILTER2(1, 14);
+      else W2L_FILTER2(1, 0);
     } else {
-      if (shmem > 64 * 1024) W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_filter2_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-      hipLaunchKernelGGL(tds_conv_filter2_k<2>, dim3((unsigned)blocks), dim3(256), shmem, s, p, dy, partial, nChunks, tBlocks, hBlocks, rowTiles);
+      if (cc == 18) W2L_FILTER2(2, 18);
+      else W2L_FILTER2(2, 0);
     }
+#undef W2L_FILTER2
     hipLaunchKernelGGL(tds_conv_filter_reduce2_k, dim3((unsigned)(p.K + 1)), dim3(256), 0, s, partial, blocks, rowTiles * 16,
                        16 * NT, p.K, d->Cout, dw, dbias);
     prof_end(s);
