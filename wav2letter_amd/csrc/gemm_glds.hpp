@@ -127,7 +127,7 @@ __device__ __forceinline__ void g_frag(float (&f)[2][4], const float* tile, int 
 // instruction, then 16 global_store_dwordx4 per lane.  Bias / ReLU / mask / accumulate are applied on
 // the float4.  Requires a 16-byte aligned C and ldc % 4 == 0 (host-checked; `wide` false otherwise).
 __device__ __forceinline__ void gemm128g_epilogue_wide(const GemmOut& out, int m0, int n0, const f32x16 (&acc)[2][2],
-                                                       float* scratch) {
+                                                       float* scratch, const float (&bv)[4]) {
   const int EPI = out.epi;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -135,10 +135,21 @@ __device__ __forceinline__ void gemm128g_epilogue_wide(const GemmOut& out, int m
   float* sc = scratch + wave * 2048;       // [32 rows][64 cols] of this wave
   const int c4 = 4 * (lane & 15), rq = lane >> 4;
   const int n = n0 + wn + c4;
-  float bv[4] = {0.f, 0.f, 0.f, 0.f};
-  if (EPI & EPI_BIAS) {
+  const bool fullVec = n + 3 < out.N;
+  // The mask (ReLU/dropout pattern of the producing layer) or the accumulate operand is fetched for all 16
+  // rows of this lane BEFORE the LDS turn-around, so its global latency (1-2 us, once per tile, with every
+  // workgroup at a tile boundary at the same time) overlaps the LDS work instead of preceding the stores.
+  const float* exSrc = (EPI & EPI_MASK) ? out.mask : ((EPI & EPI_ACCUM) ? out.C : nullptr);
+  f32x4 ex[2][8];
+  if (exSrc && fullVec) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bv[e] = n + e < out.N ? out.bias[n + e] : 0.f;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        int m = m0 + wm + 32 * i + 4 * p + rq;
+        if (m > out.M - 1) m = out.M - 1;  // rows past M are loaded (valid address) and dropped
+        ex[i][p] = *(const f32x4*)(exSrc + (size_t)m * out.ldc + n);
+      }
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -159,16 +170,18 @@ __device__ __forceinline__ void gemm128g_epilogue_wide(const GemmOut& out, int m
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
       }
-      if (n + 3 < out.N) {
+      if (fullVec) {
         if (EPI & EPI_MASK) {
-          const f32x4 mk = *(const f32x4*)(out.mask + (size_t)m * out.ldc + n);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] * out.maskScale : 0.f;
-        }
-        if (EPI & EPI_ACCUM) {
-          const f32x4 o = *(const f32x4*)dst;
+          for (int e = 0; e < 4; ++e) v[e] = ex[i][p][e] > 0.f ? v[e] * out.maskScale : 0.f;
+          if (EPI & EPI_ACCUM) {  // (both flags: the accumulate operand is read in place)
+            const f32x4 o = *(const f32x4*)dst;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += o[e];
+            for (int e = 0; e < 4; ++e) v[e] += o[e];
+          }
+        } else if (EPI & EPI_ACCUM) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += ex[i][p][e];
         }
         f32x4 w4;
         w4[0] = v[0]; w4[1] = v[1]; w4[2] = v[2]; w4[3] = v[3];
@@ -272,6 +285,13 @@ __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, Gemm
 
   for (int ord = 0;; ++ord) {
     const GSeg nxt = g_segment(plan, w, workers, ord + 1);
+    // bias of this lane's four output columns, fetched at the START of the tile (its latency hides under the K loop)
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if ((out.epi & EPI_BIAS) && seg.slab < 0) {
+      const int nb = by * 128 + wn + 4 * (lane & 15);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[e] = nb + e < out.N ? out.bias[nb + e] : 0.f;
+    }
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -352,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, Gemm
       if (t == 123.456f) out.C[0] = t;  // keeps every accumulator live
     } else if (seg.slab < 0) {
       // `stage` now names the buffer holding the prefetched next K tile; the other one is free
-      if (wide) gemm128g_epilogue_wide(out, bx * 128, by * 128, acc, smem + (stage ^ 1) * kGStageFloats);
+      if (wide) gemm128g_epilogue_wide(out, bx * 128, by * 128, acc, smem + (stage ^ 1) * kGStageFloats, bv);
       else gemm128_epilogue(out, bx * 128, by * 128, acc);
     } else {
       gemm128_store_partial(plan.slabs + (size_t)seg.slab * kSlabFloats, acc);
