@@ -130,6 +130,14 @@ int w2l_linear_backward_data(int M, int in, int out, const float* dy, const floa
                              w2l_stream_t stream);
 int w2l_linear_backward_weight(int M, int in, int out, const float* x, const float* dy, float* dw,
                                w2l_stream_t stream);
+/* y = dropout(relu?(x w + b)): fl::Dropout behind a Linear(+ReLU) folded into the GEMM epilogue; bit-identical to
+ * w2l_linear_forward followed by w2l_dropout_inplace(y, M*out, p, seed, rngStream) */
+int w2l_linear_forward_dropout(int M, int in, int out, const float* x, const float* w, const float* bias,
+                               float* y, int relu, double p, uint32_t seed, uint32_t rngStream,
+                               w2l_stream_t stream);
+/* dx = add + dy w^T (add laid out like dx): the residual join of a backward pass without copying add into dx first */
+int w2l_linear_backward_data_add(int M, int in, int out, const float* dy, const float* w, const float* add,
+                                 float* dx, w2l_stream_t stream);
 int w2l_colsum(const float* x, float* out, size_t M, int N, w2l_stream_t stream); /* bias grads */
 
 /* fl::Conv2D kw x 1 over time (arch tokens C / C2 / TDS). x [B][T][H][Cin],
@@ -166,6 +174,9 @@ int w2l_layernorm_backward(int groups, size_t inner, const float* r, const float
                            double* sums, w2l_stream_t stream);
 int w2l_dropout_inplace(float* x, size_t n, double p, uint32_t seed, uint32_t rngStream,
                         w2l_stream_t stream);
+/* y = dropout(x) out of place, same mask as w2l_dropout_inplace (16-byte aligned x, y) */
+int w2l_dropout_copy(float* y, const float* x, size_t n, double p, uint32_t seed, uint32_t rngStream,
+                     w2l_stream_t stream);
 int w2l_mask_backward(const float* dy, const float* src, float* dx, size_t n, float scale,
                       w2l_stream_t stream);
 int w2l_axpy(float* y, const float* x, size_t n, float alpha, w2l_stream_t stream);

@@ -142,6 +142,34 @@ def test_gemm_three_stage_256x128(M, N, K, akc, bkc):
     assert rel(got, old.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("M,K,N", [(300, 800, 2400),      # LDS-DMA kernel, wide epilogue
+                                    (188, 1440, 9998),     # generic kernel (unaligned N), dword epilogue
+                                    (37, 20, 13)])
+def test_fused_epilogue_variants_equal_the_unfused_ops(M, K, N):
+    """dropout folded into the Linear epilogue, the separate-addend backward-data and the out-of-place dropout are
+    bit-identical to the compositions of the plain ops they replace in the TDS block"""
+    from wav2letter_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(K, N, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    dy = torch.randn(M, N, generator=g).cuda()
+    add = torch.randn(M, K, generator=g).cuda()
+    p, seed, sid = 0.3, 12345, 7
+    want = ops.linear_forward(x, w, b, relu=True)
+    ops.dropout_(want, p, seed, sid)
+    got = ops.linear_forward_dropout(x, w, b, True, p, seed, sid)
+    assert torch.equal(got, want)
+    assert 0.2 < (got == 0).float().mean().item() < 0.95  # ReLU zeros + dropped elements
+    dx_plain = ops.linear_backward(x, w, dy)[0]
+    got = ops.linear_backward_data_add(dy, w, add)
+    assert rel(got, (add.double() + dx_plain.double()).cpu().numpy()) < 1e-6
+    src = torch.randn(4 * 1237, generator=g).cuda()
+    want = src.clone()
+    ops.dropout_(want, p, seed, sid)
+    assert torch.equal(ops.dropout_copy(src, p, seed, sid), want)
+
+
 def test_gemm_asymmetric_identity():
     """A = I with an asymmetric B catches row/col swaps in the C write (guide G9)"""
     from wav2letter_amd import ops

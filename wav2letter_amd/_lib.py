@@ -78,6 +78,9 @@ class _SIGS:
     w2l_residual_layernorm_forward = (_i, [_i, _sz, _p, _p, _p, _p, _p, _f, _d, _u32, _u32, _p, _p, _p])
     w2l_layernorm_backward = (_i, [_i, _sz, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p])
     w2l_dropout_inplace = (_i, [_p, _sz, _d, _u32, _u32, _p])
+    w2l_dropout_copy = (_i, [_p, _p, _sz, _d, _u32, _u32, _p])
+    w2l_linear_forward_dropout = (_i, [_i, _i, _i, _p, _p, _p, _p, _i, _d, _u32, _u32, _p])
+    w2l_linear_backward_data_add = (_i, [_i, _i, _i, _p, _p, _p, _p, _p])
     w2l_mask_backward = (_i, [_p, _p, _p, _sz, _f, _p])
     w2l_axpy = (_i, [_p, _p, _sz, _f, _p])
     w2l_transpose = (_i, [_p, _p, _i, _i, _i, _p])

@@ -507,6 +507,34 @@ W2L_API int w2l_layernorm_backward(int groups, size_t inner, const float* r, con
   return W2L_OK;
 }
 
+__global__ __launch_bounds__(kEwThreads) void dropout_copy_k(float* __restrict__ y, const float* __restrict__ x, size_t n,
+                                                            uint32_t thr, float keepScale, uint32_t seed, uint32_t stream) {
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = 4 * i;
+    float4 v = *(const float4*)(x + e);
+    v.x = keep_elem(e, seed, stream, thr) ? v.x * keepScale : 0.f;
+    v.y = keep_elem(e + 1, seed, stream, thr) ? v.y * keepScale : 0.f;
+    v.z = keep_elem(e + 2, seed, stream, thr) ? v.z * keepScale : 0.f;
+    v.w = keep_elem(e + 3, seed, stream, thr) ? v.w * keepScale : 0.f;
+    *(float4*)(y + e) = v;
+  }
+  for (size_t e = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
+    y[e] = keep_elem(e, seed, stream, thr) ? x[e] * keepScale : 0.f;
+}
+
+// y = dropout(x), out of place (same mask as w2l_dropout_inplace): one pass instead of copy + in-place pass
+W2L_API int w2l_dropout_copy(float* y, const float* x, size_t n, double p, uint32_t seed, uint32_t rngStream,
+                             w2l_stream_t stream) {
+  if (!x || !y || ((((uintptr_t)x) | ((uintptr_t)y)) & 15)) return W2L_EINVAL;
+  const uint32_t thr = dropout_threshold(p);
+  if (!n) return W2L_OK;
+  hipLaunchKernelGGL(dropout_copy_k, dim3(ew_grid((n >> 2) + 1)), dim3(kEwThreads), 0, W2L_S, y, x, n, thr,
+                     (float)(1.0 / (1.0 - p)), seed, rngStream);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
 W2L_API int w2l_dropout_inplace(float* x, size_t n, double p, uint32_t seed, uint32_t rngStream,
                                 w2l_stream_t stream) {
   if (!x) return W2L_EINVAL;

@@ -98,12 +98,20 @@ static int dispatch_b(const AOp& a, const float* B, int ldb, int b_kcontig, cons
 
 int gemm_f32(const float* A, int lda, int a_kcontig, const float* B, int ldb, int b_kcontig, float* C,
              int ldc, int M, int N, int K, const float* bias, int epi, int splitk, hipStream_t s,
-             const float* mask, float maskScale) {
+             const float* mask, float maskScale, const GemmExtra* extra) {
   if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return W2L_EINVAL;
   GemmOut o{C, bias, M, N, K, ldc, 0};
   o.mask = mask;
   o.maskScale = maskScale;
   if (mask) epi |= EPI_MASK;
+  if (extra) {
+    o.addend = extra->addend;
+    if (extra->addend) epi |= EPI_ACCUM;
+    if (extra->dropThr) {
+      o.dropThr = extra->dropThr; o.dropSeed = extra->dropSeed; o.dropStream = extra->dropStream; o.dropScale = extra->dropScale;
+      epi |= EPI_DROPOUT;
+    }
+  }
   splitk = 1;
   if (K % 32 == 0 && glds_ok(A, lda, M) && glds_ok(B, ldb, N) && glds_enabled())
   {
@@ -152,6 +160,29 @@ W2L_API int w2l_linear_backward_data(int M, int in, int out, const float* dy, co
   // backward of the layer that produced this Linear's input, fused into the epilogue.
   return gemm_f32(dy, out, 1, w, out, 1, dx, in, M, in, out, nullptr, accumulate ? EPI_ACCUM : 0, 1,
                   (hipStream_t)stream, maskSrc, maskScale);
+}
+
+// y = dropout(relu?(x w + b)): the dropout of fl::Dropout behind a Linear(+ReLU) folded into the GEMM epilogue; the
+// mask is the library's stateless hash of (flat index m * out + n, seed, rngStream) -- bit-identical to
+// w2l_linear_forward followed by w2l_dropout_inplace over y, one pass over y fewer
+W2L_API int w2l_linear_forward_dropout(int M, int in, int out, const float* x, const float* w, const float* bias,
+                                       float* y, int relu, double p, uint32_t seed, uint32_t rngStream,
+                                       w2l_stream_t stream) {
+  int epi = (bias ? EPI_BIAS : 0) | (relu ? EPI_RELU : 0);
+  GemmExtra ex;
+  ex.dropThr = dropout_threshold(p);
+  ex.dropSeed = seed; ex.dropStream = rngStream;
+  ex.dropScale = (float)(1.0 / (1.0 - p));
+  return gemm_f32(x, in, 1, w, out, 0, y, out, M, out, in, bias, epi, 1, (hipStream_t)stream, nullptr, 1.f, &ex);
+}
+
+// dx = add + dy w^T (add has dx's layout): the residual join of a backward pass without a copy of `add` into dx first
+W2L_API int w2l_linear_backward_data_add(int M, int in, int out, const float* dy, const float* w, const float* add,
+                                         float* dx, w2l_stream_t stream) {
+  if (!add) return W2L_EINVAL;
+  GemmExtra ex;
+  ex.addend = add;
+  return gemm_f32(dy, out, 1, w, out, 1, dx, in, M, in, out, nullptr, 0, 1, (hipStream_t)stream, nullptr, 1.f, &ex);
 }
 
 W2L_API int w2l_linear_backward_weight(int M, int in, int out, const float* x, const float* dy,

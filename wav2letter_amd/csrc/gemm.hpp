@@ -16,7 +16,7 @@ namespace w2l {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { EPI_BIAS = 1, EPI_RELU = 2, EPI_ACCUM = 4, EPI_ATOMIC = 8, EPI_MASK = 16 };
+enum { EPI_BIAS = 1, EPI_RELU = 2, EPI_ACCUM = 4, EPI_ATOMIC = 8, EPI_MASK = 16, EPI_DROPOUT = 32 };
 
 struct GemmOut {
   float* C;
@@ -25,6 +25,11 @@ struct GemmOut {
   int epi;  // EPI_* flags (runtime: the epilogue is outside the K loop)
   const float* mask = nullptr;  // EPI_MASK: v = mask[m][n] > 0 ? v * maskScale : 0 (same ld as C)
   float maskScale = 1.f;
+  const float* addend = nullptr;  // EPI_ACCUM: v += addend[m][n] (same ld as C); null = accumulate into C itself
+  // EPI_DROPOUT (after bias / ReLU): v = keep_elem(m * ldc + n, seed, stream, thr) ? v * dropScale : 0 -- the same
+  // stateless hash, on the same flat index, as dropout_k over the dense [M][ldc] output
+  uint32_t dropThr = 0, dropSeed = 0, dropStream = 0;
+  float dropScale = 1.f;
 };
 
 // A GEMM operand viewed as op(k, i): i = row of A (m) or column of B (n).
@@ -413,8 +418,9 @@ __device__ __forceinline__ void gemm128_epilogue(const GemmOut& out, int m0, int
         float v = acc[i][j][r] + bv;
         float* dst = out.C + (size_t)m * out.ldc + n;
         if (EPI & EPI_RELU) v = fmaxf(v, 0.f);
+        if (EPI & EPI_DROPOUT) v = keep_elem((uint64_t)m * out.ldc + n, out.dropSeed, out.dropStream, out.dropThr) ? v * out.dropScale : 0.f;
         if (EPI & EPI_MASK) v = out.mask[(size_t)m * out.ldc + n] > 0.f ? v * out.maskScale : 0.f;
-        if (EPI & EPI_ACCUM) v += *dst;
+        if (EPI & EPI_ACCUM) v += out.addend ? out.addend[(size_t)m * out.ldc + n] : *dst;
         *dst = v;
       }
     }
@@ -606,8 +612,9 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(AOp aop, BOp bop, G
           atomicAdd(dst, v);
         } else {
           if (EPI & EPI_RELU) v = fmaxf(v, 0.f);
+          if (EPI & EPI_DROPOUT) v = keep_elem((uint64_t)m * out.ldc + n, out.dropSeed, out.dropStream, out.dropThr) ? v * out.dropScale : 0.f;
           if (EPI & EPI_MASK) v = out.mask[(size_t)m * out.ldc + n] > 0.f ? v * out.maskScale : 0.f;
-          if (EPI & EPI_ACCUM) v += *dst;
+          if (EPI & EPI_ACCUM) v += out.addend ? out.addend[(size_t)m * out.ldc + n] : *dst;
           *dst = v;
         }
       }
@@ -652,8 +659,13 @@ inline int launch_skinny(const AOp& a, const BOp& b, GemmOut o, int epi, int spl
 // C[M][N] = op(A)[M][K] . op(B)[K][N] (+bias[n]) (relu) ; a_kcontig: A is [M][K] row-major;
 // b_kcontig: B is stored [N][K] row-major.  epi = EPI_* flags; splitk > 1 needs EPI_ATOMIC
 // and a pre-zeroed C.
+struct GemmExtra {  // optional epilogue operands of gemm_f32
+  const float* addend = nullptr;
+  uint32_t dropThr = 0, dropSeed = 0, dropStream = 0;
+  float dropScale = 1.f;
+};
 int gemm_f32(const float* A, int lda, int a_kcontig, const float* B, int ldb, int b_kcontig, float* C,
              int ldc, int M, int N, int K, const float* bias, int epi, int splitk, hipStream_t s,
-             const float* mask = nullptr, float maskScale = 1.f);
+             const float* mask = nullptr, float maskScale = 1.f, const GemmExtra* extra = nullptr);
 
 }  // namespace w2l

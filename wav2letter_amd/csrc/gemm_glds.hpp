@@ -139,7 +139,8 @@ __device__ __forceinline__ void gemm128g_epilogue_wide(const GemmOut& out, int m
   // The mask (ReLU/dropout pattern of the producing layer) or the accumulate operand is fetched for all 16
   // rows of this lane BEFORE the LDS turn-around, so its global latency (1-2 us, once per tile, with every
   // workgroup at a tile boundary at the same time) overlaps the LDS work instead of preceding the stores.
-  const float* exSrc = (EPI & EPI_MASK) ? out.mask : ((EPI & EPI_ACCUM) ? out.C : nullptr);
+  const float* accSrc = out.addend ? out.addend : out.C;
+  const float* exSrc = (EPI & EPI_MASK) ? out.mask : ((EPI & EPI_ACCUM) ? accSrc : nullptr);
   f32x4 ex[2][8];
   if (exSrc && fullVec) {
 #pragma unroll
@@ -170,12 +171,17 @@ __device__ __forceinline__ void gemm128g_epilogue_wide(const GemmOut& out, int m
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
       }
+      if (EPI & EPI_DROPOUT) {
+        const uint64_t idx = (uint64_t)m * out.ldc + n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = keep_elem(idx + e, out.dropSeed, out.dropStream, out.dropThr) ? v[e] * out.dropScale : 0.f;
+      }
       if (fullVec) {
         if (EPI & EPI_MASK) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = ex[i][p][e] > 0.f ? v[e] * out.maskScale : 0.f;
           if (EPI & EPI_ACCUM) {  // (both flags: the accumulate operand is read in place)
-            const f32x4 o = *(const f32x4*)dst;
+            const f32x4 o = *(const f32x4*)(accSrc + (size_t)m * out.ldc + n);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += o[e];
           }
@@ -192,7 +198,7 @@ __device__ __forceinline__ void gemm128g_epilogue_wide(const GemmOut& out, int m
           if (n + e >= out.N) continue;
           float t = v[e];
           if (EPI & EPI_MASK) t = out.mask[(size_t)m * out.ldc + n + e] > 0.f ? t * out.maskScale : 0.f;
-          if (EPI & EPI_ACCUM) t += dst[e];
+          if (EPI & EPI_ACCUM) t += accSrc[(size_t)m * out.ldc + n + e];
           dst[e] = t;
         }
       }

@@ -124,6 +124,12 @@ __device__ __forceinline__ void p3_epilogue_wide(const GemmOut& out, int m0, int
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
+        if (EPI & EPI_DROPOUT) {
+          const uint64_t idx = (uint64_t)m * out.ldc + n;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = keep_elem(idx + e, out.dropSeed, out.dropStream, out.dropThr) ? v[e] * out.dropScale : 0.f;
+        }
+        const float* accSrc = out.addend ? out.addend : out.C;
         if (n + 3 < out.N) {
           if (EPI & EPI_MASK) {
             const f32x4 mk = *(const f32x4*)(out.mask + (size_t)m * out.ldc + n);
@@ -131,7 +137,7 @@ __device__ __forceinline__ void p3_epilogue_wide(const GemmOut& out, int m0, int
             for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] * out.maskScale : 0.f;
           }
           if (EPI & EPI_ACCUM) {
-            const f32x4 o = *(const f32x4*)dst;
+            const f32x4 o = *(const f32x4*)(accSrc + (size_t)m * out.ldc + n);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += o[e];
           }
@@ -144,7 +150,7 @@ __device__ __forceinline__ void p3_epilogue_wide(const GemmOut& out, int m0, int
             if (n + e >= out.N) continue;
             float t = v[e];
             if (EPI & EPI_MASK) t = out.mask[(size_t)m * out.ldc + n + e] > 0.f ? t * out.maskScale : 0.f;
-            if (EPI & EPI_ACCUM) t += dst[e];
+            if (EPI & EPI_ACCUM) t += accSrc[(size_t)m * out.ldc + n + e];
             dst[e] = t;
           }
         }
@@ -351,7 +357,8 @@ inline int launch256(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o, 
   if (workers < plan.skBlocks) workers = plan.skBlocks;
   const size_t shmem = 3 * (size_t)kP3StageFloats * sizeof(float);
   static const int wideOn = [] { const char* e = getenv("W2L_GEMM_WIDE"); return e ? atoi(e) : 1; }();
-  const int wide = wideOn && (((uintptr_t)o.C) & 15) == 0 && o.ldc % 4 == 0 && (!o.mask || (((uintptr_t)o.mask) & 15) == 0);
+  const int wide = wideOn && (((uintptr_t)o.C) & 15) == 0 && o.ldc % 4 == 0 && (!o.mask || (((uintptr_t)o.mask) & 15) == 0) &&
+                   (!o.addend || (((uintptr_t)o.addend) & 15) == 0);
   dim3 grid((unsigned)workers), block(512);
   o.epi = epi;
 #define W2L_P3_LAUNCH(AK, BK)                                                                                            \

@@ -560,8 +560,9 @@ class TDSLayer : public Layer {
     // a <- dropout(relu(conv)) in place (kept: its sign pattern is the ReLU+dropout mask); r1 = a + x; y1 = LN(r1)
     w2lCheck(w2l_residual_layernorm_forward(groups, inner, a, x, r1, y1, gb1.w(cx), 1e-5f, pd, cx.seed, rngStream,
                                             (double*)(ar + st1Off), ar + mr1Off, s), "tds ln1");
-    w2lCheck(w2l_linear_forward(M, l, l2, y1, w1.w(cx), b1.w(cx), u, 1, s), "tds lin1");
-    if (pd > 0) w2lCheck(w2l_dropout_inplace(u, (size_t)M * l2, pd, cx.seed, rngStream + 1, s), "tds do1");
+    // lin1 + ReLU + dropout in one GEMM epilogue (same mask bits as a separate dropout pass over u)
+    if (pd > 0) w2lCheck(w2l_linear_forward_dropout(M, l, l2, y1, w1.w(cx), b1.w(cx), u, 1, pd, cx.seed, rngStream + 1, s), "tds lin1+do");
+    else w2lCheck(w2l_linear_forward(M, l, l2, y1, w1.w(cx), b1.w(cx), u, 1, s), "tds lin1");
     w2lCheck(w2l_linear_forward(M, l2, l, u, w2.w(cx), b2.w(cx), v, 0, s), "tds lin2");
     // r2 = dropout(v) + y1 (stored over v), out = LN(r2)
     w2lCheck(w2l_residual_layernorm_forward(groups, inner, v, y1, v, out, gb2.w(cx), 1e-5f, pd, cx.seed, rngStream + 2,
@@ -579,9 +580,8 @@ class TDSLayer : public Layer {
                                     (double*)(ar + st2Off), s), "tds ln2 bwd");
     const float* dv = ds;
     if (pd > 0) {
-      // dy1 buffer doubles as scratch for the masked copy
-      w2lCheck(hipMemcpyAsync(dy1, ds, n * sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess ? W2L_OK : W2L_EHIP, "tds copy");
-      w2lCheck(w2l_dropout_inplace(dy1, n, pd, cx.seed, rngStream + 2, s), "tds do2 bwd");
+      // dy1 buffer doubles as scratch for the masked copy (one out-of-place pass)
+      w2lCheck(w2l_dropout_copy(dy1, ds, n, pd, cx.seed, rngStream + 2, s), "tds do2 bwd");
       dv = dy1;
     }
     // lin2: dW2 = u^T dv, db2, du = (dv W2^T) masked by relu+dropout of u (u holds the dropped value)
@@ -591,8 +591,8 @@ class TDSLayer : public Layer {
     // lin1: dW1 = y1^T du, db1, dy1 = ds + du W1^T
     w2lCheck(w2l_linear_backward_weight(M, l, l2, y1, du, w1.g(cx), s), "tds lin1 bwd w");
     w2lCheck(w2l_colsum(du, b1.g(cx), (size_t)M, l2, s), "tds lin1 bwd b");
-    w2lCheck(hipMemcpyAsync(dy1, ds, n * sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess ? W2L_OK : W2L_EHIP, "tds copy");
-    w2lCheck(w2l_linear_backward_data(M, l, l2, du, w1.w(cx), dy1, 1, nullptr, 1.f, s), "tds lin1 bwd x");
+    // dy1 = ds + du W1^T: the residual join rides in the GEMM epilogue as a separate addend (no copy of ds into dy1)
+    w2lCheck(w2l_linear_backward_data_add(M, l, l2, du, w1.w(cx), ds, dy1, s), "tds lin1 bwd x");
     // LN1 backward: dr1, and in the same pass da = dr1 masked by the ReLU+dropout pattern of a
     w2lCheck(w2l_layernorm_backward(groups, inner, ar + r1Off, dy1, gb1.w(cx), ar + mr1Off, dr1, gb1.g(cx), a, da, sc,
                                     (double*)(ar + st1Off), s), "tds ln1 bwd");

@@ -103,6 +103,29 @@ def layernorm_backward(r, dy, gamma_beta, mean_rstd, groups, mask_src=None, mask
     return dr, dgb, dmask
 
 
+def linear_forward_dropout(x, w, bias, relu, p, seed, stream_id):
+    M, K = x.shape
+    N = w.shape[1]
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    check(_lib.lib().w2l_linear_forward_dropout(M, K, N, _p(x), _p(w), _p(bias), _p(y), int(relu), p, seed, stream_id, _s()), "linear_forward_dropout")
+    return y
+
+
+def linear_backward_data_add(dy, w, add):
+    M, N = dy.shape
+    K = w.shape[0]
+    dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
+    check(_lib.lib().w2l_linear_backward_data_add(M, K, N, _p(dy), _p(w), _p(add), _p(dx), _s()), "linear_bwd_data_add")
+    return dx
+
+
+def dropout_copy(x, p, seed, stream_id):
+    y = torch.empty_like(x)
+    check(_lib.lib().w2l_dropout_copy(_p(y), _p(x), x.numel(), p, seed, stream_id, _s()),
+          "dropout_copy")
+    return y
+
+
 def dropout_(x, p, seed, stream_id):
     check(_lib.lib().w2l_dropout_inplace(_p(x), x.numel(), p, seed, stream_id, _s()), "dropout")
     return x
