@@ -7,7 +7,8 @@ batch 32 per GPU, fp32 -- plus the ASG criterion time (ms/step) at the conv_glu
 LibriSpeech criterion shape (B=64, T=2000, N=30).
 
 A "step" = SpecAugment + network forward + CTC forward/backward + network backward +
-(N>1: ONE all-reduce of the flat gradient arena over RCCL) + gradient clipping + SGD with
+(N>1: RCCL all-reduce of the flat gradient arena in a few large buckets, issued on a side
+stream under the backward pass) + gradient clipping + SGD with
 momentum, exactly the reference's hot loop (recipes/slimIPL/src/Train.cpp:1454-1804).
 Inputs are synthetic, generated on the device before the timed region.
 

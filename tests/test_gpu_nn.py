@@ -170,6 +170,28 @@ def test_fused_epilogue_variants_equal_the_unfused_ops(M, K, N):
     assert torch.equal(ops.dropout_copy(src, p, seed, sid), want)
 
 
+@pytest.mark.parametrize("M,N,K", [(6016, 1440, 416), (1500, 700, 4096), (24000, 800, 2400), (800, 2400, 24000)])
+def test_gemm_in_kernel_slab_reduction_is_stable(M, N, K):
+    """stream-K partial tiles reduced inside the GEMM launch (arrival tickets + agent-scope release/acquire):
+    bit-identical to the separate fix-up launch (W2L_GEMM_INFIX=0) and to itself over many launches under load"""
+    import os
+    from wav2letter_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).cuda()
+    Bm = (torch.randn(K, N, generator=g) / K ** 0.5).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    os.environ["W2L_GEMM_INFIX"] = "0"
+    try:
+        ref = ops.gemm(A, Bm, True, False, bias, relu=True)
+    finally:
+        os.environ.pop("W2L_GEMM_INFIX")
+    for it in range(25):
+        got = ops.gemm(A, Bm, True, False, bias, relu=True)
+        assert torch.equal(got, ref), it
+    want = torch.relu(A.double() @ Bm.double() + bias.double()).cpu().numpy()
+    assert rel(ref, want) < TOL
+
+
 def test_gemm_asymmetric_identity():
     """A = I with an asymmetric B catches row/col swaps in the C write (guide G9)"""
     from wav2letter_amd import ops

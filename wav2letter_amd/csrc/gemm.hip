@@ -70,6 +70,22 @@ static inline bool glds_ok(const float* p, int ld, int extent) {
   return (((uintptr_t)p) & 15) == 0 && ld % 4 == 0 && extent % 4 == 0 && extent >= 4;
 }
 
+unsigned* sk_counters(hipStream_t s) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, unsigned*> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  unsigned*& e = cache[{dev, s}];
+  if (!e) {
+    void* p = nullptr;
+    if (hipMalloc(&p, 1024 * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 1024 * sizeof(unsigned)) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    e = (unsigned*)p;
+  }
+  return e;
+}
+
 bool sk_enabled() {
   const char* e = getenv("W2L_GEMM_SK");
   return !(e && e[0] == '0');

@@ -248,6 +248,7 @@ struct SkPlan {
   int dpTiles, skTiles, skBlocks;
   float* slabs;  // [skBlocks][2][128*128]
   int grouped;   // tile rasterisation: 0 = M-fastest, 1 = groups of 8 tile-columns, N-fastest inside a group
+  unsigned* counters;  // per stream-K tile arrival tickets for the in-kernel slab reduction (null: separate fix-up launch)
 };
 constexpr int kSkSlots = 512;           // resident 256-thread workgroups (2 per CU)
 constexpr int kSlabFloats = 128 * 128;
@@ -273,7 +274,7 @@ inline SkPlan make_sk_plan(int M, int N, int K, bool allowSk) {
   p.tilesN = (N + 127) / 128;
   p.kTiles = (K + 31) / 32;
   const int tiles = p.tilesM * p.tilesN;
-  p.dpTiles = tiles; p.skTiles = 0; p.skBlocks = 0; p.slabs = nullptr; p.grouped = 0;
+  p.dpTiles = tiles; p.skTiles = 0; p.skBlocks = 0; p.slabs = nullptr; p.grouped = 0; p.counters = nullptr;
   if (!allowSk || p.kTiles < 8) return p;
   const int rounds = (tiles + kSkSlots - 1) / kSkSlots;
   const double eff = (double)tiles / ((double)rounds * kSkSlots);
@@ -292,6 +293,19 @@ inline SkPlan make_sk_plan(int M, int N, int K, bool allowSk) {
 }
 
 float* sk_scratch(hipStream_t s, size_t bytes);  // library-owned, one buffer per stream (gemm.hip)
+unsigned* sk_counters(hipStream_t s);            // 1024 zero-initialised arrival tickets per stream (self-resetting)
+
+// first / last stream-K range that overlaps stream-K tile t
+__host__ __device__ inline void sk_tile_ranges(const SkPlan& p, int t, int& sFirst, int& sLast) {
+  const long long tb = (long long)t * p.kTiles, te = tb + p.kTiles;
+  const long long I = (long long)p.skTiles * p.kTiles;
+  int s = (int)(tb * p.skBlocks / I);
+  while (s + 1 < p.skBlocks && sk_begin(p, s + 1) <= tb) ++s;
+  while (s > 0 && sk_begin(p, s) > tb) --s;
+  sFirst = s;
+  while (s + 1 < p.skBlocks && sk_begin(p, s + 1) < te) ++s;
+  sLast = s;
+}
 bool sk_enabled();                               // W2L_GEMM_SK=0 turns the schedule off (A/B runs)
 
 // ---------------------------------------------------------------- kernels

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, Gemm
     const GSeg nxt = g_segment(plan, w, workers, ord + 1);
     // bias of this lane's four output columns, fetched at the START of the tile (its latency hides under the K loop)
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if ((out.epi & EPI_BIAS) && seg.slab < 0) {
+    if (out.epi & EPI_BIAS) {
       const int nb = by * 128 + wn + 4 * (lane & 15);
 #pragma unroll
       for (int e = 0; e < 4; ++e) bv[e] = nb + e < out.N ? out.bias[nb + e] : 0.f;
@@ -371,20 +371,70 @@ __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, Gemm
       if (!(ABL & 2)) __syncthreads();  // the stage just filled has landed (vmcnt(0)) and is visible to all waves
     }
 
+    bool doEpi = seg.slab < 0;  // whole tile: epilogue straight from the accumulators
+    int resetTicket = -1;
     if (ABL & 8) {
       float t = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) t += acc[0][0][r] + acc[0][1][r] + acc[1][0][r] + acc[1][1][r];
       if (t == 123.456f) out.C[0] = t;  // keeps every accumulator live
-    } else if (seg.slab < 0) {
+      doEpi = false;
+    } else if (!doEpi) {
+      gemm128_store_partial(plan.slabs + (size_t)seg.slab * kSlabFloats, acc);
+      if (plan.counters) {
+        // In-kernel slab reduction (replaces the fix-up launch).  Publish: every wave drains its slab stores, one lane
+        // releases at agent scope and draws the tile's arrival ticket; the workgroup that draws the LAST ticket acquires
+        // and adds ALL slabs of the tile from memory in range order (its own included: deterministic), then runs the
+        // ordinary epilogue below and re-zeroes the ticket (cdna_hip_programming.md, in-launch split-K reduction recipe).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = (int*)(smem + (stage ^ 1) * kGStageFloats);  // the stage the K loop has just released
+        const int t = seg.tile - plan.dpTiles;
+        if (tid == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          *flag = (int)__hip_atomic_fetch_add(plan.counters + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const int ticket = *flag;
+        int sF, sL;
+        sk_tile_ranges(plan, t, sF, sL);
+        if (ticket == sL - sF) {  // uniform: last arriver
+          if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          __syncthreads();  // (also: every wave has read the ticket before the stage becomes epilogue scratch)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+          for (int sr = sF; sr <= sL; ++sr) {
+            const int segIdx = t - (int)(sk_begin(plan, sr) / plan.kTiles);  // ranges span <= 2 tiles: 0 or 1
+            const f32x4* s4 = (const f32x4*)(plan.slabs + ((size_t)sr * 2 + segIdx) * kSlabFloats);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const f32x4 v = s4[((wave * 4 + i * 2 + j) * 4 + q) * 64 + lane];
+                  acc[i][j][4 * q] += v[0]; acc[i][j][4 * q + 1] += v[1]; acc[i][j][4 * q + 2] += v[2]; acc[i][j][4 * q + 3] += v[3];
+                }
+          }
+          doEpi = true;
+          resetTicket = t;
+        }
+      }
+    }
+    if (doEpi) {
       // `stage` now names the buffer holding the prefetched next K tile; the other one is free
       if (wide) gemm128g_epilogue_wide(out, bx * 128, by * 128, acc, smem + (stage ^ 1) * kGStageFloats, bv);
       else gemm128_epilogue(out, bx * 128, by * 128, acc);
-    } else {
-      gemm128_store_partial(plan.slabs + (size_t)seg.slab * kSlabFloats, acc);
+      if (resetTicket >= 0 && tid == 0) __hip_atomic_store(plan.counters + resetTicket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (!nxt.valid) break;
-    if (wide) __syncthreads();  // the next iteration's LDS-DMA lands in the slices the epilogue used
+    if (wide || plan.counters) __syncthreads();  // the next iteration's LDS-DMA lands in the slices the epilogue / ticket used
+
     seg = nxt;
     sk_tile_xy(plan, seg.tile, bx, by);
   }
@@ -397,6 +447,9 @@ inline int launch128g(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o,
   if (plan.skBlocks > 0) {
     plan.slabs = sk_scratch(s, (size_t)kSkSlots * 2 * kSlabFloats * sizeof(float));
     if (!plan.slabs) { plan = make_sk_plan(o.M, o.N, o.K, false); plan.grouped = 1; }
+    const char* eFix = getenv("W2L_GEMM_INFIX");  // read per call (tests flip it): 0 = separate fix-up launch
+    const int inFix = eFix ? atoi(eFix) : 1;
+    if (plan.skBlocks > 0 && inFix && plan.skTiles <= 1024) plan.counters = sk_counters(s);
   }
   int workers = plan.dpTiles < kSkSlots ? plan.dpTiles : kSkSlots;
   if (workers < plan.skBlocks) workers = plan.skBlocks;
@@ -433,7 +486,8 @@ inline int launch128g(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o,
   else if (akc) hipLaunchKernelGGL((gemm128g_kernel<true, false>), grid, block, shmem, s, a, b, o, plan, workers, wide);
   else if (bkc) hipLaunchKernelGGL((gemm128g_kernel<false, true>), grid, block, shmem, s, a, b, o, plan, workers, wide);
   else hipLaunchKernelGGL((gemm128g_kernel<false, false>), grid, block, shmem, s, a, b, o, plan, workers, wide);
-  if (plan.skBlocks > 0) hipLaunchKernelGGL(gemm128_fixup<0>, dim3((unsigned)plan.skTiles * 4), dim3(64), 0, s, o, plan);
+  if (plan.skBlocks > 0 && !plan.counters)
+    hipLaunchKernelGGL(gemm128_fixup<0>, dim3((unsigned)plan.skTiles * 4), dim3(64), 0, s, o, plan);
   prof_end(s);
   W2L_LAUNCH_CHECK();
   return W2L_OK;

@@ -32,7 +32,7 @@ inline SkPlan make_sk_plan_p3(int M, int N, int K, bool allowSk) {
   p.tilesN = (N + 127) / 128;
   p.kTiles = (K + 31) / 32;
   const int tiles = p.tilesM * p.tilesN;
-  p.dpTiles = tiles; p.skTiles = 0; p.skBlocks = 0; p.slabs = nullptr; p.grouped = 1;
+  p.dpTiles = tiles; p.skTiles = 0; p.skBlocks = 0; p.slabs = nullptr; p.grouped = 1; p.counters = nullptr;
   if (!allowSk || p.kTiles < 8) return p;
   const int rounds = (tiles + kP3Slots - 1) / kP3Slots;
   const double eff = (double)tiles / ((double)rounds * kP3Slots);
