@@ -178,3 +178,35 @@ def test_gradient_bucket_events_and_single_rank_rccl():
         tr.forward_backward(x, tgt)
     finally:
         dist.destroy_process_group()
+
+
+def test_checkpoint_resume_reproduces_the_next_step(tmp_path):
+    """save (params + momentum + step) after two SGD steps, load into a fresh trainer: the third step is bit-identical"""
+    from wav2letter_amd import checkpoint, recipes
+    from wav2letter_amd.trainer import Trainer
+    rng = np.random.default_rng(8)
+    nfeat, nlabel, B, T, L = 8, 12, 3, 40, 5
+    arch = recipes.tds_ctc_small_arch(c=(4,), h=nfeat, kw=5, drop=0.1)
+
+    def make(seed):
+        tr = Trainer(arch, nfeat, nlabel, "ctc", 4)
+        tr.init_params(seed)
+        tr.plan(B, T, L)
+        tr.to_device()
+        return tr
+    x = torch.tensor(rng.normal(size=(B, nfeat, T)).astype(np.float32)).cuda()
+    tgt = torch.tensor(rng.integers(0, nlabel - 1, size=(B, L)).astype(np.int32)).cuda()
+    a = make(1)
+    for _ in range(2):
+        a.forward_backward(x, tgt)
+        a.update(lr=0.05, momentum=0.9, max_grad_norm=1.0)
+    path = str(tmp_path / "ck.w2l")
+    checkpoint.save(path, a, arch, "ctc", step=2)
+    b = make(77)
+    assert checkpoint.load(path, b, arch) == 2
+    la = a.forward_backward(x, tgt).clone()
+    a.update(lr=0.05, momentum=0.9, max_grad_norm=1.0)
+    lb = b.forward_backward(x, tgt).clone()
+    b.update(lr=0.05, momentum=0.9, max_grad_norm=1.0)
+    assert torch.equal(la, lb)                  # same dropout masks: the step counter was restored
+    assert torch.equal(a.params, b.params)      # same momentum

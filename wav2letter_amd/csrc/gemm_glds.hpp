@@ -245,7 +245,8 @@ __device__ __forceinline__ GSeg g_segment(const SkPlan& p, int w, int workers, i
 
 // ABL: timing-only ablations (results are garbage) selected by W2L_GEMM_ABL for the probe tool:
 //   1 = no LDS-DMA, 2 = no per-K-tile barrier, 4 = no fragment reads in the loop, 8 = no epilogue,
-//   16 = LDS-DMA always re-reads K tile 0 (cache-resident source), 32 = LDS-DMA of the A operand only
+//   16 = LDS-DMA always re-reads K tile 0 (cache-resident source), 32 = LDS-DMA of the A operand only,
+//   64 = every tile is tile 0 (operands and output stay cache-resident: isolates new-panel memory effects)
 template <bool AKC, bool BKC, int ABL = 0, bool BUF = false>
 __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, GemmOut out, SkPlan plan, int workers, int wide) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, Gemm
     rb = __builtin_amdgcn_make_buffer_rsrc((void*)bop.p, 0, (int)bop.bytes, 0x00020000);
   }
   int bx, by;
-  sk_tile_xy(plan, seg.tile, bx, by);
+  sk_tile_xy(plan, (ABL & 64) ? 0 : seg.tile, bx, by);
   if (BUF) {
     g_init_offs<AKC>(va, aop, bx * 128, wave, lane);
     g_init_offs<BKC>(vb, bop, by * 128, wave, lane);
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, Gemm
         offA += aStep; offB += bStep;
       } else if (nxt.valid) {
         int nbx, nby;
-        sk_tile_xy(plan, nxt.tile, nbx, nby);
+        sk_tile_xy(plan, (ABL & 64) ? 0 : nxt.tile, nbx, nby);
         if (BUF) {
           g_init_offs<AKC>(va, aop, nbx * 128, wave, lane);
           g_init_offs<BKC>(vb, bop, nby * 128, wave, lane);
@@ -357,8 +358,10 @@ __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, Gemm
           } else {
             const int piece = step - 1 - g;  // steps 1,2,3,5,6,7,9,10 -> pieces 0..7
             if (BUF) {
-              if (piece < 4) g_issue1_buf(ra, va[piece], (uint32_t)(offA * 4), An, wave, piece);
-              else if (piece < 8) g_issue1_buf(rb, vb[piece - 4], (uint32_t)(offB * 4), An + 4096, wave, piece - 4);
+              if (!(ABL & 1)) {
+                if (piece < 4) g_issue1_buf(ra, va[piece], (uint32_t)(offA * 4), An, wave, piece);
+                else if (piece < 8) g_issue1_buf(rb, vb[piece - 4], (uint32_t)(offB * 4), An + 4096, wave, piece - 4);
+              }
             } else if (!(ABL & 1)) {
               if (piece < 4) g_issue1(qa[piece], (ABL & 16) ? 0 : offA, An, wave, piece);
               else if (piece < 8 && !(ABL & 32)) g_issue1(qb[piece - 4], (ABL & 16) ? 0 : offB, An + 4096, wave, piece - 4);
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, Gemm
     if (wide || plan.counters) __syncthreads();  // the next iteration's LDS-DMA lands in the slices the epilogue / ticket used
 
     seg = nxt;
-    sk_tile_xy(plan, seg.tile, bx, by);
+    sk_tile_xy(plan, (ABL & 64) ? 0 : seg.tile, bx, by);
   }
 }
 
@@ -463,6 +466,7 @@ inline int launch128g(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o,
   // buffer-addressed LDS-DMA is the default (+8 % at 4096^3, +5-7 % on the TDS fc shapes over 64-bit global
   // addresses, MI355X); W2L_GEMM_BUF=0 selects the global_load_lds variant for A/B runs
   static const int bufOn = [] { const char* e = getenv("W2L_GEMM_BUF"); return e ? atoi(e) : 1; }();
+  static const int ablBuf = [] { const char* e = getenv("W2L_GEMM_ABLBUF"); return e ? atoi(e) : 0; }();
   static const int abl = [] { const char* e = getenv("W2L_GEMM_ABL"); return e ? atoi(e) : 0; }();
   if (abl && akc && !bkc) {
     switch (abl) {
@@ -476,6 +480,15 @@ inline int launch128g(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o,
       case 9: hipLaunchKernelGGL((gemm128g_kernel<true, false, 9>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
       case 2: hipLaunchKernelGGL((gemm128g_kernel<true, false, 2>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
       default: hipLaunchKernelGGL((gemm128g_kernel<true, false, 4>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
+    }
+  } else if (ablBuf && akc && !bkc && a.bytes && b.bytes) {
+    switch (ablBuf) {
+      case 1: hipLaunchKernelGGL((gemm128g_kernel<true, false, 1, true>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
+      case 8: hipLaunchKernelGGL((gemm128g_kernel<true, false, 8, true>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
+      case 9: hipLaunchKernelGGL((gemm128g_kernel<true, false, 9, true>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
+      case 64: hipLaunchKernelGGL((gemm128g_kernel<true, false, 64, true>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
+      case 72: hipLaunchKernelGGL((gemm128g_kernel<true, false, 72, true>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
+      default: hipLaunchKernelGGL((gemm128g_kernel<true, false, 0, true>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
     }
   } else if (bufOn && a.bytes && b.bytes) {
     if (akc && bkc) hipLaunchKernelGGL((gemm128g_kernel<true, true, 0, true>), grid, block, shmem, s, a, b, o, plan, workers, wide);
