@@ -192,6 +192,34 @@ def test_gemm_in_kernel_slab_reduction_is_stable(M, N, K):
     assert rel(ref, want) < TOL
 
 
+@pytest.mark.parametrize("M,N,K", [(4, 4, 32), (260, 388, 96), (1028, 2052, 1440), (6016, 4320, 1440), (640, 136, 24000),
+                                    (24000, 2400, 800)])
+@pytest.mark.parametrize("akc,bkc", [(True, False), (True, True), (False, False), (False, True)])
+def test_gemm_loader_wave_variant(M, N, K, akc, bkc):
+    """the loader-wave kernel (a fifth wave issues every LDS-DMA piece; compute waves never wait on vmcnt in the K loop):
+    bit-identical to the four-wave kernel (same fragments, same k order, same epilogue), deterministic, float64 parity"""
+    import os
+    from wav2letter_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(7 * M + 3 * N + K)
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(K, N, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    want = (A.double() @ Bm.double() + bias.double()).numpy()
+    Ad = (A if akc else A.T.contiguous()).cuda()
+    Bd = (Bm.T.contiguous() if bkc else Bm).cuda()
+    os.environ["W2L_GEMM_LOADER"] = "1"
+    try:
+        got = ops.gemm(Ad, Bd, akc, bkc, bias.cuda(), relu=True)
+        for _ in range(5):
+            assert torch.equal(got, ops.gemm(Ad, Bd, akc, bkc, bias.cuda(), relu=True))
+        os.environ["W2L_GEMM_LOADER"] = "0"
+        old = ops.gemm(Ad, Bd, akc, bkc, bias.cuda(), relu=True)
+    finally:
+        os.environ.pop("W2L_GEMM_LOADER")
+    assert torch.equal(got, old)
+    assert rel(got, np.maximum(want, 0)) < TOL
+
+
 def test_gemm_asymmetric_identity():
     """A = I with an asymmetric B catches row/col swaps in the C write (guide G9)"""
     from wav2letter_amd import ops

@@ -26,6 +26,7 @@
 #include "gemm.hpp"
 #include "gemm_glds.hpp"
 #include "gemm_p3.hpp"
+#include "gemm_loader.hpp"
 
 namespace w2l {
 
@@ -142,6 +143,10 @@ int gemm_f32(const float* A, int lda, int a_kcontig, const float* B, int ldb, in
     if (p3 && ga.bytes && gb.bytes) {
       const double pad256 = (double)((M + 255) / 256 * 256), pad128 = (double)((M + 127) / 128 * 128);
       if (p3 == 2 || pad256 <= 1.03 * pad128) return launch256(ga, a_kcontig != 0, gb, b_kcontig != 0, o, epi, s);
+    }
+    {
+      const char* e = getenv("W2L_GEMM_LOADER");  // loader-wave variant (gemm_loader.hpp)
+      if ((e ? atoi(e) : 0) && ga.bytes && gb.bytes) return launch128w(ga, a_kcontig != 0, gb, b_kcontig != 0, o, epi, s);
     }
     return launch128g(ga, a_kcontig != 0, gb, b_kcontig != 0, o, epi, s);
   }

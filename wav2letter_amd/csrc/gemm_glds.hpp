@@ -136,22 +136,10 @@ __device__ __forceinline__ void gemm128g_epilogue_wide(const GemmOut& out, int m
   const int c4 = 4 * (lane & 15), rq = lane >> 4;
   const int n = n0 + wn + c4;
   const bool fullVec = n + 3 < out.N;
-  // The mask (ReLU/dropout pattern of the producing layer) or the accumulate operand is fetched for all 16
-  // rows of this lane BEFORE the LDS turn-around, so its global latency (1-2 us, once per tile, with every
-  // workgroup at a tile boundary at the same time) overlaps the LDS work instead of preceding the stores.
+  // (Fetching the mask / accumulate operand for all 16 rows ahead of the LDS turn-around was tried: no gain on MI355X,
+  // +40 VGPRs.  The kernel stays under 192 VGPRs so that two workgroups leave 128 registers per SIMD lane free -- room
+  // for a communication kernel's waves to co-reside during the overlapped gradient all-reduce.)
   const float* accSrc = out.addend ? out.addend : out.C;
-  const float* exSrc = (EPI & EPI_MASK) ? out.mask : ((EPI & EPI_ACCUM) ? accSrc : nullptr);
-  f32x4 ex[2][8];
-  if (exSrc && fullVec) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        int m = m0 + wm + 32 * i + 4 * p + rq;
-        if (m > out.M - 1) m = out.M - 1;  // rows past M are loaded (valid address) and dropped
-        ex[i][p] = *(const f32x4*)(exSrc + (size_t)m * out.ldc + n);
-      }
-  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -178,16 +166,14 @@ __device__ __forceinline__ void gemm128g_epilogue_wide(const GemmOut& out, int m
       }
       if (fullVec) {
         if (EPI & EPI_MASK) {
+          const f32x4 mk = *(const f32x4*)(out.mask + (size_t)m * out.ldc + n);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = ex[i][p][e] > 0.f ? v[e] * out.maskScale : 0.f;
-          if (EPI & EPI_ACCUM) {  // (both flags: the accumulate operand is read in place)
-            const f32x4 o = *(const f32x4*)(accSrc + (size_t)m * out.ldc + n);
+          for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] * out.maskScale : 0.f;
+        }
+        if (EPI & EPI_ACCUM) {
+          const f32x4 o = *(const f32x4*)(accSrc + (size_t)m * out.ldc + n);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += o[e];
-          }
-        } else if (EPI & EPI_ACCUM) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += ex[i][p][e];
+          for (int e = 0; e < 4; ++e) v[e] += o[e];
         }
         f32x4 w4;
         w4[0] = v[0]; w4[1] = v[1]; w4[2] = v[2]; w4[3] = v[3];
