@@ -9,6 +9,9 @@
 // iteration) and is the only one that waits on vmcnt; the four compute waves never wait for vector memory inside
 // the K loop (raw s_barrier + lgkmcnt only), so their stores drain in the background.  As a bonus the LDS-DMA issue
 // slots leave the MFMA waves' instruction streams.
+// MEASURED (profiles/r01_run24_gemm_loader_wave_ab.log): correct and bit-identical, but SLOWER -- forward 106 vs 112 TF/s
+// on the K = 800 shape, 136 vs 142 at 4096^3, and 72-88 vs 113-146 TF/s when both operands are k-contiguous (one wave
+// issuing 32 pieces per iteration makes the issue path itself the critical path).  Kept behind W2L_GEMM_LOADER=1.
 // Same tiles, fragments, schedule (persistent segments, stream-K tail, in-kernel slab reduction) and results as
 // gemm128g_kernel; every barrier is executed by all five waves (the loader walks the same control flow with the
 // work masked off).
