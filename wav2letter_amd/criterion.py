@@ -223,9 +223,24 @@ class ASGLoss(SequenceCriterion):
         self.transitions = torch.nn.Parameter(torch.eye(N) * float(transdiag))
         self.fac = ForceAlignmentCriterion(N, scalemode, self.transitions)
         self.fcc = FullConnectionCriterion(N, scalemode, self.transitions)
+        self._side = None
 
     def forward(self, emission, target):
-        return self.fcc(emission, target) - self.fac(emission, target)
+        # FCC and FAC are independent length-T serial scans that use B of the 256 CUs each: run them side by side
+        # (FAC on a side stream).  autograd replays each node's backward on its forward stream, so the two backward
+        # scans overlap too.
+        if not emission.is_cuda:
+            return self.fcc(emission, target) - self.fac(emission, target)  # raises the reference's error
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=emission.device)
+        cur = torch.cuda.current_stream(emission.device)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            fac = self.fac(emission, target)
+        fcc = self.fcc(emission, target)
+        cur.wait_stream(self._side)
+        fac.record_stream(cur)
+        return fcc - fac
 
     def viterbiPath(self, emission, inputSize=None):
         _emission_checks(emission)

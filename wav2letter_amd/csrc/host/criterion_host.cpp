@@ -40,9 +40,31 @@ class CTCLossImpl : public SequenceCriterion {
   int mode_;
 };
 
+// FCC and FAC are independent given the emissions: each is a length-T serial scan that occupies B of the 256 CUs
+// (one wave / workgroup per utterance), so the two run SIDE BY SIDE on the caller's stream and a library-owned side
+// stream (fork / join with events); ASG forward = max(FCC, FAC) instead of their sum, same for backward.
 class ASGLossImpl : public SequenceCriterion {
  public:
   ASGLossImpl(int N, int mode, double transdiag) : N_(N), mode_(mode), transdiag_(transdiag) {}
+  ~ASGLossImpl() override {
+    if (side_) (void)hipStreamDestroy(side_);
+    if (fork_) (void)hipEventDestroy(fork_);
+    if (join_) (void)hipEventDestroy(join_);
+  }
+  hipStream_t fork(hipStream_t main) {  // side stream that has waited for everything enqueued on `main` so far
+    if (!side_) {
+      hipCheck(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking), "asg side stream");
+      hipCheck(hipEventCreateWithFlags(&fork_, hipEventDisableTiming), "asg event");
+      hipCheck(hipEventCreateWithFlags(&join_, hipEventDisableTiming), "asg event");
+    }
+    hipCheck(hipEventRecord(fork_, main), "asg fork");
+    hipCheck(hipStreamWaitEvent(side_, fork_, 0), "asg fork");
+    return side_;
+  }
+  void join(hipStream_t main) {
+    hipCheck(hipEventRecord(join_, side_), "asg join");
+    hipCheck(hipStreamWaitEvent(main, join_, 0), "asg join");
+  }
   std::string prettyString() const override { return "AutoSegmentationCriterion"; }
   size_t paramFloats() const override { return ((size_t)N_ * N_ + 3) / 4 * 4; }
   void initParams(float* host) const override {
@@ -72,15 +94,19 @@ class ASGLossImpl : public SequenceCriterion {
     if (N != N_) throw std::invalid_argument("ASGLoss: N doesn't match with the letter size");
     Ws w = carve(ws, B, T, N, L);
     w2lCheck(w2l_batch_target_size(B, L, T, target, w.ts, c.stream), "asg target size");
+    hipStream_t s2 = fork(c.stream);
+    w2lCheck(w2l_fac_forward(B, T, N, L, mode_, em, target, w.ts, trans, w.loss2, w.fac, s2), "fac forward");
     w2lCheck(w2l_fcc_forward(B, T, N, mode_, em, w.ts, trans, loss, w.fcc, c.stream), "fcc forward");
-    w2lCheck(w2l_fac_forward(B, T, N, L, mode_, em, target, w.ts, trans, w.loss2, w.fac, c.stream), "fac forward");
+    join(c.stream);
     w2lCheck(w2l_axpy(loss, w.loss2, (size_t)B, -1.f, c.stream), "asg loss");
   }
   void backward(Ctx& c, int B, int T, int N, int L, const float*, const int* target, const float* gradLoss,
                 float* dEm, void* ws, float* trans, float* dTrans) override {
     Ws w = carve(ws, B, T, N, L);
+    hipStream_t s2 = fork(c.stream);
+    w2lCheck(w2l_fac_backward(B, T, N, L, target, w.ts, gradLoss, w.dx2, w.dt2, w.fac, s2), "fac backward");
     w2lCheck(w2l_fcc_backward(B, T, N, trans, gradLoss, dEm, dTrans, w.fcc, c.stream), "fcc backward");
-    w2lCheck(w2l_fac_backward(B, T, N, L, target, w.ts, gradLoss, w.dx2, w.dt2, w.fac, c.stream), "fac backward");
+    join(c.stream);
     w2lCheck(w2l_axpy(dEm, w.dx2, (size_t)B * T * N, -1.f, c.stream), "asg dx");
     w2lCheck(w2l_axpy(dTrans, w.dt2, (size_t)N * N, -1.f, c.stream), "asg dtrans");
   }
@@ -92,6 +118,8 @@ class ASGLossImpl : public SequenceCriterion {
  private:
   int N_, mode_;
   double transdiag_;
+  hipStream_t side_ = nullptr;
+  hipEvent_t fork_ = nullptr, join_ = nullptr;
 };
 
 }  // namespace
