@@ -229,6 +229,27 @@ def test_gemm_asymmetric_identity():
     assert (got.cpu().numpy() == Bm).all()
 
 
+@pytest.mark.parametrize("M,N", [(1, 5), (63, 1), (513, 37), (777, 9998), (6016, 1440), (24000, 800), (100000, 6), (70, 2402)])
+def test_colsum_bias_gradient(M, N):
+    """bias gradient column sums (fl::Linear / Conv2D backward): fp64 sum within 1e-4 relative, run-to-run bit-identical,
+    float4 / float2 / scalar column paths and the unaligned-base case"""
+    from wav2letter_amd import ops
+    g = torch.Generator().manual_seed(M * 31 + N)
+    x = torch.randn(M, N, generator=g) + 0.25
+    want = x.double().sum(0).numpy()
+    xd = dev(x)
+    got = ops.colsum(xd)
+    again = ops.colsum(xd)
+    assert torch.equal(got, again)
+    scale = np.abs(x.numpy()).sum(0) + 1.0
+    assert (np.abs(got.cpu().numpy() - want) / scale).max() < 1e-5
+    if N % 4 == 0 and M > 1:     # base pointer off 16-byte alignment -> narrower path, same sums
+        flat = dev(torch.cat([torch.zeros(1), x.flatten()]))
+        shifted = flat[1:].view(M, N)
+        got2 = ops.colsum(shifted)
+        assert (np.abs(got2.cpu().numpy() - want) / scale).max() < 1e-5
+
+
 @pytest.mark.parametrize("M,K,N", [(37, 20, 13), (300, 800, 2400), (188, 1440, 9998)])
 def test_linear_fwd_bwd(oracle, M, K, N):
     from wav2letter_amd import ops
@@ -264,7 +285,10 @@ CONV_CASES = [
     (2, 5, 7, 3, 20, 9, 1, 8, 0),         # causal padding, odd channel counts
     (2, 14, 14, 32, 100, 21, 1, 10, 10),  # persistent kernel, c = 14, 4 time blocks x 2 row blocks
     (1, 18, 18, 16, 70, 21, 1, 10, 10),   # persistent kernel, c = 18 (two MFMA column tiles, 16-frame tiles)
-    (2, 10, 14, 32, 61, 21, 2, 10, 10),   # persistent kernel, strided stage transition (forward only on this path)
+    (2, 10, 14, 32, 61, 21, 2, 10, 10),   # persistent kernel, strided stage transition: backward-data = 2 phase launches
+    (2, 14, 18, 16, 60, 21, 2, 10, 10),   # second stage transition (18 -> 14 channel phase kernels), even T
+    (1, 10, 10, 16, 47, 7, 3, 2, 3),      # stride 3: three phases with 3 / 2 / 2 taps
+    (1, 12, 8, 16, 23, 4, 4, 0, 1),       # stride == kw: every phase has one tap
     (8, 10, 10, 16, 2200, 21, 1, 10, 10), # 552 tiles on 512 persistent workgroups: two tiles per workgroup + prefetch
 ]
 
@@ -288,6 +312,34 @@ def test_conv_fwd_bwd(oracle, B, Cin, Cout, H, T, kw, stride, padl, padr):
     assert rel(from_fm(dx.cpu().numpy()), odx) < TOL
     assert rel(dw.cpu().numpy(), w_to_dev(odw)) < TOL
     assert rel(db, odb) < TOL
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,T,kw,stride,padl,padr", [(2, 10, 14, 32, 61, 21, 2, 10, 10), (1, 14, 18, 16, 40, 21, 2, 10, 10),
+                                                                (1, 10, 10, 16, 47, 7, 3, 2, 3), (1, 10, 10, 16, 40, 21, 1, 10, 10)])
+def test_conv_backward_data_accumulate_and_add(oracle, B, Cin, Cout, H, T, kw, stride, padl, padr):
+    """the two fused forms of Conv2D backward-data (dx += ..., dx = add + ...) on the phase-decomposed strided path
+    and the stride-1 path: equal to the plain result plus the addend"""
+    import ctypes as C
+    from wav2letter_amd import ops, _lib
+    rng = np.random.default_rng(T)
+    x = rng.normal(size=(B, Cin, H, T)).astype(np.float32)
+    w = (rng.normal(size=(Cout, Cin, kw)) / np.sqrt(Cin * kw)).astype(np.float32)
+    To = (T + padl + padr - kw) // stride + 1
+    dy = rng.normal(size=(B, Cout, H, To)).astype(np.float32)
+    odx, _, _ = oracle.conv_bwd(x, w, dy, stride, padl, padr)
+    xd, wd, dyd = dev(to_fm(x)), dev(w_to_dev(w)), dev(to_fm(dy))
+    d = ops.conv_desc(xd, wd, stride, padl, padr)
+    L = _lib.lib()
+    base = rng.normal(size=x.shape).astype(np.float32)
+    acc = dev(to_fm(base))
+    ops.check(L.w2l_conv_backward_data(C.byref(d), ops._p(dyd), ops._p(wd), ops._p(acc), 1, ops._s()), "bwd data accumulate")
+    assert rel(from_fm(acc.cpu().numpy()), odx + base) < TOL
+    add = dev(to_fm(base))
+    out = torch.empty_like(add)
+    ops.check(L.w2l_conv_backward_data_add(C.byref(d), ops._p(dyd), ops._p(wd), ops._p(add), ops._p(out), ops._s()), "bwd data add")
+    assert rel(from_fm(out.cpu().numpy()), odx + base) < TOL
+    ops.check(L.w2l_conv_backward_data_add(C.byref(d), ops._p(dyd), ops._p(wd), ops._p(add), ops._p(add), ops._s()), "bwd data add in place")
+    assert rel(from_fm(add.cpu().numpy()), odx + base) < TOL
 
 
 def test_golden_conv1d_on_device():

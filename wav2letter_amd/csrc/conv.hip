@@ -211,28 +211,80 @@ struct ConvFilterAOp {
   __device__ __forceinline__ void store_bk(float* lds, int ldS, const float (&r)[16], int tid) const { store_t<BM, BK>(lds, ldS, r, tid); }
 };
 
-// column sums: out[n] = sum_m x[m][n]   (bias gradients)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                     size_t M, int N, size_t rowsPerBlock) {
-  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int part = threadIdx.x >> 6;
-  __shared__ float sm[4][64];
+// column sums: out[n] = sum_m x[m][n]   (bias gradients).  Two deterministic passes, no atomics: row-block
+// partial sums (V-wide loads, 4 rows in flight per wave) into the library scratch, then a sum over row-blocks
+// in fixed order.  HBM-bound: M*N*4 bytes read once.
+float* sk_scratch(hipStream_t s, size_t bytes);
+constexpr int kColsumMaxParts = 256;
+
+template <int V>
+__global__ __launch_bounds__(256) void colsum_partial_k(const float* __restrict__ x, float* __restrict__ partial,
+                                                        size_t M, int N, size_t rowsPerBlock) {
+  typedef float vec_t __attribute__((ext_vector_type(V)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = (blockIdx.x * 64 + lane) * V;
+  __shared__ float sm[4][64 * V];
   size_t m0 = (size_t)blockIdx.y * rowsPerBlock;
   size_t m1 = m0 + rowsPerBlock;
   if (m1 > M) m1 = M;
-  float s = 0.f;
-  if (n < N)
-    for (size_t m = m0 + part; m < m1; m += 4) s += x[m * N + n];
-  sm[part][threadIdx.x & 63] = s;
+  vec_t a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (n < N) {
+    const float* col = x + n;
+    size_t m = m0 + wave;
+    for (; m + 12 < m1; m += 16) {
+      vec_t v0 = __builtin_nontemporal_load((const vec_t*)(col + m * N));
+      vec_t v1 = __builtin_nontemporal_load((const vec_t*)(col + (m + 4) * N));
+      vec_t v2 = __builtin_nontemporal_load((const vec_t*)(col + (m + 8) * N));
+      vec_t v3 = __builtin_nontemporal_load((const vec_t*)(col + (m + 12) * N));
+      a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; m < m1; m += 4) a0 += *(const vec_t*)(col + m * N);
+  }
+  vec_t a = (a0 + a1) + (a2 + a3);
+#pragma unroll
+  for (int v = 0; v < V; ++v) sm[wave][lane * V + v] = a[v];
   __syncthreads();
-  if (part == 0 && n < N) atomicAdd(&out[n], sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+  for (int c = threadIdx.x; c < 64 * V; c += 256) {
+    int nn = blockIdx.x * 64 * V + c;
+    if (nn < N) partial[(size_t)blockIdx.y * N + nn] = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_finish_k(const float* __restrict__ partial, float* __restrict__ out, int parts, int N) {
+  int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float s0 = 0.f, s1 = 0.f;
+  int p = 0;
+  for (; p + 1 < parts; p += 2) {
+    s0 += partial[(size_t)p * N + n];
+    s1 += partial[(size_t)(p + 1) * N + n];
+  }
+  if (p < parts) s0 += partial[(size_t)p * N + n];
+  out[n] = s0 + s1;
 }
 
 int colsum(const float* x, float* out, size_t M, int N, hipStream_t s) {
-  W2L_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s));
-  size_t rowsPerBlock = 512;
-  dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + rowsPerBlock - 1) / rowsPerBlock));
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, x, out, M, N, rowsPerBlock);
+  if (N <= 0) return W2L_OK;
+  if (M == 0) {
+    W2L_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s));
+    return W2L_OK;
+  }
+  size_t rowsPerBlock = (M + kColsumMaxParts - 1) / kColsumMaxParts;
+  if (rowsPerBlock < 64) rowsPerBlock = 64;
+  const int parts = (int)((M + rowsPerBlock - 1) / rowsPerBlock);
+  float* partial = sk_scratch(s, (size_t)kSkSlots * 2 * kSlabFloats * sizeof(float));  // shared 64 MiB stream scratch
+  if (!partial || (size_t)parts * N * sizeof(float) > (size_t)kSkSlots * 2 * kSlabFloats * sizeof(float)) return W2L_EHIP;
+  const bool al = (((uintptr_t)x) & 15) == 0;
+  const int V = (al && N % 4 == 0) ? 4 : (al && N % 2 == 0) ? 2 : 1;
+  dim3 grid((unsigned)((N + 64 * V - 1) / (64 * V)), (unsigned)parts);
+  if (V == 4)
+    hipLaunchKernelGGL(colsum_partial_k<4>, grid, dim3(256), 0, s, x, partial, M, N, rowsPerBlock);
+  else if (V == 2)
+    hipLaunchKernelGGL(colsum_partial_k<2>, grid, dim3(256), 0, s, x, partial, M, N, rowsPerBlock);
+  else
+    hipLaunchKernelGGL(colsum_partial_k<1>, grid, dim3(256), 0, s, x, partial, M, N, rowsPerBlock);
+  W2L_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_finish_k, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, partial, out, parts, N);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }
@@ -323,7 +375,7 @@ W2L_API int w2l_conv_backward_data(const w2l_conv_desc* d, const float* dy, cons
   int st = check_desc(d);
   if (st) return st;
   if (!dy || !w || !dx) return W2L_EINVAL;
-  if (tds_path() && tds_conv_applicable(d) && d->stride == 1) {
+  if (tds_path() && tds_conv_applicable(d)) {
     st = tds_conv_backward_data(d, dy, w, dx, accumulate, nullptr, (hipStream_t)stream);
     if (st != W2L_EUNSUPPORTED) return st;
   }
@@ -350,7 +402,7 @@ W2L_API int w2l_conv_backward_data_add(const w2l_conv_desc* d, const float* dy, 
   if (st) return st;
   if (!dy || !w || !dx || !add) return W2L_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (tds_path() && tds_conv_applicable(d) && d->stride == 1) {
+  if (tds_path() && tds_conv_applicable(d)) {
     st = tds_conv_backward_data(d, dy, w, dx, 0, add, s);
     if (st != W2L_EUNSUPPORTED) return st;
   }

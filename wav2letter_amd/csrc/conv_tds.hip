@@ -46,6 +46,9 @@ struct TdsConvP {
   int K, Kp, FS, NF;
   int relu, accum, flip;
   int CinW, CoutW;
+  // phase decomposition of a strided backward-data (tds_conv_backward_data): weight tap of flipped tap j is
+  // tapOff + tapStep*(kw-1-j); output frame u of the launch is frame oOff + oStep*u of a tensor with ToutFull frames
+  int tapOff, tapStep, oOff, oStep, ToutFull;
   int abl;  // timing-only ablations of the probe tool (W2L_TDS_ABL): 1 = no K loop, 2 = no slab staging, 4 = no output
 };
 
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_fwd2_k(TdsConvP p, int nTiles
             src = (size_t)kk * p.Cout + co;
           } else {
             const int tap = kk / p.Cin, c = kk - tap * p.Cin;  // c indexes CoutW, co indexes CinW
-            src = ((size_t)(p.kw - 1 - tap) * p.CinW + co) * p.CoutW + c;
+            src = ((size_t)(p.tapOff + p.tapStep * (p.kw - 1 - tap)) * p.CinW + co) * p.CoutW + c;
           }
         }
         const float t = p.w[src];
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_fwd2_k(TdsConvP p, int nTiles
   const int rstep = CIN ? 16 * CIN + 4 : p.stride * p.FS;
   const int nk = p.Kp >> 2;
   const float* sl = slab + i * p.Cin + (wave * R * p.stride) * p.FS;
-  const size_t gRow = (size_t)p.H * p.Cout;
+  const size_t gRow = (size_t)p.oStep * p.H * p.Cout;
   const int rowLen = kTdsBH * p.Cout, rq = rowLen >> 2;
 
   float biasv[NT];  // once per workgroup: a load per tile would expose a global round trip in every tile's epilogue
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_fwd2_k(TdsConvP p, int nTiles
     int tc = p.Tout - t0;
     if (tc > BT) tc = BT;
     if (p.abl & 4) tc = 0;
-    const size_t gBase = (((size_t)b * p.Tout + t0) * p.H + h0) * p.Cout;
+    const size_t gBase = (((size_t)b * p.ToutFull + p.oOff + (size_t)p.oStep * t0) * p.H + h0) * p.Cout;
     tds_batched_copy4<8>(tc * rq,
         [&](int e) {
           const int t = e / rq, o = (e - t * rq) << 2;
@@ -808,6 +811,7 @@ static TdsConvP make_p(int B, int Tin, int Tout, int H, int Cin, int Cout, int k
   p.Kp = (p.K + 3) & ~3;
   p.FS = kTdsBH * Cin + 4;
   p.NF = (bt - 1) * stride + kw;
+  p.tapOff = 0; p.tapStep = 1; p.oOff = 0; p.oStep = 1; p.ToutFull = Tout;
   return p;
 }
 
@@ -860,8 +864,10 @@ static bool try_launch_fwd2(const TdsConvP& pIn0, hipStream_t s, int* status) {
     int st;
     const int cin = p.stride == 1 ? p.Cin : 0;  // compile-time channel counts of the TDS-CTC recipe; anything else: runtime stride
     if (p.Cout <= 16) {
-      if (bt == 32) st = cin == 10 ? launch_fwd2_t<1, 8, 10>(p, shmem, s) : cin == 14 ? launch_fwd2_t<1, 8, 14>(p, shmem, s) : launch_fwd2_t<1, 8, 0>(p, shmem, s);
-      else st = cin == 10 ? launch_fwd2_t<1, 4, 10>(p, shmem, s) : cin == 14 ? launch_fwd2_t<1, 4, 14>(p, shmem, s) : launch_fwd2_t<1, 4, 0>(p, shmem, s);
+      if (bt == 32) st = cin == 10 ? launch_fwd2_t<1, 8, 10>(p, shmem, s) : cin == 14 ? launch_fwd2_t<1, 8, 14>(p, shmem, s)
+                       : cin == 18 ? launch_fwd2_t<1, 8, 18>(p, shmem, s) : launch_fwd2_t<1, 8, 0>(p, shmem, s);
+      else st = cin == 10 ? launch_fwd2_t<1, 4, 10>(p, shmem, s) : cin == 14 ? launch_fwd2_t<1, 4, 14>(p, shmem, s)
+                : cin == 18 ? launch_fwd2_t<1, 4, 18>(p, shmem, s) : launch_fwd2_t<1, 4, 0>(p, shmem, s);
     } else {
       if (bt == 32) st = cin == 18 ? launch_fwd2_t<2, 8, 18>(p, shmem, s) : launch_fwd2_t<2, 8, 0>(p, shmem, s);
       else st = cin == 18 ? launch_fwd2_t<2, 4, 18>(p, shmem, s) : launch_fwd2_t<2, 4, 0>(p, shmem, s);
@@ -903,15 +909,36 @@ int tds_conv_forward(const w2l_conv_desc* d, const float* x, const float* w, con
   return launch_fwd(p, s);
 }
 
-// stride 1 only: dx = conv(dy, flipped W^T) with left padding kw-1-padl; dx = add + conv (add may be null)
+// dx = conv(dy, flipped W^T) with left padding kw-1-padl; dx = add + conv (add may be null).
+// stride s > 1: one stride-1 launch per phase f = (ti + padl) mod s.  Only the taps tap = f + s*j reach those input
+// frames (ti + padl = s*to + tap), so phase f is a stride-1 correlation of dy with the kw_f = ceil((kw-f)/s) taps
+// W[f + s*j], written to every s-th frame of dx: no zero-stuffed dy, no wasted multiplies, each dx frame written once.
 int tds_conv_backward_data(const w2l_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate,
                            const float* add, hipStream_t s) {
-  if (d->stride != 1) return W2L_EUNSUPPORTED;
-  const int To = tds_out_len(d->T, d->kw, 1, d->padl, d->padr);
-  TdsConvP p = make_p(d->B, To, d->T, d->H, d->Cout, d->Cin, d->kw, 1, d->kw - 1 - d->padl, kTdsBT);
-  p.x = dy; p.w = w; p.y = dx; p.accum = accumulate; p.add = add; p.flip = 1;
-  p.CinW = d->Cin; p.CoutW = d->Cout;
-  return launch_fwd(p, s);
+  const int To = tds_out_len(d->T, d->kw, d->stride, d->padl, d->padr);
+  if (d->stride == 1) {
+    TdsConvP p = make_p(d->B, To, d->T, d->H, d->Cout, d->Cin, d->kw, 1, d->kw - 1 - d->padl, kTdsBT);
+    p.x = dy; p.w = w; p.y = dx; p.accum = accumulate; p.add = add; p.flip = 1;
+    p.CinW = d->Cin; p.CoutW = d->Cout;
+    return launch_fwd(p, s);
+  }
+  const int st = d->stride;
+  if (st > d->kw || getenv("W2L_TDS_BWD_STRIDED_OFF")) return W2L_EUNSUPPORTED;  // every phase needs at least one tap
+  for (int f = 0; f < st; ++f) {
+    const int kwf = (d->kw - f + st - 1) / st;
+    const int c0 = (((f - d->padl) % st) + st) % st;   // first input frame of the phase
+    if (c0 >= d->T) continue;
+    const int U = (d->T - c0 + st - 1) / st;           // input frames of the phase
+    const int s0 = (c0 + d->padl - f) / st;            // dy frame of tap f at u = 0
+    TdsConvP p = make_p(d->B, To, U, d->H, d->Cout, d->Cin, kwf, 1, kwf - 1 - s0, kTdsBT);
+    p.x = dy; p.w = w; p.y = dx; p.accum = accumulate; p.add = add; p.flip = 1;
+    p.CinW = d->Cin; p.CoutW = d->Cout;
+    p.tapOff = f; p.tapStep = st; p.oOff = c0; p.oStep = st; p.ToutFull = d->T;
+    int st2 = W2L_OK;
+    if (!try_launch_fwd2(p, s, &st2)) return f == 0 ? W2L_EUNSUPPORTED : W2L_EHIP;  // geometry is the same for every phase
+    if (st2 != W2L_OK) return st2;
+  }
+  return W2L_OK;
 }
 
 int tds_conv_backward_filter(const w2l_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,

@@ -36,6 +36,14 @@ def linear_forward(x, w, bias=None, relu=False):
     return y
 
 
+def colsum(x):
+    """out[n] = sum_m x[m][n] (bias gradient): deterministic two-pass sum"""
+    M, N = x.shape
+    out = torch.empty(N, device=x.device, dtype=torch.float32)
+    check(_lib.lib().w2l_colsum(_p(x), _p(out), M, N, _s()), "colsum")
+    return out
+
+
 def linear_backward(x, w, dy, mask_src=None, mask_scale=1.0):
     M, K = x.shape
     N = w.shape[1]
