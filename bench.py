@@ -281,7 +281,7 @@ def main():
                                "9998 classes, batch %d/GPU, fp32, SGD+momentum, CTC" % (T, B),
                    "global_batch": total_batch, "frames": T, "emission_frames": Tout, "parallelism": f"dp{world}",
                    "params": int(tr.n_net), "final_loss": round(last_loss, 4)},
-        "roofline": {"bound": "mfma", "kernel": "gemm128g_kernel (fp32 v_mfma_f32_32x32x2_f32, 128x128x32 tiles, persistent, buffer LDS-DMA staging, stream-K tail + fix-up; includes the few gemm128_kernel launches on unaligned shapes)",
+        "roofline": {"bound": "mfma", "kernel": "gemm128g_kernel / gemm160_kernel (fp32 v_mfma_f32_32x32x2_f32; 128x128x32 tiles, or 128x160 / 160x128 where 128 leaves a ragged tile column; persistent, buffer LDS-DMA staging, stream-K tail reduced in-kernel; includes the few gemm128_kernel launches on unaligned shapes)",
                      "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic("gemm128g")[0],
                      "traffic_detail": pmc_traffic("gemm128g")[1],

@@ -181,13 +181,16 @@ def test_gemm_in_kernel_slab_reduction_is_stable(M, N, K):
     Bm = (torch.randn(K, N, generator=g) / K ** 0.5).cuda()
     bias = torch.randn(N, generator=g).cuda()
     os.environ["W2L_GEMM_INFIX"] = "0"
+    os.environ["W2L_GEMM_T160"] = "0"   # the separate fix-up launch exists for the 128x128 tile only
     try:
         ref = ops.gemm(A, Bm, True, False, bias, relu=True)
-    finally:
         os.environ.pop("W2L_GEMM_INFIX")
-    for it in range(25):
-        got = ops.gemm(A, Bm, True, False, bias, relu=True)
-        assert torch.equal(got, ref), it
+        for it in range(25):
+            got = ops.gemm(A, Bm, True, False, bias, relu=True)
+            assert torch.equal(got, ref), it
+    finally:
+        os.environ.pop("W2L_GEMM_INFIX", None)
+        os.environ.pop("W2L_GEMM_T160")
     want = torch.relu(A.double() @ Bm.double() + bias.double()).cpu().numpy()
     assert rel(ref, want) < TOL
 
@@ -208,6 +211,7 @@ def test_gemm_loader_wave_variant(M, N, K, akc, bkc):
     Ad = (A if akc else A.T.contiguous()).cuda()
     Bd = (Bm.T.contiguous() if bkc else Bm).cuda()
     os.environ["W2L_GEMM_LOADER"] = "1"
+    os.environ["W2L_GEMM_T160"] = "0"   # both sides on the 128x128 tile (the 160-wide kernel splits stream-K ranges differently)
     try:
         got = ops.gemm(Ad, Bd, akc, bkc, bias.cuda(), relu=True)
         for _ in range(5):
@@ -216,8 +220,76 @@ def test_gemm_loader_wave_variant(M, N, K, akc, bkc):
         old = ops.gemm(Ad, Bd, akc, bkc, bias.cuda(), relu=True)
     finally:
         os.environ.pop("W2L_GEMM_LOADER")
+        os.environ.pop("W2L_GEMM_T160")
     assert torch.equal(got, old)
     assert rel(got, np.maximum(want, 0)) < TOL
+
+
+@pytest.mark.parametrize("M,N,K", [(4, 4, 32),             # one clamped tile, one K step
+                                    (260, 388, 96),        # ragged edge tiles in both directions
+                                    (1028, 2052, 1440),    # pure stream-K ranges crossing tiles
+                                    (6016, 1440, 4320),    # TDS fc2 (c = 18): 9 x 160 columns
+                                    (24000, 800, 2400),    # TDS fc2 (c = 10): 5 x 160 columns, 2 rounds + stream-K tail
+                                    (800, 2400, 24000),    # dW: 5 x 160 rows (TALL), very long reduction
+                                    (320, 160, 64)])       # exactly two / one 160-tiles, two K steps
+@pytest.mark.parametrize("akc,bkc", [(True, False), (True, True), (False, False), (False, True)])
+@pytest.mark.parametrize("mode", ["2", "3"])
+def test_gemm_160_wide_tiles(M, N, K, akc, bkc, mode):
+    """the 128x160 (W2L_GEMM_T160=2 forces it) and 160x128 (=3) tile kernels on every eligible shape: float64 product,
+    run-to-run bit-identity (in-kernel stream-K slab reduction), bias + ReLU, agreement with the 128x128 kernel"""
+    import os
+    from wav2letter_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(11 * M + 3 * N + K)
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(K, N, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    want = (A.double() @ Bm.double() + bias.double()).numpy()
+    Ad = (A if akc else A.T.contiguous()).cuda()
+    Bd = (Bm.T.contiguous() if bkc else Bm).cuda()
+    os.environ["W2L_GEMM_T160"] = mode
+    try:
+        got = ops.gemm(Ad, Bd, akc, bkc, bias.cuda())
+        for _ in range(4):
+            assert torch.equal(got, ops.gemm(Ad, Bd, akc, bkc, bias.cuda()))
+        gotr = ops.gemm(Ad, Bd, akc, bkc, bias.cuda(), relu=True)
+        os.environ["W2L_GEMM_T160"] = "0"
+        old = ops.gemm(Ad, Bd, akc, bkc, bias.cuda())
+    finally:
+        os.environ.pop("W2L_GEMM_T160")
+    assert rel(got, want) < TOL
+    assert rel(gotr, np.maximum(want, 0)) < TOL
+    assert rel(got, old.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("mode", ["2", "3"])
+def test_gemm_160_fused_epilogues(mode):
+    """dropout / mask / addend epilogues of the fl::Linear calls through the 160-wide kernels equal the 128x128 kernel's"""
+    import os
+    from wav2letter_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(160)
+    M, K, N = 700, 800, 2400
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(K, N, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    dy = torch.randn(M, N, generator=g).cuda()
+    add = torch.randn(M, K, generator=g).cuda()
+    msk = torch.randn(M, K, generator=g).cuda()
+    outs = {}
+    for m in (mode, "0"):
+        os.environ["W2L_GEMM_T160"] = m
+        try:
+            outs[m] = (ops.linear_forward(x, w, b, relu=True), ops.linear_forward_dropout(x, w, b, False, 0.2, 1234, 7),
+                       ops.linear_backward(x, w, dy, mask_src=msk, mask_scale=1.25), ops.linear_backward_data_add(dy, w, add))
+        finally:
+            os.environ.pop("W2L_GEMM_T160")
+    new, old = outs[mode], outs["0"]
+    assert rel(new[0], old[0].cpu().numpy()) < 1e-5
+    kept_new, kept_old = new[1] != 0, old[1] != 0
+    assert torch.equal(kept_new, kept_old)     # same stateless mask on the same flat indices
+    assert rel(new[1], old[1].cpu().numpy()) < 1e-5
+    for a, c in zip(new[2], old[2]):
+        assert rel(a, c.cpu().numpy()) < 1e-5
+    assert rel(new[3], old[3].cpu().numpy()) < 1e-5
 
 
 def test_gemm_asymmetric_identity():

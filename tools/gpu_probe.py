@@ -56,6 +56,38 @@ def probe_gemm():
         os.environ["W2L_GEMM_SK"] = "1"
 
 
+def probe_gemm160():
+    """TDS fc shapes: 128x128 tile (W2L_GEMM_T160=0) against the padded-area rule (default) -- after a burn-in, the
+    first measurement of a process runs at ramping clocks (profiles/r01_run30_gemm_offsets.log)"""
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    a = torch.randn(4096, 4096, device="cuda")
+    c = torch.empty(4096, 4096, device="cuda")
+    timeit(lambda: L.w2l_linear_forward(4096, 4096, 4096, a.data_ptr(), a.data_ptr(), None, c.data_ptr(), 0, s), n=60)
+    shapes = [("fc1 s1", 24000, 800, 2400), ("fc2 s1", 24000, 2400, 800), ("fc1 s2", 12000, 1120, 3360),
+              ("fc2 s2", 12000, 3360, 1120), ("fc1 s3", 6016, 1440, 4320), ("fc2 s3", 6016, 4320, 1440), ("4096^3", 4096, 4096, 4096)]
+    tot = {"0": 0.0, "1": 0.0, "2": 0.0, "3": 0.0}
+    for name, M, K, N in shapes:
+        x = torch.randn(M, K, device="cuda")
+        w = torch.randn(K, N, device="cuda") / K ** 0.5
+        b = torch.randn(N, device="cuda")
+        dy = torch.randn(M, N, device="cuda")
+        y = torch.empty(M, N, device="cuda")
+        dx = torch.empty(M, K, device="cuda")
+        dw = torch.empty(K, N, device="cuda")
+        fl = 2.0 * M * N * K
+        for mode in (os.environ.get("PROBE_T160_MODES", "0,1,0,1").split(",")):
+            os.environ["W2L_GEMM_T160"] = mode
+            tf = timeit(lambda: L.w2l_linear_forward(M, K, N, x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), 1, s), n=20)
+            td = timeit(lambda: L.w2l_linear_backward_data(M, K, N, dy.data_ptr(), w.data_ptr(), dx.data_ptr(), 0, None, 1.0, s), n=20)
+            tw = timeit(lambda: L.w2l_linear_backward_weight(M, K, N, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), s), n=20)
+            tot[mode] += tf + td + tw
+            print(f"[gemm160 t160={mode}] {name:7s} M={M} K={K} N={N}: fwd {tf * 1e3:.0f} us {fl / tf / 1e9:.1f} TF | "
+                  f"dX {td * 1e3:.0f} us {fl / td / 1e9:.1f} TF | dW {tw * 1e3:.0f} us {fl / tw / 1e9:.1f} TF", flush=True)
+    os.environ.pop("W2L_GEMM_T160")
+    print(f"[gemm160] sum over shapes (two passes each): 128x128 {tot['0']:.2f} ms, padded-area rule {tot['1']:.2f} ms", flush=True)
+
+
 def probe_gemmfwd():
     """forward GEMM only (ablation runs: W2L_GEMM_ABL is read once per process)"""
     L = _lib.lib()
@@ -197,6 +229,6 @@ if __name__ == "__main__":
     print("device:", torch.cuda.get_device_name(0), flush=True)
     for w in which:
         t0 = time.time()
-        {"gemm": probe_gemm, "gemmfwd": probe_gemmfwd, "ln": probe_ln, "conv": probe_conv, "asg": probe_asg, "fccbig": probe_fccbig, "fccstream": probe_fccstream,
+        {"gemm": probe_gemm, "gemm160": probe_gemm160, "gemmfwd": probe_gemmfwd, "ln": probe_ln, "conv": probe_conv, "asg": probe_asg, "fccbig": probe_fccbig, "fccstream": probe_fccstream,
          "vitbig": probe_vitbig}[w]()
         print(f"[{w}] done in {time.time() - t0:.1f} s", flush=True)

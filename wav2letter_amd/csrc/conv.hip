@@ -272,7 +272,7 @@ int colsum(const float* x, float* out, size_t M, int N, hipStream_t s) {
   size_t rowsPerBlock = (M + kColsumMaxParts - 1) / kColsumMaxParts;
   if (rowsPerBlock < 64) rowsPerBlock = 64;
   const int parts = (int)((M + rowsPerBlock - 1) / rowsPerBlock);
-  float* partial = sk_scratch(s, (size_t)kSkSlots * 2 * kSlabFloats * sizeof(float));  // shared 64 MiB stream scratch
+  float* partial = sk_scratch(s, kSkScratchBytes);  // shared 64 MiB stream scratch
   if (!partial || (size_t)parts * N * sizeof(float) > (size_t)kSkSlots * 2 * kSlabFloats * sizeof(float)) return W2L_EHIP;
   const bool al = (((uintptr_t)x) & 15) == 0;
   const int V = (al && N % 4 == 0) ? 4 : (al && N % 2 == 0) ? 2 : 1;

@@ -956,7 +956,7 @@ int tds_conv_backward_filter(const w2l_conv_desc* d, const float* x, const float
   if (shmem > 160 * 1024) return W2L_EUNSUPPORTED;
   const size_t partFloats = (size_t)blocks * rowTiles * 16 * 16 * NT;
   // partial sums live in the library's per-stream scratch (shared with the stream-K slabs: same stream => ordered)
-  float* partial = sk_scratch(s, (size_t)kSkSlots * 2 * kSlabFloats * sizeof(float));
+  float* partial = sk_scratch(s, kSkScratchBytes);
   if (!partial || partFloats > (size_t)kSkSlots * 2 * kSlabFloats) return W2L_EUNSUPPORTED;
   const double flops = 2.0 * d->B * To * (double)d->H * p.K * d->Cout;
   // pipelined kernel: whole mel blocks, float4-addressable rows, piece counts within the register budget

@@ -27,6 +27,7 @@
 #include "gemm_glds.hpp"
 #include "gemm_p3.hpp"
 #include "gemm_loader.hpp"
+#include "gemm_t160.hpp"
 
 namespace w2l {
 
@@ -147,6 +148,12 @@ int gemm_f32(const float* A, int lda, int a_kcontig, const float* B, int ldb, in
     {
       const char* e = getenv("W2L_GEMM_LOADER");  // loader-wave variant (gemm_loader.hpp)
       if ((e ? atoi(e) : 0) && ga.bytes && gb.bytes) return launch128w(ga, a_kcontig != 0, gb, b_kcontig != 0, o, epi, s);
+    }
+    // 160-wide tiles where 128 leaves a ragged last tile column / row (every TDS fc shape: gemm_t160.hpp)
+    if (const int which = t160_choice(ga, gb, o)) {
+      bool launched = false;
+      const int st = launch160(ga, a_kcontig != 0, gb, b_kcontig != 0, o, epi, which, s, &launched);
+      if (st != W2L_OK || launched) return st;
     }
     return launch128g(ga, a_kcontig != 0, gb, b_kcontig != 0, o, epi, s);
   }

@@ -252,6 +252,9 @@ struct SkPlan {
 };
 constexpr int kSkSlots = 512;           // resident 256-thread workgroups (2 per CU)
 constexpr int kSlabFloats = 128 * 128;
+// one stream scratch serves every user (stream-K slabs of the 128x128 and 128x160 kernels, conv filter partials,
+// column-sum partials): all of them request THIS size so the buffer is allocated once per stream
+constexpr size_t kSkScratchBytes = (size_t)kSkSlots * 2 * (128 * 160) * sizeof(float);
 
 __host__ __device__ inline long long sk_begin(const SkPlan& p, int s) {
   return (long long)p.skTiles * p.kTiles * s / p.skBlocks;
@@ -268,10 +271,10 @@ __host__ __device__ inline void sk_tile_xy(const SkPlan& p, int t, int& bx, int&
   bx = tin / gsize;
 }
 
-inline SkPlan make_sk_plan(int M, int N, int K, bool allowSk) {
+inline SkPlan make_sk_plan(int M, int N, int K, bool allowSk, int tileM = 128, int tileN = 128) {
   SkPlan p;
-  p.tilesM = (M + 127) / 128;
-  p.tilesN = (N + 127) / 128;
+  p.tilesM = (M + tileM - 1) / tileM;
+  p.tilesN = (N + tileN - 1) / tileN;
   p.kTiles = (K + 31) / 32;
   const int tiles = p.tilesM * p.tilesN;
   p.dpTiles = tiles; p.skTiles = 0; p.skBlocks = 0; p.slabs = nullptr; p.grouped = 0; p.counters = nullptr;
@@ -644,7 +647,7 @@ inline int launch128(const AOp& a, const BOp& b, GemmOut o, int epi, int splitk,
   const size_t shmem = 2 * (size_t)BK * ((128 + AOp::kPad) + (128 + BOp::kPad)) * sizeof(float);
   SkPlan plan = make_sk_plan(o.M, o.N, o.K, sk_enabled());
   if (plan.skBlocks > 0) {
-    plan.slabs = sk_scratch(s, (size_t)kSkSlots * 2 * kSlabFloats * sizeof(float));
+    plan.slabs = sk_scratch(s, kSkScratchBytes);
     if (!plan.slabs) plan = make_sk_plan(o.M, o.N, o.K, false);
   }
   dim3 grid((unsigned)(plan.dpTiles + plan.skBlocks)), block(256);

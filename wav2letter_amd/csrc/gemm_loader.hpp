@@ -224,7 +224,7 @@ inline int launch128w(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o,
   SkPlan plan = make_sk_plan(o.M, o.N, o.K, sk_enabled());
   plan.grouped = 1;
   if (plan.skBlocks > 0) {
-    plan.slabs = sk_scratch(s, (size_t)kSkSlots * 2 * kSlabFloats * sizeof(float));
+    plan.slabs = sk_scratch(s, kSkScratchBytes);
     if (!plan.slabs) { plan = make_sk_plan(o.M, o.N, o.K, false); plan.grouped = 1; }
     if (plan.skBlocks > 0 && plan.skTiles <= 1024) plan.counters = sk_counters(s);
   }

@@ -350,7 +350,7 @@ inline int launch256(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o, 
   epi &= ~EPI_ATOMIC;
   SkPlan plan = make_sk_plan_p3(o.M, o.N, o.K, sk_enabled());
   if (plan.skBlocks > 0) {
-    plan.slabs = sk_scratch(s, (size_t)kSkSlots * 2 * kSlabFloats * sizeof(float));  // same 64 MiB: 256 x 2 x 128 KiB
+    plan.slabs = sk_scratch(s, kSkScratchBytes);  // same 64 MiB: 256 x 2 x 128 KiB
     if (!plan.slabs) plan = make_sk_plan_p3(o.M, o.N, o.K, false);
   }
   int workers = plan.dpTiles < kP3Slots ? plan.dpTiles : kP3Slots;
