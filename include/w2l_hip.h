@@ -86,6 +86,23 @@ int w2l_fac_viterbi(int B, int T, int N, int L, const float* input, const int* t
                     const int* targetSize, const float* trans, int* bestPaths,
                     void* workspace, w2l_stream_t stream);
 
+/* LinSegCriterion (recipes/slimIPL/src/Train.cpp:589-617, --linseg): ASG on the target stretched linearly over the
+ * T frames.  Flashlight getLinearTarget [UNVENDORED]: linTarget[b][t] = target[b][t * L_b / T], L_b = leading
+ * non-negative entries of target[b][0..L); a row with L_b == 0 or L_b > T is filled with -1. */
+int w2l_linear_target(int B, int L, int T, const int* target, int* linTarget /*[B][T]*/,
+                      w2l_stream_t stream);
+/* ForceAlignmentCriterion<float> on a length-T target (one alignment: label path[b][t] at frame t):
+ * loss[b] = s_b * (sum_t input[b][t][y_t] + sum_{t>=1} trans[y_t][y_{t-1}]), target size = T in s_b.
+ * A row of -1 gives loss 0 and zero gradients (as w2l_fac_* do for an empty target). */
+int w2l_fac_fullpath_forward(int B, int T, int N, int scaleMode, const float* input,
+                             const int* path, const float* trans, float* loss,
+                             w2l_stream_t stream);
+/* inputGrad [B][T][N] and transGrad [N][N] are OVERWRITTEN (transGrad summed over b; bit-reproducible
+ * for N <= 64, float atomics above). */
+int w2l_fac_fullpath_backward(int B, int T, int N, int scaleMode, const int* path,
+                              const float* grad, float* inputGrad, float* transGrad,
+                              w2l_stream_t stream);
+
 /* ViterbiPath<float>: max-product path, first-max tie break, BIT-EXACT with the
  * CPU recursion (fp32 adds in the order (delta[j] + trans[i][j]) + x[t][i]). */
 size_t w2l_viterbi_workspace_size(int B, int T, int N);
@@ -231,6 +248,9 @@ int w2l_trainer_update(void* h, float lr, float lrcrit, float momentum, float ma
                        float totalBatch, int clampCrit, void* stream);
 int w2l_trainer_viterbi(void* h, const float* emission, int* path, void* stream);
 int w2l_trainer_set_step(void* h, uint32_t step);
+/* --linseg=n (recipes/slimIPL/src/Train.cpp:589-617, :1866-1883): the first n updates of an ASG run use
+ * LinSegCriterion on the ASG criterion's own transitions.  Call before w2l_trainer_plan. */
+int w2l_trainer_set_linseg(void* h, uint32_t updates);
 /* Data-parallel overlap (replaces fl::CoalescingReducer, recipes/slimIPL/src/Train.cpp:195, :1721-1735):
  * bucket k = [offsets[k], offsets[k+1]) of the flat gradient arena (ascending float offsets; the last
  * bucket runs to the end).  forward_backward records one event per bucket on its stream as soon as every

@@ -142,6 +142,31 @@ def asg(x, trans, target, scale_mode=SCALE_NONE, grad=None):
     return loss, dx1 - dx2, dt1 - dt2
 
 
+def linear_target(target, T):
+    """Flashlight getLinearTarget (CriterionUtils, [UNVENDORED]; used by LinearSegmentationCriterion::forward, the
+    reference's LinSegCriterion of recipes/slimIPL/src/Train.cpp:592): newTarget[b][t] = target[b][t * L_b / T] with
+    L_b = leading non-negative entries; a row with L_b == 0 or L_b > T is filled with -1.  Parity unpinned in
+    /root/reference (no LinSeg test there)."""
+    target = np.asarray(target, np.int32)
+    B, L = target.shape
+    out = np.full((B, T), -1, np.int32)
+    for b in range(B):
+        neg = np.nonzero(target[b] < 0)[0]
+        tn = int(neg[0]) if len(neg) else L
+        if tn == 0 or tn > T:
+            continue
+        out[b] = target[b][(np.arange(T, dtype=np.int64) * tn) // T]
+    return out
+
+
+def linseg(x, trans, target, scale_mode=SCALE_NONE, grad=None):
+    """LinSegCriterion = ASG on the linearly stretched target (rows that cannot be stretched: FAC part 0, FCC with
+    target size 0, as the HIP FAC / FCC do for an empty target)"""
+    x = _f32(x)
+    lin = linear_target(target, x.shape[1])
+    return asg(x, trans, lin, scale_mode, grad)
+
+
 def viterbi(x, trans):
     x = _f32(x)
     trans = _f32(trans)

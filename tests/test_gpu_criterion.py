@@ -358,3 +358,50 @@ def test_viterbi_large_n_bit_exact(oracle, B, T, N):
     crit.transitions.data = dev(Aq)
     got = crit.viterbiPath(dev(xq)).cpu().numpy()
     assert (got == oracle.viterbi(xq, Aq)).all()
+
+
+@pytest.mark.parametrize("B,T,N,L,mode", [(3, 50, 6, 9, 0), (4, 333, 30, 120, 4), (2, 64, 100, 64, 3), (5, 17, 5, 40, 2)])
+def test_linseg_criterion(oracle, B, T, N, L, mode):
+    """LinSegCriterion (ASG on the linearly stretched target; first --linseg updates): stretched target bit-exact
+    against the getLinearTarget restatement, loss / gradients within 1e-4 of the oracle's ASG on it; rows that cannot
+    be stretched (empty or longer than T) contribute FCC only; run-to-run identical for letter-sized N"""
+    from wav2letter_amd import LinSegCriterion, linear_target
+    rng = np.random.default_rng(B * 1000 + T)
+    x = rng.normal(size=(B, T, N)).astype(np.float32)
+    tgt = make_targets(rng, B, L, N, 10 ** 9, min_len=1)
+    tgt[0, :] = -1                                   # empty target
+    if L > T:
+        tgt[1, :] = rng.integers(0, N, size=L)       # longer than T
+    lin = linear_target(dev(tgt), T).cpu().numpy()
+    assert (lin == oracle.linear_target(tgt, T)).all()
+    A = (np.eye(N) * 2 + rng.normal(size=(N, N)) * 0.3).astype(np.float32)
+    crit = LinSegCriterion(N, mode).cuda()
+    crit.transitions.data = dev(A)
+    xt = dev(x).requires_grad_(True)
+    g = rng.uniform(0.5, 1.5, size=B).astype(np.float32)
+    loss = crit(xt, dev(tgt))
+    (loss * dev(g)).sum().backward()
+    ol, odx, odA = oracle.linseg(x, A, tgt, mode, grad=g.astype(np.float64))
+    assert relerr(loss.detach().cpu().numpy(), ol) < TOL
+    assert gradrel(xt.grad.cpu().numpy(), odx) < TOL
+    assert gradrel(crit.transitions.grad.cpu().numpy(), odA) < TOL
+    if N <= 64:
+        xt2 = dev(x).requires_grad_(True)
+        crit.transitions.grad = None
+        (crit(xt2, dev(tgt)) * dev(g)).sum().backward()
+        assert torch.equal(xt2.grad, xt.grad)
+
+
+def test_linseg_shares_asg_transitions():
+    """linseg->setParams(criterion->param(0), 0): one transition parameter, gradients of both criteria land on it"""
+    from wav2letter_amd import ASGLoss, LinSegCriterion
+    asg = ASGLoss(8, 0, 1.5).cuda()
+    lin = LinSegCriterion(8, 0).cuda()
+    lin.setParams(asg.transitions, 0)
+    assert lin.transitions is asg.transitions
+    x = torch.randn(2, 20, 8, device="cuda", requires_grad=True)
+    tgt = torch.tensor([[1, 2, 3, -1], [4, 4, 5, 6]], dtype=torch.int32, device="cuda")
+    lin(x, tgt).sum().backward()
+    assert asg.transitions.grad is not None and torch.isfinite(asg.transitions.grad).all()
+    with pytest.raises(Exception):
+        lin.setParams(asg.transitions, 1)

@@ -17,9 +17,11 @@ def rel(got, want):
     return np.abs(got - want).max() / max(1e-30, np.abs(want).max())
 
 
-def build(arch, nfeat, nlabel, crit, mode, transdiag, rng, B, T, L):
+def build(arch, nfeat, nlabel, crit, mode, transdiag, rng, B, T, L, linseg=0):
     from wav2letter_amd.trainer import Trainer
     tr = Trainer(arch, nfeat, nlabel, crit, mode, transdiag)
+    if linseg:
+        tr.set_linseg(linseg)
     ref = refnet.RefNet(arch, nfeat, nlabel)
     params = ref.random_params(rng)
     table = tr.param_table()
@@ -107,6 +109,36 @@ def test_conv_glu_asg_small_end_to_end(oracle):
     # Viterbi through the trainer: bit-exact
     path = tr.viterbi(tr.forward(xd, train=False)).cpu().numpy()
     assert (path == oracle.viterbi(em, A)).all()
+
+
+def test_linseg_warmup_then_asg(oracle):
+    """--linseg=1 (every ASG recipe): update 0 runs LinSegCriterion on the ASG transitions, update 1 onwards ASG;
+    both through the C++ trainer, against the oracle on the reference network's emissions"""
+    from wav2letter_amd import recipes
+    from wav2letter_amd.trainer import Trainer
+    rng = np.random.default_rng(11)
+    nfeat, nlabel, B, T, L = 6, 9, 2, 40, 7
+    arch = recipes.conv_glu_small_arch(widths=(16, 24), kws=(5, 4), pad0=2)
+    tr, ref, params, A = build(arch, nfeat, nlabel, "asg", 4, 4.0, rng, B, T, L, linseg=1)
+    x = rng.normal(size=(B, 1, nfeat, T)).astype(np.float32)
+    tgt = np.array([[1, 2, 3, 1, -1, -1, -1], [0, 5, 5, 2, 7, 1, 0]], np.int32)
+    xd = torch.tensor(x.reshape(B, nfeat, T)).cuda()
+    td = torch.tensor(tgt).cuda()
+    em_ref = ref.forward(x, params)
+    loss = tr.forward_backward(xd, td).cpu().numpy()
+    ol, odx, odA = oracle.linseg(em_ref, A, tgt, 4)
+    assert rel(loss, ol) < TOL
+    check_grads(tr, ref.backward(odx.astype(np.float32), len(params)))
+    gA = tr.grads.cpu().numpy()[tr.n_net:tr.n_net + nlabel * nlabel]
+    assert rel(gA, odA) < TOL
+    tr.set_step(1)                       # past the warm-up: the ASG criterion proper
+    loss = tr.forward_backward(xd, td).cpu().numpy()
+    ol, odx, odA = oracle.asg(em_ref, A, tgt, 4)
+    assert rel(loss, ol) < TOL
+    gA = tr.grads.cpu().numpy()[tr.n_net:tr.n_net + nlabel * nlabel]
+    assert rel(gA, odA) < TOL
+    with pytest.raises(Exception):       # "linseg may only be used with ASG criterion" (Train.cpp:593)
+        Trainer(recipes.tds_ctc_small_arch(c=(4,), h=8, kw=5), 8, 12, "ctc", 4).set_linseg(1)
 
 
 def test_training_reduces_loss():

@@ -262,3 +262,54 @@ def test_viterbi_score_le_fcc(oracle):
         s = 50 * (float(x[b, 0, p2[b, 0]]) + sum(float(x[b, t, p2[b, t]]) + float(A[p2[b, t], p2[b, t - 1]])
                                                  for t in range(1, T)))
         assert abs(s - big[b]) < 1e-3 * abs(big[b])
+
+
+def test_linear_target_properties(oracle):
+    """getLinearTarget restatement: every label appears, in order, over contiguous frame runs whose lengths differ by
+    at most one; L = T is the identity; an empty / too long target gives a row of -1"""
+    rng = np.random.default_rng(5)
+    tgt = np.full((5, 9), -1, np.int32)
+    lens = [1, 4, 9, 0, 7]
+    for b, l in enumerate(lens):
+        tgt[b, :l] = rng.integers(0, 6, size=l)
+    T = 8
+    lin = oracle.linear_target(tgt, T)
+    assert lin.shape == (5, T)
+    assert (lin[0] == tgt[0, 0]).all()
+    assert (lin[2] == -1).all() and (lin[3] == -1).all()       # L = 9 > T; L = 0
+    for b in (1, 4):
+        l = lens[b]
+        idx = (np.arange(T) * l) // T
+        assert (lin[b] == tgt[b, idx]).all()
+        assert sorted(set(idx)) == list(range(l))                 # every label is used
+        runs = np.bincount(idx)
+        assert runs.max() - runs.min() <= 1
+    sq = oracle.linear_target(tgt[4:5, :7], 7)
+    assert (sq[0] == tgt[4, :7]).all()
+
+
+def test_linseg_is_single_path_asg(oracle):
+    """LinSeg = FCC - (score of the one linear alignment): the oracle's FAC on a length-T target equals the direct
+    path score, and its gradient is the path indicator"""
+    rng = np.random.default_rng(6)
+    B, T, N, L = 3, 7, 4, 5
+    x = rng.normal(size=(B, T, N)).astype(np.float32)
+    A = rng.normal(size=(N, N)).astype(np.float32)
+    tgt = np.array([[1, 2, 3, -1, -1], [0, 0, 1, 2, 3], [2, -1, -1, -1, -1]], np.int32)
+    lin = oracle.linear_target(tgt, T)
+    loss, dx, dA = oracle.linseg(x, A, tgt)
+    fcc = oracle.FCC(x, A, np.full(B, T, np.int32))
+    lf = fcc.forward()
+    dxf, dAf = fcc.backward()
+    for b in range(B):
+        s = x[b, 0, lin[b, 0]].astype(np.float64)
+        ind = np.zeros((T, N))
+        ind[0, lin[b, 0]] = 1
+        cnt = np.zeros((N, N))
+        for t in range(1, T):
+            s += float(x[b, t, lin[b, t]]) + float(A[lin[b, t], lin[b, t - 1]])
+            ind[t, lin[b, t]] = 1
+            cnt[lin[b, t], lin[b, t - 1]] += 1
+        assert abs(loss[b] - (lf[b] - s)) < 1e-9
+        assert np.abs(dx[b] - (dxf[b] - ind)).max() < 1e-9
+    assert np.isfinite(dA).all()

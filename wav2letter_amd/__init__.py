@@ -6,4 +6,4 @@ torch.distributed (RCCL) only.
 """
 from . import _lib  # noqa: F401
 from .criterion import (ASGLoss, CTCLoss, CriterionScaleMode, ForceAlignmentCriterion,  # noqa: F401
-                        FullConnectionCriterion, SequenceCriterion, getCriterionScaleMode)
+                        FullConnectionCriterion, LinSegCriterion, SequenceCriterion, getCriterionScaleMode, linear_target)

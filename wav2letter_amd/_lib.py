@@ -57,6 +57,9 @@ class _SIGS:
     w2l_fac_forward = (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p])
     w2l_fac_backward = (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p])
     w2l_fac_viterbi = (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p])
+    w2l_linear_target = (_i, [_i, _i, _i, _p, _p, _p])
+    w2l_fac_fullpath_forward = (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p])
+    w2l_fac_fullpath_backward = (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p])
     w2l_viterbi_workspace_size = (_sz, [_i, _i, _i])
     w2l_viterbi_compute = (_i, [_i, _i, _i, _p, _p, _p, _p, _p])
     w2l_ctc_workspace_size = (_sz, [_i, _i, _i, _i])

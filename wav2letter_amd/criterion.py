@@ -131,6 +131,45 @@ class _FAC(torch.autograd.Function):
         return dx, dt, None, None, None
 
 
+class _FACFullPath(torch.autograd.Function):
+    """ForceAlignmentCriterion on a length-T target: one alignment (w2l_fac_fullpath_*)"""
+
+    @staticmethod
+    def forward(ctx, emission, trans, path, scale_mode):
+        L = _lib.lib()
+        emission = emission.contiguous()
+        trans = trans.contiguous()
+        B, T, N = emission.shape
+        loss = torch.empty(B, dtype=torch.float32, device=emission.device)
+        _lib.check(L.w2l_fac_fullpath_forward(B, T, N, int(scale_mode), emission.data_ptr(), path.data_ptr(),
+                                              trans.data_ptr(), loss.data_ptr(), _stream()), "fac_fullpath_forward")
+        ctx.save_for_backward(path)
+        ctx.dims = (B, T, N, int(scale_mode))
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad):
+        L = _lib.lib()
+        (path,) = ctx.saved_tensors
+        B, T, N, mode = ctx.dims
+        grad = grad.contiguous().float()
+        dx = torch.empty(B, T, N, dtype=torch.float32, device=grad.device)
+        dt = torch.empty(N, N, dtype=torch.float32, device=grad.device)
+        _lib.check(L.w2l_fac_fullpath_backward(B, T, N, mode, path.data_ptr(), grad.data_ptr(), dx.data_ptr(),
+                                               dt.data_ptr(), _stream()), "fac_fullpath_backward")
+        return dx, dt, None, None
+
+
+def linear_target(target, T):
+    """Flashlight getLinearTarget: [B][L] labels (-1 padded) stretched to [B][T]"""
+    _check_dev(target)
+    target = target.contiguous()
+    B, L = target.shape
+    out = torch.empty(B, T, dtype=torch.int32, device=target.device)
+    _lib.check(_lib.lib().w2l_linear_target(B, L, int(T), target.data_ptr(), out.data_ptr(), _stream()), "linear_target")
+    return out
+
+
 class _CTC(torch.autograd.Function):
     @staticmethod
     def forward(ctx, emission, target, target_size, scale_mode):
@@ -260,6 +299,37 @@ class ASGLoss(SequenceCriterion):
 
     def prettyString(self):
         return "AutoSegmentationCriterion"
+
+
+class LinSegCriterion(SequenceCriterion):
+    """LinearSegmentationCriterion: ASG on the target stretched linearly over the T frames, used for the first
+    --linseg updates of every ASG recipe with the ASG criterion's own transition parameter
+    (`linseg->setParams(criterion->param(0), 0)`, recipes/slimIPL/src/Train.cpp:592-596)."""
+
+    def __init__(self, N, scalemode=CriterionScaleMode.NONE, transitions=None):
+        super().__init__()
+        self.N, self.scalemode = N, scalemode
+        self.transitions = transitions if transitions is not None else torch.nn.Parameter(torch.zeros(N, N))
+
+    def setParams(self, var, pos=0):
+        if pos != 0:
+            raise _lib.W2LInvalidArgument("LinSegCriterion has one parameter (transitions)")
+        self.transitions = var
+
+    def forward(self, emission, target):
+        _emission_checks(emission, target)
+        _check_dev(emission, target)
+        if emission.shape[2] != self.N:
+            raise _lib.W2LInvalidArgument("LinSegCriterion: N doesn't match with the letter size")
+        T = emission.shape[1]
+        lin = linear_target(target, T)
+        ts = batch_target_size(lin, T)          # T, or 0 for a row that could not be stretched
+        fcc = _FCC.apply(emission, self.transitions, ts, self.scalemode)
+        fac = _FACFullPath.apply(emission, self.transitions, lin, self.scalemode)
+        return fcc - fac
+
+    def prettyString(self):
+        return "LinearSegmentationCriterion"
 
 
 class CTCLoss(SequenceCriterion):

@@ -215,7 +215,7 @@ struct ConvFilterAOp {
 // partial sums (V-wide loads, 4 rows in flight per wave) into the library scratch, then a sum over row-blocks
 // in fixed order.  HBM-bound: M*N*4 bytes read once.
 float* sk_scratch(hipStream_t s, size_t bytes);
-constexpr int kColsumMaxParts = 256;
+constexpr int kColsumMaxParts = 128;
 
 template <int V>
 __global__ __launch_bounds__(256) void colsum_partial_k(const float* __restrict__ x, float* __restrict__ partial,
@@ -250,17 +250,24 @@ __global__ __launch_bounds__(256) void colsum_partial_k(const float* __restrict_
   }
 }
 
+// 64 columns per workgroup; the four waves take every fourth row-block (independent loads in flight), fixed-order sums
 __global__ __launch_bounds__(256) void colsum_finish_k(const float* __restrict__ partial, float* __restrict__ out, int parts, int N) {
-  int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
-  float s0 = 0.f, s1 = 0.f;
-  int p = 0;
-  for (; p + 1 < parts; p += 2) {
-    s0 += partial[(size_t)p * N + n];
-    s1 += partial[(size_t)(p + 1) * N + n];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
+  __shared__ float sm[4][64];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (n < N) {
+    int p = wave;
+    for (; p + 12 < parts; p += 16) {
+      const float v0 = partial[(size_t)p * N + n], v1 = partial[(size_t)(p + 4) * N + n];
+      const float v2 = partial[(size_t)(p + 8) * N + n], v3 = partial[(size_t)(p + 12) * N + n];
+      s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; p < parts; p += 4) s0 += partial[(size_t)p * N + n];
   }
-  if (p < parts) s0 += partial[(size_t)p * N + n];
-  out[n] = s0 + s1;
+  sm[wave][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (wave == 0 && n < N) out[n] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
 }
 
 int colsum(const float* x, float* out, size_t M, int N, hipStream_t s) {
@@ -284,7 +291,7 @@ int colsum(const float* x, float* out, size_t M, int N, hipStream_t s) {
   else
     hipLaunchKernelGGL(colsum_partial_k<1>, grid, dim3(256), 0, s, x, partial, M, N, rowsPerBlock);
   W2L_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_finish_k, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, partial, out, parts, N);
+  hipLaunchKernelGGL(colsum_finish_k, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, partial, out, parts, N);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }

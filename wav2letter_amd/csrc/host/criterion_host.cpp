@@ -122,8 +122,64 @@ class ASGLossImpl : public SequenceCriterion {
   hipEvent_t fork_ = nullptr, join_ = nullptr;
 };
 
+// LinearSegmentationCriterion: ASG on the linearly stretched target (first --linseg updates, Train.cpp:589-617).
+// Uses the SAME parameter block as the ASG criterion it warms up (the caller passes the ASG transitions as
+// critParams, the reference's `linseg->setParams(criterion->param(0), 0)`).
+class LinSegCriterionImpl : public SequenceCriterion {
+ public:
+  LinSegCriterionImpl(int N, int mode) : N_(N), mode_(mode) {}
+  std::string prettyString() const override { return "LinearSegmentationCriterion"; }
+  size_t paramFloats() const override { return ((size_t)N_ * N_ + 3) / 4 * 4; }
+  void initParams(float* host) const override { std::memset(host, 0, sizeof(float) * paramFloats()); }
+  struct Ws { int* ts; int* lin; void* fcc; float* dx2; float* dt2; float* loss2; };
+  Ws carve(void* ws, int B, int T, int N) const {
+    char* p = (char*)ws;
+    Ws w;
+    w.ts = (int*)p; p += up(sizeof(int) * B);
+    w.lin = (int*)p; p += up(sizeof(int) * (size_t)B * T);
+    w.fcc = p; p += up(w2l_fcc_workspace_size(B, T, N));
+    w.dx2 = (float*)p; p += up(sizeof(float) * (size_t)B * T * N);
+    w.dt2 = (float*)p; p += up(sizeof(float) * (size_t)N * N);
+    w.loss2 = (float*)p;
+    return w;
+  }
+  size_t workspaceBytes(int B, int T, int N, int) const override {
+    return up(sizeof(int) * B) + up(sizeof(int) * (size_t)B * T) + up(w2l_fcc_workspace_size(B, T, N)) +
+           up(sizeof(float) * (size_t)B * T * N) + up(sizeof(float) * (size_t)N * N) + up(sizeof(float) * B) +
+           up(w2l_viterbi_workspace_size(B, T, N));
+  }
+  void forward(Ctx& c, int B, int T, int N, int L, const float* em, const int* target, float* loss, void* ws,
+               float* trans) override {
+    if (N != N_) throw std::invalid_argument("LinSegCriterion: N doesn't match with the letter size");
+    Ws w = carve(ws, B, T, N);
+    w2lCheck(w2l_linear_target(B, L, T, target, w.lin, c.stream), "linear target");
+    w2lCheck(w2l_batch_target_size(B, T, T, w.lin, w.ts, c.stream), "linseg target size");
+    w2lCheck(w2l_fac_fullpath_forward(B, T, N, mode_, em, w.lin, trans, w.loss2, c.stream), "linseg path score");
+    w2lCheck(w2l_fcc_forward(B, T, N, mode_, em, w.ts, trans, loss, w.fcc, c.stream), "fcc forward");
+    w2lCheck(w2l_axpy(loss, w.loss2, (size_t)B, -1.f, c.stream), "linseg loss");
+  }
+  void backward(Ctx& c, int B, int T, int N, int, const float*, const int*, const float* gradLoss, float* dEm,
+                void* ws, float* trans, float* dTrans) override {
+    Ws w = carve(ws, B, T, N);
+    w2lCheck(w2l_fac_fullpath_backward(B, T, N, mode_, w.lin, gradLoss, w.dx2, w.dt2, c.stream), "linseg path backward");
+    w2lCheck(w2l_fcc_backward(B, T, N, trans, gradLoss, dEm, dTrans, w.fcc, c.stream), "fcc backward");
+    w2lCheck(w2l_axpy(dEm, w.dx2, (size_t)B * T * N, -1.f, c.stream), "linseg dx");
+    w2lCheck(w2l_axpy(dTrans, w.dt2, (size_t)N * N, -1.f, c.stream), "linseg dtrans");
+  }
+  void viterbiPath(Ctx& c, int B, int T, int N, const float* em, int* path, void* ws, float* trans) override {
+    Ws w = carve(ws, B, T, N);
+    w2lCheck(w2l_viterbi_compute(B, T, N, em, trans, path, w.fcc, c.stream), "viterbi");
+  }
+
+ private:
+  int N_, mode_;
+};
+
 }  // namespace
 
+std::shared_ptr<SequenceCriterion> makeLinSegCriterion(int N, int scaleMode) {
+  return std::make_shared<LinSegCriterionImpl>(N, scaleMode);
+}
 std::shared_ptr<SequenceCriterion> makeCTCLoss(int scaleMode) { return std::make_shared<CTCLossImpl>(scaleMode); }
 std::shared_ptr<SequenceCriterion> makeASGLoss(int N, int scaleMode, double transdiag) {
   return std::make_shared<ASGLossImpl>(N, scaleMode, transdiag);

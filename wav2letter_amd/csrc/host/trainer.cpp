@@ -11,6 +11,8 @@
 #include <mutex>
 #include <vector>
 
+#include <algorithm>
+
 #include "w2l_host.hpp"
 
 namespace w2l {
@@ -30,6 +32,10 @@ struct Trainer {
   double* sumsq = nullptr;
   const float* emission = nullptr;
   uint32_t step = 0;
+  std::shared_ptr<SequenceCriterion> linseg;  // --linseg warm-up criterion (ASG only), used while step < linsegUpdates
+  uint32_t linsegUpdates = 0;
+  int scaleMode = 0;
+  SequenceCriterion* activeCrit() { return (linseg && step < linsegUpdates) ? linseg.get() : crit.get(); }
   std::string lastError;
   std::vector<hipEvent_t> bucketEvents;  // owned (w2l_trainer_set_grad_buckets)
   ~Trainer() { for (auto e : bucketEvents) (void)hipEventDestroy(e); }
@@ -54,7 +60,7 @@ W2L_API void* w2l_trainer_create(const char* archText, int nFeat, int nLabel, co
                                  int scaleMode, double transdiag) {
   try {
     auto t = new Trainer();
-    t->nFeat = nFeat; t->nLabel = nLabel; t->critName = criterion ? criterion : "ctc";
+    t->nFeat = nFeat; t->nLabel = nLabel; t->critName = criterion ? criterion : "ctc"; t->scaleMode = scaleMode;
     t->net = buildSequentialFromText(archText, nFeat, nLabel);
     if (t->critName == "ctc") t->crit = makeCTCLoss(scaleMode);
     else if (t->critName == "asg") t->crit = makeASGLoss(nLabel, scaleMode, transdiag);
@@ -115,6 +121,7 @@ W2L_API int w2l_trainer_plan(void* h, int B, int T, int L, size_t* arenaFloats, 
     size_t extra = ((size_t)B * t->Tout * t->nLabel + 63) / 64 * 64 + 3 * 64 + 64;  // dEmission, loss, gradLoss, sumsq
     t->arenaFloats = used + extra;
     t->critWsBytes = t->crit->workspaceBytes(B, t->Tout, t->nLabel, L);
+    if (t->linseg) t->critWsBytes = std::max(t->critWsBytes, t->linseg->workspaceBytes(B, t->Tout, t->nLabel, L));
     if (arenaFloats) *arenaFloats = t->arenaFloats;
     if (critWsBytes) *critWsBytes = t->critWsBytes;
     if (Tout) *Tout = t->Tout;
@@ -166,11 +173,12 @@ W2L_API int w2l_trainer_forward_backward(void* h, const float* x, const int* tar
     t->emission = t->net->forward(c, t->arena, x);
     float* cp = t->params + t->netFloats;
     float* cg = t->grads + t->netFloats;
-    t->crit->forward(c, t->B, t->Tout, t->nLabel, t->L, t->emission, target, t->loss, t->critWs, cp);
+    SequenceCriterion* crit = t->activeCrit();
+    crit->forward(c, t->B, t->Tout, t->nLabel, t->L, t->emission, target, t->loss, t->critWs, cp);
     // d(sum_b loss_b)/d loss_b = 1
     hipCheck(hipMemsetAsync(t->gradLoss, 0, sizeof(float) * 64, c.stream), "memset");
     w2lCheck(w2l_fill(t->gradLoss, (size_t)t->B, 1.f, c.stream), "fill");
-    t->crit->backward(c, t->B, t->Tout, t->nLabel, t->L, t->emission, target, t->gradLoss, t->dEm, t->critWs, cp, cg);
+    crit->backward(c, t->B, t->Tout, t->nLabel, t->L, t->emission, target, t->gradLoss, t->dEm, t->critWs, cp, cg);
     t->net->backward(c, t->arena, t->dEm);
     if (lossDev) *lossDev = t->loss;
   });
@@ -232,6 +240,18 @@ W2L_API int w2l_trainer_wait_bucket(void* h, int k, void* stream) {
   TRY(h, {
     if (k < 0 || k >= (int)t->bucketEvents.size()) throw std::invalid_argument("wait_bucket: no such bucket");
     hipCheck(hipStreamWaitEvent((hipStream_t)stream, t->bucketEvents[k], 0), "hipStreamWaitEvent");
+  });
+}
+
+// --linseg=n (Train.cpp:589-617, :1866-1883): the first n updates of an ASG run use LinSegCriterion on the ASG
+// criterion's own transitions.  Call before w2l_trainer_plan (the criterion workspace is sized for both).
+W2L_API int w2l_trainer_set_linseg(void* h, uint32_t updates) {
+  Trainer* t = (Trainer*)h;
+  TRY(h, {
+    if (updates && t->critName != "asg") throw std::invalid_argument("linseg may only be used with ASG criterion");
+    t->linsegUpdates = updates;
+    t->linseg = updates ? makeLinSegCriterion(t->nLabel, t->scaleMode) : nullptr;
+    t->arenaFloats = 0;  // forces a new plan / bind
   });
 }
 

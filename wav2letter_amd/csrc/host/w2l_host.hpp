@@ -173,6 +173,7 @@ class SequenceCriterion {
 };
 std::shared_ptr<SequenceCriterion> makeCTCLoss(int scaleMode);
 std::shared_ptr<SequenceCriterion> makeASGLoss(int N, int scaleMode, double transdiag);
+std::shared_ptr<SequenceCriterion> makeLinSegCriterion(int N, int scaleMode);  // shares the ASG transitions (caller passes them)
 
 // gflags-style flag files (--flagsfile, --k=v lines, '#' comments), recipes/*/train.cfg
 struct Flags {

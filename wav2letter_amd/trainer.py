@@ -41,6 +41,7 @@ def _lib_tr():
         L.w2l_trainer_update.argtypes = [vp, f, f, f, f, f, i, vp]
         L.w2l_trainer_viterbi.argtypes = [vp, vp, vp, vp]
         L.w2l_trainer_set_step.argtypes = [vp, u32]
+        L.w2l_trainer_set_linseg.argtypes = [vp, u32]
         L.w2l_trainer_set_grad_buckets.argtypes = [vp, i, C.POINTER(sz)]
         L.w2l_trainer_wait_bucket.argtypes = [vp, i, vp]
         L.w2l_arch_check.argtypes = [C.c_char_p, i, i, C.POINTER(i)]
@@ -173,6 +174,10 @@ class Trainer:
 
     def set_step(self, step):
         self.L.w2l_trainer_set_step(self.h, step)
+
+    def set_linseg(self, updates):
+        """--linseg=n: LinSegCriterion for the first n updates of an ASG run (call before plan())"""
+        _check(self.L.w2l_trainer_set_linseg(self.h, int(updates)), "linseg")
 
     # ---- data-parallel overlap (parallel.OverlappedReducer drives these)
     def set_grad_buckets(self, offsets):
