@@ -85,7 +85,11 @@ def test_gemm_stream_k_schedule(M, N, K, akc, bkc):
                                     (260, 388, 96),        # ragged edge tiles in both directions
                                     (1028, 2052, 1440),    # 153 tiles: pure stream-K ranges crossing tiles
                                     (6016, 4320, 1440),    # 1598 tiles: 3 persistent rounds + stream-K tail
-                                    (640, 136, 24000)])    # dW-like: few tiles, very long reduction
+                                    (640, 136, 24000),     # dW-like: few tiles, very long reduction
+                                    (300, 998, 64),        # N = 2 mod 4 (the 9998 case): 8-byte aligned k-rows, straddling chunks
+                                    (998, 262, 96),        # the same on the A side (k-row A with 998 columns)
+                                    (260, 388, 2030),      # K % 32 = 14: whole K tiles + register-staged tail, accumulated
+                                    (188, 9998, 1440)])    # final fl::Linear of the TDS-CTC recipe (one batch row block)
 @pytest.mark.parametrize("akc,bkc", [(True, False), (True, True), (False, False), (False, True)])
 def test_gemm_lds_dma_path(M, N, K, akc, bkc):
     """the persistent LDS-DMA kernel (K % 32 == 0, 16-byte aligned operands) against a float64 product
@@ -110,6 +114,9 @@ def test_gemm_lds_dma_path(M, N, K, akc, bkc):
     assert rel(got, old.cpu().numpy()) < 1e-5
     got = ops.gemm(Ad, Bd, akc, bkc, bias.cuda(), relu=True)
     assert rel(got, np.maximum(want, 0)) < TOL
+    plain = ops.gemm(Ad, Bd, akc, bkc)      # no epilogue: the form that may split a ragged K
+    assert rel(plain, (A.double() @ Bm.double()).numpy()) < TOL
+    assert torch.equal(plain, ops.gemm(Ad, Bd, akc, bkc))
 
 
 @pytest.mark.parametrize("M,N,K", [(4, 4, 32), (260, 388, 96), (1028, 2052, 1440), (6016, 4320, 1440), (640, 136, 24000),

@@ -59,7 +59,7 @@ __device__ __forceinline__ void g_init_ptrs(const float* (&q)[4], const GOp& op,
     } else {
       const int kr = (wave * 4 + j) * 2 + (lane >> 5);            // tile k-row 0..31
       int gi = i0 + 4 * (lane & 31);
-      if (gi > op.extent - 4) gi = op.extent - 4;
+      if (gi >= op.extent) gi = (op.extent - 1) & ~3;  // a chunk that straddles the row end stays in place (its tail columns are never stored)
       q[j] = op.p + (size_t)kr * op.ld + gi;
     }
   }
@@ -91,7 +91,7 @@ __device__ __forceinline__ void g_init_offs(uint32_t (&vo)[4], const GOp& op, in
     } else {
       const int kr = (wave * 4 + j) * 2 + (lane >> 5);
       int gi = i0 + 4 * (lane & 31);
-      if (gi > op.extent - 4) gi = op.extent - 4;
+      if (gi >= op.extent) gi = (op.extent - 1) & ~3;  // a chunk that straddles the row end stays in place (its tail columns are never stored)
       vo[j] = ((uint32_t)kr * (uint32_t)op.ld + (uint32_t)gi) * 4u;
     }
   }

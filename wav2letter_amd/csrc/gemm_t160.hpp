@@ -35,7 +35,7 @@ __device__ __forceinline__ uint32_t t160_off(const GOp& op, int i0, int p, int l
     const int flat = 256 * p + 4 * lane;
     const int kr = flat / W, col = flat - kr * W;
     int gi = i0 + col;
-    if (gi > op.extent - 4) gi = op.extent - 4;
+    if (gi >= op.extent) gi = (op.extent - 1) & ~3;  // a chunk that straddles the row end stays in place (its tail columns are never stored)
     return ((uint32_t)kr * (uint32_t)op.ld + (uint32_t)gi) * 4u;
   }
 }
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void gemm160_kernel(GOp aop, GOp bop, GemmO
 inline int t160_choice(const GOp& a, const GOp& b, const GemmOut& o) {
   const char* e = getenv("W2L_GEMM_T160");
   const int mode = e ? atoi(e) : 1;
-  if (!mode || !a.bytes || !b.bytes) return 0;
+  if (!mode || !a.bytes || !b.bytes || o.N % 4 != 0) return 0;
   if ((((uintptr_t)o.C) & 15) != 0 || o.ldc % 4 != 0 || (o.mask && (((uintptr_t)o.mask) & 15) != 0) ||
       (o.addend && (((uintptr_t)o.addend) & 15) != 0))
     return 0;
