@@ -369,6 +369,13 @@ CONV_CASES = [
     (1, 10, 10, 16, 47, 7, 3, 2, 3),      # stride 3: three phases with 3 / 2 / 2 taps
     (1, 12, 8, 16, 23, 4, 4, 0, 1),       # stride == kw: every phase has one tap
     (8, 10, 10, 16, 2200, 21, 1, 10, 10), # 552 tiles on 512 persistent workgroups: two tiles per workgroup + prefetch
+    # conv_glu layers (H = 1, stride 1): one LDS-DMA GEMM on overlapping rows
+    (2, 40, 100, 1, 60, 13, 1, 0, 0),     # valid convolution (every C4 layer but the first), K = 520 (ragged last K tile)
+    (3, 33, 70, 1, 45, 4, 1, 0, 0),       # odd channel count: dword-aligned rows, N % 4 = 2 (dword epilogue)
+    (2, 321, 706, 1, 64, 19, 1, 0, 0),    # C4 layer 7 channels (odd C_in), 3 utterances' worth of straddling rows dropped
+    (2, 40, 400, 1, 90, 13, 1, 170, 170), # first C4 layer: 170 frames of zero padding on both sides (padded copy + remap)
+    (1, 64, 64, 1, 37, 5, 1, 3, 1),       # asymmetric padding, T' not a multiple of anything
+    (4, 200, 440, 1, 300, 14, 1, 0, 0),   # C4 layer 2 at reduced T: several 128-row tiles per utterance
 ]
 
 
@@ -394,7 +401,8 @@ def test_conv_fwd_bwd(oracle, B, Cin, Cout, H, T, kw, stride, padl, padr):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,T,kw,stride,padl,padr", [(2, 10, 14, 32, 61, 21, 2, 10, 10), (1, 14, 18, 16, 40, 21, 2, 10, 10),
-                                                                (1, 10, 10, 16, 47, 7, 3, 2, 3), (1, 10, 10, 16, 40, 21, 1, 10, 10)])
+                                                                (1, 10, 10, 16, 47, 7, 3, 2, 3), (1, 10, 10, 16, 40, 21, 1, 10, 10),
+                                                                (2, 40, 100, 1, 60, 13, 1, 0, 0), (2, 33, 70, 1, 45, 4, 1, 2, 1)])
 def test_conv_backward_data_accumulate_and_add(oracle, B, Cin, Cout, H, T, kw, stride, padl, padr):
     """the two fused forms of Conv2D backward-data (dx += ..., dx = add + ...) on the phase-decomposed strided path
     and the stride-1 path: equal to the plain result plus the addend"""
@@ -419,6 +427,35 @@ def test_conv_backward_data_accumulate_and_add(oracle, B, Cin, Cout, H, T, kw, s
     assert rel(from_fm(out.cpu().numpy()), odx + base) < TOL
     ops.check(L.w2l_conv_backward_data_add(C.byref(d), ops._p(dyd), ops._p(wd), ops._p(add), ops._p(add), ops._s()), "bwd data add in place")
     assert rel(from_fm(add.cpu().numpy()), odx + base) < TOL
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,kw,padl,padr", [(2, 40, 100, 60, 13, 0, 0), (2, 321, 706, 64, 19, 0, 0), (2, 40, 400, 90, 13, 170, 170)])
+def test_conv_glu_overlapping_rows_equals_implicit_gemm(B, Cin, Cout, T, kw, padl, padr):
+    """the overlapping-row LDS-DMA convolution against the register-staged implicit-GEMM kernels (W2L_CONV_GLDS=0) on
+    the same inputs: forward (+bias, ReLU), backward-data, backward-filter, bias gradient; run-to-run identical"""
+    import os
+    from wav2letter_amd import ops
+    g = torch.Generator().manual_seed(Cin + T)
+    x = torch.randn(B, T, 1, Cin, generator=g).cuda()
+    w = (torch.randn(kw, Cin, Cout, generator=g) / (kw * Cin) ** 0.5).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    To = T + padl + padr - kw + 1
+    dy = torch.randn(B, To, 1, Cout, generator=g).cuda()
+    outs = {}
+    for mode in ("1", "0"):
+        os.environ["W2L_CONV_GLDS"] = mode
+        try:
+            y = ops.conv_forward(x, w, b, 1, padl, padr, relu=True)
+            dx, dw, db = ops.conv_backward(x, w, dy, 1, padl, padr)
+            outs[mode] = (y, dx, dw, db)
+            if mode == "1":
+                again = ops.conv_backward(x, w, dy, 1, padl, padr)
+                assert torch.equal(again[0], dx) and torch.equal(again[1], dw)
+        finally:
+            os.environ.pop("W2L_CONV_GLDS")
+    for a, c in zip(outs["1"], outs["0"]):
+        assert a.shape == c.shape
+        assert rel(a, c.cpu().numpy()) < 2e-5
 
 
 def test_golden_conv1d_on_device():

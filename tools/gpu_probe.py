@@ -142,6 +142,34 @@ def probe_conv():
               f"dX {td * 1e3:.0f} us {fl / td / 1e9:.1f} TF | dW+db {tw * 1e3:.0f} us {fl / tw / 1e9:.1f} TF", flush=True)
 
 
+def probe_convglu():
+    """conv_glu LibriSpeech (BASELINE config C4) WN-conv layers at B=64, T=2000: first / middle / last layer shapes of
+    recipes/conv_glu/librispeech/network.arch (valid convolutions, GLU halves the channels in between)"""
+    L = _lib.lib()
+    import ctypes as C
+    s = torch.cuda.current_stream().cuda_stream
+    B, T = 64, 2000
+    for name, Cin, Cout, kw in [("L1 40->400 k13", 40, 400, 13), ("L5 266->584 k17", 266, 584, 17), ("L9 388->852 k21", 388, 852, 21),
+                                ("L13 565->1242 k25", 565, 1242, 25), ("L17 826->1816 k29", 826, 1816, 29)]:
+        d = _lib.ConvDesc(B, T, 1, Cin, Cout, kw, 1, 0, 0)
+        To = T - kw + 1
+        x = torch.randn(B, T, 1, Cin, device="cuda")
+        w = torch.randn(kw, Cin, Cout, device="cuda") / (kw * Cin) ** 0.5
+        b = torch.randn(Cout, device="cuda")
+        y = torch.empty(B, To, 1, Cout, device="cuda")
+        dy = torch.randn(B, To, 1, Cout, device="cuda")
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        db = torch.empty_like(b)
+        fl = 2.0 * B * To * Cin * Cout * kw
+        tf = timeit(lambda: L.w2l_conv_forward(C.byref(d), x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), 0, s), n=3, warm=1)
+        td = timeit(lambda: L.w2l_conv_backward_data(C.byref(d), dy.data_ptr(), w.data_ptr(), dx.data_ptr(), 0, s), n=3, warm=1)
+        tw = timeit(lambda: L.w2l_conv_backward_filter(C.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), s), n=3, warm=1)
+        print(f"[convglu] {name} ({fl / 1e12:.2f} TFLOP): fwd {tf:.2f} ms {fl / tf / 1e9:.1f} TF | dX {td:.2f} ms {fl / td / 1e9:.1f} TF | "
+              f"dW+db {tw:.2f} ms {fl / tw / 1e9:.1f} TF", flush=True)
+        del x, w, y, dy, dx, dw
+
+
 def asg_targets(B, L, g):
     tgt = torch.full((B, L), -1, dtype=torch.int32)
     for b in range(B):
@@ -229,6 +257,6 @@ if __name__ == "__main__":
     print("device:", torch.cuda.get_device_name(0), flush=True)
     for w in which:
         t0 = time.time()
-        {"gemm": probe_gemm, "gemm160": probe_gemm160, "gemmfwd": probe_gemmfwd, "ln": probe_ln, "conv": probe_conv, "asg": probe_asg, "fccbig": probe_fccbig, "fccstream": probe_fccstream,
+        {"gemm": probe_gemm, "gemm160": probe_gemm160, "gemmfwd": probe_gemmfwd, "ln": probe_ln, "conv": probe_conv, "convglu": probe_convglu, "asg": probe_asg, "fccbig": probe_fccbig, "fccstream": probe_fccstream,
          "vitbig": probe_vitbig}[w]()
         print(f"[{w}] done in {time.time() - t0:.1f} s", flush=True)

@@ -15,6 +15,8 @@
 // Weights are stored [kw][Cin][Cout] (== [K][Cout], "k-rows" B operand).  Small
 // output widths (TDS: C = 10/14/18) use the 16x16x4 skinny kernel.
 #include <cstdlib>
+#include <map>
+#include <mutex>
 
 #include "gemm.hpp"
 
@@ -328,6 +330,133 @@ int tds_conv_backward_data(const w2l_conv_desc* d, const float* dy, const float*
 int tds_conv_backward_filter(const w2l_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
                              hipStream_t s);
 
+// =====================================================================================================
+// conv_glu path (fl::Conv2D kw x 1 over time with H == 1, stride 1: recipes/conv_glu/*/network.arch).
+// In the frame-major layout [B][T][C] the im2col row of output frame (b, t) -- frames t .. t+kw-1 -- is ONE contiguous
+// run of kw*C_in floats, so the convolution is a plain GEMM on OVERLAPPING rows: A = x viewed with leading dimension
+// C_in, K = kw*C_in.  No gather, no index arithmetic: the operand goes through the LDS-DMA kernels like a dense
+// matrix (the register-staged implicit-GEMM operand ran the C4 layers at 78-84 TF/s forward, 54-70 backward-data,
+// 60-73 backward-filter; profiles/r01_run44_convglu.log).  Rows are indexed by the GLOBAL frame r = b*Tp + t', the
+// kw-1 rows per utterance that straddle into the next one are dropped by the epilogue's row remap.
+//   forward : y  = X[r][(tap,ci)] . W[(tap,ci)][co]                    (X = x, or its zero-padded copy)
+//   bwd-data: dx = DYP[r][(tap',co)] . Wf[(tap',co)][ci],  Wf[tap'] = W[kw-1-tap']^T, DYP = dy re-pitched to Tp frames
+//             per utterance with kw-1 zero frames after (and, for the first utterance, before) each one
+//   bwd-filt: dw[(tap,ci)][co] = sum_r X[r][(tap,ci)] . DYP[r][co]     (X as a k-row operand: same memory)
+// K need not be a multiple of the K tile: the rows past K of the k-row operand lie outside its byte range and read as
+// zeros (buffer addressing), what the overlapping operand holds there is finite activation data.
+float* conv_scratch(hipStream_t s, size_t bytes) {  // library-owned, grows on demand, one buffer per stream
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, std::pair<float*, size_t>> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  auto& e = cache[{dev, s}];
+  if (e.second < bytes) {
+    if (e.first) { (void)hipStreamSynchronize(s); (void)hipFree(e.first); }
+    e.first = nullptr; e.second = 0;
+    void* p = nullptr;
+    const size_t want = bytes + bytes / 4;
+    if (hipMalloc(&p, want) != hipSuccess) return nullptr;
+    e.first = (float*)p; e.second = want;
+  }
+  return e.first;
+}
+
+// dst[b][t'][c] = src[b][t' - off][c] if 0 <= t' - off < Tsrc else 0     (frames of C floats)
+__global__ __launch_bounds__(256) void pad_frames_k(const float* __restrict__ src, float* __restrict__ dst, int Tsrc, int Tdst,
+                                                    int C, int off) {
+  const int b = blockIdx.y;
+  const size_t n = (size_t)Tdst * C;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    const int t = (int)(e / C) - off;
+    dst[(size_t)b * n + e] = (t >= 0 && t < Tsrc) ? src[((size_t)b * Tsrc + t) * C + (e % C)] : 0.f;
+  }
+}
+
+static bool glds_conv_enabled() {
+  const char* e = getenv("W2L_CONV_GLDS");
+  return !(e && e[0] == '0');
+}
+static bool glds_conv_applicable(const w2l_conv_desc* d) {
+  return glds_conv_enabled() && d->H == 1 && d->stride == 1 && d->kw * d->Cin >= 64 && d->Cout >= 32 &&
+         (int64_t)d->B * (d->T + d->padl + d->padr) < (1ll << 30);
+}
+static int pad_frames(const float* src, float* dst, int B, int Tsrc, int Tdst, int C, int off, hipStream_t s) {
+  unsigned gx = (unsigned)(((size_t)Tdst * C + 255) / 256);
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(pad_frames_k, dim3(gx, (unsigned)B), dim3(256), 0, s, src, dst, Tsrc, Tdst, C, off);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+static int glds_conv_forward(const w2l_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int relu,
+                             hipStream_t s) {
+  const int Tp = d->T + d->padl + d->padr, To = Tp - d->kw + 1;
+  const int K = d->kw * d->Cin;
+  const float* xs = x;
+  if (d->padl || d->padr) {
+    float* xp = conv_scratch(s, (size_t)d->B * Tp * d->Cin * sizeof(float));
+    if (!xp) return W2L_EUNSUPPORTED;
+    int st = pad_frames(x, xp, d->B, d->T, Tp, d->Cin, d->padl, s);
+    if (st) return st;
+    xs = xp;
+  }
+  GemmOut o{y, bias, d->B * Tp - d->kw + 1, d->Cout, K, d->Cout, 0};
+  gemm_set_row_remap(o, Tp, To, 0);
+  const int epi = (bias ? EPI_BIAS : 0) | (relu ? EPI_RELU : 0);
+  return gemm_glds_raw(xs, d->Cin, true, (size_t)d->B * Tp * d->Cin * sizeof(float), w, d->Cout, false,
+                       (size_t)K * d->Cout * sizeof(float), o, epi, s);
+}
+
+// scratch: [kw-1 zero frames | dyp [B][Tp][Cout]] [wf [kw][Cout][Cin]] ([xp [B][Tp][Cin]] for the filter gradient)
+static int glds_conv_backward_data(const w2l_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate,
+                                   const float* add, hipStream_t s) {
+  const int Tp = d->T + d->padl + d->padr, To = Tp - d->kw + 1;
+  const size_t front = (size_t)(d->kw - 1) * d->Cout, dypN = (size_t)d->B * Tp * d->Cout;
+  const size_t wfN = (size_t)d->kw * d->Cout * d->Cin;
+  const size_t dypAl = (front + dypN + 3) & ~(size_t)3;
+  float* sc = conv_scratch(s, (dypAl + wfN) * sizeof(float));
+  if (!sc) return W2L_EUNSUPPORTED;
+  float* wf = sc + dypAl;
+  W2L_HIP_CHECK(hipMemsetAsync(sc, 0, front * sizeof(float), s));
+  int st = pad_frames(dy, sc + front, d->B, To, Tp, d->Cout, 0, s);
+  if (st) return st;
+  for (int tap = 0; tap < d->kw; ++tap) {  // wf[kw-1-tap] = w[tap]^T
+    st = w2l_transpose(w + (size_t)tap * d->Cin * d->Cout, wf + (size_t)(d->kw - 1 - tap) * d->Cout * d->Cin, 1, d->Cin, d->Cout,
+                       (w2l_stream_t)s);
+    if (st) return st;
+  }
+  const int K = d->kw * d->Cout;
+  GemmOut o{dx, nullptr, d->B * Tp, d->Cin, K, d->Cin, 0};
+  if (d->padl || d->padr) gemm_set_row_remap(o, Tp, d->T, d->padl);
+  int epi = 0;
+  if (add) { o.addend = add; epi |= EPI_ACCUM; }
+  else if (accumulate) epi |= EPI_ACCUM;
+  return gemm_glds_raw(sc, d->Cout, true, (front + dypN) * sizeof(float), wf, d->Cin, false, wfN * sizeof(float), o, epi, s);
+}
+
+static int glds_conv_backward_filter(const w2l_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                                     hipStream_t s) {
+  const int Tp = d->T + d->padl + d->padr, To = Tp - d->kw + 1;
+  const size_t dypN = ((size_t)d->B * Tp * d->Cout + 3) & ~(size_t)3, xpN = (size_t)d->B * Tp * d->Cin;
+  const bool padded = d->padl || d->padr;
+  float* sc = conv_scratch(s, (dypN + (padded ? xpN : 0)) * sizeof(float));
+  if (!sc) return W2L_EUNSUPPORTED;
+  int st = pad_frames(dy, sc, d->B, To, Tp, d->Cout, 0, s);
+  if (st) return st;
+  const float* xs = x;
+  if (padded) {
+    st = pad_frames(x, sc + dypN, d->B, d->T, Tp, d->Cin, d->padl, s);
+    if (st) return st;
+    xs = sc + dypN;
+  }
+  GemmOut o{dw, nullptr, d->kw * d->Cin, d->Cout, d->B * Tp, d->Cout, 0};
+  st = gemm_glds_raw(xs, d->Cin, false, xpN * sizeof(float), sc, d->Cout, false, (size_t)d->B * Tp * d->Cout * sizeof(float), o, 0, s);
+  if (st) return st;
+  if (dbias) return colsum(dy, dbias, (size_t)d->B * To, d->Cout, s);
+  return W2L_OK;
+}
+
 static bool tds_path() {
   const char* e = getenv("W2L_CONV_TDS");
   return !(e && e[0] == '0');
@@ -367,6 +496,10 @@ W2L_API int w2l_conv_forward(const w2l_conv_desc* d, const float* x, const float
     st = tds_conv_forward(d, x, w, bias, y, relu, (hipStream_t)stream);
     if (st != W2L_EUNSUPPORTED) return st;
   }
+  if (glds_conv_applicable(d)) {
+    st = glds_conv_forward(d, x, w, bias, y, relu, (hipStream_t)stream);
+    if (st != W2L_EUNSUPPORTED) return st;
+  }
   const int To = out_len(d->T, d->kw, d->stride, d->padl, d->padr);
   const int M = d->B * To * d->H, K = d->kw * d->Cin, N = d->Cout;
   ConvGeom g{d->T, To, d->H, d->Cin, d->stride, 1, -d->padl, 1,
@@ -384,6 +517,10 @@ W2L_API int w2l_conv_backward_data(const w2l_conv_desc* d, const float* dy, cons
   if (!dy || !w || !dx) return W2L_EINVAL;
   if (tds_path() && tds_conv_applicable(d)) {
     st = tds_conv_backward_data(d, dy, w, dx, accumulate, nullptr, (hipStream_t)stream);
+    if (st != W2L_EUNSUPPORTED) return st;
+  }
+  if (glds_conv_applicable(d)) {
+    st = glds_conv_backward_data(d, dy, w, dx, accumulate, nullptr, (hipStream_t)stream);
     if (st != W2L_EUNSUPPORTED) return st;
   }
   const int To = out_len(d->T, d->kw, d->stride, d->padl, d->padr);
@@ -413,6 +550,10 @@ W2L_API int w2l_conv_backward_data_add(const w2l_conv_desc* d, const float* dy, 
     st = tds_conv_backward_data(d, dy, w, dx, 0, add, s);
     if (st != W2L_EUNSUPPORTED) return st;
   }
+  if (glds_conv_applicable(d)) {
+    st = glds_conv_backward_data(d, dy, w, dx, 0, add, s);
+    if (st != W2L_EUNSUPPORTED) return st;
+  }
   if (dx != add)
     W2L_HIP_CHECK(hipMemcpyAsync(dx, add, (size_t)d->B * d->T * d->H * d->Cin * sizeof(float), hipMemcpyDeviceToDevice, s));
   return w2l_conv_backward_data(d, dy, w, dx, 1, stream);
@@ -426,6 +567,10 @@ W2L_API int w2l_conv_backward_filter(const w2l_conv_desc* d, const float* x, con
   hipStream_t s = (hipStream_t)stream;
   if (tds_path() && tds_conv_applicable(d)) {
     st = tds_conv_backward_filter(d, x, dy, dw, dbias, s);
+    if (st != W2L_EUNSUPPORTED) return st;
+  }
+  if (glds_conv_applicable(d)) {
+    st = glds_conv_backward_filter(d, x, dy, dw, dbias, s);
     if (st != W2L_EUNSUPPORTED) return st;
   }
   const int To = out_len(d->T, d->kw, d->stride, d->padl, d->padr);

@@ -71,13 +71,14 @@ static int p3_mode() {
 static inline bool glds_ok(const float* p, int ld, int extent) {
   return (((uintptr_t)p) & 15) == 0 && ld % 4 == 0 && extent % 4 == 0 && extent >= 4;
 }
-// Relaxed eligibility of the buffer-addressed LDS-DMA kernels (W2L_GEMM_UNALIGNED=0 turns it off): 8-byte aligned
-// rows are enough for `buffer_load_dwordx4 ... lds` (dword alignment is what the instruction needs), and the extent of
+// Relaxed eligibility of the buffer-addressed LDS-DMA kernels (W2L_GEMM_UNALIGNED=0 turns it off): dword-aligned
+// rows are enough for `buffer_load_dwordx4 ... lds` (odd leading dimensions included), and the extent of
 // a k-row operand need not be a multiple of 4 -- a chunk that straddles a row end brings in the first floats of the
 // next row (zeros past the end of the buffer: num_records bounds the resource), which only feed columns >= N that
 // no epilogue stores.  This is what N = 9998 needs (final fl::Linear of the TDS-CTC recipe, dA of the ASG stress shape).
 static inline bool glds_ok_relaxed(const float* p, int ld, int extent) {
-  return (((uintptr_t)p) & 7) == 0 && ld % 2 == 0 && extent >= 4;
+  (void)ld;
+  return (((uintptr_t)p) & 3) == 0 && extent >= 4;  // dword-aligned rows: what buffer_load_dwordx4 ... lds needs (measured: r01_run45)
 }
 static bool unaligned_enabled() {
   const char* e = getenv("W2L_GEMM_UNALIGNED");
@@ -201,6 +202,23 @@ int gemm_f32(const float* A, int lda, int a_kcontig, const float* B, int ldb, in
   if (v == 4) return dispatch_b(PlainOp<false, 4>{A, lda, M, K}, B, ldb, b_kcontig, o, epi, splitk, s);
   if (v == 2) return dispatch_b(PlainOp<false, 2>{A, lda, M, K}, B, ldb, b_kcontig, o, epi, splitk, s);
   return dispatch_b(PlainOp<false, 1>{A, lda, M, K}, B, ldb, b_kcontig, o, epi, splitk, s);
+}
+
+// LDS-DMA GEMM on operand VIEWS prepared by the caller (overlapping-row convolution operands, conv.hip): no K % 32 or
+// alignment requirement beyond dword-aligned pointers.  K is rounded up to whole K tiles; the caller guarantees that
+// what the last K tile reads past K is either finite in-bounds data that meets zeros of the other operand, or lies
+// outside the operand's byte range (buffer addressing returns zeros).  W2L_EUNSUPPORTED: operand >= 2 GiB.
+int gemm_glds_raw(const float* A, int lda, bool akc, size_t aBytes, const float* B, int ldb, bool bkc, size_t bBytes,
+                  GemmOut o, int epi, hipStream_t s) {
+  if (!glds_enabled() || !unaligned_enabled()) return W2L_EUNSUPPORTED;
+  if (aBytes >= 0x7fffffffull || bBytes >= 0x7fffffffull || ((uintptr_t)A & 3) || ((uintptr_t)B & 3)) return W2L_EUNSUPPORTED;
+  GOp ga{A, lda, o.M, (unsigned)aBytes}, gb{B, ldb, o.N, (unsigned)bBytes};
+  if (const int which = t160_choice(ga, gb, o)) {
+    bool launched = false;
+    const int st = launch160(ga, akc, gb, bkc, o, epi, which, s, &launched);
+    if (st != W2L_OK || launched) return st;
+  }
+  return launch128g(ga, akc, gb, bkc, o, epi, s);
 }
 
 }  // namespace w2l

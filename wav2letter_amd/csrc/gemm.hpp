@@ -30,7 +30,31 @@ struct GemmOut {
   // stateless hash, on the same flat index, as dropout_k over the dense [M][ldc] output
   uint32_t dropThr = 0, dropSeed = 0, dropStream = 0;
   float dropScale = 1.f;
+  // Row remap of the epilogue (overlapping-row convolution GEMMs, conv.hip): GEMM row m = b * rowPin + t' is stored as
+  // output row b * rowPout + (t' - rowOff) if 0 <= t' - rowOff < rowPout and dropped otherwise.  rowPin = 0: identity.
+  int rowPin = 0, rowPout = 0, rowOff = 0;
+  uint32_t rowMul = 0, rowShr = 0;  // fast division by rowPin
 };
+
+inline void gemm_set_row_remap(GemmOut& o, int pin, int pout, int off) {
+  o.rowPin = pin; o.rowPout = pout; o.rowOff = off;
+  uint32_t sh = 0;
+  while ((1ull << sh) < (uint32_t)pin) ++sh;
+  o.rowShr = sh;
+  o.rowMul = (uint32_t)((((1ull << sh) - (uint32_t)pin) << 32) / (uint32_t)pin + 1);
+}
+
+// GEMM row -> output row (false: the row is not stored)
+__device__ __forceinline__ bool gemm_out_row(const GemmOut& o, int m, int& mo) {
+  if (m >= o.M) return false;
+  mo = m;
+  if (!o.rowPin) return true;
+  const uint32_t b = (uint32_t)(((uint64_t)__umulhi((uint32_t)m, o.rowMul) + (uint32_t)m) >> o.rowShr);
+  const int t = m - (int)b * o.rowPin - o.rowOff;
+  if (t < 0 || t >= o.rowPout) return false;
+  mo = (int)b * o.rowPout + t;
+  return true;
+}
 
 // A GEMM operand viewed as op(k, i): i = row of A (m) or column of B (n).
 //   KCONTIG = true : element (k,i) at p[i*ld + k]   (reduction index contiguous)
@@ -430,8 +454,8 @@ __device__ __forceinline__ void gemm128_epilogue(const GemmOut& out, int m0, int
       if (EPI & EPI_BIAS) bv = out.bias[n];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m >= out.M) continue;
+        int m;
+        if (!gemm_out_row(out, m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, m)) continue;
         float v = acc[i][j][r] + bv;
         float* dst = out.C + (size_t)m * out.ldc + n;
         if (EPI & EPI_RELU) v = fmaxf(v, 0.f);
@@ -684,5 +708,8 @@ struct GemmExtra {  // optional epilogue operands of gemm_f32
 int gemm_f32(const float* A, int lda, int a_kcontig, const float* B, int ldb, int b_kcontig, float* C,
              int ldc, int M, int N, int K, const float* bias, int epi, int splitk, hipStream_t s,
              const float* mask = nullptr, float maskScale = 1.f, const GemmExtra* extra = nullptr);
+// LDS-DMA kernels on caller-prepared operand views (see gemm.hip); o carries M, N, K, C, ldc, bias and the row remap
+int gemm_glds_raw(const float* A, int lda, bool akc, size_t aBytes, const float* B, int ldb, bool bkc, size_t bBytes,
+                  GemmOut o, int epi, hipStream_t s);
 
 }  // namespace w2l

@@ -151,8 +151,8 @@ __device__ __forceinline__ void gemm128g_epilogue_wide(const GemmOut& out, int m
     for (int p = 0; p < 8; ++p) {
       const int row = 4 * p + rq;
       const f32x4 v4 = *(const f32x4*)(sc + row * 64 + c4);
-      const int m = m0 + wm + 32 * i + row;
-      if (m >= out.M || n >= out.N) continue;
+      int m;
+      if (!gemm_out_row(out, m0 + wm + 32 * i + row, m) || n >= out.N) continue;
       float v[4] = {v4[0] + bv[0], v4[1] + bv[1], v4[2] + bv[2], v4[3] + bv[3]};
       float* dst = out.C + (size_t)m * out.ldc + n;
       if (EPI & EPI_RELU) {

@@ -95,8 +95,8 @@ __device__ __forceinline__ void t160_epilogue(const GemmOut& out, int m0, int n0
       for (int p = 0; p < 4; ++p) {
         const int row = 8 * p + rq;
         const f32x4 v4 = *(const f32x4*)(sc + row * 32 + c4);
-        const int m = m0 + 32 * i + row;
-        if (m >= out.M || n >= out.N) continue;
+        int m;
+        if (!gemm_out_row(out, m0 + 32 * i + row, m) || n >= out.N) continue;
         float v[4] = {v4[0] + bv[j][0], v4[1] + bv[j][1], v4[2] + bv[j][2], v4[3] + bv[j][3]};
         float* dst = out.C + (size_t)m * out.ldc + n;
         if (EPI & EPI_RELU) {
