@@ -539,6 +539,25 @@ def test_tds_block_composed_from_kernels(oracle):
     assert abs(dgb2[1].item() - g_ref["b2n"]) < 1e-3 * max(1, abs(g_ref["b2n"]))
 
 
+@pytest.mark.parametrize("K,N", [(15, 4), (520, 400), (2800, 442), (333, 77), (6099, 706)])
+def test_weightnorm_columns(oracle, K, N):
+    """fl::WeightNorm over the internal [K][Nout] layout (WN 3 C: K = kw*C_in, WN 0 L: K = in): w, dv, dg against the
+    oracle; two-pass column reductions are run-to-run identical"""
+    from wav2letter_amd import ops
+    rng = np.random.default_rng(K + N)
+    v = rng.normal(size=(K, N)).astype(np.float32)
+    g = rng.uniform(0.5, 2.0, size=N).astype(np.float32)
+    dw = rng.normal(size=(K, N)).astype(np.float32)
+    w, norm = ops.weightnorm_forward(dev(v), dev(g))
+    assert rel(w, oracle.weightnorm_fwd(v, g, K, N, 1)) < TOL
+    assert rel(norm, np.sqrt((v.astype(np.float64) ** 2).sum(0))) < 1e-5
+    dv, dg = ops.weightnorm_backward(dev(v), dev(g), norm, dev(dw))
+    odv, odg = oracle.weightnorm_bwd(v, g, dw, K, N, 1)
+    assert rel(dv, odv) < TOL and rel(dg, odg) < TOL
+    dv2, dg2 = ops.weightnorm_backward(dev(v), dev(g), norm, dev(dw))
+    assert torch.equal(dv, dv2) and torch.equal(dg, dg2)
+
+
 def test_glu_transpose_sgd(oracle):
     from wav2letter_amd import ops
     rng = np.random.default_rng(8)

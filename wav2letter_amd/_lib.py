@@ -71,6 +71,8 @@ class _SIGS:
     w2l_linear_backward_data = (_i, [_i, _i, _i, _p, _p, _p, _i, _p, _f, _p])
     w2l_linear_backward_weight = (_i, [_i, _i, _i, _p, _p, _p, _p])
     w2l_colsum = (_i, [_p, _p, _sz, _i, _p])
+    w2l_weightnorm_forward = (_i, [_p, _p, _p, _p, _i, _i, _p])
+    w2l_weightnorm_backward = (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p])
     w2l_conv_out_len = (_i, [_i, _i, _i, _i, _i])
     w2l_conv_same_pad = (_i, [_i, _i, _i])
     w2l_conv_forward = (_i, [_p, _p, _p, _p, _p, _i, _p])

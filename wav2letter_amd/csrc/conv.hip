@@ -362,14 +362,21 @@ float* conv_scratch(hipStream_t s, size_t bytes) {  // library-owned, grows on d
   return e.first;
 }
 
-// dst[b][t'][c] = src[b][t' - off][c] if 0 <= t' - off < Tsrc else 0     (frames of C floats)
+// dst[b][t'][c] = src[b][t' - off][c] if 0 <= t' - off < Tsrc else 0     (frames of C floats; V floats per access)
+template <int V>
 __global__ __launch_bounds__(256) void pad_frames_k(const float* __restrict__ src, float* __restrict__ dst, int Tsrc, int Tdst,
                                                     int C, int off) {
+  typedef float vec_t __attribute__((ext_vector_type(V)));
   const int b = blockIdx.y;
-  const size_t n = (size_t)Tdst * C;
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
-    const int t = (int)(e / C) - off;
-    dst[(size_t)b * n + e] = (t >= 0 && t < Tsrc) ? src[((size_t)b * Tsrc + t) * C + (e % C)] : 0.f;
+  const int cv = C / V;                                   // vectors per frame
+  const size_t nv = (size_t)Tdst * cv;
+  const vec_t* sv = (const vec_t*)src + (size_t)b * Tsrc * cv;
+  vec_t* dv = (vec_t*)dst + (size_t)b * nv;
+  const size_t shift = (size_t)off * cv, lim = (size_t)Tsrc * cv;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nv; e += (size_t)gridDim.x * 256) {
+    vec_t v = 0.f;
+    if (e >= shift && e - shift < lim) v = __builtin_nontemporal_load(sv + (e - shift));  // frames are contiguous: no division
+    dv[e] = v;
   }
 }
 
@@ -382,9 +389,13 @@ static bool glds_conv_applicable(const w2l_conv_desc* d) {
          (int64_t)d->B * (d->T + d->padl + d->padr) < (1ll << 30);
 }
 static int pad_frames(const float* src, float* dst, int B, int Tsrc, int Tdst, int C, int off, hipStream_t s) {
-  unsigned gx = (unsigned)(((size_t)Tdst * C + 255) / 256);
-  if (gx > 4096) gx = 4096;
-  hipLaunchKernelGGL(pad_frames_k, dim3(gx, (unsigned)B), dim3(256), 0, s, src, dst, Tsrc, Tdst, C, off);
+  const bool a16 = ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0, a8 = ((((uintptr_t)src) | ((uintptr_t)dst)) & 7) == 0;
+  const int V = (C % 4 == 0 && a16) ? 4 : (C % 2 == 0 && a8) ? 2 : 1;
+  unsigned gx = (unsigned)(((size_t)Tdst * (C / V) + 255) / 256);
+  if (gx > 2048) gx = 2048;
+  if (V == 4) hipLaunchKernelGGL(pad_frames_k<4>, dim3(gx, (unsigned)B), dim3(256), 0, s, src, dst, Tsrc, Tdst, C, off);
+  else if (V == 2) hipLaunchKernelGGL(pad_frames_k<2>, dim3(gx, (unsigned)B), dim3(256), 0, s, src, dst, Tsrc, Tdst, C, off);
+  else hipLaunchKernelGGL(pad_frames_k<1>, dim3(gx, (unsigned)B), dim3(256), 0, s, src, dst, Tsrc, Tdst, C, off);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }

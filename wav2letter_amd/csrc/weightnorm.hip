@@ -5,24 +5,79 @@
 // Both internal weight layouts ([kw*Cin][Cout] for "WN 3 C", [in][out] for "WN 0 L") are
 // [K][Nout] matrices normalised per column, so one kernel pair serves both.
 #include "common.hpp"
+#include "gemm.hpp"  // sk_scratch: the shared per-stream scratch
 
 namespace w2l {
 
-// one block per 64 columns, 4 waves split the rows; sums of squares / dot products per column
-__global__ __launch_bounds__(256) void wn_colreduce_k(const float* __restrict__ a, const float* __restrict__ b,
-                                                      float* __restrict__ out, int K, int N, int sqrtOut) {
+// per-column sums of squares / dot products over the K rows of [K][N] matrices, two deterministic passes (row-block
+// partials in the stream scratch, then a fixed-order sum): the one-pass version ran N/64 <= 29 workgroups for the 174 MB
+// weight of the last conv_glu layer (2.6 ms a call, 35 ms per C4 step; profiles/r01_run49_c4_kernel_stats.csv)
+constexpr int kWnMaxParts = 128;
+
+template <int V>
+__global__ __launch_bounds__(256) void wn_colreduce_partial_k(const float* __restrict__ a, const float* __restrict__ b,
+                                                              float* __restrict__ partial, int K, int N, int rowsPerBlock) {
+  typedef float vec_t __attribute__((ext_vector_type(V)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = (blockIdx.x * 64 + lane) * V;
+  __shared__ float sm[4][64 * V];
+  const int k0 = blockIdx.y * rowsPerBlock;
+  int k1 = k0 + rowsPerBlock;
+  if (k1 > K) k1 = K;
+  vec_t acc0 = 0.f, acc1 = 0.f;
+  if (n < N) {
+    int k = k0 + wave;
+    for (; k + 4 < k1; k += 8) {
+      const vec_t a0 = *(const vec_t*)(a + (size_t)k * N + n), b0 = *(const vec_t*)(b + (size_t)k * N + n);
+      const vec_t a1 = *(const vec_t*)(a + (size_t)(k + 4) * N + n), b1 = *(const vec_t*)(b + (size_t)(k + 4) * N + n);
+      acc0 += a0 * b0; acc1 += a1 * b1;
+    }
+    for (; k < k1; k += 4) acc0 += *(const vec_t*)(a + (size_t)k * N + n) * *(const vec_t*)(b + (size_t)k * N + n);
+  }
+  const vec_t acc = acc0 + acc1;
+#pragma unroll
+  for (int v = 0; v < V; ++v) sm[wave][lane * V + v] = acc[v];
+  __syncthreads();
+  for (int c = threadIdx.x; c < 64 * V; c += 256) {
+    const int nn = blockIdx.x * 64 * V + c;
+    if (nn < N) partial[(size_t)blockIdx.y * N + nn] = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+  }
+}
+
+__global__ __launch_bounds__(256) void wn_colreduce_finish_k(const float* __restrict__ partial, float* __restrict__ out, int parts,
+                                                             int N, int sqrtOut) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
   __shared__ float sm[4][64];
-  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int part = threadIdx.x >> 6;
   float s = 0.f;
   if (n < N)
-    for (int k = part; k < K; k += 4) s += a[(size_t)k * N + n] * b[(size_t)k * N + n];
-  sm[part][threadIdx.x & 63] = s;
+    for (int p = wave; p < parts; p += 4) s += partial[(size_t)p * N + n];
+  sm[wave][lane] = s;
   __syncthreads();
-  if (part == 0 && n < N) {
-    float t = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+  if (wave == 0 && n < N) {
+    const float t = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
     out[n] = sqrtOut ? sqrtf(t) : t;
   }
+}
+
+static int wn_colreduce(const float* a, const float* b, float* out, int K, int N, int sqrtOut, hipStream_t s) {
+  int rowsPerBlock = (K + kWnMaxParts - 1) / kWnMaxParts;
+  if (rowsPerBlock < 16) rowsPerBlock = 16;
+  const int parts = (K + rowsPerBlock - 1) / rowsPerBlock;
+  float* partial = sk_scratch(s, kSkScratchBytes);
+  if (!partial || (size_t)parts * N * sizeof(float) > kSkScratchBytes) return W2L_EHIP;
+  const bool al = ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0 && N % 4 == 0;
+  if (al) {
+    dim3 grid((unsigned)((N + 255) / 256), (unsigned)parts);
+    hipLaunchKernelGGL(wn_colreduce_partial_k<4>, grid, dim3(256), 0, s, a, b, partial, K, N, rowsPerBlock);
+  } else {
+    dim3 grid((unsigned)((N + 63) / 64), (unsigned)parts);
+    hipLaunchKernelGGL(wn_colreduce_partial_k<1>, grid, dim3(256), 0, s, a, b, partial, K, N, rowsPerBlock);
+  }
+  W2L_LAUNCH_CHECK();
+  hipLaunchKernelGGL(wn_colreduce_finish_k, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, partial, out, parts, N, sqrtOut);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
 }
 
 __global__ __launch_bounds__(256) void wn_apply_k(const float* __restrict__ v, const float* __restrict__ g,
@@ -93,8 +148,7 @@ W2L_API int w2l_weightnorm_forward(const float* v, const float* g, float* w, flo
                                    w2l_stream_t stream) {
   if (!v || !g || !w || !norm || K <= 0 || N <= 0) return W2L_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(wn_colreduce_k, dim3((N + 63) / 64), dim3(256), 0, s, v, v, norm, K, N, 1);
-  W2L_LAUNCH_CHECK();
+  { const int st = wn_colreduce(v, v, norm, K, N, 1, s); if (st) return st; }
   size_t total = (size_t)K * N;
   unsigned grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipLaunchKernelGGL(wn_apply_k, dim3(grid), dim3(256), 0, s, v, g, norm, w, total, N);
@@ -107,8 +161,7 @@ W2L_API int w2l_weightnorm_backward(const float* v, const float* g, const float*
                                     float* dv, float* dg, float* dot, int K, int N, w2l_stream_t stream) {
   if (!v || !g || !norm || !dw || !dv || !dg || !dot || K <= 0 || N <= 0) return W2L_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(wn_colreduce_k, dim3((N + 63) / 64), dim3(256), 0, s, v, dw, dot, K, N, 0);
-  W2L_LAUNCH_CHECK();
+  { const int st = wn_colreduce(v, dw, dot, K, N, 0, s); if (st) return st; }
   size_t total = (size_t)K * N;
   unsigned grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipLaunchKernelGGL(wn_bwd_k, dim3(grid), dim3(256), 0, s, v, g, norm, dot, dw, dv, dg, total, N);

@@ -36,6 +36,24 @@ def linear_forward(x, w, bias=None, relu=False):
     return y
 
 
+def weightnorm_forward(v, g):
+    """fl::WeightNorm on the internal [K][Nout] weight layout: w = v * g / ||v|| per column; returns (w, norm)"""
+    K, N = v.shape
+    w = torch.empty_like(v)
+    norm = torch.empty(N, device=v.device, dtype=torch.float32)
+    check(_lib.lib().w2l_weightnorm_forward(_p(v), _p(g), _p(w), _p(norm), K, N, _s()), "weightnorm_forward")
+    return w, norm
+
+
+def weightnorm_backward(v, g, norm, dw):
+    K, N = v.shape
+    dv = torch.empty_like(v)
+    dg = torch.empty(N, device=v.device, dtype=torch.float32)
+    dot = torch.empty(N, device=v.device, dtype=torch.float32)
+    check(_lib.lib().w2l_weightnorm_backward(_p(v), _p(g), _p(norm), _p(dw), _p(dv), _p(dg), _p(dot), K, N, _s()), "weightnorm_backward")
+    return dv, dg
+
+
 def colsum(x):
     """out[n] = sum_m x[m][n] (bias gradient): deterministic two-pass sum"""
     M, N = x.shape
