@@ -24,18 +24,19 @@ def load(path, col):
 def main():
     fetch_csv, write_csv, out_json = sys.argv[1:4]
     f, w = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
-    groups = {"gemm128g": "gemm128g_kernel", "gemm128_kernel": "gemm128_kernel", "fcc_big_gemm": "fcc_big_gemm",
-              "tds_conv_fwd2": "tds_conv_fwd2_k", "tds_conv_filter2": "tds_conv_filter2_k"}
+    groups = {"gemm_lds_dma": ("gemm128g_kernel", "gemm160_kernel"), "gemm128g": ("gemm128g_kernel",), "gemm160": ("gemm160_kernel",),
+              "gemm128_kernel": ("gemm128_kernel",), "fcc_big_gemm": ("fcc_big_gemm",),
+              "tds_conv_fwd2": ("tds_conv_fwd2_k",), "tds_conv_filter2": ("tds_conv_filter2_k",)}
     res = {}
-    for key, sub in groups.items():
+    for key, subs in groups.items():
         n = fb = wb = 0.0
         for k, (disp, v) in f.items():
-            if sub in k:
+            if any(sub in k for sub in subs):
                 n += disp
                 fb += disp * v * 1024.0 * 2.0
         nw = 0.0
         for k, (disp, v) in w.items():
-            if sub in k:
+            if any(sub in k for sub in subs):
                 nw += disp
                 wb += disp * v * 1024.0
         if n:

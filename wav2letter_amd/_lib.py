@@ -31,7 +31,8 @@ def lib():
             raise W2LError(
                 f"{SO_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C wav2letter_amd/csrc` (no CPU fallback exists)")
-        _lib = C.CDLL(SO_PATH)
+        # W2L_LIB_PATH: load another build of the same library (A/B runs of two kernel generations, tools/ only)
+        _lib = C.CDLL(os.environ.get("W2L_LIB_PATH") or SO_PATH)
         _lib.w2l_version.restype = C.c_char_p
         for name in dir(_SIGS):
             if name.startswith("w2l_"):
