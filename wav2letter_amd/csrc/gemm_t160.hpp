@@ -357,9 +357,12 @@ inline int launch160(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o, 
   const size_t shmem = 2 * (size_t)kT160StageFloats * sizeof(float);
   dim3 grid((unsigned)workers), block(256);
   o.epi = epi;
-  static bool attr = false;
-  if (!attr) {
-    attr = true;
+  static bool attr[64] = {};  // per device: the 72 KiB dynamic LDS opt-in is a property of the function ON a device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (!attr[dev]) {
+    attr[dev] = true;
 #define W2L_T160_ATTR(A, B, T) (void)hipFuncSetAttribute((const void*)gemm160_kernel<A, B, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)
     W2L_T160_ATTR(true, true, false); W2L_T160_ATTR(true, false, false); W2L_T160_ATTR(false, true, false); W2L_T160_ATTR(false, false, false);
     W2L_T160_ATTR(true, true, true); W2L_T160_ATTR(true, false, true); W2L_T160_ATTR(false, true, true); W2L_T160_ATTR(false, false, true);
