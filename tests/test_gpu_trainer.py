@@ -111,6 +111,31 @@ def test_conv_glu_asg_small_end_to_end(oracle):
     assert (path == oracle.viterbi(em, A)).all()
 
 
+def test_conv_glu_asg_wide_layers_end_to_end(oracle):
+    """the same miniature with layers wide enough for the overlapping-row LDS-DMA convolution path (kw*C_in >= 64,
+    C_out >= 32; first layer explicitly padded, second SAME-padded with an even kernel): emissions, loss, every
+    parameter gradient (weight-norm v, g, bias) and the transition gradient against the reference network + oracle"""
+    from wav2letter_amd import recipes
+    rng = np.random.default_rng(5)
+    nfeat, nlabel, B, T, L = 16, 9, 3, 50, 7
+    arch = recipes.conv_glu_small_arch(widths=(64, 96), kws=(5, 4), pad0=2)
+    tr, ref, params, A = build(arch, nfeat, nlabel, "asg", 4, 4.0, rng, B, T, L)
+    x = rng.normal(size=(B, 1, nfeat, T)).astype(np.float32)
+    tgt = np.array([[1, 2, 3, 1, -1, -1, -1], [0, 5, 5, 2, 7, 1, 0], [4, 4, -1, -1, -1, -1, -1]], np.int32)
+    xd = torch.tensor(x.reshape(B, nfeat, T)).cuda()
+    td = torch.tensor(tgt).cuda()
+    em = tr.forward(xd, train=False).cpu().numpy()
+    em_ref = ref.forward(x, params)
+    assert em.shape == em_ref.shape, (em.shape, em_ref.shape)
+    assert rel(em, em_ref) < TOL
+    loss = tr.forward_backward(xd, td).cpu().numpy()
+    ol, odx, odA = oracle.asg(em_ref, A, tgt, 4)
+    assert rel(loss, ol) < TOL
+    check_grads(tr, ref.backward(odx.astype(np.float32), len(params)))
+    gA = tr.grads.cpu().numpy()[tr.n_net:tr.n_net + nlabel * nlabel]
+    assert rel(gA, odA) < TOL
+
+
 def test_linseg_warmup_then_asg(oracle):
     """--linseg=1 (every ASG recipe): update 0 runs LinSegCriterion on the ASG transitions, update 1 onwards ASG;
     both through the C++ trainer, against the oracle on the reference network's emissions"""
