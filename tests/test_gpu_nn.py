@@ -458,6 +458,30 @@ def test_conv_glu_overlapping_rows_equals_implicit_gemm(B, Cin, Cout, T, kw, pad
         assert rel(a, c.cpu().numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("B,Cin,Cout,T,kw,padl,padr", [(64, 388, 852, 2000, 21, 0, 0),      # C4 layer 9 at full size
+                                                        (64, 40, 400, 2000, 13, 170, 170),  # C4 layer 1 (zero padding)
+                                                        (16, 826, 1816, 2000, 29, 0, 0)])   # C4 layer 17 (batch reduced)
+def test_conv_glu_full_size_adjoint_identities(B, Cin, Cout, T, kw, padl, padr):
+    """BASELINE config 4 layer sizes, where the oracle cannot run: the convolution is bilinear in (x, w), so
+    <conv(x, w), dy> = <x, backward_data(dy, w)> = <w, backward_filter(x, dy)> -- one number computed three ways through
+    three different GEMMs of the overlapping-row path -- and the bias gradient is the column sum of dy"""
+    from wav2letter_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(Cin + kw)
+    x = torch.randn(B, T, 1, Cin, generator=g, device="cuda")
+    w = torch.randn(kw, Cin, Cout, generator=g, device="cuda") / (kw * Cin) ** 0.5
+    To = T + padl + padr - kw + 1
+    dy = torch.randn(B, To, 1, Cout, generator=g, device="cuda")
+    y = ops.conv_forward(x, w, None, 1, padl, padr)
+    dx, dw, db = ops.conv_backward(x, w, dy, 1, padl, padr)
+    a = (y.double() * dy.double()).sum().item()
+    b = (x.double() * dx.double()).sum().item()
+    c = (w.double() * dw.double()).sum().item()
+    scale = (y.double().abs() * dy.double().abs()).sum().item()
+    assert abs(a - b) < 1e-5 * scale and abs(a - c) < 1e-5 * scale, (a, b, c, scale)
+    assert rel(db, dy.double().sum(dim=(0, 1, 2)).cpu().numpy()) < 1e-5
+    assert torch.isfinite(y).all() and torch.isfinite(dx).all() and torch.isfinite(dw).all()
+
+
 def test_golden_conv1d_on_device():
     """the reference's own golden vector (Conv1dTest.cpp:30-104) through the HIP conv"""
     import json, os
