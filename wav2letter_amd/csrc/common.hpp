@@ -40,6 +40,12 @@ __host__ __device__ inline float scale_of(int mode, int T, int L) {
   }
 }
 
+// natural log / exp through the hardware base-2 transcendentals (v_log_f32 / v_exp_f32, 1 ulp): the serial criterion
+// scans pay for every instruction of their per-frame dependency chain, and `__logf` under -fno-fast-math expands to
+// ocml's extended-precision sequence (~12 instructions).  Arguments are normal, positive (log) / <= ~0 (exp) here.
+__device__ __forceinline__ float fast_logf(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
+__device__ __forceinline__ float fast_expf(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+
 // ---- wavefront helpers (wave = 64 lanes) ----------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
@@ -62,6 +68,26 @@ __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, dpp_row_ror<8>(v));
   float a = readlane(v, 0), b = readlane(v, 16), c = readlane(v, 32), d = readlane(v, 48);
   return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+
+// max over the first ROWS rows of 16 lanes (ROWS = 2: lanes 0..31), result uniform.  The reduction inside a row is
+// four `v_max_f32_dpp` written in place (one instruction per step where the builtin form costs a v_mov_dpp, a
+// canonicalising v_max and the v_max proper); a DPP source written by the previous VALU instruction needs two wait
+// states (s_nop 1).  Row-scoped DPP reads and writes the same 16 lanes in one pass, so in-place is safe.
+template <int ROWS>
+__device__ __forceinline__ float wave_max_rows(float v) {
+  asm volatile(
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0"
+      : "+v"(v));
+  float m = readlane(v, 0);
+  if (ROWS > 1) m = fmaxf(m, readlane(v, 16));
+  if (ROWS > 2) m = fmaxf(m, readlane(v, 32));
+  if (ROWS > 3) m = fmaxf(m, readlane(v, 48));
+  return m;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

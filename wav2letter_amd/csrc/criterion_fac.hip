@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64) void fac_fwd(int T, int N, int L, int scaleMode
               float d = (float)(fmin(s1, s2) - m);   // <= 0, may be -inf
               float ed = __expf(d);
               float den = 1.f + ed;
-              na = m + (double)__logf(den) + (double)xc[u][p];
+              na = m + (double)fast_logf(den) + (double)xc[u][p];
               float inv = 1.f / den;
               w = (s1 >= s2) ? inv : ed * inv;
             }
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(64 * NW) void fac_fwd_blk(int T, int N, int L, int 
               const float d = (float)(fmin(s1, s2) - m);  // <= 0, may be -inf
               const float ed = __expf(d);
               const float den = 1.f + ed;
-              na = m + (double)__logf(den) + (double)xc[u][p];
+              na = m + (double)fast_logf(den) + (double)xc[u][p];
               const float inv = 1.f / den;
               w = (s1 >= s2) ? inv : ed * inv;
             }

@@ -97,10 +97,10 @@ __global__ __launch_bounds__(64) void fcc_fwd_small(int T, int N, int scaleMode,
             s1 = fmaf(EA[j + 1], readlane(e, j + 1), s1);
           }
           float s = fmaxf(s0 + s1, 1e-37f);
-          ls = __logf(s);
+          ls = fast_logf(s);
           a = act ? (xc[u] + rowmax + ls) : NEG;
         }
-        float c = wave_max(a);
+        float c = wave_max_rows<(NP > 32 ? 4 : 2)>(a);
         ah = a - c;
         C += (double)c;
         if (act) {
