@@ -114,6 +114,14 @@ __device__ __forceinline__ double lane_shift_up(double v, double fill) {
   double r = __shfl_up(v, 1);
   return lane_id() == 0 ? fill : r;
 }
+// value of lane-1 through DPP wave_shr:1 (no LDS round trip: ds_bpermute costs ~100 cycles in a serial scan)
+__device__ __forceinline__ double lane_shift_up_dpp(double v, double fill) {
+  const long long bits = __double_as_longlong(v), fb = __double_as_longlong(fill);
+  const int lo = __builtin_amdgcn_update_dpp((int)fb, (int)bits, 0x138, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(fb >> 32), (int)(bits >> 32), 0x138, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 __device__ __forceinline__ float lane_shift_down(float v, float fill) {
   float r = __shfl_down(v, 1);
   return lane_id() == 63 ? fill : r;

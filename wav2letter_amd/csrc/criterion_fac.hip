@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64) void fac_fwd(int T, int N, int L, int scaleMode
         if (t == 0) {
           if (lane == 0) alpha[0] = (double)xc[u][0];
         } else {
-          double carry = lane_shift_up(alpha[P - 1], NEG);  // alpha_{t-1}[lane*P - 1]
+          double carry = lane_shift_up_dpp(alpha[P - 1], NEG);  // alpha_{t-1}[lane*P - 1]
           double prevA = carry;
 #pragma unroll
           for (int p = 0; p < P; ++p) {
@@ -298,26 +298,27 @@ __global__ __launch_bounds__(64 * NW) void fac_fwd_blk(int T, int N, int L, int 
         if (t == 0) {
           if (tid == 0) alpha[0] = (double)xc[u][0];
         } else {
+          // all neighbour reads first, then branch-free arithmetic: the P positions of a lane are independent
+          // dependency chains and interleave (the branchy form ran them one after the other, each behind its own
+          // LDS round trip: ~500 cycles per position); 1/den through v_rcp_f32 (den in [1, 2])
+          double prevA[P];
+#pragma unroll
+          for (int p = 0; p < P; ++p) prevA[p] = sA[(t - 1) & 1][tid + NT * p];  // alpha_{t-1}[i-1]
 #pragma unroll
           for (int p = 0; p < P; ++p) {
             const int i = tid + NT * p;
-            const double prevA = sA[(t - 1) & 1][i];  // alpha_{t-1}[i-1]
-            const double cur = alpha[p];
-            const double s1 = cur + (double)selfT[p];
-            const double s2 = prevA + (double)prevT[p];
+            const double s1 = alpha[p] + (double)selfT[p];
+            const double s2 = prevA[p] + (double)prevT[p];
             const double m = fmax(s1, s2);
-            double na = NEG;
-            float w = 0.f;
-            if (i < S && m != NEG) {
-              const float d = (float)(fmin(s1, s2) - m);  // <= 0, may be -inf
-              const float ed = __expf(d);
-              const float den = 1.f + ed;
-              na = m + (double)fast_logf(den) + (double)xc[u][p];
-              const float inv = 1.f / den;
-              w = (s1 >= s2) ? inv : ed * inv;
-            }
-            if (i < S) w1b[(size_t)t * L + i] = w;
-            alpha[p] = na;
+            const bool live = i < S && m != NEG;
+            const float d = (float)(fmin(s1, s2) - m);  // <= 0, -inf for a dead branch, NaN only when !live
+            const float ed = fast_expf(d);
+            const float den = 1.f + ed;
+            const double na = m + (double)fast_logf(den) + (double)xc[u][p];
+            const float inv = __builtin_amdgcn_rcpf(den);
+            const float w = (s1 >= s2) ? inv : ed * inv;
+            if (i < S) w1b[(size_t)t * L + i] = live ? w : 0.f;
+            alpha[p] = live ? na : NEG;
           }
         }
 #pragma unroll
@@ -560,6 +561,22 @@ W2L_API int w2l_fac_forward(int B, int T, int N, int L, int scaleMode, const flo
   if (L > 512) return W2L_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   FacWs ws = fac_ws(workspace, B, T, N, L);
+  static const int waveMode = [] { const char* e = getenv("W2L_FAC_WAVE"); return e ? atoi(e) : 0; }();
+  if (waveMode && L <= 384) {  // experiment: one wave per utterance, ceil(L/64) positions per lane, DPP neighbour exchange
+    const int P = (L + 63) / 64;
+#define W2L_FAC_WAVE_GO(PP) hipLaunchKernelGGL(fac_fwd<PP>, dim3(B), dim3(64), 0, s, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws)
+    switch (P) {
+      case 1: W2L_FAC_WAVE_GO(1); break;
+      case 2: W2L_FAC_WAVE_GO(2); break;
+      case 3: W2L_FAC_WAVE_GO(3); break;
+      case 4: W2L_FAC_WAVE_GO(4); break;
+      case 5: W2L_FAC_WAVE_GO(5); break;
+      default: W2L_FAC_WAVE_GO(6); break;
+    }
+#undef W2L_FAC_WAVE_GO
+    W2L_LAUNCH_CHECK();
+    return W2L_OK;
+  }
   W2L_FAC_BLK_DISPATCH(fac_fwd_blk, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
