@@ -577,7 +577,11 @@ W2L_API int w2l_fac_forward(int B, int T, int N, int L, int scaleMode, const flo
     W2L_LAUNCH_CHECK();
     return W2L_OK;
   }
-  W2L_FAC_BLK_DISPATCH(fac_fwd_blk, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws);
+  // workgroup shapes measured at B = 64, T = 2000, L = 300 (profiles/r01_run56_fac_shapes.log): one position per lane
+  // wins the forward scan -- 8 waves x 1: 0.60 ms, 4 x 2: 0.77, 2 x 3: 0.87, 1 x 5: 1.20 -- the backward scan (a
+  // handful of fp32 operations per step, barrier-bound) is fastest with 4 waves x 2
+  if (L > 256) hipLaunchKernelGGL((fac_fwd_blk<8, 1>), dim3(B), dim3(512), 0, s, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws);
+  else W2L_FAC_BLK_DISPATCH(fac_fwd_blk, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }
