@@ -309,15 +309,32 @@ __global__ __launch_bounds__(64) void viterbi_small(int T, int N, const float* _
         if (t == 0) {
           delta = act ? xc[u] : NEG;
         } else {
-          // strict '>' scan over j upward: first maximum wins (oracle order)
-          float best = readlane(delta, 0) + A[0];
-          int arg = 0;
+          // strict '>' scan over j upward: first maximum wins (oracle order).  Four independent scans over quarter
+          // ranges, combined in range order with the same strict '>' (an earlier range keeps ties): the same
+          // argmax as one 31-link compare/select chain at a quarter of its dependency depth.
+          constexpr int Q = NP / 4;
+          float bq[4];
+          int aq[4];
 #pragma unroll
-          for (int j = 1; j < NP; ++j) {
-            float v = readlane(delta, j) + A[j];
-            bool gt = v > best;
-            best = gt ? v : best;
-            arg = gt ? j : arg;
+          for (int q = 0; q < 4; ++q) { bq[q] = readlane(delta, q * Q) + A[q * Q]; aq[q] = q * Q; }
+#pragma unroll
+          for (int jj = 1; jj < Q; ++jj) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int j = q * Q + jj;
+              const float v = readlane(delta, j) + A[j];
+              const bool gt = v > bq[q];
+              bq[q] = gt ? v : bq[q];
+              aq[q] = gt ? j : aq[q];
+            }
+          }
+          float best = bq[0];
+          int arg = aq[0];
+#pragma unroll
+          for (int q = 1; q < 4; ++q) {
+            const bool gt = bq[q] > best;
+            best = gt ? bq[q] : best;
+            arg = gt ? aq[q] : arg;
           }
           delta = act ? best + xc[u] : NEG;
           if (act) psi[(size_t)t * N + lane] = (unsigned char)arg;
