@@ -24,11 +24,13 @@
 
 namespace w2l {
 
-constexpr int kFacChunk = 4;
+constexpr int kFacChunk = 16;  // frames per prefetch chunk: ONE vmcnt drain (loads AND the frames' stores) per chunk
 constexpr int kFacMaxN = 2048;  // LDS row buffer for the input-gradient scatter
 
 struct FacWs {
-  float* w1;     // [B][T][L]
+  float* w1;     // [B][T][L]  soft-max weights of the forward scan
+  float* dal;    // [B][T][L]  g * dalpha of the backward scan (a SEPARATE buffer: written in place of w1, the stores
+                 //            alias the scan's prefetch loads and hipcc drains vmcnt(0) -- stores included -- every frame)
   float* scale;  // [B]
   float* tgpart; // [B][N][N] (only when it is small enough, else NULL -> atomics)
   unsigned char* bp;  // viterbi back pointers [B][T][L]
@@ -42,6 +44,7 @@ __host__ __device__ inline FacWs fac_ws(void* ws, int B, int T, int N, int L) {
   FacWs w;
   char* p = (char*)ws;
   w.w1 = (float*)p; p += align_up((size_t)B * T * L * sizeof(float), 256);
+  w.dal = (float*)p; p += align_up((size_t)B * T * L * sizeof(float), 256);
   w.scale = (float*)p; p += align_up((size_t)B * sizeof(float), 256);
   w.bp = (unsigned char*)w.w1;  // viterbi reuses the w1 region (needs B*T*L bytes)
   w.tgpart = fac_use_partials(B, N) ? (float*)p : nullptr;
@@ -326,6 +329,13 @@ __global__ __launch_bounds__(64 * NW) void fac_fwd_blk(int T, int N, int L, int 
         __syncthreads();
       }
     }
+    // consume the whole prefetched chunk HERE: hipcc places `s_waitcnt vmcnt(0)` at the first use of a loaded register,
+    // and on gfx9 that counter also holds the frames' global stores -- left to the first use, every frame of the next
+    // chunk drained its predecessors' stores (one L2 round trip per frame)
+#pragma unroll
+    for (int u = 0; u < kFacChunk; ++u)
+#pragma unroll
+      for (int p = 0; p < P; ++p) asm volatile("" : "+v"(xn[u][p]));
 #pragma unroll
     for (int u = 0; u < kFacChunk; ++u)
 #pragma unroll
@@ -348,7 +358,8 @@ __global__ __launch_bounds__(64 * NW) void fac_bwd_blk(int T, int N, int L, cons
   const int S = targetSize[b];
   if (S <= 0) return;  // the scatter kernel zero-fills this utterance's gradient
   const int* y = target + (size_t)b * L;
-  float* w1b = ws.w1 + (size_t)b * T * L;
+  const float* __restrict__ w1b = ws.w1 + (size_t)b * T * L;
+  float* __restrict__ dalb = ws.dal + (size_t)b * T * L;
   const float g = ws.scale[b] * grad[b];
 
   int yi[P], yp[P];
@@ -379,13 +390,13 @@ __global__ __launch_bounds__(64 * NW) void fac_bwd_blk(int T, int N, int L, cons
 #pragma unroll
       for (int p = 0; p < P; ++p) wn[u][p] = (t >= 1 && tid + NT * p < S) ? w1b[(size_t)t * L + tid + NT * p] : 0.f;
     }
+    float dst[kFacChunk][P];  // this chunk's rows of g * dalpha: stored after the chunk (no store in flight inside it)
 #pragma unroll
     for (int u = 0; u < kFacChunk; ++u) {
       const int t = thi - u;
-      if (t >= 0) {  // uniform
 #pragma unroll
-        for (int p = 0; p < P; ++p)
-          if (tid + NT * p < L) w1b[(size_t)t * L + tid + NT * p] = g * da[p];  // row t of g * dalpha (0 beyond S)
+      for (int p = 0; p < P; ++p) dst[u][p] = g * da[p];  // row t of g * dalpha (0 beyond S)
+      if (t >= 0) {  // uniform
         if (t >= 1) {
           float st[P];
 #pragma unroll
@@ -396,12 +407,25 @@ __global__ __launch_bounds__(64 * NW) void fac_bwd_blk(int T, int N, int L, cons
             accP[p] += adv;
             sAdv[t & 1][tid + NT * p] = adv;
           }
-          __syncthreads();
+          // LDS-only barrier: __syncthreads() also drains vmcnt(0) here -- the frame's global stores and the prefetch
+          // loads -- which made every frame wait for a store round trip (708 cycles per frame for five fp32 operations)
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
           for (int p = 0; p < P; ++p) da[p] = st[p] + sAdv[t & 1][tid + NT * p + 1];
         }
       }
     }
+#pragma unroll
+    for (int u = 0; u < kFacChunk; ++u) {
+      const int t = thi - u;
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        if (t >= 0 && tid + NT * p < L) dalb[(size_t)t * L + tid + NT * p] = dst[u][p];
+    }
+#pragma unroll
+    for (int u = 0; u < kFacChunk; ++u)
+#pragma unroll
+      for (int p = 0; p < P; ++p) asm volatile("" : "+v"(wn[u][p]));  // one vmcnt drain per chunk (see fac_fwd_blk)
 #pragma unroll
     for (int u = 0; u < kFacChunk; ++u)
 #pragma unroll
@@ -532,7 +556,7 @@ using namespace w2l;
 
 W2L_API size_t w2l_fac_workspace_size(int B, int T, int N, int L) {
   if (B <= 0 || T <= 0 || N <= 0 || L <= 0) return 0;
-  size_t sz = align_up((size_t)B * T * L * sizeof(float), 256) + align_up((size_t)B * sizeof(float), 256);
+  size_t sz = 2 * align_up((size_t)B * T * L * sizeof(float), 256) + align_up((size_t)B * sizeof(float), 256);
   if (fac_use_partials(B, N)) sz += align_up((size_t)B * N * N * sizeof(float), 256);
   return sz;
 }
@@ -607,7 +631,7 @@ W2L_API int w2l_fac_backward(int B, int T, int N, int L, const int* target, cons
     if (shmem > 64 * 1024)
       W2L_HIP_CHECK(hipFuncSetAttribute((const void*)fac_scatter_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL(fac_scatter_k, dim3((unsigned)((T + tch - 1) / tch), (unsigned)B), dim3(256), shmem, s, T, N, L, tch,
-                       target, targetSize, ws.w1, inputGrad);
+                       target, targetSize, ws.dal, inputGrad);
     W2L_LAUNCH_CHECK();
   }
   if (ws.tgpart) {

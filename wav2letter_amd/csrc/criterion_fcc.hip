@@ -28,6 +28,8 @@ constexpr int kDtChunks = 16;  // time chunks of the (parallel) transition-gradi
 struct FccWs {
   float* ahat;   // [B][T][N]
   float* logs;   // [B][T][N]
+  float* r;      // [B][T][N]  r_t = dalpha_t / s_t of the backward scan, for fcc_dtrans_small (its own buffer: written
+                 //            over `logs` the stores alias the scan's prefetch loads and cost a vmcnt(0) per frame)
   float* scale;  // [B]
   float* tgpart; // [B][kDtChunks][N][N] transition-gradient partials (utterance x time chunk)
 };
@@ -38,6 +40,7 @@ __host__ __device__ inline FccWs fcc_ws(void* ws, int B, int T, int N) {
   size_t btn = align_up((size_t)B * T * N * sizeof(float), 256);
   w.ahat = (float*)p; p += btn;
   w.logs = (float*)p; p += btn;
+  w.r = (float*)p; p += btn;
   w.scale = (float*)p; p += align_up((size_t)B * sizeof(float), 256);
   w.tgpart = (float*)p;
   return w;
@@ -148,9 +151,10 @@ __global__ __launch_bounds__(64) void fcc_bwd_small(int T, int N, const float* _
     EAT[i] = (act && i < N) ? __expf(trans[(size_t)i * N + lane] - rm) : 0.f;
   }
 
-  const float* ahb = ws.ahat + (size_t)b * T * N;
-  float* lsb = ws.logs + (size_t)b * T * N;
-  float* dxb = inputGrad + (size_t)b * T * N;
+  const float* __restrict__ ahb = ws.ahat + (size_t)b * T * N;
+  const float* __restrict__ lsb = ws.logs + (size_t)b * T * N;
+  float* __restrict__ rbw = ws.r + (size_t)b * T * N;
+  float* __restrict__ dxb = inputGrad + (size_t)b * T * N;
   const float g = ws.scale[b] * grad[b];
 
   // d loss / d alpha_{T-1} = softmax(ahat_{T-1})
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(64) void fcc_bwd_small(int T, int N, const float* _
         float ep = act ? __expf(ac[u]) : 0.f;       // e_{t-1}[j]
         if (act) {
           dxb[(size_t)t * N + lane] = g * da;
-          lsb[(size_t)t * N + lane] = r;   // log s_t is consumed: the slot carries r_t to fcc_dtrans_small
+          rbw[(size_t)t * N + lane] = r;   // r_t for fcc_dtrans_small
         }
         // only the matrix-vector product is on the serial chain (two packed chains, SGPR-pair operands); the
         // transition gradient sum_t r_t[i] e_{t-1}[j] has no dependence between time steps and is accumulated by a
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(64) void fcc_dtrans_small(int T, int N, const float
   const int lane = threadIdx.x;
   const bool act = lane < N;
   const float* ahb = ws.ahat + (size_t)b * T * N;
-  const float* rb = ws.logs + (size_t)b * T * N;
+  const float* rb = ws.r + (size_t)b * T * N;
   const int per = (T - 1 + kDtChunks - 1) / kDtChunks;
   const int t0 = 1 + c * per;
   int t1 = t0 + per;
@@ -390,7 +394,7 @@ W2L_API size_t w2l_fcc_workspace_size(int B, int T, int N) {
   if (B <= 0 || T <= 0 || N <= 0) return 0;
   if (N > 64) return fcc_big_supported(B, T, N) ? fcc_big_workspace_size(B, T, N) : 0;
   size_t btn = align_up((size_t)B * T * N * sizeof(float), 256);
-  return 2 * btn + align_up((size_t)B * sizeof(float), 256) +
+  return 3 * btn + align_up((size_t)B * sizeof(float), 256) +
          align_up((size_t)B * kDtChunks * N * N * sizeof(float), 256);
 }
 
