@@ -270,15 +270,21 @@ class ASGLoss(SequenceCriterion):
         # scans overlap too.
         if not emission.is_cuda:
             return self.fcc(emission, target) - self.fac(emission, target)  # raises the reference's error
+        _emission_checks(emission, target)
+        _check_dev(emission, target)
+        if emission.shape[2] != self.N:
+            raise _lib.W2LInvalidArgument("ASGLoss: N doesn't match with the letter size")
         if self._side is None:
             self._side = torch.cuda.Stream(device=emission.device)
         cur = torch.cuda.current_stream(emission.device)
+        ts = batch_target_size(target, emission.shape[1])   # once, shared by both criteria (before the fork)
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side):
-            fac = self.fac(emission, target)
-        fcc = self.fcc(emission, target)
+            fac = _FAC.apply(emission, self.transitions, target, ts, self.scalemode)
+        fcc = _FCC.apply(emission, self.transitions, ts, self.scalemode)
         cur.wait_stream(self._side)
         fac.record_stream(cur)
+        ts.record_stream(self._side)
         return fcc - fac
 
     def viterbiPath(self, emission, inputSize=None):
