@@ -22,7 +22,8 @@
 
 namespace w2l {
 
-constexpr int kChunk = 8;  // emission-row prefetch depth (steps)
+constexpr int kChunk = 16;  // frames per prefetch chunk; a chunk's loads are consumed and its rows stored at the chunk
+                           // boundary: ONE vmcnt drain per chunk (on gfx9 that counter also holds the frames' global stores)
 constexpr int kDtChunks = 16;  // time chunks of the (parallel) transition-gradient kernel
 
 struct FccWs {
@@ -141,8 +142,11 @@ __global__ __launch_bounds__(64) void fcc_bwd_small(int T, int N, const float* _
 
   // rowmax_i in lane i, then EAT[i] = exp(A[i][lane] - rowmax_i) (column `lane`)
   float rowmax = NEG;
-  for (int j = 0; j < N; ++j)
-    if (act) rowmax = fmaxf(rowmax, trans[(size_t)lane * N + j]);
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {  // unrolled: NP independent loads, one wait (the dynamic loop serialised N round trips)
+    const float a = (act && j < N) ? trans[(size_t)lane * N + j] : NEG;
+    rowmax = fmaxf(rowmax, a);
+  }
   if (!act) rowmax = 0.f;
   float EAT[NP];
 #pragma unroll
@@ -176,16 +180,16 @@ __global__ __launch_bounds__(64) void fcc_bwd_small(int T, int N, const float* _
       ln[u] = (act && t >= 1) ? lsb[(size_t)t * N + lane] : 0.f;
       an[u] = (act && t >= 1) ? ahb[(size_t)(t - 1) * N + lane] : NEG;
     }
+    float dxs[kChunk], rs[kChunk];  // this chunk's rows of g * dalpha and r: stored after the chunk
 #pragma unroll
     for (int u = 0; u < kChunk; ++u) {
       const int t = thi - u;
+      dxs[u] = 0.f; rs[u] = 0.f;
       if (t >= 1) {  // wave-uniform
         float r = act ? da * __expf(-lc[u]) : 0.f;  // da_t[i] / s_t[i]
         float ep = act ? __expf(ac[u]) : 0.f;       // e_{t-1}[j]
-        if (act) {
-          dxb[(size_t)t * N + lane] = g * da;
-          rbw[(size_t)t * N + lane] = r;   // r_t for fcc_dtrans_small
-        }
+        dxs[u] = g * da;
+        rs[u] = r;                         // r_t for fcc_dtrans_small
         // only the matrix-vector product is on the serial chain (two packed chains, SGPR-pair operands); the
         // transition gradient sum_t r_t[i] e_{t-1}[j] has no dependence between time steps and is accumulated by a
         // separate, fully parallel kernel (it cost the scan 32 more broadcasts and 16 more packed FMAs per step)
@@ -201,6 +205,16 @@ __global__ __launch_bounds__(64) void fcc_bwd_small(int T, int N, const float* _
         da = ep * ((n0.x + n0.y) + (n1.x + n1.y));
       }
     }
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) {
+      const int t = thi - u;
+      if (act && t >= 1) {
+        dxb[(size_t)t * N + lane] = dxs[u];
+        rbw[(size_t)t * N + lane] = rs[u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) { asm volatile("" : "+v"(ln[u]), "+v"(an[u])); }  // consume the prefetched chunk here
 #pragma unroll
     for (int u = 0; u < kChunk; ++u) { lc[u] = ln[u]; ac[u] = an[u]; }
   }
@@ -234,8 +248,11 @@ __global__ __launch_bounds__(64) void fcc_dtrans_small(int T, int N, const float
   float* tg = ws.tgpart + ((size_t)b * kDtChunks + c) * N * N;
   // rowmax_i (the scan's exp(A - rowmax) normalisation) in lane i
   float rowmax = -INFINITY;
-  for (int j = 0; j < N; ++j)
-    if (act) rowmax = fmaxf(rowmax, trans[(size_t)lane * N + j]);
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const float a = (act && j < N) ? trans[(size_t)lane * N + j] : -INFINITY;
+    rowmax = fmaxf(rowmax, a);
+  }
   if (!act) rowmax = 0.f;
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
@@ -306,9 +323,11 @@ __global__ __launch_bounds__(64) void viterbi_small(int T, int N, const float* _
       int tn = t0 + kChunk + u;
       xn[u] = (act && tn < T) ? xb[(size_t)tn * N + lane] : 0.f;
     }
+    int args[kChunk];
 #pragma unroll
     for (int u = 0; u < kChunk; ++u) {
       const int t = t0 + u;
+      args[u] = 0;
       if (t < T) {
         if (t == 0) {
           delta = act ? xc[u] : NEG;
@@ -341,10 +360,17 @@ __global__ __launch_bounds__(64) void viterbi_small(int T, int N, const float* _
             arg = gt ? aq[q] : arg;
           }
           delta = act ? best + xc[u] : NEG;
-          if (act) psi[(size_t)t * N + lane] = (unsigned char)arg;
+          args[u] = arg;
         }
       }
     }
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) {
+      const int t = t0 + u;
+      if (act && t >= 1 && t < T) psi[(size_t)t * N + lane] = (unsigned char)args[u];
+    }
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) asm volatile("" : "+v"(xn[u]));  // consume the prefetched chunk here
 #pragma unroll
     for (int u = 0; u < kChunk; ++u) xc[u] = xn[u];
   }
