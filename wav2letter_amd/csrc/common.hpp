@@ -122,6 +122,14 @@ __device__ __forceinline__ double lane_shift_up_dpp(double v, double fill) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// value of lane+1 through DPP wave_shl:1 (lane 63 receives `fill`)
+__device__ __forceinline__ double lane_shift_down_dpp(double v, double fill) {
+  const long long bits = __double_as_longlong(v), fb = __double_as_longlong(fill);
+  const int lo = __builtin_amdgcn_update_dpp((int)fb, (int)bits, 0x130, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(fb >> 32), (int)(bits >> 32), 0x130, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 __device__ __forceinline__ float lane_shift_down(float v, float fill) {
   float r = __shfl_down(v, 1);
   return lane_id() == 63 ? fill : r;

@@ -167,8 +167,8 @@ __global__ __launch_bounds__(kRowThreads) void ctc_rows_lse_big(int T, int N, in
 __device__ __forceinline__ double lse3(double a, double b, double c) {
   double m = fmax(a, fmax(b, c));
   if (m == -INFINITY) return m;
-  float s = __expf((float)(a - m)) + __expf((float)(b - m)) + __expf((float)(c - m));
-  return m + (double)__logf(s);
+  float s = fast_expf((float)(a - m)) + fast_expf((float)(b - m)) + fast_expf((float)(c - m));
+  return m + (double)fast_logf(s);   // s in [1, 3]: hardware log2 * ln 2 (ocml's __logf is a ~12-instruction sequence)
 }
 
 // alpha / beta over the extended label sequence; positions blocked over lanes.
@@ -230,9 +230,9 @@ __global__ __launch_bounds__(64) void ctc_lattice(int T, int N, int L, int scale
       for (int u = 0; u < D; ++u) {
         const int t = t0 + u;
         if (t < T) {
-          double c1 = lane_shift_up(a[P - 1], NEG);                              // alpha[lane*P - 1]
-          double c2 = lane_shift_up(P >= 2 ? a[P >= 2 ? P - 2 : 0] : NEG, NEG);  // alpha[lane*P - 2]
-          if (P == 1) c2 = lane_shift_up(c1, NEG);
+          double c1 = lane_shift_up_dpp(a[P - 1], NEG);                              // alpha[lane*P - 1]
+          double c2 = lane_shift_up_dpp(P >= 2 ? a[P >= 2 ? P - 2 : 0] : NEG, NEG);  // alpha[lane*P - 2]
+          if (P == 1) c2 = lane_shift_up_dpp(c1, NEG);
           double pm1 = c1, pm2 = c2;
           double* alt = al + (size_t)t * SW;
 #pragma unroll
@@ -335,9 +335,9 @@ __global__ __launch_bounds__(64) void ctc_lattice(int T, int N, int L, int scale
           }
           if (t >= 1) {
             // beta_{t-1}[s] = lse(beta_t[s], beta_t[s+1], beta_t[s+2] if allowed) + lp[t-1][s]
-            double n1 = lane_shift_down(be[0], NEG);                               // beta[(lane+1)*P]
-            double n2 = lane_shift_down(P >= 2 ? be[P >= 2 ? 1 : 0] : NEG, NEG);   // beta[(lane+1)*P + 1]
-            if (P == 1) n2 = lane_shift_down(n1, NEG);
+            double n1 = lane_shift_down_dpp(be[0], NEG);                               // beta[(lane+1)*P]
+            double n2 = lane_shift_down_dpp(P >= 2 ? be[P >= 2 ? 1 : 0] : NEG, NEG);   // beta[(lane+1)*P + 1]
+            if (P == 1) n2 = lane_shift_down_dpp(n1, NEG);
             double nb[P];
 #pragma unroll
             for (int p = P - 1; p >= 0; --p) {
