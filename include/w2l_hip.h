@@ -199,6 +199,14 @@ int w2l_mask_backward(const float* dy, const float* src, float* dx, size_t n, fl
 int w2l_axpy(float* y, const float* x, size_t n, float alpha, w2l_stream_t stream);
 int w2l_fill(float* y, size_t n, float v, w2l_stream_t stream);
 int w2l_transpose(const float* in, float* out, int G, int R, int C, w2l_stream_t stream);
+/* MFSC / log-mel front end (fl::lib::audio::Mfsc as configured by LogMelFeature.cpp:78-95, [UNVENDORED]): the linear
+ * per-frame part (pre-emphasis, window, DFT) is one w2l_gemm_f32 on overlapping rows of the audio (lda = frame stride);
+ * spectrum: spec[m][k] = |re + i im| (usePower: squared), zero-padded to ldOut columns; then the mel GEMM; then
+ * out[b][f][t] = log(max(mel[b][t][f], floor)) in the network's input layout. */
+int w2l_mfsc_spectrum(const float* reim /*[M][2*nbins]*/, float* spec /*[M][ldOut]*/, size_t M, int nbins,
+                      int ldOut, int usePower, w2l_stream_t stream);
+int w2l_mfsc_log_transpose(const float* mel /*[B][Tp][F]*/, float* out /*[B][F][T]*/, int B, int Tp, int T,
+                           int F, float floorv, w2l_stream_t stream);
 int w2l_glu_forward(const float* x, float* y, size_t M, int half, w2l_stream_t stream);
 int w2l_glu_backward(const float* x, const float* dy, float* dx, size_t M, int half,
                      w2l_stream_t stream);

@@ -167,6 +167,46 @@ def linseg(x, trans, target, scale_mode=SCALE_NONE, grad=None):
     return asg(x, trans, lin, scale_mode, grad)
 
 
+def mfsc_filterbank(num_filters, nfft, fs, low_hz=0.0, high_hz=None):
+    """Flashlight TriFilterbank (MEL), [UNVENDORED] -- recalled: numFilters + 2 points equally spaced on the mel scale
+    2595 log10(1 + f/700), converted back to Hz and then to FFT-bin units; filter j is the triangle
+    max(min((k - f_j)/(f_j+1 - f_j), (f_j+2 - k)/(f_j+2 - f_j+1)), 0) over the bins k = 0..nfft/2.  Returns H [nfft/2+1][num_filters]."""
+    high_hz = fs / 2.0 if high_hz is None else high_hz
+    nb = nfft // 2 + 1
+    mel = lambda f: 2595.0 * np.log10(1.0 + f / 700.0)
+    imel = lambda m: 700.0 * (10.0 ** (m / 2595.0) - 1.0)
+    pts = imel(np.linspace(mel(low_hz), mel(high_hz), num_filters + 2)) * (nb - 1) * 2.0 / fs
+    k = np.arange(nb, dtype=np.float64)[:, None]
+    hi = (k - pts[None, :-2]) / (pts[None, 1:-1] - pts[None, :-2])
+    lo = (pts[None, 2:] - k) / (pts[None, 2:] - pts[None, 1:-1])
+    return np.maximum(np.minimum(hi, lo), 0.0)
+
+
+def mfsc(audio, num_filters=80, fs=16000, frame_ms=25, stride_ms=10, preem=0.97, use_power=False, mel_floor=1.0):
+    """fl::lib::audio::Mfsc as LogMelFeature configures it (LogMelFeature.cpp:78-95; arithmetic [UNVENDORED], recalled:
+    PowerSpectrum = frames of round(fs*25ms) samples every round(fs*10ms), no dither, no mean removal, in-frame
+    pre-emphasis x[i] -= 0.97 x[i-1] (x[0] *= 0.03), Hamming window 0.54 - 0.46 cos(2 pi i/(N-1)), |FFT| at the next
+    power of two (usePower = false: magnitude), TriFilterbank, max(., melFloor = 1), natural log).  One utterance
+    [n_samples] -> [T][num_filters], frame by frame in fp64.  PARITY UNPINNED: the reference tree only tests that the
+    features do not depend on how the audio is chunked (LogMelFeatureTest.cpp:25-66)."""
+    x = np.asarray(audio, np.float64)
+    N = int(round(1e-3 * frame_ms * fs)); S = int(round(1e-3 * stride_ms * fs))
+    nfft = 1 << (N - 1).bit_length()
+    T = 0 if len(x) < N else 1 + (len(x) - N) // S
+    H = mfsc_filterbank(num_filters, nfft, fs)
+    win = 0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(N) / (N - 1))
+    out = np.zeros((T, num_filters))
+    for t in range(T):
+        f = x[t * S:t * S + N].copy()
+        f[1:] -= preem * f[:-1]
+        f[0] *= 1.0 - preem
+        spec = np.abs(np.fft.rfft(f * win, nfft))
+        if use_power:
+            spec = spec ** 2
+        out[t] = np.log(np.maximum(spec @ H, mel_floor))
+    return out
+
+
 def viterbi(x, trans):
     x = _f32(x)
     trans = _f32(trans)

@@ -622,3 +622,20 @@ def test_gemm_throughput_report():
             fl = 2.0 * M * K * N * (1 if name == "fwd" else 2)
             print(f"\n[gemm] {tag:8s} {name} M={M} K={K} N={N}: {dt * 1e3:.3f} ms  {fl / dt / 1e12:.1f} TFLOP/s", end="")
     print()
+
+
+@pytest.mark.parametrize("B,ns,F,power", [(3, 19200, 80, False), (2, 24000, 40, False), (1, 16000 + 37, 80, True), (4, 400, 80, False)])
+def test_mfsc_features_on_device(oracle, B, ns, F, power):
+    """log-mel front end (one overlapping-row GEMM for the spectra of all frames, |.|, mel GEMM, log + transposition to
+    [B][NFEAT][T]) against the frame-by-frame fp64 restatement; 1e-4 of the largest feature magnitude; ragged sample
+    counts (not a whole number of strides) and the one-frame utterance"""
+    from wav2letter_amd.features import Mfsc
+    rng = np.random.default_rng(ns + F)
+    audio = (rng.normal(size=(B, ns)) * 3000.0).astype(np.float32)
+    fe = Mfsc(num_filters=F, use_power=power)
+    got = fe(dev(audio))
+    T = fe.num_frames(ns)
+    assert got.shape == (B, F, T)
+    want = np.stack([oracle.mfsc(audio[b], F, use_power=power).T for b in range(B)])
+    assert np.abs(got.cpu().numpy() - want).max() < 1e-4 * np.abs(want).max()
+    assert torch.equal(got, fe(dev(audio)))

@@ -191,3 +191,36 @@ def test_dropout_hash_statistics(oracle):
     assert np.allclose(y[y != 0], 1 / 0.75)
     y2 = oracle.dropout(x, 0.25, 1234, 8)
     assert 0.5 < ((y != 0) == (y2 != 0)).mean() < 0.7  # streams decorrelated (0.75^2+0.25^2=0.625)
+
+
+def test_mfsc_oracle_properties(oracle):
+    """MFSC restatement (parity unpinned: the arithmetic is un-vendored Flashlight).  What the reference's own test
+    checks (LogMelFeatureTest.cpp:25-66): the features do not depend on how the audio is cut into chunks -- frame t
+    only sees samples [160 t, 160 t + 400).  Plus: shape conventions, the filterbank covers every FFT bin below
+    Nyquist with non-negative triangles, and the folded linear form (pre-emphasis, window, DFT as one matrix) that the
+    device path multiplies by equals the frame-by-frame computation."""
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=16000) * 2000.0
+    full = oracle.mfsc(x, 80)
+    assert full.shape == (1 + (16000 - 400) // 160, 80)
+    for cut in (400, 1999, 8000, 12345):
+        part = oracle.mfsc(x[:cut], 80)
+        assert part.shape[0] == (0 if cut < 400 else 1 + (cut - 400) // 160)
+        assert np.abs(part - full[:part.shape[0]]).max() < 1e-12
+    assert oracle.mfsc(x[:399], 80).shape == (0, 80)
+    H = oracle.mfsc_filterbank(40, 512, 16000)
+    assert H.shape == (257, 40) and (H >= 0).all() and (H.sum(0) > 0).all() and (H[1:256].sum(1) > 0).all()
+    N, S, nb = 400, 160, 257
+    n = np.arange(N)
+    win = 0.54 - 0.46 * np.cos(2 * np.pi * n / (N - 1))
+    P = np.eye(N) - 0.97 * np.eye(N, k=-1)
+    P[0, 0] = 0.03
+    ang = 2 * np.pi * np.outer(n, np.arange(nb)) / 512
+    WP = np.diag(win) @ P
+    G = np.concatenate([WP.T @ np.cos(ang), -(WP.T @ np.sin(ang))], axis=1)
+    T = full.shape[0]
+    frames = np.stack([x[t * S:t * S + N] for t in range(T)])
+    ri = frames @ G
+    folded = np.log(np.maximum(np.sqrt(ri[:, :nb] ** 2 + ri[:, nb:] ** 2) @ oracle.mfsc_filterbank(80, 512, 16000), 1.0))
+    assert np.abs(folded - full).max() < 1e-10
+    assert np.abs(oracle.mfsc(x, 80, use_power=True) - oracle.mfsc(x, 80)).max() > 1.0   # power and magnitude differ

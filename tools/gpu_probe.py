@@ -170,6 +170,19 @@ def probe_convglu():
         del x, w, y, dy, dx, dw
 
 
+def probe_feat():
+    """log-mel front end at the TDS-CTC batch shape: 32 utterances of 15 s at 16 kHz -> [32][80][1498]"""
+    from wav2letter_amd.features import Mfsc
+    B, ns = 32, 240000
+    audio = torch.randn(B, ns, device="cuda") * 3000
+    fe = Mfsc(80)
+    T = fe.num_frames(ns)
+    t = timeit(lambda: fe(audio), n=20, warm=3)
+    fl = 2.0 * B * T * (fe.N * 2 * fe.nb + fe.ld * fe.F)
+    print(f"[feat] MFSC B={B} x {ns / 16000:.0f} s -> [{B}][80][{T}]: {t * 1e3:.0f} us = {B / t * 1e3:.0f} utterances/s, "
+          f"{B * ns / 16000 / (t * 1e-3):.0f}x real time, {fl / t / 1e9:.1f} TF/s on the two GEMMs' {fl / 1e9:.1f} GFLOP", flush=True)
+
+
 def asg_targets(B, L, g):
     tgt = torch.full((B, L), -1, dtype=torch.int32)
     for b in range(B):
@@ -257,6 +270,6 @@ if __name__ == "__main__":
     print("device:", torch.cuda.get_device_name(0), flush=True)
     for w in which:
         t0 = time.time()
-        {"gemm": probe_gemm, "gemm160": probe_gemm160, "gemmfwd": probe_gemmfwd, "ln": probe_ln, "conv": probe_conv, "convglu": probe_convglu, "asg": probe_asg, "fccbig": probe_fccbig, "fccstream": probe_fccstream,
+        {"gemm": probe_gemm, "gemm160": probe_gemm160, "gemmfwd": probe_gemmfwd, "ln": probe_ln, "conv": probe_conv, "convglu": probe_convglu, "feat": probe_feat, "asg": probe_asg, "fccbig": probe_fccbig, "fccstream": probe_fccstream,
          "vitbig": probe_vitbig}[w]()
         print(f"[{w}] done in {time.time() - t0:.1f} s", flush=True)
