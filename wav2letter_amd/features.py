@@ -1,8 +1,8 @@
 """MFSC / log-mel features on the device (the input pipeline next to the hot path).
 
-Reference: fl::lib::audio::Mfsc [UNVENDORED] as configured by
-recipes/streaming_convnets/inference/inference/module/feature/LogMelFeature.cpp:78-95 and the recipes'
---filterbanks=80 / 40.  Pre-emphasis, the Hamming window and the DFT are linear in the samples of a frame,
+Reference: fl::lib::audio::Mfsc [UNVENDORED] as the trainer configures it (recipes/slimIPL/src/Train.cpp:277-290:
+useEnergy = usePower = zeroMeanFrame = false, --filterbanks=80 / 40, 25 ms frames every 10 ms) and as
+recipes/streaming_convnets/inference/inference/module/feature/LogMelFeature.cpp:78-95 does for streaming.  Pre-emphasis, the Hamming window and the DFT are linear in the samples of a frame,
 so they are folded (fp64, on the host, once) into ONE [frame x 2*bins] matrix; the frames of an utterance are
 overlapping rows of its samples (row t starts at sample t*stride), so the spectra of all frames of a batch are
 one GEMM whose A operand is the audio itself with leading dimension `stride` -- the same zero-copy operand view
