@@ -1,0 +1,50 @@
+"""Host side of the input pipeline: list files, rank partitioning, length-bucketed batching."""
+import pytest
+
+from wav2letter_amd import data
+
+
+def test_parse_list_librispeech_lines():
+    text = ("1272-128104-0000 /data/LibriSpeech/dev-clean/1272/128104/1272-128104-0000.flac 5855.0 mister quilter is the apostle\n"
+            "\n"
+            "1272-128104-0001 /data/x.flac 4815.0 nor is mister quilter's manner less interesting\n"
+            "utt-without-text /data/y.flac 1000\n")
+    s = data.parse_list(text)
+    assert [x.sample_id for x in s] == ["1272-128104-0000", "1272-128104-0001", "utt-without-text"]
+    assert s[0].duration_ms == 5855.0 and s[0].transcript == "mister quilter is the apostle"
+    assert s[1].transcript.endswith("less interesting") and s[2].transcript == ""
+    with pytest.raises(ValueError):
+        data.parse_list("only two\n")
+    with pytest.raises(ValueError):
+        data.parse_list("id path notanumber text\n")
+
+
+@pytest.mark.parametrize("n,world,bs", [(64, 8, 4), (70, 8, 4), (67, 4, 8), (5, 2, 4), (0, 2, 4), (33, 1, 32)])
+def test_partition_round_robin_is_a_partition(n, world, bs):
+    """ranks get disjoint index sets of equal size; whole global batches are covered completely, rank r takes the r-th
+    slice of each; nothing is sampled twice"""
+    parts = [data.partition_round_robin(n, r, world, bs) for r in range(world)]
+    sizes = {len(p) for p in parts}
+    assert len(sizes) == 1                                   # same number of samples (hence batches) on every rank
+    flat = [i for p in parts for i in p]
+    assert len(flat) == len(set(flat)) and all(0 <= i < n for i in flat)
+    n_global = n // (world * bs)
+    assert set(range(n_global * world * bs)) <= set(flat)     # every sample of a whole global batch is used
+    for r, p in enumerate(parts):
+        for g in range(n_global):
+            assert p[g * bs:(g + 1) * bs] == list(range(g * world * bs + r * bs, g * world * bs + (r + 1) * bs))
+    with pytest.raises(ValueError):
+        data.partition_round_robin(10, 3, 2, 4)
+
+
+def test_batches_by_length_and_duration_cap():
+    dur = [5000, 1000, 3000, 2000, 9000, 1500, 2500]
+    idx = list(range(7))
+    plain = data.batches(idx, dur, 3)
+    assert plain == [[0, 1, 2], [3, 4, 5], [6]]
+    srt = data.batches(idx, dur, 3, sort_by_length=True)
+    assert srt == [[1, 5, 3], [6, 2, 0], [4]]
+    capped = data.batches(idx, dur, 4, max_duration_ms=9000, sort_by_length=True)
+    for b in capped:
+        assert max(dur[i] for i in b) * len(b) <= 9000 or len(b) == 1
+    assert sorted(i for b in capped for i in b) == idx
