@@ -136,6 +136,34 @@ def test_conv_glu_asg_wide_layers_end_to_end(oracle):
     assert rel(gA, odA) < TOL
 
 
+def test_conv_glu_wsj_config1_end_to_end(oracle):
+    """BASELINE config 1 -- the conv_glu WSJ recipe (15 WN-conv + GLU layers, SAME padding, even kernels, 17.1 M
+    parameters), ASG criterion, 2-utterance batch -- at a reduced number of frames: emissions, ASG loss, every
+    parameter gradient and the transition gradient against the reference network (numpy) + the criterion oracle.
+    Evaluation mode of dropout (p = 0.25 in the recipe) so that both sides see the same activations."""
+    from wav2letter_amd import recipes
+    rng = np.random.default_rng(7)
+    nfeat, nlabel, B, T, L = 40, 30, 2, 72, 9
+    arch = recipes.conv_glu_wsj_arch().replace("DO 0.25", "DO 0.0")
+    tr, ref, params, A = build(arch, nfeat, nlabel, "asg", 4, 4.0, rng, B, T, L)
+    x = rng.normal(size=(B, 1, nfeat, T)).astype(np.float32)
+    tgt = np.full((B, L), -1, np.int32)
+    tgt[0, :9] = [3, 7, 1, 28, 4, 9, 9 + 1, 2, 5]
+    tgt[1, :5] = [11, 0, 27, 6, 13]
+    xd = torch.tensor(x.reshape(B, nfeat, T)).cuda()
+    td = torch.tensor(tgt).cuda()
+    em = tr.forward(xd, train=False).cpu().numpy()
+    em_ref = ref.forward(x, params)
+    assert em.shape == em_ref.shape, (em.shape, em_ref.shape)
+    assert rel(em, em_ref) < TOL
+    loss = tr.forward_backward(xd, td).cpu().numpy()
+    ol, odx, odA = oracle.asg(em_ref, A, tgt, 4)
+    assert rel(loss, ol) < TOL
+    check_grads(tr, ref.backward(odx.astype(np.float32), len(params)))
+    gA = tr.grads.cpu().numpy()[tr.n_net:tr.n_net + nlabel * nlabel]
+    assert rel(gA, odA) < TOL
+
+
 def test_linseg_warmup_then_asg(oracle):
     """--linseg=1 (every ASG recipe): update 0 runs LinSegCriterion on the ASG transitions, update 1 onwards ASG;
     both through the C++ trainer, against the oracle on the reference network's emissions"""

@@ -39,6 +39,19 @@ def conv_glu_librispeech_arch():
     return "\n".join(lines) + "\n"
 
 
+def conv_glu_wsj_arch():
+    """conv_glu WSJ (BASELINE config 1): 15 WN-Conv+GLU layers with SAME padding (-1), kernels 13, 3..15, 21"""
+    lines = ["V -1 1 NFEAT 0"]
+    outs = [200, 200, 200, 250, 250, 300, 350, 400, 450, 500, 500, 500, 600, 600, 750]
+    kws = [13, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 21]
+    cin = "NFEAT"
+    for co, kw in zip(outs, kws):
+        lines += [f"WN 3 C {cin} {co} {kw} 1 -1", "GLU 2", "DO 0.25"]
+        cin = co // 2
+    lines += ["RO 2 0 3 1", "WN 0 L 375 1000", "GLU 0", "DO 0.25", "WN 0 L 500 NLABEL"]
+    return "\n".join(lines) + "\n"
+
+
 def tds_ctc_small_arch(c=(4, 6), h=8, kw=5, l2mult=2, drop=0.0):
     """a reduced TDS-CTC of the same topology (tests)"""
     lines = [f"V -1 NFEAT 1 0"]
