@@ -136,6 +136,65 @@ def test_conv_glu_asg_wide_layers_end_to_end(oracle):
     assert rel(gA, odA) < TOL
 
 
+def test_tds_ctc_config2_full_network_end_to_end(oracle):
+    """BASELINE config 2 -- the full sota/2019 TDS-CTC recipe network (21 TDS blocks, 203.4 M parameters, 80 mel
+    rows, 9998 word pieces) -- at a reduced batch and number of frames, with SpecAugment and dropout switched off so
+    that both sides see the same activations: emissions, CTC loss and every parameter gradient against the numpy
+    reference network + the CTC oracle.  Runs every fc GEMM kernel variant of the step (128x128 and 160-wide tiles,
+    the N = 9998 final layer on dword-aligned rows) and the TDS / strided convolutions at the recipe's channel counts."""
+    import re
+    from wav2letter_amd import recipes
+    rng = np.random.default_rng(21)
+    nfeat, nlabel, B, T, L = 80, 9998, 2, 96, 5
+    arch = re.sub(r"(TDS \d+ \d+ \d+) [0-9.]+", r"\1 0.0", recipes.tds_ctc_arch())
+    arch = "\n".join(l for l in arch.splitlines() if not l.startswith("SAUG")) + "\n"
+    arch = re.sub(r"^DO [0-9.]+$", "DO 0.0", arch, flags=re.M)
+    tr, ref, params, _ = build(arch, nfeat, nlabel, "ctc", 4, 0.0, rng, B, T, L)
+    x = rng.normal(size=(B, 1, nfeat, T)).astype(np.float32)
+    tgt = np.full((B, L), -1, np.int32)
+    tgt[0, :5] = [17, 4021, 9996, 3, 3]
+    tgt[1, :2] = [9000, 12]
+    xd = torch.tensor(x.reshape(B, nfeat, T)).cuda()
+    td = torch.tensor(tgt).cuda()
+    em = tr.forward(xd, train=False).cpu().numpy()
+    em_ref = ref.forward(x, params)
+    assert em.shape == em_ref.shape == (B, 12, nlabel)
+    assert rel(em, em_ref) < TOL
+    loss = tr.forward_backward(xd, td).cpu().numpy()
+    o = oracle.CTC(em_ref, tgt, scale_mode=4)
+    assert rel(loss, o.forward()) < TOL
+    check_grads(tr, ref.backward(o.backward().astype(np.float32), len(params)))
+
+
+def test_conv_glu_librispeech_config4_full_network_end_to_end(oracle):
+    """BASELINE config 4 -- the full conv_glu LibriSpeech recipe network (17 WN-conv + GLU layers, 208.9 M parameters,
+    first layer padded by 170 frames, kernels 13..29), ASG criterion -- at a reduced batch and number of frames, dropout
+    off: emissions, ASG loss, weight-norm v / g / bias gradients of every layer and the transition gradient against the
+    numpy reference network + criterion oracle.  Every convolution runs as an overlapping-row LDS-DMA GEMM here."""
+    import re
+    from wav2letter_amd import recipes
+    rng = np.random.default_rng(44)
+    nfeat, nlabel, B, T, L = 40, 30, 2, 24, 6
+    arch = re.sub(r"^DO [0-9.]+$", "DO 0.0", recipes.conv_glu_librispeech_arch(), flags=re.M)
+    tr, ref, params, A = build(arch, nfeat, nlabel, "asg", 4, 4.0, rng, B, T, L)
+    x = rng.normal(size=(B, 1, nfeat, T)).astype(np.float32)
+    tgt = np.full((B, L), -1, np.int32)
+    tgt[0, :6] = [3, 7, 1, 28, 4, 9]
+    tgt[1, :3] = [11, 0, 27]
+    xd = torch.tensor(x.reshape(B, nfeat, T)).cuda()
+    td = torch.tensor(tgt).cuda()
+    em = tr.forward(xd, train=False).cpu().numpy()
+    em_ref = ref.forward(x, params)
+    assert em.shape == em_ref.shape == (B, T, nlabel)
+    assert rel(em, em_ref) < TOL
+    loss = tr.forward_backward(xd, td).cpu().numpy()
+    ol, odx, odA = oracle.asg(em_ref, A, tgt, 4)
+    assert rel(loss, ol) < TOL
+    check_grads(tr, ref.backward(odx.astype(np.float32), len(params)))
+    gA = tr.grads.cpu().numpy()[tr.n_net:tr.n_net + nlabel * nlabel]
+    assert rel(gA, odA) < TOL
+
+
 def test_conv_glu_wsj_config1_end_to_end(oracle):
     """BASELINE config 1 -- the conv_glu WSJ recipe (15 WN-conv + GLU layers, SAME padding, even kernels, 17.1 M
     parameters), ASG criterion, 2-utterance batch -- at a reduced number of frames: emissions, ASG loss, every
