@@ -385,7 +385,7 @@ static bool glds_conv_enabled() {
   return !(e && e[0] == '0');
 }
 static bool glds_conv_applicable(const w2l_conv_desc* d) {
-  return glds_conv_enabled() && d->H == 1 && d->stride == 1 && d->kw * d->Cin >= 64 && d->Cout >= 32 &&
+  return glds_conv_enabled() && d->H == 1 && d->stride == 1 && d->kw * d->Cin >= 64 && d->Cout >= 32 && d->Cin >= 4 &&
          (int64_t)d->B * (d->T + d->padl + d->padr) < (1ll << 30);
 }
 static int pad_frames(const float* src, float* dst, int B, int Tsrc, int Tdst, int C, int off, hipStream_t s) {
