@@ -256,6 +256,10 @@ int w2l_trainer_update(void* h, float lr, float lrcrit, float momentum, float ma
                        float totalBatch, int clampCrit, void* stream);
 int w2l_trainer_viterbi(void* h, const float* emission, int* path, void* stream);
 int w2l_trainer_set_step(void* h, uint32_t step);
+/* gradient norm seen by the last w2l_trainer_update with maxGradNorm > 0 (before the 1/totalBatch scale).  A
+ * non-finite norm means the update was SKIPPED on every rank (the norm is taken on the all-reduced gradient):
+ * the counterpart of the reference's NaN guards, recipes/slimIPL/src/Train.cpp:1651-1660, :1686-1698. */
+int w2l_trainer_grad_norm(void* h, double* norm, void* stream);
 /* --linseg=n (recipes/slimIPL/src/Train.cpp:589-617, :1866-1883): the first n updates of an ASG run use
  * LinSegCriterion on the ASG criterion's own transitions.  Call before w2l_trainer_plan. */
 int w2l_trainer_set_linseg(void* h, uint32_t updates);

@@ -253,6 +253,34 @@ def test_linseg_warmup_then_asg(oracle):
         Trainer(recipes.tds_ctc_small_arch(c=(4,), h=8, kw=5), 8, 12, "ctc", 4).set_linseg(1)
 
 
+def test_non_finite_gradient_skips_the_update():
+    """a NaN anywhere in the (reduced) gradient arena: parameters and momentum stay untouched, the reported norm is
+    non-finite; the next clean step updates again (reference: NaN guards of Train.cpp:1651-1660, :1686-1698)"""
+    import math
+    from wav2letter_amd import recipes
+    from wav2letter_amd.trainer import Trainer
+    rng = np.random.default_rng(9)
+    nfeat, nlabel, B, T, L = 8, 12, 2, 48, 4
+    tr = Trainer(recipes.tds_ctc_small_arch(c=(4,), h=nfeat, kw=5), nfeat, nlabel, "ctc", 4)
+    tr.init_params(3)
+    tr.plan(B, T, L)
+    tr.to_device()
+    x = torch.tensor(rng.normal(size=(B, nfeat, T)).astype(np.float32)).cuda()
+    tgt = torch.tensor(rng.integers(0, nlabel - 1, size=(B, L)).astype(np.int32)).cuda()
+    tr.forward_backward(x, tgt)
+    tr.update(lr=0.1, momentum=0.5, max_grad_norm=1.0, total_batch=B)
+    assert math.isfinite(tr.grad_norm()) and tr.grad_norm() > 0
+    p0, m0 = tr.params.clone(), tr.mom.clone()
+    tr.forward_backward(x, tgt)
+    tr.grads[tr.grads.numel() // 2] = float("nan")
+    tr.update(lr=0.1, momentum=0.5, max_grad_norm=1.0, total_batch=B)
+    assert not math.isfinite(tr.grad_norm())
+    assert torch.equal(tr.params, p0) and torch.equal(tr.mom, m0)
+    tr.forward_backward(x, tgt)
+    tr.update(lr=0.1, momentum=0.5, max_grad_norm=1.0, total_batch=B)
+    assert math.isfinite(tr.grad_norm()) and not torch.equal(tr.params, p0)
+
+
 def test_training_reduces_loss():
     """a few SGD steps on a fixed batch must drive the CTC loss down (plumbing sanity)"""
     from wav2letter_amd import recipes

@@ -406,6 +406,11 @@ __global__ __launch_bounds__(kEwThreads) void sgd_k(float* __restrict__ p, const
                                                    float gradScale, float maxNorm, const double* __restrict__ sumsq) {
   float coef = gradScale;
   if (maxNorm > 0.f) {
+    // Non-finite gradient norm (a NaN / Inf anywhere in the reduced gradient): leave parameters and momentum
+    // untouched.  The reference aborts on a non-finite loss (Train.cpp:1686-1698) and makes all ranks skip an update
+    // together through an all-reduced flag (:1651-1660); here the norm is computed from the ALL-REDUCED gradient, so
+    // every rank takes the same decision without a host round trip.  w2l_trainer_grad_norm() exposes the norm.
+    if (!isfinite(*sumsq)) return;
     float norm = (float)sqrt(*sumsq) * gradScale;
     float c = maxNorm / (norm + 1e-6f);
     if (c < 1.f) coef *= c;

@@ -6,6 +6,7 @@
 //   -> grads / totalBatchSize :1748-1784 -> clipGradNorm :1791-1798 -> critopt/netopt step :1801-1802.
 // The five af::sync() per step of the reference are gone: a step enqueues ~500 kernels
 // on one stream and never blocks the host.
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -252,6 +253,19 @@ W2L_API int w2l_trainer_set_linseg(void* h, uint32_t updates) {
     t->linsegUpdates = updates;
     t->linseg = updates ? makeLinSegCriterion(t->nLabel, t->scaleMode) : nullptr;
     t->arenaFloats = 0;  // forces a new plan / bind
+  });
+}
+
+// gradient norm of the last w2l_trainer_update (sqrt of the clipped-norm accumulator, BEFORE the 1/totalBatch scale);
+// NaN / Inf means that update was skipped.  Synchronises `stream`.
+W2L_API int w2l_trainer_grad_norm(void* h, double* norm, void* stream) {
+  Trainer* t = (Trainer*)h;
+  TRY(h, {
+    if (!t->sumsq || !norm) throw std::invalid_argument("trainer not bound");
+    double s = 0.0;
+    hipCheck(hipMemcpyAsync(&s, t->sumsq, sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream), "grad norm");
+    hipCheck(hipStreamSynchronize((hipStream_t)stream), "grad norm");
+    *norm = std::sqrt(s);
   });
 }
 

@@ -42,6 +42,7 @@ def _lib_tr():
         L.w2l_trainer_viterbi.argtypes = [vp, vp, vp, vp]
         L.w2l_trainer_set_step.argtypes = [vp, u32]
         L.w2l_trainer_set_linseg.argtypes = [vp, u32]
+        L.w2l_trainer_grad_norm.argtypes = [vp, C.POINTER(C.c_double), vp]
         L.w2l_trainer_set_grad_buckets.argtypes = [vp, i, C.POINTER(sz)]
         L.w2l_trainer_wait_bucket.argtypes = [vp, i, vp]
         L.w2l_arch_check.argtypes = [C.c_char_p, i, i, C.POINTER(i)]
@@ -171,6 +172,12 @@ class Trainer:
         path = torch.empty(self.B, self.Tout, dtype=torch.int32, device=self.device)
         _check(self.L.w2l_trainer_viterbi(self.h, emission.data_ptr(), path.data_ptr(), self._stream()), "viterbi")
         return path
+
+    def grad_norm(self):
+        """gradient norm of the last update (synchronises); non-finite => that update was skipped on every rank"""
+        n = C.c_double(0.0)
+        _check(self.L.w2l_trainer_grad_norm(self.h, C.byref(n), self._stream()), "grad_norm")
+        return n.value
 
     def set_step(self, step):
         self.L.w2l_trainer_set_step(self.h, step)
