@@ -313,3 +313,24 @@ def test_linseg_is_single_path_asg(oracle):
         assert abs(loss[b] - (lf[b] - s)) < 1e-9
         assert np.abs(dx[b] - (dxf[b] - ind)).max() < 1e-9
     assert np.isfinite(dA).all()
+
+
+def test_linseg_finite_differences(oracle):
+    """the LinSeg restatement's gradients (emissions and transitions) against central differences of its own loss"""
+    rng = np.random.default_rng(12)
+    B, T, N, L = 2, 6, 3, 4
+    x = rng.normal(size=(B, T, N)).astype(np.float32)
+    A = (rng.normal(size=(N, N)) * 0.5).astype(np.float32)
+    tgt = np.array([[0, 2, 1, -1], [1, 1, 0, 2]], np.int32)
+    g = np.array([0.7, 1.3])
+    loss, dx, dA = oracle.linseg(x, A, tgt, grad=g)
+    f = lambda xx, AA: float((oracle.linseg(xx, AA, tgt)[0] * g).sum())
+    eps = 1e-2
+    for idx in [(0, 0, 0), (0, 3, 2), (1, 5, 1), (1, 2, 0)]:
+        xp, xm = x.copy(), x.copy()
+        xp[idx] += eps; xm[idx] -= eps
+        assert abs((f(xp, A) - f(xm, A)) / (2 * eps) - dx[idx]) < 5e-3
+    for idx in [(0, 0), (2, 1), (1, 2)]:
+        Ap, Am = A.copy(), A.copy()
+        Ap[idx] += eps; Am[idx] -= eps
+        assert abs((f(x, Ap) - f(x, Am)) / (2 * eps) - dA[idx]) < 5e-3
