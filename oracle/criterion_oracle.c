@@ -88,6 +88,15 @@ W2L_EXPORT void w2l_oracle_batch_ctc_target_size(int B, int L, int T,
     targetSize[b] = w2l_oracle_ctc_target_size(target + (size_t)b * L, L, T);
 }
 
+static int wide_labels(int B, int N) {
+#ifdef _OPENMP
+  return N >= 512 && B < omp_get_max_threads();
+#else
+  (void)B; (void)N;
+  return 0;
+#endif
+}
+
 static double scale_of(int mode, int T, int L) {
   switch (mode) {
     case SCALE_NONE: return 1.0;
@@ -118,7 +127,10 @@ W2L_EXPORT void w2l_oracle_fcc_forward(int B, int T, int N, int scaleMode,
                                        void* workspace) {
   double* alphaAll = (double*)workspace;
   double* scaleAll = alphaAll + (size_t)B * T * N;
-#pragma omp parallel for
+  /* few utterances x many labels (the N = 9998 checks): the rows i of one step are independent,
+   * so the threads go to the i loop instead of the b loop; same arithmetic per (b, t, i) */
+  const int inner = wide_labels(B, N);
+#pragma omp parallel for if (!inner)
   for (int b = 0; b < B; ++b) {
     const float* x = input + (size_t)b * T * N;
     double* alpha = alphaAll + (size_t)b * T * N;
@@ -128,6 +140,7 @@ W2L_EXPORT void w2l_oracle_fcc_forward(int B, int T, int N, int scaleMode,
     for (int t = 1; t < T; ++t) {
       const double* ap = alpha + (size_t)(t - 1) * N;
       double* ac = alpha + (size_t)t * N;
+#pragma omp parallel for if (inner)
       for (int i = 0; i < N; ++i) {
         double m = NEG_INF;
         for (int j = 0; j < N; ++j) {
@@ -155,12 +168,14 @@ W2L_EXPORT void w2l_oracle_fcc_backward(int B, int T, int N, const float* trans,
                                         double* transGrad, void* workspace) {
   double* alphaAll = (double*)workspace;
   double* scaleAll = alphaAll + (size_t)B * T * N;
-  double* tgBatch = (double*)calloc((size_t)B * N * N, sizeof(double));
-#pragma omp parallel for
+  const int inner = wide_labels(B, N);
+  /* inner mode runs the utterances one after the other: they can share one accumulator */
+  double* tgBatch = (double*)calloc((size_t)(inner ? 1 : B) * N * N, sizeof(double));
+#pragma omp parallel for if (!inner)
   for (int b = 0; b < B; ++b) {
     const double* alpha = alphaAll + (size_t)b * T * N;
     double* dx = inputGrad + (size_t)b * T * N;
-    double* tg = tgBatch + (size_t)b * N * N;
+    double* tg = tgBatch + (inner ? 0 : (size_t)b * N * N);
     double g = scaleAll[b] * grad[b];
     double* da = (double*)malloc(sizeof(double) * 2 * N);
     double* dprev = da + N;
@@ -174,6 +189,7 @@ W2L_EXPORT void w2l_oracle_fcc_backward(int B, int T, int N, const float* trans,
     for (int t = T - 1; t >= 1; --t) {
       const double* ap = alpha + (size_t)(t - 1) * N;
       for (int j = 0; j < N; ++j) dprev[j] = 0;
+#pragma omp parallel for if (inner) reduction(+ : dprev[:N])
       for (int i = 0; i < N; ++i) {
         dx[(size_t)t * N + i] = g * da[i];
         /* lse_i = logsumexp_j(ap[j] + trans[i][j]) recomputed stably */
@@ -198,7 +214,7 @@ W2L_EXPORT void w2l_oracle_fcc_backward(int B, int T, int N, const float* trans,
   }
   for (size_t k = 0; k < (size_t)N * N; ++k) {
     double s = 0;
-    for (int b = 0; b < B; ++b) s += tgBatch[(size_t)b * N * N + k];
+    for (int b = 0; b < (inner ? 1 : B); ++b) s += tgBatch[(size_t)b * N * N + k];
     transGrad[k] = s;
   }
   free(tgBatch);
@@ -256,14 +272,15 @@ W2L_EXPORT void w2l_oracle_fac_backward(int B, int T, int N, int L,
                                         void* workspace) {
   double* alphaAll = (double*)workspace;
   double* scaleAll = alphaAll + (size_t)B * T * L;
-  double* tgBatch = (double*)calloc((size_t)B * N * N, sizeof(double));
+  const int inner = wide_labels(B, N);  /* few utterances x many labels: one after the other, one accumulator */
+  double* tgBatch = (double*)calloc((size_t)(inner ? 1 : B) * N * N, sizeof(double));
   memset(inputGrad, 0, sizeof(double) * (size_t)B * T * N);
-#pragma omp parallel for
+#pragma omp parallel for if (!inner)
   for (int b = 0; b < B; ++b) {
     const int* y = target + (size_t)b * L;
     const double* alpha = alphaAll + (size_t)b * T * L;
     double* dx = inputGrad + (size_t)b * T * N;
-    double* tg = tgBatch + (size_t)b * N * N;
+    double* tg = tgBatch + (inner ? 0 : (size_t)b * N * N);
     int S = targetSize[b];
     if (S <= 0) continue;
     double g = scaleAll[b] * grad[b];
@@ -303,7 +320,7 @@ W2L_EXPORT void w2l_oracle_fac_backward(int B, int T, int N, int L,
   }
   for (size_t k = 0; k < (size_t)N * N; ++k) {
     double s = 0;
-    for (int b = 0; b < B; ++b) s += tgBatch[(size_t)b * N * N + k];
+    for (int b = 0; b < (inner ? 1 : B); ++b) s += tgBatch[(size_t)b * N * N + k];
     transGrad[k] = s;
   }
   free(tgBatch);
@@ -518,5 +535,13 @@ W2L_EXPORT int w2l_oracle_num_threads(void) {
   return omp_get_max_threads();
 #else
   return 1;
+#endif
+}
+
+W2L_EXPORT void w2l_oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
 #endif
 }

@@ -332,6 +332,46 @@ W2L_EXPORT void w2l_oracle_dropout(const float* x, float* y, size_t n, double p,
     y[i] = w2l_oracle_keep(i, seed, stream, thr) ? x[i] * sc : 0.0f;
 }
 
+/* ---- fl::SpecAugment (arch token SAUG, recipes/joint_training_vox_populi/cpc/SequentialBuilder.cpp:602-613;
+ * recipe line recipes/sota/2019/am_arch/am_tds_ctc.arch:1 "SAUG 80 27 2 100 1.0 2").  The arithmetic is
+ * un-vendored Flashlight (fl/contrib/modules/SpecAugment.cpp) => PARITY UNPINNED; restated as recalled:
+ *   for i < nFMask: f  = randInt[0, fMaskF)  ; f0 = randInt[0, F - f) ; x(:, f0 .. f0+f, :, :) = 0
+ *   Tm = min(tMaskT, (int)(T * tMaskP)); if Tm > 0, for i < nTMask:
+ *                   t  = randInt[0, Tm)      ; t0 = randInt[0, T - t) ; x(t0 .. t0+t, :, :, :) = 0
+ * af::seq(a, b) is INCLUSIVE, so a draw of f masks f + 1 channels; af::span over the batch dim => ONE set of
+ * masks per batch; time warping (the first SAUG number) is not implemented by the reference module.
+ * The random draws are the stateless hash shared with the device (stream 1000): draw k of the call is
+ * hash32(k, seed, 1000) reduced modulo the range.  x is frame-major [B][T][F]; in place. */
+W2L_EXPORT int w2l_oracle_specaugment(float* x, int B, int T, int F, int fMaskF, int nFMask, int tMaskT,
+                                      float tMaskP, int nTMask, uint32_t seed, int* masks /* [4*8] f0,f1,t0,t1 incl. */) {
+  if (F < fMaskF || nFMask > 8 || nTMask > 8) return 1;
+  int f0s[8], f1s[8], t0s[8], t1s[8];
+  for (int k = 0; k < 8; ++k) { f0s[k] = t0s[k] = 0; f1s[k] = t1s[k] = -1; }
+  for (int k = 0; k < nFMask && fMaskF > 0; ++k) {
+    int f = (int)(w2l_hash32(4 * k, seed, 1000) % (uint32_t)fMaskF);
+    int f0 = (int)(w2l_hash32(4 * k + 1, seed, 1000) % (uint32_t)(F - f));
+    f0s[k] = f0; f1s[k] = f0 + f;
+  }
+  int Tm = (int)((float)T * tMaskP);
+  if (Tm > tMaskT) Tm = tMaskT;
+  if (Tm > T) Tm = T;
+  for (int k = 0; k < nTMask && Tm > 0; ++k) {
+    int t = (int)(w2l_hash32(4 * k + 2, seed, 1000) % (uint32_t)Tm);
+    int t0 = (int)(w2l_hash32(4 * k + 3, seed, 1000) % (uint32_t)(T - t));
+    t0s[k] = t0; t1s[k] = t0 + t;
+  }
+  for (int b = 0; b < B; ++b)
+    for (int t = 0; t < T; ++t)
+      for (int f = 0; f < F; ++f) {
+        int m = 0;
+        for (int k = 0; k < 8; ++k) m |= (f >= f0s[k] && f <= f1s[k]) || (t >= t0s[k] && t <= t1s[k]);
+        if (m) x[((size_t)b * T + t) * F + f] = 0.0f;
+      }
+  if (masks)
+    for (int k = 0; k < 8; ++k) { masks[k] = f0s[k]; masks[8 + k] = f1s[k]; masks[16 + k] = t0s[k]; masks[24 + k] = t1s[k]; }
+  return 0;
+}
+
 /* ---- streaming-library forms used only to replay the golden vectors ------- */
 /* Conv1dFbGemm.cpp:104-185: frame-major x [T][groups][cin_g]; weights
  * [cout_g][kw][cin_g] shared by all groups; y [To][groups][cout_g]. */

@@ -360,6 +360,19 @@ def dropout(x, p, seed, stream):
     return y
 
 
+def specaugment(x, f_mask_f, n_f_mask, t_mask_t, t_mask_p, n_t_mask, seed):
+    """fl::SpecAugment on frame-major x [B][T][F] (copy); returns (y, masks) with masks[4][8] = inclusive
+    f0, f1, t0, t1 per mask (f1 < f0 / t1 < t0: unused slot)"""
+    y = _f32(x).copy()
+    B, T, F = y.shape
+    masks = np.zeros((4, 8), np.int32)
+    st = lib().w2l_oracle_specaugment(_p(y), B, T, F, int(f_mask_f), int(n_f_mask), int(t_mask_t),
+                                      C.c_float(t_mask_p), int(n_t_mask), C.c_uint32(seed), _p(masks))
+    if st:
+        raise ValueError("specaugment: F < fMaskF or more than 8 masks")
+    return y, masks
+
+
 def streaming_conv1d(x, w, bias, T, groups, cin_g, cout_g, kw, stride, padl, padr):
     x = _f32(x); w = _f32(w); bias = _f32(bias)
     To = (T + padl + padr - kw) // stride + 1
@@ -371,3 +384,7 @@ def streaming_conv1d(x, w, bias, T, groups, cin_g, cout_g, kw, stride, padl, pad
 
 def num_threads():
     return lib().w2l_oracle_num_threads()
+
+
+def set_num_threads(n):
+    lib().w2l_oracle_set_num_threads(int(n))

@@ -334,3 +334,31 @@ def test_linseg_finite_differences(oracle):
         Ap, Am = A.copy(), A.copy()
         Ap[idx] += eps; Am[idx] -= eps
         assert abs((f(x, Ap) - f(x, Am)) / (2 * eps) - dA[idx]) < 5e-3
+
+
+def test_fcc_fac_thread_layouts_agree(oracle):
+    """few utterances x many labels puts the OpenMP threads on the label loop instead of the batch loop
+    (the N = 9998 parity checks); both layouts are the same arithmetic"""
+    rng = np.random.default_rng(5)
+    B, T, N, L = 2, 5, 600, 4
+    x = rng.normal(size=(B, T, N)).astype(np.float32)
+    A = rng.normal(size=(N, N)).astype(np.float32)
+    tgt = rng.integers(0, N, size=(B, L)).astype(np.int32)
+    ts = oracle.batch_target_size(tgt, T)
+    w = rng.normal(size=B)
+    n0 = oracle.num_threads()
+    res = []
+    try:
+        for nthr in (1, 4):   # 1: batch loop (serial); 4 > B: label loop
+            oracle.set_num_threads(nthr)
+            o = oracle.FCC(x, A, ts, 4)
+            l = o.forward()
+            dx, dA = o.backward(w)
+            f = oracle.FAC(x, A, tgt, scale_mode=4)
+            fl = f.forward()
+            fdx, fdA = f.backward(w)
+            res.append((l, dx, dA, fl, fdx, fdA))
+    finally:
+        oracle.set_num_threads(n0)
+    for a, b in zip(*res):
+        assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(a).max())

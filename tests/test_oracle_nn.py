@@ -224,3 +224,35 @@ def test_mfsc_oracle_properties(oracle):
     folded = np.log(np.maximum(np.sqrt(ri[:, :nb] ** 2 + ri[:, nb:] ** 2) @ oracle.mfsc_filterbank(80, 512, 16000), 1.0))
     assert np.abs(folded - full).max() < 1e-10
     assert np.abs(oracle.mfsc(x, 80, use_power=True) - oracle.mfsc(x, 80)).max() > 1.0   # power and magnitude differ
+
+
+@pytest.mark.parametrize("T,F,args", [(1500, 80, (27, 2, 100, 1.0, 2)), (57, 40, (15, 1, 50, 0.2, 2)), (9, 8, (8, 2, 100, 1.0, 1))])
+def test_specaugment_oracle_properties(oracle, T, F, args):
+    """fl::SpecAugment restatement (un-vendored => parity unpinned): one mask set per batch, inclusive af::seq ends,
+    widths drawn below fMaskF / min(tMaskT, T*p), whole rows / columns zeroed, everything else untouched"""
+    fmf, nf, tmt, tmp_, nt = args
+    rng = np.random.default_rng(T)
+    x = rng.normal(size=(3, T, F)).astype(np.float32)
+    x[x == 0] = 1.0
+    outs = set()
+    for seed in range(1, 20):
+        y, m = oracle.specaugment(x, fmf, nf, tmt, tmp_, nt, seed)
+        zero = y == 0
+        assert (zero == zero[0:1]).all()
+        fm, tm = zero[0].all(axis=0), zero[0].all(axis=1)
+        assert (zero[0] == (fm[None, :] | tm[:, None])).all()
+        assert (y[~zero] == x[~zero]).all()
+        tmax = min(tmt, int(T * tmp_), T)
+        want_f = np.zeros(F, bool)
+        want_t = np.zeros(T, bool)
+        for k in range(nf):
+            assert 0 <= m[0, k] <= m[1, k] < F and m[1, k] - m[0, k] < fmf
+            want_f[m[0, k]:m[1, k] + 1] = True
+        for k in range(nt):
+            assert 0 <= m[2, k] <= m[3, k] < T and m[3, k] - m[2, k] < tmax
+            want_t[m[2, k]:m[3, k] + 1] = True
+        assert (zero[0] == (want_f[None, :] | want_t[:, None])).all()
+        outs.add(y.tobytes())
+    assert len(outs) > 10
+    with pytest.raises(ValueError):
+        oracle.specaugment(x[:, :, :4], 27, 2, 100, 1.0, 2, 1)

@@ -95,6 +95,8 @@ class _SIGS:
     w2l_glu_forward = (_i, [_p, _p, _sz, _i, _p])
     w2l_glu_backward = (_i, [_p, _p, _p, _sz, _i, _p])
     w2l_sumsq = (_i, [_p, _sz, _p, _i, _p])
+    w2l_specaugment_inplace = (_i, [_p, _i, _i, _i, _i, _i, _i, _f, _i, _u32, _p])
+    w2l_fill = (_i, [_p, _sz, _f, _p])
     w2l_profile_enable = (_i, [_i])
     w2l_profile_report_kind = (_i, [_i, _p, _p, _p])
     w2l_sgd_step = (_i, [_p, _p, _p, _sz, _f, _f, _f, _f, _p, _p])

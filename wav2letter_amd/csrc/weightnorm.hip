@@ -102,28 +102,30 @@ __global__ __launch_bounds__(256) void wn_bwd_k(const float* __restrict__ v, con
   }
 }
 
-// SpecAugment (frequency + time masking, fill 0) on frame-major features x[B][T][F].
-// Mask positions come from the stateless hash so a step is reproducible from (seed).
+// fl::SpecAugment (SAUG token; recipes/sota/2019/am_arch/am_tds_ctc.arch:1, builder
+// recipes/joint_training_vox_populi/cpc/SequentialBuilder.cpp:602-613) on frame-major features x[B][T][F], fill 0.
+// Semantics as recalled from the un-vendored fl/contrib/modules/SpecAugment.cpp (restated in oracle/nn_oracle.c):
+// ONE set of masks per batch (af::span over the batch dim), widths drawn from [0, fMaskF) / [0, min(tMaskT, T*p)),
+// af::seq ends inclusive (a draw of f masks f + 1 rows), no time warping.  Draw k = hash32(k, seed, 1000) mod range.
 __global__ __launch_bounds__(256) void specaug_k(float* __restrict__ x, int T, int F, int fMaskF, int nFMask,
                                                  int tMaskT, float tMaskP, int nTMask, uint32_t seed) {
   const int b = blockIdx.y;
   __shared__ int f0s[8], f1s[8], t0s[8], t1s[8];
   if (threadIdx.x < 8) {
     int k = threadIdx.x;
-    f0s[k] = f1s[k] = t0s[k] = t1s[k] = 0;
-    if (k < nFMask) {
-      uint32_t h1 = hash32(4 * k, seed, 1000 + b), h2 = hash32(4 * k + 1, seed, 1000 + b);
-      int fw = (int)(h1 % (uint32_t)(fMaskF + 1));
-      if (fw > F) fw = F;
-      int f0 = (int)(h2 % (uint32_t)(F - fw + 1));
+    f0s[k] = t0s[k] = 0;
+    f1s[k] = t1s[k] = -1;
+    if (k < nFMask && fMaskF > 0) {
+      int fw = (int)(hash32(4 * k, seed, 1000) % (uint32_t)fMaskF);
+      int f0 = (int)(hash32(4 * k + 1, seed, 1000) % (uint32_t)(F - fw));
       f0s[k] = f0; f1s[k] = f0 + fw;
     }
-    if (k < nTMask) {
-      uint32_t h1 = hash32(4 * k + 2, seed, 1000 + b), h2 = hash32(4 * k + 3, seed, 1000 + b);
-      int tmax = (int)(tMaskP * T);
-      if (tmax > tMaskT) tmax = tMaskT;
-      int tw = (int)(h1 % (uint32_t)(tmax + 1));
-      int t0 = (int)(h2 % (uint32_t)(T - tw + 1));
+    int tmax = (int)((float)T * tMaskP);
+    if (tmax > tMaskT) tmax = tMaskT;
+    if (tmax > T) tmax = T;
+    if (k < nTMask && tmax > 0) {
+      int tw = (int)(hash32(4 * k + 2, seed, 1000) % (uint32_t)tmax);
+      int t0 = (int)(hash32(4 * k + 3, seed, 1000) % (uint32_t)(T - tw));
       t0s[k] = t0; t1s[k] = t0 + tw;
     }
   }
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256) void specaug_k(float* __restrict__ x, int T, i
     int t = (int)(e / F), f = (int)(e - (size_t)t * F);
     bool m = false;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) m = m || (f >= f0s[k] && f < f1s[k]) || (t >= t0s[k] && t < t1s[k]);
+    for (int k = 0; k < 8; ++k) m = m || (f >= f0s[k] && f <= f1s[k]) || (t >= t0s[k] && t <= t1s[k]);
     if (m) xb[e] = 0.f;
   }
 }
@@ -171,7 +173,8 @@ W2L_API int w2l_weightnorm_backward(const float* v, const float* g, const float*
 
 W2L_API int w2l_specaugment_inplace(float* x, int B, int T, int F, int fMaskF, int nFMask, int tMaskT,
                                     float tMaskP, int nTMask, uint32_t seed, w2l_stream_t stream) {
-  if (!x || B <= 0 || T <= 0 || F <= 0 || nFMask > 8 || nTMask > 8 || nFMask < 0 || nTMask < 0) return W2L_EINVAL;
+  if (!x || B <= 0 || T <= 0 || F <= 0 || nFMask > 8 || nTMask > 8 || nFMask < 0 || nTMask < 0 || fMaskF < 0 || tMaskT < 0 ||
+      F < fMaskF /* the reference throws: "Invalid input frequency channels" */) return W2L_EINVAL;
   size_t n = (size_t)T * F;
   unsigned gx = (unsigned)((n + 255) / 256 > 256 ? 256 : (n + 255) / 256);
   hipLaunchKernelGGL(specaug_k, dim3(gx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, T, F, fMaskF, nFMask,
