@@ -13,6 +13,7 @@ momentum, exactly the reference's hot loop (recipes/slimIPL/src/Train.cpp:1454-1
 Inputs are synthetic, generated on the device before the timed region.
 
   python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N ...            (no WORLD_SIZE in the environment: starts N ranks itself, one per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
@@ -66,6 +67,10 @@ def parse():
     ap.add_argument("--no-stress", action="store_true", help="skip the ASG N=9998 stress leg")
     ap.add_argument("--stress-frames", type=int, default=1500)
     ap.add_argument("--no-c4", action="store_true", help="skip the conv_glu LibriSpeech ASG step (BASELINE config 4) leg")
+    ap.add_argument("--no-oracle-checks", action="store_true", help="skip the oracle comparison of the stress / config-4 losses")
+    ap.add_argument("--cpu-baseline-batch", type=int, default=8)
+    ap.add_argument("--dist-selftest", action="store_true",
+                    help="launcher + process group + arena all-reduce only (gloo on a CPU-only host, RCCL on GPUs)")
     return ap.parse_args()
 
 
@@ -122,7 +127,7 @@ def asg_criterion_ms(device):
                     "the HBM roofline is quoted on the N=9998 stress shape (asg_stress)"}
 
 
-def conv_glu_asg_step(device, L, steps=2):
+def conv_glu_asg_step(device, L, steps=2, oracle_checks=True):
     """BASELINE config 4 on one GPU: conv_glu LibriSpeech (17 WN-conv + GLU layers, 208.9 M parameters), ASG criterion,
     N = 30, T = 2000 frames of 40 filterbanks, batch 64: full training step (forward, ASG, backward, clip + SGD).  The
     convolutions run as one LDS-DMA GEMM each on overlapping rows of the frame-major activations (csrc/conv.hip)."""
@@ -164,15 +169,30 @@ def conv_glu_asg_step(device, L, steps=2):
     L.w2l_profile_report_kind(0, C.byref(n_), C.byref(ms_), C.byref(w_))
     L.w2l_profile_enable(0)
     tf = w_.value / (ms_.value * 1e-3) / 1e12 if ms_.value > 0 else 0.0
+    check = None
+    if oracle_checks:
+        # outside the timed region: the criterion of the step on the network's own emissions (eval forward) against the
+        # fp64 oracle at the full shape -- loss [64] element by element (reference call site Train.cpp:408-410, :1675)
+        from oracle import pyoracle as O
+        from wav2letter_amd import ASGLoss
+        em = tr.forward(x, train=False).clone()
+        A = tr.params[tr.n_net:tr.n_net + nlabel * nlabel].view(nlabel, nlabel).clone()
+        crit = ASGLoss(nlabel, CriterionScaleMode.TARGET_SZ_SQRT, fl["transdiag"]).to(device)
+        crit.transitions.data = A
+        got = crit(em, tgt).detach().cpu().numpy()
+        ol, _, _ = O.asg(em.cpu().numpy(), A.cpu().numpy(), tgt.cpu().numpy(), 4)
+        err = float(np.abs(got - ol).max() / max(1.0, np.abs(ol).max()))
+        check = {"what": "ASG loss [64] on the step's emissions vs fp64 oracle", "max_rel_err": err, "ok": bool(err < 1e-4)}
     return {"config": "conv_glu LibriSpeech ASG (recipes/conv_glu/librispeech/network.arch): B=64/GPU, T=2000, 40 fbank, N=30, fp32",
             "ms_per_step": round(dt * 1e3, 1), "utterances_per_sec": round(B / dt, 2), "finite": bool(torch.isfinite(loss).all().item()),
+            "loss_check": check,
             "roofline": {"bound": "mfma", "kernel": "gemm128g_kernel / gemm160_kernel on overlapping-row convolution operands",
                          "achieved": round(tf, 1), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
                          "launches_per_step": n_.value // steps, "gemm_ms_per_step": round(ms_.value / steps, 1),
                          "algorithmic_tflop_per_step": round(w_.value / steps / 1e12, 2)}}
 
 
-def asg_stress(device, L, T):
+def asg_stress(device, L, T, oracle_checks=True):
     """The north-star stress shape of the ASG alpha/beta recursion: B=32, T=1500, N=9998 word pieces.
     The 400 MB transition matrix exceeds the 256 MiB Infinity Cache and is re-streamed at every one of the
     T dependent steps: algorithmic bytes per step = 4 N^2 + 8 B N.  The dominant kernel
@@ -203,12 +223,24 @@ def asg_stress(device, L, T):
     L.w2l_profile_report_kind(3, C.byref(nl), C.byref(ms), C.byref(by))
     L.w2l_profile_enable(0)
     achieved = by.value / (ms.value * 1e-3) / 1e9 if ms.value > 0 else 0.0
+    check = None
+    if oracle_checks:
+        # outside the timed region: utterance 0 of the TIMED forward (fp32 exp-domain rescaling over T dependent steps at
+        # N = 9998) against the fp64 log-domain oracle: 1.5e11 log-sum-exp terms on the host cores, label loop threaded
+        from oracle import pyoracle as O
+        t3 = time.perf_counter()
+        o = O.FCC(x[0:1].detach().cpu().numpy(), crit.transitions.detach().cpu().numpy(), np.array([8], np.int32), 4)
+        want = float(o.forward()[0])
+        got = float(loss[0].item())
+        check = {"what": f"FCC loss of utterance 0 (T={T}, N={N}) vs fp64 oracle", "got": got, "oracle": want,
+                 "rel_err": abs(got - want) / max(1.0, abs(want)), "ok": bool(abs(got - want) < 1e-4 * max(1.0, abs(want))),
+                 "oracle_seconds": round(time.perf_counter() - t3, 1)}
     step_bytes = 4.0 * N * N + 8.0 * B * N
     fwd_ms, bwd_ms = (t1 - t0) * 1e3, (t2 - t1) * 1e3
     return {"shape": f"B={B},T={T},N={N}", "fwd_ms": round(fwd_ms, 2), "bwd_ms": round(bwd_ms, 2),
             "fwd_us_per_step": round(fwd_ms * 1e3 / T, 2),
             "whole_forward_GBps": round(step_bytes * (T - 1) / (fwd_ms * 1e-3) / 1e9, 1),
-            "finite": bool(torch.isfinite(loss).all().item()),
+            "finite": bool(torch.isfinite(loss).all().item()), "loss_check": check,
             "roofline": {"bound": "hbm", "kernel": "fcc_big_gemm (packed-transition stream, fp32 MFMA 32x32x2)",
                          "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                          "frac": round(achieved / PEAK_HBM_GBPS, 4), "traffic": pmc_traffic("fcc_big_gemm")[0],
@@ -217,43 +249,78 @@ def asg_stress(device, L, T):
                          "algorithmic_bytes_per_launch": step_bytes}}
 
 
-def cpu_baseline(nfeat, nlabel, T):
-    """the oracle ("port") timed on this box's host cores on a bounded sample: ONE utterance,
-    network forward+backward + CTC, same arch and shapes (B=1)."""
+def cpu_baseline(nfeat, nlabel, T, batch=8):
+    """The reference's CPU path as BASELINE.md sec. 3 item 2 / SURVEY 8(d) prescribe it -- a declared PROXY, the
+    reference (Flashlight + ArrayFire) cannot be built here: torch-CPU (oneDNN / MKL, the libraries Flashlight's CPU
+    backend sits on) with every host core for conv / linear / LayerNorm, the OpenMP oracle for CTC; one training step
+    (forward + CTC + backward, no optimizer) of the SAME arch at the SAME T on `batch` utterances, 2 warm-ups, median of
+    up to 5 runs, bounded to ~30 s of CPU work.  A reported baseline, not the target."""
     from oracle import pyoracle as O
-    from oracle import refnet
+    from oracle import torchnet
     from wav2letter_amd import recipes
-    cores = O.num_threads()
-    Ts = T if cores >= 32 else max(200, T // 8)
-    arch = recipes.tds_ctc_arch()
-    arch = "\n".join(l for l in arch.splitlines()
-                     if not l.startswith("SAUG"))  # eval-style pass, dropout-free lines rewritten below
-    arch = "\n".join((" ".join(f[:4] + ["0.0"] + f[5:]) if f and f[0] == "TDS" else " ".join(f))
-                     for f in (l.split() for l in arch.splitlines())) + "\n"
-    net = refnet.RefNet(arch, nfeat, nlabel)
-    rng = np.random.default_rng(0)
-    params = net.random_params(rng)
-    x = rng.normal(size=(1, 1, nfeat, Ts)).astype(np.float32)
-    tgt = rng.integers(0, nlabel - 1, size=(1, 20)).astype(np.int32)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
     t0 = time.perf_counter()
-    em = net.forward(x, params)
-    ctc = O.CTC(em, tgt, scale_mode=4)
-    ctc.forward()
-    d_em = ctc.backward().astype(np.float32)
-    net.backward(d_em, len(params))
-    dt = time.perf_counter() - t0
-    return {"value": round((Ts / T) / dt, 4), "unit": "utterances/sec", "cores": cores, "kind": "port",
-            "sample": f"1 utterance x {Ts} frames (scaled to T={T}), forward+backward+CTC, no optimizer, "
-                      f"oracle C loops with OpenMP; {dt:.1f} s"}
+    # size the sample: one probe step, then as many timed runs as fit in the budget
+    probe, _ = torchnet.tds_ctc_step_seconds(recipes.tds_ctc_arch(), nfeat, nlabel, batch, T, warmup=0, runs=1)
+    runs = int(max(1, min(5, (30.0 - probe) / max(probe, 1e-3) - 1)))
+    med, times = torchnet.tds_ctc_step_seconds(recipes.tds_ctc_arch(), nfeat, nlabel, batch, T, warmup=1, runs=runs)
+    return {"value": round(batch / med, 4), "unit": "utterances/sec", "cores": cores, "kind": "proxy(torch-cpu+oracle)",
+            "torch_threads": torch.get_num_threads(), "oracle_threads": O.num_threads(),
+            "sample": f"{batch} utterances x {T} frames, TDS-CTC training step (forward + CTC + backward, no optimizer), "
+                      f"torch-CPU oneDNN/MKL network + OpenMP oracle CTC; 2 warm-ups, median of {runs} runs "
+                      f"({', '.join(f'{t:.2f}' for t in times)} s); {time.perf_counter() - t0:.1f} s of CPU work"}
+
+
+def dist_selftest(a):
+    """launcher + rendezvous + the arena all-reduce, nothing else: every rank fills a flat gradient arena whose tail
+    carries its local batch size (parallel.GradientArena, the layout Trainer.grads_full has), ONE all-reduce sums both.
+    Runs with gloo on a CPU-only host (tests/test_distributed_cpu.py drives it through the same self-launch path as a
+    real --gpus N run) and with RCCL when GPUs are visible."""
+    import torch.distributed as dist
+    from wav2letter_amd.parallel import GradientArena, init_distributed
+    use_gpu = torch.cuda.is_available() and torch.cuda.device_count() >= int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device("cuda", local_rank) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(local_rank)
+    rank, world = init_distributed("nccl" if use_gpu else "gloo", device if use_gpu else None)
+    n = 1000
+    arena = GradientArena(n, device)
+    arena.grads.fill_(float(rank + 1))
+    arena.set_local_batch(a.batch + rank)       # ragged tail batches: ranks may differ
+    total = arena.all_reduce()
+    want_g = world * (world + 1) / 2
+    want_b = world * a.batch + world * (world - 1) / 2
+    ok = bool((arena.grads == want_g).all().item()) and float(total.item()) == want_b
+    ranks = dist.get_world_size() if dist.is_initialized() else 1
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"selftest": "dist", "ok": ok, "n_gpus": world, "rccl_ranks": ranks,
+                          "backend": "nccl(rccl)" if use_gpu else "gloo", "global_batch": float(total.item())}), flush=True)
+    return 0 if ok else 1
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, RCCL over xGMI)
+        from wav2letter_amd.parallel import self_launch
+        sys.exit(self_launch(a.gpus, os.path.abspath(__file__), sys.argv[1:],
+                             need_gpus=not (a.dist_selftest and not torch.cuda.is_available())))
+    if a.dist_selftest:
+        sys.exit(dist_selftest(a))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus != world and world > 1:
+    if a.gpus != world:
+        if world > 1 and rank == 0:
+            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: running {world} ranks", file=sys.stderr)
         a.gpus = world
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, this node shows {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -275,7 +342,6 @@ def main():
     Tout = tr.plan(B, T, Lmax)
     tr.to_device()
     x, tgt = make_batch(B, T, nfeat, nlabel, Lmax, 2026 + rank, device)
-    total_batch = B * world
 
     reducer = None
     if dist is not None:
@@ -288,8 +354,10 @@ def main():
             # the flat gradient arena (814 MB fp32) in a few large buckets, last layers first, on a side
             # stream gated by per-bucket events: the sum crosses xGMI under the rest of the backward pass
             reducer.reduce()
+        # gradients / (all-reduced batch size): the local batch size rides in the arena's tail through the SAME
+        # collective (the reference all-reduces it separately, Train.cpp:1743-1747); world == 1: the local B
         tr.update(lr=fl["lr"], momentum=fl["momentum"], max_grad_norm=fl["maxgradnorm"],
-                  total_batch=total_batch)
+                  total_batch="reduced" if reducer is not None else B)
         return loss
 
     for _ in range(a.warmup):
@@ -314,6 +382,10 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
     last_loss = float(loss.float().mean().item())
+    # the global batch the optimizer divided by: read back from the (all-reduced) arena tail, not assumed
+    total_batch = int(round(tr.grads_full[tr.n_floats].item())) if reducer is not None else B
+    rccl_ranks = dist.get_world_size() if dist is not None else 1
+    skipped = tr.skipped_updates()
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -328,15 +400,22 @@ def main():
     nc, msc, flc = kind(2)           # TDS slab convolutions
     ns, mss, fls = kind(1)           # generic skinny implicit GEMM (strided backward-data only)
     L.w2l_profile_enable(0)
+    nbd, msbd, flbd = kind(4)        # TDS convolution backward-data
+    nbf, msbf, flbf = kind(5)        # TDS convolution backward-filter
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    step_flops = (flops + flc + flbd + flbf + fls) / max(1, a.steps)   # every MFMA launch of the step, algorithmic 2MNK
+    ms_step = dt / a.steps * 1e3
+
+    def tfs(f_, m_):
+        return round(f_ / (m_ * 1e-3) / 1e12, 2) if m_ > 0 else None
     out = {
         "metric": "utterances/sec", "value": round(total_batch * a.steps / dt, 3), "unit": "utterances/sec",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+        "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "seq2seq_tds LibriSpeech TDS-CTC (sota/2019 am_tds_ctc.arch): 80-mel x T=%d, "
                                "9998 classes, batch %d/GPU, fp32, SGD+momentum, CTC" % (T, B),
                    "global_batch": total_batch, "frames": T, "emission_frames": Tout, "parallelism": f"dp{world}",
-                   "params": int(tr.n_net), "final_loss": round(last_loss, 4)},
+                   "params": int(tr.n_net), "final_loss": round(last_loss, 4), "skipped_updates": int(skipped)},
         "roofline": {"bound": "mfma", "kernel": "gemm128g_kernel / gemm160_kernel (fp32 v_mfma_f32_32x32x2_f32; 128x128x32 tiles, or 128x160 / 160x128 where 128 leaves a ragged tile column; persistent, buffer LDS-DMA staging, stream-K tail reduced in-kernel; includes the few gemm128_kernel launches on unaligned shapes)",
                      "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic("gemm_lds_dma", "gemm128g")[0],
@@ -346,9 +425,19 @@ def main():
                      "algorithmic_gflop_per_launch": round(flops / max(1, nl) / 1e9, 2),
                      "gemm_ms_per_step": round(ms / max(1, a.steps), 3),
                      "algorithmic_tflop_per_step": round(flops / max(1, a.steps) / 1e12, 3),
-                     "tds_conv": {"launches_per_step": nc // max(1, a.steps), "ms_per_step": round(msc / max(1, a.steps), 3),
-                                  "achieved_TFLOPs": round(flc / (msc * 1e-3) / 1e12, 2) if msc > 0 else None,
-                                  "note": "N = C_out (10/14/18) padded to 16/16/32 MFMA columns: ceiling 62.5/87.5/56 % of peak"},
+                     "covers_frac_of_step_time": round(ms / max(1, a.steps) / ms_step, 4),
+                     "whole_step": {"algorithmic_tflop": round(step_flops / 1e12, 3), "achieved_TFLOPs": round(step_flops / (ms_step * 1e-3) / 1e12, 2),
+                                    "frac": round(step_flops / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                    "note": "all MFMA work of the step (GEMMs + convolutions) / wall time per step: what the HBM-bound "
+                                            "LayerNorm / dropout / CTC / optimizer passes and launch gaps cost on top of the dominant kernel"},
+                     "tds_conv": {"launches_per_step": (nc + nbd + nbf) // max(1, a.steps),
+                                  "ms_per_step": round((msc + msbd + msbf) / max(1, a.steps), 3),
+                                  "achieved_TFLOPs": tfs(flc + flbd + flbf, msc + msbd + msbf),
+                                  "forward": {"launches_per_step": nc // max(1, a.steps), "ms_per_step": round(msc / max(1, a.steps), 3), "achieved_TFLOPs": tfs(flc, msc)},
+                                  "backward_data": {"launches_per_step": nbd // max(1, a.steps), "ms_per_step": round(msbd / max(1, a.steps), 3), "achieved_TFLOPs": tfs(flbd, msbd)},
+                                  "backward_filter": {"launches_per_step": nbf // max(1, a.steps), "ms_per_step": round(msbf / max(1, a.steps), 3), "achieved_TFLOPs": tfs(flbf, msbf)},
+                                  "note": "TDS convolutions proper: role-swapped v_mfma_f32_32x32x2_f32 kernel (conv_tds_rs.hip), column "
+                                          "ceilings 93.8 / 91.9 / 98.4 % x time-block halo; includes the three strided C2 sub-sampling layers"},
                      "skinny_gemm": {"launches_per_step": ns // max(1, a.steps), "ms_per_step": round(mss / max(1, a.steps), 3)}},
     }
     def leg(key, fn):
@@ -364,15 +453,15 @@ def main():
     if world == 1 and not a.no_stress:
         del tr, x, tgt
         torch.cuda.empty_cache()
-        leg("asg_stress", lambda: asg_stress(device, L, a.stress_frames))
+        leg("asg_stress", lambda: asg_stress(device, L, a.stress_frames, not a.no_oracle_checks))
     if world == 1 and not a.no_c4:
-        leg("conv_glu_asg_step", lambda: conv_glu_asg_step(device, L))
+        leg("conv_glu_asg_step", lambda: conv_glu_asg_step(device, L, oracle_checks=not a.no_oracle_checks))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if world == 1 and not a.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(nfeat, nlabel, T)
+            out["cpu_baseline"] = cpu_baseline(nfeat, nlabel, T, a.cpu_baseline_batch)
         except Exception as e:  # noqa: BLE001
             out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
     print(json.dumps(out), flush=True)

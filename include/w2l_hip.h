@@ -225,6 +225,15 @@ int w2l_specaugment_inplace(float* x, int B, int T, int F, int fMaskF, int nFMas
 int w2l_sumsq(const float* g, size_t n, double* out, int zeroFirst, w2l_stream_t stream);
 int w2l_sgd_step(float* p, const float* g, float* v, size_t n, float lr, float momentum,
                  float gradScale, float maxGradNorm, const double* sumsq, w2l_stream_t stream);
+/* Non-finite guard + device-side batch size of a data-parallel step (Train.cpp:1651-1660, :1743-1747).
+ * acc[5] doubles: in  acc[0] = sum g^2 of the network gradients, acc[1] = of the criterion gradients;
+ *                 out acc[2] = clip norm^2 (acc[0] + clampCrit*acc[1]), NaN when ANY gradient or the batch size is
+ *                     non-finite, acc[3] = 1 / *batchDev (0 if batchDev is null), acc[4] += 1 per skipped update.
+ * w2l_sgd_step_guarded(guard = acc + 2) leaves p and v untouched when guard[0] is non-finite -- with or without
+ * clipping -- and scales the gradient by guard[1] instead of gradScale when guard[1] > 0. */
+int w2l_grad_guard(double* acc, const float* batchDev, int clampCrit, w2l_stream_t stream);
+int w2l_sgd_step_guarded(float* p, const float* g, float* v, size_t n, float lr, float momentum,
+                         float gradScale, float maxGradNorm, const double* guard, w2l_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * 3. Trainer: arch file -> module graph -> one optimisation step.
@@ -241,22 +250,31 @@ void w2l_trainer_destroy(void* h);
 const char* w2l_trainer_describe(void* h);
 size_t w2l_trainer_param_floats(void* h);
 size_t w2l_trainer_net_param_floats(void* h);
+/* floats of the gradient arena to bind: parameters + a 4-float tail; tail[0] = this rank's batch size, written by
+ * forward_backward, so that ONE all-reduce over [0, grad_floats) sums gradients and batch sizes
+ * (recipes/slimIPL/src/Train.cpp:1743-1747 all-reduces the batch size separately) */
+size_t w2l_trainer_grad_floats(void* h);
 int w2l_trainer_num_params(void* h);
 int w2l_trainer_param_info(void* h, int i, char* name, int nameCap, size_t* numel, size_t* offset);
 int w2l_trainer_init_params(void* h, float* h_params, uint64_t seed);
 int w2l_trainer_import_param(void* h, int i, const float* h_ref, float* h_params);
 int w2l_trainer_export_param(void* h, int i, const float* h_arena, float* h_ref);
 int w2l_trainer_plan(void* h, int B, int T, int L, size_t* arenaFloats, size_t* critWsBytes, int* Tout);
+/* params / momentum: w2l_trainer_param_floats floats; grads: w2l_trainer_grad_floats floats (4-float tail) */
 int w2l_trainer_bind(void* h, float* params, float* grads, float* momentum, float* arena, void* critWs);
 /* x: [B][NFEAT][T] (the reference's (T,NFEAT,1,B) input); target [B][L] int32, -1 padded */
 int w2l_trainer_forward(void* h, const float* x, int train, const float** emission, void* stream);
 int w2l_trainer_forward_backward(void* h, const float* x, const int* target, float** lossDev,
                                  void* stream);
+/* totalBatch > 0: scale the gradients by 1/totalBatch; totalBatch <= 0: by 1 / (the all-reduced batch size in the
+ * gradient arena's tail).  A non-finite gradient (or batch size) skips the update on every rank -- with or without
+ * clipping -- and counts it (w2l_trainer_skipped_updates). */
 int w2l_trainer_update(void* h, float lr, float lrcrit, float momentum, float maxGradNorm,
                        float totalBatch, int clampCrit, void* stream);
+int w2l_trainer_skipped_updates(void* h, uint64_t* count, void* stream);
 int w2l_trainer_viterbi(void* h, const float* emission, int* path, void* stream);
 int w2l_trainer_set_step(void* h, uint32_t step);
-/* gradient norm seen by the last w2l_trainer_update with maxGradNorm > 0 (before the 1/totalBatch scale).  A
+/* gradient norm seen by the last w2l_trainer_update (before the 1/totalBatch scale; taken on every update).  A
  * non-finite norm means the update was SKIPPED on every rank (the norm is taken on the all-reduced gradient):
  * the counterpart of the reference's NaN guards, recipes/slimIPL/src/Train.cpp:1651-1660, :1686-1698. */
 int w2l_trainer_grad_norm(void* h, double* norm, void* stream);

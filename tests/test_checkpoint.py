@@ -66,3 +66,26 @@ def test_learning_rate_schedule_matches_the_reference_formula():
     c = {"lr": 1.0, "lrcosine": True, "warmup": 1}
     assert learning_rate(c, 500, 1, n_batches=1000) == pytest.approx(math.cos(math.pi / 4))
     assert learning_rate(f, 200, 1, base=0.02) == pytest.approx(0.02 * 0.5 ** 0.2)
+
+
+def test_criterion_kind_and_odd_transitions(tmp_path):
+    """a CTC checkpoint is rejected by an ASG trainer (and the reverse); odd N: the transitions are saved as exactly
+    (N, N) although the arena slot is padded"""
+    from wav2letter_amd import checkpoint
+    arch, tr = _trainer("asg", nlabel=11)
+    path = str(tmp_path / "a.w2l")
+    checkpoint.save(path, tr, arch, "asg")
+    header, arrays = checkpoint.read(path)
+    t = [t for t in header["tensors"] if t["kind"] == "criterion"][0]
+    assert t["shape"] == [11, 11] and t["numel"] == 121
+    arch2, tr2 = _trainer("asg", nlabel=11)
+    tr2.init_params(seed=5)
+    checkpoint.load(path, tr2, arch2)
+    assert np.array_equal(tr2.host_params[:tr2.n_net + 121], tr.host_params[:tr.n_net + 121])
+    _, trc = _trainer("ctc", nlabel=11)
+    with pytest.raises(ValueError):
+        checkpoint.load(path, trc, arch)
+    pathc = str(tmp_path / "c.w2l")
+    checkpoint.save(pathc, trc, arch, "ctc")
+    with pytest.raises(ValueError):
+        checkpoint.load(pathc, tr2, arch)

@@ -48,3 +48,14 @@ def test_batches_by_length_and_duration_cap():
     for b in capped:
         assert max(dur[i] for i in b) * len(b) <= 9000 or len(b) == 1
     assert sorted(i for b in capped for i in b) == idx
+
+
+@pytest.mark.parametrize("n,world,bs", [(70, 8, 4), (67, 4, 8), (5, 2, 4), (3, 8, 4), (0, 2, 4), (33, 1, 32), (71, 8, 4)])
+def test_partition_round_robin_allow_empty_covers_every_sample(n, world, bs):
+    """validation sets (allowEmpty = true in the reference): the union over ranks is range(n), disjoint, and the
+    first rest % world ranks carry the extra sample of the tail batch (fl::partitionByRoundRobin)"""
+    parts = [data.partition_round_robin(n, r, world, bs, allow_empty=True) for r in range(world)]
+    flat = sorted(i for p in parts for i in p)
+    assert flat == list(range(n))
+    sizes = [len(p) for p in parts]
+    assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)

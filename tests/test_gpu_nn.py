@@ -17,6 +17,14 @@ def dev(a):
     return torch.as_tensor(np.ascontiguousarray(a)).cuda()
 
 
+@pytest.fixture
+def probe():
+    """kernel-variant tests run on libw2l_hip_probe.so: the only build that reads the W2L_* switches"""
+    from wav2letter_amd import _lib
+    with _lib.use_probe() as L:
+        yield L
+
+
 def rel(got, want):
     want = np.asarray(want, np.float64)
     got = np.asarray(got.detach().cpu().numpy() if torch.is_tensor(got) else got, np.float64)
@@ -91,7 +99,7 @@ def test_gemm_stream_k_schedule(M, N, K, akc, bkc):
                                     (260, 388, 2030),      # K % 32 = 14: whole K tiles + register-staged tail, accumulated
                                     (188, 9998, 1440)])    # final fl::Linear of the TDS-CTC recipe (one batch row block)
 @pytest.mark.parametrize("akc,bkc", [(True, False), (True, True), (False, False), (False, True)])
-def test_gemm_lds_dma_path(M, N, K, akc, bkc):
+def test_gemm_lds_dma_path(M, N, K, akc, bkc, probe):
     """the persistent LDS-DMA kernel (K % 32 == 0, 16-byte aligned operands) against a float64 product
     and against the register-staged kernel (W2L_GEMM_GLDS=0) on the same inputs; deterministic"""
     import os
@@ -122,7 +130,7 @@ def test_gemm_lds_dma_path(M, N, K, akc, bkc):
 @pytest.mark.parametrize("M,N,K", [(4, 4, 32), (260, 388, 96), (1028, 2052, 1440), (6016, 4320, 1440), (640, 136, 24000),
                                     (24000, 800, 2400)])
 @pytest.mark.parametrize("akc,bkc", [(True, False), (True, True), (False, False), (False, True)])
-def test_gemm_three_stage_256x128(M, N, K, akc, bkc):
+def test_gemm_three_stage_256x128(M, N, K, akc, bkc, probe):
     """the 256x128 three-stage kernel (counted vmcnt, raw barriers) forced on every eligible shape
     (W2L_GEMM_P3=2): float64 product, determinism, bias + ReLU, and agreement with the 128x128 kernel"""
     import os
@@ -178,7 +186,7 @@ def test_fused_epilogue_variants_equal_the_unfused_ops(M, K, N):
 
 
 @pytest.mark.parametrize("M,N,K", [(6016, 1440, 416), (1500, 700, 4096), (24000, 800, 2400), (800, 2400, 24000)])
-def test_gemm_in_kernel_slab_reduction_is_stable(M, N, K):
+def test_gemm_in_kernel_slab_reduction_is_stable(M, N, K, probe):
     """stream-K partial tiles reduced inside the GEMM launch (arrival tickets + agent-scope release/acquire):
     bit-identical to the separate fix-up launch (W2L_GEMM_INFIX=0) and to itself over many launches under load"""
     import os
@@ -205,7 +213,7 @@ def test_gemm_in_kernel_slab_reduction_is_stable(M, N, K):
 @pytest.mark.parametrize("M,N,K", [(4, 4, 32), (260, 388, 96), (1028, 2052, 1440), (6016, 4320, 1440), (640, 136, 24000),
                                     (24000, 2400, 800)])
 @pytest.mark.parametrize("akc,bkc", [(True, False), (True, True), (False, False), (False, True)])
-def test_gemm_loader_wave_variant(M, N, K, akc, bkc):
+def test_gemm_loader_wave_variant(M, N, K, akc, bkc, probe):
     """the loader-wave kernel (a fifth wave issues every LDS-DMA piece; compute waves never wait on vmcnt in the K loop):
     bit-identical to the four-wave kernel (same fragments, same k order, same epilogue), deterministic, float64 parity"""
     import os
@@ -241,7 +249,7 @@ def test_gemm_loader_wave_variant(M, N, K, akc, bkc):
                                     (320, 160, 64)])       # exactly two / one 160-tiles, two K steps
 @pytest.mark.parametrize("akc,bkc", [(True, False), (True, True), (False, False), (False, True)])
 @pytest.mark.parametrize("mode", ["2", "3"])
-def test_gemm_160_wide_tiles(M, N, K, akc, bkc, mode):
+def test_gemm_160_wide_tiles(M, N, K, akc, bkc, mode, probe):
     """the 128x160 (W2L_GEMM_T160=2 forces it) and 160x128 (=3) tile kernels on every eligible shape: float64 product,
     run-to-run bit-identity (in-kernel stream-K slab reduction), bias + ReLU, agreement with the 128x128 kernel"""
     import os
@@ -269,7 +277,7 @@ def test_gemm_160_wide_tiles(M, N, K, akc, bkc, mode):
 
 
 @pytest.mark.parametrize("mode", ["2", "3"])
-def test_gemm_160_fused_epilogues(mode):
+def test_gemm_160_fused_epilogues(mode, probe):
     """dropout / mask / addend epilogues of the fl::Linear calls through the 160-wide kernels equal the 128x128 kernel's"""
     import os
     from wav2letter_amd import ops
@@ -430,7 +438,7 @@ def test_conv_backward_data_accumulate_and_add(oracle, B, Cin, Cout, H, T, kw, s
 
 
 @pytest.mark.parametrize("B,Cin,Cout,T,kw,padl,padr", [(2, 40, 100, 60, 13, 0, 0), (2, 321, 706, 64, 19, 0, 0), (2, 40, 400, 90, 13, 170, 170)])
-def test_conv_glu_overlapping_rows_equals_implicit_gemm(B, Cin, Cout, T, kw, padl, padr):
+def test_conv_glu_overlapping_rows_equals_implicit_gemm(B, Cin, Cout, T, kw, padl, padr, probe):
     """the overlapping-row LDS-DMA convolution against the register-staged implicit-GEMM kernels (W2L_CONV_GLDS=0) on
     the same inputs: forward (+bias, ReLU), backward-data, backward-filter, bias gradient; run-to-run identical"""
     import os
@@ -639,3 +647,32 @@ def test_mfsc_features_on_device(oracle, B, ns, F, power):
     want = np.stack([oracle.mfsc(audio[b], F, use_power=power).T for b in range(B)])
     assert np.abs(got.cpu().numpy() - want).max() < 1e-4 * np.abs(want).max()
     assert torch.equal(got, fe(dev(audio)))
+
+
+def test_product_library_ignores_kernel_variant_switches():
+    """round-1 verdict / advisor: an inherited W2L_* variable must not change (let alone corrupt) training.  The shipped
+    libw2l_hip.so never reads the environment: with the garbage-producing ablation switches set, results stay exact;
+    the probe build (libw2l_hip_probe.so) is the only one that honours them"""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import os, torch, numpy as np\n"
+        "from wav2letter_amd import ops\n"
+        "g = torch.Generator(device='cpu').manual_seed(1)\n"
+        "A = torch.randn(512, 256, generator=g); B = torch.randn(256, 384, generator=g)\n"
+        "got = ops.gemm(A.cuda(), B.cuda(), True, False).cpu().double()\n"
+        "want = A.double() @ B.double()\n"
+        "print('REL', float((got - want).abs().max() / want.abs().max()))\n")
+    env = dict(os.environ, W2L_GEMM_ABL="1", W2L_GEMM_ABLBUF="1", W2L_FCC_ABL="1", W2L_TDS_ABL="7", W2L_GEMM_GLDS="0",
+               W2L_GEMM_P3="2", W2L_GEMM_LOADER="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rel_ = float([l for l in out.stdout.splitlines() if l.startswith("REL")][0].split()[1])
+    assert rel_ < TOL
+    # and the product library does not even contain the ablation / experimental kernels
+    so = os.path.join(root, "wav2letter_amd", "libw2l_hip.so")
+    blob = open(so, "rb").read()
+    assert b"gemm256_kernel" not in blob and b"gemm128w_kernel" not in blob
+    assert b"W2L_GEMM_ABL" not in blob and b"W2L_FCC_ABL" not in blob

@@ -281,6 +281,108 @@ def test_non_finite_gradient_skips_the_update():
     assert math.isfinite(tr.grad_norm()) and not torch.equal(tr.params, p0)
 
 
+@pytest.mark.parametrize("crit,clamp_crit", [("ctc", True), ("asg", False)])
+def test_non_finite_guard_without_clipping(crit, clamp_crit):
+    """--maxgradnorm=0 (the reference default) and clampCrit = 0: the guard must still hold -- a NaN in the network OR in
+    the criterion gradients leaves parameters and momentum of BOTH untouched, the skipped-update counter ticks, the
+    next clean update goes through (round-1 advisor finding, trainer.cpp:205)"""
+    import math
+    from wav2letter_amd import recipes
+    from wav2letter_amd.trainer import Trainer
+    rng = np.random.default_rng(10)
+    nfeat, nlabel, B, T, L = 8, 12, 2, 48, 4
+    tr = Trainer(recipes.tds_ctc_small_arch(c=(4,), h=nfeat, kw=5), nfeat, nlabel, crit, 4, 1.0)
+    tr.init_params(3)
+    tr.plan(B, T, L)
+    tr.to_device()
+    x = torch.tensor(rng.normal(size=(B, nfeat, T)).astype(np.float32)).cuda()
+    tgt = torch.tensor(rng.integers(0, nlabel - 1, size=(B, L)).astype(np.int32)).cuda()
+    kw = dict(lr=0.1, lrcrit=0.01, momentum=0.5, max_grad_norm=0.0, total_batch=B, clamp_crit=clamp_crit)
+    tr.forward_backward(x, tgt)
+    tr.update(**kw)
+    assert math.isfinite(tr.grad_norm()) and tr.grad_norm() > 0 and tr.skipped_updates() == 0
+    bad = [tr.n_net // 2] + ([tr.n_net + 5] if crit == "asg" else [])
+    for k, where in enumerate(bad):
+        p0, m0 = tr.params.clone(), tr.mom.clone()
+        tr.forward_backward(x, tgt)
+        tr.grads[where] = float("inf") if k else float("nan")
+        tr.update(**kw)
+        assert not math.isfinite(tr.grad_norm())
+        assert torch.equal(tr.params, p0) and torch.equal(tr.mom, m0)
+        assert tr.skipped_updates() == k + 1
+    tr.forward_backward(x, tgt)
+    tr.update(**kw)
+    assert math.isfinite(tr.grad_norm()) and not torch.equal(tr.params, p0)
+    assert tr.skipped_updates() == len(bad)
+
+
+def test_unclipped_update_is_plain_sgd_and_batch_size_rides_the_arena():
+    """max_grad_norm = 0: p -= lr * (mom*v + g / total_batch) exactly; total_batch = "reduced" takes 1 / (the batch
+    size in the gradient arena's tail) -- written by forward_backward, summed by the gradient all-reduce"""
+    from wav2letter_amd import recipes
+    from wav2letter_amd.trainer import Trainer
+    rng = np.random.default_rng(11)
+    nfeat, nlabel, B, T, L = 8, 12, 3, 40, 4
+    x = torch.tensor(rng.normal(size=(B, nfeat, T)).astype(np.float32)).cuda()
+    tgt = torch.tensor(rng.integers(0, nlabel - 1, size=(B, L)).astype(np.int32)).cuda()
+    outs = []
+    for tb in (B, "reduced"):
+        tr = Trainer(recipes.tds_ctc_small_arch(c=(4,), h=nfeat, kw=5), nfeat, nlabel, "ctc", 4)
+        tr.init_params(3)
+        tr.plan(B, T, L)
+        tr.to_device()
+        p0 = tr.params.clone()
+        tr.forward_backward(x, tgt)
+        assert tr.grads_full[tr.n_floats].item() == B and (tr.grads_full[tr.n_floats + 1:] == 0).all()
+        g = tr.grads.clone()
+        tr.update(lr=0.1, momentum=0.0, max_grad_norm=0.0, total_batch=tb)
+        want = p0.double() - 0.1 * g.double() / B
+        assert (tr.params.double() - want).abs().max().item() < 1e-6 * max(1.0, want.abs().max().item())
+        outs.append(tr.params.clone())
+    assert torch.equal(outs[0], outs[1])
+    # a world of 2 identical ranks: gradients and the batch slot both double, the update is unchanged
+    tr.params.copy_(p0)
+    tr.forward_backward(x, tgt)
+    tr.grads_full.mul_(2.0)
+    tr.update(lr=0.1, momentum=0.0, max_grad_norm=0.0, total_batch="reduced")
+    assert (tr.params - outs[0]).abs().max().item() < 1e-6
+
+
+def test_batch_larger_than_64_and_unbound_calls():
+    """B > 64 (round-1 limit of the loss slots) and the ABI's bound-state checks"""
+    from wav2letter_amd import _lib, recipes
+    from wav2letter_amd.trainer import Trainer
+    rng = np.random.default_rng(12)
+    nfeat, nlabel, B, T, L = 8, 12, 70, 32, 4
+    arch = recipes.tds_ctc_small_arch(c=(4,), h=nfeat, kw=5)
+    x = torch.tensor(rng.normal(size=(B, nfeat, T)).astype(np.float32)).cuda()
+    tgt = torch.tensor(rng.integers(0, nlabel - 1, size=(B, L)).astype(np.int32)).cuda()
+    tr = Trainer(arch, nfeat, nlabel, "ctc", 4)
+    tr.init_params(3)
+    tr.plan(B, T, L)
+    tr.to_device()
+    loss = tr.forward_backward(x, tgt)
+    assert loss.shape == (B,) and torch.isfinite(loss).all()
+    # the same utterances in two half batches give the same losses and the same summed gradient
+    g = tr.grads.clone()
+    h = Trainer(arch, nfeat, nlabel, "ctc", 4)
+    h.init_params(3)
+    h.plan(B // 2, T, L)
+    h.to_device()
+    l0 = h.forward_backward(x[:B // 2].contiguous(), tgt[:B // 2].contiguous()).clone()
+    g0 = h.grads.clone()
+    l1 = h.forward_backward(x[B // 2:].contiguous(), tgt[B // 2:].contiguous()).clone()
+    assert (torch.cat([l0, l1]) - loss).abs().max().item() < 1e-4 * loss.abs().max().item()
+    assert (g0 + h.grads - g).abs().max().item() < 1e-4 * g.abs().max().item()
+    with pytest.raises(_lib.W2LInvalidArgument):
+        tr.forward_backward(x[:, :, :T - 1], tgt)            # wrong shape
+    with pytest.raises(_lib.W2LInvalidArgument):
+        tr.forward_backward(x, tgt.long())                   # wrong dtype
+    u = Trainer(arch, nfeat, nlabel, "ctc", 4)               # never planned / bound
+    assert u.L.w2l_trainer_update(u.h, 0.1, 0.0, 0.0, 0.0, 1.0, 1, None) == _lib.W2L_EINVAL
+    assert u.L.w2l_trainer_forward_backward(u.h, x.data_ptr(), tgt.data_ptr(), None, None) == _lib.W2L_EINVAL
+
+
 def test_training_reduces_loss():
     """a few SGD steps on a fixed batch must drive the CTC loss down (plumbing sanity)"""
     from wav2letter_amd import recipes
@@ -334,7 +436,7 @@ def test_gradient_bucket_events_and_single_rank_rccl():
     try:
         tr = make()
         red = OverlappedReducer(tr, n_buckets=3)
-        assert red.offsets[0] == 0 and red.offsets[-1] == tr.n_floats and len(red.offsets) >= 3
+        assert red.offsets[0] == 0 and red.offsets[-1] == tr.n_floats + 4 and len(red.offsets) >= 3
         for _ in range(2):  # events are re-recorded every step
             tr.set_step(0)
             tr.grads.zero_()
@@ -376,9 +478,31 @@ def test_checkpoint_resume_reproduces_the_next_step(tmp_path):
     checkpoint.save(path, a, arch, "ctc", step=2)
     b = make(77)
     assert checkpoint.load(path, b, arch) == 2
+    # the natural resume order -- load() BEFORE to_device() -- must restore the momentum too
+    c = Trainer(arch, nfeat, nlabel, "ctc", 4)
+    assert checkpoint.load(path, c, arch) == 2
+    c.plan(B, T, L)
+    c.to_device()
+    assert torch.equal(c.mom, a.mom) and torch.equal(c.params, a.params)
     la = a.forward_backward(x, tgt).clone()
     a.update(lr=0.05, momentum=0.9, max_grad_norm=1.0)
     lb = b.forward_backward(x, tgt).clone()
     b.update(lr=0.05, momentum=0.9, max_grad_norm=1.0)
     assert torch.equal(la, lb)                  # same dropout masks: the step counter was restored
     assert torch.equal(a.params, b.params)      # same momentum
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """on a 1-GPU box `python bench.py --gpus 2` must fail loudly, not silently run one rank (round-1 verdict, missing 1)"""
+    import os
+    import subprocess
+    import sys
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("more than one GPU visible")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert "needs 2 visible GPUs" in out.stderr
+    assert not any(l.startswith("{") for l in out.stdout.splitlines())

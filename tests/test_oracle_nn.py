@@ -256,3 +256,29 @@ def test_specaugment_oracle_properties(oracle, T, F, args):
     assert len(outs) > 10
     with pytest.raises(ValueError):
         oracle.specaugment(x[:, :, :4], 27, 2, 100, 1.0, 2, 1)
+
+
+def test_torch_cpu_proxy_matches_reference_interpreter(oracle):
+    """oracle/torchnet.py (the torch-CPU proxy timed as bench.py's cpu_baseline) computes the same network as
+    oracle/refnet.RefNet: emissions and parameter gradients on a reduced TDS-CTC of the recipe's topology"""
+    from oracle import torchnet
+    from wav2letter_amd import recipes
+    arch = recipes.tds_ctc_small_arch(c=(4, 6), h=8, kw=5)
+    nfeat, nlabel, B, T = 8, 12, 2, 40
+    rng = np.random.default_rng(3)
+    ref = refnet.RefNet(arch, nfeat, nlabel)
+    params = ref.random_params(rng)
+    x = rng.normal(size=(B, 1, nfeat, T)).astype(np.float32)
+    em = ref.forward(x, params)
+    tp = [torch.from_numpy(p.copy()).requires_grad_(True) for p in params]
+    tem = torchnet.TorchNet(arch, nfeat, nlabel).forward(torch.from_numpy(x), tp)
+    assert tem.shape == em.shape
+    assert np.abs(tem.detach().numpy() - em).max() < 1e-4 * np.abs(em).max()
+    d = rng.normal(size=em.shape).astype(np.float32)
+    g = ref.backward(d, len(params))
+    tem.backward(torch.from_numpy(d))
+    for a, b in zip(tp, g):
+        b = np.asarray(b, np.float64)
+        assert np.abs(a.grad.numpy() - b).max() < 2e-4 * max(1e-6, np.abs(b).max())
+    med, times = torchnet.tds_ctc_step_seconds(arch, nfeat, nlabel, B, T, L=4, warmup=1, runs=2)
+    assert med > 0 and len(times) == 2

@@ -24,23 +24,51 @@ class W2LInvalidArgument(W2LError, ValueError):
     """mirrors the std::invalid_argument Flashlight's criteria throw"""
 
 
+def _load(path):
+    if not os.path.exists(path):
+        raise W2LError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C wav2letter_amd/csrc` (no CPU fallback exists)")
+    L = C.CDLL(path)
+    L.w2l_version.restype = C.c_char_p
+    for name in dir(_SIGS):
+        if name.startswith("w2l_"):
+            fn = getattr(L, name)
+            restype, argtypes = getattr(_SIGS, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+    return L
+
+
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(SO_PATH):
-            raise W2LError(
-                f"{SO_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "or `make -C wav2letter_amd/csrc` (no CPU fallback exists)")
         # W2L_LIB_PATH: load another build of the same library (A/B runs of two kernel generations, tools/ only)
-        _lib = C.CDLL(os.environ.get("W2L_LIB_PATH") or SO_PATH)
-        _lib.w2l_version.restype = C.c_char_p
-        for name in dir(_SIGS):
-            if name.startswith("w2l_"):
-                fn = getattr(_lib, name)
-                restype, argtypes = getattr(_SIGS, name)
-                fn.restype = restype
-                fn.argtypes = argtypes
+        _lib = _load(os.environ.get("W2L_LIB_PATH") or SO_PATH)
     return _lib
+
+
+PROBE_SO_PATH = os.path.join(_HERE, "libw2l_hip_probe.so")
+_probe = None
+
+
+class use_probe:
+    """context manager: route every call of this package through libw2l_hip_probe.so (built with -DW2L_PROBE: the only
+    build that honours the W2L_* kernel-variant switches and carries the ablation / experimental kernels).  For tools/
+    and the kernel-variant tests; the product library ignores those environment variables."""
+
+    def __enter__(self):
+        global _lib, _probe
+        if _probe is None:
+            _probe = _load(PROBE_SO_PATH)
+        self._saved = lib()
+        _lib = _probe
+        return _probe
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._saved
+        return False
 
 
 _p, _i, _sz, _f, _u32, _u64, _d = C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_uint32, C.c_uint64, C.c_double
@@ -100,6 +128,8 @@ class _SIGS:
     w2l_profile_enable = (_i, [_i])
     w2l_profile_report_kind = (_i, [_i, _p, _p, _p])
     w2l_sgd_step = (_i, [_p, _p, _p, _sz, _f, _f, _f, _f, _p, _p])
+    w2l_sgd_step_guarded = (_i, [_p, _p, _p, _sz, _f, _f, _f, _f, _p, _p])
+    w2l_grad_guard = (_i, [_p, _p, _i, _p])
 
 
 class ConvDesc(C.Structure):

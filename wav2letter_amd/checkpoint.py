@@ -41,10 +41,12 @@ def save(path, trainer, arch_text, criterion, step=0, flags=None, momentum=True)
         blobs.append(np.ascontiguousarray(ref, np.float32))
     ncrit = trainer.n_floats - trainer.n_net
     if ncrit:
-        n = int(round(math.sqrt(ncrit)))
-        shape = [n, n] if n * n == ncrit else [int(ncrit)]
-        tensors.append({"name": "criterion.transitions", "kind": "criterion", "numel": int(ncrit), "shape": shape})
-        blobs.append(np.ascontiguousarray(host[trainer.n_net:trainer.n_floats], np.float32))
+        # ASG transitions: exactly N*N floats, (N, N) [to][from] (the arena slot may be padded to a multiple of 4)
+        n = trainer.nlabel
+        nn = n * n if criterion == "asg" and n * n <= ncrit else int(ncrit)
+        shape = [n, n] if nn == n * n else [nn]
+        tensors.append({"name": "criterion.transitions", "kind": "criterion", "numel": nn, "shape": shape})
+        blobs.append(np.ascontiguousarray(host[trainer.n_net:trainer.n_net + nn], np.float32))
     if momentum and trainer.mom is not None:
         tensors.append({"name": "netoptim.momentum(internal arena)", "kind": "momentum", "numel": int(trainer.n_floats),
                         "shape": [int(trainer.n_floats)]})
@@ -92,6 +94,9 @@ def load(path, trainer, arch_text=None):
         raise ValueError("checkpoint was written for a different NFEAT / NLABEL")
     if arch_text is not None and hashlib.sha256(arch_text.encode()).hexdigest() != header["arch_sha256"]:
         raise ValueError("checkpoint was written for a different architecture file")
+    want = getattr(trainer, "criterion", None)
+    if want is not None and header.get("criterion") not in (None, want):
+        raise ValueError(f"checkpoint was written for criterion {header['criterion']!r}, this trainer runs {want!r}")
     table = trainer.param_table()
     net = [(t, a) for t, a in zip(header["tensors"], arrays) if t["kind"] == "network"]
     if len(net) != len(table) or any(t["numel"] != row[1] for (t, _), row in zip(net, table)):
@@ -100,14 +105,20 @@ def load(path, trainer, arch_text=None):
         trainer.import_param(i, a)
     for t, a in zip(header["tensors"], arrays):
         if t["kind"] == "criterion":
-            if t["numel"] != trainer.n_floats - trainer.n_net:
+            if t["numel"] > trainer.n_floats - trainer.n_net or t["numel"] + 3 < trainer.n_floats - trainer.n_net:
                 raise ValueError("criterion parameters do not match")
-            trainer.host_params[trainer.n_net:trainer.n_floats] = a
+            trainer.host_params[trainer.n_net:trainer.n_net + t["numel"]] = a
+    if (trainer.n_floats > trainer.n_net) != any(t["kind"] == "criterion" for t in header["tensors"]):
+        raise ValueError("criterion parameters do not match (one side has transitions, the other has none)")
     mom = [a for t, a in zip(header["tensors"], arrays) if t["kind"] == "momentum"]
+    if mom and mom[0].size != trainer.n_floats:
+        raise ValueError("momentum arena does not match this trainer")
     if trainer.params is not None:
         trainer.params.copy_(torch.from_numpy(trainer.host_params))
-        if mom and trainer.mom is not None and mom[0].size == trainer.n_floats:
+        if mom:
             trainer.mom.copy_(torch.from_numpy(mom[0]))
+    elif mom:
+        trainer._pending_mom = mom[0]   # applied by Trainer.to_device() (load() before to_device() is the natural order)
     trainer.set_step(header["step"])
     return header["step"]
 

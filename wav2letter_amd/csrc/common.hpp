@@ -1,6 +1,7 @@
 // common.hpp -- shared device/host helpers for libw2l_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include <math.h>
 
@@ -138,6 +139,15 @@ __device__ __forceinline__ double lane_shift_down(double v, double fill) {
   double r = __shfl_down(v, 1);
   return lane_id() == 63 ? fill : r;
 }
+
+// ---- kernel-variant switches (A/B work, ablations): the PRODUCT library never reads the environment -- an
+// inherited variable must not be able to change (let alone corrupt) training.  Only the probe build
+// (-DW2L_PROBE -> libw2l_hip_probe.so, loaded by tools/ and by the variant tests) honours W2L_* variables.
+#ifdef W2L_PROBE
+inline const char* tune_env(const char* name) { return std::getenv(name); }
+#else
+inline const char* tune_env(const char*) { return nullptr; }
+#endif
 
 // ---- stateless dropout hash: must stay bit-identical to oracle/nn_oracle.c --
 __host__ __device__ inline uint32_t hash32(uint32_t idx, uint32_t seed, uint32_t stream) {

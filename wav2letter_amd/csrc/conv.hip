@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void pad_frames_k(const float* __restrict__ sr
 }
 
 static bool glds_conv_enabled() {
-  const char* e = getenv("W2L_CONV_GLDS");
+  const char* e = tune_env("W2L_CONV_GLDS");
   return !(e && e[0] == '0');
 }
 static bool glds_conv_applicable(const w2l_conv_desc* d) {
@@ -469,7 +469,7 @@ static int glds_conv_backward_filter(const w2l_conv_desc* d, const float* x, con
 }
 
 static bool tds_path() {
-  const char* e = getenv("W2L_CONV_TDS");
+  const char* e = tune_env("W2L_CONV_TDS");
   return !(e && e[0] == '0');
 }
 

@@ -794,6 +794,9 @@ __global__ __launch_bounds__(256) void tds_conv_filter_reduce_k(const float* __r
 }
 
 float* sk_scratch(hipStream_t s, size_t bytes);
+// conv_tds_rs.hip: role-swapped 32x32x2 kernel for the TDS convolutions proper (C -> C, stride 1)
+bool tds_rs_try(const float* x, const float* w, const float* bias, const float* add, float* y, int B, int Tin, int Tout, int H,
+                int C, int kw, int padl, int relu, int accum, int flip, int profKind, hipStream_t s, int* status);
 
 static inline int tds_out_len(int T, int kw, int stride, int padl, int padr) {
   int n = T + padl + padr - kw;
@@ -847,10 +850,9 @@ static int launch_fwd2_t(const TdsConvP& p, size_t shmem, hipStream_t s) {
 }
 
 // persistent register-prefetching kernel when the geometry allows it; `pIn` was built for 32-frame tiles
-static bool try_launch_fwd2(const TdsConvP& pIn0, hipStream_t s, int* status) {
-  if (getenv("W2L_TDS_FWD_V1")) return false;
+static bool try_launch_fwd2(const TdsConvP& pIn0, hipStream_t s, int* status, int profKind = PROF_TDSCONV) {
   TdsConvP pIn = pIn0;
-  { const char* e = getenv("W2L_TDS_ABL"); pIn.abl = e ? atoi(e) : 0; }
+  pIn.abl = 0;
   if (pIn.H % kTdsBH || ((pIn.H * pIn.Cin) & 3) || ((pIn.H * pIn.Cout) & 3) || ((kTdsBH * pIn.Cin) & 3) || ((kTdsBH * pIn.Cout) & 3)) return false;
   if ((((uintptr_t)pIn.x | (uintptr_t)pIn.y | (uintptr_t)pIn.add) & 15) != 0) return false;
   for (int bt = 32; bt >= 16; bt >>= 1) {
@@ -860,7 +862,7 @@ static bool try_launch_fwd2(const TdsConvP& pIn0, hipStream_t s, int* status) {
     const size_t shmem = fwd2_lds_bytes(p, bt);
     if (pieces > kTdsMaxXV || 2 * shmem > 160 * 1024) continue;  // two workgroups per CU or nothing
     const double flops = 2.0 * p.B * p.Tout * (double)p.H * p.K * p.Cout;
-    prof_begin(s, flops, PROF_TDSCONV);
+    prof_begin(s, flops, profKind);
     int st;
     const int cin = p.stride == 1 ? p.Cin : 0;  // compile-time channel counts of the TDS-CTC recipe; anything else: runtime stride
     if (p.Cout <= 16) {
@@ -880,14 +882,18 @@ static bool try_launch_fwd2(const TdsConvP& pIn0, hipStream_t s, int* status) {
   return false;
 }
 
-static int launch_fwd(const TdsConvP& p, hipStream_t s) {
+static int launch_fwd(const TdsConvP& p, hipStream_t s, int profKind = PROF_TDSCONV) {
   int st2 = W2L_OK;
-  if (try_launch_fwd2(p, s, &st2)) return st2;
+  // the TDS convolutions proper: role-swapped 32x32x2 kernel (conv_tds_rs.hip)
+  if (p.stride == 1 && p.Cin == p.Cout && p.tapStep == 1 && p.oStep == 1 &&
+      tds_rs_try(p.x, p.w, p.bias, p.add, p.y, p.B, p.Tin, p.Tout, p.H, p.Cin, p.kw, p.padl, p.relu, p.accum, p.flip, profKind, s, &st2))
+    return st2;
+  if (try_launch_fwd2(p, s, &st2, profKind)) return st2;
   const size_t shmem = fwd_lds_bytes(p);
   if (shmem > 160 * 1024) return W2L_EUNSUPPORTED;
   dim3 grid((unsigned)((p.H + kTdsBH - 1) / kTdsBH), (unsigned)((p.Tout + kTdsBT - 1) / kTdsBT), (unsigned)p.B);
   const double flops = 2.0 * p.B * p.Tout * (double)p.H * p.K * p.Cout;
-  prof_begin(s, flops, PROF_TDSCONV);
+  prof_begin(s, flops, profKind);
   if (p.Cout <= 16) {
     if (shmem > 64 * 1024) W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_fwd_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL(tds_conv_fwd_k<1>, grid, dim3(256), shmem, s, p);
@@ -920,10 +926,10 @@ int tds_conv_backward_data(const w2l_conv_desc* d, const float* dy, const float*
     TdsConvP p = make_p(d->B, To, d->T, d->H, d->Cout, d->Cin, d->kw, 1, d->kw - 1 - d->padl, kTdsBT);
     p.x = dy; p.w = w; p.y = dx; p.accum = accumulate; p.add = add; p.flip = 1;
     p.CinW = d->Cin; p.CoutW = d->Cout;
-    return launch_fwd(p, s);
+    return launch_fwd(p, s, PROF_TDS_BWD_DATA);
   }
   const int st = d->stride;
-  if (st > d->kw || getenv("W2L_TDS_BWD_STRIDED_OFF")) return W2L_EUNSUPPORTED;  // every phase needs at least one tap
+  if (st > d->kw) return W2L_EUNSUPPORTED;  // every phase needs at least one tap
   for (int f = 0; f < st; ++f) {
     const int kwf = (d->kw - f + st - 1) / st;
     const int c0 = (((f - d->padl) % st) + st) % st;   // first input frame of the phase
@@ -935,7 +941,7 @@ int tds_conv_backward_data(const w2l_conv_desc* d, const float* dy, const float*
     p.CinW = d->Cin; p.CoutW = d->Cout;
     p.tapOff = f; p.tapStep = st; p.oOff = c0; p.oStep = st; p.ToutFull = d->T;
     int st2 = W2L_OK;
-    if (!try_launch_fwd2(p, s, &st2)) return f == 0 ? W2L_EUNSUPPORTED : W2L_EHIP;  // geometry is the same for every phase
+    if (!try_launch_fwd2(p, s, &st2, PROF_TDS_BWD_DATA)) return f == 0 ? W2L_EUNSUPPORTED : W2L_EHIP;  // geometry is the same for every phase
     if (st2 != W2L_OK) return st2;
   }
   return W2L_OK;
@@ -963,8 +969,8 @@ int tds_conv_backward_filter(const w2l_conv_desc* d, const float* x, const float
   const int xPieces = (p.NF * ((kTdsBH * p.Cin) >> 2) + 255) / 256, dPieces = (kTdsBTF * ((kTdsBH * p.Cout) >> 2) + 255) / 256;
   const bool fast = d->H % kTdsBH == 0 && (d->H * d->Cin) % 4 == 0 && (d->H * d->Cout) % 4 == 0 && (kTdsBH * d->Cin) % 4 == 0 &&
                     (kTdsBH * d->Cout) % 4 == 0 && xPieces <= kTdsMaxXV && dPieces <= kTdsMaxDV &&
-                    (((uintptr_t)x | (uintptr_t)dy) & 15) == 0 && !getenv("W2L_TDS_FILTER_V1");
-  prof_begin(s, flops, PROF_TDSCONV);
+                    (((uintptr_t)x | (uintptr_t)dy) & 15) == 0 && !tune_env("W2L_TDS_FILTER_V1");
+  prof_begin(s, flops, PROF_TDS_BWD_FILTER);
   if (fast) {
 #define W2L_FILTER2(NTv, Cv)                                                                                                    \
   do {                                                                                                                          \
@@ -975,7 +981,7 @@ int tds_conv_backward_filter(const w2l_conv_desc* d, const float* x, const float
                        tBlocks, hBlocks, rowTiles);                                                                             \
   } while (0)
     // lean K loop for the TDS convolutions proper (C -> C, stride 1, 3..6 row tiles per wave)
-    const int cc = (d->Cin == d->Cout && d->stride == 1 && rowTiles >= 12 && !getenv("W2L_TDS_FILTER_GENERIC")) ? d->Cin : 0;
+    const int cc = (d->Cin == d->Cout && d->stride == 1 && rowTiles >= 12 && !tune_env("W2L_TDS_FILTER_GENERIC")) ? d->Cin : 0;
     if (NT == 1) {
       if (cc == 10) W2L_FILTER2(1, 10);
       else if (cc == 14) W2L_FILTER2(1, 14);

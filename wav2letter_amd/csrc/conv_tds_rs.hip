@@ -1,0 +1,251 @@
+// conv_tds_rs.hip -- the TDS time convolution proper (fl::TDSBlock's Conv2D kw x 1, C -> C channels with
+// C = 10 / 14 / 18, kw = 21, stride 1, H = 80 mel rows; recipes/sota/2019/am_arch/am_tds_ctc.arch:3-37,
+// builder recipes/joint_training_vox_populi/cpc/SequentialBuilder.cpp:254-268) forward and backward-data in the
+// ROLE-SWAPPED formulation SURVEY 7 hard-part 3(b) names.
+//
+// Why: with N = C_out on the MFMA columns (conv_tds.hip) 10 / 14 / 18 columns sit in 16 / 16 / 32-wide tiles --
+// a 62.5 / 87.5 / 56 % ceiling before the first instruction is issued -- and every 32-cycle 16x16x4 MFMA needs its
+// own LDS fragment read: the loop ran issue-bound at 34 % of the fp32 MFMA peak (round-1 verdict, weak 4).
+//
+// Here the kw taps are cut into G groups of J consecutive taps and the GROUP index joins the output channel on
+// the MFMA column axis:
+//     Y[tau][(g, co)] = sum_{j < J, ci}  X[tau + j][ci] * W[g*J + j][ci][co]          (one 32x32x2 MFMA chain)
+//     out[u][co]      = sum_{g < G}      Y[u + g*J][(g, co)]                          (overlap-add through LDS)
+// rows tau = 32 consecutive FRAMES of one (utterance, mel row), K = (j, ci) = J*C, columns (g, co) = G*C:
+//     C = 10: G = 3, J = 7 :  30 of  32 columns, K =  70 (35 MFMAs per 32x32 tile)            93.8 % of the lanes useful
+//     C = 14: G = 11, J = 2: 154 of 160 columns, K =  28 (5 column tiles x 14 MFMAs), 21/22 taps    91.9 %
+//     C = 18: G = 7, J = 3 : 126 of 128 columns, K =  54 (4 column tiles x 27 MFMAs)                98.4 %
+// v_mfma_f32_32x32x2_f32 issues every 64 cycles (twice the 16x16x4 budget per instruction) and
+//   * the B operand (the weights of a column tile) lives in REGISTERS for the whole persistent kernel
+//     (35 / 70 / 108 VGPRs): no B fragment reads at all;
+//   * the A operand is one ds_read_b32 per K step and row tile, shared by all column tiles (the slab is stored
+//     TIME-FASTEST, slab[(h, ci)][frame], so the 32 lanes of a fragment read 32 consecutive floats: conflict-free,
+//     and every (j, ci) of the K loop is an immediate offset from one address VGPR);
+//   * the overlap-add is 16 ds_add_f32 per 32x32 accumulator tile into out[(h, co)][u] -- every output address is
+//     only ever touched by ONE wave (a wave owns a mel row and walks its frames in order), so the sum order is
+//     program order: run-to-run deterministic, no cross-wave atomics.
+// The price of the overlap-add is a halo of (G-1)*J Y rows per time block (they only feed outputs of the
+// neighbouring block): blocks are cut so that blockLen + halo is a whole number of 32-row tiles.
+//
+// backward-data is the same kernel on dy with tap-flipped, transposed weights (conv_tds.hip keeps the strided C2
+// sub-sampling layers and every other geometry).
+#include <cstdlib>
+
+#include "gemm.hpp"
+
+namespace w2l {
+
+constexpr int kRsMaxTb = 16;
+
+struct TdsRsP {
+  const float* x;     // [B][Tin][H][C]
+  const float* w;     // [kw][C][C] (forward orientation [tap][ci][co])
+  const float* bias;  // [C] or null
+  const float* add;   // optional addend with the layout of y, or null
+  float* y;           // [B][Tout][H][C]
+  int B, Tin, Tout, H, kw, padl;
+  int relu, accum, flip;
+  int nTb, hBlocks;
+  int tStart[kRsMaxTb];  // first output frame of time block i
+  int kt[kRsMaxTb];      // 32-row tiles of time block i (block length = 32*kt - halo, clipped to Tout)
+};
+
+template <int C, int G, int J, int KTMAX>
+struct RsCfg {
+  static constexpr int HH = 4;                          // mel rows per workgroup = waves
+  static constexpr int NCT = (G * C + 31) / 32;         // column tiles
+  static constexpr int NK = J * C / 2;                  // MFMA steps per column tile
+  static constexpr int HALO = (G - 1) * J;
+  static constexpr int NFMAX = 32 * KTMAX + J - 1;      // slab frames
+  static constexpr int FT = NFMAX | 1;                  // slab row stride (floats), odd
+  static constexpr int OT = (32 * KTMAX + HALO) | 1;    // out row stride
+  static constexpr int ROWS = HH * C;
+  static constexpr int Q = ROWS / 4;                    // float4 pieces per frame
+  static constexpr int XV = (NFMAX * Q + 255) / 256;    // pieces per thread
+  static constexpr size_t LDS = (size_t)(ROWS * FT + (ROWS + 1) * OT) * sizeof(float);
+  static_assert(C % 2 == 0 && ROWS % 4 == 0, "channel count");
+};
+
+template <int C, int G, int J, int KTMAX>
+__global__ __launch_bounds__(256, 2) void tds_conv_rs_k(TdsRsP p, int nTiles) {
+  using Cfg = RsCfg<C, G, J, KTMAX>;
+  constexpr int NCT = Cfg::NCT, NK = Cfg::NK, HALO = Cfg::HALO, FT = Cfg::FT, OT = Cfg::OT, ROWS = Cfg::ROWS, Q = Cfg::Q,
+                XV = Cfg::XV;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* slab = lds;               // [ROWS][FT]   slab[(hh*C + ci)][frame]
+  float* outA = lds + ROWS * FT;   // [ROWS + 1][OT]  out[(hh*C + co)][HALO + u]; row ROWS absorbs the padding columns
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+
+  // ---- once per workgroup: the weights of every column tile, in MFMA B-operand order, into registers
+  // step s = (j, pp): the two k of the MFMA are ci = 2pp (lanes 0-31) and 2pp + 1 (lanes 32-63); column r of
+  // tile ct is (g, co) = divmod(32 ct + r, C)
+  float bw[NCT][NK];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    const int n = 32 * ct + r, g = n / C, co = n - g * C;
+#pragma unroll
+    for (int s = 0; s < NK; ++s) {
+      const int j = s / (C / 2), ci = 2 * (s % (C / 2)) + hf;
+      const int tap = g * J + j;
+      const bool ok = g < G && tap < p.kw;
+      // forward: W[tap][ci][co]; backward-data: dx[., n] = sum dy[., k] W[kw-1-tap][n][k]
+      const size_t src = !p.flip ? ((size_t)tap * C + ci) * C + co : ((size_t)(p.kw - 1 - tap) * C + co) * C + ci;
+      const float t = p.w[ok ? src : 0];
+      bw[ct][s] = ok ? t : 0.f;
+    }
+  }
+  int ob[NCT];  // overlap-add base of this lane's column: out row (wave, co), shifted back by the group's g*J frames
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    const int n = 32 * ct + r, g = n / C, co = n - g * C;
+    ob[ct] = (g < G ? (wave * C + co) * OT + HALO - g * J : ROWS * OT) + 4 * hf;
+  }
+  const float* ab = slab + (wave * C + hf) * FT + r;
+  const int HC = p.H * C;
+
+  float4 xr[XV];
+  auto fetch = [&](int tile) {
+    const int hb = tile % p.hBlocks, tb = (tile / p.hBlocks) % p.nTb, b = tile / (p.hBlocks * p.nTb);
+    const int tIn0 = p.tStart[tb] - p.padl, nf = 32 * p.kt[tb] + J - 1;
+    const float* xb = p.x + ((size_t)b * p.Tin * p.H + hb * 4) * C;
+#pragma unroll
+    for (int v = 0; v < XV; ++v) {
+      const int e = tid + 256 * v, f = e / Q, q = e - f * Q;
+      const int ti = tIn0 + f;
+      const bool ok = f < nf && ti >= 0 && ti < p.Tin;
+      const float4 t4 = *(const float4*)(xb + (size_t)(ok ? ti : 0) * HC + 4 * q);
+      xr[v] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < nTiles) fetch(tile);
+  for (; tile < nTiles; tile += gridDim.x) {
+    const int hb = tile % p.hBlocks, tb = (tile / p.hBlocks) % p.nTb, b = tile / (p.hBlocks * p.nTb);
+    const int t0 = p.tStart[tb], kt = p.kt[tb];
+    const int nf = 32 * kt + J - 1;
+    __syncthreads();  // the previous tile's epilogue has read outA; its fragment reads of the slab are long done
+    // slab <- prefetched pieces, transposed to time-fastest; outA <- 0
+#pragma unroll
+    for (int v = 0; v < XV; ++v) {
+      const int e = tid + 256 * v, f = e / Q, q = e - f * Q;
+      if (f < nf) {
+        float* d = slab + (4 * q) * FT + f;
+        d[0] = xr[v].x; d[FT] = xr[v].y; d[2 * FT] = xr[v].z; d[3 * FT] = xr[v].w;
+      }
+    }
+    {
+      const int no = 32 * kt + HALO;
+      for (int e = tid; e < ROWS * no; e += 256) {
+        const int row = e / no, u = e - row * no;
+        outA[row * OT + u] = 0.f;
+      }
+    }
+    __syncthreads();
+    {
+      const int nxt = tile + gridDim.x;
+      fetch(nxt < nTiles ? nxt : tile);  // in flight behind this tile's MFMAs
+    }
+
+    for (int kti = 0; kti < kt; ++kti) {
+      const float* at = ab + 32 * kti;
+      float a[NK];
+#pragma unroll
+      for (int s = 0; s < NK; ++s) a[s] = at[(2 * (s % (C / 2))) * FT + s / (C / 2)];
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NK; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bw[ct][s], acc, 0, 0, 0);
+        // D: column = lane & 31, rows 8i + 4 (lane >> 5) + jj  ->  out[(wave, co)][tau - g*J]
+        float* o = outA + ob[ct] + 32 * kti;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            __hip_atomic_fetch_add(o + 8 * i + jj, acc[4 * i + jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    __syncthreads();
+
+    // ---- epilogue: out tile -> y[b][t0 + u][4 hb + hh][c], whole (4 C)-float frames as float4
+    int tc = p.Tout - t0;
+    if (tc > 32 * kt - HALO) tc = 32 * kt - HALO;
+    const size_t gBase = (((size_t)b * p.Tout + t0) * p.H + hb * 4) * C;
+    for (int e = tid; e < tc * Q; e += 256) {
+      const int u = e / Q, q = e - u * Q;
+      const float* s4 = outA + (4 * q) * OT + HALO + u;
+      float4 v = make_float4(s4[0], s4[OT], s4[2 * OT], s4[3 * OT]);
+      if (p.bias) {
+        const int c0 = (4 * q) % C;  // float 4q of a frame piece is (hh, c) = divmod(4q, C)
+        v.x += p.bias[c0]; v.y += p.bias[(c0 + 1) % C]; v.z += p.bias[(c0 + 2) % C]; v.w += p.bias[(c0 + 3) % C];
+      }
+      if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      const size_t gq = gBase + (size_t)u * HC + 4 * q;
+      if (p.add) { const float4 a4 = *(const float4*)(p.add + gq); v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w; }
+      if (p.accum) { const float4 y0 = *(const float4*)(p.y + gq); v.x += y0.x; v.y += y0.y; v.z += y0.z; v.w += y0.w; }
+      *(float4*)(p.y + gq) = v;
+    }
+  }
+}
+
+// time blocks: n blocks whose lengths + halo are whole 32-row tiles, at most KTMAX tiles each, as even as possible
+static bool rs_plan(int Tout, int halo, int ktMax, TdsRsP& p) {
+  for (int n = 1; n <= kRsMaxTb; ++n) {
+    const int total = (Tout + n * halo + 31) / 32;
+    if ((total + n - 1) / n > ktMax) continue;
+    int t = 0;
+    for (int i = 0; i < n; ++i) {
+      const int k = total / n + (i < total % n ? 1 : 0);
+      p.tStart[i] = t;
+      p.kt[i] = k;
+      t += 32 * k - halo;
+    }
+    p.nTb = n;
+    return t >= Tout && p.tStart[n - 1] < Tout;
+  }
+  return false;
+}
+
+template <int C, int G, int J, int KTMAX>
+static int rs_launch(TdsRsP p, hipStream_t s) {
+  using Cfg = RsCfg<C, G, J, KTMAX>;
+  p.hBlocks = p.H / Cfg::HH;
+  const int nTiles = p.B * p.nTb * p.hBlocks;
+  const int perCu = (int)(160 * 1024 / Cfg::LDS) < 2 ? 1 : 2;
+  const int blocks = nTiles < 256 * perCu ? nTiles : 256 * perCu;
+  static bool attr = false;
+  if (!attr && Cfg::LDS > 64 * 1024) {
+    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_rs_k<C, G, J, KTMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
+    attr = true;
+  }
+  hipLaunchKernelGGL((tds_conv_rs_k<C, G, J, KTMAX>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p, nTiles);
+  return W2L_OK;
+}
+
+// true + *status when this geometry runs on the role-swapped kernel
+bool tds_rs_try(const float* x, const float* w, const float* bias, const float* add, float* y, int B, int Tin, int Tout, int H,
+                int C, int kw, int padl, int relu, int accum, int flip, int profKind, hipStream_t s, int* status) {
+  if (tune_env("W2L_TDS_RS_OFF")) return false;
+  if (!(C == 10 || C == 14 || C == 18) || kw > 21 || kw < 1 || H % 4) return false;
+  if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)add) & 15) != 0) return false;
+  TdsRsP p{};
+  p.x = x; p.w = w; p.bias = bias; p.add = add; p.y = y;
+  p.B = B; p.Tin = Tin; p.Tout = Tout; p.H = H; p.kw = kw; p.padl = padl; p.relu = relu; p.accum = accum; p.flip = flip;
+  const bool planned = C == 10 ? rs_plan(Tout, RsCfg<10, 3, 7, 6>::HALO, 6, p)
+                     : C == 14 ? rs_plan(Tout, RsCfg<14, 11, 2, 5>::HALO, 5, p) : rs_plan(Tout, RsCfg<18, 7, 3, 4>::HALO, 4, p);
+  if (!planned) return false;
+  prof_begin(s, 2.0 * B * Tout * (double)H * kw * C * C, profKind);
+  int st;
+  if (C == 10) st = rs_launch<10, 3, 7, 6>(p, s);
+  else if (C == 14) st = rs_launch<14, 11, 2, 5>(p, s);
+  else st = rs_launch<18, 7, 3, 4>(p, s);
+  prof_end(s);
+  if (st == W2L_OK && hipGetLastError() != hipSuccess) st = W2L_EHIP;
+  *status = st;
+  return true;
+}
+
+}  // namespace w2l

@@ -585,7 +585,7 @@ W2L_API int w2l_fac_forward(int B, int T, int N, int L, int scaleMode, const flo
   if (L > 512) return W2L_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   FacWs ws = fac_ws(workspace, B, T, N, L);
-  static const int waveMode = [] { const char* e = getenv("W2L_FAC_WAVE"); return e ? atoi(e) : 0; }();
+  static const int waveMode = [] { const char* e = tune_env("W2L_FAC_WAVE"); return e ? atoi(e) : 0; }();
   if (waveMode && L <= 384) {  // experiment: one wave per utterance, ceil(L/64) positions per lane, DPP neighbour exchange
     const int P = (L + 63) / 64;
 #define W2L_FAC_WAVE_GO(PP) hipLaunchKernelGGL(fac_fwd<PP>, dim3(B), dim3(64), 0, s, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws)

@@ -70,7 +70,7 @@ struct BigDims {
 // 48 NB VGPRs + 32 NB accumulators).  W2L_FCC_WPC overrides the NB = 1 choice (1 or 2) for A/B runs.
 inline int big_workers_per_cu(int NB) {
   if (NB >= 2) return 1;
-  const char* e = getenv("W2L_FCC_WPC");
+  const char* e = tune_env("W2L_FCC_WPC");
   if (e && e[0] >= '1' && e[0] <= '2') return e[0] - '0';
   return 2;
 }
@@ -83,7 +83,7 @@ inline int big_workers_per_cu(int NB) {
 // wide shape for A/B runs.  NB >= 2 keeps RT = 2 (registers).
 inline int big_row_tiles(int NB) {
   if (NB >= 2) return 2;
-  const char* e = getenv("W2L_FCC_RT");
+  const char* e = tune_env("W2L_FCC_RT");
   if (e && e[0] == '4') return 4;
   return 2;
 }
@@ -97,12 +97,12 @@ inline BigDims big_dims(int B, int T, int N) {
   d.NB = nb <= 1 ? 1 : (nb <= 2 ? 2 : 4);
   d.Bp = 32 * d.NB;
   d.RT = big_row_tiles(d.NB);
-  { const char* e = getenv("W2L_FCC_RING"); d.ring = e ? atoi(e) : 0; }
-  { const char* e = getenv("W2L_FCC_ABL"); d.abl = e ? atoi(e) : 0; }
-  { const char* e = getenv("W2L_FCC_ASM"); d.asmv = e ? atoi(e) : 0; }
+  { const char* e = tune_env("W2L_FCC_RING"); d.ring = e ? atoi(e) : 0; }
+  { const char* e = tune_env("W2L_FCC_ABL"); d.abl = e ? atoi(e) : 0; }
+  { const char* e = tune_env("W2L_FCC_ASM"); d.asmv = e ? atoi(e) : 0; }
   // LDS-DMA ring with a nontemporal transition stream is the default (0 = register ping-pong): measured on MI355X
   // (profiles/r01_run16_fcc_dma_ring_variants.log) 2x3 85.5 us, 1x6 85.8, 2x3 nt 77.6, 1x6 nt 76.0, ping-pong 94.0
-  { const char* e = getenv("W2L_FCC_DMA"); d.dma = e ? atoi(e) : 4; }
+  { const char* e = tune_env("W2L_FCC_DMA"); d.dma = e ? atoi(e) : 4; }
   d.Np = (N + 32 * d.RT - 1) / (32 * d.RT) * (32 * d.RT);
   d.G = d.Np / (32 * d.RT);
   // The step is cut into U = G * nS stage-units (64 rows x 32 k) in row-group-major order and dealt

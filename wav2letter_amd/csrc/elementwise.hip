@@ -398,22 +398,39 @@ __global__ __launch_bounds__(kEwThreads) void sumsq_k(const float* __restrict__ 
   if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
 }
 
+// acc[0] = sum g^2 over the network gradients, acc[1] = over the criterion gradients (w2l_sumsq), batch = the
+// all-reduced number of utterances (device scalar riding in the gradient arena's tail) or null.
+// -> acc[2] = the clip norm^2 (network, + criterion if clampCrit) or NaN if ANY gradient is non-finite,
+//    acc[3] = 1 / batch (0: caller's gradScale stands), acc[4] += 1 for a skipped (non-finite) update.
+__global__ void grad_guard_k(double* __restrict__ acc, const float* __restrict__ batch, int clampCrit) {
+  const double tot = acc[0] + acc[1];
+  const bool ok = isfinite(tot) && (!batch || (isfinite(*batch) && *batch > 0.f));
+  acc[2] = ok ? acc[0] + (clampCrit ? acc[1] : 0.0) : __longlong_as_double(0x7ff8000000000000ll);
+  acc[3] = (ok && batch) ? 1.0 / (double)*batch : 0.0;
+  if (!ok) acc[4] += 1.0;
+}
+
 // fl::SGDOptimizer::step with momentum (no dampening/nesterov/wd, as the recipes use):
 //   g' = g * gradScale * clipCoef ; v = mom*v + g' ; p -= lr * v
 // clipCoef = min(1, maxNorm / (||g*gradScale|| + 1e-6))  (fl::clipGradNorm), maxNorm <= 0: off.
 __global__ __launch_bounds__(kEwThreads) void sgd_k(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ v, size_t n, float lr, float mom,
-                                                   float gradScale, float maxNorm, const double* __restrict__ sumsq) {
+                                                   float gradScale, float maxNorm, const double* __restrict__ sumsq,
+                                                   int guarded) {
   float coef = gradScale;
-  if (maxNorm > 0.f) {
+  if (sumsq) {
     // Non-finite gradient norm (a NaN / Inf anywhere in the reduced gradient): leave parameters and momentum
-    // untouched.  The reference aborts on a non-finite loss (Train.cpp:1686-1698) and makes all ranks skip an update
-    // together through an all-reduced flag (:1651-1660); here the norm is computed from the ALL-REDUCED gradient, so
-    // every rank takes the same decision without a host round trip.  w2l_trainer_grad_norm() exposes the norm.
-    if (!isfinite(*sumsq)) return;
-    float norm = (float)sqrt(*sumsq) * gradScale;
-    float c = maxNorm / (norm + 1e-6f);
-    if (c < 1.f) coef *= c;
+    // untouched -- ALWAYS, whether or not clipping is on (--maxgradnorm=0 is the reference default).  The reference
+    // aborts on a non-finite loss (Train.cpp:1686-1698) and makes all ranks skip an update together through an
+    // all-reduced flag (:1651-1660); here the norm is computed from the ALL-REDUCED gradient, so every rank takes the
+    // same decision without a host round trip.  w2l_trainer_grad_norm() / w2l_trainer_skipped_updates() expose it.
+    if (!isfinite(sumsq[0])) return;
+    if (guarded && sumsq[1] > 0.0) coef = gradScale = (float)sumsq[1];  // 1 / all-reduced batch size (grad_guard_k)
+    if (maxNorm > 0.f) {
+      float norm = (float)sqrt(sumsq[0]) * gradScale;
+      float c = maxNorm / (norm + 1e-6f);
+      if (c < 1.f) coef *= c;
+    }
   }
   const size_t n4 = n >> 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -612,7 +629,24 @@ W2L_API int w2l_sgd_step(float* p, const float* g, float* v, size_t n, float lr,
   if (!p || !g || (momentum != 0.f && !v) || (maxGradNorm > 0.f && !sumsq)) return W2L_EINVAL;
   if (!n) return W2L_OK;
   hipLaunchKernelGGL(sgd_k, dim3(ew_grid((n >> 2) + 1)), dim3(kEwThreads), 0, W2L_S, p, g, v, n, lr, momentum,
-                     gradScale, maxGradNorm, sumsq);
+                     gradScale, maxGradNorm, sumsq, 0);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+W2L_API int w2l_grad_guard(double* acc, const float* batchDev, int clampCrit, w2l_stream_t stream) {
+  if (!acc) return W2L_EINVAL;
+  hipLaunchKernelGGL(grad_guard_k, dim3(1), dim3(1), 0, W2L_S, acc, batchDev, clampCrit);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+W2L_API int w2l_sgd_step_guarded(float* p, const float* g, float* v, size_t n, float lr, float momentum,
+                                 float gradScale, float maxGradNorm, const double* guard, w2l_stream_t stream) {
+  if (!p || !g || (momentum != 0.f && !v) || !guard) return W2L_EINVAL;
+  if (!n) return W2L_OK;
+  hipLaunchKernelGGL(sgd_k, dim3(ew_grid((n >> 2) + 1)), dim3(kEwThreads), 0, W2L_S, p, g, v, n, lr, momentum,
+                     gradScale, maxGradNorm, guard, 1);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }

@@ -436,7 +436,7 @@ inline int launch128g(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o,
   if (plan.skBlocks > 0) {
     plan.slabs = sk_scratch(s, kSkScratchBytes);
     if (!plan.slabs) { plan = make_sk_plan(o.M, o.N, o.K, false); plan.grouped = 1; }
-    const char* eFix = getenv("W2L_GEMM_INFIX");  // read per call (tests flip it): 0 = separate fix-up launch
+    const char* eFix = tune_env("W2L_GEMM_INFIX");  // read per call (tests flip it): 0 = separate fix-up launch
     const int inFix = eFix ? atoi(eFix) : 1;
     if (plan.skBlocks > 0 && inFix && plan.skTiles <= 1024) plan.counters = sk_counters(s);
   }
@@ -446,14 +446,15 @@ inline int launch128g(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o,
   dim3 grid((unsigned)workers), block(256);
   o.epi = epi;
   prof_begin(s, 2.0 * o.M * (double)o.N * o.K);
-  static const int wideOn = [] { const char* e = getenv("W2L_GEMM_WIDE"); return e ? atoi(e) : 1; }();
+  static const int wideOn = [] { const char* e = tune_env("W2L_GEMM_WIDE"); return e ? atoi(e) : 1; }();
   const int wide = wideOn && (((uintptr_t)o.C) & 15) == 0 && o.ldc % 4 == 0 &&
                    (!o.mask || (((uintptr_t)o.mask) & 15) == 0);
   // buffer-addressed LDS-DMA is the default (+8 % at 4096^3, +5-7 % on the TDS fc shapes over 64-bit global
   // addresses, MI355X); W2L_GEMM_BUF=0 selects the global_load_lds variant for A/B runs
-  static const int bufOn = [] { const char* e = getenv("W2L_GEMM_BUF"); return e ? atoi(e) : 1; }();
-  static const int ablBuf = [] { const char* e = getenv("W2L_GEMM_ABLBUF"); return e ? atoi(e) : 0; }();
-  static const int abl = [] { const char* e = getenv("W2L_GEMM_ABL"); return e ? atoi(e) : 0; }();
+  static const int bufOn = [] { const char* e = tune_env("W2L_GEMM_BUF"); return e ? atoi(e) : 1; }();
+#ifdef W2L_PROBE  // timing-only ablations (results are garbage): compiled into the probe library only
+  static const int ablBuf = [] { const char* e = tune_env("W2L_GEMM_ABLBUF"); return e ? atoi(e) : 0; }();
+  static const int abl = [] { const char* e = tune_env("W2L_GEMM_ABL"); return e ? atoi(e) : 0; }();
   if (abl && akc && !bkc) {
     switch (abl) {
       case 1: hipLaunchKernelGGL((gemm128g_kernel<true, false, 1>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
@@ -476,7 +477,9 @@ inline int launch128g(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o,
       case 72: hipLaunchKernelGGL((gemm128g_kernel<true, false, 72, true>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
       default: hipLaunchKernelGGL((gemm128g_kernel<true, false, 0, true>), grid, block, shmem, s, a, b, o, plan, workers, wide); break;
     }
-  } else if (bufOn && a.bytes && b.bytes) {
+  } else
+#endif
+  if (bufOn && a.bytes && b.bytes) {
     if (akc && bkc) hipLaunchKernelGGL((gemm128g_kernel<true, true, 0, true>), grid, block, shmem, s, a, b, o, plan, workers, wide);
     else if (akc) hipLaunchKernelGGL((gemm128g_kernel<true, false, 0, true>), grid, block, shmem, s, a, b, o, plan, workers, wide);
     else if (bkc) hipLaunchKernelGGL((gemm128g_kernel<false, true, 0, true>), grid, block, shmem, s, a, b, o, plan, workers, wide);

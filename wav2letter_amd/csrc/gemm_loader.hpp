@@ -231,7 +231,7 @@ inline int launch128w(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o,
   int workers = plan.dpTiles < kSkSlots ? plan.dpTiles : kSkSlots;
   if (workers < plan.skBlocks) workers = plan.skBlocks;
   const size_t shmem = 2 * (size_t)kGStageFloats * sizeof(float);
-  static const int wideOn = [] { const char* e = getenv("W2L_GEMM_WIDE"); return e ? atoi(e) : 1; }();
+  static const int wideOn = [] { const char* e = tune_env("W2L_GEMM_WIDE"); return e ? atoi(e) : 1; }();
   const int wide = wideOn && (((uintptr_t)o.C) & 15) == 0 && o.ldc % 4 == 0 &&
                    (!o.mask || (((uintptr_t)o.mask) & 15) == 0) && (!o.addend || (((uintptr_t)o.addend) & 15) == 0);
   dim3 grid((unsigned)workers), block(320);

@@ -356,7 +356,7 @@ inline int launch256(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o, 
   int workers = plan.dpTiles < kP3Slots ? plan.dpTiles : kP3Slots;
   if (workers < plan.skBlocks) workers = plan.skBlocks;
   const size_t shmem = 3 * (size_t)kP3StageFloats * sizeof(float);
-  static const int wideOn = [] { const char* e = getenv("W2L_GEMM_WIDE"); return e ? atoi(e) : 1; }();
+  static const int wideOn = [] { const char* e = tune_env("W2L_GEMM_WIDE"); return e ? atoi(e) : 1; }();
   const int wide = wideOn && (((uintptr_t)o.C) & 15) == 0 && o.ldc % 4 == 0 && (!o.mask || (((uintptr_t)o.mask) & 15) == 0) &&
                    (!o.addend || (((uintptr_t)o.addend) & 15) == 0);
   dim3 grid((unsigned)workers), block(512);

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void gemm160_kernel(GOp aop, GOp bop, GemmO
 // 0 = not eligible / not worth it, 1 = WIDE (128x160), 2 = TALL (160x128): the variant whose padded tile area is
 // smallest, if it saves at least 2 % of the 128x128 grid's padded area.  W2L_GEMM_T160: 0 = never, 2 = whenever eligible.
 inline int t160_choice(const GOp& a, const GOp& b, const GemmOut& o) {
-  const char* e = getenv("W2L_GEMM_T160");
+  const char* e = tune_env("W2L_GEMM_T160");
   const int mode = e ? atoi(e) : 1;
   if (!mode || !a.bytes || !b.bytes || o.N % 4 != 0) return 0;
   if ((((uintptr_t)o.C) & 15) != 0 || o.ldc % 4 != 0 || (o.mask && (((uintptr_t)o.mask) & 15) != 0) ||

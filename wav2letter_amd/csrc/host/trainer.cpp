@@ -30,7 +30,8 @@ struct Trainer {
   float *params = nullptr, *grads = nullptr, *mom = nullptr, *arena = nullptr;
   void* critWs = nullptr;
   float *loss = nullptr, *gradLoss = nullptr, *dEm = nullptr;
-  double* sumsq = nullptr;
+  double* sumsq = nullptr;   // acc[8]: see w2l_grad_guard (include/w2l_hip.h)
+  float* batchSlot = nullptr;  // grads[paramFloats]: this rank's utterance count, summed by the SAME all-reduce as the gradients
   const float* emission = nullptr;
   uint32_t step = 0;
   std::shared_ptr<SequenceCriterion> linseg;  // --linseg warm-up criterion (ASG only), used while step < linsegUpdates
@@ -38,6 +39,7 @@ struct Trainer {
   int scaleMode = 0;
   SequenceCriterion* activeCrit() { return (linseg && step < linsegUpdates) ? linseg.get() : crit.get(); }
   std::string lastError;
+  bool guardZeroed = false;
   std::vector<hipEvent_t> bucketEvents;  // owned (w2l_trainer_set_grad_buckets)
   ~Trainer() { for (auto e : bucketEvents) (void)hipEventDestroy(e); }
 };
@@ -79,6 +81,9 @@ W2L_API void w2l_trainer_destroy(void* h) { delete (Trainer*)h; }
 
 W2L_API size_t w2l_trainer_param_floats(void* h) { Trainer* t = (Trainer*)h; return t->netFloats + t->critFloats; }
 W2L_API size_t w2l_trainer_net_param_floats(void* h) { return ((Trainer*)h)->netFloats; }
+// size of the GRADIENT arena the caller binds: parameters + a 4-float tail whose first element carries the local
+// batch size through the gradient all-reduce (the reference all-reduces it separately, Train.cpp:1743-1747)
+W2L_API size_t w2l_trainer_grad_floats(void* h) { Trainer* t = (Trainer*)h; return t->netFloats + t->critFloats + 4; }
 W2L_API int w2l_trainer_num_params(void* h) { return (int)((Trainer*)h)->net->params().size(); }
 W2L_API const char* w2l_trainer_describe(void* h) {
   Trainer* t = (Trainer*)h;
@@ -115,11 +120,13 @@ W2L_API int w2l_trainer_plan(void* h, int B, int T, int L, size_t* arenaFloats, 
                              int* Tout) {
   Trainer* t = (Trainer*)h;
   TRY(h, {
+    if (B <= 0 || T <= 0 || L <= 0) throw std::invalid_argument("plan: B, T, L must be positive");
     size_t used = t->net->plan(B, T, t->nFeat);
     t->B = B; t->T = T; t->L = L;
     t->Tout = t->net->outAct().T;
     if (t->net->outAct().F != t->nLabel) throw std::invalid_argument("network output width != NLABEL");
-    size_t extra = ((size_t)B * t->Tout * t->nLabel + 63) / 64 * 64 + 3 * 64 + 64;  // dEmission, loss, gradLoss, sumsq
+    const size_t bSlots = ((size_t)B + 63) / 64 * 64;
+    size_t extra = ((size_t)B * t->Tout * t->nLabel + 63) / 64 * 64 + 2 * bSlots + 64;  // dEmission, loss, gradLoss, guard doubles
     t->arenaFloats = used + extra;
     t->critWsBytes = t->crit->workspaceBytes(B, t->Tout, t->nLabel, L);
     if (t->linseg) t->critWsBytes = std::max(t->critWsBytes, t->linseg->workspaceBytes(B, t->Tout, t->nLabel, L));
@@ -135,16 +142,25 @@ W2L_API int w2l_trainer_bind(void* h, float* params, float* grads, float* moment
   Trainer* t = (Trainer*)h;
   if (!params || !grads || !arena || !critWs || !t->arenaFloats) return W2L_EINVAL;
   t->params = params; t->grads = grads; t->mom = momentum; t->arena = arena; t->critWs = critWs;
-  size_t used = t->arenaFloats - (((size_t)t->B * t->Tout * t->nLabel + 63) / 64 * 64 + 3 * 64 + 64);
+  const size_t bSlots = ((size_t)t->B + 63) / 64 * 64;
+  const size_t emSlots = ((size_t)t->B * t->Tout * t->nLabel + 63) / 64 * 64;
+  size_t used = t->arenaFloats - (emSlots + 2 * bSlots + 64);
   t->dEm = arena + used;
-  t->loss = t->dEm + ((size_t)t->B * t->Tout * t->nLabel + 63) / 64 * 64;
-  t->gradLoss = t->loss + ((size_t)t->B + 63) / 64 * 64;
-  t->sumsq = (double*)(t->gradLoss + ((size_t)t->B + 63) / 64 * 64 + 64);
-  if (t->B > 64) return W2L_EUNSUPPORTED;  // loss / gradLoss slots are 64 floats
+  t->loss = t->dEm + emSlots;
+  t->gradLoss = t->loss + bSlots;
+  t->sumsq = (double*)(t->gradLoss + bSlots);  // 64 floats = 32 doubles, 256-byte aligned
+  t->batchSlot = grads + t->netFloats + t->critFloats;
+  t->guardZeroed = false;
   return W2L_OK;
 }
 
+static void requireBound(Trainer* t) {
+  if (!t->arenaFloats || !t->params || !t->grads || !t->arena || !t->critWs)
+    throw std::invalid_argument("trainer not planned / bound (w2l_trainer_plan + w2l_trainer_bind first)");
+}
+
 static Ctx makeCtx(Trainer* t, void* stream, bool train) {
+  requireBound(t);
   Ctx c;
   c.stream = (hipStream_t)stream;
   c.train = train;
@@ -158,6 +174,7 @@ static Ctx makeCtx(Trainer* t, void* stream, bool train) {
 W2L_API int w2l_trainer_forward(void* h, const float* x, int train, const float** emission, void* stream) {
   Trainer* t = (Trainer*)h;
   TRY(h, {
+    if (!x) throw std::invalid_argument("forward: null input");
     Ctx c = makeCtx(t, stream, train != 0);
     t->emission = t->net->forward(c, t->arena, x);
     if (emission) *emission = t->emission;
@@ -177,8 +194,11 @@ W2L_API int w2l_trainer_forward_backward(void* h, const float* x, const int* tar
     SequenceCriterion* crit = t->activeCrit();
     crit->forward(c, t->B, t->Tout, t->nLabel, t->L, t->emission, target, t->loss, t->critWs, cp);
     // d(sum_b loss_b)/d loss_b = 1
-    hipCheck(hipMemsetAsync(t->gradLoss, 0, sizeof(float) * 64, c.stream), "memset");
+    if (!x || !target) throw std::invalid_argument("forward_backward: null input");
+    hipCheck(hipMemsetAsync(t->gradLoss, 0, sizeof(float) * (((size_t)t->B + 63) / 64 * 64), c.stream), "memset");
     w2lCheck(w2l_fill(t->gradLoss, (size_t)t->B, 1.f, c.stream), "fill");
+    w2lCheck(w2l_fill(t->batchSlot, 1, (float)t->B, c.stream), "batch slot");  // rides the gradient all-reduce
+    hipCheck(hipMemsetAsync(t->batchSlot + 1, 0, sizeof(float) * 3, c.stream), "memset");
     crit->backward(c, t->B, t->Tout, t->nLabel, t->L, t->emission, target, t->gradLoss, t->dEm, t->critWs, cp, cg);
     t->net->backward(c, t->arena, t->dEm);
     if (lossDev) *lossDev = t->loss;
@@ -191,16 +211,19 @@ W2L_API int w2l_trainer_update(void* h, float lr, float lrcrit, float momentum, 
                                float totalBatch, int clampCrit, void* stream) {
   Trainer* t = (Trainer*)h;
   TRY(h, {
+    requireBound(t);
     hipStream_t s = (hipStream_t)stream;
-    const float gs = 1.f / totalBatch;
-    if (maxGradNorm > 0.f) {
-      size_t n = t->netFloats + (clampCrit ? t->critFloats : 0);
-      w2lCheck(w2l_sumsq(t->grads, n, t->sumsq, 1, s), "sumsq");
-    }
+    // totalBatch > 0: the caller's number; <= 0: the all-reduced utterance count in the gradient arena's tail
+    const float gs = totalBatch > 0.f ? 1.f / totalBatch : 0.f;
+    if (!t->guardZeroed) { hipCheck(hipMemsetAsync(t->sumsq, 0, sizeof(double) * 8, s), "memset"); t->guardZeroed = true; }
+    // the norm is taken on EVERY update (also with --maxgradnorm=0): it is the non-finite guard of the step
+    w2lCheck(w2l_sumsq(t->grads, t->netFloats, t->sumsq, 1, s), "sumsq");
+    w2lCheck(w2l_sumsq(t->grads + t->netFloats, t->critFloats, t->sumsq + 1, 1, s), "sumsq");
+    w2lCheck(w2l_grad_guard(t->sumsq, totalBatch > 0.f ? nullptr : t->batchSlot, clampCrit, s), "guard");
     if (t->critFloats)
-      w2lCheck(w2l_sgd_step(t->params + t->netFloats, t->grads + t->netFloats, nullptr, t->critFloats, lrcrit, 0.f, gs,
-                            clampCrit ? maxGradNorm : 0.f, t->sumsq, s), "crit sgd");
-    w2lCheck(w2l_sgd_step(t->params, t->grads, t->mom, t->netFloats, lr, momentum, gs, maxGradNorm, t->sumsq, s), "net sgd");
+      w2lCheck(w2l_sgd_step_guarded(t->params + t->netFloats, t->grads + t->netFloats, nullptr, t->critFloats, lrcrit, 0.f, gs,
+                                    clampCrit ? maxGradNorm : 0.f, t->sumsq + 2, s), "crit sgd");
+    w2lCheck(w2l_sgd_step_guarded(t->params, t->grads, t->mom, t->netFloats, lr, momentum, gs, maxGradNorm, t->sumsq + 2, s), "net sgd");
     t->step++;
   });
 }
@@ -253,6 +276,8 @@ W2L_API int w2l_trainer_set_linseg(void* h, uint32_t updates) {
     t->linsegUpdates = updates;
     t->linseg = updates ? makeLinSegCriterion(t->nLabel, t->scaleMode) : nullptr;
     t->arenaFloats = 0;  // forces a new plan / bind
+    t->params = t->grads = t->mom = t->arena = nullptr;
+    t->critWs = nullptr;
   });
 }
 
@@ -263,9 +288,23 @@ W2L_API int w2l_trainer_grad_norm(void* h, double* norm, void* stream) {
   TRY(h, {
     if (!t->sumsq || !norm) throw std::invalid_argument("trainer not bound");
     double s = 0.0;
-    hipCheck(hipMemcpyAsync(&s, t->sumsq, sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream), "grad norm");
+    hipCheck(hipMemcpyAsync(&s, t->sumsq + 2, sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream), "grad norm");
     hipCheck(hipStreamSynchronize((hipStream_t)stream), "grad norm");
     *norm = std::sqrt(s);
+  });
+}
+
+// number of updates skipped so far because the (all-reduced) gradient or batch size was non-finite.  Synchronises.
+W2L_API int w2l_trainer_skipped_updates(void* h, uint64_t* count, void* stream) {
+  Trainer* t = (Trainer*)h;
+  TRY(h, {
+    if (!t->sumsq || !count) throw std::invalid_argument("trainer not bound");
+    double s = 0.0;
+    if (t->guardZeroed) {
+      hipCheck(hipMemcpyAsync(&s, t->sumsq + 4, sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream), "skipped");
+      hipCheck(hipStreamSynchronize((hipStream_t)stream), "skipped");
+    }
+    *count = (uint64_t)s;
   });
 }
 

@@ -56,9 +56,15 @@ def partition_round_robin(n_samples: int, rank: int, world: int, batch_size: int
         base = g * per_global + rank * batch_size
         out.extend(range(base, base + batch_size))
     rest = n_samples - n_global * per_global
-    if rest > 0 and (allow_empty or rest >= world):
-        per = rest // world                      # equal shares: every rank gets one more (smaller) batch or none
+    if rest >= world or (allow_empty and rest > 0):
+        # the tail batch (fl::partitionByRoundRobin, un-vendored, as recalled): equal shares of rest // world; with
+        # allow_empty (validation sets) the first rest % world ranks take one sample more, so that the union over
+        # ranks is every sample; without it the remainder is dropped so that all ranks see equal batch counts
+        per, remaining = divmod(rest, world)
         base = n_global * per_global + rank * per
+        if allow_empty:
+            base += min(rank, remaining)
+            per += 1 if rank < remaining else 0
         out.extend(range(base, base + per))
     return out
 

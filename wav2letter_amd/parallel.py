@@ -31,6 +31,35 @@ def init_distributed(backend=None, device=None):
     return rank, world
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n_ranks, script, argv, need_gpus=True):
+    """Start `script argv` as n_ranks processes on this node, one per GPU, and return the exit code -- what the
+    reference's users do with `mpirun -n 8 Train ...` (recipes/slimIPL/src/Train.cpp:188-196 initDistributed reads the
+    MPI world).  Called by an entry point that was asked for N > 1 devices without a WORLD_SIZE in its environment, so
+    that `python bench.py --gpus 8` IS an 8-rank RCCL job.  Rendezvous on 127.0.0.1 (the container hostname may not
+    resolve).  Fails loudly when fewer than n_ranks devices are visible."""
+    import subprocess
+    import sys
+    if n_ranks < 2:
+        raise ValueError("self_launch: n_ranks must be >= 2")
+    if need_gpus:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n_ranks:
+            raise RuntimeError(f"--gpus {n_ranks} needs {n_ranks} visible GPUs, this node shows {have} "
+                               "(one process per GPU; set --gpus to the number of devices or fix HIP_VISIBLE_DEVICES)")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def shard_range(n_items, rank, world):
     """contiguous shard [lo, hi) of a global minibatch for this rank (createDataset(..., rank, world))"""
     per, rem = divmod(n_items, world)
@@ -97,14 +126,16 @@ class OverlappedReducer:
         self.tr = trainer
         offs = bucket_offsets(trainer.param_table(), trainer.n_floats, n_buckets)
         trainer.set_grad_buckets(offs)
-        self.offsets = offs + [trainer.n_floats]
+        # the last bucket runs over the 4-float tail too: tail[0] = local batch size, summed with the gradients
+        # (the reference all-reduces the batch size on its own, recipes/slimIPL/src/Train.cpp:1743-1747)
+        self.offsets = offs + [trainer.grads_full.numel()]
         self.comm = torch.cuda.Stream(device=trainer.device)
 
     def reduce(self):
         """call right after trainer.forward_backward(); returns when every collective is enqueued and the
         current (compute) stream has been made to wait for them"""
         works = []
-        g = self.tr.grads
+        g = self.tr.grads_full
         for k in reversed(range(len(self.offsets) - 1)):
             self.tr.wait_bucket(k, self.comm)
             with torch.cuda.stream(self.comm):

@@ -12,13 +12,12 @@ import torch
 from . import _lib
 from .criterion import CriterionScaleMode
 
-_sigs_done = False
+_sigs_done = set()   # ids of the CDLL objects whose trainer signatures are declared (product / probe library)
 
 
 def _lib_tr():
-    global _sigs_done
     L = _lib.lib()
-    if not _sigs_done:
+    if id(L) not in _sigs_done:
         vp, i, sz, f, d, u32, u64 = C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_double, C.c_uint32, C.c_uint64
         L.w2l_host_last_error.restype = C.c_char_p
         L.w2l_trainer_create.restype = vp
@@ -26,7 +25,7 @@ def _lib_tr():
         L.w2l_trainer_destroy.argtypes = [vp]
         L.w2l_trainer_describe.restype = C.c_char_p
         L.w2l_trainer_describe.argtypes = [vp]
-        for n in ("w2l_trainer_param_floats", "w2l_trainer_net_param_floats"):
+        for n in ("w2l_trainer_param_floats", "w2l_trainer_net_param_floats", "w2l_trainer_grad_floats"):
             getattr(L, n).restype = sz
             getattr(L, n).argtypes = [vp]
         L.w2l_trainer_num_params.argtypes = [vp]
@@ -43,11 +42,12 @@ def _lib_tr():
         L.w2l_trainer_set_step.argtypes = [vp, u32]
         L.w2l_trainer_set_linseg.argtypes = [vp, u32]
         L.w2l_trainer_grad_norm.argtypes = [vp, C.POINTER(C.c_double), vp]
+        L.w2l_trainer_skipped_updates.argtypes = [vp, C.POINTER(u64), vp]
         L.w2l_trainer_set_grad_buckets.argtypes = [vp, i, C.POINTER(sz)]
         L.w2l_trainer_wait_bucket.argtypes = [vp, i, vp]
         L.w2l_arch_check.argtypes = [C.c_char_p, i, i, C.POINTER(i)]
         L.w2l_flags_check.argtypes = [C.c_char_p, C.POINTER(i)]
-        _sigs_done = True
+        _sigs_done.add(id(L))
     return L
 
 
@@ -82,6 +82,8 @@ class Trainer:
         if not self.h:
             raise _lib.W2LInvalidArgument(L.w2l_host_last_error().decode())
         self.nfeat, self.nlabel = nfeat, nlabel
+        self.criterion = criterion
+        self._pending_mom = None
         self.device = device
         self.n_floats = L.w2l_trainer_param_floats(self.h)
         self.n_net = L.w2l_trainer_net_param_floats(self.h)
@@ -126,8 +128,14 @@ class Trainer:
     def to_device(self):
         """upload host_params, allocate grads / momentum"""
         self.params = torch.from_numpy(self.host_params).to(self.device)
-        self.grads = torch.zeros_like(self.params)
+        # gradient arena = parameters + a 4-float tail: tail[0] carries this rank's batch size through the SAME
+        # all-reduce as the gradients (Train.cpp:1743-1747 reduces it separately)
+        self.grads_full = torch.zeros(self.L.w2l_trainer_grad_floats(self.h), dtype=torch.float32, device=self.device)
+        self.grads = self.grads_full[:self.n_floats]
         self.mom = torch.zeros_like(self.params)
+        if getattr(self, "_pending_mom", None) is not None:   # checkpoint.load() before to_device()
+            self.mom.copy_(torch.from_numpy(self._pending_mom))
+            self._pending_mom = None
         if self.B:
             self._bind()
 
@@ -142,21 +150,33 @@ class Trainer:
         return to.value
 
     def _bind(self):
-        _check(self.L.w2l_trainer_bind(self.h, self.params.data_ptr(), self.grads.data_ptr(), self.mom.data_ptr(),
+        _check(self.L.w2l_trainer_bind(self.h, self.params.data_ptr(), self.grads_full.data_ptr(), self.mom.data_ptr(),
                                        self.arena.data_ptr(), self.crit_ws.data_ptr()), "bind")
 
     @staticmethod
     def _stream():
         return torch.cuda.current_stream().cuda_stream
 
+    def _check_input(self, x, target=None):
+        if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+                and tuple(x.shape) == (self.B, self.nfeat, self.T)):
+            raise _lib.W2LInvalidArgument(
+                f"input must be a contiguous float32 CUDA tensor [B={self.B}][NFEAT={self.nfeat}][T={self.T}], got "
+                f"{tuple(x.shape) if torch.is_tensor(x) else type(x)}")
+        if target is not None and not (torch.is_tensor(target) and target.is_cuda and target.dtype == torch.int32
+                                       and target.is_contiguous() and tuple(target.shape) == (self.B, self.Lt)):
+            raise _lib.W2LInvalidArgument(f"target must be a contiguous int32 CUDA tensor [B={self.B}][L={self.Lt}]")
+
     def forward(self, x, train=False):
         """x: [B][NFEAT][T] float32 -> emissions view [B][T'][N] (aliases the arena)"""
+        self._check_input(x)
         ptr = C.c_void_p(0)
         _check(self.L.w2l_trainer_forward(self.h, x.data_ptr(), int(train), C.byref(ptr), self._stream()), "forward")
         off = (ptr.value - self.arena.data_ptr()) // 4
         return self.arena[off:off + self.B * self.Tout * self.nlabel].view(self.B, self.Tout, self.nlabel)
 
     def forward_backward(self, x, target):
+        self._check_input(x, target)
         ptr = C.c_void_p(0)
         _check(self.L.w2l_trainer_forward_backward(self.h, x.data_ptr(), target.data_ptr(), C.byref(ptr),
                                                    self._stream()), "forward_backward")
@@ -164,6 +184,10 @@ class Trainer:
         return self.arena[off:off + self.B]
 
     def update(self, lr, lrcrit=0.0, momentum=0.0, max_grad_norm=0.0, total_batch=None, clamp_crit=True):
+        """total_batch: None -> this rank's B; a number -> that; 0 (or "reduced") -> the all-reduced batch size that
+        rode in the gradient arena's tail (data-parallel runs)"""
+        if total_batch == "reduced":
+            total_batch = 0
         tb = float(total_batch if total_batch is not None else self.B)
         _check(self.L.w2l_trainer_update(self.h, lr, lrcrit, momentum, max_grad_norm, tb, int(clamp_crit),
                                          self._stream()), "update")
@@ -177,6 +201,12 @@ class Trainer:
         """gradient norm of the last update (synchronises); non-finite => that update was skipped on every rank"""
         n = C.c_double(0.0)
         _check(self.L.w2l_trainer_grad_norm(self.h, C.byref(n), self._stream()), "grad_norm")
+        return n.value
+
+    def skipped_updates(self):
+        """updates skipped because the reduced gradient was non-finite (synchronises)"""
+        n = C.c_uint64(0)
+        _check(self.L.w2l_trainer_skipped_updates(self.h, C.byref(n), self._stream()), "skipped_updates")
         return n.value
 
     def set_step(self, step):
