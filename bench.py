@@ -74,6 +74,14 @@ def parse():
     return ap.parse_args()
 
 
+_T0 = time.perf_counter()
+
+
+def note(msg):
+    """progress on stderr (the JSON line is the only thing on stdout): which leg is running, since when"""
+    print(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def make_batch(B, T, nfeat, nlabel, Lmax, seed, device):
     g = torch.Generator(device="cpu").manual_seed(seed)
     x = torch.randn(B, nfeat, T, generator=g, dtype=torch.float32)  # reference input (T,NFEAT,1,B)
@@ -227,14 +235,24 @@ def asg_stress(device, L, T, oracle_checks=True):
     if oracle_checks:
         # outside the timed region: utterance 0 of the TIMED forward (fp32 exp-domain rescaling over T dependent steps at
         # N = 9998) against the fp64 log-domain oracle: 1.5e11 log-sum-exp terms on the host cores, label loop threaded
+        # The oracle costs N^2 log-sum-exp terms per frame: it is calibrated on 3 frames and then given the first Tc
+        # frames that fit ~12 s of host time (the full T = 1500 recursion against fp64 is a -m gpu test at N = 1000:
+        # tests/test_gpu_parity_shapes.py::test_fcc_long_recursion_t1500_matches_fp64_oracle)
         from oracle import pyoracle as O
+        An = crit.transitions.detach().cpu().numpy()
+        x0 = x[0:1].detach().cpu().numpy()
         t3 = time.perf_counter()
-        o = O.FCC(x[0:1].detach().cpu().numpy(), crit.transitions.detach().cpu().numpy(), np.array([8], np.int32), 4)
-        want = float(o.forward()[0])
-        got = float(loss[0].item())
-        check = {"what": f"FCC loss of utterance 0 (T={T}, N={N}) vs fp64 oracle", "got": got, "oracle": want,
-                 "rel_err": abs(got - want) / max(1.0, abs(want)), "ok": bool(abs(got - want) < 1e-4 * max(1.0, abs(want))),
-                 "oracle_seconds": round(time.perf_counter() - t3, 1)}
+        O.FCC(np.ascontiguousarray(x0[:, :3]), An, np.array([8], np.int32), 4).forward()
+        per_frame = max(1e-4, (time.perf_counter() - t3) / 2)
+        Tc = int(max(4, min(T, 12.0 / per_frame)))
+        note(f"stress oracle check: {per_frame * 1e3:.0f} ms per frame on the host -> first {Tc} frames")
+        xc = np.ascontiguousarray(x0[:, :Tc])
+        want = float(O.FCC(xc, An, np.array([8], np.int32), 4).forward()[0])
+        with torch.no_grad():
+            got = float(crit(torch.from_numpy(xc).to(device), tgt[0:1])[0].item())
+        check = {"what": f"FCC loss of utterance 0 over its first {Tc} frames (N={N}, random transitions) vs fp64 oracle",
+                 "frames": Tc, "got": got, "oracle": want, "rel_err": abs(got - want) / max(1.0, abs(want)),
+                 "ok": bool(abs(got - want) < 1e-4 * max(1.0, abs(want))), "oracle_seconds": round(time.perf_counter() - t3, 1)}
     step_bytes = 4.0 * N * N + 8.0 * B * N
     fwd_ms, bwd_ms = (t1 - t0) * 1e3, (t2 - t1) * 1e3
     return {"shape": f"B={B},T={T},N={N}", "fwd_ms": round(fwd_ms, 2), "bwd_ms": round(bwd_ms, 2),
@@ -258,17 +276,25 @@ def cpu_baseline(nfeat, nlabel, T, batch=8):
     from oracle import pyoracle as O
     from oracle import torchnet
     from wav2letter_amd import recipes
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))   # what this process may actually use (cgroup / affinity), not the socket
+    except AttributeError:
+        cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
+    O.set_num_threads(cores)
     t0 = time.perf_counter()
-    # size the sample: one probe step, then as many timed runs as fit in the budget
-    probe, _ = torchnet.tds_ctc_step_seconds(recipes.tds_ctc_arch(), nfeat, nlabel, batch, T, warmup=0, runs=1)
-    runs = int(max(1, min(5, (30.0 - probe) / max(probe, 1e-3) - 1)))
-    med, times = torchnet.tds_ctc_step_seconds(recipes.tds_ctc_arch(), nfeat, nlabel, batch, T, warmup=1, runs=runs)
+    # size the sample: a one-utterance probe step, then the batch and as many timed runs as fit ~30 s
+    probe, _ = torchnet.tds_ctc_step_seconds(recipes.tds_ctc_arch(), nfeat, nlabel, 1, T, warmup=0, runs=1)
+    note(f"cpu baseline probe: 1 utterance in {probe:.2f} s on {cores} cores")
+    batch = int(max(1, min(batch, 6.0 / max(probe, 1e-3))))       # a step of `batch` utterances within ~6 s
+    est = probe * max(1.0, batch * 0.6)
+    runs = int(max(1, min(5, 24.0 / max(est, 1e-3) - 2)))
+    warm = 2 if runs >= 3 else 1
+    med, times = torchnet.tds_ctc_step_seconds(recipes.tds_ctc_arch(), nfeat, nlabel, batch, T, warmup=warm, runs=runs)
     return {"value": round(batch / med, 4), "unit": "utterances/sec", "cores": cores, "kind": "proxy(torch-cpu+oracle)",
             "torch_threads": torch.get_num_threads(), "oracle_threads": O.num_threads(),
             "sample": f"{batch} utterances x {T} frames, TDS-CTC training step (forward + CTC + backward, no optimizer), "
-                      f"torch-CPU oneDNN/MKL network + OpenMP oracle CTC; 2 warm-ups, median of {runs} runs "
+                      f"torch-CPU oneDNN/MKL network + OpenMP oracle CTC; {warm} warm-up(s), median of {runs} run(s) "
                       f"({', '.join(f'{t:.2f}' for t in times)} s); {time.perf_counter() - t0:.1f} s of CPU work"}
 
 
@@ -381,6 +407,7 @@ def main():
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
+    note(f"headline: {a.steps} steps in {dt:.2f} s")
     last_loss = float(loss.float().mean().item())
     # the global batch the optimizer divided by: read back from the (all-reduced) arena tail, not assumed
     total_batch = int(round(tr.grads_full[tr.n_floats].item())) if reducer is not None else B
@@ -442,6 +469,7 @@ def main():
     }
     def leg(key, fn):
         # the additional legs never take the headline line down with them: a failure is reported in place
+        note(f"leg {key} ...")
         try:
             out[key] = fn()
         except Exception as e:  # noqa: BLE001
@@ -460,10 +488,12 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if world == 1 and not a.no_cpu_baseline:
+        note("leg cpu_baseline ...")
         try:
             out["cpu_baseline"] = cpu_baseline(nfeat, nlabel, T, a.cpu_baseline_batch)
         except Exception as e:  # noqa: BLE001
             out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+    note("done")
     print(json.dumps(out), flush=True)
 
 

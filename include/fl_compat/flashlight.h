@@ -1,0 +1,279 @@
+/*
+ * fl_compat/flashlight.h -- the Flashlight (<= 0.3.2) surface the wav2letter recipes' Trainer touches on the
+ * acoustic-training hot path, re-hosted on libw2l_hip.so (hand-written HIP for gfx950; no ArrayFire).
+ *
+ * BASELINE.json north_star: "host code stays C++ and exposes the same fl::Module / SequenceCriterion /
+ * fl::app::asr::Trainer surface so recipes/ configs load unchanged".  What is mirrored, with the reference file:line
+ * that shows each shape (Flashlight itself is un-vendored, so the in-repo USES are the witnesses):
+ *
+ *   af::dim4, af::array (device buffer + dims in ArrayFire order, d0 fastest)    every call site below
+ *   fl::Variable, fl::input / fl::noGrad, .array() .dims() .grad() .backward()   recipes/slimIPL/src/Train.cpp:1454-1470, :1718-1720
+ *   fl::Module / Container / Sequential: forward(std::vector<Variable>),
+ *       params(), param(i), setParams(), train(), eval(), prettyString()         recipes/slimIPL/100h_supervised.cpp:37-75; Train.cpp:396-401
+ *   fl::pkg::runtime::ModulePlugin(path).arch(nFeature, nLabel)
+ *       -> dlopen + extern "C" fl::Module* createModule(int64_t, int64_t)        recipes/slimIPL/100h_supervised.cpp:84-87; Train.cpp:390-395
+ *   fl::pkg::speech::buildSequentialModule(archfile, nFeatures, nClasses)        recipes/joint_training_vox_populi/cpc/SequentialBuilder.h:23-26
+ *   fl::pkg::speech::SequenceCriterion { forward({emission (N,T,B), target (L,B)}) -> {loss (B)},
+ *       viterbiPath(input, inputSize), viterbiPathWithTarget, prettyString }     recipes/joint_training_vox_populi/cpc/CPCCriterion.h:30-50
+ *   ASGLoss(N, scaleMode, transdiag), CTCLoss(scaleMode), getCriterionScaleMode  recipes/slimIPL/src/Train.cpp:389, :406-410
+ *   fl::SGDOptimizer(params, lr, momentum, wd), zeroGrad(), step(), setLr();
+ *       fl::clipGradNorm(params, maxNorm)                                         recipes/slimIPL/src/Train.cpp:577-582, :1718, :1791-1802
+ *
+ * Not ArrayFire: af::array here is only a ref-counted device buffer with dims and a dtype (f32 / s32) -- enough to
+ * carry tensors across this boundary; arithmetic on arrays belongs to the kernels behind the modules.  Memory order
+ * is ArrayFire's (column-major, d0 fastest), so an (N, T, B) emission array IS the [B][T][N] buffer of the C ABI.
+ *
+ * The network built from an arch file is ONE planned pipeline (static layer list, activations in one arena, the
+ * parameters / gradients in flat arenas: w2l_host.hpp); fl::Sequential::modules() lists its lines for prettyString
+ * and parameter bookkeeping, the forward / backward run as a whole.  A plugin module (createModule) composes such
+ * pipelines; a free-form layer zoo with per-op autograd is outside the hot path and is not provided.
+ */
+#pragma once
+#include <stdint.h>
+
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#define FL_COMPAT_API __attribute__((visibility("default")))
+
+namespace af {
+typedef long long dim_t;
+
+class FL_COMPAT_API dim4 {
+ public:
+  dim_t dims[4];
+  dim4(dim_t d0 = 1, dim_t d1 = 1, dim_t d2 = 1, dim_t d3 = 1) : dims{d0, d1, d2, d3} {}
+  dim_t elements() const { return dims[0] * dims[1] * dims[2] * dims[3]; }
+  dim_t ndims() const {
+    if (elements() == 0) return 0;
+    for (int i = 3; i > 0; --i) if (dims[i] != 1) return i + 1;
+    return 1;
+  }
+  dim_t& operator[](int i) { return dims[i]; }
+  const dim_t& operator[](int i) const { return dims[i]; }
+  bool operator==(const dim4& o) const { return dims[0] == o.dims[0] && dims[1] == o.dims[1] && dims[2] == o.dims[2] && dims[3] == o.dims[3]; }
+  bool operator!=(const dim4& o) const { return !(*this == o); }
+};
+
+enum dtype { f32 = 0, s32 = 5 };  // ArrayFire's enumerator values
+
+// ref-counted device buffer; copies share storage (like af::array handles)
+class FL_COMPAT_API array {
+ public:
+  array() {}
+  explicit array(const dim4& dims, dtype ty = f32);                       // uninitialised
+  array(const dim4& dims, const float* host);                             // afHost source
+  array(const dim4& dims, const int* host);
+  // fl_compat extension: a view over memory somebody else owns (`owner` keeps it alive; may be null)
+  static array wrap(void* dev, const dim4& dims, dtype ty, std::shared_ptr<void> owner = nullptr);
+  dim4 dims() const { return dims_; }
+  dim_t dims(int i) const { return dims_[i]; }
+  dim_t elements() const { return ptr_ ? dims_.elements() : 0; }
+  dtype type() const { return type_; }
+  bool isempty() const { return elements() == 0; }
+  size_t bytes() const { return (size_t)elements() * 4; }
+  template <class T> T* device() const { return (T*)ptr_; }                // raw device pointer (no lock bookkeeping)
+  void unlock() const {}
+  template <class T> void host(T* out) const { hostCopy((void*)out); }     // synchronous device -> host
+  template <class T> T scalar() const { T v[1]; if (elements() < 1) throw std::invalid_argument("scalar() of an empty array"); firstElement((void*)v); return v[0]; }
+  array copy() const;                                                     // deep copy
+
+ private:
+  void hostCopy(void* out) const;
+  void firstElement(void* out) const;
+  std::shared_ptr<void> owner_;
+  void* ptr_ = nullptr;
+  dim4 dims_{0, 0, 0, 0};
+  dtype type_ = f32;
+};
+
+FL_COMPAT_API array constant(double v, const dim4& dims, dtype ty = f32);
+FL_COMPAT_API void sync();          // wait for the stream every fl_compat call enqueues on
+}  // namespace af
+
+namespace fl {
+
+FL_COMPAT_API void* currentStream();                 // hipStream_t the facade enqueues on (default: a private non-blocking stream)
+FL_COMPAT_API void setCurrentStream(void* stream);
+
+class FL_COMPAT_API Variable {
+ public:
+  using GradFunc = std::function<void(std::vector<Variable>& inputs, const Variable& gradOutput)>;
+  Variable() : s_(std::make_shared<Shared>()) {}
+  Variable(af::array data, bool calcGrad) : s_(std::make_shared<Shared>()) { s_->data = std::move(data); s_->calcGrad = calcGrad; }
+  Variable(af::array data, std::vector<Variable> inputs, GradFunc gradFunc);
+  af::array& array() const { return s_->data; }
+  Variable& grad() const;
+  bool isCalcGrad() const { return s_->calcGrad; }
+  bool isGradAvailable() const { return s_->grad != nullptr; }
+  af::dim4 dims() const { return s_->data.dims(); }
+  af::dim_t dims(int i) const { return s_->data.dims(i); }
+  af::dim_t elements() const { return s_->data.elements(); }
+  af::dtype type() const { return s_->data.type(); }
+  bool isempty() const { return s_->data.isempty(); }
+  void setCalcGrad(bool b) { s_->calcGrad = b; }
+  void addGrad(const Variable& g);            // accumulates (axpy on the device) like Flashlight
+  void zeroGrad() { s_->grad.reset(); }
+  void backward(bool retainGraph = false);    // d/d(this) with an all-ones seed (a loss vector of B utterances: sum)
+  void backward(const Variable& grad, bool retainGraph = false);
+  template <class T> T scalar() const { return s_->data.scalar<T>(); }
+  template <class T> void host(T* p) const { s_->data.host(p); }
+
+ private:
+  struct Shared {
+    af::array data;
+    std::unique_ptr<Variable> grad;
+    bool calcGrad = false;
+    std::vector<Variable> inputs;
+    GradFunc gradFunc;
+  };
+  std::shared_ptr<Shared> s_;
+  friend struct VariableAccess;
+};
+
+inline Variable input(const af::array& a) { return Variable(a, false); }
+inline Variable noGrad(const af::array& a) { return Variable(a, false); }
+inline Variable param(const af::array& a) { return Variable(a, true); }
+
+class FL_COMPAT_API Module {
+ public:
+  virtual ~Module() {}
+  std::vector<Variable> params() const { return params_; }
+  Variable param(int i) const { return params_.at(i); }
+  virtual void setParams(const Variable& var, int position);
+  virtual void train() { train_ = true; }
+  virtual void eval() { train_ = false; }
+  bool isTrainMode() const { return train_; }
+  void zeroGrad() { for (auto& p : params_) p.zeroGrad(); }
+  virtual std::vector<Variable> forward(const std::vector<Variable>& inputs) = 0;
+  std::vector<Variable> operator()(const std::vector<Variable>& inputs) { return forward(inputs); }
+  virtual std::string prettyString() const = 0;
+
+ protected:
+  std::vector<Variable> params_;
+  bool train_ = true;
+};
+
+class FL_COMPAT_API Container : public Module {
+ public:
+  void add(std::shared_ptr<Module> m);                       // the child's parameters join params()
+  std::shared_ptr<Module> module(int i) const { return modules_.at(i); }
+  std::vector<std::shared_ptr<Module>> modules() const { return modules_; }
+  void train() override { train_ = true; for (auto& m : modules_) m->train(); }
+  void eval() override { train_ = false; for (auto& m : modules_) m->eval(); }
+  void setParams(const Variable& var, int position) override;
+
+ protected:
+  std::vector<std::shared_ptr<Module>> modules_;
+  std::vector<int> childOfParam_, childIndexOfParam_;
+};
+
+// user-composed chain: output of module i feeds module i + 1
+class FL_COMPAT_API Sequential : public Container {
+ public:
+  std::vector<Variable> forward(const std::vector<Variable>& inputs) override;
+  Variable forward(const Variable& in) { return forward(std::vector<Variable>{in}).front(); }
+  std::string prettyString() const override;
+};
+
+// ---- optimizers (recipes/slimIPL/src/Train.cpp:577-582: SGDOptimizer(params, lr, momentum, weightdecay))
+class FL_COMPAT_API FirstOrderOptimizer {
+ public:
+  FirstOrderOptimizer(const std::vector<Variable>& params, double lr) : parameters_(params), lr_(lr) {}
+  virtual ~FirstOrderOptimizer() {}
+  virtual void step() = 0;
+  double getLr() const { return lr_; }
+  void setLr(double lr) { lr_ = lr; }
+  virtual void zeroGrad() { for (auto& p : parameters_) p.zeroGrad(); }
+  virtual std::string prettyString() const = 0;
+
+ protected:
+  std::vector<Variable> parameters_;
+  double lr_;
+};
+
+class FL_COMPAT_API SGDOptimizer : public FirstOrderOptimizer {
+ public:
+  SGDOptimizer(const std::vector<Variable>& params, double lr, double momentum = 0, double weightDecay = 0, bool useNesterov = false);
+  void step() override;
+  std::string prettyString() const override;
+
+ private:
+  double mu_, wd_;
+  bool nesterov_;
+  std::vector<af::array> velocities_;
+};
+
+// global-norm clipping over the gradients that are available; returns the norm before clipping
+FL_COMPAT_API double clipGradNorm(const std::vector<Variable>& params, double maxNorm);
+
+namespace pkg {
+namespace runtime {
+// dlopen(path, RTLD_LAZY) + dlsym("createModule"): extern "C" fl::Module* createModule(int64_t nFeature, int64_t nLabel)
+// returns an OWNING raw pointer (recipes/slimIPL/100h_supervised.cpp:84-87; loader call Train.cpp:390-395).
+// A name that ends in ".arch" is not a plugin: arch() then goes through buildSequentialModule, which is what the
+// reference's `--arch` flag does when it names an arch file.
+class FL_COMPAT_API ModulePlugin {
+ public:
+  explicit ModulePlugin(const std::string& name);
+  ~ModulePlugin();
+  std::shared_ptr<fl::Module> arch(int64_t nFeatures, int64_t nClasses);
+
+ private:
+  std::string name_;
+  void* handle_ = nullptr;
+  fl::Module* (*create_)(int64_t, int64_t) = nullptr;
+};
+}  // namespace runtime
+
+namespace speech {
+enum class CriterionScaleMode { NONE = 0, INPUT_SZ = 1, INPUT_SZ_SQRT = 2, TARGET_SZ = 3, TARGET_SZ_SQRT = 4 };
+FL_COMPAT_API CriterionScaleMode getCriterionScaleMode(const std::string& onorm, bool sqnorm);
+
+// arch file -> network.  forward({features (T, NFEAT, 1, B) f32 [, inputSizes]}) -> {emissions (NLABEL, T', B)}
+FL_COMPAT_API std::shared_ptr<fl::Sequential> buildSequentialModule(const std::string& archfile, int64_t nFeatures, int64_t nClasses);
+FL_COMPAT_API std::shared_ptr<fl::Sequential> buildSequentialModuleFromText(const std::string& archText, int64_t nFeatures, int64_t nClasses);
+
+class FL_COMPAT_API SequenceCriterion : public fl::Container {
+ public:
+  // inputs {emission (N, T, B) f32, target (L, B) s32 (padded with negative values)} -> {loss (B)}
+  std::vector<Variable> forward(const std::vector<Variable>& inputs) override = 0;
+  virtual af::array viterbiPath(const af::array& input, const af::array& inputSize = af::array()) = 0;              // (T, B) s32
+  virtual af::array viterbiPathWithTarget(const af::array& input, const af::array& target,
+                                          const af::array& inputSizes = af::array(), const af::array& targetSizes = af::array()) = 0;
+  std::string prettyString() const override = 0;
+};
+
+class FL_COMPAT_API ASGLoss : public SequenceCriterion {
+ public:
+  ASGLoss(int N, CriterionScaleMode scalemode = CriterionScaleMode::NONE, double transdiag = 0.0);
+  std::vector<Variable> forward(const std::vector<Variable>& inputs) override;
+  af::array viterbiPath(const af::array& input, const af::array& inputSize = af::array()) override;
+  af::array viterbiPathWithTarget(const af::array& input, const af::array& target, const af::array& inputSizes = af::array(),
+                                  const af::array& targetSizes = af::array()) override;
+  std::string prettyString() const override;
+  Variable transitions() const { return params_[0]; }   // (N, N), [to][from]
+
+ private:
+  int N_;
+  CriterionScaleMode scaleMode_;
+};
+
+class FL_COMPAT_API CTCLoss : public SequenceCriterion {
+ public:
+  explicit CTCLoss(CriterionScaleMode scalemode = CriterionScaleMode::NONE);
+  std::vector<Variable> forward(const std::vector<Variable>& inputs) override;
+  af::array viterbiPath(const af::array& input, const af::array& inputSize = af::array()) override;   // per-frame argmax
+  af::array viterbiPathWithTarget(const af::array& input, const af::array& target, const af::array& inputSizes = af::array(),
+                                  const af::array& targetSizes = af::array()) override;
+  std::string prettyString() const override;
+
+ private:
+  CriterionScaleMode scaleMode_;
+};
+}  // namespace speech
+}  // namespace pkg
+}  // namespace fl

@@ -1,0 +1,128 @@
+"""The fl:: C++ surface (include/fl_compat/flashlight.h) driven by a COMPILED C++ caller (tests/cpp/fl_compat_test.cpp,
+built by __graft_entry__.build() with plain g++ against libw2l_hip.so), checked against the oracle:
+
+  * fl::pkg::speech::ASGLoss / CTCLoss: forward({emission (N,T,B), target (L,B)}) -> loss (B), loss.backward(),
+    param(0).grad(), viterbiPath, viterbiPathWithTarget  (reference shapes: cpc/CPCCriterion.h:30-50, Train.cpp:406-410)
+  * buildSequentialModule / ModulePlugin(dlopen createModule) + SGDOptimizer + clipGradNorm: one training step in the
+    reference's order (Train.cpp:1454-1804) equals the same step through the ctypes Trainer
+"""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "fl_compat_test")
+PLUGIN = os.path.join(ROOT, "tests", "cpp", "libplugin_model.so")
+TOL = 1e-4
+
+
+def run(args):
+    if not os.path.exists(BIN):
+        pytest.fail(f"{BIN} missing: __graft_entry__.build() compiles it (make -C tests/cpp)")
+    out = subprocess.run([BIN] + args, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    return out.stdout
+
+
+@pytest.mark.parametrize("kind,mode,B,T,N,L", [("asg", 4, 3, 60, 30, 20), ("asg", 0, 2, 9, 100, 5), ("ctc", 4, 3, 40, 50, 12)])
+def test_criteria_through_compiled_cpp(oracle, tmp_path, kind, mode, B, T, N, L):
+    rng = np.random.default_rng(B * 100 + T)
+    em = rng.normal(size=(B, T, N)).astype(np.float32)
+    tgt = np.full((B, L), -1, np.int32)
+    for b in range(B):
+        l = int(rng.integers(1, min(L, T) + 1))
+        tgt[b, :l] = rng.integers(0, N - 1, size=l)
+    A = (rng.normal(size=(N, N)) * 0.3 + 2 * np.eye(N)).astype(np.float32)
+    gw = rng.uniform(0.5, 1.5, size=B).astype(np.float32)
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<4i", N, T, B, L))
+        f.write(em.tobytes()); f.write(tgt.tobytes()); f.write(A.tobytes()); f.write(gw.tobytes())
+    stdout = run(["crit", kind, str(mode), fin, fout])
+    raw = open(fout, "rb").read()
+    off = 0
+
+    def take(n, dt):
+        nonlocal off
+        a = np.frombuffer(raw, dt, n, off)
+        off += 4 * n
+        return a
+    loss = take(B, np.float32)
+    dem = take(B * T * N, np.float32).reshape(B, T, N)
+    if kind == "asg":
+        assert "AutoSegmentationCriterion" in stdout
+        dA = take(N * N, np.float32).reshape(N, N)
+        path = take(B * T, np.int32).reshape(B, T)
+        fpath = take(B * T, np.int32).reshape(B, T)
+        ol, odx, odA = oracle.asg(em, A, tgt, mode, grad=gw.astype(np.float64))
+        assert np.abs(dA - odA).max() < TOL * np.abs(odA).max()
+        assert (path == oracle.viterbi(em, A)).all()
+        fac = oracle.FAC(em, A, tgt, scale_mode=mode)
+        fac.forward()
+        assert (fpath == fac.viterbi()).all()
+    else:
+        assert "ConnectionistTemporalClassificationCriterion" in stdout
+        path = take(B * T, np.int32).reshape(B, T)
+        o = oracle.CTC(em, tgt, scale_mode=mode)
+        ol = o.forward()
+        odx = o.backward(gw.astype(np.float64))
+        assert (path == oracle.ctc_viterbi(em)).all()
+    assert off == len(raw)
+    assert np.abs(loss - ol).max() < TOL * max(1.0, np.abs(ol).max())
+    assert np.abs(dem - odx).max() < TOL * np.abs(odx).max()
+
+
+@pytest.mark.parametrize("via", ["arch", "plugin"])
+def test_training_step_through_fl_surface_equals_trainer(tmp_path, via):
+    """network from an arch FILE (buildSequentialModule) or from a dlopen'ed createModule plugin, CTCLoss, zeroGrad,
+    loss.backward(), grads / batch, clipGradNorm, SGD steps -- the compiled C++ caller reproduces the ctypes Trainer's
+    losses before and after the update (same init seed, dropout off)"""
+    from wav2letter_amd import recipes
+    from wav2letter_amd.trainer import Trainer
+    nfeat, nlabel, B, T, L = 8, 12, 3, 40, 5
+    arch = ("V -1 NFEAT 1 0\nC2 1 4 5 1 2 1 -1 -1\nR\nDO 0.0\nLN 0 1 2\n"
+            f"TDS 4 5 {nfeat} 0.0 {4 * nfeat * 2}\nTDS 4 5 {nfeat} 0.0 0\nV 0 {4 * nfeat} 1 0\nRO 1 0 3 2\nL {4 * nfeat} NLABEL\n")
+    rng = np.random.default_rng(21)
+    x = rng.normal(size=(B, nfeat, T)).astype(np.float32)
+    tgt = rng.integers(0, nlabel - 1, size=(B, L)).astype(np.int32)
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<3i", T, B, L))
+        f.write(x.tobytes()); f.write(tgt.tobytes())
+    if via == "arch":
+        target = str(tmp_path / "net.arch")
+        open(target, "w").write(arch)
+    else:
+        target = PLUGIN
+        assert os.path.exists(PLUGIN)
+    stdout = run(["net", target, str(nfeat), str(nlabel), fin, fout])
+    assert "TDS" in stdout or "Model" in stdout
+    raw = open(fout, "rb").read()
+    l0 = np.frombuffer(raw, np.float32, B, 0)
+    l1 = np.frombuffer(raw, np.float32, B, 4 * B)
+    checksum = np.frombuffer(raw, np.float32, 1, 8 * B)[0]
+    nparams = np.frombuffer(raw, np.int32, 1, 8 * B + 4)[0]
+    gnorm = np.frombuffer(raw, np.float32, 1, 8 * B + 8)[0]
+
+    tr = Trainer(arch, nfeat, nlabel, "ctc", 4)
+    tr.init_params(seed=1)     # the facade initialises with seed 1 too
+    tr.plan(B, T, L)
+    tr.to_device()
+    xd, td = torch.tensor(x).cuda(), torch.tensor(tgt).cuda()
+    em = tr.forward(xd, train=False)
+    assert abs(em.double().sum().item() - checksum) < 1e-3 * max(1.0, abs(checksum))
+    assert nparams == len(tr.param_table())
+    # the reference step order with dropout-free arch: train-mode forward == eval forward
+    want0 = tr.forward_backward(xd, td).cpu().numpy().copy()
+    tr.update(lr=0.05, momentum=0.5, max_grad_norm=1.0, total_batch=B)
+    want_norm = tr.grad_norm() / B
+    want1 = tr.forward_backward(xd, td).cpu().numpy().copy()
+    assert np.abs(l0 - want0).max() < TOL * np.abs(want0).max()
+    assert abs(gnorm - want_norm) < 1e-3 * want_norm
+    assert np.abs(l1 - want1).max() < 1e-3 * np.abs(want1).max()
+    assert (l1 < l0).any()      # the update did something

@@ -13,7 +13,9 @@
 //     out[u][co]      = sum_{g < G}      Y[u + g*J][(g, co)]                          (overlap-add through LDS)
 // rows tau = 32 consecutive FRAMES of one (utterance, mel row), K = (j, ci) = J*C, columns (g, co) = G*C:
 //     C = 10: G = 3, J = 7 :  30 of  32 columns, K =  70 (35 MFMAs per 32x32 tile)            93.8 % of the lanes useful
-//     C = 14: G = 11, J = 2: 154 of 160 columns, K =  28 (5 column tiles x 14 MFMAs), 21/22 taps    91.9 %
+//     C = 14: G = 2, J = 11 :  28 of  32 columns, K = 154 (77 MFMAs), 21 of 22 taps                  83.5 %
+//             (G = 11, J = 2 would use 91.9 % of the lanes but needs 80 overlap-add registers per 70 MFMAs, and rows
+//              4 apart collide inside ONE instruction when J divides 4)
 //     C = 18: G = 7, J = 3 : 126 of 128 columns, K =  54 (4 column tiles x 27 MFMAs)                98.4 %
 // v_mfma_f32_32x32x2_f32 issues every 64 cycles (twice the 16x16x4 budget per instruction) and
 //   * the B operand (the weights of a column tile) lives in REGISTERS for the whole persistent kernel
@@ -21,9 +23,13 @@
 //   * the A operand is one ds_read_b32 per K step and row tile, shared by all column tiles (the slab is stored
 //     TIME-FASTEST, slab[(h, ci)][frame], so the 32 lanes of a fragment read 32 consecutive floats: conflict-free,
 //     and every (j, ci) of the K loop is an immediate offset from one address VGPR);
-//   * the overlap-add is 16 ds_add_f32 per 32x32 accumulator tile into out[(h, co)][u] -- every output address is
-//     only ever touched by ONE wave (a wave owns a mel row and walks its frames in order), so the sum order is
-//     program order: run-to-run deterministic, no cross-wave atomics.
+//   * the overlap-add is a read-modify-write of out[(h, co)][u] in LDS by the ONE wave that owns the mel row (it walks
+//     its frames in order; a wave's LDS operations execute in issue order), so there are no atomics and the sum order
+//     is program order: run-to-run deterministic.  (ds_add_f32 was measured at ~0.6 us per wave-instruction on
+//     MI355X -- 1300+ cycles, lanes serialised -- which made the first version 3-9x SLOWER than conv_tds.hip:
+//     profiles/r02_run1_conv_rs_ds_add.log.)  Two accumulator registers can target the same output address from
+//     different lanes (rows that differ by a multiple of J), so the 16 registers of a tile are coloured at compile
+//     time into rounds of mutually disjoint registers: read round, add, write round, next round.
 // The price of the overlap-add is a halo of (G-1)*J Y rows per time block (they only feed outputs of the
 // neighbouring block): blocks are cut so that blockLen + halo is a whole number of 32-row tiles.
 //
@@ -64,6 +70,41 @@ struct RsCfg {
   static constexpr int XV = (NFMAX * Q + 255) / 256;    // pieces per thread
   static constexpr size_t LDS = (size_t)(ROWS * FT + (ROWS + 1) * OT) * sizeof(float);
   static_assert(C % 2 == 0 && ROWS % 4 == 0, "channel count");
+};
+
+// Overlap-add rounds.  Register q = 4i + jj of a 32x32 accumulator holds rows 8i + jj (lanes 0-31) and 8i + jj + 4
+// (lanes 32-63).  Lanes of different tap groups add rows that differ by d*J (0 < d < G) into the same output frame,
+// so two registers conflict when any of their rows differ by such a multiple; greedy colouring at compile time.
+template <int G, int J>
+struct RsRounds {
+  static_assert(!(4 % J == 0 && 4 / J < G), "rows 4 apart (the two lane halves of one register) must not collide");
+  static constexpr bool conflict(int a, int b) {
+    const int ra = 8 * (a / 4) + (a % 4), rb = 8 * (b / 4) + (b % 4);
+    for (int ha = 0; ha < 2; ++ha)
+      for (int hb = 0; hb < 2; ++hb) {
+        int d = (ra + 4 * ha) - (rb + 4 * hb);
+        if (d < 0) d = -d;
+        if (d != 0 && d % J == 0 && d / J < G) return true;
+      }
+    return false;
+  }
+  struct Table { int color[16]; int n; };
+  static constexpr Table make() {
+    Table t{};
+    t.n = 0;
+    for (int q = 0; q < 16; ++q) {
+      int c = 0;
+      for (;; ++c) {
+        bool ok = true;
+        for (int r = 0; r < q; ++r)
+          if (t.color[r] == c && conflict(q, r)) ok = false;
+        if (ok) break;
+      }
+      t.color[q] = c;
+      if (c + 1 > t.n) t.n = c + 1;
+    }
+    return t;
+  }
 };
 
 template <int C, int G, int J, int KTMAX>
@@ -161,11 +202,21 @@ __global__ __launch_bounds__(256, 2) void tds_conv_rs_k(TdsRsP p, int nTiles) {
         for (int s = 0; s < NK; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bw[ct][s], acc, 0, 0, 0);
         // D: column = lane & 31, rows 8i + 4 (lane >> 5) + jj  ->  out[(wave, co)][tau - g*J]
         float* o = outA + ob[ct] + 32 * kti;
+        constexpr auto rounds = RsRounds<G, J>::make();
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int c = 0; c < rounds.n; ++c) {
+          // the reads of this round must be ISSUED after the writes of the previous one (other lanes' addresses):
+          // a compiler-level fence; the LDS itself executes a wave's operations in order
+          asm volatile("" ::: "memory");
+          float old[16];
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj)
-            __hip_atomic_fetch_add(o + 8 * i + jj, acc[4 * i + jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          for (int q = 0; q < 16; ++q)
+            if (rounds.color[q] == c) old[q] = o[8 * (q / 4) + (q % 4)];
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            if (rounds.color[q] == c) o[8 * (q / 4) + (q % 4)] = old[q] + acc[q];
+        }
+        asm volatile("" ::: "memory");
       }
     }
     __syncthreads();
@@ -235,12 +286,12 @@ bool tds_rs_try(const float* x, const float* w, const float* bias, const float* 
   p.x = x; p.w = w; p.bias = bias; p.add = add; p.y = y;
   p.B = B; p.Tin = Tin; p.Tout = Tout; p.H = H; p.kw = kw; p.padl = padl; p.relu = relu; p.accum = accum; p.flip = flip;
   const bool planned = C == 10 ? rs_plan(Tout, RsCfg<10, 3, 7, 6>::HALO, 6, p)
-                     : C == 14 ? rs_plan(Tout, RsCfg<14, 11, 2, 5>::HALO, 5, p) : rs_plan(Tout, RsCfg<18, 7, 3, 4>::HALO, 4, p);
+                     : C == 14 ? rs_plan(Tout, RsCfg<14, 2, 11, 5>::HALO, 5, p) : rs_plan(Tout, RsCfg<18, 7, 3, 4>::HALO, 4, p);
   if (!planned) return false;
   prof_begin(s, 2.0 * B * Tout * (double)H * kw * C * C, profKind);
   int st;
   if (C == 10) st = rs_launch<10, 3, 7, 6>(p, s);
-  else if (C == 14) st = rs_launch<14, 11, 2, 5>(p, s);
+  else if (C == 14) st = rs_launch<14, 2, 11, 5>(p, s);
   else st = rs_launch<18, 7, 3, 4>(p, s);
   prof_end(s);
   if (st == W2L_OK && hipGetLastError() != hipSuccess) st = W2L_EHIP;

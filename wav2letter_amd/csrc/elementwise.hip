@@ -161,6 +161,37 @@ __global__ __launch_bounds__(kEwThreads) void residual_ln_small_k(
   }
 }
 
+// Same op for a group size that is not a multiple of 4 (the reference's TDSBlock golden vector: inner = 5 mel rows x
+// 2 channels = 10): scalar loads, one block per group, forward only.  Not on the training hot path.
+__global__ __launch_bounds__(kEwThreads) void residual_ln_scalar_k(
+    float* __restrict__ a, const float* __restrict__ x, float* __restrict__ r, float* __restrict__ y,
+    float* __restrict__ meanRstd, size_t inner, const float* __restrict__ gammaBeta, float eps,
+    uint32_t thr, float keepScale, uint32_t seed, uint32_t stream) {
+  __shared__ double bc[2];
+  const int g = blockIdx.x;
+  const size_t base = (size_t)g * inner;
+  double s = 0, ss = 0;
+  for (size_t i = threadIdx.x; i < inner; i += kEwThreads) {
+    const size_t e = base + i;
+    float av = a[e];
+    if (thr) { av = keep_elem(e, seed, stream, thr) ? av * keepScale : 0.f; a[e] = av; }
+    const float rv = (x ? x[e] : 0.f) + av;
+    r[e] = rv;
+    s += (double)rv;
+    ss += (double)(rv * rv);
+  }
+  block_partial2(s, ss, bc);
+  __syncthreads();
+  const double mu = bc[0] / (double)inner;
+  double var = bc[1] / (double)inner - mu * mu;
+  if (var < 0) var = 0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float muf = (float)mu;
+  if (threadIdx.x == 0) { meanRstd[2 * g] = muf; meanRstd[2 * g + 1] = rstd; }
+  const float gam = gammaBeta[0] * rstd, bet = gammaBeta[1];
+  for (size_t i = threadIdx.x; i < inner; i += kEwThreads) y[base + i] = (r[base + i] - muf) * gam + bet;
+}
+
 // backward reduce: part[g][bx] = (sum dy, sum dy * xhat), xhat = (r - mu) * rstd
 __global__ __launch_bounds__(kEwThreads) void ln_bwd_reduce_k(const float* __restrict__ r,
                                                              const float* __restrict__ dy,
@@ -482,10 +513,16 @@ W2L_API int w2l_residual_layernorm_forward(int groups, size_t inner, float* a, c
                                            float* y, const float* gammaBeta, float eps, double p,
                                            uint32_t seed, uint32_t rngStream, double* stats,
                                            float* meanRstd, w2l_stream_t stream) {
-  if (groups <= 0 || inner == 0 || (inner & 3) || !a || !r || !y || !gammaBeta || !stats || !meanRstd)
-    return W2L_EINVAL;
+  if (groups <= 0 || inner == 0 || !a || !r || !y || !gammaBeta || !stats || !meanRstd) return W2L_EINVAL;
   const uint32_t thr = dropout_threshold(p);
   const float ks = (float)(1.0 / (1.0 - p));
+  if (inner & 3) {  // odd group sizes (golden-vector geometry): scalar kernel, r must not alias a
+    if (r == a) return W2L_EINVAL;
+    hipLaunchKernelGGL(residual_ln_scalar_k, dim3((unsigned)groups), dim3(kEwThreads), 0, W2L_S, a, x, r, y, meanRstd,
+                       inner, gammaBeta, eps, thr, ks, seed, rngStream);
+    W2L_LAUNCH_CHECK();
+    return W2L_OK;
+  }
   if (inner <= kLnSmall) {
     hipLaunchKernelGGL(residual_ln_small_k, dim3((unsigned)groups), dim3(kEwThreads), 0, W2L_S, a, x, r, y, meanRstd,
                        inner, gammaBeta, eps, thr, ks, seed, rngStream);
