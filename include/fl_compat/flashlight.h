@@ -134,6 +134,11 @@ class FL_COMPAT_API Variable {
   friend struct VariableAccess;
 };
 
+// scalar arithmetic the Trainer uses on losses and gradients (`p.grad() = p.grad() / totalBatchSize`,
+// recipes/slimIPL/src/Train.cpp:1748-1784): results are plain (no-grad) Variables
+FL_COMPAT_API Variable operator*(const Variable& v, double s);
+FL_COMPAT_API Variable operator/(const Variable& v, double s);
+
 inline Variable input(const af::array& a) { return Variable(a, false); }
 inline Variable noGrad(const af::array& a) { return Variable(a, false); }
 inline Variable param(const af::array& a) { return Variable(a, true); }
@@ -247,6 +252,12 @@ class FL_COMPAT_API SequenceCriterion : public fl::Container {
   std::string prettyString() const override = 0;
 };
 
+// fl_compat extension: the flat gradient arena behind a network built from an arch file (one data-parallel
+// all-reduce / one fused optimizer launch instead of one per parameter); {nullptr, 0} for any other module
+struct FlatView { float* ptr; size_t floats; };
+FL_COMPAT_API FlatView flatParameters(const std::shared_ptr<fl::Module>& network);
+FL_COMPAT_API FlatView flatGradients(const std::shared_ptr<fl::Module>& network);
+
 class FL_COMPAT_API ASGLoss : public SequenceCriterion {
  public:
   ASGLoss(int N, CriterionScaleMode scalemode = CriterionScaleMode::NONE, double transdiag = 0.0);
@@ -256,6 +267,7 @@ class FL_COMPAT_API ASGLoss : public SequenceCriterion {
                                   const af::array& targetSizes = af::array()) override;
   std::string prettyString() const override;
   Variable transitions() const { return params_[0]; }   // (N, N), [to][from]
+  CriterionScaleMode scaleMode() const { return scaleMode_; }
 
  private:
   int N_;
@@ -270,6 +282,7 @@ class FL_COMPAT_API CTCLoss : public SequenceCriterion {
   af::array viterbiPathWithTarget(const af::array& input, const af::array& target, const af::array& inputSizes = af::array(),
                                   const af::array& targetSizes = af::array()) override;
   std::string prettyString() const override;
+  CriterionScaleMode scaleMode() const { return scaleMode_; }
 
  private:
   CriterionScaleMode scaleMode_;

@@ -126,3 +126,47 @@ def test_training_step_through_fl_surface_equals_trainer(tmp_path, via):
     assert abs(gnorm - want_norm) < 1e-3 * want_norm
     assert np.abs(l1 - want1).max() < 1e-3 * np.abs(want1).max()
     assert (l1 < l0).any()      # the update did something
+
+
+@pytest.mark.parametrize("recipe", ["tds_ctc", "conv_glu"])
+def test_train_binary_reads_reference_cfg_and_prints_reference_log_keys(tmp_path, recipe):
+    """`Train train --flagsfile=<the reference's train.cfg, unchanged> --rundir=... --archdir=... --tokensdir=...`:
+    the recipe's own flags + arch files drive the C++ Trainer over the fl:: surface; the log line carries the reference's
+    keys in the reference's order (recipes/slimIPL/src/MyLogger.cpp:40-106), 001_log / 001_config land in the run dir"""
+    from wav2letter_amd import recipes
+    exe = os.path.join(ROOT, "wav2letter_amd", "bin", "Train")
+    assert os.path.exists(exe), "build() links wav2letter_amd/bin/Train"
+    d = tmp_path
+    if recipe == "tds_ctc":
+        cfg, arch_rel, arch = recipes.tds_ctc_train_cfg(), "am_arch/am_tds_ctc.arch", recipes.tds_ctc_arch()
+        tokens, ntok = "librispeech-train-all-unigram-10000.tokens", 9997
+        extra = ["--w2l_synth_frames=320", "--batchsize=2", "--w2l_synth_target_len=20"]
+    else:
+        cfg, arch_rel, arch = recipes.conv_glu_train_cfg(), "network.arch", recipes.conv_glu_librispeech_arch()
+        tokens, ntok = "tokens.txt", 28
+        extra = ["--w2l_synth_frames=400", "--batchsize=2", "--w2l_synth_target_len=60", "--linseg=0"]
+    os.makedirs(d / "arch" / os.path.dirname(arch_rel), exist_ok=True)
+    open(d / "arch" / arch_rel, "w").write(arch)
+    os.makedirs(d / "am")
+    open(d / "am" / tokens, "w").write("".join(f"tok{i}\n" for i in range(ntok)))
+    open(d / "train.cfg", "w").write(cfg)
+    cmd = [exe, "train", f"--flagsfile={d / 'train.cfg'}", f"--rundir={d / 'runs'}", f"--archdir={d / 'arch'}",
+           f"--tokensdir={d / 'am'}", "--w2l_synth_updates=3", "--reportiters=1"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("epoch:")]
+    assert len(lines) == 3
+    keys = [kv.split(":")[0].strip() for kv in lines[-1].split(" | ")]
+    assert keys[:18] == ["epoch", "nupdates", "lr", "lrcriterion", "runtime", "bch(ms)", "smp(ms)", "fwd(ms)", "crit-fwd(ms)", "bwd(ms)",
+                         "optim(ms)", "loss", "train-TER", "train-WER", "avg-isz", "avg-tsz", "max-tsz", "avr-batchsz"]
+    vals = dict((kv.split(":")[0].strip(), kv.split(":", 1)[1].strip()) for kv in lines[-1].split(" | "))
+    assert int(vals["nupdates"]) == 3 and float(vals["loss"]) > 0 and np.isfinite(float(vals["loss"]))
+    assert float(vals["fwd(ms)"]) > 0 and float(vals["bwd(ms)"]) > 0
+    name = "am_tds_ctc_librispeech" if recipe == "tds_ctc" else "librispeech_conv_glu"
+    assert os.path.exists(d / "runs" / name / "001_log") and os.path.exists(d / "runs" / name / "001_config")
+    assert "--criterion=" + ("ctc" if recipe == "tds_ctc" else "asg") in open(d / "runs" / name / "001_config").read()
+    crit = "ConnectionistTemporalClassificationCriterion" if recipe == "tds_ctc" else "AutoSegmentationCriterion"
+    assert crit in out.stdout
+    # a bad flag value fails like the reference (exception text, non-zero exit)
+    bad = subprocess.run(cmd + ["--criterion=seq2seq"], capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "criterion" in bad.stderr

@@ -23,6 +23,14 @@ def test_generators_reproduce_reference_arch_files():
 
 
 @need_ref
+def test_generators_reproduce_reference_train_cfgs():
+    """the flags files the `Train` binary is exercised with on the GPU box ARE the reference's (line for line)"""
+    from wav2letter_amd import recipes
+    assert _lines(recipes.tds_ctc_train_cfg()) == _lines(open(f"{REF}/sota/2019/librispeech/train_am_tds_ctc.cfg").read())
+    assert _lines(recipes.conv_glu_train_cfg()) == _lines(open(f"{REF}/conv_glu/librispeech/train.cfg").read())
+
+
+@need_ref
 def test_all_reference_arch_files_parse():
     from wav2letter_amd.trainer import arch_check
     files = sorted(glob.glob(f"{REF}/**/*.arch", recursive=True))

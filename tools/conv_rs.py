@@ -79,7 +79,60 @@ def main():
         # determinism of the overlap-add
         again, _ = run(prod, d, x, w, b, dy, reps=1)
         print("    run-to-run identical:", all(torch.equal(new[k], again[k]) for k in ("y", "dx")))
+        if "--abl" in sys.argv:
+            # timing-only ablations of the role-swapped kernel (probe library): where does the time go?
+            for abl, what in [(0, "full"), (1, "no MFMAs"), (2, "no overlap-add"), (4, "no epilogue"), (8, "no staging/zero"),
+                              (16, "no prefetch"), (3, "no MFMA+add"), (15, "launch + tile loop only")]:
+                os.environ["W2L_TDS_RS_ABL"] = str(abl)
+                with _lib.use_probe() as P:
+                    _, ta = run(P, d, x, w, b, dy, reps=10)
+                os.environ.pop("W2L_TDS_RS_ABL")
+                print(f"    abl {abl:2d} ({what:22s}): fwd {ta['fwd']:7.1f} us")
+
+
+def small_shapes():
+    """the shapes of the reduced full-network test (T = 96 -> 48 / 24 / 12 frames, B = 2): every element of y, dx (with
+    an addend, as the TDS block's backward calls it) against the previous kernels and a float64 reference"""
+    prod = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    for (Cc, T) in [(10, 48), (14, 24), (18, 12), (10, 50), (18, 15), (14, 77), (10, 1), (18, 2)]:
+        B, H, kw = 2, 80, 21
+        d = _lib.ConvDesc(B, T, H, Cc, Cc, kw, 1, 10, 10)
+        g = torch.Generator(device="cpu").manual_seed(Cc * 100 + T)
+        x = torch.randn(B, T, H, Cc, generator=g).cuda()
+        w = (torch.randn(kw, Cc, Cc, generator=g) / (kw * Cc) ** 0.5).cuda()
+        b = torch.randn(Cc, generator=g).cuda()
+        dy = torch.randn(B, T, H, Cc, generator=g).cuda()
+        add = torch.randn(B, T, H, Cc, generator=g).cuda()
+        outs = {}
+        for name, L in (("new", prod), ("old", None)):
+            def go(L):
+                y = torch.empty_like(x); dx = torch.empty_like(x)
+                assert L.w2l_conv_forward(C.byref(d), x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), 1, s) == 0
+                assert L.w2l_conv_backward_data_add(C.byref(d), dy.data_ptr(), w.data_ptr(), add.data_ptr(), dx.data_ptr(), s) == 0
+                torch.cuda.synchronize()
+                return y, dx
+            if L is None:
+                os.environ["W2L_TDS_RS_OFF"] = "1"
+                with _lib.use_probe() as P:
+                    outs[name] = go(P)
+                os.environ.pop("W2L_TDS_RS_OFF")
+            else:
+                outs[name] = go(L)
+        xr = x.double().permute(0, 3, 2, 1).requires_grad_(True)          # [B][C][H][T]
+        wr = w.double().permute(2, 1, 0)[:, :, None, :]
+        yr = F.conv2d(F.pad(xr, (10, 10)), wr, b.double())
+        yr.backward(dy.double().permute(0, 3, 2, 1))
+        ref_y = torch.relu(yr).permute(0, 3, 2, 1)
+        ref_dx = xr.grad.permute(0, 3, 2, 1) + add.double()
+        def e(a, r):
+            return ((a.double() - r).abs().max() / r.abs().max()).item()
+        print(f"small C={Cc} T={T}: new vs fp64 y {e(outs['new'][0], ref_y):.1e} dx+add {e(outs['new'][1], ref_dx):.1e} | "
+              f"old vs fp64 y {e(outs['old'][0], ref_y):.1e} dx+add {e(outs['old'][1], ref_dx):.1e}")
 
 
 if __name__ == "__main__":
-    main()
+    if "--small" in sys.argv:
+        small_shapes()
+    else:
+        main()

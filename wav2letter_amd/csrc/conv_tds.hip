@@ -797,6 +797,8 @@ float* sk_scratch(hipStream_t s, size_t bytes);
 // conv_tds_rs.hip: role-swapped 32x32x2 kernel for the TDS convolutions proper (C -> C, stride 1)
 bool tds_rs_try(const float* x, const float* w, const float* bias, const float* add, float* y, int B, int Tin, int Tout, int H,
                 int C, int kw, int padl, int relu, int accum, int flip, int profKind, hipStream_t s, int* status);
+bool tds_rsf_try(const float* x, const float* dy, float* dw, float* dbias, int B, int Tin, int Tout, int H, int C, int kw, int padl,
+                 hipStream_t s, int* status);
 
 static inline int tds_out_len(int T, int kw, int stride, int padl, int padr) {
   int n = T + padl + padr - kw;
@@ -950,6 +952,10 @@ int tds_conv_backward_data(const w2l_conv_desc* d, const float* dy, const float*
 int tds_conv_backward_filter(const w2l_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
                              hipStream_t s) {
   const int To = tds_out_len(d->T, d->kw, d->stride, d->padl, d->padr);
+  if (d->stride == 1 && d->Cin == d->Cout) {  // the TDS convolutions proper: role-swapped 32x32x2 kernel (conv_tds_rs.hip)
+    int st2 = W2L_OK;
+    if (tds_rsf_try(x, dy, dw, dbias, d->B, d->T, To, d->H, d->Cin, d->kw, d->padl, s, &st2)) return st2;
+  }
   TdsConvP p = make_p(d->B, d->T, To, d->H, d->Cin, d->Cout, d->kw, d->stride, d->padl, kTdsBTF);
   p.x = x;
   const int rowTiles = (p.K + 1 + 15) / 16;

@@ -54,6 +54,7 @@ struct TdsRsP {
   int nTb, hBlocks;
   int tStart[kRsMaxTb];  // first output frame of time block i
   int kt[kRsMaxTb];      // 32-row tiles of time block i (block length = 32*kt - halo, clipped to Tout)
+  int abl;               // probe build only (W2L_TDS_RS_ABL): timing ablations, results are garbage
 };
 
 template <int C, int G, int J, int KTMAX>
@@ -165,17 +166,23 @@ __global__ __launch_bounds__(256, 2) void tds_conv_rs_k(TdsRsP p, int nTiles) {
     const int hb = tile % p.hBlocks, tb = (tile / p.hBlocks) % p.nTb, b = tile / (p.hBlocks * p.nTb);
     const int t0 = p.tStart[tb], kt = p.kt[tb];
     const int nf = 32 * kt + J - 1;
+#ifdef W2L_PROBE
+    const int abl = p.abl;   // 1: no MFMAs, 2: no overlap-add, 4: no epilogue, 8: no staging / zero fill, 16: no prefetch
+#else
+    constexpr int abl = 0;
+#endif
     __syncthreads();  // the previous tile's epilogue has read outA; its fragment reads of the slab are long done
     // slab <- prefetched pieces, transposed to time-fastest; outA <- 0
 #pragma unroll
     for (int v = 0; v < XV; ++v) {
+      if (abl & 8) break;
       const int e = tid + 256 * v, f = e / Q, q = e - f * Q;
       if (f < nf) {
         float* d = slab + (4 * q) * FT + f;
         d[0] = xr[v].x; d[FT] = xr[v].y; d[2 * FT] = xr[v].z; d[3 * FT] = xr[v].w;
       }
     }
-    {
+    if (!(abl & 8)) {
       const int no = 32 * kt + HALO;
       for (int e = tid; e < ROWS * no; e += 256) {
         const int row = e / no, u = e - row * no;
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_rs_k(TdsRsP p, int nTiles) {
     __syncthreads();
     {
       const int nxt = tile + gridDim.x;
-      fetch(nxt < nTiles ? nxt : tile);  // in flight behind this tile's MFMAs
+      if (!(abl & 16)) fetch(nxt < nTiles ? nxt : tile);  // in flight behind this tile's MFMAs
     }
 
     for (int kti = 0; kti < kt; ++kti) {
@@ -199,7 +206,11 @@ __global__ __launch_bounds__(256, 2) void tds_conv_rs_k(TdsRsP p, int nTiles) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 #pragma unroll
-        for (int s = 0; s < NK; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bw[ct][s], acc, 0, 0, 0);
+        for (int s = 0; s < NK; ++s) {
+          if ((abl & 1) && s > 0) break;
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bw[ct][s], acc, 0, 0, 0);
+        }
+        if (abl & 2) { if (acc[0] == 123.456f) outA[0] = acc[3]; continue; }
         // D: column = lane & 31, rows 8i + 4 (lane >> 5) + jj  ->  out[(wave, co)][tau - g*J]
         float* o = outA + ob[ct] + 32 * kti;
         constexpr auto rounds = RsRounds<G, J>::make();
@@ -224,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_rs_k(TdsRsP p, int nTiles) {
     // ---- epilogue: out tile -> y[b][t0 + u][4 hb + hh][c], whole (4 C)-float frames as float4
     int tc = p.Tout - t0;
     if (tc > 32 * kt - HALO) tc = 32 * kt - HALO;
+    if (abl & 4) tc = 0;
     const size_t gBase = (((size_t)b * p.Tout + t0) * p.H + hb * 4) * C;
     for (int e = tid; e < tc * Q; e += 256) {
       const int u = e / Q, q = e - u * Q;
@@ -285,6 +297,7 @@ bool tds_rs_try(const float* x, const float* w, const float* bias, const float* 
   TdsRsP p{};
   p.x = x; p.w = w; p.bias = bias; p.add = add; p.y = y;
   p.B = B; p.Tin = Tin; p.Tout = Tout; p.H = H; p.kw = kw; p.padl = padl; p.relu = relu; p.accum = accum; p.flip = flip;
+  { const char* e = tune_env("W2L_TDS_RS_ABL"); p.abl = e ? atoi(e) : 0; }
   const bool planned = C == 10 ? rs_plan(Tout, RsCfg<10, 3, 7, 6>::HALO, 6, p)
                      : C == 14 ? rs_plan(Tout, RsCfg<14, 2, 11, 5>::HALO, 5, p) : rs_plan(Tout, RsCfg<18, 7, 3, 4>::HALO, 4, p);
   if (!planned) return false;
@@ -294,6 +307,232 @@ bool tds_rs_try(const float* x, const float* w, const float* bias, const float* 
   else if (C == 14) st = rs_launch<14, 2, 11, 5>(p, s);
   else st = rs_launch<18, 7, 3, 4>(p, s);
   prof_end(s);
+  if (st == W2L_OK && hipGetLastError() != hipSuccess) st = W2L_EHIP;
+  *status = st;
+  return true;
+}
+
+// ================================================================================================ backward-filter
+// dW[tap][ci][co] = sum_{b,t,h} X[t + tap - padl][h][ci] * dY[t][h][co],   dbias[co] = sum dY[t][h][co]
+// is a GEMM with a huge K = (b, t, h) and a 21*C x C result: with the result on 16-wide tiles of 16x16x4 MFMAs
+// (conv_tds.hip) C = 10 / 14 / 18 columns fill 62.5 / 87.5 / 56 % of the lanes and the loop was issue-bound at ~30-47 %.
+// Role swap for the filter gradient: split tap = ga*GB + gb and shift BOTH operands along time,
+//     D[(ga, ci)][(gb, co)] = sum_{t'} X[t' + ga*GB - padl][ci] * dY[t' - gb][co]          (t' = t + gb)
+// rows (ga, ci) = GA*C (+ one all-ones row: its gb = 0 columns are the bias gradient), columns (gb, co) = GB*C, K = time:
+//     C = 10: GA = 3, GB = 7 : 1 x 3 tiles of 32x32, 21 taps     68 % of the MFMA lanes carry a wanted product
+//     C = 14: GA = 2, GB = 11: 1 x 5 tiles, 22 taps (21 wanted)  80 %
+//     C = 18: GA = 7, GB = 3 : 4 x 2 tiles, 21 taps              83 %
+// Both operands are read straight out of time-fastest slabs (x[(h, ci)][frame], dy[(h, co)][frame]): a fragment read is
+// 32 consecutive floats of one row, the K step is an immediate offset, NRT + NCT ds_read_b32 feed NRT*NCT 64-cycle MFMAs.
+// A wave owns one mel row of the workgroup's tile and keeps its NRT x NCT accumulators in registers over ALL its tiles;
+// at the end the four waves of a workgroup are added in wave order through LDS and one partial per workgroup goes to
+// the stream scratch; tds_rsf_reduce_k adds the partials in workgroup order (deterministic) and scatters into dW / dbias.
+struct TdsRsfP {
+  const float* x;   // [B][Tin][H][C]
+  const float* dy;  // [B][Tout][H][C]
+  int B, Tin, Tout, H, kw, padl;
+  int nStrips, hBlocks;
+};
+
+template <int C, int GA, int GB, int TS>
+struct RsfCfg {
+  static constexpr int HH = 4;
+  static constexpr int ROWS = HH * C;
+  static constexpr int Q = ROWS / 4;
+  static constexpr int NRT = (GA * C + 1 + 31) / 32;
+  static constexpr int NCT = (GB * C + 31) / 32;
+  static constexpr int XF = TS + (GA - 1) * GB;   // x slab frames
+  static constexpr int DF = TS + GB - 1;          // dy slab frames
+  static constexpr int FT = XF | 1;
+  static constexpr int DT = DF | 1;
+  static constexpr int ZT = (TS + 2) | 1;         // zero / ones rows
+  static constexpr int XOFF = 0, DOFF = ROWS * FT, ZOFF = DOFF + ROWS * DT, OOFF = ZOFF + ZT, END = OOFF + ZT;
+  static constexpr int ACCF = NRT * NCT * 16 * 64;                      // floats of one wave's accumulators
+  static constexpr int LDSF = END > ACCF ? END : ACCF;
+  static constexpr size_t LDS = (size_t)LDSF * sizeof(float);
+  static constexpr int XV = (XF * Q + 255) / 256, DV = (DF * Q + 255) / 256;
+  static_assert(TS % 2 == 0 && C % 2 == 0, "strip length / channel count");
+};
+
+template <int C, int GA, int GB, int TS>
+__global__ __launch_bounds__(256, (160 * 1024 / RsfCfg<C, GA, GB, TS>::LDS) >= 3 ? 3 : 2) void tds_conv_rsf_k(TdsRsfP p, float* __restrict__ partial, int nTiles) {
+  using Cfg = RsfCfg<C, GA, GB, TS>;
+  constexpr int NRT = Cfg::NRT, NCT = Cfg::NCT, FT = Cfg::FT, DT = Cfg::DT, Q = Cfg::Q, XF = Cfg::XF, DF = Cfg::DF, XV = Cfg::XV,
+                DV = Cfg::DV;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+
+  int ab[NRT], bb[NCT];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) {
+    const int m = 32 * rt + r, ga = m / C, ci = m - ga * C;
+    ab[rt] = (m < GA * C ? Cfg::XOFF + (wave * C + ci) * FT + ga * GB : m == GA * C ? Cfg::OOFF : Cfg::ZOFF) + hf;
+  }
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    const int n = 32 * ct + r, gb = n / C, co = n - gb * C;
+    bb[ct] = (gb < GB ? Cfg::DOFF + (wave * C + co) * DT + (GB - 1 - gb) : Cfg::ZOFF) + hf;
+  }
+  for (int e = tid; e < Cfg::ZT; e += 256) { lds[Cfg::ZOFF + e] = 0.f; lds[Cfg::OOFF + e] = 1.f; }
+
+  f32x16 acc[NRT][NCT];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[rt][ct][q] = 0.f;
+
+  const int HC = p.H * C;
+  for (int tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+    const int hb = tile % p.hBlocks, st = (tile / p.hBlocks) % p.nStrips, b = tile / (p.hBlocks * p.nStrips);
+    const int s0 = st * TS;                       // first t' of the strip
+    __syncthreads();                              // the previous tile's fragment reads are done
+    {  // x slab: frame f <-> input frame s0 - padl + f
+      const float* xb = p.x + ((size_t)b * p.Tin * p.H + hb * 4) * C;
+      float4 v[XV];
+#pragma unroll
+      for (int k = 0; k < XV; ++k) {
+        const int e = tid + 256 * k, f = e / Q, q = e - f * Q;
+        const int ti = s0 - p.padl + f;
+        const bool ok = f < XF && ti >= 0 && ti < p.Tin;
+        const float4 t4 = *(const float4*)(xb + (size_t)(ok ? ti : 0) * HC + 4 * q);
+        v[k] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < XV; ++k) {
+        const int e = tid + 256 * k, f = e / Q, q = e - f * Q;
+        if (f < XF) {
+          float* d = lds + Cfg::XOFF + (4 * q) * FT + f;
+          d[0] = v[k].x; d[FT] = v[k].y; d[2 * FT] = v[k].z; d[3 * FT] = v[k].w;
+        }
+      }
+    }
+    {  // dy slab: frame f <-> output frame s0 - (GB - 1) + f
+      const float* db = p.dy + ((size_t)b * p.Tout * p.H + hb * 4) * C;
+      float4 v[DV];
+#pragma unroll
+      for (int k = 0; k < DV; ++k) {
+        const int e = tid + 256 * k, f = e / Q, q = e - f * Q;
+        const int ti = s0 - (GB - 1) + f;
+        const bool ok = f < DF && ti >= 0 && ti < p.Tout;
+        const float4 t4 = *(const float4*)(db + (size_t)(ok ? ti : 0) * HC + 4 * q);
+        v[k] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < DV; ++k) {
+        const int e = tid + 256 * k, f = e / Q, q = e - f * Q;
+        if (f < DF) {
+          float* d = lds + Cfg::DOFF + (4 * q) * DT + f;
+          d[0] = v[k].x; d[DT] = v[k].y; d[2 * DT] = v[k].z; d[3 * DT] = v[k].w;
+        }
+      }
+    }
+    __syncthreads();
+    // K loop over the strip: step s covers t' = s0 + 2s (lanes 0-31) and s0 + 2s + 1 (lanes 32-63)
+#pragma unroll 8
+    for (int s = 0; s < TS / 2; ++s) {
+      float a[NRT], bv[NCT];
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) a[rt] = lds[ab[rt] + 2 * s];
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) bv[ct] = lds[bb[ct] + 2 * s];
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rt], bv[ct], acc[rt][ct], 0, 0, 0);
+    }
+  }
+  // ---- the four waves of the workgroup, added in wave order through LDS (register layout kept: [tile][q][lane])
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            float* d = lds + ((rt * NCT + ct) * 16 + q) * 64 + lane;
+            *d = (w == 0 ? 0.f : *d) + acc[rt][ct][q];
+          }
+    }
+  }
+  __syncthreads();
+  float* dst = partial + (size_t)blockIdx.x * Cfg::ACCF;
+  for (int e = tid; e < Cfg::ACCF; e += 256) dst[e] = lds[e];
+}
+
+// dw / dbias = sum over the workgroups' partials, in workgroup order.  One thread per (element, slice of the partials);
+// 64 elements x 4 slices per block, slices combined in fixed order through LDS.
+template <int C, int GA, int GB, int NRT, int NCT>
+__global__ __launch_bounds__(256) void tds_rsf_reduce_k(const float* __restrict__ partial, int nParts, int kw, float* __restrict__ dw,
+                                                       float* __restrict__ dbias) {
+  constexpr int ACCF = NRT * NCT * 16 * 64;
+  __shared__ float red[4][64];
+  const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;   // index in register order: ((rt*NCT + ct)*16 + q)*64 + lane
+  float s = 0.f;
+  const int per = (nParts + 3) / 4;
+  const int g0 = sl * per, g1 = g0 + per < nParts ? g0 + per : nParts;
+  if (e < ACCF)
+    for (int g = g0; g < g1; ++g) s += partial[(size_t)g * ACCF + e];
+  red[sl][el] = s;
+  __syncthreads();
+  if (sl == 0 && e < ACCF) {
+    const float t = ((red[0][el] + red[1][el]) + red[2][el]) + red[3][el];
+    const int lane = e & 63, q = (e >> 6) & 15, tl = e >> 10, rt = tl / NCT, ct = tl - rt * NCT;
+    const int m = 32 * rt + 8 * (q >> 2) + 4 * (lane >> 5) + (q & 3), n = 32 * ct + (lane & 31);
+    const int gb = n / C, co = n - gb * C;
+    if (gb < GB) {
+      if (m < GA * C) {
+        const int ga = m / C, ci = m - ga * C, tap = ga * GB + gb;
+        if (tap < kw) dw[((size_t)tap * C + ci) * C + co] = t;
+      } else if (m == GA * C && gb == 0 && dbias) {
+        dbias[co] = t;
+      }
+    }
+  }
+}
+
+float* sk_scratch(hipStream_t s, size_t bytes);
+
+template <int C, int GA, int GB, int TS>
+static int rsf_launch(TdsRsfP p, float* dw, float* dbias, hipStream_t s) {
+  using Cfg = RsfCfg<C, GA, GB, TS>;
+  p.hBlocks = p.H / Cfg::HH;
+  p.nStrips = (p.Tout + GB - 1 + TS - 1) / TS;
+  const int nTiles = p.B * p.nStrips * p.hBlocks;
+  const int perCu = (int)(160 * 1024 / Cfg::LDS) >= 3 ? 3 : 2;
+  const int blocks = nTiles < 256 * perCu ? nTiles : 256 * perCu;
+  float* partial = sk_scratch(s, kSkScratchBytes);
+  if (!partial || (size_t)blocks * Cfg::ACCF * sizeof(float) > kSkScratchBytes) return W2L_EUNSUPPORTED;
+  static bool attr = false;
+  if (!attr && Cfg::LDS > 64 * 1024) {
+    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_rsf_k<C, GA, GB, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
+    attr = true;
+  }
+  hipLaunchKernelGGL((tds_conv_rsf_k<C, GA, GB, TS>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p, partial, nTiles);
+  hipLaunchKernelGGL((tds_rsf_reduce_k<C, GA, GB, Cfg::NRT, Cfg::NCT>), dim3((unsigned)((Cfg::ACCF + 63) / 64)), dim3(256), 0, s, partial,
+                     blocks, p.kw, dw, dbias);
+  return W2L_OK;
+}
+
+// true + *status when this geometry runs on the role-swapped filter-gradient kernel
+bool tds_rsf_try(const float* x, const float* dy, float* dw, float* dbias, int B, int Tin, int Tout, int H, int C, int kw, int padl,
+                 hipStream_t s, int* status) {
+  if (tune_env("W2L_TDS_RS_OFF") || tune_env("W2L_TDS_RSF_OFF")) return false;
+  if (!(C == 10 || C == 14 || C == 18) || kw > 21 || kw < 1 || H % 4) return false;
+  if ((((uintptr_t)x | (uintptr_t)dy) & 15) != 0) return false;
+  TdsRsfP p{};
+  p.x = x; p.dy = dy; p.B = B; p.Tin = Tin; p.Tout = Tout; p.H = H; p.kw = kw; p.padl = padl;
+  prof_begin(s, 2.0 * B * Tout * (double)H * kw * C * C, PROF_TDS_BWD_FILTER);
+  int st;
+  if (C == 10) st = rsf_launch<10, 3, 7, 128>(p, dw, dbias, s);
+  else if (C == 14) st = rsf_launch<14, 2, 11, 128>(p, dw, dbias, s);
+  else st = rsf_launch<18, 7, 3, 96>(p, dw, dbias, s);
+  prof_end(s);
+  if (st == W2L_EUNSUPPORTED) return false;
   if (st == W2L_OK && hipGetLastError() != hipSuccess) st = W2L_EHIP;
   *status = st;
   return true;

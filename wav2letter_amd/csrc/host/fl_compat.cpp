@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstring>
 #include <sstream>
+#include <unordered_map>
 #include <unordered_set>
 
 #include "../../../include/fl_compat/flashlight.h"
@@ -144,6 +145,14 @@ void Variable::backward(const Variable& grad, bool retainGraph) {
 void Variable::backward(bool retainGraph) {
   backward(Variable(af::constant(1.0, dims(), af::f32), false), retainGraph);
 }
+
+Variable operator*(const Variable& v, double s) {
+  af::array out = af::constant(0.0, v.dims(), af::f32);
+  if (v.type() != af::f32) throw std::invalid_argument("Variable * scalar: f32 only");
+  w2l::w2lCheck(w2l_axpy(out.device<float>(), v.array().device<float>(), (size_t)v.elements(), (float)s, S()), "scale");
+  return Variable(out, false);
+}
+Variable operator/(const Variable& v, double s) { return v * (1.0 / s); }
 
 void Module::setParams(const Variable& var, int position) { params_.at(position) = var; }
 
@@ -328,6 +337,8 @@ class PlannedNet : public fl::Sequential {
   }
   std::string prettyString() const override { return net_->prettyString(); }
   w2l::Sequential& impl() { return *net_; }
+  float* paramPtr() { return (float*)paramArena_.get(); }
+  float* gradPtr() { return (float*)gradArena_.get(); }
 
  private:
   std::shared_ptr<w2l::Sequential> net_;
@@ -345,6 +356,15 @@ std::shared_ptr<fl::Sequential> buildSequentialModuleFromText(const std::string&
 }
 std::shared_ptr<fl::Sequential> buildSequentialModule(const std::string& archfile, int64_t nFeatures, int64_t nClasses) {
   return buildSequentialModuleFromText(w2l::readFile(archfile), nFeatures, nClasses);
+}
+
+FlatView flatParameters(const std::shared_ptr<fl::Module>& network) {
+  auto* p = dynamic_cast<PlannedNet*>(network.get());
+  return p ? FlatView{p->paramPtr(), p->impl().paramFloats()} : FlatView{nullptr, 0};
+}
+FlatView flatGradients(const std::shared_ptr<fl::Module>& network) {
+  auto* p = dynamic_cast<PlannedNet*>(network.get());
+  return p ? FlatView{p->gradPtr(), p->impl().paramFloats()} : FlatView{nullptr, 0};
 }
 
 // ------------------------------------------------------------------------------------------------ criteria

@@ -1,0 +1,341 @@
+// train_main.cpp -- `Train train --flagsfile=... [--k=v ...]`: the reference Trainer's command line
+// (recipes/slimIPL/src/Train.cpp:110-179: `train [flags]` | `continue [directory] [flags]` | `fork [model] [flags]`)
+// over the fl:: surface of include/fl_compat/flashlight.h.
+//
+// It reads the recipes' own train.cfg / *.arch files UNCHANGED (gflags `--flagsfile`, later flags win), builds
+//   network   = fl::pkg::runtime::ModulePlugin(FLAGS_arch).arch(numFeatures, numClasses)   (Train.cpp:390-395)
+//   criterion = CTCLoss(scalemode) | ASGLoss(numClasses, scalemode, FLAGS_transdiag)         (:406-410)
+//   netoptim / critoptim = SGD(lr, momentum) / SGD(lrcrit)                                  (:577-582)
+// and runs the hot loop of Train.cpp:1454-1804 (forward, criterion, zeroGrad, backward, grads / batch, clipGradNorm,
+// critopt->step, netopt->step) with the reference's meters, printing the log line of MyLogger.cpp:40-106
+// (`epoch | nupdates | lr | lrcriterion | runtime | bch(ms) | smp(ms) | fwd(ms) | crit-fwd(ms) | bwd(ms) | optim(ms) |
+// loss | train-TER | train-WER | ...`) to stdout and to <rundir>/<runname>/001_log, next to 001_config (:644-651).
+//
+// What is NOT here (SURVEY 8 marks it out of scope or "next"): audio decoding, the lexicon / word-piece pipeline, the
+// decoder, cereal checkpoints.  The data the step consumes is therefore SYNTHETIC unless --train names list files
+// that exist: LibriSpeech-shaped padded batches (--w2l_synth_frames frames of --filterbanks features, random targets),
+// which is exactly what bench.py times.  Flags of this driver that the reference does not have are prefixed w2l_.
+// Data-parallel runs are driven from Python (bench.py / wav2letter_amd.parallel over torch.distributed = RCCL).
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <iostream>
+#include <random>
+#include <sstream>
+
+#include "../../../include/fl_compat/flashlight.h"
+#include "w2l_host.hpp"
+
+using namespace fl;
+using namespace fl::pkg::speech;
+
+namespace {
+
+struct Timer {
+  double total = 0;
+  int n = 0;
+  std::chrono::steady_clock::time_point t0;
+  void resume() { t0 = std::chrono::steady_clock::now(); }
+  void stop() { total += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+  void stopAndIncUnit() { stop(); ++n; }
+  double value() const { return n ? total / n : 0.0; }  // seconds per unit, like fl::TimeMeter(true)
+  void reset() { total = 0; n = 0; }
+};
+
+std::string fmt(const char* f, double v) { char b[64]; snprintf(b, sizeof b, f, v); return b; }
+std::string fmti(const char* f, long v) { char b[64]; snprintf(b, sizeof b, f, v); return b; }
+
+int editDistance(const std::vector<int>& a, const std::vector<int>& b) {
+  std::vector<int> prev(b.size() + 1), cur(b.size() + 1);
+  for (size_t j = 0; j <= b.size(); ++j) prev[j] = (int)j;
+  for (size_t i = 1; i <= a.size(); ++i) {
+    cur[0] = (int)i;
+    for (size_t j = 1; j <= b.size(); ++j)
+      cur[j] = std::min({prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (a[i - 1] != b[j - 1])});
+    std::swap(prev, cur);
+  }
+  return prev[b.size()];
+}
+
+bool fileExists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+void mkdirs(const std::string& p) {
+  std::string cur;
+  for (size_t i = 0; i <= p.size(); ++i) {
+    if (i == p.size() || p[i] == '/') { if (!cur.empty()) mkdir(cur.c_str(), 0755); }
+    if (i < p.size()) cur += p[i];
+  }
+}
+std::string pathJoin(const std::string& a, const std::string& b) {
+  if (a.empty() || (!b.empty() && b[0] == '/')) return b;
+  return a.back() == '/' ? a + b : a + "/" + b;
+}
+
+int countTokens(const std::string& path) {
+  std::ifstream f(path);
+  if (!f) return -1;
+  int n = 0;
+  std::string line;
+  while (std::getline(f, line)) if (!line.empty()) ++n;
+  return n;
+}
+
+int usage(const char* exe) {
+  std::cerr << "Usage: \n " << exe << " train [flags]\n or " << exe << " continue [directory] [flags]\n or " << exe
+            << " fork [directory/model] [flags]" << std::endl;
+  return 2;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc <= 1) return usage(argv[0]);
+  const std::string runStatus = argv[1];
+  try {
+    int first = 2;
+    if (runStatus == "continue" || runStatus == "fork") {
+      // the reference reloads flags + model from a cereal checkpoint (Train.cpp:132-173); this build's container is
+      // wav2letter_amd/checkpoint.py (documented layout) -- resuming through this binary is not wired yet
+      std::cerr << "Train " << runStatus << ": resuming from a checkpoint goes through wav2letter_amd.checkpoint (Python) in this build"
+                << std::endl;
+      return 3;
+    }
+    if (runStatus != "train") return usage(argv[0]);
+
+    // ---- flags: --flagsfile first, then the command line in order (gflags semantics: the last definition wins)
+    w2l::Flags flags;
+    for (int i = first; i < argc; ++i) {
+      w2l::Flags one = w2l::parseFlagsText(argv[i]);
+      for (auto& kv : one.kv) flags.kv.push_back(kv);
+    }
+    const std::string criterionName = flags.get("criterion", "asg");    // the reference default (FLAGS_criterion)
+    const int batch = (int)flags.geti("batchsize", 1);
+    const int nFeat = flags.getb("mfcc", false) ? (int)flags.geti("mfcccoeffs", 13) * 3
+                      : flags.getb("pow", false) ? (int)flags.geti("framesizems", 25) * 8 + 1 : (int)flags.geti("filterbanks", 40);
+    const double lr0 = flags.getd("lr", 1.0), lrcrit0 = flags.getd("lrcrit", 0.0), momentum = flags.getd("momentum", 0.0);
+    const double maxgradnorm = flags.getd("maxgradnorm", 0.0);
+    const long iters = flags.geti("w2l_synth_updates", flags.geti("iter", 8));
+    const long reportiters = flags.geti("reportiters", 0);
+    const int T = (int)flags.geti("w2l_synth_frames", 1500);
+    const int Lmax = (int)flags.geti("w2l_synth_target_len", criterionName == "ctc" ? 80 : 300);
+    const long linseg = flags.geti("linseg", 0);
+    const long warmup = flags.geti("warmup", 1);
+    const uint64_t seed = (uint64_t)flags.geti("seed", 0);
+
+    // ---- number of classes: the token dictionary (+ replabels for ASG, + blank for CTC: Train.cpp:230-251)
+    int numClasses = (int)flags.geti("w2l_nlabel", 0);
+    if (!numClasses) {
+      const std::string tok = pathJoin(flags.get("tokensdir", ""), flags.get("tokens", "tokens.txt"));
+      const int n = countTokens(tok);
+      if (n <= 0) throw std::invalid_argument("cannot read the token dictionary '" + tok + "' (--tokensdir / --tokens); pass --w2l_nlabel=N for a synthetic run");
+      numClasses = n;
+      if (criterionName == "asg") numClasses += (int)flags.geti("replabel", 0);
+      if (criterionName == "ctc") numClasses += 1;  // blank, appended LAST
+    }
+
+    // ---- run directory: NNN_log, NNN_config (Train.cpp:644-651)
+    std::string runPath = pathJoin(flags.get("rundir", ""), flags.get("runname", ""));
+    std::ofstream logFile;
+    if (!flags.get("rundir", "").empty() && flags.get("rundir", "") != "[...]") {
+      mkdirs(runPath);
+      logFile.open(pathJoin(runPath, "001_log"));
+      std::ofstream cfg(pathJoin(runPath, "001_config"));
+      for (auto& kv : flags.kv) cfg << "--" << kv.first << "=" << kv.second << "\n";
+    }
+
+    // ---- network / criterion / optimizers
+    const std::string archPath = pathJoin(flags.get("archdir", ""), flags.get("arch", ""));
+    if (!fileExists(archPath)) throw std::invalid_argument("arch file / plugin '" + archPath + "' not found (--archdir / --arch)");
+    auto scalemode = getCriterionScaleMode(flags.get("onorm", "none"), flags.getb("sqnorm", false));
+    std::cout << "Loading architecture file from " << archPath << std::endl;
+    std::shared_ptr<fl::Module> network = fl::pkg::runtime::ModulePlugin(archPath).arch(nFeat, numClasses);
+    std::shared_ptr<SequenceCriterion> criterion;
+    if (criterionName == "ctc") criterion = std::make_shared<CTCLoss>(scalemode);
+    else if (criterionName == "asg") criterion = std::make_shared<ASGLoss>(numClasses, scalemode, flags.getd("transdiag", 0.0));
+    else throw std::invalid_argument("unsupported criterion '" + criterionName + "' (this build: ctc, asg)");
+    if (linseg > 0 && criterionName != "asg") throw std::invalid_argument("linseg may only be used with ASG criterion");  // Train.cpp:593
+    size_t nparams = 0;
+    for (auto& p : network->params()) nparams += (size_t)p.elements();
+    std::cout << "[Network] " << network->prettyString() << std::endl;
+    std::cout << "[Network Params: " << nparams << "]" << std::endl;
+    std::cout << "[Criterion] " << criterion->prettyString() << std::endl;
+    auto netoptim = std::make_shared<SGDOptimizer>(network->params(), lr0, momentum, 0.0);
+    auto critoptim = std::make_shared<SGDOptimizer>(criterion->params(), lrcrit0, 0.0, 0.0);
+    std::cout << "[Network Optimizer] " << netoptim->prettyString() << std::endl;
+    std::cout << "[Criterion Optimizer] " << critoptim->prettyString() << std::endl;
+
+    // ---- data
+    std::string trainLists = flags.get("train", "");
+    const bool haveLists = !trainLists.empty() && trainLists.find("[DATA_DST]") == std::string::npos &&
+                           fileExists(trainLists.substr(0, trainLists.find(',')));
+    if (haveLists)
+      std::cout << "note: audio list files are present, but feature extraction from audio is not part of this build "
+                   "(SURVEY 8 f3): running on synthetic batches of the same shape" << std::endl;
+    std::mt19937_64 rng(2026 + seed);
+    std::normal_distribution<float> gauss(0.f, 1.f);
+    const int nTok = criterionName == "ctc" ? numClasses - 1 : std::max(1, numClasses - (int)flags.geti("replabel", 0));
+    std::vector<float> hx((size_t)batch * nFeat * T);
+    std::vector<int> ht((size_t)batch * Lmax);
+
+    // ---- meters (MyLogger.cpp:40-106)
+    Timer runtime, timer, sampletimer, fwdtimer, critfwdtimer, bwdtimer, optimtimer;
+    double lossSum = 0;
+    long lossN = 0, editErr = 0, editLen = 0, tszTotal = 0, tszMax = 0, nsamples = 0, nbatches = 0;
+    runtime.resume();
+    network->train();
+    criterion->train();
+    const bool clampCrit = true;
+
+    auto logStatus = [&](long epoch, long nupdates, double lr, double lrcrit) {
+      runtime.stop();
+      std::ostringstream s;
+      auto item = [&](const std::string& k, const std::string& v) { s << (s.tellp() > 0 ? " | " : "") << k << ": " << v; };
+      const int rt = (int)runtime.total;
+      char rtb[32];
+      snprintf(rtb, sizeof rtb, "%02d:%02d:%02d", rt / 3600, (rt / 60) % 60, rt % 60);
+      item("epoch", fmti("%8ld", epoch));
+      item("nupdates", fmti("%12ld", nupdates));
+      item("lr", fmt("%4.6lf", lr));
+      item("lrcriterion", fmt("%4.6lf", lrcrit));
+      item("runtime", rtb);
+      item("bch(ms)", fmt("%.2f", timer.value() * 1000));
+      item("smp(ms)", fmt("%.2f", sampletimer.value() * 1000));
+      item("fwd(ms)", fmt("%.2f", fwdtimer.value() * 1000));
+      item("crit-fwd(ms)", fmt("%.2f", critfwdtimer.value() * 1000));
+      item("bwd(ms)", fmt("%.2f", bwdtimer.value() * 1000));
+      item("optim(ms)", fmt("%.2f", optimtimer.value() * 1000));
+      item("loss", fmt("%10.5f", lossN ? lossSum / lossN : 0.0));
+      const double ter = editLen ? 100.0 * editErr / editLen : 0.0;
+      item("train-TER", fmt("%5.2f", ter));
+      item("train-WER", fmt("%5.2f", ter));  // synthetic targets: every token is its own word
+      const double framesPerSample = T;
+      item("avg-isz", fmti("%03ld", (long)framesPerSample));
+      item("avg-tsz", fmti("%03ld", nsamples ? tszTotal / nsamples : 0));
+      item("max-tsz", fmti("%03ld", tszMax));
+      item("avr-batchsz", fmt("%7.2f", nbatches ? (double)nsamples / nbatches : 0.0));
+      const double audioSec = nsamples * framesPerSample * flags.getd("framestridems", 10) / 1000.0;
+      item("hrs", fmt("%7.2f", audioSec / 3600.0));
+      const double timeTaken = timer.value() * nbatches;
+      item("thrpt(sec/sec)", timeTaken > 0 ? fmt("%.2f", audioSec / timeTaken) : std::string("n/a"));
+      std::time_t now = std::time(nullptr);
+      char ts[64];
+      std::strftime(ts, sizeof ts, "%Y-%m-%d %H:%M:%S", std::localtime(&now));
+      item("timestamp", ts);
+      std::cout << s.str() << std::endl;
+      if (logFile.is_open()) logFile << s.str() << std::endl;
+      runtime.resume();
+    };
+
+    // ---- the hot loop (Train.cpp:1454-1804)
+    double lr = lr0, lrcrit = lrcrit0;
+    for (long curBatch = 1; curBatch <= iters; ++curBatch) {
+      // learning rate: warmup * gamma^(batch / stepsize) (Train.cpp:1334-1348)
+      const double sched = std::pow(flags.getd("gamma", 1.0), (double)curBatch / flags.getd("stepsize", 1e18)) *
+                           std::min((double)curBatch / std::max<long>(1, warmup), 1.0);
+      lr = lr0 * sched;
+      lrcrit = lrcrit0 * sched;
+      netoptim->setLr(lr);
+      critoptim->setLr(lrcrit);
+
+      timer.resume();
+      sampletimer.resume();
+      for (auto& v : hx) v = gauss(rng);
+      for (int b = 0; b < batch; ++b) {
+        const int lo = criterionName == "ctc" ? 20 : 60;
+        const int len = lo + (int)(rng() % (uint64_t)std::max(1, Lmax - lo + 1));
+        int prev = -1;
+        for (int i = 0; i < Lmax; ++i) {
+          int y = -1;
+          if (i < len) {
+            y = (int)(rng() % (uint64_t)nTok);
+            if (criterionName == "asg" && y == prev) y = (y + 1) % nTok;  // replabel convention: no identical neighbours
+            prev = y;
+          }
+          ht[(size_t)b * Lmax + i] = y;
+        }
+        tszTotal += len;
+        tszMax = std::max<long>(tszMax, len);
+      }
+      fl::Variable input = fl::input(af::array(af::dim4(T, nFeat, 1, batch), hx.data()));
+      fl::Variable target(af::array(af::dim4(Lmax, batch), ht.data()), false);
+      af::sync();
+      sampletimer.stopAndIncUnit();
+
+      // forward
+      fwdtimer.resume();
+      auto output = network->forward({input, fl::noGrad(af::constant(T, af::dim4(1, batch)))}).front();
+      af::sync();
+      critfwdtimer.resume();
+      auto loss = criterion->forward({output, target}).front();
+      af::sync();
+      fwdtimer.stopAndIncUnit();
+      critfwdtimer.stopAndIncUnit();
+      std::vector<float> hl(batch);
+      loss.host(hl.data());
+      for (float v : hl) {
+        if (!std::isfinite(v)) throw std::runtime_error("Loss has NaN values");   // LOG(FATAL), Train.cpp:1686-1698
+        lossSum += v;
+        ++lossN;
+      }
+      if (reportiters > 0 && curBatch % reportiters == 0) {  // token error of the Viterbi path (evalOutput, Train.cpp:1699-1716)
+        std::vector<int> path((size_t)batch * output.dims(1));
+        criterion->viterbiPath(output.array()).host(path.data());
+        const int To = (int)output.dims(1);
+        for (int b = 0; b < batch; ++b) {
+          std::vector<int> hyp, ref;
+          int prev = -1;
+          for (int t = 0; t < To; ++t) {
+            const int y = path[(size_t)b * To + t];
+            if (y != prev && !(criterionName == "ctc" && y == numClasses - 1)) hyp.push_back(y);
+            prev = y;
+          }
+          for (int i = 0; i < Lmax && ht[(size_t)b * Lmax + i] >= 0; ++i) ref.push_back(ht[(size_t)b * Lmax + i]);
+          editErr += editDistance(hyp, ref);
+          editLen += (long)ref.size();
+        }
+      }
+
+      // backward
+      bwdtimer.resume();
+      netoptim->zeroGrad();
+      critoptim->zeroGrad();
+      loss.backward();
+      af::sync();
+      bwdtimer.stopAndIncUnit();
+
+      // optimizer: scale down gradients by batchsize, clamp, update
+      optimtimer.resume();
+      const double totalBatchSize = (double)loss.dims(0);
+      for (const auto& p : network->params())
+        if (p.isGradAvailable()) p.grad() = p.grad() / totalBatchSize;
+      for (const auto& p : criterion->params())
+        if (p.isGradAvailable()) p.grad() = p.grad() / totalBatchSize;
+      if (maxgradnorm > 0) {
+        auto params = network->params();
+        if (clampCrit) {
+          auto cp = criterion->params();
+          params.insert(params.end(), cp.begin(), cp.end());
+        }
+        fl::clipGradNorm(params, maxgradnorm);
+      }
+      critoptim->step();
+      netoptim->step();
+      af::sync();
+      optimtimer.stopAndIncUnit();
+      timer.stopAndIncUnit();
+      nsamples += batch;
+      ++nbatches;
+
+      if ((reportiters > 0 && curBatch % reportiters == 0) || curBatch == iters) logStatus(1, curBatch, lr, lrcrit);
+    }
+    std::cout << "Finished training" << std::endl;
+    return 0;
+  } catch (const std::exception& e) {
+    std::cerr << "Train: " << e.what() << std::endl;
+    return 1;
+  }
+}

@@ -80,3 +80,31 @@ TDS_CTC_FLAGS = dict(criterion="ctc", lr=0.3, momentum=0.5, maxgradnorm=1.0, ono
 CONV_GLU_FLAGS = dict(criterion="asg", lr=0.6, lrcrit=0.006, momentum=0.8, maxgradnorm=0.2, onorm="target",
                       sqnorm=True, filterbanks=40, batchsize=4, transdiag=4, replabel=2, linseg=1)
 #                                                        recipes/conv_glu/librispeech/train.cfg:12-26
+
+
+def tds_ctc_train_cfg():
+    """recipes/sota/2019/librispeech/train_am_tds_ctc.cfg, regenerated (tests/test_recipes.py checks it against the
+    reference file line for line when /root/reference is present): the flags file `Train train --flagsfile=...` reads"""
+    fl = [("runname", "am_tds_ctc_librispeech"), ("rundir", "[...]"), ("archdir", "[...]"), ("arch", "am_arch/am_tds_ctc.arch"),
+          ("tokensdir", "[MODEL_DST]/am"), ("tokens", "librispeech-train-all-unigram-10000.tokens"),
+          ("lexicon", "[MODEL_DST]/am/librispeech-train+dev-unigram-10000-nbest10.lexicon"),
+          ("train", "[DATA_DST]/lists/train-clean-100.lst,[DATA_DST]/lists/train-clean-360.lst,[DATA_DST]/lists/train-other-500.lst"),
+          ("valid", "dev-clean:[DATA_DST]/lists/dev-clean.lst,dev-other:[DATA_DST]/lists/dev-other.lst"),
+          ("batchsize", "4"), ("lr", "0.3"), ("momentum", "0.5"), ("maxgradnorm", "1"), ("onorm", "target"), ("sqnorm", "true"),
+          ("mfsc", "true"), ("nthread", "10"), ("criterion", "ctc"), ("memstepsize", "8338608"), ("wordseparator", "_"),
+          ("usewordpiece", "true"), ("filterbanks", "80"), ("gamma", "0.5"), ("enable_distributed", "true"), ("stepsize", "200"),
+          ("framesizems", "30"), ("framestridems", "10"), ("seed", "2"), ("lr_decay", "10000")]
+    return "# Replace `[...]`, `[MODEL_DST]`, `[DATA_DST]`, with appropriate paths\n" + "".join(f"--{k}={v}\n" for k, v in fl)
+
+
+def conv_glu_train_cfg():
+    """recipes/conv_glu/librispeech/train.cfg, regenerated (checked like tds_ctc_train_cfg)"""
+    fl = [("runname", "librispeech_conv_glu"), ("rundir", "[...]"), ("tokensdir", "[MODEL_DST]/am"), ("archdir", "[...]"),
+          ("train", "[DATA_DST]/lists/train-clean-100.lst,[DATA_DST]/lists/train-clean-360.lst,[DATA_DST]/lists/train-other-500.lst"),
+          ("valid", "dev-clean:[DATA_DST]/lists/dev-clean.lst,dev-other:[DATA_DST]/lists/dev-other.lst"),
+          ("lexicon", "[MODEL_DST]/am/lexicon_train+dev.txt"), ("arch", "network.arch"), ("tokens", "tokens.txt"), ("criterion", "asg"),
+          ("lr", "0.6"), ("lrcrit", "0.006"), ("linseg", "1"), ("momentum", "0.8"), ("maxgradnorm", "0.2"), ("replabel", "2"),
+          ("surround", "|"), ("onorm", "target"), ("sqnorm", "true"), ("mfsc", "true"), ("nthread", "6"), ("batchsize", "4"),
+          ("transdiag", "4"), ("filterbanks", "40")]
+    return ("# Training config for Librispeech using Gated ConvNets\n# Replace `[...]`, `[MODEL_DST]`, `[DATA_DST]` with appropriate paths\n"
+            + "".join(f"--{k}={v}\n" for k, v in fl))
