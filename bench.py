@@ -442,9 +442,9 @@ def main():
     nl, ms, flops = kind(0)          # the dominant kernel: 128x128 fp32 MFMA GEMM (+ its stream-K fix-up)
     nc, msc, flc = kind(2)           # TDS slab convolutions
     ns, mss, fls = kind(1)           # generic skinny implicit GEMM (strided backward-data only)
-    L.w2l_profile_enable(0)
     nbd, msbd, flbd = kind(4)        # TDS convolution backward-data
     nbf, msbf, flbf = kind(5)        # TDS convolution backward-filter
+    L.w2l_profile_enable(0)
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     step_flops = (flops + flc + flbd + flbf + fls) / max(1, a.steps)   # every MFMA launch of the step, algorithmic 2MNK
     ms_step = dt / a.steps * 1e3

@@ -79,10 +79,17 @@ def main():
         # determinism of the overlap-add
         again, _ = run(prod, d, x, w, b, dy, reps=1)
         print("    run-to-run identical:", all(torch.equal(new[k], again[k]) for k in ("y", "dx")))
+        if "--stagger" in sys.argv:
+            for st in (0, 1, 2, 3, 4, 6, 8):
+                os.environ["W2L_TDS_RS_STAGGER"] = str(st)
+                with _lib.use_probe() as P:
+                    _, ta = run(P, d, x, w, b, dy, reps=10)
+                os.environ.pop("W2L_TDS_RS_STAGGER")
+                print(f"    stagger {st}: fwd {ta['fwd']:7.1f} us  bwd_data {ta['bwd_data']:7.1f} us")
         if "--abl" in sys.argv:
             # timing-only ablations of the role-swapped kernel (probe library): where does the time go?
-            for abl, what in [(0, "full"), (1, "no MFMAs"), (2, "no overlap-add"), (4, "no epilogue"), (8, "no staging/zero"),
-                              (16, "no prefetch"), (3, "no MFMA+add"), (15, "launch + tile loop only")]:
+            for abl, what in [(0, "full"), (1, "no MFMAs"), (2, "no overlap-add"), (4, "no epilogue"), (8, "no staging"),
+                              (32, "no zero fill"), (3, "no MFMA+add"), (12, "no staging+epilogue"), (47, "launch + tile loop only")]:
                 os.environ["W2L_TDS_RS_ABL"] = str(abl)
                 with _lib.use_probe() as P:
                     _, ta = run(P, d, x, w, b, dy, reps=10)

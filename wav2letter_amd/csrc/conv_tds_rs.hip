@@ -39,6 +39,8 @@
 
 #include "gemm.hpp"
 
+namespace w2l { typedef __attribute__((address_space(3))) void* lptr_t; }
+
 namespace w2l {
 
 constexpr int kRsMaxTb = 16;
@@ -55,6 +57,7 @@ struct TdsRsP {
   int tStart[kRsMaxTb];  // first output frame of time block i
   int kt[kRsMaxTb];      // 32-row tiles of time block i (block length = 32*kt - halo, clipped to Tout)
   int abl;               // probe build only (W2L_TDS_RS_ABL): timing ablations, results are garbage
+  int stagger;           // start offset between the co-resident workgroups of a CU, in s_sleep(127) units (~3.4 us)
 };
 
 template <int C, int G, int J, int KTMAX>
@@ -68,8 +71,14 @@ struct RsCfg {
   static constexpr int OT = (32 * KTMAX + HALO) | 1;    // out row stride
   static constexpr int ROWS = HH * C;
   static constexpr int Q = ROWS / 4;                    // float4 pieces per frame
-  static constexpr int XV = (NFMAX * Q + 255) / 256;    // pieces per thread
+  // staging / epilogue thread mapping: thread = (frame chunk f0 = tid / Q, piece q = tid % Q); its pieces are frames
+  // f0, f0 + FSTEP, f0 + 2 FSTEP ... of piece q -- the (frame, piece) split costs one division per KERNEL, the bias of a
+  // thread's four channels sits in registers, every LDS / global offset is base + constant * v
+  static constexpr int FSTEP = 256 / Q;
+  static constexpr int XV = (NFMAX + FSTEP - 1) / FSTEP;   // pieces per thread
+  static constexpr int EV = (32 * KTMAX - HALO + FSTEP - 1) / FSTEP;
   static constexpr size_t LDS = (size_t)(ROWS * FT + (ROWS + 1) * OT) * sizeof(float);
+  static constexpr int WGS = (3 * LDS <= 160 * 1024) ? 3 : (2 * LDS <= 160 * 1024 ? 2 : 1);   // workgroups per CU
   static_assert(C % 2 == 0 && ROWS % 4 == 0, "channel count");
 };
 
@@ -109,10 +118,10 @@ struct RsRounds {
 };
 
 template <int C, int G, int J, int KTMAX>
-__global__ __launch_bounds__(256, 2) void tds_conv_rs_k(TdsRsP p, int nTiles) {
+__global__ __launch_bounds__(256, (RsCfg<C, G, J, KTMAX>::WGS)) void tds_conv_rs_k(TdsRsP p, int nTiles) {
   using Cfg = RsCfg<C, G, J, KTMAX>;
   constexpr int NCT = Cfg::NCT, NK = Cfg::NK, HALO = Cfg::HALO, FT = Cfg::FT, OT = Cfg::OT, ROWS = Cfg::ROWS, Q = Cfg::Q,
-                XV = Cfg::XV;
+                XV = Cfg::XV, FSTEP = Cfg::FSTEP, EV = Cfg::EV;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* slab = lds;               // [ROWS][FT]   slab[(hh*C + ci)][frame]
   float* outA = lds + ROWS * FT;   // [ROWS + 1][OT]  out[(hh*C + co)][HALO + u]; row ROWS absorbs the padding columns
@@ -144,24 +153,35 @@ __global__ __launch_bounds__(256, 2) void tds_conv_rs_k(TdsRsP p, int nTiles) {
   }
   const float* ab = slab + (wave * C + hf) * FT + r;
   const int HC = p.H * C;
+  const int f0 = tid / Q, q4 = 4 * (tid - f0 * Q);
+  const bool act = f0 < FSTEP;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);   // the four channels (4q + k) mod C of this thread's pieces
+  if (p.bias) bias4 = make_float4(p.bias[q4 % C], p.bias[(q4 + 1) % C], p.bias[(q4 + 2) % C], p.bias[(q4 + 3) % C]);
+  for (int e = tid; e < (ROWS + 1) * OT; e += 256) outA[e] = 0.f;   // every tile leaves it zeroed again
 
   float4 xr[XV];
   auto fetch = [&](int tile) {
     const int hb = tile % p.hBlocks, tb = (tile / p.hBlocks) % p.nTb, b = tile / (p.hBlocks * p.nTb);
     const int tIn0 = p.tStart[tb] - p.padl, nf = 32 * p.kt[tb] + J - 1;
-    const float* xb = p.x + ((size_t)b * p.Tin * p.H + hb * 4) * C;
+    const float* xb = p.x + ((size_t)b * p.Tin * p.H + hb * 4) * C + q4;
 #pragma unroll
     for (int v = 0; v < XV; ++v) {
-      const int e = tid + 256 * v, f = e / Q, q = e - f * Q;
+      const int f = f0 + FSTEP * v;
       const int ti = tIn0 + f;
-      const bool ok = f < nf && ti >= 0 && ti < p.Tin;
-      const float4 t4 = *(const float4*)(xb + (size_t)(ok ? ti : 0) * HC + 4 * q);
+      const bool ok = act && f < nf && ti >= 0 && ti < p.Tin;
+      const float4 t4 = *(const float4*)(xb + (size_t)(ok ? ti : 0) * HC);
       xr[v] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
 
   int tile = blockIdx.x;
   if (tile < nTiles) fetch(tile);
+  // The co-resident workgroups of a CU start together and, doing identical work, stay in lockstep: their MFMA phases
+  // collide on the matrix pipes and their staging / epilogue phases collide on the LDS, nothing overlaps (ablation:
+  // time = MFMA time + everything else, profiles/r02_run8_conv_rs_diet_ablation.log).  Break the symmetry once: the k-th
+  // workgroup dispatched to a CU (block index / 256 in breadth-first dispatch; only speed depends on that guess) starts
+  // k * stagger later, so one workgroup's MFMA phase runs beside another's memory phase from then on.
+  for (int i = 0; i < p.stagger * (int)((blockIdx.x >> 8) % Cfg::WGS); ++i) __builtin_amdgcn_s_sleep(127);
   for (; tile < nTiles; tile += gridDim.x) {
     const int hb = tile % p.hBlocks, tb = (tile / p.hBlocks) % p.nTb, b = tile / (p.hBlocks * p.nTb);
     const int t0 = p.tStart[tb], kt = p.kt[tb];
@@ -171,22 +191,16 @@ __global__ __launch_bounds__(256, 2) void tds_conv_rs_k(TdsRsP p, int nTiles) {
 #else
     constexpr int abl = 0;
 #endif
-    __syncthreads();  // the previous tile's epilogue has read outA; its fragment reads of the slab are long done
-    // slab <- prefetched pieces, transposed to time-fastest; outA <- 0
+    __syncthreads();  // the previous tile's epilogue has read (and re-zeroed) outA; its fragment reads of the slab are long done
+    // slab <- prefetched pieces, transposed to time-fastest
+    {
+      float* d = slab + q4 * FT + f0;
 #pragma unroll
-    for (int v = 0; v < XV; ++v) {
-      if (abl & 8) break;
-      const int e = tid + 256 * v, f = e / Q, q = e - f * Q;
-      if (f < nf) {
-        float* d = slab + (4 * q) * FT + f;
-        d[0] = xr[v].x; d[FT] = xr[v].y; d[2 * FT] = xr[v].z; d[3 * FT] = xr[v].w;
-      }
-    }
-    if (!(abl & 8)) {
-      const int no = 32 * kt + HALO;
-      for (int e = tid; e < ROWS * no; e += 256) {
-        const int row = e / no, u = e - row * no;
-        outA[row * OT + u] = 0.f;
+      for (int v = 0; v < XV; ++v) {
+        if (abl & 8) break;
+        if (act && f0 + FSTEP * v < nf) {
+          d[FSTEP * v] = xr[v].x; d[FT + FSTEP * v] = xr[v].y; d[2 * FT + FSTEP * v] = xr[v].z; d[3 * FT + FSTEP * v] = xr[v].w;
+        }
       }
     }
     __syncthreads();
@@ -195,6 +209,10 @@ __global__ __launch_bounds__(256, 2) void tds_conv_rs_k(TdsRsP p, int nTiles) {
       if (!(abl & 16)) fetch(nxt < nTiles ? nxt : tile);  // in flight behind this tile's MFMAs
     }
 
+    // ---- MFMA phase.  (A software-pipelined variant -- the overlap-add of unit u-1 issued piecewise under the MFMAs of
+    // unit u with a second accumulator set, A fragments re-loaded right after their last use, sched_barrier after every
+    // MFMA slot -- was built and measured: no gain at C = 10 (123 vs 117 us), and at C = 18 hipcc no longer unrolled the
+    // column-tile loop, indexed the weight registers dynamically and fell to 308 us: profiles/r02_run9_conv_rs_swpipe_negative.log.)
     for (int kti = 0; kti < kt; ++kti) {
       const float* at = ab + 32 * kti;
       float a[NK];
@@ -232,27 +250,230 @@ __global__ __launch_bounds__(256, 2) void tds_conv_rs_k(TdsRsP p, int nTiles) {
     }
     __syncthreads();
 
-    // ---- epilogue: out tile -> y[b][t0 + u][4 hb + hh][c], whole (4 C)-float frames as float4
+    // ---- epilogue: out tile -> y[b][t0 + u][4 hb + hh][c], whole (4 C)-float frames as float4; every column read is
+    // written back as zero, so the next tile finds the overlap-add buffer clear (no separate zero-fill pass)
     int tc = p.Tout - t0;
     if (tc > 32 * kt - HALO) tc = 32 * kt - HALO;
     if (abl & 4) tc = 0;
-    const size_t gBase = (((size_t)b * p.Tout + t0) * p.H + hb * 4) * C;
-    for (int e = tid; e < tc * Q; e += 256) {
-      const int u = e / Q, q = e - u * Q;
-      const float* s4 = outA + (4 * q) * OT + HALO + u;
-      float4 v = make_float4(s4[0], s4[OT], s4[2 * OT], s4[3 * OT]);
-      if (p.bias) {
-        const int c0 = (4 * q) % C;  // float 4q of a frame piece is (hh, c) = divmod(4q, C)
-        v.x += p.bias[c0]; v.y += p.bias[(c0 + 1) % C]; v.z += p.bias[(c0 + 2) % C]; v.w += p.bias[(c0 + 3) % C];
+    const int ue = 32 * kt - HALO;   // columns [HALO, 32 kt) hold outputs (the last time block stores only tc of them)
+    const size_t gBase = (((size_t)b * p.Tout + t0) * p.H + hb * 4) * C + q4;
+    float* s4 = outA + q4 * OT + HALO + f0;
+#pragma unroll
+    for (int it = 0; it < EV; ++it) {
+      const int u = f0 + FSTEP * it;
+      if (!act || u >= ue) break;
+      float4 v = make_float4(s4[FSTEP * it], s4[OT + FSTEP * it], s4[2 * OT + FSTEP * it], s4[3 * OT + FSTEP * it]);
+      s4[FSTEP * it] = 0.f; s4[OT + FSTEP * it] = 0.f; s4[2 * OT + FSTEP * it] = 0.f; s4[3 * OT + FSTEP * it] = 0.f;
+      if (u < tc) {
+        v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        const size_t gq = gBase + (size_t)u * HC;
+        if (p.add) { const float4 a4 = *(const float4*)(p.add + gq); v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w; }
+        if (p.accum) { const float4 y0 = *(const float4*)(p.y + gq); v.x += y0.x; v.y += y0.y; v.z += y0.z; v.w += y0.w; }
+        *(float4*)(p.y + gq) = v;
       }
-      if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      const size_t gq = gBase + (size_t)u * HC + 4 * q;
-      if (p.add) { const float4 a4 = *(const float4*)(p.add + gq); v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w; }
-      if (p.accum) { const float4 y0 = *(const float4*)(p.y + gq); v.x += y0.x; v.y += y0.y; v.z += y0.z; v.w += y0.w; }
-      *(float4*)(p.y + gq) = v;
+    }
+    // the halo columns [0, HALO) and [32 kt, 32 kt + HALO) took overlap-add partial sums that belong to the neighbouring
+    // time blocks (which recompute them): clear
+    for (int e = tid; e < ROWS * 2 * HALO; e += 256) {
+      const int row = e / (2 * HALO), c = e - row * (2 * HALO);
+      outA[row * OT + (c < HALO ? c : 32 * kt + c - HALO)] = 0.f;
     }
   }
 }
+
+#ifdef W2L_PROBE  // kept for A/B work only: measured SLOWER than the cooperative kernel above
+// ------------------------------------------------------------------------------------------------ v2: autonomous waves
+// Measured on the cooperative kernel above (profiles/r02_run3_conv_rs_rmw_ablation.log, C = 10): 142 us, of which the
+// MFMAs alone 75 -- staging the slab through registers with a transpose (31 us), the zero fill, the epilogue (26 us) and
+// three workgroup barriers per tile all ran IN SERIES with the matrix pipe, and two co-resident workgroups start in
+// lockstep.  v2 removes every barrier: a workgroup is ONE wave that owns (utterance, mel row, time block) tiles:
+//   * staging = LDS-DMA: `buffer_load_dword ... lds` writes lane l's dword to M0 + 4 l, so with lane <-> FRAME one
+//     instruction drops 64 consecutive frames of one input channel straight into the time-fastest slab row -- the
+//     transpose costs nothing, no VGPRs, no ds_write; frames before / after the utterance are out of the buffer
+//     resource's range and arrive as zeros (the padding);
+//   * the next tile's DMA is issued right after the MFMA phase has consumed the slab, under the epilogue;
+//   * 8 such waves per CU in different phases keep the matrix pipe fed while others stage or store.
+// A launch block is FOUR such waves on the four adjacent mel rows of one (utterance, time block): they never
+// synchronise, but they run on one CU at about the same pace, so the 128-byte lines a 40-byte (C floats) piece of a
+// frame sits in are fetched into that CU's L1 once and serve all four (with one-wave blocks, adjacent rows went to
+// different XCDs and every XCD's L2 pulled every line: 190 us instead of 142, profiles/r02_run6_conv_rs2_first.log).
+template <int C, int G, int J, int KTMAX>
+struct Rs2Cfg {
+  static constexpr int NCT = (G * C + 31) / 32;
+  static constexpr int NK = J * C / 2;
+  static constexpr int HALO = (G - 1) * J;
+  static constexpr int NFMAX = 32 * KTMAX + J - 1;
+  static constexpr int FT = NFMAX | 1;
+  static constexpr int OT = (32 * KTMAX + HALO) | 1;
+  static constexpr int LDSF = C * FT + (C + 1) * OT + 32;   // slab | out (+ the row that absorbs padding columns) | bias
+  static constexpr size_t LDS = (size_t)LDSF * sizeof(float);
+};
+
+template <int C, int G, int J, int KTMAX>
+__global__ __launch_bounds__(256) void tds_conv_rs2_k(TdsRsP p, int nTiles) {
+  using Cfg = Rs2Cfg<C, G, J, KTMAX>;
+  constexpr int NCT = Cfg::NCT, NK = Cfg::NK, HALO = Cfg::HALO, FT = Cfg::FT, OT = Cfg::OT;
+  extern __shared__ __attribute__((aligned(16))) float ldsAll[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hf = lane >> 5;
+  float* lds = ldsAll + wave * Cfg::LDSF;   // this wave's private slab / out tile / bias
+  float* slab = lds;                 // [C][FT]      slab[ci][frame]
+  float* outA = lds + C * FT;        // [C + 1][OT]  out[co][HALO + u]
+  float* biasS = outA + (C + 1) * OT;
+
+  float bw[NCT][NK];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    const int n = 32 * ct + r, g = n / C, co = n - g * C;
+#pragma unroll
+    for (int s = 0; s < NK; ++s) {
+      const int j = s / (C / 2), ci = 2 * (s % (C / 2)) + hf;
+      const int tap = g * J + j;
+      const bool ok = g < G && tap < p.kw;
+      const size_t src = !p.flip ? ((size_t)tap * C + ci) * C + co : ((size_t)(p.kw - 1 - tap) * C + co) * C + ci;
+      const float t = p.w[ok ? src : 0];
+      bw[ct][s] = ok ? t : 0.f;
+    }
+  }
+  int ob[NCT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    const int n = 32 * ct + r, g = n / C, co = n - g * C;
+    ob[ct] = (g < G ? co * OT + HALO - g * J : C * OT) + 4 * hf;
+  }
+  if (lane < C) biasS[lane] = p.bias ? p.bias[lane] : 0.f;
+  for (int e = lane; e < (C + 1) * OT; e += 64) outA[e] = 0.f;
+  const float* ab = slab + hf * FT + r;
+  const int HC = p.H * C;
+  const int hq = p.H >> 2, tilesPerB = p.nTb * hq;   // a block tile = (b, time block, 4 mel rows); this wave: row 4 hb + wave
+
+  // LDS-DMA of one tile's slab: channel ci, frames [64 c, 64 c + 64) -> slab[ci][64 c + lane]
+  auto stage = [&](int tile) {
+    const int b = tile / tilesPerB, rem = tile - b * tilesPerB, tb = rem / hq, h = 4 * (rem - tb * hq) + wave;
+    const int nf = 32 * p.kt[tb] + J - 1;
+    const int tIn0 = p.tStart[tb] - p.padl;
+    const float* base = p.x + ((size_t)b * p.Tin * p.H + h) * C;   // frame 0, mel row h of utterance b
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(((size_t)(p.Tin - 1) * HC + C) * sizeof(float)), 0x00020000);
+    const int nch = (nf + 63) >> 6;
+    for (int c = 0; c < nch; ++c) {
+      const int f = 64 * c + lane;
+      const int voff = (tIn0 + f) * HC * (int)sizeof(float);        // negative / past the end: out of range -> zeros
+      if (f < nf) {
+#pragma unroll
+        for (int ci = 0; ci < C; ++ci)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(slab + ci * FT + 64 * c), 4, voff, ci * (int)sizeof(float), 0, 0);
+      }
+    }
+  };
+
+#ifdef W2L_PROBE
+  const int abl = p.abl;   // 1: no MFMAs, 2: no overlap-add, 4: no epilogue, 8: no staging, 32: no zero fill
+#else
+  constexpr int abl = 0;
+#endif
+  int tile = blockIdx.x;
+  if (tile < nTiles && !(abl & 8)) stage(tile);
+  for (; tile < nTiles; tile += gridDim.x) {
+    const int b = tile / tilesPerB, rem = tile - b * tilesPerB, tb = rem / hq, h = 4 * (rem - tb * hq) + wave;
+    const int t0 = p.tStart[tb], kt = p.kt[tb];
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this tile's slab has landed (and the previous tile's stores have left)
+
+    for (int kti = 0; kti < kt; ++kti) {
+      const float* at = ab + 32 * kti;
+      float a[NK];
+#pragma unroll
+      for (int s = 0; s < NK; ++s) a[s] = at[(2 * (s % (C / 2))) * FT + s / (C / 2)];
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NK; ++s) {
+          if ((abl & 1) && s > 0) break;
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bw[ct][s], acc, 0, 0, 0);
+        }
+        if (abl & 2) { if (acc[0] == 123.456f) outA[0] = acc[3]; continue; }
+        float* o = outA + ob[ct] + 32 * kti;
+        constexpr auto rounds = RsRounds<G, J>::make();
+#pragma unroll
+        for (int c = 0; c < rounds.n; ++c) {
+          asm volatile("" ::: "memory");
+          float old[16];
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            if (rounds.color[q] == c) old[q] = o[8 * (q / 4) + (q % 4)];
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            if (rounds.color[q] == c) o[8 * (q / 4) + (q % 4)] = old[q] + acc[q];
+        }
+        asm volatile("" ::: "memory");
+      }
+    }
+    // the slab is consumed (all fragment reads have returned: their values fed the MFMAs above): next tile's DMA now
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+    {
+      const int nxt = tile + gridDim.x;
+      if (nxt < nTiles && !(abl & 8)) stage(nxt);
+    }
+    // ---- epilogue: out[co][u] -> y[b][t0 + u][h][co]; the out tile is left zeroed for the next tile
+    int tc = p.Tout - t0;
+    if (tc > 32 * kt - HALO) tc = 32 * kt - HALO;
+    if (abl & 4) tc = 0;
+    const size_t gBase = (((size_t)b * p.Tout + t0) * p.H + h) * C;
+    const int total = tc * C;
+    for (int e0 = 0; e0 < total; e0 += 256) {
+      float v[4], ad[4];
+      int gi[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = e0 + 64 * k + lane;
+        const int u = e / C, co = e - u * C;
+        gi[k] = e < total ? u * HC + co : -1;
+        v[k] = e < total ? outA[co * OT + HALO + u] + biasS[co] : 0.f;
+        ad[k] = 0.f;
+        if (gi[k] >= 0) {
+          if (p.add) ad[k] = p.add[gBase + gi[k]];
+          if (p.accum) ad[k] += p.y[gBase + gi[k]];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (gi[k] < 0) continue;
+        float t = v[k];
+        if (p.relu) t = fmaxf(t, 0.f);
+        p.y[gBase + gi[k]] = t + ad[k];
+      }
+    }
+    if (!(abl & 32)) {
+      const int no = 32 * kt + HALO;
+      for (int e = lane; e < C * no; e += 64) {
+        const int row = e / no, u = e - row * no;
+        outA[row * OT + u] = 0.f;
+      }
+    }
+  }
+}
+
+template <int C, int G, int J, int KTMAX>
+static int rs2_launch(TdsRsP p, hipStream_t s) {
+  using Cfg = Rs2Cfg<C, G, J, KTMAX>;
+  const int nTiles = p.B * p.nTb * (p.H / 4);
+  const size_t shmem = 4 * Cfg::LDS;
+  int bpc = (int)(160 * 1024 / shmem);      // blocks (of 4 waves) per CU
+  if (bpc > 3) bpc = 3;
+  if (bpc < 1) return W2L_EUNSUPPORTED;
+  const int blocks = nTiles < 256 * bpc ? nTiles : 256 * bpc;
+  static bool attr = false;
+  if (!attr && shmem > 64 * 1024) {
+    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_rs2_k<C, G, J, KTMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    attr = true;
+  }
+  hipLaunchKernelGGL((tds_conv_rs2_k<C, G, J, KTMAX>), dim3((unsigned)blocks), dim3(256), shmem, s, p, nTiles);
+  return W2L_OK;
+}
+
+#endif  // W2L_PROBE
 
 // time blocks: n blocks whose lengths + halo are whole 32-row tiles, at most KTMAX tiles each, as even as possible
 static bool rs_plan(int Tout, int halo, int ktMax, TdsRsP& p) {
@@ -277,7 +498,7 @@ static int rs_launch(TdsRsP p, hipStream_t s) {
   using Cfg = RsCfg<C, G, J, KTMAX>;
   p.hBlocks = p.H / Cfg::HH;
   const int nTiles = p.B * p.nTb * p.hBlocks;
-  const int perCu = (int)(160 * 1024 / Cfg::LDS) < 2 ? 1 : 2;
+  const int perCu = Cfg::WGS;
   const int blocks = nTiles < 256 * perCu ? nTiles : 256 * perCu;
   static bool attr = false;
   if (!attr && Cfg::LDS > 64 * 1024) {
@@ -298,14 +519,27 @@ bool tds_rs_try(const float* x, const float* w, const float* bias, const float* 
   p.x = x; p.w = w; p.bias = bias; p.add = add; p.y = y;
   p.B = B; p.Tin = Tin; p.Tout = Tout; p.H = H; p.kw = kw; p.padl = padl; p.relu = relu; p.accum = accum; p.flip = flip;
   { const char* e = tune_env("W2L_TDS_RS_ABL"); p.abl = e ? atoi(e) : 0; }
-  const bool planned = C == 10 ? rs_plan(Tout, RsCfg<10, 3, 7, 6>::HALO, 6, p)
+  { const char* e = tune_env("W2L_TDS_RS_STAGGER"); p.stagger = e ? atoi(e) : (C == 10 ? 4 : 0); }
+  if (C == 14 && !tune_env("W2L_TDS_RS_C14")) return false;   // C = 14: conv_tds.hip's 16-wide tiles (87.5 % of the lanes) stay ahead
+  const bool v2 = tune_env("W2L_TDS_RS_V2") != nullptr;       // probe build: the autonomous-wave LDS-DMA variant (measured slower)
+  const bool planned = C == 10 ? rs_plan(Tout, RsCfg<10, 3, 7, 4>::HALO, v2 ? 6 : 4, p)
                      : C == 14 ? rs_plan(Tout, RsCfg<14, 2, 11, 5>::HALO, 5, p) : rs_plan(Tout, RsCfg<18, 7, 3, 4>::HALO, 4, p);
   if (!planned) return false;
   prof_begin(s, 2.0 * B * Tout * (double)H * kw * C * C, profKind);
   int st;
-  if (C == 10) st = rs_launch<10, 3, 7, 6>(p, s);
-  else if (C == 14) st = rs_launch<14, 2, 11, 5>(p, s);
-  else st = rs_launch<18, 7, 3, 4>(p, s);
+  if (!v2) {
+    if (C == 10) st = rs_launch<10, 3, 7, 4>(p, s);
+    else if (C == 14) st = rs_launch<14, 2, 11, 5>(p, s);
+    else st = rs_launch<18, 7, 3, 4>(p, s);
+  } else {
+#ifdef W2L_PROBE
+    if (C == 10) st = rs2_launch<10, 3, 7, 6>(p, s);
+    else if (C == 14) st = rs2_launch<14, 2, 11, 5>(p, s);
+    else st = rs2_launch<18, 7, 3, 4>(p, s);
+#else
+    st = W2L_EUNSUPPORTED;
+#endif
+  }
   prof_end(s);
   if (st == W2L_OK && hipGetLastError() != hipSuccess) st = W2L_EHIP;
   *status = st;
@@ -523,6 +757,7 @@ bool tds_rsf_try(const float* x, const float* dy, float* dw, float* dbias, int B
                  hipStream_t s, int* status) {
   if (tune_env("W2L_TDS_RS_OFF") || tune_env("W2L_TDS_RSF_OFF")) return false;
   if (!(C == 10 || C == 14 || C == 18) || kw > 21 || kw < 1 || H % 4) return false;
+  if (C == 14 && !tune_env("W2L_TDS_RS_C14")) return false;   // measured: 152 us against 103 us of conv_tds.hip's kernel
   if ((((uintptr_t)x | (uintptr_t)dy) & 15) != 0) return false;
   TdsRsfP p{};
   p.x = x; p.dy = dy; p.B = B; p.Tin = Tin; p.Tout = Tout; p.H = H; p.kw = kw; p.padl = padl;
