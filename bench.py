@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--no-stress", action="store_true", help="skip the ASG N=9998 stress leg")
     ap.add_argument("--stress-frames", type=int, default=1500)
     ap.add_argument("--no-c4", action="store_true", help="skip the conv_glu LibriSpeech ASG step (BASELINE config 4) leg")
+    ap.add_argument("--no-c3", action="store_true", help="skip the streaming TDS fp32 / bf16 step (BASELINE config 3) leg")
     ap.add_argument("--no-oracle-checks", action="store_true", help="skip the oracle comparison of the stress / config-4 losses")
     ap.add_argument("--cpu-baseline-batch", type=int, default=8)
     ap.add_argument("--dist-selftest", action="store_true",
@@ -198,6 +199,52 @@ def conv_glu_asg_step(device, L, steps=2, oracle_checks=True):
                          "achieved": round(tf, 1), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
                          "launches_per_step": n_.value // steps, "gemm_ms_per_step": round(ms_.value / steps, 1),
                          "algorithmic_tflop_per_step": round(w_.value / steps / 1e12, 2)}}
+
+
+def streaming_tds_step(device, L, steps=3):
+    """BASELINE config 3 on one GPU: streaming_convnets LibriSpeech TDS-CTC (am_500ms_future_context.arch, 115.1 M
+    parameters), batch 64, T = 1500: the full training step in fp32 and with bf16 multiplies in the fl::Linear GEMMs
+    (fp32 accumulate, fp32 storage and master weights, fp32 criterion) -- the mixed-precision mode of
+    w2l_trainer_set_mixed_precision.  Parity of the two: tests/test_gpu_trainer.py::test_mixed_precision_streaming_tds_step."""
+    import ctypes as C
+    from wav2letter_amd import CriterionScaleMode, recipes
+    from wav2letter_amd.trainer import Trainer
+    B, T, nfeat, nlabel, Lmax = 64, 1500, 80, 9998, 80
+    fl = recipes.STREAMING_TDS_FLAGS
+    x, tgt = make_batch(B, T, nfeat, nlabel, Lmax, 3, device)
+    out = {"config": "streaming_convnets LibriSpeech TDS-CTC (am_500ms_future_context.arch): B=64/GPU, T=1500, 80 mel, 9998 classes"}
+    for mode in ("f32", "bf16"):
+        tr = Trainer(recipes.streaming_tds_arch(), nfeat, nlabel, "ctc", CriterionScaleMode.TARGET_SZ_SQRT, device=device)
+        tr.init_params(seed=1)
+        tr.plan(B, T, Lmax)
+        tr.to_device()
+        tr.set_mixed_precision(mode == "bf16")
+
+        def step():
+            loss = tr.forward_backward(x, tgt)
+            tr.update(lr=fl["lr"], momentum=fl["momentum"], max_grad_norm=fl["maxgradnorm"], total_batch=B)
+            return loss
+        step()
+        torch.cuda.synchronize()
+        L.w2l_profile_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        n_, ms_, w_ = C.c_int(0), C.c_double(0), C.c_double(0)
+        L.w2l_profile_report_kind(6 if mode == "bf16" else 0, C.byref(n_), C.byref(ms_), C.byref(w_))
+        L.w2l_profile_enable(0)
+        tf = w_.value / (ms_.value * 1e-3) / 1e12 if ms_.value > 0 else 0.0
+        out[mode] = {"ms_per_step": round(dt * 1e3, 1), "utterances_per_sec": round(B / dt, 1),
+                     "finite": bool(torch.isfinite(loss).all().item()), "loss": round(float(loss.mean().item()), 4),
+                     "gemm_TFLOPs": round(tf, 1), "gemm_ms_per_step": round(ms_.value / steps, 1), "gemm_launches_per_step": n_.value // steps}
+        del tr
+        torch.cuda.empty_cache()
+    out["bf16_speedup"] = round(out["f32"]["ms_per_step"] / out["bf16"]["ms_per_step"], 3)
+    out["note"] = ("dtype of this leg: bf16 multiply / fp32 accumulate in the fl::Linear GEMMs (v_mfma_f32_32x32x16_bf16), fp32 everywhere "
+                   "else; the bf16 GEMM is bound by staging fp32 operands through LDS, not by the 2.5 PFLOP/s matrix peak")
+    return out
 
 
 def asg_stress(device, L, T, oracle_checks=True):
@@ -500,6 +547,8 @@ def main():
         leg("asg_stress", lambda: asg_stress(device, L, a.stress_frames, not a.no_oracle_checks))
     if world == 1 and not a.no_c4:
         leg("conv_glu_asg_step", lambda: conv_glu_asg_step(device, L, oracle_checks=not a.no_oracle_checks))
+    if world == 1 and not a.no_c3:
+        leg("streaming_tds_bf16_step", lambda: streaming_tds_step(device, L))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -155,6 +155,11 @@ int w2l_linear_forward_dropout(int M, int in, int out, const float* x, const flo
 /* dx = add + dy w^T (add laid out like dx): the residual join of a backward pass without copying add into dx first */
 int w2l_linear_backward_data_add(int M, int in, int out, const float* dy, const float* w, const float* add,
                                  float* dx, w2l_stream_t stream);
+/* Mixed precision (BASELINE config 3; fl's --fl_amp_use_mixed_precision, recipes/joint_training_vox_populi/cpc/Train.cpp:1184
+ * keeps the criterion input in f32): mode 1 = every fl::Linear GEMM multiplies in bf16 (v_mfma_f32_32x32x16_bf16, operands
+ * rounded to nearest even on the way into LDS) and accumulates in fp32; operands, results, master weights and the
+ * criteria stay fp32.  Process-wide, returns the previous mode. */
+int w2l_set_matmul_precision(int mode);
 int w2l_colsum(const float* x, float* out, size_t M, int N, w2l_stream_t stream); /* bias grads */
 
 /* fl::Conv2D kw x 1 over time (arch tokens C / C2 / TDS). x [B][T][H][Cin],
@@ -274,6 +279,10 @@ int w2l_trainer_update(void* h, float lr, float lrcrit, float momentum, float ma
 int w2l_trainer_skipped_updates(void* h, uint64_t* count, void* stream);
 int w2l_trainer_viterbi(void* h, const float* emission, int* path, void* stream);
 int w2l_trainer_set_step(void* h, uint32_t step);
+/* --fl_amp_use_mixed_precision restated for bf16 (BASELINE config 3): the network's fl::Linear GEMMs multiply in bf16
+ * with fp32 accumulation (w2l_set_matmul_precision scoped to the network's calls); storage, master weights, convolutions,
+ * LayerNorm, the criterion (recipes/joint_training_vox_populi/cpc/Train.cpp:1184) and the optimizer stay fp32 */
+int w2l_trainer_set_mixed_precision(void* h, int on);
 /* gradient norm seen by the last w2l_trainer_update (before the 1/totalBatch scale; taken on every update).  A
  * non-finite norm means the update was SKIPPED on every rank (the norm is taken on the all-reduced gradient):
  * the counterpart of the reference's NaN guards, recipes/slimIPL/src/Train.cpp:1651-1660, :1686-1698. */

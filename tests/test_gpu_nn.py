@@ -676,3 +676,71 @@ def test_product_library_ignores_kernel_variant_switches():
     blob = open(so, "rb").read()
     assert b"gemm256_kernel" not in blob and b"gemm128w_kernel" not in blob
     assert b"W2L_GEMM_ABL" not in blob and b"W2L_FCC_ABL" not in blob
+
+
+# ----------------------------------------------------------------------------------------------
+# mixed precision (BASELINE config 3): bf16 multiply / fp32 accumulate GEMM, fp32 storage
+# ----------------------------------------------------------------------------------------------
+BF16_TOL = 1e-2   # stated tolerance: operands rounded to bf16 (8 significant bits, relative 2^-9 per element), fp32
+                  # accumulation: |error| / max|reference| stays below 1e-2 for reductions up to ~1e4 terms
+
+
+@pytest.fixture
+def bf16_matmul():
+    from wav2letter_amd import _lib
+    prev = _lib.lib().w2l_set_matmul_precision(1)
+    try:
+        yield
+    finally:
+        _lib.lib().w2l_set_matmul_precision(prev)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (130, 250, 70), (257, 129, 33), (1200, 1520, 96), (11968, 1200, 1200),
+                                    (1200, 1200, 11968), (188, 9998, 2160)])
+@pytest.mark.parametrize("akc,bkc", [(True, False), (True, True), (False, False), (False, True)])
+def test_gemm_bf16_all_layouts(bf16_matmul, M, N, K, akc, bkc):
+    """every operand layout of the fl::Linear calls (forward k-contiguous x k-rows, dX both k-contiguous, dW both k-rows
+    with the split-K slabs) against a float64 product AND against a float64 product of bf16-rounded operands (the
+    kernel's only approximation is that rounding): 1e-2 / 1e-5; bias + ReLU epilogue; run-to-run identical"""
+    from wav2letter_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + 3 * N + 7 * K)
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(K, N, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    want = (A.double() @ Bm.double() + bias.double()).numpy()
+    want_r = (A.bfloat16().double() @ Bm.bfloat16().double() + bias.double()).numpy()
+    Ad = (A if akc else A.T.contiguous()).cuda()
+    Bd = (Bm.T.contiguous() if bkc else Bm).cuda()
+    got = ops.gemm(Ad, Bd, akc, bkc, bias.cuda())
+    assert rel(got, want) < BF16_TOL
+    assert rel(got, want_r) < 2e-5          # exact up to fp32 accumulation order
+    assert torch.equal(got, ops.gemm(Ad, Bd, akc, bkc, bias.cuda()))
+    assert rel(ops.gemm(Ad, Bd, akc, bkc, bias.cuda(), relu=True), np.maximum(want, 0)) < BF16_TOL
+    plain = ops.gemm(Ad, Bd, akc, bkc)       # no epilogue: the form that may split K over slabs
+    assert rel(plain, (A.bfloat16().double() @ Bm.bfloat16().double()).numpy()) < 2e-5
+    assert torch.equal(plain, ops.gemm(Ad, Bd, akc, bkc))
+
+
+def test_linear_ops_bf16_epilogues(oracle, bf16_matmul):
+    """the fl::Linear entry points of the TDS block under bf16 multiplies: dropout epilogue mask identical to the fp32
+    path (same stateless hash), mask / addend epilogues, weight gradient; against the fp64 oracle at the bf16 tolerance"""
+    from wav2letter_amd import _lib, ops
+    rng = np.random.default_rng(5)
+    M, K, N = 300, 96, 160
+    x = rng.normal(size=(M, K)).astype(np.float32)
+    w = (rng.normal(size=(K, N)) / K ** 0.5).astype(np.float32)
+    b = rng.normal(size=N).astype(np.float32)
+    y = ops.linear_forward(dev(x), dev(w), dev(b), relu=True)
+    assert rel(y, np.maximum(oracle.linear_fwd(x, w, b), 0)) < BF16_TOL
+    yd = ops.linear_forward_dropout(dev(x), dev(w), dev(b), True, 0.3, 7, 3)
+    prev = _lib.lib().w2l_set_matmul_precision(0)
+    yd32 = ops.linear_forward_dropout(dev(x), dev(w), dev(b), True, 0.3, 7, 3)
+    _lib.lib().w2l_set_matmul_precision(prev)
+    assert torch.equal(yd == 0, yd32 == 0) or ((yd == 0) != (yd32 == 0)).float().mean().item() < 1e-3   # ReLU zeros may differ at the rounding level
+    assert rel(yd, yd32.cpu().numpy()) < BF16_TOL
+    dy = rng.normal(size=(M, N)).astype(np.float32)
+    dx, dw, db = ops.linear_backward(dev(x), dev(w), dev(dy))
+    odx, odw, odb = oracle.linear_bwd(x, w, dy)
+    assert rel(dx, odx) < BF16_TOL and rel(dw, odw) < BF16_TOL and rel(db, odb) < 1e-4   # the bias gradient is an fp32 column sum
+    add = rng.normal(size=(M, K)).astype(np.float32)
+    assert rel(ops.linear_backward_data_add(dev(dy), dev(w), dev(add)), odx + add) < BF16_TOL

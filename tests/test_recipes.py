@@ -20,6 +20,8 @@ def test_generators_reproduce_reference_arch_files():
     assert _lines(recipes.tds_ctc_arch()) == _lines(open(f"{REF}/sota/2019/am_arch/am_tds_ctc.arch").read())
     assert _lines(recipes.conv_glu_librispeech_arch()) == _lines(open(f"{REF}/conv_glu/librispeech/network.arch").read())
     assert _lines(recipes.conv_glu_wsj_arch()) == _lines(open(f"{REF}/conv_glu/wsj/network.arch").read())
+    assert _lines(recipes.streaming_tds_arch()) == _lines(
+        open(f"{REF}/streaming_convnets/librispeech/am_500ms_future_context.arch").read())
 
 
 @need_ref

@@ -100,6 +100,7 @@ class _SIGS:
     w2l_linear_backward_data = (_i, [_i, _i, _i, _p, _p, _p, _i, _p, _f, _p])
     w2l_linear_backward_weight = (_i, [_i, _i, _i, _p, _p, _p, _p])
     w2l_colsum = (_i, [_p, _p, _sz, _i, _p])
+    w2l_set_matmul_precision = (_i, [_i])
     w2l_mfsc_spectrum = (_i, [_p, _p, _sz, _i, _i, _i, _p])
     w2l_mfsc_log_transpose = (_i, [_p, _p, _i, _i, _i, _i, _f, _p])
     w2l_weightnorm_forward = (_i, [_p, _p, _p, _p, _i, _i, _p])

@@ -18,6 +18,7 @@
 // in K-major form  As[k][m], Bs[k][n]  so that a half-wave's fragment read is 32
 // consecutive dwords (conflict-free ds_read_b32), double-buffered with register
 // prefetch of the next K-tile (one barrier per K-tile).
+#include <atomic>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -30,6 +31,7 @@
 #include "gemm_loader.hpp"
 #endif
 #include "gemm_t160.hpp"
+#include "gemm_bf16.hpp"
 
 namespace w2l {
 
@@ -132,6 +134,23 @@ static int dispatch_b(const AOp& a, const float* B, int ldb, int b_kcontig, cons
   return launch128(a, PlainOp<false, 1>{B, ldb, o.N, o.K}, o, epi, splitk, s);
 }
 
+// ---- mixed precision (BASELINE config 3): w2l_set_matmul_precision(1) routes the fl::Linear GEMMs through the
+// bf16-multiply / fp32-accumulate kernel of gemm_bf16.hpp; operands and results stay fp32 in memory
+static std::atomic<int> g_matmul_bf16{0};
+
+static int gemm_bf16(const float* A, int lda, int a_kcontig, const float* B, int ldb, int b_kcontig, const GemmOut& o, int epi,
+                     hipStream_t s) {
+  const bool va = pick_vec(A, lda, a_kcontig ? o.K : o.M) == 4, vb = pick_vec(B, ldb, b_kcontig ? o.K : o.N) == 4;
+  if (a_kcontig) {
+    const BfOp<true> a{A, lda, o.M, o.K, va};
+    if (b_kcontig) return launch128_bf16(a, BfOp<true>{B, ldb, o.N, o.K, vb}, o, epi, s);
+    return launch128_bf16(a, BfOp<false>{B, ldb, o.N, o.K, vb}, o, epi, s);
+  }
+  const BfOp<false> a{A, lda, o.M, o.K, va};
+  if (b_kcontig) return launch128_bf16(a, BfOp<true>{B, ldb, o.N, o.K, vb}, o, epi, s);
+  return launch128_bf16(a, BfOp<false>{B, ldb, o.N, o.K, vb}, o, epi, s);
+}
+
 int gemm_f32(const float* A, int lda, int a_kcontig, const float* B, int ldb, int b_kcontig, float* C,
              int ldc, int M, int N, int K, const float* bias, int epi, int splitk, hipStream_t s,
              const float* mask, float maskScale, const GemmExtra* extra) {
@@ -149,6 +168,7 @@ int gemm_f32(const float* A, int lda, int a_kcontig, const float* B, int ldb, in
     }
   }
   splitk = 1;
+  if (g_matmul_bf16.load(std::memory_order_relaxed) && K >= 32) return gemm_bf16(A, lda, a_kcontig, B, ldb, b_kcontig, o, epi, s);
   const bool strict = glds_ok(A, lda, M) && glds_ok(B, ldb, N);
   const bool relaxed = !strict && unaligned_enabled() && glds_ok_relaxed(A, lda, M) && glds_ok_relaxed(B, ldb, N);
   // address range of each operand in bytes (buffer-addressed variant needs 32-bit offsets)
@@ -230,6 +250,10 @@ int gemm_glds_raw(const float* A, int lda, bool akc, size_t aBytes, const float*
 }  // namespace w2l
 
 using namespace w2l;
+
+// 0 = fp32 MFMA (default), 1 = bf16 multiply / fp32 accumulate for every w2l_linear_* / w2l_gemm_f32 call of this
+// process from now on; returns the previous mode.  (fl's --fl_amp_use_mixed_precision, restated for bf16.)
+W2L_API int w2l_set_matmul_precision(int mode) { return g_matmul_bf16.exchange(mode ? 1 : 0); }
 
 // ---- C ABI: fl::linear forward / backward ----------------------------------
 W2L_API int w2l_linear_forward(int M, int in, int out, const float* x, const float* w,

@@ -233,7 +233,7 @@ struct PlainOp {
 // by a pair of hipEvents on ITS stream; w2l_profile_report(kind) sums durations and the
 // algorithmic work (FLOPs for the MFMA kinds, bytes for the HBM-streaming kind).
 enum { PROF_GEMM128 = 0, PROF_SKINNY = 1, PROF_TDSCONV = 2 /* forward */, PROF_FCC_STREAM = 3, PROF_TDS_BWD_DATA = 4,
-       PROF_TDS_BWD_FILTER = 5, PROF_KINDS = 6 };
+       PROF_TDS_BWD_FILTER = 5, PROF_GEMM_BF16 = 6, PROF_KINDS = 7 };
 struct GemmProf {
   bool on = false;
   std::vector<hipEvent_t> ev;      // pairs

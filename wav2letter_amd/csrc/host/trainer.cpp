@@ -40,6 +40,9 @@ struct Trainer {
   SequenceCriterion* activeCrit() { return (linseg && step < linsegUpdates) ? linseg.get() : crit.get(); }
   std::string lastError;
   bool guardZeroed = false;
+  bool mixedPrecision = false;   // fl's --fl_amp_use_mixed_precision, restated for bf16: the network's fl::Linear GEMMs multiply
+                                 // in bf16 (fp32 accumulate, fp32 storage, fp32 master weights); convolutions, LayerNorm, the
+                                 // criterion and the optimizer stay fp32
   std::vector<hipEvent_t> bucketEvents;  // owned (w2l_trainer_set_grad_buckets)
   ~Trainer() { for (auto e : bucketEvents) (void)hipEventDestroy(e); }
 };
@@ -159,6 +162,13 @@ static void requireBound(Trainer* t) {
     throw std::invalid_argument("trainer not planned / bound (w2l_trainer_plan + w2l_trainer_bind first)");
 }
 
+struct MatmulMode {   // scoped: the mode only covers the network's own calls (the criterion stays fp32)
+  int prev;
+  bool on;
+  explicit MatmulMode(bool bf16) : prev(0), on(bf16) { if (on) prev = w2l_set_matmul_precision(1); }
+  ~MatmulMode() { if (on) w2l_set_matmul_precision(prev); }
+};
+
 static Ctx makeCtx(Trainer* t, void* stream, bool train) {
   requireBound(t);
   Ctx c;
@@ -176,7 +186,7 @@ W2L_API int w2l_trainer_forward(void* h, const float* x, int train, const float*
   TRY(h, {
     if (!x) throw std::invalid_argument("forward: null input");
     Ctx c = makeCtx(t, stream, train != 0);
-    t->emission = t->net->forward(c, t->arena, x);
+    { MatmulMode mm(t->mixedPrecision); t->emission = t->net->forward(c, t->arena, x); }
     if (emission) *emission = t->emission;
   });
 }
@@ -188,7 +198,7 @@ W2L_API int w2l_trainer_forward_backward(void* h, const float* x, const int* tar
   Trainer* t = (Trainer*)h;
   TRY(h, {
     Ctx c = makeCtx(t, stream, true);
-    t->emission = t->net->forward(c, t->arena, x);
+    { MatmulMode mm(t->mixedPrecision); t->emission = t->net->forward(c, t->arena, x); }
     float* cp = t->params + t->netFloats;
     float* cg = t->grads + t->netFloats;
     SequenceCriterion* crit = t->activeCrit();
@@ -200,7 +210,7 @@ W2L_API int w2l_trainer_forward_backward(void* h, const float* x, const int* tar
     w2lCheck(w2l_fill(t->batchSlot, 1, (float)t->B, c.stream), "batch slot");  // rides the gradient all-reduce
     hipCheck(hipMemsetAsync(t->batchSlot + 1, 0, sizeof(float) * 3, c.stream), "memset");
     crit->backward(c, t->B, t->Tout, t->nLabel, t->L, t->emission, target, t->gradLoss, t->dEm, t->critWs, cp, cg);
-    t->net->backward(c, t->arena, t->dEm);
+    { MatmulMode mm(t->mixedPrecision); t->net->backward(c, t->arena, t->dEm); }
     if (lossDev) *lossDev = t->loss;
   });
 }
@@ -307,6 +317,8 @@ W2L_API int w2l_trainer_skipped_updates(void* h, uint64_t* count, void* stream) 
     *count = (uint64_t)s;
   });
 }
+
+W2L_API int w2l_trainer_set_mixed_precision(void* h, int on) { ((Trainer*)h)->mixedPrecision = on != 0; return W2L_OK; }
 
 W2L_API int w2l_trainer_set_step(void* h, uint32_t step) { ((Trainer*)h)->step = step; return W2L_OK; }
 

@@ -39,6 +39,23 @@ def conv_glu_librispeech_arch():
     return "\n".join(lines) + "\n"
 
 
+def streaming_tds_arch():
+    """streaming_convnets LibriSpeech (BASELINE config 3, am_500ms_future_context.arch): 4 stages of asymmetric-padded
+    strided C2 + per-frame LayerNorm + TDS blocks with c = 15 / 19 / 23 / 27 channels, fc width = c*80, 115.1 M params"""
+    lines = ["V -1 NFEAT 1 0", "SAUG 80 27 2 100 1.0 2"]
+    stages = [("PD 0 5 3", 1, 15, 10, 2, [(9, 1)] * 2), ("PD 0 7 1", 15, 19, 10, 2, [(9, 1)] * 3),
+              ("PD 0 9 1", 19, 23, 12, 2, [(11, 1)] * 3 + [(11, 0)]), ("PD 0 10 0", 23, 27, 11, 1, [(11, 0)] * 5)]
+    for pd, cin, c, kw, stride, blocks in stages:
+        lines += [pd, f"C2 {cin} {c} {kw} 1 {stride} 1 0 0", "R", "DO 0.1", "LN 1 2"]
+        lines += [f"TDS {c} {k} 80 0.1 0 {rpad} 0" for k, rpad in blocks]
+    lines += ["RO 2 1 0 3", "V 2160 -1 1 0", "L 2160 NLABEL", "V NLABEL 0 -1 1"]
+    return "\n".join(lines) + "\n"
+
+
+STREAMING_TDS_FLAGS = dict(criterion="ctc", lr=0.4, momentum=0.0, maxgradnorm=0.5, onorm="target", sqnorm=True,
+                           filterbanks=80, batchsize=8)   # recipes/streaming_convnets/librispeech/train_am_500ms_future_context.cfg
+
+
 def conv_glu_wsj_arch():
     """conv_glu WSJ (BASELINE config 1): 15 WN-Conv+GLU layers with SAME padding (-1), kernels 13, 3..15, 21"""
     lines = ["V -1 1 NFEAT 0"]

@@ -40,6 +40,7 @@ def _lib_tr():
         L.w2l_trainer_update.argtypes = [vp, f, f, f, f, f, i, vp]
         L.w2l_trainer_viterbi.argtypes = [vp, vp, vp, vp]
         L.w2l_trainer_set_step.argtypes = [vp, u32]
+        L.w2l_trainer_set_mixed_precision.argtypes = [vp, i]
         L.w2l_trainer_set_linseg.argtypes = [vp, u32]
         L.w2l_trainer_grad_norm.argtypes = [vp, C.POINTER(C.c_double), vp]
         L.w2l_trainer_skipped_updates.argtypes = [vp, C.POINTER(u64), vp]
@@ -208,6 +209,10 @@ class Trainer:
         n = C.c_uint64(0)
         _check(self.L.w2l_trainer_skipped_updates(self.h, C.byref(n), self._stream()), "skipped_updates")
         return n.value
+
+    def set_mixed_precision(self, on=True):
+        """bf16 multiplies (fp32 accumulate / storage / master weights) in the network's fl::Linear GEMMs"""
+        _check(self.L.w2l_trainer_set_mixed_precision(self.h, int(bool(on))), "mixed precision")
 
     def set_step(self, step):
         self.L.w2l_trainer_set_step(self.h, step)
