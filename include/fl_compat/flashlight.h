@@ -257,6 +257,9 @@ class FL_COMPAT_API SequenceCriterion : public fl::Container {
 struct FlatView { float* ptr; size_t floats; };
 FL_COMPAT_API FlatView flatParameters(const std::shared_ptr<fl::Module>& network);
 FL_COMPAT_API FlatView flatGradients(const std::shared_ptr<fl::Module>& network);
+// --fl_amp_use_mixed_precision, restated for bf16: the fl::Linear GEMMs of a network built from an arch file multiply in
+// bf16 with fp32 accumulation; storage, master weights and the criterion stay fp32 (no-op for any other module)
+FL_COMPAT_API void setMixedPrecision(const std::shared_ptr<fl::Module>& network, bool on);
 
 class FL_COMPAT_API ASGLoss : public SequenceCriterion {
  public:

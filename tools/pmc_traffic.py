@@ -26,7 +26,8 @@ def main():
     f, w = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
     groups = {"gemm_lds_dma": ("gemm128g_kernel", "gemm160_kernel"), "gemm128g": ("gemm128g_kernel",), "gemm160": ("gemm160_kernel",),
               "gemm128_kernel": ("gemm128_kernel",), "fcc_big_gemm": ("fcc_big_gemm",),
-              "tds_conv_fwd2": ("tds_conv_fwd2_k",), "tds_conv_filter2": ("tds_conv_filter2_k",)}
+              "tds_conv_fwd2": ("tds_conv_fwd2_k",), "tds_conv_filter2": ("tds_conv_filter2_k",),
+              "tds_conv_rs": ("tds_conv_rs_k",), "tds_conv_rsf": ("tds_conv_rsf_k",), "gemm_bf16": ("gemm128_bf16_kernel",)}
     res = {}
     for key, subs in groups.items():
         n = fb = wb = 0.0

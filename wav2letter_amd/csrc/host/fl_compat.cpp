@@ -317,7 +317,9 @@ class PlannedNet : public fl::Sequential {
     w2l::Ctx c;
     c.stream = S(); c.train = train_; c.seed = 0x9E3779B9u * (++step_);
     c.params = (float*)paramArena_.get(); c.grads = (float*)gradArena_.get();
+    const int prevMode = mixed_ ? w2l_set_matmul_precision(1) : 0;
     const float* em = net_->forward(c, (float*)arena_.get(), in.array().device<float>());
+    if (mixed_) w2l_set_matmul_precision(prevMode);
     const int To = net_->outAct().T;
     af::array out = af::array::wrap((void*)em, af::dim4(nLabel_, To, B), af::f32, arena_);
     auto self = this;
@@ -327,7 +329,9 @@ class PlannedNet : public fl::Sequential {
     return {Variable(out, deps, [self, ctx](std::vector<Variable>& ins, const Variable& gradOut) mutable {
       // whole-network backward: overwrites every parameter gradient in the flat gradient arena, then hands each
       // parameter a VIEW of its slice (no per-parameter copies; netoptim steps on the views)
+      const int prevMode = self->mixed_ ? w2l_set_matmul_precision(1) : 0;
       self->net_->backward(ctx, (float*)self->arena_.get(), gradOut.array().device<float>());
+      if (self->mixed_) w2l_set_matmul_precision(prevMode);
       for (size_t i = 0; i + 1 < ins.size(); ++i) {
         const auto& pi = self->net_->params()[i];
         ins[i].zeroGrad();
@@ -339,6 +343,7 @@ class PlannedNet : public fl::Sequential {
   w2l::Sequential& impl() { return *net_; }
   float* paramPtr() { return (float*)paramArena_.get(); }
   float* gradPtr() { return (float*)gradArena_.get(); }
+  bool mixed_ = false;
 
  private:
   std::shared_ptr<w2l::Sequential> net_;
@@ -361,6 +366,9 @@ std::shared_ptr<fl::Sequential> buildSequentialModule(const std::string& archfil
 FlatView flatParameters(const std::shared_ptr<fl::Module>& network) {
   auto* p = dynamic_cast<PlannedNet*>(network.get());
   return p ? FlatView{p->paramPtr(), p->impl().paramFloats()} : FlatView{nullptr, 0};
+}
+void setMixedPrecision(const std::shared_ptr<fl::Module>& network, bool on) {
+  if (auto* p = dynamic_cast<PlannedNet*>(network.get())) p->mixed_ = on;
 }
 FlatView flatGradients(const std::shared_ptr<fl::Module>& network) {
   auto* p = dynamic_cast<PlannedNet*>(network.get());

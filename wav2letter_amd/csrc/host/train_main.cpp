@@ -153,6 +153,10 @@ int main(int argc, char** argv) {
     auto scalemode = getCriterionScaleMode(flags.get("onorm", "none"), flags.getb("sqnorm", false));
     std::cout << "Loading architecture file from " << archPath << std::endl;
     std::shared_ptr<fl::Module> network = fl::pkg::runtime::ModulePlugin(archPath).arch(nFeat, numClasses);
+    if (flags.getb("fl_amp_use_mixed_precision", false)) {
+      setMixedPrecision(network, true);   // bf16 multiplies in the fl::Linear GEMMs, fp32 master weights / criterion
+      std::cout << "Mixed precision training enabled (bf16 matrix multiplies, fp32 accumulation and storage)" << std::endl;
+    }
     std::shared_ptr<SequenceCriterion> criterion;
     if (criterionName == "ctc") criterion = std::make_shared<CTCLoss>(scalemode);
     else if (criterionName == "asg") criterion = std::make_shared<ASGLoss>(numClasses, scalemode, flags.getd("transdiag", 0.0));
