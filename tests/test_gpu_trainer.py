@@ -605,3 +605,37 @@ def test_mixed_precision_streaming_tds_step(oracle):
         losses.append(tr16.forward_backward(x, tgt).sum().item())
         tr16.update(lr=0.05, momentum=0.0, max_grad_norm=0.5)
     assert np.isfinite(losses).all() and losses[-1] < 0.8 * losses[0], losses
+
+
+def test_linseg_phase_has_its_own_momentum():
+    """the reference trains the --linseg warm-up with separate optimizers (linNetoptim / linCritoptim, Train.cpp:589-617):
+    the first ASG update starts from ZERO momentum, not from the warm-up's"""
+    from wav2letter_amd import recipes
+    from wav2letter_amd.trainer import Trainer
+    rng = np.random.default_rng(3)
+    nfeat, nlabel, B, T, L = 40, 12, 2, 40, 5
+    arch = recipes.conv_glu_small_arch()
+    x = torch.tensor(rng.normal(size=(B, nfeat, T)).astype(np.float32)).cuda()
+    tgt = torch.tensor(rng.integers(0, nlabel - 2, size=(B, L)).astype(np.int32)).cuda()
+    tr = Trainer(arch, nfeat, nlabel, "asg", 4, 1.0)
+    tr.set_linseg(2)
+    tr.init_params(3)
+    tr.plan(B, T, L)
+    tr.to_device()
+    kw = dict(lr=0.05, lrcrit=0.001, momentum=0.9, max_grad_norm=1.0, total_batch=B)
+    for _ in range(2):                      # two warm-up updates build up momentum
+        tr.forward_backward(x, tgt)
+        tr.update(**kw)
+    assert tr.mom.abs().max().item() > 0
+    tr.forward_backward(x, tgt)             # update 2: the ASG criterion proper
+    g = tr.grads.clone()
+    p0 = tr.params.clone()
+    tr.update(**kw)
+    # with zero starting momentum the step is exactly -lr * clip(g / B)
+    n = tr.n_net
+    gs = g[:n].double() / B
+    norm = (g.double() / B).norm().item()
+    gs = gs * min(1.0, 1.0 / (norm + 1e-6))
+    want = p0[:n].double() - 0.05 * gs
+    assert (tr.params[:n].double() - want).abs().max().item() < 1e-6 * max(1.0, want.abs().max().item())
+    assert (tr.mom[:n].double() - gs).abs().max().item() < 1e-6 * max(1.0, gs.abs().max().item())

@@ -226,6 +226,10 @@ W2L_API int w2l_trainer_update(void* h, float lr, float lrcrit, float momentum, 
     // totalBatch > 0: the caller's number; <= 0: the all-reduced utterance count in the gradient arena's tail
     const float gs = totalBatch > 0.f ? 1.f / totalBatch : 0.f;
     if (!t->guardZeroed) { hipCheck(hipMemsetAsync(t->sumsq, 0, sizeof(double) * 8, s), "memset"); t->guardZeroed = true; }
+    // --linseg: the reference trains the warm-up phase with its OWN optimizers (linNetoptim / linCritoptim,
+    // Train.cpp:589-617), so the ASG phase proper starts from zero momentum: clear the arena at the switch
+    if (t->linseg && t->linsegUpdates && t->step == t->linsegUpdates && t->mom && momentum != 0.f)
+      hipCheck(hipMemsetAsync(t->mom, 0, sizeof(float) * (t->netFloats + t->critFloats), s), "linseg momentum reset");
     // the norm is taken on EVERY update (also with --maxgradnorm=0): it is the non-finite guard of the step
     w2lCheck(w2l_sumsq(t->grads, t->netFloats, t->sumsq, 1, s), "sumsq");
     w2lCheck(w2l_sumsq(t->grads + t->netFloats, t->critFloats, t->sumsq + 1, 1, s), "sumsq");
