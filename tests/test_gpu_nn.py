@@ -437,6 +437,86 @@ def test_conv_backward_data_accumulate_and_add(oracle, B, Cin, Cout, H, T, kw, s
     assert rel(from_fm(add.cpu().numpy()), odx + base) < TOL
 
 
+TDS_RS3_SHAPES = [(10, 48, 2, 80), (18, 12, 2, 80), (10, 50, 2, 80), (18, 15, 3, 80), (10, 1, 1, 80), (18, 2, 2, 80), (10, 129, 3, 80),
+                  (18, 188, 5, 80), (10, 750, 3, 80), (10, 64, 1, 80), (18, 46, 7, 80), (10, 331, 9, 80), (18, 97, 33, 80), (10, 77, 5, 8),
+                  (18, 150, 2, 24), (10, 2100, 2, 16)]
+
+
+def _tds_conv_ref64(x, w, b, dy, add, kw, padl):
+    import torch.nn.functional as F
+    xr = x.double().permute(0, 3, 2, 1).requires_grad_(True)          # [B][C][H][T]
+    wr = w.double().permute(2, 1, 0)[:, :, None, :]
+    yr = F.conv2d(F.pad(xr, (padl, kw - 1 - padl)), wr, b.double())
+    yr.backward(dy.double().permute(0, 3, 2, 1))
+    return yr.permute(0, 3, 2, 1).detach(), xr.grad.permute(0, 3, 2, 1) + add.double()
+
+
+@pytest.mark.parametrize("Cc,T,B,H", TDS_RS3_SHAPES)
+def test_tds_conv_streamed_wave_specialised_kernel(Cc, T, B, H):
+    """conv_tds_rs3.hpp (the TDS convolution proper, C = 10 / 18, H % 8 == 0): forward with bias, with and without the fused
+    ReLU, and backward-data with the fused addend, every element against a float64 convolution; segment cuts in the
+    middle of utterances, utterances shorter than one tile, one- and two-frame inputs, short kernels, causal padding;
+    run-to-run identical (the overlap-add order is program order)"""
+    import ctypes as C
+    from wav2letter_amd import _lib
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    for kw, padl in ((21, 10), (21, 20), (9, 0)):
+        if kw - 1 - padl >= T + padl and T < 3:
+            continue
+        d = _lib.ConvDesc(B, T, H, Cc, Cc, kw, 1, padl, kw - 1 - padl)
+        g = torch.Generator(device="cpu").manual_seed(Cc * 1000 + T + kw)
+        x = torch.randn(B, T, H, Cc, generator=g).cuda()
+        w = (torch.randn(kw, Cc, Cc, generator=g) / (kw * Cc) ** 0.5).cuda()
+        b = torch.randn(Cc, generator=g).cuda()
+        dy = torch.randn(B, T, H, Cc, generator=g).cuda()
+        add = torch.randn(B, T, H, Cc, generator=g).cuda()
+        ry, rdx = _tds_conv_ref64(x, w, b, dy, add, kw, padl)
+        outs = []
+        for rep in range(2):
+            y = torch.full_like(x, float("nan")); yr = torch.full_like(x, float("nan")); dx = torch.full_like(x, float("nan"))
+            assert L.w2l_conv_forward(C.byref(d), x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), 0, s) == 0
+            assert L.w2l_conv_forward(C.byref(d), x.data_ptr(), w.data_ptr(), b.data_ptr(), yr.data_ptr(), 1, s) == 0
+            assert L.w2l_conv_backward_data_add(C.byref(d), dy.data_ptr(), w.data_ptr(), add.data_ptr(), dx.data_ptr(), s) == 0
+            torch.cuda.synchronize()
+            outs.append((y, yr, dx))
+        y, yr, dx = outs[0]
+        assert rel(y, ry.cpu().numpy()) < TOL
+        assert rel(yr, torch.relu(ry).cpu().numpy()) < TOL
+        assert rel(dx, rdx.cpu().numpy()) < TOL
+        assert all(torch.equal(a, b2) for a, b2 in zip(outs[0], outs[1]))
+
+
+@pytest.mark.parametrize("Cc,T,B", [(10, 331, 3), (18, 97, 5), (14, 77, 2)])
+def test_tds_conv_kernel_generations_agree(Cc, T, B, probe):
+    """the previous generations stay selectable in the probe library (W2L_TDS_RS3_OFF: the cooperative role-swapped kernel,
+    W2L_TDS_RS_OFF: conv_tds.hip's 16-wide tiles) and agree with the product kernels"""
+    import ctypes as C
+    import os
+    from wav2letter_amd import _lib
+    s = torch.cuda.current_stream().cuda_stream
+    H, kw = 80, 21
+    d = _lib.ConvDesc(B, T, H, Cc, Cc, kw, 1, 10, 10)
+    g = torch.Generator(device="cpu").manual_seed(Cc + T)
+    x = torch.randn(B, T, H, Cc, generator=g).cuda()
+    w = (torch.randn(kw, Cc, Cc, generator=g) / (kw * Cc) ** 0.5).cuda()
+    b = torch.randn(Cc, generator=g).cuda()
+
+    def fwd(Lx):
+        y = torch.empty_like(x)
+        assert Lx.w2l_conv_forward(C.byref(d), x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), 1, s) == 0
+        torch.cuda.synchronize()
+        return y
+    want = fwd(_lib.lib())
+    for sw in ("W2L_TDS_RS3_OFF", "W2L_TDS_RS_OFF"):
+        os.environ[sw] = "1"
+        try:
+            got = fwd(probe)
+        finally:
+            os.environ.pop(sw)
+        assert rel(got, want.cpu().numpy()) < TOL
+
+
 @pytest.mark.parametrize("B,Cin,Cout,T,kw,padl,padr", [(2, 40, 100, 60, 13, 0, 0), (2, 321, 706, 64, 19, 0, 0), (2, 40, 400, 90, 13, 170, 170)])
 def test_conv_glu_overlapping_rows_equals_implicit_gemm(B, Cin, Cout, T, kw, padl, padr, probe):
     """the overlapping-row LDS-DMA convolution against the register-staged implicit-GEMM kernels (W2L_CONV_GLDS=0) on

@@ -36,6 +36,7 @@
 // backward-data is the same kernel on dy with tap-flipped, transposed weights (conv_tds.hip keeps the strided C2
 // sub-sampling layers and every other geometry).
 #include <cstdlib>
+#include <type_traits>
 
 #include "gemm.hpp"
 
@@ -116,6 +117,44 @@ struct RsRounds {
     return t;
   }
 };
+
+// the same colouring over register PAIRS (2m, 2m+1): usable when the two rows of a pair (and their +4 lane halves) can
+// never meet at one output
+template <int G, int J>
+struct RsPairRounds {
+  static constexpr bool pconflict(int m, int n) {
+    for (int a = 2 * m; a < 2 * m + 2; ++a)
+      for (int b = 2 * n; b < 2 * n + 2; ++b)
+        if (RsRounds<G, J>::conflict(a, b)) return true;
+    return false;
+  }
+  static constexpr bool ok() {
+    for (int m = 0; m < 8; ++m)
+      if (RsRounds<G, J>::conflict(2 * m, 2 * m + 1)) return false;
+    return true;
+  }
+  struct Table { int color[8]; int n; };
+  static constexpr Table make() {
+    Table t{};
+    t.n = 0;
+    for (int m = 0; m < 8; ++m) {
+      int c = 0;
+      for (;; ++c) {
+        bool free = true;
+        for (int r = 0; r < m; ++r)
+          if (t.color[r] == c && pconflict(m, r)) free = false;
+        if (free) break;
+      }
+      t.color[m] = c;
+      if (c + 1 > t.n) t.n = c + 1;
+    }
+    return t;
+  }
+};
+
+}  // namespace w2l
+#include "conv_tds_rs3.hpp"
+namespace w2l {
 
 template <int C, int G, int J, int KTMAX>
 __global__ __launch_bounds__(256, (RsCfg<C, G, J, KTMAX>::WGS)) void tds_conv_rs_k(TdsRsP p, int nTiles) {
@@ -509,6 +548,53 @@ static int rs_launch(TdsRsP p, hipStream_t s) {
   return W2L_OK;
 }
 
+template <int C, int G, int J, int HH, int CS, int KT>
+static int rs3_launch(const TdsRsP& q, hipStream_t s) {
+  using Cfg = Rs3Cfg<C, G, J, HH, CS, KT>;
+  if (q.H % HH) return W2L_EUNSUPPORTED;
+  TdsRs3P p{};
+  p.x = q.x; p.w = q.w; p.bias = q.bias; p.add = q.add; p.y = q.y;
+  p.B = q.B; p.Tin = q.Tin; p.Tout = q.Tout; p.H = q.H; p.kw = q.kw; p.padl = q.padl; p.relu = q.relu; p.accum = q.accum; p.flip = q.flip;
+  p.abl = q.abl;
+  { const char* e = tune_env("W2L_TDS_RS3_PRIO"); p.prio = e ? atoi(e) : 0; }
+  { const char* e = tune_env("W2L_TDS_RS3_DBG"); p.dbg = e ? (long long*)strtoull(e, nullptr, 10) : nullptr; }
+  p.hBlocks = q.H / HH;
+  const long long total = (long long)q.B * p.hBlocks * q.Tout;
+  if (total <= 0 || total > (1ll << 30)) return W2L_EUNSUPPORTED;
+  if ((long long)q.Tin * q.H * C * 4 >= (1ll << 31) || (long long)q.Tout * q.H * C * 4 >= (1ll << 31)) return W2L_EUNSUPPORTED;   // one utterance per buffer resource
+  // one workgroup per CU; short inputs: at least two full tiles of outputs per workgroup
+  long long wgs = total / (2 * Cfg::L);
+  if (wgs < 1) wgs = 1;
+  if (wgs > 256) wgs = 256;
+  p.quota = (int)((total + wgs - 1) / wgs);
+  const int blocks = (int)((total + p.quota - 1) / p.quota);
+#ifdef W2L_PROBE
+  if (p.abl) {
+    bool done = false;
+    auto go = [&](auto tag) {
+      constexpr int M = decltype(tag)::value;
+      if (p.abl != M || done || p.add) return;
+      (void)hipFuncSetAttribute((const void*)tds_conv_rs3_k<C, G, J, HH, CS, KT, false, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
+      hipLaunchKernelGGL((tds_conv_rs3_k<C, G, J, HH, CS, KT, false, M>), dim3((unsigned)blocks), dim3(768), Cfg::LDS, s, p);
+      done = true;
+    };
+    go(std::integral_constant<int, 2>{}); go(std::integral_constant<int, 32>{}); go(std::integral_constant<int, 34>{});
+    go(std::integral_constant<int, 92>{}); go(std::integral_constant<int, 94>{}); go(std::integral_constant<int, 126>{});
+    go(std::integral_constant<int, 35>{}); go(std::integral_constant<int, 28>{});
+    if (done) return W2L_OK;
+  }
+#endif
+  static bool attr = false;
+  if (!attr) {
+    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_rs3_k<C, G, J, HH, CS, KT, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
+    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_rs3_k<C, G, J, HH, CS, KT, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
+    attr = true;
+  }
+  if (p.add) hipLaunchKernelGGL((tds_conv_rs3_k<C, G, J, HH, CS, KT, true, 0>), dim3((unsigned)blocks), dim3(768), Cfg::LDS, s, p);
+  else hipLaunchKernelGGL((tds_conv_rs3_k<C, G, J, HH, CS, KT, false, 0>), dim3((unsigned)blocks), dim3(768), Cfg::LDS, s, p);
+  return W2L_OK;
+}
+
 // true + *status when this geometry runs on the role-swapped kernel
 bool tds_rs_try(const float* x, const float* w, const float* bias, const float* add, float* y, int B, int Tin, int Tout, int H,
                 int C, int kw, int padl, int relu, int accum, int flip, int profKind, hipStream_t s, int* status) {
@@ -520,6 +606,17 @@ bool tds_rs_try(const float* x, const float* w, const float* bias, const float* 
   p.B = B; p.Tin = Tin; p.Tout = Tout; p.H = H; p.kw = kw; p.padl = padl; p.relu = relu; p.accum = accum; p.flip = flip;
   { const char* e = tune_env("W2L_TDS_RS_ABL"); p.abl = e ? atoi(e) : 0; }
   { const char* e = tune_env("W2L_TDS_RS_STAGGER"); p.stagger = e ? atoi(e) : (C == 10 ? 4 : 0); }
+  // third generation (conv_tds_rs3.hpp): wave-specialised, streamed time axis.  One utterance per 2 GiB buffer resource.
+  const bool rs3 = !tune_env("W2L_TDS_RS3_OFF") && H % 8 == 0 && C != 14 && !accum && (long long)B * (H / 4) * Tout <= (1ll << 30) &&
+                   (long long)Tin * H * C * 4 < (1ll << 31) && (long long)Tout * H * C * 4 < (1ll << 31);
+  if (rs3) {
+    prof_begin(s, 2.0 * B * Tout * (double)H * kw * C * C, profKind);
+    int st = C == 10 ? rs3_launch<10, 3, 7, 8, 1, 2>(p, s) : rs3_launch<18, 7, 3, 4, 2, 2>(p, s);
+    prof_end(s);
+    if (st == W2L_OK && hipGetLastError() != hipSuccess) st = W2L_EHIP;
+    *status = st;
+    return true;
+  }
   if (C == 14 && !tune_env("W2L_TDS_RS_C14")) return false;   // C = 14: conv_tds.hip's 16-wide tiles (87.5 % of the lanes) stay ahead
   const bool v2 = tune_env("W2L_TDS_RS_V2") != nullptr;       // probe build: the autonomous-wave LDS-DMA variant (measured slower)
   const bool planned = C == 10 ? rs_plan(Tout, RsCfg<10, 3, 7, 4>::HALO, v2 ? 6 : 4, p)
