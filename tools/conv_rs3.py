@@ -67,17 +67,18 @@ def big():
         b = torch.randn(Cc, device="cuda")
         dy = torch.randn(B, T, H, Cc, device="cuda")
         os.environ["W2L_TDS_RS3_OFF"] = "1"
+        os.environ["W2L_TDS_RSF3_OFF"] = "1"
         with _lib.use_probe() as P:
             old, to = run(P, d, x, w, b, dy)
-        os.environ.pop("W2L_TDS_RS3_OFF")
+        os.environ.pop("W2L_TDS_RS3_OFF"); os.environ.pop("W2L_TDS_RSF3_OFF")
         os.environ["W2L_TDS_RS3"] = "1"
         os.environ["W2L_TDS_RS_C14"] = "1"
         with _lib.use_probe() as P:
             new, tn = run(P, d, x, w, b, dy)
-        e_ab = {k: ((new[k].double() - old[k].double()).abs().max() / old[k].double().abs().max()).item() for k in ("y", "dx")}
+        e_ab = {k: ((new[k].double() - old[k].double()).abs().max() / old[k].double().abs().max()).item() for k in ("y", "dx", "dw", "db")}
         flops = 2.0 * B * T * H * kw * Cc * Cc
         print(f"C={Cc} T={T} B={B}: rs3 vs previous generation " + " ".join(f"{k} {v:.1e}" for k, v in e_ab.items()))
-        for k in ("fwd", "bwd_data"):
+        for k in ("fwd", "bwd_data", "bwd_filter"):
             print(f"    {k:10s} rs3 {tn[k]:8.1f} us = {flops / tn[k] / 1e6:6.1f} TF/s   previous {to[k]:8.1f} us = {flops / to[k] / 1e6:6.1f} TF/s")
         dbg = torch.zeros(256 * 8, dtype=torch.int64, device="cuda")
         os.environ["W2L_TDS_RS3_DBG"] = str(dbg.data_ptr())

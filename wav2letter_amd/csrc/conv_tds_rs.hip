@@ -795,23 +795,34 @@ __global__ __launch_bounds__(256, (160 * 1024 / RsfCfg<C, GA, GB, TS>::LDS) >= 3
 }
 
 // dw / dbias = sum over the workgroups' partials, in workgroup order.  One thread per (element, slice of the partials);
-// 64 elements x 4 slices per block, slices combined in fixed order through LDS.
+// 64 elements x 16 slices per block (the partials of a slice are independent loads: 16 in flight per thread with 256
+// workgroups), slices combined in fixed order through LDS.  (With 4 slices and one load stream per thread this launch
+// took 17-20 us, a fifth of the whole filter gradient: profiles/r02_run15_*.)
 template <int C, int GA, int GB, int NRT, int NCT>
-__global__ __launch_bounds__(256) void tds_rsf_reduce_k(const float* __restrict__ partial, int nParts, int kw, float* __restrict__ dw,
-                                                       float* __restrict__ dbias) {
-  constexpr int ACCF = NRT * NCT * 16 * 64;
-  __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void tds_rsf_reduce_k(const float* __restrict__ partial, int nParts, int kw, float* __restrict__ dw,
+                                                        float* __restrict__ dbias) {
+  constexpr int ACCF = NRT * NCT * 16 * 64, NS = 16;
+  __shared__ float red[NS][64];
   const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + el;   // index in register order: ((rt*NCT + ct)*16 + q)*64 + lane
   float s = 0.f;
-  const int per = (nParts + 3) / 4;
+  const int per = (nParts + NS - 1) / NS;
   const int g0 = sl * per, g1 = g0 + per < nParts ? g0 + per : nParts;
-  if (e < ACCF)
-    for (int g = g0; g < g1; ++g) s += partial[(size_t)g * ACCF + e];
+  if (e < ACCF) {
+    int g = g0;
+    for (; g + 4 <= g1; g += 4) {
+      const float a0 = partial[(size_t)g * ACCF + e], a1 = partial[(size_t)(g + 1) * ACCF + e], a2 = partial[(size_t)(g + 2) * ACCF + e],
+                  a3 = partial[(size_t)(g + 3) * ACCF + e];
+      s = (((s + a0) + a1) + a2) + a3;
+    }
+    for (; g < g1; ++g) s += partial[(size_t)g * ACCF + e];
+  }
   red[sl][el] = s;
   __syncthreads();
   if (sl == 0 && e < ACCF) {
-    const float t = ((red[0][el] + red[1][el]) + red[2][el]) + red[3][el];
+    float t = red[0][el];
+#pragma unroll
+    for (int k = 1; k < NS; ++k) t += red[k][el];
     const int lane = e & 63, q = (e >> 6) & 15, tl = e >> 10, rt = tl / NCT, ct = tl - rt * NCT;
     const int m = 32 * rt + 8 * (q >> 2) + 4 * (lane >> 5) + (q & 3), n = 32 * ct + (lane & 31);
     const int gb = n / C, co = n - gb * C;
@@ -827,6 +838,36 @@ __global__ __launch_bounds__(256) void tds_rsf_reduce_k(const float* __restrict_
 }
 
 float* sk_scratch(hipStream_t s, size_t bytes);
+
+}  // namespace w2l
+#include "conv_tds_rsf3.hpp"
+namespace w2l {
+
+template <int C, int GA, int GB, int HH, int TS>
+static int rsf3_launch(const TdsRsfP& q, float* dw, float* dbias, hipStream_t s) {
+  using Cfg = Rsf3Cfg<C, GA, GB, HH, TS>;
+  if (q.H % HH) return W2L_EUNSUPPORTED;
+  if ((long long)q.Tin * q.H * C * 4 >= (1ll << 31) || (long long)q.Tout * q.H * C * 4 >= (1ll << 31)) return W2L_EUNSUPPORTED;   // one utterance per buffer resource
+  TdsRsf3P p{};
+  p.x = q.x; p.dy = q.dy; p.B = q.B; p.Tin = q.Tin; p.Tout = q.Tout; p.H = q.H; p.kw = q.kw; p.padl = q.padl;
+  p.hBlocks = q.H / HH;
+  p.nStrips = (q.Tout + GB - 1 + TS - 1) / TS;
+  const long long tiles = (long long)q.B * p.nStrips * p.hBlocks;
+  if (tiles > (1ll << 30)) return W2L_EUNSUPPORTED;
+  p.nTiles = (int)tiles;
+  const int blocks = p.nTiles < 256 ? p.nTiles : 256;
+  float* partial = sk_scratch(s, kSkScratchBytes);
+  if (!partial || (size_t)blocks * Cfg::ACCF * sizeof(float) > kSkScratchBytes) return W2L_EUNSUPPORTED;
+  static bool attr = false;
+  if (!attr) {
+    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_rsf3_k<C, GA, GB, HH, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
+    attr = true;
+  }
+  hipLaunchKernelGGL((tds_conv_rsf3_k<C, GA, GB, HH, TS>), dim3((unsigned)blocks), dim3(Cfg::WAVES * 64), Cfg::LDS, s, p, partial);
+  hipLaunchKernelGGL((tds_rsf_reduce_k<C, GA, GB, Cfg::NRT, Cfg::NCT>), dim3((unsigned)((Cfg::ACCF + 63) / 64)), dim3(1024), 0, s, partial,
+                     blocks, q.kw, dw, dbias);
+  return W2L_OK;
+}
 
 template <int C, int GA, int GB, int TS>
 static int rsf_launch(TdsRsfP p, float* dw, float* dbias, hipStream_t s) {
@@ -844,7 +885,7 @@ static int rsf_launch(TdsRsfP p, float* dw, float* dbias, hipStream_t s) {
     attr = true;
   }
   hipLaunchKernelGGL((tds_conv_rsf_k<C, GA, GB, TS>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p, partial, nTiles);
-  hipLaunchKernelGGL((tds_rsf_reduce_k<C, GA, GB, Cfg::NRT, Cfg::NCT>), dim3((unsigned)((Cfg::ACCF + 63) / 64)), dim3(256), 0, s, partial,
+  hipLaunchKernelGGL((tds_rsf_reduce_k<C, GA, GB, Cfg::NRT, Cfg::NCT>), dim3((unsigned)((Cfg::ACCF + 63) / 64)), dim3(1024), 0, s, partial,
                      blocks, p.kw, dw, dbias);
   return W2L_OK;
 }
@@ -859,7 +900,11 @@ bool tds_rsf_try(const float* x, const float* dy, float* dw, float* dbias, int B
   TdsRsfP p{};
   p.x = x; p.dy = dy; p.B = B; p.Tin = Tin; p.Tout = Tout; p.H = H; p.kw = kw; p.padl = padl;
   prof_begin(s, 2.0 * B * Tout * (double)H * kw * C * C, PROF_TDS_BWD_FILTER);
-  int st;
+  int st = W2L_EUNSUPPORTED;
+  if (!tune_env("W2L_TDS_RSF3_OFF") && H % 8 == 0 && C != 14)   // wave-specialised generation (conv_tds_rsf3.hpp)
+    st = C == 10 ? rsf3_launch<10, 3, 7, 8, 96>(p, dw, dbias, s) : rsf3_launch<18, 7, 3, 4, 96>(p, dw, dbias, s);
+  if (st != W2L_EUNSUPPORTED) {
+  } else
   if (C == 10) st = rsf_launch<10, 3, 7, 128>(p, dw, dbias, s);
   else if (C == 14) st = rsf_launch<14, 2, 11, 128>(p, dw, dbias, s);
   else st = rsf_launch<18, 7, 3, 96>(p, dw, dbias, s);
