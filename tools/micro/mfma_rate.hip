@@ -27,11 +27,14 @@ __global__ __launch_bounds__(768) void k(float* out, long long* clk, int iters) 
 #pragma unroll
     for (int s = 0; s < NK; ++s) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
-      if (LDSOPS >= 1 && s < 32) {
+      if (LDSOPS >= 1 && LDSOPS < 10 && s < 32) {
         if (s % 2 == 0) old[s / 2] = o[s / 2];
         else o[s / 2] = old[s / 2] + accP[s / 2];
       }
-      if (LDSOPS >= 2) a[s] += lds[4096 + ((tid + s * 67) & 2047)] * 1e-30f;
+      if (LDSOPS >= 2 && LDSOPS < 10) a[s] += lds[4096 + ((tid + s * 67) & 2047)] * 1e-30f;
+      if (LDSOPS == 10) asm volatile("s_add_u32 s40, s40, 1\n\ts_add_u32 s41, s41, 1\n\ts_add_u32 s42, s42, 1\n\ts_add_u32 s43, s43, 1" ::: "s40", "s41", "s42", "s43");
+      if (LDSOPS == 11) asm volatile("v_add_u32 %0, %0, 1\n\tv_add_u32 %1, %1, 1\n\tv_add_u32 %2, %2, 1\n\tv_add_u32 %3, %3, 1" : "+v"(b[(s + 5) % NK]), "+v"(b[(s + 9) % NK]), "+v"(b[(s + 13) % NK]), "+v"(b[(s + 17) % NK]));
+      if (LDSOPS == 12) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_waitcnt lgkmcnt(0)");
       __builtin_amdgcn_sched_barrier(0);
     }
     if (RESET) {
@@ -84,5 +87,8 @@ int main() {
   for (int w : {4, 8, 12}) run<35, 2, 1, 0>("+ one fragment ds_read per MFMA as well", w);
   for (int w : {8, 12}) run<35, 2, 1, 1>("+ workgroup barrier every 70 MFMAs", w);
   for (int w : {8}) run<27, 2, 1, 1>("the same with chains of 27", w);
+  for (int w : {4, 8}) run<35, 10, 1, 0>("chains + 4 SALU instructions per MFMA", w);
+  for (int w : {4, 8}) run<35, 11, 1, 0>("chains + 4 VALU instructions per MFMA", w);
+  for (int w : {4, 8}) run<35, 12, 1, 0>("chains + 4 s_waitcnt per MFMA", w);
   return 0;
 }
