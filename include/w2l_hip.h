@@ -201,6 +201,13 @@ int w2l_dropout_copy(float* y, const float* x, size_t n, double p, uint32_t seed
                      w2l_stream_t stream);
 int w2l_mask_backward(const float* dy, const float* src, float* dx, size_t n, float scale,
                       w2l_stream_t stream);
+
+/* fl::Conv2D with a kh x kw kernel, kh > 1 (the "C2 cin cout kw kh sx 1 px -1" lines of
+ * recipes/sota/2019/am_arch/am_tds_ctc_librivox.arch:3-26; builder recipes/joint_training_vox_populi/cpc/SequentialBuilder.cpp:285-300)
+ * runs as a kw x 1 convolution over kh*C channels: xe[r][h][dh*C + c] = x[r][h + dh - padh][c], zero outside the mel
+ * axis; rows = utterances x frames.  _backward is the adjoint (sum over dh). */
+int w2l_hexpand_forward(const float* x, float* xe, size_t rows, int H, int C, int kh, int padh, w2l_stream_t stream);
+int w2l_hexpand_backward(const float* dxe, float* dx, size_t rows, int H, int C, int kh, int padh, w2l_stream_t stream);
 int w2l_axpy(float* y, const float* x, size_t n, float alpha, w2l_stream_t stream);
 int w2l_fill(float* y, size_t n, float v, w2l_stream_t stream);
 int w2l_transpose(const float* in, float* out, int G, int R, int C, w2l_stream_t stream);

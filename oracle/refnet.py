@@ -125,8 +125,9 @@ class RefNet:
                     out.append(("wn.g", (cout,)))
                 out.append(("conv.b", (cout,)))
             elif t[0] == "C2":
-                cin, cout, kw = int(t[1]), int(t[2]), int(t[3])
-                out += [("conv.w", (cout, cin, kw)), ("conv.b", (cout,))]
+                cin, cout, kw, kh = int(t[1]), int(t[2]), int(t[3]), int(t[4])
+                # Flashlight Conv2D weight, ArrayFire dims (kw, kh, cin, cout) == row-major [cout][cin][kh][kw]
+                out += [("conv.w", (cout, cin, kw) if kh == 1 else (cout, cin, kh, kw)), ("conv.b", (cout,))]
             elif t[0] == "L":
                 out.append(("linear.w", (int(t[1]), int(t[2]))))
                 if wn:
@@ -203,6 +204,21 @@ class RefNet:
                 T = a.shape[3]
                 cin, cout, kw, stride, pl, pr = self._conv_pads(t, T)
                 w = params[pi]; pi += 1
+                kh = int(t[4]) if t[0] == "C2" else 1
+                if kh > 1:
+                    # kh x kw kernel, SAME on the mel axis (am_tds_ctc_librivox.arch): a kw x 1 convolution over kh*cin
+                    # channels, channel dh*cin + ci of mel row h = input row h + dh - (kh-1)/2 (zero outside)
+                    assert wn_dim is None and kh % 2 == 1 and (len(t) <= 8 or int(t[8]) in (-1, (kh - 1) // 2)), t
+                    B_, _, H_, T_ = a.shape
+                    ph = (kh - 1) // 2
+                    ap = np.zeros((B_, cin, H_ + 2 * ph, T_), a.dtype)
+                    ap[:, :, ph:ph + H_] = a
+                    ae = np.concatenate([ap[:, :, dh:dh + H_] for dh in range(kh)], axis=1)
+                    we = np.ascontiguousarray(w.transpose(0, 2, 1, 3)).reshape(cout, kh * cin, kw)
+                    b = params[pi]; pi += 1
+                    self.tape.append(("C2D", ae, we, stride, pl, pr, pi, kh, cin))
+                    a = O.conv_fwd(np.ascontiguousarray(ae), we, b, stride, pl, pr)
+                    continue
                 v = w
                 g = None
                 if wn_dim is not None:
@@ -290,6 +306,18 @@ class RefNet:
                 else:
                     g[pi - 2] = dw
                 da = dx
+            elif k == "C2D":
+                _, ae, we, stride, pl, pr, pi, kh, cin = rec
+                dxe, dwe, db = O.conv_bwd(np.ascontiguousarray(ae), we, da, stride, pl, pr)
+                g[pi - 1] = db
+                cout = we.shape[0]
+                g[pi - 2] = np.ascontiguousarray(dwe.reshape(cout, kh, cin, -1).transpose(0, 2, 1, 3))
+                B_, _, H_, T_ = dxe.shape
+                ph = (kh - 1) // 2
+                dp = np.zeros((B_, cin, H_ + 2 * ph, T_), dxe.dtype)
+                for dh in range(kh):
+                    dp[:, :, dh:dh + H_] += dxe[:, dh * cin:(dh + 1) * cin]
+                da = dp[:, :, ph:ph + H_]
             elif k == "L":
                 _, z, w, v, gg, shp, pi = rec
                 dz, dw, db = O.linear_bwd(z, w, np.ascontiguousarray(da).reshape(z.shape[0], -1))

@@ -67,7 +67,12 @@ class TorchNet:
                 pad = int(t[7]) if len(t) > 7 else 0
                 if pad == -1:
                     pad = O.same_pad(a.shape[3], kw, stride)
-                a = self._conv(a, params[pi], params[pi + 1], stride, pad, pad)
+                kh = int(t[4])
+                if kh > 1:   # [cout][cin][kh][kw] kernel, SAME on the mel axis
+                    ph = (kh - 1) // 2
+                    a = F.conv2d(F.pad(a, (pad, pad, ph, ph)), params[pi], params[pi + 1], stride=(1, stride))
+                else:
+                    a = self._conv(a, params[pi], params[pi + 1], stride, pad, pad)
                 pi += 2
             elif k == "L":
                 nin = int(t[1])

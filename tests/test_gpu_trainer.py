@@ -215,6 +215,27 @@ def test_tds_ctc_recipe_channel_counts_strict_gradients(oracle, stages):
     check_grads(tr, ref.backward(o.backward().astype(np.float32), len(params)))
 
 
+def test_librivox_two_dimensional_subsampling_convolutions(oracle):
+    """am_tds_ctc_librivox.arch's geometry: `C2 cin cout 21 3 2 1 -1 -1` (21 frames x 3 mel rows, SAME on both axes)
+    between TDS stages of 16 / 32 channels on 80 mel rows -- emissions, CTC loss and every parameter gradient (the
+    [cout][cin][kh][kw] kernels included) against the reference network + criterion oracle"""
+    rng = np.random.default_rng(33)
+    nfeat, nlabel, B, T, L = 80, 30, 2, 64, 5
+    arch = ("V -1 NFEAT 1 0\nC2 1 16 21 3 2 1 -1 -1\nR\nDO 0.0\nLN 0 1 2\nTDS 16 21 80 0.0 2400\nC2 16 32 21 3 2 1 -1 -1\nR\nDO 0.0\n"
+            "LN 0 1 2\nTDS 32 21 80 0.0 0\nV 0 2560 1 0\nRO 1 0 3 2\nL 2560 NLABEL\n")
+    tr, ref, params, _ = build(arch, nfeat, nlabel, "ctc", 4, 0.0, rng, B, T, L)
+    x = rng.normal(size=(B, 1, nfeat, T)).astype(np.float32)
+    tgt = rng.integers(0, nlabel - 1, size=(B, L)).astype(np.int32)
+    xd = torch.tensor(x.reshape(B, nfeat, T)).cuda()
+    td = torch.tensor(tgt).cuda()
+    em_ref = ref.forward(x, params)
+    assert rel(tr.forward(xd, train=False).cpu().numpy(), em_ref) < TOL
+    loss = tr.forward_backward(xd, td).cpu().numpy()
+    o = oracle.CTC(em_ref, tgt, scale_mode=4)
+    assert rel(loss, o.forward()) < TOL
+    check_grads(tr, ref.backward(o.backward().astype(np.float32), len(params)))
+
+
 def test_conv_glu_librispeech_config4_full_network_end_to_end(oracle):
     """BASELINE config 4 -- the full conv_glu LibriSpeech recipe network (17 WN-conv + GLU layers, 208.9 M parameters,
     first layer padded by 170 frames, kernels 13..29), ASG criterion -- at a reduced batch and number of frames, dropout

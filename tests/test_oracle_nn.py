@@ -282,3 +282,29 @@ def test_torch_cpu_proxy_matches_reference_interpreter(oracle):
         assert np.abs(a.grad.numpy() - b).max() < 2e-4 * max(1e-6, np.abs(b).max())
     med, times = torchnet.tds_ctc_step_seconds(arch, nfeat, nlabel, B, T, L=4, warmup=1, runs=2)
     assert med > 0 and len(times) == 2
+
+
+def test_two_dimensional_conv_oracles_agree(oracle):
+    """kh x kw Conv2D (am_tds_ctc_librivox.arch): the numpy / C reference network (mel axis unrolled into channels) against
+    torch's conv2d on the [cout][cin][kh][kw] kernel -- emissions and every parameter gradient"""
+    from oracle import torchnet
+    arch = ("V -1 NFEAT 1 0\nC2 1 4 5 3 2 1 -1 -1\nR\nDO 0.0\nLN 0 1 2\nTDS 4 5 8 0.0 48\nC2 4 6 5 3 1 1 -1 -1\nR\nDO 0.0\nLN 0 1 2\n"
+            "TDS 6 5 8 0.0 0\nV 0 48 1 0\nRO 1 0 3 2\nL 48 NLABEL\n")
+    nfeat, nlabel, B, T = 8, 11, 2, 36
+    rng = np.random.default_rng(8)
+    ref = refnet.RefNet(arch, nfeat, nlabel)
+    params = ref.random_params(rng)
+    assert params[0].shape == (4, 1, 3, 5)
+    x = rng.normal(size=(B, 1, nfeat, T)).astype(np.float32)
+    em = ref.forward(x, params)
+    tp = [torch.from_numpy(p.astype(np.float64)).requires_grad_(True) for p in params]
+    tem = torchnet.TorchNet(arch, nfeat, nlabel).forward(torch.from_numpy(x.astype(np.float64)), tp)
+    assert tem.shape == em.shape
+    assert np.abs(tem.detach().numpy() - em).max() < 1e-4 * np.abs(em).max()
+    d = rng.normal(size=em.shape).astype(np.float32)
+    g = ref.backward(d, len(params))
+    tem.backward(torch.from_numpy(d.astype(np.float64)))
+    for a, b in zip(tp, g):
+        b = np.asarray(b, np.float64)
+        assert a.grad.shape == b.shape
+        assert np.abs(a.grad.numpy() - b).max() < 2e-4 * max(1e-6, np.abs(b).max())

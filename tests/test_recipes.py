@@ -22,6 +22,7 @@ def test_generators_reproduce_reference_arch_files():
     assert _lines(recipes.conv_glu_wsj_arch()) == _lines(open(f"{REF}/conv_glu/wsj/network.arch").read())
     assert _lines(recipes.streaming_tds_arch()) == _lines(
         open(f"{REF}/streaming_convnets/librispeech/am_500ms_future_context.arch").read())
+    assert _lines(recipes.tds_ctc_librivox_arch()) == _lines(open(f"{REF}/sota/2019/am_arch/am_tds_ctc_librivox.arch").read())
 
 
 @need_ref
@@ -79,6 +80,24 @@ def test_headline_archs_build_and_have_the_published_parameter_counts():
     t = Trainer(recipes.conv_glu_librispeech_arch(), 40, 30, "asg", transdiag=4.0, device="cpu")
     n = sum(n for _, n, _ in t.param_table())
     assert abs(n - 208.9e6) < 0.1e6, n
+
+
+def test_librivox_arch_with_two_dimensional_subsampling_convolutions_builds():
+    """am_tds_ctc_librivox.arch: `C2 cin cout 21 3 2 1 -1 -1` (21 frames x 3 mel rows) -- parameter shapes in the
+    reference's order and dims, and the network plans at a recipe-sized batch"""
+    from wav2letter_amd import recipes
+    from wav2letter_amd.trainer import Trainer
+    t = Trainer(recipes.tds_ctc_librivox_arch(), 80, 9998, "ctc", device="cpu")
+    table = t.param_table()
+    assert table[0][1] == 21 * 3 * 1 * 16 and table[1][1] == 16          # first C2: weight (kw, kh, cin, cout), bias
+    convs = [n for name, n, _ in table if name == "conv.w"]
+    assert 21 * 3 * 16 * 16 in convs and 21 * 3 * 16 * 32 in convs and 21 * 1 * 32 * 48 in convs
+    assert t.plan(4, 800, 40) == 100                                      # three stride-2 stages, the fourth keeps T
+    from wav2letter_amd._lib import W2LInvalidArgument
+    with pytest.raises(W2LInvalidArgument):                               # even kh / stride on the mel axis: not a recipe geometry
+        Trainer("V -1 NFEAT 1 0\nC2 1 4 5 2 1 1 -1 -1\n", 8, 5, "ctc", device="cpu")
+    with pytest.raises(W2LInvalidArgument):
+        Trainer("V -1 NFEAT 1 0\nC2 1 4 5 3 1 2 -1 -1\n", 8, 5, "ctc", device="cpu")
 
 
 def test_unsupported_layers_fail_loudly():

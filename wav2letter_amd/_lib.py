@@ -119,6 +119,8 @@ class _SIGS:
     w2l_linear_forward_dropout = (_i, [_i, _i, _i, _p, _p, _p, _p, _i, _d, _u32, _u32, _p])
     w2l_linear_backward_data_add = (_i, [_i, _i, _i, _p, _p, _p, _p, _p])
     w2l_mask_backward = (_i, [_p, _p, _p, _sz, _f, _p])
+    w2l_hexpand_forward = (_i, [_p, _p, _sz, _i, _i, _i, _i, _p])
+    w2l_hexpand_backward = (_i, [_p, _p, _sz, _i, _i, _i, _i, _p])
     w2l_axpy = (_i, [_p, _p, _sz, _f, _p])
     w2l_transpose = (_i, [_p, _p, _i, _i, _i, _p])
     w2l_glu_forward = (_i, [_p, _p, _sz, _i, _p])

@@ -614,6 +614,56 @@ W2L_API int w2l_mask_backward(const float* dy, const float* src, float* dx, size
   return W2L_OK;
 }
 
+// Conv2D with a kh x kw kernel (kh > 1: the librivox TDS arch, recipes/sota/2019/am_arch/am_tds_ctc_librivox.arch:3) as a
+// kw x 1 convolution over kh*C channels: the mel axis is unrolled into the channels of each mel row,
+//   xe[r][h][dh*C + c] = x[r][h + dh - padh][c]   (zero outside [0, H));   r = (utterance, frame)
+__global__ __launch_bounds__(256) void hexpand_k(const float* __restrict__ x, float* __restrict__ xe, size_t n, int H, int C, int kh, int padh) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int c = (int)(i % C);
+    size_t q = i / C;
+    const int dh = (int)(q % kh); q /= kh;
+    const int h = (int)(q % H);
+    const size_t r = q / H;
+    const int hs = h + dh - padh;
+    xe[i] = hs >= 0 && hs < H ? x[(r * H + hs) * C + c] : 0.f;
+  }
+}
+// the adjoint: dx[r][h][c] = sum_dh dxe[r][h - dh + padh][dh*C + c]
+__global__ __launch_bounds__(256) void hfold_k(const float* __restrict__ dxe, float* __restrict__ dx, size_t n, int H, int C, int kh, int padh) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int c = (int)(i % C);
+    size_t q = i / C;
+    const int h = (int)(q % H);
+    const size_t r = q / H;
+    float s = 0.f;
+    for (int dh = 0; dh < kh; ++dh) {
+      const int hd = h - dh + padh;
+      if (hd >= 0 && hd < H) s += dxe[((r * H + hd) * kh + dh) * C + c];
+    }
+    dx[i] = s;
+  }
+}
+
+W2L_API int w2l_hexpand_forward(const float* x, float* xe, size_t rows, int H, int C, int kh, int padh, w2l_stream_t stream) {
+  if (!x || !xe || H < 1 || C < 1 || kh < 1 || padh < 0 || padh >= kh) return W2L_EINVAL;
+  const size_t n = rows * H * kh * C;
+  if (!n) return W2L_OK;
+  hipLaunchKernelGGL(hexpand_k, dim3(ew_grid(n)), dim3(kEwThreads), 0, W2L_S, x, xe, n, H, C, kh, padh);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+W2L_API int w2l_hexpand_backward(const float* dxe, float* dx, size_t rows, int H, int C, int kh, int padh, w2l_stream_t stream) {
+  if (!dxe || !dx || H < 1 || C < 1 || kh < 1 || padh < 0 || padh >= kh) return W2L_EINVAL;
+  const size_t n = rows * H * C;
+  if (!n) return W2L_OK;
+  hipLaunchKernelGGL(hfold_k, dim3(ew_grid(n)), dim3(kEwThreads), 0, W2L_S, dxe, dx, n, H, C, kh, padh);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
 W2L_API int w2l_axpy(float* y, const float* x, size_t n, float alpha, w2l_stream_t stream) {
   if (!y || !x) return W2L_EINVAL;
   if (!n) return W2L_OK;

@@ -240,6 +240,8 @@ struct WNState {
 class Conv2DLayer : public Layer {
  public:
   int cin, cout, kw, stride, pad;  // pad -1 = SAME
+  int kh = 1, padH = 0;            // kh > 1: the mel axis is unrolled into kh*cin channels (w2l_hexpand_*), SAME padding on it
+  size_t xeOff = 0, dxeOff = 0, nIn = 0;
   bool hasBias = true, fuseRelu = false;
   int extraPadL = 0, extraPadR = 0;  // from a preceding "PD" (time axis)
   WNState wn;
@@ -252,17 +254,17 @@ class Conv2DLayer : public Layer {
   std::string name() const override { return wn.on ? "WeightNorm(Conv2D)" : "Conv2D"; }
   void registerParams(std::vector<ParamInfo>& t) override {
     ParamInfo pw;
-    pw.numel = (size_t)kw * cin * cout;
-    pw.refShape = {kw, 1, cin, cout};
-    pw.kind = 1; pw.kw = kw; pw.cin = cin; pw.cout = cout;
-    pw.initBound = std::sqrt(1.0 / ((double)cin * kw));
+    pw.numel = (size_t)kw * kh * cin * cout;
+    pw.refShape = {kw, kh, cin, cout};
+    pw.kind = 1; pw.kw = kw; pw.kh = kh; pw.cin = cin; pw.cout = cout;
+    pw.initBound = std::sqrt(1.0 / ((double)cin * kw * kh));
     if (wn.on) {
       pw.name = "wn.v";
       addParam(t, pw, wn.v);
       ParamInfo pg;
       pg.name = "wn.g"; pg.numel = cout; pg.refShape = {1, 1, 1, cout}; pg.kind = 4;  // init = ||v||
       addParam(t, pg, wn.g);
-      wn.K = kw * cin; wn.N = cout;
+      wn.K = kw * kh * cin; wn.N = cout;
     } else {
       pw.name = "conv.w";
       addParam(t, pw, w);
@@ -270,7 +272,7 @@ class Conv2DLayer : public Layer {
     if (hasBias) {
       ParamInfo pb;
       pb.name = "conv.b"; pb.numel = cout; pb.refShape = {1, 1, cout, 1};
-      pb.initBound = std::sqrt(1.0 / ((double)cin * kw));
+      pb.initBound = std::sqrt(1.0 / ((double)cin * kw * kh));
       addParam(t, pb, b);
     }
   }
@@ -280,13 +282,15 @@ class Conv2DLayer : public Layer {
     int pL, pR;
     if (pad == -1) pL = pR = samePad(in.T, kw, stride); else pL = pR = pad;
     pL += extraPadL; pR += extraPadR;
-    d = {in.B, in.T, H, cin, cout, kw, stride, pL, pR};
+    d = {in.B, in.T, H, kh * cin, cout, kw, stride, pL, pR};
     int To = w2l_conv_out_len(in.T, kw, stride, pL, pR);
     if (To <= 0) throw std::invalid_argument("Conv2D: input too short: " + in.str());
     Act o = convOutAct(in, To, H, cout);
     nOut = o.numel();
     yOff = pl.alloc(nOut);
     dxOff = pl.alloc(in.numel());
+    nIn = in.numel();
+    if (kh > 1) { xeOff = pl.alloc(nIn * kh); dxeOff = pl.alloc(nIn * kh); }
     if (wn.on) {
       wn.wOff = pl.alloc((size_t)wn.K * wn.N);
       wn.dwOff = pl.alloc((size_t)wn.K * wn.N);
@@ -302,6 +306,10 @@ class Conv2DLayer : public Layer {
   }
   void forward(Ctx& c, float* arena, const float* x, float*& y) override {
     y = arena + yOff;
+    if (kh > 1) {
+      w2lCheck(w2l_hexpand_forward(x, arena + xeOff, (size_t)d.B * d.T, d.H, cin, kh, padH, c.stream), "conv H unroll");
+      x = arena + xeOff;
+    }
     xSaved = x;
     const float* wt = weight(c, arena);
     w2lCheck(w2l_conv_forward(&d, x, wt, hasBias ? b.w(c) : nullptr, y, fuseRelu ? 1 : 0, c.stream), "conv fwd");
@@ -314,7 +322,12 @@ class Conv2DLayer : public Layer {
     const float* wt = wn.on ? arena + wn.wOff : w.w(c);
     if (needDx) {
       dx = arena + dxOff;
-      w2lCheck(w2l_conv_backward_data(&d, dym, wt, dx, 0, c.stream), "conv bwd data");
+      if (kh > 1) {
+        w2lCheck(w2l_conv_backward_data(&d, dym, wt, arena + dxeOff, 0, c.stream), "conv bwd data");
+        w2lCheck(w2l_hexpand_backward(arena + dxeOff, dx, (size_t)d.B * d.T, d.H, cin, kh, padH, c.stream), "conv H fold");
+      } else {
+        w2lCheck(w2l_conv_backward_data(&d, dym, wt, dx, 0, c.stream), "conv bwd data");
+      }
     }
     if (wn.on)
       w2lCheck(w2l_weightnorm_backward(wn.v.w(c), wn.g.w(c), arena + wn.normOff, dwt, wn.v.g(c), wn.g.g(c),
@@ -704,11 +717,12 @@ static inline uint64_t splitmix(uint64_t& s) {
 void Sequential::importParam(size_t i, const float* ref, float* host) const {
   const ParamInfo& p = params_[i];
   float* dst = host + p.offset;
-  if (p.kind == 1) {  // reference memory [cout][cin][kw] -> internal [kw][cin][cout]
+  if (p.kind == 1) {  // reference memory [cout][cin][kh][kw] (ArrayFire dims (kw, kh, cin, cout)) -> internal [kw][kh][cin][cout]
     for (int co = 0; co < p.cout; ++co)
       for (int ci = 0; ci < p.cin; ++ci)
-        for (int k = 0; k < p.kw; ++k)
-          dst[((size_t)k * p.cin + ci) * p.cout + co] = ref[((size_t)co * p.cin + ci) * p.kw + k];
+        for (int dh = 0; dh < p.kh; ++dh)
+          for (int k = 0; k < p.kw; ++k)
+            dst[(((size_t)k * p.kh + dh) * p.cin + ci) * p.cout + co] = ref[(((size_t)co * p.cin + ci) * p.kh + dh) * p.kw + k];
   } else if (p.kind == 2 && !p.rowPerm.empty()) {  // reference memory [in][out]; internal row r = reference row rowPerm[r]
     for (int r = 0; r < p.cin; ++r) std::memcpy(dst + (size_t)r * p.cout, ref + (size_t)p.rowPerm[r] * p.cout, sizeof(float) * p.cout);
   } else {
@@ -722,8 +736,9 @@ void Sequential::exportParam(size_t i, const float* host, float* ref) const {
   if (p.kind == 1) {
     for (int co = 0; co < p.cout; ++co)
       for (int ci = 0; ci < p.cin; ++ci)
-        for (int k = 0; k < p.kw; ++k)
-          ref[((size_t)co * p.cin + ci) * p.kw + k] = src[((size_t)k * p.cin + ci) * p.cout + co];
+        for (int dh = 0; dh < p.kh; ++dh)
+          for (int k = 0; k < p.kw; ++k)
+            ref[(((size_t)co * p.cin + ci) * p.kh + dh) * p.kw + k] = src[(((size_t)k * p.kh + dh) * p.cin + ci) * p.cout + co];
   } else if (p.kind == 2 && !p.rowPerm.empty()) {
     for (int r = 0; r < p.cin; ++r) std::memcpy(ref + (size_t)p.rowPerm[r] * p.cout, src + (size_t)r * p.cout, sizeof(float) * p.cout);
   } else {
@@ -787,10 +802,19 @@ static std::shared_ptr<Layer> buildOne(const LayerSpec& s, const LayerSpec* wnPa
   if (s.tok == "C2") {
     auto l = std::make_shared<Conv2DLayer>();
     l->cin = toI(a[0]); l->cout = toI(a[1]); l->kw = toI(a[2]);
-    if (toI(a[3]) != 1 || toI(a[5]) != 1) throw std::invalid_argument("only kw x 1 convolutions (time axis) are supported: " + s.line);
+    l->kh = toI(a[3]);
+    if (l->kh < 1 || toI(a[5]) != 1) throw std::invalid_argument("stride on the H axis is not supported: " + s.line);
     l->stride = toI(a[4]);
     l->pad = a.size() >= 7 ? toI(a[6]) : 0;
-    if (a.size() >= 8 && toI(a[7]) != 0 && toI(a[7]) != -1) throw std::invalid_argument("padding on the H axis not supported: " + s.line);
+    const int py = a.size() >= 8 ? toI(a[7]) : 0;
+    if (l->kh == 1) {
+      if (py != 0 && py != -1) throw std::invalid_argument("padding on the H axis not supported: " + s.line);
+    } else {
+      // kh > 1 (recipes/sota/2019/am_arch/am_tds_ctc_librivox.arch: "C2 1 16 21 3 2 1 -1 -1"): SAME on the mel axis only
+      if (l->kh % 2 == 0 || (py != -1 && py != (l->kh - 1) / 2))
+        throw std::invalid_argument("kh x kw convolutions keep the H axis (odd kh, padding -1 or (kh-1)/2): " + s.line);
+      l->padH = (l->kh - 1) / 2;
+    }
     if ((a.size() >= 9 && toI(a[8]) != 1) || (a.size() >= 10 && toI(a[9]) != 1)) throw std::invalid_argument("dilation not supported: " + s.line);
     return l;
   }

@@ -71,7 +71,7 @@ struct ParamInfo {
   std::vector<int> rowPerm;      // linear: internal row r holds reference row rowPerm[r]
   double initBound = 0;          // uniform(-b, b); 0 => constant initConst
   float initConst = 0;
-  int kw = 0, cin = 0, cout = 0;
+  int kw = 0, kh = 1, cin = 0, cout = 0;
 };
 
 struct Ctx {

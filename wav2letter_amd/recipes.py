@@ -23,6 +23,19 @@ def tds_ctc_arch():
     return "\n".join(lines) + "\n"
 
 
+def tds_ctc_librivox_arch():
+    """sota/2019 TDS-CTC for the LibriVox-scale model (am_tds_ctc_librivox.arch): 21 x 3 sub-sampling convolutions over
+    (time, mel), channel counts 16 / 16 / 32 / 48, 19 TDS blocks"""
+    lines = ["SAUG 80 27 2 100 1.0 2", "V -1 NFEAT 1 0"]
+    stages = [(1, 16, "21 3 2", 2400, [0.05, 0.05]), (16, 16, "21 3 2", 2400, [0.05, 0.05]), (16, 32, "21 3 2", 4800, [0.1] * 5),
+              (32, 48, "21 1 1", 7200, [0.1] * 6)]
+    for cin, c, geom, l2, drops in stages:
+        lines += [f"C2 {cin} {c} {geom} 1 -1 -1", "R", "DO 0.0", "LN 0 1 2"]
+        lines += [f"TDS {c} 21 80 {p} {l2}" for p in drops]
+    lines += ["V 0 3840 1 0", "RO 1 0 3 2", "L 3840 NLABEL"]
+    return "\n".join(lines) + "\n"
+
+
 def conv_glu_librispeech_arch():
     """conv_glu LibriSpeech: 17 WN-Conv+GLU layers, widths x1.1, kernel 13..29, 208.9 M params"""
     lines = ["V -1 1 NFEAT 0"]
