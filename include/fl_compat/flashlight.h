@@ -215,8 +215,46 @@ class FL_COMPAT_API SGDOptimizer : public FirstOrderOptimizer {
 // global-norm clipping over the gradients that are available; returns the norm before clipping
 FL_COMPAT_API double clipGradNorm(const std::vector<Variable>& params, double maxNorm);
 
+// ---- data parallelism (recipes/slimIPL/src/Train.cpp:188-199, :1078-1079, :1721-1747): one process per GPU, RCCL over xGMI.
+// librccl.so is dlopen()ed by initDistributed only: a single-GPU run never touches it.
+FL_COMPAT_API int getWorldRank();
+FL_COMPAT_API int getWorldSize();
+FL_COMPAT_API void allReduce(af::array& arr, double scale = 1.0);           // in place, sum over ranks (then * scale)
+FL_COMPAT_API void allReduce(Variable& var, double scale = 1.0);
+FL_COMPAT_API void allReduceParameters(const std::shared_ptr<const Module>& module);   // average: replicas start identical
+FL_COMPAT_API void barrier();
+
+class FL_COMPAT_API Reducer {
+ public:
+  virtual ~Reducer() {}
+  virtual void add(Variable& var) = 0;
+  virtual void finalize() = 0;
+};
+// fl::CoalescingReducer(scale, async, contiguous): gradients are added as backward produces them and reduced in
+// buckets; here the parameters of a planned network already sit in ONE flat arena, so adjacent gradients coalesce into
+// a single ncclAllReduce over the whole arena (the reference issues dozens of ~20 MB buckets)
+class FL_COMPAT_API CoalescingReducer : public Reducer {
+ public:
+  CoalescingReducer(double scale, bool async, bool contiguous);
+  ~CoalescingReducer() override;
+  void add(Variable& var) override;
+  void finalize() override;
+  size_t lastCollectives() const { return lastCollectives_; }   // fl_compat extension: ncclAllReduce calls of the last finalize()
+
+ private:
+  double scale_;
+  bool async_, contiguous_;
+  struct Span { float* ptr; size_t n; };
+  std::vector<Span> spans_;
+  size_t lastCollectives_ = 0;
+};
+
 namespace pkg {
 namespace runtime {
+// fl::pkg::runtime::initDistributed(worldRank, worldSize, maxDevicesPerNode, rndvFilepath) (Train.cpp:189-194): binds
+// this process to GPU worldRank % maxDevicesPerNode and creates the RCCL communicator; the ncclUniqueId travels through
+// the file <rndvFilepath>/w2l_nccl_id.<worldSize> written by rank 0 (the reference's file-system rendezvous)
+FL_COMPAT_API void initDistributed(int worldRank, int worldSize, int maxDevicesPerNode, const std::string& rndvFilepath);
 // dlopen(path, RTLD_LAZY) + dlsym("createModule"): extern "C" fl::Module* createModule(int64_t nFeature, int64_t nLabel)
 // returns an OWNING raw pointer (recipes/slimIPL/100h_supervised.cpp:84-87; loader call Train.cpp:390-395).
 // A name that ends in ".arch" is not a plugin: arch() then goes through buildSequentialModule, which is what the

@@ -234,6 +234,126 @@ double clipGradNorm(const std::vector<Variable>& params, double maxNorm) {
   return norm;
 }
 
+// ------------------------------------------------------------------------------------------------ data parallelism
+// RCCL through dlopen: the types come from <rccl/rccl.h>, the entry points are resolved when initDistributed runs, so
+// neither the library nor a single-GPU process depends on librccl.so (a Python process that already carries torch's
+// RCCL gets that copy: RTLD_NOLOAD first).
+}  // namespace fl
+#include <rccl/rccl.h>
+#include <unistd.h>
+#include <fstream>
+namespace fl {
+namespace {
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclComm_t comm = nullptr;
+  int rank = 0, size = 1;
+};
+Rccl& rccl() { static Rccl r; return r; }
+void ncclCheck(ncclResult_t st, const char* what) {
+  if (st != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(st) : "RCCL error"));
+}
+template <class F> void bindSym(void* lib, const char* name, F& f) {
+  f = (F)dlsym(lib, name);
+  if (!f) throw std::runtime_error(std::string("librccl.so lacks ") + name);
+}
+void allReduceRaw(float* p, size_t n, double scale) {
+  Rccl& r = rccl();
+  if (!r.comm || !n) return;   // (a communicator of ONE rank still goes through RCCL: the plumbing is what a 1-GPU box can test)
+  ncclCheck(r.AllReduce(p, p, n, ncclFloat32, ncclSum, r.comm, (hipStream_t)S()), "ncclAllReduce");
+  if (scale != 1.0) w2l::w2lCheck(w2l_axpy(p, p, n, (float)(scale - 1.0), S()), "allReduce scale");
+}
+}  // namespace
+
+int getWorldRank() { return rccl().rank; }
+int getWorldSize() { return rccl().size; }
+void allReduce(af::array& arr, double scale) {
+  if (arr.type() != af::f32) throw std::invalid_argument("allReduce: f32 arrays only");
+  allReduceRaw(arr.device<float>(), (size_t)arr.elements(), scale);
+}
+void allReduce(Variable& var, double scale) { allReduce(var.array(), scale); }
+void allReduceParameters(const std::shared_ptr<const Module>& module) {
+  if (!rccl().comm) return;
+  for (auto& p : module->params()) allReduceRaw(p.array().device<float>(), (size_t)p.elements(), 1.0 / rccl().size);
+}
+void barrier() {
+  if (!rccl().comm) return;
+  static std::shared_ptr<void> one = devAlloc(sizeof(float));
+  w2l::hipCheck(hipMemsetAsync(one.get(), 0, sizeof(float), (hipStream_t)S()), "barrier");
+  allReduceRaw((float*)one.get(), 1, 1.0);
+  w2l::hipCheck(hipStreamSynchronize((hipStream_t)S()), "barrier");
+}
+
+CoalescingReducer::CoalescingReducer(double scale, bool async, bool contiguous) : scale_(scale), async_(async), contiguous_(contiguous) {}
+CoalescingReducer::~CoalescingReducer() {}
+void CoalescingReducer::add(Variable& var) {
+  if (var.type() != af::f32) throw std::invalid_argument("CoalescingReducer: f32 gradients only");
+  float* p = var.array().device<float>();
+  const size_t n = (size_t)var.elements();
+  if (!n) return;
+  if (!spans_.empty() && spans_.back().ptr + spans_.back().n == p) spans_.back().n += n;   // the next piece of the same arena
+  else spans_.push_back({p, n});
+}
+void CoalescingReducer::finalize() {
+  lastCollectives_ = 0;
+  for (auto& sp : spans_) {
+    allReduceRaw(sp.ptr, sp.n, scale_);
+    ++lastCollectives_;
+  }
+  spans_.clear();
+}
+
+namespace pkg {
+namespace runtime {
+void initDistributed(int worldRank, int worldSize, int maxDevicesPerNode, const std::string& rndvFilepath) {
+  Rccl& r = rccl();
+  if (r.comm) throw std::runtime_error("initDistributed called twice");
+  if (worldSize < 1 || worldRank < 0 || worldRank >= worldSize) throw std::invalid_argument("initDistributed: bad rank / world size");
+  int ndev = 0;
+  w2l::hipCheck(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
+  const int perNode = std::max(1, std::min(maxDevicesPerNode > 0 ? maxDevicesPerNode : ndev, ndev));
+  w2l::hipCheck(hipSetDevice(worldRank % perNode), "hipSetDevice");
+  r.lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+  if (!r.lib) r.lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!r.lib) r.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!r.lib) throw std::runtime_error(std::string("cannot load librccl.so: ") + dlerror());
+  bindSym(r.lib, "ncclGetUniqueId", r.GetUniqueId);
+  bindSym(r.lib, "ncclCommInitRank", r.CommInitRank);
+  bindSym(r.lib, "ncclAllReduce", r.AllReduce);
+  bindSym(r.lib, "ncclCommDestroy", r.CommDestroy);
+  bindSym(r.lib, "ncclGetErrorString", r.GetErrorString);
+  ncclUniqueId id;
+  std::memset(&id, 0, sizeof id);
+  const std::string path = rndvFilepath + "/w2l_nccl_id." + std::to_string(worldSize);
+  if (worldSize > 1 && rndvFilepath.empty()) throw std::invalid_argument("initDistributed: --rndv_filepath is needed for world_size > 1");
+  if (worldRank == 0) {
+    ncclCheck(r.GetUniqueId(&id), "ncclGetUniqueId");
+    if (worldSize > 1) {   // write to a temporary name, then rename: readers never see a partial file
+      const std::string tmp = path + ".tmp";
+      { std::ofstream f(tmp, std::ios::binary); f.write((const char*)&id, sizeof id); if (!f) throw std::runtime_error("cannot write " + tmp); }
+      if (rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error("cannot publish " + path);
+    }
+  } else {
+    bool got = false;
+    for (int tries = 0; tries < 6000 && !got; ++tries) {   // up to 10 minutes
+      std::ifstream f(path, std::ios::binary);
+      if (f && f.read((char*)&id, sizeof id)) got = true;
+      else usleep(100000);
+    }
+    if (!got) throw std::runtime_error("rendezvous file " + path + " did not appear");
+  }
+  ncclCheck(r.CommInitRank(&r.comm, worldSize, id, worldRank), "ncclCommInitRank");
+  r.rank = worldRank;
+  r.size = worldSize;
+}
+}  // namespace runtime
+}  // namespace pkg
+
 // ------------------------------------------------------------------------------------------------ plugin loader
 namespace pkg {
 namespace runtime {

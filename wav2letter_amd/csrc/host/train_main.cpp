@@ -15,7 +15,9 @@
 // decoder, cereal checkpoints.  The data the step consumes is therefore SYNTHETIC unless --train names list files
 // that exist: LibriSpeech-shaped padded batches (--w2l_synth_frames frames of --filterbanks features, random targets),
 // which is exactly what bench.py times.  Flags of this driver that the reference does not have are prefixed w2l_.
-// Data-parallel runs are driven from Python (bench.py / wav2letter_amd.parallel over torch.distributed = RCCL).
+// Data parallelism is the reference's: --enable_distributed --world_rank --world_size --max_devices_per_node
+// --rndv_filepath (Train.cpp:188-199; RANK / WORLD_SIZE / LOCAL_WORLD_SIZE of a torchrun-style launcher are read when the
+// flags are absent): one process per GPU, fl::CoalescingReducer over RCCL, batch size all-reduced with the gradients.
 #include <sys/stat.h>
 
 #include <chrono>
@@ -172,6 +174,21 @@ int main(int argc, char** argv) {
     std::cout << "[Network Optimizer] " << netoptim->prettyString() << std::endl;
     std::cout << "[Criterion Optimizer] " << critoptim->prettyString() << std::endl;
 
+    // ---- data parallelism (Train.cpp:188-199, :1078-1079)
+    std::shared_ptr<fl::Reducer> reducer;
+    if (flags.getb("enable_distributed", false)) {
+      auto envi = [](const char* k, long dflt) { const char* v = getenv(k); return v ? atol(v) : dflt; };
+      const int worldRank = (int)flags.geti("world_rank", envi("RANK", 0));
+      const int worldSize = (int)flags.geti("world_size", envi("WORLD_SIZE", 1));
+      fl::pkg::runtime::initDistributed(worldRank, worldSize, (int)flags.geti("max_devices_per_node", envi("LOCAL_WORLD_SIZE", 8)),
+                                        flags.get("rndv_filepath", ""));
+      reducer = std::make_shared<fl::CoalescingReducer>(1.0, true, true);
+      fl::allReduceParameters(network);     // replicas start identical
+      fl::allReduceParameters(criterion);
+      std::cout << "[Distributed] world rank " << fl::getWorldRank() << " of " << fl::getWorldSize() << " (RCCL)" << std::endl;
+    }
+    const bool isMaster = fl::getWorldRank() == 0;
+
     // ---- data
     std::string trainLists = flags.get("train", "");
     const bool haveLists = !trainLists.empty() && trainLists.find("[DATA_DST]") == std::string::npos &&
@@ -179,7 +196,7 @@ int main(int argc, char** argv) {
     if (haveLists)
       std::cout << "note: audio list files are present, but feature extraction from audio is not part of this build "
                    "(SURVEY 8 f3): running on synthetic batches of the same shape" << std::endl;
-    std::mt19937_64 rng(2026 + seed);
+    std::mt19937_64 rng(2026 + seed + 7919ull * (uint64_t)fl::getWorldRank());   // every rank draws its own shard of the (synthetic) minibatch
     std::normal_distribution<float> gauss(0.f, 1.f);
     const int nTok = criterionName == "ctc" ? numClasses - 1 : std::max(1, numClasses - (int)flags.geti("replabel", 0));
     std::vector<float> hx((size_t)batch * nFeat * T);
@@ -308,12 +325,25 @@ int main(int argc, char** argv) {
       netoptim->zeroGrad();
       critoptim->zeroGrad();
       loss.backward();
+      if (reducer) {   // Train.cpp:1721-1735
+        for (auto& p : network->params()) {
+          if (!p.isGradAvailable()) p.addGrad(fl::Variable(af::constant(0.0, p.dims(), p.type()), false));
+          reducer->add(p.grad());
+        }
+        for (auto& p : criterion->params()) {
+          if (!p.isGradAvailable()) p.addGrad(fl::Variable(af::constant(0.0, p.dims(), p.type()), false));
+          reducer->add(p.grad());
+        }
+        reducer->finalize();
+      }
       af::sync();
       bwdtimer.stopAndIncUnit();
 
       // optimizer: scale down gradients by batchsize, clamp, update
       optimtimer.resume();
-      const double totalBatchSize = (double)loss.dims(0);
+      af::array totalBatchSizeArr = af::constant((double)loss.dims(0), af::dim4(1), af::f32);   // Train.cpp:1743-1747
+      if (reducer) fl::allReduce(totalBatchSizeArr);
+      const double totalBatchSize = (double)totalBatchSizeArr.scalar<float>();
       for (const auto& p : network->params())
         if (p.isGradAvailable()) p.grad() = p.grad() / totalBatchSize;
       for (const auto& p : criterion->params())
@@ -334,7 +364,7 @@ int main(int argc, char** argv) {
       nsamples += batch;
       ++nbatches;
 
-      if ((reportiters > 0 && curBatch % reportiters == 0) || curBatch == iters) logStatus(1, curBatch, lr, lrcrit);
+      if (isMaster && ((reportiters > 0 && curBatch % reportiters == 0) || curBatch == iters)) logStatus(1, curBatch, lr, lrcrit);
     }
     std::cout << "Finished training" << std::endl;
     return 0;
