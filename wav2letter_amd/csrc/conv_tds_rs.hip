@@ -556,7 +556,6 @@ static int rs3_launch(const TdsRsP& q, hipStream_t s) {
   p.x = q.x; p.w = q.w; p.bias = q.bias; p.add = q.add; p.y = q.y;
   p.B = q.B; p.Tin = q.Tin; p.Tout = q.Tout; p.H = q.H; p.kw = q.kw; p.padl = q.padl; p.relu = q.relu; p.accum = q.accum; p.flip = q.flip;
   p.abl = q.abl;
-  { const char* e = tune_env("W2L_TDS_RS3_PRIO"); p.prio = e ? atoi(e) : 0; }
   { const char* e = tune_env("W2L_TDS_RS3_DBG"); p.dbg = e ? (long long*)strtoull(e, nullptr, 10) : nullptr; }
   p.hBlocks = q.H / HH;
   const long long total = (long long)q.B * p.hBlocks * q.Tout;

@@ -45,7 +45,6 @@ struct TdsRs3P {
   int hBlocks;        // H / HH
   int quota;          // output frames of the flattened (utterance, mel-row block, frame) axis per workgroup
   int abl;            // probe build only: timing ablations (results are garbage)
-  int prio;           // 1: movers at s_setprio 3, 2: consumers at s_setprio 3
   long long* dbg;     // probe build: per workgroup 8 cycle counters (consumer work / wait, mover stage / fetch / epilogue / wait)
 };
 
