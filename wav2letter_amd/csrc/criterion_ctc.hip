@@ -435,19 +435,27 @@ __global__ __launch_bounds__(kRowThreads) void ctc_rows_argmax(int N, const floa
   }
 }
 
-__global__ void batch_target_size_k(int B, int L, int maxSize, const int* __restrict__ target,
-                                    int* __restrict__ targetSize, int ctc) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
+// one wavefront per utterance (a thread per utterance walked the L labels with dependent, uncoalesced loads: 49 us at
+// L = 300 in front of every criterion call -- profiles/r02_run16_asg_timeline.log)
+__global__ __launch_bounds__(64) void batch_target_size_k(int B, int L, int maxSize, const int* __restrict__ target,
+                                                          int* __restrict__ targetSize, int ctc) {
+  const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= B) return;
   const int* y = target + (size_t)b * L;
-  int n = 0;
-  while (n < L && y[n] >= 0) ++n;
+  int first = L;   // index of the first negative label
+  for (int i = lane; i < L; i += 64)
+    if (y[i] < 0) { first = i; break; }
+  for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off));
+  const int n = first;
   if (!ctc) {
-    targetSize[b] = n < maxSize ? n : maxSize;
-  } else {
-    int R = 0;
-    for (int i = 1; i < n; ++i) R += (y[i] == y[i - 1]);
-    int m = (n + R < maxSize ? n + R : maxSize) - R;
+    if (lane == 0) targetSize[b] = n < maxSize ? n : maxSize;
+    return;
+  }
+  int R = 0;
+  for (int i = 1 + lane; i < n; i += 64) R += (y[i] == y[i - 1]);
+  for (int off = 32; off > 0; off >>= 1) R += __shfl_xor(R, off);
+  if (lane == 0) {
+    const int m = (n + R < maxSize ? n + R : maxSize) - R;
     targetSize[b] = m < 0 ? 0 : m;
   }
 }
@@ -459,7 +467,7 @@ using namespace w2l;
 W2L_API int w2l_batch_target_size(int B, int L, int maxSize, const int* target, int* targetSize,
                                   w2l_stream_t stream) {
   if (B <= 0 || L <= 0 || !target || !targetSize) return W2L_EINVAL;
-  hipLaunchKernelGGL(batch_target_size_k, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, L, maxSize, target, targetSize, 0);
+  hipLaunchKernelGGL(batch_target_size_k, dim3(B), dim3(64), 0, (hipStream_t)stream, B, L, maxSize, target, targetSize, 0);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }
@@ -467,7 +475,7 @@ W2L_API int w2l_batch_target_size(int B, int L, int maxSize, const int* target, 
 W2L_API int w2l_batch_ctc_target_size(int B, int L, int T, const int* target, int* targetSize,
                                       w2l_stream_t stream) {
   if (B <= 0 || L <= 0 || !target || !targetSize) return W2L_EINVAL;
-  hipLaunchKernelGGL(batch_target_size_k, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, L, T, target, targetSize, 1);
+  hipLaunchKernelGGL(batch_target_size_k, dim3(B), dim3(64), 0, (hipStream_t)stream, B, L, T, target, targetSize, 1);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }

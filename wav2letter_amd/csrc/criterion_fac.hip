@@ -442,6 +442,266 @@ __global__ __launch_bounds__(64 * NW) void fac_bwd_blk(int T, int N, int L, cons
   }
 }
 
+// ---------------------------------------------------------------- skewed wave pipeline (no workgroup barrier per frame)
+// fac_*_blk above pay ONE s_barrier + LDS round trip per frame (~580-700 cycles per frame at 8 waves: the frame's own
+// arithmetic is ~150).  But a position only needs its LEFT neighbour's alpha of the previous frame (forward) / its RIGHT
+// neighbour's advance term of the same step (backward): inside a wave that is a DPP lane shift, and across waves it is
+// ONE value per frame per wave boundary.  So the waves of an utterance run skewed instead of in lockstep: wave w-1 stays
+// at least a frame ahead of wave w (forward; w+1 ahead of w in the backward scan) and hands its boundary value over
+// through an LDS mailbox ring (value, then frame tag; the reader polls the tag -- in steady state the value has been
+// there for a frame), with back-pressure every kMbRing/2 frames so that a leader never laps its follower.
+// One position per lane (L <= 64 NW).  Same arithmetic, same order as fac_*_blk: bit-identical results.
+// MEASURED (profiles/r02_run16_fac_pipeline_negative.log): correct, and NOT faster -- 517 us against 487 us forward at 5 waves.
+// The premise was wrong: ONE wave with no neighbour at all (L = 60) already needs 459 cycles per frame -- the frame is a
+// chain of ~16 dependent fp64 / transcendental operations -- and the barrier version adds only ~125 cycles to that at 5
+// waves.  What the first versions of this kernel taught on the way: `volatile` LDS accesses make hipcc drain vmcnt(0)
+// around each one (2150 cycles per frame), a store in flight costs the same in front of every poll loop (1100), and a
+// `while` poll is unrolled 16x with a ~100-instruction exit cascade (740) -- hence relaxed workgroup atomics, stores
+// after the chunk, `unroll(disable)`.  Kept in the probe library (W2L_FAC_PIPE=1); the product runs fac_*_blk.
+constexpr int kMbRing = 16;
+constexpr int kMbSpinMax = 1 << 22;   // a poll that never succeeds ends the kernel with a poisoned loss instead of hanging the GPU
+
+// mailbox accesses: relaxed workgroup-scope atomics = plain ds_read / ds_write.  (`volatile` made hipcc drain vmcnt(0) -- the
+// frame's global stores -- around every access: 2150 cycles per frame.)
+template <class T> __device__ __forceinline__ T mb_load(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+template <class T> __device__ __forceinline__ void mb_store(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// poll *p until pred(value) (bounded; hipcc unrolls a `while` poll 16x with a ~100-instruction exit cascade: keep it a 4-instruction loop)
+template <class Pred> __device__ __forceinline__ bool mb_poll(const int* p, Pred pred) {
+  int spins = 0;
+  int vv;
+#pragma clang loop unroll(disable)
+  do { vv = mb_load(p); } while (!pred(vv) && ++spins < kMbSpinMax);
+  return pred(vv);
+}
+__device__ __forceinline__ int dpp_wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false); }   // lane l <- lane l-1
+__device__ __forceinline__ int dpp_wave_shl1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xF, 0xF, false); }   // lane l <- lane l+1
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void fac_fwd_pipe(int T, int N, int L, int scaleMode,
+                                                        const float* __restrict__ x,
+                                                        const int* __restrict__ target,
+                                                        const int* __restrict__ targetSize,
+                                                        const float* __restrict__ trans,
+                                                        float* __restrict__ loss, FacWs ws) {
+  __shared__ double mbVal[NW + 1][kMbRing];   // row NW: where the lanes that publish nothing write
+  __shared__ int mbTag[NW + 1][kMbRing];
+  __shared__ int prog[NW + 1];   // prog[w] = last frame wave w has finished (-1: none)
+  __shared__ int bad;
+  __shared__ double sink[64];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int S = targetSize[b];
+  const float sc = scale_of(scaleMode, T, S);
+  if (tid == 0) ws.scale[b] = sc;
+  if (S <= 0) {
+    if (tid == 0) loss[b] = 0.f;
+    return;
+  }
+  for (int e = tid; e < (NW + 1) * kMbRing; e += 64 * NW) (&mbTag[0][0])[e] = -1;
+  if (tid <= NW) prog[tid] = -1;
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  const int* y = target + (size_t)b * L;
+  const float* xb = x + (size_t)b * T * N;
+  float* w1b = ws.w1 + (size_t)b * T * L;
+  const double NEG = -INFINITY;
+  const int i = tid;
+  const bool v = i < S;
+  const int yi = v ? y[i] : 0;
+  const int yp = (v && i > 0) ? y[i - 1] : 0;
+  const float selfT = v ? trans[(size_t)yi * N + yi] : 0.f;
+  const float prevT = (v && i > 0) ? trans[(size_t)yi * N + yp] : 0.f;
+  double alpha = NEG;
+  const int lastWave = (S - 1) >> 6;   // waves beyond the target's last position have nothing to do and nobody waits for them
+  if (wave > lastWave) return;
+  const bool feeds = wave < lastWave;  // somebody consumes this wave's boundary value
+  const bool fed = wave > 0;
+  const int src = fed ? wave - 1 : NW;
+  // every lane runs the mailbox accesses (the reads are broadcasts, the writes of lanes != 63 go to a sink): no divergent
+  // region in the frame; the value for frame t+1 is read one frame early -- in steady state the leader is frames ahead
+  double* const pubVal = lane == 63 && feeds ? &mbVal[wave][0] : &sink[lane] - 0;
+  int* const pubTag = lane == 63 && feeds ? &mbTag[wave][0] : &mbTag[NW][0];
+  const int pubStep = lane == 63 && feeds ? 1 : 0;
+  int pfTag = -2;
+  double pfVal = NEG;
+
+  float xc[kFacChunk], xn[kFacChunk];
+#pragma unroll
+  for (int u = 0; u < kFacChunk; ++u) xc[u] = (u < T && v) ? xb[(size_t)u * N + yi] : 0.f;
+
+  for (int t0 = 0; t0 < T; t0 += kFacChunk) {
+#pragma unroll
+    for (int u = 0; u < kFacChunk; ++u) {
+      const int tn = t0 + kFacChunk + u;
+      xn[u] = (tn < T && v) ? xb[(size_t)tn * N + yi] : 0.f;
+    }
+    float wst[kFacChunk];   // this chunk's rows of w1: stored after the chunk -- a store in flight makes hipcc's vmcnt(0) in front
+                            // of every poll loop wait for its round trip (the frame's arithmetic is 5x shorter)
+#pragma unroll
+    for (int u = 0; u < kFacChunk; ++u) {
+      const int t = t0 + u;
+      wst[u] = 0.f;
+      if (t < T) {  // uniform
+        if (t == 0) {
+          if (tid == 0) alpha = (double)xc[u];
+        } else {
+          // alpha_{t-1}[i-1]: the lane below, or the previous wave's last lane through the mailbox
+          const long long ab = __double_as_longlong(alpha);
+          const int lo = dpp_wave_shr1((int)(ab & 0xffffffffll)), hi = dpp_wave_shr1((int)(ab >> 32));
+          double prevA = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+          if (fed) {  // uniform
+            const int slot = (t - 1) & (kMbRing - 1);
+            if (pfTag != t - 1) {   // uniform (a broadcast value): the early read came before the leader's write
+              if (!mb_poll(&mbTag[src][slot], [&](int g) { return g == t - 1; })) mb_store(&bad, 1);
+              pfVal = mb_load(&mbVal[src][slot]);
+            }
+            if (lane == 0) prevA = pfVal;
+            pfTag = mb_load(&mbTag[src][t & (kMbRing - 1)]);   // frame t's boundary value, for frame t + 1
+            pfVal = mb_load(&mbVal[src][t & (kMbRing - 1)]);
+          } else if (lane == 0) {
+            prevA = NEG;
+          }
+          const double s1 = alpha + (double)selfT;
+          const double s2 = prevA + (double)prevT;
+          const double m = fmax(s1, s2);
+          const bool live = v && m != NEG;
+          const float d = (float)(fmin(s1, s2) - m);
+          const float ed = fast_expf(d);
+          const float den = 1.f + ed;
+          const double na = m + (double)fast_logf(den) + (double)xc[u];
+          const float inv = __builtin_amdgcn_rcpf(den);
+          const float w = (s1 >= s2) ? inv : ed * inv;
+          wst[u] = live ? w : 0.f;
+          alpha = live ? na : NEG;
+        }
+        if (feeds) {  // uniform
+          // never overwrite a slot the follower has not read: every kMbRing / 2 frames make sure it finished frame t - kMbRing / 2
+          if ((t & (kMbRing / 2 - 1)) == 0 && t >= kMbRing / 2)
+            if (!mb_poll(&prog[wave + 1], [&](int g) { return g >= t - kMbRing / 2; })) mb_store(&bad, 1);
+        }
+        {
+          const int slot = (t & (kMbRing - 1)) * pubStep;
+          mb_store(pubVal + slot, alpha);
+          asm volatile("" ::: "memory");   // value, then tag: the LDS executes a wave's operations in order
+          mb_store(pubTag + slot, t);
+        }
+        if (fed && (t & (kMbRing / 2 - 1)) == 0 && lane == 0) mb_store(&prog[wave], t);   // (read frame t-1 of the leader: its slots up to t-1 are free)
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kFacChunk; ++u) {
+      const int t = t0 + u;
+      if (t >= 1 && t < T && v) w1b[(size_t)t * L + i] = wst[u];
+    }
+#pragma unroll
+    for (int u = 0; u < kFacChunk; ++u) asm volatile("" : "+v"(xn[u]));   // one vmcnt drain per chunk (see fac_fwd_blk)
+#pragma unroll
+    for (int u = 0; u < kFacChunk; ++u) xc[u] = xn[u];
+  }
+  if (i == S - 1) loss[b] = mb_load(&bad) ? __builtin_nanf("") : (float)((double)sc * alpha);
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void fac_bwd_pipe(int T, int N, int L, const int* __restrict__ target,
+                                                        const int* __restrict__ targetSize,
+                                                        const float* __restrict__ grad,
+                                                        float* __restrict__ transGrad, FacWs ws) {
+  __shared__ float mbVal[NW + 1][kMbRing];
+  __shared__ int mbTag[NW + 1][kMbRing];
+  __shared__ int prog[NW + 1];   // prog[w + 1] = lowest frame wave w has finished (scans run from T-1 down)
+  __shared__ float sink[64];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int S = targetSize[b];
+  if (S <= 0) return;  // the scatter kernel zero-fills this utterance's gradient
+  for (int e = tid; e < (NW + 1) * kMbRing; e += 64 * NW) (&mbTag[0][0])[e] = -1;
+  if (tid <= NW) prog[tid] = 0x3fffffff;
+  __syncthreads();
+  const int* y = target + (size_t)b * L;
+  const float* __restrict__ w1b = ws.w1 + (size_t)b * T * L;
+  float* __restrict__ dalb = ws.dal + (size_t)b * T * L;
+  const float g = ws.scale[b] * grad[b];
+  const int i = tid;
+  const bool v = i < S;
+  const int yi = v ? y[i] : 0;
+  const int yp = (v && i > 0) ? y[i - 1] : 0;
+  float da = (i == S - 1) ? 1.f : 0.f, accS = 0.f, accP = 0.f;
+  const int lastWave = (S - 1) >> 6;
+  if (wave > lastWave) return;          // (fac_scatter_k reads positions < S only)
+  const bool feeds = wave > 0;          // wave w-1 consumes this wave's lane-0 advance term
+  const bool fed = wave < lastWave;     // this wave's lane 63 needs wave w+1's
+  const int src = fed ? wave + 1 : NW;
+  float* const pubVal = lane == 0 && feeds ? &mbVal[wave][0] : &sink[lane];
+  int* const pubTag = lane == 0 && feeds ? &mbTag[wave][0] : &mbTag[NW][0];
+  const int pubStep = lane == 0 && feeds ? 1 : 0;
+  int pfTag = -2;
+  float pfVal = 0.f;
+
+  float wc[kFacChunk], wn[kFacChunk];
+#pragma unroll
+  for (int u = 0; u < kFacChunk; ++u) {
+    const int t = T - 1 - u;
+    wc[u] = (t >= 1 && v) ? w1b[(size_t)t * L + i] : 0.f;
+  }
+  for (int thi = T - 1; thi >= 0; thi -= kFacChunk) {
+#pragma unroll
+    for (int u = 0; u < kFacChunk; ++u) {
+      const int t = thi - kFacChunk - u;
+      wn[u] = (t >= 1 && v) ? w1b[(size_t)t * L + i] : 0.f;
+    }
+    float dst[kFacChunk];
+#pragma unroll
+    for (int u = 0; u < kFacChunk; ++u) {
+      const int t = thi - u;
+      dst[u] = g * da;
+      if (t >= 1) {  // uniform
+        const float st = da * wc[u];
+        const float adv = da - st;
+        accS += st;
+        accP += adv;
+        const int k = T - 1 - t;   // step counter (frames run downwards)
+        if (feeds && (k & (kMbRing / 2 - 1)) == 0 && k >= kMbRing / 2)
+          mb_poll(&prog[wave], [&](int gg) { return gg <= t + kMbRing / 2; });   // prog[wave] = progress of wave - 1
+        {
+          const int slot = (t & (kMbRing - 1)) * pubStep;
+          mb_store(pubVal + slot, adv);
+          asm volatile("" ::: "memory");
+          mb_store(pubTag + slot, t);
+        }
+        float right = __int_as_float(dpp_wave_shl1(__float_as_int(adv)));   // advance term of position i + 1
+        if (fed) {  // uniform
+          const int slot = t & (kMbRing - 1);
+          if (pfTag != t) {
+            mb_poll(&mbTag[src][slot], [&](int gg) { return gg == t; });
+            pfVal = mb_load(&mbVal[src][slot]);
+          }
+          if (lane == 63) right = pfVal;
+          pfTag = mb_load(&mbTag[src][(t - 1) & (kMbRing - 1)]);   // the step after this one
+          pfVal = mb_load(&mbVal[src][(t - 1) & (kMbRing - 1)]);
+        } else if (lane == 63) {
+          right = 0.f;
+        }
+        da = st + right;
+        if (fed && (k & (kMbRing / 2 - 1)) == 0 && lane == 63) mb_store(&prog[wave + 1], t);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kFacChunk; ++u) {
+      const int t = thi - u;
+      if (t >= 0 && i < L) dalb[(size_t)t * L + i] = dst[u];
+    }
+#pragma unroll
+    for (int u = 0; u < kFacChunk; ++u) asm volatile("" : "+v"(wn[u]));
+#pragma unroll
+    for (int u = 0; u < kFacChunk; ++u) wc[u] = wn[u];
+  }
+  float* tg = ws.tgpart ? ws.tgpart + (size_t)b * N * N : transGrad;
+  if (v) {
+    if (accS != 0.f) atomicAdd(&tg[(size_t)yi * N + yi], g * accS);
+    if (i > 0 && accP != 0.f) atomicAdd(&tg[(size_t)yi * N + yp], g * accP);
+  }
+}
+
 // emission gradient: dx[b][t][n] = sum_{i : y_i = n} (g dalpha_t)[i], frames in chunks of TCH.
 // grid (ceil(T / TCH), B), 256 threads, dynamic LDS TCH * N floats.
 __global__ __launch_bounds__(256) void fac_scatter_k(int T, int N, int L, int TCH, const int* __restrict__ target,
@@ -604,6 +864,23 @@ W2L_API int w2l_fac_forward(int B, int T, int N, int L, int scaleMode, const flo
   // workgroup shapes measured at B = 64, T = 2000, L = 300 (profiles/r01_run56_fac_shapes.log): one position per lane
   // wins the forward scan -- 8 waves x 1: 0.60 ms, 4 x 2: 0.77, 2 x 3: 0.87, 1 x 5: 1.20 -- the backward scan (a
   // handful of fp32 operations per step, barrier-bound) is fastest with 4 waves x 2
+  if (tune_env("W2L_FAC_PIPE")) {   // probe build: skewed wave pipeline (one position per lane, no per-frame workgroup barrier) -- measured NOT faster
+    const int nw = (L + 63) / 64;
+#define W2L_FAC_PIPE_GO(NWV) hipLaunchKernelGGL((fac_fwd_pipe<NWV>), dim3(B), dim3(64 * NWV), 0, s, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws)
+    switch (nw) {
+      case 1: W2L_FAC_PIPE_GO(1); break;
+      case 2: W2L_FAC_PIPE_GO(2); break;
+      case 3: W2L_FAC_PIPE_GO(3); break;
+      case 4: W2L_FAC_PIPE_GO(4); break;
+      case 5: W2L_FAC_PIPE_GO(5); break;
+      case 6: W2L_FAC_PIPE_GO(6); break;
+      case 7: W2L_FAC_PIPE_GO(7); break;
+      default: W2L_FAC_PIPE_GO(8); break;
+    }
+#undef W2L_FAC_PIPE_GO
+    W2L_LAUNCH_CHECK();
+    return W2L_OK;
+  }
   if (L > 256) hipLaunchKernelGGL((fac_fwd_blk<8, 1>), dim3(B), dim3(512), 0, s, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws);
   else W2L_FAC_BLK_DISPATCH(fac_fwd_blk, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws);
   W2L_LAUNCH_CHECK();
@@ -621,7 +898,23 @@ W2L_API int w2l_fac_backward(int B, int T, int N, int L, const int* target, cons
   size_t n = (size_t)N * N;
   if (ws.tgpart) W2L_HIP_CHECK(hipMemsetAsync(ws.tgpart, 0, (size_t)B * n * sizeof(float), s));
   else W2L_HIP_CHECK(hipMemsetAsync(transGrad, 0, n * sizeof(float), s));
-  W2L_FAC_BLK_DISPATCH(fac_bwd_blk, T, N, L, target, targetSize, grad, transGrad, ws);
+  if (tune_env("W2L_FAC_PIPE")) {
+    const int nw = (L + 63) / 64;
+#define W2L_FAC_PIPE_GO(NWV) hipLaunchKernelGGL((fac_bwd_pipe<NWV>), dim3(B), dim3(64 * NWV), 0, s, T, N, L, target, targetSize, grad, transGrad, ws)
+    switch (nw) {
+      case 1: W2L_FAC_PIPE_GO(1); break;
+      case 2: W2L_FAC_PIPE_GO(2); break;
+      case 3: W2L_FAC_PIPE_GO(3); break;
+      case 4: W2L_FAC_PIPE_GO(4); break;
+      case 5: W2L_FAC_PIPE_GO(5); break;
+      case 6: W2L_FAC_PIPE_GO(6); break;
+      case 7: W2L_FAC_PIPE_GO(7); break;
+      default: W2L_FAC_PIPE_GO(8); break;
+    }
+#undef W2L_FAC_PIPE_GO
+  } else {
+    W2L_FAC_BLK_DISPATCH(fac_bwd_blk, T, N, L, target, targetSize, grad, transGrad, ws);
+  }
   W2L_LAUNCH_CHECK();
   {
     int tch = 32768 / N;  // <= 128 KiB of LDS rows

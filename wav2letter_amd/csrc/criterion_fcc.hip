@@ -24,7 +24,7 @@ namespace w2l {
 
 constexpr int kChunk = 16;  // frames per prefetch chunk; a chunk's loads are consumed and its rows stored at the chunk
                            // boundary: ONE vmcnt drain per chunk (on gfx9 that counter also holds the frames' global stores)
-constexpr int kDtChunks = 16;  // time chunks of the (parallel) transition-gradient kernel
+constexpr int kDtChunks = 64;  // time chunks of the (parallel) transition-gradient kernel (16 chunks: 85 us behind the scan at T = 2000)
 
 struct FccWs {
   float* ahat;   // [B][T][N]
