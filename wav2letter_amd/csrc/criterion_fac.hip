@@ -442,6 +442,7 @@ __global__ __launch_bounds__(64 * NW) void fac_bwd_blk(int T, int N, int L, cons
   }
 }
 
+#ifdef W2L_PROBE  // measured not faster than fac_*_blk: kept for A/B work only
 // ---------------------------------------------------------------- skewed wave pipeline (no workgroup barrier per frame)
 // fac_*_blk above pay ONE s_barrier + LDS round trip per frame (~580-700 cycles per frame at 8 waves: the frame's own
 // arithmetic is ~150).  But a position only needs its LEFT neighbour's alpha of the previous frame (forward) / its RIGHT
@@ -702,6 +703,8 @@ __global__ __launch_bounds__(64 * NW) void fac_bwd_pipe(int T, int N, int L, con
   }
 }
 
+#endif  // W2L_PROBE
+
 // emission gradient: dx[b][t][n] = sum_{i : y_i = n} (g dalpha_t)[i], frames in chunks of TCH.
 // grid (ceil(T / TCH), B), 256 threads, dynamic LDS TCH * N floats.
 __global__ __launch_bounds__(256) void fac_scatter_k(int T, int N, int L, int TCH, const int* __restrict__ target,
@@ -864,6 +867,7 @@ W2L_API int w2l_fac_forward(int B, int T, int N, int L, int scaleMode, const flo
   // workgroup shapes measured at B = 64, T = 2000, L = 300 (profiles/r01_run56_fac_shapes.log): one position per lane
   // wins the forward scan -- 8 waves x 1: 0.60 ms, 4 x 2: 0.77, 2 x 3: 0.87, 1 x 5: 1.20 -- the backward scan (a
   // handful of fp32 operations per step, barrier-bound) is fastest with 4 waves x 2
+#ifdef W2L_PROBE
   if (tune_env("W2L_FAC_PIPE")) {   // probe build: skewed wave pipeline (one position per lane, no per-frame workgroup barrier) -- measured NOT faster
     const int nw = (L + 63) / 64;
 #define W2L_FAC_PIPE_GO(NWV) hipLaunchKernelGGL((fac_fwd_pipe<NWV>), dim3(B), dim3(64 * NWV), 0, s, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws)
@@ -881,6 +885,7 @@ W2L_API int w2l_fac_forward(int B, int T, int N, int L, int scaleMode, const flo
     W2L_LAUNCH_CHECK();
     return W2L_OK;
   }
+#endif
   if (L > 256) hipLaunchKernelGGL((fac_fwd_blk<8, 1>), dim3(B), dim3(512), 0, s, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws);
   else W2L_FAC_BLK_DISPATCH(fac_fwd_blk, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws);
   W2L_LAUNCH_CHECK();
@@ -898,6 +903,7 @@ W2L_API int w2l_fac_backward(int B, int T, int N, int L, const int* target, cons
   size_t n = (size_t)N * N;
   if (ws.tgpart) W2L_HIP_CHECK(hipMemsetAsync(ws.tgpart, 0, (size_t)B * n * sizeof(float), s));
   else W2L_HIP_CHECK(hipMemsetAsync(transGrad, 0, n * sizeof(float), s));
+#ifdef W2L_PROBE
   if (tune_env("W2L_FAC_PIPE")) {
     const int nw = (L + 63) / 64;
 #define W2L_FAC_PIPE_GO(NWV) hipLaunchKernelGGL((fac_bwd_pipe<NWV>), dim3(B), dim3(64 * NWV), 0, s, T, N, L, target, targetSize, grad, transGrad, ws)
@@ -912,7 +918,9 @@ W2L_API int w2l_fac_backward(int B, int T, int N, int L, const int* target, cons
       default: W2L_FAC_PIPE_GO(8); break;
     }
 #undef W2L_FAC_PIPE_GO
-  } else {
+  } else
+#endif
+  {
     W2L_FAC_BLK_DISPATCH(fac_bwd_blk, T, N, L, target, targetSize, grad, transGrad, ws);
   }
   W2L_LAUNCH_CHECK();
