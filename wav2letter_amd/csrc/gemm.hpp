@@ -274,6 +274,12 @@ struct SkPlan {
   float* slabs;  // [skBlocks][2][128*128]
   int grouped;   // tile rasterisation: 0 = M-fastest, 1 = groups of 8 tile-columns, N-fastest inside a group
   unsigned* counters;  // per stream-K tile arrival tickets for the in-kernel slab reduction (null: separate fix-up launch)
+  // aligned K split (gemm160 only; 0 = off): the K axis is cut into `ksplit` chunks of kChunk K tiles, the SAME cut for
+  // every tile, and the units (chunk, tile) are dealt chunk-major: unit u = worker + round * workers.  The 64 workers of
+  // an XCD then multiply 64 neighbouring tiles over the same K range at the same time and share their operand panels
+  // in that XCD's L2 -- the classic stream-K ranges start at a different k in every tile and share nothing (weight
+  // gradients: 10 % L2 hits, profiles/r02_run17_*).  One partial slab per unit (index u), ksplit arrivals per tile.
+  int ksplit = 0, kChunk = 0;
 };
 constexpr int kSkSlots = 512;           // resident 256-thread workgroups (2 per CU)
 constexpr int kSlabFloats = 128 * 128;
@@ -303,6 +309,7 @@ inline SkPlan make_sk_plan(int M, int N, int K, bool allowSk, int tileM = 128, i
   p.kTiles = (K + 31) / 32;
   const int tiles = p.tilesM * p.tilesN;
   p.dpTiles = tiles; p.skTiles = 0; p.skBlocks = 0; p.slabs = nullptr; p.grouped = 0; p.counters = nullptr;
+  p.ksplit = 0; p.kChunk = 0;
   if (!allowSk || p.kTiles < 8) return p;
   const int rounds = (tiles + kSkSlots - 1) / kSkSlots;
   const double eff = (double)tiles / ((double)rounds * kSkSlots);

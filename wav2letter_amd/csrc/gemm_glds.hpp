@@ -203,6 +203,17 @@ __device__ __forceinline__ GSeg g_segment(const SkPlan& p, int w, int workers, i
   GSeg s;
   s.valid = false;
   s.tile = 0; s.kb = 0; s.ke = 0; s.slab = -1;
+  if (p.ksplit) {   // aligned K split: unit u = (chunk, tile), chunk-major
+    const int u = w + ord * workers;
+    if (u >= p.ksplit * p.skTiles) return s;
+    const int x = u / p.skTiles;
+    s.tile = u - x * p.skTiles;
+    s.kb = x * p.kChunk;
+    s.ke = s.kb + p.kChunk < p.kTiles ? s.kb + p.kChunk : p.kTiles;
+    s.slab = u;
+    s.valid = true;
+    return s;
+  }
   const int nDp = w < p.dpTiles ? (p.dpTiles - w + workers - 1) / workers : 0;
   if (ord < nDp) {
     s.tile = w + ord * workers; s.kb = 0; s.ke = p.kTiles; s.valid = true;

@@ -285,8 +285,8 @@ __global__ __launch_bounds__(256, 2) void gemm160_kernel(GOp aop, GOp bop, GemmO
       }
       __syncthreads();
       const int ticket = *flag;
-      int sF, sL;
-      sk_tile_ranges(plan, t, sF, sL);
+      int sF = 0, sL = plan.ksplit - 1;
+      if (!plan.ksplit) sk_tile_ranges(plan, t, sF, sL);
       if (ticket == sL - sF) {  // uniform: last arriver
         if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __syncthreads();  // (also: every wave has read the ticket before the stage becomes epilogue scratch)
@@ -295,8 +295,14 @@ __global__ __launch_bounds__(256, 2) void gemm160_kernel(GOp aop, GOp bop, GemmO
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
         for (int sr = sF; sr <= sL; ++sr) {
-          const int segIdx = t - (int)(sk_begin(plan, sr) / plan.kTiles);  // ranges span <= 2 tiles: 0 or 1
-          const f32x4* s4 = (const f32x4*)(plan.slabs + ((size_t)sr * 2 + segIdx) * kT160SlabFloats);
+          size_t slab;
+          if (plan.ksplit) {
+            slab = (size_t)sr * plan.skTiles + t;   // chunk sr of this tile
+          } else {
+            const int segIdx = t - (int)(sk_begin(plan, sr) / plan.kTiles);  // ranges span <= 2 tiles: 0 or 1
+            slab = (size_t)sr * 2 + segIdx;
+          }
+          const f32x4* s4 = (const f32x4*)(plan.slabs + slab * kT160SlabFloats);
 #pragma unroll
           for (int b = 0; b < 5; ++b)
 #pragma unroll
@@ -320,6 +326,15 @@ __global__ __launch_bounds__(256, 2) void gemm160_kernel(GOp aop, GOp bop, GemmO
     seg = nxt;
     sk_tile_xy(plan, seg.tile, bx, by);
   }
+}
+
+// MEASURED (profiles/r02_run17_gemm_aligned_ksplit_negative.log): correct, the L2 sharing is real, and it does not pay --
+// 120-127 TF/s against 126-132 of the classic ranges on the six weight-gradient shapes (a wash at K = 24000, 6-8 % slower
+// at K = 12000 / 6016): whole rounds of 512 units are 88-93 % full where stream-K balances to the K tile.  Probe library
+// only (W2L_GEMM_KSPLIT=1).
+inline bool t160_ksplit_enabled() {
+  const char* e = tune_env("W2L_GEMM_KSPLIT");
+  return e && atoi(e) != 0;
 }
 
 // 0 = not eligible / not worth it, 1 = WIDE (128x160), 2 = TALL (160x128): the variant whose padded tile area is
@@ -354,6 +369,21 @@ inline int launch160(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o, 
   }
   int workers = plan.dpTiles < kSkSlots ? plan.dpTiles : kSkSlots;
   if (workers < plan.skBlocks) workers = plan.skBlocks;
+  // aligned K split for a GEMM that is all stream-K (fewer tiles than workgroup slots: the weight gradients): the
+  // smallest number of chunks that fills >= 88 % of whole rounds of 512 units, at most 1024 units (one slab each)
+  if (plan.skBlocks > 0 && plan.dpTiles == 0 && plan.slabs && t160_ksplit_enabled()) {
+    const int tiles = plan.skTiles;
+    for (int X = 2; X <= 8; ++X) {
+      const int units = tiles * X, rounds = (units + kSkSlots - 1) / kSkSlots;
+      const int chunk = (plan.kTiles + X - 1) / X;
+      if (units > 2 * kSkSlots || chunk < 8 || (X - 1) * chunk >= plan.kTiles) continue;
+      if ((double)units / ((double)rounds * kSkSlots) < 0.88) continue;
+      plan.ksplit = X;
+      plan.kChunk = chunk;
+      workers = units < kSkSlots ? units : kSkSlots;
+      break;
+    }
+  }
   const size_t shmem = 2 * (size_t)kT160StageFloats * sizeof(float);
   dim3 grid((unsigned)workers), block(256);
   o.epi = epi;
