@@ -439,7 +439,7 @@ def test_conv_backward_data_accumulate_and_add(oracle, B, Cin, Cout, H, T, kw, s
 
 TDS_RS3_SHAPES = [(10, 48, 2, 80), (18, 12, 2, 80), (10, 50, 2, 80), (18, 15, 3, 80), (10, 1, 1, 80), (18, 2, 2, 80), (10, 129, 3, 80),
                   (18, 188, 5, 80), (10, 750, 3, 80), (10, 64, 1, 80), (18, 46, 7, 80), (10, 331, 9, 80), (18, 97, 33, 80), (10, 77, 5, 8),
-                  (18, 150, 2, 24), (10, 2100, 2, 16)]
+                  (18, 150, 2, 24), (10, 2100, 2, 16), (14, 24, 2, 80), (14, 77, 2, 80), (14, 375, 3, 80), (14, 1, 1, 80), (14, 33, 5, 16), (14, 200, 9, 8)]
 
 
 def _tds_conv_ref64(x, w, b, dy, add, kw, padl):
@@ -453,7 +453,7 @@ def _tds_conv_ref64(x, w, b, dy, add, kw, padl):
 
 @pytest.mark.parametrize("Cc,T,B,H", TDS_RS3_SHAPES)
 def test_tds_conv_streamed_wave_specialised_kernel(Cc, T, B, H):
-    """conv_tds_rs3.hpp (the TDS convolution proper, C = 10 / 18, H % 8 == 0): forward with bias, with and without the fused
+    """conv_tds_rs3.hpp (the TDS convolution proper, C = 10 / 14 / 18, H % 8 == 0): forward with bias, with and without the fused
     ReLU, and backward-data with the fused addend, every element against a float64 convolution; segment cuts in the
     middle of utterances, utterances shorter than one tile, one- and two-frame inputs, short kernels, causal padding;
     run-to-run identical (the overlap-add order is program order)"""

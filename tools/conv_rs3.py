@@ -35,7 +35,6 @@ def small():
         dy = torch.randn(B, T, H, Cc, generator=g).cuda()
         add = torch.randn(B, T, H, Cc, generator=g).cuda()
         os.environ["W2L_TDS_RS3"] = "1"
-        os.environ["W2L_TDS_RS_C14"] = "1"
         with _lib.use_probe() as P:
             y = torch.full_like(x, float("nan")); dx = torch.full_like(x, float("nan"))
             assert P.w2l_conv_forward(C.byref(d), x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), 1, s) == 0
@@ -44,7 +43,7 @@ def small():
             y2 = torch.full_like(x, float("nan"))
             P.w2l_conv_forward(C.byref(d), x.data_ptr(), w.data_ptr(), b.data_ptr(), y2.data_ptr(), 1, s)
             torch.cuda.synchronize()
-        os.environ.pop("W2L_TDS_RS3"); os.environ.pop("W2L_TDS_RS_C14")
+        os.environ.pop("W2L_TDS_RS3")
         ry, rdx = ref64(x, w, b, dy, add)
         ey = ((y.double() - ry).abs().max() / ry.abs().max()).item()
         edx = ((dx.double() - rdx).abs().max() / rdx.abs().max()).item()
@@ -72,7 +71,6 @@ def big():
             old, to = run(P, d, x, w, b, dy)
         os.environ.pop("W2L_TDS_RS3_OFF"); os.environ.pop("W2L_TDS_RSF3_OFF")
         os.environ["W2L_TDS_RS3"] = "1"
-        os.environ["W2L_TDS_RS_C14"] = "1"
         with _lib.use_probe() as P:
             new, tn = run(P, d, x, w, b, dy)
         e_ab = {k: ((new[k].double() - old[k].double()).abs().max() / old[k].double().abs().max()).item() for k in ("y", "dx", "dw", "db")}
@@ -104,7 +102,7 @@ def big():
                     _, ta = run(P, d, x, w, b, dy, reps=10)
                 os.environ.pop("W2L_TDS_RS_ABL")
                 print(f"    abl {abl:2d} ({what:26s}): fwd {ta['fwd']:7.1f} us")
-        os.environ.pop("W2L_TDS_RS3"); os.environ.pop("W2L_TDS_RS_C14")
+        os.environ.pop("W2L_TDS_RS3")
 
 
 if __name__ == "__main__" and "--scale" not in sys.argv:
@@ -120,7 +118,6 @@ def scale():
         a @ a
     torch.cuda.synchronize()
     os.environ["W2L_TDS_RS3"] = "1"
-    os.environ["W2L_TDS_RS_C14"] = "1"
     for (Cc, T) in [(10, 750), (18, 188)]:
         for abl in (0, 126, 127, 35):
             row = []

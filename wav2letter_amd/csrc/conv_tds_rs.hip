@@ -606,11 +606,11 @@ bool tds_rs_try(const float* x, const float* w, const float* bias, const float* 
   { const char* e = tune_env("W2L_TDS_RS_ABL"); p.abl = e ? atoi(e) : 0; }
   { const char* e = tune_env("W2L_TDS_RS_STAGGER"); p.stagger = e ? atoi(e) : (C == 10 ? 4 : 0); }
   // third generation (conv_tds_rs3.hpp): wave-specialised, streamed time axis.  One utterance per 2 GiB buffer resource.
-  const bool rs3 = !tune_env("W2L_TDS_RS3_OFF") && H % 8 == 0 && C != 14 && !accum && (long long)B * (H / 4) * Tout <= (1ll << 30) &&
+  const bool rs3 = !tune_env("W2L_TDS_RS3_OFF") && H % 8 == 0 && !accum && (long long)B * (H / 4) * Tout <= (1ll << 30) &&
                    (long long)Tin * H * C * 4 < (1ll << 31) && (long long)Tout * H * C * 4 < (1ll << 31);
   if (rs3) {
     prof_begin(s, 2.0 * B * Tout * (double)H * kw * C * C, profKind);
-    int st = C == 10 ? rs3_launch<10, 3, 7, 8, 1, 2>(p, s) : rs3_launch<18, 7, 3, 4, 2, 2>(p, s);
+    int st = C == 10 ? rs3_launch<10, 3, 7, 8, 1, 2>(p, s) : C == 14 ? rs3_launch<14, 2, 11, 8, 1, 1>(p, s) : rs3_launch<18, 7, 3, 4, 2, 2>(p, s);
     prof_end(s);
     if (st == W2L_OK && hipGetLastError() != hipSuccess) st = W2L_EHIP;
     *status = st;

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(768) void tds_conv_rs3_k(TdsRs3P p) {
     static_assert(PER >= 2, "overlap-add rounds do not fit between the MFMAs of one chain");
     constexpr int NPF = (NK + 1) / 2;   // fragment prefetch: pairs of k-steps whose slab offsets are < 256 dwords apart (one ds_read2_b32)
     constexpr int U = KT * NCT;   // units of a full tile; unit u accumulates in set u & 1 while the set of unit u-1 is added out
-    static_assert(U % 2 == 0, "accumulator ping-pong");
+    // (U odd -- one unit per tile at C = 14 -- costs one 16-register copy per tile: see the end of consume())
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x16 accS[2];
 #pragma unroll
@@ -268,9 +268,14 @@ __global__ __launch_bounds__(768) void tds_conv_rs3_k(TdsRs3P p) {
     };
     auto consume = [&](const Rs3Tile& d, const float* slab, float* outB) {
       const float* ab = slab + aoff;
-      float a[KT][NK];
+      // fragments: with KT > 1 the next row tile's NK values are read during this row tile's last chain (a[kti + 1]);
+      // with ONE row tile per round (C = 14: 77 weight registers) they are STREAMED through a ring of RING registers,
+      // each value read RING MFMAs before its use
+      constexpr bool STREAM = KT == 1;
+      constexpr int RING = 16;
+      float a[STREAM ? 1 : KT][STREAM ? RING : NK];
 #pragma unroll
-      for (int s = 0; s < NK; ++s) a[0][s] = (abl & 32) ? bw[0][s] : ab[aidx(s)];
+      for (int s = 0; s < (STREAM ? RING : NK); ++s) a[0][s] = (abl & 32) ? bw[0][s] : ab[aidx(s)];
 #pragma unroll
       for (int kti = 0; kti < KT; ++kti) {
         if (kti < d.kt()) {
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(768) void tds_conv_rs3_k(TdsRs3P p) {
             for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 #pragma unroll
             for (int s = 0; s < NK; ++s) {
-              if (!((abl & 1) && s > 0)) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kti][s], bw[ct][s], acc, 0, 0, 0);
+              if (!((abl & 1) && s > 0)) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[STREAM ? 0 : kti][STREAM ? s % RING : s], bw[ct][s], acc, 0, 0, 0);
               if (!(abl & 2)) {
 #pragma unroll
                 for (int c = 0; c < NR; ++c) {
@@ -299,7 +304,11 @@ __global__ __launch_bounds__(768) void tds_conv_rs3_k(TdsRs3P p) {
                   }
                 }
               }
-              if (ct == NCT - 1 && kti + 1 < KT && !(abl & 32) && s % 2 == 0 && s / 2 < NPF) {   // (beyond the tile when kt < KT: never used)
+              if (STREAM && !(abl & 32) && s % 2 == 1) {   // the two ring slots just used take the values of steps s - 1 + RING, s + RING
+                if (s - 1 + RING < NK) a[0][(s - 1) % RING] = ab[aidx(s - 1 + RING)];
+                if (s + RING < NK) a[0][s % RING] = ab[aidx(s + RING)];
+              }
+              if (!STREAM && ct == NCT - 1 && kti + 1 < KT && !(abl & 32) && s % 2 == 0 && s / 2 < NPF) {   // (beyond the tile when kt < KT: never used)
                 constexpr auto pf = Rs3Prefetch<C, J>::make();
                 const int s1 = pf.a[s / 2], s2 = pf.b[s / 2];
                 a[kti + 1 < KT ? kti + 1 : kti][s1] = ab[32 * (kti + 1) + aidx(s1)];
