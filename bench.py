@@ -526,8 +526,8 @@ def main():
                                   "forward": {"launches_per_step": nc // max(1, a.steps), "ms_per_step": round(msc / max(1, a.steps), 3), "achieved_TFLOPs": tfs(flc, msc)},
                                   "backward_data": {"launches_per_step": nbd // max(1, a.steps), "ms_per_step": round(msbd / max(1, a.steps), 3), "achieved_TFLOPs": tfs(flbd, msbd)},
                                   "backward_filter": {"launches_per_step": nbf // max(1, a.steps), "ms_per_step": round(msbf / max(1, a.steps), 3), "achieved_TFLOPs": tfs(flbf, msbf)},
-                                  "note": "TDS convolutions proper: wave-specialised role-swapped v_mfma_f32_32x32x2_f32 kernels (conv_tds_rs3.hpp / "
-                                          "conv_tds_rsf3.hpp at C = 10 / 18, conv_tds.hip at C = 14); includes the three strided C2 sub-sampling layers"},
+                                  "note": "TDS convolutions proper: wave-specialised role-swapped v_mfma_f32_32x32x2_f32 kernels (conv_tds_rs3.hpp at C = 10 / 14 / 18, "
+                                          "conv_tds_rsf3.hpp at C = 10 / 18, conv_tds.hip's filter gradient at C = 14); includes the three strided C2 sub-sampling layers"},
                      "skinny_gemm": {"launches_per_step": ns // max(1, a.steps), "ms_per_step": round(mss / max(1, a.steps), 3)}},
     }
     def leg(key, fn):
