@@ -208,6 +208,33 @@ int w2l_mask_backward(const float* dy, const float* src, float* dx, size_t n, fl
  * axis; rows = utterances x frames.  _backward is the adjoint (sum over dh). */
 int w2l_hexpand_forward(const float* x, float* xe, size_t rows, int H, int C, int kh, int padh, w2l_stream_t stream);
 int w2l_hexpand_backward(const float* dxe, float* dx, size_t rows, int H, int C, int kh, int padh, w2l_stream_t stream);
+/* fl::Transformer's attention core (arch token `TR`, recipes/sota/2019/am_arch/am_transformer_ctc.arch:15-38; block:
+ * recipes/joint_training_vox_populi/cpc/TransformerCPC.cpp:117-151; fl::multiheadAttention is [UNVENDORED] Flashlight).
+ * Strided batched GEMM over G1 x G2 problems, C = (C +) A B: element (m, k) of A of problem (g1, g2) at
+ * A[g1*a1 + g2*a2 + m*sam + k*sak], (k, n) of B at B[g1*b1 + g2*b2 + k*sbk + n*sbn], (m, n) of C at
+ * C[g1*c1 + g2*c2 + m*ldc + n]; strides in floats.  With frame-major [B][T][heads*d] q / k / v this is QK^T, PV and their
+ * gradients per (utterance, head) without a transpose. */
+typedef struct {
+  int M, N, K, G1, G2;
+  long long sam, sak, a1, a2;
+  long long sbk, sbn, b1, b2;
+  long long ldc, c1, c2;
+  int accumulate;
+} w2l_bgemm_desc;
+int w2l_bgemm_f32(const w2l_bgemm_desc* d, const float* A, const float* B, float* C, w2l_stream_t stream);
+/* S[b][h][i][j] (in: q_i . k_j) -> P = softmax_j(scale * (S + R[(b*T + i)*H + h][j - i + n0 - rlo])) in place; R (may be
+ * NULL: no position term) holds q_i . E[rlo + w] for w < W, row stride ldr; entries outside [0, W) count as 0
+ * (relativePositionEmbeddingRotate pads with zeros). */
+int w2l_attn_softmax_forward(float* S, const float* R, int B, int H, int T, int ldr, int rlo, int W, int n0, float scale,
+                             w2l_stream_t stream);
+/* dS (in: dL/dP) -> dL/dS (pre-scale scores) in place; dR (may be NULL) receives the skewed copy, zeros elsewhere */
+int w2l_attn_softmax_backward(const float* P, float* dS, float* dR, int B, int H, int T, int ldr, int rlo, int W, int n0,
+                              float scale, w2l_stream_t stream);
+/* fl::Pool2D(w, 1, stride, 1, 0, 0, MAX) over time on frame-major x[B][T][F] -> y[B][(T-w)/stride+1][F] (arch token `M`,
+ * SequentialBuilder.cpp:398-414); backward routes each dy to the first maximum of its window */
+int w2l_pool_time_forward(const float* x, float* y, int B, int T, int F, int w, int stride, w2l_stream_t stream);
+int w2l_pool_time_backward(const float* x, const float* dy, float* dx, int B, int T, int F, int w, int stride,
+                           w2l_stream_t stream);
 int w2l_axpy(float* y, const float* x, size_t n, float alpha, w2l_stream_t stream);
 int w2l_fill(float* y, size_t n, float v, w2l_stream_t stream);
 int w2l_transpose(const float* in, float* out, int G, int R, int C, w2l_stream_t stream);

@@ -141,6 +141,9 @@ class RefNet:
                 l2 = int(t[5]) if len(t) > 5 and int(t[5]) else l
                 out += [("conv.w", (c, c, kw)), ("conv.b", (c,)), ("ln", (2,)), ("linear.w", (l, l2)), ("linear.b", (l2,)),
                         ("linear.w", (l2, l)), ("linear.b", (l,)), ("ln", (2,))]
+            elif t[0] == "TR":
+                from oracle import transformer_oracle as TO
+                out += TO.tr_param_shapes(int(t[1]), int(t[2]), int(t[3]), int(t[4]))
         return out
 
     def random_params(self, rng):
@@ -278,6 +281,28 @@ class RefNet:
                 out, saved = tds_fwd(a, p, pl, pr, mode, keep=True)
                 self.tape.append(("TDS", p, saved, pl, pr, mode, pi))
                 a = out
+            elif t[0] == "M":
+                # fl::Pool2D(wx, 1, sx, 1, MAX) over time (SequentialBuilder.cpp:398-414)
+                wx, wy, sx, sy = (int(v) for v in t[1:5])
+                assert wy == 1 and sy == 1 and all(int(v) == 0 for v in t[5:]), t
+                To = (a.shape[3] - wx) // sx + 1
+                win = np.stack([a[..., k:k + (To - 1) * sx + 1:sx] for k in range(wx)], axis=0)
+                arg = win.argmax(axis=0)          # first maximum, as a scan over the window finds it
+                self.tape.append(("M", a.shape, arg, sx))
+                a = np.ascontiguousarray(win.max(axis=0))
+            elif t[0] == "TR":
+                import torch
+                from oracle import transformer_oracle as TO
+                C, mlp, nheads, csz = int(t[1]), int(t[2]), int(t[3]), int(t[4])
+                assert float(t[5]) == 0.0 and (len(t) <= 6 or float(t[6]) == 0.0), "reference interpreter runs dropout-free archs"
+                n = len(TO.tr_param_shapes(C, mlp, nheads, csz))
+                assert a.shape[0] == 1 and a.shape[3] == C, a.shape     # (C, T, B, 1)
+                xt = torch.tensor(a[0], dtype=torch.float64, requires_grad=True)
+                pt = [torch.tensor(np.asarray(p), dtype=torch.float64, requires_grad=True) for p in params[pi:pi + n]]
+                pi += n
+                yt = TO.tr_block(xt, pt, nheads, csz)
+                self.tape.append(("TR", xt, pt, yt, pi))
+                a = yt.detach().numpy().astype(np.float32)[None]
             else:
                 raise ValueError(t[0])
         # (N, T, B, 1) -> [B][T][N]
@@ -337,6 +362,21 @@ class RefNet:
             elif k == "GLU":
                 _, a, outer, half, inner = rec
                 da = O.glu_bwd(a, np.ascontiguousarray(da, dtype=np.float32), outer, half, inner).reshape(a.shape)
+            elif k == "M":
+                _, shp, arg, sx = rec
+                dx = np.zeros(shp, np.float32)
+                To = arg.shape[3]
+                tpos = arg + (np.arange(To) * sx)[None, None, None, :]
+                b, c, h, _ = np.indices(arg.shape)
+                np.add.at(dx, (b, c, h, tpos), np.asarray(da, np.float32))
+                da = dx
+            elif k == "TR":
+                import torch
+                _, xt, pt, yt, pi = rec
+                gs = torch.autograd.grad(yt, [xt] + pt, grad_outputs=torch.tensor(np.asarray(da[0]), dtype=torch.float64))
+                da = gs[0].numpy().astype(np.float32)[None]
+                for j, gj in enumerate(gs[1:]):
+                    g[pi - len(pt) + j] = gj.numpy().astype(np.float32)
             elif k == "TDS":
                 _, p, saved, pl, pr, mode, pi = rec
                 da, gg = tds_bwd(np.ascontiguousarray(da, dtype=np.float32), p, saved, pl, pr, mode)

@@ -1,0 +1,135 @@
+"""fl::Transformer's attention core and the time-axis max pool through the C ABI (wav2letter_amd/csrc/attention.hip):
+the strided batched GEMM in every operand orientation the block uses, the softmax with the gathered relative-position
+term and its backward, and a whole TR network end to end against oracle/transformer_oracle.py (torch float64 restatement
+of recipes/joint_training_vox_populi/cpc/TransformerCPC.cpp)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import refnet
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def rel(got, want):
+    want = np.asarray(want, np.float64).reshape(-1)
+    got = np.asarray(got, np.float64).reshape(-1)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    return np.abs(got - want).max() / max(1e-30, np.abs(want).max())
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("B,H,T,d", [(2, 4, 47, 8), (3, 2, 64, 32), (1, 4, 188, 256), (2, 1, 5, 4), (2, 3, 130, 20)])
+def test_batched_gemm_head_products(B, H, T, d):
+    """QK^T, PV, P^T dC and dS^T Q straight out of frame-major [B][T][H*d] buffers, against float64 einsums"""
+    from wav2letter_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    Cc = H * d
+    q = torch.randn(B, T, Cc, generator=g).cuda()
+    k = torch.randn(B, T, Cc, generator=g).cuda()
+    P = torch.randn(B, H, T, T, generator=g).cuda()
+    qh = q.double().reshape(B, T, H, d).permute(0, 2, 1, 3)
+    kh = k.double().reshape(B, T, H, d).permute(0, 2, 1, 3)
+    TC, TT = T * Cc, T * T
+    # S = q k^T
+    S = torch.full((B, H, T, T), float("nan"), device="cuda")
+    D = _lib.BgemmDesc(M=T, N=T, K=d, G1=B, G2=H, sam=Cc, sak=1, a1=TC, a2=d, sbk=1, sbn=Cc, b1=TC, b2=d, ldc=T, c1=H * TT, c2=TT)
+    assert L.w2l_bgemm_f32(C.byref(D), q.data_ptr(), k.data_ptr(), S.data_ptr(), _stream()) == 0
+    assert rel(S.cpu().numpy(), (qh @ kh.transpose(-1, -2)).cpu().numpy()) < TOL
+    # ctx = P k  (k in the role of v), written back frame-major
+    ctx = torch.full((B, T, Cc), float("nan"), device="cuda")
+    D = _lib.BgemmDesc(M=T, N=d, K=T, G1=B, G2=H, sam=T, sak=1, a1=H * TT, a2=TT, sbk=Cc, sbn=1, b1=TC, b2=d, ldc=Cc, c1=TC, c2=d)
+    assert L.w2l_bgemm_f32(C.byref(D), P.data_ptr(), k.data_ptr(), ctx.data_ptr(), _stream()) == 0
+    want = (P.double() @ kh).permute(0, 2, 1, 3).reshape(B, T, Cc)
+    assert rel(ctx.cpu().numpy(), want.cpu().numpy()) < TOL
+    # dv = P^T q (A read transposed: sam = 1), accumulated onto a previous value
+    dv = torch.randn(B, T, Cc, generator=g).cuda()
+    dv0 = dv.clone()
+    D = _lib.BgemmDesc(M=T, N=d, K=T, G1=B, G2=H, sam=1, sak=T, a1=H * TT, a2=TT, sbk=Cc, sbn=1, b1=TC, b2=d, ldc=Cc, c1=TC, c2=d,
+                       accumulate=1)
+    assert L.w2l_bgemm_f32(C.byref(D), P.data_ptr(), q.data_ptr(), dv.data_ptr(), _stream()) == 0
+    want = dv0.double() + (P.double().transpose(-1, -2) @ qh).permute(0, 2, 1, 3).reshape(B, T, Cc)
+    assert rel(dv.cpu().numpy(), want.cpu().numpy()) < TOL
+
+
+@pytest.mark.parametrize("B,H,T,d,csz", [(2, 4, 23, 8, 30), (2, 2, 40, 16, 7), (1, 4, 188, 64, 460), (3, 1, 1, 4, 2)])
+def test_relative_position_products_and_softmax(B, H, T, d, csz):
+    """R = Qflat E_win^T, softmax(scale (S + skew(R))) and its backward (dS and the skewed dR) against the float64
+    restatement of multiheadAttention's score path"""
+    from oracle import transformer_oracle as TO
+    from wav2letter_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(T * 10 + csz)
+    Cc = H * d
+    q = torch.randn(B, T, Cc, generator=g)
+    S = torch.randn(B, H, T, T, generator=g)
+    E = torch.randn(2 * csz - 1, d, generator=g) * 0.5
+    dP = torch.randn(B, H, T, T, generator=g)
+    n0 = csz - 1
+    rlo = max(0, n0 - (T - 1))
+    W = min(2 * csz - 1, n0 + T) - rlo
+    ldr = (W + 3) // 4 * 4
+    scale = 1.0 / np.sqrt(d)
+    qd, Sd, Ed = q.cuda(), S.cuda(), E.cuda()
+    R = torch.full((B * T * H, ldr), float("nan"), device="cuda")
+    D = _lib.BgemmDesc(M=B * T * H, N=W, K=d, G1=1, G2=1, sam=d, sak=1, sbk=1, sbn=d, ldc=ldr)
+    assert L.w2l_bgemm_f32(C.byref(D), qd.data_ptr(), Ed[rlo:].data_ptr(), R.data_ptr(), _stream()) == 0
+    Pd = Sd.clone()
+    assert L.w2l_attn_softmax_forward(Pd.data_ptr(), R.data_ptr(), B, H, T, ldr, rlo, W, n0, scale, _stream()) == 0
+    # oracle
+    S64 = S.double().requires_grad_(True)
+    q64 = q.double().requires_grad_(True)
+    E64 = E.double().requires_grad_(True)
+    qh = q64.reshape(B, T, H, d).permute(0, 2, 1, 3)
+    rot = TO.relative_position_rotate(qh @ E64.t())
+    n = E.shape[0] // 2
+    Pref = torch.softmax((S64 + rot[..., n:n + T]) * scale, dim=-1)
+    assert rel(Pd.cpu().numpy(), Pref.detach().numpy()) < TOL
+    Pref.backward(dP.double())
+    dS = dP.cuda().clone()
+    dR = torch.full((B * T * H, ldr), float("nan"), device="cuda")
+    assert L.w2l_attn_softmax_backward(Pd.data_ptr(), dS.data_ptr(), dR.data_ptr(), B, H, T, ldr, rlo, W, n0, scale, _stream()) == 0
+    assert rel(dS.cpu().numpy(), S64.grad.numpy()) < TOL
+    assert torch.isfinite(dR).all()
+    # dq (relative part) = dR E_win, dE_win = dR^T Qflat
+    dq = torch.zeros(B, T, Cc, device="cuda")
+    D = _lib.BgemmDesc(M=B * T * H, N=d, K=W, G1=1, G2=1, sam=ldr, sak=1, sbk=d, sbn=1, ldc=d, accumulate=1)
+    assert L.w2l_bgemm_f32(C.byref(D), dR.data_ptr(), Ed[rlo:].data_ptr(), dq.data_ptr(), _stream()) == 0
+    assert rel(dq.cpu().numpy(), q64.grad.numpy()) < TOL
+    dEp = torch.full((B, W, d), float("nan"), device="cuda")
+    D = _lib.BgemmDesc(M=W, N=d, K=T * H, G1=B, G2=1, sam=1, sak=ldr, a1=T * H * ldr, sbk=d, sbn=1, b1=T * Cc, ldc=d, c1=W * d)
+    assert L.w2l_bgemm_f32(C.byref(D), dR.data_ptr(), qd.data_ptr(), dEp.data_ptr(), _stream()) == 0
+    dE = torch.zeros(2 * csz - 1, d, device="cuda")
+    assert L.w2l_colsum(dEp.data_ptr(), dE[rlo:].data_ptr(), B, W * d, _stream()) == 0
+    assert rel(dE.cpu().numpy(), E64.grad.numpy()) < TOL
+    # no position term: plain softmax
+    P0 = Sd.clone()
+    assert L.w2l_attn_softmax_forward(P0.data_ptr(), None, B, H, T, 0, 0, 0, 0, scale, _stream()) == 0
+    assert rel(P0.cpu().numpy(), torch.softmax(S.double() * scale, -1).numpy()) < TOL
+
+
+@pytest.mark.parametrize("B,T,F,w,stride", [(2, 21, 32, 1, 2), (3, 20, 12, 2, 2), (2, 17, 8, 3, 2), (1, 9, 4, 3, 1)])
+def test_time_max_pool(B, T, F, w, stride):
+    from wav2letter_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(B, T, F, generator=g)
+    To = (T - w) // stride + 1
+    xr = x.double().permute(0, 2, 1).requires_grad_(True)                 # [B][F][T]
+    yr = torch.nn.functional.max_pool1d(xr, w, stride)
+    dy = torch.randn(B, To, F, generator=g)
+    yr.backward(dy.double().permute(0, 2, 1))
+    xd, dyd = x.cuda(), dy.cuda()
+    y = torch.empty(B, To, F, device="cuda")
+    dx = torch.full((B, T, F), float("nan"), device="cuda")
+    assert L.w2l_pool_time_forward(xd.data_ptr(), y.data_ptr(), B, T, F, w, stride, _stream()) == 0
+    assert L.w2l_pool_time_backward(xd.data_ptr(), dyd.data_ptr(), dx.data_ptr(), B, T, F, w, stride, _stream()) == 0
+    assert torch.equal(y.cpu().double(), yr.detach().permute(0, 2, 1))
+    assert rel(dx.cpu().numpy(), xr.grad.permute(0, 2, 1).numpy()) < 1e-6

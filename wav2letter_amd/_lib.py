@@ -121,6 +121,11 @@ class _SIGS:
     w2l_mask_backward = (_i, [_p, _p, _p, _sz, _f, _p])
     w2l_hexpand_forward = (_i, [_p, _p, _sz, _i, _i, _i, _i, _p])
     w2l_hexpand_backward = (_i, [_p, _p, _sz, _i, _i, _i, _i, _p])
+    w2l_bgemm_f32 = (_i, [_p, _p, _p, _p, _p])
+    w2l_attn_softmax_forward = (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p])
+    w2l_attn_softmax_backward = (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p])
+    w2l_pool_time_forward = (_i, [_p, _p, _i, _i, _i, _i, _i, _p])
+    w2l_pool_time_backward = (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p])
     w2l_axpy = (_i, [_p, _p, _sz, _f, _p])
     w2l_transpose = (_i, [_p, _p, _i, _i, _i, _p])
     w2l_glu_forward = (_i, [_p, _p, _sz, _i, _p])
@@ -137,6 +142,12 @@ class _SIGS:
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "T", "H", "Cin", "Cout", "kw", "stride", "padl", "padr")]
+
+
+class BgemmDesc(C.Structure):  # w2l_bgemm_desc
+    _fields_ = ([(n, C.c_int) for n in ("M", "N", "K", "G1", "G2")] +
+                [(n, C.c_longlong) for n in ("sam", "sak", "a1", "a2", "sbk", "sbn", "b1", "b2", "ldc", "c1", "c2")] +
+                [("accumulate", C.c_int)])
 
 
 def check(status, what=""):

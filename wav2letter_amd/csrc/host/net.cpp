@@ -617,6 +617,243 @@ class TDSLayer : public Layer {
   }
 };
 
+// fl::Pool2D(wx, 1, sx, 1, 0, 0, MAX) on (T, H, C, B): the `M 1 1 2 1` lines between the front end's convolutions
+// (recipes/sota/2019/am_arch/am_transformer_ctc.arch:5; grammar SequentialBuilder.cpp:398-414)
+class PoolTimeLayer : public Layer {
+ public:
+  int w = 1, stride = 1;
+  int B = 0, T = 0, To = 0, F = 0;
+  size_t yOff = 0, dxOff = 0;
+  const float* xSaved = nullptr;
+  std::string name() const override { return "Pool2D"; }
+  Act plan(const Act& in, Planner& pl) override {
+    if (!isKind(in.d[0], F_TIME) || !isKind(in.d[3], F_BATCH))
+      throw std::invalid_argument("Pool2D: input must be (T, H, C, B), got " + in.str());
+    if (in.T < w) throw std::invalid_argument("Pool2D: fewer frames than the window");
+    B = in.B; T = in.T; F = in.F;
+    To = (T - w) / stride + 1;
+    Act o = in;
+    o.T = To;
+    yOff = pl.alloc((size_t)B * To * F);
+    dxOff = pl.alloc(in.numel());
+    return o;
+  }
+  void forward(Ctx& c, float* arena, const float* x, float*& y) override {
+    y = arena + yOff;
+    xSaved = x;
+    w2lCheck(w2l_pool_time_forward(x, y, B, T, F, w, stride, c.stream), "pool fwd");
+  }
+  void backward(Ctx& c, float* arena, const float* dy, float*& dx, bool needDx) override {
+    if (!needDx) return;
+    dx = arena + dxOff;
+    w2lCheck(w2l_pool_time_backward(xSaved, dy, dx, B, T, F, w, stride, c.stream), "pool bwd");
+  }
+};
+
+// fl::Transformer(modelDim, modelDim / nHeads, mlpDim, nHeads, csz, pDropout, pLayerdrop) -- arch token `TR`
+// (SequentialBuilder.cpp:136-158).  Block as the in-repo copy states it, recipes/joint_training_vox_populi/cpc/
+// TransformerCPC.cpp: parameters and their order :41-95 (position table, w1, w2, wq, wk, wv, wf, norm1, norm2), post-LN data
+// flow :153-182, mlp :97-101 (no dropout inside), selfAttention :117-151 (q scaled by 1/sqrt(d), dropout on the attention
+// probabilities only, no padding mask on this path: the network is called with an empty mask).
+//   h   = LN1(f * Wf attention(x) + x)          f = 0 with probability pLayerdrop while training, else 1
+//   out = LN2(f * W2 relu(W1 h) + h)
+// Input (C, T, B, 1) == frame-major [B*T][C]; heads are contiguous slices of a frame (moddims(T, d, heads*B)).
+class TransformerLayer : public Layer {
+ public:
+  int C = 0, mlp = 0, nH = 0, csz = 0;
+  double p = 0, pLayerDrop = 0;
+  int d = 0;
+  P pe, w1, b1, w2, b2, wq, bq, wk, bk, wv, bv, wf, bf, gb1, gb2;
+  int B = 0, T = 0, M = 0, W = 0, rlo = 0, ldr = 0, n0 = 0;
+  size_t qOff, kOff, vOff, sOff, pdOff, rOff, ctxOff, oOff, hOff, uOff, m2Off, outOff, st1Off, mr1Off, st2Off, mr2Off;
+  size_t ds2Off, duOff, dhOff, dr1Off, dctxOff, dsOff, dRoff, dqOff, dkOff, dvOff, dxOff, dEpOff;
+  const float* xSaved = nullptr;
+  bool dropped = false;
+
+  std::string name() const override { return "Transformer"; }
+  void registerParams(std::vector<ParamInfo>& t) override {
+    d = C / nH;
+    auto lin = [&](const char* nm, int in, int out, double wBound, double bBound, P& w, P& b) {
+      ParamInfo q;
+      q.name = std::string(nm) + ".w"; q.numel = (size_t)in * out; q.refShape = {out, in}; q.kind = 2; q.cin = in; q.cout = out;
+      q.initBound = wBound; addParam(t, q, w);
+      q = ParamInfo(); q.name = std::string(nm) + ".b"; q.numel = out; q.refShape = {out}; q.initBound = bBound; addParam(t, q, b);
+    };
+    if (csz > 0) {
+      ParamInfo q;  // ArrayFire (2 csz - 1, d), column-major == memory [d][2 csz - 1]; internal [2 csz - 1][d]
+      q.name = "tr.posemb"; q.numel = (size_t)(2 * csz - 1) * d; q.refShape = {2 * csz - 1, d}; q.kind = 5;
+      q.cin = 2 * csz - 1; q.cout = d; q.initBound = 0.1; addParam(t, q, pe);
+    }
+    const double g = 0.707 * std::sqrt(6.0 / (2.0 * C));
+    lin("tr.w1", C, mlp, std::sqrt(1.0 / C), std::sqrt(1.0 / C), w1, b1);
+    lin("tr.w2", mlp, C, std::sqrt(1.0 / mlp), std::sqrt(1.0 / mlp), w2, b2);
+    lin("tr.wq", C, C, g, std::sqrt(1.0 / C), wq, bq);
+    lin("tr.wk", C, C, g, std::sqrt(1.0 / C), wk, bk);
+    lin("tr.wv", C, C, g, std::sqrt(1.0 / C), wv, bv);
+    lin("tr.wf", C, C, std::sqrt(6.0 / (2.0 * C)), 0.0, wf, bf);
+    ParamInfo q;
+    q.name = "tr.norm1.weight+bias"; q.numel = 2; q.refShape = {1}; q.kind = 3; addParam(t, q, gb1);
+    q = ParamInfo(); q.name = "tr.norm2.weight+bias"; q.numel = 2; q.refShape = {1}; q.kind = 3; addParam(t, q, gb2);
+  }
+  Act plan(const Act& in, Planner& pl) override {
+    bool ok = in.d[0].f.size() == 1 && in.d[0].f[0].kind == F_FEAT && in.d[0].f[0].stride == 1 && in.d[0].size() == C && in.F == C &&
+              isKind(in.d[1], F_TIME) && isKind(in.d[2], F_BATCH) && in.d[3].f.empty();
+    if (!ok) throw std::invalid_argument("Transformer(" + std::to_string(C) + "): input must be (C, T, B, 1), got " + in.str());
+    if (C % nH || (C / nH) % 4) throw std::invalid_argument("Transformer: head size must be a multiple of 4");
+    B = in.B; T = in.T; M = B * T;
+    n0 = csz - 1;
+    if (csz > 0) {  // table rows j - i + n0 a T-frame utterance reaches, clipped to the table
+      rlo = std::max(0, n0 - (T - 1));
+      W = std::min(2 * csz - 1, n0 + T) - rlo;
+      ldr = (W + 3) / 4 * 4;
+    } else { rlo = W = ldr = 0; }
+    const size_t n = (size_t)M * C, ns = (size_t)B * nH * T * T, nr = (size_t)M * nH * ldr;
+    qOff = pl.alloc(n); kOff = pl.alloc(n); vOff = pl.alloc(n); sOff = pl.alloc(ns); pdOff = p > 0 ? pl.alloc(ns) : sOff;
+    rOff = pl.alloc(nr); ctxOff = pl.alloc(n); oOff = pl.alloc(n); hOff = pl.alloc(n); uOff = pl.alloc((size_t)M * mlp);
+    m2Off = pl.alloc(n); outOff = pl.alloc(n);
+    st1Off = pl.alloc(2 * w2l_layernorm_scratch_doubles(M, C)); mr1Off = pl.alloc(2 * (size_t)M);
+    st2Off = pl.alloc(2 * w2l_layernorm_scratch_doubles(M, C)); mr2Off = pl.alloc(2 * (size_t)M);
+    ds2Off = pl.alloc(n); duOff = pl.alloc((size_t)M * mlp); dhOff = pl.alloc(n); dr1Off = pl.alloc(n); dctxOff = pl.alloc(n);
+    dsOff = pl.alloc(ns); dRoff = pl.alloc(nr); dqOff = pl.alloc(n); dkOff = pl.alloc(n); dvOff = pl.alloc(n); dxOff = pl.alloc(n);
+    dEpOff = pl.alloc((size_t)B * W * d);
+    return in;
+  }
+  // per-(utterance, head) product over frame-major operands; see w2l_bgemm_desc
+  w2l_bgemm_desc heads(int Mm, int Nn, int Kk) const {
+    w2l_bgemm_desc g{};
+    g.M = Mm; g.N = Nn; g.K = Kk; g.G1 = B; g.G2 = nH;
+    return g;
+  }
+  void forward(Ctx& cx, float* ar, const float* x, float*& y) override {
+    hipStream_t s = cx.stream;
+    xSaved = x;
+    const double pd = cx.train ? p : 0.0;
+    dropped = false;
+    if (cx.train && pLayerDrop > 0) {  // one draw per block and step (af::randu(1) in the reference)
+      uint64_t st = ((uint64_t)cx.seed << 32) ^ (uint64_t)(rngStream + 3) * 0x9E3779B97F4A7C15ull;
+      st = (st ^ (st >> 30)) * 0xBF58476D1CE4E5B9ull; st = (st ^ (st >> 27)) * 0x94D049BB133111EBull; st ^= st >> 31;
+      dropped = (double)(st >> 11) * (1.0 / 9007199254740992.0) < pLayerDrop;
+    }
+    float *q = ar + qOff, *k = ar + kOff, *v = ar + vOff, *S = ar + sOff, *Pd = ar + pdOff, *R = ar + rOff, *ctx = ar + ctxOff;
+    float *o = ar + oOff, *h = ar + hOff, *u = ar + uOff, *m2 = ar + m2Off, *out = ar + outOff;
+    float* xm = const_cast<float*>(x);
+    if (dropped) {  // f = 0: both sublayers vanish, the two LayerNorms remain
+      w2lCheck(w2l_residual_layernorm_forward(M, C, xm, nullptr, xm, h, gb1.w(cx), 1e-5f, 0.0, 0, 0, (double*)(ar + st1Off), ar + mr1Off, s), "tr ln1");
+      w2lCheck(w2l_residual_layernorm_forward(M, C, h, nullptr, h, out, gb2.w(cx), 1e-5f, 0.0, 0, 0, (double*)(ar + st2Off), ar + mr2Off, s), "tr ln2");
+      y = out;
+      return;
+    }
+    w2lCheck(w2l_linear_forward(M, C, C, x, wq.w(cx), bq.w(cx), q, 0, s), "tr q");
+    w2lCheck(w2l_linear_forward(M, C, C, x, wk.w(cx), bk.w(cx), k, 0, s), "tr k");
+    w2lCheck(w2l_linear_forward(M, C, C, x, wv.w(cx), bv.w(cx), v, 0, s), "tr v");
+    const long long TC = (long long)T * C, TT = (long long)T * T;
+    {  // S[b][h][i][j] = q_i . k_j
+      w2l_bgemm_desc g = heads(T, T, d);
+      g.sam = C; g.sak = 1; g.a1 = TC; g.a2 = d; g.sbk = 1; g.sbn = C; g.b1 = TC; g.b2 = d; g.ldc = T; g.c1 = nH * TT; g.c2 = TT;
+      w2lCheck(w2l_bgemm_f32(&g, q, k, S, s), "tr qk");
+    }
+    if (csz > 0) {  // R[(b, i, h)][w] = q_i . E[rlo + w]
+      w2l_bgemm_desc g{};
+      g.M = M * nH; g.N = W; g.K = d; g.G1 = g.G2 = 1; g.sam = d; g.sak = 1; g.sbk = 1; g.sbn = d; g.ldc = ldr;
+      w2lCheck(w2l_bgemm_f32(&g, q, pe.w(cx) + (size_t)rlo * d, R, s), "tr qE");
+    }
+    w2lCheck(w2l_attn_softmax_forward(S, csz > 0 ? R : nullptr, B, nH, T, ldr, rlo, W, n0, (float)(1.0 / std::sqrt((double)d)), s), "tr softmax");
+    if (pd > 0) w2lCheck(w2l_dropout_copy(Pd, S, (size_t)B * nH * TT, pd, cx.seed, rngStream, s), "tr attn dropout");
+    {  // ctx_i = sum_j P[i][j] v_j
+      w2l_bgemm_desc g = heads(T, d, T);
+      g.sam = T; g.sak = 1; g.a1 = nH * TT; g.a2 = TT; g.sbk = C; g.sbn = 1; g.b1 = TC; g.b2 = d; g.ldc = C; g.c1 = TC; g.c2 = d;
+      w2lCheck(w2l_bgemm_f32(&g, pd > 0 ? Pd : S, v, ctx, s), "tr pv");
+    }
+    w2lCheck(w2l_linear_forward(M, C, C, ctx, wf.w(cx), bf.w(cx), o, 0, s), "tr wf");
+    // r1 = o + x (stored over o), h = LN1(r1)
+    w2lCheck(w2l_residual_layernorm_forward(M, C, o, x, o, h, gb1.w(cx), 1e-5f, 0.0, 0, 0, (double*)(ar + st1Off), ar + mr1Off, s), "tr ln1");
+    w2lCheck(w2l_linear_forward(M, C, mlp, h, w1.w(cx), b1.w(cx), u, 1, s), "tr w1");
+    w2lCheck(w2l_linear_forward(M, mlp, C, u, w2.w(cx), b2.w(cx), m2, 0, s), "tr w2");
+    w2lCheck(w2l_residual_layernorm_forward(M, C, m2, h, m2, out, gb2.w(cx), 1e-5f, 0.0, 0, 0, (double*)(ar + st2Off), ar + mr2Off, s), "tr ln2");
+    y = out;
+  }
+  void zeroGrad(Ctx& cx, const P& w, hipStream_t s) {
+    const ParamInfo& pi = (*w.table)[w.idx];
+    w2lCheck(w2l_fill(w.g(cx), pi.numel, 0.f, s), "tr zero grad");
+  }
+  void backward(Ctx& cx, float* ar, const float* dy, float*& dx, bool needDx) override {
+    hipStream_t s = cx.stream;
+    const double pd = cx.train ? p : 0.0;
+    float *q = ar + qOff, *k = ar + kOff, *v = ar + vOff, *S = ar + sOff, *Pd = ar + pdOff, *ctx = ar + ctxOff;
+    float *o = ar + oOff, *h = ar + hOff, *u = ar + uOff, *m2 = ar + m2Off;
+    float *ds2 = ar + ds2Off, *du = ar + duOff, *dh = ar + dhOff, *dr1 = ar + dr1Off, *dctx = ar + dctxOff, *dS = ar + dsOff;
+    float *dR = ar + dRoff, *dq = ar + dqOff, *dk = ar + dkOff, *dv = ar + dvOff, *dEp = ar + dEpOff;
+    (void)needDx;  // a Transformer block is never the first parameterised layer
+    dx = ar + dxOff;
+    if (dropped) {
+      w2lCheck(w2l_layernorm_backward(M, C, h, dy, gb2.w(cx), ar + mr2Off, dh, gb2.g(cx), nullptr, nullptr, 1.f, (double*)(ar + st2Off), s), "tr ln2 bwd");
+      w2lCheck(w2l_layernorm_backward(M, C, xSaved, dh, gb1.w(cx), ar + mr1Off, dx, gb1.g(cx), nullptr, nullptr, 1.f, (double*)(ar + st1Off), s), "tr ln1 bwd");
+      for (const P* w : {&w1, &b1, &w2, &b2, &wq, &bq, &wk, &bk, &wv, &bv, &wf, &bf}) zeroGrad(cx, *w, s);
+      if (csz > 0) zeroGrad(cx, pe, s);
+      return;
+    }
+    const long long TC = (long long)T * C, TT = (long long)T * T;
+    w2lCheck(w2l_layernorm_backward(M, C, m2, dy, gb2.w(cx), ar + mr2Off, ds2, gb2.g(cx), nullptr, nullptr, 1.f, (double*)(ar + st2Off), s), "tr ln2 bwd");
+    w2lCheck(w2l_linear_backward_weight(M, mlp, C, u, ds2, w2.g(cx), s), "tr w2 bwd w");
+    w2lCheck(w2l_colsum(ds2, b2.g(cx), (size_t)M, C, s), "tr w2 bwd b");
+    w2lCheck(w2l_linear_backward_data(M, mlp, C, ds2, w2.w(cx), du, 0, u, 1.f, s), "tr w2 bwd x");
+    w2lCheck(w2l_linear_backward_weight(M, C, mlp, h, du, w1.g(cx), s), "tr w1 bwd w");
+    w2lCheck(w2l_colsum(du, b1.g(cx), (size_t)M, mlp, s), "tr w1 bwd b");
+    w2lCheck(w2l_linear_backward_data_add(M, C, mlp, du, w1.w(cx), ds2, dh, s), "tr w1 bwd x");
+    w2lCheck(w2l_layernorm_backward(M, C, o, dh, gb1.w(cx), ar + mr1Off, dr1, gb1.g(cx), nullptr, nullptr, 1.f, (double*)(ar + st1Off), s), "tr ln1 bwd");
+    w2lCheck(w2l_linear_backward_weight(M, C, C, ctx, dr1, wf.g(cx), s), "tr wf bwd w");
+    w2lCheck(w2l_colsum(dr1, bf.g(cx), (size_t)M, C, s), "tr wf bwd b");
+    w2lCheck(w2l_linear_backward_data(M, C, C, dr1, wf.w(cx), dctx, 0, nullptr, 1.f, s), "tr wf bwd x");
+    {  // dPd[i][j] = dctx_i . v_j
+      w2l_bgemm_desc g = heads(T, T, d);
+      g.sam = C; g.sak = 1; g.a1 = TC; g.a2 = d; g.sbk = 1; g.sbn = C; g.b1 = TC; g.b2 = d; g.ldc = T; g.c1 = nH * TT; g.c2 = TT;
+      w2lCheck(w2l_bgemm_f32(&g, dctx, v, dS, s), "tr dP");
+    }
+    {  // dv_j = sum_i Pd[i][j] dctx_i
+      w2l_bgemm_desc g = heads(T, d, T);
+      g.sam = 1; g.sak = T; g.a1 = nH * TT; g.a2 = TT; g.sbk = C; g.sbn = 1; g.b1 = TC; g.b2 = d; g.ldc = C; g.c1 = TC; g.c2 = d;
+      w2lCheck(w2l_bgemm_f32(&g, pd > 0 ? Pd : S, dctx, dv, s), "tr dv");
+    }
+    if (pd > 0) w2lCheck(w2l_dropout_inplace(dS, (size_t)B * nH * TT, pd, cx.seed, rngStream, s), "tr attn dropout bwd");
+    w2lCheck(w2l_attn_softmax_backward(S, dS, csz > 0 ? dR : nullptr, B, nH, T, ldr, rlo, W, n0, (float)(1.0 / std::sqrt((double)d)), s), "tr softmax bwd");
+    {  // dq_i = sum_j dS[i][j] k_j
+      w2l_bgemm_desc g = heads(T, d, T);
+      g.sam = T; g.sak = 1; g.a1 = nH * TT; g.a2 = TT; g.sbk = C; g.sbn = 1; g.b1 = TC; g.b2 = d; g.ldc = C; g.c1 = TC; g.c2 = d;
+      w2lCheck(w2l_bgemm_f32(&g, dS, k, dq, s), "tr dq");
+    }
+    {  // dk_j = sum_i dS[i][j] q_i
+      w2l_bgemm_desc g = heads(T, d, T);
+      g.sam = 1; g.sak = T; g.a1 = nH * TT; g.a2 = TT; g.sbk = C; g.sbn = 1; g.b1 = TC; g.b2 = d; g.ldc = C; g.c1 = TC; g.c2 = d;
+      w2lCheck(w2l_bgemm_f32(&g, dS, q, dk, s), "tr dk");
+    }
+    if (csz > 0) {
+      const float* Ew = pe.w(cx) + (size_t)rlo * d;
+      {  // dq_(b,i,h) += sum_w dR[(b,i,h)][w] E[rlo + w]
+        w2l_bgemm_desc g{};
+        g.M = M * nH; g.N = d; g.K = W; g.G1 = g.G2 = 1; g.sam = ldr; g.sak = 1; g.sbk = d; g.sbn = 1; g.ldc = d; g.accumulate = 1;
+        w2lCheck(w2l_bgemm_f32(&g, dR, Ew, dq, s), "tr dq rel");
+      }
+      {  // dE[rlo + w] = sum_(b,i,h) dR[(b,i,h)][w] q_(b,i,h): one partial per utterance, then a column sum
+        w2l_bgemm_desc g{};
+        g.M = W; g.N = d; g.K = T * nH; g.G1 = B; g.G2 = 1; g.sam = 1; g.sak = ldr; g.a1 = (long long)T * nH * ldr;
+        g.sbk = d; g.sbn = 1; g.b1 = TC; g.ldc = d; g.c1 = (long long)W * d;
+        w2lCheck(w2l_bgemm_f32(&g, dR, q, dEp, s), "tr dE");
+        zeroGrad(cx, pe, s);
+        w2lCheck(w2l_colsum(dEp, pe.g(cx) + (size_t)rlo * d, (size_t)B, W * d, s), "tr dE sum");
+      }
+    }
+    w2lCheck(w2l_linear_backward_weight(M, C, C, xSaved, dq, wq.g(cx), s), "tr wq bwd w");
+    w2lCheck(w2l_colsum(dq, bq.g(cx), (size_t)M, C, s), "tr wq bwd b");
+    w2lCheck(w2l_linear_backward_weight(M, C, C, xSaved, dk, wk.g(cx), s), "tr wk bwd w");
+    w2lCheck(w2l_colsum(dk, bk.g(cx), (size_t)M, C, s), "tr wk bwd b");
+    w2lCheck(w2l_linear_backward_weight(M, C, C, xSaved, dv, wv.g(cx), s), "tr wv bwd w");
+    w2lCheck(w2l_colsum(dv, bv.g(cx), (size_t)M, C, s), "tr wv bwd b");
+    w2lCheck(w2l_linear_backward_data_add(M, C, C, dq, wq.w(cx), dr1, dx, s), "tr wq bwd x");
+    w2lCheck(w2l_linear_backward_data(M, C, C, dk, wk.w(cx), dx, 1, nullptr, 1.f, s), "tr wk bwd x");
+    w2lCheck(w2l_linear_backward_data(M, C, C, dv, wv.w(cx), dx, 1, nullptr, 1.f, s), "tr wv bwd x");
+  }
+};
+
 }  // namespace
 
 // ============================================================================ Sequential
@@ -725,6 +962,9 @@ void Sequential::importParam(size_t i, const float* ref, float* host) const {
             dst[(((size_t)k * p.kh + dh) * p.cin + ci) * p.cout + co] = ref[(((size_t)co * p.cin + ci) * p.kh + dh) * p.kw + k];
   } else if (p.kind == 2 && !p.rowPerm.empty()) {  // reference memory [in][out]; internal row r = reference row rowPerm[r]
     for (int r = 0; r < p.cin; ++r) std::memcpy(dst + (size_t)r * p.cout, ref + (size_t)p.rowPerm[r] * p.cout, sizeof(float) * p.cout);
+  } else if (p.kind == 5) {  // ArrayFire (rows, cols) column-major == memory [cols][rows] -> internal [rows][cols]
+    for (int r = 0; r < p.cin; ++r)
+      for (int c = 0; c < p.cout; ++c) dst[(size_t)r * p.cout + c] = ref[(size_t)c * p.cin + r];
   } else {
     std::memcpy(dst, ref, sizeof(float) * p.numel);
   }
@@ -741,6 +981,9 @@ void Sequential::exportParam(size_t i, const float* host, float* ref) const {
             ref[(((size_t)co * p.cin + ci) * p.kh + dh) * p.kw + k] = src[(((size_t)k * p.kh + dh) * p.cin + ci) * p.cout + co];
   } else if (p.kind == 2 && !p.rowPerm.empty()) {
     for (int r = 0; r < p.cin; ++r) std::memcpy(ref + (size_t)p.rowPerm[r] * p.cout, src + (size_t)r * p.cout, sizeof(float) * p.cout);
+  } else if (p.kind == 5) {
+    for (int r = 0; r < p.cin; ++r)
+      for (int c = 0; c < p.cout; ++c) ref[(size_t)c * p.cin + r] = src[(size_t)r * p.cout + c];
   } else {
     std::memcpy(ref, src, sizeof(float) * p.numel);
   }
@@ -833,6 +1076,25 @@ static std::shared_ptr<Layer> buildOne(const LayerSpec& s, const LayerSpec* wnPa
     if (l->l2 == 0) l->l2 = l->l;
     l->rPad = a.size() >= 6 ? toI(a[5]) : -1;
     l->lnTime = !(a.size() >= 7 && toI(a[6]) == 0);
+    return l;
+  }
+  if (s.tok == "M") {
+    if (a.size() < 4) throw std::invalid_argument("Failed parsing - " + s.line);
+    if (toI(a[1]) != 1 || toI(a[3]) != 1 || (a.size() > 4 && toI(a[4]) != 0) || (a.size() > 5 && toI(a[5]) != 0))
+      throw std::invalid_argument("M: max pooling is supported over the time axis, unpadded: " + s.line);
+    auto l = std::make_shared<PoolTimeLayer>();
+    l->w = toI(a[0]); l->stride = toI(a[2]);
+    if (l->w < 1 || l->stride < 1) throw std::invalid_argument("Failed parsing - " + s.line);
+    return l;
+  }
+  if (s.tok == "TR") {
+    if (a.size() < 5 || a.size() > 8) throw std::invalid_argument("Failed parsing - " + s.line);
+    auto l = std::make_shared<TransformerLayer>();
+    l->C = toI(a[0]); l->mlp = toI(a[1]); l->nH = toI(a[2]); l->csz = toI(a[3]); l->p = toD(a[4]);
+    l->pLayerDrop = a.size() >= 6 ? toD(a[5]) : 0.0;
+    if ((a.size() >= 7 && toI(a[6]) != 0) || (a.size() >= 8 && toI(a[7]) != 0))
+      throw std::invalid_argument("TR: pre-LayerNorm / future-mask variants are outside this build: " + s.line);
+    if (l->nH < 1 || l->C % l->nH) throw std::invalid_argument("TR: heads must divide the model size: " + s.line);
     return l;
   }
   if (s.tok == "LN") {

@@ -67,7 +67,7 @@ struct ParamInfo {
   size_t numel = 0;
   size_t offset = 0;             // into the flat arenas (floats)
   std::vector<int> refShape;     // ArrayFire dims of the Flashlight parameter
-  int kind = 0;                  // 0 plain, 1 conv weight, 2 linear weight (rows may be permuted), 3 scalar pair half
+  int kind = 0;                  // 0 plain, 1 conv weight, 2 linear weight (rows may be permuted), 3 scalar pair, 4 WeightNorm g, 5 2-D table stored transposed
   std::vector<int> rowPerm;      // linear: internal row r holds reference row rowPerm[r]
   double initBound = 0;          // uniform(-b, b); 0 => constant initConst
   float initConst = 0;
