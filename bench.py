@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--stress-frames", type=int, default=1500)
     ap.add_argument("--no-c4", action="store_true", help="skip the conv_glu LibriSpeech ASG step (BASELINE config 4) leg")
     ap.add_argument("--no-c3", action="store_true", help="skip the streaming TDS fp32 / bf16 step (BASELINE config 3) leg")
+    ap.add_argument("--no-c5", action="store_true", help="skip the Transformer-CTC fp32 / bf16 step (BASELINE config 5) leg")
     ap.add_argument("--no-oracle-checks", action="store_true", help="skip the oracle comparison of the stress / config-4 losses")
     ap.add_argument("--cpu-baseline-batch", type=int, default=8)
     ap.add_argument("--dist-selftest", action="store_true",
@@ -244,6 +245,50 @@ def streaming_tds_step(device, L, steps=3):
     out["bf16_speedup"] = round(out["f32"]["ms_per_step"] / out["bf16"]["ms_per_step"], 3)
     out["note"] = ("dtype of this leg: bf16 multiply / fp32 accumulate in the fl::Linear GEMMs (v_mfma_f32_32x32x16_bf16), fp32 everywhere "
                    "else; the bf16 GEMM is bound by staging fp32 operands through LDS, not by the 2.5 PFLOP/s matrix peak")
+    return out
+
+
+def transformer_ctc_step(device, L, steps=3):
+    """BASELINE config 5 on one GPU: sota/2019 Transformer-CTC (am_transformer_ctc.arch: WN-conv + GLU + max-pool front end,
+    24 blocks of width 1024 / 4 heads / +-460 relative positions, 322.6 M parameters), batch 16, T = 1500 -> 188 frames,
+    9998 word pieces: the full training step (dropout 0.2 and layer drop 0.2 live, as the recipe trains) in fp32 and with
+    bf16 multiplies in the fl::Linear GEMMs.  The attention products (QK^T, PV, the relative-position GEMMs and their
+    gradients) stay fp32 on v_mfma_f32_32x32x2_f32: they are ~5 % of a block's flops at 188 frames.
+    Parity: tests/test_gpu_trainer.py::test_transformer_ctc_small_end_to_end, tests/test_gpu_attention.py."""
+    from wav2letter_amd import CriterionScaleMode, recipes
+    from wav2letter_amd.trainer import Trainer
+    B, T, nfeat, nlabel, Lmax = 16, 1500, 80, 9998, 80
+    fl = recipes.TRANSFORMER_CTC_FLAGS
+    x, tgt = make_batch(B, T, nfeat, nlabel, Lmax, 5, device)
+    out = {"config": "sota/2019 Transformer-CTC (am_transformer_ctc.arch): B=16/GPU, T=1500 (188 frames after 3 max-pools), 80 mel, 9998 classes"}
+    for mode in ("f32", "bf16"):
+        tr = Trainer(recipes.transformer_ctc_arch(), nfeat, nlabel, "ctc", CriterionScaleMode.TARGET_SZ_SQRT, device=device)
+        tr.init_params(seed=1)
+        tr.plan(B, T, Lmax)
+        tr.to_device()
+        tr.set_mixed_precision(mode == "bf16")
+        it = [0]
+
+        def step():
+            it[0] += 1
+            tr.set_step(it[0])
+            loss = tr.forward_backward(x, tgt)
+            tr.update(lr=fl["lr"], momentum=fl["momentum"], max_grad_norm=fl["maxgradnorm"], total_batch=B)
+            return loss
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out[mode] = {"ms_per_step": round(dt * 1e3, 1), "utterances_per_sec": round(B / dt, 1),
+                     "finite": bool(torch.isfinite(loss).all().item()), "loss": round(float(loss.mean().item()), 4)}
+        del tr
+        torch.cuda.empty_cache()
+    out["bf16_speedup"] = round(out["f32"]["ms_per_step"] / out["bf16"]["ms_per_step"], 3)
+    out["note"] = ("SGD with momentum stands in for the recipe's --netoptim=adagrad (the optimizer is outside SURVEY 8's rows); layer drop "
+                   "skips a dropped block's GEMMs, so ms_per_step is the mean over the drawn masks of these steps")
     return out
 
 
@@ -549,6 +594,8 @@ def main():
         leg("conv_glu_asg_step", lambda: conv_glu_asg_step(device, L, oracle_checks=not a.no_oracle_checks))
     if world == 1 and not a.no_c3:
         leg("streaming_tds_bf16_step", lambda: streaming_tds_step(device, L))
+    if world == 1 and not a.no_c5:
+        leg("transformer_ctc_step", lambda: transformer_ctc_step(device, L))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -294,13 +294,17 @@ class RefNet:
                 import torch
                 from oracle import transformer_oracle as TO
                 C, mlp, nheads, csz = int(t[1]), int(t[2]), int(t[3]), int(t[4])
-                assert float(t[5]) == 0.0 and (len(t) <= 6 or float(t[6]) == 0.0), "reference interpreter runs dropout-free archs"
+                # training-mode randomness is supplied by the caller: self.tr_opts = [{"attn_mask": ..., "f": ...}, ...] per block
+                opts = getattr(self, "tr_opts", None)
+                opt = opts[sum(1 for r in self.tape if r[0] == "TR")] if opts else {}
+                assert opts or (float(t[5]) == 0.0 and (len(t) <= 6 or float(t[6]) == 0.0)), "dropout needs the caller's masks"
                 n = len(TO.tr_param_shapes(C, mlp, nheads, csz))
                 assert a.shape[0] == 1 and a.shape[3] == C, a.shape     # (C, T, B, 1)
                 xt = torch.tensor(a[0], dtype=torch.float64, requires_grad=True)
                 pt = [torch.tensor(np.asarray(p), dtype=torch.float64, requires_grad=True) for p in params[pi:pi + n]]
                 pi += n
-                yt = TO.tr_block(xt, pt, nheads, csz)
+                am = opt.get("attn_mask")
+                yt = TO.tr_block(xt, pt, nheads, csz, None if am is None else torch.tensor(am, dtype=torch.float64), opt.get("f", 1.0))
                 self.tape.append(("TR", xt, pt, yt, pi))
                 a = yt.detach().numpy().astype(np.float32)[None]
             else:
@@ -373,7 +377,9 @@ class RefNet:
             elif k == "TR":
                 import torch
                 _, xt, pt, yt, pi = rec
-                gs = torch.autograd.grad(yt, [xt] + pt, grad_outputs=torch.tensor(np.asarray(da[0]), dtype=torch.float64))
+                gs = torch.autograd.grad(yt, [xt] + pt, grad_outputs=torch.tensor(np.asarray(da[0]), dtype=torch.float64),
+                                         allow_unused=True)
+                gs = [torch.zeros_like(v) if gq is None else gq for gq, v in zip(gs, [xt] + pt)]
                 da = gs[0].numpy().astype(np.float32)[None]
                 for j, gj in enumerate(gs[1:]):
                     g[pi - len(pt) + j] = gj.numpy().astype(np.float32)

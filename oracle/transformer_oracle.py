@@ -31,8 +31,9 @@ def relative_position_rotate(ps):
     return flat.reshape(lead + (T, d0 + T - 1))                            # moddims(d0 + T - 1, T, .)
 
 
-def attention(q, k, v, E, nheads):
-    """q (already scaled), k, v [B][T][C]; E [2 csz - 1][d] or None -> [B][T][C]"""
+def attention(q, k, v, E, nheads, attn_mask=None):
+    """q (already scaled), k, v [B][T][C]; E [2 csz - 1][d] or None -> [B][T][C]; attn_mask [B][heads][T][T]: the dropout
+    multiplier of the attention probabilities (0 or 1 / (1 - p)), None in evaluation mode"""
     B, T, C = q.shape
     d = C // nheads
     split = lambda z: z.reshape(B, T, nheads, d).permute(0, 2, 1, 3)       # moddims(T, d, heads * B): head h = features h d ..
@@ -43,13 +44,15 @@ def attention(q, k, v, E, nheads):
         rot = relative_position_rotate(qh @ E.t())
         scores = scores + rot[..., n:n + T]
     attn = torch.softmax(scores, dim=-1)
+    if attn_mask is not None:
+        attn = attn * attn_mask
     return (attn @ vh).permute(0, 2, 1, 3).reshape(B, T, C)
 
 
-def tr_block(x, params, nheads, csz):
+def tr_block(x, params, nheads, csz, attn_mask=None, f=1.0):
     """x [B][T][C]; params in the reference's params() order and memory layouts: position table [d][2 csz - 1] (ArrayFire
     (2 csz - 1, d), column-major; absent when csz == 0), then w1, w2, wq, wk, wv, wf as (W [in][out], b [out]) pairs,
-    then the (gamma, beta) pairs of norm1 and norm2"""
+    then the (gamma, beta) pairs of norm1 and norm2.  f: the layer-drop factor of this step (0 = block dropped)"""
     B, T, C = x.shape
     d = C // nheads
     i = 0
@@ -61,9 +64,9 @@ def tr_block(x, params, nheads, csz):
     lin = lambda z, w, b: z @ w + b
     ln = lambda z, gb: F.layer_norm(z, (C,), eps=1e-5) * gb[0] + gb[1]
     q = lin(x, wq, bq) / math.sqrt(d)
-    o = lin(attention(q, lin(x, wk, bk), lin(x, wv, bv), E, nheads), wf, bf)
-    h = ln(o + x, g1)
-    return ln(lin(torch.relu(lin(h, w1, b1)), w2, b2) + h, g2)
+    o = lin(attention(q, lin(x, wk, bk), lin(x, wv, bv), E, nheads, attn_mask), wf, bf)
+    h = ln(f * o + x, g1)
+    return ln(f * lin(torch.relu(lin(h, w1, b1)), w2, b2) + h, g2)
 
 
 def tr_param_shapes(C, mlp, nheads, csz):

@@ -273,6 +273,81 @@ def test_transformer_ctc_small_end_to_end(oracle, T, csz):
     check_grads(tr, want)
 
 
+def test_transformer_block_at_config5_width(oracle):
+    """one TR block at the recipe's own width -- `TR 1024 4096 4 460`: 4 heads of 256, 919-row position table, 188 frames
+    (T = 1500 after the three max-pools), i.e. the GEMM / batched-GEMM / softmax launch shapes of BASELINE config 5 at a
+    2-utterance batch -- emissions, CTC loss and every parameter gradient against the float64 restatement"""
+    rng = np.random.default_rng(12)
+    nfeat, nlabel, B, T, L = 1024, 40, 2, 188, 20
+    arch = "V -1 1 NFEAT 0\nRO 2 0 3 1\nTR 1024 4096 4 460 0.0 0.0\nL 1024 NLABEL\n"
+    tr, ref, params, _ = build(arch, nfeat, nlabel, "ctc", 4, 0.0, rng, B, T, L)
+    x = rng.normal(size=(B, 1, nfeat, T)).astype(np.float32)
+    tgt = rng.integers(0, nlabel - 1, size=(B, L)).astype(np.int32)
+    xd = torch.tensor(x.reshape(B, nfeat, T)).cuda()
+    td = torch.tensor(tgt).cuda()
+    em_ref = ref.forward(x, params)
+    assert rel(tr.forward(xd, train=False).cpu().numpy(), em_ref) < TOL
+    loss = tr.forward_backward(xd, td).cpu().numpy()
+    o = oracle.CTC(em_ref, tgt, scale_mode=4)
+    assert rel(loss, o.forward()) < TOL
+    want = ref.backward(o.backward().astype(np.float32), len(params))
+    g = tr.grads.cpu().numpy()
+    for i, (name, _n, _off) in enumerate(tr.param_table()):
+        if name == "tr.wk.b":   # exactly zero (see test_transformer_ctc_small_end_to_end)
+            assert np.abs(tr.export_from(i, g)).max() < 1e-5 * np.abs(want[i - 2]).max()
+            want[i] = None
+    check_grads(tr, want)
+
+
+def test_transformer_training_mode_attention_dropout_and_layer_drop(oracle):
+    """training mode of a TR block: (a) dropout 0.3 on the attention probabilities -- the mask is the library's stateless
+    integer hash (oracle/nn_oracle.c holds the same function), so the oracle applies the IDENTICAL mask and loss and
+    gradients are held to the usual tolerance; (b) layer drop with probability 1: both sublayers vanish, h = LN1(x),
+    out = LN2(h), their parameters receive exactly zero gradient (TransformerCPC.cpp:170-181)"""
+    nfeat, nlabel, B, T, L, H = 32, 9, 2, 19, 3, 4
+    for p, pld in ((0.3, 0.0), (0.0, 1.0)):
+        rng = np.random.default_rng(5)
+        arch = f"V -1 1 NFEAT 0\nRO 2 0 3 1\nTR 32 48 {H} 6 {p} {pld}\nL 32 NLABEL\n"
+        tr, ref, params, _ = build(arch, nfeat, nlabel, "ctc", 4, 0.0, rng, B, T, L)
+        x = rng.normal(size=(B, 1, nfeat, T)).astype(np.float32)
+        tgt = rng.integers(0, nlabel - 1, size=(B, L)).astype(np.int32)
+        xd = torch.tensor(x.reshape(B, nfeat, T)).cuda()
+        td = torch.tensor(tgt).cuda()
+        step = 7
+        tr.set_step(step)
+        loss = tr.forward_backward(xd, td).cpu().numpy()
+        if p > 0:
+            seed = (0x9E3779B9 * (step + 1)) & 0xFFFFFFFF          # host/trainer.cpp: the step's dropout seed
+            stream = 1 + 4 * 2                                     # layer 2 of the Sequential (V, RO, TR, L)
+            mask = oracle.dropout(np.ones(B * H * T * T, np.float32), p, seed, stream).reshape(B, H, T, T)
+            assert 0.2 < (mask == 0).mean() < 0.4
+            ref.tr_opts = [{"attn_mask": mask}]
+        else:
+            ref.tr_opts = [{"f": 0.0}]
+        em_ref = ref.forward(x, params)
+        o = oracle.CTC(em_ref, tgt, scale_mode=4)
+        assert rel(loss, o.forward()) < TOL, (p, pld)
+        want = ref.backward(o.backward().astype(np.float32), len(params))
+        g = tr.grads.cpu().numpy()
+        table = tr.param_table()
+        for i, (name, _n, _off) in enumerate(table):
+            zero = name == "tr.wk.b" or (pld > 0 and name.startswith("tr.") and "norm" not in name)
+            if zero:
+                assert np.abs(want[i]).max() < 1e-9 and np.abs(tr.export_from(i, g)).max() < (1e-6 if pld == 0 else 1e-30), (i, name)
+                want[i] = None
+            if pld > 0 and name == "tr.norm1.weight+bias":
+                # LN2(gamma1 * xhat + beta1) does not depend on gamma1 / beta1 (up to eps): a near-zero gradient on both
+                # sides, compared on the scale of norm2's
+                n2 = np.abs(want[i + 1]).max()
+                assert np.abs(want[i]).max() < 1e-3 * n2 and np.abs(tr.export_from(i, g) - want[i]).max() < 1e-4 * n2, (i, name)
+                want[i] = None
+        check_grads(tr, want)
+        # evaluation mode ignores both
+        ref.tr_opts = None
+        em_eval = refnet.RefNet(arch.replace(f"{p} {pld}", "0.0 0.0"), nfeat, nlabel).forward(x, params)
+        assert rel(tr.forward(xd, train=False).cpu().numpy(), em_eval) < TOL
+
+
 def test_conv_glu_librispeech_config4_full_network_end_to_end(oracle):
     """BASELINE config 4 -- the full conv_glu LibriSpeech recipe network (17 WN-conv + GLU layers, 208.9 M parameters,
     first layer padded by 170 frames, kernels 13..29), ASG criterion -- at a reduced batch and number of frames, dropout

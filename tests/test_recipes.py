@@ -23,6 +23,7 @@ def test_generators_reproduce_reference_arch_files():
     assert _lines(recipes.streaming_tds_arch()) == _lines(
         open(f"{REF}/streaming_convnets/librispeech/am_500ms_future_context.arch").read())
     assert _lines(recipes.tds_ctc_librivox_arch()) == _lines(open(f"{REF}/sota/2019/am_arch/am_tds_ctc_librivox.arch").read())
+    assert _lines(recipes.transformer_ctc_arch()) == _lines(open(f"{REF}/sota/2019/am_arch/am_transformer_ctc.arch").read())
 
 
 @need_ref
@@ -100,10 +101,34 @@ def test_librivox_arch_with_two_dimensional_subsampling_convolutions_builds():
         Trainer("V -1 NFEAT 1 0\nC2 1 4 5 3 1 2 -1 -1\n", 8, 5, "ctc", device="cpu")
 
 
+def test_transformer_ctc_arch_builds():
+    """am_transformer_ctc.arch (BASELINE config 5): parameter table in the reference's order (position table, w1, w2, wq,
+    wk, wv, wf, norm1, norm2 per block -- TransformerCPC.cpp:79-94), parameter count, and the frames left after the three
+    max-pools"""
+    from wav2letter_amd import recipes
+    from wav2letter_amd.trainer import Trainer
+    t = Trainer(recipes.transformer_ctc_arch(), 80, 9998, "ctc", device="cpu")
+    table = t.param_table()
+    names = [n for n, _, _ in table]
+    i = names.index("tr.posemb")
+    assert names[i:i + 15] == ["tr.posemb", "tr.w1.w", "tr.w1.b", "tr.w2.w", "tr.w2.b", "tr.wq.w", "tr.wq.b", "tr.wk.w", "tr.wk.b",
+                               "tr.wv.w", "tr.wv.b", "tr.wf.w", "tr.wf.b", "tr.norm1.weight+bias", "tr.norm2.weight+bias"]
+    assert table[i][1] == (2 * 460 - 1) * 256 and table[i + 1][1] == 1024 * 4096
+    assert names.count("tr.posemb") == 24
+    n = sum(m for name, m, _ in table) - 24 * 2          # LayerNorm pairs are stored as 2 floats, counted as 2 params each
+    assert abs(n - 322.6e6) < 0.5e6, n
+    assert t.plan(2, 1500, 40) == 188
+    from wav2letter_amd._lib import W2LInvalidArgument
+    with pytest.raises(W2LInvalidArgument):               # a Transformer block wants (C, T, B, 1): the Reorder is missing
+        Trainer("V -1 1 NFEAT 0\nTR 80 320 4 460 0.2\n", 80, 30, "ctc", device="cpu")
+    with pytest.raises(W2LInvalidArgument):               # pre-LayerNorm variant: not a BASELINE recipe
+        Trainer("V -1 1 NFEAT 0\nRO 2 0 3 1\nTR 80 320 4 460 0.2 0.0 1\n", 80, 30, "ctc", device="cpu")
+
+
 def test_unsupported_layers_fail_loudly():
     from wav2letter_amd._lib import W2LInvalidArgument
     from wav2letter_amd.trainer import Trainer
     with pytest.raises(W2LInvalidArgument):
-        Trainer("V -1 1 NFEAT 0\nTR 80 320 4 460 0.2\n", 80, 30, "ctc", device="cpu")
+        Trainer("V -1 1 NFEAT 0\nRO 2 0 3 1\nCFR 80 320 4 460 0.2 0.1 31\n", 80, 30, "ctc", device="cpu")
     with pytest.raises(W2LInvalidArgument):
         Trainer("V -1 NFEAT 1 0\nL 80 NLABEL\n", 80, 30, "seq2seq", device="cpu")

@@ -7,6 +7,7 @@ recipes load unchanged:
   recipes/sota/2019/am_arch/am_tds_ctc.arch                        (BASELINE config 2)
   recipes/conv_glu/librispeech/network.arch, conv_glu/wsj/network.arch   (configs 4, 1)
   recipes/streaming_convnets/librispeech/am_500ms_future_context.arch    (config 3)
+  recipes/sota/2019/am_arch/am_transformer_ctc.arch                      (config 5)
 """
 
 
@@ -34,6 +35,20 @@ def tds_ctc_librivox_arch():
         lines += [f"TDS {c} 21 80 {p} {l2}" for p in drops]
     lines += ["V 0 3840 1 0", "RO 1 0 3 2", "L 3840 NLABEL"]
     return "\n".join(lines) + "\n"
+
+
+def transformer_ctc_arch():
+    """sota/2019 Transformer-CTC (am_transformer_ctc.arch): three WN-Conv(k=3) + GLU + max-pool(2) stages, 24 Transformer
+    blocks of width 1024 (4 heads, 4096-wide MLP, +-460 frames of relative position), Linear; 322.6 M params"""
+    lines = ["V -1 1 NFEAT 0"]
+    for cin, cout in (("NFEAT", 1024), (512, 1024), (512, 2048)):
+        lines += [f"WN 3 C {cin} {cout} 3 1 -1", "GLU 2", "DO 0.2", "M 1 1 2 1"]
+    lines += ["RO 2 0 3 1"] + ["TR 1024 4096 4 460 0.2 0.2"] * 24 + ["DO 0.2", "L 1024 NLABEL"]
+    return "\n".join(lines) + "\n"
+
+
+TRANSFORMER_CTC_FLAGS = dict(criterion="ctc", lr=0.02, momentum=0.95, maxgradnorm=1.0, onorm="target", sqnorm=True,
+                             batchsize=5)   # recipes/sota/2019/librivox/train_am_transformer_ctc.cfg:15-44 (netoptim adagrad there)
 
 
 def conv_glu_librispeech_arch():
