@@ -308,3 +308,40 @@ def test_two_dimensional_conv_oracles_agree(oracle):
         b = np.asarray(b, np.float64)
         assert a.grad.shape == b.shape
         assert np.abs(a.grad.numpy() - b).max() < 2e-4 * max(1e-6, np.abs(b).max())
+
+
+def test_transformer_oracle_relative_position_rotate_and_block():
+    """oracle/transformer_oracle.py: (a) the literal restatement of relativePositionEmbeddingRotate (pad, re-pitch, slice)
+    equals the closed form rel[i][j] = q_i . E[j - i + csz - 1], zero outside the table -- for tables longer and shorter
+    than the utterance; (b) attention rows sum to one through the block's plumbing: with v = 1 and Wf = I the attention
+    sublayer outputs ones; (c) the interpreter's `M` max-pool routes gradients to the first maximum"""
+    import torch
+    from oracle import transformer_oracle as TO
+    torch.manual_seed(0)
+    for T, csz in [(7, 12), (9, 4), (5, 5), (1, 3), (12, 1)]:
+        d, d0 = 8, 2 * csz - 1
+        q = torch.randn(2, 3, T, d, dtype=torch.float64)
+        E = torch.randn(d0, d, dtype=torch.float64)
+        rot = TO.relative_position_rotate(q @ E.t())[..., d0 // 2:d0 // 2 + T]
+        want = torch.zeros(2, 3, T, T, dtype=torch.float64)
+        for i in range(T):
+            for j in range(T):
+                r = j - i + csz - 1
+                if 0 <= r < d0:
+                    want[..., i, j] = q[..., i, :] @ E[r]
+        assert (rot - want).abs().max() < 1e-12, (T, csz)
+    B, T, C, H = 2, 6, 8, 2
+    q = torch.randn(B, T, C, dtype=torch.float64)
+    ctx = TO.attention(q, torch.randn(B, T, C, dtype=torch.float64), torch.ones(B, T, C, dtype=torch.float64),
+                       torch.randn(9, C // H, dtype=torch.float64), H)
+    assert (ctx - 1).abs().max() < 1e-12
+    arch = "V -1 1 NFEAT 0\nM 3 1 2 1\nRO 2 0 3 1\nL 4 NLABEL\n"
+    net = refnet.RefNet(arch, 4, 3)
+    x = np.array([[1, 5, 5, 2, 0, 7, 7]], np.float32).repeat(4, 0).reshape(1, 1, 4, 7)
+    ps = net.random_params(np.random.default_rng(0))
+    em = net.forward(x, ps)
+    assert em.shape == (1, 3, 3)
+    net.backward(np.ones_like(em), len(ps))
+    # windows [0..2], [2..4], [4..6]: first maxima at t = 1, 2, 5
+    k, shp, arg, sx = net.tape[1]
+    assert k == "M" and (arg[0, 0, 0] == [1, 0, 1]).all()
