@@ -267,13 +267,14 @@ def transformer_ctc_step(device, L, steps=3):
         tr.plan(B, T, Lmax)
         tr.to_device()
         tr.set_mixed_precision(mode == "bf16")
+        tr.set_optimizer(fl["netoptim"], fl["critoptim"])
         it = [0]
 
         def step():
             it[0] += 1
             tr.set_step(it[0])
             loss = tr.forward_backward(x, tgt)
-            tr.update(lr=fl["lr"], momentum=fl["momentum"], max_grad_norm=fl["maxgradnorm"], total_batch=B)
+            tr.update(lr=fl["lr"], lrcrit=fl["lrcrit"], momentum=fl["momentum"], max_grad_norm=fl["maxgradnorm"], total_batch=B)
             return loss
         step()
         torch.cuda.synchronize()
@@ -287,8 +288,8 @@ def transformer_ctc_step(device, L, steps=3):
         del tr
         torch.cuda.empty_cache()
     out["bf16_speedup"] = round(out["f32"]["ms_per_step"] / out["bf16"]["ms_per_step"], 3)
-    out["note"] = ("SGD with momentum stands in for the recipe's --netoptim=adagrad (the optimizer is outside SURVEY 8's rows); layer drop "
-                   "skips a dropped block's GEMMs, so ms_per_step is the mean over the drawn masks of these steps")
+    out["note"] = ("optimizer: the recipe's --netoptim=adadelta (librispeech/train_am_transformer_ctc.cfg); layer drop skips a dropped "
+                   "block's GEMMs, so ms_per_step is the mean over the masks these steps drew")
     return out
 
 

@@ -212,6 +212,30 @@ class FL_COMPAT_API SGDOptimizer : public FirstOrderOptimizer {
   std::vector<af::array> velocities_;
 };
 
+// --netoptim=adagrad (recipes/sota/2019/librivox/train_am_transformer_ctc.cfg:25-26): variance += g^2, p -= lr g / (sqrt(variance) + eps)
+class FL_COMPAT_API AdagradOptimizer : public FirstOrderOptimizer {
+ public:
+  AdagradOptimizer(const std::vector<Variable>& params, double lr, double eps = 1e-8, double weightDecay = 0);
+  void step() override;
+  std::string prettyString() const override;
+
+ private:
+  double eps_;
+  std::vector<af::array> variance_;
+};
+
+// --netoptim=adadelta (recipes/sota/2019/librispeech/train_am_transformer_ctc.cfg:23-26)
+class FL_COMPAT_API AdadeltaOptimizer : public FirstOrderOptimizer {
+ public:
+  AdadeltaOptimizer(const std::vector<Variable>& params, double lr = 1.0, double rho = 0.9, double eps = 1e-8, double weightDecay = 0);
+  void step() override;
+  std::string prettyString() const override;
+
+ private:
+  double rho_, eps_;
+  std::vector<af::array> accGrad_, accDelta_;
+};
+
 // global-norm clipping over the gradients that are available; returns the norm before clipping
 FL_COMPAT_API double clipGradNorm(const std::vector<Variable>& params, double maxNorm);
 

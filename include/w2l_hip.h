@@ -273,6 +273,16 @@ int w2l_sgd_step(float* p, const float* g, float* v, size_t n, float lr, float m
 int w2l_grad_guard(double* acc, const float* batchDev, int clampCrit, w2l_stream_t stream);
 int w2l_sgd_step_guarded(float* p, const float* g, float* v, size_t n, float lr, float momentum,
                          float gradScale, float maxGradNorm, const double* guard, w2l_stream_t stream);
+/* fl::AdagradOptimizer::step (--netoptim=adagrad, recipes/sota/2019/librivox/train_am_transformer_ctc.cfg:25-26; un-vendored
+ * Flashlight class): var += g'^2, p -= lr g' / (sqrt(var) + eps) with g' = g * gradScale * clip; guard as w2l_sgd_step_guarded
+ * (NULL: no guard, no clip, gradScale as given) */
+int w2l_adagrad_step_guarded(float* p, const float* g, float* var, size_t n, float lr, float eps, float gradScale,
+                             float maxGradNorm, const double* guard, w2l_stream_t stream);
+/* fl::AdadeltaOptimizer::step (--netoptim=adadelta, recipes/sota/2019/librispeech/train_am_transformer_ctc.cfg:23-26; un-vendored
+ * Flashlight class): accGrad = rho accGrad + (1-rho) g'^2, delta = sqrt(accDelta + eps) / sqrt(accGrad + eps) g', p -= lr delta,
+ * accDelta = rho accDelta + (1-rho) delta^2 */
+int w2l_adadelta_step_guarded(float* p, const float* g, float* accGrad, float* accDelta, size_t n, float lr, float rho,
+                              float eps, float gradScale, float maxGradNorm, const double* guard, w2l_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * 3. Trainer: arch file -> module graph -> one optimisation step.
@@ -311,6 +321,12 @@ int w2l_trainer_forward_backward(void* h, const float* x, const int* target, flo
 int w2l_trainer_update(void* h, float lr, float lrcrit, float momentum, float maxGradNorm,
                        float totalBatch, int clampCrit, void* stream);
 int w2l_trainer_skipped_updates(void* h, uint64_t* count, void* stream);
+/* optimizer of the network / criterion parameters for w2l_trainer_update: 0 = SGD with momentum (default), 1 = Adagrad
+ * (eps 1e-8; the momentum arena holds the accumulated squared gradients), 2 = Adadelta (rho 0.9, eps 1e-8; accGrad in the
+ * momentum arena, accDelta in a second arena of the same size: w2l_trainer_bind_state2).
+ * Train.cpp:577-582 initOptimizer(--netoptim / --critoptim) */
+int w2l_trainer_set_optimizer(void* h, int netKind, int critKind);
+int w2l_trainer_bind_state2(void* h, float* state2);
 int w2l_trainer_viterbi(void* h, const float* emission, int* path, void* stream);
 int w2l_trainer_set_step(void* h, uint32_t step);
 /* --fl_amp_use_mixed_precision restated for bf16 (BASELINE config 3): the network's fl::Linear GEMMs multiply in bf16

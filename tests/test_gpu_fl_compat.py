@@ -128,7 +128,7 @@ def test_training_step_through_fl_surface_equals_trainer(tmp_path, via):
     assert (l1 < l0).any()      # the update did something
 
 
-@pytest.mark.parametrize("recipe", ["tds_ctc", "conv_glu"])
+@pytest.mark.parametrize("recipe", ["tds_ctc", "conv_glu", "transformer_ctc"])
 def test_train_binary_reads_reference_cfg_and_prints_reference_log_keys(tmp_path, recipe):
     """`Train train --flagsfile=<the reference's train.cfg, unchanged> --rundir=... --archdir=... --tokensdir=...`:
     the recipe's own flags + arch files drive the C++ Trainer over the fl:: surface; the log line carries the reference's
@@ -141,6 +141,10 @@ def test_train_binary_reads_reference_cfg_and_prints_reference_log_keys(tmp_path
         cfg, arch_rel, arch = recipes.tds_ctc_train_cfg(), "am_arch/am_tds_ctc.arch", recipes.tds_ctc_arch()
         tokens, ntok = "librispeech-train-all-unigram-10000.tokens", 9997
         extra = ["--w2l_synth_frames=320", "--batchsize=2", "--w2l_synth_target_len=20"]
+    elif recipe == "transformer_ctc":   # BASELINE config 5: 24 TR blocks, --netoptim=adadelta, bare --mfsc / --sqnorm flags
+        cfg, arch_rel, arch = recipes.transformer_ctc_train_cfg(), "am_arch/am_transformer_ctc.arch", recipes.transformer_ctc_arch()
+        tokens, ntok = "librispeech-train-all-unigram-10000.tokens", 9997
+        extra = ["--w2l_synth_frames=320", "--batchsize=2", "--w2l_synth_target_len=12"]
     else:
         cfg, arch_rel, arch = recipes.conv_glu_train_cfg(), "network.arch", recipes.conv_glu_librispeech_arch()
         tokens, ntok = "tokens.txt", 28
@@ -162,11 +166,13 @@ def test_train_binary_reads_reference_cfg_and_prints_reference_log_keys(tmp_path
     vals = dict((kv.split(":")[0].strip(), kv.split(":", 1)[1].strip()) for kv in lines[-1].split(" | "))
     assert int(vals["nupdates"]) == 3 and float(vals["loss"]) > 0 and np.isfinite(float(vals["loss"]))
     assert float(vals["fwd(ms)"]) > 0 and float(vals["bwd(ms)"]) > 0
-    name = "am_tds_ctc_librispeech" if recipe == "tds_ctc" else "librispeech_conv_glu"
+    name = {"tds_ctc": "am_tds_ctc_librispeech", "conv_glu": "librispeech_conv_glu", "transformer_ctc": "am_transformer_ctc_librispeech"}[recipe]
     assert os.path.exists(d / "runs" / name / "001_log") and os.path.exists(d / "runs" / name / "001_config")
-    assert "--criterion=" + ("ctc" if recipe == "tds_ctc" else "asg") in open(d / "runs" / name / "001_config").read()
-    crit = "ConnectionistTemporalClassificationCriterion" if recipe == "tds_ctc" else "AutoSegmentationCriterion"
+    assert "--criterion=" + ("asg" if recipe == "conv_glu" else "ctc") in open(d / "runs" / name / "001_config").read()
+    crit = "AutoSegmentationCriterion" if recipe == "conv_glu" else "ConnectionistTemporalClassificationCriterion"
     assert crit in out.stdout
+    if recipe == "transformer_ctc":
+        assert "[Network Optimizer] Adadelta (rho=0.9)" in out.stdout and "Transformer" in out.stdout
     # a bad flag value fails like the reference (exception text, non-zero exit)
     bad = subprocess.run(cmd + ["--criterion=seq2seq"], capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and "criterion" in bad.stderr

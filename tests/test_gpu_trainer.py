@@ -530,6 +530,88 @@ def test_unclipped_update_is_plain_sgd_and_batch_size_rides_the_arena():
     assert (tr.params - outs[0]).abs().max().item() < 1e-6
 
 
+def test_adagrad_updates_follow_the_recurrence():
+    """--netoptim=adagrad --critoptim=adagrad (the Transformer-CTC recipe): three updates of an ASG network against the fp64
+    recurrence  g' = clip(g / B),  var += g'^2,  p -= lr g' / (sqrt(var) + 1e-8)  on network and transition parameters (each
+    with its own learning rate, one global clip coefficient); a non-finite gradient leaves parameters AND sums untouched"""
+    from wav2letter_amd import recipes
+    from wav2letter_amd.trainer import Trainer
+    rng = np.random.default_rng(21)
+    nfeat, nlabel, B, T, L = 8, 7, 3, 30, 4
+    x = torch.tensor(rng.normal(size=(B, nfeat, T)).astype(np.float32)).cuda()
+    tgt = torch.tensor(rng.integers(0, nlabel, size=(B, L)).astype(np.int32)).cuda()
+    tr = Trainer(recipes.conv_glu_small_arch(), nfeat, nlabel, "asg", 4, 1.0)
+    tr.init_params(5)
+    tr.plan(B, T, L)
+    tr.to_device()
+    tr.set_optimizer("adagrad", "adagrad")
+    n_net = tr.n_net
+    p = tr.params.double().clone()
+    var = torch.zeros_like(p)
+    lr, lrcrit, clip = 0.02, 0.005, 0.05
+    for it in range(3):
+        tr.forward_backward(x, tgt)
+        g = tr.grads.double().clone() / B
+        c = min(1.0, clip / (g.norm().item() + 1e-6))
+        assert it > 0 or c < 1.0                       # the clip is live on the first update
+        g = g * c
+        var += g * g
+        step = g / (var.sqrt() + 1e-8)
+        p[:n_net] -= lr * step[:n_net]
+        p[n_net:] -= lrcrit * step[n_net:]
+        tr.update(lr=lr, lrcrit=lrcrit, momentum=0.0, max_grad_norm=clip, total_batch=B)
+        assert (tr.params.double() - p).abs().max().item() < 2e-6 * max(1.0, p.abs().max().item()), it
+    assert (tr.mom.double() - var).abs().max().item() < 1e-6 * var.abs().max().item()
+    before, vbefore = tr.params.clone(), tr.mom.clone()
+    tr.forward_backward(x, tgt)
+    tr.grads[5] = float("nan")
+    tr.update(lr=lr, lrcrit=lrcrit, momentum=0.0, max_grad_norm=clip, total_batch=B)
+    assert torch.equal(tr.params, before) and torch.equal(tr.mom, vbefore) and tr.skipped_updates() == 1
+
+
+def test_adadelta_updates_follow_the_recurrence():
+    """--netoptim=adadelta --critoptim=adadelta --lr=0.4 (the LibriSpeech Transformer-CTC recipe): four updates against the fp64
+    recurrence of fl::AdadeltaOptimizer (rho 0.9, eps 1e-8) on both parameter groups; without the second state arena the
+    update is refused"""
+    from wav2letter_amd import recipes
+    from wav2letter_amd._lib import W2LInvalidArgument
+    from wav2letter_amd.trainer import Trainer
+    rng = np.random.default_rng(22)
+    nfeat, nlabel, B, T, L = 8, 7, 3, 30, 4
+    x = torch.tensor(rng.normal(size=(B, nfeat, T)).astype(np.float32)).cuda()
+    tgt = torch.tensor(rng.integers(0, nlabel, size=(B, L)).astype(np.int32)).cuda()
+    tr = Trainer(recipes.conv_glu_small_arch(), nfeat, nlabel, "asg", 4, 1.0)
+    tr.init_params(5)
+    tr.plan(B, T, L)
+    tr.to_device()
+    tr.set_optimizer("adadelta", "adadelta")
+    n_net = tr.n_net
+    p = tr.params.double().clone()
+    ag, ad = torch.zeros_like(p), torch.zeros_like(p)
+    lr, lrcrit, clip, rho, eps = 0.4, 0.1, 0.05, 0.9, 1e-8
+    for it in range(4):
+        tr.forward_backward(x, tgt)
+        g = tr.grads.double().clone() / B
+        g = g * min(1.0, clip / (g.norm().item() + 1e-6))
+        ag = rho * ag + (1 - rho) * g * g
+        delta = (ad + eps).sqrt() / (ag + eps).sqrt() * g
+        p[:n_net] -= lr * delta[:n_net]
+        p[n_net:] -= lrcrit * delta[n_net:]
+        ad = rho * ad + (1 - rho) * delta * delta
+        tr.update(lr=lr, lrcrit=lrcrit, momentum=0.0, max_grad_norm=clip, total_batch=B)
+        assert (tr.params.double() - p).abs().max().item() < 5e-6 * max(1.0, p.abs().max().item()), it
+    assert (tr.mom.double() - ag).abs().max().item() < 1e-5 * ag.abs().max().item()
+    assert (tr.state2.double() - ad).abs().max().item() < 1e-4 * ad.abs().max().item()
+    tr2 = Trainer(recipes.conv_glu_small_arch(), nfeat, nlabel, "asg", 4, 1.0)
+    tr2.init_params(5)
+    tr2.plan(B, T, L)
+    tr2.to_device()
+    tr2.L.w2l_trainer_set_optimizer(tr2.h, 2, 2)      # behind the wrapper's back: no second arena bound
+    tr2.forward_backward(x, tgt)
+    with pytest.raises(W2LInvalidArgument):
+        tr2.update(lr=lr, lrcrit=lrcrit, total_batch=B)
+
+
 def test_batch_larger_than_64_and_unbound_calls():
     """B > 64 (round-1 limit of the loss slots) and the ABI's bound-state checks"""
     from wav2letter_amd import _lib, recipes

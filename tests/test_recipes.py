@@ -32,6 +32,7 @@ def test_generators_reproduce_reference_train_cfgs():
     from wav2letter_amd import recipes
     assert _lines(recipes.tds_ctc_train_cfg()) == _lines(open(f"{REF}/sota/2019/librispeech/train_am_tds_ctc.cfg").read())
     assert _lines(recipes.conv_glu_train_cfg()) == _lines(open(f"{REF}/conv_glu/librispeech/train.cfg").read())
+    assert _lines(recipes.transformer_ctc_train_cfg()) == _lines(open(f"{REF}/sota/2019/librispeech/train_am_transformer_ctc.cfg").read())
 
 
 @need_ref

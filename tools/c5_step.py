@@ -24,13 +24,14 @@ tr.init_params(seed=1)
 Tout = tr.plan(B, T, Lmax)
 tr.to_device()
 tr.set_mixed_precision(mode == "bf16")
+tr.set_optimizer(fl["netoptim"], fl["critoptim"])
 it = [0]
 
 def step():
     it[0] += 1
     tr.set_step(it[0])
     loss = tr.forward_backward(x, tgt)
-    tr.update(lr=fl["lr"], momentum=fl["momentum"], max_grad_norm=fl["maxgradnorm"], total_batch=B)
+    tr.update(lr=fl["lr"], lrcrit=fl["lrcrit"], momentum=fl["momentum"], max_grad_norm=fl["maxgradnorm"], total_batch=B)
     return loss
 
 step()

@@ -137,6 +137,8 @@ class _SIGS:
     w2l_profile_report_kind = (_i, [_i, _p, _p, _p])
     w2l_sgd_step = (_i, [_p, _p, _p, _sz, _f, _f, _f, _f, _p, _p])
     w2l_sgd_step_guarded = (_i, [_p, _p, _p, _sz, _f, _f, _f, _f, _p, _p])
+    w2l_adagrad_step_guarded = (_i, [_p, _p, _p, _sz, _f, _f, _f, _f, _p, _p])
+    w2l_adadelta_step_guarded = (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _p, _p])
     w2l_grad_guard = (_i, [_p, _p, _i, _p])
 
 

@@ -499,6 +499,80 @@ __global__ __launch_bounds__(kEwThreads) void sgd_k(float* __restrict__ p, const
   }
 }
 
+// fl::AdagradOptimizer::step (--netoptim=adagrad of recipes/sota/2019/librivox/train_am_transformer_ctc.cfg:25-26; the class is
+// un-vendored Flashlight: variance += g'^2 ; p -= lr * g' / (sqrt(variance) + eps), eps = 1e-8), with the same gradient scale,
+// global-norm clip and non-finite guard as sgd_k
+__global__ __launch_bounds__(kEwThreads) void adagrad_k(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ var, size_t n, float lr, float eps,
+                                                       float gradScale, float maxNorm, const double* __restrict__ sumsq,
+                                                       int guarded) {
+  float coef = gradScale;
+  if (sumsq) {
+    if (!isfinite(sumsq[0])) return;
+    if (guarded && sumsq[1] > 0.0) coef = gradScale = (float)sumsq[1];
+    if (maxNorm > 0.f) {
+      float norm = (float)sqrt(sumsq[0]) * gradScale;
+      float c = maxNorm / (norm + 1e-6f);
+      if (c < 1.f) coef *= c;
+    }
+  }
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 pv = *(const float4*)(p + 4 * i), gv = *(const float4*)(g + 4 * i), vv = *(const float4*)(var + 4 * i);
+    gv.x *= coef; gv.y *= coef; gv.z *= coef; gv.w *= coef;
+    vv.x += gv.x * gv.x; vv.y += gv.y * gv.y; vv.z += gv.z * gv.z; vv.w += gv.w * gv.w;
+    *(float4*)(var + 4 * i) = vv;
+    pv.x -= lr * gv.x / (sqrtf(vv.x) + eps); pv.y -= lr * gv.y / (sqrtf(vv.y) + eps);
+    pv.z -= lr * gv.z / (sqrtf(vv.z) + eps); pv.w -= lr * gv.w / (sqrtf(vv.w) + eps);
+    *(float4*)(p + 4 * i) = pv;
+  }
+  for (size_t e = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    float gg = g[e] * coef;
+    float vv = var[e] + gg * gg;
+    var[e] = vv;
+    p[e] -= lr * gg / (sqrtf(vv) + eps);
+  }
+}
+
+// fl::AdadeltaOptimizer::step (--netoptim=adadelta --lr=0.4 of recipes/sota/2019/librispeech/train_am_transformer_ctc.cfg:23-26;
+// un-vendored Flashlight class, rho = 0.9, eps = 1e-8 by the Trainer's --optimrho / --optimepsilon defaults):
+//   accGrad = rho accGrad + (1 - rho) g'^2 ; delta = sqrt(accDelta + eps) / sqrt(accGrad + eps) g' ; p -= lr delta ;
+//   accDelta = rho accDelta + (1 - rho) delta^2
+__global__ __launch_bounds__(kEwThreads) void adadelta_k(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ accG, float* __restrict__ accD, size_t n, float lr,
+                                                        float rho, float eps, float gradScale, float maxNorm,
+                                                        const double* __restrict__ sumsq, int guarded) {
+  float coef = gradScale;
+  if (sumsq) {
+    if (!isfinite(sumsq[0])) return;
+    if (guarded && sumsq[1] > 0.0) coef = gradScale = (float)sumsq[1];
+    if (maxNorm > 0.f) {
+      float norm = (float)sqrt(sumsq[0]) * gradScale;
+      float c = maxNorm / (norm + 1e-6f);
+      if (c < 1.f) coef *= c;
+    }
+  }
+  const float om = 1.f - rho;
+  auto one = [&](float& pv, float gv, float& ag, float& ad) {
+    gv *= coef;
+    ag = rho * ag + om * gv * gv;
+    const float d = sqrtf(ad + eps) / sqrtf(ag + eps) * gv;
+    pv -= lr * d;
+    ad = rho * ad + om * d * d;
+  };
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 pv = *(const float4*)(p + 4 * i), gv = *(const float4*)(g + 4 * i);
+    float4 ag = *(const float4*)(accG + 4 * i), ad = *(const float4*)(accD + 4 * i);
+    one(pv.x, gv.x, ag.x, ad.x); one(pv.y, gv.y, ag.y, ad.y); one(pv.z, gv.z, ag.z, ad.z); one(pv.w, gv.w, ag.w, ad.w);
+    *(float4*)(accG + 4 * i) = ag;
+    *(float4*)(accD + 4 * i) = ad;
+    *(float4*)(p + 4 * i) = pv;
+  }
+  for (size_t e = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
+    one(p[e], g[e], accG[e], accD[e]);
+}
+
 }  // namespace w2l
 
 using namespace w2l;
@@ -749,6 +823,26 @@ W2L_API int w2l_sgd_step_guarded(float* p, const float* g, float* v, size_t n, f
   if (!n) return W2L_OK;
   hipLaunchKernelGGL(sgd_k, dim3(ew_grid((n >> 2) + 1)), dim3(kEwThreads), 0, W2L_S, p, g, v, n, lr, momentum,
                      gradScale, maxGradNorm, guard, 1);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+W2L_API int w2l_adagrad_step_guarded(float* p, const float* g, float* var, size_t n, float lr, float eps, float gradScale,
+                                     float maxGradNorm, const double* guard, w2l_stream_t stream) {
+  if (!p || !g || !var || (maxGradNorm > 0.f && !guard)) return W2L_EINVAL;
+  if (!n) return W2L_OK;
+  hipLaunchKernelGGL(adagrad_k, dim3(ew_grid((n >> 2) + 1)), dim3(kEwThreads), 0, W2L_S, p, g, var, n, lr, eps, gradScale,
+                     maxGradNorm, guard, guard ? 1 : 0);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+W2L_API int w2l_adadelta_step_guarded(float* p, const float* g, float* accGrad, float* accDelta, size_t n, float lr, float rho,
+                                      float eps, float gradScale, float maxGradNorm, const double* guard, w2l_stream_t stream) {
+  if (!p || !g || !accGrad || !accDelta || (maxGradNorm > 0.f && !guard)) return W2L_EINVAL;
+  if (!n) return W2L_OK;
+  hipLaunchKernelGGL(adadelta_k, dim3(ew_grid((n >> 2) + 1)), dim3(kEwThreads), 0, W2L_S, p, g, accGrad, accDelta, n, lr, rho, eps,
+                     gradScale, maxGradNorm, guard, guard ? 1 : 0);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }

@@ -210,6 +210,48 @@ std::string SGDOptimizer::prettyString() const {
   return ss.str();
 }
 
+AdagradOptimizer::AdagradOptimizer(const std::vector<Variable>& params, double lr, double eps, double weightDecay)
+    : FirstOrderOptimizer(params, lr), eps_(eps) {
+  if (weightDecay != 0) throw std::invalid_argument("fl_compat AdagradOptimizer: weight decay is not on the hot path of the recipes");
+  for (auto& p : parameters_) variance_.push_back(af::constant(0.0, p.dims(), af::f32));
+}
+void AdagradOptimizer::step() {
+  for (size_t i = 0; i < parameters_.size(); ++i) {
+    auto& p = parameters_[i];
+    if (!p.isGradAvailable()) continue;
+    w2l::w2lCheck(w2l_adagrad_step_guarded(p.array().device<float>(), p.grad().array().device<float>(), variance_[i].device<float>(),
+                                           (size_t)p.elements(), (float)lr_, (float)eps_, 1.f, 0.f, nullptr, S()), "adagrad");
+  }
+}
+std::string AdagradOptimizer::prettyString() const {
+  std::ostringstream ss;
+  ss << "Adagrad (epsilon=" << eps_ << ")";
+  return ss.str();
+}
+
+AdadeltaOptimizer::AdadeltaOptimizer(const std::vector<Variable>& params, double lr, double rho, double eps, double weightDecay)
+    : FirstOrderOptimizer(params, lr), rho_(rho), eps_(eps) {
+  if (weightDecay != 0) throw std::invalid_argument("fl_compat AdadeltaOptimizer: weight decay is not on the hot path of the recipes");
+  for (auto& p : parameters_) {
+    accGrad_.push_back(af::constant(0.0, p.dims(), af::f32));
+    accDelta_.push_back(af::constant(0.0, p.dims(), af::f32));
+  }
+}
+void AdadeltaOptimizer::step() {
+  for (size_t i = 0; i < parameters_.size(); ++i) {
+    auto& p = parameters_[i];
+    if (!p.isGradAvailable()) continue;
+    w2l::w2lCheck(w2l_adadelta_step_guarded(p.array().device<float>(), p.grad().array().device<float>(), accGrad_[i].device<float>(),
+                                            accDelta_[i].device<float>(), (size_t)p.elements(), (float)lr_, (float)rho_, (float)eps_, 1.f,
+                                            0.f, nullptr, S()), "adadelta");
+  }
+}
+std::string AdadeltaOptimizer::prettyString() const {
+  std::ostringstream ss;
+  ss << "Adadelta (rho=" << rho_ << ") (epsilon=" << eps_ << ")";
+  return ss.str();
+}
+
 double clipGradNorm(const std::vector<Variable>& params, double maxNorm) {
   static std::shared_ptr<void> acc = devAlloc(sizeof(double));
   double* d = (double*)acc.get();

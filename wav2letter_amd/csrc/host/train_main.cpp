@@ -5,7 +5,7 @@
 // It reads the recipes' own train.cfg / *.arch files UNCHANGED (gflags `--flagsfile`, later flags win), builds
 //   network   = fl::pkg::runtime::ModulePlugin(FLAGS_arch).arch(numFeatures, numClasses)   (Train.cpp:390-395)
 //   criterion = CTCLoss(scalemode) | ASGLoss(numClasses, scalemode, FLAGS_transdiag)         (:406-410)
-//   netoptim / critoptim = SGD(lr, momentum) / SGD(lrcrit)                                  (:577-582)
+//   netoptim / critoptim = initOptimizer(--netoptim / --critoptim: sgd | adagrad | adadelta)                                (:577-582)
 // and runs the hot loop of Train.cpp:1454-1804 (forward, criterion, zeroGrad, backward, grads / batch, clipGradNorm,
 // critopt->step, netopt->step) with the reference's meters, printing the log line of MyLogger.cpp:40-106
 // (`epoch | nupdates | lr | lrcriterion | runtime | bch(ms) | smp(ms) | fwd(ms) | crit-fwd(ms) | bwd(ms) | optim(ms) |
@@ -169,8 +169,17 @@ int main(int argc, char** argv) {
     std::cout << "[Network] " << network->prettyString() << std::endl;
     std::cout << "[Network Params: " << nparams << "]" << std::endl;
     std::cout << "[Criterion] " << criterion->prettyString() << std::endl;
-    auto netoptim = std::make_shared<SGDOptimizer>(network->params(), lr0, momentum, 0.0);
-    auto critoptim = std::make_shared<SGDOptimizer>(criterion->params(), lrcrit0, 0.0, 0.0);
+    // initOptimizer(nets, --netoptim, lr, momentum, weightdecay) (Train.cpp:577-582): sgd, adadelta (librispeech/train_am_transformer_ctc.cfg:23-24)
+    // and adagrad (librivox/train_am_transformer_ctc.cfg:25-26) are the ones the BASELINE recipes name
+    const double optimrho = flags.getd("optimrho", 0.9), optimepsilon = flags.getd("optimepsilon", 1e-8);
+    auto initOptimizer = [&](const std::vector<fl::Variable>& params, const std::string& kind, double lr, double mom) -> std::shared_ptr<fl::FirstOrderOptimizer> {
+      if (kind == "sgd") return std::make_shared<SGDOptimizer>(params, lr, mom, 0.0);
+      if (kind == "adagrad") return std::make_shared<fl::AdagradOptimizer>(params, lr);
+      if (kind == "adadelta") return std::make_shared<fl::AdadeltaOptimizer>(params, lr, optimrho, optimepsilon);
+      throw std::invalid_argument("unsupported optimizer '" + kind + "' (this build: sgd, adagrad, adadelta)");
+    };
+    auto netoptim = initOptimizer(network->params(), flags.get("netoptim", "sgd"), lr0, momentum);
+    auto critoptim = initOptimizer(criterion->params(), flags.get("critoptim", "sgd"), lrcrit0, 0.0);
     std::cout << "[Network Optimizer] " << netoptim->prettyString() << std::endl;
     std::cout << "[Criterion Optimizer] " << critoptim->prettyString() << std::endl;
 

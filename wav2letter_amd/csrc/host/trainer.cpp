@@ -40,6 +40,8 @@ struct Trainer {
   SequenceCriterion* activeCrit() { return (linseg && step < linsegUpdates) ? linseg.get() : crit.get(); }
   std::string lastError;
   bool guardZeroed = false;
+  int netOptim = 0, critOptim = 0;  // 0 SGD(momentum), 1 Adagrad (variance in the momentum arena), 2 Adadelta (+ state2)
+  float* state2 = nullptr;          // Adadelta's accDelta, same size and layout as the momentum arena
   bool mixedPrecision = false;   // fl's --fl_amp_use_mixed_precision, restated for bf16: the network's fl::Linear GEMMs multiply
                                  // in bf16 (fp32 accumulate, fp32 storage, fp32 master weights); convolutions, LayerNorm, the
                                  // criterion and the optimizer stay fp32
@@ -234,10 +236,21 @@ W2L_API int w2l_trainer_update(void* h, float lr, float lrcrit, float momentum, 
     w2lCheck(w2l_sumsq(t->grads, t->netFloats, t->sumsq, 1, s), "sumsq");
     w2lCheck(w2l_sumsq(t->grads + t->netFloats, t->critFloats, t->sumsq + 1, 1, s), "sumsq");
     w2lCheck(w2l_grad_guard(t->sumsq, totalBatch > 0.f ? nullptr : t->batchSlot, clampCrit, s), "guard");
-    if (t->critFloats)
-      w2lCheck(w2l_sgd_step_guarded(t->params + t->netFloats, t->grads + t->netFloats, nullptr, t->critFloats, lrcrit, 0.f, gs,
-                                    clampCrit ? maxGradNorm : 0.f, t->sumsq + 2, s), "crit sgd");
-    w2lCheck(w2l_sgd_step_guarded(t->params, t->grads, t->mom, t->netFloats, lr, momentum, gs, maxGradNorm, t->sumsq + 2, s), "net sgd");
+    const bool needState = t->netOptim != 0 || (t->critOptim != 0 && t->critFloats);
+    const bool needState2 = t->netOptim == 2 || (t->critOptim == 2 && t->critFloats);
+    if (needState && !t->mom) throw std::invalid_argument("Adagrad / Adadelta need the momentum arena bound (it holds the gradient statistics)");
+    if (needState2 && !t->state2) throw std::invalid_argument("Adadelta needs w2l_trainer_bind_state2");
+    auto stepOne = [&](int kind, size_t off, size_t n, float rate, float mom, float clip, const char* what) {
+      float* v = t->mom ? t->mom + off : nullptr;
+      if (kind == 1)
+        w2lCheck(w2l_adagrad_step_guarded(t->params + off, t->grads + off, v, n, rate, 1e-8f, gs, clip, t->sumsq + 2, s), what);
+      else if (kind == 2)
+        w2lCheck(w2l_adadelta_step_guarded(t->params + off, t->grads + off, v, t->state2 + off, n, rate, 0.9f, 1e-8f, gs, clip, t->sumsq + 2, s), what);
+      else
+        w2lCheck(w2l_sgd_step_guarded(t->params + off, t->grads + off, mom != 0.f ? v : nullptr, n, rate, mom, gs, clip, t->sumsq + 2, s), what);
+    };
+    if (t->critFloats) stepOne(t->critOptim, t->netFloats, t->critFloats, lrcrit, 0.f, clampCrit ? maxGradNorm : 0.f, "criterion optimizer");
+    stepOne(t->netOptim, 0, t->netFloats, lr, momentum, maxGradNorm, "network optimizer");
     t->step++;
   });
 }
@@ -322,6 +335,16 @@ W2L_API int w2l_trainer_skipped_updates(void* h, uint64_t* count, void* stream) 
   });
 }
 
+W2L_API int w2l_trainer_set_optimizer(void* h, int netKind, int critKind) {
+  if (!h || netKind < 0 || netKind > 2 || critKind < 0 || critKind > 2) return W2L_EINVAL;
+  ((Trainer*)h)->netOptim = netKind; ((Trainer*)h)->critOptim = critKind;
+  return W2L_OK;
+}
+W2L_API int w2l_trainer_bind_state2(void* h, float* state2) {
+  if (!h) return W2L_EINVAL;
+  ((Trainer*)h)->state2 = state2;
+  return W2L_OK;
+}
 W2L_API int w2l_trainer_set_mixed_precision(void* h, int on) { ((Trainer*)h)->mixedPrecision = on != 0; return W2L_OK; }
 
 W2L_API int w2l_trainer_set_step(void* h, uint32_t step) { ((Trainer*)h)->step = step; return W2L_OK; }

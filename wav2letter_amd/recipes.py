@@ -47,8 +47,26 @@ def transformer_ctc_arch():
     return "\n".join(lines) + "\n"
 
 
-TRANSFORMER_CTC_FLAGS = dict(criterion="ctc", lr=0.02, momentum=0.95, maxgradnorm=1.0, onorm="target", sqnorm=True,
-                             batchsize=5)   # recipes/sota/2019/librivox/train_am_transformer_ctc.cfg:15-44 (netoptim adagrad there)
+# recipes/sota/2019/librispeech/train_am_transformer_ctc.cfg:11-41
+TRANSFORMER_CTC_FLAGS = dict(criterion="ctc", netoptim="adadelta", critoptim="adadelta", lr=0.4, lrcrit=0.4, momentum=0.0,
+                             maxgradnorm=1.0, onorm="target", sqnorm=True, batchsize=8)
+
+
+def transformer_ctc_train_cfg():
+    """recipes/sota/2019/librispeech/train_am_transformer_ctc.cfg, regenerated (checked line for line by tests/test_recipes.py)"""
+    fl = [("runname", "am_transformer_ctc_librispeech"), ("rundir", "[...]"), ("archdir", "[...]"), ("arch", "am_arch/am_transformer_ctc.arch"),
+          ("tokensdir", "[MODEL_DST]/am"), ("tokens", "librispeech-train-all-unigram-10000.tokens"),
+          ("lexicon", "[MODEL_DST]/am/librispeech-train+dev-unigram-10000-nbest10.lexicon"),
+          ("train", "[DATA_DST]/lists/train-clean-100.lst,[DATA_DST]/lists/train-clean-360.lst,[DATA_DST]/lists/train-other-500.lst"),
+          ("valid", "dev-clean:[DATA_DST]/lists/dev-clean.lst,dev-other:[DATA_DST]/lists/dev-other.lst"),
+          ("criterion", "ctc"), ("mfsc", None), ("usewordpiece", "true"), ("wordseparator", "_"), ("labelsmooth", "0.05"),
+          ("dataorder", "output_spiral"), ("inputbinsize", "25"), ("softwstd", "4"), ("memstepsize", "5000000"), ("pcttraineval", "1"),
+          ("pctteacherforcing", "99"), ("sampletarget", "0.01"), ("netoptim", "adadelta"), ("critoptim", "adadelta"), ("lr", "0.4"),
+          ("lrcrit", "0.4"), ("linseg", "0"), ("momentum", "0.0"), ("maxgradnorm", "1.0"), ("onorm", "target"), ("sqnorm", None),
+          ("nthread", "6"), ("batchsize", "8"), ("filterbanks", "80"), ("minisz", "200"), ("mintsz", "2"), ("enable_distributed", None),
+          ("warmup", "32000"), ("saug_start_update", "32000"), ("lr_decay", "180"), ("lr_decay_step", "40")]
+    return ("# Replace `[...]`, `[MODEL_DST]`, `[DATA_DST]`, with appropriate paths\n" +
+            "".join(f"--{k}\n" if v is None else f"--{k}={v}\n" for k, v in fl))
 
 
 def conv_glu_librispeech_arch():

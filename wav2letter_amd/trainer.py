@@ -41,6 +41,8 @@ def _lib_tr():
         L.w2l_trainer_viterbi.argtypes = [vp, vp, vp, vp]
         L.w2l_trainer_set_step.argtypes = [vp, u32]
         L.w2l_trainer_set_mixed_precision.argtypes = [vp, i]
+        L.w2l_trainer_set_optimizer.argtypes = [vp, i, i]
+        L.w2l_trainer_bind_state2.argtypes = [vp, vp]
         L.w2l_trainer_set_linseg.argtypes = [vp, u32]
         L.w2l_trainer_grad_norm.argtypes = [vp, C.POINTER(C.c_double), vp]
         L.w2l_trainer_skipped_updates.argtypes = [vp, C.POINTER(u64), vp]
@@ -137,8 +139,14 @@ class Trainer:
         if getattr(self, "_pending_mom", None) is not None:   # checkpoint.load() before to_device()
             self.mom.copy_(torch.from_numpy(self._pending_mom))
             self._pending_mom = None
+        self._bind_state2()
         if self.B:
             self._bind()
+
+    def _bind_state2(self):
+        if self.params is not None and "adadelta" in getattr(self, "_optim", ()) and getattr(self, "state2", None) is None:
+            self.state2 = torch.zeros_like(self.params)            # Adadelta's accDelta (accGrad lives in self.mom)
+            _check(self.L.w2l_trainer_bind_state2(self.h, self.state2.data_ptr()), "bind_state2")
 
     def plan(self, B, T, L):
         af, cw, to = C.c_size_t(0), C.c_size_t(0), C.c_int(0)
@@ -213,6 +221,15 @@ class Trainer:
     def set_mixed_precision(self, on=True):
         """bf16 multiplies (fp32 accumulate / storage / master weights) in the network's fl::Linear GEMMs"""
         _check(self.L.w2l_trainer_set_mixed_precision(self.h, int(bool(on))), "mixed precision")
+
+    def set_optimizer(self, netoptim="sgd", critoptim="sgd"):
+        """--netoptim / --critoptim of the reference Trainer (Train.cpp:577-582): "sgd" (momentum) "adagrad" or "adadelta" (rho 0.9, eps 1e-8:
+        the recipe of BASELINE config 5).  Adagrad keeps its squared-gradient sums in the momentum arena; Adadelta its accGrad
+        there and accDelta in a second arena (self.state2)"""
+        kinds = {"sgd": 0, "adagrad": 1, "adadelta": 2}
+        _check(self.L.w2l_trainer_set_optimizer(self.h, kinds[netoptim], kinds[critoptim]), "set_optimizer")
+        self._optim = (netoptim, critoptim)
+        self._bind_state2()
 
     def set_step(self, step):
         self.L.w2l_trainer_set_step(self.h, step)
