@@ -405,3 +405,37 @@ def test_linseg_shares_asg_transitions():
     assert asg.transitions.grad is not None and torch.isfinite(asg.transitions.grad).all()
     with pytest.raises(Exception):
         lin.setParams(asg.transitions, 1)
+
+
+def test_fcc_large_n_folded_step_variant_is_bit_identical():
+    """W2L_FCC_FOLD=1 (probe library): the forward step epilogue folded into the transition stream -- last arriver of each
+    row group, device-scope stores / loads for the cross-XCD hand-over -- gives the product's two-launch result bit for bit
+    (and run to run); the product ignores the switch.  Measured slower, kept for the record"""
+    import os
+    from wav2letter_amd import _lib
+    from wav2letter_amd.criterion import CriterionScaleMode, FullConnectionCriterion
+    B, T, N = 5, 40, 1500
+    g = torch.Generator(device="cpu").manual_seed(9)
+    x = torch.randn(B, T, N, generator=g).cuda()
+    tgt = torch.zeros(B, 4, dtype=torch.int32).cuda()
+    A = (torch.randn(N, N, generator=g) * 0.3).cuda()
+
+    def run():
+        crit = FullConnectionCriterion(N, CriterionScaleMode.TARGET_SZ_SQRT).cuda()
+        crit.transitions.data = A
+        xx = x.clone().requires_grad_(True)
+        loss = crit(xx, tgt)
+        loss.sum().backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), xx.grad.clone(), crit.transitions.grad.clone()
+    want = run()
+    os.environ["W2L_FCC_FOLD"] = "1"
+    try:
+        assert all(torch.equal(a, b) for a, b in zip(run(), want))      # the product never reads the environment
+        with _lib.use_probe():
+            got = run()
+            again = run()
+    finally:
+        os.environ.pop("W2L_FCC_FOLD")
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    assert all(torch.equal(a, b) for a, b in zip(got, again))

@@ -62,6 +62,9 @@ struct BigDims {
   int ring; // 1: three operand register sets in a ring, 0: two in ping-pong (W2L_FCC_RING, A/B runs)
   int asmv; // 1: hand-counted asm-load kernel (W2L_FCC_ASM)
   int dma;  // W2L_FCC_DMA: 0 = register ping-pong kernel; 1..5 = LDS-DMA ring (chunks per stage x depth, nontemporal): 1 = 2x3, 2 = 1x6, 3 = 2x3 nt, 4 = 1x6 nt
+  int fold; // W2L_FCC_FOLD=1 (probe library): the forward step's log / add-x / rescale epilogue runs inside the streaming kernel
+            // (last arriver of each row group) instead of the separate fcc_big_step launch.  Bit-identical, MEASURED SLOWER:
+            // 85.3 us per step against 82.4 (profiles/r02_run21_fcc_fold_negative.log), so the product keeps two launches
   int abl;  // W2L_FCC_ABL: timing-only ablations 1 = no MFMA, 2 = no E-operand traffic; 4 = nontemporal loads of the
             // transition stream (results stay correct)
 };
@@ -103,6 +106,7 @@ inline BigDims big_dims(int B, int T, int N) {
   // LDS-DMA ring with a nontemporal transition stream is the default (0 = register ping-pong): measured on MI355X
   // (profiles/r01_run16_fcc_dma_ring_variants.log) 2x3 85.5 us, 1x6 85.8, 2x3 nt 77.6, 1x6 nt 76.0, ping-pong 94.0
   { const char* e = tune_env("W2L_FCC_DMA"); d.dma = e ? atoi(e) : 4; }
+  { const char* e = tune_env("W2L_FCC_FOLD"); d.fold = e ? atoi(e) : 0; }
   d.Np = (N + 32 * d.RT - 1) / (32 * d.RT) * (32 * d.RT);
   d.G = d.Np / (32 * d.RT);
   // The step is cut into U = G * nS stage-units (64 rows x 32 k) in row-group-major order and dealt
@@ -150,6 +154,7 @@ struct BigWs {
   double* cacc;   // [B] running sum of the per-step maxima
   float* scale;   // [B]
   float* gb;      // [B] scale * upstream grad
+  unsigned* cnt;  // [G] arrival tickets of the folded step (self-resetting; zeroed once per call)
   size_t bytes;
 };
 
@@ -170,6 +175,7 @@ __host__ __device__ inline BigWs big_ws(void* ws, const BigDims& d) {
   w.cacc = (double*)take((size_t)d.B * sizeof(double));
   w.scale = (float*)take((size_t)d.B * sizeof(float));
   w.gb = (float*)take((size_t)d.B * sizeof(float));
+  w.cnt = (unsigned*)take((size_t)d.G * sizeof(unsigned));
   w.bytes = (size_t)(p - (char*)ws);
   return w;
 }
@@ -533,11 +539,42 @@ __global__ __launch_bounds__(256, 2) void fcc_big_gemm_asm(const float4* __restr
 // stage (an L2 hit) so that the count stays uniform.
 constexpr int kDmaWaveFloats = 3 * 2 * 256 * 3;  // ring of one wave: U x D = 6 chunks of (a0, a1, e) pieces = 18 KiB
 
+// The forward step's second kernel folded into the stream (FOLD): the LAST worker to deliver a row group's partial slab
+// (one arrival ticket per row group) adds the slabs in worker order, takes the log, adds x_t and the row maximum, and
+// stores a_t plain and packed, 1 / s_t and -- by an atomic max into one of the kBigParts cells of each utterance -- the
+// running maximum the next step rescales by.  Nobody waits: a worker that is not last moves on to its next segment.
+// Slabs cross XCDs inside one kernel, so the hand-over is a device-scope release (L2 write-back) by the deliverer
+// and a device-scope acquire (L1 / L2 invalidate) by the last arriver; everything the fold writes is consumed by the
+// NEXT launch.  Removes the fcc_big_step launch at every one of the T steps -- and is slower than it: with device-scope
+// fences the hand-over costs 58 us per step (whole-L2 write-back / invalidate under the stream); with per-access device-scope
+// stores and loads (below) it is a chain of three memory round trips (write-through acknowledge, ticket, coherent loads)
+// at the tail of every launch, 3 us longer than the kernel boundary + fcc_big_step it replaces.  Probe switch only.
+__device__ __forceinline__ size_t packed_op_index(int b, int i0, int NC);
+
+struct BigFold {
+  const float* x;     // x_t row base: x + t * N, utterance stride T * N
+  const float* rm;
+  float* a;           // ws.e + t * B * N
+  float* invs;        // ws.invs + t * B * N
+  float* apk;         // ws.ep[t & 1]
+  float* pmax;        // ws.pmax + t * B * kBigParts, pre-filled with -inf
+  unsigned* cnt;
+  size_t xStride;     // T * N
+};
+
+// max into a float cell holding -inf or a previous maximum: order-preserving integer views of IEEE floats
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
+  if (v >= 0.f) atomicMax((int*)addr, __float_as_int(v));
+  else atomicMin((unsigned*)addr, __float_as_uint(v));
+}
+
 // U = chunks per stage, D = ring depth (U * D == 6), NT = nontemporal loads of the transition stream
-template <bool EXPOP, int kDmaU, int kDmaD, bool NT>
+template <bool EXPOP, int kDmaU, int kDmaD, bool NT, bool FOLD = false>
 __global__ __launch_bounds__(256, 2) void fcc_big_gemm_dma(const float4* __restrict__ pack, const float4* __restrict__ op,
-                                                           const float* __restrict__ pmax, float* __restrict__ part, BigDims d) {
+                                                           const float* __restrict__ pmax, float* __restrict__ part, BigDims d,
+                                                           BigFold f) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][3 stages][6 pieces][256 floats]; reused as `red`
+  __shared__ int foldLast[2];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int NC = d.NC, Np = d.Np, Bp = d.Bp, B = d.B;
@@ -572,6 +609,7 @@ __global__ __launch_bounds__(256, 2) void fcc_big_gemm_dma(const float4* __restr
     // this wave's range in DMA stages
     const int s0 = (sb + (int)((long long)len * wave / 4)) * ratio, s1 = (sb + (int)((long long)len * (wave + 1) / 4)) * ratio;
     const int piece = w - big_worker_of(d, g * d.nS);
+    const int npFold = FOLD ? big_pieces(d, g) : 0;   // off the critical path of the hand-over
     f32x16 acc[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -636,7 +674,84 @@ __global__ __launch_bounds__(256, 2) void fcc_big_gemm_dma(const float4* __restr
       const int r = rr & 15, h = rr >> 4;
       const int b = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
       const int i = 64 * g + 32 * h + (l & 31);
-      dst[(size_t)b * Np + i] = v;
+      // FOLD: device-scope write-through (sc1) instead of a plain store: the slab crosses XCDs inside this kernel
+      if (FOLD) __hip_atomic_store(&dst[(size_t)b * Np + i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else dst[(size_t)b * Np + i] = v;
+    }
+    if (FOLD) {
+      // no fence: a device-scope release / acquire pair writes back and invalidates the whole L2 under the transition
+      // stream (measured: 140 us per step against 82 unfolded).  The slab went out with device-scope stores; they are
+      // acknowledged (vmcnt) before the barrier, the ticket is taken after it, and the last arriver reads the slabs
+      // with device-scope loads, which are served at the coherence point and not by a stale line of its own L2.
+      // x_t and the row maxima of this thread's eight labels do not depend on the slabs: in flight across the hand-over
+      float xv[2][4], rv[2][4];
+      {
+        const int b = threadIdx.x >> 3, qq = threadIdx.x & 7;
+        const float* xr = f.x + (size_t)(b < B ? b : 0) * f.xStride;
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int i = 64 * g + 4 * (qq + 8 * it) + u;
+            const int ic = i < d.N ? i : d.N - 1;
+            xv[it][u] = xr[ic];
+            rv[it][u] = f.rm[ic];
+          }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const int np = npFold;
+        const unsigned tk = __hip_atomic_fetch_add(&f.cnt[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = tk == (unsigned)np - 1u;
+        if (last) __hip_atomic_store(&f.cnt[g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the next launch counts from zero
+        foldLast[0] = last;
+        foldLast[1] = np;
+      }
+      __syncthreads();
+      if (foldLast[0]) {
+        const int np = foldLast[1], N = d.N;
+        const int b = threadIdx.x >> 3, qq = threadIdx.x & 7;
+        float m = -INFINITY;
+        if (b < B) {
+          float* ar = f.a + (size_t)b * N;
+          float* ir = f.invs + (size_t)b * N;
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int i0 = 64 * g + 4 * (qq + 8 * it);
+            if (i0 < N) {
+              float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+              for (int sl = 0; sl < np; ++sl) {   // worker order: the same sum as fcc_big_step
+                const float* pp = part + ((size_t)sl * Bp + b) * Np + i0;
+                s4.x += __hip_atomic_load(pp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s4.y += __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s4.z += __hip_atomic_load(pp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s4.w += __hip_atomic_load(pp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+              const float ssum[4] = {s4.x, s4.y, s4.z, s4.w};
+              float a4[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u;
+                float v = -INFINITY;
+                if (i < N) {
+                  const float sc = fmaxf(ssum[u], 1e-37f);
+                  v = xv[it][u] + (rv[it][u] + __logf(sc));
+                  ir[i] = 1.f / sc;
+                  ar[i] = v;
+                }
+                a4[u] = v;
+                m = fmaxf(m, v);
+              }
+              *(float4*)(f.apk + packed_op_index(b, i0, NC)) = make_float4(a4[0], a4[1], a4[2], a4[3]);
+            }
+          }
+        }
+        m = fmaxf(m, __shfl_xor(m, 1));
+        m = fmaxf(m, __shfl_xor(m, 2));
+        m = fmaxf(m, __shfl_xor(m, 4));
+        if (qq == 0 && b < B && m > -INFINITY) atomic_max_f32(f.pmax + (size_t)b * kBigParts + (g & (kBigParts - 1)), m);
+      }
     }
     u0 += len;
     __syncthreads();  // `red` (= the rings) is reused by the next segment
@@ -863,8 +978,14 @@ static int launch_big_gemm(const BigDims& d, const float* pack, const float* op,
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }
-template <bool EXPOP>
-static int big_gemm(const BigDims& d, const float* pack, const float* op, const float* pmax, float* part, hipStream_t s) {
+// the streaming kernel that can carry the folded forward step (big_gemm's first branch)
+static inline bool big_fold_ok(const BigDims& d) {
+  return d.fold && d.NB == 1 && d.RT == 2 && d.dma && !d.abl && (size_t)d.Np * d.Kp * 4 < 0x7fffffffull;
+}
+
+template <bool EXPOP, bool FOLD = false>
+static int big_gemm(const BigDims& d, const float* pack, const float* op, const float* pmax, float* part, hipStream_t s,
+                    const BigFold& fold = BigFold{}) {
   if (d.NB == 1 && d.RT == 2 && d.dma && !d.abl && (size_t)d.Np * d.Kp * 4 < 0x7fffffffull) {
     const size_t shmem = (size_t)4 * kDmaWaveFloats * sizeof(float);  // 72 KiB (>= the 32 KiB reduction buffer)
     prof_begin(s, 4.0 * d.N * (double)d.N + 8.0 * d.B * (double)d.N, PROF_FCC_STREAM);
@@ -872,12 +993,12 @@ static int big_gemm(const BigDims& d, const float* pack, const float* op, const 
   do {                                                                                                                         \
     static bool attr = false;                                                                                                  \
     if (!attr) {                                                                                                               \
-      W2L_HIP_CHECK(hipFuncSetAttribute((const void*)fcc_big_gemm_dma<EXPOP, U, D, NTF>,                                       \
+      W2L_HIP_CHECK(hipFuncSetAttribute((const void*)fcc_big_gemm_dma<EXPOP, U, D, NTF, FOLD>,                                 \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                              \
       attr = true;                                                                                                             \
     }                                                                                                                          \
-    hipLaunchKernelGGL((fcc_big_gemm_dma<EXPOP, U, D, NTF>), dim3((unsigned)d.W), dim3(256), shmem, s, (const float4*)pack,    \
-                       (const float4*)op, pmax, part, d);                                                                      \
+    hipLaunchKernelGGL((fcc_big_gemm_dma<EXPOP, U, D, NTF, FOLD>), dim3((unsigned)d.W), dim3(256), shmem, s,                   \
+                       (const float4*)pack, (const float4*)op, pmax, part, d, fold);                                           \
   } while (0)
     switch (d.dma) {
       case 2: W2L_DMA_LAUNCH(1, 6, false); break;
@@ -954,8 +1075,24 @@ int fcc_big_forward(int B, int T, int N, int scaleMode, const float* input, cons
   hipLaunchKernelGGL(big_fill_k, dim3(512), dim3(256), 0, s, ws.ep[0], opFloats, -INFINITY);
   W2L_LAUNCH_CHECK();
   const dim3 sgrid(kBigParts, (unsigned)B);
+  const bool fold = big_fold_ok(d) && T > 1;
+  if (fold) {
+    // partial maxima of steps 1 .. T-1 arrive by atomic max; arrival tickets start at zero (and reset themselves)
+    hipLaunchKernelGGL(big_fill_k, dim3(512), dim3(256), 0, s, ws.pmax, (size_t)T * B * kBigParts, -INFINITY);
+    W2L_LAUNCH_CHECK();
+    W2L_HIP_CHECK(hipMemsetAsync(ws.cnt, 0, (size_t)d.G * sizeof(unsigned), s));
+  }
   for (int t = 0; t < T; ++t) {
     if (t > 0) {
+      if (fold) {
+        BigFold f;
+        f.x = input + (size_t)t * N; f.xStride = (size_t)T * N; f.rm = ws.rm;
+        f.a = ws.e + (size_t)t * B * N; f.invs = ws.invs + (size_t)t * B * N; f.apk = ws.ep[t & 1];
+        f.pmax = ws.pmax + (size_t)t * B * kBigParts; f.cnt = ws.cnt;
+        st = big_gemm<true, true>(d, ws.pack, ws.ep[(t - 1) & 1], ws.pmax + (size_t)(t - 1) * B * kBigParts, ws.part, s, f);
+        if (st) return st;
+        continue;
+      }
       st = big_gemm<true>(d, ws.pack, ws.ep[(t - 1) & 1], ws.pmax + (size_t)(t - 1) * B * kBigParts, ws.part, s);
       if (st) return st;
     }
