@@ -224,9 +224,13 @@ typedef struct {
 int w2l_bgemm_f32(const w2l_bgemm_desc* d, const float* A, const float* B, float* C, w2l_stream_t stream);
 /* S[b][h][i][j] (in: q_i . k_j) -> P = softmax_j(scale * (S + R[(b*T + i)*H + h][j - i + n0 - rlo])) in place; R (may be
  * NULL: no position term) holds q_i . E[rlo + w] for w < W, row stride ldr; entries outside [0, W) count as 0
- * (relativePositionEmbeddingRotate pads with zeros). */
-int w2l_attn_softmax_forward(float* S, const float* R, int B, int H, int T, int ldr, int rlo, int W, int n0, float scale,
-                             w2l_stream_t stream);
+ * (relativePositionEmbeddingRotate pads with zeros).  keyLen (may be NULL): keys j >= keyLen[b] are padding and get
+ * probability 0 (the log(padMask) term of TransformerCPC.cpp:138-144). */
+int w2l_attn_softmax_forward(float* S, const float* R, const int* keyLen, int B, int H, int T, int ldr, int rlo, int W, int n0,
+                             float scale, w2l_stream_t stream);
+/* valid keys per utterance from the batch's input sizes (any unit), as forwardSequentialModuleWithPadMask builds the mask
+ * (cpc/SequentialBuilder.cpp:58-81): n_b = ceil(size_b * Tin / max size) valid input frames, resized to Tk (nearest) */
+int w2l_attn_key_lengths(const float* inputSizes, int B, int Tin, int Tk, int* keyLen, w2l_stream_t stream);
 /* dS (in: dL/dP) -> dL/dS (pre-scale scores) in place; dR (may be NULL) receives the skewed copy, zeros elsewhere */
 int w2l_attn_softmax_backward(const float* P, float* dS, float* dR, int B, int H, int T, int ldr, int rlo, int W, int n0,
                               float scale, w2l_stream_t stream);
@@ -326,6 +330,9 @@ int w2l_trainer_skipped_updates(void* h, uint64_t* count, void* stream);
  * momentum arena, accDelta in a second arena of the same size: w2l_trainer_bind_state2).
  * Train.cpp:577-582 initOptimizer(--netoptim / --critoptim) */
 int w2l_trainer_set_optimizer(void* h, int netKind, int critKind);
+/* input sizes of the NEXT forward calls (device, [B] floats in any unit; NULL = every utterance fills the batch): the
+ * Transformer blocks mask the padded keys as the reference's forwardSequentialModuleWithPadMask does.  Call after plan. */
+int w2l_trainer_set_input_sizes(void* h, const float* inputSizesDev);
 int w2l_trainer_bind_state2(void* h, float* state2);
 int w2l_trainer_viterbi(void* h, const float* emission, int* path, void* stream);
 int w2l_trainer_set_step(void* h, uint32_t step);

@@ -178,6 +178,7 @@ class RefNet:
         a = x
         pi = 0
         self.tape = []
+        self.input_frames = x.shape[3]
         for f in self.lines:
             t = f
             wn_dim = None
@@ -304,7 +305,10 @@ class RefNet:
                 pt = [torch.tensor(np.asarray(p), dtype=torch.float64, requires_grad=True) for p in params[pi:pi + n]]
                 pi += n
                 am = opt.get("attn_mask")
-                yt = TO.tr_block(xt, pt, nheads, csz, None if am is None else torch.tensor(am, dtype=torch.float64), opt.get("f", 1.0))
+                kl = None
+                if getattr(self, "input_sizes", None) is not None:   # set by the caller: per-utterance input sizes of the batch
+                    kl = TO.key_lengths(self.input_sizes, self.input_frames, xt.shape[1])
+                yt = TO.tr_block(xt, pt, nheads, csz, None if am is None else torch.tensor(am, dtype=torch.float64), opt.get("f", 1.0), kl)
                 self.tape.append(("TR", xt, pt, yt, pi))
                 a = yt.detach().numpy().astype(np.float32)[None]
             else:

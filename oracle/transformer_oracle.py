@@ -31,7 +31,25 @@ def relative_position_rotate(ps):
     return flat.reshape(lead + (T, d0 + T - 1))                            # moddims(d0 + T - 1, T, .)
 
 
-def attention(q, k, v, E, nheads, attn_mask=None):
+def key_lengths(input_sizes, t_in, t_k):
+    """valid keys per utterance as the reference builds its padding mask: forwardSequentialModuleWithPadMask
+    (recipes/joint_training_vox_populi/cpc/SequentialBuilder.cpp:58-81): n_b = ceil(size_b * T / max size), mask[t][b] = t < n_b
+    on the T frames of the padded input; TransformerCPC.cpp:138-144 resizes it to the block's frames with af::resize
+    ([UNVENDORED] ArrayFire; nearest neighbour: source index round(j * T / T_k), clamped to T - 1) and adds log(mask) to the
+    scores.  float32 arithmetic as ArrayFire's."""
+    import numpy as np
+    sz = np.asarray(input_sizes, np.float32)
+    nb = np.ceil(sz * np.float32(t_in) / sz.max())
+    xf = np.float32(t_in) / np.float32(t_k)
+    xs = (np.arange(t_k, dtype=np.float32) * xf).astype(np.float32)
+    lo = np.floor(xs)
+    src = np.minimum(lo + ((xs - lo) >= 0.5), t_in - 1)          # C round(): halves away from zero
+    mask = src[None, :] < nb[:, None]
+    assert all((m[:-1] >= m[1:]).all() for m in mask)                                # monotone: a prefix is valid
+    return mask.sum(axis=1).astype(np.int32)
+
+
+def attention(q, k, v, E, nheads, attn_mask=None, key_len=None):
     """q (already scaled), k, v [B][T][C]; E [2 csz - 1][d] or None -> [B][T][C]; attn_mask [B][heads][T][T]: the dropout
     multiplier of the attention probabilities (0 or 1 / (1 - p)), None in evaluation mode"""
     B, T, C = q.shape
@@ -43,13 +61,16 @@ def attention(q, k, v, E, nheads, attn_mask=None):
         n = E.shape[0] // 2
         rot = relative_position_rotate(qh @ E.t())
         scores = scores + rot[..., n:n + T]
+    if key_len is not None:    # log(padMask): -inf on the padded keys of each utterance
+        pad = torch.arange(T)[None, :] >= torch.as_tensor(key_len)[:, None]
+        scores = scores.masked_fill(pad[:, None, None, :], float("-inf"))
     attn = torch.softmax(scores, dim=-1)
     if attn_mask is not None:
         attn = attn * attn_mask
     return (attn @ vh).permute(0, 2, 1, 3).reshape(B, T, C)
 
 
-def tr_block(x, params, nheads, csz, attn_mask=None, f=1.0):
+def tr_block(x, params, nheads, csz, attn_mask=None, f=1.0, key_len=None):
     """x [B][T][C]; params in the reference's params() order and memory layouts: position table [d][2 csz - 1] (ArrayFire
     (2 csz - 1, d), column-major; absent when csz == 0), then w1, w2, wq, wk, wv, wf as (W [in][out], b [out]) pairs,
     then the (gamma, beta) pairs of norm1 and norm2.  f: the layer-drop factor of this step (0 = block dropped)"""
@@ -64,7 +85,7 @@ def tr_block(x, params, nheads, csz, attn_mask=None, f=1.0):
     lin = lambda z, w, b: z @ w + b
     ln = lambda z, gb: F.layer_norm(z, (C,), eps=1e-5) * gb[0] + gb[1]
     q = lin(x, wq, bq) / math.sqrt(d)
-    o = lin(attention(q, lin(x, wk, bk), lin(x, wv, bv), E, nheads, attn_mask), wf, bf)
+    o = lin(attention(q, lin(x, wk, bk), lin(x, wv, bv), E, nheads, attn_mask, key_len), wf, bf)
     h = ln(f * o + x, g1)
     return ln(f * lin(torch.relu(lin(h, w1, b1)), w2, b2) + h, g2)
 

@@ -82,7 +82,7 @@ def test_relative_position_products_and_softmax(B, H, T, d, csz):
     D = _lib.BgemmDesc(M=B * T * H, N=W, K=d, G1=1, G2=1, sam=d, sak=1, sbk=1, sbn=d, ldc=ldr)
     assert L.w2l_bgemm_f32(C.byref(D), qd.data_ptr(), Ed[rlo:].data_ptr(), R.data_ptr(), _stream()) == 0
     Pd = Sd.clone()
-    assert L.w2l_attn_softmax_forward(Pd.data_ptr(), R.data_ptr(), B, H, T, ldr, rlo, W, n0, scale, _stream()) == 0
+    assert L.w2l_attn_softmax_forward(Pd.data_ptr(), R.data_ptr(), None, B, H, T, ldr, rlo, W, n0, scale, _stream()) == 0
     # oracle
     S64 = S.double().requires_grad_(True)
     q64 = q.double().requires_grad_(True)
@@ -111,7 +111,7 @@ def test_relative_position_products_and_softmax(B, H, T, d, csz):
     assert rel(dE.cpu().numpy(), E64.grad.numpy()) < TOL
     # no position term: plain softmax
     P0 = Sd.clone()
-    assert L.w2l_attn_softmax_forward(P0.data_ptr(), None, B, H, T, 0, 0, 0, 0, scale, _stream()) == 0
+    assert L.w2l_attn_softmax_forward(P0.data_ptr(), None, None, B, H, T, 0, 0, 0, 0, scale, _stream()) == 0
     assert rel(P0.cpu().numpy(), torch.softmax(S.double() * scale, -1).numpy()) < TOL
 
 
@@ -133,3 +133,27 @@ def test_time_max_pool(B, T, F, w, stride):
     assert L.w2l_pool_time_backward(xd.data_ptr(), dyd.data_ptr(), dx.data_ptr(), B, T, F, w, stride, _stream()) == 0
     assert torch.equal(y.cpu().double(), yr.detach().permute(0, 2, 1))
     assert rel(dx.cpu().numpy(), xr.grad.permute(0, 2, 1).numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("Tin,Tk", [(1500, 188), (44, 22), (37, 5), (64, 64), (10, 3)])
+def test_padding_mask_key_lengths_and_masked_softmax(Tin, Tk):
+    """valid keys per utterance from the batch's input sizes (forwardSequentialModuleWithPadMask + af::resize, restated in
+    oracle/transformer_oracle.key_lengths) bit-exact, and the softmax with the padded keys at probability 0"""
+    from oracle import transformer_oracle as TO
+    from wav2letter_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(Tin + Tk)
+    B, H = 7, 2
+    sizes = np.concatenate([[16000.0 * 9.3], rng.uniform(0.05, 1.0, size=B - 1) * 16000.0 * 9.3]).astype(np.float32)
+    kl = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    assert L.w2l_attn_key_lengths(torch.tensor(sizes).cuda().data_ptr(), B, Tin, Tk, kl.data_ptr(), _stream()) == 0
+    want = TO.key_lengths(sizes, Tin, Tk)
+    assert (kl.cpu().numpy() == want).all(), (kl.cpu().numpy(), want)
+    assert want[0] == Tk and want.min() >= 1
+    S = torch.randn(B, H, Tk, Tk, generator=torch.Generator().manual_seed(1))
+    P = S.cuda().clone()
+    assert L.w2l_attn_softmax_forward(P.data_ptr(), None, kl.data_ptr(), B, H, Tk, 0, 0, 0, 0, 0.5, _stream()) == 0
+    pad = torch.arange(Tk)[None, :] >= torch.tensor(want)[:, None]
+    ref = torch.softmax((S.double() * 0.5).masked_fill(pad[:, None, None, :], float("-inf")), -1)
+    assert rel(P.cpu().numpy(), ref.numpy()) < TOL
+    assert (P.cpu()[pad[:, None, None, :].expand_as(P)] == 0).all()

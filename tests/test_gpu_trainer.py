@@ -299,6 +299,40 @@ def test_transformer_block_at_config5_width(oracle):
     check_grads(tr, want)
 
 
+def test_transformer_padding_mask_from_input_sizes(oracle):
+    """a ragged batch: the trainer is given the utterances' input sizes and every Transformer block masks the padded keys
+    (forwardSequentialModuleWithPadMask, cpc/SequentialBuilder.cpp:58-81; TransformerCPC.cpp:138-144) -- emissions, CTC loss
+    and every parameter gradient against the oracle with the same mask; without sizes the mask is off again"""
+    rng = np.random.default_rng(3)
+    nfeat, nlabel, B, T, L = 16, 12, 4, 37, 3
+    arch = ("V -1 1 NFEAT 0\nWN 3 C NFEAT 64 3 1 -1\nGLU 2\nDO 0.0\nM 1 1 2 1\nRO 2 0 3 1\n"
+            "TR 32 64 4 9 0.0 0.0\nTR 32 64 4 9 0.0 0.0\nL 32 NLABEL\n")
+    tr, ref, params, _ = build(arch, nfeat, nlabel, "ctc", 4, 0.0, rng, B, T, L)
+    x = rng.normal(size=(B, 1, nfeat, T)).astype(np.float32)
+    tgt = rng.integers(0, nlabel - 1, size=(B, L)).astype(np.int32)
+    xd = torch.tensor(x.reshape(B, nfeat, T)).cuda()
+    td = torch.tensor(tgt).cuda()
+    sizes = np.array([5920.0, 3100.0, 5000.0, 1700.0], np.float32)       # samples; the longest fills the batch
+    em_full = ref.forward(x, params)
+    tr.set_input_sizes(torch.tensor(sizes).cuda())
+    ref.input_sizes = sizes
+    em_ref = ref.forward(x, params)
+    assert rel(em_ref, em_full) > 1e-2                                     # the mask matters on this batch
+    assert rel(tr.forward(xd, train=False).cpu().numpy(), em_ref) < TOL
+    loss = tr.forward_backward(xd, td).cpu().numpy()
+    o = oracle.CTC(em_ref, tgt, scale_mode=4)
+    assert rel(loss, o.forward()) < TOL
+    want = ref.backward(o.backward().astype(np.float32), len(params))
+    g = tr.grads.cpu().numpy()
+    for i, (name, _n, _off) in enumerate(tr.param_table()):
+        if name == "tr.wk.b":
+            assert np.abs(tr.export_from(i, g)).max() < 1e-5 * np.abs(want[i - 2]).max()
+            want[i] = None
+    check_grads(tr, want)
+    tr.set_input_sizes(None)
+    assert rel(tr.forward(xd, train=False).cpu().numpy(), em_full) < TOL
+
+
 def test_transformer_training_mode_attention_dropout_and_layer_drop(oracle):
     """training mode of a TR block: (a) dropout 0.3 on the attention probabilities -- the mask is the library's stateless
     integer hash (oracle/nn_oracle.c holds the same function), so the oracle applies the IDENTICAL mask and loss and

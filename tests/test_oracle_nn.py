@@ -345,3 +345,21 @@ def test_transformer_oracle_relative_position_rotate_and_block():
     # windows [0..2], [2..4], [4..6]: first maxima at t = 1, 2, 5
     k, shp, arg, sx = net.tape[1]
     assert k == "M" and (arg[0, 0, 0] == [1, 0, 1]).all()
+
+
+def test_transformer_oracle_padding_mask_key_lengths():
+    """oracle/transformer_oracle.key_lengths: the longest utterance keeps every key, sizes scale linearly, an equal-length
+    resize is the identity, and masked attention rows still sum to one over the valid keys only"""
+    import torch
+    from oracle import transformer_oracle as TO
+    assert list(TO.key_lengths([10.0, 5.0, 2.5], 40, 40)) == [40, 20, 10]
+    assert list(TO.key_lengths([3.0, 3.0], 1500, 188)) == [188, 188]
+    kl = TO.key_lengths([16000.0, 8000.0, 100.0], 1500, 188)
+    assert kl[0] == 188 and abs(kl[1] - 94) <= 1 and 1 <= kl[2] <= 2
+    B, T, C, H = 3, 9, 8, 2
+    g = torch.Generator().manual_seed(0)
+    q, k = (torch.randn(B, T, C, generator=g, dtype=torch.float64) for _ in range(2))
+    v = torch.zeros(B, T, C, dtype=torch.float64)
+    v[:, :, 0] = torch.arange(T, dtype=torch.float64)            # ctx[..., 0] = expected key index
+    ctx = TO.attention(q, k, v, None, H, key_len=[9, 4, 1])
+    assert ctx[1, :, 0].max() <= 3.0 + 1e-12 and (ctx[2, :, 0].abs() < 1e-12).all() and ctx[0, :, 0].max() > 3.0

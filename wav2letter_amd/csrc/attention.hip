@@ -130,6 +130,7 @@ struct SmP {
   const float* P;
   float* dR;
   const float* R;
+  const int* keyLen;   // [B] keys j >= keyLen[b] are padding (log(0) added to their scores); NULL: none
   int B, H, T, ldr, rlo, W, n0;
   float scale;
 };
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(256) void attn_softmax_fwd_k(SmP p) {
   const int i = row % p.T, bh = row / p.T, h = bh % p.H, b = bh / p.H;
   float* s = p.S + (size_t)row * p.T;
   const float* r = p.R ? p.R + ((size_t)(b * p.T + i) * p.H + h) * p.ldr : nullptr;
+  const int kl = p.keyLen ? min(p.keyLen[b], p.T) : p.T;
   float mx = -INFINITY;
   for (int j = lane; j < p.T; j += 64) {
     float v = s[j];
@@ -147,19 +149,19 @@ __global__ __launch_bounds__(256) void attn_softmax_fwd_k(SmP p) {
       const int w = j - i + p.n0 - p.rlo;
       if (w >= 0 && w < p.W) v += r[w];
     }
-    v *= p.scale;
+    v = j < kl ? v * p.scale : -INFINITY;
     s[j] = v;
     mx = fmaxf(mx, v);
   }
   mx = wave_max(mx);
   float sum = 0.f;
   for (int j = lane; j < p.T; j += 64) {
-    float e = expf(s[j] - mx);
+    float e = j < kl ? expf(s[j] - mx) : 0.f;
     s[j] = e;
     sum += e;
   }
   sum = wave_sum(sum);
-  const float inv = 1.f / sum;
+  const float inv = sum > 0.f ? 1.f / sum : 0.f;   // an utterance with no valid key: zeros (the reference's softmax gives NaN)
   for (int j = lane; j < p.T; j += 64) s[j] *= inv;
 }
 
@@ -183,6 +185,26 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_k(SmP p) {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // those loads have landed before d changes
   }
   for (int j = lane; j < p.T; j += 64) d[j] = p.scale * pr[j] * (d[j] - dot);
+}
+
+// ---- padding mask of the keys (forwardSequentialModuleWithPadMask, recipes/joint_training_vox_populi/cpc/SequentialBuilder.cpp:58-81,
+// and TransformerCPC.cpp:138-144): valid input frames  n_b = ceil(inputSizes[b] * Tin / max(inputSizes)),  mask[t][b] = t < n_b on
+// the Tin input frames, resized to the block's Tk frames (af::resize, nearest: source index round(j * Tin / Tk), clamped) and added
+// to the scores as log(mask).  The mask is monotone, so it is kept as the count of valid keys per utterance.
+__global__ void attn_key_len_k(const float* __restrict__ sizes, int B, int Tin, int Tk, int* __restrict__ keyLen) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float mx = sizes[0];
+  for (int q = 1; q < B; ++q) mx = fmaxf(mx, sizes[q]);
+  const float nb = ceilf(sizes[b] * (float)Tin / mx);
+  const float xf = (float)Tin / (float)Tk;
+  int n = 0;
+  for (int j = 0; j < Tk; ++j) {
+    int src = (int)roundf((float)j * xf);
+    if (src >= Tin) src = Tin - 1;
+    if ((float)src < nb) n = j + 1; else break;
+  }
+  keyLen[b] = n;
 }
 
 // ---- fl::Pool2D(wx, 1, sx, 1, MAX) over time on frame-major rows ------------------------------------------------------
@@ -263,11 +285,18 @@ static int sm_params(SmP& p, int B, int H, int T, int ldr, int rlo, int W, int n
   return W2L_OK;
 }
 
-W2L_API int w2l_attn_softmax_forward(float* S, const float* R, int B, int H, int T, int ldr, int rlo, int W, int n0,
-                                     float scale, w2l_stream_t stream) {
+W2L_API int w2l_attn_key_lengths(const float* inputSizes, int B, int Tin, int Tk, int* keyLen, w2l_stream_t stream) {
+  if (!inputSizes || !keyLen || B <= 0 || Tin <= 0 || Tk <= 0) return W2L_EINVAL;
+  hipLaunchKernelGGL(attn_key_len_k, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, W2L_S, inputSizes, B, Tin, Tk, keyLen);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+W2L_API int w2l_attn_softmax_forward(float* S, const float* R, const int* keyLen, int B, int H, int T, int ldr, int rlo, int W,
+                                     int n0, float scale, w2l_stream_t stream) {
   SmP p{};
   if (!S || sm_params(p, B, H, T, ldr, rlo, W, n0, scale) != W2L_OK) return W2L_EINVAL;
-  p.S = S; p.R = R;
+  p.S = S; p.R = R; p.keyLen = keyLen;
   hipLaunchKernelGGL(attn_softmax_fwd_k, dim3((unsigned)((B * H * T + 3) / 4)), dim3(256), 0, W2L_S, p);
   W2L_LAUNCH_CHECK();
   return W2L_OK;

@@ -479,6 +479,11 @@ class PlannedNet : public fl::Sequential {
     w2l::Ctx c;
     c.stream = S(); c.train = train_; c.seed = 0x9E3779B9u * (++step_);
     c.params = (float*)paramArena_.get(); c.grads = (float*)gradArena_.get();
+    if (inputs.size() >= 2 && !inputs[1].isempty()) {  // inputSizes (1, B): padding mask of the Transformer blocks
+      if (inputs[1].type() != af::f32 || inputs[1].elements() != B) throw std::invalid_argument("network forward: inputSizes must be f32 (1, B)");
+      c.inputSizes = inputs[1].array().device<float>();
+      c.inputT = T;
+    }
     const int prevMode = mixed_ ? w2l_set_matmul_precision(1) : 0;
     const float* em = net_->forward(c, (float*)arena_.get(), in.array().device<float>());
     if (mixed_) w2l_set_matmul_precision(prevMode);

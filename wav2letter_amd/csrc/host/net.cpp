@@ -654,7 +654,7 @@ class PoolTimeLayer : public Layer {
 // (SequentialBuilder.cpp:136-158).  Block as the in-repo copy states it, recipes/joint_training_vox_populi/cpc/
 // TransformerCPC.cpp: parameters and their order :41-95 (position table, w1, w2, wq, wk, wv, wf, norm1, norm2), post-LN data
 // flow :153-182, mlp :97-101 (no dropout inside), selfAttention :117-151 (q scaled by 1/sqrt(d), dropout on the attention
-// probabilities only, no padding mask on this path: the network is called with an empty mask).
+// probabilities only; padding mask of the keys when the caller supplies the batch's input sizes, Ctx::inputSizes).
 //   h   = LN1(f * Wf attention(x) + x)          f = 0 with probability pLayerdrop while training, else 1
 //   out = LN2(f * W2 relu(W1 h) + h)
 // Input (C, T, B, 1) == frame-major [B*T][C]; heads are contiguous slices of a frame (moddims(T, d, heads*B)).
@@ -666,7 +666,7 @@ class TransformerLayer : public Layer {
   P pe, w1, b1, w2, b2, wq, bq, wk, bk, wv, bv, wf, bf, gb1, gb2;
   int B = 0, T = 0, M = 0, W = 0, rlo = 0, ldr = 0, n0 = 0;
   size_t qOff, kOff, vOff, sOff, pdOff, rOff, ctxOff, oOff, hOff, uOff, m2Off, outOff, st1Off, mr1Off, st2Off, mr2Off;
-  size_t ds2Off, duOff, dhOff, dr1Off, dctxOff, dsOff, dRoff, dqOff, dkOff, dvOff, dxOff, dEpOff;
+  size_t ds2Off, duOff, dhOff, dr1Off, dctxOff, dsOff, dRoff, dqOff, dkOff, dvOff, dxOff, dEpOff, klOff;
   const float* xSaved = nullptr;
   bool dropped = false;
 
@@ -716,6 +716,7 @@ class TransformerLayer : public Layer {
     ds2Off = pl.alloc(n); duOff = pl.alloc((size_t)M * mlp); dhOff = pl.alloc(n); dr1Off = pl.alloc(n); dctxOff = pl.alloc(n);
     dsOff = pl.alloc(ns); dRoff = pl.alloc(nr); dqOff = pl.alloc(n); dkOff = pl.alloc(n); dvOff = pl.alloc(n); dxOff = pl.alloc(n);
     dEpOff = pl.alloc((size_t)B * W * d);
+    klOff = pl.alloc((size_t)B);
     return in;
   }
   // per-(utterance, head) product over frame-major operands; see w2l_bgemm_desc
@@ -757,7 +758,13 @@ class TransformerLayer : public Layer {
       g.M = M * nH; g.N = W; g.K = d; g.G1 = g.G2 = 1; g.sam = d; g.sak = 1; g.sbk = 1; g.sbn = d; g.ldc = ldr;
       w2lCheck(w2l_bgemm_f32(&g, q, pe.w(cx) + (size_t)rlo * d, R, s), "tr qE");
     }
-    w2lCheck(w2l_attn_softmax_forward(S, csz > 0 ? R : nullptr, B, nH, T, ldr, rlo, W, n0, (float)(1.0 / std::sqrt((double)d)), s), "tr softmax");
+    const int* keyLen = nullptr;
+    if (cx.inputSizes) {  // padding mask of the keys (cpc/SequentialBuilder.cpp:58-81, TransformerCPC.cpp:138-144)
+      int* kl = (int*)(ar + klOff);
+      w2lCheck(w2l_attn_key_lengths(cx.inputSizes, B, cx.inputT, T, kl, s), "tr key lengths");
+      keyLen = kl;
+    }
+    w2lCheck(w2l_attn_softmax_forward(S, csz > 0 ? R : nullptr, keyLen, B, nH, T, ldr, rlo, W, n0, (float)(1.0 / std::sqrt((double)d)), s), "tr softmax");
     if (pd > 0) w2lCheck(w2l_dropout_copy(Pd, S, (size_t)B * nH * TT, pd, cx.seed, rngStream, s), "tr attn dropout");
     {  // ctx_i = sum_j P[i][j] v_j
       w2l_bgemm_desc g = heads(T, d, T);

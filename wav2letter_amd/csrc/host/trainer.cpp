@@ -41,6 +41,7 @@ struct Trainer {
   std::string lastError;
   bool guardZeroed = false;
   int netOptim = 0, critOptim = 0;  // 0 SGD(momentum), 1 Adagrad (variance in the momentum arena), 2 Adadelta (+ state2)
+  const float* inputSizes = nullptr;  // w2l_trainer_set_input_sizes
   float* state2 = nullptr;          // Adadelta's accDelta, same size and layout as the momentum arena
   bool mixedPrecision = false;   // fl's --fl_amp_use_mixed_precision, restated for bf16: the network's fl::Linear GEMMs multiply
                                  // in bf16 (fp32 accumulate, fp32 storage, fp32 master weights); convolutions, LayerNorm, the
@@ -179,6 +180,7 @@ static Ctx makeCtx(Trainer* t, void* stream, bool train) {
   c.seed = 0x9E3779B9u * (t->step + 1);
   c.params = t->params;
   c.grads = t->grads;
+  c.inputSizes = t->inputSizes; c.inputT = t->T;
   return c;
 }
 
@@ -338,6 +340,11 @@ W2L_API int w2l_trainer_skipped_updates(void* h, uint64_t* count, void* stream) 
 W2L_API int w2l_trainer_set_optimizer(void* h, int netKind, int critKind) {
   if (!h || netKind < 0 || netKind > 2 || critKind < 0 || critKind > 2) return W2L_EINVAL;
   ((Trainer*)h)->netOptim = netKind; ((Trainer*)h)->critOptim = critKind;
+  return W2L_OK;
+}
+W2L_API int w2l_trainer_set_input_sizes(void* h, const float* inputSizesDev) {
+  if (!h) return W2L_EINVAL;
+  ((Trainer*)h)->inputSizes = inputSizesDev;
   return W2L_OK;
 }
 W2L_API int w2l_trainer_bind_state2(void* h, float* state2) {

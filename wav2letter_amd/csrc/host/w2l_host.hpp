@@ -80,6 +80,8 @@ struct Ctx {
   uint32_t seed = 0;     // dropout seed of this step
   float* params = nullptr;
   float* grads = nullptr;
+  const float* inputSizes = nullptr;  // device [B] (any unit) or null: padding mask of the Transformer blocks
+  int inputT = 0;                     // frames of the padded network input the sizes refer to
 };
 
 class Planner {  // bump allocator over the activation arena (sizes only until bound)

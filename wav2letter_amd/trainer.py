@@ -43,6 +43,7 @@ def _lib_tr():
         L.w2l_trainer_set_mixed_precision.argtypes = [vp, i]
         L.w2l_trainer_set_optimizer.argtypes = [vp, i, i]
         L.w2l_trainer_bind_state2.argtypes = [vp, vp]
+        L.w2l_trainer_set_input_sizes.argtypes = [vp, vp]
         L.w2l_trainer_set_linseg.argtypes = [vp, u32]
         L.w2l_trainer_grad_norm.argtypes = [vp, C.POINTER(C.c_double), vp]
         L.w2l_trainer_skipped_updates.argtypes = [vp, C.POINTER(u64), vp]
@@ -230,6 +231,17 @@ class Trainer:
         _check(self.L.w2l_trainer_set_optimizer(self.h, kinds[netoptim], kinds[critoptim]), "set_optimizer")
         self._optim = (netoptim, critoptim)
         self._bind_state2()
+
+    def set_input_sizes(self, sizes):
+        """per-utterance input sizes of the next batches (float32 CUDA tensor [B] in any unit, or None): the Transformer blocks
+        mask the padded keys as forwardSequentialModuleWithPadMask does (cpc/SequentialBuilder.cpp:58-81); the tensor is kept
+        alive by the trainer and read at every forward"""
+        if sizes is not None:
+            if not (torch.is_tensor(sizes) and sizes.dtype == torch.float32 and sizes.is_cuda and sizes.is_contiguous()
+                    and sizes.numel() == self.B):
+                raise ValueError("input sizes: contiguous float32 CUDA tensor of B elements")
+        self._input_sizes = sizes
+        _check(self.L.w2l_trainer_set_input_sizes(self.h, sizes.data_ptr() if sizes is not None else None), "set_input_sizes")
 
     def set_step(self, step):
         self.L.w2l_trainer_set_step(self.h, step)
