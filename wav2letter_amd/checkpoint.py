@@ -10,11 +10,13 @@ so that a maintainer can convert either way with a few lines of cereal code:
     bytes 0..7    magic  b"W2LAMD01"
     bytes 8..11   little-endian uint32  n = length of the JSON header
     bytes 12..    JSON header (utf-8): {"nfeat", "nlabel", "criterion", "arch_sha256", "step", "flags": {...},
-                   "tensors": [{"name", "kind": "network"|"criterion"|"momentum", "shape": [...], "numel"}]}
+                   "optim": [netoptim, critoptim],
+                   "tensors": [{"name", "kind": "network"|"criterion"|"momentum"|"state2", "shape": [...], "numel"}]}
     then, 16-byte aligned, every tensor's float32 data in header order (little endian, reference layout).
 
 Network tensors go through `Trainer.export_from / import_param` (internal layout <-> reference layout);
-criterion parameters (ASG transitions `(N, N)`, `[to][from]`) and the momentum arena are raw.
+criterion parameters (ASG transitions `(N, N)`, `[to][from]`) and the optimizer arenas are raw: "momentum" is SGD's velocity,
+Adagrad's squared-gradient sums or Adadelta's accGrad (header "optim" says which), "state2" is Adadelta's accDelta.
 """
 import hashlib
 import json
@@ -51,7 +53,12 @@ def save(path, trainer, arch_text, criterion, step=0, flags=None, momentum=True)
         tensors.append({"name": "netoptim.momentum(internal arena)", "kind": "momentum", "numel": int(trainer.n_floats),
                         "shape": [int(trainer.n_floats)]})
         blobs.append(np.ascontiguousarray(trainer.mom.detach().cpu().numpy(), np.float32))
+        if getattr(trainer, "state2", None) is not None:
+            tensors.append({"name": "netoptim.accDelta(internal arena)", "kind": "state2", "numel": int(trainer.n_floats),
+                            "shape": [int(trainer.n_floats)]})
+            blobs.append(np.ascontiguousarray(trainer.state2.detach().cpu().numpy(), np.float32))
     header = json.dumps({"nfeat": trainer.nfeat, "nlabel": trainer.nlabel, "criterion": criterion,
+                         "optim": list(getattr(trainer, "_optim", ("sgd", "sgd"))),
                          "arch_sha256": hashlib.sha256(arch_text.encode()).hexdigest(), "step": int(step),
                          "flags": flags or {}, "tensors": tensors}).encode()
     with open(path, "wb") as f:
@@ -111,14 +118,26 @@ def load(path, trainer, arch_text=None):
     if (trainer.n_floats > trainer.n_net) != any(t["kind"] == "criterion" for t in header["tensors"]):
         raise ValueError("criterion parameters do not match (one side has transitions, the other has none)")
     mom = [a for t, a in zip(header["tensors"], arrays) if t["kind"] == "momentum"]
-    if mom and mom[0].size != trainer.n_floats:
-        raise ValueError("momentum arena does not match this trainer")
+    st2 = [a for t, a in zip(header["tensors"], arrays) if t["kind"] == "state2"]
+    if (mom and mom[0].size != trainer.n_floats) or (st2 and st2[0].size != trainer.n_floats):
+        raise ValueError("optimizer arenas do not match this trainer")
+    optim = tuple(header.get("optim", ("sgd", "sgd")))
+    if mom and optim != tuple(getattr(trainer, "_optim", ("sgd", "sgd"))):
+        # the arena's MEANING depends on the optimizer (velocity / squared-gradient sums / accGrad)
+        raise ValueError(f"checkpoint holds the state of optimizers {optim}; call trainer.set_optimizer{optim} before load()")
+    if ("adadelta" in optim) != bool(st2) and mom:
+        raise ValueError("Adadelta checkpoint without its accDelta arena")
     if trainer.params is not None:
         trainer.params.copy_(torch.from_numpy(trainer.host_params))
         if mom:
             trainer.mom.copy_(torch.from_numpy(mom[0]))
-    elif mom:
-        trainer._pending_mom = mom[0]   # applied by Trainer.to_device() (load() before to_device() is the natural order)
+        if st2:
+            trainer.state2.copy_(torch.from_numpy(st2[0]))
+    else:
+        if mom:
+            trainer._pending_mom = mom[0]   # applied by Trainer.to_device() (load() before to_device() is the natural order)
+        if st2:
+            trainer._pending_state2 = st2[0]
     trainer.set_step(header["step"])
     return header["step"]
 

@@ -147,6 +147,9 @@ class Trainer:
     def _bind_state2(self):
         if self.params is not None and "adadelta" in getattr(self, "_optim", ()) and getattr(self, "state2", None) is None:
             self.state2 = torch.zeros_like(self.params)            # Adadelta's accDelta (accGrad lives in self.mom)
+            if getattr(self, "_pending_state2", None) is not None:  # checkpoint.load() before to_device()
+                self.state2.copy_(torch.from_numpy(self._pending_state2))
+                self._pending_state2 = None
             _check(self.L.w2l_trainer_bind_state2(self.h, self.state2.data_ptr()), "bind_state2")
 
     def plan(self, B, T, L):
