@@ -13,7 +13,8 @@ scores = q k^T + rotate(E q^T)[n .. n + T - 1]^T with n = (2 csz - 1) / 2, softm
 query's column of position scores with T zeros, re-reads the buffer with a row pitch one shorter, and so shifts column i
 down by i rows.  PARITY UNPINNED for this function: the reference holds no golden vector or test for it; the restatement
 is cross-checked against the closed form  rel[i][j] = q_i . E[j - i + csz - 1]  (zero outside the table) in
-tests/test_oracle_nn.py, and the GPU path is held to this oracle.
+tests/test_oracle_nn.py, its position-free core is checked against torch's scaled_dot_product_attention (with and without a
+key-padding mask), and the GPU path is held to this oracle.
 """
 import math
 

@@ -646,6 +646,34 @@ def test_adadelta_updates_follow_the_recurrence():
         tr2.update(lr=lr, lrcrit=lrcrit, total_batch=B)
 
 
+@pytest.mark.parametrize("kind", ["adagrad", "adadelta"])
+def test_optimizer_kernels_against_torch_optim(kind):
+    """w2l_adagrad_step_guarded / w2l_adadelta_step_guarded (no clip, no guard) against torch.optim's Adagrad (eps 1e-8) and
+    Adadelta (rho 0.9, eps 1e-8) -- a second implementation of the recurrences fl::AdagradOptimizer / fl::AdadeltaOptimizer
+    restate -- over five steps on an odd-length vector (float4 body + scalar tail)"""
+    from wav2letter_amd import _lib
+    L = _lib.lib()
+    n = 4099
+    g = torch.Generator().manual_seed(4)
+    p0 = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) * (0.1 + i) for i in range(5)]
+    ref = p0.double().clone().requires_grad_(True)
+    opt = (torch.optim.Adagrad([ref], lr=0.02, eps=1e-8) if kind == "adagrad"
+           else torch.optim.Adadelta([ref], lr=0.4, rho=0.9, eps=1e-8))
+    p = p0.cuda().clone()
+    s1, s2 = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for gi in grads:
+        ref.grad = gi.double().clone()
+        opt.step()
+        gd = gi.cuda()
+        if kind == "adagrad":
+            assert L.w2l_adagrad_step_guarded(p.data_ptr(), gd.data_ptr(), s1.data_ptr(), n, 0.02, 1e-8, 1.0, 0.0, None, st) == 0
+        else:
+            assert L.w2l_adadelta_step_guarded(p.data_ptr(), gd.data_ptr(), s1.data_ptr(), s2.data_ptr(), n, 0.4, 0.9, 1e-8, 1.0, 0.0, None, st) == 0
+        assert (p.cpu().double() - ref.detach()).abs().max().item() < 1e-5
+
+
 def test_batch_larger_than_64_and_unbound_calls():
     """B > 64 (round-1 limit of the loss slots) and the ABI's bound-state checks"""
     from wav2letter_amd import _lib, recipes

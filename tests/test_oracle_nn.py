@@ -363,3 +363,25 @@ def test_transformer_oracle_padding_mask_key_lengths():
     v[:, :, 0] = torch.arange(T, dtype=torch.float64)            # ctx[..., 0] = expected key index
     ctx = TO.attention(q, k, v, None, H, key_len=[9, 4, 1])
     assert ctx[1, :, 0].max() <= 3.0 + 1e-12 and (ctx[2, :, 0].abs() < 1e-12).all() and ctx[0, :, 0].max() > 3.0
+
+
+def test_transformer_oracle_attention_against_torch_sdpa():
+    """independent pin of the restated attention core where a second implementation exists: without the position table and
+    masks, oracle/transformer_oracle.attention is torch's scaled_dot_product_attention per (utterance, head); with key lengths
+    it is SDPA under the boolean key-padding mask"""
+    import math
+    import torch
+    import torch.nn.functional as F
+    from oracle import transformer_oracle as TO
+    g = torch.Generator().manual_seed(3)
+    B, T, H, d = 3, 11, 4, 8
+    q, k, v = (torch.randn(B, T, H * d, generator=g, dtype=torch.float64) for _ in range(3))
+    split = lambda z: z.reshape(B, T, H, d).permute(0, 2, 1, 3)
+    got = TO.attention(q / math.sqrt(d), k, v, None, H)
+    want = F.scaled_dot_product_attention(split(q), split(k), split(v)).permute(0, 2, 1, 3).reshape(B, T, H * d)
+    assert (got - want).abs().max() < 1e-12
+    kl = [11, 6, 2]
+    keep = (torch.arange(T)[None, :] < torch.tensor(kl)[:, None])[:, None, None, :]
+    got = TO.attention(q / math.sqrt(d), k, v, None, H, key_len=kl)
+    want = F.scaled_dot_product_attention(split(q), split(k), split(v), attn_mask=keep).permute(0, 2, 1, 3).reshape(B, T, H * d)
+    assert (got - want).abs().max() < 1e-12
