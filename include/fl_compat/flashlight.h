@@ -184,6 +184,22 @@ class FL_COMPAT_API Sequential : public Container {
   std::string prettyString() const override;
 };
 
+// fl::SpecAugment as the Trainer instantiates it from --saug_start_update (recipes/slimIPL/src/Train.cpp:1026-1048, applied
+// at :1453-1461): frequency / time masking with zeros on the features (T, NFEAT, 1, B); identity in eval mode.  Same kernel as
+// the SAUG arch token (w2l_specaugment_inplace; one mask set per batch).  Time warping (tWarpW) is not applied by the
+// reference's own module either in this configuration (the first argument is the filterbank count).
+class FL_COMPAT_API SpecAugment : public Module {
+ public:
+  SpecAugment(int tWarpW, int fMaskF, int nFMask, int tMaskT, float tMaskP, int nTMask);
+  std::vector<Variable> forward(const std::vector<Variable>& inputs) override;
+  std::string prettyString() const override;
+
+ private:
+  int fMaskF_, nFMask_, tMaskT_, nTMask_;
+  float tMaskP_;
+  uint32_t calls_ = 0;
+};
+
 // ---- optimizers (recipes/slimIPL/src/Train.cpp:577-582: SGDOptimizer(params, lr, momentum, weightdecay))
 class FL_COMPAT_API FirstOrderOptimizer {
  public:

@@ -206,3 +206,32 @@ def test_train_binary_data_parallel_path_single_rank(tmp_path):
     # a rank outside the world is refused like any bad flag
     bad = subprocess.run(base + ["--enable_distributed=true", "--world_rank=2", "--world_size=2"], capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and "rank" in bad.stderr
+
+
+def test_train_binary_lr_decay_and_specaugment_start(tmp_path):
+    """the Trainer's schedule pieces the Transformer-CTC recipe uses (Train.cpp:1170-1175, :1334-1348, :1026-1048, :1453-1461):
+    lr = lr0 * 0.5^(0 before --lr_decay, then 1 + (epoch - lr_decay) / lr_decay_step) * warm-up, and SpecAugment on the
+    features from --saug_start_update on"""
+    exe = os.path.join(ROOT, "wav2letter_amd", "bin", "Train")
+    d = tmp_path
+    arch = ("V -1 NFEAT 1 0\nC2 1 4 5 1 2 1 -1 -1\nR\nDO 0.0\nLN 0 1 2\nTDS 4 5 8 0.0 64\nV 0 32 1 0\nRO 1 0 3 2\nL 32 NLABEL\n")
+    os.makedirs(d / "arch")
+    open(d / "arch" / "net.arch", "w").write(arch)
+    cmd = [exe, "train", f"--archdir={d / 'arch'}", "--arch=net.arch", "--criterion=ctc", "--filterbanks=8", "--w2l_nlabel=12",
+           "--batchsize=3", "--w2l_synth_frames=64", "--w2l_synth_target_len=6", "--w2l_synth_updates=4", "--reportiters=1",
+           "--lr=0.8", "--momentum=0.0", "--maxgradnorm=1.0", "--onorm=target", "--sqnorm",
+           "--lr_decay=2", "--lr_decay_step=1", "--w2l_synth_batches_per_epoch=1",
+           "--saug_start_update=3", "--saug_fmaskf=2", "--saug_fmaskn=1", "--saug_tmaskt=5", "--saug_tmaskn=1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    assert "[SpecAugment from update 3] SpecAugment ( W: 0, F: 2, mF: 1, T: 5, p: 1, mT: 1 )" in out.stdout
+    rows = [dict((kv.split(":")[0].strip(), kv.split(":", 1)[1].strip()) for kv in r.split(" | "))
+            for r in out.stdout.splitlines() if r.startswith("epoch:")]
+    assert [float(r["lr"]) for r in rows] == [0.8, 0.4, 0.2, 0.1]
+    assert all(np.isfinite(float(r["loss"])) for r in rows)
+    # the same run without SpecAugment: identical until the start update, different from it on
+    base = subprocess.run([c for c in cmd if not c.startswith("--saug")], capture_output=True, text=True, timeout=600)
+    brow = [l.split(" | ") for l in base.stdout.splitlines() if l.startswith("epoch:")]
+    loss = lambda rws: [dict((kv.split(":")[0].strip(), kv.split(":", 1)[1].strip()) for kv in r)["loss"] for r in rws]
+    a, b = [r["loss"] for r in rows], loss(brow)
+    assert a[:2] == b[:2] and a[2:] != b[2:]

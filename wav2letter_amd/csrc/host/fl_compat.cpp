@@ -187,6 +187,31 @@ std::string Sequential::prettyString() const {
   return ss.str();
 }
 
+// ------------------------------------------------------------------------------------------------ SpecAugment
+SpecAugment::SpecAugment(int tWarpW, int fMaskF, int nFMask, int tMaskT, float tMaskP, int nTMask)
+    : fMaskF_(fMaskF), nFMask_(nFMask), tMaskT_(tMaskT), nTMask_(nTMask), tMaskP_(tMaskP) {
+  (void)tWarpW;
+}
+std::vector<Variable> SpecAugment::forward(const std::vector<Variable>& inputs) {
+  if (inputs.empty()) throw std::invalid_argument("SpecAugment: no input");
+  const Variable& in = inputs[0];
+  if (!train_) return {in};
+  if (in.type() != af::f32) throw std::invalid_argument("SpecAugment: features must be f32");
+  // (T, F, 1, B) is time-fastest [B][F][T]; the masking kernel works on frames [B][T][F]
+  const int T = (int)in.dims(0), F = (int)(in.dims(1) * in.dims(2)), B = (int)in.dims(3);
+  af::array frames(af::dim4(F, T, B)), out(in.dims());
+  w2l::w2lCheck(w2l_transpose(in.array().device<float>(), frames.device<float>(), B, F, T, S()), "saug transpose");
+  w2l::w2lCheck(w2l_specaugment_inplace(frames.device<float>(), B, T, F, fMaskF_, nFMask_, tMaskT_, tMaskP_, nTMask_,
+                                        0x9E3779B9u * (++calls_), S()), "saug");
+  w2l::w2lCheck(w2l_transpose(frames.device<float>(), out.device<float>(), B, T, F, S()), "saug transpose back");
+  return {Variable(out, false)};
+}
+std::string SpecAugment::prettyString() const {
+  std::ostringstream ss;
+  ss << "SpecAugment ( W: 0, F: " << fMaskF_ << ", mF: " << nFMask_ << ", T: " << tMaskT_ << ", p: " << tMaskP_ << ", mT: " << nTMask_ << " )";
+  return ss.str();
+}
+
 // ------------------------------------------------------------------------------------------------ optimizers
 SGDOptimizer::SGDOptimizer(const std::vector<Variable>& params, double lr, double momentum, double weightDecay, bool useNesterov)
     : FirstOrderOptimizer(params, lr), mu_(momentum), wd_(weightDecay), nesterov_(useNesterov) {

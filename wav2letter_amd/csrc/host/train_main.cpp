@@ -18,6 +18,7 @@
 // Data parallelism is the reference's: --enable_distributed --world_rank --world_size --max_devices_per_node
 // --rndv_filepath (Train.cpp:188-199; RANK / WORLD_SIZE / LOCAL_WORLD_SIZE of a torchrun-style launcher are read when the
 // flags are absent): one process per GPU, fl::CoalescingReducer over RCCL, batch size all-reduced with the gradients.
+#include <limits>
 #include <sys/stat.h>
 
 #include <chrono>
@@ -260,12 +261,29 @@ int main(int argc, char** argv) {
       runtime.resume();
     };
 
+    const long batchesPerEpoch = std::max<long>(1, flags.geti("w2l_synth_batches_per_epoch", iters));
+    const long lrDecay = flags.geti("lr_decay", std::numeric_limits<int>::max());
+    const long lrDecayStep = std::max<long>(1, flags.geti("lr_decay_step", std::numeric_limits<int>::max()));
+    // --saug_start_update (Train.cpp:1026-1048): SpecAugment on the features from that update on (archs without a SAUG line)
+    const long saugStart = flags.geti("saug_start_update", -1);
+    std::shared_ptr<fl::SpecAugment> saug;
+    if (saugStart >= 0)
+      saug = std::make_shared<fl::SpecAugment>((int)flags.geti("filterbanks", 40), (int)flags.geti("saug_fmaskf", 27), (int)flags.geti("saug_fmaskn", 2),
+                                               (int)flags.geti("saug_tmaskt", 100), (float)flags.getd("saug_tmaskp", 1.0), (int)flags.geti("saug_tmaskn", 2));
+    if (saug) std::cout << "[SpecAugment from update " << saugStart << "] " << saug->prettyString() << std::endl;
+
     // ---- the hot loop (Train.cpp:1454-1804)
     double lr = lr0, lrcrit = lrcrit0;
     for (long curBatch = 1; curBatch <= iters; ++curBatch) {
-      // learning rate: warmup * gamma^(batch / stepsize) (Train.cpp:1334-1348)
-      const double sched = std::pow(flags.getd("gamma", 1.0), (double)curBatch / flags.getd("stepsize", 1e18)) *
-                           std::min((double)curBatch / std::max<long>(1, warmup), 1.0);
+      // learning rate (Train.cpp:1170-1175, :1334-1348): 0.5^(epoch steps after --lr_decay) * (cosine | gamma^(batch / stepsize)) * warm-up;
+      // an epoch of the synthetic run is --w2l_synth_batches_per_epoch updates (default: the whole run is epoch 1)
+      const long curEpoch = 1 + (curBatch - 1) / batchesPerEpoch;
+      const long afterDecay = curEpoch - lrDecay;
+      const double lrDecayScale = std::pow(0.5, afterDecay < 0 ? 0.0 : (double)(1 + afterDecay / lrDecayStep));
+      const double lrScheduleScale = flags.getb("lrcosine", false)
+                                         ? std::cos((double)curBatch / (double)iters * std::acos(-1.0) / 2.0)
+                                         : std::pow(flags.getd("gamma", 1.0), (double)curBatch / flags.getd("stepsize", 1e18));
+      const double sched = lrDecayScale * lrScheduleScale * std::min((double)curBatch / std::max<long>(1, warmup), 1.0);
       lr = lr0 * sched;
       lrcrit = lrcrit0 * sched;
       netoptim->setLr(lr);
@@ -291,6 +309,7 @@ int main(int argc, char** argv) {
         tszMax = std::max<long>(tszMax, len);
       }
       fl::Variable input = fl::input(af::array(af::dim4(T, nFeat, 1, batch), hx.data()));
+      if (saug && curBatch >= saugStart) input = saug->forward({input}).front();   // Train.cpp:1453-1461
       fl::Variable target(af::array(af::dim4(Lmax, batch), ht.data()), false);
       af::sync();
       sampletimer.stopAndIncUnit();
