@@ -268,3 +268,28 @@ def test_specaugment_rejects_narrow_input():
     from wav2letter_amd import _lib
     x = torch.zeros(1, 10, 8, device="cuda")
     assert _lib.lib().w2l_specaugment_inplace(x.data_ptr(), 1, 10, 8, 27, 2, 100, 1.0, 2, 1, None) == _lib.W2L_EINVAL
+
+
+def test_golden_transformer_block_through_hip_path():
+    """tests/golden/transformer_block_golden.json -- the hand-over vector for a reference-side check of the Transformer block
+    (generator: tests/golden/make_transformer_golden.py) -- through the C++ host graph and the HIP attention path: parameters
+    imported in the reference's order and ArrayFire layouts, output with and without the padding mask"""
+    from wav2letter_amd.trainer import Trainer
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "transformer_block_golden.json")))
+    C, T, B = g["modelDim"], g["T"], g["B"]
+    tr = Trainer("V -1 1 NFEAT 0\nRO 2 0 3 1\n" + g["arch_line"] + "\n", C, C, "ctc", 4)
+    table = tr.param_table()
+    assert len(table) == len(g["params"]) == 15
+    for i, p in enumerate(g["params"]):
+        assert table[i][1] == len(p["data"]), (table[i], p["name"])
+        tr.import_param(i, np.array(p["data"], np.float32))
+    tr.plan(B, T, 2)
+    tr.to_device()
+    x = np.array(g["x"], np.float32).reshape(B, T, C)
+    xd = torch.tensor(np.ascontiguousarray(x.transpose(0, 2, 1))).cuda()          # features (T, NFEAT, 1, B) == [B][NFEAT][T]
+    y = tr.forward(xd, train=False).cpu().numpy()
+    assert relerr(y.reshape(-1), np.array(g["y"])) < g["tol"]
+    tr.set_input_sizes(torch.tensor(g["input_sizes"], dtype=torch.float32).cuda())
+    ym = tr.forward(xd, train=False).cpu().numpy()
+    assert relerr(ym.reshape(-1), np.array(g["y_masked"])) < g["tol"]
+    assert relerr(ym.reshape(-1), np.array(g["y"])) > 1e-3

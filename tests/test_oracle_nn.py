@@ -385,3 +385,28 @@ def test_transformer_oracle_attention_against_torch_sdpa():
     got = TO.attention(q / math.sqrt(d), k, v, None, H, key_len=kl)
     want = F.scaled_dot_product_attention(split(q), split(k), split(v), attn_mask=keep).permute(0, 2, 1, 3).reshape(B, T, H * d)
     assert (got - want).abs().max() < 1e-12
+
+
+def test_transformer_block_golden_vector_oracle_side():
+    """tests/golden/transformer_block_golden.json (the hand-over vector for a reference-side check; generated by
+    tests/golden/make_transformer_golden.py from the oracle): the oracle reproduces it, through the reference-layout
+    interpreter too"""
+    import json
+    import os
+    import torch
+    from oracle import transformer_oracle as TO
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "transformer_block_golden.json")))
+    C, T, B = g["modelDim"], g["T"], g["B"]
+    # LayerNorm entries hold the module's two scalar parameters (weight, bias), each of af dims (1)
+    params = [np.array(p["data"], np.float32).reshape(p["af_dims"][::-1] if "norm" not in p["name"] else (2,)) for p in g["params"]]
+    x = np.array(g["x"], np.float32).reshape(B, T, C)
+    y = TO.tr_block(torch.tensor(x, dtype=torch.float64), [torch.tensor(p, dtype=torch.float64) for p in params],
+                    g["nHeads"], g["csz"]).numpy()
+    assert np.abs(y.reshape(-1) - np.array(g["y"])).max() < 1e-9
+    assert list(TO.key_lengths(g["input_sizes"], T, T)) == g["key_lengths"]
+    net = refnet.RefNet("V -1 1 NFEAT 0\nRO 2 0 3 1\n" + g["arch_line"] + "\n", C, C)
+    em = net.forward(np.ascontiguousarray(x.transpose(0, 2, 1))[:, None], params)     # input (T, 1, C, B) == [B][1][C][T]
+    assert np.abs(em.reshape(-1) - np.array(g["y"], np.float32)).max() < 1e-5
+    net.input_sizes = np.array(g["input_sizes"], np.float32)
+    em = net.forward(np.ascontiguousarray(x.transpose(0, 2, 1))[:, None], params)
+    assert np.abs(em.reshape(-1) - np.array(g["y_masked"], np.float32)).max() < 1e-5
