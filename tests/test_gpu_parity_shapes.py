@@ -293,3 +293,32 @@ def test_golden_transformer_block_through_hip_path():
     ym = tr.forward(xd, train=False).cpu().numpy()
     assert relerr(ym.reshape(-1), np.array(g["y_masked"])) < g["tol"]
     assert relerr(ym.reshape(-1), np.array(g["y"])) > 1e-3
+
+
+def test_golden_criterion_handover_through_hip_path():
+    """tests/golden/criterion_handover.json -- the hand-over vector for a reference-side check of ASG (FAC, FCC, Viterbi) and
+    CTC -- through the HIP criteria: losses and gradients within 1e-4, Viterbi paths and the forced alignment bit-exact"""
+    from wav2letter_amd import ASGLoss, CTCLoss
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "criterion_handover.json")))
+    B, T, N, L = g["B"], g["T"], g["N"], g["L"]
+    em = np.array(g["emissions"], np.float32).reshape(B, T, N)
+    A = np.array(g["transitions"], np.float32).reshape(N, N)
+    tgt = np.array(g["target"], np.int32).reshape(B, L)
+    asg = ASGLoss(N).cuda()
+    asg.transitions.data = dev(A)
+    x = dev(em).requires_grad_(True)
+    loss = asg(x, dev(tgt))
+    loss.sum().backward()
+    assert relerr(loss.detach().cpu().numpy(), g["asg_loss"]) < g["tol"]
+    assert gradrel(x.grad.cpu().numpy().reshape(-1), g["asg_grad_emissions"]) < g["tol"]
+    assert gradrel(asg.transitions.grad.cpu().numpy().reshape(-1), g["asg_grad_transitions"]) < g["tol"]
+    assert (asg.viterbiPath(dev(em)).cpu().numpy().reshape(-1) == np.array(g["viterbi_path"])).all()
+    assert (asg.viterbiPathWithTarget(dev(em), dev(tgt)).cpu().numpy().reshape(-1) == np.array(g["fac_viterbi_alignment"])).all()
+    ct = np.array(g["ctc_target"], np.int32).reshape(B, L)
+    xc = dev(em).requires_grad_(True)
+    ctc = CTCLoss()
+    lc = ctc(xc, dev(ct))
+    lc.sum().backward()
+    assert relerr(lc.detach().cpu().numpy(), g["ctc_loss"]) < g["tol"]
+    assert gradrel(xc.grad.cpu().numpy().reshape(-1), g["ctc_grad_emissions"]) < g["tol"]
+    assert (ctc.viterbiPath(dev(em)).cpu().numpy().reshape(-1) == np.array(g["ctc_viterbi_path"])).all()

@@ -362,3 +362,28 @@ def test_fcc_fac_thread_layouts_agree(oracle):
         oracle.set_num_threads(n0)
     for a, b in zip(*res):
         assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(a).max())
+
+
+def test_criterion_handover_vector(oracle):
+    """tests/golden/criterion_handover.json (generator alongside): the oracle reproduces it, ASG = FCC - FAC, and its CTC
+    numbers agree with torch's ctc_loss (blank last) -- the one second implementation available here"""
+    import json
+    import os
+    import torch
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "criterion_handover.json")))
+    B, T, N, L = g["B"], g["T"], g["N"], g["L"]
+    em = np.array(g["emissions"], np.float32).reshape(B, T, N)
+    A = np.array(g["transitions"], np.float32).reshape(N, N)
+    tgt = np.array(g["target"], np.int32).reshape(B, L)
+    loss, dx, dA = oracle.asg(em, A, tgt)
+    assert np.abs(loss - np.array(g["asg_loss"])).max() < 1e-9
+    assert np.abs(np.array(g["fcc"]) - np.array(g["fac"]) - np.array(g["asg_loss"])).max() < 1e-9
+    assert (oracle.viterbi(em, A).reshape(-1) == np.array(g["viterbi_path"])).all()
+    assert np.abs(np.asarray(dA).reshape(-1) - np.array(g["asg_grad_transitions"])).max() < 1e-9
+    ct = np.array(g["ctc_target"], np.int32).reshape(B, L)
+    lens = (ct >= 0).sum(1)
+    lp = torch.log_softmax(torch.tensor(em, dtype=torch.float64), -1).permute(1, 0, 2)
+    want = torch.nn.functional.ctc_loss(lp, torch.tensor(np.where(ct >= 0, ct, 0)), torch.full((B,), T), torch.tensor(lens),
+                                        blank=N - 1, reduction="none")
+    assert np.abs(want.numpy() - np.array(g["ctc_loss"])).max() < 1e-9
+    assert np.abs(oracle.CTC(em, ct).forward() - np.array(g["ctc_loss"])).max() < 1e-9
