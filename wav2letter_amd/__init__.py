@@ -5,5 +5,6 @@ include/w2l_hip.h).  torch is used for device memory, streams and
 torch.distributed (RCCL) only.
 """
 from . import _lib  # noqa: F401
+from . import text  # noqa: F401  (token dictionary, lexicon, targets, TER / WER remap: host logic)
 from .criterion import (ASGLoss, CTCLoss, CriterionScaleMode, ForceAlignmentCriterion,  # noqa: F401
                         FullConnectionCriterion, LinSegCriterion, SequenceCriterion, getCriterionScaleMode, linear_target)
