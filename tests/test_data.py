@@ -59,3 +59,37 @@ def test_partition_round_robin_allow_empty_covers_every_sample(n, world, bs):
     assert flat == list(range(n))
     sizes = [len(p) for p in parts]
     assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def test_read_audio_wav_and_raw_and_batch_padding(tmp_path):
+    """the loader side of a .lst line: WAV PCM (16 / 24 bit, stereo -> mono) and raw PCM back as float32 in [-1, 1), a padded
+    batch with its input sizes; containers without a decoder here are refused"""
+    import wave
+    import numpy as np
+    import pytest
+    from wav2letter_amd import data
+    t = np.arange(1600) / 16000.0
+    sig = (0.5 * np.sin(2 * np.pi * 440 * t)).astype(np.float32)
+    pcm = np.round(sig * 32767).astype("<i2")
+    with wave.open(str(tmp_path / "a.wav"), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm.tobytes())
+    a, rate = data.read_audio(str(tmp_path / "a.wav"))
+    assert rate == 16000 and a.dtype == np.float32 and a.shape == (1600,) and np.abs(a - sig).max() < 1e-4
+    st = np.stack([pcm, -pcm], axis=1)                                   # stereo: the channels cancel
+    with wave.open(str(tmp_path / "s.wav"), "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(8000); w.writeframes(st.tobytes())
+    s, rate = data.read_audio(str(tmp_path / "s.wav"))
+    assert rate == 8000 and s.shape == (1600,) and np.abs(s).max() < 1e-6
+    v24 = (np.round(sig * (2 ** 23 - 1)).astype(np.int32)) & 0xFFFFFF
+    b24 = np.stack([v24 & 0xFF, (v24 >> 8) & 0xFF, (v24 >> 16) & 0xFF], axis=1).astype(np.uint8)
+    with wave.open(str(tmp_path / "h.wav"), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(3); w.setframerate(16000); w.writeframes(b24.tobytes())
+    h, _ = data.read_audio(str(tmp_path / "h.wav"))
+    assert np.abs(h - sig).max() < 1e-6
+    pcm.tofile(str(tmp_path / "r.raw"))
+    r, _ = data.read_audio(str(tmp_path / "r.raw"))
+    assert np.array_equal(r, a)
+    with pytest.raises(ValueError):
+        data.read_audio(str(tmp_path / "x.flac"))
+    batch, sizes = data.pad_batch([a, a[:700]])
+    assert batch.shape == (2, 1600) and list(sizes) == [1600.0, 700.0] and (batch[1, 700:] == 0).all()

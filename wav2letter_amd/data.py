@@ -89,3 +89,48 @@ def batches(indices: Sequence[int], durations_ms: Sequence[float], batch_size: i
     if cur:
         out.append(cur)
     return out
+
+
+def read_audio(path: str):
+    """one utterance as float32 samples in [-1, 1) plus its sample rate.  The reference decodes through libsndfile
+    (fl::pkg::speech::loadSound, un-vendored; the recipes' lists point at .flac / .wav files): here RIFF / WAV PCM (8 / 16 /
+    24 / 32 bit, via the standard library) and headerless float32 `.f32` / int16 `.raw` / `.pcm` at 16 kHz; FLAC needs a
+    decoder this image does not carry and raises.  Multi-channel files are averaged to mono, as the Trainer's `--channels=1`
+    pipelines expect a single channel."""
+    import numpy as np
+    low = path.lower()
+    if low.endswith(".wav"):
+        import wave
+        with wave.open(path, "rb") as w:
+            nch, width, rate, n = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
+            raw = w.readframes(n)
+        if width == 1:
+            a = (np.frombuffer(raw, np.uint8).astype(np.float32) - 128.0) / 128.0
+        elif width == 2:
+            a = np.frombuffer(raw, "<i2").astype(np.float32) / 32768.0
+        elif width == 3:
+            b = np.frombuffer(raw, np.uint8).reshape(-1, 3).astype(np.int32)
+            v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+            a = (np.where(v >= 1 << 23, v - (1 << 24), v)).astype(np.float32) / float(1 << 23)
+        elif width == 4:
+            a = np.frombuffer(raw, "<i4").astype(np.float32) / float(1 << 31)
+        else:
+            raise ValueError(f"{path}: unsupported sample width {width}")
+        if nch > 1:
+            a = a.reshape(-1, nch).mean(axis=1)
+        return np.ascontiguousarray(a, np.float32), rate
+    if low.endswith(".f32"):
+        return np.fromfile(path, "<f4"), 16000
+    if low.endswith(".raw") or low.endswith(".pcm"):
+        return np.fromfile(path, "<i2").astype(np.float32) / 32768.0, 16000
+    raise ValueError(f"{path}: no decoder for this container in this image (WAV / raw PCM only; the reference uses libsndfile)")
+
+
+def pad_batch(audios):
+    """[B][max samples] float32, zero padded, plus the per-utterance sample counts (the `inputSizes` of the batch)"""
+    import numpy as np
+    n = np.array([len(a) for a in audios], np.float32)
+    out = np.zeros((len(audios), int(n.max()) if len(audios) else 0), np.float32)
+    for b, a in enumerate(audios):
+        out[b, :len(a)] = a
+    return out, n
