@@ -318,7 +318,8 @@ inline SkPlan make_sk_plan(int M, int N, int K, bool allowSk, int tileM = 128, i
   // a partial-tile round trip per worker (~43 us at 192 tiles) that a K of a few tiles cannot repay.  Fitted on MI355X
   // (profiles/r02_run22_gemm_c5_shapes.log; M = 3008, N = 1024: K = 1024 -> 74.5 us data-parallel against 86.1 stream-K,
   // K = 4096 -> 258 against 213):  t_dp = 2.1 kTiles + 7,  t_sk = 3.6 tiles kTiles / 512 + 43  [us]
-  if (tiles <= kSkSlots / 2 && (double)p.kTiles * (2.1 - 3.6 * tiles / kSkSlots) < 36.0) return p;
+  // (fitted between 128 and 256 tiles; a grid of a few tiles still gains from being split, its partial traffic is small)
+  if (tiles > kSkSlots / 4 && tiles <= kSkSlots / 2 && (double)p.kTiles * (2.1 - 3.6 * tiles / kSkSlots) < 36.0) return p;
   const int full = tiles / kSkSlots;
   p.dpTiles = full * kSkSlots;
   p.skTiles = tiles - p.dpTiles;
