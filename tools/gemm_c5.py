@@ -1,6 +1,6 @@
 """GEMM shapes of a Transformer block at BASELINE config 5 (M = 16 x 188 = 3008 frames, width 1024 / 4096): each fl::Linear
 call alone, and the three independent q / k / v projections (forward, weight gradient) on ONE stream against THREE."""
-import ctypes as C, os, sys
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from wav2letter_amd import _lib
