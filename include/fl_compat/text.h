@@ -1,0 +1,214 @@
+// fl_compat/text.h -- the Trainer's token dictionary, target packing and evaluation remap on the reference's own names
+// (header only, host code, no device dependency).  Python mirror: wav2letter_amd/text.py; tests: tests/test_text.py (Python)
+// and tests/cpp/text_test.cpp (this header, compiled with g++ by the CPU test suite).
+//
+// In-repo witnesses: class inventory of a run recipes/slimIPL/src/Train.cpp:235-251 (tokens file, `<1>`..`<replabel>`, the CTC
+// blank LAST); evaluation :829-872 (viterbiPath -> tknPrediction2Ltr / tknTarget2Ltr -> tkn2Wrd -> edit distances).  The
+// functions themselves are un-vendored Flashlight (fl::lib::text::Dictionary, fl::pkg::speech::{packReplabels,
+// unpackReplabels, tknPrediction2Ltr, tknTarget2Ltr, tknIdx2Ltr, tkn2Wrd}, fl::EditDistanceMeter): restated from their
+// published behaviour.
+#pragma once
+#include <algorithm>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace fl {
+namespace lib {
+namespace text {
+
+class Dictionary {
+ public:
+  Dictionary() {}
+  explicit Dictionary(const std::string& path) {
+    std::ifstream f(path);
+    if (!f) throw std::runtime_error("Dictionary: cannot open " + path);
+    std::string line;
+    while (std::getline(f, line)) addLine(line);
+  }
+  explicit Dictionary(const std::vector<std::string>& lines) { for (auto& l : lines) addLine(l); }
+
+  // one index per line; further entries on the same line are aliases of it
+  void addLine(const std::string& line) {
+    std::istringstream ss(line);
+    std::string tok;
+    int idx = -1;
+    while (ss >> tok) {
+      if (entry2idx_.count(tok)) throw std::invalid_argument("Dictionary: duplicate entry " + tok);
+      if (idx < 0) { idx = (int)idx2entry_.size(); idx2entry_.push_back(tok); }
+      entry2idx_[tok] = idx;
+    }
+  }
+  void addEntry(const std::string& entry) { addLine(entry); }
+  size_t indexSize() const { return idx2entry_.size(); }
+  bool contains(const std::string& e) const { return entry2idx_.count(e) != 0; }
+  int getIndex(const std::string& e) const {
+    auto it = entry2idx_.find(e);
+    if (it == entry2idx_.end()) throw std::invalid_argument("Dictionary: unknown entry " + e);
+    return it->second;
+  }
+  const std::string& getEntry(int idx) const {
+    if (idx < 0 || (size_t)idx >= idx2entry_.size()) throw std::invalid_argument("Dictionary: index out of range");
+    return idx2entry_[(size_t)idx];
+  }
+
+ private:
+  std::unordered_map<std::string, int> entry2idx_;
+  std::vector<std::string> idx2entry_;
+};
+
+}  // namespace text
+}  // namespace lib
+
+namespace pkg {
+namespace speech {
+
+constexpr const char* kBlankToken = "#";
+constexpr const char* kCtcCriterion = "ctc";
+constexpr const char* kAsgCriterion = "asg";
+
+inline std::string replabelToken(int r) { return "<" + std::to_string(r) + ">"; }
+
+// Train.cpp:235-251
+inline lib::text::Dictionary createTokenDict(lib::text::Dictionary d, const std::string& criterion, int replabel) {
+  for (int r = 1; r <= replabel; ++r) d.addEntry(replabelToken(r));
+  if (criterion == kCtcCriterion) d.addEntry(kBlankToken);
+  return d;
+}
+
+// `a a a b` -> `a <2> b`: a run becomes the token + the replabel counting the EXTRA repetitions
+inline std::vector<int> packReplabels(const std::vector<int>& tokens, const lib::text::Dictionary& dict, int maxReps) {
+  if (tokens.empty() || maxReps <= 0) return tokens;
+  std::vector<int> repIdx((size_t)maxReps + 1);
+  for (int r = 1; r <= maxReps; ++r) repIdx[(size_t)r] = dict.getIndex(replabelToken(r));
+  std::vector<int> out;
+  int prev = -1, reps = 0;
+  for (int t : tokens) {
+    if (t == prev && reps < maxReps) { ++reps; continue; }
+    if (reps > 0) { out.push_back(repIdx[(size_t)reps]); reps = 0; }
+    out.push_back(t);
+    prev = t;
+  }
+  if (reps > 0) out.push_back(repIdx[(size_t)reps]);
+  return out;
+}
+
+inline std::vector<int> unpackReplabels(const std::vector<int>& tokens, const lib::text::Dictionary& dict, int maxReps) {
+  if (tokens.empty() || maxReps <= 0) return tokens;
+  std::unordered_map<int, int> value;
+  for (int r = 1; r <= maxReps; ++r) value[dict.getIndex(replabelToken(r))] = r;
+  std::vector<int> out;
+  int prev = -1;
+  for (int t : tokens) {
+    auto it = value.find(t);
+    if (it == value.end()) { out.push_back(t); prev = t; }
+    else if (prev != -1) { out.insert(out.end(), (size_t)it->second, prev); prev = -1; }
+  }
+  return out;
+}
+
+inline void uniq(std::vector<int>& v) { v.erase(std::unique(v.begin(), v.end()), v.end()); }
+
+// UTF-8 code points of a token
+inline std::vector<std::string> splitWrd(const std::string& w) {
+  std::vector<std::string> out;
+  for (size_t i = 0; i < w.size();) {
+    const unsigned char c = (unsigned char)w[i];
+    const size_t n = c < 0x80 ? 1 : (c >> 5) == 0x6 ? 2 : (c >> 4) == 0xE ? 3 : (c >> 3) == 0x1E ? 4 : 1;
+    out.push_back(w.substr(i, n));
+    i += n;
+  }
+  return out;
+}
+
+inline std::vector<std::string> tknIdx2Ltr(const std::vector<int>& labels, const lib::text::Dictionary& d, bool useWordPiece,
+                                           const std::string& wordSep) {
+  std::vector<std::string> out;
+  for (int id : labels) {
+    const std::string& tok = d.getEntry(id);
+    if (useWordPiece) { for (auto& c : splitWrd(tok)) out.push_back(c); }
+    else out.push_back(tok);
+  }
+  if (!out.empty() && !wordSep.empty()) {
+    if (out.front() == wordSep) out.erase(out.begin());
+    if (!out.empty() && out.back() == wordSep) out.pop_back();
+  }
+  return out;
+}
+
+inline void remapLabels(std::vector<int>& labels, const lib::text::Dictionary& dict, const std::string& surround, int replabel) {
+  if (replabel > 0) labels = unpackReplabels(labels, dict, replabel);
+  if (!surround.empty() && dict.contains(surround)) {
+    const int s = dict.getIndex(surround);
+    if (!labels.empty() && labels.back() == s) labels.pop_back();
+    if (!labels.empty() && labels.front() == s) labels.erase(labels.begin());
+  }
+}
+
+// a Viterbi path (one label per frame) -> letters: collapse repeated frames, drop the CTC blank, undo replabels
+inline std::vector<std::string> tknPrediction2Ltr(std::vector<int> tokens, const lib::text::Dictionary& dict,
+                                                  const std::string& criterion, const std::string& surround, int replabel,
+                                                  bool useWordPiece, const std::string& wordSep) {
+  tokens.erase(std::remove_if(tokens.begin(), tokens.end(), [](int t) { return t < 0; }), tokens.end());
+  if (tokens.empty()) return {};
+  if (criterion == kCtcCriterion || criterion == kAsgCriterion) uniq(tokens);
+  if (criterion == kCtcCriterion) {
+    const int blank = dict.getIndex(kBlankToken);
+    tokens.erase(std::remove(tokens.begin(), tokens.end(), blank), tokens.end());
+  }
+  remapLabels(tokens, dict, surround, criterion == kAsgCriterion ? replabel : 0);
+  return tknIdx2Ltr(tokens, dict, useWordPiece, wordSep);
+}
+
+inline std::vector<std::string> tknTarget2Ltr(std::vector<int> tokens, const lib::text::Dictionary& dict, const std::string& criterion,
+                                              const std::string& surround, int replabel, bool useWordPiece,
+                                              const std::string& wordSep) {
+  tokens.erase(std::remove_if(tokens.begin(), tokens.end(), [](int t) { return t < 0; }), tokens.end());   // batch padding
+  if (tokens.empty()) return {};
+  remapLabels(tokens, dict, surround, criterion == kAsgCriterion ? replabel : 0);
+  return tknIdx2Ltr(tokens, dict, useWordPiece, wordSep);
+}
+
+inline std::vector<std::string> tkn2Wrd(const std::vector<std::string>& letters, const std::string& wordSep) {
+  std::vector<std::string> words;
+  std::string cur;
+  for (auto& t : letters) {
+    if (t == wordSep) { if (!cur.empty()) { words.push_back(cur); cur.clear(); } }
+    else cur += t;
+  }
+  if (!cur.empty()) words.push_back(cur);
+  return words;
+}
+
+}  // namespace speech
+}  // namespace pkg
+
+// fl::EditDistanceMeter as the Trainer logs it: 100 * (ins + del + sub) / reference length over everything added
+class EditDistanceMeter {
+ public:
+  template <class T>
+  void add(const std::vector<T>& hyp, const std::vector<T>& ref) {
+    std::vector<size_t> prev(ref.size() + 1), cur(ref.size() + 1);
+    for (size_t j = 0; j <= ref.size(); ++j) prev[j] = j;
+    for (size_t i = 1; i <= hyp.size(); ++i) {
+      cur[0] = i;
+      for (size_t j = 1; j <= ref.size(); ++j)
+        cur[j] = std::min({prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (hyp[i - 1] == ref[j - 1] ? 0u : 1u)});
+      std::swap(prev, cur);
+    }
+    errors_ += prev[ref.size()];
+    length_ += ref.size();
+  }
+  double value() const { return length_ ? 100.0 * (double)errors_ / (double)length_ : 0.0; }
+  size_t errors() const { return errors_; }
+  size_t length() const { return length_; }
+  void reset() { errors_ = length_ = 0; }
+
+ private:
+  size_t errors_ = 0, length_ = 0;
+};
+
+}  // namespace fl

@@ -99,3 +99,15 @@ def test_generated_recipe_tokens_match_the_prepare_script():
     src = open(p).read()
     assert 'fout.write("|\\n")' in src and "fout.write(\"'\\n\")" in src and 'range(ord("a"), ord("z") + 1)' in src
     assert '"{word}\\t{tokens} |\\n"' in src          # the lexicon line format load_lexicon parses
+
+
+def test_cpp_header_mirror_compiles_and_agrees(tmp_path):
+    """include/fl_compat/text.h (the same logic on the reference's C++ names) through tests/cpp/text_test.cpp: plain g++, no
+    device code -- the worked examples of this file, asserted in C++"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "text_test")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", os.path.join(root, "tests", "cpp", "text_test.cpp"), "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, check=True)
+    assert "text ok" in out.stdout
