@@ -60,6 +60,32 @@ class Dictionary {
   std::vector<std::string> idx2entry_;
 };
 
+// word -> spellings (token strings), in file order: `word<TAB or space>tok tok ...`, one spelling per line
+using LexiconMap = std::unordered_map<std::string, std::vector<std::vector<std::string>>>;
+
+inline LexiconMap loadWordsFromLines(const std::vector<std::string>& lines, int maxSpellings = 0) {
+  LexiconMap lex;
+  for (auto& line : lines) {
+    std::istringstream ss(line);
+    std::string word, tok;
+    if (!(ss >> word)) continue;
+    std::vector<std::string> sp;
+    while (ss >> tok) sp.push_back(tok);
+    if (sp.empty()) continue;
+    auto& all = lex[word];
+    if (std::find(all.begin(), all.end(), sp) == all.end() && (maxSpellings <= 0 || (int)all.size() < maxSpellings)) all.push_back(sp);
+  }
+  return lex;
+}
+inline LexiconMap loadWords(const std::string& path, int maxSpellings = 0) {
+  std::ifstream f(path);
+  if (!f) throw std::runtime_error("loadWords: cannot open " + path);
+  std::vector<std::string> lines;
+  std::string line;
+  while (std::getline(f, line)) lines.push_back(line);
+  return loadWordsFromLines(lines, maxSpellings);
+}
+
 }  // namespace text
 }  // namespace lib
 
@@ -77,6 +103,44 @@ inline lib::text::Dictionary createTokenDict(lib::text::Dictionary d, const std:
   for (int r = 1; r <= replabel; ++r) d.addEntry(replabelToken(r));
   if (criterion == kCtcCriterion) d.addEntry(kBlankToken);
   return d;
+}
+
+// UTF-8 code points of a token
+inline std::vector<std::string> splitWrd(const std::string& w) {
+  std::vector<std::string> out;
+  for (size_t i = 0; i < w.size();) {
+    const unsigned char c = (unsigned char)w[i];
+    const size_t n = c < 0x80 ? 1 : (c >> 5) == 0x6 ? 2 : (c >> 4) == 0xE ? 3 : (c >> 3) == 0x1E ? 4 : 1;
+    out.push_back(w.substr(i, n));
+    i += n;
+  }
+  return out;
+}
+
+// transcription words -> token strings: the first spelling of the lexicon; an out-of-lexicon word falls back to its letters
+// (word separator on the chosen sides) when every letter is a token, else it is skipped (skipUnk) or an error
+inline std::vector<std::string> wrd2Target(const std::vector<std::string>& words, const lib::text::LexiconMap& lexicon,
+                                           const lib::text::Dictionary& dict, const std::string& wordSeparator = "",
+                                           bool fallback2LtrWordSepLeft = false, bool fallback2LtrWordSepRight = true,
+                                           bool skipUnk = false) {
+  std::vector<std::string> out;
+  for (auto& w : words) {
+    auto it = lexicon.find(w);
+    if (it != lexicon.end() && !it->second.empty()) {
+      out.insert(out.end(), it->second.front().begin(), it->second.front().end());
+      continue;
+    }
+    auto letters = splitWrd(w);
+    const bool spellable = std::all_of(letters.begin(), letters.end(), [&](const std::string& c) { return dict.contains(c); });
+    if (spellable) {
+      if (fallback2LtrWordSepLeft && !wordSeparator.empty()) out.push_back(wordSeparator);
+      out.insert(out.end(), letters.begin(), letters.end());
+      if (fallback2LtrWordSepRight && !wordSeparator.empty()) out.push_back(wordSeparator);
+    } else if (!skipUnk) {
+      throw std::invalid_argument("wrd2Target: word '" + w + "' is not in the lexicon and cannot be spelled with the token set");
+    }
+  }
+  return out;
 }
 
 // `a a a b` -> `a <2> b`: a run becomes the token + the replabel counting the EXTRA repetitions
@@ -110,19 +174,16 @@ inline std::vector<int> unpackReplabels(const std::vector<int>& tokens, const li
   return out;
 }
 
-inline void uniq(std::vector<int>& v) { v.erase(std::unique(v.begin(), v.end()), v.end()); }
-
-// UTF-8 code points of a token
-inline std::vector<std::string> splitWrd(const std::string& w) {
-  std::vector<std::string> out;
-  for (size_t i = 0; i < w.size();) {
-    const unsigned char c = (unsigned char)w[i];
-    const size_t n = c < 0x80 ? 1 : (c >> 5) == 0x6 ? 2 : (c >> 4) == 0xE ? 3 : (c >> 3) == 0x1E ? 4 : 1;
-    out.push_back(w.substr(i, n));
-    i += n;
-  }
-  return out;
+// one transcription -> the int32 target row of the criterion (before -1 padding)
+inline std::vector<int> targetIndices(const std::vector<std::string>& words, const lib::text::LexiconMap& lexicon,
+                                      const lib::text::Dictionary& dict, const std::string& criterion, int replabel,
+                                      const std::string& wordSeparator) {
+  std::vector<int> idx;
+  for (auto& t : wrd2Target(words, lexicon, dict, wordSeparator)) idx.push_back(dict.getIndex(t));
+  return criterion == kAsgCriterion && replabel > 0 ? packReplabels(idx, dict, replabel) : idx;
 }
+
+inline void uniq(std::vector<int>& v) { v.erase(std::unique(v.begin(), v.end()), v.end()); }
 
 inline std::vector<std::string> tknIdx2Ltr(const std::vector<int>& labels, const lib::text::Dictionary& d, bool useWordPiece,
                                            const std::string& wordSep) {

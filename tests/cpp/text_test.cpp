@@ -55,6 +55,17 @@ int main() {
   ter.add(ltr, lt);
   wer.add(tkn2Wrd(ltr, "_"), tkn2Wrd(lt, "_"));
   assert(ter.errors() == 1 && ter.length() == 7 && wer.errors() == 1 && wer.length() == 2 && wer.value() == 50.0);
+  // lexicon + target generation
+  auto lex = fl::lib::text::loadWordsFromLines({"hello\th e l l o |", "aaa\ta a a |", "bee\tb e e |", "bee\tb e |"});
+  assert(lex["bee"].size() == 2 && lex["bee"][1].size() == 3);
+  assert((names(targetIndices({"hello", "aaa"}, lex, asg, "asg", 2, "|"), asg) ==
+          std::vector<std::string>{"h", "e", "l", "<1>", "o", "|", "a", "<2>", "|"}));
+  assert(targetIndices({"hello", "aaa"}, lex, asg, "ctc", 0, "|") == idx("hello|aaa|"));
+  assert(targetIndices({"zed"}, lex, asg, "ctc", 0, "|") == idx("zed|"));                     // out of lexicon: letters + separator
+  bool threw = false;
+  try { targetIndices({"z3d"}, lex, asg, "ctc", 0, "|"); } catch (const std::invalid_argument&) { threw = true; }
+  assert(threw);
+  assert(wrd2Target({"z3d", "bee"}, lex, asg, "|", false, true, true) == chars("bee|"));
   // UTF-8 code points
   assert((splitWrd("a\xC3\xA9z") == std::vector<std::string>{"a", "\xC3\xA9", "z"}));
   std::printf("text ok\n");
