@@ -93,3 +93,16 @@ def test_read_audio_wav_and_raw_and_batch_padding(tmp_path):
         data.read_audio(str(tmp_path / "x.flac"))
     batch, sizes = data.pad_batch([a, a[:700]])
     assert batch.shape == (2, 1600) and list(sizes) == [1600.0, 700.0] and (batch[1, 700:] == 0).all()
+
+
+def test_cpp_header_mirror_of_list_and_partitioning(tmp_path):
+    """include/fl_compat/data.h through tests/cpp/data_test.cpp (g++, no device code); the worked partition below is checked
+    against the Python implementation too"""
+    import os
+    import subprocess
+    from wav2letter_amd import data
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "data_test")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", os.path.join(root, "tests", "cpp", "data_test.cpp"), "-o", exe], check=True)
+    assert "data ok" in subprocess.run([exe], capture_output=True, text=True, check=True).stdout
+    assert data.partition_round_robin(20, 1, 2, 4) == [4, 5, 6, 7, 12, 13, 14, 15, 18, 19]
