@@ -29,35 +29,41 @@ struct BgOperand {
 
 struct BgRegs { float v[4]; };
 
-// 64 x 16 tile of an operand -> registers.  Two thread maps: k contiguous (4 k of one row per thread) or row contiguous
-// (4 rows of one k per thread); anything else takes the k map with two strides.
+// operand access modes, fixed per launch (template parameters: the tile loop has no mode branches)
+constexpr int kBgRowVec = 0;   // the 64-wide tile dimension is contiguous: one float4 of 4 rows per thread (k = tid / 16)
+constexpr int kBgKVec = 1;     // k is contiguous: one float4 of 4 k per thread (row = tid / 4)
+constexpr int kBgGeneric = 2;  // anything else, or extents / alignment that forbid float4: four bounds-checked scalar loads
+
+// 64 x 16 tile of an operand -> registers
+template <int MODE>
 __device__ __forceinline__ BgRegs bg_load(const BgOperand& o, int tid, int rv, int k0, int K) {
   BgRegs r;
-  if (o.sR == 1) {
+  if (MODE == kBgRowVec) {
+    const int k = k0 + (tid >> 4), rq = (tid & 15) * 4;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    if (k < K && rq < rv) t = *(const f32x4*)(o.p + (long long)k * o.sK + rq);   // extents are multiples of 4
+    r.v[0] = t[0]; r.v[1] = t[1]; r.v[2] = t[2]; r.v[3] = t[3];
+  } else if (MODE == kBgKVec) {
+    const int row = tid >> 2, k = k0 + (tid & 3) * 4;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    if (row < rv && k < K) t = *(const f32x4*)(o.p + (long long)row * o.sR + k);
+    r.v[0] = t[0]; r.v[1] = t[1]; r.v[2] = t[2]; r.v[3] = t[3];
+  } else if (o.sR == 1) {
     const int k = k0 + (tid >> 4), rq = (tid & 15) * 4;
     const float* src = o.p + (long long)k * o.sK + rq;
-    if (o.vec && k < K && rq < rv) {
-      f32x4 t = *(const f32x4*)src;
-      r.v[0] = t[0]; r.v[1] = t[1]; r.v[2] = t[2]; r.v[3] = t[3];
-    } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) r.v[i] = (k < K && rq + i < rv) ? src[i] : 0.f;
-    }
+    for (int i = 0; i < 4; ++i) r.v[i] = (k < K && rq + i < rv) ? src[i] : 0.f;
   } else {
     const int row = tid >> 2, k = k0 + (tid & 3) * 4;
     const float* src = o.p + (long long)row * o.sR + (long long)k * o.sK;
-    if (o.vec && o.sK == 1 && row < rv && k < K) {
-      f32x4 t = *(const f32x4*)src;
-      r.v[0] = t[0]; r.v[1] = t[1]; r.v[2] = t[2]; r.v[3] = t[3];
-    } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) r.v[i] = (row < rv && k + i < K) ? src[(long long)i * o.sK] : 0.f;
-    }
+    for (int i = 0; i < 4; ++i) r.v[i] = (row < rv && k + i < K) ? src[(long long)i * o.sK] : 0.f;
   }
   return r;
 }
+template <int MODE>
 __device__ __forceinline__ void bg_store(const BgOperand& o, int tid, const BgRegs& r, float (*s)[kBgPitch]) {
-  if (o.sR == 1) {
+  if (MODE == kBgRowVec || (MODE == kBgGeneric && o.sR == 1)) {
     f32x4 t = {r.v[0], r.v[1], r.v[2], r.v[3]};
     *(f32x4*)&s[tid >> 4][(tid & 15) * 4] = t;
   } else {
@@ -74,6 +80,7 @@ struct BgP {
   int accumulate;
 };
 
+template <int AM, int BM>
 __global__ __launch_bounds__(256) void bgemm_k(BgP p) {
   __shared__ __attribute__((aligned(16))) float As[2][kBgK][kBgPitch];
   __shared__ __attribute__((aligned(16))) float Bs[2][kBgK][kBgPitch];
@@ -89,23 +96,23 @@ __global__ __launch_bounds__(256) void bgemm_k(BgP p) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   const int nk = (p.K + kBgK - 1) / kBgK;
-  BgRegs ra = bg_load(a, tid, mv, 0, p.K), rb = bg_load(b, tid, nv, 0, p.K);
-  bg_store(a, tid, ra, As[0]);
-  bg_store(b, tid, rb, Bs[0]);
+  BgRegs ra = bg_load<AM>(a, tid, mv, 0, p.K), rb = bg_load<BM>(b, tid, nv, 0, p.K);
+  bg_store<AM>(a, tid, ra, As[0]);
+  bg_store<BM>(b, tid, rb, Bs[0]);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nk;
     if (more) {
-      ra = bg_load(a, tid, mv, (kt + 1) * kBgK, p.K);
-      rb = bg_load(b, tid, nv, (kt + 1) * kBgK, p.K);
+      ra = bg_load<AM>(a, tid, mv, (kt + 1) * kBgK, p.K);
+      rb = bg_load<BM>(b, tid, nv, (kt + 1) * kBgK, p.K);
     }
 #pragma unroll
     for (int kk = 0; kk < kBgK / 2; ++kk)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[cur][2 * kk + lh][wm + li], Bs[cur][2 * kk + lh][wn + li], acc, 0, 0, 0);
     if (more) {
-      bg_store(a, tid, ra, As[cur ^ 1]);
-      bg_store(b, tid, rb, Bs[cur ^ 1]);
+      bg_store<AM>(a, tid, ra, As[cur ^ 1]);
+      bg_store<BM>(b, tid, rb, Bs[cur ^ 1]);
     }
     __syncthreads();
   }
@@ -274,7 +281,22 @@ W2L_API int w2l_bgemm_f32(const w2l_bgemm_desc* d, const float* A, const float* 
   p.accumulate = d->accumulate;
   const long long tiles = (long long)((d->M + 63) / 64) * p.tilesN;
   if (tiles > 0x7fffffffLL) return W2L_EINVAL;
-  hipLaunchKernelGGL(bgemm_k, dim3((unsigned)tiles, (unsigned)(d->G1 * d->G2)), dim3(256), 0, W2L_S, p);
+  const int am = !p.A.vec ? kBgGeneric : (d->sam == 1 ? kBgRowVec : kBgKVec);
+  const int bm = !p.B.vec ? kBgGeneric : (d->sbn == 1 ? kBgRowVec : kBgKVec);
+  const dim3 grid((unsigned)tiles, (unsigned)(d->G1 * d->G2));
+#define W2L_BG(AMv, BMv) hipLaunchKernelGGL((bgemm_k<AMv, BMv>), grid, dim3(256), 0, W2L_S, p)
+  switch (am * 3 + bm) {
+    case 0: W2L_BG(0, 0); break;
+    case 1: W2L_BG(0, 1); break;
+    case 2: W2L_BG(0, 2); break;
+    case 3: W2L_BG(1, 0); break;
+    case 4: W2L_BG(1, 1); break;
+    case 5: W2L_BG(1, 2); break;
+    case 6: W2L_BG(2, 0); break;
+    case 7: W2L_BG(2, 1); break;
+    default: W2L_BG(2, 2); break;
+  }
+#undef W2L_BG
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }
