@@ -13,6 +13,30 @@ def relu(x):
     return np.maximum(x, 0)
 
 
+def bf16_round(a):
+    """fp32 -> nearest bf16 (ties to even, what v_cvt_pk_bf16_f32 does) -> fp32: the value a bf16 GEMM operand carries"""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u >> 16) & 1) + 0x7FFF
+    return ((u + r) & 0xFFFF0000).astype(np.uint32).view(np.float32).reshape(np.shape(a))
+
+
+def lin_fwd(x, w, b, bf16=False):
+    """fl::Linear forward; bf16: both GEMM operands rounded to bf16 (fp32 accumulate, fp32 bias and result) -- the
+    arithmetic of the mixed-precision mode (fl's AMP casts the operands of linear / conv, cpc/Train.cpp:1184 keeps the
+    criterion input f32)"""
+    if bf16:
+        return O.linear_fwd(bf16_round(x), bf16_round(w), b)
+    return O.linear_fwd(x, w, b)
+
+
+def lin_bwd(x, w, dy, bf16=False):
+    """(dx, dw, db); bf16: dx = bf(dy) bf(w)^T, dw = bf(x)^T bf(dy), db = column sums of the UNROUNDED dy"""
+    if bf16:
+        dx, dw, _ = O.linear_bwd(bf16_round(x), bf16_round(w), bf16_round(dy))
+        return dx, dw, np.asarray(dy, np.float64).sum(axis=0).astype(np.float32)
+    return O.linear_bwd(x, w, dy)
+
+
 def ln_fwd(x, mode, gamma=1.0, beta=0.0, eps=1e-5, streaming=False):
     """x [B][C][H][T]; mode 'all' = LN axes {0,1,2} (per utterance), 'frame' = {1,2} (per frame)."""
     B, Cc, H, T = x.shape
@@ -61,14 +85,14 @@ class TDSParams:
         self.g2 = np.float32(1.0 + 0.1 * rng.normal()); self.b2n = np.float32(0.1 * rng.normal())
 
 
-def tds_fwd(x, p, padl, padr, ln_mode="all", streaming=False, eps=1e-5, keep=False):
+def tds_fwd(x, p, padl, padr, ln_mode="all", streaming=False, eps=1e-5, keep=False, bf16=False):
     B, Cc, H, T = x.shape
     a = O.conv_fwd(x, p.wc, p.bc, 1, padl, padr)
     r = relu(a) + x
     y = ln_fwd(r, ln_mode, float(p.g1), float(p.b1n), eps, streaming)
     z = to_frames(y)
-    u = O.linear_fwd(z, p.w1, p.b1)
-    v = O.linear_fwd(relu(u), p.w2, p.b2)
+    u = lin_fwd(z, p.w1, p.b1, bf16)
+    v = lin_fwd(relu(u), p.w2, p.b2, bf16)
     s = from_frames(v, B, Cc, H, T) + y
     out = ln_fwd(s, ln_mode, float(p.g2), float(p.b2n), eps, streaming)
     if keep:
@@ -76,7 +100,7 @@ def tds_fwd(x, p, padl, padr, ln_mode="all", streaming=False, eps=1e-5, keep=Fal
     return out
 
 
-def tds_bwd(dout, p, saved, padl, padr, ln_mode="all", eps=1e-5):
+def tds_bwd(dout, p, saved, padl, padr, ln_mode="all", eps=1e-5, bf16=False):
     """returns dx and a dict of parameter grads"""
     x, a, r, y, z, u, s = (saved[k] for k in "x a r y z u s".split())
     B, Cc, H, T = x.shape
@@ -84,9 +108,9 @@ def tds_bwd(dout, p, saved, padl, padr, ln_mode="all", eps=1e-5):
     ds, g["g2"], g["b2n"] = ln_bwd(s, dout, ln_mode, float(p.g2), eps)
     dy = ds.copy()
     dv = to_frames(ds)
-    dru, g["w2"], g["b2"] = O.linear_bwd(relu(u), p.w2, dv)
+    dru, g["w2"], g["b2"] = lin_bwd(relu(u), p.w2, dv, bf16)
     du = dru * (u > 0)
-    dz, g["w1"], g["b1"] = O.linear_bwd(z, p.w1, du)
+    dz, g["w1"], g["b1"] = lin_bwd(z, p.w1, du, bf16)
     dy += from_frames(dz, B, Cc, H, T)
     dr, g["g1"], g["b1n"] = ln_bwd(r, dy, ln_mode, float(p.g1), eps)
     da = dr * (a > 0)
@@ -101,7 +125,10 @@ def tds_bwd(dout, p, saved, padl, padr, ln_mode="all", eps=1e-5):
 #   conv w [cout][cin][kw], conv b [cout], linear W [in][out], b [out], LN (gamma, beta) pair,
 #   WeightNorm: v (as the wrapped weight), g [nout], (bias)
 class RefNet:
-    def __init__(self, arch_text, nfeat, nlabel):
+    def __init__(self, arch_text, nfeat, nlabel, bf16=False):
+        """bf16: every fl::Linear (stand-alone `L` lines and the two inside a TDS block) multiplies bf16-rounded operands
+        -- the reference side of the mixed-precision parity tests (BASELINE config 3)"""
+        self.bf16 = bf16
         self.lines = []
         for raw in arch_text.splitlines():
             l = raw.strip()
@@ -186,6 +213,14 @@ class RefNet:
                 wn_dim, t = int(t[1]), t[2:]
             if t[0] == "SAUG":
                 continue
+            if t[0] == "PD":
+                # fl::Padding(val, {l0, r0}, ...) on ArrayFire dim 0 = time (streaming arch: asymmetric padding ahead of an
+                # unpadded convolution, am_500ms_future_context.arch:3)
+                assert float(t[1]) == 0.0 and all(int(v) == 0 for v in t[4:]), t
+                l0, r0 = int(t[2]), int(t[3])
+                self.tape.append(("PD", l0, a.shape[3]))
+                a = np.ascontiguousarray(np.pad(a, ((0, 0), (0, 0), (0, 0), (l0, r0))))
+                continue
             if t[0] == "V":
                 dims = [int(v) for v in t[1:5]]
                 cur = list(a.shape[::-1])
@@ -243,7 +278,7 @@ class RefNet:
                 assert shp[3] == nin, (shp, nin)
                 z = np.ascontiguousarray(a).reshape(-1, nin)
                 self.tape.append(("L", z, w, v, g, shp, pi))
-                a = O.linear_fwd(z, w, b).reshape(shp[:3] + (nout,))
+                a = lin_fwd(z, w, b, self.bf16).reshape(shp[:3] + (nout,))
             elif t[0] == "R":
                 self.tape.append(("R", a))
                 a = relu(a)
@@ -279,7 +314,7 @@ class RefNet:
                 else:
                     pr, pl = rpad, kw - 1 - rpad
                 mode = "frame" if (len(t) > 7 and int(t[7]) == 0) else "all"
-                out, saved = tds_fwd(a, p, pl, pr, mode, keep=True)
+                out, saved = tds_fwd(a, p, pl, pr, mode, keep=True, bf16=self.bf16)
                 self.tape.append(("TDS", p, saved, pl, pr, mode, pi))
                 a = out
             elif t[0] == "M":
@@ -323,7 +358,9 @@ class RefNet:
         da = d_em[None]
         for rec in reversed(self.tape):
             k = rec[0]
-            if k == "V":
+            if k == "PD":
+                da = np.ascontiguousarray(da[..., rec[1]:rec[1] + rec[2]])
+            elif k == "V":
                 da = np.ascontiguousarray(da).reshape(rec[1])
             elif k == "RO":
                 inv = np.argsort(rec[1])
@@ -353,7 +390,7 @@ class RefNet:
                 da = dp[:, :, ph:ph + H_]
             elif k == "L":
                 _, z, w, v, gg, shp, pi = rec
-                dz, dw, db = O.linear_bwd(z, w, np.ascontiguousarray(da).reshape(z.shape[0], -1))
+                dz, dw, db = lin_bwd(z, w, np.ascontiguousarray(da, dtype=np.float32).reshape(z.shape[0], -1), self.bf16)
                 g[pi - 1] = db
                 if gg is not None:
                     dv, dg = O.weightnorm_bwd(v, gg, dw, v.shape[0], v.shape[1], 1)
@@ -389,7 +426,7 @@ class RefNet:
                     g[pi - len(pt) + j] = gj.numpy().astype(np.float32)
             elif k == "TDS":
                 _, p, saved, pl, pr, mode, pi = rec
-                da, gg = tds_bwd(np.ascontiguousarray(da, dtype=np.float32), p, saved, pl, pr, mode)
+                da, gg = tds_bwd(np.ascontiguousarray(da, dtype=np.float32), p, saved, pl, pr, mode, bf16=self.bf16)
                 base = pi - 8
                 g[base], g[base + 1] = gg["wc"], gg["bc"]
                 g[base + 2] = np.array([gg["g1"], gg["b1n"]], np.float32)

@@ -46,6 +46,10 @@ class TorchNet:
             k = t[0]
             if k in ("SAUG",):
                 continue
+            if k == "PD":   # zero padding of the time axis ahead of an unpadded convolution (streaming arch)
+                assert float(t[1]) == 0.0 and all(int(v) == 0 for v in t[4:]), t
+                a = F.pad(a, (int(t[2]), int(t[3])))
+                continue
             if k == "V":
                 dims = [int(v) for v in t[1:5]]
                 cur = list(a.shape[::-1])

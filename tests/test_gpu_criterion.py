@@ -65,7 +65,7 @@ def test_wave_ops_selftest():
 
 
 @pytest.mark.parametrize("B,T,N", [(3, 1, 2), (2, 2, 5), (3, 9, 30), (2, 50, 33), (2, 17, 64), (4, 301, 30)])
-@pytest.mark.parametrize("mode", [0, 4])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 def test_fcc_matches_oracle(oracle, B, T, N, mode):
     from wav2letter_amd import FullConnectionCriterion
     rng = np.random.default_rng(B * 1000 + T * 10 + N)
@@ -89,7 +89,7 @@ def test_fcc_matches_oracle(oracle, B, T, N, mode):
 
 @pytest.mark.parametrize("B,T,N,L", [(3, 6, 4, 3), (2, 40, 30, 40), (3, 90, 30, 70), (2, 300, 28, 200),
                                       (2, 400, 30, 300), (2, 120, 100, 64), (2, 50, 1500, 20)])
-@pytest.mark.parametrize("mode", [0, 4])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 def test_fac_matches_oracle(oracle, B, T, N, L, mode):
     from wav2letter_amd import ForceAlignmentCriterion
     rng = np.random.default_rng(L * 7 + T)
@@ -186,7 +186,7 @@ def test_viterbi_full_size_bit_exact(oracle):
 
 @pytest.mark.parametrize("B,T,N,L", [(3, 8, 3, 4), (4, 30, 29, 10), (2, 50, 1000, 40), (3, 64, 9998, 80),
                                       (2, 300, 50, 140), (2, 20, 12290, 5)])
-@pytest.mark.parametrize("mode", [0, 4])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 def test_ctc_matches_oracle(oracle, B, T, N, L, mode):
     from wav2letter_amd import CTCLoss
     rng = np.random.default_rng(N + L)
@@ -206,6 +206,37 @@ def test_ctc_matches_oracle(oracle, B, T, N, L, mode):
     assert relerr(loss.detach().cpu().numpy(), ol) < TOL
     assert gradrel(xt.grad.cpu().numpy(), odx) < TOL
     assert (crit.viterbiPath(dev(x)).cpu().numpy() == oracle.ctc_viterbi(x)).all()
+
+
+@pytest.mark.parametrize("B,T,N,L", [(2, 700, 40, 300), (3, 640, 29, 256), (2, 1300, 30, 600), (2, 1100, 12, 1023)])
+def test_ctc_long_transcriptions(oracle, B, T, N, L):
+    """letter-level CTC recipes have transcriptions longer than 255 labels (round 2 refused 2L+1 > 512): 16 / 32 label
+    positions per lane, up to L = 1023; every utterance of the batch uses (nearly) the whole target width, one has
+    repeats that need the blank between them"""
+    from wav2letter_amd import CTCLoss
+    rng = np.random.default_rng(L)
+    x = (rng.normal(size=(B, T, N)) * 2).astype(np.float32)
+    tgt = make_targets(rng, B, L, N, T, min_len=L - 3, hi=N - 1)
+    tgt[0, :L] = rng.integers(0, N - 1, size=L)
+    tgt[0, 10:14] = [1, 1, 1, 0]
+    w = rng.normal(size=B).astype(np.float32)
+    crit = CTCLoss(4)
+    xt = dev(x).requires_grad_(True)
+    loss = crit(xt, dev(tgt))
+    (loss * dev(w)).sum().backward()
+    o = oracle.CTC(x, tgt, scale_mode=4)
+    ol = o.forward()
+    assert np.isfinite(ol).all()
+    assert relerr(loss.detach().cpu().numpy(), ol) < TOL
+    assert gradrel(xt.grad.cpu().numpy(), o.backward(w.astype(np.float64))) < TOL
+
+
+def test_ctc_refuses_more_than_1023_labels():
+    from wav2letter_amd import CTCLoss
+    from wav2letter_amd._lib import W2LError
+    x = torch.zeros(1, 1100, 5, device="cuda")
+    with pytest.raises(W2LError, match="UNSUPPORTED"):
+        CTCLoss()(x, torch.zeros(1, 1024, dtype=torch.int32, device="cuda"))
 
 
 def test_ctc_target_longer_than_input_is_truncated(oracle):
@@ -287,7 +318,7 @@ def test_criterion_timings_report():
 # large label sets (N > 64): criterion_fcc_big.hip -- packed-transition streaming MFMA recursion
 # ----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,T,N", [(3, 1, 70), (2, 7, 100), (5, 12, 257), (33, 5, 130), (70, 4, 96), (2, 30, 1000)])
-@pytest.mark.parametrize("mode", [0, 4])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 def test_fcc_large_n_matches_oracle(oracle, B, T, N, mode):
     from wav2letter_amd import FullConnectionCriterion
     rng = np.random.default_rng(B * 1000 + T * 10 + N)

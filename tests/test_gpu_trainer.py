@@ -920,6 +920,86 @@ def test_mixed_precision_streaming_tds_step(oracle):
     assert np.isfinite(losses).all() and losses[-1] < 0.8 * losses[0], losses
 
 
+def _streaming_arch_no_dropout():
+    import re
+    from wav2letter_amd import recipes
+    arch = re.sub(r"(TDS \d+ \d+ \d+) [0-9.]+", r"\1 0.0", recipes.streaming_tds_arch())
+    arch = "\n".join(l for l in arch.splitlines() if not l.startswith("SAUG")) + "\n"
+    return re.sub(r"^DO [0-9.]+$", "DO 0.0", arch, flags=re.M)
+
+
+def test_streaming_tds_config3_full_network_end_to_end(oracle):
+    """BASELINE config 3 in fp32 -- the full streaming_convnets recipe network (am_500ms_future_context.arch: `PD`
+    asymmetric padding, unpadded strided C2, per-frame LayerNorm, 16 TDS blocks with 15 / 19 / 23 / 27 channels and a
+    right padding, 115.1 M parameters, 9998 word pieces) -- at a reduced batch and number of frames, dropout and
+    SpecAugment off: emissions, CTC loss and every parameter gradient against the numpy reference network
+    (oracle/refnet.py, itself held to torch autograd on this arch by tests/test_oracle_nn.py) + the CTC oracle."""
+    rng = np.random.default_rng(31)
+    nfeat, nlabel, B, T, L = 80, 9998, 2, 160, 6
+    arch = _streaming_arch_no_dropout()
+    tr, ref, params, _ = build(arch, nfeat, nlabel, "ctc", 4, 0.0, rng, B, T, L)
+    x = rng.normal(size=(B, 1, nfeat, T)).astype(np.float32)
+    tgt = np.full((B, L), -1, np.int32)
+    tgt[0, :6] = [17, 4021, 9996, 3, 3, 77]
+    tgt[1, :2] = [9000, 12]
+    xd = torch.tensor(x.reshape(B, nfeat, T)).cuda()
+    td = torch.tensor(tgt).cuda()
+    em = tr.forward(xd, train=False).cpu().numpy()
+    em_ref = ref.forward(x, params)
+    assert em.shape == em_ref.shape == (B, 20, nlabel)
+    assert rel(em, em_ref) < TOL
+    loss = tr.forward_backward(xd, td).cpu().numpy()
+    o = oracle.CTC(em_ref, tgt, scale_mode=4)
+    assert rel(loss, o.forward()) < TOL
+    n_strict, n = check_grads_relu_robust(tr, ref.backward(o.backward().astype(np.float32), len(params)))
+    assert n_strict >= 2      # the final Linear has no ReLU kink between itself and the loss
+
+
+def test_streaming_tds_config3_bf16_against_bf16_operand_oracle(oracle):
+    """BASELINE config 3 in its mixed-precision mode against the ORACLE (not against the fp32 HIP step): the reference
+    network with every fl::Linear multiplying bf16-ROUNDED operands (refnet.RefNet(bf16=True): x, w, dy rounded to nearest
+    even, fp32 accumulation, fp32 bias / LayerNorm / convolutions / criterion -- cpc/Train.cpp:1184 keeps the criterion
+    input f32).  Emissions and loss within the stated bf16 tolerance 1e-2 of the largest reference magnitude; parameter
+    gradients in direction and size.  A rounding boundary crossed on one side only (an activation that rounds up here and
+    down there because the fp32 values differ in the last bit) moves a product by 2^-8 relative: hence 1e-2, not 1e-4."""
+    rng = np.random.default_rng(32)
+    nfeat, nlabel, B, T, L = 80, 9998, 2, 160, 6
+    arch = _streaming_arch_no_dropout()
+    tr, _, params, _ = build(arch, nfeat, nlabel, "ctc", 4, 0.0, rng, B, T, L)
+    tr.set_mixed_precision(True)
+    ref = refnet.RefNet(arch, nfeat, nlabel, bf16=True)
+    ref32 = refnet.RefNet(arch, nfeat, nlabel)
+    x = rng.normal(size=(B, 1, nfeat, T)).astype(np.float32)
+    tgt = np.full((B, L), -1, np.int32)
+    tgt[0, :4] = [5, 5, 9000, 1]
+    tgt[1, :6] = [1, 2, 3, 4, 5, 6]
+    xd = torch.tensor(x.reshape(B, nfeat, T)).cuda()
+    td = torch.tensor(tgt).cuda()
+    em = tr.forward(xd, train=False).cpu().numpy()
+    em_ref = ref.forward(x, params)
+    em_32 = ref32.forward(x, params)
+    BF16_TOL = 1e-2
+    assert rel(em, em_ref) < BF16_TOL
+    # the bf16 path really ran, and it is closer to the bf16-operand oracle than the fp32 oracle is
+    assert rel(em, em_32) > 1e-5 and rel(em, em_ref) <= rel(em_32, em_ref) * 1.5 + 1e-4
+    loss = tr.forward_backward(xd, td).cpu().numpy()
+    o = oracle.CTC(em_ref, tgt, scale_mode=4)
+    assert rel(loss, o.forward()) < BF16_TOL
+    ref_grads = ref.backward(o.backward().astype(np.float32), len(params))
+    g = tr.grads.cpu().numpy()
+    table = tr.param_table()
+    for i, want in enumerate(ref_grads):
+        got = np.asarray(tr.export_from(i, g), np.float64).reshape(-1)
+        w = np.asarray(want, np.float64).reshape(-1)
+        assert np.isfinite(got).all()
+        if w.size <= 2:
+            continue   # LayerNorm (gain, offset): two sums over every activation with heavy cancellation
+        l2 = np.linalg.norm(got - w) / max(1e-30, np.linalg.norm(w))
+        cos = float(got @ w) / max(1e-30, np.linalg.norm(got) * np.linalg.norm(w))
+        lim = (0.1, 0.99) if w.size > 64 else (0.25, 0.97)
+        assert l2 < lim[0] and cos > lim[1], (i, table[i][0], l2, cos)
+
+
 def test_linseg_phase_has_its_own_momentum():
     """the reference trains the --linseg warm-up with separate optimizers (linNetoptim / linCritoptim, Train.cpp:589-617):
     the first ASG update starts from ZERO momentum, not from the warm-up's"""

@@ -205,6 +205,27 @@ def test_ctc_vs_torch(oracle, seed):
     assert np.allclose(dx, xt.grad.numpy(), atol=1e-8)
 
 
+def test_ctc_long_transcription_vs_torch(oracle):
+    """the oracle at transcriptions longer than 255 labels (the shapes tests/test_gpu_criterion.py::test_ctc_long_transcriptions
+    holds the HIP scan to) against torch's ctc_loss, loss and gradient"""
+    rng = np.random.default_rng(77)
+    B, T, N, L = 2, 700, 40, 300
+    x = (rng.normal(size=(B, T, N)) * 2).astype(np.float32)
+    tgt = rng.integers(0, N - 1, size=(B, L)).astype(np.int32)
+    tgt[0, 10:14] = [1, 1, 1, 0]
+    ctc = oracle.CTC(x, tgt)
+    loss = ctc.forward()
+    w = rng.normal(size=B)
+    dx = ctc.backward(w)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    lp = torch.log_softmax(xt, -1).transpose(0, 1)
+    ref = torch.nn.functional.ctc_loss(lp, torch.tensor(tgt, dtype=torch.long), torch.full((B,), T), torch.full((B,), L),
+                                       blank=N - 1, reduction="none")
+    assert np.allclose(loss, ref.detach().numpy(), rtol=1e-10, atol=1e-7)
+    (ref * torch.tensor(w)).sum().backward()
+    assert np.allclose(dx, xt.grad.numpy(), atol=1e-8)
+
+
 def test_ctc_target_truncation(oracle):
     # L + repeats > T: target size is reduced to what fits (App. B.0)
     tgt = np.array([[1, 1, 1, 1, -1]], np.int32)

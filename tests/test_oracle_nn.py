@@ -410,3 +410,53 @@ def test_transformer_block_golden_vector_oracle_side():
     net.input_sizes = np.array(g["input_sizes"], np.float32)
     em = net.forward(np.ascontiguousarray(x.transpose(0, 2, 1))[:, None], params)
     assert np.abs(em.reshape(-1) - np.array(g["y_masked"], np.float32)).max() < 1e-5
+
+
+def test_streaming_arch_reference_interpreter_against_torch(oracle):
+    """BASELINE config 3's arch (am_500ms_future_context.arch: `PD` asymmetric padding ahead of unpadded strided
+    convolutions, per-frame LayerNorm, TDS blocks with a right padding and lNormIncludeTime = 0, the V / RO tail) through
+    oracle/refnet.RefNet against torch autograd (oracle/torchnet.py): emissions and every parameter gradient.  Pins the
+    reference side of tests/test_gpu_trainer.py::test_streaming_tds_config3_full_network_end_to_end."""
+    import re
+    from oracle import torchnet
+    from wav2letter_amd import recipes
+    arch = re.sub(r"(TDS \d+ \d+ \d+) [0-9.]+", r"\1 0.0", recipes.streaming_tds_arch())
+    arch = "\n".join(l for l in arch.splitlines() if not l.startswith("SAUG")) + "\n"
+    arch = re.sub(r"^DO [0-9.]+$", "DO 0.0", arch, flags=re.M)
+    nfeat, nlabel, B, T = 80, 50, 2, 96
+    rng = np.random.default_rng(8)
+    ref = refnet.RefNet(arch, nfeat, nlabel)
+    params = ref.random_params(rng)
+    x = rng.normal(size=(B, 1, nfeat, T)).astype(np.float32)
+    em = ref.forward(x, params)
+    assert em.shape == (B, 12, nlabel)          # 96 -> 48 -> 24 -> 12 -> 12 frames
+    tp = [torch.from_numpy(p.copy()).requires_grad_(True) for p in params]
+    tem = torchnet.TorchNet(arch, nfeat, nlabel).forward(torch.from_numpy(x), tp)
+    assert tem.shape == em.shape
+    assert np.abs(tem.detach().numpy() - em).max() < 1e-4 * np.abs(em).max()
+    d = rng.normal(size=em.shape).astype(np.float32)
+    g = ref.backward(d, len(params))
+    tem.backward(torch.from_numpy(d))
+    for a, b in zip(tp, g):
+        b = np.asarray(b, np.float64).reshape(a.shape)
+        assert np.abs(a.grad.numpy() - b).max() < 5e-4 * max(1e-6, np.abs(b).max())
+
+
+def test_bf16_operand_rounding_of_the_reference_interpreter(oracle):
+    """refnet.bf16_round == torch's fp32 -> bfloat16 conversion (round to nearest even) bit for bit, incl. ties, and the
+    bf16 mode of the reference interpreter multiplies exactly those rounded operands"""
+    rng = np.random.default_rng(5)
+    a = np.concatenate([rng.normal(size=4096).astype(np.float32) * 10.0 ** rng.integers(-6, 6, 4096),
+                        np.array([1.0, 1.00390625, 1.01171875, -1.00390625, 0.0, 3.0e38, 1e-39], np.float32)])
+    want = torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy()
+    got = refnet.bf16_round(a)
+    assert got.tobytes() == want.tobytes()
+    x = rng.normal(size=(7, 24)).astype(np.float32); w = rng.normal(size=(24, 5)).astype(np.float32); b = rng.normal(size=5).astype(np.float32)
+    y = refnet.lin_fwd(x, w, b, bf16=True)
+    yt = (torch.from_numpy(refnet.bf16_round(x)).double() @ torch.from_numpy(refnet.bf16_round(w)).double() + torch.from_numpy(b).double()).numpy()
+    assert np.abs(y - yt).max() < 1e-5 * np.abs(yt).max()
+    dy = rng.normal(size=(7, 5)).astype(np.float32)
+    dx, dw, db = refnet.lin_bwd(x, w, dy, bf16=True)
+    assert np.abs(dx - refnet.bf16_round(dy).astype(np.float64) @ refnet.bf16_round(w).astype(np.float64).T).max() < 1e-5
+    assert np.abs(dw - refnet.bf16_round(x).astype(np.float64).T @ refnet.bf16_round(dy).astype(np.float64)).max() < 1e-5
+    assert np.abs(db - dy.sum(0)).max() < 1e-5

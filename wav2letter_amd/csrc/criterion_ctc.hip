@@ -12,13 +12,14 @@
 //                  registers (coalesced, 16 B/lane where alignment allows) and
 //                  reduced to lse[b][t]; the <= 2L+1 label log-probs the lattice
 //                  needs are gathered from the register-resident row's source.
-//   ctc_lattice    one wavefront per utterance: alpha and beta scans over the
-//                  2L+1 extended labels (positions blocked over lanes, fp64
-//                  carries with fp32 log-sum-exp corrections), loss, and the
-//                  occupancies gamma[t][s] = exp(alpha+beta-lp-logZ).
+//   ctc_scan       two wavefronts per utterance, side by side: the alpha scan and
+//                  the beta scan over the 2L+1 extended labels (positions blocked
+//                  over lanes, fp64 carries with fp32 log-sum-exp corrections);
+//                  the alpha wave also writes the loss.
 //   ctc_rows_grad  one workgroup per row: grad = g*(softmax(x) - occupancy):
 //                  streams x once more, writes grad once, then subtracts the
-//                  <= 2L+1 occupancies of that frame.
+//                  <= 2L+1 occupancies gamma[t][s] = exp(alpha+beta-lp-logZ) of
+//                  that frame.
 // Algorithmic HBM bytes: 4BTN (fwd) + 8BTN (bwd) = 12*B*T*N.
 #include "common.hpp"
 
@@ -29,8 +30,9 @@ constexpr int kRowMaxPer = 48;  // register-resident row: N <= 256*48 = 12288
 
 struct CtcWs {
   float* lse;     // [B][T]
-  float* lp;      // [B][T][S]   label log-probs, later overwritten by gamma
+  float* lp;      // [B][T][S]   label log-probs
   double* alpha;  // [B][T][S]
+  double* beta;   // [B][T][S]   (beta includes lp[t][s], as alpha does)
   float* scale;   // [B]
   float* nll;     // [B]  (-log likelihood, unscaled)
   int S;          // 2L+1 for the padded L
@@ -44,6 +46,7 @@ __host__ __device__ inline CtcWs ctc_ws(void* ws, int B, int T, int N, int L) {
   w.lse = (float*)p; p += align_up((size_t)B * T * sizeof(float), 256);
   w.lp = (float*)p; p += align_up((size_t)B * T * w.S * sizeof(float), 256);
   w.alpha = (double*)p; p += align_up((size_t)B * T * w.S * sizeof(double), 256);
+  w.beta = (double*)p; p += align_up((size_t)B * T * w.S * sizeof(double), 256);
   w.scale = (float*)p; p += align_up((size_t)B * sizeof(float), 256);
   w.nll = (float*)p;
   return w;
@@ -171,51 +174,51 @@ __device__ __forceinline__ double lse3(double a, double b, double c) {
   return m + (double)fast_logf(s);   // s in [1, 3]: hardware log2 * ln 2 (ocml's __logf is a ~12-instruction sequence)
 }
 
-// alpha / beta over the extended label sequence; positions blocked over lanes.
-template <int P>
-__global__ __launch_bounds__(64) void ctc_lattice(int T, int N, int L, int scaleMode,
-                                                  const int* __restrict__ target,
-                                                  const int* __restrict__ targetSize,
-                                                  float* __restrict__ loss, CtcWs ws) {
+// alpha OR beta over the extended label sequence (blockIdx.y = 0: alpha, 1: beta): one wavefront per (utterance,
+// direction), positions blocked over lanes (P per lane).  The two scans of an utterance are independent, so they run
+// as two waves side by side (they used to be one wave doing alpha, then beta + occupancies: 364 us at T' = 188,
+// 1.9 us per frame, memory-latency bound on a 4-step prefetch that every store of the scan drained).  Each scan now
+// reads ONE array (the label log-probs lp[t][s]) through a register double buffer D steps deep (2 D P floats = 128
+// registers whatever P is) and writes its lattice row (fp64) fire-and-forget; the occupancies
+// gamma[t][s] = exp(alpha + beta - lp - logZ) have no dependence between frames and are taken in ctc_rows_grad.
+template <int P, int D>
+__global__ __launch_bounds__(64) void ctc_scan(int T, int N, int L, int scaleMode,
+                                               const int* __restrict__ target,
+                                               const int* __restrict__ targetSize,
+                                               float* __restrict__ loss, CtcWs ws) {
   const int b = blockIdx.x;
+  const bool isBeta = blockIdx.y == 1;
   const int lane = threadIdx.x;
   const int Lb = targetSize[b];
   const int S = 2 * Lb + 1;
   const int SW = ws.S;
   const int* y = target + (size_t)b * L;
-  float* lp = ws.lp + (size_t)b * T * SW;
-  double* al = ws.alpha + (size_t)b * T * SW;
+  const float* lp = ws.lp + (size_t)b * T * SW;
   const double NEG = -INFINITY;
-  const float sc = scale_of(scaleMode, T, Lb);
 
-  bool skipPrev[P];  // may come from s-2
-  bool skipNext[P];  // may go to s+2
+  if (!isBeta) {
+    double* al = ws.alpha + (size_t)b * T * SW;
+    bool skipPrev[P];  // may come from s-2
 #pragma unroll
-  for (int p = 0; p < P; ++p) {
-    int si = lane * P + p;
-    int e0 = (si & 1) ? ((si >> 1) < Lb ? y[si >> 1] : -1) : (N - 1);
-    int em2 = (si >= 2 && (si & 1)) ? y[(si - 2) >> 1] : -2;
-    int ep2 = ((si & 1) && si + 2 < S) ? y[(si + 2) >> 1] : -2;
-    skipPrev[p] = (si < S) && (si & 1) && si >= 2 && e0 != em2;
-    skipNext[p] = (si < S) && (si & 1) && si + 2 < S && e0 != ep2;
-  }
-
-  // ---- alpha
-  constexpr int D = 4;  // lattice-row prefetch depth (steps)
-  double a[P];
+    for (int p = 0; p < P; ++p) {
+      const int si = lane * P + p;
+      const int e0 = (si & 1) ? ((si >> 1) < Lb ? y[si >> 1] : -1) : (N - 1);
+      const int em2 = (si >= 2 && (si & 1) && ((si - 2) >> 1) < Lb) ? y[(si - 2) >> 1] : -2;
+      skipPrev[p] = (si < S) && (si & 1) && si >= 2 && e0 != em2;
+    }
+    double a[P];
 #pragma unroll
-  for (int p = 0; p < P; ++p) {
-    int si = lane * P + p;
-    a[p] = (si < S && si < 2) ? (double)lp[si] : NEG;
-    if (si < S) al[si] = a[p];
-  }
-  {
+    for (int p = 0; p < P; ++p) {
+      const int si = lane * P + p;
+      a[p] = (si < S && si < 2) ? (double)lp[si] : NEG;
+      if (si < S) al[si] = a[p];
+    }
     float lc[D][P], ln[D][P];
 #pragma unroll
     for (int u = 0; u < D; ++u)
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        int si = lane * P + p, t = 1 + u;
+        const int si = lane * P + p, t = 1 + u;
         lc[u][p] = (t < T && si < S) ? lp[(size_t)t * SW + si] : 0.f;
       }
     for (int t0 = 1; t0 < T; t0 += D) {
@@ -223,23 +226,22 @@ __global__ __launch_bounds__(64) void ctc_lattice(int T, int N, int L, int scale
       for (int u = 0; u < D; ++u)
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-          int si = lane * P + p, t = t0 + D + u;
+          const int si = lane * P + p, t = t0 + D + u;
           ln[u][p] = (t < T && si < S) ? lp[(size_t)t * SW + si] : 0.f;
         }
 #pragma unroll
       for (int u = 0; u < D; ++u) {
         const int t = t0 + u;
         if (t < T) {
-          double c1 = lane_shift_up_dpp(a[P - 1], NEG);                              // alpha[lane*P - 1]
-          double c2 = lane_shift_up_dpp(P >= 2 ? a[P >= 2 ? P - 2 : 0] : NEG, NEG);  // alpha[lane*P - 2]
-          if (P == 1) c2 = lane_shift_up_dpp(c1, NEG);
+          const double c1 = lane_shift_up_dpp(a[P - 1], NEG);                                    // alpha[lane*P - 1]
+          const double c2 = P >= 2 ? lane_shift_up_dpp(a[P >= 2 ? P - 2 : 0], NEG) : lane_shift_up_dpp(c1, NEG);  // alpha[lane*P - 2]
           double pm1 = c1, pm2 = c2;
           double* alt = al + (size_t)t * SW;
 #pragma unroll
           for (int p = 0; p < P; ++p) {
-            int si = lane * P + p;
-            double cur = a[p];
-            double v = lse3(cur, pm1, skipPrev[p] ? pm2 : NEG);
+            const int si = lane * P + p;
+            const double cur = a[p];
+            const double v = lse3(cur, pm1, skipPrev[p] ? pm2 : NEG);
             double na = NEG;
             if (si < S && v != NEG) na = v + (double)lc[u][p];
             if (si < S) alt[si] = na;
@@ -254,109 +256,92 @@ __global__ __launch_bounds__(64) void ctc_lattice(int T, int N, int L, int scale
 #pragma unroll
         for (int p = 0; p < P; ++p) lc[u][p] = ln[u][p];
     }
-  }
-  // log-likelihood = lse(alpha[T-1][S-1], alpha[T-1][S-2])
-  double ll = NEG;
-  {
+    // log-likelihood = lse(alpha[T-1][S-1], alpha[T-1][S-2])
     double v1 = NEG, v2 = NEG;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      int si = lane * P + p;
+      const int si = lane * P + p;
       if (si == S - 1) v1 = a[p];
       if (si == S - 2) v2 = a[p];
     }
-    // gather across lanes
-    double m1 = v1, m2 = v2;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-      m1 = fmax(m1, __shfl_xor(m1, off));
-      m2 = fmax(m2, __shfl_xor(m2, off));
+      v1 = fmax(v1, __shfl_xor(v1, off));
+      v2 = fmax(v2, __shfl_xor(v2, off));
     }
-    ll = lse3(m1, m2, NEG);
-  }
-  if (lane == 0) {
-    loss[b] = (float)(-(double)sc * ll);
-    ws.scale[b] = sc;
-    ws.nll[b] = (float)(-ll);
+    const double ll = lse3(v1, v2, NEG);
+    if (lane == 0) {
+      const float sc = scale_of(scaleMode, T, Lb);
+      loss[b] = (float)(-(double)sc * ll);
+      ws.scale[b] = sc;
+      ws.nll[b] = (float)(-ll);
+    }
+    return;
   }
 
-  // ---- beta, fused with gamma[t][s] = exp(alpha + beta - lp - ll) (overwrites lp)
+  // ---- beta[t][s] (includes lp[t][s], like alpha): beta[T-1][s] = lp[T-1][s] for s >= S-2,
+  //      beta[t-1][s] = lse(beta[t][s], beta[t][s+1], beta[t][s+2] if allowed) + lp[t-1][s]
+  double* bt = ws.beta + (size_t)b * T * SW;
+  bool skipNext[P];  // may go to s+2
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int si = lane * P + p;
+    const int e0 = (si & 1) ? ((si >> 1) < Lb ? y[si >> 1] : -1) : (N - 1);
+    const int ep2 = ((si & 1) && si + 2 < S) ? y[(si + 2) >> 1] : -2;
+    skipNext[p] = (si < S) && (si & 1) && si + 2 < S && e0 != ep2;
+  }
   double be[P];
   {
     const float* lpt = lp + (size_t)(T - 1) * SW;
+    double* btt = bt + (size_t)(T - 1) * SW;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      int si = lane * P + p;
+      const int si = lane * P + p;
       be[p] = (si < S && si >= S - 2) ? (double)lpt[si] : NEG;
+      if (si < S) btt[si] = be[p];
     }
   }
-  __syncthreads();  // alpha stores of this wave drained before they are re-read
-  {
-    // per step t (descending): lpA = lp[t], alA = alpha[t], lpB = lp[t-1]
-    float lpA[D][P], lpB[D][P], nlpA[D][P], nlpB[D][P];
-    double alA[D][P], nalA[D][P];
+  float lc[D][P], ln[D][P];  // lc[u] = lp[thi - 1 - u]
+#pragma unroll
+  for (int u = 0; u < D; ++u)
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int si = lane * P + p, t = T - 2 - u;
+      lc[u][p] = (t >= 0 && si < S) ? lp[(size_t)t * SW + si] : 0.f;
+    }
+  for (int thi = T - 1; thi >= 1; thi -= D) {
 #pragma unroll
     for (int u = 0; u < D; ++u)
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        int si = lane * P + p, t = T - 1 - u;
-        bool ok = t >= 0 && si < S;
-        lpA[u][p] = ok ? lp[(size_t)t * SW + si] : 0.f;
-        alA[u][p] = ok ? al[(size_t)t * SW + si] : NEG;
-        lpB[u][p] = (ok && t >= 1) ? lp[(size_t)(t - 1) * SW + si] : 0.f;
-      }
-    for (int thi = T - 1; thi >= 0; thi -= D) {
-#pragma unroll
-      for (int u = 0; u < D; ++u)
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-          int si = lane * P + p, t = thi - D - u;
-          bool ok = t >= 0 && si < S;
-          nlpA[u][p] = ok ? lp[(size_t)t * SW + si] : 0.f;
-          nalA[u][p] = ok ? al[(size_t)t * SW + si] : NEG;
-          nlpB[u][p] = (ok && t >= 1) ? lp[(size_t)(t - 1) * SW + si] : 0.f;
-        }
-#pragma unroll
-      for (int u = 0; u < D; ++u) {
-        const int t = thi - u;
-        if (t >= 0) {
-          float* lpt = lp + (size_t)t * SW;
-          // gamma for frame t from beta_t (be) and alpha_t; overwrites lp[t]
-#pragma unroll
-          for (int p = 0; p < P; ++p) {
-            int si = lane * P + p;
-            if (si < S) {
-              double av = alA[u][p];
-              float gm = 0.f;
-              if (av != NEG && be[p] != NEG && ll != NEG)
-                gm = __expf((float)(av + be[p] - (double)lpA[u][p] - ll));
-              lpt[si] = gm;
-            }
-          }
-          if (t >= 1) {
-            // beta_{t-1}[s] = lse(beta_t[s], beta_t[s+1], beta_t[s+2] if allowed) + lp[t-1][s]
-            double n1 = lane_shift_down_dpp(be[0], NEG);                               // beta[(lane+1)*P]
-            double n2 = lane_shift_down_dpp(P >= 2 ? be[P >= 2 ? 1 : 0] : NEG, NEG);   // beta[(lane+1)*P + 1]
-            if (P == 1) n2 = lane_shift_down_dpp(n1, NEG);
-            double nb[P];
-#pragma unroll
-            for (int p = P - 1; p >= 0; --p) {
-              int si = lane * P + p;
-              double b1 = (p + 1 < P) ? be[p + 1 < P ? p + 1 : 0] : n1;
-              double b2 = (p + 2 < P) ? be[p + 2 < P ? p + 2 : 0] : ((p + 1 < P) ? n1 : n2);
-              double v = lse3(be[p], b1, skipNext[p] ? b2 : NEG);
-              nb[p] = (si < S && v != NEG) ? v + (double)lpB[u][p] : NEG;
-            }
-#pragma unroll
-            for (int p = 0; p < P; ++p) be[p] = nb[p];
-          }
-        }
+        const int si = lane * P + p, t = thi - 1 - D - u;
+        ln[u][p] = (t >= 0 && si < S) ? lp[(size_t)t * SW + si] : 0.f;
       }
 #pragma unroll
-      for (int u = 0; u < D; ++u)
+    for (int u = 0; u < D; ++u) {
+      const int t = thi - u;  // beta_t -> beta_{t-1}
+      if (t >= 1) {
+        const double n1 = lane_shift_down_dpp(be[0], NEG);                                        // beta[(lane+1)*P]
+        const double n2 = P >= 2 ? lane_shift_down_dpp(be[P >= 2 ? 1 : 0], NEG) : lane_shift_down_dpp(n1, NEG);  // beta[(lane+1)*P + 1]
+        double nb[P];
+        double* btt = bt + (size_t)(t - 1) * SW;
 #pragma unroll
-        for (int p = 0; p < P; ++p) { lpA[u][p] = nlpA[u][p]; alA[u][p] = nalA[u][p]; lpB[u][p] = nlpB[u][p]; }
+        for (int p = P - 1; p >= 0; --p) {
+          const int si = lane * P + p;
+          const double b1 = (p + 1 < P) ? be[p + 1 < P ? p + 1 : 0] : n1;
+          const double b2 = (p + 2 < P) ? be[p + 2 < P ? p + 2 : 0] : ((p + 1 < P) ? n1 : n2);
+          const double v = lse3(be[p], b1, skipNext[p] ? b2 : NEG);
+          nb[p] = (si < S && v != NEG) ? v + (double)lc[u][p] : NEG;
+          if (si < S) btt[si] = nb[p];
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) be[p] = nb[p];
+      }
     }
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+#pragma unroll
+      for (int p = 0; p < P; ++p) lc[u][p] = ln[u][p];
   }
 }
 
@@ -397,11 +382,21 @@ __global__ __launch_bounds__(kRowThreads) void ctc_rows_grad(int T, int N, int L
   const int Lb = targetSize[b];
   const int S = 2 * Lb + 1;
   const int* y = target + (size_t)b * L;
-  const float* gm = ws.lp + r * ws.S;
-  for (int si = tid; si < S; si += kRowThreads) {
-    int lab = (si & 1) ? y[si >> 1] : (N - 1);
-    float v = gm[si];
-    if (v != 0.f) atomicAdd(&out[lab], -g * v);
+  // occupancy of label position s at this frame: exp(alpha + beta - lp - logZ) (alpha and beta both carry lp[t][s])
+  const float* lpr = ws.lp + r * ws.S;
+  const double* alr = ws.alpha + r * ws.S;
+  const double* ber = ws.beta + r * ws.S;
+  const float nll = ws.nll[b];
+  if (nll != INFINITY) {   // an infeasible target (logZ = -inf) has no occupancy: its loss is +inf, its gradient g * softmax
+    const double ll = -(double)nll;
+    for (int si = tid; si < S; si += kRowThreads) {
+      const int lab = (si & 1) ? y[si >> 1] : (N - 1);
+      const double av = alr[si], bv = ber[si];
+      if (av != -INFINITY && bv != -INFINITY) {
+        const float v = __expf((float)(av + bv - (double)lpr[si] - ll));
+        if (v != 0.f) atomicAdd(&out[lab], -g * v);
+      }
+    }
   }
 }
 
@@ -484,7 +479,7 @@ W2L_API size_t w2l_ctc_workspace_size(int B, int T, int N, int L) {
   if (B <= 0 || T <= 0 || N <= 0 || L < 0) return 0;
   size_t S = 2 * (size_t)L + 1;
   return align_up((size_t)B * T * sizeof(float), 256) + align_up((size_t)B * T * S * sizeof(float), 256) +
-         align_up((size_t)B * T * S * sizeof(double), 256) + 2 * align_up((size_t)B * sizeof(float), 256);
+         2 * align_up((size_t)B * T * S * sizeof(double), 256) + 2 * align_up((size_t)B * sizeof(float), 256);
 }
 
 W2L_API int w2l_ctc_forward(int B, int T, int N, int L, int scaleMode, const float* input,
@@ -492,7 +487,7 @@ W2L_API int w2l_ctc_forward(int B, int T, int N, int L, int scaleMode, const flo
                             void* workspace, w2l_stream_t stream) {
   if (B <= 0 || T <= 0 || N <= 1 || L <= 0 || !input || !target || !targetSize || !loss || !workspace)
     return W2L_EINVAL;
-  if (2 * L + 1 > 64 * 8) return W2L_EUNSUPPORTED;
+  if (2 * L + 1 > 64 * 32) return W2L_EUNSUPPORTED;   // L <= 1023 label positions per utterance (32 per lane)
   hipStream_t s = (hipStream_t)stream;
   CtcWs ws = ctc_ws(workspace, B, T, N, L);
   const unsigned rows = (unsigned)((size_t)B * T);
@@ -502,10 +497,13 @@ W2L_API int w2l_ctc_forward(int B, int T, int N, int L, int scaleMode, const flo
     hipLaunchKernelGGL(ctc_rows_lse_big, dim3(rows), dim3(kRowThreads), 0, s, T, N, L, input, target, targetSize, ws);
   W2L_LAUNCH_CHECK();
   const int S = 2 * L + 1;
-  if (S <= 64) hipLaunchKernelGGL(ctc_lattice<1>, dim3(B), dim3(64), 0, s, T, N, L, scaleMode, target, targetSize, loss, ws);
-  else if (S <= 128) hipLaunchKernelGGL(ctc_lattice<2>, dim3(B), dim3(64), 0, s, T, N, L, scaleMode, target, targetSize, loss, ws);
-  else if (S <= 256) hipLaunchKernelGGL(ctc_lattice<4>, dim3(B), dim3(64), 0, s, T, N, L, scaleMode, target, targetSize, loss, ws);
-  else hipLaunchKernelGGL(ctc_lattice<8>, dim3(B), dim3(64), 0, s, T, N, L, scaleMode, target, targetSize, loss, ws);
+  const dim3 grid((unsigned)B, 2), blk(64);   // (utterance, alpha | beta)
+  if (S <= 64) hipLaunchKernelGGL((ctc_scan<1, 32>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws);
+  else if (S <= 128) hipLaunchKernelGGL((ctc_scan<2, 32>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws);
+  else if (S <= 256) hipLaunchKernelGGL((ctc_scan<4, 16>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws);
+  else if (S <= 512) hipLaunchKernelGGL((ctc_scan<8, 8>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws);
+  else if (S <= 1024) hipLaunchKernelGGL((ctc_scan<16, 4>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws);
+  else hipLaunchKernelGGL((ctc_scan<32, 2>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }
