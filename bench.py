@@ -137,6 +137,51 @@ def asg_criterion_ms(device):
                     "the HBM roofline is quoted on the N=9998 stress shape (asg_stress)"}
 
 
+def ctc_criterion_ms(device, L):
+    """CTC forward + backward through the C ABI at the two shapes SURVEY 8(d) names: the model-shaped criterion of the
+    headline step (B=32, T'=188, N=9998) and the north-star stress (T=1500): 12 B T N algorithmic bytes (emissions read
+    for the row normalisers, read again and the gradient written); preallocated buffers, HIP events around n calls"""
+    from wav2letter_amd import criterion as Cr
+    out = {}
+    for name, (B, T, N, Lt, n) in {"model_shaped": (32, 188, 9998, 80, 20), "stress_T1500": (32, 1500, 9998, 80, 5)}.items():
+        g = torch.Generator(device="cpu").manual_seed(11)
+        x = torch.randn(B, T, N, generator=g).to(device)
+        tgt = torch.full((B, Lt), -1, dtype=torch.int32)
+        for b in range(B):
+            l = int(torch.randint(20, Lt + 1, (1,), generator=g))
+            tgt[b, :l] = torch.randint(0, N - 1, (l,), generator=g, dtype=torch.int32)
+        tgt = tgt.to(device)
+        ts = Cr.batch_target_size(tgt, T, ctc=True)
+        ws = torch.empty(L.w2l_ctc_workspace_size(B, T, N, Lt), dtype=torch.uint8, device=device)
+        loss = torch.empty(B, device=device)
+        grad = torch.ones(B, device=device)
+        dx = torch.empty_like(x)
+        st = torch.cuda.current_stream().cuda_stream
+
+        def fwd():
+            _lib_check(L.w2l_ctc_forward(B, T, N, Lt, 4, x.data_ptr(), tgt.data_ptr(), ts.data_ptr(), loss.data_ptr(), ws.data_ptr(), st))
+
+        def bwd():
+            _lib_check(L.w2l_ctc_backward(B, T, N, Lt, x.data_ptr(), tgt.data_ptr(), ts.data_ptr(), grad.data_ptr(), dx.data_ptr(), ws.data_ptr(), st))
+        f_ms = _timeit(fwd, n=n)
+        fb_ms = _timeit(lambda: (fwd(), bwd()), n=n)
+        by = 12.0 * B * T * N
+        out[name] = {"shape": f"B={B},T={T},N={N},L<={Lt}", "fwd_ms": round(f_ms, 4), "fwd_bwd_ms": round(fb_ms, 4),
+                     "algorithmic_bytes": by, "achieved_GBps": round(by / (fb_ms * 1e-3) / 1e9, 1),
+                     "frac_of_hbm_peak": round(by / (fb_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                     "finite": bool(torch.isfinite(loss).all().item())}
+        del x, dx, ws
+        torch.cuda.empty_cache()
+    out["note"] = ("ctc_rows_lse (one streaming pass) + ctc_scan (alpha and beta side by side, one wave each per utterance) + "
+                   "ctc_rows_grad (one streaming pass + occupancies); the scans are T dependent steps and do not stream")
+    return out
+
+
+def _lib_check(st):
+    if st != 0:
+        raise RuntimeError(f"C ABI call failed with status {st}")
+
+
 def conv_glu_asg_step(device, L, steps=2, oracle_checks=True):
     """BASELINE config 4 on one GPU: conv_glu LibriSpeech (17 WN-conv + GLU layers, 208.9 M parameters), ASG criterion,
     N = 30, T = 2000 frames of 40 filterbanks, batch 64: full training step (forward, ASG, backward, clip + SGD).  The
@@ -202,7 +247,23 @@ def conv_glu_asg_step(device, L, steps=2, oracle_checks=True):
                          "algorithmic_tflop_per_step": round(w_.value / steps / 1e12, 2)}}
 
 
-def streaming_tds_step(device, L, steps=3):
+def ctc_loss_check(tr, x, tgt, what):
+    """outside the timed region: the CTC criterion on the network's OWN emissions (eval forward of the stepped
+    parameters) through the HIP criterion and through the fp64 oracle, loss [B] element by element (reference call site
+    Train.cpp:406-407, :1675; the criterion input is f32 in every precision mode, cpc/Train.cpp:1184)"""
+    from oracle import pyoracle as O
+    from wav2letter_amd import CTCLoss, CriterionScaleMode
+    O.set_num_threads(host_threads())
+    em = tr.forward(x, train=False).clone()
+    got = CTCLoss(CriterionScaleMode.TARGET_SZ_SQRT)(em, tgt).detach().cpu().numpy()
+    want = O.CTC(em.cpu().numpy(), tgt.cpu().numpy(), scale_mode=4).forward()
+    fin = np.isfinite(want)
+    err = float(np.abs(got[fin] - want[fin]).max() / max(1.0, np.abs(want[fin]).max())) if fin.any() else 0.0
+    return {"what": what, "max_rel_err": err, "utterances": int(fin.sum()),
+            "ok": bool(err < 1e-4 and (np.isfinite(got) == fin).all())}
+
+
+def streaming_tds_step(device, L, steps=3, oracle_checks=True):
     """BASELINE config 3 on one GPU: streaming_convnets LibriSpeech TDS-CTC (am_500ms_future_context.arch, 115.1 M
     parameters), batch 64, T = 1500: the full training step in fp32 and with bf16 multiplies in the fl::Linear GEMMs
     (fp32 accumulate, fp32 storage and master weights, fp32 criterion) -- the mixed-precision mode of
@@ -240,6 +301,8 @@ def streaming_tds_step(device, L, steps=3):
         out[mode] = {"ms_per_step": round(dt * 1e3, 1), "utterances_per_sec": round(B / dt, 1),
                      "finite": bool(torch.isfinite(loss).all().item()), "loss": round(float(loss.mean().item()), 4),
                      "gemm_TFLOPs": round(tf, 1), "gemm_ms_per_step": round(ms_.value / steps, 1), "gemm_launches_per_step": n_.value // steps}
+        if oracle_checks and mode == "bf16":
+            out["loss_check"] = ctc_loss_check(tr, x, tgt, f"CTC loss [{B}] on the {mode} step's emissions (eval forward) vs fp64 oracle")
         del tr
         torch.cuda.empty_cache()
     out["bf16_speedup"] = round(out["f32"]["ms_per_step"] / out["bf16"]["ms_per_step"], 3)
@@ -248,7 +311,7 @@ def streaming_tds_step(device, L, steps=3):
     return out
 
 
-def transformer_ctc_step(device, L, steps=3):
+def transformer_ctc_step(device, L, steps=3, oracle_checks=True):
     """BASELINE config 5 on one GPU: sota/2019 Transformer-CTC (am_transformer_ctc.arch: WN-conv + GLU + max-pool front end,
     24 blocks of width 1024 / 4 heads / +-460 relative positions, 322.6 M parameters), batch 16, T = 1500 -> 188 frames,
     9998 word pieces: the full training step (dropout 0.2 and layer drop 0.2 live, as the recipe trains) in fp32 and with
@@ -285,6 +348,8 @@ def transformer_ctc_step(device, L, steps=3):
         dt = (time.perf_counter() - t0) / steps
         out[mode] = {"ms_per_step": round(dt * 1e3, 1), "utterances_per_sec": round(B / dt, 1),
                      "finite": bool(torch.isfinite(loss).all().item()), "loss": round(float(loss.mean().item()), 4)}
+        if oracle_checks and mode == "bf16":
+            out["loss_check"] = ctc_loss_check(tr, x, tgt, f"CTC loss [{B}] on the {mode} step's emissions (eval forward) vs fp64 oracle")
         del tr
         torch.cuda.empty_cache()
     out["bf16_speedup"] = round(out["f32"]["ms_per_step"] / out["bf16"]["ms_per_step"], 3)
@@ -312,18 +377,25 @@ def asg_stress(device, L, T, oracle_checks=True):
     x.grad = None                # the timed backward reuses the warm-up's gradient buffers instead of allocating 2.3 GB
     crit.transitions.grad = None
     torch.cuda.synchronize()
+
+    def kind(k):
+        n_, ms_, w_ = C.c_int(0), C.c_double(0), C.c_double(0)
+        L.w2l_profile_report_kind(k, C.byref(n_), C.byref(ms_), C.byref(w_))
+        return n_.value, ms_.value, w_.value
     L.w2l_profile_enable(1)
     t0 = time.perf_counter()
     loss = crit(x, tgt)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
+    nl, ms, by = kind(3)             # the alpha pass's transition-stream launches
+    L.w2l_profile_enable(1)          # (resets the event list)
     loss.sum().backward()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    nl, ms, by = C.c_int(0), C.c_double(0), C.c_double(0)
-    L.w2l_profile_report_kind(3, C.byref(nl), C.byref(ms), C.byref(by))
+    nlb, msb, byb = kind(3)          # the beta pass's transition-stream launches
+    nda, msda, flda = kind(0)        # dA = (g r)^T e: one fp32 MFMA GEMM over (t, b), not part of the HBM-bound recursion
     L.w2l_profile_enable(0)
-    achieved = by.value / (ms.value * 1e-3) / 1e9 if ms.value > 0 else 0.0
+    achieved = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     check = None
     if oracle_checks:
         # outside the timed region: utterance 0 of the TIMED forward (fp32 exp-domain rescaling over T dependent steps at
@@ -349,16 +421,28 @@ def asg_stress(device, L, T, oracle_checks=True):
                  "ok": bool(abs(got - want) < 1e-4 * max(1.0, abs(want))), "oracle_seconds": round(time.perf_counter() - t3, 1)}
     step_bytes = 4.0 * N * N + 8.0 * B * N
     fwd_ms, bwd_ms = (t1 - t0) * 1e3, (t2 - t1) * 1e3
+    whole = step_bytes * (T - 1) / (fwd_ms * 1e-3) / 1e9
+    achieved_b = byb / (msb * 1e-3) / 1e9 if msb > 0 else 0.0
+    beta_ms = bwd_ms - msda          # the recursion proper: the dA GEMM (MFMA-bound, 2 N^2 T B flop) is timed by its own events
+    whole_b = step_bytes * (T - 1) / (beta_ms * 1e-3) / 1e9 if beta_ms > 0 else 0.0
+    tr_, trd = pmc_traffic("fcc_big_gemm")
     return {"shape": f"B={B},T={T},N={N}", "fwd_ms": round(fwd_ms, 2), "bwd_ms": round(bwd_ms, 2),
             "fwd_us_per_step": round(fwd_ms * 1e3 / T, 2),
-            "whole_forward_GBps": round(step_bytes * (T - 1) / (fwd_ms * 1e-3) / 1e9, 1),
+            "whole_forward_GBps": round(whole, 1),
             "finite": bool(torch.isfinite(loss).all().item()), "loss_check": check,
-            "roofline": {"bound": "hbm", "kernel": "fcc_big_gemm (packed-transition stream, fp32 MFMA 32x32x2)",
-                         "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / PEAK_HBM_GBPS, 4), "traffic": pmc_traffic("fcc_big_gemm")[0],
-                         "traffic_detail": pmc_traffic("fcc_big_gemm")[1],
-                         "launches": nl.value, "avg_launch_us": round(ms.value * 1e3 / max(1, nl.value), 2),
-                         "algorithmic_bytes_per_launch": step_bytes}}
+            # frac = the WHOLE alpha pass (every launch of the T dependent steps, wall time); the streaming kernel alone beside it
+            "roofline": {"bound": "hbm", "kernel": "alpha pass of FullConnectionCriterion at N = 9998: per frame fcc_big_gemm_dma "
+                                                   "(packed-transition stream, fp32 MFMA 32x32x2) + fcc_big_step",
+                         "achieved": round(whole, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": round(whole / PEAK_HBM_GBPS, 4), "traffic": tr_, "traffic_detail": trd,
+                         "algorithmic_bytes_per_frame": step_bytes, "frames": T - 1,
+                         "stream_kernel_only": {"achieved": round(achieved, 1), "frac": round(achieved / PEAK_HBM_GBPS, 4),
+                                                "launches": nl, "avg_launch_us": round(ms * 1e3 / max(1, nl), 2)},
+                         "beta_pass": {"achieved": round(whole_b, 1), "frac": round(whole_b / PEAK_HBM_GBPS, 4),
+                                       "ms": round(beta_ms, 2), "note": "bwd_ms minus the dA GEMM",
+                                       "dA_gemm_ms": round(msda, 2), "dA_gemm_TFLOPs": round(flda / (msda * 1e-3) / 1e12, 1) if msda > 0 else None,
+                                       "stream_kernel_only": {"achieved": round(achieved_b, 1), "frac": round(achieved_b / PEAK_HBM_GBPS, 4),
+                                                              "launches": nlb, "avg_launch_us": round(msb * 1e3 / max(1, nlb), 2)}}}}
 
 
 def host_threads():
@@ -451,9 +535,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus != world:
-        if world > 1 and rank == 0:
-            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: running {world} ranks", file=sys.stderr)
-        a.gpus = world
+        # a launcher that started a different number of ranks than --gpus asks for would report a throughput for the
+        # wrong N: refuse (the driver launches `torch.distributed.run --nproc-per-node N bench.py --gpus N`)
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: the launcher and --gpus disagree")
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, this node shows {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
@@ -482,6 +566,16 @@ def main():
     if dist is not None:
         from wav2letter_amd.parallel import OverlappedReducer
         reducer = OverlappedReducer(tr, n_buckets=a.buckets)
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {a.gpus}")
+        if rank == 0:
+            try:
+                ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:  # noqa: BLE001
+                ver = f"unknown ({type(e).__name__})"
+            note(f"data parallel: {dist.get_world_size()} ranks over RCCL {ver} (torch backend 'nccl'), "
+                 f"{len(reducer.bucket_bytes())} gradient buckets per step, bytes in issue order (last layers first): "
+                 f"{reducer.bucket_bytes()}; arena {4 * tr.grads_full.numel()} bytes incl. the 16-byte batch-size tail")
 
     def step():
         loss = tr.forward_backward(x, tgt)
@@ -587,6 +681,8 @@ def main():
 
     if not a.no_asg:
         leg("asg_loss_ms_per_step", lambda: asg_criterion_ms(device))
+        if world == 1:
+            leg("ctc_loss_ms_per_step", lambda: ctc_criterion_ms(device, L))
     if world == 1 and not a.no_stress:
         del tr, x, tgt
         torch.cuda.empty_cache()
@@ -594,9 +690,9 @@ def main():
     if world == 1 and not a.no_c4:
         leg("conv_glu_asg_step", lambda: conv_glu_asg_step(device, L, oracle_checks=not a.no_oracle_checks))
     if world == 1 and not a.no_c3:
-        leg("streaming_tds_bf16_step", lambda: streaming_tds_step(device, L))
+        leg("streaming_tds_bf16_step", lambda: streaming_tds_step(device, L, oracle_checks=not a.no_oracle_checks))
     if world == 1 and not a.no_c5:
-        leg("transformer_ctc_step", lambda: transformer_ctc_step(device, L))
+        leg("transformer_ctc_step", lambda: transformer_ctc_step(device, L, oracle_checks=not a.no_oracle_checks))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -148,3 +148,63 @@ def test_self_launch_refuses_missing_gpus():
         pytest.skip("this host really has 64 GPUs")
     with pytest.raises(RuntimeError, match="visible GPUs"):
         parallel.self_launch(64, "bench.py", [])
+
+
+def _arena_worker(rank, world, port, ret):
+    """OverlappedReducer on the REAL trainer arena layout of BASELINE config 2 (203.4 M parameters: bucket offsets cut at the
+    trainer's parameter boundaries, the 4-float tail carrying the local batch size, buckets walked last-to-first), gloo."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from wav2letter_amd import parallel, recipes
+    from wav2letter_amd.trainer import Trainer
+    parallel.init_distributed("gloo")
+    tr = Trainer(recipes.tds_ctc_arch(), 80, 9998, "ctc", 4, device="cpu")      # layout only: no kernel runs on the host
+    n = tr.n_floats
+    tr.params = torch.zeros(n)
+    tr.grads_full = torch.zeros(tr.L.w2l_trainer_grad_floats(tr.h))
+    tr.grads = tr.grads_full[:n]
+    assert tr.grads_full.numel() == n + 4
+    red = parallel.OverlappedReducer(tr, n_buckets=4)
+    offs = red.offsets
+    table_offs = {off for _, _, off in tr.param_table()}
+    assert offs[0] == 0 and offs[-1] == n + 4 and len(offs) == 5 and all(o in table_offs for o in offs[1:-1])
+    assert red.bucket_bytes() == [4 * (offs[k + 1] - offs[k]) for k in (3, 2, 1, 0)] and sum(red.bucket_bytes()) == 4 * (n + 4)
+
+    # integer-valued "gradients" (every partial sum is exact in fp32, so the result is independent of the order of
+    # the additions and can be compared bit for bit): utterance u contributes ((i * (u + 3)) mod 11) - 5 to element i
+    idx = torch.arange(n, dtype=torch.int64)
+
+    def utt_grad(u):
+        return ((idx * (u + 3)) % 11 - 5).to(torch.float32)
+    B = 5                                            # ragged split: ranks hold 3 and 2 utterances
+    lo, hi = parallel.shard_range(B, rank, world)
+    for u in range(lo, hi):
+        tr.grads += utt_grad(u)
+    tr.grads_full[n] = float(hi - lo)                # what forward_backward writes (w2l_trainer_grad_floats tail)
+    red.reduce()
+    total = tr.grads_full[n].item()
+    assert total == float(B)                         # the batch size rode the LAST bucket's collective
+    # update(total_batch="reduced") restated on the host: plain SGD on gradients / all-reduced batch size
+    tr.params -= 0.25 * tr.grads / total
+    # a single process on the concatenated batch
+    want_g = torch.zeros(n)
+    for u in range(B):
+        want_g += utt_grad(u)
+    assert torch.equal(tr.grads, want_g)
+    assert torch.equal(tr.params, -0.25 * want_g / float(B))
+    gathered = [torch.zeros(1024) for _ in range(world)]
+    probe = torch.cat([tr.params[:512], tr.params[-512:]])
+    dist.all_gather(gathered, probe)
+    assert all(torch.equal(gathered[0], g) for g in gathered)
+    digest = float(tr.params.double().sum().item())
+    ret[rank] = digest
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_overlapped_reducer_on_the_real_trainer_arena_two_gloo_ranks():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_arena_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret[0] == ret[1]

@@ -127,36 +127,6 @@ def test_gemm_lds_dma_path(M, N, K, akc, bkc, probe):
     assert torch.equal(plain, ops.gemm(Ad, Bd, akc, bkc))
 
 
-@pytest.mark.parametrize("M,N,K", [(4, 4, 32), (260, 388, 96), (1028, 2052, 1440), (6016, 4320, 1440), (640, 136, 24000),
-                                    (24000, 800, 2400)])
-@pytest.mark.parametrize("akc,bkc", [(True, False), (True, True), (False, False), (False, True)])
-def test_gemm_three_stage_256x128(M, N, K, akc, bkc, probe):
-    """the 256x128 three-stage kernel (counted vmcnt, raw barriers) forced on every eligible shape
-    (W2L_GEMM_P3=2): float64 product, determinism, bias + ReLU, and agreement with the 128x128 kernel"""
-    import os
-    from wav2letter_amd import ops
-    g = torch.Generator(device="cpu").manual_seed(5 * M + 3 * N + K)
-    A = torch.randn(M, K, generator=g)
-    Bm = torch.randn(K, N, generator=g) / K ** 0.5
-    bias = torch.randn(N, generator=g)
-    want = (A.double() @ Bm.double() + bias.double()).numpy()
-    Ad = (A if akc else A.T.contiguous()).cuda()
-    Bd = (Bm.T.contiguous() if bkc else Bm).cuda()
-    os.environ["W2L_GEMM_P3"] = "2"
-    try:
-        got = ops.gemm(Ad, Bd, akc, bkc, bias.cuda())
-        got2 = ops.gemm(Ad, Bd, akc, bkc, bias.cuda())
-        gotr = ops.gemm(Ad, Bd, akc, bkc, bias.cuda(), relu=True)
-        os.environ["W2L_GEMM_P3"] = "0"
-        old = ops.gemm(Ad, Bd, akc, bkc, bias.cuda())
-    finally:
-        os.environ.pop("W2L_GEMM_P3")
-    assert rel(got, want) < TOL
-    assert torch.equal(got, got2)
-    assert rel(gotr, np.maximum(want, 0)) < TOL
-    assert rel(got, old.cpu().numpy()) < 1e-5
-
-
 @pytest.mark.parametrize("M,K,N", [(300, 800, 2400),      # LDS-DMA kernel, wide epilogue
                                     (188, 1440, 9998),     # generic kernel (unaligned N), dword epilogue
                                     (37, 20, 13)])
@@ -208,36 +178,6 @@ def test_gemm_in_kernel_slab_reduction_is_stable(M, N, K, probe):
         os.environ.pop("W2L_GEMM_T160")
     want = torch.relu(A.double() @ Bm.double() + bias.double()).cpu().numpy()
     assert rel(ref, want) < TOL
-
-
-@pytest.mark.parametrize("M,N,K", [(4, 4, 32), (260, 388, 96), (1028, 2052, 1440), (6016, 4320, 1440), (640, 136, 24000),
-                                    (24000, 2400, 800)])
-@pytest.mark.parametrize("akc,bkc", [(True, False), (True, True), (False, False), (False, True)])
-def test_gemm_loader_wave_variant(M, N, K, akc, bkc, probe):
-    """the loader-wave kernel (a fifth wave issues every LDS-DMA piece; compute waves never wait on vmcnt in the K loop):
-    bit-identical to the four-wave kernel (same fragments, same k order, same epilogue), deterministic, float64 parity"""
-    import os
-    from wav2letter_amd import ops
-    g = torch.Generator(device="cpu").manual_seed(7 * M + 3 * N + K)
-    A = torch.randn(M, K, generator=g)
-    Bm = torch.randn(K, N, generator=g) / K ** 0.5
-    bias = torch.randn(N, generator=g)
-    want = (A.double() @ Bm.double() + bias.double()).numpy()
-    Ad = (A if akc else A.T.contiguous()).cuda()
-    Bd = (Bm.T.contiguous() if bkc else Bm).cuda()
-    os.environ["W2L_GEMM_LOADER"] = "1"
-    os.environ["W2L_GEMM_T160"] = "0"   # both sides on the 128x128 tile (the 160-wide kernel splits stream-K ranges differently)
-    try:
-        got = ops.gemm(Ad, Bd, akc, bkc, bias.cuda(), relu=True)
-        for _ in range(5):
-            assert torch.equal(got, ops.gemm(Ad, Bd, akc, bkc, bias.cuda(), relu=True))
-        os.environ["W2L_GEMM_LOADER"] = "0"
-        old = ops.gemm(Ad, Bd, akc, bkc, bias.cuda(), relu=True)
-    finally:
-        os.environ.pop("W2L_GEMM_LOADER")
-        os.environ.pop("W2L_GEMM_T160")
-    assert torch.equal(got, old)
-    assert rel(got, np.maximum(want, 0)) < TOL
 
 
 @pytest.mark.parametrize("M,N,K", [(4, 4, 32),             # one clamped tile, one K step
@@ -744,8 +684,7 @@ def test_product_library_ignores_kernel_variant_switches():
         "got = ops.gemm(A.cuda(), B.cuda(), True, False).cpu().double()\n"
         "want = A.double() @ B.double()\n"
         "print('REL', float((got - want).abs().max() / want.abs().max()))\n")
-    env = dict(os.environ, W2L_GEMM_ABL="1", W2L_GEMM_ABLBUF="1", W2L_FCC_ABL="1", W2L_TDS_ABL="7", W2L_GEMM_GLDS="0",
-               W2L_GEMM_P3="2", W2L_GEMM_LOADER="1")
+    env = dict(os.environ, W2L_GEMM_ABL="1", W2L_GEMM_ABLBUF="1", W2L_FCC_ABL="1", W2L_TDS_ABL="7", W2L_GEMM_GLDS="0")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -754,7 +693,6 @@ def test_product_library_ignores_kernel_variant_switches():
     # and the product library does not even contain the ablation / experimental kernels
     so = os.path.join(root, "wav2letter_amd", "libw2l_hip.so")
     blob = open(so, "rb").read()
-    assert b"gemm256_kernel" not in blob and b"gemm128w_kernel" not in blob
     assert b"W2L_GEMM_ABL" not in blob and b"W2L_FCC_ABL" not in blob
 
 

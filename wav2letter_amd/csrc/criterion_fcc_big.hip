@@ -45,6 +45,7 @@ constexpr int kBigMaxNB = 4;      // utterance tiles of 32 -> B <= 128
 constexpr int kBigStepThreads = 1024;  // per-utterance kernels that run once per call
 constexpr int kBigParts = 16;          // workgroups (partial maxima) per utterance and step
 constexpr int kBigMaxSW = 16;          // bound on partial slabs per row group
+constexpr int kBigCachePermille = 0;   // product default of BigDims::cache (see there)
 
 struct BigDims {
   int B, T, N;
@@ -65,6 +66,10 @@ struct BigDims {
   int fold; // W2L_FCC_FOLD=1 (probe library): the forward step's log / add-x / rescale epilogue runs inside the streaming kernel
             // (last arriver of each row group) instead of the separate fcc_big_step launch.  Bit-identical, MEASURED SLOWER:
             // 85.3 us per step against 82.4 (profiles/r02_run21_fcc_fold_negative.log), so the product keeps two launches
+  int cache; // per mille of every worker's share of the transition stream that is loaded with the DEFAULT cache policy (the
+            // rest nontemporal).  A worker reads the same slice at every one of the T steps: the default-policy part can stay
+            // resident in the 256 MiB Infinity Cache between steps while the nontemporal rest streams past it (a 400 MB
+            // stream loaded entirely with the default policy evicts itself before it is reused).  W2L_FCC_CACHE (probe).
   int abl;  // W2L_FCC_ABL: timing-only ablations 1 = no MFMA, 2 = no E-operand traffic; 4 = nontemporal loads of the
             // transition stream (results stay correct)
 };
@@ -107,6 +112,7 @@ inline BigDims big_dims(int B, int T, int N) {
   // (profiles/r01_run16_fcc_dma_ring_variants.log) 2x3 85.5 us, 1x6 85.8, 2x3 nt 77.6, 1x6 nt 76.0, ping-pong 94.0
   { const char* e = tune_env("W2L_FCC_DMA"); d.dma = e ? atoi(e) : 4; }
   { const char* e = tune_env("W2L_FCC_FOLD"); d.fold = e ? atoi(e) : 0; }
+  { const char* e = tune_env("W2L_FCC_CACHE"); d.cache = e ? atoi(e) : kBigCachePermille; if (d.cache < 0) d.cache = 0; if (d.cache > 1000) d.cache = 1000; }
   d.Np = (N + 32 * d.RT - 1) / (32 * d.RT) * (32 * d.RT);
   d.G = d.Np / (32 * d.RT);
   // The step is cut into U = G * nS stage-units (64 rows x 32 k) in row-group-major order and dealt
@@ -155,6 +161,7 @@ struct BigWs {
   float* scale;   // [B]
   float* gb;      // [B] scale * upstream grad
   unsigned* cnt;  // [G] arrival tickets of the folded step (self-resetting; zeroed once per call)
+  int* np;        // [G] partial slabs per row group (big_pieces: two 64-bit divisions each, taken once per call, not per frame)
   size_t bytes;
 };
 
@@ -176,6 +183,7 @@ __host__ __device__ inline BigWs big_ws(void* ws, const BigDims& d) {
   w.scale = (float*)take((size_t)d.B * sizeof(float));
   w.gb = (float*)take((size_t)d.B * sizeof(float));
   w.cnt = (unsigned*)take((size_t)d.G * sizeof(unsigned));
+  w.np = (int*)take((size_t)d.G * sizeof(int));
   w.bytes = (size_t)(p - (char*)ws);
   return w;
 }
@@ -601,6 +609,8 @@ __global__ __launch_bounds__(256, 2) void fcc_big_gemm_dma(const float4* __restr
   const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)op, 0, (int)((size_t)Bp * d.Kp * 4), 0x00020000);
   float* ring = lds + wave * kDmaWaveFloats;
   const int voff = lane * 16;
+  // DMA stages (global index) below this one belong to the cached part of this worker's share (BigDims::cache)
+  const long long sCache = NT ? ((long long)u0 + (long long)(u1 - u0) * d.cache / 1000) * (kBigU / kDmaU) : 0;
 
   while (u0 < u1) {
     const int g = u0 / d.nS, sb = u0 - g * d.nS;
@@ -617,13 +627,20 @@ __global__ __launch_bounds__(256, 2) void fcc_big_gemm_dma(const float4* __restr
       for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
     const uint32_t t0 = (uint32_t)(2 * g) * (uint32_t)NC, t1 = t0 + (uint32_t)NC;  // chunk index bases of the two row tiles
 
+    const long long sBase = (long long)g * d.nS * ratio;   // global index of DMA stage 0 of this row group
     auto issue = [&](int st, int slot) {  // 6 pieces of DMA stage st into ring slot
       float* base = ring + slot * kDmaStageFloats;
+      const bool nt = NT && sBase + st >= sCache;   // wave-uniform
 #pragma unroll
       for (int u = 0; u < kDmaU; ++u) {
         const uint32_t c = (uint32_t)st * kDmaU + u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lp_t)(base + (0 * kDmaU + u) * 256), 16, voff, (int)((t0 + c) * 1024u), 0, NT ? 2 : 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lp_t)(base + (1 * kDmaU + u) * 256), 16, voff, (int)((t1 + c) * 1024u), 0, NT ? 2 : 0);
+        if (nt) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lp_t)(base + (0 * kDmaU + u) * 256), 16, voff, (int)((t0 + c) * 1024u), 0, 2);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lp_t)(base + (1 * kDmaU + u) * 256), 16, voff, (int)((t1 + c) * 1024u), 0, 2);
+        } else {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lp_t)(base + (0 * kDmaU + u) * 256), 16, voff, (int)((t0 + c) * 1024u), 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lp_t)(base + (1 * kDmaU + u) * 256), 16, voff, (int)((t1 + c) * 1024u), 0, 0);
+        }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(re, (lp_t)(base + (2 * kDmaU + u) * 256), 16, voff, (int)(c * 1024u), 0, 0);
       }
     };
@@ -815,7 +832,7 @@ __global__ __launch_bounds__(256) void fcc_big_step(BigDims d, int t, const floa
     float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (t > 0) {
       float4 p4[kBigMaxSW];  // all slab loads in flight together, added in worker order
-      const int np = big_pieces(d, i0 / (32 * d.RT));
+      const int np = ws.np[i0 / (32 * d.RT)];
 #pragma unroll
       for (int s = 0; s < kBigMaxSW; ++s)
         p4[s] = s < np ? *(const float4*)(ws.part + ((size_t)s * d.Bp + b) * d.Np + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -927,7 +944,7 @@ __global__ __launch_bounds__(256) void fcc_big_bwd_step(BigDims d, int tm, float
   float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
   {
     float4 p4[kBigMaxSW];
-    const int np = big_pieces(d, i0 / (32 * d.RT));
+    const int np = ws.np[i0 / (32 * d.RT)];
 #pragma unroll
     for (int s = 0; s < kBigMaxSW; ++s)
       p4[s] = s < np ? *(const float4*)(ws.part + ((size_t)s * d.Bp + b) * d.Np + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1058,6 +1075,11 @@ static int big_pack(const BigDims& d, const BigWs& ws, const float* trans, bool 
   return W2L_OK;
 }
 
+__global__ __launch_bounds__(256) void big_pieces_k(BigDims d, int* __restrict__ np) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g < d.G) np[g] = big_pieces(d, g);
+}
+
 // packed operand buffers: forward operand a (padding must read as -inf -> exp = 0), backward r (padding 0)
 __global__ __launch_bounds__(256) void big_fill_k(float* __restrict__ p, size_t n, float v) {
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) p[e] = v;
@@ -1068,6 +1090,7 @@ int fcc_big_forward(int B, int T, int N, int scaleMode, const float* input, cons
   const BigDims d = big_dims(B, T, N);
   const BigWs ws = big_ws(workspace, d);
   hipLaunchKernelGGL(big_rowmax_k, dim3((unsigned)((d.Np + 3) / 4)), dim3(256), 0, s, N, d.Np, trans, ws.rm);
+  hipLaunchKernelGGL(big_pieces_k, dim3((unsigned)((d.G + 255) / 256)), dim3(256), 0, s, d, ws.np);
   W2L_LAUNCH_CHECK();
   int st = big_pack(d, ws, trans, false, s);
   if (st) return st;
@@ -1108,7 +1131,7 @@ int fcc_big_backward(int B, int T, int N, const float* trans, const float* grad,
                      float* transGrad, void* workspace, hipStream_t s) {
   const BigDims d = big_dims(B, T, N);
   const BigWs ws = big_ws(workspace, d);
-  int st = big_pack(d, ws, trans, true, s);  // rm is still valid from forward
+  int st = big_pack(d, ws, trans, true, s);  // rm and the piece table are still valid from forward
   if (st) return st;
   W2L_HIP_CHECK(hipMemsetAsync(ws.ep[0], 0, 2 * align_up((size_t)d.Bp * d.Kp * sizeof(float), 256), s));
   hipLaunchKernelGGL(fcc_big_bwd_init, dim3((unsigned)B), dim3(kBigStepThreads), 0, s, d, grad, inputGrad, ws);

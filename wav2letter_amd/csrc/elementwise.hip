@@ -9,6 +9,7 @@
 // recipes/streaming_convnets/inference/inference/module/nn/TDSBlock.cpp:58-70.
 // All kernels are float4-vectorised grid-stride loops (coalesced 16 B/lane).
 #include "common.hpp"
+#include "gemm.hpp"  // sk_scratch: the shared per-stream scratch (sumsq partials)
 
 namespace w2l {
 
@@ -441,7 +442,32 @@ __global__ __launch_bounds__(kEwThreads) void sumsq_k(const float* __restrict__ 
     s += (double)g[e] * g[e];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+  // DETERMINISTIC: one partial per workgroup (waves added in wave order), the partials added in a fixed order by
+  // sumsq_finish_k.  The norm gates every update (clip coefficient, non-finite skip) on every data-parallel rank: with
+  // atomicAdd(double) in arrival order the float clip coefficient could differ by an ulp between replicas and let them drift.
+  __shared__ double sm[kEwThreads / 64];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0;
+#pragma unroll
+    for (int w = 0; w < kEwThreads / 64; ++w) t += sm[w];
+    out[blockIdx.x] = t;
+  }
+}
+
+// out[0] = (accumulate ? out[0] : 0) + sum of the `parts` workgroup partials, always in the same order
+__global__ __launch_bounds__(256) void sumsq_finish_k(const double* __restrict__ part, int parts, double* __restrict__ out, int accumulate) {
+  __shared__ double sm[256];
+  double t = 0;
+  for (int i = threadIdx.x; i < parts; i += 256) t += part[i];
+  sm[threadIdx.x] = t;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.0) + sm[0];
 }
 
 // acc[0] = sum g^2 over the network gradients, acc[1] = over the criterion gradients (w2l_sumsq), batch = the
@@ -793,9 +819,15 @@ W2L_API int w2l_glu_backward(const float* x, const float* dy, float* dx, size_t 
 
 W2L_API int w2l_sumsq(const float* g, size_t n, double* out, int zeroFirst, w2l_stream_t stream) {
   if (!g || !out) return W2L_EINVAL;
-  if (zeroFirst) W2L_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(double), W2L_S));
-  if (!n) return W2L_OK;
-  hipLaunchKernelGGL(sumsq_k, dim3(ew_grid((n >> 2) + 1)), dim3(kEwThreads), 0, W2L_S, g, n, out);
+  if (!n) {
+    if (zeroFirst) W2L_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(double), W2L_S));
+    return W2L_OK;
+  }
+  const unsigned grid = ew_grid((n >> 2) + 1);
+  double* part = (double*)sk_scratch(W2L_S, kSkScratchBytes);   // the stream's scratch (work on a stream is serialised)
+  if (!part) return W2L_EHIP;
+  hipLaunchKernelGGL(sumsq_k, dim3(grid), dim3(kEwThreads), 0, W2L_S, g, n, part);
+  hipLaunchKernelGGL(sumsq_finish_k, dim3(1), dim3(256), 0, W2L_S, part, (int)grid, out, zeroFirst ? 0 : 1);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }

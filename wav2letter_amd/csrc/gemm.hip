@@ -26,10 +26,6 @@
 
 #include "gemm.hpp"
 #include "gemm_glds.hpp"
-#ifdef W2L_PROBE  // measured-slower kernel generations, kept for A/B work only
-#include "gemm_p3.hpp"
-#include "gemm_loader.hpp"
-#endif
 #include "gemm_t160.hpp"
 #include "gemm_bf16.hpp"
 
@@ -66,13 +62,6 @@ static bool glds_enabled() {
   const char* e = tune_env("W2L_GEMM_GLDS");
   return !(e && e[0] == '0');
 }
-
-#ifdef W2L_PROBE
-static int p3_mode() {
-  const char* e = tune_env("W2L_GEMM_P3");
-  return e ? atoi(e) : 0;
-}
-#endif
 
 static inline bool glds_ok(const float* p, int ld, int extent) {
   return (((uintptr_t)p) & 15) == 0 && ld % 4 == 0 && extent % 4 == 0 && extent >= 4;
@@ -196,20 +185,6 @@ int gemm_f32(const float* A, int lda, int a_kcontig, const float* B, int ldb, in
       }
       return launch128g(ga, a_kcontig != 0, gb, b_kcontig != 0, o, epi, s);
     }
-    // The 256x128 three-stage kernel (gemm_p3.hpp) is correct but measured SLOWER than the 128x128 two-stage
-    // kernel on MI355X (4096^3: 131 vs 143 TF/s; TDS fc shapes -5..8 %, profiles/r01_run13_gemm_256x128_3stage_ab.log):
-    // kept for A/B work, off by default.  W2L_GEMM_P3: 1 = by padded-area rule, 2 = whenever eligible.
-#ifdef W2L_PROBE
-    const int p3 = p3_mode();
-    if (p3 && ga.bytes && gb.bytes) {
-      const double pad256 = (double)((M + 255) / 256 * 256), pad128 = (double)((M + 127) / 128 * 128);
-      if (p3 == 2 || pad256 <= 1.03 * pad128) return launch256(ga, a_kcontig != 0, gb, b_kcontig != 0, o, epi, s);
-    }
-    {
-      const char* e = tune_env("W2L_GEMM_LOADER");  // loader-wave variant (gemm_loader.hpp)
-      if ((e ? atoi(e) : 0) && ga.bytes && gb.bytes) return launch128w(ga, a_kcontig != 0, gb, b_kcontig != 0, o, epi, s);
-    }
-#endif
     // 160-wide tiles where 128 leaves a ragged last tile column / row (every TDS fc shape: gemm_t160.hpp)
     if (const int which = t160_choice(ga, gb, o)) {
       bool launched = false;

@@ -5,6 +5,7 @@
 // the DAG in reverse topological order.  Only two kinds of nodes exist on the hot path -- "criterion" and "planned
 // network" -- so one loss.backward() is: criterion backward kernels -> dEmission -> the whole network's backward.
 #include <dlfcn.h>
+#include <time.h>
 
 #include <algorithm>
 #include <cmath>
@@ -394,27 +395,46 @@ void initDistributed(int worldRank, int worldSize, int maxDevicesPerNode, const 
   bindSym(r.lib, "ncclAllReduce", r.AllReduce);
   bindSym(r.lib, "ncclCommDestroy", r.CommDestroy);
   bindSym(r.lib, "ncclGetErrorString", r.GetErrorString);
-  ncclUniqueId id;
-  std::memset(&id, 0, sizeof id);
+  // File rendezvous (the reference's --rndv_filepath).  The record carries a magic word and rank 0's wall-clock time of
+  // publication: a reader only accepts a record published no earlier than two minutes before its own start, rank 0
+  // removes whatever an earlier run left under the name before it publishes, and removes its own record once every rank
+  // has joined (ncclCommInitRank is collective) -- so a `continue` / re-run with the same --rndv_filepath never picks up
+  // the previous run's ncclUniqueId (which would hang ncclCommInitRank).
+  struct RndvRecord { unsigned long long magic; long long publishedNs; ncclUniqueId id; };
+  constexpr unsigned long long kRndvMagic = 0x7732'6c72'6e64'7631ull;   // "w2lrndv1"
+  auto nowNs = [] { timespec ts; clock_gettime(CLOCK_REALTIME, &ts); return (long long)ts.tv_sec * 1000000000ll + ts.tv_nsec; };
+  const long long startNs = nowNs();
+  RndvRecord rec;
+  std::memset(&rec, 0, sizeof rec);
+  ncclUniqueId& id = rec.id;
   const std::string path = rndvFilepath + "/w2l_nccl_id." + std::to_string(worldSize);
   if (worldSize > 1 && rndvFilepath.empty()) throw std::invalid_argument("initDistributed: --rndv_filepath is needed for world_size > 1");
   if (worldRank == 0) {
     ncclCheck(r.GetUniqueId(&id), "ncclGetUniqueId");
     if (worldSize > 1) {   // write to a temporary name, then rename: readers never see a partial file
+      (void)unlink(path.c_str());   // a record left behind by a run that died during its rendezvous
+      rec.magic = kRndvMagic;
+      rec.publishedNs = nowNs();
       const std::string tmp = path + ".tmp";
-      { std::ofstream f(tmp, std::ios::binary); f.write((const char*)&id, sizeof id); if (!f) throw std::runtime_error("cannot write " + tmp); }
+      { std::ofstream f(tmp, std::ios::binary); f.write((const char*)&rec, sizeof rec); if (!f) throw std::runtime_error("cannot write " + tmp); }
       if (rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error("cannot publish " + path);
     }
   } else {
     bool got = false;
     for (int tries = 0; tries < 6000 && !got; ++tries) {   // up to 10 minutes
       std::ifstream f(path, std::ios::binary);
-      if (f && f.read((char*)&id, sizeof id)) got = true;
-      else usleep(100000);
+      RndvRecord in;
+      if (f && f.read((char*)&in, sizeof in) && in.magic == kRndvMagic && in.publishedNs >= startNs - 120ll * 1000000000ll) {
+        rec = in;
+        got = true;
+      } else {
+        usleep(100000);
+      }
     }
-    if (!got) throw std::runtime_error("rendezvous file " + path + " did not appear");
+    if (!got) throw std::runtime_error("rendezvous file " + path + " did not appear (or only a stale one from an earlier run)");
   }
   ncclCheck(r.CommInitRank(&r.comm, worldSize, id, worldRank), "ncclCommInitRank");
+  if (worldRank == 0 && worldSize > 1) (void)unlink(path.c_str());   // every rank has read it: nothing stale survives a successful start
   r.rank = worldRank;
   r.size = worldSize;
 }

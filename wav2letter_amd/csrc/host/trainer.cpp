@@ -201,6 +201,7 @@ W2L_API int w2l_trainer_forward_backward(void* h, const float* x, const int* tar
                                          void* stream) {
   Trainer* t = (Trainer*)h;
   TRY(h, {
+    if (!x || !target) throw std::invalid_argument("forward_backward: null input");   // before anything is enqueued with them
     Ctx c = makeCtx(t, stream, true);
     { MatmulMode mm(t->mixedPrecision); t->emission = t->net->forward(c, t->arena, x); }
     float* cp = t->params + t->netFloats;
@@ -208,7 +209,6 @@ W2L_API int w2l_trainer_forward_backward(void* h, const float* x, const int* tar
     SequenceCriterion* crit = t->activeCrit();
     crit->forward(c, t->B, t->Tout, t->nLabel, t->L, t->emission, target, t->loss, t->critWs, cp);
     // d(sum_b loss_b)/d loss_b = 1
-    if (!x || !target) throw std::invalid_argument("forward_backward: null input");
     hipCheck(hipMemsetAsync(t->gradLoss, 0, sizeof(float) * (((size_t)t->B + 63) / 64 * 64), c.stream), "memset");
     w2lCheck(w2l_fill(t->gradLoss, (size_t)t->B, 1.f, c.stream), "fill");
     w2lCheck(w2l_fill(t->batchSlot, 1, (float)t->B, c.stream), "batch slot");  // rides the gradient all-reduce
@@ -231,9 +231,15 @@ W2L_API int w2l_trainer_update(void* h, float lr, float lrcrit, float momentum, 
     const float gs = totalBatch > 0.f ? 1.f / totalBatch : 0.f;
     if (!t->guardZeroed) { hipCheck(hipMemsetAsync(t->sumsq, 0, sizeof(double) * 8, s), "memset"); t->guardZeroed = true; }
     // --linseg: the reference trains the warm-up phase with its OWN optimizers (linNetoptim / linCritoptim,
-    // Train.cpp:589-617), so the ASG phase proper starts from zero momentum: clear the arena at the switch
-    if (t->linseg && t->linsegUpdates && t->step == t->linsegUpdates && t->mom && momentum != 0.f)
-      hipCheck(hipMemsetAsync(t->mom, 0, sizeof(float) * (t->netFloats + t->critFloats), s), "linseg momentum reset");
+    // Train.cpp:589-617), so the ASG phase proper starts from fresh optimizer state: clear the momentum arena -- SGD
+    // velocity, or the Adagrad / Adadelta gradient statistics it holds -- and Adadelta's second arena at the switch
+    if (t->linseg && t->linsegUpdates && t->step == t->linsegUpdates) {
+      const bool stateful = momentum != 0.f || t->netOptim != 0 || t->critOptim != 0;
+      if (t->mom && stateful)
+        hipCheck(hipMemsetAsync(t->mom, 0, sizeof(float) * (t->netFloats + t->critFloats), s), "linseg optimizer-state reset");
+      if (t->state2 && (t->netOptim == 2 || t->critOptim == 2))
+        hipCheck(hipMemsetAsync(t->state2, 0, sizeof(float) * (t->netFloats + t->critFloats), s), "linseg optimizer-state reset");
+    }
     // the norm is taken on EVERY update (also with --maxgradnorm=0): it is the non-finite guard of the step
     w2lCheck(w2l_sumsq(t->grads, t->netFloats, t->sumsq, 1, s), "sumsq");
     w2lCheck(w2l_sumsq(t->grads + t->netFloats, t->critFloats, t->sumsq + 1, 1, s), "sumsq");

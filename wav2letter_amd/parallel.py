@@ -125,11 +125,22 @@ class OverlappedReducer:
     def __init__(self, trainer, n_buckets=4):
         self.tr = trainer
         offs = bucket_offsets(trainer.param_table(), trainer.n_floats, n_buckets)
-        trainer.set_grad_buckets(offs)
         # the last bucket runs over the 4-float tail too: tail[0] = local batch size, summed with the gradients
         # (the reference all-reduces the batch size on its own, recipes/slimIPL/src/Train.cpp:1743-1747)
         self.offsets = offs + [trainer.grads_full.numel()]
-        self.comm = torch.cuda.Stream(device=trainer.device)
+        # A gradient arena on the host (the world_size-2 gloo tests of the bucket walk on the REAL arena layout,
+        # tests/test_distributed_cpu.py) has no streams and no bucket events: the same walk, issued synchronously.
+        self.on_gpu = trainer.grads_full.is_cuda
+        if self.on_gpu:
+            trainer.set_grad_buckets(offs)
+            self.comm = torch.cuda.Stream(device=trainer.device)
+        else:
+            trainer.bucket_offsets = list(offs)
+            self.comm = None
+
+    def bucket_bytes(self):
+        """bytes each collective of a step moves, in issue order (last bucket first)"""
+        return [4 * (self.offsets[k + 1] - self.offsets[k]) for k in reversed(range(len(self.offsets) - 1))]
 
     def reduce(self):
         """call right after trainer.forward_backward(); returns when every collective is enqueued and the
@@ -137,8 +148,11 @@ class OverlappedReducer:
         works = []
         g = self.tr.grads_full
         for k in reversed(range(len(self.offsets) - 1)):
-            self.tr.wait_bucket(k, self.comm)
-            with torch.cuda.stream(self.comm):
+            if self.on_gpu:
+                self.tr.wait_bucket(k, self.comm)
+                with torch.cuda.stream(self.comm):
+                    works.append(dist.all_reduce(g[self.offsets[k]:self.offsets[k + 1]], async_op=True))
+            else:
                 works.append(dist.all_reduce(g[self.offsets[k]:self.offsets[k + 1]], async_op=True))
         for w in works:
             w.wait()
