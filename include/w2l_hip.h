@@ -160,6 +160,26 @@ int w2l_linear_backward_data_add(int M, int in, int out, const float* dy, const 
  * rounded to nearest even on the way into LDS) and accumulates in fp32; operands, results, master weights and the
  * criteria stay fp32.  Process-wide, returns the previous mode. */
 int w2l_set_matmul_precision(int mode);
+/* Mixed precision with bf16 OPERAND STORAGE (round 3): the activations, the output gradients and per-step copies of the fp32
+ * master weights are kept as bf16 images in HBM and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; results,
+ * bias, every non-GEMM operator and the criterion stay fp32 (cpc/Train.cpp:1184).
+ * w2l_bf16_convert: x [rows][cols] fp32 (leading dimension ldx) -> rowMajor [rows][ldRows] and / or transposed [cols][ldTrans]
+ *   bf16 (round to nearest even), zero-padded to the leading dimension; either may be NULL; ldRows >= cols, ldTrans >= rows,
+ *   both multiples of 16 elements (use the reduction length rounded up to 64); 16-byte aligned outputs.
+ * w2l_gemm_bf16: C[M][N] (fp32, ldc) = A[M][K] . B[N][K]^T (+ bias[n]) (ReLU) (dropout) (mask) (+ addend | + C); A and B are
+ *   k-contiguous bf16 images whose rows are ZERO from column K up to K rounded to 64 (lda, ldb >= that, even). */
+typedef struct {
+  const float* mask;  /* v = mask[m][n] > 0 ? v * maskScale : 0  (layout of C) */
+  float maskScale;
+  const float* addend; /* v += addend[m][n] (layout of C) */
+  int accumulate;      /* v += C[m][n] (ignored when addend is set) */
+  double dropP;        /* > 0: dropout with the library's stateless hash of (m * ldc + n, dropSeed, dropStream) */
+  uint32_t dropSeed, dropStream;
+} w2l_gemm_epilogue;
+int w2l_bf16_convert(const float* x, size_t rows, int cols, size_t ldx, uint16_t* rowMajor, size_t ldRows,
+                     uint16_t* transposed, size_t ldTrans, w2l_stream_t stream);
+int w2l_gemm_bf16(int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B, int ldb, float* C, int ldc,
+                  const float* bias, int relu, const w2l_gemm_epilogue* epilogue, w2l_stream_t stream);
 int w2l_colsum(const float* x, float* out, size_t M, int N, w2l_stream_t stream); /* bias grads */
 
 /* fl::Conv2D kw x 1 over time (arch tokens C / C2 / TDS). x [B][T][H][Cin],

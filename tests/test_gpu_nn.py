@@ -762,3 +762,82 @@ def test_linear_ops_bf16_epilogues(oracle, bf16_matmul):
     assert rel(dx, odx) < BF16_TOL and rel(dw, odw) < BF16_TOL and rel(db, odb) < 1e-4   # the bias gradient is an fp32 column sum
     add = rng.normal(size=(M, K)).astype(np.float32)
     assert rel(ops.linear_backward_data_add(dev(dy), dev(w), dev(add)), odx + add) < BF16_TOL
+
+
+# ----------------------------------------------------------------------------------------------
+# mixed precision with bf16 OPERAND STORAGE (round 3): convert.hip + gemm_bf16g.hpp
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,cols", [(1, 1), (5, 3), (64, 64), (70, 130), (187, 2160), (300, 9998), (1200, 77)])
+def test_bf16_convert_images(rows, cols):
+    """both images of w2l_bf16_convert against torch's fp32 -> bfloat16 conversion (round to nearest even) BIT FOR BIT, zero
+    padding of either leading dimension to the next multiple of 64 included; each image alone gives the same bytes"""
+    from wav2letter_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(rows * 31 + cols)
+    x = (torch.randn(rows, cols, generator=g) * 10.0 ** torch.randint(-3, 4, (rows, cols), generator=g)).cuda()
+    want = x.to(torch.bfloat16)
+    rm, tr = ops.bf16_convert(x, True, True)
+    colsP, rowsP = (cols + 63) // 64 * 64, (rows + 63) // 64 * 64
+    assert rm.shape == (rows, colsP) and tr.shape == (cols, rowsP)
+    assert torch.equal(rm[:, :cols].view(torch.int16), want.view(torch.int16))
+    assert torch.equal(tr[:, :rows].view(torch.int16), want.T.contiguous().view(torch.int16))
+    assert (rm[:, cols:].view(torch.int16) == 0).all() and (tr[:, rows:].view(torch.int16) == 0).all()
+    rm2, none = ops.bf16_convert(x, True, False)
+    none2, tr2 = ops.bf16_convert(x, False, True)
+    assert none is None and none2 is None
+    assert torch.equal(rm2.view(torch.int16), rm.view(torch.int16)) and torch.equal(tr2.view(torch.int16), tr.view(torch.int16))
+
+
+def _bf16_ref(a):
+    return a.to(torch.bfloat16).double()
+
+
+@pytest.mark.parametrize("M,N,K", [(4, 4, 8), (128, 128, 64), (260, 388, 96), (1028, 2052, 1440), (187 * 4, 1200, 1200),
+                                    (11968, 2160, 2160), (3008, 9998, 1024), (640, 136, 24000), (2160, 9998, 748),
+                                    (1200, 1200, 11968)])
+def test_gemm_bf16_operand_storage(M, N, K):
+    """C = A B^T on bf16 images against the float64 product of the SAME bf16-rounded operands (the kernel's only rounding is
+    the fp32 accumulation: 2e-5 of the largest magnitude), run-to-run determinism (stream-K slabs are added in range order),
+    and the shapes of the three products of config 3 / config 5 layers incl. a ragged K and an N that is not a multiple of 4"""
+    from wav2letter_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + 3 * N + 7 * K)
+    A = torch.randn(M, K, generator=g).cuda()
+    B = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    Ab, _ = ops.bf16_convert(A)
+    Bb, _ = ops.bf16_convert(B)
+    want = (_bf16_ref(A) @ _bf16_ref(B).T).cpu().numpy()
+    got = ops.gemm_bf16(Ab, Bb, K)
+    assert rel(got, want) < 2e-5
+    assert torch.equal(got, ops.gemm_bf16(Ab, Bb, K))
+    # against the UNROUNDED product: the stated bf16 tolerance
+    assert rel(got, (A.double() @ B.double().T).cpu().numpy()) < BF16_TOL
+    wb = want + bias.double().cpu().numpy()
+    assert rel(ops.gemm_bf16(Ab, Bb, K, bias=bias, relu=True), np.maximum(wb, 0)) < 2e-5
+
+
+def test_gemm_bf16_operand_storage_epilogues(oracle):
+    """the fp32 engine's epilogue on the bf16 product: mask, addend, accumulate into C, dropout (the library's stateless hash:
+    bit-identical keep pattern to w2l_dropout_inplace over the dense output)"""
+    from wav2letter_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(11)
+    M, N, K = 700, 520, 333
+    A = torch.randn(M, K, generator=g).cuda()
+    B = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    mask = torch.randn(M, N, generator=g).cuda()
+    add = torch.randn(M, N, generator=g).cuda()
+    Ab, _ = ops.bf16_convert(A)
+    Bb, _ = ops.bf16_convert(B)
+    base = (_bf16_ref(A) @ _bf16_ref(B).T)
+    got = ops.gemm_bf16(Ab, Bb, K, mask=mask, mask_scale=1.25)
+    assert rel(got, (torch.where(mask.double() > 0, base * 1.25, torch.zeros_like(base))).cpu().numpy()) < 2e-5
+    got = ops.gemm_bf16(Ab, Bb, K, addend=add)
+    assert rel(got, (base + add.double()).cpu().numpy()) < 2e-5
+    c = add.clone()
+    ops.gemm_bf16(Ab, Bb, K, out=c, accumulate=True)
+    assert rel(c, (base + add.double()).cpu().numpy()) < 2e-5
+    p, seed, sid = 0.3, 1234, 7
+    y = ops.gemm_bf16(Ab, Bb, K, bias=bias, relu=True, drop_p=p, drop_seed=seed, drop_stream=sid)
+    y0 = ops.gemm_bf16(Ab, Bb, K, bias=bias, relu=True)
+    ops.dropout_(y0, p, seed, sid)
+    assert torch.equal(y, y0)

@@ -101,6 +101,8 @@ class _SIGS:
     w2l_linear_backward_weight = (_i, [_i, _i, _i, _p, _p, _p, _p])
     w2l_colsum = (_i, [_p, _p, _sz, _i, _p])
     w2l_set_matmul_precision = (_i, [_i])
+    w2l_bf16_convert = (_i, [_p, _sz, _i, _sz, _p, _sz, _p, _sz, _p])
+    w2l_gemm_bf16 = (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p])
     w2l_mfsc_spectrum = (_i, [_p, _p, _sz, _i, _i, _i, _p])
     w2l_mfsc_log_transpose = (_i, [_p, _p, _i, _i, _i, _i, _f, _p])
     w2l_weightnorm_forward = (_i, [_p, _p, _p, _p, _i, _i, _p])
@@ -145,6 +147,11 @@ class _SIGS:
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "T", "H", "Cin", "Cout", "kw", "stride", "padl", "padr")]
+
+
+class GemmEpilogue(C.Structure):  # w2l_gemm_epilogue
+    _fields_ = [("mask", C.c_void_p), ("maskScale", C.c_float), ("addend", C.c_void_p), ("accumulate", C.c_int),
+                ("dropP", C.c_double), ("dropSeed", C.c_uint32), ("dropStream", C.c_uint32)]
 
 
 class BgemmDesc(C.Structure):  # w2l_bgemm_desc

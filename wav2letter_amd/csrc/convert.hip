@@ -1,0 +1,95 @@
+// convert.hip -- fp32 -> bf16 operand copies of the mixed-precision mode (BASELINE configs 3 / 5; fl's AMP casts the
+// operands of linear / conv to half precision and keeps fp32 master weights: recipes/slimIPL/src/Train.cpp:211,
+// :1681-1760, recipes/joint_training_vox_populi/cpc/Train.cpp:365, :1184).
+//
+// One pass over an fp32 matrix x [rows][cols] (leading dimension ldx) writes up to two bf16 images
+//   rowMajor   [rows][ldRows]    rowMajor[r][c]   = bf16(x[r][c]),  columns cols .. ldRows-1 ZERO
+//   transposed [cols][ldTrans]   transposed[c][r] = bf16(x[r][c]),  columns rows .. ldTrans-1 ZERO
+// (round to nearest even, v_cvt_pk_bf16_f32).  The zero padding is what lets the bf16 GEMM (gemm_bf16g.hpp) run whole
+// 64-k tiles without a tail: ldRows / ldTrans are the reduction lengths rounded up to 64.  The transposed image is the
+// k-contiguous operand of the weight-gradient product dW = x^T dy (reduction over the rows of x) and of the forward
+// product against a weight stored [in][out].
+// HBM-bound: 4 bytes read, 2 (+2) bytes written per element.
+#include "common.hpp"
+
+namespace w2l {
+
+typedef __bf16 cv_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float cv_f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t cv_pack2(float a, float b) {
+  const cv_f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, cv_bf16x2_t));
+}
+
+constexpr int kCvTile = 64;
+
+// grid (ceil(max(cols, ldRows) / 64), ceil(max(rows, ldTrans) / 64)), 256 threads: a 64 x 64 tile of x
+__global__ __launch_bounds__(256) void cvt_bf16_k(const float* __restrict__ x, size_t rows, int cols, size_t ldx,
+                                                  uint16_t* __restrict__ rowMajor, size_t ldRows,
+                                                  uint16_t* __restrict__ transposed, size_t ldTrans) {
+  __shared__ float tile[kCvTile][kCvTile + 1];
+  const size_t r0 = (size_t)blockIdx.y * kCvTile;
+  const int c0 = blockIdx.x * kCvTile;
+  const int tid = threadIdx.x;
+  const int cq = (tid & 15) * 4, rr = tid >> 4;   // 4 columns at c0 + cq, rows rr + 16 i
+  const bool vec = (((uintptr_t)x) & 15) == 0 && (ldx & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const size_t r = r0 + rr + 16 * i;
+    const int c = c0 + cq;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows) {
+      const float* src = x + r * ldx + c;
+      if (vec && c + 3 < cols) {
+        const float4 q = *(const float4*)src;
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c + e < cols) v[e] = src[e];
+      }
+    }
+    if (rowMajor && r < rows && (size_t)c < ldRows) {   // ldRows % 4 == 0 (host-checked): whole 8-byte stores
+      const uint2 q = make_uint2(cv_pack2(v[0], v[1]), cv_pack2(v[2], v[3]));
+      *(uint2*)(rowMajor + r * ldRows + c) = q;
+    }
+    if (transposed) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tile[rr + 16 * i][cq + e] = v[e];
+    }
+  }
+  if (!transposed) return;
+  __syncthreads();
+  // transposed image: thread -> column c0 + (tid >> 2), 16 consecutive rows r0 + 16 (tid & 3) .. + 16 = 32 bytes
+  const int c = c0 + (tid >> 2);
+  const size_t rb = r0 + 16 * (tid & 3);
+  if (c >= cols || rb >= ldTrans) return;   // ldTrans % 16 == 0 (host-checked): whole 32-byte runs
+  uint32_t p[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) p[e] = cv_pack2(tile[16 * (tid & 3) + 2 * e][tid >> 2], tile[16 * (tid & 3) + 2 * e + 1][tid >> 2]);
+  uint4* dst = (uint4*)(transposed + (size_t)c * ldTrans + rb);
+  dst[0] = make_uint4(p[0], p[1], p[2], p[3]);
+  dst[1] = make_uint4(p[4], p[5], p[6], p[7]);
+}
+
+}  // namespace w2l
+
+using namespace w2l;
+
+// x [rows][cols] fp32 (leading dimension ldx) -> rowMajor [rows][ldRows] and / or transposed [cols][ldTrans] bf16, zero
+// padded (see the file header).  Either output may be null.  ldRows >= cols and ldTrans >= rows, both multiples of 16;
+// outputs 16-byte aligned.
+W2L_API int w2l_bf16_convert(const float* x, size_t rows, int cols, size_t ldx, uint16_t* rowMajor, size_t ldRows,
+                             uint16_t* transposed, size_t ldTrans, w2l_stream_t stream) {
+  if (!x || rows == 0 || cols <= 0 || ldx < (size_t)cols || (!rowMajor && !transposed)) return W2L_EINVAL;
+  if (rowMajor && (ldRows < (size_t)cols || (ldRows & 15) || (((uintptr_t)rowMajor) & 15))) return W2L_EINVAL;
+  if (transposed && (ldTrans < rows || (ldTrans & 15) || (((uintptr_t)transposed) & 15))) return W2L_EINVAL;
+  const size_t spanC = rowMajor && ldRows > (size_t)cols ? ldRows : (size_t)cols;
+  const size_t spanR = transposed && ldTrans > rows ? ldTrans : rows;
+  const dim3 grid((unsigned)((spanC + kCvTile - 1) / kCvTile), (unsigned)((spanR + kCvTile - 1) / kCvTile));
+  if (grid.y > 65535u) return W2L_EUNSUPPORTED;
+  hipLaunchKernelGGL(cvt_bf16_k, grid, dim3(256), 0, (hipStream_t)stream, x, rows, cols, ldx, rowMajor, ldRows, transposed, ldTrans);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}

@@ -167,11 +167,16 @@ __global__ __launch_bounds__(kRowThreads) void ctc_rows_lse_big(int T, int N, in
   }
 }
 
+// log-sum-exp of three fp64 lattice values with fp32 corrections.  The correction terms use the FULL-precision fp32 expf /
+// logf (ocml, < 1 ulp, unbiased), not the 1-ulp hardware v_exp_f32 / v_log_f32 the ASG scans use: the hardware functions
+// round faithfully, not to nearest, and their ~1e-7 per-step bias adds up LINEARLY over a long scan -- at T = 700 frames and
+// 300 labels the occupancies were off by 1e-4 (run j1).  The two scans of an utterance now run side by side with a deep
+// prefetch, so the few extra instructions per step are affordable.
 __device__ __forceinline__ double lse3(double a, double b, double c) {
   double m = fmax(a, fmax(b, c));
   if (m == -INFINITY) return m;
-  float s = fast_expf((float)(a - m)) + fast_expf((float)(b - m)) + fast_expf((float)(c - m));
-  return m + (double)fast_logf(s);   // s in [1, 3]: hardware log2 * ln 2 (ocml's __logf is a ~12-instruction sequence)
+  float s = expf((float)(a - m)) + expf((float)(b - m)) + expf((float)(c - m));
+  return m + (double)logf(s);   // s in [1, 3]
 }
 
 // alpha OR beta over the extended label sequence (blockIdx.y = 0: alpha, 1: beta): one wavefront per (utterance,

@@ -28,6 +28,7 @@
 #include "gemm_glds.hpp"
 #include "gemm_t160.hpp"
 #include "gemm_bf16.hpp"
+#include "gemm_bf16g.hpp"
 
 namespace w2l {
 
@@ -277,6 +278,30 @@ W2L_API int w2l_linear_backward_weight(int M, int in, int out, const float* x, c
   // The output is small (in x out) and the reduction long: the stream-K schedule splits K.
   hipStream_t s = (hipStream_t)stream;
   return gemm_f32(x, in, 0, dy, out, 0, dw, out, in, out, M, nullptr, 0, 1, s);
+}
+
+// ---- mixed precision with bf16 OPERANDS in HBM (gemm_bf16g.hpp): C[M][N] (fp32) = A[M][K] . B[N][K]^T, both operands
+// k-contiguous bf16 images written by w2l_bf16_convert (rows zero-padded to a multiple of 64 k), fp32 accumulation and the
+// fp32 engine's epilogue: bias[n], ReLU, dropout, mask, addend / accumulate.  The three products of fl::Linear:
+//   forward  y  = x w + b      A = x  [M][in]   (row-major image),  B = w^T  [out][in]  (transposed image of w [in][out])
+//   dx       dx = dy w^T       A = dy [M][out]  (row-major image),  B = w    [in][out]  (row-major image)
+//   dw       dw = x^T dy       A = x^T [in][M]  (transposed image), B = dy^T [out][M]   (transposed image), C = dw [in][out]
+W2L_API int w2l_gemm_bf16(int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B, int ldb, float* C, int ldc,
+                          const float* bias, int relu, const w2l_gemm_epilogue* e, w2l_stream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return W2L_EINVAL;
+  GemmOut o{C, bias, M, N, K, ldc, 0};
+  int epi = (bias ? EPI_BIAS : 0) | (relu ? EPI_RELU : 0);
+  if (e) {
+    if (e->mask) { o.mask = e->mask; o.maskScale = e->maskScale; epi |= EPI_MASK; }
+    if (e->addend) { o.addend = e->addend; epi |= EPI_ACCUM; }
+    else if (e->accumulate) epi |= EPI_ACCUM;
+    if (e->dropP > 0.0) {
+      o.dropThr = dropout_threshold(e->dropP); o.dropSeed = e->dropSeed; o.dropStream = e->dropStream;
+      o.dropScale = (float)(1.0 / (1.0 - e->dropP));
+      epi |= EPI_DROPOUT;
+    }
+  }
+  return launch128h(A, lda, B, ldb, o, epi, (hipStream_t)stream);
 }
 
 // generic entry (tests / benchmarks): C[M][N] = op(A) op(B) (+bias)(relu)

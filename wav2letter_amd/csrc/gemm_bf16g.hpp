@@ -1,0 +1,226 @@
+// gemm_bf16g.hpp -- bf16-operand MFMA GEMM for the mixed-precision mode (BASELINE configs 3 and 5, fl's
+// --fl_amp_use_mixed_precision restated for bf16: recipes/slimIPL/src/Train.cpp:211, :1681-1760; the criterion input stays
+// f32, recipes/joint_training_vox_populi/cpc/Train.cpp:1184).
+//
+//   C[M][N] (fp32) = A[M][K] . B[N][K]^T,  A and B bf16 in HBM, k contiguous, rows zero-padded to a multiple of 64 k
+//
+// Round 2's kernel (gemm_bf16.hpp) kept fp32 operands in HBM and converted them on the way into LDS: it was bound by
+// staging 4-byte operands (190 TF/s in the config-3 step).  Here the operands ARE bf16 (activations and weight copies are
+// converted once per step by convert.hip, the transposed copies the weight-gradient product needs included), so the tile
+// traffic halves, the K tile doubles to 64 and the whole staging path is the fp32 engine's LDS-DMA one:
+//   * a 128 x 64 bf16 operand tile is byte for byte the 128 x 32 fp32 tile of gemm_glds.hpp (128 rows of 128 bytes), so the
+//     buffer-addressed `buffer_load_dwordx4 ... lds` pieces, their XOR-swizzled source chunks and the conflict-free
+//     ds_read_b128 fragment reads are reused unchanged: the 16 bytes a lane reads are now 8 consecutive k of its row --
+//     exactly the A / B operand of ONE v_mfma_f32_32x32x16_bf16 (lane l: row l & 31, k = 16 s + 8 (l >> 5) .. + 8);
+//   * 4 waves x (2 x 2) 32 x 32 fp32 accumulators per 128 x 128 tile: the C layout is dtype-independent on gfx950, so the
+//     fp32 engine's epilogues (bias / ReLU / dropout / mask / addend, 16-byte stores through LDS), its persistent
+//     XCD-major schedule and its in-kernel stream-K slab reduction are shared as they are;
+//   * a K tile is 16 MFMAs of 32 cycles per wave instead of 64 of 64: the next tile's eight LDS-DMA pieces are issued at the
+//     TOP of the iteration (they have the whole tile, and the co-resident workgroup's, to land) and the fragment reads of
+//     k-step s + 1 sit between the MFMAs of k-step s.
+#pragma once
+#include "gemm_glds.hpp"
+
+namespace w2l {
+
+typedef __bf16 bf16x8v_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8v_t h_frag(const float* tile, int row, int s, int lh, int li) {
+  // chunk (2 s + lh) of the 128-byte row, at the XOR-swizzled slot the DMA source permutation put it in (g_init_offs<true>)
+  const int c = (2 * s) ^ lh ^ ((li >> 1) & 7);
+  const f32x4 v = *(const f32x4*)(tile + row * 32 + 4 * c);
+  return __builtin_bit_cast(bf16x8v_t, v);
+}
+
+// segment fields as SGPRs: left in VGPRs (the schedule's 64-bit divisions), the K-tile index makes hipcc wrap every LDS-DMA
+// issue in a readfirstlane "waterfall" loop for its scalar offset (seen in the first build: 8 loops per K tile)
+__device__ __forceinline__ GSeg h_pin(GSeg s) {
+  s.tile = __builtin_amdgcn_readfirstlane(s.tile);
+  s.kb = __builtin_amdgcn_readfirstlane(s.kb);
+  s.ke = __builtin_amdgcn_readfirstlane(s.ke);
+  s.slab = __builtin_amdgcn_readfirstlane(s.slab);
+  s.valid = __builtin_amdgcn_readfirstlane((int)s.valid) != 0;
+  return s;
+}
+
+// aop / bop: bf16 matrices viewed as float matrices of half the width (p, ld in floats = bf16 elements / 2); plan.kTiles
+// counts 64-k tiles.  Same launch geometry as gemm128g_kernel.
+__global__ __launch_bounds__(256, 2) void gemm128h_kernel(GOp aop, GOp bop, GemmOut out, SkPlan plan, int workers, int wide) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int li = lane & 31, lh = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(xcd_major(blockIdx.x, workers));
+  constexpr uint32_t kStepBytes = 128;   // one K tile = 64 bf16 = 128 bytes along a row
+
+  GSeg seg = h_pin(g_segment(plan, w, workers, 0));
+  if (!seg.valid) return;
+  uint32_t va[4], vb[4];
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)aop.p, 0, (int)aop.bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)bop.p, 0, (int)bop.bytes, 0x00020000);
+  int bx, by;
+  sk_tile_xy(plan, seg.tile, bx, by);
+  g_init_offs<true>(va, aop, bx * 128, wave, lane);
+  g_init_offs<true>(vb, bop, by * 128, wave, lane);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    g_issue1_buf(ra, va[j], kStepBytes * (uint32_t)seg.kb, smem, wave, j);
+    g_issue1_buf(rb, vb[j], kStepBytes * (uint32_t)seg.kb, smem + 4096, wave, j);
+  }
+  int stage = 0;
+  __syncthreads();  // (drains the LDS-DMA: vmcnt(0) precedes the barrier)
+
+  for (int ord = 0;; ++ord) {
+    const GSeg nxt = h_pin(g_segment(plan, w, workers, ord + 1));
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (out.epi & EPI_BIAS) {
+      const int nb = by * 128 + wn + 4 * (lane & 15);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[e] = nb + e < out.N ? out.bias[nb + e] : 0.f;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int kt = seg.kb; kt < seg.ke; ++kt) {
+      const float* As = smem + stage * kGStageFloats;
+      const float* Bs = As + 4096;
+      float* An = smem + (stage ^ 1) * kGStageFloats;
+      // what goes to the other stage during this iteration: the next K tile, or the first K tile of the next segment, or
+      // (very last iteration of this worker) a harmless re-load of this tile
+      uint32_t offA = kStepBytes * (uint32_t)kt, offB = offA;
+      if (kt + 1 < seg.ke) {
+        offA += kStepBytes; offB += kStepBytes;
+      } else if (nxt.valid) {
+        int nbx, nby;
+        sk_tile_xy(plan, nxt.tile, nbx, nby);
+        g_init_offs<true>(va, aop, nbx * 128, wave, lane);
+        g_init_offs<true>(vb, bop, nby * 128, wave, lane);
+        offA = offB = kStepBytes * (uint32_t)nxt.kb;
+      }
+      offA = (uint32_t)__builtin_amdgcn_readfirstlane((int)offA);
+      offB = (uint32_t)__builtin_amdgcn_readfirstlane((int)offB);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        g_issue1_buf(ra, va[j], offA, An, wave, j);
+        g_issue1_buf(rb, vb[j], offB, An + 4096, wave, j);
+      }
+      bf16x8v_t fa[2][2], fb[2][2];
+      fa[0][0] = h_frag(As, wm + li, 0, lh, li);
+      fa[0][1] = h_frag(As, wm + 32 + li, 0, lh, li);
+      fb[0][0] = h_frag(Bs, wn + li, 0, lh, li);
+      fb[0][1] = h_frag(Bs, wn + 32 + li, 0, lh, li);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int cur = s & 1;
+        if (s < 3) {
+          fa[cur ^ 1][0] = h_frag(As, wm + li, s + 1, lh, li);
+          fa[cur ^ 1][1] = h_frag(As, wm + 32 + li, s + 1, lh, li);
+          fb[cur ^ 1][0] = h_frag(Bs, wn + li, s + 1, lh, li);
+          fb[cur ^ 1][1] = h_frag(Bs, wn + 32 + li, s + 1, lh, li);
+        }
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0], fb[cur][0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0], fb[cur][1], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][1], fb[cur][0], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][1], fb[cur][1], acc[1][1], 0, 0, 0);
+      }
+      stage ^= 1;
+      __syncthreads();  // the stage just filled has landed (vmcnt(0)) and is visible to all waves
+    }
+
+    bool doEpi = seg.slab < 0;  // whole tile: epilogue straight from the accumulators
+    int resetTicket = -1;
+    if (!doEpi) {
+      gemm128_store_partial(plan.slabs + (size_t)seg.slab * kSlabFloats, acc);
+      if (plan.counters) {
+        // in-kernel slab reduction: the same release / ticket / acquire hand-over as gemm128g_kernel (see there)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = (int*)(smem + (stage ^ 1) * kGStageFloats);  // the stage the K loop has just released
+        const int t = seg.tile - plan.dpTiles;
+        if (tid == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          *flag = (int)__hip_atomic_fetch_add(plan.counters + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const int ticket = *flag;
+        int sF, sL;
+        sk_tile_ranges(plan, t, sF, sL);
+        if (ticket == sL - sF) {  // uniform: last arriver
+          if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          __syncthreads();
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+          for (int sr = sF; sr <= sL; ++sr) {
+            const int segIdx = t - (int)(sk_begin(plan, sr) / plan.kTiles);  // ranges span <= 2 tiles: 0 or 1
+            const f32x4* s4 = (const f32x4*)(plan.slabs + ((size_t)sr * 2 + segIdx) * kSlabFloats);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const f32x4 v = s4[((wave * 4 + i * 2 + j) * 4 + q) * 64 + lane];
+                  acc[i][j][4 * q] += v[0]; acc[i][j][4 * q + 1] += v[1]; acc[i][j][4 * q + 2] += v[2]; acc[i][j][4 * q + 3] += v[3];
+                }
+          }
+          doEpi = true;
+          resetTicket = t;
+        }
+      }
+    }
+    if (doEpi) {
+      // `stage` now names the buffer holding the prefetched next K tile; the other one is free
+      if (wide) gemm128g_epilogue_wide(out, bx * 128, by * 128, acc, smem + (stage ^ 1) * kGStageFloats, bv);
+      else gemm128_epilogue(out, bx * 128, by * 128, acc);
+      if (resetTicket >= 0 && tid == 0) __hip_atomic_store(plan.counters + resetTicket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!nxt.valid) break;
+    if (wide || plan.counters) __syncthreads();  // the next iteration's LDS-DMA lands in the slices the epilogue / ticket used
+
+    seg = nxt;
+    sk_tile_xy(plan, seg.tile, bx, by);
+  }
+}
+
+// A [M][lda], B [N][ldb] bf16 (lda, ldb in bf16 elements, even, >= Kp), Kp = K rounded up to 64: columns K .. Kp of every
+// row must be ZERO in both operands (convert.hip writes them so).  W2L_EUNSUPPORTED when the schedule cannot run in-kernel.
+inline int launch128h(const uint16_t* A, int lda, const uint16_t* B, int ldb, GemmOut o, int epi, hipStream_t s) {
+  const int Kp = (o.K + 63) / 64 * 64;
+  if ((lda & 1) || (ldb & 1) || lda < Kp || ldb < Kp || (((uintptr_t)A | (uintptr_t)B) & 3)) return W2L_EINVAL;
+  const unsigned long long ab = 2ull * ((unsigned long long)(o.M - 1) * lda + Kp), bb = 2ull * ((unsigned long long)(o.N - 1) * ldb + Kp);
+  if (ab >= 0x7fffffffull || bb >= 0x7fffffffull) return W2L_EUNSUPPORTED;
+  epi &= ~EPI_ATOMIC;
+  const double flops = 2.0 * o.M * (double)o.N * o.K;
+  SkPlan plan = make_sk_plan(o.M, o.N, Kp / 2, sk_enabled());   // kTiles = Kp / 64
+  plan.grouped = 1;
+  if (plan.skBlocks > 0) {
+    plan.slabs = sk_scratch(s, kSkScratchBytes);
+    if (plan.slabs && plan.skTiles <= 1024) plan.counters = sk_counters(s);
+    if (!plan.slabs || !plan.counters) { plan = make_sk_plan(o.M, o.N, Kp / 2, false); plan.grouped = 1; }
+  }
+  int workers = plan.dpTiles < kSkSlots ? plan.dpTiles : kSkSlots;
+  if (workers < plan.skBlocks) workers = plan.skBlocks;
+  const size_t shmem = 2 * (size_t)kGStageFloats * sizeof(float);
+  o.epi = epi;
+  const int wide = (((uintptr_t)o.C) & 15) == 0 && o.ldc % 4 == 0 && (!o.mask || (((uintptr_t)o.mask) & 15) == 0) &&
+                   (!o.addend || (((uintptr_t)o.addend) & 15) == 0);
+  GOp ga{(const float*)A, lda / 2, o.M, (unsigned)ab}, gb{(const float*)B, ldb / 2, o.N, (unsigned)bb};
+  prof_begin(s, flops, PROF_GEMM_BF16);
+  hipLaunchKernelGGL(gemm128h_kernel, dim3((unsigned)workers), dim3(256), shmem, s, ga, gb, o, plan, workers, wide);
+  prof_end(s);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+}  // namespace w2l

@@ -229,6 +229,63 @@ class SpecAugmentLayer : public Layer {
   void backward(Ctx&, float*, const float* dy, float*& dx, bool) override { dx = const_cast<float*>(dy); }
 };
 
+
+// ---- mixed precision with bf16 operand storage (Ctx::bf16; gemm_bf16g.hpp, convert.hip) -------------------------------
+// fl's AMP (recipes/slimIPL/src/Train.cpp:211, :1681-1760; cpc/Train.cpp:365) casts the operands of fl::linear to half
+// precision and keeps fp32 master weights; here the half type is bf16 and every operand of the three products of an
+// fl::Linear is a bf16 IMAGE in the activation arena, written once per step:
+//   activation x [M][in]   -> rows image [M][inP] (forward A) + transposed image [in][MP] (weight-gradient A)
+//   gradient  dy [M][out]  -> rows image [M][outP] (backward-data A) + transposed image [out][MP] (weight-gradient B)
+//   weight     w [in][out] -> rows image [in][outP] (backward-data B) + transposed image [out][inP] (forward B)
+// (inP / outP / MP: rounded up to 64, zero-filled: the GEMM runs whole 64-k tiles).  Results, bias, LayerNorm, residual,
+// dropout and the criterion stay fp32.
+static inline int pad64(int n) { return (n + 63) / 64 * 64; }
+static inline uint16_t* bfp(float* arena, size_t off) { return (uint16_t*)(arena + off); }
+
+struct BfImage {   // the two bf16 images of an fp32 matrix [rows][cols]
+  size_t rowsOff = 0, transOff = 0;
+  int rows = 0, cols = 0, colsP = 0, rowsP = 0;
+  void plan(Planner& pl, int r, int c) {
+    rows = r; cols = c; colsP = pad64(c); rowsP = pad64(r);
+    rowsOff = pl.allocBf16((size_t)rows * colsP);
+    transOff = pl.allocBf16((size_t)cols * rowsP);
+  }
+  void convert(Ctx& c, float* arena, const float* x, const char* what) const {
+    w2lCheck(w2l_bf16_convert(x, (size_t)rows, cols, (size_t)cols, bfp(arena, rowsOff), (size_t)colsP, bfp(arena, transOff), (size_t)rowsP,
+                              c.stream), what);
+  }
+  const uint16_t* r(float* arena) const { return bfp(arena, rowsOff); }
+  const uint16_t* t(float* arena) const { return bfp(arena, transOff); }
+};
+
+struct BfLinear {   // the weight images of one fl::Linear(in, out) and its three products on M frames
+  int M = 0, in = 0, out = 0;
+  BfImage w;        // w [in][out]: rows image = B of backward-data, transposed image [out][inP] = B of forward
+  void plan(Planner& pl, int M_, int in_, int out_) { M = M_; in = in_; out = out_; w.plan(pl, in, out); }
+  void convertWeight(Ctx& c, float* arena, const float* wf) const { w.convert(c, arena, wf, "bf16 weight images"); }
+  // y [M][out] = x w + b (ReLU) (dropout); xImg: images of x [M][in]
+  void forward(Ctx& c, float* arena, const BfImage& xImg, const float* bias, float* y, int relu, double dropP, uint32_t seed,
+               uint32_t stream) const {
+    w2l_gemm_epilogue e{};
+    e.dropP = dropP; e.dropSeed = seed; e.dropStream = stream;
+    w2lCheck(w2l_gemm_bf16(M, out, in, xImg.r(arena), xImg.colsP, w.t(arena), w.rowsP, y, out, bias, relu, dropP > 0 ? &e : nullptr,
+                           c.stream), "bf16 linear fwd");
+  }
+  // dx [M][in] = dy w^T (mask) (+ addend | += dx); dyImg: images of dy [M][out]
+  void backwardData(Ctx& c, float* arena, const BfImage& dyImg, float* dx, const float* mask, float maskScale, const float* addend,
+                    int accumulate) const {
+    w2l_gemm_epilogue e{};
+    e.mask = mask; e.maskScale = maskScale; e.addend = addend; e.accumulate = accumulate;
+    w2lCheck(w2l_gemm_bf16(M, in, out, dyImg.r(arena), dyImg.colsP, w.r(arena), w.colsP, dx, in, nullptr, 0,
+                           (mask || addend || accumulate) ? &e : nullptr, c.stream), "bf16 linear bwd data");
+  }
+  // dw [in][out] = x^T dy
+  void backwardWeight(Ctx& c, float* arena, const BfImage& xImg, const BfImage& dyImg, float* dw) const {
+    w2lCheck(w2l_gemm_bf16(in, out, M, xImg.t(arena), xImg.rowsP, dyImg.t(arena), dyImg.rowsP, dw, out, nullptr, 0, nullptr, c.stream),
+             "bf16 linear bwd weight");
+  }
+};
+
 // optional WeightNorm state shared by Conv2D / Linear
 struct WNState {
   bool on = false;
@@ -345,6 +402,8 @@ class LinearLayer : public Layer {
   size_t yOff = 0, dxOff = 0;
   const float* xSaved = nullptr;
   std::vector<ParamInfo>* table = nullptr;
+  BfLinear bl;          // mixed precision: weight images and the bf16 products
+  BfImage xImg, dyImg;  // images of this layer's input and output gradient
 
   std::string name() const override { return wn.on ? "WeightNorm(Linear)" : "Linear"; }
   void registerParams(std::vector<ParamInfo>& t) override {
@@ -410,6 +469,9 @@ class LinearLayer : public Layer {
       wn.normOff = pl.alloc(wn.N);
       wn.dotOff = pl.alloc(wn.N);
     }
+    bl.plan(pl, M, in, out);
+    xImg.plan(pl, M, in);
+    dyImg.plan(pl, M, out);
     return o;
   }
   void forward(Ctx& c, float* arena, const float* x, float*& y) override {
@@ -420,6 +482,12 @@ class LinearLayer : public Layer {
       w2lCheck(w2l_weightnorm_forward(wn.v.w(c), wn.g.w(c), arena + wn.wOff, arena + wn.normOff, wn.K, wn.N, c.stream), "wn fwd");
       wt = arena + wn.wOff;
     }
+    if (c.bf16) {
+      xImg.convert(c, arena, x, "linear input images");
+      bl.convertWeight(c, arena, wt);
+      bl.forward(c, arena, xImg, hasBias ? b.w(c) : nullptr, y, fuseRelu ? 1 : 0, 0.0, 0, 0);
+      return;
+    }
     w2lCheck(w2l_linear_forward(M, in, out, x, wt, hasBias ? b.w(c) : nullptr, y, fuseRelu ? 1 : 0, c.stream), "linear fwd");
   }
   void backward(Ctx& c, float* arena, const float* dy, float*& dx, bool needDx) override {
@@ -427,11 +495,21 @@ class LinearLayer : public Layer {
     if (fuseRelu) w2lCheck(w2l_mask_backward(dy, arena + yOff, dym, (size_t)M * out, 1.f, c.stream), "linear relu bwd");
     float* dwt = wn.on ? arena + wn.dwOff : w.g(c);
     const float* wt = wn.on ? arena + wn.wOff : w.w(c);
+    if (c.bf16) {   // the images of x and of the weight were written by forward
+      dyImg.convert(c, arena, dym, "linear output-gradient images");
+      bl.backwardWeight(c, arena, xImg, dyImg, dwt);
+      if (hasBias) w2lCheck(w2l_colsum(dym, b.g(c), (size_t)M, out, c.stream), "linear bwd b");
+      if (needDx) {
+        dx = arena + dxOff;
+        bl.backwardData(c, arena, dyImg, dx, nullptr, 1.f, nullptr, 0);
+      }
+    } else {
     w2lCheck(w2l_linear_backward_weight(M, in, out, xSaved, dym, dwt, c.stream), "linear bwd w");
     if (hasBias) w2lCheck(w2l_colsum(dym, b.g(c), (size_t)M, out, c.stream), "linear bwd b");
     if (needDx) {
       dx = arena + dxOff;
       w2lCheck(w2l_linear_backward_data(M, in, out, dym, wt, dx, 0, nullptr, 1.f, c.stream), "linear bwd x");
+    }
     }
     if (wn.on)
       w2lCheck(w2l_weightnorm_backward(wn.v.w(c), wn.g.w(c), arena + wn.normOff, dwt, wn.v.g(c), wn.g.g(c),
@@ -528,6 +606,8 @@ class TDSLayer : public Layer {
   size_t aOff, r1Off, y1Off, uOff, vOff, outOff, st1Off, mr1Off, st2Off, mr2Off;   // forward (r2 aliases v)
   size_t dsOff, duOff, dy1Off, dr1Off, daOff, dxOff;                        // backward
   const float* xSaved = nullptr;
+  BfLinear bl1, bl2;                    // mixed precision: lin1 (l -> l2), lin2 (l2 -> l)
+  BfImage y1Img, uImg, dvImg, duImg;    // images of the two Linear inputs and of the two output gradients
 
   std::string name() const override { return "TDSBlock"; }
   void registerParams(std::vector<ParamInfo>& t) override {
@@ -562,6 +642,8 @@ class TDSLayer : public Layer {
     st2Off = pl.alloc(2 * w2l_layernorm_scratch_doubles(groups, inner)); mr2Off = pl.alloc(2 * (size_t)groups);
     dsOff = pl.alloc(n); duOff = pl.alloc((size_t)M * l2); dy1Off = pl.alloc(n); dr1Off = pl.alloc(n);
     daOff = pl.alloc(n); dxOff = pl.alloc(n);
+    bl1.plan(pl, M, l, l2); bl2.plan(pl, M, l2, l);
+    y1Img.plan(pl, M, l); uImg.plan(pl, M, l2); dvImg.plan(pl, M, l); duImg.plan(pl, M, l2);
     return in;
   }
   void forward(Ctx& cx, float* ar, const float* x, float*& y) override {
@@ -573,10 +655,21 @@ class TDSLayer : public Layer {
     // a <- dropout(relu(conv)) in place (kept: its sign pattern is the ReLU+dropout mask); r1 = a + x; y1 = LN(r1)
     w2lCheck(w2l_residual_layernorm_forward(groups, inner, a, x, r1, y1, gb1.w(cx), 1e-5f, pd, cx.seed, rngStream,
                                             (double*)(ar + st1Off), ar + mr1Off, s), "tds ln1");
+    if (cx.bf16) {
+      // the same two products on bf16 images: y1 and u are converted once (row image for this product, transposed image for
+      // the weight gradient in backward), the weights once per step (both orientations)
+      y1Img.convert(cx, ar, y1, "tds y1 images");
+      bl1.convertWeight(cx, ar, w1.w(cx));
+      bl1.forward(cx, ar, y1Img, b1.w(cx), u, 1, pd, cx.seed, rngStream + 1);
+      uImg.convert(cx, ar, u, "tds u images");
+      bl2.convertWeight(cx, ar, w2.w(cx));
+      bl2.forward(cx, ar, uImg, b2.w(cx), v, 0, 0.0, 0, 0);
+    } else {
     // lin1 + ReLU + dropout in one GEMM epilogue (same mask bits as a separate dropout pass over u)
     if (pd > 0) w2lCheck(w2l_linear_forward_dropout(M, l, l2, y1, w1.w(cx), b1.w(cx), u, 1, pd, cx.seed, rngStream + 1, s), "tds lin1+do");
     else w2lCheck(w2l_linear_forward(M, l, l2, y1, w1.w(cx), b1.w(cx), u, 1, s), "tds lin1");
     w2lCheck(w2l_linear_forward(M, l2, l, u, w2.w(cx), b2.w(cx), v, 0, s), "tds lin2");
+    }
     // r2 = dropout(v) + y1 (stored over v), out = LN(r2)
     w2lCheck(w2l_residual_layernorm_forward(groups, inner, v, y1, v, out, gb2.w(cx), 1e-5f, pd, cx.seed, rngStream + 2,
                                             (double*)(ar + st2Off), ar + mr2Off, s), "tds ln2");
@@ -597,6 +690,17 @@ class TDSLayer : public Layer {
       w2lCheck(w2l_dropout_copy(dy1, ds, n, pd, cx.seed, rngStream + 2, s), "tds do2 bwd");
       dv = dy1;
     }
+    if (cx.bf16) {
+      // (dv may live in dy1 -- the masked copy above --, which the last product overwrites: its images are taken first)
+      dvImg.convert(cx, ar, dv, "tds dv images");
+      bl2.backwardWeight(cx, ar, uImg, dvImg, w2.g(cx));
+      w2lCheck(w2l_colsum(dv, b2.g(cx), (size_t)M, l, s), "tds lin2 bwd b");
+      bl2.backwardData(cx, ar, dvImg, du, u, sc, nullptr, 0);
+      duImg.convert(cx, ar, du, "tds du images");
+      bl1.backwardWeight(cx, ar, y1Img, duImg, w1.g(cx));
+      w2lCheck(w2l_colsum(du, b1.g(cx), (size_t)M, l2, s), "tds lin1 bwd b");
+      bl1.backwardData(cx, ar, duImg, dy1, nullptr, 1.f, ds, 0);
+    } else {
     // lin2: dW2 = u^T dv, db2, du = (dv W2^T) masked by relu+dropout of u (u holds the dropped value)
     w2lCheck(w2l_linear_backward_weight(M, l2, l, u, dv, w2.g(cx), s), "tds lin2 bwd w");
     w2lCheck(w2l_colsum(dv, b2.g(cx), (size_t)M, l, s), "tds lin2 bwd b");
@@ -606,6 +710,7 @@ class TDSLayer : public Layer {
     w2lCheck(w2l_colsum(du, b1.g(cx), (size_t)M, l2, s), "tds lin1 bwd b");
     // dy1 = ds + du W1^T: the residual join rides in the GEMM epilogue as a separate addend (no copy of ds into dy1)
     w2lCheck(w2l_linear_backward_data_add(M, l, l2, du, w1.w(cx), ds, dy1, s), "tds lin1 bwd x");
+    }
     // LN1 backward: dr1, and in the same pass da = dr1 masked by the ReLU+dropout pattern of a
     w2lCheck(w2l_layernorm_backward(groups, inner, ar + r1Off, dy1, gb1.w(cx), ar + mr1Off, dr1, gb1.g(cx), a, da, sc,
                                     (double*)(ar + st1Off), s), "tds ln1 bwd");

@@ -181,6 +181,7 @@ static Ctx makeCtx(Trainer* t, void* stream, bool train) {
   c.params = t->params;
   c.grads = t->grads;
   c.inputSizes = t->inputSizes; c.inputT = t->T;
+  c.bf16 = t->mixedPrecision;
   return c;
 }
 

@@ -82,11 +82,13 @@ struct Ctx {
   float* grads = nullptr;
   const float* inputSizes = nullptr;  // device [B] (any unit) or null: padding mask of the Transformer blocks
   int inputT = 0;                     // frames of the padded network input the sizes refer to
+  bool bf16 = false;                  // mixed precision: the fl::Linear products run on bf16 operand images (gemm_bf16g.hpp)
 };
 
 class Planner {  // bump allocator over the activation arena (sizes only until bound)
  public:
   size_t alloc(size_t floats) { size_t o = used_; used_ += (floats + 63) / 64 * 64; return o; }
+  size_t allocBf16(size_t elements) { return alloc((elements + 1) / 2); }   // a bf16 image, addressed in float slots
   size_t used() const { return used_; }
  private:
   size_t used_ = 0;

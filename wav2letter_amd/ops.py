@@ -185,3 +185,34 @@ def sgd_step_(p, g, v, lr, momentum, grad_scale=1.0, max_grad_norm=0.0):
     if max_grad_norm > 0:
         check(L.w2l_sumsq(_p(g), g.numel(), _p(ss), 1, _s()), "sumsq")
     check(L.w2l_sgd_step(_p(p), _p(g), _p(v), p.numel(), lr, momentum, grad_scale, max_grad_norm, _p(ss), _s()), "sgd")
+
+
+def bf16_convert(x, rows_image=True, transposed_image=False):
+    """w2l_bf16_convert: x [rows][cols] fp32 -> (rowMajor [rows][colsP], transposed [cols][rowsP]) bf16 images, zero-padded to
+    the next multiple of 64 (None for an image that was not asked for).  The images are torch.bfloat16 tensors."""
+    x = x.contiguous()
+    rows, cols = x.shape
+    colsP, rowsP = (cols + 63) // 64 * 64, (rows + 63) // 64 * 64
+    rm = torch.empty(rows, colsP, dtype=torch.bfloat16, device=x.device) if rows_image else None
+    tr = torch.empty(cols, rowsP, dtype=torch.bfloat16, device=x.device) if transposed_image else None
+    _lib.check(_lib.lib().w2l_bf16_convert(_p(x), rows, cols, cols, _p(rm) if rm is not None else None, colsP,
+                                           _p(tr) if tr is not None else None, rowsP, _s()), "bf16_convert")
+    return rm, tr
+
+
+def gemm_bf16(A, B, K, bias=None, relu=False, mask=None, mask_scale=1.0, addend=None, out=None, accumulate=False,
+              drop_p=0.0, drop_seed=0, drop_stream=0):
+    """w2l_gemm_bf16: C[M][N] fp32 = A[M][>=K] . B[N][>=K]^T on bf16 images (rows zero from column K to the next multiple of 64)"""
+    import ctypes as C
+    M, N = A.shape[0], B.shape[0]
+    c = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=A.device)
+    e = _lib.GemmEpilogue()
+    e.mask = _p(mask) if mask is not None else None
+    e.maskScale = mask_scale
+    e.addend = _p(addend) if addend is not None else None
+    e.accumulate = int(accumulate)
+    e.dropP = drop_p
+    e.dropSeed, e.dropStream = drop_seed, drop_stream
+    _lib.check(_lib.lib().w2l_gemm_bf16(M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(c), c.stride(0),
+                                        _p(bias) if bias is not None else None, int(relu), C.byref(e), _s()), "gemm_bf16")
+    return c
