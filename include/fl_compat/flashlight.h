@@ -35,6 +35,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #define FL_COMPAT_API __attribute__((visibility("default")))
@@ -193,6 +194,8 @@ class FL_COMPAT_API SpecAugment : public Module {
   SpecAugment(int tWarpW, int fMaskF, int nFMask, int tMaskT, float tMaskP, int nTMask);
   std::vector<Variable> forward(const std::vector<Variable>& inputs) override;
   std::string prettyString() const override;
+  uint32_t calls() const { return calls_; }          // fl_compat extension: the mask stream position (checkpoints)
+  void setCalls(uint32_t n) { calls_ = n; }
 
  private:
   int fMaskF_, nFMask_, tMaskT_, nTMask_;
@@ -210,6 +213,11 @@ class FL_COMPAT_API FirstOrderOptimizer {
   void setLr(double lr) { lr_ = lr; }
   virtual void zeroGrad() { for (auto& p : parameters_) p.zeroGrad(); }
   virtual std::string prettyString() const = 0;
+  // fl_compat extension (checkpoints, fl::pkg::runtime::Serializer): "sgd" | "adagrad" | "adadelta", and the per-parameter
+  // state arrays -- slot 0: SGD velocity / Adagrad variance / Adadelta accGrad, slot 1: Adadelta accDelta (empty: stateless)
+  virtual const char* kind() const = 0;
+  virtual std::vector<std::vector<af::array>*> state() { return {}; }
+  const std::vector<Variable>& parameters() const { return parameters_; }
 
  protected:
   std::vector<Variable> parameters_;
@@ -221,6 +229,8 @@ class FL_COMPAT_API SGDOptimizer : public FirstOrderOptimizer {
   SGDOptimizer(const std::vector<Variable>& params, double lr, double momentum = 0, double weightDecay = 0, bool useNesterov = false);
   void step() override;
   std::string prettyString() const override;
+  const char* kind() const override { return "sgd"; }
+  std::vector<std::vector<af::array>*> state() override { return velocities_.empty() ? std::vector<std::vector<af::array>*>{} : std::vector<std::vector<af::array>*>{&velocities_}; }
 
  private:
   double mu_, wd_;
@@ -234,6 +244,8 @@ class FL_COMPAT_API AdagradOptimizer : public FirstOrderOptimizer {
   AdagradOptimizer(const std::vector<Variable>& params, double lr, double eps = 1e-8, double weightDecay = 0);
   void step() override;
   std::string prettyString() const override;
+  const char* kind() const override { return "adagrad"; }
+  std::vector<std::vector<af::array>*> state() override { return {&variance_}; }
 
  private:
   double eps_;
@@ -246,6 +258,8 @@ class FL_COMPAT_API AdadeltaOptimizer : public FirstOrderOptimizer {
   AdadeltaOptimizer(const std::vector<Variable>& params, double lr = 1.0, double rho = 0.9, double eps = 1e-8, double weightDecay = 0);
   void step() override;
   std::string prettyString() const override;
+  const char* kind() const override { return "adadelta"; }
+  std::vector<std::vector<af::array>*> state() override { return {&accGrad_, &accDelta_}; }
 
  private:
   double rho_, eps_;
@@ -280,13 +294,14 @@ class FL_COMPAT_API CoalescingReducer : public Reducer {
   void add(Variable& var) override;
   void finalize() override;
   size_t lastCollectives() const { return lastCollectives_; }   // fl_compat extension: ncclAllReduce calls of the last finalize()
+  size_t lastOverlapped() const { return lastOverlapped_; }     // ... of which were issued on the side stream behind a bucket event
 
  private:
   double scale_;
   bool async_, contiguous_;
   struct Span { float* ptr; size_t n; };
   std::vector<Span> spans_;
-  size_t lastCollectives_ = 0;
+  size_t lastCollectives_ = 0, lastOverlapped_ = 0;
 };
 
 namespace pkg {
@@ -295,6 +310,23 @@ namespace runtime {
 // this process to GPU worldRank % maxDevicesPerNode and creates the RCCL communicator; the ncclUniqueId travels through
 // the file <rndvFilepath>/w2l_nccl_id.<worldSize> written by rank 0 (the reference's file-system rendezvous)
 FL_COMPAT_API void initDistributed(int worldRank, int worldSize, int maxDevicesPerNode, const std::string& rndvFilepath);
+// fl::pkg::runtime::Serializer::save(filename, version, config, network, criterion, netoptim, critoptim) / load(...)
+// (recipes/slimIPL/src/Train.cpp:132-173 header-only load of `continue` / `fork`, :452-463 model loads, :767-790 saves).
+// The reference's container is cereal (needs Flashlight to read); this one is the documented W2LAMD01 layout of
+// wav2letter_amd/checkpoint.py -- network tensors in the REFERENCE's parameter order and array layouts, the ASG
+// transitions, the optimizer state as flat arenas, `config` in the JSON header -- written and read by both languages.
+struct FL_COMPAT_API Serializer {
+  using Config = std::unordered_map<std::string, std::string>;
+  static void save(const std::string& path, const std::string& version, const Config& config, const std::shared_ptr<fl::Module>& network,
+                   const std::shared_ptr<fl::Module>& criterion, const std::shared_ptr<fl::FirstOrderOptimizer>& netoptim,
+                   const std::shared_ptr<fl::FirstOrderOptimizer>& critoptim);
+  static void load(const std::string& path, std::string& version, Config& config);
+  static void load(const std::string& path, std::string& version, Config& config, const std::shared_ptr<fl::Module>& network,
+                   const std::shared_ptr<fl::Module>& criterion);
+  static void load(const std::string& path, std::string& version, Config& config, const std::shared_ptr<fl::Module>& network,
+                   const std::shared_ptr<fl::Module>& criterion, const std::shared_ptr<fl::FirstOrderOptimizer>& netoptim,
+                   const std::shared_ptr<fl::FirstOrderOptimizer>& critoptim);
+};
 // dlopen(path, RTLD_LAZY) + dlsym("createModule"): extern "C" fl::Module* createModule(int64_t nFeature, int64_t nLabel)
 // returns an OWNING raw pointer (recipes/slimIPL/100h_supervised.cpp:84-87; loader call Train.cpp:390-395).
 // A name that ends in ".arch" is not a plugin: arch() then goes through buildSequentialModule, which is what the
@@ -338,6 +370,10 @@ FL_COMPAT_API FlatView flatGradients(const std::shared_ptr<fl::Module>& network)
 // --fl_amp_use_mixed_precision, restated for bf16: the fl::Linear GEMMs of a network built from an arch file multiply in
 // bf16 with fp32 accumulation; storage, master weights and the criterion stay fp32 (no-op for any other module)
 FL_COMPAT_API void setMixedPrecision(const std::shared_ptr<fl::Module>& network, bool on);
+// fl_compat extension: forwards so far of a network built from an arch file = the position of its dropout-seed stream
+// (restored by Serializer::load; `Train fork` starts it from zero)
+FL_COMPAT_API uint32_t networkStep(const std::shared_ptr<fl::Module>& network);
+FL_COMPAT_API void setNetworkStep(const std::shared_ptr<fl::Module>& network, uint32_t step);
 
 class FL_COMPAT_API ASGLoss : public SequenceCriterion {
  public:

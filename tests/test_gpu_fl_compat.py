@@ -235,3 +235,91 @@ def test_train_binary_lr_decay_and_specaugment_start(tmp_path):
     loss = lambda rws: [dict((kv.split(":")[0].strip(), kv.split(":", 1)[1].strip()) for kv in r)["loss"] for r in rws]
     a, b = [r["loss"] for r in rows], loss(brow)
     assert a[:2] == b[:2] and a[2:] != b[2:]
+
+
+_TINY_ARCH = ("V -1 NFEAT 1 0\nC2 1 4 5 1 2 1 -1 -1\nR\nDO 0.1\nLN 0 1 2\nTDS 4 5 8 0.1 64\nV 0 32 1 0\nRO 1 0 3 2\nL 32 NLABEL\n")
+
+
+def _tiny_train_cmd(d, rundir, updates, extra=()):
+    exe = os.path.join(ROOT, "wav2letter_amd", "bin", "Train")
+    return [exe, "train", f"--archdir={d / 'arch'}", "--arch=net.arch", "--criterion=ctc", "--filterbanks=8", "--w2l_nlabel=12",
+            "--batchsize=3", "--w2l_synth_frames=64", "--w2l_synth_target_len=6", f"--w2l_synth_updates={updates}", "--reportiters=1",
+            "--lr=0.05", "--momentum=0.5", "--maxgradnorm=1.0", "--onorm=target", "--sqnorm=true", f"--rundir={rundir}",
+            "--runname=exp"] + list(extra)
+
+
+@pytest.mark.parametrize("optim", ["sgd", "adadelta"])
+def test_train_binary_continue_is_bit_identical_and_fork_starts_fresh(tmp_path, optim):
+    """`Train continue <directory>` (recipes/slimIPL/src/Train.cpp:117, :124-150, :460-467): three updates, stop, continue to
+    five == five uninterrupted updates BIT FOR BIT (network, optimizer state; dropout is live, so the seed stream and the
+    sample stream must resume where they stopped); run files are NNN_log / NNN_config / NNN_model_last.bin (:644-651, :767);
+    the container is wav2letter_amd/checkpoint.py's (read back by the Python side, arch hash included).  `Train fork <model>`
+    (:118, :151-166, :452-459) starts a new run from the model's network + criterion with fresh optimizers."""
+    from wav2letter_amd import checkpoint
+    from wav2letter_amd.trainer import Trainer
+    exe = os.path.join(ROOT, "wav2letter_amd", "bin", "Train")
+    d = tmp_path
+    os.makedirs(d / "arch")
+    open(d / "arch" / "net.arch", "w").write(_TINY_ARCH)
+    opt = [f"--netoptim={optim}", f"--critoptim={optim}"] + (["--lr=1.0"] if optim == "adadelta" else [])
+
+    def run(cmd):
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
+        return out.stdout
+    run(_tiny_train_cmd(d, d / "A", 5, opt))
+    run(_tiny_train_cmd(d, d / "B", 3, opt))
+    text = run([exe, "continue", str(d / "B" / "exp"), "--w2l_synth_updates=5"])
+    assert "Loaded model for continue training" in text
+    rows = [l for l in text.splitlines() if l.startswith("epoch:")]
+    assert [int(dict((kv.split(":")[0].strip(), kv.split(":", 1)[1].strip()) for kv in r.split(" | "))["nupdates"]) for r in rows] == [4, 5]
+    for f in ("001_log", "001_config", "001_model_last.bin", "002_log", "002_config", "002_model_last.bin"):
+        assert os.path.exists(d / "B" / "exp" / f), f
+    ha, ta = checkpoint.read(str(d / "A" / "exp" / "001_model_last.bin"))
+    hb, tb = checkpoint.read(str(d / "B" / "exp" / "002_model_last.bin"))
+    assert ha["step"] == hb["step"] == 5 and ha["flags"]["nbupdates"] == hb["flags"]["nbupdates"] == "5"
+    assert [t["kind"] for t in ha["tensors"]] == [t["kind"] for t in hb["tensors"]]
+    assert "momentum" in [t["kind"] for t in ha["tensors"]] and (("state2" in [t["kind"] for t in ha["tensors"]]) == (optim == "adadelta"))
+    for t, a, b in zip(ha["tensors"], ta, tb):
+        assert np.array_equal(a, b), t["name"]
+    # three updates differ from five (the comparison above is not vacuous)
+    _, t3 = checkpoint.read(str(d / "B" / "exp" / "001_model_last.bin"))
+    assert not np.array_equal(t3[0], ta[0])
+    # the Python side reads the C++ container: same arch hash, reference-layout tensors land in the same arena
+    tr = Trainer(_TINY_ARCH, 8, 12, "ctc", 4)
+    tr.set_optimizer(optim, optim)
+    tr.init_params(seed=99)
+    assert checkpoint.load(str(d / "A" / "exp" / "001_model_last.bin"), tr, _TINY_ARCH) == 5
+    assert "--criterion=ctc" in ha["flags"]["gflags"] and ha["optim"] == [optim, optim]
+    for i, (name, n, off) in enumerate(tr.param_table()):
+        assert np.array_equal(tr.export_from(i, tr.host_params), ta[i]), name
+    # fork: new run directory, network from the model, optimizers fresh
+    text = run([exe, "fork", str(d / "B" / "exp" / "001_model_last.bin"), f"--rundir={d / 'C'}", "--runname=forked", "--w2l_synth_updates=2"])
+    assert "for fork" in text and os.path.exists(d / "C" / "forked" / "001_model_last.bin")
+    hc, _ = checkpoint.read(str(d / "C" / "forked" / "001_model_last.bin"))
+    assert hc["step"] == 2 and hc["flags"]["nbupdates"] == "2"
+    # continue without a model is refused
+    bad = subprocess.run([exe, "continue", str(d / "nowhere")], capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "model_last.bin" in bad.stderr
+
+
+def test_train_binary_overlapped_bucket_reducer_single_rank(tmp_path):
+    """the C++ Train's gradient reduction is the bucketed, event-gated one (fl::CoalescingReducer over the planned network's
+    flat gradient arena: first update one collective, then one per bucket on the side stream, last bucket first, each behind the
+    event backward() records when that part of the arena is final) -- with one rank it must leave the run bit-identical"""
+    exe = os.path.join(ROOT, "wav2letter_amd", "bin", "Train")
+    d = tmp_path
+    os.makedirs(d / "arch"); os.makedirs(d / "rndv")
+    open(d / "arch" / "net.arch", "w").write(_TINY_ARCH)
+    a = subprocess.run(_tiny_train_cmd(d, d / "S", 4), capture_output=True, text=True, timeout=600)
+    b = subprocess.run(_tiny_train_cmd(d, d / "D", 4, ["--enable_distributed=true", "--world_rank=0", "--world_size=1",
+                                                       f"--rndv_filepath={d / 'rndv'}"]), capture_output=True, text=True, timeout=600)
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr[-1500:], b.stderr[-1500:])
+    import re
+    m = re.search(r"gradient collectives of the last update: (\d+) \((\d+) issued on the side stream", b.stdout)
+    assert m and int(m.group(2)) >= 2 and int(m.group(1)) == int(m.group(2)), b.stdout[-800:]
+    from wav2letter_amd import checkpoint
+    _, ta = checkpoint.read(str(d / "S" / "exp" / "001_model_last.bin"))
+    _, tb = checkpoint.read(str(d / "D" / "exp" / "001_model_last.bin"))
+    assert all(np.array_equal(x, y) for x, y in zip(ta, tb))
+    assert not os.path.exists(d / "rndv" / "w2l_nccl_id.1")   # a world of one publishes no rendezvous record

@@ -357,6 +357,36 @@ void barrier() {
   w2l::hipCheck(hipStreamSynchronize((hipStream_t)S()), "barrier");
 }
 
+// ---- the planned networks' gradient arenas, as the reducer sees them (defined next to PlannedNet further down)
+namespace {
+struct ArenaInfo { float* base = nullptr; size_t floats = 0; void* net = nullptr; };
+bool findArena(const float* p, ArenaInfo& out);
+std::vector<size_t> arenaParamOffsets(void* net);
+const std::vector<size_t>& arenaBucketOffsets(void* net);
+hipEvent_t arenaBucketEvent(void* net, size_t k);
+void arenaInstallBuckets(void* net, std::vector<size_t> offs);
+
+// cut [0, total) into <= nBuckets pieces of roughly equal size at parameter boundaries (wav2letter_amd/parallel.bucket_offsets)
+std::vector<size_t> cutBuckets(const std::vector<size_t>& bounds, size_t total, int nBuckets) {
+  std::vector<size_t> out{0};
+  for (int k = 1; k < nBuckets; ++k) {
+    const size_t want = total * (size_t)k / (size_t)nBuckets;
+    size_t best = 0, bestD = (size_t)-1;
+    for (size_t b : bounds) {
+      const size_t d = b > want ? b - want : want - b;
+      if (d < bestD) { bestD = d; best = b; }
+    }
+    if (best > out.back()) out.push_back(best);
+  }
+  return out;
+}
+hipStream_t commStream() {
+  static hipStream_t s = nullptr;
+  if (!s) w2l::hipCheck(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "reducer stream");
+  return s;
+}
+}  // namespace
+
 CoalescingReducer::CoalescingReducer(double scale, bool async, bool contiguous) : scale_(scale), async_(async), contiguous_(contiguous) {}
 CoalescingReducer::~CoalescingReducer() {}
 void CoalescingReducer::add(Variable& var) {
@@ -364,16 +394,54 @@ void CoalescingReducer::add(Variable& var) {
   float* p = var.array().device<float>();
   const size_t n = (size_t)var.elements();
   if (!n) return;
-  if (!spans_.empty() && spans_.back().ptr + spans_.back().n == p) spans_.back().n += n;   // the next piece of the same arena
+  if (!spans_.empty() && spans_.back().ptr + spans_.back().n == p) spans_.back().n += n;   // the next piece of the same buffer
   else spans_.push_back({p, n});
 }
+// Gradients that are views of a planned network's flat gradient arena are reduced as that ARENA (its alignment padding
+// included: a handful of floats), in a few large buckets: from the second step on, backward() has recorded one event per
+// bucket on the compute stream as soon as every gradient at that offset or beyond was final (w2l::Sequential::backward),
+// and finalize() -- called right after loss.backward() has been ENQUEUED -- walks the buckets last to first, makes the side
+// stream wait for the bucket's event and issues the ncclAllReduce there: the last layers' gradients cross xGMI while the
+// GPU still computes the first layers' backward (the reference's CoalescingReducer overlaps the same way, bucket by
+// bucket, recipes/slimIPL/src/Train.cpp:1721-1735).  The first step (no events yet) reduces the arena in one piece and
+// installs the buckets.  Everything else (the criterion's transitions) goes through one collective per buffer.
 void CoalescingReducer::finalize() {
-  lastCollectives_ = 0;
+  lastCollectives_ = lastOverlapped_ = 0;
+  std::vector<ArenaInfo> arenas;
   for (auto& sp : spans_) {
+    ArenaInfo ai;
+    if (rccl().comm && findArena(sp.ptr, ai)) {
+      bool seen = false;
+      for (auto& a : arenas) seen = seen || a.net == ai.net;
+      if (!seen) arenas.push_back(ai);
+      continue;
+    }
     allReduceRaw(sp.ptr, sp.n, scale_);
-    ++lastCollectives_;
+    if (rccl().comm) ++lastCollectives_;
   }
   spans_.clear();
+  Rccl& r = rccl();
+  for (auto& ai : arenas) {
+    const std::vector<size_t>& offs = arenaBucketOffsets(ai.net);
+    if (offs.empty() || scale_ != 1.0) {
+      allReduceRaw(ai.base, ai.floats, scale_);
+      ++lastCollectives_;
+      if (offs.empty()) arenaInstallBuckets(ai.net, cutBuckets(arenaParamOffsets(ai.net), ai.floats, 4));
+      continue;
+    }
+    hipStream_t cs = commStream();
+    for (size_t k = offs.size(); k-- > 0;) {
+      const size_t lo = offs[k], hi = k + 1 < offs.size() ? offs[k + 1] : ai.floats;
+      w2l::hipCheck(hipStreamWaitEvent(cs, arenaBucketEvent(ai.net, k), 0), "bucket wait");
+      ncclCheck(r.AllReduce(ai.base + lo, ai.base + lo, hi - lo, ncclFloat32, ncclSum, r.comm, cs), "ncclAllReduce");
+      ++lastCollectives_;
+      ++lastOverlapped_;
+    }
+    static hipEvent_t done = nullptr;
+    if (!done) w2l::hipCheck(hipEventCreateWithFlags(&done, hipEventDisableTiming), "reducer event");
+    w2l::hipCheck(hipEventRecord(done, cs), "reducer event");
+    w2l::hipCheck(hipStreamWaitEvent(S(), done, 0), "reducer join");   // the optimizer step waits for the reduced gradients
+  }
 }
 
 namespace pkg {
@@ -524,6 +592,7 @@ class PlannedNet : public fl::Sequential {
     w2l::Ctx c;
     c.stream = S(); c.train = train_; c.seed = 0x9E3779B9u * (++step_);
     c.params = (float*)paramArena_.get(); c.grads = (float*)gradArena_.get();
+    c.bf16 = mixed_;
     if (inputs.size() >= 2 && !inputs[1].isempty()) {  // inputSizes (1, B): padding mask of the Transformer blocks
       if (inputs[1].type() != af::f32 || inputs[1].elements() != B) throw std::invalid_argument("network forward: inputSizes must be f32 (1, B)");
       c.inputSizes = inputs[1].array().device<float>();
@@ -556,6 +625,25 @@ class PlannedNet : public fl::Sequential {
   float* paramPtr() { return (float*)paramArena_.get(); }
   float* gradPtr() { return (float*)gradArena_.get(); }
   bool mixed_ = false;
+  std::string archSha_;             // sha-256 of the arch text this network was built from (checkpoint header)
+  int nFeat() const { return nFeat_; }
+  int nLabel() const { return nLabel_; }
+  uint32_t step() const { return step_; }      // forwards so far = position of the dropout-seed stream
+  void setStep(uint32_t s) { step_ = s; }
+  // gradient buckets of the data-parallel overlap (CoalescingReducer): events recorded by backward() on the compute stream
+  std::vector<size_t> bucketOffsets_;
+  std::vector<hipEvent_t> bucketEvents_;
+  void installBuckets(std::vector<size_t> offs) {
+    for (auto e : bucketEvents_) (void)hipEventDestroy(e);
+    bucketEvents_.clear();
+    for (size_t k = 0; k < offs.size(); ++k) {
+      hipEvent_t e;
+      w2l::hipCheck(hipEventCreateWithFlags(&e, hipEventDisableTiming), "bucket event");
+      bucketEvents_.push_back(e);
+    }
+    bucketOffsets_ = offs;
+    net_->setGradBuckets(offs, bucketEvents_);
+  }
 
  private:
   std::shared_ptr<w2l::Sequential> net_;
@@ -568,12 +656,79 @@ class PlannedNet : public fl::Sequential {
 
 }  // namespace
 
+namespace {
+// ---- sha-256 (FIPS 180-4) of the arch text: the checkpoint header's "arch_sha256" (wav2letter_amd/checkpoint.py hashes the same bytes)
+std::string sha256Hex(const std::string& msg) {
+  static const uint32_t K[64] = {
+      0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+      0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+      0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+      0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+      0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+      0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+  uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  std::string m = msg;
+  const uint64_t bits = (uint64_t)msg.size() * 8;
+  m.push_back((char)0x80);
+  while (m.size() % 64 != 56) m.push_back('\0');
+  for (int i = 7; i >= 0; --i) m.push_back((char)((bits >> (8 * i)) & 0xff));
+  auto rotr = [](uint32_t x, int n) { return (x >> n) | (x << (32 - n)); };
+  for (size_t off = 0; off < m.size(); off += 64) {
+    uint32_t w[64];
+    for (int i = 0; i < 16; ++i)
+      w[i] = ((uint32_t)(uint8_t)m[off + 4 * i] << 24) | ((uint32_t)(uint8_t)m[off + 4 * i + 1] << 16) | ((uint32_t)(uint8_t)m[off + 4 * i + 2] << 8) |
+             (uint32_t)(uint8_t)m[off + 4 * i + 3];
+    for (int i = 16; i < 64; ++i) {
+      const uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+      w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; ++i) {
+      const uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25), ch = (e & f) ^ (~e & g), t1 = hh + S1 + ch + K[i] + w[i];
+      const uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22), mj = (a & b) ^ (a & c) ^ (b & c), t2 = S0 + mj;
+      hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+  }
+  char out[65];
+  for (int i = 0; i < 8; ++i) snprintf(out + 8 * i, 9, "%08x", h[i]);
+  return std::string(out, 64);
+}
+std::vector<PlannedNet*>& plannedNets() { static std::vector<PlannedNet*> v; return v; }
+}  // namespace
+
 std::shared_ptr<fl::Sequential> buildSequentialModuleFromText(const std::string& archText, int64_t nFeatures, int64_t nClasses) {
-  return std::make_shared<PlannedNet>(w2l::buildSequentialFromText(archText, nFeatures, nClasses), nFeatures, nClasses);
+  auto net = std::make_shared<PlannedNet>(w2l::buildSequentialFromText(archText, nFeatures, nClasses), nFeatures, nClasses);
+  net->archSha_ = sha256Hex(archText);
+  plannedNets().push_back(net.get());   // (networks live as long as the trainer process: no removal)
+  return net;
 }
 std::shared_ptr<fl::Sequential> buildSequentialModule(const std::string& archfile, int64_t nFeatures, int64_t nClasses) {
   return buildSequentialModuleFromText(w2l::readFile(archfile), nFeatures, nClasses);
 }
+
+}  // namespace speech
+}  // namespace pkg
+namespace {
+bool findArena(const float* p, ArenaInfo& out) {
+  for (auto* n : pkg::speech::plannedNets()) {
+    float* b = n->gradPtr();
+    const size_t fl = n->impl().paramFloats();
+    if (p >= b && p < b + fl) { out.base = b; out.floats = fl; out.net = n; return true; }
+  }
+  return false;
+}
+std::vector<size_t> arenaParamOffsets(void* net) {
+  std::vector<size_t> v;
+  for (const auto& pi : ((pkg::speech::PlannedNet*)net)->impl().params()) v.push_back(pi.offset);
+  return v;
+}
+const std::vector<size_t>& arenaBucketOffsets(void* net) { return ((pkg::speech::PlannedNet*)net)->bucketOffsets_; }
+hipEvent_t arenaBucketEvent(void* net, size_t k) { return ((pkg::speech::PlannedNet*)net)->bucketEvents_.at(k); }
+void arenaInstallBuckets(void* net, std::vector<size_t> offs) { ((pkg::speech::PlannedNet*)net)->installBuckets(std::move(offs)); }
+}  // namespace
+namespace pkg {
+namespace speech {
 
 FlatView flatParameters(const std::shared_ptr<fl::Module>& network) {
   auto* p = dynamic_cast<PlannedNet*>(network.get());
@@ -581,6 +736,13 @@ FlatView flatParameters(const std::shared_ptr<fl::Module>& network) {
 }
 void setMixedPrecision(const std::shared_ptr<fl::Module>& network, bool on) {
   if (auto* p = dynamic_cast<PlannedNet*>(network.get())) p->mixed_ = on;
+}
+uint32_t networkStep(const std::shared_ptr<fl::Module>& network) {
+  auto* p = dynamic_cast<PlannedNet*>(network.get());
+  return p ? p->step() : 0;
+}
+void setNetworkStep(const std::shared_ptr<fl::Module>& network, uint32_t step) {
+  if (auto* p = dynamic_cast<PlannedNet*>(network.get())) p->setStep(step);
 }
 FlatView flatGradients(const std::shared_ptr<fl::Module>& network) {
   auto* p = dynamic_cast<PlannedNet*>(network.get());
@@ -712,5 +874,387 @@ af::array CTCLoss::viterbiPathWithTarget(const af::array&, const af::array&, con
 std::string CTCLoss::prettyString() const { return "ConnectionistTemporalClassificationCriterion"; }
 
 }  // namespace speech
+}  // namespace pkg
+}  // namespace fl
+
+// ------------------------------------------------------------------------------------------------ Serializer
+// The W2LAMD01 container of wav2letter_amd/checkpoint.py (see the layout there): 8-byte magic, uint32 JSON-header length,
+// JSON header, then every tensor's float32 data 16-byte aligned in header order.  Network tensors are stored in the
+// REFERENCE's layouts (w2l::Sequential::exportParam / importParam), the ASG transitions (N, N) raw, the optimizer state
+// as flat arenas [network parameters in arena order | criterion parameters] ("momentum": SGD velocity / Adagrad variance /
+// Adadelta accGrad; "state2": Adadelta accDelta) -- the same bytes the Python front-end writes, so either side resumes
+// the other's run.
+namespace fl {
+namespace pkg {
+namespace runtime {
+namespace {
+
+struct JVal {   // the subset of JSON the header uses
+  enum Kind { NUL, NUM, STR, ARR, OBJ } kind = NUL;
+  double num = 0;
+  std::string str;
+  std::vector<JVal> arr;
+  std::vector<std::pair<std::string, JVal>> obj;
+  const JVal* get(const std::string& k) const {
+    for (auto& kv : obj) if (kv.first == k) return &kv.second;
+    return nullptr;
+  }
+};
+struct JParser {
+  const std::string& s;
+  size_t i = 0;
+  explicit JParser(const std::string& t) : s(t) {}
+  void ws() { while (i < s.size() && (s[i] == ' ' || s[i] == '\n' || s[i] == '\t' || s[i] == '\r')) ++i; }
+  [[noreturn]] void fail(const char* what) { throw std::runtime_error(std::string("checkpoint header: ") + what + " at byte " + std::to_string(i)); }
+  std::string parseString() {
+    if (s[i] != '"') fail("expected a string");
+    ++i;
+    std::string out;
+    while (i < s.size() && s[i] != '"') {
+      char c = s[i++];
+      if (c == '\\') {
+        if (i >= s.size()) fail("bad escape");
+        char e = s[i++];
+        switch (e) {
+          case 'n': out += '\n'; break;
+          case 't': out += '\t'; break;
+          case 'r': out += '\r'; break;
+          case 'b': out += '\b'; break;
+          case 'f': out += '\f'; break;
+          case 'u': {
+            if (i + 4 > s.size()) fail("bad \\u escape");
+            unsigned cp = (unsigned)std::stoul(s.substr(i, 4), nullptr, 16);
+            i += 4;
+            if (cp < 0x80) out += (char)cp;
+            else if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 0x3F)); }
+            else { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
+            break;
+          }
+          default: out += e;
+        }
+      } else {
+        out += c;
+      }
+    }
+    if (i >= s.size()) fail("unterminated string");
+    ++i;
+    return out;
+  }
+  JVal parse() {
+    ws();
+    if (i >= s.size()) fail("unexpected end");
+    JVal v;
+    const char c = s[i];
+    if (c == '{') {
+      v.kind = JVal::OBJ;
+      ++i; ws();
+      if (s[i] == '}') { ++i; return v; }
+      for (;;) {
+        ws();
+        std::string k = parseString();
+        ws();
+        if (s[i] != ':') fail("expected ':'");
+        ++i;
+        v.obj.emplace_back(std::move(k), parse());
+        ws();
+        if (s[i] == ',') { ++i; continue; }
+        if (s[i] == '}') { ++i; break; }
+        fail("expected ',' or '}'");
+      }
+    } else if (c == '[') {
+      v.kind = JVal::ARR;
+      ++i; ws();
+      if (s[i] == ']') { ++i; return v; }
+      for (;;) {
+        v.arr.push_back(parse());
+        ws();
+        if (s[i] == ',') { ++i; continue; }
+        if (s[i] == ']') { ++i; break; }
+        fail("expected ',' or ']'");
+      }
+    } else if (c == '"') {
+      v.kind = JVal::STR;
+      v.str = parseString();
+    } else if (s.compare(i, 4, "true") == 0) { v.kind = JVal::NUM; v.num = 1; i += 4; }
+    else if (s.compare(i, 5, "false") == 0) { v.kind = JVal::NUM; v.num = 0; i += 5; }
+    else if (s.compare(i, 4, "null") == 0) { i += 4; }
+    else {
+      size_t used = 0;
+      v.kind = JVal::NUM;
+      try { v.num = std::stod(s.substr(i, 64), &used); } catch (...) { fail("bad number"); }
+      i += used;
+    }
+    return v;
+  }
+};
+std::string jstr(const std::string& t) {
+  std::string o = "\"";
+  for (unsigned char c : t) {
+    if (c == '"') o += "\\\"";
+    else if (c == '\\') o += "\\\\";
+    else if (c == '\n') o += "\\n";
+    else if (c == '\t') o += "\\t";
+    else if (c == '\r') o += "\\r";
+    else if (c < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", c); o += b; }
+    else o += (char)c;
+  }
+  return o + "\"";
+}
+
+struct Tensor { std::string name, kind; std::vector<long> shape; std::vector<float> data; };
+
+std::vector<float> toHost(const float* dev, size_t n) {
+  std::vector<float> h(n);
+  if (n) {
+    w2l::hipCheck(hipMemcpyAsync(h.data(), dev, n * sizeof(float), hipMemcpyDeviceToHost, S()), "checkpoint copy");
+    w2l::hipCheck(hipStreamSynchronize(S()), "checkpoint copy");
+  }
+  return h;
+}
+void toDevice(float* dev, const float* host, size_t n) {
+  if (!n) return;
+  w2l::hipCheck(hipMemcpyAsync(dev, host, n * sizeof(float), hipMemcpyHostToDevice, S()), "checkpoint copy");
+  w2l::hipCheck(hipStreamSynchronize(S()), "checkpoint copy");
+}
+speech::PlannedNet& planned(const std::shared_ptr<fl::Module>& network) {
+  auto* p = dynamic_cast<speech::PlannedNet*>(network.get());
+  if (!p) throw std::invalid_argument("Serializer: the network must come from an arch file (buildSequentialModule / ModulePlugin::arch)");
+  return *p;
+}
+std::string critName(const std::shared_ptr<fl::Module>& criterion) {
+  if (dynamic_cast<speech::ASGLoss*>(criterion.get())) return "asg";
+  if (dynamic_cast<speech::CTCLoss*>(criterion.get())) return "ctc";
+  throw std::invalid_argument("Serializer: unsupported criterion (this build: ASGLoss, CTCLoss)");
+}
+size_t critSlot(const std::shared_ptr<fl::Module>& criterion) {   // floats the criterion occupies in the flat arenas (16-byte slots)
+  size_t n = 0;
+  for (auto& p : criterion->params()) n += ((size_t)p.elements() + 3) / 4 * 4;
+  return n;
+}
+// flat optimizer arena [network | criterion] <- per-parameter state arrays (slot 0 or 1); false when neither optimizer has that slot
+bool gatherState(speech::PlannedNet& net, const std::shared_ptr<fl::Module>& criterion, fl::FirstOrderOptimizer* no, fl::FirstOrderOptimizer* co,
+                 size_t slot, std::vector<float>& flat) {
+  const size_t nNet = net.impl().paramFloats();
+  flat.assign(nNet + critSlot(criterion), 0.f);
+  bool any = false;
+  if (no) {
+    auto st = no->state();
+    if (slot < st.size()) {
+      any = true;
+      const auto& table = net.impl().params();
+      if (st[slot]->size() != table.size()) throw std::logic_error("Serializer: network optimizer state does not match the network");
+      for (size_t i = 0; i < table.size(); ++i) {
+        auto h = toHost((*st[slot])[i].device<float>(), table[i].numel);
+        std::copy(h.begin(), h.end(), flat.begin() + table[i].offset);
+      }
+    }
+  }
+  if (co) {
+    auto st = co->state();
+    if (slot < st.size()) {
+      any = true;
+      size_t off = nNet;
+      for (size_t i = 0; i < st[slot]->size(); ++i) {
+        const size_t n = (size_t)(*st[slot])[i].elements();
+        auto h = toHost((*st[slot])[i].device<float>(), n);
+        std::copy(h.begin(), h.end(), flat.begin() + off);
+        off += (n + 3) / 4 * 4;
+      }
+    }
+  }
+  return any;
+}
+void scatterState(speech::PlannedNet& net, fl::FirstOrderOptimizer* no, fl::FirstOrderOptimizer* co, size_t slot, const std::vector<float>& flat) {
+  const size_t nNet = net.impl().paramFloats();
+  if (no) {
+    auto st = no->state();
+    if (slot < st.size()) {
+      const auto& table = net.impl().params();
+      for (size_t i = 0; i < table.size(); ++i) toDevice((*st[slot])[i].device<float>(), flat.data() + table[i].offset, table[i].numel);
+    }
+  }
+  if (co) {
+    auto st = co->state();
+    if (slot < st.size()) {
+      size_t off = nNet;
+      for (size_t i = 0; i < st[slot]->size(); ++i) {
+        const size_t n = (size_t)(*st[slot])[i].elements();
+        if (off + n > flat.size()) throw std::runtime_error("checkpoint: optimizer arena too short for the criterion state");
+        toDevice((*st[slot])[i].device<float>(), flat.data() + off, n);
+        off += (n + 3) / 4 * 4;
+      }
+    }
+  }
+}
+
+struct Loaded { JVal header; std::vector<std::vector<float>> arrays; };
+Loaded readFile(const std::string& path, bool headerOnly) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) throw std::runtime_error("cannot open checkpoint " + path);
+  char magic[8];
+  uint32_t n = 0;
+  if (!f.read(magic, 8) || std::memcmp(magic, "W2LAMD01", 8) != 0) throw std::runtime_error(path + ": not a W2LAMD01 checkpoint");
+  if (!f.read((char*)&n, 4)) throw std::runtime_error(path + ": truncated");
+  std::string hdr(n, '\0');
+  if (!f.read(&hdr[0], n)) throw std::runtime_error(path + ": truncated header");
+  Loaded L;
+  L.header = JParser(hdr).parse();
+  if (headerOnly) return L;
+  const JVal* ts = L.header.get("tensors");
+  if (!ts || ts->kind != JVal::ARR) throw std::runtime_error(path + ": header without a tensor list");
+  size_t pos = 12 + (size_t)n;
+  for (auto& t : ts->arr) {
+    const JVal* ne = t.get("numel");
+    if (!ne) throw std::runtime_error(path + ": tensor without numel");
+    const size_t numel = (size_t)ne->num;
+    const size_t at = (pos + 15) / 16 * 16;
+    f.seekg((std::streamoff)at);
+    std::vector<float> a(numel);
+    if (numel && !f.read((char*)a.data(), (std::streamsize)(numel * 4))) throw std::runtime_error(path + ": truncated tensor data");
+    L.arrays.push_back(std::move(a));
+    pos = at + numel * 4;
+  }
+  return L;
+}
+void configFromHeader(const JVal& h, std::string& version, Serializer::Config& config) {
+  config.clear();
+  if (const JVal* fl = h.get("flags"))
+    for (auto& kv : fl->obj) config[kv.first] = kv.second.kind == JVal::STR ? kv.second.str : (kv.second.kind == JVal::NUM ? std::to_string((long long)kv.second.num) : "");
+  auto it = config.find("version");
+  version = it == config.end() ? "" : it->second;
+}
+void loadModel(const std::string& path, std::string& version, Serializer::Config& config, const std::shared_ptr<fl::Module>& network,
+               const std::shared_ptr<fl::Module>& criterion, fl::FirstOrderOptimizer* no, fl::FirstOrderOptimizer* co) {
+  Loaded L = readFile(path, false);
+  configFromHeader(L.header, version, config);
+  speech::PlannedNet& net = planned(network);
+  auto num = [&](const char* k) { const JVal* v = L.header.get(k); return v ? (long)v->num : -1L; };
+  if (num("nfeat") != net.nFeat() || num("nlabel") != net.nLabel()) throw std::runtime_error("checkpoint was written for a different NFEAT / NLABEL");
+  const JVal* sha = L.header.get("arch_sha256");
+  if (sha && sha->kind == JVal::STR && !sha->str.empty() && sha->str != net.archSha_) throw std::runtime_error("checkpoint was written for a different architecture file");
+  const JVal* cn = L.header.get("criterion");
+  if (cn && cn->kind == JVal::STR && cn->str != critName(criterion)) throw std::runtime_error("checkpoint was written for criterion '" + cn->str + "'");
+  const auto& table = net.impl().params();
+  const JVal& ts = *L.header.get("tensors");
+  std::vector<float> host = toHost(net.paramPtr(), net.impl().paramFloats());
+  size_t ni = 0;
+  const std::vector<float>* mom = nullptr;
+  const std::vector<float>* st2 = nullptr;
+  bool haveCrit = false;
+  for (size_t k = 0; k < ts.arr.size(); ++k) {
+    const JVal* kind = ts.arr[k].get("kind");
+    const std::string kd = kind ? kind->str : "";
+    if (kd == "network") {
+      if (ni >= table.size() || L.arrays[k].size() != table[ni].numel) throw std::runtime_error("checkpoint: parameter list does not match this network");
+      net.impl().importParam(ni, L.arrays[k].data(), host.data());
+      ++ni;
+    } else if (kd == "criterion") {
+      auto cp = criterion->params();
+      if (cp.empty() || (size_t)cp[0].elements() != L.arrays[k].size()) throw std::runtime_error("checkpoint: criterion parameters do not match");
+      toDevice(cp[0].array().device<float>(), L.arrays[k].data(), L.arrays[k].size());
+      haveCrit = true;
+    } else if (kd == "momentum") {
+      mom = &L.arrays[k];
+    } else if (kd == "state2") {
+      st2 = &L.arrays[k];
+    }
+  }
+  if (ni != table.size()) throw std::runtime_error("checkpoint: parameter list does not match this network");
+  if (haveCrit != !criterion->params().empty()) throw std::runtime_error("checkpoint: criterion parameters do not match (one side has transitions, the other has none)");
+  toDevice(net.paramPtr(), host.data(), host.size());
+  if (no || co) {
+    const JVal* op = L.header.get("optim");
+    const std::string wantNet = no ? no->kind() : "sgd", wantCrit = co ? co->kind() : "sgd";
+    if (op && op->kind == JVal::ARR && op->arr.size() == 2 && (mom || st2) && (op->arr[0].str != wantNet || op->arr[1].str != wantCrit))
+      throw std::runtime_error("checkpoint holds the state of optimizers (" + op->arr[0].str + ", " + op->arr[1].str + "), this run uses (" + wantNet + ", " + wantCrit + ")");
+    const size_t want = net.impl().paramFloats() + critSlot(criterion);
+    if (mom) { if (mom->size() != want) throw std::runtime_error("checkpoint: optimizer arena does not match this trainer"); scatterState(net, no, co, 0, *mom); }
+    if (st2) { if (st2->size() != want) throw std::runtime_error("checkpoint: optimizer arena does not match this trainer"); scatterState(net, no, co, 1, *st2); }
+  }
+  net.setStep((uint32_t)std::max(0L, num("step")));
+}
+
+}  // namespace
+
+void Serializer::save(const std::string& path, const std::string& version, const Config& config, const std::shared_ptr<fl::Module>& network,
+                      const std::shared_ptr<fl::Module>& criterion, const std::shared_ptr<fl::FirstOrderOptimizer>& netoptim,
+                      const std::shared_ptr<fl::FirstOrderOptimizer>& critoptim) {
+  speech::PlannedNet& net = planned(network);
+  const auto& table = net.impl().params();
+  std::vector<Tensor> tensors;
+  const std::vector<float> host = toHost(net.paramPtr(), net.impl().paramFloats());
+  for (size_t i = 0; i < table.size(); ++i) {
+    Tensor t;
+    t.name = table[i].name; t.kind = "network"; t.shape = {(long)table[i].numel};
+    t.data.resize(table[i].numel);
+    net.impl().exportParam(i, host.data(), t.data.data());
+    tensors.push_back(std::move(t));
+  }
+  for (auto& p : criterion->params()) {
+    Tensor t;
+    t.name = "criterion.transitions"; t.kind = "criterion";
+    t.shape = {(long)p.dims(0), (long)p.dims(1)};
+    t.data = toHost(p.array().device<float>(), (size_t)p.elements());
+    tensors.push_back(std::move(t));
+  }
+  std::vector<float> flat;
+  if (gatherState(net, criterion, netoptim.get(), critoptim.get(), 0, flat)) {
+    Tensor t; t.name = "netoptim.momentum(internal arena)"; t.kind = "momentum"; t.shape = {(long)flat.size()}; t.data = flat;
+    tensors.push_back(std::move(t));
+  }
+  if (gatherState(net, criterion, netoptim.get(), critoptim.get(), 1, flat)) {
+    Tensor t; t.name = "netoptim.accDelta(internal arena)"; t.kind = "state2"; t.shape = {(long)flat.size()}; t.data = flat;
+    tensors.push_back(std::move(t));
+  }
+  std::ostringstream h;
+  h << "{\"nfeat\": " << net.nFeat() << ", \"nlabel\": " << net.nLabel() << ", \"criterion\": " << jstr(critName(criterion))
+    << ", \"optim\": [" << jstr(netoptim ? netoptim->kind() : "sgd") << ", " << jstr(critoptim ? critoptim->kind() : "sgd") << "]"
+    << ", \"arch_sha256\": " << jstr(net.archSha_) << ", \"step\": " << net.step() << ", \"flags\": {" << jstr("version") << ": " << jstr(version);
+  for (auto& kv : config)
+    if (kv.first != "version") h << ", " << jstr(kv.first) << ": " << jstr(kv.second);
+  h << "}, \"tensors\": [";
+  for (size_t i = 0; i < tensors.size(); ++i) {
+    h << (i ? ", " : "") << "{\"name\": " << jstr(tensors[i].name) << ", \"kind\": " << jstr(tensors[i].kind) << ", \"numel\": " << tensors[i].data.size()
+      << ", \"shape\": [";
+    for (size_t k = 0; k < tensors[i].shape.size(); ++k) h << (k ? ", " : "") << tensors[i].shape[k];
+    h << "]}";
+  }
+  h << "]}";
+  const std::string hdr = h.str();
+  const std::string tmp = path + ".tmp";
+  {
+    std::ofstream f(tmp, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot write " + tmp);
+    f.write("W2LAMD01", 8);
+    const uint32_t n = (uint32_t)hdr.size();
+    f.write((const char*)&n, 4);
+    f.write(hdr.data(), (std::streamsize)hdr.size());
+    size_t pos = 12 + hdr.size();
+    static const char zeros[16] = {0};
+    for (auto& t : tensors) {
+      const size_t pad = (pos + 15) / 16 * 16 - pos;
+      f.write(zeros, (std::streamsize)pad);
+      f.write((const char*)t.data.data(), (std::streamsize)(t.data.size() * 4));
+      pos += pad + t.data.size() * 4;
+    }
+    if (!f) throw std::runtime_error("cannot write " + tmp);
+  }
+  if (rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error("cannot publish " + path);   // never a half-written model_last.bin
+}
+
+void Serializer::load(const std::string& path, std::string& version, Config& config) {
+  configFromHeader(readFile(path, true).header, version, config);
+}
+void Serializer::load(const std::string& path, std::string& version, Config& config, const std::shared_ptr<fl::Module>& network,
+                      const std::shared_ptr<fl::Module>& criterion) {
+  loadModel(path, version, config, network, criterion, nullptr, nullptr);
+}
+void Serializer::load(const std::string& path, std::string& version, Config& config, const std::shared_ptr<fl::Module>& network,
+                      const std::shared_ptr<fl::Module>& criterion, const std::shared_ptr<fl::FirstOrderOptimizer>& netoptim,
+                      const std::shared_ptr<fl::FirstOrderOptimizer>& critoptim) {
+  loadModel(path, version, config, network, criterion, netoptim.get(), critoptim.get());
+}
+
+}  // namespace runtime
 }  // namespace pkg
 }  // namespace fl

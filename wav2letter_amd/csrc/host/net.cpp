@@ -774,6 +774,9 @@ class TransformerLayer : public Layer {
   size_t ds2Off, duOff, dhOff, dr1Off, dctxOff, dsOff, dRoff, dqOff, dkOff, dvOff, dxOff, dEpOff, klOff;
   const float* xSaved = nullptr;
   bool dropped = false;
+  // mixed precision: the six fl::Linear of the block on bf16 images (the attention products stay on the fp32 batched GEMM)
+  BfLinear blq, blk, blv, blf, bl1, bl2;
+  BfImage xImg, ctxImg, hImg, uImg, dqImg, dkImg, dvImg, dr1Img, duImg, ds2Img;
 
   std::string name() const override { return "Transformer"; }
   void registerParams(std::vector<ParamInfo>& t) override {
@@ -822,6 +825,9 @@ class TransformerLayer : public Layer {
     dsOff = pl.alloc(ns); dRoff = pl.alloc(nr); dqOff = pl.alloc(n); dkOff = pl.alloc(n); dvOff = pl.alloc(n); dxOff = pl.alloc(n);
     dEpOff = pl.alloc((size_t)B * W * d);
     klOff = pl.alloc((size_t)B);
+    blq.plan(pl, M, C, C); blk.plan(pl, M, C, C); blv.plan(pl, M, C, C); blf.plan(pl, M, C, C); bl1.plan(pl, M, C, mlp); bl2.plan(pl, M, mlp, C);
+    xImg.plan(pl, M, C); ctxImg.plan(pl, M, C); hImg.plan(pl, M, C); uImg.plan(pl, M, mlp);
+    dqImg.plan(pl, M, C); dkImg.plan(pl, M, C); dvImg.plan(pl, M, C); dr1Img.plan(pl, M, C); duImg.plan(pl, M, mlp); ds2Img.plan(pl, M, C);
     return in;
   }
   // per-(utterance, head) product over frame-major operands; see w2l_bgemm_desc
@@ -849,9 +855,18 @@ class TransformerLayer : public Layer {
       y = out;
       return;
     }
+    const bool mixed = cx.bf16;
+    if (mixed) {   // one pair of images of x serves the three projections (and their weight gradients in backward)
+      xImg.convert(cx, ar, x, "tr x images");
+      blq.convertWeight(cx, ar, wq.w(cx)); blk.convertWeight(cx, ar, wk.w(cx)); blv.convertWeight(cx, ar, wv.w(cx));
+      blq.forward(cx, ar, xImg, bq.w(cx), q, 0, 0.0, 0, 0);
+      blk.forward(cx, ar, xImg, bk.w(cx), k, 0, 0.0, 0, 0);
+      blv.forward(cx, ar, xImg, bv.w(cx), v, 0, 0.0, 0, 0);
+    } else {
     w2lCheck(w2l_linear_forward(M, C, C, x, wq.w(cx), bq.w(cx), q, 0, s), "tr q");
     w2lCheck(w2l_linear_forward(M, C, C, x, wk.w(cx), bk.w(cx), k, 0, s), "tr k");
     w2lCheck(w2l_linear_forward(M, C, C, x, wv.w(cx), bv.w(cx), v, 0, s), "tr v");
+    }
     const long long TC = (long long)T * C, TT = (long long)T * T;
     {  // S[b][h][i][j] = q_i . k_j
       w2l_bgemm_desc g = heads(T, T, d);
@@ -876,11 +891,26 @@ class TransformerLayer : public Layer {
       g.sam = T; g.sak = 1; g.a1 = nH * TT; g.a2 = TT; g.sbk = C; g.sbn = 1; g.b1 = TC; g.b2 = d; g.ldc = C; g.c1 = TC; g.c2 = d;
       w2lCheck(w2l_bgemm_f32(&g, pd > 0 ? Pd : S, v, ctx, s), "tr pv");
     }
-    w2lCheck(w2l_linear_forward(M, C, C, ctx, wf.w(cx), bf.w(cx), o, 0, s), "tr wf");
+    if (mixed) {
+      ctxImg.convert(cx, ar, ctx, "tr ctx images");
+      blf.convertWeight(cx, ar, wf.w(cx));
+      blf.forward(cx, ar, ctxImg, bf.w(cx), o, 0, 0.0, 0, 0);
+    } else {
+      w2lCheck(w2l_linear_forward(M, C, C, ctx, wf.w(cx), bf.w(cx), o, 0, s), "tr wf");
+    }
     // r1 = o + x (stored over o), h = LN1(r1)
     w2lCheck(w2l_residual_layernorm_forward(M, C, o, x, o, h, gb1.w(cx), 1e-5f, 0.0, 0, 0, (double*)(ar + st1Off), ar + mr1Off, s), "tr ln1");
+    if (mixed) {
+      hImg.convert(cx, ar, h, "tr h images");
+      bl1.convertWeight(cx, ar, w1.w(cx));
+      bl1.forward(cx, ar, hImg, b1.w(cx), u, 1, 0.0, 0, 0);
+      uImg.convert(cx, ar, u, "tr u images");
+      bl2.convertWeight(cx, ar, w2.w(cx));
+      bl2.forward(cx, ar, uImg, b2.w(cx), m2, 0, 0.0, 0, 0);
+    } else {
     w2lCheck(w2l_linear_forward(M, C, mlp, h, w1.w(cx), b1.w(cx), u, 1, s), "tr w1");
     w2lCheck(w2l_linear_forward(M, mlp, C, u, w2.w(cx), b2.w(cx), m2, 0, s), "tr w2");
+    }
     w2lCheck(w2l_residual_layernorm_forward(M, C, m2, h, m2, out, gb2.w(cx), 1e-5f, 0.0, 0, 0, (double*)(ar + st2Off), ar + mr2Off, s), "tr ln2");
     y = out;
   }
@@ -906,16 +936,35 @@ class TransformerLayer : public Layer {
     }
     const long long TC = (long long)T * C, TT = (long long)T * T;
     w2lCheck(w2l_layernorm_backward(M, C, m2, dy, gb2.w(cx), ar + mr2Off, ds2, gb2.g(cx), nullptr, nullptr, 1.f, (double*)(ar + st2Off), s), "tr ln2 bwd");
+    const bool mixed = cx.bf16;
+    if (mixed) {
+      ds2Img.convert(cx, ar, ds2, "tr ds2 images");
+      bl2.backwardWeight(cx, ar, uImg, ds2Img, w2.g(cx));
+      w2lCheck(w2l_colsum(ds2, b2.g(cx), (size_t)M, C, s), "tr w2 bwd b");
+      bl2.backwardData(cx, ar, ds2Img, du, u, 1.f, nullptr, 0);
+      duImg.convert(cx, ar, du, "tr du images");
+      bl1.backwardWeight(cx, ar, hImg, duImg, w1.g(cx));
+      w2lCheck(w2l_colsum(du, b1.g(cx), (size_t)M, mlp, s), "tr w1 bwd b");
+      bl1.backwardData(cx, ar, duImg, dh, nullptr, 1.f, ds2, 0);
+    } else {
     w2lCheck(w2l_linear_backward_weight(M, mlp, C, u, ds2, w2.g(cx), s), "tr w2 bwd w");
     w2lCheck(w2l_colsum(ds2, b2.g(cx), (size_t)M, C, s), "tr w2 bwd b");
     w2lCheck(w2l_linear_backward_data(M, mlp, C, ds2, w2.w(cx), du, 0, u, 1.f, s), "tr w2 bwd x");
     w2lCheck(w2l_linear_backward_weight(M, C, mlp, h, du, w1.g(cx), s), "tr w1 bwd w");
     w2lCheck(w2l_colsum(du, b1.g(cx), (size_t)M, mlp, s), "tr w1 bwd b");
     w2lCheck(w2l_linear_backward_data_add(M, C, mlp, du, w1.w(cx), ds2, dh, s), "tr w1 bwd x");
+    }
     w2lCheck(w2l_layernorm_backward(M, C, o, dh, gb1.w(cx), ar + mr1Off, dr1, gb1.g(cx), nullptr, nullptr, 1.f, (double*)(ar + st1Off), s), "tr ln1 bwd");
+    if (mixed) {
+      dr1Img.convert(cx, ar, dr1, "tr dr1 images");
+      blf.backwardWeight(cx, ar, ctxImg, dr1Img, wf.g(cx));
+      w2lCheck(w2l_colsum(dr1, bf.g(cx), (size_t)M, C, s), "tr wf bwd b");
+      blf.backwardData(cx, ar, dr1Img, dctx, nullptr, 1.f, nullptr, 0);
+    } else {
     w2lCheck(w2l_linear_backward_weight(M, C, C, ctx, dr1, wf.g(cx), s), "tr wf bwd w");
     w2lCheck(w2l_colsum(dr1, bf.g(cx), (size_t)M, C, s), "tr wf bwd b");
     w2lCheck(w2l_linear_backward_data(M, C, C, dr1, wf.w(cx), dctx, 0, nullptr, 1.f, s), "tr wf bwd x");
+    }
     {  // dPd[i][j] = dctx_i . v_j
       w2l_bgemm_desc g = heads(T, T, d);
       g.sam = C; g.sak = 1; g.a1 = TC; g.a2 = d; g.sbk = 1; g.sbn = C; g.b1 = TC; g.b2 = d; g.ldc = T; g.c1 = nH * TT; g.c2 = TT;
@@ -953,6 +1002,19 @@ class TransformerLayer : public Layer {
         zeroGrad(cx, pe, s);
         w2lCheck(w2l_colsum(dEp, pe.g(cx) + (size_t)rlo * d, (size_t)B, W * d, s), "tr dE sum");
       }
+    }
+    if (mixed) {
+      dqImg.convert(cx, ar, dq, "tr dq images"); dkImg.convert(cx, ar, dk, "tr dk images"); dvImg.convert(cx, ar, dv, "tr dv images");
+      blq.backwardWeight(cx, ar, xImg, dqImg, wq.g(cx));
+      blk.backwardWeight(cx, ar, xImg, dkImg, wk.g(cx));
+      blv.backwardWeight(cx, ar, xImg, dvImg, wv.g(cx));
+      w2lCheck(w2l_colsum(dq, bq.g(cx), (size_t)M, C, s), "tr wq bwd b");
+      w2lCheck(w2l_colsum(dk, bk.g(cx), (size_t)M, C, s), "tr wk bwd b");
+      w2lCheck(w2l_colsum(dv, bv.g(cx), (size_t)M, C, s), "tr wv bwd b");
+      blq.backwardData(cx, ar, dqImg, dx, nullptr, 1.f, dr1, 0);
+      blk.backwardData(cx, ar, dkImg, dx, nullptr, 1.f, nullptr, 1);
+      blv.backwardData(cx, ar, dvImg, dx, nullptr, 1.f, nullptr, 1);
+      return;
     }
     w2lCheck(w2l_linear_backward_weight(M, C, C, xSaved, dq, wq.g(cx), s), "tr wq bwd w");
     w2lCheck(w2l_colsum(dq, bq.g(cx), (size_t)M, C, s), "tr wq bwd b");

@@ -11,6 +11,13 @@
 // (`epoch | nupdates | lr | lrcriterion | runtime | bch(ms) | smp(ms) | fwd(ms) | crit-fwd(ms) | bwd(ms) | optim(ms) |
 // loss | train-TER | train-WER | ...`) to stdout and to <rundir>/<runname>/001_log, next to 001_config (:644-651).
 //
+// `Train continue <directory>` / `Train fork <model>` (Train.cpp:124-179, :452-463): the run directory holds NNN_log, NNN_config and
+// NNN_model_last.bin (getRunFile, :644-651, :767-790); `continue` looks for the highest NNN_model_last.bin, re-reads the flags
+// stored in it (the command line overrides them), restores network, criterion, both optimizers, the update counter and the
+// position of every random stream, and goes on as run NNN+1 -- bit for bit where an uninterrupted run would be; `fork` takes
+// flags + network + criterion from a model file and starts a fresh run in --rundir.  The container is the documented
+// W2LAMD01 layout of wav2letter_amd/checkpoint.py (fl::pkg::runtime::Serializer), not cereal.
+//
 // What is NOT here (SURVEY 8 marks it out of scope or "next"): audio decoding, the lexicon / word-piece pipeline, the
 // decoder, cereal checkpoints.  The data the step consumes is therefore SYNTHETIC unless --train names list files
 // that exist: LibriSpeech-shaped padded batches (--w2l_synth_frames frames of --filterbanks features, random targets),
@@ -21,6 +28,7 @@
 #include <limits>
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -100,17 +108,46 @@ int main(int argc, char** argv) {
   const std::string runStatus = argv[1];
   try {
     int first = 2;
-    if (runStatus == "continue" || runStatus == "fork") {
-      // the reference reloads flags + model from a cereal checkpoint (Train.cpp:132-173); this build's container is
-      // wav2letter_amd/checkpoint.py (documented layout) -- resuming through this binary is not wired yet
-      std::cerr << "Train " << runStatus << ": resuming from a checkpoint goes through wav2letter_amd.checkpoint (Python) in this build"
-                << std::endl;
-      return 3;
-    }
-    if (runStatus != "train") return usage(argv[0]);
-
-    // ---- flags: --flagsfile first, then the command line in order (gflags semantics: the last definition wins)
+    int runIdx = 1;                 // current #runs in this path (Train.cpp:124)
+    std::string runPath, reloadPath;
+    long startUpdate = 0;
+    using Serializer = fl::pkg::runtime::Serializer;
+    Serializer::Config reloadCfg;
+    auto getRunFile = [](const std::string& name, int idx, const std::string& path) {
+      char b[16];
+      snprintf(b, sizeof b, "%03d_", idx);
+      return pathJoin(path, std::string(b) + name);
+    };
     w2l::Flags flags;
+    if (runStatus == "continue") {
+      if (argc <= 2) return usage(argv[0]);
+      runPath = argv[2];
+      first = 3;
+      while (fileExists(getRunFile("model_last.bin", runIdx, runPath))) ++runIdx;
+      if (runIdx == 1) throw std::invalid_argument("continue: no 001_model_last.bin in '" + runPath + "'");
+      reloadPath = getRunFile("model_last.bin", runIdx - 1, runPath);
+      std::cout << "reload path is " << reloadPath << std::endl;
+    } else if (runStatus == "fork") {
+      if (argc <= 2) return usage(argv[0]);
+      reloadPath = argv[2];
+      first = 3;
+    } else if (runStatus != "train") {
+      return usage(argv[0]);
+    }
+    if (!reloadPath.empty()) {
+      std::string version;
+      Serializer::load(reloadPath, version, reloadCfg);
+      auto it = reloadCfg.find("gflags");
+      if (it == reloadCfg.end()) throw std::invalid_argument("Invalid config loaded from " + reloadPath);
+      std::cout << "Reading flags from config file " << reloadPath << std::endl;
+      flags = w2l::parseFlagsText(it->second);
+      if (runStatus == "continue") {
+        auto up = reloadCfg.find("nbupdates");
+        if (up == reloadCfg.end()) std::cout << "Did not find #updates to start from, starting from 0." << std::endl;
+        else startUpdate = std::stol(up->second);
+      }
+    }
+    // ---- flags: (the checkpoint's,) --flagsfile, then the command line in order (gflags semantics: the last definition wins)
     for (int i = first; i < argc; ++i) {
       w2l::Flags one = w2l::parseFlagsText(argv[i]);
       for (auto& kv : one.kv) flags.kv.push_back(kv);
@@ -140,15 +177,17 @@ int main(int argc, char** argv) {
       if (criterionName == "ctc") numClasses += 1;  // blank, appended LAST
     }
 
-    // ---- run directory: NNN_log, NNN_config (Train.cpp:644-651)
-    std::string runPath = pathJoin(flags.get("rundir", ""), flags.get("runname", ""));
-    std::ofstream logFile;
-    if (!flags.get("rundir", "").empty() && flags.get("rundir", "") != "[...]") {
-      mkdirs(runPath);
-      logFile.open(pathJoin(runPath, "001_log"));
-      std::ofstream cfg(pathJoin(runPath, "001_config"));
-      for (auto& kv : flags.kv) cfg << "--" << kv.first << "=" << kv.second << "\n";
+    // ---- run directory: NNN_log, NNN_config, NNN_model_last.bin (Train.cpp:644-651, :767)
+    if (runStatus != "continue") runPath = pathJoin(flags.get("rundir", ""), flags.get("runname", ""));
+    const bool haveRunDir = runStatus == "continue" || (!flags.get("rundir", "").empty() && flags.get("rundir", "") != "[...]");
+    std::string gflagsText;   // what `continue` / `fork` read back (the reference serialises its gflags the same way)
+    {
+      // later definitions win, so the effective value of every flag once, in first-appearance order
+      std::vector<std::string> order;
+      for (auto& kv : flags.kv) if (std::find(order.begin(), order.end(), kv.first) == order.end()) order.push_back(kv.first);
+      for (auto& k : order) if (k != "flagsfile") gflagsText += "--" + k + "=" + flags.get(k) + "\n";
     }
+    std::ofstream logFile;
 
     // ---- network / criterion / optimizers
     const std::string archPath = pathJoin(flags.get("archdir", ""), flags.get("arch", ""));
@@ -183,6 +222,18 @@ int main(int argc, char** argv) {
     auto critoptim = initOptimizer(criterion->params(), flags.get("critoptim", "sgd"), lrcrit0, 0.0);
     std::cout << "[Network Optimizer] " << netoptim->prettyString() << std::endl;
     std::cout << "[Criterion Optimizer] " << critoptim->prettyString() << std::endl;
+    if (runStatus == "fork") {            // Train.cpp:452-459: network + criterion, fresh optimizers
+      std::string version;
+      Serializer::Config unused;
+      Serializer::load(reloadPath, version, unused, network, criterion);
+      fl::pkg::speech::setNetworkStep(network, 0);
+      std::cout << "Loaded model " << reloadPath << " for fork" << std::endl;
+    } else if (runStatus == "continue") { // Train.cpp:460-467
+      std::string version;
+      Serializer::Config unused;
+      Serializer::load(reloadPath, version, unused, network, criterion, netoptim, critoptim);
+      std::cout << "Loaded model for continue training" << std::endl;
+    }
 
     // ---- data parallelism (Train.cpp:188-199, :1078-1079)
     std::shared_ptr<fl::Reducer> reducer;
@@ -198,6 +249,13 @@ int main(int argc, char** argv) {
       std::cout << "[Distributed] world rank " << fl::getWorldRank() << " of " << fl::getWorldSize() << " (RCCL)" << std::endl;
     }
     const bool isMaster = fl::getWorldRank() == 0;
+    if (haveRunDir && isMaster) {
+      mkdirs(runPath);
+      logFile.open(getRunFile("log", runIdx, runPath));
+      if (!logFile) throw std::runtime_error("failed to open log file for writing");
+      std::ofstream cfg(getRunFile("config", runIdx, runPath));
+      cfg << gflagsText;
+    }
 
     // ---- data
     std::string trainLists = flags.get("train", "");
@@ -211,6 +269,10 @@ int main(int argc, char** argv) {
     const int nTok = criterionName == "ctc" ? numClasses - 1 : std::max(1, numClasses - (int)flags.geti("replabel", 0));
     std::vector<float> hx((size_t)batch * nFeat * T);
     std::vector<int> ht((size_t)batch * Lmax);
+    if (runStatus == "continue") {   // the sample stream goes on where the saved run stopped (per rank)
+      auto it = reloadCfg.find("w2l_data_rng." + std::to_string(fl::getWorldRank()));
+      if (it != reloadCfg.end()) { std::istringstream is(it->second); is >> rng >> gauss; }
+    }
 
     // ---- meters (MyLogger.cpp:40-106)
     Timer runtime, timer, sampletimer, fwdtimer, critfwdtimer, bwdtimer, optimtimer;
@@ -271,10 +333,40 @@ int main(int argc, char** argv) {
       saug = std::make_shared<fl::SpecAugment>((int)flags.geti("filterbanks", 40), (int)flags.geti("saug_fmaskf", 27), (int)flags.geti("saug_fmaskn", 2),
                                                (int)flags.geti("saug_tmaskt", 100), (float)flags.getd("saug_tmaskp", 1.0), (int)flags.geti("saug_tmaskn", 2));
     if (saug) std::cout << "[SpecAugment from update " << saugStart << "] " << saug->prettyString() << std::endl;
+    if (saug && runStatus == "continue") {
+      auto it = reloadCfg.find("w2l_saug_calls");
+      if (it != reloadCfg.end()) saug->setCalls((uint32_t)std::stoul(it->second));
+    }
+
+    // ---- checkpoints (saveModels, Train.cpp:718-790): NNN_model_last.bin after every epoch of the run and at its end
+    auto saveModels = [&](long epoch, long totalUpdates) {
+      if (!haveRunDir) return;
+      // every rank's sample-stream position travels in rank 0's file: the others hand theirs over through the run directory
+      std::ostringstream rs;
+      rs << rng << " " << gauss;
+      const std::string mine = getRunFile("rng." + std::to_string(fl::getWorldRank()), runIdx, runPath);
+      if (!isMaster) { std::ofstream f(mine); f << rs.str(); }
+      if (fl::getWorldSize() > 1) fl::barrier();
+      if (!isMaster) return;
+      Serializer::Config config;
+      config["gflags"] = gflagsText;
+      config["epoch"] = std::to_string(epoch);
+      config["nbupdates"] = std::to_string(totalUpdates);
+      config["runIdx"] = std::to_string(runIdx);
+      config["w2l_data_rng.0"] = rs.str();
+      for (int r = 1; r < fl::getWorldSize(); ++r) {
+        std::ifstream f(getRunFile("rng." + std::to_string(r), runIdx, runPath));
+        std::stringstream b;
+        b << f.rdbuf();
+        config["w2l_data_rng." + std::to_string(r)] = b.str();
+      }
+      if (saug) config["w2l_saug_calls"] = std::to_string(saug->calls());
+      Serializer::save(getRunFile("model_last.bin", runIdx, runPath), "0.1", config, network, criterion, netoptim, critoptim);
+    };
 
     // ---- the hot loop (Train.cpp:1454-1804)
     double lr = lr0, lrcrit = lrcrit0;
-    for (long curBatch = 1; curBatch <= iters; ++curBatch) {
+    for (long curBatch = startUpdate + 1; curBatch <= iters; ++curBatch) {
       // learning rate (Train.cpp:1170-1175, :1334-1348): 0.5^(epoch steps after --lr_decay) * (cosine | gamma^(batch / stepsize)) * warm-up;
       // an epoch of the synthetic run is --w2l_synth_batches_per_epoch updates (default: the whole run is epoch 1)
       const long curEpoch = 1 + (curBatch - 1) / batchesPerEpoch;
@@ -392,8 +484,12 @@ int main(int argc, char** argv) {
       nsamples += batch;
       ++nbatches;
 
-      if (isMaster && ((reportiters > 0 && curBatch % reportiters == 0) || curBatch == iters)) logStatus(1, curBatch, lr, lrcrit);
+      if (isMaster && ((reportiters > 0 && curBatch % reportiters == 0) || curBatch == iters)) logStatus(curEpoch, curBatch, lr, lrcrit);
+      if (curBatch % batchesPerEpoch == 0 || curBatch == iters) saveModels(curEpoch, curBatch);
     }
+    if (auto* cr = dynamic_cast<fl::CoalescingReducer*>(reducer.get()))
+      std::cout << "[Distributed] gradient collectives of the last update: " << cr->lastCollectives() << " (" << cr->lastOverlapped()
+                << " issued on the side stream behind bucket events of the backward pass)" << std::endl;
     std::cout << "Finished training" << std::endl;
     return 0;
   } catch (const std::exception& e) {
