@@ -198,6 +198,18 @@ int w2l_conv_backward_data_add(const w2l_conv_desc* d, const float* dy, const fl
                                const float* add, float* dx, w2l_stream_t stream);
 int w2l_conv_backward_filter(const w2l_conv_desc* d, const float* x, const float* dy, float* dw,
                              float* dbias, w2l_stream_t stream);
+/* fl::TDSBlock's time convolution (C -> C channels, stride 1, T preserved) in the mixed-precision mode (bf16 operand storage, see w2l_gemm_bf16): x / dy and the weights rounded to
+ * bf16, fp32 accumulation on v_mfma_f32_32x32x16_bf16, fp32 bias / ReLU / addend / results (conv_tds_bf16.hip).
+ * w2l_tds_conv_bf16_image_elems: bf16 elements of ONE weight image of the geometry; 0 = no bf16 kernel for it (use w2l_conv_*).
+ * w2l_tds_conv_bf16_prepare: once per step, the forward and the backward-data images of the fp32 weights w [kw][C][C].
+ * backward_filter: dw [kw][C][C] only -- the bias gradient stays the fp32 column sum (w2l_colsum over [B T H][C]). */
+size_t w2l_tds_conv_bf16_image_elems(const w2l_conv_desc* d);
+int w2l_tds_conv_bf16_prepare(const w2l_conv_desc* d, const float* w, uint16_t* imgForward, uint16_t* imgBackward, w2l_stream_t stream);
+int w2l_tds_conv_bf16_forward(const w2l_conv_desc* d, const float* x, const uint16_t* imgForward, const float* bias, float* y,
+                              int relu, w2l_stream_t stream);
+int w2l_tds_conv_bf16_backward_data(const w2l_conv_desc* d, const float* dy, const uint16_t* imgBackward, const float* add,
+                                    float* dx, w2l_stream_t stream);
+int w2l_tds_conv_bf16_backward_filter(const w2l_conv_desc* d, const float* x, const float* dy, float* dw, w2l_stream_t stream);
 
 /* r = dropout(a) + x ; y = LayerNorm(r) over `groups` contiguous chunks of `inner`
  * elements with scalar affine gammaBeta[2] (fl::LayerNorm axes {0,1,2}: groups = B).

@@ -86,8 +86,10 @@ class TDSParams:
 
 
 def tds_fwd(x, p, padl, padr, ln_mode="all", streaming=False, eps=1e-5, keep=False, bf16=False):
+    """bf16: the operands of the block's convolution and of its two Linear layers are rounded to bf16 (fl's AMP casts the
+    operands of conv2d and linear: recipes/slimIPL/src/Train.cpp:211, :1681-1760); accumulation, bias, ReLU, LayerNorm, fp32"""
     B, Cc, H, T = x.shape
-    a = O.conv_fwd(x, p.wc, p.bc, 1, padl, padr)
+    a = O.conv_fwd(bf16_round(x), bf16_round(p.wc), p.bc, 1, padl, padr) if bf16 else O.conv_fwd(x, p.wc, p.bc, 1, padl, padr)
     r = relu(a) + x
     y = ln_fwd(r, ln_mode, float(p.g1), float(p.b1n), eps, streaming)
     z = to_frames(y)
@@ -114,7 +116,11 @@ def tds_bwd(dout, p, saved, padl, padr, ln_mode="all", eps=1e-5, bf16=False):
     dy += from_frames(dz, B, Cc, H, T)
     dr, g["g1"], g["b1n"] = ln_bwd(r, dy, ln_mode, float(p.g1), eps)
     da = dr * (a > 0)
-    dxc, g["wc"], g["bc"] = O.conv_bwd(x, p.wc, da, 1, padl, padr)
+    if bf16:   # dx = conv^T(bf(da), bf(w)), dw = bf(x) (*) bf(da), db = sums of the unrounded da
+        dxc, g["wc"], _ = O.conv_bwd(bf16_round(x), bf16_round(p.wc), bf16_round(da), 1, padl, padr)
+        g["bc"] = np.asarray(da, np.float64).sum(axis=(0, 2, 3)).astype(np.float32)
+    else:
+        dxc, g["wc"], g["bc"] = O.conv_bwd(x, p.wc, da, 1, padl, padr)
     return dr + dxc, g
 
 

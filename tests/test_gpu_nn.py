@@ -841,3 +841,52 @@ def test_gemm_bf16_operand_storage_epilogues(oracle):
     y0 = ops.gemm_bf16(Ab, Bb, K, bias=bias, relu=True)
     ops.dropout_(y0, p, seed, sid)
     assert torch.equal(y, y0)
+
+
+@pytest.mark.parametrize("B,C,H,T,kw,padl,padr", [(2, 15, 80, 187, 9, 7, 1), (3, 19, 80, 70, 9, 7, 1), (2, 23, 80, 93, 11, 9, 1),
+                                                  (2, 27, 80, 187, 11, 10, 0), (1, 27, 16, 5, 11, 10, 0), (2, 10, 80, 130, 21, 10, 10),
+                                                  (1, 18, 80, 66, 21, 10, 10), (2, 14, 32, 64, 21, 10, 10)])
+def test_tds_conv_bf16_three_passes(oracle, B, C, H, T, kw, padl, padr):
+    """the TDS convolution of the mixed-precision mode (conv_tds_bf16.hip) at the streaming recipe's channel counts /
+    kernel widths / asymmetric paddings (and the sota/2019 TDS-CTC ones): forward (+ bias, ReLU), backward-data (+ addend)
+    and backward-filter against the oracle on the SAME bf16-rounded operands -- only the fp32 accumulation differs (2e-5 of the
+    largest magnitude) -- plus the stated 1e-2 against the unrounded convolution and run-to-run determinism"""
+    from oracle import refnet
+    from wav2letter_amd import ops
+    rng = np.random.default_rng(C * 100 + T)
+    x = rng.normal(size=(B, C, H, T)).astype(np.float32)
+    w = (rng.normal(size=(C, C, kw)) / np.sqrt(C * kw)).astype(np.float32)
+    b = rng.normal(size=C).astype(np.float32)
+    xr, wr = refnet.bf16_round(x), refnet.bf16_round(w)
+    y_ref = oracle.conv_fwd(xr, wr, b, 1, padl, padr)
+    xd, wd = dev(to_fm(x)), dev(w_to_dev(w))
+    out = ops.tds_conv_bf16(xd, wd, dev(b), padl, padr)
+    assert out is not None, "geometry of the recipes must have a bf16 kernel"
+    y, imgs, d = out
+    assert rel(from_fm(y.cpu().numpy()), y_ref) < 2e-5
+    assert rel(from_fm(y.cpu().numpy()), oracle.conv_fwd(x, w, b, 1, padl, padr)) < BF16_TOL
+    yr, _, _ = ops.tds_conv_bf16(xd, wd, dev(b), padl, padr, relu=True)
+    assert rel(from_fm(yr.cpu().numpy()), np.maximum(y_ref, 0)) < 2e-5
+    dy = rng.normal(size=y_ref.shape).astype(np.float32)
+    add = rng.normal(size=x.shape).astype(np.float32)
+    odx, _, _ = oracle.conv_bwd(xr, wr, refnet.bf16_round(dy), 1, padl, padr)
+    _, odw, _ = oracle.conv_bwd(xr, wr, refnet.bf16_round(dy), 1, padl, padr)
+    dyd, addd = dev(to_fm(dy)), dev(to_fm(add))
+    dx, dw = ops.tds_conv_bf16_backward(xd, dyd, imgs, d, add=addd)
+    assert rel(from_fm(dx.cpu().numpy()), odx + add) < 2e-5
+    assert rel(dw.cpu().numpy(), w_to_dev(odw)) < 5e-5
+    dx2, dw2 = ops.tds_conv_bf16_backward(xd, dyd, imgs, d, add=addd)
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2)
+    dx0, _ = ops.tds_conv_bf16_backward(xd, dyd, imgs, d)
+    assert rel(from_fm(dx0.cpu().numpy()), odx) < 2e-5
+
+
+def test_tds_conv_bf16_refuses_other_geometries():
+    import ctypes as C
+    from wav2letter_amd import _lib, ops
+    x = torch.zeros(1, 20, 80, 40, device="cuda")
+    assert ops.tds_conv_bf16(x, torch.zeros(9, 40, 40, device="cuda"), None, 4, 4) is None          # C > 32
+    x = torch.zeros(1, 20, 80, 15, device="cuda")
+    assert ops.tds_conv_bf16(x, torch.zeros(7, 15, 15, device="cuda"), None, 3, 3) is None          # kw outside the instantiated set
+    d = ops.conv_desc(x, torch.zeros(9, 15, 15, device="cuda"), 2, 4, 4)
+    assert _lib.lib().w2l_tds_conv_bf16_image_elems(C.byref(d)) == 0                               # strided

@@ -13,9 +13,10 @@
 //                  reduced to lse[b][t]; the <= 2L+1 label log-probs the lattice
 //                  needs are gathered from the register-resident row's source.
 //   ctc_scan       two wavefronts per utterance, side by side: the alpha scan and
-//                  the beta scan over the 2L+1 extended labels (positions blocked
-//                  over lanes, fp64 carries with fp32 log-sum-exp corrections);
-//                  the alpha wave also writes the loss.
+//                  the beta scan over the 2L+1 extended labels in the scaled
+//                  linear domain (fp64 mantissas, one power-of-two exponent per
+//                  lane: no exp / log on the dependency chain); the alpha wave
+//                  also writes the loss.
 //   ctc_rows_grad  one workgroup per row: grad = g*(softmax(x) - occupancy):
 //                  streams x once more, writes grad once, then subtracts the
 //                  <= 2L+1 occupancies gamma[t][s] = exp(alpha+beta-lp-logZ) of
@@ -32,21 +33,36 @@ struct CtcWs {
   float* lse;     // [B][T]
   float* lp;      // [B][T][S]   label log-probs
   double* alpha;  // [B][T][S]
-  double* beta;   // [B][T][S]   (beta includes lp[t][s], as alpha does)
+  double* beta;   // [B][T][S]   (beta includes p_t(s), as alpha does)
+  int* eA;        // [B][T][64]  lane exponents of the alpha mantissas
+  int* eB;        // [B][T][64]
+  double* zhat;   // [B]  Z = zhat * 2^ez
+  int* ez;        // [B]
   float* scale;   // [B]
   float* nll;     // [B]  (-log likelihood, unscaled)
   int S;          // 2L+1 for the padded L
+  int P;          // lattice positions per lane of the scans
 };
+
+__host__ __device__ inline int ctc_positions_per_lane(int L) {
+  const int S = 2 * L + 1;
+  return S <= 128 ? 2 : S <= 256 ? 4 : S <= 512 ? 8 : S <= 1024 ? 16 : 32;
+}
 
 __host__ __device__ inline CtcWs ctc_ws(void* ws, int B, int T, int N, int L) {
   (void)N;
   CtcWs w;
   w.S = 2 * L + 1;
+  w.P = ctc_positions_per_lane(L);
   char* p = (char*)ws;
   w.lse = (float*)p; p += align_up((size_t)B * T * sizeof(float), 256);
   w.lp = (float*)p; p += align_up((size_t)B * T * w.S * sizeof(float), 256);
   w.alpha = (double*)p; p += align_up((size_t)B * T * w.S * sizeof(double), 256);
   w.beta = (double*)p; p += align_up((size_t)B * T * w.S * sizeof(double), 256);
+  w.eA = (int*)p; p += align_up((size_t)B * T * 64 * sizeof(int), 256);
+  w.eB = (int*)p; p += align_up((size_t)B * T * 64 * sizeof(int), 256);
+  w.zhat = (double*)p; p += align_up((size_t)B * sizeof(double), 256);
+  w.ez = (int*)p; p += align_up((size_t)B * sizeof(int), 256);
   w.scale = (float*)p; p += align_up((size_t)B * sizeof(float), 256);
   w.nll = (float*)p;
   return w;
@@ -167,30 +183,32 @@ __global__ __launch_bounds__(kRowThreads) void ctc_rows_lse_big(int T, int N, in
   }
 }
 
-// log-sum-exp of three fp64 lattice values with fp32 corrections.  The correction terms use the FULL-precision fp32 expf /
-// logf (ocml, < 1 ulp, unbiased), not the 1-ulp hardware v_exp_f32 / v_log_f32 the ASG scans use: the hardware functions
-// round faithfully, not to nearest, and their ~1e-7 per-step bias adds up LINEARLY over a long scan -- at T = 700 frames and
-// 300 labels the occupancies were off by 1e-4 (run j1).  The two scans of an utterance now run side by side with a deep
-// prefetch, so the few extra instructions per step are affordable.
-__device__ __forceinline__ double lse3(double a, double b, double c) {
-  double m = fmax(a, fmax(b, c));
-  if (m == -INFINITY) return m;
-  float s = expf((float)(a - m)) + expf((float)(b - m)) + expf((float)(c - m));
-  return m + (double)logf(s);   // s in [1, 3]
-}
+// ---- alpha / beta lattice scans in the SCALED LINEAR domain -----------------------------------------------------------
+// alpha_t(s) = (alpha_{t-1}(s) + alpha_{t-1}(s-1) + [skip] alpha_{t-1}(s-2)) * p_t(s) in fp64, every LANE carrying its own
+// power-of-two exponent for the P consecutive lattice positions it owns (value = mantissa * 2^e, renormalised every step to
+// a lane maximum in [1, 2)).  Against the log-domain recursion this
+//   * takes the transcendentals OFF the dependency chain: p_t(s) = exp(lp) is one hardware v_exp_f32 per element in the
+//     prefetch stage; a step is adds, one multiply and v_ldexp_f64 -- no exp / log per position and step;
+//   * removes the accumulated rounding of T dependent fp32 log-sum-exp corrections (round 3, run j1 / j3: 1e-4 .. 2e-4 of
+//     the gradient at 700 .. 1100 frames; the hardware exp / log round faithfully, not to nearest, so their error adds up
+//     linearly): sums and products are fp64, the only fp32 quantities are lp and exp(lp), each used once per path factor;
+//   * keeps the log domain's dynamic range where it matters: positions interact with their two lower (alpha) / upper
+//     (beta) neighbours only, and a neighbour lane's values are brought to this lane's exponent with v_ldexp_f64 -- a
+//     contribution 2^-1074 below the receiving lane's own scale is lost, nothing else (a single per-utterance scale would
+//     flush an improbable-so-far prefix that the rest of the utterance makes the only feasible path).
+// One wavefront per (utterance, direction): blockIdx.y = 0 alpha, 1 beta; lane l owns positions l P .. l P + P - 1.
+// Stored: the mantissas alpha^[t][s], beta^[t][s] (fp64) and the lane exponents eA[t][lane], eB[t][lane]; both scans
+// include p_t(s), so the occupancy is gamma_t(s) = alpha^ beta^ / (p z^) * 2^(eA + eB - ez), taken in ctc_rows_grad.
+__device__ __forceinline__ int dpp_up_i32(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int dpp_down_i32(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }
+constexpr int kCtcNoExp = -(1 << 28);   // exponent of a lane that holds no mass yet
 
-// alpha OR beta over the extended label sequence (blockIdx.y = 0: alpha, 1: beta): one wavefront per (utterance,
-// direction), positions blocked over lanes (P per lane).  The two scans of an utterance are independent, so they run
-// as two waves side by side (they used to be one wave doing alpha, then beta + occupancies: 364 us at T' = 188,
-// 1.9 us per frame, memory-latency bound on a 4-step prefetch that every store of the scan drained).  Each scan now
-// reads ONE array (the label log-probs lp[t][s]) through a register double buffer D steps deep (2 D P floats = 128
-// registers whatever P is) and writes its lattice row (fp64) fire-and-forget; the occupancies
-// gamma[t][s] = exp(alpha + beta - lp - logZ) have no dependence between frames and are taken in ctc_rows_grad.
 template <int P, int D>
 __global__ __launch_bounds__(64) void ctc_scan(int T, int N, int L, int scaleMode,
                                                const int* __restrict__ target,
                                                const int* __restrict__ targetSize,
                                                float* __restrict__ loss, CtcWs ws) {
+  static_assert(P >= 2, "a lane's two lower / upper neighbours must live in ONE neighbouring lane");
   const int b = blockIdx.x;
   const bool isBeta = blockIdx.y == 1;
   const int lane = threadIdx.x;
@@ -199,154 +217,152 @@ __global__ __launch_bounds__(64) void ctc_scan(int T, int N, int L, int scaleMod
   const int SW = ws.S;
   const int* y = target + (size_t)b * L;
   const float* lp = ws.lp + (size_t)b * T * SW;
-  const double NEG = -INFINITY;
+  double* lat = (isBeta ? ws.beta : ws.alpha) + (size_t)b * T * SW;
+  int* lex = (isBeta ? ws.eB : ws.eA) + (size_t)b * T * 64;
 
-  if (!isBeta) {
-    double* al = ws.alpha + (size_t)b * T * SW;
-    bool skipPrev[P];  // may come from s-2
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int si = lane * P + p;
-      const int e0 = (si & 1) ? ((si >> 1) < Lb ? y[si >> 1] : -1) : (N - 1);
-      const int em2 = (si >= 2 && (si & 1) && ((si - 2) >> 1) < Lb) ? y[(si - 2) >> 1] : -2;
-      skipPrev[p] = (si < S) && (si & 1) && si >= 2 && e0 != em2;
-    }
-    double a[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int si = lane * P + p;
-      a[p] = (si < S && si < 2) ? (double)lp[si] : NEG;
-      if (si < S) al[si] = a[p];
-    }
-    float lc[D][P], ln[D][P];
-#pragma unroll
-    for (int u = 0; u < D; ++u)
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        const int si = lane * P + p, t = 1 + u;
-        lc[u][p] = (t < T && si < S) ? lp[(size_t)t * SW + si] : 0.f;
-      }
-    for (int t0 = 1; t0 < T; t0 += D) {
-#pragma unroll
-      for (int u = 0; u < D; ++u)
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-          const int si = lane * P + p, t = t0 + D + u;
-          ln[u][p] = (t < T && si < S) ? lp[(size_t)t * SW + si] : 0.f;
-        }
-#pragma unroll
-      for (int u = 0; u < D; ++u) {
-        const int t = t0 + u;
-        if (t < T) {
-          const double c1 = lane_shift_up_dpp(a[P - 1], NEG);                                    // alpha[lane*P - 1]
-          const double c2 = P >= 2 ? lane_shift_up_dpp(a[P >= 2 ? P - 2 : 0], NEG) : lane_shift_up_dpp(c1, NEG);  // alpha[lane*P - 2]
-          double pm1 = c1, pm2 = c2;
-          double* alt = al + (size_t)t * SW;
-#pragma unroll
-          for (int p = 0; p < P; ++p) {
-            const int si = lane * P + p;
-            const double cur = a[p];
-            const double v = lse3(cur, pm1, skipPrev[p] ? pm2 : NEG);
-            double na = NEG;
-            if (si < S && v != NEG) na = v + (double)lc[u][p];
-            if (si < S) alt[si] = na;
-            pm2 = pm1;
-            pm1 = cur;
-            a[p] = na;
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < D; ++u)
-#pragma unroll
-        for (int p = 0; p < P; ++p) lc[u][p] = ln[u][p];
-    }
-    // log-likelihood = lse(alpha[T-1][S-1], alpha[T-1][S-2])
-    double v1 = NEG, v2 = NEG;
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int si = lane * P + p;
-      if (si == S - 1) v1 = a[p];
-      if (si == S - 2) v2 = a[p];
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      v1 = fmax(v1, __shfl_xor(v1, off));
-      v2 = fmax(v2, __shfl_xor(v2, off));
-    }
-    const double ll = lse3(v1, v2, NEG);
-    if (lane == 0) {
-      const float sc = scale_of(scaleMode, T, Lb);
-      loss[b] = (float)(-(double)sc * ll);
-      ws.scale[b] = sc;
-      ws.nll[b] = (float)(-ll);
-    }
-    return;
-  }
-
-  // ---- beta[t][s] (includes lp[t][s], like alpha): beta[T-1][s] = lp[T-1][s] for s >= S-2,
-  //      beta[t-1][s] = lse(beta[t][s], beta[t][s+1], beta[t][s+2] if allowed) + lp[t-1][s]
-  double* bt = ws.beta + (size_t)b * T * SW;
-  bool skipNext[P];  // may go to s+2
+  bool skip[P];   // alpha: position s may be entered from s - 2; beta: position s may go to s + 2
 #pragma unroll
   for (int p = 0; p < P; ++p) {
     const int si = lane * P + p;
     const int e0 = (si & 1) ? ((si >> 1) < Lb ? y[si >> 1] : -1) : (N - 1);
-    const int ep2 = ((si & 1) && si + 2 < S) ? y[(si + 2) >> 1] : -2;
-    skipNext[p] = (si < S) && (si & 1) && si + 2 < S && e0 != ep2;
+    if (!isBeta) {
+      const int em2 = (si >= 2 && (si & 1) && ((si - 2) >> 1) < Lb) ? y[(si - 2) >> 1] : -2;
+      skip[p] = (si < S) && (si & 1) && si >= 2 && e0 != em2;
+    } else {
+      const int ep2 = ((si & 1) && si + 2 < S) ? y[(si + 2) >> 1] : -2;
+      skip[p] = (si < S) && (si & 1) && si + 2 < S && e0 != ep2;
+    }
   }
-  double be[P];
+  // frame order of this scan: alpha walks t = 0 .. T-1, beta t = T-1 .. 0
+  auto frame = [&](int k) { return isBeta ? T - 1 - k : k; };
+  auto prob = [&](int k, int si) -> float { return (k < T && si < S) ? __expf(lp[(size_t)frame(k) * SW + si]) : 0.f; };
+
+  // ---- first frame: alpha_0(s) = p_0(s) for s < 2; beta_{T-1}(s) = p_{T-1}(s) for s >= S - 2
+  double a[P];
+  int ex = kCtcNoExp;
   {
-    const float* lpt = lp + (size_t)(T - 1) * SW;
-    double* btt = bt + (size_t)(T - 1) * SW;
+    double m = 0.0;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int si = lane * P + p;
-      be[p] = (si < S && si >= S - 2) ? (double)lpt[si] : NEG;
-      if (si < S) btt[si] = be[p];
+      const bool on = si < S && (isBeta ? si >= S - 2 : si < 2);
+      a[p] = on ? (double)prob(0, si) : 0.0;
+      m = fmax(m, a[p]);
     }
+    if (m > 0.0) {
+      const int e = __builtin_amdgcn_frexp_exp(m) - 1;
+      ex = e;
+#pragma unroll
+      for (int p = 0; p < P; ++p) a[p] = ldexp(a[p], -e);
+    }
+    double* row = lat + (size_t)frame(0) * SW;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int si = lane * P + p;
+      if (si < S) row[si] = a[p];
+    }
+    lex[(size_t)frame(0) * 64 + lane] = ex;
   }
-  float lc[D][P], ln[D][P];  // lc[u] = lp[thi - 1 - u]
+
+  float pc[D][P], pn[D][P];   // p of steps k0 .. k0 + D - 1 (current chunk) and of the next chunk
 #pragma unroll
   for (int u = 0; u < D; ++u)
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int si = lane * P + p, t = T - 2 - u;
-      lc[u][p] = (t >= 0 && si < S) ? lp[(size_t)t * SW + si] : 0.f;
-    }
-  for (int thi = T - 1; thi >= 1; thi -= D) {
+    for (int p = 0; p < P; ++p) pc[u][p] = prob(1 + u, lane * P + p);
+  for (int k0 = 1; k0 < T; k0 += D) {
 #pragma unroll
     for (int u = 0; u < D; ++u)
 #pragma unroll
-      for (int p = 0; p < P; ++p) {
-        const int si = lane * P + p, t = thi - 1 - D - u;
-        ln[u][p] = (t >= 0 && si < S) ? lp[(size_t)t * SW + si] : 0.f;
-      }
+      for (int p = 0; p < P; ++p) pn[u][p] = prob(k0 + D + u, lane * P + p);
 #pragma unroll
     for (int u = 0; u < D; ++u) {
-      const int t = thi - u;  // beta_t -> beta_{t-1}
-      if (t >= 1) {
-        const double n1 = lane_shift_down_dpp(be[0], NEG);                                        // beta[(lane+1)*P]
-        const double n2 = P >= 2 ? lane_shift_down_dpp(be[P >= 2 ? 1 : 0], NEG) : lane_shift_down_dpp(n1, NEG);  // beta[(lane+1)*P + 1]
-        double nb[P];
-        double* btt = bt + (size_t)(t - 1) * SW;
-#pragma unroll
-        for (int p = P - 1; p >= 0; --p) {
-          const int si = lane * P + p;
-          const double b1 = (p + 1 < P) ? be[p + 1 < P ? p + 1 : 0] : n1;
-          const double b2 = (p + 2 < P) ? be[p + 2 < P ? p + 2 : 0] : ((p + 1 < P) ? n1 : n2);
-          const double v = lse3(be[p], b1, skipNext[p] ? b2 : NEG);
-          nb[p] = (si < S && v != NEG) ? v + (double)lc[u][p] : NEG;
-          if (si < S) btt[si] = nb[p];
+      const int k = k0 + u;
+      if (k < T) {
+        // the neighbour lane's two boundary values and its exponent (alpha: lane - 1's last two; beta: lane + 1's first two)
+        double n1, n2;
+        int exn;
+        if (!isBeta) {
+          n1 = lane_shift_up_dpp(a[P - 1], 0.0);
+          n2 = lane_shift_up_dpp(a[P - 2], 0.0);
+          exn = dpp_up_i32(ex, kCtcNoExp);
+        } else {
+          n1 = lane_shift_down_dpp(a[0], 0.0);
+          n2 = lane_shift_down_dpp(a[1], 0.0);
+          exn = dpp_down_i32(ex, kCtcNoExp);
         }
+        const bool nbOn = (n1 != 0.0 || n2 != 0.0) && exn != kCtcNoExp;
+        const int eb = ex > (nbOn ? exn : kCtcNoExp) ? ex : exn;   // common exponent of this step (kCtcNoExp: nothing anywhere)
+        double na[P];
+        double m = 0.0;
+        if (eb != kCtcNoExp) {
+          const int dOwn = ex == kCtcNoExp ? 0 : ex - eb, dNb = nbOn ? exn - eb : 0;
+          double o[P];
 #pragma unroll
-        for (int p = 0; p < P; ++p) be[p] = nb[p];
+          for (int p = 0; p < P; ++p) o[p] = ldexp(a[p], dOwn);
+          n1 = nbOn ? ldexp(n1, dNb) : 0.0;
+          n2 = nbOn ? ldexp(n2, dNb) : 0.0;
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            double v1, v2;   // the position one / two steps towards the neighbour lane
+            if (!isBeta) {
+              v1 = p >= 1 ? o[p >= 1 ? p - 1 : 0] : n1;
+              v2 = p >= 2 ? o[p >= 2 ? p - 2 : 0] : (p == 1 ? n1 : n2);
+            } else {
+              v1 = p + 1 < P ? o[p + 1 < P ? p + 1 : 0] : n1;
+              v2 = p + 2 < P ? o[p + 2 < P ? p + 2 : 0] : (p + 1 < P ? n1 : n2);
+            }
+            const double sum = (o[p] + v1) + (skip[p] ? v2 : 0.0);
+            na[p] = sum * (double)pc[u][p];     // p = 0 beyond S: stays zero
+            m = fmax(m, na[p]);
+          }
+        }
+        if (m > 0.0) {
+          const int e = __builtin_amdgcn_frexp_exp(m) - 1;
+#pragma unroll
+          for (int p = 0; p < P; ++p) a[p] = ldexp(na[p], -e);
+          ex = eb + e;
+        } else {
+#pragma unroll
+          for (int p = 0; p < P; ++p) a[p] = 0.0;
+          ex = kCtcNoExp;
+        }
+        double* row = lat + (size_t)frame(k) * SW;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const int si = lane * P + p;
+          if (si < S) row[si] = a[p];
+        }
+        lex[(size_t)frame(k) * 64 + lane] = ex;
       }
     }
 #pragma unroll
     for (int u = 0; u < D; ++u)
 #pragma unroll
-      for (int p = 0; p < P; ++p) lc[u][p] = ln[u][p];
+      for (int p = 0; p < P; ++p) pc[u][p] = pn[u][p];
+  }
+  if (isBeta) return;
+
+  // ---- likelihood Z = alpha_{T-1}(S-1) + alpha_{T-1}(S-2) = zhat * 2^ez (the two positions may sit in two lanes)
+  double z = 0.0;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int si = lane * P + p;
+    if (si == S - 1 || si == S - 2) z += a[p];
+  }
+  int ez = z > 0.0 ? ex : kCtcNoExp;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(ez, off); ez = o > ez ? o : ez; }
+  double zs = (z > 0.0 && ez != kCtcNoExp) ? ldexp(z, ex - ez) : 0.0;
+  zs = wave_sum_f64(zs);
+  if (lane == 0) {
+    const float sc = scale_of(scaleMode, T, Lb);
+    double ll = -INFINITY;
+    if (zs > 0.0) ll = log(zs) + (double)ez * 0.69314718055994530942;
+    loss[b] = (float)(-(double)sc * ll);
+    ws.scale[b] = sc;
+    ws.nll[b] = (float)(-ll);
+    ws.zhat[b] = zs;
+    ws.ez[b] = ez;
   }
 }
 
@@ -387,18 +403,22 @@ __global__ __launch_bounds__(kRowThreads) void ctc_rows_grad(int T, int N, int L
   const int Lb = targetSize[b];
   const int S = 2 * Lb + 1;
   const int* y = target + (size_t)b * L;
-  // occupancy of label position s at this frame: exp(alpha + beta - lp - logZ) (alpha and beta both carry lp[t][s])
+  // occupancy of label position s at this frame: alpha beta / (p Z) = alpha^ beta^ / (p zhat) * 2^(eA + eB - ez)
+  // (alpha and beta both carry p_t(s); p is the SAME v_exp_f32 of the same lp the scans multiplied by)
   const float* lpr = ws.lp + r * ws.S;
   const double* alr = ws.alpha + r * ws.S;
   const double* ber = ws.beta + r * ws.S;
-  const float nll = ws.nll[b];
-  if (nll != INFINITY) {   // an infeasible target (logZ = -inf) has no occupancy: its loss is +inf, its gradient g * softmax
-    const double ll = -(double)nll;
+  const int* ear = ws.eA + r * 64;
+  const int* ebr = ws.eB + r * 64;
+  const double zh = ws.zhat[b];
+  if (zh > 0.0) {   // an infeasible target (Z = 0) has no occupancy: its loss is +inf, its gradient g * softmax
+    const int ez = ws.ez[b], P = ws.P;
     for (int si = tid; si < S; si += kRowThreads) {
       const int lab = (si & 1) ? y[si >> 1] : (N - 1);
       const double av = alr[si], bv = ber[si];
-      if (av != -INFINITY && bv != -INFINITY) {
-        const float v = __expf((float)(av + bv - (double)lpr[si] - ll));
+      if (av > 0.0 && bv > 0.0) {
+        const double pv = (double)__expf(lpr[si]);
+        const float v = (float)ldexp(av * bv / (pv * zh), ear[si / P] + ebr[si / P] - ez);
         if (v != 0.f) atomicAdd(&out[lab], -g * v);
       }
     }
@@ -484,7 +504,8 @@ W2L_API size_t w2l_ctc_workspace_size(int B, int T, int N, int L) {
   if (B <= 0 || T <= 0 || N <= 0 || L < 0) return 0;
   size_t S = 2 * (size_t)L + 1;
   return align_up((size_t)B * T * sizeof(float), 256) + align_up((size_t)B * T * S * sizeof(float), 256) +
-         2 * align_up((size_t)B * T * S * sizeof(double), 256) + 2 * align_up((size_t)B * sizeof(float), 256);
+         2 * align_up((size_t)B * T * S * sizeof(double), 256) + 2 * align_up((size_t)B * T * 64 * sizeof(int), 256) +
+         align_up((size_t)B * sizeof(double), 256) + align_up((size_t)B * sizeof(int), 256) + 2 * align_up((size_t)B * sizeof(float), 256);
 }
 
 W2L_API int w2l_ctc_forward(int B, int T, int N, int L, int scaleMode, const float* input,
@@ -503,12 +524,13 @@ W2L_API int w2l_ctc_forward(int B, int T, int N, int L, int scaleMode, const flo
   W2L_LAUNCH_CHECK();
   const int S = 2 * L + 1;
   const dim3 grid((unsigned)B, 2), blk(64);   // (utterance, alpha | beta)
-  if (S <= 64) hipLaunchKernelGGL((ctc_scan<1, 32>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws);
-  else if (S <= 128) hipLaunchKernelGGL((ctc_scan<2, 32>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws);
-  else if (S <= 256) hipLaunchKernelGGL((ctc_scan<4, 16>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws);
-  else if (S <= 512) hipLaunchKernelGGL((ctc_scan<8, 8>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws);
-  else if (S <= 1024) hipLaunchKernelGGL((ctc_scan<16, 4>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws);
-  else hipLaunchKernelGGL((ctc_scan<32, 2>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws);
+  switch (ws.P) {   // (positions per lane, prefetch depth): 2 D P floats of p_t(s) in registers
+    case 2: hipLaunchKernelGGL((ctc_scan<2, 32>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws); break;
+    case 4: hipLaunchKernelGGL((ctc_scan<4, 16>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws); break;
+    case 8: hipLaunchKernelGGL((ctc_scan<8, 8>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws); break;
+    case 16: hipLaunchKernelGGL((ctc_scan<16, 4>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws); break;
+    default: hipLaunchKernelGGL((ctc_scan<32, 2>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws); break;
+  }
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }

@@ -608,6 +608,7 @@ class TDSLayer : public Layer {
   const float* xSaved = nullptr;
   BfLinear bl1, bl2;                    // mixed precision: lin1 (l -> l2), lin2 (l2 -> l)
   BfImage y1Img, uImg, dvImg, duImg;    // images of the two Linear inputs and of the two output gradients
+  size_t convImgElems = 0, convImgFOff = 0, convImgBOff = 0;   // bf16 weight images of the convolution (0: fp32 kernels only)
 
   std::string name() const override { return "TDSBlock"; }
   void registerParams(std::vector<ParamInfo>& t) override {
@@ -644,6 +645,8 @@ class TDSLayer : public Layer {
     daOff = pl.alloc(n); dxOff = pl.alloc(n);
     bl1.plan(pl, M, l, l2); bl2.plan(pl, M, l2, l);
     y1Img.plan(pl, M, l); uImg.plan(pl, M, l2); dvImg.plan(pl, M, l); duImg.plan(pl, M, l2);
+    convImgElems = h % 16 == 0 ? w2l_tds_conv_bf16_image_elems(&d) : 0;
+    if (convImgElems) { convImgFOff = pl.allocBf16(convImgElems); convImgBOff = pl.allocBf16(convImgElems); }
     return in;
   }
   void forward(Ctx& cx, float* ar, const float* x, float*& y) override {
@@ -651,7 +654,12 @@ class TDSLayer : public Layer {
     const double pd = cx.train ? p : 0.0;
     xSaved = x;
     float *a = ar + aOff, *r1 = ar + r1Off, *y1 = ar + y1Off, *u = ar + uOff, *v = ar + vOff, *out = ar + outOff;
-    w2lCheck(w2l_conv_forward(&d, x, wc.w(cx), bc.w(cx), a, 1, s), "tds conv");
+    if (cx.bf16 && convImgElems) {   // bf16 operands, fp32 accumulation / bias / ReLU (conv_tds_bf16.hip); images once per step
+      w2lCheck(w2l_tds_conv_bf16_prepare(&d, wc.w(cx), bfp(ar, convImgFOff), bfp(ar, convImgBOff), s), "tds conv images");
+      w2lCheck(w2l_tds_conv_bf16_forward(&d, x, bfp(ar, convImgFOff), bc.w(cx), a, 1, s), "tds conv bf16");
+    } else {
+      w2lCheck(w2l_conv_forward(&d, x, wc.w(cx), bc.w(cx), a, 1, s), "tds conv");
+    }
     // a <- dropout(relu(conv)) in place (kept: its sign pattern is the ReLU+dropout mask); r1 = a + x; y1 = LN(r1)
     w2lCheck(w2l_residual_layernorm_forward(groups, inner, a, x, r1, y1, gb1.w(cx), 1e-5f, pd, cx.seed, rngStream,
                                             (double*)(ar + st1Off), ar + mr1Off, s), "tds ln1");
@@ -714,6 +722,15 @@ class TDSLayer : public Layer {
     // LN1 backward: dr1, and in the same pass da = dr1 masked by the ReLU+dropout pattern of a
     w2lCheck(w2l_layernorm_backward(groups, inner, ar + r1Off, dy1, gb1.w(cx), ar + mr1Off, dr1, gb1.g(cx), a, da, sc,
                                     (double*)(ar + st1Off), s), "tds ln1 bwd");
+    if (cx.bf16 && convImgElems) {
+      w2lCheck(w2l_tds_conv_bf16_backward_filter(&d, xSaved, da, wc.g(cx), s), "tds conv bwd filter bf16");
+      w2lCheck(w2l_colsum(da, bc.g(cx), (size_t)M * h, c, s), "tds conv bwd bias");
+      if (needDx) {
+        dx = ar + dxOff;
+        w2lCheck(w2l_tds_conv_bf16_backward_data(&d, da, bfp(ar, convImgBOff), dr1, dx, s), "tds conv bwd data bf16");
+      }
+      return;
+    }
     w2lCheck(w2l_conv_backward_filter(&d, xSaved, da, wc.g(cx), bc.g(cx), s), "tds conv bwd filter");
     if (needDx) {
       dx = ar + dxOff;

@@ -216,3 +216,28 @@ def gemm_bf16(A, B, K, bias=None, relu=False, mask=None, mask_scale=1.0, addend=
     _lib.check(_lib.lib().w2l_gemm_bf16(M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(c), c.stride(0),
                                         _p(bias) if bias is not None else None, int(relu), C.byref(e), _s()), "gemm_bf16")
     return c
+
+
+def tds_conv_bf16(x, w, bias, padl, padr, relu=False):
+    """the TDS convolution on bf16-rounded operands (w2l_tds_conv_bf16_*): x [B][T][H][C], w [kw][C][C] -> y; None when the
+    geometry has no bf16 kernel"""
+    import ctypes as C
+    d = conv_desc(x, w, 1, padl, padr)
+    n = _lib.lib().w2l_tds_conv_bf16_image_elems(C.byref(d))
+    if not n:
+        return None
+    imgs = torch.empty(2, n, dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().w2l_tds_conv_bf16_prepare(C.byref(d), _p(w), _p(imgs[0]), _p(imgs[1]), _s()), "tds_conv_bf16_prepare")
+    y = torch.empty_like(x)
+    check(_lib.lib().w2l_tds_conv_bf16_forward(C.byref(d), _p(x), _p(imgs[0]), _p(bias), _p(y), int(relu), _s()), "tds_conv_bf16_forward")
+    return y, imgs, d
+
+
+def tds_conv_bf16_backward(x, dy, imgs, d, add=None):
+    """(dx, dw) of the same convolution: dx = add + conv^T(dy), dw = x (*) dy, both on bf16-rounded operands"""
+    import ctypes as C
+    dx = torch.empty_like(x)
+    check(_lib.lib().w2l_tds_conv_bf16_backward_data(C.byref(d), _p(dy), _p(imgs[1]), _p(add), _p(dx), _s()), "tds_conv_bf16_backward_data")
+    dw = torch.empty(d.kw, d.Cin, d.Cout, dtype=torch.float32, device=x.device)
+    check(_lib.lib().w2l_tds_conv_bf16_backward_filter(C.byref(d), _p(x), _p(dy), _p(dw), _s()), "tds_conv_bf16_backward_filter")
+    return dx, dw
