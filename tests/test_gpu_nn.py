@@ -256,7 +256,8 @@ def test_gemm_asymmetric_identity():
     assert (got.cpu().numpy() == Bm).all()
 
 
-@pytest.mark.parametrize("M,N", [(1, 5), (63, 1), (513, 37), (777, 9998), (6016, 1440), (24000, 800), (100000, 6), (70, 2402)])
+@pytest.mark.parametrize("M,N", [(1, 5), (63, 1), (513, 37), (777, 9998), (6016, 1440), (24000, 800), (100000, 6), (70, 2402),
+                                 (957440, 27), (153600, 15), (4100, 19), (40960, 23), (8192, 63)])
 def test_colsum_bias_gradient(M, N):
     """bias gradient column sums (fl::Linear / Conv2D backward): fp64 sum within 1e-4 relative, run-to-run bit-identical,
     float4 / float2 / scalar column paths and the unaligned-base case"""

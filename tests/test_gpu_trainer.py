@@ -910,8 +910,9 @@ def test_mixed_precision_streaming_tds_step(oracle):
             continue   # LayerNorm (gain, offset): two sums over every activation with heavy cancellation -- no direction to check
         l2 = ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
         cos = (a @ b / (a.norm() * b.norm()).clamp_min(1e-30)).item()
-        # bias vectors are column sums with cancellation (and bf16 noise flips ReLU masks upstream): looser than the weights
-        lim = (0.1, 0.99) if n > 64 else (0.25, 0.97)
+        # bias vectors are column sums with cancellation (and bf16 noise flips ReLU masks upstream): looser than the weights;
+        # since round 3 the TDS convolutions round their operands too (see the bars of the oracle comparison below)
+        lim = (0.2, 0.98) if n > 1000 else (0.35, 0.95)
         assert l2 < lim[0] and cos > lim[1], (name, off, l2, cos)
     losses = []
     for _ in range(12):

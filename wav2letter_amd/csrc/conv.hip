@@ -272,11 +272,38 @@ __global__ __launch_bounds__(256) void colsum_finish_k(const float* __restrict__
   if (wave == 0 && n < N) out[n] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
 }
 
+// out[n] = sum_g tmp[g N + n], g ascending
+__global__ __launch_bounds__(64) void colsum_fold_k(const float* __restrict__ tmp, float* __restrict__ out, int G, int N) {
+  const int n = blockIdx.x * 64 + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int g = 0; g < G; ++g) s += tmp[(size_t)g * N + n];
+  out[n] = s;
+}
+
 int colsum(const float* x, float* out, size_t M, int N, hipStream_t s) {
   if (N <= 0) return W2L_OK;
   if (M == 0) {
     W2L_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s));
     return W2L_OK;
+  }
+  // NARROW matrices (the bias gradient of a TDS convolution: [B T H][C], C = 10 .. 27): a row is a fraction of one wave's
+  // 64 lanes and an odd C forbids vector loads (colsum_partial_k<1> on [957 k][27]: 304 us, 0.34 TB/s, run j4).  G
+  // consecutive rows are read as ONE row of G N floats (same bytes), summed by the wide kernels, and the G groups folded.
+  if (N < 64 && M >= 4096) {
+    int G = 0;
+    for (int g = 16; g >= 4; g >>= 1)
+      if (M % (size_t)g == 0 && (g * N) % 4 == 0) { G = g; break; }
+    if (G) {
+      float* scratch = sk_scratch(s, kSkScratchBytes);
+      if (!scratch) return W2L_EHIP;
+      float* tmp = scratch + (size_t)(1 << 20);          // behind the row-block partials of the inner call (<= 128 x 1008 floats)
+      const int st = colsum(x, tmp, M / (size_t)G, G * N, s);
+      if (st != W2L_OK) return st;
+      hipLaunchKernelGGL(colsum_fold_k, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s, tmp, out, G, N);
+      W2L_LAUNCH_CHECK();
+      return W2L_OK;
+    }
   }
   size_t rowsPerBlock = (M + kColsumMaxParts - 1) / kColsumMaxParts;
   if (rowsPerBlock < 64) rowsPerBlock = 64;

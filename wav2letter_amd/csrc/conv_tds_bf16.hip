@@ -82,24 +82,38 @@ __global__ __launch_bounds__(256) void tds_conv_bf_k(TdsBfP p) {
   }
   __syncthreads();
   {
+    // (the loads of a batch are issued back to back, THEN converted and stored: one exposed memory latency per batch of 8
+    // float4 instead of one per float4 -- the first build waited for every load before issuing the next: 150 - 350 us per call)
     const int runF4 = 2 * C;                     // float4 per frame: 8 mel rows x C floats (H * C % 4 == 0: host-checked)
     const float* xb = p.x + ((size_t)b * p.T * p.H + h0) * C;
     const size_t frameStride = (size_t)p.H * C;
     const int hValid = p.H - h0 < kTbHB ? p.H - h0 : kTbHB;
-    for (int q = tid; q < NF * runF4; q += 256) {
-      const int f = q / runF4, j = q - f * runF4;
-      const int tin = t0 - p.padl + f;
-      if (tin < 0 || tin >= p.T) continue;
-      const int e0 = 4 * j;
-      if (e0 >= hValid * C) continue;
-      const float4 v4 = *(const float4*)(xb + (size_t)tin * frameStride + e0);
-      const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    const int total = NF * runF4;
+    constexpr int NV = 8;
+    for (int base = 0; base < total; base += NV * 256) {
+      float4 v4[NV];
+      int fo[NV], eo[NV];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int e = e0 + u;
-        const int h = (int)(((uint64_t)e * p.cMagic) >> 32);
-        const int c = e - h * C;
-        if (h < hValid) *(uint16_t*)(slab + f * FS + (h * CP + c) * 2) = tb_bf16(v[u]);
+      for (int u = 0; u < NV; ++u) {
+        const int q = base + tid + 256 * u;
+        const int f = q / runF4, j = q - f * runF4;
+        const int tin = t0 - p.padl + f;
+        const bool ok = q < total && tin >= 0 && tin < p.T && 4 * j < hValid * C;
+        fo[u] = ok ? f : -1;
+        eo[u] = 4 * j;
+        v4[u] = ok ? *(const float4*)(xb + (size_t)tin * frameStride + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        if (fo[u] < 0) continue;
+        const float v[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int e = eo[u] + k;
+          const int h = (int)(((uint64_t)e * p.cMagic) >> 32);
+          const int c = e - h * C;
+          if (h < hValid) *(uint16_t*)(slab + fo[u] * FS + (h * CP + c) * 2) = tb_bf16(v[k]);
+        }
       }
     }
   }
@@ -223,18 +237,39 @@ __global__ __launch_bounds__(256) void tds_conv_bf_filter_k(TdsBfFilterP p) {
     const int t0 = tt * kTfTT, h0 = hb * kTfHB;
     __syncthreads();                             // the previous item's fragments have been read
     // ---- staging: frames of x (with the tap halo) and of dy, transposed to mel-fastest bf16; zeros outside the utterance
-    for (int f = wave; f < NFX + kTfTT; f += 4) {
-      const bool isX = f < NFX;
-      const int fl = isX ? f : f - NFX;
-      const int tin = isX ? t0 - p.padl + fl : t0 + fl;
-      const bool in = tin >= 0 && tin < p.T;
-      const float* src = (isX ? p.x : p.dy) + ((((size_t)b * p.T + (in ? tin : 0)) * p.H + h0 + 2 * hp) * C);
-      unsigned char* dst = (isX ? xs : ys) + fl * FSX + hp * 4;
-      for (int c = cl; c < C; c += 8) {
-        float v0 = 0.f, v1 = 0.f;
-        if (in) { v0 = src[c]; v1 = src[C + c]; }
-        const tb_f32x2_t pr = {v0, v1};
-        *(uint32_t*)(dst + c * kTfPitch) = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, tb_bf16x2_t));
+    // (two frames x up to four channel passes = 16 scalar loads in flight per lane before the first conversion)
+    for (int f0 = wave; f0 < NFX + kTfTT; f0 += 8) {
+      float v0[2][4], v1[2][4];
+#pragma unroll
+      for (int ff = 0; ff < 2; ++ff) {
+        const int f = f0 + 4 * ff;
+        const bool isX = f < NFX;
+        const int fl = isX ? f : f - NFX;
+        const int tin = isX ? t0 - p.padl + fl : t0 + fl;
+        const bool in = f < NFX + kTfTT && tin >= 0 && tin < p.T;
+        const float* src = (isX ? p.x : p.dy) + ((((size_t)b * p.T + (in ? tin : 0)) * p.H + h0 + 2 * hp) * C);
+#pragma unroll
+        for (int cp = 0; cp < 4; ++cp) {
+          const int c = cl + 8 * cp;
+          const bool ok = in && c < C;
+          v0[ff][cp] = ok ? src[c] : 0.f;
+          v1[ff][cp] = ok ? src[C + c] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int ff = 0; ff < 2; ++ff) {
+        const int f = f0 + 4 * ff;
+        if (f >= NFX + kTfTT) continue;
+        const bool isX = f < NFX;
+        const int fl = isX ? f : f - NFX;
+        unsigned char* dst = (isX ? xs : ys) + fl * FSX + hp * 4;
+#pragma unroll
+        for (int cp = 0; cp < 4; ++cp) {
+          const int c = cl + 8 * cp;
+          if (c >= C) continue;
+          const tb_f32x2_t pr = {v0[ff][cp], v1[ff][cp]};
+          *(uint32_t*)(dst + c * kTfPitch) = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, tb_bf16x2_t));
+        }
       }
     }
     __syncthreads();
@@ -265,16 +300,28 @@ __global__ __launch_bounds__(256) void tds_conv_bf_filter_k(TdsBfFilterP p) {
   }
 }
 
-// dw[tap][ci][co] = sum over the workgroups' partials, in workgroup order
+// dw[tap][ci][co] = sum over the workgroups' partials, always in the same order: 16 outputs x 16 worker lanes per
+// workgroup, a lane adds every 16th partial, the 16 lane sums are added in lane order (the first build walked all 512
+// partials in ONE thread per output: 135 us per call)
 __global__ __launch_bounds__(256) void tds_bf_filter_reduce_k(const float* __restrict__ partial, int workers, int rows32, int kw, int C, int CP,
                                                               float* __restrict__ dw) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= kw * C * C) return;
-  const int co = e % C, ci = (e / C) % C, tap = e / (C * C);
-  const size_t at = (size_t)(tap * CP + ci) * 32 + co;
+  __shared__ float sm[16][17];
+  const int o = threadIdx.x & 15, wl = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + o, n = kw * C * C;
   float s = 0.f;
-  for (int w = 0; w < workers; ++w) s += partial[(size_t)w * rows32 * 32 + at];
-  dw[e] = s;
+  if (e < n) {
+    const int co = e % C, ci = (e / C) % C, tap = e / (C * C);
+    const size_t at = (size_t)(tap * CP + ci) * 32 + co;
+    for (int w = wl; w < workers; w += 16) s += partial[(size_t)w * rows32 * 32 + at];
+  }
+  sm[wl][o] = s;
+  __syncthreads();
+  if (wl == 0 && e < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sm[k][o];
+    dw[e] = t;
+  }
 }
 
 template <int CP, int NSTEP>
@@ -296,7 +343,7 @@ static int tb_launch_filter(const TdsBfFilterP& p0, float* dw, hipStream_t s) {
   if (shmem > 96 * 1024) return W2L_EUNSUPPORTED;
   hipLaunchKernelGGL((tds_conv_bf_filter_k<CP, NSTEP>), dim3((unsigned)workers), dim3(256), shmem, s, p);
   const int n = p.kw * p.C * p.C;
-  hipLaunchKernelGGL(tds_bf_filter_reduce_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.partial, workers, NRT * 32, p.kw, p.C, CP, dw);
+  hipLaunchKernelGGL(tds_bf_filter_reduce_k, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, p.partial, workers, NRT * 32, p.kw, p.C, CP, dw);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }
