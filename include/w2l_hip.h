@@ -254,6 +254,9 @@ typedef struct {
   int accumulate;
 } w2l_bgemm_desc;
 int w2l_bgemm_f32(const w2l_bgemm_desc* d, const float* A, const float* B, float* C, w2l_stream_t stream);
+/* the same product with bf16 multiplies: fp32 operands rounded to nearest-even bf16 on the way into LDS, v_mfma_f32_32x32x16_bf16,
+ * fp32 accumulation and result (BASELINE config 5, "bf16 MFMA attention") */
+int w2l_bgemm_bf16(const w2l_bgemm_desc* d, const float* A, const float* B, float* C, w2l_stream_t stream);
 /* S[b][h][i][j] (in: q_i . k_j) -> P = softmax_j(scale * (S + R[(b*T + i)*H + h][j - i + n0 - rlo])) in place; R (may be
  * NULL: no position term) holds q_i . E[rlo + w] for w < W, row stride ldr; entries outside [0, W) count as 0
  * (relativePositionEmbeddingRotate pads with zeros).  keyLen (may be NULL): keys j >= keyLen[b] are padding and get

@@ -59,6 +59,39 @@ def test_batched_gemm_head_products(B, H, T, d):
     assert rel(dv.cpu().numpy(), want.cpu().numpy()) < TOL
 
 
+@pytest.mark.parametrize("B,H,T,d", [(2, 4, 47, 8), (3, 2, 64, 32), (1, 4, 188, 256), (2, 1, 5, 4), (2, 3, 130, 20)])
+def test_batched_gemm_bf16_operands(B, H, T, d):
+    """the mixed-precision attention products: operands rounded to bf16 on the way into LDS, fp32 accumulate and fp32 C.
+    Exact restatement = float64 product of the bf16-rounded operands; the accumulate orientation adds onto fp32 unrounded"""
+    from wav2letter_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(B * 77 + T)
+    Cc = H * d
+    q = torch.randn(B, T, Cc, generator=g).cuda()
+    k = torch.randn(B, T, Cc, generator=g).cuda()
+    P = torch.randn(B, H, T, T, generator=g).cuda()
+    r = lambda x: x.bfloat16().double()
+    qh = r(q).reshape(B, T, H, d).permute(0, 2, 1, 3)
+    kh = r(k).reshape(B, T, H, d).permute(0, 2, 1, 3)
+    TC, TT = T * Cc, T * T
+    S = torch.full((B, H, T, T), float("nan"), device="cuda")
+    D = _lib.BgemmDesc(M=T, N=T, K=d, G1=B, G2=H, sam=Cc, sak=1, a1=TC, a2=d, sbk=1, sbn=Cc, b1=TC, b2=d, ldc=T, c1=H * TT, c2=TT)
+    assert L.w2l_bgemm_bf16(C.byref(D), q.data_ptr(), k.data_ptr(), S.data_ptr(), _stream()) == 0
+    assert rel(S.cpu().numpy(), (qh @ kh.transpose(-1, -2)).cpu().numpy()) < 2e-5
+    ctx = torch.full((B, T, Cc), float("nan"), device="cuda")
+    D = _lib.BgemmDesc(M=T, N=d, K=T, G1=B, G2=H, sam=T, sak=1, a1=H * TT, a2=TT, sbk=Cc, sbn=1, b1=TC, b2=d, ldc=Cc, c1=TC, c2=d)
+    assert L.w2l_bgemm_bf16(C.byref(D), P.data_ptr(), k.data_ptr(), ctx.data_ptr(), _stream()) == 0
+    want = (r(P) @ kh).permute(0, 2, 1, 3).reshape(B, T, Cc)
+    assert rel(ctx.cpu().numpy(), want.cpu().numpy()) < 2e-5
+    dv = torch.randn(B, T, Cc, generator=g).cuda()
+    dv0 = dv.clone()
+    D = _lib.BgemmDesc(M=T, N=d, K=T, G1=B, G2=H, sam=1, sak=T, a1=H * TT, a2=TT, sbk=Cc, sbn=1, b1=TC, b2=d, ldc=Cc, c1=TC, c2=d,
+                       accumulate=1)
+    assert L.w2l_bgemm_bf16(C.byref(D), P.data_ptr(), q.data_ptr(), dv.data_ptr(), _stream()) == 0
+    want = dv0.double() + (r(P).transpose(-1, -2) @ qh).permute(0, 2, 1, 3).reshape(B, T, Cc)
+    assert rel(dv.cpu().numpy(), want.cpu().numpy()) < 2e-5
+
+
 @pytest.mark.parametrize("B,H,T,d,csz", [(2, 4, 23, 8, 30), (2, 2, 40, 16, 7), (1, 4, 188, 64, 460), (3, 1, 1, 4, 2)])
 def test_relative_position_products_and_softmax(B, H, T, d, csz):
     """R = Qflat E_win^T, softmax(scale (S + skew(R))) and its backward (dS and the skewed dR) against the float64

@@ -129,6 +129,7 @@ class _SIGS:
     w2l_hexpand_forward = (_i, [_p, _p, _sz, _i, _i, _i, _i, _p])
     w2l_hexpand_backward = (_i, [_p, _p, _sz, _i, _i, _i, _i, _p])
     w2l_bgemm_f32 = (_i, [_p, _p, _p, _p, _p])
+    w2l_bgemm_bf16 = (_i, [_p, _p, _p, _p, _p])
     w2l_attn_softmax_forward = (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p])
     w2l_attn_key_lengths = (_i, [_p, _i, _i, _i, _p, _p])
     w2l_attn_softmax_backward = (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p])

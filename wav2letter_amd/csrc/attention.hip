@@ -130,6 +130,127 @@ __global__ __launch_bounds__(256) void bgemm_k(BgP p) {
   }
 }
 
+
+// ---- the same batched product with bf16 MULTIPLIES (mixed precision, BASELINE config 5 "bf16 MFMA attention"): fp32 operands
+// in memory (q / k / v, probabilities, gradients: whatever the block holds), rounded to nearest-even bf16 on the way into LDS,
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation, fp32 result.  64 x 64 x 32 tiles; the LDS image of an operand tile is
+// [row][k] with k contiguous (80-byte rows = 16 bytes x 5: conflict-free ds_read_b128 fragments of 8 k), whatever the
+// operand's orientation in memory: a k-contiguous source stores eight k with one ds_write_b128, a row-contiguous source
+// (k strided) scatters eight rows of one k.  Eight elements per thread, operand and K tile.
+typedef __bf16 bg_bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bg_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float bg_f32x2_t __attribute__((ext_vector_type(2)));
+constexpr int kBhK = 32, kBhPitch = 40;   // bf16 elements
+
+struct BhRegs { float v[8]; };
+
+__device__ __forceinline__ uint32_t bh_pack2(float a, float b) {
+  const bg_f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bg_bf16x2_t));
+}
+
+template <int MODE>
+__device__ __forceinline__ BhRegs bh_load(const BgOperand& o, int tid, int rv, int k0, int K) {
+  BhRegs r;
+  if (MODE == kBgRowVec) {           // rows contiguous: k = tid / 8, rows (tid % 8) * 8 .. + 8
+    const int k = k0 + (tid >> 3), rq = (tid & 7) * 8;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    if (k < K) {
+      const float* src = o.p + (long long)k * o.sK + rq;
+      if (rq < rv) a = *(const f32x4*)src;            // extents are multiples of 4
+      if (rq + 4 < rv) b = *(const f32x4*)(src + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r.v[i] = a[i]; r.v[4 + i] = b[i]; }
+  } else if (MODE == kBgKVec) {      // k contiguous: row = tid / 4, k (tid % 4) * 8 .. + 8
+    const int row = tid >> 2, k = k0 + (tid & 3) * 8;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    if (row < rv) {
+      const float* src = o.p + (long long)row * o.sR + k;
+      if (k < K) a = *(const f32x4*)src;
+      if (k + 4 < K) b = *(const f32x4*)(src + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r.v[i] = a[i]; r.v[4 + i] = b[i]; }
+  } else if (o.sR == 1) {
+    const int k = k0 + (tid >> 3), rq = (tid & 7) * 8;
+    const float* src = o.p + (long long)k * o.sK + rq;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = (k < K && rq + i < rv) ? src[i] : 0.f;
+  } else {
+    const int row = tid >> 2, k = k0 + (tid & 3) * 8;
+    const float* src = o.p + (long long)row * o.sR + (long long)k * o.sK;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = (row < rv && k + i < K) ? src[(long long)i * o.sK] : 0.f;
+  }
+  return r;
+}
+template <int MODE>
+__device__ __forceinline__ void bh_store(const BgOperand& o, int tid, const BhRegs& r, uint16_t (*s)[kBhPitch]) {
+  if (MODE == kBgRowVec || (MODE == kBgGeneric && o.sR == 1)) {
+    const int kl = tid >> 3, rq = (tid & 7) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[rq + i][kl] = (uint16_t)(bh_pack2(r.v[i], 0.f) & 0xffffu);
+  } else {
+    const int row = tid >> 2, kq = (tid & 3) * 8;
+    const uint4 q = make_uint4(bh_pack2(r.v[0], r.v[1]), bh_pack2(r.v[2], r.v[3]), bh_pack2(r.v[4], r.v[5]), bh_pack2(r.v[6], r.v[7]));
+    *(uint4*)&s[row][kq] = q;
+  }
+}
+
+template <int AM, int BM>
+__global__ __launch_bounds__(256) void bgemm_bf_k(BgP p) {
+  __shared__ __attribute__((aligned(16))) uint16_t As[2][64][kBhPitch];
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[2][64][kBhPitch];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tm = blockIdx.x / p.tilesN, tn = blockIdx.x - tm * p.tilesN;
+  const int g1 = blockIdx.y / p.G2, g2 = blockIdx.y - g1 * p.G2;
+  BgOperand a = p.A, b = p.B;
+  a.p += g1 * p.a1 + g2 * p.a2 + (long long)tm * 64 * a.sR;
+  b.p += g1 * p.b1 + g2 * p.b2 + (long long)tn * 64 * b.sR;
+  const int mv = min(64, p.M - tm * 64), nv = min(64, p.N - tn * 64);
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32, li = lane & 31, lh = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int nk = (p.K + kBhK - 1) / kBhK;
+  BhRegs ra = bh_load<AM>(a, tid, mv, 0, p.K), rb = bh_load<BM>(b, tid, nv, 0, p.K);
+  bh_store<AM>(a, tid, ra, As[0]);
+  bh_store<BM>(b, tid, rb, Bs[0]);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) {
+      ra = bh_load<AM>(a, tid, mv, (kt + 1) * kBhK, p.K);
+      rb = bh_load<BM>(b, tid, nv, (kt + 1) * kBhK, p.K);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bg_bf16x8_t fa = *(const bg_bf16x8_t*)&As[cur][wm + li][16 * ks + 8 * lh];
+      const bg_bf16x8_t fb = *(const bg_bf16x8_t*)&Bs[cur][wn + li][16 * ks + 8 * lh];
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+    }
+    if (more) {
+      bh_store<AM>(a, tid, ra, As[cur ^ 1]);
+      bh_store<BM>(b, tid, rb, Bs[cur ^ 1]);
+    }
+    __syncthreads();
+  }
+  float* C = p.C + g1 * p.c1 + g2 * p.c2;
+  const int n = tn * 64 + wn + li;
+  if (n < p.N) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = tm * 64 + wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m < p.M) {
+        float* dst = C + (long long)m * p.ldc + n;
+        *dst = p.accumulate ? *dst + acc[r] : acc[r];
+      }
+    }
+  }
+}
+
 // ---- softmax over the keys of one query row, relative-position term gathered from R ------------------------------------
 // one wave per row (b, h, i); S row in place -> P.  R row of (b, i, h): entry w holds q_i . E[rlo + w]
 struct SmP {
@@ -261,7 +382,7 @@ static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 using namespace w2l;
 #define W2L_S ((hipStream_t)stream)
 
-W2L_API int w2l_bgemm_f32(const w2l_bgemm_desc* d, const float* A, const float* B, float* C, w2l_stream_t stream) {
+static int bgemm_launch(const w2l_bgemm_desc* d, const float* A, const float* B, float* C, bool bf16, w2l_stream_t stream) {
   if (!d || !A || !B || !C) return W2L_EINVAL;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->G1 <= 0 || d->G2 <= 0) return W2L_EINVAL;
   if ((long long)d->G1 * d->G2 > 65535) return W2L_EINVAL;
@@ -284,7 +405,11 @@ W2L_API int w2l_bgemm_f32(const w2l_bgemm_desc* d, const float* A, const float* 
   const int am = !p.A.vec ? kBgGeneric : (d->sam == 1 ? kBgRowVec : kBgKVec);
   const int bm = !p.B.vec ? kBgGeneric : (d->sbn == 1 ? kBgRowVec : kBgKVec);
   const dim3 grid((unsigned)tiles, (unsigned)(d->G1 * d->G2));
-#define W2L_BG(AMv, BMv) hipLaunchKernelGGL((bgemm_k<AMv, BMv>), grid, dim3(256), 0, W2L_S, p)
+#define W2L_BG(AMv, BMv)                                                                      \
+  do {                                                                                        \
+    if (bf16) hipLaunchKernelGGL((bgemm_bf_k<AMv, BMv>), grid, dim3(256), 0, W2L_S, p);       \
+    else hipLaunchKernelGGL((bgemm_k<AMv, BMv>), grid, dim3(256), 0, W2L_S, p);               \
+  } while (0)
   switch (am * 3 + bm) {
     case 0: W2L_BG(0, 0); break;
     case 1: W2L_BG(0, 1); break;
@@ -299,6 +424,15 @@ W2L_API int w2l_bgemm_f32(const w2l_bgemm_desc* d, const float* A, const float* 
 #undef W2L_BG
   W2L_LAUNCH_CHECK();
   return W2L_OK;
+}
+
+W2L_API int w2l_bgemm_f32(const w2l_bgemm_desc* d, const float* A, const float* B, float* C, w2l_stream_t stream) {
+  return bgemm_launch(d, A, B, C, false, stream);
+}
+// the same product with bf16 multiplies (operands rounded to nearest even on the way into LDS), fp32 accumulation and result:
+// the attention products of a Transformer block in the mixed-precision mode
+W2L_API int w2l_bgemm_bf16(const w2l_bgemm_desc* d, const float* A, const float* B, float* C, w2l_stream_t stream) {
+  return bgemm_launch(d, A, B, C, true, stream);
 }
 
 static int sm_params(SmP& p, int B, int H, int T, int ldr, int rlo, int W, int n0, float scale) {

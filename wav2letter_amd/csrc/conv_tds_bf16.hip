@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void tds_conv_bf_k(TdsBfP p) {
     const int runF4 = 2 * C;                     // float4 per frame: 8 mel rows x C floats (H * C % 4 == 0: host-checked)
     const float* xb = p.x + ((size_t)b * p.T * p.H + h0) * C;
     const size_t frameStride = (size_t)p.H * C;
-    const int hValid = p.H - h0 < kTbHB ? p.H - h0 : kTbHB;
+    const int hValid = kTbHB;                    // H % 8 == 0 (host-checked)
     const int total = NF * runF4;
     constexpr int NV = 8;
     for (int base = 0; base < total; base += NV * 256) {
@@ -95,13 +95,17 @@ __global__ __launch_bounds__(256) void tds_conv_bf_k(TdsBfP p) {
       int fo[NV], eo[NV];
 #pragma unroll
       for (int u = 0; u < NV; ++u) {
+        // UNCONDITIONAL loads from clamped (always valid) addresses, zero selected afterwards: a load inside a branch makes
+        // hipcc wait vmcnt(0) right behind it (seen in the second build's ISA: eight serialized round trips per batch)
         const int q = base + tid + 256 * u;
-        const int f = q / runF4, j = q - f * runF4;
+        const int qq = q < total ? q : total - 1;
+        const int f = qq / runF4, j = qq - f * runF4;
         const int tin = t0 - p.padl + f;
-        const bool ok = q < total && tin >= 0 && tin < p.T && 4 * j < hValid * C;
+        const int tc = tin < 0 ? 0 : (tin >= p.T ? p.T - 1 : tin);
+        const bool ok = q < total && tin == tc && 4 * j < hValid * C;
         fo[u] = ok ? f : -1;
         eo[u] = 4 * j;
-        v4[u] = ok ? *(const float4*)(xb + (size_t)tin * frameStride + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v4[u] = *(const float4*)(xb + (size_t)tc * frameStride + 4 * j);
       }
 #pragma unroll
       for (int u = 0; u < NV; ++u) {
@@ -138,25 +142,48 @@ __global__ __launch_bounds__(256) void tds_conv_bf_k(TdsBfP p) {
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, wf[s], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, wf[s], acc1, 0, 0, 0);
     }
-    // epilogue: C layout col = li (output channel), row = (r & 3) + 8 (r >> 2) + 4 lh (frame)
-    if (li < C) {
-      const float bv = p.bias ? p.bias[li] : 0.f;
+    // epilogue: C layout col = li (output channel), row = (r & 3) + 8 (r >> 2) + 4 lh (frame).  The addend of backward-data
+    // is fetched for all 32 outputs of the lane FIRST, unconditionally from clamped addresses (a load inside the bounds
+    // branch serialises: hipcc waits vmcnt(0) behind each, and on gfx9 that counter also holds the stores in between)
+    const int lc = li < C ? li : C - 1;
+    const float bv = p.bias ? p.bias[lc] : 0.f;
+    const size_t tile = (((size_t)b * p.T + t0) * p.H + h0) * C;   // wave-uniform; per-output offsets stay 32-bit
+    const float* addb = p.add ? p.add + tile : nullptr;
+    float* yb = p.y + tile;
+    const int tl0 = 32 * th + 4 * lh, tlMax = p.T - 1 - t0, hC = p.H * C;
+    float av[2][16];
+    auto off = [&](int hh, int r) {
+      const int tl = tl0 + (r & 3) + 8 * (r >> 2);
+      return (tl < tlMax ? tl : tlMax) * hC + (2 * wave + hh) * C + lc;
+    };
+    if (addb) {
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const int h = h0 + 2 * wave + hh;
-        if (h >= p.H) continue;
+      for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int t = t0 + 32 * th + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (t >= p.T) continue;
-          const size_t idx = (((size_t)b * p.T + t) * p.H + h) * C + li;
-          float v = (hh ? acc1[r] : acc0[r]) + bv;
-          if (p.relu) v = fmaxf(v, 0.f);
-          if (p.add) v += p.add[idx];
-          p.y[idx] = v;
-        }
-      }
+        for (int r = 0; r < 16; ++r) av[hh][r] = addb[off(hh, r)];
+    } else {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) av[hh][r] = 0.f;
     }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = (hh ? acc1[r] : acc0[r]) + bv;
+        if (p.relu) v = fmaxf(v, 0.f);
+        v += av[hh][r];
+        asm volatile("" : "+v"(v));   // the sum (and with it the wait for the addend) stays outside the bounds branch
+        av[hh][r] = v;
+      }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int tl = tl0 + (r & 3) + 8 * (r >> 2);
+        if (li < C && tl <= tlMax) yb[off(hh, r)] = av[hh][r];
+      }
   }
 }
 
@@ -249,11 +276,13 @@ __global__ __launch_bounds__(256) void tds_conv_bf_filter_k(TdsBfFilterP p) {
         const bool in = f < NFX + kTfTT && tin >= 0 && tin < p.T;
         const float* src = (isX ? p.x : p.dy) + ((((size_t)b * p.T + (in ? tin : 0)) * p.H + h0 + 2 * hp) * C);
 #pragma unroll
-        for (int cp = 0; cp < 4; ++cp) {
+        for (int cp = 0; cp < 4; ++cp) {   // unconditional loads from clamped addresses, zero selected afterwards
           const int c = cl + 8 * cp;
+          const int cc = c < C ? c : C - 1;
+          const float a0 = src[cc], a1 = src[C + cc];
           const bool ok = in && c < C;
-          v0[ff][cp] = ok ? src[c] : 0.f;
-          v1[ff][cp] = ok ? src[C + c] : 0.f;
+          v0[ff][cp] = ok ? a0 : 0.f;
+          v1[ff][cp] = ok ? a1 : 0.f;
         }
       }
 #pragma unroll
@@ -351,7 +380,7 @@ static int tb_launch_filter(const TdsBfFilterP& p0, float* dw, hipStream_t s) {
 struct TbGeom { int CP, NSTEP; };
 static bool tb_geometry(const w2l_conv_desc* d, TbGeom& g) {
   if (!d || d->stride != 1 || d->Cin != d->Cout || d->Cin < 1 || d->Cin > 32 || d->kw < 1) return false;
-  if (d->padl + d->padr != d->kw - 1 || ((size_t)d->H * d->Cin) % 4 != 0) return false;
+  if (d->padl + d->padr != d->kw - 1 || d->H % kTbHB != 0) return false;   // whole 8-row mel blocks (16-byte aligned runs of 8 C floats)
   const int C = d->Cin;
   g.CP = C <= 16 ? 16 : C <= 24 ? 24 : 32;
   int n = (d->kw * g.CP + 15) / 16;

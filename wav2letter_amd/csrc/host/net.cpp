@@ -855,6 +855,7 @@ class TransformerLayer : public Layer {
   }
   void forward(Ctx& cx, float* ar, const float* x, float*& y) override {
     hipStream_t s = cx.stream;
+    auto bg = cx.bf16 ? w2l_bgemm_bf16 : w2l_bgemm_f32;   // mixed precision: the attention products multiply in bf16 too
     xSaved = x;
     const double pd = cx.train ? p : 0.0;
     dropped = false;
@@ -888,12 +889,12 @@ class TransformerLayer : public Layer {
     {  // S[b][h][i][j] = q_i . k_j
       w2l_bgemm_desc g = heads(T, T, d);
       g.sam = C; g.sak = 1; g.a1 = TC; g.a2 = d; g.sbk = 1; g.sbn = C; g.b1 = TC; g.b2 = d; g.ldc = T; g.c1 = nH * TT; g.c2 = TT;
-      w2lCheck(w2l_bgemm_f32(&g, q, k, S, s), "tr qk");
+      w2lCheck(bg(&g, q, k, S, s), "tr qk");
     }
     if (csz > 0) {  // R[(b, i, h)][w] = q_i . E[rlo + w]
       w2l_bgemm_desc g{};
       g.M = M * nH; g.N = W; g.K = d; g.G1 = g.G2 = 1; g.sam = d; g.sak = 1; g.sbk = 1; g.sbn = d; g.ldc = ldr;
-      w2lCheck(w2l_bgemm_f32(&g, q, pe.w(cx) + (size_t)rlo * d, R, s), "tr qE");
+      w2lCheck(bg(&g, q, pe.w(cx) + (size_t)rlo * d, R, s), "tr qE");
     }
     const int* keyLen = nullptr;
     if (cx.inputSizes) {  // padding mask of the keys (cpc/SequentialBuilder.cpp:58-81, TransformerCPC.cpp:138-144)
@@ -906,7 +907,7 @@ class TransformerLayer : public Layer {
     {  // ctx_i = sum_j P[i][j] v_j
       w2l_bgemm_desc g = heads(T, d, T);
       g.sam = T; g.sak = 1; g.a1 = nH * TT; g.a2 = TT; g.sbk = C; g.sbn = 1; g.b1 = TC; g.b2 = d; g.ldc = C; g.c1 = TC; g.c2 = d;
-      w2lCheck(w2l_bgemm_f32(&g, pd > 0 ? Pd : S, v, ctx, s), "tr pv");
+      w2lCheck(bg(&g, pd > 0 ? Pd : S, v, ctx, s), "tr pv");
     }
     if (mixed) {
       ctxImg.convert(cx, ar, ctx, "tr ctx images");
@@ -937,6 +938,7 @@ class TransformerLayer : public Layer {
   }
   void backward(Ctx& cx, float* ar, const float* dy, float*& dx, bool needDx) override {
     hipStream_t s = cx.stream;
+    auto bg = cx.bf16 ? w2l_bgemm_bf16 : w2l_bgemm_f32;
     const double pd = cx.train ? p : 0.0;
     float *q = ar + qOff, *k = ar + kOff, *v = ar + vOff, *S = ar + sOff, *Pd = ar + pdOff, *ctx = ar + ctxOff;
     float *o = ar + oOff, *h = ar + hOff, *u = ar + uOff, *m2 = ar + m2Off;
@@ -985,37 +987,37 @@ class TransformerLayer : public Layer {
     {  // dPd[i][j] = dctx_i . v_j
       w2l_bgemm_desc g = heads(T, T, d);
       g.sam = C; g.sak = 1; g.a1 = TC; g.a2 = d; g.sbk = 1; g.sbn = C; g.b1 = TC; g.b2 = d; g.ldc = T; g.c1 = nH * TT; g.c2 = TT;
-      w2lCheck(w2l_bgemm_f32(&g, dctx, v, dS, s), "tr dP");
+      w2lCheck(bg(&g, dctx, v, dS, s), "tr dP");
     }
     {  // dv_j = sum_i Pd[i][j] dctx_i
       w2l_bgemm_desc g = heads(T, d, T);
       g.sam = 1; g.sak = T; g.a1 = nH * TT; g.a2 = TT; g.sbk = C; g.sbn = 1; g.b1 = TC; g.b2 = d; g.ldc = C; g.c1 = TC; g.c2 = d;
-      w2lCheck(w2l_bgemm_f32(&g, pd > 0 ? Pd : S, dctx, dv, s), "tr dv");
+      w2lCheck(bg(&g, pd > 0 ? Pd : S, dctx, dv, s), "tr dv");
     }
     if (pd > 0) w2lCheck(w2l_dropout_inplace(dS, (size_t)B * nH * TT, pd, cx.seed, rngStream, s), "tr attn dropout bwd");
     w2lCheck(w2l_attn_softmax_backward(S, dS, csz > 0 ? dR : nullptr, B, nH, T, ldr, rlo, W, n0, (float)(1.0 / std::sqrt((double)d)), s), "tr softmax bwd");
     {  // dq_i = sum_j dS[i][j] k_j
       w2l_bgemm_desc g = heads(T, d, T);
       g.sam = T; g.sak = 1; g.a1 = nH * TT; g.a2 = TT; g.sbk = C; g.sbn = 1; g.b1 = TC; g.b2 = d; g.ldc = C; g.c1 = TC; g.c2 = d;
-      w2lCheck(w2l_bgemm_f32(&g, dS, k, dq, s), "tr dq");
+      w2lCheck(bg(&g, dS, k, dq, s), "tr dq");
     }
     {  // dk_j = sum_i dS[i][j] q_i
       w2l_bgemm_desc g = heads(T, d, T);
       g.sam = 1; g.sak = T; g.a1 = nH * TT; g.a2 = TT; g.sbk = C; g.sbn = 1; g.b1 = TC; g.b2 = d; g.ldc = C; g.c1 = TC; g.c2 = d;
-      w2lCheck(w2l_bgemm_f32(&g, dS, q, dk, s), "tr dk");
+      w2lCheck(bg(&g, dS, q, dk, s), "tr dk");
     }
     if (csz > 0) {
       const float* Ew = pe.w(cx) + (size_t)rlo * d;
       {  // dq_(b,i,h) += sum_w dR[(b,i,h)][w] E[rlo + w]
         w2l_bgemm_desc g{};
         g.M = M * nH; g.N = d; g.K = W; g.G1 = g.G2 = 1; g.sam = ldr; g.sak = 1; g.sbk = d; g.sbn = 1; g.ldc = d; g.accumulate = 1;
-        w2lCheck(w2l_bgemm_f32(&g, dR, Ew, dq, s), "tr dq rel");
+        w2lCheck(bg(&g, dR, Ew, dq, s), "tr dq rel");
       }
       {  // dE[rlo + w] = sum_(b,i,h) dR[(b,i,h)][w] q_(b,i,h): one partial per utterance, then a column sum
         w2l_bgemm_desc g{};
         g.M = W; g.N = d; g.K = T * nH; g.G1 = B; g.G2 = 1; g.sam = 1; g.sak = ldr; g.a1 = (long long)T * nH * ldr;
         g.sbk = d; g.sbn = 1; g.b1 = TC; g.ldc = d; g.c1 = (long long)W * d;
-        w2lCheck(w2l_bgemm_f32(&g, dR, q, dEp, s), "tr dE");
+        w2lCheck(bg(&g, dR, q, dEp, s), "tr dE");
         zeroGrad(cx, pe, s);
         w2lCheck(w2l_colsum(dEp, pe.g(cx) + (size_t)rlo * d, (size_t)B, W * d, s), "tr dE sum");
       }
