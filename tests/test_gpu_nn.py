@@ -794,11 +794,14 @@ def _bf16_ref(a):
 
 @pytest.mark.parametrize("M,N,K", [(4, 4, 8), (128, 128, 64), (260, 388, 96), (1028, 2052, 1440), (187 * 4, 1200, 1200),
                                     (11968, 2160, 2160), (3008, 9998, 1024), (640, 136, 24000), (2160, 9998, 748),
-                                    (1200, 1200, 11968)])
+                                    (1200, 1200, 11968), (2100, 2100, 6100), (4000, 3100, 200), (2160, 2160, 11968),
+                                    (11968, 1200, 1200), (513, 6200, 4000)])
 def test_gemm_bf16_operand_storage(M, N, K):
     """C = A B^T on bf16 images against the float64 product of the SAME bf16-rounded operands (the kernel's only rounding is
     the fp32 accumulation: 2e-5 of the largest magnitude), run-to-run determinism (stream-K slabs are added in range order),
-    and the shapes of the three products of config 3 / config 5 layers incl. a ragged K and an N that is not a multiple of 4"""
+    and the shapes of the three products of config 3 / config 5 layers incl. a ragged K and an N that is not a multiple of 4.
+    The larger shapes run on the 256 x 256 tile kernel: whole tiles only (K = 200), stream-K ranges only (2100 x 2100 x 6100,
+    the weight-gradient shape), a full round plus ranges (11968 x 2160), the dword epilogue (N = 9998), one row of tiles"""
     from wav2letter_amd import ops
     g = torch.Generator(device="cpu").manual_seed(M + 3 * N + 7 * K)
     A = torch.randn(M, K, generator=g).cuda()
@@ -816,12 +819,12 @@ def test_gemm_bf16_operand_storage(M, N, K):
     assert rel(ops.gemm_bf16(Ab, Bb, K, bias=bias, relu=True), np.maximum(wb, 0)) < 2e-5
 
 
-def test_gemm_bf16_operand_storage_epilogues(oracle):
+@pytest.mark.parametrize("M,N,K", [(700, 520, 333), (4000, 3100, 333)])
+def test_gemm_bf16_operand_storage_epilogues(oracle, M, N, K):
     """the fp32 engine's epilogue on the bf16 product: mask, addend, accumulate into C, dropout (the library's stateless hash:
     bit-identical keep pattern to w2l_dropout_inplace over the dense output)"""
     from wav2letter_amd import ops
     g = torch.Generator(device="cpu").manual_seed(11)
-    M, N, K = 700, 520, 333
     A = torch.randn(M, K, generator=g).cuda()
     B = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
     bias = torch.randn(N, generator=g).cuda()

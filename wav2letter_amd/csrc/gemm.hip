@@ -103,6 +103,16 @@ bool sk_enabled() {
   return !(e && e[0] == '0');
 }
 
+bool sk_forced() {   // W2L_GEMM_SK=2 (probe build): take the stream-K schedule whenever the planner offers one
+  const char* e = tune_env("W2L_GEMM_SK");
+  return e && e[0] == '2';
+}
+
+int h256_mode() {
+  const char* e = tune_env("W2L_GEMM_H256");
+  return e ? (e[0] == '1' ? 1 : 0) : -1;
+}
+
 static inline int pick_vec(const float* p, int ld, int extent) {
   if ((((uintptr_t)p) & 15) == 0 && ld % 4 == 0 && extent % 4 == 0) return 4;
   if ((((uintptr_t)p) & 7) == 0 && ld % 2 == 0 && extent % 2 == 0) return 2;

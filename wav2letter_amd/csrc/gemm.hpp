@@ -302,7 +302,7 @@ __host__ __device__ inline void sk_tile_xy(const SkPlan& p, int t, int& bx, int&
   bx = tin / gsize;
 }
 
-inline SkPlan make_sk_plan(int M, int N, int K, bool allowSk, int tileM = 128, int tileN = 128) {
+inline SkPlan make_sk_plan(int M, int N, int K, bool allowSk, int tileM = 128, int tileN = 128, int slots = kSkSlots) {
   SkPlan p;
   p.tilesM = (M + tileM - 1) / tileM;
   p.tilesN = (N + tileN - 1) / tileN;
@@ -311,21 +311,21 @@ inline SkPlan make_sk_plan(int M, int N, int K, bool allowSk, int tileM = 128, i
   p.dpTiles = tiles; p.skTiles = 0; p.skBlocks = 0; p.slabs = nullptr; p.grouped = 0; p.counters = nullptr;
   p.ksplit = 0; p.kChunk = 0;
   if (!allowSk || p.kTiles < 8) return p;
-  const int rounds = (tiles + kSkSlots - 1) / kSkSlots;
-  const double eff = (double)tiles / ((double)rounds * kSkSlots);
+  const int rounds = (tiles + slots - 1) / slots;
+  const double eff = (double)tiles / ((double)rounds * slots);
   if (eff >= 0.93) return p;
   // A grid that fits one workgroup per CU with a SHORT reduction is better left data-parallel: splitting it 512 ways costs
   // a partial-tile round trip per worker (~43 us at 192 tiles) that a K of a few tiles cannot repay.  Fitted on MI355X
   // (profiles/r02_run22_gemm_c5_shapes.log; M = 3008, N = 1024: K = 1024 -> 74.5 us data-parallel against 86.1 stream-K,
   // K = 4096 -> 258 against 213):  t_dp = 2.1 kTiles + 7,  t_sk = 3.6 tiles kTiles / 512 + 43  [us]
   // (fitted between 128 and 256 tiles; a grid of a few tiles still gains from being split, its partial traffic is small)
-  if (tiles > kSkSlots / 4 && tiles <= kSkSlots / 2 && (double)p.kTiles * (2.1 - 3.6 * tiles / kSkSlots) < 36.0) return p;
-  const int full = tiles / kSkSlots;
-  p.dpTiles = full * kSkSlots;
+  if (slots == kSkSlots && tiles > kSkSlots / 4 && tiles <= kSkSlots / 2 && (double)p.kTiles * (2.1 - 3.6 * tiles / kSkSlots) < 36.0) return p;
+  const int full = tiles / slots;
+  p.dpTiles = full * slots;
   p.skTiles = tiles - p.dpTiles;
   long long iters = (long long)p.skTiles * p.kTiles;
   long long blocks = iters / 4;  // >= 4 K iterations per workgroup
-  if (blocks > kSkSlots) blocks = kSkSlots;
+  if (blocks > slots) blocks = slots;
   if (blocks < 1) blocks = 1;
   p.skBlocks = (int)blocks;
   // every range must stay within two tiles

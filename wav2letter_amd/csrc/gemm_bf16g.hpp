@@ -32,17 +32,6 @@ __device__ __forceinline__ bf16x8v_t h_frag(const float* tile, int row, int s, i
   return __builtin_bit_cast(bf16x8v_t, v);
 }
 
-// segment fields as SGPRs: left in VGPRs (the schedule's 64-bit divisions), the K-tile index makes hipcc wrap every LDS-DMA
-// issue in a readfirstlane "waterfall" loop for its scalar offset (seen in the first build: 8 loops per K tile)
-__device__ __forceinline__ GSeg h_pin(GSeg s) {
-  s.tile = __builtin_amdgcn_readfirstlane(s.tile);
-  s.kb = __builtin_amdgcn_readfirstlane(s.kb);
-  s.ke = __builtin_amdgcn_readfirstlane(s.ke);
-  s.slab = __builtin_amdgcn_readfirstlane(s.slab);
-  s.valid = __builtin_amdgcn_readfirstlane((int)s.valid) != 0;
-  return s;
-}
-
 // aop / bop: bf16 matrices viewed as float matrices of half the width (p, ld in floats = bf16 elements / 2); plan.kTiles
 // counts 64-k tiles.  Same launch geometry as gemm128g_kernel.
 __global__ __launch_bounds__(256, 2) void gemm128h_kernel(GOp aop, GOp bop, GemmOut out, SkPlan plan, int workers, int wide) {
@@ -54,7 +43,7 @@ __global__ __launch_bounds__(256, 2) void gemm128h_kernel(GOp aop, GOp bop, Gemm
   const int w = __builtin_amdgcn_readfirstlane(xcd_major(blockIdx.x, workers));
   constexpr uint32_t kStepBytes = 128;   // one K tile = 64 bf16 = 128 bytes along a row
 
-  GSeg seg = h_pin(g_segment(plan, w, workers, 0));
+  GSeg seg = g_pin(g_segment(plan, w, workers, 0));
   if (!seg.valid) return;
   uint32_t va[4], vb[4];
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)aop.p, 0, (int)aop.bytes, 0x00020000);
@@ -72,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void gemm128h_kernel(GOp aop, GOp bop, Gemm
   __syncthreads();  // (drains the LDS-DMA: vmcnt(0) precedes the barrier)
 
   for (int ord = 0;; ++ord) {
-    const GSeg nxt = h_pin(g_segment(plan, w, workers, ord + 1));
+    const GSeg nxt = g_pin(g_segment(plan, w, workers, ord + 1));
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (out.epi & EPI_BIAS) {
       const int nb = by * 128 + wn + 4 * (lane & 15);
@@ -124,10 +113,14 @@ __global__ __launch_bounds__(256, 2) void gemm128h_kernel(GOp aop, GOp bop, Gemm
           fb[cur ^ 1][0] = h_frag(Bs, wn + li, s + 1, lh, li);
           fb[cur ^ 1][1] = h_frag(Bs, wn + 32 + li, s + 1, lh, li);
         }
+        // keep the order written here: left alone, hipcc funnels every fragment through ONE register quad (read, wait
+        // lgkmcnt(0), two MFMAs, read, ...) and exposes an LDS round trip per MFMA pair -- seen in the ISA of both kernels
+        __builtin_amdgcn_sched_barrier(0);
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0], fb[cur][0], acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0], fb[cur][1], acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][1], fb[cur][0], acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][1], fb[cur][1], acc[1][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
       stage ^= 1;
       __syncthreads();  // the stage just filled has landed (vmcnt(0)) and is visible to all waves
@@ -193,6 +186,136 @@ __global__ __launch_bounds__(256, 2) void gemm128h_kernel(GOp aop, GOp bop, Gemm
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 tiles, 8 waves, whole tiles only.  Counters of the 128 x 128 kernel on the config-3 fc shape (M = 11968,
+// N = K = 2160; profiles/r03_run2_gemm128h_pmc.txt): 33 % MFMA busy, 48 % of the wave cycles parked at the per-K-tile DMA
+// drain, 1.95 GB of operand tiles through the L2 for 166 us.  A 256 x 256 tile halves the staged bytes per flop and, with
+// one 8-wave workgroup per CU (two waves per SIMD, 128 accumulator registers each), a K tile is 32 MFMAs = 1024 MFMA
+// cycles per wave: the eight 1 KiB LDS-DMA pieces a wave issues at the top of the iteration have twice the time to land.
+//   * wave w: column half g = w >> 2, quadrant q = w & 3 of BOTH 128-row halves -- rows si 128 + (q >> 1) 64 + {0, 32} + li
+//     (si = 0, 1), columns g 128 + (q & 1) 64 + {0, 32} + li: every 128 x 128 sub-tile (si, g) is held by four waves in
+//     the fp32 engine's quadrant layout, so its epilogues are reused per sub-tile (two 4-wave groups side by side);
+//   * LDS: 2 stages x (A 256 rows + B 256 rows) x 128 bytes = 128 KiB; pieces, swizzle and fragment reads as above;
+//   * schedule: <= 256 persistent workers (XCD-major), worker w takes tiles w, w + workers, ...  No stream-K: at bf16 speed
+//     a K tile costs 2 us and a 256 KiB partial slab round trip ~45 us of serial tail -- on every config-3 / config-5 shape
+//     whole tiles won, for either tile size (profiles/r03_run3_gemm_bf16_schedules.log).  Wins over the 128 x 128 kernel
+//     where the tile count fits the 256 workers well (M = 11968 x N = 1200 / 2160, the N = 9998 output layer, 8192^3: 1.10
+//     PFLOP/s against 1.00); the host picks per shape (launch128h).
+constexpr int kH2StageFloats = 2 * 256 * 32;
+constexpr int kH2Slots = 256;
+
+__global__ __launch_bounds__(512, 1) void gemm256h_kernel(GOp aop, GOp bop, GemmOut out, SkPlan plan, int workers, int wide) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, quad = wave & 3;
+  const int wm = (quad >> 1) * 64, wn = grp * 128 + (quad & 1) * 64;
+  const int li = lane & 31, lh = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(xcd_major(blockIdx.x, workers));
+  constexpr uint32_t kStepBytes = 128;
+  const int tiles = plan.dpTiles, kTiles = plan.kTiles;
+  if (w >= tiles) return;
+
+  uint32_t va[4], vb[4];
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)aop.p, 0, (int)aop.bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)bop.p, 0, (int)bop.bytes, 0x00020000);
+  int bx, by;
+  sk_tile_xy(plan, w, bx, by);
+  g_init_offs<true>(va, aop, bx * 256, wave, lane);   // piece wave * 4 + j = rows 8 (wave * 4 + j) .. + 8 of the 256-row tile
+  g_init_offs<true>(vb, bop, by * 256, wave, lane);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    g_issue1_buf(ra, va[j], 0, smem, wave, j);
+    g_issue1_buf(rb, vb[j], 0, smem + 8192, wave, j);
+  }
+  int stage = 0;
+  __syncthreads();
+
+  for (int tile = w; tile < tiles; tile += workers) {
+    const bool more = tile + workers < tiles;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (out.epi & EPI_BIAS) {
+      const int nb = by * 256 + wn + 4 * (lane & 15);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[e] = nb + e < out.N ? out.bias[nb + e] : 0.f;
+    }
+    f32x16 acc[2][2][2];
+#pragma unroll
+    for (int si = 0; si < 2; ++si)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[si][i][j][r] = 0.f;
+
+    for (int kt = 0; kt < kTiles; ++kt) {
+      const float* As = smem + stage * kH2StageFloats;
+      const float* Bs = As + 8192;
+      float* An = smem + (stage ^ 1) * kH2StageFloats;
+      // to the other stage during this iteration: the next K tile, or the first K tile of the worker's next tile, or (very
+      // last iteration of this worker) a harmless re-load of this one
+      uint32_t off = kStepBytes * (uint32_t)kt;
+      if (kt + 1 < kTiles) {
+        off += kStepBytes;
+      } else if (more) {
+        int nbx, nby;
+        sk_tile_xy(plan, tile + workers, nbx, nby);
+        g_init_offs<true>(va, aop, nbx * 256, wave, lane);
+        g_init_offs<true>(vb, bop, nby * 256, wave, lane);
+        off = 0;
+      }
+      off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        g_issue1_buf(ra, va[j], off, An, wave, j);
+        g_issue1_buf(rb, vb[j], off, An + 8192, wave, j);
+      }
+      bf16x8v_t fa[2][4], fb[2][2];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) fa[0][a] = h_frag(As, (a >> 1) * 128 + wm + (a & 1) * 32 + li, 0, lh, li);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) fb[0][b] = h_frag(Bs, wn + b * 32 + li, 0, lh, li);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int cur = s & 1;
+        if (s < 3) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) fa[cur ^ 1][a] = h_frag(As, (a >> 1) * 128 + wm + (a & 1) * 32 + li, s + 1, lh, li);
+#pragma unroll
+          for (int b = 0; b < 2; ++b) fb[cur ^ 1][b] = h_frag(Bs, wn + b * 32 + li, s + 1, lh, li);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // the six reads of k-step s + 1 are in flight under the eight MFMAs of k-step s
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc[a >> 1][a & 1][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][a], fb[cur][b], acc[a >> 1][a & 1][b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      stage ^= 1;
+      __syncthreads();
+    }
+
+    // `stage` names the buffer holding the prefetched next K tile; the other one is free: eight 8 KiB wave slices
+    float* scratch = smem + (stage ^ 1) * kH2StageFloats;
+    if (wide) {
+      gemm128g_epilogue_wide(out, bx * 256, by * 256 + grp * 128, acc[0], scratch, bv, quad, wave);
+      gemm128g_epilogue_wide(out, bx * 256 + 128, by * 256 + grp * 128, acc[1], scratch, bv, quad, wave);
+    } else {
+      gemm128_epilogue(out, bx * 256, by * 256 + grp * 128, acc[0], quad);
+      gemm128_epilogue(out, bx * 256 + 128, by * 256 + grp * 128, acc[1], quad);
+    }
+    if (!more) break;
+    __syncthreads();   // the next iteration's LDS-DMA lands in the slices the epilogue used
+    sk_tile_xy(plan, tile + workers, bx, by);
+  }
+}
+
+// which tile shape: 1 = 256 x 256 (W2L_GEMM_H256=1 / 0 force it on / off for A/B runs; default by problem size)
+int h256_mode();
+bool sk_forced();
+
 // A [M][lda], B [N][ldb] bf16 (lda, ldb in bf16 elements, even, >= Kp), Kp = K rounded up to 64: columns K .. Kp of every
 // row must be ZERO in both operands (convert.hip writes them so).  W2L_EUNSUPPORTED when the schedule cannot run in-kernel.
 inline int launch128h(const uint16_t* A, int lda, const uint16_t* B, int ldb, GemmOut o, int epi, hipStream_t s) {
@@ -202,22 +325,47 @@ inline int launch128h(const uint16_t* A, int lda, const uint16_t* B, int ldb, Ge
   if (ab >= 0x7fffffffull || bb >= 0x7fffffffull) return W2L_EUNSUPPORTED;
   epi &= ~EPI_ATOMIC;
   const double flops = 2.0 * o.M * (double)o.N * o.K;
-  SkPlan plan = make_sk_plan(o.M, o.N, Kp / 2, sk_enabled());   // kTiles = Kp / 64
-  plan.grouped = 1;
-  if (plan.skBlocks > 0) {
-    plan.slabs = sk_scratch(s, kSkScratchBytes);
-    if (plan.slabs && plan.skTiles <= 1024) plan.counters = sk_counters(s);
-    if (!plan.slabs || !plan.counters) { plan = make_sk_plan(o.M, o.N, Kp / 2, false); plan.grouped = 1; }
-  }
-  int workers = plan.dpTiles < kSkSlots ? plan.dpTiles : kSkSlots;
-  if (workers < plan.skBlocks) workers = plan.skBlocks;
-  const size_t shmem = 2 * (size_t)kGStageFloats * sizeof(float);
   o.epi = epi;
   const int wide = (((uintptr_t)o.C) & 15) == 0 && o.ldc % 4 == 0 && (!o.mask || (((uintptr_t)o.mask) & 15) == 0) &&
                    (!o.addend || (((uintptr_t)o.addend) & 15) == 0);
   GOp ga{(const float*)A, lda / 2, o.M, (unsigned)ab}, gb{(const float*)B, ldb / 2, o.N, (unsigned)bb};
+  // Which kernel: predicted time of whole-tile schedules of the two tile sizes, fitted on MI355X over the config-3 / config-5
+  // shapes (profiles/r03_run3_gemm_bf16_schedules.log).  128: a CU holds two workgroups, its busiest one works through
+  // ceil(tiles / 256) tile PAIRS at ~0.55 us a K tile; 256: ceil(tiles / 256) tiles at 2.0 us a K tile.  Stream-K only for a
+  // handful of tiles with a long reduction (1200 x 1200 x 11968: 106 us against 132), 128 kernel.
+  const int kt = Kp / 64;
+  const long long tiles1 = (long long)((o.M + 127) / 128) * ((o.N + 127) / 128);
+  const long long tiles2 = (long long)((o.M + 255) / 256) * ((o.N + 255) / 256);
+  const double t1 = (double)((tiles1 + 255) / 256) * (kt * 0.55 + 3.0), t2 = (double)((tiles2 + 255) / 256) * (kt * 2.0 + 8.0);
+  const int mode = h256_mode();
+  const bool big = o.M >= 256 && o.N >= 256 && tiles2 < (1 << 30) && (mode == 1 || (mode < 0 && t2 < t1));
+  SkPlan plan;
+  if (big) {
+    plan = make_sk_plan(o.M, o.N, Kp / 2, false, 256, 256, kH2Slots);
+  } else {
+    const bool sk = sk_enabled() && (sk_forced() || (tiles1 <= 128 && kt >= 96));
+    plan = make_sk_plan(o.M, o.N, Kp / 2, sk);
+    if (plan.skBlocks > 0) {
+      plan.slabs = sk_scratch(s, kSkScratchBytes);
+      if (plan.slabs && plan.skTiles <= 1024) plan.counters = sk_counters(s);
+      if (!plan.slabs || !plan.counters) plan = make_sk_plan(o.M, o.N, Kp / 2, false);
+    }
+  }
+  plan.grouped = 1;
+  const int slots = big ? kH2Slots : kSkSlots;
+  int workers = plan.dpTiles < slots ? plan.dpTiles : slots;
+  if (workers < plan.skBlocks) workers = plan.skBlocks;
+  static const bool attr = hipFuncSetAttribute((const void*)gemm256h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               2 * kH2StageFloats * (int)sizeof(float)) == hipSuccess;
+  if (big && !attr) return W2L_EHIP;
   prof_begin(s, flops, PROF_GEMM_BF16);
-  hipLaunchKernelGGL(gemm128h_kernel, dim3((unsigned)workers), dim3(256), shmem, s, ga, gb, o, plan, workers, wide);
+  if (big) {
+    hipLaunchKernelGGL(gemm256h_kernel, dim3((unsigned)workers), dim3(512), 2 * (size_t)kH2StageFloats * sizeof(float), s, ga, gb, o,
+                       plan, workers, wide);
+  } else {
+    hipLaunchKernelGGL(gemm128h_kernel, dim3((unsigned)workers), dim3(256), 2 * (size_t)kGStageFloats * sizeof(float), s, ga, gb, o,
+                       plan, workers, wide);
+  }
   prof_end(s);
   W2L_LAUNCH_CHECK();
   return W2L_OK;

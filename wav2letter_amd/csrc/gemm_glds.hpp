@@ -126,13 +126,15 @@ __device__ __forceinline__ void g_frag(float (&f)[2][4], const float* tile, int 
 // released (two 32-row halves): ds_write_b32 in C layout, ds_read_b128 as 4 rows x 16 float4 per
 // instruction, then 16 global_store_dwordx4 per lane.  Bias / ReLU / mask / accumulate are applied on
 // the float4.  Requires a 16-byte aligned C and ldc % 4 == 0 (host-checked; `wide` false otherwise).
+// quad: which 64 x 64 quadrant of the 128 x 128 tile this wave holds (-1: threadIdx.x >> 6); slice: which 8 KiB slice of
+// `scratch` it turns its rows through (-1: the same) -- the 256 x 256 kernel runs two 4-wave groups side by side
 __device__ __forceinline__ void gemm128g_epilogue_wide(const GemmOut& out, int m0, int n0, const f32x16 (&acc)[2][2],
-                                                       float* scratch, const float (&bv)[4]) {
+                                                       float* scratch, const float (&bv)[4], int quad = -1, int slice = -1) {
   const int EPI = out.epi;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = quad >= 0 ? quad : (int)(threadIdx.x >> 6);
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int li = lane & 31, lh = lane >> 5;
-  float* sc = scratch + wave * 2048;       // [32 rows][64 cols] of this wave
+  float* sc = scratch + (slice >= 0 ? slice : wave) * 2048;       // [32 rows][64 cols] of this wave
   const int c4 = 4 * (lane & 15), rq = lane >> 4;
   const int n = n0 + wn + c4;
   const bool fullVec = n + 3 < out.N;
@@ -240,6 +242,17 @@ __device__ __forceinline__ GSeg g_segment(const SkPlan& p, int w, int workers, i
   return s;
 }
 
+// segment fields as SGPRs: left in VGPRs (the schedule's 64-bit divisions), the K-tile index makes hipcc wrap every
+// buffer-addressed LDS-DMA issue in a readfirstlane "waterfall" loop for its scalar offset (8 loops per K tile in the ISA)
+__device__ __forceinline__ GSeg g_pin(GSeg s) {
+  s.tile = __builtin_amdgcn_readfirstlane(s.tile);
+  s.kb = __builtin_amdgcn_readfirstlane(s.kb);
+  s.ke = __builtin_amdgcn_readfirstlane(s.ke);
+  s.slab = __builtin_amdgcn_readfirstlane(s.slab);
+  s.valid = __builtin_amdgcn_readfirstlane((int)s.valid) != 0;
+  return s;
+}
+
 // ABL: timing-only ablations (results are garbage) selected by W2L_GEMM_ABL for the probe tool:
 //   1 = no LDS-DMA, 2 = no per-K-tile barrier, 4 = no fragment reads in the loop, 8 = no epilogue,
 //   16 = LDS-DMA always re-reads K tile 0 (cache-resident source), 32 = LDS-DMA of the A operand only,
@@ -252,11 +265,11 @@ __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, Gemm
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int li = lane & 31, lh = lane >> 5;
-  const int w = xcd_major(blockIdx.x, workers);
+  const int w = __builtin_amdgcn_readfirstlane(xcd_major(blockIdx.x, workers));
   const size_t aStep = AKC ? 32 : (size_t)32 * aop.ld;
   const size_t bStep = BKC ? 32 : (size_t)32 * bop.ld;
 
-  GSeg seg = g_segment(plan, w, workers, 0);
+  GSeg seg = g_pin(g_segment(plan, w, workers, 0));
   if (!seg.valid) return;
   const float* qa[4];
   const float* qb[4];
@@ -288,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, Gemm
   __syncthreads();  // (drains the LDS-DMA: vmcnt(0) precedes the barrier)
 
   for (int ord = 0;; ++ord) {
-    const GSeg nxt = g_segment(plan, w, workers, ord + 1);
+    const GSeg nxt = g_pin(g_segment(plan, w, workers, ord + 1));
     // bias of this lane's four output columns, fetched at the START of the tile (its latency hides under the K loop)
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (out.epi & EPI_BIAS) {
@@ -333,6 +346,8 @@ __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, Gemm
         }
         offA = aStep * nxt.kb; offB = bStep * nxt.kb;
       }
+      const uint32_t sOffA = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(offA * 4));
+      const uint32_t sOffB = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(offB * 4));
       // 16 k-steps of 4 MFMAs; the 8 LDS-DMA pieces and the fragment reads of the next 8-k group are
       // slotted BETWEEN k-steps (one filler per gap, order pinned) so that their issue cost and latency
       // sit behind MFMA execution instead of in front of it.
@@ -356,8 +371,8 @@ __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, Gemm
             const int piece = step - 1 - g;  // steps 1,2,3,5,6,7,9,10 -> pieces 0..7
             if (BUF) {
               if (!(ABL & 1)) {
-                if (piece < 4) g_issue1_buf(ra, va[piece], (uint32_t)(offA * 4), An, wave, piece);
-                else if (piece < 8) g_issue1_buf(rb, vb[piece - 4], (uint32_t)(offB * 4), An + 4096, wave, piece - 4);
+                if (piece < 4) g_issue1_buf(ra, va[piece], sOffA, An, wave, piece);
+                else if (piece < 8) g_issue1_buf(rb, vb[piece - 4], sOffB, An + 4096, wave, piece - 4);
               }
             } else if (!(ABL & 1)) {
               if (piece < 4) g_issue1(qa[piece], (ABL & 16) ? 0 : offA, An, wave, piece);
