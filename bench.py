@@ -475,7 +475,7 @@ def cpu_baseline(nfeat, nlabel, T, batch=8):
     note(f"cpu baseline pre-probe: 1 utterance x {max(64, T // 8)} frames in {probe8:.2f} s on {cores} threads")
     if probe8 > 6.0:   # a full-length utterance would blow the budget: report the short sample, scaled
         return {"value": round((max(64, T // 8) / T) / probe8, 4), "unit": "utterances/sec", "cores": cores,
-                "kind": "proxy(torch-cpu+oracle)", "sample": f"1 utterance x {max(64, T // 8)} frames scaled to T={T} (single run, {probe8:.1f} s): "
+                "kind": "port", "port_of": "oracle/torchnet.py (torch-CPU oneDNN/MKL restatement of the network) + oracle CTC (OpenMP C)", "sample": f"1 utterance x {max(64, T // 8)} frames scaled to T={T} (single run, {probe8:.1f} s): "
                 "the host is too slow for the full sample inside the 30 s budget"}
     probe, _ = torchnet.tds_ctc_step_seconds(recipes.tds_ctc_arch(), nfeat, nlabel, 1, T, warmup=0, runs=1)
     note(f"cpu baseline probe: 1 utterance in {probe:.2f} s on {cores} threads")
@@ -484,7 +484,8 @@ def cpu_baseline(nfeat, nlabel, T, batch=8):
     runs = int(max(1, min(5, 24.0 / max(est, 1e-3) - 2)))
     warm = 2 if runs >= 3 else 1
     med, times = torchnet.tds_ctc_step_seconds(recipes.tds_ctc_arch(), nfeat, nlabel, batch, T, warmup=warm, runs=runs)
-    return {"value": round(batch / med, 4), "unit": "utterances/sec", "cores": cores, "kind": "proxy(torch-cpu+oracle)",
+    return {"value": round(batch / med, 4), "unit": "utterances/sec", "cores": cores, "kind": "port",
+            "port_of": "oracle/torchnet.py (torch-CPU oneDNN/MKL restatement of the network) + oracle CTC (OpenMP C)",
             "torch_threads": torch.get_num_threads(), "oracle_threads": O.num_threads(),
             "sample": f"{batch} utterances x {T} frames, TDS-CTC training step (forward + CTC + backward, no optimizer), "
                       f"torch-CPU oneDNN/MKL network + OpenMP oracle CTC; {warm} warm-up(s), median of {runs} run(s) "

@@ -263,6 +263,25 @@ int w2l_bgemm_bf16(const w2l_bgemm_desc* d, const float* A, const float* B, floa
  * probability 0 (the log(padMask) term of TransformerCPC.cpp:138-144). */
 int w2l_attn_softmax_forward(float* S, const float* R, const int* keyLen, int B, int H, int T, int ldr, int rlo, int W, int n0,
                              float scale, w2l_stream_t stream);
+/* The attention core of one Transformer block's FORWARD pass in one launch (mixed-precision mode; attention_fused.hip):
+ *   P = softmax_j(scale * (q_i . k_j + q_i . posTable[j - i + n0]) + log padMask),  Pd = dropout(P),  ctx_i = sum_j Pd[i][j] v_j
+ * q, k, v: [B][T][ld] fp32, head h in columns h*d .. (h+1)*d (ld = C, or 3 C for an interleaved q|k|v buffer); posTable: the
+ * [2 csz - 1][d] table in the library's internal layout or NULL; rows rlo .. rlo + W are the ones T frames reach (entries outside
+ * count as 0); keyLen as in w2l_attn_softmax_forward.  Writes P [B][H][T][T] (the backward pass reads it), Pd (same shape, only when
+ * dropP > 0: the same keep pattern as w2l_dropout_copy over P) and ctx [B][T][ldc].  Operands are rounded to bf16 where
+ * w2l_bgemm_bf16 rounds them; the result equals the unfused sequence to fp32 summation order.
+ * W2L_EUNSUPPORTED when the geometry has no fused kernel (d in {32, 256}, T <= 192, 16-byte aligned rows): run the unfused one.
+ * Replaces: TransformerCPC.cpp:117-151 (selfAttention) for the forward pass. */
+typedef struct {
+  int B, H, T, d;
+  int ld, ldc;
+  int W, n0, rlo;
+  float scale;
+  double dropP;
+  uint32_t dropSeed, dropStream;
+} w2l_attn_fused_desc;
+int w2l_attn_fused_forward(const w2l_attn_fused_desc* d, const float* q, const float* k, const float* v, const float* posTable,
+                           const int* keyLen, float* P, float* Pd, float* ctx, w2l_stream_t stream);
 /* valid keys per utterance from the batch's input sizes (any unit), as forwardSequentialModuleWithPadMask builds the mask
  * (cpc/SequentialBuilder.cpp:58-81): n_b = ceil(size_b * Tin / max size) valid input frames, resized to Tk (nearest) */
 int w2l_attn_key_lengths(const float* inputSizes, int B, int Tin, int Tk, int* keyLen, w2l_stream_t stream);

@@ -148,6 +148,81 @@ def test_relative_position_products_and_softmax(B, H, T, d, csz):
     assert rel(P0.cpu().numpy(), torch.softmax(S.double() * scale, -1).numpy()) < TOL
 
 
+@pytest.mark.parametrize("B,H,T,d,csz,p,ragged", [(2, 4, 188, 256, 460, 0.0, False), (2, 4, 188, 256, 460, 0.2, True),
+                                                   (1, 2, 64, 32, 7, 0.0, False), (2, 3, 130, 32, 460, 0.3, False),
+                                                   (2, 2, 33, 32, 0, 0.0, True), (3, 1, 1, 32, 2, 0.0, False),
+                                                   (1, 2, 190, 32, 40, 0.1, True)])
+def test_fused_attention_forward(B, H, T, d, csz, p, ragged):
+    """w2l_attn_fused_forward (scores + position term + padding mask + softmax + dropout + P V in one launch) against
+    (a) the float64 restatement of TransformerCPC.cpp:117-151's score path on the SAME bf16-rounded operands -- only the fp32
+    accumulation differs: 2e-5 of the largest magnitude for P, and ctx from the kernel's own P --, (b) the unfused launch
+    sequence (bit-identical dropout pattern: the hash runs over the same [B][H][T][T] index), incl. the recipe geometry
+    1024 / 4 heads / 919-row table / 188 frames, a ragged batch, T not a multiple of 4, one frame, no table"""
+    from oracle import transformer_oracle as TO
+    from wav2letter_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(T * 7 + d + csz)
+    Cc = H * d
+    q = torch.randn(B, T, Cc, generator=g).cuda()
+    k = torch.randn(B, T, Cc, generator=g).cuda()
+    v = torch.randn(B, T, Cc, generator=g).cuda()
+    E = (torch.randn(max(1, 2 * csz - 1), d, generator=g) * 0.5).cuda()
+    n0 = csz - 1
+    rlo = max(0, n0 - (T - 1)) if csz else 0
+    W = (min(2 * csz - 1, n0 + T) - rlo) if csz else 0
+    scale = 1.0 / np.sqrt(d)
+    keyLen = None
+    if ragged:
+        keyLen = torch.tensor([T] + [max(1, (T * (3 + b)) // (5 + b)) for b in range(1, B)], dtype=torch.int32).cuda()
+    seed, sid = 4321, 5
+    P = torch.full((B, H, T, T), float("nan"), device="cuda")
+    Pd = torch.full((B, H, T, T), float("nan"), device="cuda")
+    ctx = torch.full((B, T, Cc), float("nan"), device="cuda")
+    D = _lib.AttnFusedDesc(B=B, H=H, T=T, d=d, ld=Cc, ldc=Cc, W=W, n0=n0, rlo=rlo, scale=scale, dropP=p, dropSeed=seed, dropStream=sid)
+    st = L.w2l_attn_fused_forward(C.byref(D), q.data_ptr(), k.data_ptr(), v.data_ptr(), E.data_ptr() if csz else None,
+                                  keyLen.data_ptr() if ragged else None, P.data_ptr(), Pd.data_ptr() if p > 0 else None,
+                                  ctx.data_ptr(), _stream())
+    assert st == 0
+    # (a) float64 on bf16-rounded operands
+    r = lambda x: x.bfloat16().double()
+    qh = r(q).reshape(B, T, H, d).permute(0, 2, 1, 3)
+    kh = r(k).reshape(B, T, H, d).permute(0, 2, 1, 3)
+    vh = r(v).reshape(B, T, H, d).permute(0, 2, 1, 3)
+    S = qh @ kh.transpose(-1, -2)
+    if csz:
+        rot = TO.relative_position_rotate((qh @ r(E).t()).cpu()).cuda()
+        n = E.shape[0] // 2
+        S = S + rot[..., n:n + T]
+    S = S * scale
+    if ragged:
+        jj = torch.arange(T, device="cuda")
+        S = S.masked_fill(jj[None, None, None, :] >= keyLen.long()[:, None, None, None], float("-inf"))
+    Pref = torch.softmax(S, dim=-1)
+    assert rel(P.cpu().numpy(), Pref.cpu().numpy()) < 2e-5
+    Puse = Pd if p > 0 else P
+    cref = (r(Puse) @ vh).permute(0, 2, 1, 3).reshape(B, T, Cc)
+    assert rel(ctx.cpu().numpy(), cref.cpu().numpy()) < 2e-5
+    # (b) the unfused sequence
+    TC, TT = T * Cc, T * T
+    S2 = torch.full((B, H, T, T), float("nan"), device="cuda")
+    G = _lib.BgemmDesc(M=T, N=T, K=d, G1=B, G2=H, sam=Cc, sak=1, a1=TC, a2=d, sbk=1, sbn=Cc, b1=TC, b2=d, ldc=T, c1=H * TT, c2=TT)
+    assert L.w2l_bgemm_bf16(C.byref(G), q.data_ptr(), k.data_ptr(), S2.data_ptr(), _stream()) == 0
+    ldr = (W + 3) // 4 * 4
+    R = None
+    if csz:
+        R = torch.full((B * T * H, ldr), float("nan"), device="cuda")
+        G = _lib.BgemmDesc(M=B * T * H, N=W, K=d, G1=1, G2=1, sam=d, sak=1, sbk=1, sbn=d, ldc=ldr)
+        assert L.w2l_bgemm_bf16(C.byref(G), q.data_ptr(), E[rlo:].data_ptr(), R.data_ptr(), _stream()) == 0
+    assert L.w2l_attn_softmax_forward(S2.data_ptr(), R.data_ptr() if csz else None, keyLen.data_ptr() if ragged else None,
+                                      B, H, T, ldr, rlo, W, n0, scale, _stream()) == 0
+    assert rel(P.cpu().numpy(), S2.cpu().numpy()) < 2e-6
+    if p > 0:
+        Pd2 = torch.empty_like(S2)
+        assert L.w2l_dropout_copy(Pd2.data_ptr(), P.data_ptr(), B * H * TT, p, seed, sid, _stream()) == 0
+        assert torch.equal(Pd2, Pd)                                       # same keep pattern, same scaling
+        assert 0.5 * p < float((Pd == 0).float().mean()) - float((P == 0).float().mean()) < 1.5 * p
+
+
 @pytest.mark.parametrize("B,T,F,w,stride", [(2, 21, 32, 1, 2), (3, 20, 12, 2, 2), (2, 17, 8, 3, 2), (1, 9, 4, 3, 1)])
 def test_time_max_pool(B, T, F, w, stride):
     from wav2letter_amd import _lib

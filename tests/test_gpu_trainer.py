@@ -299,6 +299,39 @@ def test_transformer_block_at_config5_width(oracle):
     check_grads(tr, want)
 
 
+def test_transformer_block_at_config5_width_bf16(oracle):
+    """the same block in the mixed-precision mode (BASELINE config 5's dtype): every product -- the six fl::Linear GEMMs and
+    the attention products Q K^T, Q E^T, P V and their gradients -- on bf16-rounded operands with fp32 accumulation, softmax /
+    LayerNorm / CTC in fp32.  Against the UNROUNDED float64 restatement at the stated bf16 tolerance: emissions and CTC loss
+    1e-2 of the largest magnitude; parameter gradients by direction and size (a bf16 operand carries 2^-9 relative rounding,
+    a gradient is a sum of many such terms: cosine > 0.995, relative L2 < 8 %)"""
+    rng = np.random.default_rng(12)
+    nfeat, nlabel, B, T, L = 1024, 40, 2, 188, 20
+    arch = "V -1 1 NFEAT 0\nRO 2 0 3 1\nTR 1024 4096 4 460 0.0 0.0\nL 1024 NLABEL\n"
+    tr, ref, params, _ = build(arch, nfeat, nlabel, "ctc", 4, 0.0, rng, B, T, L)
+    tr.set_mixed_precision(True)
+    x = rng.normal(size=(B, 1, nfeat, T)).astype(np.float32)
+    tgt = rng.integers(0, nlabel - 1, size=(B, L)).astype(np.int32)
+    xd = torch.tensor(x.reshape(B, nfeat, T)).cuda()
+    td = torch.tensor(tgt).cuda()
+    em_ref = ref.forward(x, params)
+    em = tr.forward(xd, train=False).cpu().numpy()
+    assert rel(em, em_ref) < 1e-2
+    loss = tr.forward_backward(xd, td).cpu().numpy()
+    o = oracle.CTC(em_ref, tgt, scale_mode=4)
+    assert rel(loss, o.forward()) < 1e-2
+    want = ref.backward(o.backward().astype(np.float32), len(params))
+    g = tr.grads.cpu().numpy()
+    for i, (name, _n, _off) in enumerate(tr.param_table()):
+        if name == "tr.wk.b":   # exactly zero in exact arithmetic
+            continue
+        got = tr.export_from(i, g).astype(np.float64).reshape(-1)
+        w = np.asarray(want[i], np.float64).reshape(-1)
+        cos = float(got @ w / (np.linalg.norm(got) * np.linalg.norm(w) + 1e-300))
+        l2 = float(np.linalg.norm(got - w) / (np.linalg.norm(w) + 1e-300))
+        assert cos > 0.995 and l2 < 0.08, (name, cos, l2)
+
+
 def test_transformer_padding_mask_from_input_sizes(oracle):
     """a ragged batch: the trainer is given the utterances' input sizes and every Transformer block masks the padded keys
     (forwardSequentialModuleWithPadMask, cpc/SequentialBuilder.cpp:58-81; TransformerCPC.cpp:138-144) -- emissions, CTC loss

@@ -131,6 +131,7 @@ class _SIGS:
     w2l_bgemm_f32 = (_i, [_p, _p, _p, _p, _p])
     w2l_bgemm_bf16 = (_i, [_p, _p, _p, _p, _p])
     w2l_attn_softmax_forward = (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p])
+    w2l_attn_fused_forward = (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p])
     w2l_attn_key_lengths = (_i, [_p, _i, _i, _i, _p, _p])
     w2l_attn_softmax_backward = (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p])
     w2l_pool_time_forward = (_i, [_p, _p, _i, _i, _i, _i, _i, _p])
@@ -164,6 +165,11 @@ class BgemmDesc(C.Structure):  # w2l_bgemm_desc
     _fields_ = ([(n, C.c_int) for n in ("M", "N", "K", "G1", "G2")] +
                 [(n, C.c_longlong) for n in ("sam", "sak", "a1", "a2", "sbk", "sbn", "b1", "b2", "ldc", "c1", "c2")] +
                 [("accumulate", C.c_int)])
+
+
+class AttnFusedDesc(C.Structure):  # w2l_attn_fused_desc
+    _fields_ = ([(n, C.c_int) for n in ("B", "H", "T", "d", "ld", "ldc", "W", "n0", "rlo")] + [("scale", C.c_float), ("dropP", C.c_double),
+                ("dropSeed", C.c_uint32), ("dropStream", C.c_uint32)])
 
 
 def check(status, what=""):

@@ -886,6 +886,23 @@ class TransformerLayer : public Layer {
     w2lCheck(w2l_linear_forward(M, C, C, x, wv.w(cx), bv.w(cx), v, 0, s), "tr v");
     }
     const long long TC = (long long)T * C, TT = (long long)T * T;
+    const int* keyLen = nullptr;
+    if (cx.inputSizes) {  // padding mask of the keys (cpc/SequentialBuilder.cpp:58-81, TransformerCPC.cpp:138-144)
+      int* kl = (int*)(ar + klOff);
+      w2lCheck(w2l_attn_key_lengths(cx.inputSizes, B, cx.inputT, T, kl, s), "tr key lengths");
+      keyLen = kl;
+    }
+    const float scale = (float)(1.0 / std::sqrt((double)d));
+    bool fused = false;
+    if (mixed) {   // scores, position term, softmax, dropout and P V in one launch where the geometry has a fused kernel
+      w2l_attn_fused_desc fd{};
+      fd.B = B; fd.H = nH; fd.T = T; fd.d = d; fd.ld = C; fd.ldc = C; fd.W = W; fd.n0 = n0; fd.rlo = rlo; fd.scale = scale;
+      fd.dropP = pd; fd.dropSeed = cx.seed; fd.dropStream = (uint32_t)rngStream;
+      const int st = w2l_attn_fused_forward(&fd, q, k, v, csz > 0 ? pe.w(cx) : nullptr, keyLen, S, pd > 0 ? Pd : nullptr, ctx, s);
+      if (st != W2L_EUNSUPPORTED) w2lCheck(st, "tr fused attention");
+      fused = st == W2L_OK;
+    }
+    if (!fused) {
     {  // S[b][h][i][j] = q_i . k_j
       w2l_bgemm_desc g = heads(T, T, d);
       g.sam = C; g.sak = 1; g.a1 = TC; g.a2 = d; g.sbk = 1; g.sbn = C; g.b1 = TC; g.b2 = d; g.ldc = T; g.c1 = nH * TT; g.c2 = TT;
@@ -896,18 +913,13 @@ class TransformerLayer : public Layer {
       g.M = M * nH; g.N = W; g.K = d; g.G1 = g.G2 = 1; g.sam = d; g.sak = 1; g.sbk = 1; g.sbn = d; g.ldc = ldr;
       w2lCheck(bg(&g, q, pe.w(cx) + (size_t)rlo * d, R, s), "tr qE");
     }
-    const int* keyLen = nullptr;
-    if (cx.inputSizes) {  // padding mask of the keys (cpc/SequentialBuilder.cpp:58-81, TransformerCPC.cpp:138-144)
-      int* kl = (int*)(ar + klOff);
-      w2lCheck(w2l_attn_key_lengths(cx.inputSizes, B, cx.inputT, T, kl, s), "tr key lengths");
-      keyLen = kl;
-    }
-    w2lCheck(w2l_attn_softmax_forward(S, csz > 0 ? R : nullptr, keyLen, B, nH, T, ldr, rlo, W, n0, (float)(1.0 / std::sqrt((double)d)), s), "tr softmax");
+    w2lCheck(w2l_attn_softmax_forward(S, csz > 0 ? R : nullptr, keyLen, B, nH, T, ldr, rlo, W, n0, scale, s), "tr softmax");
     if (pd > 0) w2lCheck(w2l_dropout_copy(Pd, S, (size_t)B * nH * TT, pd, cx.seed, rngStream, s), "tr attn dropout");
     {  // ctx_i = sum_j P[i][j] v_j
       w2l_bgemm_desc g = heads(T, d, T);
       g.sam = T; g.sak = 1; g.a1 = nH * TT; g.a2 = TT; g.sbk = C; g.sbn = 1; g.b1 = TC; g.b2 = d; g.ldc = C; g.c1 = TC; g.c2 = d;
       w2lCheck(bg(&g, pd > 0 ? Pd : S, v, ctx, s), "tr pv");
+    }
     }
     if (mixed) {
       ctxImg.convert(cx, ar, ctx, "tr ctx images");
