@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--stress-frames", type=int, default=1500)
     ap.add_argument("--no-c4", action="store_true", help="skip the conv_glu LibriSpeech ASG step (BASELINE config 4) leg")
     ap.add_argument("--no-c3", action="store_true", help="skip the streaming TDS fp32 / bf16 step (BASELINE config 3) leg")
+    ap.add_argument("--no-input-pipeline", action="store_true", help="skip the prefetching-loader leg (SURVEY 8 f3)")
     ap.add_argument("--no-c5", action="store_true", help="skip the Transformer-CTC fp32 / bf16 step (BASELINE config 5) leg")
     ap.add_argument("--no-oracle-checks", action="store_true", help="skip the oracle comparison of the stress / config-4 losses")
     ap.add_argument("--cpu-baseline-batch", type=int, default=8)
@@ -492,6 +493,70 @@ def cpu_baseline(nfeat, nlabel, T, batch=8):
                       f"({', '.join(f'{t:.2f}' for t in times)} s); {time.perf_counter() - t0:.1f} s of CPU work"}
 
 
+def input_pipeline_leg(device, tr, tgt, fl, B, T, nfeat, ms_step_resident, steps=10):
+    """SURVEY 8 f3 'input pipeline at speed': the prefetching loader (wav2letter_amd/loader.py: decode threads -> pinned ring
+    -> H2D on a side stream -> MFSC on the device) timed alone and underneath the headline training step.  Synthetic 16-bit
+    mono WAV files of exactly T frames (15 s at T = 1500), written once to a temporary directory and re-read every batch
+    (page-cache resident: this measures decode + pad + PCIe + MFSC, not a disk)."""
+    import shutil
+    import tempfile
+    import wave
+    import numpy as np
+    from wav2letter_amd.features import Mfsc
+    from wav2letter_amd.loader import PrefetchLoader, read_audio_int16
+    mfsc = Mfsc(num_filters=nfeat, device=device)
+    ns = (T - 1) * mfsc.S + mfsc.N
+    tmp = tempfile.mkdtemp(prefix="w2l_bench_wav_")
+    try:
+        rng = np.random.default_rng(5)
+        paths = []
+        for i in range(2 * B):
+            pth = os.path.join(tmp, f"u{i:03d}.wav")
+            with wave.open(pth, "wb") as w:
+                w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+                w.writeframes((rng.normal(size=ns) * 3000).astype("<i2").tobytes())
+            paths.append(pth)
+        nb = steps + 2
+        batches = [[(n * B + j) % len(paths) for j in range(B)] for n in range(nb)]
+        workers = min(8, host_threads())
+        mk = lambda: PrefetchLoader(paths, batches, mfsc, device=device, workers=workers, depth=3, read=read_audio_int16)
+        # alone
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        for feats, sizes, _ids in mk():
+            n += feats.shape[0]
+        torch.cuda.synchronize()
+        alone = time.perf_counter() - t0
+        assert tuple(feats.shape) == (B, nfeat, T), tuple(feats.shape)
+        # underneath the training step (2 untimed batches first)
+        it = iter(mk())
+        for _ in range(2):
+            feats, sizes, _ids = next(it)
+            tr.forward_backward(feats, tgt)
+            tr.update(lr=fl["lr"], momentum=fl["momentum"], max_grad_norm=fl["maxgradnorm"], total_batch=B)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        k = 0
+        for feats, sizes, _ids in it:
+            loss = tr.forward_backward(feats, tgt)
+            tr.update(lr=fl["lr"], momentum=fl["momentum"], max_grad_norm=fl["maxgradnorm"], total_batch=B)
+            k += 1
+        torch.cuda.synchronize()
+        fed = (time.perf_counter() - t0) / max(1, k)
+        return {"loader_alone": {"utterances_per_sec": round(n / alone, 1), "ms_per_batch": round(alone / nb * 1e3, 2),
+                                 "pcm_MB_per_sec": round(n * ns * 2 / alone / 1e6, 1)},
+                "step_fed_by_loader": {"ms_per_step": round(fed * 1e3, 3), "utterances_per_sec": round(B / fed, 2), "steps": k,
+                                       "vs_resident_input": round(fed * 1e3 / ms_step_resident, 4),
+                                       "finite": bool(torch.isfinite(loss).all().item())},
+                "needed_utterances_per_sec": round(B / (ms_step_resident * 1e-3), 1),
+                "workers": workers, "depth": 3,
+                "source": f"{len(paths)} synthetic 16-bit mono WAV files x {ns} samples ({ns / 16000:.2f} s), page-cache resident; "
+                          "int16 over PCIe, scaling + MFSC (two GEMMs) on the device, side stream"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def dist_selftest(a):
     """launcher + rendezvous + the arena all-reduce, nothing else: every rank fills a flat gradient arena whose tail
     carries its local batch size (parallel.GradientArena, the layout Trainer.grads_full has), ONE all-reduce sums both.
@@ -680,6 +745,8 @@ def main():
             out[key] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
 
+    if world == 1 and not a.no_input_pipeline:
+        leg("input_pipeline", lambda: input_pipeline_leg(device, tr, tgt, fl, B, T, nfeat, ms_step))
     if not a.no_asg:
         leg("asg_loss_ms_per_step", lambda: asg_criterion_ms(device))
         if world == 1:

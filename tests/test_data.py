@@ -106,3 +106,30 @@ def test_cpp_header_mirror_of_list_and_partitioning(tmp_path):
     subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", os.path.join(root, "tests", "cpp", "data_test.cpp"), "-o", exe], check=True)
     assert "data ok" in subprocess.run([exe], capture_output=True, text=True, check=True).stdout
     assert data.partition_round_robin(20, 1, 2, 4) == [4, 5, 6, 7, 12, 13, 14, 15, 18, 19]
+
+
+def test_read_audio_int16_keeps_pcm_words(tmp_path):
+    """the prefetching loader's decoder (wav2letter_amd/loader.py): 16-bit mono WAV / raw PCM stay int16 (scaled on the device),
+    equal to data.read_audio * 32768; anything else falls back to the float decoder"""
+    import wave
+    import numpy as np
+    from wav2letter_amd import data
+    from wav2letter_amd.loader import read_audio_int16
+    a = (np.arange(-500, 500) * 37).astype(np.int16)
+    p = str(tmp_path / "a.wav")
+    with wave.open(p, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes(a.astype("<i2").tobytes())
+    got, rate = read_audio_int16(p)
+    assert got.dtype == np.int16 and rate == 16000 and np.array_equal(got, a)
+    f, _ = data.read_audio(p)
+    assert np.array_equal(f, a.astype(np.float32) / 32768.0)
+    a.astype("<i2").tofile(str(tmp_path / "b.raw"))
+    got, rate = read_audio_int16(str(tmp_path / "b.raw"))
+    assert got.dtype == np.int16 and np.array_equal(got, a)
+    st = str(tmp_path / "s.wav")
+    with wave.open(st, "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes(np.stack([a, a], 1).astype("<i2").tobytes())
+    got, _ = read_audio_int16(st)
+    assert got.dtype == np.float32 and len(got) == len(a)

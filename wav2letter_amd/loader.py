@@ -1,0 +1,161 @@
+"""Prefetching input pipeline: list file -> decoded audio -> padded batch -> device -> MFSC features,
+running AHEAD of the training step so that the step never waits for the host.
+
+Reference: the Trainer builds its datasets with `--nthread` prefetch workers and consumes `[input, target, sizes...]`
+batches that are already on the device (recipes/slimIPL/src/Train.cpp:277-339: featurisation parameters, list datasets,
+batching; the `fl::PrefetchDataset` wrapper is un-vendored).  Design here, MI355X-first rather than a thread pool of CPU
+featurisers: the host only DECODES and PADS (int16 PCM, 2 bytes a sample over PCIe), the device does the arithmetic --
+
+  decode threads (file -> int16 / float32 samples)           `workers` threads, order-preserving futures
+  assembler thread: pad a batch into a PINNED ring buffer    `depth` buffers: batch n + depth reuses buffer n only after
+    -> async H2D copy on a SIDE stream                        its copy completed (event)
+    -> int16 -> float32 scaling, MFSC (features.Mfsc: two GEMMs + two elementwise launches) on that stream
+    -> event; (features, sizes, sample indices) into a bounded queue
+  consumer (the training loop): `for feats, sizes, ids in loader:` -- the current stream waits for the batch's event, the
+    tensors are marked as used by it (`record_stream`), no host synchronisation anywhere.
+
+The step at BASELINE config 2 consumes 315 utterances/s per GPU (15 s each: 151 MB/s of PCM); `bench.py`'s `input_pipeline`
+leg times this loader alone and underneath the training step.
+"""
+import queue
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+from . import data as D
+
+
+class PrefetchLoader:
+    """iterate over `batches` (lists of sample indices into `samples`) yielding (features [B][F][T] float32 on `device`,
+    sizes [B] float32 on `device` -- the utterances' sample counts, the batch's `inputSizes` --, the batch's sample indices).
+
+    samples: objects with a `.path` (data.Sample) or plain paths; mfsc: features.Mfsc on `device`; `read` decodes one file to
+    (float32 or int16 samples, rate) -- default data.read_audio."""
+
+    def __init__(self, samples, batches, mfsc, device="cuda", workers=4, depth=3, read=None, sample_rate=16000):
+        if depth < 2:
+            raise ValueError("PrefetchLoader: depth must be >= 2 (one batch in use, one in flight)")
+        self.paths = [s.path if hasattr(s, "path") else s for s in samples]
+        self.batches = [list(b) for b in batches]
+        self.mfsc, self.device = mfsc, torch.device(device)
+        self.workers, self.depth, self.rate = int(workers), int(depth), int(sample_rate)
+        self.read = read or D.read_audio
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._q = None
+        self._thread = None
+        self._stop = threading.Event()
+        self._error = None
+
+    def __len__(self):
+        return len(self.batches)
+
+    def _decode(self, i):
+        a, rate = self.read(self.paths[i])
+        if rate != self.rate:
+            raise ValueError(f"{self.paths[i]}: sample rate {rate}, the pipeline is configured for {self.rate}")
+        return a
+
+    def _assemble(self):
+        try:
+            pinned = [None] * self.depth
+            done = [None] * self.depth          # event: the H2D copy out of pinned[i] has completed
+            with ThreadPoolExecutor(self.workers) as pool:
+                # decode futures run at most `depth` batches ahead of the assembler
+                ahead = []
+                nxt = 0
+
+                def submit_until(n):
+                    nonlocal nxt
+                    while nxt < min(n, len(self.batches)):
+                        ahead.append([pool.submit(self._decode, i) for i in self.batches[nxt]])
+                        nxt += 1
+
+                submit_until(self.depth)
+                for n, idx in enumerate(self.batches):
+                    if self._stop.is_set():
+                        break
+                    audios = [f.result() for f in ahead.pop(0)]
+                    submit_until(n + 1 + self.depth)
+                    lens = np.array([len(a) for a in audios], np.float32)
+                    longest = int(lens.max())
+                    as_i16 = all(a.dtype == np.int16 for a in audios)
+                    slot = n % self.depth
+                    if done[slot] is not None:
+                        done[slot].synchronize()   # the copy that last used this pinned buffer (depth batches ago)
+                    need = len(audios) * longest
+                    dt = torch.int16 if as_i16 else torch.float32
+                    if pinned[slot] is None or pinned[slot].numel() < need or pinned[slot].dtype != dt:
+                        pinned[slot] = torch.empty(max(need, 1), dtype=dt).pin_memory()
+                    host = pinned[slot][:need].view(len(audios), longest)
+                    hv = host.numpy()
+                    for b, a in enumerate(audios):
+                        hv[b, :len(a)] = a
+                        hv[b, len(a):] = 0
+                    with torch.cuda.stream(self.stream):
+                        dev = host.to(self.device, non_blocking=True)
+                        ev_copy = torch.cuda.Event()
+                        ev_copy.record(self.stream)
+                        done[slot] = ev_copy
+                        audio = dev.float().mul_(1.0 / 32768.0) if as_i16 else dev
+                        feats = self.mfsc(audio)
+                        sizes = torch.from_numpy(lens).to(self.device, non_blocking=True)
+                        ready = torch.cuda.Event()
+                        ready.record(self.stream)
+                    self._put((feats, sizes, idx, ready))
+            self._put(None)
+        except BaseException as e:   # surfaced in the consumer
+            self._error = e
+            self._put(None)
+
+    def _put(self, item):
+        while not self._stop.is_set():
+            try:
+                self._q.put(item, timeout=0.1)
+                return
+            except queue.Full:
+                continue
+
+    def __iter__(self):
+        self.close()
+        self._stop.clear()
+        self._error = None
+        self._q = queue.Queue(maxsize=self.depth - 1)
+        self._thread = threading.Thread(target=self._assemble, name="w2l-prefetch", daemon=True)
+        self._thread.start()
+        try:
+            while True:
+                item = self._q.get()
+                if item is None:
+                    if self._error is not None:
+                        raise self._error
+                    return
+                feats, sizes, idx, ready = item
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ready)
+                feats.record_stream(cur)
+                sizes.record_stream(cur)
+                yield feats, sizes, idx
+        finally:
+            self.close()
+
+    def close(self):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join()
+            self._thread = None
+
+
+def read_audio_int16(path):
+    """16-bit PCM WAV / raw files as int16 (the loader scales on the device: half the PCIe bytes); anything else through
+    data.read_audio (float32)"""
+    low = path.lower()
+    if low.endswith(".wav"):
+        import wave
+        with wave.open(path, "rb") as w:
+            if w.getsampwidth() == 2 and w.getnchannels() == 1:
+                return np.frombuffer(w.readframes(w.getnframes()), "<i2"), w.getframerate()
+    elif low.endswith(".raw") or low.endswith(".pcm"):
+        return np.fromfile(path, "<i2"), 16000
+    return D.read_audio(path)
