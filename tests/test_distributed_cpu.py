@@ -208,3 +208,47 @@ def test_overlapped_reducer_on_the_real_trainer_arena_two_gloo_ranks():
     ret = mgr.dict()
     mp.spawn(_arena_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     assert ret[0] == ret[1]
+
+
+def _bf16_bucket_worker(rank, world, port, ret):
+    """bf16 gradient buckets (mixed-precision mode) on a small trainer arena over gloo: every rank ends with
+    fp32(bf16(g_0) + bf16(g_1)) -- bf16 operands, the sum rounded once to bf16 --, identical on both ranks, half the bytes per
+    gradient collective; the batch-size tail is reduced in fp32 and stays exact"""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from wav2letter_amd import parallel
+    from wav2letter_amd.trainer import Trainer
+    parallel.init_distributed("gloo")
+    arch = "V -1 NFEAT 1 0\nC2 1 4 5 1 2 1 -1 -1\nR\nDO 0.1\nLN 0 1 2\nTDS 4 5 8 0.1 64\nV 0 32 1 0\nRO 1 0 3 2\nL 32 NLABEL\n"
+    tr = Trainer(arch, 8, 12, "ctc", 4, device="cpu")
+    n = tr.n_floats
+    tr.grads_full = torch.zeros(tr.L.w2l_trainer_grad_floats(tr.h))
+    tr.grads = tr.grads_full[:n]
+    red32 = parallel.OverlappedReducer(tr, n_buckets=3)
+    red = parallel.OverlappedReducer(tr, n_buckets=3, bf16=True)
+    assert red.offsets == red32.offsets
+    b32, b16 = red32.bucket_bytes(), red.bucket_bytes()
+    assert sum(b16) == 2 * n + 16 and sum(b32) == 4 * (n + 4) and len(b16) == len(b32) + 1 and b16[1] == 16
+    gen = torch.Generator().manual_seed(100 + rank)
+    mine = torch.randn(n, generator=gen) * 3.0
+    tr.grads.copy_(mine)
+    tr.grads_full[n] = 37.0 + 4 * rank                   # batch sizes whose sum (78) a bf16 sum could not be trusted with in general
+    red.reduce()
+    assert tr.grads_full[n].item() == 78.0
+    parts = []
+    for r in range(world):
+        g = torch.randn(n, generator=torch.Generator().manual_seed(100 + r)) * 3.0
+        parts.append(g.bfloat16())
+    want = (parts[0].float() + parts[1].float()).bfloat16().float()
+    assert torch.equal(tr.grads, want)
+    ret[rank] = float(tr.grads.double().sum().item())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bf16_gradient_buckets_two_gloo_ranks():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bf16_bucket_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret[0] == ret[1]

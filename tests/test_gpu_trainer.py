@@ -807,6 +807,16 @@ def test_gradient_bucket_events_and_single_rank_rccl():
         assert torch.equal(tr.params, ref.params)
         with pytest.raises(Exception):
             tr.wait_bucket(99, red.comm)
+        # bf16 buckets (mixed-precision mode): one rank's "sum" is its own gradients rounded to bf16; the batch-size tail
+        # goes through its own fp32 collective and stays exact
+        tb = make()
+        rb = OverlappedReducer(tb, n_buckets=3, bf16=True)
+        tb.forward_backward(x, tgt)
+        rb.reduce()
+        torch.cuda.synchronize()
+        assert torch.equal(tb.grads, g_ref.bfloat16().float())
+        assert tb.grads_full[tb.n_floats].item() == float(B)
+        assert sum(rb.bucket_bytes()) == 2 * tb.n_floats + 16
         tr.set_grad_buckets([])  # hooks off again
         tr.forward_backward(x, tgt)
     finally:

@@ -5,6 +5,7 @@ ROCm; "gloo" for the CPU tests).  Mirrors the reference's use of fl::distributed
 collective per step over the flat gradient arena instead of dozens of ~20 MB buckets
 (the batch-size scalar rides in the arena tail).
 """
+import contextlib
 import os
 
 import torch
@@ -122,7 +123,7 @@ class OverlappedReducer:
     still computing the backward pass of the first layers.  Few large buckets (default 4, ~200 MB each for
     TDS-CTC): xGMI rings are per-link bound, large messages keep them at line rate."""
 
-    def __init__(self, trainer, n_buckets=4):
+    def __init__(self, trainer, n_buckets=4, bf16=False):
         self.tr = trainer
         offs = bucket_offsets(trainer.param_table(), trainer.n_floats, n_buckets)
         # the last bucket runs over the 4-float tail too: tail[0] = local batch size, summed with the gradients
@@ -137,22 +138,59 @@ class OverlappedReducer:
         else:
             trainer.bucket_offsets = list(offs)
             self.comm = None
+        # bf16 buckets (the mixed-precision mode: fl's AMP all-reduces half-precision gradients, fp32 master weights stay local;
+        # recipes/slimIPL/src/Train.cpp:1681-1760): a bucket's gradients are rounded to bf16 on the side stream, summed in
+        # bf16 -- half the bytes over xGMI -- and written back as fp32; the 4-float tail (the batch size must stay exact) is
+        # reduced in fp32 by a collective of its own.
+        self.bf16 = bool(bf16)
+        self._stage = {}
+
+    def _bf16_stage(self, k, n):
+        b = self._stage.get(k)
+        if b is None or b.numel() != n:
+            b = torch.empty(n, dtype=torch.bfloat16, device=self.tr.grads_full.device)
+            self._stage[k] = b
+        return b
 
     def bucket_bytes(self):
-        """bytes each collective of a step moves, in issue order (last bucket first)"""
-        return [4 * (self.offsets[k + 1] - self.offsets[k]) for k in reversed(range(len(self.offsets) - 1))]
+        """bytes each collective of a step moves, in issue order (last bucket first; bf16 mode: the fp32 tail collective
+        follows the last bucket's)"""
+        nf = self.tr.n_floats
+        out = []
+        for k in reversed(range(len(self.offsets) - 1)):
+            lo, hi = self.offsets[k], self.offsets[k + 1]
+            if not self.bf16:
+                out.append(4 * (hi - lo))
+            else:
+                out.append(2 * (min(hi, nf) - lo))
+                if hi > nf:
+                    out.append(4 * (hi - nf))
+        return out
 
     def reduce(self):
         """call right after trainer.forward_backward(); returns when every collective is enqueued and the
         current (compute) stream has been made to wait for them"""
         works = []
         g = self.tr.grads_full
+        nf = self.tr.n_floats
         for k in reversed(range(len(self.offsets) - 1)):
+            lo, hi = self.offsets[k], self.offsets[k + 1]
             if self.on_gpu:
                 self.tr.wait_bucket(k, self.comm)
-                with torch.cuda.stream(self.comm):
-                    works.append(dist.all_reduce(g[self.offsets[k]:self.offsets[k + 1]], async_op=True))
-            else:
-                works.append(dist.all_reduce(g[self.offsets[k]:self.offsets[k + 1]], async_op=True))
+            ctx = torch.cuda.stream(self.comm) if self.on_gpu else contextlib.nullcontext()
+            with ctx:
+                if not self.bf16:
+                    works.append(dist.all_reduce(g[lo:hi], async_op=True))
+                    continue
+                hg = min(hi, nf)
+                stage = self._bf16_stage(k, hg - lo)
+                stage.copy_(g[lo:hg])                       # round to nearest even
+                w = dist.all_reduce(stage, async_op=True)
+                w.wait()                                    # stream-ordered on the GPU, blocking on the host
+                g[lo:hg].copy_(stage)
+                if hi > nf:
+                    works.append(dist.all_reduce(g[nf:hi], async_op=True))
         for w in works:
             w.wait()
+        if self.on_gpu and self.bf16:
+            torch.cuda.current_stream(self.tr.device).wait_stream(self.comm)
