@@ -180,6 +180,11 @@ int w2l_bf16_convert(const float* x, size_t rows, int cols, size_t ldx, uint16_t
                      uint16_t* transposed, size_t ldTrans, w2l_stream_t stream);
 int w2l_gemm_bf16(int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B, int ldb, float* C, int ldc,
                   const float* bias, int relu, const w2l_gemm_epilogue* epilogue, w2l_stream_t stream);
+/* `groups` (1 .. 4) products of ONE shape in one launch, C_g [M][N] = A_g . B_g^T (+ bias_g): the tiles of all problems share the
+ * persistent grid (a Transformer block's four C x C weight gradients at M = 3008 frames are 64 tiles each -- a quarter of the chip
+ * one at a time).  A, B, C, bias are HOST arrays of device pointers (bias, or single entries of it, may be NULL). */
+int w2l_gemm_bf16_grouped(int groups, int M, int N, int K, const uint16_t* const* A, int lda, const uint16_t* const* B, int ldb,
+                          float* const* C, int ldc, const float* const* bias, w2l_stream_t stream);
 int w2l_colsum(const float* x, float* out, size_t M, int N, w2l_stream_t stream); /* bias grads */
 
 /* fl::Conv2D kw x 1 over time (arch tokens C / C2 / TDS). x [B][T][H][Cin],

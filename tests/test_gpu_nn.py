@@ -819,6 +819,27 @@ def test_gemm_bf16_operand_storage(M, N, K):
     assert rel(ops.gemm_bf16(Ab, Bb, K, bias=bias, relu=True), np.maximum(wb, 0)) < 2e-5
 
 
+@pytest.mark.parametrize("n,M,N,K", [(4, 1024, 1024, 3008), (3, 3008, 1024, 1024), (2, 200, 136, 70), (1, 129, 260, 64), (4, 64, 64, 4100)])
+def test_gemm_bf16_grouped(n, M, N, K):
+    """w2l_gemm_bf16_grouped: up to four products of one shape in one launch (the Transformer block's four projection weight
+    gradients / its q, k, v projections), each equal to the single launch bit for bit, with and without biases"""
+    from wav2letter_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(n * 1000 + M + K)
+    As = [ops.bf16_convert(torch.randn(M, K, generator=g).cuda())[0] for _ in range(n)]
+    Bs = [ops.bf16_convert((torch.randn(N, K, generator=g) / K ** 0.5).cuda())[0] for _ in range(n)]
+    if n > 1:
+        As[1] = As[0]                                     # shared operand (x images feed q, k and v)
+    biases = [torch.randn(N, generator=g).cuda() if i != 1 else None for i in range(n)]
+    outs = ops.gemm_bf16_grouped(As, Bs, K)
+    for i in range(n):
+        assert torch.equal(outs[i], ops.gemm_bf16(As[i], Bs[i], K))
+    outs = ops.gemm_bf16_grouped(As, Bs, K, biases)
+    for i in range(n):
+        assert torch.equal(outs[i], ops.gemm_bf16(As[i], Bs[i], K, bias=biases[i]))
+    with pytest.raises(Exception):
+        ops.gemm_bf16_grouped((As * 5)[:5], (Bs * 5)[:5], K)   # more than four problems
+
+
 @pytest.mark.parametrize("M,N,K", [(700, 520, 333), (4000, 3100, 333)])
 def test_gemm_bf16_operand_storage_epilogues(oracle, M, N, K):
     """the fp32 engine's epilogue on the bf16 product: mask, addend, accumulate into C, dropout (the library's stateless hash:

@@ -103,6 +103,7 @@ class _SIGS:
     w2l_set_matmul_precision = (_i, [_i])
     w2l_bf16_convert = (_i, [_p, _sz, _i, _sz, _p, _sz, _p, _sz, _p])
     w2l_gemm_bf16 = (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p])
+    w2l_gemm_bf16_grouped = (_i, [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p])
     w2l_tds_conv_bf16_image_elems = (_sz, [_p])
     w2l_tds_conv_bf16_prepare = (_i, [_p, _p, _p, _p, _p])
     w2l_tds_conv_bf16_forward = (_i, [_p, _p, _p, _p, _p, _i, _p])

@@ -314,6 +314,13 @@ W2L_API int w2l_gemm_bf16(int M, int N, int K, const uint16_t* A, int lda, const
   return launch128h(A, lda, B, ldb, o, epi, (hipStream_t)stream);
 }
 
+// `groups` (1 .. 4) products of ONE shape in one launch: C_g = A_g . B_g^T (+ bias_g); A, B, C, bias: host arrays of device pointers
+W2L_API int w2l_gemm_bf16_grouped(int groups, int M, int N, int K, const uint16_t* const* A, int lda, const uint16_t* const* B, int ldb,
+                                  float* const* C, int ldc, const float* const* bias, w2l_stream_t stream) {
+  if (!A || !B || !C) return W2L_EINVAL;
+  return launch128h_grouped(groups, A, lda, B, ldb, C, ldc, bias, M, N, K, (hipStream_t)stream);
+}
+
 // generic entry (tests / benchmarks): C[M][N] = op(A) op(B) (+bias)(relu)
 W2L_API int w2l_gemm_f32(int M, int N, int K, const float* A, int lda, int a_kcontig, const float* B,
                          int ldb, int b_kcontig, float* C, int ldc, const float* bias, int relu,

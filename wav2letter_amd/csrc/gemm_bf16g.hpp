@@ -34,7 +34,20 @@ __device__ __forceinline__ bf16x8v_t h_frag(const float* tile, int row, int s, i
 
 // aop / bop: bf16 matrices viewed as float matrices of half the width (p, ld in floats = bf16 elements / 2); plan.kTiles
 // counts 64-k tiles.  Same launch geometry as gemm128g_kernel.
-__global__ __launch_bounds__(256, 2) void gemm128h_kernel(GOp aop, GOp bop, GemmOut out, SkPlan plan, int workers, int wide) {
+// GROUPED launches (GRP): up to kHMaxGroups problems of the SAME shape (own A, B, C, bias) share one persistent grid -- tile
+// index t = g * grp.tiles + local tile.  The weight gradients of a Transformer block's four C x C projections are 64 tiles
+// each at M = 3008 frames: one at a time they occupy a quarter of the chip (38 us each, 164 TFLOP/s), together they fill it.
+constexpr int kHMaxGroups = 4;
+struct HGroups {
+  const float* a[kHMaxGroups];
+  const float* b[kHMaxGroups];
+  float* c[kHMaxGroups];
+  const float* bias[kHMaxGroups];
+  int n = 0, tiles = 0;      // problems, tiles per problem
+};
+
+template <bool GRP>
+__global__ __launch_bounds__(256, 2) void gemm128h_kernel(GOp aop, GOp bop, GemmOut out, SkPlan plan, int workers, int wide, HGroups grp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -46,8 +59,15 @@ __global__ __launch_bounds__(256, 2) void gemm128h_kernel(GOp aop, GOp bop, Gemm
   GSeg seg = g_pin(g_segment(plan, w, workers, 0));
   if (!seg.valid) return;
   uint32_t va[4], vb[4];
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)aop.p, 0, (int)aop.bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)bop.p, 0, (int)bop.bytes, 0x00020000);
+  int grpIdx = 0, grpNext = 0;
+  if (GRP) {
+    grpIdx = seg.tile / grp.tiles;
+    seg.tile -= grpIdx * grp.tiles;
+    aop.p = grp.a[grpIdx]; bop.p = grp.b[grpIdx];
+  }
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)aop.p, 0, (int)aop.bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)bop.p, 0, (int)bop.bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t raN = ra, rbN = rb;
   int bx, by;
   sk_tile_xy(plan, seg.tile, bx, by);
   g_init_offs<true>(va, aop, bx * 128, wave, lane);
@@ -61,9 +81,19 @@ __global__ __launch_bounds__(256, 2) void gemm128h_kernel(GOp aop, GOp bop, Gemm
   __syncthreads();  // (drains the LDS-DMA: vmcnt(0) precedes the barrier)
 
   for (int ord = 0;; ++ord) {
-    const GSeg nxt = g_pin(g_segment(plan, w, workers, ord + 1));
+    GSeg nxt = g_pin(g_segment(plan, w, workers, ord + 1));
+    if (GRP) {
+      if (nxt.valid) {
+        grpNext = nxt.tile / grp.tiles;
+        nxt.tile -= grpNext * grp.tiles;
+        raN = __builtin_amdgcn_make_buffer_rsrc((void*)grp.a[grpNext], 0, (int)aop.bytes, 0x00020000);
+        rbN = __builtin_amdgcn_make_buffer_rsrc((void*)grp.b[grpNext], 0, (int)bop.bytes, 0x00020000);
+      }
+      out.C = grp.c[grpIdx];
+      out.bias = grp.bias[grpIdx];
+    }
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (out.epi & EPI_BIAS) {
+    if ((out.epi & EPI_BIAS) && out.bias) {
       const int nb = by * 128 + wn + 4 * (lane & 15);
 #pragma unroll
       for (int e = 0; e < 4; ++e) bv[e] = nb + e < out.N ? out.bias[nb + e] : 0.f;
@@ -83,9 +113,11 @@ __global__ __launch_bounds__(256, 2) void gemm128h_kernel(GOp aop, GOp bop, Gemm
       // what goes to the other stage during this iteration: the next K tile, or the first K tile of the next segment, or
       // (very last iteration of this worker) a harmless re-load of this tile
       uint32_t offA = kStepBytes * (uint32_t)kt, offB = offA;
+      bool toNext = false;   // this iteration's pieces belong to the next segment (GRP: possibly another problem's operands)
       if (kt + 1 < seg.ke) {
         offA += kStepBytes; offB += kStepBytes;
       } else if (nxt.valid) {
+        toNext = true;
         int nbx, nby;
         sk_tile_xy(plan, nxt.tile, nbx, nby);
         g_init_offs<true>(va, aop, nbx * 128, wave, lane);
@@ -94,10 +126,11 @@ __global__ __launch_bounds__(256, 2) void gemm128h_kernel(GOp aop, GOp bop, Gemm
       }
       offA = (uint32_t)__builtin_amdgcn_readfirstlane((int)offA);
       offB = (uint32_t)__builtin_amdgcn_readfirstlane((int)offB);
+      const __amdgpu_buffer_rsrc_t rA = (GRP && toNext) ? raN : ra, rB = (GRP && toNext) ? rbN : rb;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        g_issue1_buf(ra, va[j], offA, An, wave, j);
-        g_issue1_buf(rb, vb[j], offB, An + 4096, wave, j);
+        g_issue1_buf(rA, va[j], offA, An, wave, j);
+        g_issue1_buf(rB, vb[j], offB, An + 4096, wave, j);
       }
       bf16x8v_t fa[2][2], fb[2][2];
       fa[0][0] = h_frag(As, wm + li, 0, lh, li);
@@ -182,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void gemm128h_kernel(GOp aop, GOp bop, Gemm
     if (wide || plan.counters) __syncthreads();  // the next iteration's LDS-DMA lands in the slices the epilogue / ticket used
 
     seg = nxt;
+    if (GRP) { grpIdx = grpNext; ra = raN; rb = rbN; }
     sk_tile_xy(plan, seg.tile, bx, by);
   }
 }
@@ -363,9 +397,44 @@ inline int launch128h(const uint16_t* A, int lda, const uint16_t* B, int ldb, Ge
     hipLaunchKernelGGL(gemm256h_kernel, dim3((unsigned)workers), dim3(512), 2 * (size_t)kH2StageFloats * sizeof(float), s, ga, gb, o,
                        plan, workers, wide);
   } else {
-    hipLaunchKernelGGL(gemm128h_kernel, dim3((unsigned)workers), dim3(256), 2 * (size_t)kGStageFloats * sizeof(float), s, ga, gb, o,
-                       plan, workers, wide);
+    hipLaunchKernelGGL(gemm128h_kernel<false>, dim3((unsigned)workers), dim3(256), 2 * (size_t)kGStageFloats * sizeof(float), s, ga, gb, o,
+                       plan, workers, wide, HGroups{});
   }
+  prof_end(s);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+// n <= kHMaxGroups problems C_g [M][N] = A_g [M][>= Kp] . B_g [N][>= Kp]^T (+ bias_g) of one shape in one launch (whole 128 x 128
+// tiles, grouped over the persistent grid).  Same operand rules as launch128h.
+inline int launch128h_grouped(int n, const uint16_t* const* A, int lda, const uint16_t* const* B, int ldb, float* const* C, int ldc,
+                              const float* const* bias, int M, int N, int K, hipStream_t s) {
+  if (n < 1 || n > kHMaxGroups || M <= 0 || N <= 0 || K <= 0) return W2L_EINVAL;
+  const int Kp = (K + 63) / 64 * 64;
+  if ((lda & 1) || (ldb & 1) || lda < Kp || ldb < Kp) return W2L_EINVAL;
+  const unsigned long long ab = 2ull * ((unsigned long long)(M - 1) * lda + Kp), bb = 2ull * ((unsigned long long)(N - 1) * ldb + Kp);
+  if (ab >= 0x7fffffffull || bb >= 0x7fffffffull) return W2L_EUNSUPPORTED;
+  HGroups g;
+  int wide = (ldc % 4) == 0;
+  bool anyBias = false;
+  for (int i = 0; i < n; ++i) {
+    if (!A[i] || !B[i] || !C[i] || ((((uintptr_t)A[i]) | ((uintptr_t)B[i])) & 3)) return W2L_EINVAL;
+    g.a[i] = (const float*)A[i]; g.b[i] = (const float*)B[i]; g.c[i] = C[i]; g.bias[i] = bias ? bias[i] : nullptr;
+    anyBias = anyBias || g.bias[i];
+    if (((uintptr_t)C[i]) & 15) wide = 0;
+  }
+  for (int i = n; i < kHMaxGroups; ++i) { g.a[i] = g.a[0]; g.b[i] = g.b[0]; g.c[i] = g.c[0]; g.bias[i] = nullptr; }
+  SkPlan plan = make_sk_plan(M, N, Kp / 2, false);
+  plan.grouped = 1;
+  g.n = n; g.tiles = plan.dpTiles;
+  plan.dpTiles *= n;
+  GemmOut o{};
+  o.C = C[0]; o.bias = nullptr; o.M = M; o.N = N; o.K = K; o.ldc = ldc; o.epi = anyBias ? EPI_BIAS : 0;
+  GOp ga{(const float*)A[0], lda / 2, M, (unsigned)ab}, gb{(const float*)B[0], ldb / 2, N, (unsigned)bb};
+  const int workers = plan.dpTiles < kSkSlots ? plan.dpTiles : kSkSlots;
+  prof_begin(s, 2.0 * n * M * (double)N * K, PROF_GEMM_BF16);
+  hipLaunchKernelGGL(gemm128h_kernel<true>, dim3((unsigned)workers), dim3(256), 2 * (size_t)kGStageFloats * sizeof(float), s, ga, gb, o, plan,
+                     workers, wide, g);
   prof_end(s);
   W2L_LAUNCH_CHECK();
   return W2L_OK;

@@ -877,9 +877,13 @@ class TransformerLayer : public Layer {
     if (mixed) {   // one pair of images of x serves the three projections (and their weight gradients in backward)
       xImg.convert(cx, ar, x, "tr x images");
       blq.convertWeight(cx, ar, wq.w(cx)); blk.convertWeight(cx, ar, wk.w(cx)); blv.convertWeight(cx, ar, wv.w(cx));
-      blq.forward(cx, ar, xImg, bq.w(cx), q, 0, 0.0, 0, 0);
-      blk.forward(cx, ar, xImg, bk.w(cx), k, 0, 0.0, 0, 0);
-      blv.forward(cx, ar, xImg, bv.w(cx), v, 0, 0.0, 0, 0);
+      {   // the three projections in ONE grouped launch: 3 x 192 tiles share the grid (one at a time each fills 3/8 of the slots)
+        const uint16_t* A3[3] = {xImg.r(ar), xImg.r(ar), xImg.r(ar)};
+        const uint16_t* B3[3] = {blq.w.t(ar), blk.w.t(ar), blv.w.t(ar)};
+        float* C3[3] = {q, k, v};
+        const float* b3[3] = {bq.w(cx), bk.w(cx), bv.w(cx)};
+        w2lCheck(w2l_gemm_bf16_grouped(3, M, C, C, A3, xImg.colsP, B3, blq.w.rowsP, C3, C, b3, s), "tr q k v");
+      }
     } else {
     w2lCheck(w2l_linear_forward(M, C, C, x, wq.w(cx), bq.w(cx), q, 0, s), "tr q");
     w2lCheck(w2l_linear_forward(M, C, C, x, wk.w(cx), bk.w(cx), k, 0, s), "tr k");
@@ -988,7 +992,7 @@ class TransformerLayer : public Layer {
     w2lCheck(w2l_layernorm_backward(M, C, o, dh, gb1.w(cx), ar + mr1Off, dr1, gb1.g(cx), nullptr, nullptr, 1.f, (double*)(ar + st1Off), s), "tr ln1 bwd");
     if (mixed) {
       dr1Img.convert(cx, ar, dr1, "tr dr1 images");
-      blf.backwardWeight(cx, ar, ctxImg, dr1Img, wf.g(cx));
+      // (wf's weight gradient joins those of wq / wk / wv in one grouped launch at the end of this function)
       w2lCheck(w2l_colsum(dr1, bf.g(cx), (size_t)M, C, s), "tr wf bwd b");
       blf.backwardData(cx, ar, dr1Img, dctx, nullptr, 1.f, nullptr, 0);
     } else {
@@ -1036,9 +1040,12 @@ class TransformerLayer : public Layer {
     }
     if (mixed) {
       dqImg.convert(cx, ar, dq, "tr dq images"); dkImg.convert(cx, ar, dk, "tr dk images"); dvImg.convert(cx, ar, dv, "tr dv images");
-      blq.backwardWeight(cx, ar, xImg, dqImg, wq.g(cx));
-      blk.backwardWeight(cx, ar, xImg, dkImg, wk.g(cx));
-      blv.backwardWeight(cx, ar, xImg, dvImg, wv.g(cx));
+      {   // the four C x C weight gradients (64 tiles each at the recipe's width) in ONE grouped launch
+        const uint16_t* A4[4] = {xImg.t(ar), xImg.t(ar), xImg.t(ar), ctxImg.t(ar)};
+        const uint16_t* B4[4] = {dqImg.t(ar), dkImg.t(ar), dvImg.t(ar), dr1Img.t(ar)};
+        float* C4[4] = {wq.g(cx), wk.g(cx), wv.g(cx), wf.g(cx)};
+        w2lCheck(w2l_gemm_bf16_grouped(4, C, C, M, A4, xImg.rowsP, B4, dqImg.rowsP, C4, C, nullptr, s), "tr projection weight gradients");
+      }
       w2lCheck(w2l_colsum(dq, bq.g(cx), (size_t)M, C, s), "tr wq bwd b");
       w2lCheck(w2l_colsum(dk, bk.g(cx), (size_t)M, C, s), "tr wk bwd b");
       w2lCheck(w2l_colsum(dv, bv.g(cx), (size_t)M, C, s), "tr wv bwd b");

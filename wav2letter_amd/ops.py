@@ -218,6 +218,18 @@ def gemm_bf16(A, B, K, bias=None, relu=False, mask=None, mask_scale=1.0, addend=
     return c
 
 
+def gemm_bf16_grouped(As, Bs, K, biases=None):
+    """w2l_gemm_bf16_grouped: [C_g = A_g . B_g^T (+ bias_g)] for up to 4 problems of one shape in one launch"""
+    import ctypes as C
+    n = len(As)
+    M, N = As[0].shape[0], Bs[0].shape[0]
+    outs = [torch.empty(M, N, dtype=torch.float32, device=As[0].device) for _ in range(n)]
+    arr = lambda ts: (C.c_void_p * n)(*[(_p(t) if t is not None else None) for t in ts])
+    _lib.check(_lib.lib().w2l_gemm_bf16_grouped(n, M, N, K, arr(As), As[0].stride(0), arr(Bs), Bs[0].stride(0), arr(outs), N,
+                                                arr(biases) if biases is not None else None, _s()), "gemm_bf16_grouped")
+    return outs
+
+
 def tds_conv_bf16(x, w, bias, padl, padr, relu=False):
     """the TDS convolution on bf16-rounded operands (w2l_tds_conv_bf16_*): x [B][T][H][C], w [kw][C][C] -> y; None when the
     geometry has no bf16 kernel"""
