@@ -30,10 +30,10 @@ def lin_fwd(x, w, b, bf16=False):
 
 
 def lin_bwd(x, w, dy, bf16=False):
-    """(dx, dw, db); bf16: dx = bf(dy) bf(w)^T, dw = bf(x)^T bf(dy), db = column sums of the UNROUNDED dy"""
+    """(dx, dw, db); bf16: dx = bf(dy) bf(w)^T, dw = bf(x)^T bf(dy), db = column sums of bf(dy) (the bias gradient is a row of the
+    weight-gradient product: a row of ones in the x^T image, host/net.cpp BfImage::onesRow)"""
     if bf16:
-        dx, dw, _ = O.linear_bwd(bf16_round(x), bf16_round(w), bf16_round(dy))
-        return dx, dw, np.asarray(dy, np.float64).sum(axis=0).astype(np.float32)
+        return O.linear_bwd(bf16_round(x), bf16_round(w), bf16_round(dy))
     return O.linear_bwd(x, w, dy)
 
 

@@ -459,4 +459,4 @@ def test_bf16_operand_rounding_of_the_reference_interpreter(oracle):
     dx, dw, db = refnet.lin_bwd(x, w, dy, bf16=True)
     assert np.abs(dx - refnet.bf16_round(dy).astype(np.float64) @ refnet.bf16_round(w).astype(np.float64).T).max() < 1e-5
     assert np.abs(dw - refnet.bf16_round(x).astype(np.float64).T @ refnet.bf16_round(dy).astype(np.float64)).max() < 1e-5
-    assert np.abs(db - dy.sum(0)).max() < 1e-5
+    assert np.abs(db - refnet.bf16_round(dy).astype(np.float64).sum(0)).max() < 1e-5   # the bias gradient rides on the weight-gradient product: sums of the ROUNDED dy

@@ -245,14 +245,27 @@ static inline uint16_t* bfp(float* arena, size_t off) { return (uint16_t*)(arena
 struct BfImage {   // the two bf16 images of an fp32 matrix [rows][cols]
   size_t rowsOff = 0, transOff = 0;
   int rows = 0, cols = 0, colsP = 0, rowsP = 0;
-  void plan(Planner& pl, int r, int c) {
+  // onesRow: the transposed image carries one more row, index `cols`, of bf16 ones.  As the A operand of a weight-gradient
+  // product x^T dy it makes the product's row `cols` the column sums of dy: the BIAS gradient, which sits right behind the
+  // weight gradient in the arena, comes out of the same launch (no column-sum kernels).  Written once per plan.
+  bool onesRow = false;
+  mutable const float* onesArena = nullptr;   // the arena the ones row was written into (a re-bound arena gets it again)
+  void plan(Planner& pl, int r, int c, bool ones = false) {
     rows = r; cols = c; colsP = pad64(c); rowsP = pad64(r);
+    onesRow = ones; onesArena = nullptr;
     rowsOff = pl.allocBf16((size_t)rows * colsP);
-    transOff = pl.allocBf16((size_t)cols * rowsP);
+    transOff = pl.allocBf16((size_t)(cols + (ones ? 1 : 0)) * rowsP);
   }
   void convert(Ctx& c, float* arena, const float* x, const char* what) const {
     w2lCheck(w2l_bf16_convert(x, (size_t)rows, cols, (size_t)cols, bfp(arena, rowsOff), (size_t)colsP, bfp(arena, transOff), (size_t)rowsP,
                               c.stream), what);
+    if (onesRow && onesArena != arena) {   // two bf16 ones per float slot; columns past `rows` multiply the zero padding of dy's image
+      float pair;
+      const uint32_t bits = 0x3F803F80u;
+      std::memcpy(&pair, &bits, 4);
+      w2lCheck(w2l_fill((float*)(bfp(arena, transOff) + (size_t)cols * rowsP), (size_t)rowsP / 2, pair, c.stream), "bf16 ones row");
+      onesArena = arena;
+    }
   }
   const uint16_t* r(float* arena) const { return bfp(arena, rowsOff); }
   const uint16_t* t(float* arena) const { return bfp(arena, transOff); }
@@ -280,9 +293,14 @@ struct BfLinear {   // the weight images of one fl::Linear(in, out) and its thre
                            (mask || addend || accumulate) ? &e : nullptr, c.stream), "bf16 linear bwd data");
   }
   // dw [in][out] = x^T dy
-  void backwardWeight(Ctx& c, float* arena, const BfImage& xImg, const BfImage& dyImg, float* dw) const {
-    w2lCheck(w2l_gemm_bf16(in, out, M, xImg.t(arena), xImg.rowsP, dyImg.t(arena), dyImg.rowsP, dw, out, nullptr, 0, nullptr, c.stream),
-             "bf16 linear bwd weight");
+  // withBias: xImg carries the ones row and db == dw + in * out (the caller checked): row `in` of the product is the bias gradient
+  void backwardWeight(Ctx& c, float* arena, const BfImage& xImg, const BfImage& dyImg, float* dw, bool withBias = false) const {
+    w2lCheck(w2l_gemm_bf16(in + (withBias ? 1 : 0), out, M, xImg.t(arena), xImg.rowsP, dyImg.t(arena), dyImg.rowsP, dw, out, nullptr, 0,
+                           nullptr, c.stream), "bf16 linear bwd weight");
+  }
+  // the bias gradient can ride on the weight-gradient product: its slot follows the weight's in the gradient arena
+  bool biasRides(const BfImage& xImg, const float* dw, const float* db) const {
+    return xImg.onesRow && db == dw + (size_t)in * out;
   }
 };
 
@@ -470,7 +488,7 @@ class LinearLayer : public Layer {
       wn.dotOff = pl.alloc(wn.N);
     }
     bl.plan(pl, M, in, out);
-    xImg.plan(pl, M, in);
+    xImg.plan(pl, M, in, hasBias && !wn.on);
     dyImg.plan(pl, M, out);
     return o;
   }
@@ -497,8 +515,9 @@ class LinearLayer : public Layer {
     const float* wt = wn.on ? arena + wn.wOff : w.w(c);
     if (c.bf16) {   // the images of x and of the weight were written by forward
       dyImg.convert(c, arena, dym, "linear output-gradient images");
-      bl.backwardWeight(c, arena, xImg, dyImg, dwt);
-      if (hasBias) w2lCheck(w2l_colsum(dym, b.g(c), (size_t)M, out, c.stream), "linear bwd b");
+      const bool rides = hasBias && bl.biasRides(xImg, dwt, b.g(c));
+      bl.backwardWeight(c, arena, xImg, dyImg, dwt, rides);
+      if (hasBias && !rides) w2lCheck(w2l_colsum(dym, b.g(c), (size_t)M, out, c.stream), "linear bwd b");
       if (needDx) {
         dx = arena + dxOff;
         bl.backwardData(c, arena, dyImg, dx, nullptr, 1.f, nullptr, 0);
@@ -644,7 +663,7 @@ class TDSLayer : public Layer {
     dsOff = pl.alloc(n); duOff = pl.alloc((size_t)M * l2); dy1Off = pl.alloc(n); dr1Off = pl.alloc(n);
     daOff = pl.alloc(n); dxOff = pl.alloc(n);
     bl1.plan(pl, M, l, l2); bl2.plan(pl, M, l2, l);
-    y1Img.plan(pl, M, l); uImg.plan(pl, M, l2); dvImg.plan(pl, M, l); duImg.plan(pl, M, l2);
+    y1Img.plan(pl, M, l, true); uImg.plan(pl, M, l2, true); dvImg.plan(pl, M, l); duImg.plan(pl, M, l2);
     convImgElems = h % 16 == 0 ? w2l_tds_conv_bf16_image_elems(&d) : 0;
     if (convImgElems) { convImgFOff = pl.allocBf16(convImgElems); convImgBOff = pl.allocBf16(convImgElems); }
     return in;
@@ -701,12 +720,14 @@ class TDSLayer : public Layer {
     if (cx.bf16) {
       // (dv may live in dy1 -- the masked copy above --, which the last product overwrites: its images are taken first)
       dvImg.convert(cx, ar, dv, "tds dv images");
-      bl2.backwardWeight(cx, ar, uImg, dvImg, w2.g(cx));
-      w2lCheck(w2l_colsum(dv, b2.g(cx), (size_t)M, l, s), "tds lin2 bwd b");
+      const bool rides2 = bl2.biasRides(uImg, w2.g(cx), b2.g(cx));
+      bl2.backwardWeight(cx, ar, uImg, dvImg, w2.g(cx), rides2);
+      if (!rides2) w2lCheck(w2l_colsum(dv, b2.g(cx), (size_t)M, l, s), "tds lin2 bwd b");
       bl2.backwardData(cx, ar, dvImg, du, u, sc, nullptr, 0);
       duImg.convert(cx, ar, du, "tds du images");
-      bl1.backwardWeight(cx, ar, y1Img, duImg, w1.g(cx));
-      w2lCheck(w2l_colsum(du, b1.g(cx), (size_t)M, l2, s), "tds lin1 bwd b");
+      const bool rides1 = bl1.biasRides(y1Img, w1.g(cx), b1.g(cx));
+      bl1.backwardWeight(cx, ar, y1Img, duImg, w1.g(cx), rides1);
+      if (!rides1) w2lCheck(w2l_colsum(du, b1.g(cx), (size_t)M, l2, s), "tds lin1 bwd b");
       bl1.backwardData(cx, ar, duImg, dy1, nullptr, 1.f, ds, 0);
     } else {
     // lin2: dW2 = u^T dv, db2, du = (dv W2^T) masked by relu+dropout of u (u holds the dropped value)
@@ -843,7 +864,7 @@ class TransformerLayer : public Layer {
     dEpOff = pl.alloc((size_t)B * W * d);
     klOff = pl.alloc((size_t)B);
     blq.plan(pl, M, C, C); blk.plan(pl, M, C, C); blv.plan(pl, M, C, C); blf.plan(pl, M, C, C); bl1.plan(pl, M, C, mlp); bl2.plan(pl, M, mlp, C);
-    xImg.plan(pl, M, C); ctxImg.plan(pl, M, C); hImg.plan(pl, M, C); uImg.plan(pl, M, mlp);
+    xImg.plan(pl, M, C, true); ctxImg.plan(pl, M, C, true); hImg.plan(pl, M, C, true); uImg.plan(pl, M, mlp, true);
     dqImg.plan(pl, M, C); dkImg.plan(pl, M, C); dvImg.plan(pl, M, C); dr1Img.plan(pl, M, C); duImg.plan(pl, M, mlp); ds2Img.plan(pl, M, C);
     return in;
   }
@@ -974,12 +995,14 @@ class TransformerLayer : public Layer {
     const bool mixed = cx.bf16;
     if (mixed) {
       ds2Img.convert(cx, ar, ds2, "tr ds2 images");
-      bl2.backwardWeight(cx, ar, uImg, ds2Img, w2.g(cx));
-      w2lCheck(w2l_colsum(ds2, b2.g(cx), (size_t)M, C, s), "tr w2 bwd b");
+      const bool rides2 = bl2.biasRides(uImg, w2.g(cx), b2.g(cx));
+      bl2.backwardWeight(cx, ar, uImg, ds2Img, w2.g(cx), rides2);
+      if (!rides2) w2lCheck(w2l_colsum(ds2, b2.g(cx), (size_t)M, C, s), "tr w2 bwd b");
       bl2.backwardData(cx, ar, ds2Img, du, u, 1.f, nullptr, 0);
       duImg.convert(cx, ar, du, "tr du images");
-      bl1.backwardWeight(cx, ar, hImg, duImg, w1.g(cx));
-      w2lCheck(w2l_colsum(du, b1.g(cx), (size_t)M, mlp, s), "tr w1 bwd b");
+      const bool rides1 = bl1.biasRides(hImg, w1.g(cx), b1.g(cx));
+      bl1.backwardWeight(cx, ar, hImg, duImg, w1.g(cx), rides1);
+      if (!rides1) w2lCheck(w2l_colsum(du, b1.g(cx), (size_t)M, mlp, s), "tr w1 bwd b");
       bl1.backwardData(cx, ar, duImg, dh, nullptr, 1.f, ds2, 0);
     } else {
     w2lCheck(w2l_linear_backward_weight(M, mlp, C, u, ds2, w2.g(cx), s), "tr w2 bwd w");
@@ -992,8 +1015,7 @@ class TransformerLayer : public Layer {
     w2lCheck(w2l_layernorm_backward(M, C, o, dh, gb1.w(cx), ar + mr1Off, dr1, gb1.g(cx), nullptr, nullptr, 1.f, (double*)(ar + st1Off), s), "tr ln1 bwd");
     if (mixed) {
       dr1Img.convert(cx, ar, dr1, "tr dr1 images");
-      // (wf's weight gradient joins those of wq / wk / wv in one grouped launch at the end of this function)
-      w2lCheck(w2l_colsum(dr1, bf.g(cx), (size_t)M, C, s), "tr wf bwd b");
+      // (wf's weight and bias gradients join those of wq / wk / wv in one grouped launch at the end of this function)
       blf.backwardData(cx, ar, dr1Img, dctx, nullptr, 1.f, nullptr, 0);
     } else {
     w2lCheck(w2l_linear_backward_weight(M, C, C, ctx, dr1, wf.g(cx), s), "tr wf bwd w");
@@ -1044,11 +1066,18 @@ class TransformerLayer : public Layer {
         const uint16_t* A4[4] = {xImg.t(ar), xImg.t(ar), xImg.t(ar), ctxImg.t(ar)};
         const uint16_t* B4[4] = {dqImg.t(ar), dkImg.t(ar), dvImg.t(ar), dr1Img.t(ar)};
         float* C4[4] = {wq.g(cx), wk.g(cx), wv.g(cx), wf.g(cx)};
-        w2lCheck(w2l_gemm_bf16_grouped(4, C, C, M, A4, xImg.rowsP, B4, dqImg.rowsP, C4, C, nullptr, s), "tr projection weight gradients");
+        // with the ones rows of the x / ctx images the four bias gradients are row C of the four products
+        const bool rides = blq.biasRides(xImg, wq.g(cx), bq.g(cx)) && blk.biasRides(xImg, wk.g(cx), bk.g(cx)) &&
+                           blv.biasRides(xImg, wv.g(cx), bv.g(cx)) && blf.biasRides(ctxImg, wf.g(cx), bf.g(cx));
+        w2lCheck(w2l_gemm_bf16_grouped(4, C + (rides ? 1 : 0), C, M, A4, xImg.rowsP, B4, dqImg.rowsP, C4, C, nullptr, s),
+                 "tr projection weight gradients");
+        if (!rides) {
+          w2lCheck(w2l_colsum(dr1, bf.g(cx), (size_t)M, C, s), "tr wf bwd b");
+          w2lCheck(w2l_colsum(dq, bq.g(cx), (size_t)M, C, s), "tr wq bwd b");
+          w2lCheck(w2l_colsum(dk, bk.g(cx), (size_t)M, C, s), "tr wk bwd b");
+          w2lCheck(w2l_colsum(dv, bv.g(cx), (size_t)M, C, s), "tr wv bwd b");
+        }
       }
-      w2lCheck(w2l_colsum(dq, bq.g(cx), (size_t)M, C, s), "tr wq bwd b");
-      w2lCheck(w2l_colsum(dk, bk.g(cx), (size_t)M, C, s), "tr wk bwd b");
-      w2lCheck(w2l_colsum(dv, bv.g(cx), (size_t)M, C, s), "tr wv bwd b");
       blq.backwardData(cx, ar, dqImg, dx, nullptr, 1.f, dr1, 0);
       blk.backwardData(cx, ar, dkImg, dx, nullptr, 1.f, nullptr, 1);
       blv.backwardData(cx, ar, dvImg, dx, nullptr, 1.f, nullptr, 1);
