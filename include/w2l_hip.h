@@ -178,6 +178,18 @@ typedef struct {
 } w2l_gemm_epilogue;
 int w2l_bf16_convert(const float* x, size_t rows, int cols, size_t ldx, uint16_t* rowMajor, size_t ldRows,
                      uint16_t* transposed, size_t ldTrans, w2l_stream_t stream);
+/* n (1 .. 8) conversions in one launch (small matrices are launch-bound one at a time); each entry = the arguments of w2l_bf16_convert */
+typedef struct {
+  const float* x;
+  size_t rows;
+  int cols;
+  size_t ldx;
+  uint16_t* rowMajor;
+  size_t ldRows;
+  uint16_t* transposed;
+  size_t ldTrans;
+} w2l_bf16_convert_desc;
+int w2l_bf16_convert_multi(int n, const w2l_bf16_convert_desc* descs, w2l_stream_t stream);
 int w2l_gemm_bf16(int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B, int ldb, float* C, int ldc,
                   const float* bias, int relu, const w2l_gemm_epilogue* epilogue, w2l_stream_t stream);
 /* `groups` (1 .. 4) products of ONE shape in one launch, C_g [M][N] = A_g . B_g^T (+ bias_g): the tiles of all problems share the

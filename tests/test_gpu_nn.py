@@ -788,6 +788,31 @@ def test_bf16_convert_images(rows, cols):
     assert torch.equal(rm2.view(torch.int16), rm.view(torch.int16)) and torch.equal(tr2.view(torch.int16), tr.view(torch.int16))
 
 
+def test_bf16_convert_multi():
+    """w2l_bf16_convert_multi: several matrices in one launch, each image bit-identical to its own w2l_bf16_convert"""
+    import ctypes as C
+    from wav2letter_amd import _lib, ops
+    g = torch.Generator().manual_seed(4)
+    shapes = [(1024, 1024), (64, 4096), (100, 37), (1, 64), (300, 129), (65, 65), (7, 1000), (129, 2)]
+    xs = [torch.randn(r, c, generator=g).cuda() for r, c in shapes]
+    want = [ops.bf16_convert(x, True, True) for x in xs]
+    for n in (1, 3, 8):
+        rms, trs, arr = [], [], (_lib.Bf16ConvertDesc * n)()
+        for i in range(n):
+            r, c = shapes[i]
+            rm = torch.full((r, (c + 63) // 64 * 64), -1, dtype=torch.bfloat16, device="cuda")
+            tr = torch.full((c, (r + 63) // 64 * 64), -1, dtype=torch.bfloat16, device="cuda") if i != 1 else None
+            rms.append(rm); trs.append(tr)
+            arr[i] = _lib.Bf16ConvertDesc(x=xs[i].data_ptr(), rows=r, cols=c, ldx=c, rowMajor=rm.data_ptr(), ldRows=rm.shape[1],
+                                          transposed=tr.data_ptr() if tr is not None else None, ldTrans=tr.shape[1] if tr is not None else 0)
+        assert _lib.lib().w2l_bf16_convert_multi(n, arr, torch.cuda.current_stream().cuda_stream) == 0
+        for i in range(n):
+            assert torch.equal(rms[i].view(torch.int16), want[i][0].view(torch.int16))
+            if trs[i] is not None:
+                assert torch.equal(trs[i].view(torch.int16), want[i][1].view(torch.int16))
+    assert _lib.lib().w2l_bf16_convert_multi(9, arr, torch.cuda.current_stream().cuda_stream) != 0
+
+
 def _bf16_ref(a):
     return a.to(torch.bfloat16).double()
 

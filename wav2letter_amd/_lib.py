@@ -102,6 +102,7 @@ class _SIGS:
     w2l_colsum = (_i, [_p, _p, _sz, _i, _p])
     w2l_set_matmul_precision = (_i, [_i])
     w2l_bf16_convert = (_i, [_p, _sz, _i, _sz, _p, _sz, _p, _sz, _p])
+    w2l_bf16_convert_multi = (_i, [_i, _p, _p])
     w2l_gemm_bf16 = (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p])
     w2l_gemm_bf16_grouped = (_i, [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p])
     w2l_tds_conv_bf16_image_elems = (_sz, [_p])
@@ -166,6 +167,11 @@ class BgemmDesc(C.Structure):  # w2l_bgemm_desc
     _fields_ = ([(n, C.c_int) for n in ("M", "N", "K", "G1", "G2")] +
                 [(n, C.c_longlong) for n in ("sam", "sak", "a1", "a2", "sbk", "sbn", "b1", "b2", "ldc", "c1", "c2")] +
                 [("accumulate", C.c_int)])
+
+
+class Bf16ConvertDesc(C.Structure):  # w2l_bf16_convert_desc
+    _fields_ = [("x", C.c_void_p), ("rows", C.c_size_t), ("cols", C.c_int), ("ldx", C.c_size_t), ("rowMajor", C.c_void_p),
+                ("ldRows", C.c_size_t), ("transposed", C.c_void_p), ("ldTrans", C.c_size_t)]
 
 
 class AttnFusedDesc(C.Structure):  # w2l_attn_fused_desc

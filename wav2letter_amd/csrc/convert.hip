@@ -24,13 +24,13 @@ __device__ __forceinline__ uint32_t cv_pack2(float a, float b) {
 
 constexpr int kCvTile = 64;
 
-// grid (ceil(max(cols, ldRows) / 64), ceil(max(rows, ldTrans) / 64)), 256 threads: a 64 x 64 tile of x
-__global__ __launch_bounds__(256) void cvt_bf16_k(const float* __restrict__ x, size_t rows, int cols, size_t ldx,
-                                                  uint16_t* __restrict__ rowMajor, size_t ldRows,
-                                                  uint16_t* __restrict__ transposed, size_t ldTrans) {
+// one 64 x 64 tile (bx, by) of x; 256 threads
+__device__ __forceinline__ void cvt_tile(const float* __restrict__ x, size_t rows, int cols, size_t ldx,
+                                         uint16_t* __restrict__ rowMajor, size_t ldRows,
+                                         uint16_t* __restrict__ transposed, size_t ldTrans, unsigned bx, unsigned by) {
   __shared__ float tile[kCvTile][kCvTile + 1];
-  const size_t r0 = (size_t)blockIdx.y * kCvTile;
-  const int c0 = blockIdx.x * kCvTile;
+  const size_t r0 = (size_t)by * kCvTile;
+  const int c0 = (int)bx * kCvTile;
   const int tid = threadIdx.x;
   const int cq = (tid & 15) * 4, rr = tid >> 4;   // 4 columns at c0 + cq, rows rr + 16 i
   const bool vec = (((uintptr_t)x) & 15) == 0 && (ldx & 3) == 0;
@@ -73,6 +73,30 @@ __global__ __launch_bounds__(256) void cvt_bf16_k(const float* __restrict__ x, s
   dst[1] = make_uint4(p[4], p[5], p[6], p[7]);
 }
 
+// grid (ceil(max(cols, ldRows) / 64), ceil(max(rows, ldTrans) / 64))
+__global__ __launch_bounds__(256) void cvt_bf16_k(const float* __restrict__ x, size_t rows, int cols, size_t ldx,
+                                                  uint16_t* __restrict__ rowMajor, size_t ldRows,
+                                                  uint16_t* __restrict__ transposed, size_t ldTrans) {
+  cvt_tile(x, rows, cols, ldx, rowMajor, ldRows, transposed, ldTrans, blockIdx.x, blockIdx.y);
+}
+
+// several matrices in one launch (the six weights of a Transformer block are 8 us conversions each: launch-bound one at a
+// time): the tiles of all of them are laid end to end over a 1-D grid
+constexpr int kCvMaxMulti = 8;
+struct CvMulti {
+  w2l_bf16_convert_desc d[kCvMaxMulti];
+  unsigned first[kCvMaxMulti + 1];   // first tile of matrix i
+  unsigned gx[kCvMaxMulti];          // tiles per tile row of matrix i
+  int n;
+};
+__global__ __launch_bounds__(256) void cvt_bf16_multi_k(CvMulti m) {
+  int i = 0;
+  while (i + 1 < m.n && blockIdx.x >= m.first[i + 1]) ++i;
+  const unsigned t = blockIdx.x - m.first[i];
+  const w2l_bf16_convert_desc& d = m.d[i];
+  cvt_tile(d.x, d.rows, d.cols, d.ldx, d.rowMajor, d.ldRows, d.transposed, d.ldTrans, t % m.gx[i], t / m.gx[i]);
+}
+
 }  // namespace w2l
 
 using namespace w2l;
@@ -90,6 +114,38 @@ W2L_API int w2l_bf16_convert(const float* x, size_t rows, int cols, size_t ldx, 
   const dim3 grid((unsigned)((spanC + kCvTile - 1) / kCvTile), (unsigned)((spanR + kCvTile - 1) / kCvTile));
   if (grid.y > 65535u) return W2L_EUNSUPPORTED;
   hipLaunchKernelGGL(cvt_bf16_k, grid, dim3(256), 0, (hipStream_t)stream, x, rows, cols, ldx, rowMajor, ldRows, transposed, ldTrans);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+static int cv_check(const w2l_bf16_convert_desc& d) {
+  if (!d.x || d.rows == 0 || d.cols <= 0 || d.ldx < (size_t)d.cols || (!d.rowMajor && !d.transposed)) return W2L_EINVAL;
+  if (d.rowMajor && (d.ldRows < (size_t)d.cols || (d.ldRows & 15) || (((uintptr_t)d.rowMajor) & 15))) return W2L_EINVAL;
+  if (d.transposed && (d.ldTrans < d.rows || (d.ldTrans & 15) || (((uintptr_t)d.transposed) & 15))) return W2L_EINVAL;
+  return W2L_OK;
+}
+
+// n (1 .. 8) conversions in one launch; each entry as the arguments of w2l_bf16_convert
+W2L_API int w2l_bf16_convert_multi(int n, const w2l_bf16_convert_desc* descs, w2l_stream_t stream) {
+  if (n < 1 || n > kCvMaxMulti || !descs) return W2L_EINVAL;
+  CvMulti m;
+  m.n = n;
+  unsigned long long total = 0;
+  for (int i = 0; i < n; ++i) {
+    const w2l_bf16_convert_desc& d = descs[i];
+    const int st = cv_check(d);
+    if (st != W2L_OK) return st;
+    const size_t spanC = d.rowMajor && d.ldRows > (size_t)d.cols ? d.ldRows : (size_t)d.cols;
+    const size_t spanR = d.transposed && d.ldTrans > d.rows ? d.ldTrans : d.rows;
+    m.d[i] = d;
+    m.first[i] = (unsigned)total;
+    m.gx[i] = (unsigned)((spanC + kCvTile - 1) / kCvTile);
+    total += (unsigned long long)m.gx[i] * ((spanR + kCvTile - 1) / kCvTile);
+    if (total >= 0x7fffffffull) return W2L_EUNSUPPORTED;
+  }
+  m.first[n] = (unsigned)total;
+  for (int i = n; i < kCvMaxMulti; ++i) { m.d[i] = m.d[0]; m.gx[i] = 1; m.first[i + 1] = (unsigned)total; }
+  hipLaunchKernelGGL(cvt_bf16_multi_k, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, m);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }

@@ -269,6 +269,13 @@ struct BfImage {   // the two bf16 images of an fp32 matrix [rows][cols]
   }
   const uint16_t* r(float* arena) const { return bfp(arena, rowsOff); }
   const uint16_t* t(float* arena) const { return bfp(arena, transOff); }
+  // entry of a w2l_bf16_convert_multi call (images without a ones row: weights, gradients)
+  w2l_bf16_convert_desc desc(float* arena, const float* x) const {
+    w2l_bf16_convert_desc d;
+    d.x = x; d.rows = (size_t)rows; d.cols = cols; d.ldx = (size_t)cols;
+    d.rowMajor = bfp(arena, rowsOff); d.ldRows = (size_t)colsP; d.transposed = bfp(arena, transOff); d.ldTrans = (size_t)rowsP;
+    return d;
+  }
 };
 
 struct BfLinear {   // the weight images of one fl::Linear(in, out) and its three products on M frames
@@ -897,7 +904,11 @@ class TransformerLayer : public Layer {
     const bool mixed = cx.bf16;
     if (mixed) {   // one pair of images of x serves the three projections (and their weight gradients in backward)
       xImg.convert(cx, ar, x, "tr x images");
-      blq.convertWeight(cx, ar, wq.w(cx)); blk.convertWeight(cx, ar, wk.w(cx)); blv.convertWeight(cx, ar, wv.w(cx));
+      {   // the six weights of the block in ONE conversion launch (8 us each on their own: launch-bound)
+        const w2l_bf16_convert_desc wd[6] = {blq.w.desc(ar, wq.w(cx)), blk.w.desc(ar, wk.w(cx)), blv.w.desc(ar, wv.w(cx)),
+                                             blf.w.desc(ar, wf.w(cx)), bl1.w.desc(ar, w1.w(cx)), bl2.w.desc(ar, w2.w(cx))};
+        w2lCheck(w2l_bf16_convert_multi(6, wd, s), "tr weight images");
+      }
       {   // the three projections in ONE grouped launch: 3 x 192 tiles share the grid (one at a time each fills 3/8 of the slots)
         const uint16_t* A3[3] = {xImg.r(ar), xImg.r(ar), xImg.r(ar)};
         const uint16_t* B3[3] = {blq.w.t(ar), blk.w.t(ar), blv.w.t(ar)};
@@ -948,7 +959,6 @@ class TransformerLayer : public Layer {
     }
     if (mixed) {
       ctxImg.convert(cx, ar, ctx, "tr ctx images");
-      blf.convertWeight(cx, ar, wf.w(cx));
       blf.forward(cx, ar, ctxImg, bf.w(cx), o, 0, 0.0, 0, 0);
     } else {
       w2lCheck(w2l_linear_forward(M, C, C, ctx, wf.w(cx), bf.w(cx), o, 0, s), "tr wf");
@@ -957,10 +967,8 @@ class TransformerLayer : public Layer {
     w2lCheck(w2l_residual_layernorm_forward(M, C, o, x, o, h, gb1.w(cx), 1e-5f, 0.0, 0, 0, (double*)(ar + st1Off), ar + mr1Off, s), "tr ln1");
     if (mixed) {
       hImg.convert(cx, ar, h, "tr h images");
-      bl1.convertWeight(cx, ar, w1.w(cx));
       bl1.forward(cx, ar, hImg, b1.w(cx), u, 1, 0.0, 0, 0);
       uImg.convert(cx, ar, u, "tr u images");
-      bl2.convertWeight(cx, ar, w2.w(cx));
       bl2.forward(cx, ar, uImg, b2.w(cx), m2, 0, 0.0, 0, 0);
     } else {
     w2lCheck(w2l_linear_forward(M, C, mlp, h, w1.w(cx), b1.w(cx), u, 1, s), "tr w1");
@@ -986,8 +994,21 @@ class TransformerLayer : public Layer {
     if (dropped) {
       w2lCheck(w2l_layernorm_backward(M, C, h, dy, gb2.w(cx), ar + mr2Off, dh, gb2.g(cx), nullptr, nullptr, 1.f, (double*)(ar + st2Off), s), "tr ln2 bwd");
       w2lCheck(w2l_layernorm_backward(M, C, xSaved, dh, gb1.w(cx), ar + mr1Off, dx, gb1.g(cx), nullptr, nullptr, 1.f, (double*)(ar + st1Off), s), "tr ln1 bwd");
-      for (const P* w : {&w1, &b1, &w2, &b2, &wq, &bq, &wk, &bk, &wv, &bv, &wf, &bf}) zeroGrad(cx, *w, s);
-      if (csz > 0) zeroGrad(cx, pe, s);
+      {   // the block's weight / bias / table gradients are one contiguous run of the arena: one fill, not thirteen
+        size_t lo = (size_t)-1, hi = 0;
+        std::vector<const P*> ps = {&w1, &b1, &w2, &b2, &wq, &bq, &wk, &bk, &wv, &bv, &wf, &bf};
+        if (csz > 0) ps.push_back(&pe);
+        size_t total = 0;
+        for (const P* w : ps) {
+          const ParamInfo& pi = (*w->table)[w->idx];
+          lo = std::min(lo, pi.offset); hi = std::max(hi, pi.offset + pi.numel);
+          total += (pi.numel + 3) / 4 * 4;
+        }
+        // gb1 / gb2 (the LayerNorm pairs, written by the two LayerNorm backward calls above) may lie inside the run: only fill
+        // the run when nothing else does (slots are 4-float aligned, so a gap-free run has hi - lo within the padded total)
+        if (hi - lo <= total) w2lCheck(w2l_fill(cx.grads + lo, hi - lo, 0.f, s), "tr zero grads");
+        else for (const P* w : ps) zeroGrad(cx, *w, s);
+      }
       return;
     }
     const long long TC = (long long)T * C, TT = (long long)T * T;
@@ -1061,7 +1082,10 @@ class TransformerLayer : public Layer {
       }
     }
     if (mixed) {
-      dqImg.convert(cx, ar, dq, "tr dq images"); dkImg.convert(cx, ar, dk, "tr dk images"); dvImg.convert(cx, ar, dv, "tr dv images");
+      {
+        const w2l_bf16_convert_desc gd[3] = {dqImg.desc(ar, dq), dkImg.desc(ar, dk), dvImg.desc(ar, dv)};
+        w2lCheck(w2l_bf16_convert_multi(3, gd, s), "tr dq / dk / dv images");
+      }
       {   // the four C x C weight gradients (64 tiles each at the recipe's width) in ONE grouped launch
         const uint16_t* A4[4] = {xImg.t(ar), xImg.t(ar), xImg.t(ar), ctxImg.t(ar)};
         const uint16_t* B4[4] = {dqImg.t(ar), dkImg.t(ar), dvImg.t(ar), dr1Img.t(ar)};
