@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF headline includes 2:1 sparsity)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md chip table
 PEAK_HBM_GBPS = 8000.0         # same table (6.29 TB/s measured-achievable)
 
@@ -266,9 +267,10 @@ def ctc_loss_check(tr, x, tgt, what):
 
 def streaming_tds_step(device, L, steps=3, oracle_checks=True):
     """BASELINE config 3 on one GPU: streaming_convnets LibriSpeech TDS-CTC (am_500ms_future_context.arch, 115.1 M
-    parameters), batch 64, T = 1500: the full training step in fp32 and with bf16 multiplies in the fl::Linear GEMMs
-    (fp32 accumulate, fp32 storage and master weights, fp32 criterion) -- the mixed-precision mode of
-    w2l_trainer_set_mixed_precision.  Parity of the two: tests/test_gpu_trainer.py::test_mixed_precision_streaming_tds_step."""
+    parameters), batch 64, T = 1500: the full training step in fp32 and in the mixed-precision mode of
+    w2l_trainer_set_mixed_precision -- bf16 OPERAND STORAGE for the fl::Linear products (images written once per step,
+    gemm_bf16g.hpp) and the TDS convolutions (conv_tds_bf16.hip), fp32 accumulation, master weights, LayerNorm and criterion.
+    Parity: tests/test_gpu_trainer.py::test_streaming_tds_config3_* (fp32 and bf16 against the oracle)."""
     import ctypes as C
     from wav2letter_amd import CriterionScaleMode, recipes
     from wav2letter_amd.trainer import Trainer
@@ -307,18 +309,29 @@ def streaming_tds_step(device, L, steps=3, oracle_checks=True):
         del tr
         torch.cuda.empty_cache()
     out["bf16_speedup"] = round(out["f32"]["ms_per_step"] / out["bf16"]["ms_per_step"], 3)
-    out["note"] = ("dtype of this leg: bf16 multiply / fp32 accumulate in the fl::Linear GEMMs (v_mfma_f32_32x32x16_bf16), fp32 everywhere "
-                   "else; the bf16 GEMM is bound by staging fp32 operands through LDS, not by the 2.5 PFLOP/s matrix peak")
+    bf = out["bf16"]
+    out["roofline"] = {"bound": "mfma", "kernel": "gemm128h_kernel / gemm256h_kernel (v_mfma_f32_32x32x16_bf16 on bf16 operand images, "
+                       "128x128x64 or 256x256x64 tiles, whole-tile persistent schedules)", "achieved": bf["gemm_TFLOPs"],
+                       "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(bf["gemm_TFLOPs"] / PEAK_BF16_MFMA_TFLOPS, 4),
+                       "covers_frac_of_step_time": round(bf["gemm_ms_per_step"] / bf["ms_per_step"], 4),
+                       "hbm_view": "an fc product of this step (M = 11968, N = K = 2160) moves 164 MB of operands + result for 112 GFLOP: "
+                                   "680 flop per byte, the HBM bound (8 TB/s) would be 5.4 PFLOP/s -- the GEMMs are matrix-pipe bound, what "
+                                   "is HBM-bound in this step is everything else (LayerNorm, image conversions, dropout / masks: about a "
+                                   "quarter of the step time, DESIGN 3.1)"}
+    out["note"] = ("dtype of this leg: bf16 operands (stored as bf16 images) / fp32 accumulate in the fl::Linear GEMMs and the TDS "
+                   "convolutions, fp32 everywhere else")
     return out
 
 
 def transformer_ctc_step(device, L, steps=3, oracle_checks=True):
     """BASELINE config 5 on one GPU: sota/2019 Transformer-CTC (am_transformer_ctc.arch: WN-conv + GLU + max-pool front end,
     24 blocks of width 1024 / 4 heads / +-460 relative positions, 322.6 M parameters), batch 16, T = 1500 -> 188 frames,
-    9998 word pieces: the full training step (dropout 0.2 and layer drop 0.2 live, as the recipe trains) in fp32 and with
-    bf16 multiplies in the fl::Linear GEMMs.  The attention products (QK^T, PV, the relative-position GEMMs and their
-    gradients) stay fp32 on v_mfma_f32_32x32x2_f32: they are ~5 % of a block's flops at 188 frames.
-    Parity: tests/test_gpu_trainer.py::test_transformer_ctc_small_end_to_end, tests/test_gpu_attention.py."""
+    9998 word pieces: the full training step (dropout 0.2 and layer drop 0.2 live, as the recipe trains) in fp32 and in the
+    mixed-precision mode: bf16 operand images for the six fl::Linear of a block (grouped launches for q / k / v and for the four
+    projection weight gradients), bf16 MFMA attention -- the fused forward kernel (attention_fused.hip) and the bf16 batched
+    GEMM for the backward products.
+    Parity: tests/test_gpu_trainer.py::test_transformer_* (incl. the block at the recipe's width in fp32 and bf16),
+    tests/test_gpu_attention.py."""
     from wav2letter_amd import CriterionScaleMode, recipes
     from wav2letter_amd.trainer import Trainer
     B, T, nfeat, nlabel, Lmax = 16, 1500, 80, 9998, 80
@@ -342,18 +355,29 @@ def transformer_ctc_step(device, L, steps=3, oracle_checks=True):
             return loss
         step()
         torch.cuda.synchronize()
+        L.w2l_profile_enable(1)
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = step()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        n_, ms_, w_ = C.c_int(0), C.c_double(0), C.c_double(0)
+        L.w2l_profile_report_kind(6 if mode == "bf16" else 0, C.byref(n_), C.byref(ms_), C.byref(w_))
+        L.w2l_profile_enable(0)
+        tf = w_.value / (ms_.value * 1e-3) / 1e12 if ms_.value > 0 else 0.0
         out[mode] = {"ms_per_step": round(dt * 1e3, 1), "utterances_per_sec": round(B / dt, 1),
-                     "finite": bool(torch.isfinite(loss).all().item()), "loss": round(float(loss.mean().item()), 4)}
+                     "finite": bool(torch.isfinite(loss).all().item()), "loss": round(float(loss.mean().item()), 4),
+                     "gemm_TFLOPs": round(tf, 1), "gemm_ms_per_step": round(ms_.value / steps, 1), "gemm_launches_per_step": n_.value // steps}
         if oracle_checks and mode == "bf16":
             out["loss_check"] = ctc_loss_check(tr, x, tgt, f"CTC loss [{B}] on the {mode} step's emissions (eval forward) vs fp64 oracle")
         del tr
         torch.cuda.empty_cache()
     out["bf16_speedup"] = round(out["f32"]["ms_per_step"] / out["bf16"]["ms_per_step"], 3)
+    bf = out["bf16"]
+    out["roofline"] = {"bound": "mfma", "kernel": "gemm128h_kernel (incl. its grouped launches)", "achieved": bf["gemm_TFLOPs"],
+                       "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(bf["gemm_TFLOPs"] / PEAK_BF16_MFMA_TFLOPS, 4),
+                       "covers_frac_of_step_time": round(bf["gemm_ms_per_step"] / bf["ms_per_step"], 4),
+                       "note": "M = 3008 frames per step: 192-tile grids and 16-K-tile reductions on a 256-CU chip (DESIGN 3.1)"}
     out["note"] = ("optimizer: the recipe's --netoptim=adadelta (librispeech/train_am_transformer_ctc.cfg); layer drop skips a dropped "
                    "block's GEMMs, so ms_per_step is the mean over the masks these steps drew")
     return out

@@ -1,0 +1,19 @@
+#!/bin/bash
+# round-3 evidence run on the final tree: the default bench line, rocprofv3 kernel statistics per bench leg, PMC traffic passes
+# usage (on the GPU box): bash tools/evidence.sh <tag>      -> gpurun_out/<tag>_*
+tag=${1:-ev}
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+(time timeout 900 python bench.py) > gpurun_out/${tag}_bench.log 2> gpurun_out/${tag}_bench.err
+common="--no-cpu-baseline --no-input-pipeline --no-oracle-checks"
+timeout 400 bash tools/prof.sh ${tag}_headline_asg_ctc bench.py --steps 3 --warmup 1 --no-stress --no-c4 --no-c3 --no-c5 $common
+timeout 400 bash tools/prof.sh ${tag}_stress bench.py --steps 1 --warmup 0 --no-asg --no-c4 --no-c3 --no-c5 $common
+timeout 400 bash tools/prof.sh ${tag}_c4 bench.py --steps 1 --warmup 0 --no-asg --no-stress --no-c3 --no-c5 $common
+timeout 300 bash tools/prof.sh ${tag}_c3 tools/c3_step.py 3 bf16
+timeout 300 bash tools/prof.sh ${tag}_c5 tools/c5_step.py 3 bf16
+# HBM-side traffic (separate counter passes, no tracing domains): headline GEMM + the alpha-pass stream + the bf16 legs
+timeout 500 bash tools/pmc.sh ${tag}_fetch "FETCH_SIZE" bench.py --steps 1 --warmup 0 --no-asg --no-c4 --no-c5 --stress-frames 40 $common
+timeout 500 bash tools/pmc.sh ${tag}_write "WRITE_SIZE" bench.py --steps 1 --warmup 0 --no-asg --no-c4 --no-c5 --stress-frames 40 $common
+python tools/pmc_traffic.py gpurun_out/${tag}_fetch_pmc.csv gpurun_out/${tag}_write_pmc.csv gpurun_out/${tag}_pmc_traffic.json > /dev/null 2>&1
+echo done
