@@ -9,6 +9,7 @@
 // published behaviour.
 #pragma once
 #include <algorithm>
+#include <cstdint>
 #include <fstream>
 #include <sstream>
 #include <stdexcept>
@@ -63,7 +64,9 @@ class Dictionary {
 // word -> spellings (token strings), in file order: `word<TAB or space>tok tok ...`, one spelling per line
 using LexiconMap = std::unordered_map<std::string, std::vector<std::vector<std::string>>>;
 
-inline LexiconMap loadWordsFromLines(const std::vector<std::string>& lines, int maxSpellings = 0) {
+// maxWords: the reference's second argument (loadWords(FLAGS_lexicon, FLAGS_maxword), e.g. recipes/slimIPL/src/Train.cpp): at most
+// that many distinct WORDS are kept (-1: all); every spelling line of a kept word is kept, duplicates included, in file order
+inline LexiconMap loadWordsFromLines(const std::vector<std::string>& lines, int maxWords = -1) {
   LexiconMap lex;
   for (auto& line : lines) {
     std::istringstream ss(line);
@@ -72,18 +75,18 @@ inline LexiconMap loadWordsFromLines(const std::vector<std::string>& lines, int 
     std::vector<std::string> sp;
     while (ss >> tok) sp.push_back(tok);
     if (sp.empty()) continue;
-    auto& all = lex[word];
-    if (std::find(all.begin(), all.end(), sp) == all.end() && (maxSpellings <= 0 || (int)all.size() < maxSpellings)) all.push_back(sp);
+    if (lex.find(word) == lex.end() && maxWords >= 0 && (int)lex.size() >= maxWords) continue;
+    lex[word].push_back(sp);
   }
   return lex;
 }
-inline LexiconMap loadWords(const std::string& path, int maxSpellings = 0) {
+inline LexiconMap loadWords(const std::string& path, int maxWords = -1) {
   std::ifstream f(path);
   if (!f) throw std::runtime_error("loadWords: cannot open " + path);
   std::vector<std::string> lines;
   std::string line;
   while (std::getline(f, line)) lines.push_back(line);
-  return loadWordsFromLines(lines, maxSpellings);
+  return loadWordsFromLines(lines, maxWords);
 }
 
 }  // namespace text
@@ -117,17 +120,23 @@ inline std::vector<std::string> splitWrd(const std::string& w) {
   return out;
 }
 
-// transcription words -> token strings: the first spelling of the lexicon; an out-of-lexicon word falls back to its letters
-// (word separator on the chosen sides) when every letter is a token, else it is skipped (skipUnk) or an error
+// transcription words -> token strings, argument order of the reference's wrd2Target(words, lexicon, dict, wordSeparator,
+// targetSamplePct, fallback2LtrWordSepLeft, fallback2LtrWordSepRight, skipUnk): the first spelling of the lexicon, or with
+// probability targetSamplePct one of the word's spellings drawn uniformly (--sampletarget); an out-of-lexicon word falls back to
+// its letters (word separator on the chosen sides) when every letter is a token, else it is skipped (skipUnk) or an error
 inline std::vector<std::string> wrd2Target(const std::vector<std::string>& words, const lib::text::LexiconMap& lexicon,
                                            const lib::text::Dictionary& dict, const std::string& wordSeparator = "",
-                                           bool fallback2LtrWordSepLeft = false, bool fallback2LtrWordSepRight = true,
-                                           bool skipUnk = false) {
+                                           float targetSamplePct = 0.f, bool fallback2LtrWordSepLeft = false,
+                                           bool fallback2LtrWordSepRight = true, bool skipUnk = false) {
+  static thread_local uint64_t rng = 0x9E3779B97F4A7C15ull;
+  auto draw = [&]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (double)(rng >> 11) * (1.0 / 9007199254740992.0); };
   std::vector<std::string> out;
   for (auto& w : words) {
     auto it = lexicon.find(w);
     if (it != lexicon.end() && !it->second.empty()) {
-      out.insert(out.end(), it->second.front().begin(), it->second.front().end());
+      size_t pick = 0;
+      if (targetSamplePct > 0.f && draw() < (double)targetSamplePct) pick = (size_t)(draw() * (double)it->second.size()) % it->second.size();
+      out.insert(out.end(), it->second[pick].begin(), it->second[pick].end());
       continue;
     }
     auto letters = splitWrd(w);
@@ -179,7 +188,7 @@ inline std::vector<int> targetIndices(const std::vector<std::string>& words, con
                                       const lib::text::Dictionary& dict, const std::string& criterion, int replabel,
                                       const std::string& wordSeparator) {
   std::vector<int> idx;
-  for (auto& t : wrd2Target(words, lexicon, dict, wordSeparator)) idx.push_back(dict.getIndex(t));
+  for (auto& t : wrd2Target(words, lexicon, dict, wordSeparator, 0.f)) idx.push_back(dict.getIndex(t));
   return criterion == kAsgCriterion && replabel > 0 ? packReplabels(idx, dict, replabel) : idx;
 }
 

@@ -65,7 +65,9 @@ int main() {
   bool threw = false;
   try { targetIndices({"z3d"}, lex, asg, "ctc", 0, "|"); } catch (const std::invalid_argument&) { threw = true; }
   assert(threw);
-  assert(wrd2Target({"z3d", "bee"}, lex, asg, "|", false, true, true) == chars("bee|"));
+  assert(wrd2Target({"z3d", "bee"}, lex, asg, "|", 0.f, false, true, true) == chars("bee|"));   // the reference's argument order
+  assert(lex.at("bee").size() == 2);
+  assert(fl::lib::text::loadWordsFromLines({"a\ta |", "b\tb |", "a\ta a |", "c\tc |"}, 2).size() == 2);   // maxWords caps WORDS
   // UTF-8 code points
   assert((splitWrd("a\xC3\xA9z") == std::vector<std::string>{"a", "\xC3\xA9", "z"}));
   std::printf("text ok\n");

@@ -76,17 +76,19 @@ def create_token_dict(tokens, criterion: str, replabel: int = 0) -> Dictionary:
     return d
 
 
-def load_lexicon(source, max_spellings: int = 0) -> Dict[str, List[List[str]]]:
-    """`word<TAB or space>tok tok ...` per line; a word may appear on several lines (n-best spellings, kept in file order)"""
+def load_lexicon(source, max_words: int = -1) -> Dict[str, List[List[str]]]:
+    """`word<TAB or space>tok tok ...` per line; a word may appear on several lines (n-best spellings, all kept, in file order).
+    `max_words` is the reference's second argument of loadWords(FLAGS_lexicon, FLAGS_maxword): at most that many distinct words
+    are kept (-1: all)"""
     lines = open(source).read().splitlines() if isinstance(source, str) else list(source)
     lex: Dict[str, List[List[str]]] = {}
     for line in lines:
         parts = line.split()
         if len(parts) < 2:
             continue
-        sp = lex.setdefault(parts[0], [])
-        if parts[1:] not in sp and (max_spellings <= 0 or len(sp) < max_spellings):
-            sp.append(parts[1:])
+        if parts[0] not in lex and 0 <= max_words <= len(lex):
+            continue
+        lex.setdefault(parts[0], []).append(parts[1:])
     return lex
 
 
