@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from wav2letter_amd import ops, _lib
-if os.environ.get("W2L_GEMM_H256") is not None: _lib.use_probe().__enter__()   # the probe build honours the variant switch
+if os.environ.get("W2L_GEMM_H256") is not None or os.environ.get("W2L_GEMM_KSPLIT") is not None: _lib.use_probe().__enter__()   # the probe build honours the variant switch
 M, N, K = [int(v) for v in sys.argv[1:4]]
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 a = torch.randn(M, K, device="cuda"); b = torch.randn(N, K, device="cuda")

@@ -108,6 +108,11 @@ bool sk_forced() {   // W2L_GEMM_SK=2 (probe build): take the stream-K schedule 
   return e && e[0] == '2';
 }
 
+bool ksplit_enabled() {
+  const char* e = tune_env("W2L_GEMM_KSPLIT");
+  return !(e && e[0] == '0');
+}
+
 int h256_mode() {
   const char* e = tune_env("W2L_GEMM_H256");
   return e ? (e[0] == '1' ? 1 : 0) : -1;

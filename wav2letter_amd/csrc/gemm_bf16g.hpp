@@ -176,8 +176,8 @@ __global__ __launch_bounds__(256, 2) void gemm128h_kernel(GOp aop, GOp bop, Gemm
         }
         __syncthreads();
         const int ticket = *flag;
-        int sF, sL;
-        sk_tile_ranges(plan, t, sF, sL);
+        int sF = 0, sL = plan.ksplit - 1;   // aligned K split: chunk sr of this tile is slab sr * skTiles + t
+        if (!plan.ksplit) sk_tile_ranges(plan, t, sF, sL);
         if (ticket == sL - sF) {  // uniform: last arriver
           if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
           __syncthreads();
@@ -188,8 +188,14 @@ __global__ __launch_bounds__(256, 2) void gemm128h_kernel(GOp aop, GOp bop, Gemm
 #pragma unroll
               for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
           for (int sr = sF; sr <= sL; ++sr) {
-            const int segIdx = t - (int)(sk_begin(plan, sr) / plan.kTiles);  // ranges span <= 2 tiles: 0 or 1
-            const f32x4* s4 = (const f32x4*)(plan.slabs + ((size_t)sr * 2 + segIdx) * kSlabFloats);
+            size_t slabIdx;
+            if (plan.ksplit) {
+              slabIdx = (size_t)sr * plan.skTiles + t;
+            } else {
+              const int segIdx = t - (int)(sk_begin(plan, sr) / plan.kTiles);  // ranges span <= 2 tiles: 0 or 1
+              slabIdx = (size_t)sr * 2 + segIdx;
+            }
+            const f32x4* s4 = (const f32x4*)(plan.slabs + slabIdx * kSlabFloats);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -349,6 +355,7 @@ __global__ __launch_bounds__(512, 1) void gemm256h_kernel(GOp aop, GOp bop, Gemm
 // which tile shape: 1 = 256 x 256 (W2L_GEMM_H256=1 / 0 force it on / off for A/B runs; default by problem size)
 int h256_mode();
 bool sk_forced();
+bool ksplit_enabled();   // W2L_GEMM_KSPLIT=0 (probe build) turns the aligned K split off
 
 // A [M][lda], B [N][ldb] bf16 (lda, ldb in bf16 elements, even, >= Kp), Kp = K rounded up to 64: columns K .. Kp of every
 // row must be ZERO in both operands (convert.hip writes them so).  W2L_EUNSUPPORTED when the schedule cannot run in-kernel.
@@ -370,15 +377,40 @@ inline int launch128h(const uint16_t* A, int lda, const uint16_t* B, int ldb, Ge
   const int kt = Kp / 64;
   const long long tiles1 = (long long)((o.M + 127) / 128) * ((o.N + 127) / 128);
   const long long tiles2 = (long long)((o.M + 255) / 256) * ((o.N + 255) / 256);
-  const double t1 = (double)((tiles1 + 255) / 256) * (kt * 0.55 + 3.0), t2 = (double)((tiles2 + 255) / 256) * (kt * 2.0 + 8.0);
+  // (128 tiles: a CU works through its tiles at 0.45 us per K tile with two workgroups resident -- 0.54 on long reductions, where
+  // the panels fall out of the L2 --, at 0.80 with one; + 5 us of prologue / epilogue per tile)
+  // (up to 512 tiles every workgroup is resident from the start and runs at 0.80 us per K tile, shared CU or not)
+  const double t1 = tiles1 <= 512 ? kt * 0.80 + 5.0 : (double)((tiles1 + 255) / 256) * (kt * (kt >= 96 ? 0.54 : 0.45) + 5.0);
+  const double t2 = (double)((tiles2 + 255) / 256) * (kt * 2.0 + 8.0);
   const int mode = h256_mode();
   const bool big = o.M >= 256 && o.N >= 256 && tiles2 < (1 << 30) && (mode == 1 || (mode < 0 && t2 < t1));
   SkPlan plan;
   if (big) {
     plan = make_sk_plan(o.M, o.N, Kp / 2, false, 256, 256, kH2Slots);
   } else {
-    const bool sk = sk_enabled() && (sk_forced() || (tiles1 <= 128 && kt >= 96));
+    // Few tiles, long reduction (the weight gradients: 100 - 300 tiles x 190 - 750 K tiles): whole tiles leave CUs idle, and
+    // stream-K ranges share nothing -- every tile streams its full-K operand panels on its own, 2.4 GB through the fabric for
+    // 230 MB of operands at 1200 x 1200 x 47936 (383 us).  ALIGNED K split instead: the K axis is cut into X chunks, the same
+    // cut for every tile, units (chunk, tile) dealt chunk-major -- the 64 workers of an XCD run neighbouring tiles over the SAME
+    // k range and share the panels in its L2; one partial slab per unit, added in chunk order by the tile's last arriver.
+    int X = 0;
+    if (sk_enabled() && ksplit_enabled() && kt >= 64 && tiles1 * 2 <= 2 * kSkSlots) {
+      double bestT = t1;
+      for (int x = 2; x <= 8; ++x) {
+        const long long units = tiles1 * x;
+        const int chunk = (kt + x - 1) / x;
+        if (units > 1024 || chunk < 16 || (x - 1) * chunk >= kt) continue;
+        const double tx = (double)((units + kSkSlots - 1) / kSkSlots) * (chunk * 1.0 + 6.0) + 15.0 + 4.0 * x;   // + slab round trips
+        if (tx < (X ? bestT : 0.8 * t1)) { bestT = tx; X = x; }   // the models are +-15 %: a split must win clearly
+      }
+    }
+    const bool sk = X == 0 && sk_enabled() && (sk_forced() || (tiles1 <= 128 && kt >= 96));
     plan = make_sk_plan(o.M, o.N, Kp / 2, sk);
+    if (X) {
+      plan.skTiles = plan.dpTiles; plan.dpTiles = 0;
+      plan.ksplit = X; plan.kChunk = (kt + X - 1) / X;
+      plan.skBlocks = plan.skTiles * X;     // units; the worker count below
+    }
     if (plan.skBlocks > 0) {
       plan.slabs = sk_scratch(s, kSkScratchBytes);
       if (plan.slabs && plan.skTiles <= 1024) plan.counters = sk_counters(s);
@@ -389,6 +421,7 @@ inline int launch128h(const uint16_t* A, int lda, const uint16_t* B, int ldb, Ge
   const int slots = big ? kH2Slots : kSkSlots;
   int workers = plan.dpTiles < slots ? plan.dpTiles : slots;
   if (workers < plan.skBlocks) workers = plan.skBlocks;
+  if (workers > slots) workers = slots;
   static const bool attr = hipFuncSetAttribute((const void*)gemm256h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                2 * kH2StageFloats * (int)sizeof(float)) == hipSuccess;
   if (big && !attr) return W2L_EHIP;
