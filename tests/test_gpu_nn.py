@@ -844,6 +844,50 @@ def test_gemm_bf16_operand_storage(M, N, K):
     assert rel(ops.gemm_bf16(Ab, Bb, K, bias=bias, relu=True), np.maximum(wb, 0)) < 2e-5
 
 
+@pytest.mark.parametrize("B,T,Cin,Cout,kw,padl,padr", [(2, 50, 80, 64, 3, 1, 1), (3, 37, 32, 48, 5, 2, 2), (2, 40, 512, 1024, 3, 1, 1),
+                                                       (2, 33, 64, 96, 7, 0, 0), (1, 90, 48, 32, 13, 12, 0)])
+def test_conv_overlapping_rows_bf16_mode(B, T, Cin, Cout, kw, padl, padr):
+    """the kw x 1 convolutions (WN-Conv front end of the Transformer recipe, conv_glu layers) under w2l_set_matmul_precision(1):
+    forward and backward-data run as overlapping-row GEMMs on bf16 images (conv.hip); against the float64 convolution of the
+    SAME bf16-rounded operands (2e-5 of the largest magnitude: fp32 accumulation only) and the stated 1e-2 against the unrounded
+    one; the filter gradient stays on the fp32 path (1e-4).  The mode is restored afterwards."""
+    import torch.nn.functional as F
+    from wav2letter_amd import _lib, ops
+    g = torch.Generator().manual_seed(Cin + 7 * kw)
+    x = torch.randn(B, T, 1, Cin, generator=g).cuda()
+    w = (torch.randn(kw, Cin, Cout, generator=g) / (Cin * kw) ** 0.5).cuda()
+    bias = torch.randn(Cout, generator=g).cuda()
+    To = T + padl + padr - kw + 1
+    dy = torch.randn(B, To, 1, Cout, generator=g).cuda()
+
+    def ref(xx, ww, dd):
+        xx = xx.double().reshape(B, T, Cin).permute(0, 2, 1)                 # [B][Cin][T]
+        xx = F.pad(xx, (padl, padr)).requires_grad_(True)
+        wt = ww.double().permute(2, 1, 0).contiguous().requires_grad_(True)  # [Cout][Cin][kw]
+        y = F.conv1d(xx, wt)                                                 # [B][Cout][To]
+        (y * dd.double().reshape(B, To, Cout).permute(0, 2, 1)).sum().backward()
+        dx = xx.grad[:, :, padl:padl + T].permute(0, 2, 1).reshape(B, T, 1, Cin)
+        return y.permute(0, 2, 1).reshape(B, To, 1, Cout).detach(), dx, wt.grad.permute(2, 1, 0)
+    r = lambda t: t.bfloat16().float()
+    L = _lib.lib()
+    prev = L.w2l_set_matmul_precision(1)
+    try:
+        y = ops.conv_forward(x, w, bias, 1, padl, padr)
+        dx, dw, db = ops.conv_backward(x, w, dy, 1, padl, padr)
+    finally:
+        L.w2l_set_matmul_precision(prev)
+    yr, _, _ = ref(r(x), r(w), dy)
+    assert rel(y, (yr + bias.double()).cpu().numpy()) < 2e-5
+    _, dxr, _ = ref(x, r(w), r(dy))
+    assert rel(dx, dxr.cpu().numpy()) < 2e-5
+    y0, dx0, dw0 = ref(x, w, dy)
+    assert rel(y, (y0 + bias.double()).cpu().numpy()) < BF16_TOL and rel(dx, dx0.cpu().numpy()) < BF16_TOL
+    assert rel(dw, dw0.cpu().numpy()) < 1e-4
+    assert rel(db, dy.double().sum((0, 1, 2)).cpu().numpy()) < 1e-4
+    # and the fp32 mode is untouched
+    assert rel(ops.conv_forward(x, w, bias, 1, padl, padr), (y0 + bias.double()).cpu().numpy()) < 1e-4
+
+
 @pytest.mark.parametrize("n,M,N,K", [(4, 1024, 1024, 3008), (3, 3008, 1024, 1024), (2, 200, 136, 70), (1, 129, 260, 64), (4, 64, 64, 4100)])
 def test_gemm_bf16_grouped(n, M, N, K):
     """w2l_gemm_bf16_grouped: up to four products of one shape in one launch (the Transformer block's four projection weight

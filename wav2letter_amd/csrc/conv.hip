@@ -446,6 +446,73 @@ static int glds_conv_forward(const w2l_conv_desc* d, const float* x, const float
                        (size_t)K * d->Cout * sizeof(float), o, epi, s);
 }
 
+// Mixed-precision mode (w2l_set_matmul_precision(1): the network passes of configs 3 / 5): the same overlapping-row GEMMs on
+// bf16 images.  The activation image keeps the frame pitch (ld = channels, NOT padded: row m of the GEMM must run on into
+// frame m + 1), so the K padding of a row reads the next frame's data -- finite numbers against the zero rows that pad the
+// weight image -- and the last rows read past the image, where the buffer range returns zeros.
+static inline size_t al4(size_t floats) { return (floats + 3) & ~(size_t)3; }
+static bool bf16_conv_ok(int chan, size_t rows) { return chan % 16 == 0 && rows * (size_t)chan * 2 < 0x7fffffffull; }
+
+static int glds_conv_forward_bf16(const w2l_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int relu,
+                                  hipStream_t s) {
+  const int Tp = d->T + d->padl + d->padr, To = Tp - d->kw + 1;
+  const int K = d->kw * d->Cin, Kp = (K + 63) / 64 * 64;
+  const size_t rows = (size_t)d->B * Tp, xN = rows * d->Cin;
+  const bool padded = d->padl || d->padr;
+  const size_t xpF = padded ? al4(xN) : 0, imgF = al4((xN + 1) / 2), wimgF = al4(((size_t)d->Cout * Kp + 1) / 2);
+  float* sc = conv_scratch(s, (xpF + imgF + wimgF) * sizeof(float));
+  if (!sc) return W2L_EUNSUPPORTED;
+  const float* xs = x;
+  if (padded) {
+    int st = pad_frames(x, sc, d->B, d->T, Tp, d->Cin, d->padl, s);
+    if (st) return st;
+    xs = sc;
+  }
+  uint16_t* img = (uint16_t*)(sc + xpF);
+  uint16_t* wimg = (uint16_t*)(sc + xpF + imgF);
+  int st = w2l_bf16_convert(xs, rows, d->Cin, (size_t)d->Cin, img, (size_t)d->Cin, nullptr, 0, (w2l_stream_t)s);
+  if (st) return st;
+  st = w2l_bf16_convert(w, (size_t)K, d->Cout, (size_t)d->Cout, nullptr, 0, wimg, (size_t)Kp, (w2l_stream_t)s);   // [Cout][Kp], k contiguous
+  if (st) return st;
+  GemmOut o{y, bias, d->B * Tp - d->kw + 1, d->Cout, K, d->Cout, 0};
+  gemm_set_row_remap(o, Tp, To, 0);
+  const int epi = (bias ? EPI_BIAS : 0) | (relu ? EPI_RELU : 0);
+  return gemm_bf16_images(img, d->Cin, 2ull * xN, wimg, Kp, 0, o, epi, s);
+}
+
+static int glds_conv_backward_data_bf16(const w2l_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate,
+                                        const float* add, hipStream_t s) {
+  const int Tp = d->T + d->padl + d->padr, To = Tp - d->kw + 1;
+  const int K = d->kw * d->Cout, Kp = (K + 63) / 64 * 64;
+  const size_t front = (size_t)(d->kw - 1) * d->Cout, dypN = (size_t)d->B * Tp * d->Cout;
+  const size_t wfN = (size_t)d->kw * d->Cout * d->Cin;
+  const size_t dypF = al4(front + dypN), wfF = al4(wfN), imgF = al4((front + dypN + 1) / 2), wimgF = al4(((size_t)d->Cin * Kp + 1) / 2);
+  float* sc = conv_scratch(s, (dypF + wfF + imgF + wimgF) * sizeof(float));
+  if (!sc) return W2L_EUNSUPPORTED;
+  float* wf = sc + dypF;
+  uint16_t* img = (uint16_t*)(sc + dypF + wfF);
+  uint16_t* wimg = (uint16_t*)(sc + dypF + wfF + imgF);
+  W2L_HIP_CHECK(hipMemsetAsync(sc, 0, front * sizeof(float), s));
+  int st = pad_frames(dy, sc + front, d->B, To, Tp, d->Cout, 0, s);
+  if (st) return st;
+  for (int tap = 0; tap < d->kw; ++tap) {  // wf[kw-1-tap] = w[tap]^T
+    st = w2l_transpose(w + (size_t)tap * d->Cin * d->Cout, wf + (size_t)(d->kw - 1 - tap) * d->Cout * d->Cin, 1, d->Cin, d->Cout,
+                       (w2l_stream_t)s);
+    if (st) return st;
+  }
+  // the re-pitched dy (kw - 1 zero frames in front) as ONE image of (front + dypN) / Cout rows; wf [K][Cin] -> [Cin][Kp]
+  st = w2l_bf16_convert(sc, (front + dypN) / d->Cout, d->Cout, (size_t)d->Cout, img, (size_t)d->Cout, nullptr, 0, (w2l_stream_t)s);
+  if (st) return st;
+  st = w2l_bf16_convert(wf, (size_t)K, d->Cin, (size_t)d->Cin, nullptr, 0, wimg, (size_t)Kp, (w2l_stream_t)s);
+  if (st) return st;
+  GemmOut o{dx, nullptr, d->B * Tp, d->Cin, K, d->Cin, 0};
+  if (d->padl || d->padr) gemm_set_row_remap(o, Tp, d->T, d->padl);
+  int epi = 0;
+  if (add) { o.addend = add; epi |= EPI_ACCUM; }
+  else if (accumulate) epi |= EPI_ACCUM;
+  return gemm_bf16_images(img, d->Cout, 2ull * (front + dypN), wimg, Kp, 0, o, epi, s);
+}
+
 // scratch: [kw-1 zero frames | dyp [B][Tp][Cout]] [wf [kw][Cout][Cin]] ([xp [B][Tp][Cin]] for the filter gradient)
 static int glds_conv_backward_data(const w2l_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate,
                                    const float* add, hipStream_t s) {
@@ -535,6 +602,10 @@ W2L_API int w2l_conv_forward(const w2l_conv_desc* d, const float* x, const float
     if (st != W2L_EUNSUPPORTED) return st;
   }
   if (glds_conv_applicable(d)) {
+    if (matmul_bf16_mode() && bf16_conv_ok(d->Cin, (size_t)d->B * (d->T + d->padl + d->padr))) {
+      st = glds_conv_forward_bf16(d, x, w, bias, y, relu, (hipStream_t)stream);
+      if (st != W2L_EUNSUPPORTED) return st;
+    }
     st = glds_conv_forward(d, x, w, bias, y, relu, (hipStream_t)stream);
     if (st != W2L_EUNSUPPORTED) return st;
   }
@@ -558,6 +629,10 @@ W2L_API int w2l_conv_backward_data(const w2l_conv_desc* d, const float* dy, cons
     if (st != W2L_EUNSUPPORTED) return st;
   }
   if (glds_conv_applicable(d)) {
+    if (matmul_bf16_mode() && bf16_conv_ok(d->Cout, (size_t)d->B * (d->T + d->padl + d->padr) + d->kw)) {
+      st = glds_conv_backward_data_bf16(d, dy, w, dx, accumulate, nullptr, (hipStream_t)stream);
+      if (st != W2L_EUNSUPPORTED) return st;
+    }
     st = glds_conv_backward_data(d, dy, w, dx, accumulate, nullptr, (hipStream_t)stream);
     if (st != W2L_EUNSUPPORTED) return st;
   }
@@ -589,6 +664,10 @@ W2L_API int w2l_conv_backward_data_add(const w2l_conv_desc* d, const float* dy, 
     if (st != W2L_EUNSUPPORTED) return st;
   }
   if (glds_conv_applicable(d)) {
+    if (matmul_bf16_mode() && bf16_conv_ok(d->Cout, (size_t)d->B * (d->T + d->padl + d->padr) + d->kw)) {
+      st = glds_conv_backward_data_bf16(d, dy, w, dx, 0, add, s);
+      if (st != W2L_EUNSUPPORTED) return st;
+    }
     st = glds_conv_backward_data(d, dy, w, dx, 0, add, s);
     if (st != W2L_EUNSUPPORTED) return st;
   }

@@ -246,6 +246,15 @@ using namespace w2l;
 // process from now on; returns the previous mode.  (fl's --fl_amp_use_mixed_precision, restated for bf16.)
 W2L_API int w2l_set_matmul_precision(int mode) { return g_matmul_bf16.exchange(mode ? 1 : 0); }
 
+namespace w2l {
+bool matmul_bf16_mode() { return g_matmul_bf16.load(std::memory_order_relaxed) != 0; }
+// the bf16-image GEMM for other translation units (conv.hip: overlapping-row operand views)
+int gemm_bf16_images(const uint16_t* A, int lda, unsigned long long aView, const uint16_t* B, int ldb, unsigned long long bView,
+                     const GemmOut& o, int epi, hipStream_t s) {
+  return launch128h(A, lda, B, ldb, o, epi, s, aView, bView);
+}
+}  // namespace w2l
+
 // ---- C ABI: fl::linear forward / backward ----------------------------------
 W2L_API int w2l_linear_forward(int M, int in, int out, const float* x, const float* w,
                                const float* bias, float* y, int relu, w2l_stream_t stream) {

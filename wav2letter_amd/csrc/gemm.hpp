@@ -334,6 +334,9 @@ inline SkPlan make_sk_plan(int M, int N, int K, bool allowSk, int tileM = 128, i
 }
 
 float* sk_scratch(hipStream_t s, size_t bytes);  // library-owned, one buffer per stream (gemm.hip)
+bool matmul_bf16_mode();                         // w2l_set_matmul_precision(1) is in force (the mixed-precision network pass)
+int gemm_bf16_images(const uint16_t* A, int lda, unsigned long long aView, const uint16_t* B, int ldb, unsigned long long bView,
+                     const GemmOut& o, int epi, hipStream_t s);   // gemm_bf16g.hpp's launch128h (gemm.hip)
 unsigned* sk_counters(hipStream_t s);            // 1024 zero-initialised arrival tickets per stream (self-resetting)
 
 // first / last stream-K range that overlaps stream-K tile t

@@ -359,10 +359,14 @@ bool ksplit_enabled();   // W2L_GEMM_KSPLIT=0 (probe build) turns the aligned K 
 
 // A [M][lda], B [N][ldb] bf16 (lda, ldb in bf16 elements, even, >= Kp), Kp = K rounded up to 64: columns K .. Kp of every
 // row must be ZERO in both operands (convert.hip writes them so).  W2L_EUNSUPPORTED when the schedule cannot run in-kernel.
-inline int launch128h(const uint16_t* A, int lda, const uint16_t* B, int ldb, GemmOut o, int epi, hipStream_t s) {
+// aView / bView (bytes; 0 = a dense image): the address range of an operand whose rows OVERLAP (row stride < Kp: the
+// convolution-as-GEMM view of conv.hip, A row m = frames m .. m + kw of the activation image) -- reads past it return zeros
+inline int launch128h(const uint16_t* A, int lda, const uint16_t* B, int ldb, GemmOut o, int epi, hipStream_t s,
+                      unsigned long long aView = 0, unsigned long long bView = 0) {
   const int Kp = (o.K + 63) / 64 * 64;
-  if ((lda & 1) || (ldb & 1) || lda < Kp || ldb < Kp || (((uintptr_t)A | (uintptr_t)B) & 3)) return W2L_EINVAL;
-  const unsigned long long ab = 2ull * ((unsigned long long)(o.M - 1) * lda + Kp), bb = 2ull * ((unsigned long long)(o.N - 1) * ldb + Kp);
+  if ((lda & 1) || (ldb & 1) || (!aView && lda < Kp) || (!bView && ldb < Kp) || (((uintptr_t)A | (uintptr_t)B) & 3)) return W2L_EINVAL;
+  const unsigned long long ab = aView ? aView : 2ull * ((unsigned long long)(o.M - 1) * lda + Kp);
+  const unsigned long long bb = bView ? bView : 2ull * ((unsigned long long)(o.N - 1) * ldb + Kp);
   if (ab >= 0x7fffffffull || bb >= 0x7fffffffull) return W2L_EUNSUPPORTED;
   epi &= ~EPI_ATOMIC;
   const double flops = 2.0 * o.M * (double)o.N * o.K;
