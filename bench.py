@@ -568,8 +568,34 @@ def input_pipeline_leg(device, tr, tgt, fl, B, T, nfeat, ms_step_resident, steps
             k += 1
         torch.cuda.synchronize()
         fed = (time.perf_counter() - t0) / max(1, k)
+        # the same through the library's FLAC decoder (csrc/host/flac.cpp: frame CRCs + STREAMINFO MD5 verified per file): four
+        # files written by the tests' specification-level encoder (LPC order 8, the shape of a libFLAC level-5 stream)
+        flac = None
+        try:
+            from tests import flac_encode as FE
+            fpaths = []
+            for i in range(4):
+                with wave.open(paths[i], "rb") as w_:
+                    pcm = np.frombuffer(w_.readframes(ns), "<i2").astype(np.int64)
+                sm = np.convolve(pcm, np.ones(8) / 8.0, mode="same").round().astype(np.int64)   # low-passed noise: predictable
+                fp = os.path.join(tmp, f"f{i}.flac")
+                with open(fp, "wb") as f_:
+                    f_.write(FE.encode(sm, kind="lpc", order=8, porder=4, lpc=(12, 9, [970, -300, 120, -60, 30, -10, 5, -2])))
+                fpaths.append(fp)
+            fb = [[(n_ * B + j) % 4 for j in range(B)] for n_ in range(6)]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nf = 0
+            for feats_f, _s, _i in PrefetchLoader(fpaths, fb, mfsc, device=device, workers=workers, depth=3, read=read_audio_int16):
+                nf += feats_f.shape[0]
+            torch.cuda.synchronize()
+            tf = time.perf_counter() - t0
+            flac = {"utterances_per_sec": round(nf / tf, 1), "compressed_fraction_of_pcm": round(os.path.getsize(fpaths[0]) / (2.0 * ns), 3)}
+        except Exception as e:  # noqa: BLE001
+            flac = {"error": f"{type(e).__name__}: {e}"}
         return {"loader_alone": {"utterances_per_sec": round(n / alone, 1), "ms_per_batch": round(alone / nb * 1e3, 2),
                                  "pcm_MB_per_sec": round(n * ns * 2 / alone / 1e6, 1)},
+                "loader_alone_flac": flac,
                 "step_fed_by_loader": {"ms_per_step": round(fed * 1e3, 3), "utterances_per_sec": round(B / fed, 2), "steps": k,
                                        "vs_resident_input": round(fed * 1e3 / ms_step_resident, 4),
                                        "finite": bool(torch.isfinite(loss).all().item())},

@@ -368,6 +368,16 @@ int w2l_adadelta_step_guarded(float* p, const float* g, float* accGrad, float* a
  * data-parallel all-reduce is ONE collective over `grads` between forward_backward and update.
  * ---------------------------------------------------------------------- */
 const char* w2l_host_last_error(void);
+
+/* ---- FLAC decoding (host side of the input pipeline).  Replaces: fl::pkg::speech::loadSound through libsndfile for
+ * the .flac files the recipes' lists point at (data/librispeech/utils.py:36-46).  A from-specification decoder (RFC 9639): the native
+ * container, every subframe type, Rice / Rice2 residuals, all stereo decorrelations, 4-32 bits; frame CRC-8 / CRC-16 and the
+ * STREAMINFO MD5 of the decoded audio are verified.  `data` is the whole file in memory. */
+int w2l_flac_info(const uint8_t* data, size_t bytes, int* sampleRate, int* channels, int* bitsPerSample, uint64_t* totalSamples);
+/* out[sample][channel] interleaved int32, room for `capacity` inter-channel samples; *md5: 1 signature verified, -1 the file has none
+ * (a mismatch returns W2L_EINVAL, as does any malformed or corrupted frame: w2l_flac_last_error() says which) */
+int w2l_flac_decode(const uint8_t* data, size_t bytes, int32_t* out, uint64_t capacity, uint64_t* decoded, int* md5);
+const char* w2l_flac_last_error(void);
 void* w2l_trainer_create(const char* archText, int nFeat, int nLabel, const char* criterion,
                          int scaleMode, double transdiag);
 void w2l_trainer_destroy(void* h);

@@ -76,6 +76,9 @@ _p, _i, _sz, _f, _u32, _u64, _d = C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.
 
 class _SIGS:
     w2l_last_hip_error = (_i, [])
+    w2l_flac_info = (_i, [_p, _sz, _p, _p, _p, _p])
+    w2l_flac_decode = (_i, [_p, _sz, _p, _u64, _p, _p])
+    w2l_flac_last_error = (C.c_char_p, [])
     w2l_selftest_wave_ops = (_i, [_p, _p, _p])
     w2l_batch_target_size = (_i, [_i, _i, _i, _p, _p, _p])
     w2l_batch_ctc_target_size = (_i, [_i, _i, _i, _p, _p, _p])

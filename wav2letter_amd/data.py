@@ -91,12 +91,27 @@ def batches(indices: Sequence[int], durations_ms: Sequence[float], batch_size: i
     return out
 
 
+def decode_flac(data: bytes):
+    """a FLAC file's bytes -> (int32 samples [n][channels], sample rate, bits per sample): wav2letter_amd/csrc/host/flac.cpp through the
+    C ABI (w2l_flac_info / w2l_flac_decode) -- frame CRCs and the STREAMINFO MD5 of the decoded audio are verified there; a
+    malformed or corrupted stream raises ValueError with the decoder's message"""
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    L = _lib.lib()
+    buf = (C.c_ubyte * len(data)).from_buffer_copy(data)
+    rate, ch, bps, total = C.c_int(0), C.c_int(0), C.c_int(0), C.c_uint64(0)
+    if L.w2l_flac_info(buf, len(data), C.byref(rate), C.byref(ch), C.byref(bps), C.byref(total)) != 0:
+        raise ValueError(L.w2l_flac_last_error().decode())
+    cap = total.value if total.value else max(1, len(data) * 8)       # unknown length: a frame never codes a sample in under a bit
+    out = np.empty((cap, ch.value), np.int32)
+    done, md5 = C.c_uint64(0), C.c_int(0)
+    if L.w2l_flac_decode(buf, len(data), out.ctypes.data_as(C.c_void_p), cap, C.byref(done), C.byref(md5)) != 0:
+        raise ValueError(L.w2l_flac_last_error().decode())
+    return out[:done.value], rate.value, bps.value
+
+
 def read_audio(path: str):
-    """one utterance as float32 samples in [-1, 1) plus its sample rate.  The reference decodes through libsndfile
-    (fl::pkg::speech::loadSound, un-vendored; the recipes' lists point at .flac / .wav files): here RIFF / WAV PCM (8 / 16 /
-    24 / 32 bit, via the standard library) and headerless float32 `.f32` / int16 `.raw` / `.pcm` at 16 kHz; FLAC needs a
-    decoder this image does not carry and raises.  Multi-channel files are averaged to mono, as the Trainer's `--channels=1`
-    pipelines expect a single channel."""
     import numpy as np
     low = path.lower()
     if low.endswith(".wav"):
@@ -119,11 +134,16 @@ def read_audio(path: str):
         if nch > 1:
             a = a.reshape(-1, nch).mean(axis=1)
         return np.ascontiguousarray(a, np.float32), rate
+    if low.endswith(".flac"):
+        with open(path, "rb") as f:
+            pcm, rate, bps = decode_flac(f.read())
+        a = pcm.astype(np.float32) / float(1 << (bps - 1))
+        return np.ascontiguousarray(a.mean(axis=1) if a.shape[1] > 1 else a[:, 0], np.float32), rate
     if low.endswith(".f32"):
         return np.fromfile(path, "<f4"), 16000
     if low.endswith(".raw") or low.endswith(".pcm"):
         return np.fromfile(path, "<i2").astype(np.float32) / 32768.0, 16000
-    raise ValueError(f"{path}: no decoder for this container in this image (WAV / raw PCM only; the reference uses libsndfile)")
+    raise ValueError(f"{path}: no decoder for this container (WAV, FLAC and raw PCM are read; the reference uses libsndfile)")
 
 
 def pad_batch(audios):

@@ -156,6 +156,11 @@ def read_audio_int16(path):
         with wave.open(path, "rb") as w:
             if w.getsampwidth() == 2 and w.getnchannels() == 1:
                 return np.frombuffer(w.readframes(w.getnframes()), "<i2"), w.getframerate()
+    elif low.endswith(".flac"):
+        with open(path, "rb") as f:
+            pcm, rate, bps = D.decode_flac(f.read())
+        if bps == 16 and pcm.shape[1] == 1:
+            return pcm[:, 0].astype(np.int16), rate
     elif low.endswith(".raw") or low.endswith(".pcm"):
         return np.fromfile(path, "<i2"), 16000
     return D.read_audio(path)
