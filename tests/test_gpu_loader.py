@@ -18,8 +18,8 @@ def _write_wav(path, samples):
         w.writeframes(samples.astype("<i2").tobytes())
 
 
-@pytest.mark.parametrize("int16_path", [True, False])
-def test_prefetch_loader_matches_direct_featurisation(tmp_path, int16_path):
+@pytest.mark.parametrize("fmt", ["wav_int16", "wav_float", "flac"])
+def test_prefetch_loader_matches_direct_featurisation(tmp_path, fmt):
     from wav2letter_amd import data
     from wav2letter_amd.features import Mfsc
     from wav2letter_amd.loader import PrefetchLoader, read_audio_int16
@@ -29,14 +29,20 @@ def test_prefetch_loader_matches_direct_featurisation(tmp_path, int16_path):
     for i, n in enumerate(lens):
         a = (rng.normal(size=n) * 4000).astype(np.int16)
         audio.append(a)
-        p = str(tmp_path / f"u{i}.wav")
-        _write_wav(p, a)
+        if fmt == "flac":     # the LibriSpeech container, through the library's decoder (csrc/host/flac.cpp)
+            from tests import flac_encode as FE
+            p = str(tmp_path / f"u{i}.flac")
+            with open(p, "wb") as f:
+                f.write(FE.encode(a.astype(np.int64), kind="fixed", order=2, porder=2, block=4096))
+        else:
+            p = str(tmp_path / f"u{i}.wav")
+            _write_wav(p, a)
         paths.append(p)
     samples = data.parse_list("\n".join(f"id{i} {p} {1000.0 * n / 16000:.1f} a b" for i, (p, n) in enumerate(zip(paths, lens))))
     batches = data.batches(range(len(samples)), [s.duration_ms for s in samples], 4, sort_by_length=True)
     assert [len(b) for b in batches] == [4, 4, 3]
     mfsc = Mfsc(num_filters=40)
-    loader = PrefetchLoader(samples, batches, mfsc, workers=3, depth=2, read=read_audio_int16 if int16_path else None)
+    loader = PrefetchLoader(samples, batches, mfsc, workers=3, depth=2, read=None if fmt == "wav_float" else read_audio_int16)
     got = []
     for feats, sizes, ids in loader:
         got.append((feats.clone(), sizes.clone(), list(ids)))
