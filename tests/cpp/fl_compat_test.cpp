@@ -8,6 +8,9 @@
 //   fl_compat_test net <plugin.so|file.arch> <nfeat> <nlabel> <in.bin> <out.bin>
 //       in : int32 T B L | float x[B][nfeat][T] | int32 target[B][L]
 //       out: float loss0[B] | float loss1[B] (after one SGD step) | float emission checksum | int32 nparams | float gradnorm
+//   fl_compat_test mfsc <audio file> <nfilters> <out.bin>
+//       fl::pkg::speech::loadSound + fl::lib::audio::Mfsc (include/fl_compat/audio.h) of one utterance
+//       out: int32 T F rate nsamples | float feat[F][T]
 // The step is the reference's (recipes/slimIPL/src/Train.cpp:1454-1804): forward, criterion forward, zeroGrad,
 // loss.backward(), grads / batch, clipGradNorm, critopt->step(), netopt->step().
 #include <cstdio>
@@ -18,6 +21,7 @@
 #include <vector>
 
 #include "fl_compat/flashlight.h"
+#include "fl_compat/audio.h"
 
 using namespace fl;
 using namespace fl::pkg::speech;
@@ -56,6 +60,10 @@ static int runCrit(const std::string& kind, int mode, const char* in, const char
   Variable target(af::array(af::dim4(L, B), tgt), false);
   auto loss = crit->forward({emission, target}).front();
   if (loss.dims(0) != B) { std::cerr << "loss dims\n"; return 1; }
+  // the Trainer decodes BETWEEN the criterion's forward and loss.backward() on every report iteration (Train.cpp:1699-1716):
+  // the decode must not disturb what backward reads (it once shared the criterion's workspace)
+  std::vector<int> hp0((size_t)B * T);
+  crit->viterbiPath(emission.array()).host(hp0.data());
   loss.backward(Variable(af::array(af::dim4(B), gw), false));
 
   FILE* f = fopen(outp, "wb");
@@ -72,6 +80,7 @@ static int runCrit(const std::string& kind, int mode, const char* in, const char
   }
   std::vector<int> hp((size_t)B * T);
   crit->viterbiPath(emission.array()).host(hp.data());
+  if (hp != hp0) { std::cerr << "viterbiPath before and after backward differ\n"; return 1; }
   fwrite(hp.data(), 4, hp.size(), f);
   if (kind == "asg") {
     crit->viterbiPathWithTarget(emission.array(), target.array()).host(hp.data());
@@ -146,8 +155,31 @@ static int runNet(const std::string& arch, int nfeat, int nlabel, const char* in
   return 0;
 }
 
+static int runMfsc(const char* path, int nfilters, const char* outp) {
+  Sound snd = loadSound(path);
+  fl::lib::audio::FeatureParams fp;
+  fp.samplingFreq = snd.rate;
+  fp.numFilterbankChans = nfilters;
+  fl::lib::audio::Mfsc mfsc(fp);
+  const long S = mfsc.frameStride(), n = (long)snd.samples.size(), nP = (n + S - 1) / S * S;
+  std::vector<float> padded((size_t)nP, 0.f);
+  std::copy(snd.samples.begin(), snd.samples.end(), padded.begin());
+  af::array feats = mfsc.apply(af::array(af::dim4(nP, 1), padded.data()));
+  const int Tall = (int)feats.dims(0), T = mfsc.numFrames(n);
+  std::vector<float> h((size_t)feats.elements());
+  feats.host(h.data());
+  FILE* f = fopen(outp, "wb");
+  if (!f) { perror(outp); return 2; }
+  const int hd[4] = {T, nfilters, snd.rate, (int)n};
+  fwrite(hd, 4, 4, f);
+  for (int k = 0; k < nfilters; ++k) fwrite(h.data() + (size_t)k * Tall, 4, (size_t)T, f);
+  fclose(f);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   try {
+    if (argc == 5 && std::string(argv[1]) == "mfsc") return runMfsc(argv[2], atoi(argv[3]), argv[4]);
     if (argc == 6 && std::string(argv[1]) == "crit") return runCrit(argv[2], atoi(argv[3]), argv[4], argv[5]);
     if (argc == 7 && std::string(argv[1]) == "net") return runNet(argv[2], atoi(argv[3]), atoi(argv[4]), argv[5], argv[6]);
   } catch (const std::exception& e) {

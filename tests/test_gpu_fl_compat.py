@@ -323,3 +323,94 @@ def test_train_binary_overlapped_bucket_reducer_single_rank(tmp_path):
     _, tb = checkpoint.read(str(d / "D" / "exp" / "001_model_last.bin"))
     assert all(np.array_equal(x, y) for x, y in zip(ta, tb))
     assert not os.path.exists(d / "rndv" / "w2l_nccl_id.1")   # a world of one publishes no rendezvous record
+
+
+def _write_wav16(path, x):
+    import wave
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes(np.asarray(x, "<i2").tobytes())
+
+
+def test_cpp_loadsound_and_mfsc_match_the_python_pipeline(tmp_path):
+    """include/fl_compat/audio.h through the compiled C++ caller: loadSound of a WAV and of a FLAC file holding the same samples
+    and fl::lib::audio::Mfsc on the device give the features of wav2letter_amd.features.Mfsc (the same folded pre-emphasis /
+    window / DFT matrix and mel filterbank, computed independently in C++)"""
+    from tests import flac_encode as FE
+    from wav2letter_amd.features import Mfsc
+    rng = np.random.default_rng(2)
+    n = 16000 + 777
+    t = np.arange(n) / 16000.0
+    x = np.round((0.3 * np.sin(2 * np.pi * 310 * t) + 0.05 * rng.normal(size=n)) * 20000).astype(np.int16)
+    _write_wav16(tmp_path / "a.wav", x)
+    (tmp_path / "a.flac").write_bytes(FE.encode(x.astype(np.int64), kind="fixed", order=2, porder=3))
+    want = Mfsc(num_filters=40)(torch.tensor(x.astype(np.float32) / 32768.0).cuda()[None])[0].cpu().numpy()   # [F][T]
+    for name in ("a.wav", "a.flac"):
+        out = tmp_path / (name + ".bin")
+        run(["mfsc", str(tmp_path / name), "40", str(out)])
+        raw = out.read_bytes()
+        T, F, rate, ns = np.frombuffer(raw[:16], np.int32)
+        got = np.frombuffer(raw[16:], np.float32).reshape(F, T)
+        assert (T, F, rate, ns) == (want.shape[1], 40, 16000, n)
+        assert np.abs(got - want).max() < 2e-4 * np.abs(want).max()
+
+
+def test_train_binary_on_list_files(tmp_path):
+    """`Train train` on REAL list files (recipes/slimIPL/src/Train.cpp:277-339): `id path duration transcript` lines over WAV and
+    FLAC audio, letter tokens + lexicon, ASG with two replabels; features, targets and batching happen in the binary
+    (fl_compat/audio.h, data.h, text.h).  The loss falls, the log line carries train-TER / train-WER from the Viterbi path, the
+    run is reproducible, and `continue` picks the list data up again."""
+    from tests import flac_encode as FE
+    exe = os.path.join(ROOT, "wav2letter_amd", "bin", "Train")
+    d = tmp_path
+    os.makedirs(d / "arch")
+    os.makedirs(d / "audio")
+    from wav2letter_amd import recipes
+    (d / "arch" / "net.arch").write_text(recipes.conv_glu_small_arch(widths=(32, 48), kws=(5, 5)))
+    letters = ["|", "'"] + [chr(c) for c in range(ord("a"), ord("z") + 1)]
+    (d / "tokens.txt").write_text("\n".join(letters) + "\n")
+    words = ["hello", "aaa", "bee", "zoo", "add"]
+    (d / "lexicon.txt").write_text("".join(f"{w}\t{' '.join(w)} |\n" for w in words))
+    rng = np.random.default_rng(0)
+    lines = []
+    for k, (n, tr) in enumerate([(9600, "hello bee"), (6400, "aaa"), (8000, "zoo hello"), (4800, "bee"), (7300, "add zoo"), (5100, "hello")]):
+        t = np.arange(n) / 16000.0
+        sig = np.round((0.3 * np.sin(2 * np.pi * (200 + 150 * k) * t) + 0.05 * rng.normal(size=n)) * 30000).astype(np.int16)
+        if k % 2:
+            p = d / "audio" / f"u{k}.flac"
+            p.write_bytes(FE.encode(sig.astype(np.int64), kind="fixed", order=2, porder=2))
+        else:
+            p = d / "audio" / f"u{k}.wav"
+            _write_wav16(p, sig)
+        lines.append(f"u{k} {p if k < 3 else 'audio/' + p.name} {n / 16.0:.1f} {tr}")    # absolute paths (as the recipes write) and --datadir-relative ones
+    (d / "train.lst").write_text("\n".join(lines) + "\n")
+    cmd = [exe, "train", f"--archdir={d / 'arch'}", "--arch=net.arch", "--criterion=asg", "--replabel=2", "--filterbanks=40", f"--tokensdir={d}",
+           "--tokens=tokens.txt", f"--lexicon={d / 'lexicon.txt'}", f"--datadir={d}", "--train=train.lst", "--batchsize=3", "--iter=60",
+           "--reportiters=20", "--lr=0.05", "--lrcrit=0.002", "--momentum=0.8", "--maxgradnorm=1.0", "--onorm=target", "--sqnorm=true",
+           f"--rundir={d / 'run'}", "--runname=exp"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "[Data] 6 samples in 1 list(s), 6 on this rank, 2 batches of 3 per epoch; 40 MFSC features; 30 classes" in out.stdout
+
+    def rows(text):
+        r = []
+        for line in text.splitlines():
+            if line.startswith("epoch:"):
+                r.append({k.strip(): v.strip() for k, v in (item.split(":", 1) for item in line.split(" | "))})
+        return r
+    rr = rows(out.stdout)
+    assert [int(r["nupdates"]) for r in rr] == [20, 40, 60] and [int(r["epoch"]) for r in rr] == [10, 20, 30]
+    losses = [float(r["loss"]) for r in rr]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert all(0.0 <= float(r["train-TER"]) <= 300.0 and 0.0 <= float(r["train-WER"]) <= 300.0 for r in rr)
+    assert float(rr[-1]["train-TER"]) < 100.0
+    assert rr[0]["avr-batchsz"].strip() == "3.00" and int(rr[0]["max-tsz"]) == 10    # "hello bee" -> h e l <1> o | b e <1> |
+    # same command again: the same numbers (fixed seeds, deterministic kernels)
+    out2 = subprocess.run(cmd[:-2] + [f"--rundir={d / 'run2'}", "--runname=exp"], capture_output=True, text=True, timeout=600, env=env)
+    assert [r["loss"] for r in rows(out2.stdout)] == [r["loss"] for r in rr]
+    # continue: four more updates on the same lists
+    out3 = subprocess.run([exe, "continue", str(d / "run" / "exp"), "--iter=64", "--reportiters=2"], capture_output=True, text=True, timeout=600, env=env)
+    assert out3.returncode == 0, out3.stdout[-2000:] + out3.stderr[-2000:]
+    r3 = rows(out3.stdout)
+    assert [int(r["nupdates"]) for r in r3] == [62, 64] and "[Data] 6 samples" in out3.stdout

@@ -761,6 +761,15 @@ struct CritState {
     if (need > wsBytes) { ws = devAlloc(need); wsBytes = need; }
     return ws.get();
   }
+  // viterbiPath has a workspace of ITS OWN: the Trainer decodes between the criterion's forward and loss.backward() on every
+  // report iteration (Train.cpp:1699-1716), and the backward kernels read what forward left in `ws`
+  std::shared_ptr<void> vws;
+  size_t vwsBytes = 0;
+  void* viterbiWorkspace(int B, int T, int N) {
+    const size_t need = impl->workspaceBytes(B, T, N, 1) + 256;
+    if (need > vwsBytes) { vws = devAlloc(need); vwsBytes = need; }
+    return vws.get();
+  }
 };
 
 void checkCritInputs(const std::vector<Variable>& inputs, int& N, int& T, int& B, int& L) {
@@ -835,7 +844,7 @@ af::array ASGLoss::viterbiPath(const af::array& input, const af::array&) {
   af::array path(af::dim4(T, B), af::s32);
   w2l::Ctx c;
   c.stream = S();
-  st->impl->viterbiPath(c, B, T, N, input.device<float>(), path.device<int>(), st->workspace(B, T, N, 1), params_[0].array().device<float>());
+  st->impl->viterbiPath(c, B, T, N, input.device<float>(), path.device<int>(), st->viterbiWorkspace(B, T, N), params_[0].array().device<float>());
   return path;
 }
 af::array ASGLoss::viterbiPathWithTarget(const af::array& input, const af::array& target, const af::array&, const af::array&) {

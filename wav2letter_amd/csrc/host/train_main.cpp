@@ -18,10 +18,14 @@
 // flags + network + criterion from a model file and starts a fresh run in --rundir.  The container is the documented
 // W2LAMD01 layout of wav2letter_amd/checkpoint.py (fl::pkg::runtime::Serializer), not cereal.
 //
-// What is NOT here (SURVEY 8 marks it out of scope or "next"): audio decoding, the lexicon / word-piece pipeline, the
-// decoder, cereal checkpoints.  The data the step consumes is therefore SYNTHETIC unless --train names list files
-// that exist: LibriSpeech-shaped padded batches (--w2l_synth_frames frames of --filterbanks features, random targets),
-// which is exactly what bench.py times.  Flags of this driver that the reference does not have are prefixed w2l_.
+// Data (Train.cpp:277-339): when --train names list files that exist (relative to --datadir, comma separated), the step consumes
+// THEM -- `id path duration transcript` lines, audio decoded on the host (WAV / FLAC / raw PCM: fl_compat/audio.h), MFSC features
+// and the per-utterance normalisation on the device, targets from --tokens / --lexicon through fl_compat/text.h (replabels for
+// ASG), batches of --batchsize in list order, rank r taking its share of every global batch (partitionByRoundRobin); train-TER /
+// train-WER of the log line come from the Viterbi path through tknPrediction2Ltr / tkn2Wrd (Train.cpp:829-872).  Without lists the
+// data is SYNTHETIC: LibriSpeech-shaped padded batches (--w2l_synth_frames frames of --filterbanks features, random targets), which
+// is exactly what bench.py times.  Not here (out of scope): the decoder, cereal checkpoints, validation sets.
+// Flags of this driver that the reference does not have are prefixed w2l_.
 // Data parallelism is the reference's: --enable_distributed --world_rank --world_size --max_devices_per_node
 // --rndv_filepath (Train.cpp:188-199; RANK / WORLD_SIZE / LOCAL_WORLD_SIZE of a torchrun-style launcher are read when the
 // flags are absent): one process per GPU, fl::CoalescingReducer over RCCL, batch size all-reduced with the gradients.
@@ -40,6 +44,9 @@
 #include <sstream>
 
 #include "../../../include/fl_compat/flashlight.h"
+#include "../../../include/fl_compat/audio.h"
+#include "../../../include/fl_compat/data.h"
+#include "../../../include/fl_compat/text.h"
 #include "w2l_host.hpp"
 
 using namespace fl;
@@ -94,6 +101,74 @@ int countTokens(const std::string& path) {
   while (std::getline(f, line)) if (!line.empty()) ++n;
   return n;
 }
+
+// ---- list files -> padded device batches (Train.cpp:277-339)
+struct ListData {
+  std::vector<fl::pkg::speech::ListSample> samples;
+  std::vector<long> mine;                       // this rank's sample indices, in list order
+  fl::lib::text::Dictionary dict;
+  fl::lib::text::LexiconMap lexicon;
+  std::string wordsep, criterion;
+  int replabel = 0, nFeat = 0, batch = 1, padFrames = 64, rate = 16000;
+  std::unique_ptr<fl::lib::audio::Mfsc> mfsc;
+  af::array unit;                               // LayerNorm (gamma, beta) = (1, 0): the per-utterance normalisation
+  long batches() const { return ((long)mine.size() + batch - 1) / batch; }
+
+  // batch k -> features (T, NFEAT, 1, B) on the device, zero beyond every utterance's own frames; targets [B][L] (-1 padded);
+  // sizes [B] in samples.  Returns B (the last batch of an epoch may be short).
+  int get(long k, af::array& input, std::vector<int>& tgt, int& L, std::vector<float>& sizes, int& T) {
+    const long lo = k * batch, hi = std::min<long>(lo + batch, (long)mine.size());
+    const int B = (int)(hi - lo);
+    const int S = mfsc->frameStride();
+    std::vector<std::vector<float>> audio((size_t)B);
+    std::vector<std::vector<int>> rows((size_t)B);
+    long nsMax = 0;
+    L = 1;
+    sizes.assign((size_t)B, 0.f);
+    for (int b = 0; b < B; ++b) {
+      const auto& smp = samples[(size_t)mine[(size_t)(lo + b)]];
+      fl::pkg::speech::Sound snd = fl::pkg::speech::loadSound(smp.path);
+      if (snd.rate != rate) throw std::runtime_error(smp.path + ": sample rate " + std::to_string(snd.rate) + ", --samplerate is " + std::to_string(rate));
+      if ((long)snd.samples.size() < mfsc->frameSize()) throw std::runtime_error(smp.path + ": shorter than one analysis frame");
+      sizes[(size_t)b] = (float)snd.samples.size();
+      nsMax = std::max<long>(nsMax, (long)snd.samples.size());
+      audio[(size_t)b] = std::move(snd.samples);
+      rows[(size_t)b] = fl::pkg::speech::targetIndices(smp.transcript, lexicon, dict, criterion, replabel, wordsep);
+      L = std::max<int>(L, (int)rows[(size_t)b].size());
+    }
+    // pad to whole strides and to a multiple of padFrames frames: few distinct (B, T) plans of the network
+    int Tb = mfsc->numFrames(nsMax);
+    Tb = (Tb + padFrames - 1) / padFrames * padFrames;
+    const long ns = (long)(Tb - 1) * S + mfsc->frameSize();
+    const long nsP = (ns + S - 1) / S * S;
+    std::vector<float> host((size_t)B * nsP, 0.f);
+    for (int b = 0; b < B; ++b) memcpy(host.data() + (size_t)b * nsP, audio[(size_t)b].data(), audio[(size_t)b].size() * sizeof(float));
+    af::array dev(af::dim4(nsP, B), host.data());
+    af::array feats = mfsc->apply(dev);          // (Tall, NFEAT, 1, B), Tall >= Tb
+    const int Tall = (int)feats.dims(0);
+    T = Tb;
+    input = af::constant(0.0, af::dim4(T, nFeat, 1, B));
+    // per-utterance normalisation over the utterance's OWN frames (fl::lib::audio normalize(): zero mean, unit variance; applied
+    // before padding in the reference): gather [NFEAT][T_b] -> LayerNorm with (1, 0) -> scatter into the zeroed batch
+    hipStream_t st = (hipStream_t)fl::currentStream();
+    const size_t cap = (size_t)nFeat * Tall;
+    af::array tmp(af::dim4((af::dim_t)cap)), nrm(af::dim4((af::dim_t)cap)), mr(af::dim4(2));
+    af::array stats(af::dim4((af::dim_t)(2 * w2l_layernorm_scratch_doubles(1, cap) + 2)));
+    for (int b = 0; b < B; ++b) {
+      const int tb = std::min(mfsc->numFrames((long)sizes[(size_t)b]), T);
+      const float* src = feats.device<float>() + (size_t)b * nFeat * Tall;
+      w2l::hipCheck(hipMemcpy2DAsync(tmp.device<float>(), (size_t)tb * 4, src, (size_t)Tall * 4, (size_t)tb * 4, (size_t)nFeat, hipMemcpyDeviceToDevice, st), "gather features");
+      w2l::w2lCheck(w2l_residual_layernorm_forward(1, (size_t)nFeat * tb, tmp.device<float>(), nullptr, tmp.device<float>(), nrm.device<float>(),
+                                                   unit.device<float>(), 1e-10f, 0.0, 0, 0, (double*)stats.device<float>(), mr.device<float>(), st), "normalise features");
+      w2l::hipCheck(hipMemcpy2DAsync(input.device<float>() + (size_t)b * nFeat * T, (size_t)T * 4, nrm.device<float>(), (size_t)tb * 4, (size_t)tb * 4, (size_t)nFeat,
+                                     hipMemcpyDeviceToDevice, st), "scatter features");
+    }
+    tgt.assign((size_t)B * L, -1);
+    for (int b = 0; b < B; ++b) std::copy(rows[(size_t)b].begin(), rows[(size_t)b].end(), tgt.begin() + (size_t)b * L);
+    af::sync();   // tmp / nrm / stats go out of scope
+    return B;
+  }
+};
 
 int usage(const char* exe) {
   std::cerr << "Usage: \n " << exe << " train [flags]\n or " << exe << " continue [directory] [flags]\n or " << exe
@@ -259,11 +334,51 @@ int main(int argc, char** argv) {
 
     // ---- data
     std::string trainLists = flags.get("train", "");
-    const bool haveLists = !trainLists.empty() && trainLists.find("[DATA_DST]") == std::string::npos &&
-                           fileExists(trainLists.substr(0, trainLists.find(',')));
-    if (haveLists)
-      std::cout << "note: audio list files are present, but feature extraction from audio is not part of this build "
-                   "(SURVEY 8 f3): running on synthetic batches of the same shape" << std::endl;
+    const std::string dataDir = flags.get("datadir", "");
+    std::vector<std::string> listPaths;
+    {
+      std::istringstream ls(trainLists);
+      for (std::string one; std::getline(ls, one, ',');) if (!one.empty()) listPaths.push_back(pathJoin(dataDir, one));
+    }
+    const bool haveLists = !listPaths.empty() && trainLists.find("[DATA_DST]") == std::string::npos && fileExists(listPaths[0]);
+    ListData data;
+    if (haveLists) {
+      for (auto& lp : listPaths) {
+        std::ifstream lf(lp);
+        if (!lf) throw std::invalid_argument("cannot read the list file '" + lp + "' (--train / --datadir)");
+        std::stringstream buf;
+        buf << lf.rdbuf();
+        for (auto& smp : fl::pkg::speech::parseList(buf.str())) {
+          data.samples.push_back(smp);
+          auto& pth = data.samples.back().path;   // the recipes' lists hold absolute paths; a relative one is taken from --datadir
+          if (!pth.empty() && pth[0] != '/' && !fileExists(pth)) pth = pathJoin(dataDir, pth);
+        }
+      }
+      if (data.samples.empty()) throw std::invalid_argument("the --train lists hold no samples");
+      data.criterion = criterionName;
+      data.replabel = criterionName == "asg" ? (int)flags.geti("replabel", 0) : 0;
+      data.wordsep = flags.get("wordseparator", "|");
+      data.dict = fl::pkg::speech::createTokenDict(fl::lib::text::Dictionary(pathJoin(flags.get("tokensdir", ""), flags.get("tokens", "tokens.txt"))),
+                                                   criterionName, data.replabel);
+      if ((int)data.dict.indexSize() != numClasses) throw std::invalid_argument("token dictionary size != number of classes");
+      const std::string lexPath = flags.get("lexicon", "");
+      if (!lexPath.empty() && fileExists(lexPath)) data.lexicon = fl::lib::text::loadWords(lexPath, (int)flags.geti("maxword", -1));
+      data.nFeat = nFeat;
+      data.batch = batch;
+      data.rate = (int)flags.geti("samplerate", 16000);
+      data.padFrames = (int)flags.geti("w2l_pad_frames", 64);
+      fl::lib::audio::FeatureParams fp;
+      fp.samplingFreq = data.rate; fp.frameSizeMs = (int)flags.geti("framesizems", 25); fp.frameStrideMs = (int)flags.geti("framestridems", 10);
+      fp.numFilterbankChans = nFeat; fp.preemCoef = (float)flags.getd("preemcoef", 0.97); fp.melFloor = (float)flags.getd("melfloor", 1.0);
+      if (flags.getb("mfcc", false) || flags.getb("pow", false)) throw std::invalid_argument("list data: only --mfsc features are built (--mfcc / --pow are not)");
+      data.mfsc.reset(new fl::lib::audio::Mfsc(fp));
+      const float unit[2] = {1.f, 0.f};
+      data.unit = af::array(af::dim4(2), unit);
+      for (long i : fl::lib::partitionByRoundRobin((long)data.samples.size(), fl::getWorldRank(), fl::getWorldSize(), batch)) data.mine.push_back(i);
+      if (data.mine.empty()) throw std::invalid_argument("this rank has no samples (fewer samples than world_size * batchsize)");
+      std::cout << "[Data] " << data.samples.size() << " samples in " << listPaths.size() << " list(s), " << data.mine.size() << " on this rank, "
+                << data.batches() << " batches of " << batch << " per epoch; " << nFeat << " MFSC features; " << data.dict.indexSize() << " classes" << std::endl;
+    }
     std::mt19937_64 rng(2026 + seed + 7919ull * (uint64_t)fl::getWorldRank());   // every rank draws its own shard of the (synthetic) minibatch
     std::normal_distribution<float> gauss(0.f, 1.f);
     const int nTok = criterionName == "ctc" ? numClasses - 1 : std::max(1, numClasses - (int)flags.geti("replabel", 0));
@@ -278,6 +393,8 @@ int main(int argc, char** argv) {
     Timer runtime, timer, sampletimer, fwdtimer, critfwdtimer, bwdtimer, optimtimer;
     double lossSum = 0;
     long lossN = 0, editErr = 0, editLen = 0, tszTotal = 0, tszMax = 0, nsamples = 0, nbatches = 0;
+    fl::EditDistanceMeter wordMeter;   // list data: train-WER over words
+    long framesTotal = 0;              // list data: padded input frames consumed (avg-isz, hrs)
     runtime.resume();
     network->train();
     criterion->train();
@@ -304,8 +421,8 @@ int main(int argc, char** argv) {
       item("loss", fmt("%10.5f", lossN ? lossSum / lossN : 0.0));
       const double ter = editLen ? 100.0 * editErr / editLen : 0.0;
       item("train-TER", fmt("%5.2f", ter));
-      item("train-WER", fmt("%5.2f", ter));  // synthetic targets: every token is its own word
-      const double framesPerSample = T;
+      item("train-WER", fmt("%5.2f", haveLists ? wordMeter.value() : ter));  // synthetic targets: every token is its own word
+      const double framesPerSample = haveLists && nsamples ? (double)framesTotal / nsamples : T;
       item("avg-isz", fmti("%03ld", (long)framesPerSample));
       item("avg-tsz", fmti("%03ld", nsamples ? tszTotal / nsamples : 0));
       item("max-tsz", fmti("%03ld", tszMax));
@@ -323,7 +440,7 @@ int main(int argc, char** argv) {
       runtime.resume();
     };
 
-    const long batchesPerEpoch = std::max<long>(1, flags.geti("w2l_synth_batches_per_epoch", iters));
+    const long batchesPerEpoch = haveLists ? data.batches() : std::max<long>(1, flags.geti("w2l_synth_batches_per_epoch", iters));
     const long lrDecay = flags.geti("lr_decay", std::numeric_limits<int>::max());
     const long lrDecayStep = std::max<long>(1, flags.geti("lr_decay_step", std::numeric_limits<int>::max()));
     // --saug_start_update (Train.cpp:1026-1048): SpecAugment on the features from that update on (archs without a SAUG line)
@@ -383,6 +500,30 @@ int main(int argc, char** argv) {
 
       timer.resume();
       sampletimer.resume();
+      int curB = batch, curT = T, curL = Lmax;   // this batch's shape (list data: per batch)
+      fl::Variable input;
+      af::array inputSizes;
+      if (haveLists) {
+        af::array feats;
+        std::vector<float> sizes;
+        curB = data.get((curBatch - 1) % data.batches(), feats, ht, curL, sizes, curT);
+        for (int b = 0; b < curB; ++b) {
+          long len = 0;
+          while (len < curL && ht[(size_t)b * curL + len] >= 0) ++len;
+          tszTotal += len;
+          tszMax = std::max<long>(tszMax, len);
+        }
+        input = fl::input(feats);
+        inputSizes = af::array(af::dim4(1, curB), sizes.data());
+        if (curBatch <= 2 && !flags.get("w2l_dump_features", "").empty()) {   // debugging aid: [B][NFEAT][T] float32 of the first two batches
+          std::vector<float> hf((size_t)feats.elements());
+          feats.host(hf.data());
+          std::ofstream df(flags.get("w2l_dump_features") + "." + std::to_string(curBatch), std::ios::binary);
+          const int hd[3] = {curB, nFeat, curT};
+          df.write((const char*)hd, sizeof hd);
+          df.write((const char*)hf.data(), (std::streamsize)(hf.size() * 4));
+        }
+      } else {
       for (auto& v : hx) v = gauss(rng);
       for (int b = 0; b < batch; ++b) {
         const int lo = criterionName == "ctc" ? 20 : 60;
@@ -400,33 +541,46 @@ int main(int argc, char** argv) {
         tszTotal += len;
         tszMax = std::max<long>(tszMax, len);
       }
-      fl::Variable input = fl::input(af::array(af::dim4(T, nFeat, 1, batch), hx.data()));
+      input = fl::input(af::array(af::dim4(T, nFeat, 1, batch), hx.data()));
+      inputSizes = af::constant(T, af::dim4(1, batch));
+      }
       if (saug && curBatch >= saugStart) input = saug->forward({input}).front();   // Train.cpp:1453-1461
-      fl::Variable target(af::array(af::dim4(Lmax, batch), ht.data()), false);
+      fl::Variable target(af::array(af::dim4(curL, curB), ht.data()), false);
       af::sync();
       sampletimer.stopAndIncUnit();
 
       // forward
       fwdtimer.resume();
-      auto output = network->forward({input, fl::noGrad(af::constant(T, af::dim4(1, batch)))}).front();
+      auto output = network->forward({input, fl::noGrad(inputSizes)}).front();
       af::sync();
       critfwdtimer.resume();
       auto loss = criterion->forward({output, target}).front();
       af::sync();
       fwdtimer.stopAndIncUnit();
       critfwdtimer.stopAndIncUnit();
-      std::vector<float> hl(batch);
+      std::vector<float> hl((size_t)curB);
       loss.host(hl.data());
       for (float v : hl) {
-        if (!std::isfinite(v)) throw std::runtime_error("Loss has NaN values");   // LOG(FATAL), Train.cpp:1686-1698
+        if (!std::isfinite(v)) {   // LOG(FATAL), Train.cpp:1686-1698
+          std::ostringstream m;
+          m << "Loss has NaN values (update " << curBatch << ", per-utterance losses:";
+          for (float q : hl) m << " " << q;
+          std::vector<float> he((size_t)output.elements());
+          output.array().host(he.data());
+          float mx = 0.f;
+          size_t bad = 0;
+          for (float q : he) { if (std::isfinite(q)) mx = std::max(mx, std::fabs(q)); else ++bad; }
+          m << "; emissions: max |x| " << mx << ", " << bad << " non-finite of " << he.size() << ")";
+          throw std::runtime_error(m.str());
+        }
         lossSum += v;
         ++lossN;
       }
       if (reportiters > 0 && curBatch % reportiters == 0) {  // token error of the Viterbi path (evalOutput, Train.cpp:1699-1716)
-        std::vector<int> path((size_t)batch * output.dims(1));
+        std::vector<int> path((size_t)curB * output.dims(1));
         criterion->viterbiPath(output.array()).host(path.data());
         const int To = (int)output.dims(1);
-        for (int b = 0; b < batch; ++b) {
+        for (int b = 0; b < curB; ++b) {
           std::vector<int> hyp, ref;
           int prev = -1;
           for (int t = 0; t < To; ++t) {
@@ -434,9 +588,16 @@ int main(int argc, char** argv) {
             if (y != prev && !(criterionName == "ctc" && y == numClasses - 1)) hyp.push_back(y);
             prev = y;
           }
-          for (int i = 0; i < Lmax && ht[(size_t)b * Lmax + i] >= 0; ++i) ref.push_back(ht[(size_t)b * Lmax + i]);
+          for (int i = 0; i < curL && ht[(size_t)b * curL + i] >= 0; ++i) ref.push_back(ht[(size_t)b * curL + i]);
           editErr += editDistance(hyp, ref);
           editLen += (long)ref.size();
+          if (haveLists) {   // words: path -> letters (replabels undone, blank dropped) -> split at the word separator (Train.cpp:829-872)
+            std::vector<int> pv(path.begin() + (size_t)b * To, path.begin() + (size_t)(b + 1) * To);
+            const bool wp = flags.getb("usewordpiece", false);
+            auto hw = tkn2Wrd(tknPrediction2Ltr(pv, data.dict, criterionName, flags.get("surround", ""), data.replabel, wp, data.wordsep), data.wordsep);
+            auto rw = tkn2Wrd(tknTarget2Ltr(ref, data.dict, criterionName, flags.get("surround", ""), data.replabel, wp, data.wordsep), data.wordsep);
+            wordMeter.add(hw, rw);
+          }
         }
       }
 
@@ -474,14 +635,24 @@ int main(int argc, char** argv) {
           auto cp = criterion->params();
           params.insert(params.end(), cp.begin(), cp.end());
         }
-        fl::clipGradNorm(params, maxgradnorm);
+        const bool dbg = flags.getb("w2l_debug_gradnorm", false);
+        double gEm = 0, gCrit = 0, gNet = 0;
+        if (dbg) {   // (norms after the division by the batch size; 1e30 never clips)
+          if (output.isGradAvailable()) gEm = fl::clipGradNorm({output}, 1e30);
+          gCrit = fl::clipGradNorm(criterion->params(), 1e30);
+          gNet = fl::clipGradNorm(network->params(), 1e30);
+        }
+        const double gnorm = fl::clipGradNorm(params, maxgradnorm);
+        if (dbg) std::cout << "[debug] update " << curBatch << " gradient norm " << gnorm << " (network " << gNet << ", criterion " << gCrit
+                           << ", emissions (unscaled) " << gEm << ")" << std::endl;
       }
       critoptim->step();
       netoptim->step();
       af::sync();
       optimtimer.stopAndIncUnit();
       timer.stopAndIncUnit();
-      nsamples += batch;
+      nsamples += curB;
+      framesTotal += (long)curB * curT;
       ++nbatches;
 
       if (isMaster && ((reportiters > 0 && curBatch % reportiters == 0) || curBatch == iters)) logStatus(curEpoch, curBatch, lr, lrcrit);
