@@ -38,10 +38,14 @@
 #include <cstdio>
 #include <cstring>
 #include <ctime>
+#include <atomic>
 #include <fstream>
+#include <future>
 #include <iostream>
+#include <memory>
 #include <random>
 #include <sstream>
+#include <thread>
 
 #include "../../../include/fl_compat/flashlight.h"
 #include "../../../include/fl_compat/audio.h"
@@ -114,26 +118,64 @@ struct ListData {
   af::array unit;                               // LayerNorm (gamma, beta) = (1, 0): the per-utterance normalisation
   long batches() const { return ((long)mine.size() + batch - 1) / batch; }
 
-  // batch k -> features (T, NFEAT, 1, B) on the device, zero beyond every utterance's own frames; targets [B][L] (-1 padded);
-  // sizes [B] in samples.  Returns B (the last batch of an epoch may be short).
-  int get(long k, af::array& input, std::vector<int>& tgt, int& L, std::vector<float>& sizes, int& T) {
+  // host half of a batch: decoded audio + target rows.  Prepared AHEAD of the step by `nthread` decode threads (the reference's
+  // --nthread prefetch workers, Train.cpp:331): a LibriSpeech batch is 32 FLAC files x ~10 ms each
+  struct HostBatch {
+    std::vector<std::vector<float>> audio;
+    std::vector<std::vector<int>> rows;
+    std::vector<float> sizes;
+    std::string error;
+  };
+  int nthread = 6;
+  std::future<std::shared_ptr<HostBatch>> pending;
+  long pendingK = -1;
+
+  std::shared_ptr<HostBatch> decode(long k) const {
+    auto hb = std::make_shared<HostBatch>();
     const long lo = k * batch, hi = std::min<long>(lo + batch, (long)mine.size());
     const int B = (int)(hi - lo);
+    hb->audio.resize((size_t)B); hb->rows.resize((size_t)B); hb->sizes.assign((size_t)B, 0.f);
+    std::vector<std::string> errs((size_t)B);
+    auto one = [&](int b) {
+      try {
+        const auto& smp = samples[(size_t)mine[(size_t)(lo + b)]];
+        fl::pkg::speech::Sound snd = fl::pkg::speech::loadSound(smp.path);
+        if (snd.rate != rate) throw std::runtime_error(smp.path + ": sample rate " + std::to_string(snd.rate) + ", --samplerate is " + std::to_string(rate));
+        if ((long)snd.samples.size() < mfsc->frameSize()) throw std::runtime_error(smp.path + ": shorter than one analysis frame");
+        hb->sizes[(size_t)b] = (float)snd.samples.size();
+        hb->audio[(size_t)b] = std::move(snd.samples);
+        hb->rows[(size_t)b] = fl::pkg::speech::targetIndices(smp.transcript, lexicon, dict, criterion, replabel, wordsep);
+      } catch (const std::exception& e) { errs[(size_t)b] = e.what(); }
+    };
+    const int nt = std::max(1, std::min(nthread, B));
+    std::vector<std::thread> pool;
+    std::atomic<int> next{0};
+    for (int t = 0; t < nt; ++t)
+      pool.emplace_back([&]() { for (int b = next++; b < B; b = next++) one(b); });
+    for (auto& th : pool) th.join();
+    for (auto& e : errs) if (!e.empty()) { hb->error = e; break; }
+    return hb;
+  }
+
+  // batch k -> features (T, NFEAT, 1, B) on the device, zero beyond every utterance's own frames; targets [B][L] (-1 padded);
+  // sizes [B] in samples.  Returns B (the last batch of an epoch may be short).  The NEXT batch's files are decoded in the
+  // background while the caller trains on this one.
+  int get(long k, af::array& input, std::vector<int>& tgt, int& L, std::vector<float>& sizes, int& T) {
+    std::shared_ptr<HostBatch> hb;
+    if (pending.valid() && pendingK == k) hb = pending.get();
+    else { if (pending.valid()) pending.get(); hb = decode(k); }
+    pendingK = (k + 1) % batches();
+    pending = std::async(std::launch::async, [this]() { return decode(pendingK); });
+    if (!hb->error.empty()) throw std::runtime_error(hb->error);
+    const int B = (int)hb->audio.size();
     const int S = mfsc->frameStride();
-    std::vector<std::vector<float>> audio((size_t)B);
-    std::vector<std::vector<int>> rows((size_t)B);
+    auto& audio = hb->audio;
+    auto& rows = hb->rows;
+    sizes = hb->sizes;
     long nsMax = 0;
     L = 1;
-    sizes.assign((size_t)B, 0.f);
     for (int b = 0; b < B; ++b) {
-      const auto& smp = samples[(size_t)mine[(size_t)(lo + b)]];
-      fl::pkg::speech::Sound snd = fl::pkg::speech::loadSound(smp.path);
-      if (snd.rate != rate) throw std::runtime_error(smp.path + ": sample rate " + std::to_string(snd.rate) + ", --samplerate is " + std::to_string(rate));
-      if ((long)snd.samples.size() < mfsc->frameSize()) throw std::runtime_error(smp.path + ": shorter than one analysis frame");
-      sizes[(size_t)b] = (float)snd.samples.size();
-      nsMax = std::max<long>(nsMax, (long)snd.samples.size());
-      audio[(size_t)b] = std::move(snd.samples);
-      rows[(size_t)b] = fl::pkg::speech::targetIndices(smp.transcript, lexicon, dict, criterion, replabel, wordsep);
+      nsMax = std::max<long>(nsMax, (long)audio[(size_t)b].size());
       L = std::max<int>(L, (int)rows[(size_t)b].size());
     }
     // pad to whole strides and to a multiple of padFrames frames: few distinct (B, T) plans of the network
@@ -367,6 +409,7 @@ int main(int argc, char** argv) {
       data.batch = batch;
       data.rate = (int)flags.geti("samplerate", 16000);
       data.padFrames = (int)flags.geti("w2l_pad_frames", 64);
+      data.nthread = (int)flags.geti("nthread", 6);
       fl::lib::audio::FeatureParams fp;
       fp.samplingFreq = data.rate; fp.frameSizeMs = (int)flags.geti("framesizems", 25); fp.frameStrideMs = (int)flags.geti("framestridems", 10);
       fp.numFilterbankChans = nFeat; fp.preemCoef = (float)flags.getd("preemcoef", 0.97); fp.melFloor = (float)flags.getd("melfloor", 1.0);
