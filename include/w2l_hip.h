@@ -269,6 +269,10 @@ typedef struct {
   long long sbk, sbn, b1, b2;
   long long ldc, c1, c2;
   int accumulate;
+  /* banded A operand (w2l_bgemm_bf16 only; 0 = dense): the skewed score gradient dR of the relative-position products is non-zero,
+   * in row (b, i, h), only at the bandT table rows w = j - i + bandOff, j in [0, bandT).  1: rows = (b, i, h) flattened (bandH heads),
+   * k = w; 2: rows = w, k = (i, h) flattened.  K tiles outside the band are skipped (they multiply exact zeros). */
+  int bandMode, bandT, bandH, bandOff;
 } w2l_bgemm_desc;
 int w2l_bgemm_f32(const w2l_bgemm_desc* d, const float* A, const float* B, float* C, w2l_stream_t stream);
 /* the same product with bf16 multiplies: fp32 operands rounded to nearest-even bf16 on the way into LDS, v_mfma_f32_32x32x16_bf16,

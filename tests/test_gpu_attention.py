@@ -223,6 +223,42 @@ def test_fused_attention_forward(B, H, T, d, csz, p, ragged):
         assert 0.5 * p < float((Pd == 0).float().mean()) - float((P == 0).float().mean()) < 1.5 * p
 
 
+@pytest.mark.parametrize("B,H,T,d,csz", [(2, 4, 188, 256, 460), (3, 2, 50, 32, 30), (2, 3, 130, 20, 460), (1, 1, 7, 8, 3), (2, 2, 64, 16, 10)])
+def test_banded_position_products_bf16(B, H, T, d, csz):
+    """the two relative-position products of the attention backward on the bf16 batched GEMM with the BAND of the skewed score
+    gradient declared (w2l_bgemm_desc::bandMode): dq += dR E (rows (b, i, h), k = w) and dE = dR^T q (rows w, k = (i, h)) skip the
+    K tiles where dR is zero by construction -- bit-identical to the dense launches"""
+    from wav2letter_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(T + csz)
+    Cc = H * d
+    n0 = csz - 1
+    rlo = max(0, n0 - (T - 1))
+    W = min(2 * csz - 1, n0 + T) - rlo
+    ldr = (W + 3) // 4 * 4
+    P = torch.softmax(torch.randn(B, H, T, T, generator=g), -1).cuda()
+    dS = torch.randn(B, H, T, T, generator=g).cuda()
+    dR = torch.full((B * T * H, ldr), float("nan"), device="cuda")
+    assert L.w2l_attn_softmax_backward(P.data_ptr(), dS.data_ptr(), dR.data_ptr(), B, H, T, ldr, rlo, W, n0, d ** -0.5, _stream()) == 0
+    E = (torch.randn(2 * csz - 1, d, generator=g) * 0.5).cuda()
+    q = torch.randn(B, T, Cc, generator=g).cuda()
+    outs = {}
+    for band in (0, 1):
+        dq = torch.ones(B, T, Cc, device="cuda")
+        D = _lib.BgemmDesc(M=B * T * H, N=d, K=W, G1=1, G2=1, sam=ldr, sak=1, sbk=d, sbn=1, ldc=d, accumulate=1,
+                           bandMode=1 if band else 0, bandT=T, bandH=H, bandOff=n0 - rlo)
+        assert L.w2l_bgemm_bf16(C.byref(D), dR.data_ptr(), E[rlo:].data_ptr(), dq.data_ptr(), _stream()) == 0
+        dEp = torch.full((B, W, d), float("nan"), device="cuda")
+        D = _lib.BgemmDesc(M=W, N=d, K=T * H, G1=B, G2=1, sam=1, sak=ldr, a1=T * H * ldr, sbk=d, sbn=1, b1=T * Cc, ldc=d, c1=W * d,
+                           bandMode=2 if band else 0, bandT=T, bandH=H, bandOff=n0 - rlo)
+        assert L.w2l_bgemm_bf16(C.byref(D), dR.data_ptr(), q.data_ptr(), dEp.data_ptr(), _stream()) == 0
+        outs[band] = (dq, dEp)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.isfinite(outs[1][0]).all() and torch.isfinite(outs[1][1]).all()
+    bad = _lib.BgemmDesc(M=4, N=4, K=4, G1=1, G2=1, sam=4, sak=1, sbk=4, sbn=1, ldc=4, bandMode=3, bandT=1, bandH=1)
+    assert L.w2l_bgemm_bf16(C.byref(bad), dR.data_ptr(), E.data_ptr(), q.data_ptr(), _stream()) != 0
+
+
 @pytest.mark.parametrize("B,T,F,w,stride", [(2, 21, 32, 1, 2), (3, 20, 12, 2, 2), (2, 17, 8, 3, 2), (1, 9, 4, 3, 1)])
 def test_time_max_pool(B, T, F, w, stride):
     from wav2letter_amd import _lib

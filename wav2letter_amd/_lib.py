@@ -169,7 +169,7 @@ class GemmEpilogue(C.Structure):  # w2l_gemm_epilogue
 class BgemmDesc(C.Structure):  # w2l_bgemm_desc
     _fields_ = ([(n, C.c_int) for n in ("M", "N", "K", "G1", "G2")] +
                 [(n, C.c_longlong) for n in ("sam", "sak", "a1", "a2", "sbk", "sbn", "b1", "b2", "ldc", "c1", "c2")] +
-                [("accumulate", C.c_int)])
+                [("accumulate", C.c_int), ("bandMode", C.c_int), ("bandT", C.c_int), ("bandH", C.c_int), ("bandOff", C.c_int)])
 
 
 class Bf16ConvertDesc(C.Structure):  # w2l_bf16_convert_desc

@@ -78,7 +78,32 @@ struct BgP {
   int M, N, K, G2, tilesN;
   long long a1, a2, b1, b2, ldc, c1, c2;
   int accumulate;
+  int bandMode = 0, bandT = 0, bandH = 0, bandOff = 0;   // w2l_bgemm_desc::bandMode (bf16 kernel only)
 };
+
+// K range [kLo, kHi) that can hold non-zeros for the 64-row tile at row r0 of a BANDED A operand (the skewed score gradient dR of
+// the relative-position products: row (b, i, h) is non-zero only at the T table rows w = j - i + bandOff, j in [0, T)):
+//   mode 1  rows = (b, i, h) flattened, k = w          (dq += dR E)
+//   mode 2  rows = w, k = (i, h) flattened             (dE = dR^T q, per utterance)
+// Skipped K tiles multiply exact zeros: the result is bit-identical to the full product.
+__device__ __forceinline__ void bg_band(const BgP& p, int r0, int& kLo, int& kHi) {
+  kLo = 0; kHi = p.K;
+  if (p.bandMode == 1) {
+    const int r1 = min(r0 + 63, p.M - 1);
+    const int q0 = r0 / p.bandH, q1 = r1 / p.bandH;          // (b, i) flattened
+    if (q0 / p.bandT == q1 / p.bandT) {                       // one utterance
+      const int iLo = q0 % p.bandT, iHi = q1 % p.bandT;
+      kLo = max(0, p.bandOff - iHi);
+      kHi = min(p.K, p.bandOff - iLo + p.bandT);
+    }
+  } else if (p.bandMode == 2) {
+    const int w1 = min(r0 + 63, p.M - 1);
+    const int iLo = max(0, p.bandOff - w1), iHi = min(p.bandT - 1, p.bandOff - r0 + p.bandT - 1);
+    kLo = iLo * p.bandH;
+    kHi = min(p.K, (iHi + 1) * p.bandH);
+  }
+  if (kHi < kLo) kHi = kLo;
+}
 
 template <int AM, int BM>
 __global__ __launch_bounds__(256) void bgemm_k(BgP p) {
@@ -213,12 +238,14 @@ __global__ __launch_bounds__(256) void bgemm_bf_k(BgP p) {
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  const int nk = (p.K + kBhK - 1) / kBhK;
-  BhRegs ra = bh_load<AM>(a, tid, mv, 0, p.K), rb = bh_load<BM>(b, tid, nv, 0, p.K);
-  bh_store<AM>(a, tid, ra, As[0]);
-  bh_store<BM>(b, tid, rb, Bs[0]);
+  int kLo, kHi;
+  bg_band(p, tm * 64, kLo, kHi);
+  const int kt0 = kLo / kBhK, nk = (kHi + kBhK - 1) / kBhK;   // K tiles kt0 .. nk (an empty band leaves C = 0 / untouched below)
+  BhRegs ra = bh_load<AM>(a, tid, mv, kt0 * kBhK, p.K), rb = bh_load<BM>(b, tid, nv, kt0 * kBhK, p.K);
+  bh_store<AM>(a, tid, ra, As[kt0 & 1]);
+  bh_store<BM>(b, tid, rb, Bs[kt0 & 1]);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = kt0; kt < nk; ++kt) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nk;
     if (more) {
@@ -400,6 +427,8 @@ static int bgemm_launch(const w2l_bgemm_desc* d, const float* A, const float* B,
   p.tilesN = (d->N + 63) / 64;
   p.a1 = d->a1; p.a2 = d->a2; p.b1 = d->b1; p.b2 = d->b2; p.ldc = d->ldc; p.c1 = d->c1; p.c2 = d->c2;
   p.accumulate = d->accumulate;
+  p.bandMode = d->bandMode; p.bandT = d->bandT; p.bandH = d->bandH; p.bandOff = d->bandOff;
+  if (p.bandMode < 0 || p.bandMode > 2 || (p.bandMode && (p.bandT <= 0 || p.bandH <= 0))) return W2L_EINVAL;
   const long long tiles = (long long)((d->M + 63) / 64) * p.tilesN;
   if (tiles > 0x7fffffffLL) return W2L_EINVAL;
   const int am = !p.A.vec ? kBgGeneric : (d->sam == 1 ? kBgRowVec : kBgKVec);

@@ -1070,12 +1070,14 @@ class TransformerLayer : public Layer {
       {  // dq_(b,i,h) += sum_w dR[(b,i,h)][w] E[rlo + w]
         w2l_bgemm_desc g{};
         g.M = M * nH; g.N = d; g.K = W; g.G1 = g.G2 = 1; g.sam = ldr; g.sak = 1; g.sbk = d; g.sbn = 1; g.ldc = d; g.accumulate = 1;
+        g.bandMode = 1; g.bandT = T; g.bandH = nH; g.bandOff = n0 - rlo;   // row (b, i, h) of dR is zero outside w = j - i + n0 - rlo
         w2lCheck(bg(&g, dR, Ew, dq, s), "tr dq rel");
       }
       {  // dE[rlo + w] = sum_(b,i,h) dR[(b,i,h)][w] q_(b,i,h): one partial per utterance, then a column sum
         w2l_bgemm_desc g{};
         g.M = W; g.N = d; g.K = T * nH; g.G1 = B; g.G2 = 1; g.sam = 1; g.sak = ldr; g.a1 = (long long)T * nH * ldr;
         g.sbk = d; g.sbn = 1; g.b1 = TC; g.ldc = d; g.c1 = (long long)W * d;
+        g.bandMode = 2; g.bandT = T; g.bandH = nH; g.bandOff = n0 - rlo;
         w2lCheck(bg(&g, dR, q, dEp, s), "tr dE");
         zeroGrad(cx, pe, s);
         w2lCheck(w2l_colsum(dEp, pe.g(cx) + (size_t)rlo * d, (size_t)B, W * d, s), "tr dE sum");
