@@ -215,11 +215,15 @@ int w2l_conv_backward_data_add(const w2l_conv_desc* d, const float* dy, const fl
                                const float* add, float* dx, w2l_stream_t stream);
 int w2l_conv_backward_filter(const w2l_conv_desc* d, const float* x, const float* dy, float* dw,
                              float* dbias, w2l_stream_t stream);
-/* fl::TDSBlock's time convolution (C -> C channels, stride 1, T preserved) in the mixed-precision mode (bf16 operand storage, see w2l_gemm_bf16): x / dy and the weights rounded to
- * bf16, fp32 accumulation on v_mfma_f32_32x32x16_bf16, fp32 bias / ReLU / addend / results (conv_tds_bf16.hip).
- * w2l_tds_conv_bf16_image_elems: bf16 elements of ONE weight image of the geometry; 0 = no bf16 kernel for it (use w2l_conv_*).
- * w2l_tds_conv_bf16_prepare: once per step, the forward and the backward-data images of the fp32 weights w [kw][C][C].
- * backward_filter: dw [kw][C][C] only -- the bias gradient stays the fp32 column sum (w2l_colsum over [B T H][C]). */
+/* The kw x 1 convolutions over the mel rows of the TDS recipes in the mixed-precision mode (bf16 operand storage, see
+ * w2l_gemm_bf16) -- fl::TDSBlock's time convolution (C -> C channels, stride 1) and the sub-sampling `C2 cin cout kw 1 s 1`
+ * lines between the blocks (cin != cout <= 32 channels, stride 1 or 2, any padding): x / dy and the weights rounded to bf16,
+ * fp32 accumulation on v_mfma_f32_32x32x16_bf16, fp32 bias / ReLU / addend / results (conv_tds_bf16.hip).  Layouts as
+ * w2l_conv_*: x [B][T][H][Cin], w [kw][Cin][Cout], y / dy [B][To][H][Cout].
+ * w2l_tds_conv_bf16_image_elems: bf16 elements of ONE weight image buffer of the geometry (the forward image, or the images
+ *   of all phases of a strided backward-data pass, whichever is larger); 0 = no bf16 kernel for it (use w2l_conv_*).
+ * w2l_tds_conv_bf16_prepare: once per step, the forward and the backward-data images of the fp32 weights.
+ * backward_filter: dw only (H % 16 == 0) -- the bias gradient stays the fp32 column sum (w2l_colsum over [B To H][Cout]). */
 size_t w2l_tds_conv_bf16_image_elems(const w2l_conv_desc* d);
 int w2l_tds_conv_bf16_prepare(const w2l_conv_desc* d, const float* w, uint16_t* imgForward, uint16_t* imgBackward, w2l_stream_t stream);
 int w2l_tds_conv_bf16_forward(const w2l_conv_desc* d, const float* x, const uint16_t* imgForward, const float* bias, float* y,

@@ -20,6 +20,29 @@ def bf16_round(a):
     return ((u + r) & 0xFFFF0000).astype(np.uint32).view(np.float32).reshape(np.shape(a))
 
 
+# the (padded channels, k-steps, stride) triples the mixed-precision mode has convolution kernels for (conv_tds_bf16.hip):
+# geometries outside stay in fp32 there, so the restatement leaves their operands unrounded too
+_BF16_CONV_FWD = {(16, 9, 1), (16, 21, 1), (24, 15, 1), (24, 18, 1), (24, 33, 1), (32, 22, 1), (16, 5, 1), (16, 11, 1), (24, 9, 1),
+                  (16, 10, 2), (24, 18, 2), (16, 21, 2)}
+_BF16_CONV_FILTER = _BF16_CONV_FWD - {(16, 5, 1), (16, 11, 1), (24, 9, 1)}
+
+
+def conv_rounds_to_bf16(cin, cout, kw, stride, H):
+    """True when the product's mixed-precision mode multiplies this kw x 1 convolution (over H mel rows) in bf16"""
+    if stride not in (1, 2) or not (1 <= cin <= 32 and 1 <= cout <= 32) or kw < stride or H % 16:
+        return False
+    cp = lambda c: 16 if c <= 16 else 24 if c <= 24 else 32
+
+    def nstep(k, c):
+        n = (k * c + 15) // 16
+        while (n * 16) % c:
+            n += 1
+        return n
+    f = (cp(cin), nstep(kw, cp(cin)), stride)
+    b = (cp(cout), nstep((kw + stride - 1) // stride, cp(cout)), 1)
+    return f in _BF16_CONV_FILTER and b in _BF16_CONV_FWD
+
+
 def lin_fwd(x, w, b, bf16=False):
     """fl::Linear forward; bf16: both GEMM operands rounded to bf16 (fp32 accumulate, fp32 bias and result) -- the
     arithmetic of the mixed-precision mode (fl's AMP casts the operands of linear / conv, cpc/Train.cpp:1184 keeps the
@@ -270,7 +293,12 @@ class RefNet:
                     g = params[pi]; pi += 1
                     w = O.weightnorm_fwd(v, g, 1, cout, cin * kw).reshape(v.shape)
                 b = params[pi]; pi += 1
-                self.tape.append(("C", a, w, v, g, stride, pl, pr, pi))
+                rnd = self.bf16 and conv_rounds_to_bf16(cin, cout, kw, stride, a.shape[2])
+                if rnd:   # the mixed-precision mode's sub-sampling convolutions: bf16 operands, fp32 accumulation and bias
+                    self.tape.append(("C", bf16_round(a), bf16_round(w), v, g, stride, pl, pr, pi, True))
+                    a = O.conv_fwd(bf16_round(a), bf16_round(w), b, stride, pl, pr)
+                    continue
+                self.tape.append(("C", a, w, v, g, stride, pl, pr, pi, False))
                 a = O.conv_fwd(a, w, b, stride, pl, pr)
             elif t[0] == "L":
                 nin, nout = int(t[1]), int(t[2])
@@ -372,8 +400,13 @@ class RefNet:
                 inv = np.argsort(rec[1])
                 da = np.ascontiguousarray(da.transpose(inv))
             elif k == "C":
-                _, a, w, v, gg, stride, pl, pr, pi = rec
-                dx, dw, db = O.conv_bwd(a, w, da, stride, pl, pr)
+                _, a, w, v, gg, stride, pl, pr, pi, rnd = rec
+                if rnd:   # dx, dw from the rounded gradient; the bias gradient sums the unrounded one
+                    da = np.ascontiguousarray(da, dtype=np.float32)
+                    dx, dw, _ = O.conv_bwd(a, w, bf16_round(da), stride, pl, pr)
+                    db = da.sum(axis=(0, 2, 3), dtype=np.float64).astype(np.float32)
+                else:
+                    dx, dw, db = O.conv_bwd(a, w, da, stride, pl, pr)
                 g[pi - 1] = db
                 if gg is not None:
                     cout = w.shape[0]

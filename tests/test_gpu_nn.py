@@ -982,5 +982,48 @@ def test_tds_conv_bf16_refuses_other_geometries():
     assert ops.tds_conv_bf16(x, torch.zeros(9, 40, 40, device="cuda"), None, 4, 4) is None          # C > 32
     x = torch.zeros(1, 20, 80, 15, device="cuda")
     assert ops.tds_conv_bf16(x, torch.zeros(7, 15, 15, device="cuda"), None, 3, 3) is None          # kw outside the instantiated set
+    d = ops.conv_desc(x, torch.zeros(9, 15, 15, device="cuda"), 3, 4, 4)
+    assert _lib.lib().w2l_tds_conv_bf16_image_elems(C.byref(d)) == 0                               # stride 3
     d = ops.conv_desc(x, torch.zeros(9, 15, 15, device="cuda"), 2, 4, 4)
-    assert _lib.lib().w2l_tds_conv_bf16_image_elems(C.byref(d)) == 0                               # strided
+    assert _lib.lib().w2l_tds_conv_bf16_image_elems(C.byref(d)) == 0                               # stride 2 at a kw without a kernel
+    y = torch.zeros(1, 20, 80, 15, device="cuda")
+    assert _lib.lib().w2l_tds_conv_bf16_forward(C.byref(d), x.data_ptr(), x.data_ptr(), None, y.data_ptr(), 0, None) == _lib.W2L_EUNSUPPORTED
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,T,kw,stride,padl,padr", [
+    (2, 1, 15, 80, 301, 10, 2, 5, 3), (2, 15, 19, 80, 160, 10, 2, 7, 1), (2, 19, 23, 80, 131, 12, 2, 9, 1), (2, 23, 27, 80, 70, 11, 1, 10, 0),
+    (1, 19, 23, 16, 13, 12, 2, 9, 1), (2, 1, 10, 80, 200, 21, 2, 10, 10), (2, 10, 14, 80, 171, 21, 2, 10, 10), (1, 14, 18, 32, 90, 21, 2, 10, 10),
+    (1, 15, 19, 16, 64, 10, 2, 0, 0)])
+def test_subsampling_conv_bf16_three_passes(oracle, B, Cin, Cout, H, T, kw, stride, padl, padr):
+    """the recipes' SUB-SAMPLING convolutions (C_in != C_out, stride 2 or 1; streaming recipe 1 -> 15 -> 19 -> 23 -> 27 with its
+    asymmetric PD paddings, sota/2019 TDS-CTC 1 -> 10 -> 14 -> 18 at kw 21) on the bf16 kernels: forward (+ bias, ReLU), the
+    phase-decomposed backward-data (+ addend; odd and even lengths) and backward-filter against the oracle on the SAME
+    bf16-rounded operands (fp32 accumulation order is the only difference: 2e-5 / 5e-5 of the largest magnitude), the stated
+    1e-2 against the unrounded convolution, run-to-run determinism"""
+    from oracle import refnet
+    from wav2letter_amd import ops
+    rng = np.random.default_rng(Cin * 100 + T)
+    x = rng.normal(size=(B, Cin, H, T)).astype(np.float32)
+    w = (rng.normal(size=(Cout, Cin, kw)) / np.sqrt(Cin * kw)).astype(np.float32)
+    b = rng.normal(size=Cout).astype(np.float32)
+    xr, wr = refnet.bf16_round(x), refnet.bf16_round(w)
+    y_ref = oracle.conv_fwd(xr, wr, b, stride, padl, padr)
+    xd, wd = dev(to_fm(x)), dev(w_to_dev(w))
+    out = ops.tds_conv_bf16(xd, wd, dev(b), padl, padr, stride=stride)
+    assert out is not None, "geometry of the recipes must have a bf16 kernel"
+    y, imgs, d = out
+    assert rel(from_fm(y.cpu().numpy()), y_ref) < 2e-5
+    assert rel(from_fm(y.cpu().numpy()), oracle.conv_fwd(x, w, b, stride, padl, padr)) < BF16_TOL
+    yr, _, _ = ops.tds_conv_bf16(xd, wd, dev(b), padl, padr, relu=True, stride=stride)
+    assert rel(from_fm(yr.cpu().numpy()), np.maximum(y_ref, 0)) < 2e-5
+    dy = rng.normal(size=y_ref.shape).astype(np.float32)
+    add = rng.normal(size=x.shape).astype(np.float32)
+    odx, odw, _ = oracle.conv_bwd(xr, wr, refnet.bf16_round(dy), stride, padl, padr)
+    dyd, addd = dev(to_fm(dy)), dev(to_fm(add))
+    dx, dw = ops.tds_conv_bf16_backward(xd, dyd, imgs, d, add=addd)
+    assert rel(from_fm(dx.cpu().numpy()), odx + add) < 2e-5
+    assert rel(dw.cpu().numpy(), w_to_dev(odw)) < 5e-5
+    dx2, dw2 = ops.tds_conv_bf16_backward(xd, dyd, imgs, d, add=addd)
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2)
+    dx0, _ = ops.tds_conv_bf16_backward(xd, dyd, imgs, d)
+    assert rel(from_fm(dx0.cpu().numpy()), odx) < 2e-5

@@ -23,7 +23,14 @@
 //   * epilogue from the accumulators: bias, ReLU, the residual / upstream addend of backward-data, fp32 stores of C
 //     consecutive floats per (frame, mel row).
 // Padded channels and taps multiply zeros of the weight image; the slab is zero-filled first so that they read finite
-// values.  Geometry outside (stride 1, C <= 32, H * C % 4 == 0, the instantiated (CP, k-steps) pairs) returns
+// values.
+//
+// The same kernels serve the recipe's SUB-SAMPLING convolutions (`C2 cin cout kw 1 s 1`: 1 -> 15 -> 19 -> 23 -> 27 channels,
+// stride 2 / 2 / 2 / 1): C_in != C_out (CP pads the INPUT channels, the <= 32 output channels are the MFMA columns), the
+// stride is a template parameter (row t of a fragment reads slab frame STRIDE * t + tap), and a strided backward-data is one
+// stride-1 launch per PHASE f = (frame + padl) mod stride over dy with the taps f, f + s, ... (tap-flipped image per phase),
+// written to every s-th frame of dx -- no zero-stuffed dy, no wasted multiplies (the decomposition of conv_tds.hip).
+// Geometry outside (stride 1 / 2, channels <= 32, H % 8 == 0, the instantiated (CP, k-steps, stride) triples) returns
 // W2L_EUNSUPPORTED and the caller stays on the fp32 kernels.
 #include "gemm.hpp"
 
@@ -37,13 +44,14 @@ constexpr int kTbTT = 64;   // output frames per workgroup
 constexpr int kTbHB = 8;    // mel rows per workgroup (two per wave)
 
 struct TdsBfP {
-  const float* x;        // [B][T][H][C] fp32: the activations (forward) or the output gradient (backward-data)
-  const uint16_t* wimg;  // [32][Kp] bf16, k = tap * CP + c
-  const float* bias;     // [C] or null
+  const float* x;        // [B][Tin][H][Cin] fp32: the activations (forward) or the output gradient (backward-data)
+  const uint16_t* wimg;  // [32][Kp] bf16, k = tap * CP + c_in
+  const float* bias;     // [Cout] or null
   const float* add;      // layout of y, or null
-  float* y;              // [B][T][H][C]
-  int B, T, H, C, kw, padl, relu;
-  uint32_t cMagic;       // ceil(2^32 / C): e / C for e < 2^16
+  float* y;              // [B][ToutFull][H][Cout]; row t of this launch is frame oOff + oStep * t of it
+  int B, Tin, Tout, H, Cin, Cout, padl, relu;
+  int oOff, oStep, ToutFull;
+  uint32_t cMagic;       // ceil(2^32 / Cin): e / Cin for e < 2^16 (unused at Cin == 1)
 };
 
 __device__ __forceinline__ uint16_t tb_bf16(float v) {
@@ -54,18 +62,111 @@ __device__ __forceinline__ uint16_t tb_bf16(float v) {
 // frame pitch in bytes: HB rows of CP bf16, rounded up to 16 bytes x an odd number
 __host__ __device__ constexpr int tb_frame_pitch(int CP) { return ((kTbHB * CP * 2 / 16) | 1) * 16; }
 
-template <int CP, int NSTEP>
+// ---- staging: frames tFirst .. tFirst + nFrames - 1 of one utterance's HB mel rows (src = its [T][H][C] block + h0 * C floats)
+// -> slab[f][h][CP] as bf16.  Frames outside [0, T) are written as zeros; the padded channels c >= C are never written (the
+// kernels zero-fill the slab first).
+//
+// The first generation walked the fp32 block as aligned float4 and scattered the four elements one by one -- with odd channel
+// counts every element needs its own (mel row, channel) split and its own 2-byte LDS store: ~130 VALU instructions per 16 bytes
+// (ISA count), and the convolutions ran at the rate the SIMDs could stage, 1.7 - 2.9 TB/s.  Here a lane owns one CHUNK of the
+// slab -- 4 consecutive channels of one (frame, mel row): a dword-aligned 16-byte global load (channel counts are odd: the
+// chunk starts wherever the row starts), two packed conversions, ONE 8-byte LDS store; all index arithmetic divides by
+// compile-time constants.  The chunk that holds the row's last channels is loaded shifted back to END at the row's end (no
+// read past the tensor) and shifted down in registers, zeros filling its padded slots.  C >= 4.
+typedef float tb_f32x4u_t __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int CP, int HB>
+__device__ __forceinline__ void tb_stage(unsigned char* slab, int FS, const float* __restrict__ src, int C, size_t frameStride, int tFirst,
+                                         int nFrames, int T, int tid) {
+  constexpr int G = CP / 4, PER = HB * G, NV = 8;
+  const int total = nFrames * PER;
+  const int gLast = (C - 1) >> 2;         // the chunk with the row's last channels
+  const int over = 4 * gLast + 4 - C;     // its 0 .. 3 slots past the row
+  for (int base = 0; base < total; base += NV * 256) {
+    tb_f32x4u_t w[NV];
+    int dst[NV];                          // LDS byte offset | 1: the row's last chunk | 2: frame outside the utterance; -1: nothing to write
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {        // unconditional loads from clamped addresses (a load inside a branch serialises)
+      const int q = base + tid + 256 * u;
+      const int qq = q < total ? q : total - 1;
+      const int f = qq / PER, r = qq - f * PER;
+      const int h = r / G, cg = r - h * G;
+      const int tin = tFirst + f;
+      const int tc = tin < 0 ? 0 : (tin >= T ? T - 1 : tin);
+      const int cgc = cg < gLast ? cg : gLast;
+      const int c0 = cgc < gLast ? 4 * cgc : C - 4;
+      w[u] = *(const tb_f32x4u_t*)(src + (size_t)tc * frameStride + h * C + c0);
+      dst[u] = (q < total && cg <= gLast) ? ((f * FS + (h * CP + 4 * cg) * 2) | (cg == gLast ? 1 : 0) | (tin != tc ? 2 : 0)) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const tb_f32x4u_t a = w[u];
+      // the last chunk was loaded `over` channels early: slot k holds channel 4 gLast + k - over
+      const float s0 = over == 0 ? a.x : over == 1 ? a.y : over == 2 ? a.z : a.w;
+      const float s1 = over == 0 ? a.y : over == 1 ? a.z : over == 2 ? a.w : 0.f;
+      const float s2 = over == 0 ? a.z : over == 1 ? a.w : 0.f;
+      const float s3 = over == 0 ? a.w : 0.f;
+      const bool last = (dst[u] & 1) != 0, zero = (dst[u] & 2) != 0;
+      const tb_f32x2_t lo = {last ? s0 : a.x, last ? s1 : a.y}, hi = {last ? s2 : a.z, last ? s3 : a.w};
+      uint2 pk = make_uint2(__builtin_bit_cast(uint32_t, __builtin_convertvector(lo, tb_bf16x2_t)),
+                            __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, tb_bf16x2_t)));
+      if (zero) pk = make_uint2(0u, 0u);
+      if (dst[u] >= 0) *(uint2*)(slab + (dst[u] & ~7)) = pk;
+    }
+  }
+}
+
+// any C (the one-channel input of the first sub-sampling convolution): aligned float4 over the HB * C floats of a frame,
+// element-wise split into (mel row, channel)
+template <int CP, int HB>
+__device__ __forceinline__ void tb_stage_generic(unsigned char* slab, int FS, const float* __restrict__ src, int C, uint32_t magic,
+                                                 size_t frameStride, int tFirst, int nFrames, int T, int tid) {
+  const int runF4 = HB * C / 4;                  // float4 per frame (HB % 4 == 0)
+  const int total = nFrames * runF4;
+  constexpr int NV = 8;
+  for (int base = 0; base < total; base += NV * 256) {
+    float4 v4[NV];
+    int fo[NV], eo[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int q = base + tid + 256 * u;
+      const int qq = q < total ? q : total - 1;
+      const int f = qq / runF4, j = qq - f * runF4;
+      const int tin = tFirst + f;
+      const int tc = tin < 0 ? 0 : (tin >= T ? T - 1 : tin);
+      fo[u] = q < total ? (tin == tc ? f : f | 0x40000000) : -1;
+      eo[u] = 4 * j;
+      v4[u] = *(const float4*)(src + (size_t)tc * frameStride + 4 * j);
+    }
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      if (fo[u] < 0) continue;
+      const bool zero = (fo[u] & 0x40000000) != 0;
+      const int f = fo[u] & 0x3fffffff;
+      const float v[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = eo[u] + k;
+        const int h = C == 1 ? e : (int)(((uint64_t)e * magic) >> 32);
+        const int c = e - h * C;
+        *(uint16_t*)(slab + f * FS + (h * CP + c) * 2) = zero ? (uint16_t)0 : tb_bf16(v[k]);
+      }
+    }
+  }
+}
+
+template <int CP, int NSTEP, int STRIDE>
 __global__ __launch_bounds__(256) void tds_conv_bf_k(TdsBfP p) {
   static_assert((NSTEP * 16) % CP == 0, "whole taps");
   constexpr int KWP = NSTEP * 16 / CP;          // taps the K loop walks (>= kw; the weight image is zero beyond kw)
-  constexpr int NF = kTbTT + KWP - 1;           // slab frames
+  constexpr int NF = (kTbTT - 1) * STRIDE + KWP;   // slab frames
   constexpr int FS = tb_frame_pitch(CP);        // bytes
   extern __shared__ __attribute__((aligned(16))) unsigned char slab[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int h0 = blockIdx.x * kTbHB, t0 = blockIdx.y * kTbTT, b = blockIdx.z;
-  const int C = p.C;
+  const int C = p.Cin, Co = p.Cout;
 
   // ---- weight fragments: column li, k = 16 s + 8 lh .. + 8 of every k-step (registers for the whole workgroup)
   tb_bf16x8_t wf[NSTEP];
@@ -82,44 +183,10 @@ __global__ __launch_bounds__(256) void tds_conv_bf_k(TdsBfP p) {
   }
   __syncthreads();
   {
-    // (the loads of a batch are issued back to back, THEN converted and stored: one exposed memory latency per batch of 8
-    // float4 instead of one per float4 -- the first build waited for every load before issuing the next: 150 - 350 us per call)
-    const int runF4 = 2 * C;                     // float4 per frame: 8 mel rows x C floats (H * C % 4 == 0: host-checked)
-    const float* xb = p.x + ((size_t)b * p.T * p.H + h0) * C;
+    const float* xb = p.x + ((size_t)b * p.Tin * p.H + h0) * C;
     const size_t frameStride = (size_t)p.H * C;
-    const int hValid = kTbHB;                    // H % 8 == 0 (host-checked)
-    const int total = NF * runF4;
-    constexpr int NV = 8;
-    for (int base = 0; base < total; base += NV * 256) {
-      float4 v4[NV];
-      int fo[NV], eo[NV];
-#pragma unroll
-      for (int u = 0; u < NV; ++u) {
-        // UNCONDITIONAL loads from clamped (always valid) addresses, zero selected afterwards: a load inside a branch makes
-        // hipcc wait vmcnt(0) right behind it (seen in the second build's ISA: eight serialized round trips per batch)
-        const int q = base + tid + 256 * u;
-        const int qq = q < total ? q : total - 1;
-        const int f = qq / runF4, j = qq - f * runF4;
-        const int tin = t0 - p.padl + f;
-        const int tc = tin < 0 ? 0 : (tin >= p.T ? p.T - 1 : tin);
-        const bool ok = q < total && tin == tc && 4 * j < hValid * C;
-        fo[u] = ok ? f : -1;
-        eo[u] = 4 * j;
-        v4[u] = *(const float4*)(xb + (size_t)tc * frameStride + 4 * j);
-      }
-#pragma unroll
-      for (int u = 0; u < NV; ++u) {
-        if (fo[u] < 0) continue;
-        const float v[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int e = eo[u] + k;
-          const int h = (int)(((uint64_t)e * p.cMagic) >> 32);
-          const int c = e - h * C;
-          if (h < hValid) *(uint16_t*)(slab + fo[u] * FS + (h * CP + c) * 2) = tb_bf16(v[k]);
-        }
-      }
-    }
+    if (C >= 4) tb_stage<CP, kTbHB>(slab, FS, xb, C, frameStride, t0 * STRIDE - p.padl, NF, p.Tin, tid);
+    else tb_stage_generic<CP, kTbHB>(slab, FS, xb, C, p.cMagic, frameStride, t0 * STRIDE - p.padl, NF, p.Tin, tid);
   }
   __syncthreads();
 
@@ -129,7 +196,7 @@ __global__ __launch_bounds__(256) void tds_conv_bf_k(TdsBfP p) {
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    const unsigned char* a0 = slab + (32 * th + li) * FS + (2 * wave) * CP * 2;
+    const unsigned char* a0 = slab + (STRIDE * (32 * th + li)) * FS + (2 * wave) * CP * 2;
     const unsigned char* a1 = a0 + CP * 2;
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
@@ -145,16 +212,16 @@ __global__ __launch_bounds__(256) void tds_conv_bf_k(TdsBfP p) {
     // epilogue: C layout col = li (output channel), row = (r & 3) + 8 (r >> 2) + 4 lh (frame).  The addend of backward-data
     // is fetched for all 32 outputs of the lane FIRST, unconditionally from clamped addresses (a load inside the bounds
     // branch serialises: hipcc waits vmcnt(0) behind each, and on gfx9 that counter also holds the stores in between)
-    const int lc = li < C ? li : C - 1;
+    const int lc = li < Co ? li : Co - 1;
     const float bv = p.bias ? p.bias[lc] : 0.f;
-    const size_t tile = (((size_t)b * p.T + t0) * p.H + h0) * C;   // wave-uniform; per-output offsets stay 32-bit
+    const size_t tile = (((size_t)b * p.ToutFull + p.oOff + (size_t)p.oStep * t0) * p.H + h0) * Co;   // wave-uniform; per-output offsets stay 32-bit
     const float* addb = p.add ? p.add + tile : nullptr;
     float* yb = p.y + tile;
-    const int tl0 = 32 * th + 4 * lh, tlMax = p.T - 1 - t0, hC = p.H * C;
+    const int tl0 = 32 * th + 4 * lh, tlMax = p.Tout - 1 - t0, hC = p.oStep * p.H * Co;
     float av[2][16];
     auto off = [&](int hh, int r) {
       const int tl = tl0 + (r & 3) + 8 * (r >> 2);
-      return (tl < tlMax ? tl : tlMax) * hC + (2 * wave + hh) * C + lc;
+      return (tl < tlMax ? tl : tlMax) * hC + (2 * wave + hh) * Co + lc;
     };
     if (addb) {
 #pragma unroll
@@ -182,134 +249,160 @@ __global__ __launch_bounds__(256) void tds_conv_bf_k(TdsBfP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int tl = tl0 + (r & 3) + 8 * (r >> 2);
-        if (li < C && tl <= tlMax) yb[off(hh, r)] = av[hh][r];
+        if (li < Co && tl <= tlMax) yb[off(hh, r)] = av[hh][r];
       }
   }
 }
 
-// weight image [32][Kp] bf16 of w [kw][C][C] (forward: w[tap][ci][co]):
-//   flip == 0: img[co][tap * CP + ci] = w[tap][ci][co]
-//   flip == 1: img[ci][j * CP + co]   = w[kw - 1 - j][ci][co]      (backward-data: a forward pass over dy)
-__global__ __launch_bounds__(256) void tds_bf_wprep_k(const float* __restrict__ w, int kw, int C, int CP, int Kp, int flip,
-                                                      uint16_t* __restrict__ img) {
+// weight image [32][Kp] bf16 of w [kw][Cin][Cout] (w[tap][ci][co]); the image walks kwEff logical taps j:
+//   flip == 0 (forward):        img[co][j * CP + ci] = w[j][ci][co]                                    CP pads Cin
+//   flip == 1 (backward-data):  img[ci][j * CP + co] = w[tapOff + tapStep * (kwEff - 1 - j)][ci][co]   CP pads Cout
+// (a forward pass over dy; tapOff / tapStep select the taps of one phase of a strided convolution)
+__global__ __launch_bounds__(256) void tds_bf_wprep_k(const float* __restrict__ w, int kw, int Cin, int Cout, int CP, int Kp, int kwEff,
+                                                      int tapOff, int tapStep, int flip, uint16_t* __restrict__ img) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= 32 * Kp) return;
   const int n = e / Kp, k = e - n * Kp;
-  const int tap = k / CP, c = k - tap * CP;
+  const int j = k / CP, c = k - j * CP;
   float v = 0.f;
-  if (n < C && c < C && tap < kw) v = flip ? w[((size_t)(kw - 1 - tap) * C + n) * C + c] : w[((size_t)tap * C + c) * C + n];
+  if (j < kwEff) {
+    if (flip) {
+      const int tap = tapOff + tapStep * (kwEff - 1 - j);
+      if (n < Cin && c < Cout && tap < kw) v = w[((size_t)tap * Cin + n) * Cout + c];
+    } else if (n < Cout && c < Cin) {
+      v = w[((size_t)j * Cin + c) * Cout + n];
+    }
+  }
   img[e] = tb_bf16(v);
 }
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// backward-filter:  dW[tap][ci][co] = sum over (utterance, frame t, mel row h) of x[t + tap - padl][h][ci] * dy[t][h][co]
-// The contraction runs over POSITIONS, so both MFMA operands need 8 consecutive positions per lane: the slabs are staged
-// MEL-FASTEST, xs[frame][ci][h] and ys[frame][co][h] (bf16), and the 16 mel rows of a workgroup's block are the k dimension
-// of one v_mfma_f32_32x32x16_bf16 (a tap shift moves whole frames, never the 16-byte alignment of a fragment; a
-// time-fastest slab would misalign every odd tap).  Rows of the product = (tap, ci) in the forward K order k = tap CP + ci,
-// 32 per tile; columns = co.  The transposition happens in the STAGING: lane = (channel c = lane >> 3, mel pair = lane & 7)
-// loads x[..][2 hp][c] and x[..][2 hp + 1][c] and stores ONE packed dword -- 8 channels x 8 pairs per instruction land in
-// (nearly) distinct banks at a 48-byte row pitch.  512 persistent workgroups walk the (utterance, 16-frame tile, 16-mel
-// block) items; a wave owns a quarter of the row tiles and keeps their accumulators in registers over every item (no
-// cross-wave reduction), the per-workgroup partials are added in workgroup order by tds_bf_filter_reduce_k (deterministic).
-constexpr int kTfTT = 16;      // frames per item
-constexpr int kTfHB = 16;      // mel rows per item = k of one MFMA
-constexpr int kTfPitch = 48;   // bytes per (frame, channel) row: 16 mel rows of bf16 + 16 bytes (16 x an odd number)
+// backward-filter:  dW[tap][ci][co] = sum over (utterance, frame t, mel row h) of x[STRIDE t + tap - padl][h][ci] * dy[t][h][co]
+// The contraction runs over POSITIONS, so both MFMA operands need 8 consecutive positions per lane -- k of one
+// v_mfma_f32_32x32x16_bf16 = the 16 mel rows of a workgroup's block (a tap shift moves whole frames, never the alignment of a
+// fragment; a time-fastest slab would misalign every odd tap); rows of the product = (tap, ci) in the forward K order
+// k = tap CP + ci, 32 per tile; columns = co.
+//
+// The slabs are FRAME-MAJOR like the forward kernel's, slab[frame][mel row][CP channels], and the position-contiguous fragments
+// come out of the LDS TRANSPOSE READ: with ds_read_b64_tr_b16 (gfx950) the 8-byte chunks of the 16 lanes of a group form a 4 x 16
+// matrix (row r = the chunks of lanes 4 r .. 4 r + 3) and lane l receives COLUMN l & 15 (tools/micro/tr16_probe.hip pins this
+// with permuted addresses) -- so when lane (r, cb) supplies the address of channels 4 cb .. 4 cb + 3 at mel row r, every lane
+// ends up with ONE channel at four consecutive mel rows.  Two reads = the 8 positions of an MFMA operand; four consecutive rows
+// (tap, ci) of a chunk never straddle a tap because CP % 4 == 0.  Per dy frame two reads for B (shared by the row tiles), per
+// MFMA two for A.  Frame pitch = 16 rows * CP * 2 + 128 bytes: at CP = 16 the two 16-row groups of a read (two taps) land in
+// disjoint bank halves.  Staging = tb_stage for both x and dy.  512 persistent workgroups walk the (utterance, 16 dy frames,
+// 16 mel rows) items, two per CU (one stages while the other multiplies); a wave owns a quarter of the row tiles and keeps
+// their accumulators in registers over every item (no cross-wave reduction); the per-workgroup partials are added in workgroup
+// order by tds_bf_filter_reduce_k (deterministic).
+// (First generation, run 41: mel-fastest slabs xs[frame][ci][h] filled by scalar loads and packed pair stores -- 56 - 70 TFLOP/s
+// in the config-3 step; the transposition was paid in the staging.  profiles/r03_run13_*.)
 constexpr int kTfWorkers = 512;
 
 struct TdsBfFilterP {
-  const float* x;    // [B][T][H][C]
-  const float* dy;   // [B][T][H][C]
+  const float* x;    // [B][Tin][H][Cin]
+  const float* dy;   // [B][Tout][H][Cout]
   float* partial;    // [workers][NRT * 32][32]
-  int B, T, H, C, kw, padl;
+  int B, Tin, Tout, H, Cin, Cout, kw, padl;
 };
 
-template <int CP, int NSTEP>
-__global__ __launch_bounds__(256) void tds_conv_bf_filter_k(TdsBfFilterP p) {
+// dw[tap][ci][co] = sum over the workgroups' partials, always in the same order: 16 outputs x 16 worker lanes per
+// workgroup, a lane adds every 16th partial, the 16 lane sums are added in lane order (the first build walked all 512
+// partials in ONE thread per output: 135 us per call)
+__global__ __launch_bounds__(256) void tds_bf_filter_reduce_k(const float* __restrict__ partial, int workers, int rows32, int kw, int Cin, int Cout,
+                                                              int CP, float* __restrict__ dw) {
+  __shared__ float sm[16][17];
+  const int o = threadIdx.x & 15, wl = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + o, n = kw * Cin * Cout;
+  float s = 0.f;
+  if (e < n) {
+    const int co = e % Cout, ci = (e / Cout) % Cin, tap = e / (Cin * Cout);
+    const size_t at = (size_t)(tap * CP + ci) * 32 + co;
+    for (int w = wl; w < workers; w += 16) s += partial[(size_t)w * rows32 * 32 + at];
+  }
+  sm[wl][o] = s;
+  __syncthreads();
+  if (wl == 0 && e < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sm[k][o];
+    dw[e] = t;
+  }
+}
+
+constexpr int kTgTT = 16, kTgHB = 16;
+__host__ __device__ constexpr int tg_pitch(int CP) { return kTgHB * CP * 2 + 128; }
+
+typedef short tg_s16x4_t __attribute__((ext_vector_type(4)));
+typedef short tg_s16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ tb_bf16x8_t tg_read8(const unsigned char* p0, int step) {   // k 0 .. 3 at p0, k 4 .. 7 at p0 + step
+  typedef __attribute__((address_space(3))) tg_s16x4_t* lptr;
+  const tg_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p0));
+  const tg_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p0 + step));
+  return __builtin_bit_cast(tb_bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int CP, int NSTEP, int STRIDE, int CPO>
+__global__ __launch_bounds__(256) void tds_conv_bf_filter_tr_k(TdsBfFilterP p, uint32_t magicI, uint32_t magicO) {
   constexpr int KWP = NSTEP * 16 / CP, Kp = NSTEP * 16;
-  constexpr int NRT = (Kp + 31) / 32;            // row tiles of 32 (tap, ci) rows
-  constexpr int NRTW = (NRT + 3) / 4;            // row tiles per wave
-  constexpr int NFX = kTfTT + KWP - 1;
+  constexpr int NRT = (Kp + 31) / 32, NRTW = (NRT + 3) / 4;
+  constexpr int NFX = (kTgTT - 1) * STRIDE + KWP;
+  constexpr int FSX = tg_pitch(CP);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int C = p.C;
-  const int FSX = C * kTfPitch;                  // bytes per slab frame (C rows)
+  constexpr int FSY = tg_pitch(CPO);
   unsigned char* xs = lds;
   unsigned char* ys = lds + NFX * FSX;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
-  const int tTiles = (p.T + kTfTT - 1) / kTfTT, hBlocks = p.H / kTfHB;
+  const int tTiles = (p.Tout + kTgTT - 1) / kTgTT, hBlocks = p.H / kTgHB;
   const int nItems = p.B * tTiles * hBlocks;
 
+  {   // zero fill once: the padded channels are never written again
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    const int bytes = NFX * FSX + kTgTT * FSY;
+    for (int o = tid * 16; o < bytes; o += 256 * 16) *(uint4*)(lds + o) = z;
+  }
+  // this lane's chunk in a transpose read: mel row kRow (+ 4 for the second read), operand rows / columns idx0 .. idx0 + 3
+  const int q = lane & 15, grp = lane >> 4;
+  const int kRow = 8 * (grp >> 1) + (q >> 2);
+  const int idx0 = 16 * (grp & 1) + 4 * (q & 3);
   f32x16 acc[NRTW];
-  int rowOff[NRTW];   // byte offset of this lane's (tap, ci) row inside the x slab, + the lane half's 8 mel rows
+  int rowOff[NRTW];
 #pragma unroll
   for (int j = 0; j < NRTW; ++j) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    const int rt = wave + 4 * j;
-    int k = 32 * rt + li;
-    if (k > Kp - 1) k = Kp - 1;                  // rows past K: any valid address (never stored)
-    const int tap = k / CP;
-    int ci = k - tap * CP;
-    if (ci > C - 1) ci = C - 1;                  // padded channels: any valid row (never stored)
-    rowOff[j] = tap * FSX + ci * kTfPitch + 16 * lh;
+    int i = 32 * (wave + 4 * j) + idx0;
+    if (i > Kp - 4) i = Kp - 4;                  // rows past K: any valid chunk (never stored)
+    const int tap = i / CP, ci = i - tap * CP;
+    rowOff[j] = tap * FSX + kRow * CP * 2 + ci * 2;
   }
-  const int bOff = (li < C ? li : C - 1) * kTfPitch + 16 * lh;
-  const int cl = lane >> 3, hp = lane & 7;       // staging role: channel cl (+ 8 per pass), mel rows 2 hp, 2 hp + 1
+  const int bOff = kRow * CPO * 2 + (idx0 < CPO ? idx0 : 0) * 2;
+  const size_t fsIn = (size_t)p.H * p.Cin, fsOut = (size_t)p.H * p.Cout;
 
   for (int item = blockIdx.x; item < nItems; item += gridDim.x) {
     const int hb = item % hBlocks, tt = (item / hBlocks) % tTiles, b = item / (hBlocks * tTiles);
-    const int t0 = tt * kTfTT, h0 = hb * kTfHB;
-    __syncthreads();                             // the previous item's fragments have been read
-    // ---- staging: frames of x (with the tap halo) and of dy, transposed to mel-fastest bf16; zeros outside the utterance
-    // (two frames x up to four channel passes = 16 scalar loads in flight per lane before the first conversion)
-    for (int f0 = wave; f0 < NFX + kTfTT; f0 += 8) {
-      float v0[2][4], v1[2][4];
-#pragma unroll
-      for (int ff = 0; ff < 2; ++ff) {
-        const int f = f0 + 4 * ff;
-        const bool isX = f < NFX;
-        const int fl = isX ? f : f - NFX;
-        const int tin = isX ? t0 - p.padl + fl : t0 + fl;
-        const bool in = f < NFX + kTfTT && tin >= 0 && tin < p.T;
-        const float* src = (isX ? p.x : p.dy) + ((((size_t)b * p.T + (in ? tin : 0)) * p.H + h0 + 2 * hp) * C);
-#pragma unroll
-        for (int cp = 0; cp < 4; ++cp) {   // unconditional loads from clamped addresses, zero selected afterwards
-          const int c = cl + 8 * cp;
-          const int cc = c < C ? c : C - 1;
-          const float a0 = src[cc], a1 = src[C + cc];
-          const bool ok = in && c < C;
-          v0[ff][cp] = ok ? a0 : 0.f;
-          v1[ff][cp] = ok ? a1 : 0.f;
-        }
-      }
-#pragma unroll
-      for (int ff = 0; ff < 2; ++ff) {
-        const int f = f0 + 4 * ff;
-        if (f >= NFX + kTfTT) continue;
-        const bool isX = f < NFX;
-        const int fl = isX ? f : f - NFX;
-        unsigned char* dst = (isX ? xs : ys) + fl * FSX + hp * 4;
-#pragma unroll
-        for (int cp = 0; cp < 4; ++cp) {
-          const int c = cl + 8 * cp;
-          if (c >= C) continue;
-          const tb_f32x2_t pr = {v0[ff][cp], v1[ff][cp]};
-          *(uint32_t*)(dst + c * kTfPitch) = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, tb_bf16x2_t));
-        }
-      }
+    const int t0 = tt * kTgTT, h0 = hb * kTgHB;
+    __syncthreads();                             // the previous item's fragments have been read (and the zero fill is done)
+    {
+      const float* xb = p.x + ((size_t)b * p.Tin * p.H + h0) * p.Cin;
+      const float* yb = p.dy + ((size_t)b * p.Tout * p.H + h0) * p.Cout;
+      if (p.Cin >= 4) tb_stage<CP, kTgHB>(xs, FSX, xb, p.Cin, fsIn, t0 * STRIDE - p.padl, NFX, p.Tin, tid);
+      else tb_stage_generic<CP, kTgHB>(xs, FSX, xb, p.Cin, magicI, fsIn, t0 * STRIDE - p.padl, NFX, p.Tin, tid);
+      if (p.Cout >= 4) tb_stage<CPO, kTgHB>(ys, FSY, yb, p.Cout, fsOut, t0, kTgTT, p.Tout, tid);
+      else tb_stage_generic<CPO, kTgHB>(ys, FSY, yb, p.Cout, magicO, fsOut, t0, kTgTT, p.Tout, tid);
     }
     __syncthreads();
-    // ---- one MFMA per (frame, row tile): k = the 16 mel rows of the block
+    // ---- one MFMA per (dy frame, row tile): k = the 16 mel rows of the block
 #pragma unroll 4
-    for (int t = 0; t < kTfTT; ++t) {
-      const tb_bf16x8_t bf = *(const tb_bf16x8_t*)(ys + t * FSX + bOff);
+    for (int t = 0; t < kTgTT; ++t) {
+      const tb_bf16x8_t bf = tg_read8(ys + t * FSY + bOff, 4 * CPO * 2);
 #pragma unroll
       for (int j = 0; j < NRTW; ++j) {
         if (wave + 4 * j < NRT) {
-          const tb_bf16x8_t af = *(const tb_bf16x8_t*)(xs + t * FSX + rowOff[j]);
+          const tb_bf16x8_t af = tg_read8(xs + (t * STRIDE) * FSX + rowOff[j], 4 * CP * 2);
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[j], 0, 0, 0);
         }
       }
@@ -329,99 +422,123 @@ __global__ __launch_bounds__(256) void tds_conv_bf_filter_k(TdsBfFilterP p) {
   }
 }
 
-// dw[tap][ci][co] = sum over the workgroups' partials, always in the same order: 16 outputs x 16 worker lanes per
-// workgroup, a lane adds every 16th partial, the 16 lane sums are added in lane order (the first build walked all 512
-// partials in ONE thread per output: 135 us per call)
-__global__ __launch_bounds__(256) void tds_bf_filter_reduce_k(const float* __restrict__ partial, int workers, int rows32, int kw, int C, int CP,
-                                                              float* __restrict__ dw) {
-  __shared__ float sm[16][17];
-  const int o = threadIdx.x & 15, wl = threadIdx.x >> 4;
-  const int e = blockIdx.x * 16 + o, n = kw * C * C;
-  float s = 0.f;
-  if (e < n) {
-    const int co = e % C, ci = (e / C) % C, tap = e / (C * C);
-    const size_t at = (size_t)(tap * CP + ci) * 32 + co;
-    for (int w = wl; w < workers; w += 16) s += partial[(size_t)w * rows32 * 32 + at];
-  }
-  sm[wl][o] = s;
-  __syncthreads();
-  if (wl == 0 && e < n) {
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t += sm[k][o];
-    dw[e] = t;
-  }
-}
+static inline int tb_cp(int C) { return C <= 16 ? 16 : C <= 24 ? 24 : 32; }
+static inline uint32_t tb_magic(int C) { return C == 1 ? 0u : (uint32_t)((0x100000000ull + C - 1) / C); }
 
-template <int CP, int NSTEP>
+template <int CP, int NSTEP, int STRIDE, int CPO>
 static int tb_launch_filter(const TdsBfFilterP& p0, float* dw, hipStream_t s) {
-  constexpr int KWP = NSTEP * 16 / CP, Kp = NSTEP * 16, NRT = (Kp + 31) / 32;
+  constexpr int KWP = NSTEP * 16 / CP, Kp = NSTEP * 16, NRT = (Kp + 31) / 32, NFX = (kTgTT - 1) * STRIDE + KWP;
   TdsBfFilterP p = p0;
-  const int tTiles = (p.T + kTfTT - 1) / kTfTT, nItems = p.B * tTiles * (p.H / kTfHB);
+  const int tTiles = (p.Tout + kTgTT - 1) / kTgTT, nItems = p.B * tTiles * (p.H / kTgHB);
   const int workers = nItems < kTfWorkers ? nItems : kTfWorkers;
   const size_t need = (size_t)workers * NRT * 32 * 32 * sizeof(float);
   if (need > kSkScratchBytes) return W2L_EUNSUPPORTED;
+  const size_t shmem = (size_t)NFX * tg_pitch(CP) + (size_t)kTgTT * tg_pitch(CPO);
+  if (shmem > 80 * 1024) return W2L_EUNSUPPORTED;   // two workgroups per CU: one stages while the other multiplies
   p.partial = sk_scratch(s, kSkScratchBytes);
   if (!p.partial) return W2L_EHIP;
-  const size_t shmem = (size_t)(kTfTT + KWP - 1 + kTfTT) * p.C * kTfPitch;
   static bool attr = false;
   if (!attr) {
-    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_bf_filter_k<CP, NSTEP>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_bf_filter_tr_k<CP, NSTEP, STRIDE, CPO>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     attr = true;
   }
-  if (shmem > 96 * 1024) return W2L_EUNSUPPORTED;
-  hipLaunchKernelGGL((tds_conv_bf_filter_k<CP, NSTEP>), dim3((unsigned)workers), dim3(256), shmem, s, p);
-  const int n = p.kw * p.C * p.C;
-  hipLaunchKernelGGL(tds_bf_filter_reduce_k, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, p.partial, workers, NRT * 32, p.kw, p.C, CP, dw);
+  hipLaunchKernelGGL((tds_conv_bf_filter_tr_k<CP, NSTEP, STRIDE, CPO>), dim3((unsigned)workers), dim3(256), shmem, s, p, tb_magic(p.Cin), tb_magic(p.Cout));
+  const int n = p.kw * p.Cin * p.Cout;
+  hipLaunchKernelGGL(tds_bf_filter_reduce_k, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, p.partial, workers, NRT * 32, p.kw, p.Cin, p.Cout, CP, dw);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }
 
-struct TbGeom { int CP, NSTEP; };
-static bool tb_geometry(const w2l_conv_desc* d, TbGeom& g) {
-  if (!d || d->stride != 1 || d->Cin != d->Cout || d->Cin < 1 || d->Cin > 32 || d->kw < 1) return false;
-  if (d->padl + d->padr != d->kw - 1 || d->H % kTbHB != 0) return false;   // whole 8-row mel blocks (16-byte aligned runs of 8 C floats)
-  const int C = d->Cin;
-  g.CP = C <= 16 ? 16 : C <= 24 ? 24 : 32;
-  int n = (d->kw * g.CP + 15) / 16;
-  while ((n * 16) % g.CP) ++n;
-  g.NSTEP = n;
-  // the instantiated pairs (streaming recipe: (16, 9) (24, 15) (24, 18) (32, 22); sota/2019 TDS-CTC channel counts at kw = 21: (16, 21) (24, 33))
-  return (g.CP == 16 && (n == 9 || n == 21)) || (g.CP == 24 && (n == 15 || n == 18 || n == 33)) || (g.CP == 32 && n == 22);
+// ---------------------------------------------------------------------------------------------------------------------
+// geometry of a w2l_conv_desc: padded channel counts, k-steps, the phases of its backward-data pass
+static inline int tb_nstep(int kw, int CP) {
+  int n = (kw * CP + 15) / 16;
+  while ((n * 16) % CP) ++n;
+  return n;
+}
+struct TbPhase { int kwf, c0, U, padl, tapOff; };
+struct TbGeom {
+  int stride, To;
+  int CPf, NSf;        // forward and backward-filter: CP pads Cin, k-steps over kw taps
+  int CPb, NSb;        // backward-data: CP pads Cout (the channels of dy), k-steps over the longest phase
+  int phases;
+  TbPhase ph[2];
+};
+
+// the instantiated (CP, k-steps, stride) triples.  Streaming recipe (am_500ms_future_context.arch): TDS blocks (16, 9) (24, 15)
+// (24, 18) (32, 22); sub-sampling convolutions 1 -> 15 -> 19 (kw 10, stride 2), 19 -> 23 (kw 12, stride 2), 23 -> 27 (kw 11):
+// forward / filter (16, 10, s2) (24, 18, s2) (24, 18), backward phases (16, 5) (24, 9) (32, 22).  sota/2019 TDS-CTC (kw 21):
+// blocks (16, 21) (24, 33); sub-sampling 1 -> 10 -> 14 -> 18 at stride 2: (16, 21, s2), phases (16, 11) (24, 18).
+#define W2L_TB_FWD_LIST(X) X(16, 9, 1) X(16, 21, 1) X(24, 15, 1) X(24, 18, 1) X(24, 33, 1) X(32, 22, 1) \
+                           X(16, 5, 1) X(16, 11, 1) X(24, 9, 1) X(16, 10, 2) X(24, 18, 2) X(16, 21, 2)
+// (filter gradient: + the padded channel count of dy)
+#define W2L_TB_FILTER_LIST(X) X(16, 9, 1, 16) X(16, 21, 1, 16) X(24, 15, 1, 24) X(24, 18, 1, 24) X(24, 33, 1, 24) X(32, 22, 1, 32) \
+                              X(16, 10, 2, 16) X(16, 10, 2, 24) X(24, 18, 2, 24) X(24, 18, 1, 32) X(16, 21, 2, 16) X(16, 21, 2, 24)
+
+static bool tb_has_fwd(int CP, int NS, int ST) {
+#define X(a, b, c) if (CP == a && NS == b && ST == c) return true;
+  W2L_TB_FWD_LIST(X)
+#undef X
+  return false;
+}
+static bool tb_has_filter(int CP, int NS, int ST, int CPO) {
+#define X(a, b, c, d) if (CP == a && NS == b && ST == c && CPO == d) return true;
+  W2L_TB_FILTER_LIST(X)
+#undef X
+  return false;
 }
 
-template <int CP, int NSTEP>
+static bool tb_geometry(const w2l_conv_desc* d, TbGeom& g) {
+  if (!d || (d->stride != 1 && d->stride != 2) || d->Cin < 1 || d->Cin > 32 || d->Cout < 1 || d->Cout > 32 || d->kw < d->stride) return false;
+  if (d->B < 1 || d->T < 1 || d->padl < 0 || d->padr < 0 || d->H % kTbHB != 0) return false;   // whole 8-row mel blocks (16-byte aligned runs of 8 C floats)
+  const int n = d->T + d->padl + d->padr - d->kw;
+  if (n < 0) return false;
+  const int st = d->stride;
+  g.stride = st;
+  g.To = n / st + 1;
+  g.CPf = tb_cp(d->Cin); g.NSf = tb_nstep(d->kw, g.CPf);
+  g.CPb = tb_cp(d->Cout); g.NSb = tb_nstep((d->kw + st - 1) / st, g.CPb);
+  g.phases = 0;
+  for (int f = 0; f < st; ++f) {   // input frames ti with (ti + padl) mod st == f are reached by the taps f, f + st, ... only
+    TbPhase& q = g.ph[g.phases];
+    q.kwf = (d->kw - f + st - 1) / st;
+    q.c0 = (((f - d->padl) % st) + st) % st;
+    if (q.c0 >= d->T) continue;
+    q.U = (d->T - q.c0 + st - 1) / st;
+    const int s0 = (q.c0 + d->padl - f) / st;   // dy frame of tap f at the phase's first input frame
+    q.padl = q.kwf - 1 - s0;
+    q.tapOff = f;
+    ++g.phases;
+  }
+  return g.phases == st && tb_has_fwd(g.CPf, g.NSf, st) && tb_has_fwd(g.CPb, g.NSb, 1);
+}
+
+template <int CP, int NSTEP, int STRIDE>
 static int tb_launch(const TdsBfP& p, hipStream_t s) {
   constexpr int KWP = NSTEP * 16 / CP;
-  const size_t shmem = (size_t)(kTbTT + KWP - 1) * tb_frame_pitch(CP);
+  const size_t shmem = (size_t)((kTbTT - 1) * STRIDE + KWP) * tb_frame_pitch(CP);
   static bool attr = false;
   if (!attr && shmem > 64 * 1024) {
-    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_bf_k<CP, NSTEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_bf_k<CP, NSTEP, STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     attr = true;
   }
-  const dim3 grid((unsigned)((p.H + kTbHB - 1) / kTbHB), (unsigned)((p.T + kTbTT - 1) / kTbTT), (unsigned)p.B);
-  hipLaunchKernelGGL((tds_conv_bf_k<CP, NSTEP>), grid, dim3(256), shmem, s, p);
+  const dim3 grid((unsigned)(p.H / kTbHB), (unsigned)((p.Tout + kTbTT - 1) / kTbTT), (unsigned)p.B);
+  hipLaunchKernelGGL((tds_conv_bf_k<CP, NSTEP, STRIDE>), grid, dim3(256), shmem, s, p);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }
 
-static int tb_dispatch(const TbGeom& g, const TdsBfP& p, hipStream_t s) {
-  if (g.CP == 16 && g.NSTEP == 9) return tb_launch<16, 9>(p, s);
-  if (g.CP == 16 && g.NSTEP == 21) return tb_launch<16, 21>(p, s);
-  if (g.CP == 24 && g.NSTEP == 15) return tb_launch<24, 15>(p, s);
-  if (g.CP == 24 && g.NSTEP == 18) return tb_launch<24, 18>(p, s);
-  if (g.CP == 24 && g.NSTEP == 33) return tb_launch<24, 33>(p, s);
-  if (g.CP == 32 && g.NSTEP == 22) return tb_launch<32, 22>(p, s);
+static int tb_dispatch(int CP, int NS, int ST, const TdsBfP& p, hipStream_t s) {
+#define X(a, b, c) if (CP == a && NS == b && ST == c) return tb_launch<a, b, c>(p, s);
+  W2L_TB_FWD_LIST(X)
+#undef X
   return W2L_EUNSUPPORTED;
 }
 
-static int tb_dispatch_filter(const TbGeom& g, const TdsBfFilterP& p, float* dw, hipStream_t s) {
-  if (g.CP == 16 && g.NSTEP == 9) return tb_launch_filter<16, 9>(p, dw, s);
-  if (g.CP == 16 && g.NSTEP == 21) return tb_launch_filter<16, 21>(p, dw, s);
-  if (g.CP == 24 && g.NSTEP == 15) return tb_launch_filter<24, 15>(p, dw, s);
-  if (g.CP == 24 && g.NSTEP == 18) return tb_launch_filter<24, 18>(p, dw, s);
-  if (g.CP == 24 && g.NSTEP == 33) return tb_launch_filter<24, 33>(p, dw, s);
-  if (g.CP == 32 && g.NSTEP == 22) return tb_launch_filter<32, 22>(p, dw, s);
+static int tb_dispatch_filter(int CP, int NS, int ST, int CPO, const TdsBfFilterP& p, float* dw, hipStream_t s) {
+#define X(a, b, c, d) if (CP == a && NS == b && ST == c && CPO == d) return tb_launch_filter<a, b, c, d>(p, dw, s);
+  W2L_TB_FILTER_LIST(X)
+#undef X
   return W2L_EUNSUPPORTED;
 }
 
@@ -429,61 +546,76 @@ static int tb_dispatch_filter(const TbGeom& g, const TdsBfFilterP& p, float* dw,
 
 using namespace w2l;
 
-// bf16 elements of ONE weight image of this geometry (0: the geometry has no bf16 kernel -- stay on w2l_conv_*)
+// bf16 elements of ONE weight image buffer of this geometry -- the forward image, or the backward-data images of all phases
+// of a strided convolution, whichever is larger (0: the geometry has no bf16 kernel -- stay on w2l_conv_*)
 W2L_API size_t w2l_tds_conv_bf16_image_elems(const w2l_conv_desc* d) {
   TbGeom g;
-  return tb_geometry(d, g) ? (size_t)32 * g.NSTEP * 16 : 0;
+  if (!tb_geometry(d, g)) return 0;
+  const size_t f = (size_t)32 * g.NSf * 16, b = (size_t)g.phases * 32 * g.NSb * 16;
+  return f > b ? f : b;
 }
 
-// once per step: the forward and the backward-data weight images of w [kw][C][C] (fp32 master weights)
+// once per step: the forward and the backward-data weight images of w [kw][Cin][Cout] (fp32 master weights)
 W2L_API int w2l_tds_conv_bf16_prepare(const w2l_conv_desc* d, const float* w, uint16_t* imgForward, uint16_t* imgBackward,
                                       w2l_stream_t stream) {
   TbGeom g;
   if (!w || (!imgForward && !imgBackward)) return W2L_EINVAL;
   if (!tb_geometry(d, g)) return W2L_EUNSUPPORTED;
-  const int Kp = g.NSTEP * 16;
-  const unsigned blocks = (unsigned)((32 * Kp + 255) / 256);
-  if (imgForward) hipLaunchKernelGGL(tds_bf_wprep_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, d->kw, d->Cin, g.CP, Kp, 0, imgForward);
-  if (imgBackward) hipLaunchKernelGGL(tds_bf_wprep_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, d->kw, d->Cin, g.CP, Kp, 1, imgBackward);
+  if (imgForward) {
+    const int Kp = g.NSf * 16;
+    hipLaunchKernelGGL(tds_bf_wprep_k, dim3((unsigned)((32 * Kp + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, d->kw, d->Cin, d->Cout,
+                       g.CPf, Kp, d->kw, 0, 1, 0, imgForward);
+  }
+  if (imgBackward) {
+    const int Kp = g.NSb * 16;
+    for (int f = 0; f < g.phases; ++f)
+      hipLaunchKernelGGL(tds_bf_wprep_k, dim3((unsigned)((32 * Kp + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, d->kw, d->Cin, d->Cout,
+                         g.CPb, Kp, g.ph[f].kwf, g.ph[f].tapOff, g.stride, 1, imgBackward + (size_t)f * 32 * Kp);
+  }
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }
 
-// y = (relu)(conv(bf16(x), imgForward) + bias)
+// y [B][To][H][Cout] = (relu)(conv(bf16(x), imgForward) + bias)
 W2L_API int w2l_tds_conv_bf16_forward(const w2l_conv_desc* d, const float* x, const uint16_t* imgForward, const float* bias, float* y,
                                       int relu, w2l_stream_t stream) {
   TbGeom g;
   if (!x || !imgForward || !y) return W2L_EINVAL;
   if (!tb_geometry(d, g)) return W2L_EUNSUPPORTED;
-  TdsBfP p{x, imgForward, bias, nullptr, y, d->B, d->T, d->H, d->Cin, d->kw, d->padl, relu, (uint32_t)((0x100000000ull + d->Cin - 1) / d->Cin)};
-  prof_begin((hipStream_t)stream, 2.0 * d->B * (double)d->T * d->H * d->Cin * (double)d->Cout * d->kw, PROF_TDSCONV);
-  const int st = tb_dispatch(g, p, (hipStream_t)stream);
+  TdsBfP p{x, imgForward, bias, nullptr, y, d->B, d->T, g.To, d->H, d->Cin, d->Cout, d->padl, relu, 0, 1, g.To, tb_magic(d->Cin)};
+  prof_begin((hipStream_t)stream, 2.0 * d->B * (double)g.To * d->H * d->Cin * (double)d->Cout * d->kw, PROF_TDSCONV);
+  const int st = tb_dispatch(g.CPf, g.NSf, g.stride, p, (hipStream_t)stream);
   prof_end((hipStream_t)stream);
   return st;
 }
 
-// dx = (add +) conv^T(bf16(dy), w): a forward pass over dy with the flipped image and the mirrored left padding
+// dx [B][T][H][Cin] = (add +) conv^T(bf16(dy), w): forward passes over dy with the flipped images, one per phase of the stride
 W2L_API int w2l_tds_conv_bf16_backward_data(const w2l_conv_desc* d, const float* dy, const uint16_t* imgBackward, const float* add,
                                             float* dx, w2l_stream_t stream) {
   TbGeom g;
   if (!dy || !imgBackward || !dx) return W2L_EINVAL;
   if (!tb_geometry(d, g)) return W2L_EUNSUPPORTED;
-  TdsBfP p{dy, imgBackward, nullptr, add, dx, d->B, d->T, d->H, d->Cin, d->kw, d->kw - 1 - d->padl, 0, (uint32_t)((0x100000000ull + d->Cin - 1) / d->Cin)};
-  prof_begin((hipStream_t)stream, 2.0 * d->B * (double)d->T * d->H * d->Cin * (double)d->Cout * d->kw, PROF_TDS_BWD_DATA);
-  const int st = tb_dispatch(g, p, (hipStream_t)stream);
+  prof_begin((hipStream_t)stream, 2.0 * d->B * (double)g.To * d->H * d->Cin * (double)d->Cout * d->kw, PROF_TDS_BWD_DATA);
+  int st = W2L_OK;
+  for (int f = 0; f < g.phases && st == W2L_OK; ++f) {
+    const TbPhase& q = g.ph[f];
+    TdsBfP p{dy, imgBackward + (size_t)f * 32 * g.NSb * 16, nullptr, add, dx, d->B, g.To, q.U, d->H, d->Cout, d->Cin, q.padl, 0,
+             q.c0, g.stride, d->T, tb_magic(d->Cout)};
+    st = tb_dispatch(g.CPb, g.NSb, 1, p, (hipStream_t)stream);
+  }
   prof_end((hipStream_t)stream);
   return st;
 }
 
-// dw [kw][C][C] = x (*) dy on bf16-rounded operands (fp32 accumulation); the bias gradient is an fp32 column sum of dy
-// (w2l_colsum over [B T H][C]) and not part of this call.  H must be a multiple of 16.
+// dw [kw][Cin][Cout] = x (*) dy on bf16-rounded operands (fp32 accumulation); the bias gradient is an fp32 column sum of dy
+// (w2l_colsum over [B To H][Cout]) and not part of this call.  H must be a multiple of 16.
 W2L_API int w2l_tds_conv_bf16_backward_filter(const w2l_conv_desc* d, const float* x, const float* dy, float* dw, w2l_stream_t stream) {
   TbGeom g;
   if (!x || !dy || !dw) return W2L_EINVAL;
-  if (!tb_geometry(d, g) || d->H % kTfHB != 0) return W2L_EUNSUPPORTED;
-  TdsBfFilterP p{x, dy, nullptr, d->B, d->T, d->H, d->Cin, d->kw, d->padl};
-  prof_begin((hipStream_t)stream, 2.0 * d->B * (double)d->T * d->H * d->Cin * (double)d->Cout * d->kw, PROF_TDS_BWD_FILTER);
-  const int st = tb_dispatch_filter(g, p, dw, (hipStream_t)stream);
+  if (!tb_geometry(d, g) || d->H % kTgHB != 0 || !tb_has_filter(g.CPf, g.NSf, g.stride, g.CPb)) return W2L_EUNSUPPORTED;
+  TdsBfFilterP p{x, dy, nullptr, d->B, d->T, g.To, d->H, d->Cin, d->Cout, d->kw, d->padl};
+  prof_begin((hipStream_t)stream, 2.0 * d->B * (double)g.To * d->H * d->Cin * (double)d->Cout * d->kw, PROF_TDS_BWD_FILTER);
+  const int st = tb_dispatch_filter(g.CPf, g.NSf, g.stride, g.CPb, p, dw, (hipStream_t)stream);
   prof_end((hipStream_t)stream);
   return st;
 }

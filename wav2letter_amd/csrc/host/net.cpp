@@ -332,6 +332,8 @@ class Conv2DLayer : public Layer {
   size_t yOff = 0, dxOff = 0;
   size_t nOut = 0;
   const float* xSaved = nullptr;
+  // mixed precision: the sub-sampling convolutions of the TDS recipes (<= 32 channels over the mel rows) on the bf16 kernels
+  size_t convImgElems = 0, convImgFOff = 0, convImgBOff = 0;
 
   std::string name() const override { return wn.on ? "WeightNorm(Conv2D)" : "Conv2D"; }
   void registerParams(std::vector<ParamInfo>& t) override {
@@ -373,6 +375,8 @@ class Conv2DLayer : public Layer {
     dxOff = pl.alloc(in.numel());
     nIn = in.numel();
     if (kh > 1) { xeOff = pl.alloc(nIn * kh); dxeOff = pl.alloc(nIn * kh); }
+    convImgElems = H % 16 == 0 ? w2l_tds_conv_bf16_image_elems(&d) : 0;
+    if (convImgElems) { convImgFOff = pl.allocBf16(convImgElems); convImgBOff = pl.allocBf16(convImgElems); }
     if (wn.on) {
       wn.wOff = pl.alloc((size_t)wn.K * wn.N);
       wn.dwOff = pl.alloc((size_t)wn.K * wn.N);
@@ -394,17 +398,33 @@ class Conv2DLayer : public Layer {
     }
     xSaved = x;
     const float* wt = weight(c, arena);
+    if (c.bf16 && convImgElems) {   // bf16 operands, fp32 accumulation / bias / ReLU (conv_tds_bf16.hip); images once per step
+      w2lCheck(w2l_tds_conv_bf16_prepare(&d, wt, bfp(arena, convImgFOff), bfp(arena, convImgBOff), c.stream), "conv images");
+      w2lCheck(w2l_tds_conv_bf16_forward(&d, x, bfp(arena, convImgFOff), hasBias ? b.w(c) : nullptr, y, fuseRelu ? 1 : 0, c.stream), "conv fwd bf16");
+      return;
+    }
     w2lCheck(w2l_conv_forward(&d, x, wt, hasBias ? b.w(c) : nullptr, y, fuseRelu ? 1 : 0, c.stream), "conv fwd");
   }
   void backward(Ctx& c, float* arena, const float* dy, float*& dx, bool needDx) override {
     float* dym = const_cast<float*>(dy);
     if (fuseRelu) w2lCheck(w2l_mask_backward(dy, arena + yOff, dym, nOut, 1.f, c.stream), "conv relu bwd");
     float* dwt = wn.on ? arena + wn.dwOff : w.g(c);
-    w2lCheck(w2l_conv_backward_filter(&d, xSaved, dym, dwt, hasBias ? b.g(c) : nullptr, c.stream), "conv bwd filter");
+    const bool bf = c.bf16 && convImgElems;
+    if (bf) {
+      w2lCheck(w2l_tds_conv_bf16_backward_filter(&d, xSaved, dym, dwt, c.stream), "conv bwd filter bf16");
+      if (hasBias) w2lCheck(w2l_colsum(dym, b.g(c), nOut / (size_t)cout, cout, c.stream), "conv bwd bias");
+    } else {
+      w2lCheck(w2l_conv_backward_filter(&d, xSaved, dym, dwt, hasBias ? b.g(c) : nullptr, c.stream), "conv bwd filter");
+    }
     const float* wt = wn.on ? arena + wn.wOff : w.w(c);
     if (needDx) {
       dx = arena + dxOff;
-      if (kh > 1) {
+      if (bf && kh > 1) {
+        w2lCheck(w2l_tds_conv_bf16_backward_data(&d, dym, bfp(arena, convImgBOff), nullptr, arena + dxeOff, c.stream), "conv bwd data bf16");
+        w2lCheck(w2l_hexpand_backward(arena + dxeOff, dx, (size_t)d.B * d.T, d.H, cin, kh, padH, c.stream), "conv H fold");
+      } else if (bf) {
+        w2lCheck(w2l_tds_conv_bf16_backward_data(&d, dym, bfp(arena, convImgBOff), nullptr, dx, c.stream), "conv bwd data bf16");
+      } else if (kh > 1) {
         w2lCheck(w2l_conv_backward_data(&d, dym, wt, arena + dxeOff, 0, c.stream), "conv bwd data");
         w2lCheck(w2l_hexpand_backward(arena + dxeOff, dx, (size_t)d.B * d.T, d.H, cin, kh, padH, c.stream), "conv H fold");
       } else {

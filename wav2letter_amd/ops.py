@@ -230,17 +230,18 @@ def gemm_bf16_grouped(As, Bs, K, biases=None):
     return outs
 
 
-def tds_conv_bf16(x, w, bias, padl, padr, relu=False):
-    """the TDS convolution on bf16-rounded operands (w2l_tds_conv_bf16_*): x [B][T][H][C], w [kw][C][C] -> y; None when the
-    geometry has no bf16 kernel"""
+def tds_conv_bf16(x, w, bias, padl, padr, relu=False, stride=1):
+    """the TDS / sub-sampling convolution on bf16-rounded operands (w2l_tds_conv_bf16_*): x [B][T][H][Cin], w [kw][Cin][Cout] ->
+    y [B][To][H][Cout]; None when the geometry has no bf16 kernel"""
     import ctypes as C
-    d = conv_desc(x, w, 1, padl, padr)
+    d = conv_desc(x, w, stride, padl, padr)
     n = _lib.lib().w2l_tds_conv_bf16_image_elems(C.byref(d))
     if not n:
         return None
     imgs = torch.empty(2, n, dtype=torch.bfloat16, device=x.device)
     check(_lib.lib().w2l_tds_conv_bf16_prepare(C.byref(d), _p(w), _p(imgs[0]), _p(imgs[1]), _s()), "tds_conv_bf16_prepare")
-    y = torch.empty_like(x)
+    To = _lib.lib().w2l_conv_out_len(d.T, d.kw, stride, padl, padr)
+    y = torch.empty(d.B, To, d.H, d.Cout, device=x.device, dtype=torch.float32)
     check(_lib.lib().w2l_tds_conv_bf16_forward(C.byref(d), _p(x), _p(imgs[0]), _p(bias), _p(y), int(relu), _s()), "tds_conv_bf16_forward")
     return y, imgs, d
 
