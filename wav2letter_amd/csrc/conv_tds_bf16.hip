@@ -52,6 +52,7 @@ struct TdsBfP {
   int B, Tin, Tout, H, Cin, Cout, padl, relu;
   int oOff, oStep, ToutFull;
   uint32_t cMagic;       // ceil(2^32 / Cin): e / Cin for e < 2^16 (unused at Cin == 1)
+  int abl;               // timing ablations (probe library only; 0 in the product): 1 no staging, 2 no MFMAs, 4 no stores
 };
 
 __device__ __forceinline__ uint16_t tb_bf16(float v) {
@@ -63,8 +64,8 @@ __device__ __forceinline__ uint16_t tb_bf16(float v) {
 __host__ __device__ constexpr int tb_frame_pitch(int CP) { return ((kTbHB * CP * 2 / 16) | 1) * 16; }
 
 // ---- staging: frames tFirst .. tFirst + nFrames - 1 of one utterance's HB mel rows (src = its [T][H][C] block + h0 * C floats)
-// -> slab[f][h][CP] as bf16.  Frames outside [0, T) are written as zeros; the padded channels c >= C are never written (the
-// kernels zero-fill the slab first).
+// -> slab[f][h][CP] as bf16.  Frames outside [0, T) and the padded channels c >= C are written as zeros: tb_stage defines every
+// byte of the frames it stages (tb_stage_generic leaves the padded channels alone: its callers zero-fill the slab first).
 //
 // The first generation walked the fp32 block as aligned float4 and scattered the four elements one by one -- with odd channel
 // counts every element needs its own (mel row, channel) split and its own 2-byte LDS store: ~130 VALU instructions per 16 bytes
@@ -84,7 +85,7 @@ __device__ __forceinline__ void tb_stage(unsigned char* slab, int FS, const floa
   const int over = 4 * gLast + 4 - C;     // its 0 .. 3 slots past the row
   for (int base = 0; base < total; base += NV * 256) {
     tb_f32x4u_t w[NV];
-    int dst[NV];                          // LDS byte offset | 1: the row's last chunk | 2: frame outside the utterance; -1: nothing to write
+    int dst[NV];                          // LDS byte offset | 1: the row's last chunk | 2: zeros (frame outside the utterance, padded chunk); -1: nothing to write
 #pragma unroll
     for (int u = 0; u < NV; ++u) {        // unconditional loads from clamped addresses (a load inside a branch serialises)
       const int q = base + tid + 256 * u;
@@ -96,7 +97,7 @@ __device__ __forceinline__ void tb_stage(unsigned char* slab, int FS, const floa
       const int cgc = cg < gLast ? cg : gLast;
       const int c0 = cgc < gLast ? 4 * cgc : C - 4;
       w[u] = *(const tb_f32x4u_t*)(src + (size_t)tc * frameStride + h * C + c0);
-      dst[u] = (q < total && cg <= gLast) ? ((f * FS + (h * CP + 4 * cg) * 2) | (cg == gLast ? 1 : 0) | (tin != tc ? 2 : 0)) : -1;
+      dst[u] = q < total ? ((f * FS + (h * CP + 4 * cg) * 2) | (cg == gLast ? 1 : 0) | ((tin != tc || cg > gLast) ? 2 : 0)) : -1;
     }
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
@@ -176,16 +177,20 @@ __global__ __launch_bounds__(256) void tds_conv_bf_k(TdsBfP p) {
     for (int s = 0; s < NSTEP; ++s) wf[s] = *(const tb_bf16x8_t*)(wr + 16 * s);
   }
 
-  // ---- slab: zero fill, then the valid (frame, mel row, channel) elements as bf16
-  {
+  // ---- slab: zero fill (the padded channels are never written; frames outside the utterance are staged as zeros).
+  // One tile per workgroup: a persistent variant (launch, weight fetch and zero fill once per workgroup -- 41 of the 135 us of
+  // the C = 15 forward pass are such fixed costs, run 45) was SLOWER, 144 us: with one tile per workgroup the dispatcher
+  // starts the next workgroup while this one's stores drain; a persistent workgroup serialises stage / multiply / store.
+  if (C < 4) {   // (tb_stage writes the whole slab itself)
     const uint4 z = make_uint4(0u, 0u, 0u, 0u);
     for (int o = tid * 16; o < NF * FS; o += 256 * 16) *(uint4*)(slab + o) = z;
+    __syncthreads();
   }
-  __syncthreads();
   {
     const float* xb = p.x + ((size_t)b * p.Tin * p.H + h0) * C;
     const size_t frameStride = (size_t)p.H * C;
-    if (C >= 4) tb_stage<CP, kTbHB>(slab, FS, xb, C, frameStride, t0 * STRIDE - p.padl, NF, p.Tin, tid);
+    if (p.abl & 1) {}
+    else if (C >= 4) tb_stage<CP, kTbHB>(slab, FS, xb, C, frameStride, t0 * STRIDE - p.padl, NF, p.Tin, tid);
     else tb_stage_generic<CP, kTbHB>(slab, FS, xb, C, p.cMagic, frameStride, t0 * STRIDE - p.padl, NF, p.Tin, tid);
   }
   __syncthreads();
@@ -198,6 +203,7 @@ __global__ __launch_bounds__(256) void tds_conv_bf_k(TdsBfP p) {
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     const unsigned char* a0 = slab + (STRIDE * (32 * th + li)) * FS + (2 * wave) * CP * 2;
     const unsigned char* a1 = a0 + CP * 2;
+    if (!(p.abl & 2))
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
       // k = 16 s + 8 lh: tap = k / CP, c0 = k % CP -- constants of the unrolled step, selected by the lane half
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(256) void tds_conv_bf_k(TdsBfP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int tl = tl0 + (r & 3) + 8 * (r >> 2);
-        if (li < Co && tl <= tlMax) yb[off(hh, r)] = av[hh][r];
+        if (li < Co && tl <= tlMax && (!(p.abl & 4) || av[hh][r] == 12345.f)) yb[off(hh, r)] = av[hh][r];
       }
   }
 }
@@ -304,6 +310,7 @@ struct TdsBfFilterP {
   const float* dy;   // [B][Tout][H][Cout]
   float* partial;    // [workers][NRT * 32][32]
   int B, Tin, Tout, H, Cin, Cout, kw, padl;
+  int abl;           // timing ablations (probe library only; 0 in the product): 1 no staging, 2 no MFMAs
 };
 
 // dw[tap][ci][co] = sum over the workgroups' partials, always in the same order: 16 outputs x 16 worker lanes per
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(256) void tds_conv_bf_filter_tr_k(TdsBfFilterP p, u
     const int hb = item % hBlocks, tt = (item / hBlocks) % tTiles, b = item / (hBlocks * tTiles);
     const int t0 = tt * kTgTT, h0 = hb * kTgHB;
     __syncthreads();                             // the previous item's fragments have been read (and the zero fill is done)
-    {
+    if (!(p.abl & 1)) {
       const float* xb = p.x + ((size_t)b * p.Tin * p.H + h0) * p.Cin;
       const float* yb = p.dy + ((size_t)b * p.Tout * p.H + h0) * p.Cout;
       if (p.Cin >= 4) tb_stage<CP, kTgHB>(xs, FSX, xb, p.Cin, fsIn, t0 * STRIDE - p.padl, NFX, p.Tin, tid);
@@ -396,15 +403,17 @@ __global__ __launch_bounds__(256) void tds_conv_bf_filter_tr_k(TdsBfFilterP p, u
     }
     __syncthreads();
     // ---- one MFMA per (dy frame, row tile): k = the 16 mel rows of the block
+    if (!(p.abl & 2))
 #pragma unroll 4
     for (int t = 0; t < kTgTT; ++t) {
       const tb_bf16x8_t bf = tg_read8(ys + t * FSY + bOff, 4 * CPO * 2);
+      // every wave multiplies NRTW row tiles, present or not (a tile past NRT reads clamped rows and is never stored): a
+      // wave-uniform `if` around the MFMA made hipcc branch per MFMA and copy the accumulators AGPR <-> VGPR around each --
+      // the loop took 183 of the kernel's 295 us (run 45 ablations)
 #pragma unroll
       for (int j = 0; j < NRTW; ++j) {
-        if (wave + 4 * j < NRT) {
-          const tb_bf16x8_t af = tg_read8(xs + (t * STRIDE) * FSX + rowOff[j], 4 * CP * 2);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[j], 0, 0, 0);
-        }
+        const tb_bf16x8_t af = tg_read8(xs + (t * STRIDE) * FSX + rowOff[j], 4 * CP * 2);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[j], 0, 0, 0);
       }
     }
   }
@@ -423,6 +432,7 @@ __global__ __launch_bounds__(256) void tds_conv_bf_filter_tr_k(TdsBfFilterP p, u
 }
 
 static inline int tb_cp(int C) { return C <= 16 ? 16 : C <= 24 ? 24 : 32; }
+static inline int tb_abl() { const char* e = tune_env("W2L_TBF_ABL"); return e ? atoi(e) : 0; }
 static inline uint32_t tb_magic(int C) { return C == 1 ? 0u : (uint32_t)((0x100000000ull + C - 1) / C); }
 
 template <int CP, int NSTEP, int STRIDE, int CPO>
@@ -582,7 +592,7 @@ W2L_API int w2l_tds_conv_bf16_forward(const w2l_conv_desc* d, const float* x, co
   TbGeom g;
   if (!x || !imgForward || !y) return W2L_EINVAL;
   if (!tb_geometry(d, g)) return W2L_EUNSUPPORTED;
-  TdsBfP p{x, imgForward, bias, nullptr, y, d->B, d->T, g.To, d->H, d->Cin, d->Cout, d->padl, relu, 0, 1, g.To, tb_magic(d->Cin)};
+  TdsBfP p{x, imgForward, bias, nullptr, y, d->B, d->T, g.To, d->H, d->Cin, d->Cout, d->padl, relu, 0, 1, g.To, tb_magic(d->Cin), tb_abl()};
   prof_begin((hipStream_t)stream, 2.0 * d->B * (double)g.To * d->H * d->Cin * (double)d->Cout * d->kw, PROF_TDSCONV);
   const int st = tb_dispatch(g.CPf, g.NSf, g.stride, p, (hipStream_t)stream);
   prof_end((hipStream_t)stream);
@@ -600,7 +610,7 @@ W2L_API int w2l_tds_conv_bf16_backward_data(const w2l_conv_desc* d, const float*
   for (int f = 0; f < g.phases && st == W2L_OK; ++f) {
     const TbPhase& q = g.ph[f];
     TdsBfP p{dy, imgBackward + (size_t)f * 32 * g.NSb * 16, nullptr, add, dx, d->B, g.To, q.U, d->H, d->Cout, d->Cin, q.padl, 0,
-             q.c0, g.stride, d->T, tb_magic(d->Cout)};
+             q.c0, g.stride, d->T, tb_magic(d->Cout), tb_abl()};
     st = tb_dispatch(g.CPb, g.NSb, 1, p, (hipStream_t)stream);
   }
   prof_end((hipStream_t)stream);
@@ -613,7 +623,7 @@ W2L_API int w2l_tds_conv_bf16_backward_filter(const w2l_conv_desc* d, const floa
   TbGeom g;
   if (!x || !dy || !dw) return W2L_EINVAL;
   if (!tb_geometry(d, g) || d->H % kTgHB != 0 || !tb_has_filter(g.CPf, g.NSf, g.stride, g.CPb)) return W2L_EUNSUPPORTED;
-  TdsBfFilterP p{x, dy, nullptr, d->B, d->T, g.To, d->H, d->Cin, d->Cout, d->kw, d->padl};
+  TdsBfFilterP p{x, dy, nullptr, d->B, d->T, g.To, d->H, d->Cin, d->Cout, d->kw, d->padl, tb_abl()};
   prof_begin((hipStream_t)stream, 2.0 * d->B * (double)g.To * d->H * d->Cin * (double)d->Cout * d->kw, PROF_TDS_BWD_FILTER);
   const int st = tb_dispatch_filter(g.CPf, g.NSf, g.stride, g.CPb, p, dw, (hipStream_t)stream);
   prof_end((hipStream_t)stream);
