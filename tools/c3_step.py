@@ -8,6 +8,9 @@ import bench
 from wav2letter_amd import CriterionScaleMode, _lib, recipes
 from wav2letter_amd.trainer import Trainer
 
+if os.environ.get("W2L_USE_PROBE"):   # A/B runs of probe-library switches
+    _lib.use_probe().__enter__()
+
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 mode = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 64
