@@ -178,6 +178,10 @@ typedef struct {
 } w2l_gemm_epilogue;
 int w2l_bf16_convert(const float* x, size_t rows, int cols, size_t ldx, uint16_t* rowMajor, size_t ldRows,
                      uint16_t* transposed, size_t ldTrans, w2l_stream_t stream);
+/* the images of dropout(x): mask and scale of w2l_dropout_copy(p, seed, rngStream) over the dense [rows][ldx] matrix, applied on the
+ * way (the masked copy is never written) -- a dropout layer's backward pass when the masked gradient is only a GEMM operand */
+int w2l_bf16_convert_dropout(const float* x, size_t rows, int cols, size_t ldx, uint16_t* rowMajor, size_t ldRows,
+                             uint16_t* transposed, size_t ldTrans, double p, uint32_t seed, uint32_t rngStream, w2l_stream_t stream);
 /* n (1 .. 8) conversions in one launch (small matrices are launch-bound one at a time); each entry = the arguments of w2l_bf16_convert */
 typedef struct {
   const float* x;

@@ -975,6 +975,24 @@ def test_tds_conv_bf16_three_passes(oracle, B, C, H, T, kw, padl, padr):
     assert rel(from_fm(dx0.cpu().numpy()), odx) < 2e-5
 
 
+@pytest.mark.parametrize("rows,cols,p", [(300, 200, 0.1), (64, 64, 0.5), (1000, 1203, 0.25), (7, 5, 0.3), (4097, 130, 0.1)])
+def test_bf16_convert_with_dropout_mask(rows, cols, p):
+    """w2l_bf16_convert_dropout: the images of dropout(x) in one pass -- bit-identical to w2l_dropout_copy (same p, seed, stream:
+    the library's stateless hash of the flat index) followed by w2l_bf16_convert, padding included; p = 0 is the plain conversion"""
+    from wav2letter_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(rows + cols)
+    x = torch.randn(rows, cols, generator=g).cuda()
+    want_r, want_t = ops.bf16_convert(ops.dropout_copy(x, p, 77, 5), True, True)
+    got_r, got_t = ops.bf16_convert_dropout(x, p, 77, 5)
+    assert torch.equal(got_r.view(torch.int16), want_r.view(torch.int16))
+    assert torch.equal(got_t.view(torch.int16), want_t.view(torch.int16))
+    zero = (want_r[:, :cols].float() == 0).float().mean().item()
+    assert abs(zero - p) < 0.05 + 3.0 / (rows * cols) ** 0.5
+    plain_r, plain_t = ops.bf16_convert(x, True, True)
+    g0_r, g0_t = ops.bf16_convert_dropout(x, 0.0, 77, 5)
+    assert torch.equal(g0_r.view(torch.int16), plain_r.view(torch.int16)) and torch.equal(g0_t.view(torch.int16), plain_t.view(torch.int16))
+
+
 def test_tds_conv_bf16_refuses_other_geometries():
     import ctypes as C
     from wav2letter_amd import _lib, ops

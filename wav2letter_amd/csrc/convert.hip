@@ -25,9 +25,14 @@ __device__ __forceinline__ uint32_t cv_pack2(float a, float b) {
 constexpr int kCvTile = 64;
 
 // one 64 x 64 tile (bx, by) of x; 256 threads
+// DROP: the images are those of dropout(x) -- element (r, c) kept (and scaled) by the library's stateless hash of r * ldx + c,
+// the mask w2l_dropout_copy over the dense [rows][ldx] matrix applies (the masked copy is never materialised)
+struct CvDrop { uint32_t thr, seed, stream; float scale; };
+template <bool DROP = false>
 __device__ __forceinline__ void cvt_tile(const float* __restrict__ x, size_t rows, int cols, size_t ldx,
                                          uint16_t* __restrict__ rowMajor, size_t ldRows,
-                                         uint16_t* __restrict__ transposed, size_t ldTrans, unsigned bx, unsigned by) {
+                                         uint16_t* __restrict__ transposed, size_t ldTrans, unsigned bx, unsigned by,
+                                         CvDrop dr = CvDrop{0u, 0u, 0u, 1.f}) {
   __shared__ float tile[kCvTile][kCvTile + 1];
   const size_t r0 = (size_t)by * kCvTile;
   const int c0 = (int)bx * kCvTile;
@@ -48,6 +53,11 @@ __device__ __forceinline__ void cvt_tile(const float* __restrict__ x, size_t row
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (c + e < cols) v[e] = src[e];
+      }
+      if (DROP) {
+        const uint64_t idx = (uint64_t)r * ldx + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = keep_elem(idx + e, dr.seed, dr.stream, dr.thr) ? v[e] * dr.scale : 0.f;
       }
     }
     if (rowMajor && r < rows && (size_t)c < ldRows) {   // ldRows % 4 == 0 (host-checked): whole 8-byte stores
@@ -78,6 +88,12 @@ __global__ __launch_bounds__(256) void cvt_bf16_k(const float* __restrict__ x, s
                                                   uint16_t* __restrict__ rowMajor, size_t ldRows,
                                                   uint16_t* __restrict__ transposed, size_t ldTrans) {
   cvt_tile(x, rows, cols, ldx, rowMajor, ldRows, transposed, ldTrans, blockIdx.x, blockIdx.y);
+}
+
+__global__ __launch_bounds__(256) void cvt_bf16_drop_k(const float* __restrict__ x, size_t rows, int cols, size_t ldx,
+                                                       uint16_t* __restrict__ rowMajor, size_t ldRows,
+                                                       uint16_t* __restrict__ transposed, size_t ldTrans, CvDrop dr) {
+  cvt_tile<true>(x, rows, cols, ldx, rowMajor, ldRows, transposed, ldTrans, blockIdx.x, blockIdx.y, dr);
 }
 
 // several matrices in one launch (the six weights of a Transformer block are 8 us conversions each: launch-bound one at a
@@ -114,6 +130,26 @@ W2L_API int w2l_bf16_convert(const float* x, size_t rows, int cols, size_t ldx, 
   const dim3 grid((unsigned)((spanC + kCvTile - 1) / kCvTile), (unsigned)((spanR + kCvTile - 1) / kCvTile));
   if (grid.y > 65535u) return W2L_EUNSUPPORTED;
   hipLaunchKernelGGL(cvt_bf16_k, grid, dim3(256), 0, (hipStream_t)stream, x, rows, cols, ldx, rowMajor, ldRows, transposed, ldTrans);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+// the images of dropout(x) (the mask of w2l_dropout_copy / w2l_dropout_inplace with the same p, seed, rngStream over the dense
+// [rows][ldx] matrix): the backward pass of a dropout layer whose masked gradient is only ever a GEMM operand -- one pass over
+// the gradient instead of a masked copy + a conversion
+W2L_API int w2l_bf16_convert_dropout(const float* x, size_t rows, int cols, size_t ldx, uint16_t* rowMajor, size_t ldRows,
+                                     uint16_t* transposed, size_t ldTrans, double p, uint32_t seed, uint32_t rngStream,
+                                     w2l_stream_t stream) {
+  if (!(p > 0.0)) return w2l_bf16_convert(x, rows, cols, ldx, rowMajor, ldRows, transposed, ldTrans, stream);
+  if (!x || rows == 0 || cols <= 0 || ldx < (size_t)cols || (!rowMajor && !transposed) || p >= 1.0) return W2L_EINVAL;
+  if (rowMajor && (ldRows < (size_t)cols || (ldRows & 15) || (((uintptr_t)rowMajor) & 15))) return W2L_EINVAL;
+  if (transposed && (ldTrans < rows || (ldTrans & 15) || (((uintptr_t)transposed) & 15))) return W2L_EINVAL;
+  const size_t spanC = rowMajor && ldRows > (size_t)cols ? ldRows : (size_t)cols;
+  const size_t spanR = transposed && ldTrans > rows ? ldTrans : rows;
+  const dim3 grid((unsigned)((spanC + kCvTile - 1) / kCvTile), (unsigned)((spanR + kCvTile - 1) / kCvTile));
+  if (grid.y > 65535u) return W2L_EUNSUPPORTED;
+  const CvDrop dr{dropout_threshold(p), seed, rngStream, (float)(1.0 / (1.0 - p))};
+  hipLaunchKernelGGL(cvt_bf16_drop_k, grid, dim3(256), 0, (hipStream_t)stream, x, rows, cols, ldx, rowMajor, ldRows, transposed, ldTrans, dr);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }

@@ -267,6 +267,11 @@ struct BfImage {   // the two bf16 images of an fp32 matrix [rows][cols]
       onesArena = arena;
     }
   }
+  // the images of dropout(x) (mask of w2l_dropout_copy with the same p / seed / stream), without the masked copy
+  void convertDropout(Ctx& c, float* arena, const float* x, double p, uint32_t seed, uint32_t stream, const char* what) const {
+    w2lCheck(w2l_bf16_convert_dropout(x, (size_t)rows, cols, (size_t)cols, bfp(arena, rowsOff), (size_t)colsP, bfp(arena, transOff),
+                                      (size_t)rowsP, p, seed, stream, c.stream), what);
+  }
   const uint16_t* r(float* arena) const { return bfp(arena, rowsOff); }
   const uint16_t* t(float* arena) const { return bfp(arena, transOff); }
   // entry of a w2l_bf16_convert_multi call (images without a ones row: weights, gradients)
@@ -739,15 +744,19 @@ class TDSLayer : public Layer {
     w2lCheck(w2l_layernorm_backward(groups, inner, v, dy, gb2.w(cx), ar + mr2Off, ds, gb2.g(cx), nullptr, nullptr, 1.f,
                                     (double*)(ar + st2Off), s), "tds ln2 bwd");
     const float* dv = ds;
-    if (pd > 0) {
+    const bool rides2 = cx.bf16 && bl2.biasRides(uImg, w2.g(cx), b2.g(cx));
+    // mixed precision with the bias gradient riding on the weight-gradient product: dv = dropout-masked ds is only ever a GEMM
+    // operand -- its images are taken straight from ds with the mask applied on the way, no masked copy
+    const bool maskInConvert = pd > 0 && rides2;
+    if (pd > 0 && !maskInConvert) {
       // dy1 buffer doubles as scratch for the masked copy (one out-of-place pass)
       w2lCheck(w2l_dropout_copy(dy1, ds, n, pd, cx.seed, rngStream + 2, s), "tds do2 bwd");
       dv = dy1;
     }
     if (cx.bf16) {
       // (dv may live in dy1 -- the masked copy above --, which the last product overwrites: its images are taken first)
-      dvImg.convert(cx, ar, dv, "tds dv images");
-      const bool rides2 = bl2.biasRides(uImg, w2.g(cx), b2.g(cx));
+      if (maskInConvert) dvImg.convertDropout(cx, ar, ds, pd, cx.seed, rngStream + 2, "tds dv images (masked)");
+      else dvImg.convert(cx, ar, dv, "tds dv images");
       bl2.backwardWeight(cx, ar, uImg, dvImg, w2.g(cx), rides2);
       if (!rides2) w2lCheck(w2l_colsum(dv, b2.g(cx), (size_t)M, l, s), "tds lin2 bwd b");
       bl2.backwardData(cx, ar, dvImg, du, u, sc, nullptr, 0);

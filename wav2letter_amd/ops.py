@@ -200,6 +200,18 @@ def bf16_convert(x, rows_image=True, transposed_image=False):
     return rm, tr
 
 
+def bf16_convert_dropout(x, p, seed, stream_id, rows_image=True, transposed_image=True):
+    """w2l_bf16_convert_dropout: the bf16 images of dropout(x) (mask of dropout_copy(p, seed, stream_id)) in one pass over x"""
+    x = x.contiguous()
+    rows, cols = x.shape
+    colsP, rowsP = (cols + 63) // 64 * 64, (rows + 63) // 64 * 64
+    rm = torch.empty(rows, colsP, dtype=torch.bfloat16, device=x.device) if rows_image else None
+    tr = torch.empty(cols, rowsP, dtype=torch.bfloat16, device=x.device) if transposed_image else None
+    _lib.check(_lib.lib().w2l_bf16_convert_dropout(_p(x), rows, cols, cols, _p(rm) if rm is not None else None, colsP,
+                                                   _p(tr) if tr is not None else None, rowsP, p, seed, stream_id, _s()), "bf16_convert_dropout")
+    return rm, tr
+
+
 def gemm_bf16(A, B, K, bias=None, relu=False, mask=None, mask_scale=1.0, addend=None, out=None, accumulate=False,
               drop_p=0.0, drop_seed=0, drop_stream=0):
     """w2l_gemm_bf16: C[M][N] fp32 = A[M][>=K] . B[N][>=K]^T on bf16 images (rows zero from column K to the next multiple of 64)"""
