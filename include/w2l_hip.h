@@ -227,7 +227,7 @@ int w2l_conv_backward_filter(const w2l_conv_desc* d, const float* x, const float
  * w2l_tds_conv_bf16_image_elems: bf16 elements of ONE weight image buffer of the geometry (the forward image, or the images
  *   of all phases of a strided backward-data pass, whichever is larger); 0 = no bf16 kernel for it (use w2l_conv_*).
  * w2l_tds_conv_bf16_prepare: once per step, the forward and the backward-data images of the fp32 weights.
- * backward_filter: dw only (H % 16 == 0) -- the bias gradient stays the fp32 column sum (w2l_colsum over [B To H][Cout]). */
+ * backward_filter: dw only (H % 16 == 0); backward_filter_bias: dw and the bias gradient (sums of the ROUNDED dy) in one launch. */
 size_t w2l_tds_conv_bf16_image_elems(const w2l_conv_desc* d);
 int w2l_tds_conv_bf16_prepare(const w2l_conv_desc* d, const float* w, uint16_t* imgForward, uint16_t* imgBackward, w2l_stream_t stream);
 int w2l_tds_conv_bf16_forward(const w2l_conv_desc* d, const float* x, const uint16_t* imgForward, const float* bias, float* y,
@@ -235,6 +235,9 @@ int w2l_tds_conv_bf16_forward(const w2l_conv_desc* d, const float* x, const uint
 int w2l_tds_conv_bf16_backward_data(const w2l_conv_desc* d, const float* dy, const uint16_t* imgBackward, const float* add,
                                     float* dx, w2l_stream_t stream);
 int w2l_tds_conv_bf16_backward_filter(const w2l_conv_desc* d, const float* x, const float* dy, float* dw, w2l_stream_t stream);
+/* the same launch also produces dbias [Cout] = column sums of the bf16-rounded dy (summed from the slabs the kernel stages anyway) */
+int w2l_tds_conv_bf16_backward_filter_bias(const w2l_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                                           w2l_stream_t stream);
 
 /* r = dropout(a) + x ; y = LayerNorm(r) over `groups` contiguous chunks of `inner`
  * elements with scalar affine gammaBeta[2] (fl::LayerNorm axes {0,1,2}: groups = B).

@@ -139,9 +139,9 @@ def tds_bwd(dout, p, saved, padl, padr, ln_mode="all", eps=1e-5, bf16=False):
     dy += from_frames(dz, B, Cc, H, T)
     dr, g["g1"], g["b1n"] = ln_bwd(r, dy, ln_mode, float(p.g1), eps)
     da = dr * (a > 0)
-    if bf16:   # dx = conv^T(bf(da), bf(w)), dw = bf(x) (*) bf(da), db = sums of the unrounded da
-        dxc, g["wc"], _ = O.conv_bwd(bf16_round(x), bf16_round(p.wc), bf16_round(da), 1, padl, padr)
-        g["bc"] = np.asarray(da, np.float64).sum(axis=(0, 2, 3)).astype(np.float32)
+    if bf16:   # dx = conv^T(bf(da), bf(w)), dw = bf(x) (*) bf(da), db = sums of bf(da) (summed from the slabs of the filter-gradient kernel)
+        dxc, g["wc"], dbr = O.conv_bwd(bf16_round(x), bf16_round(p.wc), bf16_round(da), 1, padl, padr)
+        g["bc"] = dbr
     else:
         dxc, g["wc"], g["bc"] = O.conv_bwd(x, p.wc, da, 1, padl, padr)
     return dr + dxc, g
@@ -401,10 +401,9 @@ class RefNet:
                 da = np.ascontiguousarray(da.transpose(inv))
             elif k == "C":
                 _, a, w, v, gg, stride, pl, pr, pi, rnd = rec
-                if rnd:   # dx, dw from the rounded gradient; the bias gradient sums the unrounded one
+                if rnd:   # dx, dw and the bias gradient from the rounded gradient
                     da = np.ascontiguousarray(da, dtype=np.float32)
-                    dx, dw, _ = O.conv_bwd(a, w, bf16_round(da), stride, pl, pr)
-                    db = da.sum(axis=(0, 2, 3), dtype=np.float64).astype(np.float32)
+                    dx, dw, db = O.conv_bwd(a, w, bf16_round(da), stride, pl, pr)
                 else:
                     dx, dw, db = O.conv_bwd(a, w, da, stride, pl, pr)
                 g[pi - 1] = db

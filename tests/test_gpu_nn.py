@@ -1036,11 +1036,16 @@ def test_subsampling_conv_bf16_three_passes(oracle, B, Cin, Cout, H, T, kw, stri
     assert rel(from_fm(yr.cpu().numpy()), np.maximum(y_ref, 0)) < 2e-5
     dy = rng.normal(size=y_ref.shape).astype(np.float32)
     add = rng.normal(size=x.shape).astype(np.float32)
-    odx, odw, _ = oracle.conv_bwd(xr, wr, refnet.bf16_round(dy), stride, padl, padr)
+    odx, odw, odb = oracle.conv_bwd(xr, wr, refnet.bf16_round(dy), stride, padl, padr)
     dyd, addd = dev(to_fm(dy)), dev(to_fm(add))
     dx, dw = ops.tds_conv_bf16_backward(xd, dyd, imgs, d, add=addd)
     assert rel(from_fm(dx.cpu().numpy()), odx + add) < 2e-5
     assert rel(dw.cpu().numpy(), w_to_dev(odw)) < 5e-5
+    # the bias gradient from the same launch: column sums of the rounded dy; dx / dw unchanged by the option
+    dxb, dwb, db = ops.tds_conv_bf16_backward(xd, dyd, imgs, d, add=addd, with_bias=True)
+    assert torch.equal(dxb, dx) and torch.equal(dwb, dw)
+    assert rel(db.cpu().numpy(), odb) < 1e-5
+    assert torch.equal(db, ops.tds_conv_bf16_backward(xd, dyd, imgs, d, add=addd, with_bias=True)[2])
     dx2, dw2 = ops.tds_conv_bf16_backward(xd, dyd, imgs, d, add=addd)
     assert torch.equal(dx, dx2) and torch.equal(dw, dw2)
     dx0, _ = ops.tds_conv_bf16_backward(xd, dyd, imgs, d)

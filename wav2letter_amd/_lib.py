@@ -114,6 +114,7 @@ class _SIGS:
     w2l_tds_conv_bf16_forward = (_i, [_p, _p, _p, _p, _p, _i, _p])
     w2l_tds_conv_bf16_backward_data = (_i, [_p, _p, _p, _p, _p, _p])
     w2l_tds_conv_bf16_backward_filter = (_i, [_p, _p, _p, _p, _p])
+    w2l_tds_conv_bf16_backward_filter_bias = (_i, [_p, _p, _p, _p, _p, _p])
     w2l_mfsc_spectrum = (_i, [_p, _p, _sz, _i, _i, _i, _p])
     w2l_mfsc_log_transpose = (_i, [_p, _p, _i, _i, _i, _i, _f, _p])
     w2l_weightnorm_forward = (_i, [_p, _p, _p, _p, _i, _i, _p])

@@ -308,32 +308,36 @@ constexpr int kTfWorkers = 512;
 struct TdsBfFilterP {
   const float* x;    // [B][Tin][H][Cin]
   const float* dy;   // [B][Tout][H][Cout]
-  float* partial;    // [workers][NRT * 32][32]
+  float* partial;    // [workers][NRT * 32][32], then (withBias) [workers][32]: the workers' column sums of dy
   int B, Tin, Tout, H, Cin, Cout, kw, padl;
   int abl;           // timing ablations (probe library only; 0 in the product): 1 no staging, 2 no MFMAs
+  int withBias;      // also sum the (bf16-rounded) dy slab per output channel: the bias gradient, no column-sum launches
 };
 
 // dw[tap][ci][co] = sum over the workgroups' partials, always in the same order: 16 outputs x 16 worker lanes per
 // workgroup, a lane adds every 16th partial, the 16 lane sums are added in lane order (the first build walked all 512
 // partials in ONE thread per output: 135 us per call)
 __global__ __launch_bounds__(256) void tds_bf_filter_reduce_k(const float* __restrict__ partial, int workers, int rows32, int kw, int Cin, int Cout,
-                                                              int CP, float* __restrict__ dw) {
+                                                              int CP, float* __restrict__ dw, float* __restrict__ dbias) {
   __shared__ float sm[16][17];
   const int o = threadIdx.x & 15, wl = threadIdx.x >> 4;
-  const int e = blockIdx.x * 16 + o, n = kw * Cin * Cout;
+  const int e = blockIdx.x * 16 + o, n = kw * Cin * Cout, nAll = n + (dbias ? Cout : 0);
   float s = 0.f;
   if (e < n) {
     const int co = e % Cout, ci = (e / Cout) % Cin, tap = e / (Cin * Cout);
     const size_t at = (size_t)(tap * CP + ci) * 32 + co;
     for (int w = wl; w < workers; w += 16) s += partial[(size_t)w * rows32 * 32 + at];
+  } else if (e < nAll) {   // bias gradient: the workers' column sums of dy, stored behind the product partials
+    const float* pb = partial + (size_t)workers * rows32 * 32 + (e - n);
+    for (int w = wl; w < workers; w += 16) s += pb[(size_t)w * 32];
   }
   sm[wl][o] = s;
   __syncthreads();
-  if (wl == 0 && e < n) {
+  if (wl == 0 && e < nAll) {
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += sm[k][o];
-    dw[e] = t;
+    if (e < n) dw[e] = t; else dbias[e - n] = t;
   }
 }
 
@@ -388,6 +392,9 @@ __global__ __launch_bounds__(256) void tds_conv_bf_filter_tr_k(TdsBfFilterP p, u
   }
   const int bOff = kRow * CPO * 2 + (idx0 < CPO ? idx0 : 0) * 2;
   const size_t fsIn = (size_t)p.H * p.Cin, fsOut = (size_t)p.H * p.Cout;
+  // bias gradient: thread (co = tid & 31, part = tid >> 5) sums 32 of an item's 256 (frame, mel row) positions of channel co
+  float bsum = 0.f;
+  const int bco = (tid & 31) < CPO ? (tid & 31) : 0, bpart = tid >> 5;
 
   for (int item = blockIdx.x; item < nItems; item += gridDim.x) {
     const int hb = item % hBlocks, tt = (item / hBlocks) % tTiles, b = item / (hBlocks * tTiles);
@@ -402,6 +409,14 @@ __global__ __launch_bounds__(256) void tds_conv_bf_filter_tr_k(TdsBfFilterP p, u
       else tb_stage_generic<CPO, kTgHB>(ys, FSY, yb, p.Cout, magicO, fsOut, t0, kTgTT, p.Tout, tid);
     }
     __syncthreads();
+    if (p.withBias) {
+#pragma unroll 8
+      for (int q2 = 0; q2 < 32; ++q2) {
+        const int pos = bpart * 32 + q2;   // frame pos >> 4, mel row pos & 15
+        const uint32_t h16 = *(const uint16_t*)(ys + (pos >> 4) * FSY + ((pos & 15) * CPO + bco) * 2);
+        bsum += __builtin_bit_cast(float, h16 << 16);
+      }
+    }
     // ---- one MFMA per (dy frame, row tile): k = the 16 mel rows of the block
     if (!(p.abl & 2))
 #pragma unroll 4
@@ -429,6 +444,18 @@ __global__ __launch_bounds__(256) void tds_conv_bf_filter_tr_k(TdsBfFilterP p, u
       out[(size_t)row * 32 + li] = acc[j][r];
     }
   }
+  if (p.withBias) {   // the 8 parts of a channel in part order (deterministic), one row of 32 sums per workgroup
+    __syncthreads();
+    float* sb = (float*)lds;
+    sb[tid] = bsum;
+    __syncthreads();
+    if (tid < 32) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += sb[32 * k + tid];
+      p.partial[(size_t)gridDim.x * (NRT * 32) * 32 + (size_t)blockIdx.x * 32 + tid] = tid < p.Cout ? t : 0.f;
+    }
+  }
 }
 
 static inline int tb_cp(int C) { return C <= 16 ? 16 : C <= 24 ? 24 : 32; }
@@ -436,13 +463,14 @@ static inline int tb_abl() { const char* e = tune_env("W2L_TBF_ABL"); return e ?
 static inline uint32_t tb_magic(int C) { return C == 1 ? 0u : (uint32_t)((0x100000000ull + C - 1) / C); }
 
 template <int CP, int NSTEP, int STRIDE, int CPO>
-static int tb_launch_filter(const TdsBfFilterP& p0, float* dw, hipStream_t s) {
+static int tb_launch_filter(const TdsBfFilterP& p0, float* dw, float* dbias, hipStream_t s) {
   constexpr int KWP = NSTEP * 16 / CP, Kp = NSTEP * 16, NRT = (Kp + 31) / 32, NFX = (kTgTT - 1) * STRIDE + KWP;
   TdsBfFilterP p = p0;
   const int tTiles = (p.Tout + kTgTT - 1) / kTgTT, nItems = p.B * tTiles * (p.H / kTgHB);
   const int workers = nItems < kTfWorkers ? nItems : kTfWorkers;
-  const size_t need = (size_t)workers * NRT * 32 * 32 * sizeof(float);
+  const size_t need = ((size_t)workers * NRT * 32 * 32 + (size_t)workers * 32) * sizeof(float);
   if (need > kSkScratchBytes) return W2L_EUNSUPPORTED;
+  p.withBias = dbias ? 1 : 0;
   const size_t shmem = (size_t)NFX * tg_pitch(CP) + (size_t)kTgTT * tg_pitch(CPO);
   if (shmem > 80 * 1024) return W2L_EUNSUPPORTED;   // two workgroups per CU: one stages while the other multiplies
   p.partial = sk_scratch(s, kSkScratchBytes);
@@ -453,8 +481,9 @@ static int tb_launch_filter(const TdsBfFilterP& p0, float* dw, hipStream_t s) {
     attr = true;
   }
   hipLaunchKernelGGL((tds_conv_bf_filter_tr_k<CP, NSTEP, STRIDE, CPO>), dim3((unsigned)workers), dim3(256), shmem, s, p, tb_magic(p.Cin), tb_magic(p.Cout));
-  const int n = p.kw * p.Cin * p.Cout;
-  hipLaunchKernelGGL(tds_bf_filter_reduce_k, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, p.partial, workers, NRT * 32, p.kw, p.Cin, p.Cout, CP, dw);
+  const int n = p.kw * p.Cin * p.Cout + (dbias ? p.Cout : 0);
+  hipLaunchKernelGGL(tds_bf_filter_reduce_k, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, p.partial, workers, NRT * 32, p.kw, p.Cin, p.Cout, CP, dw,
+                     dbias);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }
@@ -545,8 +574,8 @@ static int tb_dispatch(int CP, int NS, int ST, const TdsBfP& p, hipStream_t s) {
   return W2L_EUNSUPPORTED;
 }
 
-static int tb_dispatch_filter(int CP, int NS, int ST, int CPO, const TdsBfFilterP& p, float* dw, hipStream_t s) {
-#define X(a, b, c, d) if (CP == a && NS == b && ST == c && CPO == d) return tb_launch_filter<a, b, c, d>(p, dw, s);
+static int tb_dispatch_filter(int CP, int NS, int ST, int CPO, const TdsBfFilterP& p, float* dw, float* dbias, hipStream_t s) {
+#define X(a, b, c, d) if (CP == a && NS == b && ST == c && CPO == d) return tb_launch_filter<a, b, c, d>(p, dw, dbias, s);
   W2L_TB_FILTER_LIST(X)
 #undef X
   return W2L_EUNSUPPORTED;
@@ -617,15 +646,22 @@ W2L_API int w2l_tds_conv_bf16_backward_data(const w2l_conv_desc* d, const float*
   return st;
 }
 
-// dw [kw][Cin][Cout] = x (*) dy on bf16-rounded operands (fp32 accumulation); the bias gradient is an fp32 column sum of dy
-// (w2l_colsum over [B To H][Cout]) and not part of this call.  H must be a multiple of 16.
-W2L_API int w2l_tds_conv_bf16_backward_filter(const w2l_conv_desc* d, const float* x, const float* dy, float* dw, w2l_stream_t stream) {
+// dw [kw][Cin][Cout] = x (*) dy on bf16-rounded operands (fp32 accumulation).  H must be a multiple of 16.
+// dbias [Cout] (may be null): the column sums of the bf16-rounded dy over [B To H], summed from the dy slabs the kernel stages
+// anyway (fixed order: deterministic) -- no column-sum launches for the convolution's bias.
+W2L_API int w2l_tds_conv_bf16_backward_filter_bias(const w2l_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                                                   w2l_stream_t stream) {
   TbGeom g;
   if (!x || !dy || !dw) return W2L_EINVAL;
   if (!tb_geometry(d, g) || d->H % kTgHB != 0 || !tb_has_filter(g.CPf, g.NSf, g.stride, g.CPb)) return W2L_EUNSUPPORTED;
-  TdsBfFilterP p{x, dy, nullptr, d->B, d->T, g.To, d->H, d->Cin, d->Cout, d->kw, d->padl, tb_abl()};
+  TdsBfFilterP p{x, dy, nullptr, d->B, d->T, g.To, d->H, d->Cin, d->Cout, d->kw, d->padl, tb_abl(), 0};
   prof_begin((hipStream_t)stream, 2.0 * d->B * (double)g.To * d->H * d->Cin * (double)d->Cout * d->kw, PROF_TDS_BWD_FILTER);
-  const int st = tb_dispatch_filter(g.CPf, g.NSf, g.stride, g.CPb, p, dw, (hipStream_t)stream);
+  const int st = tb_dispatch_filter(g.CPf, g.NSf, g.stride, g.CPb, p, dw, dbias, (hipStream_t)stream);
   prof_end((hipStream_t)stream);
   return st;
+}
+
+// (the weight gradient alone: the bias gradient by the caller's means, e.g. an fp32 w2l_colsum of dy over [B To H][Cout])
+W2L_API int w2l_tds_conv_bf16_backward_filter(const w2l_conv_desc* d, const float* x, const float* dy, float* dw, w2l_stream_t stream) {
+  return w2l_tds_conv_bf16_backward_filter_bias(d, x, dy, dw, nullptr, stream);
 }

@@ -416,8 +416,7 @@ class Conv2DLayer : public Layer {
     float* dwt = wn.on ? arena + wn.dwOff : w.g(c);
     const bool bf = c.bf16 && convImgElems;
     if (bf) {
-      w2lCheck(w2l_tds_conv_bf16_backward_filter(&d, xSaved, dym, dwt, c.stream), "conv bwd filter bf16");
-      if (hasBias) w2lCheck(w2l_colsum(dym, b.g(c), nOut / (size_t)cout, cout, c.stream), "conv bwd bias");
+      w2lCheck(w2l_tds_conv_bf16_backward_filter_bias(&d, xSaved, dym, dwt, hasBias ? b.g(c) : nullptr, c.stream), "conv bwd filter + bias bf16");
     } else {
       w2lCheck(w2l_conv_backward_filter(&d, xSaved, dym, dwt, hasBias ? b.g(c) : nullptr, c.stream), "conv bwd filter");
     }
@@ -780,8 +779,7 @@ class TDSLayer : public Layer {
     w2lCheck(w2l_layernorm_backward(groups, inner, ar + r1Off, dy1, gb1.w(cx), ar + mr1Off, dr1, gb1.g(cx), a, da, sc,
                                     (double*)(ar + st1Off), s), "tds ln1 bwd");
     if (cx.bf16 && convImgElems) {
-      w2lCheck(w2l_tds_conv_bf16_backward_filter(&d, xSaved, da, wc.g(cx), s), "tds conv bwd filter bf16");
-      w2lCheck(w2l_colsum(da, bc.g(cx), (size_t)M * h, c, s), "tds conv bwd bias");
+      w2lCheck(w2l_tds_conv_bf16_backward_filter_bias(&d, xSaved, da, wc.g(cx), bc.g(cx), s), "tds conv bwd filter + bias bf16");
       if (needDx) {
         dx = ar + dxOff;
         w2lCheck(w2l_tds_conv_bf16_backward_data(&d, da, bfp(ar, convImgBOff), dr1, dx, s), "tds conv bwd data bf16");

@@ -258,11 +258,16 @@ def tds_conv_bf16(x, w, bias, padl, padr, relu=False, stride=1):
     return y, imgs, d
 
 
-def tds_conv_bf16_backward(x, dy, imgs, d, add=None):
-    """(dx, dw) of the same convolution: dx = add + conv^T(dy), dw = x (*) dy, both on bf16-rounded operands"""
+def tds_conv_bf16_backward(x, dy, imgs, d, add=None, with_bias=False):
+    """(dx, dw[, db]) of the same convolution: dx = add + conv^T(dy), dw = x (*) dy, both on bf16-rounded operands; with_bias: the
+    bias gradient (column sums of the rounded dy) from the same launch"""
     import ctypes as C
     dx = torch.empty_like(x)
     check(_lib.lib().w2l_tds_conv_bf16_backward_data(C.byref(d), _p(dy), _p(imgs[1]), _p(add), _p(dx), _s()), "tds_conv_bf16_backward_data")
     dw = torch.empty(d.kw, d.Cin, d.Cout, dtype=torch.float32, device=x.device)
+    if with_bias:
+        db = torch.empty(d.Cout, dtype=torch.float32, device=x.device)
+        check(_lib.lib().w2l_tds_conv_bf16_backward_filter_bias(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _s()), "tds_conv_bf16_backward_filter_bias")
+        return dx, dw, db
     check(_lib.lib().w2l_tds_conv_bf16_backward_filter(C.byref(d), _p(x), _p(dy), _p(dw), _s()), "tds_conv_bf16_backward_filter")
     return dx, dw
