@@ -259,6 +259,9 @@ struct BfImage {   // the two bf16 images of an fp32 matrix [rows][cols]
   void convert(Ctx& c, float* arena, const float* x, const char* what) const {
     w2lCheck(w2l_bf16_convert(x, (size_t)rows, cols, (size_t)cols, bfp(arena, rowsOff), (size_t)colsP, bfp(arena, transOff), (size_t)rowsP,
                               c.stream), what);
+    ensureOnes(c, arena);
+  }
+  void ensureOnes(Ctx& c, float* arena) const {
     if (onesRow && onesArena != arena) {   // two bf16 ones per float slot; columns past `rows` multiply the zero padding of dy's image
       float pair;
       const uint32_t bits = 0x3F803F80u;
@@ -274,7 +277,7 @@ struct BfImage {   // the two bf16 images of an fp32 matrix [rows][cols]
   }
   const uint16_t* r(float* arena) const { return bfp(arena, rowsOff); }
   const uint16_t* t(float* arena) const { return bfp(arena, transOff); }
-  // entry of a w2l_bf16_convert_multi call (images without a ones row: weights, gradients)
+  // entry of a w2l_bf16_convert_multi call (an image with a ones row: ensureOnes() after the call)
   w2l_bf16_convert_desc desc(float* arena, const float* x) const {
     w2l_bf16_convert_desc d;
     d.x = x; d.rows = (size_t)rows; d.cols = cols; d.ldx = (size_t)cols;
@@ -716,11 +719,13 @@ class TDSLayer : public Layer {
     if (cx.bf16) {
       // the same two products on bf16 images: y1 and u are converted once (row image for this product, transposed image for
       // the weight gradient in backward), the weights once per step (both orientations)
-      y1Img.convert(cx, ar, y1, "tds y1 images");
-      bl1.convertWeight(cx, ar, w1.w(cx));
+      {   // y1 and both weights of the block in ONE conversion launch (the weights are 10 us each on their own: launch-bound)
+        const w2l_bf16_convert_desc wd[3] = {y1Img.desc(ar, y1), bl1.w.desc(ar, w1.w(cx)), bl2.w.desc(ar, w2.w(cx))};
+        w2lCheck(w2l_bf16_convert_multi(3, wd, s), "tds y1 + weight images");
+        y1Img.ensureOnes(cx, ar);
+      }
       bl1.forward(cx, ar, y1Img, b1.w(cx), u, 1, pd, cx.seed, rngStream + 1);
       uImg.convert(cx, ar, u, "tds u images");
-      bl2.convertWeight(cx, ar, w2.w(cx));
       bl2.forward(cx, ar, uImg, b2.w(cx), v, 0, 0.0, 0, 0);
     } else {
     // lin1 + ReLU + dropout in one GEMM epilogue (same mask bits as a separate dropout pass over u)
