@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kEwThreads) void residual_dropout_stats_k(
       av.y = keep_elem(e + 1, seed, stream, thr) ? av.y * keepScale : 0.f;
       av.z = keep_elem(e + 2, seed, stream, thr) ? av.z * keepScale : 0.f;
       av.w = keep_elem(e + 3, seed, stream, thr) ? av.w * keepScale : 0.f;
-      *(float4*)(a + e) = av;
+      if (r != a || !x) *(float4*)(a + e) = av;   // (r stored over a: the sum below is what lands there -- one store, not two)
     }
     rv.x += av.x; rv.y += av.y; rv.z += av.z; rv.w += av.w;
     if (r != a || x) *(float4*)(r + e) = rv;  // plain LayerNorm (r aliases a, no residual): nothing to write
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kEwThreads) void residual_ln_small_k(
         av.y = keep_elem(e + 1, seed, stream, thr) ? av.y * keepScale : 0.f;
         av.z = keep_elem(e + 2, seed, stream, thr) ? av.z * keepScale : 0.f;
         av.w = keep_elem(e + 3, seed, stream, thr) ? av.w * keepScale : 0.f;
-        *(float4*)(a + e) = av;
+        if (r != a || !x) *(float4*)(a + e) = av;   // (r stored over a: the sum below is what lands there -- one store, not two)
       }
       rv.x += av.x; rv.y += av.y; rv.z += av.z; rv.w += av.w;
       if (r != a || x) *(float4*)(r + e) = rv;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(kEwThreads) void residual_ln_scalar_k(
   for (size_t i = threadIdx.x; i < inner; i += kEwThreads) {
     const size_t e = base + i;
     float av = a[e];
-    if (thr) { av = keep_elem(e, seed, stream, thr) ? av * keepScale : 0.f; a[e] = av; }
+    if (thr) { av = keep_elem(e, seed, stream, thr) ? av * keepScale : 0.f; if (r != a || !x) a[e] = av; }
     const float rv = (x ? x[e] : 0.f) + av;
     r[e] = rv;
     s += (double)rv;
