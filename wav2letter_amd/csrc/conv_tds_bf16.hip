@@ -79,25 +79,33 @@ typedef float tb_f32x4u_t __attribute__((ext_vector_type(4), aligned(4)));
 template <int CP, int HB>
 __device__ __forceinline__ void tb_stage(unsigned char* slab, int FS, const float* __restrict__ src, int C, size_t frameStride, int tFirst,
                                          int nFrames, int T, int tid) {
-  constexpr int G = CP / 4, PER = HB * G, NV = 8;
-  const int total = nFrames * PER;
+  // A thread keeps ONE chunk role (mel row h, channels 4 cg .. 4 cg + 3) for the whole call and walks frames: FPT frames per
+  // pass over the workgroup's FPT * PER role slots (threads past them idle: 16 of 256 at CP = 24, HB = 8).  Everything but
+  // the frame index is then loop-invariant -- the address arithmetic per chunk shrinks to a clamp and one multiply-add
+  // (SQ counters of the first chunk version, which re-derived (frame, h, cg) from a flat index per load: 35 VALU instructions
+  // per MFMA, ~60 us of VALU issue in the 122 us forward pass at C = 15, profiles/r03_run24_conv_bf16_sq_lds_pmc.csv).
+  constexpr int G = CP / 4, PER = HB * G, FPT = 256 / PER, NV = 8;
+  static_assert(FPT >= 1, "a frame's chunks fit one pass");
   const int gLast = (C - 1) >> 2;         // the chunk with the row's last channels
   const int over = 4 * gLast + 4 - C;     // its 0 .. 3 slots past the row
-  for (int base = 0; base < total; base += NV * 256) {
+  const int role = tid % PER, fl0 = tid / PER;
+  const bool active = fl0 < FPT;
+  const int h = role / G, cg = role - h * G;
+  const int cgc = cg < gLast ? cg : gLast;
+  const int srcOff = h * C + (cgc < gLast ? 4 * cgc : C - 4);   // floats inside the frame's block
+  const int dstOff = (h * CP + 4 * cg) * 2;                     // bytes inside the slab frame
+  const bool last = cg == gLast, pad = cg > gLast;
+  for (int k0 = 0; k0 < nFrames; k0 += FPT * NV) {
     tb_f32x4u_t w[NV];
-    int dst[NV];                          // LDS byte offset | 1: the row's last chunk | 2: zeros (frame outside the utterance, padded chunk); -1: nothing to write
+    int fo[NV];                           // slab frame | 0x40000000: zeros (frame outside the utterance); -1: nothing to write
 #pragma unroll
     for (int u = 0; u < NV; ++u) {        // unconditional loads from clamped addresses (a load inside a branch serialises)
-      const int q = base + tid + 256 * u;
-      const int qq = q < total ? q : total - 1;
-      const int f = qq / PER, r = qq - f * PER;
-      const int h = r / G, cg = r - h * G;
-      const int tin = tFirst + f;
+      const int f = k0 + fl0 + FPT * u;
+      const int fc = f < nFrames ? f : nFrames - 1;
+      const int tin = tFirst + fc;
       const int tc = tin < 0 ? 0 : (tin >= T ? T - 1 : tin);
-      const int cgc = cg < gLast ? cg : gLast;
-      const int c0 = cgc < gLast ? 4 * cgc : C - 4;
-      w[u] = *(const tb_f32x4u_t*)(src + (size_t)tc * frameStride + h * C + c0);
-      dst[u] = q < total ? ((f * FS + (h * CP + 4 * cg) * 2) | (cg == gLast ? 1 : 0) | ((tin != tc || cg > gLast) ? 2 : 0)) : -1;
+      w[u] = *(const tb_f32x4u_t*)(src + (size_t)tc * frameStride + srcOff);
+      fo[u] = (active && f < nFrames) ? (tin != tc ? (f | 0x40000000) : f) : -1;
     }
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
@@ -107,12 +115,11 @@ __device__ __forceinline__ void tb_stage(unsigned char* slab, int FS, const floa
       const float s1 = over == 0 ? a.y : over == 1 ? a.z : over == 2 ? a.w : 0.f;
       const float s2 = over == 0 ? a.z : over == 1 ? a.w : 0.f;
       const float s3 = over == 0 ? a.w : 0.f;
-      const bool last = (dst[u] & 1) != 0, zero = (dst[u] & 2) != 0;
       const tb_f32x2_t lo = {last ? s0 : a.x, last ? s1 : a.y}, hi = {last ? s2 : a.z, last ? s3 : a.w};
       uint2 pk = make_uint2(__builtin_bit_cast(uint32_t, __builtin_convertvector(lo, tb_bf16x2_t)),
                             __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, tb_bf16x2_t)));
-      if (zero) pk = make_uint2(0u, 0u);
-      if (dst[u] >= 0) *(uint2*)(slab + (dst[u] & ~7)) = pk;
+      if (pad || (fo[u] & 0x40000000)) pk = make_uint2(0u, 0u);
+      if (fo[u] >= 0) *(uint2*)(slab + (fo[u] & 0x3fffffff) * FS + dstOff) = pk;
     }
   }
 }
