@@ -24,7 +24,9 @@ def bf16_round(a):
 # geometries outside stay in fp32 there, so the restatement leaves their operands unrounded too
 _BF16_CONV_FWD = {(16, 9, 1), (16, 21, 1), (24, 15, 1), (24, 18, 1), (24, 33, 1), (32, 22, 1), (16, 5, 1), (16, 11, 1), (24, 9, 1),
                   (16, 10, 2), (24, 18, 2), (16, 21, 2)}
-_BF16_CONV_FILTER = _BF16_CONV_FWD - {(16, 5, 1), (16, 11, 1), (24, 9, 1)}
+# filter gradient: (padded input channels, k-steps, stride, padded output channels)
+_BF16_CONV_FILTER = {(16, 9, 1, 16), (16, 21, 1, 16), (24, 15, 1, 24), (24, 18, 1, 24), (24, 33, 1, 24), (32, 22, 1, 32), (16, 10, 2, 16),
+                     (16, 10, 2, 24), (24, 18, 2, 24), (24, 18, 1, 32), (16, 21, 2, 16), (16, 21, 2, 24)}
 
 
 def conv_rounds_to_bf16(cin, cout, kw, stride, H):
@@ -40,7 +42,7 @@ def conv_rounds_to_bf16(cin, cout, kw, stride, H):
         return n
     f = (cp(cin), nstep(kw, cp(cin)), stride)
     b = (cp(cout), nstep((kw + stride - 1) // stride, cp(cout)), 1)
-    return f in _BF16_CONV_FILTER and b in _BF16_CONV_FWD
+    return f in _BF16_CONV_FWD and b in _BF16_CONV_FWD and f + (cp(cout),) in _BF16_CONV_FILTER
 
 
 def lin_fwd(x, w, b, bf16=False):

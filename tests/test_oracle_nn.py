@@ -460,3 +460,31 @@ def test_bf16_operand_rounding_of_the_reference_interpreter(oracle):
     assert np.abs(dx - refnet.bf16_round(dy).astype(np.float64) @ refnet.bf16_round(w).astype(np.float64).T).max() < 1e-5
     assert np.abs(dw - refnet.bf16_round(x).astype(np.float64).T @ refnet.bf16_round(dy).astype(np.float64)).max() < 1e-5
     assert np.abs(db - refnet.bf16_round(dy).astype(np.float64).sum(0)).max() < 1e-5   # the bias gradient rides on the weight-gradient product: sums of the ROUNDED dy
+
+
+def test_oracle_and_library_agree_on_which_convolutions_multiply_in_bf16():
+    """the mixed-precision mode rounds a convolution's operands to bf16 exactly when the library has bf16 kernels for its
+    geometry (w2l_tds_conv_bf16_image_elems != 0: host logic, no GPU needed); the oracle's restatement of that rule
+    (refnet.conv_rounds_to_bf16) must give the same answer for every geometry, or a full-network comparison would silently
+    compare a rounded product with an unrounded reference"""
+    import ctypes as C
+    from oracle import refnet
+    from wav2letter_amd import _lib
+    L = _lib.lib()
+    n = yes = 0
+    for stride in (1, 2, 3):
+        for H in (8, 16, 80):
+            for kw in (1, 5, 9, 10, 11, 12, 21):
+                for cin in (1, 3, 10, 14, 15, 16, 18, 19, 23, 24, 27, 32, 33):
+                    for cout in (1, 10, 14, 15, 16, 18, 19, 23, 27, 32, 40):
+                        for padl, padr in ((0, 0), (kw - 1, 0), (kw // 2, (kw - 1) // 2)):
+                            d = _lib.ConvDesc(2, 64, H, cin, cout, kw, stride, padl, padr)
+                            lib_says = L.w2l_tds_conv_bf16_image_elems(C.byref(d)) != 0
+                            assert lib_says == refnet.conv_rounds_to_bf16(cin, cout, kw, stride, H), (cin, cout, kw, stride, H, padl, padr)
+                            n += 1
+                            yes += lib_says
+    assert n > 10000 and yes > 50
+    # the recipes' layers are among them
+    for cin, cout, kw, stride in ((1, 15, 10, 2), (15, 19, 10, 2), (19, 23, 12, 2), (23, 27, 11, 1), (15, 15, 9, 1), (27, 27, 11, 1),
+                                  (1, 10, 21, 2), (10, 14, 21, 2), (14, 18, 21, 2), (18, 18, 21, 1)):
+        assert refnet.conv_rounds_to_bf16(cin, cout, kw, stride, 80), (cin, cout, kw, stride)

@@ -536,7 +536,7 @@ static bool tb_has_filter(int CP, int NS, int ST, int CPO) {
 
 static bool tb_geometry(const w2l_conv_desc* d, TbGeom& g) {
   if (!d || (d->stride != 1 && d->stride != 2) || d->Cin < 1 || d->Cin > 32 || d->Cout < 1 || d->Cout > 32 || d->kw < d->stride) return false;
-  if (d->B < 1 || d->T < 1 || d->padl < 0 || d->padr < 0 || d->H % kTbHB != 0) return false;   // whole 8-row mel blocks (16-byte aligned runs of 8 C floats)
+  if (d->B < 1 || d->T < 1 || d->padl < 0 || d->padr < 0 || d->H % kTbHB != 0) return false;   // whole mel blocks (16-byte aligned runs of 8 C floats)
   const int n = d->T + d->padl + d->padr - d->kw;
   if (n < 0) return false;
   const int st = d->stride;
@@ -556,7 +556,10 @@ static bool tb_geometry(const w2l_conv_desc* d, TbGeom& g) {
     q.tapOff = f;
     ++g.phases;
   }
-  return g.phases == st && tb_has_fwd(g.CPf, g.NSf, st) && tb_has_fwd(g.CPb, g.NSb, 1);
+  // one answer for the three passes: a layer is either wholly on the bf16 kernels or wholly on the fp32 entry points (the
+  // filter gradient stages 16-row mel blocks)
+  return g.phases == st && tb_has_fwd(g.CPf, g.NSf, st) && tb_has_fwd(g.CPb, g.NSb, 1) && d->H % kTgHB == 0 &&
+         tb_has_filter(g.CPf, g.NSf, st, g.CPb);
 }
 
 template <int CP, int NSTEP, int STRIDE>
@@ -660,7 +663,7 @@ W2L_API int w2l_tds_conv_bf16_backward_filter_bias(const w2l_conv_desc* d, const
                                                    w2l_stream_t stream) {
   TbGeom g;
   if (!x || !dy || !dw) return W2L_EINVAL;
-  if (!tb_geometry(d, g) || d->H % kTgHB != 0 || !tb_has_filter(g.CPf, g.NSf, g.stride, g.CPb)) return W2L_EUNSUPPORTED;
+  if (!tb_geometry(d, g)) return W2L_EUNSUPPORTED;
   TdsBfFilterP p{x, dy, nullptr, d->B, d->T, g.To, d->H, d->Cin, d->Cout, d->kw, d->padl, tb_abl(), 0};
   prof_begin((hipStream_t)stream, 2.0 * d->B * (double)g.To * d->H * d->Cin * (double)d->Cout * d->kw, PROF_TDS_BWD_FILTER);
   const int st = tb_dispatch_filter(g.CPf, g.NSf, g.stride, g.CPb, p, dw, dbias, (hipStream_t)stream);
