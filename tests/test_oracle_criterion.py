@@ -408,3 +408,48 @@ def test_criterion_handover_vector(oracle):
                                         blank=N - 1, reduction="none")
     assert np.abs(want.numpy() - np.array(g["ctc_loss"])).max() < 1e-9
     assert np.abs(oracle.CTC(em, ct).forward() - np.array(g["ctc_loss"])).max() < 1e-9
+
+
+def _torch_asg(x, A, y):
+    """independent restatement for the test below: the two recursions as torch float64 logsumexp loops (vectorised over states /
+    positions), gradients by autograd -- no code shared with oracle/criterion_oracle.c"""
+    T, N = x.shape
+    S = len(y)
+    alpha = x[0]
+    for t in range(1, T):                                  # FCC: alpha_t[j] = x_t[j] + lse_i(alpha_{t-1}[i] + A[j][i])
+        alpha = x[t] + torch.logsumexp(alpha.unsqueeze(0) + A, dim=1)
+    fcc = torch.logsumexp(alpha, dim=0)
+    yt = torch.tensor(y, dtype=torch.long)
+    self_t = A[yt, yt]
+    prev_t = torch.cat([torch.zeros(1, dtype=torch.float64), A[yt[1:], yt[:-1]]])
+    neg = torch.full((1,), -1e30, dtype=torch.float64)     # "unreachable": finite, so that autograd of lse(-inf, -inf) is 0, not NaN
+    a = torch.cat([x[0, yt[:1]], neg.expand(S - 1)]) if S > 1 else x[0, yt[:1]]
+    for t in range(1, T):                                  # FAC: stay or advance from position i - 1
+        stay = a + self_t
+        adv = torch.cat([neg, a[:-1] + prev_t[1:]]) if S > 1 else neg
+        a = x[t, yt] + torch.logsumexp(torch.stack([stay, adv]), dim=0)
+    return fcc, a[S - 1]
+
+
+@pytest.mark.parametrize("T,N,L,S,scale", [(60, 8, 12, 9, 1.0), (400, 30, 120, 77, 1.0), (2000, 30, 300, 300, 1.0), (700, 30, 300, 41, 6.0)])
+def test_fcc_fac_against_torch_autograd_at_recipe_scale(oracle, T, N, L, S, scale):
+    """a second, independent implementation at the conv_glu recipe's sizes (T = 2000 frames, N = 30 tokens, 300 labels), where
+    brute force cannot go: losses to 1e-10 relative, the oracle's hand-written backward passes (input and transition gradients
+    of FCC and FAC separately) against autograd to 1e-8 of the largest entry"""
+    rng = np.random.default_rng(T + S)
+    x = (rng.normal(size=(1, T, N)) * scale).astype(np.float32)
+    A = (rng.normal(size=(N, N)) * 0.5 + np.eye(N)).astype(np.float32)
+    tgt = np.full((1, L), -1, np.int32)
+    tgt[0, :S] = rng.integers(0, N, S)
+    xt = torch.tensor(x[0], dtype=torch.float64, requires_grad=True)
+    At = torch.tensor(A, dtype=torch.float64, requires_grad=True)
+    fcc_t, fac_t = _torch_asg(xt, At, tgt[0, :S].tolist())
+    fac = oracle.FAC(x, A, tgt)
+    fcc = oracle.FCC(x, A, fac.ts)
+    lf, la = fcc.forward()[0], fac.forward()[0]
+    assert abs(lf - fcc_t.item()) < 1e-10 * abs(lf) and abs(la - fac_t.item()) < 1e-10 * max(1.0, abs(la))
+    for loss_t, o in ((fcc_t, fcc), (fac_t, fac)):
+        gx, gA = torch.autograd.grad(loss_t, (xt, At), retain_graph=True)
+        dx, dA = o.backward()
+        assert np.abs(dx[0] - gx.numpy()).max() < 1e-8 * max(1.0, np.abs(gx.numpy()).max())
+        assert np.abs(dA - gA.numpy()).max() < 1e-8 * max(1.0, np.abs(gA.numpy()).max())
