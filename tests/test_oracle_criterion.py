@@ -453,3 +453,24 @@ def test_fcc_fac_against_torch_autograd_at_recipe_scale(oracle, T, N, L, S, scal
         dx, dA = o.backward()
         assert np.abs(dx[0] - gx.numpy()).max() < 1e-8 * max(1.0, np.abs(gx.numpy()).max())
         assert np.abs(dA - gA.numpy()).max() < 1e-8 * max(1.0, np.abs(gA.numpy()).max())
+
+
+@pytest.mark.parametrize("T,N,scale", [(2000, 30, 1.0), (300, 200, 3.0), (64, 9998, 1.0)])
+def test_viterbi_against_an_independent_dp_at_recipe_scale(oracle, T, N, scale):
+    """ViterbiPath at sizes brute force cannot reach (the conv_glu recipe's T = 2000 x N = 30, and N = 9998 word pieces): a
+    vectorised numpy max-product DP in float32 -- the oracle's arithmetic type -- with argmax taking the FIRST maximum, as the
+    reference's strict `>` scan does; the paths must be identical"""
+    rng = np.random.default_rng(T + N)
+    x = (rng.normal(size=(1, T, N)) * scale).astype(np.float32)
+    A = (rng.normal(size=(N, N)) * 0.5).astype(np.float32)
+    score = x[0, 0].copy()
+    back = np.zeros((T, N), np.int32)
+    for t in range(1, T):
+        cand = score[None, :] + A                      # cand[to][from], float32
+        back[t] = cand.argmax(axis=1)                  # first maximum
+        score = (cand.max(axis=1) + x[0, t]).astype(np.float32)
+    path = np.zeros(T, np.int32)
+    path[T - 1] = int(score.argmax())
+    for t in range(T - 1, 0, -1):
+        path[t - 1] = back[t, path[t]]
+    assert (oracle.viterbi(x, A)[0] == path).all()
