@@ -106,3 +106,146 @@ def fac_forward_linear(x, trans, target, S, group=1):
     if mant[last] <= 0:
         return -np.inf, w1
     return base + np.log(mant[last]) + float(expo[gid[last]]) * np.log(2.0), w1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: models of the arithmetic the shipped N <= 31 kernels run (csrc/criterion_asg_small.hip), op for op where it
+# matters for the numerics: the FCC scan with a LAGGED power-of-two scale (no maximum on the dependency chain), its backward
+# scan in the same scaled domain (beta recursion, no logs), and the FAC scan with fp64 mantissas, one exponent per lane of P
+# adjacent positions, renormalised every R frames with a decaying maximum-scan over the lane exponents.
+def fcc_kernel_model(x, trans, dtype=np.float32, kclamp=64):
+    """x [T][N], trans [N][N].  Returns (loss, u [T][N], q [T][N], ks [T]) as fcc_fwd_dpp computes them:
+         u_0 = 2 ** (z_0 - max z_0),                       z_0 = x_0 log2(e)
+         s_t = E u_{t-1},  u_t = s_t * q_t,                 q_t = 2 ** (zz_t - max zz_t) * 2 ** -k_t,  zz_t = x_t log2(e) + rowmax log2(e)
+         k_{t+1} = clamp(exponent(sum_j u_{t-1}[j]) - k_t)  (the sum arrives as one more row of the mat-vec: E[31][j] = 1)
+       so the magnitude of u_t is bounded by the growth of TWO frames and nothing but the mat-vec and one multiply is on the chain."""
+    x = np.asarray(x, np.float64)
+    A = np.asarray(trans, np.float64)
+    T, N = x.shape
+    L2E = 1.4426950408889634
+    rowmax = A.max(axis=1)
+    E = np.exp(A - rowmax[:, None]).astype(dtype)
+    u = np.zeros((T, N), dtype)
+    q = np.zeros((T, N), dtype)
+    ks = np.zeros(T, np.int64)
+    z0 = (x[0] * L2E).astype(dtype)
+    C2 = float(z0.max())
+    u[0] = np.exp2((z0 - z0.max()).astype(dtype)).astype(dtype)
+    k = 0
+    for t in range(1, T):
+        zz = (x[t] * L2E + rowmax * L2E).astype(dtype)
+        mz = zz.max()
+        P = np.exp2((zz - mz).astype(dtype)).astype(dtype)
+        s = (E @ u[t - 1]).astype(dtype)
+        mass = dtype(u[t - 1].sum(dtype=dtype))          # what row 31 of the mat-vec delivers with s_t
+        q[t] = np.ldexp(P, -k).astype(dtype)
+        u[t] = (s * q[t]).astype(dtype)
+        ks[t] = k
+        C2 += float(mz) + k
+        e = int(np.frexp(max(float(mass), 1e-45))[1]) - 1     # floor(log2(mass)) = the biased-exponent field - 127
+        k = int(np.clip(e - k, -kclamp, kclamp))
+    return C2 / L2E + float(np.log(u[T - 1].astype(np.float64).sum())), u, q, ks
+
+
+def fcc_kernel_model_backward(u, q, trans, dtype=np.float32):
+    """the backward scan of fcc_bwd_dpp on the forward's u, q: b_{T-1} = 1 / sum u_{T-1}; r_t = b_t q_t; b_{t-1} = E^T r_t;
+    returns (dx [T][N] = u_t b_t (d loss / d x_t), dA [N][N] = E .* sum_t r_t u_{t-1}^T)"""
+    A = np.asarray(trans, np.float64)
+    T, N = u.shape
+    E = np.exp(A - A.max(axis=1)[:, None]).astype(dtype)
+    b = np.full(N, dtype(1.0) / dtype(u[T - 1].sum(dtype=dtype)), dtype)
+    dx = np.zeros((T, N), np.float64)
+    acc = np.zeros((N, N), np.float64)
+    for t in range(T - 1, 0, -1):
+        dx[t] = (u[t] * b).astype(dtype)
+        r = (b * q[t]).astype(dtype)
+        acc += np.outer(r.astype(np.float64), u[t - 1].astype(np.float64))
+        b = (E.T @ r).astype(dtype)
+    dx[0] = (u[0] * b).astype(dtype)
+    return dx, E.astype(np.float64) * acc
+
+
+def fac_kernel_model(x, trans, target, S, P=5, R=4, D=600):
+    """x [T][N], trans [N][N], target[0..S).  Returns (loss, w1 [T][S]) as fac_fwd_lin computes them.
+       h_t[i] = alpha_t[i] * exp(A[y_i][y_i]) (linear, frame-shifted): h_t[i] = c_t[y_i] * (h_{t-1}[i] + kappa[i] h_{t-1}[i-1]),
+       c_t[n] = 2 ** (z_t[n] - max_n z_t[n]), z_t[n] = (x_t[n] + A[n][n]) log2(e) -- ONE row of N values per frame, computed with an
+       integer / fraction split so that it cannot underflow -- kappa[i] = exp(A[y_i][y_{i-1}] - A[y_{i-1}][y_{i-1}]).
+       Lane l holds positions l P .. l P + P - 1 as fp64 mantissas with ONE integer exponent e_l; the left neighbour's last
+       position arrives scaled by 2 ** (e_{l-1} - e_l).  Every R frames -- and at once when some lane's largest mantissa has left
+       [2 ** -200, 2 ** 300] -- the lanes renormalise:
+         * positions that can no longer reach the end (i < S - (T - t): the reference never computes them, SURVEY App. B.1 `low`)
+           are zeroed.  Without this a tight alignment (T ~ S) loses its answer: the lagging, useless positions outgrow the
+           lattice front by thousands of bits, and the front IS the only path that finishes;
+         * a lane with mass takes e_l = max(own, e_{l'} - D * (lanes with mass between l' and l)): what arrives from the left can
+           be at most 2 ** D larger than what the lane holds (no overflow); what such a lane flushes lies 1000+ bits below a
+           feasible position at most a few labels away, i.e. is negligible as long as one stay gains less than ~100 bits;
+         * an empty lane copies the exponent of the nearest lane with mass on its left (the lattice front enters it unscaled)."""
+    x = np.asarray(x, np.float64)
+    A = np.asarray(trans, np.float64)
+    y = np.asarray(target[:S], np.int64)
+    T, N = x.shape
+    L2E = 1.4426950408889634
+    NL = (S + P - 1) // P
+    SP = NL * P
+    kappa = np.zeros(SP)
+    kappa[1:S] = np.exp((A[y[1:], y[:-1]] - A[y[:-1], y[:-1]]).astype(np.float32)).astype(np.float32)
+    yy = np.zeros(SP, np.int64)
+    yy[:S] = y
+    pos = np.arange(SP)
+    valid = pos < S
+    lane = pos // P
+    NEGE = -(1 << 30)
+
+    def crow(t):
+        z = ((x[t] + np.diag(A)) * L2E).astype(np.float32)
+        zm = z.max()
+        zr = np.maximum((z - zm).astype(np.float32), -4000.0)
+        zi = np.rint(zr)
+        frac = np.exp2((zr - zi).astype(np.float32)).astype(np.float32)
+        return np.ldexp(frac.astype(np.float64), zi.astype(np.int64)), float(zm)
+
+    h = np.zeros(SP)
+    e = np.zeros(NL, np.int64)
+    d = np.zeros(NL, np.int64)
+    c, zsum = crow(0)
+    h[0] = c[yy[0]]
+    w1 = np.zeros((T, S))
+
+    def lane_max(h):
+        return np.array([h[l * P:(l + 1) * P].max() for l in range(NL)])
+
+    def renorm(h, e, t):
+        h = np.where(pos >= S - (T - t), h, 0.0)                    # prune what cannot finish any more
+        mx = lane_max(h)
+        has = mx > 0
+        k = np.where(has, np.frexp(np.where(has, mx, 1.0))[1], 0).astype(np.int64)
+        cand = np.where(has, e + k, NEGE)
+        cnt = np.cumsum(has)
+        v = np.where(has, cand + D * cnt, NEGE)
+        run = np.maximum.accumulate(v)
+        en = np.where(run > NEGE, run - D * cnt, e)
+        sh = np.clip(e - en, -2200, 2200)
+        h = np.ldexp(h, sh[lane].astype(np.int64))
+        d = np.zeros(NL, np.int64)
+        d[1:] = np.clip(en[:-1] - en[1:], -2200, 2200)
+        return h, en, d
+
+    h, e, d = renorm(h, e, 0)
+    for t in range(1, T):
+        c, zm = crow(t)
+        zsum += zm
+        prev = np.concatenate(([0.0], h[:-1]))
+        first = pos % P == 0
+        prev = np.where(first, np.ldexp(prev, d[lane].astype(np.int64)), prev)
+        tot = h + prev * kappa
+        with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+            w = (h * (1.0 / np.maximum(tot, 2.0 ** -1000))).astype(np.float32)
+        w1[t] = np.where(valid, w, 0.0)[:S]
+        h = np.where(valid, c[yy] * tot, 0.0)
+        mxl = lane_max(h)
+        if t % R == 0 or ((mxl > 0) & ((mxl < 2.0 ** -200) | (mxl > 2.0 ** 300))).any():
+            h, e, d = renorm(h, e, t)
+    last = S - 1
+    if h[last] <= 0:
+        return -np.inf, w1
+    return (zsum + float(e[last // P])) / L2E + np.log(h[last]) - A[y[last], y[last]], w1

@@ -57,3 +57,53 @@ def test_one_exponent_per_frame_is_not_enough_for_fac():
     good, _ = LD.fac_forward_linear(x[0], A, tgt[0], 120, group=5)
     assert abs(good - want) < 1e-9 * abs(want)
     assert not np.isfinite(bad) or abs(bad - want) > 1.0
+
+
+# ---- round 4: models of the arithmetic of the shipped kernels (csrc/criterion_asg_small.hip) ---------------------------------
+@pytest.mark.parametrize("T,N,scale,tscale", [(50, 6, 1.0, 0.5), (400, 30, 1.0, 0.5), (2000, 30, 1.0, 0.5), (600, 30, 12.0, 0.5),
+                                              (500, 31, 3.0, 4.0), (300, 30, 40.0, 8.0)])
+def test_fcc_kernel_model_lagged_scale(T, N, scale, tscale):
+    """the lagged power-of-two scale (exponent of the total mass two frames back, minus the correction already under way) keeps
+    the fp32 chain in range for unit and for very large emissions / transition spreads; loss 2e-6, gradients 1e-4 of the
+    largest entry (the parity bar), against the log-domain fp64 oracle"""
+    rng = np.random.default_rng(T * 31 + N)
+    x = (rng.normal(size=(1, T, N)) * scale).astype(np.float32)
+    A = (rng.normal(size=(N, N)) * tscale + np.eye(N) * 4).astype(np.float32)
+    f = O.FCC(x, A, np.array([4], np.int32))
+    want = f.forward()[0]
+    got, u, q, ks = LD.fcc_kernel_model(x[0], A)
+    assert np.isfinite(u).all() and abs(got - want) < 2e-6 * abs(want), (got, want)
+    mass = u.astype(np.float64).sum(axis=1)
+    assert mass.min() > 2.0 ** -100 and mass.max() < 2.0 ** 40, (mass.min(), mass.max())
+    odx, odA = f.backward()
+    dx, dA = LD.fcc_kernel_model_backward(u, q, A)
+    assert np.abs(dx - odx[0]).max() < 1e-4 * np.abs(odx).max()
+    assert np.abs(dA - odA).max() < 1e-4 * np.abs(odA).max()
+
+
+@pytest.mark.parametrize("T,N,L,S,scale,P", [(40, 6, 8, 5, 1.0, 1), (500, 30, 100, 77, 1.0, 2), (2000, 30, 300, 300, 1.0, 5),
+                                             (2000, 30, 300, 120, 8.0, 5), (300, 30, 300, 299, 2.0, 5), (64, 30, 40, 1, 1.0, 1),
+                                             (700, 30, 64, 64, 30.0, 1), (900, 30, 320, 310, 25.0, 5), (301, 30, 300, 298, 60.0, 5), (200, 30, 64, 64, 120.0, 1)])
+def test_fac_kernel_model_lane_exponents(T, N, L, S, scale, P):
+    """fp64 mantissas, one exponent per lane of P positions, renormalised every 4 frames through the decaying maximum scan:
+    loss 1e-6 relative (the per-frame factors are fp32 exp2 values), stay weights within 1e-5 of the oracle's wherever the
+    backward pass can reach"""
+    x, A, tgt = _case(T, N, L, S, scale, T + S + 7)
+    f = O.FAC(x, A, tgt)
+    want = f.forward()[0]
+    got, w1 = LD.fac_kernel_model(x[0], A, tgt[0], S, P=P)
+    assert np.isfinite(got) and abs(got - want) < 1e-6 * max(1.0, abs(want)), (got, want)
+    assert (w1 >= 0).all() and (w1 <= 1.0 + 1e-6).all()
+    # the backward recursion on the model's stay weights gives the oracle's input gradient (occupancies)
+    dx, _ = f.backward()
+    da = np.zeros(S)
+    da[S - 1] = 1.0
+    occ = np.zeros((T, N))
+    y = tgt[0, :S]
+    for t in range(T - 1, -1, -1):
+        np.add.at(occ[t], y, da)
+        if t >= 1:
+            st = da * w1[t]
+            adv = da - st
+            da = st + np.concatenate((adv[1:], [0.0]))
+    assert np.abs(occ - dx[0]).max() < 1e-4

@@ -1,0 +1,224 @@
+"""Round 4: the N <= 31 ASG kernels (csrc/criterion_asg_dpp.hpp: FCC and Viterbi on DPP row rotations in a scaled linear
+domain; csrc/criterion_fac_lin.hpp: FAC with fp64 mantissas and one exponent per lane) and the widened CTC label
+probabilities, against the CPU oracle through the C ABI.
+
+Bar (BASELINE.json north_star): Viterbi paths bit-exact; loss / gradients within 1e-4 of the oracle relative to the largest
+reference magnitude.  The cases walk the edges of the new machine mappings: state counts around the 16-lane row boundary and
+up to 31, frame counts around the 16-frame chunk and its parity, target lengths around the positions-per-lane steps, emission
+and transition magnitudes far beyond what fp32 exp() can hold (the scaled domains must not care)."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_criterion import TOL, dev, gradrel, make_targets, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N", [1, 2, 15, 16, 17, 29, 30, 31])
+@pytest.mark.parametrize("T", [1, 2, 3, 15, 16, 17, 32, 33, 257])
+def test_fcc_dpp_state_and_frame_edges(oracle, N, T):
+    from wav2letter_amd import FullConnectionCriterion
+    rng = np.random.default_rng(N * 1000 + T)
+    B = 3
+    x = (rng.normal(size=(B, T, N)) * 1.5).astype(np.float32)
+    A = rng.normal(size=(N, N)).astype(np.float32)
+    tgt = make_targets(rng, B, 5, N, T)
+    w = rng.normal(size=B).astype(np.float32)
+    crit = FullConnectionCriterion(N, 0).cuda()
+    crit.transitions.data = dev(A)
+    xt = dev(x).requires_grad_(True)
+    loss = crit(xt, dev(tgt))
+    (loss * dev(w)).sum().backward()
+    o = oracle.FCC(x, A, oracle.batch_target_size(tgt, T), 0)
+    ol = o.forward()
+    odx, odA = o.backward(w.astype(np.float64))
+    assert relerr(loss.detach().cpu().numpy(), ol) < TOL
+    assert gradrel(xt.grad.cpu().numpy(), odx) < TOL
+    if T > 1:
+        assert gradrel(crit.transitions.grad.cpu().numpy(), odA) < TOL
+    else:
+        assert np.abs(crit.transitions.grad.cpu().numpy()).max() == 0
+
+
+@pytest.mark.parametrize("xscale,ascale,diag", [(1.0, 0.1, 4.0), (12.0, 0.5, 4.0), (40.0, 2.0, 0.0), (0.01, 8.0, 0.0), (3.0, 0.0, 0.0)])
+def test_fcc_dpp_magnitudes(oracle, xscale, ascale, diag):
+    """the lagged power-of-two scale: emissions of +-100 and more, transition rows spread over tens of nats, T = 2000 frames"""
+    from wav2letter_amd import FullConnectionCriterion
+    rng = np.random.default_rng(int(xscale * 10 + ascale * 100))
+    B, T, N = 2, 2000, 30
+    x = (rng.normal(size=(B, T, N)) * xscale).astype(np.float32)
+    A = (rng.normal(size=(N, N)) * ascale + np.eye(N) * diag).astype(np.float32)
+    tgt = make_targets(rng, B, 5, N, T)
+    crit = FullConnectionCriterion(N, 0).cuda()
+    crit.transitions.data = dev(A)
+    xt = dev(x).requires_grad_(True)
+    loss = crit(xt, dev(tgt))
+    loss.sum().backward()
+    o = oracle.FCC(x, A, oracle.batch_target_size(tgt, T), 0)
+    ol = o.forward()
+    odx, odA = o.backward(np.ones(B))
+    assert np.isfinite(loss.detach().cpu().numpy()).all()
+    assert relerr(loss.detach().cpu().numpy(), ol) < TOL
+    assert gradrel(xt.grad.cpu().numpy(), odx) < TOL
+    assert gradrel(crit.transitions.grad.cpu().numpy(), odA) < TOL
+
+
+@pytest.mark.parametrize("L", [1, 2, 5, 63, 64, 65, 128, 129, 192, 193, 256, 257, 300, 320])
+def test_fac_lin_positions_per_lane_edges(oracle, L):
+    from wav2letter_amd import ForceAlignmentCriterion
+    rng = np.random.default_rng(L)
+    B, N = 3, 30
+    T = max(L + 7, 40)
+    x = (rng.normal(size=(B, T, N)) * 1.5).astype(np.float32)
+    A = rng.normal(size=(N, N)).astype(np.float32)
+    tgt = make_targets(rng, B, L, N, T)
+    tgt[0, :L] = rng.integers(0, N, size=L)        # the whole width
+    tgt[1, :] = -1
+    tgt[1, 0] = 3                                  # a single label
+    w = rng.normal(size=B).astype(np.float32)
+    crit = ForceAlignmentCriterion(N, 4).cuda()
+    crit.transitions.data = dev(A)
+    xt = dev(x).requires_grad_(True)
+    loss = crit(xt, dev(tgt))
+    (loss * dev(w)).sum().backward()
+    o = oracle.FAC(x, A, tgt, scale_mode=4)
+    ol = o.forward()
+    odx, odA = o.backward(w.astype(np.float64))
+    assert relerr(loss.detach().cpu().numpy(), ol) < TOL
+    assert gradrel(xt.grad.cpu().numpy(), odx) < TOL
+    assert gradrel(crit.transitions.grad.cpu().numpy(), odA) < TOL
+
+
+@pytest.mark.parametrize("T,L,xscale,ascale", [(2000, 300, 1.0, 0.1), (2000, 120, 8.0, 0.5), (900, 310, 22.0, 1.0), (700, 64, 22.0, 2.0),
+                                               (300, 299, 2.0, 0.5), (301, 300, 22.0, 0.5), (304, 300, 20.0, 0.5), (330, 300, 15.0, 3.0),
+                                               (301, 300, 60.0, 0.5), (304, 300, 60.0, 0.5), (1500, 7, 40.0, 3.0), (600, 200, 3.0, 12.0)])
+def test_fac_lin_magnitudes(oracle, T, L, xscale, ascale):
+    """one exponent per lane, renormalised every 4 frames: tight alignments (T ~ L: the lattice front IS the path), emissions
+    whose per-frame spread exceeds what one fp32 (or one shared) scale can hold (scale 22: ~130 bits per frame, inside the
+    range the linear-domain kernel keeps exact); beyond kFacSafeBits (scale 40, 60; transition spreads of tens of nats) the
+    kernel flags the utterance and the log-domain kernel recomputes it -- the result must be right either way"""
+    from wav2letter_amd import ForceAlignmentCriterion
+    rng = np.random.default_rng(T + L)
+    B, N = 2, 30
+    x = (rng.normal(size=(B, T, N)) * xscale).astype(np.float32)
+    A = (rng.normal(size=(N, N)) * ascale + np.eye(N) * 4).astype(np.float32)
+    tgt = make_targets(rng, B, L, N, T, min_len=max(1, L - 5))
+    crit = ForceAlignmentCriterion(N, 0).cuda()
+    crit.transitions.data = dev(A)
+    xt = dev(x).requires_grad_(True)
+    loss = crit(xt, dev(tgt))
+    loss.sum().backward()
+    o = oracle.FAC(x, A, tgt, scale_mode=0)
+    ol = o.forward()
+    odx, odA = o.backward(np.ones(B))
+    assert np.isfinite(loss.detach().cpu().numpy()).all()
+    assert relerr(loss.detach().cpu().numpy(), ol) < TOL
+    assert gradrel(xt.grad.cpu().numpy(), odx) < TOL
+    assert gradrel(crit.transitions.grad.cpu().numpy(), odA) < TOL
+
+
+@pytest.mark.parametrize("N", [1, 2, 15, 16, 17, 30, 31])
+@pytest.mark.parametrize("T", [1, 2, 16, 17, 129, 300])
+def test_viterbi_dpp_bit_exact_edges(oracle, N, T):
+    from wav2letter_amd import ASGLoss
+    rng = np.random.default_rng(N * 77 + T)
+    B = 3
+    x = rng.normal(size=(B, T, N)).astype(np.float32)
+    A = rng.normal(size=(N, N)).astype(np.float32)
+    crit = ASGLoss(N).cuda()
+    crit.transitions.data = dev(A)
+    assert (crit.viterbiPath(dev(x)).cpu().numpy() == oracle.viterbi(x, A)).all()
+    # heavy ties (first maximum must win exactly like the CPU scan), and scores large enough that fp32 sums round
+    xq = (np.round(x * 2) / 2).astype(np.float32)
+    Aq = (np.round(A * 2) / 2).astype(np.float32)
+    crit.transitions.data = dev(Aq)
+    assert (crit.viterbiPath(dev(xq)).cpu().numpy() == oracle.viterbi(xq, Aq)).all()
+    xb = (x * 1000).astype(np.float32)
+    crit.transitions.data = dev(A)
+    assert (crit.viterbiPath(dev(xb)).cpu().numpy() == oracle.viterbi(xb, A)).all()
+
+
+@pytest.mark.parametrize("B,T,N,L,scale", [(2, 40, 30, 12, 60.0), (2, 25, 9998, 20, 40.0), (2, 300, 29, 140, 80.0)])
+def test_ctc_wide_logit_gaps(oracle, B, T, N, L, scale):
+    """labels 100+ nats below the frame's normaliser (round-3 advice): the scans multiply by exp(lp) as an fp64 value built from
+    an integer / fraction split, so a confident-wrong frame keeps a finite probability; one utterance has T' == number of
+    lattice steps it needs (every frame is forced)"""
+    from wav2letter_amd import CTCLoss
+    rng = np.random.default_rng(N + T)
+    x = (rng.normal(size=(B, T, N)) * scale).astype(np.float32)
+    tgt = make_targets(rng, B, L, N, T, hi=N - 1, no_adjacent_repeat=True)
+    l0 = min(L, T)
+    y0 = rng.integers(0, N - 1, size=l0)
+    for i in range(1, l0):
+        while y0[i] == y0[i - 1]:
+            y0[i] = rng.integers(0, N - 1)
+    tgt[0, :] = -1
+    tgt[0, :l0] = y0
+    w = rng.normal(size=B).astype(np.float32)
+    crit = CTCLoss(0)
+    xt = dev(x).requires_grad_(True)
+    loss = crit(xt, dev(tgt))
+    (loss * dev(w)).sum().backward()
+    o = oracle.CTC(x, tgt, scale_mode=0)
+    ol = o.forward()
+    assert np.isfinite(ol).all() and np.isfinite(loss.detach().cpu().numpy()).all()
+    assert relerr(loss.detach().cpu().numpy(), ol) < TOL
+    assert gradrel(xt.grad.cpu().numpy(), o.backward(w.astype(np.float64))) < TOL
+
+
+def test_asg_generations_agree_and_timing():
+    """the probe library can run the previous kernel generation (W2L_ASG_OLD=1): both agree at the bench shape; prints the
+    four kernel timings side by side (informational)"""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, json, numpy as np, torch
+sys.path.insert(0, os.getcwd())
+from wav2letter_amd import _lib
+_lib.use_probe()
+from wav2letter_amd import ASGLoss, CriterionScaleMode
+B, T, N, L = 64, 2000, 30, 300
+g = torch.Generator(device="cpu").manual_seed(4)
+x = torch.randn(B, T, N, generator=g).cuda().requires_grad_(True)
+tgt = torch.full((B, L), -1, dtype=torch.int32)
+for b in range(B):
+    l = int(torch.randint(60, L + 1, (1,), generator=g))
+    y = torch.randint(0, 28, (l,), generator=g, dtype=torch.int32)
+    for i in range(1, l):
+        if y[i] == y[i - 1]:
+            y[i] = (y[i] + 1) % 28
+    tgt[b, :l] = y
+tgt = tgt.cuda()
+crit = ASGLoss(N, CriterionScaleMode.TARGET_SZ_SQRT, 4.0).cuda()
+def timeit(fn, n=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+loss = crit(x, tgt); loss.sum().backward()
+out = {"loss": loss.detach().cpu().numpy().tolist(), "dx": x.grad.cpu().numpy().ravel()[::997].tolist(),
+       "dA": crit.transitions.grad.cpu().numpy().ravel().tolist(), "path": crit.viterbiPath(x.detach()).cpu().numpy().ravel()[::13].tolist(),
+       "fwd_ms": timeit(lambda: crit(x, tgt)), "fwd_bwd_ms": timeit(lambda: crit(x, tgt).sum().backward()),
+       "fcc_ms": timeit(lambda: crit.fcc(x, tgt)), "fac_ms": timeit(lambda: crit.fac(x, tgt)), "vit_ms": timeit(lambda: crit.viterbiPath(x.detach()))}
+print("RESULT" + json.dumps(out))
+'''
+    res = {}
+    for name, env in (("new", {}), ("old", {"W2L_ASG_OLD": "1"})):
+        e = dict(os.environ)
+        e.update(env)
+        p = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert p.returncode == 0, p.stderr[-2000:]
+        import json
+        res[name] = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT")][0][6:])
+    n, o = res["new"], res["old"]
+    print("ASG generations (ms): " + ", ".join(f"{k} new {n[k]:.3f} old {o[k]:.3f}" for k in ("fwd_ms", "fwd_bwd_ms", "fcc_ms", "fac_ms", "vit_ms")))
+    assert np.abs(np.array(n["loss"]) - np.array(o["loss"])).max() < 1e-4 * np.abs(np.array(o["loss"])).max()
+    assert np.abs(np.array(n["dx"]) - np.array(o["dx"])).max() < 1e-4 * np.abs(np.array(o["dx"])).max()
+    assert np.abs(np.array(n["dA"]) - np.array(o["dA"])).max() < 1e-4 * np.abs(np.array(o["dA"])).max()
+    assert n["path"] == o["path"]

@@ -32,6 +32,8 @@ constexpr int kRowMaxPer = 48;  // register-resident row: N <= 256*48 = 12288
 struct CtcWs {
   float* lse;     // [B][T]
   float* lp;      // [B][T][S]   label log-probs
+  double* pd;     // [B][T][S]   exp(lp) in fp64, written by the row kernels through an integer / fraction split: a label
+                  //             100+ nats below the row's normaliser keeps a finite probability (fp32 exp flushes below -87)
   double* alpha;  // [B][T][S]
   double* beta;   // [B][T][S]   (beta includes p_t(s), as alpha does)
   int* eA;        // [B][T][64]  lane exponents of the alpha mantissas
@@ -57,6 +59,7 @@ __host__ __device__ inline CtcWs ctc_ws(void* ws, int B, int T, int N, int L) {
   char* p = (char*)ws;
   w.lse = (float*)p; p += align_up((size_t)B * T * sizeof(float), 256);
   w.lp = (float*)p; p += align_up((size_t)B * T * w.S * sizeof(float), 256);
+  w.pd = (double*)p; p += align_up((size_t)B * T * w.S * sizeof(double), 256);
   w.alpha = (double*)p; p += align_up((size_t)B * T * w.S * sizeof(double), 256);
   w.beta = (double*)p; p += align_up((size_t)B * T * w.S * sizeof(double), 256);
   w.eA = (int*)p; p += align_up((size_t)B * T * 64 * sizeof(int), 256);
@@ -66,6 +69,15 @@ __host__ __device__ inline CtcWs ctc_ws(void* ws, int B, int T, int N, int L) {
   w.scale = (float*)p; p += align_up((size_t)B * sizeof(float), 256);
   w.nll = (float*)p;
   return w;
+}
+
+// exp(lp) for lp <= ~0 over the whole fp64 range: 2^frac by the hardware fp32 exp2 (frac in [-0.5, 0.5]), the integer part by
+// v_ldexp_f64.  __expf(lp) alone is 0 below -87 (-103 with denormals): one confident-wrong frame would make its lattice cells
+// impossible, and with a tight alignment the whole likelihood 0 (loss +inf) where the log-domain reference stays finite.
+__device__ __forceinline__ double exp_wide(float lp) {
+  const float z = fmaxf(lp * 1.44269504088896341f, -1090.f);
+  const float zi = __builtin_rintf(z);
+  return __builtin_amdgcn_ldexp((double)__builtin_amdgcn_exp2f(z - zi), (int)zi);
 }
 
 __device__ __forceinline__ float block_reduce_max(float v, float* sm) {
@@ -148,9 +160,12 @@ __global__ __launch_bounds__(kRowThreads) void ctc_rows_lse(int T, int N, int L,
   const int S = 2 * Lb + 1;
   const int* y = target + (size_t)b * L;
   float* lp = ws.lp + r * ws.S;
+  double* pd = ws.pd + r * ws.S;
   for (int si = tid; si < S; si += kRowThreads) {
     int lab = (si & 1) ? y[si >> 1] : (N - 1);
-    lp[si] = row[lab] - lse;
+    const float l = row[lab] - lse;
+    lp[si] = l;
+    pd[si] = exp_wide(l);
   }
 }
 
@@ -177,9 +192,12 @@ __global__ __launch_bounds__(kRowThreads) void ctc_rows_lse_big(int T, int N, in
   const int S = 2 * Lb + 1;
   const int* y = target + (size_t)b * L;
   float* lp = ws.lp + r * ws.S;
+  double* pd = ws.pd + r * ws.S;
   for (int si = tid; si < S; si += kRowThreads) {
     int lab = (si & 1) ? y[si >> 1] : (N - 1);
-    lp[si] = row[lab] - lse;
+    const float l = row[lab] - lse;
+    lp[si] = l;
+    pd[si] = exp_wide(l);
   }
 }
 
@@ -216,7 +234,7 @@ __global__ __launch_bounds__(64) void ctc_scan(int T, int N, int L, int scaleMod
   const int S = 2 * Lb + 1;
   const int SW = ws.S;
   const int* y = target + (size_t)b * L;
-  const float* lp = ws.lp + (size_t)b * T * SW;
+  const double* pd = ws.pd + (size_t)b * T * SW;
   double* lat = (isBeta ? ws.beta : ws.alpha) + (size_t)b * T * SW;
   int* lex = (isBeta ? ws.eB : ws.eA) + (size_t)b * T * 64;
 
@@ -235,7 +253,7 @@ __global__ __launch_bounds__(64) void ctc_scan(int T, int N, int L, int scaleMod
   }
   // frame order of this scan: alpha walks t = 0 .. T-1, beta t = T-1 .. 0
   auto frame = [&](int k) { return isBeta ? T - 1 - k : k; };
-  auto prob = [&](int k, int si) -> float { return (k < T && si < S) ? __expf(lp[(size_t)frame(k) * SW + si]) : 0.f; };
+  auto prob = [&](int k, int si) -> double { return (k < T && si < S) ? pd[(size_t)frame(k) * SW + si] : 0.0; };
 
   // ---- first frame: alpha_0(s) = p_0(s) for s < 2; beta_{T-1}(s) = p_{T-1}(s) for s >= S - 2
   double a[P];
@@ -246,7 +264,7 @@ __global__ __launch_bounds__(64) void ctc_scan(int T, int N, int L, int scaleMod
     for (int p = 0; p < P; ++p) {
       const int si = lane * P + p;
       const bool on = si < S && (isBeta ? si >= S - 2 : si < 2);
-      a[p] = on ? (double)prob(0, si) : 0.0;
+      a[p] = on ? prob(0, si) : 0.0;
       m = fmax(m, a[p]);
     }
     if (m > 0.0) {
@@ -264,7 +282,7 @@ __global__ __launch_bounds__(64) void ctc_scan(int T, int N, int L, int scaleMod
     lex[(size_t)frame(0) * 64 + lane] = ex;
   }
 
-  float pc[D][P], pn[D][P];   // p of steps k0 .. k0 + D - 1 (current chunk) and of the next chunk
+  double pc[D][P], pn[D][P];   // p of steps k0 .. k0 + D - 1 (current chunk) and of the next chunk
 #pragma unroll
   for (int u = 0; u < D; ++u)
 #pragma unroll
@@ -312,7 +330,7 @@ __global__ __launch_bounds__(64) void ctc_scan(int T, int N, int L, int scaleMod
               v2 = p + 2 < P ? o[p + 2 < P ? p + 2 : 0] : (p + 1 < P ? n1 : n2);
             }
             const double sum = (o[p] + v1) + (skip[p] ? v2 : 0.0);
-            na[p] = sum * (double)pc[u][p];     // p = 0 beyond S: stays zero
+            na[p] = sum * pc[u][p];     // p = 0 beyond S: stays zero
             m = fmax(m, na[p]);
           }
         }
@@ -404,8 +422,8 @@ __global__ __launch_bounds__(kRowThreads) void ctc_rows_grad(int T, int N, int L
   const int S = 2 * Lb + 1;
   const int* y = target + (size_t)b * L;
   // occupancy of label position s at this frame: alpha beta / (p Z) = alpha^ beta^ / (p zhat) * 2^(eA + eB - ez)
-  // (alpha and beta both carry p_t(s); p is the SAME v_exp_f32 of the same lp the scans multiplied by)
-  const float* lpr = ws.lp + r * ws.S;
+  // (alpha and beta both carry p_t(s); p is the SAME fp64 value pd[t][s] the scans multiplied by)
+  const double* pdr = ws.pd + r * ws.S;
   const double* alr = ws.alpha + r * ws.S;
   const double* ber = ws.beta + r * ws.S;
   const int* ear = ws.eA + r * 64;
@@ -417,7 +435,7 @@ __global__ __launch_bounds__(kRowThreads) void ctc_rows_grad(int T, int N, int L
       const int lab = (si & 1) ? y[si >> 1] : (N - 1);
       const double av = alr[si], bv = ber[si];
       if (av > 0.0 && bv > 0.0) {
-        const double pv = (double)__expf(lpr[si]);
+        const double pv = pdr[si];
         const float v = (float)ldexp(av * bv / (pv * zh), ear[si / P] + ebr[si / P] - ez);
         if (v != 0.f) atomicAdd(&out[lab], -g * v);
       }
@@ -504,7 +522,7 @@ W2L_API size_t w2l_ctc_workspace_size(int B, int T, int N, int L) {
   if (B <= 0 || T <= 0 || N <= 0 || L < 0) return 0;
   size_t S = 2 * (size_t)L + 1;
   return align_up((size_t)B * T * sizeof(float), 256) + align_up((size_t)B * T * S * sizeof(float), 256) +
-         2 * align_up((size_t)B * T * S * sizeof(double), 256) + 2 * align_up((size_t)B * T * 64 * sizeof(int), 256) +
+         3 * align_up((size_t)B * T * S * sizeof(double), 256) + 2 * align_up((size_t)B * T * 64 * sizeof(int), 256) +
          align_up((size_t)B * sizeof(double), 256) + align_up((size_t)B * sizeof(int), 256) + 2 * align_up((size_t)B * sizeof(float), 256);
 }
 
@@ -525,11 +543,11 @@ W2L_API int w2l_ctc_forward(int B, int T, int N, int L, int scaleMode, const flo
   const int S = 2 * L + 1;
   const dim3 grid((unsigned)B, 2), blk(64);   // (utterance, alpha | beta)
   switch (ws.P) {   // (positions per lane, prefetch depth): 2 D P floats of p_t(s) in registers
-    case 2: hipLaunchKernelGGL((ctc_scan<2, 32>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws); break;
-    case 4: hipLaunchKernelGGL((ctc_scan<4, 16>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws); break;
-    case 8: hipLaunchKernelGGL((ctc_scan<8, 8>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws); break;
-    case 16: hipLaunchKernelGGL((ctc_scan<16, 4>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws); break;
-    default: hipLaunchKernelGGL((ctc_scan<32, 2>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws); break;
+    case 2: hipLaunchKernelGGL((ctc_scan<2, 16>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws); break;
+    case 4: hipLaunchKernelGGL((ctc_scan<4, 8>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws); break;
+    case 8: hipLaunchKernelGGL((ctc_scan<8, 4>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws); break;
+    case 16: hipLaunchKernelGGL((ctc_scan<16, 2>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws); break;
+    default: hipLaunchKernelGGL((ctc_scan<32, 1>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws); break;
   }
   W2L_LAUNCH_CHECK();
   return W2L_OK;

@@ -34,6 +34,8 @@ struct FacWs {
   float* scale;  // [B]
   float* tgpart; // [B][N][N] (only when it is small enough, else NULL -> atomics)
   unsigned char* bp;  // viterbi back pointers [B][T][L]
+  int* redo;     // [B]  set by fac_fwd_lin: the utterance's dynamics exceed what the per-lane exponents hold exactly ->
+                 //      fac_fwd_blk (log domain), launched behind it, recomputes that utterance
 };
 
 __host__ __device__ inline bool fac_use_partials(int B, int N) {
@@ -46,9 +48,22 @@ __host__ __device__ inline FacWs fac_ws(void* ws, int B, int T, int N, int L) {
   w.w1 = (float*)p; p += align_up((size_t)B * T * L * sizeof(float), 256);
   w.dal = (float*)p; p += align_up((size_t)B * T * L * sizeof(float), 256);
   w.scale = (float*)p; p += align_up((size_t)B * sizeof(float), 256);
+  w.redo = (int*)p; p += align_up((size_t)B * sizeof(int), 256);
   w.bp = (unsigned char*)w.w1;  // viterbi reuses the w1 region (needs B*T*L bytes)
   w.tgpart = fac_use_partials(B, N) ? (float*)p : nullptr;
   return w;
+}
+
+}  // namespace w2l
+
+#include "criterion_fac_lin.hpp"   // N <= 32, L <= 320: scaled linear domain, one wave per utterance (fac_fwd_lin, fac_bwd_wave)
+
+namespace w2l {
+
+// the probe library can put the previous generation (fac_*_blk) back for A/B work (W2L_ASG_OLD=1)
+inline bool fac_lin_path(int N, int L) {
+  static const bool old = tune_env("W2L_ASG_OLD") != nullptr;
+  return N <= 32 && L <= 320 && !old;
 }
 
 template <int P>
@@ -251,10 +266,11 @@ __global__ __launch_bounds__(64 * NW) void fac_fwd_blk(int T, int N, int L, int 
                                                        const int* __restrict__ target,
                                                        const int* __restrict__ targetSize,
                                                        const float* __restrict__ trans,
-                                                       float* __restrict__ loss, FacWs ws) {
+                                                       float* __restrict__ loss, FacWs ws, const int* __restrict__ redo = nullptr) {
   constexpr int NT = 64 * NW;
   __shared__ double sA[2][NT * P + 1];  // sA[buf][i + 1] = alpha[i]; sA[buf][0] = -inf (position -1)
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (redo && !redo[b]) return;   // launched behind fac_fwd_lin: only the utterances it flagged
   const int S = targetSize[b];
   const float sc = scale_of(scaleMode, T, S);
   if (tid == 0) ws.scale[b] = sc;
@@ -819,7 +835,8 @@ using namespace w2l;
 
 W2L_API size_t w2l_fac_workspace_size(int B, int T, int N, int L) {
   if (B <= 0 || T <= 0 || N <= 0 || L <= 0) return 0;
-  size_t sz = 2 * align_up((size_t)B * T * L * sizeof(float), 256) + align_up((size_t)B * sizeof(float), 256);
+  size_t sz = 2 * align_up((size_t)B * T * L * sizeof(float), 256) + align_up((size_t)B * sizeof(float), 256) +
+              align_up((size_t)B * sizeof(int), 256);
   if (fac_use_partials(B, N)) sz += align_up((size_t)B * N * N * sizeof(float), 256);
   return sz;
 }
@@ -848,6 +865,23 @@ W2L_API int w2l_fac_forward(int B, int T, int N, int L, int scaleMode, const flo
   if (L > 512) return W2L_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   FacWs ws = fac_ws(workspace, B, T, N, L);
+  if (fac_lin_path(N, L)) {
+#define W2L_FAC_LIN_GO(PP) hipLaunchKernelGGL(fac_fwd_lin<PP>, dim3(B), dim3(64), 0, s, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws)
+    switch ((L + 63) / 64) {
+      case 1: W2L_FAC_LIN_GO(1); break;
+      case 2: W2L_FAC_LIN_GO(2); break;
+      case 3: W2L_FAC_LIN_GO(3); break;
+      case 4: W2L_FAC_LIN_GO(4); break;
+      default: W2L_FAC_LIN_GO(5); break;
+    }
+#undef W2L_FAC_LIN_GO
+    W2L_LAUNCH_CHECK();
+    // the exact log-domain kernel for the utterances fac_fwd_lin flagged (returns at once for the others)
+    if (L > 256) hipLaunchKernelGGL((fac_fwd_blk<8, 1>), dim3(B), dim3(512), 0, s, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws, (const int*)ws.redo);
+    else W2L_FAC_BLK_DISPATCH(fac_fwd_blk, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws, (const int*)ws.redo);
+    W2L_LAUNCH_CHECK();
+    return W2L_OK;
+  }
   static const int waveMode = [] { const char* e = tune_env("W2L_FAC_WAVE"); return e ? atoi(e) : 0; }();
   if (waveMode && L <= 384) {  // experiment: one wave per utterance, ceil(L/64) positions per lane, DPP neighbour exchange
     const int P = (L + 63) / 64;
@@ -903,6 +937,17 @@ W2L_API int w2l_fac_backward(int B, int T, int N, int L, const int* target, cons
   size_t n = (size_t)N * N;
   if (ws.tgpart) W2L_HIP_CHECK(hipMemsetAsync(ws.tgpart, 0, (size_t)B * n * sizeof(float), s));
   else W2L_HIP_CHECK(hipMemsetAsync(transGrad, 0, n * sizeof(float), s));
+  if (fac_lin_path(N, L)) {
+#define W2L_FAC_LIN_GO(PP) hipLaunchKernelGGL(fac_bwd_wave<PP>, dim3(B), dim3(64), 0, s, T, N, L, target, targetSize, grad, transGrad, ws)
+    switch ((L + 63) / 64) {
+      case 1: W2L_FAC_LIN_GO(1); break;
+      case 2: W2L_FAC_LIN_GO(2); break;
+      case 3: W2L_FAC_LIN_GO(3); break;
+      case 4: W2L_FAC_LIN_GO(4); break;
+      default: W2L_FAC_LIN_GO(5); break;
+    }
+#undef W2L_FAC_LIN_GO
+  } else
 #ifdef W2L_PROBE
   if (tune_env("W2L_FAC_PIPE")) {
     const int nw = (L + 63) / 64;

@@ -33,6 +33,8 @@ struct FccWs {
                  //            over `logs` the stores alias the scan's prefetch loads and cost a vmcnt(0) per frame)
   float* scale;  // [B]
   float* tgpart; // [B][kDtChunks][N][N] transition-gradient partials (utterance x time chunk)
+  int* redo;     // [B]  N <= 31: 1 = the transition rows spread too far for the fp32 linear-domain scan (fcc_fwd_dpp sets it):
+                 //      the utterance runs on the log-domain kernels (fcc_*_small), whose workspace semantics it then has
 };
 
 __host__ __device__ inline FccWs fcc_ws(void* ws, int B, int T, int N) {
@@ -43,8 +45,21 @@ __host__ __device__ inline FccWs fcc_ws(void* ws, int B, int T, int N) {
   w.logs = (float*)p; p += btn;
   w.r = (float*)p; p += btn;
   w.scale = (float*)p; p += align_up((size_t)B * sizeof(float), 256);
-  w.tgpart = (float*)p;
+  w.tgpart = (float*)p; p += align_up((size_t)B * kDtChunks * N * N * sizeof(float), 256);
+  w.redo = (int*)p;
   return w;
+}
+
+}  // namespace w2l
+
+#include "criterion_asg_dpp.hpp"   // N <= 31: scaled linear domain on DPP row rotations (fcc_fwd_dpp, fcc_bwd_dpp, vit_fwd_dpp, vit_bt_k)
+
+namespace w2l {
+
+// N <= 31 runs the DPP kernels; the probe library can put the previous generation back for A/B work (W2L_ASG_OLD=1)
+inline bool asg_dpp_path(int N) {
+  static const bool old = tune_env("W2L_ASG_OLD") != nullptr;
+  return N <= 31 && !old;
 }
 
 template <int NP>
@@ -52,9 +67,10 @@ __global__ __launch_bounds__(64) void fcc_fwd_small(int T, int N, int scaleMode,
                                                     const float* __restrict__ x,
                                                     const int* __restrict__ targetSize,
                                                     const float* __restrict__ trans,
-                                                    float* __restrict__ loss, FccWs ws) {
+                                                    float* __restrict__ loss, FccWs ws, const int* __restrict__ redo = nullptr) {
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
+  if (redo && !redo[b]) return;   // launched behind fcc_fwd_dpp: only the utterances it flagged
   const bool act = lane < N;
   const float NEG = -INFINITY;
 
@@ -134,9 +150,10 @@ __global__ __launch_bounds__(64) void fcc_fwd_small(int T, int N, int scaleMode,
 template <int NP>
 __global__ __launch_bounds__(64) void fcc_bwd_small(int T, int N, const float* __restrict__ trans,
                                                     const float* __restrict__ grad,
-                                                    float* __restrict__ inputGrad, FccWs ws) {
+                                                    float* __restrict__ inputGrad, FccWs ws, const int* __restrict__ redo = nullptr) {
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
+  if (redo && !redo[b]) return;
   const bool act = lane < N;
   const float NEG = -INFINITY;
 
@@ -223,10 +240,12 @@ __global__ __launch_bounds__(64) void fcc_bwd_small(int T, int N, const float* _
 
 // transition gradient of one (utterance, time chunk): part[i][j] = g * EA[i][j] * sum_{t in chunk} r_t[i] e_{t-1}[j]
 // lane = j; r_t (left in the log-s slots by the scan) is broadcast per i.  No dependence between steps.
-template <int NP>
+// LIN: the workspace of the DPP scans -- `ahat` holds u_t itself (scaled linear domain), r_t = b_t q_t.
+template <int NP, bool LIN = false>
 __global__ __launch_bounds__(64) void fcc_dtrans_small(int T, int N, const float* __restrict__ trans,
                                                        const float* __restrict__ grad, FccWs ws) {
   const int b = blockIdx.x, c = blockIdx.y;
+  const bool lin = LIN && !ws.redo[b];   // a flagged utterance ran on the log-domain kernels
   const int lane = threadIdx.x;
   const bool act = lane < N;
   const float* ahb = ws.ahat + (size_t)b * T * N;
@@ -240,7 +259,8 @@ __global__ __launch_bounds__(64) void fcc_dtrans_small(int T, int N, const float
   for (int i = 0; i < NP; ++i) acc[i] = 0.f;
   for (int t = t0; t < t1; ++t) {
     const float r = act ? rb[(size_t)t * N + lane] : 0.f;
-    const float e = act ? __expf(ahb[(size_t)(t - 1) * N + lane]) : 0.f;
+    const float ev = act ? ahb[(size_t)(t - 1) * N + lane] : 0.f;
+    const float e = lin ? ev : (act ? __expf(ev) : 0.f);
 #pragma unroll
     for (int i = 0; i < NP; ++i) acc[i] = fmaf(readlane(r, i), e, acc[i]);
   }
@@ -421,7 +441,7 @@ W2L_API size_t w2l_fcc_workspace_size(int B, int T, int N) {
   if (N > 64) return fcc_big_supported(B, T, N) ? fcc_big_workspace_size(B, T, N) : 0;
   size_t btn = align_up((size_t)B * T * N * sizeof(float), 256);
   return 3 * btn + align_up((size_t)B * sizeof(float), 256) +
-         align_up((size_t)B * kDtChunks * N * N * sizeof(float), 256);
+         align_up((size_t)B * kDtChunks * N * N * sizeof(float), 256) + align_up((size_t)B * sizeof(int), 256);
 }
 
 W2L_API int w2l_fcc_forward(int B, int T, int N, int scaleMode, const float* input,
@@ -435,7 +455,12 @@ W2L_API int w2l_fcc_forward(int B, int T, int N, int scaleMode, const float* inp
   }
   hipStream_t s = (hipStream_t)stream;
   FccWs ws = fcc_ws(workspace, B, T, N);
-  if (N <= 32)
+  if (asg_dpp_path(N)) {
+    hipLaunchKernelGGL(fcc_fwd_dpp, dim3(B), dim3(64), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws);
+    W2L_LAUNCH_CHECK();
+    // the log-domain kernel for the utterances fcc_fwd_dpp flagged (returns at once for the others)
+    hipLaunchKernelGGL(fcc_fwd_small<32>, dim3(B), dim3(64), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws, (const int*)ws.redo);
+  } else if (N <= 32)
     hipLaunchKernelGGL(fcc_fwd_small<32>, dim3(B), dim3(64), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws);
   else
     hipLaunchKernelGGL(fcc_fwd_small<64>, dim3(B), dim3(64), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws);
@@ -454,12 +479,19 @@ W2L_API int w2l_fcc_backward(int B, int T, int N, const float* trans, const floa
   }
   hipStream_t s = (hipStream_t)stream;
   FccWs ws = fcc_ws(workspace, B, T, N);
-  if (N <= 32)
+  const bool dpp = asg_dpp_path(N);
+  if (dpp) {
+    hipLaunchKernelGGL(fcc_bwd_dpp, dim3(B), dim3(64), 0, s, T, N, trans, grad, inputGrad, ws);
+    W2L_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fcc_bwd_small<32>, dim3(B), dim3(64), 0, s, T, N, trans, grad, inputGrad, ws, (const int*)ws.redo);
+  } else if (N <= 32)
     hipLaunchKernelGGL(fcc_bwd_small<32>, dim3(B), dim3(64), 0, s, T, N, trans, grad, inputGrad, ws);
   else
     hipLaunchKernelGGL(fcc_bwd_small<64>, dim3(B), dim3(64), 0, s, T, N, trans, grad, inputGrad, ws);
   W2L_LAUNCH_CHECK();
-  if (N <= 32)
+  if (dpp)
+    hipLaunchKernelGGL((fcc_dtrans_small<32, true>), dim3(B, kDtChunks), dim3(64), 0, s, T, N, trans, grad, ws);
+  else if (N <= 32)
     hipLaunchKernelGGL(fcc_dtrans_small<32>, dim3(B, kDtChunks), dim3(64), 0, s, T, N, trans, grad, ws);
   else
     hipLaunchKernelGGL(fcc_dtrans_small<64>, dim3(B, kDtChunks), dim3(64), 0, s, T, N, trans, grad, ws);
@@ -475,7 +507,8 @@ W2L_API int w2l_fcc_backward(int B, int T, int N, const float* trans, const floa
 W2L_API size_t w2l_viterbi_workspace_size(int B, int T, int N) {
   if (B <= 0 || T <= 0 || N <= 0) return 0;
   if (N > 64) return viterbi_big_supported(B, T, N) ? viterbi_big_workspace_size(B, T, N) : 0;
-  return align_up((size_t)B * T * N, 256);
+  // N <= 31: the delta rows [B][T][N] fp32 (vit_fwd_dpp -> vit_bt_k); else the back-pointer bytes of viterbi_small
+  return align_up((size_t)B * T * N * (N <= 31 ? sizeof(float) : 1), 256);
 }
 
 W2L_API int w2l_viterbi_compute(int B, int T, int N, const float* input, const float* trans,
@@ -486,7 +519,11 @@ W2L_API int w2l_viterbi_compute(int B, int T, int N, const float* input, const f
     return viterbi_big_compute(B, T, N, input, trans, path, workspace, (hipStream_t)stream);
   }
   hipStream_t s = (hipStream_t)stream;
-  if (N <= 32)
+  if (asg_dpp_path(N)) {
+    hipLaunchKernelGGL(vit_fwd_dpp, dim3(B), dim3(64), 0, s, T, N, input, trans, (float*)workspace);
+    W2L_LAUNCH_CHECK();
+    hipLaunchKernelGGL(vit_bt_k, dim3(B), dim3(256), 0, s, T, N, trans, (const float*)workspace, path);
+  } else if (N <= 32)
     hipLaunchKernelGGL(viterbi_small<32>, dim3(B), dim3(64), 0, s, T, N, input, trans, path, (unsigned char*)workspace);
   else
     hipLaunchKernelGGL(viterbi_small<64>, dim3(B), dim3(64), 0, s, T, N, input, trans, path, (unsigned char*)workspace);
