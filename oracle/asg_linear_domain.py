@@ -249,3 +249,20 @@ def fac_kernel_model(x, trans, target, S, P=5, R=4, D=600):
     if h[last] <= 0:
         return -np.inf, w1
     return (zsum + float(e[last // P])) / L2E + np.log(h[last]) - A[y[last], y[last]], w1
+
+
+FAC_SAFE_BITS = 160.0   # kFacSafeBits of csrc/criterion_fac_lin.hpp
+
+
+def fac_kernel_gain_bits(x, trans, target, S):
+    """what fac_fwd_lin measures to decide whether its per-lane exponents are exact for an utterance: the largest per-frame
+    spread of the label scores (x_t[n] + A[n][n]) log2 e plus the largest |log2 kappa| of the target; beyond FAC_SAFE_BITS the
+    utterance is flagged and the log-domain kernel recomputes it"""
+    x = np.asarray(x, np.float64)
+    A = np.asarray(trans, np.float64)
+    y = np.asarray(target[:S], np.int64)
+    L2E = 1.4426950408889634
+    z = ((x + np.diag(A)) * L2E).astype(np.float32)
+    spread = float((z.max(axis=1) - z.min(axis=1)).max())
+    kb = float(np.abs((A[y[1:], y[:-1]] - A[y[:-1], y[:-1]]).astype(np.float32)).max() * L2E) if S > 1 else 0.0
+    return spread + kb

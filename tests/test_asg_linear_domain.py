@@ -83,7 +83,8 @@ def test_fcc_kernel_model_lagged_scale(T, N, scale, tscale):
 
 @pytest.mark.parametrize("T,N,L,S,scale,P", [(40, 6, 8, 5, 1.0, 1), (500, 30, 100, 77, 1.0, 2), (2000, 30, 300, 300, 1.0, 5),
                                              (2000, 30, 300, 120, 8.0, 5), (300, 30, 300, 299, 2.0, 5), (64, 30, 40, 1, 1.0, 1),
-                                             (700, 30, 64, 64, 30.0, 1), (900, 30, 320, 310, 25.0, 5), (301, 30, 300, 298, 60.0, 5), (200, 30, 64, 64, 120.0, 1)])
+                                             (700, 30, 64, 64, 30.0, 1), (900, 30, 320, 310, 25.0, 5), (301, 30, 300, 298, 22.0, 5), (301, 30, 300, 300, 22.0, 5),
+                                             (304, 30, 300, 300, 20.0, 5), (200, 30, 64, 64, 22.0, 1)])
 def test_fac_kernel_model_lane_exponents(T, N, L, S, scale, P):
     """fp64 mantissas, one exponent per lane of P positions, renormalised every 4 frames through the decaying maximum scan:
     loss 1e-6 relative (the per-frame factors are fp32 exp2 values), stay weights within 1e-5 of the oracle's wherever the
@@ -107,3 +108,31 @@ def test_fac_kernel_model_lane_exponents(T, N, L, S, scale, P):
             adv = da - st
             da = st + np.concatenate((adv[1:], [0.0]))
     assert np.abs(occ - dx[0]).max() < 1e-4
+
+
+def test_fac_kernel_model_flags_what_it_cannot_hold():
+    """a tight alignment under emissions of scale 60 (frames that cost the forced path 400+ nats) is beyond one exponent per
+    lane of 5 positions: the model returns a WRONG finite loss there -- and the quantity the kernel measures (largest per-frame
+    spread + largest |log2 kappa|) is far above the bound at which it hands the utterance to the log-domain kernel; every case
+    below the bound is exact"""
+    x, A, tgt = _case(301, 30, 300, 298, 60.0, 301 + 298 + 7)
+    want = O.FAC(x, A, tgt).forward()[0]
+    got, _ = LD.fac_kernel_model(x[0], A, tgt[0], 298, P=5)
+    assert LD.fac_kernel_gain_bits(x[0], A, tgt[0], 298) > 2 * LD.FAC_SAFE_BITS
+    assert not np.isfinite(got) or abs(got - want) > 1e-3 * abs(want)
+    # 40 random utterances at the bound (tight, loose, 1 / 2 / 5 positions per lane): all exact
+    rng0 = np.random.default_rng(5)
+    for it in range(40):
+        S = int(rng0.integers(1, 320))
+        T = max(2, S + int(rng0.choice([0, 1, 2, 3, 5, 8, 20, 60, 300])))
+        P = 5 if S > 128 else int(rng0.choice([1, 2, 5])) if S <= 64 else int(rng0.choice([2, 5]))
+        rng = np.random.default_rng(1000 + it)
+        x = (rng.normal(size=(1, T, 30)) * float(rng0.choice([1, 5, 15, 19]))).astype(np.float32)
+        A = (rng.normal(size=(30, 30)) * float(rng0.choice([0.1, 1.0, 3.0])) + np.eye(30) * 4).astype(np.float32)
+        tgt = np.full((1, 320), -1, np.int32)
+        tgt[0, :S] = rng.integers(0, 30, S)
+        if LD.fac_kernel_gain_bits(x[0], A, tgt[0], S) > LD.FAC_SAFE_BITS:
+            continue
+        want = O.FAC(x, A, tgt).forward()[0]
+        got, _ = LD.fac_kernel_model(x[0], A, tgt[0], S, P=P)
+        assert np.isfinite(got) and abs(got - want) < 1e-6 * max(1.0, abs(want)) + 1e-7 * T, (it, T, S, P, got, want)   # (the factors are fp32 exp2 values: the error grows with T, not with the loss)
