@@ -39,7 +39,13 @@ def pmc_traffic(key, fallback=None):
     (profiles/*_pmc_traffic.json, written by tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE passes over this same bench command; gfx950 corrections applied there).  None if absent."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    import re
+
+    def order(p):   # r<round>_run<n>_...: the newest counter summary of the newest round (NOT alphabetical: run17 > run9)
+        m = re.match(r"r(\d+)_run(\d+)_", os.path.basename(p))
+        return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+    files = sorted(set(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")) +
+                       glob.glob(os.path.join(ROOT, "profiles", "*_pmc_headline*.json"))), key=order)
     if not files:
         return None, None
     try:

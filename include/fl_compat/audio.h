@@ -74,7 +74,7 @@ inline Sound loadSound(const std::string& path) {
     size_t off = 12;
     while (off + 8 <= d.size()) {
       const uint32_t len = le(off + 4, 4);
-      if (memcmp(d.data() + off, "fmt ", 4) == 0 && len >= 16) {
+      if (memcmp(d.data() + off, "fmt ", 4) == 0 && len >= 16 && off + 24 <= d.size()) {   // (a truncated header must not be read past the file)
         fmt = (int)le(off + 8, 2); ch = (int)le(off + 10, 2); out.rate = (int)le(off + 12, 4); bits = (int)le(off + 22, 2);
       } else if (memcmp(d.data() + off, "data", 4) == 0) {
         if (fmt != 1 || ch < 1 || (bits != 8 && bits != 16 && bits != 24 && bits != 32)) throw std::runtime_error(path + ": unsupported WAV encoding (PCM 8/16/24/32 only)");

@@ -348,7 +348,9 @@ namespace speech {
 enum class CriterionScaleMode { NONE = 0, INPUT_SZ = 1, INPUT_SZ_SQRT = 2, TARGET_SZ = 3, TARGET_SZ_SQRT = 4 };
 FL_COMPAT_API CriterionScaleMode getCriterionScaleMode(const std::string& onorm, bool sqnorm);
 
-// arch file -> network.  forward({features (T, NFEAT, 1, B) f32 [, inputSizes]}) -> {emissions (NLABEL, T', B)}
+// arch file -> network.  forward({features (T, NFEAT, 1, B) f32 [, inputSizes (1, B)]}) -> {emissions (NLABEL, T', B)}
+// (inputSizes may carry one more entry, (1, B + 1): the size the T frames correspond to when the batch is padded beyond its
+// longest utterance -- the denominator of the Transformer padding mask; the reference pads to the longest only)
 FL_COMPAT_API std::shared_ptr<fl::Sequential> buildSequentialModule(const std::string& archfile, int64_t nFeatures, int64_t nClasses);
 FL_COMPAT_API std::shared_ptr<fl::Sequential> buildSequentialModuleFromText(const std::string& archText, int64_t nFeatures, int64_t nClasses);
 
@@ -367,8 +369,10 @@ class FL_COMPAT_API SequenceCriterion : public fl::Container {
 struct FlatView { float* ptr; size_t floats; };
 FL_COMPAT_API FlatView flatParameters(const std::shared_ptr<fl::Module>& network);
 FL_COMPAT_API FlatView flatGradients(const std::shared_ptr<fl::Module>& network);
-// --fl_amp_use_mixed_precision, restated for bf16: the fl::Linear GEMMs of a network built from an arch file multiply in
-// bf16 with fp32 accumulation; storage, master weights and the criterion stay fp32 (no-op for any other module)
+// --fl_amp_use_mixed_precision, restated for bf16: in a network built from an arch file every fl::Linear product, the TDS and
+// sub-sampling convolutions and the attention products (scores, position term, P V and their gradients) multiply bf16 operand
+// images with fp32 accumulation; activations, master weights, LayerNorm, the optimizer and the criterion stay fp32 (no-op for
+// any other module)
 FL_COMPAT_API void setMixedPrecision(const std::shared_ptr<fl::Module>& network, bool on);
 // fl_compat extension: forwards so far of a network built from an arch file = the position of its dropout-seed stream
 // (restored by Serializer::load; `Train fork` starts it from zero)

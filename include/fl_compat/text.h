@@ -65,7 +65,8 @@ class Dictionary {
 using LexiconMap = std::unordered_map<std::string, std::vector<std::vector<std::string>>>;
 
 // maxWords: the reference's second argument (loadWords(FLAGS_lexicon, FLAGS_maxword), e.g. recipes/slimIPL/src/Train.cpp): at most
-// that many distinct WORDS are kept (-1: all); every spelling line of a kept word is kept, duplicates included, in file order
+// that many distinct WORDS are kept (-1: all); reading STOPS at the first new word beyond the limit, as the reference's loop does
+// (spellings of kept words further down the file are not collected)
 inline LexiconMap loadWordsFromLines(const std::vector<std::string>& lines, int maxWords = -1) {
   LexiconMap lex;
   for (auto& line : lines) {
@@ -75,7 +76,7 @@ inline LexiconMap loadWordsFromLines(const std::vector<std::string>& lines, int 
     std::vector<std::string> sp;
     while (ss >> tok) sp.push_back(tok);
     if (sp.empty()) continue;
-    if (lex.find(word) == lex.end() && maxWords >= 0 && (int)lex.size() >= maxWords) continue;
+    if (lex.find(word) == lex.end() && maxWords >= 0 && (int)lex.size() >= maxWords) break;
     lex[word].push_back(sp);
   }
   return lex;

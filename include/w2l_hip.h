@@ -317,6 +317,10 @@ int w2l_attn_fused_forward(const w2l_attn_fused_desc* d, const float* q, const f
 /* valid keys per utterance from the batch's input sizes (any unit), as forwardSequentialModuleWithPadMask builds the mask
  * (cpc/SequentialBuilder.cpp:58-81): n_b = ceil(size_b * Tin / max size) valid input frames, resized to Tk (nearest) */
 int w2l_attn_key_lengths(const float* inputSizes, int B, int Tin, int Tk, int* keyLen, w2l_stream_t stream);
+/* the same for a batch padded BEYOND its longest utterance: *fullSize (device scalar, same unit; NULL = the call above) is the
+ * size the Tin input frames correspond to and replaces max size as the denominator */
+int w2l_attn_key_lengths_full(const float* inputSizes, const float* fullSize, int B, int Tin, int Tk, int* keyLen,
+                              w2l_stream_t stream);
 /* dS (in: dL/dP) -> dL/dS (pre-scale scores) in place; dR (may be NULL) receives the skewed copy, zeros elsewhere */
 int w2l_attn_softmax_backward(const float* P, float* dS, float* dR, int B, int H, int T, int ldr, int rlo, int W, int n0,
                               float scale, w2l_stream_t stream);

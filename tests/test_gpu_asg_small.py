@@ -139,7 +139,7 @@ def test_viterbi_dpp_bit_exact_edges(oracle, N, T):
     assert (crit.viterbiPath(dev(xb)).cpu().numpy() == oracle.viterbi(xb, A)).all()
 
 
-@pytest.mark.parametrize("B,T,N,L,scale", [(2, 40, 30, 12, 60.0), (2, 25, 9998, 20, 40.0), (2, 300, 29, 140, 80.0)])
+@pytest.mark.parametrize("B,T,N,L,scale", [(2, 40, 30, 12, 60.0), (2, 25, 9998, 20, 40.0), (2, 300, 29, 140, 40.0)])
 def test_ctc_wide_logit_gaps(oracle, B, T, N, L, scale):
     """labels 100+ nats below the frame's normaliser (round-3 advice): the scans multiply by exp(lp) as an fp64 value built from
     an integer / fraction split, so a confident-wrong frame keeps a finite probability; one utterance has T' == number of
@@ -177,7 +177,7 @@ def test_asg_generations_agree_and_timing():
 import os, sys, json, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 from wav2letter_amd import _lib
-_lib.use_probe()
+_lib.use_probe().__enter__()
 from wav2letter_amd import ASGLoss, CriterionScaleMode
 B, T, N, L = 64, 2000, 30, 300
 g = torch.Generator(device="cpu").manual_seed(4)
@@ -222,3 +222,46 @@ print("RESULT" + json.dumps(out))
     assert np.abs(np.array(n["dx"]) - np.array(o["dx"])).max() < 1e-4 * np.abs(np.array(o["dx"])).max()
     assert np.abs(np.array(n["dA"]) - np.array(o["dA"])).max() < 1e-4 * np.abs(np.array(o["dA"])).max()
     assert n["path"] == o["path"]
+
+
+_VARIANT_CODE = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+from wav2letter_amd import _lib
+_lib.use_probe().__enter__()
+from oracle import pyoracle as O
+from wav2letter_amd import ForceAlignmentCriterion, FullConnectionCriterion
+from test_gpu_criterion import dev, gradrel, make_targets, relerr
+for (B, T, N, L, xs) in [(3, 33, 30, 12, 1.5), (2, 700, 30, 300, 1.0), (2, 301, 29, 300, 6.0), (2, 257, 17, 130, 2.0), (2, 1, 5, 1, 1.0)]:
+    rng = np.random.default_rng(T + L)
+    x = (rng.normal(size=(B, T, N)) * xs).astype(np.float32)
+    A = rng.normal(size=(N, N)).astype(np.float32)
+    tgt = make_targets(rng, B, L, N, T, min_len=max(1, min(L, T) - 3))
+    w = rng.normal(size=B).astype(np.float32)
+    for cls, orc in ((FullConnectionCriterion, None), (ForceAlignmentCriterion, None)):
+        crit = cls(N, 4).cuda(); crit.transitions.data = dev(A)
+        xt = dev(x).requires_grad_(True)
+        loss = crit(xt, dev(tgt)); (loss * dev(w)).sum().backward()
+        o = O.FCC(x, A, O.batch_target_size(tgt, T), 4) if cls is FullConnectionCriterion else O.FAC(x, A, tgt, scale_mode=4)
+        ol = o.forward(); odx, odA = o.backward(w.astype(np.float64))
+        assert relerr(loss.detach().cpu().numpy(), ol) < 1e-4, (cls.__name__, T, L)
+        assert gradrel(xt.grad.cpu().numpy(), odx) < 1e-4, (cls.__name__, T, L)
+        if T > 1: assert gradrel(crit.transitions.grad.cpu().numpy(), odA) < 1e-4, (cls.__name__, T, L)
+print("VARIANT OK")
+'''
+
+
+@pytest.mark.parametrize("env", [{"W2L_FCC_1WAVE": "1"}, {"W2L_FAC_GEN": "wave", "W2L_FAC_BWD": "wave"}, {"W2L_FAC_GEN": "blin", "W2L_FAC_BWD": "blk51"},
+                                 {"W2L_FAC_GEN": "blin2", "W2L_FAC_BWD": "blk42"}, {"W2L_ASG_OLD": "1"}])
+def test_asg_kernel_variants_of_the_probe_library(env):
+    """the kernel generations the product does not run stay selectable in the probe library (A/B work) and stay correct: the
+    one-wave FCC scans, the one-wave FAC scans (with their hand-over to the log-domain kernel), the barrier-per-frame FAC scans (rows by a sixth wave / from the pre-pass; backward 5 x 1 and 4 x 2),
+    the round-3 log-domain kernels"""
+    import os
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env)
+    p = subprocess.run([sys.executable, "-c", _VARIANT_CODE], env=e, capture_output=True, text=True, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert p.returncode == 0 and "VARIANT OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])

@@ -140,6 +140,7 @@ class _SIGS:
     w2l_attn_softmax_forward = (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p])
     w2l_attn_fused_forward = (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p])
     w2l_attn_key_lengths = (_i, [_p, _i, _i, _i, _p, _p])
+    w2l_attn_key_lengths_full = (_i, [_p, _p, _i, _i, _i, _p, _p])
     w2l_attn_softmax_backward = (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p])
     w2l_pool_time_forward = (_i, [_p, _p, _i, _i, _i, _i, _i, _p])
     w2l_pool_time_backward = (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p])

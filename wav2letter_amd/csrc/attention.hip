@@ -346,11 +346,16 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_k(SmP p) {
 // and TransformerCPC.cpp:138-144): valid input frames  n_b = ceil(inputSizes[b] * Tin / max(inputSizes)),  mask[t][b] = t < n_b on
 // the Tin input frames, resized to the block's Tk frames (af::resize, nearest: source index round(j * Tin / Tk), clamped) and added
 // to the scores as log(mask).  The mask is monotone, so it is kept as the count of valid keys per utterance.
-__global__ void attn_key_len_k(const float* __restrict__ sizes, int B, int Tin, int Tk, int* __restrict__ keyLen) {
+// `full` (device scalar, may be null): the size the Tin input frames correspond to when the batch is padded BEYOND its longest
+// utterance (a caller that rounds T up for the sake of few distinct plans); the reference pads to the longest only, where the
+// denominator is max(sizes).
+__global__ void attn_key_len_k(const float* __restrict__ sizes, const float* __restrict__ full, int B, int Tin, int Tk,
+                               int* __restrict__ keyLen) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   float mx = sizes[0];
   for (int q = 1; q < B; ++q) mx = fmaxf(mx, sizes[q]);
+  if (full) mx = fmaxf(mx, *full);
   const float nb = ceilf(sizes[b] * (float)Tin / mx);
   const float xf = (float)Tin / (float)Tk;
   int n = 0;
@@ -470,9 +475,17 @@ static int sm_params(SmP& p, int B, int H, int T, int ldr, int rlo, int W, int n
   return W2L_OK;
 }
 
+W2L_API int w2l_attn_key_lengths_full(const float* inputSizes, const float* fullSize, int B, int Tin, int Tk, int* keyLen,
+                                      w2l_stream_t stream) {
+  if (!inputSizes || !keyLen || B <= 0 || Tin <= 0 || Tk <= 0) return W2L_EINVAL;
+  hipLaunchKernelGGL(attn_key_len_k, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, W2L_S, inputSizes, fullSize, B, Tin, Tk, keyLen);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
 W2L_API int w2l_attn_key_lengths(const float* inputSizes, int B, int Tin, int Tk, int* keyLen, w2l_stream_t stream) {
   if (!inputSizes || !keyLen || B <= 0 || Tin <= 0 || Tk <= 0) return W2L_EINVAL;
-  hipLaunchKernelGGL(attn_key_len_k, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, W2L_S, inputSizes, B, Tin, Tk, keyLen);
+  hipLaunchKernelGGL(attn_key_len_k, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, W2L_S, inputSizes, (const float*)nullptr, B, Tin, Tk, keyLen);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }

@@ -30,9 +30,10 @@
 // gradient E .* sum_t r_t u_{t-1}^T by the parallel kernel fcc_dtrans_small<.., true>.
 // Viterbi: the same rotations with (+, max): 16 v_add_f32_dpp + 8 v_max3_f32 per frame.  Only delta is on the chain; the
 // back-pointers psi_t[i] = first argmax_j(delta_{t-1}[j] + A[i][j]) -- same fp32 sums, first maximum wins, as the oracle's
-// strict '>' scan -- are recomputed from the stored delta rows by the parallel kernel vit_bt_k, which also walks the path.
+// strict '>' scan -- are recomputed from the stored delta rows by the parallel kernel vit_psi_k and walked by vit_walk_k.
 #pragma once
 #include "common.hpp"
+#include <type_traits>
 
 namespace w2l {
 
@@ -399,6 +400,309 @@ __global__ __launch_bounds__(64) void fcc_bwd_dpp(int T, int N, const float* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------------ FCC, two waves per utterance
+// tools/micro/clock_probe.hip (profiles/r04_run3_clock_probe.log): a wave alone on its SIMD issues one VALU instruction every
+// ~6.5 cycles, dependent or not -- a frame of a one-wave scan costs (instructions it issues) x 6.5 cycles, and fcc_fwd_dpp above
+// issues ~67 per frame of which only ~25 are the dependency chain (0.46 ms at T = 2000).  So the utterance gets a SECOND wave on
+// another SIMD of the same CU for everything that is not the chain:
+//   wave 0 (chain):  q = ldexp(P_t, -k_t) ; u = combine(dpp_dot16(u, E)) * q ; scale bookkeeping ; u, q -> LDS
+//   wave 1 (helper): P_t = 2^(zz_t - max zz_t) of the NEXT chunk of 16 frames -> LDS (emission loads, the wave maxima, exp2,
+//                    the fp64 sum of the maxima) and the PREVIOUS chunk's u, q from LDS -> workspace
+// one s_barrier per chunk of 16 frames (double-buffered LDS rings).  The backward scan splits the same way.
+struct FccPair { float u, q; };
+
+__global__ __launch_bounds__(128) void fcc_fwd_dpp2(int T, int N, int scaleMode, const float* __restrict__ x,
+                                                    const int* __restrict__ targetSize, const float* __restrict__ trans,
+                                                    float* __restrict__ loss, FccWs ws) {
+  __shared__ float sP[2][kDppChunk][64];
+  __shared__ float sU[2][kDppChunk][2][64];   // [.][.][0] = u_t, [1] = q_t (one ds_write2_b32)
+  __shared__ double sC2;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const bool chain = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+  const DppGeom g = dpp_geom(lane);
+  const float NEG = -INFINITY;
+  const bool actG = g.sG < N, actH = g.sH < N;
+
+  // rowmax of the two rows of A this lane works with; the spread of row sG for the range check (both waves compute it: uniform)
+  float rmG = NEG, rmH = NEG, rnG = INFINITY;
+  bool nanRow = false;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const float aG = (g.sG < N && j < N) ? trans[(size_t)g.sG * N + j] : NEG;
+    const float aH = (g.sH < N && j < N) ? trans[(size_t)g.sH * N + j] : NEG;
+    rmG = fmaxf(rmG, aG);
+    rmH = fmaxf(rmH, aH);
+    if (g.sG < N && j < N) { rnG = fminf(rnG, aG); nanRow = nanRow || aG != aG; }
+  }
+  {
+    const float sp = wave_max(g.sG < N ? rmG - rnG : 0.f);
+    const bool risky = __any(nanRow) || !(sp <= kFccSafeSpread);
+    if (tid == 0) ws.redo[b] = risky ? 1 : 0;
+    if (risky) return;   // fcc_fwd_small, launched behind this kernel, computes the utterance (both waves leave: no barrier yet)
+  }
+  const float* xb = x + (size_t)b * T * N;
+
+  if (!chain) {
+    // ---------------------------------------------------------------- helper wave
+    const float rmlG = actG ? rmG * kLog2e : 0.f, rmlH = actH ? rmH * kLog2e : 0.f;
+    float* ub = ws.ahat + (size_t)b * T * N;
+    float* qb = ws.logs + (size_t)b * T * N;
+    float xc[kDppChunk], xn[kDppChunk];
+#pragma unroll
+    for (int s = 0; s < kDppChunk; ++s) {
+      const bool odd = s & 1;
+      xc[s] = ((odd ? actG : actH) && s < T) ? xb[(size_t)s * N + (odd ? g.sG : g.sH)] : 0.f;
+    }
+    double C2 = 0.0;
+    auto produce = [&](const float (&xv)[kDppChunk], int t0, int buf) {   // P of frames t0 .. t0 + 15 -> sP[buf]
+#pragma unroll
+      for (int s = 0; s < kDppChunk; ++s) {
+        const int t = t0 + s;
+        const bool odd = s & 1;
+        const bool act = odd ? actG : actH;
+        const float rml = t == 0 ? 0.f : (odd ? rmlG : rmlH);
+        const float zz = act ? fmaf(xv[s], kLog2e, rml) : NEG;
+        const float mz = odd ? dpp_state_max<true>(zz) : dpp_state_max<false>(zz);
+        sP[buf][s][lane] = act ? __builtin_amdgcn_exp2f(zz - mz) : 0.f;
+        if (t < T) C2 += (double)mz;
+      }
+    };
+    auto flush = [&](int t0, int buf) {   // u, q of frames t0 .. t0 + 15: LDS -> workspace
+#pragma unroll
+      for (int s = 0; s < kDppChunk; ++s) {
+        const int t = t0 + s;
+        const bool odd = s & 1;
+        const bool st = odd ? (g.primG && actG) : (g.primH && actH);
+        const int sx = odd ? g.sG : g.sH;
+        const float uv = sU[buf][s][0][lane], qv = sU[buf][s][1][lane];
+        if (st && t < T) {
+          ub[(size_t)t * N + sx] = uv;
+          qb[(size_t)t * N + sx] = qv;
+        }
+      }
+    };
+    produce(xc, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int c = 0;
+    for (int t0 = 0; t0 < T; t0 += kDppChunk, ++c) {
+#pragma unroll
+      for (int s = 0; s < kDppChunk; ++s) {
+        const int tn = t0 + 2 * kDppChunk + s;
+        const bool odd = s & 1;
+        xn[s] = ((odd ? actG : actH) && tn < T) ? xb[(size_t)tn * N + (odd ? g.sG : g.sH)] : 0.f;
+      }
+      // (xc holds chunk c + 1 from the second iteration on: shift below)
+      if (c == 0) {
+#pragma unroll
+        for (int s = 0; s < kDppChunk; ++s) {
+          const int tn = kDppChunk + s;
+          const bool odd = s & 1;
+          xc[s] = ((odd ? actG : actH) && tn < T) ? xb[(size_t)tn * N + (odd ? g.sG : g.sH)] : 0.f;
+        }
+      }
+      if (t0 + kDppChunk < T) produce(xc, t0 + kDppChunk, (c + 1) & 1);
+      if (c >= 1) flush(t0 - kDppChunk, (c - 1) & 1);
+#pragma unroll
+      for (int s = 0; s < kDppChunk; ++s) asm volatile("" : "+v"(xn[s]));
+#pragma unroll
+      for (int s = 0; s < kDppChunk; ++s) xc[s] = xn[s];
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    flush((c - 1) * kDppChunk, (c - 1) & 1);
+    if (lane == 0) sC2 = C2;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    return;
+  }
+
+  // ------------------------------------------------------------------ chain wave
+  float EA[16], EB[16];
+  dpp_tables(lane, g, [&](int i, int j) -> float {
+    if (j >= N) return 0.f;
+    if (i == 31) return 1.f;                       // row 31: the total mass sum_j u[j]
+    if (i >= N) return 0.f;
+    const float rm = (i == g.sG) ? rmG : rmH;
+    return __expf(trans[(size_t)i * N + j] - rm);
+  }, EA, EB);
+  float u = 0.f;
+  int ksum = 0, k = 0;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // P of chunk 0 is in sP[0]
+  int c = 0;
+  for (int t0 = 0; t0 < T; t0 += kDppChunk, ++c) {
+    const int buf = c & 1;
+    float Pc[kDppChunk];
+#pragma unroll
+    for (int s = 0; s < kDppChunk; ++s) Pc[s] = sP[buf][s][lane];
+    auto frames = [&](auto full) {   // full: every frame of the chunk exists -- no per-frame bound check in the instruction stream
+#pragma unroll
+      for (int s = 0; s < kDppChunk; ++s) {
+        const int t = t0 + s;
+        if (decltype(full)::value || t < T) {   // wave-uniform
+          float q = 0.f;
+          if (t == 0) {
+            u = Pc[s];
+          } else {
+            const bool odd = s & 1;
+            q = ldexp_f32(Pc[s], -k);
+            float sv;
+            if (odd) sv = comb_add32(dpp_dot16(u, EA));   // H -> G
+            else sv = comb_add16(dpp_dot16(u, EB));       // G -> H
+            u = sv * q;
+            const float mass = readlane(sv, 63);          // row 31 of the product (lane 63 holds state 31 in both arrangements)
+            const int e = (int)((__float_as_uint(mass) >> 23) & 0xffu) - 127;
+            ksum += k;
+            int kn = e - k;
+            kn = kn < -kFccKClamp ? -kFccKClamp : (kn > kFccKClamp ? kFccKClamp : kn);
+            k = __builtin_amdgcn_readfirstlane(kn);       // (uniform: keep the bookkeeping on the scalar unit)
+          }
+          sU[buf][s][0][lane] = u;
+          sU[buf][s][1][lane] = q;
+        }
+      }
+    };
+    if (t0 + kDppChunk <= T) frames(std::true_type{});
+    else frames(std::false_type{});
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  const bool lastOdd = (T - 1) & 1;
+  const bool prim = lastOdd ? (g.primG && actG) : (g.primH && actH);
+  const float tot = wave_sum(prim ? u : 0.f);
+  const float sc = scale_of(scaleMode, T, targetSize[b]);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the helper's sum of the frame maxima is in sC2
+  if (lane == 0) {
+    const double l = (double)sc * ((sC2 + (double)ksum) * 0.69314718055994530942 + (double)__logf(tot));
+    loss[b] = g.ok ? (float)l : __builtin_nanf("");
+    ws.scale[b] = sc;
+  }
+}
+
+__global__ __launch_bounds__(128) void fcc_bwd_dpp2(int T, int N, const float* __restrict__ trans, const float* __restrict__ grad,
+                                                    float* __restrict__ inputGrad, FccWs ws) {
+  __shared__ float sQ[2][kDppChunk][64];   // q_t of the chunk the chain wave works on (helper -> chain)
+  __shared__ float sB[2][kDppChunk][64];   // b_t before the frame's step (chain -> helper)
+  __shared__ float sRm[32];
+  __shared__ float sTot;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  if (ws.redo[b]) return;   // this utterance ran (and will be differentiated) on the log-domain kernels
+  const bool chain = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+  const DppGeom g = dpp_geom(lane);
+  const float NEG = -INFINITY;
+  const bool actG = g.sG < N, actH = g.sH < N;
+  const float* __restrict__ ub = ws.ahat + (size_t)b * T * N;
+  const float* __restrict__ qb = ws.logs + (size_t)b * T * N;
+  const int par = (T - 1) & 1;   // frame t = thi - s is held in arrangement G when t is odd: odd(s) = (s & 1) != par
+  if (tid < 32) {
+    float rm = NEG;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) rm = fmaxf(rm, (tid < N && j < N) ? trans[(size_t)tid * N + j] : NEG);
+    sRm[tid] = rm;
+  }
+  if (tid == 64) sTot = 0.f;
+  __syncthreads();
+
+  if (!chain) {
+    // ---------------------------------------------------------------- helper wave: loads u, q; q -> LDS; dx, r from the chain's b
+    float* __restrict__ rb = ws.r + (size_t)b * T * N;
+    float* __restrict__ dxb = inputGrad + (size_t)b * T * N;
+    const float gsc = ws.scale[b] * grad[b];
+    float uc[kDppChunk], qc[kDppChunk], un[kDppChunk], qn[kDppChunk];
+    auto fetch = [&](float (&uv)[kDppChunk], float (&qv)[kDppChunk], int thi) {
+#pragma unroll
+      for (int s = 0; s < kDppChunk; ++s) {
+        const int t = thi - s;
+        const bool odd = (s & 1) != par;
+        const bool act = odd ? actG : actH;
+        const int st = odd ? g.sG : g.sH;
+        uv[s] = (act && t >= 0) ? ub[(size_t)t * N + st] : 0.f;
+        qv[s] = (act && t >= 1) ? qb[(size_t)t * N + st] : 0.f;
+      }
+    };
+    fetch(uc, qc, T - 1);
+    {   // sum_j u_{T-1}[j] for b_{T-1}
+      const bool prim = par ? (g.primG && actG) : (g.primH && actH);
+      const float tot = wave_sum(prim ? uc[0] : 0.f);
+      if (lane == 0) sTot = tot;
+    }
+#pragma unroll
+    for (int s = 0; s < kDppChunk; ++s) sQ[0][s][lane] = qc[s];
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int c = 0;
+    float up[kDppChunk], qp[kDppChunk];   // the chunk the chain wave has just finished (its b values are in sB[(c - 1) & 1])
+    for (int thi = T - 1; thi >= 0; thi -= kDppChunk, ++c) {
+      fetch(un, qn, thi - kDppChunk);
+#pragma unroll
+      for (int s = 0; s < kDppChunk; ++s) sQ[(c + 1) & 1][s][lane] = qn[s];
+      if (c >= 1) {
+        const int th = thi + kDppChunk;
+#pragma unroll
+        for (int s = 0; s < kDppChunk; ++s) {
+          const int t = th - s;
+          const bool odd = (s & 1) != par;
+          const bool st = odd ? (g.primG && actG) : (g.primH && actH);
+          const int sx = odd ? g.sG : g.sH;
+          const float bv = sB[(c - 1) & 1][s][lane];
+          if (st && t >= 0) {
+            dxb[(size_t)t * N + sx] = g.ok ? gsc * (up[s] * bv) : __builtin_nanf("");
+            if (t >= 1) rb[(size_t)t * N + sx] = bv * qp[s];
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < kDppChunk; ++s) { up[s] = uc[s]; qp[s] = qc[s]; uc[s] = un[s]; qc[s] = qn[s]; }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    {   // the last chunk
+      const int th = T - 1 - (c - 1) * kDppChunk;
+#pragma unroll
+      for (int s = 0; s < kDppChunk; ++s) {
+        const int t = th - s;
+        const bool odd = (s & 1) != par;
+        const bool st = odd ? (g.primG && actG) : (g.primH && actH);
+        const int sx = odd ? g.sG : g.sH;
+        const float bv = sB[(c - 1) & 1][s][lane];
+        if (st && t >= 0) {
+          dxb[(size_t)t * N + sx] = g.ok ? gsc * (up[s] * bv) : __builtin_nanf("");
+          if (t >= 1) rb[(size_t)t * N + sx] = bv * qp[s];
+        }
+      }
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------ chain wave: b_{t-1} = E^T (b_t q_t)
+  float EA[16], EB[16];
+  dpp_tables(lane, g, [&](int j, int i) -> float {   // produces b[j] from r[i]
+    if (i >= N || j >= N) return 0.f;
+    return __expf(trans[(size_t)i * N + j] - sRm[i]);
+  }, EA, EB);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // q of the first chunk and sTot are there
+  float bv = (par ? actG : actH) ? 1.f / sTot : 0.f;
+  int c = 0;
+  for (int thi = T - 1; thi >= 0; thi -= kDppChunk, ++c) {
+    const int buf = c & 1;
+    float qv[kDppChunk];
+#pragma unroll
+    for (int s = 0; s < kDppChunk; ++s) qv[s] = sQ[buf][s][lane];
+    auto frames = [&](auto full) {   // full: the chunk does not reach frame 0 -- no per-frame checks
+#pragma unroll
+      for (int s = 0; s < kDppChunk; ++s) {
+        const int t = thi - s;
+        if (decltype(full)::value || t >= 0) {   // wave-uniform
+          sB[buf][s][lane] = bv;
+          if (decltype(full)::value || t >= 1) {
+            const float r = bv * qv[s];
+            // frame t in G (t odd) -> frame t - 1 in H through step B; H -> G through step A.  par is uniform: two unrolled bodies
+            if (((s & 1) != 0) != (par != 0)) bv = comb_add16(dpp_dot16(r, EB));
+            else bv = comb_add32(dpp_dot16(r, EA));
+          }
+        }
+      }
+    };
+    if (thi - kDppChunk >= 0) frames(std::true_type{});
+    else frames(std::false_type{});
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ Viterbi
 struct VitDppWs {
   float* delta;         // [B][T][N]
@@ -424,6 +728,8 @@ __global__ __launch_bounds__(64) void vit_fwd_dpp(int T, int N, const float* __r
     const int st = odd ? g.sG : g.sH;
     xc[s] = (act && s < T) ? xb[(size_t)s * N + st] : 0.f;
   }
+#pragma unroll
+  for (int s = 0; s < kDppChunk; ++s) asm volatile("" : "+v"(xc[s]));   // landed before the loop: no pending load at its head
   float d = NEG;
   for (int t0 = 0; t0 < T; t0 += kDppChunk) {
 #pragma unroll
@@ -435,24 +741,33 @@ __global__ __launch_bounds__(64) void vit_fwd_dpp(int T, int N, const float* __r
       xn[s] = (act && tn < T) ? xb[(size_t)tn * N + st] : 0.f;
     }
     float ds[kDppChunk];
+    auto frames = [&](auto full) {
 #pragma unroll
-    for (int s = 0; s < kDppChunk; ++s) {
-      const int t = t0 + s;
-      ds[s] = NEG;
-      if (t < T) {
-        const bool odd = s & 1;
-        const bool act = odd ? actG : actH;
-        if (t == 0) {
-          d = act ? xc[s] : NEG;
-        } else {
-          float best;
-          if (odd) best = comb_max32(dpp_maxplus16(d, AA));
-          else best = comb_max16(dpp_maxplus16(d, AB));
-          d = act ? best + xc[s] : NEG;
+      for (int s = 0; s < kDppChunk; ++s) {
+        const int t = t0 + s;
+        ds[s] = NEG;
+        if (decltype(full)::value || t < T) {
+          const bool odd = s & 1;
+          const bool act = odd ? actG : actH;
+          if (t == 0) {
+            d = act ? xc[s] : NEG;
+          } else {
+            float best;
+            if (odd) best = comb_max32(dpp_maxplus16(d, AA));
+            else best = comb_max16(dpp_maxplus16(d, AB));
+            d = act ? best + xc[s] : NEG;
+          }
+          ds[s] = d;
         }
-        ds[s] = d;
       }
-    }
+    };
+    if (t0 + kDppChunk <= T) frames(std::true_type{});
+    else frames(std::false_type{});
+    // the prefetched chunk is consumed BEFORE the frames' stores are issued: hipcc waits vmcnt(0) at the first use of a loaded
+    // register when stores may have been issued behind the load (the counter is shared and in order), i.e. a store round trip
+    // per chunk if the stores come first -- this way the loads have had the whole chunk to land and the stores drain meanwhile
+#pragma unroll
+    for (int s = 0; s < kDppChunk; ++s) asm volatile("" : "+v"(xn[s]));
 #pragma unroll
     for (int s = 0; s < kDppChunk; ++s) {
       const int t = t0 + s;
@@ -462,71 +777,122 @@ __global__ __launch_bounds__(64) void vit_fwd_dpp(int T, int N, const float* __r
       if (st && t < T) db[(size_t)t * N + sx] = g.ok ? ds[s] : __builtin_nanf("");
     }
 #pragma unroll
-    for (int s = 0; s < kDppChunk; ++s) asm volatile("" : "+v"(xn[s]));
-#pragma unroll
     for (int s = 0; s < kDppChunk; ++s) xc[s] = xn[s];
   }
 }
 
-// back-pointers from the stored delta rows + the walk.  One workgroup per utterance, chunks of kVbChunk frames from the end:
-// psi_t[i] = first j maximising delta_{t-1}[j] + A[i][j] (fp32 sums, strict '>' upwards in j: the oracle's scan), then lane 0
-// follows the path through the chunk.
-constexpr int kVbChunk = 128;
-__global__ __launch_bounds__(256) void vit_bt_k(int T, int N, const float* __restrict__ trans, const float* __restrict__ deltaAll,
-                                                int* __restrict__ path) {
+// back-pointers from the stored delta rows + the walk, in two parallel kernels (a frame of a serial walk is a dependent LDS
+// read: 2000 of them cost more than the whole scan -- vit_bt_k of the first version, 520 us at T = 2000):
+//   vit_psi_k   grid (chunks of kVpChunk frames, B): psi_t[i] = first j maximising delta_{t-1}[j] + A[i][j] (fp32 sums, strict '>'
+//               upwards in j: the oracle's scan) for the chunk's frames -> psi bytes [B][T][32]; then the chunk's back-pointers
+//               are COMPOSED: comp_c[i] = the state at the chunk's first frame - 1 when the path is in state i at its last frame
+//               (kVpChunk dependent LDS reads, every chunk of every utterance in parallel);
+//   vit_walk_k  one wave per utterance: the end state of every chunk by walking the composed maps (T / kVpChunk dependent
+//               steps), then every lane walks ONE chunk from its end state through the psi bytes staged in LDS.
+// Serial depth 2 * kVpChunk + T / kVpChunk steps instead of T.
+constexpr int kVpChunk = 32;
+struct VitBtWs {
+  unsigned char* psi;    // [B][T][32]
+  unsigned char* comp;   // [B][nChunks][32]
+};
+__host__ __device__ inline int vit_chunks(int T) { return (T - 1 + kVpChunk - 1) / kVpChunk; }   // frames 1 .. T-1 in chunks
+__host__ __device__ inline VitBtWs vit_bt_ws(void* base, int B, int T, int N) {
+  VitBtWs w;
+  char* p = (char*)base + align_up((size_t)B * T * N * sizeof(float), 256);   // behind the delta rows
+  w.psi = (unsigned char*)p; p += align_up((size_t)B * T * 32, 256);
+  w.comp = (unsigned char*)p;
+  return w;
+}
+__host__ __device__ inline size_t vit_dpp_ws_bytes(int B, int T, int N) {
+  return align_up((size_t)B * T * N * sizeof(float), 256) + align_up((size_t)B * T * 32, 256) +
+         align_up((size_t)B * (size_t)(vit_chunks(T) + 1) * 32, 256);
+}
+
+// chunk c covers frames t = 1 + c * kVpChunk .. min(T - 1, (c + 1) * kVpChunk)
+__global__ __launch_bounds__(64) void vit_psi_k(int T, int N, const float* __restrict__ trans, const float* __restrict__ deltaAll,
+                                                VitBtWs ws) {
   __shared__ float sA[32 * 33];
-  __shared__ float sD[(kVbChunk + 1) * 32];
-  __shared__ unsigned char sPsi[kVbChunk * 32];
-  __shared__ int sPath[kVbChunk];
-  __shared__ int sCur;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ float sD[kVpChunk * 32];          // delta rows t - 1 of the chunk's frames
+  __shared__ unsigned char sPsi[kVpChunk * 32];
+  const int c = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const int tlo = 1 + c * kVpChunk;
+  int thi = tlo + kVpChunk - 1;
+  if (thi > T - 1) thi = T - 1;
+  const int nf = thi - tlo + 1;
   const float* db = deltaAll + (size_t)b * T * N;
-  int* pb = path + (size_t)b * T;
-  for (int e = tid; e < N * N; e += 256) sA[(e / N) * 33 + (e % N)] = trans[e];
-  if (tid < 64) {   // final state: first argmax_i delta_{T-1}[i]
-    const float v = tid < N ? db[(size_t)(T - 1) * N + tid] : -INFINITY;
-    const float m = wave_max(v);
-    const unsigned long long eq = __ballot(tid < N && v == m);
-    if (tid == 0) sCur = eq ? __ffsll((long long)eq) - 1 : 0;
+  for (int e = lane; e < N * N; e += 64) sA[(e / N) * 33 + (e % N)] = trans[e];
+  for (int e = lane; e < nf * N; e += 64) sD[(e / N) * 32 + (e % N)] = db[(size_t)(tlo - 1) * N + e];
+  __syncthreads();
+  // two frames at a time: lanes 0..31 the even, 32..63 the odd frame of a pair; lane & 31 = state i
+  const int i = lane & 31, half = lane >> 5;
+  for (int f = half; f < nf; f += 2) {
+    if (i < N) {
+      const float* dr = sD + f * 32;
+      const float* ar = sA + i * 33;
+      float best = dr[0] + ar[0];
+      int arg = 0;
+      for (int j = 1; j < N; ++j) {
+        const float v = dr[j] + ar[j];
+        if (v > best) { best = v; arg = j; }
+      }
+      sPsi[f * 32 + i] = (unsigned char)arg;
+    }
   }
   __syncthreads();
-  for (int thi = T - 1; thi >= 0; thi -= kVbChunk) {
-    int tlo = thi - kVbChunk + 1;
-    if (tlo < 0) tlo = 0;
-    const int nst = thi - tlo + 1;
-    // delta rows tlo-1 .. thi-1 (row r of sD = frame tlo - 1 + r)
-    const int r0 = tlo >= 1 ? 0 : 1;
-    for (int e = tid; e < (nst + 1 - r0) * N; e += 256) {
-      const int r = r0 + e / N, j = e % N;
-      sD[r * 32 + j] = db[(size_t)(tlo - 1 + r) * N + j];
+  unsigned char* pg = ws.psi + ((size_t)b * T + tlo) * 32;
+  for (int e = lane; e < nf * 32; e += 64) pg[e] = sPsi[e];
+  if (lane < 32) {   // compose from the chunk's last frame down: state at frame tlo - 1 given state `lane` at frame thi
+    int cur = lane < N ? lane : 0;
+    for (int f = nf - 1; f >= 0; --f) cur = sPsi[f * 32 + cur];
+    ws.comp[((size_t)b * (vit_chunks(T) + 1) + c) * 32 + lane] = (unsigned char)cur;
+  }
+}
+
+// stage = 1: the utterance's psi bytes fit in LDS (T <= ~4800) and are walked there; 0: walked in global memory
+__global__ __launch_bounds__(64) void vit_walk_k(int T, int N, int stage, const float* __restrict__ deltaAll, VitBtWs ws,
+                                                 int* __restrict__ path) {
+  extern __shared__ unsigned char sm[];   // [psi bytes of the utterance [T][32],] comp [nChunks][32], end states [nChunks + 1] ints
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int nC = vit_chunks(T);
+  const size_t psiBytes = stage ? (size_t)T * 32 : 0;
+  unsigned char* sComp = sm + psiBytes;
+  int* sEnd = (int*)(sm + ((psiBytes + (size_t)nC * 32 + 15) & ~(size_t)15));
+  const unsigned char* sPsi = stage ? sm : ws.psi + (size_t)b * T * 32;
+  {   // stage (16 B per lane and load)
+    const uint4* src = (const uint4*)(ws.psi + (size_t)b * T * 32);
+    uint4* dst = (uint4*)sm;
+    if (stage)
+      for (int e = lane; e < T * 2; e += 64) dst[e] = src[e];
+    const uint4* cs = (const uint4*)(ws.comp + (size_t)b * (nC + 1) * 32);
+    uint4* cd = (uint4*)sComp;
+    for (int e = lane; e < nC * 2; e += 64) cd[e] = cs[e];
+  }
+  // final state: first argmax_i delta_{T-1}[i]
+  const float* db = deltaAll + (size_t)b * T * N;
+  const float v = lane < N ? db[(size_t)(T - 1) * N + lane] : -INFINITY;
+  const float m = wave_max(v);
+  const unsigned long long eq = __ballot(lane < N && v == m);
+  int cur = eq ? __ffsll((long long)eq) - 1 : 0;
+  __syncthreads();
+  if (lane == 0) {   // end state of chunk c = state at frame min(T - 1, (c + 1) kVpChunk); sEnd[c] for c = nC - 1 .. 0, sEnd[-1] -> frame 0
+    for (int c = nC - 1; c >= 0; --c) {
+      sEnd[c + 1] = cur;
+      cur = sComp[c * 32 + cur];
     }
-    __syncthreads();
-    for (int e = tid; e < nst * N; e += 256) {
-      const int tt = e / N, i = e % N;   // frame tlo + tt, previous frame = row tt of sD
-      int arg = 0;
-      if (tlo + tt >= 1) {
-        const float* dr = sD + tt * 32;
-        const float* ar = sA + i * 33;
-        float best = dr[0] + ar[0];
-        for (int j = 1; j < N; ++j) {
-          const float v = dr[j] + ar[j];
-          if (v > best) { best = v; arg = j; }
-        }
-      }
-      sPsi[tt * 32 + i] = (unsigned char)arg;
+    sEnd[0] = cur;   // the state at frame 0
+  }
+  __syncthreads();
+  int* pb = path + (size_t)b * T;
+  if (lane == 0) pb[0] = sEnd[0];
+  for (int c = lane; c < nC; c += 64) {
+    const int tlo = 1 + c * kVpChunk;
+    int thi = tlo + kVpChunk - 1;
+    if (thi > T - 1) thi = T - 1;
+    int s = sEnd[c + 1];
+    for (int t = thi; t >= tlo; --t) {
+      pb[t] = s;
+      s = sPsi[(size_t)t * 32 + s];
     }
-    __syncthreads();
-    if (tid == 0) {
-      int cur = sCur;
-      for (int t = thi; t >= tlo; --t) {
-        sPath[t - tlo] = cur;
-        if (t >= 1) cur = sPsi[(t - tlo) * 32 + cur];
-      }
-      sCur = cur;
-    }
-    __syncthreads();
-    for (int e = tid; e < nst; e += 256) pb[tlo + e] = sPath[e];
-    __syncthreads();
   }
 }
 

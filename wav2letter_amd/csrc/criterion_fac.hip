@@ -21,6 +21,7 @@
 // Emission values x[t][y_i] are gathered straight from the coalesced [B][T][N]
 // rows (L1/L2 resident: the row is 120 B at N = 30), prefetched kFacChunk steps ahead.
 #include "common.hpp"
+#include <cstring>
 
 namespace w2l {
 
@@ -34,6 +35,8 @@ struct FacWs {
   float* scale;  // [B]
   float* tgpart; // [B][N][N] (only when it is small enough, else NULL -> atomics)
   unsigned char* bp;  // viterbi back pointers [B][T][L]
+  double* crow;  // [B][T][32] label rows c_t[n] of fac_rows_k (N <= 32 only, else NULL)
+  float* zmax;   // [B][T]     frame maxima (base 2) of the label scores
   int* redo;     // [B]  set by fac_fwd_lin: the utterance's dynamics exceed what the per-lane exponents hold exactly ->
                  //      fac_fwd_blk (log domain), launched behind it, recomputes that utterance
 };
@@ -51,6 +54,12 @@ __host__ __device__ inline FacWs fac_ws(void* ws, int B, int T, int N, int L) {
   w.redo = (int*)p; p += align_up((size_t)B * sizeof(int), 256);
   w.bp = (unsigned char*)w.w1;  // viterbi reuses the w1 region (needs B*T*L bytes)
   w.tgpart = fac_use_partials(B, N) ? (float*)p : nullptr;
+  if (w.tgpart) p += align_up((size_t)B * N * N * sizeof(float), 256);
+  w.crow = nullptr; w.zmax = nullptr;
+  if (N <= 32) {
+    w.crow = (double*)p; p += align_up((size_t)B * T * 32 * sizeof(double), 256);
+    w.zmax = (float*)p;
+  }
   return w;
 }
 
@@ -838,6 +847,7 @@ W2L_API size_t w2l_fac_workspace_size(int B, int T, int N, int L) {
   size_t sz = 2 * align_up((size_t)B * T * L * sizeof(float), 256) + align_up((size_t)B * sizeof(float), 256) +
               align_up((size_t)B * sizeof(int), 256);
   if (fac_use_partials(B, N)) sz += align_up((size_t)B * N * N * sizeof(float), 256);
+  if (N <= 32) sz += align_up((size_t)B * T * 32 * sizeof(double), 256) + align_up((size_t)B * T * sizeof(float), 256);
   return sz;
 }
 
@@ -866,19 +876,61 @@ W2L_API int w2l_fac_forward(int B, int T, int N, int L, int scaleMode, const flo
   hipStream_t s = (hipStream_t)stream;
   FacWs ws = fac_ws(workspace, B, T, N, L);
   if (fac_lin_path(N, L)) {
+    // scaled linear domain (criterion_fac_lin.hpp).  Product: label rows by a pre-pass, one position per thread with its own
+    // exponent, the waves of an utterance as a skewed pipeline that synchronises once per 16 frames (fac_fwd_plin).  The probe
+    // library runs the other generations for A/B work: W2L_FAC_GEN = blin2 (the same with one workgroup barrier per frame),
+    // blin (rows by a sixth wave), wave (one wave per utterance, five positions per lane, flags what it cannot hold for the
+    // log-domain kernel behind it); W2L_ASG_OLD=1 = the round-3 log-domain kernels.
+    static const int gen = [] {
+      const char* e = tune_env("W2L_FAC_GEN");
+      if (!e) return 0;
+      return !strcmp(e, "blin2") ? 1 : !strcmp(e, "blin") ? 2 : !strcmp(e, "wave") ? 3 : 0;
+    }();
+    const int nw = (L + 63) / 64;
+    if (gen == 3) {
 #define W2L_FAC_LIN_GO(PP) hipLaunchKernelGGL(fac_fwd_lin<PP>, dim3(B), dim3(64), 0, s, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws)
-    switch ((L + 63) / 64) {
-      case 1: W2L_FAC_LIN_GO(1); break;
-      case 2: W2L_FAC_LIN_GO(2); break;
-      case 3: W2L_FAC_LIN_GO(3); break;
-      case 4: W2L_FAC_LIN_GO(4); break;
-      default: W2L_FAC_LIN_GO(5); break;
-    }
+      switch (nw) {
+        case 1: W2L_FAC_LIN_GO(1); break;
+        case 2: W2L_FAC_LIN_GO(2); break;
+        case 3: W2L_FAC_LIN_GO(3); break;
+        case 4: W2L_FAC_LIN_GO(4); break;
+        default: W2L_FAC_LIN_GO(5); break;
+      }
 #undef W2L_FAC_LIN_GO
+      W2L_LAUNCH_CHECK();
+      if (L > 256) hipLaunchKernelGGL((fac_fwd_blk<8, 1>), dim3(B), dim3(512), 0, s, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws, (const int*)ws.redo);
+      else W2L_FAC_BLK_DISPATCH(fac_fwd_blk, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws, (const int*)ws.redo);
+      W2L_LAUNCH_CHECK();
+      return W2L_OK;
+    }
+    if (gen == 2) {
+#define W2L_FAC_BLIN_GO(NWV) hipLaunchKernelGGL((fac_fwd_blin<NWV>), dim3(B), dim3(64 * (NWV + 1)), 0, s, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws)
+      switch (nw) {
+        case 1: W2L_FAC_BLIN_GO(1); break;
+        case 2: W2L_FAC_BLIN_GO(2); break;
+        case 3: W2L_FAC_BLIN_GO(3); break;
+        case 4: W2L_FAC_BLIN_GO(4); break;
+        default: W2L_FAC_BLIN_GO(5); break;
+      }
+#undef W2L_FAC_BLIN_GO
+      W2L_LAUNCH_CHECK();
+      return W2L_OK;
+    }
+    hipLaunchKernelGGL(fac_rows_k, dim3((unsigned)((T + kFacRowsPerWave - 1) / kFacRowsPerWave), (unsigned)B), dim3(64), 0, s, T, N, input,
+                       trans, ws.crow, ws.zmax);
     W2L_LAUNCH_CHECK();
-    // the exact log-domain kernel for the utterances fac_fwd_lin flagged (returns at once for the others)
-    if (L > 256) hipLaunchKernelGGL((fac_fwd_blk<8, 1>), dim3(B), dim3(512), 0, s, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws, (const int*)ws.redo);
-    else W2L_FAC_BLK_DISPATCH(fac_fwd_blk, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws, (const int*)ws.redo);
+#define W2L_FAC_P_GO(K, NWV) hipLaunchKernelGGL((K<NWV>), dim3(B), dim3(64 * NWV), 0, s, T, N, L, scaleMode, target, targetSize, trans, loss, ws)
+#define W2L_FAC_P_SWITCH(K)               \
+    switch (nw) {                         \
+      case 1: W2L_FAC_P_GO(K, 1); break;  \
+      case 2: W2L_FAC_P_GO(K, 2); break;  \
+      case 3: W2L_FAC_P_GO(K, 3); break;  \
+      case 4: W2L_FAC_P_GO(K, 4); break;  \
+      default: W2L_FAC_P_GO(K, 5); break; \
+    }
+    if (gen == 1) { W2L_FAC_P_SWITCH(fac_fwd_blin2) } else { W2L_FAC_P_SWITCH(fac_fwd_plin) }
+#undef W2L_FAC_P_SWITCH
+#undef W2L_FAC_P_GO
     W2L_LAUNCH_CHECK();
     return W2L_OK;
   }
@@ -937,7 +989,24 @@ W2L_API int w2l_fac_backward(int B, int T, int N, int L, const int* target, cons
   size_t n = (size_t)N * N;
   if (ws.tgpart) W2L_HIP_CHECK(hipMemsetAsync(ws.tgpart, 0, (size_t)B * n * sizeof(float), s));
   else W2L_HIP_CHECK(hipMemsetAsync(transGrad, 0, n * sizeof(float), s));
-  if (fac_lin_path(N, L)) {
+  // product (N <= 32, L <= 320): the pipelined backward scan fac_bwd_plin; probe: W2L_FAC_BWD = wave (one wave per utterance),
+  // blk51 (five waves x one position, a workgroup barrier per frame), blk42 (the round-3 shape)
+  static const int bgen = [] {
+    const char* e = tune_env("W2L_FAC_BWD");
+    if (!e) return 0;
+    return !strcmp(e, "wave") ? 1 : !strcmp(e, "blk51") ? 2 : !strcmp(e, "blk42") ? 3 : 0;
+  }();
+  if (fac_lin_path(N, L) && bgen == 0) {
+#define W2L_FAC_PB_GO(NWV) hipLaunchKernelGGL((fac_bwd_plin<NWV>), dim3(B), dim3(64 * NWV), 0, s, T, N, L, target, targetSize, grad, transGrad, ws)
+    switch ((L + 63) / 64) {
+      case 1: W2L_FAC_PB_GO(1); break;
+      case 2: W2L_FAC_PB_GO(2); break;
+      case 3: W2L_FAC_PB_GO(3); break;
+      case 4: W2L_FAC_PB_GO(4); break;
+      default: W2L_FAC_PB_GO(5); break;
+    }
+#undef W2L_FAC_PB_GO
+  } else if (fac_lin_path(N, L) && bgen == 1) {
 #define W2L_FAC_LIN_GO(PP) hipLaunchKernelGGL(fac_bwd_wave<PP>, dim3(B), dim3(64), 0, s, T, N, L, target, targetSize, grad, transGrad, ws)
     switch ((L + 63) / 64) {
       case 1: W2L_FAC_LIN_GO(1); break;
@@ -947,6 +1016,8 @@ W2L_API int w2l_fac_backward(int B, int T, int N, int L, const int* target, cons
       default: W2L_FAC_LIN_GO(5); break;
     }
 #undef W2L_FAC_LIN_GO
+  } else if (bgen == 2 && L > 256 && L <= 320) {
+    hipLaunchKernelGGL((fac_bwd_blk<5, 1>), dim3(B), dim3(320), 0, s, T, N, L, target, targetSize, grad, transGrad, ws);
   } else
 #ifdef W2L_PROBE
   if (tune_env("W2L_FAC_PIPE")) {

@@ -31,6 +31,7 @@
 // the one wave instead of an LDS row + workgroup barrier per frame.
 #pragma once
 #include "common.hpp"
+#include <type_traits>
 
 namespace w2l {
 
@@ -322,6 +323,552 @@ __global__ __launch_bounds__(64) void fac_bwd_wave(int T, int N, int L, const in
       if (accS[p] != 0.f) atomicAdd(&tg[(size_t)yi[p] * N + yi[p]], g * accS[p]);
       if (i > 0 && accP[p] != 0.f) atomicAdd(&tg[(size_t)yi[p] * N + yp[p]], g * accP[p]);
     }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// fac_fwd_blin: the same linear-domain recursion, ONE POSITION PER THREAD with ITS OWN exponent, one workgroup per utterance.
+// What tools/micro/clock_probe.hip measured on MI355X (profiles/r04_run3_clock_probe.log): a wave that is alone on its SIMD
+// issues one VALU instruction every ~6.5 cycles whether or not the instructions depend on each other (fp32, fp64 and DPP
+// alike), and an LDS write -> s_barrier -> LDS read hand-over costs ~65 cycles.  A frame of a serial scan therefore costs
+// (instructions ONE wave issues) x 6.5 cycles: fac_fwd_lin above, five positions per lane, issues ~160 instructions per frame
+// (0.88 ms at T = 2000 -- measured slower than the log-domain fac_fwd_blk, 0.49 ms) -- while with one position per thread the
+// waves of the workgroup issue side by side and a frame is ~25 instructions plus one barrier:
+//   position i (thread i):  (m_nb, e_nb) <- LDS record of position i-1 (previous frame)       c <- LDS label row[y_i]
+//     E = max(e, e_nb);  tot = ldexp(m, e - E) + kappa_i ldexp(m_nb, e_nb - E);  w1 = m' / tot;  h = c tot
+//     (m, e) <- (frexp_mant(h), E + frexp_exp(h))   -> LDS record of position i (this frame);  s_barrier
+//   one more wave (the "row wave") computes the label row c_{t+1}[n] = 2^(z - max z) of the NEXT frame meanwhile
+//   (integer / fraction split, fp64 ldexp: no underflow) and sums the frame maxima.
+// An exponent per position is the `group = 1` case of oracle/asg_linear_domain.py::fac_forward_linear: every position keeps the
+// full fp64 range on its own -- no renormalisation scan, no pruning, no range check, no fallback.
+struct FacRec { double m; int e; int pad; };
+constexpr int kFacBlinChunk = 16;
+
+template <int NW>
+__global__ __launch_bounds__(64 * (NW + 1)) void fac_fwd_blin(int T, int N, int L, int scaleMode, const float* __restrict__ x,
+                                                              const int* __restrict__ target, const int* __restrict__ targetSize,
+                                                              const float* __restrict__ trans, float* __restrict__ loss, FacWs ws) {
+  constexpr int NT = 64 * NW;
+  __shared__ FacRec sH[2][NT + 1];   // sH[buf][i + 1] = position i after the frame of parity buf; [0] = position -1 (no mass)
+  __shared__ double sC[2][32];       // label row of the frame of parity buf
+  __shared__ double sZ;              // sum of the frame maxima (base 2), left by the row wave
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool rowWave = wave == NW;
+  const int S = targetSize[b];
+  const float sc = scale_of(scaleMode, T, S);
+  if (tid == 0) { ws.scale[b] = sc; ws.redo[b] = 0; }
+  if (S <= 0) {
+    if (tid == 0) loss[b] = 0.f;
+    return;
+  }
+  const float NEG = -INFINITY;
+  const float L2E = 1.44269504088896341f;
+  const int* y = target + (size_t)b * L;
+  const float* xb = x + (size_t)b * T * N;
+  float* w1b = ws.w1 + (size_t)b * T * L;
+  const int lane = tid & 63;
+  if (tid == 0) { sH[0][0].m = 0.0; sH[0][0].e = kFacEmptyExp; sH[1][0].m = 0.0; sH[1][0].e = kFacEmptyExp; }
+
+  if (rowWave) {
+    // ---- the row wave: label rows one frame ahead
+    const bool act = lane < N;
+    const float adl = act ? trans[(size_t)lane * N + lane] * L2E : 0.f;
+    float xc[kFacBlinChunk], xn[kFacBlinChunk];
+#pragma unroll
+    for (int s = 0; s < kFacBlinChunk; ++s) xc[s] = (act && s < T) ? xb[(size_t)s * N + lane] : 0.f;
+    double zsum = 0.0;
+    auto row = [&](float xv, int t) {   // row of frame t -> sC[t & 1]
+      const float z = act ? fmaf(xv, L2E, adl) : NEG;
+      const float zm = wave_max_rows<2>(z);
+      const float zr = fmaxf(z - zm, -4000.f);
+      const float zi = __builtin_rintf(zr);
+      const double c = __builtin_amdgcn_ldexp((double)__builtin_amdgcn_exp2f(zr - zi), (int)zi);
+      if (act) sC[t & 1][lane] = c;
+      zsum += (double)zm;
+    };
+    row(xc[0], 0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int t0 = 0; t0 < T; t0 += kFacBlinChunk) {
+#pragma unroll
+      for (int s = 0; s < kFacBlinChunk; ++s) {
+        const int tn = t0 + kFacBlinChunk + s;
+        xn[s] = (act && tn < T) ? xb[(size_t)tn * N + lane] : 0.f;
+      }
+#pragma unroll
+      for (int s = 0; s < kFacBlinChunk; ++s) {
+        const int t = t0 + s;
+        if (t < T) {   // uniform
+          if (t + 1 < T) row(s + 1 < kFacBlinChunk ? xc[s + 1 < kFacBlinChunk ? s + 1 : 0] : xn[0], t + 1);
+          if (t + 1 == T && lane == 0) sZ = zsum;
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < kFacBlinChunk; ++s) asm volatile("" : "+v"(xn[s]));
+#pragma unroll
+      for (int s = 0; s < kFacBlinChunk; ++s) xc[s] = xn[s];
+    }
+    return;
+  }
+
+  // ---- position threads
+  const int i = tid;
+  const bool valid = i < S;
+  const int yi = valid ? y[i] : 0;
+  const int yp = (valid && i > 0) ? y[i - 1] : 0;
+  const float dk = (valid && i > 0) ? trans[(size_t)yi * N + yp] - trans[(size_t)yp * N + yp] : NEG;
+  const double kap = (double)__expf(dk);   // 0 for position 0 and beyond the target
+  double m = 0.0;
+  int e = kFacEmptyExp;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // row 0 is in sC[0]
+  for (int t0 = 0; t0 < T; t0 += kFacBlinChunk) {
+    float wst[kFacBlinChunk];
+#pragma unroll
+    for (int s = 0; s < kFacBlinChunk; ++s) {
+      const int t = t0 + s;
+      wst[s] = 0.f;
+      if (t < T) {   // uniform
+        const double c = sC[t & 1][yi];
+        double h;
+        int E;
+        if (t == 0) {
+          h = i == 0 ? c : 0.0;   // alpha_0[0] = x_0[y_0]
+          E = 0;
+        } else {
+          const FacRec nb = sH[(t - 1) & 1][i];   // position i - 1 after frame t - 1
+          E = max(e, nb.e);
+          const double ms = __builtin_amdgcn_ldexp(m, e - E);
+          const double tot = fma(__builtin_amdgcn_ldexp(nb.m, nb.e - E), kap, ms);
+          // v_rcp_f64: 2^-23 relative, the accuracy of the fp32 w1 (the log-domain kernel takes v_rcp_f32 here)
+          wst[s] = (float)(ms * __builtin_amdgcn_rcp(fmax(tot, 0x1p-1000)));
+          h = valid ? c * tot : 0.0;
+        }
+        m = __builtin_amdgcn_frexp_mant(h);
+        e = h > 0.0 ? E + __builtin_amdgcn_frexp_exp(h) : kFacEmptyExp;
+        FacRec out;
+        out.m = m; out.e = e; out.pad = 0;
+        sH[t & 1][i + 1] = out;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < kFacBlinChunk; ++s) {
+      const int t = t0 + s;
+      if (valid && t >= 1 && t < T) w1b[(size_t)t * L + i] = wst[s];
+    }
+  }
+  if (i == S - 1) {   // loss = scale * alpha_{T-1}[S-1],  alpha = (zsum + e + log2 m) ln 2 - A[y][y]
+    float out = -INFINITY;
+    if (m > 0.0) {
+      const double l2 = sZ + (double)e + (double)__builtin_amdgcn_logf((float)m);
+      out = (float)((double)sc * (l2 * 0.69314718055994530942 - (double)trans[(size_t)yi * N + yi]));
+    }
+    loss[b] = out;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// fac_rows_k + fac_fwd_blin2: the label rows do not depend on the recursion, so they come from a parallel pre-pass over all
+// (utterance, frame) pairs -- c_t[n] as fp64 in the workspace ([B][T][32]) and the frame maxima [B][T] -- and the scan's position
+// threads gather c_t[y_i] straight from there, prefetched a chunk of 16 frames ahead (the way fac_fwd_blk gathers x_t[y_i]).
+// Against fac_fwd_blin: no row wave (one wave less on the CU's four SIMDs), no LDS row, three instructions less per frame.
+constexpr int kFacRowsPerWave = 8;
+__global__ __launch_bounds__(64) void fac_rows_k(int T, int N, const float* __restrict__ x, const float* __restrict__ trans,
+                                                 double* __restrict__ crow, float* __restrict__ zmax) {
+  const int b = blockIdx.y, lane = threadIdx.x;
+  const int t0 = blockIdx.x * kFacRowsPerWave;
+  const float L2E = 1.44269504088896341f;
+  const bool act = lane < N;
+  const float adl = act ? trans[(size_t)lane * N + lane] * L2E : 0.f;
+  const float* xb = x + (size_t)b * T * N;
+  float xv[kFacRowsPerWave];
+#pragma unroll
+  for (int s = 0; s < kFacRowsPerWave; ++s) xv[s] = (act && t0 + s < T) ? xb[(size_t)(t0 + s) * N + lane] : 0.f;
+#pragma unroll
+  for (int s = 0; s < kFacRowsPerWave; ++s) {
+    const int t = t0 + s;
+    if (t < T) {
+      const float z = act ? fmaf(xv[s], L2E, adl) : -INFINITY;
+      const float zm = wave_max_rows<2>(z);
+      const float zr = fmaxf(z - zm, -4000.f);
+      const float zi = __builtin_rintf(zr);
+      const double c = __builtin_amdgcn_ldexp((double)__builtin_amdgcn_exp2f(zr - zi), (int)zi);
+      if (lane < 32) crow[((size_t)b * T + t) * 32 + lane] = act ? c : 0.0;
+      if (lane == 0) zmax[(size_t)b * T + t] = zm;
+    }
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void fac_fwd_blin2(int T, int N, int L, int scaleMode, const int* __restrict__ target,
+                                                         const int* __restrict__ targetSize, const float* __restrict__ trans,
+                                                         float* __restrict__ loss, FacWs ws) {
+  constexpr int NT = 64 * NW;
+  __shared__ FacRec sH[2][NT + 1];   // sH[buf][i + 1] = position i after the frame of parity buf; [0] = position -1 (no mass)
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int S = targetSize[b];
+  const float sc = scale_of(scaleMode, T, S);
+  if (tid == 0) { ws.scale[b] = sc; ws.redo[b] = 0; }
+  if (S <= 0) {
+    if (tid == 0) loss[b] = 0.f;
+    return;
+  }
+  const float NEG = -INFINITY;
+  const int* y = target + (size_t)b * L;
+  float* w1b = ws.w1 + (size_t)b * T * L;
+  if (tid == 0) { sH[0][0].m = 0.0; sH[0][0].e = kFacEmptyExp; sH[1][0].m = 0.0; sH[1][0].e = kFacEmptyExp; }
+  const int i = tid;
+  const bool valid = i < S;
+  const int yi = valid ? y[i] : 0;
+  const int yp = (valid && i > 0) ? y[i - 1] : 0;
+  const float dk = (valid && i > 0) ? trans[(size_t)yi * N + yp] - trans[(size_t)yp * N + yp] : NEG;
+  const double kap = (double)__expf(dk);   // 0 for position 0 and beyond the target
+  const double* cb = ws.crow + (size_t)b * T * 32 + yi;
+  double cc[kFacBlinChunk], cn[kFacBlinChunk];
+#pragma unroll
+  for (int s = 0; s < kFacBlinChunk; ++s) cc[s] = (valid && s < T) ? cb[(size_t)s * 32] : 0.0;
+#pragma unroll
+  for (int s = 0; s < kFacBlinChunk; ++s) asm volatile("" : "+v"(cc[s]));   // landed before the loop (see fac_fwd_plin)
+  double m = 0.0;
+  int e = kFacEmptyExp;
+  __syncthreads();
+  for (int t0 = 0; t0 < T; t0 += kFacBlinChunk) {
+#pragma unroll
+    for (int s = 0; s < kFacBlinChunk; ++s) {
+      const int tn = t0 + kFacBlinChunk + s;
+      cn[s] = (valid && tn < T) ? cb[(size_t)tn * 32] : 0.0;
+    }
+    float wst[kFacBlinChunk];
+#pragma unroll
+    for (int s = 0; s < kFacBlinChunk; ++s) {
+      const int t = t0 + s;
+      wst[s] = 0.f;
+      if (t < T) {   // uniform
+        double h;
+        int E;
+        if (t == 0) {
+          h = i == 0 ? cc[s] : 0.0;   // alpha_0[0] = x_0[y_0]
+          E = 0;
+        } else {
+          const FacRec nb = sH[(t - 1) & 1][i];   // position i - 1 after frame t - 1
+          E = max(e, nb.e);
+          const double ms = __builtin_amdgcn_ldexp(m, e - E);
+          const double tot = fma(__builtin_amdgcn_ldexp(nb.m, nb.e - E), kap, ms);
+          wst[s] = (float)(ms * __builtin_amdgcn_rcp(fmax(tot, 0x1p-1000)));   // (v_rcp_f64: 2^-23 relative, as the fp32 w1)
+          h = cc[s] * tot;
+        }
+        m = __builtin_amdgcn_frexp_mant(h);
+        e = h > 0.0 ? E + __builtin_amdgcn_frexp_exp(h) : kFacEmptyExp;
+        FacRec out;
+        out.m = m; out.e = e; out.pad = 0;
+        sH[t & 1][i + 1] = out;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < kFacBlinChunk; ++s) asm volatile("" : "+v"(cn[s]));   // (before the stores: see fac_fwd_plin)
+#pragma unroll
+    for (int s = 0; s < kFacBlinChunk; ++s) {
+      const int t = t0 + s;
+      if (valid && t >= 1 && t < T) w1b[(size_t)t * L + i] = wst[s];
+    }
+#pragma unroll
+    for (int s = 0; s < kFacBlinChunk; ++s) cc[s] = cn[s];
+  }
+  // loss = scale * alpha_{T-1}[S-1],  alpha = (sum_t zmax_t + e + log2 m) ln 2 - A[y][y]; the wave that holds position S - 1 sums
+  if ((tid >> 6) == ((S - 1) >> 6)) {   // wave-uniform
+    const float* zb = ws.zmax + (size_t)b * T;
+    double zs = 0.0;
+    for (int t = tid & 63; t < T; t += 64) zs += (double)zb[t];
+    zs = wave_sum_f64(zs);
+    if (i == S - 1) {
+      float out = -INFINITY;
+      if (m > 0.0) {
+        const double l2 = zs + (double)e + (double)__builtin_amdgcn_logf((float)m);
+        out = (float)((double)sc * (l2 * 0.69314718055994530942 - (double)trans[(size_t)yi * N + yi]));
+      }
+      loss[b] = out;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// fac_fwd_plin / fac_bwd_plin: the waves of an utterance as a SKEWED PIPELINE -- no workgroup barrier at all.
+// Measured (profiles/r04_run4 / run6): with one position per thread a frame is ~27 instructions (~175 cycles), but the
+// s_barrier that keeps 5-6 waves in lockstep costs ~400 cycles per frame (fac_fwd_blin 0.50 ms, fac_bwd_blk<5,1> 0.35 ms at
+// T = 2000): the barrier IS the kernel.  A position needs its LEFT neighbour's value of the PREVIOUS frame (forward) / its RIGHT
+// neighbour's advance term of the same step (backward): inside a wave that is a DPP lane shift, and between waves it is ONE
+// record per frame per wave boundary.  So wave w runs a whole chunk of kPlinChunk frames behind wave w - 1 (forward; ahead of
+// it in the backward scan): the boundary records go through an LDS ring of kPlinRing frames, and the waves synchronise ONCE PER
+// CHUNK through a progress word (poll until the leader has finished the chunk; the leader checks that its follower is less
+// than three chunks behind before it overwrites ring slots).  Per frame that leaves: 3 DPP moves, one broadcast LDS read,
+// one single-lane LDS write.  (The round-2 pipeline, fac_fwd_pipe, checked a tag EVERY frame and carried the log-domain
+// arithmetic: 459 cycles per frame alone; it measured no faster than the barrier version.)  Every poll is bounded: a wave that
+// never sees its leader poisons the loss (NaN) instead of hanging the GPU.  Label rows: fac_rows_k (pre-pass).
+constexpr int kPlinChunk = 16;
+constexpr int kPlinRing = 64;
+constexpr int kPlinSpinMax = 1 << 18;   // ~10 ms: a legitimate wait is a few microseconds
+
+__device__ __forceinline__ bool plin_wait_ge(const int* p, int want) {   // poll *p >= want (relaxed LDS loads), bounded
+  int spins = 0, v;
+#pragma clang loop unroll(disable)
+  do {
+    v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (v >= want) return true;
+    __builtin_amdgcn_s_sleep(1);
+  } while (++spins < kPlinSpinMax);
+  return false;
+}
+__device__ __forceinline__ bool plin_wait_le(const int* p, int want) {
+  int spins = 0, v;
+#pragma clang loop unroll(disable)
+  do {
+    v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (v <= want) return true;
+    __builtin_amdgcn_s_sleep(1);
+  } while (++spins < kPlinSpinMax);
+  return false;
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void fac_fwd_plin(int T, int N, int L, int scaleMode, const int* __restrict__ target,
+                                                        const int* __restrict__ targetSize, const float* __restrict__ trans,
+                                                        float* __restrict__ loss, FacWs ws) {
+  __shared__ FacRec ring[NW][kPlinRing];   // ring[w][t & 63]: position 64 w + 63 after frame t
+  __shared__ int prog[NW];                 // last frame wave w has finished
+  __shared__ int bad;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int S = targetSize[b];
+  const float sc = scale_of(scaleMode, T, S);
+  if (tid == 0) { ws.scale[b] = sc; ws.redo[b] = 0; }
+  if (S <= 0) {
+    if (tid == 0) loss[b] = 0.f;
+    return;
+  }
+  if (tid < NW) prog[tid] = -1;
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  const int lastWave = (S - 1) >> 6;
+  if (wave > lastWave) return;           // nothing to do, and nobody waits for these waves
+  const bool fed = wave > 0, feeds = wave < lastWave;
+  const float NEG = -INFINITY;
+  const int* y = target + (size_t)b * L;
+  float* w1b = ws.w1 + (size_t)b * T * L;
+  const int i = tid;
+  const bool valid = i < S;
+  const int yi = valid ? y[i] : 0;
+  const int yp = (valid && i > 0) ? y[i - 1] : 0;
+  const float dk = (valid && i > 0) ? trans[(size_t)yi * N + yp] - trans[(size_t)yp * N + yp] : NEG;
+  const double kap = (double)__expf(dk);   // 0 for position 0 and beyond the target
+  const double* cb = ws.crow + (size_t)b * T * 32 + yi;
+  double cc[kPlinChunk], cn[kPlinChunk];
+#pragma unroll
+  for (int s = 0; s < kPlinChunk; ++s) cc[s] = (valid && s < T) ? cb[(size_t)s * 32] : 0.0;
+#pragma unroll
+  for (int s = 0; s < kPlinChunk; ++s) asm volatile("" : "+v"(cc[s]));   // landed before the loop: with a load pending at the loop head
+                                                                        // hipcc waits vmcnt(0) at every frame's first use -- i.e. for
+                                                                        // the NEXT chunk's prefetch, one memory latency per chunk
+  double m = 0.0;
+  int e = kFacEmptyExp;
+  bool ok = true;
+  const FacRec* srcRing = &ring[fed ? wave - 1 : 0][0];
+  FacRec* dstRing = &ring[wave][0];
+  for (int t0 = 0; t0 < T; t0 += kPlinChunk) {
+    const int tlast = min(t0 + kPlinChunk, T) - 1;
+    if (fed) ok = plin_wait_ge(&prog[wave - 1], tlast) && ok;                                  // the leader has finished this chunk
+    if (feeds && t0 >= kPlinRing - kPlinChunk) ok = plin_wait_ge(&prog[wave + 1], t0 - (kPlinRing - kPlinChunk)) && ok;   // ring slots free
+#pragma unroll
+    for (int s = 0; s < kPlinChunk; ++s) {
+      const int tn = t0 + kPlinChunk + s;
+      cn[s] = (valid && tn < T) ? cb[(size_t)tn * 32] : 0.0;
+    }
+    // the leader's records of frames t0 - 1 .. t0 + 14 (position 64 wave - 1 after the frame BEFORE each of this chunk's frames):
+    // all sixteen at the top of the chunk -- a broadcast LDS read per frame, none of them on the recursion's chain
+    double rm[kPlinChunk];
+    int re[kPlinChunk];
+#pragma unroll
+    for (int s = 0; s < kPlinChunk; ++s) { rm[s] = 0.0; re[s] = kFacEmptyExp; }
+    if (fed) {   // uniform
+#pragma unroll
+      for (int s = 0; s < kPlinChunk; ++s) {
+        const FacRec r = srcRing[(t0 + s - 1) & (kPlinRing - 1)];   // (t0 = 0 never gets here with s = 0 used: frame 0 has no predecessor)
+        rm[s] = r.m; re[s] = r.e;
+      }
+    }
+    float wst[kPlinChunk];
+    double pm[kPlinChunk];   // this lane's (m, e) after each frame: lane 63's are published at the end of the chunk
+    int pe[kPlinChunk];
+    auto frames = [&](auto full) {
+#pragma unroll
+      for (int s = 0; s < kPlinChunk; ++s) {
+        const int t = t0 + s;
+        wst[s] = 0.f; pm[s] = 0.0; pe[s] = kFacEmptyExp;
+        if (decltype(full)::value || t < T) {   // uniform
+          double h;
+          int E;
+          if (t == 0) {
+            h = i == 0 ? cc[s] : 0.0;   // alpha_0[0] = x_0[y_0]
+            E = 0;
+          } else {
+            // position i - 1 after frame t - 1: the lane below (DPP wave_shr:1); lane 0 keeps the `old` operand = the record
+            const long long mb = __double_as_longlong(m), rb = __double_as_longlong(rm[s]);
+            const int lo = __builtin_amdgcn_update_dpp((int)rb, (int)mb, 0x138, 0xf, 0xf, false);
+            const int hi = __builtin_amdgcn_update_dpp((int)(rb >> 32), (int)(mb >> 32), 0x138, 0xf, 0xf, false);
+            const double nm = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+            const int ne = __builtin_amdgcn_update_dpp(re[s], e, 0x138, 0xf, 0xf, false);
+            E = max(e, ne);
+            const double ms = __builtin_amdgcn_ldexp(m, e - E);
+            const double tot = fma(__builtin_amdgcn_ldexp(nm, ne - E), kap, ms);
+            wst[s] = (float)(ms * __builtin_amdgcn_rcp(fmax(tot, 0x1p-1000)));   // (v_rcp_f64: 2^-23 relative, as the fp32 w1)
+            h = cc[s] * tot;
+          }
+          m = __builtin_amdgcn_frexp_mant(h);
+          e = h > 0.0 ? E + __builtin_amdgcn_frexp_exp(h) : kFacEmptyExp;
+          pm[s] = m; pe[s] = e;
+        }
+      }
+    };
+    if (t0 + kPlinChunk <= T) frames(std::true_type{});
+    else frames(std::false_type{});
+    if (feeds) {   // the chunk's records (lane 63), then the progress word: the LDS executes a wave's operations in order
+      if (lane == 63) {
+        FacRec* d = dstRing + (t0 & (kPlinRing - 1));   // t0 is a multiple of the chunk: the chunk's slots are contiguous
+#pragma unroll
+        for (int s = 0; s < kPlinChunk; ++s) { FacRec out; out.m = pm[s]; out.e = pe[s]; out.pad = 0; d[s] = out; }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (lane == 0) __hip_atomic_store(&prog[wave], tlast, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // the prefetched chunk is consumed BEFORE this chunk's stores are issued (a use behind the stores makes hipcc wait for the
+    // stores' round trip too: the counter is shared and in order)
+#pragma unroll
+    for (int s = 0; s < kPlinChunk; ++s) asm volatile("" : "+v"(cn[s]));
+#pragma unroll
+    for (int s = 0; s < kPlinChunk; ++s) {
+      const int t = t0 + s;
+      if (valid && t >= 1 && t < T) w1b[(size_t)t * L + i] = wst[s];
+    }
+#pragma unroll
+    for (int s = 0; s < kPlinChunk; ++s) cc[s] = cn[s];
+  }
+  if (!ok && lane == 0) __hip_atomic_store(&bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  // loss = scale * alpha_{T-1}[S-1],  alpha = (sum_t zmax_t + e + log2 m) ln 2 - A[y][y]; the wave that holds position S - 1 sums
+  if (wave == lastWave) {
+    const float* zb = ws.zmax + (size_t)b * T;
+    double zs = 0.0;
+    for (int t = lane; t < T; t += 64) zs += (double)zb[t];
+    zs = wave_sum_f64(zs);
+    if (i == S - 1) {
+      float out = -INFINITY;
+      if (m > 0.0) {
+        const double l2 = zs + (double)e + (double)__builtin_amdgcn_logf((float)m);
+        out = (float)((double)sc * (l2 * 0.69314718055994530942 - (double)trans[(size_t)yi * N + yi]));
+      }
+      // (the leaders finished before this wave did: their verdicts are in `bad`)
+      loss[b] = (ok && !__hip_atomic_load(&bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) ? out : __builtin_nanf("");
+    }
+  }
+}
+
+// backward scan as the mirrored pipeline: wave w + 1 leads wave w (a position needs its RIGHT neighbour's advance term of the
+// same step); consumes w1[t][i], leaves g * dalpha_t[i] in ws.dal for fac_scatter_k
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void fac_bwd_plin(int T, int N, int L, const int* __restrict__ target,
+                                                        const int* __restrict__ targetSize, const float* __restrict__ grad,
+                                                        float* __restrict__ transGrad, FacWs ws) {
+  __shared__ float ring[NW][kPlinRing];   // ring[w][t & 63]: advance term of position 64 w at step t
+  __shared__ int prog[NW];                // lowest frame wave w has finished (steps run from T - 1 down)
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int S = targetSize[b];
+  if (S <= 0) return;  // the scatter kernel zero-fills this utterance's gradient
+  if (tid < NW) prog[tid] = 0x3fffffff;
+  __syncthreads();
+  const int lastWave = (S - 1) >> 6;
+  const int* y = target + (size_t)b * L;
+  const float* __restrict__ w1b = ws.w1 + (size_t)b * T * L;
+  float* __restrict__ dalb = ws.dal + (size_t)b * T * L;
+  const float g = ws.scale[b] * grad[b];
+  const int i = tid;
+  const bool valid = i < S;
+  if (wave > lastWave) return;   // no mass here, nobody waits for these waves (fac_scatter_k reads positions < S only)
+  const int yi = valid ? y[i] : 0;
+  const int yp = (valid && i > 0) ? y[i - 1] : 0;
+  float da = (i == S - 1) ? 1.f : 0.f, accS = 0.f, accP = 0.f;
+  const bool fed = wave < lastWave, feeds = wave > 0;   // wave + 1 supplies lane 63's right neighbour; lane 0 supplies wave - 1
+  bool ok = true;
+  const float* srcRing = &ring[fed ? wave + 1 : 0][0];
+  float* dstRing = &ring[wave][0];
+  float wc[kPlinChunk], wn[kPlinChunk];
+#pragma unroll
+  for (int s = 0; s < kPlinChunk; ++s) {
+    const int t = T - 1 - s;
+    wc[s] = (t >= 1 && valid) ? w1b[(size_t)t * L + i] : 0.f;
+  }
+#pragma unroll
+  for (int s = 0; s < kPlinChunk; ++s) asm volatile("" : "+v"(wc[s]));   // landed before the loop (see fac_fwd_plin)
+  // chunks are aligned to multiples of kPlinChunk from the TOP frame: step index k = T - 1 - t, ring slot k & 63
+  for (int k0 = 0; k0 < T; k0 += kPlinChunk) {
+    const int thi = T - 1 - k0;
+    const int tlow = max(thi - kPlinChunk + 1, 0);
+    if (fed) ok = plin_wait_le(&prog[wave + 1], tlow) && ok;                                        // the leader has finished this chunk
+    if (feeds && k0 >= kPlinRing - kPlinChunk) ok = plin_wait_le(&prog[wave - 1], thi + (kPlinRing - kPlinChunk)) && ok;   // ring slots free
+#pragma unroll
+    for (int s = 0; s < kPlinChunk; ++s) {
+      const int t = thi - kPlinChunk - s;
+      wn[s] = (t >= 1 && valid) ? w1b[(size_t)t * L + i] : 0.f;
+    }
+    float rr[kPlinChunk];   // the leader's advance terms of this chunk's steps (position 64 (wave + 1))
+#pragma unroll
+    for (int s = 0; s < kPlinChunk; ++s) rr[s] = 0.f;
+    if (fed) {   // uniform
+      const float* sr = srcRing + (k0 & (kPlinRing - 1));
+#pragma unroll
+      for (int s = 0; s < kPlinChunk; ++s) rr[s] = sr[s];
+    }
+    float dstv[kPlinChunk], pa[kPlinChunk];
+#pragma unroll
+    for (int s = 0; s < kPlinChunk; ++s) {
+      const int t = thi - s;
+      dstv[s] = g * da;   // row t of g * dalpha (0 beyond S)
+      pa[s] = 0.f;
+      if (t >= 1) {   // uniform
+        const float st = da * wc[s];
+        const float adv = da - st;
+        accS += st;
+        accP += adv;
+        pa[s] = adv;
+        // advance term of position i + 1: the lane above (DPP wave_shl:1); lane 63 keeps the `old` operand = the leader's
+        const float right = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(rr[s]), __float_as_int(adv), 0x130, 0xf, 0xf, false));
+        da = st + right;
+      }
+    }
+    if (feeds) {
+      if (lane == 0) {
+        float* d = dstRing + (k0 & (kPlinRing - 1));
+#pragma unroll
+        for (int s = 0; s < kPlinChunk; ++s) d[s] = pa[s];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (lane == 0) __hip_atomic_store(&prog[wave], tlow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+    for (int s = 0; s < kPlinChunk; ++s) asm volatile("" : "+v"(wn[s]));   // (before the stores: see fac_fwd_plin)
+#pragma unroll
+    for (int s = 0; s < kPlinChunk; ++s) {
+      const int t = thi - s;
+      if (t >= 0 && i < L) dalb[(size_t)t * L + i] = ok ? dstv[s] : __builtin_nanf("");
+    }
+#pragma unroll
+    for (int s = 0; s < kPlinChunk; ++s) wc[s] = wn[s];
+  }
+  float* tg = ws.tgpart ? ws.tgpart + (size_t)b * N * N : transGrad;
+  if (valid) {
+    if (accS != 0.f) atomicAdd(&tg[(size_t)yi * N + yi], g * accS);
+    if (i > 0 && accP != 0.f) atomicAdd(&tg[(size_t)yi * N + yp], g * accP);
   }
 }
 

@@ -52,7 +52,7 @@ __host__ __device__ inline FccWs fcc_ws(void* ws, int B, int T, int N) {
 
 }  // namespace w2l
 
-#include "criterion_asg_dpp.hpp"   // N <= 31: scaled linear domain on DPP row rotations (fcc_fwd_dpp, fcc_bwd_dpp, vit_fwd_dpp, vit_bt_k)
+#include "criterion_asg_dpp.hpp"   // N <= 31: scaled linear domain on DPP row rotations (fcc_fwd_dpp, fcc_bwd_dpp, vit_fwd_dpp, vit_psi_k, vit_walk_k)
 
 namespace w2l {
 
@@ -456,7 +456,9 @@ W2L_API int w2l_fcc_forward(int B, int T, int N, int scaleMode, const float* inp
   hipStream_t s = (hipStream_t)stream;
   FccWs ws = fcc_ws(workspace, B, T, N);
   if (asg_dpp_path(N)) {
-    hipLaunchKernelGGL(fcc_fwd_dpp, dim3(B), dim3(64), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws);
+    static const bool oneWave = tune_env("W2L_FCC_1WAVE") != nullptr;   // probe: the one-wave scan (A/B)
+    if (oneWave) hipLaunchKernelGGL(fcc_fwd_dpp, dim3(B), dim3(64), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws);
+    else hipLaunchKernelGGL(fcc_fwd_dpp2, dim3(B), dim3(128), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws);
     W2L_LAUNCH_CHECK();
     // the log-domain kernel for the utterances fcc_fwd_dpp flagged (returns at once for the others)
     hipLaunchKernelGGL(fcc_fwd_small<32>, dim3(B), dim3(64), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws, (const int*)ws.redo);
@@ -481,7 +483,9 @@ W2L_API int w2l_fcc_backward(int B, int T, int N, const float* trans, const floa
   FccWs ws = fcc_ws(workspace, B, T, N);
   const bool dpp = asg_dpp_path(N);
   if (dpp) {
-    hipLaunchKernelGGL(fcc_bwd_dpp, dim3(B), dim3(64), 0, s, T, N, trans, grad, inputGrad, ws);
+    static const bool oneWave = tune_env("W2L_FCC_1WAVE") != nullptr;
+    if (oneWave) hipLaunchKernelGGL(fcc_bwd_dpp, dim3(B), dim3(64), 0, s, T, N, trans, grad, inputGrad, ws);
+    else hipLaunchKernelGGL(fcc_bwd_dpp2, dim3(B), dim3(128), 0, s, T, N, trans, grad, inputGrad, ws);
     W2L_LAUNCH_CHECK();
     hipLaunchKernelGGL(fcc_bwd_small<32>, dim3(B), dim3(64), 0, s, T, N, trans, grad, inputGrad, ws, (const int*)ws.redo);
   } else if (N <= 32)
@@ -507,8 +511,9 @@ W2L_API int w2l_fcc_backward(int B, int T, int N, const float* trans, const floa
 W2L_API size_t w2l_viterbi_workspace_size(int B, int T, int N) {
   if (B <= 0 || T <= 0 || N <= 0) return 0;
   if (N > 64) return viterbi_big_supported(B, T, N) ? viterbi_big_workspace_size(B, T, N) : 0;
-  // N <= 31: the delta rows [B][T][N] fp32 (vit_fwd_dpp -> vit_bt_k); else the back-pointer bytes of viterbi_small
-  return align_up((size_t)B * T * N * (N <= 31 ? sizeof(float) : 1), 256);
+  // N <= 31: the delta rows [B][T][N] fp32 + back-pointer bytes + composed chunk maps (vit_fwd_dpp -> vit_psi_k -> vit_walk_k);
+  // else the back-pointer bytes of viterbi_small
+  return N <= 31 ? vit_dpp_ws_bytes(B, T, N) : align_up((size_t)B * T * N, 256);
 }
 
 W2L_API int w2l_viterbi_compute(int B, int T, int N, const float* input, const float* trans,
@@ -522,7 +527,16 @@ W2L_API int w2l_viterbi_compute(int B, int T, int N, const float* input, const f
   if (asg_dpp_path(N)) {
     hipLaunchKernelGGL(vit_fwd_dpp, dim3(B), dim3(64), 0, s, T, N, input, trans, (float*)workspace);
     W2L_LAUNCH_CHECK();
-    hipLaunchKernelGGL(vit_bt_k, dim3(B), dim3(256), 0, s, T, N, trans, (const float*)workspace, path);
+    const VitBtWs bw = vit_bt_ws(workspace, B, T, N);
+    const int nC = vit_chunks(T);
+    if (nC > 0) {
+      hipLaunchKernelGGL(vit_psi_k, dim3((unsigned)nC, (unsigned)B), dim3(64), 0, s, T, N, trans, (const float*)workspace, bw);
+      W2L_LAUNCH_CHECK();
+    }
+    const int stage = (size_t)T * 32 + (size_t)nC * 36 + 64 <= (size_t)150 * 1024;   // the psi bytes of an utterance in LDS
+    const size_t shm = (((stage ? (size_t)T * 32 : 0) + (size_t)nC * 32 + 15) & ~(size_t)15) + (size_t)(nC + 1) * sizeof(int);
+    if (shm > 64 * 1024) W2L_HIP_CHECK(hipFuncSetAttribute((const void*)vit_walk_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL(vit_walk_k, dim3(B), dim3(64), shm, s, T, N, stage, (const float*)workspace, bw, path);
   } else if (N <= 32)
     hipLaunchKernelGGL(viterbi_small<32>, dim3(B), dim3(64), 0, s, T, N, input, trans, path, (unsigned char*)workspace);
   else

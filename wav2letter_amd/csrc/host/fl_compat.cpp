@@ -308,7 +308,11 @@ double clipGradNorm(const std::vector<Variable>& params, double maxNorm) {
 // RCCL gets that copy: RTLD_NOLOAD first).
 }  // namespace fl
 #include <rccl/rccl.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
+#include <atomic>
 #include <fstream>
 namespace fl {
 namespace {
@@ -321,8 +325,92 @@ struct Rccl {
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   ncclComm_t comm = nullptr;
   int rank = 0, size = 1;
+  struct ShmColl* shm = nullptr;   // the host-memory test collective (initDistributed("shm:<file>")): no RCCL involved
+  bool on() const { return comm != nullptr || shm != nullptr; }
 };
 Rccl& rccl() { static Rccl r; return r; }
+
+// ---- host-memory collective for TESTS ("host-memory fake collective"): N processes that share ONE GPU -- RCCL
+// refuses two ranks on one device -- reduce through a file in /dev/shm.  Selected explicitly by a rendezvous path of the form
+// shm:<file>; same call sites, same stream semantics as the RCCL path (the collective is ordered behind everything enqueued on
+// its stream before it, and everything enqueued after it sees the result): the stream is drained, the slice goes to the
+// rank's slot, all slots are summed IN RANK ORDER by every rank (bit-identical results on all ranks), and the sum is copied
+// back.  Not a performance path: it exists so that allReduceParameters, the bucketed event-gated CoalescingReducer, the batch
+// size reduce and the barrier of the data-parallel Train run with world_size > 1 on a one-GPU box.
+struct ShmColl {
+  struct Header { std::atomic<unsigned long long> magic; std::atomic<unsigned> arrived, generation; };
+  static constexpr unsigned long long kMagic = 0x77326c73686d3031ull;   // "w2lshm01"
+  static constexpr size_t kChunk = (size_t)4 << 20;                       // floats per rank slot (16 MiB)
+  Header* hdr = nullptr;
+  float* slots = nullptr;
+  std::vector<float> acc;
+  int rank = 0, size = 1;
+  void barrier() {
+    const unsigned gen = hdr->generation.load(std::memory_order_acquire);
+    if (hdr->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == (unsigned)size) {
+      hdr->arrived.store(0, std::memory_order_relaxed);
+      hdr->generation.store(gen + 1, std::memory_order_release);
+      return;
+    }
+    for (long spins = 0; hdr->generation.load(std::memory_order_acquire) == gen; ++spins) {
+      if (spins > 2400000) throw std::runtime_error("host-memory collective: a rank did not arrive within two minutes");
+      usleep(50);
+    }
+  }
+  void allReduce(float* p, size_t n, hipStream_t s) {
+    w2l::hipCheck(hipStreamSynchronize(s), "shm collective: drain");
+    acc.resize(std::min(n, kChunk));
+    for (size_t off = 0; off < n; off += kChunk) {
+      const size_t m = std::min(kChunk, n - off);
+      w2l::hipCheck(hipMemcpy(slots + (size_t)rank * kChunk, p + off, m * sizeof(float), hipMemcpyDeviceToHost), "shm collective: out");
+      barrier();
+      for (size_t i = 0; i < m; ++i) acc[i] = slots[i];
+      for (int r = 1; r < size; ++r) {
+        const float* q = slots + (size_t)r * kChunk;
+        for (size_t i = 0; i < m; ++i) acc[i] += q[i];
+      }
+      barrier();   // every rank has read every slot: they may be overwritten
+      w2l::hipCheck(hipMemcpyAsync(p + off, acc.data(), m * sizeof(float), hipMemcpyHostToDevice, s), "shm collective: in");
+      w2l::hipCheck(hipStreamSynchronize(s), "shm collective: in");
+    }
+  }
+};
+ShmColl* shmOpen(const std::string& file, int rank, int size) {
+  const size_t bytes = 4096 + (size_t)size * ShmColl::kChunk * sizeof(float);
+  int fd = -1;
+  if (rank == 0) {
+    (void)unlink(file.c_str());
+    fd = open(file.c_str(), O_RDWR | O_CREAT | O_EXCL, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) throw std::runtime_error("host-memory collective: cannot create " + file);
+  } else {
+    for (int tries = 0; tries < 1200 && fd < 0; ++tries) {   // up to two minutes
+      fd = open(file.c_str(), O_RDWR);
+      struct stat st;
+      if (fd >= 0 && (fstat(fd, &st) != 0 || (size_t)st.st_size < bytes)) { close(fd); fd = -1; }
+      if (fd < 0) usleep(100000);
+    }
+    if (fd < 0) throw std::runtime_error("host-memory collective: " + file + " did not appear");
+  }
+  void* base = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (base == MAP_FAILED) throw std::runtime_error("host-memory collective: mmap failed");
+  auto* c = new ShmColl;
+  c->hdr = (ShmColl::Header*)base;
+  c->slots = (float*)((char*)base + 4096);
+  c->rank = rank; c->size = size;
+  if (rank == 0) {
+    c->hdr->arrived.store(0); c->hdr->generation.store(0);
+    c->hdr->magic.store(ShmColl::kMagic, std::memory_order_release);
+  } else {
+    for (long spins = 0; c->hdr->magic.load(std::memory_order_acquire) != ShmColl::kMagic; ++spins) {
+      if (spins > 1200) throw std::runtime_error("host-memory collective: rank 0 never initialised " + file);
+      usleep(100000);
+    }
+  }
+  c->barrier();
+  if (rank == 0) (void)unlink(file.c_str());   // everybody has it mapped: nothing stale survives the run
+  return c;
+}
 void ncclCheck(ncclResult_t st, const char* what) {
   if (st != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(st) : "RCCL error"));
 }
@@ -330,10 +418,16 @@ template <class F> void bindSym(void* lib, const char* name, F& f) {
   f = (F)dlsym(lib, name);
   if (!f) throw std::runtime_error(std::string("librccl.so lacks ") + name);
 }
+// one all-reduce(sum) of p[0..n) ordered on stream s, through whichever backend is up
+void collectiveSum(float* p, size_t n, hipStream_t s) {
+  Rccl& r = rccl();
+  if (r.shm) { r.shm->allReduce(p, n, s); return; }
+  ncclCheck(r.AllReduce(p, p, n, ncclFloat32, ncclSum, r.comm, s), "ncclAllReduce");
+}
 void allReduceRaw(float* p, size_t n, double scale) {
   Rccl& r = rccl();
-  if (!r.comm || !n) return;   // (a communicator of ONE rank still goes through RCCL: the plumbing is what a 1-GPU box can test)
-  ncclCheck(r.AllReduce(p, p, n, ncclFloat32, ncclSum, r.comm, (hipStream_t)S()), "ncclAllReduce");
+  if (!r.on() || !n) return;   // (a communicator of ONE rank still goes through RCCL: the plumbing is what a 1-GPU box can test)
+  collectiveSum(p, n, (hipStream_t)S());
   if (scale != 1.0) w2l::w2lCheck(w2l_axpy(p, p, n, (float)(scale - 1.0), S()), "allReduce scale");
 }
 }  // namespace
@@ -346,11 +440,11 @@ void allReduce(af::array& arr, double scale) {
 }
 void allReduce(Variable& var, double scale) { allReduce(var.array(), scale); }
 void allReduceParameters(const std::shared_ptr<const Module>& module) {
-  if (!rccl().comm) return;
+  if (!rccl().on()) return;
   for (auto& p : module->params()) allReduceRaw(p.array().device<float>(), (size_t)p.elements(), 1.0 / rccl().size);
 }
 void barrier() {
-  if (!rccl().comm) return;
+  if (!rccl().on()) return;
   static std::shared_ptr<void> one = devAlloc(sizeof(float));
   w2l::hipCheck(hipMemsetAsync(one.get(), 0, sizeof(float), (hipStream_t)S()), "barrier");
   allReduceRaw((float*)one.get(), 1, 1.0);
@@ -410,14 +504,14 @@ void CoalescingReducer::finalize() {
   std::vector<ArenaInfo> arenas;
   for (auto& sp : spans_) {
     ArenaInfo ai;
-    if (rccl().comm && findArena(sp.ptr, ai)) {
+    if (rccl().on() && findArena(sp.ptr, ai)) {
       bool seen = false;
       for (auto& a : arenas) seen = seen || a.net == ai.net;
       if (!seen) arenas.push_back(ai);
       continue;
     }
     allReduceRaw(sp.ptr, sp.n, scale_);
-    if (rccl().comm) ++lastCollectives_;
+    if (rccl().on()) ++lastCollectives_;
   }
   spans_.clear();
   Rccl& r = rccl();
@@ -433,7 +527,7 @@ void CoalescingReducer::finalize() {
     for (size_t k = offs.size(); k-- > 0;) {
       const size_t lo = offs[k], hi = k + 1 < offs.size() ? offs[k + 1] : ai.floats;
       w2l::hipCheck(hipStreamWaitEvent(cs, arenaBucketEvent(ai.net, k), 0), "bucket wait");
-      ncclCheck(r.AllReduce(ai.base + lo, ai.base + lo, hi - lo, ncclFloat32, ncclSum, r.comm, cs), "ncclAllReduce");
+      collectiveSum(ai.base + lo, hi - lo, cs);
       ++lastCollectives_;
       ++lastOverlapped_;
     }
@@ -448,12 +542,18 @@ namespace pkg {
 namespace runtime {
 void initDistributed(int worldRank, int worldSize, int maxDevicesPerNode, const std::string& rndvFilepath) {
   Rccl& r = rccl();
-  if (r.comm) throw std::runtime_error("initDistributed called twice");
+  if (r.on()) throw std::runtime_error("initDistributed called twice");
   if (worldSize < 1 || worldRank < 0 || worldRank >= worldSize) throw std::invalid_argument("initDistributed: bad rank / world size");
   int ndev = 0;
   w2l::hipCheck(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
   const int perNode = std::max(1, std::min(maxDevicesPerNode > 0 ? maxDevicesPerNode : ndev, ndev));
   w2l::hipCheck(hipSetDevice(worldRank % perNode), "hipSetDevice");
+  if (rndvFilepath.rfind("shm:", 0) == 0) {   // the host-memory test collective: ranks may share a device
+    r.shm = shmOpen(rndvFilepath.substr(4), worldRank, worldSize);
+    r.rank = worldRank;
+    r.size = worldSize;
+    return;
+  }
   r.lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
   if (!r.lib) r.lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
   if (!r.lib) r.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
@@ -594,8 +694,11 @@ class PlannedNet : public fl::Sequential {
     c.params = (float*)paramArena_.get(); c.grads = (float*)gradArena_.get();
     c.bf16 = mixed_;
     if (inputs.size() >= 2 && !inputs[1].isempty()) {  // inputSizes (1, B): padding mask of the Transformer blocks
-      if (inputs[1].type() != af::f32 || inputs[1].elements() != B) throw std::invalid_argument("network forward: inputSizes must be f32 (1, B)");
+      // (1, B + 1): the extra entry is the size the T input frames correspond to -- a batch padded beyond its longest utterance
+      if (inputs[1].type() != af::f32 || (inputs[1].elements() != B && inputs[1].elements() != B + 1))
+        throw std::invalid_argument("network forward: inputSizes must be f32 (1, B)");
       c.inputSizes = inputs[1].array().device<float>();
+      if (inputs[1].elements() == B + 1) c.inputSizeFull = c.inputSizes + B;
       c.inputT = T;
     }
     const int prevMode = mixed_ ? w2l_set_matmul_precision(1) : 0;

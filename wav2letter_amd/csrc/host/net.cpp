@@ -957,7 +957,7 @@ class TransformerLayer : public Layer {
     const int* keyLen = nullptr;
     if (cx.inputSizes) {  // padding mask of the keys (cpc/SequentialBuilder.cpp:58-81, TransformerCPC.cpp:138-144)
       int* kl = (int*)(ar + klOff);
-      w2lCheck(w2l_attn_key_lengths(cx.inputSizes, B, cx.inputT, T, kl, s), "tr key lengths");
+      w2lCheck(w2l_attn_key_lengths_full(cx.inputSizes, cx.inputSizeFull, B, cx.inputT, T, kl, s), "tr key lengths");
       keyLen = kl;
     }
     const float scale = (float)(1.0 / std::sqrt((double)d));

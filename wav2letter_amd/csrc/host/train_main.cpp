@@ -117,6 +117,24 @@ struct ListData {
   std::unique_ptr<fl::lib::audio::Mfsc> mfsc;
   af::array unit;                               // LayerNorm (gamma, beta) = (1, 0): the per-utterance normalisation
   long batches() const { return ((long)mine.size() + batch - 1) / batch; }
+  // the batch an update trains on: every epoch walks this rank's batches in a fresh order, the SAME order on every rank (the
+  // global batch g stays the union of the ranks' batches g), a function of (--seed, epoch) only so that `continue` resumes on the
+  // batch the uninterrupted run would have taken (the reference reshuffles per epoch with the epoch as seed:
+  // loadPrefetchDataset(trainset, nthread, true /*shuffle*/, curEpoch), recipes/slimIPL/src/Train.cpp:1183)
+  uint64_t shuffleSeed = 0;
+  mutable long permEpoch = -1;
+  mutable std::vector<long> perm;
+  long batchOfUpdate(long update) const {   // update = 1, 2, ...
+    const long nb = batches(), epoch = (update - 1) / nb, pos = (update - 1) % nb;
+    if (epoch != permEpoch) {
+      perm.resize((size_t)nb);
+      for (long i = 0; i < nb; ++i) perm[(size_t)i] = i;
+      std::mt19937_64 g(0x9E3779B97F4A7C15ull * (shuffleSeed + 1) + (uint64_t)epoch);
+      for (long i = nb - 1; i > 0; --i) std::swap(perm[(size_t)i], perm[(size_t)(g() % (uint64_t)(i + 1))]);   // (std::shuffle is not portable across libraries)
+      permEpoch = epoch;
+    }
+    return perm[(size_t)pos];
+  }
 
   // host half of a batch: decoded audio + target rows.  Prepared AHEAD of the step by `nthread` decode threads (the reference's
   // --nthread prefetch workers, Train.cpp:331): a LibriSpeech batch is 32 FLAC files x ~10 ms each
@@ -160,18 +178,18 @@ struct ListData {
   // batch k -> features (T, NFEAT, 1, B) on the device, zero beyond every utterance's own frames; targets [B][L] (-1 padded);
   // sizes [B] in samples.  Returns B (the last batch of an epoch may be short).  The NEXT batch's files are decoded in the
   // background while the caller trains on this one.
-  int get(long k, af::array& input, std::vector<int>& tgt, int& L, std::vector<float>& sizes, int& T) {
+  int get(long k, long kNext, af::array& input, std::vector<int>& tgt, int& L, std::vector<float>& sizes, int& T) {
     std::shared_ptr<HostBatch> hb;
     if (pending.valid() && pendingK == k) hb = pending.get();
     else { if (pending.valid()) pending.get(); hb = decode(k); }
-    pendingK = (k + 1) % batches();
+    pendingK = kNext;
     pending = std::async(std::launch::async, [this]() { return decode(pendingK); });
     if (!hb->error.empty()) throw std::runtime_error(hb->error);
     const int B = (int)hb->audio.size();
     const int S = mfsc->frameStride();
     auto& audio = hb->audio;
     auto& rows = hb->rows;
-    sizes = hb->sizes;
+    sizes = hb->sizes;   // (+ one entry below: the sample count the T padded frames stand for)
     long nsMax = 0;
     L = 1;
     for (int b = 0; b < B; ++b) {
@@ -183,6 +201,9 @@ struct ListData {
     Tb = (Tb + padFrames - 1) / padFrames * padFrames;
     const long ns = (long)(Tb - 1) * S + mfsc->frameSize();
     const long nsP = (ns + S - 1) / S * S;
+    // T is rounded up beyond the longest utterance: the Transformer blocks' padding mask must divide by what T frames span, not by
+    // the longest utterance (the reference pads to the longest only; cpc/SequentialBuilder.cpp:58-81)
+    sizes.push_back((float)ns);
     std::vector<float> host((size_t)B * nsP, 0.f);
     for (int b = 0; b < B; ++b) memcpy(host.data() + (size_t)b * nsP, audio[(size_t)b].data(), audio[(size_t)b].size() * sizeof(float));
     af::array dev(af::dim4(nsP, B), host.data());
@@ -407,6 +428,7 @@ int main(int argc, char** argv) {
       if (!lexPath.empty() && fileExists(lexPath)) data.lexicon = fl::lib::text::loadWords(lexPath, (int)flags.geti("maxword", -1));
       data.nFeat = nFeat;
       data.batch = batch;
+      data.shuffleSeed = seed;
       data.rate = (int)flags.geti("samplerate", 16000);
       data.padFrames = (int)flags.geti("w2l_pad_frames", 64);
       data.nthread = (int)flags.geti("nthread", 6);
@@ -549,7 +571,7 @@ int main(int argc, char** argv) {
       if (haveLists) {
         af::array feats;
         std::vector<float> sizes;
-        curB = data.get((curBatch - 1) % data.batches(), feats, ht, curL, sizes, curT);
+        curB = data.get(data.batchOfUpdate(curBatch), data.batchOfUpdate(curBatch + 1), feats, ht, curL, sizes, curT);
         for (int b = 0; b < curB; ++b) {
           long len = 0;
           while (len < curL && ht[(size_t)b * curL + len] >= 0) ++len;
@@ -557,7 +579,7 @@ int main(int argc, char** argv) {
           tszMax = std::max<long>(tszMax, len);
         }
         input = fl::input(feats);
-        inputSizes = af::array(af::dim4(1, curB), sizes.data());
+        inputSizes = af::array(af::dim4(1, (af::dim_t)sizes.size()), sizes.data());   // curB sizes + the padded length
         if (curBatch <= 2 && !flags.get("w2l_dump_features", "").empty()) {   // debugging aid: [B][NFEAT][T] float32 of the first two batches
           std::vector<float> hf((size_t)feats.elements());
           feats.host(hf.data());

@@ -82,6 +82,7 @@ struct Ctx {
   float* grads = nullptr;
   const float* inputSizes = nullptr;  // device [B] (any unit) or null: padding mask of the Transformer blocks
   int inputT = 0;                     // frames of the padded network input the sizes refer to
+  const float* inputSizeFull = nullptr;  // device scalar or null: the size inputT frames correspond to (a batch padded beyond its longest utterance)
   bool bf16 = false;                  // mixed precision: the fl::Linear products run on bf16 operand images (gemm_bf16g.hpp)
 };
 

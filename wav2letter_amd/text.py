@@ -79,7 +79,7 @@ def create_token_dict(tokens, criterion: str, replabel: int = 0) -> Dictionary:
 def load_lexicon(source, max_words: int = -1) -> Dict[str, List[List[str]]]:
     """`word<TAB or space>tok tok ...` per line; a word may appear on several lines (n-best spellings, all kept, in file order).
     `max_words` is the reference's second argument of loadWords(FLAGS_lexicon, FLAGS_maxword): at most that many distinct words
-    are kept (-1: all)"""
+    are kept (-1: all); reading stops at the first new word beyond the limit, as the reference's loop does"""
     lines = open(source).read().splitlines() if isinstance(source, str) else list(source)
     lex: Dict[str, List[List[str]]] = {}
     for line in lines:
@@ -87,7 +87,7 @@ def load_lexicon(source, max_words: int = -1) -> Dict[str, List[List[str]]]:
         if len(parts) < 2:
             continue
         if parts[0] not in lex and 0 <= max_words <= len(lex):
-            continue
+            break
         lex.setdefault(parts[0], []).append(parts[1:])
     return lex
 
