@@ -332,6 +332,97 @@ def test_transformer_block_at_config5_width_bf16(oracle):
         assert cos > 0.995 and l2 < 0.08, (name, cos, l2)
 
 
+def _transformer_ctc_arch_no_dropout():
+    import re
+    from wav2letter_amd import recipes
+    arch = re.sub(r"^DO [0-9.]+$", "DO 0.0", recipes.transformer_ctc_arch(), flags=re.M)
+    return re.sub(r"^(TR \d+ \d+ \d+ \d+) [0-9.]+ [0-9.]+$", r"\1 0.0 0.0", arch, flags=re.M)
+
+
+def _config5_case(rng):
+    nfeat, nlabel, B, T, L = 80, 9998, 2, 296, 6
+    x = rng.normal(size=(B, 1, nfeat, T)).astype(np.float32)
+    tgt = np.full((B, L), -1, np.int32)
+    tgt[0, :6] = [17, 4021, 9996, 3, 3, 77]
+    tgt[1, :2] = [9000, 12]
+    return nfeat, nlabel, B, T, L, x, tgt
+
+
+def test_transformer_ctc_config5_full_network_end_to_end(oracle):
+    """BASELINE config 5 in fp32 -- the full sota/2019 Transformer-CTC recipe network (am_transformer_ctc.arch: three WN-conv +
+    GLU + max-pool stages, 24 `TR 1024 4096 4 460` blocks, Linear to 9998 word pieces; 323 M parameters with the position
+    tables) -- at a reduced batch and number of frames (T = 296 -> 37 frames in the blocks), dropout and layer drop off:
+    emissions, CTC loss and every parameter gradient against the reference-layout interpreter (oracle/refnet.py with the
+    float64 Transformer block of oracle/transformer_oracle.py) + the CTC oracle.  24 ReLU MLPs deep: the gradient bar is the
+    deep-network one (direction and size of every tensor; the strict bar where no kink lies between tensor and loss), as
+    for configs 2 and 3."""
+    rng = np.random.default_rng(51)
+    nfeat, nlabel, B, T, L, x, tgt = _config5_case(rng)
+    arch = _transformer_ctc_arch_no_dropout()
+    tr, ref, params, _ = build(arch, nfeat, nlabel, "ctc", 4, 0.0, rng, B, T, L)
+    xd = torch.tensor(x.reshape(B, nfeat, T)).cuda()
+    td = torch.tensor(tgt).cuda()
+    em = tr.forward(xd, train=False).cpu().numpy()
+    em_ref = ref.forward(x, params)
+    assert em.shape == em_ref.shape == (B, 37, nlabel)
+    assert rel(em, em_ref) < TOL
+    loss = tr.forward_backward(xd, td).cpu().numpy()
+    o = oracle.CTC(em_ref, tgt, scale_mode=4)
+    assert rel(loss, o.forward()) < TOL
+    want = ref.backward(o.backward().astype(np.float32), len(params))
+    g = tr.grads.cpu().numpy()
+    table = tr.param_table()
+    n_strict = 0
+    for i, (name, _n, _off) in enumerate(table):
+        got = np.asarray(tr.export_from(i, g), np.float64).reshape(-1)
+        w = np.asarray(want[i], np.float64).reshape(-1)
+        if name == "tr.wk.b":   # exactly zero (softmax ignores a per-query constant): compared on the scale of the query bias
+            assert np.abs(got).max() < 1e-3 * max(1e-30, np.abs(np.asarray(want[i - 2])).max()), (i, name)   # (measured: 1e-4 of it, rounding noise)
+            continue
+        l2 = np.linalg.norm(got - w) / max(1e-30, np.linalg.norm(w))
+        cos = float(got @ w) / max(1e-30, np.linalg.norm(got) * np.linalg.norm(w))
+        assert l2 < 0.1 and cos > 0.99, (i, name, l2, cos)
+        n_strict += rel(got, w) < 2 * TOL
+    assert n_strict >= len(table) // 2, (n_strict, len(table))   # most tensors sit at the strict bar; the rest carry a flipped kink
+
+
+def test_transformer_ctc_config5_full_network_bf16(oracle):
+    """the same network in the mixed-precision mode (BASELINE config 5's dtype) against the UNROUNDED float64 restatement at the
+    stated bf16 bars: emissions / loss 2e-2 of the largest magnitude (24 blocks of bf16 products), parameter gradients by
+    direction and size (cosine > 0.97, relative L2 < 25 %; a deep bf16 network agrees with any second implementation only
+    statistically -- tests/test_gpu_trainer.py::test_streaming_tds_config3_bf16_against_bf16_operand_oracle); the exactness of
+    the bf16 products is held per operator and by the one-block test above"""
+    rng = np.random.default_rng(51)
+    nfeat, nlabel, B, T, L, x, tgt = _config5_case(rng)
+    arch = _transformer_ctc_arch_no_dropout()
+    tr, ref, params, _ = build(arch, nfeat, nlabel, "ctc", 4, 0.0, rng, B, T, L)
+    tr.set_mixed_precision(True)
+    xd = torch.tensor(x.reshape(B, nfeat, T)).cuda()
+    td = torch.tensor(tgt).cuda()
+    em = tr.forward(xd, train=False).cpu().numpy()
+    em_ref = ref.forward(x, params)
+    assert rel(em, em_ref) < 2e-2
+    assert rel(em, em_ref) > 1e-6          # the bf16 path really ran
+    loss = tr.forward_backward(xd, td).cpu().numpy()
+    o = oracle.CTC(em_ref, tgt, scale_mode=4)
+    assert rel(loss, o.forward()) < 2e-2
+    want = ref.backward(o.backward().astype(np.float32), len(params))
+    g = tr.grads.cpu().numpy()
+    for i, (name, _n, _off) in enumerate(tr.param_table()):
+        if name == "tr.wk.b":
+            continue
+        got = np.asarray(tr.export_from(i, g), np.float64).reshape(-1)
+        w = np.asarray(want[i], np.float64).reshape(-1)
+        assert np.isfinite(got).all()
+        if w.size <= 2:
+            continue   # LayerNorm (gain, offset): two sums over every activation with heavy cancellation
+        l2 = np.linalg.norm(got - w) / max(1e-30, np.linalg.norm(w))
+        cos = float(got @ w) / max(1e-30, np.linalg.norm(got) * np.linalg.norm(w))
+        # measured (profiles/r04_run13_config5_tests.log): the worst tensor is a block's position table, relative L2 0.21, cosine 0.984
+        lim = (0.25, 0.97) if w.size > 1000 else (0.35, 0.95)
+        assert l2 < lim[0] and cos > lim[1], (i, name, l2, cos)
+
+
 def test_transformer_padding_mask_from_input_sizes(oracle):
     """a ragged batch: the trainer is given the utterances' input sizes and every Transformer block masks the padded keys
     (forwardSequentialModuleWithPadMask, cpc/SequentialBuilder.cpp:58-81; TransformerCPC.cpp:138-144) -- emissions, CTC loss

@@ -384,7 +384,8 @@ int main(int argc, char** argv) {
       reducer = std::make_shared<fl::CoalescingReducer>(1.0, true, true);
       fl::allReduceParameters(network);     // replicas start identical
       fl::allReduceParameters(criterion);
-      std::cout << "[Distributed] world rank " << fl::getWorldRank() << " of " << fl::getWorldSize() << " (RCCL)" << std::endl;
+      std::cout << "[Distributed] world rank " << fl::getWorldRank() << " of " << fl::getWorldSize()
+                << (flags.get("rndv_filepath", "").rfind("shm:", 0) == 0 ? " (host-memory test collective)" : " (RCCL)") << std::endl;
     }
     const bool isMaster = fl::getWorldRank() == 0;
     if (haveRunDir && isMaster) {
@@ -446,6 +447,13 @@ int main(int argc, char** argv) {
     }
     std::mt19937_64 rng(2026 + seed + 7919ull * (uint64_t)fl::getWorldRank());   // every rank draws its own shard of the (synthetic) minibatch
     std::normal_distribution<float> gauss(0.f, 1.f);
+    // --w2l_synth_emulate_world=W (one process): the batch is the concatenation of the shards W ranks of --batchsize / W would
+    // draw -- the reference run a data-parallel run of W ranks must reproduce (tests)
+    const int emuWorld = (int)flags.geti("w2l_synth_emulate_world", 1);
+    if (emuWorld < 1 || batch % emuWorld) throw std::invalid_argument("--w2l_synth_emulate_world must divide --batchsize");
+    std::vector<std::mt19937_64> emuRng;
+    std::vector<std::normal_distribution<float>> emuGauss((size_t)emuWorld, std::normal_distribution<float>(0.f, 1.f));
+    for (int r = 0; r < emuWorld; ++r) emuRng.emplace_back(2026 + seed + 7919ull * (uint64_t)r);
     const int nTok = criterionName == "ctc" ? numClasses - 1 : std::max(1, numClasses - (int)flags.geti("replabel", 0));
     std::vector<float> hx((size_t)batch * nFeat * T);
     std::vector<int> ht((size_t)batch * Lmax);
@@ -529,7 +537,16 @@ int main(int argc, char** argv) {
       const std::string mine = getRunFile("rng." + std::to_string(fl::getWorldRank()), runIdx, runPath);
       if (!isMaster) { std::ofstream f(mine); f << rs.str(); }
       if (fl::getWorldSize() > 1) fl::barrier();
-      if (!isMaster) return;
+      if (!isMaster) {
+        if (flags.getb("w2l_save_all_ranks", false)) {   // tests: the replica of a rank other than 0 (the replicas must stay in step)
+          mkdirs(runPath);
+          Serializer::Config rc;
+          rc["nbupdates"] = std::to_string(totalUpdates);
+          Serializer::save(getRunFile("model_last.bin.rank" + std::to_string(fl::getWorldRank()), runIdx, runPath), "0.1", rc, network, criterion,
+                           netoptim, critoptim);
+        }
+        return;
+      }
       Serializer::Config config;
       config["gflags"] = gflagsText;
       config["epoch"] = std::to_string(epoch);
@@ -589,22 +606,29 @@ int main(int argc, char** argv) {
           df.write((const char*)hf.data(), (std::streamsize)(hf.size() * 4));
         }
       } else {
-      for (auto& v : hx) v = gauss(rng);
-      for (int b = 0; b < batch; ++b) {
-        const int lo = criterionName == "ctc" ? 20 : 60;
-        const int len = lo + (int)(rng() % (uint64_t)std::max(1, Lmax - lo + 1));
-        int prev = -1;
-        for (int i = 0; i < Lmax; ++i) {
-          int y = -1;
-          if (i < len) {
-            y = (int)(rng() % (uint64_t)nTok);
-            if (criterionName == "asg" && y == prev) y = (y + 1) % nTok;  // replabel convention: no identical neighbours
-            prev = y;
+      const int shard = batch / emuWorld;
+      for (int r = 0; r < emuWorld; ++r) {   // (emuWorld = 1: this rank's own stream)
+        auto& rg = emuWorld > 1 ? emuRng[(size_t)r] : rng;
+        auto& gs = emuWorld > 1 ? emuGauss[(size_t)r] : gauss;
+        float* hxr = hx.data() + (size_t)r * shard * nFeat * T;
+        for (size_t k = 0; k < (size_t)shard * nFeat * T; ++k) hxr[k] = gs(rg);
+        for (int bb = 0; bb < shard; ++bb) {
+          const int b = r * shard + bb;
+          const int lo = criterionName == "ctc" ? 20 : 60;
+          const int len = lo + (int)(rg() % (uint64_t)std::max(1, Lmax - lo + 1));
+          int prev = -1;
+          for (int i = 0; i < Lmax; ++i) {
+            int y = -1;
+            if (i < len) {
+              y = (int)(rg() % (uint64_t)nTok);
+              if (criterionName == "asg" && y == prev) y = (y + 1) % nTok;  // replabel convention: no identical neighbours
+              prev = y;
+            }
+            ht[(size_t)b * Lmax + i] = y;
           }
-          ht[(size_t)b * Lmax + i] = y;
+          tszTotal += len;
+          tszMax = std::max<long>(tszMax, len);
         }
-        tszTotal += len;
-        tszMax = std::max<long>(tszMax, len);
       }
       input = fl::input(af::array(af::dim4(T, nFeat, 1, batch), hx.data()));
       inputSizes = af::constant(T, af::dim4(1, batch));
