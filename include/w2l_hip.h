@@ -199,6 +199,11 @@ int w2l_gemm_bf16(int M, int N, int K, const uint16_t* A, int lda, const uint16_
 /* `groups` (1 .. 4) products of ONE shape in one launch, C_g [M][N] = A_g . B_g^T (+ bias_g): the tiles of all problems share the
  * persistent grid (a Transformer block's four C x C weight gradients at M = 3008 frames are 64 tiles each -- a quarter of the chip
  * one at a time).  A, B, C, bias are HOST arrays of device pointers (bias, or single entries of it, may be NULL). */
+/* the same with k-MAJOR operands read in place: aKMajor -> A stored [K][lda] (lda >= M), bKMajor -> B stored [K][ldb] (ldb >= N);
+ * lda / ldb multiples of 8, bases 16-byte aligned; rows k >= K are not read.  x^T dy from the row-major images of x and dy,
+ * x w from the row-major image of w: no transposed bf16 image of either operand */
+int w2l_gemm_bf16_ex(int M, int N, int K, const uint16_t* A, int lda, int aKMajor, const uint16_t* B, int ldb, int bKMajor, float* C,
+                     int ldc, const float* bias, int relu, const w2l_gemm_epilogue* e, w2l_stream_t stream);
 int w2l_gemm_bf16_grouped(int groups, int M, int N, int K, const uint16_t* const* A, int lda, const uint16_t* const* B, int ldb,
                           float* const* C, int ldc, const float* const* bias, w2l_stream_t stream);
 int w2l_colsum(const float* x, float* out, size_t M, int N, w2l_stream_t stream); /* bias grads */

@@ -844,6 +844,37 @@ def test_gemm_bf16_operand_storage(M, N, K):
     assert rel(ops.gemm_bf16(Ab, Bb, K, bias=bias, relu=True), np.maximum(wb, 0)) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 100), (1200, 1200, 11968), (1520, 1200, 3000), (300, 2160, 2160), (11968, 1200, 1200),
+                                   (64, 9998, 2160), (1024, 1024, 3008), (40, 24, 8)])
+def test_gemm_bf16_k_major_operands(M, N, K):
+    """round 4: the bf16 GEMM reads k-MAJOR operands in place (A stored [K][M], B stored [K][N]: the row-major image of an
+    activation as the operand of a weight gradient x^T dy, the row-major image of a weight as the B operand of x w) through the
+    LDS transpose read -- no transposed bf16 image.  All four operand combinations against the k-contiguous kernel on the
+    transposed copies of the SAME bf16 values: the MFMA sequence is the same, so the results must be BIT-IDENTICAL; and against
+    the float64 product of the rounded operands at 2e-5."""
+    from wav2letter_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + 3 * N + 7 * K)
+    A = torch.randn(M, K, generator=g).cuda()
+    B = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    Ab, _ = ops.bf16_convert(A)                     # [M][Kp], zero padded
+    Bb, _ = ops.bf16_convert(B)
+    M8, N8 = (M + 7) // 8 * 8, (N + 7) // 8 * 8
+    At = torch.zeros(K, M8, dtype=torch.bfloat16, device="cuda")      # k-major: [K][M], row stride a multiple of 8
+    At[:, :M] = Ab[:, :K].T
+    Bt = torch.zeros(K, N8, dtype=torch.bfloat16, device="cuda")
+    Bt[:, :N] = Bb[:, :K].T
+    base = ops.gemm_bf16(Ab, Bb, K)
+    want = (_bf16_ref(A) @ _bf16_ref(B).T).cpu().numpy()
+    assert rel(base, want) < 2e-5
+    for ta, tb in ((True, True), (True, False), (False, True)):
+        got = ops.gemm_bf16_ex(At if ta else Ab, Bt if tb else Bb, M, N, K, a_kmajor=ta, b_kmajor=tb)
+        assert rel(got, want) < 2e-5, (ta, tb)
+        assert torch.equal(got, base), (ta, tb, float((got - base).abs().max()))
+    got = ops.gemm_bf16_ex(At, Bt, M, N, K, a_kmajor=True, b_kmajor=True, bias=bias, relu=True)
+    assert rel(got, np.maximum(want + bias.double().cpu().numpy(), 0)) < 2e-5
+
+
 @pytest.mark.parametrize("B,T,Cin,Cout,kw,padl,padr", [(2, 50, 80, 64, 3, 1, 1), (3, 37, 32, 48, 5, 2, 2), (2, 40, 512, 1024, 3, 1, 1),
                                                        (2, 33, 64, 96, 7, 0, 0), (1, 90, 48, 32, 13, 12, 0)])
 def test_conv_overlapping_rows_bf16_mode(B, T, Cin, Cout, kw, padl, padr):

@@ -108,6 +108,7 @@ class _SIGS:
     w2l_bf16_convert_multi = (_i, [_i, _p, _p])
     w2l_bf16_convert_dropout = (_i, [_p, _sz, _i, _sz, _p, _sz, _p, _sz, _d, _u32, _u32, _p])
     w2l_gemm_bf16 = (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p])
+    w2l_gemm_bf16_ex = (_i, [_i, _i, _i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _i, _p, _p])
     w2l_gemm_bf16_grouped = (_i, [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p])
     w2l_tds_conv_bf16_image_elems = (_sz, [_p])
     w2l_tds_conv_bf16_prepare = (_i, [_p, _p, _p, _p, _p])

@@ -15,8 +15,8 @@
 //   ctc_scan       two wavefronts per utterance, side by side: the alpha scan and
 //                  the beta scan over the 2L+1 extended labels in the scaled
 //                  linear domain (fp64 mantissas, one power-of-two exponent per
-//                  lane: no exp / log on the dependency chain); the alpha wave
-//                  also writes the loss.
+//                  lattice position: no exp / log on the dependency chain); the
+//                  alpha wave also writes the loss.
 //   ctc_rows_grad  one workgroup per row: grad = g*(softmax(x) - occupancy):
 //                  streams x once more, writes grad once, then subtracts the
 //                  <= 2L+1 occupancies gamma[t][s] = exp(alpha+beta-lp-logZ) of
@@ -36,34 +36,36 @@ struct CtcWs {
                   //             100+ nats below the row's normaliser keeps a finite probability (fp32 exp flushes below -87)
   double* alpha;  // [B][T][S]
   double* beta;   // [B][T][S]   (beta includes p_t(s), as alpha does)
-  int* eA;        // [B][T][64]  lane exponents of the alpha mantissas
-  int* eB;        // [B][T][64]
+  int* eA;        // [B][T][S]   power-of-two exponents of the alpha mantissas (one per lattice position)
+  int* eB;        // [B][T][S]
   double* zhat;   // [B]  Z = zhat * 2^ez
   int* ez;        // [B]
   float* scale;   // [B]
   float* nll;     // [B]  (-log likelihood, unscaled)
-  int S;          // 2L+1 for the padded L
+  int S;          // row stride of the per-position arrays: 64 * P >= 2 L + 1
   int P;          // lattice positions per lane of the scans
 };
 
 __host__ __device__ inline int ctc_positions_per_lane(int L) {
   const int S = 2 * L + 1;
-  return S <= 128 ? 2 : S <= 256 ? 4 : S <= 512 ? 8 : S <= 1024 ? 16 : 32;
+  // (a step of the scans costs instructions per position: no more positions per lane than the lattice needs)
+  return S <= 128 ? 2 : S <= 192 ? 3 : S <= 256 ? 4 : S <= 320 ? 5 : S <= 384 ? 6 : S <= 512 ? 8 : S <= 1024 ? 16 : 32;
 }
 
 __host__ __device__ inline CtcWs ctc_ws(void* ws, int B, int T, int N, int L) {
   (void)N;
   CtcWs w;
-  w.S = 2 * L + 1;
   w.P = ctc_positions_per_lane(L);
+  w.S = 64 * w.P;   // row stride of the per-position arrays: every lane's P positions lie inside a row (positions >= 2 L_b + 1 hold
+                    // p = 0, written by the row kernels), rows are 16-byte aligned: the scans move whole lanes with vector accesses
   char* p = (char*)ws;
   w.lse = (float*)p; p += align_up((size_t)B * T * sizeof(float), 256);
   w.lp = (float*)p; p += align_up((size_t)B * T * w.S * sizeof(float), 256);
   w.pd = (double*)p; p += align_up((size_t)B * T * w.S * sizeof(double), 256);
   w.alpha = (double*)p; p += align_up((size_t)B * T * w.S * sizeof(double), 256);
   w.beta = (double*)p; p += align_up((size_t)B * T * w.S * sizeof(double), 256);
-  w.eA = (int*)p; p += align_up((size_t)B * T * 64 * sizeof(int), 256);
-  w.eB = (int*)p; p += align_up((size_t)B * T * 64 * sizeof(int), 256);
+  w.eA = (int*)p; p += align_up((size_t)B * T * w.S * sizeof(int), 256);
+  w.eB = (int*)p; p += align_up((size_t)B * T * w.S * sizeof(int), 256);
   w.zhat = (double*)p; p += align_up((size_t)B * sizeof(double), 256);
   w.ez = (int*)p; p += align_up((size_t)B * sizeof(int), 256);
   w.scale = (float*)p; p += align_up((size_t)B * sizeof(float), 256);
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(kRowThreads) void ctc_rows_lse(int T, int N, int L,
     lp[si] = l;
     pd[si] = exp_wide(l);
   }
+  for (int si = S + tid; si < ws.S; si += kRowThreads) pd[si] = 0.0;   // positions beyond the utterance's lattice: p = 0
 }
 
 // generic-N fallback (N > 256*kRowMaxPer): two passes over the row
@@ -199,27 +202,29 @@ __global__ __launch_bounds__(kRowThreads) void ctc_rows_lse_big(int T, int N, in
     lp[si] = l;
     pd[si] = exp_wide(l);
   }
+  for (int si = S + tid; si < ws.S; si += kRowThreads) pd[si] = 0.0;   // positions beyond the utterance's lattice: p = 0
 }
 
 // ---- alpha / beta lattice scans in the SCALED LINEAR domain -----------------------------------------------------------
-// alpha_t(s) = (alpha_{t-1}(s) + alpha_{t-1}(s-1) + [skip] alpha_{t-1}(s-2)) * p_t(s) in fp64, every LANE carrying its own
-// power-of-two exponent for the P consecutive lattice positions it owns (value = mantissa * 2^e, renormalised every step to
-// a lane maximum in [1, 2)).  Against the log-domain recursion this
-//   * takes the transcendentals OFF the dependency chain: p_t(s) = exp(lp) is one hardware v_exp_f32 per element in the
-//     prefetch stage; a step is adds, one multiply and v_ldexp_f64 -- no exp / log per position and step;
-//   * removes the accumulated rounding of T dependent fp32 log-sum-exp corrections (round 3, run j1 / j3: 1e-4 .. 2e-4 of
-//     the gradient at 700 .. 1100 frames; the hardware exp / log round faithfully, not to nearest, so their error adds up
-//     linearly): sums and products are fp64, the only fp32 quantities are lp and exp(lp), each used once per path factor;
-//   * keeps the log domain's dynamic range where it matters: positions interact with their two lower (alpha) / upper
-//     (beta) neighbours only, and a neighbour lane's values are brought to this lane's exponent with v_ldexp_f64 -- a
-//     contribution 2^-1074 below the receiving lane's own scale is lost, nothing else (a single per-utterance scale would
-//     flush an improbable-so-far prefix that the rest of the utterance makes the only feasible path).
-// One wavefront per (utterance, direction): blockIdx.y = 0 alpha, 1 beta; lane l owns positions l P .. l P + P - 1.
-// Stored: the mantissas alpha^[t][s], beta^[t][s] (fp64) and the lane exponents eA[t][lane], eB[t][lane]; both scans
-// include p_t(s), so the occupancy is gamma_t(s) = alpha^ beta^ / (p z^) * 2^(eA + eB - ez), taken in ctc_rows_grad.
+// alpha_t(s) = (alpha_{t-1}(s) + alpha_{t-1}(s-1) + [skip] alpha_{t-1}(s-2)) * p_t(s) in fp64, every lattice POSITION carrying its
+// own power-of-two exponent (value = mantissa * 2^e, mantissa in [0.5, 1) after every step).  Against the log-domain recursion this
+//   * takes the transcendentals OFF the dependency chain: p_t(s) = exp(lp) comes as an fp64 value from the row kernel (exp_wide:
+//     no underflow); a step is three v_ldexp_f64, two adds, one multiply and a v_frexp pair per position -- no exp / log;
+//   * removes the accumulated rounding of T dependent fp32 log-sum-exp corrections: sums and products are fp64;
+//   * keeps the log domain's dynamic range: the three inputs of a position are brought to their largest exponent with
+//     v_ldexp_f64 -- a contribution 2^-1074 below the largest of the three is lost, nothing else.
+// Round 4: one exponent per POSITION instead of one per lane (round 3).  A wave that is alone on its SIMD issues one instruction
+// every ~6.5 cycles (tools/micro/clock_probe.hip), and the per-lane-exponent step -- align the neighbour lane, align the own
+// positions, renormalise the lane -- was ~155 instructions at two positions per lane (0.43 us per frame); this one is ~45.
+// One wavefront per (utterance, direction): blockIdx.y = 0 alpha, 1 beta; lane l owns positions l P .. l P + P - 1; the two
+// lower (alpha) / upper (beta) neighbours of a lane's first / last position come by DPP from the neighbouring lane.
+// Stored per position: mantissa (fp64) and exponent of alpha and of beta; both scans include p_t(s), so the occupancy is
+// gamma_t(s) = alpha^ beta^ / (p z^) * 2^(eA + eB - ez), taken in ctc_rows_grad.  Rows are stored a chunk of D steps at a time,
+// BEHIND the consumption of the prefetched p values (a store in flight in front of a loaded register's first use makes hipcc
+// wait for its round trip).
 __device__ __forceinline__ int dpp_up_i32(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ int dpp_down_i32(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }
-constexpr int kCtcNoExp = -(1 << 28);   // exponent of a lane that holds no mass yet
+constexpr int kCtcNoExp = -(1 << 28);   // exponent of a position that holds no mass
 
 template <int P, int D>
 __global__ __launch_bounds__(64) void ctc_scan(int T, int N, int L, int scaleMode,
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(64) void ctc_scan(int T, int N, int L, int scaleMod
   const int* y = target + (size_t)b * L;
   const double* pd = ws.pd + (size_t)b * T * SW;
   double* lat = (isBeta ? ws.beta : ws.alpha) + (size_t)b * T * SW;
-  int* lex = (isBeta ? ws.eB : ws.eA) + (size_t)b * T * 64;
+  int* lex = (isBeta ? ws.eB : ws.eA) + (size_t)b * T * SW;
 
   bool skip[P];   // alpha: position s may be entered from s - 2; beta: position s may go to s + 2
 #pragma unroll
@@ -251,108 +256,119 @@ __global__ __launch_bounds__(64) void ctc_scan(int T, int N, int L, int scaleMod
       skip[p] = (si < S) && (si & 1) && si + 2 < S && e0 != ep2;
     }
   }
-  // frame order of this scan: alpha walks t = 0 .. T-1, beta t = T-1 .. 0
-  auto frame = [&](int k) { return isBeta ? T - 1 - k : k; };
-  auto prob = [&](int k, int si) -> double { return (k < T && si < S) ? pd[(size_t)frame(k) * SW + si] : 0.0; };
+  // frame order of this scan: alpha walks t = 0 .. T-1, beta t = T-1 .. 0.  Every lane moves its P consecutive positions of a
+  // row with 16-byte vector accesses (rows are 64 P positions wide: no bounds, p = 0 beyond the lattice), and the row addresses
+  // advance by a constant stride per step -- the per-access index arithmetic was a third of the step's instructions
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  typedef int i2_t __attribute__((ext_vector_type(2)));
+  const long rstride = isBeta ? -(long)SW : (long)SW;
+  const long row0 = (long)(isBeta ? T - 1 : 0) * SW + (long)lane * P;
+  const d2_t* pdp = (const d2_t*)(pd + row0);   // p of step k at pdp + k * rstride (in doubles: / 2 vectors)
+  d2_t* latp = (d2_t*)(lat + row0);
+  i2_t* lexp = (i2_t*)(lex + row0);
+  auto loadp = [&](double (&dst)[P], int k) {
+    const double* q1 = (const double*)pdp + (long)k * rstride;
+    if constexpr (P % 2 == 0) {
+      const d2_t* q = (const d2_t*)q1;
+#pragma unroll
+      for (int p = 0; p < P; p += 2) { const d2_t v = k < T ? q[p / 2] : d2_t{0.0, 0.0}; dst[p] = v[0]; dst[p + 1] = v[1]; }
+    } else {   // odd P: a lane's positions are 8-byte aligned only
+#pragma unroll
+      for (int p = 0; p < P; ++p) dst[p] = k < T ? q1[p] : 0.0;
+    }
+  };
+  auto storerow = [&](const double (&mv)[P], const int (&ev)[P], int k) {
+    double* q1 = (double*)latp + (long)k * rstride;
+    int* qe1 = (int*)lexp + (long)k * rstride;
+    if constexpr (P % 2 == 0) {
+      d2_t* q = (d2_t*)q1;
+      i2_t* qe = (i2_t*)qe1;
+#pragma unroll
+      for (int p = 0; p < P; p += 2) { q[p / 2] = d2_t{mv[p], mv[p + 1]}; qe[p / 2] = i2_t{ev[p], ev[p + 1]}; }
+    } else {
+#pragma unroll
+      for (int p = 0; p < P; ++p) { q1[p] = mv[p]; qe1[p] = ev[p]; }
+    }
+  };
 
   // ---- first frame: alpha_0(s) = p_0(s) for s < 2; beta_{T-1}(s) = p_{T-1}(s) for s >= S - 2
-  double a[P];
-  int ex = kCtcNoExp;
+  double m[P];
+  int e[P];
   {
-    double m = 0.0;
+    double p0[P];
+    loadp(p0, 0);
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int si = lane * P + p;
       const bool on = si < S && (isBeta ? si >= S - 2 : si < 2);
-      a[p] = on ? prob(0, si) : 0.0;
-      m = fmax(m, a[p]);
+      const double h = on ? p0[p] : 0.0;
+      m[p] = __builtin_amdgcn_frexp_mant(h);
+      e[p] = h > 0.0 ? __builtin_amdgcn_frexp_exp(h) : kCtcNoExp;
     }
-    if (m > 0.0) {
-      const int e = __builtin_amdgcn_frexp_exp(m) - 1;
-      ex = e;
-#pragma unroll
-      for (int p = 0; p < P; ++p) a[p] = ldexp(a[p], -e);
-    }
-    double* row = lat + (size_t)frame(0) * SW;
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int si = lane * P + p;
-      if (si < S) row[si] = a[p];
-    }
-    lex[(size_t)frame(0) * 64 + lane] = ex;
+    storerow(m, e, 0);
   }
 
   double pc[D][P], pn[D][P];   // p of steps k0 .. k0 + D - 1 (current chunk) and of the next chunk
 #pragma unroll
+  for (int u = 0; u < D; ++u) loadp(pc[u], 1 + u);
+#pragma unroll
   for (int u = 0; u < D; ++u)
 #pragma unroll
-    for (int p = 0; p < P; ++p) pc[u][p] = prob(1 + u, lane * P + p);
+    for (int p = 0; p < P; ++p) asm volatile("" : "+v"(pc[u][p]));   // landed before the loop: no load pending at its head (a pending load
+                                                                     // there makes hipcc wait vmcnt(0) at every step's first use)
   for (int k0 = 1; k0 < T; k0 += D) {
 #pragma unroll
-    for (int u = 0; u < D; ++u)
-#pragma unroll
-      for (int p = 0; p < P; ++p) pn[u][p] = prob(k0 + D + u, lane * P + p);
+    for (int u = 0; u < D; ++u) loadp(pn[u], k0 + D + u);
+    double sm[D][P];   // this chunk's rows: stored after the chunk
+    int se[D][P];
 #pragma unroll
     for (int u = 0; u < D; ++u) {
       const int k = k0 + u;
+#pragma unroll
+      for (int p = 0; p < P; ++p) { sm[u][p] = 0.0; se[u][p] = kCtcNoExp; }
       if (k < T) {
-        // the neighbour lane's two boundary values and its exponent (alpha: lane - 1's last two; beta: lane + 1's first two)
-        double n1, n2;
-        int exn;
+        // the neighbour lane's two boundary positions (alpha: lane - 1's last two; beta: lane + 1's first two)
+        double n1m, n2m;
+        int n1e, n2e;
         if (!isBeta) {
-          n1 = lane_shift_up_dpp(a[P - 1], 0.0);
-          n2 = lane_shift_up_dpp(a[P - 2], 0.0);
-          exn = dpp_up_i32(ex, kCtcNoExp);
+          n1m = lane_shift_up_dpp(m[P - 1], 0.0); n1e = dpp_up_i32(e[P - 1], kCtcNoExp);
+          n2m = lane_shift_up_dpp(m[P - 2], 0.0); n2e = dpp_up_i32(e[P - 2], kCtcNoExp);
         } else {
-          n1 = lane_shift_down_dpp(a[0], 0.0);
-          n2 = lane_shift_down_dpp(a[1], 0.0);
-          exn = dpp_down_i32(ex, kCtcNoExp);
+          n1m = lane_shift_down_dpp(m[0], 0.0); n1e = dpp_down_i32(e[0], kCtcNoExp);
+          n2m = lane_shift_down_dpp(m[1], 0.0); n2e = dpp_down_i32(e[1], kCtcNoExp);
         }
-        const bool nbOn = (n1 != 0.0 || n2 != 0.0) && exn != kCtcNoExp;
-        const int eb = ex > (nbOn ? exn : kCtcNoExp) ? ex : exn;   // common exponent of this step (kCtcNoExp: nothing anywhere)
-        double na[P];
-        double m = 0.0;
-        if (eb != kCtcNoExp) {
-          const int dOwn = ex == kCtcNoExp ? 0 : ex - eb, dNb = nbOn ? exn - eb : 0;
-          double o[P];
-#pragma unroll
-          for (int p = 0; p < P; ++p) o[p] = ldexp(a[p], dOwn);
-          n1 = nbOn ? ldexp(n1, dNb) : 0.0;
-          n2 = nbOn ? ldexp(n2, dNb) : 0.0;
-#pragma unroll
-          for (int p = 0; p < P; ++p) {
-            double v1, v2;   // the position one / two steps towards the neighbour lane
-            if (!isBeta) {
-              v1 = p >= 1 ? o[p >= 1 ? p - 1 : 0] : n1;
-              v2 = p >= 2 ? o[p >= 2 ? p - 2 : 0] : (p == 1 ? n1 : n2);
-            } else {
-              v1 = p + 1 < P ? o[p + 1 < P ? p + 1 : 0] : n1;
-              v2 = p + 2 < P ? o[p + 2 < P ? p + 2 : 0] : (p + 1 < P ? n1 : n2);
-            }
-            const double sum = (o[p] + v1) + (skip[p] ? v2 : 0.0);
-            na[p] = sum * pc[u][p];     // p = 0 beyond S: stays zero
-            m = fmax(m, na[p]);
-          }
-        }
-        if (m > 0.0) {
-          const int e = __builtin_amdgcn_frexp_exp(m) - 1;
-#pragma unroll
-          for (int p = 0; p < P; ++p) a[p] = ldexp(na[p], -e);
-          ex = eb + e;
-        } else {
-#pragma unroll
-          for (int p = 0; p < P; ++p) a[p] = 0.0;
-          ex = kCtcNoExp;
-        }
-        double* row = lat + (size_t)frame(k) * SW;
+        double nm[P];
+        int ne[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-          const int si = lane * P + p;
-          if (si < S) row[si] = a[p];
+          double m1, m2;   // the position one / two steps towards the neighbour lane
+          int e1, e2;
+          if (!isBeta) {
+            m1 = p >= 1 ? m[p >= 1 ? p - 1 : 0] : n1m;                       e1 = p >= 1 ? e[p >= 1 ? p - 1 : 0] : n1e;
+            m2 = p >= 2 ? m[p >= 2 ? p - 2 : 0] : (p == 1 ? n1m : n2m);      e2 = p >= 2 ? e[p >= 2 ? p - 2 : 0] : (p == 1 ? n1e : n2e);
+          } else {
+            m1 = p + 1 < P ? m[p + 1 < P ? p + 1 : 0] : n1m;                 e1 = p + 1 < P ? e[p + 1 < P ? p + 1 : 0] : n1e;
+            m2 = p + 2 < P ? m[p + 2 < P ? p + 2 : 0] : (p + 1 < P ? n1m : n2m);
+            e2 = p + 2 < P ? e[p + 2 < P ? p + 2 : 0] : (p + 1 < P ? n1e : n2e);
+          }
+          if (!skip[p]) e2 = kCtcNoExp;   // (2^28 below everything: the term shifts out to exactly 0)
+          const int E = max(max(e[p], e1), e2);
+          const double sum = (__builtin_amdgcn_ldexp(m[p], e[p] - E) + __builtin_amdgcn_ldexp(m1, e1 - E)) + __builtin_amdgcn_ldexp(m2, e2 - E);
+          const double h = sum * pc[u][p];     // p = 0 beyond S: stays zero
+          nm[p] = __builtin_amdgcn_frexp_mant(h);
+          ne[p] = h > 0.0 ? E + __builtin_amdgcn_frexp_exp(h) : kCtcNoExp;
         }
-        lex[(size_t)frame(k) * 64 + lane] = ex;
+#pragma unroll
+        for (int p = 0; p < P; ++p) { m[p] = nm[p]; e[p] = ne[p]; sm[u][p] = nm[p]; se[u][p] = ne[p]; }
       }
     }
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+#pragma unroll
+      for (int p = 0; p < P; ++p) asm volatile("" : "+v"(pn[u][p]));   // consumed BEFORE the chunk's stores are issued
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+      if (k0 + u < T) storerow(sm[u], se[u], k0 + u);
 #pragma unroll
     for (int u = 0; u < D; ++u)
 #pragma unroll
@@ -361,16 +377,20 @@ __global__ __launch_bounds__(64) void ctc_scan(int T, int N, int L, int scaleMod
   if (isBeta) return;
 
   // ---- likelihood Z = alpha_{T-1}(S-1) + alpha_{T-1}(S-2) = zhat * 2^ez (the two positions may sit in two lanes)
-  double z = 0.0;
+  int ez = kCtcNoExp;
 #pragma unroll
   for (int p = 0; p < P; ++p) {
     const int si = lane * P + p;
-    if (si == S - 1 || si == S - 2) z += a[p];
+    if ((si == S - 1 || si == S - 2) && m[p] > 0.0) ez = max(ez, e[p]);
   }
-  int ez = z > 0.0 ? ex : kCtcNoExp;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(ez, off); ez = o > ez ? o : ez; }
-  double zs = (z > 0.0 && ez != kCtcNoExp) ? ldexp(z, ex - ez) : 0.0;
+  double zs = 0.0;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int si = lane * P + p;
+    if ((si == S - 1 || si == S - 2) && m[p] > 0.0) zs += __builtin_amdgcn_ldexp(m[p], e[p] - ez);
+  }
   zs = wave_sum_f64(zs);
   if (lane == 0) {
     const float sc = scale_of(scaleMode, T, Lb);
@@ -426,17 +446,17 @@ __global__ __launch_bounds__(kRowThreads) void ctc_rows_grad(int T, int N, int L
   const double* pdr = ws.pd + r * ws.S;
   const double* alr = ws.alpha + r * ws.S;
   const double* ber = ws.beta + r * ws.S;
-  const int* ear = ws.eA + r * 64;
-  const int* ebr = ws.eB + r * 64;
+  const int* ear = ws.eA + r * ws.S;
+  const int* ebr = ws.eB + r * ws.S;
   const double zh = ws.zhat[b];
   if (zh > 0.0) {   // an infeasible target (Z = 0) has no occupancy: its loss is +inf, its gradient g * softmax
-    const int ez = ws.ez[b], P = ws.P;
+    const int ez = ws.ez[b];
     for (int si = tid; si < S; si += kRowThreads) {
       const int lab = (si & 1) ? y[si >> 1] : (N - 1);
       const double av = alr[si], bv = ber[si];
       if (av > 0.0 && bv > 0.0) {
         const double pv = pdr[si];
-        const float v = (float)ldexp(av * bv / (pv * zh), ear[si / P] + ebr[si / P] - ez);
+        const float v = (float)ldexp(av * bv / (pv * zh), ear[si] + ebr[si] - ez);
         if (v != 0.f) atomicAdd(&out[lab], -g * v);
       }
     }
@@ -520,9 +540,9 @@ W2L_API int w2l_batch_ctc_target_size(int B, int L, int T, const int* target, in
 
 W2L_API size_t w2l_ctc_workspace_size(int B, int T, int N, int L) {
   if (B <= 0 || T <= 0 || N <= 0 || L < 0) return 0;
-  size_t S = 2 * (size_t)L + 1;
+  size_t S = 64 * (size_t)ctc_positions_per_lane(L);
   return align_up((size_t)B * T * sizeof(float), 256) + align_up((size_t)B * T * S * sizeof(float), 256) +
-         3 * align_up((size_t)B * T * S * sizeof(double), 256) + 2 * align_up((size_t)B * T * 64 * sizeof(int), 256) +
+         3 * align_up((size_t)B * T * S * sizeof(double), 256) + 2 * align_up((size_t)B * T * S * sizeof(int), 256) +
          align_up((size_t)B * sizeof(double), 256) + align_up((size_t)B * sizeof(int), 256) + 2 * align_up((size_t)B * sizeof(float), 256);
 }
 
@@ -544,7 +564,10 @@ W2L_API int w2l_ctc_forward(int B, int T, int N, int L, int scaleMode, const flo
   const dim3 grid((unsigned)B, 2), blk(64);   // (utterance, alpha | beta)
   switch (ws.P) {   // (positions per lane, prefetch depth): 2 D P floats of p_t(s) in registers
     case 2: hipLaunchKernelGGL((ctc_scan<2, 16>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws); break;
+    case 3: hipLaunchKernelGGL((ctc_scan<3, 10>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws); break;
     case 4: hipLaunchKernelGGL((ctc_scan<4, 8>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws); break;
+    case 5: hipLaunchKernelGGL((ctc_scan<5, 6>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws); break;
+    case 6: hipLaunchKernelGGL((ctc_scan<6, 5>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws); break;
     case 8: hipLaunchKernelGGL((ctc_scan<8, 4>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws); break;
     case 16: hipLaunchKernelGGL((ctc_scan<16, 2>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws); break;
     default: hipLaunchKernelGGL((ctc_scan<32, 1>), grid, blk, 0, s, T, N, L, scaleMode, target, targetSize, loss, ws); break;

@@ -328,6 +328,27 @@ W2L_API int w2l_gemm_bf16(int M, int N, int K, const uint16_t* A, int lda, const
   return launch128h(A, lda, B, ldb, o, epi, (hipStream_t)stream);
 }
 
+// the same product with k-MAJOR operands read in place (gemm_bf16g.hpp): aKMajor: A is stored [K][lda] (an activation x
+// [frames][in] as the A operand of x^T dy), bKMajor: B is stored [K][ldb] (a weight w [in][out] as the B operand of x w) --
+// no transposed bf16 image of either is needed
+W2L_API int w2l_gemm_bf16_ex(int M, int N, int K, const uint16_t* A, int lda, int aKMajor, const uint16_t* B, int ldb, int bKMajor, float* C,
+                             int ldc, const float* bias, int relu, const w2l_gemm_epilogue* e, w2l_stream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return W2L_EINVAL;
+  GemmOut o{C, bias, M, N, K, ldc, 0};
+  int epi = (bias ? EPI_BIAS : 0) | (relu ? EPI_RELU : 0);
+  if (e) {
+    if (e->mask) { o.mask = e->mask; o.maskScale = e->maskScale; epi |= EPI_MASK; }
+    if (e->addend) { o.addend = e->addend; epi |= EPI_ACCUM; }
+    else if (e->accumulate) epi |= EPI_ACCUM;
+    if (e->dropP > 0.0) {
+      o.dropThr = dropout_threshold(e->dropP); o.dropSeed = e->dropSeed; o.dropStream = e->dropStream;
+      o.dropScale = (float)(1.0 / (1.0 - e->dropP));
+      epi |= EPI_DROPOUT;
+    }
+  }
+  return launch128h(A, lda, B, ldb, o, epi, (hipStream_t)stream, 0, 0, aKMajor != 0, bKMajor != 0);
+}
+
 // `groups` (1 .. 4) products of ONE shape in one launch: C_g = A_g . B_g^T (+ bias_g); A, B, C, bias: host arrays of device pointers
 W2L_API int w2l_gemm_bf16_grouped(int groups, int M, int N, int K, const uint16_t* const* A, int lda, const uint16_t* const* B, int ldb,
                                   float* const* C, int ldc, const float* const* bias, w2l_stream_t stream) {

@@ -32,6 +32,47 @@ __device__ __forceinline__ bf16x8v_t h_frag(const float* tile, int row, int s, i
   return __builtin_bit_cast(bf16x8v_t, v);
 }
 
+// ---- k-MAJOR operands (round 4): a bf16 matrix stored [K][extent] (k is the ROW index, the MFMA row / column index i is
+// contiguous) -- an activation x [frames][in] as the A operand of a weight gradient x^T dy, a weight w [in][out] as the B operand
+// of the forward product x w -- read IN PLACE instead of from a transposed bf16 image (convert.hip wrote one per operand and
+// step: half of all conversion traffic of the mixed-precision step).
+//   * a K tile is 64 k-rows x 128 columns = 64 rows of 256 bytes; an LDS-DMA piece (1 KiB, one wave instruction) is 4 k-rows;
+//     the 16-byte chunk c of k-row k lands at chunk position c ^ (4 (k & 3)) of its row (permutation applied to the per-lane
+//     SOURCE address: the DMA destination is lane-linear);
+//   * the fragment of one v_mfma_f32_32x32x16_bf16 -- lane l: 8 consecutive k of column l & 31 -- is two ds_read_b64_tr_b16: inside
+//     each 16-lane group the lanes' 8-byte chunks form a 4 x 16 matrix (row = chunks of lanes 4 j .. 4 j + 3) and lane t receives
+//     column t (tools/micro/tr16_probe.hip, profiles/r03_run13_tr16_probe.log): lane t = 4 j + q supplies the address of
+//     [k0 + j][col0 + 4 q .. + 3], lane t receives [k0 .. k0 + 3][col0 + t].  With the permutation above the 32 lanes of a
+//     half-wave (two groups: columns col0 .. + 15 and + 16 .. + 31, the same four k-rows) touch 32 distinct 8-byte slots of
+//     the 256-byte bank row: conflict-free.
+typedef short s16x4v_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8v_t h_frag_t(const float* tile, int col0, int s, int lane) {
+  const int G = lane >> 4, t = lane & 15, j = t >> 2, q = t & 3;
+  const int k0 = 16 * s + 8 * (G >> 1) + j;                 // k-row of the first read (the second: + 4); k0 & 3 == j
+  const int col = col0 + 16 * (G & 1) + 4 * q;
+  const int chunk = (col >> 3) ^ (4 * j), half = (col >> 2) & 1;
+  const char* a0 = (const char*)tile + k0 * 256 + 16 * chunk + 8 * half;
+  const s16x4v_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v_t*)a0);
+  const s16x4v_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v_t*)(a0 + 4 * 256));
+  typedef short s16x8v_t __attribute__((ext_vector_type(8)));
+  const s16x8v_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8v_t, v);
+}
+// per-lane byte offsets of the four LDS-DMA pieces of this wave for a k-major operand: piece wave * 4 + j = k-rows 4 (wave * 4 + j) ..
+// + 4 of the K tile, lane L -> k-row + (L >> 4), chunk position L & 15 <- source chunk (L & 15) ^ (4 (L >> 4)).  op.ld in floats
+// (= bf16 elements / 2), op.extent = number of columns; a chunk that starts beyond the last column re-reads the last valid one
+// (columns past the extent are never stored)
+__device__ __forceinline__ void t_init_offs(uint32_t (&vo)[4], const GOp& op, int i0, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int kr = (wave * 4 + j) * 4 + (lane >> 4);
+    const int c = (lane & 15) ^ (4 * (lane >> 4));
+    int col = i0 + 8 * c;
+    if (col >= op.extent) col = (op.extent - 1) & ~7;
+    vo[j] = ((uint32_t)kr * (uint32_t)op.ld) * 4u + (uint32_t)col * 2u;
+  }
+}
+
 // aop / bop: bf16 matrices viewed as float matrices of half the width (p, ld in floats = bf16 elements / 2); plan.kTiles
 // counts 64-k tiles.  Same launch geometry as gemm128g_kernel.
 // GROUPED launches (GRP): up to kHMaxGroups problems of the SAME shape (own A, B, C, bias) share one persistent grid -- tile
@@ -46,7 +87,8 @@ struct HGroups {
   int n = 0, tiles = 0;      // problems, tiles per problem
 };
 
-template <bool GRP>
+// TA / TB: the operand is k-MAJOR ([K][M] / [K][N], see above) instead of k-contiguous
+template <bool GRP, bool TA = false, bool TB = false>
 __global__ __launch_bounds__(256, 2) void gemm128h_kernel(GOp aop, GOp bop, GemmOut out, SkPlan plan, int workers, int wide, HGroups grp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -54,7 +96,8 @@ __global__ __launch_bounds__(256, 2) void gemm128h_kernel(GOp aop, GOp bop, Gemm
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int li = lane & 31, lh = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(xcd_major(blockIdx.x, workers));
-  constexpr uint32_t kStepBytes = 128;   // one K tile = 64 bf16 = 128 bytes along a row
+  // one K tile = 64 bf16: 128 bytes along a row (k-contiguous operand) / 64 rows (k-major operand)
+  const uint32_t stepA = TA ? 256u * (uint32_t)aop.ld : 128u, stepB = TB ? 256u * (uint32_t)bop.ld : 128u;
 
   GSeg seg = g_pin(g_segment(plan, w, workers, 0));
   if (!seg.valid) return;
@@ -70,12 +113,12 @@ __global__ __launch_bounds__(256, 2) void gemm128h_kernel(GOp aop, GOp bop, Gemm
   __amdgpu_buffer_rsrc_t raN = ra, rbN = rb;
   int bx, by;
   sk_tile_xy(plan, seg.tile, bx, by);
-  g_init_offs<true>(va, aop, bx * 128, wave, lane);
-  g_init_offs<true>(vb, bop, by * 128, wave, lane);
+  if (TA) t_init_offs(va, aop, bx * 128, wave, lane); else g_init_offs<true>(va, aop, bx * 128, wave, lane);
+  if (TB) t_init_offs(vb, bop, by * 128, wave, lane); else g_init_offs<true>(vb, bop, by * 128, wave, lane);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    g_issue1_buf(ra, va[j], kStepBytes * (uint32_t)seg.kb, smem, wave, j);
-    g_issue1_buf(rb, vb[j], kStepBytes * (uint32_t)seg.kb, smem + 4096, wave, j);
+    g_issue1_buf(ra, va[j], stepA * (uint32_t)seg.kb, smem, wave, j);
+    g_issue1_buf(rb, vb[j], stepB * (uint32_t)seg.kb, smem + 4096, wave, j);
   }
   int stage = 0;
   __syncthreads();  // (drains the LDS-DMA: vmcnt(0) precedes the barrier)
@@ -112,17 +155,17 @@ __global__ __launch_bounds__(256, 2) void gemm128h_kernel(GOp aop, GOp bop, Gemm
       float* An = smem + (stage ^ 1) * kGStageFloats;
       // what goes to the other stage during this iteration: the next K tile, or the first K tile of the next segment, or
       // (very last iteration of this worker) a harmless re-load of this tile
-      uint32_t offA = kStepBytes * (uint32_t)kt, offB = offA;
+      uint32_t offA = stepA * (uint32_t)kt, offB = stepB * (uint32_t)kt;
       bool toNext = false;   // this iteration's pieces belong to the next segment (GRP: possibly another problem's operands)
       if (kt + 1 < seg.ke) {
-        offA += kStepBytes; offB += kStepBytes;
+        offA += stepA; offB += stepB;
       } else if (nxt.valid) {
         toNext = true;
         int nbx, nby;
         sk_tile_xy(plan, nxt.tile, nbx, nby);
-        g_init_offs<true>(va, aop, nbx * 128, wave, lane);
-        g_init_offs<true>(vb, bop, nby * 128, wave, lane);
-        offA = offB = kStepBytes * (uint32_t)nxt.kb;
+        if (TA) t_init_offs(va, aop, nbx * 128, wave, lane); else g_init_offs<true>(va, aop, nbx * 128, wave, lane);
+        if (TB) t_init_offs(vb, bop, nby * 128, wave, lane); else g_init_offs<true>(vb, bop, nby * 128, wave, lane);
+        offA = stepA * (uint32_t)nxt.kb; offB = stepB * (uint32_t)nxt.kb;
       }
       offA = (uint32_t)__builtin_amdgcn_readfirstlane((int)offA);
       offB = (uint32_t)__builtin_amdgcn_readfirstlane((int)offB);
@@ -133,18 +176,18 @@ __global__ __launch_bounds__(256, 2) void gemm128h_kernel(GOp aop, GOp bop, Gemm
         g_issue1_buf(rB, vb[j], offB, An + 4096, wave, j);
       }
       bf16x8v_t fa[2][2], fb[2][2];
-      fa[0][0] = h_frag(As, wm + li, 0, lh, li);
-      fa[0][1] = h_frag(As, wm + 32 + li, 0, lh, li);
-      fb[0][0] = h_frag(Bs, wn + li, 0, lh, li);
-      fb[0][1] = h_frag(Bs, wn + 32 + li, 0, lh, li);
+      fa[0][0] = TA ? h_frag_t(As, wm, 0, lane) : h_frag(As, wm + li, 0, lh, li);
+      fa[0][1] = TA ? h_frag_t(As, wm + 32, 0, lane) : h_frag(As, wm + 32 + li, 0, lh, li);
+      fb[0][0] = TB ? h_frag_t(Bs, wn, 0, lane) : h_frag(Bs, wn + li, 0, lh, li);
+      fb[0][1] = TB ? h_frag_t(Bs, wn + 32, 0, lane) : h_frag(Bs, wn + 32 + li, 0, lh, li);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int cur = s & 1;
         if (s < 3) {
-          fa[cur ^ 1][0] = h_frag(As, wm + li, s + 1, lh, li);
-          fa[cur ^ 1][1] = h_frag(As, wm + 32 + li, s + 1, lh, li);
-          fb[cur ^ 1][0] = h_frag(Bs, wn + li, s + 1, lh, li);
-          fb[cur ^ 1][1] = h_frag(Bs, wn + 32 + li, s + 1, lh, li);
+          fa[cur ^ 1][0] = TA ? h_frag_t(As, wm, s + 1, lane) : h_frag(As, wm + li, s + 1, lh, li);
+          fa[cur ^ 1][1] = TA ? h_frag_t(As, wm + 32, s + 1, lane) : h_frag(As, wm + 32 + li, s + 1, lh, li);
+          fb[cur ^ 1][0] = TB ? h_frag_t(Bs, wn, s + 1, lane) : h_frag(Bs, wn + li, s + 1, lh, li);
+          fb[cur ^ 1][1] = TB ? h_frag_t(Bs, wn + 32, s + 1, lane) : h_frag(Bs, wn + 32 + li, s + 1, lh, li);
         }
         // keep the order written here: left alone, hipcc funnels every fragment through ONE register quad (read, wait
         // lgkmcnt(0), two MFMAs, read, ...) and exposes an LDS round trip per MFMA pair -- seen in the ISA of both kernels
@@ -361,12 +404,17 @@ bool ksplit_enabled();   // W2L_GEMM_KSPLIT=0 (probe build) turns the aligned K 
 // row must be ZERO in both operands (convert.hip writes them so).  W2L_EUNSUPPORTED when the schedule cannot run in-kernel.
 // aView / bView (bytes; 0 = a dense image): the address range of an operand whose rows OVERLAP (row stride < Kp: the
 // convolution-as-GEMM view of conv.hip, A row m = frames m .. m + kw of the activation image) -- reads past it return zeros
+// ta / tb: the operand is k-MAJOR -- A stored [K][lda] (lda >= M), B stored [K][ldb] (ldb >= N), lda / ldb multiples of 8, base
+// 16-byte aligned; rows k >= K are never read (the buffer ends there: out-of-range loads return 0), so a k-contiguous partner's
+// zero padding is not needed on this side.  128 x 128 kernel only.
 inline int launch128h(const uint16_t* A, int lda, const uint16_t* B, int ldb, GemmOut o, int epi, hipStream_t s,
-                      unsigned long long aView = 0, unsigned long long bView = 0) {
+                      unsigned long long aView = 0, unsigned long long bView = 0, bool ta = false, bool tb = false) {
   const int Kp = (o.K + 63) / 64 * 64;
-  if ((lda & 1) || (ldb & 1) || (!aView && lda < Kp) || (!bView && ldb < Kp) || (((uintptr_t)A | (uintptr_t)B) & 3)) return W2L_EINVAL;
-  const unsigned long long ab = aView ? aView : 2ull * ((unsigned long long)(o.M - 1) * lda + Kp);
-  const unsigned long long bb = bView ? bView : 2ull * ((unsigned long long)(o.N - 1) * ldb + Kp);
+  if ((lda & 1) || (ldb & 1) || (!ta && !aView && lda < Kp) || (!tb && !bView && ldb < Kp) || (((uintptr_t)A | (uintptr_t)B) & 3)) return W2L_EINVAL;
+  if ((ta && ((lda & 7) || lda < o.M || (((uintptr_t)A) & 15) || aView)) || (tb && ((ldb & 7) || ldb < o.N || (((uintptr_t)B) & 15) || bView)))
+    return W2L_EINVAL;
+  const unsigned long long ab = ta ? 2ull * (unsigned long long)o.K * lda : aView ? aView : 2ull * ((unsigned long long)(o.M - 1) * lda + Kp);
+  const unsigned long long bb = tb ? 2ull * (unsigned long long)o.K * ldb : bView ? bView : 2ull * ((unsigned long long)(o.N - 1) * ldb + Kp);
   if (ab >= 0x7fffffffull || bb >= 0x7fffffffull) return W2L_EUNSUPPORTED;
   epi &= ~EPI_ATOMIC;
   const double flops = 2.0 * o.M * (double)o.N * o.K;
@@ -387,7 +435,7 @@ inline int launch128h(const uint16_t* A, int lda, const uint16_t* B, int ldb, Ge
   const double t1 = tiles1 <= 512 ? kt * 0.80 + 5.0 : (double)((tiles1 + 255) / 256) * (kt * (kt >= 96 ? 0.54 : 0.45) + 5.0);
   const double t2 = (double)((tiles2 + 255) / 256) * (kt * 2.0 + 8.0);
   const int mode = h256_mode();
-  const bool big = o.M >= 256 && o.N >= 256 && tiles2 < (1 << 30) && (mode == 1 || (mode < 0 && t2 < t1));
+  const bool big = !ta && !tb && o.M >= 256 && o.N >= 256 && tiles2 < (1 << 30) && (mode == 1 || (mode < 0 && t2 < t1));
   SkPlan plan;
   if (big) {
     plan = make_sk_plan(o.M, o.N, Kp / 2, false, 256, 256, kH2Slots);
@@ -434,8 +482,11 @@ inline int launch128h(const uint16_t* A, int lda, const uint16_t* B, int ldb, Ge
     hipLaunchKernelGGL(gemm256h_kernel, dim3((unsigned)workers), dim3(512), 2 * (size_t)kH2StageFloats * sizeof(float), s, ga, gb, o,
                        plan, workers, wide);
   } else {
-    hipLaunchKernelGGL(gemm128h_kernel<false>, dim3((unsigned)workers), dim3(256), 2 * (size_t)kGStageFloats * sizeof(float), s, ga, gb, o,
-                       plan, workers, wide, HGroups{});
+    const size_t shm = 2 * (size_t)kGStageFloats * sizeof(float);
+    if (ta && tb) hipLaunchKernelGGL((gemm128h_kernel<false, true, true>), dim3((unsigned)workers), dim3(256), shm, s, ga, gb, o, plan, workers, wide, HGroups{});
+    else if (ta) hipLaunchKernelGGL((gemm128h_kernel<false, true, false>), dim3((unsigned)workers), dim3(256), shm, s, ga, gb, o, plan, workers, wide, HGroups{});
+    else if (tb) hipLaunchKernelGGL((gemm128h_kernel<false, false, true>), dim3((unsigned)workers), dim3(256), shm, s, ga, gb, o, plan, workers, wide, HGroups{});
+    else hipLaunchKernelGGL(gemm128h_kernel<false>, dim3((unsigned)workers), dim3(256), shm, s, ga, gb, o, plan, workers, wide, HGroups{});
   }
   prof_end(s);
   W2L_LAUNCH_CHECK();

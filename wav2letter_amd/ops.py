@@ -230,6 +230,15 @@ def gemm_bf16(A, B, K, bias=None, relu=False, mask=None, mask_scale=1.0, addend=
     return c
 
 
+def gemm_bf16_ex(A, B, M, N, K, a_kmajor=False, b_kmajor=False, bias=None, relu=False):
+    """w2l_gemm_bf16_ex: C[M][N] fp32 = op(A) op(B)^T with k-MAJOR operands read in place: a_kmajor -> A is [K][>= M],
+    b_kmajor -> B is [K][>= N] (row strides multiples of 8 elements); otherwise as gemm_bf16"""
+    c = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    _lib.check(_lib.lib().w2l_gemm_bf16_ex(M, N, K, _p(A), A.stride(0), int(a_kmajor), _p(B), B.stride(0), int(b_kmajor), _p(c), c.stride(0),
+                                           _p(bias) if bias is not None else None, int(relu), None, _s()), "gemm_bf16_ex")
+    return c
+
+
 def gemm_bf16_grouped(As, Bs, K, biases=None):
     """w2l_gemm_bf16_grouped: [C_g = A_g . B_g^T (+ bias_g)] for up to 4 problems of one shape in one launch"""
     import ctypes as C
