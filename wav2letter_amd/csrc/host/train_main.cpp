@@ -457,6 +457,9 @@ int main(int argc, char** argv) {
     const int nTok = criterionName == "ctc" ? numClasses - 1 : std::max(1, numClasses - (int)flags.geti("replabel", 0));
     std::vector<float> hx((size_t)batch * nFeat * T);
     std::vector<int> ht((size_t)batch * Lmax);
+    const long synthPool = flags.geti("w2l_synth_pool", 0);
+    std::vector<float> hxPool;
+    std::vector<int> htPool;
     if (runStatus == "continue") {   // the sample stream goes on where the saved run stopped (per rank)
       auto it = reloadCfg.find("w2l_data_rng." + std::to_string(fl::getWorldRank()));
       if (it != reloadCfg.end()) { std::istringstream is(it->second); is >> rng >> gauss; }
@@ -606,29 +609,51 @@ int main(int argc, char** argv) {
           df.write((const char*)hf.data(), (std::streamsize)(hf.size() * 4));
         }
       } else {
-      const int shard = batch / emuWorld;
-      for (int r = 0; r < emuWorld; ++r) {   // (emuWorld = 1: this rank's own stream)
-        auto& rg = emuWorld > 1 ? emuRng[(size_t)r] : rng;
-        auto& gs = emuWorld > 1 ? emuGauss[(size_t)r] : gauss;
-        float* hxr = hx.data() + (size_t)r * shard * nFeat * T;
-        for (size_t k = 0; k < (size_t)shard * nFeat * T; ++k) hxr[k] = gs(rg);
-        for (int bb = 0; bb < shard; ++bb) {
-          const int b = r * shard + bb;
-          const int lo = criterionName == "ctc" ? 20 : 60;
-          const int len = lo + (int)(rg() % (uint64_t)std::max(1, Lmax - lo + 1));
-          int prev = -1;
-          for (int i = 0; i < Lmax; ++i) {
-            int y = -1;
-            if (i < len) {
-              y = (int)(rg() % (uint64_t)nTok);
-              if (criterionName == "asg" && y == prev) y = (y + 1) % nTok;  // replabel convention: no identical neighbours
-              prev = y;
+      // --w2l_synth_pool=K: K batches are drawn once (before the first timed update) and update u trains on batch (u - 1) % K --
+      // what a prefetching loader hides in a real run; the default draws every batch inside smp(ms) (3.8 M normal deviates)
+      auto draw = [&](float* hxd, int* htd) {
+        const int shard = batch / emuWorld;
+        for (int r = 0; r < emuWorld; ++r) {   // (emuWorld = 1: this rank's own stream)
+          auto& rg = emuWorld > 1 ? emuRng[(size_t)r] : rng;
+          auto& gs = emuWorld > 1 ? emuGauss[(size_t)r] : gauss;
+          float* hxr = hxd + (size_t)r * shard * nFeat * T;
+          for (size_t k = 0; k < (size_t)shard * nFeat * T; ++k) hxr[k] = gs(rg);
+          for (int bb = 0; bb < shard; ++bb) {
+            const int b = r * shard + bb;
+            const int lo = criterionName == "ctc" ? 20 : 60;
+            const int len = lo + (int)(rg() % (uint64_t)std::max(1, Lmax - lo + 1));
+            int prev = -1;
+            for (int i = 0; i < Lmax; ++i) {
+              int y = -1;
+              if (i < len) {
+                y = (int)(rg() % (uint64_t)nTok);
+                if (criterionName == "asg" && y == prev) y = (y + 1) % nTok;  // replabel convention: no identical neighbours
+                prev = y;
+              }
+              htd[(size_t)b * Lmax + i] = y;
             }
-            ht[(size_t)b * Lmax + i] = y;
           }
-          tszTotal += len;
-          tszMax = std::max<long>(tszMax, len);
         }
+      };
+      if (synthPool > 0) {
+        if (hxPool.empty()) {
+          sampletimer.stop(); timer.stop();
+          hxPool.resize((size_t)synthPool * hx.size());
+          htPool.resize((size_t)synthPool * ht.size());
+          for (long k = 0; k < synthPool; ++k) draw(hxPool.data() + (size_t)k * hx.size(), htPool.data() + (size_t)k * ht.size());
+          timer.resume(); sampletimer.resume();
+        }
+        const size_t slot = (size_t)((curBatch - 1) % synthPool);
+        std::memcpy(hx.data(), hxPool.data() + slot * hx.size(), hx.size() * sizeof(float));
+        std::memcpy(ht.data(), htPool.data() + slot * ht.size(), ht.size() * sizeof(int));
+      } else {
+        draw(hx.data(), ht.data());
+      }
+      for (int b = 0; b < batch; ++b) {
+        long len = 0;
+        while (len < Lmax && ht[(size_t)b * Lmax + len] >= 0) ++len;
+        tszTotal += len;
+        tszMax = std::max<long>(tszMax, len);
       }
       input = fl::input(af::array(af::dim4(T, nFeat, 1, batch), hx.data()));
       inputSizes = af::constant(T, af::dim4(1, batch));
