@@ -319,6 +319,23 @@ typedef struct {
 } w2l_attn_fused_desc;
 int w2l_attn_fused_forward(const w2l_attn_fused_desc* d, const float* q, const float* k, const float* v, const float* posTable,
                            const int* keyLen, float* P, float* Pd, float* ctx, w2l_stream_t stream);
+/* The attention core of the same block's BACKWARD pass (mixed-precision mode; attention_fused_bwd.hip): from dctx [B][T][ldc], the
+ * forward's P and its operands
+ *   dP = dctx v^T with the forward's dropout mask (recomputed from dropP / dropSeed / dropStream: Pd is not read),
+ *   dS = scale * P o (dP - rowsum(P o dP)),   dq_i = sum_j dS[i][j] (k_j + posTable[j - i + n0]),   dk_j = sum_i dS[i][j] q_i,
+ *   dv_j = sum_i Pd[i][j] dctx_i,   dPosTable[w] = sum_(b, h, i) dS[i][i + w - n0] q_i
+ * in four launches (E^T image, query side, key side, table-gradient reduce) instead of eleven.  dq, dk, dv: [B][T][ld]
+ * (overwritten); dPosTable: the whole [2 n0 + 1][d] table gradient (overwritten, zero outside the rows T frames reach; ignored
+ * when posTable is NULL).  Operands are rounded to bf16 where the unfused w2l_bgemm_bf16 sequence rounds them (dctx, v, Pd, dS, k,
+ * q, posTable); the result equals that sequence to fp32 summation order.  workspace: w2l_attn_fused_backward_workspace(d,
+ * posTable != NULL) bytes, 256-byte aligned; it holds the bf16 images dS^T / Pd^T [B H][32 NT][32 NT] (row = key, column = query,
+ * NT = ceil(T / 32) rounded up to 2, 4 or 6) first, which tests read.  The key-padding mask needs no argument: P is zero there.
+ * W2L_EUNSUPPORTED (workspace size 0) for a geometry without a fused kernel: the same set as the forward call.
+ * Replaces: the gradient of TransformerCPC.cpp:117-151 (selfAttention). */
+size_t w2l_attn_fused_backward_workspace(const w2l_attn_fused_desc* d, int withPosTable);
+int w2l_attn_fused_backward(const w2l_attn_fused_desc* d, const float* q, const float* k, const float* v, const float* posTable,
+                            const float* P, const float* dctx, float* dq, float* dk, float* dv, float* dPosTable, void* workspace,
+                            size_t workspaceBytes, w2l_stream_t stream);
 /* valid keys per utterance from the batch's input sizes (any unit), as forwardSequentialModuleWithPadMask builds the mask
  * (cpc/SequentialBuilder.cpp:58-81): n_b = ceil(size_b * Tin / max size) valid input frames, resized to Tk (nearest) */
 int w2l_attn_key_lengths(const float* inputSizes, int B, int Tin, int Tk, int* keyLen, w2l_stream_t stream);

@@ -223,6 +223,137 @@ def test_fused_attention_forward(B, H, T, d, csz, p, ragged):
         assert 0.5 * p < float((Pd == 0).float().mean()) - float((P == 0).float().mean()) < 1.5 * p
 
 
+@pytest.mark.parametrize("B,H,T,d,csz,p,ragged", [(2, 4, 188, 256, 460, 0.0, False), (2, 4, 188, 256, 460, 0.2, True),
+                                                   (1, 2, 64, 32, 7, 0.0, False), (2, 3, 130, 32, 460, 0.3, False),
+                                                   (2, 2, 33, 32, 0, 0.0, True), (3, 1, 1, 32, 2, 0.0, False),
+                                                   (1, 2, 190, 32, 40, 0.1, True), (2, 2, 96, 256, 3, 0.25, False),
+                                                   (2, 4, 37, 256, 460, 0.0, False)])
+def test_fused_attention_backward(B, H, T, d, csz, p, ragged):
+    """w2l_attn_fused_backward (dP, dropout mask, softmax backward, dq incl. the position term, dk, dv, table gradient in four
+    launches) on the P of the fused forward, against (a) the float64 restatement of the gradient of TransformerCPC.cpp:117-151 on
+    the SAME bf16-rounded operands: the kernel's dS image (read from the documented head of the workspace) at bf16 resolution
+    against the float64 dS, its Pd image bit for bit, and dq / dk / dv / dE from the kernel's own dS at 2e-5 of the largest
+    magnitude (only fp32 accumulation differs); (b) the unfused launch sequence of host/net.cpp at the bar a flipped bf16
+    rounding of one dS entry allows.  Same geometries as the forward test plus a short table (band narrower than T)."""
+    from wav2letter_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(T * 11 + d + csz)
+    Cc = H * d
+    q = torch.randn(B, T, Cc, generator=g).cuda()
+    k = torch.randn(B, T, Cc, generator=g).cuda()
+    v = torch.randn(B, T, Cc, generator=g).cuda()
+    dctx = torch.randn(B, T, Cc, generator=g).cuda()
+    E = (torch.randn(max(1, 2 * csz - 1), d, generator=g) * 0.5).cuda()
+    n0 = csz - 1
+    rlo = max(0, n0 - (T - 1)) if csz else 0
+    W = (min(2 * csz - 1, n0 + T) - rlo) if csz else 0
+    scale = 1.0 / np.sqrt(d)
+    keyLen = None
+    if ragged:
+        keyLen = torch.tensor([T] + [max(1, (T * (3 + b)) // (5 + b)) for b in range(1, B)], dtype=torch.int32).cuda()
+    seed, sid = 977, 3
+    P = torch.full((B, H, T, T), float("nan"), device="cuda")
+    Pd = torch.full((B, H, T, T), float("nan"), device="cuda")
+    ctx = torch.full((B, T, Cc), float("nan"), device="cuda")
+    D = _lib.AttnFusedDesc(B=B, H=H, T=T, d=d, ld=Cc, ldc=Cc, W=W, n0=n0, rlo=rlo, scale=scale, dropP=p, dropSeed=seed, dropStream=sid)
+    assert L.w2l_attn_fused_forward(C.byref(D), q.data_ptr(), k.data_ptr(), v.data_ptr(), E.data_ptr() if csz else None,
+                                    keyLen.data_ptr() if ragged else None, P.data_ptr(), Pd.data_ptr() if p > 0 else None,
+                                    ctx.data_ptr(), _stream()) == 0
+    if p == 0:
+        Pd = P
+    nws = L.w2l_attn_fused_backward_workspace(C.byref(D), 1 if csz else 0)
+    assert nws > 0
+    ws = torch.full((nws,), 0xff, dtype=torch.uint8, device="cuda")     # (0xffff: a bf16 NaN in every unwritten slot)
+    dq = torch.full((B, T, Cc), float("nan"), device="cuda")
+    dk = torch.full((B, T, Cc), float("nan"), device="cuda")
+    dv = torch.full((B, T, Cc), float("nan"), device="cuda")
+    dE = torch.full((max(1, 2 * csz - 1), d), float("nan"), device="cuda")
+    st = L.w2l_attn_fused_backward(C.byref(D), q.data_ptr(), k.data_ptr(), v.data_ptr(), E.data_ptr() if csz else None, P.data_ptr(),
+                                   dctx.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dE.data_ptr() if csz else None,
+                                   ws.data_ptr(), nws, _stream())
+    assert st == 0
+    assert L.w2l_attn_fused_backward(C.byref(D), q.data_ptr(), k.data_ptr(), v.data_ptr(), E.data_ptr() if csz else None, P.data_ptr(),
+                                     dctx.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dE.data_ptr() if csz else None,
+                                     ws.data_ptr(), nws - 1, _stream()) != 0      # a short workspace is refused
+    for t_ in (dq, dk, dv):
+        assert torch.isfinite(t_).all()
+    # (a) float64 on bf16-rounded operands
+    r = lambda x: x.bfloat16().double()
+    heads = lambda x: x.reshape(B, T, H, d).permute(0, 2, 1, 3)
+    qh, kh, vh, dch = heads(r(q)), heads(r(k)), heads(r(v)), heads(r(dctx))
+    ks = 1.0 / (1.0 - p)
+    dP = dch @ vh.transpose(-1, -2)
+    if p > 0:
+        dP = dP * (Pd != 0).double() * ks
+    P64 = P.double()
+    dS64 = scale * P64 * (dP - (P64 * dP).sum(-1, keepdim=True))
+    nt = (T + 31) // 32
+    TP = 32 * (2 if nt <= 2 else 4 if nt <= 4 else 6)
+    img = ws[:2 * B * H * TP * TP * 2].view(torch.bfloat16).view(2, B, H, TP, TP)
+    dSk = img[0, :, :, :T, :T].transpose(-1, -2).double()          # the kernel's dS, [query][key]
+    assert rel(dSk.cpu().numpy(), dS64.cpu().numpy()) < 4.2e-3     # bf16: 2^-8 of the largest entry
+    assert torch.equal(img[1, :, :, :T, :T].transpose(-1, -2), Pd.bfloat16())
+    if TP > T:
+        assert float(img[0, :, :, T:, :T].float().abs().max()) == 0.0 and float(img[1, :, :, T:, :T].float().abs().max()) == 0.0   # padded key rows
+    dq_ref = dSk @ kh
+    dk_ref = dSk.transpose(-1, -2) @ qh
+    dv_ref = r(Pd).transpose(-1, -2) @ dch
+    dE_ref = torch.zeros(max(1, 2 * csz - 1), d, dtype=torch.float64, device="cuda")
+    if csz:
+        Er = r(E)
+        for delta in range(-(T - 1), T):
+            w = delta + n0
+            if not 0 <= w < 2 * csz - 1:
+                continue
+            diag = dSk.diagonal(offset=delta, dim1=-2, dim2=-1)    # [B][H][n]: entries (i, i + delta)
+            lo = max(0, -delta)
+            n = diag.shape[-1]
+            dq_ref[:, :, lo:lo + n] += diag[..., None] * Er[w]
+            dE_ref[w] += (diag[..., None] * qh[:, :, lo:lo + n]).sum((0, 1, 2))
+    unheads = lambda x: x.permute(0, 2, 1, 3).reshape(B, T, Cc)
+    assert rel(dq.cpu().numpy(), unheads(dq_ref).cpu().numpy()) < 2e-5
+    assert rel(dk.cpu().numpy(), unheads(dk_ref).cpu().numpy()) < 2e-5
+    assert rel(dv.cpu().numpy(), unheads(dv_ref).cpu().numpy()) < 2e-5
+    if csz:
+        assert torch.isfinite(dE).all()
+        assert rel(dE.cpu().numpy(), dE_ref.cpu().numpy()) < 2e-5
+        if rlo > 0:
+            assert float(dE[:rlo].abs().max()) == 0.0             # rows no frame pair reaches
+    # (b) the unfused sequence (host/net.cpp before this kernel)
+    TC, TT = T * Cc, T * T
+    dS2 = torch.full((B, H, T, T), float("nan"), device="cuda")
+    G = _lib.BgemmDesc(M=T, N=T, K=d, G1=B, G2=H, sam=Cc, sak=1, a1=TC, a2=d, sbk=1, sbn=Cc, b1=TC, b2=d, ldc=T, c1=H * TT, c2=TT)
+    assert L.w2l_bgemm_bf16(C.byref(G), dctx.data_ptr(), v.data_ptr(), dS2.data_ptr(), _stream()) == 0
+    dv2 = torch.full((B, T, Cc), float("nan"), device="cuda")
+    G = _lib.BgemmDesc(M=T, N=d, K=T, G1=B, G2=H, sam=1, sak=T, a1=H * TT, a2=TT, sbk=Cc, sbn=1, b1=TC, b2=d, ldc=Cc, c1=TC, c2=d)
+    assert L.w2l_bgemm_bf16(C.byref(G), Pd.data_ptr(), dctx.data_ptr(), dv2.data_ptr(), _stream()) == 0
+    if p > 0:
+        assert L.w2l_dropout_inplace(dS2.data_ptr(), B * H * TT, p, seed, sid, _stream()) == 0
+    ldr = (W + 3) // 4 * 4
+    dR = torch.full((B * T * H, max(ldr, 4)), float("nan"), device="cuda")
+    assert L.w2l_attn_softmax_backward(P.data_ptr(), dS2.data_ptr(), dR.data_ptr() if csz else None, B, H, T, ldr, rlo, W, n0, scale,
+                                       _stream()) == 0
+    assert rel(dSk.cpu().numpy(), dS2.cpu().numpy()) < 4.2e-3
+    dq2 = torch.full((B, T, Cc), float("nan"), device="cuda")
+    G = _lib.BgemmDesc(M=T, N=d, K=T, G1=B, G2=H, sam=T, sak=1, a1=H * TT, a2=TT, sbk=Cc, sbn=1, b1=TC, b2=d, ldc=Cc, c1=TC, c2=d)
+    assert L.w2l_bgemm_bf16(C.byref(G), dS2.data_ptr(), k.data_ptr(), dq2.data_ptr(), _stream()) == 0
+    dk2 = torch.full((B, T, Cc), float("nan"), device="cuda")
+    G = _lib.BgemmDesc(M=T, N=d, K=T, G1=B, G2=H, sam=1, sak=T, a1=H * TT, a2=TT, sbk=Cc, sbn=1, b1=TC, b2=d, ldc=Cc, c1=TC, c2=d)
+    assert L.w2l_bgemm_bf16(C.byref(G), dS2.data_ptr(), q.data_ptr(), dk2.data_ptr(), _stream()) == 0
+    if csz:
+        G = _lib.BgemmDesc(M=B * T * H, N=d, K=W, G1=1, G2=1, sam=ldr, sak=1, sbk=d, sbn=1, ldc=d, accumulate=1)
+        assert L.w2l_bgemm_bf16(C.byref(G), dR.data_ptr(), E[rlo:].data_ptr(), dq2.data_ptr(), _stream()) == 0
+        dEp = torch.full((B, W, d), float("nan"), device="cuda")
+        G = _lib.BgemmDesc(M=W, N=d, K=T * H, G1=B, G2=1, sam=1, sak=ldr, a1=T * H * ldr, sbk=d, sbn=1, b1=T * Cc, ldc=d, c1=W * d)
+        assert L.w2l_bgemm_bf16(C.byref(G), dR.data_ptr(), q.data_ptr(), dEp.data_ptr(), _stream()) == 0
+        dE2 = torch.zeros(2 * csz - 1, d, device="cuda")
+        assert L.w2l_colsum(dEp.data_ptr(), dE2[rlo:].data_ptr(), B, W * d, _stream()) == 0
+        assert rel(dE.cpu().numpy(), dE2.cpu().numpy()) < 1e-3
+    assert rel(dv.cpu().numpy(), dv2.cpu().numpy()) < 2e-5
+    assert rel(dq.cpu().numpy(), dq2.cpu().numpy()) < 1e-3
+    assert rel(dk.cpu().numpy(), dk2.cpu().numpy()) < 1e-3
+
+
 @pytest.mark.parametrize("B,H,T,d,csz", [(2, 4, 188, 256, 460), (3, 2, 50, 32, 30), (2, 3, 130, 20, 460), (1, 1, 7, 8, 3), (2, 2, 64, 16, 10)])
 def test_banded_position_products_bf16(B, H, T, d, csz):
     """the two relative-position products of the attention backward on the bf16 batched GEMM with the BAND of the skewed score

@@ -426,25 +426,40 @@ def test_transformer_ctc_config5_full_network_bf16(oracle):
     assert rel(loss, o.forward()) < 2e-2
     want = ref.backward(o.backward().astype(np.float32), len(params))
     g = tr.grads.cpu().numpy()
+    # the attention's q / k path (see the fp32 test above: its gradients are 1e-5 .. 1e-6 of the block's at initialisation, the rest
+    # cancels): with bf16 operands the cancellation leaves bf16 rounding of the COMMON-MODE operands -- up to 750 x the tensor's own
+    # size in the last block, identically with the fused attention backward and with the unfused launch sequence
+    # (profiles/r04_run19_c5_qk_noise.log) -- so those tensors are held on the scale of the block's gradients (its wv.w) at 5e-3
+    # (measured 4e-4), every other tensor on its own scale
+    qk_path = {"tr.posemb", "tr.wq.w", "tr.wq.b", "tr.wk.w", "tr.wk.b"}
+    table = tr.param_table()
     fails = []
     worst = {}
-    for i, (name, _n, _off) in enumerate(tr.param_table()):
-        if name == "tr.wk.b":
-            continue
+    for i, (name, _n, _off) in enumerate(table):
         got = np.asarray(tr.export_from(i, g), np.float64).reshape(-1)
         w = np.asarray(want[i], np.float64).reshape(-1)
         assert np.isfinite(got).all()
         if w.size <= 2:
             continue   # LayerNorm (gain, offset): two sums over every activation with heavy cancellation
+        if name in qk_path:
+            j = i
+            while table[j][0] != "tr.wv.w":
+                j += 1
+            err = np.abs(got - w).max() / np.abs(np.asarray(want[j])).max()
+            if not err < 5e-3:
+                fails.append((i, name, "block scale", err))
+            if err > worst.get(name, (0, 0))[0]:
+                worst[name] = (err, 0.0)
+            continue
         l2 = np.linalg.norm(got - w) / max(1e-30, np.linalg.norm(w))
         cos = float(got @ w) / max(1e-30, np.linalg.norm(got) * np.linalg.norm(w))
-        # measured (profiles/r04_run13_config5_tests.log): the worst tensor is a block's position table, relative L2 0.21, cosine 0.984
-        lim = (0.25, 0.97) if w.size > 1000 else (0.35, 0.95)
+        lim = (0.25, 0.97) if w.size > 1000 else (0.35, 0.95)   # measured: 0.13 / 0.9915 (profiles/r04_run19_c5_qk_noise.log)
         if not (l2 < lim[0] and cos > lim[1]):
             fails.append((i, name, l2, cos))
         if l2 > worst.get(name, (0, 0))[0]:
             worst[name] = (l2, cos)
-    print("config 5 bf16, worst relative L2 / cosine per tensor kind:", {k: (round(v[0], 3), round(v[1], 4)) for k, v in worst.items()})
+    print("config 5 bf16, worst relative L2 / cosine per tensor kind (q / k path: error on the block's scale):",
+          {k: (float("%.3g" % v[0]), round(v[1], 4)) for k, v in worst.items()})
     assert not fails, (len(fails), fails[:12])
 
 

@@ -140,6 +140,8 @@ class _SIGS:
     w2l_bgemm_bf16 = (_i, [_p, _p, _p, _p, _p])
     w2l_attn_softmax_forward = (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p])
     w2l_attn_fused_forward = (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p])
+    w2l_attn_fused_backward_workspace = (_sz, [_p, _i])
+    w2l_attn_fused_backward = (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p])
     w2l_attn_key_lengths = (_i, [_p, _i, _i, _i, _p, _p])
     w2l_attn_key_lengths_full = (_i, [_p, _p, _i, _i, _i, _p, _p])
     w2l_attn_softmax_backward = (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p])

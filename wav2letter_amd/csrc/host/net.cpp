@@ -849,8 +849,9 @@ class TransformerLayer : public Layer {
   int B = 0, T = 0, M = 0, W = 0, rlo = 0, ldr = 0, n0 = 0;
   size_t qOff, kOff, vOff, sOff, pdOff, rOff, ctxOff, oOff, hOff, uOff, m2Off, outOff, st1Off, mr1Off, st2Off, mr2Off;
   size_t ds2Off, duOff, dhOff, dr1Off, dctxOff, dsOff, dRoff, dqOff, dkOff, dvOff, dxOff, dEpOff, klOff;
+  size_t abwOff = 0, abwBytes = 0;   // workspace of the fused attention backward (0: geometry without a fused kernel)
   const float* xSaved = nullptr;
-  bool dropped = false;
+  bool dropped = false, fusedFwd = false;
   // mixed precision: the six fl::Linear of the block on bf16 images (the attention products stay on the fp32 batched GEMM)
   BfLinear blq, blk, blv, blf, bl1, bl2;
   BfImage xImg, ctxImg, hImg, uImg, dqImg, dkImg, dvImg, dr1Img, duImg, ds2Img;
@@ -902,10 +903,22 @@ class TransformerLayer : public Layer {
     dsOff = pl.alloc(ns); dRoff = pl.alloc(nr); dqOff = pl.alloc(n); dkOff = pl.alloc(n); dvOff = pl.alloc(n); dxOff = pl.alloc(n);
     dEpOff = pl.alloc((size_t)B * W * d);
     klOff = pl.alloc((size_t)B);
+    {
+      const w2l_attn_fused_desc fd = fusedDesc(0.0, 0);
+      abwBytes = w2l_attn_fused_backward_workspace(&fd, csz > 0 ? 1 : 0);
+      if (abwBytes) abwOff = pl.alloc((abwBytes + 3) / 4);   // (arena slots are 256-byte aligned: 64 floats)
+    }
     blq.plan(pl, M, C, C); blk.plan(pl, M, C, C); blv.plan(pl, M, C, C); blf.plan(pl, M, C, C); bl1.plan(pl, M, C, mlp); bl2.plan(pl, M, mlp, C);
     xImg.plan(pl, M, C, true); ctxImg.plan(pl, M, C, true); hImg.plan(pl, M, C, true); uImg.plan(pl, M, mlp, true);
     dqImg.plan(pl, M, C); dkImg.plan(pl, M, C); dvImg.plan(pl, M, C); dr1Img.plan(pl, M, C); duImg.plan(pl, M, mlp); ds2Img.plan(pl, M, C);
     return in;
+  }
+  w2l_attn_fused_desc fusedDesc(double pd, uint32_t seed) const {
+    w2l_attn_fused_desc fd{};
+    fd.B = B; fd.H = nH; fd.T = T; fd.d = d; fd.ld = C; fd.ldc = C; fd.W = W; fd.n0 = n0; fd.rlo = rlo;
+    fd.scale = (float)(1.0 / std::sqrt((double)d));
+    fd.dropP = pd; fd.dropSeed = seed; fd.dropStream = (uint32_t)rngStream;
+    return fd;
   }
   // per-(utterance, head) product over frame-major operands; see w2l_bgemm_desc
   w2l_bgemm_desc heads(int Mm, int Nn, int Kk) const {
@@ -963,13 +976,12 @@ class TransformerLayer : public Layer {
     const float scale = (float)(1.0 / std::sqrt((double)d));
     bool fused = false;
     if (mixed) {   // scores, position term, softmax, dropout and P V in one launch where the geometry has a fused kernel
-      w2l_attn_fused_desc fd{};
-      fd.B = B; fd.H = nH; fd.T = T; fd.d = d; fd.ld = C; fd.ldc = C; fd.W = W; fd.n0 = n0; fd.rlo = rlo; fd.scale = scale;
-      fd.dropP = pd; fd.dropSeed = cx.seed; fd.dropStream = (uint32_t)rngStream;
+      const w2l_attn_fused_desc fd = fusedDesc(pd, cx.seed);
       const int st = w2l_attn_fused_forward(&fd, q, k, v, csz > 0 ? pe.w(cx) : nullptr, keyLen, S, pd > 0 ? Pd : nullptr, ctx, s);
       if (st != W2L_EUNSUPPORTED) w2lCheck(st, "tr fused attention");
       fused = st == W2L_OK;
     }
+    fusedFwd = fused;
     if (!fused) {
     {  // S[b][h][i][j] = q_i . k_j
       w2l_bgemm_desc g = heads(T, T, d);
@@ -1075,6 +1087,15 @@ class TransformerLayer : public Layer {
     w2lCheck(w2l_colsum(dr1, bf.g(cx), (size_t)M, C, s), "tr wf bwd b");
     w2lCheck(w2l_linear_backward_data(M, C, C, dr1, wf.w(cx), dctx, 0, nullptr, 1.f, s), "tr wf bwd x");
     }
+    bool fusedBwd = false;
+    if (mixed && fusedFwd && abwBytes) {   // dP, dropout mask, softmax backward, dq (+ position term), dk, dv, table gradient: four launches
+      const w2l_attn_fused_desc fd = fusedDesc(pd, cx.seed);
+      const int st = w2l_attn_fused_backward(&fd, q, k, v, csz > 0 ? pe.w(cx) : nullptr, S, dctx, dq, dk, dv, csz > 0 ? pe.g(cx) : nullptr,
+                                             ar + abwOff, abwBytes, s);
+      if (st != W2L_EUNSUPPORTED) w2lCheck(st, "tr fused attention backward");
+      fusedBwd = st == W2L_OK;
+    }
+    if (!fusedBwd) {
     {  // dPd[i][j] = dctx_i . v_j
       w2l_bgemm_desc g = heads(T, T, d);
       g.sam = C; g.sak = 1; g.a1 = TC; g.a2 = d; g.sbk = 1; g.sbn = C; g.b1 = TC; g.b2 = d; g.ldc = T; g.c1 = nH * TT; g.c2 = TT;
@@ -1114,6 +1135,7 @@ class TransformerLayer : public Layer {
         zeroGrad(cx, pe, s);
         w2lCheck(w2l_colsum(dEp, pe.g(cx) + (size_t)rlo * d, (size_t)B, W * d, s), "tr dE sum");
       }
+    }
     }
     if (mixed) {
       {
