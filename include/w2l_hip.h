@@ -244,6 +244,16 @@ int w2l_tds_conv_bf16_backward_filter(const w2l_conv_desc* d, const float* x, co
 int w2l_tds_conv_bf16_backward_filter_bias(const w2l_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
                                            w2l_stream_t stream);
 
+/* bf16 operand images written by the kernel that PRODUCES a matrix [rows][cols] instead of a w2l_bf16_convert pass over an fp32
+ * copy (mixed-precision mode): `rowMajor` [rows][ldRows] and / or `transposed` [cols][ldTrans], the layouts of w2l_bf16_convert;
+ * either pointer may be NULL.  Only elements of the matrix are written (a kernel may write zeros into the padding): the zero
+ * padding w2l_bf16_convert leaves beyond cols / rows must already be there -- images the caller zero-filled once. */
+typedef struct {
+  uint16_t* rowMajor;
+  size_t ldRows;
+  uint16_t* transposed;
+  size_t ldTrans;
+} w2l_bf16_image_sink;
 /* r = dropout(a) + x ; y = LayerNorm(r) over `groups` contiguous chunks of `inner`
  * elements with scalar affine gammaBeta[2] (fl::LayerNorm axes {0,1,2}: groups = B).
  * a is updated in place to its dropped value; r, meanRstd[2*groups] are kept for
@@ -259,6 +269,19 @@ int w2l_layernorm_backward(int groups, size_t inner, const float* r, const float
                            const float* gammaBeta, const float* meanRstd, float* dr,
                            float* dGammaBeta, const float* maskSrc, float* dmask, float maskScale,
                            double* sums, w2l_stream_t stream);
+/* The per-frame LayerNorm of the mixed-precision mode with the images of its result written in the same pass
+ * (layernorm_images.hip): as the two calls above for rows of inner <= 2304 floats (inner % 4 == 0; W2L_EUNSUPPORTED otherwise: run
+ * the plain call and w2l_bf16_convert), plus yImages = images of y, resp. drImages = images of dr -- of dropout(dr) when
+ * imageDropP > 0 (the mask of w2l_dropout_copy with imageDropSeed / imageDropStream over the flat index; dr itself stays
+ * unmasked: what w2l_bf16_convert_dropout produced).  ldTrans must hold the rows rounded up to 16 (runs of 16 rows are written).
+ * Replaces: fl::LayerNorm + the AMP casts of the next fl::Linear (recipes/slimIPL/src/Train.cpp:209-216). */
+int w2l_residual_layernorm_forward_images(int groups, size_t inner, float* a, const float* x, float* r, float* y,
+                                          const float* gammaBeta, float eps, double p, uint32_t seed, uint32_t rngStream,
+                                          float* meanRstd, const w2l_bf16_image_sink* yImages, w2l_stream_t stream);
+int w2l_layernorm_backward_images(int groups, size_t inner, const float* r, const float* dy, const float* gammaBeta,
+                                  const float* meanRstd, float* dr, float* dGammaBeta, const float* maskSrc, float* dmask,
+                                  float maskScale, double* sums, const w2l_bf16_image_sink* drImages, double imageDropP,
+                                  uint32_t imageDropSeed, uint32_t imageDropStream, w2l_stream_t stream);
 int w2l_dropout_inplace(float* x, size_t n, double p, uint32_t seed, uint32_t rngStream,
                         w2l_stream_t stream);
 /* y = dropout(x) out of place, same mask as w2l_dropout_inplace (16-byte aligned x, y) */
@@ -332,6 +355,16 @@ int w2l_attn_fused_forward(const w2l_attn_fused_desc* d, const float* q, const f
  * NT = ceil(T / 32) rounded up to 2, 4 or 6) first, which tests read.  The key-padding mask needs no argument: P is zero there.
  * W2L_EUNSUPPORTED (workspace size 0) for a geometry without a fused kernel: the same set as the forward call.
  * Replaces: the gradient of TransformerCPC.cpp:117-151 (selfAttention). */
+/* The same two calls writing the bf16 images the NEXT product reads (w2l_bf16_image_sink) instead of, or beside, the fp32 result
+ * [B T][ldc or ld]: no fp32 copy, no w2l_bf16_convert pass.  The fp32 pointer may be NULL when images are given. */
+int w2l_attn_fused_forward_images(const w2l_attn_fused_desc* d, const float* q, const float* k, const float* v, const float* posTable,
+                                  const int* keyLen, float* P, float* Pd, float* ctx, const w2l_bf16_image_sink* ctxImages,
+                                  w2l_stream_t stream);
+int w2l_attn_fused_backward_images(const w2l_attn_fused_desc* d, const float* q, const float* k, const float* v, const float* posTable,
+                                   const float* P, const float* dctx, float* dq, float* dk, float* dv,
+                                   const w2l_bf16_image_sink* dqImages, const w2l_bf16_image_sink* dkImages,
+                                   const w2l_bf16_image_sink* dvImages, float* dPosTable, void* workspace, size_t workspaceBytes,
+                                   w2l_stream_t stream);
 size_t w2l_attn_fused_backward_workspace(const w2l_attn_fused_desc* d, int withPosTable);
 int w2l_attn_fused_backward(const w2l_attn_fused_desc* d, const float* q, const float* k, const float* v, const float* posTable,
                             const float* P, const float* dctx, float* dq, float* dk, float* dv, float* dPosTable, void* workspace,

@@ -277,6 +277,33 @@ def test_fused_attention_backward(B, H, T, d, csz, p, ragged):
                                      ws.data_ptr(), nws - 1, _stream()) != 0      # a short workspace is refused
     for t_ in (dq, dk, dv):
         assert torch.isfinite(t_).all()
+    # the same results as bf16 images written by the kernels (w2l_attn_fused_backward_images, no fp32 copies): bit for bit the
+    # rounding of the fp32 results, nothing outside the matrix touched; likewise ctx of the forward call
+    M = B * T
+    ldR, ldT = (Cc + 63) // 64 * 64 + 64, (M + 63) // 64 * 64
+    def sink():
+        rows = torch.full((M, ldR), 7.0, dtype=torch.bfloat16, device="cuda")
+        trans = torch.full((Cc, ldT), 7.0, dtype=torch.bfloat16, device="cuda")
+        return rows, trans, _lib.Bf16ImageSink(rowMajor=rows.data_ptr(), ldRows=ldR, transposed=trans.data_ptr(), ldTrans=ldT)
+    sinks = [sink() for _ in range(4)]
+    dE_i = torch.full_like(dE, float("nan"))
+    assert L.w2l_attn_fused_backward_images(C.byref(D), q.data_ptr(), k.data_ptr(), v.data_ptr(), E.data_ptr() if csz else None, P.data_ptr(),
+                                            dctx.data_ptr(), None, None, None, C.byref(sinks[0][2]), C.byref(sinks[1][2]), C.byref(sinks[2][2]),
+                                            dE_i.data_ptr() if csz else None, ws.data_ptr(), nws, _stream()) == 0
+    P_i, Pd_i = torch.empty_like(P), torch.empty_like(P)
+    assert L.w2l_attn_fused_forward_images(C.byref(D), q.data_ptr(), k.data_ptr(), v.data_ptr(), E.data_ptr() if csz else None,
+                                           keyLen.data_ptr() if ragged else None, P_i.data_ptr(), Pd_i.data_ptr() if p > 0 else None,
+                                           None, C.byref(sinks[3][2]), _stream()) == 0
+    assert torch.equal(P_i, P)
+    for (rows, trans, _), ref32 in zip(sinks, (dq, dk, dv, ctx)):
+        want = ref32.reshape(M, Cc).bfloat16()
+        assert torch.equal(rows[:, :Cc], want) and torch.equal(trans[:, :M], want.t())
+        assert bool((rows[:, Cc:] == 7.0).all()) and bool((trans[:, M:] == 7.0).all())
+    if csz:
+        assert torch.equal(dE_i, dE)
+    assert L.w2l_attn_fused_backward_images(C.byref(D), q.data_ptr(), k.data_ptr(), v.data_ptr(), E.data_ptr() if csz else None, P.data_ptr(),
+                                            dctx.data_ptr(), None, dk.data_ptr(), dv.data_ptr(), None, None, None,
+                                            dE_i.data_ptr() if csz else None, ws.data_ptr(), nws, _stream()) != 0   # neither dq nor its images
     # (a) float64 on bf16-rounded operands
     r = lambda x: x.bfloat16().double()
     heads = lambda x: x.reshape(B, T, H, d).permute(0, 2, 1, 3)

@@ -127,6 +127,8 @@ class _SIGS:
     w2l_conv_backward_data_add = (_i, [_p, _p, _p, _p, _p, _p])
     w2l_conv_backward_filter = (_i, [_p, _p, _p, _p, _p, _p])
     w2l_layernorm_scratch_doubles = (_sz, [_i, _sz])
+    w2l_residual_layernorm_forward_images = (_i, [_i, _sz, _p, _p, _p, _p, _p, _f, _d, _u32, _u32, _p, _p, _p])
+    w2l_layernorm_backward_images = (_i, [_i, _sz, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _d, _u32, _u32, _p])
     w2l_residual_layernorm_forward = (_i, [_i, _sz, _p, _p, _p, _p, _p, _f, _d, _u32, _u32, _p, _p, _p])
     w2l_layernorm_backward = (_i, [_i, _sz, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p])
     w2l_dropout_inplace = (_i, [_p, _sz, _d, _u32, _u32, _p])
@@ -141,6 +143,8 @@ class _SIGS:
     w2l_attn_softmax_forward = (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p])
     w2l_attn_fused_forward = (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p])
     w2l_attn_fused_backward_workspace = (_sz, [_p, _i])
+    w2l_attn_fused_forward_images = (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p])
+    w2l_attn_fused_backward_images = (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p])
     w2l_attn_fused_backward = (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p])
     w2l_attn_key_lengths = (_i, [_p, _i, _i, _i, _p, _p])
     w2l_attn_key_lengths_full = (_i, [_p, _p, _i, _i, _i, _p, _p])
@@ -181,6 +185,10 @@ class BgemmDesc(C.Structure):  # w2l_bgemm_desc
 class Bf16ConvertDesc(C.Structure):  # w2l_bf16_convert_desc
     _fields_ = [("x", C.c_void_p), ("rows", C.c_size_t), ("cols", C.c_int), ("ldx", C.c_size_t), ("rowMajor", C.c_void_p),
                 ("ldRows", C.c_size_t), ("transposed", C.c_void_p), ("ldTrans", C.c_size_t)]
+
+
+class Bf16ImageSink(C.Structure):  # w2l_bf16_image_sink
+    _fields_ = [("rowMajor", C.c_void_p), ("ldRows", C.c_size_t), ("transposed", C.c_void_p), ("ldTrans", C.c_size_t)]
 
 
 class AttnFusedDesc(C.Structure):  # w2l_attn_fused_desc

@@ -37,7 +37,8 @@ struct AfP {
   const float *q, *k, *v;   // [B][T][ld], head h at columns h d .. (h + 1) d
   const float* E;           // position table rows [2 csz - 1][d] (internal layout), or null
   const int* keyLen;
-  float *P, *Pd, *ctx;      // P, Pd [B][H][T][T]; ctx [B][T][ldc]
+  float *P, *Pd, *ctx;      // P, Pd [B][H][T][T]; ctx [B][T][ldc] (may be null when its images are asked for)
+  w2l_bf16_image_sink ctxI; // bf16 images of ctx written in place of a conversion pass (null pointers: none)
   int B, H, T, ld, ldc;
   int W, n0, rlo;           // table rows rlo .. rlo + W are the ones an utterance of T frames reaches
   float scale;
@@ -279,9 +280,23 @@ __global__ __launch_bounds__(256, 1) void attn_fused_fwd_k(AfP p, int blocksPerW
           o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf[t][u], o, 0, 0, 0);
         }
       if (iq < T) {
-        float* dst = p.ctx + (rowBase + iq) * p.ldc + hc + 32 * ct + 4 * lh;
+        if (p.ctx) {
+          float* dst = p.ctx + (rowBase + iq) * p.ldc + hc + 32 * ct + 4 * lh;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) *(af_f32x4*)(dst + 8 * g) = af_f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+          for (int g = 0; g < 4; ++g) *(af_f32x4*)(dst + 8 * g) = af_f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+        }
+        // the bf16 images the next product reads (attention_fused_bwd.hip::ab_store_tile): 8-byte stores into the row-major image,
+        // 2-byte stores contiguous over the lanes into the transposed one
+        if (p.ctxI.rowMajor) {
+          uint16_t* dst = p.ctxI.rowMajor + (rowBase + iq) * p.ctxI.ldRows + hc + 32 * ct + 4 * lh;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) *(uint2*)(dst + 8 * g) = make_uint2(af_pack2(o[4 * g], o[4 * g + 1]), af_pack2(o[4 * g + 2], o[4 * g + 3]));
+        }
+        if (p.ctxI.transposed) {
+          uint16_t* dst = p.ctxI.transposed + (size_t)(hc + 32 * ct + 4 * lh) * p.ctxI.ldTrans + rowBase + iq;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[(size_t)((r & 3) + 8 * (r >> 2)) * p.ctxI.ldTrans] = (uint16_t)af_pack2(o[r], 0.f);
+        }
       }
     }
   }
@@ -318,9 +333,13 @@ static int af_launch(const AfP& p, hipStream_t s) {
 using namespace w2l;
 
 // returns W2L_EUNSUPPORTED for a geometry without a fused kernel (the caller runs the unfused sequence then)
-W2L_API int w2l_attn_fused_forward(const w2l_attn_fused_desc* d, const float* q, const float* k, const float* v, const float* posTable,
-                                   const int* keyLen, float* P, float* Pd, float* ctx, w2l_stream_t stream) {
-  if (!d || !q || !k || !v || !P || !ctx) return W2L_EINVAL;
+W2L_API int w2l_attn_fused_forward_images(const w2l_attn_fused_desc* d, const float* q, const float* k, const float* v,
+                                          const float* posTable, const int* keyLen, float* P, float* Pd, float* ctx,
+                                          const w2l_bf16_image_sink* ctxImages, w2l_stream_t stream) {
+  if (!d || !q || !k || !v || !P) return W2L_EINVAL;
+  const bool images = ctxImages && (ctxImages->rowMajor || ctxImages->transposed);
+  if (!ctx && !images) return W2L_EINVAL;
+  if (images && ctxImages->rowMajor && ((ctxImages->ldRows & 3) || (((uintptr_t)ctxImages->rowMajor) & 7))) return W2L_EINVAL;
   if (d->B <= 0 || d->H <= 0 || d->T <= 0 || d->d <= 0 || d->B > 65535 || d->H > 65535) return W2L_EINVAL;
   if (d->dropP < 0.0 || d->dropP >= 1.0 || (d->dropP > 0.0 && !Pd)) return W2L_EINVAL;
   if (posTable && (d->W <= 0 || d->rlo < 0)) return W2L_EINVAL;
@@ -330,6 +349,7 @@ W2L_API int w2l_attn_fused_forward(const w2l_attn_fused_desc* d, const float* q,
     return W2L_EUNSUPPORTED;
   AfP p;
   p.q = q; p.k = k; p.v = v; p.E = posTable; p.keyLen = keyLen; p.P = P; p.Pd = Pd; p.ctx = ctx;
+  p.ctxI = images ? *ctxImages : w2l_bf16_image_sink{nullptr, 0, nullptr, 0};
   p.B = d->B; p.H = d->H; p.T = d->T; p.ld = d->ld; p.ldc = d->ldc; p.W = d->W; p.n0 = d->n0; p.rlo = d->rlo; p.scale = d->scale;
   p.thr = dropout_threshold(d->dropP);
   p.seed = d->dropSeed; p.stream = d->dropStream;
@@ -341,4 +361,10 @@ W2L_API int w2l_attn_fused_forward(const w2l_attn_fused_desc* d, const float* q,
   W2L_AF(2, 256) W2L_AF(4, 256) W2L_AF(6, 256)
 #undef W2L_AF
   return W2L_EUNSUPPORTED;
+}
+
+W2L_API int w2l_attn_fused_forward(const w2l_attn_fused_desc* d, const float* q, const float* k, const float* v, const float* posTable,
+                                   const int* keyLen, float* P, float* Pd, float* ctx, w2l_stream_t stream) {
+  if (!ctx) return W2L_EINVAL;
+  return w2l_attn_fused_forward_images(d, q, k, v, posTable, keyLen, P, Pd, ctx, nullptr, stream);
 }

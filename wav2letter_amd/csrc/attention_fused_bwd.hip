@@ -42,7 +42,8 @@ struct AbP {
   const float* E;           // position table rows [2 csz - 1][d] (internal layout), or null
   const float* P;           // [B][H][T][T] of the forward pass
   const float* dctx;        // [B][T][ldc]
-  float *dq, *dk, *dv;      // [B][T][ld]
+  float *dq, *dk, *dv;      // [B][T][ld] (each may be null when its images are asked for)
+  w2l_bf16_image_sink dqI, dkI, dvI;   // bf16 images of dq / dk / dv written in place of a conversion pass (null pointers: none)
   float* dE;                // [2 n0 + 1][d] or null
   uint16_t *dSt, *Pdt;      // bf16 [B H][TP][TP]: row = key, column = query
   uint16_t* dRt;            // bf16 [B H][GW][TP]: row = window row (global numbering), column = query
@@ -63,6 +64,29 @@ __device__ __forceinline__ uint16_t ab_bf16(float a) { return (uint16_t)ab_pack2
 __device__ __forceinline__ ab_bf16x8 ab_pack8(ab_f32x4 a, ab_f32x4 b) {
   const uint4 u = make_uint4(ab_pack2(a[0], a[1]), ab_pack2(a[2], a[3]), ab_pack2(b[0], b[1]), ab_pack2(b[2], b[3]));
   return __builtin_bit_cast(ab_bf16x8, u);
+}
+
+// One 32 x 32 output tile in the MFMA C layout -- this lane holds result row `row`, columns col0 + (r & 3) + 8 (r >> 2) + 4 lh -- as
+// fp32 and / or as bf16 images: the row-major image takes 8-byte stores, the transposed one 2-byte stores that are contiguous
+// over the 32 lanes of a half-wave (64-byte runs)
+__device__ __forceinline__ void ab_store_tile(const ab_f32x16& o, bool ok, size_t row, int col0, int lh, float* f, size_t ldf,
+                                              const w2l_bf16_image_sink& im) {
+  if (!ok) return;
+  if (f) {
+    float* dst = f + row * ldf + col0 + 4 * lh;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) *(ab_f32x4*)(dst + 8 * g) = ab_f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+  }
+  if (im.rowMajor) {
+    uint16_t* dst = im.rowMajor + row * im.ldRows + col0 + 4 * lh;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) *(uint2*)(dst + 8 * g) = make_uint2(ab_pack2(o[4 * g], o[4 * g + 1]), ab_pack2(o[4 * g + 2], o[4 * g + 3]));
+  }
+  if (im.transposed) {
+    uint16_t* dst = im.transposed + (size_t)(col0 + 4 * lh) * im.ldTrans + row;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[(size_t)((r & 3) + 8 * (r >> 2)) * im.ldTrans] = ab_bf16(o[r]);
+  }
 }
 
 // Window rows are numbered globally per (utterance, head): wg = w - wOrg, wOrg = (n0 - rlo) - 31 - 32 (NT - 1), so that query block
@@ -327,11 +351,7 @@ __global__ __launch_bounds__(256, 1) void attn_fused_bwd_q_k(AbP p, int blocksPe
             o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ea, rf[e][u], o, 0, 0, 0);
           }
       }
-      if (iq < T) {
-        float* dst = p.dq + (rowBase + iq) * p.ld + hc + 32 * ct + 4 * lh;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) *(ab_f32x4*)(dst + 8 * g) = ab_f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
-      }
+      ab_store_tile(o, iq < T, rowBase + iqc, hc + 32 * ct, lh, p.dq, (size_t)p.ld, p.dqI);
     }
   }
 }
@@ -412,19 +432,10 @@ __global__ __launch_bounds__(64 * NT, 1) void attn_fused_bwd_kv_k(AbP p) {
       o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, bf[s], o, 0, 0, 0);
     }
     const int row = 32 * g + li;
-    float* dst;
-    bool st;
-    if (role < 2) {
-      st = row < T;
-      dst = (role == 0 ? p.dk : p.dv) + (rowBase + (st ? row : 0)) * p.ld + hc + 32 * ct + 4 * lh;
-    } else {
-      st = true;
-      dst = p.dEp + (bh * GW + row) * D + 32 * ct + 4 * lh;
-    }
-    if (st) {
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) *(ab_f32x4*)(dst + 8 * q4) = ab_f32x4{o[4 * q4], o[4 * q4 + 1], o[4 * q4 + 2], o[4 * q4 + 3]};
-    }
+    const w2l_bf16_image_sink none{nullptr, 0, nullptr, 0};
+    if (role == 0) ab_store_tile(o, row < T, rowBase + (row < T ? row : 0), hc + 32 * ct, lh, p.dk, (size_t)p.ld, p.dkI);
+    else if (role == 1) ab_store_tile(o, row < T, rowBase + (row < T ? row : 0), hc + 32 * ct, lh, p.dv, (size_t)p.ld, p.dvI);
+    else ab_store_tile(o, true, bh * GW + row, 32 * ct, lh, p.dEp, (size_t)D, none);
   }
 }
 
@@ -442,7 +453,15 @@ __global__ __launch_bounds__(256) void attn_bwd_de_reduce_k(AbP p) {
     const int wg = w - ab_w_origin<NT>(p.n0, p.rlo);
     const float* src = p.dEp + (size_t)wg * D + 4 * c4;
     const int n = p.B * p.H;
-    for (int i = 0; i < n; ++i) {
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {   // eight loads in flight; the order of the additions is fixed
+      ab_f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *(const ab_f32x4*)(src + (size_t)(i + u) * GW * D);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s[0] += v[u][0]; s[1] += v[u][1]; s[2] += v[u][2]; s[3] += v[u][3]; }
+    }
+    for (; i < n; ++i) {
       const ab_f32x4 v = *(const ab_f32x4*)(src + (size_t)i * GW * D);
       s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
     }
@@ -534,10 +553,19 @@ W2L_API size_t w2l_attn_fused_backward_workspace(const w2l_attn_fused_desc* d, i
 }
 
 // returns W2L_EUNSUPPORTED for a geometry without a fused kernel (the caller runs the unfused sequence then)
-W2L_API int w2l_attn_fused_backward(const w2l_attn_fused_desc* d, const float* q, const float* k, const float* v, const float* posTable,
-                                    const float* P, const float* dctx, float* dq, float* dk, float* dv, float* dPosTable,
-                                    void* workspace, size_t workspaceBytes, w2l_stream_t stream) {
-  if (!d || !q || !k || !v || !P || !dctx || !dq || !dk || !dv || !workspace) return W2L_EINVAL;
+static bool ab_sink_ok(const w2l_bf16_image_sink* s, const float* f) {
+  if (!s || (!s->rowMajor && !s->transposed)) return f != nullptr;     // no images: the fp32 result is required
+  if (s->rowMajor && ((s->ldRows & 3) || (((uintptr_t)s->rowMajor) & 7))) return false;
+  return true;
+}
+
+W2L_API int w2l_attn_fused_backward_images(const w2l_attn_fused_desc* d, const float* q, const float* k, const float* v,
+                                           const float* posTable, const float* P, const float* dctx, float* dq, float* dk, float* dv,
+                                           const w2l_bf16_image_sink* dqImages, const w2l_bf16_image_sink* dkImages,
+                                           const w2l_bf16_image_sink* dvImages, float* dPosTable, void* workspace,
+                                           size_t workspaceBytes, w2l_stream_t stream) {
+  if (!d || !q || !k || !v || !P || !dctx || !workspace) return W2L_EINVAL;
+  if (!ab_sink_ok(dqImages, dq) || !ab_sink_ok(dkImages, dk) || !ab_sink_ok(dvImages, dv)) return W2L_EINVAL;
   if (d->B <= 0 || d->H <= 0 || d->T <= 0 || d->d <= 0 || d->B > 65535 || d->H > 65535) return W2L_EINVAL;
   if (d->dropP < 0.0 || d->dropP >= 1.0) return W2L_EINVAL;
   if (posTable && (d->W <= 0 || d->rlo < 0 || d->n0 < 0 || !dPosTable)) return W2L_EINVAL;
@@ -550,6 +578,8 @@ W2L_API int w2l_attn_fused_backward(const w2l_attn_fused_desc* d, const float* q
     return W2L_EUNSUPPORTED;
   AbP p{};
   p.q = q; p.k = k; p.v = v; p.E = posTable; p.P = P; p.dctx = dctx; p.dq = dq; p.dk = dk; p.dv = dv; p.dE = dPosTable;
+  const w2l_bf16_image_sink none{nullptr, 0, nullptr, 0};
+  p.dqI = dqImages ? *dqImages : none; p.dkI = dkImages ? *dkImages : none; p.dvI = dvImages ? *dvImages : none;
   p.B = d->B; p.H = d->H; p.T = d->T; p.ld = d->ld; p.ldc = d->ldc; p.W = d->W; p.n0 = d->n0; p.rlo = d->rlo; p.scale = d->scale;
   p.thr = dropout_threshold(d->dropP);
   p.seed = d->dropSeed; p.stream = d->dropStream;
@@ -560,4 +590,12 @@ W2L_API int w2l_attn_fused_backward(const w2l_attn_fused_desc* d, const float* q
   W2L_AB(2, 256) W2L_AB(4, 256) W2L_AB(6, 256)
 #undef W2L_AB
   return W2L_EUNSUPPORTED;
+}
+
+W2L_API int w2l_attn_fused_backward(const w2l_attn_fused_desc* d, const float* q, const float* k, const float* v, const float* posTable,
+                                    const float* P, const float* dctx, float* dq, float* dk, float* dv, float* dPosTable,
+                                    void* workspace, size_t workspaceBytes, w2l_stream_t stream) {
+  if (!dq || !dk || !dv) return W2L_EINVAL;
+  return w2l_attn_fused_backward_images(d, q, k, v, posTable, P, dctx, dq, dk, dv, nullptr, nullptr, nullptr, dPosTable, workspace,
+                                        workspaceBytes, stream);
 }

@@ -599,6 +599,13 @@ __global__ __launch_bounds__(kEwThreads) void adadelta_k(float* __restrict__ p, 
     one(p[e], g[e], accG[e], accD[e]);
 }
 
+// (shared with layernorm_images.hip)
+int ln_param_grad(const double* sums, int groups, float* dGammaBeta, hipStream_t stream) {
+  hipLaunchKernelGGL(ln_param_grad_k, dim3(1), dim3(1024), 0, stream, sums, groups, dGammaBeta);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
 }  // namespace w2l
 
 using namespace w2l;

@@ -252,7 +252,7 @@ struct BfImage {   // the two bf16 images of an fp32 matrix [rows][cols]
   mutable const float* onesArena = nullptr;   // the arena the ones row was written into (a re-bound arena gets it again)
   void plan(Planner& pl, int r, int c, bool ones = false) {
     rows = r; cols = c; colsP = pad64(c); rowsP = pad64(r);
-    onesRow = ones; onesArena = nullptr;
+    onesRow = ones; onesArena = nullptr; sinkArena = nullptr;
     rowsOff = pl.allocBf16((size_t)rows * colsP);
     transOff = pl.allocBf16((size_t)(cols + (ones ? 1 : 0)) * rowsP);
   }
@@ -274,6 +274,22 @@ struct BfImage {   // the two bf16 images of an fp32 matrix [rows][cols]
   void convertDropout(Ctx& c, float* arena, const float* x, double p, uint32_t seed, uint32_t stream, const char* what) const {
     w2lCheck(w2l_bf16_convert_dropout(x, (size_t)rows, cols, (size_t)cols, bfp(arena, rowsOff), (size_t)colsP, bfp(arena, transOff),
                                       (size_t)rowsP, p, seed, stream, c.stream), what);
+  }
+  // the images as the OUTPUT of the kernel that produces the matrix (w2l_bf16_image_sink: only elements of the matrix are written).
+  // The zero padding a conversion pass would leave is written once per arena -- the planner never aliases an image.
+  mutable const float* sinkArena = nullptr;
+  w2l_bf16_image_sink sink(Ctx& c, float* arena) const {
+    if (sinkArena != arena) {
+      if (colsP != cols) w2lCheck(w2l_fill((float*)bfp(arena, rowsOff), ((size_t)rows * colsP + 1) / 2, 0.f, c.stream), "bf16 image padding");
+      if (rowsP != rows) {
+        w2lCheck(w2l_fill((float*)bfp(arena, transOff), ((size_t)cols * rowsP + 1) / 2, 0.f, c.stream), "bf16 image padding");
+      }
+      sinkArena = arena;
+    }
+    ensureOnes(c, arena);
+    w2l_bf16_image_sink k;
+    k.rowMajor = bfp(arena, rowsOff); k.ldRows = (size_t)colsP; k.transposed = bfp(arena, transOff); k.ldTrans = (size_t)rowsP;
+    return k;
   }
   const uint16_t* r(float* arena) const { return bfp(arena, rowsOff); }
   const uint16_t* t(float* arena) const { return bfp(arena, transOff); }
@@ -976,8 +992,11 @@ class TransformerLayer : public Layer {
     const float scale = (float)(1.0 / std::sqrt((double)d));
     bool fused = false;
     if (mixed) {   // scores, position term, softmax, dropout and P V in one launch where the geometry has a fused kernel
+      // (ctx is only ever the operand of the wf products in this mode: the kernel writes its bf16 images, no fp32 copy)
       const w2l_attn_fused_desc fd = fusedDesc(pd, cx.seed);
-      const int st = w2l_attn_fused_forward(&fd, q, k, v, csz > 0 ? pe.w(cx) : nullptr, keyLen, S, pd > 0 ? Pd : nullptr, ctx, s);
+      const w2l_bf16_image_sink ctxSink = ctxImg.sink(cx, ar);
+      const int st = w2l_attn_fused_forward_images(&fd, q, k, v, csz > 0 ? pe.w(cx) : nullptr, keyLen, S, pd > 0 ? Pd : nullptr, nullptr,
+                                                   &ctxSink, s);
       if (st != W2L_EUNSUPPORTED) w2lCheck(st, "tr fused attention");
       fused = st == W2L_OK;
     }
@@ -1002,7 +1021,7 @@ class TransformerLayer : public Layer {
     }
     }
     if (mixed) {
-      ctxImg.convert(cx, ar, ctx, "tr ctx images");
+      if (!fused) ctxImg.convert(cx, ar, ctx, "tr ctx images");
       blf.forward(cx, ar, ctxImg, bf.w(cx), o, 0, 0.0, 0, 0);
     } else {
       w2lCheck(w2l_linear_forward(M, C, C, ctx, wf.w(cx), bf.w(cx), o, 0, s), "tr wf");
@@ -1020,6 +1039,11 @@ class TransformerLayer : public Layer {
     }
     w2lCheck(w2l_residual_layernorm_forward(M, C, m2, h, m2, out, gb2.w(cx), 1e-5f, 0.0, 0, 0, (double*)(ar + st2Off), ar + mr2Off, s), "tr ln2");
     y = out;
+  }
+  // the four projection bias gradients are row C of the grouped weight-gradient product (ones rows in the x / ctx images)
+  bool projectionBiasRides(Ctx& cx) const {
+    return blq.biasRides(xImg, wq.g(cx), bq.g(cx)) && blk.biasRides(xImg, wk.g(cx), bk.g(cx)) && blv.biasRides(xImg, wv.g(cx), bv.g(cx)) &&
+           blf.biasRides(ctxImg, wf.g(cx), bf.g(cx));
   }
   void zeroGrad(Ctx& cx, const P& w, hipStream_t s) {
     const ParamInfo& pi = (*w.table)[w.idx];
@@ -1089,9 +1113,14 @@ class TransformerLayer : public Layer {
     }
     bool fusedBwd = false;
     if (mixed && fusedFwd && abwBytes) {   // dP, dropout mask, softmax backward, dq (+ position term), dk, dv, table gradient: four launches
+      // dq / dk / dv are only ever GEMM operands once their bias gradients ride on the weight-gradient products: bf16 images from the
+      // kernels, no fp32 copies, no conversion launch
       const w2l_attn_fused_desc fd = fusedDesc(pd, cx.seed);
-      const int st = w2l_attn_fused_backward(&fd, q, k, v, csz > 0 ? pe.w(cx) : nullptr, S, dctx, dq, dk, dv, csz > 0 ? pe.g(cx) : nullptr,
-                                             ar + abwOff, abwBytes, s);
+      const bool rides = projectionBiasRides(cx);
+      const w2l_bf16_image_sink sq = dqImg.sink(cx, ar), sk = dkImg.sink(cx, ar), sv = dvImg.sink(cx, ar);
+      const int st = w2l_attn_fused_backward_images(&fd, q, k, v, csz > 0 ? pe.w(cx) : nullptr, S, dctx, rides ? nullptr : dq,
+                                                    rides ? nullptr : dk, rides ? nullptr : dv, &sq, &sk, &sv,
+                                                    csz > 0 ? pe.g(cx) : nullptr, ar + abwOff, abwBytes, s);
       if (st != W2L_EUNSUPPORTED) w2lCheck(st, "tr fused attention backward");
       fusedBwd = st == W2L_OK;
     }
@@ -1138,7 +1167,7 @@ class TransformerLayer : public Layer {
     }
     }
     if (mixed) {
-      {
+      if (!fusedBwd) {
         const w2l_bf16_convert_desc gd[3] = {dqImg.desc(ar, dq), dkImg.desc(ar, dk), dvImg.desc(ar, dv)};
         w2lCheck(w2l_bf16_convert_multi(3, gd, s), "tr dq / dk / dv images");
       }
@@ -1147,8 +1176,7 @@ class TransformerLayer : public Layer {
         const uint16_t* B4[4] = {dqImg.t(ar), dkImg.t(ar), dvImg.t(ar), dr1Img.t(ar)};
         float* C4[4] = {wq.g(cx), wk.g(cx), wv.g(cx), wf.g(cx)};
         // with the ones rows of the x / ctx images the four bias gradients are row C of the four products
-        const bool rides = blq.biasRides(xImg, wq.g(cx), bq.g(cx)) && blk.biasRides(xImg, wk.g(cx), bk.g(cx)) &&
-                           blv.biasRides(xImg, wv.g(cx), bv.g(cx)) && blf.biasRides(ctxImg, wf.g(cx), bf.g(cx));
+        const bool rides = projectionBiasRides(cx);
         w2lCheck(w2l_gemm_bf16_grouped(4, C + (rides ? 1 : 0), C, M, A4, xImg.rowsP, B4, dqImg.rowsP, C4, C, nullptr, s),
                  "tr projection weight gradients");
         if (!rides) {
