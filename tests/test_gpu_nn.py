@@ -1024,6 +1024,86 @@ def test_bf16_convert_with_dropout_mask(rows, cols, p):
     assert torch.equal(g0_r.view(torch.int16), plain_r.view(torch.int16)) and torch.equal(g0_t.view(torch.int16), plain_t.view(torch.int16))
 
 
+@pytest.mark.parametrize("groups,inner", [(1500, 1200), (37, 2160), (50, 1024), (3, 2304), (17, 8), (16, 64)])
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_layernorm_writes_the_bf16_images_of_its_result(groups, inner, p):
+    """w2l_residual_layernorm_forward_images / w2l_layernorm_backward_images (layernorm_images.hip: 16 rows per workgroup, the
+    rounded rows through an LDS tile into the transposed image): r / y / dr / dmask / the parameter gradients against the plain
+    kernels (the wave-level reduction order differs: 2e-6), the dropout pattern bit for bit, the images bit for bit the rounding
+    of the kernel's OWN fp32 result -- of dropout(dr) with the library hash where asked (= w2l_bf16_convert_dropout) -- and nothing
+    written beyond the matrix except zeros in the transposed image's row padding; rows the kernel does not hold are refused"""
+    import ctypes as C
+    from wav2letter_amd import _lib, ops
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cpu").manual_seed(groups * 7 + inner)
+    a = torch.relu(torch.randn(groups, inner, generator=g)).cuda()
+    x = torch.randn(groups, inner, generator=g).cuda()
+    gb = torch.tensor([1.3, -0.2]).cuda()
+    a_ref = a.clone()
+    y_ref, r_ref, mr_ref = ops.residual_layernorm_forward(a_ref, x, gb, groups, 1e-5, p, 77, 5)
+    ldR, ldT = (inner + 63) // 64 * 64 + 64, (groups + 63) // 64 * 64
+
+    def sink():
+        rows = torch.full((groups, ldR), 7.0, dtype=torch.bfloat16, device="cuda")
+        trans = torch.full((inner, ldT), 7.0, dtype=torch.bfloat16, device="cuda")
+        return rows, trans, _lib.Bf16ImageSink(rowMajor=rows.data_ptr(), ldRows=ldR, transposed=trans.data_ptr(), ldTrans=ldT)
+
+    def check_images(rows, trans, want32):
+        want = want32.bfloat16()
+        assert torch.equal(rows[:, :inner], want) and torch.equal(trans[:, :groups], want.t())
+        assert bool((rows[:, inner:] == 7.0).all())
+        g16 = (groups + 15) // 16 * 16
+        assert bool((trans[:, groups:g16] == 0.0).all()) and bool((trans[:, g16:] == 7.0).all())
+
+    a2 = a.clone()
+    r = torch.empty_like(a); y = torch.empty_like(a); mr = torch.empty(2 * groups, device="cuda")
+    rows, trans, k = sink()
+    assert L.w2l_residual_layernorm_forward_images(groups, inner, a2.data_ptr(), x.data_ptr(), r.data_ptr(), y.data_ptr(), gb.data_ptr(), 1e-5, p,
+                                                   77, 5, mr.data_ptr(), C.byref(k), s) == 0
+    assert torch.equal(a2, a_ref) and torch.equal(r, r_ref)
+    assert rel(y, y_ref.cpu().numpy()) < 2e-6 and rel(mr, mr_ref.cpu().numpy()) < 2e-6
+    check_images(rows, trans, y)
+    # r stored over a, no residual input: the Transformer block's call pattern
+    a3 = a.clone()
+    y3 = torch.empty_like(a)
+    rows3, trans3, k3 = sink()
+    assert L.w2l_residual_layernorm_forward_images(groups, inner, a3.data_ptr(), None, a3.data_ptr(), y3.data_ptr(), gb.data_ptr(), 1e-5, 0.0, 0, 0,
+                                                   mr.data_ptr(), C.byref(k3), s) == 0
+    y3_ref, _, _ = ops.residual_layernorm_forward(a.clone(), None, gb, groups)
+    assert torch.equal(a3, a) and rel(y3, y3_ref.cpu().numpy()) < 2e-6
+    check_images(rows3, trans3, y3)
+    # backward
+    dy = torch.randn(groups, inner, generator=g).cuda()
+    for masked in (False, True):
+        dr_ref, dgb_ref, dm_ref = ops.layernorm_backward(r_ref, dy, gb, mr_ref, groups, mask_src=a_ref if masked else None, mask_scale=1.25)
+        dr = torch.empty_like(a); dm = torch.empty_like(a); dgb = torch.empty(2, device="cuda")
+        sums = torch.empty(2 * groups + 64, dtype=torch.float64, device="cuda")
+        rows, trans, k = sink()
+        assert L.w2l_layernorm_backward_images(groups, inner, r_ref.data_ptr(), dy.data_ptr(), gb.data_ptr(), mr_ref.data_ptr(), dr.data_ptr(),
+                                               dgb.data_ptr(), a_ref.data_ptr() if masked else None, dm.data_ptr() if masked else None, 1.25,
+                                               sums.data_ptr(), C.byref(k), p, 91, 6, s) == 0
+        assert rel(dr, dr_ref.cpu().numpy()) < 2e-6
+        assert rel(dgb, dgb_ref.cpu().numpy()) < 1e-5
+        if masked:
+            assert rel(dm, dm_ref.cpu().numpy()) < 2e-6
+        check_images(rows, trans, ops.dropout_copy(dr, p, 91, 6) if p > 0 else dr)
+        if p > 0:
+            want_r, want_t = ops.bf16_convert_dropout(dr, p, 91, 6)
+            assert torch.equal(rows[:, :inner], want_r[:, :inner]) and torch.equal(trans[:, :groups], want_t[:inner, :groups])
+    # refusals: a row the kernel does not hold, no images, a transposed pitch shorter than the rows rounded up to 16
+    big = torch.zeros(2, 2308, device="cuda")
+    assert L.w2l_residual_layernorm_forward_images(2, 2308, big.data_ptr(), None, big.data_ptr(), big.data_ptr(), gb.data_ptr(), 1e-5, 0.0, 0, 0,
+                                                   mr.data_ptr(), C.byref(k), s) == _lib.W2L_EUNSUPPORTED
+    none = _lib.Bf16ImageSink(rowMajor=None, ldRows=0, transposed=None, ldTrans=0)
+    assert L.w2l_residual_layernorm_forward_images(groups, inner, a2.data_ptr(), None, a2.data_ptr(), y.data_ptr(), gb.data_ptr(), 1e-5, 0.0, 0, 0,
+                                                   mr.data_ptr(), C.byref(none), s) == _lib.W2L_EINVAL
+    short = _lib.Bf16ImageSink(rowMajor=None, ldRows=0, transposed=trans.data_ptr(), ldTrans=max(8, (groups - 1) // 8 * 8))
+    if short.ldTrans < (groups + 15) // 16 * 16:
+        assert L.w2l_residual_layernorm_forward_images(groups, inner, a2.data_ptr(), None, a2.data_ptr(), y.data_ptr(), gb.data_ptr(), 1e-5, 0.0, 0,
+                                                       0, mr.data_ptr(), C.byref(short), s) == _lib.W2L_EINVAL
+
+
 def test_tds_conv_bf16_refuses_other_geometries():
     import ctypes as C
     from wav2letter_amd import _lib, ops

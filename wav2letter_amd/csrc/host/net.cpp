@@ -335,6 +335,35 @@ struct BfLinear {   // the weight images of one fl::Linear(in, out) and its thre
   }
 };
 
+// LayerNorm of the mixed-precision mode: where the normalised rows are the rows of the next product's operand (`img` non-null,
+// rows of at most 2304 floats) the images come out of the LayerNorm kernel itself (layernorm_images.hip) -- returns true then;
+// otherwise the plain kernels run and the caller converts.
+static bool lnForward(Ctx& cx, float* ar, int groups, size_t inner, float* a, const float* x, float* r, float* y, const float* gb, double p,
+                      uint32_t seed, uint32_t stream, double* stats, float* mr, const BfImage* img, const char* what) {
+  if (img && img->rows == groups && (size_t)img->cols == inner) {
+    const w2l_bf16_image_sink k = img->sink(cx, ar);
+    const int st = w2l_residual_layernorm_forward_images(groups, inner, a, x, r, y, gb, 1e-5f, p, seed, stream, mr, &k, cx.stream);
+    if (st == W2L_OK) return true;
+    if (st != W2L_EUNSUPPORTED) w2lCheck(st, what);
+  }
+  w2lCheck(w2l_residual_layernorm_forward(groups, inner, a, x, r, y, gb, 1e-5f, p, seed, stream, stats, mr, cx.stream), what);
+  return false;
+}
+// imgP > 0: the images are those of dropout(dr) (hash over the flat index with imgSeed / imgStream), dr stays unmasked
+static bool lnBackward(Ctx& cx, float* ar, int groups, size_t inner, const float* r, const float* dy, const float* gb, const float* mr, float* dr,
+                       float* dgb, const float* maskSrc, float* dmask, float maskScale, double* sums, const BfImage* img, double imgP,
+                       uint32_t imgSeed, uint32_t imgStream, const char* what) {
+  if (img && img->rows == groups && (size_t)img->cols == inner) {
+    const w2l_bf16_image_sink k = img->sink(cx, ar);
+    const int st = w2l_layernorm_backward_images(groups, inner, r, dy, gb, mr, dr, dgb, maskSrc, dmask, maskScale, sums, &k, imgP, imgSeed,
+                                                 imgStream, cx.stream);
+    if (st == W2L_OK) return true;
+    if (st != W2L_EUNSUPPORTED) w2lCheck(st, what);
+  }
+  w2lCheck(w2l_layernorm_backward(groups, inner, r, dy, gb, mr, dr, dgb, maskSrc, dmask, maskScale, sums, cx.stream), what);
+  return false;
+}
+
 // optional WeightNorm state shared by Conv2D / Linear
 struct WNState {
   bool on = false;
@@ -472,6 +501,7 @@ class LinearLayer : public Layer {
   std::vector<ParamInfo>* table = nullptr;
   BfLinear bl;          // mixed precision: weight images and the bf16 products
   BfImage xImg, dyImg;  // images of this layer's input and output gradient
+  BfImage xSeen;        // the images of x this step's products read: xImg, or the producer's (Ctx::imgOf)
 
   std::string name() const override { return wn.on ? "WeightNorm(Linear)" : "Linear"; }
   void registerParams(std::vector<ParamInfo>& t) override {
@@ -551,9 +581,15 @@ class LinearLayer : public Layer {
       wt = arena + wn.wOff;
     }
     if (c.bf16) {
-      xImg.convert(c, arena, x, "linear input images");
+      xSeen = xImg;
+      if (c.imgOf == x && c.imgRows == M && c.imgCols == in) {   // written by the layer that produced x (a Transformer block's LayerNorm)
+        xSeen.rowsOff = c.imgRowsOff; xSeen.transOff = c.imgTransOff;
+        xSeen.onesRow = true;
+      } else {
+        xImg.convert(c, arena, x, "linear input images");
+      }
       bl.convertWeight(c, arena, wt);
-      bl.forward(c, arena, xImg, hasBias ? b.w(c) : nullptr, y, fuseRelu ? 1 : 0, 0.0, 0, 0);
+      bl.forward(c, arena, xSeen, hasBias ? b.w(c) : nullptr, y, fuseRelu ? 1 : 0, 0.0, 0, 0);
       return;
     }
     w2lCheck(w2l_linear_forward(M, in, out, x, wt, hasBias ? b.w(c) : nullptr, y, fuseRelu ? 1 : 0, c.stream), "linear fwd");
@@ -565,8 +601,8 @@ class LinearLayer : public Layer {
     const float* wt = wn.on ? arena + wn.wOff : w.w(c);
     if (c.bf16) {   // the images of x and of the weight were written by forward
       dyImg.convert(c, arena, dym, "linear output-gradient images");
-      const bool rides = hasBias && bl.biasRides(xImg, dwt, b.g(c));
-      bl.backwardWeight(c, arena, xImg, dyImg, dwt, rides);
+      const bool rides = hasBias && bl.biasRides(xSeen, dwt, b.g(c));
+      bl.backwardWeight(c, arena, xSeen, dyImg, dwt, rides);
       if (hasBias && !rides) w2lCheck(w2l_colsum(dym, b.g(c), (size_t)M, out, c.stream), "linear bwd b");
       if (needDx) {
         dx = arena + dxOff;
@@ -730,12 +766,16 @@ class TDSLayer : public Layer {
       w2lCheck(w2l_conv_forward(&d, x, wc.w(cx), bc.w(cx), a, 1, s), "tds conv");
     }
     // a <- dropout(relu(conv)) in place (kept: its sign pattern is the ReLU+dropout mask); r1 = a + x; y1 = LN(r1)
-    w2lCheck(w2l_residual_layernorm_forward(groups, inner, a, x, r1, y1, gb1.w(cx), 1e-5f, pd, cx.seed, rngStream,
-                                            (double*)(ar + st1Off), ar + mr1Off, s), "tds ln1");
+    const bool y1Images = lnForward(cx, ar, groups, inner, a, x, r1, y1, gb1.w(cx), pd, cx.seed, rngStream, (double*)(ar + st1Off), ar + mr1Off,
+                                    cx.bf16 ? &y1Img : nullptr, "tds ln1");
     if (cx.bf16) {
-      // the same two products on bf16 images: y1 and u are converted once (row image for this product, transposed image for
-      // the weight gradient in backward), the weights once per step (both orientations)
-      {   // y1 and both weights of the block in ONE conversion launch (the weights are 10 us each on their own: launch-bound)
+      // the same two products on bf16 images: y1 and u as images (row image for this product, transposed image for the weight
+      // gradient in backward), the weights once per step (both orientations).  y1's images come out of the LayerNorm kernel when
+      // it normalises per frame; otherwise y1 joins the weights' conversion launch (10 us each on their own: launch-bound)
+      if (y1Images) {
+        const w2l_bf16_convert_desc wd[2] = {bl1.w.desc(ar, w1.w(cx)), bl2.w.desc(ar, w2.w(cx))};
+        w2lCheck(w2l_bf16_convert_multi(2, wd, s), "tds weight images");
+      } else {
         const w2l_bf16_convert_desc wd[3] = {y1Img.desc(ar, y1), bl1.w.desc(ar, w1.w(cx)), bl2.w.desc(ar, w2.w(cx))};
         w2lCheck(w2l_bf16_convert_multi(3, wd, s), "tds y1 + weight images");
         y1Img.ensureOnes(cx, ar);
@@ -761,13 +801,15 @@ class TDSLayer : public Layer {
     float *a = ar + aOff, *y1 = ar + y1Off, *u = ar + uOff, *v = ar + vOff;
     float *ds = ar + dsOff, *du = ar + duOff, *dy1 = ar + dy1Off, *dr1 = ar + dr1Off, *da = ar + daOff;
     // LN2 backward: ds = d r2 ; dv = ds masked by the dropout of v
-    w2lCheck(w2l_layernorm_backward(groups, inner, v, dy, gb2.w(cx), ar + mr2Off, ds, gb2.g(cx), nullptr, nullptr, 1.f,
-                                    (double*)(ar + st2Off), s), "tds ln2 bwd");
-    const float* dv = ds;
     const bool rides2 = cx.bf16 && bl2.biasRides(uImg, w2.g(cx), b2.g(cx));
     // mixed precision with the bias gradient riding on the weight-gradient product: dv = dropout-masked ds is only ever a GEMM
-    // operand -- its images are taken straight from ds with the mask applied on the way, no masked copy
+    // operand -- its images are taken straight from ds with the mask applied on the way, no masked copy; where the LayerNorm
+    // normalises per frame they come out of its backward kernel and there is no conversion launch either
     const bool maskInConvert = pd > 0 && rides2;
+    const bool dvImages = lnBackward(cx, ar, groups, inner, v, dy, gb2.w(cx), ar + mr2Off, ds, gb2.g(cx), nullptr, nullptr, 1.f,
+                                     (double*)(ar + st2Off), cx.bf16 && (pd == 0 || maskInConvert) ? &dvImg : nullptr, pd, cx.seed,
+                                     rngStream + 2, "tds ln2 bwd");
+    const float* dv = ds;
     if (pd > 0 && !maskInConvert) {
       // dy1 buffer doubles as scratch for the masked copy (one out-of-place pass)
       w2lCheck(w2l_dropout_copy(dy1, ds, n, pd, cx.seed, rngStream + 2, s), "tds do2 bwd");
@@ -775,7 +817,8 @@ class TDSLayer : public Layer {
     }
     if (cx.bf16) {
       // (dv may live in dy1 -- the masked copy above --, which the last product overwrites: its images are taken first)
-      if (maskInConvert) dvImg.convertDropout(cx, ar, ds, pd, cx.seed, rngStream + 2, "tds dv images (masked)");
+      if (dvImages) {}
+      else if (maskInConvert) dvImg.convertDropout(cx, ar, ds, pd, cx.seed, rngStream + 2, "tds dv images (masked)");
       else dvImg.convert(cx, ar, dv, "tds dv images");
       bl2.backwardWeight(cx, ar, uImg, dvImg, w2.g(cx), rides2);
       if (!rides2) w2lCheck(w2l_colsum(dv, b2.g(cx), (size_t)M, l, s), "tds lin2 bwd b");
@@ -871,6 +914,8 @@ class TransformerLayer : public Layer {
   // mixed precision: the six fl::Linear of the block on bf16 images (the attention products stay on the fp32 batched GEMM)
   BfLinear blq, blk, blv, blf, bl1, bl2;
   BfImage xImg, ctxImg, hImg, uImg, dqImg, dkImg, dvImg, dr1Img, duImg, ds2Img;
+  BfImage outImg;           // images of the block's output, written by its last LayerNorm: the next block's x images (Ctx::imgOf)
+  BfImage xSeen;            // the images of x this step's products read: xImg, or the previous block's outImg
 
   std::string name() const override { return "Transformer"; }
   void registerParams(std::vector<ParamInfo>& t) override {
@@ -927,6 +972,7 @@ class TransformerLayer : public Layer {
     blq.plan(pl, M, C, C); blk.plan(pl, M, C, C); blv.plan(pl, M, C, C); blf.plan(pl, M, C, C); bl1.plan(pl, M, C, mlp); bl2.plan(pl, M, mlp, C);
     xImg.plan(pl, M, C, true); ctxImg.plan(pl, M, C, true); hImg.plan(pl, M, C, true); uImg.plan(pl, M, mlp, true);
     dqImg.plan(pl, M, C); dkImg.plan(pl, M, C); dvImg.plan(pl, M, C); dr1Img.plan(pl, M, C); duImg.plan(pl, M, mlp); ds2Img.plan(pl, M, C);
+    outImg.plan(pl, M, C, true);
     return in;
   }
   w2l_attn_fused_desc fusedDesc(double pd, uint32_t seed) const {
@@ -964,18 +1010,24 @@ class TransformerLayer : public Layer {
     }
     const bool mixed = cx.bf16;
     if (mixed) {   // one pair of images of x serves the three projections (and their weight gradients in backward)
-      xImg.convert(cx, ar, x, "tr x images");
+      if (cx.imgOf == x && cx.imgRows == M && cx.imgCols == C) {   // the previous block's LayerNorm wrote them already
+        xSeen = xImg;
+        xSeen.rowsOff = cx.imgRowsOff; xSeen.transOff = cx.imgTransOff;
+      } else {
+        xImg.convert(cx, ar, x, "tr x images");
+        xSeen = xImg;
+      }
       {   // the six weights of the block in ONE conversion launch (8 us each on their own: launch-bound)
         const w2l_bf16_convert_desc wd[6] = {blq.w.desc(ar, wq.w(cx)), blk.w.desc(ar, wk.w(cx)), blv.w.desc(ar, wv.w(cx)),
                                              blf.w.desc(ar, wf.w(cx)), bl1.w.desc(ar, w1.w(cx)), bl2.w.desc(ar, w2.w(cx))};
         w2lCheck(w2l_bf16_convert_multi(6, wd, s), "tr weight images");
       }
       {   // the three projections in ONE grouped launch: 3 x 192 tiles share the grid (one at a time each fills 3/8 of the slots)
-        const uint16_t* A3[3] = {xImg.r(ar), xImg.r(ar), xImg.r(ar)};
+        const uint16_t* A3[3] = {xSeen.r(ar), xSeen.r(ar), xSeen.r(ar)};
         const uint16_t* B3[3] = {blq.w.t(ar), blk.w.t(ar), blv.w.t(ar)};
         float* C3[3] = {q, k, v};
         const float* b3[3] = {bq.w(cx), bk.w(cx), bv.w(cx)};
-        w2lCheck(w2l_gemm_bf16_grouped(3, M, C, C, A3, xImg.colsP, B3, blq.w.rowsP, C3, C, b3, s), "tr q k v");
+        w2lCheck(w2l_gemm_bf16_grouped(3, M, C, C, A3, xSeen.colsP, B3, blq.w.rowsP, C3, C, b3, s), "tr q k v");
       }
     } else {
     w2lCheck(w2l_linear_forward(M, C, C, x, wq.w(cx), bq.w(cx), q, 0, s), "tr q");
@@ -1027,9 +1079,9 @@ class TransformerLayer : public Layer {
       w2lCheck(w2l_linear_forward(M, C, C, ctx, wf.w(cx), bf.w(cx), o, 0, s), "tr wf");
     }
     // r1 = o + x (stored over o), h = LN1(r1)
-    w2lCheck(w2l_residual_layernorm_forward(M, C, o, x, o, h, gb1.w(cx), 1e-5f, 0.0, 0, 0, (double*)(ar + st1Off), ar + mr1Off, s), "tr ln1");
+    const bool hImages = lnForward(cx, ar, M, C, o, x, o, h, gb1.w(cx), 0.0, 0, 0, (double*)(ar + st1Off), ar + mr1Off, mixed ? &hImg : nullptr, "tr ln1");
     if (mixed) {
-      hImg.convert(cx, ar, h, "tr h images");
+      if (!hImages) hImg.convert(cx, ar, h, "tr h images");
       bl1.forward(cx, ar, hImg, b1.w(cx), u, 1, 0.0, 0, 0);
       uImg.convert(cx, ar, u, "tr u images");
       bl2.forward(cx, ar, uImg, b2.w(cx), m2, 0, 0.0, 0, 0);
@@ -1037,7 +1089,11 @@ class TransformerLayer : public Layer {
     w2lCheck(w2l_linear_forward(M, C, mlp, h, w1.w(cx), b1.w(cx), u, 1, s), "tr w1");
     w2lCheck(w2l_linear_forward(M, mlp, C, u, w2.w(cx), b2.w(cx), m2, 0, s), "tr w2");
     }
-    w2lCheck(w2l_residual_layernorm_forward(M, C, m2, h, m2, out, gb2.w(cx), 1e-5f, 0.0, 0, 0, (double*)(ar + st2Off), ar + mr2Off, s), "tr ln2");
+    const bool outImages = lnForward(cx, ar, M, C, m2, h, m2, out, gb2.w(cx), 0.0, 0, 0, (double*)(ar + st2Off), ar + mr2Off,
+                                     mixed ? &outImg : nullptr, "tr ln2");
+    if (outImages) {   // a following Transformer block of the same width reads them as its x images
+      cx.imgOf = out; cx.imgRowsOff = outImg.rowsOff; cx.imgTransOff = outImg.transOff; cx.imgRows = M; cx.imgCols = C;
+    }
     y = out;
   }
   // the four projection bias gradients are row C of the grouped weight-gradient product (ones rows in the x / ctx images)
@@ -1080,10 +1136,11 @@ class TransformerLayer : public Layer {
       return;
     }
     const long long TC = (long long)T * C, TT = (long long)T * T;
-    w2lCheck(w2l_layernorm_backward(M, C, m2, dy, gb2.w(cx), ar + mr2Off, ds2, gb2.g(cx), nullptr, nullptr, 1.f, (double*)(ar + st2Off), s), "tr ln2 bwd");
     const bool mixed = cx.bf16;
+    const bool ds2Images = lnBackward(cx, ar, M, C, m2, dy, gb2.w(cx), ar + mr2Off, ds2, gb2.g(cx), nullptr, nullptr, 1.f, (double*)(ar + st2Off),
+                                      mixed ? &ds2Img : nullptr, 0.0, 0, 0, "tr ln2 bwd");
     if (mixed) {
-      ds2Img.convert(cx, ar, ds2, "tr ds2 images");
+      if (!ds2Images) ds2Img.convert(cx, ar, ds2, "tr ds2 images");
       const bool rides2 = bl2.biasRides(uImg, w2.g(cx), b2.g(cx));
       bl2.backwardWeight(cx, ar, uImg, ds2Img, w2.g(cx), rides2);
       if (!rides2) w2lCheck(w2l_colsum(ds2, b2.g(cx), (size_t)M, C, s), "tr w2 bwd b");
@@ -1101,9 +1158,10 @@ class TransformerLayer : public Layer {
     w2lCheck(w2l_colsum(du, b1.g(cx), (size_t)M, mlp, s), "tr w1 bwd b");
     w2lCheck(w2l_linear_backward_data_add(M, C, mlp, du, w1.w(cx), ds2, dh, s), "tr w1 bwd x");
     }
-    w2lCheck(w2l_layernorm_backward(M, C, o, dh, gb1.w(cx), ar + mr1Off, dr1, gb1.g(cx), nullptr, nullptr, 1.f, (double*)(ar + st1Off), s), "tr ln1 bwd");
+    const bool dr1Images = lnBackward(cx, ar, M, C, o, dh, gb1.w(cx), ar + mr1Off, dr1, gb1.g(cx), nullptr, nullptr, 1.f, (double*)(ar + st1Off),
+                                      mixed ? &dr1Img : nullptr, 0.0, 0, 0, "tr ln1 bwd");
     if (mixed) {
-      dr1Img.convert(cx, ar, dr1, "tr dr1 images");
+      if (!dr1Images) dr1Img.convert(cx, ar, dr1, "tr dr1 images");
       // (wf's weight and bias gradients join those of wq / wk / wv in one grouped launch at the end of this function)
       blf.backwardData(cx, ar, dr1Img, dctx, nullptr, 1.f, nullptr, 0);
     } else {
@@ -1172,12 +1230,12 @@ class TransformerLayer : public Layer {
         w2lCheck(w2l_bf16_convert_multi(3, gd, s), "tr dq / dk / dv images");
       }
       {   // the four C x C weight gradients (64 tiles each at the recipe's width) in ONE grouped launch
-        const uint16_t* A4[4] = {xImg.t(ar), xImg.t(ar), xImg.t(ar), ctxImg.t(ar)};
+        const uint16_t* A4[4] = {xSeen.t(ar), xSeen.t(ar), xSeen.t(ar), ctxImg.t(ar)};
         const uint16_t* B4[4] = {dqImg.t(ar), dkImg.t(ar), dvImg.t(ar), dr1Img.t(ar)};
         float* C4[4] = {wq.g(cx), wk.g(cx), wv.g(cx), wf.g(cx)};
         // with the ones rows of the x / ctx images the four bias gradients are row C of the four products
         const bool rides = projectionBiasRides(cx);
-        w2lCheck(w2l_gemm_bf16_grouped(4, C + (rides ? 1 : 0), C, M, A4, xImg.rowsP, B4, dqImg.rowsP, C4, C, nullptr, s),
+        w2lCheck(w2l_gemm_bf16_grouped(4, C + (rides ? 1 : 0), C, M, A4, xSeen.rowsP, B4, dqImg.rowsP, C4, C, nullptr, s),
                  "tr projection weight gradients");
         if (!rides) {
           w2lCheck(w2l_colsum(dr1, bf.g(cx), (size_t)M, C, s), "tr wf bwd b");
@@ -1263,12 +1321,15 @@ const float* Sequential::forward(Ctx& c, float* arena, const float* xRef) {
   float* x = arena + inOff_;
   w2lCheck(w2l_transpose(xRef, x, in_.B, in_.F, in_.T, c.stream), "input transpose");
   const float* cur = x;
+  c.imgOf = nullptr;
   for (size_t i = 0; i < layers_.size(); ++i) {
     float* y = nullptr;
     layers_[i]->forward(c, arena, cur, y);
+    if (c.imgOf != y) c.imgOf = nullptr;   // a note about bf16 images only ever describes the activation handed to the NEXT layer
     ys_[i] = y;
     cur = y;
   }
+  c.imgOf = nullptr;
   return cur;
 }
 

@@ -84,6 +84,13 @@ struct Ctx {
   int inputT = 0;                     // frames of the padded network input the sizes refer to
   const float* inputSizeFull = nullptr;  // device scalar or null: the size inputT frames correspond to (a batch padded beyond its longest utterance)
   bool bf16 = false;                  // mixed precision: the fl::Linear products run on bf16 operand images (gemm_bf16g.hpp)
+  // mixed precision: bf16 images of the activation `imgOf` that the layer producing it has already written (row-major
+  // [imgRows][pad64(imgCols)] at arena float offset imgRowsOff, transposed [imgCols + 1 ones row][pad64(imgRows)] at imgTransOff).
+  // Sequential::forward clears the note unless the layer that just ran left it for its own output; a consumer whose input matrix
+  // has another shape ignores it.
+  const float* imgOf = nullptr;
+  size_t imgRowsOff = 0, imgTransOff = 0;
+  int imgRows = 0, imgCols = 0;
 };
 
 class Planner {  // bump allocator over the activation arena (sizes only until bound)

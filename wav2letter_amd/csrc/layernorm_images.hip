@@ -8,8 +8,8 @@
 //   images    row-major [row][ldRows] and transposed [column][ldTrans] bf16 (nearest even) of y, resp. of dr -- optionally of
 //             dropout(dr) with the library's stateless hash over the flat index: what w2l_bf16_convert_dropout produced
 //
-// The transposed image needs runs along the ROW index, so one workgroup owns 16 consecutive rows (a wave normalises one row at a
-// time, the row in registers between statistics and apply, wave reductions only -- no block barrier per row), leaves the rounded
+// The transposed image needs runs along the ROW index, so one workgroup of 16 waves owns 16 consecutive rows (a wave normalises one
+// row, the row in registers between statistics and apply, wave reductions only -- no block barrier per row), leaves the rounded
 // rows in an LDS tile [16][inner] and writes the tile out column by column as 32-byte runs.  HBM-bound like the kernels it
 // replaces: + 4 bytes per element of writes, instead of a second kernel's 4 read + 4 written.
 // Reference: fl::LayerNorm in the arch grammar (recipes/joint_training_vox_populi/cpc/SequentialBuilder.cpp:358-377); the casts of
@@ -20,8 +20,9 @@ namespace w2l {
 
 int ln_param_grad(const double* sums, int groups, float* dGammaBeta, hipStream_t stream);   // elementwise.hip
 
-constexpr int kLiRows = 16;         // rows per workgroup
-constexpr int kLiThreads = 256;     // four waves, four rows each
+constexpr int kLiRows = 16;         // rows per workgroup: 32-byte runs of the transposed image (32 rows / 64-byte runs: the same
+                                    // time on rows of 2160 floats, slower on 1024: fewer workgroups; profiles/r04_run23_*)
+constexpr int kLiThreads = 1024;    // sixteen waves, one row each: every row of the tile is in flight at once
 constexpr int kLiMaxV = 9;          // float4 per lane: rows of at most 64 * 4 * 9 = 2304 floats
 constexpr size_t kLiMaxInner = 64 * 4 * kLiMaxV;
 
@@ -59,8 +60,11 @@ __device__ __forceinline__ void li_write_transposed(const uint32_t* tile, int pi
     }
     uint4* d0 = (uint4*)(im.transposed + (size_t)(2 * cp) * im.ldTrans + g0);
     uint4* d1 = (uint4*)(im.transposed + (size_t)(2 * cp + 1) * im.ldTrans + g0);
-    d0[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]); d0[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
-    d1[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]); d1[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+#pragma unroll
+    for (int q = 0; q < kLiRows / 8; ++q) {
+      d0[q] = make_uint4(lo[4 * q], lo[4 * q + 1], lo[4 * q + 2], lo[4 * q + 3]);
+      d1[q] = make_uint4(hi[4 * q], hi[4 * q + 1], hi[4 * q + 2], hi[4 * q + 3]);
+    }
   }
 }
 
@@ -73,13 +77,12 @@ __global__ __launch_bounds__(kLiThreads) void ln_rows_images_k(LiP p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g0 = blockIdx.x * kLiRows;
 #pragma unroll 1
-  for (int q = 0; q < kLiRows / 4; ++q) {
-    const int rr = wave + 4 * q, g = g0 + rr;
+  for (int q = 0; q < kLiRows / 16; ++q) {
+    const int rr = wave + 16 * q, g = g0 + rr;
     uint32_t* trow = tile + rr * pitchDw;
     if (g >= p.groups) {   // past the last row: zeros in the tile (the transposed runs cover 16 rows)
       for (int i = lane; i < n4; i += 64) *(uint2*)(trow + 2 * i) = make_uint2(0u, 0u);
-      continue;
-    }
+    } else {
     const size_t base = (size_t)g * inner;
     if constexpr (!BWD) {
       float4 v[kLiMaxV];
@@ -183,6 +186,7 @@ __global__ __launch_bounds__(kLiThreads) void ln_rows_images_k(LiP p) {
         }
       }
     }
+    }
   }
   __syncthreads();
   li_write_transposed(tile, pitchDw, inner, g0, p.im);
@@ -220,6 +224,7 @@ W2L_API int w2l_residual_layernorm_forward_images(int groups, size_t inner, floa
   if (groups <= 0 || inner == 0 || !a || !r || !y || !gammaBeta || !meanRstd) return W2L_EINVAL;
   if (p < 0.0 || p >= 1.0) return W2L_EINVAL;
   if ((inner & 3) || inner > kLiMaxInner) return W2L_EUNSUPPORTED;
+  if (tune_env("W2L_LN_IMG_OFF")) return W2L_EUNSUPPORTED;   // probe build: A/B against LayerNorm + conversion pass
   if (!li_sink_ok(yImages, groups, inner)) return W2L_EINVAL;
   if ((((uintptr_t)a) | ((uintptr_t)x) | ((uintptr_t)r) | ((uintptr_t)y)) & 15) return W2L_EINVAL;
   LiP q{};
@@ -238,6 +243,7 @@ W2L_API int w2l_layernorm_backward_images(int groups, size_t inner, const float*
   if (groups <= 0 || inner == 0 || !r || !dy || !gammaBeta || !meanRstd || !dr || !sums) return W2L_EINVAL;
   if (imageDropP < 0.0 || imageDropP >= 1.0 || (maskSrc && !dmask)) return W2L_EINVAL;
   if ((inner & 3) || inner > kLiMaxInner) return W2L_EUNSUPPORTED;
+  if (tune_env("W2L_LN_IMG_OFF")) return W2L_EUNSUPPORTED;
   if (!li_sink_ok(drImages, groups, inner)) return W2L_EINVAL;
   if ((((uintptr_t)r) | ((uintptr_t)dy) | ((uintptr_t)dr) | ((uintptr_t)maskSrc) | ((uintptr_t)dmask)) & 15) return W2L_EINVAL;
   LiP q{};
