@@ -338,9 +338,13 @@ struct BfLinear {   // the weight images of one fl::Linear(in, out) and its thre
 // LayerNorm of the mixed-precision mode: where the normalised rows are the rows of the next product's operand (`img` non-null,
 // rows of at most 2304 floats) the images come out of the LayerNorm kernel itself (layernorm_images.hip) -- returns true then;
 // otherwise the plain kernels run and the caller converts.
+// Measured on one box (profiles/r04_run24_ln_images_ab.log): at config 5's 3008 x 1024 matrices the image-writing kernels replace a
+// launch-bound conversion; at config 3's 11968 x 1200 ... 2160 they stream at 3.5 TB/s against 5.4 for LayerNorm + conversion and
+// the step LOSES 0.8 ms -- so they are used below kLnImageElems only.
+constexpr size_t kLnImageElems = (size_t)1 << 22;
 static bool lnForward(Ctx& cx, float* ar, int groups, size_t inner, float* a, const float* x, float* r, float* y, const float* gb, double p,
                       uint32_t seed, uint32_t stream, double* stats, float* mr, const BfImage* img, const char* what) {
-  if (img && img->rows == groups && (size_t)img->cols == inner) {
+  if (img && img->rows == groups && (size_t)img->cols == inner && (size_t)groups * inner <= kLnImageElems) {
     const w2l_bf16_image_sink k = img->sink(cx, ar);
     const int st = w2l_residual_layernorm_forward_images(groups, inner, a, x, r, y, gb, 1e-5f, p, seed, stream, mr, &k, cx.stream);
     if (st == W2L_OK) return true;
@@ -353,7 +357,7 @@ static bool lnForward(Ctx& cx, float* ar, int groups, size_t inner, float* a, co
 static bool lnBackward(Ctx& cx, float* ar, int groups, size_t inner, const float* r, const float* dy, const float* gb, const float* mr, float* dr,
                        float* dgb, const float* maskSrc, float* dmask, float maskScale, double* sums, const BfImage* img, double imgP,
                        uint32_t imgSeed, uint32_t imgStream, const char* what) {
-  if (img && img->rows == groups && (size_t)img->cols == inner) {
+  if (img && img->rows == groups && (size_t)img->cols == inner && (size_t)groups * inner <= kLnImageElems) {
     const w2l_bf16_image_sink k = img->sink(cx, ar);
     const int st = w2l_layernorm_backward_images(groups, inner, r, dy, gb, mr, dr, dgb, maskSrc, dmask, maskScale, sums, &k, imgP, imgSeed,
                                                  imgStream, cx.stream);
