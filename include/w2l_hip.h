@@ -474,6 +474,11 @@ int w2l_trainer_bind(void* h, float* params, float* grads, float* momentum, floa
 int w2l_trainer_forward(void* h, const float* x, int train, const float** emission, void* stream);
 int w2l_trainer_forward_backward(void* h, const float* x, const int* target, float** lossDev,
                                  void* stream);
+/* backward pass of the network alone from a caller-supplied gradient of the emissions [B][T'][N] (device): the fl::Module boundary
+ * for a binder that keeps its own criterion.  After w2l_trainer_forward(train = 1) of the same step; leaves the network's
+ * gradients in the gradient arena (unscaled).  Replaces: fl::Variable::backward through the module graph
+ * (recipes/slimIPL/src/Train.cpp:1719-1721). */
+int w2l_trainer_backward(void* handle, const float* dEmission, void* stream);
 /* totalBatch > 0: scale the gradients by 1/totalBatch; totalBatch <= 0: by 1 / (the all-reduced batch size in the
  * gradient arena's tail).  A non-finite gradient (or batch size) skips the update on every rank -- with or without
  * clipping -- and counts it (w2l_trainer_skipped_updates). */

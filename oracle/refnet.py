@@ -394,6 +394,9 @@ class RefNet:
         da = d_em[None]
         for rec in reversed(self.tape):
             k = rec[0]
+            if k in ("TDS", "TR") and getattr(self, "upstream", None) is not None:
+                # teacher-forced per-block tests: the gradient arriving at this block's output, beside the record that holds its input
+                self.upstream.append((rec, np.array(da, dtype=np.float32, copy=True)))
             if k == "PD":
                 da = np.ascontiguousarray(da[..., rec[1]:rec[1] + rec[2]])
             elif k == "V":

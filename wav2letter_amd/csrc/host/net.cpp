@@ -1309,8 +1309,16 @@ size_t Sequential::plan(int B, int T, int nFeat) {
   }
   out_ = a;
   // emissions must be (N, T', B, 1) == physical [B][T'][N]
-  bool ok = out_.d[0].f.size() <= 1 && (out_.d[0].f.empty() || (out_.d[0].f[0].kind == F_FEAT && out_.d[0].f[0].stride == 1)) &&
-            out_.d[0].size() == out_.F;
+  // (dimension 0 may be several feature factors -- a View over a convolution layout -- as long as they tile the frame contiguously,
+  // fastest first: the flat feature index is then the logical one)
+  bool ok = out_.d[0].size() == out_.F;
+  {
+    long run = 1;
+    for (auto& f : out_.d[0].f) {
+      ok = ok && f.kind == F_FEAT && f.stride == run;
+      run *= f.size;
+    }
+  }
   std::vector<FKind> rest;
   for (int i = 1; i < 4; ++i)
     for (auto& f : out_.d[i].f) rest.push_back(f.kind);

@@ -220,6 +220,21 @@ W2L_API int w2l_trainer_forward_backward(void* h, const float* x, const int* tar
   });
 }
 
+// backward pass of the NETWORK alone from a caller-supplied gradient of the emissions [B][T'][N] -- the fl::Module boundary for
+// a binder that keeps its own criterion (and the hook of the teacher-forced per-layer parity tests).  Call after
+// w2l_trainer_forward(train = 1) of the same step: leaves the network's gradients in the grads arena (unscaled), the
+// criterion's part untouched.
+W2L_API int w2l_trainer_backward(void* h, const float* dEmission, void* stream) {
+  Trainer* t = (Trainer*)h;
+  TRY(h, {
+    requireBound(t);
+    if (!dEmission) throw std::invalid_argument("backward: null gradient");
+    if (!t->emission) throw std::invalid_argument("backward: no forward pass to differentiate");
+    Ctx c = makeCtx(t, stream, true);
+    { MatmulMode mm(t->mixedPrecision); t->net->backward(c, t->arena, dEmission); }
+  });
+}
+
 // optimizer: grads *= 1/totalBatch, global-norm clip (network, and criterion if clampCrit), SGD+momentum
 // on the network (lr, momentum), plain SGD on the criterion (lrcrit)  [Train.cpp:577-582, :1791-1802]
 W2L_API int w2l_trainer_update(void* h, float lr, float lrcrit, float momentum, float maxGradNorm,

@@ -37,6 +37,7 @@ def _lib_tr():
         L.w2l_trainer_bind.argtypes = [vp, vp, vp, vp, vp, vp]
         L.w2l_trainer_forward.argtypes = [vp, vp, i, C.POINTER(vp), vp]
         L.w2l_trainer_forward_backward.argtypes = [vp, vp, vp, C.POINTER(vp), vp]
+        L.w2l_trainer_backward.argtypes = [vp, vp, vp]
         L.w2l_trainer_update.argtypes = [vp, f, f, f, f, f, i, vp]
         L.w2l_trainer_viterbi.argtypes = [vp, vp, vp, vp]
         L.w2l_trainer_set_step.argtypes = [vp, u32]
@@ -195,6 +196,13 @@ class Trainer:
                                                    self._stream()), "forward_backward")
         off = (ptr.value - self.arena.data_ptr()) // 4
         return self.arena[off:off + self.B]
+
+    def backward(self, d_emission):
+        """the network's backward pass alone from a caller-supplied gradient of the emissions [B][T'][N] (after
+        forward(train=True)): the fl::Module boundary for a binder that keeps its own criterion"""
+        assert d_emission.is_cuda and d_emission.dtype == torch.float32 and d_emission.is_contiguous()
+        assert d_emission.numel() == self.B * self.Tout * self.nlabel, (tuple(d_emission.shape), self.B, self.Tout, self.nlabel)
+        _check(self.L.w2l_trainer_backward(self.h, d_emission.data_ptr(), self._stream()), "backward")
 
     def update(self, lr, lrcrit=0.0, momentum=0.0, max_grad_norm=0.0, total_batch=None, clamp_crit=True):
         """total_batch: None -> this rank's B; a number -> that; 0 (or "reduced") -> the all-reduced batch size that
