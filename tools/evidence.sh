@@ -1,12 +1,12 @@
 #!/bin/bash
-# round-3 evidence run on the final tree: the default bench line, rocprofv3 kernel statistics per bench leg, PMC traffic passes
+# evidence run on the final tree (rounds 3 and 4): the default bench line, rocprofv3 kernel statistics per bench leg, PMC traffic passes
 # usage (on the GPU box): bash tools/evidence.sh <tag>      -> gpurun_out/<tag>_*
 tag=${1:-ev}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 (time timeout 900 python bench.py) > gpurun_out/${tag}_bench.log 2> gpurun_out/${tag}_bench.err
-common="--no-cpu-baseline --no-input-pipeline --no-oracle-checks"
+common="--no-cpu-baseline --no-input-pipeline --no-oracle-checks --no-train-binary"
 timeout 400 bash tools/prof.sh ${tag}_headline_asg_ctc bench.py --steps 3 --warmup 1 --no-stress --no-c4 --no-c3 --no-c5 $common
 timeout 400 bash tools/prof.sh ${tag}_stress bench.py --steps 1 --warmup 0 --no-asg --no-c4 --no-c3 --no-c5 $common
 timeout 400 bash tools/prof.sh ${tag}_c4 bench.py --steps 1 --warmup 0 --no-asg --no-stress --no-c3 --no-c5 $common

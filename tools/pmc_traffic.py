@@ -26,6 +26,8 @@ def main():
     f, w = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
     groups = {"gemm_lds_dma": ("gemm128g_kernel", "gemm160_kernel"), "gemm128g": ("gemm128g_kernel",), "gemm160": ("gemm160_kernel",),
               "gemm128_kernel": ("gemm128_kernel",), "fcc_big_gemm": ("fcc_big_gemm",),
+              "fcc_big_gemm_alpha": ("fcc_big_gemm_dma<true",), "fcc_big_gemm_beta": ("fcc_big_gemm_dma<false",),
+              "attn_fused_bwd": ("attn_fused_bwd_q_k", "attn_fused_bwd_kv_k"), "ln_images": ("ln_rows_images_k",),
               "tds_conv_fwd2": ("tds_conv_fwd2_k",), "tds_conv_filter2": ("tds_conv_filter2_k",),
               "tds_conv_rs": ("tds_conv_rs_k", "tds_conv_rs3_k"), "tds_conv_rsf": ("tds_conv_rsf_k", "tds_conv_rsf3_k"), "gemm_bf16": ("gemm128_bf16_kernel",),
               "gemm_bf16_images": ("gemm128h_kernel", "gemm256h_kernel"), "cvt_bf16": ("cvt_bf16_k", "cvt_bf16_multi_k"),

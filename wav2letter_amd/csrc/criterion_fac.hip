@@ -751,10 +751,13 @@ __global__ __launch_bounds__(256) void fac_scatter_k(int T, int N, int L, int TC
     for (int i = threadIdx.x; i < S; i += 256) {
       float* const col = rows + y[i];
       const float* src = dr + i;
-#pragma unroll 8
-      for (int tt = 0; tt < tc; ++tt) {
-        const float v = src[(size_t)tt * L];
-        if (v != 0.f) atomicAdd(col + tt * N, v);
+      for (int t8 = 0; t8 < tc; t8 += 8) {   // eight row loads in flight, THEN the LDS atomics (an atomic orders the loads behind it)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = t8 + u < tc ? src[(size_t)(t8 + u) * L] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (v[u] != 0.f) atomicAdd(col + (t8 + u) * N, v[u]);
       }
     }
   }
@@ -767,7 +770,15 @@ __global__ void reduce_over_b_fac(int B, size_t n, const float* __restrict__ par
   size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   float s = 0.f;
-  for (int b = 0; b < B; ++b) s += part[(size_t)b * n + k];
+  int b = 0;
+  for (; b + 7 < B; b += 8) {   // eight loads in flight; the additions keep their order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + u) * n + k];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; b < B; ++b) s += part[(size_t)b * n + k];
   out[k] = s;
 }
 

@@ -287,11 +287,12 @@ __global__ void reduce_over_b(int B, size_t n, const float* __restrict__ part, f
   if (k >= n) return;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int b = 0;
-  for (; b + 3 < B; b += 4) {   // four loads in flight
-    s0 += part[(size_t)b * stride * n + k];
-    s1 += part[(size_t)(b + 1) * stride * n + k];
-    s2 += part[(size_t)(b + 2) * stride * n + k];
-    s3 += part[(size_t)(b + 3) * stride * n + k];
+  for (; b + 7 < B; b += 8) {   // eight loads in flight (a handful of blocks: the kernel is one load latency per iteration)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + u) * stride * n + k];
+    s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
+    s0 += v[4]; s1 += v[5]; s2 += v[6]; s3 += v[7];
   }
   for (; b < B; ++b) s0 += part[(size_t)b * stride * n + k];
   out[k] = (s0 + s1) + (s2 + s3);
@@ -303,8 +304,14 @@ __global__ void reduce_chunks(int C, size_t n, float* __restrict__ part) {
   if (k >= n) return;
   float* p = part + (size_t)blockIdx.y * C * n;
   float s0 = 0.f, s1 = 0.f;
-  for (int c = 0; c + 1 < C; c += 2) { s0 += p[(size_t)c * n + k]; s1 += p[(size_t)(c + 1) * n + k]; }
-  if (C & 1) s0 += p[(size_t)(C - 1) * n + k];
+  int c = 0;
+  for (; c + 7 < C; c += 8) {   // eight loads in flight
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(c + u) * n + k];
+    s0 += v[0]; s1 += v[1]; s0 += v[2]; s1 += v[3]; s0 += v[4]; s1 += v[5]; s0 += v[6]; s1 += v[7];
+  }
+  for (; c < C; ++c) s0 += p[(size_t)c * n + k];
   p[k] = s0 + s1;
 }
 
