@@ -281,6 +281,61 @@ __global__ __launch_bounds__(64) void fcc_dtrans_small(int T, int N, const float
   }
 }
 
+// The same partial for the N <= 31 path on the matrix pipe: sum_t r_t[i] e_{t-1}[j] is a [N x frames] . [frames x N] product -- one
+// v_mfma_f32_32x32x2_f32 per two frames (A: lane (i, k) = r_{t+k}[i], B: lane (k, j) = e_{t+k-1}[j]) instead of 30 broadcasts + 30
+// FMAs per frame: 39 -> ~8 us behind the backward scan at B = 64, T = 2000 (it is on the criterion's critical path).
+__global__ __launch_bounds__(64) void fcc_dtrans_mfma(int T, int N, const float* __restrict__ trans, const float* __restrict__ grad, FccWs ws) {
+  typedef float f32x16_t __attribute__((ext_vector_type(16)));
+  const int b = blockIdx.x, c = blockIdx.y;
+  const bool lin = !ws.redo[b];   // a flagged utterance ran on the log-domain kernels: `ahat` holds logarithms there
+  const int lane = threadIdx.x, li = lane & 31, lh = lane >> 5;
+  const bool act = li < N;
+  const float* ahb = ws.ahat + (size_t)b * T * N;
+  const float* rb = ws.r + (size_t)b * T * N;
+  const int per = (T - 1 + kDtChunks - 1) / kDtChunks;
+  const int t0 = 1 + c * per;
+  int t1 = t0 + per;
+  if (t1 > T) t1 = T;
+  f32x16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int t = t0; t < t1; t += 8) {   // four frame pairs per round: eight loads in flight
+    float rv[4], ev[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int tt = t + 2 * u + lh;
+      const bool ok = act && tt < t1;
+      const int tc = tt < t1 ? tt : t0;
+      rv[u] = rb[(size_t)tc * N + (act ? li : 0)];
+      ev[u] = ahb[(size_t)(tc - 1) * N + (act ? li : 0)];
+      if (!ok) rv[u] = 0.f;
+      if (!lin) ev[u] = __expf(ev[u]);
+      if (!ok) ev[u] = 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rv[u], ev[u], acc, 0, 0, 0);
+  }
+  const float g = ws.scale[b] * grad[b];
+  float* tg = ws.tgpart + ((size_t)b * kDtChunks + c) * N * N;
+  // rowmax_i (the scan's exp(A - rowmax) normalisation) in lane i; a lane of the C layout holds column j = li of rows (r & 3) + 8 (r >> 2) + 4 lh
+  float rowmax = -INFINITY;
+  {
+    float tv[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) tv[j] = (lane < N && j < N) ? trans[(size_t)lane * N + j] : -INFINITY;   // all loads issued at once
+#pragma unroll
+    for (int j = 0; j < 32; ++j) rowmax = fmaxf(rowmax, tv[j]);
+    if (lane >= N) rowmax = 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i0 = (r & 3) + 8 * (r >> 2);
+    const float rm = lh ? readlane(rowmax, i0 + 4) : readlane(rowmax, i0);
+    const int i = i0 + 4 * lh;
+    if (act && i < N) tg[(size_t)i * N + li] = g * __expf(trans[(size_t)i * N + li] - rm) * acc[r];
+  }
+}
+
 // out[k] = sum_b part[b * stride][k]  (deterministic order)
 __global__ void reduce_over_b(int B, size_t n, const float* __restrict__ part, float* __restrict__ out, int stride = 1) {
   size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -500,7 +555,9 @@ W2L_API int w2l_fcc_backward(int B, int T, int N, const float* trans, const floa
   else
     hipLaunchKernelGGL(fcc_bwd_small<64>, dim3(B), dim3(64), 0, s, T, N, trans, grad, inputGrad, ws);
   W2L_LAUNCH_CHECK();
-  if (dpp)
+  if (dpp && !tune_env("W2L_FCC_DTRANS_OLD"))
+    hipLaunchKernelGGL(fcc_dtrans_mfma, dim3(B, kDtChunks), dim3(64), 0, s, T, N, trans, grad, ws);
+  else if (dpp)
     hipLaunchKernelGGL((fcc_dtrans_small<32, true>), dim3(B, kDtChunks), dim3(64), 0, s, T, N, trans, grad, ws);
   else if (N <= 32)
     hipLaunchKernelGGL(fcc_dtrans_small<32>, dim3(B, kDtChunks), dim3(64), 0, s, T, N, trans, grad, ws);
