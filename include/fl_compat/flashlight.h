@@ -224,6 +224,10 @@ class FL_COMPAT_API FirstOrderOptimizer {
   double lr_;
 };
 
+// every gradient of `params` multiplied by `s` IN PLACE (Train.cpp:1748-1760 writes `p.grad() = p.grad() / totalBatchSize`, one
+// temporary per parameter); gradients that are the slices of one planned network's gradient arena are scaled as the arena
+FL_COMPAT_API void scaleGradients(const std::vector<Variable>& params, double s);
+
 class FL_COMPAT_API SGDOptimizer : public FirstOrderOptimizer {
  public:
   SGDOptimizer(const std::vector<Variable>& params, double lr, double momentum = 0, double weightDecay = 0, bool useNesterov = false);
@@ -236,6 +240,13 @@ class FL_COMPAT_API SGDOptimizer : public FirstOrderOptimizer {
   double mu_, wd_;
   bool nesterov_;
   std::vector<af::array> velocities_;
+  // parameters that are exactly the slices of ONE planned network's flat parameter arena: the velocities are views of one flat
+  // buffer with the same offsets and step() is a single launch over (parameters, gradients, velocities) -- the reference walks
+  // the parameters one by one (a few hundred launches per update); anything else falls back to that walk
+  float* flatParams_ = nullptr;
+  float* flatVel_ = nullptr;
+  size_t flatFloats_ = 0;
+  std::vector<size_t> flatOffsets_;
 };
 
 // --netoptim=adagrad (recipes/sota/2019/librivox/train_am_transformer_ctc.cfg:25-26): variance += g^2, p -= lr g / (sqrt(variance) + eps)

@@ -214,13 +214,52 @@ std::string SpecAugment::prettyString() const {
 }
 
 // ------------------------------------------------------------------------------------------------ optimizers
+namespace {
+// Gradient (or parameter) storage of a parameter list as contiguous runs: the parameters of a planned network are slices of its
+// flat arenas, and when ALL of them are in the list (at their own offsets) they collapse to the arena -- one launch instead of one
+// per parameter (4-float alignment gaps between the slices are zero: nothing ever writes them).  Defined below, next to the arenas.
+struct FlatRun { float* p; size_t n; };
+std::vector<FlatRun> gradientRuns(const std::vector<Variable>& params);
+bool flatParameterArena(const std::vector<Variable>& params, float*& base, size_t& floats, std::vector<size_t>& offsets);
+bool gradientArenaOf(const float* g, float*& base);
+}  // namespace
+
+void scaleGradients(const std::vector<Variable>& params, double s) {
+  if (s == 1.0) return;
+  for (const FlatRun& r : gradientRuns(params)) w2l::w2lCheck(w2l_axpy(r.p, r.p, r.n, (float)(s - 1.0), S()), "scaleGradients");
+}
+
 SGDOptimizer::SGDOptimizer(const std::vector<Variable>& params, double lr, double momentum, double weightDecay, bool useNesterov)
     : FirstOrderOptimizer(params, lr), mu_(momentum), wd_(weightDecay), nesterov_(useNesterov) {
   if (wd_ != 0 || nesterov_) throw std::invalid_argument("fl_compat SGDOptimizer: weight decay / Nesterov are not on the hot path of the recipes");
+  if (flatParameterArena(parameters_, flatParams_, flatFloats_, flatOffsets_)) {
+    if (mu_ != 0) {   // one flat velocity buffer, the per-parameter arrays (checkpoints read them) are views of it
+      std::shared_ptr<void> owner = devAlloc(flatFloats_ * sizeof(float));
+      w2l::hipCheck(hipMemsetAsync(owner.get(), 0, flatFloats_ * sizeof(float), S()), "sgd velocities");
+      flatVel_ = (float*)owner.get();
+      for (size_t i = 0; i < parameters_.size(); ++i)
+        velocities_.push_back(af::array::wrap(flatVel_ + flatOffsets_[i], parameters_[i].dims(), af::f32, owner));
+    }
+    return;
+  }
+  flatParams_ = nullptr;
   if (mu_ != 0)
     for (auto& p : parameters_) velocities_.push_back(af::constant(0.0, p.dims(), af::f32));
 }
 void SGDOptimizer::step() {
+  if (flatParams_) {   // every gradient (and velocity) still at its arena offset?  then the whole network is one launch
+    float* gbase = nullptr;
+    bool flat = !parameters_.empty() && parameters_[0].isGradAvailable() && gradientArenaOf(parameters_[0].grad().array().device<float>(), gbase);
+    for (size_t i = 0; flat && i < parameters_.size(); ++i) {
+      auto& p = parameters_[i];
+      flat = p.isGradAvailable() && p.array().device<float>() == flatParams_ + flatOffsets_[i] &&
+             p.grad().array().device<float>() == gbase + flatOffsets_[i] && (mu_ == 0 || velocities_[i].device<float>() == flatVel_ + flatOffsets_[i]);
+    }
+    if (flat) {
+      w2l::w2lCheck(w2l_sgd_step(flatParams_, gbase, mu_ != 0 ? flatVel_ : nullptr, flatFloats_, (float)lr_, (float)mu_, 1.f, 0.f, nullptr, S()), "sgd");
+      return;
+    }
+  }
   for (size_t i = 0; i < parameters_.size(); ++i) {
     auto& p = parameters_[i];
     if (!p.isGradAvailable()) continue;
@@ -282,9 +321,9 @@ double clipGradNorm(const std::vector<Variable>& params, double maxNorm) {
   static std::shared_ptr<void> acc = devAlloc(sizeof(double));
   double* d = (double*)acc.get();
   bool first = true;
-  for (auto& p : params) {
-    if (!p.isGradAvailable()) continue;
-    w2l::w2lCheck(w2l_sumsq(p.grad().array().device<float>(), (size_t)p.elements(), d, first ? 1 : 0, S()), "clipGradNorm");
+  const std::vector<FlatRun> runs = gradientRuns(params);
+  for (const FlatRun& r : runs) {
+    w2l::w2lCheck(w2l_sumsq(r.p, r.n, d, first ? 1 : 0, S()), "clipGradNorm");
     first = false;
   }
   if (first) return 0.0;
@@ -294,11 +333,7 @@ double clipGradNorm(const std::vector<Variable>& params, double maxNorm) {
   const double norm = std::sqrt(ss);
   const double scale = maxNorm / (norm + 1e-6);
   if (scale < 1.0)
-    for (auto& p : params)
-      if (p.isGradAvailable()) {
-        float* g = p.grad().array().device<float>();
-        w2l::w2lCheck(w2l_axpy(g, g, (size_t)p.elements(), (float)(scale - 1.0), S()), "clipGradNorm");
-      }
+    for (const FlatRun& r : runs) w2l::w2lCheck(w2l_axpy(r.p, r.p, r.n, (float)(scale - 1.0), S()), "clipGradNorm");
   return norm;
 }
 
@@ -653,6 +688,9 @@ class PlannedNet : public fl::Sequential {
     const size_t n = net_->paramFloats();
     paramArena_ = devAlloc((n + 4) * sizeof(float));
     gradArena_ = devAlloc((n + 4) * sizeof(float));
+    // (the 4-float alignment gaps between the parameters are never written again: whole-arena norms / updates read zeros there)
+    w2l::hipCheck(hipMemsetAsync(paramArena_.get(), 0, (n + 4) * sizeof(float), S()), "params");
+    w2l::hipCheck(hipMemsetAsync(gradArena_.get(), 0, (n + 4) * sizeof(float), S()), "grads");
     std::vector<float> host(n);
     net_->initParams(host.data(), 1);
     w2l::hipCheck(hipMemcpyAsync(paramArena_.get(), host.data(), n * sizeof(float), hipMemcpyHostToDevice, S()), "params");
@@ -818,6 +856,61 @@ bool findArena(const float* p, ArenaInfo& out) {
     float* b = n->gradPtr();
     const size_t fl = n->impl().paramFloats();
     if (p >= b && p < b + fl) { out.base = b; out.floats = fl; out.net = n; return true; }
+  }
+  return false;
+}
+bool gradientArenaOf(const float* g, float*& base) {
+  ArenaInfo ai;
+  if (!findArena(g, ai)) return false;
+  base = ai.base;
+  return true;
+}
+std::vector<FlatRun> gradientRuns(const std::vector<Variable>& params) {
+  std::vector<FlatRun> runs;
+  std::vector<std::pair<void*, size_t>> seen;   // (network, parameters of it found at their own offsets)
+  std::vector<ArenaInfo> info(params.size());
+  std::vector<char> inArena(params.size(), 0);
+  for (size_t i = 0; i < params.size(); ++i) {
+    if (!params[i].isGradAvailable()) continue;
+    float* g = params[i].grad().array().device<float>();
+    if (params[i].grad().type() != af::f32 || !findArena(g, info[i])) continue;
+    const auto& pis = ((pkg::speech::PlannedNet*)info[i].net)->impl().params();
+    bool slice = false;
+    for (const auto& pi : pis) slice = slice || (g == info[i].base + pi.offset && (size_t)params[i].elements() == pi.numel);
+    if (!slice) continue;
+    inArena[i] = 1;
+    bool found = false;
+    for (auto& sp : seen)
+      if (sp.first == info[i].net) { ++sp.second; found = true; }
+    if (!found) seen.push_back({info[i].net, 1});
+  }
+  std::vector<void*> whole;
+  for (auto& sp : seen)
+    if (sp.second == ((pkg::speech::PlannedNet*)sp.first)->impl().params().size()) whole.push_back(sp.first);
+  std::vector<void*> emitted;
+  for (size_t i = 0; i < params.size(); ++i) {
+    if (!params[i].isGradAvailable()) continue;
+    const bool w = inArena[i] && std::find(whole.begin(), whole.end(), info[i].net) != whole.end();
+    if (!w) { runs.push_back({params[i].grad().array().device<float>(), (size_t)params[i].elements()}); continue; }
+    if (std::find(emitted.begin(), emitted.end(), info[i].net) != emitted.end()) continue;
+    emitted.push_back(info[i].net);
+    runs.push_back({info[i].base, info[i].floats});
+  }
+  return runs;
+}
+bool flatParameterArena(const std::vector<Variable>& params, float*& base, size_t& floats, std::vector<size_t>& offsets) {
+  if (params.empty()) return false;
+  for (auto* n : pkg::speech::plannedNets()) {
+    const auto& pis = n->impl().params();
+    if (pis.size() != params.size()) continue;
+    bool all = true;
+    for (size_t i = 0; all && i < pis.size(); ++i)
+      all = params[i].type() == af::f32 && params[i].array().device<float>() == n->paramPtr() + pis[i].offset && (size_t)params[i].elements() == pis[i].numel;
+    if (!all) continue;
+    base = n->paramPtr(); floats = n->impl().paramFloats();
+    offsets.clear();
+    for (const auto& pi : pis) offsets.push_back(pi.offset);
+    return true;
   }
   return false;
 }

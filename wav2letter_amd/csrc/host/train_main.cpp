@@ -739,10 +739,10 @@ int main(int argc, char** argv) {
       af::array totalBatchSizeArr = af::constant((double)loss.dims(0), af::dim4(1), af::f32);   // Train.cpp:1743-1747
       if (reducer) fl::allReduce(totalBatchSizeArr);
       const double totalBatchSize = (double)totalBatchSizeArr.scalar<float>();
-      for (const auto& p : network->params())
-        if (p.isGradAvailable()) p.grad() = p.grad() / totalBatchSize;
-      for (const auto& p : criterion->params())
-        if (p.isGradAvailable()) p.grad() = p.grad() / totalBatchSize;
+      // (Train.cpp:1748-1760: `p.grad() = p.grad() / totalBatchSize` per parameter -- here in place, the planned network's
+      // gradient arena in one launch)
+      fl::scaleGradients(network->params(), 1.0 / totalBatchSize);
+      fl::scaleGradients(criterion->params(), 1.0 / totalBatchSize);
       if (maxgradnorm > 0) {
         auto params = network->params();
         if (clampCrit) {
@@ -770,6 +770,14 @@ int main(int argc, char** argv) {
       ++nbatches;
 
       if (isMaster && ((reportiters > 0 && curBatch % reportiters == 0) || curBatch == iters)) logStatus(curEpoch, curBatch, lr, lrcrit);
+      if (reportiters > 0 && curBatch % reportiters == 0) {
+        // every report starts the next readings afresh (resetTimeStatMeters + the train meters, Train.cpp:1081-1090, :1125-1131,
+        // :1844-1847): a report's timers are those of its own window, not of the run so far
+        timer.reset(); sampletimer.reset(); fwdtimer.reset(); critfwdtimer.reset(); bwdtimer.reset(); optimtimer.reset();
+        runtime.total = 0;
+        lossSum = 0; lossN = 0; editErr = 0; editLen = 0; tszTotal = 0; tszMax = 0; nsamples = 0; nbatches = 0; framesTotal = 0;
+        wordMeter = fl::EditDistanceMeter();
+      }
       if (curBatch % batchesPerEpoch == 0 || curBatch == iters) saveModels(curEpoch, curBatch);
     }
     if (auto* cr = dynamic_cast<fl::CoalescingReducer*>(reducer.get()))
