@@ -43,6 +43,7 @@ struct LiP {
   // both
   int groups; int inner;
   w2l_bf16_image_sink im;
+  int abl;   // probe build, timing only: 1 no transposed image, 2 no row image, 4 no LDS tile, 8 no fp32 result stores; 16 plain block -> row-block mapping
 };
 
 // the rounded tile -> transposed image: thread = a pair of adjacent columns, 16 rows each -> two 32-byte runs
@@ -75,7 +76,16 @@ __global__ __launch_bounds__(kLiThreads) void ln_rows_images_k(LiP p) {
   const int inner = p.inner, n4 = inner >> 2;
   const int pitchDw = (inner + 8) >> 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g0 = blockIdx.x * kLiRows;
+  // Row block of this workgroup.  Consecutive workgroups go to different XCDs (round robin), each with its own L2, and FOUR
+  // consecutive row blocks share every 128-byte line of the transposed image (16 rows x 2 bytes each): with the plain mapping the
+  // four quarters of a line are written from four L2s and reach memory as partial lines (the transposed image cost 50 of the
+  // forward kernel's 175 us at 11968 x 2160: profiles/r04_run38_ln_images_ablations.log).  Here XCD x owns a contiguous range
+  // of row blocks, so the quarters of a line meet in one L2.
+  const int nrb = (p.groups + kLiRows - 1) / kLiRows;
+  const int perXcd = ((nrb + 7) / 8 + 3) / 4 * 4;
+  const int rbk = (p.abl & 16) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * perXcd + (int)(blockIdx.x >> 3);
+  if (rbk >= nrb) return;
+  const int g0 = rbk * kLiRows;
 #pragma unroll 1
   for (int q = 0; q < kLiRows / 16; ++q) {
     const int rr = wave + 16 * q, g = g0 + rr;
@@ -126,10 +136,10 @@ __global__ __launch_bounds__(kLiThreads) void ln_rows_images_k(LiP p) {
           float4 o = v[j];
           o.x = (o.x - muf) * gam + bet; o.y = (o.y - muf) * gam + bet;
           o.z = (o.z - muf) * gam + bet; o.w = (o.w - muf) * gam + bet;
-          *(float4*)(p.y + base + 4 * (size_t)i) = o;
+          if (!(p.abl & 8)) *(float4*)(p.y + base + 4 * (size_t)i) = o;
           const uint2 b = make_uint2(li_pack2(o.x, o.y), li_pack2(o.z, o.w));
-          if (irow) *(uint2*)(irow + 4 * i) = b;
-          *(uint2*)(trow + 2 * i) = b;
+          if (irow && !(p.abl & 2)) *(uint2*)(irow + 4 * i) = b;
+          if (!(p.abl & 4)) *(uint2*)(trow + 2 * i) = b;
         }
       }
     } else {
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(kLiThreads) void ln_rows_images_k(LiP p) {
           o.y = gr * (dv[j].y - c1 - xh[j].y * c2);
           o.z = gr * (dv[j].z - c1 - xh[j].z * c2);
           o.w = gr * (dv[j].w - c1 - xh[j].w * c2);
-          *(float4*)(p.dr + e) = o;
+          if (!(p.abl & 8)) *(float4*)(p.dr + e) = o;
           if (p.dmask) {
             const float4 mv = *(const float4*)(p.maskSrc + e);
             float4 d2;
@@ -181,15 +191,15 @@ __global__ __launch_bounds__(kLiThreads) void ln_rows_images_k(LiP p) {
             o.w = keep_elem(e + 3, p.iseed, p.istream, p.ithr) ? o.w * p.ikeepScale : 0.f;
           }
           const uint2 b = make_uint2(li_pack2(o.x, o.y), li_pack2(o.z, o.w));
-          if (irow) *(uint2*)(irow + 4 * i) = b;
-          *(uint2*)(trow + 2 * i) = b;
+          if (irow && !(p.abl & 2)) *(uint2*)(irow + 4 * i) = b;
+          if (!(p.abl & 4)) *(uint2*)(trow + 2 * i) = b;
         }
       }
     }
     }
   }
   __syncthreads();
-  li_write_transposed(tile, pitchDw, inner, g0, p.im);
+  if (!(p.abl & 1)) li_write_transposed(tile, pitchDw, inner, g0, p.im);
 }
 
 static bool li_sink_ok(const w2l_bf16_image_sink* s, int groups, size_t inner) {
@@ -202,12 +212,15 @@ static bool li_sink_ok(const w2l_bf16_image_sink* s, int groups, size_t inner) {
 }
 
 template <bool BWD>
-static int li_launch(const LiP& p, hipStream_t s) {
+static int li_launch(LiP p, hipStream_t s) {
+  { const char* e = tune_env("W2L_LI_ABL"); p.abl = e ? atoi(e) : 0; }
   const size_t shmem = (size_t)kLiRows * (p.inner + 8) * 2;
   static const bool attr =
       hipFuncSetAttribute((const void*)ln_rows_images_k<BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLiRows * (kLiMaxInner + 8) * 2)) == hipSuccess;
   if (!attr) return W2L_EHIP;
-  hipLaunchKernelGGL((ln_rows_images_k<BWD>), dim3((unsigned)((p.groups + kLiRows - 1) / kLiRows)), dim3(kLiThreads), shmem, s, p);
+  const int nrb = (p.groups + kLiRows - 1) / kLiRows;
+  const int perXcd = ((nrb + 7) / 8 + 3) / 4 * 4;
+  hipLaunchKernelGGL((ln_rows_images_k<BWD>), dim3((unsigned)(8 * perXcd)), dim3(kLiThreads), shmem, s, p);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }
