@@ -222,6 +222,15 @@ class FL_COMPAT_API FirstOrderOptimizer {
  protected:
   std::vector<Variable> parameters_;
   double lr_;
+  // parameters that are exactly the slices of ONE planned network's flat parameter arena: the optimizer's state arrays are views of
+  // flat buffers with the same offsets and step() is a single launch over (parameters, gradients, state) -- the reference walks
+  // the parameters one by one (a few hundred launches per update); anything else falls back to that walk
+  float* flatParams_ = nullptr;
+  float* flatState_[2] = {nullptr, nullptr};
+  size_t flatFloats_ = 0;
+  std::vector<size_t> flatOffsets_;
+  void flatStateViews(int slot, std::vector<af::array>& views);   // allocates flatState_[slot] (zeros) and fills `views`
+  bool flatNow(float*& gradBase, const std::vector<af::array>* s0, const std::vector<af::array>* s1) const;
 };
 
 // every gradient of `params` multiplied by `s` IN PLACE (Train.cpp:1748-1760 writes `p.grad() = p.grad() / totalBatchSize`, one
@@ -240,13 +249,6 @@ class FL_COMPAT_API SGDOptimizer : public FirstOrderOptimizer {
   double mu_, wd_;
   bool nesterov_;
   std::vector<af::array> velocities_;
-  // parameters that are exactly the slices of ONE planned network's flat parameter arena: the velocities are views of one flat
-  // buffer with the same offsets and step() is a single launch over (parameters, gradients, velocities) -- the reference walks
-  // the parameters one by one (a few hundred launches per update); anything else falls back to that walk
-  float* flatParams_ = nullptr;
-  float* flatVel_ = nullptr;
-  size_t flatFloats_ = 0;
-  std::vector<size_t> flatOffsets_;
 };
 
 // --netoptim=adagrad (recipes/sota/2019/librivox/train_am_transformer_ctc.cfg:25-26): variance += g^2, p -= lr g / (sqrt(variance) + eps)

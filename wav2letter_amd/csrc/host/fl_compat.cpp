@@ -229,17 +229,33 @@ void scaleGradients(const std::vector<Variable>& params, double s) {
   for (const FlatRun& r : gradientRuns(params)) w2l::w2lCheck(w2l_axpy(r.p, r.p, r.n, (float)(s - 1.0), S()), "scaleGradients");
 }
 
+void FirstOrderOptimizer::flatStateViews(int slot, std::vector<af::array>& views) {
+  std::shared_ptr<void> owner = devAlloc(flatFloats_ * sizeof(float));
+  w2l::hipCheck(hipMemsetAsync(owner.get(), 0, flatFloats_ * sizeof(float), S()), "optimizer state");
+  flatState_[slot] = (float*)owner.get();
+  for (size_t i = 0; i < parameters_.size(); ++i)
+    views.push_back(af::array::wrap(flatState_[slot] + flatOffsets_[i], parameters_[i].dims(), af::f32, owner));
+}
+// every parameter, gradient and state array still at its arena offset?  then the whole network is one launch
+bool FirstOrderOptimizer::flatNow(float*& gbase, const std::vector<af::array>* s0, const std::vector<af::array>* s1) const {
+  if (!flatParams_ || parameters_.empty() || !parameters_[0].isGradAvailable()) return false;
+  if (!gradientArenaOf(parameters_[0].grad().array().device<float>(), gbase)) return false;
+  for (size_t i = 0; i < parameters_.size(); ++i) {
+    const auto& p = parameters_[i];
+    if (!p.isGradAvailable() || p.array().device<float>() != flatParams_ + flatOffsets_[i] ||
+        p.grad().array().device<float>() != gbase + flatOffsets_[i])
+      return false;
+    if (s0 && (*s0)[i].device<float>() != flatState_[0] + flatOffsets_[i]) return false;
+    if (s1 && (*s1)[i].device<float>() != flatState_[1] + flatOffsets_[i]) return false;
+  }
+  return true;
+}
+
 SGDOptimizer::SGDOptimizer(const std::vector<Variable>& params, double lr, double momentum, double weightDecay, bool useNesterov)
     : FirstOrderOptimizer(params, lr), mu_(momentum), wd_(weightDecay), nesterov_(useNesterov) {
   if (wd_ != 0 || nesterov_) throw std::invalid_argument("fl_compat SGDOptimizer: weight decay / Nesterov are not on the hot path of the recipes");
   if (flatParameterArena(parameters_, flatParams_, flatFloats_, flatOffsets_)) {
-    if (mu_ != 0) {   // one flat velocity buffer, the per-parameter arrays (checkpoints read them) are views of it
-      std::shared_ptr<void> owner = devAlloc(flatFloats_ * sizeof(float));
-      w2l::hipCheck(hipMemsetAsync(owner.get(), 0, flatFloats_ * sizeof(float), S()), "sgd velocities");
-      flatVel_ = (float*)owner.get();
-      for (size_t i = 0; i < parameters_.size(); ++i)
-        velocities_.push_back(af::array::wrap(flatVel_ + flatOffsets_[i], parameters_[i].dims(), af::f32, owner));
-    }
+    if (mu_ != 0) flatStateViews(0, velocities_);   // one flat velocity buffer, the per-parameter arrays (checkpoints read them) are views of it
     return;
   }
   flatParams_ = nullptr;
@@ -247,18 +263,10 @@ SGDOptimizer::SGDOptimizer(const std::vector<Variable>& params, double lr, doubl
     for (auto& p : parameters_) velocities_.push_back(af::constant(0.0, p.dims(), af::f32));
 }
 void SGDOptimizer::step() {
-  if (flatParams_) {   // every gradient (and velocity) still at its arena offset?  then the whole network is one launch
-    float* gbase = nullptr;
-    bool flat = !parameters_.empty() && parameters_[0].isGradAvailable() && gradientArenaOf(parameters_[0].grad().array().device<float>(), gbase);
-    for (size_t i = 0; flat && i < parameters_.size(); ++i) {
-      auto& p = parameters_[i];
-      flat = p.isGradAvailable() && p.array().device<float>() == flatParams_ + flatOffsets_[i] &&
-             p.grad().array().device<float>() == gbase + flatOffsets_[i] && (mu_ == 0 || velocities_[i].device<float>() == flatVel_ + flatOffsets_[i]);
-    }
-    if (flat) {
-      w2l::w2lCheck(w2l_sgd_step(flatParams_, gbase, mu_ != 0 ? flatVel_ : nullptr, flatFloats_, (float)lr_, (float)mu_, 1.f, 0.f, nullptr, S()), "sgd");
-      return;
-    }
+  float* gbase = nullptr;
+  if (flatNow(gbase, mu_ != 0 ? &velocities_ : nullptr, nullptr)) {
+    w2l::w2lCheck(w2l_sgd_step(flatParams_, gbase, mu_ != 0 ? flatState_[0] : nullptr, flatFloats_, (float)lr_, (float)mu_, 1.f, 0.f, nullptr, S()), "sgd");
+    return;
   }
   for (size_t i = 0; i < parameters_.size(); ++i) {
     auto& p = parameters_[i];
@@ -278,9 +286,16 @@ std::string SGDOptimizer::prettyString() const {
 AdagradOptimizer::AdagradOptimizer(const std::vector<Variable>& params, double lr, double eps, double weightDecay)
     : FirstOrderOptimizer(params, lr), eps_(eps) {
   if (weightDecay != 0) throw std::invalid_argument("fl_compat AdagradOptimizer: weight decay is not on the hot path of the recipes");
+  if (flatParameterArena(parameters_, flatParams_, flatFloats_, flatOffsets_)) { flatStateViews(0, variance_); return; }
+  flatParams_ = nullptr;
   for (auto& p : parameters_) variance_.push_back(af::constant(0.0, p.dims(), af::f32));
 }
 void AdagradOptimizer::step() {
+  float* gbase = nullptr;
+  if (flatNow(gbase, &variance_, nullptr)) {
+    w2l::w2lCheck(w2l_adagrad_step_guarded(flatParams_, gbase, flatState_[0], flatFloats_, (float)lr_, (float)eps_, 1.f, 0.f, nullptr, S()), "adagrad");
+    return;
+  }
   for (size_t i = 0; i < parameters_.size(); ++i) {
     auto& p = parameters_[i];
     if (!p.isGradAvailable()) continue;
@@ -297,12 +312,24 @@ std::string AdagradOptimizer::prettyString() const {
 AdadeltaOptimizer::AdadeltaOptimizer(const std::vector<Variable>& params, double lr, double rho, double eps, double weightDecay)
     : FirstOrderOptimizer(params, lr), rho_(rho), eps_(eps) {
   if (weightDecay != 0) throw std::invalid_argument("fl_compat AdadeltaOptimizer: weight decay is not on the hot path of the recipes");
+  if (flatParameterArena(parameters_, flatParams_, flatFloats_, flatOffsets_)) {
+    flatStateViews(0, accGrad_);
+    flatStateViews(1, accDelta_);
+    return;
+  }
+  flatParams_ = nullptr;
   for (auto& p : parameters_) {
     accGrad_.push_back(af::constant(0.0, p.dims(), af::f32));
     accDelta_.push_back(af::constant(0.0, p.dims(), af::f32));
   }
 }
 void AdadeltaOptimizer::step() {
+  float* gbase = nullptr;
+  if (flatNow(gbase, &accGrad_, &accDelta_)) {
+    w2l::w2lCheck(w2l_adadelta_step_guarded(flatParams_, gbase, flatState_[0], flatState_[1], flatFloats_, (float)lr_, (float)rho_, (float)eps_, 1.f,
+                                            0.f, nullptr, S()), "adadelta");
+    return;
+  }
   for (size_t i = 0; i < parameters_.size(); ++i) {
     auto& p = parameters_[i];
     if (!p.isGradAvailable()) continue;
