@@ -626,7 +626,8 @@ void initDistributed(int worldRank, int worldSize, int maxDevicesPerNode, const 
   bindSym(r.lib, "ncclCommDestroy", r.CommDestroy);
   bindSym(r.lib, "ncclGetErrorString", r.GetErrorString);
   // File rendezvous (the reference's --rndv_filepath).  The record carries a magic word and rank 0's wall-clock time of
-  // publication: a reader only accepts a record published no earlier than two minutes before its own start, rank 0
+  // publication: a reader accepts a record published no earlier than two minutes before its own start at once (an older one
+  // only after it has stayed unchanged for 30 s, below), rank 0
   // removes whatever an earlier run left under the name before it publishes, and removes its own record once every rank
   // has joined (ncclCommInitRank is collective) -- so a `continue` / re-run with the same --rndv_filepath never picks up
   // the previous run's ncclUniqueId (which would hang ncclCommInitRank).
@@ -650,16 +651,29 @@ void initDistributed(int worldRank, int worldSize, int maxDevicesPerNode, const 
       if (rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error("cannot publish " + path);
     }
   } else {
+    // A record published within two minutes of this rank's start is taken at once.  An OLDER one is either a rank 0 that started
+    // long before this rank (staggered container start-up, clock skew between nodes) or the left-over of a run that died during
+    // its rendezvous: it is accepted once it has stayed unchanged for 30 s -- a live rank 0 of THIS run would have replaced a
+    // left-over by then (it unlinks and republishes at start-up).  (Round-3 advice: the old rule rejected the valid record of a
+    // rank 0 more than two minutes ahead and failed after ten.)
     bool got = false;
+    long long oldSince = 0, oldPublished = 0;
     for (int tries = 0; tries < 6000 && !got; ++tries) {   // up to 10 minutes
       std::ifstream f(path, std::ios::binary);
       RndvRecord in;
-      if (f && f.read((char*)&in, sizeof in) && in.magic == kRndvMagic && in.publishedNs >= startNs - 120ll * 1000000000ll) {
-        rec = in;
-        got = true;
+      if (f && f.read((char*)&in, sizeof in) && in.magic == kRndvMagic) {
+        const long long now = nowNs();
+        if (in.publishedNs >= startNs - 120ll * 1000000000ll) {
+          rec = in; got = true;
+        } else if (oldPublished == in.publishedNs && now - oldSince >= 30ll * 1000000000ll) {
+          rec = in; got = true;
+        } else if (oldPublished != in.publishedNs) {
+          oldPublished = in.publishedNs; oldSince = now;
+        }
       } else {
-        usleep(100000);
+        oldPublished = 0;
       }
+      if (!got) usleep(100000);
     }
     if (!got) throw std::runtime_error("rendezvous file " + path + " did not appear (or only a stale one from an earlier run)");
   }
