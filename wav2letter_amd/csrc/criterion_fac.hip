@@ -1013,7 +1013,17 @@ W2L_API int w2l_fac_backward(int B, int T, int N, int L, const int* target, cons
     if (!e) return 0;
     return !strcmp(e, "wave") ? 1 : !strcmp(e, "blk51") ? 2 : !strcmp(e, "blk42") ? 3 : 0;
   }();
-  if (fac_lin_path(N, L) && bgen == 0) {
+  if (fac_lin_path(N, L) && bgen == 0 && tune_env("W2L_FAC_BWD32")) {   // probe: 32 frames per chunk (half the per-chunk round trips)
+#define W2L_FAC_PB_GO(NWV) hipLaunchKernelGGL((fac_bwd_plin<NWV, 32>), dim3(B), dim3(64 * NWV), 0, s, T, N, L, target, targetSize, grad, transGrad, ws)
+    switch ((L + 63) / 64) {
+      case 1: W2L_FAC_PB_GO(1); break;
+      case 2: W2L_FAC_PB_GO(2); break;
+      case 3: W2L_FAC_PB_GO(3); break;
+      case 4: W2L_FAC_PB_GO(4); break;
+      default: W2L_FAC_PB_GO(5); break;
+    }
+#undef W2L_FAC_PB_GO
+  } else if (fac_lin_path(N, L) && bgen == 0) {
 #define W2L_FAC_PB_GO(NWV) hipLaunchKernelGGL((fac_bwd_plin<NWV>), dim3(B), dim3(64 * NWV), 0, s, T, N, L, target, targetSize, grad, transGrad, ws)
     switch ((L + 63) / 64) {
       case 1: W2L_FAC_PB_GO(1); break;

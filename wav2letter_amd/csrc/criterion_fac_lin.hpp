@@ -775,11 +775,11 @@ __global__ __launch_bounds__(64 * NW) void fac_fwd_plin(int T, int N, int L, int
 
 // backward scan as the mirrored pipeline: wave w + 1 leads wave w (a position needs its RIGHT neighbour's advance term of the
 // same step); consumes w1[t][i], leaves g * dalpha_t[i] in ws.dal for fac_scatter_k
-template <int NW>
+template <int NW, int KC = kPlinChunk>   // KC: frames per chunk (the ring holds four chunks)
 __global__ __launch_bounds__(64 * NW) void fac_bwd_plin(int T, int N, int L, const int* __restrict__ target,
                                                         const int* __restrict__ targetSize, const float* __restrict__ grad,
                                                         float* __restrict__ transGrad, FacWs ws) {
-  __shared__ float ring[NW][kPlinRing];   // ring[w][t & 63]: advance term of position 64 w at step t
+  __shared__ float ring[NW][(4 * KC)];   // ring[w][t & 63]: advance term of position 64 w at step t
   __shared__ int prog[NW];                // lowest frame wave w has finished (steps run from T - 1 down)
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -802,36 +802,36 @@ __global__ __launch_bounds__(64 * NW) void fac_bwd_plin(int T, int N, int L, con
   bool ok = true;
   const float* srcRing = &ring[fed ? wave + 1 : 0][0];
   float* dstRing = &ring[wave][0];
-  float wc[kPlinChunk], wn[kPlinChunk];
+  float wc[KC], wn[KC];
 #pragma unroll
-  for (int s = 0; s < kPlinChunk; ++s) {
+  for (int s = 0; s < KC; ++s) {
     const int t = T - 1 - s;
     wc[s] = (t >= 1 && valid) ? w1b[(size_t)t * L + i] : 0.f;
   }
 #pragma unroll
-  for (int s = 0; s < kPlinChunk; ++s) asm volatile("" : "+v"(wc[s]));   // landed before the loop (see fac_fwd_plin)
-  // chunks are aligned to multiples of kPlinChunk from the TOP frame: step index k = T - 1 - t, ring slot k & 63
-  for (int k0 = 0; k0 < T; k0 += kPlinChunk) {
+  for (int s = 0; s < KC; ++s) asm volatile("" : "+v"(wc[s]));   // landed before the loop (see fac_fwd_plin)
+  // chunks are aligned to multiples of KC from the TOP frame: step index k = T - 1 - t, ring slot k & 63
+  for (int k0 = 0; k0 < T; k0 += KC) {
     const int thi = T - 1 - k0;
-    const int tlow = max(thi - kPlinChunk + 1, 0);
+    const int tlow = max(thi - KC + 1, 0);
     if (fed) ok = plin_wait_le(&prog[wave + 1], tlow) && ok;                                        // the leader has finished this chunk
-    if (feeds && k0 >= kPlinRing - kPlinChunk) ok = plin_wait_le(&prog[wave - 1], thi + (kPlinRing - kPlinChunk)) && ok;   // ring slots free
+    if (feeds && k0 >= (4 * KC) - KC) ok = plin_wait_le(&prog[wave - 1], thi + ((4 * KC) - KC)) && ok;   // ring slots free
 #pragma unroll
-    for (int s = 0; s < kPlinChunk; ++s) {
-      const int t = thi - kPlinChunk - s;
+    for (int s = 0; s < KC; ++s) {
+      const int t = thi - KC - s;
       wn[s] = (t >= 1 && valid) ? w1b[(size_t)t * L + i] : 0.f;
     }
-    float rr[kPlinChunk];   // the leader's advance terms of this chunk's steps (position 64 (wave + 1))
+    float rr[KC];   // the leader's advance terms of this chunk's steps (position 64 (wave + 1))
 #pragma unroll
-    for (int s = 0; s < kPlinChunk; ++s) rr[s] = 0.f;
+    for (int s = 0; s < KC; ++s) rr[s] = 0.f;
     if (fed) {   // uniform
-      const float* sr = srcRing + (k0 & (kPlinRing - 1));
+      const float* sr = srcRing + (k0 & ((4 * KC) - 1));
 #pragma unroll
-      for (int s = 0; s < kPlinChunk; ++s) rr[s] = sr[s];
+      for (int s = 0; s < KC; ++s) rr[s] = sr[s];
     }
-    float dstv[kPlinChunk], pa[kPlinChunk];
+    float dstv[KC], pa[KC];
 #pragma unroll
-    for (int s = 0; s < kPlinChunk; ++s) {
+    for (int s = 0; s < KC; ++s) {
       const int t = thi - s;
       dstv[s] = g * da;   // row t of g * dalpha (0 beyond S)
       pa[s] = 0.f;
@@ -848,22 +848,22 @@ __global__ __launch_bounds__(64 * NW) void fac_bwd_plin(int T, int N, int L, con
     }
     if (feeds) {
       if (lane == 0) {
-        float* d = dstRing + (k0 & (kPlinRing - 1));
+        float* d = dstRing + (k0 & ((4 * KC) - 1));
 #pragma unroll
-        for (int s = 0; s < kPlinChunk; ++s) d[s] = pa[s];
+        for (int s = 0; s < KC; ++s) d[s] = pa[s];
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     if (lane == 0) __hip_atomic_store(&prog[wave], tlow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-    for (int s = 0; s < kPlinChunk; ++s) asm volatile("" : "+v"(wn[s]));   // (before the stores: see fac_fwd_plin)
+    for (int s = 0; s < KC; ++s) asm volatile("" : "+v"(wn[s]));   // (before the stores: see fac_fwd_plin)
 #pragma unroll
-    for (int s = 0; s < kPlinChunk; ++s) {
+    for (int s = 0; s < KC; ++s) {
       const int t = thi - s;
       if (t >= 0 && i < L) dalb[(size_t)t * L + i] = ok ? dstv[s] : __builtin_nanf("");
     }
 #pragma unroll
-    for (int s = 0; s < kPlinChunk; ++s) wc[s] = wn[s];
+    for (int s = 0; s < KC; ++s) wc[s] = wn[s];
   }
   float* tg = ws.tgpart ? ws.tgpart + (size_t)b * N * N : transGrad;
   if (valid) {
