@@ -381,6 +381,41 @@ def test_fused_attention_backward(B, H, T, d, csz, p, ragged):
     assert rel(dk.cpu().numpy(), dk2.cpu().numpy()) < 1e-3
 
 
+@pytest.mark.parametrize("B,H,T,d,csz", [(2, 2, 37, 32, 460), (1, 2, 130, 32, 460), (2, 4, 188, 256, 460)])
+def test_fused_attention_whole_table_window(B, H, T, d, csz):
+    """w2l_attn_fused_desc's window may be WIDER than the rows T frames reach ("entries outside count as 0"): with rlo = 0 and
+    W = 2 csz - 1 (the whole table) the fused forward and backward give bit for bit what the clipped window gives, and the table
+    gradient is zero on the rows no frame pair reaches (the reduce kernel must not look for partial sums there)."""
+    from wav2letter_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(T + d)
+    Cc = H * d
+    q, k, v, dctx = (torch.randn(B, T, Cc, generator=g).cuda() for _ in range(4))
+    E = (torch.randn(2 * csz - 1, d, generator=g) * 0.5).cuda()
+    n0 = csz - 1
+    out = []
+    for (rlo, W) in [(max(0, n0 - (T - 1)), min(2 * csz - 1, n0 + T) - max(0, n0 - (T - 1))), (0, 2 * csz - 1)]:
+        D = _lib.AttnFusedDesc(B=B, H=H, T=T, d=d, ld=Cc, ldc=Cc, W=W, n0=n0, rlo=rlo, scale=d ** -0.5, dropP=0.1, dropSeed=5, dropStream=2)
+        P = torch.full((B, H, T, T), float("nan"), device="cuda")
+        Pd = torch.full((B, H, T, T), float("nan"), device="cuda")
+        ctx = torch.full((B, T, Cc), float("nan"), device="cuda")
+        assert L.w2l_attn_fused_forward(C.byref(D), q.data_ptr(), k.data_ptr(), v.data_ptr(), E.data_ptr(), None, P.data_ptr(), Pd.data_ptr(),
+                                        ctx.data_ptr(), _stream()) == 0
+        nws = L.w2l_attn_fused_backward_workspace(C.byref(D), 1)
+        ws = torch.full((nws,), 0xff, dtype=torch.uint8, device="cuda")
+        dq, dk, dv = (torch.full((B, T, Cc), float("nan"), device="cuda") for _ in range(3))
+        dE = torch.full((2 * csz - 1, d), float("nan"), device="cuda")
+        assert L.w2l_attn_fused_backward(C.byref(D), q.data_ptr(), k.data_ptr(), v.data_ptr(), E.data_ptr(), P.data_ptr(), dctx.data_ptr(),
+                                         dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dE.data_ptr(), ws.data_ptr(), nws, _stream()) == 0
+        torch.cuda.synchronize()
+        out.append((P, Pd, ctx, dq, dk, dv, dE))
+    for a, b in zip(*out):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    reach = torch.zeros(2 * csz - 1, dtype=torch.bool)
+    reach[max(0, n0 - (T - 1)):min(2 * csz - 1, n0 + T)] = True
+    assert float(out[1][6][~reach.cuda()].abs().max()) == 0.0 and float(out[1][6][reach.cuda()].abs().min()) > 0.0
+
+
 @pytest.mark.parametrize("B,H,T,d,csz", [(2, 4, 188, 256, 460), (3, 2, 50, 32, 30), (2, 3, 130, 20, 460), (1, 1, 7, 8, 3), (2, 2, 64, 16, 10)])
 def test_banded_position_products_bf16(B, H, T, d, csz):
     """the two relative-position products of the attention backward on the bf16 batched GEMM with the BAND of the skewed score

@@ -449,8 +449,8 @@ __global__ __launch_bounds__(256) void attn_bwd_de_reduce_k(AbP p) {
   const int row = idx / (D / 4), c4 = idx - row * (D / 4);
   const int w = row - p.rlo;
   ab_f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  if (w >= 0 && w < p.W) {
-    const int wg = w - ab_w_origin<NT>(p.n0, p.rlo);
+  const int wg = w - ab_w_origin<NT>(p.n0, p.rlo);
+  if (w >= 0 && w < p.W && wg >= 0 && wg < GW) {   // (a window wider than the rows T frames reach: no (i, j) pair lands on the rest)
     const float* src = p.dEp + (size_t)wg * D + 4 * c4;
     const int n = p.B * p.H;
     int i = 0;
