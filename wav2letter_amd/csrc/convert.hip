@@ -39,6 +39,51 @@ __device__ __forceinline__ void cvt_tile(const float* __restrict__ x, size_t row
   const int tid = threadIdx.x;
   const int cq = (tid & 15) * 4, rr = tid >> 4;   // 4 columns at c0 + cq, rows rr + 16 i
   const bool vec = (((uintptr_t)x) & 15) == 0 && (ldx & 3) == 0;
+  // Interior tiles (every tile but the last row / column of tiles): all four loads of the thread are issued, and have LANDED at one
+  // unconditional point, before the first store.  On gfx9 stores count in vmcnt too: with load i + 1 issued behind store i, hipcc's
+  // `s_waitcnt vmcnt(0)` in front of the loaded value also waited for the store's round trip -- four serialised round trips per
+  // tile (ISA of the round-3 kernel); and any per-element bounds branch between the loads makes the compiler wait after each.
+  const bool interior = vec && r0 + kCvTile <= rows && c0 + kCvTile <= cols;   // (uniform over the workgroup)
+  if (interior) {
+    const int c = c0 + cq;
+    float4 q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = *(const float4*)(x + (r0 + rr + 16 * i) * ldx + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(q[i].x), "+v"(q[i].y), "+v"(q[i].z), "+v"(q[i].w));
+    if (DROP) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint64_t idx = (uint64_t)(r0 + rr + 16 * i) * ldx + c;
+        q[i].x = keep_elem(idx, dr.seed, dr.stream, dr.thr) ? q[i].x * dr.scale : 0.f;
+        q[i].y = keep_elem(idx + 1, dr.seed, dr.stream, dr.thr) ? q[i].y * dr.scale : 0.f;
+        q[i].z = keep_elem(idx + 2, dr.seed, dr.stream, dr.thr) ? q[i].z * dr.scale : 0.f;
+        q[i].w = keep_elem(idx + 3, dr.seed, dr.stream, dr.thr) ? q[i].w * dr.scale : 0.f;
+      }
+    }
+    if (transposed) {   // (the barrier drains vmcnt: no store may be in flight in front of it)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        tile[rr + 16 * i][cq] = q[i].x; tile[rr + 16 * i][cq + 1] = q[i].y;
+        tile[rr + 16 * i][cq + 2] = q[i].z; tile[rr + 16 * i][cq + 3] = q[i].w;
+      }
+      __syncthreads();
+    }
+    if (rowMajor) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *(uint2*)(rowMajor + (r0 + rr + 16 * i) * ldRows + c) = make_uint2(cv_pack2(q[i].x, q[i].y), cv_pack2(q[i].z, q[i].w));
+    }
+    if (transposed) {   // thread -> column c0 + (tid >> 2), 16 consecutive rows: 32 bytes (interior: inside cols and ldTrans)
+      uint32_t p[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) p[e] = cv_pack2(tile[16 * (tid & 3) + 2 * e][tid >> 2], tile[16 * (tid & 3) + 2 * e + 1][tid >> 2]);
+      uint4* dst = (uint4*)(transposed + (size_t)(c0 + (tid >> 2)) * ldTrans + r0 + 16 * (tid & 3));
+      dst[0] = make_uint4(p[0], p[1], p[2], p[3]);
+      dst[1] = make_uint4(p[4], p[5], p[6], p[7]);
+    }
+    return;
+  } else {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const size_t r = r0 + rr + 16 * i;
@@ -68,6 +113,7 @@ __device__ __forceinline__ void cvt_tile(const float* __restrict__ x, size_t row
 #pragma unroll
       for (int e = 0; e < 4; ++e) tile[rr + 16 * i][cq + e] = v[e];
     }
+  }
   }
   if (!transposed) return;
   __syncthreads();

@@ -31,7 +31,7 @@ constexpr int kRowMaxPer = 48;  // register-resident row: N <= 256*48 = 12288
 
 struct CtcWs {
   float* lse;     // [B][T]
-  float* lp;      // [B][T][S]   label log-probs
+  float* lp;      // [B][T][S]   (unused since the scans moved to the linear domain: the slot stays in the workspace layout)
   double* pd;     // [B][T][S]   exp(lp) in fp64, written by the row kernels through an integer / fraction split: a label
                   //             100+ nats below the row's normaliser keeps a finite probability (fp32 exp flushes below -87)
   double* alpha;  // [B][T][S]
@@ -117,7 +117,7 @@ __device__ __forceinline__ RowSplit row_split(const float* row, int N) {
   return r;
 }
 
-// lse[b][t] and the label log-probs lp[b][t][s] = x[ext_s] - lse
+// lse[b][t] and the label probabilities pd[b][t][s] = exp(x[ext_s] - lse) in fp64
 __global__ __launch_bounds__(kRowThreads) void ctc_rows_lse(int T, int N, int L,
                                                             const float* __restrict__ x,
                                                             const int* __restrict__ target,
@@ -161,13 +161,10 @@ __global__ __launch_bounds__(kRowThreads) void ctc_rows_lse(int T, int N, int L,
   const int Lb = targetSize[b];
   const int S = 2 * Lb + 1;
   const int* y = target + (size_t)b * L;
-  float* lp = ws.lp + r * ws.S;
   double* pd = ws.pd + r * ws.S;
   for (int si = tid; si < S; si += kRowThreads) {
     int lab = (si & 1) ? y[si >> 1] : (N - 1);
-    const float l = row[lab] - lse;
-    lp[si] = l;
-    pd[si] = exp_wide(l);
+    pd[si] = exp_wide(row[lab] - lse);
   }
   for (int si = S + tid; si < ws.S; si += kRowThreads) pd[si] = 0.0;   // positions beyond the utterance's lattice: p = 0
 }
@@ -194,13 +191,10 @@ __global__ __launch_bounds__(kRowThreads) void ctc_rows_lse_big(int T, int N, in
   const int Lb = targetSize[b];
   const int S = 2 * Lb + 1;
   const int* y = target + (size_t)b * L;
-  float* lp = ws.lp + r * ws.S;
   double* pd = ws.pd + r * ws.S;
   for (int si = tid; si < S; si += kRowThreads) {
     int lab = (si & 1) ? y[si >> 1] : (N - 1);
-    const float l = row[lab] - lse;
-    lp[si] = l;
-    pd[si] = exp_wide(l);
+    pd[si] = exp_wide(row[lab] - lse);
   }
   for (int si = S + tid; si < ws.S; si += kRowThreads) pd[si] = 0.0;   // positions beyond the utterance's lattice: p = 0
 }
@@ -226,14 +220,16 @@ __device__ __forceinline__ int dpp_up_i32(int v, int fill) { return __builtin_am
 __device__ __forceinline__ int dpp_down_i32(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }
 constexpr int kCtcNoExp = -(1 << 28);   // exponent of a position that holds no mass
 
-template <int P, int D>
-__global__ __launch_bounds__(64) void ctc_scan(int T, int N, int L, int scaleMode,
-                                               const int* __restrict__ target,
-                                               const int* __restrict__ targetSize,
-                                               float* __restrict__ loss, CtcWs ws) {
+// The direction is a TEMPLATE parameter and the chunk loop has a check-free main part: with `isBeta` a run-time value and
+// `k < T` tested per step and per load, hipcc kept uniform branches and register copies around every step -- ~125 instructions per
+// frame at P = 3 for ~50 of arithmetic (ISA), on a wave that issues one instruction every ~6.5 cycles.
+template <int P, int D, bool isBeta>
+__device__ __forceinline__ void ctc_scan_body(int T, int N, int L, int scaleMode,
+                                              const int* __restrict__ target,
+                                              const int* __restrict__ targetSize,
+                                              float* __restrict__ loss, const CtcWs& ws) {
   static_assert(P >= 2, "a lane's two lower / upper neighbours must live in ONE neighbouring lane");
   const int b = blockIdx.x;
-  const bool isBeta = blockIdx.y == 1;
   const int lane = threadIdx.x;
   const int Lb = targetSize[b];
   const int S = 2 * Lb + 1;
@@ -266,15 +262,16 @@ __global__ __launch_bounds__(64) void ctc_scan(int T, int N, int L, int scaleMod
   const d2_t* pdp = (const d2_t*)(pd + row0);   // p of step k at pdp + k * rstride (in doubles: / 2 vectors)
   d2_t* latp = (d2_t*)(lat + row0);
   i2_t* lexp = (i2_t*)(lex + row0);
-  auto loadp = [&](double (&dst)[P], int k) {
+  auto loadp = [&](double (&dst)[P], int k, auto checked) {   // checked: std::true_type = step k may lie beyond the last frame
+    constexpr bool CHECK = decltype(checked)::value;
     const double* q1 = (const double*)pdp + (long)k * rstride;
     if constexpr (P % 2 == 0) {
       const d2_t* q = (const d2_t*)q1;
 #pragma unroll
-      for (int p = 0; p < P; p += 2) { const d2_t v = k < T ? q[p / 2] : d2_t{0.0, 0.0}; dst[p] = v[0]; dst[p + 1] = v[1]; }
+      for (int p = 0; p < P; p += 2) { const d2_t v = (!CHECK || k < T) ? q[p / 2] : d2_t{0.0, 0.0}; dst[p] = v[0]; dst[p + 1] = v[1]; }
     } else {   // odd P: a lane's positions are 8-byte aligned only
 #pragma unroll
-      for (int p = 0; p < P; ++p) dst[p] = k < T ? q1[p] : 0.0;
+      for (int p = 0; p < P; ++p) dst[p] = (!CHECK || k < T) ? q1[p] : 0.0;
     }
   };
   auto storerow = [&](const double (&mv)[P], const int (&ev)[P], int k) {
@@ -296,7 +293,7 @@ __global__ __launch_bounds__(64) void ctc_scan(int T, int N, int L, int scaleMod
   int e[P];
   {
     double p0[P];
-    loadp(p0, 0);
+    loadp(p0, 0, std::false_type{});
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int si = lane * P + p;
@@ -310,15 +307,17 @@ __global__ __launch_bounds__(64) void ctc_scan(int T, int N, int L, int scaleMod
 
   double pc[D][P], pn[D][P];   // p of steps k0 .. k0 + D - 1 (current chunk) and of the next chunk
 #pragma unroll
-  for (int u = 0; u < D; ++u) loadp(pc[u], 1 + u);
+  for (int u = 0; u < D; ++u) loadp(pc[u], 1 + u, std::true_type{});
 #pragma unroll
   for (int u = 0; u < D; ++u)
 #pragma unroll
     for (int p = 0; p < P; ++p) asm volatile("" : "+v"(pc[u][p]));   // landed before the loop: no load pending at its head (a pending load
                                                                      // there makes hipcc wait vmcnt(0) at every step's first use)
-  for (int k0 = 1; k0 < T; k0 += D) {
+  // steps k0 .. k0 + D - 1 on the p values in pc, the next chunk's p into pn; checked = std::false_type: this chunk AND the next lie inside T
+  auto chunk = [&](double (&pc)[D][P], double (&pn)[D][P], const int k0, auto checked) {
+    constexpr bool CHECK = decltype(checked)::value;
 #pragma unroll
-    for (int u = 0; u < D; ++u) loadp(pn[u], k0 + D + u);
+    for (int u = 0; u < D; ++u) loadp(pn[u], k0 + D + u, checked);
     double sm[D][P];   // this chunk's rows: stored after the chunk
     int se[D][P];
 #pragma unroll
@@ -326,7 +325,7 @@ __global__ __launch_bounds__(64) void ctc_scan(int T, int N, int L, int scaleMod
       const int k = k0 + u;
 #pragma unroll
       for (int p = 0; p < P; ++p) { sm[u][p] = 0.0; se[u][p] = kCtcNoExp; }
-      if (k < T) {
+      if (!CHECK || k < T) {
         // the neighbour lane's two boundary positions (alpha: lane - 1's last two; beta: lane + 1's first two)
         double n1m, n2m;
         int n1e, n2e;
@@ -368,13 +367,21 @@ __global__ __launch_bounds__(64) void ctc_scan(int T, int N, int L, int scaleMod
       for (int p = 0; p < P; ++p) asm volatile("" : "+v"(pn[u][p]));   // consumed BEFORE the chunk's stores are issued
 #pragma unroll
     for (int u = 0; u < D; ++u)
-      if (k0 + u < T) storerow(sm[u], se[u], k0 + u);
+      if (!CHECK || k0 + u < T) storerow(sm[u], se[u], k0 + u);
+  };
+  int k0 = 1;
+  for (; k0 + 3 * D <= T; k0 += 2 * D) {   // two chunks per trip, the two p buffers swapping roles: no D P register copies per chunk
+    chunk(pc, pn, k0, std::false_type{});
+    chunk(pn, pc, k0 + D, std::false_type{});
+  }
+  for (; k0 < T; k0 += D) {
+    chunk(pc, pn, k0, std::true_type{});
 #pragma unroll
     for (int u = 0; u < D; ++u)
 #pragma unroll
       for (int p = 0; p < P; ++p) pc[u][p] = pn[u][p];
   }
-  if (isBeta) return;
+  if constexpr (isBeta) return;
 
   // ---- likelihood Z = alpha_{T-1}(S-1) + alpha_{T-1}(S-2) = zhat * 2^ez (the two positions may sit in two lanes)
   int ez = kCtcNoExp;
@@ -404,6 +411,15 @@ __global__ __launch_bounds__(64) void ctc_scan(int T, int N, int L, int scaleMod
   }
 }
 
+template <int P, int D>
+__global__ __launch_bounds__(64) void ctc_scan(int T, int N, int L, int scaleMode,
+                                               const int* __restrict__ target,
+                                               const int* __restrict__ targetSize,
+                                               float* __restrict__ loss, CtcWs ws) {
+  if (blockIdx.y == 1) ctc_scan_body<P, D, true>(T, N, L, scaleMode, target, targetSize, loss, ws);
+  else ctc_scan_body<P, D, false>(T, N, L, scaleMode, target, targetSize, loss, ws);
+}
+
 // grad row = g * softmax(x); then subtract g * gamma at the frame's labels
 __global__ __launch_bounds__(kRowThreads) void ctc_rows_grad(int T, int N, int L,
                                                              const float* __restrict__ x,
@@ -420,7 +436,41 @@ __global__ __launch_bounds__(kRowThreads) void ctc_rows_grad(int T, int N, int L
   const float lse = ws.lse[r];
   RowSplit sp = row_split(row, N);  // dx has the same alignment as x modulo 16 B iff bases agree
   const bool same = ((((uintptr_t)row) ^ ((uintptr_t)out)) & 15) == 0;
-  if (same) {
+  if (same && N <= kRowThreads * kRowMaxPer && sp.nbody4 >= 1) {
+    // Every load of the row issued before the first use, as ctc_rows_lse does, and LANDED at one unconditional point before the
+    // first store: on gfx9 stores count in vmcnt too, and wherever a load was still pending on some path hipcc put
+    // `s_waitcnt vmcnt(0)` in front of the next use -- behind a store that meant waiting for the store's round trip (the rolled
+    // loop below: one load in flight per wave, every load behind the previous store; 4.3 TB/s read + written where the forward
+    // pass reads at 5.9).  Loads are unconditional (idle lanes re-read the row's first vector) so that no branch separates them.
+    const float4* body = (const float4*)(row + sp.nh);
+    float4* obody = (float4*)(out + sp.nh);
+    float4 v[kRowMaxPer / 4];
+#pragma unroll
+    for (int k = 0; k < kRowMaxPer / 4; ++k) {
+      const int idx = tid + kRowThreads * k;
+      v[k] = body[idx < sp.nbody4 ? idx : 0];
+    }
+    int hn = 0;   // head / tail scalar of this thread (element 0 for the threads that own none: a harmless read)
+    bool hasH = false;
+    if (tid < sp.nh) { hn = tid; hasH = true; }
+    else if (tid >= 64 && tid - 64 < sp.ntail) { hn = sp.nh + 4 * sp.nbody4 + (tid - 64); hasH = true; }
+    float hv = row[hn];
+#pragma unroll
+    for (int k = 0; k < kRowMaxPer / 4; ++k)
+      asm volatile("" : "+v"(v[k].x), "+v"(v[k].y), "+v"(v[k].z), "+v"(v[k].w));
+    asm volatile("" : "+v"(hv));
+#pragma unroll
+    for (int k = 0; k < kRowMaxPer / 4; ++k) {
+      const int idx = tid + kRowThreads * k;
+      if (idx < sp.nbody4) {
+        float4 o = v[k];
+        o.x = g * __expf(o.x - lse); o.y = g * __expf(o.y - lse);
+        o.z = g * __expf(o.z - lse); o.w = g * __expf(o.w - lse);
+        obody[idx] = o;
+      }
+    }
+    if (hasH) out[hn] = g * __expf(hv - lse);
+  } else if (same) {
     const float4* body = (const float4*)(row + sp.nh);
     float4* obody = (float4*)(out + sp.nh);
     for (int idx = tid; idx < sp.nbody4; idx += kRowThreads) {
