@@ -252,6 +252,36 @@ def test_ctc_target_longer_than_input_is_truncated(oracle):
     assert relerr(loss[fin], ol[fin]) < TOL
 
 
+def test_ctc_infeasible_forced_target_size_has_infinite_loss(oracle):
+    """a caller-supplied target size the frames cannot hold (a repeat needs a blank: 3 labels with one repeat in 3 frames): the
+    likelihood is exactly 0 -- loss +inf, gradient = grad * softmax, as the log-domain oracle; the utterance beside it is untouched.
+    (Before round 4 a position nothing feeds inherited 2^-2^28 from a disallowed skip and the loss came out as 1.9e8:
+    oracle/ctc_linear_domain.py, tests/test_ctc_linear_domain.py.)"""
+    import ctypes as C
+    from wav2letter_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    B, T, N, Lt = 2, 3, 7, 3
+    x = rng.normal(size=(B, T, N)).astype(np.float32)
+    tgt = np.array([[1, 1, 2], [1, 2, 3]], np.int32)
+    ts = np.array([3, 3], np.int32)
+    w = np.array([0.5, -1.25], np.float32)
+    xd, td, sd, wd = dev(x), dev(tgt), dev(ts), dev(w)
+    ws = torch.zeros(L.w2l_ctc_workspace_size(B, T, N, Lt), dtype=torch.uint8, device="cuda")
+    loss = torch.zeros(B, device="cuda")
+    dx = torch.full((B, T, N), float("nan"), device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert L.w2l_ctc_forward(B, T, N, Lt, 0, xd.data_ptr(), td.data_ptr(), sd.data_ptr(), loss.data_ptr(), ws.data_ptr(), st) == 0
+    assert L.w2l_ctc_backward(B, T, N, Lt, xd.data_ptr(), td.data_ptr(), sd.data_ptr(), wd.data_ptr(), dx.data_ptr(), ws.data_ptr(), st) == 0
+    o = oracle.CTC(x, tgt, target_size=ts)
+    ol = o.forward()
+    odx = o.backward(w.astype(np.float64))
+    got = loss.cpu().numpy()
+    assert ol[0] == np.inf and got[0] == np.inf
+    assert abs(got[1] - ol[1]) < TOL * abs(ol[1])
+    assert gradrel(dx.cpu().numpy(), odx) < TOL
+
+
 def test_ctc_tds_shape_full_size(oracle):
     """BASELINE config 2 criterion shape: B=32, T'=188, N=9998 word pieces + blank."""
     from wav2letter_amd import CTCLoss, CriterionScaleMode

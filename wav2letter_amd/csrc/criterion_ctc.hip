@@ -350,7 +350,11 @@ __device__ __forceinline__ void ctc_scan_body(int T, int N, int L, int scaleMode
             m2 = p + 2 < P ? m[p + 2 < P ? p + 2 : 0] : (p + 1 < P ? n1m : n2m);
             e2 = p + 2 < P ? e[p + 2 < P ? p + 2 : 0] : (p + 1 < P ? n1e : n2e);
           }
-          if (!skip[p]) e2 = kCtcNoExp;   // (2^28 below everything: the term shifts out to exactly 0)
+          // not enterable from two positions away: the term must shift out to exactly 0 -- also when NOTHING else feeds the position
+          // (E = kCtcNoExp): with e2 = kCtcNoExp the shift would be 0 there and the position would inherit a ghost mass of
+          // 2^-2^28 from a place it cannot be reached from (harmless next to real mass, but an infeasible target's likelihood
+          // came out as 2^-2^28 instead of 0: loss 1.9e8 where the reference's is +inf; oracle/ctc_linear_domain.py)
+          if (!skip[p]) e2 = kCtcNoExp - 4096;
           const int E = max(max(e[p], e1), e2);
           const double sum = (__builtin_amdgcn_ldexp(m[p], e[p] - E) + __builtin_amdgcn_ldexp(m1, e1 - E)) + __builtin_amdgcn_ldexp(m2, e2 - E);
           const double h = sum * pc[u][p];     // p = 0 beyond S: stays zero
