@@ -594,6 +594,60 @@ static int rs3_launch(const TdsRsP& q, hipStream_t s) {
   return W2L_OK;
 }
 
+
+// ================================================================================================ block-Toeplitz generation
+}  // namespace w2l
+#include "conv_tds_tz.hpp"
+namespace w2l {
+
+template <int C, int R, int NCT>
+static int tz_launch(const TdsRsP& q, hipStream_t s) {
+  using Cfg = TzCfg<C, R, NCT>;
+  TdsTzP p{};
+  p.x = q.x; p.w = q.w; p.bias = q.bias; p.add = q.add; p.y = q.y;
+  p.B = q.B; p.Tin = q.Tin; p.Tout = q.Tout; p.H = q.H; p.kw = q.kw; p.padl = q.padl; p.relu = q.relu; p.flip = q.flip;
+  { const char* e = tune_env("W2L_TDS_TZ_DBG"); p.dbg = e ? (long long*)strtoull(e, nullptr, 10) : nullptr; }
+  p.hBlocks = q.H / Cfg::HB;
+  p.rps = (q.Tout + Cfg::RF - 1) / Cfg::RF;
+  const long long rounds = (long long)q.B * p.hBlocks * p.rps;
+  if (rounds <= 0 || rounds > (1ll << 30)) return W2L_EUNSUPPORTED;
+  p.nRounds = (int)rounds;
+  // two workgroups per CU; equal contiguous shares of the round axis
+  int wgMax = 512;
+  { const char* e = tune_env("W2L_TDS_TZ_WGS"); if (e && atoi(e) > 0) wgMax = atoi(e); }
+  const int wgs = p.nRounds < wgMax ? p.nRounds : wgMax;
+  p.rpw = (p.nRounds + wgs - 1) / wgs;
+  const int blocks = (p.nRounds + p.rpw - 1) / p.rpw;
+#ifdef W2L_PROBE
+  if (q.abl) {
+    bool done = false;
+    auto go = [&](auto tag) {
+      constexpr int M = decltype(tag)::value;
+      if (q.abl != M || done || p.add || p.flip) return;
+      (void)hipFuncSetAttribute((const void*)tds_conv_tz_k<C, R, NCT, false, false, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
+      hipLaunchKernelGGL((tds_conv_tz_k<C, R, NCT, false, false, M>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p);
+      done = true;
+    };
+    go(std::integral_constant<int, 1>{}); go(std::integral_constant<int, 2>{}); go(std::integral_constant<int, 4>{});
+    go(std::integral_constant<int, 8>{}); go(std::integral_constant<int, 14>{}); go(std::integral_constant<int, 12>{});
+    if (done) return W2L_OK;
+  }
+#endif
+  static bool attr = false;
+  if (!attr) {
+    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_tz_k<C, R, NCT, false, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
+    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_tz_k<C, R, NCT, false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
+    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_tz_k<C, R, NCT, true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
+    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_tz_k<C, R, NCT, true, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
+    attr = true;
+  }
+  if (p.add && p.flip) hipLaunchKernelGGL((tds_conv_tz_k<C, R, NCT, true, true, 0>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p);
+  else if (p.add) hipLaunchKernelGGL((tds_conv_tz_k<C, R, NCT, true, false, 0>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p);
+  else if (p.flip) hipLaunchKernelGGL((tds_conv_tz_k<C, R, NCT, false, true, 0>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p);
+  else hipLaunchKernelGGL((tds_conv_tz_k<C, R, NCT, false, false, 0>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p);
+  return W2L_OK;
+}
+
 // true + *status when this geometry runs on the role-swapped kernel
 bool tds_rs_try(const float* x, const float* w, const float* bias, const float* add, float* y, int B, int Tin, int Tout, int H,
                 int C, int kw, int padl, int relu, int accum, int flip, int profKind, hipStream_t s, int* status) {
@@ -605,6 +659,17 @@ bool tds_rs_try(const float* x, const float* w, const float* bias, const float* 
   p.B = B; p.Tin = Tin; p.Tout = Tout; p.H = H; p.kw = kw; p.padl = padl; p.relu = relu; p.accum = accum; p.flip = flip;
   { const char* e = tune_env("W2L_TDS_RS_ABL"); p.abl = e ? atoi(e) : 0; }
   { const char* e = tune_env("W2L_TDS_RS_STAGGER"); p.stagger = e ? atoi(e) : (C == 10 ? 4 : 0); }
+  // fourth generation (conv_tds_tz.hpp): block-Toeplitz weights in registers, slab in the global layout, no overlap-add
+  const bool tz = !tune_env("W2L_TDS_TZ_OFF") && H % 16 == 0 && !accum && !(add && relu) && (long long)Tin * H * C * 4 < (1ll << 31) &&
+                  (long long)Tout * H * C * 4 < (1ll << 31);
+  if (tz) {
+    prof_begin(s, 2.0 * B * Tout * (double)H * kw * C * C, profKind);
+    int st = C == 10 ? tz_launch<10, 3, 1>(p, s) : C == 14 ? tz_launch<14, 2, 1>(p, s) : tz_launch<18, 3, 2>(p, s);
+    prof_end(s);
+    if (st == W2L_OK && hipGetLastError() != hipSuccess) st = W2L_EHIP;
+    *status = st;
+    return true;
+  }
   // third generation (conv_tds_rs3.hpp): wave-specialised, streamed time axis.  One utterance per 2 GiB buffer resource.
   const bool rs3 = !tune_env("W2L_TDS_RS3_OFF") && H % 8 == 0 && !accum && (long long)B * (H / 4) * Tout <= (1ll << 30) &&
                    (long long)Tin * H * C * 4 < (1ll << 31) && (long long)Tout * H * C * 4 < (1ll << 31);

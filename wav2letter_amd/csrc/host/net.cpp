@@ -163,6 +163,7 @@ class ViewLayer : public Layer {
   long dims[4];
   std::string name() const override { return "View"; }
   Act plan(const Act& in, Planner&) override { return actView(in, dims); }
+  bool passesInputThrough(const Ctx&) const override { return true; }
   void forward(Ctx&, float*, const float* x, float*& y) override { y = const_cast<float*>(x); }
   void backward(Ctx&, float*, const float* dy, float*& dx, bool) override { dx = const_cast<float*>(dy); }
 };
@@ -172,6 +173,7 @@ class ReorderLayer : public Layer {
   int perm[4];
   std::string name() const override { return "Reorder"; }
   Act plan(const Act& in, Planner&) override { return actReorder(in, perm); }
+  bool passesInputThrough(const Ctx&) const override { return true; }
   void forward(Ctx&, float*, const float* x, float*& y) override { y = const_cast<float*>(x); }
   void backward(Ctx&, float*, const float* dy, float*& dx, bool) override { dx = const_cast<float*>(dy); }
 };
@@ -199,6 +201,7 @@ class DropoutLayer : public Layer {
   size_t n = 0;
   std::string name() const override { return "Dropout"; }
   Act plan(const Act& in, Planner&) override { n = in.numel(); return in; }
+  bool passesInputThrough(const Ctx& c) const override { return !(c.train && p > 0); }
   void forward(Ctx& c, float*, const float* x, float*& y) override {
     y = const_cast<float*>(x);
     if (c.train && p > 0) w2lCheck(w2l_dropout_inplace(y, n, p, c.seed, rngStream, c.stream), "dropout");
@@ -220,6 +223,7 @@ class SpecAugmentLayer : public Layer {
     B = in.B; T = in.T; F = in.F;
     return in;
   }
+  bool passesInputThrough(const Ctx& c) const override { return !c.train; }
   void forward(Ctx& c, float*, const float* x, float*& y) override {
     y = const_cast<float*>(x);
     if (c.train)
@@ -1336,8 +1340,13 @@ const float* Sequential::forward(Ctx& c, float* arena, const float* xRef) {
   c.imgOf = nullptr;
   for (size_t i = 0; i < layers_.size(); ++i) {
     float* y = nullptr;
+    const float* noteBefore = c.imgOf;
     layers_[i]->forward(c, arena, cur, y);
-    if (c.imgOf != y) c.imgOf = nullptr;   // a note about bf16 images only ever describes the activation handed to the NEXT layer
+    // a note about bf16 images only ever describes the activation handed to the NEXT layer, and only its CURRENT values: a
+    // layer that rewrites its input in place (Dropout in training, ReLU, SpecAugment) returns the same pointer with other
+    // contents -- the images the producer wrote are stale then, and the next fl::Linear must convert again
+    if (c.imgOf == noteBefore && !layers_[i]->passesInputThrough(c)) c.imgOf = nullptr;
+    if (c.imgOf != y) c.imgOf = nullptr;
     ys_[i] = y;
     cur = y;
   }

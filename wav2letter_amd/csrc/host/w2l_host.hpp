@@ -112,6 +112,9 @@ class Layer {
   virtual void forward(Ctx& c, float* arena, const float* x, float*& y) = 0;
   // dy: gradient wrt output; writes dx unless !needDx
   virtual void backward(Ctx& c, float* arena, const float* dy, float*& dx, bool needDx) = 0;
+  // true when forward() hands its input through UNCHANGED (same pointer, same values) under this context: only then may
+  // a note about the bf16 images of the input (Ctx::imgOf) go on describing the output
+  virtual bool passesInputThrough(const Ctx& c) const { (void)c; return false; }
   int rngStream = 0;  // distinct dropout stream per layer
 };
 
