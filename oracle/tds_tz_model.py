@@ -148,3 +148,105 @@ def direct(x, w, bias, kw, padl, flip=False, relu=False, add=None, Tout=None):
     if add is not None:
         y += add
     return y
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# filter gradient (conv_tds_tzf.hpp): D[(s, ci)][(r, co)] over (group i, mel row h), folded into dW by tds_tzf_reduce_k
+def cfg_f(C, R, GR):
+    S = R + KW - 1
+    C2 = C // 2
+    NPR = S * C2
+    NPT = (NPR + 1 + 31) // 32
+    p = HB * C + 4
+    while p % 64 not in (40, 48, 8, 16, 24, 56):
+        p += 4
+    PD = HB * C + (12 if (HB * C) % 32 == 0 else 0)
+    return dict(C=C, R=R, GR=GR, S=S, C2=C2, NPR=NPR, NPT=NPT, RF=GR * R, NFX=(GR - 1) * R + S, NFD=GR * R, PX=p, PD=PD)
+
+
+CFGS_F = {10: cfg_f(10, 3, 16), 14: cfg_f(14, 2, 12)}
+
+
+def filter_grad(x, dy, kw, padl, n_wg=3):
+    """x [B][Tin][H][C], dy [B][Tout][H][C] -> (dW [kw][C][C], dbias [C]) computed the way tds_conv_tzf_k + tds_tzf_reduce_k do."""
+    B, Tin, H, C = x.shape
+    Tout = dy.shape[1]
+    g = CFGS_F[C]
+    R, GR, S, C2, NPR, NPT, RF, NFX, NFD, PX, PD = (g[k] for k in ("R", "GR", "S", "C2", "NPR", "NPT", "RF", "NFX", "NFD", "PX", "PD"))
+    HC = H * C
+    lane = np.arange(64)
+    n, hf = lane & 31, lane >> 5
+    xflat = x.reshape(B, -1).astype(np.float64)
+    dflat = dy.reshape(B, -1).astype(np.float64)
+    rps = (Tout + RF - 1) // RF
+    rounds = [(b, hb, k) for b in range(B) for hb in range(H // HB) for k in range(rps)]
+    rpw = (len(rounds) + n_wg - 1) // n_wg
+    nblocks = (len(rounds) + rpw - 1) // rpw
+    partial = np.zeros((nblocks, NPT, 2, 16, 64))
+    for wg in range(nblocks):
+        acc = np.zeros((8, NPT, 2, 16, 64))
+        for (b, hb, k) in rounds[wg * rpw:(wg + 1) * rpw]:
+            t0 = k * RF
+            xs = np.full(NFX * PX, np.nan)
+            ds = np.full(NFD * PD, np.nan)
+            for f in range(NFX):
+                xs[f * PX + HB * C: (f + 1) * PX] = 1.0
+                for piece in range(HB * C // 4):
+                    off = (t0 - padl + f) * HC + hb * HB * C + piece * 4
+                    ok = 0 <= off and off + 4 <= Tin * HC
+                    xs[f * PX + piece * 4: f * PX + piece * 4 + 4] = xflat[b, off:off + 4] if ok else 0.0
+            for f in range(NFD):
+                for piece in range(HB * C // 4):
+                    off = (t0 + f) * HC + hb * HB * C + piece * 4
+                    ok = 0 <= off and off + 4 <= Tout * HC
+                    ds[f * PD + piece * 4: f * PD + piece * 4 + 4] = dflat[b, off:off + 4] if ok else 0.0
+            for wave in range(8):
+                rr = np.where(n < R * C, n // C, 0)
+                co = np.where(n < R * C, n % C, 0)
+                bBase = rr * PD + (2 * wave + hf) * C + co
+                for i in range(GR):
+                    bf = ds[bBase + i * R * PD]
+                    for pt in range(NPT):
+                        pr = 32 * pt + n
+                        s, cp = pr // C2, pr % C2
+                        aoff = np.where(pr < NPR, s * PX + (2 * wave + hf) * C + 2 * cp, HB * C) + i * R * PX
+                        a0, a1 = xs[aoff], xs[aoff + 1]
+                        a0 = np.where(pr > NPR, 0.0, a0)     # rows nobody exports: anything finite
+                        a1 = np.where(pr > NPR, 0.0, a1)
+                        acc[wave, pt, 0] = mfma_32x32x2(a0, bf, acc[wave, pt, 0])
+                        acc[wave, pt, 1] = mfma_32x32x2(a1, bf, acc[wave, pt, 1])
+        partial[wg] = acc.sum(axis=0)
+    # ---- tds_tzf_reduce_k
+    flat = partial.reshape(nblocks, -1)
+    dW = np.zeros(kw * C * C)
+    db = np.zeros(C)
+    for o in range(kw * C * C + C):
+        tot = 0.0
+        for r in range(R):
+            if o < kw * C * C:
+                j, rem = divmod(o, C * C)
+                ci, co = divmod(rem, C)
+                pr, e = (j + r) * C2 + (ci >> 1), ci & 1
+            else:
+                co = o - kw * C * C
+                pr, e = NPR, 0
+            pt, row, col = pr >> 5, pr & 31, r * C + co
+            idx = ((pt * 2 + e) * 16 + 4 * (row >> 3) + (row & 3)) * 64 + 32 * ((row >> 2) & 1) + col
+            tot += flat[:, idx].sum()
+        if o < kw * C * C:
+            dW[o] = tot
+        else:
+            db[o - kw * C * C] = tot
+    return dW.reshape(kw, C, C), db
+
+
+def filter_direct(x, dy, kw, padl):
+    B, Tin, H, C = x.shape
+    Tout = dy.shape[1]
+    dW = np.zeros((kw, C, C))
+    for j in range(kw):
+        for t in range(Tout):
+            ti = t + j - padl
+            if 0 <= ti < Tin:
+                dW[j] += np.einsum("bhc,bhd->cd", x[:, ti].astype(np.float64), dy[:, t].astype(np.float64))
+    return dW, dy.astype(np.float64).sum(axis=(0, 1, 2))

@@ -194,8 +194,12 @@ def test_tds_ctc_config2_full_network_end_to_end(oracle):
 @pytest.mark.parametrize("stages", [[(10, 1, 2400)], [(10, 1, 0), (14, 1, 0), (18, 1, 0)], [(18, 3, 4320)]])
 def test_tds_ctc_recipe_channel_counts_strict_gradients(oracle, stages):
     """the recipe's TDS geometry (80 mel rows, kw = 21, C = 10 / 14 / 18, the 3x fc width, strided C2 layers between the
-    stages) at a depth where no ReLU input sits on a kink: every parameter gradient at the strict 2e-4 bar"""
-    rng = np.random.default_rng(21)
+    stages) at a depth where no ReLU input sits on a kink: every parameter gradient at the strict 2e-4 bar.
+    (The seed is one for which that holds with the kernels of the day: under the block-Toeplitz convolutions of round 5,
+    whose sums run in another order, seed 21 puts one input of the first block's fc ReLU across zero -- tds.lin1.w off by 5e-2,
+    everything upstream of that ReLU by 1e-3, everything downstream at 1e-7 -- while seeds 22 .. 26 agree to 1e-6 with both
+    generations: profiles/r05_run8_relu_kink_diag_seed21.log.)"""
+    rng = np.random.default_rng(22)
     nfeat, nlabel, B, T, L = 80, 40, 2, 96, 5
     lines = ["V -1 NFEAT 1 0"]
     cin = 1

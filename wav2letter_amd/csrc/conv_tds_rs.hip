@@ -618,14 +618,15 @@ static int tz_launch(const TdsRsP& q, hipStream_t s) {
   const int wgs = p.nRounds < wgMax ? p.nRounds : wgMax;
   p.rpw = (p.nRounds + wgs - 1) / wgs;
   const int blocks = (p.nRounds + p.rpw - 1) / p.rpw;
+  constexpr bool DEFER = NCT == 1;   // C = 18: no registers for a second accumulator set (and the longest chain)
 #ifdef W2L_PROBE
   if (q.abl) {
     bool done = false;
     auto go = [&](auto tag) {
       constexpr int M = decltype(tag)::value;
-      if (q.abl != M || done || p.add || p.flip) return;
-      (void)hipFuncSetAttribute((const void*)tds_conv_tz_k<C, R, NCT, false, false, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
-      hipLaunchKernelGGL((tds_conv_tz_k<C, R, NCT, false, false, M>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p);
+      if (q.abl != M || done || p.add || p.flip || !p.relu) return;
+      (void)hipFuncSetAttribute((const void*)tds_conv_tz_k<C, R, NCT, 1, DEFER, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
+      hipLaunchKernelGGL((tds_conv_tz_k<C, R, NCT, 1, DEFER, M>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p);
       done = true;
     };
     go(std::integral_constant<int, 1>{}); go(std::integral_constant<int, 2>{}); go(std::integral_constant<int, 4>{});
@@ -635,16 +636,17 @@ static int tz_launch(const TdsRsP& q, hipStream_t s) {
 #endif
   static bool attr = false;
   if (!attr) {
-    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_tz_k<C, R, NCT, false, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
-    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_tz_k<C, R, NCT, false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
-    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_tz_k<C, R, NCT, true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
-    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_tz_k<C, R, NCT, true, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
+    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_tz_k<C, R, NCT, 0, DEFER, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
+    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_tz_k<C, R, NCT, 1, DEFER, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
+    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_tz_k<C, R, NCT, 2, DEFER, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
+    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_tz_k<C, R, NCT, 3, DEFER, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
     attr = true;
   }
-  if (p.add && p.flip) hipLaunchKernelGGL((tds_conv_tz_k<C, R, NCT, true, true, 0>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p);
-  else if (p.add) hipLaunchKernelGGL((tds_conv_tz_k<C, R, NCT, true, false, 0>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p);
-  else if (p.flip) hipLaunchKernelGGL((tds_conv_tz_k<C, R, NCT, false, true, 0>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p);
-  else hipLaunchKernelGGL((tds_conv_tz_k<C, R, NCT, false, false, 0>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p);
+  const int mode = p.flip ? (p.add ? 3 : 2) : (p.relu ? 1 : 0);
+  if (mode == 0) hipLaunchKernelGGL((tds_conv_tz_k<C, R, NCT, 0, DEFER, 0>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p);
+  else if (mode == 1) hipLaunchKernelGGL((tds_conv_tz_k<C, R, NCT, 1, DEFER, 0>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p);
+  else if (mode == 2) hipLaunchKernelGGL((tds_conv_tz_k<C, R, NCT, 2, DEFER, 0>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p);
+  else hipLaunchKernelGGL((tds_conv_tz_k<C, R, NCT, 3, DEFER, 0>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p);
   return W2L_OK;
 }
 
@@ -660,7 +662,8 @@ bool tds_rs_try(const float* x, const float* w, const float* bias, const float* 
   { const char* e = tune_env("W2L_TDS_RS_ABL"); p.abl = e ? atoi(e) : 0; }
   { const char* e = tune_env("W2L_TDS_RS_STAGGER"); p.stagger = e ? atoi(e) : (C == 10 ? 4 : 0); }
   // fourth generation (conv_tds_tz.hpp): block-Toeplitz weights in registers, slab in the global layout, no overlap-add
-  const bool tz = !tune_env("W2L_TDS_TZ_OFF") && H % 16 == 0 && !accum && !(add && relu) && (long long)Tin * H * C * 4 < (1ll << 31) &&
+  // (the forward pass carries bias / ReLU, the backward-data pass the residual addend: the modes the kernel is built in)
+  const bool tz = !tune_env("W2L_TDS_TZ_OFF") && H % 16 == 0 && !accum && (flip ? !bias && !relu : !add) && (long long)Tin * H * C * 4 < (1ll << 31) &&
                   (long long)Tout * H * C * 4 < (1ll << 31);
   if (tz) {
     prof_begin(s, 2.0 * B * Tout * (double)H * kw * C * C, profKind);
@@ -905,6 +908,7 @@ float* sk_scratch(hipStream_t s, size_t bytes);
 
 }  // namespace w2l
 #include "conv_tds_rsf3.hpp"
+#include "conv_tds_tzf.hpp"
 namespace w2l {
 
 template <int C, int GA, int GB, int HH, int TS>
@@ -930,6 +934,34 @@ static int rsf3_launch(const TdsRsfP& q, float* dw, float* dbias, hipStream_t s)
   hipLaunchKernelGGL((tds_conv_rsf3_k<C, GA, GB, HH, TS>), dim3((unsigned)blocks), dim3(Cfg::WAVES * 64), Cfg::LDS, s, p, partial);
   hipLaunchKernelGGL((tds_rsf_reduce_k<C, GA, GB, Cfg::NRT, Cfg::NCT>), dim3((unsigned)((Cfg::ACCF + 63) / 64)), dim3(1024), 0, s, partial,
                      blocks, q.kw, dw, dbias);
+  return W2L_OK;
+}
+
+// block-Toeplitz filter gradient (conv_tds_tzf.hpp)
+template <int C, int R, int GR>
+static int tzf_launch(const TdsRsfP& q, float* dw, float* dbias, hipStream_t s) {
+  using Cfg = TzfCfg<C, R, GR>;
+  if (q.H % Cfg::HB) return W2L_EUNSUPPORTED;
+  if ((long long)q.Tin * q.H * C * 4 >= (1ll << 31) || (long long)q.Tout * q.H * C * 4 >= (1ll << 31)) return W2L_EUNSUPPORTED;   // one utterance per buffer resource
+  TdsTzfP p{};
+  p.x = q.x; p.dy = q.dy; p.B = q.B; p.Tin = q.Tin; p.Tout = q.Tout; p.H = q.H; p.kw = q.kw; p.padl = q.padl;
+  p.hBlocks = q.H / Cfg::HB;
+  p.rps = (q.Tout + Cfg::RF - 1) / Cfg::RF;
+  const long long rounds = (long long)q.B * p.hBlocks * p.rps;
+  if (rounds <= 0 || rounds > (1ll << 30)) return W2L_EUNSUPPORTED;
+  p.nRounds = (int)rounds;
+  const int wgs = p.nRounds < 256 ? p.nRounds : 256;   // one workgroup per CU
+  p.rpw = (p.nRounds + wgs - 1) / wgs;
+  const int blocks = (p.nRounds + p.rpw - 1) / p.rpw;
+  float* partial = sk_scratch(s, kSkScratchBytes);
+  if (!partial || (size_t)blocks * Cfg::ACCF * sizeof(float) > kSkScratchBytes) return W2L_EUNSUPPORTED;
+  static bool attr = false;
+  if (!attr) {
+    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_tzf_k<C, R, GR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
+    attr = true;
+  }
+  hipLaunchKernelGGL((tds_conv_tzf_k<C, R, GR>), dim3((unsigned)blocks), dim3(512), Cfg::LDS, s, p, partial);
+  hipLaunchKernelGGL((tds_tzf_reduce_k<C, R, GR>), dim3((unsigned)((q.kw * C * C + C + 15) / 16)), dim3(1024), 0, s, partial, blocks, q.kw, dw, dbias);
   return W2L_OK;
 }
 
@@ -959,12 +991,16 @@ bool tds_rsf_try(const float* x, const float* dy, float* dw, float* dbias, int B
                  hipStream_t s, int* status) {
   if (tune_env("W2L_TDS_RS_OFF") || tune_env("W2L_TDS_RSF_OFF")) return false;
   if (!(C == 10 || C == 14 || C == 18) || kw > 21 || kw < 1 || H % 4) return false;
-  if (C == 14 && !tune_env("W2L_TDS_RS_C14")) return false;   // measured: 152 us against 103 us of conv_tds.hip's kernel
   if ((((uintptr_t)x | (uintptr_t)dy) & 15) != 0) return false;
+  const bool tzf = !tune_env("W2L_TDS_TZF_OFF") && H % 16 == 0 && (C == 10 || C == 14);   // block-Toeplitz generation (conv_tds_tzf.hpp)
+  if (C == 14 && !tzf && !tune_env("W2L_TDS_RS_C14")) return false;   // measured: 152 us against 103 us of conv_tds.hip's kernel
   TdsRsfP p{};
   p.x = x; p.dy = dy; p.B = B; p.Tin = Tin; p.Tout = Tout; p.H = H; p.kw = kw; p.padl = padl;
   prof_begin(s, 2.0 * B * Tout * (double)H * kw * C * C, PROF_TDS_BWD_FILTER);
   int st = W2L_EUNSUPPORTED;
+  if (tzf) st = C == 10 ? tzf_launch<10, 3, 16>(p, dw, dbias, s) : tzf_launch<14, 2, 12>(p, dw, dbias, s);
+  if (st != W2L_EUNSUPPORTED) {
+  } else
   if (!tune_env("W2L_TDS_RSF3_OFF") && H % 8 == 0 && C != 14)   // wave-specialised generation (conv_tds_rsf3.hpp)
     st = C == 10 ? rsf3_launch<10, 3, 7, 8, 96>(p, dw, dbias, s) : rsf3_launch<18, 7, 3, 4, 96>(p, dw, dbias, s);
   if (st != W2L_EUNSUPPORTED) {

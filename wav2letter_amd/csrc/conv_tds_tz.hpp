@@ -85,18 +85,29 @@ struct TzCfg {
   static_assert((2 * (SP - 1) + 1) * PITCH * 4 + C * 4 < 65536 && (S - 1) * PITCH * 4 + 2 * TR * 8 < 65536, "ds offset field");
 };
 
+// MODE: 0 forward, 1 forward + ReLU, 2 backward-data (tap-flipped transposed weights), 3 backward-data + residual addend.
+// DEFER: the epilogue of tile n-1 (bias, ReLU, 16 stores) rides between the MFMAs of tile n's chain (a second accumulator
+//   set; C = 18 has no registers for it and needs it least: its chain is 208 MFMAs long).
 // ABL (probe library only; results are garbage): 1 one MFMA per chain, 2 no fragment reads, 4 no stores / addend loads, 8 no DMA
-template <int C, int R, int NCT, bool ADD, bool FLIP, int ABL>
+template <int C, int R, int NCT, int MODE, bool DEFER, int ABL>
 __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
   using Cfg = TzCfg<C, R, NCT>;
+  constexpr bool FLIP = MODE >= 2, ADD = MODE == 3, RELU = MODE == 1;
   constexpr int HB = Cfg::HB, S = Cfg::S, C2 = Cfg::C2, SP = Cfg::SP, TR = Cfg::TR, NRD = Cfg::NRD, NK = Cfg::NK, RF = Cfg::RF,
                 NF = Cfg::NF, PITCH = Cfg::PITCH, CPF = Cfg::CPF, PARTS = Cfg::PARTS, BUFB = Cfg::BUFB;
+  static_assert(NF % 4 == 0, "every wave stages the same number of frames");
+  constexpr int NDMA = NF / 4 * PARTS;                 // LDS-DMA instructions per wave and round
+  static_assert(2 * NDMA + 2 < NRD && 36 < NRD, "the chain's first half carries the staging and the deferred epilogue");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* const ldsb = (char*)lds;
+  typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) const char* lcptr_t;
+  typedef __attribute__((address_space(3))) const float* lfptr_t;
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hf = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rt = NCT == 1 ? wave : wave >> 1, ct = NCT == 1 ? 0 : wave & 1;
   const int HC = p.H * C;
+  const unsigned ldsBase = (unsigned)(size_t)(lcptr_t)ldsb;
 
 #ifdef W2L_PROBE
   const long long wEntry = wall_clock64();
@@ -119,117 +130,192 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
   auto advance = [&](Pos& q) {
     if (++q.k == p.rps) { q.k = 0; if (++q.hb == p.hBlocks) { q.hb = 0; ++q.b; } }
   };
-  // stage the NF frames [t0 - padl, ...) of strip (b, hb) into slab `buf`: wave w issues the frames w, w + 4, ...; frames
-  // outside the utterance are outside the buffer's range and arrive as zeros
-  auto stage = [&](const Pos& q, char* buf) {
+  // buffer descriptor (raw, 32-bit offsets, range-checked) of `bytes` bytes at `base`, as four scalars for inline asm
+  auto vsharp = [](const void* base, unsigned bytes) -> u32x4v {
+    const unsigned long long a = (unsigned long long)base;
+    return u32x4v{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+  };
+  // One LDS-DMA instruction: lanes [0, nLanes) copy 16 bytes each from rs[voff] to LDS ldsAddr + 16 lane.  As asm so that
+  // it can sit BETWEEN the MFMAs of a chain without a branch (the lane mask is an exec write, not a divergent `if`); an
+  // out-of-range source arrives as zeros.  (s_mov m0 needs one wait state before the LDS-DMA reads it.)
+  auto dma = [&](const u32x4v& rs, unsigned ldsAddr, int voff, int nLanes) {
     if (ABL & 8) return;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)q.b * p.Tin * HC), 0, p.Tin * HC * 4, 0x00020000);
-    const int base = ((q.k * RF - p.padl) * HC + q.hb * HB * C) * 4;
-#pragma unroll
-    for (int j = 0; j < (NF + 3) / 4; ++j) {
-      const int f = wave + 4 * j;
-      if (f < NF) {
-#pragma unroll
-        for (int part = 0; part < PARTS; ++part)
-          if (lane + 64 * part < CPF)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(buf + f * (PITCH * 4) + part * 1024), 16,
-                                                     base + f * HC * 4 + (lane + 64 * part) * 16, 0, 0, 0);
-      }
+    if (nLanes >= 64) {
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(ldsAddr), "v"(voff), "s"(rs) : "memory");
+    } else {
+      const unsigned long long mask = (1ull << nLanes) - 1;
+      asm volatile("s_mov_b32 m0, %0\n\ts_mov_b64 exec, %3\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b64 exec, -1"
+                   ::"s"(ldsAddr), "v"(voff), "s"(rs), "s"(mask) : "memory");
     }
   };
+  // staging of round q into slab `buf`: NDMA instructions per wave (wave w: frames w, w + 4, ...); frames outside the
+  // utterance are outside the descriptor's range and arrive as zeros.  `live` false: a zero-length descriptor (nothing read)
+  struct Stage { u32x4v rs; int base; };
+  auto stage_of = [&](const Pos& q, bool live) -> Stage {
+    Stage st;
+    st.rs = vsharp(p.x + (size_t)q.b * p.Tin * HC, live ? (unsigned)(p.Tin * HC * 4) : 0u);
+    st.base = ((q.k * RF - p.padl) * HC + q.hb * HB * C) * 4;
+    return st;
+  };
+  const int dmaLane = lane * 16;
+  auto stage_issue = [&](const Stage& st, int buf, int j) {   // instruction j of NDMA
+    const int f = wave + 4 * (j / PARTS), part = j % PARTS;
+    dma(st.rs, ldsBase + buf * BUFB + f * (PITCH * 4) + part * 1024, st.base + f * HC * 4 + part * 1024 + dmaLane, CPF - 64 * part);
+  };
 
-  stage(nx, ldsb);
+  // ---- prologue: first slab -> buffer 0, the weights -> buffer 1
+  {
+    const Stage s0 = stage_of(nx, true);
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) stage_issue(s0, 0, j);
+  }
   Pos here = nx;
   advance(nx);
   // the padding pair of the last frame's last mel row lies behind the slab: its weights are zero, the bytes must not be NaN
   if (tid < 32) *(float*)(ldsb + (tid >> 4) * BUFB + NF * PITCH * 4 + (tid & 15) * 4) = 0.f;
 
-  // ---- the block-Toeplitz weights of this lane's column (r, co) in MFMA B-operand order: step 2 (sp C2 + cp) + e is
-  // k = (s = 2 sp + hf, ci = 2 cp + e); the tail steps are (s = S - 1, ci = 2 (q + hf TR) + e)
+  // The weights as they lie in HBM, [tap][ci][co], with P zero taps in front and zeros behind (NQ taps in all), copied once
+  // per workgroup by LDS-DMA (the range check of the descriptor IS the zero padding); every lane then gathers the block-
+  // Toeplitz column it owns -- step 2 (sp C2 + cp) + e is k = (s = 2 sp + hf, ci = 2 cp + e), the tail steps are (s = S - 1,
+  // ci = 2 (q + hf TR) + e) -- with ds_read_b32 at immediate offsets of ONE address.  (First version: one global gather per
+  // register: 116-208 divergent loads per wave at ~32 TCP cycles each = 14-22 us before the first MFMA;
+  // profiles/r05_run3_conv_tz_independent_weight_loads.log.)
+  constexpr int NQ = S + R - 1;
+  constexpr int WJ = (NQ * C * C / 4 + 255) / 256;     // LDS-DMA instructions per wave
+  static_assert((C * C) % 4 == 0 && WJ * 256 * 16 <= BUFB, "weights fit the second slab");
+  const int P = FLIP ? S - p.kw : R - 1;
+  {
+    const u32x4v rw = vsharp(p.w, (unsigned)(p.kw * C * C * 4));
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+      const int blk = 4 * j + wave;
+      dma(rw, ldsBase + BUFB + blk * 1024, ((blk * 64 + lane) * 4 - P * C * C) * 4, 64);
+    }
+  }
   const int nn = 32 * ct + n;
-  const int rr = nn / C, co = nn - rr * C;
   const bool colOk = nn < R * C;
-  // One buffer load per register, ALL in flight together: an invalid (tap, column) is an out-of-range offset and loads 0,
-  // so there is neither a select nor a clamp -- and no wait between the groups (the first version waited for each frame
-  // pair's ten loads in turn: twelve round trips to L2 with 2048 waves asking for the same 66 cache lines = 20-25 us
-  // before the first MFMA of an 80 us kernel, profiles/r05_run2_conv_tz.log).
+  const int rr = colOk ? nn / C : 0, co = colOk ? nn - (nn / C) * C : 0;   // (the padding columns compute something finite nobody stores)
+  float biasv = 0.f;
+  if (p.bias && colOk) biasv = p.bias[co];
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   float bw[NK];
   {
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.kw * C * C * 4, 0x00020000);
-    constexpr int CISTEP = FLIP ? 1 : C;            // distance of consecutive ci: w[tap][ci][co], flipped w[kw-1-tap][co][ci]
-    const int colPart = FLIP ? co * C : co;
-    constexpr int OOB = (int)0x80000000;
+    const lfptr_t wl = (lfptr_t)(ldsb + BUFB);
+    if (!FLIP) {
+      const lfptr_t bm = wl + (hf - rr + P) * (C * C) + co;
 #pragma unroll
-    for (int sp = 0; sp < SP; ++sp) {
-      const int tap = 2 * sp + hf - rr;
-      const bool ok = colOk && tap >= 0 && tap < p.kw;
-      const int off = ok ? ((FLIP ? p.kw - 1 - tap : tap) * C * C + colPart) * 4 : OOB;
+      for (int sp = 0; sp < SP; ++sp)
 #pragma unroll
-      for (int u = 0; u < C; ++u)
-        bw[2 * sp * C2 + u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, off + u * CISTEP * 4, 0, 0));
-    }
-    if (TR > 0) {
-      const int tap = S - 1 - rr;
-      const bool ok = colOk && tap >= 0 && tap < p.kw;
-      const int base = ((FLIP ? p.kw - 1 - tap : tap) * C * C + colPart) * 4;
+        for (int u = 0; u < C; ++u) bw[2 * sp * C2 + u] = bm[2 * sp * C * C + u * C];
+      if (TR > 0) {
+        const lfptr_t bt = wl + (S - 1 - rr + P) * (C * C) + 2 * hf * TR * C + co;
 #pragma unroll
-      for (int u = 0; u < 2 * TR; ++u) {
-        const int ci = 2 * hf * TR + u;
-        const int off = ok && ci < C ? base + ci * CISTEP * 4 : OOB;
-        bw[2 * SP * C2 + u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, off, 0, 0));
+        for (int u = 0; u < 2 * TR; ++u) {
+          float t = bt[u * C];
+          if (2 * TR + u >= C) t = hf ? 0.f : t;       // ci = 2 hf TR + u >= C: the padding pair
+          bw[2 * SP * C2 + u] = t;
+        }
+      }
+    } else {
+      // w'[tap][ci][co] = w[kw - 1 - tap][co][ci]: tap 2 sp + hf - rr is LDS tap (kw - 1 - hf + rr + P) - 2 sp
+      const lfptr_t bm = wl + (p.kw - 1 - hf + rr + P - 2 * (SP - 1)) * (C * C) + co * C;
+#pragma unroll
+      for (int sp = 0; sp < SP; ++sp)
+#pragma unroll
+        for (int u = 0; u < C; ++u) bw[2 * sp * C2 + u] = bm[2 * (SP - 1 - sp) * C * C + u];
+      if (TR > 0) {
+        const lfptr_t bt = wl + (p.kw - S + rr + P) * (C * C) + co * C + 2 * hf * TR;
+#pragma unroll
+        for (int u = 0; u < 2 * TR; ++u) {
+          float t = bt[u];
+          if (2 * TR + u >= C) t = hf ? 0.f : t;
+          bw[2 * SP * C2 + u] = t;
+        }
       }
     }
   }
-  float biasv = 0.f;
-  if (p.bias && colOk) biasv = p.bias[co];
 
   // ---- per-lane addresses.  Row n of the tile = (group n >> 4, mel row n & 15) of the wave's two groups.
   const int rowOff = (R * (n >> 4) + 2 * R * rt) * PITCH + (n & 15) * C;                       // dwords into the slab
-  typedef __attribute__((address_space(3))) const char* lcptr_t;
   const lcptr_t aMain = (lcptr_t)ldsb + (rowOff + hf * PITCH) * 4;   // half hf reads frame 2 sp + hf
   const lcptr_t aTail = (lcptr_t)ldsb + rowOff * 4 + hf * TR * 8;      // ... and the channel pairs [hf TR, hf TR + TR) of the last frame
   // accumulator v of this lane: row 8 (v >> 2) + 4 hf + (v & 3) -> group v >> 3, mel row 8 ((v >> 2) & 1) + 4 hf + (v & 3);
   // column (rr, co) -> output frame t0 + R (2 rt + group) + rr
   const int yLane = colOk ? ((rr + 2 * R * rt) * HC + 4 * hf * C + co) * 4 : (int)0x80000000;       // invalid columns: out of every range
+  auto vOff = [](int v) { return (8 * ((v >> 2) & 1) + (v & 3)) * C * 4; };
+  // output offsets of the two groups of a round as OPAQUE values: the per-accumulator constants then fold into the
+  // instructions' immediate fields (left alone, hipcc re-associates them onto the loop-invariant lane part: 16 registers)
+  auto y_offsets = [&](const Pos& q, int (&g)[2]) {
+    g[0] = yLane + (q.k * RF * HC + q.hb * HB * C) * 4;
+    g[1] = g[0] + R * HC * 4;
+    asm volatile("" : "+v"(g[0]), "+v"(g[1]));
+  };
+  auto finish = [&](float v) -> float {               // bias, ReLU (as asm: fmaxf() puts a canonicalising v_max in front;
+    if (!FLIP) asm("v_add_f32 %0, %0, %1" : "+v"(v) : "v"(biasv));   //  a vector add keeps a 16-register splat of the bias alive)
+    if (RELU) asm("v_max_f32 %0, %0, 0" : "+v"(v));
+    return v;
+  };
 
 #ifdef W2L_PROBE
   long long cStage = 0, cChain = 0, cWait = 0, cEpi = 0, cBar = 0;
   const long long wLoop = wall_clock64();
 #endif
-  // the first slab has to be there
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  // every lane has its weights: the second slab may be overwritten
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  f32x16 accPrev;                 // DEFER: the finished tile of the previous round
+  int yPrev[2] = {(int)0x80000000, (int)0x80000000};
+  int bPrev = 0;
+  f32x16 addNext;                 // DEFER && ADD: the residual addend of the next round's tile
+#pragma unroll
+  for (int v = 0; v < 16; ++v) { accPrev[v] = 0.f; addNext[v] = 0.f; }
+  if (DEFER && ADD && !(ABL & 4)) {
+    int g[2];
+    y_offsets(here, g);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.add + (size_t)here.b * p.Tout * HC), 0, p.Tout * HC * 4, 0x00020000);
+#pragma unroll
+    for (int v = 0; v < 16; ++v) addNext[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, g[v >> 3] + vOff(v), 0, 0));
+  }
 
   for (int it = 0; rd < rdEnd; ++rd, ++it) {
 #ifdef W2L_PROBE
     const long long c0 = clock64();
 #endif
     const int cur = it & 1;
-    if (rd + 1 < rdEnd) stage(nx, ldsb + (cur ^ 1) * BUFB);
-    const int b = here.b, hb = here.hb, t0 = here.k * RF;
+    const bool more = rd + 1 < rdEnd;
+    const Stage st = stage_of(nx, more);
+    int yOffG[2];
+    y_offsets(here, yOffG);
+    const int b = here.b;
+    // DEFER: the stores of the previous round's tile go to ITS utterance (a zero-length descriptor in the first round)
+    const __amdgpu_buffer_rsrc_t ryP = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (size_t)bPrev * p.Tout * HC), 0, it > 0 ? p.Tout * HC * 4 : 0, 0x00020000);
+    // DEFER && ADD: the addend of the NEXT round's tile is fetched under this chain
+    int yNext[2] = {0, 0};
+    if (DEFER && ADD) y_offsets(nx, yNext);
+    const __amdgpu_buffer_rsrc_t raN = __builtin_amdgcn_make_buffer_rsrc((void*)(p.add + (size_t)nx.b * p.Tout * HC), 0, more ? p.Tout * HC * 4 : 0, 0x00020000);
     here = nx;
     advance(nx);
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (size_t)b * p.Tout * HC), 0, p.Tout * HC * 4, 0x00020000);
-    // the two groups' offsets as opaque per-round values: the per-accumulator constants then fold into the instructions'
-    // immediate fields (left alone, hipcc re-associates them onto the loop-invariant lane part: 16 address registers)
-    int yOffG[2];
-    yOffG[0] = yLane + (t0 * HC + hb * HB * C) * 4;
-    yOffG[1] = yOffG[0] + R * HC * 4;
-    asm volatile("" : "+v"(yOffG[0]), "+v"(yOffG[1]));
     // the accumulators start from the residual addend (backward-data) or from zero (an inline constant of the first MFMA:
     // no registers); the bias joins in the epilogue
     f32x16 acc;
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[v] = 0.f;
     if (ADD && !(ABL & 4)) {
-      const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.add + (size_t)b * p.Tout * HC), 0, p.Tout * HC * 4, 0x00020000);
+      if (DEFER) {
+        acc = addNext;
+      } else {
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.add + (size_t)b * p.Tout * HC), 0, p.Tout * HC * 4, 0x00020000);
 #pragma unroll
-      for (int v = 0; v < 16; ++v)
-        acc[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, yOffG[v >> 3] + (8 * ((v >> 2) & 1) + (v & 3)) * C * 4, 0, 0));
+        for (int v = 0; v < 16; ++v) acc[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, yOffG[v >> 3] + vOff(v), 0, 0));
+      }
     }
 #ifdef W2L_PROBE
     const long long c1 = clock64();
 #endif
-    // ---- the chain: NK dependent MFMAs, fragment read d + D issued in the slots of read d
+    // ---- the chain: NK dependent MFMAs; fragment read d + D is issued in the slots of read d.  The chain's FIRST HALF also
+    // carries, one instruction per MFMA slot, the staging of the next round (even d) and the deferred epilogue of the
+    // previous tile (odd d): bias, ReLU, store -- and the next tile's addend load.  All vector memory traffic of a round is
+    // issued by d = 36, so the s_waitcnt vmcnt(0) behind the chain finds it complete.
     {
       typedef float f32x2 __attribute__((ext_vector_type(2)));
       constexpr int D = 3, RING = 4;
@@ -251,34 +337,43 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
       for (int d = 0; d < NRD; ++d) {
         if (d + D < NRD) ring[(d + D) % RING] = rdfrag(d + D);
         if (!((ABL & 1) && d > 0)) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[d % RING].x, bw[2 * d], acc, 0, 0, 0);
+        if (d % 2 == 0 && d / 2 < NDMA) stage_issue(st, cur ^ 1, d / 2);
+        if (DEFER && d % 2 == 1 && d / 2 < 16 && !(ABL & 4)) {
+          const int v = d / 2;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, finish(accPrev[v])), ryP, yPrev[v >> 3] + vOff(v), 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        if (!(ABL & 1)) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[d % RING].y, bw[2 * d + 1], acc, 0, 0, 0);
+        if (DEFER && d == NRD - 1) {
+          // the chain's last MFMA writes the finished tile where the next round's epilogue expects it (no 16-register copy)
+          accPrev = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[d % RING].y, bw[2 * d + 1], acc, 0, 0, 0);
+        } else if (!(ABL & 1)) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[d % RING].y, bw[2 * d + 1], acc, 0, 0, 0);
+        }
+        if (DEFER && ADD && d % 2 == 1 && d / 2 < 16 && !(ABL & 4)) {
+          const int v = d / 2;
+          addNext[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(raN, yNext[v >> 3] + vOff(v), 0, 0));
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
 #ifdef W2L_PROBE
     const long long c2 = clock64();
 #endif
-    // the next round's slab (issued a whole chain ago) has landed; nothing else of this wave is in flight
+    // the next round's slab has landed; nothing else of this wave is in flight
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef W2L_PROBE
     const long long c3 = clock64();
 #endif
-    if (!(ABL & 4)) {
-      if (p.bias) {   // (as asm: hipcc otherwise keeps a 16-register splat of the bias alive through the chain)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) asm("v_add_f32 %0, %0, %1" : "+v"(acc[v]) : "v"(biasv));
-      }
-      if (p.relu) {
-#pragma unroll
-        for (int v = 0; v < 16; ++v) asm("v_max_f32 %0, %0, 0" : "+v"(acc[v]));   // (fmaxf() puts a canonicalising v_max in front)
-      }
+    if (DEFER) {
+      yPrev[0] = yOffG[0]; yPrev[1] = yOffG[1];
+      bPrev = b;
+    } else if (!(ABL & 4)) {
+      const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (size_t)b * p.Tout * HC), 0, p.Tout * HC * 4, 0x00020000);
 #pragma unroll
       for (int v = 0; v < 16; ++v)
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)acc[v]), ry, yOffG[v >> 3] + (8 * ((v >> 2) & 1) + (v & 3)) * C * 4, 0, 0);
-    } else if (acc[0] == 123.456f) {
-      p.y[0] = acc[5];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, finish(acc[v])), ry, yOffG[v >> 3] + vOff(v), 0, 0);
     }
+    if ((ABL & 4) && (DEFER ? accPrev[0] : acc[0]) == 123.456f) p.y[0] = DEFER ? accPrev[5] : acc[5];
 #ifdef W2L_PROBE
     const long long c4 = clock64();
 #endif
@@ -288,6 +383,12 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
     const long long c5 = clock64();
     cStage += c1 - c0; cChain += c2 - c1; cWait += c3 - c2; cEpi += c4 - c3; cBar += c5 - c4;
 #endif
+  }
+  if (DEFER && !(ABL & 4)) {   // the last tile
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (size_t)bPrev * p.Tout * HC), 0, p.Tout * HC * 4, 0x00020000);
+#pragma unroll
+    for (int v = 0; v < 16; ++v)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, finish(accPrev[v])), ry, yPrev[v >> 3] + vOff(v), 0, 0);
   }
 #ifdef W2L_PROBE
   if (p.dbg && tid == 0) {
