@@ -13,22 +13,31 @@ KW = 21
 HB = 16
 
 
-def cfg(C, R, NCT):
-    S = R + KW - 1
-    C2 = C // 2
+def cfg(CI, CO, R, NCT, SIG=1, KWM=21, ST=1):
+    S = SIG * (R - 1) + KWM
+    C2 = CI // 2
     SP = S // 2
     TAIL = S % 2
     TR = (C2 + 1) // 2 if TAIL else 0
     NRD = SP * C2 + TR
     RT = 4 // NCT
     GR = 2 * RT
-    p = HB * C
-    while (R * p) % 64 != 32:
+    GSTEP = SIG * R
+    NF = (GSTEP * (GR - 1) + S + 3) // 4 * 4
+    p = HB * CI
+    while (GSTEP * p) % 64 != 32:
         p += 4
-    return dict(C=C, R=R, NCT=NCT, S=S, C2=C2, SP=SP, TR=TR, NRD=NRD, NK=2 * NRD, RT=RT, GR=GR, RF=GR * R, NF=(GR - 1) * R + S, PITCH=p)
+    if 4 * ((NF * p * 4 + 64 + 1023) // 1024 * 1024) > 160 * 1024:
+        p = HB * CI
+    return dict(CI=CI, CO=CO, R=R, NCT=NCT, SIG=SIG, KWM=KWM, ST=ST, S=S, C2=C2, SP=SP, TR=TR, NRD=NRD, NK=2 * NRD, RT=RT, GR=GR, RF=GR * R,
+                GSTEP=GSTEP, NF=NF, PITCH=p, NQF=S + SIG * (R - 1), NQB=ST * (S + R - 1))
 
 
-CFGS = {10: cfg(10, 3, 1), 14: cfg(14, 2, 1), 18: cfg(18, 3, 2)}
+# the instances conv_tds_rs.hip launches: (CI, CO, stride of the layer / tap step of the phase, backward?)
+CFGS = {(10, 10, 1, False): cfg(10, 10, 3, 1), (14, 14, 1, False): cfg(14, 14, 2, 1), (18, 18, 1, False): cfg(18, 18, 3, 2),
+        (10, 10, 1, True): cfg(10, 10, 3, 1), (14, 14, 1, True): cfg(14, 14, 2, 1), (18, 18, 1, True): cfg(18, 18, 3, 2),
+        (10, 14, 2, False): cfg(10, 14, 2, 1, SIG=2), (14, 18, 2, False): cfg(14, 18, 3, 2, SIG=2),
+        (14, 10, 2, True): cfg(14, 10, 3, 1, KWM=11, ST=2), (18, 14, 2, True): cfg(18, 14, 2, 1, KWM=11, ST=2)}
 
 
 def mfma_32x32x2(a, b, acc):
@@ -43,70 +52,91 @@ def mfma_32x32x2(a, b, acc):
     return acc
 
 
-def forward(x, w, bias, kw, padl, flip=False, relu=False, add=None, Tout=None):
-    """x [B][Tin][H][C], w [kw][C][C]; returns y [B][Tout][H][C] computed the way tds_conv_tz_k does."""
-    B, Tin, H, C = x.shape
-    g = CFGS[C]
-    R, NCT, S, C2, SP, TR, NRD, RT, RF, NF, PITCH = (g[k] for k in ("R", "NCT", "S", "C2", "SP", "TR", "NRD", "RT", "RF", "NF", "PITCH"))
-    if Tout is None:
-        Tout = Tin
-    assert H % HB == 0 and kw <= KW
-    y = np.full((B, Tout, H, C), np.nan)
+def launch(x, w, bias, kw, padl, y, g, flip=False, relu=False, add=None, Tout=None, tapOff=0, oOff=0, oStep=1):
+    """one launch of tds_conv_tz_k<g>: x [B][Tin][H][CI], w the layer's weights [kwFull][.][.] (forward: [tap][ci][co]; backward:
+    read as w[tapOff + ST (kw - 1 - tap)][co][ci]); writes frames oOff + oStep u (u < Tout) of y [B][ToutFull][H][CO] (NaN =
+    never written)."""
+    B, Tin, H, CI = x.shape
+    CO, R, NCT, SIG, ST, S, C2, SP, TR, NRD, RT, RF, GSTEP, NF, PITCH = (g[k] for k in (
+        "CO", "R", "NCT", "SIG", "ST", "S", "C2", "SP", "TR", "NRD", "RT", "RF", "GSTEP", "NF", "PITCH"))
+    assert CI == g["CI"] and H % HB == 0 and kw <= g["KWM"] and y.shape[3] == CO
+    ToutFull = y.shape[1]
     yflat = y.reshape(B, -1)
     xflat = x.reshape(B, -1).astype(np.float64)
-    HC = H * C
+    HCI, HCO = H * CI, H * CO
+    CC = CI * CO
     lane = np.arange(64)
     n, hf = lane & 31, lane >> 5
     rps = (Tout + RF - 1) // RF
     wf = w.astype(np.float64).reshape(-1)
+    kwFull = w.shape[0]
+    # ---- the zero-padded weight copy of the prologue (LDS, second slab)
+    NQ = g["NQB"] if flip else g["NQF"]
+    P = ST * (S - kw) if flip else SIG * (R - 1)
+    wl = np.zeros(((NQ * CC // 4 + 255) // 256) * 256 * 4 + 4 * CC)
+    for e in range(NQ * CC):
+        src = e - P * CC
+        wl[e] = wf[src] if 0 <= src < kwFull * CC else 0.0
     for b in range(B):
         for hb in range(H // HB):
             for k in range(rps):
-                t0 = k * RF
-                # ---- stage: NF frames, CPF 16-byte chunks each, buffer range check -> zeros; bytes behind the slab are zero
+                # ---- stage: NF frames, buffer range check -> zeros; the bytes behind the slab are zero
                 slab = np.full(NF * PITCH + 16, np.nan)
                 slab[NF * PITCH:] = 0.0
                 for f in range(NF):
-                    for piece in range(HB * C // 4):
-                        off = ((t0 - padl + f) * HC + hb * HB * C) + piece * 4      # dwords
-                        ok = 0 <= off and off + 4 <= Tin * HC
+                    if TR and PITCH > HB * CI:
+                        slab[f * PITCH + HB * CI: (f + 1) * PITCH] = 0.0     # zeroed once by the kernel's prologue
+                    for piece in range(HB * CI // 4):
+                        off = ((k * RF * SIG - padl + f) * HCI + hb * HB * CI) + piece * 4      # dwords
+                        ok = 0 <= off and off + 4 <= Tin * HCI
                         slab[f * PITCH + piece * 4: f * PITCH + piece * 4 + 4] = xflat[b, off:off + 4] if ok else 0.0
                 for wave in range(4):
                     rt, ct = (wave, 0) if NCT == 1 else (wave >> 1, wave & 1)
                     nn = 32 * ct + n
-                    rr, co = nn // C, nn % C
-                    colOk = nn < R * C
-                    # ---- B registers
+                    colOk = nn < R * CO
+                    rr = np.where(colOk, nn // CO, 0)
+                    co = np.where(colOk, nn % CO, 0)
+                    # ---- B registers: gathers out of the LDS copy at one base + immediates
                     bw = np.zeros((2 * NRD, 64))
-                    wstep = 1 if flip else C
-                    for sp in range(SP):
-                        tap = 2 * sp + hf - rr
-                        ok = colOk & (tap >= 0) & (tap < kw)
-                        tc = np.where(ok, tap, 0)
-                        base = ((kw - 1 - tc) * C + co) * C if flip else tc * C * C + co
-                        for u in range(C):
-                            bw[2 * sp * C2 + u] = np.where(ok, wf[base + u * wstep], 0.0)
-                    if TR:
-                        tap = S - 1 - rr
-                        ok = colOk & (tap >= 0) & (tap < kw)
-                        tc = np.where(ok, tap, 0)
-                        base = ((kw - 1 - tc) * C + co) * C if flip else tc * C * C + co
-                        for u in range(2 * TR):
-                            ci = 2 * hf * TR + u
-                            okc = ok & (ci < C)
-                            bw[2 * SP * C2 + u] = np.where(okc, wf[base + np.where(okc, ci, 0) * wstep], 0.0)
-                    rowOff = (R * (n >> 4) + 2 * R * rt) * PITCH + (n & 15) * C
+                    if not flip:
+                        bm = (hf - SIG * rr + P) * CC + co
+                        assert (bm >= 0).all()
+                        for sp in range(SP):
+                            for u in range(CI):
+                                bw[2 * sp * C2 + u] = wl[bm + 2 * sp * CC + u * CO]
+                        if TR:
+                            bt = (S - 1 - SIG * rr + P) * CC + 2 * hf * TR * CO + co
+                            for u in range(2 * TR):
+                                t = wl[bt + u * CO]
+                                if 2 * TR + u >= CI:
+                                    t = np.where(hf == 1, 0.0, t)
+                                bw[2 * SP * C2 + u] = t
+                    else:
+                        bm = (tapOff + ST * (kw - 1 - hf + rr) + P - 2 * ST * (SP - 1)) * CC + co * CI
+                        assert (bm >= 0).all()
+                        for sp in range(SP):
+                            for u in range(CI):
+                                bw[2 * sp * C2 + u] = wl[bm + 2 * ST * (SP - 1 - sp) * CC + u]
+                        if TR:
+                            bt = (tapOff + ST * (kw - S + rr) + P) * CC + co * CI + 2 * hf * TR
+                            assert (bt >= 0).all()
+                            for u in range(2 * TR):
+                                t = wl[bt + u]
+                                if 2 * TR + u >= CI:
+                                    t = np.where(hf == 1, 0.0, t)
+                                bw[2 * SP * C2 + u] = t
+                    rowOff = (GSTEP * (n >> 4) + 2 * GSTEP * rt) * PITCH + (n & 15) * CI
                     aMain = rowOff + hf * PITCH
                     aTail = rowOff + hf * TR * 2
-                    yLane = np.where(colOk, (rr + 2 * R * rt) * HC + 4 * hf * C + co, -(1 << 40))
-                    yOff = yLane + t0 * HC + hb * HB * C
+                    yLane = np.where(colOk, (rr + 2 * R * rt) * oStep * HCO + 4 * hf * CO + co, -(1 << 40))
+                    g0 = yLane + (k * RF * oStep + oOff) * HCO + hb * HB * CO
                     acc = np.zeros((16, 64))
-                    voff = [yOff + (v >> 3) * R * HC + (8 * ((v >> 2) & 1) + (v & 3)) * C for v in range(16)]
+                    voff = [g0 + (v >> 3) * R * oStep * HCO + (8 * ((v >> 2) & 1) + (v & 3)) * CO for v in range(16)]
                     if add is not None:
                         af = add.reshape(B, -1)
                         for v in range(16):
-                            inr = (voff[v] >= 0) & (voff[v] < Tout * HC)
-                            acc[v] = np.where(inr, af[b, np.clip(voff[v], 0, Tout * HC - 1)], 0.0)
+                            inr = (voff[v] >= 0) & (voff[v] < ToutFull * HCO)
+                            acc[v] = np.where(inr, af[b, np.clip(voff[v], 0, ToutFull * HCO - 1)], 0.0)
                     for d in range(NRD):
                         if d < SP * C2:
                             sp, cp = divmod(d, C2)
@@ -115,32 +145,60 @@ def forward(x, w, bias, kw, padl, flip=False, relu=False, add=None, Tout=None):
                             addr = aTail + (S - 1) * PITCH + 2 * (d - SP * C2)
                         acc = mfma_32x32x2(slab[addr], bw[2 * d], acc)
                         acc = mfma_32x32x2(slab[addr + 1], bw[2 * d + 1], acc)
+                    acc = np.where(colOk, acc, 0.0)            # (the padding columns: something nobody stores)
                     if bias is not None:
                         acc = acc + np.where(colOk, bias.astype(np.float64)[co], 0.0)
                     if relu:
                         acc = np.maximum(acc, 0.0)
                     for v in range(16):
-                        inr = (voff[v] >= 0) & (voff[v] < Tout * HC)
+                        inr = (voff[v] >= 0) & (voff[v] < ToutFull * HCO)
                         assert np.isnan(yflat[b, voff[v][inr]]).all(), "an output is written twice"
                         yflat[b, voff[v][inr]] = acc[v][inr]
     return y
 
 
-def direct(x, w, bias, kw, padl, flip=False, relu=False, add=None, Tout=None):
-    """out[t][h][co] = bias[co] + sum_{j, ci} x[t + j - padl][h][ci] W[j][ci][co]; flip: W'[j][ci][co] = W[kw-1-j][co][ci]"""
-    B, Tin, H, C = x.shape
+def forward(x, w, bias, kw, padl, flip=False, relu=False, add=None, Tout=None, stride=1):
+    """the layer's forward pass (stride 1 or 2), or with flip its stride-1 backward-data pass, the way tds_conv_tz_k does it"""
+    B, Tin, H, CI = x.shape
+    CO = w.shape[1] if flip else w.shape[2]
+    if Tout is None:
+        Tout = Tin
+    y = np.full((B, Tout, H, CO), np.nan)
+    return launch(x, w, bias, kw, padl, y, CFGS[(CI, CO, stride, flip)], flip, relu, add, Tout)
+
+
+def backward_data_strided(dy, w, T, kw, stride, padl, add=None):
+    """dx [B][T][H][Cin] of a stride-2 layer from dy [B][To][H][Cout]: one launch per phase of the stride, as
+    tds_conv_backward_data (conv_tds.hip) cuts it"""
+    B, To, H, Cout = dy.shape
+    Cin = w.shape[1]
+    dx = np.full((B, T, H, Cin), np.nan)
+    for f in range(stride):
+        kwf = (kw - f + stride - 1) // stride
+        c0 = (f - padl) % stride
+        if c0 >= T:
+            continue
+        U = (T - c0 + stride - 1) // stride
+        s0 = (c0 + padl - f) // stride
+        launch(dy, w, None, kwf, kwf - 1 - s0, dx, CFGS[(Cout, Cin, stride, True)], True, False, add, U, tapOff=f, oOff=c0, oStep=stride)
+    return dx
+
+
+def direct(x, w, bias, kw, padl, flip=False, relu=False, add=None, Tout=None, stride=1):
+    """out[t][h][co] = bias[co] + sum_{j, ci} x[stride t + j - padl][h][ci] W[j][ci][co]; flip: W'[j][ci][co] = W[kw-1-j][co][ci]"""
+    B, Tin, H, CI = x.shape
     if Tout is None:
         Tout = Tin
     ww = w.astype(np.float64)
     if flip:
         ww = ww[::-1].transpose(0, 2, 1)
-    y = np.zeros((B, Tout, H, C))
-    xp = np.zeros((B, Tout + kw - 1 + max(0, padl) + 64, H, C))
-    for t in range(Tin):
-        if 0 <= t + padl < xp.shape[1]:
-            xp[:, t + padl] = x[:, t]
-    for j in range(kw):
-        y += np.einsum("bthc,cd->bthd", xp[:, j:j + Tout], ww[j])
+    CO = ww.shape[2]
+    y = np.zeros((B, Tout, H, CO))
+    for t in range(Tout):
+        for j in range(kw):
+            ti = stride * t + j - padl
+            if 0 <= ti < Tin:
+                y[:, t] += np.einsum("bhc,cd->bhd", x[:, ti].astype(np.float64), ww[j])
     if bias is not None:
         y += bias
     if relu:
@@ -148,6 +206,21 @@ def direct(x, w, bias, kw, padl, flip=False, relu=False, add=None, Tout=None):
     if add is not None:
         y += add
     return y
+
+
+def direct_backward_data(dy, w, T, kw, stride, padl, add=None):
+    """dx[ti][h][ci] = sum_{to, j: stride to + j - padl = ti} dy[to][h][co] W[j][ci][co]"""
+    B, To, H, Cout = dy.shape
+    Cin = w.shape[1]
+    dx = np.zeros((B, T, H, Cin))
+    for to in range(To):
+        for j in range(kw):
+            ti = stride * to + j - padl
+            if 0 <= ti < T:
+                dx[:, ti] += np.einsum("bhd,cd->bhc", dy[:, to].astype(np.float64), w[j].astype(np.float64))
+    if add is not None:
+        dx += add
+    return dx
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

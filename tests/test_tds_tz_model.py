@@ -31,6 +31,30 @@ def test_forward_decomposition(C, T, B, H, kw, padl, flip, relu, use_add):
     assert np.abs(y - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("CI,CO,T,B,H,kw,padl,padr", [(10, 14, 41, 1, 16, 21, 10, 10), (14, 18, 37, 2, 16, 21, 9, 10), (10, 14, 60, 1, 32, 21, 10, 9),
+                                                      (14, 18, 8, 1, 16, 7, 3, 3)])
+def test_strided_layers_decomposition(CI, CO, T, B, H, kw, padl, padr):
+    """the sub-sampling layers between the TDS stages (stride 2, CI != CO): forward with a group step of 2 R input frames and
+    the Toeplitz index s - 2 r (padded frame pitch: the tail's padding pair must read zeros, not stale LDS); backward-data as one
+    launch per phase of the stride (every second tap, every second output frame), with and without the addend"""
+    rng = np.random.default_rng(CI * 100 + T)
+    To = (T + padl + padr - kw) // 2 + 1
+    x = rng.normal(size=(B, T, H, CI))
+    w = rng.normal(size=(kw, CI, CO))
+    bias = rng.normal(size=CO)
+    y = M.forward(x, w, bias, kw, padl, False, True, None, To, stride=2)
+    ref = M.direct(x, w, bias, kw, padl, False, True, None, To, stride=2)
+    assert not np.isnan(y).any()
+    assert np.abs(y - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
+    dy = rng.normal(size=(B, To, H, CO))
+    add = rng.normal(size=(B, T, H, CI))
+    for a in (None, add):
+        dx = M.backward_data_strided(dy, w, T, kw, 2, padl, a)
+        rd = M.direct_backward_data(dy, w, T, kw, 2, padl, a)
+        assert not np.isnan(dx).any()
+        assert np.abs(dx - rd).max() < 1e-12 * max(1.0, np.abs(rd).max())
+
+
 @pytest.mark.parametrize("C,T,B,H,kw,padl", [(10, 30, 1, 16, 21, 10), (14, 19, 2, 16, 21, 10), (10, 53, 1, 32, 9, 0), (14, 40, 1, 16, 21, 20),
                                              (10, 1, 1, 16, 21, 10)])
 def test_filter_gradient_decomposition(C, T, B, H, kw, padl):

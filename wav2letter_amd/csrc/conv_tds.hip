@@ -817,6 +817,9 @@ __global__ __launch_bounds__(1024) void tds_conv_filter_reduce_k(const float* __
 
 float* sk_scratch(hipStream_t s, size_t bytes);
 // conv_tds_rs.hip: role-swapped 32x32x2 kernel for the TDS convolutions proper (C -> C, stride 1)
+bool tds_tz_try(const float* x, const float* w, const float* bias, const float* add, float* y, int B, int Tin, int Tout, int H,
+                int Cin, int Cout, int kw, int stride, int padl, int relu, int accum, int flip, int tapOff, int tapStep, int oOff,
+                int oStep, int ToutFull, int profKind, hipStream_t s, int* status);
 bool tds_rs_try(const float* x, const float* w, const float* bias, const float* add, float* y, int B, int Tin, int Tout, int H,
                 int C, int kw, int padl, int relu, int accum, int flip, int profKind, hipStream_t s, int* status);
 bool tds_rsf_try(const float* x, const float* dy, float* dw, float* dbias, int B, int Tin, int Tout, int H, int C, int kw, int padl,
@@ -908,7 +911,12 @@ static bool try_launch_fwd2(const TdsConvP& pIn0, hipStream_t s, int* status, in
 
 static int launch_fwd(const TdsConvP& p, hipStream_t s, int profKind = PROF_TDSCONV) {
   int st2 = W2L_OK;
-  // the TDS convolutions proper: role-swapped 32x32x2 kernel (conv_tds_rs.hip)
+  // block-Toeplitz generation (conv_tds_tz.hpp): the TDS convolutions proper and the strided layers between the stages
+  if (p.CinW == (p.flip ? p.Cout : p.Cin) && p.CoutW == (p.flip ? p.Cin : p.Cout) &&
+      tds_tz_try(p.x, p.w, p.bias, p.add, p.y, p.B, p.Tin, p.Tout, p.H, p.Cin, p.Cout, p.kw, p.stride, p.padl, p.relu, p.accum, p.flip,
+                 p.tapOff, p.tapStep, p.oOff, p.oStep, p.ToutFull, profKind, s, &st2))
+    return st2;
+  // the previous generation for the geometries it does not take: role-swapped 32x32x2 kernel (conv_tds_rs.hip)
   if (p.stride == 1 && p.Cin == p.Cout && p.tapStep == 1 && p.oStep == 1 &&
       tds_rs_try(p.x, p.w, p.bias, p.add, p.y, p.B, p.Tin, p.Tout, p.H, p.Cin, p.kw, p.padl, p.relu, p.accum, p.flip, profKind, s, &st2))
     return st2;
@@ -965,6 +973,11 @@ int tds_conv_backward_data(const w2l_conv_desc* d, const float* dy, const float*
     p.CinW = d->Cin; p.CoutW = d->Cout;
     p.tapOff = f; p.tapStep = st; p.oOff = c0; p.oStep = st; p.ToutFull = d->T;
     int st2 = W2L_OK;
+    if (tds_tz_try(p.x, p.w, p.bias, p.add, p.y, p.B, p.Tin, p.Tout, p.H, p.Cin, p.Cout, p.kw, p.stride, p.padl, p.relu, p.accum, p.flip,
+                   p.tapOff, p.tapStep, p.oOff, p.oStep, p.ToutFull, PROF_TDS_BWD_DATA, s, &st2)) {
+      if (st2 != W2L_OK) return st2;
+      continue;
+    }
     if (!try_launch_fwd2(p, s, &st2, PROF_TDS_BWD_DATA)) return f == 0 ? W2L_EUNSUPPORTED : W2L_EHIP;  // geometry is the same for every phase
     if (st2 != W2L_OK) return st2;
   }

@@ -600,16 +600,13 @@ static int rs3_launch(const TdsRsP& q, hipStream_t s) {
 #include "conv_tds_tz.hpp"
 namespace w2l {
 
-template <int C, int R, int NCT>
-static int tz_launch(const TdsRsP& q, hipStream_t s) {
-  using Cfg = TzCfg<C, R, NCT>;
-  TdsTzP p{};
-  p.x = q.x; p.w = q.w; p.bias = q.bias; p.add = q.add; p.y = q.y;
-  p.B = q.B; p.Tin = q.Tin; p.Tout = q.Tout; p.H = q.H; p.kw = q.kw; p.padl = q.padl; p.relu = q.relu; p.flip = q.flip;
+template <int CI, int CO, int R, int NCT, int SIG, int KWM, int ST, bool FWD>
+static int tz_launch(TdsTzP p, int abl, hipStream_t s) {
+  using Cfg = TzCfg<CI, CO, R, NCT, SIG, KWM, ST>;
   { const char* e = tune_env("W2L_TDS_TZ_DBG"); p.dbg = e ? (long long*)strtoull(e, nullptr, 10) : nullptr; }
-  p.hBlocks = q.H / Cfg::HB;
-  p.rps = (q.Tout + Cfg::RF - 1) / Cfg::RF;
-  const long long rounds = (long long)q.B * p.hBlocks * p.rps;
+  p.hBlocks = p.H / Cfg::HB;
+  p.rps = (p.Tout + Cfg::RF - 1) / Cfg::RF;
+  const long long rounds = (long long)p.B * p.hBlocks * p.rps;
   if (rounds <= 0 || rounds > (1ll << 30)) return W2L_EUNSUPPORTED;
   p.nRounds = (int)rounds;
   // two workgroups per CU; equal contiguous shares of the round axis
@@ -619,14 +616,15 @@ static int tz_launch(const TdsRsP& q, hipStream_t s) {
   p.rpw = (p.nRounds + wgs - 1) / wgs;
   const int blocks = (p.nRounds + p.rpw - 1) / p.rpw;
   constexpr bool DEFER = NCT == 1;   // C = 18: no registers for a second accumulator set (and the longest chain)
+  constexpr int M0 = FWD ? 0 : 2;    // the two modes of the direction: plain / + ReLU, plain / + addend
 #ifdef W2L_PROBE
-  if (q.abl) {
+  if (abl && FWD) {
     bool done = false;
     auto go = [&](auto tag) {
       constexpr int M = decltype(tag)::value;
-      if (q.abl != M || done || p.add || p.flip || !p.relu) return;
-      (void)hipFuncSetAttribute((const void*)tds_conv_tz_k<C, R, NCT, 1, DEFER, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
-      hipLaunchKernelGGL((tds_conv_tz_k<C, R, NCT, 1, DEFER, M>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p);
+      if (abl != M || done || !p.relu) return;
+      (void)hipFuncSetAttribute((const void*)tds_conv_tz_k<CI, CO, R, NCT, SIG, KWM, ST, 1, DEFER, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
+      hipLaunchKernelGGL((tds_conv_tz_k<CI, CO, R, NCT, SIG, KWM, ST, 1, DEFER, M>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p);
       done = true;
     };
     go(std::integral_constant<int, 1>{}); go(std::integral_constant<int, 2>{}); go(std::integral_constant<int, 4>{});
@@ -636,18 +634,55 @@ static int tz_launch(const TdsRsP& q, hipStream_t s) {
 #endif
   static bool attr = false;
   if (!attr) {
-    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_tz_k<C, R, NCT, 0, DEFER, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
-    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_tz_k<C, R, NCT, 1, DEFER, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
-    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_tz_k<C, R, NCT, 2, DEFER, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
-    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_tz_k<C, R, NCT, 3, DEFER, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
+    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_tz_k<CI, CO, R, NCT, SIG, KWM, ST, M0, DEFER, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
+    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_tz_k<CI, CO, R, NCT, SIG, KWM, ST, M0 + 1, DEFER, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
     attr = true;
   }
-  const int mode = p.flip ? (p.add ? 3 : 2) : (p.relu ? 1 : 0);
-  if (mode == 0) hipLaunchKernelGGL((tds_conv_tz_k<C, R, NCT, 0, DEFER, 0>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p);
-  else if (mode == 1) hipLaunchKernelGGL((tds_conv_tz_k<C, R, NCT, 1, DEFER, 0>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p);
-  else if (mode == 2) hipLaunchKernelGGL((tds_conv_tz_k<C, R, NCT, 2, DEFER, 0>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p);
-  else hipLaunchKernelGGL((tds_conv_tz_k<C, R, NCT, 3, DEFER, 0>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p);
+  const bool second = FWD ? p.relu != 0 : p.add != nullptr;
+  if (second) hipLaunchKernelGGL((tds_conv_tz_k<CI, CO, R, NCT, SIG, KWM, ST, M0 + 1, DEFER, 0>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p);
+  else hipLaunchKernelGGL((tds_conv_tz_k<CI, CO, R, NCT, SIG, KWM, ST, M0, DEFER, 0>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p);
   return W2L_OK;
+}
+
+// true + *status when the block-Toeplitz generation (conv_tds_tz.hpp) runs this convolution: the TDS convolutions proper
+// (C -> C, stride 1, both directions), the strided sub-sampling layers between the stages (10 -> 14, 14 -> 18, stride 2)
+// forward, and the phases of their backward-data pass (every second tap, every second output frame)
+bool tds_tz_try(const float* x, const float* w, const float* bias, const float* add, float* y, int B, int Tin, int Tout, int H,
+                int Cin, int Cout, int kw, int stride, int padl, int relu, int accum, int flip, int tapOff, int tapStep, int oOff,
+                int oStep, int ToutFull, int profKind, hipStream_t s, int* status) {
+  if (tune_env("W2L_TDS_TZ_OFF") || H % 16 || accum || kw < 1) return false;
+  if (flip ? (bias || relu || stride != 1) : (add || tapOff || tapStep != 1 || oOff || oStep != 1)) return false;
+  if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)add | (uintptr_t)w) & 15) != 0) return false;
+  if ((long long)Tin * H * Cin * 4 >= (1ll << 31) || (long long)ToutFull * H * Cout * 4 >= (1ll << 31)) return false;   // one utterance per buffer resource
+  TdsTzP p{};
+  p.x = x; p.w = w; p.bias = bias; p.add = add; p.y = y;
+  p.B = B; p.Tin = Tin; p.Tout = Tout; p.H = H; p.kw = kw; p.padl = padl; p.relu = relu; p.flip = flip;
+  p.kwFull = flip ? tapOff + tapStep * (kw - 1) + 1 : kw;
+  p.tapOff = tapOff; p.oOff = oOff; p.oStep = oStep; p.ToutFull = ToutFull;
+  int abl = 0;
+  { const char* e = tune_env("W2L_TDS_RS_ABL"); abl = e ? atoi(e) : 0; }
+  int st = W2L_EUNSUPPORTED;
+  const bool same = Cin == Cout && stride == 1 && tapStep == 1 && kw <= 21;
+  const bool sub = !flip && stride == 2 && kw <= 21 && !tune_env("W2L_TDS_TZ_C2_OFF");
+  const bool phase = flip && tapStep == 2 && kw <= 11 && !tune_env("W2L_TDS_TZ_C2_OFF");
+  if (!(same && (Cin == 10 || Cin == 14 || Cin == 18)) && !(sub && ((Cin == 10 && Cout == 14) || (Cin == 14 && Cout == 18))) &&
+      !(phase && ((Cin == 14 && Cout == 10) || (Cin == 18 && Cout == 14))))
+    return false;
+  prof_begin(s, 2.0 * B * Tout * (double)H * kw * Cin * Cout, profKind);
+  if (same) {
+    if (!flip) st = Cin == 10 ? tz_launch<10, 10, 3, 1, 1, 21, 1, true>(p, abl, s) : Cin == 14 ? tz_launch<14, 14, 2, 1, 1, 21, 1, true>(p, abl, s)
+                                                                                                  : tz_launch<18, 18, 3, 2, 1, 21, 1, true>(p, abl, s);
+    else st = Cin == 10 ? tz_launch<10, 10, 3, 1, 1, 21, 1, false>(p, abl, s) : Cin == 14 ? tz_launch<14, 14, 2, 1, 1, 21, 1, false>(p, abl, s)
+                                                                                              : tz_launch<18, 18, 3, 2, 1, 21, 1, false>(p, abl, s);
+  } else if (sub) {
+    st = Cin == 10 ? tz_launch<10, 14, 2, 1, 2, 21, 1, true>(p, 0, s) : tz_launch<14, 18, 3, 2, 2, 21, 1, true>(p, 0, s);
+  } else {
+    st = Cin == 14 ? tz_launch<14, 10, 3, 1, 1, 11, 2, false>(p, 0, s) : tz_launch<18, 14, 2, 1, 1, 11, 2, false>(p, 0, s);
+  }
+  prof_end(s);
+  if (st == W2L_OK && hipGetLastError() != hipSuccess) st = W2L_EHIP;
+  *status = st;
+  return true;
 }
 
 // true + *status when this geometry runs on the role-swapped kernel
@@ -661,18 +696,6 @@ bool tds_rs_try(const float* x, const float* w, const float* bias, const float* 
   p.B = B; p.Tin = Tin; p.Tout = Tout; p.H = H; p.kw = kw; p.padl = padl; p.relu = relu; p.accum = accum; p.flip = flip;
   { const char* e = tune_env("W2L_TDS_RS_ABL"); p.abl = e ? atoi(e) : 0; }
   { const char* e = tune_env("W2L_TDS_RS_STAGGER"); p.stagger = e ? atoi(e) : (C == 10 ? 4 : 0); }
-  // fourth generation (conv_tds_tz.hpp): block-Toeplitz weights in registers, slab in the global layout, no overlap-add
-  // (the forward pass carries bias / ReLU, the backward-data pass the residual addend: the modes the kernel is built in)
-  const bool tz = !tune_env("W2L_TDS_TZ_OFF") && H % 16 == 0 && !accum && (flip ? !bias && !relu : !add) && (long long)Tin * H * C * 4 < (1ll << 31) &&
-                  (long long)Tout * H * C * 4 < (1ll << 31);
-  if (tz) {
-    prof_begin(s, 2.0 * B * Tout * (double)H * kw * C * C, profKind);
-    int st = C == 10 ? tz_launch<10, 3, 1>(p, s) : C == 14 ? tz_launch<14, 2, 1>(p, s) : tz_launch<18, 3, 2>(p, s);
-    prof_end(s);
-    if (st == W2L_OK && hipGetLastError() != hipSuccess) st = W2L_EHIP;
-    *status = st;
-    return true;
-  }
   // third generation (conv_tds_rs3.hpp): wave-specialised, streamed time axis.  One utterance per 2 GiB buffer resource.
   const bool rs3 = !tune_env("W2L_TDS_RS3_OFF") && H % 8 == 0 && !accum && (long long)B * (H / 4) * Tout <= (1ll << 30) &&
                    (long long)Tin * H * C * 4 < (1ll << 31) && (long long)Tout * H * C * 4 < (1ll << 31);

@@ -34,17 +34,24 @@
 // (from L2: the previous round of the same workgroup touched them), which makes rounds INDEPENDENT work items: the
 // flattened (utterance, strip, round) axis is cut into equal contiguous shares, one per workgroup.  One LDS/DMA barrier
 // per round.  The sum order of every output is program order over K: deterministic, independent of the grid.
+//
+// The same kernel runs the strided sub-sampling layers between the TDS stages (`C2 cin cout 21 1 2 1 -1 -1`,
+// am_tds_ctc.arch:3, :12, :22): stride SIG in the forward pass is a group step of SIG R input frames and the Toeplitz index
+// s - SIG r (S = SIG (R - 1) + kw); their backward-data pass is, per phase of the stride, a stride-1 correlation of dy with
+// every SIG-th tap (conv_tds.hip, tds_conv_backward_data) whose outputs are every SIG-th frame of dx: tap step ST, output
+// frame step / offset in the store addresses.  CI != CO: the slab / K side counts CI channels, the columns / outputs CO.
 #pragma once
 
 namespace w2l {
 
 struct TdsTzP {
-  const float* x;     // [B][Tin][H][C]
-  const float* w;     // [kw][C][C]
-  const float* bias;  // [C] or null
+  const float* x;     // [B][Tin][H][CI]
+  const float* w;     // [kwFull][CI][CO] (forward);  backward-data reads it as w[tapOff + tapStep (kw - 1 - tap)][co][ci]
+  const float* bias;  // [CO] or null
   const float* add;   // optional addend with the layout of y (no ReLU then), or null
-  float* y;           // [B][Tout][H][C]
+  float* y;           // [B][ToutFull][H][CO]; output frame u of this launch is frame oOff + oStep u
   int B, Tin, Tout, H, kw, padl;
+  int kwFull, tapOff, oOff, oStep, ToutFull;
   int relu, flip;
   int hBlocks;        // H / 16
   int rps;            // rounds per (utterance, strip)
@@ -54,12 +61,12 @@ struct TdsTzP {
                       // rounds, HW_ID | XCC_ID << 32, 100 MHz wall clock at (entry, first round, exit)
 };
 
-template <int C, int R, int NCT>
+template <int CI, int CO, int R, int NCT, int SIG, int KWM, int ST>
 struct TzCfg {
-  static constexpr int KW = 21;
+  static constexpr int KW = KWM;                     // taps the instance is built for (a launch may have fewer)
   static constexpr int HB = 16;                      // mel rows of a strip
-  static constexpr int S = R + KW - 1;               // frames one output group reaches
-  static constexpr int C2 = C / 2;                   // channel pairs
+  static constexpr int S = SIG * (R - 1) + KW;       // input frames one output group reaches
+  static constexpr int C2 = CI / 2;                  // channel pairs
   static constexpr int SP = S / 2;                   // frame pairs (s, s + 1): lane half hf reads frame 2 sp + hf
   static constexpr int TAIL = S % 2;                 // S odd: the last frame's channel pairs are split between the halves
   static constexpr int TR = TAIL ? (C2 + 1) / 2 : 0; // ... TR reads: half 0 pairs [0, TR), half 1 pairs [TR, 2 TR) (the last one may be padding)
@@ -68,36 +75,43 @@ struct TzCfg {
   static constexpr int RT = 4 / NCT;                 // row tiles of a round (one per wave, or per wave pair)
   static constexpr int GR = 2 * RT;                  // frame groups of a round (a row tile = 2 groups x 16 mel rows)
   static constexpr int RF = GR * R;                  // output frames of a round
-  static constexpr int NF = (GR - 1) * R + S;        // slab frames of a round
+  static constexpr int GSTEP = SIG * R;              // input frames between groups
+  static constexpr int NF = (GSTEP * (GR - 1) + S + 3) / 4 * 4;   // slab frames of a round (every wave stages NF / 4 of them)
+  // frame pitch: GSTEP PITCH = 32 (mod 64) dwords puts the two groups of a lane half on disjoint bank pairs; where two
+  // workgroups' double slabs do not fit the CU with that padding, the plain pitch (2-way conflicts on the fragment reads)
   static constexpr int pitch_pick() {
-    int p = HB * C;
-    while ((R * p) % 64 != 32) p += 4;
-    return p;
+    int p = HB * CI;
+    while ((GSTEP * p) % 64 != 32) p += 4;
+    return 4 * ((NF * p * 4 + 64 + 1023) / 1024 * 1024) <= 160 * 1024 ? p : HB * CI;
   }
   static constexpr int PITCH = pitch_pick();         // dwords between slab frames
-  static constexpr int CPF = HB * C / 4;             // 16-byte chunks of one frame of the strip
+  static constexpr int CPF = HB * CI / 4;            // 16-byte chunks of one frame of the strip
   static constexpr int PARTS = (CPF + 63) / 64;      // LDS-DMA instructions per frame
   static constexpr int BUFB = (NF * PITCH * 4 + 64 + 1023) / 1024 * 1024;   // (+ 64: the padding pair of the last frame's last row)
   static constexpr size_t LDS = 2 * (size_t)BUFB;
-  static_assert(C % 2 == 0 && (HB * C) % 4 == 0, "channel pairs, 16-byte chunks");
-  static_assert(R * C <= 32 * NCT, "columns");
+  // taps of the zero-padded weight copy in LDS (second slab, prologue only)
+  static constexpr int NQF = S + SIG * (R - 1);      // forward
+  static constexpr int NQB = ST * (S + R - 1);       // backward-data
+  static_assert(CI % 2 == 0 && (HB * CI) % 4 == 0 && (CI * CO) % 4 == 0, "channel pairs, 16-byte chunks");
+  static_assert(R * CO <= 32 * NCT, "columns");
   static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
-  static_assert((2 * (SP - 1) + 1) * PITCH * 4 + C * 4 < 65536 && (S - 1) * PITCH * 4 + 2 * TR * 8 < 65536, "ds offset field");
+  static_assert((2 * (SP - 1) + 1) * PITCH * 4 + CI * 4 < 65536 && (S - 1) * PITCH * 4 + 2 * TR * 8 < 65536, "ds offset field");
 };
 
 // MODE: 0 forward, 1 forward + ReLU, 2 backward-data (tap-flipped transposed weights), 3 backward-data + residual addend.
 // DEFER: the epilogue of tile n-1 (bias, ReLU, 16 stores) rides between the MFMAs of tile n's chain (a second accumulator
 //   set; C = 18 has no registers for it and needs it least: its chain is 208 MFMAs long).
 // ABL (probe library only; results are garbage): 1 one MFMA per chain, 2 no fragment reads, 4 no stores / addend loads, 8 no DMA
-template <int C, int R, int NCT, int MODE, bool DEFER, int ABL>
+template <int CI, int CO, int R, int NCT, int SIG, int KWM, int ST, int MODE, bool DEFER, int ABL>
 __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
-  using Cfg = TzCfg<C, R, NCT>;
+  using Cfg = TzCfg<CI, CO, R, NCT, SIG, KWM, ST>;
   constexpr bool FLIP = MODE >= 2, ADD = MODE == 3, RELU = MODE == 1;
   constexpr int HB = Cfg::HB, S = Cfg::S, C2 = Cfg::C2, SP = Cfg::SP, TR = Cfg::TR, NRD = Cfg::NRD, NK = Cfg::NK, RF = Cfg::RF,
-                NF = Cfg::NF, PITCH = Cfg::PITCH, CPF = Cfg::CPF, PARTS = Cfg::PARTS, BUFB = Cfg::BUFB;
+                NF = Cfg::NF, PITCH = Cfg::PITCH, CPF = Cfg::CPF, PARTS = Cfg::PARTS, BUFB = Cfg::BUFB, GSTEP = Cfg::GSTEP;
+  static_assert(!FLIP || SIG == 1, "a backward-data phase is a stride-1 correlation");
   static_assert(NF % 4 == 0, "every wave stages the same number of frames");
   constexpr int NDMA = NF / 4 * PARTS;                 // LDS-DMA instructions per wave and round
-  static_assert(2 * NDMA + 2 < NRD && 36 < NRD, "the chain's first half carries the staging and the deferred epilogue");
+  static_assert(2 * NDMA + 2 <= NRD && 34 < NRD, "the chain carries the staging and the deferred epilogue");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* const ldsb = (char*)lds;
   typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
@@ -106,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hf = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rt = NCT == 1 ? wave : wave >> 1, ct = NCT == 1 ? 0 : wave & 1;
-  const int HC = p.H * C;
+  const int HCI = p.H * CI, HCO = p.H * CO;
   const unsigned ldsBase = (unsigned)(size_t)(lcptr_t)ldsb;
 
 #ifdef W2L_PROBE
@@ -153,14 +167,14 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
   struct Stage { u32x4v rs; int base; };
   auto stage_of = [&](const Pos& q, bool live) -> Stage {
     Stage st;
-    st.rs = vsharp(p.x + (size_t)q.b * p.Tin * HC, live ? (unsigned)(p.Tin * HC * 4) : 0u);
-    st.base = ((q.k * RF - p.padl) * HC + q.hb * HB * C) * 4;
+    st.rs = vsharp(p.x + (size_t)q.b * p.Tin * HCI, live ? (unsigned)(p.Tin * HCI * 4) : 0u);
+    st.base = ((q.k * RF * SIG - p.padl) * HCI + q.hb * HB * CI) * 4;
     return st;
   };
   const int dmaLane = lane * 16;
   auto stage_issue = [&](const Stage& st, int buf, int j) {   // instruction j of NDMA
     const int f = wave + 4 * (j / PARTS), part = j % PARTS;
-    dma(st.rs, ldsBase + buf * BUFB + f * (PITCH * 4) + part * 1024, st.base + f * HC * 4 + part * 1024 + dmaLane, CPF - 64 * part);
+    dma(st.rs, ldsBase + buf * BUFB + f * (PITCH * 4) + part * 1024, st.base + f * HCI * 4 + part * 1024 + dmaLane, CPF - 64 * part);
   };
 
   // ---- prologue: first slab -> buffer 0, the weights -> buffer 1
@@ -173,6 +187,17 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
   advance(nx);
   // the padding pair of the last frame's last mel row lies behind the slab: its weights are zero, the bytes must not be NaN
   if (tid < 32) *(float*)(ldsb + (tid >> 4) * BUFB + NF * PITCH * 4 + (tid & 15) * 4) = 0.f;
+  // ... and with a padded frame pitch it lies in the frame's padding, which the staging never writes (the second slab
+  // holds the weights for now: its padding is cleared once they are in registers)
+  constexpr int PADW = PITCH - HB * CI;
+  auto clear_padding = [&](int buf) {
+    if (TR > 0 && PADW > 0)
+      for (int e = tid; e < NF * PADW; e += 256) {
+        const int f = e / (PADW > 0 ? PADW : 1), c = e - f * PADW;
+        *(float*)(ldsb + buf * BUFB + (f * PITCH + HB * CI + c) * 4) = 0.f;
+      }
+  };
+  clear_padding(0);
 
   // The weights as they lie in HBM, [tap][ci][co], with P zero taps in front and zeros behind (NQ taps in all), copied once
   // per workgroup by LDS-DMA (the range check of the descriptor IS the zero padding); every lane then gathers the block-
@@ -180,21 +205,22 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
   // ci = 2 (q + hf TR) + e) -- with ds_read_b32 at immediate offsets of ONE address.  (First version: one global gather per
   // register: 116-208 divergent loads per wave at ~32 TCP cycles each = 14-22 us before the first MFMA;
   // profiles/r05_run3_conv_tz_independent_weight_loads.log.)
-  constexpr int NQ = S + R - 1;
-  constexpr int WJ = (NQ * C * C / 4 + 255) / 256;     // LDS-DMA instructions per wave
-  static_assert((C * C) % 4 == 0 && WJ * 256 * 16 <= BUFB, "weights fit the second slab");
-  const int P = FLIP ? S - p.kw : R - 1;
+  constexpr int NQ = FLIP ? Cfg::NQB : Cfg::NQF;
+  constexpr int CC = CI * CO;
+  constexpr int WJ = (NQ * CC / 4 + 255) / 256;        // LDS-DMA instructions per wave
+  static_assert(WJ * 256 * 16 <= BUFB, "weights fit the second slab");
+  const int P = FLIP ? ST * (S - p.kw) : SIG * (R - 1);
   {
-    const u32x4v rw = vsharp(p.w, (unsigned)(p.kw * C * C * 4));
+    const u32x4v rw = vsharp(p.w, (unsigned)(p.kwFull * CC * 4));
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
       const int blk = 4 * j + wave;
-      dma(rw, ldsBase + BUFB + blk * 1024, ((blk * 64 + lane) * 4 - P * C * C) * 4, 64);
+      dma(rw, ldsBase + BUFB + blk * 1024, ((blk * 64 + lane) * 4 - P * CC) * 4, 64);
     }
   }
   const int nn = 32 * ct + n;
-  const bool colOk = nn < R * C;
-  const int rr = colOk ? nn / C : 0, co = colOk ? nn - (nn / C) * C : 0;   // (the padding columns compute something finite nobody stores)
+  const bool colOk = nn < R * CO;
+  const int rr = colOk ? nn / CO : 0, co = colOk ? nn - (nn / CO) * CO : 0;   // (the padding columns compute something finite nobody stores)
   float biasv = 0.f;
   if (p.bias && colOk) biasv = p.bias[co];
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -202,33 +228,35 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
   {
     const lfptr_t wl = (lfptr_t)(ldsb + BUFB);
     if (!FLIP) {
-      const lfptr_t bm = wl + (hf - rr + P) * (C * C) + co;
+      // w[tap][ci][co]: tap (2 sp + hf) - SIG rr is LDS tap (hf - SIG rr + P) + 2 sp
+      const lfptr_t bm = wl + (hf - SIG * rr + P) * CC + co;
 #pragma unroll
       for (int sp = 0; sp < SP; ++sp)
 #pragma unroll
-        for (int u = 0; u < C; ++u) bw[2 * sp * C2 + u] = bm[2 * sp * C * C + u * C];
+        for (int u = 0; u < CI; ++u) bw[2 * sp * C2 + u] = bm[2 * sp * CC + u * CO];
       if (TR > 0) {
-        const lfptr_t bt = wl + (S - 1 - rr + P) * (C * C) + 2 * hf * TR * C + co;
+        const lfptr_t bt = wl + (S - 1 - SIG * rr + P) * CC + 2 * hf * TR * CO + co;
 #pragma unroll
         for (int u = 0; u < 2 * TR; ++u) {
-          float t = bt[u * C];
-          if (2 * TR + u >= C) t = hf ? 0.f : t;       // ci = 2 hf TR + u >= C: the padding pair
+          float t = bt[u * CO];
+          if (2 * TR + u >= CI) t = hf ? 0.f : t;       // ci = 2 hf TR + u >= CI: the padding pair
           bw[2 * SP * C2 + u] = t;
         }
       }
     } else {
-      // w'[tap][ci][co] = w[kw - 1 - tap][co][ci]: tap 2 sp + hf - rr is LDS tap (kw - 1 - hf + rr + P) - 2 sp
-      const lfptr_t bm = wl + (p.kw - 1 - hf + rr + P - 2 * (SP - 1)) * (C * C) + co * C;
+      // w'[tap][ci][co] = w[tapOff + ST (kw - 1 - tap)][co][ci]: tap 2 sp + hf - rr is LDS tap
+      // tapOff + ST (kw - 1 - hf + rr) + P - 2 ST sp
+      const lfptr_t bm = wl + (p.tapOff + ST * (p.kw - 1 - hf + rr) + P - 2 * ST * (SP - 1)) * CC + co * CI;
 #pragma unroll
       for (int sp = 0; sp < SP; ++sp)
 #pragma unroll
-        for (int u = 0; u < C; ++u) bw[2 * sp * C2 + u] = bm[2 * (SP - 1 - sp) * C * C + u];
+        for (int u = 0; u < CI; ++u) bw[2 * sp * C2 + u] = bm[2 * ST * (SP - 1 - sp) * CC + u];
       if (TR > 0) {
-        const lfptr_t bt = wl + (p.kw - S + rr + P) * (C * C) + co * C + 2 * hf * TR;
+        const lfptr_t bt = wl + (p.tapOff + ST * (p.kw - S + rr) + P) * CC + co * CI + 2 * hf * TR;
 #pragma unroll
         for (int u = 0; u < 2 * TR; ++u) {
           float t = bt[u];
-          if (2 * TR + u >= C) t = hf ? 0.f : t;
+          if (2 * TR + u >= CI) t = hf ? 0.f : t;
           bw[2 * SP * C2 + u] = t;
         }
       }
@@ -236,18 +264,20 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
   }
 
   // ---- per-lane addresses.  Row n of the tile = (group n >> 4, mel row n & 15) of the wave's two groups.
-  const int rowOff = (R * (n >> 4) + 2 * R * rt) * PITCH + (n & 15) * C;                       // dwords into the slab
+  const int rowOff = (GSTEP * (n >> 4) + 2 * GSTEP * rt) * PITCH + (n & 15) * CI;              // dwords into the slab
   const lcptr_t aMain = (lcptr_t)ldsb + (rowOff + hf * PITCH) * 4;   // half hf reads frame 2 sp + hf
   const lcptr_t aTail = (lcptr_t)ldsb + rowOff * 4 + hf * TR * 8;      // ... and the channel pairs [hf TR, hf TR + TR) of the last frame
   // accumulator v of this lane: row 8 (v >> 2) + 4 hf + (v & 3) -> group v >> 3, mel row 8 ((v >> 2) & 1) + 4 hf + (v & 3);
   // column (rr, co) -> output frame t0 + R (2 rt + group) + rr
-  const int yLane = colOk ? ((rr + 2 * R * rt) * HC + 4 * hf * C + co) * 4 : (int)0x80000000;       // invalid columns: out of every range
-  auto vOff = [](int v) { return (8 * ((v >> 2) & 1) + (v & 3)) * C * 4; };
+  // (output frame u of the launch is frame oOff + oStep u of the tensor)
+  const int yLane = colOk ? ((rr + 2 * R * rt) * p.oStep * HCO + 4 * hf * CO + co) * 4 : (int)0x80000000;   // invalid columns: out of every range
+  auto vOff = [](int v) { return (8 * ((v >> 2) & 1) + (v & 3)) * CO * 4; };
+  const int yBytes = p.ToutFull * HCO * 4;
   // output offsets of the two groups of a round as OPAQUE values: the per-accumulator constants then fold into the
   // instructions' immediate fields (left alone, hipcc re-associates them onto the loop-invariant lane part: 16 registers)
   auto y_offsets = [&](const Pos& q, int (&g)[2]) {
-    g[0] = yLane + (q.k * RF * HC + q.hb * HB * C) * 4;
-    g[1] = g[0] + R * HC * 4;
+    g[0] = yLane + ((q.k * RF * p.oStep + p.oOff) * HCO + q.hb * HB * CO) * 4;
+    g[1] = g[0] + R * p.oStep * HCO * 4;
     asm volatile("" : "+v"(g[0]), "+v"(g[1]));
   };
   auto finish = [&](float v) -> float {               // bias, ReLU (as asm: fmaxf() puts a canonicalising v_max in front;
@@ -262,6 +292,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
 #endif
   // every lane has its weights: the second slab may be overwritten
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  clear_padding(1);   // (read first in round 1, a barrier away)
 
   f32x16 accPrev;                 // DEFER: the finished tile of the previous round
   int yPrev[2] = {(int)0x80000000, (int)0x80000000};
@@ -272,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
   if (DEFER && ADD && !(ABL & 4)) {
     int g[2];
     y_offsets(here, g);
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.add + (size_t)here.b * p.Tout * HC), 0, p.Tout * HC * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.add + (size_t)here.b * p.ToutFull * HCO), 0, yBytes, 0x00020000);
 #pragma unroll
     for (int v = 0; v < 16; ++v) addNext[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, g[v >> 3] + vOff(v), 0, 0));
   }
@@ -288,11 +319,11 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
     y_offsets(here, yOffG);
     const int b = here.b;
     // DEFER: the stores of the previous round's tile go to ITS utterance (a zero-length descriptor in the first round)
-    const __amdgpu_buffer_rsrc_t ryP = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (size_t)bPrev * p.Tout * HC), 0, it > 0 ? p.Tout * HC * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ryP = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (size_t)bPrev * p.ToutFull * HCO), 0, it > 0 ? yBytes : 0, 0x00020000);
     // DEFER && ADD: the addend of the NEXT round's tile is fetched under this chain
     int yNext[2] = {0, 0};
     if (DEFER && ADD) y_offsets(nx, yNext);
-    const __amdgpu_buffer_rsrc_t raN = __builtin_amdgcn_make_buffer_rsrc((void*)(p.add + (size_t)nx.b * p.Tout * HC), 0, more ? p.Tout * HC * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t raN = __builtin_amdgcn_make_buffer_rsrc((void*)(p.add + (size_t)nx.b * p.ToutFull * HCO), 0, more ? yBytes : 0, 0x00020000);
     here = nx;
     advance(nx);
     // the accumulators start from the residual addend (backward-data) or from zero (an inline constant of the first MFMA:
@@ -304,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
       if (DEFER) {
         acc = addNext;
       } else {
-        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.add + (size_t)b * p.Tout * HC), 0, p.Tout * HC * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.add + (size_t)b * p.ToutFull * HCO), 0, yBytes, 0x00020000);
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, yOffG[v >> 3] + vOff(v), 0, 0));
       }
@@ -368,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
       yPrev[0] = yOffG[0]; yPrev[1] = yOffG[1];
       bPrev = b;
     } else if (!(ABL & 4)) {
-      const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (size_t)b * p.Tout * HC), 0, p.Tout * HC * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (size_t)b * p.ToutFull * HCO), 0, yBytes, 0x00020000);
 #pragma unroll
       for (int v = 0; v < 16; ++v)
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, finish(acc[v])), ry, yOffG[v >> 3] + vOff(v), 0, 0);
@@ -385,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
 #endif
   }
   if (DEFER && !(ABL & 4)) {   // the last tile
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (size_t)bPrev * p.Tout * HC), 0, p.Tout * HC * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (size_t)bPrev * p.ToutFull * HCO), 0, yBytes, 0x00020000);
 #pragma unroll
     for (int v = 0; v < 16; ++v)
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, finish(accPrev[v])), ry, yPrev[v >> 3] + vOff(v), 0, 0);
