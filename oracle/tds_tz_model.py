@@ -225,28 +225,28 @@ def direct_backward_data(dy, w, T, kw, stride, padl, add=None):
 
 # ---------------------------------------------------------------------------------------------------------------------------
 # filter gradient (conv_tds_tzf.hpp): D[(s, ci)][(r, co)] over (group i, mel row h), folded into dW by tds_tzf_reduce_k
-def cfg_f(C, R, GR):
-    S = R + KW - 1
-    C2 = C // 2
+def cfg_f(CI, CO, R, GR, SIG=1):
+    S = SIG * (R - 1) + KW
+    C2 = CI // 2
     NPR = S * C2
     NPT = (NPR + 1 + 31) // 32
-    p = HB * C + 4
+    p = HB * CI + 4
     while p % 64 not in (40, 48, 8, 16, 24, 56):
         p += 4
-    PD = HB * C + (12 if (HB * C) % 32 == 0 else 0)
-    return dict(C=C, R=R, GR=GR, S=S, C2=C2, NPR=NPR, NPT=NPT, RF=GR * R, NFX=(GR - 1) * R + S, NFD=GR * R, PX=p, PD=PD)
+    PD = HB * CO + (12 if (HB * CO) % 32 == 0 else 0)
+    return dict(CI=CI, CO=CO, R=R, GR=GR, SIG=SIG, S=S, C2=C2, NPR=NPR, NPT=NPT, RF=GR * R, NFX=SIG * R * (GR - 1) + S, NFD=GR * R, PX=p, PD=PD)
 
 
-CFGS_F = {10: cfg_f(10, 3, 16), 14: cfg_f(14, 2, 12)}
+CFGS_F = {(10, 10, 1): cfg_f(10, 10, 3, 16), (14, 14, 1): cfg_f(14, 14, 2, 12), (10, 14, 2): cfg_f(10, 14, 2, 12, 2), (14, 18, 2): cfg_f(14, 18, 1, 12, 2)}
 
 
-def filter_grad(x, dy, kw, padl, n_wg=3):
-    """x [B][Tin][H][C], dy [B][Tout][H][C] -> (dW [kw][C][C], dbias [C]) computed the way tds_conv_tzf_k + tds_tzf_reduce_k do."""
-    B, Tin, H, C = x.shape
-    Tout = dy.shape[1]
-    g = CFGS_F[C]
-    R, GR, S, C2, NPR, NPT, RF, NFX, NFD, PX, PD = (g[k] for k in ("R", "GR", "S", "C2", "NPR", "NPT", "RF", "NFX", "NFD", "PX", "PD"))
-    HC = H * C
+def filter_grad(x, dy, kw, padl, n_wg=3, stride=1):
+    """x [B][Tin][H][CI], dy [B][Tout][H][CO] -> (dW [kw][CI][CO], dbias [CO]) computed the way tds_conv_tzf_k + tds_tzf_reduce_k do."""
+    B, Tin, H, CI = x.shape
+    Tout, CO = dy.shape[1], dy.shape[3]
+    g = CFGS_F[(CI, CO, stride)]
+    R, GR, SIG, S, C2, NPR, NPT, RF, NFX, NFD, PX, PD = (g[k] for k in ("R", "GR", "SIG", "S", "C2", "NPR", "NPT", "RF", "NFX", "NFD", "PX", "PD"))
+    HCI, HCO = H * CI, H * CO
     lane = np.arange(64)
     n, hf = lane & 31, lane >> 5
     xflat = x.reshape(B, -1).astype(np.float64)
@@ -263,26 +263,26 @@ def filter_grad(x, dy, kw, padl, n_wg=3):
             xs = np.full(NFX * PX, np.nan)
             ds = np.full(NFD * PD, np.nan)
             for f in range(NFX):
-                xs[f * PX + HB * C: (f + 1) * PX] = 1.0
-                for piece in range(HB * C // 4):
-                    off = (t0 - padl + f) * HC + hb * HB * C + piece * 4
-                    ok = 0 <= off and off + 4 <= Tin * HC
+                xs[f * PX + HB * CI: (f + 1) * PX] = 1.0
+                for piece in range(HB * CI // 4):
+                    off = (t0 * SIG - padl + f) * HCI + hb * HB * CI + piece * 4
+                    ok = 0 <= off and off + 4 <= Tin * HCI
                     xs[f * PX + piece * 4: f * PX + piece * 4 + 4] = xflat[b, off:off + 4] if ok else 0.0
             for f in range(NFD):
-                for piece in range(HB * C // 4):
-                    off = (t0 + f) * HC + hb * HB * C + piece * 4
-                    ok = 0 <= off and off + 4 <= Tout * HC
+                for piece in range(HB * CO // 4):
+                    off = (t0 + f) * HCO + hb * HB * CO + piece * 4
+                    ok = 0 <= off and off + 4 <= Tout * HCO
                     ds[f * PD + piece * 4: f * PD + piece * 4 + 4] = dflat[b, off:off + 4] if ok else 0.0
             for wave in range(8):
-                rr = np.where(n < R * C, n // C, 0)
-                co = np.where(n < R * C, n % C, 0)
-                bBase = rr * PD + (2 * wave + hf) * C + co
+                rr = np.where(n < R * CO, n // CO, 0)
+                co = np.where(n < R * CO, n % CO, 0)
+                bBase = rr * PD + (2 * wave + hf) * CO + co
                 for i in range(GR):
                     bf = ds[bBase + i * R * PD]
                     for pt in range(NPT):
                         pr = 32 * pt + n
                         s, cp = pr // C2, pr % C2
-                        aoff = np.where(pr < NPR, s * PX + (2 * wave + hf) * C + 2 * cp, HB * C) + i * R * PX
+                        aoff = np.where(pr < NPR, s * PX + (2 * wave + hf) * CI + 2 * cp, HB * CI) + i * SIG * R * PX
                         a0, a1 = xs[aoff], xs[aoff + 1]
                         a0 = np.where(pr > NPR, 0.0, a0)     # rows nobody exports: anything finite
                         a1 = np.where(pr > NPR, 0.0, a1)
@@ -291,35 +291,36 @@ def filter_grad(x, dy, kw, padl, n_wg=3):
         partial[wg] = acc.sum(axis=0)
     # ---- tds_tzf_reduce_k
     flat = partial.reshape(nblocks, -1)
-    dW = np.zeros(kw * C * C)
-    db = np.zeros(C)
-    for o in range(kw * C * C + C):
+    nW = kw * CI * CO
+    dW = np.zeros(nW)
+    db = np.zeros(CO)
+    for o in range(nW + CO):
         tot = 0.0
         for r in range(R):
-            if o < kw * C * C:
-                j, rem = divmod(o, C * C)
-                ci, co = divmod(rem, C)
-                pr, e = (j + r) * C2 + (ci >> 1), ci & 1
+            if o < nW:
+                j, rem = divmod(o, CI * CO)
+                ci, co = divmod(rem, CO)
+                pr, e = (j + SIG * r) * C2 + (ci >> 1), ci & 1
             else:
-                co = o - kw * C * C
+                co = o - nW
                 pr, e = NPR, 0
-            pt, row, col = pr >> 5, pr & 31, r * C + co
+            pt, row, col = pr >> 5, pr & 31, r * CO + co
             idx = ((pt * 2 + e) * 16 + 4 * (row >> 3) + (row & 3)) * 64 + 32 * ((row >> 2) & 1) + col
             tot += flat[:, idx].sum()
-        if o < kw * C * C:
+        if o < nW:
             dW[o] = tot
         else:
-            db[o - kw * C * C] = tot
-    return dW.reshape(kw, C, C), db
+            db[o - nW] = tot
+    return dW.reshape(kw, CI, CO), db
 
 
-def filter_direct(x, dy, kw, padl):
-    B, Tin, H, C = x.shape
-    Tout = dy.shape[1]
-    dW = np.zeros((kw, C, C))
+def filter_direct(x, dy, kw, padl, stride=1):
+    B, Tin, H, CI = x.shape
+    Tout, CO = dy.shape[1], dy.shape[3]
+    dW = np.zeros((kw, CI, CO))
     for j in range(kw):
         for t in range(Tout):
-            ti = t + j - padl
+            ti = stride * t + j - padl
             if 0 <= ti < Tin:
                 dW[j] += np.einsum("bhc,bhd->cd", x[:, ti].astype(np.float64), dy[:, t].astype(np.float64))
     return dW, dy.astype(np.float64).sum(axis=(0, 1, 2))

@@ -65,3 +65,17 @@ def test_filter_gradient_decomposition(C, T, B, H, kw, padl):
     rW, rb = M.filter_direct(x, dy, kw, padl)
     assert np.abs(dW - rW).max() < 1e-12 * max(1.0, np.abs(rW).max())
     assert np.abs(db - rb).max() < 1e-12 * max(1.0, np.abs(rb).max())
+
+
+@pytest.mark.parametrize("CI,CO,T,B,H,kw,padl,padr", [(10, 14, 41, 1, 16, 21, 10, 10), (14, 18, 37, 2, 16, 21, 9, 10), (10, 14, 75, 1, 32, 21, 10, 9),
+                                                      (14, 18, 30, 1, 16, 7, 3, 3)])
+def test_strided_filter_gradient_decomposition(CI, CO, T, B, H, kw, padl, padr):
+    """the filter gradient of the stride-2 layers: x groups 2 R input frames apart, D's diagonals j + 2 r"""
+    rng = np.random.default_rng(CI * 10 + T)
+    To = (T + padl + padr - kw) // 2 + 1
+    x = rng.normal(size=(B, T, H, CI))
+    dy = rng.normal(size=(B, To, H, CO))
+    dW, db = M.filter_grad(x, dy, kw, padl, stride=2)
+    rW, rb = M.filter_direct(x, dy, kw, padl, stride=2)
+    assert np.abs(dW - rW).max() < 1e-12 * max(1.0, np.abs(rW).max())
+    assert np.abs(db - rb).max() < 1e-12 * max(1.0, np.abs(rb).max())

@@ -822,6 +822,12 @@ bool tds_tz_try(const float* x, const float* w, const float* bias, const float* 
                 int oStep, int ToutFull, int profKind, hipStream_t s, int* status);
 bool tds_rs_try(const float* x, const float* w, const float* bias, const float* add, float* y, int B, int Tin, int Tout, int H,
                 int C, int kw, int padl, int relu, int accum, int flip, int profKind, hipStream_t s, int* status);
+bool tds_c1_fwd_try(const float* x, const float* w, const float* bias, float* y, int B, int Tin, int Tout, int H, int Cout, int kw, int stride,
+                    int padl, int relu, int profKind, hipStream_t s, int* status);
+bool tds_c1_filter_try(const float* x, const float* dy, float* dw, float* dbias, int B, int Tin, int Tout, int H, int Cout, int kw, int stride,
+                       int padl, hipStream_t s, int* status);
+bool tds_tzf_strided_try(const float* x, const float* dy, float* dw, float* dbias, int B, int Tin, int Tout, int H, int Cin, int Cout, int kw,
+                         int stride, int padl, hipStream_t s, int* status);
 bool tds_rsf_try(const float* x, const float* dy, float* dw, float* dbias, int B, int Tin, int Tout, int H, int C, int kw, int padl,
                  hipStream_t s, int* status);
 
@@ -911,6 +917,10 @@ static bool try_launch_fwd2(const TdsConvP& pIn0, hipStream_t s, int* status, in
 
 static int launch_fwd(const TdsConvP& p, hipStream_t s, int profKind = PROF_TDSCONV) {
   int st2 = W2L_OK;
+  // the one-channel first layer (conv_tds_c1.hpp)
+  if (p.Cin == 1 && !p.flip && !p.add && !p.accum && p.CinW == 1 && p.CoutW == p.Cout && p.tapStep == 1 && p.oStep == 1 &&
+      tds_c1_fwd_try(p.x, p.w, p.bias, p.y, p.B, p.Tin, p.Tout, p.H, p.Cout, p.kw, p.stride, p.padl, p.relu, profKind, s, &st2))
+    return st2;
   // block-Toeplitz generation (conv_tds_tz.hpp): the TDS convolutions proper and the strided layers between the stages
   if (p.CinW == (p.flip ? p.Cout : p.Cin) && p.CoutW == (p.flip ? p.Cin : p.Cout) &&
       tds_tz_try(p.x, p.w, p.bias, p.add, p.y, p.B, p.Tin, p.Tout, p.H, p.Cin, p.Cout, p.kw, p.stride, p.padl, p.relu, p.accum, p.flip,
@@ -990,6 +1000,14 @@ int tds_conv_backward_filter(const w2l_conv_desc* d, const float* x, const float
   if (d->stride == 1 && d->Cin == d->Cout) {  // the TDS convolutions proper: role-swapped 32x32x2 kernel (conv_tds_rs.hip)
     int st2 = W2L_OK;
     if (tds_rsf_try(x, dy, dw, dbias, d->B, d->T, To, d->H, d->Cin, d->kw, d->padl, s, &st2)) return st2;
+  }
+  if (d->Cin == 1) {  // the one-channel first layer (conv_tds_c1.hpp)
+    int st2 = W2L_OK;
+    if (tds_c1_filter_try(x, dy, dw, dbias, d->B, d->T, To, d->H, d->Cout, d->kw, d->stride, d->padl, s, &st2)) return st2;
+  }
+  {  // the strided layers between the TDS stages: block-Toeplitz filter gradient (conv_tds_tzf.hpp)
+    int st2 = W2L_OK;
+    if (tds_tzf_strided_try(x, dy, dw, dbias, d->B, d->T, To, d->H, d->Cin, d->Cout, d->kw, d->stride, d->padl, s, &st2)) return st2;
   }
   TdsConvP p = make_p(d->B, d->T, To, d->H, d->Cin, d->Cout, d->kw, d->stride, d->padl, kTdsBTF);
   p.x = x;

@@ -932,6 +932,7 @@ float* sk_scratch(hipStream_t s, size_t bytes);
 }  // namespace w2l
 #include "conv_tds_rsf3.hpp"
 #include "conv_tds_tzf.hpp"
+#include "conv_tds_c1.hpp"
 namespace w2l {
 
 template <int C, int GA, int GB, int HH, int TS>
@@ -961,11 +962,11 @@ static int rsf3_launch(const TdsRsfP& q, float* dw, float* dbias, hipStream_t s)
 }
 
 // block-Toeplitz filter gradient (conv_tds_tzf.hpp)
-template <int C, int R, int GR>
+template <int CI, int CO, int R, int GR, int SIG>
 static int tzf_launch(const TdsRsfP& q, float* dw, float* dbias, hipStream_t s) {
-  using Cfg = TzfCfg<C, R, GR>;
+  using Cfg = TzfCfg<CI, CO, R, GR, SIG>;
   if (q.H % Cfg::HB) return W2L_EUNSUPPORTED;
-  if ((long long)q.Tin * q.H * C * 4 >= (1ll << 31) || (long long)q.Tout * q.H * C * 4 >= (1ll << 31)) return W2L_EUNSUPPORTED;   // one utterance per buffer resource
+  if ((long long)q.Tin * q.H * CI * 4 >= (1ll << 31) || (long long)q.Tout * q.H * CO * 4 >= (1ll << 31)) return W2L_EUNSUPPORTED;   // one utterance per buffer resource
   TdsTzfP p{};
   p.x = q.x; p.dy = q.dy; p.B = q.B; p.Tin = q.Tin; p.Tout = q.Tout; p.H = q.H; p.kw = q.kw; p.padl = q.padl;
   p.hBlocks = q.H / Cfg::HB;
@@ -980,11 +981,11 @@ static int tzf_launch(const TdsRsfP& q, float* dw, float* dbias, hipStream_t s) 
   if (!partial || (size_t)blocks * Cfg::ACCF * sizeof(float) > kSkScratchBytes) return W2L_EUNSUPPORTED;
   static bool attr = false;
   if (!attr) {
-    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_tzf_k<C, R, GR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
+    W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_tzf_k<CI, CO, R, GR, SIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
     attr = true;
   }
-  hipLaunchKernelGGL((tds_conv_tzf_k<C, R, GR>), dim3((unsigned)blocks), dim3(512), Cfg::LDS, s, p, partial);
-  hipLaunchKernelGGL((tds_tzf_reduce_k<C, R, GR>), dim3((unsigned)((q.kw * C * C + C + 15) / 16)), dim3(1024), 0, s, partial, blocks, q.kw, dw, dbias);
+  hipLaunchKernelGGL((tds_conv_tzf_k<CI, CO, R, GR, SIG>), dim3((unsigned)blocks), dim3(512), Cfg::LDS, s, p, partial);
+  hipLaunchKernelGGL((tds_tzf_reduce_k<CI, CO, R, GR, SIG>), dim3((unsigned)((q.kw * CI * CO + CO + 15) / 16)), dim3(1024), 0, s, partial, blocks, q.kw, dw, dbias);
   return W2L_OK;
 }
 
@@ -1009,6 +1010,58 @@ static int rsf_launch(TdsRsfP p, float* dw, float* dbias, hipStream_t s) {
   return W2L_OK;
 }
 
+// the one-input-channel first layer of the TDS recipes (conv_tds_c1.hpp): forward, and filter + bias gradient
+bool tds_c1_fwd_try(const float* x, const float* w, const float* bias, float* y, int B, int Tin, int Tout, int H, int Cout, int kw, int stride,
+                    int padl, int relu, int profKind, hipStream_t s, int* status) {
+  if (tune_env("W2L_TDS_C1_OFF") || Cout != 10 || kw > 21 || kw < 1 || (((uintptr_t)y) & 7) != 0) return false;
+  TdsC1P p{};
+  p.x = x; p.w = w; p.bias = bias; p.y = y; p.B = B; p.Tin = Tin; p.Tout = Tout; p.H = H; p.kw = kw; p.stride = stride; p.padl = padl; p.relu = relu;
+  const long long total = (long long)B * Tout * H;
+  if (total <= 0 || total > (1ll << 31) - 512) return false;
+  prof_begin(s, 2.0 * B * Tout * (double)H * kw * Cout, profKind);
+  hipLaunchKernelGGL((tds_c1_fwd_k<10, 21>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+  prof_end(s);
+  *status = hipGetLastError() == hipSuccess ? W2L_OK : W2L_EHIP;
+  return true;
+}
+
+bool tds_c1_filter_try(const float* x, const float* dy, float* dw, float* dbias, int B, int Tin, int Tout, int H, int Cout, int kw, int stride,
+                       int padl, hipStream_t s, int* status) {
+  if (tune_env("W2L_TDS_C1_OFF") || Cout != 10 || kw > 21 || kw < 1) return false;
+  TdsC1P p{};
+  p.x = x; p.dy = dy; p.B = B; p.Tin = Tin; p.Tout = Tout; p.H = H; p.kw = kw; p.stride = stride; p.padl = padl;
+  const long long total = (long long)B * Tout * H;
+  if (total <= 0) return false;
+  long long blocks = (total + 127) / 128;
+  if (blocks > 512) blocks = 512;
+  constexpr int ROW = 21 * 10 + 10;
+  float* partial = sk_scratch(s, kSkScratchBytes);
+  if (!partial || (size_t)blocks * ROW * sizeof(float) > kSkScratchBytes) return false;
+  prof_begin(s, 2.0 * B * Tout * (double)H * kw * Cout, PROF_TDS_BWD_FILTER);
+  hipLaunchKernelGGL((tds_c1_filter_k<10, 21>), dim3((unsigned)blocks), dim3(256), 0, s, p, partial);
+  hipLaunchKernelGGL((tds_c1_filter_reduce_k<10, 21>), dim3((ROW + 31) / 32), dim3(1024), 0, s, partial, (int)blocks, kw, dw, dbias);
+  prof_end(s);
+  *status = hipGetLastError() == hipSuccess ? W2L_OK : W2L_EHIP;
+  return true;
+}
+
+// true + *status when the block-Toeplitz filter gradient runs a strided sub-sampling layer (10 -> 14, 14 -> 18, stride 2)
+bool tds_tzf_strided_try(const float* x, const float* dy, float* dw, float* dbias, int B, int Tin, int Tout, int H, int Cin, int Cout, int kw,
+                         int stride, int padl, hipStream_t s, int* status) {
+  if (tune_env("W2L_TDS_TZF_OFF") || tune_env("W2L_TDS_TZ_C2_OFF") || stride != 2 || kw > 21 || kw < 1 || H % 16) return false;
+  if (!((Cin == 10 && Cout == 14) || (Cin == 14 && Cout == 18))) return false;
+  if ((((uintptr_t)x | (uintptr_t)dy) & 15) != 0) return false;
+  TdsRsfP p{};
+  p.x = x; p.dy = dy; p.B = B; p.Tin = Tin; p.Tout = Tout; p.H = H; p.kw = kw; p.padl = padl;
+  prof_begin(s, 2.0 * B * Tout * (double)H * kw * Cin * Cout, PROF_TDS_BWD_FILTER);
+  int st = Cin == 10 ? tzf_launch<10, 14, 2, 12, 2>(p, dw, dbias, s) : tzf_launch<14, 18, 1, 12, 2>(p, dw, dbias, s);
+  prof_end(s);
+  if (st == W2L_EUNSUPPORTED) return false;
+  if (st == W2L_OK && hipGetLastError() != hipSuccess) st = W2L_EHIP;
+  *status = st;
+  return true;
+}
+
 // true + *status when this geometry runs on the role-swapped filter-gradient kernel
 bool tds_rsf_try(const float* x, const float* dy, float* dw, float* dbias, int B, int Tin, int Tout, int H, int C, int kw, int padl,
                  hipStream_t s, int* status) {
@@ -1021,7 +1074,7 @@ bool tds_rsf_try(const float* x, const float* dy, float* dw, float* dbias, int B
   p.x = x; p.dy = dy; p.B = B; p.Tin = Tin; p.Tout = Tout; p.H = H; p.kw = kw; p.padl = padl;
   prof_begin(s, 2.0 * B * Tout * (double)H * kw * C * C, PROF_TDS_BWD_FILTER);
   int st = W2L_EUNSUPPORTED;
-  if (tzf) st = C == 10 ? tzf_launch<10, 3, 16>(p, dw, dbias, s) : tzf_launch<14, 2, 12>(p, dw, dbias, s);
+  if (tzf) st = C == 10 ? tzf_launch<10, 10, 3, 16, 1>(p, dw, dbias, s) : tzf_launch<14, 14, 2, 12, 1>(p, dw, dbias, s);
   if (st != W2L_EUNSUPPORTED) {
   } else
   if (!tune_env("W2L_TDS_RSF3_OFF") && H % 8 == 0 && C != 14)   // wave-specialised generation (conv_tds_rsf3.hpp)
