@@ -191,6 +191,37 @@ def test_tds_ctc_config2_full_network_end_to_end(oracle):
     assert n_strict >= 2
 
 
+def test_tds_ctc_config2_teacher_forced_blocks_fp32(oracle):
+    """BASELINE config 2 at FULL DEPTH, block by block, at the strict fp32 bar (round-4 verdict item 6): the 21 TDS blocks of the
+    sota/2019 recipe network (C = 10 / 14 / 18, 80 mel rows, kw = 21, fc widths 2400 / 3360 / 4320) each run alone on the
+    oracle's activation and upstream gradient -- teacher_forced_tds_blocks_fp32.  The statistical full-depth bars of
+    test_tds_ctc_config2_full_network_end_to_end (cosine / relative L2) stay as the end-to-end plumbing check; THIS is the
+    per-tensor 1e-4 statement for the headline config: block outputs, and the eight parameter gradients of every block that
+    has no ReLU input on the other side of zero than the oracle (the others: counted, held downstream of their ReLUs and by
+    direction and size upstream)."""
+    import re
+    from wav2letter_amd import recipes
+    rng = np.random.default_rng(23)
+    nfeat, nlabel, B, T, L = 80, 9998, 2, 200, 5
+    arch = re.sub(r"(TDS \d+ \d+ \d+) [0-9.]+", r"\1 0.0", recipes.tds_ctc_arch())
+    arch = "\n".join(l for l in arch.splitlines() if not l.startswith("SAUG")) + "\n"
+    arch = re.sub(r"^DO [0-9.]+$", "DO 0.0", arch, flags=re.M)
+    ref = refnet.RefNet(arch, nfeat, nlabel)
+    params = ref.random_params(rng)
+    x = rng.normal(size=(B, 1, nfeat, T)).astype(np.float32)
+    tgt = np.full((B, L), -1, np.int32)
+    tgt[0, :5] = [17, 4021, 9996, 3, 3]
+    tgt[1, :2] = [9000, 12]
+    em_ref = ref.forward(x, params)
+    o = oracle.CTC(em_ref, tgt, scale_mode=4)
+    o.forward()
+    ref.upstream = []
+    ref_grads = ref.backward(o.backward().astype(np.float32), len(params))
+    n, kinked, worst = teacher_forced_tds_blocks_fp32(ref, arch, params, ref_grads)
+    print("config 2 fp32, %d teacher-forced TDS blocks: %d with a flipped ReLU input; worst strict error of the others %.2e" % (n, kinked, worst))
+    assert n == 21 and kinked <= 4
+
+
 @pytest.mark.parametrize("stages", [[(10, 1, 2400)], [(10, 1, 0), (14, 1, 0), (18, 1, 0)], [(18, 3, 4320)]])
 def test_tds_ctc_recipe_channel_counts_strict_gradients(oracle, stages):
     """the recipe's TDS geometry (80 mel rows, kw = 21, C = 10 / 14 / 18, the 3x fc width, strided C2 layers between the
@@ -426,6 +457,65 @@ def teacher_forced_tds_blocks(ref, arch, params, ref_grads):
                 worst = max(worst, err, e)
         del tr
     return len(blocks), worst
+
+
+def teacher_forced_tds_blocks_fp32(ref, arch, params, ref_grads):
+    """Every TDS block of the network ALONE in fp32, at the geometry and with the parameters it has in the network, fed the
+    oracle's own input activation and the oracle's own gradient at its output: output and every parameter gradient at the
+    STRICT bar (1e-4 of the largest reference magnitude; the two-element LayerNorm (gain, offset) pairs, sums of every
+    activation with heavy cancellation, 1e-3).  With the inputs forced nothing compounds from block to block; what can still
+    differ is the sign of a ReLU input that lies within fp32 rounding of zero (the block has two ReLUs, 0.2 - 3.8 M inputs each).
+    Every block keeps the strict bar on its output (ReLU is continuous) and on the gradients downstream of both ReLUs (lin2,
+    ln2); a block whose other gradients all meet the strict bar too is counted as clean, one where any does not is counted
+    as carrying a flipped ReLU input and held by direction and size (relative L2 < 10 %).  Returns (blocks, blocks with a
+    flipped ReLU input, worst strict error of the clean ones)."""
+    lines = [l.split() for l in arch.splitlines() if l.startswith("TDS")]
+    blocks = [(rec, da) for rec, da in reversed(ref.upstream) if rec[0] == "TDS"]     # network order
+    assert len(blocks) == len(lines) > 0
+    from wav2letter_amd.trainer import Trainer
+    worst, kinked = 0.0, 0
+    for (rec, da), tok in zip(blocks, lines):
+        _, p, saved, pl, pr, mode, pi = rec
+        xin = np.ascontiguousarray(saved["x"], dtype=np.float32)                        # [B][c][h][T]
+        B, c, h, T = xin.shape
+        assert (c, h) == (int(tok[1]), int(tok[3]))
+        l = c * h
+        out = refnet.tds_fwd(xin, p, pl, pr, mode)
+        one = ("V -1 %d %d 0\nRO 0 2 1 3\n%s\nRO 2 1 0 3\nV %d -1 1 0\nV %d 0 -1 1\n" % (c, h, " ".join(tok[:4] + ["0.0"] + tok[5:]), l, l))
+        tr = Trainer(one, l, l, "ctc", 4, 0.0)
+        table = tr.param_table()
+        assert len(table) == 8
+        for i, q in enumerate(params[pi - 8:pi]):
+            tr.import_param(i, q)
+        tr.plan(B, T, 1)
+        tr.to_device()
+        to_em = lambda a: np.ascontiguousarray(a.transpose(0, 3, 2, 1)).reshape(B, T, l)   # [B][c][h][T] -> [B][T][h * C + c]
+        feed = np.ascontiguousarray(xin.transpose(0, 2, 1, 3)).reshape(B, l, T)            # [B][h * C + c][T]
+        em = tr.forward(torch.tensor(feed).cuda(), train=True).cpu().numpy()
+        e = rel(em, to_em(out))
+        assert e < TOL, (pi, tok, "output", e)
+        worst = max(worst, e)
+        tr.backward(torch.tensor(to_em(np.asarray(da, np.float32))).cuda())
+        g = tr.grads.cpu().numpy()
+        errs = {}
+        for i in range(8):
+            want = np.asarray(ref_grads[pi - 8 + i], np.float64).reshape(-1)
+            got = np.asarray(tr.export_from(i, g), np.float64).reshape(-1)
+            errs[table[i][0]] = (rel(got, want), want.size, np.linalg.norm(got - want) / max(1e-30, np.linalg.norm(want)))
+        bar = lambda size: TOL if size > 2 else 1e-3
+        # downstream of both ReLUs: always strict
+        for name in ("tds.lin2.w", "tds.lin2.b", "tds.ln2.weight+bias"):
+            assert errs[name][0] < bar(errs[name][1]), (pi, tok, name, errs[name])
+        flipped = any(v[0] >= bar(v[1]) for v in errs.values())
+        kinked += flipped
+        for name, (err, size, l2) in errs.items():
+            if not flipped:
+                if size > 2:
+                    worst = max(worst, err)
+            elif size > 2:
+                assert l2 < 0.1, (pi, tok, name, l2)      # a flipped ReLU input: direction and size
+        del tr
+    return len(blocks), kinked, worst
 
 
 def teacher_forced_tr_blocks(ref, arch, params, ref_grads):
