@@ -16,8 +16,10 @@ HB = 16
 def cfg(CI, CO, R, NCT, SIG=1, KWM=21, ST=1):
     S = SIG * (R - 1) + KWM
     C2 = CI // 2
-    SP = S // 2
-    TAIL = S % 2
+    SSPLIT = 1 if (NCT == 2 and R == 3) else 0
+    SW = S - SIG * SSPLIT
+    SP = SW // 2
+    TAIL = SW % 2
     TR = (C2 + 1) // 2 if TAIL else 0
     NRD = SP * C2 + TR
     RT = 4 // NCT
@@ -29,7 +31,7 @@ def cfg(CI, CO, R, NCT, SIG=1, KWM=21, ST=1):
         p += 4
     if 4 * ((NF * p * 4 + 64 + 1023) // 1024 * 1024) > 160 * 1024:
         p = HB * CI
-    return dict(CI=CI, CO=CO, R=R, NCT=NCT, SIG=SIG, KWM=KWM, ST=ST, S=S, C2=C2, SP=SP, TR=TR, NRD=NRD, NK=2 * NRD, RT=RT, GR=GR, RF=GR * R,
+    return dict(CI=CI, CO=CO, R=R, NCT=NCT, SIG=SIG, KWM=KWM, ST=ST, S=S, SW=SW, SSPLIT=SSPLIT, C2=C2, SP=SP, TR=TR, NRD=NRD, NK=2 * NRD, RT=RT, GR=GR, RF=GR * R,
                 GSTEP=GSTEP, NF=NF, PITCH=p, NQF=S + SIG * (R - 1), NQB=ST * (S + R - 1))
 
 
@@ -57,8 +59,8 @@ def launch(x, w, bias, kw, padl, y, g, flip=False, relu=False, add=None, Tout=No
     read as w[tapOff + ST (kw - 1 - tap)][co][ci]); writes frames oOff + oStep u (u < Tout) of y [B][ToutFull][H][CO] (NaN =
     never written)."""
     B, Tin, H, CI = x.shape
-    CO, R, NCT, SIG, ST, S, C2, SP, TR, NRD, RT, RF, GSTEP, NF, PITCH = (g[k] for k in (
-        "CO", "R", "NCT", "SIG", "ST", "S", "C2", "SP", "TR", "NRD", "RT", "RF", "GSTEP", "NF", "PITCH"))
+    CO, R, NCT, SIG, ST, S, SW, SSPLIT, C2, SP, TR, NRD, RT, RF, GSTEP, NF, PITCH = (g[k] for k in (
+        "CO", "R", "NCT", "SIG", "ST", "S", "SW", "SSPLIT", "C2", "SP", "TR", "NRD", "RT", "RF", "GSTEP", "NF", "PITCH"))
     assert CI == g["CI"] and H % HB == 0 and kw <= g["KWM"] and y.shape[3] == CO
     ToutFull = y.shape[1]
     yflat = y.reshape(B, -1)
@@ -94,31 +96,32 @@ def launch(x, w, bias, kw, padl, y, g, flip=False, relu=False, add=None, Tout=No
                     rt, ct = (wave, 0) if NCT == 1 else (wave >> 1, wave & 1)
                     nn = 32 * ct + n
                     colOk = nn < R * CO
-                    rr = np.where(colOk, nn // CO, 0)
+                    s0 = SIG * ct if SSPLIT else 0
+                    rr = np.where(colOk, nn // CO, ct if SSPLIT else 0)
                     co = np.where(colOk, nn % CO, 0)
                     # ---- B registers: gathers out of the LDS copy at one base + immediates
                     bw = np.zeros((2 * NRD, 64))
                     if not flip:
-                        bm = (hf - SIG * rr + P) * CC + co
+                        bm = (s0 + hf - SIG * rr + P) * CC + co
                         assert (bm >= 0).all()
                         for sp in range(SP):
                             for u in range(CI):
                                 bw[2 * sp * C2 + u] = wl[bm + 2 * sp * CC + u * CO]
                         if TR:
-                            bt = (S - 1 - SIG * rr + P) * CC + 2 * hf * TR * CO + co
+                            bt = (s0 + SW - 1 - SIG * rr + P) * CC + 2 * hf * TR * CO + co
                             for u in range(2 * TR):
                                 t = wl[bt + u * CO]
                                 if 2 * TR + u >= CI:
                                     t = np.where(hf == 1, 0.0, t)
                                 bw[2 * SP * C2 + u] = t
                     else:
-                        bm = (tapOff + ST * (kw - 1 - hf + rr) + P - 2 * ST * (SP - 1)) * CC + co * CI
+                        bm = (tapOff + ST * (kw - 1 - hf - s0 + rr) + P - 2 * ST * (SP - 1)) * CC + co * CI
                         assert (bm >= 0).all()
                         for sp in range(SP):
                             for u in range(CI):
                                 bw[2 * sp * C2 + u] = wl[bm + 2 * ST * (SP - 1 - sp) * CC + u]
                         if TR:
-                            bt = (tapOff + ST * (kw - S + rr) + P) * CC + co * CI + 2 * hf * TR
+                            bt = (tapOff + ST * (kw - s0 - SW + rr) + P) * CC + co * CI + 2 * hf * TR
                             assert (bt >= 0).all()
                             for u in range(2 * TR):
                                 t = wl[bt + u]
@@ -126,8 +129,8 @@ def launch(x, w, bias, kw, padl, y, g, flip=False, relu=False, add=None, Tout=No
                                     t = np.where(hf == 1, 0.0, t)
                                 bw[2 * SP * C2 + u] = t
                     rowOff = (GSTEP * (n >> 4) + 2 * GSTEP * rt) * PITCH + (n & 15) * CI
-                    aMain = rowOff + hf * PITCH
-                    aTail = rowOff + hf * TR * 2
+                    aMain = rowOff + (s0 + hf) * PITCH
+                    aTail = rowOff + s0 * PITCH + hf * TR * 2
                     yLane = np.where(colOk, (rr + 2 * R * rt) * oStep * HCO + 4 * hf * CO + co, -(1 << 40))
                     g0 = yLane + (k * RF * oStep + oOff) * HCO + hb * HB * CO
                     acc = np.zeros((16, 64))
@@ -142,7 +145,7 @@ def launch(x, w, bias, kw, padl, y, g, flip=False, relu=False, add=None, Tout=No
                             sp, cp = divmod(d, C2)
                             addr = aMain + 2 * sp * PITCH + 2 * cp
                         else:
-                            addr = aTail + (S - 1) * PITCH + 2 * (d - SP * C2)
+                            addr = aTail + (SW - 1) * PITCH + 2 * (d - SP * C2)
                         acc = mfma_32x32x2(slab[addr], bw[2 * d], acc)
                         acc = mfma_32x32x2(slab[addr + 1], bw[2 * d + 1], acc)
                     acc = np.where(colOk, acc, 0.0)            # (the padding columns: something nobody stores)

@@ -615,7 +615,7 @@ static int tz_launch(TdsTzP p, int abl, hipStream_t s) {
   const int wgs = p.nRounds < wgMax ? p.nRounds : wgMax;
   p.rpw = (p.nRounds + wgs - 1) / wgs;
   const int blocks = (p.nRounds + p.rpw - 1) / p.rpw;
-  constexpr bool DEFER = NCT == 1;   // C = 18: no registers for a second accumulator set (and the longest chain)
+  constexpr bool DEFER = true;       // (C = 18 has the registers for the second accumulator set since its waves walk their own 22-frame windows)
   constexpr int M0 = FWD ? 0 : 2;    // the two modes of the direction: plain / + ReLU, plain / + addend
 #ifdef W2L_PROBE
   if (abl && FWD) {

@@ -67,8 +67,13 @@ struct TzCfg {
   static constexpr int HB = 16;                      // mel rows of a strip
   static constexpr int S = SIG * (R - 1) + KW;       // input frames one output group reaches
   static constexpr int C2 = CI / 2;                  // channel pairs
-  static constexpr int SP = S / 2;                   // frame pairs (s, s + 1): lane half hf reads frame 2 sp + hf
-  static constexpr int TAIL = S % 2;                 // S odd: the last frame's channel pairs are split between the halves
+  // Two column tiles of R = 3 output frames (C = 18: 54 columns): tile ct holds the frames r = ct, ct + 1 only, so its
+  // Toeplitz rows are zero outside the window s in [SIG ct, SIG ct + SW), SW = S - SIG: each wave of the pair walks ITS
+  // window (198 MFMAs instead of 208 at C = 18, an even window: no split tail, ten weight registers less)
+  static constexpr int SSPLIT = (NCT == 2 && R == 3) ? 1 : 0;
+  static constexpr int SW = S - SIG * SSPLIT;        // frames a wave's chain walks
+  static constexpr int SP = SW / 2;                  // frame pairs (s, s + 1): lane half hf reads frame s0 + 2 sp + hf
+  static constexpr int TAIL = SW % 2;                // SW odd: the last frame's channel pairs are split between the halves
   static constexpr int TR = TAIL ? (C2 + 1) / 2 : 0; // ... TR reads: half 0 pairs [0, TR), half 1 pairs [TR, 2 TR) (the last one may be padding)
   static constexpr int NRD = SP * C2 + TR;           // ds_read_b64 per chain
   static constexpr int NK = 2 * NRD;                 // MFMAs per chain
@@ -95,7 +100,7 @@ struct TzCfg {
   static_assert(CI % 2 == 0 && (HB * CI) % 4 == 0 && (CI * CO) % 4 == 0, "channel pairs, 16-byte chunks");
   static_assert(R * CO <= 32 * NCT, "columns");
   static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
-  static_assert((2 * (SP - 1) + 1) * PITCH * 4 + CI * 4 < 65536 && (S - 1) * PITCH * 4 + 2 * TR * 8 < 65536, "ds offset field");
+  static_assert((2 * (SP - 1) + 1) * PITCH * 4 + CI * 4 < 65536 && (SW - 1) * PITCH * 4 + 2 * TR * 8 < 65536, "ds offset field");
 };
 
 // MODE: 0 forward, 1 forward + ReLU, 2 backward-data (tap-flipped transposed weights), 3 backward-data + residual addend.
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
   using Cfg = TzCfg<CI, CO, R, NCT, SIG, KWM, ST>;
   constexpr bool FLIP = MODE >= 2, ADD = MODE == 3, RELU = MODE == 1;
   constexpr int HB = Cfg::HB, S = Cfg::S, C2 = Cfg::C2, SP = Cfg::SP, TR = Cfg::TR, NRD = Cfg::NRD, NK = Cfg::NK, RF = Cfg::RF,
-                NF = Cfg::NF, PITCH = Cfg::PITCH, CPF = Cfg::CPF, PARTS = Cfg::PARTS, BUFB = Cfg::BUFB, GSTEP = Cfg::GSTEP;
+                NF = Cfg::NF, PITCH = Cfg::PITCH, CPF = Cfg::CPF, PARTS = Cfg::PARTS, BUFB = Cfg::BUFB, GSTEP = Cfg::GSTEP, SW = Cfg::SW;
   static_assert(!FLIP || SIG == 1, "a backward-data phase is a stride-1 correlation");
   static_assert(NF % 4 == 0, "every wave stages the same number of frames");
   constexpr int NDMA = NF / 4 * PARTS;                 // LDS-DMA instructions per wave and round
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
 
   // The weights as they lie in HBM, [tap][ci][co], with P zero taps in front and zeros behind (NQ taps in all), copied once
   // per workgroup by LDS-DMA (the range check of the descriptor IS the zero padding); every lane then gathers the block-
-  // Toeplitz column it owns -- step 2 (sp C2 + cp) + e is k = (s = 2 sp + hf, ci = 2 cp + e), the tail steps are (s = S - 1,
+  // Toeplitz column it owns -- step 2 (sp C2 + cp) + e is k = (s = 2 sp + hf, ci = 2 cp + e), the tail steps are (s = s0 + SW - 1,
   // ci = 2 (q + hf TR) + e) -- with ds_read_b32 at immediate offsets of ONE address.  (First version: one global gather per
   // register: 116-208 divergent loads per wave at ~32 TCP cycles each = 14-22 us before the first MFMA;
   // profiles/r05_run3_conv_tz_independent_weight_loads.log.)
@@ -220,7 +225,9 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
   }
   const int nn = 32 * ct + n;
   const bool colOk = nn < R * CO;
-  const int rr = colOk ? nn / CO : 0, co = colOk ? nn - (nn / CO) * CO : 0;   // (the padding columns compute something finite nobody stores)
+  const int s0 = Cfg::SSPLIT ? SIG * ct : 0;         // first frame of this wave's window
+  // (the padding columns compute something finite nobody stores: any output frame of the tile)
+  const int rr = colOk ? nn / CO : (Cfg::SSPLIT ? ct : 0), co = colOk ? nn - (nn / CO) * CO : 0;
   float biasv = 0.f;
   if (p.bias && colOk) biasv = p.bias[co];
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -229,13 +236,13 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
     const lfptr_t wl = (lfptr_t)(ldsb + BUFB);
     if (!FLIP) {
       // w[tap][ci][co]: tap (2 sp + hf) - SIG rr is LDS tap (hf - SIG rr + P) + 2 sp
-      const lfptr_t bm = wl + (hf - SIG * rr + P) * CC + co;
+      const lfptr_t bm = wl + (s0 + hf - SIG * rr + P) * CC + co;
 #pragma unroll
       for (int sp = 0; sp < SP; ++sp)
 #pragma unroll
         for (int u = 0; u < CI; ++u) bw[2 * sp * C2 + u] = bm[2 * sp * CC + u * CO];
       if (TR > 0) {
-        const lfptr_t bt = wl + (S - 1 - SIG * rr + P) * CC + 2 * hf * TR * CO + co;
+        const lfptr_t bt = wl + (s0 + SW - 1 - SIG * rr + P) * CC + 2 * hf * TR * CO + co;
 #pragma unroll
         for (int u = 0; u < 2 * TR; ++u) {
           float t = bt[u * CO];
@@ -246,13 +253,13 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
     } else {
       // w'[tap][ci][co] = w[tapOff + ST (kw - 1 - tap)][co][ci]: tap 2 sp + hf - rr is LDS tap
       // tapOff + ST (kw - 1 - hf + rr) + P - 2 ST sp
-      const lfptr_t bm = wl + (p.tapOff + ST * (p.kw - 1 - hf + rr) + P - 2 * ST * (SP - 1)) * CC + co * CI;
+      const lfptr_t bm = wl + (p.tapOff + ST * (p.kw - 1 - hf - s0 + rr) + P - 2 * ST * (SP - 1)) * CC + co * CI;
 #pragma unroll
       for (int sp = 0; sp < SP; ++sp)
 #pragma unroll
         for (int u = 0; u < CI; ++u) bw[2 * sp * C2 + u] = bm[2 * ST * (SP - 1 - sp) * CC + u];
       if (TR > 0) {
-        const lfptr_t bt = wl + (p.tapOff + ST * (p.kw - S + rr) + P) * CC + co * CI + 2 * hf * TR;
+        const lfptr_t bt = wl + (p.tapOff + ST * (p.kw - s0 - SW + rr) + P) * CC + co * CI + 2 * hf * TR;
 #pragma unroll
         for (int u = 0; u < 2 * TR; ++u) {
           float t = bt[u];
@@ -265,8 +272,8 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
 
   // ---- per-lane addresses.  Row n of the tile = (group n >> 4, mel row n & 15) of the wave's two groups.
   const int rowOff = (GSTEP * (n >> 4) + 2 * GSTEP * rt) * PITCH + (n & 15) * CI;              // dwords into the slab
-  const lcptr_t aMain = (lcptr_t)ldsb + (rowOff + hf * PITCH) * 4;   // half hf reads frame 2 sp + hf
-  const lcptr_t aTail = (lcptr_t)ldsb + rowOff * 4 + hf * TR * 8;      // ... and the channel pairs [hf TR, hf TR + TR) of the last frame
+  const lcptr_t aMain = (lcptr_t)ldsb + (rowOff + (s0 + hf) * PITCH) * 4;   // half hf reads frame s0 + 2 sp + hf
+  const lcptr_t aTail = (lcptr_t)ldsb + (rowOff + s0 * PITCH) * 4 + hf * TR * 8;   // ... and the channel pairs [hf TR, hf TR + TR) of the last frame
   // accumulator v of this lane: row 8 (v >> 2) + 4 hf + (v & 3) -> group v >> 3, mel row 8 ((v >> 2) & 1) + 4 hf + (v & 3);
   // column (rr, co) -> output frame t0 + R (2 rt + group) + rr
   // (output frame u of the launch is frame oOff + oStep u of the tensor)
@@ -297,10 +304,13 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
   f32x16 accPrev;                 // DEFER: the finished tile of the previous round
   int yPrev[2] = {(int)0x80000000, (int)0x80000000};
   int bPrev = 0;
-  f32x16 addNext;                 // DEFER && ADD: the residual addend of the next round's tile
+  // the residual addend of the NEXT round's tile is fetched under the chain where there are registers for a third
+  // accumulator set (one column tile); with two column tiles (C = 18) it is loaded at the start of its own chain
+  constexpr bool PFA = DEFER && ADD && NCT == 1;
+  f32x16 addNext;                 // PFA: the residual addend of the next round's tile
 #pragma unroll
   for (int v = 0; v < 16; ++v) { accPrev[v] = 0.f; addNext[v] = 0.f; }
-  if (DEFER && ADD && !(ABL & 4)) {
+  if (PFA && !(ABL & 4)) {
     int g[2];
     y_offsets(here, g);
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.add + (size_t)here.b * p.ToutFull * HCO), 0, yBytes, 0x00020000);
@@ -322,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
     const __amdgpu_buffer_rsrc_t ryP = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (size_t)bPrev * p.ToutFull * HCO), 0, it > 0 ? yBytes : 0, 0x00020000);
     // DEFER && ADD: the addend of the NEXT round's tile is fetched under this chain
     int yNext[2] = {0, 0};
-    if (DEFER && ADD) y_offsets(nx, yNext);
+    if (PFA) y_offsets(nx, yNext);
     const __amdgpu_buffer_rsrc_t raN = __builtin_amdgcn_make_buffer_rsrc((void*)(p.add + (size_t)nx.b * p.ToutFull * HCO), 0, more ? yBytes : 0, 0x00020000);
     here = nx;
     advance(nx);
@@ -332,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[v] = 0.f;
     if (ADD && !(ABL & 4)) {
-      if (DEFER) {
+      if (PFA) {
         acc = addNext;
       } else {
         const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.add + (size_t)b * p.ToutFull * HCO), 0, yBytes, 0x00020000);
@@ -359,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
           const int sp = d / C2, cp = d - sp * C2;
           return *(lfrag_t)(am + (2 * sp * PITCH + 2 * cp) * 4);
         }
-        return *(lfrag_t)(at + ((S - 1) * PITCH + 2 * (d - SP * C2)) * 4);
+        return *(lfrag_t)(at + ((SW - 1) * PITCH + 2 * (d - SP * C2)) * 4);
       };
 #pragma unroll
       for (int d = 0; d < D; ++d) ring[d % RING] = rdfrag(d);
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
         } else if (!(ABL & 1)) {
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[d % RING].y, bw[2 * d + 1], acc, 0, 0, 0);
         }
-        if (DEFER && ADD && d % 2 == 1 && d / 2 < 16 && !(ABL & 4)) {
+        if (PFA && d % 2 == 1 && d / 2 < 16 && !(ABL & 4)) {
           const int v = d / 2;
           addNext[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(raN, yNext[v >> 3] + vOff(v), 0, 0));
         }
