@@ -76,6 +76,10 @@ inline LexiconMap loadWordsFromLines(const std::vector<std::string>& lines, int 
     std::vector<std::string> sp;
     while (ss >> tok) sp.push_back(tok);
     if (sp.empty()) continue;
+    // [UNVENDORED] fl::lib::text::loadWords is not in /root/reference: the limit is applied as "at most maxWords distinct
+    // words; reading stops at the first NEW word beyond it", so further spellings of already-kept words that precede that
+    // word in the file are kept.  If upstream breaks right after the insertion that reaches the limit, those spellings are
+    // the one difference (recipes sort the lexicon by word, where the two rules coincide).
     if (lex.find(word) == lex.end() && maxWords >= 0 && (int)lex.size() >= maxWords) break;
     lex[word].push_back(sp);
   }

@@ -214,6 +214,8 @@ static bool li_sink_ok(const w2l_bf16_image_sink* s, int groups, size_t inner) {
 template <bool BWD>
 static int li_launch(LiP p, hipStream_t s) {
   { const char* e = tune_env("W2L_LI_ABL"); p.abl = e ? atoi(e) : 0; }
+  // (69 - 74 KB of LDS at the TDS widths: this library is gfx950-only -- 160 KB per CU, csrc/Makefile builds no other
+  // target -- so the opt-in below cannot fail for want of LDS; a port to a 64 KB part would cap kLiMaxInner at 2040)
   const size_t shmem = (size_t)kLiRows * (p.inner + 8) * 2;
   static const bool attr =
       hipFuncSetAttribute((const void*)ln_rows_images_k<BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLiRows * (kLiMaxInner + 8) * 2)) == hipSuccess;
