@@ -26,15 +26,24 @@
  * The network built from an arch file is ONE planned pipeline (static layer list, activations in one arena, the
  * parameters / gradients in flat arenas: w2l_host.hpp); fl::Sequential::modules() lists its lines for prettyString
  * and parameter bookkeeping, the forward / backward run as a whole.  A plugin module (createModule) composes such
- * pipelines; a free-form layer zoo with per-op autograd is outside the hot path and is not provided.
+ * pipelines -- from arch text, or (round 5) from LAYER OBJECTS the way the reference's plugins are written:
+ * fl::View / Reorder / Dropout / ReLU / GatedLinearUnit / LayerNorm / Linear / Conv2D / Pool2D / Transformer / TDSBlock /
+ * WeightNorm, constructed with the reference's arguments and add()ed to an fl::Sequential, are their lines of the arch
+ * grammar, and the Sequential plans one pipeline out of them on first use (tests/cpp/plugin_layers.cpp).  What is NOT
+ * provided is per-layer execution (`modules()[i]->forward(x)`, a custom forward() that interleaves af:: arithmetic, as
+ * recipes/slimIPL/100h_supervised.cpp:44-66 does for its padding mask): a free-form per-op autograd is outside the hot
+ * path; the padding mask that forward builds is what the planned pipeline's Transformer blocks derive from inputSizes.
  */
 #pragma once
 #include <stdint.h>
+#include <cstdio>
+#include <initializer_list>
 
 #include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -147,7 +156,7 @@ inline Variable param(const af::array& a) { return Variable(a, true); }
 class FL_COMPAT_API Module {
  public:
   virtual ~Module() {}
-  std::vector<Variable> params() const { return params_; }
+  virtual std::vector<Variable> params() const { return params_; }   // (virtual: a Sequential of layer objects plans itself on first use)
   Variable param(int i) const { return params_.at(i); }
   virtual void setParams(const Variable& var, int position);
   virtual void train() { train_ = true; }
@@ -177,12 +186,110 @@ class FL_COMPAT_API Container : public Module {
   std::vector<int> childOfParam_, childIndexOfParam_;
 };
 
-// user-composed chain: output of module i feeds module i + 1
+// A layer AS AN OBJECT, the way a reference model plugin builds its network (recipes/slimIPL/100h_supervised.cpp:24-43:
+// `convFrontend_->add(std::make_shared<fl::Conv2D>(nFeature, 1536, 7, 1, 3, 1, -1, 0, 1, 1))`, `fl::View`, `fl::LayerNorm`,
+// `fl::GatedLinearUnit`, `fl::Dropout`, `fl::Reorder`, `fl::Transformer`, `fl::Linear`).  Here a layer object IS its line of the
+// arch grammar (cpc/SequentialBuilder.cpp:92-626, the same constructor arguments in the same order): add()ed to an
+// fl::Sequential it appends that line, and the Sequential plans ONE pipeline out of its lines on first use (params() /
+// forward()), exactly as buildSequentialModule does for an arch file.  A layer object cannot run on its own: forward() on it
+// throws -- per-layer execution with a free-form autograd is outside the hot path (see the header comment).
+class FL_COMPAT_API ArchLayer : public Module {
+ public:
+  explicit ArchLayer(std::string line) : line_(std::move(line)) {}
+  const std::string& archLine() const { return line_; }
+  std::vector<Variable> forward(const std::vector<Variable>&) override {
+    throw std::logic_error("fl_compat: a layer object runs as part of the fl::Sequential it was added to (one planned pipeline): " + line_);
+  }
+  std::string prettyString() const override { return line_; }
+
+ protected:
+  static std::string join(const char* tok, std::initializer_list<double> v) {
+    std::string s(tok);
+    for (double x : v) {
+      char b[40];
+      if (x == (double)(long long)x) snprintf(b, sizeof b, " %lld", (long long)x); else snprintf(b, sizeof b, " %.9g", x);
+      s += b;
+    }
+    return s;
+  }
+  std::string line_;
+};
+class View : public ArchLayer { public: explicit View(const af::dim4& d) : ArchLayer(join("V", {(double)d[0], (double)d[1], (double)d[2], (double)d[3]})) {} };
+class Reorder : public ArchLayer { public: Reorder(int d0, int d1, int d2, int d3) : ArchLayer(join("RO", {(double)d0, (double)d1, (double)d2, (double)d3})) {} };
+class Dropout : public ArchLayer { public: explicit Dropout(double p = 0.5) : ArchLayer(join("DO", {p})) {} };
+class ReLU : public ArchLayer { public: ReLU() : ArchLayer("R") {} };
+class GatedLinearUnit : public ArchLayer { public: explicit GatedLinearUnit(int dim) : ArchLayer(join("GLU", {(double)dim})) {} };
+class LayerNorm : public ArchLayer {
+ public:
+  explicit LayerNorm(const std::vector<int>& axes) : ArchLayer(lineOf(axes)) {}
+ private:
+  static std::string lineOf(const std::vector<int>& axes) { std::string s("LN"); for (int a : axes) s += " " + std::to_string(a); return s; }
+};
+class Linear : public ArchLayer {
+ public:
+  Linear(int in, int out, bool bias = true) : ArchLayer(join("L", {(double)in, (double)out})) {
+    if (!bias) throw std::invalid_argument("fl_compat: fl::Linear without bias is not in the arch grammar");
+  }
+};
+// fl::Conv2D(nIn, nOut, wx, wy, sx, sy, px, py, dx, dy, bias, groups): wx along time (ArrayFire dim 0); px / py = -1 is PaddingMode::SAME
+class Conv2D : public ArchLayer {
+ public:
+  Conv2D(int nIn, int nOut, int wx, int wy, int sx = 1, int sy = 1, int px = 0, int py = 0, int dx = 1, int dy = 1, bool bias = true, int groups = 1)
+      : ArchLayer(dx == 1 && dy == 1 ? join("C2", {(double)nIn, (double)nOut, (double)wx, (double)wy, (double)sx, (double)sy, (double)px, (double)py})
+                                     : join("C2", {(double)nIn, (double)nOut, (double)wx, (double)wy, (double)sx, (double)sy, (double)px, (double)py, (double)dx, (double)dy})) {
+    if (!bias || groups != 1) throw std::invalid_argument("fl_compat: fl::Conv2D without bias / with groups is not in the arch grammar");
+  }
+};
+enum class PoolingMode { MAX = 0 };
+class Pool2D : public ArchLayer {
+ public:
+  Pool2D(int wx, int wy, int sx = 1, int sy = 1, int px = 0, int py = 0, PoolingMode mode = PoolingMode::MAX)
+      : ArchLayer(px == 0 && py == 0 ? join("M", {(double)wx, (double)wy, (double)sx, (double)sy}) : join("M", {(double)wx, (double)wy, (double)sx, (double)sy, (double)px, (double)py})) { (void)mode; }
+};
+// fl::Transformer(modelDim, headDim, mlpDim, nHeads, bptt, pDropout, pLayerdrop, useMask, preLN)
+class Transformer : public ArchLayer {
+ public:
+  Transformer(int modelDim, int headDim, int mlpDim, int nHeads, int bptt, float pDropout, float pLayerdrop, bool useMask = false, bool preLN = false)
+      : ArchLayer(join("TR", {(double)modelDim, (double)mlpDim, (double)nHeads, (double)bptt, (double)pDropout, (double)pLayerdrop})) {
+    if (headDim * nHeads != modelDim || useMask || preLN)
+      throw std::invalid_argument("fl_compat: fl::Transformer with headDim * nHeads != modelDim, a causal mask or pre-LN is not in the arch grammar");
+  }
+};
+// fl::TDSBlock(channels, kernelSize, width, dropout, innerLinearDim)
+class TDSBlock : public ArchLayer {
+ public:
+  TDSBlock(int c, int kw, int h, double dropout = 0, int innerLinearDim = 0)
+      : ArchLayer(innerLinearDim ? join("TDS", {(double)c, (double)kw, (double)h, dropout, (double)innerLinearDim}) : join("TDS", {(double)c, (double)kw, (double)h, dropout})) {}
+};
+// fl::WeightNorm(module, dim)
+class WeightNorm : public ArchLayer {
+ public:
+  WeightNorm(const std::shared_ptr<ArchLayer>& child, int dim) : ArchLayer("WN " + std::to_string(dim) + " " + child->archLine()) {}
+  WeightNorm(const ArchLayer& child, int dim) : ArchLayer("WN " + std::to_string(dim) + " " + child.archLine()) {}
+};
+
+// user-composed chain: output of module i feeds module i + 1.  With layer objects (above) the chain is one planned pipeline:
+// the lines of the layers added so far, planned on first use; layer objects and other modules do not mix in one Sequential.
 class FL_COMPAT_API Sequential : public Container {
  public:
+  void add(std::shared_ptr<Module> m);                        // (hides Container::add: a layer object contributes its arch line)
+  template <class T, class = typename std::enable_if<std::is_base_of<Module, T>::value>::type>
+  void add(const T& layer) { add(std::static_pointer_cast<Module>(std::make_shared<T>(layer))); }   // fl's add(const T&)
+  std::vector<Variable> params() const override;
+  void setParams(const Variable& var, int position) override;
+  void train() override;
+  void eval() override;
   std::vector<Variable> forward(const std::vector<Variable>& inputs) override;
   Variable forward(const Variable& in) { return forward(std::vector<Variable>{in}).front(); }
   std::string prettyString() const override;
+  std::shared_ptr<Sequential> planned() const;                // the pipeline behind a Sequential of layer objects (null otherwise)
+  void setInputFeatures(int nFeat) { inputFeatures_ = nFeat; } // fl_compat extension: NFEAT of the (T, NFEAT, 1, B) input when the first layer does not say it
+
+ private:
+  void materialize();
+  std::string archText_;                                      // lines of the layer objects added so far
+  std::shared_ptr<Sequential> planned_;
+  int inputFeatures_ = 0;
 };
 
 // fl::SpecAugment as the Trainer instantiates it from --saug_start_update (recipes/slimIPL/src/Train.cpp:1026-1048, applied

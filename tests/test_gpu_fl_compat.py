@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "tests", "cpp", "fl_compat_test")
 PLUGIN = os.path.join(ROOT, "tests", "cpp", "libplugin_model.so")
+PLUGIN_LAYERS = os.path.join(ROOT, "tests", "cpp", "libplugin_layers.so")
 TOL = 1e-4
 
 
@@ -77,9 +78,11 @@ def test_criteria_through_compiled_cpp(oracle, tmp_path, kind, mode, B, T, N, L)
     assert np.abs(dem - odx).max() < TOL * np.abs(odx).max()
 
 
-@pytest.mark.parametrize("via", ["arch", "plugin"])
+@pytest.mark.parametrize("via", ["arch", "plugin", "layers"])
 def test_training_step_through_fl_surface_equals_trainer(tmp_path, via):
-    """network from an arch FILE (buildSequentialModule) or from a dlopen'ed createModule plugin, CTCLoss, zeroGrad,
+    """network from an arch FILE (buildSequentialModule), from a dlopen'ed createModule plugin that assembles arch text, or from
+    one that builds it out of LAYER OBJECTS (`encoder->add(std::make_shared<fl::Conv2D>(...))`, tests/cpp/plugin_layers.cpp, the
+    style of recipes/slimIPL/100h_supervised.cpp:24-43), CTCLoss, zeroGrad,
     loss.backward(), grads / batch, clipGradNorm, SGD steps -- the compiled C++ caller reproduces the ctypes Trainer's
     losses before and after the update (same init seed, dropout off)"""
     from wav2letter_amd import recipes
@@ -98,8 +101,8 @@ def test_training_step_through_fl_surface_equals_trainer(tmp_path, via):
         target = str(tmp_path / "net.arch")
         open(target, "w").write(arch)
     else:
-        target = PLUGIN
-        assert os.path.exists(PLUGIN)
+        target = PLUGIN if via == "plugin" else PLUGIN_LAYERS
+        assert os.path.exists(target)
     stdout = run(["net", target, str(nfeat), str(nlabel), fin, fout])
     assert "TDS" in stdout or "Model" in stdout
     raw = open(fout, "rb").read()

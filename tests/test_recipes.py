@@ -133,3 +133,21 @@ def test_unsupported_layers_fail_loudly():
         Trainer("V -1 1 NFEAT 0\nRO 2 0 3 1\nCFR 80 320 4 460 0.2 0.1 31\n", 80, 30, "ctc", device="cpu")
     with pytest.raises(W2LInvalidArgument):
         Trainer("V -1 NFEAT 1 0\nL 80 NLABEL\n", 80, 30, "seq2seq", device="cpu")
+
+
+def test_layer_objects_are_their_arch_lines(tmp_path):
+    """include/fl_compat/flashlight.h: fl::View / LayerNorm / Conv2D / GatedLinearUnit / Dropout / Reorder / Transformer / Linear /
+    TDSBlock / Pool2D / WeightNorm constructed the way the reference's model plugin constructs them
+    (recipes/slimIPL/100h_supervised.cpp:16-33) are the corresponding lines of the arch grammar
+    (cpc/SequentialBuilder.cpp:92-626); a combination the grammar does not have throws, a lone layer object does not run.
+    tests/cpp/layers_test.cpp, plain g++ against the library (loads without a GPU)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "wav2letter_amd")
+    if not os.path.exists(os.path.join(lib, "libw2l_hip.so")):
+        pytest.skip("library not built")
+    exe = str(tmp_path / "layers_test")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "layers_test.cpp"),
+                    "-o", exe, "-L" + lib, "-lw2l_hip", "-Wl,-rpath," + lib], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert out.strip() == "ok"

@@ -174,12 +174,61 @@ void Container::setParams(const Variable& var, int position) {
     modules_[childOfParam_[position]]->setParams(var, childIndexOfParam_[position]);
 }
 
+// ---- fl::Sequential of layer objects: the layers' arch lines, planned as one pipeline on first use
+void Sequential::add(std::shared_ptr<Module> m) {
+  if (!m) throw std::invalid_argument("can't add null Module to Sequential");
+  if (auto* l = dynamic_cast<ArchLayer*>(m.get())) {
+    if (planned_) throw std::logic_error("fl_compat: this fl::Sequential has been planned (params() / forward() was called): add every layer first");
+    if (!modules_.empty() && archText_.empty()) throw std::logic_error("fl_compat: layer objects and other modules do not mix in one fl::Sequential");
+    archText_ += l->archLine() + "\n";
+    modules_.push_back(std::move(m));       // (listed for modules() / prettyString; the parameters appear when the pipeline is planned)
+    return;
+  }
+  if (!archText_.empty()) throw std::logic_error("fl_compat: layer objects and other modules do not mix in one fl::Sequential");
+  Container::add(std::move(m));
+}
+void Sequential::materialize() {
+  if (planned_ || archText_.empty()) return;
+  // Feature / label counts are not arguments of a layer list.  The label count is the last layer's output (taken after
+  // planning); the feature count is needed to plan at all (the dry plan fixes the Linear row permutations), and a model that
+  // starts the way the reference's do -- fl::View(af::dim4(-1, a, b, 0)) over the (T, NFEAT, 1, B) input -- says it: NFEAT = a b
+  long d[4] = {0, 0, 0, 0};
+  int nFeat = inputFeatures_;
+  if (nFeat <= 0 && sscanf(archText_.c_str(), "V %ld %ld %ld %ld", &d[0], &d[1], &d[2], &d[3]) == 4 && d[0] == -1 && d[3] == 0 && d[1] > 0 && d[2] > 0)
+    nFeat = (int)(d[1] * d[2]);
+  if (nFeat <= 0)
+    throw std::logic_error("fl_compat: an fl::Sequential of layer objects that does not start with fl::View(af::dim4(-1, a, b, 0)) needs "
+                           "setInputFeatures(NFEAT) before params() / forward()");
+  planned_ = pkg::speech::buildSequentialModuleFromText(archText_, nFeat, -1);
+  params_ = planned_->params();
+  childOfParam_.assign(params_.size(), -1);
+  childIndexOfParam_.assign(params_.size(), 0);
+  if (!train_) planned_->eval();
+}
+std::shared_ptr<Sequential> Sequential::planned() const {
+  const_cast<Sequential*>(this)->materialize();
+  return planned_;
+}
+std::vector<Variable> Sequential::params() const {
+  const_cast<Sequential*>(this)->materialize();
+  return params_;
+}
+void Sequential::setParams(const Variable& var, int position) {
+  materialize();
+  if (planned_) { planned_->setParams(var, position); params_ = planned_->params(); return; }
+  Container::setParams(var, position);
+}
+void Sequential::train() { Container::train(); if (planned_) planned_->train(); }
+void Sequential::eval() { Container::eval(); if (planned_) planned_->eval(); }
 std::vector<Variable> Sequential::forward(const std::vector<Variable>& inputs) {
+  materialize();
+  if (planned_) return planned_->forward(inputs);
   std::vector<Variable> cur = inputs;
   for (auto& m : modules_) cur = m->forward(cur);
   return cur;
 }
 std::string Sequential::prettyString() const {
+  if (planned_) return planned_->prettyString();
   std::ostringstream ss;
   ss << "Sequential [input";
   for (size_t i = 0; i < modules_.size(); ++i) ss << " -> (" << i << ")";
@@ -757,12 +806,14 @@ class PlannedNet : public fl::Sequential {
     const Variable& in = inputs[0];
     if (in.type() != af::f32) throw std::invalid_argument("network forward: features must be f32");
     const int T = (int)in.dims(0), B = (int)in.dims(3);
+    if (nFeat_ < 0) nFeat_ = (int)(in.dims(1) * in.dims(2));   // (a Sequential of layer objects: the first input says)
     if (in.dims(1) * in.dims(2) != nFeat_) throw std::invalid_argument("network forward: feature dimension != NFEAT");
     for (size_t i = 0; i < params_.size(); ++i)
       if (params_[i].array().device<float>() != (float*)paramArena_.get() + net_->params()[i].offset)
         throw std::logic_error("setParams on a planned network must write INTO the parameter (copy), not rebind it");
     if (B != B_ || T != T_) {
       const size_t fl = net_->plan(B, T, nFeat_);
+      if (nLabel_ < 0) nLabel_ = net_->outAct().F;           // (... and the last layer the label count)
       arena_ = devAlloc(fl * sizeof(float));
       arenaFloats_ = fl;
       B_ = B; T_ = T;
@@ -967,22 +1018,31 @@ void arenaInstallBuckets(void* net, std::vector<size_t> offs) { ((pkg::speech::P
 namespace pkg {
 namespace speech {
 
+namespace {
+// the planned pipeline behind a network handle: the PlannedNet itself, or the one a Sequential of layer objects plans
+PlannedNet* plannedOf(fl::Module* m) {
+  if (auto* p = dynamic_cast<PlannedNet*>(m)) return p;
+  if (auto* s = dynamic_cast<fl::Sequential*>(m)) return dynamic_cast<PlannedNet*>(s->planned().get());
+  return nullptr;
+}
+}  // namespace
+
 FlatView flatParameters(const std::shared_ptr<fl::Module>& network) {
-  auto* p = dynamic_cast<PlannedNet*>(network.get());
+  auto* p = plannedOf(network.get());
   return p ? FlatView{p->paramPtr(), p->impl().paramFloats()} : FlatView{nullptr, 0};
 }
 void setMixedPrecision(const std::shared_ptr<fl::Module>& network, bool on) {
-  if (auto* p = dynamic_cast<PlannedNet*>(network.get())) p->mixed_ = on;
+  if (auto* p = plannedOf(network.get())) p->mixed_ = on;
 }
 uint32_t networkStep(const std::shared_ptr<fl::Module>& network) {
-  auto* p = dynamic_cast<PlannedNet*>(network.get());
+  auto* p = plannedOf(network.get());
   return p ? p->step() : 0;
 }
 void setNetworkStep(const std::shared_ptr<fl::Module>& network, uint32_t step) {
-  if (auto* p = dynamic_cast<PlannedNet*>(network.get())) p->setStep(step);
+  if (auto* p = plannedOf(network.get())) p->setStep(step);
 }
 FlatView flatGradients(const std::shared_ptr<fl::Module>& network) {
-  auto* p = dynamic_cast<PlannedNet*>(network.get());
+  auto* p = plannedOf(network.get());
   return p ? FlatView{p->gradPtr(), p->impl().paramFloats()} : FlatView{nullptr, 0};
 }
 
