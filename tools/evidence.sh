@@ -1,5 +1,5 @@
 #!/bin/bash
-# evidence run on the final tree (rounds 3 and 4): the default bench line, rocprofv3 kernel statistics per bench leg, PMC traffic passes
+# evidence run on the final tree (rounds 3 - 5): the default bench line, rocprofv3 kernel statistics per bench leg, PMC traffic passes
 # usage (on the GPU box): bash tools/evidence.sh <tag>      -> gpurun_out/<tag>_*
 tag=${1:-ev}
 cd $GRAFT_REPO_ROOT
@@ -13,7 +13,9 @@ timeout 400 bash tools/prof.sh ${tag}_c4 bench.py --steps 1 --warmup 0 --no-asg 
 timeout 300 bash tools/prof.sh ${tag}_c3 tools/c3_step.py 3 bf16
 timeout 300 bash tools/prof.sh ${tag}_c5 tools/c5_step.py 3 bf16
 # HBM-side traffic (separate counter passes, no tracing domains): headline GEMM + the alpha-pass stream + the bf16 legs
-timeout 500 bash tools/pmc.sh ${tag}_fetch "FETCH_SIZE" bench.py --steps 1 --warmup 0 --no-asg --no-c4 --no-c5 --stress-frames 40 $common
-timeout 500 bash tools/pmc.sh ${tag}_write "WRITE_SIZE" bench.py --steps 1 --warmup 0 --no-asg --no-c4 --no-c5 --stress-frames 40 $common
+# (--no-c3: the config-3 fp32 leg launches the same GEMM kernels as the headline -- with it the "gemm_lds_dma" group mixed the two
+#  workloads and roofline.traffic was not the headline kernel's own bytes: round-4 verdict, evidence hygiene)
+timeout 500 bash tools/pmc.sh ${tag}_fetch "FETCH_SIZE" bench.py --steps 1 --warmup 0 --no-asg --no-c3 --no-c4 --no-c5 --stress-frames 40 $common
+timeout 500 bash tools/pmc.sh ${tag}_write "WRITE_SIZE" bench.py --steps 1 --warmup 0 --no-asg --no-c3 --no-c4 --no-c5 --stress-frames 40 $common
 python tools/pmc_traffic.py gpurun_out/${tag}_fetch_pmc.csv gpurun_out/${tag}_write_pmc.csv gpurun_out/${tag}_pmc_traffic.json > /dev/null 2>&1
 echo done

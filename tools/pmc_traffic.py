@@ -29,6 +29,7 @@ def main():
               "fcc_big_gemm_alpha": ("fcc_big_gemm_dma<true",), "fcc_big_gemm_beta": ("fcc_big_gemm_dma<false",),
               "attn_fused_bwd": ("attn_fused_bwd_q_k", "attn_fused_bwd_kv_k"), "ln_images": ("ln_rows_images_k",),
               "tds_conv_fwd2": ("tds_conv_fwd2_k",), "tds_conv_filter2": ("tds_conv_filter2_k",),
+              "tds_conv_tz": ("tds_conv_tz_k",), "tds_conv_tzf": ("tds_conv_tzf_k",), "tds_conv_c1": ("tds_c1_fwd_k", "tds_c1_filter_k"),
               "tds_conv_rs": ("tds_conv_rs_k", "tds_conv_rs3_k"), "tds_conv_rsf": ("tds_conv_rsf_k", "tds_conv_rsf3_k"), "gemm_bf16": ("gemm128_bf16_kernel",),
               "gemm_bf16_images": ("gemm128h_kernel", "gemm256h_kernel"), "cvt_bf16": ("cvt_bf16_k", "cvt_bf16_multi_k"),
               "tds_conv_bf16": ("tds_conv_bf_k",), "tds_conv_bf16_filter": ("tds_conv_bf_filter",), "attn_fused_fwd": ("attn_fused_fwd_k",)}
