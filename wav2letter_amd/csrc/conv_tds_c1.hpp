@@ -23,32 +23,47 @@ struct TdsC1P {
 
 template <int CO, int KWM>
 __global__ __launch_bounds__(256) void tds_c1_fwd_k(TdsC1P p) {
+  // a thread's CO outputs are contiguous, a workgroup's 256 x CO too: they leave through LDS as whole 16-byte vectors (five 8-byte
+  // stores per thread, 40 bytes apart between lanes, touched every cache line of the span five times: 43 us for 77 MB)
+  __shared__ float so[256 * CO];
   const long long total = (long long)p.B * p.Tout * p.H;
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int h = (int)(idx % p.H);
-  const long long bt = idx / p.H;
-  const int t = (int)(bt % p.Tout), b = (int)(bt / p.Tout);
-  const float* xb = p.x + (size_t)b * p.Tin * p.H + h;
-  const int ti0 = t * p.stride - p.padl;
-  float acc[CO];
+  const long long base = (long long)blockIdx.x * 256;
+  const long long idx = base + threadIdx.x;
+  if (idx < total) {
+    const int h = (int)((unsigned)idx % (unsigned)p.H);
+    const unsigned bt = (unsigned)idx / (unsigned)p.H;
+    const int t = (int)(bt % (unsigned)p.Tout), b = (int)(bt / (unsigned)p.Tout);
+    const float* xb = p.x + (size_t)b * p.Tin * p.H + h;
+    const int ti0 = t * p.stride - p.padl;
+    float acc[CO];
 #pragma unroll
-  for (int c = 0; c < CO; ++c) acc[c] = p.bias ? p.bias[c] : 0.f;
+    for (int c = 0; c < CO; ++c) acc[c] = p.bias ? p.bias[c] : 0.f;
+    // all 21 loads first, unconditional (a frame outside the utterance reads frame 0 and is zeroed by a select): behind a
+    // predicate every load waits for the one before it
+    float xv[KWM];
 #pragma unroll
-  for (int j = 0; j < KWM; ++j) {
-    const int ti = ti0 + j;
-    float xv = 0.f;
-    if (j < p.kw && ti >= 0 && ti < p.Tin) xv = xb[(size_t)ti * p.H];
-    const float* wj = p.w + (j < p.kw ? j : 0) * CO;      // uniform: scalar loads
+    for (int j = 0; j < KWM; ++j) {
+      const int ti = ti0 + j;
+      const bool ok = j < p.kw && ti >= 0 && ti < p.Tin;
+      const float v = xb[(size_t)(ok ? ti : 0) * p.H];
+      xv[j] = ok ? v : 0.f;
+    }
 #pragma unroll
-    for (int c = 0; c < CO; ++c) acc[c] = fmaf(xv, wj[c], acc[c]);
+    for (int j = 0; j < KWM; ++j) {
+      const float* wj = p.w + (j < p.kw ? j : 0) * CO;      // uniform: scalar loads
+#pragma unroll
+      for (int c = 0; c < CO; ++c) acc[c] = fmaf(xv[j], wj[c], acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < CO; ++c) so[threadIdx.x * CO + c] = p.relu ? fmaxf(acc[c], 0.f) : acc[c];
   }
-  float2* dst = (float2*)(p.y + (size_t)idx * CO);
-#pragma unroll
-  for (int c = 0; c < CO; c += 2) {
-    float a0 = acc[c], a1 = acc[c + 1];
-    if (p.relu) { a0 = fmaxf(a0, 0.f); a1 = fmaxf(a1, 0.f); }
-    dst[c / 2] = make_float2(a0, a1);
+  __syncthreads();
+  const long long left = total - base;
+  const int nOut = (int)(left < 256 ? left : 256) * CO;           // floats of this workgroup (256 CO = a multiple of 4)
+  float* dst = p.y + (size_t)base * CO;                            // 16-byte aligned: base CO floats = 256 CO blockIdx
+  for (int e = 4 * threadIdx.x; e < nOut; e += 1024) {
+    if (e + 4 <= nOut) *(float4*)(dst + e) = *(const float4*)(so + e);
+    else for (int k = e; k < nOut; ++k) dst[k] = so[k];
   }
 }
 
@@ -68,26 +83,43 @@ __global__ __launch_bounds__(256) void tds_c1_filter_k(TdsC1P p, float* __restri
     for (int c = 0; c < CH; ++c) acc[j][c] = 0.f;
 #pragma unroll
   for (int c = 0; c < CH; ++c) accb[c] = 0.f;
-  for (long long pos = (long long)blockIdx.x * 128 + slot; pos < total; pos += (long long)gridDim.x * 128) {
-    const int h = (int)(pos % p.H);
-    const long long bt = pos / p.H;
-    const int t = (int)(bt % p.Tout), b = (int)(bt / p.Tout);
+  // the loads of position i + 1 are issued before the 110 FMAs of position i (one dependent global round trip per
+  // iteration was all this loop did: 29 iterations x ~2 us); idle lanes of the last step load position 0 and add zeros
+  const unsigned step = gridDim.x * 128u;
+  auto fetch = [&](unsigned pos, float (&xv)[KWM], float (&dv)[CH]) {
+    const bool live = pos < (unsigned)total;
+    const unsigned q = live ? pos : 0u;
+    const int h = (int)(q % (unsigned)p.H);
+    const unsigned bt = q / (unsigned)p.H;
+    const int t = (int)(bt % (unsigned)p.Tout), b = (int)(bt / (unsigned)p.Tout);
     const float* xb = p.x + (size_t)b * p.Tin * p.H + h;
     const int ti0 = t * p.stride - p.padl;
-    float dv[CH];
-    const float* dp = p.dy + (size_t)pos * CO + half * CH;
+    const float* dp = p.dy + (size_t)q * CO + half * CH;
 #pragma unroll
-    for (int c = 0; c < CH; ++c) dv[c] = dp[c];
-#pragma unroll
-    for (int c = 0; c < CH; ++c) accb[c] += dv[c];
+    for (int c = 0; c < CH; ++c) { const float v = dp[c]; dv[c] = live ? v : 0.f; }
 #pragma unroll
     for (int j = 0; j < KWM; ++j) {
       const int ti = ti0 + j;
-      float xv = 0.f;
-      if (j < p.kw && ti >= 0 && ti < p.Tin) xv = xb[(size_t)ti * p.H];
-#pragma unroll
-      for (int c = 0; c < CH; ++c) acc[j][c] = fmaf(xv, dv[c], acc[j][c]);
+      const bool ok = j < p.kw && ti >= 0 && ti < p.Tin;
+      const float v = xb[(size_t)(ok ? ti : 0) * p.H];
+      xv[j] = ok ? v : 0.f;
     }
+  };
+  float xc[KWM], dc[CH], xn[KWM], dn[CH];
+  unsigned pos = blockIdx.x * 128u + slot;
+  fetch(pos, xc, dc);
+  for (; pos < (unsigned)total; pos += step) {
+    fetch(pos + step, xn, dn);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) accb[c] += dc[c];
+#pragma unroll
+    for (int j = 0; j < KWM; ++j)
+#pragma unroll
+      for (int c = 0; c < CH; ++c) acc[j][c] = fmaf(xc[j], dc[c], acc[j][c]);
+#pragma unroll
+    for (int j = 0; j < KWM; ++j) xc[j] = xn[j];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) dc[c] = dn[c];
   }
   // waves by DPP, then the two waves of a half through LDS, in wave order
 #pragma unroll

@@ -1013,7 +1013,7 @@ static int rsf_launch(TdsRsfP p, float* dw, float* dbias, hipStream_t s) {
 // the one-input-channel first layer of the TDS recipes (conv_tds_c1.hpp): forward, and filter + bias gradient
 bool tds_c1_fwd_try(const float* x, const float* w, const float* bias, float* y, int B, int Tin, int Tout, int H, int Cout, int kw, int stride,
                     int padl, int relu, int profKind, hipStream_t s, int* status) {
-  if (tune_env("W2L_TDS_C1_OFF") || Cout != 10 || kw > 21 || kw < 1 || (((uintptr_t)y) & 7) != 0) return false;
+  if (tune_env("W2L_TDS_C1_OFF") || Cout != 10 || kw > 21 || kw < 1 || (((uintptr_t)y) & 15) != 0) return false;
   TdsC1P p{};
   p.x = x; p.w = w; p.bias = bias; p.y = y; p.B = B; p.Tin = Tin; p.Tout = Tout; p.H = H; p.kw = kw; p.stride = stride; p.padl = padl; p.relu = relu;
   const long long total = (long long)B * Tout * H;
