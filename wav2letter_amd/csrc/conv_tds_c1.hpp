@@ -75,7 +75,6 @@ __global__ __launch_bounds__(256) void tds_c1_filter_k(TdsC1P p, float* __restri
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = wave & 1;                    // waves 0, 2: channels [0, CH); waves 1, 3: [CH, CO)
   const int slot = (wave >> 1) * 64 + lane;     // 128 positions per workgroup and step
-  const long long total = (long long)p.B * p.Tout * p.H;
   float acc[KWM][CH], accb[CH];
 #pragma unroll
   for (int j = 0; j < KWM; ++j)
@@ -83,43 +82,57 @@ __global__ __launch_bounds__(256) void tds_c1_filter_k(TdsC1P p, float* __restri
     for (int c = 0; c < CH; ++c) acc[j][c] = 0.f;
 #pragma unroll
   for (int c = 0; c < CH; ++c) accb[c] = 0.f;
-  // the loads of position i + 1 are issued before the 110 FMAs of position i (one dependent global round trip per
-  // iteration was all this loop did: 29 iterations x ~2 us); idle lanes of the last step load position 0 and add zeros
+  // A thread walks RUNS of KT consecutive output frames of one mel row: the 2 KT + 19 input frames of a run are loaded once
+  // and shared by its KT positions (a position alone loads 21 + 5 values for 110 FMAs -- one dependent global round trip
+  // per 110 FMAs was all the first version did: 67 us for 92 MB), and the next run's loads are issued before this run's FMAs.
+  constexpr int KT = 4;
+  const unsigned H = (unsigned)p.H, nRunsT = ((unsigned)p.Tout + KT - 1) / KT;
+  const unsigned totalRuns = (unsigned)p.B * nRunsT * H;          // run index = (b * nRunsT + r) * H + h
   const unsigned step = gridDim.x * 128u;
-  auto fetch = [&](unsigned pos, float (&xv)[KWM], float (&dv)[CH]) {
-    const bool live = pos < (unsigned)total;
-    const unsigned q = live ? pos : 0u;
-    const int h = (int)(q % (unsigned)p.H);
-    const unsigned bt = q / (unsigned)p.H;
-    const int t = (int)(bt % (unsigned)p.Tout), b = (int)(bt / (unsigned)p.Tout);
-    const float* xb = p.x + (size_t)b * p.Tin * p.H + h;
-    const int ti0 = t * p.stride - p.padl;
-    const float* dp = p.dy + (size_t)q * CO + half * CH;
+  constexpr int NX = 2 * (KT - 1) + KWM;                          // stride 2 only (host-checked)
+  auto fetch = [&](unsigned run, float (&xv)[NX], float (&dv)[KT][CH]) {
+    const bool live = run < totalRuns;
+    const unsigned q = live ? run : 0u;
+    const unsigned h = q % H, br = q / H;
+    const unsigned r = br % nRunsT, b = br / nRunsT;
+    const int t0 = (int)r * KT;
+    const float* xb = p.x + (size_t)b * p.Tin * H + h;
+    const int ti0 = t0 * 2 - p.padl;
 #pragma unroll
-    for (int c = 0; c < CH; ++c) { const float v = dp[c]; dv[c] = live ? v : 0.f; }
+    for (int k = 0; k < KT; ++k) {
+      const bool okt = live && t0 + k < p.Tout;
+      const float* dp = p.dy + (((size_t)b * p.Tout + (okt ? t0 + k : 0)) * H + h) * CO + half * CH;
 #pragma unroll
-    for (int j = 0; j < KWM; ++j) {
+      for (int c = 0; c < CH; ++c) { const float v = dp[c]; dv[k][c] = okt ? v : 0.f; }
+    }
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
       const int ti = ti0 + j;
-      const bool ok = j < p.kw && ti >= 0 && ti < p.Tin;
-      const float v = xb[(size_t)(ok ? ti : 0) * p.H];
+      const bool ok = ti >= 0 && ti < p.Tin;
+      const float v = xb[(size_t)(ok ? ti : 0) * H];
       xv[j] = ok ? v : 0.f;
     }
   };
-  float xc[KWM], dc[CH], xn[KWM], dn[CH];
-  unsigned pos = blockIdx.x * 128u + slot;
-  fetch(pos, xc, dc);
-  for (; pos < (unsigned)total; pos += step) {
-    fetch(pos + step, xn, dn);
+  float xc[NX], dc[KT][CH], xn[NX], dn[KT][CH];
+  unsigned run = blockIdx.x * 128u + slot;
+  fetch(run, xc, dc);
+  for (; run < totalRuns; run += step) {
+    fetch(run + step, xn, dn);
 #pragma unroll
-    for (int c = 0; c < CH; ++c) accb[c] += dc[c];
+    for (int k = 0; k < KT; ++k) {
 #pragma unroll
-    for (int j = 0; j < KWM; ++j)
+      for (int c = 0; c < CH; ++c) accb[c] += dc[k][c];
 #pragma unroll
-      for (int c = 0; c < CH; ++c) acc[j][c] = fmaf(xc[j], dc[c], acc[j][c]);
+      for (int j = 0; j < KWM; ++j)
 #pragma unroll
-    for (int j = 0; j < KWM; ++j) xc[j] = xn[j];
+        for (int c = 0; c < CH; ++c) acc[j][c] = fmaf(xc[2 * k + j], dc[k][c], acc[j][c]);   // (taps >= kw: computed, never exported)
+    }
 #pragma unroll
-    for (int c = 0; c < CH; ++c) dc[c] = dn[c];
+    for (int j = 0; j < NX; ++j) xc[j] = xn[j];
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+      for (int c = 0; c < CH; ++c) dc[k][c] = dn[k][c];
   }
   // waves by DPP, then the two waves of a half through LDS, in wave order
 #pragma unroll

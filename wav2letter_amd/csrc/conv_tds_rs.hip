@@ -1027,11 +1027,11 @@ bool tds_c1_fwd_try(const float* x, const float* w, const float* bias, float* y,
 
 bool tds_c1_filter_try(const float* x, const float* dy, float* dw, float* dbias, int B, int Tin, int Tout, int H, int Cout, int kw, int stride,
                        int padl, hipStream_t s, int* status) {
-  if (tune_env("W2L_TDS_C1_OFF") || Cout != 10 || kw > 21 || kw < 1) return false;
+  if (tune_env("W2L_TDS_C1_OFF") || Cout != 10 || kw > 21 || kw < 1 || stride != 2) return false;   // (the kernel's sliding window is written for stride 2)
   TdsC1P p{};
   p.x = x; p.dy = dy; p.B = B; p.Tin = Tin; p.Tout = Tout; p.H = H; p.kw = kw; p.stride = stride; p.padl = padl;
-  const long long total = (long long)B * Tout * H;
-  if (total <= 0) return false;
+  const long long total = (long long)B * ((Tout + 3) / 4) * H;   // runs of four output frames
+  if (total <= 0 || (long long)B * Tout * H > (1ll << 31) - 65536 * 128) return false;
   long long blocks = (total + 127) / 128;
   if (blocks > 512) blocks = 512;
   constexpr int ROW = 21 * 10 + 10;
