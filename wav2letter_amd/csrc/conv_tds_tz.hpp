@@ -97,6 +97,18 @@ struct TzCfg {
   // taps of the zero-padded weight copy in LDS (second slab, prologue only)
   static constexpr int NQF = S + SIG * (R - 1);      // forward
   static constexpr int NQB = ST * (S + R - 1);       // backward-data
+  // ... and its tap pitch in dwords: a lane gathers at (frame shift of its column) * pitch + co + immediates, the shift of
+  // output frame rr being -SIG rr taps (forward) / +ST rr taps (backward-data); with SIG * pitch = -CO, ST * pitch = +CO
+  // (mod 32) the 32 lanes of a half read banks nn mod 32: conflict-free (at the plain pitch CI CO the three output frames'
+  // lanes overlapped: 2-3 passes per ds_read_b32, 116-208 of them per lane)
+  static constexpr int wp_pick(int mult, int target) {
+    int q = CI * CO;
+    while ((mult * q) % 32 != target) ++q;
+    return q;
+  }
+  static constexpr int WPF = wp_pick(SIG, (32 - CO % 32) % 32);
+  static constexpr int WPB = wp_pick(ST, CO % 32);
+  static_assert((SIG % 2 == 1 && ST % 2 == 1) || CO % 2 == 0, "an even tap step needs an even CO for the conflict-free pitch");
   static_assert(CI % 2 == 0 && (HB * CI) % 4 == 0 && (CI * CO) % 4 == 0, "channel pairs, 16-byte chunks");
   static_assert(R * CO <= 32 * NCT, "columns");
   static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
@@ -182,7 +194,28 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
     dma(st.rs, ldsBase + buf * BUFB + f * (PITCH * 4) + part * 1024, st.base + f * HCI * 4 + part * 1024 + dmaLane, CPF - 64 * part);
   };
 
-  // ---- prologue: first slab -> buffer 0, the weights -> buffer 1
+  // ---- prologue: the weights -> registers -> buffer 1 (padded, transposed), first slab -> buffer 0
+  // The weights, [tap][.][.] as they lie in HBM, with P zero taps in front and zeros behind (NQ taps in all: the range check of
+  // the descriptor IS the zero padding) are loaded FIRST, 16 bytes per lane and instruction: they come back from L2 while the
+  // slab's frames, issued behind them, come from HBM, and the gather below runs under that latency.  (Loads as asm with a
+  // counted wait: the compiler does not see the LDS-DMA instructions behind them and would wait for everything.)
+  constexpr int NQ = FLIP ? Cfg::NQB : Cfg::NQF;
+  constexpr int WP = FLIP ? Cfg::WPB : Cfg::WPF;
+  constexpr int CC = CI * CO;
+  constexpr int WJ = (NQ * CC / 4 + 255) / 256;        // 16-byte loads per lane
+  static_assert(NQ * WP * 4 <= NF * PITCH * 4, "weights fit the frames of the second slab");
+  static_assert(NDMA <= 48, "counted wait");
+  const int P = FLIP ? ST * (S - p.kw) : SIG * (R - 1);
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  f32x4v wv[WJ];
+  {
+    const u32x4v rw = vsharp(p.w, (unsigned)(p.kwFull * CC * 4));
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+      const int voff = ((j * 256 + tid) * 4 - P * CC) * 4;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(wv[j]) : "v"(voff), "s"(rw) : "memory");
+    }
+  }
   {
     const Stage s0 = stage_of(nx, true);
 #pragma unroll
@@ -204,24 +237,28 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
   };
   clear_padding(0);
 
-  // The weights as they lie in HBM, [tap][ci][co], with P zero taps in front and zeros behind (NQ taps in all), copied once
-  // per workgroup by LDS-DMA (the range check of the descriptor IS the zero padding); every lane then gathers the block-
-  // Toeplitz column it owns -- step 2 (sp C2 + cp) + e is k = (s = 2 sp + hf, ci = 2 cp + e), the tail steps are (s = s0 + SW - 1,
-  // ci = 2 (q + hf TR) + e) -- with ds_read_b32 at immediate offsets of ONE address.  (First version: one global gather per
-  // register: 116-208 divergent loads per wave at ~32 TCP cycles each = 14-22 us before the first MFMA;
-  // profiles/r05_run3_conv_tz_independent_weight_loads.log.)
-  constexpr int NQ = FLIP ? Cfg::NQB : Cfg::NQF;
-  constexpr int CC = CI * CO;
-  constexpr int WJ = (NQ * CC / 4 + 255) / 256;        // LDS-DMA instructions per wave
-  static_assert(WJ * 256 * 16 <= BUFB, "weights fit the second slab");
-  const int P = FLIP ? ST * (S - p.kw) : SIG * (R - 1);
-  {
-    const u32x4v rw = vsharp(p.w, (unsigned)(p.kwFull * CC * 4));
+  // The copy in LDS is [tap][ci][co] at the tap pitch WP for both passes (the backward pass's w[tap][co][ci] is transposed by
+  // the scatter); every lane then gathers the block-Toeplitz column it owns -- step 2 (sp C2 + cp) + e is k = (s = 2 sp + hf,
+  // ci = 2 cp + e), the tail steps are (s = s0 + SW - 1, ci = 2 (q + hf TR) + e) -- with ds_read_b32 at immediate offsets
+  // of ONE address.  (First version: one global gather per register: 116-208 divergent loads per wave at ~32 TCP cycles each
+  // = 14-22 us before the first MFMA; profiles/r05_run3_conv_tz_independent_weight_loads.log.)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");   // the weights have landed (the slab's DMA may still fly)
 #pragma unroll
-    for (int j = 0; j < WJ; ++j) {
-      const int blk = 4 * j + wave;
-      dma(rw, ldsBase + BUFB + blk * 1024, ((blk * 64 + lane) * 4 - P * CC) * 4, 64);
-    }
+  for (int j = 0; j < WJ; ++j) asm volatile("" : "+v"(wv[j]));   // (uses stay behind the wait)
+  {
+    float* const wl = (float*)(ldsb + BUFB);
+#pragma unroll
+    for (int j = 0; j < WJ; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = (j * 256 + tid) * 4 + q;             // element of the unpadded [NQ][CC] copy
+        if (e < NQ * CC) {
+          const int tap = e / CC, r = e - tap * CC;
+          int dst = tap * WP + r;
+          if (FLIP) { const int c0 = r / CI, c1 = r - c0 * CI; dst = tap * WP + c1 * CO + c0; }
+          wl[dst] = wv[j][q];
+        }
+      }
   }
   const int nn = 32 * ct + n;
   const bool colOk = nn < R * CO;
@@ -230,42 +267,25 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
   const int rr = colOk ? nn / CO : (Cfg::SSPLIT ? ct : 0), co = colOk ? nn - (nn / CO) * CO : 0;
   float biasv = 0.f;
   if (p.bias && colOk) biasv = p.bias[co];
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   float bw[NK];
   {
     const lfptr_t wl = (lfptr_t)(ldsb + BUFB);
-    if (!FLIP) {
-      // w[tap][ci][co]: tap (2 sp + hf) - SIG rr is LDS tap (hf - SIG rr + P) + 2 sp
-      const lfptr_t bm = wl + (s0 + hf - SIG * rr + P) * CC + co;
+    // forward: tap (2 sp + hf) - SIG rr is LDS tap (hf - SIG rr + P) + 2 sp;  backward-data: w'[tap] = w[tapOff + ST (kw - 1 - tap)],
+    // tap 2 sp + hf - rr is LDS tap tapOff + ST (kw - 1 - hf + rr) + P - 2 ST sp
+    const lfptr_t bm = FLIP ? wl + (p.tapOff + ST * (p.kw - 1 - hf - s0 + rr) + P - 2 * ST * (SP - 1)) * WP + co
+                            : wl + (s0 + hf - SIG * rr + P) * WP + co;
 #pragma unroll
-      for (int sp = 0; sp < SP; ++sp)
+    for (int sp = 0; sp < SP; ++sp)
 #pragma unroll
-        for (int u = 0; u < CI; ++u) bw[2 * sp * C2 + u] = bm[2 * sp * CC + u * CO];
-      if (TR > 0) {
-        const lfptr_t bt = wl + (s0 + SW - 1 - SIG * rr + P) * CC + 2 * hf * TR * CO + co;
+      for (int u = 0; u < CI; ++u) bw[2 * sp * C2 + u] = bm[(FLIP ? 2 * ST * (SP - 1 - sp) : 2 * sp) * WP + u * CO];
+    if (TR > 0) {
+      const lfptr_t bt = (FLIP ? wl + (p.tapOff + ST * (p.kw - s0 - SW + rr) + P) * WP : wl + (s0 + SW - 1 - SIG * rr + P) * WP) + 2 * hf * TR * CO + co;
 #pragma unroll
-        for (int u = 0; u < 2 * TR; ++u) {
-          float t = bt[u * CO];
-          if (2 * TR + u >= CI) t = hf ? 0.f : t;       // ci = 2 hf TR + u >= CI: the padding pair
-          bw[2 * SP * C2 + u] = t;
-        }
-      }
-    } else {
-      // w'[tap][ci][co] = w[tapOff + ST (kw - 1 - tap)][co][ci]: tap 2 sp + hf - rr is LDS tap
-      // tapOff + ST (kw - 1 - hf + rr) + P - 2 ST sp
-      const lfptr_t bm = wl + (p.tapOff + ST * (p.kw - 1 - hf - s0 + rr) + P - 2 * ST * (SP - 1)) * CC + co * CI;
-#pragma unroll
-      for (int sp = 0; sp < SP; ++sp)
-#pragma unroll
-        for (int u = 0; u < CI; ++u) bw[2 * sp * C2 + u] = bm[2 * ST * (SP - 1 - sp) * CC + u];
-      if (TR > 0) {
-        const lfptr_t bt = wl + (p.tapOff + ST * (p.kw - s0 - SW + rr) + P) * CC + co * CI + 2 * hf * TR;
-#pragma unroll
-        for (int u = 0; u < 2 * TR; ++u) {
-          float t = bt[u];
-          if (2 * TR + u >= CI) t = hf ? 0.f : t;
-          bw[2 * SP * C2 + u] = t;
-        }
+      for (int u = 0; u < 2 * TR; ++u) {
+        float t = bt[u * CO];
+        if (2 * TR + u >= CI) t = hf ? 0.f : t;       // ci = 2 hf TR + u >= CI: the padding pair
+        bw[2 * SP * C2 + u] = t;
       }
     }
   }
@@ -297,8 +317,8 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
   long long cStage = 0, cChain = 0, cWait = 0, cEpi = 0, cBar = 0;
   const long long wLoop = wall_clock64();
 #endif
-  // every lane has its weights: the second slab may be overwritten
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  // every lane has its weights: the second slab may be overwritten; the first slab has landed
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   clear_padding(1);   // (read first in round 1, a barrier away)
 
   f32x16 accPrev;                 // DEFER: the finished tile of the previous round

@@ -45,6 +45,7 @@ constexpr int kBigMaxNB = 4;      // utterance tiles of 32 -> B <= 128
 constexpr int kBigStepThreads = 1024;  // per-utterance kernels that run once per call
 constexpr int kBigParts = 16;          // workgroups (partial maxima) per utterance and step
 constexpr int kBigMaxSW = 16;          // bound on partial slabs per row group
+constexpr int kBigStepV = 7;           // product default of BigDims::stepv (see there)
 constexpr int kBigCachePermille = 500; // product default of BigDims::cache (see there): 84.5 -> 79.4 us per step at T = 300
                                        // (0.595 -> 0.633 of the HBM peak; profiles/r03_run1_fcc_cache_policy.log)
 
@@ -71,6 +72,13 @@ struct BigDims {
             // rest nontemporal).  A worker reads the same slice at every one of the T steps: the default-policy part can stay
             // resident in the 256 MiB Infinity Cache between steps while the nontemporal rest streams past it (a 400 MB
             // stream loaded entirely with the default policy evicts itself before it is reused).  W2L_FCC_CACHE (probe).
+  int stepv; // step-kernel variants (W2L_FCC_STEPV, probe; product: kBigStepV): 1 = every one of the P slabs of a row group is
+            // read unconditionally (the slabs no worker writes are zeroed once per call) instead of np[g] of them -- the
+            // table load was a dependent memory round trip in front of the slab loads of every step of both passes;
+            // 2 = the backward step reads the frame's maximum c_t from cfin (one value, written by fcc_big_loss) instead of
+            // taking the maximum of the frame's kBigParts partial maxima; 4 = nontemporal stores of what no later frame of
+            // the pass reads (dx, g r, e: backward; a, 1 / s: forward), so that they do not displace the cached half of the
+            // transition stream in the Infinity Cache
   int abl;  // W2L_FCC_ABL: timing-only ablations 1 = no MFMA, 2 = no E-operand traffic; 4 = nontemporal loads of the
             // transition stream (results stay correct)
 };
@@ -113,6 +121,7 @@ inline BigDims big_dims(int B, int T, int N) {
   // (profiles/r01_run16_fcc_dma_ring_variants.log) 2x3 85.5 us, 1x6 85.8, 2x3 nt 77.6, 1x6 nt 76.0, ping-pong 94.0
   { const char* e = tune_env("W2L_FCC_DMA"); d.dma = e ? atoi(e) : 4; }
   { const char* e = tune_env("W2L_FCC_FOLD"); d.fold = e ? atoi(e) : 0; }
+  { const char* e = tune_env("W2L_FCC_STEPV"); d.stepv = e ? atoi(e) : kBigStepV; }
   { const char* e = tune_env("W2L_FCC_CACHE"); d.cache = e ? atoi(e) : kBigCachePermille; if (d.cache < 0) d.cache = 0; if (d.cache > 1000) d.cache = 1000; }
   d.Np = (N + 32 * d.RT - 1) / (32 * d.RT) * (32 * d.RT);
   d.G = d.Np / (32 * d.RT);
@@ -163,6 +172,7 @@ struct BigWs {
   float* gb;      // [B] scale * upstream grad
   unsigned* cnt;  // [G] arrival tickets of the folded step (self-resetting; zeroed once per call)
   int* np;        // [G] partial slabs per row group (big_pieces: two 64-bit divisions each, taken once per call, not per frame)
+  float* cfin;    // [T][B] c_t = the maximum of a_t (of its kBigParts partial maxima), written by fcc_big_loss for the backward pass
   size_t bytes;
 };
 
@@ -185,6 +195,7 @@ __host__ __device__ inline BigWs big_ws(void* ws, const BigDims& d) {
   w.gb = (float*)take((size_t)d.B * sizeof(float));
   w.cnt = (unsigned*)take((size_t)d.G * sizeof(unsigned));
   w.np = (int*)take((size_t)d.G * sizeof(int));
+  w.cfin = (float*)take((size_t)d.T * d.B * sizeof(float));
   w.bytes = (size_t)(p - (char*)ws);
   return w;
 }
@@ -833,7 +844,7 @@ __global__ __launch_bounds__(256) void fcc_big_step(BigDims d, int t, const floa
     float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (t > 0) {
       float4 p4[kBigMaxSW];  // all slab loads in flight together, added in worker order
-      const int np = ws.np[i0 / (32 * d.RT)];
+      const int np = (d.stepv & 1) ? d.P : ws.np[i0 / (32 * d.RT)];
 #pragma unroll
       for (int s = 0; s < kBigMaxSW; ++s)
         p4[s] = s < np ? *(const float4*)(ws.part + ((size_t)s * d.Bp + b) * d.Np + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -851,9 +862,11 @@ __global__ __launch_bounds__(256) void fcc_big_step(BigDims d, int t, const floa
         if (t > 0) {
           const float sc = fmaxf(ssum[u], 1e-37f);
           v += ws.rm[i] + __logf(sc);
-          ir[i] = 1.f / sc;
+          if (d.stepv & 4) __builtin_nontemporal_store(1.f / sc, &ir[i]);
+          else ir[i] = 1.f / sc;
         }
-        ar[i] = v;
+        if (d.stepv & 4) __builtin_nontemporal_store(v, &ar[i]);
+        else ar[i] = v;
       }
       a4[u] = v;
       m = fmaxf(m, v);
@@ -871,7 +884,11 @@ __global__ __launch_bounds__(kBigStepThreads) void fcc_big_loss(BigDims d, int s
   __shared__ double smd[kBigStepThreads / 64];
   const int b = blockIdx.x, N = d.N, T = d.T;
   double C = 0.0;
-  for (int t = threadIdx.x; t < T; t += kBigStepThreads) C += (double)big_cmax(ws.pmax, d.B, t, b);
+  for (int t = threadIdx.x; t < T; t += kBigStepThreads) {
+    const float m = big_cmax(ws.pmax, d.B, t, b);
+    ws.cfin[(size_t)t * d.B + b] = m;
+    C += (double)m;
+  }
   C = wave_sum_f64(C);
   if ((threadIdx.x & 63) == 0) smd[threadIdx.x >> 6] = C;
   __syncthreads();
@@ -937,7 +954,7 @@ __global__ __launch_bounds__(256) void fcc_big_bwd_step(BigDims d, int tm, float
   const int i0 = 4 * (blockIdx.x * 256 + threadIdx.x);
   if (i0 >= N) return;
   const float g = ws.gb[b];
-  const float c = big_cmax(ws.pmax, d.B, tm, b);
+  const float c = (d.stepv & 2) ? ws.cfin[(size_t)tm * d.B + b] : big_cmax(ws.pmax, d.B, tm, b);
   float* er = ws.e + ((size_t)tm * d.B + b) * N;
   const float* ir = ws.invs + ((size_t)tm * d.B + b) * N;
   float* dxr = dx + ((size_t)b * d.T + tm) * N;
@@ -945,13 +962,14 @@ __global__ __launch_bounds__(256) void fcc_big_bwd_step(BigDims d, int tm, float
   float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
   {
     float4 p4[kBigMaxSW];
-    const int np = ws.np[i0 / (32 * d.RT)];
+    const int np = (d.stepv & 1) ? d.P : ws.np[i0 / (32 * d.RT)];
 #pragma unroll
     for (int s = 0; s < kBigMaxSW; ++s)
       p4[s] = s < np ? *(const float4*)(ws.part + ((size_t)s * d.Bp + b) * d.Np + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int s = 0; s < kBigMaxSW; ++s) { s4.x += p4[s].x; s4.y += p4[s].y; s4.z += p4[s].z; s4.w += p4[s].w; }
   }
+  const bool nt = (d.stepv & 4) != 0;
   const float D[4] = {s4.x, s4.y, s4.z, s4.w};
   float r4[4];
 #pragma unroll
@@ -960,12 +978,13 @@ __global__ __launch_bounds__(256) void fcc_big_bwd_step(BigDims d, int tm, float
     r4[u] = 0.f;
     if (i < N) {
       const float e = __expf(er[i] - c);
-      er[i] = e;
       const float da = e * D[u];
-      dxr[i] = g * da;
+      if (nt) { __builtin_nontemporal_store(e, &er[i]); __builtin_nontemporal_store(g * da, &dxr[i]); }
+      else { er[i] = e; dxr[i] = g * da; }
       if (tm > 0) {
         r4[u] = da * ir[i];
-        rgr[i] = g * r4[u];
+        if (nt) __builtin_nontemporal_store(g * r4[u], &rgr[i]);
+        else rgr[i] = g * r4[u];
       }
     }
   }
@@ -1098,6 +1117,8 @@ int fcc_big_forward(int B, int T, int N, int scaleMode, const float* input, cons
   const size_t opFloats = 2 * align_up((size_t)d.Bp * d.Kp * sizeof(float), 256) / sizeof(float);
   hipLaunchKernelGGL(big_fill_k, dim3(512), dim3(256), 0, s, ws.ep[0], opFloats, -INFINITY);
   W2L_LAUNCH_CHECK();
+  // (stepv & 1) the step kernels add all P slabs of a row group: the ones its workers never write read as zero
+  if (d.stepv & 1) W2L_HIP_CHECK(hipMemsetAsync(ws.part, 0, (size_t)d.P * d.Bp * d.Np * sizeof(float), s));
   const dim3 sgrid(kBigParts, (unsigned)B);
   const bool fold = big_fold_ok(d) && T > 1;
   if (fold) {
@@ -1135,6 +1156,7 @@ int fcc_big_backward(int B, int T, int N, const float* trans, const float* grad,
   int st = big_pack(d, ws, trans, true, s);  // rm and the piece table are still valid from forward
   if (st) return st;
   W2L_HIP_CHECK(hipMemsetAsync(ws.ep[0], 0, 2 * align_up((size_t)d.Bp * d.Kp * sizeof(float), 256), s));
+  if (d.stepv & 1) W2L_HIP_CHECK(hipMemsetAsync(ws.part, 0, (size_t)d.P * d.Bp * d.Np * sizeof(float), s));
   hipLaunchKernelGGL(fcc_big_bwd_init, dim3((unsigned)B), dim3(kBigStepThreads), 0, s, d, grad, inputGrad, ws);
   W2L_LAUNCH_CHECK();
   const dim3 sgrid((unsigned)((N + 1023) / 1024), (unsigned)B);
