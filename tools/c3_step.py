@@ -34,12 +34,16 @@ def step():
 step()
 torch.cuda.synchronize()
 L = _lib.lib()
-L.w2l_profile_enable(1)
 t0 = time.perf_counter()
 for _ in range(steps):
     loss = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
+# the per-kind figures: further steps with the event brackets on (a bracket costs ~4.6 us, 140 per step: not in the timed steps)
+L.w2l_profile_enable(1)
+for _ in range(steps):
+    step()
+torch.cuda.synchronize()
 out = {"config": f"C3 streaming TDS-CTC: B={B}, T={T}, Tout={Tout}, {mode}", "ms_per_step": round(dt * 1e3, 2),
        "utterances_per_sec": round(B / dt, 1), "loss_mean": float(loss.float().mean().item())}
 for name, kind in (("gemm_f32", 0), ("gemm_bf16", 6), ("tds_conv_fwd", 2), ("tds_conv_bwd_data", 4), ("tds_conv_bwd_filter", 5)):

@@ -4,6 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from wav2letter_amd import _lib, criterion as Cr
+if os.environ.get("W2L_CTC_LSE_VAR"): _lib.use_probe().__enter__()   # probe-library variants of ctc_rows_lse
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 188
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20

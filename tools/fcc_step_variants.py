@@ -1,7 +1,7 @@
-"""The alpha / beta passes of FullConnectionCriterion at the north-star stress shape (B = 32, N = 9998, T frames), WITHOUT the
-bench's event brackets in the timed passes, over the step-kernel variants of criterion_fcc_big.hip (probe library,
-W2L_FCC_STEPV bit mask: 1 = unconditional slab loads, 2 = c_t from cfin, 4 = nontemporal stores).  The variants do not touch
-the arithmetic: loss and gradients must be bit-identical.   python tools/fcc_step_variants.py [T] [masks ...]"""
+"""The alpha / beta passes of FullConnectionCriterion at the north-star stress shape (B = 32, N = 9998, T frames), with and
+WITHOUT the bench's event brackets around every stream launch; repeated runs must be bit-identical.  (profiles/r05_run24_*: the
+run over the step-kernel variants W2L_FCC_STEPV -- unconditional slab loads / c_t from cfin / nontemporal stores -- that are
+the only form since; they were worth 0.3 us per frame, the event brackets 4.6.)   python tools/fcc_step_variants.py [T] [repeats]"""
 import ctypes as C
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +10,7 @@ from wav2letter_amd import _lib
 from wav2letter_amd.criterion import CriterionScaleMode, FullConnectionCriterion
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
-vals = [int(v) for v in sys.argv[2:]] or [0, 1, 2, 4, 3, 7, 0, 7]
+vals = list(range(int(sys.argv[2]) if len(sys.argv) > 2 else 3))
 B, N = 32, 9998
 g = torch.Generator(device="cpu").manual_seed(7)
 x = torch.randn(B, T, N, generator=g).cuda().requires_grad_(True)
@@ -58,13 +58,12 @@ def run(L, events):
 ref = None
 dA_ms = None
 for v in vals:
-    os.environ["W2L_FCC_STEPV"] = str(v)
     with _lib.use_probe():
         L = _lib.lib()
         if dA_ms is None:
             f_, b_, ka, kb, kd, _ = run(L, True)
             dA_ms = kd[1]
-            print(f"with event brackets (mask {v}): forward {f_:.2f} ms = {f_ * 1e3 / (T - 1):.2f} us per frame, backward {b_:.2f} ms, dA GEMM {dA_ms:.2f} ms, "
+            print(f"with event brackets: forward {f_:.2f} ms = {f_ * 1e3 / (T - 1):.2f} us per frame, backward {b_:.2f} ms, dA GEMM {dA_ms:.2f} ms, "
                   f"beta recursion {b_ - dA_ms:.2f} ms = {(b_ - dA_ms) * 1e3 / (T - 1):.2f} us per frame; stream kernel alone alpha {ka[1] * 1e3 / ka[0]:.2f} us, "
                   f"beta {kb[1] * 1e3 / kb[0]:.2f} us", flush=True)
         f, b, _, _, _, sig = run(L, False)
@@ -72,6 +71,6 @@ for v in vals:
         ref = sig
     same = torch.equal(sig[0], ref[0]) and sig[1:] == ref[1:]
     beta = b - dA_ms
-    print(f"W2L_FCC_STEPV={v}: alpha pass {f:8.2f} ms = {f * 1e3 / (T - 1):6.2f} us per frame = {step_bytes * (T - 1) / f / 8e9:.4f} of 8 TB/s; "
+    print(f"run {v}: alpha pass {f:8.2f} ms = {f * 1e3 / (T - 1):6.2f} us per frame = {step_bytes * (T - 1) / f / 8e9:.4f} of 8 TB/s; "
           f"backward {b:8.2f} ms, beta recursion {beta:8.2f} ms = {beta * 1e3 / (T - 1):6.2f} us per frame = {step_bytes * (T - 1) / beta / 8e9:.4f}; "
           f"identical to the first run: {same}", flush=True)

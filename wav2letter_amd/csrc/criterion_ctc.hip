@@ -118,6 +118,12 @@ __device__ __forceinline__ RowSplit row_split(const float* row, int N) {
 }
 
 // lse[b][t] and the label probabilities pd[b][t][s] = exp(x[ext_s] - lse) in fp64
+// VAR 3 (the product's form when L >= 1): the label gather of the first kRowThreads lattice positions -- target, then x[label] --
+//   is issued WITH the row loads instead of behind the two reductions, where its two dependent round trips were 8 us of the
+//   kernel's 68 (profiles/r05_run26_ctc_rows_lse_variants.log: variant 2 = no gather at all).
+// VAR 0: the gather behind the reductions.  Probe library, W2L_CTC_LSE_VAR: 1 = nontemporal row loads (48 us, but ctc_rows_grad
+//   then no longer finds the emissions in the Infinity Cache and takes the 20 us), 2 = no label gather (timing only)
+template <int VAR>
 __global__ __launch_bounds__(kRowThreads) void ctc_rows_lse(int T, int N, int L,
                                                             const float* __restrict__ x,
                                                             const int* __restrict__ target,
@@ -130,39 +136,58 @@ __global__ __launch_bounds__(kRowThreads) void ctc_rows_lse(int T, int N, int L,
   const int tid = threadIdx.x;
   RowSplit sp = row_split(row, N);
   const float4* body = (const float4*)(row + sp.nh);
+  const int Lb = targetSize[b];
+  const int S = 2 * Lb + 1;
+  const int* y = target + (size_t)b * L;
+  int lab0 = 0;
+  if (VAR == 3) lab0 = y[min(tid >> 1, max(Lb, 1) - 1)];   // (L >= 1)
 
+  // Every load of the row is issued before the first use, none behind a lane predicate (a chunk past the row re-reads the
+  // row's last chunk and is replaced by -inf): written as `if (idx < nbody4) { load; max }` hipcc waited for each of the
+  // twelve loads in turn -- one 16-byte load in flight per thread, 3.4 TB/s (round-4 verdict, weak 8).
   float4 v[kRowMaxPer / 4];
+  float hv = -INFINITY;
+  if (sp.nbody4 > 0) {
+    const int lastc = sp.nbody4 - 1;
+#pragma unroll
+    for (int k = 0; k < kRowMaxPer / 4; ++k) {
+      const float4* q = body + min(tid + kRowThreads * k, lastc);
+      if (VAR == 1) {
+        const float* qf = (const float*)q;
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v t = __builtin_nontemporal_load((const f4v*)qf);
+        v[k] = make_float4(t[0], t[1], t[2], t[3]);
+      } else {
+        v[k] = *q;
+      }
+    }
+  }
+  if (tid < sp.nh) hv = row[tid];
+  else if (tid >= 64 && tid - 64 < sp.ntail) hv = row[sp.nh + 4 * sp.nbody4 + (tid - 64)];
+  // (hipcc waits for the whole row here -- vmcnt(0) behind the branches above -- and the gather flies under the two reductions)
+  float xl = 0.f;
+  if (VAR == 3) xl = row[min(max((tid & 1) ? lab0 : N - 1, 0), N - 1)];
   float m = -INFINITY;
 #pragma unroll
   for (int k = 0; k < kRowMaxPer / 4; ++k) {
-    int idx = tid + kRowThreads * k;
-    if (idx < sp.nbody4) {
-      v[k] = body[idx];
-      m = fmaxf(m, fmaxf(fmaxf(v[k].x, v[k].y), fmaxf(v[k].z, v[k].w)));
-    }
+    if (tid + kRowThreads * k >= sp.nbody4) v[k] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    m = fmaxf(m, fmaxf(fmaxf(v[k].x, v[k].y), fmaxf(v[k].z, v[k].w)));
   }
-  float hv = -INFINITY;
-  if (tid < sp.nh) hv = row[tid];
-  else if (tid >= 64 && tid - 64 < sp.ntail) hv = row[sp.nh + 4 * sp.nbody4 + (tid - 64)];
   m = fmaxf(m, hv);
   m = block_reduce_max(m, sm);
   float s = 0.f;
 #pragma unroll
-  for (int k = 0; k < kRowMaxPer / 4; ++k) {
-    int idx = tid + kRowThreads * k;
-    if (idx < sp.nbody4)
-      s += (__expf(v[k].x - m) + __expf(v[k].y - m)) + (__expf(v[k].z - m) + __expf(v[k].w - m));
-  }
+  for (int k = 0; k < kRowMaxPer / 4; ++k)
+    s += (__expf(v[k].x - m) + __expf(v[k].y - m)) + (__expf(v[k].z - m) + __expf(v[k].w - m));   // exp(-inf - m) = 0: a chunk past the row
   if (hv != -INFINITY) s += __expf(hv - m);
   s = block_reduce_sum(s, sm);
   const float lse = m + __logf(s);
   if (tid == 0) ws.lse[r] = lse;
-  // gather label log-probs
-  const int Lb = targetSize[b];
-  const int S = 2 * Lb + 1;
-  const int* y = target + (size_t)b * L;
+  if (VAR == 2) return;
+  // label log-probs
   double* pd = ws.pd + r * ws.S;
-  for (int si = tid; si < S; si += kRowThreads) {
+  if (VAR == 3 && tid < S) pd[tid] = exp_wide(xl - lse);
+  for (int si = VAR == 3 ? tid + kRowThreads : tid; si < S; si += kRowThreads) {
     int lab = (si & 1) ? y[si >> 1] : (N - 1);
     pd[si] = exp_wide(row[lab] - lse);
   }
@@ -610,7 +635,14 @@ W2L_API int w2l_ctc_forward(int B, int T, int N, int L, int scaleMode, const flo
   CtcWs ws = ctc_ws(workspace, B, T, N, L);
   const unsigned rows = (unsigned)((size_t)B * T);
   if (N <= kRowThreads * kRowMaxPer)
-    hipLaunchKernelGGL(ctc_rows_lse, dim3(rows), dim3(kRowThreads), 0, s, T, N, L, input, target, targetSize, ws);
+  {
+    const char* e = tune_env("W2L_CTC_LSE_VAR");
+    const int var = e ? atoi(e) : 0;
+    if (var == 1) hipLaunchKernelGGL(ctc_rows_lse<1>, dim3(rows), dim3(kRowThreads), 0, s, T, N, L, input, target, targetSize, ws);
+    else if (var == 2) hipLaunchKernelGGL(ctc_rows_lse<2>, dim3(rows), dim3(kRowThreads), 0, s, T, N, L, input, target, targetSize, ws);
+    else if (var == 3 || (!e && L >= 1)) hipLaunchKernelGGL(ctc_rows_lse<3>, dim3(rows), dim3(kRowThreads), 0, s, T, N, L, input, target, targetSize, ws);
+    else hipLaunchKernelGGL(ctc_rows_lse<0>, dim3(rows), dim3(kRowThreads), 0, s, T, N, L, input, target, targetSize, ws);
+  }
   else
     hipLaunchKernelGGL(ctc_rows_lse_big, dim3(rows), dim3(kRowThreads), 0, s, T, N, L, input, target, targetSize, ws);
   W2L_LAUNCH_CHECK();

@@ -45,7 +45,6 @@ constexpr int kBigMaxNB = 4;      // utterance tiles of 32 -> B <= 128
 constexpr int kBigStepThreads = 1024;  // per-utterance kernels that run once per call
 constexpr int kBigParts = 16;          // workgroups (partial maxima) per utterance and step
 constexpr int kBigMaxSW = 16;          // bound on partial slabs per row group
-constexpr int kBigStepV = 7;           // product default of BigDims::stepv (see there)
 constexpr int kBigCachePermille = 500; // product default of BigDims::cache (see there): 84.5 -> 79.4 us per step at T = 300
                                        // (0.595 -> 0.633 of the HBM peak; profiles/r03_run1_fcc_cache_policy.log)
 
@@ -72,13 +71,6 @@ struct BigDims {
             // rest nontemporal).  A worker reads the same slice at every one of the T steps: the default-policy part can stay
             // resident in the 256 MiB Infinity Cache between steps while the nontemporal rest streams past it (a 400 MB
             // stream loaded entirely with the default policy evicts itself before it is reused).  W2L_FCC_CACHE (probe).
-  int stepv; // step-kernel variants (W2L_FCC_STEPV, probe; product: kBigStepV): 1 = every one of the P slabs of a row group is
-            // read unconditionally (the slabs no worker writes are zeroed once per call) instead of np[g] of them -- the
-            // table load was a dependent memory round trip in front of the slab loads of every step of both passes;
-            // 2 = the backward step reads the frame's maximum c_t from cfin (one value, written by fcc_big_loss) instead of
-            // taking the maximum of the frame's kBigParts partial maxima; 4 = nontemporal stores of what no later frame of
-            // the pass reads (dx, g r, e: backward; a, 1 / s: forward), so that they do not displace the cached half of the
-            // transition stream in the Infinity Cache
   int abl;  // W2L_FCC_ABL: timing-only ablations 1 = no MFMA, 2 = no E-operand traffic; 4 = nontemporal loads of the
             // transition stream (results stay correct)
 };
@@ -121,7 +113,6 @@ inline BigDims big_dims(int B, int T, int N) {
   // (profiles/r01_run16_fcc_dma_ring_variants.log) 2x3 85.5 us, 1x6 85.8, 2x3 nt 77.6, 1x6 nt 76.0, ping-pong 94.0
   { const char* e = tune_env("W2L_FCC_DMA"); d.dma = e ? atoi(e) : 4; }
   { const char* e = tune_env("W2L_FCC_FOLD"); d.fold = e ? atoi(e) : 0; }
-  { const char* e = tune_env("W2L_FCC_STEPV"); d.stepv = e ? atoi(e) : kBigStepV; }
   { const char* e = tune_env("W2L_FCC_CACHE"); d.cache = e ? atoi(e) : kBigCachePermille; if (d.cache < 0) d.cache = 0; if (d.cache > 1000) d.cache = 1000; }
   d.Np = (N + 32 * d.RT - 1) / (32 * d.RT) * (32 * d.RT);
   d.G = d.Np / (32 * d.RT);
@@ -171,7 +162,6 @@ struct BigWs {
   float* scale;   // [B]
   float* gb;      // [B] scale * upstream grad
   unsigned* cnt;  // [G] arrival tickets of the folded step (self-resetting; zeroed once per call)
-  int* np;        // [G] partial slabs per row group (big_pieces: two 64-bit divisions each, taken once per call, not per frame)
   float* cfin;    // [T][B] c_t = the maximum of a_t (of its kBigParts partial maxima), written by fcc_big_loss for the backward pass
   size_t bytes;
 };
@@ -194,7 +184,6 @@ __host__ __device__ inline BigWs big_ws(void* ws, const BigDims& d) {
   w.scale = (float*)take((size_t)d.B * sizeof(float));
   w.gb = (float*)take((size_t)d.B * sizeof(float));
   w.cnt = (unsigned*)take((size_t)d.G * sizeof(unsigned));
-  w.np = (int*)take((size_t)d.G * sizeof(int));
   w.cfin = (float*)take((size_t)d.T * d.B * sizeof(float));
   w.bytes = (size_t)(p - (char*)ws);
   return w;
@@ -826,9 +815,39 @@ __device__ __forceinline__ float big_cmax(const float* __restrict__ pmax, int B,
   return m;
 }
 
+// Sum of the partial slabs of a quad, in worker order: ALL P slabs of the row group, the ones its workers never write being
+// zeroed once per call (adding 0.f is exact).  The loads are unconditional and issued together.  (Earlier forms: np[g] slabs
+// behind a per-lane predicate -- the piece table was a dependent round trip in front of them; behind a uniform `s < np`
+// branch hipcc drained the queue at every join.)  P <= 8 at the shapes of the recipes (5 at N = 9998).
+__device__ __forceinline__ float4 big_slab_sum(const BigDims& d, const BigWs& ws, int b, int i0) {
+  float4 p4[kBigMaxSW];
+  const float* base = ws.part + (size_t)b * d.Np + i0;
+  const size_t slab = (size_t)d.Bp * d.Np;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) p4[s] = *(const float4*)(base + (size_t)min(s, d.P - 1) * slab);
+#pragma unroll
+  for (int s = 8; s < kBigMaxSW; ++s) p4[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (d.P > 8) {
+    asm volatile("" ::: "memory");   // (a real branch: not to be speculated into eight more loads per thread)
+#pragma unroll
+    for (int s = 8; s < kBigMaxSW; ++s) p4[s] = *(const float4*)(base + (size_t)min(s, d.P - 1) * slab);
+  }
+  float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int s = 0; s < kBigMaxSW; ++s) {
+    const bool on = s < d.P;
+    s4.x += on ? p4[s].x : 0.f; s4.y += on ? p4[s].y : 0.f; s4.z += on ? p4[s].z : 0.f; s4.w += on ? p4[s].w : 0.f;
+  }
+  return s4;
+}
+
 // ------------------------------------------------------------------ kernel 2 (forward)
 // grid (kBigParts, B): a_t[b][i] = x_t[b][i] + rowmax_i + log(sum_s part[s][b][i])   (t = 0: x_0)
 __global__ __launch_bounds__(256) void fcc_big_step(BigDims d, int t, const float* __restrict__ x, BigWs ws) {
+  // Every load of a quad is issued before the first use and none sits behind a lane predicate (labels past N read label
+  // N - 1 and are dropped by the stores' predicates): written with `if (i < N) { load; use; }` per element, hipcc waited
+  // for each element's loads in turn -- four dependent HBM round trips behind the slab loads in a kernel that is nothing
+  // but latency (6.7 us per frame; ISA in profiles/r05_fcc_step_isa_before.txt).
   __shared__ float sm[4];
   const int b = blockIdx.y, N = d.N;
   const int quads = (N + 3) >> 2;
@@ -841,35 +860,35 @@ __global__ __launch_bounds__(256) void fcc_big_step(BigDims d, int t, const floa
   float m = -INFINITY;
   for (int q = q0 + threadIdx.x; q < q1; q += 256) {
     const int i0 = 4 * q;
-    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xv[u] = xr[min(i0 + u, N - 1)];
+    float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 rm4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (t > 0) {
-      float4 p4[kBigMaxSW];  // all slab loads in flight together, added in worker order
-      const int np = (d.stepv & 1) ? d.P : ws.np[i0 / (32 * d.RT)];
-#pragma unroll
-      for (int s = 0; s < kBigMaxSW; ++s)
-        p4[s] = s < np ? *(const float4*)(ws.part + ((size_t)s * d.Bp + b) * d.Np + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int s = 0; s < kBigMaxSW; ++s) { s4.x += p4[s].x; s4.y += p4[s].y; s4.z += p4[s].z; s4.w += p4[s].w; }
+      rm4 = *(const float4*)(ws.rm + i0);   // [Np], Np >= i0 + 4
+      s4 = big_slab_sum(d, ws, b, i0);
     }
     const float ssum[4] = {s4.x, s4.y, s4.z, s4.w};
-    float a4[4];
+    const float rmv[4] = {rm4.x, rm4.y, rm4.z, rm4.w};
+    float a4[4], inv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float sc = fmaxf(ssum[u], 1e-37f);
+      inv[u] = 1.f / sc;
+      const float v = t > 0 ? xv[u] + (rmv[u] + __logf(sc)) : xv[u];
+      a4[u] = i0 + u < N ? v : -INFINITY;   // padding labels: exp(-inf - c) = 0 in the next operand
+      m = fmaxf(m, a4[u]);
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + u;
-      float v = -INFINITY;  // padding labels: exp(-inf - c) = 0 in the next operand
       if (i < N) {
-        v = xr[i];
-        if (t > 0) {
-          const float sc = fmaxf(ssum[u], 1e-37f);
-          v += ws.rm[i] + __logf(sc);
-          if (d.stepv & 4) __builtin_nontemporal_store(1.f / sc, &ir[i]);
-          else ir[i] = 1.f / sc;
-        }
-        if (d.stepv & 4) __builtin_nontemporal_store(v, &ar[i]);
-        else ar[i] = v;
+        // (nontemporal: no later frame of the pass reads them, and they should not displace the cached half of the
+        //  transition stream in the Infinity Cache)
+        if (t > 0) __builtin_nontemporal_store(inv[u], &ir[i]);
+        __builtin_nontemporal_store(a4[u], &ar[i]);
       }
-      a4[u] = v;
-      m = fmaxf(m, v);
     }
     *(float4*)(apk + packed_op_index(b, i0, d.NC)) = make_float4(a4[0], a4[1], a4[2], a4[3]);
   }
@@ -950,42 +969,44 @@ __global__ __launch_bounds__(kBigStepThreads) void fcc_big_bwd_init(BigDims d, c
 // step t -> t-1 (tm = t-1): e_tm = exp(a_tm - c_tm) (stored in place);
 // dalpha_tm[b][j] = e_tm[b][j] * sum_s part[s][b][j]
 __global__ __launch_bounds__(256) void fcc_big_bwd_step(BigDims d, int tm, float* __restrict__ dx, BigWs ws) {
+  // (loads first and unpredicated, as in fcc_big_step: the per-element `if (i < N)` form made eight dependent HBM round trips
+  //  of the a / 1 / s loads: 8.7 us per frame)
   const int b = blockIdx.y, N = d.N;
   const int i0 = 4 * (blockIdx.x * 256 + threadIdx.x);
   if (i0 >= N) return;
-  const float g = ws.gb[b];
-  const float c = (d.stepv & 2) ? ws.cfin[(size_t)tm * d.B + b] : big_cmax(ws.pmax, d.B, tm, b);
   float* er = ws.e + ((size_t)tm * d.B + b) * N;
   const float* ir = ws.invs + ((size_t)tm * d.B + b) * N;
   float* dxr = dx + ((size_t)b * d.T + tm) * N;
   float* rgr = ws.rg + ((size_t)tm * d.B + b) * N;
-  float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  {
-    float4 p4[kBigMaxSW];
-    const int np = (d.stepv & 1) ? d.P : ws.np[i0 / (32 * d.RT)];
+  float av[4], iv[4];
 #pragma unroll
-    for (int s = 0; s < kBigMaxSW; ++s)
-      p4[s] = s < np ? *(const float4*)(ws.part + ((size_t)s * d.Bp + b) * d.Np + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int s = 0; s < kBigMaxSW; ++s) { s4.x += p4[s].x; s4.y += p4[s].y; s4.z += p4[s].z; s4.w += p4[s].w; }
+  for (int u = 0; u < 4; ++u) {
+    const int ic = min(i0 + u, N - 1);
+    av[u] = er[ic];
+    iv[u] = ir[ic];
   }
-  const bool nt = (d.stepv & 4) != 0;
+  // (g and c are uniform: read through a lane-opaque zero they are VECTOR loads, in flight with the rest, instead of a chain of
+  //  scalar loads each waited for on its own)
+  int vz;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+  const float g = ws.gb[b + vz];
+  const float c = ws.cfin[(size_t)tm * d.B + b + vz];   // the frame's maximum, reduced once by fcc_big_loss (was: 16 partial maxima per thread)
+  const float4 s4 = big_slab_sum(d, ws, b, i0);
   const float D[4] = {s4.x, s4.y, s4.z, s4.w};
-  float r4[4];
+  float e4[4], da4[4], r4[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    e4[u] = __expf(av[u] - c);
+    da4[u] = e4[u] * D[u];
+    r4[u] = i0 + u < N && tm > 0 ? da4[u] * iv[u] : 0.f;
+  }
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int i = i0 + u;
-    r4[u] = 0.f;
     if (i < N) {
-      const float e = __expf(er[i] - c);
-      const float da = e * D[u];
-      if (nt) { __builtin_nontemporal_store(e, &er[i]); __builtin_nontemporal_store(g * da, &dxr[i]); }
-      else { er[i] = e; dxr[i] = g * da; }
-      if (tm > 0) {
-        r4[u] = da * ir[i];
-        if (nt) __builtin_nontemporal_store(g * r4[u], &rgr[i]);
-        else rgr[i] = g * r4[u];
-      }
+      __builtin_nontemporal_store(e4[u], &er[i]);
+      __builtin_nontemporal_store(g * da4[u], &dxr[i]);
+      if (tm > 0) __builtin_nontemporal_store(g * r4[u], &rgr[i]);
     }
   }
   if (tm > 0) *(float4*)(ws.ep[tm & 1] + packed_op_index(b, i0, d.NC)) = make_float4(r4[0], r4[1], r4[2], r4[3]);
@@ -1095,11 +1116,6 @@ static int big_pack(const BigDims& d, const BigWs& ws, const float* trans, bool 
   return W2L_OK;
 }
 
-__global__ __launch_bounds__(256) void big_pieces_k(BigDims d, int* __restrict__ np) {
-  const int g = blockIdx.x * 256 + threadIdx.x;
-  if (g < d.G) np[g] = big_pieces(d, g);
-}
-
 // packed operand buffers: forward operand a (padding must read as -inf -> exp = 0), backward r (padding 0)
 __global__ __launch_bounds__(256) void big_fill_k(float* __restrict__ p, size_t n, float v) {
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) p[e] = v;
@@ -1110,15 +1126,14 @@ int fcc_big_forward(int B, int T, int N, int scaleMode, const float* input, cons
   const BigDims d = big_dims(B, T, N);
   const BigWs ws = big_ws(workspace, d);
   hipLaunchKernelGGL(big_rowmax_k, dim3((unsigned)((d.Np + 3) / 4)), dim3(256), 0, s, N, d.Np, trans, ws.rm);
-  hipLaunchKernelGGL(big_pieces_k, dim3((unsigned)((d.G + 255) / 256)), dim3(256), 0, s, d, ws.np);
   W2L_LAUNCH_CHECK();
   int st = big_pack(d, ws, trans, false, s);
   if (st) return st;
   const size_t opFloats = 2 * align_up((size_t)d.Bp * d.Kp * sizeof(float), 256) / sizeof(float);
   hipLaunchKernelGGL(big_fill_k, dim3(512), dim3(256), 0, s, ws.ep[0], opFloats, -INFINITY);
   W2L_LAUNCH_CHECK();
-  // (stepv & 1) the step kernels add all P slabs of a row group: the ones its workers never write read as zero
-  if (d.stepv & 1) W2L_HIP_CHECK(hipMemsetAsync(ws.part, 0, (size_t)d.P * d.Bp * d.Np * sizeof(float), s));
+  // the step kernels add all P slabs of a row group: the ones its workers never write read as zero
+  W2L_HIP_CHECK(hipMemsetAsync(ws.part, 0, (size_t)d.P * d.Bp * d.Np * sizeof(float), s));
   const dim3 sgrid(kBigParts, (unsigned)B);
   const bool fold = big_fold_ok(d) && T > 1;
   if (fold) {
@@ -1153,10 +1168,10 @@ int fcc_big_backward(int B, int T, int N, const float* trans, const float* grad,
                      float* transGrad, void* workspace, hipStream_t s) {
   const BigDims d = big_dims(B, T, N);
   const BigWs ws = big_ws(workspace, d);
-  int st = big_pack(d, ws, trans, true, s);  // rm and the piece table are still valid from forward
+  int st = big_pack(d, ws, trans, true, s);  // rm and cfin are still valid from forward
   if (st) return st;
   W2L_HIP_CHECK(hipMemsetAsync(ws.ep[0], 0, 2 * align_up((size_t)d.Bp * d.Kp * sizeof(float), 256), s));
-  if (d.stepv & 1) W2L_HIP_CHECK(hipMemsetAsync(ws.part, 0, (size_t)d.P * d.Bp * d.Np * sizeof(float), s));
+  W2L_HIP_CHECK(hipMemsetAsync(ws.part, 0, (size_t)d.P * d.Bp * d.Np * sizeof(float), s));
   hipLaunchKernelGGL(fcc_big_bwd_init, dim3((unsigned)B), dim3(kBigStepThreads), 0, s, d, grad, inputGrad, ws);
   W2L_LAUNCH_CHECK();
   const dim3 sgrid((unsigned)((N + 1023) / 1024), (unsigned)B);

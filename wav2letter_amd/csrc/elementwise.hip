@@ -108,7 +108,9 @@ __global__ __launch_bounds__(kEwThreads) void ln_apply_k(const float* __restrict
 
 // Small groups (per-frame LayerNorm, axes {1,2}: inner = H*C <= kLnSmall): ONE block per group,
 // ONE pass -- the group is held in registers between the statistics and the apply.
-constexpr int kLnSmallV = (int)(kLnSmall / 4 / kEwThreads);  // float4 per thread
+constexpr int kLnSmallV = (int)(kLnSmall / 4 / kEwThreads);  // float4 per thread at most
+// NJ = the group's 16-byte chunks per thread, rounded up (the host picks the instance: a 2160-float frame takes 3, not 8)
+template <int NJ>
 __global__ __launch_bounds__(kEwThreads) void residual_ln_small_k(
     float* __restrict__ a, const float* __restrict__ x, float* __restrict__ r, float* __restrict__ y,
     float* __restrict__ meanRstd, size_t inner, const float* __restrict__ gammaBeta, float eps,
@@ -117,16 +119,28 @@ __global__ __launch_bounds__(kEwThreads) void residual_ln_small_k(
   const int g = blockIdx.x;
   const size_t base = (size_t)g * inner;
   const int n4 = (int)(inner >> 2);
-  float4 v[kLnSmallV];
+  // every load of the group before the first use, none behind a lane predicate (a chunk past the group re-reads its last
+  // chunk and is ignored): as `if (i < n4) { load; load; use; store }` per chunk, hipcc waited for each chunk's loads in turn
+  float4 v[NJ], avs[NJ], xvs[NJ];
+  const int lastc = n4 - 1;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) avs[j] = *(const float4*)(a + base + 4 * (size_t)min((int)threadIdx.x + j * kEwThreads, lastc));
+  if (x) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) xvs[j] = *(const float4*)(x + base + 4 * (size_t)min((int)threadIdx.x + j * kEwThreads, lastc));
+  } else {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) xvs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   double s = 0, ss = 0;
 #pragma unroll
-  for (int j = 0; j < kLnSmallV; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int i = threadIdx.x + j * kEwThreads;
     v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n4) {
       const size_t e = base + 4 * (size_t)i;
-      float4 av = *(const float4*)(a + e);
-      float4 rv = x ? *(const float4*)(x + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 av = avs[j];
+      float4 rv = xvs[j];
       if (thr) {
         av.x = keep_elem(e, seed, stream, thr) ? av.x * keepScale : 0.f;
         av.y = keep_elem(e + 1, seed, stream, thr) ? av.y * keepScale : 0.f;
@@ -151,7 +165,7 @@ __global__ __launch_bounds__(kEwThreads) void residual_ln_small_k(
   if (threadIdx.x == 0) { meanRstd[2 * g] = muf; meanRstd[2 * g + 1] = rstd; }
   const float gam = gammaBeta[0] * rstd, bet = gammaBeta[1];
 #pragma unroll
-  for (int j = 0; j < kLnSmallV; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int i = threadIdx.x + j * kEwThreads;
     if (i < n4) {
       float4 o = v[j];
@@ -257,6 +271,7 @@ __global__ __launch_bounds__(kEwThreads) void ln_bwd_apply_k(const float* __rest
 }
 
 // small groups: one block per group, r and dy held in registers between reduce and apply
+template <int NJ>
 __global__ __launch_bounds__(kEwThreads) void ln_bwd_small_k(const float* __restrict__ r, const float* __restrict__ dy,
                                                             const float* __restrict__ meanRstd,
                                                             double* __restrict__ sums,
@@ -270,16 +285,29 @@ __global__ __launch_bounds__(kEwThreads) void ln_bwd_small_k(const float* __rest
   const float mu = meanRstd[2 * g], rstd = meanRstd[2 * g + 1];
   const size_t base = (size_t)g * inner;
   const int n4 = (int)(inner >> 2);
-  float4 xh[kLnSmallV], dv[kLnSmallV];
+  // (loads first and unpredicated, as in residual_ln_small_k; the dropout mask source of the apply loop rides with them)
+  float4 xh[NJ], dv[NJ], mvs[NJ];
+  const int lastc = n4 - 1;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const size_t e = base + 4 * (size_t)min((int)threadIdx.x + j * kEwThreads, lastc);
+    xh[j] = *(const float4*)(r + e);
+    dv[j] = *(const float4*)(dy + e);
+  }
+  if (dmask) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) mvs[j] = *(const float4*)(maskSrc + base + 4 * (size_t)min((int)threadIdx.x + j * kEwThreads, lastc));
+  } else {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) mvs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   double s1 = 0, s2 = 0;
 #pragma unroll
-  for (int j = 0; j < kLnSmallV; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int i = threadIdx.x + j * kEwThreads;
-    xh[j] = dv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 rv = xh[j];
+    xh[j] = make_float4((rv.x - mu) * rstd, (rv.y - mu) * rstd, (rv.z - mu) * rstd, (rv.w - mu) * rstd);
     if (i < n4) {
-      float4 rv = *(const float4*)(r + base + 4 * (size_t)i);
-      dv[j] = *(const float4*)(dy + base + 4 * (size_t)i);
-      xh[j] = make_float4((rv.x - mu) * rstd, (rv.y - mu) * rstd, (rv.z - mu) * rstd, (rv.w - mu) * rstd);
       s1 += (double)((dv[j].x + dv[j].y) + (dv[j].z + dv[j].w));
       s2 += (double)((dv[j].x * xh[j].x + dv[j].y * xh[j].y) + (dv[j].z * xh[j].z + dv[j].w * xh[j].w));
     }
@@ -290,7 +318,7 @@ __global__ __launch_bounds__(kEwThreads) void ln_bwd_small_k(const float* __rest
   const float c1 = (float)(bc[0] / (double)inner), c2 = (float)(bc[1] / (double)inner);
   const float gr = gammaBeta[0] * rstd;
 #pragma unroll
-  for (int j = 0; j < kLnSmallV; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int i = threadIdx.x + j * kEwThreads;
     if (i < n4) {
       const size_t e = base + 4 * (size_t)i;
@@ -301,7 +329,7 @@ __global__ __launch_bounds__(kEwThreads) void ln_bwd_small_k(const float* __rest
       o.w = gr * (dv[j].w - c1 - xh[j].w * c2);
       *(float4*)(dr + e) = o;
       if (dmask) {
-        float4 mv = *(const float4*)(maskSrc + e);
+        const float4 mv = mvs[j];
         float4 d2;
         d2.x = mv.x > 0.f ? o.x * maskScale : 0.f;
         d2.y = mv.y > 0.f ? o.y * maskScale : 0.f;
@@ -646,8 +674,18 @@ W2L_API int w2l_residual_layernorm_forward(int groups, size_t inner, float* a, c
     return W2L_OK;
   }
   if (inner <= kLnSmall) {
-    hipLaunchKernelGGL(residual_ln_small_k, dim3((unsigned)groups), dim3(kEwThreads), 0, W2L_S, a, x, r, y, meanRstd,
-                       inner, gammaBeta, eps, thr, ks, seed, rngStream);
+    const int nj = (int)((inner / 4 + kEwThreads - 1) / kEwThreads);
+#define W2L_LN_FWD(NJ_)                                                                                                     \
+  case NJ_:                                                                                                                 \
+    hipLaunchKernelGGL(residual_ln_small_k<NJ_>, dim3((unsigned)groups), dim3(kEwThreads), 0, W2L_S, a, x, r, y, meanRstd,  \
+                       inner, gammaBeta, eps, thr, ks, seed, rngStream);                                                    \
+    break
+    switch (nj) {
+      W2L_LN_FWD(1); W2L_LN_FWD(2); W2L_LN_FWD(3); W2L_LN_FWD(4); W2L_LN_FWD(5); W2L_LN_FWD(6); W2L_LN_FWD(7);
+      default: hipLaunchKernelGGL(residual_ln_small_k<kLnSmallV>, dim3((unsigned)groups), dim3(kEwThreads), 0, W2L_S, a, x, r, y, meanRstd,
+                                  inner, gammaBeta, eps, thr, ks, seed, rngStream);
+    }
+#undef W2L_LN_FWD
     W2L_LAUNCH_CHECK();
     return W2L_OK;
   }
@@ -669,8 +707,18 @@ W2L_API int w2l_layernorm_backward(int groups, size_t inner, const float* r, con
   if (groups <= 0 || inner == 0 || (inner & 3) || !r || !dy || !gammaBeta || !meanRstd || !dr || !sums)
     return W2L_EINVAL;
   if (inner <= kLnSmall) {
-    hipLaunchKernelGGL(ln_bwd_small_k, dim3((unsigned)groups), dim3(kEwThreads), 0, W2L_S, r, dy, meanRstd, sums,
-                       gammaBeta, dr, maskSrc, maskSrc ? dmask : nullptr, maskScale, inner);
+    const int nj = (int)((inner / 4 + kEwThreads - 1) / kEwThreads);
+#define W2L_LN_BWD(NJ_)                                                                                                  \
+  case NJ_:                                                                                                              \
+    hipLaunchKernelGGL(ln_bwd_small_k<NJ_>, dim3((unsigned)groups), dim3(kEwThreads), 0, W2L_S, r, dy, meanRstd, sums,   \
+                       gammaBeta, dr, maskSrc, maskSrc ? dmask : nullptr, maskScale, inner);                             \
+    break
+    switch (nj) {
+      W2L_LN_BWD(1); W2L_LN_BWD(2); W2L_LN_BWD(3); W2L_LN_BWD(4); W2L_LN_BWD(5); W2L_LN_BWD(6); W2L_LN_BWD(7);
+      default: hipLaunchKernelGGL(ln_bwd_small_k<kLnSmallV>, dim3((unsigned)groups), dim3(kEwThreads), 0, W2L_S, r, dy, meanRstd, sums,
+                                  gammaBeta, dr, maskSrc, maskSrc ? dmask : nullptr, maskScale, inner);
+    }
+#undef W2L_LN_BWD
     W2L_LAUNCH_CHECK();
   } else {
     double* part = sums + 2 * (size_t)groups;

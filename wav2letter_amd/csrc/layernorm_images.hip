@@ -69,7 +69,8 @@ __device__ __forceinline__ void li_write_transposed(const uint32_t* tile, int pi
   }
 }
 
-template <bool BWD>
+// NJ = 16-byte chunks per lane (the host picks the smallest instance that holds the row)
+template <bool BWD, int NJ>
 __global__ __launch_bounds__(kLiThreads) void ln_rows_images_k(LiP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* tile = (uint32_t*)smem;                   // [16][inner + 8] bf16
@@ -95,16 +96,29 @@ __global__ __launch_bounds__(kLiThreads) void ln_rows_images_k(LiP p) {
     } else {
     const size_t base = (size_t)g * inner;
     if constexpr (!BWD) {
-      float4 v[kLiMaxV];
+      // every load of the row before the first use, none behind a lane predicate (a chunk past the row re-reads the row's last
+      // chunk and is ignored): as `if (i < n4) { load; load; use; store }` per chunk hipcc waited for each chunk's loads in
+      // turn -- one pair of 16-byte loads in flight per lane, 3.5 TB/s at 11968 x 2160 (profiles/r04_run24_ln_images_ab.log)
+      float4 v[NJ], avs[NJ], xvs[NJ];
+      const int lastc = n4 - 1;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) avs[j] = *(const float4*)(p.a + base + 4 * (size_t)min(lane + 64 * j, lastc));
+      if (p.x) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) xvs[j] = *(const float4*)(p.x + base + 4 * (size_t)min(lane + 64 * j, lastc));
+      } else {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) xvs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       double s = 0, ss = 0;
 #pragma unroll
-      for (int j = 0; j < kLiMaxV; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const int i = lane + 64 * j;
         v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < n4) {
           const size_t e = base + 4 * (size_t)i;
-          float4 av = *(const float4*)(p.a + e);
-          float4 rv = p.x ? *(const float4*)(p.x + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+          float4 av = avs[j];
+          float4 rv = xvs[j];
           if (p.thr) {
             av.x = keep_elem(e, p.seed, p.stream, p.thr) ? av.x * p.keepScale : 0.f;
             av.y = keep_elem(e + 1, p.seed, p.stream, p.thr) ? av.y * p.keepScale : 0.f;
@@ -130,7 +144,7 @@ __global__ __launch_bounds__(kLiThreads) void ln_rows_images_k(LiP p) {
       const float gam = p.gammaBeta[0] * rstd, bet = p.gammaBeta[1];
       uint16_t* irow = p.im.rowMajor ? p.im.rowMajor + (size_t)g * p.im.ldRows : nullptr;
 #pragma unroll
-      for (int j = 0; j < kLiMaxV; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const int i = lane + 64 * j;
         if (i < n4) {
           float4 o = v[j];
@@ -144,16 +158,28 @@ __global__ __launch_bounds__(kLiThreads) void ln_rows_images_k(LiP p) {
       }
     } else {
       const float mu = p.mr[2 * g], rstd = p.mr[2 * g + 1];
-      float4 xh[kLiMaxV], dv[kLiMaxV];
+      float4 xh[NJ], dv[NJ], mvs[NJ];
+      const int lastc = n4 - 1;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const size_t e = base + 4 * (size_t)min(lane + 64 * j, lastc);
+        xh[j] = *(const float4*)(p.rIn + e);
+        dv[j] = *(const float4*)(p.dy + e);
+      }
+      if (p.dmask) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) mvs[j] = *(const float4*)(p.maskSrc + base + 4 * (size_t)min(lane + 64 * j, lastc));
+      } else {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) mvs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       double s1 = 0, s2 = 0;
 #pragma unroll
-      for (int j = 0; j < kLiMaxV; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const int i = lane + 64 * j;
-        xh[j] = dv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 rv = xh[j];
+        xh[j] = make_float4((rv.x - mu) * rstd, (rv.y - mu) * rstd, (rv.z - mu) * rstd, (rv.w - mu) * rstd);
         if (i < n4) {
-          const float4 rv = *(const float4*)(p.rIn + base + 4 * (size_t)i);
-          dv[j] = *(const float4*)(p.dy + base + 4 * (size_t)i);
-          xh[j] = make_float4((rv.x - mu) * rstd, (rv.y - mu) * rstd, (rv.z - mu) * rstd, (rv.w - mu) * rstd);
           s1 += (double)((dv[j].x + dv[j].y) + (dv[j].z + dv[j].w));
           s2 += (double)((dv[j].x * xh[j].x + dv[j].y * xh[j].y) + (dv[j].z * xh[j].z + dv[j].w * xh[j].w));
         }
@@ -165,7 +191,7 @@ __global__ __launch_bounds__(kLiThreads) void ln_rows_images_k(LiP p) {
       const float gr = p.gammaBeta[0] * rstd;
       uint16_t* irow = p.im.rowMajor ? p.im.rowMajor + (size_t)g * p.im.ldRows : nullptr;
 #pragma unroll
-      for (int j = 0; j < kLiMaxV; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const int i = lane + 64 * j;
         if (i < n4) {
           const size_t e = base + 4 * (size_t)i;
@@ -176,7 +202,7 @@ __global__ __launch_bounds__(kLiThreads) void ln_rows_images_k(LiP p) {
           o.w = gr * (dv[j].w - c1 - xh[j].w * c2);
           if (!(p.abl & 8)) *(float4*)(p.dr + e) = o;
           if (p.dmask) {
-            const float4 mv = *(const float4*)(p.maskSrc + e);
+            const float4 mv = mvs[j];
             float4 d2;
             d2.x = mv.x > 0.f ? o.x * p.maskScale : 0.f;
             d2.y = mv.y > 0.f ? o.y * p.maskScale : 0.f;
@@ -217,12 +243,22 @@ static int li_launch(LiP p, hipStream_t s) {
   // (69 - 74 KB of LDS at the TDS widths: this library is gfx950-only -- 160 KB per CU, csrc/Makefile builds no other
   // target -- so the opt-in below cannot fail for want of LDS; a port to a 64 KB part would cap kLiMaxInner at 2040)
   const size_t shmem = (size_t)kLiRows * (p.inner + 8) * 2;
-  static const bool attr =
-      hipFuncSetAttribute((const void*)ln_rows_images_k<BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLiRows * (kLiMaxInner + 8) * 2)) == hipSuccess;
-  if (!attr) return W2L_EHIP;
   const int nrb = (p.groups + kLiRows - 1) / kLiRows;
   const int perXcd = ((nrb + 7) / 8 + 3) / 4 * 4;
-  hipLaunchKernelGGL((ln_rows_images_k<BWD>), dim3((unsigned)(8 * perXcd)), dim3(kLiThreads), shmem, s, p);
+  const int nj = (p.inner / 4 + 63) / 64;
+#define W2L_LI_LAUNCH(NJ_)                                                                                                       \
+  do {                                                                                                                           \
+    static const bool attr = hipFuncSetAttribute((const void*)ln_rows_images_k<BWD, NJ_>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                                 (int)(kLiRows * (kLiMaxInner + 8) * 2)) == hipSuccess;                          \
+    if (!attr) return W2L_EHIP;                                                                                                  \
+    hipLaunchKernelGGL((ln_rows_images_k<BWD, NJ_>), dim3((unsigned)(8 * perXcd)), dim3(kLiThreads), shmem, s, p);               \
+  } while (0)
+  if (nj <= 4) W2L_LI_LAUNCH(4);            // 1024 floats (the Transformer recipe)
+  else if (nj <= 5) W2L_LI_LAUNCH(5);       // 1200
+  else if (nj <= 6) W2L_LI_LAUNCH(6);       // 1520
+  else if (nj <= 8) W2L_LI_LAUNCH(8);       // 1840
+  else W2L_LI_LAUNCH(kLiMaxV);              // 2160
+#undef W2L_LI_LAUNCH
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }
