@@ -17,5 +17,7 @@ timeout 300 bash tools/prof.sh ${tag}_c5 tools/c5_step.py 3 bf16
 #  workloads and roofline.traffic was not the headline kernel's own bytes: round-4 verdict, evidence hygiene)
 timeout 500 bash tools/pmc.sh ${tag}_fetch "FETCH_SIZE" bench.py --steps 1 --warmup 0 --no-asg --no-c3 --no-c4 --no-c5 --stress-frames 40 $common
 timeout 500 bash tools/pmc.sh ${tag}_write "WRITE_SIZE" bench.py --steps 1 --warmup 0 --no-asg --no-c3 --no-c4 --no-c5 --stress-frames 40 $common
+# the RCCL path of the headline step with one rank (process group, bucketed reducer on the side stream, batch size through the arena's tail)
+(timeout 300 python bench.py --force-dist --steps 4 --warmup 2 --no-asg --no-stress --no-c4 --no-c3 --no-c5 $common) > gpurun_out/${tag}_bench_force_dist_1rank.log 2> gpurun_out/${tag}_bench_force_dist_1rank.err
 python tools/pmc_traffic.py gpurun_out/${tag}_fetch_pmc.csv gpurun_out/${tag}_write_pmc.csv gpurun_out/${tag}_pmc_traffic.json > /dev/null 2>&1
 echo done
