@@ -31,7 +31,6 @@ constexpr int kRowMaxPer = 48;  // register-resident row: N <= 256*48 = 12288
 
 struct CtcWs {
   float* lse;     // [B][T]
-  float* lp;      // [B][T][S]   (unused since the scans moved to the linear domain: the slot stays in the workspace layout)
   double* pd;     // [B][T][S]   exp(lp) in fp64, written by the row kernels through an integer / fraction split: a label
                   //             100+ nats below the row's normaliser keeps a finite probability (fp32 exp flushes below -87)
   double* alpha;  // [B][T][S]
@@ -60,7 +59,6 @@ __host__ __device__ inline CtcWs ctc_ws(void* ws, int B, int T, int N, int L) {
                     // p = 0, written by the row kernels), rows are 16-byte aligned: the scans move whole lanes with vector accesses
   char* p = (char*)ws;
   w.lse = (float*)p; p += align_up((size_t)B * T * sizeof(float), 256);
-  w.lp = (float*)p; p += align_up((size_t)B * T * w.S * sizeof(float), 256);
   w.pd = (double*)p; p += align_up((size_t)B * T * w.S * sizeof(double), 256);
   w.alpha = (double*)p; p += align_up((size_t)B * T * w.S * sizeof(double), 256);
   w.beta = (double*)p; p += align_up((size_t)B * T * w.S * sizeof(double), 256);
@@ -620,7 +618,7 @@ W2L_API int w2l_batch_ctc_target_size(int B, int L, int T, const int* target, in
 W2L_API size_t w2l_ctc_workspace_size(int B, int T, int N, int L) {
   if (B <= 0 || T <= 0 || N <= 0 || L < 0) return 0;
   size_t S = 64 * (size_t)ctc_positions_per_lane(L);
-  return align_up((size_t)B * T * sizeof(float), 256) + align_up((size_t)B * T * S * sizeof(float), 256) +
+  return align_up((size_t)B * T * sizeof(float), 256) +
          3 * align_up((size_t)B * T * S * sizeof(double), 256) + 2 * align_up((size_t)B * T * S * sizeof(int), 256) +
          align_up((size_t)B * sizeof(double), 256) + align_up((size_t)B * sizeof(int), 256) + 2 * align_up((size_t)B * sizeof(float), 256);
 }

@@ -680,21 +680,38 @@ void initDistributed(int worldRank, int worldSize, int maxDevicesPerNode, const 
   // removes whatever an earlier run left under the name before it publishes, and removes its own record once every rank
   // has joined (ncclCommInitRank is collective) -- so a `continue` / re-run with the same --rndv_filepath never picks up
   // the previous run's ncclUniqueId (which would hang ncclCommInitRank).
-  struct RndvRecord { unsigned long long magic; long long publishedNs; ncclUniqueId id; };
-  constexpr unsigned long long kRndvMagic = 0x7732'6c72'6e64'7631ull;   // "w2lrndv1"
+  // A launcher that can name its launch closes the remaining window (round-4 advice: a left-over record stays "unchanged for
+  // 30 s" too, and is accepted when THIS run's rank 0 starts more than 30 s late): `--rndv_filepath=<dir>#<launch id>` -- any text
+  // that is the same on every rank of one launch and differs between launches (a job id, rank 0's start time).  The record then
+  // carries a hash of it, readers take a record with their own launch id at once and no other, whatever its age.
+  struct RndvRecord { unsigned long long magic; long long publishedNs; unsigned long long launch; ncclUniqueId id; };
+  constexpr unsigned long long kRndvMagic = 0x7732'6c72'6e64'7632ull;   // "w2lrndv2"
+  std::string rndvDir = rndvFilepath;
+  unsigned long long launch = 0;   // 0 = no launch id given: the time rules below
+  {
+    const size_t h = rndvFilepath.rfind('#');
+    if (h != std::string::npos) {
+      rndvDir = rndvFilepath.substr(0, h);
+      launch = 1469598103934665603ull;   // FNV-1a of the id text (never 0 for a non-empty id; an empty id counts as none)
+      for (size_t i = h + 1; i < rndvFilepath.size(); ++i) launch = (launch ^ (unsigned char)rndvFilepath[i]) * 1099511628211ull;
+      if (h + 1 == rndvFilepath.size()) launch = 0;
+      else if (launch == 0) launch = 1;
+    }
+  }
   auto nowNs = [] { timespec ts; clock_gettime(CLOCK_REALTIME, &ts); return (long long)ts.tv_sec * 1000000000ll + ts.tv_nsec; };
   const long long startNs = nowNs();
   RndvRecord rec;
   std::memset(&rec, 0, sizeof rec);
   ncclUniqueId& id = rec.id;
-  const std::string path = rndvFilepath + "/w2l_nccl_id." + std::to_string(worldSize);
-  if (worldSize > 1 && rndvFilepath.empty()) throw std::invalid_argument("initDistributed: --rndv_filepath is needed for world_size > 1");
+  const std::string path = rndvDir + "/w2l_nccl_id." + std::to_string(worldSize);
+  if (worldSize > 1 && rndvDir.empty()) throw std::invalid_argument("initDistributed: --rndv_filepath is needed for world_size > 1");
   if (worldRank == 0) {
     ncclCheck(r.GetUniqueId(&id), "ncclGetUniqueId");
     if (worldSize > 1) {   // write to a temporary name, then rename: readers never see a partial file
       (void)unlink(path.c_str());   // a record left behind by a run that died during its rendezvous
       rec.magic = kRndvMagic;
       rec.publishedNs = nowNs();
+      rec.launch = launch;
       const std::string tmp = path + ".tmp";
       { std::ofstream f(tmp, std::ios::binary); f.write((const char*)&rec, sizeof rec); if (!f) throw std::runtime_error("cannot write " + tmp); }
       if (rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error("cannot publish " + path);
@@ -712,7 +729,9 @@ void initDistributed(int worldRank, int worldSize, int maxDevicesPerNode, const 
       RndvRecord in;
       if (f && f.read((char*)&in, sizeof in) && in.magic == kRndvMagic) {
         const long long now = nowNs();
-        if (in.publishedNs >= startNs - 120ll * 1000000000ll) {
+        if (launch != 0 || in.launch != 0) {
+          if (in.launch == launch) { rec = in; got = true; }   // (a record of another launch, or of a run without an id: keep waiting)
+        } else if (in.publishedNs >= startNs - 120ll * 1000000000ll) {
           rec = in; got = true;
         } else if (oldPublished == in.publishedNs && now - oldSince >= 30ll * 1000000000ll) {
           rec = in; got = true;

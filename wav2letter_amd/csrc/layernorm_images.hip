@@ -240,8 +240,9 @@ static bool li_sink_ok(const w2l_bf16_image_sink* s, int groups, size_t inner) {
 template <bool BWD>
 static int li_launch(LiP p, hipStream_t s) {
   { const char* e = tune_env("W2L_LI_ABL"); p.abl = e ? atoi(e) : 0; }
-  // (69 - 74 KB of LDS at the TDS widths: this library is gfx950-only -- 160 KB per CU, csrc/Makefile builds no other
-  // target -- so the opt-in below cannot fail for want of LDS; a port to a 64 KB part would cap kLiMaxInner at 2040)
+  // 69 - 74 KB of LDS at the TDS widths: more than the 64 KB a kernel gets without the opt-in below.  gfx950 has 160 KB per CU;
+  // where the opt-in fails (a part with a smaller LDS) the call returns W2L_EUNSUPPORTED and host/net.cpp's lnForward /
+  // lnBackward run LayerNorm + conversion instead (round-4 advice)
   const size_t shmem = (size_t)kLiRows * (p.inner + 8) * 2;
   const int nrb = (p.groups + kLiRows - 1) / kLiRows;
   const int perXcd = ((nrb + 7) / 8 + 3) / 4 * 4;
@@ -250,7 +251,7 @@ static int li_launch(LiP p, hipStream_t s) {
   do {                                                                                                                           \
     static const bool attr = hipFuncSetAttribute((const void*)ln_rows_images_k<BWD, NJ_>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                                  (int)(kLiRows * (kLiMaxInner + 8) * 2)) == hipSuccess;                          \
-    if (!attr) return W2L_EHIP;                                                                                                  \
+    if (!attr) { (void)hipGetLastError(); return W2L_EUNSUPPORTED; }   /* less LDS than the tile needs: the caller runs the plain kernels */ \
     hipLaunchKernelGGL((ln_rows_images_k<BWD, NJ_>), dim3((unsigned)(8 * perXcd)), dim3(kLiThreads), shmem, s, p);               \
   } while (0)
   if (nj <= 4) W2L_LI_LAUNCH(4);            // 1024 floats (the Transformer recipe)
