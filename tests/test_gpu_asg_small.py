@@ -92,12 +92,15 @@ def test_fac_lin_positions_per_lane_edges(oracle, L):
 
 @pytest.mark.parametrize("T,L,xscale,ascale", [(2000, 300, 1.0, 0.1), (2000, 120, 8.0, 0.5), (900, 310, 22.0, 1.0), (700, 64, 22.0, 2.0),
                                                (300, 299, 2.0, 0.5), (301, 300, 22.0, 0.5), (304, 300, 20.0, 0.5), (330, 300, 15.0, 3.0),
-                                               (301, 300, 60.0, 0.5), (304, 300, 60.0, 0.5), (1500, 7, 40.0, 3.0), (600, 200, 3.0, 12.0)])
+                                               (301, 300, 60.0, 0.5), (304, 300, 60.0, 0.5), (1500, 7, 40.0, 3.0), (600, 200, 3.0, 12.0),
+                                               (2000, 300, 1.0, 25.0), (600, 200, 3.0, 50.0), (2000, 64, 1.0, 100.0)])
 def test_fac_lin_magnitudes(oracle, T, L, xscale, ascale):
     """one exponent per lane, renormalised every 4 frames: tight alignments (T ~ L: the lattice front IS the path), emissions
     whose per-frame spread exceeds what one fp32 (or one shared) scale can hold (scale 22: ~130 bits per frame, inside the
     range the linear-domain kernel keeps exact); beyond kFacSafeBits (scale 40, 60; transition spreads of tens of nats) the
-    kernel flags the utterance and the log-domain kernel recomputes it -- the result must be right either way"""
+    kernel flags the utterance and the log-domain kernel recomputes it -- the result must be right either way.  Transition
+    rows 100+ nats wide (ascale 25 ... 100; round 5): kappa = exp(A[y_i][y_{i-1}] - A[y_{i-1}][y_{i-1}]) leaves the fp32 range --
+    taken with __expf it was 0 or inf and the loss of such an utterance -inf / NaN (tools/exp/asg_wide_transitions.py)"""
     from wav2letter_amd import ForceAlignmentCriterion
     rng = np.random.default_rng(T + L)
     B, N = 2, 30

@@ -39,6 +39,16 @@ constexpr int kFacLinChunk = 8;    // frames per chunk (prefetch, LDS label rows
 constexpr int kFacRenorm = 4;      // frames between two renormalisations (divides kFacLinChunk)
 constexpr int kFacDecay = 600;     // bits per lane WITH MASS in the exponent scan
 constexpr int kFacEmptyExp = -(1 << 30);
+// exp(d) as an fp64 value for any float d: the fraction by the fp32 exp2, the integer part by ldexp; exp(-inf) = 0.  (__expf is 0 /
+// inf beyond -87 / +88 nats: with transition rows that wide -- kappa is exp of a DIFFERENCE of two transitions -- a forced alignment
+// through such a step came out -inf / NaN while the log-domain reference stays finite: round 5, tools/exp/asg_wide_transitions.py)
+__device__ __forceinline__ double fac_exp_wide(float d) {
+  if (!(d > -INFINITY)) return d != d ? (double)d : 0.0;   // -inf -> 0 (position 0, positions beyond the target); NaN stays NaN
+  const double z = fmin(fmax((double)d * 1.4426950408889634, -1070.0), 1020.0);
+  const double zi = rint(z);
+  return __builtin_amdgcn_ldexp((double)__builtin_amdgcn_exp2f((float)(z - zi)), (int)zi);
+}
+
 constexpr float kFacSafeBits = 160.f;   // per-decision gain up to which the per-lane exponents are exact (tests/test_asg_linear_domain.py)
 
 // inclusive maximum scan over the 64 lanes (DPP row shifts + the two row broadcasts of a wave scan)
@@ -92,7 +102,7 @@ __global__ __launch_bounds__(64) void fac_fwd_lin(int T, int N, int L, int scale
     yi[p] = valid[p] ? y[i] : 0;
     const int yp = (valid[p] && i > 0) ? y[i - 1] : 0;
     const float dk = (valid[p] && i > 0) ? trans[(size_t)yi[p] * N + yp] - trans[(size_t)yp * N + yp] : NEG;
-    kap[p] = (double)__expf(dk);   // exp(-inf) = 0 for position 0 and beyond the target
+    kap[p] = fac_exp_wide(dk);   // exp(-inf) = 0 for position 0 and beyond the target
     h[p] = 0.0;
     if (valid[p] && i > 0) {
       const float kb = fabsf(dk) * L2E;
@@ -419,7 +429,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void fac_fwd_blin(int T, int N, int 
   const int yi = valid ? y[i] : 0;
   const int yp = (valid && i > 0) ? y[i - 1] : 0;
   const float dk = (valid && i > 0) ? trans[(size_t)yi * N + yp] - trans[(size_t)yp * N + yp] : NEG;
-  const double kap = (double)__expf(dk);   // 0 for position 0 and beyond the target
+  const double kap = fac_exp_wide(dk);   // 0 for position 0 and beyond the target
   double m = 0.0;
   int e = kFacEmptyExp;
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // row 0 is in sC[0]
@@ -524,7 +534,7 @@ __global__ __launch_bounds__(64 * NW) void fac_fwd_blin2(int T, int N, int L, in
   const int yi = valid ? y[i] : 0;
   const int yp = (valid && i > 0) ? y[i - 1] : 0;
   const float dk = (valid && i > 0) ? trans[(size_t)yi * N + yp] - trans[(size_t)yp * N + yp] : NEG;
-  const double kap = (double)__expf(dk);   // 0 for position 0 and beyond the target
+  const double kap = fac_exp_wide(dk);   // 0 for position 0 and beyond the target
   const double* cb = ws.crow + (size_t)b * T * 32 + yi;
   double cc[kFacBlinChunk], cn[kFacBlinChunk];
 #pragma unroll
@@ -662,7 +672,7 @@ __global__ __launch_bounds__(64 * NW) void fac_fwd_plin(int T, int N, int L, int
   const int yi = valid ? y[i] : 0;
   const int yp = (valid && i > 0) ? y[i - 1] : 0;
   const float dk = (valid && i > 0) ? trans[(size_t)yi * N + yp] - trans[(size_t)yp * N + yp] : NEG;
-  const double kap = (double)__expf(dk);   // 0 for position 0 and beyond the target
+  const double kap = fac_exp_wide(dk);   // 0 for position 0 and beyond the target
   const double* cb = ws.crow + (size_t)b * T * 32 + yi;
   double cc[kPlinChunk], cn[kPlinChunk];
 #pragma unroll
