@@ -349,6 +349,51 @@ def test_conv_fwd_bwd(oracle, B, Cin, Cout, H, T, kw, stride, padl, padr):
     assert rel(db, odb) < TOL
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_conv_random_geometries(oracle, seed):
+    """randomised geometries around the kernel switches of the TDS convolutions (round 5: block-Toeplitz kernels for C = 10 / 14 / 18
+    with H % 16 == 0, the strided layers between the stages and the one-channel first layer; everything else on the older
+    generations): any kw <= 21, any left / right padding that leaves at least one output frame, T from 1 frame, ragged batches"""
+    from wav2letter_amd import ops
+    rng = np.random.default_rng(1000 + seed)
+    for c in range(24):
+        kind = int(rng.integers(0, 5))
+        H = int(rng.choice([16, 32, 48, 80, 80, 5, 8, 24, 40]))
+        if kind == 0:
+            Cin = Cout = int(rng.choice([10, 14, 18])); stride = 1
+        elif kind == 1:
+            Cin, Cout = [(10, 14), (14, 18)][int(rng.integers(0, 2))]; stride = 2
+        elif kind == 2:
+            Cin, Cout, stride = 1, 10, 2
+        elif kind == 3:
+            Cin = Cout = int(rng.choice([10, 14, 18])); stride = 1; H = 16 * int(rng.integers(1, 6))
+        else:
+            Cin, Cout, stride = int(rng.integers(1, 20)), int(rng.integers(1, 20)), int(rng.integers(1, 4))
+        kw = int(rng.choice([21, 21, 21, 9, 1, 2, 5, 11, 20]))
+        padl = int(rng.integers(0, kw))
+        padr = int(rng.integers(0, kw))
+        B = int(rng.integers(1, 5))
+        T = int(rng.choice([1, 2, 3, 7, 23, 24, 25, 47, 48, 49, 96, 97, 130, 200]))
+        if (T + padl + padr - kw) // stride + 1 < 1:
+            padr = kw - 1; padl = kw - 1
+        x = rng.normal(size=(B, Cin, H, T)).astype(np.float32)
+        w = (rng.normal(size=(Cout, Cin, kw)) / np.sqrt(Cin * kw)).astype(np.float32)
+        b = rng.normal(size=Cout).astype(np.float32)
+        what = f"case {c}: B={B} Cin={Cin} Cout={Cout} H={H} T={T} kw={kw} stride={stride} padl={padl} padr={padr}"
+        y_ref = oracle.conv_fwd(x, w, b, stride, padl, padr)
+        xd, wd = dev(to_fm(x)), dev(w_to_dev(w))
+        y = ops.conv_forward(xd, wd, dev(b), stride, padl, padr)
+        assert rel(from_fm(y.cpu().numpy()), y_ref) < TOL, what
+        yr = ops.conv_forward(xd, wd, dev(b), stride, padl, padr, relu=True)
+        assert rel(from_fm(yr.cpu().numpy()), np.maximum(y_ref, 0)) < TOL, what
+        dy = rng.normal(size=y_ref.shape).astype(np.float32)
+        odx, odw, odb = oracle.conv_bwd(x, w, dy, stride, padl, padr)
+        dx, dw, db = ops.conv_backward(xd, wd, dev(to_fm(dy)), stride, padl, padr)
+        assert rel(from_fm(dx.cpu().numpy()), odx) < TOL, what
+        assert rel(dw.cpu().numpy(), w_to_dev(odw)) < TOL, what
+        assert rel(db, odb) < TOL, what
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H,T,kw,stride,padl,padr", [(2, 10, 14, 32, 61, 21, 2, 10, 10), (1, 14, 18, 16, 40, 21, 2, 10, 10),
                                                                 (1, 10, 10, 16, 47, 7, 3, 2, 3), (1, 10, 10, 16, 40, 21, 1, 10, 10),
                                                                 (2, 40, 100, 1, 60, 13, 1, 0, 0), (2, 33, 70, 1, 45, 4, 1, 2, 1)])
@@ -524,7 +569,9 @@ def test_golden_conv1d_on_device():
     assert np.abs(y.cpu().numpy().reshape(-1) - np.array(g["target"])).max() < 2e-3
 
 
-@pytest.mark.parametrize("B,inner", [(3, 4 * 1237), (37, 1440), (5, 8192), (2, 4 * 40001)])
+@pytest.mark.parametrize("B,inner", [(3, 4 * 1237), (37, 1440), (5, 8192), (2, 4 * 40001),
+                                     # every chunks-per-thread instance of the one-pass kernels (round 5): 1 ... 8 x 1024 floats, ragged last chunk
+                                     (7, 4), (6, 1028), (5, 2800), (4, 4000), (3, 5600), (3, 6800), (2, 8188)])
 @pytest.mark.parametrize("p", [0.0, 0.25])
 def test_residual_dropout_layernorm(oracle, p, B, inner):
     """utterance-sized groups (two-level deterministic reduction) and frame-sized groups (one-pass kernel)"""
@@ -1024,7 +1071,8 @@ def test_bf16_convert_with_dropout_mask(rows, cols, p):
     assert torch.equal(g0_r.view(torch.int16), plain_r.view(torch.int16)) and torch.equal(g0_t.view(torch.int16), plain_t.view(torch.int16))
 
 
-@pytest.mark.parametrize("groups,inner", [(1500, 1200), (37, 2160), (50, 1024), (3, 2304), (17, 8), (16, 64)])
+@pytest.mark.parametrize("groups,inner", [(1500, 1200), (37, 2160), (50, 1024), (3, 2304), (17, 8), (16, 64),
+                                          (20, 1520), (21, 1840), (9, 300), (33, 1284)])   # the other chunks-per-lane instances
 @pytest.mark.parametrize("p", [0.0, 0.2])
 def test_layernorm_writes_the_bf16_images_of_its_result(groups, inner, p):
     """w2l_residual_layernorm_forward_images / w2l_layernorm_backward_images (layernorm_images.hip: 16 rows per workgroup, the
