@@ -349,6 +349,43 @@ def test_conv_fwd_bwd(oracle, B, Cin, Cout, H, T, kw, stride, padl, padr):
     assert rel(db, odb) < TOL
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_gemm_and_linear_random_shapes(seed):
+    """randomised shapes around the tile / schedule switches of the fp32 GEMM (128 / 160-wide tiles, stream-K tails, the dword and
+    scalar epilogues of unaligned N, K not a multiple of the 32-deep K tile, single rows / columns) in all four operand layouts,
+    with bias / ReLU epilogues, and fl::Linear forward + backward on the same shapes, against float64"""
+    from wav2letter_amd import ops
+    rng = np.random.default_rng(4242 + seed)
+    g = torch.Generator(device="cpu").manual_seed(99 + seed)
+    sizes = [1, 2, 3, 5, 17, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 159, 160, 161, 255, 256, 257, 320, 500, 513, 1000, 1440, 2047]
+    for c in range(30):
+        M, N, K = (int(rng.choice(sizes)) for _ in range(3))
+        if c % 5 == 0:
+            M = int(rng.choice([3000, 6016, 4097]))      # several rounds of tiles + a stream-K tail
+        akc, bkc = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        A = torch.randn((M, K) if akc else (K, M), generator=g)
+        Bm = torch.randn((N, K) if bkc else (K, N), generator=g)
+        bias = torch.randn(N, generator=g) if rng.integers(0, 2) else None
+        relu = bool(rng.integers(0, 2))
+        want = (A.double() if akc else A.double().t()) @ (Bm.double().t() if bkc else Bm.double())
+        if bias is not None:
+            want = want + bias.double()
+        if relu:
+            want = want.clamp_min(0)
+        got = ops.gemm(A.cuda(), Bm.cuda(), akc, bkc, None if bias is None else bias.cuda(), relu)
+        what = f"case {c}: M={M} N={N} K={K} a_kcontig={akc} b_kcontig={bkc} bias={bias is not None} relu={relu}"
+        assert rel(got, want.numpy()) < TOL, what
+        # fl::Linear on the same sizes: y = x w + b, dx = dy w^T, dw = x^T dy, db = column sums
+        x = torch.randn(M, K, generator=g); w = torch.randn(K, N, generator=g) / K ** 0.5; dy = torch.randn(M, N, generator=g)
+        y = ops.linear_forward(x.cuda(), w.cuda(), None if bias is None else bias.cuda(), relu)
+        yw = x.double() @ w.double() + (0 if bias is None else bias.double())
+        assert rel(y, (yw.clamp_min(0) if relu else yw).numpy()) < TOL, what
+        dx, dw, db = ops.linear_backward(x.cuda(), w.cuda(), dy.cuda())
+        assert rel(dx, (dy.double() @ w.double().t()).numpy()) < TOL, what
+        assert rel(dw, (x.double().t() @ dy.double()).numpy()) < TOL, what
+        assert rel(db, dy.double().sum(0).numpy()) < TOL, what
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_conv_random_geometries(oracle, seed):
     """randomised geometries around the kernel switches of the TDS convolutions (round 5: block-Toeplitz kernels for C = 10 / 14 / 18

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np
 import torch
 from oracle import pyoracle as O
-from wav2letter_amd import CTCLoss, ForceAlignmentCriterion, FullConnectionCriterion
+from wav2letter_amd import ASGLoss, CTCLoss, ForceAlignmentCriterion, FullConnectionCriterion
 
 def rel(got, want):
     want = np.asarray(want, np.float64); got = np.asarray(got, np.float64)
@@ -60,6 +60,18 @@ def run(cases, seed, x_scales=(0.1, 1.0, 5.0, 20.0, 50.0), a_scales=(0.0, 0.3, 2
             flag = "" if max(el, ex, ea) < 1e-3 else " BAD"
             bad += bool(flag)
             line += f" {name} {el:.1e}/{ex:.1e}/{ea:.1e}{flag}"
+        # Viterbi paths: bit-exact (the free path of ASGLoss::viterbiPath and the forced alignment)
+        asg = ASGLoss(N, mode, 0.0).cuda()
+        asg.transitions.data = torch.from_numpy(A).cuda()
+        vp = asg.viterbiPath(torch.from_numpy(x).cuda()).cpu().numpy()
+        okv = bool((vp == O.viterbi(x, A)).all())
+        fac = ForceAlignmentCriterion(N, mode).cuda()
+        fac.transitions.data = torch.from_numpy(A).cuda()
+        fp = fac.viterbiPath(torch.from_numpy(x).cuda(), torch.from_numpy(tgt).cuda()).cpu().numpy()
+        okf_ = bool((fp == O.FAC(x, A, tgt, scale_mode=mode).viterbi()).all())
+        if not (okv and okf_):
+            bad += 1
+            line += f" VITERBI free {okv} forced {okf_} BAD"
         # CTC: N includes the blank (last index); targets without the blank
         if N >= 2 and T >= 1:
             tg = np.where(tgt >= 0, np.minimum(tgt, N - 2), -1).astype(np.int32)
