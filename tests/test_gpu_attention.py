@@ -494,3 +494,22 @@ def test_padding_mask_key_lengths_and_masked_softmax(Tin, Tk):
     ref = torch.softmax((S.double() * 0.5).masked_fill(pad[:, None, None, :], float("-inf")), -1)
     assert rel(P.cpu().numpy(), ref.numpy()) < TOL
     assert (P.cpu()[pad[:, None, None, :].expand_as(P)] == 0).all()
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fused_attention_random_geometries(seed):
+    """the two tests above over random batch / head / frame counts (T = 1 ... 200, on and off the 4- and 16-frame tile edges), both
+    head widths the fused kernels hold, tables shorter and longer than the sequence, with and without dropout and ragged key lengths"""
+    rng = np.random.default_rng(700 + seed)
+    for c in range(10):
+        B, H = int(rng.integers(1, 4)), int(rng.integers(1, 5))
+        T = int(rng.choice([1, 2, 3, 15, 16, 17, 31, 33, 63, 64, 65, 100, 127, 129, 188, 191, 192]))   # (the fused kernels hold T <= 192)
+        d = int(rng.choice([32, 256]))
+        csz = int(rng.choice([0, 1, 2, 7, 40, 200, 460]))
+        p = float(rng.choice([0.0, 0.2]))
+        ragged = bool(rng.integers(0, 2))
+        try:
+            test_fused_attention_forward(B, H, T, d, csz, p, ragged)
+            test_fused_attention_backward(B, H, T, d, csz, p, ragged)
+        except AssertionError as e:
+            raise AssertionError(f"case {c}: B={B} H={H} T={T} d={d} csz={csz} p={p} ragged={ragged}: {e}") from e
