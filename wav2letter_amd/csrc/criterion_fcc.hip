@@ -238,6 +238,113 @@ __global__ __launch_bounds__(64) void fcc_bwd_small(int T, int N, const float* _
   if (act) dxb[lane] = g * da;
 }
 
+// ---------------------------------------------------------------- the log-domain pair behind the N <= 31 scans (round 5)
+// The utterances the linear-domain scans flag (transition rows more than 30 nats wide) used to re-run on fcc_*_small above,
+// which are scaled-exp recursions too -- exp(A - rowmax) and exp(alpha - c_t) as separate fp32 factors, a floor of 1e-37 under
+// the sums -- and clamp a state that is more than ~87 nats behind: with emissions AND transitions tens of nats wide the posterior
+// moved to another path (loss within 1e-4, gradients off by O(1): profiles/r05_run32_criterion_fuzz.log).  These two evaluate
+// every term as ONE exponential of a sum that is <= 0 by construction, as the reference's recursion does:
+//   L_t[i]  = log sum_j exp(ahat_{t-1}[j] + A[i][j])  (max over j first),      alpha_t[i] = x_t[i] + L_t[i],  ahat = alpha - c_t
+//   w_t[i][j] = exp(ahat_{t-1}[j] + A[i][j] - L_t[i]) in (0, 1],   dalpha_{t-1}[j] = sum_i dalpha_t[i] w_t[i][j],
+//   dA[i][j] = sum_t dalpha_t[i] w_t[i][j]   (accumulated by the same loop: no r_t hand-over to the fcc_dtrans kernels).
+// One wave per flagged utterance, lane = state, N <= 32; `ahat` and `logs` (= L_t) keep the workspace meaning of the other kernels.
+__global__ __launch_bounds__(64) void fcc_fwd_log(int T, int N, int scaleMode, const float* __restrict__ x,
+                                                  const int* __restrict__ targetSize, const float* __restrict__ trans,
+                                                  float* __restrict__ loss, FccWs ws) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (!ws.redo[b]) return;
+  const bool act = lane < N;
+  const float NEG = -INFINITY;
+  float Ar[32];   // row `lane` of the transitions
+#pragma unroll
+  for (int j = 0; j < 32; ++j) Ar[j] = (act && j < N) ? trans[(size_t)lane * N + j] : NEG;
+  const float* xb = x + (size_t)b * T * N;
+  float* ahb = ws.ahat + (size_t)b * T * N;
+  float* lsb = ws.logs + (size_t)b * T * N;
+  float ah = 0.f;
+  double C = 0.0;
+  float xc = act ? xb[lane] : 0.f;
+  for (int t = 0; t < T; ++t) {
+    const float xn = (act && t + 1 < T) ? xb[(size_t)(t + 1) * N + lane] : 0.f;
+    float a, L = 0.f;
+    if (t == 0) {
+      a = act ? xc : NEG;
+    } else {
+      float v[32];
+      float m = NEG;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) { v[j] = readlane(ah, j) + Ar[j]; m = fmaxf(m, v[j]); }   // (-inf for j >= N and for dead states)
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) sum += fast_expf(v[j] - m);   // every term <= 1, the maximum's is 1
+      L = m + fast_logf(sum);
+      a = act && m > NEG ? xc + L : NEG;
+    }
+    const float c = wave_max_rows<2>(a);
+    ah = a - c;
+    C += (double)c;
+    if (act) {
+      ahb[(size_t)t * N + lane] = ah;
+      lsb[(size_t)t * N + lane] = L;
+    }
+    xc = xn;
+  }
+  const float e = act ? __expf(ah) : 0.f;
+  const float tot = wave_sum(e);
+  const float sc = scale_of(scaleMode, T, targetSize[b]);
+  if (lane == 0) {
+    loss[b] = (float)((double)sc * (C + (double)__logf(tot)));
+    ws.scale[b] = sc;
+  }
+}
+
+__global__ __launch_bounds__(64) void fcc_bwd_log(int T, int N, const float* __restrict__ trans, const float* __restrict__ grad,
+                                                  float* __restrict__ inputGrad, FccWs ws) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (!ws.redo[b]) return;
+  const bool act = lane < N;
+  const float NEG = -INFINITY;
+  float Ac[32];   // column `lane` of the transitions: Ac[i] = A[i][lane]
+#pragma unroll
+  for (int i = 0; i < 32; ++i) Ac[i] = (act && i < N) ? trans[(size_t)i * N + lane] : NEG;
+  const float* ahb = ws.ahat + (size_t)b * T * N;
+  const float* lsb = ws.logs + (size_t)b * T * N;
+  float* dxb = inputGrad + (size_t)b * T * N;
+  const float g = ws.scale[b] * grad[b];
+  float acc[32];   // acc[i] = sum_t dalpha_t[i] w_t[i][lane]
+#pragma unroll
+  for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+  const float e = act ? __expf(ahb[(size_t)(T - 1) * N + lane]) : 0.f;
+  float da = e / wave_sum(e);   // d loss / d alpha_{T-1} = softmax(ahat_{T-1})
+  const int li = act ? lane : 0;
+  float Lt = lsb[(size_t)(T - 1) * N + li];                    // L_t[i] in lane i
+  float ap = T >= 2 ? ahb[(size_t)(T - 2) * N + li] : NEG;    // ahat_{t-1}[j] in lane j (= this lane)
+  for (int t = T - 1; t >= 1; --t) {
+    // the next frame's rows first (unpredicated, clamped): they land under this frame's 32 exponentials
+    const float Ln = lsb[(size_t)max(t - 1, 0) * N + li];
+    const float an = ahb[(size_t)max(t - 2, 0) * N + li];
+    if (act) dxb[(size_t)t * N + lane] = g * da;
+    const float apj = act ? ap : NEG;
+    float nd = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const float di = readlane(da, i);
+      const float w = fast_expf(apj + Ac[i] - readlane(Lt, i));   // w_t[i][lane]; exp(-inf) = 0 for i >= N, dead states
+      const float dw = di > 0.f ? di * w : 0.f;                   // (0 x anything: a state without posterior mass hands nothing on)
+      acc[i] += dw;
+      nd += dw;
+    }
+    da = nd;
+    Lt = Ln; ap = an;
+  }
+  if (act) dxb[lane] = g * da;
+  // the transition-gradient partial of this utterance: time chunk 0 (the fcc_dtrans kernels zero the other chunks of a flagged utterance)
+  float* tg = ws.tgpart + (size_t)b * kDtChunks * N * N;
+#pragma unroll
+  for (int i = 0; i < 32; ++i)
+    if (act && i < N) tg[(size_t)i * N + lane] = g * acc[i];
+}
+
 // transition gradient of one (utterance, time chunk): part[i][j] = g * EA[i][j] * sum_{t in chunk} r_t[i] e_{t-1}[j]
 // lane = j; r_t (left in the log-s slots by the scan) is broadcast per i.  No dependence between steps.
 // LIN: the workspace of the DPP scans -- `ahat` holds u_t itself (scaled linear domain), r_t = b_t q_t.
@@ -245,9 +352,16 @@ template <int NP, bool LIN = false>
 __global__ __launch_bounds__(64) void fcc_dtrans_small(int T, int N, const float* __restrict__ trans,
                                                        const float* __restrict__ grad, FccWs ws) {
   const int b = blockIdx.x, c = blockIdx.y;
-  const bool lin = LIN && !ws.redo[b];   // a flagged utterance ran on the log-domain kernels
+  const bool lin = LIN;
   const int lane = threadIdx.x;
   const bool act = lane < N;
+  if (LIN && ws.redo[b]) {   // a flagged utterance ran on fcc_fwd_log / fcc_bwd_log: its whole transition gradient is in chunk 0
+    if (c > 0 && act) {
+      float* tz = ws.tgpart + ((size_t)b * kDtChunks + c) * N * N;
+      for (int i = 0; i < N; ++i) tz[(size_t)i * N + lane] = 0.f;
+    }
+    return;
+  }
   const float* ahb = ws.ahat + (size_t)b * T * N;
   const float* rb = ws.r + (size_t)b * T * N;
   const int per = (T - 1 + kDtChunks - 1) / kDtChunks;
@@ -287,9 +401,16 @@ __global__ __launch_bounds__(64) void fcc_dtrans_small(int T, int N, const float
 __global__ __launch_bounds__(64) void fcc_dtrans_mfma(int T, int N, const float* __restrict__ trans, const float* __restrict__ grad, FccWs ws) {
   typedef float f32x16_t __attribute__((ext_vector_type(16)));
   const int b = blockIdx.x, c = blockIdx.y;
-  const bool lin = !ws.redo[b];   // a flagged utterance ran on the log-domain kernels: `ahat` holds logarithms there
+  const bool lin = true;
   const int lane = threadIdx.x, li = lane & 31, lh = lane >> 5;
   const bool act = li < N;
+  if (ws.redo[b]) {   // a flagged utterance ran on fcc_fwd_log / fcc_bwd_log: its whole transition gradient is in chunk 0
+    if (c > 0 && lane < N) {
+      float* tz = ws.tgpart + ((size_t)b * kDtChunks + c) * N * N;
+      for (int i = 0; i < N; ++i) tz[(size_t)i * N + lane] = 0.f;
+    }
+    return;
+  }
   const float* ahb = ws.ahat + (size_t)b * T * N;
   const float* rb = ws.r + (size_t)b * T * N;
   const int per = (T - 1 + kDtChunks - 1) / kDtChunks;
@@ -523,7 +644,7 @@ W2L_API int w2l_fcc_forward(int B, int T, int N, int scaleMode, const float* inp
     else hipLaunchKernelGGL(fcc_fwd_dpp2, dim3(B), dim3(128), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws);
     W2L_LAUNCH_CHECK();
     // the log-domain kernel for the utterances fcc_fwd_dpp flagged (returns at once for the others)
-    hipLaunchKernelGGL(fcc_fwd_small<32>, dim3(B), dim3(64), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws, (const int*)ws.redo);
+    hipLaunchKernelGGL(fcc_fwd_log, dim3(B), dim3(64), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws);
   } else if (N <= 32)
     hipLaunchKernelGGL(fcc_fwd_small<32>, dim3(B), dim3(64), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws);
   else
@@ -549,7 +670,7 @@ W2L_API int w2l_fcc_backward(int B, int T, int N, const float* trans, const floa
     if (oneWave) hipLaunchKernelGGL(fcc_bwd_dpp, dim3(B), dim3(64), 0, s, T, N, trans, grad, inputGrad, ws);
     else hipLaunchKernelGGL(fcc_bwd_dpp2, dim3(B), dim3(128), 0, s, T, N, trans, grad, inputGrad, ws);
     W2L_LAUNCH_CHECK();
-    hipLaunchKernelGGL(fcc_bwd_small<32>, dim3(B), dim3(64), 0, s, T, N, trans, grad, inputGrad, ws, (const int*)ws.redo);
+    hipLaunchKernelGGL(fcc_bwd_log, dim3(B), dim3(64), 0, s, T, N, trans, grad, inputGrad, ws);
   } else if (N <= 32)
     hipLaunchKernelGGL(fcc_bwd_small<32>, dim3(B), dim3(64), 0, s, T, N, trans, grad, inputGrad, ws);
   else
