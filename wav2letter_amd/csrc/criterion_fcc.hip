@@ -263,31 +263,48 @@ __global__ __launch_bounds__(64) void fcc_fwd_log(int T, int N, int scaleMode, c
   float* lsb = ws.logs + (size_t)b * T * N;
   float ah = 0.f;
   double C = 0.0;
-  float xc = act ? xb[lane] : 0.f;
-  for (int t = 0; t < T; ++t) {
-    const float xn = (act && t + 1 < T) ? xb[(size_t)(t + 1) * N + lane] : 0.f;
-    float a, L = 0.f;
-    if (t == 0) {
-      a = act ? xc : NEG;
-    } else {
-      float v[32];
-      float m = NEG;
+  // frames in chunks of kChunk as in fcc_fwd_small: the next chunk's emissions are loaded at the top of a chunk and consumed at its
+  // end, so that no frame waits on the memory counter (which also holds the frames' stores)
+  float xc[kChunk], xn[kChunk];
 #pragma unroll
-      for (int j = 0; j < 32; ++j) { v[j] = readlane(ah, j) + Ar[j]; m = fmaxf(m, v[j]); }   // (-inf for j >= N and for dead states)
-      float sum = 0.f;
+  for (int u = 0; u < kChunk; ++u) xc[u] = (act && u < T) ? xb[(size_t)u * N + lane] : 0.f;
+  for (int t0 = 0; t0 < T; t0 += kChunk) {
 #pragma unroll
-      for (int j = 0; j < 32; ++j) sum += fast_expf(v[j] - m);   // every term <= 1, the maximum's is 1
-      L = m + fast_logf(sum);
-      a = act && m > NEG ? xc + L : NEG;
+    for (int u = 0; u < kChunk; ++u) {
+      const int tn = t0 + kChunk + u;
+      xn[u] = (act && tn < T) ? xb[(size_t)tn * N + lane] : 0.f;
     }
-    const float c = wave_max_rows<2>(a);
-    ah = a - c;
-    C += (double)c;
-    if (act) {
-      ahb[(size_t)t * N + lane] = ah;
-      lsb[(size_t)t * N + lane] = L;
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) {
+      const int t = t0 + u;
+      if (t < T) {   // wave-uniform
+        float a, L = 0.f;
+        if (t == 0) {
+          a = act ? xc[u] : NEG;
+        } else {
+          float v[32];
+          float m = NEG;
+#pragma unroll
+          for (int j = 0; j < 32; ++j) { v[j] = readlane(ah, j) + Ar[j]; m = fmaxf(m, v[j]); }   // (-inf for j >= N and for dead states)
+          float sum = 0.f;
+#pragma unroll
+          for (int j = 0; j < 32; ++j) sum += fast_expf(v[j] - m);   // every term <= 1, the maximum's is 1
+          L = m + fast_logf(sum);
+          a = act && m > NEG ? xc[u] + L : NEG;
+        }
+        const float c = wave_max_rows<2>(a);
+        ah = a - c;
+        C += (double)c;
+        if (act) {
+          ahb[(size_t)t * N + lane] = ah;
+          lsb[(size_t)t * N + lane] = L;
+        }
+      }
     }
-    xc = xn;
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) asm volatile("" : "+v"(xn[u]));
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) xc[u] = xn[u];
   }
   const float e = act ? __expf(ah) : 0.f;
   const float tot = wave_sum(e);
@@ -317,25 +334,50 @@ __global__ __launch_bounds__(64) void fcc_bwd_log(int T, int N, const float* __r
   const float e = act ? __expf(ahb[(size_t)(T - 1) * N + lane]) : 0.f;
   float da = e / wave_sum(e);   // d loss / d alpha_{T-1} = softmax(ahat_{T-1})
   const int li = act ? lane : 0;
-  float Lt = lsb[(size_t)(T - 1) * N + li];                    // L_t[i] in lane i
-  float ap = T >= 2 ? ahb[(size_t)(T - 2) * N + li] : NEG;    // ahat_{t-1}[j] in lane j (= this lane)
-  for (int t = T - 1; t >= 1; --t) {
-    // the next frame's rows first (unpredicated, clamped): they land under this frame's 32 exponentials
-    const float Ln = lsb[(size_t)max(t - 1, 0) * N + li];
-    const float an = ahb[(size_t)max(t - 2, 0) * N + li];
-    if (act) dxb[(size_t)t * N + lane] = g * da;
-    const float apj = act ? ap : NEG;
-    float nd = 0.f;
+  // chunks of kChunk steps from the top frame (as fcc_bwd_small): step t needs L_t (lane i) and ahat_{t-1} (lane j)
+  float lc[kChunk], ac[kChunk], ln[kChunk], an[kChunk];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const float di = readlane(da, i);
-      const float w = fast_expf(apj + Ac[i] - readlane(Lt, i));   // w_t[i][lane]; exp(-inf) = 0 for i >= N, dead states
-      const float dw = di > 0.f ? di * w : 0.f;                   // (0 x anything: a state without posterior mass hands nothing on)
-      acc[i] += dw;
-      nd += dw;
+  for (int u = 0; u < kChunk; ++u) {
+    const int t = T - 1 - u;
+    lc[u] = lsb[(size_t)max(t, 0) * N + li];
+    ac[u] = ahb[(size_t)max(t - 1, 0) * N + li];
+  }
+  for (int thi = T - 1; thi >= 1; thi -= kChunk) {
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) {
+      const int t = thi - kChunk - u;
+      ln[u] = lsb[(size_t)max(t, 0) * N + li];
+      an[u] = ahb[(size_t)max(t - 1, 0) * N + li];
     }
-    da = nd;
-    Lt = Ln; ap = an;
+    float dxs[kChunk];
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) {
+      const int t = thi - u;
+      dxs[u] = 0.f;
+      if (t >= 1) {   // wave-uniform
+        dxs[u] = g * da;
+        const float apj = act ? ac[u] : NEG;
+        float nd = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+          const float di = readlane(da, i);
+          const float w = fast_expf(apj + Ac[i] - readlane(lc[u], i));   // w_t[i][lane]; exp(-inf) = 0 for i >= N, dead states
+          const float dw = di > 0.f ? di * w : 0.f;                      // (0 x anything: a state without posterior mass hands nothing on)
+          acc[i] += dw;
+          nd += dw;
+        }
+        da = nd;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) {
+      const int t = thi - u;
+      if (act && t >= 1) dxb[(size_t)t * N + lane] = dxs[u];
+    }
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) asm volatile("" : "+v"(ln[u]), "+v"(an[u]));
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) { lc[u] = ln[u]; ac[u] = an[u]; }
   }
   if (act) dxb[lane] = g * da;
   // the transition-gradient partial of this utterance: time chunk 0 (the fcc_dtrans kernels zero the other chunks of a flagged utterance)
