@@ -824,6 +824,38 @@ def test_gemm_bf16_all_layouts(bf16_matmul, M, N, K, akc, bkc):
     assert torch.equal(plain, ops.gemm(Ad, Bd, akc, bkc))
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_gemm_bf16_random_shapes(bf16_matmul, seed):
+    """the bf16-operand GEMM behind w2l_set_matmul_precision over random shapes and layouts (odd K, single rows, N % 8 != 0,
+    several rounds of tiles): exact up to fp32 accumulation order against a float64 product of the bf16-rounded operands"""
+    from wav2letter_amd import ops
+    rng = np.random.default_rng(777 + seed)
+    g = torch.Generator(device="cpu").manual_seed(55 + seed)
+    sizes = [1, 2, 3, 7, 31, 32, 33, 64, 65, 96, 127, 128, 129, 250, 256, 257, 500, 1000, 1200, 1521]
+    for c in range(24):
+        M, N, K = (int(rng.choice(sizes)) for _ in range(3))
+        if c % 6 == 0:
+            M = int(rng.choice([3008, 6016, 11968]))
+        akc, bkc = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        A = torch.randn(M, K, generator=g)
+        Bm = torch.randn(K, N, generator=g) / K ** 0.5
+        bias = torch.randn(N, generator=g) if rng.integers(0, 2) else None
+        relu = bool(rng.integers(0, 2))
+        want = A.bfloat16().double() @ Bm.bfloat16().double()
+        exact = A.double() @ Bm.double()
+        if bias is not None:
+            want, exact = want + bias.double(), exact + bias.double()
+        if relu:
+            want, exact = want.clamp_min(0), exact.clamp_min(0)
+        Ad = (A if akc else A.T.contiguous()).cuda()
+        Bd = (Bm.T.contiguous() if bkc else Bm).cuda()
+        got = ops.gemm(Ad, Bd, akc, bkc, None if bias is None else bias.cuda(), relu)
+        what = f"case {c}: M={M} N={N} K={K} a_kcontig={akc} b_kcontig={bkc} bias={bias is not None} relu={relu}"
+        # (shapes the bf16 kernels do not take -- K below a tile, unaligned operands -- run on the fp32 GEMM: the unrounded product)
+        assert rel(got, want.numpy()) < 2e-5 or rel(got, exact.numpy()) < TOL, what
+        assert torch.equal(got, ops.gemm(Ad, Bd, akc, bkc, None if bias is None else bias.cuda(), relu)), what
+
+
 def test_linear_ops_bf16_epilogues(oracle, bf16_matmul):
     """the fl::Linear entry points of the TDS block under bf16 multiplies: dropout epilogue mask identical to the fp32
     path (same stateless hash), mask / addend epilogues, weight gradient; against the fp64 oracle at the bf16 tolerance"""
