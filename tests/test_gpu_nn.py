@@ -1122,6 +1122,31 @@ def test_tds_conv_bf16_three_passes(oracle, B, C, H, T, kw, padl, padr):
     assert rel(from_fm(dx0.cpu().numpy()), odx) < 2e-5
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_tds_conv_bf16_random_geometries(oracle, seed):
+    """the test above over random batch / frame / mel-row counts, kernel widths and paddings (geometries without a bf16 kernel are
+    refused by the library -- `None` -- and skipped here: at least a third of the draws must run)"""
+    rng = np.random.default_rng(31 + seed)
+    ran = 0
+    for c in range(20):
+        B = int(rng.integers(1, 4))
+        C = int(rng.choice([10, 14, 15, 18, 19, 23, 27]))
+        H = int(rng.choice([16, 32, 80, 80, 24, 5]))
+        T = int(rng.choice([1, 2, 5, 16, 17, 31, 33, 64, 65, 100, 187, 200]))
+        kw = int(rng.choice([9, 10, 11, 12, 21]))
+        padl, padr = int(rng.integers(0, kw)), int(rng.integers(0, kw))
+        if T + padl + padr - kw + 1 < 1:
+            padl = padr = kw - 1
+        try:
+            test_tds_conv_bf16_three_passes(oracle, B, C, H, T, kw, padl, padr)
+            ran += 1
+        except AssertionError as e:
+            if "must have a bf16 kernel" in str(e):
+                continue
+            raise AssertionError(f"case {c}: B={B} C={C} H={H} T={T} kw={kw} padl={padl} padr={padr}: {e}") from e
+    assert ran >= 6, ran
+
+
 @pytest.mark.parametrize("rows,cols,p", [(300, 200, 0.1), (64, 64, 0.5), (1000, 1203, 0.25), (7, 5, 0.3), (4097, 130, 0.1)])
 def test_bf16_convert_with_dropout_mask(rows, cols, p):
     """w2l_bf16_convert_dropout: the images of dropout(x) in one pass -- bit-identical to w2l_dropout_copy (same p, seed, stream:
