@@ -107,6 +107,39 @@ def test_tds_ctc_small_end_to_end(oracle):
     assert rel(tr.params.cpu().numpy(), want) < 1e-5
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_tds_ctc_random_small_networks(oracle, seed):
+    """the reduced TDS-CTC topology over random channel counts (incl. the recipe's 10 / 14 / 18, whose convolutions run on the
+    block-Toeplitz kernels when the mel rows are a multiple of 16), mel-row counts, kernel widths, batch and frame counts: emissions
+    and loss at 1e-4, every parameter gradient by direction and size (a ReLU input may sit on the kink: check_grads_relu_robust)"""
+    from wav2letter_amd import recipes
+    rng = np.random.default_rng(4000 + seed)
+    for c in range(5):
+        chans = [(4, 6), (10, 14), (14, 18), (3, 5), (10, 10)][int(rng.integers(0, 5))]
+        nfeat = int(rng.choice([8, 16, 32, 48]))
+        kw = int(rng.choice([5, 9, 21]))
+        B, T, L = int(rng.integers(1, 4)), int(rng.choice([24, 40, 64, 97])), 4
+        nlabel = int(rng.choice([9, 21, 40]))
+        arch = recipes.tds_ctc_small_arch(c=chans, h=nfeat, kw=kw)
+        what = f"case {c}: channels {chans} nfeat {nfeat} kw {kw} B {B} T {T} nlabel {nlabel}"
+        tr, ref, params, _ = build(arch, nfeat, nlabel, "ctc", 4, 0.0, rng, B, T, L)
+        x = rng.normal(size=(B, 1, nfeat, T)).astype(np.float32)
+        tgt = np.full((B, L), -1, np.int32)
+        for b in range(B):
+            l = int(rng.integers(1, L + 1))
+            tgt[b, :l] = rng.integers(0, nlabel - 1, l)
+        xd = torch.tensor(x.reshape(B, nfeat, T)).cuda()
+        em_ref = ref.forward(x, params)
+        assert rel(tr.forward(xd, train=False).cpu().numpy(), em_ref) < TOL, what
+        loss = tr.forward_backward(xd, torch.tensor(tgt).cuda()).cpu().numpy()
+        o = oracle.CTC(em_ref, tgt, scale_mode=4)
+        assert rel(loss, o.forward()) < TOL, what
+        try:
+            check_grads_relu_robust(tr, ref.backward(o.backward().astype(np.float32), len(params)))
+        except AssertionError as e:
+            raise AssertionError(f"{what}: {e}") from e
+
+
 def test_conv_glu_asg_small_end_to_end(oracle):
     """BASELINE config 1 geometry in miniature: WN-Conv+GLU stack, ASG criterion, 2 utterances"""
     from wav2letter_amd import recipes
