@@ -122,8 +122,10 @@ def test_bucketed_reduce_equals_one_collective():
     mp.spawn(_bucket_worker, args=(2, _free_port()), nprocs=2, join=True)
 
 
-def test_bench_self_launch_two_gloo_ranks():
-    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must start 2 ranks itself (round-1 verdict,
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_bench_self_launch_two_gloo_ranks(ranks):
+    """(ranks = 8: the node size the driver's scaling run uses -- round-5 verdict 9d)
+    `python bench.py --gpus 2` with no WORLD_SIZE in the environment must start 2 ranks itself (round-1 verdict,
     missing 1).  --dist-selftest runs the launcher, the rendezvous and the arena all-reduce (gradients + the batch-size
     scalar in the arena tail) on gloo when the host has no GPU -- the same self_launch() path a real multi-GPU run takes"""
     import json
@@ -133,13 +135,14 @@ def test_bench_self_launch_two_gloo_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     env["CUDA_VISIBLE_DEVICES"] = ""
     env["HIP_VISIBLE_DEVICES"] = ""
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-selftest", "--batch", "32"],
-                         env=env, capture_output=True, text=True, timeout=600)
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--dist-selftest", "--batch", "32"],
+                         env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["ok"] and d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"] == "gloo"
-    assert d["global_batch"] == 32 + 33          # all-reduced, not assumed (ranks carry different batch sizes)
+    assert d["ok"] and d["n_gpus"] == ranks and d["rccl_ranks"] == ranks and d["backend"] == "gloo"
+    assert d["global_batch"] == sum(32 + r for r in range(ranks))   # all-reduced, not assumed (ranks carry different batch sizes)
 
 
 def test_self_launch_refuses_missing_gpus():

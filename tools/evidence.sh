@@ -20,4 +20,9 @@ timeout 500 bash tools/pmc.sh ${tag}_write "WRITE_SIZE" bench.py --steps 1 --war
 # the RCCL path of the headline step with one rank (process group, bucketed reducer on the side stream, batch size through the arena's tail)
 (timeout 300 python bench.py --force-dist --steps 4 --warmup 2 --no-asg --no-stress --no-c4 --no-c3 --no-c5 $common) > gpurun_out/${tag}_bench_force_dist_1rank.log 2> gpurun_out/${tag}_bench_force_dist_1rank.err
 python tools/pmc_traffic.py gpurun_out/${tag}_fetch_pmc.csv gpurun_out/${tag}_write_pmc.csv gpurun_out/${tag}_pmc_traffic.json > /dev/null 2>&1
+
+# every record kept from this run must parse (a stdout without its bench line is not evidence)
+python tools/check_evidence.py gpurun_out/${tag}_bench.log gpurun_out/${tag}_bench_force_dist_1rank.log gpurun_out/${tag}_pmc_traffic.json \
+  gpurun_out/${tag}_headline_asg_ctc_kernel_stats.csv gpurun_out/${tag}_stress_kernel_stats.csv gpurun_out/${tag}_c4_kernel_stats.csv \
+  gpurun_out/${tag}_c3_kernel_stats.csv gpurun_out/${tag}_c5_kernel_stats.csv || { echo "evidence run INCOMPLETE"; exit 1; }
 echo done

@@ -144,6 +144,25 @@ class OverlappedReducer:
         # reduced in fp32 by a collective of its own.
         self.bf16 = bool(bf16)
         self._stage = {}
+        # self-diagnosis of a multi-GPU run (bench.py --gpus N): with timing on, reduce() brackets every bucket's collective with
+        # events on the side stream and marks where the compute stream starts to wait for the last of them
+        self.timing = False
+        self._ev = None
+
+    def enable_timing(self, on=True):
+        self.timing = bool(on) and self.on_gpu
+        self._ev = None
+
+    def timings(self):
+        """after a synchronize: what the LAST timed reduce() cost -- per-bucket collective durations on the side stream in issue
+        order (last layers first; a duration includes the wait for the slowest peer) and the exposed communication time = how
+        long the compute stream sat at the join behind the backward pass.  None without timing / on the host path."""
+        if not self._ev:
+            return None
+        pairs, reach, done = self._ev
+        return {"bucket_allreduce_us": [round(a.elapsed_time(b) * 1e3, 1) for a, b in pairs],
+                "bucket_bytes": self.bucket_bytes(),
+                "comm_exposed_ms": round(max(0.0, reach.elapsed_time(done)), 4)}
 
     def _bf16_stage(self, k, n):
         b = self._stage.get(k)
@@ -171,6 +190,7 @@ class OverlappedReducer:
         """call right after trainer.forward_backward(); returns when every collective is enqueued and the
         current (compute) stream has been made to wait for them"""
         works = []
+        pairs = []
         g = self.tr.grads_full
         nf = self.tr.n_floats
         for k in reversed(range(len(self.offsets) - 1)):
@@ -179,8 +199,19 @@ class OverlappedReducer:
                 self.tr.wait_bucket(k, self.comm)
             ctx = torch.cuda.stream(self.comm) if self.on_gpu else contextlib.nullcontext()
             with ctx:
+                if self.timing:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    pairs.append((e0, e1))
+                    e0.record(self.comm)
                 if not self.bf16:
-                    works.append(dist.all_reduce(g[lo:hi], async_op=True))
+                    w = dist.all_reduce(g[lo:hi], async_op=True)
+                    if self.timing:
+                        # (the collective runs on the backend's own stream: the side stream joins it so that the closing event
+                        #  lies behind it; the compute stream then waits for the side stream instead of for the work objects)
+                        w.wait()
+                        e1.record(self.comm)
+                    else:
+                        works.append(w)
                     continue
                 hg = min(hi, nf)
                 stage = self._bf16_stage(k, hg - lo)
@@ -189,8 +220,19 @@ class OverlappedReducer:
                 w.wait()                                    # stream-ordered on the GPU, blocking on the host
                 g[lo:hg].copy_(stage)
                 if hi > nf:
-                    works.append(dist.all_reduce(g[nf:hi], async_op=True))
+                    w = dist.all_reduce(g[nf:hi], async_op=True)
+                    if self.timing:
+                        w.wait()
+                    else:
+                        works.append(w)
+                if self.timing:
+                    e1.record(self.comm)
+        if self.timing:
+            reach, done = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reach.record(torch.cuda.current_stream(self.tr.device))   # the backward pass has been enqueued up to here
+            done.record(self.comm)                                    # behind the last collective
+            self._ev = (pairs, reach, done)
         for w in works:
             w.wait()
-        if self.on_gpu and self.bf16:
+        if self.on_gpu and (self.bf16 or self.timing):
             torch.cuda.current_stream(self.tr.device).wait_stream(self.comm)
