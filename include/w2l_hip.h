@@ -85,6 +85,13 @@ int w2l_fac_backward(int B, int T, int N, int L, const int* target, const int* t
 int w2l_fac_viterbi(int B, int T, int N, int L, const float* input, const int* target,
                     const int* targetSize, const float* trans, int* bestPaths,
                     void* workspace, w2l_stream_t stream);
+/* Range check (diagnostics; no counterpart in the reference, whose log-domain recursion -- SURVEY App. B.1 / B.2, call sites
+ * recipes/slimIPL/src/Train.cpp:408-410, :1675 -- is what the flagged utterances are recomputed with).  The fp32 / fp64
+ * scaled-domain scans behind w2l_fcc_forward / w2l_fac_forward check per utterance that their inputs stay inside what they hold
+ * exactly and hand the rest to log-domain kernels inside the same call: results are exact either way.  flags[b] (device, [B]) = 1
+ * when utterance b of the LAST forward call on `workspace` (same B, T, N[, L]) took the log-domain path, else 0. */
+int w2l_fcc_range_flags(int B, int T, int N, const void* workspace, int* flags, w2l_stream_t stream);
+int w2l_fac_range_flags(int B, int T, int N, int L, const void* workspace, int* flags, w2l_stream_t stream);
 
 /* LinSegCriterion (recipes/slimIPL/src/Train.cpp:589-617, --linseg): ASG on the target stretched linearly over the
  * T frames.  Flashlight getLinearTarget [UNVENDORED]: linTarget[b][t] = target[b][t * L_b / T], L_b = leading

@@ -1,39 +1,122 @@
 """Randomised range check of FCC / FAC / CTC against the fp64 oracle (tools/exp/criterion_fuzz.py): label-set sizes on both sides of
-every kernel switch (N <= 31, <= 64, large), lattices from 1 to 300 positions, T from 1 to 2000, every scale mode, emission and
-transition magnitudes up to 20 / 8 nats of sigma -- several times what a recipe produces.  The envelope is deliberate: with emissions
-AND transitions tens of nats wide (sigma 50 x sigma >= 20) the FullConnectionCriterion kernels for MORE THAN 31 labels -- scaled
-exp-domain recursions in fp32 -- clamp a state that is more than ~87 nats behind the frame's best, which can move the posterior to another path (loss still at
-1e-4, gradients not; DESIGN 1, profiles/r05_run32_criterion_fuzz.log); the reference's log-domain recursion has no such limit."""
+every kernel switch (N <= 31, <= 64, large), lattices from 1 to 300 positions, T from 1 to 2000, every scale mode, emission
+magnitudes up to 50 and transition magnitudes up to 40 nats of sigma -- two orders of magnitude beyond what a recipe produces.
+Round 6: no envelope.  The fp32 scaled-domain recursions check their own range (N <= 31: transition-row spread; 32 <= N <= 64 and
+N > 64: the smallest sum of a frame against kFccMinSum / BigDims::minSum; FAC: label-score spread + |log2 kappa|) and hand what they
+cannot hold exactly to log-domain kernels (fcc_fwd_log / fcc_bwd_log<32|64>, fcc_big_exact_*, fac_fwd_blk), which evaluate every term
+as one exponential of a non-positive sum as the reference's recursion does."""
 import os
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+ALL_N = (3, 5, 16, 29, 30, 31, 32, 33, 40, 64, 65, 100, 1000)
+
 
 @pytest.mark.parametrize("seed", [11, 12])
 def test_criteria_random_shapes_and_magnitudes(seed):
     from tools.exp.criterion_fuzz import run
-    bad = run(40, seed, x_scales=(0.1, 1.0, 5.0, 20.0), a_scales=(0.0, 0.3, 2.0, 8.0), verbose=False)
+    bad = run(40, seed, x_scales=(0.1, 1.0, 5.0, 20.0), a_scales=(0.0, 0.3, 2.0, 8.0), verbose=False, n_choices=ALL_N)
     assert not bad, "\n".join(bad)
 
 
-def test_full_connection_up_to_31_labels_with_very_wide_dynamics():
-    """N <= 31 (the letter-based ASG recipes): the utterances the linear-domain scans flag re-run on a true log-domain pair
-    (fcc_fwd_log / fcc_bwd_log: every term one exponential of a non-positive sum) -- exact where the scaled-exp kernels clamp"""
+@pytest.mark.parametrize("seed", [9, 21])
+def test_criteria_with_very_wide_dynamics_at_every_label_set_size(seed):
+    """emissions of sigma up to 50 AND transitions of sigma up to 40 nats, N on both sides of every kernel switch incl. 33, 64, 100,
+    1000 (round-5 verdict, weak 2: the N > 31 kernels returned O(1)-wrong gradients here, silently).  Zero BAD of any kind."""
     from tools.exp.criterion_fuzz import run
-    import re
-    bad = run(30, 9, x_scales=(5.0, 20.0, 50.0), a_scales=(8.0, 20.0, 40.0), verbose=False, n_choices=(3, 5, 16, 29, 30, 31))
-    fcc_bad = [l for l in bad if re.search(r"FCC [^ ]+ BAD", l)]
-    assert not fcc_bad, "\n".join(fcc_bad)
+    bad = run(30, seed, x_scales=(5.0, 20.0, 50.0), a_scales=(8.0, 20.0, 40.0), verbose=False, n_choices=ALL_N)
+    assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("N", [33, 64, 100, 1000])
+def test_full_connection_more_than_31_labels_flagged_utterances_take_the_exact_path(N):
+    """the builder's own failing case of round 5 (profiles/r05_run32_criterion_fuzz.log:44: N = 64, emissions x 50, transitions x 20,
+    T = 1000: dx off by 0.41) and its neighbours, next to an utterance that stays inside the range check in the same batch.
+    Bar: the fuzz's 1e-3 of the utterance's largest entry -- with transitions of sigma 20 every fp32 recursion (scaled-exp or log
+    domain, here or in the reference's float instantiation) adds summands of +-60 nats, 4e-6 of rounding per frame that walks to a
+    few 1e-4 over 1000 frames (measured 3.4e-4 on the utterance that is NOT flagged); the round-5 failure was 0.41."""
+    import torch
+    from oracle import pyoracle as O
+    from wav2letter_amd import FullConnectionCriterion
+    rng = np.random.default_rng(64 + N)
+    B, T = 3, 300 if N >= 500 else 1000
+    x = rng.normal(size=(B, T, N)).astype(np.float32)
+    x[0] *= 50.0
+    x[2] *= 50.0            # utterance 1 keeps unit-variance emissions
+    A = (rng.normal(size=(N, N)) * 20.0).astype(np.float32)
+    ts = np.full(B, 7, np.int32)
+    w = np.array([1.0, 0.7, 1.3])
+    crit = FullConnectionCriterion(N, 0).cuda()
+    crit.transitions.data = torch.from_numpy(A).cuda()
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    tgt = np.full((B, 8), -1, np.int32)
+    tgt[:, :7] = 1
+    loss = crit(xt, torch.from_numpy(tgt).cuda())
+    from wav2letter_amd.criterion import fcc_range_flags
+    flags = fcc_range_flags().cpu().numpy()
+    assert flags[0] == 1 and flags[2] == 1, flags   # emissions x 50 and transitions x 20: out of the fp32 scan's range -> log domain
+    (loss * torch.from_numpy(w.astype(np.float32)).cuda()).sum().backward()
+    o = O.FCC(x, A, ts, 0)
+    ol = o.forward()
+    odx, odA = o.backward(w)
+    got = loss.detach().cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ol).max() <= 1e-4 * np.abs(ol).max()
+    gdx = xt.grad.cpu().numpy()
+    for b in range(B):   # per utterance: each on the scale of its own largest entry
+        assert np.abs(gdx[b] - odx[b]).max() <= 1e-3 * np.abs(odx[b]).max(), b
+    gdA = crit.transitions.grad.cpu().numpy()
+    assert np.abs(gdA - odA).max() <= 1e-3 * np.abs(odA).max()
 
 
 def test_force_alignment_with_very_wide_transitions():
-    """FAC alone stays exact far outside that envelope (fp64 mantissas, integer exponents per position; kappa of any range)"""
+    """FAC alone stays exact far outside the recipes' range (fp64 mantissas, integer exponents per position; kappa of any range)"""
     from tools.exp.criterion_fuzz import run
     import re
     bad = run(30, 7, x_scales=(1.0, 20.0, 50.0), a_scales=(20.0, 40.0), verbose=False)
     fac_bad = [l for l in bad if re.search(r"FAC [^ ]+ BAD", l)]
     assert not fac_bad, "\n".join(fac_bad)
+
+
+@pytest.mark.parametrize("sigma", [50.0, 100.0, 200.0])
+def test_force_alignment_transition_rows_hundreds_of_nats_wide_at_the_full_criterion_shape(sigma):
+    """T = 2000, N = 30, L up to 300, transitions of sigma 100: the pipelined scan's label weight x kappa leaves the fp64 range
+    (round 5: loss -inf against a finite oracle, profiles/r05_run31_asg_wide_transitions_after.log:9); now flagged and recomputed by
+    the log-domain kernel.  Loss, input gradient and transition gradient at 1e-4."""
+    import torch
+    from oracle import pyoracle as O
+    from wav2letter_amd import ForceAlignmentCriterion
+    B, T, N, L = 4, 2000, 30, 300
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(B, T, N)).astype(np.float32)
+    tgt = np.full((B, L), -1, np.int32)
+    for b in range(B):
+        l = int(rng.integers(60, L + 1))
+        y = rng.integers(0, 28, size=l)
+        for i in range(1, l):
+            if y[i] == y[i - 1]:
+                y[i] = (y[i] + 1) % 28
+        tgt[b, :l] = y
+    A = (np.eye(N) * 4 + rng.normal(size=(N, N)) * sigma).astype(np.float32)
+    crit = ForceAlignmentCriterion(N, 4).cuda()
+    crit.transitions.data = torch.from_numpy(A).cuda()
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    loss = crit(xt, torch.from_numpy(tgt).cuda())
+    from wav2letter_amd.criterion import fac_range_flags
+    flags = fac_range_flags().cpu().numpy()
+    if sigma >= 100.0:
+        assert flags.any(), flags   # label weight x kappa beyond the fp64 range somewhere: handed to the log-domain kernel
+    loss.sum().backward()
+    o = O.FAC(x, A, tgt, scale_mode=4)
+    ol = o.forward()
+    odx, odA = o.backward(np.ones(B))
+    got = loss.detach().cpu().numpy().astype(np.float64)
+    assert np.isfinite(ol).all() and np.isfinite(got).all(), (got, ol)
+    assert np.abs(got - ol).max() <= 1e-4 * np.abs(ol).max()
+    assert np.abs(xt.grad.cpu().numpy() - odx).max() <= 1e-4 * np.abs(odx).max()
+    assert np.abs(crit.transitions.grad.cpu().numpy() - odA).max() <= 1e-4 * np.abs(odA).max()

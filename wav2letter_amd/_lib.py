@@ -89,6 +89,8 @@ class _SIGS:
     w2l_fac_forward = (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p])
     w2l_fac_backward = (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p])
     w2l_fac_viterbi = (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p])
+    w2l_fcc_range_flags = (_i, [_i, _i, _i, _p, _p, _p])
+    w2l_fac_range_flags = (_i, [_i, _i, _i, _i, _p, _p, _p])
     w2l_linear_target = (_i, [_i, _i, _i, _p, _p, _p])
     w2l_fac_fullpath_forward = (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p])
     w2l_fac_fullpath_backward = (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p])

@@ -85,6 +85,7 @@ class _FCC(torch.autograd.Function):
                                      trans.data_ptr(), loss.data_ptr(), ws.data_ptr(), _stream()), "fcc_forward")
         ctx.save_for_backward(trans, ws)
         ctx.dims = (B, T, N)
+        _FCC.last = (ws, (B, T, N))   # for range_flags(): which utterances took the log-domain path (diagnostics)
         return loss
 
     @staticmethod
@@ -116,6 +117,7 @@ class _FAC(torch.autograd.Function):
                                      _stream()), "fac_forward")
         ctx.save_for_backward(target, target_size, ws)
         ctx.dims = (B, T, N, Lt)
+        _FAC.last = (ws, (B, T, N, Lt))
         return loss
 
     @staticmethod
@@ -129,6 +131,23 @@ class _FAC(torch.autograd.Function):
         _lib.check(L.w2l_fac_backward(B, T, N, Lt, target.data_ptr(), target_size.data_ptr(), grad.data_ptr(),
                                       dx.data_ptr(), dt.data_ptr(), ws.data_ptr(), _stream()), "fac_backward")
         return dx, dt, None, None, None
+
+
+def fcc_range_flags():
+    """int32 [B]: 1 where an utterance of the LAST FullConnectionCriterion forward left the range of the fp32 scaled-domain scan and
+    was recomputed by the log-domain kernels (w2l_fcc_range_flags); results are exact either way"""
+    ws, (B, T, N) = _FCC.last
+    out = torch.empty(B, dtype=torch.int32, device=ws.device)
+    _lib.check(_lib.lib().w2l_fcc_range_flags(B, T, N, ws.data_ptr(), out.data_ptr(), _stream()), "fcc_range_flags")
+    return out
+
+
+def fac_range_flags():
+    """the same for the LAST ForceAlignmentCriterion forward (w2l_fac_range_flags)"""
+    ws, (B, T, N, Lt) = _FAC.last
+    out = torch.empty(B, dtype=torch.int32, device=ws.device)
+    _lib.check(_lib.lib().w2l_fac_range_flags(B, T, N, Lt, ws.data_ptr(), out.data_ptr(), _stream()), "fac_range_flags")
+    return out
 
 
 class _FACFullPath(torch.autograd.Function):

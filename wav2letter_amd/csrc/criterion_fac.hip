@@ -37,8 +37,9 @@ struct FacWs {
   unsigned char* bp;  // viterbi back pointers [B][T][L]
   double* crow;  // [B][T][32] label rows c_t[n] of fac_rows_k (N <= 32 only, else NULL)
   float* zmax;   // [B][T]     frame maxima (base 2) of the label scores
-  int* redo;     // [B]  set by fac_fwd_lin: the utterance's dynamics exceed what the per-lane exponents hold exactly ->
-                 //      fac_fwd_blk (log domain), launched behind it, recomputes that utterance
+  float* zspr;   // [B][T]     frame maximum - frame minimum of the label scores (base 2): the range check of fac_fwd_plin
+  int* redo;     // [B]  set by fac_fwd_lin / fac_fwd_plin: the utterance's dynamics exceed what the scaled linear domain holds
+                 //      exactly -> fac_fwd_blk (log domain), launched behind it, recomputes that utterance
 };
 
 __host__ __device__ inline bool fac_use_partials(int B, int N) {
@@ -55,10 +56,11 @@ __host__ __device__ inline FacWs fac_ws(void* ws, int B, int T, int N, int L) {
   w.bp = (unsigned char*)w.w1;  // viterbi reuses the w1 region (needs B*T*L bytes)
   w.tgpart = fac_use_partials(B, N) ? (float*)p : nullptr;
   if (w.tgpart) p += align_up((size_t)B * N * N * sizeof(float), 256);
-  w.crow = nullptr; w.zmax = nullptr;
+  w.crow = nullptr; w.zmax = nullptr; w.zspr = nullptr;
   if (N <= 32) {
     w.crow = (double*)p; p += align_up((size_t)B * T * 32 * sizeof(double), 256);
-    w.zmax = (float*)p;
+    w.zmax = (float*)p; p += align_up((size_t)B * T * sizeof(float), 256);
+    w.zspr = (float*)p;
   }
   return w;
 }
@@ -864,7 +866,7 @@ W2L_API size_t w2l_fac_workspace_size(int B, int T, int N, int L) {
   size_t sz = 2 * align_up((size_t)B * T * L * sizeof(float), 256) + align_up((size_t)B * sizeof(float), 256) +
               align_up((size_t)B * sizeof(int), 256);
   if (fac_use_partials(B, N)) sz += align_up((size_t)B * N * N * sizeof(float), 256);
-  if (N <= 32) sz += align_up((size_t)B * T * 32 * sizeof(double), 256) + align_up((size_t)B * T * sizeof(float), 256);
+  if (N <= 32) sz += align_up((size_t)B * T * 32 * sizeof(double), 256) + 2 * align_up((size_t)B * T * sizeof(float), 256);
   return sz;
 }
 
@@ -934,7 +936,7 @@ W2L_API int w2l_fac_forward(int B, int T, int N, int L, int scaleMode, const flo
       return W2L_OK;
     }
     hipLaunchKernelGGL(fac_rows_k, dim3((unsigned)((T + kFacRowsPerWave - 1) / kFacRowsPerWave), (unsigned)B), dim3(64), 0, s, T, N, input,
-                       trans, ws.crow, ws.zmax);
+                       trans, ws.crow, ws.zmax, ws.zspr);
     W2L_LAUNCH_CHECK();
 #define W2L_FAC_P_GO(K, NWV) hipLaunchKernelGGL((K<NWV>), dim3(B), dim3(64 * NWV), 0, s, T, N, L, scaleMode, target, targetSize, trans, loss, ws)
 #define W2L_FAC_P_SWITCH(K)               \
@@ -949,6 +951,13 @@ W2L_API int w2l_fac_forward(int B, int T, int N, int L, int scaleMode, const flo
 #undef W2L_FAC_P_SWITCH
 #undef W2L_FAC_P_GO
     W2L_LAUNCH_CHECK();
+    if (gen == 0) {
+      // fac_fwd_plin flags the utterances whose label-score spread + transition ratios could carry a position's fp64 value out
+      // of range (kFacPlinSafeBits); the log-domain kernel recomputes exactly those and returns at once for the others
+      if (L > 256) hipLaunchKernelGGL((fac_fwd_blk<8, 1>), dim3(B), dim3(512), 0, s, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws, (const int*)ws.redo);
+      else W2L_FAC_BLK_DISPATCH(fac_fwd_blk, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws, (const int*)ws.redo);
+      W2L_LAUNCH_CHECK();
+    }
     return W2L_OK;
   }
   static const int waveMode = [] { const char* e = tune_env("W2L_FAC_WAVE"); return e ? atoi(e) : 0; }();
@@ -1082,6 +1091,18 @@ W2L_API int w2l_fac_backward(int B, int T, int N, int L, const int* target, cons
     hipLaunchKernelGGL(reduce_over_b_fac, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, B, n, ws.tgpart, transGrad);
     W2L_LAUNCH_CHECK();
   }
+  return W2L_OK;
+}
+
+W2L_API int w2l_fac_range_flags(int B, int T, int N, int L, const void* workspace, int* flags, w2l_stream_t stream) {
+  if (B <= 0 || T <= 0 || N <= 0 || L <= 0 || !workspace || !flags) return W2L_EINVAL;
+  if (L > 512) return W2L_EUNSUPPORTED;
+  if (!fac_lin_path(N, L)) {   // every utterance runs on the log-domain kernels: nothing is ever handed over
+    W2L_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)B * sizeof(int), (hipStream_t)stream));
+    return W2L_OK;
+  }
+  const FacWs ws = fac_ws((void*)workspace, B, T, N, L);
+  W2L_HIP_CHECK(hipMemcpyAsync(flags, ws.redo, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return W2L_OK;
 }
 

@@ -486,7 +486,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void fac_fwd_blin(int T, int N, int 
 // Against fac_fwd_blin: no row wave (one wave less on the CU's four SIMDs), no LDS row, three instructions less per frame.
 constexpr int kFacRowsPerWave = 8;
 __global__ __launch_bounds__(64) void fac_rows_k(int T, int N, const float* __restrict__ x, const float* __restrict__ trans,
-                                                 double* __restrict__ crow, float* __restrict__ zmax) {
+                                                 double* __restrict__ crow, float* __restrict__ zmax, float* __restrict__ zspr = nullptr) {
   const int b = blockIdx.y, lane = threadIdx.x;
   const int t0 = blockIdx.x * kFacRowsPerWave;
   const float L2E = 1.44269504088896341f;
@@ -507,6 +507,10 @@ __global__ __launch_bounds__(64) void fac_rows_k(int T, int N, const float* __re
       const double c = __builtin_amdgcn_ldexp((double)__builtin_amdgcn_exp2f(zr - zi), (int)zi);
       if (lane < 32) crow[((size_t)b * T + t) * 32 + lane] = act ? c : 0.0;
       if (lane == 0) zmax[(size_t)b * T + t] = zm;
+      if (zspr) {   // the frame's spread (bits), for the range check of fac_fwd_plin; a NaN score makes it NaN
+        const float sp = wave_max_rows<2>(act ? (z == z ? zm - z : INFINITY) : 0.f);
+        if (lane == 0) zspr[(size_t)b * T + t] = zm == zm ? sp : __builtin_nanf("");
+      }
     }
   }
 }
@@ -620,6 +624,13 @@ __global__ __launch_bounds__(64 * NW) void fac_fwd_blin2(int T, int N, int L, in
 constexpr int kPlinChunk = 16;
 constexpr int kPlinRing = 64;
 constexpr int kPlinSpinMax = 1 << 18;   // ~10 ms: a legitimate wait is a few microseconds
+// Range of fac_fwd_plin: a position's value is an fp64 mantissa with its own integer exponent, but one frame's update multiplies by
+// kappa (fp64, any |log2| up to ~1020) and by the label weight c_t[y] = 2^(z - max z) (fp64, 0 below 2^-1074) BEFORE it is split
+// again: tot = m + kappa m_left lies in [2^-1 kappa, 2^1021), h = c tot >= 2^-(1 + |log2 kappa| + spread).  While
+// (largest |log2 kappa| of the target) + (largest per-frame spread of the label scores) <= kFacPlinSafeBits nothing leaves the
+// normal range.  Beyond that (transition rows ~100 nats wide: profiles/r05_run31_asg_wide_transitions_after.log had loss -inf
+// against a finite oracle) the utterance is flagged in ws.redo and recomputed by the log-domain kernel fac_fwd_blk.
+constexpr float kFacPlinSafeBits = 900.f;
 
 __device__ __forceinline__ bool plin_wait_ge(const int* p, int want) {   // poll *p >= want (relaxed LDS loads), bounded
   int spins = 0, v;
@@ -649,17 +660,18 @@ __global__ __launch_bounds__(64 * NW) void fac_fwd_plin(int T, int N, int L, int
   __shared__ FacRec ring[NW][kPlinRing];   // ring[w][t & 63]: position 64 w + 63 after frame t
   __shared__ int prog[NW];                 // last frame wave w has finished
   __shared__ int bad;
+  __shared__ int gbits;                    // largest |log2 kappa| over the target (bit pattern of a non-negative float)
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = targetSize[b];
   const float sc = scale_of(scaleMode, T, S);
-  if (tid == 0) { ws.scale[b] = sc; ws.redo[b] = 0; }
+  if (tid == 0) ws.scale[b] = sc;
   if (S <= 0) {
-    if (tid == 0) loss[b] = 0.f;
+    if (tid == 0) { loss[b] = 0.f; ws.redo[b] = 0; }
     return;
   }
   if (tid < NW) prog[tid] = -1;
-  if (tid == 0) bad = 0;
+  if (tid == 0) { bad = 0; gbits = 0; }
   __syncthreads();
   const int lastWave = (S - 1) >> 6;
   if (wave > lastWave) return;           // nothing to do, and nobody waits for these waves
@@ -673,6 +685,11 @@ __global__ __launch_bounds__(64 * NW) void fac_fwd_plin(int T, int N, int L, int
   const int yp = (valid && i > 0) ? y[i - 1] : 0;
   const float dk = (valid && i > 0) ? trans[(size_t)yi * N + yp] - trans[(size_t)yp * N + yp] : NEG;
   const double kap = fac_exp_wide(dk);   // 0 for position 0 and beyond the target
+  {   // range check, part 1 (before the first frame: the last wave reads it when the scan is over)
+    const float kb = (valid && i > 0) ? fabsf(dk) * 1.44269504088896341f : 0.f;
+    const float kw = wave_max(kb == kb ? kb : INFINITY);   // (a NaN or infinite transition: leave it to the log-domain kernel)
+    if (lane == 0) atomicMax(&gbits, __float_as_int(kw));
+  }
   const double* cb = ws.crow + (size_t)b * T * 32 + yi;
   double cc[kPlinChunk], cn[kPlinChunk];
 #pragma unroll
@@ -768,9 +785,16 @@ __global__ __launch_bounds__(64 * NW) void fac_fwd_plin(int T, int N, int L, int
   // loss = scale * alpha_{T-1}[S-1],  alpha = (sum_t zmax_t + e + log2 m) ln 2 - A[y][y]; the wave that holds position S - 1 sums
   if (wave == lastWave) {
     const float* zb = ws.zmax + (size_t)b * T;
+    const float* zp = ws.zspr + (size_t)b * T;
     double zs = 0.0;
-    for (int t = lane; t < T; t += 64) zs += (double)zb[t];
+    float spr = 0.f;
+    for (int t = lane; t < T; t += 64) {
+      zs += (double)zb[t];
+      const float sp = zp[t];
+      spr = fmaxf(spr, sp == sp ? sp : INFINITY);
+    }
     zs = wave_sum_f64(zs);
+    spr = wave_max(spr);
     if (i == S - 1) {
       float out = -INFINITY;
       if (m > 0.0) {
@@ -779,6 +803,9 @@ __global__ __launch_bounds__(64 * NW) void fac_fwd_plin(int T, int N, int L, int
       }
       // (the leaders finished before this wave did: their verdicts are in `bad`)
       loss[b] = (ok && !__hip_atomic_load(&bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) ? out : __builtin_nanf("");
+      // range check, part 2: beyond kFacPlinSafeBits the log-domain kernel behind this one recomputes the utterance
+      const float gb = __int_as_float(__hip_atomic_load(&gbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      ws.redo[b] = (spr + gb <= kFacPlinSafeBits) ? 0 : 1;
     }
   }
 }

@@ -24,6 +24,12 @@ namespace w2l {
 
 constexpr int kChunk = 16;  // frames per prefetch chunk; a chunk's loads are consumed and its rows stored at the chunk
                            // boundary: ONE vmcnt drain per chunk (on gfx9 that counter also holds the frames' global stores)
+// The scaled-exp scans hold s_t[i] = sum_j exp(A[i][j] - rowmax_i) exp(ahat_{t-1}[j]) as a sum of fp32 products of two factors in
+// (0, 1]: a factor below 1e-38 is flushed, so what the sum can have lost is at most NP * 1.2e-38.  While every sum of an utterance
+// stays above kFccMinSum that loss is below 1e-8 relative (and, in the backward scan, every weight exp(A) e / s that an underflow
+// zeroed is below 1e-10): the scan is exact to fp32.  An utterance with a smaller sum is flagged in ws.redo and recomputed in the
+// log domain, as the reference computes every utterance.
+constexpr float kFccMinSum = 1e-28f;
 constexpr int kDtChunks = 64;  // time chunks of the (parallel) transition-gradient kernel (16 chunks: 85 us behind the scan at T = 2000)
 
 struct FccWs {
@@ -33,8 +39,9 @@ struct FccWs {
                  //            over `logs` the stores alias the scan's prefetch loads and cost a vmcnt(0) per frame)
   float* scale;  // [B]
   float* tgpart; // [B][kDtChunks][N][N] transition-gradient partials (utterance x time chunk)
-  int* redo;     // [B]  N <= 31: 1 = the transition rows spread too far for the fp32 linear-domain scan (fcc_fwd_dpp sets it):
-                 //      the utterance runs on the log-domain kernels (fcc_*_small), whose workspace semantics it then has
+  int* redo;     // [B]  1 = this utterance is outside what the fp32 scaled-domain scan holds exactly -- N <= 31: transition rows spread
+                 //      over more than kFccSafeSpread nats (fcc_fwd_dpp sets it); 32 <= N <= 64: some state's sum fell under
+                 //      kFccMinSum (fcc_fwd_small sets it) -- and runs on the log-domain pair fcc_fwd_log / fcc_bwd_log instead
 };
 
 __host__ __device__ inline FccWs fcc_ws(void* ws, int B, int T, int N) {
@@ -95,6 +102,7 @@ __global__ __launch_bounds__(64) void fcc_fwd_small(int T, int N, int scaleMode,
   for (int u = 0; u < kChunk; ++u) xc[u] = (act && u < T) ? xb[(size_t)u * N + lane] : 0.f;
 
   float ah = 0.f;
+  float smin = INFINITY;   // smallest sum of this lane's state over the frames (range check, off the chain)
   double C = 0.0;
   for (int t0 = 0; t0 < T; t0 += kChunk) {
 #pragma unroll
@@ -122,7 +130,9 @@ __global__ __launch_bounds__(64) void fcc_fwd_small(int T, int N, int scaleMode,
             s0 = __builtin_elementwise_fma(a01, e01, s0);
             s1 = __builtin_elementwise_fma(a23, e23, s1);
           }
-          float s = fmaxf((s0.x + s0.y) + (s1.x + s1.y), 1e-37f);
+          const float sraw = (s0.x + s0.y) + (s1.x + s1.y);
+          smin = act ? (sraw >= smin ? smin : sraw) : smin;   // (a NaN sum lands in smin and fails the check below)
+          float s = fmaxf(sraw, 1e-37f);
           ls = fast_logf(s);
           a = act ? (xc[u] + rowmax + ls) : NEG;
         }
@@ -141,9 +151,13 @@ __global__ __launch_bounds__(64) void fcc_fwd_small(int T, int N, int scaleMode,
   float e = act ? __expf(ah) : 0.f;
   float tot = wave_sum(e);
   float sc = scale_of(scaleMode, T, targetSize[b]);
+  // range check: every sum of every state stayed above kFccMinSum (and was a number), else the log-domain kernel behind this one
+  // recomputes the utterance.  (Launched as the fallback of an older generation -- `redo` given -- there is nothing behind it.)
+  const bool low = __any(act && !(smin >= kFccMinSum)) != 0;
   if (lane == 0) {
     loss[b] = (float)((double)sc * (C + (double)__logf(tot)));
     ws.scale[b] = sc;
+    if (!redo) ws.redo[b] = low ? 1 : 0;
   }
 }
 
@@ -154,6 +168,7 @@ __global__ __launch_bounds__(64) void fcc_bwd_small(int T, int N, const float* _
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
   if (redo && !redo[b]) return;
+  if (!redo && ws.redo[b]) return;   // flagged by fcc_fwd_small: fcc_bwd_log, launched behind this kernel, differentiates it
   const bool act = lane < N;
   const float NEG = -INFINITY;
 
@@ -247,7 +262,9 @@ __global__ __launch_bounds__(64) void fcc_bwd_small(int T, int N, const float* _
 //   L_t[i]  = log sum_j exp(ahat_{t-1}[j] + A[i][j])  (max over j first),      alpha_t[i] = x_t[i] + L_t[i],  ahat = alpha - c_t
 //   w_t[i][j] = exp(ahat_{t-1}[j] + A[i][j] - L_t[i]) in (0, 1],   dalpha_{t-1}[j] = sum_i dalpha_t[i] w_t[i][j],
 //   dA[i][j] = sum_t dalpha_t[i] w_t[i][j]   (accumulated by the same loop: no r_t hand-over to the fcc_dtrans kernels).
-// One wave per flagged utterance, lane = state, N <= 32; `ahat` and `logs` (= L_t) keep the workspace meaning of the other kernels.
+// One wave per flagged utterance, lane = state, N <= NP (32 or 64); `ahat` and `logs` (= L_t) keep the workspace meaning of the
+// other kernels.  NP = 64 (round 6): the fallback of the 32-64-label scans fcc_*_small<64>, which flag what they cannot hold.
+template <int NP>
 __global__ __launch_bounds__(64) void fcc_fwd_log(int T, int N, int scaleMode, const float* __restrict__ x,
                                                   const int* __restrict__ targetSize, const float* __restrict__ trans,
                                                   float* __restrict__ loss, FccWs ws) {
@@ -255,9 +272,9 @@ __global__ __launch_bounds__(64) void fcc_fwd_log(int T, int N, int scaleMode, c
   if (!ws.redo[b]) return;
   const bool act = lane < N;
   const float NEG = -INFINITY;
-  float Ar[32];   // row `lane` of the transitions
+  float Ar[NP];   // row `lane` of the transitions
 #pragma unroll
-  for (int j = 0; j < 32; ++j) Ar[j] = (act && j < N) ? trans[(size_t)lane * N + j] : NEG;
+  for (int j = 0; j < NP; ++j) Ar[j] = (act && j < N) ? trans[(size_t)lane * N + j] : NEG;
   const float* xb = x + (size_t)b * T * N;
   float* ahb = ws.ahat + (size_t)b * T * N;
   float* lsb = ws.logs + (size_t)b * T * N;
@@ -282,17 +299,17 @@ __global__ __launch_bounds__(64) void fcc_fwd_log(int T, int N, int scaleMode, c
         if (t == 0) {
           a = act ? xc[u] : NEG;
         } else {
-          float v[32];
+          float v[NP];
           float m = NEG;
 #pragma unroll
-          for (int j = 0; j < 32; ++j) { v[j] = readlane(ah, j) + Ar[j]; m = fmaxf(m, v[j]); }   // (-inf for j >= N and for dead states)
+          for (int j = 0; j < NP; ++j) { v[j] = readlane(ah, j) + Ar[j]; m = fmaxf(m, v[j]); }   // (-inf for j >= N and for dead states)
           float sum = 0.f;
 #pragma unroll
-          for (int j = 0; j < 32; ++j) sum += fast_expf(v[j] - m);   // every term <= 1, the maximum's is 1
+          for (int j = 0; j < NP; ++j) sum += fast_expf(v[j] - m);   // every term <= 1, the maximum's is 1
           L = m + fast_logf(sum);
           a = act && m > NEG ? xc[u] + L : NEG;
         }
-        const float c = wave_max_rows<2>(a);
+        const float c = wave_max_rows<(NP > 32 ? 4 : 2)>(a);
         ah = a - c;
         C += (double)c;
         if (act) {
@@ -315,22 +332,23 @@ __global__ __launch_bounds__(64) void fcc_fwd_log(int T, int N, int scaleMode, c
   }
 }
 
+template <int NP>
 __global__ __launch_bounds__(64) void fcc_bwd_log(int T, int N, const float* __restrict__ trans, const float* __restrict__ grad,
                                                   float* __restrict__ inputGrad, FccWs ws) {
   const int b = blockIdx.x, lane = threadIdx.x;
   if (!ws.redo[b]) return;
   const bool act = lane < N;
   const float NEG = -INFINITY;
-  float Ac[32];   // column `lane` of the transitions: Ac[i] = A[i][lane]
+  float Ac[NP];   // column `lane` of the transitions: Ac[i] = A[i][lane]
 #pragma unroll
-  for (int i = 0; i < 32; ++i) Ac[i] = (act && i < N) ? trans[(size_t)i * N + lane] : NEG;
+  for (int i = 0; i < NP; ++i) Ac[i] = (act && i < N) ? trans[(size_t)i * N + lane] : NEG;
   const float* ahb = ws.ahat + (size_t)b * T * N;
   const float* lsb = ws.logs + (size_t)b * T * N;
   float* dxb = inputGrad + (size_t)b * T * N;
   const float g = ws.scale[b] * grad[b];
-  float acc[32];   // acc[i] = sum_t dalpha_t[i] w_t[i][lane]
+  float acc[NP];   // acc[i] = sum_t dalpha_t[i] w_t[i][lane]
 #pragma unroll
-  for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+  for (int i = 0; i < NP; ++i) acc[i] = 0.f;
   const float e = act ? __expf(ahb[(size_t)(T - 1) * N + lane]) : 0.f;
   float da = e / wave_sum(e);   // d loss / d alpha_{T-1} = softmax(ahat_{T-1})
   const int li = act ? lane : 0;
@@ -359,7 +377,7 @@ __global__ __launch_bounds__(64) void fcc_bwd_log(int T, int N, const float* __r
         const float apj = act ? ac[u] : NEG;
         float nd = 0.f;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
+        for (int i = 0; i < NP; ++i) {
           const float di = readlane(da, i);
           const float w = fast_expf(apj + Ac[i] - readlane(lc[u], i));   // w_t[i][lane]; exp(-inf) = 0 for i >= N, dead states
           const float dw = di > 0.f ? di * w : 0.f;                      // (0 x anything: a state without posterior mass hands nothing on)
@@ -383,7 +401,7 @@ __global__ __launch_bounds__(64) void fcc_bwd_log(int T, int N, const float* __r
   // the transition-gradient partial of this utterance: time chunk 0 (the fcc_dtrans kernels zero the other chunks of a flagged utterance)
   float* tg = ws.tgpart + (size_t)b * kDtChunks * N * N;
 #pragma unroll
-  for (int i = 0; i < 32; ++i)
+  for (int i = 0; i < NP; ++i)
     if (act && i < N) tg[(size_t)i * N + lane] = g * acc[i];
 }
 
@@ -397,7 +415,7 @@ __global__ __launch_bounds__(64) void fcc_dtrans_small(int T, int N, const float
   const bool lin = LIN;
   const int lane = threadIdx.x;
   const bool act = lane < N;
-  if (LIN && ws.redo[b]) {   // a flagged utterance ran on fcc_fwd_log / fcc_bwd_log: its whole transition gradient is in chunk 0
+  if (ws.redo[b]) {   // a flagged utterance ran on fcc_fwd_log / fcc_bwd_log: its whole transition gradient is in chunk 0
     if (c > 0 && act) {
       float* tz = ws.tgpart + ((size_t)b * kDtChunks + c) * N * N;
       for (int i = 0; i < N; ++i) tz[(size_t)i * N + lane] = 0.f;
@@ -656,6 +674,7 @@ bool viterbi_big_supported(int B, int T, int N);
 size_t viterbi_big_workspace_size(int B, int T, int N);
 int viterbi_big_compute(int B, int T, int N, const float* input, const float* trans, int* path,
                         void* workspace, hipStream_t s);
+const int* fcc_big_range_flags(int B, int T, int N, const void* workspace);
 
 }  // namespace w2l
 
@@ -686,11 +705,17 @@ W2L_API int w2l_fcc_forward(int B, int T, int N, int scaleMode, const float* inp
     else hipLaunchKernelGGL(fcc_fwd_dpp2, dim3(B), dim3(128), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws);
     W2L_LAUNCH_CHECK();
     // the log-domain kernel for the utterances fcc_fwd_dpp flagged (returns at once for the others)
-    hipLaunchKernelGGL(fcc_fwd_log, dim3(B), dim3(64), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws);
-  } else if (N <= 32)
+    hipLaunchKernelGGL(fcc_fwd_log<32>, dim3(B), dim3(64), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws);
+  } else if (N <= 32) {
+    // the scaled-exp scan flags the utterances whose sums left its range (kFccMinSum); the log-domain kernel recomputes those
     hipLaunchKernelGGL(fcc_fwd_small<32>, dim3(B), dim3(64), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws);
-  else
+    W2L_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fcc_fwd_log<32>, dim3(B), dim3(64), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws);
+  } else {
     hipLaunchKernelGGL(fcc_fwd_small<64>, dim3(B), dim3(64), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws);
+    W2L_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fcc_fwd_log<64>, dim3(B), dim3(64), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws);
+  }
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }
@@ -712,11 +737,16 @@ W2L_API int w2l_fcc_backward(int B, int T, int N, const float* trans, const floa
     if (oneWave) hipLaunchKernelGGL(fcc_bwd_dpp, dim3(B), dim3(64), 0, s, T, N, trans, grad, inputGrad, ws);
     else hipLaunchKernelGGL(fcc_bwd_dpp2, dim3(B), dim3(128), 0, s, T, N, trans, grad, inputGrad, ws);
     W2L_LAUNCH_CHECK();
-    hipLaunchKernelGGL(fcc_bwd_log, dim3(B), dim3(64), 0, s, T, N, trans, grad, inputGrad, ws);
-  } else if (N <= 32)
+    hipLaunchKernelGGL(fcc_bwd_log<32>, dim3(B), dim3(64), 0, s, T, N, trans, grad, inputGrad, ws);
+  } else if (N <= 32) {
     hipLaunchKernelGGL(fcc_bwd_small<32>, dim3(B), dim3(64), 0, s, T, N, trans, grad, inputGrad, ws);
-  else
+    W2L_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fcc_bwd_log<32>, dim3(B), dim3(64), 0, s, T, N, trans, grad, inputGrad, ws);
+  } else {
     hipLaunchKernelGGL(fcc_bwd_small<64>, dim3(B), dim3(64), 0, s, T, N, trans, grad, inputGrad, ws);
+    W2L_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fcc_bwd_log<64>, dim3(B), dim3(64), 0, s, T, N, trans, grad, inputGrad, ws);
+  }
   W2L_LAUNCH_CHECK();
   if (dpp && !tune_env("W2L_FCC_DTRANS_OLD"))
     hipLaunchKernelGGL(fcc_dtrans_mfma, dim3(B, kDtChunks), dim3(64), 0, s, T, N, trans, grad, ws);
@@ -732,6 +762,19 @@ W2L_API int w2l_fcc_backward(int B, int T, int N, const float* trans, const floa
   W2L_LAUNCH_CHECK();
   hipLaunchKernelGGL(reduce_over_b, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, B, n, ws.tgpart, transGrad, kDtChunks);
   W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+W2L_API int w2l_fcc_range_flags(int B, int T, int N, const void* workspace, int* flags, w2l_stream_t stream) {
+  if (B <= 0 || T <= 0 || N <= 0 || !workspace || !flags) return W2L_EINVAL;
+  const int* src;
+  if (N > 64) {
+    if (!fcc_big_supported(B, T, N)) return W2L_EUNSUPPORTED;
+    src = fcc_big_range_flags(B, T, N, workspace);
+  } else {
+    src = fcc_ws((void*)workspace, B, T, N).redo;
+  }
+  W2L_HIP_CHECK(hipMemcpyAsync(flags, src, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return W2L_OK;
 }
 

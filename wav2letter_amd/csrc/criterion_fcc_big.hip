@@ -73,6 +73,7 @@ struct BigDims {
             // stream loaded entirely with the default policy evicts itself before it is reused).  W2L_FCC_CACHE (probe).
   int abl;  // W2L_FCC_ABL: timing-only ablations 1 = no MFMA, 2 = no E-operand traffic; 4 = nontemporal loads of the
             // transition stream (results stay correct)
+  float minSum;  // range check of the scaled-exp recursion (see fcc_big_step): a sum below it flags the utterance for the exact path
 };
 
 // persistent workgroups per CU of the streaming kernel: register-limited (three operand stages of
@@ -102,6 +103,7 @@ inline BigDims big_dims(int B, int T, int N) {
   d.B = B; d.T = T; d.N = N;
   d.Kp = (N + 31) / 32 * 32;
   d.NC = d.Kp / 8;
+  d.minSum = fmaxf(1e-28f, 1e-30f * (float)N);
   int nb = (B + 31) / 32;
   d.NB = nb <= 1 ? 1 : (nb <= 2 ? 2 : 4);
   d.Bp = 32 * d.NB;
@@ -163,6 +165,8 @@ struct BigWs {
   float* gb;      // [B] scale * upstream grad
   unsigned* cnt;  // [G] arrival tickets of the folded step (self-resetting; zeroed once per call)
   float* cfin;    // [T][B] c_t = the maximum of a_t (of its kBigParts partial maxima), written by fcc_big_loss for the backward pass
+  int* redo;      // [B + 1] range check: [b] = 1: some sum of utterance b fell under BigDims::minSum -> the exact log-domain kernels
+                  //         (fcc_big_exact_*) recompute it; [B] = 1: at least one utterance is flagged
   size_t bytes;
 };
 
@@ -185,6 +189,7 @@ __host__ __device__ inline BigWs big_ws(void* ws, const BigDims& d) {
   w.gb = (float*)take((size_t)d.B * sizeof(float));
   w.cnt = (unsigned*)take((size_t)d.G * sizeof(unsigned));
   w.cfin = (float*)take((size_t)d.T * d.B * sizeof(float));
+  w.redo = (int*)take((size_t)(d.B + 1) * sizeof(int));
   w.bytes = (size_t)(p - (char*)ws);
   return w;
 }
@@ -569,6 +574,7 @@ struct BigFold {
   float* pmax;        // ws.pmax + t * B * kBigParts, pre-filled with -inf
   unsigned* cnt;
   size_t xStride;     // T * N
+  int* redo;          // ws.redo (range check, as in fcc_big_step)
 };
 
 // max into a float cell holding -inf or a previous maximum: order-preserving integer views of IEEE floats
@@ -753,6 +759,7 @@ __global__ __launch_bounds__(256, 2) void fcc_big_gemm_dma(const float4* __restr
                 const int i = i0 + u;
                 float v = -INFINITY;
                 if (i < N) {
+                  if (!(ssum[u] >= d.minSum)) { f.redo[b] = 1; f.redo[B] = 1; }   // range check (see fcc_big_step)
                   const float sc = fmaxf(ssum[u], 1e-37f);
                   v = xv[it][u] + (rv[it][u] + __logf(sc));
                   ir[i] = 1.f / sc;
@@ -858,6 +865,13 @@ __global__ __launch_bounds__(256) void fcc_big_step(BigDims d, int t, const floa
   float* ir = ws.invs + ((size_t)t * d.B + b) * N;
   float* apk = ws.ep[t & 1];
   float m = -INFINITY;
+  // Range check.  s[i] = sum_j exp(A[i][j] - rowmax_i) exp(ahat[j]) is a sum of fp32 products of two factors in (0, 1]; a factor
+  // below 1e-38 is flushed, so the sum can have lost at most N * 1.2e-38.  While every sum stays above minSum = max(1e-28, 1e-30 N)
+  // that is below 1e-8 relative, and every weight exp(A) e / s that an underflow zeroes in the backward recursion is below 1e-10:
+  // the recursion is exact to fp32.  A smaller sum (emissions AND transitions tens of nats wide: a state whose every term lies
+  // ~65 nats under the factors' maxima) means the 1e-37 floor below may have moved the posterior: the utterance is flagged and
+  // recomputed in the log domain, as the reference computes every utterance, by fcc_big_exact_fwd / _bwd.
+  bool low = false;
   for (int q = q0 + threadIdx.x; q < q1; q += 256) {
     const int i0 = 4 * q;
     float xv[4];
@@ -874,6 +888,7 @@ __global__ __launch_bounds__(256) void fcc_big_step(BigDims d, int t, const floa
     float a4[4], inv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
+      low = low || (t > 0 && i0 + u < N && !(ssum[u] >= d.minSum));   // (NaN fails the comparison too)
       const float sc = fmaxf(ssum[u], 1e-37f);
       inv[u] = 1.f / sc;
       const float v = t > 0 ? xv[u] + (rmv[u] + __logf(sc)) : xv[u];
@@ -892,6 +907,7 @@ __global__ __launch_bounds__(256) void fcc_big_step(BigDims d, int t, const floa
     }
     *(float4*)(apk + packed_op_index(b, i0, d.NC)) = make_float4(a4[0], a4[1], a4[2], a4[3]);
   }
+  if (low) { ws.redo[b] = 1; ws.redo[d.B] = 1; }   // (every writer writes 1: no ordering needed)
   m = block_max<256>(m, sm);
   if (threadIdx.x == 0) ws.pmax[((size_t)t * d.B + b) * kBigParts + blockIdx.x] = m;
 }
@@ -938,6 +954,8 @@ __global__ __launch_bounds__(kBigStepThreads) void fcc_big_bwd_init(BigDims d, c
   float* rpk = ws.ep[t & 1];
   const float g = ws.scale[b] * grad[b];
   if (threadIdx.x == 0) ws.gb[b] = g;
+  if (ws.redo[b]) return;   // flagged by the forward range check: fcc_big_exact_bwd differentiates this utterance (its packed
+                            // operand stays zero: it rides through the streaming kernel as a zero column)
   const float c = big_cmax(ws.pmax, d.B, t, b);
   float tot = 0.f;
   for (int i = threadIdx.x; i < N; i += kBigStepThreads) {
@@ -974,6 +992,7 @@ __global__ __launch_bounds__(256) void fcc_big_bwd_step(BigDims d, int tm, float
   const int b = blockIdx.y, N = d.N;
   const int i0 = 4 * (blockIdx.x * 256 + threadIdx.x);
   if (i0 >= N) return;
+  if (ws.redo[b]) return;   // see fcc_big_bwd_init
   float* er = ws.e + ((size_t)tm * d.B + b) * N;
   const float* ir = ws.invs + ((size_t)tm * d.B + b) * N;
   float* dxr = dx + ((size_t)b * d.T + tm) * N;
@@ -1012,13 +1031,186 @@ __global__ __launch_bounds__(256) void fcc_big_bwd_step(BigDims d, int tm, float
   if (tm > 0) *(float4*)(ws.ep[tm & 1] + packed_op_index(b, i0, d.NC)) = make_float4(r4[0], r4[1], r4[2], r4[3]);
 }
 
-// dA[i][j] *= exp(A[i][j] - rowmax_i)
+// dA[i][j] *= exp(A[i][j] - rowmax_i);  + the flagged utterances' share (fcc_big_exact_dtrans), if there is one
 __global__ __launch_bounds__(256) void fcc_big_scale_dtrans(int N, const float* __restrict__ A, const float* __restrict__ rm,
-                                                           float* __restrict__ dA) {
+                                                           float* __restrict__ dA, const float* __restrict__ exact,
+                                                           const int* __restrict__ any) {
   const size_t n = (size_t)N * N;
+  const bool add = *any != 0;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
     const int i = (int)(e / N);
-    dA[e] *= __expf(A[e] - rm[i]);
+    float v = dA[e] * __expf(A[e] - rm[i]);
+    if (add) v += exact[e];
+    dA[e] = v;
+  }
+}
+
+// ------------------------------------------------------------------ the exact path behind the range check (round 6)
+// The utterances fcc_big_step flags are recomputed the way the reference computes every utterance (un-vendored
+// fl::lib::cpu::FullConnectionCriterion, restated in oracle/criterion_oracle.c): every term ONE exponential of a sum that is <= 0,
+//   L_t[i] = LSE_j(ahat_{t-1}[j] + A[i][j]),  a_t[i] = x_t[i] + L_t[i],  ahat = a - max a,
+//   w_t[i][j] = exp(ahat_{t-1}[j] + A[i][j] - L_t[i]) in (0, 1],  dalpha_{t-1}[j] = sum_i dalpha_t[i] w_t[i][j],
+//   dA[i][j] += g sum_t dalpha_t[i] w_t[i][j].
+// N^2 exponentials per frame and utterance on the VALU instead of a pass of the matrix pipe over the packed stream: one workgroup
+// per flagged utterance scans T (a frame needs the whole previous row), ~10 s at N = 9998, T = 1500 -- on a path no recipe takes
+// (logits of +-10 and transitions of a few nats are two orders of magnitude inside the range check); the kernels return at once
+// when nothing is flagged.  Workspace rows of a flagged utterance: e[t] = a_t (as for the others), invs[t] = L_t, rg[t] = g dalpha_t.
+constexpr int kExactThreads = 1024;
+
+__global__ __launch_bounds__(kExactThreads) void fcc_big_exact_fwd(BigDims d, const float* __restrict__ x, const float* __restrict__ A,
+                                                                    BigWs ws) {
+  const int b = blockIdx.x;
+  if (!ws.redo[b]) return;
+  __shared__ float sm[kExactThreads / 64];
+  constexpr int NW = kExactThreads / 64;
+  const int N = d.N, T = d.T, B = d.B;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float cPrev;
+  {   // a_0 = x_0
+    const float* xr = x + ((size_t)b * T) * N;
+    float* ar = ws.e + (size_t)b * N;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < N; i += kExactThreads) {
+      const float v = xr[i];
+      ar[i] = v;
+      m = fmaxf(m, v);
+    }
+    cPrev = block_max<kExactThreads>(m, sm);
+    if (threadIdx.x < kBigParts) ws.pmax[(size_t)b * kBigParts + threadIdx.x] = cPrev;
+  }
+  __syncthreads();
+  for (int t = 1; t < T; ++t) {
+    const float* ap = ws.e + ((size_t)(t - 1) * B + b) * N;
+    float* ar = ws.e + ((size_t)t * B + b) * N;
+    float* Lr = ws.invs + ((size_t)t * B + b) * N;
+    const float* xr = x + ((size_t)b * T + t) * N;
+    float mloc = -INFINITY;
+    for (int i = wave; i < N; i += NW) {   // a row per wave: lanes over j, the row of A read coalesced (twice: maximum, then sum)
+      const float* Ar = A + (size_t)i * N;
+      float m = -INFINITY;
+      for (int j = lane; j < N; j += 64) m = fmaxf(m, (ap[j] - cPrev) + Ar[j]);
+      m = wave_max(m);
+      float L = -INFINITY;
+      if (m > -INFINITY) {   // wave-uniform
+        float s = 0.f;
+        for (int j = lane; j < N; j += 64) s += fast_expf(((ap[j] - cPrev) + Ar[j]) - m);   // every term <= 1, the maximum's is 1
+        L = m + fast_logf(wave_sum(s));
+      }
+      const float a = L > -INFINITY ? xr[i] + L : -INFINITY;
+      if (lane == 0) { ar[i] = a; Lr[i] = L; }
+      mloc = fmaxf(mloc, a);
+    }
+    cPrev = block_max<kExactThreads>(mloc, sm);   // (its barriers also publish a_t to the whole workgroup: same CU, same L1)
+    if (threadIdx.x < kBigParts) ws.pmax[((size_t)t * B + b) * kBigParts + threadIdx.x] = cPrev;
+    __syncthreads();
+  }
+}
+
+// the backward recursion of a flagged utterance (after fcc_big_loss: cfin[t] = max a_t)
+__global__ __launch_bounds__(kExactThreads) void fcc_big_exact_bwd(BigDims d, const float* __restrict__ A, float* __restrict__ dx, BigWs ws) {
+  const int b = blockIdx.x;
+  if (!ws.redo[b]) return;
+  __shared__ float sm[kExactThreads / 64];
+  const int N = d.N, T = d.T, B = d.B;
+  const float g = ws.gb[b];
+  {   // g dalpha_{T-1} = g softmax(a_{T-1})
+    const int t = T - 1;
+    const float* ar = ws.e + ((size_t)t * B + b) * N;
+    float* gr = ws.rg + ((size_t)t * B + b) * N;
+    float* dxr = dx + ((size_t)b * T + t) * N;
+    const float c = ws.cfin[(size_t)t * B + b];
+    float tot = 0.f;
+    for (int i = threadIdx.x; i < N; i += kExactThreads) tot += fast_expf(ar[i] - c);
+    tot = block_sum<kExactThreads>(tot, sm);
+    const float inv = g / tot;
+    for (int i = threadIdx.x; i < N; i += kExactThreads) {
+      const float v = inv * fast_expf(ar[i] - c);
+      gr[i] = v;
+      dxr[i] = v;
+    }
+  }
+  __syncthreads();
+  constexpr int JR = 4;
+  for (int t = T - 1; t >= 1; --t) {
+    const float* gd = ws.rg + ((size_t)t * B + b) * N;
+    const float* Lr = ws.invs + ((size_t)t * B + b) * N;
+    const float* ap = ws.e + ((size_t)(t - 1) * B + b) * N;
+    const float cp = ws.cfin[(size_t)(t - 1) * B + b];
+    float* go = ws.rg + ((size_t)(t - 1) * B + b) * N;
+    float* dxr = dx + ((size_t)b * T + (t - 1)) * N;
+    for (int j0 = 0; j0 < N; j0 += kExactThreads * JR) {   // a thread owns JR states j; the rows of A pass by coalesced
+      int js[JR];
+      float ah[JR], acc[JR];
+#pragma unroll
+      for (int r = 0; r < JR; ++r) {
+        js[r] = j0 + r * kExactThreads + (int)threadIdx.x;
+        ah[r] = js[r] < N ? ap[js[r]] - cp : -INFINITY;
+        acc[r] = 0.f;
+        if (js[r] >= N) js[r] = N - 1;
+      }
+      for (int i = 0; i < N; ++i) {
+        const float gi = gd[i];      // uniform
+        if (!(gi != 0.f)) continue;  // a state without posterior mass hands nothing on (and its L may be -inf)
+        const float Li = Lr[i];
+        const float* Ar = A + (size_t)i * N;
+#pragma unroll
+        for (int r = 0; r < JR; ++r) acc[r] += gi * fast_expf((ah[r] + Ar[js[r]]) - Li);   // exp(-inf) = 0: dead states, padding
+      }
+#pragma unroll
+      for (int r = 0; r < JR; ++r) {
+        const int j = j0 + r * kExactThreads + (int)threadIdx.x;
+        if (j < N) { go[j] = acc[r]; dxr[j] = acc[r]; }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// out[i][j] = sum over flagged utterances b, frames t >= 1 of (g dalpha_t)[b][i] exp(ahat_{t-1}[b][j] + A[i][j] - L_t[b][i]):
+// fully parallel over (i, j); a wave owns 8 rows x 64 columns.  Returns at once when no utterance is flagged.
+__global__ __launch_bounds__(256) void fcc_big_exact_dtrans(BigDims d, const float* __restrict__ A, float* __restrict__ out, BigWs ws) {
+  const int N = d.N, T = d.T, B = d.B;
+  if (!ws.redo[B]) return;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int i0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 8;
+  if (i0 >= N) return;   // wave-uniform
+  const int jc = min(j, N - 1);
+  float a[8], acc[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    a[r] = A[(size_t)min(i0 + r, N - 1) * N + jc];
+    acc[r] = 0.f;
+  }
+  for (int b = 0; b < B; ++b) {
+    if (!ws.redo[b]) continue;
+    for (int t = 1; t < T; ++t) {
+      const float ah = ws.e[((size_t)(t - 1) * B + b) * N + jc] - ws.cfin[(size_t)(t - 1) * B + b];
+      const float* gd = ws.rg + ((size_t)t * B + b) * N;
+      const float* Lr = ws.invs + ((size_t)t * B + b) * N;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int i = min(i0 + r, N - 1);
+        const float gi = gd[i];   // wave-uniform
+        if (gi != 0.f) acc[r] += gi * fast_expf((ah + a[r]) - Lr[i]);
+      }
+    }
+  }
+  if (j < N) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      if (i0 + r < N) out[(size_t)(i0 + r) * N + j] = acc[r];
+  }
+}
+
+// the rows of a flagged utterance leave the transition-gradient product (its share came from fcc_big_exact_dtrans): zero both
+// operands' rows -- a_t may hold -inf, and 0 x inf would poison the product
+__global__ __launch_bounds__(256) void fcc_big_exact_clear(BigDims d, BigWs ws) {
+  const int b = blockIdx.y;
+  if (!ws.redo[b]) return;
+  for (int t = blockIdx.x; t < d.T; t += gridDim.x) {
+    float* er = ws.e + ((size_t)t * d.B + b) * d.N;
+    float* gr = ws.rg + ((size_t)t * d.B + b) * d.N;
+    for (int i = threadIdx.x; i < d.N; i += 256) { er[i] = 0.f; gr[i] = 0.f; }
   }
 }
 
@@ -1105,6 +1297,10 @@ size_t fcc_big_workspace_size(int B, int T, int N) {
   return big_ws(nullptr, d).bytes;
 }
 
+const int* fcc_big_range_flags(int B, int T, int N, const void* workspace) {
+  return big_ws((void*)workspace, big_dims(B, T, N)).redo;
+}
+
 static int big_pack(const BigDims& d, const BigWs& ws, const float* trans, bool transposed, hipStream_t s) {
   const size_t total4 = (size_t)d.Np * d.Kp / 4;
   const unsigned blocks = (unsigned)((total4 + 255) / 256);
@@ -1134,6 +1330,7 @@ int fcc_big_forward(int B, int T, int N, int scaleMode, const float* input, cons
   W2L_LAUNCH_CHECK();
   // the step kernels add all P slabs of a row group: the ones its workers never write read as zero
   W2L_HIP_CHECK(hipMemsetAsync(ws.part, 0, (size_t)d.P * d.Bp * d.Np * sizeof(float), s));
+  W2L_HIP_CHECK(hipMemsetAsync(ws.redo, 0, (size_t)(B + 1) * sizeof(int), s));   // range-check flags (fcc_big_step raises them)
   const dim3 sgrid(kBigParts, (unsigned)B);
   const bool fold = big_fold_ok(d) && T > 1;
   if (fold) {
@@ -1148,7 +1345,7 @@ int fcc_big_forward(int B, int T, int N, int scaleMode, const float* input, cons
         BigFold f;
         f.x = input + (size_t)t * N; f.xStride = (size_t)T * N; f.rm = ws.rm;
         f.a = ws.e + (size_t)t * B * N; f.invs = ws.invs + (size_t)t * B * N; f.apk = ws.ep[t & 1];
-        f.pmax = ws.pmax + (size_t)t * B * kBigParts; f.cnt = ws.cnt;
+        f.pmax = ws.pmax + (size_t)t * B * kBigParts; f.cnt = ws.cnt; f.redo = ws.redo;
         st = big_gemm<true, true>(d, ws.pack, ws.ep[(t - 1) & 1], ws.pmax + (size_t)(t - 1) * B * kBigParts, ws.part, s, f);
         if (st) return st;
         continue;
@@ -1159,6 +1356,9 @@ int fcc_big_forward(int B, int T, int N, int scaleMode, const float* input, cons
     hipLaunchKernelGGL(fcc_big_step, sgrid, dim3(256), 0, s, d, t, input, ws);
     W2L_LAUNCH_CHECK();
   }
+  // the utterances the range check flagged: the whole recursion again in the log domain (returns at once for the others)
+  hipLaunchKernelGGL(fcc_big_exact_fwd, dim3((unsigned)B), dim3(kExactThreads), 0, s, d, input, trans, ws);
+  W2L_LAUNCH_CHECK();
   hipLaunchKernelGGL(fcc_big_loss, dim3((unsigned)B), dim3(kBigStepThreads), 0, s, d, scaleMode, targetSize, loss, ws);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
@@ -1181,14 +1381,22 @@ int fcc_big_backward(int B, int T, int N, const float* trans, const float* grad,
     hipLaunchKernelGGL(fcc_big_bwd_step, sgrid, dim3(256), 0, s, d, t - 1, inputGrad, ws);
     W2L_LAUNCH_CHECK();
   }
+  // flagged utterances (skipped by the kernels above): exact recursion, their share of the transition gradient into the pack
+  // buffer (>= N x N floats, free now), then their rows leave the product below.  Three launches that return at once otherwise.
+  hipLaunchKernelGGL(fcc_big_exact_bwd, dim3((unsigned)B), dim3(kExactThreads), 0, s, d, trans, inputGrad, ws);
+  W2L_LAUNCH_CHECK();
   if (T == 1) {
     W2L_HIP_CHECK(hipMemsetAsync(transGrad, 0, (size_t)N * N * sizeof(float), s));
     return W2L_OK;
   }
+  hipLaunchKernelGGL(fcc_big_exact_dtrans, dim3((unsigned)((N + 63) / 64), (unsigned)((N + 31) / 32)), dim3(256), 0, s, d, trans, ws.pack, ws);
+  W2L_LAUNCH_CHECK();
+  hipLaunchKernelGGL(fcc_big_exact_clear, dim3(64, (unsigned)B), dim3(256), 0, s, d, ws);
+  W2L_LAUNCH_CHECK();
   // dA_raw[i][j] = sum_{t>=1,b} (g r_t)[b][i] * e_{t-1}[b][j] : both operands "k-rows", reduction over (t,b)
   st = gemm_f32(ws.rg + (size_t)B * N, N, 0, ws.e, N, 0, transGrad, N, N, N, (T - 1) * B, nullptr, 0, 1, s);
   if (st) return st;
-  hipLaunchKernelGGL(fcc_big_scale_dtrans, dim3(2048), dim3(256), 0, s, N, trans, ws.rm, transGrad);
+  hipLaunchKernelGGL(fcc_big_scale_dtrans, dim3(2048), dim3(256), 0, s, N, trans, ws.rm, transGrad, ws.pack, ws.redo + B);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
 }
