@@ -255,11 +255,12 @@ print("VARIANT OK")
 
 
 @pytest.mark.parametrize("env", [{"W2L_FCC_1WAVE": "1"}, {"W2L_FAC_GEN": "wave", "W2L_FAC_BWD": "wave"}, {"W2L_FAC_GEN": "blin", "W2L_FAC_BWD": "blk51"},
-                                 {"W2L_FAC_GEN": "blin2", "W2L_FAC_BWD": "blk42"}, {"W2L_ASG_OLD": "1"}, {"W2L_FCC_DTRANS_OLD": "1"}, {"W2L_FAC_BWD32": "1"}])
+                                 {"W2L_FAC_GEN": "blin2", "W2L_FAC_BWD": "blk42"}, {"W2L_ASG_OLD": "1"}, {"W2L_FCC_DTRANS_OLD": "1"}, {"W2L_FAC_BWD32": "1"}, {"W2L_ASG_NOMITM": "1"}])
 def test_asg_kernel_variants_of_the_probe_library(env):
     """the kernel generations the product does not run stay selectable in the probe library (A/B work) and stay correct: the
     one-wave FCC scans, the one-wave FAC scans (with their hand-over to the log-domain kernel), the barrier-per-frame FAC scans (rows by a sixth wave / from the pre-pass; backward 5 x 1 and 4 x 2),
-    the round-3 log-domain kernels, the transition gradient by lane broadcasts instead of the MFMA kernel, the FAC backward scan with 32-frame chunks"""
+    the round-3 log-domain kernels, the transition gradient by lane broadcasts instead of the MFMA kernel, the FAC backward scan with 32-frame chunks,
+    the round-4 / round-5 full-length scans (fcc_*_dpp2, fac_*_plin) that the meet-in-the-middle pair replaced in round 6"""
     import os
     import subprocess
     import sys

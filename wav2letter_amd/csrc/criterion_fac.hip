@@ -22,11 +22,14 @@
 // rows (L1/L2 resident: the row is 120 B at N = 30), prefetched kFacChunk steps ahead.
 #include "common.hpp"
 #include <cstring>
+#include <cstdlib>
 
 namespace w2l {
 
 constexpr int kFacChunk = 16;  // frames per prefetch chunk: ONE vmcnt drain (loads AND the frames' stores) per chunk
 constexpr int kFacMaxN = 2048;  // LDS row buffer for the input-gradient scatter
+
+struct FacRec;   // (criterion_fac_lin.hpp) fp64 mantissa + integer exponent of one lattice position
 
 struct FacWs {
   float* w1;     // [B][T][L]  soft-max weights of the forward scan
@@ -38,6 +41,9 @@ struct FacWs {
   double* crow;  // [B][T][32] label rows c_t[n] of fac_rows_k (N <= 32 only, else NULL)
   float* zmax;   // [B][T]     frame maxima (base 2) of the label scores
   float* zspr;   // [B][T]     frame maximum - frame minimum of the label scores (base 2): the range check of fac_fwd_plin
+  FacRec* hm;    // [B][320]   meet in the middle (criterion_fac_mitm.hpp): h_m of the alpha half, per position
+  FacRec* gm;    // [B][320]   ... g_m of the beta half
+  float* gam;    // [B][320]   ... the middle frame's posterior gamma_m = h_m g_m / Z
   int* redo;     // [B]  set by fac_fwd_lin / fac_fwd_plin: the utterance's dynamics exceed what the scaled linear domain holds
                  //      exactly -> fac_fwd_blk (log domain), launched behind it, recomputes that utterance
 };
@@ -56,11 +62,14 @@ __host__ __device__ inline FacWs fac_ws(void* ws, int B, int T, int N, int L) {
   w.bp = (unsigned char*)w.w1;  // viterbi reuses the w1 region (needs B*T*L bytes)
   w.tgpart = fac_use_partials(B, N) ? (float*)p : nullptr;
   if (w.tgpart) p += align_up((size_t)B * N * N * sizeof(float), 256);
-  w.crow = nullptr; w.zmax = nullptr; w.zspr = nullptr;
+  w.crow = nullptr; w.zmax = nullptr; w.zspr = nullptr; w.hm = nullptr; w.gm = nullptr; w.gam = nullptr;
   if (N <= 32) {
     w.crow = (double*)p; p += align_up((size_t)B * T * 32 * sizeof(double), 256);
     w.zmax = (float*)p; p += align_up((size_t)B * T * sizeof(float), 256);
-    w.zspr = (float*)p;
+    w.zspr = (float*)p; p += align_up((size_t)B * T * sizeof(float), 256);
+    w.hm = (FacRec*)p; p += align_up((size_t)B * 320 * 16, 256);
+    w.gm = (FacRec*)p; p += align_up((size_t)B * 320 * 16, 256);
+    w.gam = (float*)p;
   }
   return w;
 }
@@ -68,6 +77,7 @@ __host__ __device__ inline FacWs fac_ws(void* ws, int B, int T, int N, int L) {
 }  // namespace w2l
 
 #include "criterion_fac_lin.hpp"   // N <= 32, L <= 320: scaled linear domain, one wave per utterance (fac_fwd_lin, fac_bwd_wave)
+#include "criterion_fac_mitm.hpp"  // ... the product: the pipelined scans from both ends to the middle frame (fac_mitm_fwd, fac_mitm_bwd)
 
 namespace w2l {
 
@@ -75,6 +85,20 @@ namespace w2l {
 inline bool fac_lin_path(int N, int L) {
   static const bool old = tune_env("W2L_ASG_OLD") != nullptr;
   return N <= 32 && L <= 320 && !old;
+}
+// product: the meet-in-the-middle pair; the probe library runs the round-4 / round-5 full-length scans under W2L_ASG_NOMITM=1 or any
+// of the generation switches (W2L_FAC_GEN, W2L_FAC_BWD, W2L_FAC_BWD32)
+inline int fac_mitm_only() {   // probe, timing only: one half of the meet-in-the-middle kernels alone (W2L_MITM_ONLY=0 / 1)
+  static const int v = [] { const char* e = tune_env("W2L_MITM_ONLY"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+  return v;
+}
+inline int fac_mitm_abl() {   // probe, timing only: W2L_FAC_ABL bit 0 = no label-weight loads, bit 1 = no w1 stores in fac_mitm_fwd
+  static const int v = [] { const char* e = tune_env("W2L_FAC_ABL"); return e ? atoi(e) : 0; }();
+  return v;
+}
+inline bool fac_mitm_path() {
+  static const bool off = tune_env("W2L_ASG_NOMITM") || tune_env("W2L_FAC_GEN") || tune_env("W2L_FAC_BWD") || tune_env("W2L_FAC_BWD32");
+  return !off;
 }
 
 template <int P>
@@ -866,7 +890,8 @@ W2L_API size_t w2l_fac_workspace_size(int B, int T, int N, int L) {
   size_t sz = 2 * align_up((size_t)B * T * L * sizeof(float), 256) + align_up((size_t)B * sizeof(float), 256) +
               align_up((size_t)B * sizeof(int), 256);
   if (fac_use_partials(B, N)) sz += align_up((size_t)B * N * N * sizeof(float), 256);
-  if (N <= 32) sz += align_up((size_t)B * T * 32 * sizeof(double), 256) + 2 * align_up((size_t)B * T * sizeof(float), 256);
+  if (N <= 32) sz += align_up((size_t)B * T * 32 * sizeof(double), 256) + 2 * align_up((size_t)B * T * sizeof(float), 256) +
+                     2 * align_up((size_t)B * 320 * 16, 256) + align_up((size_t)B * 320 * sizeof(float), 256);
   return sz;
 }
 
@@ -906,6 +931,28 @@ W2L_API int w2l_fac_forward(int B, int T, int N, int L, int scaleMode, const flo
       return !strcmp(e, "blin2") ? 1 : !strcmp(e, "blin") ? 2 : !strcmp(e, "wave") ? 3 : 0;
     }();
     const int nw = (L + 63) / 64;
+    if (fac_mitm_path()) {
+      hipLaunchKernelGGL(fac_rows_k, dim3((unsigned)((T + kFacRowsPerWave - 1) / kFacRowsPerWave), (unsigned)B), dim3(64), 0, s, T, N, input,
+                         trans, ws.crow, ws.zmax, ws.zspr);
+      W2L_LAUNCH_CHECK();
+#define W2L_FAC_M_GO(NWV) hipLaunchKernelGGL((fac_mitm_fwd<NWV>), dim3(B, fac_mitm_only() < 0 ? 2 : 1), dim3(64 * NWV), 0, s, T, N, L, target, targetSize, trans, ws, fac_mitm_only() < 0 ? 0 : fac_mitm_only(), fac_mitm_abl())
+      switch (nw) {
+        case 1: W2L_FAC_M_GO(1); break;
+        case 2: W2L_FAC_M_GO(2); break;
+        case 3: W2L_FAC_M_GO(3); break;
+        case 4: W2L_FAC_M_GO(4); break;
+        default: W2L_FAC_M_GO(5); break;
+      }
+#undef W2L_FAC_M_GO
+      W2L_LAUNCH_CHECK();
+      hipLaunchKernelGGL(fac_mitm_finish, dim3(B), dim3(kFacFinishThreads), 0, s, T, N, L, scaleMode, target, targetSize, trans, loss, ws);
+      W2L_LAUNCH_CHECK();
+      // the utterances the range check flagged: the whole forward scan again in the log domain (returns at once for the others)
+      if (L > 256) hipLaunchKernelGGL((fac_fwd_blk<8, 1>), dim3(B), dim3(512), 0, s, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws, (const int*)ws.redo);
+      else W2L_FAC_BLK_DISPATCH(fac_fwd_blk, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws, (const int*)ws.redo);
+      W2L_LAUNCH_CHECK();
+      return W2L_OK;
+    }
     if (gen == 3) {
 #define W2L_FAC_LIN_GO(PP) hipLaunchKernelGGL(fac_fwd_lin<PP>, dim3(B), dim3(64), 0, s, T, N, L, scaleMode, input, target, targetSize, trans, loss, ws)
       switch (nw) {
@@ -1022,7 +1069,17 @@ W2L_API int w2l_fac_backward(int B, int T, int N, int L, const int* target, cons
     if (!e) return 0;
     return !strcmp(e, "wave") ? 1 : !strcmp(e, "blk51") ? 2 : !strcmp(e, "blk42") ? 3 : 0;
   }();
-  if (fac_lin_path(N, L) && bgen == 0 && tune_env("W2L_FAC_BWD32")) {   // probe: 32 frames per chunk (half the per-chunk round trips)
+  if (fac_lin_path(N, L) && fac_mitm_path()) {
+#define W2L_FAC_M_GO(NWV) hipLaunchKernelGGL((fac_mitm_bwd<NWV>), dim3(B, fac_mitm_only() < 0 ? 2 : 1), dim3(64 * NWV), 0, s, T, N, L, target, targetSize, grad, transGrad, ws, fac_mitm_only() < 0 ? 0 : fac_mitm_only())
+    switch ((L + 63) / 64) {
+      case 1: W2L_FAC_M_GO(1); break;
+      case 2: W2L_FAC_M_GO(2); break;
+      case 3: W2L_FAC_M_GO(3); break;
+      case 4: W2L_FAC_M_GO(4); break;
+      default: W2L_FAC_M_GO(5); break;
+    }
+#undef W2L_FAC_M_GO
+  } else if (fac_lin_path(N, L) && bgen == 0 && tune_env("W2L_FAC_BWD32")) {   // probe: 32 frames per chunk (half the per-chunk round trips)
 #define W2L_FAC_PB_GO(NWV) hipLaunchKernelGGL((fac_bwd_plin<NWV, 32>), dim3(B), dim3(64 * NWV), 0, s, T, N, L, target, targetSize, grad, transGrad, ws)
     switch ((L + 63) / 64) {
       case 1: W2L_FAC_PB_GO(1); break;

@@ -39,6 +39,10 @@ struct FccWs {
                  //            over `logs` the stores alias the scan's prefetch loads and cost a vmcnt(0) per frame)
   float* scale;  // [B]
   float* tgpart; // [B][kDtChunks][N][N] transition-gradient partials (utterance x time chunk)
+  float* r2;     // [B][T][N]  N <= 31, meet in the middle: b_t q'_t of the forward pass's beta half (frames above the middle)
+  double* half;  // [B][2]  ... : base-2 scale sums of the alpha half (frames 0 .. m) and of the beta half (m+1 .. T-1)
+  float* bm;     // [B][32] ... : b_m of the beta half, by state
+  float* ginv;   // [B]     ... : 1 / sum_i u_m[i] b_m[i]
   int* redo;     // [B]  1 = this utterance is outside what the fp32 scaled-domain scan holds exactly -- N <= 31: transition rows spread
                  //      over more than kFccSafeSpread nats (fcc_fwd_dpp sets it); 32 <= N <= 64: some state's sum fell under
                  //      kFccMinSum (fcc_fwd_small sets it) -- and runs on the log-domain pair fcc_fwd_log / fcc_bwd_log instead
@@ -53,13 +57,21 @@ __host__ __device__ inline FccWs fcc_ws(void* ws, int B, int T, int N) {
   w.r = (float*)p; p += btn;
   w.scale = (float*)p; p += align_up((size_t)B * sizeof(float), 256);
   w.tgpart = (float*)p; p += align_up((size_t)B * kDtChunks * N * N * sizeof(float), 256);
-  w.redo = (int*)p;
+  w.redo = (int*)p; p += align_up((size_t)B * sizeof(int), 256);
+  w.r2 = nullptr; w.half = nullptr; w.bm = nullptr; w.ginv = nullptr;
+  if (N <= 31) {
+    w.r2 = (float*)p; p += btn;
+    w.half = (double*)p; p += align_up((size_t)B * 2 * sizeof(double), 256);
+    w.bm = (float*)p; p += align_up((size_t)B * 32 * sizeof(float), 256);
+    w.ginv = (float*)p;
+  }
   return w;
 }
 
 }  // namespace w2l
 
 #include "criterion_asg_dpp.hpp"   // N <= 31: scaled linear domain on DPP row rotations (fcc_fwd_dpp, fcc_bwd_dpp, vit_fwd_dpp, vit_psi_k, vit_walk_k)
+#include "criterion_asg_mitm.hpp"  // N <= 31, the product: the same scans from both ends to the middle frame (fcc_mitm_fwd, fcc_mitm_bwd)
 
 namespace w2l {
 
@@ -67,6 +79,16 @@ namespace w2l {
 inline bool asg_dpp_path(int N) {
   static const bool old = tune_env("W2L_ASG_OLD") != nullptr;
   return N <= 31 && !old;
+}
+// ... and, for A/B work, the round-4 full-length scans of criterion_asg_dpp.hpp instead of the meet-in-the-middle pair (W2L_ASG_NOMITM=1)
+// probe, timing only (results are wrong): W2L_MITM_ONLY=0 / 1 launches one half of every meet-in-the-middle kernel alone
+inline int mitm_only() {
+  static const int v = [] { const char* e = tune_env("W2L_MITM_ONLY"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+  return v;
+}
+inline bool asg_mitm_path() {
+  static const bool off = tune_env("W2L_ASG_NOMITM") != nullptr || tune_env("W2L_FCC_1WAVE") != nullptr;
+  return !off;
 }
 
 template <int NP>
@@ -264,12 +286,15 @@ __global__ __launch_bounds__(64) void fcc_bwd_small(int T, int N, const float* _
 //   dA[i][j] = sum_t dalpha_t[i] w_t[i][j]   (accumulated by the same loop: no r_t hand-over to the fcc_dtrans kernels).
 // One wave per flagged utterance, lane = state, N <= NP (32 or 64); `ahat` and `logs` (= L_t) keep the workspace meaning of the
 // other kernels.  NP = 64 (round 6): the fallback of the 32-64-label scans fcc_*_small<64>, which flag what they cannot hold.
-template <int NP>
+template <int NP, bool MITM = false>
 __global__ __launch_bounds__(64) void fcc_fwd_log(int T, int N, int scaleMode, const float* __restrict__ x,
                                                   const int* __restrict__ targetSize, const float* __restrict__ trans,
                                                   float* __restrict__ loss, FccWs ws) {
   const int b = blockIdx.x, lane = threadIdx.x;
-  if (!ws.redo[b]) return;
+  if (!ws.redo[b]) {
+    if (MITM) fcc_mitm_finish(b, lane, T, N, scaleMode, targetSize, loss, ws);   // loss of the two linear-domain halves
+    return;
+  }
   const bool act = lane < N;
   const float NEG = -INFINITY;
   float Ar[NP];   // row `lane` of the transitions
@@ -684,8 +709,11 @@ W2L_API size_t w2l_fcc_workspace_size(int B, int T, int N) {
   if (B <= 0 || T <= 0 || N <= 0) return 0;
   if (N > 64) return fcc_big_supported(B, T, N) ? fcc_big_workspace_size(B, T, N) : 0;
   size_t btn = align_up((size_t)B * T * N * sizeof(float), 256);
-  return 3 * btn + align_up((size_t)B * sizeof(float), 256) +
-         align_up((size_t)B * kDtChunks * N * N * sizeof(float), 256) + align_up((size_t)B * sizeof(int), 256);
+  size_t sz = 3 * btn + align_up((size_t)B * sizeof(float), 256) +
+              align_up((size_t)B * kDtChunks * N * N * sizeof(float), 256) + align_up((size_t)B * sizeof(int), 256);
+  if (N <= 31)   // the meet-in-the-middle scans (criterion_asg_mitm.hpp): r2, half, bm, ginv
+    sz += btn + align_up((size_t)B * 2 * sizeof(double), 256) + align_up((size_t)B * 32 * sizeof(float), 256) + align_up((size_t)B * sizeof(float), 256);
+  return sz;
 }
 
 W2L_API int w2l_fcc_forward(int B, int T, int N, int scaleMode, const float* input,
@@ -699,7 +727,13 @@ W2L_API int w2l_fcc_forward(int B, int T, int N, int scaleMode, const float* inp
   }
   hipStream_t s = (hipStream_t)stream;
   FccWs ws = fcc_ws(workspace, B, T, N);
-  if (asg_dpp_path(N)) {
+  if (asg_dpp_path(N) && asg_mitm_path()) {
+    // product: alpha over frames 0 .. m and beta over T-1 .. m in two workgroups per utterance; the loss from the middle frame
+    // (and the log-domain recursion for the utterances the range check flagged) by the second launch
+    hipLaunchKernelGGL(fcc_mitm_fwd, dim3(B, mitm_only() < 0 ? 2 : 1), dim3(128), 0, s, T, N, input, trans, ws, mitm_only() < 0 ? 0 : mitm_only());
+    W2L_LAUNCH_CHECK();
+    hipLaunchKernelGGL((fcc_fwd_log<32, true>), dim3(B), dim3(64), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws);
+  } else if (asg_dpp_path(N)) {
     static const bool oneWave = tune_env("W2L_FCC_1WAVE") != nullptr;   // probe: the one-wave scan (A/B)
     if (oneWave) hipLaunchKernelGGL(fcc_fwd_dpp, dim3(B), dim3(64), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws);
     else hipLaunchKernelGGL(fcc_fwd_dpp2, dim3(B), dim3(128), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws);
@@ -732,7 +766,11 @@ W2L_API int w2l_fcc_backward(int B, int T, int N, const float* trans, const floa
   hipStream_t s = (hipStream_t)stream;
   FccWs ws = fcc_ws(workspace, B, T, N);
   const bool dpp = asg_dpp_path(N);
-  if (dpp) {
+  if (dpp && asg_mitm_path()) {
+    hipLaunchKernelGGL(fcc_mitm_bwd, dim3(B, mitm_only() < 0 ? 2 : 1), dim3(128), 0, s, T, N, trans, grad, inputGrad, ws, mitm_only() < 0 ? 0 : mitm_only());
+    W2L_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fcc_bwd_log<32>, dim3(B), dim3(64), 0, s, T, N, trans, grad, inputGrad, ws);
+  } else if (dpp) {
     static const bool oneWave = tune_env("W2L_FCC_1WAVE") != nullptr;
     if (oneWave) hipLaunchKernelGGL(fcc_bwd_dpp, dim3(B), dim3(64), 0, s, T, N, trans, grad, inputGrad, ws);
     else hipLaunchKernelGGL(fcc_bwd_dpp2, dim3(B), dim3(128), 0, s, T, N, trans, grad, inputGrad, ws);
