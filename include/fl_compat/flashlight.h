@@ -157,7 +157,7 @@ class FL_COMPAT_API Module {
  public:
   virtual ~Module() {}
   virtual std::vector<Variable> params() const { return params_; }   // (virtual: a Sequential of layer objects plans itself on first use)
-  Variable param(int i) const { return params_.at(i); }
+  Variable param(int i) const { return params().at(i); }   // (through params(): a Sequential of layer objects plans itself on first use)
   virtual void setParams(const Variable& var, int position);
   virtual void train() { train_ = true; }
   virtual void eval() { train_ = false; }
@@ -174,7 +174,8 @@ class FL_COMPAT_API Module {
 
 class FL_COMPAT_API Container : public Module {
  public:
-  void add(std::shared_ptr<Module> m);                       // the child's parameters join params()
+  virtual void add(std::shared_ptr<Module> m);               // the child's parameters join params() (virtual: a layer object added through a
+                                                             //  Container reference to an fl::Sequential still contributes its arch line)
   std::shared_ptr<Module> module(int i) const { return modules_.at(i); }
   std::vector<std::shared_ptr<Module>> modules() const { return modules_; }
   void train() override { train_ = true; for (auto& m : modules_) m->train(); }
@@ -215,13 +216,14 @@ class FL_COMPAT_API ArchLayer : public Module {
   std::string line_;
 };
 class View : public ArchLayer { public: explicit View(const af::dim4& d) : ArchLayer(join("V", {(double)d[0], (double)d[1], (double)d[2], (double)d[3]})) {} };
-class Reorder : public ArchLayer { public: Reorder(int d0, int d1, int d2, int d3) : ArchLayer(join("RO", {(double)d0, (double)d1, (double)d2, (double)d3})) {} };
+class Reorder : public ArchLayer { public: Reorder(int d0, int d1, int d2 = 2, int d3 = 3) : ArchLayer(join("RO", {(double)d0, (double)d1, (double)d2, (double)d3})) {} };
 class Dropout : public ArchLayer { public: explicit Dropout(double p = 0.5) : ArchLayer(join("DO", {p})) {} };
 class ReLU : public ArchLayer { public: ReLU() : ArchLayer("R") {} };
 class GatedLinearUnit : public ArchLayer { public: explicit GatedLinearUnit(int dim) : ArchLayer(join("GLU", {(double)dim})) {} };
 class LayerNorm : public ArchLayer {
  public:
   explicit LayerNorm(const std::vector<int>& axes) : ArchLayer(lineOf(axes)) {}
+  explicit LayerNorm(int axis) : ArchLayer(lineOf({axis})) {}   // fl::LayerNorm(int axis, ...)
  private:
   static std::string lineOf(const std::vector<int>& axes) { std::string s("LN"); for (int a : axes) s += " " + std::to_string(a); return s; }
 };
@@ -272,7 +274,7 @@ class WeightNorm : public ArchLayer {
 // the lines of the layers added so far, planned on first use; layer objects and other modules do not mix in one Sequential.
 class FL_COMPAT_API Sequential : public Container {
  public:
-  void add(std::shared_ptr<Module> m);                        // (hides Container::add: a layer object contributes its arch line)
+  void add(std::shared_ptr<Module> m) override;               // a layer object contributes its arch line
   template <class T, class = typename std::enable_if<std::is_base_of<Module, T>::value>::type>
   void add(const T& layer) { add(std::static_pointer_cast<Module>(std::make_shared<T>(layer))); }   // fl's add(const T&)
   std::vector<Variable> params() const override;

@@ -527,6 +527,9 @@ int w2l_profile_report(int* launches, double* totalMs, double* totalFlops); /* k
 /* kind: 0 = 128x128 MFMA GEMM, 1 = skinny implicit GEMM, 2 = TDS slab convolution (work = FLOPs),
  * 3 = FCC transition stream (work = algorithmic bytes), -1 = all */
 int w2l_profile_report_kind(int kind, int* launches, double* totalMs, double* totalWork);
+/* per-launch rows of one kind (bench.py's per-shape table of the dominant kernel): ms[i], work[i], dims[4 i ..] = M, N, K, kernel tag
+ * (1 = gemm128_kernel, 2 = gemm128g_kernel, 3 = gemm160_kernel 128 x 160, 4 = 160 x 128; 0 = not recorded); returns the row count */
+int w2l_profile_launches(int kind, int maxRows, double* ms, double* work, int* dims);
 int w2l_arch_check(const char* archText, int nFeat, int nLabel, int* numLayers);
 int w2l_flags_check(const char* flagsText, int* numFlags);
 

@@ -18,6 +18,8 @@ int main() {
   expect(fl::GatedLinearUnit(2), "GLU 2");
   expect(fl::Dropout(0.3), "DO 0.3");
   expect(fl::Reorder(2, 0, 3, 1), "RO 2 0 3 1");
+  expect(fl::Reorder(1, 0), "RO 1 0 2 3");          // fl::Reorder(dim0, dim1, dim2 = 2, dim3 = 3)
+  expect(fl::LayerNorm(3), "LN 3");                  // fl::LayerNorm(int axis)
   expect(fl::Transformer(768, 192, 3072, 4, 920, 0.3f, 0.3f, false, false), "TR 768 3072 4 920 0.300000012 0.300000012");
   expect(fl::Linear(768, 31), "L 768 31");
   // am_tds_ctc.arch / am_transformer_ctc.arch

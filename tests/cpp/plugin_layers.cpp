@@ -14,7 +14,8 @@ class MyModel : public fl::Container {
     encoder_->add(std::make_shared<fl::View>(af::dim4(-1, nf, 1, 0)));
     // Time x nFeature x 1 x Batch
     encoder_->add(std::make_shared<fl::Conv2D>(1, 4, 5, 1, 2, 1, -1, -1));
-    encoder_->add(std::make_shared<fl::ReLU>());
+    fl::Container& asContainer = *encoder_;   // Container::add is virtual: through a base reference a layer object still contributes its line
+    asContainer.add(std::make_shared<fl::ReLU>());
     encoder_->add(std::make_shared<fl::Dropout>(0.0));
     std::vector<int> lnDims = {0, 1, 2};
     encoder_->add(std::make_shared<fl::LayerNorm>(lnDims));
@@ -26,6 +27,7 @@ class MyModel : public fl::Container {
     encoder_->add(fl::View(af::dim4(0, 4 * nf, 1, 0)));          // fl's add(const T&)
     encoder_->add(std::make_shared<fl::Reorder>(1, 0, 3, 2));
     encoder_->add(std::make_shared<fl::Linear>(4 * nf, (int)nLabel));
+    if (encoder_->param(0).elements() != 4 * 5) throw std::logic_error("param(0) of an unplanned Sequential");   // param(i) plans, like params()
     add(encoder_);
   }
   std::vector<fl::Variable> forward(const std::vector<fl::Variable>& input) override {

@@ -318,6 +318,14 @@ CONV_CASES = [
     (1, 10, 10, 16, 47, 7, 3, 2, 3),      # stride 3: three phases with 3 / 2 / 2 taps
     (1, 12, 8, 16, 23, 4, 4, 0, 1),       # stride == kw: every phase has one tap
     (8, 10, 10, 16, 2200, 21, 1, 10, 10), # 552 tiles on 512 persistent workgroups: two tiles per workgroup + prefetch
+    # more rounds than the block-Toeplitz kernels have workgroups (512 / 768): every workgroup runs >= 2 rounds, i.e. the second-slab
+    # double buffering, the deferred epilogue and the addend prefetch of conv_tds_tz.hpp and the GR rounds of conv_tds_tzf.hpp --
+    # what production (B >= 4, T = 1500, H = 80) always runs and the small cases above never do (round-5 advisor, medium)
+    (8, 14, 14, 16, 2200, 21, 1, 10, 10),
+    (8, 18, 18, 16, 1200, 21, 1, 10, 10), # two MFMA column tiles (the SSPLIT path)
+    (8, 10, 14, 32, 2200, 21, 2, 10, 10), # strided 10 -> 14 forward, backward-data phase kernels (ST = 2)
+    (8, 14, 18, 32, 2200, 21, 2, 10, 10), # strided 14 -> 18
+    (4, 10, 10, 80, 1500, 21, 1, 10, 10), # the production geometry of the first stage at B = 4
     # conv_glu layers (H = 1, stride 1): one LDS-DMA GEMM on overlapping rows
     (2, 40, 100, 1, 60, 13, 1, 0, 0),     # valid convolution (every C4 layer but the first), K = 520 (ragged last K tile)
     (3, 33, 70, 1, 45, 4, 1, 0, 0),       # odd channel count: dword-aligned rows, N % 4 = 2 (dword epilogue)
@@ -433,7 +441,12 @@ def test_conv_random_geometries(oracle, seed):
 
 @pytest.mark.parametrize("B,Cin,Cout,H,T,kw,stride,padl,padr", [(2, 10, 14, 32, 61, 21, 2, 10, 10), (1, 14, 18, 16, 40, 21, 2, 10, 10),
                                                                 (1, 10, 10, 16, 47, 7, 3, 2, 3), (1, 10, 10, 16, 40, 21, 1, 10, 10),
-                                                                (2, 40, 100, 1, 60, 13, 1, 0, 0), (2, 33, 70, 1, 45, 4, 1, 2, 1)])
+                                                                (2, 40, 100, 1, 60, 13, 1, 0, 0), (2, 33, 70, 1, 45, 4, 1, 2, 1),
+                                                                # several rounds per workgroup: the addend prefetch (PFA) of the
+                                                                # block-Toeplitz backward-data kernels and of their phase kernels
+                                                                (8, 10, 10, 16, 2200, 21, 1, 10, 10), (8, 14, 14, 16, 2200, 21, 1, 10, 10),
+                                                                (8, 18, 18, 16, 1200, 21, 1, 10, 10), (8, 10, 14, 32, 2200, 21, 2, 10, 10),
+                                                                (8, 14, 18, 32, 2200, 21, 2, 10, 10)])
 def test_conv_backward_data_accumulate_and_add(oracle, B, Cin, Cout, H, T, kw, stride, padl, padr):
     """the two fused forms of Conv2D backward-data (dx += ..., dx = add + ...) on the phase-decomposed strided path
     and the stride-1 path: equal to the plain result plus the addend"""

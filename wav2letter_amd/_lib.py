@@ -162,6 +162,7 @@ class _SIGS:
     w2l_fill = (_i, [_p, _sz, _f, _p])
     w2l_profile_enable = (_i, [_i])
     w2l_profile_report_kind = (_i, [_i, _p, _p, _p])
+    w2l_profile_launches = (_i, [_i, _i, _p, _p, _p])
     w2l_sgd_step = (_i, [_p, _p, _p, _sz, _f, _f, _f, _f, _p, _p])
     w2l_sgd_step_guarded = (_i, [_p, _p, _p, _sz, _f, _f, _f, _f, _p, _p])
     w2l_adagrad_step_guarded = (_i, [_p, _p, _p, _sz, _f, _f, _f, _f, _p, _p])

@@ -47,6 +47,18 @@ __host__ __device__ inline float scale_of(int mode, int T, int L) {
 __device__ __forceinline__ float fast_logf(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
 __device__ __forceinline__ float fast_expf(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 
+// MaxDynamicSharedMemorySize opt-ins are a property of a function ON a device: `static bool seen[64] = {};` at the call site,
+// true the first time the CURRENT device passes (a second device in the same process would otherwise launch without the opt-in;
+// two threads racing here set the attribute twice, which is harmless)
+__host__ inline bool first_on_device(bool (&seen)[64]) {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  if (d < 0 || d >= 64) d = 0;
+  if (seen[d]) return false;
+  seen[d] = true;
+  return true;
+}
+
 // ---- wavefront helpers (wave = 64 lanes) ----------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

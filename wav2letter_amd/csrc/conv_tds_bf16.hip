@@ -482,10 +482,9 @@ static int tb_launch_filter(const TdsBfFilterP& p0, float* dw, float* dbias, hip
   if (shmem > 80 * 1024) return W2L_EUNSUPPORTED;   // two workgroups per CU: one stages while the other multiplies
   p.partial = sk_scratch(s, kSkScratchBytes);
   if (!p.partial) return W2L_EHIP;
-  static bool attr = false;
-  if (!attr) {
+  static bool attr[64] = {};
+  if (first_on_device(attr)) {
     W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_bf_filter_tr_k<CP, NSTEP, STRIDE, CPO>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    attr = true;
   }
   hipLaunchKernelGGL((tds_conv_bf_filter_tr_k<CP, NSTEP, STRIDE, CPO>), dim3((unsigned)workers), dim3(256), shmem, s, p, tb_magic(p.Cin), tb_magic(p.Cout));
   const int n = p.kw * p.Cin * p.Cout + (dbias ? p.Cout : 0);
@@ -566,10 +565,9 @@ template <int CP, int NSTEP, int STRIDE>
 static int tb_launch(const TdsBfP& p, hipStream_t s) {
   constexpr int KWP = NSTEP * 16 / CP;
   const size_t shmem = (size_t)((kTbTT - 1) * STRIDE + KWP) * tb_frame_pitch(CP);
-  static bool attr = false;
-  if (!attr && shmem > 64 * 1024) {
+  static bool attr[64] = {};
+  if (shmem > 64 * 1024 && first_on_device(attr)) {
     W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_bf_k<CP, NSTEP, STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    attr = true;
   }
   const dim3 grid((unsigned)(p.H / kTbHB), (unsigned)((p.Tout + kTbTT - 1) / kTbTT), (unsigned)p.B);
   hipLaunchKernelGGL((tds_conv_bf_k<CP, NSTEP, STRIDE>), grid, dim3(256), shmem, s, p);

@@ -503,10 +503,9 @@ static int rs2_launch(TdsRsP p, hipStream_t s) {
   if (bpc > 3) bpc = 3;
   if (bpc < 1) return W2L_EUNSUPPORTED;
   const int blocks = nTiles < 256 * bpc ? nTiles : 256 * bpc;
-  static bool attr = false;
-  if (!attr && shmem > 64 * 1024) {
+  static bool attr[64] = {};
+  if (shmem > 64 * 1024 && first_on_device(attr)) {
     W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_rs2_k<C, G, J, KTMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    attr = true;
   }
   hipLaunchKernelGGL((tds_conv_rs2_k<C, G, J, KTMAX>), dim3((unsigned)blocks), dim3(256), shmem, s, p, nTiles);
   return W2L_OK;
@@ -539,10 +538,9 @@ static int rs_launch(TdsRsP p, hipStream_t s) {
   const int nTiles = p.B * p.nTb * p.hBlocks;
   const int perCu = Cfg::WGS;
   const int blocks = nTiles < 256 * perCu ? nTiles : 256 * perCu;
-  static bool attr = false;
-  if (!attr && Cfg::LDS > 64 * 1024) {
+  static bool attr[64] = {};
+  if (Cfg::LDS > 64 * 1024 && first_on_device(attr)) {
     W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_rs_k<C, G, J, KTMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
-    attr = true;
   }
   hipLaunchKernelGGL((tds_conv_rs_k<C, G, J, KTMAX>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p, nTiles);
   return W2L_OK;
@@ -583,11 +581,10 @@ static int rs3_launch(const TdsRsP& q, hipStream_t s) {
     if (done) return W2L_OK;
   }
 #endif
-  static bool attr = false;
-  if (!attr) {
+  static bool attr[64] = {};
+  if (first_on_device(attr)) {
     W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_rs3_k<C, G, J, HH, CS, KT, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
     W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_rs3_k<C, G, J, HH, CS, KT, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
-    attr = true;
   }
   if (p.add) hipLaunchKernelGGL((tds_conv_rs3_k<C, G, J, HH, CS, KT, true, 0>), dim3((unsigned)blocks), dim3(768), Cfg::LDS, s, p);
   else hipLaunchKernelGGL((tds_conv_rs3_k<C, G, J, HH, CS, KT, false, 0>), dim3((unsigned)blocks), dim3(768), Cfg::LDS, s, p);
@@ -634,11 +631,10 @@ static int tz_launch(TdsTzP p, int abl, hipStream_t s) {
     if (done) return W2L_OK;
   }
 #endif
-  static bool attr = false;
-  if (!attr) {
+  static bool attr[64] = {};
+  if (first_on_device(attr)) {
     W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_tz_k<CI, CO, R, NCT, SIG, KWM, ST, M0, DEFER, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
     W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_tz_k<CI, CO, R, NCT, SIG, KWM, ST, M0 + 1, DEFER, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
-    attr = true;
   }
   const bool second = FWD ? p.relu != 0 : p.add != nullptr;
   if (second) hipLaunchKernelGGL((tds_conv_tz_k<CI, CO, R, NCT, SIG, KWM, ST, M0 + 1, DEFER, 0>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p);
@@ -682,6 +678,7 @@ bool tds_tz_try(const float* x, const float* w, const float* bias, const float* 
     st = Cin == 14 ? tz_launch<14, 10, 3, 1, 1, 11, 2, false>(p, 0, s) : tz_launch<18, 14, 2, 1, 1, 11, 2, false>(p, 0, s);
   }
   prof_end(s);
+  if (st == W2L_EUNSUPPORTED) return false;   // tz_launch refused (round count out of range): the older generations take it
   if (st == W2L_OK && hipGetLastError() != hipSuccess) st = W2L_EHIP;
   *status = st;
   return true;
@@ -952,10 +949,9 @@ static int rsf3_launch(const TdsRsfP& q, float* dw, float* dbias, hipStream_t s)
   const int blocks = p.nTiles < 256 ? p.nTiles : 256;
   float* partial = sk_scratch(s, kSkScratchBytes);
   if (!partial || (size_t)blocks * Cfg::ACCF * sizeof(float) > kSkScratchBytes) return W2L_EUNSUPPORTED;
-  static bool attr = false;
-  if (!attr) {
+  static bool attr[64] = {};
+  if (first_on_device(attr)) {
     W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_rsf3_k<C, GA, GB, HH, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
-    attr = true;
   }
   hipLaunchKernelGGL((tds_conv_rsf3_k<C, GA, GB, HH, TS>), dim3((unsigned)blocks), dim3(Cfg::WAVES * 64), Cfg::LDS, s, p, partial);
   hipLaunchKernelGGL((tds_rsf_reduce_k<C, GA, GB, Cfg::NRT, Cfg::NCT>), dim3((unsigned)((Cfg::ACCF + 63) / 64)), dim3(1024), 0, s, partial,
@@ -981,10 +977,9 @@ static int tzf_launch(const TdsRsfP& q, float* dw, float* dbias, hipStream_t s) 
   const int blocks = (p.nRounds + p.rpw - 1) / p.rpw;
   float* partial = sk_scratch(s, kSkScratchBytes);
   if (!partial || (size_t)blocks * Cfg::ACCF * sizeof(float) > kSkScratchBytes) return W2L_EUNSUPPORTED;
-  static bool attr = false;
-  if (!attr) {
+  static bool attr[64] = {};
+  if (first_on_device(attr)) {
     W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_tzf_k<CI, CO, R, GR, SIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
-    attr = true;
   }
   hipLaunchKernelGGL((tds_conv_tzf_k<CI, CO, R, GR, SIG>), dim3((unsigned)blocks), dim3(512), Cfg::LDS, s, p, partial);
   hipLaunchKernelGGL((tds_tzf_reduce_k<CI, CO, R, GR, SIG>), dim3((unsigned)((q.kw * CI * CO + CO + 15) / 16)), dim3(1024), 0, s, partial, blocks, q.kw, dw, dbias);
@@ -1001,10 +996,9 @@ static int rsf_launch(TdsRsfP p, float* dw, float* dbias, hipStream_t s) {
   const int blocks = nTiles < 256 * perCu ? nTiles : 256 * perCu;
   float* partial = sk_scratch(s, kSkScratchBytes);
   if (!partial || (size_t)blocks * Cfg::ACCF * sizeof(float) > kSkScratchBytes) return W2L_EUNSUPPORTED;
-  static bool attr = false;
-  if (!attr && Cfg::LDS > 64 * 1024) {
+  static bool attr[64] = {};
+  if (Cfg::LDS > 64 * 1024 && first_on_device(attr)) {
     W2L_HIP_CHECK(hipFuncSetAttribute((const void*)tds_conv_rsf_k<C, GA, GB, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
-    attr = true;
   }
   hipLaunchKernelGGL((tds_conv_rsf_k<C, GA, GB, TS>), dim3((unsigned)blocks), dim3(256), Cfg::LDS, s, p, partial, nTiles);
   hipLaunchKernelGGL((tds_rsf_reduce_k<C, GA, GB, Cfg::NRT, Cfg::NCT>), dim3((unsigned)((Cfg::ACCF + 63) / 64)), dim3(1024), 0, s, partial,

@@ -168,15 +168,17 @@ __global__ __launch_bounds__(256, 2) void tds_conv_tz_k(TdsTzP p) {
   };
   // One LDS-DMA instruction: lanes [0, nLanes) copy 16 bytes each from rs[voff] to LDS ldsAddr + 16 lane.  As asm so that
   // it can sit BETWEEN the MFMAs of a chain without a branch (the lane mask is an exec write, not a divergent `if`); an
-  // out-of-range source arrives as zeros.  (s_mov m0 needs one wait state before the LDS-DMA reads it.)
+  // out-of-range source arrives as zeros.  (s_mov m0 needs one wait state before the LDS-DMA reads it.)  m0 is declared clobbered;
+  // exec is written and restored to ALL LANES, which is only right in wave-uniform control flow: every call site is -- the round
+  // loop, its prologue and epilogue branch on kernel arguments and round counters only (never on a lane index).
   auto dma = [&](const u32x4v& rs, unsigned ldsAddr, int voff, int nLanes) {
     if (ABL & 8) return;
     if (nLanes >= 64) {
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(ldsAddr), "v"(voff), "s"(rs) : "memory");
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(ldsAddr), "v"(voff), "s"(rs) : "memory", "m0");
     } else {
       const unsigned long long mask = (1ull << nLanes) - 1;
       asm volatile("s_mov_b32 m0, %0\n\ts_mov_b64 exec, %3\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b64 exec, -1"
-                   ::"s"(ldsAddr), "v"(voff), "s"(rs), "s"(mask) : "memory");
+                   ::"s"(ldsAddr), "v"(voff), "s"(rs), "s"(mask) : "memory", "m0");
     }
   };
   // staging of round q into slab `buf`: NDMA instructions per wave (wave w: frames w, w + 4, ...); frames outside the

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(512) void tds_conv_tzf_k(TdsTzfP p, float* __restri
   // one LDS-DMA instruction under the lane mask `mask` (see conv_tds_tz.hpp): 16 bytes per lane, zeros when out of range
   auto dma = [&](const u32x4v& rs, unsigned ldsAddr, int voff, unsigned long long mask) {
     asm volatile("s_mov_b32 m0, %0\n\ts_mov_b64 exec, %3\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b64 exec, -1"
-                 ::"s"(ldsAddr), "v"(voff), "s"(rs), "s"(mask) : "memory");
+                 ::"s"(ldsAddr), "v"(voff), "s"(rs), "s"(mask) : "memory", "m0");
   };
   struct Stage { u32x4v rx, rd; int bx, bd; };
   auto stage_of = [&](const Pos& q, bool live) -> Stage {

@@ -1241,11 +1241,10 @@ static int big_gemm(const BigDims& d, const float* pack, const float* op, const 
     prof_begin(s, 4.0 * d.N * (double)d.N + 8.0 * d.B * (double)d.N, PROF_FCC_STREAM);
 #define W2L_DMA_LAUNCH(U, D, NTF)                                                                                              \
   do {                                                                                                                         \
-    static bool attr = false;                                                                                                  \
-    if (!attr) {                                                                                                               \
+    static bool attr[64] = {};                                                                                                  \
+    if (first_on_device(attr)) {                                                                                                               \
       W2L_HIP_CHECK(hipFuncSetAttribute((const void*)fcc_big_gemm_dma<EXPOP, U, D, NTF, FOLD>,                                 \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                              \
-      attr = true;                                                                                                             \
     }                                                                                                                          \
     hipLaunchKernelGGL((fcc_big_gemm_dma<EXPOP, U, D, NTF, FOLD>), dim3((unsigned)d.W), dim3(256), shmem, s,                   \
                        (const float4*)pack, (const float4*)op, pmax, part, d, fold);                                           \

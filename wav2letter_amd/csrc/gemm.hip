@@ -374,7 +374,27 @@ W2L_API int w2l_profile_enable(int on) {
   p.used = 0;
   p.work.clear();
   p.kind.clear();
+  p.dims.clear();
   return W2L_OK;
+}
+// per-launch rows of one kind (after a device synchronisation): ms[i], work[i], dims[4 i .. 4 i + 3] = M, N, K, kernel tag (see
+// prof_begin); returns the number of rows of that kind (rows beyond maxRows are counted, not written)
+W2L_API int w2l_profile_launches(int kind, int maxRows, double* ms, double* work, int* dims) {
+  GemmProf& p = gemm_prof();
+  int n = 0;
+  for (size_t i = 0; i + 1 < p.used; i += 2) {
+    if (kind >= 0 && p.kind[i / 2] != kind) continue;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, p.ev[i], p.ev[i + 1]) != hipSuccess) continue;
+    if (n < maxRows) {
+      if (ms) ms[n] = t;
+      if (work) work[n] = p.work[i / 2];
+      if (dims)
+        for (int k = 0; k < 4; ++k) dims[4 * n + k] = p.dims[4 * (i / 2) + k];
+    }
+    ++n;
+  }
+  return n;
 }
 // call after a device synchronisation: launches, total ms, total algorithmic work of one kind
 W2L_API int w2l_profile_report_kind(int kind, int* launches, double* totalMs, double* totalWork) {

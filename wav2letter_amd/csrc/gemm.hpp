@@ -239,10 +239,13 @@ struct GemmProf {
   std::vector<hipEvent_t> ev;      // pairs
   std::vector<double> work;
   std::vector<int> kind;
+  std::vector<int> dims;           // 4 per launch: M, N, K, kernel tag (0 = not a GEMM / unknown): the per-shape table of w2l_profile_launches
   size_t used = 0;
 };
 GemmProf& gemm_prof();
-inline void prof_begin(hipStream_t s, double work, int kind = PROF_GEMM128) {
+// kernel tags of the per-launch table: 1 = gemm128_kernel (generic operands), 2 = gemm128g_kernel (LDS-DMA 128 x 128), 3 = gemm160_kernel
+// 128 x 160, 4 = gemm160_kernel 160 x 128 ("tall")
+inline void prof_begin(hipStream_t s, double work, int kind = PROF_GEMM128, int M = 0, int N = 0, int K = 0, int tag = 0) {
   GemmProf& p = gemm_prof();
   if (!p.on) return;
   if (p.used + 2 > p.ev.size()) {
@@ -250,6 +253,7 @@ inline void prof_begin(hipStream_t s, double work, int kind = PROF_GEMM128) {
   }
   p.work.push_back(work);
   p.kind.push_back(kind);
+  p.dims.push_back(M); p.dims.push_back(N); p.dims.push_back(K); p.dims.push_back(tag);
   (void)hipEventRecord(p.ev[p.used], s);
 }
 inline void prof_end(hipStream_t s) {
@@ -693,7 +697,7 @@ inline int launch128(const AOp& a, const BOp& b, GemmOut o, int epi, int splitk,
   }
   dim3 grid((unsigned)(plan.dpTiles + plan.skBlocks)), block(256);
   o.epi = epi;
-  prof_begin(s, 2.0 * o.M * (double)o.N * o.K);
+  prof_begin(s, 2.0 * o.M * (double)o.N * o.K, PROF_GEMM128, o.M, o.N, o.K, 1);
   hipLaunchKernelGGL((gemm128_kernel<AOp, BOp>), grid, block, shmem, s, a, b, o, plan);
   if (plan.skBlocks > 0) hipLaunchKernelGGL(gemm128_fixup<0>, dim3((unsigned)plan.skTiles * 4), dim3(64), 0, s, o, plan);
   prof_end(s);

@@ -471,7 +471,7 @@ inline int launch128g(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o,
   const size_t shmem = 2 * (size_t)kGStageFloats * sizeof(float);
   dim3 grid((unsigned)workers), block(256);
   o.epi = epi;
-  prof_begin(s, 2.0 * o.M * (double)o.N * o.K);
+  prof_begin(s, 2.0 * o.M * (double)o.N * o.K, PROF_GEMM128, o.M, o.N, o.K, 2);
   static const int wideOn = [] { const char* e = tune_env("W2L_GEMM_WIDE"); return e ? atoi(e) : 1; }();
   const int wide = wideOn && (((uintptr_t)o.C) & 15) == 0 && o.ldc % 4 == 0 &&
                    (!o.mask || (((uintptr_t)o.mask) & 15) == 0);

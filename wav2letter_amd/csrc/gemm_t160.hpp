@@ -398,7 +398,7 @@ inline int launch160(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o, 
     W2L_T160_ATTR(true, true, true); W2L_T160_ATTR(true, false, true); W2L_T160_ATTR(false, true, true); W2L_T160_ATTR(false, false, true);
 #undef W2L_T160_ATTR
   }
-  prof_begin(s, 2.0 * o.M * (double)o.N * o.K);
+  prof_begin(s, 2.0 * o.M * (double)o.N * o.K, PROF_GEMM128, o.M, o.N, o.K, tall ? 4 : 3);
 #define W2L_T160_GO(A, B, T) hipLaunchKernelGGL((gemm160_kernel<A, B, T>), grid, block, shmem, s, a, b, o, plan, workers)
   if (!tall) {
     if (akc && bkc) W2L_T160_GO(true, true, false);

@@ -689,7 +689,11 @@ void initDistributed(int worldRank, int worldSize, int maxDevicesPerNode, const 
   std::string rndvDir = rndvFilepath;
   unsigned long long launch = 0;   // 0 = no launch id given: the time rules below
   {
-    const size_t h = rndvFilepath.rfind('#');
+    // ('#' separates the id only when the whole text does not name an existing directory: a rendezvous directory whose own path
+    //  contains '#' keeps working as before -- round-5 advice)
+    struct stat sb;
+    const bool wholeIsDir = stat(rndvFilepath.c_str(), &sb) == 0 && S_ISDIR(sb.st_mode);
+    const size_t h = wholeIsDir ? std::string::npos : rndvFilepath.rfind('#');
     if (h != std::string::npos) {
       rndvDir = rndvFilepath.substr(0, h);
       launch = 1469598103934665603ull;   // FNV-1a of the id text (never 0 for a non-empty id; an empty id counts as none)
@@ -731,6 +735,9 @@ void initDistributed(int worldRank, int worldSize, int maxDevicesPerNode, const 
         const long long now = nowNs();
         if (launch != 0 || in.launch != 0) {
           if (in.launch == launch) { rec = in; got = true; }   // (a record of another launch, or of a run without an id: keep waiting)
+          else if (tries % 300 == 299)                          // every 30 s: say what is being waited for
+            std::fprintf(stderr, "initDistributed: rank %d waits for a rendezvous record of launch %016llx in %s; the record there is of launch %016llx\n",
+                         worldRank, launch, path.c_str(), in.launch);
         } else if (in.publishedNs >= startNs - 120ll * 1000000000ll) {
           rec = in; got = true;
         } else if (oldPublished == in.publishedNs && now - oldSince >= 30ll * 1000000000ll) {
