@@ -224,17 +224,18 @@ def test_tds_ctc_config2_full_network_end_to_end(oracle):
     assert n_strict >= 2
 
 
-def test_tds_ctc_config2_teacher_forced_blocks_fp32(oracle):
+@pytest.mark.parametrize("seed", [23, 21])
+def test_tds_ctc_config2_teacher_forced_blocks_fp32(oracle, seed):
     """BASELINE config 2 at FULL DEPTH, block by block, at the strict fp32 bar (round-4 verdict item 6): the 21 TDS blocks of the
     sota/2019 recipe network (C = 10 / 14 / 18, 80 mel rows, kw = 21, fc widths 2400 / 3360 / 4320) each run alone on the
     oracle's activation and upstream gradient -- teacher_forced_tds_blocks_fp32.  The statistical full-depth bars of
     test_tds_ctc_config2_full_network_end_to_end (cosine / relative L2) stay as the end-to-end plumbing check; THIS is the
-    per-tensor 1e-4 statement for the headline config: block outputs, and the eight parameter gradients of every block that
-    has no ReLU input on the other side of zero than the oracle (the others: counted, held downstream of their ReLUs and by
-    direction and size upstream)."""
+    per-tensor 1e-4 statement for the headline config: block outputs and the eight parameter gradients of EVERY block -- each
+    block's input is first moved off the ReLU kinks with an asserted margin (kink_free_block_input; round-5 verdict, weak 4:
+    no `kinked <= 4`, no chosen seed)."""
     import re
     from wav2letter_amd import recipes
-    rng = np.random.default_rng(23)
+    rng = np.random.default_rng(seed)
     nfeat, nlabel, B, T, L = 80, 9998, 2, 200, 5
     arch = re.sub(r"(TDS \d+ \d+ \d+) [0-9.]+", r"\1 0.0", recipes.tds_ctc_arch())
     arch = "\n".join(l for l in arch.splitlines() if not l.startswith("SAUG")) + "\n"
@@ -250,21 +251,34 @@ def test_tds_ctc_config2_teacher_forced_blocks_fp32(oracle):
     o.forward()
     ref.upstream = []
     ref_grads = ref.backward(o.backward().astype(np.float32), len(params))
-    n, kinked, worst = teacher_forced_tds_blocks_fp32(ref, arch, params, ref_grads)
-    print("config 2 fp32, %d teacher-forced TDS blocks: %d with a flipped ReLU input; worst strict error of the others %.2e" % (n, kinked, worst))
-    assert n == 21 and kinked <= 4
+    n, tries, worst = teacher_forced_tds_blocks_fp32(ref, arch, params, ref_grads, seed)
+    print("config 2 fp32, seed %d: %d teacher-forced TDS blocks, ALL strict (worst error %.2e); at most %d input perturbations to clear the ReLU kinks" % (seed, n, worst, tries))
+    assert n == 21
 
 
+def relu_kink_margin(ref):
+    """smallest |input| / rms over every ReLU of the network the reference interpreter has just run (arch `R` lines and the two
+    ReLUs inside every TDS block)"""
+    m = np.inf
+    for rec in ref.tape:
+        zs = [rec[1]] if rec[0] == "R" else [rec[2]["a"], rec[2]["u"]] if rec[0] == "TDS" else []
+        for z in zs:
+            m = min(m, float(np.abs(z).min() / np.sqrt(np.mean(np.square(z, dtype=np.float64)))))
+    return m
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23, 24, 25, 26])
 @pytest.mark.parametrize("stages", [[(10, 1, 2400)], [(10, 1, 0), (14, 1, 0), (18, 1, 0)], [(18, 3, 4320)]])
-def test_tds_ctc_recipe_channel_counts_strict_gradients(oracle, stages):
+def test_tds_ctc_recipe_channel_counts_strict_gradients(oracle, stages, seed):
     """the recipe's TDS geometry (80 mel rows, kw = 21, C = 10 / 14 / 18, the 3x fc width, strided C2 layers between the
-    stages) at a depth where no ReLU input sits on a kink: every parameter gradient at the strict 2e-4 bar.
-    (The seed is one for which that holds with the kernels of the day: under the block-Toeplitz convolutions of round 5,
-    whose sums run in another order, seed 21 puts one input of the first block's fc ReLU across zero -- tds.lin1.w off by 5e-2,
-    everything upstream of that ReLU by 1e-3, everything downstream at 1e-7 -- while seeds 22 .. 26 agree to 1e-6 with both
-    generations: profiles/r05_run8_relu_kink_diag_seed21.log.)"""
-    rng = np.random.default_rng(22)
+    stages): every parameter gradient at the strict 2e-4 bar, for EVERY seed (round-5 verdict, weak 4: the round-5 test was
+    re-seeded 21 -> 22 when a new summation order put one ReLU input of seed 21 across zero).  relu'(0) is a discontinuity, so the
+    test first makes its input kink-free: the features are perturbed (relative 1e-3 noise) until no ReLU input anywhere in the
+    oracle's network lies within KINK_MARGIN x rms of zero -- the margin is asserted -- and then nothing is excused."""
+    rng = np.random.default_rng(seed)
     nfeat, nlabel, B, T, L = 80, 40, 2, 96, 5
+    if sum(nb for _, nb, _ in stages) >= 3 and stages[0][2]:
+        B, T = 1, 64   # three wide blocks: 1.8 M ReLU inputs at B = 2, T = 96 -- ~6 of them inside the margin per draw, hundreds of draws
     lines = ["V -1 NFEAT 1 0"]
     cin = 1
     for c, nb, l2 in stages:
@@ -273,11 +287,22 @@ def test_tds_ctc_recipe_channel_counts_strict_gradients(oracle, stages):
     lines += [f"V 0 {cin * 80} 1 0", "RO 1 0 3 2", f"L {cin * 80} NLABEL"]
     arch = "\n".join(lines) + "\n"
     tr, ref, params, _ = build(arch, nfeat, nlabel, "ctc", 4, 0.0, rng, B, T, L)
-    x = rng.normal(size=(B, 1, nfeat, T)).astype(np.float32)
+    x0 = rng.normal(size=(B, 1, nfeat, T)).astype(np.float32)
     tgt = rng.integers(0, nlabel - 1, size=(B, L)).astype(np.int32)
+    best = None
+    for k in range(400):
+        x = x0 if k == 0 else (x0 * (1.0 + 1e-3 * rng.standard_normal(x0.shape))).astype(np.float32)
+        em_ref = ref.forward(x, params)
+        m = relu_kink_margin(ref)
+        if best is None or m > best[0]:
+            best = (m, x)
+        if m >= KINK_MARGIN:
+            break
+    assert best[0] >= KINK_MARGIN, ("no kink-free input found", best[0])
+    x = best[1]
+    em_ref = ref.forward(x, params)   # (the tape of the input that is used)
     xd = torch.tensor(x.reshape(B, nfeat, T)).cuda()
     td = torch.tensor(tgt).cuda()
-    em_ref = ref.forward(x, params)
     assert rel(tr.forward(xd, train=False).cpu().numpy(), em_ref) < TOL
     loss = tr.forward_backward(xd, td).cpu().numpy()
     o = oracle.CTC(em_ref, tgt, scale_mode=4)
@@ -492,28 +517,54 @@ def teacher_forced_tds_blocks(ref, arch, params, ref_grads):
     return len(blocks), worst
 
 
-def teacher_forced_tds_blocks_fp32(ref, arch, params, ref_grads):
+KINK_MARGIN = 4e-6   # of the rms of a ReLU layer's inputs: twice what an fp32 sum of ~1000 terms can differ by between two summation orders
+
+
+def kink_free_block_input(xin, p, pl, pr, mode, rng, tries=200):
+    """A TDS block has two ReLUs (0.2 - 3.8 M inputs each at the recipe's sizes).  relu'(0) is a discontinuity: an input within fp32
+    rounding of zero passes its gradient or not depending on the summation order of whoever computes it, and ONE flipped input
+    moves a weight gradient by ~1 / sqrt(N) of its size.  Instead of counting such blocks (round 5: `kinked <= 4`) or choosing a
+    seed, the block's input is perturbed (relative noise of 1e-3, a few tries) until NO ReLU input of the oracle's block lies
+    within KINK_MARGIN x rms of zero; the margin is asserted, and then every tensor of every block is held to the strict bar.
+    Returns (input, oracle output, oracle tape, tries used, smallest |input| / rms over both ReLUs)."""
+    best = None
+    for k in range(tries):
+        x = xin if k == 0 else (xin * (1.0 + 1e-3 * rng.standard_normal(xin.shape))).astype(np.float32)
+        out, saved = refnet.tds_fwd(x, p, pl, pr, mode, keep=True)
+        m = min(float(np.abs(saved[name]).min() / np.sqrt(np.mean(np.square(saved[name], dtype=np.float64)))) for name in ("a", "u"))
+        if best is None or m > best[4]:
+            best = (x, out, saved, k + 1, m)
+        if m >= KINK_MARGIN:
+            break
+    return best
+
+
+def teacher_forced_tds_blocks_fp32(ref, arch, params, ref_grads, seed=0):
     """Every TDS block of the network ALONE in fp32, at the geometry and with the parameters it has in the network, fed the
-    oracle's own input activation and the oracle's own gradient at its output: output and every parameter gradient at the
-    STRICT bar (1e-4 of the largest reference magnitude; the two-element LayerNorm (gain, offset) pairs, sums of every
-    activation with heavy cancellation, 1e-3).  With the inputs forced nothing compounds from block to block; what can still
-    differ is the sign of a ReLU input that lies within fp32 rounding of zero (the block has two ReLUs, 0.2 - 3.8 M inputs each).
-    Every block keeps the strict bar on its output (ReLU is continuous) and on the gradients downstream of both ReLUs (lin2,
-    ln2); a block whose other gradients all meet the strict bar too is counted as clean, one where any does not is counted
-    as carrying a flipped ReLU input and held by direction and size (relative L2 < 10 %).  Returns (blocks, blocks with a
-    flipped ReLU input, worst strict error of the clean ones)."""
+    oracle's input activation (made kink-free: kink_free_block_input) and the oracle's own gradient at its output: output and every
+    parameter gradient at the STRICT bar (1e-4 of the largest reference magnitude; the two-element LayerNorm (gain, offset)
+    pairs, sums of every activation with heavy cancellation, 1e-3).  With the inputs forced nothing compounds from block to
+    block, and with every ReLU input at least KINK_MARGIN x rms away from zero (asserted) no summation order can flip one:
+    EVERY block is strict on EVERY tensor.  Returns (blocks, most perturbation tries a block needed, worst strict error)."""
     lines = [l.split() for l in arch.splitlines() if l.startswith("TDS")]
     blocks = [(rec, da) for rec, da in reversed(ref.upstream) if rec[0] == "TDS"]     # network order
     assert len(blocks) == len(lines) > 0
     from wav2letter_amd.trainer import Trainer
-    worst, kinked = 0.0, 0
+    rng = np.random.default_rng(1000 + seed)
+    worst, most_tries = 0.0, 0
     for (rec, da), tok in zip(blocks, lines):
-        _, p, saved, pl, pr, mode, pi = rec
-        xin = np.ascontiguousarray(saved["x"], dtype=np.float32)                        # [B][c][h][T]
-        B, c, h, T = xin.shape
+        _, p, saved0, pl, pr, mode, pi = rec
+        xin0 = np.ascontiguousarray(saved0["x"], dtype=np.float32)                      # [B][c][h][T]
+        B, c, h, T = xin0.shape
         assert (c, h) == (int(tok[1]), int(tok[3]))
         l = c * h
-        out = refnet.tds_fwd(xin, p, pl, pr, mode)
+        xin, out, saved, tries, margin = kink_free_block_input(xin0, p, pl, pr, mode, rng)
+        assert margin >= KINK_MARGIN, (pi, tok, "no kink-free input found", margin)
+        most_tries = max(most_tries, tries)
+        da = np.ascontiguousarray(da, dtype=np.float32)
+        _, gg = refnet.tds_bwd(da, p, saved, pl, pr, mode)
+        want_grads = [gg["wc"], gg["bc"], np.array([gg["g1"], gg["b1n"]], np.float32), gg["w1"], gg["b1"], gg["w2"], gg["b2"],
+                      np.array([gg["g2"], gg["b2n"]], np.float32)]
         one = ("V -1 %d %d 0\nRO 0 2 1 3\n%s\nRO 2 1 0 3\nV %d -1 1 0\nV %d 0 -1 1\n" % (c, h, " ".join(tok[:4] + ["0.0"] + tok[5:]), l, l))
         tr = Trainer(one, l, l, "ctc", 4, 0.0)
         table = tr.param_table()
@@ -528,27 +579,17 @@ def teacher_forced_tds_blocks_fp32(ref, arch, params, ref_grads):
         e = rel(em, to_em(out))
         assert e < TOL, (pi, tok, "output", e)
         worst = max(worst, e)
-        tr.backward(torch.tensor(to_em(np.asarray(da, np.float32))).cuda())
+        tr.backward(torch.tensor(to_em(da)).cuda())
         g = tr.grads.cpu().numpy()
-        errs = {}
         for i in range(8):
-            want = np.asarray(ref_grads[pi - 8 + i], np.float64).reshape(-1)
+            want = np.asarray(want_grads[i], np.float64).reshape(-1)
             got = np.asarray(tr.export_from(i, g), np.float64).reshape(-1)
-            errs[table[i][0]] = (rel(got, want), want.size, np.linalg.norm(got - want) / max(1e-30, np.linalg.norm(want)))
-        bar = lambda size: TOL if size > 2 else 1e-3
-        # downstream of both ReLUs: always strict
-        for name in ("tds.lin2.w", "tds.lin2.b", "tds.ln2.weight+bias"):
-            assert errs[name][0] < bar(errs[name][1]), (pi, tok, name, errs[name])
-        flipped = any(v[0] >= bar(v[1]) for v in errs.values())
-        kinked += flipped
-        for name, (err, size, l2) in errs.items():
-            if not flipped:
-                if size > 2:
-                    worst = max(worst, err)
-            elif size > 2:
-                assert l2 < 0.1, (pi, tok, name, l2)      # a flipped ReLU input: direction and size
+            err = rel(got, want)
+            assert err < (TOL if want.size > 2 else 1e-3), (pi, tok, table[i][0], err, "kink margin %.1e after %d tries" % (margin, tries))
+            if want.size > 2:
+                worst = max(worst, err)
         del tr
-    return len(blocks), kinked, worst
+    return len(blocks), most_tries, worst
 
 
 def teacher_forced_tr_blocks(ref, arch, params, ref_grads):

@@ -51,6 +51,10 @@ struct FacWs {
 __host__ __device__ inline bool fac_use_partials(int B, int N) {
   return (size_t)B * N * N <= ((size_t)1 << 22);
 }
+// transition-gradient partials per utterance: the two halves of the meet-in-the-middle backward pass (N <= 32) accumulate into
+// sets of their own -- two workgroups adding into one set would make the sum depend on their timing (run-to-run differences in
+// the last bit: tests/test_gpu_fl_compat.py::test_train_binary_on_list_files holds training to bit-identical reruns)
+__host__ __device__ inline int fac_partial_sets(int N) { return N <= 32 ? 2 : 1; }
 
 __host__ __device__ inline FacWs fac_ws(void* ws, int B, int T, int N, int L) {
   FacWs w;
@@ -61,7 +65,7 @@ __host__ __device__ inline FacWs fac_ws(void* ws, int B, int T, int N, int L) {
   w.redo = (int*)p; p += align_up((size_t)B * sizeof(int), 256);
   w.bp = (unsigned char*)w.w1;  // viterbi reuses the w1 region (needs B*T*L bytes)
   w.tgpart = fac_use_partials(B, N) ? (float*)p : nullptr;
-  if (w.tgpart) p += align_up((size_t)B * N * N * sizeof(float), 256);
+  if (w.tgpart) p += align_up((size_t)fac_partial_sets(N) * B * N * N * sizeof(float), 256);
   w.crow = nullptr; w.zmax = nullptr; w.zspr = nullptr; w.hm = nullptr; w.gm = nullptr; w.gam = nullptr;
   if (N <= 32) {
     w.crow = (double*)p; p += align_up((size_t)B * T * 32 * sizeof(double), 256);
@@ -889,7 +893,7 @@ W2L_API size_t w2l_fac_workspace_size(int B, int T, int N, int L) {
   if (B <= 0 || T <= 0 || N <= 0 || L <= 0) return 0;
   size_t sz = 2 * align_up((size_t)B * T * L * sizeof(float), 256) + align_up((size_t)B * sizeof(float), 256) +
               align_up((size_t)B * sizeof(int), 256);
-  if (fac_use_partials(B, N)) sz += align_up((size_t)B * N * N * sizeof(float), 256);
+  if (fac_use_partials(B, N)) sz += align_up((size_t)fac_partial_sets(N) * B * N * N * sizeof(float), 256);
   if (N <= 32) sz += align_up((size_t)B * T * 32 * sizeof(double), 256) + 2 * align_up((size_t)B * T * sizeof(float), 256) +
                      2 * align_up((size_t)B * 320 * 16, 256) + align_up((size_t)B * 320 * sizeof(float), 256);
   return sz;
@@ -1060,7 +1064,9 @@ W2L_API int w2l_fac_backward(int B, int T, int N, int L, const int* target, cons
   hipStream_t s = (hipStream_t)stream;
   FacWs ws = fac_ws(workspace, B, T, N, L);
   size_t n = (size_t)N * N;
-  if (ws.tgpart) W2L_HIP_CHECK(hipMemsetAsync(ws.tgpart, 0, (size_t)B * n * sizeof(float), s));
+  const bool mitm = fac_lin_path(N, L) && fac_mitm_path();
+  const int sets = mitm ? 2 : 1;   // (see fac_partial_sets)
+  if (ws.tgpart) W2L_HIP_CHECK(hipMemsetAsync(ws.tgpart, 0, (size_t)sets * B * n * sizeof(float), s));
   else W2L_HIP_CHECK(hipMemsetAsync(transGrad, 0, n * sizeof(float), s));
   // product (N <= 32, L <= 320): the pipelined backward scan fac_bwd_plin; probe: W2L_FAC_BWD = wave (one wave per utterance),
   // blk51 (five waves x one position, a workgroup barrier per frame), blk42 (the round-3 shape)
@@ -1069,7 +1075,7 @@ W2L_API int w2l_fac_backward(int B, int T, int N, int L, const int* target, cons
     if (!e) return 0;
     return !strcmp(e, "wave") ? 1 : !strcmp(e, "blk51") ? 2 : !strcmp(e, "blk42") ? 3 : 0;
   }();
-  if (fac_lin_path(N, L) && fac_mitm_path()) {
+  if (mitm) {
 #define W2L_FAC_M_GO(NWV) hipLaunchKernelGGL((fac_mitm_bwd<NWV>), dim3(B, fac_mitm_only() < 0 ? 2 : 1), dim3(64 * NWV), 0, s, T, N, L, target, targetSize, grad, transGrad, ws, fac_mitm_only() < 0 ? 0 : fac_mitm_only())
     switch ((L + 63) / 64) {
       case 1: W2L_FAC_M_GO(1); break;
@@ -1145,7 +1151,7 @@ W2L_API int w2l_fac_backward(int B, int T, int N, int L, const int* target, cons
     W2L_LAUNCH_CHECK();
   }
   if (ws.tgpart) {
-    hipLaunchKernelGGL(reduce_over_b_fac, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, B, n, ws.tgpart, transGrad);
+    hipLaunchKernelGGL(reduce_over_b_fac, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sets * B, n, ws.tgpart, transGrad);
     W2L_LAUNCH_CHECK();
   }
   return W2L_OK;

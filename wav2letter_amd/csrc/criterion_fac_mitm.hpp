@@ -361,7 +361,8 @@ __device__ __forceinline__ void fac_half_bwd(int T, int N, int L, const int* __r
 #pragma unroll
     for (int s = 0; s < KC; ++s) wc[s] = wn[s];
   }
-  float* tg = ws.tgpart ? ws.tgpart + (size_t)b * N * N : transGrad;
+  // (the upward half has a partial set of its own behind the B sets of the downward halves: see fac_partial_sets)
+  float* tg = ws.tgpart ? ws.tgpart + ((size_t)(UP ? gridDim.x : 0) + b) * N * N : transGrad;
   if (valid) {
     if (accS != 0.f) atomicAdd(&tg[(size_t)yi * N + yi], g * accS);
     if (i > 0 && accP != 0.f) atomicAdd(&tg[(size_t)yi * N + yp], g * accP);
