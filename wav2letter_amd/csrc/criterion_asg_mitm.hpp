@@ -23,7 +23,10 @@
 
 namespace w2l {
 
-__host__ __device__ inline int fcc_mitm_mid(int T) { return (T - 1) / 2; }
+// the middle frame.  Not the centre: per frame the beta half of the forward pass costs 158 ns against the alpha half's 136 (its
+// emission rows, scale rows and r rows run against the address order) and the continuations 135 / 148 ns
+// (profiles/r06_run10_asg_mitm_halves_after_fixes.log), so alpha takes 8 / 15 of the frames
+__host__ __device__ inline int fcc_mitm_mid(int T) { return (int)(((long long)(T - 1) * 8) / 15); }
 
 // E: entry "to i from j" of the forward operator (row 31: the total mass when MASS); ET: "to j from i" of the backward one
 struct MitmRows {

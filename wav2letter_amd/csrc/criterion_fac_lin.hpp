@@ -485,10 +485,11 @@ __global__ __launch_bounds__(64 * (NW + 1)) void fac_fwd_blin(int T, int N, int 
 // threads gather c_t[y_i] straight from there, prefetched a chunk of 16 frames ahead (the way fac_fwd_blk gathers x_t[y_i]).
 // Against fac_fwd_blin: no row wave (one wave less on the CU's four SIMDs), no LDS row, three instructions less per frame.
 constexpr int kFacRowsPerWave = 8;
-__global__ __launch_bounds__(64) void fac_rows_k(int T, int N, const float* __restrict__ x, const float* __restrict__ trans,
+constexpr int kFacRowsWaves = 4;   // waves per workgroup (16000 one-wave workgroups at B = 64, T = 2000 were launch-rate bound: 20 us)
+__global__ __launch_bounds__(64 * kFacRowsWaves) static void fac_rows_k(int T, int N, const float* __restrict__ x, const float* __restrict__ trans,
                                                  double* __restrict__ crow, float* __restrict__ zmax, float* __restrict__ zspr = nullptr) {
-  const int b = blockIdx.y, lane = threadIdx.x;
-  const int t0 = blockIdx.x * kFacRowsPerWave;
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int t0 = (blockIdx.x * kFacRowsWaves + (threadIdx.x >> 6)) * kFacRowsPerWave;
   const float L2E = 1.44269504088896341f;
   const bool act = lane < N;
   const float adl = act ? trans[(size_t)lane * N + lane] * L2E : 0.f;

@@ -22,7 +22,8 @@
 
 namespace w2l {
 
-__host__ __device__ inline int fac_mitm_mid(int T) { return (T - 1) / 2; }
+// the middle frame: alpha takes 6 / 11 of the frames -- 168 ns per frame against the beta half's 202 (profiles/r06_run10_*)
+__host__ __device__ inline int fac_mitm_mid(int T) { return (int)(((long long)(T - 1) * 6) / 11); }
 
 // One half of the forward pass.  Frames are counted k = 0 .. nK - 1 from the half's own end of the utterance: alpha k <-> frame k,
 // beta k <-> frame T - 1 - k; k = 0 is the initial row.  ring[w][k & 63] = the boundary position of wave w after frame k.
