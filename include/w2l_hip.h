@@ -154,8 +154,17 @@ int w2l_linear_backward_data(int M, int in, int out, const float* dy, const floa
                              w2l_stream_t stream);
 int w2l_linear_backward_weight(int M, int in, int out, const float* x, const float* dy, float* dw,
                                w2l_stream_t stream);
+/* both parameter gradients of fl::Linear in one call: dw[in][out] = x^T dy and db[out] = sum_m dy[m][.] (db may be NULL: the
+ * call above).  Where the product runs on the 160-wide LDS-DMA kernel the column sums ride on it -- the first tile row adds
+ * up the dy fragments it multiplies, no second pass over dy --, otherwise w2l_colsum follows.  Both are deterministic. */
+int w2l_linear_backward_weight_bias(int M, int in, int out, const float* x, const float* dy, float* dw, float* db,
+                                    w2l_stream_t stream);
 /* y = dropout(relu?(x w + b)): fl::Dropout behind a Linear(+ReLU) folded into the GEMM epilogue; bit-identical to
  * w2l_linear_forward followed by w2l_dropout_inplace(y, M*out, p, seed, rngStream) */
+/* y = dropout(relu?(x w + b)) + add: the residual join behind a Linear in the same epilogue (fl::TDSBlock: r2 = dropout(lin2) + y1);
+ * bit-identical to w2l_linear_forward_dropout followed by an elementwise add of `add` ([M][out]); p = 0: no dropout */
+int w2l_linear_forward_dropout_add(int M, int in, int out, const float* x, const float* w, const float* bias, const float* add,
+                                   float* y, int relu, double p, uint32_t seed, uint32_t rngStream, w2l_stream_t stream);
 int w2l_linear_forward_dropout(int M, int in, int out, const float* x, const float* w, const float* bias,
                                float* y, int relu, double p, uint32_t seed, uint32_t rngStream,
                                w2l_stream_t stream);

@@ -146,6 +146,13 @@ def test_fused_epilogue_variants_equal_the_unfused_ops(M, K, N):
     got = ops.linear_forward_dropout(x, w, b, True, p, seed, sid)
     assert torch.equal(got, want)
     assert 0.2 < (got == 0).float().mean().item() < 0.95  # ReLU zeros + dropped elements
+    # ... and the residual join in the same epilogue (the TDS block's r2 = dropout(lin2(u)) + y1), with and without dropout
+    res = torch.randn(M, N, generator=g).cuda()
+    for pp in (p, 0.0):
+        want2 = ops.linear_forward(x, w, b, relu=False)
+        if pp > 0:
+            ops.dropout_(want2, pp, seed, sid)
+        assert torch.equal(ops.linear_forward_dropout_add(x, w, b, res, False, pp, seed, sid), want2 + res)
     dx_plain = ops.linear_backward(x, w, dy)[0]
     got = ops.linear_backward_data_add(dy, w, add)
     assert rel(got, (add.double() + dx_plain.double()).cpu().numpy()) < 1e-6
@@ -392,6 +399,30 @@ def test_gemm_and_linear_random_shapes(seed):
         assert rel(dx, (dy.double() @ w.double().t()).numpy()) < TOL, what
         assert rel(dw, (x.double().t() @ dy.double()).numpy()) < TOL, what
         assert rel(db, dy.double().sum(0).numpy()) < TOL, what
+
+
+@pytest.mark.parametrize("M,nin,nout", [
+    (2048, 256, 320),      # 128 x 160 tiles, four of them: every tile cut by stream-K, partial column sums added by the last arriver
+    (2048, 320, 256),      # 160 x 128 tiles (every wave sums its own 32 columns)
+    (64, 2048, 5120),      # 512 whole tiles: column sums straight from the first tile row's registers
+    (4096, 800, 2400),     # recipe widths (first TDS stage): 95 tiles over 512 workers
+    (3008, 1440, 4320),    # third stage: 160 x 128 tiles
+    (1504, 1120, 3364),    # N % 160 != 0: a ragged last tile column
+    (1000, 300, 514),      # not eligible for the 160-wide kernel's alignment rules: the separate column-sum launch
+])
+def test_linear_weight_and_bias_gradient_in_one_product(M, nin, nout):
+    """w2l_linear_backward_weight_bias: the bias gradient rides on the weight-gradient product (gemm160_kernel<.., CS>) -- against
+    float64, and bit-identical from run to run (fixed summation order, no atomics)"""
+    from wav2letter_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + nin + nout)
+    x = torch.randn(M, nin, generator=g); w = torch.randn(nin, nout, generator=g); dy = torch.randn(M, nout, generator=g) + 0.25
+    xc, wc, dyc = x.cuda(), w.cuda(), dy.cuda()
+    _, dw, db = ops.linear_backward(xc, wc, dyc)
+    assert rel(dw, (x.double().t() @ dy.double()).numpy()) < TOL
+    assert rel(db, dy.double().sum(0).numpy()) < 1e-5
+    for _ in range(3):
+        _, dw2, db2 = ops.linear_backward(xc, wc, dyc)
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])

@@ -104,6 +104,7 @@ class _SIGS:
     w2l_linear_forward = (_i, [_i, _i, _i, _p, _p, _p, _p, _i, _p])
     w2l_linear_backward_data = (_i, [_i, _i, _i, _p, _p, _p, _i, _p, _f, _p])
     w2l_linear_backward_weight = (_i, [_i, _i, _i, _p, _p, _p, _p])
+    w2l_linear_backward_weight_bias = (_i, [_i, _i, _i, _p, _p, _p, _p, _p])
     w2l_colsum = (_i, [_p, _p, _sz, _i, _p])
     w2l_set_matmul_precision = (_i, [_i])
     w2l_bf16_convert = (_i, [_p, _sz, _i, _sz, _p, _sz, _p, _sz, _p])
@@ -136,6 +137,7 @@ class _SIGS:
     w2l_dropout_inplace = (_i, [_p, _sz, _d, _u32, _u32, _p])
     w2l_dropout_copy = (_i, [_p, _p, _sz, _d, _u32, _u32, _p])
     w2l_linear_forward_dropout = (_i, [_i, _i, _i, _p, _p, _p, _p, _i, _d, _u32, _u32, _p])
+    w2l_linear_forward_dropout_add = (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _d, _u32, _u32, _p])
     w2l_linear_backward_data_add = (_i, [_i, _i, _i, _p, _p, _p, _p, _p])
     w2l_mask_backward = (_i, [_p, _p, _p, _sz, _f, _p])
     w2l_hexpand_forward = (_i, [_p, _p, _sz, _i, _i, _i, _i, _p])

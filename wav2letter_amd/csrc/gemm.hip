@@ -193,20 +193,16 @@ int gemm_f32(const float* A, int lda, int a_kcontig, const float* B, int ldb, in
   if (K % 32 == 0 && glds_enabled() && (strict || (relaxed && bufOk)))
   {
     GOp ga{A, lda, M, ab < 0x7fffffffull ? (unsigned)ab : 0u}, gb{B, ldb, N, bb < 0x7fffffffull ? (unsigned)bb : 0u};
-    if (relaxed) {  // default kernels only (buffer addressing bounds the straddling chunks)
-      if (const int which = t160_choice(ga, gb, o)) {
-        bool launched = false;
-        const int st = launch160(ga, a_kcontig != 0, gb, b_kcontig != 0, o, epi, which, s, &launched);
-        if (st != W2L_OK || launched) return st;
-      }
-      return launch128g(ga, a_kcontig != 0, gb, b_kcontig != 0, o, epi, s);
-    }
-    // 160-wide tiles where 128 leaves a ragged last tile column / row (every TDS fc shape: gemm_t160.hpp)
+    // 160-wide tiles where 128 leaves a ragged last tile column / row (every TDS fc shape: gemm_t160.hpp); with relaxed
+    // alignment: default kernels only (buffer addressing bounds the straddling chunks)
+    if (extra && extra->colsum) o.colsum = extra->colsum;
     if (const int which = t160_choice(ga, gb, o)) {
-      bool launched = false;
-      const int st = launch160(ga, a_kcontig != 0, gb, b_kcontig != 0, o, epi, which, s, &launched);
+      bool launched = false, csDone = false;
+      const int st = launch160(ga, a_kcontig != 0, gb, b_kcontig != 0, o, epi, which, s, &launched, &csDone);
+      if (extra) extra->colsumDone = csDone;
       if (st != W2L_OK || launched) return st;
     }
+    o.colsum = nullptr;
     return launch128g(ga, a_kcontig != 0, gb, b_kcontig != 0, o, epi, s);
   }
   if (a_kcontig) {
@@ -286,6 +282,21 @@ W2L_API int w2l_linear_forward_dropout(int M, int in, int out, const float* x, c
   return gemm_f32(x, in, 1, w, out, 0, y, out, M, out, in, bias, epi, 1, (hipStream_t)stream, nullptr, 1.f, &ex);
 }
 
+// y = dropout(relu?(x w + b)) + add (add has y's layout; p = 0: no dropout): the residual join behind a Linear in the GEMM epilogue,
+// bit-identical to w2l_linear_forward_dropout followed by an elementwise add -- fl::TDSBlock's r2 = dropout(lin2(.)) + y1
+W2L_API int w2l_linear_forward_dropout_add(int M, int in, int out, const float* x, const float* w, const float* bias,
+                                           const float* add, float* y, int relu, double p, uint32_t seed, uint32_t rngStream,
+                                           w2l_stream_t stream) {
+  if (!add) return W2L_EINVAL;
+  int epi = (bias ? EPI_BIAS : 0) | (relu ? EPI_RELU : 0);
+  GemmExtra ex;
+  ex.addend = add;
+  ex.dropThr = dropout_threshold(p);
+  ex.dropSeed = seed; ex.dropStream = rngStream;
+  ex.dropScale = (float)(1.0 / (1.0 - p));
+  return gemm_f32(x, in, 1, w, out, 0, y, out, M, out, in, bias, epi, 1, (hipStream_t)stream, nullptr, 1.f, &ex);
+}
+
 // dx = add + dy w^T (add has dx's layout): the residual join of a backward pass without a copy of `add` into dx first
 W2L_API int w2l_linear_backward_data_add(int M, int in, int out, const float* dy, const float* w, const float* add,
                                          float* dx, w2l_stream_t stream) {
@@ -302,6 +313,20 @@ W2L_API int w2l_linear_backward_weight(int M, int in, int out, const float* x, c
   // The output is small (in x out) and the reduction long: the stream-K schedule splits K.
   hipStream_t s = (hipStream_t)stream;
   return gemm_f32(x, in, 0, dy, out, 0, dw, out, in, out, M, nullptr, 0, 1, s);
+}
+
+// the same product with the bias gradient db[out] = sum_m dy[m][out] (fl::Linear's two parameter gradients).  On the 160-wide
+// LDS-DMA kernel the column sums ride on the product (the first tile row adds up the dy fragments it multiplies: no extra pass
+// over dy); any other kernel is followed by the column-sum launch -- the same values either way up to the summation order.
+W2L_API int w2l_linear_backward_weight_bias(int M, int in, int out, const float* x, const float* dy, float* dw, float* db,
+                                            w2l_stream_t stream) {
+  if (!db) return w2l_linear_backward_weight(M, in, out, x, dy, dw, stream);
+  hipStream_t s = (hipStream_t)stream;
+  GemmExtra ex;
+  ex.colsum = db;
+  const int st = gemm_f32(x, in, 0, dy, out, 0, dw, out, in, out, M, nullptr, 0, 1, s, nullptr, 1.f, &ex);
+  if (st != W2L_OK || ex.colsumDone) return st;
+  return colsum(dy, db, (size_t)M, out, s);
 }
 
 // ---- mixed precision with bf16 OPERANDS in HBM (gemm_bf16g.hpp): C[M][N] (fp32) = A[M][K] . B[N][K]^T, both operands

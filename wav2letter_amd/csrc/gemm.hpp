@@ -34,6 +34,12 @@ struct GemmOut {
   // output row b * rowPout + (t' - rowOff) if 0 <= t' - rowOff < rowPout and dropped otherwise.  rowPin = 0: identity.
   int rowPin = 0, rowPout = 0, rowOff = 0;
   uint32_t rowMul = 0, rowShr = 0;  // fast division by rowPin
+  // Column sums of the B operand over the whole reduction, colsum[n] = sum_k B[k][n] (gemm160_kernel<false, false, *, true> only):
+  // the bias gradient of fl::Linear riding on its weight-gradient product x^T dy -- the tiles of the first tile row add up the dy
+  // fragments they already hold in registers.  csPart: per-slab partial sums of the stream-K ranges (behind the slabs in the
+  // stream scratch), added in range order by the tile's last arriver: deterministic like the product itself.
+  float* colsum = nullptr;
+  float* csPart = nullptr;
 };
 
 inline void gemm_set_row_remap(GemmOut& o, int pin, int pout, int off) {
@@ -289,7 +295,8 @@ constexpr int kSkSlots = 512;           // resident 256-thread workgroups (2 per
 constexpr int kSlabFloats = 128 * 128;
 // one stream scratch serves every user (stream-K slabs of the 128x128 and 128x160 kernels, conv filter partials,
 // column-sum partials): all of them request THIS size so the buffer is allocated once per stream
-constexpr size_t kSkScratchBytes = (size_t)kSkSlots * 2 * (128 * 160) * sizeof(float);
+constexpr size_t kSkSlabBytes = (size_t)kSkSlots * 2 * (128 * 160) * sizeof(float);
+constexpr size_t kSkScratchBytes = kSkSlabBytes + (size_t)kSkSlots * 2 * 160 * sizeof(float);   // + column-sum partials (GemmOut::csPart)
 
 __host__ __device__ inline long long sk_begin(const SkPlan& p, int s) {
   return (long long)p.skTiles * p.kTiles * s / p.skBlocks;
@@ -725,7 +732,10 @@ struct GemmExtra {  // optional epilogue operands of gemm_f32
   const float* addend = nullptr;
   uint32_t dropThr = 0, dropSeed = 0, dropStream = 0;
   float dropScale = 1.f;
+  float* colsum = nullptr;  // also produce colsum[n] = sum_k B[k][n] (GemmOut::colsum) where the kernel that runs can ...
+  mutable bool colsumDone = false;   // ... and say so: false -> the caller runs its own column-sum launch
 };
+int colsum(const float* x, float* out, size_t M, int N, hipStream_t s);   // conv.hip: out[n] = sum_m x[m][n]
 int gemm_f32(const float* A, int lda, int a_kcontig, const float* B, int ldb, int b_kcontig, float* C,
              int ldc, int M, int N, int K, const float* bias, int epi, int splitk, hipStream_t s,
              const float* mask = nullptr, float maskScale = 1.f, const GemmExtra* extra = nullptr);

@@ -14,6 +14,8 @@
 // Requirements (host-checked, otherwise gemm128g_kernel runs): as gemm_glds.hpp, plus buffer-addressable
 // operands (< 2 GiB), a 16-byte aligned C with ldc % 4 == 0, and <= 1024 stream-K tiles.
 #pragma once
+#include <type_traits>
+
 #include "gemm_glds.hpp"
 
 namespace w2l {
@@ -150,7 +152,12 @@ __device__ __forceinline__ GSeg t160_segment(const SkPlan& p, int w, int workers
   return s;
 }
 
-template <bool AKC, bool BKC, bool TALL>
+// CS (k-row operands only: the weight gradient x^T dy): the tiles of tile row 0 also add up the B fragments they multiply --
+// out.colsum[n] = sum_k B[k][n], the bias gradient (GemmOut::colsum).  WIDE: the four waves hold the same B fragments, wave 0
+// sums them (5 v_add per K step on the 1 / tilesM of the tiles that have bx == 0); TALL: every wave sums its own 32 columns.
+// A lane's sum runs over the k it holds (k = 8g + 4 (lane >> 5) + q) in ascending order, the two lane halves are added at the
+// end of the segment, the segments of a stream-K tile in range order by the tile's last arriver: run-to-run identical.
+template <bool AKC, bool BKC, bool TALL, bool CS = false>
 __global__ __launch_bounds__(256, 2) void gemm160_kernel(GOp aop, GOp bop, GemmOut out, SkPlan plan, int workers) {
   constexpr int BM = TALL ? 160 : 128, BN = TALL ? 128 : 160;
   constexpr int MI = TALL ? 5 : 1, NJ = TALL ? 1 : 5;
@@ -212,7 +219,18 @@ __global__ __launch_bounds__(256, 2) void gemm160_kernel(GOp aop, GOp bop, GemmO
     for (int b = 0; b < 5; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    float csum[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) csum[j] = 0.f;
+    const bool csTile = CS && out.colsum && bx == 0;     // workgroup-uniform
+    const bool csOn = csTile && (TALL || wave == 0);      // the waves that deliver the tile's column sums
 
+    // The K loop, instantiated per column-sum role QS so that the loop of an ordinary tile carries neither the adds nor a branch
+    // (measured: a scalar branch per K step in every tile cost the weight gradients 2-3.5 %): -1 = none, 4 = every K step (TALL:
+    // a wave's own 32 columns), 0 .. 3 = the K steps q == QS of each 8-k group (WIDE: the four waves hold the same B fragments
+    // and share the work; their partial sums meet in LDS after the loop).
+    auto kloop = [&](auto qsTag) {
+    constexpr int QS = decltype(qsTag)::value;
     for (int kt = seg.kb; kt < seg.ke; ++kt) {
       const float* As = smem + stage * kT160StageFloats;
       const float* Bs = As + BM * 32;
@@ -250,6 +268,10 @@ __global__ __launch_bounds__(256, 2) void gemm160_kernel(GOp aop, GOp bop, GemmO
             for (int j = 0; j < NJ; ++j)
               acc[i * NJ + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][q], fb[cur][j][q], acc[i * NJ + j], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
+          if (QS == 4 || QS == q) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) csum[j] += fb[cur][j][q];
+          }
           if (q == 0) {
             if (g < 3) {
               t160_frag<AKC, BM, MI>(fa[cur ^ 1], As, wm, g + 1, li, lh);
@@ -268,9 +290,37 @@ __global__ __launch_bounds__(256, 2) void gemm160_kernel(GOp aop, GOp bop, GemmO
       stage ^= 1;
       __syncthreads();  // the stage just filled has landed (vmcnt(0)) and is visible to all waves
     }
+    };
+    if (!csTile) kloop(std::integral_constant<int, -1>{});
+    else if (TALL) kloop(std::integral_constant<int, 4>{});
+    else if (wave == 0) kloop(std::integral_constant<int, 0>{});
+    else if (wave == 1) kloop(std::integral_constant<int, 1>{});
+    else if (wave == 2) kloop(std::integral_constant<int, 2>{});
+    else kloop(std::integral_constant<int, 3>{});
 
     bool doEpi = seg.slab < 0;  // whole tile: epilogue straight from the accumulators
     int resetTicket = -1;
+    if (CS && csTile && !TALL) {   // the four waves' shares meet in the stage the K loop has released (behind the epilogue's slices)
+      float* cs = smem + (stage ^ 1) * kT160StageFloats + 4096;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) cs[wave * 320 + j * 64 + lane] = csum[j];
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) csum[j] = ((cs[j * 64 + lane] + cs[320 + j * 64 + lane]) + cs[640 + j * 64 + lane]) + cs[960 + j * 64 + lane];
+      }
+    }
+    if (CS && csOn) {   // this segment's column sums: lanes 0 .. 31 hold columns wn + 32 j + lane of the tile
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const float t = csum[j] + __shfl_xor(csum[j], 32);
+        const int col = wn + 32 * j + lane;
+        if (lane < 32) {
+          if (doEpi) { if (by * BN + col < out.N) out.colsum[by * BN + col] = t; }
+          else out.csPart[(size_t)seg.slab * 160 + col] = t;
+        }
+      }
+    }
     if (!doEpi) {
       t160_store_partial(plan.slabs + (size_t)seg.slab * kT160SlabFloats, acc, wave, lane);
       // in-kernel slab reduction: see gemm128g_kernel
@@ -294,6 +344,8 @@ __global__ __launch_bounds__(256, 2) void gemm160_kernel(GOp aop, GOp bop, GemmO
         for (int b = 0; b < 5; ++b)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) csum[j] = 0.f;
         for (int sr = sF; sr <= sL; ++sr) {
           size_t slab;
           if (plan.ksplit) {
@@ -310,6 +362,17 @@ __global__ __launch_bounds__(256, 2) void gemm160_kernel(GOp aop, GOp bop, GemmO
               const f32x4 v = s4[((wave * 5 + b) * 4 + q) * 64 + lane];
               acc[b][4 * q] += v[0]; acc[b][4 * q + 1] += v[1]; acc[b][4 * q + 2] += v[2]; acc[b][4 * q + 3] += v[3];
             }
+          if (CS && csOn && lane < 32) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) csum[j] += out.csPart[slab * 160 + wn + 32 * j + lane];
+          }
+        }
+        if (CS && csOn && lane < 32) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int n = by * BN + wn + 32 * j + lane;
+            if (n < out.N) out.colsum[n] = csum[j];
+          }
         }
         doEpi = true;
         resetTicket = t;
@@ -355,7 +418,9 @@ inline int t160_choice(const GOp& a, const GOp& b, const GemmOut& o) {
   return best <= 0.98 * p128 ? which : 0;
 }
 
-inline int launch160(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o, int epi, int which, hipStream_t s, bool* launched) {
+// csDone (may be null): set when o.colsum was produced by the launch (k-row operands on this kernel); otherwise the caller sums
+inline int launch160(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o, int epi, int which, hipStream_t s, bool* launched,
+                     bool* csDone = nullptr) {
   epi &= ~EPI_ATOMIC;
   const bool tall = which == 2;
   SkPlan plan = make_sk_plan(o.M, o.N, o.K, sk_enabled(), tall ? 160 : 128, tall ? 128 : 160);
@@ -367,6 +432,12 @@ inline int launch160(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o, 
     plan.counters = sk_counters(s);
     if (!plan.slabs || !plan.counters) return W2L_OK;
   }
+  bool cs = o.colsum && !akc && !bkc;
+  if (cs && plan.skBlocks > 0) {
+    if (plan.slabs) o.csPart = plan.slabs + kSkSlabBytes / sizeof(float);
+    else cs = false;
+  }
+  if (!cs) o.colsum = nullptr;
   int workers = plan.dpTiles < kSkSlots ? plan.dpTiles : kSkSlots;
   if (workers < plan.skBlocks) workers = plan.skBlocks;
   // aligned K split for a GEMM that is all stream-K (fewer tiles than workgroup slots: the weight gradients): the
@@ -396,11 +467,17 @@ inline int launch160(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o, 
 #define W2L_T160_ATTR(A, B, T) (void)hipFuncSetAttribute((const void*)gemm160_kernel<A, B, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)
     W2L_T160_ATTR(true, true, false); W2L_T160_ATTR(true, false, false); W2L_T160_ATTR(false, true, false); W2L_T160_ATTR(false, false, false);
     W2L_T160_ATTR(true, true, true); W2L_T160_ATTR(true, false, true); W2L_T160_ATTR(false, true, true); W2L_T160_ATTR(false, false, true);
+    (void)hipFuncSetAttribute((const void*)gemm160_kernel<false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    (void)hipFuncSetAttribute((const void*)gemm160_kernel<false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
 #undef W2L_T160_ATTR
   }
   prof_begin(s, 2.0 * o.M * (double)o.N * o.K, PROF_GEMM128, o.M, o.N, o.K, tall ? 4 : 3);
 #define W2L_T160_GO(A, B, T) hipLaunchKernelGGL((gemm160_kernel<A, B, T>), grid, block, shmem, s, a, b, o, plan, workers)
-  if (!tall) {
+  if (cs) {
+    if (!tall) hipLaunchKernelGGL((gemm160_kernel<false, false, false, true>), grid, block, shmem, s, a, b, o, plan, workers);
+    else hipLaunchKernelGGL((gemm160_kernel<false, false, true, true>), grid, block, shmem, s, a, b, o, plan, workers);
+    if (csDone) *csDone = true;
+  } else if (!tall) {
     if (akc && bkc) W2L_T160_GO(true, true, false);
     else if (akc) W2L_T160_GO(true, false, false);
     else if (bkc) W2L_T160_GO(false, true, false);

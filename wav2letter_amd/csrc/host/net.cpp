@@ -617,8 +617,7 @@ class LinearLayer : public Layer {
         bl.backwardData(c, arena, dyImg, dx, nullptr, 1.f, nullptr, 0);
       }
     } else {
-    w2lCheck(w2l_linear_backward_weight(M, in, out, xSaved, dym, dwt, c.stream), "linear bwd w");
-    if (hasBias) w2lCheck(w2l_colsum(dym, b.g(c), (size_t)M, out, c.stream), "linear bwd b");
+    w2lCheck(w2l_linear_backward_weight_bias(M, in, out, xSaved, dym, dwt, hasBias ? b.g(c) : nullptr, c.stream), "linear bwd w + b");
     if (needDx) {
       dx = arena + dxOff;
       w2lCheck(w2l_linear_backward_data(M, in, out, dym, wt, dx, 0, nullptr, 1.f, c.stream), "linear bwd x");
@@ -795,7 +794,14 @@ class TDSLayer : public Layer {
     // lin1 + ReLU + dropout in one GEMM epilogue (same mask bits as a separate dropout pass over u)
     if (pd > 0) w2lCheck(w2l_linear_forward_dropout(M, l, l2, y1, w1.w(cx), b1.w(cx), u, 1, pd, cx.seed, rngStream + 1, s), "tds lin1+do");
     else w2lCheck(w2l_linear_forward(M, l, l2, y1, w1.w(cx), b1.w(cx), u, 1, s), "tds lin1");
-    w2lCheck(w2l_linear_forward(M, l2, l, u, w2.w(cx), b2.w(cx), v, 0, s), "tds lin2");
+    // lin2 with the second dropout and the residual join in its epilogue: v <- r2 = dropout(lin2(u)) + y1 (the same mask bits as a
+    // dropout pass over v: backward re-derives them from the hash), then a plain LayerNorm of r2 -- two tensor passes fewer than
+    // residual_layernorm(v, y1) behind a plain lin2
+    w2lCheck(w2l_linear_forward_dropout_add(M, l2, l, u, w2.w(cx), b2.w(cx), y1, v, 0, pd, cx.seed, rngStream + 2, s), "tds lin2+do+res");
+    w2lCheck(w2l_residual_layernorm_forward(groups, inner, v, nullptr, v, out, gb2.w(cx), 1e-5f, 0.0, 0, 0,
+                                            (double*)(ar + st2Off), ar + mr2Off, s), "tds ln2");
+    y = out;
+    return;
     }
     // r2 = dropout(v) + y1 (stored over v), out = LN(r2)
     w2lCheck(w2l_residual_layernorm_forward(groups, inner, v, y1, v, out, gb2.w(cx), 1e-5f, pd, cx.seed, rngStream + 2,
@@ -838,12 +844,10 @@ class TDSLayer : public Layer {
       bl1.backwardData(cx, ar, duImg, dy1, nullptr, 1.f, ds, 0);
     } else {
     // lin2: dW2 = u^T dv, db2, du = (dv W2^T) masked by relu+dropout of u (u holds the dropped value)
-    w2lCheck(w2l_linear_backward_weight(M, l2, l, u, dv, w2.g(cx), s), "tds lin2 bwd w");
-    w2lCheck(w2l_colsum(dv, b2.g(cx), (size_t)M, l, s), "tds lin2 bwd b");
+    w2lCheck(w2l_linear_backward_weight_bias(M, l2, l, u, dv, w2.g(cx), b2.g(cx), s), "tds lin2 bwd w + b");
     w2lCheck(w2l_linear_backward_data(M, l2, l, dv, w2.w(cx), du, 0, u, sc, s), "tds lin2 bwd x");
     // lin1: dW1 = y1^T du, db1, dy1 = ds + du W1^T
-    w2lCheck(w2l_linear_backward_weight(M, l, l2, y1, du, w1.g(cx), s), "tds lin1 bwd w");
-    w2lCheck(w2l_colsum(du, b1.g(cx), (size_t)M, l2, s), "tds lin1 bwd b");
+    w2lCheck(w2l_linear_backward_weight_bias(M, l, l2, y1, du, w1.g(cx), b1.g(cx), s), "tds lin1 bwd w + b");
     // dy1 = ds + du W1^T: the residual join rides in the GEMM epilogue as a separate addend (no copy of ds into dy1)
     w2lCheck(w2l_linear_backward_data_add(M, l, l2, du, w1.w(cx), ds, dy1, s), "tds lin1 bwd x");
     }

@@ -70,8 +70,7 @@ def linear_backward(x, w, dy, mask_src=None, mask_scale=1.0):
     db = torch.empty(N, device=x.device, dtype=torch.float32)
     L = _lib.lib()
     check(L.w2l_linear_backward_data(M, K, N, _p(dy), _p(w), _p(dx), 0, _p(mask_src), mask_scale, _s()), "linear_bwd_data")
-    check(L.w2l_linear_backward_weight(M, K, N, _p(x), _p(dy), _p(dw), _s()), "linear_bwd_weight")
-    check(L.w2l_colsum(_p(dy), _p(db), M, N, _s()), "colsum")
+    check(L.w2l_linear_backward_weight_bias(M, K, N, _p(x), _p(dy), _p(dw), _p(db), _s()), "linear_bwd_weight_bias")
     return dx, dw, db
 
 
@@ -134,6 +133,15 @@ def linear_forward_dropout(x, w, bias, relu, p, seed, stream_id):
     N = w.shape[1]
     y = torch.empty(M, N, device=x.device, dtype=torch.float32)
     check(_lib.lib().w2l_linear_forward_dropout(M, K, N, _p(x), _p(w), _p(bias), _p(y), int(relu), p, seed, stream_id, _s()), "linear_forward_dropout")
+    return y
+
+
+def linear_forward_dropout_add(x, w, bias, add, relu, p, seed, stream_id):
+    M, K = x.shape
+    N = w.shape[1]
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    check(_lib.lib().w2l_linear_forward_dropout_add(M, K, N, _p(x), _p(w), _p(bias), _p(add), _p(y), int(relu), p, seed, stream_id, _s()),
+          "linear_forward_dropout_add")
     return y
 
 
