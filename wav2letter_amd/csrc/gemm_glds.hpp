@@ -142,8 +142,21 @@ __device__ __forceinline__ void gemm128g_epilogue_wide(const GemmOut& out, int m
   // +40 VGPRs.  The kernel stays under 192 VGPRs so that two workgroups leave 128 registers per SIMD lane free -- room
   // for a communication kernel's waves to co-reside during the overlapped gradient all-reduce.)
   const float* accSrc = out.addend ? out.addend : out.C;
+  // the mask (or, without one, the addend / accumulate operand) of a half's eight row passes is fetched BEFORE the half's LDS turn,
+  // addresses clamped instead of predicated (see t160_epilogue: in the pass loop every pass paid its own memory round trip)
+  const bool preMask = (EPI & EPI_MASK) != 0, preAdd = !preMask && (EPI & EPI_ACCUM);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
+    f32x4 pre[8];
+    if (preMask || preAdd) {
+      const float* src = preMask ? out.mask : accSrc;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        int m;
+        const bool ok = gemm_out_row(out, m0 + wm + 32 * i + 4 * p + rq, m) && fullVec;
+        pre[p] = __builtin_nontemporal_load((const f32x4*)(src + (ok ? (size_t)m * out.ldc + n : (size_t)0)));   // read once: not worth a cache line next to the operand panels
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -168,12 +181,12 @@ __device__ __forceinline__ void gemm128g_epilogue_wide(const GemmOut& out, int m
       }
       if (fullVec) {
         if (EPI & EPI_MASK) {
-          const f32x4 mk = *(const f32x4*)(out.mask + (size_t)m * out.ldc + n);
+          const f32x4 mk = pre[p];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] * out.maskScale : 0.f;
         }
         if (EPI & EPI_ACCUM) {
-          const f32x4 o = *(const f32x4*)(accSrc + (size_t)m * out.ldc + n);
+          const f32x4 o = preAdd ? pre[p] : *(const f32x4*)(accSrc + (size_t)m * out.ldc + n);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += o[e];
         }

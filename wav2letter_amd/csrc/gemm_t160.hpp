@@ -75,7 +75,12 @@ __device__ __forceinline__ void t160_store_partial(float* slab, const f32x16 (&a
 
 // Epilogue: each 32x32 accumulator block turns through the wave's own 4 KiB of the released LDS stage (ds_write_b32
 // in C layout, ds_read_b128 as 8 rows x 8 float4), then 4 global_store_dwordx4 per lane: 128-byte row segments.
-template <int MI, int NJ>
+// PRE: the mask (or, without one, the addend / accumulate operand) of a block's four row passes is fetched BEFORE the block's LDS
+// turn, addresses clamped instead of predicated.  Left in the pass loop, every pass paid its own memory round trip (the row checks
+// are branches, and behind a branch the wait for a pending load is vmcnt(0), which on gfx9 also waits for the previous pass's
+// store): 20 round trips per tile, +20 ... +45 us per product on the TDS shapes and +136 ... +460 us at M = 11968, N = 1200 /
+// 2160 (profiles/r06_run26_gemm_epilogue_operand_cost.log).  Off in the column-sum instances (no such operand there; registers).
+template <int MI, int NJ, bool PRE = true>
 __device__ __forceinline__ void t160_epilogue(const GemmOut& out, int m0, int n0, const f32x16 (&acc)[5], float* scratch,
                                               const float (&bv)[NJ][4], int wave, int lane) {
   const int EPI = out.epi;
@@ -88,11 +93,22 @@ __device__ __forceinline__ void t160_epilogue(const GemmOut& out, int m0, int n0
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int b = i * NJ + j;
+      const int n = n0 + 32 * j + c4;
+      const bool fullVec = n + 3 < out.N;
+      f32x4 pre[4];
+      const bool preMask = PRE && (EPI & EPI_MASK), preAdd = PRE && !preMask && (EPI & EPI_ACCUM);
+      if (preMask || preAdd) {
+        const float* src = preMask ? out.mask : accSrc;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          int m;
+          const bool ok = gemm_out_row(out, m0 + 32 * i + 8 * p + rq, m) && fullVec;
+          pre[p] = __builtin_nontemporal_load((const f32x4*)(src + (ok ? (size_t)m * out.ldc + n : (size_t)0)));   // read once: not worth a cache line next to the operand panels
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) sc[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[b][r];
       // same wave wrote and reads: LDS operations of one wave complete in order, no barrier needed
-      const int n = n0 + 32 * j + c4;
-      const bool fullVec = n + 3 < out.N;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int row = 8 * p + rq;
@@ -112,12 +128,12 @@ __device__ __forceinline__ void t160_epilogue(const GemmOut& out, int m0, int n0
         }
         if (fullVec) {
           if (EPI & EPI_MASK) {
-            const f32x4 mk = *(const f32x4*)(out.mask + (size_t)m * out.ldc + n);
+            const f32x4 mk = preMask ? pre[p] : *(const f32x4*)(out.mask + (size_t)m * out.ldc + n);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] * out.maskScale : 0.f;
           }
           if (EPI & EPI_ACCUM) {
-            const f32x4 o = *(const f32x4*)(accSrc + (size_t)m * out.ldc + n);
+            const f32x4 o = preAdd ? pre[p] : *(const f32x4*)(accSrc + (size_t)m * out.ldc + n);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += o[e];
           }
@@ -380,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void gemm160_kernel(GOp aop, GOp bop, GemmO
     }
     if (doEpi) {
       // `stage` now names the buffer holding the prefetched next K tile; the other one is free
-      t160_epilogue<MI, NJ>(out, bx * BM + wm, by * BN + wn, acc, smem + (stage ^ 1) * kT160StageFloats, bv, wave, lane);
+      t160_epilogue<MI, NJ, !CS>(out, bx * BM + wm, by * BN + wn, acc, smem + (stage ^ 1) * kT160StageFloats, bv, wave, lane);
       if (resetTicket >= 0 && tid == 0) __hip_atomic_store(plan.counters + resetTicket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (!nxt.valid) break;

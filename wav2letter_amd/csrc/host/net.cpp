@@ -319,6 +319,13 @@ struct BfLinear {   // the weight images of one fl::Linear(in, out) and its thre
     w2lCheck(w2l_gemm_bf16(M, out, in, xImg.r(arena), xImg.colsP, w.t(arena), w.rowsP, y, out, bias, relu, dropP > 0 ? &e : nullptr,
                            c.stream), "bf16 linear fwd");
   }
+  // y [M][out] = dropout(x w + b) + add: the residual join behind the product in its epilogue (w2l_linear_forward_dropout_add)
+  void forwardAdd(Ctx& c, float* arena, const BfImage& xImg, const float* bias, const float* add, float* y, double dropP, uint32_t seed,
+                  uint32_t stream) const {
+    w2l_gemm_epilogue e{};
+    e.dropP = dropP; e.dropSeed = seed; e.dropStream = stream; e.addend = add;
+    w2lCheck(w2l_gemm_bf16(M, out, in, xImg.r(arena), xImg.colsP, w.t(arena), w.rowsP, y, out, bias, 0, &e, c.stream), "bf16 linear fwd + add");
+  }
   // dx [M][in] = dy w^T (mask) (+ addend | += dx); dyImg: images of dy [M][out]
   void backwardData(Ctx& c, float* arena, const BfImage& dyImg, float* dx, const float* mask, float maskScale, const float* addend,
                     int accumulate) const {
@@ -789,19 +796,29 @@ class TDSLayer : public Layer {
       }
       bl1.forward(cx, ar, y1Img, b1.w(cx), u, 1, pd, cx.seed, rngStream + 1);
       uImg.convert(cx, ar, u, "tds u images");
-      bl2.forward(cx, ar, uImg, b2.w(cx), v, 0, 0.0, 0, 0);
+      // (as in the fp32 branch below: second dropout + residual join in lin2's epilogue, a plain LayerNorm behind it)
+      bl2.forwardAdd(cx, ar, uImg, b2.w(cx), y1, v, pd, cx.seed, rngStream + 2);
+      w2lCheck(w2l_residual_layernorm_forward(groups, inner, v, nullptr, v, out, gb2.w(cx), 1e-5f, 0.0, 0, 0,
+                                              (double*)(ar + st2Off), ar + mr2Off, s), "tds ln2");
+      y = out;
+      return;
     } else {
     // lin1 + ReLU + dropout in one GEMM epilogue (same mask bits as a separate dropout pass over u)
     if (pd > 0) w2lCheck(w2l_linear_forward_dropout(M, l, l2, y1, w1.w(cx), b1.w(cx), u, 1, pd, cx.seed, rngStream + 1, s), "tds lin1+do");
     else w2lCheck(w2l_linear_forward(M, l, l2, y1, w1.w(cx), b1.w(cx), u, 1, s), "tds lin1");
     // lin2 with the second dropout and the residual join in its epilogue: v <- r2 = dropout(lin2(u)) + y1 (the same mask bits as a
     // dropout pass over v: backward re-derives them from the hash), then a plain LayerNorm of r2 -- two tensor passes fewer than
-    // residual_layernorm(v, y1) behind a plain lin2
+    // residual_layernorm(v, y1) behind a plain lin2.  Where the product runs on the LDS-DMA kernels (l2 % 32 == 0: their epilogues
+    // fetch the addend ahead of the LDS turn); the register-staged kernel pays more for the addend than the LayerNorm saves
+    // (config 3 in fp32, l2 = 3600 ... 6480: profiles/r06_run24_c3_lin2_epilogue_ab.log).
+    if (l2 % 32 == 0) {
     w2lCheck(w2l_linear_forward_dropout_add(M, l2, l, u, w2.w(cx), b2.w(cx), y1, v, 0, pd, cx.seed, rngStream + 2, s), "tds lin2+do+res");
     w2lCheck(w2l_residual_layernorm_forward(groups, inner, v, nullptr, v, out, gb2.w(cx), 1e-5f, 0.0, 0, 0,
                                             (double*)(ar + st2Off), ar + mr2Off, s), "tds ln2");
     y = out;
     return;
+    }
+    w2lCheck(w2l_linear_forward(M, l2, l, u, w2.w(cx), b2.w(cx), v, 0, s), "tds lin2");
     }
     // r2 = dropout(v) + y1 (stored over v), out = LN(r2)
     w2lCheck(w2l_residual_layernorm_forward(groups, inner, v, y1, v, out, gb2.w(cx), 1e-5f, pd, cx.seed, rngStream + 2,
@@ -1086,22 +1103,23 @@ class TransformerLayer : public Layer {
     }
     if (mixed) {
       if (!fused) ctxImg.convert(cx, ar, ctx, "tr ctx images");
-      blf.forward(cx, ar, ctxImg, bf.w(cx), o, 0, 0.0, 0, 0);
+      blf.forwardAdd(cx, ar, ctxImg, bf.w(cx), x, o, 0.0, 0, 0);
     } else {
-      w2lCheck(w2l_linear_forward(M, C, C, ctx, wf.w(cx), bf.w(cx), o, 0, s), "tr wf");
+      w2lCheck(w2l_linear_forward_dropout_add(M, C, C, ctx, wf.w(cx), bf.w(cx), x, o, 0, 0.0, 0, 0, s), "tr wf + res");
     }
-    // r1 = o + x (stored over o), h = LN1(r1)
-    const bool hImages = lnForward(cx, ar, M, C, o, x, o, h, gb1.w(cx), 0.0, 0, 0, (double*)(ar + st1Off), ar + mr1Off, mixed ? &hImg : nullptr, "tr ln1");
+    // o = r1 = wf(ctx) + x (the residual join in the product's epilogue), h = LN1(r1)
+    const bool hImages = lnForward(cx, ar, M, C, o, nullptr, o, h, gb1.w(cx), 0.0, 0, 0, (double*)(ar + st1Off), ar + mr1Off, mixed ? &hImg : nullptr, "tr ln1");
     if (mixed) {
       if (!hImages) hImg.convert(cx, ar, h, "tr h images");
       bl1.forward(cx, ar, hImg, b1.w(cx), u, 1, 0.0, 0, 0);
       uImg.convert(cx, ar, u, "tr u images");
-      bl2.forward(cx, ar, uImg, b2.w(cx), m2, 0, 0.0, 0, 0);
+      bl2.forwardAdd(cx, ar, uImg, b2.w(cx), h, m2, 0.0, 0, 0);
     } else {
     w2lCheck(w2l_linear_forward(M, C, mlp, h, w1.w(cx), b1.w(cx), u, 1, s), "tr w1");
-    w2lCheck(w2l_linear_forward(M, mlp, C, u, w2.w(cx), b2.w(cx), m2, 0, s), "tr w2");
+    w2lCheck(w2l_linear_forward_dropout_add(M, mlp, C, u, w2.w(cx), b2.w(cx), h, m2, 0, 0.0, 0, 0, s), "tr w2 + res");
     }
-    const bool outImages = lnForward(cx, ar, M, C, m2, h, m2, out, gb2.w(cx), 0.0, 0, 0, (double*)(ar + st2Off), ar + mr2Off,
+    // m2 = r2 = w2(u) + h
+    const bool outImages = lnForward(cx, ar, M, C, m2, nullptr, m2, out, gb2.w(cx), 0.0, 0, 0, (double*)(ar + st2Off), ar + mr2Off,
                                      mixed ? &outImg : nullptr, "tr ln2");
     if (outImages) {   // a following Transformer block of the same width reads them as its x images
       cx.imgOf = out; cx.imgRowsOff = outImg.rowsOff; cx.imgTransOff = outImg.transOff; cx.imgRows = M; cx.imgCols = C;
