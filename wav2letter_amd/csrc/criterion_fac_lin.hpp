@@ -486,31 +486,47 @@ __global__ __launch_bounds__(64 * (NW + 1)) void fac_fwd_blin(int T, int N, int 
 // Against fac_fwd_blin: no row wave (one wave less on the CU's four SIMDs), no LDS row, three instructions less per frame.
 constexpr int kFacRowsPerWave = 8;
 constexpr int kFacRowsWaves = 4;   // waves per workgroup (16000 one-wave workgroups at B = 64, T = 2000 were launch-rate bound: 20 us)
+// max over the 32 lanes of this lane's half of the wave (every lane gets it): the in-row DPP reduction of wave_max_rows, then the
+// two rows of the half through a 16-lane swap
+__device__ __forceinline__ float half_wave_max(float v) {
+  asm volatile(
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0"
+      : "+v"(v));
+  return fmaxf(v, __shfl_xor(v, 16));
+}
+// Two frames per pass (round 6): N <= 32 labels fill half a wave, so lanes 0 .. 31 take frame t and lanes 32 .. 63 frame t + 1 --
+// half the instructions per frame, 512-byte stores; the values are those of the one-frame-per-pass kernel bit for bit (a maximum
+// does not round).  21 -> 12 us at B = 64, T = 2000.
 __global__ __launch_bounds__(64 * kFacRowsWaves) static void fac_rows_k(int T, int N, const float* __restrict__ x, const float* __restrict__ trans,
                                                  double* __restrict__ crow, float* __restrict__ zmax, float* __restrict__ zspr = nullptr) {
-  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int b = blockIdx.y, lane = threadIdx.x & 63, half = lane >> 5, n = lane & 31;
   const int t0 = (blockIdx.x * kFacRowsWaves + (threadIdx.x >> 6)) * kFacRowsPerWave;
   const float L2E = 1.44269504088896341f;
-  const bool act = lane < N;
-  const float adl = act ? trans[(size_t)lane * N + lane] * L2E : 0.f;
+  const bool act = n < N;
+  const float adl = act ? trans[(size_t)n * N + n] * L2E : 0.f;
   const float* xb = x + (size_t)b * T * N;
-  float xv[kFacRowsPerWave];
+  float xv[kFacRowsPerWave / 2];
 #pragma unroll
-  for (int s = 0; s < kFacRowsPerWave; ++s) xv[s] = (act && t0 + s < T) ? xb[(size_t)(t0 + s) * N + lane] : 0.f;
+  for (int s = 0; s < kFacRowsPerWave / 2; ++s) xv[s] = (act && t0 + 2 * s + half < T) ? xb[(size_t)(t0 + 2 * s + half) * N + n] : 0.f;
 #pragma unroll
-  for (int s = 0; s < kFacRowsPerWave; ++s) {
-    const int t = t0 + s;
+  for (int s = 0; s < kFacRowsPerWave / 2; ++s) {
+    const int t = t0 + 2 * s + half;
+    const float z = act ? fmaf(xv[s], L2E, adl) : -INFINITY;
+    const float zm = half_wave_max(z);
+    const float zr = fmaxf(z - zm, -4000.f);
+    const float zi = __builtin_rintf(zr);
+    const double c = __builtin_amdgcn_ldexp((double)__builtin_amdgcn_exp2f(zr - zi), (int)zi);
+    float sp = 0.f;
+    if (zspr) sp = half_wave_max(act ? (z == z ? zm - z : INFINITY) : 0.f);   // the frame's spread (bits), for the range check of fac_fwd_plin; a NaN score makes it NaN
     if (t < T) {
-      const float z = act ? fmaf(xv[s], L2E, adl) : -INFINITY;
-      const float zm = wave_max_rows<2>(z);
-      const float zr = fmaxf(z - zm, -4000.f);
-      const float zi = __builtin_rintf(zr);
-      const double c = __builtin_amdgcn_ldexp((double)__builtin_amdgcn_exp2f(zr - zi), (int)zi);
-      if (lane < 32) crow[((size_t)b * T + t) * 32 + lane] = act ? c : 0.0;
-      if (lane == 0) zmax[(size_t)b * T + t] = zm;
-      if (zspr) {   // the frame's spread (bits), for the range check of fac_fwd_plin; a NaN score makes it NaN
-        const float sp = wave_max_rows<2>(act ? (z == z ? zm - z : INFINITY) : 0.f);
-        if (lane == 0) zspr[(size_t)b * T + t] = zm == zm ? sp : __builtin_nanf("");
+      crow[((size_t)b * T + t) * 32 + n] = act ? c : 0.0;
+      if (n == 0) {
+        zmax[(size_t)b * T + t] = zm;
+        if (zspr) zspr[(size_t)b * T + t] = zm == zm ? sp : __builtin_nanf("");
       }
     }
   }
