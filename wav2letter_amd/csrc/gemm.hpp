@@ -290,6 +290,10 @@ struct SkPlan {
   // in that XCD's L2 -- the classic stream-K ranges start at a different k in every tile and share nothing (weight
   // gradients: 10 % L2 hits, profiles/r02_run17_*).  One partial slab per unit (index u), ksplit arrivals per tile.
   int ksplit = 0, kChunk = 0;
+  // probe library only (W2L_GEMM_DBG = device address): per workgroup {start, end (100 MHz ticks), hardware id, XCC id}
+  long long* dbg = nullptr;
+  // wave priority of the two workgroups that share a CU (g_tile_prio, gemm_glds.hpp): 0 = leave it, 1 = alternate per segment
+  int prio = 0;
 };
 constexpr int kSkSlots = 512;           // resident 256-thread workgroups (2 per CU)
 constexpr int kSlabFloats = 128 * 128;
@@ -320,7 +324,7 @@ inline SkPlan make_sk_plan(int M, int N, int K, bool allowSk, int tileM = 128, i
   p.kTiles = (K + 31) / 32;
   const int tiles = p.tilesM * p.tilesN;
   p.dpTiles = tiles; p.skTiles = 0; p.skBlocks = 0; p.slabs = nullptr; p.grouped = 0; p.counters = nullptr;
-  p.ksplit = 0; p.kChunk = 0;
+  p.ksplit = 0; p.kChunk = 0; p.dbg = nullptr; p.prio = 0;
   if (!allowSk || p.kTiles < 8) return p;
   const int rounds = (tiles + slots - 1) / slots;
   const double eff = (double)tiles / ((double)rounds * slots);

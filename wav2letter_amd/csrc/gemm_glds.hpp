@@ -266,6 +266,40 @@ __device__ __forceinline__ GSeg g_pin(GSeg s) {
   return s;
 }
 
+constexpr int kGemmPrioMode = 0;   // the product's value (W2L_GEMM_PRIO overrides it in the probe library)
+__device__ __forceinline__ void g_dbg_record(long long* dbg, long long t0) {
+  unsigned hw, xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  long long* d = dbg + 4 * (size_t)blockIdx.x;
+  d[0] = t0; d[1] = wall_clock64(); d[2] = hw; d[3] = xcc;
+}
+// Fair shares for the two workgroups of a CU.  Left alone, one of the pair runs ~8 % faster than the other for the whole launch (the
+// arbiter's tie-break is not fair), finishes 80 - 140 us early and leaves its partner alone on the CU for 10 - 19 % of the launch
+// (profiles/r06_run35_gemm_workgroup_end_times.log) -- and one workgroup alone does not keep the matrix pipe busy through its
+// barriers and epilogues.  mode 1: the pair swaps priority every segment (who is high first follows the LDS allocation base), so
+// that over two segments both get the same share.  mode 2 (probe): the second workgroup stays low (sensitivity check).
+__device__ __forceinline__ int g_lds_second() {
+  unsigned la;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(la));
+  return (la & 0xfffu) != 0;
+}
+__device__ __forceinline__ void g_tile_prio(int mode, int second, int ord) {
+  if (mode == 1) {
+    if ((ord + second) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+  } else if (mode == 2) {
+    if (second) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
+  }
+}
+inline int gemm_prio_mode() {
+  static const int v = [] { const char* e = tune_env("W2L_GEMM_PRIO"); return e ? atoi(e) : kGemmPrioMode; }();
+  return v;
+}
+inline long long* gemm_dbg_ptr() {
+  const char* e = tune_env("W2L_GEMM_DBG");
+  return e ? (long long*)strtoull(e, nullptr, 10) : nullptr;
+}
+
 // ABL: timing-only ablations (results are garbage) selected by W2L_GEMM_ABL for the probe tool:
 //   1 = no LDS-DMA, 2 = no per-K-tile barrier, 4 = no fragment reads in the loop, 8 = no epilogue,
 //   16 = LDS-DMA always re-reads K tile 0 (cache-resident source), 32 = LDS-DMA of the A operand only,
@@ -284,6 +318,8 @@ __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, Gemm
 
   GSeg seg = g_pin(g_segment(plan, w, workers, 0));
   if (!seg.valid) return;
+  const long long dbgT0 = plan.dbg ? wall_clock64() : 0;
+  const int second = plan.prio ? g_lds_second() : 0;
   const float* qa[4];
   const float* qb[4];
   uint32_t va[4], vb[4];
@@ -314,6 +350,7 @@ __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, Gemm
   __syncthreads();  // (drains the LDS-DMA: vmcnt(0) precedes the barrier)
 
   for (int ord = 0;; ++ord) {
+    if (plan.prio) g_tile_prio(plan.prio, second, ord);
     const GSeg nxt = g_pin(g_segment(plan, w, workers, ord + 1));
     // bias of this lane's four output columns, fetched at the START of the tile (its latency hides under the K loop)
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -466,6 +503,7 @@ __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, Gemm
     seg = nxt;
     sk_tile_xy(plan, (ABL & 64) ? 0 : seg.tile, bx, by);
   }
+  if (plan.dbg && tid == 0) g_dbg_record(plan.dbg, dbgT0);
 }
 
 inline int launch128g(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o, int epi, hipStream_t s) {
@@ -481,6 +519,8 @@ inline int launch128g(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o,
   }
   int workers = plan.dpTiles < kSkSlots ? plan.dpTiles : kSkSlots;
   if (workers < plan.skBlocks) workers = plan.skBlocks;
+  plan.dbg = gemm_dbg_ptr();
+  plan.prio = gemm_prio_mode();
   const size_t shmem = 2 * (size_t)kGStageFloats * sizeof(float);
   dim3 grid((unsigned)workers), block(256);
   o.epi = epi;

@@ -189,6 +189,8 @@ __global__ __launch_bounds__(256, 2) void gemm160_kernel(GOp aop, GOp bop, GemmO
 
   GSeg seg = t160_segment(plan, w, workers, 0);
   if (!seg.valid) return;
+  const long long dbgT0 = plan.dbg ? wall_clock64() : 0;
+  const int second = plan.prio ? g_lds_second() : 0;
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)aop.p, 0, (int)aop.bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)bop.p, 0, (int)bop.bytes, 0x00020000);
   uint32_t va[PA], vb[PB];
@@ -208,6 +210,7 @@ __global__ __launch_bounds__(256, 2) void gemm160_kernel(GOp aop, GOp bop, GemmO
   __syncthreads();  // (drains the LDS-DMA: vmcnt(0) precedes the barrier)
 
   for (int ord = 0;; ++ord) {
+    if (plan.prio) g_tile_prio(plan.prio, second, ord);
     const GSeg nxt = t160_segment(plan, w, workers, ord + 1);
     // bias of this lane's output columns, fetched at the START of the tile (its latency hides under the K loop)
     float bv[NJ][4];
@@ -405,6 +408,7 @@ __global__ __launch_bounds__(256, 2) void gemm160_kernel(GOp aop, GOp bop, GemmO
     seg = nxt;
     sk_tile_xy(plan, seg.tile, bx, by);
   }
+  if (plan.dbg && tid == 0) g_dbg_record(plan.dbg, dbgT0);
 }
 
 // MEASURED (profiles/r02_run17_gemm_aligned_ksplit_negative.log): correct, the L2 sharing is real, and it does not pay --
@@ -471,6 +475,8 @@ inline int launch160(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o, 
       break;
     }
   }
+  plan.dbg = gemm_dbg_ptr();
+  plan.prio = gemm_prio_mode();
   const size_t shmem = 2 * (size_t)kT160StageFloats * sizeof(float);
   dim3 grid((unsigned)workers), block(256);
   o.epi = epi;
