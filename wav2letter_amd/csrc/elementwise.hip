@@ -176,6 +176,76 @@ __global__ __launch_bounds__(kEwThreads) void residual_ln_small_k(
   }
 }
 
+// The same one-pass LayerNorm with ONE WAVE per group (round 6; rows of at most 64 * kLnWaveV float4 = 2304 floats: the per-frame
+// LayerNorms of the streaming recipe, 1200 ... 2160 floats).  Against residual_ln_small_k (one 256-thread block per group): no LDS, no
+// __syncthreads between the statistics and the apply (the two double sums cross the wave by shuffles), 44 of 256 threads no longer
+// idle on a 300-chunk row, and a workgroup's four rows are independent -- 11968 x 1200: 100 -> ~60 us (profiles/r06_run37_*).
+// NJ = 16-byte chunks per lane.  Values: the block kernel's, up to the order of the double-precision sums.
+constexpr int kLnWaveV = 9;
+template <int NJ>
+__global__ __launch_bounds__(kEwThreads) void residual_ln_wave_k(
+    int groups, float* __restrict__ a, const float* __restrict__ x, float* __restrict__ r, float* __restrict__ y,
+    float* __restrict__ meanRstd, size_t inner, const float* __restrict__ gammaBeta, float eps,
+    uint32_t thr, float keepScale, uint32_t seed, uint32_t stream) {
+  const int lane = threadIdx.x & 63;
+  const int g = blockIdx.x * (kEwThreads / 64) + (threadIdx.x >> 6);
+  if (g >= groups) return;
+  const size_t base = (size_t)g * inner;
+  const int n4 = (int)(inner >> 2), lastc = n4 - 1;
+  float4 v[NJ], avs[NJ], xvs[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) avs[j] = *(const float4*)(a + base + 4 * (size_t)min(lane + 64 * j, lastc));
+  if (x) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) xvs[j] = *(const float4*)(x + base + 4 * (size_t)min(lane + 64 * j, lastc));
+  } else {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) xvs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  double s = 0, ss = 0;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int i = lane + 64 * j;
+    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+      const size_t e = base + 4 * (size_t)i;
+      float4 av = avs[j];
+      float4 rv = xvs[j];
+      if (thr) {
+        av.x = keep_elem(e, seed, stream, thr) ? av.x * keepScale : 0.f;
+        av.y = keep_elem(e + 1, seed, stream, thr) ? av.y * keepScale : 0.f;
+        av.z = keep_elem(e + 2, seed, stream, thr) ? av.z * keepScale : 0.f;
+        av.w = keep_elem(e + 3, seed, stream, thr) ? av.w * keepScale : 0.f;
+        if (r != a || !x) *(float4*)(a + e) = av;
+      }
+      rv.x += av.x; rv.y += av.y; rv.z += av.z; rv.w += av.w;
+      if (r != a || x) *(float4*)(r + e) = rv;
+      v[j] = rv;
+      s += (double)((rv.x + rv.y) + (rv.z + rv.w));
+      ss += (double)((rv.x * rv.x + rv.y * rv.y) + (rv.z * rv.z + rv.w * rv.w));
+    }
+  }
+  s = wave_sum_f64(s);
+  ss = wave_sum_f64(ss);
+  const double mu = s / (double)inner;
+  double var = ss / (double)inner - mu * mu;
+  if (var < 0) var = 0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float muf = (float)mu;
+  if (lane == 0) { meanRstd[2 * g] = muf; meanRstd[2 * g + 1] = rstd; }
+  const float gam = gammaBeta[0] * rstd, bet = gammaBeta[1];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int i = lane + 64 * j;
+    if (i < n4) {
+      float4 o = v[j];
+      o.x = (o.x - muf) * gam + bet; o.y = (o.y - muf) * gam + bet;
+      o.z = (o.z - muf) * gam + bet; o.w = (o.w - muf) * gam + bet;
+      *(float4*)(y + base + 4 * (size_t)i) = o;
+    }
+  }
+}
+
 // Same op for a group size that is not a multiple of 4 (the reference's TDSBlock golden vector: inner = 5 mel rows x
 // 2 channels = 10): scalar loads, one block per group, forward only.  Not on the training hot path.
 __global__ __launch_bounds__(kEwThreads) void residual_ln_scalar_k(
@@ -320,6 +390,72 @@ __global__ __launch_bounds__(kEwThreads) void ln_bwd_small_k(const float* __rest
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int i = threadIdx.x + j * kEwThreads;
+    if (i < n4) {
+      const size_t e = base + 4 * (size_t)i;
+      float4 o;
+      o.x = gr * (dv[j].x - c1 - xh[j].x * c2);
+      o.y = gr * (dv[j].y - c1 - xh[j].y * c2);
+      o.z = gr * (dv[j].z - c1 - xh[j].z * c2);
+      o.w = gr * (dv[j].w - c1 - xh[j].w * c2);
+      *(float4*)(dr + e) = o;
+      if (dmask) {
+        const float4 mv = mvs[j];
+        float4 d2;
+        d2.x = mv.x > 0.f ? o.x * maskScale : 0.f;
+        d2.y = mv.y > 0.f ? o.y * maskScale : 0.f;
+        d2.z = mv.z > 0.f ? o.z * maskScale : 0.f;
+        d2.w = mv.w > 0.f ? o.w * maskScale : 0.f;
+        *(float4*)(dmask + e) = d2;
+      }
+    }
+  }
+}
+
+// one wave per group (see residual_ln_wave_k)
+template <int NJ>
+__global__ __launch_bounds__(kEwThreads) void ln_bwd_wave_k(int groups, const float* __restrict__ r, const float* __restrict__ dy,
+                                                           const float* __restrict__ meanRstd, double* __restrict__ sums,
+                                                           const float* __restrict__ gammaBeta, float* __restrict__ dr,
+                                                           const float* __restrict__ maskSrc, float* __restrict__ dmask, float maskScale,
+                                                           size_t inner) {
+  const int lane = threadIdx.x & 63;
+  const int g = blockIdx.x * (kEwThreads / 64) + (threadIdx.x >> 6);
+  if (g >= groups) return;
+  const float mu = meanRstd[2 * g], rstd = meanRstd[2 * g + 1];
+  const size_t base = (size_t)g * inner;
+  const int n4 = (int)(inner >> 2), lastc = n4 - 1;
+  float4 xh[NJ], dv[NJ], mvs[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const size_t e = base + 4 * (size_t)min(lane + 64 * j, lastc);
+    xh[j] = *(const float4*)(r + e);
+    dv[j] = *(const float4*)(dy + e);
+  }
+  if (dmask) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) mvs[j] = *(const float4*)(maskSrc + base + 4 * (size_t)min(lane + 64 * j, lastc));
+  } else {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) mvs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  double s1 = 0, s2 = 0;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const float4 rv = xh[j];
+    xh[j] = make_float4((rv.x - mu) * rstd, (rv.y - mu) * rstd, (rv.z - mu) * rstd, (rv.w - mu) * rstd);
+    if (lane + 64 * j < n4) {
+      s1 += (double)((dv[j].x + dv[j].y) + (dv[j].z + dv[j].w));
+      s2 += (double)((dv[j].x * xh[j].x + dv[j].y * xh[j].y) + (dv[j].z * xh[j].z + dv[j].w * xh[j].w));
+    }
+  }
+  s1 = wave_sum_f64(s1);
+  s2 = wave_sum_f64(s2);
+  if (lane == 0) { sums[2 * g] = s1; sums[2 * g + 1] = s2; }
+  const float c1 = (float)(s1 / (double)inner), c2 = (float)(s2 / (double)inner);
+  const float gr = gammaBeta[0] * rstd;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int i = lane + 64 * j;
     if (i < n4) {
       const size_t e = base + 4 * (size_t)i;
       float4 o;
@@ -640,6 +776,12 @@ using namespace w2l;
 
 #define W2L_S ((hipStream_t)stream)
 
+// W2L_LN_WAVE=0 (probe library): the one-block-per-group kernels for groups of <= 2304 floats too (A/B runs)
+static bool ln_wave_enabled() {
+  static const bool v = [] { const char* e = tune_env("W2L_LN_WAVE"); return !(e && e[0] == '0'); }();
+  return v;
+}
+
 static inline unsigned ln_parts(size_t inner) {
   size_t g = ((inner >> 2) + kEwThreads * 4 - 1) / (kEwThreads * 4);  // >= 4 float4 per thread
   if (g > (size_t)kLnMaxParts) g = kLnMaxParts;
@@ -670,6 +812,23 @@ W2L_API int w2l_residual_layernorm_forward(int groups, size_t inner, float* a, c
     if (r == a) return W2L_EINVAL;
     hipLaunchKernelGGL(residual_ln_scalar_k, dim3((unsigned)groups), dim3(kEwThreads), 0, W2L_S, a, x, r, y, meanRstd,
                        inner, gammaBeta, eps, thr, ks, seed, rngStream);
+    W2L_LAUNCH_CHECK();
+    return W2L_OK;
+  }
+  if (inner / 4 <= 64 * (size_t)kLnWaveV && ln_wave_enabled()) {   // one wave per group
+    const int nj = (int)((inner / 4 + 63) / 64);
+    const dim3 grid((unsigned)((groups + kEwThreads / 64 - 1) / (kEwThreads / 64)));
+#define W2L_LN_FWDW(NJ_)                                                                                                    \
+  case NJ_:                                                                                                                 \
+    hipLaunchKernelGGL(residual_ln_wave_k<NJ_>, grid, dim3(kEwThreads), 0, W2L_S, groups, a, x, r, y, meanRstd, inner,      \
+                       gammaBeta, eps, thr, ks, seed, rngStream);                                                           \
+    break
+    switch (nj) {
+      W2L_LN_FWDW(1); W2L_LN_FWDW(2); W2L_LN_FWDW(3); W2L_LN_FWDW(4); W2L_LN_FWDW(5); W2L_LN_FWDW(6); W2L_LN_FWDW(7); W2L_LN_FWDW(8);
+      default: hipLaunchKernelGGL(residual_ln_wave_k<kLnWaveV>, grid, dim3(kEwThreads), 0, W2L_S, groups, a, x, r, y, meanRstd, inner,
+                                  gammaBeta, eps, thr, ks, seed, rngStream);
+    }
+#undef W2L_LN_FWDW
     W2L_LAUNCH_CHECK();
     return W2L_OK;
   }
@@ -706,7 +865,22 @@ W2L_API int w2l_layernorm_backward(int groups, size_t inner, const float* r, con
                                    double* sums, w2l_stream_t stream) {
   if (groups <= 0 || inner == 0 || (inner & 3) || !r || !dy || !gammaBeta || !meanRstd || !dr || !sums)
     return W2L_EINVAL;
-  if (inner <= kLnSmall) {
+  if (inner / 4 <= 64 * (size_t)kLnWaveV && ln_wave_enabled()) {   // one wave per group
+    const int nj = (int)((inner / 4 + 63) / 64);
+    const dim3 grid((unsigned)((groups + kEwThreads / 64 - 1) / (kEwThreads / 64)));
+#define W2L_LN_BWDW(NJ_)                                                                                                 \
+  case NJ_:                                                                                                              \
+    hipLaunchKernelGGL(ln_bwd_wave_k<NJ_>, grid, dim3(kEwThreads), 0, W2L_S, groups, r, dy, meanRstd, sums, gammaBeta,   \
+                       dr, maskSrc, maskSrc ? dmask : nullptr, maskScale, inner);                                        \
+    break
+    switch (nj) {
+      W2L_LN_BWDW(1); W2L_LN_BWDW(2); W2L_LN_BWDW(3); W2L_LN_BWDW(4); W2L_LN_BWDW(5); W2L_LN_BWDW(6); W2L_LN_BWDW(7); W2L_LN_BWDW(8);
+      default: hipLaunchKernelGGL(ln_bwd_wave_k<kLnWaveV>, grid, dim3(kEwThreads), 0, W2L_S, groups, r, dy, meanRstd, sums, gammaBeta,
+                                  dr, maskSrc, maskSrc ? dmask : nullptr, maskScale, inner);
+    }
+#undef W2L_LN_BWDW
+    W2L_LAUNCH_CHECK();
+  } else if (inner <= kLnSmall) {
     const int nj = (int)((inner / 4 + kEwThreads - 1) / kEwThreads);
 #define W2L_LN_BWD(NJ_)                                                                                                  \
   case NJ_:                                                                                                              \
