@@ -270,6 +270,15 @@ typedef struct {
   uint16_t* transposed;
   size_t ldTrans;
 } w2l_bf16_image_sink;
+/* w2l_gemm_bf16 whose RESULT leaves as the bf16 images the next products read (`images`: row-major [M][ldRows] and / or transposed
+ * [N][ldTrans], what w2l_bf16_convert would make of C bit for bit; only elements of the matrix are written) instead of, or beside,
+ * the fp32 C (C may be NULL when images are given); maskImage: the mask operand as a bf16 row-major image [M][ldMask] (> 0 test,
+ * replaces epilogue->mask).  An activation that is only ever a GEMM operand and a ReLU / dropout mask then lives only as bf16,
+ * as under the reference's AMP (recipes/slimIPL/src/Train.cpp:209-216).  N % 4 == 0; ldc (>= N) still names the flat index
+ * m * ldc + n of the dropout hash.  W2L_EUNSUPPORTED where the wide epilogue cannot run. */
+int w2l_gemm_bf16_images(int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B, int ldb, float* C, int ldc,
+                         const float* bias, int relu, const w2l_gemm_epilogue* epilogue, const w2l_bf16_image_sink* images,
+                         const uint16_t* maskImage, size_t ldMask, float maskScale, w2l_stream_t stream);
 /* r = dropout(a) + x ; y = LayerNorm(r) over `groups` contiguous chunks of `inner`
  * elements with scalar affine gammaBeta[2] (fl::LayerNorm axes {0,1,2}: groups = B).
  * a is updated in place to its dropped value; r, meanRstd[2*groups] are kept for

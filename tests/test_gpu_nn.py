@@ -1128,6 +1128,42 @@ def test_gemm_bf16_operand_storage_epilogues(oracle, M, N, K):
     assert torch.equal(y, y0)
 
 
+@pytest.mark.parametrize("M,N,K", [(700, 520, 333),       # 128 x 128 kernel, ragged last tile row (700 = 5 x 128 + 60) and column
+                                   (4000, 3100, 333),     # many tiles; 3100 = 24 x 128 + 28 columns
+                                   (11968, 1200, 400),    # config 3's frame count: the last tile row holds 64 rows
+                                   (1024, 2048, 2048),    # 256 x 256 kernel
+                                   (130, 36, 64)])        # a handful of rows / columns
+def test_gemm_bf16_writes_the_bf16_images_of_its_result(M, N, K):
+    """w2l_gemm_bf16_images: the result leaves as the two bf16 images w2l_bf16_convert would make of the fp32 C -- bit for bit, with
+    bias + ReLU + dropout applied, padding untouched (zero) -- with or without the fp32 copy; and a bf16 image serves as the mask
+    operand of a backward-data product exactly like the fp32 matrix it is the image of"""
+    from wav2letter_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).cuda()
+    B = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    Ab, _ = ops.bf16_convert(A)
+    Bb, _ = ops.bf16_convert(B)
+    p, seed, sid = 0.2, 99, 5
+    want = ops.gemm_bf16(Ab, Bb, K, bias=bias, relu=True, drop_p=p, drop_seed=seed, drop_stream=sid)
+    wr, wt = ops.bf16_convert(want, True, True)
+    for keep in (False, True):
+        c, rm, tr = ops.gemm_bf16_images(Ab, Bb, K, bias=bias, relu=True, keep_f32=keep, drop_p=p, drop_seed=seed, drop_stream=sid)
+        assert torch.equal(rm.view(torch.int16), wr.view(torch.int16))
+        assert torch.equal(tr.view(torch.int16), wt.view(torch.int16))
+        assert (c is None) if not keep else torch.equal(c, want)
+    _, rm, _ = ops.gemm_bf16_images(Ab, Bb, K, bias=bias, relu=True, transposed_image=False, drop_p=p, drop_seed=seed, drop_stream=sid)
+    assert torch.equal(rm.view(torch.int16), wr.view(torch.int16))
+    _, _, tr = ops.gemm_bf16_images(Ab, Bb, K, bias=bias, relu=True, rows_image=False, drop_p=p, drop_seed=seed, drop_stream=sid)
+    assert torch.equal(tr.view(torch.int16), wt.view(torch.int16))
+    # the mask operand as a bf16 image: dX[M][N] = dY W^T masked by (u > 0), u given as its row image
+    u = torch.randn(M, N, generator=g).cuda().clamp_min(0)      # a ReLU output: zeros and positives
+    uImg, _ = ops.bf16_convert(u)
+    ref = ops.gemm_bf16(Ab, Bb, K, mask=u, mask_scale=1.25)
+    got, _, _ = ops.gemm_bf16_images(Ab, Bb, K, keep_f32=True, rows_image=False, transposed_image=False, mask_image=uImg, mask_scale=1.25)
+    assert torch.equal(got, ref)
+
+
 @pytest.mark.parametrize("B,C,H,T,kw,padl,padr", [(2, 15, 80, 187, 9, 7, 1), (3, 19, 80, 70, 9, 7, 1), (2, 23, 80, 93, 11, 9, 1),
                                                   (2, 27, 80, 187, 11, 10, 0), (1, 27, 16, 5, 11, 10, 0), (2, 10, 80, 130, 21, 10, 10),
                                                   (1, 18, 80, 66, 21, 10, 10), (2, 14, 32, 64, 21, 10, 10)])

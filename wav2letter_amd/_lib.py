@@ -109,6 +109,7 @@ class _SIGS:
     w2l_set_matmul_precision = (_i, [_i])
     w2l_bf16_convert = (_i, [_p, _sz, _i, _sz, _p, _sz, _p, _sz, _p])
     w2l_bf16_convert_multi = (_i, [_i, _p, _p])
+    w2l_gemm_bf16_images = (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _sz, _f, _p])
     w2l_bf16_convert_dropout = (_i, [_p, _sz, _i, _sz, _p, _sz, _p, _sz, _d, _u32, _u32, _p])
     w2l_gemm_bf16 = (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p])
     w2l_gemm_bf16_ex = (_i, [_i, _i, _i, _p, _i, _i, _p, _i, _i, _p, _i, _p, _i, _p, _p])

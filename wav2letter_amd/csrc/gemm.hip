@@ -353,6 +353,39 @@ W2L_API int w2l_gemm_bf16(int M, int N, int K, const uint16_t* A, int lda, const
   return launch128h(A, lda, B, ldb, o, epi, (hipStream_t)stream);
 }
 
+// the same product whose RESULT leaves as the two bf16 images the next products read (w2l_bf16_image_sink: what w2l_bf16_convert
+// would make of C, bit for bit) instead of, or beside, the fp32 C (C may be NULL when images are given), and whose mask operand may
+// be a bf16 row-major image (maskImage [M][ldMask], > 0 test; replaces epilogue->mask): an activation that is only ever a GEMM
+// operand and a ReLU / dropout mask (fl::TDSBlock's u = dropout(relu(lin1)), its gradient du; the Transformer's MLP) then lives
+// ONLY as bf16 -- no fp32 copy, no conversion pass (the reference's AMP keeps it in half precision: recipes/slimIPL/src/Train.cpp:
+// 209-216).  N % 4 == 0; ldc (>= N) still names the flat index m * ldc + n of the dropout hash.
+W2L_API int w2l_gemm_bf16_images(int M, int N, int K, const uint16_t* A, int lda, const uint16_t* B, int ldb, float* C, int ldc,
+                                 const float* bias, int relu, const w2l_gemm_epilogue* e, const w2l_bf16_image_sink* images,
+                                 const uint16_t* maskImage, size_t ldMask, float maskScale, w2l_stream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !B || (!C && !images)) return W2L_EINVAL;
+  GemmOut o{C, bias, M, N, K, ldc, 0};
+  int epi = (bias ? EPI_BIAS : 0) | (relu ? EPI_RELU : 0);
+  if (e) {
+    if (e->mask) { o.mask = e->mask; o.maskScale = e->maskScale; epi |= EPI_MASK; }
+    if (e->addend) { o.addend = e->addend; epi |= EPI_ACCUM; }
+    else if (e->accumulate && C) epi |= EPI_ACCUM;
+    if (e->dropP > 0.0) {
+      o.dropThr = dropout_threshold(e->dropP); o.dropSeed = e->dropSeed; o.dropStream = e->dropStream;
+      o.dropScale = (float)(1.0 / (1.0 - e->dropP));
+      epi |= EPI_DROPOUT;
+    }
+  }
+  if (maskImage) {
+    if (o.mask) return W2L_EINVAL;
+    o.maskH = maskImage; o.ldMaskH = (int)ldMask; o.maskScale = maskScale; epi |= EPI_MASK;
+  }
+  if (images) {
+    o.imgRows = images->rowMajor; o.ldImgRows = (int)images->ldRows;
+    o.imgTrans = images->transposed; o.ldImgTrans = (int)images->ldTrans;
+  }
+  return launch128h(A, lda, B, ldb, o, epi, (hipStream_t)stream);
+}
+
 // the same product with k-MAJOR operands read in place (gemm_bf16g.hpp): aKMajor: A is stored [K][lda] (an activation x
 // [frames][in] as the A operand of x^T dy), bKMajor: B is stored [K][ldb] (a weight w [in][out] as the B operand of x w) --
 // no transposed bf16 image of either is needed

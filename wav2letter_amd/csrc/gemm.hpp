@@ -40,6 +40,14 @@ struct GemmOut {
   // stream scratch), added in range order by the tile's last arriver: deterministic like the product itself.
   float* colsum = nullptr;
   float* csPart = nullptr;
+  // bf16 images of the RESULT written by the epilogue itself (gemm128g_epilogue_wide<true>: the bf16-operand kernels), instead of or
+  // beside the fp32 C (C may be null then): imgRows [M][ldImgRows] row-major, imgTrans [N][ldImgTrans] transposed -- what
+  // w2l_bf16_convert would make of C, bit for bit (round to nearest even), only elements of the matrix are written (the zero
+  // padding is the caller's).  maskH: the EPI_MASK operand as a bf16 row-major image (> 0 test on the bf16 value).
+  uint16_t* imgRows = nullptr;
+  uint16_t* imgTrans = nullptr;
+  const uint16_t* maskH = nullptr;
+  int ldImgRows = 0, ldImgTrans = 0, ldMaskH = 0;
 };
 
 inline void gemm_set_row_remap(GemmOut& o, int pin, int pout, int off) {

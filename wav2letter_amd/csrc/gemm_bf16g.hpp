@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void gemm128h_kernel(GOp aop, GOp bop, Gemm
     }
     if (doEpi) {
       // `stage` now names the buffer holding the prefetched next K tile; the other one is free
-      if (wide) gemm128g_epilogue_wide(out, bx * 128, by * 128, acc, smem + (stage ^ 1) * kGStageFloats, bv);
+      if (wide) gemm128g_epilogue_wide<true>(out, bx * 128, by * 128, acc, smem + (stage ^ 1) * kGStageFloats, bv);
       else gemm128_epilogue(out, bx * 128, by * 128, acc);
       if (resetTicket >= 0 && tid == 0) __hip_atomic_store(plan.counters + resetTicket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -383,8 +383,8 @@ __global__ __launch_bounds__(512, 1) void gemm256h_kernel(GOp aop, GOp bop, Gemm
     // `stage` names the buffer holding the prefetched next K tile; the other one is free: eight 8 KiB wave slices
     float* scratch = smem + (stage ^ 1) * kH2StageFloats;
     if (wide) {
-      gemm128g_epilogue_wide(out, bx * 256, by * 256 + grp * 128, acc[0], scratch, bv, quad, wave);
-      gemm128g_epilogue_wide(out, bx * 256 + 128, by * 256 + grp * 128, acc[1], scratch, bv, quad, wave);
+      gemm128g_epilogue_wide<true>(out, bx * 256, by * 256 + grp * 128, acc[0], scratch, bv, quad, wave);
+      gemm128g_epilogue_wide<true>(out, bx * 256 + 128, by * 256 + grp * 128, acc[1], scratch, bv, quad, wave);
     } else {
       gemm128_epilogue(out, bx * 256, by * 256 + grp * 128, acc[0], quad);
       gemm128_epilogue(out, bx * 256 + 128, by * 256 + grp * 128, acc[1], quad);
@@ -421,6 +421,13 @@ inline int launch128h(const uint16_t* A, int lda, const uint16_t* B, int ldb, Ge
   o.epi = epi;
   const int wide = (((uintptr_t)o.C) & 15) == 0 && o.ldc % 4 == 0 && (!o.mask || (((uintptr_t)o.mask) & 15) == 0) &&
                    (!o.addend || (((uintptr_t)o.addend) & 15) == 0);
+  if (o.imgRows || o.imgTrans || o.maskH || !o.C) {   // images of the result / a bf16 mask image: the wide epilogue only
+    if (!wide || (o.N & 3) || o.rowPin || (!o.C && !o.imgRows && !o.imgTrans)) return W2L_EUNSUPPORTED;
+    if ((o.imgRows && ((((uintptr_t)o.imgRows) & 7) || (o.ldImgRows & 3) || o.ldImgRows < o.N)) ||
+        (o.imgTrans && ((((uintptr_t)o.imgTrans) & 15) || (o.ldImgTrans & 31) || o.ldImgTrans < o.M)) ||
+        (o.maskH && ((((uintptr_t)o.maskH) & 7) || (o.ldMaskH & 3) || o.ldMaskH < o.N)))
+      return W2L_EINVAL;
+  }
   GOp ga{(const float*)A, lda / 2, o.M, (unsigned)ab}, gb{(const float*)B, ldb / 2, o.N, (unsigned)bb};
   // Which kernel: predicted time of whole-tile schedules of the two tile sizes, fitted on MI355X over the config-3 / config-5
   // shapes (profiles/r03_run3_gemm_bf16_schedules.log).  128: a CU holds two workgroups, its busiest one works through

@@ -128,6 +128,19 @@ __device__ __forceinline__ void g_frag(float (&f)[2][4], const float* tile, int 
 // the float4.  Requires a 16-byte aligned C and ldc % 4 == 0 (host-checked; `wide` false otherwise).
 // quad: which 64 x 64 quadrant of the 128 x 128 tile this wave holds (-1: threadIdx.x >> 6); slice: which 8 KiB slice of
 // `scratch` it turns its rows through (-1: the same) -- the 256 x 256 kernel runs two 4-wave groups side by side
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 g_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float g_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t g_pack2(float a, float b) {   // two bf16, round to nearest even (v_cvt_pk_bf16_f32): convert.hip's cv_pack2
+  const g_f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, g_bf16x2_t));
+}
+// IMG (the bf16-operand kernels): out.imgRows / out.imgTrans / out.maskH are honoured (see GemmOut).  The row image leaves with the
+// float4 as four bf16 (128-byte row segments per 16 lanes); for the transposed image the finished float4 goes back into its LDS slot
+// and, after the half's eight passes, lane c reads column c of the 32 x 64 slice and stores 32 consecutive rows = 64 bytes of
+// image row n0 + c (the two halves of a wave complete the 128-byte line in the L2).
+template <bool IMG = false>
 __device__ __forceinline__ void gemm128g_epilogue_wide(const GemmOut& out, int m0, int n0, const f32x16 (&acc)[2][2],
                                                        float* scratch, const float (&bv)[4], int quad = -1, int slice = -1) {
   const int EPI = out.epi;
@@ -148,7 +161,16 @@ __device__ __forceinline__ void gemm128g_epilogue_wide(const GemmOut& out, int m
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     f32x4 pre[8];
-    if (preMask || preAdd) {
+    if (IMG && preMask && out.maskH) {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        int m;
+        const bool ok = gemm_out_row(out, m0 + wm + 32 * i + 4 * p + rq, m) && fullVec;
+        const u32x2 u = __builtin_nontemporal_load((const u32x2*)(out.maskH + (ok ? (size_t)m * out.ldMaskH + n : (size_t)0)));
+        pre[p][0] = __uint_as_float(u[0] << 16); pre[p][1] = __uint_as_float(u[0] & 0xffff0000u);
+        pre[p][2] = __uint_as_float(u[1] << 16); pre[p][3] = __uint_as_float(u[1] & 0xffff0000u);
+      }
+    } else if (preMask || preAdd) {
       const float* src = preMask ? out.mask : accSrc;
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
@@ -192,7 +214,13 @@ __device__ __forceinline__ void gemm128g_epilogue_wide(const GemmOut& out, int m
         }
         f32x4 w4;
         w4[0] = v[0]; w4[1] = v[1]; w4[2] = v[2]; w4[3] = v[3];
-        *(f32x4*)dst = w4;
+        if (!IMG || out.C) *(f32x4*)dst = w4;
+        if (IMG && out.imgRows) {
+          u32x2 h;
+          h[0] = g_pack2(v[0], v[1]); h[1] = g_pack2(v[2], v[3]);
+          *(u32x2*)(out.imgRows + (size_t)m * out.ldImgRows + n) = h;
+        }
+        if (IMG && out.imgTrans) *(f32x4*)(sc + row * 64 + c4) = w4;   // back into its slot, for the column pass below
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -201,6 +229,27 @@ __device__ __forceinline__ void gemm128g_epilogue_wide(const GemmOut& out, int m
           if (EPI & EPI_MASK) t = out.mask[(size_t)m * out.ldc + n + e] > 0.f ? t * out.maskScale : 0.f;
           if (EPI & EPI_ACCUM) t += accSrc[(size_t)m * out.ldc + n + e];
           dst[e] = t;
+        }
+      }
+    }
+    if (IMG && out.imgTrans) {   // (host: N % 4 == 0, no row remap -- every stored float4 above was a full one)
+      const int nn = n0 + wn + lane, mb = m0 + wm + 32 * i;
+      int rv = out.M - mb;
+      rv = rv > 32 ? 32 : rv;
+      if (nn < out.N && rv > 0) {
+        uint32_t pk[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) pk[q] = g_pack2(sc[(2 * q) * 64 + lane], sc[(2 * q + 1) * 64 + lane]);
+        uint16_t* d = out.imgTrans + (size_t)nn * out.ldImgTrans + mb;
+        if (rv == 32) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            u32x4 t;
+            t[0] = pk[4 * q]; t[1] = pk[4 * q + 1]; t[2] = pk[4 * q + 2]; t[3] = pk[4 * q + 3];
+            *(u32x4*)(d + 8 * q) = t;
+          }
+        } else {
+          for (int rr = 0; rr < rv; ++rr) d[rr] = (uint16_t)(pk[rr >> 1] >> (16 * (rr & 1)));
         }
       }
     }

@@ -326,6 +326,32 @@ struct BfLinear {   // the weight images of one fl::Linear(in, out) and its thre
     e.dropP = dropP; e.dropSeed = seed; e.dropStream = stream; e.addend = add;
     w2lCheck(w2l_gemm_bf16(M, out, in, xImg.r(arena), xImg.colsP, w.t(arena), w.rowsP, y, out, bias, 0, &e, c.stream), "bf16 linear fwd + add");
   }
+  // y = dropout(relu?(x w + b)) leaving ONLY as the bf16 images yImg (w2l_gemm_bf16_images: no fp32 y, no conversion pass): for an
+  // activation that is only ever a GEMM operand and a ReLU / dropout mask.  false: this geometry has no such epilogue (caller: the
+  // fp32 result + conversion)
+  bool forwardImages(Ctx& c, float* arena, const BfImage& xImg, const float* bias, const BfImage& yImg, int relu, double dropP, uint32_t seed,
+                     uint32_t stream) const {
+    w2l_gemm_epilogue e{};
+    e.dropP = dropP; e.dropSeed = seed; e.dropStream = stream;
+    const w2l_bf16_image_sink k = yImg.sink(c, arena);
+    const int st = w2l_gemm_bf16_images(M, out, in, xImg.r(arena), xImg.colsP, w.t(arena), w.rowsP, nullptr, out, bias, relu,
+                                        dropP > 0 ? &e : nullptr, &k, nullptr, 0, 1.f, c.stream);
+    if (st == W2L_EUNSUPPORTED) return false;
+    w2lCheck(st, "bf16 linear fwd -> images");
+    return true;
+  }
+  // dx = (dy w^T) masked by (maskImg > 0) * maskScale, maskImg the bf16 row image of the forward activation; dx leaves as the images
+  // dxImg only (dx == nullptr) or as fp32 too
+  bool backwardDataImages(Ctx& c, float* arena, const BfImage& dyImg, float* dx, const BfImage* dxImg, const BfImage& maskImg,
+                          float maskScale) const {
+    w2l_bf16_image_sink k{};
+    if (dxImg) k = dxImg->sink(c, arena);
+    const int st = w2l_gemm_bf16_images(M, in, out, dyImg.r(arena), dyImg.colsP, w.r(arena), w.colsP, dx, in, nullptr, 0, nullptr,
+                                        dxImg ? &k : nullptr, maskImg.r(arena), (size_t)maskImg.colsP, maskScale, c.stream);
+    if (st == W2L_EUNSUPPORTED) return false;
+    w2lCheck(st, "bf16 linear bwd data -> images");
+    return true;
+  }
   // dx [M][in] = dy w^T (mask) (+ addend | += dx); dyImg: images of dy [M][out]
   void backwardData(Ctx& c, float* arena, const BfImage& dyImg, float* dx, const float* mask, float maskScale, const float* addend,
                     int accumulate) const {
@@ -725,6 +751,7 @@ class TDSLayer : public Layer {
   size_t aOff, r1Off, y1Off, uOff, vOff, outOff, st1Off, mr1Off, st2Off, mr2Off;   // forward (r2 aliases v)
   size_t dsOff, duOff, dy1Off, dr1Off, daOff, dxOff;                        // backward
   const float* xSaved = nullptr;
+  bool uOnlyImages = false;             // mixed precision, this step: u exists only as uImg (set by forward, read by backward)
   BfLinear bl1, bl2;                    // mixed precision: lin1 (l -> l2), lin2 (l2 -> l)
   BfImage y1Img, uImg, dvImg, duImg;    // images of the two Linear inputs and of the two output gradients
   size_t convImgElems = 0, convImgFOff = 0, convImgBOff = 0;   // bf16 weight images of the convolution (0: fp32 kernels only)
@@ -794,8 +821,13 @@ class TDSLayer : public Layer {
         w2lCheck(w2l_bf16_convert_multi(3, wd, s), "tds y1 + weight images");
         y1Img.ensureOnes(cx, ar);
       }
-      bl1.forward(cx, ar, y1Img, b1.w(cx), u, 1, pd, cx.seed, rngStream + 1);
-      uImg.convert(cx, ar, u, "tds u images");
+      // u = dropout(relu(lin1(y1))) is only ever an operand of lin2's products and the mask of lin2's backward-data product: it lives
+      // ONLY as its two bf16 images, written by lin1's epilogue (uOnlyImages; where that epilogue cannot run: fp32 u + conversion)
+      uOnlyImages = bl1.forwardImages(cx, ar, y1Img, b1.w(cx), uImg, 1, pd, cx.seed, rngStream + 1);
+      if (!uOnlyImages) {
+        bl1.forward(cx, ar, y1Img, b1.w(cx), u, 1, pd, cx.seed, rngStream + 1);
+        uImg.convert(cx, ar, u, "tds u images");
+      }
       // (as in the fp32 branch below: second dropout + residual join in lin2's epilogue, a plain LayerNorm behind it)
       bl2.forwardAdd(cx, ar, uImg, b2.w(cx), y1, v, pd, cx.seed, rngStream + 2);
       w2lCheck(w2l_residual_layernorm_forward(groups, inner, v, nullptr, v, out, gb2.w(cx), 1e-5f, 0.0, 0, 0,
@@ -853,9 +885,14 @@ class TDSLayer : public Layer {
       else dvImg.convert(cx, ar, dv, "tds dv images");
       bl2.backwardWeight(cx, ar, uImg, dvImg, w2.g(cx), rides2);
       if (!rides2) w2lCheck(w2l_colsum(dv, b2.g(cx), (size_t)M, l, s), "tds lin2 bwd b");
-      bl2.backwardData(cx, ar, dvImg, du, u, sc, nullptr, 0);
-      duImg.convert(cx, ar, du, "tds du images");
+      // du = (dv W2^T) masked by u > 0: mask from u's bf16 image, and du itself -- an operand of lin1's two backward products and
+      // nothing else once its bias gradient rides on the weight-gradient product -- leaves only as its images
       const bool rides1 = bl1.biasRides(y1Img, w1.g(cx), b1.g(cx));
+      if (!(uOnlyImages && bl2.backwardDataImages(cx, ar, dvImg, rides1 ? nullptr : du, &duImg, uImg, sc))) {
+        if (uOnlyImages) throw std::runtime_error("TDSBlock: u was kept as images only, but the image-writing backward-data product refused");
+        bl2.backwardData(cx, ar, dvImg, du, u, sc, nullptr, 0);
+        duImg.convert(cx, ar, du, "tds du images");
+      }
       bl1.backwardWeight(cx, ar, y1Img, duImg, w1.g(cx), rides1);
       if (!rides1) w2lCheck(w2l_colsum(du, b1.g(cx), (size_t)M, l2, s), "tds lin1 bwd b");
       bl1.backwardData(cx, ar, duImg, dy1, nullptr, 1.f, ds, 0);
@@ -939,7 +976,7 @@ class TransformerLayer : public Layer {
   size_t ds2Off, duOff, dhOff, dr1Off, dctxOff, dsOff, dRoff, dqOff, dkOff, dvOff, dxOff, dEpOff, klOff;
   size_t abwOff = 0, abwBytes = 0;   // workspace of the fused attention backward (0: geometry without a fused kernel)
   const float* xSaved = nullptr;
-  bool dropped = false, fusedFwd = false;
+  bool dropped = false, fusedFwd = false, uOnlyImages = false;
   // mixed precision: the six fl::Linear of the block on bf16 images (the attention products stay on the fp32 batched GEMM)
   BfLinear blq, blk, blv, blf, bl1, bl2;
   BfImage xImg, ctxImg, hImg, uImg, dqImg, dkImg, dvImg, dr1Img, duImg, ds2Img;
@@ -1111,8 +1148,12 @@ class TransformerLayer : public Layer {
     const bool hImages = lnForward(cx, ar, M, C, o, nullptr, o, h, gb1.w(cx), 0.0, 0, 0, (double*)(ar + st1Off), ar + mr1Off, mixed ? &hImg : nullptr, "tr ln1");
     if (mixed) {
       if (!hImages) hImg.convert(cx, ar, h, "tr h images");
-      bl1.forward(cx, ar, hImg, b1.w(cx), u, 1, 0.0, 0, 0);
-      uImg.convert(cx, ar, u, "tr u images");
+      // u = relu(w1 h) is only ever an operand of w2's products and the mask of w2's backward-data product: bf16 images only
+      uOnlyImages = bl1.forwardImages(cx, ar, hImg, b1.w(cx), uImg, 1, 0.0, 0, 0);
+      if (!uOnlyImages) {
+        bl1.forward(cx, ar, hImg, b1.w(cx), u, 1, 0.0, 0, 0);
+        uImg.convert(cx, ar, u, "tr u images");
+      }
       bl2.forwardAdd(cx, ar, uImg, b2.w(cx), h, m2, 0.0, 0, 0);
     } else {
     w2lCheck(w2l_linear_forward(M, C, mlp, h, w1.w(cx), b1.w(cx), u, 1, s), "tr w1");
@@ -1174,9 +1215,12 @@ class TransformerLayer : public Layer {
       const bool rides2 = bl2.biasRides(uImg, w2.g(cx), b2.g(cx));
       bl2.backwardWeight(cx, ar, uImg, ds2Img, w2.g(cx), rides2);
       if (!rides2) w2lCheck(w2l_colsum(ds2, b2.g(cx), (size_t)M, C, s), "tr w2 bwd b");
-      bl2.backwardData(cx, ar, ds2Img, du, u, 1.f, nullptr, 0);
-      duImg.convert(cx, ar, du, "tr du images");
       const bool rides1 = bl1.biasRides(hImg, w1.g(cx), b1.g(cx));
+      if (!(uOnlyImages && bl2.backwardDataImages(cx, ar, ds2Img, rides1 ? nullptr : du, &duImg, uImg, 1.f))) {
+        if (uOnlyImages) throw std::runtime_error("Transformer: u was kept as images only, but the image-writing backward-data product refused");
+        bl2.backwardData(cx, ar, ds2Img, du, u, 1.f, nullptr, 0);
+        duImg.convert(cx, ar, du, "tr du images");
+      }
       bl1.backwardWeight(cx, ar, hImg, duImg, w1.g(cx), rides1);
       if (!rides1) w2lCheck(w2l_colsum(du, b1.g(cx), (size_t)M, mlp, s), "tr w1 bwd b");
       bl1.backwardData(cx, ar, duImg, dh, nullptr, 1.f, ds2, 0);

@@ -238,6 +238,33 @@ def gemm_bf16(A, B, K, bias=None, relu=False, mask=None, mask_scale=1.0, addend=
     return c
 
 
+def gemm_bf16_images(A, B, K, bias=None, relu=False, keep_f32=False, rows_image=True, transposed_image=True, mask_image=None,
+                     mask_scale=1.0, addend=None, drop_p=0.0, drop_seed=0, drop_stream=0):
+    """w2l_gemm_bf16_images: the product's result as bf16 images (zero-padded to multiples of 64 here, the caller's job in the ABI)
+    instead of / beside the fp32 C; mask_image: a bf16 row-major image as the mask operand.  Returns (C or None, rows, transposed)."""
+    import ctypes as C
+    M, N = A.shape[0], B.shape[0]
+    colsP, rowsP = (N + 63) // 64 * 64, (M + 63) // 64 * 64
+    c = torch.empty(M, N, dtype=torch.float32, device=A.device) if keep_f32 else None
+    rm = torch.zeros(M, colsP, dtype=torch.bfloat16, device=A.device) if rows_image else None
+    tr = torch.zeros(N, rowsP, dtype=torch.bfloat16, device=A.device) if transposed_image else None
+    e = _lib.GemmEpilogue()
+    e.mask = None; e.maskScale = 1.0
+    e.addend = _p(addend) if addend is not None else None
+    e.accumulate = 0
+    e.dropP = drop_p
+    e.dropSeed, e.dropStream = drop_seed, drop_stream
+    k = _lib.Bf16ImageSink()
+    k.rowMajor = _p(rm) if rm is not None else None; k.ldRows = colsP
+    k.transposed = _p(tr) if tr is not None else None; k.ldTrans = rowsP
+    _lib.check(_lib.lib().w2l_gemm_bf16_images(M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(c) if c is not None else None, N,
+                                               _p(bias) if bias is not None else None, int(relu), C.byref(e),
+                                               C.byref(k) if (rm is not None or tr is not None) else None,
+                                               _p(mask_image) if mask_image is not None else None,
+                                               mask_image.stride(0) if mask_image is not None else 0, mask_scale, _s()), "gemm_bf16_images")
+    return c, rm, tr
+
+
 def gemm_bf16_ex(A, B, M, N, K, a_kmajor=False, b_kmajor=False, bias=None, relu=False):
     """w2l_gemm_bf16_ex: C[M][N] fp32 = op(A) op(B)^T with k-MAJOR operands read in place: a_kmajor -> A is [K][>= M],
     b_kmajor -> B is [K][>= N] (row strides multiples of 8 elements); otherwise as gemm_bf16"""
