@@ -94,9 +94,11 @@ class ASGLossImpl : public SequenceCriterion {
     if (N != N_) throw std::invalid_argument("ASGLoss: N doesn't match with the letter size");
     Ws w = carve(ws, B, T, N, L);
     w2lCheck(w2l_batch_target_size(B, L, T, target, w.ts, c.stream), "asg target size");
+    // the two criteria side by side; the LONGER chain (FAC: label rows -> half scans -> finish, ~215 us at N = 30 against FCC's ~135)
+    // stays on the caller's stream, so that the fork / join events sit on the chain that has the slack
     hipStream_t s2 = fork(c.stream);
-    w2lCheck(w2l_fac_forward(B, T, N, L, mode_, em, target, w.ts, trans, w.loss2, w.fac, s2), "fac forward");
-    w2lCheck(w2l_fcc_forward(B, T, N, mode_, em, w.ts, trans, loss, w.fcc, c.stream), "fcc forward");
+    w2lCheck(w2l_fcc_forward(B, T, N, mode_, em, w.ts, trans, loss, w.fcc, s2), "fcc forward");
+    w2lCheck(w2l_fac_forward(B, T, N, L, mode_, em, target, w.ts, trans, w.loss2, w.fac, c.stream), "fac forward");
     join(c.stream);
     w2lCheck(w2l_axpy(loss, w.loss2, (size_t)B, -1.f, c.stream), "asg loss");
   }
@@ -104,8 +106,8 @@ class ASGLossImpl : public SequenceCriterion {
                 float* dEm, void* ws, float* trans, float* dTrans) override {
     Ws w = carve(ws, B, T, N, L);
     hipStream_t s2 = fork(c.stream);
-    w2lCheck(w2l_fac_backward(B, T, N, L, target, w.ts, gradLoss, w.dx2, w.dt2, w.fac, s2), "fac backward");
-    w2lCheck(w2l_fcc_backward(B, T, N, trans, gradLoss, dEm, dTrans, w.fcc, c.stream), "fcc backward");
+    w2lCheck(w2l_fcc_backward(B, T, N, trans, gradLoss, dEm, dTrans, w.fcc, s2), "fcc backward");
+    w2lCheck(w2l_fac_backward(B, T, N, L, target, w.ts, gradLoss, w.dx2, w.dt2, w.fac, c.stream), "fac backward");
     join(c.stream);
     w2lCheck(w2l_axpy(dEm, w.dx2, (size_t)B * T * N, -1.f, c.stream), "asg dx");
     w2lCheck(w2l_axpy(dTrans, w.dt2, (size_t)N * N, -1.f, c.stream), "asg dtrans");
