@@ -48,6 +48,7 @@ struct GemmOut {
   uint16_t* imgTrans = nullptr;
   const uint16_t* maskH = nullptr;
   int ldImgRows = 0, ldImgTrans = 0, ldMaskH = 0;
+  int ntStore = 0;   // probe (W2L_GEMM_NTSTORE): the wide epilogues store C nontemporal
 };
 
 inline void gemm_set_row_remap(GemmOut& o, int pin, int pout, int off) {

@@ -214,7 +214,7 @@ __device__ __forceinline__ void gemm128g_epilogue_wide(const GemmOut& out, int m
         }
         f32x4 w4;
         w4[0] = v[0]; w4[1] = v[1]; w4[2] = v[2]; w4[3] = v[3];
-        if (!IMG || out.C) *(f32x4*)dst = w4;
+        if (!IMG || out.C) { if (out.ntStore) __builtin_nontemporal_store(w4, (f32x4*)dst); else *(f32x4*)dst = w4; }
         if (IMG && out.imgRows) {
           u32x2 h;
           h[0] = g_pack2(v[0], v[1]); h[1] = g_pack2(v[2], v[3]);
@@ -570,6 +570,7 @@ inline int launch128g(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o,
   if (workers < plan.skBlocks) workers = plan.skBlocks;
   plan.dbg = gemm_dbg_ptr();
   plan.prio = gemm_prio_mode();
+  { static const int nt = [] { const char* e = tune_env("W2L_GEMM_NTSTORE"); return e ? atoi(e) : 0; }(); o.ntStore = nt; }
   const size_t shmem = 2 * (size_t)kGStageFloats * sizeof(float);
   dim3 grid((unsigned)workers), block(256);
   o.epi = epi;

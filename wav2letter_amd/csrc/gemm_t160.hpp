@@ -139,7 +139,7 @@ __device__ __forceinline__ void t160_epilogue(const GemmOut& out, int m0, int n0
           }
           f32x4 w4;
           w4[0] = v[0]; w4[1] = v[1]; w4[2] = v[2]; w4[3] = v[3];
-          *(f32x4*)dst = w4;
+          if (out.ntStore) __builtin_nontemporal_store(w4, (f32x4*)dst); else *(f32x4*)dst = w4;
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -477,6 +477,7 @@ inline int launch160(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o, 
   }
   plan.dbg = gemm_dbg_ptr();
   plan.prio = gemm_prio_mode();
+  { static const int nt = [] { const char* e = tune_env("W2L_GEMM_NTSTORE"); return e ? atoi(e) : 0; }(); o.ntStore = nt; }
   const size_t shmem = 2 * (size_t)kT160StageFloats * sizeof(float);
   dim3 grid((unsigned)workers), block(256);
   o.epi = epi;
