@@ -27,6 +27,7 @@
 #include "gemm.hpp"
 #include "gemm_glds.hpp"
 #include "gemm_t160.hpp"
+#include "gemm_p5.hpp"
 #include "gemm_bf16.hpp"
 #include "gemm_bf16g.hpp"
 

@@ -555,6 +555,8 @@ __global__ __launch_bounds__(256, 2) void gemm128g_kernel(GOp aop, GOp bop, Gemm
   if (plan.dbg && tid == 0) g_dbg_record(plan.dbg, dbgT0);
 }
 
+inline bool launch128p(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o, int epi, const SkPlan& plan0, int wide, hipStream_t s);   // gemm_p5.hpp
+
 inline int launch128g(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o, int epi, hipStream_t s) {
   epi &= ~EPI_ATOMIC;
   SkPlan plan = make_sk_plan(o.M, o.N, o.K, sk_enabled());
@@ -582,6 +584,7 @@ inline int launch128g(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o,
   // addresses, MI355X); W2L_GEMM_BUF=0 selects the global_load_lds variant for A/B runs
   static const int bufOn = [] { const char* e = tune_env("W2L_GEMM_BUF"); return e ? atoi(e) : 1; }();
 #ifdef W2L_PROBE  // timing-only ablations (results are garbage): compiled into the probe library only
+  if (launch128p(a, akc, b, bkc, o, epi, plan, wide, s)) { prof_end(s); W2L_LAUNCH_CHECK(); return W2L_OK; }
   static const int ablBuf = [] { const char* e = tune_env("W2L_GEMM_ABLBUF"); return e ? atoi(e) : 0; }();
   static const int abl = [] { const char* e = tune_env("W2L_GEMM_ABL"); return e ? atoi(e) : 0; }();
   if (abl && akc && !bkc) {
