@@ -151,9 +151,10 @@ __device__ __forceinline__ void gemm128g_epilogue_wide(const GemmOut& out, int m
   const int c4 = 4 * (lane & 15), rq = lane >> 4;
   const int n = n0 + wn + c4;
   const bool fullVec = n + 3 < out.N;
-  // (Fetching the mask / accumulate operand for all 16 rows ahead of the LDS turn-around was tried: no gain on MI355X,
-  // +40 VGPRs.  The kernel stays under 192 VGPRs so that two workgroups leave 128 registers per SIMD lane free -- room
-  // for a communication kernel's waves to co-reside during the overlapped gradient all-reduce.)
+  // (Register budget: 187 - 195 VGPRs with the eight prefetched operand vectors of a half below -- two workgroups leave ~120
+  // registers per SIMD lane free, room for a communication kernel's waves to co-reside during the overlapped gradient all-reduce.
+  // Round 1 had tried the prefetch for all 16 rows of a wave at once and seen no gain; per half, with clamped instead of predicated
+  // addresses, it is worth 10 - 15 us per product that has a mask or an addend: profiles/r06_run26 ... r06_run28_*.)
   const float* accSrc = out.addend ? out.addend : out.C;
   // the mask (or, without one, the addend / accumulate operand) of a half's eight row passes is fetched BEFORE the half's LDS turn,
   // addresses clamped instead of predicated (see t160_epilogue: in the pass loop every pass paid its own memory round trip)
