@@ -161,6 +161,17 @@ inline const char* tune_env(const char* name) { return std::getenv(name); }
 inline const char* tune_env(const char*) { return nullptr; }
 #endif
 
+// A CU to itself: dynamic LDS nobody reads, sized so that no second workgroup of this kind fits beside the first (2 x 84 KiB > the
+// CU's 160 KiB).  For the meet-in-the-middle ASG scans: 2 B workgroups of FullConnectionCriterion and 2 B of ForceAlignmentCriterion
+// run side by side on two streams, each a chain of T / 2 dependent frames on one lone-wave pipeline, and where the dispatcher puts
+// two of them on one CU both slow down (fcc_mitm_bwd 128 -> 140 ... 231 us, profiles/r06_run49_*).  With the request every one of
+// the 4 B <= 256 workgroups gets a CU of its own by construction.  0 when they would not all fit (the request would serialise them).
+constexpr unsigned kExclusiveLdsBytes = 84 * 1024;
+inline unsigned exclusive_cu_lds(int B) {
+  static const bool off = tune_env("W2L_ASG_SHARE_CUS") != nullptr;   // probe library: the plain placement (A/B runs)
+  return (!off && 4 * B <= 256) ? kExclusiveLdsBytes : 0u;
+}
+
 // ---- stateless dropout hash: must stay bit-identical to oracle/nn_oracle.c --
 __host__ __device__ inline uint32_t hash32(uint32_t idx, uint32_t seed, uint32_t stream) {
   uint32_t h = idx * 0x9E3779B1u + seed;

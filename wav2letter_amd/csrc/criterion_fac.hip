@@ -986,6 +986,13 @@ __global__ __launch_bounds__(64) void fac_vit(int T, int N, int L, const float* 
 
 using namespace w2l;
 
+// dynamic LDS request that gives a scan workgroup a CU of its own (exclusive_cu_lds), with the > 64 KiB opt-in of the function
+static unsigned mitm_excl(int B, const void* fn) {
+  const unsigned bytes = exclusive_cu_lds(B);
+  if (bytes) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return bytes;
+}
+
 W2L_API size_t w2l_fac_workspace_size(int B, int T, int N, int L) {
   if (B <= 0 || T <= 0 || N <= 0 || L <= 0) return 0;
   size_t sz = 2 * align_up((size_t)B * T * L * sizeof(float), 256) + align_up((size_t)B * sizeof(float), 256) +
@@ -1037,7 +1044,7 @@ W2L_API int w2l_fac_forward(int B, int T, int N, int L, int scaleMode, const flo
       hipLaunchKernelGGL(fac_rows_k, dim3((unsigned)((T + kFacRowsPerWave * kFacRowsWaves - 1) / (kFacRowsPerWave * kFacRowsWaves)), (unsigned)B), dim3(64 * kFacRowsWaves), 0, s, T, N, input,
                          trans, ws.crow, ws.zmax, ws.zspr);
       W2L_LAUNCH_CHECK();
-#define W2L_FAC_M_GO(NWV) hipLaunchKernelGGL((fac_mitm_fwd<NWV>), dim3(B, fac_mitm_only() < 0 ? 2 : 1), dim3(64 * NWV), 0, s, T, N, L, target, targetSize, trans, ws, fac_mitm_only() < 0 ? 0 : fac_mitm_only(), fac_mitm_abl())
+#define W2L_FAC_M_GO(NWV) hipLaunchKernelGGL((fac_mitm_fwd<NWV>), dim3(B, fac_mitm_only() < 0 ? 2 : 1), dim3(64 * NWV), mitm_excl(B, (const void*)fac_mitm_fwd<NWV>), s, T, N, L, target, targetSize, trans, ws, fac_mitm_only() < 0 ? 0 : fac_mitm_only(), fac_mitm_abl())
       switch (nw) {
         case 1: W2L_FAC_M_GO(1); break;
         case 2: W2L_FAC_M_GO(2); break;
@@ -1178,7 +1185,7 @@ W2L_API int w2l_fac_backward(int B, int T, int N, int L, const int* target, cons
     return !strcmp(e, "wave") ? 1 : !strcmp(e, "blk51") ? 2 : !strcmp(e, "blk42") ? 3 : 0;
   }();
   if (mitm) {
-#define W2L_FAC_M_GO(NWV) hipLaunchKernelGGL((fac_mitm_bwd<NWV>), dim3(B, fac_mitm_only() < 0 ? 2 : 1), dim3(64 * NWV), 0, s, T, N, L, target, targetSize, grad, transGrad, ws, fac_mitm_only() < 0 ? 0 : fac_mitm_only())
+#define W2L_FAC_M_GO(NWV) hipLaunchKernelGGL((fac_mitm_bwd<NWV>), dim3(B, fac_mitm_only() < 0 ? 2 : 1), dim3(64 * NWV), mitm_excl(B, (const void*)fac_mitm_bwd<NWV>), s, T, N, L, target, targetSize, grad, transGrad, ws, fac_mitm_only() < 0 ? 0 : fac_mitm_only())
     switch ((L + 63) / 64) {
       case 1: W2L_FAC_M_GO(1); break;
       case 2: W2L_FAC_M_GO(2); break;

@@ -705,6 +705,13 @@ const int* fcc_big_range_flags(int B, int T, int N, const void* workspace);
 
 using namespace w2l;
 
+// dynamic LDS request that gives a scan workgroup a CU of its own (exclusive_cu_lds), with the > 64 KiB opt-in of the function
+static unsigned mitm_excl(int B, const void* fn) {
+  const unsigned bytes = exclusive_cu_lds(B);
+  if (bytes) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return bytes;
+}
+
 W2L_API size_t w2l_fcc_workspace_size(int B, int T, int N) {
   if (B <= 0 || T <= 0 || N <= 0) return 0;
   if (N > 64) return fcc_big_supported(B, T, N) ? fcc_big_workspace_size(B, T, N) : 0;
@@ -730,7 +737,7 @@ W2L_API int w2l_fcc_forward(int B, int T, int N, int scaleMode, const float* inp
   if (asg_dpp_path(N) && asg_mitm_path()) {
     // product: alpha over frames 0 .. m and beta over T-1 .. m in two workgroups per utterance; the loss from the middle frame
     // (and the log-domain recursion for the utterances the range check flagged) by the second launch
-    hipLaunchKernelGGL(fcc_mitm_fwd, dim3(B, mitm_only() < 0 ? 2 : 1), dim3(128), 0, s, T, N, input, trans, ws, mitm_only() < 0 ? 0 : mitm_only());
+    hipLaunchKernelGGL(fcc_mitm_fwd, dim3(B, mitm_only() < 0 ? 2 : 1), dim3(128), mitm_excl(B, (const void*)fcc_mitm_fwd), s, T, N, input, trans, ws, mitm_only() < 0 ? 0 : mitm_only());
     W2L_LAUNCH_CHECK();
     hipLaunchKernelGGL((fcc_fwd_log<32, true>), dim3(B), dim3(64), 0, s, T, N, scaleMode, input, targetSize, trans, loss, ws);
   } else if (asg_dpp_path(N)) {
@@ -767,7 +774,7 @@ W2L_API int w2l_fcc_backward(int B, int T, int N, const float* trans, const floa
   FccWs ws = fcc_ws(workspace, B, T, N);
   const bool dpp = asg_dpp_path(N);
   if (dpp && asg_mitm_path()) {
-    hipLaunchKernelGGL(fcc_mitm_bwd, dim3(B, mitm_only() < 0 ? 2 : 1), dim3(128), 0, s, T, N, trans, grad, inputGrad, ws, mitm_only() < 0 ? 0 : mitm_only());
+    hipLaunchKernelGGL(fcc_mitm_bwd, dim3(B, mitm_only() < 0 ? 2 : 1), dim3(128), mitm_excl(B, (const void*)fcc_mitm_bwd), s, T, N, trans, grad, inputGrad, ws, mitm_only() < 0 ? 0 : mitm_only());
     W2L_LAUNCH_CHECK();
     hipLaunchKernelGGL(fcc_bwd_log<32>, dim3(B), dim3(64), 0, s, T, N, trans, grad, inputGrad, ws);
   } else if (dpp) {
