@@ -85,6 +85,19 @@ int w2l_fac_backward(int B, int T, int N, int L, const int* target, const int* t
 int w2l_fac_viterbi(int B, int T, int N, int L, const float* input, const int* target,
                     const int* targetSize, const float* trans, int* bestPaths,
                     void* workspace, w2l_stream_t stream);
+/* AutoSegmentationCriterion in ONE call: loss[b] = FullConnectionCriterion - ForceAlignmentCriterion, the composition
+ * fl::pkg::speech::ASGLoss::forward makes of the two criteria above (constructed at recipes/slimIPL/src/Train.cpp:408-410, run at
+ * :1675, backward at :1720; math SURVEY App. B.1 / B.2).  target is the [B][L] batch as the Trainer hands it over (padded with
+ * negative labels; the target sizes are counted on the device), trans the shared [N][N] transition parameter.  The two criteria
+ * run side by side on `stream` and a library-owned side stream of the device; for the letter-sized label sets (N <= 31, L <= 320)
+ * the launches that exist only to glue two calls together (target sizes, the loss / gradient differences) ride on their
+ * neighbours (csrc/criterion_asg_fused.hpp).  backward OVERWRITES inputGrad [B][T][N] and transGrad [N][N] with the gradients of
+ * sum_b grad[b] loss[b]; it needs the workspace of the forward call of the same batch.  Results equal the composed calls bit for bit. */
+size_t w2l_asg_workspace_size(int B, int T, int N, int L);
+int w2l_asg_forward(int B, int T, int N, int L, int scaleMode, const float* input, const int* target, const float* trans,
+                    float* loss, void* workspace, w2l_stream_t stream);
+int w2l_asg_backward(int B, int T, int N, int L, const int* target, const float* trans, const float* grad, float* inputGrad,
+                     float* transGrad, void* workspace, w2l_stream_t stream);
 /* Range check (diagnostics; no counterpart in the reference, whose log-domain recursion -- SURVEY App. B.1 / B.2, call sites
  * recipes/slimIPL/src/Train.cpp:408-410, :1675 -- is what the flagged utterances are recomputed with).  The fp32 / fp64
  * scaled-domain scans behind w2l_fcc_forward / w2l_fac_forward check per utterance that their inputs stay inside what they hold

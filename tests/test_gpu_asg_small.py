@@ -269,3 +269,79 @@ def test_asg_kernel_variants_of_the_probe_library(env):
     p = subprocess.run([sys.executable, "-c", _VARIANT_CODE], env=e, capture_output=True, text=True, timeout=900,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert p.returncode == 0 and "VARIANT OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
+
+
+def _asg_composed(Lb, B, T, N, L, mode, x, tgt, A, w):
+    """ASG as the composition of the two criterion calls (the sequence up to round 5): target sizes, FCC, FAC, three axpy"""
+    from wav2letter_amd import _lib
+    s = torch.cuda.current_stream().cuda_stream
+    ts = torch.empty(B, dtype=torch.int32, device="cuda")
+    loss = torch.empty(B, device="cuda"); loss2 = torch.empty(B, device="cuda")
+    dx = torch.empty_like(x); dx2 = torch.empty_like(x)
+    dt = torch.empty(N, N, device="cuda"); dt2 = torch.empty(N, N, device="cuda")
+    wf = torch.empty(Lb.w2l_fcc_workspace_size(B, T, N), dtype=torch.uint8, device="cuda")
+    wa = torch.empty(Lb.w2l_fac_workspace_size(B, T, N, L), dtype=torch.uint8, device="cuda")
+    _lib.check(Lb.w2l_batch_target_size(B, L, T, tgt.data_ptr(), ts.data_ptr(), s))
+    _lib.check(Lb.w2l_fcc_forward(B, T, N, mode, x.data_ptr(), ts.data_ptr(), A.data_ptr(), loss.data_ptr(), wf.data_ptr(), s))
+    _lib.check(Lb.w2l_fac_forward(B, T, N, L, mode, x.data_ptr(), tgt.data_ptr(), ts.data_ptr(), A.data_ptr(), loss2.data_ptr(), wa.data_ptr(), s))
+    _lib.check(Lb.w2l_axpy(loss.data_ptr(), loss2.data_ptr(), B, -1.0, s))
+    _lib.check(Lb.w2l_fcc_backward(B, T, N, A.data_ptr(), w.data_ptr(), dx.data_ptr(), dt.data_ptr(), wf.data_ptr(), s))
+    _lib.check(Lb.w2l_fac_backward(B, T, N, L, tgt.data_ptr(), ts.data_ptr(), w.data_ptr(), dx2.data_ptr(), dt2.data_ptr(), wa.data_ptr(), s))
+    _lib.check(Lb.w2l_axpy(dx.data_ptr(), dx2.data_ptr(), B * T * N, -1.0, s))
+    _lib.check(Lb.w2l_axpy(dt.data_ptr(), dt2.data_ptr(), N * N, -1.0, s))
+    torch.cuda.synchronize()
+    return loss, dx, dt
+
+
+@pytest.mark.parametrize("B,T,N,L,mode,ascale", [(3, 57, 30, 20, 0, 0.3),      # the fused sequence (N <= 31, L <= 320)
+                                                 (5, 257, 29, 300, 4, 0.3),    # five waves of positions, TARGET_SZ_SQRT
+                                                 (4, 64, 32, 40, 0, 0.3),      # FAC fused, FCC on its 32-state kernels
+                                                 (2, 700, 30, 120, 2, 60.0),   # every utterance flagged: the log-domain recomputation inside the finish launch
+                                                 (3, 40, 40, 25, 0, 0.3),      # N > 32: the composed calls behind the same entry points
+                                                 (2, 33, 30, 330, 0, 0.3)])    # L > 320: likewise
+def test_asg_in_one_call_equals_the_composed_calls_and_the_oracle(oracle, B, T, N, L, mode, ascale):
+    """w2l_asg_forward / w2l_asg_backward (what fl::pkg::speech::ASGLoss and the trainer enqueue): bit-identical to the composition
+    of w2l_fcc_* and w2l_fac_* (same operations, same operands, same order), 1e-4 against the fp64 oracle; with an empty target in
+    the batch, targets longer than T (capped), a second backward on the same forward, and two workspaces interleaved"""
+    from wav2letter_amd import _lib
+    Lb = _lib.lib()
+    rng = np.random.default_rng(B * 100 + T + N)
+    x = dev((rng.normal(size=(B, T, N)) * 1.5).astype(np.float32))
+    A = dev((rng.normal(size=(N, N)) * ascale + np.eye(N) * 2.0).astype(np.float32))
+    tg = make_targets(rng, B, L, N, T)
+    tg[0, :] = -1                                 # an utterance without a transcription
+    if L > T: tg[1, :] = rng.integers(0, N, L)    # longer than the utterance: the target size is capped at T
+    tgt = dev(tg)
+    wv = rng.normal(size=B).astype(np.float32)
+    w = dev(wv)
+    s = torch.cuda.current_stream().cuda_stream
+    want = _asg_composed(Lb, B, T, N, L, mode, x, tgt, A, w)
+
+    def run(ws, second_backward=False):
+        loss = torch.empty(B, device="cuda"); dx = torch.empty_like(x); dt = torch.empty(N, N, device="cuda")
+        _lib.check(Lb.w2l_asg_forward(B, T, N, L, mode, x.data_ptr(), tgt.data_ptr(), A.data_ptr(), loss.data_ptr(), ws.data_ptr(), s))
+        return loss, dx, dt
+
+    def bwd(ws, dx, dt):
+        _lib.check(Lb.w2l_asg_backward(B, T, N, L, tgt.data_ptr(), A.data_ptr(), w.data_ptr(), dx.data_ptr(), dt.data_ptr(), ws.data_ptr(), s))
+    nbytes = Lb.w2l_asg_workspace_size(B, T, N, L)
+    assert nbytes > 0
+    ws1 = torch.empty(nbytes, dtype=torch.uint8, device="cuda"); ws2 = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    loss, dx, dt = run(ws1)
+    bwd(ws1, dx, dt)
+    torch.cuda.synchronize()
+    for got, ref in zip((loss, dx, dt), want):
+        assert torch.equal(got, ref)
+    bwd(ws1, dx, dt)                              # a second backward on the same forward
+    torch.cuda.synchronize()
+    assert torch.equal(dx, want[1]) and torch.equal(dt, want[2])
+    l1, dx1, dt1 = run(ws1); l2, dx2, dt2 = run(ws2)   # two forwards pending, backwards in the other order
+    bwd(ws2, dx2, dt2); bwd(ws1, dx1, dt1)
+    torch.cuda.synchronize()
+    for got in ((l1, dx1, dt1), (l2, dx2, dt2)):
+        for g_, ref in zip(got, want):
+            assert torch.equal(g_, ref)
+    ol, odx, odt = oracle.asg(x.cpu().numpy(), A.cpu().numpy(), tg, mode, wv.astype(np.float64))
+    assert relerr(loss.cpu().numpy(), ol) < TOL
+    assert gradrel(dx.cpu().numpy(), odx) < TOL
+    assert gradrel(dt.cpu().numpy(), odt) < TOL

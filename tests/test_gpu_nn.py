@@ -223,6 +223,37 @@ def test_gemm_160_wide_tiles(M, N, K, akc, bkc, mode, probe):
     assert rel(got, old.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(4, 4, 32), (260, 388, 96), (1028, 2052, 1440), (6016, 1440, 4320), (24000, 800, 2400),
+                                    (131, 160, 64), (12000, 1120, 3360)])
+@pytest.mark.parametrize("bkc", [False, True])
+def test_gemm_160_a_operand_straight_into_registers(M, N, K, bkc, probe):
+    """128x160 tiles with a k-contiguous A: the K loop that loads the wave's own A rows straight into the fragment registers
+    (gemm160_kernel<..., ADIR>, the default) against the all-LDS loop (W2L_GEMM_ADIR=0): same k-slot assignment, same sum
+    order -- bit-identical, incl. clamped edge rows, stream-K ranges and the bias + ReLU epilogue; and the float64 product"""
+    import os
+    from wav2letter_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(7 * M + 5 * N + K)
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(K, N, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    want = (A.double() @ Bm.double() + bias.double()).numpy()
+    Ad = A.cuda()
+    Bd = (Bm.T.contiguous() if bkc else Bm).cuda()
+    os.environ["W2L_GEMM_T160"] = "2"
+    try:
+        os.environ["W2L_GEMM_ADIR"] = "1"
+        got = ops.gemm(Ad, Bd, True, bkc, bias.cuda())
+        gotr = ops.gemm(Ad, Bd, True, bkc, bias.cuda(), relu=True)
+        os.environ["W2L_GEMM_ADIR"] = "0"
+        old = ops.gemm(Ad, Bd, True, bkc, bias.cuda())
+        oldr = ops.gemm(Ad, Bd, True, bkc, bias.cuda(), relu=True)
+    finally:
+        os.environ.pop("W2L_GEMM_T160")
+        os.environ.pop("W2L_GEMM_ADIR", None)
+    assert rel(got, want) < TOL
+    assert torch.equal(got, old) and torch.equal(gotr, oldr)
+
+
 @pytest.mark.parametrize("mode", ["2", "3"])
 def test_gemm_160_fused_epilogues(mode, probe):
     """dropout / mask / addend epilogues of the fl::Linear calls through the 160-wide kernels equal the 128x128 kernel's"""

@@ -88,6 +88,9 @@ class _SIGS:
     w2l_fac_workspace_size = (_sz, [_i, _i, _i, _i])
     w2l_fac_forward = (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p])
     w2l_fac_backward = (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p])
+    w2l_asg_workspace_size = (_sz, [_i, _i, _i, _i])
+    w2l_asg_forward = (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p])
+    w2l_asg_backward = (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p])
     w2l_fac_viterbi = (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p])
     w2l_fcc_range_flags = (_i, [_i, _i, _i, _p, _p, _p])
     w2l_fac_range_flags = (_i, [_i, _i, _i, _i, _p, _p, _p])

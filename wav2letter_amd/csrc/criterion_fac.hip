@@ -21,6 +21,7 @@
 // Emission values x[t][y_i] are gathered straight from the coalesced [B][T][N]
 // rows (L1/L2 resident: the row is 120 B at N = 30), prefetched kFacChunk steps ahead.
 #include "common.hpp"
+#include "criterion_asg_fused.hpp"
 #include <cstring>
 #include <cstdlib>
 
@@ -302,12 +303,12 @@ __global__ __launch_bounds__(64) void fac_bwd(int T, int N, int L, const int* __
 
 // ---------------------------------------------------------------- workgroup-per-utterance kernels
 template <int NW, int P>
-__global__ __launch_bounds__(64 * NW) void fac_fwd_blk(int T, int N, int L, int scaleMode,
-                                                       const float* __restrict__ x,
-                                                       const int* __restrict__ target,
-                                                       const int* __restrict__ targetSize,
-                                                       const float* __restrict__ trans,
-                                                       float* __restrict__ loss, FacWs ws, const int* __restrict__ redo = nullptr) {
+__device__ __forceinline__ void fac_fwd_blk_body(int T, int N, int L, int scaleMode,
+                                                 const float* __restrict__ x,
+                                                 const int* __restrict__ target,
+                                                 const int* __restrict__ targetSize,
+                                                 const float* __restrict__ trans,
+                                                 float* loss, const FacWs& ws, const int* __restrict__ redo = nullptr) {
   constexpr int NT = 64 * NW;
   __shared__ double sA[2][NT * P + 1];  // sA[buf][i + 1] = alpha[i]; sA[buf][0] = -inf (position -1)
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -401,6 +402,34 @@ __global__ __launch_bounds__(64 * NW) void fac_fwd_blk(int T, int N, int L, int 
 #pragma unroll
   for (int p = 0; p < P; ++p)
     if (tid + NT * p == S - 1) loss[b] = (float)((double)sc * alpha[p]);
+}
+template <int NW, int P>
+__global__ __launch_bounds__(64 * NW) void fac_fwd_blk(int T, int N, int L, int scaleMode,
+                                                       const float* __restrict__ x,
+                                                       const int* __restrict__ target,
+                                                       const int* __restrict__ targetSize,
+                                                       const float* __restrict__ trans,
+                                                       float* __restrict__ loss, FacWs ws, const int* __restrict__ redo = nullptr) {
+  fac_fwd_blk_body<NW, P>(T, N, L, scaleMode, x, target, targetSize, trans, loss, ws, redo);
+}
+
+// The tail of the ASG criterion's fused forward sequence (fac_forward_asg below) in ONE launch: fac_mitm_finish (Z, loss, the middle
+// frame's posterior, the range check), the log-domain recomputation of an utterance the check flagged (fac_fwd_blk<8, 1>: any L <= 512;
+// a path no recipe input takes), and ASG's own subtraction  minuend[b] = minuend[b] - loss[b]  (minuend = FullConnectionCriterion's
+// loss: the caller has joined that stream in front of this launch).  Two launches and an axpy fewer on the forward chain.
+__global__ __launch_bounds__(kFacFinishThreads) void fac_mitm_finish_all(int T, int N, int L, int scaleMode, const float* __restrict__ x,
+                                                                         const int* __restrict__ target, const int* __restrict__ targetSize,
+                                                                         const float* __restrict__ trans, float* loss, FacWs ws,
+                                                                         float* minuend) {
+  static_assert(kFacFinishThreads == 512, "fac_fwd_blk<8, 1> is a 512-thread body");
+  const int b = blockIdx.x;
+  fac_mitm_finish_body(T, N, L, scaleMode, target, targetSize, trans, loss, ws);
+  __syncthreads();   // the flag and the loss of thread 0, visible to the workgroup
+  if (*(volatile int*)(ws.redo + b) != 0) {   // workgroup-uniform
+    fac_fwd_blk_body<8, 1>(T, N, L, scaleMode, x, target, targetSize, trans, loss, ws, nullptr);
+    __syncthreads();
+  }
+  if (minuend && threadIdx.x == 0) minuend[b] = minuend[b] - *(volatile float*)(loss + b);
 }
 
 // backward scan: consumes w1[t][i], leaves g * dalpha_t[i] in its place; transition gradients per position
@@ -808,36 +837,7 @@ constexpr int kScF = 32;
 // wave's count and every lane's rank inside it; the waves' counts and the label offsets are combined through LDS.
 __global__ __launch_bounds__(512) void fac_csr_k(int N, int L, const int* __restrict__ target, const int* __restrict__ targetSize,
                                                 int* __restrict__ csr) {
-  __shared__ int cnt[8][64];
-  __shared__ int offs[65];
-  const int b = blockIdx.x, i = threadIdx.x, lane = i & 63, wave = i >> 6;
-  const int S = min(targetSize[b], L);
-  int* pos = csr + (size_t)b * (L + 68);
-  int* off = pos + L;
-  if (S <= 0) return;
-  const int yi = i < S ? target[(size_t)b * L + i] : -1;
-  const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
-  int rank = 0;
-  for (int n = 0; n < N; ++n) {
-    const unsigned long long m = __ballot(yi == n);
-    if (lane == 0) cnt[wave][n] = __popcll(m);
-    if (yi == n) rank = __popcll(m & below);
-  }
-  __syncthreads();
-  if (i <= N) {   // off[n] = positions with a smaller label
-    int less = 0;
-    for (int n = 0; n < i; ++n)
-#pragma unroll
-      for (int w = 0; w < 8; ++w) less += cnt[w][n];
-    offs[i] = less;
-    off[i] = less;
-  }
-  __syncthreads();
-  if (yi >= 0 && yi < N) {
-    int base = offs[yi];
-    for (int w = 0; w < wave; ++w) base += cnt[w][yi];
-    pos[base + rank] = i;
-  }
+  fac_csr_body(N, L, target, targetSize, csr);   // (criterion_fac_mitm.hpp: the fused ASG sequence runs it inside its backward scan launch)
 }
 
 template <int NP>   // NP = ceil(L / 64): row segments per lane
@@ -907,6 +907,41 @@ __global__ void reduce_over_b_fac(int B, size_t n, const float* __restrict__ par
   }
   for (; b < B; ++b) s += part[(size_t)b * n + k];
   out[k] = s;
+}
+
+// The ASG criterion's backward tail in one launch (fac_backward_asg): the first blocks reduce ForceAlignmentCriterion's transition-
+// gradient partials and subtract them from FullConnectionCriterion's transition gradient (reduce_over_b_fac), the others
+// subtract its input gradient from FullConnectionCriterion's (w2l_axpy with alpha = -1: y + (-1) x == y - x) -- one launch behind
+// the join of the two streams instead of a reduce in front of it and two axpy behind it.
+constexpr int kAsgCombineReduceThreads = 256;
+__global__ __launch_bounds__(256) void asg_bwd_combine_k(int parts, unsigned nn, const float* __restrict__ part, float* __restrict__ dTrans,
+                                                         float* __restrict__ dEm, const float* __restrict__ dx2, size_t n, unsigned redBlocks) {
+  if (blockIdx.x < redBlocks) {
+    const unsigned k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= nn) return;
+    const float prev = dTrans[k];
+    float s = 0.f;
+    int b = 0;
+    for (; b + 7 < parts; b += 8) {   // (reduce_over_b_fac's order)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + u) * nn + k];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < parts; ++b) s += part[(size_t)b * nn + k];
+    dTrans[k] = prev - s;
+    return;
+  }
+  const size_t n4 = n >> 2, stride = (size_t)(gridDim.x - redBlocks) * 256;
+  for (size_t i = (size_t)(blockIdx.x - redBlocks) * 256 + threadIdx.x; i < n4; i += stride) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f a = *(const v4f*)(dEm + 4 * i);
+    const v4f x = __builtin_nontemporal_load((const v4f*)(dx2 + 4 * i));   // read once
+    a -= x;
+    *(v4f*)(dEm + 4 * i) = a;
+  }
+  for (size_t e = (n4 << 2) + (size_t)(blockIdx.x - redBlocks) * 256 + threadIdx.x; e < n; e += stride) dEm[e] -= dx2[e];
 }
 
 constexpr int kFacBt = 128;  // backtrace chunk
@@ -1042,7 +1077,7 @@ W2L_API int w2l_fac_forward(int B, int T, int N, int L, int scaleMode, const flo
     const int nw = (L + 63) / 64;
     if (fac_mitm_path()) {
       hipLaunchKernelGGL(fac_rows_k, dim3((unsigned)((T + kFacRowsPerWave * kFacRowsWaves - 1) / (kFacRowsPerWave * kFacRowsWaves)), (unsigned)B), dim3(64 * kFacRowsWaves), 0, s, T, N, input,
-                         trans, ws.crow, ws.zmax, ws.zspr);
+                         trans, ws.crow, ws.zmax, ws.zspr, (const int*)nullptr, 0, (int*)nullptr);
       W2L_LAUNCH_CHECK();
 #define W2L_FAC_M_GO(NWV) hipLaunchKernelGGL((fac_mitm_fwd<NWV>), dim3(B, fac_mitm_only() < 0 ? 2 : 1), dim3(64 * NWV), mitm_excl(B, (const void*)fac_mitm_fwd<NWV>), s, T, N, L, target, targetSize, trans, ws, fac_mitm_only() < 0 ? 0 : fac_mitm_only(), fac_mitm_abl())
       switch (nw) {
@@ -1287,6 +1322,86 @@ W2L_API int w2l_fac_backward(int B, int T, int N, int L, const int* target, cons
   }
   return W2L_OK;
 }
+
+// ---- the ASG criterion's fused sequence (criterion_asg_fused.hpp)
+namespace w2l {
+
+bool fac_asg_fused_ok(int B, int T, int N, int L) {
+  return B > 0 && T > 0 && L > 0 && fac_lin_path(N, L) && fac_mitm_path() && fac_mitm_only() < 0 && fac_use_partials(B, N);
+}
+
+int fac_forward_asg(int B, int T, int N, int L, int scaleMode, const float* input, const int* target, int* ts, const float* trans,
+                    float* loss2, float* minuend, void* workspace, hipStream_t s, AsgHook hook, void* arg) {
+  if (!fac_asg_fused_ok(B, T, N, L)) return W2L_EUNSUPPORTED;
+  if (!input || !target || !ts || !trans || !loss2 || !workspace) return W2L_EINVAL;
+  FacWs ws = fac_ws(workspace, B, T, N, L);
+  hipLaunchKernelGGL(fac_rows_k, dim3((unsigned)((T + kFacRowsPerWave * kFacRowsWaves - 1) / (kFacRowsPerWave * kFacRowsWaves)), (unsigned)B), dim3(64 * kFacRowsWaves), 0, s, T, N, input,
+                     trans, ws.crow, ws.zmax, ws.zspr, target, L, ts, ws.tgpart, (unsigned)((size_t)2 * B * N * N));
+  W2L_LAUNCH_CHECK();
+  if (hook) hook(arg, ASG_TARGET_SIZES_QUEUED);
+#define W2L_FAC_M_GO(NWV) hipLaunchKernelGGL((fac_mitm_fwd<NWV>), dim3(B, 2), dim3(64 * NWV), mitm_excl(B, (const void*)fac_mitm_fwd<NWV>), s, T, N, L, target, (const int*)ts, trans, ws, 0, 0)
+  switch ((L + 63) / 64) {
+    case 1: W2L_FAC_M_GO(1); break;
+    case 2: W2L_FAC_M_GO(2); break;
+    case 3: W2L_FAC_M_GO(3); break;
+    case 4: W2L_FAC_M_GO(4); break;
+    default: W2L_FAC_M_GO(5); break;
+  }
+#undef W2L_FAC_M_GO
+  W2L_LAUNCH_CHECK();
+  if (hook && minuend) hook(arg, ASG_NEED_FCC_LOSS);
+  hipLaunchKernelGGL(fac_mitm_finish_all, dim3(B), dim3(kFacFinishThreads), 0, s, T, N, L, scaleMode, input, target, (const int*)ts, trans, loss2, ws, minuend);
+  W2L_LAUNCH_CHECK();
+  return W2L_OK;
+}
+
+int fac_backward_asg(int B, int T, int N, int L, const int* target, const int* ts, const float* grad, float* dEm, float* dTrans,
+                     float* dx2, void* workspace, bool partialsClear, hipStream_t s, AsgHook hook, void* arg) {
+  if (!fac_asg_fused_ok(B, T, N, L)) return W2L_EUNSUPPORTED;
+  if (!target || !ts || !grad || !dEm || !dTrans || !dx2 || !workspace) return W2L_EINVAL;
+  FacWs ws = fac_ws(workspace, B, T, N, L);
+  const size_t n = (size_t)N * N;
+  // the transition-gradient partials: cleared by forward's label-row launch; a second backward pass on the same forward fills them here
+  if (!partialsClear) W2L_HIP_CHECK(hipMemsetAsync(ws.tgpart, 0, (size_t)2 * B * n * sizeof(float), s));
+#define W2L_FAC_M_GO(NWV) hipLaunchKernelGGL((fac_mitm_bwd<NWV>), dim3(B, 2), dim3(64 * NWV), mitm_excl(B, (const void*)fac_mitm_bwd<NWV>), s, T, N, L, target, ts, grad, dTrans, ws, 0, 1)
+  switch ((L + 63) / 64) {
+    case 1: W2L_FAC_M_GO(1); break;
+    case 2: W2L_FAC_M_GO(2); break;
+    case 3: W2L_FAC_M_GO(3); break;
+    case 4: W2L_FAC_M_GO(4); break;
+    default: W2L_FAC_M_GO(5); break;
+  }
+#undef W2L_FAC_M_GO
+  W2L_LAUNCH_CHECK();
+  {
+    const size_t shmem = (size_t)kScF * (L | 1) * sizeof(float) + (size_t)(L + N + 1) * sizeof(int);   // < 64 KiB at L <= 320
+    const dim3 grid((unsigned)((T + kScF - 1) / kScF), (unsigned)B);
+#define W2L_FAC_SC_GO(NPV) hipLaunchKernelGGL(fac_scatter_csr_k<NPV>, grid, dim3(256), shmem, s, T, N, L, ts, (const int*)ws.csr, (const float*)ws.dal, dx2)
+    switch ((L + 63) / 64) {
+      case 1: W2L_FAC_SC_GO(1); break;
+      case 2: W2L_FAC_SC_GO(2); break;
+      case 3: W2L_FAC_SC_GO(3); break;
+      case 4: W2L_FAC_SC_GO(4); break;
+      default: W2L_FAC_SC_GO(5); break;
+    }
+#undef W2L_FAC_SC_GO
+    W2L_LAUNCH_CHECK();
+  }
+  if (hook) hook(arg, ASG_NEED_FCC_GRADS);
+  {
+    const size_t tot = (size_t)B * T * N;
+    const unsigned redBlocks = (unsigned)((n + 255) / 256);
+    size_t axBlocks = ((tot >> 2) + 255) / 256;
+    if (axBlocks > 4096) axBlocks = 4096;
+    if (axBlocks < 1) axBlocks = 1;
+    hipLaunchKernelGGL(asg_bwd_combine_k, dim3(redBlocks + (unsigned)axBlocks), dim3(256), 0, s, 2 * B, (unsigned)n, (const float*)ws.tgpart, dTrans,
+                       dEm, (const float*)dx2, tot, redBlocks);
+    W2L_LAUNCH_CHECK();
+  }
+  return W2L_OK;
+}
+
+}  // namespace w2l
 
 W2L_API int w2l_fac_range_flags(int B, int T, int N, int L, const void* workspace, int* flags, w2l_stream_t stream) {
   if (B <= 0 || T <= 0 || N <= 0 || L <= 0 || !workspace || !flags) return W2L_EINVAL;

@@ -502,7 +502,24 @@ __device__ __forceinline__ float half_wave_max(float v) {
 // half the instructions per frame, 512-byte stores; the values are those of the one-frame-per-pass kernel bit for bit (a maximum
 // does not round).  21 -> 12 us at B = 64, T = 2000.
 __global__ __launch_bounds__(64 * kFacRowsWaves) static void fac_rows_k(int T, int N, const float* __restrict__ x, const float* __restrict__ trans,
-                                                 double* __restrict__ crow, float* __restrict__ zmax, float* __restrict__ zspr = nullptr) {
+                                                 double* __restrict__ crow, float* __restrict__ zmax, float* __restrict__ zspr = nullptr,
+                                                 const int* __restrict__ tsTarget = nullptr, int tsL = 0, int* __restrict__ tsOut = nullptr,
+                                                 float* __restrict__ zeroBuf = nullptr, unsigned zeroCount = 0) {
+  // (zeroBuf: the transition-gradient partials of the backward pass, cleared here -- backward starts without a fill launch)
+  if (zeroBuf) {
+    const unsigned stride = gridDim.x * gridDim.y * blockDim.x;
+    for (unsigned k = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; k < zeroCount; k += stride) zeroBuf[k] = 0.f;
+  }
+  // (tsOut: the ASG criterion's fused sequence -- the utterance's target size, batch_target_size_k's count of the labels in front of
+  //  the first negative one capped at T, by the first wave of the utterance's first block: no launch of its own in front of the scans)
+  if (tsOut && blockIdx.x == 0 && threadIdx.x < 64) {
+    const int* y = tsTarget + (size_t)blockIdx.y * tsL;
+    int first = tsL;
+    for (int i = (int)threadIdx.x; i < tsL; i += 64)
+      if (y[i] < 0) { first = i; break; }
+    for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off));
+    if (threadIdx.x == 0) tsOut[blockIdx.y] = first < T ? first : T;
+  }
   const int b = blockIdx.y, lane = threadIdx.x & 63, half = lane >> 5, n = lane & 31;
   const int t0 = (blockIdx.x * kFacRowsWaves + (threadIdx.x >> 6)) * kFacRowsPerWave;
   const float L2E = 1.44269504088896341f;

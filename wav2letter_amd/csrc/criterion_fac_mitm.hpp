@@ -177,9 +177,9 @@ __global__ __launch_bounds__(64 * NW) void fac_mitm_fwd(int T, int N, int L, con
 // Z, loss, the middle frame's posterior and the range check (see kFacPlinSafeBits); one workgroup per utterance: every wave sums a
 // share of the frame maxima / spreads (T loads from one wave were 32 dependent round trips: 16 us), wave 0 combines the records
 constexpr int kFacFinishThreads = 512;
-__global__ __launch_bounds__(kFacFinishThreads) void fac_mitm_finish(int T, int N, int L, int scaleMode, const int* __restrict__ target,
+__device__ __forceinline__ void fac_mitm_finish_body(int T, int N, int L, int scaleMode, const int* __restrict__ target,
                                                       const int* __restrict__ targetSize, const float* __restrict__ trans,
-                                                      float* __restrict__ loss, FacWs ws) {
+                                                      float* loss, const FacWs& ws) {
   __shared__ double sZs[kFacFinishThreads / 64];
   __shared__ float sSp[kFacFinishThreads / 64];
   const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -266,6 +266,11 @@ __global__ __launch_bounds__(kFacFinishThreads) void fac_mitm_finish(int T, int 
     // range check: beyond kFacPlinSafeBits the log-domain kernel behind this one recomputes the utterance (loss and every w1 row)
     ws.redo[b] = (spr + kb <= kFacPlinSafeBits) ? 0 : 1;
   }
+}
+__global__ __launch_bounds__(kFacFinishThreads) void fac_mitm_finish(int T, int N, int L, int scaleMode, const int* __restrict__ target,
+                                                      const int* __restrict__ targetSize, const float* __restrict__ trans,
+                                                      float* __restrict__ loss, FacWs ws) {
+  fac_mitm_finish_body(T, N, L, scaleMode, target, targetSize, trans, loss, ws);
 }
 
 // One half of the backward pass: UP = false: frames Ttop .. 0 (gamma_{t-1} from gamma_t, the leader is the wave above);
@@ -370,13 +375,55 @@ __device__ __forceinline__ void fac_half_bwd(int T, int N, int L, const int* __r
   }
 }
 
+// positions of an utterance sorted by label for fac_scatter_csr_k (criterion_fac.hip, where fac_csr_k is this body as a launch)
+__device__ __forceinline__ void fac_csr_body(int N, int L, const int* __restrict__ target, const int* __restrict__ targetSize,
+                                                int* __restrict__ csr) {
+  __shared__ int cnt[8][64];
+  __shared__ int offs[65];
+  const int b = blockIdx.x, i = threadIdx.x, lane = i & 63, wave = i >> 6;
+  const int nWaves = (int)(blockDim.x >> 6);   // 8 in fac_csr_k; ceil(L / 64) inside the backward scan launch (thread = position either way)
+  const int S = min(targetSize[b], L);
+  int* pos = csr + (size_t)b * (L + 68);
+  int* off = pos + L;
+  if (S <= 0) return;
+  const int yi = i < S ? target[(size_t)b * L + i] : -1;
+  const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+  int rank = 0;
+  for (int n = 0; n < N; ++n) {
+    const unsigned long long m = __ballot(yi == n);
+    if (lane == 0) cnt[wave][n] = __popcll(m);
+    if (yi == n) rank = __popcll(m & below);
+  }
+  __syncthreads();
+  if (i <= N) {   // off[n] = positions with a smaller label
+    int less = 0;
+    for (int n = 0; n < i; ++n)
+      for (int w = 0; w < nWaves; ++w) less += cnt[w][n];
+    offs[i] = less;
+    off[i] = less;
+  }
+  __syncthreads();
+  if (yi >= 0 && yi < N) {
+    int base = offs[yi];
+    for (int w = 0; w < wave; ++w) base += cnt[w][yi];
+    pos[base + rank] = i;
+  }
+}
+
+
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void fac_mitm_bwd(int T, int N, int L, const int* __restrict__ target,
                                                         const int* __restrict__ targetSize, const float* __restrict__ grad,
-                                                        float* __restrict__ transGrad, FacWs ws, int dir0 = 0) {
+                                                        float* __restrict__ transGrad, FacWs ws, int dir0 = 0, int csrInline = 0) {
   __shared__ float ring[NW][4 * kPlinChunk];
   __shared__ int prog[NW];
   const int b = blockIdx.x;
+  // csrInline (the fused ASG sequence): the utterance's upward block sorts the positions by label for the scatter launch behind this
+  // one before it starts its half (the shorter one) -- no fac_csr_k launch in front of the scans
+  if (csrInline && blockIdx.y + dir0 == 1) {
+    fac_csr_body(N, L, target, targetSize, ws.csr);
+    __syncthreads();
+  }
   if (targetSize[b] <= 0) return;   // the scatter kernel zero-fills this utterance's gradient
   if (threadIdx.x < NW) prog[threadIdx.x] = -1;
   __syncthreads();

@@ -173,8 +173,18 @@ __device__ __forceinline__ GSeg t160_segment(const SkPlan& p, int w, int workers
 // sums them (5 v_add per K step on the 1 / tilesM of the tiles that have bx == 0); TALL: every wave sums its own 32 columns.
 // A lane's sum runs over the k it holds (k = 8g + 4 (lane >> 5) + q) in ascending order, the two lane halves are added at the
 // end of the segment, the segments of a stream-K tile in range order by the tile's last arriver: run-to-run identical.
-template <bool AKC, bool BKC, bool TALL, bool CS = false>
+//
+// ADIR (WIDE tiles with a k-contiguous A: the forward and backward-data products): in the 128 x 160 layout a wave multiplies only
+// its OWN 32 rows of the A tile, so that operand's trip through LDS is private to the wave -- it is loaded straight into the
+// fragment registers instead (four buffer_load_dwordx4 per K tile and wave: lane (li, lh) takes the 16 bytes at k = 8g + 4 lh of
+// row 32 wave + li, the k-slot assignment of t160_frag), double-buffered in registers one K tile ahead.  The LDS-DMA stream of a K
+// tile shrinks from 9 to 5 pieces per wave, the four ds_read_b128 of the A fragments go away, and the sum order is unchanged
+// (bit-identical results).  MEASURED (profiles/r06_run53_gemm_adir_ab.log): level with the all-LDS loop on every shape of the step
+// (84.52 / 84.55 ms step-weighted, twice) -- the operand stream costs what it costs whichever path its bytes take into the CU
+// (DESIGN section 3.5), so the loop stays off in the product; W2L_GEMM_ADIR=1 (probe library) runs it, and a parity test holds it.
+template <bool AKC, bool BKC, bool TALL, bool CS = false, bool ADIR = false>
 __global__ __launch_bounds__(256, 2) void gemm160_kernel(GOp aop, GOp bop, GemmOut out, SkPlan plan, int workers) {
+  static_assert(!ADIR || (AKC && !TALL && !CS), "A-direct: k-contiguous A on the 128 x 160 tile");
   constexpr int BM = TALL ? 160 : 128, BN = TALL ? 128 : 160;
   constexpr int MI = TALL ? 5 : 1, NJ = TALL ? 1 : 5;
   constexpr int PA = BM / 32, PB = BN / 32;  // LDS-DMA pieces per wave and K tile
@@ -196,13 +206,29 @@ __global__ __launch_bounds__(256, 2) void gemm160_kernel(GOp aop, GOp bop, GemmO
   uint32_t va[PA], vb[PB];
   int bx, by;
   sk_tile_xy(plan, seg.tile, bx, by);
+  // ADIR: byte offset of this lane's row of the A tile (+ its half's four k); the row is clamped like a piece's
+  auto adir_off = [&](int m0) {
+    int gi = m0 + wm + li;
+    if (gi > aop.extent - 1) gi = aop.extent - 1;
+    return ((uint32_t)gi * (uint32_t)aop.ld + 4u * (uint32_t)lh) * 4u;
+  };
+  uint32_t vaD = 0;
+  u32x4 aCur[4], aNxt[4];
+  if (ADIR) {
+    vaD = adir_off(bx * BM);
 #pragma unroll
-  for (int j = 0; j < PA; ++j) va[j] = t160_off<AKC, BM>(aop, bx * BM, wave * PA + j, lane);
+    for (int g = 0; g < 4; ++g) aCur[g] = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(vaD + 32u * g), (int)(aStepB * seg.kb), 0);
+  } else {
+#pragma unroll
+    for (int j = 0; j < PA; ++j) va[j] = t160_off<AKC, BM>(aop, bx * BM, wave * PA + j, lane);
+  }
 #pragma unroll
   for (int j = 0; j < PB; ++j) vb[j] = t160_off<BKC, BN>(bop, by * BN, wave * PB + j, lane);
+  if (!ADIR) {
 #pragma unroll
-  for (int j = 0; j < PA; ++j)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(smem + (wave * PA + j) * 256), 16, (int)va[j], (int)(aStepB * seg.kb), 0, 0);
+    for (int j = 0; j < PA; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(smem + (wave * PA + j) * 256), 16, (int)va[j], (int)(aStepB * seg.kb), 0, 0);
+  }
 #pragma unroll
   for (int j = 0; j < PB; ++j)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)(smem + BM * 32 + (wave * PB + j) * 256), 16, (int)vb[j], (int)(bStepB * seg.kb), 0, 0);
@@ -256,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void gemm160_kernel(GOp aop, GOp bop, GemmO
       float* An = smem + (stage ^ 1) * kT160StageFloats;
       float* Bn = An + BM * 32;
       float fa[2][MI][4], fb[2][NJ][4];
-      t160_frag<AKC, BM, MI>(fa[0], As, wm, 0, li, lh);
+      if (!ADIR) t160_frag<AKC, BM, MI>(fa[0], As, wm, 0, li, lh);
       t160_frag<BKC, BN, NJ>(fb[0], Bs, wn, 0, li, lh);
       // What goes to the other stage during this iteration: the next K tile, or the first K tile of the next
       // segment, or (very last iteration of this worker) a harmless re-load of this tile.
@@ -266,8 +292,11 @@ __global__ __launch_bounds__(256, 2) void gemm160_kernel(GOp aop, GOp bop, GemmO
       } else if (nxt.valid) {
         int nbx, nby;
         sk_tile_xy(plan, nxt.tile, nbx, nby);
+        if (ADIR) vaD = adir_off(nbx * BM);
+        else {
 #pragma unroll
-        for (int j = 0; j < PA; ++j) va[j] = t160_off<AKC, BM>(aop, nbx * BM, wave * PA + j, lane);
+          for (int j = 0; j < PA; ++j) va[j] = t160_off<AKC, BM>(aop, nbx * BM, wave * PA + j, lane);
+        }
 #pragma unroll
         for (int j = 0; j < PB; ++j) vb[j] = t160_off<BKC, BN>(bop, nby * BN, wave * PB + j, lane);
         soA = aStepB * (uint32_t)nxt.kb; soB = bStepB * (uint32_t)nxt.kb;
@@ -285,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void gemm160_kernel(GOp aop, GOp bop, GemmO
           for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-              acc[i * NJ + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][q], fb[cur][j][q], acc[i * NJ + j], 0, 0, 0);
+              acc[i * NJ + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ADIR ? __uint_as_float(aCur[g][q]) : fa[cur][i][q], fb[cur][j][q], acc[i * NJ + j], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           if (QS == 4 || QS == q) {
 #pragma unroll
@@ -293,14 +322,15 @@ __global__ __launch_bounds__(256, 2) void gemm160_kernel(GOp aop, GOp bop, GemmO
           }
           if (q == 0) {
             if (g < 3) {
-              t160_frag<AKC, BM, MI>(fa[cur ^ 1], As, wm, g + 1, li, lh);
+              if (!ADIR) t160_frag<AKC, BM, MI>(fa[cur ^ 1], As, wm, g + 1, li, lh);
               t160_frag<BKC, BN, NJ>(fb[cur ^ 1], Bs, wn, g + 1, li, lh);
             }
           } else {
             const int piece = 3 * g + q - 1;  // steps 1,2,3,5,6,7,9,10,11 -> pieces 0..8
-            if (piece < PA)
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(An + (wave * PA + piece) * 256), 16, (int)va[piece], (int)soA, 0, 0);
-            else if (piece < PA + PB)
+            if (piece < PA) {
+              if (ADIR) aNxt[piece] = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(vaD + 32u * piece), (int)soA, 0);
+              else __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(An + (wave * PA + piece) * 256), 16, (int)va[piece], (int)soA, 0, 0);
+            } else if (piece < PA + PB)
               __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)(Bn + (wave * PB + piece - PA) * 256), 16, (int)vb[piece - PA], (int)soB, 0, 0);
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -308,6 +338,10 @@ __global__ __launch_bounds__(256, 2) void gemm160_kernel(GOp aop, GOp bop, GemmO
       }
       stage ^= 1;
       __syncthreads();  // the stage just filled has landed (vmcnt(0)) and is visible to all waves
+      if (ADIR) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) aCur[g] = aNxt[g];
+      }
     }
     };
     if (!csTile) kloop(std::integral_constant<int, -1>{});
@@ -420,6 +454,13 @@ inline bool t160_ksplit_enabled() {
   return e && atoi(e) != 0;
 }
 
+// A-direct K loop (gemm160_kernel<..., ADIR>) for the 128 x 160 products with a k-contiguous A: W2L_GEMM_ADIR=1 (probe library)
+constexpr int kT160AdirDefault = 0;   // measured level with the all-LDS loop (profiles/r06_run53_gemm_adir_ab.log): kept as a probe variant
+inline bool t160_adir_enabled() {
+  const char* e = tune_env("W2L_GEMM_ADIR");   // read per call (the variant test flips it)
+  return (e ? atoi(e) : kT160AdirDefault) != 0;
+}
+
 // 0 = not eligible / not worth it, 1 = WIDE (128x160), 2 = TALL (160x128): the variant whose padded tile area is
 // smallest, if it saves at least 2 % of the 128x128 grid's padded area.  W2L_GEMM_T160: 0 = never, 2 = whenever eligible.
 inline int t160_choice(const GOp& a, const GOp& b, const GemmOut& o) {
@@ -492,6 +533,8 @@ inline int launch160(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o, 
     W2L_T160_ATTR(true, true, true); W2L_T160_ATTR(true, false, true); W2L_T160_ATTR(false, true, true); W2L_T160_ATTR(false, false, true);
     (void)hipFuncSetAttribute((const void*)gemm160_kernel<false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     (void)hipFuncSetAttribute((const void*)gemm160_kernel<false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    (void)hipFuncSetAttribute((const void*)gemm160_kernel<true, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    (void)hipFuncSetAttribute((const void*)gemm160_kernel<true, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
 #undef W2L_T160_ATTR
   }
   prof_begin(s, 2.0 * o.M * (double)o.N * o.K, PROF_GEMM128, o.M, o.N, o.K, tall ? 4 : 3);
@@ -500,6 +543,9 @@ inline int launch160(const GOp& a, bool akc, const GOp& b, bool bkc, GemmOut o, 
     if (!tall) hipLaunchKernelGGL((gemm160_kernel<false, false, false, true>), grid, block, shmem, s, a, b, o, plan, workers);
     else hipLaunchKernelGGL((gemm160_kernel<false, false, true, true>), grid, block, shmem, s, a, b, o, plan, workers);
     if (csDone) *csDone = true;
+  } else if (!tall && akc && t160_adir_enabled()) {
+    if (bkc) hipLaunchKernelGGL((gemm160_kernel<true, true, false, false, true>), grid, block, shmem, s, a, b, o, plan, workers);
+    else hipLaunchKernelGGL((gemm160_kernel<true, false, false, false, true>), grid, block, shmem, s, a, b, o, plan, workers);
   } else if (!tall) {
     if (akc && bkc) W2L_T160_GO(true, true, false);
     else if (akc) W2L_T160_GO(true, false, false);
