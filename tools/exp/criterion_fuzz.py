@@ -46,7 +46,14 @@ def run(cases, seed, x_scales=(0.1, 1.0, 5.0, 20.0, 50.0), a_scales=(0.0, 0.3, 2
         ts = O.batch_target_size(tgt, T)
         w = rng.uniform(0.5, 1.5, size=B)
         line = f"case {c:3d} B={B} T={T:4d} N={N:3d} L<={Lmax:3d} x*{xs:<4} A*{as_:<4} diag {diag} mode {mode}:"
-        for name, cls, orc in (("FCC", FullConnectionCriterion, lambda: O.FCC(x, A, ts, mode)), ("FAC", ForceAlignmentCriterion, lambda: O.FAC(x, A, tgt, scale_mode=mode))):
+        class _AsgOracle:   # FCC - FAC on the same transitions (oracle/pyoracle.py::asg)
+            def forward(self):
+                self.r = O.asg(x, A, tgt, mode, w)
+                return self.r[0]
+            def backward(self, _w):
+                return self.r[1], self.r[2]
+        for name, cls, orc in (("FCC", FullConnectionCriterion, lambda: O.FCC(x, A, ts, mode)), ("FAC", ForceAlignmentCriterion, lambda: O.FAC(x, A, tgt, scale_mode=mode)),
+                               ("ASG", lambda n_, m_: ASGLoss(n_, m_, 0.0), _AsgOracle)):   # ASGLoss: w2l_asg_forward / w2l_asg_backward (N <= 31: the fused sequence)
             crit = cls(N, mode).cuda()
             crit.transitions.data = torch.from_numpy(A).cuda()
             xt = torch.from_numpy(x).cuda().requires_grad_(True)

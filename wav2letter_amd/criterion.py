@@ -133,6 +133,42 @@ class _FAC(torch.autograd.Function):
         return dx, dt, None, None, None
 
 
+class _ASG(torch.autograd.Function):
+    """ASGLoss = FullConnectionCriterion - ForceAlignmentCriterion in one call each way (w2l_asg_forward / w2l_asg_backward: the two
+    criteria side by side on the current stream and a library-owned side stream, the launch sequence of the C++ criterion)"""
+
+    @staticmethod
+    def forward(ctx, emission, trans, target, scale_mode):
+        L = _lib.lib()
+        emission = emission.contiguous()
+        trans = trans.contiguous()
+        target = target.contiguous()
+        B, T, N = emission.shape
+        Lt = target.shape[1]
+        nbytes = L.w2l_asg_workspace_size(B, T, N, Lt)
+        if not nbytes:
+            raise _lib.W2LError("w2l_asg_workspace_size: unsupported shape")
+        ws = _ws(nbytes, emission.device)
+        loss = torch.empty(B, dtype=torch.float32, device=emission.device)
+        _lib.check(L.w2l_asg_forward(B, T, N, Lt, int(scale_mode), emission.data_ptr(), target.data_ptr(), trans.data_ptr(),
+                                     loss.data_ptr(), ws.data_ptr(), _stream()), "asg_forward")
+        ctx.save_for_backward(target, trans, ws)
+        ctx.dims = (B, T, N, Lt)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad):
+        L = _lib.lib()
+        target, trans, ws = ctx.saved_tensors
+        B, T, N, Lt = ctx.dims
+        grad = grad.contiguous().float()
+        dx = torch.empty(B, T, N, dtype=torch.float32, device=grad.device)
+        dt = torch.empty(N, N, dtype=torch.float32, device=grad.device)
+        _lib.check(L.w2l_asg_backward(B, T, N, Lt, target.data_ptr(), trans.data_ptr(), grad.data_ptr(), dx.data_ptr(), dt.data_ptr(),
+                                      ws.data_ptr(), _stream()), "asg_backward")
+        return dx, dt, None, None
+
+
 def fcc_range_flags():
     """int32 [B]: 1 where an utterance of the LAST FullConnectionCriterion forward left the range of the fp32 scaled-domain scan and
     was recomputed by the log-domain kernels (w2l_fcc_range_flags); results are exact either way"""
@@ -284,27 +320,15 @@ class ASGLoss(SequenceCriterion):
         self._side = None
 
     def forward(self, emission, target):
-        # FCC and FAC are independent length-T serial scans that use B of the 256 CUs each: run them side by side
-        # (FAC on a side stream).  autograd replays each node's backward on its forward stream, so the two backward
-        # scans overlap too.
+        # FCC and FAC are independent length-T serial scans that use B of the 256 CUs each: w2l_asg_forward / w2l_asg_backward run
+        # them side by side (one call each way: the C++ criterion's launch sequence, fused for the letter-sized label sets)
         if not emission.is_cuda:
             return self.fcc(emission, target) - self.fac(emission, target)  # raises the reference's error
         _emission_checks(emission, target)
         _check_dev(emission, target)
         if emission.shape[2] != self.N:
             raise _lib.W2LInvalidArgument("ASGLoss: N doesn't match with the letter size")
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=emission.device)
-        cur = torch.cuda.current_stream(emission.device)
-        ts = batch_target_size(target, emission.shape[1])   # once, shared by both criteria (before the fork)
-        self._side.wait_stream(cur)
-        with torch.cuda.stream(self._side):
-            fac = _FAC.apply(emission, self.transitions, target, ts, self.scalemode)
-        fcc = _FCC.apply(emission, self.transitions, ts, self.scalemode)
-        cur.wait_stream(self._side)
-        fac.record_stream(cur)
-        ts.record_stream(self._side)
-        return fcc - fac
+        return _ASG.apply(emission, self.transitions, target, self.scalemode)
 
     def viterbiPath(self, emission, inputSize=None):
         _emission_checks(emission)

@@ -1,17 +1,19 @@
-// criterion_asg_fused.hpp -- the ASG criterion's fused launch sequence for small label sets (N <= 31, L <= 320: the letter recipes),
-// internal to libw2l_hip.so: criterion_host.cpp (fl::pkg::speech::ASGLoss = FullConnectionCriterion - ForceAlignmentCriterion,
-// recipes/slimIPL/src/Train.cpp:408-410, :1675) drives it, criterion_fac.hip / criterion_fcc.hip implement it.  The C-ABI entry
-// points (w2l_fac_forward / w2l_fac_backward / w2l_fcc_backward, include/w2l_hip.h) keep their one-criterion-one-call meaning; what
-// this sequence removes are the launches that exist only because ASG composes two such calls:
+// criterion_asg_fused.hpp -- the ASG criterion's fused launch sequence for small label sets (N <= 32, L <= 320: the letter recipes),
+// internal to libw2l_hip.so: criterion_host.cpp (AsgSequence: fl::pkg::speech::ASGLoss = FullConnectionCriterion -
+// ForceAlignmentCriterion, recipes/slimIPL/src/Train.cpp:408-410, :1675; also behind w2l_asg_forward / w2l_asg_backward) drives it,
+// criterion_fac.hip implements it.  The C-ABI entry points of the single criteria (w2l_fac_forward / w2l_fac_backward / w2l_fcc_*,
+// include/w2l_hip.h) keep their one-criterion-one-call meaning; what this sequence removes are the launches that exist only because
+// ASG composes two such calls:
 //   forward   batch_target_size (rides on the label-row pre-pass), the flagged-utterance launch (folded into the finish launch),
 //             the loss axpy (the finish launch subtracts from FullConnectionCriterion's loss);
 //   backward  the sort of the positions by label (inside the backward scan launch, in front of its shorter half), the clearing of
-//             the transition-gradient partials (by forward's label-row launch); the partials'
-//             reduce and the two axpy launches are ONE launch behind the join.
+//             the transition-gradient partials (by forward's label-row launch); the partials' reduce and the two axpy launches are
+//             ONE launch behind the join.
 //             (Measured and dropped: the scatter subtracting in place from FullConnectionCriterion's input gradient -- at N = 30
 //             that criterion's backward scan is the LONGER one, 170 against 152 us, and a wait on another stream's event costs the
 //             waiting stream ~7 - 13 us: profiles/r06_run56_asg_timelines.txt.)
-// Results are bit-identical to the composed calls (the same operations on the same operands in the same order).
+// Results are bit-identical to the composed calls (the same operations on the same operands in the same order).  At B = 64,
+// T = 2000, N = 30, L <= 300: forward 0.239 -> 0.2245 ms, forward + backward 0.479 -> 0.460 ms (profiles/r06_run59_*).
 #pragma once
 #include <hip/hip_runtime.h>
 
