@@ -172,6 +172,13 @@ inline unsigned exclusive_cu_lds(int B) {
   return (!off && 4 * B <= 256) ? kExclusiveLdsBytes : 0u;
 }
 
+// dynamic LDS request that gives a scan workgroup a CU of its own (exclusive_cu_lds), with the > 64 KiB opt-in of the function
+inline unsigned mitm_excl(int B, const void* fn) {
+  const unsigned bytes = exclusive_cu_lds(B);
+  if (bytes) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return bytes;
+}
+
 // ---- stateless dropout hash: must stay bit-identical to oracle/nn_oracle.c --
 __host__ __device__ inline uint32_t hash32(uint32_t idx, uint32_t seed, uint32_t stream) {
   uint32_t h = idx * 0x9E3779B1u + seed;

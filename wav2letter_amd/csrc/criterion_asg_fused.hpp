@@ -37,4 +37,11 @@ int fac_forward_asg(int B, int T, int N, int L, int scaleMode, const float* inpu
 int fac_backward_asg(int B, int T, int N, int L, const int* target, const int* ts, const float* grad, float* dEm, float* dTrans,
                      float* dx2, void* workspace, bool partialsClear, hipStream_t s, AsgHook hook, void* arg);
 
+// One-launch forward pass (criterion_asg.hip): label rows (+ target sizes, + partials fill) -> the four half scans of the two criteria
+// in ONE launch -> both finishes and the difference in one launch; no side stream.  ok: the fused sequence's conditions and
+// FullConnectionCriterion on its meet-in-the-middle scans (N <= 31) with a CU per scan workgroup (4 B <= 256).
+bool asg_forward_merged_ok(int B, int T, int N, int L);
+int asg_forward_merged(int B, int T, int N, int L, int scaleMode, const float* input, const int* target, int* ts, const float* trans,
+                       float* loss, float* loss2, void* fccWorkspace, void* facWorkspace, hipStream_t s);
+
 }  // namespace w2l

@@ -56,13 +56,14 @@ __device__ __forceinline__ MitmRows mitm_rows(int lane, const DppGeom& g, int N,
 #define W2L_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // ------------------------------------------------------------------------------------------------ forward: the two halves
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) void fcc_mitm_fwd(int T, int N, const float* __restrict__ x, const float* __restrict__ trans, FccWs ws,
-                                                    int dir0 = 0 /* probe: time one half alone (grid (B, 1)) */) {
+// (the body is also a role of the one-launch forward pass of the ASG criterion, asg_mitm_fwd in criterion_asg.hip: `dir` = which half,
+//  threads 0 .. 127 of the workgroup)
+__device__ __forceinline__ void fcc_mitm_fwd_body(int T, int N, const float* __restrict__ x, const float* __restrict__ trans, const FccWs& ws, int dir) {
   __shared__ float sP[2][kDppChunk][64];
   __shared__ float sU[2][kDppChunk][2][64];   // chain -> helper: [0] = u_t (alpha) / r_t = b_t q'_t (beta), [1] = the frame's scale q
   __shared__ double sC2;
   __shared__ float sRm[32];
-  const int b = blockIdx.x, dir = blockIdx.y + dir0, tid = threadIdx.x, lane = tid & 63;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const bool chain = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
   const DppGeom g = dpp_geom(lane);
   const float NEG = -INFINITY;
@@ -352,6 +353,11 @@ __device__ __forceinline__ void fcc_mitm_finish(int b, int lane, int T, int N, i
     ws.scale[b] = sc;
     ws.ginv[b] = 1.f / G;
   }
+}
+
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) void fcc_mitm_fwd(int T, int N, const float* __restrict__ x, const float* __restrict__ trans, FccWs ws,
+                                                    int dir0 = 0 /* probe: time one half alone (grid (B, 1)) */) {
+  fcc_mitm_fwd_body(T, N, x, trans, ws, (int)blockIdx.y + dir0);
 }
 
 // ------------------------------------------------------------------------------------------------ backward: the two continuations

@@ -844,13 +844,13 @@ template <int NP>   // NP = ceil(L / 64): row segments per lane
 __global__ __launch_bounds__(256) void fac_scatter_csr_k(int T, int N, int L, const int* __restrict__ targetSize,
                                                         const int* __restrict__ csr, const float* __restrict__ dal,
                                                         float* __restrict__ dx) {
-  extern __shared__ float sm[];
+  extern __shared__ float smSc[];
   const int b = blockIdx.y, t0 = blockIdx.x * kScF, tid = threadIdx.x;
   const int tc = min(kScF, T - t0);
   const int S = min(targetSize[b], L);
   const int Lp = L | 1;                      // odd row pitch: the frame index does not pick the bank
-  float* tile = sm;                          // [kScF][Lp]
-  int* pos = (int*)(sm + kScF * Lp);         // [L] positions sorted by label
+  float* tile = smSc;                          // [kScF][Lp]
+  int* pos = (int*)(smSc + kScF * Lp);         // [L] positions sorted by label
   int* off = pos + L;                        // [N + 1]
   float* out = dx + ((size_t)b * T + t0) * N;
   if (S <= 0) {
@@ -1021,12 +1021,6 @@ __global__ __launch_bounds__(64) void fac_vit(int T, int N, int L, const float* 
 
 using namespace w2l;
 
-// dynamic LDS request that gives a scan workgroup a CU of its own (exclusive_cu_lds), with the > 64 KiB opt-in of the function
-static unsigned mitm_excl(int B, const void* fn) {
-  const unsigned bytes = exclusive_cu_lds(B);
-  if (bytes) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  return bytes;
-}
 
 W2L_API size_t w2l_fac_workspace_size(int B, int T, int N, int L) {
   if (B <= 0 || T <= 0 || N <= 0 || L <= 0) return 0;

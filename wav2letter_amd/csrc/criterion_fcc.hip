@@ -287,9 +287,9 @@ __global__ __launch_bounds__(64) void fcc_bwd_small(int T, int N, const float* _
 // One wave per flagged utterance, lane = state, N <= NP (32 or 64); `ahat` and `logs` (= L_t) keep the workspace meaning of the
 // other kernels.  NP = 64 (round 6): the fallback of the 32-64-label scans fcc_*_small<64>, which flag what they cannot hold.
 template <int NP, bool MITM = false>
-__global__ __launch_bounds__(64) void fcc_fwd_log(int T, int N, int scaleMode, const float* __restrict__ x,
-                                                  const int* __restrict__ targetSize, const float* __restrict__ trans,
-                                                  float* __restrict__ loss, FccWs ws) {
+__device__ __forceinline__ void fcc_fwd_log_body(int T, int N, int scaleMode, const float* __restrict__ x,
+                                                 const int* __restrict__ targetSize, const float* __restrict__ trans,
+                                                 float* loss, const FccWs& ws) {
   const int b = blockIdx.x, lane = threadIdx.x;
   if (!ws.redo[b]) {
     if (MITM) fcc_mitm_finish(b, lane, T, N, scaleMode, targetSize, loss, ws);   // loss of the two linear-domain halves
@@ -355,6 +355,12 @@ __global__ __launch_bounds__(64) void fcc_fwd_log(int T, int N, int scaleMode, c
     loss[b] = (float)((double)sc * (C + (double)__logf(tot)));
     ws.scale[b] = sc;
   }
+}
+template <int NP, bool MITM = false>
+__global__ __launch_bounds__(64) void fcc_fwd_log(int T, int N, int scaleMode, const float* __restrict__ x,
+                                                  const int* __restrict__ targetSize, const float* __restrict__ trans,
+                                                  float* __restrict__ loss, FccWs ws) {
+  fcc_fwd_log_body<NP, MITM>(T, N, scaleMode, x, targetSize, trans, loss, ws);
 }
 
 template <int NP>
@@ -705,12 +711,6 @@ const int* fcc_big_range_flags(int B, int T, int N, const void* workspace);
 
 using namespace w2l;
 
-// dynamic LDS request that gives a scan workgroup a CU of its own (exclusive_cu_lds), with the > 64 KiB opt-in of the function
-static unsigned mitm_excl(int B, const void* fn) {
-  const unsigned bytes = exclusive_cu_lds(B);
-  if (bytes) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  return bytes;
-}
 
 W2L_API size_t w2l_fcc_workspace_size(int B, int T, int N) {
   if (B <= 0 || T <= 0 || N <= 0) return 0;

@@ -63,6 +63,11 @@ class AsgSequence {
   void forward(hipStream_t main, int B, int T, int N, int L, int mode, const float* em, const int* target, float* trans, float* loss,
                const AsgBuffers& w) {
     init();
+    if (asg_forward_merged_ok(B, T, N, L)) {   // the four half scans of the pass in one launch: no side stream, no events
+      w2lCheck(asg_forward_merged(B, T, N, L, mode, em, target, w.ts, trans, loss, w.loss2, w.fcc, w.fac, main), "asg forward");
+      clearWs_ = w.fac;
+      return;
+    }
     if (fac_asg_fused_ok(B, T, N, L)) {
       FwdHook h{this, main, B, T, N, L, mode, em, target, trans, loss, &w};
       w2lCheck(fac_forward_asg(B, T, N, L, mode, em, target, w.ts, trans, w.loss2, loss, w.fac, main, fwdHook, &h), "asg forward");
