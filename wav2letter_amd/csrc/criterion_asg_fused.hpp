@@ -13,7 +13,8 @@
 //             that criterion's backward scan is the LONGER one, 170 against 152 us, and a wait on another stream's event costs the
 //             waiting stream ~7 - 13 us: profiles/r06_run56_asg_timelines.txt.)
 // Results are bit-identical to the composed calls (the same operations on the same operands in the same order).  At B = 64,
-// T = 2000, N = 30, L <= 300: forward 0.239 -> 0.2245 ms, forward + backward 0.479 -> 0.460 ms (profiles/r06_run59_*).
+// T = 2000, N = 30, L <= 300: forward 0.239 -> 0.2245 ms, forward + backward 0.479 -> 0.460 ms (profiles/r06_run59_*); with the
+// one-launch forward pass at the end of this file (criterion_asg.hip) 0.211 / 0.449 ms (profiles/r06_run65_*).
 #pragma once
 #include <hip/hip_runtime.h>
 
