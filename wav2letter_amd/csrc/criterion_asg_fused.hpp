@@ -24,7 +24,7 @@ namespace w2l {
 enum AsgHookPoint {
   ASG_TARGET_SIZES_QUEUED = 0,   // forward: the launch that writes ts is on `s` -- fork FullConnectionCriterion's stream here
   ASG_NEED_FCC_LOSS = 1,         // forward: the next launch subtracts from FullConnectionCriterion's loss
-  ASG_NEED_FCC_GRADS = 2,        // backward: the next launch subtracts from FullConnectionCriterion's two gradients
+  ASG_NEED_FCC_GRADS = 2,        // backward: the next launch (on sOut) combines the two criteria's gradients: both streams joined
 };
 typedef void (*AsgHook)(void* arg, int what);
 
@@ -34,9 +34,16 @@ bool fac_asg_fused_ok(int B, int T, int N, int L);
 int fac_forward_asg(int B, int T, int N, int L, int scaleMode, const float* input, const int* target, int* ts, const float* trans,
                     float* loss2, float* minuend, void* workspace, hipStream_t s, AsgHook hook, void* arg);
 // backward: dEm -= input gradient (through the scratch dx2 [B][T][N]), dTrans -= transition gradient, in one launch behind the
-// hook; partialsClear: no backward pass has run on this workspace since fac_forward_asg cleared the transition-gradient partials
+// hook; partialsClear: no backward pass has run on this workspace since fac_forward_asg cleared the transition-gradient partials;
+// fccPart (may be null): FullConnectionCriterion's per-utterance partials [b * fccStride][N][N] (fcc_backward_impl, partialsOnly) --
+// the launch then also sums those over the utterances instead of reading that criterion's finished transition gradient from dTrans
 int fac_backward_asg(int B, int T, int N, int L, const int* target, const int* ts, const float* grad, float* dEm, float* dTrans,
-                     float* dx2, void* workspace, bool partialsClear, hipStream_t s, AsgHook hook, void* arg);
+                     float* dx2, void* workspace, bool partialsClear, const float* fccPart, int fccStride, hipStream_t s, hipStream_t sOut,
+                     AsgHook hook, void* arg);   // scan + scatter on `s`, the combine launch (behind the hook) on `sOut`
+// w2l_fcc_backward; partialsOnly: without its last launch (the sum of the transition-gradient partials over the utterances)
+int fcc_backward_impl(int B, int T, int N, const float* trans, const float* grad, float* inputGrad, float* transGrad, void* workspace,
+                      hipStream_t stream, bool partialsOnly);
+const float* fcc_transgrad_partials(void* workspace, int B, int T, int N, int* stride);   // null: N > 64 (no such partials)
 
 // One-launch forward pass (criterion_asg.hip): label rows (+ target sizes, + partials fill) -> the four half scans of the two criteria
 // in ONE launch -> both finishes and the difference in one launch; no side stream.  ok: the fused sequence's conditions and

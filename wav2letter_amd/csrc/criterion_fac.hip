@@ -915,11 +915,27 @@ __global__ void reduce_over_b_fac(int B, size_t n, const float* __restrict__ par
 // the join of the two streams instead of a reduce in front of it and two axpy behind it.
 constexpr int kAsgCombineReduceThreads = 256;
 __global__ __launch_bounds__(256) void asg_bwd_combine_k(int parts, unsigned nn, const float* __restrict__ part, float* __restrict__ dTrans,
-                                                         float* __restrict__ dEm, const float* __restrict__ dx2, size_t n, unsigned redBlocks) {
+                                                         float* __restrict__ dEm, const float* __restrict__ dx2, size_t n, unsigned redBlocks,
+                                                         const float* __restrict__ fccPart = nullptr, int fccB = 0, int fccStride = 0) {
   if (blockIdx.x < redBlocks) {
     const unsigned k = blockIdx.x * 256u + threadIdx.x;
     if (k >= nn) return;
-    const float prev = dTrans[k];
+    float prev;
+    if (fccPart) {   // FullConnectionCriterion's sum over the utterances, in reduce_over_b's order (criterion_fcc.hip)
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int b = 0;
+      for (; b + 7 < fccB; b += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = fccPart[(size_t)(b + u) * fccStride * nn + k];
+        s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
+        s0 += v[4]; s1 += v[5]; s2 += v[6]; s3 += v[7];
+      }
+      for (; b < fccB; ++b) s0 += fccPart[(size_t)b * fccStride * nn + k];
+      prev = (s0 + s1) + (s2 + s3);
+    } else {
+      prev = dTrans[k];
+    }
     float s = 0.f;
     int b = 0;
     for (; b + 7 < parts; b += 8) {   // (reduce_over_b_fac's order)
@@ -1350,7 +1366,8 @@ int fac_forward_asg(int B, int T, int N, int L, int scaleMode, const float* inpu
 }
 
 int fac_backward_asg(int B, int T, int N, int L, const int* target, const int* ts, const float* grad, float* dEm, float* dTrans,
-                     float* dx2, void* workspace, bool partialsClear, hipStream_t s, AsgHook hook, void* arg) {
+                     float* dx2, void* workspace, bool partialsClear, const float* fccPart, int fccStride, hipStream_t s, hipStream_t sOut,
+                     AsgHook hook, void* arg) {
   if (!fac_asg_fused_ok(B, T, N, L)) return W2L_EUNSUPPORTED;
   if (!target || !ts || !grad || !dEm || !dTrans || !dx2 || !workspace) return W2L_EINVAL;
   FacWs ws = fac_ws(workspace, B, T, N, L);
@@ -1388,8 +1405,8 @@ int fac_backward_asg(int B, int T, int N, int L, const int* target, const int* t
     size_t axBlocks = ((tot >> 2) + 255) / 256;
     if (axBlocks > 4096) axBlocks = 4096;
     if (axBlocks < 1) axBlocks = 1;
-    hipLaunchKernelGGL(asg_bwd_combine_k, dim3(redBlocks + (unsigned)axBlocks), dim3(256), 0, s, 2 * B, (unsigned)n, (const float*)ws.tgpart, dTrans,
-                       dEm, (const float*)dx2, tot, redBlocks);
+    hipLaunchKernelGGL(asg_bwd_combine_k, dim3(redBlocks + (unsigned)axBlocks), dim3(256), 0, sOut, 2 * B, (unsigned)n, (const float*)ws.tgpart, dTrans,
+                       dEm, (const float*)dx2, tot, redBlocks, fccPart, B, fccStride);
     W2L_LAUNCH_CHECK();
   }
   return W2L_OK;

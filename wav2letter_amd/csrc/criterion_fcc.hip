@@ -19,6 +19,7 @@
 // then needs neither the emissions nor any exp-domain re-summation:
 //   w_ij = EA[i][j] e_j / s_i.
 #include "common.hpp"
+#include "criterion_asg_fused.hpp"
 
 namespace w2l {
 
@@ -764,6 +765,14 @@ W2L_API int w2l_fcc_forward(int B, int T, int N, int scaleMode, const float* inp
 W2L_API int w2l_fcc_backward(int B, int T, int N, const float* trans, const float* grad,
                              float* inputGrad, float* transGrad, void* workspace,
                              w2l_stream_t stream) {
+  return w2l::fcc_backward_impl(B, T, N, trans, grad, inputGrad, transGrad, workspace, (hipStream_t)stream, false);
+}
+
+// partialsOnly (the ASG criterion's fused backward sequence, N <= 64): the per-utterance transition-gradient partials stay in the
+// workspace ([B][kDtChunks][N][N], chunk 0 of every utterance reduced over its chunks) and the caller's combine launch sums them
+// over the utterances in reduce_over_b's order (asg_bwd_combine_k) -- one launch fewer on this criterion's chain
+int w2l::fcc_backward_impl(int B, int T, int N, const float* trans, const float* grad, float* inputGrad, float* transGrad,
+                           void* workspace, hipStream_t stream, bool partialsOnly) {
   if (B <= 0 || T <= 0 || N <= 0 || !trans || !grad || !inputGrad || !transGrad || !workspace)
     return W2L_EINVAL;
   if (N > 64) {
@@ -805,9 +814,16 @@ W2L_API int w2l_fcc_backward(int B, int T, int N, const float* trans, const floa
   size_t n = (size_t)N * N;
   hipLaunchKernelGGL(reduce_chunks, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, s, kDtChunks, n, ws.tgpart);
   W2L_LAUNCH_CHECK();
+  if (partialsOnly) return W2L_OK;
   hipLaunchKernelGGL(reduce_over_b, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, B, n, ws.tgpart, transGrad, kDtChunks);
   W2L_LAUNCH_CHECK();
   return W2L_OK;
+}
+
+const float* w2l::fcc_transgrad_partials(void* workspace, int B, int T, int N, int* stride) {
+  if (N > 64) return nullptr;
+  *stride = kDtChunks;
+  return fcc_ws(workspace, B, T, N).tgpart;
 }
 
 W2L_API int w2l_fcc_range_flags(int B, int T, int N, const void* workspace, int* flags, w2l_stream_t stream) {

@@ -90,10 +90,16 @@ class AsgSequence {
     if (fac_asg_fused_ok(B, T, N, L)) {
       const bool clear = clearWs_ == w.fac;   // forward's label-row launch cleared the transition-gradient partials of this workspace ...
       clearWs_ = nullptr;                     // ... and this pass uses them up (a second backward on the same forward fills them itself)
+      // At these sizes FullConnectionCriterion's backward chain is the longer one (scan 167 us + 33 us of transition-gradient
+      // launches against 150 + 42 us): it stays on the caller's stream and starts at once; ForceAlignmentCriterion's scan and scatter
+      // go to the side stream, and the one combine launch behind the join sums both criteria's partials and subtracts.
       hipStream_t s2 = fork(main);
-      w2lCheck(w2l_fcc_backward(B, T, N, trans, gradLoss, dEm, dTrans, w.fcc, s2), "fcc backward");
+      int fccStride = 0;
+      const float* fccPart = fcc_transgrad_partials(w.fcc, B, T, N, &fccStride);
+      w2lCheck(fcc_backward_impl(B, T, N, trans, gradLoss, dEm, dTrans, w.fcc, main, fccPart != nullptr), "fcc backward");
       BwdHook h{this, main};
-      w2lCheck(fac_backward_asg(B, T, N, L, target, w.ts, gradLoss, dEm, dTrans, w.dx2, w.fac, clear, main, bwdHook, &h), "asg backward");
+      w2lCheck(fac_backward_asg(B, T, N, L, target, w.ts, gradLoss, dEm, dTrans, w.dx2, w.fac, clear, fccPart, fccStride, s2, main, bwdHook, &h),
+               "asg backward");
       return;
     }
     hipStream_t s2 = fork(main);
