@@ -275,6 +275,7 @@ w2l::AsgBuffers asg_carve(void* ws, int B, int T, int N, int L) {
   w.dt2 = (float*)p;
   return w;
 }
+std::mutex g_asgEnqueue;   // the device's sequence (its side stream, its events) is shared by every caller of w2l_asg_*: one enqueue at a time
 w2l::AsgSequence* asg_sequence_of_device() {
   static std::mutex mu;
   static w2l::AsgSequence* seqs[64] = {};
@@ -306,6 +307,7 @@ W2L_API int w2l_asg_forward(int B, int T, int N, int L, int scaleMode, const flo
   if (!w2l_asg_workspace_size(B, T, N, L)) return W2L_EUNSUPPORTED;
   w2l::AsgSequence* seq = asg_sequence_of_device();
   if (!seq) return W2L_EUNSUPPORTED;
+  std::lock_guard<std::mutex> g(g_asgEnqueue);
   return asg_guard([&] {
     seq->forward((hipStream_t)stream, B, T, N, L, scaleMode, input, target, (float*)trans, loss, asg_carve(workspace, B, T, N, L));
   });
@@ -317,6 +319,7 @@ W2L_API int w2l_asg_backward(int B, int T, int N, int L, const int* target, cons
   if (!w2l_asg_workspace_size(B, T, N, L)) return W2L_EUNSUPPORTED;
   w2l::AsgSequence* seq = asg_sequence_of_device();
   if (!seq) return W2L_EUNSUPPORTED;
+  std::lock_guard<std::mutex> g(g_asgEnqueue);
   return asg_guard([&] {
     seq->backward((hipStream_t)stream, B, T, N, L, target, grad, inputGrad, (float*)trans, transGrad, asg_carve(workspace, B, T, N, L));
   });
