@@ -24,6 +24,10 @@ def test_workspace_queries_are_pure_host_functions():
     assert lib.w2l_viterbi_workspace_size(64, 2000, 30) >= 64 * 2000 * 30
     assert lib.w2l_ctc_workspace_size(32, 188, 9998, 80) > 0
     assert lib.w2l_fcc_workspace_size(0, 10, 10) == 0
+    # ASG in one call: room for both criteria's workspaces, the target sizes, the second loss and the gradient scratch
+    asg = lib.w2l_asg_workspace_size(64, 2000, 30, 300)
+    assert asg >= lib.w2l_fcc_workspace_size(64, 2000, 30) + lib.w2l_fac_workspace_size(64, 2000, 30, 300) + 64 * 2000 * 30 * 4
+    assert lib.w2l_asg_workspace_size(64, 2000, 30, 0) == 0 and lib.w2l_asg_workspace_size(0, 2000, 30, 300) == 0
 
 
 def test_null_and_bad_shapes_are_rejected_without_touching_the_gpu():
@@ -33,6 +37,8 @@ def test_null_and_bad_shapes_are_rejected_without_touching_the_gpu():
     assert lib.w2l_fcc_forward(2, 10, 10, 0, None, None, None, None, None, None) == _lib.W2L_EINVAL
     assert lib.w2l_ctc_forward(2, 10, 1, 4, 0, None, None, None, None, None, None) == _lib.W2L_EINVAL
     assert lib.w2l_viterbi_compute(1, 1, 0, None, None, None, None, None) == _lib.W2L_EINVAL
+    assert lib.w2l_asg_forward(2, 10, 5, 3, 0, None, None, None, None, None, None) == _lib.W2L_EINVAL
+    assert lib.w2l_asg_backward(2, 10, 5, 0, None, None, None, None, None, None, None) == _lib.W2L_EINVAL
 
 
 def test_scale_mode_mapping():
