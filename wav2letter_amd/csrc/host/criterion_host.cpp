@@ -48,10 +48,11 @@ class CTCLossImpl : public SequenceCriterion {
 // stream (fork / join with events); ASG forward = max(FCC, FAC) instead of their sum, same for backward.
 //
 // AsgSequence: that launch sequence, shared by the criterion object below and by the one-call C ABI (w2l_asg_forward /
-// w2l_asg_backward at the end of this file).  Small label sets (the letter recipes: N <= 31, L <= 320) take the fused sequence of
+// w2l_asg_backward at the end of this file).  Small label sets (the letter recipes: N <= 31, L <= 320) take the fused sequences of
 // criterion_asg_fused.hpp: the launches that exist only because ASG composes two criterion calls (target sizes, the flagged-utterance
-// launch, three axpy, and -- moved into forward's slack on the side stream -- the backward pass's position sort and partials fill)
-// are folded into their neighbours; everything else runs the composed calls.
+// launch, three axpy, the backward pass's position sort and partials fill) are folded into their neighbours, and with at most 64
+// utterances the forward pass's four half scans are ONE launch on the caller's stream (criterion_asg.hip: no side stream, no
+// events); everything else runs the composed calls.
 struct AsgBuffers { int* ts; void* fcc; void* fac; float* dx2; float* dt2; float* loss2; };
 class AsgSequence {
  public:
